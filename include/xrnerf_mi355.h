@@ -1,0 +1,186 @@
+/*
+ * libxrnerf_mi355.so -- C-ABI of the MI355X-native (gfx950) Instant-NGP hot path that drops in
+ * behind openxrlab/xrnerf's `raymarch_cuda` extension module and its `tinycudann` dependency.
+ *
+ * Conventions (all entry points):
+ *   - `extern "C"`, plain pointers and sizes, no torch types.  Every pointer is a DEVICE pointer
+ *     unless its name ends in `_host`.  Tensors are contiguous fp32 / int32 / uint8 in exactly the
+ *     layouts the reference's pybind entry points take (file:line cited per function; paths are
+ *     relative to /root/reference/).
+ *   - returns 0 on success, a negative XR_E* code on failure (message: xr_last_error()); never
+ *     throws, never allocates, never synchronises: work is enqueued on `stream` (a hipStream_t
+ *     passed as void*; NULL = the default stream).  Scratch memory is caller supplied
+ *     (`workspace`, size from the matching *_workspace_bytes()).
+ *   - the reference keeps hidden global RNG state (`static pcg32 rng{9121}`,
+ *     extensions/ngp_raymarch/include/raymarch_shared.h:38, advanced by 2^32 after each launch);
+ *     here the generator state is an explicit argument (rng_state, rng_inc), obtained from
+ *     xr_pcg32_host_state(seed, n_previous_calls).
+ *   - sample order: the reference reserves output ranges with atomicAdd, so its sample order is
+ *     schedule dependent; this library assigns bases as the exclusive prefix sum in RAY ORDER
+ *     (one valid schedule of the reference, and the one its serial CPU build produces), which
+ *     makes every output bit-reproducible.
+ */
+#ifndef XRNERF_MI355_H
+#define XRNERF_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XR_OK 0
+#define XR_EINVAL (-22)   /* bad argument (null pointer, size, alignment)      */
+#define XR_ENOMEM (-12)   /* workspace too small                                */
+#define XR_EHIP (-5)      /* a HIP runtime call / kernel launch failed         */
+
+#define XR_NERF_STEPS 1024u      /* raymarch_shared.h:42 */
+#define XR_NERF_CASCADES 8u      /* :43 */
+#define XR_NERF_GRIDSIZE 128u    /* :48 */
+#define XR_GRID_CELLS (128u * 128u * 128u)
+
+/* ENerfActivation, raymarch_shared.h:619-625 */
+enum { XR_ACT_NONE = 0, XR_ACT_RELU = 1, XR_ACT_LOGISTIC = 2, XR_ACT_EXPONENTIAL = 3 };
+
+const char* xr_last_error(void);
+int xr_version(void);
+/* number of compute units of the current device (for persistent-grid sizing by callers) */
+int xr_device_cus(void);
+
+/* host helper: state of `pcg32 rng{seed}` after `ncalls` launches (each launch ends with
+ * rng.advance() = 2^32; ray_sampler.cu:198, generate_grid_samples_nerf_nonuniform.cu:84) */
+void xr_pcg32_host_state(uint64_t seed, uint64_t ncalls, uint64_t* state_host, uint64_t* inc_host);
+
+/* ------------------------------------------------------------------------------------------
+ * K1  rays_sampler_api   (extensions/ngp_raymarch/src/ray_sampler.cu:119-200, kernel :5-116)
+ * in : rays_o, rays_d [n_rays,3] f32; bitfield [8*128^3/8] u8
+ *      (metadata / img_ids / xforms of the reference are loaded-but-dead there, :34-38)
+ * out: coords_out [max_samples,7] f32 rows {pos3, warped dt, warped dir3}; rays_index [n_rays]
+ *      i32; rays_numsteps [n_rays,2] i32 = (n, base); counter2 [2] u32 = (rays, samples).
+ * counter2 is zeroed by this call.  workspace: xr_rays_sampler_workspace_bytes(n_rays). */
+size_t xr_rays_sampler_workspace_bytes(uint32_t n_rays);
+int xr_rays_sampler(const float* rays_o, const float* rays_d, const uint8_t* bitfield, uint32_t n_rays,
+                    float aabb0, float aabb1, float near_distance, float cone_angle, uint32_t max_samples,
+                    uint64_t rng_state, uint64_t rng_inc, float* coords_out, int32_t* rays_index,
+                    int32_t* rays_numsteps, uint32_t* counter2, void* workspace, size_t workspace_bytes,
+                    void* stream);
+
+/* K2  compacted_coord_api (src/compacted_coord.cu:79-143, kernel :6-77).  The reference's
+ * transmittance loop cannot influence any output (its `break` is commented out, :41-44), so
+ * network_output is not an argument.  counters are zeroed by this call.
+ * out: coords_out [max_compacted,7]; numsteps_out [n_rays,2] = (n_clipped, base_c);
+ *      rays_counter [1], numstep_counter [1] u32 (numstep_counter = UNCLIPPED total).
+ * workspace: xr_rays_sampler_workspace_bytes(n_rays). */
+int xr_compacted_coord(const float* coords_in, const int32_t* numsteps_in, uint32_t n_rays,
+                       uint32_t max_compacted, float* coords_out, int32_t* numsteps_out,
+                       uint32_t* rays_counter, uint32_t* numstep_counter, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
+/* K3  calc_rgb_forward_api (src/calc_rgb.cu:208-264, kernel :6-67) */
+int xr_calc_rgb_forward(const float* network_output /*[S,4]*/, const float* coords /*[S,7]*/,
+                        const int32_t* rays_numsteps, const int32_t* rays_numsteps_compacted,
+                        const float* bg_color /*[n_rays,3]*/, uint32_t n_rays, int rgb_activation,
+                        int density_activation, float* rgb_output /*[n_rays,3]*/, void* stream);
+/* K4  calc_rgb_backward_api (src/calc_rgb.cu:267-327, kernel :71-140); rows of dloss_doutput
+ * not covered by a ray are left untouched (caller zero-fills, as renders/hashnerf_render.py:121) */
+int xr_calc_rgb_backward(const float* network_output, const int32_t* rays_numsteps_compacted,
+                         const float* coords, const float* grad_rgb /*[n_rays,3]*/,
+                         const float* rgb_output /*[n_rays,3] saved forward result*/,
+                         const float* density_grid_mean /*device, [0] read*/, uint32_t n_rays,
+                         int rgb_activation, int density_activation, float* dloss_doutput /*[S,4]*/,
+                         void* stream);
+/* K5  calc_rgb_influence_api (src/calc_rgb.cu:330-389, kernel :144-206); bg is by value like the
+ * reference's host tensor */
+int xr_calc_rgb_inference(const float* network_output, const float* coords, const int32_t* rays_numsteps,
+                          float bg_r, float bg_g, float bg_b, uint32_t n_rays, int rgb_activation,
+                          int density_activation, float* rgb_output, float* alpha_output, void* stream);
+
+/* K6  generate_grid_samples_nerf_nonuniform_api (src/generate_grid_samples_nerf_nonuniform.cu:44-87) */
+int xr_generate_grid_samples(const float* density_grid, uint32_t ema_step, uint32_t n_elements,
+                             uint32_t n_cascades /* = max_cascade+1 */, float thresh, float aabb0, float aabb1,
+                             uint64_t rng_state, uint64_t rng_inc, float* positions /*[n,3]*/,
+                             int32_t* indices /*[n]*/, void* stream);
+/* K7  mark_untrained_density_grid_api (src/mark_untrained_density_grid.cu:54-82): writes 0 where
+ * the cell is visible from any training camera, -1 elsewhere (the reference leaves visible cells of
+ * its UNINITIALISED buffer untouched when they happen to be >= 0) */
+int xr_mark_untrained_density_grid(const float* focal_lengths /*[n_img,2]*/, const float* xforms /*[n_img,4,3]*/,
+                                   uint32_t n_elements, uint32_t n_images, int resolution0, int resolution1,
+                                   float* density_grid, void* stream);
+/* K8  splat_grid_samples_nerf_max_nearest_neighbor_api (src/splat_...cu:30-57) */
+int xr_splat_grid_samples(const float* mlp_out, const int32_t* indices, uint32_t padded_output_width,
+                          uint32_t n_samples, float* density_grid_tmp, void* stream);
+/* K9  ema_grid_samples_nerf_api (src/ema_grid_samples_nerf.cu:29-50) */
+int xr_ema_grid_samples(const float* density_grid_tmp, uint32_t n_elements, float decay, float* density_grid,
+                        void* stream);
+/* K10+K11  update_bitfield_api (src/update_bitfield.cu:74-116): mean of max(v,0) over level 0
+ * (fixed-order tree => bit-reproducible), threshold min(0.01, mean), bitfield + 7 max-pools.
+ * density_grid_mean: device, [0] written.  workspace: xr_update_bitfield_workspace_bytes(). */
+size_t xr_update_bitfield_workspace_bytes(void);
+int xr_update_bitfield(const float* density_grid, float* density_grid_mean, uint8_t* bitfield, void* workspace,
+                       size_t workspace_bytes, void* stream);
+/* K11 alone with the mean supplied (device pointer) -- for bit-exact tests against the reference */
+int xr_bitfield_from_mean(const float* density_grid, const float* density_grid_mean, uint8_t* bitfield,
+                          void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * tiny-cuda-nn surface used by xrnerf/models/mlps/hashnerf_mlp.py:34-45,55-111
+ *
+ * Hash grid (tcnn.Encoding otype=HashGrid).  Level geometry is computed ONCE on the host
+ * (xr_hashgrid_meta) and passed to every call, so that host oracle and device agree on indices.
+ * Table layout: per level `offset[l]` entries of F=2 floats, levels consecutive (tcnn `params`).
+ * Positions are read with an element stride (`x_stride` floats between samples) so the [S,7]
+ * coordinate rows of K1 can be consumed in place.
+ * Encoded features are FEATURE-MAJOR: enc_t [2*n_levels][ld] with ld >= n (what both the encoder's
+ * stores and the MLP's MFMA operand loads want for coalescing). */
+void xr_hashgrid_meta(int n_levels, int log2_hashmap_size, int base_resolution, double per_level_scale,
+                      float* scale_host, uint32_t* resolution_host, uint32_t* offset_host /*[L+1]*/);
+int xr_hashgrid_fwd(const float* table, const float* x, uint32_t x_stride, uint32_t n, int n_levels,
+                    const float* scale_host, const uint32_t* resolution_host, const uint32_t* offset_host,
+                    float* enc_t, uint32_t ld, void* stream);
+/* grad_table[idx,f] += w * denc_t[2l+f][i]; caller zero-fills grad_table */
+int xr_hashgrid_bwd(const float* x, uint32_t x_stride, const float* denc_t, uint32_t ld, uint32_t n, int n_levels,
+                    const float* scale_host, const uint32_t* resolution_host, const uint32_t* offset_host,
+                    float* grad_table, void* stream);
+/* tcnn.Encoding otype=SphericalHarmonics degree 4; dirs in [0,1] (the sampler's warp_direction);
+ * out row-major [n,16] */
+int xr_sh4(const float* dirs, uint32_t dir_stride, uint32_t n, float* out, void* stream);
+
+/* HashNerfMLP.run_mlp fused (hashnerf_mlp.py:55-79): density_net (32 -> nhd x 64 -> 16) on the encoded
+ * features, SH-4 of the view direction, color_net (15+16 (+1 pad = pad_value) -> nhc x 64 -> 16),
+ * raw [n,4] = [r,g,b,sigma].  fp32 MFMA (v_mfma_f32_32x32x2_f32 == an fmaf chain, exact fp32).
+ * Weights: tcnn `params` layout = row-major [out,in] matrices in layer order, out padded to 16.
+ * dirs may be NULL (run_density, hashnerf_mlp.py:107-111: only raw[:,3] is meaningful then). */
+int xr_nerf_mlp_fwd(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
+                    const float* w_density, const float* w_color, int n_hidden_density, int n_hidden_color,
+                    float pad_value, float* raw /*[n,4]*/, void* stream);
+/* backward of the above given dL/draw [n,4]: writes denc_t [32][ld] (for xr_hashgrid_bwd) and
+ * ACCUMULATES weight gradients into grad_w_density / grad_w_color (caller zero-fills).
+ * Activations are recomputed in-kernel (nothing saved by the forward).
+ * workspace: xr_nerf_mlp_bwd_workspace_bytes(n). */
+size_t xr_nerf_mlp_bwd_workspace_bytes(uint32_t n);
+int xr_nerf_mlp_bwd(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
+                    const float* w_density, const float* w_color, int n_hidden_density, int n_hidden_color,
+                    float pad_value, const float* draw /*[n,4]*/, float* denc_t, float* grad_w_density,
+                    float* grad_w_color, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * callers either side of the path
+ * ray generation, get_rays_np_hash (xrnerf/datasets/load_data/get_rays.py:35-69) in fp32:
+ * rows [row0, row0+nrows) of an H x W image; pose_host = the python [4,3] matrix. */
+int xr_gen_rays(const float* pose43_host, int H, int W, float fx, float fy, float cx, float cy, int row0,
+                int nrows, float* rays_o, float* rays_d, void* stream);
+/* loss = scale * sum huber_delta(rgb - target) (networks/hashnerf.py:37-44, utils/metrics.py);
+ * writes dL/drgb and ADDS the loss into loss_out[0] (caller zero-fills) */
+int xr_huber_loss_grad(const float* rgb, const float* target, uint32_t n_elems, float delta, float scale,
+                       float* grad, float* loss_out, void* stream);
+/* torch.optim.Adam step with L2 weight decay (configs/instant_ngp/nerf_blender_local01.py:14-18),
+ * fused with the optional EMA copy of mmcv's EMAHook (:24): ema = (1-mom)*ema + mom*p. */
+int xr_adam_step(float* p, const float* g, float* m, float* v, size_t n, int step, float lr, float beta1,
+                 float beta2, float eps, float weight_decay, float* ema /*nullable*/, float ema_momentum,
+                 void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

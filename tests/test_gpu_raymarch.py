@@ -1,0 +1,204 @@
+"""GPU parity (through the C-ABI) of K1..K11 against the CPU oracle on identical inputs.
+Bar: bit-exact sample indices / counts / positions; fp32 compositor within 1e-4 abs (north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import bits
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def edge_rays():
+    """rays the reference's slab test / DDA treat specially: axis aligned (zero components ->
+    inf/NaN in 1/d), missing the box, starting inside the box, grazing a face, degenerate."""
+    o = [[0.5, 0.5, -1.0], [0.5, 0.5, -1.0], [-1.0, 0.5, 0.5], [0.5, 2.0, 0.5], [0.5, 0.5, 0.5], [0.5, 0.5, 0.5],
+         [3.0, 3.0, 3.0], [0.0, 0.5, -1.0], [1.0, 1.0, -1.0], [0.45, 0.55, -2.0], [0.5, 0.5, -1.0], [0.31, 0.4, 0.35]]
+    d = [[0.0, 0.0, 1.0], [0.0, 0.0, -1.0], [1.0, 0.0, 0.0], [0.0, -1.0, 0.0], [0.577, 0.577, 0.577], [0.0, 1.0, 0.0],
+         [1.0, 0.0, 0.0], [0.0, 0.0, 1.0], [0.0, 0.0, 1.0], [0.01, -0.01, 0.9999], [1e-9, 1e-9, 1.0], [-0.6, 0.0, 0.8]]
+    return np.array(o, np.float32), np.array(d, np.float32)
+
+
+def run_k1(ops, dev, o, d, bf, max_samples, calls):
+    c, ri, ns, cnt = ops.rays_sampler(T(o, dev), T(d, dev), T(bf, dev), (0.0, 1.0), 0.05, 1.0 / 256, max_samples, calls)
+    torch.cuda.synchronize()
+    return c.cpu().numpy(), ri.cpu().numpy(), ns.cpu().numpy(), cnt.cpu().numpy()
+
+
+@pytest.mark.parametrize('n_rays,calls', [(4096, 0), (4096, 1), (1000, 3), (70000, 0)])
+def test_k1_bit_exact(O, lego, dev, n_rays, calls):
+    from xrnerf_amd import ops, synthetic as S
+    o, d, _ = S.training_rays(lego['poses'], n_rays, seed=11 + calls)
+    eo, ed = edge_rays()
+    o, d = np.concatenate([eo, o]), np.concatenate([ed, d])
+    n = o.shape[0]
+    rc, ri, rn, rcnt = O.rays_sampler(o, d, lego['bitfield'], rng_calls=calls, max_samples=n * 64)
+    gc, gi, gn, gcnt = run_k1(ops, dev, o, d, lego['bitfield'], n * 64, calls)
+    assert np.array_equal(gcnt, rcnt), (gcnt, rcnt)
+    assert np.array_equal(gn, rn)
+    assert np.array_equal(gi, ri)
+    S_ = int(rcnt[1])
+    assert S_ > n   # the scene is actually hit
+    assert np.array_equal(bits(gc[:S_]), bits(rc[:S_]))
+
+
+def test_k1_overflow_and_k2_clip(O, lego, dev):
+    """max_samples smaller than the demand: overflowing rays get (0, base) and no index (ray_sampler.cu:76-82);
+    K2 clips at max_compacted (compacted_coord.cu:63-64)."""
+    from xrnerf_amd import ops, synthetic as S
+    o, d, _ = S.training_rays(lego['poses'], 3000, seed=5)
+    full = O.rays_sampler(o, d, lego['bitfield'])
+    total = int(full[3][1])
+    for cap in (total // 2, total - 1, total, 7):
+        rc, ri, rn, rcnt = O.rays_sampler(o, d, lego['bitfield'], max_samples=cap)
+        gc, gi, gn, gcnt = run_k1(ops, dev, o, d, lego['bitfield'], cap, 0)
+        assert np.array_equal(gcnt, rcnt) and np.array_equal(gn, rn) and np.array_equal(gi, ri)
+        valid = rn[:, 0] > 0
+        for i in np.nonzero(valid)[0][:200]:
+            b, k = rn[i, 1], rn[i, 0]
+            assert np.array_equal(bits(gc[b:b + k]), bits(rc[b:b + k]))
+    # K2 on the un-truncated march
+    rc, ri, rn, rcnt = full
+    for cap in (1 << 18, total // 3, 5):
+        oc, onc, orc, osc = O.compacted_coord(rc[:total], rn, cap)
+        gc, gnc, grc, gsc = ops.compacted_coord(T(rc[:total], dev), T(rn, dev), cap)
+        torch.cuda.synchronize()
+        assert np.array_equal(gnc.cpu().numpy(), onc)
+        assert int(grc.item()) == int(orc[0]) and int(gsc.item()) == int(osc[0])
+        kept = min(cap, total)
+        assert np.array_equal(bits(gc.cpu().numpy()[:kept]), bits(oc[:kept]))
+
+
+def make_samples(O, lego, n_rays, seed):
+    from xrnerf_amd import synthetic as S
+    o, d, _ = S.training_rays(lego['poses'], n_rays, seed=seed)
+    c, ri, ns, cnt = O.rays_sampler(o, d, lego['bitfield'])
+    total = int(cnt[1])
+    rng = np.random.default_rng(seed)
+    raw = rng.normal(0, 1.5, (total, 4)).astype(np.float32)
+    raw[:, 3] = rng.normal(2.0, 3.0, total)   # exp density from ~0 to large
+    return c[:total].copy(), ns, raw, rng
+
+
+@pytest.mark.parametrize('rgb_act,density_act', [(2, 3), (3, 3), (1, 1), (0, 2)])
+def test_compositor_fwd_bwd_inference(O, lego, dev, rgb_act, density_act):
+    from xrnerf_amd import ops
+    coords, ns, raw, rng = make_samples(O, lego, 3000, 21)
+    n = ns.shape[0]
+    if density_act != 3:
+        raw[:, 3] = np.abs(raw[:, 3])
+    bg = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    # a clipped "compacted" view: half of the rays lose their tail (then no bg term, calc_rgb.cu:61-64)
+    nsc = ns.copy()
+    cut = rng.uniform(0, 1, n) < 0.3
+    nsc[cut, 0] = nsc[cut, 0] // 2
+    ref = O.calc_rgb_forward(raw, coords, ns, nsc, bg, rgb_act, density_act)
+    got = ops.calc_rgb_forward(T(raw, dev), T(coords, dev), T(ns, dev), T(nsc, dev), T(bg, dev), rgb_act, density_act)
+    assert np.abs(got.cpu().numpy() - ref).max() <= 1e-4
+    # backward
+    grad = rng.normal(0, 1, (n, 3)).astype(np.float32)
+    for mean in (0.001, 0.5):   # toggles the L1 density regulariser (calc_rgb.cu:104)
+        rb = O.calc_rgb_backward(raw, nsc, coords, grad, ref, mean, rgb_act, density_act)
+        gb = ops.calc_rgb_backward(T(raw, dev), T(nsc, dev), T(coords, dev), T(grad, dev), T(ref, dev),
+                                   T(np.array([mean], np.float32), dev), rgb_act, density_act).cpu().numpy()
+        err = np.abs(gb - rb).max()
+        assert err <= 1e-4 * max(1.0, np.abs(rb).max()), err
+    # inference
+    rr, ra = O.calc_rgb_inference(raw, coords, ns, [0.2, 0.5, 0.9], rgb_act, density_act)
+    gr, ga = ops.calc_rgb_inference(T(raw, dev), T(coords, dev), T(ns, dev), [0.2, 0.5, 0.9], rgb_act, density_act)
+    assert np.abs(gr.cpu().numpy() - rr).max() <= 1e-4 and np.abs(ga.cpu().numpy() - ra).max() <= 1e-4
+
+
+def test_compositor_zero_sample_rays(O, dev):
+    from xrnerf_amd import ops
+    ns = np.zeros((130, 2), np.int32)
+    raw = np.zeros((4, 4), np.float32); coords = np.zeros((4, 7), np.float32)
+    bg = np.random.default_rng(0).uniform(0, 1, (130, 3)).astype(np.float32)
+    got = ops.calc_rgb_forward(T(raw, dev), T(coords, dev), T(ns, dev), T(ns, dev), T(bg, dev), 2, 3).cpu().numpy()
+    assert np.array_equal(got, bg)
+    r, a = ops.calc_rgb_inference(T(raw, dev), T(coords, dev), T(ns, dev), [1, 0, 1], 2, 3)
+    assert np.array_equal(r.cpu().numpy(), np.tile(np.array([1, 0, 1], np.float32), (130, 1))) and float(a.abs().max()) == 0
+
+
+def test_k6_grid_samples_bit_exact(O, lego, dev):
+    from xrnerf_amd import ops
+    rng = np.random.default_rng(3)
+    grid = (lego['grid'] * rng.uniform(0.0, 0.05, lego['grid'].shape)).astype(np.float32)
+    grid[rng.uniform(0, 1, grid.shape) < 0.1] = -1.0
+    g = T(grid, dev)
+    for (n, step, casc, thr, calls) in [(100000, 0, 1, -0.01, 0), (100000, 7, 1, 0.01, 1), (65536, 3, 5, 0.01, 4)]:
+        rp, ri = O.generate_grid_samples(grid, step, n, casc - 1, thr, rng_calls=calls)
+        gp, gi = ops.generate_grid_samples(g, step, n, casc, thr, (0.0, 1.0), calls)
+        assert np.array_equal(gi.cpu().numpy(), ri)
+        assert np.array_equal(bits(gp.cpu().numpy()), bits(rp))
+
+
+def test_k7_mark_untrained(O, lego, dev):
+    from xrnerf_amd import ops, synthetic as S
+    poses = lego['poses'][:7]
+    focal = np.full((7, 2), S.LEGO_FOCAL, np.float32)
+    n = 2 * 128 ** 3
+    ref = O.mark_untrained(focal, poses, n, (800, 800))
+    got = ops.mark_untrained_density_grid(T(focal, dev), T(poses, dev), n, (800, 800)).cpu().numpy()
+    assert np.array_equal(got, ref)
+    assert 0 < (ref < 0).sum() < n
+
+
+def test_k8_k9_k10_k11(O, lego, dev):
+    from xrnerf_amd import ops
+    rng = np.random.default_rng(8)
+    n = 200000
+    idx = rng.integers(0, 128 ** 3, n).astype(np.int32)
+    idx[:1000] = idx[0]   # heavy collisions on one cell
+    mlp = rng.normal(0, 2, (n, 1)).astype(np.float32)
+    tmp0 = np.zeros(8 * 128 ** 3, np.float32)
+    ref_tmp = O.splat(mlp, idx, tmp0)
+    got_tmp = ops.splat_grid_samples(T(mlp, dev), T(idx, dev), 1, n, T(tmp0, dev)).cpu().numpy()
+    assert np.allclose(got_tmp, ref_tmp, rtol=2e-6, atol=0)
+    grid = (lego['grid'] * 0.02).astype(np.float32)
+    grid[rng.uniform(0, 1, grid.shape) < 0.05] = -1.0
+    ref_grid = O.ema(ref_tmp, grid)
+    got_grid = ops.ema_grid_samples(T(ref_tmp, dev), grid.size, 0.95, T(grid, dev)).cpu().numpy()
+    assert np.array_equal(bits(got_grid), bits(ref_grid))
+    # K10 mean (order of summation differs -> relative tolerance) and K11 given the SAME mean: bit exact
+    mean = torch.zeros(16384, dtype=torch.float32, device=dev)
+    bf = torch.zeros(128 ** 3, dtype=torch.uint8, device=dev)
+    ops.update_bitfield(T(ref_grid, dev), mean, bf)
+    ref_mean = O.density_mean(ref_grid)
+    assert abs(float(mean[0]) - ref_mean) <= 1e-5 * ref_mean
+    for m in (float(mean[0]), 0.5, 1e-5):
+        mt = torch.tensor([m], dtype=torch.float32, device=dev)
+        got_bf = ops.bitfield_from_mean(T(ref_grid, dev), mt, torch.zeros_like(bf)).cpu().numpy()
+        assert np.array_equal(got_bf, O.bitfield_given_mean(ref_grid, np.float32(m)))
+    # the end-to-end call agrees with K11 at its own mean, and is reproducible
+    assert np.array_equal(bf.cpu().numpy(), O.bitfield_given_mean(ref_grid, np.float32(float(mean[0]))))
+    mean2 = torch.zeros_like(mean); bf2 = torch.zeros_like(bf)
+    ops.update_bitfield(T(ref_grid, dev), mean2, bf2)
+    assert float(mean2[0]) == float(mean[0]) and torch.equal(bf, bf2)
+
+
+def test_gen_rays_huber_adam(O, lego, dev):
+    from xrnerf_amd import ops, synthetic as S
+    pose = lego['poses'][3]
+    f = np.float32(S.LEGO_FOCAL)
+    ro, rd = O.gen_rays(pose, 800, 800, f, f, 400.0, 400.0, row0=100, nrows=50)
+    go, gd = ops.gen_rays(pose, 800, 800, float(f), float(f), 400.0, 400.0, row0=100, nrows=50, device=dev)
+    assert np.array_equal(bits(go.cpu().numpy()), bits(ro))
+    assert np.abs(gd.cpu().numpy() - rd).max() <= 1e-7
+    rng = np.random.default_rng(1)
+    rgb = rng.uniform(0, 1, (5000, 3)).astype(np.float32); tgt = rng.uniform(0, 1, (5000, 3)).astype(np.float32)
+    rl, rg = O.huber_loss_grad(rgb, tgt)
+    gl, gg = ops.huber_loss_grad(T(rgb, dev), T(tgt, dev))
+    assert abs(float(gl) - rl) <= 1e-5 * rl and np.abs(gg.cpu().numpy() - rg).max() <= 1e-6
+    n = 100003
+    p = rng.normal(0, 1, n).astype(np.float32); g = rng.normal(0, 1e-2, n).astype(np.float32)
+    m = np.zeros(n, np.float32); v = np.zeros(n, np.float32)
+    tp, tm, tv = T(p, dev), T(m, dev), T(v, dev)
+    for step in (1, 2, 3):
+        O.adam(p, g, m, v, step)
+        ops.adam_step(tp, T(g, dev), tm, tv, step)
+    assert np.abs(tp.cpu().numpy() - p).max() <= 1e-5 and np.abs(tv.cpu().numpy() - v).max() <= 1e-9

@@ -1,0 +1,75 @@
+"""ctypes binding of libxrnerf_mi355.so (the C-ABI of include/xrnerf_mi355.h).
+
+There is NO fallback: if the library is missing or a call fails this raises. The product path never
+imports anything from oracle/.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libxrnerf_mi355.so')
+
+_vp, _u32, _i32, _f, _u64, _sz, _d = C.c_void_p, C.c_uint32, C.c_int, C.c_float, C.c_uint64, C.c_size_t, C.c_double
+
+# name -> (restype, argtypes); mirrors include/xrnerf_mi355.h one to one
+SIGNATURES = {
+    'xr_last_error': (C.c_char_p, []),
+    'xr_version': (_i32, []),
+    'xr_device_cus': (_i32, []),
+    'xr_pcg32_host_state': (None, [_u64, _u64, _vp, _vp]),
+    'xr_rays_sampler_workspace_bytes': (_sz, [_u32]),
+    'xr_rays_sampler': (_i32, [_vp, _vp, _vp, _u32, _f, _f, _f, _f, _u32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'xr_compacted_coord': (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'xr_calc_rgb_forward': (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, _i32, _i32, _vp, _vp]),
+    'xr_calc_rgb_backward': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _i32, _i32, _vp, _vp]),
+    'xr_calc_rgb_inference': (_i32, [_vp, _vp, _vp, _f, _f, _f, _u32, _i32, _i32, _vp, _vp, _vp]),
+    'xr_generate_grid_samples': (_i32, [_vp, _u32, _u32, _u32, _f, _f, _f, _u64, _u64, _vp, _vp, _vp]),
+    'xr_mark_untrained_density_grid': (_i32, [_vp, _vp, _u32, _u32, _i32, _i32, _vp, _vp]),
+    'xr_splat_grid_samples': (_i32, [_vp, _vp, _u32, _u32, _vp, _vp]),
+    'xr_ema_grid_samples': (_i32, [_vp, _u32, _f, _vp, _vp]),
+    'xr_update_bitfield_workspace_bytes': (_sz, []),
+    'xr_update_bitfield': (_i32, [_vp, _vp, _vp, _vp, _sz, _vp]),
+    'xr_bitfield_from_mean': (_i32, [_vp, _vp, _vp, _vp]),
+    'xr_hashgrid_meta': (None, [_i32, _i32, _i32, _d, _vp, _vp, _vp]),
+    'xr_hashgrid_fwd': (_i32, [_vp, _vp, _u32, _u32, _i32, _vp, _vp, _vp, _vp, _u32, _vp]),
+    'xr_hashgrid_bwd': (_i32, [_vp, _u32, _vp, _u32, _u32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'xr_sh4': (_i32, [_vp, _u32, _u32, _vp, _vp]),
+    'xr_nerf_mlp_fwd': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _i32, _i32, _f, _vp, _vp]),
+    'xr_nerf_mlp_bwd_workspace_bytes': (_sz, [_u32]),
+    'xr_nerf_mlp_bwd': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _i32, _i32, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'xr_gen_rays': (_i32, [_vp, _i32, _i32, _f, _f, _f, _f, _i32, _i32, _vp, _vp, _vp]),
+    'xr_huber_loss_grad': (_i32, [_vp, _vp, _u32, _f, _f, _vp, _vp, _vp]),
+    'xr_adam_step': (_i32, [_vp, _vp, _vp, _vp, _sz, _i32, _f, _f, _f, _f, _f, _vp, _f, _vp]),
+}
+
+_lib = None
+
+
+class XrError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the library (building it first when the sources are newer and hipcc is present)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        try:
+            from . import build as _build
+            _build.build()
+        except Exception as e:  # noqa: BLE001
+            raise XrError('libxrnerf_mi355.so is missing and could not be built: %s. '
+                          'Run `python -m xrnerf_amd.build` (needs hipcc).' % e)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        raise XrError('%s failed (%d): %s' % (what, rc, load().xr_last_error().decode()))

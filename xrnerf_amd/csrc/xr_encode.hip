@@ -1,0 +1,210 @@
+// Multiresolution hash-grid encoding (forward gather / backward scatter-add) and SH-4.
+// This is the tiny-cuda-nn surface of /root/reference/xrnerf/models/mlps/hashnerf_mlp.py:34-37,
+// rebuilt from the published algorithm -- tcnn itself is not in the
+// reference tree.  fp32 tables, fp32 interpolation.
+//
+// MI355X mapping: one thread per (sample, level).  blockIdx -> (XCD, level slot, sample block)
+// so that a given level's table slice is only ever touched from ONE XCD (block b runs on XCD
+// b % 8): each private 4 MiB L2 then caches 2 of the 16 levels instead of thrashing over all of
+// them.  Features are written FEATURE-MAJOR ([2L][ld]) so that both these stores and the MLP's
+// MFMA operand loads are 256-B coalesced rows.
+#include "xr_common.h"
+
+#define EN_BLOCK 256
+#define EN_MAX_LEVELS 16
+
+struct GridMeta {
+    float scale[EN_MAX_LEVELS];
+    uint32_t res[EN_MAX_LEVELS];
+    uint32_t off[EN_MAX_LEVELS + 1];
+    int n_levels;
+};
+
+extern "C" void xr_hashgrid_meta(int n_levels, int log2_hashmap_size, int base_resolution, double per_level_scale,
+                                 float* scale, uint32_t* resolution, uint32_t* offset) {
+    // tcnn keeps per_level_scale (and its log2) as float
+    const float log2b = log2f((float)per_level_scale);
+    uint32_t off = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        const float s = exp2f((float)l * log2b) * (float)base_resolution - 1.0f;
+        const uint32_t res = (uint32_t)ceilf(s) + 1u;
+        scale[l] = s; resolution[l] = res; offset[l] = off;
+        const double cube = (double)res * res * res;
+        uint32_t n = cube > 2147483647.0 ? 2147483647u : (uint32_t)cube;
+        n = (n + 7u) / 8u * 8u;
+        const uint32_t cap = 1u << log2_hashmap_size;
+        if (n > cap) n = cap;
+        off += n;
+    }
+    offset[n_levels] = off;
+}
+
+__device__ inline uint32_t grid_index(uint32_t cx, uint32_t cy, uint32_t cz, uint32_t res, uint32_t hsize, bool hashed) {
+    uint32_t index;
+    if (hashed) index = cx ^ (cy * 2654435761u) ^ (cz * 805459861u);
+    else index = cx + cy * res + cz * res * res;
+    return index % hsize;
+}
+// tcnn's stride loop (`for dim while stride <= hashmap_size`) followed by `if hashmap_size < stride`
+// reduces, for 3-D inputs, to: hashed iff res^3 > hashmap_size (computed on the host side of the
+// launch in 64-bit, passed as a flag bit per level)
+__device__ inline void level_of_block(const GridMeta& gm, uint32_t* level, uint32_t* sblock) {
+    const uint32_t per_xcd = (gm.n_levels + 7) / 8;
+    const uint32_t xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    *level = xcd + 8 * (j % per_xcd);
+    *sblock = j / per_xcd;
+}
+
+__global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_fwd(GridMeta gm, uint32_t hashed_mask, const float* __restrict__ table,
+                                                            const float* __restrict__ x, uint32_t x_stride, uint32_t n,
+                                                            float* __restrict__ enc_t, uint32_t ld) {
+    uint32_t l, sb;
+    level_of_block(gm, &l, &sb);
+    if (l >= (uint32_t)gm.n_levels) return;
+    const uint32_t i = sb * EN_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float scale = gm.scale[l];
+    const uint32_t res = gm.res[l], hsize = gm.off[l + 1] - gm.off[l];
+    const bool hashed = (hashed_mask >> l) & 1;
+    const float2* __restrict__ tab = (const float2*)table + gm.off[l];
+    const float* xp = x + (size_t)i * x_stride;
+    float w[3]; uint32_t g[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float p = xp[d] * scale + 0.5f;
+        const float f = floorf(p);
+        g[d] = (uint32_t)(int)f; w[d] = p - f;
+    }
+    float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float wt = ((c & 1) ? w[0] : 1.f - w[0]) * ((c & 2) ? w[1] : 1.f - w[1]) * ((c & 4) ? w[2] : 1.f - w[2]);
+        const uint32_t idx = grid_index(g[0] + (c & 1), g[1] + ((c >> 1) & 1), g[2] + ((c >> 2) & 1), res, hsize, hashed);
+        const float2 v = tab[idx];
+        r0 += wt * v.x; r1 += wt * v.y;
+    }
+    enc_t[(size_t)(2 * l) * ld + i] = r0;
+    enc_t[(size_t)(2 * l + 1) * ld + i] = r1;
+}
+
+__global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_bwd(GridMeta gm, uint32_t hashed_mask, const float* __restrict__ x,
+                                                            uint32_t x_stride, const float* __restrict__ denc_t, uint32_t ld,
+                                                            uint32_t n, float* __restrict__ grad_table) {
+    uint32_t l, sb;
+    level_of_block(gm, &l, &sb);
+    if (l >= (uint32_t)gm.n_levels) return;
+    const uint32_t i = sb * EN_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float d0 = denc_t[(size_t)(2 * l) * ld + i], d1 = denc_t[(size_t)(2 * l + 1) * ld + i];
+    if (d0 == 0.f && d1 == 0.f) return;   // adding +-0 is a no-op
+    const float scale = gm.scale[l];
+    const uint32_t res = gm.res[l], hsize = gm.off[l + 1] - gm.off[l];
+    const bool hashed = (hashed_mask >> l) & 1;
+    float* __restrict__ tab = grad_table + 2 * (size_t)gm.off[l];
+    const float* xp = x + (size_t)i * x_stride;
+    float w[3]; uint32_t g[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float p = xp[d] * scale + 0.5f;
+        const float f = floorf(p);
+        g[d] = (uint32_t)(int)f; w[d] = p - f;
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float wt = ((c & 1) ? w[0] : 1.f - w[0]) * ((c & 2) ? w[1] : 1.f - w[1]) * ((c & 4) ? w[2] : 1.f - w[2]);
+        const uint32_t idx = grid_index(g[0] + (c & 1), g[1] + ((c >> 1) & 1), g[2] + ((c >> 2) & 1), res, hsize, hashed);
+        // hardware fp32 atomic add, result unused (no-return form)
+        unsafeAtomicAdd(tab + 2 * (size_t)idx, wt * d0);
+        unsafeAtomicAdd(tab + 2 * (size_t)idx + 1, wt * d1);
+    }
+}
+
+static int fill_meta(GridMeta* gm, uint32_t* hashed_mask, int n_levels, const float* scale, const uint32_t* res,
+                     const uint32_t* off) {
+    if (n_levels < 1 || n_levels > EN_MAX_LEVELS || !scale || !res || !off) return -1;
+    gm->n_levels = n_levels;
+    *hashed_mask = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        gm->scale[l] = scale[l]; gm->res[l] = res[l]; gm->off[l] = off[l];
+        const uint64_t hsize = off[l + 1] - off[l];
+        // tcnn: stride accumulates while stride <= hsize; hashed iff hsize < final stride
+        uint64_t stride = 1;
+        for (int d = 0; d < 3 && stride <= hsize; ++d) stride *= res[l];
+        if (hsize < stride) *hashed_mask |= 1u << l;
+    }
+    gm->off[n_levels] = off[n_levels];
+    return 0;
+}
+
+extern "C" int xr_hashgrid_fwd(const float* table, const float* x, uint32_t x_stride, uint32_t n, int n_levels,
+                               const float* scale_host, const uint32_t* resolution_host, const uint32_t* offset_host,
+                               float* enc_t, uint32_t ld, void* stream_) {
+    if (n == 0) return XR_OK;
+    XR_REQUIRE(table && x && enc_t, "null pointer");
+    XR_REQUIRE(x_stride >= 3 && ld >= n, "bad stride");
+    XR_REQUIRE(((uintptr_t)table & 7) == 0, "table must be 8-byte aligned");
+    GridMeta gm; uint32_t hm;
+    XR_REQUIRE(fill_meta(&gm, &hm, n_levels, scale_host, resolution_host, offset_host) == 0, "bad level metadata");
+    const uint32_t per_xcd = (n_levels + 7) / 8;
+    const uint32_t blocks = 8 * per_xcd * xr_div_up(n, EN_BLOCK);
+    hipLaunchKernelGGL(k_hashgrid_fwd, dim3(blocks), dim3(EN_BLOCK), 0, (hipStream_t)stream_, gm, hm, table, x, x_stride, n,
+                       enc_t, ld);
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}
+
+extern "C" int xr_hashgrid_bwd(const float* x, uint32_t x_stride, const float* denc_t, uint32_t ld, uint32_t n, int n_levels,
+                               const float* scale_host, const uint32_t* resolution_host, const uint32_t* offset_host,
+                               float* grad_table, void* stream_) {
+    if (n == 0) return XR_OK;
+    XR_REQUIRE(x && denc_t && grad_table, "null pointer");
+    XR_REQUIRE(x_stride >= 3 && ld >= n, "bad stride");
+    GridMeta gm; uint32_t hm;
+    XR_REQUIRE(fill_meta(&gm, &hm, n_levels, scale_host, resolution_host, offset_host) == 0, "bad level metadata");
+    const uint32_t per_xcd = (n_levels + 7) / 8;
+    const uint32_t blocks = 8 * per_xcd * xr_div_up(n, EN_BLOCK);
+    hipLaunchKernelGGL(k_hashgrid_bwd, dim3(blocks), dim3(EN_BLOCK), 0, (hipStream_t)stream_, gm, hm, x, x_stride, denc_t, ld,
+                       n, grad_table);
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}
+
+// ------------------------------------------------------------------ SH degree 4 (tcnn SphericalHarmonics)
+__device__ inline void sh4_eval(float x, float y, float z, float* o) {
+    const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+    o[0] = 0.28209479177387814f;
+    o[1] = -0.48860251190291987f * y;
+    o[2] = 0.48860251190291987f * z;
+    o[3] = -0.48860251190291987f * x;
+    o[4] = 1.0925484305920792f * xy;
+    o[5] = -1.0925484305920792f * yz;
+    o[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+    o[7] = -1.0925484305920792f * xz;
+    o[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+    o[9] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
+    o[10] = 2.8906114426405538f * xy * z;
+    o[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
+    o[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
+    o[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
+    o[14] = 1.4453057213202769f * z * (x2 - y2);
+    o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+}
+__global__ __launch_bounds__(EN_BLOCK) void k_sh4(const float* __restrict__ dirs, uint32_t stride, uint32_t n,
+                                                   float4* __restrict__ out) {
+    const uint32_t i = blockIdx.x * EN_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float* d = dirs + (size_t)i * stride;
+    float o[16];
+    sh4_eval(d[0] * 2.f - 1.f, d[1] * 2.f - 1.f, d[2] * 2.f - 1.f, o);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) out[4 * (size_t)i + q] = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+}
+extern "C" int xr_sh4(const float* dirs, uint32_t dir_stride, uint32_t n, float* out, void* stream_) {
+    if (n == 0) return XR_OK;
+    XR_REQUIRE(dirs && out && dir_stride >= 3, "bad argument");
+    XR_REQUIRE(((uintptr_t)out & 15) == 0, "out must be 16-byte aligned");
+    hipLaunchKernelGGL(k_sh4, dim3(xr_div_up(n, EN_BLOCK)), dim3(EN_BLOCK), 0, (hipStream_t)stream_, dirs, dir_stride, n,
+                       (float4*)out);
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}

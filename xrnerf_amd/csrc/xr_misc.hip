@@ -1,0 +1,127 @@
+// Library plumbing (error string, version, RNG host helper) and the small kernels on either side
+// of the path: ray generation, Huber loss gradient, fused Adam(+EMA).
+#include "xr_common.h"
+#include <cstdarg>
+
+static thread_local char g_err[512] = "";
+void xr_set_error(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* xr_last_error(void) { return g_err; }
+extern "C" int xr_version(void) { return 100; }
+
+extern "C" void xr_pcg32_host_state(uint64_t seed, uint64_t ncalls, uint64_t* state_host, uint64_t* inc_host) {
+    xr_pcg32 r; r.seed(seed, 1u);
+    for (uint64_t c = 0; c < ncalls; ++c) r.advance(1ull << 32);
+    *state_host = r.state; *inc_host = r.inc;
+}
+
+// ------------------------------------------------------------------ ray generation
+// get_rays_np_hash (/root/reference/xrnerf/datasets/load_data/get_rays.py:35-69) in fp32:
+// pixel centre +0.5, dir = ((i-cx)/fx, (j-cy)/fy, 1), d = R*dir, normalise, o = translation.
+struct Pose43 { float m[12]; };
+__global__ __launch_bounds__(256) void k_gen_rays(Pose43 p, int W, float fx, float fy, float cx, float cy, int row0,
+                                                   uint32_t n, float* __restrict__ rays_o, float* __restrict__ rays_d) {
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= n) return;
+    const int r = q / W, c = q % W;
+    const float i = (float)c + 0.5f, j = (float)(row0 + r) + 0.5f;
+    const float dx = (i - cx) / fx, dy = (j - cy) / fy;
+    float v[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float a = __fmul_rn(p.m[k], dx);
+        a = __fadd_rn(a, __fmul_rn(p.m[3 + k], dy));
+        v[k] = __fadd_rn(a, p.m[6 + k]);
+    }
+    const float nrm = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(v[0], v[0]), __fmul_rn(v[1], v[1])), __fmul_rn(v[2], v[2])));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { rays_d[3 * (size_t)q + k] = v[k] / nrm; rays_o[3 * (size_t)q + k] = p.m[9 + k]; }
+}
+extern "C" int xr_gen_rays(const float* pose43_host, int H, int W, float fx, float fy, float cx, float cy, int row0,
+                           int nrows, float* rays_o, float* rays_d, void* stream_) {
+    XR_REQUIRE(pose43_host && rays_o && rays_d, "null pointer");
+    XR_REQUIRE(H > 0 && W > 0 && row0 >= 0 && nrows > 0 && row0 + nrows <= H, "bad image window");
+    Pose43 p; memcpy(p.m, pose43_host, sizeof(p.m));
+    const uint32_t n = (uint32_t)nrows * (uint32_t)W;
+    hipLaunchKernelGGL(k_gen_rays, dim3(xr_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream_, p, W, fx, fy, cx, cy, row0, n,
+                       rays_o, rays_d);
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}
+
+// ------------------------------------------------------------------ Huber loss * scale, gradient
+__global__ __launch_bounds__(256) void k_huber(const float* __restrict__ rgb, const float* __restrict__ target, uint32_t n,
+                                                float delta, float scale, float* __restrict__ grad, float* __restrict__ loss) {
+    __shared__ float ws[4];
+    float acc = 0.f;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float r = rgb[i] - target[i], a = fabsf(r);
+        if (a < delta) { acc += 0.5f * r * r; grad[i] = scale * r; }
+        else { acc += delta * (a - 0.5f * delta); grad[i] = scale * delta * (r > 0.f ? 1.f : -1.f); }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, scale * ((ws[0] + ws[1]) + (ws[2] + ws[3])));
+}
+extern "C" int xr_huber_loss_grad(const float* rgb, const float* target, uint32_t n_elems, float delta, float scale,
+                                  float* grad, float* loss_out, void* stream_) {
+    XR_REQUIRE(rgb && target && grad && loss_out && n_elems > 0, "bad argument");
+    hipLaunchKernelGGL(k_huber, dim3(min(xr_div_up(n_elems, 256), 1024u)), dim3(256), 0, (hipStream_t)stream_, rgb, target,
+                       n_elems, delta, scale, grad, loss_out);
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}
+
+// ------------------------------------------------------------------ fused Adam (+L2 weight decay, + optional EMA)
+// torch.optim.Adam semantics; one pass over p,g,m,v(,ema): 16 B per lane per stream.
+__device__ inline void adam1(float& p, float g, float& m, float& v, float b1, float b2, float step_size, float bc2s,
+                             float eps, float wd) {
+    g = g + wd * p;
+    m = b1 * m + (1.f - b1) * g;
+    v = b2 * v + (1.f - b2) * g * g;
+    p = p - step_size * (m / (sqrtf(v) / bc2s + eps));
+}
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                               float* __restrict__ v, size_t n, float b1, float b2, float step_size,
+                                               float bc2s, float eps, float wd, float* __restrict__ ema, float mom) {
+    const size_t n4 = n / 4;
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 pp = ((float4*)p)[i], mm = ((float4*)m)[i], vv = ((float4*)v)[i];
+        const float4 gg = ((const float4*)g)[i];
+        adam1(pp.x, gg.x, mm.x, vv.x, b1, b2, step_size, bc2s, eps, wd);
+        adam1(pp.y, gg.y, mm.y, vv.y, b1, b2, step_size, bc2s, eps, wd);
+        adam1(pp.z, gg.z, mm.z, vv.z, b1, b2, step_size, bc2s, eps, wd);
+        adam1(pp.w, gg.w, mm.w, vv.w, b1, b2, step_size, bc2s, eps, wd);
+        ((float4*)p)[i] = pp; ((float4*)m)[i] = mm; ((float4*)v)[i] = vv;
+        if (ema) {
+            float4 e = ((float4*)ema)[i];
+            e.x = (1.f - mom) * e.x + mom * pp.x; e.y = (1.f - mom) * e.y + mom * pp.y;
+            e.z = (1.f - mom) * e.z + mom * pp.z; e.w = (1.f - mom) * e.w + mom * pp.w;
+            ((float4*)ema)[i] = e;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t i = n4 * 4 + threadIdx.x;
+        float pp = p[i], mm = m[i], vv = v[i];
+        adam1(pp, g[i], mm, vv, b1, b2, step_size, bc2s, eps, wd);
+        p[i] = pp; m[i] = mm; v[i] = vv;
+        if (ema) ema[i] = (1.f - mom) * ema[i] + mom * pp;
+    }
+}
+extern "C" int xr_adam_step(float* p, const float* g, float* m, float* v, size_t n, int step, float lr, float beta1,
+                            float beta2, float eps, float weight_decay, float* ema, float ema_momentum, void* stream_) {
+    if (n == 0) return XR_OK;
+    XR_REQUIRE(p && g && m && v && step >= 1, "bad argument");
+    XR_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)ema) & 15) == 0, "buffers must be 16-byte aligned");
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    const uint32_t blocks = min(xr_div_up(n / 4 + 1, 256), 2048u);
+    hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, p, g, m, v, n, beta1, beta2, lr / bc1,
+                       sqrtf(bc2), eps, weight_decay, ema, ema_momentum);
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}

@@ -1,0 +1,474 @@
+// Fully fused tiny MLP of the Instant-NGP path (density_net + SH-4 + color_net), forward and
+// backward, on the CDNA4 matrix cores -- the only GEMM-shaped work on the path.
+//
+// Replaces tcnn.Network(FullyFusedMLP) x2 + tcnn.Encoding(SphericalHarmonics) as called from
+// /root/reference/xrnerf/models/mlps/hashnerf_mlp.py:39-45,55-79,107-111.
+//
+// Design (gfx950, wave64):
+//   * everything is computed TRANSPOSED: neurons x samples.  One wave owns a tile of 32 samples;
+//     v_mfma_f32_32x32x2_f32 (fp32 in / fp32 accumulate == an fmaf chain, exact fp32) produces a
+//     32(neurons) x 32(samples) tile whose C/D register layout is
+//         lane l: column (sample) = l & 31,  row (neuron) = (reg & 3) + 8*(reg >> 2) + 4*(l >> 5).
+//     The B operand of the NEXT layer wants  B[k = l>>5][n = l&31]  for a pair of k: because a
+//     sum over k may be taken in any order, K-step `reg` simply uses the pair of neurons that
+//     register `reg` already holds in the two lane halves -- so hidden activations NEVER leave
+//     registers, there is no LDS round trip and no shuffle between layers.  The matching
+//     permutation is applied to the A operand (the weights) purely through LDS addressing.
+//   * weights live in LDS once per workgroup, row-major [out][in] with an odd row stride (in+1):
+//     conflict-free for the forward access (32 lanes = 32 rows) and for the transposed access of
+//     the backward chain (32 lanes = 32 consecutive columns).
+//   * backward recomputes the forward activations in registers (nothing is saved by the
+//     forward: 0 B/sample of HBM instead of 768 B), runs the dX chain with the same trick on W^T,
+//     and forms dW = G * H^T on the matrix cores as well; that contraction runs over SAMPLES, i.e.
+//     it needs both operands transposed, which is the one place a per-wave LDS staging tile
+//     ([neuron][33]) is used.  dW accumulates in registers across all tiles a wave processes,
+//     then block-reduces through LDS atomics into one partial per workgroup; a second tiny
+//     kernel sums the partials (fixed order).
+//   * the color net's input is cat(density_out[1:16], SH16) + one pad lane (tcnn pads the
+//     Identity-encoded input with 1.0).  In "slot" space m = 0..31 we use column (m+31)%32 of the
+//     first color layer, i.e. slot m>=1 is input m-1 and slot 0 is the pad: then slot m <-> density
+//     output row m for m<16, so density_out registers feed the color net in place and its input
+//     gradient lands back on the density-output registers with no data movement either.
+#include "xr_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+#define MLP_WAVES 4
+#define MLP_THREADS (MLP_WAVES * 64)
+#define W_HID 64          // n_neurons of the reference config (nerf_blender_local01.py:106-124)
+#define ENC_DIM 32        // 16 levels x 2 features
+#define ST33 33
+
+__device__ __forceinline__ constexpr int drow(int r) { return (r & 3) + 8 * (r >> 2); }
+
+// ---- topology bookkeeping --------------------------------------------------------------------
+// layer list of one network: in(32) -> NH x 64 -> out(16, padded to a 32-row tile in LDS)
+__host__ __device__ constexpr int net_in_dim(int l) { return l == 0 ? 32 : W_HID; }
+__host__ __device__ constexpr int net_out_dim(int nh, int l) { return l == nh ? 16 : W_HID; }        // global rows
+__host__ __device__ constexpr int net_out_rows_lds(int nh, int l) { return l == nh ? 32 : W_HID; }   // padded rows
+__host__ __device__ constexpr int net_stride(int l) { return net_in_dim(l) + 1; }
+__host__ __device__ constexpr int net_lds_off(int nh, int l) {
+    int o = 0;
+    for (int i = 0; i < l; ++i) o += net_out_rows_lds(nh, i) * net_stride(i);
+    return o;
+}
+__host__ __device__ constexpr int net_glb_off(int nh, int l) {
+    int o = 0;
+    for (int i = 0; i < l; ++i) o += net_out_dim(nh, i) * net_in_dim(i);
+    return o;
+}
+template <int NH>
+struct NetShape {
+    static constexpr int n_mats = NH + 1;
+    __host__ __device__ static constexpr int in_dim(int l) { return net_in_dim(l); }
+    __host__ __device__ static constexpr int out_dim(int l) { return net_out_dim(NH, l); }
+    __host__ __device__ static constexpr int out_rows_lds(int l) { return net_out_rows_lds(NH, l); }
+    __host__ __device__ static constexpr int stride(int l) { return net_stride(l); }
+    __host__ __device__ static constexpr int lds_off(int l) { return net_lds_off(NH, l); }
+    __host__ __device__ static constexpr int glb_off(int l) { return net_glb_off(NH, l); }
+    static constexpr int lds_floats = net_lds_off(NH, NH + 1);
+    static constexpr int glb_floats = net_glb_off(NH, NH + 1);
+};
+
+// copy a network's weights global -> LDS (padded stride, zero-padded output rows).
+// first_layer_rot: apply the color-net slot permutation  LDS[o][m] = W[o][(m+31)&31].
+template <int NH>
+__device__ inline void load_weights(float* __restrict__ lds, const float* __restrict__ w, bool first_layer_rot) {
+    using S = NetShape<NH>;
+#pragma unroll
+    for (int l = 0; l <= NH; ++l) {
+        const int K = S::in_dim(l), rows = S::out_dim(l), prow = S::out_rows_lds(l), st = S::stride(l);
+        float* dst = lds + S::lds_off(l);
+        const float* src = w + S::glb_off(l);
+        for (int e = threadIdx.x; e < prow * K; e += MLP_THREADS) {
+            const int o = e / K, m = e % K;
+            const int col = (l == 0 && first_layer_rot) ? ((m + 31) & 31) : m;
+            dst[o * st + m] = o < rows ? src[o * K + col] : 0.f;
+        }
+    }
+}
+
+// ---- building blocks (all tiles in the C/D register layout described above) ------------------
+// out[TO] = W[TO*32][TI*32] . in[TI]
+template <int TI, int TO>
+__device__ __forceinline__ void layer_fwd(const float* __restrict__ W, const f32x16 (&in)[TI], f32x16 (&out)[TO], int col, int hi) {
+    constexpr int ST = TI * 32 + 1;
+#pragma unroll
+    for (int to = 0; to < TO; ++to)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[to][r] = 0.f;
+    const float* wl = W + col * ST + 4 * hi;
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float b = in[ti][r];
+#pragma unroll
+            for (int to = 0; to < TO; ++to) {
+                const float a = wl[to * 32 * ST + ti * 32 + drow(r)];
+                out[to] = MFMA32(a, b, out[to]);
+            }
+        }
+}
+// gin[TI] = W^T . g[TO]     (W is [TO*32][TI*32], stride TI*32+1)
+template <int TO, int TI>
+__device__ __forceinline__ void layer_bwd(const float* __restrict__ W, const f32x16 (&g)[TO], f32x16 (&gin)[TI], int col, int hi) {
+    constexpr int ST = TI * 32 + 1;
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gin[ti][r] = 0.f;
+    const float* wl = W + (4 * hi) * ST + col;
+#pragma unroll
+    for (int to = 0; to < TO; ++to)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float b = g[to][r];
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti) {
+                const float a = wl[(to * 32 + drow(r)) * ST + ti * 32];
+                gin[ti] = MFMA32(a, b, gin[ti]);
+            }
+        }
+}
+__device__ __forceinline__ void relu_tile(f32x16& t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = t[r] > 0.f ? t[r] : 0.f;
+}
+__device__ __forceinline__ void relu_mask(f32x16& g, const f32x16& h) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g[r] = h[r] > 0.f ? g[r] : 0.f;
+}
+// acc[to][ti] += g[to] (rows = out neurons) x h[ti]^T (rows = in neurons), contraction over the
+// 32 samples of the tile; `stage` is this wave's private LDS tile [(TO+TI)*32][33].
+template <int TO, int TI>
+__device__ __forceinline__ void dw_accumulate(f32x16 (&acc)[TO][TI], const f32x16 (&g)[TO], const f32x16 (&h)[TI],
+                                              float* __restrict__ stage, int col, int hi) {
+#pragma unroll
+    for (int to = 0; to < TO; ++to)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stage[(to * 32 + drow(r) + 4 * hi) * ST33 + col] = g[to][r];
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stage[((TO + ti) * 32 + drow(r) + 4 * hi) * ST33 + col] = h[ti][r];
+    __builtin_amdgcn_wave_barrier();   // same-wave LDS ops complete in order; keep the compiler from reordering
+    const float* sg = stage + col * ST33 + hi;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        float a[TO], b[TI];
+#pragma unroll
+        for (int to = 0; to < TO; ++to) a[to] = sg[(to * 32) * ST33 + 2 * t];
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) b[ti] = sg[((TO + ti) * 32) * ST33 + 2 * t];
+#pragma unroll
+        for (int to = 0; to < TO; ++to)
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti) acc[to][ti] = MFMA32(a[to], b[ti], acc[to][ti]);
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+// block-level reduction target: LDS buffer in the GLOBAL (compact, [out][in]) parameter layout
+template <int TO, int TI>
+__device__ __forceinline__ void dw_flush(const f32x16 (&acc)[TO][TI], float* __restrict__ dst, int rows, int K, bool rot,
+                                         int col, int hi) {
+#pragma unroll
+    for (int to = 0; to < TO; ++to)
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = to * 32 + drow(r) + 4 * hi;
+                int m = ti * 32 + col;
+                if (rot) m = (m + 31) & 31;
+                if (o < rows) atomicAdd(&dst[o * K + m], acc[to][ti][r]);   // ds_add_f32
+            }
+}
+
+// SH-4 on d' = 2x-1 (tcnn SphericalHarmonics degree 4)
+__device__ __forceinline__ void sh4_eval(float x, float y, float z, float* o) {
+    const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+    o[0] = 0.28209479177387814f;
+    o[1] = -0.48860251190291987f * y;
+    o[2] = 0.48860251190291987f * z;
+    o[3] = -0.48860251190291987f * x;
+    o[4] = 1.0925484305920792f * xy;
+    o[5] = -1.0925484305920792f * yz;
+    o[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+    o[7] = -1.0925484305920792f * xz;
+    o[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+    o[9] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
+    o[10] = 2.8906114426405538f * xy * z;
+    o[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
+    o[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
+    o[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
+    o[14] = 1.4453057213202769f * z * (x2 - y2);
+    o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+}
+
+// ---- per-tile pieces ---------------------------------------------------------------------------
+__device__ __forceinline__ void load_enc_tile(const float* __restrict__ enc_t, uint32_t ld, uint32_t s, f32x16& xe, int hi) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xe[r] = enc_t[(size_t)(drow(r) + 4 * hi) * ld + s];
+}
+// color-net input tile in slot space from the density output tile + SH of the view direction
+__device__ __forceinline__ void build_color_in(const f32x16& dout, const float* __restrict__ dirs, uint32_t dir_stride,
+                                               uint32_t s, float pad_value, f32x16& cin, int hi) {
+    const float* d = dirs + (size_t)s * dir_stride;
+    float sh[16];
+    sh4_eval(d[0] * 2.f - 1.f, d[1] * 2.f - 1.f, d[2] * 2.f - 1.f, sh);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) cin[r] = dout[r];
+    if (hi == 0) cin[0] = pad_value;                       // slot 0 = pad (density row 0 is sigma, not an input)
+#pragma unroll
+    for (int r = 8; r < 16; ++r) {                         // slots 16..31 = SH[0..15]
+        const int m0 = drow(r) - 16;                       // hi = 0 -> m0, hi = 1 -> m0 + 4
+        cin[r] = hi ? sh[m0 + 4] : sh[m0];
+    }
+}
+
+// ------------------------------------------------------------------ forward kernel
+template <int NHD, int NHC, bool WITH_COLOR>
+__global__ __launch_bounds__(MLP_THREADS, 2) void k_nerf_mlp_fwd(const float* __restrict__ enc_t, uint32_t ld,
+                                                               const float* __restrict__ dirs, uint32_t dir_stride,
+                                                               uint32_t n, const float* __restrict__ w_density,
+                                                               const float* __restrict__ w_color, float pad_value,
+                                                               float4* __restrict__ raw) {
+    using SD = NetShape<NHD>;
+    using SC = NetShape<NHC>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* wd = lds;
+    float* wc = lds + SD::lds_floats;
+    load_weights<NHD>(wd, w_density, false);
+    if (WITH_COLOR) load_weights<NHC>(wc, w_color, true);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, hi = lane >> 5;
+    const uint32_t n_tiles = (n + 31) / 32;
+    for (uint32_t tile = blockIdx.x * MLP_WAVES + wave; tile < n_tiles; tile += gridDim.x * MLP_WAVES) {
+        const uint32_t s = tile * 32 + col;
+        const uint32_t sc = s < n ? s : n - 1;             // clamp loads of the ragged last tile
+        f32x16 x[1], h[2], h2[2], dout[1];
+        load_enc_tile(enc_t, ld, sc, x[0], hi);
+        layer_fwd<1, 2>(wd + SD::lds_off(0), x, h, col, hi);
+        relu_tile(h[0]); relu_tile(h[1]);
+#pragma unroll
+        for (int l = 1; l < NHD; ++l) {
+            layer_fwd<2, 2>(wd + SD::lds_off(l), h, h2, col, hi);
+            relu_tile(h2[0]); relu_tile(h2[1]);
+            h[0] = h2[0]; h[1] = h2[1];
+        }
+        layer_fwd<2, 1>(wd + SD::lds_off(NHD), h, dout, col, hi);
+        float4 o = make_float4(0.f, 0.f, 0.f, dout[0][0]);   // hi==0, reg 0 <-> row 0 = sigma
+        if (WITH_COLOR) {
+            f32x16 cin[1], cout[1];
+            build_color_in(dout[0], dirs, dir_stride, sc, pad_value, cin[0], hi);
+            layer_fwd<1, 2>(wc + SC::lds_off(0), cin, h, col, hi);
+            relu_tile(h[0]); relu_tile(h[1]);
+#pragma unroll
+            for (int l = 1; l < NHC; ++l) {
+                layer_fwd<2, 2>(wc + SC::lds_off(l), h, h2, col, hi);
+                relu_tile(h2[0]); relu_tile(h2[1]);
+                h[0] = h2[0]; h[1] = h2[1];
+            }
+            layer_fwd<2, 1>(wc + SC::lds_off(NHC), h, cout, col, hi);
+            o.x = cout[0][0]; o.y = cout[0][1]; o.z = cout[0][2];   // rows 0,1,2 in the hi==0 half
+        }
+        if (hi == 0 && s < n) raw[s] = o;
+    }
+}
+
+// ------------------------------------------------------------------ backward kernel
+// Specialised for the reference topology family NHD = 1, NHC = 2 (density 32->64->16,
+// color 32->64->64->16): every activation and all 12 dW accumulator tiles stay in registers.
+__global__ __launch_bounds__(MLP_THREADS, 1) void k_nerf_mlp_bwd_1_2(
+    const float* __restrict__ enc_t, uint32_t ld, const float* __restrict__ dirs, uint32_t dir_stride, uint32_t n,
+    const float* __restrict__ w_density, const float* __restrict__ w_color, float pad_value,
+    const float4* __restrict__ draw, float* __restrict__ denc_t, float* __restrict__ partial /*[grid][GW]*/) {
+    using SD = NetShape<1>;
+    using SC = NetShape<2>;
+    constexpr int GW = SD::glb_floats + SC::glb_floats;                // 3072 + 7168
+    constexpr int STAGE = 4 * 32 * ST33;                               // floats per wave
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* wd = lds;
+    float* wc = wd + SD::lds_floats;
+    float* stage_all = wc + SC::lds_floats;                            // MLP_WAVES * STAGE floats (>= GW)
+    load_weights<1>(wd, w_density, false);
+    load_weights<2>(wc, w_color, true);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, hi = lane >> 5;
+    float* stage = stage_all + wave * STAGE;
+
+    f32x16 a_d0[2][1], a_d1[1][2], a_c0[2][1], a_c1[2][2], a_c2[1][2];   // dW accumulators
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        a_d0[0][0][r] = a_d0[1][0][r] = 0.f; a_d1[0][0][r] = a_d1[0][1][r] = 0.f;
+        a_c0[0][0][r] = a_c0[1][0][r] = 0.f;
+        a_c1[0][0][r] = a_c1[0][1][r] = a_c1[1][0][r] = a_c1[1][1][r] = 0.f;
+        a_c2[0][0][r] = a_c2[0][1][r] = 0.f;
+    }
+
+    const uint32_t n_tiles = (n + 31) / 32;
+    for (uint32_t tile = blockIdx.x * MLP_WAVES + wave; tile < n_tiles; tile += gridDim.x * MLP_WAVES) {
+        const uint32_t s = tile * 32 + col;
+        const bool live = s < n;
+        const uint32_t sc = live ? s : n - 1;
+        // ---- recompute forward, keep activations
+        f32x16 xe[1], hd[2], dout[1], cin[1], hc1[2], hc2[2];
+        load_enc_tile(enc_t, ld, sc, xe[0], hi);
+        layer_fwd<1, 2>(wd + SD::lds_off(0), xe, hd, col, hi);
+        relu_tile(hd[0]); relu_tile(hd[1]);
+        layer_fwd<2, 1>(wd + SD::lds_off(1), hd, dout, col, hi);
+        build_color_in(dout[0], dirs, dir_stride, sc, pad_value, cin[0], hi);
+        layer_fwd<1, 2>(wc + SC::lds_off(0), cin, hc1, col, hi);
+        relu_tile(hc1[0]); relu_tile(hc1[1]);
+        layer_fwd<2, 2>(wc + SC::lds_off(1), hc1, hc2, col, hi);
+        relu_tile(hc2[0]); relu_tile(hc2[1]);
+        // ---- output gradients: rows 0..2 of the color output tile = dL/d(rgb raw), all else 0.
+        // dead (ragged) samples get a zero gradient so they contribute nothing to dW.
+        float4 dr = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live && hi == 0) dr = draw[s];
+        f32x16 g1[1], g2[2], g2b[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g1[0][r] = 0.f;
+        g1[0][0] = dr.x; g1[0][1] = dr.y; g1[0][2] = dr.z;             // hi==1 lanes hold zeros
+        // color output layer
+        dw_accumulate<1, 2>(a_c2, g1, hc2, stage, col, hi);
+        layer_bwd<1, 2>(wc + SC::lds_off(2), g1, g2, col, hi);
+        relu_mask(g2[0], hc2[0]); relu_mask(g2[1], hc2[1]);
+        // color hidden layer 2
+        dw_accumulate<2, 2>(a_c1, g2, hc1, stage, col, hi);
+        layer_bwd<2, 2>(wc + SC::lds_off(1), g2, g2b, col, hi);
+        relu_mask(g2b[0], hc1[0]); relu_mask(g2b[1], hc1[1]);
+        // color input layer
+        dw_accumulate<2, 1>(a_c0, g2b, cin, stage, col, hi);
+        layer_bwd<2, 1>(wc + SC::lds_off(0), g2b, g1, col, hi);       // g1 = dL/d(color input slots)
+        // slots 1..15 are density-output rows 1..15; row 0 takes dL/d(sigma raw); rows >= 16 are padding
+#pragma unroll
+        for (int r = 8; r < 16; ++r) g1[0][r] = 0.f;
+        if (hi == 0) g1[0][0] = dr.w;
+        // density output layer
+        dw_accumulate<1, 2>(a_d1, g1, hd, stage, col, hi);
+        layer_bwd<1, 2>(wd + SD::lds_off(1), g1, g2, col, hi);
+        relu_mask(g2[0], hd[0]); relu_mask(g2[1], hd[1]);
+        // density input layer
+        dw_accumulate<2, 1>(a_d0, g2, xe, stage, col, hi);
+        layer_bwd<2, 1>(wd + SD::lds_off(0), g2, g1, col, hi);        // g1 = dL/d(encoded features)
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) denc_t[(size_t)(drow(r) + 4 * hi) * ld + s] = g1[0][r];
+        }
+    }
+    // ---- block reduction of dW through LDS (compact global layout), then one partial per block
+    __syncthreads();
+    float* red = stage_all;
+    for (int e = threadIdx.x; e < GW; e += MLP_THREADS) red[e] = 0.f;
+    __syncthreads();
+    dw_flush<2, 1>(a_d0, red + SD::glb_off(0), 64, 32, false, col, hi);
+    dw_flush<1, 2>(a_d1, red + SD::glb_off(1), 16, 64, false, col, hi);
+    float* redc = red + SD::glb_floats;
+    dw_flush<2, 1>(a_c0, redc + SC::glb_off(0), 64, 32, true, col, hi);
+    dw_flush<2, 2>(a_c1, redc + SC::glb_off(1), 64, 64, false, col, hi);
+    dw_flush<1, 2>(a_c2, redc + SC::glb_off(2), 16, 64, false, col, hi);
+    __syncthreads();
+    float* out = partial + (size_t)blockIdx.x * GW;
+    for (int e = threadIdx.x; e < GW; e += MLP_THREADS) out[e] = red[e];
+}
+
+// grad[j] += sum_b partial[b][j], fixed order over b
+__global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict__ partial, uint32_t nb, uint32_t gw,
+                                                          uint32_t split, float* __restrict__ g_density,
+                                                          float* __restrict__ g_color) {
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= gw) return;
+    float s = 0.f;
+    for (uint32_t b = 0; b < nb; ++b) s += partial[(size_t)b * gw + j];
+    if (j < split) g_density[j] += s; else g_color[j - split] += s;
+}
+
+// ------------------------------------------------------------------ host side
+static int g_cus = 0;
+extern "C" int xr_device_cus(void) {
+    if (g_cus == 0) {
+        int dev = 0; hipDeviceProp_t p;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
+        g_cus = p.multiProcessorCount;
+    }
+    return g_cus;
+}
+
+template <int NHD, int NHC>
+static int launch_fwd(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
+                      const float* wd, const float* wc, float pad, float* raw, hipStream_t stream) {
+    const int cus = xr_device_cus() > 0 ? xr_device_cus() : 256;
+    const uint32_t n_tiles = (n + 31) / 32;
+    const uint32_t grid = min(xr_div_up(n_tiles, MLP_WAVES), (uint32_t)cus * 3u);
+    if (dirs) {
+        const size_t lds = (NetShape<NHD>::lds_floats + NetShape<NHC>::lds_floats) * sizeof(float);
+        auto k = k_nerf_mlp_fwd<NHD, NHC, true>;
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XR_EHIP;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, wd, wc, pad, (float4*)raw);
+    } else {
+        const size_t lds = NetShape<NHD>::lds_floats * sizeof(float);
+        auto k = k_nerf_mlp_fwd<NHD, NHC, false>;
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XR_EHIP;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, wd, wc, pad, (float4*)raw);
+    }
+    return XR_OK;
+}
+
+extern "C" int xr_nerf_mlp_fwd(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
+                               const float* w_density, const float* w_color, int n_hidden_density, int n_hidden_color,
+                               float pad_value, float* raw, void* stream_) {
+    if (n == 0) return XR_OK;
+    XR_REQUIRE(enc_t && w_density && raw, "null pointer");
+    XR_REQUIRE(!dirs || (w_color && dir_stride >= 3), "color path needs w_color and dir_stride >= 3");
+    XR_REQUIRE(ld >= n && ((uintptr_t)raw & 15) == 0, "bad ld / raw alignment");
+    int rc;
+    if (n_hidden_density == 1 && n_hidden_color == 2) rc = launch_fwd<1, 2>(enc_t, ld, dirs, dir_stride, n, w_density, w_color, pad_value, raw, (hipStream_t)stream_);
+    else if (n_hidden_density == 1 && n_hidden_color == 1) rc = launch_fwd<1, 1>(enc_t, ld, dirs, dir_stride, n, w_density, w_color, pad_value, raw, (hipStream_t)stream_);
+    else if (n_hidden_density == 2 && n_hidden_color == 2) rc = launch_fwd<2, 2>(enc_t, ld, dirs, dir_stride, n, w_density, w_color, pad_value, raw, (hipStream_t)stream_);
+    else if (n_hidden_density == 2 && n_hidden_color == 3) rc = launch_fwd<2, 3>(enc_t, ld, dirs, dir_stride, n, w_density, w_color, pad_value, raw, (hipStream_t)stream_);
+    else { xr_set_error("xr_nerf_mlp_fwd: unsupported hidden-layer counts (%d,%d)", n_hidden_density, n_hidden_color); return XR_EINVAL; }
+    if (rc != XR_OK) { xr_set_error("xr_nerf_mlp_fwd: cannot configure dynamic LDS"); return rc; }
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}
+
+static uint32_t bwd_grid(uint32_t n) {
+    const int cus = xr_device_cus() > 0 ? xr_device_cus() : 256;
+    const uint32_t n_tiles = (n + 31) / 32;
+    return min(xr_div_up(n_tiles, MLP_WAVES), (uint32_t)cus);
+}
+extern "C" size_t xr_nerf_mlp_bwd_workspace_bytes(uint32_t n) {
+    (void)n;
+    const int cus = xr_device_cus() > 0 ? xr_device_cus() : 256;
+    return (size_t)cus * (NetShape<1>::glb_floats + NetShape<2>::glb_floats) * sizeof(float);
+}
+
+extern "C" int xr_nerf_mlp_bwd(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
+                               const float* w_density, const float* w_color, int n_hidden_density, int n_hidden_color,
+                               float pad_value, const float* draw, float* denc_t, float* grad_w_density,
+                               float* grad_w_color, void* workspace, size_t workspace_bytes, void* stream_) {
+    if (n == 0) return XR_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    XR_REQUIRE(enc_t && dirs && w_density && w_color && draw && denc_t && grad_w_density && grad_w_color, "null pointer");
+    XR_REQUIRE(ld >= n && dir_stride >= 3 && ((uintptr_t)draw & 15) == 0, "bad ld / stride / alignment");
+    if (!(n_hidden_density == 1 && n_hidden_color == 2)) {
+        xr_set_error("xr_nerf_mlp_bwd: only the (1,2) hidden-layer topology of configs/instant_ngp is built (got %d,%d)",
+                     n_hidden_density, n_hidden_color);
+        return XR_EINVAL;
+    }
+    XR_REQUIRE(workspace && workspace_bytes >= xr_nerf_mlp_bwd_workspace_bytes(n), "workspace too small");
+    constexpr int GW = NetShape<1>::glb_floats + NetShape<2>::glb_floats;
+    const size_t lds = (NetShape<1>::lds_floats + NetShape<2>::lds_floats + MLP_WAVES * 4 * 32 * ST33) * sizeof(float);
+    static_assert(MLP_WAVES * 4 * 32 * ST33 >= GW, "stage area doubles as the dW reduction buffer");
+    XR_HIP(hipFuncSetAttribute((const void*)k_nerf_mlp_bwd_1_2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const uint32_t grid = bwd_grid(n);
+    hipLaunchKernelGGL(k_nerf_mlp_bwd_1_2, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n,
+                       w_density, w_color, pad_value, (const float4*)draw, denc_t, (float*)workspace);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(xr_div_up(GW, 256)), dim3(256), 0, stream, (const float*)workspace, grid,
+                       (uint32_t)GW, (uint32_t)NetShape<1>::glb_floats, grad_w_density, grad_w_color);
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}

@@ -1,0 +1,424 @@
+// K1 (occupancy-grid ray march), K2 (re-pack), K3/K4/K5 (compositor fwd / bwd / inference).
+// Hand-written for gfx950 (wave64).  This translation unit is compiled with -ffp-contract=off:
+// K1's index decisions hinge on `o + t*d` being mul-then-add exactly like the reference's
+// CPU-compiled kernels (the only runnable reference; SURVEY.md section 7 "Hard parts").
+//
+// Reference: /root/reference/extensions/ngp_raymarch/src/{ray_sampler,compacted_coord,calc_rgb}.cu
+// and include/{ray_sampler_header,raymarch_shared}.h (line cites inline).
+#include "xr_common.h"
+#include <cfloat>
+
+#define RM_BLOCK 256
+
+// ------------------------------------------------------------------ block-wide exclusive scan
+// 256 threads = 4 wave64.  Returns the exclusive prefix of v; *total gets the block sum.
+__device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t* total, uint32_t* lds4) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) lds4[wid] = inc;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < RM_BLOCK / 64; ++w) {
+        uint32_t t = lds4[w];
+        if (w < wid) woff += t;
+        tot += t;
+    }
+    __syncthreads();
+    *total = tot;
+    return woff + inc - v;
+}
+
+// ------------------------------------------------------------------ march helpers
+struct Ray { float ox, oy, oz, dx, dy, dz, ix, iy, iz; };
+
+__device__ inline float rm_calc_dt(float t, float cone) {           // ray_sampler_header.h:24-25
+    return xr_clampf(t * cone, xr_min_step(), xr_max_step());
+}
+__device__ inline int rm_mip_from_pos(float px, float py, float pz) { // :37-43
+    float m = fabsf(px - 0.5f);
+    float b = fabsf(py - 0.5f); if (b > m) m = b;
+    float c = fabsf(pz - 0.5f); if (c > m) m = c;
+    int e; frexpf(m, &e);
+    return min(7, max(0, e + 1));
+}
+__device__ inline int rm_mip_from_dt(float dt, float px, float py, float pz) { // :45-54
+    int mip = rm_mip_from_pos(px, py, pz);
+    dt *= 256.0f;
+    if (dt < 1.f) return mip;
+    int e; frexpf(dt, &e);
+    return min(7, max(e, mip));
+}
+__device__ inline bool rm_occupied(float px, float py, float pz, const uint8_t* __restrict__ bf, int mip) { // :298-319
+    float s = scalbnf(1.0f, -mip);
+    float qx = (px - 0.5f) * s + 0.5f, qy = (py - 0.5f) * s + 0.5f, qz = (pz - 0.5f) * s + 0.5f;
+    int ix = (int)(qx * 128.0f), iy = (int)(qy * 128.0f), iz = (int)(qz * 128.0f);
+    ix = min(max(ix, 0), 127); iy = min(max(iy, 0), 127); iz = min(max(iz, 0), 127);
+    uint32_t idx = xr_morton3d((uint32_t)ix, (uint32_t)iy, (uint32_t)iz);
+    return (bf[(idx >> 3) + (uint32_t)mip * (XR_GRID_CELLS / 8)] >> (idx & 7)) & 1;
+}
+__device__ inline float rm_lt_min(float a, float b) { return a < b ? a : b; }  // reference `min` = a<b?a:b
+__device__ inline float rm_advance(float t, float cone, float px, float py, float pz, const Ray& r, uint32_t res) { // :271-296
+    float rf = (float)res;
+    float ppx = rf * px, ppy = rf * py, ppz = rf * pz;
+    float tx = (floorf(ppx + 0.5f + 0.5f * copysignf(1.0f, r.dx)) - ppx) * r.ix;
+    float ty = (floorf(ppy + 0.5f + 0.5f * copysignf(1.0f, r.dy)) - ppy) * r.iy;
+    float tz = (floorf(ppz + 0.5f + 0.5f * copysignf(1.0f, r.dz)) - ppz) * r.iz;
+    float tt = rm_lt_min(rm_lt_min(tx, ty), tz);
+    float target = t + fmaxf(tt / rf, 0.0f);
+    do { t += rm_calc_dt(t, cone); } while (t < target);
+    return t;
+}
+__device__ inline float rm_aabb_tmin(float lo, float hi, const Ray& r) {   // raymarch_shared.h:506-563
+    float tmin = (lo - r.ox) / r.dx, tmax = (hi - r.ox) / r.dx;
+    if (tmin > tmax) { float s = tmin; tmin = tmax; tmax = s; }
+    float tymin = (lo - r.oy) / r.dy, tymax = (hi - r.oy) / r.dy;
+    if (tymin > tymax) { float s = tymin; tymin = tymax; tymax = s; }
+    if (tmin > tymax || tymin > tmax) return FLT_MAX;
+    if (tymin > tmin) tmin = tymin;
+    if (tymax < tmax) tmax = tymax;
+    float tzmin = (lo - r.oz) / r.dz, tzmax = (hi - r.oz) / r.dz;
+    if (tzmin > tzmax) { float s = tzmin; tzmin = tzmax; tzmax = s; }
+    if (tmin > tzmax || tzmin > tmax) return FLT_MAX;
+    if (tzmin > tmin) tmin = tzmin;
+    return tmin;
+}
+__device__ inline bool rm_contains(float lo, float hi, float px, float py, float pz) { // :570-575
+    return px >= lo && px <= hi && py >= lo && py <= hi && pz >= lo && pz <= hi;
+}
+__device__ inline Ray rm_load_ray(const float* __restrict__ o, const float* __restrict__ d, uint32_t i) {
+    Ray r;
+    r.ox = o[3 * i]; r.oy = o[3 * i + 1]; r.oz = o[3 * i + 2];
+    r.dx = d[3 * i]; r.dy = d[3 * i + 1]; r.dz = d[3 * i + 2];
+    r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
+    return r;
+}
+
+// ------------------------------------------------------------------ K1 pass A: count (ray_sampler.cu:26-74)
+__global__ __launch_bounds__(RM_BLOCK) void k1_count(
+    uint32_t n_rays, float lo, float hi, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+    const uint8_t* __restrict__ bitfield, float cone, float near_distance, xr_pcg32 rng,
+    uint32_t* __restrict__ cnt, uint32_t* __restrict__ local_off, float* __restrict__ start_t,
+    uint32_t* __restrict__ block_tot) {
+    __shared__ uint32_t lds4[4];
+    const uint32_t i = blockIdx.x * RM_BLOCK + threadIdx.x;
+    uint32_t j = 0; float startt = 0.f;
+    if (i < n_rays) {
+        rng.advance((uint64_t)(i * 8u));                                     // :31
+        Ray r = rm_load_ray(rays_o, rays_d, i);
+        float tmin = fmaxf(rm_aabb_tmin(lo, hi, r), near_distance);          // :42-46
+        startt = tmin;
+        startt += rm_calc_dt(startt, cone) * rng.next_float();               // :50
+        float t = startt;
+        for (;;) {                                                           // :58-72
+            float px = r.ox + t * r.dx, py = r.oy + t * r.dy, pz = r.oz + t * r.dz;
+            if (!(rm_contains(lo, hi, px, py, pz) && j < XR_NERF_STEPS)) break;
+            float dt = rm_calc_dt(t, cone);
+            int mip = rm_mip_from_dt(dt, px, py, pz);
+            if (rm_occupied(px, py, pz, bitfield, mip)) { ++j; t += dt; }
+            else t = rm_advance(t, cone, px, py, pz, r, XR_NERF_GRIDSIZE >> mip);
+        }
+    }
+    uint32_t tot;
+    uint32_t off = block_excl_scan(j, &tot, lds4);
+    if (i < n_rays) { cnt[i] = j; local_off[i] = off; start_t[i] = startt; }
+    if (threadIdx.x == 0) block_tot[blockIdx.x] = tot;
+}
+
+// ------------------------------------------------------------------ block-total scan (single block)
+// block_base[b] = sum_{b'<b} block_tot[b'];  info[0] = grand total, info[1] = first block whose
+// end exceeds `limit` (or nb if none).
+__global__ __launch_bounds__(1024) void k_scan_blocks(uint32_t nb, const uint32_t* __restrict__ block_tot,
+                                                      uint32_t limit, uint32_t* __restrict__ block_base,
+                                                      uint32_t* __restrict__ info) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t s_running, s_cross;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (threadIdx.x == 0) { s_running = 0; s_cross = nb; }
+    __syncthreads();
+    for (uint32_t c0 = 0; c0 < nb; c0 += 1024) {
+        uint32_t b = c0 + threadIdx.x;
+        uint32_t v = b < nb ? block_tot[b] : 0, inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+        if (lane == 63) wsum[wid] = inc;
+        __syncthreads();
+        uint32_t woff = 0, ctot = 0;
+        for (int w = 0; w < 16; ++w) { uint32_t t = wsum[w]; if (w < wid) woff += t; ctot += t; }
+        uint32_t base = s_running + woff + inc - v;
+        if (b < nb) {
+            block_base[b] = base;
+            if ((uint64_t)base + v > (uint64_t)limit) atomicMin(&s_cross, b);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_running += ctot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { info[0] = s_running; info[1] = s_cross; }
+}
+
+// ------------------------------------------------------------------ K1 pass B: write (ray_sampler.cu:75-115)
+__global__ __launch_bounds__(RM_BLOCK) void k1_write(
+    uint32_t n_rays, float lo, float hi, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+    const uint8_t* __restrict__ bitfield, float cone, uint32_t max_samples, const uint32_t* __restrict__ cnt,
+    const uint32_t* __restrict__ local_off, const float* __restrict__ start_t,
+    const uint32_t* __restrict__ block_base, const uint32_t* __restrict__ info, float* __restrict__ coords_out,
+    int32_t* __restrict__ rays_index, int32_t* __restrict__ numsteps_out, uint32_t* __restrict__ counter2) {
+    __shared__ uint32_t lds4[4];
+    const uint32_t b = blockIdx.x, i = b * RM_BLOCK + threadIdx.x;
+    const uint32_t cross = info[1], nb = gridDim.x;
+    const uint32_t bbase = block_base[b];
+    uint32_t n = 0, base = 0; bool in = i < n_rays;
+    if (in) { n = cnt[i]; base = bbase + local_off[i]; }
+    // a ray is "valid" unless its range would overflow the sample buffer (:76-82)
+    bool valid = in && !((uint64_t)base + n > (uint64_t)max_samples);
+    // serial ray index = number of valid rays before this one (:86).  Blocks before the first
+    // overflowing block are all-valid, blocks after it are all-invalid.
+    uint32_t vtot;
+    uint32_t voff = block_excl_scan(valid ? 1u : 0u, &vtot, lds4);
+    uint32_t valid_before = (b <= cross) ? b * RM_BLOCK : 0u;  // b > cross: unused (nothing valid)
+    if (in) {
+        if (!valid) {
+            numsteps_out[2 * i] = 0; numsteps_out[2 * i + 1] = (int32_t)base; rays_index[i] = 0;
+        } else {
+            numsteps_out[2 * i] = (int32_t)n; numsteps_out[2 * i + 1] = (int32_t)base;
+            rays_index[i] = n == 0 ? -1 : (int32_t)(valid_before + voff);
+        }
+    }
+    // counters: samples = grand total (the atomicAdd of :75 runs for every ray, overflowing or
+    // not); rays = number of valid rays
+    if (threadIdx.x == 0) {
+        if (b == 0) counter2[1] = info[0];
+        if (b == cross || (cross == nb && b == nb - 1)) counter2[0] = valid_before + vtot;
+    }
+    if (!valid || n == 0) return;
+    Ray r = rm_load_ray(rays_o, rays_d, i);
+    const float wdx = (r.dx + 1.0f) * 0.5f, wdy = (r.dy + 1.0f) * 0.5f, wdz = (r.dz + 1.0f) * 0.5f; // warp_direction
+    const float diag = hi - lo;
+    float t = start_t[i];
+    uint32_t j = 0;
+    float* __restrict__ out = coords_out + 7 * (size_t)base;
+    for (;;) {                                                               // :99-115
+        float px = r.ox + t * r.dx, py = r.oy + t * r.dy, pz = r.oz + t * r.dz;
+        if (!(rm_contains(lo, hi, px, py, pz) && j < n)) break;
+        float dt = rm_calc_dt(t, cone);
+        int mip = rm_mip_from_dt(dt, px, py, pz);
+        if (rm_occupied(px, py, pz, bitfield, mip)) {
+            float* c = out + 7 * (size_t)j;
+            c[0] = (px - lo) / diag; c[1] = (py - lo) / diag; c[2] = (pz - lo) / diag;
+            c[3] = (dt - xr_min_step()) / (xr_max_warp_step() - xr_min_step());   // warp_dt
+            c[4] = wdx; c[5] = wdy; c[6] = wdz;
+            ++j; t += dt;
+        } else t = rm_advance(t, cone, px, py, pz, r, XR_NERF_GRIDSIZE >> mip);
+    }
+}
+
+struct RmWorkspace { uint32_t *cnt, *local_off, *block_tot, *block_base, *info; float* start_t; };
+static size_t rm_ws_layout(uint32_t n_rays, char* base, RmWorkspace* w) {
+    const size_t nb = xr_div_up(n_rays, RM_BLOCK);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return base ? base + o : (char*)nullptr; };
+    char* p0 = take(4ull * n_rays); char* p1 = take(4ull * n_rays); char* p2 = take(4ull * n_rays);
+    char* p3 = take(4 * nb); char* p4 = take(4 * nb); char* p5 = take(16);
+    if (w) { w->cnt = (uint32_t*)p0; w->local_off = (uint32_t*)p1; w->start_t = (float*)p2;
+             w->block_tot = (uint32_t*)p3; w->block_base = (uint32_t*)p4; w->info = (uint32_t*)p5; }
+    return off;
+}
+
+extern "C" size_t xr_rays_sampler_workspace_bytes(uint32_t n_rays) { return rm_ws_layout(n_rays, nullptr, nullptr); }
+
+extern "C" int xr_rays_sampler(const float* rays_o, const float* rays_d, const uint8_t* bitfield, uint32_t n_rays,
+                               float aabb0, float aabb1, float near_distance, float cone_angle, uint32_t max_samples,
+                               uint64_t rng_state, uint64_t rng_inc, float* coords_out, int32_t* rays_index,
+                               int32_t* rays_numsteps, uint32_t* counter2, void* workspace, size_t workspace_bytes,
+                               void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    XR_REQUIRE(rays_o && rays_d && bitfield && coords_out && rays_index && rays_numsteps && counter2, "null pointer");
+    XR_REQUIRE(n_rays > 0 && n_rays <= (1u << 28), "n_rays out of range");
+    XR_REQUIRE(workspace && workspace_bytes >= xr_rays_sampler_workspace_bytes(n_rays), "workspace too small");
+    RmWorkspace w; rm_ws_layout(n_rays, (char*)workspace, &w);
+    xr_pcg32 rng{rng_state, rng_inc};
+    const uint32_t nb = xr_div_up(n_rays, RM_BLOCK);
+    hipLaunchKernelGGL(k1_count, dim3(nb), dim3(RM_BLOCK), 0, stream, n_rays, aabb0, aabb1, rays_o, rays_d, bitfield,
+                       cone_angle, near_distance, rng, w.cnt, w.local_off, w.start_t, w.block_tot);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, nb, w.block_tot, max_samples, w.block_base, w.info);
+    hipLaunchKernelGGL(k1_write, dim3(nb), dim3(RM_BLOCK), 0, stream, n_rays, aabb0, aabb1, rays_o, rays_d, bitfield,
+                       cone_angle, max_samples, w.cnt, w.local_off, w.start_t, w.block_base, w.info, coords_out,
+                       rays_index, rays_numsteps, counter2);
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}
+
+// ------------------------------------------------------------------ K2 re-pack (compacted_coord.cu:22-76)
+__global__ __launch_bounds__(RM_BLOCK) void k2_count(uint32_t n_rays, const int32_t* __restrict__ numsteps_in,
+                                                      uint32_t* __restrict__ local_off, uint32_t* __restrict__ block_tot) {
+    __shared__ uint32_t lds4[4];
+    const uint32_t i = blockIdx.x * RM_BLOCK + threadIdx.x;
+    uint32_t n = i < n_rays ? (uint32_t)numsteps_in[2 * i] : 0u, tot;
+    uint32_t off = block_excl_scan(n, &tot, lds4);
+    if (i < n_rays) local_off[i] = off;
+    if (threadIdx.x == 0) block_tot[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(RM_BLOCK) void k2_copy(uint32_t n_rays, uint32_t max_compacted,
+                                                     const float* __restrict__ coords_in, const int32_t* __restrict__ numsteps_in,
+                                                     const uint32_t* __restrict__ local_off, const uint32_t* __restrict__ block_base,
+                                                     const uint32_t* __restrict__ info, float* __restrict__ coords_out,
+                                                     int32_t* __restrict__ numsteps_out, uint32_t* __restrict__ rays_counter,
+                                                     uint32_t* __restrict__ numstep_counter) {
+    const uint32_t i = blockIdx.x * RM_BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    uint32_t n = 0, base = 0, cbase = 0, nc = 0;
+    if (i < n_rays) {
+        n = (uint32_t)numsteps_in[2 * i]; base = (uint32_t)numsteps_in[2 * i + 1];
+        cbase = block_base[blockIdx.x] + local_off[i];                                   // :63
+        nc = min(max_compacted - min(max_compacted, cbase), n);                          // :64
+        numsteps_out[2 * i] = (int32_t)nc; numsteps_out[2 * i + 1] = (int32_t)cbase;
+    }
+    // rays with nc > 0 (:67-71): one wave-level count, one atomic per wave
+    unsigned long long m = __ballot(nc > 0);
+    if (lane == 0 && m) atomicAdd(rays_counter, (uint32_t)__popcll(m));
+    if (i == 0) *numstep_counter = info[0];
+    // cooperative copy: the wave walks its 64 rays, all lanes copy one ray's rows coalesced
+    for (int s = 0; s < 64; ++s) {
+        uint32_t rn = __shfl(nc, s, 64);
+        if (rn == 0) continue;
+        uint32_t rb = __shfl(base, s, 64), rc = __shfl(cbase, s, 64);
+        const float* __restrict__ src = coords_in + 7 * (size_t)rb;
+        float* __restrict__ dst = coords_out + 7 * (size_t)rc;
+        for (uint32_t e = lane; e < 7 * rn; e += 64) dst[e] = src[e];
+    }
+}
+
+extern "C" int xr_compacted_coord(const float* coords_in, const int32_t* numsteps_in, uint32_t n_rays,
+                                  uint32_t max_compacted, float* coords_out, int32_t* numsteps_out,
+                                  uint32_t* rays_counter, uint32_t* numstep_counter, void* workspace,
+                                  size_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    XR_REQUIRE(coords_in && numsteps_in && coords_out && numsteps_out && rays_counter && numstep_counter, "null pointer");
+    XR_REQUIRE(n_rays > 0, "n_rays == 0");
+    XR_REQUIRE(workspace && workspace_bytes >= xr_rays_sampler_workspace_bytes(n_rays), "workspace too small");
+    RmWorkspace w; rm_ws_layout(n_rays, (char*)workspace, &w);
+    const uint32_t nb = xr_div_up(n_rays, RM_BLOCK);
+    XR_HIP(hipMemsetAsync(rays_counter, 0, 4, stream));
+    hipLaunchKernelGGL(k2_count, dim3(nb), dim3(RM_BLOCK), 0, stream, n_rays, numsteps_in, w.local_off, w.block_tot);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, nb, w.block_tot, 0xffffffffu, w.block_base, w.info);
+    hipLaunchKernelGGL(k2_copy, dim3(nb), dim3(RM_BLOCK), 0, stream, n_rays, max_compacted, coords_in, numsteps_in,
+                       w.local_off, w.block_base, w.info, coords_out, numsteps_out, rays_counter, numstep_counter);
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}
+
+// ------------------------------------------------------------------ K3 / K5 compositor forward
+// one ray per lane, front-to-back (calc_rgb.cu:20-66, :158-205).
+template <bool INFERENCE>
+__global__ __launch_bounds__(RM_BLOCK) void k_composite_fwd(
+    uint32_t n_rays, const float4* __restrict__ raw, const float* __restrict__ coords,
+    const int32_t* __restrict__ numsteps, const int32_t* __restrict__ numsteps_c, const float* __restrict__ bg,
+    float bg_r, float bg_g, float bg_b, int rgb_act, int density_act, float* __restrict__ rgb_out,
+    float* __restrict__ alpha_out) {
+    const uint32_t i = blockIdx.x * RM_BLOCK + threadIdx.x;
+    if (i >= n_rays) return;
+    float br, bgc, bb;
+    if (INFERENCE) { br = bg_r; bgc = bg_g; bb = bg_b; }
+    else { br = bg[3 * i]; bgc = bg[3 * i + 1]; bb = bg[3 * i + 2]; }
+    const uint32_t n = (uint32_t)numsteps_c[2 * i], base = (uint32_t)numsteps_c[2 * i + 1];
+    if (n == 0) {
+        rgb_out[3 * i] = br; rgb_out[3 * i + 1] = bgc; rgb_out[3 * i + 2] = bb;
+        if (INFERENCE) alpha_out[i] = 0.f;
+        return;
+    }
+    float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f;
+    for (uint32_t k = 0; k < n; ++k) {
+        const float4 o = raw[base + k];
+        const float dt = xr_unwarp_dt(coords[7 * (size_t)(base + k) + 3]);
+        const float density = xr_act_density(o.w, density_act);
+        const float alpha = 1.f - __expf(-density * dt);
+        const float w = alpha * T;
+        cr += w * xr_act_rgb(o.x, rgb_act); cg += w * xr_act_rgb(o.y, rgb_act); cb += w * xr_act_rgb(o.z, rgb_act);
+        T *= (1.f - alpha);
+    }
+    const bool add_bg = INFERENCE ? true : (n == (uint32_t)numsteps[2 * i]);   // :61-64 / :200-203
+    if (add_bg) { cr += T * br; cg += T * bgc; cb += T * bb; }
+    rgb_out[3 * i] = cr; rgb_out[3 * i + 1] = cg; rgb_out[3 * i + 2] = cb;
+    if (INFERENCE) alpha_out[i] = 1.f - T;
+}
+
+extern "C" int xr_calc_rgb_forward(const float* network_output, const float* coords, const int32_t* rays_numsteps,
+                                   const int32_t* rays_numsteps_compacted, const float* bg_color, uint32_t n_rays,
+                                   int rgb_activation, int density_activation, float* rgb_output, void* stream_) {
+    XR_REQUIRE(network_output && coords && rays_numsteps && rays_numsteps_compacted && bg_color && rgb_output, "null pointer");
+    XR_REQUIRE(((uintptr_t)network_output & 15) == 0, "network_output must be 16-byte aligned");
+    XR_REQUIRE(n_rays > 0, "n_rays == 0");
+    hipLaunchKernelGGL(k_composite_fwd<false>, dim3(xr_div_up(n_rays, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream_,
+                       n_rays, (const float4*)network_output, coords, rays_numsteps, rays_numsteps_compacted, bg_color,
+                       0.f, 0.f, 0.f, rgb_activation, density_activation, rgb_output, (float*)nullptr);
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}
+
+extern "C" int xr_calc_rgb_inference(const float* network_output, const float* coords, const int32_t* rays_numsteps,
+                                     float bg_r, float bg_g, float bg_b, uint32_t n_rays, int rgb_activation,
+                                     int density_activation, float* rgb_output, float* alpha_output, void* stream_) {
+    XR_REQUIRE(network_output && coords && rays_numsteps && rgb_output && alpha_output, "null pointer");
+    XR_REQUIRE(((uintptr_t)network_output & 15) == 0, "network_output must be 16-byte aligned");
+    XR_REQUIRE(n_rays > 0, "n_rays == 0");
+    hipLaunchKernelGGL(k_composite_fwd<true>, dim3(xr_div_up(n_rays, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream_,
+                       n_rays, (const float4*)network_output, coords, rays_numsteps, rays_numsteps, (const float*)nullptr,
+                       bg_r, bg_g, bg_b, rgb_activation, density_activation, rgb_output, alpha_output);
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}
+
+// ------------------------------------------------------------------ K4 compositor backward (calc_rgb.cu:87-139)
+__global__ __launch_bounds__(RM_BLOCK) void k_composite_bwd(
+    uint32_t n_rays, const float4* __restrict__ raw, const int32_t* __restrict__ numsteps_c,
+    const float* __restrict__ coords, const float* __restrict__ grad_rgb, const float* __restrict__ rgb_final,
+    const float* __restrict__ density_grid_mean, int rgb_act, int density_act, float4* __restrict__ dout) {
+    const uint32_t i = blockIdx.x * RM_BLOCK + threadIdx.x;
+    if (i >= n_rays) return;
+    float loss_scale = 128.f; loss_scale /= (float)n_rays;                        // :92-93
+    const float l2 = rgb_act == XR_ACT_EXPONENTIAL ? 1e-4f : 0.0f;                // :103
+    const float l1 = density_grid_mean[0] < 0.01f ? 1e-4f : 0.0f;                 // :104
+    const uint32_t n = (uint32_t)numsteps_c[2 * i], base = (uint32_t)numsteps_c[2 * i + 1];
+    const float gr = grad_rgb[3 * i], gg = grad_rgb[3 * i + 1], gb = grad_rgb[3 * i + 2];
+    const float fr = rgb_final[3 * i], fg = rgb_final[3 * i + 1], fb = rgb_final[3 * i + 2];
+    float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f;
+    for (uint32_t k = 0; k < n; ++k) {
+        const float4 o = raw[base + k];
+        const float r = xr_act_rgb(o.x, rgb_act), g = xr_act_rgb(o.y, rgb_act), b = xr_act_rgb(o.z, rgb_act);
+        const float dt = xr_unwarp_dt(coords[7 * (size_t)(base + k) + 3]);
+        const float density = xr_act_density(o.w, density_act);
+        const float alpha = 1.f - __expf(-density * dt);
+        const float w = alpha * T;
+        cr += w * r; cg += w * g; cb += w * b;
+        T *= (1.f - alpha);
+        const float sr = fr - cr, sg = fg - cg, sb = fb - cb;                     // suffix
+        float4 d;
+        d.x = loss_scale * ((w * gr) * xr_dact_rgb(o.x, rgb_act) + fmaxf(0.0f, l2 * o.x));
+        d.y = loss_scale * ((w * gg) * xr_dact_rgb(o.y, rgb_act) + fmaxf(0.0f, l2 * o.y));
+        d.z = loss_scale * ((w * gb) * xr_dact_rgb(o.z, rgb_act) + fmaxf(0.0f, l2 * o.z));
+        const float dot = gr * (T * r - sr) + gg * (T * g - sg) + gb * (T * b - sb);
+        d.w = loss_scale * (xr_dact_density(o.w, density_act) * (dt * dot)) + (o.w < 0.f ? -l1 : 0.0f);
+        dout[base + k] = d;
+    }
+}
+
+extern "C" int xr_calc_rgb_backward(const float* network_output, const int32_t* rays_numsteps_compacted,
+                                    const float* coords, const float* grad_rgb, const float* rgb_output,
+                                    const float* density_grid_mean, uint32_t n_rays, int rgb_activation,
+                                    int density_activation, float* dloss_doutput, void* stream_) {
+    XR_REQUIRE(network_output && rays_numsteps_compacted && coords && grad_rgb && rgb_output && density_grid_mean &&
+               dloss_doutput, "null pointer");
+    XR_REQUIRE((((uintptr_t)network_output | (uintptr_t)dloss_doutput) & 15) == 0, "raw/grad buffers must be 16-byte aligned");
+    XR_REQUIRE(n_rays > 0, "n_rays == 0");
+    hipLaunchKernelGGL(k_composite_bwd, dim3(xr_div_up(n_rays, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream_,
+                       n_rays, (const float4*)network_output, rays_numsteps_compacted, coords, grad_rgb, rgb_output,
+                       density_grid_mean, rgb_activation, density_activation, (float4*)dloss_doutput);
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}

@@ -1,0 +1,278 @@
+"""Tensor-level front-end of the C-ABI: torch is used only for device memory and streams.
+
+Every function takes contiguous CUDA(ROCm) tensors, enqueues on torch's current stream and does
+NOT synchronise.  There is no CPU path: a non-CUDA tensor is an error.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+G3 = 128 ** 3
+N_GRID = 8 * G3
+
+_workspaces = {}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.XrError('xrnerf_amd ops need ROCm device tensors (got a %s tensor): there is no CPU fallback' % t.device)
+    if not t.is_contiguous():
+        raise _lib.XrError('tensor must be contiguous')
+    return C.c_void_p(t.data_ptr())
+
+
+def _ws(device, nbytes, tag):
+    key = (str(device), tag)
+    w = _workspaces.get(key)
+    if w is None or w.numel() < nbytes:
+        w = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _workspaces[key] = w
+    return w
+
+
+def pcg32_host_state(ncalls, seed=9121):
+    s, i = C.c_uint64(), C.c_uint64()
+    _lib.load().xr_pcg32_host_state(seed, ncalls, C.byref(s), C.byref(i))
+    return s.value, i.value
+
+
+# ---------------------------------------------------------------- K1 / K2
+def rays_sampler(rays_o, rays_d, bitfield, aabb, near_distance, cone_angle, max_samples, rng_calls,
+                 coords_out=None):
+    """returns coords_out [max_samples,7], rays_index [n,1], rays_numsteps [n,2], counter [2] (device)."""
+    L = _lib.load()
+    n = rays_o.shape[0]
+    dev = rays_o.device
+    if coords_out is None:
+        coords_out = torch.empty((max_samples, 7), dtype=torch.float32, device=dev)
+    rays_index = torch.empty((n, 1), dtype=torch.int32, device=dev)
+    numsteps = torch.empty((n, 2), dtype=torch.int32, device=dev)
+    counter = torch.empty((2,), dtype=torch.int32, device=dev)
+    nb = L.xr_rays_sampler_workspace_bytes(n)
+    ws = _ws(dev, nb, 'k1')
+    st, inc = pcg32_host_state(rng_calls)
+    _lib.check(L.xr_rays_sampler(_ptr(rays_o), _ptr(rays_d), _ptr(bitfield), n, aabb[0], aabb[1], near_distance,
+                                 cone_angle, max_samples, st, inc, _ptr(coords_out), _ptr(rays_index),
+                                 _ptr(numsteps), _ptr(counter), _ptr(ws), ws.numel(), _stream()), 'xr_rays_sampler')
+    return coords_out, rays_index, numsteps, counter
+
+
+def compacted_coord(coords_in, numsteps, max_compacted, coords_out=None):
+    L = _lib.load()
+    n = numsteps.shape[0]
+    dev = coords_in.device
+    if coords_out is None:
+        coords_out = torch.zeros((max_compacted, 7), dtype=torch.float32, device=dev)
+    nc = torch.empty((n, 2), dtype=torch.int32, device=dev)
+    rc = torch.empty((1,), dtype=torch.int32, device=dev)
+    sc = torch.empty((1,), dtype=torch.int32, device=dev)
+    ws = _ws(dev, L.xr_rays_sampler_workspace_bytes(n), 'k1')
+    _lib.check(L.xr_compacted_coord(_ptr(coords_in), _ptr(numsteps), n, max_compacted, _ptr(coords_out), _ptr(nc),
+                                    _ptr(rc), _ptr(sc), _ptr(ws), ws.numel(), _stream()), 'xr_compacted_coord')
+    return coords_out, nc, rc, sc
+
+
+# ---------------------------------------------------------------- K3 / K4 / K5
+def calc_rgb_forward(raw, coords, numsteps, numsteps_c, bg, rgb_act, density_act, out=None):
+    L = _lib.load()
+    n = numsteps.shape[0]
+    if out is None:
+        out = torch.empty((n, 3), dtype=torch.float32, device=raw.device)
+    _lib.check(L.xr_calc_rgb_forward(_ptr(raw), _ptr(coords), _ptr(numsteps), _ptr(numsteps_c), _ptr(bg), n,
+                                     int(rgb_act), int(density_act), _ptr(out), _stream()), 'xr_calc_rgb_forward')
+    return out
+
+
+def calc_rgb_backward(raw, numsteps_c, coords, grad_rgb, rgb_out, density_grid_mean, rgb_act, density_act, out=None):
+    L = _lib.load()
+    n = numsteps_c.shape[0]
+    if out is None:
+        out = torch.zeros_like(raw)
+    _lib.check(L.xr_calc_rgb_backward(_ptr(raw), _ptr(numsteps_c), _ptr(coords), _ptr(grad_rgb), _ptr(rgb_out),
+                                      _ptr(density_grid_mean), n, int(rgb_act), int(density_act), _ptr(out),
+                                      _stream()), 'xr_calc_rgb_backward')
+    return out
+
+
+def calc_rgb_inference(raw, coords, numsteps, bg3, rgb_act, density_act):
+    L = _lib.load()
+    n = numsteps.shape[0]
+    rgb = torch.empty((n, 3), dtype=torch.float32, device=raw.device)
+    alpha = torch.empty((n, 1), dtype=torch.float32, device=raw.device)
+    _lib.check(L.xr_calc_rgb_inference(_ptr(raw), _ptr(coords), _ptr(numsteps), float(bg3[0]), float(bg3[1]),
+                                       float(bg3[2]), n, int(rgb_act), int(density_act), _ptr(rgb), _ptr(alpha),
+                                       _stream()), 'xr_calc_rgb_inference')
+    return rgb, alpha
+
+
+# ---------------------------------------------------------------- K6 .. K11
+def generate_grid_samples(grid, ema_step, n_elements, n_cascades, thresh, aabb, rng_calls):
+    L = _lib.load()
+    dev = grid.device
+    pos = torch.empty((n_elements, 3), dtype=torch.float32, device=dev)
+    idx = torch.empty((n_elements,), dtype=torch.int32, device=dev)
+    st, inc = pcg32_host_state(rng_calls)
+    _lib.check(L.xr_generate_grid_samples(_ptr(grid), ema_step, n_elements, n_cascades, thresh, aabb[0], aabb[1],
+                                          st, inc, _ptr(pos), _ptr(idx), _stream()), 'xr_generate_grid_samples')
+    return pos, idx
+
+
+def mark_untrained_density_grid(focal, xforms, n_elements, resolutions, grid=None):
+    L = _lib.load()
+    if grid is None:
+        grid = torch.empty((n_elements,), dtype=torch.float32, device=focal.device)
+    _lib.check(L.xr_mark_untrained_density_grid(_ptr(focal), _ptr(xforms), n_elements, xforms.shape[0],
+                                                int(resolutions[0]), int(resolutions[1]), _ptr(grid), _stream()),
+               'xr_mark_untrained_density_grid')
+    return grid
+
+
+def splat_grid_samples(mlp_out, indices, padded_width, n_samples, grid_tmp):
+    _lib.check(_lib.load().xr_splat_grid_samples(_ptr(mlp_out), _ptr(indices), padded_width, n_samples,
+                                                 _ptr(grid_tmp), _stream()), 'xr_splat_grid_samples')
+    return grid_tmp
+
+
+def ema_grid_samples(grid_tmp, n_elements, decay, grid):
+    _lib.check(_lib.load().xr_ema_grid_samples(_ptr(grid_tmp), n_elements, decay, _ptr(grid), _stream()),
+               'xr_ema_grid_samples')
+    return grid
+
+
+def update_bitfield(grid, mean, bitfield):
+    L = _lib.load()
+    ws = _ws(grid.device, L.xr_update_bitfield_workspace_bytes(), 'k10')
+    _lib.check(L.xr_update_bitfield(_ptr(grid), _ptr(mean), _ptr(bitfield), _ptr(ws), ws.numel(), _stream()),
+               'xr_update_bitfield')
+    return bitfield, mean
+
+
+def bitfield_from_mean(grid, mean, bitfield):
+    _lib.check(_lib.load().xr_bitfield_from_mean(_ptr(grid), _ptr(mean), _ptr(bitfield), _stream()),
+               'xr_bitfield_from_mean')
+    return bitfield
+
+
+# ---------------------------------------------------------------- hash grid / SH / MLP
+class GridMeta:
+    """Host-side level geometry (shared verbatim with the oracle)."""
+
+    def __init__(self, n_levels=16, log2_hashmap_size=19, base_resolution=16, per_level_scale=None):
+        if per_level_scale is None:
+            per_level_scale = float(np.exp2(np.log2(2048 * 1 / 16) / (16 - 1)))  # hashnerf_mlp.py:17-20
+        self.n_levels = int(n_levels)
+        self.n_features = 2
+        self.scale = np.zeros(n_levels, np.float32)
+        self.resolution = np.zeros(n_levels, np.uint32)
+        self.offset = np.zeros(n_levels + 1, np.uint32)
+        _lib.load().xr_hashgrid_meta(n_levels, log2_hashmap_size, base_resolution, per_level_scale,
+                                     self.scale.ctypes.data, self.resolution.ctypes.data, self.offset.ctypes.data)
+        self.n_params = int(self.offset[-1]) * 2
+        self.n_output_dims = 2 * self.n_levels
+
+    def _args(self):
+        return self.scale.ctypes.data, self.resolution.ctypes.data, self.offset.ctypes.data
+
+
+def _pos_view(x):
+    """(tensor, element stride) for an [n,>=3] fp32 position source: a contiguous [n,3] tensor, or
+    the leading 3 columns of contiguous [n,7] coordinate rows (consumed in place)."""
+    if x.dim() != 2 or x.shape[1] < 3 or x.dtype != torch.float32:
+        raise _lib.XrError('positions must be a 2-D float32 tensor with >= 3 columns')
+    if x.stride(1) != 1:
+        raise _lib.XrError('positions must have unit column stride')
+    return x, int(x.stride(0))
+
+
+def hashgrid_fwd(table, x, meta, enc_t=None, ld=None):
+    """x: [n,3] (or a column slice of [n,7] rows) -> enc_t [2L, ld] feature-major."""
+    L = _lib.load()
+    x, xs = _pos_view(x)
+    n = x.shape[0]
+    if ld is None:
+        ld = (n + 63) // 64 * 64
+    if enc_t is None:
+        enc_t = torch.empty((meta.n_output_dims, ld), dtype=torch.float32, device=x.device)
+    s, r, o = meta._args()
+    _lib.check(L.xr_hashgrid_fwd(_ptr(table), C.c_void_p(x.data_ptr()), xs, n, meta.n_levels, s, r, o, _ptr(enc_t), ld,
+                                 _stream()), 'xr_hashgrid_fwd')
+    return enc_t
+
+
+def hashgrid_bwd(x, denc_t, meta, grad_table):
+    L = _lib.load()
+    x, xs = _pos_view(x)
+    n = x.shape[0]
+    s, r, o = meta._args()
+    _lib.check(L.xr_hashgrid_bwd(C.c_void_p(x.data_ptr()), xs, _ptr(denc_t), denc_t.shape[1], n, meta.n_levels, s, r, o,
+                                 _ptr(grad_table), _stream()), 'xr_hashgrid_bwd')
+    return grad_table
+
+
+def sh4(dirs):
+    dirs, ds = _pos_view(dirs)
+    n = dirs.shape[0]
+    out = torch.empty((n, 16), dtype=torch.float32, device=dirs.device)
+    _lib.check(_lib.load().xr_sh4(C.c_void_p(dirs.data_ptr()), ds, n, _ptr(out), _stream()), 'xr_sh4')
+    return out
+
+
+def nerf_mlp_fwd(enc_t, dirs, n, w_density, w_color, nhd, nhc, pad_value=1.0, raw=None):
+    L = _lib.load()
+    if raw is None:
+        raw = torch.empty((n, 4), dtype=torch.float32, device=enc_t.device)
+    if dirs is not None:
+        dirs, ds = _pos_view(dirs)
+        dp = C.c_void_p(dirs.data_ptr())
+    else:
+        ds, dp = 0, None
+    _lib.check(L.xr_nerf_mlp_fwd(_ptr(enc_t), enc_t.shape[1], dp, ds, n, _ptr(w_density),
+                                 _ptr(w_color) if w_color is not None else None, nhd, nhc, pad_value, _ptr(raw),
+                                 _stream()), 'xr_nerf_mlp_fwd')
+    return raw
+
+
+def nerf_mlp_bwd(enc_t, dirs, n, w_density, w_color, nhd, nhc, draw, grad_wd, grad_wc, pad_value=1.0, denc_t=None):
+    L = _lib.load()
+    dirs, ds = _pos_view(dirs)
+    if denc_t is None:
+        denc_t = torch.empty_like(enc_t)
+    ws = _ws(enc_t.device, L.xr_nerf_mlp_bwd_workspace_bytes(n), 'mlpbwd')
+    _lib.check(L.xr_nerf_mlp_bwd(_ptr(enc_t), enc_t.shape[1], C.c_void_p(dirs.data_ptr()), ds, n, _ptr(w_density),
+                                 _ptr(w_color), nhd, nhc, pad_value, _ptr(draw), _ptr(denc_t), _ptr(grad_wd),
+                                 _ptr(grad_wc), _ptr(ws), ws.numel(), _stream()), 'xr_nerf_mlp_bwd')
+    return denc_t
+
+
+# ---------------------------------------------------------------- callers either side
+def gen_rays(pose43, H, W, fx, fy, cx, cy, row0=0, nrows=None, device='cuda'):
+    pose = np.ascontiguousarray(np.asarray(pose43, dtype=np.float32).reshape(4, 3))
+    nrows = H - row0 if nrows is None else nrows
+    o = torch.empty((nrows * W, 3), dtype=torch.float32, device=device)
+    d = torch.empty((nrows * W, 3), dtype=torch.float32, device=device)
+    _lib.check(_lib.load().xr_gen_rays(pose.ctypes.data, H, W, fx, fy, cx, cy, row0, nrows, _ptr(o), _ptr(d),
+                                       _stream()), 'xr_gen_rays')
+    return o, d
+
+
+def huber_loss_grad(rgb, target, delta=0.1, scale=5.0):
+    grad = torch.empty_like(rgb)
+    loss = torch.zeros((1,), dtype=torch.float32, device=rgb.device)
+    _lib.check(_lib.load().xr_huber_loss_grad(_ptr(rgb), _ptr(target), rgb.numel(), delta, scale, _ptr(grad),
+                                              _ptr(loss), _stream()), 'xr_huber_loss_grad')
+    return loss, grad
+
+
+def adam_step(p, g, m, v, step, lr=1e-2, beta1=0.9, beta2=0.99, eps=1e-15, weight_decay=1e-6, ema=None,
+              ema_momentum=0.05):
+    _lib.check(_lib.load().xr_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), step, lr, beta1, beta2, eps,
+                                        weight_decay, _ptr(ema), ema_momentum, _stream()), 'xr_adam_step')
