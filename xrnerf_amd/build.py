@@ -19,7 +19,8 @@ COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-at
 SOURCES = {
     'xr_raymarch.hip': ['-ffp-contract=off'],
     'xr_grid.hip': ['-ffp-contract=off'],
-    'xr_encode.hip': [],
+    # the hash-grid cell index is floor(x*scale+0.5): an index decision at scale up to 2047
+    'xr_encode.hip': ['-ffp-contract=off'],
     'xr_mlp.hip': [],
     'xr_misc.hip': ['-ffp-contract=off'],
 }
