@@ -1,0 +1,209 @@
+#!/usr/bin/env python
+"""Headline benchmark: Instant-NGP Lego training throughput (rays/s) on N MI355X, fp32.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+A "step" is one full training iteration of configs/instant_ngp/nerf_blender_local01.py on one batch
+of synthetic 800x800 Lego-shaped rays that are already resident in HBM: hooks -> batch slice + random
+bg -> K1 ray march (+ the every-16th occupancy-grid refresh K6..K11 with its density queries) ->
+hash-grid encode -> fused MLP -> K3 composite -> 5*Huber -> K4 -> MLP backward -> hash-grid scatter ->
+[gradient all-reduce over RCCL when N>1] -> fused Adam(+EMA) over all 12.2 M parameters.  The batch is the
+reference's adaptive one (4096 rays initially, re-sized every 16 iterations so that ~2^18 samples are
+marched).  Weak scaling: every rank trains on its own rays, value = rays of all ranks / max-rank time.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from xrnerf_amd import dist as xdist  # noqa: E402
+from xrnerf_amd import ops  # noqa: E402
+from xrnerf_amd.train import Trainer, render_frame  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0         # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # same guide: fp32-input MFMA = the fp32 vector rate
+
+# ALGORITHMIC work per unit (SURVEY.md section 8d, fp32 parity mode)
+L_, F_ = 16, 2
+ALGO = {
+    # per sample: 12 B position + L*8 corners*F*4 B table reads + L*F*4 B features written
+    'xr_hashgrid_fwd': ('hbm', 12 + L_ * 8 * F_ * 4 + L_ * F_ * 4),
+    # per sample: 12 B position + L*F*4 B feature gradients + L*8*F atomic read-modify-writes (4+4 B)
+    'xr_hashgrid_bwd': ('hbm', 12 + L_ * F_ * 4 + L_ * 8 * F_ * 8),
+    # per sample: density 32*64+64*16, color 32*64+64*64+64*16 MACs = 10240 MAC = 20480 flop
+    'xr_nerf_mlp_fwd': ('mfma', 20480),
+    # recompute (without the color output layer) + dX chain + dW: 3 x 20480 - 2048
+    'xr_nerf_mlp_bwd': ('mfma', 3 * 20480 - 2048),
+    # per sample: 16 B raw + 4 B dt read (+ per ray 40 B, folded in as 3 B/sample at ~14 samples/ray)
+    'xr_calc_rgb_forward': ('hbm', 20 + 3),
+    'xr_calc_rgb_backward': ('hbm', 36 + 2),
+    # per emitted sample 28 B written + per ray 36 B (folded: ~3 B/sample)
+    # per RAY: 36 B in/out + 28 B per emitted sample at ~14 samples/ray
+    'xr_rays_sampler': ('hbm', 36 + 28 * 14),
+}
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The oracle's plain-C port of the SAME training iteration on the host, one thread, on a bounded
+    sample (1024-ray batches of the same synthetic workload, fixed Lego occupancy)."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import oracle as O
+    from xrnerf_amd import synthetic as S
+    O.set_threads(1)
+    meta = O.GridMeta()
+    grid = S.lego_density_grid()
+    bf = O.bitfield_given_mean(grid, O.density_mean(grid))
+    poses = S.lego_cameras(20)
+    table = S.hash_table(meta.n_params)
+    wd, wc = S.mlp_weights(32, 64, 1, 16, 4), S.mlp_weights(32, 64, 2, 16, 5)
+    params = [table, wd, wc]
+    ms = [np.zeros_like(p) for p in params]
+    vs = [np.zeros_like(p) for p in params]
+    n_rays, rays_done, it = 1024, 0, 0
+    rng = np.random.default_rng(0)
+    t0 = time.time()
+    while True:
+        o, d, _ = S.training_rays(poses, n_rays, seed=100 + it)
+        tgt = rng.uniform(0, 1, (n_rays, 3)).astype(np.float32)
+        bg = rng.uniform(0, 1, (n_rays, 3)).astype(np.float32)
+        t1 = time.time()
+        coords, _, ns, cnt = O.rays_sampler(o, d, bf, rng_calls=it, max_samples=n_rays * 256)
+        s = int(cnt[1])
+        c = coords[:s]
+        pts, dirs = np.ascontiguousarray(c[:, :3]), np.ascontiguousarray(c[:, 4:])
+        raw = O.nerf_mlp_fwd(table, wd, wc, pts, dirs, meta)
+        rgb = O.calc_rgb_forward(raw, c, ns, ns, bg)
+        _, g = O.huber_loss_grad(rgb, tgt)
+        draw = O.calc_rgb_backward(raw, ns, c, g, rgb, 0.05)
+        gt, gd, gc = O.nerf_mlp_bwd(table, wd, wc, pts, dirs, draw, meta)
+        for p, gr, m, v in zip(params, (gt, gd, gc), ms, vs):
+            O.adam(p, gr, m, v, it + 1)
+        it += 1
+        rays_done += n_rays
+        el = time.time() - t0
+        if el > seconds_budget or it >= 64:
+            break
+    return {'value': rays_done / el, 'unit': 'rays/s', 'cores': 1, 'kind': 'port',
+            'sample': '%d training iterations of %d rays (K1+encode+MLP+K3+Huber+K4+backward+Adam over 12.2M params), '
+                      'oracle/ngp_oracle.c, 1 thread, ray generation excluded' % (it, n_rays)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=128)
+    ap.add_argument('--warmup', type=int, default=48)
+    ap.add_argument('--n-img', type=int, default=20)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-render', action='store_true')
+    args = ap.parse_args()
+
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: there is no CPU path')
+    rank, local, world = xdist.init_from_env('nccl')
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run' % (args.gpus, world))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+
+    tr = Trainer(dev, n_img=args.n_img, world_size=world, rank=rank)
+    for _ in range(args.warmup):
+        tr.step()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    ops.TIMER = ops.KernelTimer()
+    rays0, samples0 = tr.rays_done, tr.samples_done
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timer, ops.TIMER = ops.TIMER, None
+
+    rays = tr.rays_done - rays0
+    samples = tr.samples_done - samples0
+    stats = torch.tensor([elapsed, float(rays), float(samples)], dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = stats.clone()
+        torch.distributed.all_reduce(mx, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(stats, op=torch.distributed.ReduceOp.SUM)
+        elapsed_max, rays_all, samples_all = float(mx[0]), float(stats[1]), float(stats[2])
+    else:
+        elapsed_max, rays_all, samples_all = elapsed, float(rays), float(samples)
+
+    # ---- roofline of the dominant kernel, from events recorded on the launch stream in the timed region
+    summ = timer.summary()
+    dom = max((k for k in summ if k in ALGO), key=lambda k: summ[k][1])
+    launches, total_ms, work_units = summ[dom]     # units = samples (rays for K1) summed over the launches
+    bound, per_sample = ALGO[dom]
+    if bound == 'hbm':
+        achieved = work_units * per_sample / (total_ms * 1e-3) / 1e9
+        roof = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': achieved / HBM_PEAK_GBS, 'traffic': None}
+    else:
+        achieved = work_units * per_sample / (total_ms * 1e-3) / 1e12
+        roof = {'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': achieved / MFMA_F32_PEAK_TFLOPS, 'traffic': None}
+    roof['kernel'] = dom
+    roof['avg_launch_us'] = total_ms * 1e3 / max(launches, 1)
+    roof['launches'] = launches
+    roof['algorithmic_per_sample'] = per_sample
+
+    extra = {}
+    if not args.no_render:
+        H = W = 800
+        pose = tr.data.poses[0]
+        row0, nrows = xdist.row_band(H, rank, world)
+        for _ in range(2):
+            rgb, alpha = render_frame(tr.net, pose, H, W, tr.data.focal, row0=row0, nrows=nrows)
+            xdist.gather_image(torch.cat([rgb, alpha], -1), H, rank, world)
+        barrier()
+        t1 = time.perf_counter()
+        n_frames = 5
+        for f in range(n_frames):
+            rgb, alpha = render_frame(tr.net, tr.data.poses[f % tr.data.n_img], H, W, tr.data.focal, row0=row0, nrows=nrows)
+            img = xdist.gather_image(torch.cat([rgb, alpha], -1), H, rank, world)
+        barrier()
+        extra['render_ms_per_800x800_frame'] = (time.perf_counter() - t1) * 1e3 / n_frames
+        extra['render_samples_per_ray'] = float(tr.net.sampler.coords.shape[0]) / max(1, nrows * W)
+
+    if rank == 0:
+        out = {
+            'metric': 'training rays/s, Instant-NGP Lego (configs/instant_ngp/nerf_blender_local01.py), synthetic 800x800 rays',
+            'value': rays_all / elapsed_max, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': elapsed_max * 1e3 / args.steps, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'Instant-NGP Lego, hash L=16 F=2 T=2^19, 64-wide fused MLP (1+2 hidden), 800x800, '
+                                   'adaptive batch targeting 2^18 samples, grid refresh every 16 its',
+                       'rays_per_step': rays_all / args.steps / world, 'samples_per_ray': samples_all / max(rays_all, 1),
+                       'samples_per_s': samples_all / elapsed_max, 'n_images': args.n_img,
+                       'parallelism': 'ray-sharded data parallel x%d, gradient all-reduce (RCCL)' % world if world > 1 else 'single GPU'},
+            'roofline': roof,
+            'kernel_ms_per_step': {k: v[1] / args.steps for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])},
+        }
+        out.update(extra)
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+            out['cpu_baseline']['host_cores_available'] = os.cpu_count()
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

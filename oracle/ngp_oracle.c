@@ -744,14 +744,15 @@ void xo_gen_rays(const float* pose43, int H, int W, float fx, float fy, float cx
     }
 }
 
-/* ---------------------------------------------------------------- loss (xrnerf/models/networks/utils/metrics.py:3-16
- * + networks/hashnerf.py:37-44): loss = 5 * sum huber_{delta=0.1}(rgb - target); returns dL/drgb. */
+/* ---------------------------------------------------------------- loss
+ * HuberLoss (xrnerf/models/networks/utils/metrics.py:8-16): rel=|x-y|; rel > delta ? rel - delta/2
+ * : 0.5/delta*rel^2, summed; times 5 in train_step (networks/hashnerf.py:37-44). Returns dL/drgb. */
 float xo_huber_loss_grad(const float* rgb, const float* target, int n3, float delta, float scale, float* grad) {
     double loss = 0;
     for (int i = 0; i < n3; ++i) {
         float r = rgb[i] - target[i], a = fabsf(r);
-        if (a < delta) { loss += 0.5 * r * r; grad[i] = scale * r; }
-        else { loss += delta * (a - 0.5 * delta); grad[i] = scale * delta * (r > 0 ? 1.f : -1.f); }
+        if (a > delta) { loss += a - 0.5f * delta; grad[i] = scale * (r > 0 ? 1.f : -1.f); }
+        else { loss += 0.5f / delta * a * a; grad[i] = scale * (r / delta); }
     }
     return (float)(loss * scale);
 }

@@ -1,0 +1,11 @@
+"""xrnerf_amd: MI355X-native Instant-NGP hot path behind openxrlab/xrnerf's module registry.
+
+Importing the package registers the reference's type names (`HashNerfNetwork`, `NGPGridSampler`,
+`HashNerfMLP`, `HashNerfRender`) in `xrnerf_amd.builder.MODELS`, so
+`build_network(cfg.model)` works on the reference's configs/instant_ngp/*.py unchanged.
+"""
+from . import builder  # noqa: F401
+from .builder import build_embedder, build_mlp, build_network, build_render, build_sampler  # noqa: F401
+from . import mlps, networks, renders, samplers  # noqa: F401,E402
+
+__version__ = '0.1.0'

@@ -52,15 +52,16 @@ extern "C" int xr_gen_rays(const float* pose43_host, int H, int W, float fx, flo
     return XR_OK;
 }
 
-// ------------------------------------------------------------------ Huber loss * scale, gradient
+// ------------------------------------------------------------------ scale * HuberLoss(sum) and its gradient
 __global__ __launch_bounds__(256) void k_huber(const float* __restrict__ rgb, const float* __restrict__ target, uint32_t n,
                                                 float delta, float scale, float* __restrict__ grad, float* __restrict__ loss) {
     __shared__ float ws[4];
     float acc = 0.f;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const float r = rgb[i] - target[i], a = fabsf(r);
-        if (a < delta) { acc += 0.5f * r * r; grad[i] = scale * r; }
-        else { acc += delta * (a - 0.5f * delta); grad[i] = scale * delta * (r > 0.f ? 1.f : -1.f); }
+        // HuberLoss of the reference (utils/metrics.py:8-16): rel > delta ? rel - delta/2 : 0.5/delta*rel^2
+        if (a > delta) { acc += a - 0.5f * delta; grad[i] = scale * (r > 0.f ? 1.f : -1.f); }
+        else { acc += 0.5f / delta * a * a; grad[i] = scale * (r / delta); }
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);

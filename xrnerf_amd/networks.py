@@ -1,0 +1,147 @@
+"""`HashNerfNetwork`: sampler -> mlp -> render, the registered type of
+/root/reference/xrnerf/models/networks/hashnerf.py:16-112 (base class behaviour from
+networks/nerf.py:23-69,171-173 and networks/base.py:9-37)."""
+import time
+
+import torch
+from torch import nn
+
+from . import builder
+from .builder import NETWORKS
+
+
+def get_dist_info():
+    """mmcv.runner.get_dist_info"""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+# networks/utils/metrics.py:3-16
+def img2mse(x, y):
+    return torch.mean((x - y) ** 2)
+
+
+def mse2psnr(x):
+    return -10. * torch.log(x) / torch.log(torch.Tensor([10.]).to(x.device))
+
+
+def HuberLoss(x, y, delta=0.1, reduction='sum'):
+    rel = (x - y).abs()
+    sqr = 0.5 / delta * rel * rel
+    loss = torch.where(rel > delta, rel - 0.5 * delta, sqr)
+    if reduction == 'mean':
+        loss = loss.mean()
+    elif reduction == 'sum':
+        loss = loss.sum()
+    return loss
+
+
+def unfold_batching(data):   # networks/utils/batching.py:5-12
+    if len(data.shape) > 1:
+        bs = data.shape[0]
+        data = torch.cat([data[b] for b in range(bs)], 0)
+    return data
+
+
+def recover_shape(data, to_shape):   # networks/utils/transforms.py:5-9
+    to_shape = list(to_shape[:-1]) + list(data.shape[1:])
+    return torch.reshape(data, to_shape)
+
+
+class BaseNerfNetwork(nn.Module):
+    def __init__(self, **kwarg):
+        super().__init__()
+
+    def train_step(self, data, optimizer, **kwargs):
+        raise NotImplementedError
+
+    def val_step(self, data, **kwargs):
+        raise NotImplementedError
+
+
+@NETWORKS.register_module()
+class HashNerfNetwork(BaseNerfNetwork):
+    def __init__(self, cfg, sampler=None, mlp=None, render=None):
+        super().__init__()
+        cfg = builder.ConfigDict.wrap(dict(cfg))
+        self.phase = cfg.get('phase', 'train')
+        if 'chunk' in cfg: self.chunk = cfg.chunk
+        if 'bs_data' in cfg: self.bs_data = cfg.bs_data
+        self.sampler = builder.build_sampler(sampler)
+        self.mlp = builder.build_mlp(mlp)
+        self.render = builder.build_render(render)
+
+    def forward(self, data, is_test=False):
+        data = self.sampler.sample(data, self.mlp, is_test)
+        data = self.mlp(data)
+        data, ret = self.render(data, self.sampler, is_test)
+        return ret
+
+    def batchify_forward(self, data, is_test=False):
+        """forward in smaller minibatches (networks/nerf.py:50-69)."""
+        N = data[self.bs_data].shape[0]
+        all_ret = {}
+        for i in range(0, N, self.chunk):
+            data_chunk = {}
+            for k in data:
+                if data[k].shape[0] == N:
+                    data_chunk[k] = data[k][i:i + self.chunk]
+                else:
+                    data_chunk[k] = data[k]
+            ret = self.forward(data_chunk, is_test)
+            for k in ret:
+                all_ret.setdefault(k, []).append(ret[k])
+        return {k: torch.cat(all_ret[k], 0) for k in all_ret}
+
+    def train_step(self, data, optimizer, **kwargs):
+        for k in data:
+            data[k] = unfold_batching(data[k])
+        ret = self.forward(data, is_test=False)
+        bs = ret['rgb'].shape[0]
+        alpha = data['alpha'].detach()
+        huber_loss = HuberLoss(ret['rgb'], data['target_s'], 0.1, 'sum')
+        mse_loss = img2mse(ret['rgb'] * alpha, data['target_s'] * alpha)
+        psnr = mse2psnr(mse_loss)
+        loss = huber_loss * 5
+        log_vars = {'loss': loss.item(), 'psnr': psnr.item()}
+        return {'loss': loss, 'log_vars': log_vars, 'num_samples': bs}
+
+    def val_step(self, data, optimizer=None, **kwargs):
+        if self.phase == 'test':
+            return self.test_step(data, **kwargs)
+        rank, world_size = get_dist_info()
+        if rank != 0:
+            return {}
+        for k in data:
+            data[k] = unfold_batching(data[k])
+        poses, images = data['poses'], data['images']
+        rgbs, disps, gt_imgs, elapsed_time_list = [], [], [], []
+        for i in range(poses.shape[0]):
+            start = time.time()
+            frame = self.val_pipeline({'pose': poses[i], 'idx': i})
+            ret = self.batchify_forward(frame, is_test=True)
+            rgb = recover_shape(ret['rgb'], frame['src_shape'])
+            rgb = rgb.cpu().numpy()           # D2H inside the timer ends the frame, as the reference's does
+            elapsed_time_list.append(time.time() - start)
+            alpha = images[i].cpu().numpy()[:, :, 3:]
+            gt_img = images[i].cpu().numpy()[:, :, :3]
+            rgbs.append(rgb * alpha)
+            gt_imgs.append(gt_img * alpha)
+        return {'rgbs': rgbs, 'disps': disps, 'gt_imgs': gt_imgs, 'elapsed_time': elapsed_time_list}
+
+    def test_step(self, data, **kwargs):
+        rank, world_size = get_dist_info()
+        if rank != 0:
+            return {}
+        for k in data:
+            data[k] = unfold_batching(data[k])
+        idx = data['idx'].item()
+        ret = self.batchify_forward(data, is_test=True)
+        rgb = recover_shape(ret['rgb'], data['src_shape']).cpu().numpy()
+        alpha = recover_shape(ret['alpha'], data['src_shape']).cpu().numpy()
+        return {'spiral_rgb': rgb, 'spiral_alpha': alpha, 'idx': idx}
+
+    def set_val_pipeline(self, func):
+        self.val_pipeline = func

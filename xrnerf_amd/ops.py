@@ -16,6 +16,53 @@ N_GRID = 8 * G3
 _workspaces = {}
 
 
+class KernelTimer:
+    """Optional per-entry-point device timing with events recorded on the launch stream (torch's
+    current stream IS the stream every kernel of this library is enqueued on).  bench.py uses it to
+    get the dominant kernel's average duration live inside the timed region."""
+
+    def __init__(self):
+        self.events = {}
+
+    def span(self, name, units=0):
+        return _Span(self, name, units)
+
+    def summary(self):
+        """name -> (launches, total_ms, total_units); call after torch.cuda.synchronize()"""
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b, _ in v), sum(u for _, _, u in v))
+                for k, v in self.events.items()}
+
+
+class _Span:
+    def __init__(self, timer, name, units):
+        self.timer, self.name, self.units = timer, name, units
+
+    def __enter__(self):
+        self.a = torch.cuda.Event(enable_timing=True)
+        self.b = torch.cuda.Event(enable_timing=True)
+        self.a.record()
+
+    def __exit__(self, *exc):
+        self.b.record()
+        self.timer.events.setdefault(self.name, []).append((self.a, self.b, self.units))
+
+
+class _NoSpan:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+TIMER = None
+_NOSPAN = _NoSpan()
+
+
+def _span(name, units=0):
+    return TIMER.span(name, units) if TIMER is not None else _NOSPAN
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -60,9 +107,10 @@ def rays_sampler(rays_o, rays_d, bitfield, aabb, near_distance, cone_angle, max_
     nb = L.xr_rays_sampler_workspace_bytes(n)
     ws = _ws(dev, nb, 'k1')
     st, inc = pcg32_host_state(rng_calls)
-    _lib.check(L.xr_rays_sampler(_ptr(rays_o), _ptr(rays_d), _ptr(bitfield), n, aabb[0], aabb[1], near_distance,
-                                 cone_angle, max_samples, st, inc, _ptr(coords_out), _ptr(rays_index),
-                                 _ptr(numsteps), _ptr(counter), _ptr(ws), ws.numel(), _stream()), 'xr_rays_sampler')
+    with _span('xr_rays_sampler', n):
+        _lib.check(L.xr_rays_sampler(_ptr(rays_o), _ptr(rays_d), _ptr(bitfield), n, aabb[0], aabb[1], near_distance,
+                                     cone_angle, max_samples, st, inc, _ptr(coords_out), _ptr(rays_index),
+                                     _ptr(numsteps), _ptr(counter), _ptr(ws), ws.numel(), _stream()), 'xr_rays_sampler')
     return coords_out, rays_index, numsteps, counter
 
 
@@ -87,8 +135,9 @@ def calc_rgb_forward(raw, coords, numsteps, numsteps_c, bg, rgb_act, density_act
     n = numsteps.shape[0]
     if out is None:
         out = torch.empty((n, 3), dtype=torch.float32, device=raw.device)
-    _lib.check(L.xr_calc_rgb_forward(_ptr(raw), _ptr(coords), _ptr(numsteps), _ptr(numsteps_c), _ptr(bg), n,
-                                     int(rgb_act), int(density_act), _ptr(out), _stream()), 'xr_calc_rgb_forward')
+    with _span('xr_calc_rgb_forward', raw.shape[0]):
+        _lib.check(L.xr_calc_rgb_forward(_ptr(raw), _ptr(coords), _ptr(numsteps), _ptr(numsteps_c), _ptr(bg), n,
+                                         int(rgb_act), int(density_act), _ptr(out), _stream()), 'xr_calc_rgb_forward')
     return out
 
 
@@ -97,9 +146,10 @@ def calc_rgb_backward(raw, numsteps_c, coords, grad_rgb, rgb_out, density_grid_m
     n = numsteps_c.shape[0]
     if out is None:
         out = torch.zeros_like(raw)
-    _lib.check(L.xr_calc_rgb_backward(_ptr(raw), _ptr(numsteps_c), _ptr(coords), _ptr(grad_rgb), _ptr(rgb_out),
-                                      _ptr(density_grid_mean), n, int(rgb_act), int(density_act), _ptr(out),
-                                      _stream()), 'xr_calc_rgb_backward')
+    with _span('xr_calc_rgb_backward', raw.shape[0]):
+        _lib.check(L.xr_calc_rgb_backward(_ptr(raw), _ptr(numsteps_c), _ptr(coords), _ptr(grad_rgb), _ptr(rgb_out),
+                                          _ptr(density_grid_mean), n, int(rgb_act), int(density_act), _ptr(out),
+                                          _stream()), 'xr_calc_rgb_backward')
     return out
 
 
@@ -137,7 +187,10 @@ def mark_untrained_density_grid(focal, xforms, n_elements, resolutions, grid=Non
 
 
 def splat_grid_samples(mlp_out, indices, padded_width, n_samples, grid_tmp):
-    _lib.check(_lib.load().xr_splat_grid_samples(_ptr(mlp_out), _ptr(indices), padded_width, n_samples,
+    """mlp_out may be a strided [n,1] view: `padded_width` is its row stride in floats."""
+    if not mlp_out.is_cuda:
+        raise _lib.XrError('xrnerf_amd ops need ROCm device tensors: there is no CPU fallback')
+    _lib.check(_lib.load().xr_splat_grid_samples(C.c_void_p(mlp_out.data_ptr()), _ptr(indices), padded_width, n_samples,
                                                  _ptr(grid_tmp), _stream()), 'xr_splat_grid_samples')
     return grid_tmp
 
@@ -190,6 +243,8 @@ def _pos_view(x):
         raise _lib.XrError('positions must be a 2-D float32 tensor with >= 3 columns')
     if x.stride(1) != 1:
         raise _lib.XrError('positions must have unit column stride')
+    if not x.is_cuda:
+        raise _lib.XrError('xrnerf_amd ops need ROCm device tensors (got a %s tensor): there is no CPU fallback' % x.device)
     return x, int(x.stride(0))
 
 
@@ -203,8 +258,9 @@ def hashgrid_fwd(table, x, meta, enc_t=None, ld=None):
     if enc_t is None:
         enc_t = torch.empty((meta.n_output_dims, ld), dtype=torch.float32, device=x.device)
     s, r, o = meta._args()
-    _lib.check(L.xr_hashgrid_fwd(_ptr(table), C.c_void_p(x.data_ptr()), xs, n, meta.n_levels, s, r, o, _ptr(enc_t), ld,
-                                 _stream()), 'xr_hashgrid_fwd')
+    with _span('xr_hashgrid_fwd', n):
+        _lib.check(L.xr_hashgrid_fwd(_ptr(table), C.c_void_p(x.data_ptr()), xs, n, meta.n_levels, s, r, o, _ptr(enc_t), ld,
+                                     _stream()), 'xr_hashgrid_fwd')
     return enc_t
 
 
@@ -213,8 +269,9 @@ def hashgrid_bwd(x, denc_t, meta, grad_table):
     x, xs = _pos_view(x)
     n = x.shape[0]
     s, r, o = meta._args()
-    _lib.check(L.xr_hashgrid_bwd(C.c_void_p(x.data_ptr()), xs, _ptr(denc_t), denc_t.shape[1], n, meta.n_levels, s, r, o,
-                                 _ptr(grad_table), _stream()), 'xr_hashgrid_bwd')
+    with _span('xr_hashgrid_bwd', n):
+        _lib.check(L.xr_hashgrid_bwd(C.c_void_p(x.data_ptr()), xs, _ptr(denc_t), denc_t.shape[1], n, meta.n_levels, s, r, o,
+                                     _ptr(grad_table), _stream()), 'xr_hashgrid_bwd')
     return grad_table
 
 
@@ -235,9 +292,10 @@ def nerf_mlp_fwd(enc_t, dirs, n, w_density, w_color, nhd, nhc, pad_value=1.0, ra
         dp = C.c_void_p(dirs.data_ptr())
     else:
         ds, dp = 0, None
-    _lib.check(L.xr_nerf_mlp_fwd(_ptr(enc_t), enc_t.shape[1], dp, ds, n, _ptr(w_density),
-                                 _ptr(w_color) if w_color is not None else None, nhd, nhc, pad_value, _ptr(raw),
-                                 _stream()), 'xr_nerf_mlp_fwd')
+    with _span('xr_nerf_mlp_fwd', n):
+        _lib.check(L.xr_nerf_mlp_fwd(_ptr(enc_t), enc_t.shape[1], dp, ds, n, _ptr(w_density),
+                                     _ptr(w_color) if w_color is not None else None, nhd, nhc, pad_value, _ptr(raw),
+                                     _stream()), 'xr_nerf_mlp_fwd')
     return raw
 
 
@@ -247,9 +305,10 @@ def nerf_mlp_bwd(enc_t, dirs, n, w_density, w_color, nhd, nhc, draw, grad_wd, gr
     if denc_t is None:
         denc_t = torch.empty_like(enc_t)
     ws = _ws(enc_t.device, L.xr_nerf_mlp_bwd_workspace_bytes(n), 'mlpbwd')
-    _lib.check(L.xr_nerf_mlp_bwd(_ptr(enc_t), enc_t.shape[1], C.c_void_p(dirs.data_ptr()), ds, n, _ptr(w_density),
-                                 _ptr(w_color), nhd, nhc, pad_value, _ptr(draw), _ptr(denc_t), _ptr(grad_wd),
-                                 _ptr(grad_wc), _ptr(ws), ws.numel(), _stream()), 'xr_nerf_mlp_bwd')
+    with _span('xr_nerf_mlp_bwd', n):
+        _lib.check(L.xr_nerf_mlp_bwd(_ptr(enc_t), enc_t.shape[1], C.c_void_p(dirs.data_ptr()), ds, n, _ptr(w_density),
+                                     _ptr(w_color), nhd, nhc, pad_value, _ptr(draw), _ptr(denc_t), _ptr(grad_wd),
+                                     _ptr(grad_wc), _ptr(ws), ws.numel(), _stream()), 'xr_nerf_mlp_bwd')
     return denc_t
 
 
@@ -274,5 +333,6 @@ def huber_loss_grad(rgb, target, delta=0.1, scale=5.0):
 
 def adam_step(p, g, m, v, step, lr=1e-2, beta1=0.9, beta2=0.99, eps=1e-15, weight_decay=1e-6, ema=None,
               ema_momentum=0.05):
-    _lib.check(_lib.load().xr_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), step, lr, beta1, beta2, eps,
+    with _span('xr_adam_step', p.numel()):
+      _lib.check(_lib.load().xr_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), step, lr, beta1, beta2, eps,
                                         weight_decay, _ptr(ema), ema_momentum, _stream()), 'xr_adam_step')

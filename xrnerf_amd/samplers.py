@@ -1,0 +1,198 @@
+"""`NGPGridSampler`: occupancy-grid ray marching (Instant-NGP Appendix E), the registered type of
+/root/reference/xrnerf/models/samplers/ngp_grid_sampler.py:11-284, on the MI355X kernels.
+
+Same constructor signature, same public attributes (`coords`, `rays_numsteps`,
+`rays_numsteps_compacted`, `density_grid_mean`, `aabb_range`, `rgb_activation`,
+`density_activation`, `n_rays_per_batch`, registered buffer `density_grid_bitfield`), same schedule
+(grid refresh every `update_grid_freq` iterations, rays-per-batch adaptation every 16th).
+
+Deliberate differences, none of which changes a result:
+  * no per-kernel device synchronisation (the reference syncs after each of its 4-9 launches); the
+    only host read-back per training iteration is the emitted-sample count, as in
+    samplers/utils/rays_sampler.py:72;
+  * the reference runs the MLP without grad over all S samples only to feed K2, whose transmittance
+    loop is dead code (extensions/ngp_raymarch/src/compacted_coord.cu:41-44): K2's outputs do not
+    depend on the network output, so that pass is skipped;
+  * sample bases are the exclusive prefix sum in ray order (deterministic) instead of atomicAdd
+    order, so when nothing is clipped K1's output already IS the compacted layout and K2 is a no-op
+    alias (it runs only when S > target_batch_size or K1 overflowed);
+  * the hidden global RNG (`static pcg32 rng{9121}` per translation unit) becomes two explicit call
+    counters on this object.
+"""
+import torch
+from torch import nn
+
+from . import ops
+from .builder import SAMPLERS
+
+
+@SAMPLERS.register_module()
+class NGPGridSampler(nn.Module):
+    def __init__(self, update_grid_freq=16, update_block_size=5000000, n_rays_per_batch=4096,
+                 cone_angle_constant=0.00390625, near_distance=0.2, target_batch_size=1 << 18, rgb_activation=2,
+                 density_activation=3):
+        super().__init__()
+        self.update_grid_freq = update_grid_freq
+        self.update_block_size = update_block_size
+        self.n_rays_per_batch = n_rays_per_batch
+        self.target_batch_size = target_batch_size
+        self.rgb_activation = rgb_activation
+        self.density_activation = density_activation
+        self.density_mlp_padded_density_output_width = 1
+
+        n_threads_linear = 128
+        self.density_grid_ema_step = 0
+        self.NERF_CASCADES = 8
+        self.NERF_GRIDSIZE = 128
+        # the reference overrides both ctor arguments with the raymarch_shared.h constants
+        # (ngp_grid_sampler.py:41,44); kept for result parity
+        self.near_distance = 0.05
+        self.ema_grid_decay = 0.95
+        self.MAX_STEP = 1024
+        self.cone_angle_constant = 0.00390625
+        self.NERF_MIN_OPTICAL_THICKNESS = 0.01
+        self.num_coords_elements = self.n_rays_per_batch * self.MAX_STEP
+
+        g3 = self.NERF_GRIDSIZE ** 3
+        self.density_n_elements = self.NERF_CASCADES * g3
+        self.density_grid_tmp = torch.zeros([self.density_n_elements], dtype=torch.float32)
+        self.density_grid_mean = torch.zeros([(g3 + n_threads_linear - 1) // n_threads_linear], dtype=torch.float32)
+        self.register_buffer('density_grid_bitfield', torch.zeros([g3 * self.NERF_CASCADES // 8], dtype=torch.uint8))
+        self.measured_batch_size = torch.zeros((1,), dtype=torch.int32)
+        self.iter_n = 0
+        # explicit replacements of the reference's two hidden per-TU generators
+        self.k1_calls = 0
+        self.k6_calls = 0
+        self.device = None
+
+    # ------------------------------------------------------------------ hooks' entry points
+    def set_data(self, alldata, datainfo):
+        self.resolutions = [datainfo['H'], datainfo['W']]
+        self.transforms = torch.as_tensor(alldata['poses'], dtype=torch.float32).contiguous()
+        self.focal = torch.as_tensor(alldata['focal'], dtype=torch.float32).contiguous()
+        self.aabb_scale = alldata['aabb_scale']
+        self.aabb_range = alldata['aabb_range']
+        self.metadata = torch.as_tensor(alldata['metadata'], dtype=torch.float32).contiguous()
+        self.n_img = alldata['poses'].shape[0]
+        self.max_cascade = 0
+        while (1 << self.max_cascade) < self.aabb_scale:
+            self.max_cascade += 1
+
+    def set_iter(self, iter_n):
+        self.iter_n = iter_n
+
+    # ------------------------------------------------------------------ density grid upkeep (K6..K11)
+    def update_density_grid_func(self, n_uniform, n_nonuniform, mlp):
+        n_elements = self.density_n_elements
+        aabb = (float(self.aabb_range[0]), float(self.aabb_range[1]))
+        if not hasattr(self, 'density_grid'):
+            self.density_grid = ops.mark_untrained_density_grid(self.focal, self.transforms, n_elements,
+                                                                self.resolutions)
+        pos_u, idx_u = ops.generate_grid_samples(self.density_grid, self.density_grid_ema_step, n_uniform,
+                                                 self.max_cascade + 1, -0.01, aabb, self.k6_calls)
+        self.k6_calls += 1
+        pos_n, idx_n = ops.generate_grid_samples(self.density_grid, self.density_grid_ema_step, n_nonuniform,
+                                                 self.max_cascade + 1, self.NERF_MIN_OPTICAL_THICKNESS, aabb,
+                                                 self.k6_calls)
+        self.k6_calls += 1     # the reference's rng advances on every call, also for n == 0
+        positions = torch.cat([pos_u, pos_n]) if n_nonuniform > 0 else pos_u
+        indices = torch.cat([idx_u, idx_n]) if n_nonuniform > 0 else idx_u
+        self.density_grid_tmp.zero_()
+        with torch.no_grad():
+            for i in range(0, positions.shape[0], self.update_block_size):
+                density = mlp.run_density(positions[i:i + self.update_block_size])   # [m,1] view, row stride 4
+                ops.splat_grid_samples(density, indices[i:i + self.update_block_size], density.stride(0),
+                                       density.shape[0], self.density_grid_tmp)
+        ops.ema_grid_samples(self.density_grid_tmp, n_elements, self.ema_grid_decay, self.density_grid)
+        self.density_grid_ema_step += 1
+        ops.update_bitfield(self.density_grid, self.density_grid_mean, self.density_grid_bitfield)
+
+    def update_density_grid(self, mlp):
+        n_cascades = self.max_cascade + 1
+        M = self.NERF_GRIDSIZE ** 3 * n_cascades
+        if self.iter_n < 256:
+            self.update_density_grid_func(M, 0, mlp)
+        else:
+            self.update_density_grid_func(M // 4, M // 4, mlp)
+
+    def check_device(self, data):
+        device = data['rays_o'].device
+        if self.device != device:
+            self.device = device
+            for attr in ['transforms', 'focal', 'metadata', 'density_grid_mean', 'density_grid_bitfield',
+                         'density_grid_tmp', 'measured_batch_size']:
+                if hasattr(self, attr):
+                    setattr(self, attr, getattr(self, attr).to(device).contiguous())
+            if hasattr(self, 'density_grid'):
+                self.density_grid = self.density_grid.to(device)
+
+    # ------------------------------------------------------------------ sampling (K1, K2)
+    def sample(self, data, mlp, is_test=False):
+        is_training = not is_test
+        self.check_device(data)
+        if is_training and (self.iter_n % self.update_grid_freq == 0 or not hasattr(self, 'density_grid')):
+            self.update_density_grid(mlp)
+
+        rays_o = data['rays_o'].contiguous().float()
+        rays_d = data['rays_d'].contiguous().float()
+        if 'bg_color' in data:
+            data['bg_color'] = data['bg_color'].to(torch.float32).contiguous()
+        n_rays = rays_o.shape[0]
+        aabb = (float(self.aabb_range[0]), float(self.aabb_range[1]))
+        # the reference sizes the buffer n_rays_per_batch*1024 rows (117 MB zero-filled per call,
+        # samplers/utils/rays_sampler.py:20-21); nothing reads rows past the counter, so it is not cleared
+        max_samples = max(self.num_coords_elements, n_rays * 64) if is_training else n_rays * self.MAX_STEP
+        max_samples = min(max_samples, n_rays * self.MAX_STEP)
+        coords, rays_index, rays_numsteps, counter = ops.rays_sampler(
+            rays_o, rays_d, self.density_grid_bitfield, aabb, self.near_distance, self.cone_angle_constant,
+            max_samples, self.k1_calls, coords_out=self._coords_buffer(max_samples))
+        self.k1_calls += 1
+        n_valid, samples = counter.tolist()      # the one host read-back (rays_sampler.py:72)
+        if samples > max_samples:                # some rays overflowed and were dropped (ray_sampler.cu:76-82)
+            samples_kept = int(rays_numsteps[:, 0].sum().item())
+        else:
+            samples_kept = samples
+        coords = coords[:min(samples, max_samples)]
+        self.rays_index = rays_index
+
+        if not is_training:
+            self.coords = coords
+            self.rays_numsteps = rays_numsteps
+            data['pts'], data['viewdirs'] = coords[..., :3], coords[..., 4:]
+            return data
+
+        if samples <= max_samples and samples <= self.target_batch_size:
+            # K1's ray-ordered bases are exactly what K2 would assign: alias instead of copying
+            coords_compacted, rays_numsteps_compacted, compacted_total = coords, rays_numsteps, samples
+        else:
+            coords_compacted, rays_numsteps_compacted, _, sc = ops.compacted_coord(
+                coords, rays_numsteps, self.target_batch_size)
+            compacted_total = int(sc.item())
+            coords_compacted = coords_compacted[:min(compacted_total, self.target_batch_size)]
+        self.measured_batch_size += compacted_total        # pre-clip counter (ngp_grid_sampler.py:252)
+        self._measured_host = getattr(self, '_measured_host', 0) + compacted_total
+        self.update_batch_rays(is_training)
+
+        self.coords = coords_compacted
+        self.rays_numsteps = rays_numsteps
+        self.rays_numsteps_compacted = rays_numsteps_compacted
+        data['pts'], data['viewdirs'] = coords_compacted[..., :3], coords_compacted[..., 4:]
+        return data
+
+    def _coords_buffer(self, rows):
+        buf = getattr(self, '_coords_buf', None)
+        if buf is None or buf.shape[0] < rows or buf.device != self.device:
+            buf = torch.empty((rows, 7), dtype=torch.float32, device=self.device)
+            self._coords_buf = buf
+        return buf[:rows]
+
+    def update_batch_rays(self, is_training):
+        if is_training and self.iter_n % self.update_grid_freq == (self.update_grid_freq - 1):
+            measured = max(self._measured_host / 16, 1)      # == measured_batch_size.item() / 16, without the sync
+            rays_per_batch = int(self.n_rays_per_batch * self.target_batch_size / measured)
+            self.n_rays_per_batch = int(min(self.div_round_up(int(rays_per_batch), 128) * 128, self.target_batch_size))
+            self.measured_batch_size.zero_()
+            self._measured_host = 0
+
+    def div_round_up(self, val, divisor):
+        return (val + divisor - 1) // divisor

@@ -1,0 +1,216 @@
+"""Host-side driver pieces around the network for benchmarking and smoke tests: the fused optimiser,
+a device-resident synthetic "Lego-shaped" dataset, the per-iteration hook semantics of the reference
+(`PassSamplerIterHook`, `ModifyBatchsizeHook`, `PassDatasetHook`;
+/root/reference/xrnerf/core/hooks/hash_hook.py:12-42) and frame rendering.
+
+This is NOT a re-implementation of the reference's mmcv runner / dataset stack (out of scope,
+SURVEY.md section 2a rows 10-16): only what a bench needs to drive `HashNerfNetwork.train_step`.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops, synthetic
+from .builder import build_network
+
+
+def ngp_lego_model_cfg(n_rays=4096):
+    """The `model` dict of /root/reference/configs/instant_ngp/nerf_blender_local01.py:78-138,
+    restated (the reference tree does not exist on the GPU box; tests/test_config.py checks this
+    against the real file when it is present and against tests/golden/ngp_model_cfg.json)."""
+    return dict(
+        type='HashNerfNetwork',
+        cfg=dict(phase='train', chunk=4096, bs_data='rays_o'),
+        mlp=dict(
+            type='HashNerfMLP', bound=1,
+            embedder_pos=dict(n_input_dims=3, encoding_config=dict(
+                otype='HashGrid', n_levels=16, n_features_per_level=2, log2_hashmap_size=19, base_resolution=16,
+                interpolation='Linear')),
+            embedder_dir=dict(n_input_dims=3, encoding_config=dict(otype='SphericalHarmonics', degree=4)),
+            density_net=dict(n_input_dims=32, n_output_dims=16, network_config=dict(
+                otype='FullyFusedMLP', activation='ReLU', output_activation='None', n_neurons=64, num_layers=1)),
+            color_net=dict(n_output_dims=3, network_config=dict(
+                otype='FullyFusedMLP', activation='ReLU', output_activation='None', n_neurons=64, num_layers=2))),
+        sampler=dict(type='NGPGridSampler', update_grid_freq=16, update_block_size=5000000, n_rays_per_batch=n_rays,
+                     cone_angle_constant=0.00390625, near_distance=0.2, target_batch_size=1 << 18, rgb_activation=2,
+                     density_activation=3),
+        render=dict(type='HashNerfRender', bg_color=[0, 0, 0]),
+    )
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam semantics (L2 weight decay folded into the gradient) + the EMA copy that
+    mmcv's EMAHook keeps (configs/instant_ngp/nerf_blender_local01.py:14-24), in ONE pass over
+    p, g, m, v(, ema) per tensor (xr_adam_step)."""
+
+    def __init__(self, params, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, weight_decay=1e-6, ema_momentum=None):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
+                                      ema_momentum=ema_momentum))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        for group in self.param_groups:
+            for p in group['params']:
+                if p.grad is None or p.numel() == 0:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st['step'] = 0
+                    st['m'] = torch.zeros_like(p)
+                    st['v'] = torch.zeros_like(p)
+                    if group['ema_momentum'] is not None:
+                        st['ema'] = p.detach().clone()
+                st['step'] += 1
+                ops.adam_step(p, p.grad.contiguous(), st['m'], st['v'], st['step'], group['lr'], group['betas'][0],
+                              group['betas'][1], group['eps'], group['weight_decay'], st.get('ema'),
+                              group['ema_momentum'] or 0.0)
+
+
+def step_lr(base_lr, it, step=10000, gamma=0.2):
+    """lr_config = dict(policy='step', step=10000, gamma=0.2) (nerf_blender_local01.py:22)"""
+    return base_lr * gamma ** (it // step)
+
+
+class SyntheticLego:
+    """Device-resident stand-in for HashNerfDataset (hashnerf_dataset.py:26-73): cameras on the
+    Blender hemisphere in NGP space, all training rays [N*H*W, 11] = (o3, d3, rgba4, img_id)
+    precomputed ON THE DEVICE with xr_gen_rays, targets rendered analytically from a union of
+    axis-aligned boxes ("Lego-shaped", ~6 % of the level-0 cells), pre-shuffled once like the
+    reference's np.random.shuffle."""
+
+    def __init__(self, device, n_img=20, H=800, W=800, seed=1, shuffle=True):
+        self.device, self.H, self.W, self.n_img = device, H, W, n_img
+        self.focal = float(synthetic.LEGO_FOCAL) * W / 800.0
+        self.poses = synthetic.lego_cameras(n_img, seed=seed)
+        self.boxes = _lego_boxes()
+        rows = []
+        for k in range(n_img):
+            o, d = ops.gen_rays(self.poses[k], H, W, self.focal, self.focal, 0.5 * W, 0.5 * H, device=device)
+            rgba = _render_boxes(o, d, self.boxes.to(device))
+            ids = torch.full((o.shape[0], 1), float(k), dtype=torch.float32, device=device)
+            rows.append(torch.cat([o, d, rgba, ids], 1))
+        self.rays_rgb = torch.cat(rows, 0)
+        if shuffle:
+            g = torch.Generator(device='cpu').manual_seed(seed)
+            perm = torch.randperm(self.rays_rgb.shape[0], generator=g).to(device)
+            self.rays_rgb = self.rays_rgb[perm].contiguous()
+        self.cur_i = 0
+        self.N_rand = 4096
+        self.gen = torch.Generator(device=device).manual_seed(seed + 100)
+
+    # HashNerfDataset.get_alldata / get_info
+    def get_alldata(self):
+        aabb_scale = 1
+        return {'aabb_scale': aabb_scale, 'aabb_range': (0.5 - aabb_scale / 2, 0.5 + aabb_scale / 2),
+                'poses': self.poses, 'focal': np.ones((self.n_img, 2), dtype=float) * self.focal,
+                'metadata': synthetic.metadata_rows(self.n_img, self.focal)}
+
+    def get_info(self):
+        return {'H': self.H, 'W': self.W, 'focal': self.focal}
+
+    def set_batchsize(self, bs):          # ModifyBatchsizeHook
+        self.N_rand = int(bs)
+
+    def next_batch(self):
+        """HashBatchSample + RandomBGColor (pipelines/create.py:153-191, augment.py:290-317), on device."""
+        n = self.N_rand
+        if self.cur_i + n >= self.rays_rgb.shape[0]:
+            self.cur_i = 0
+        b = self.rays_rgb[self.cur_i:self.cur_i + n]
+        self.cur_i += n
+        alpha = b[:, 9:10]
+        bg = torch.rand((n, 3), device=self.device, generator=self.gen)
+        target = b[:, 6:9] * alpha + bg * (1 - alpha)
+        return {'rays_o': b[:, 0:3].contiguous(), 'rays_d': b[:, 3:6].contiguous(), 'target_s': target, 'alpha': alpha,
+                'img_ids': b[:, 10:].to(torch.int32), 'bg_color': bg}
+
+
+def _lego_boxes(seed=2, fill=0.07, n_boxes=40):
+    """the same boxes synthetic.lego_density_grid rasterises -> [B,2,3] (lo, hi)"""
+    rng = np.random.default_rng(seed)
+    lo, hi = [np.array([0.30, 0.38, 0.33])], [np.array([0.72, 0.62, 0.47])]
+    vol = np.prod(hi[0] - lo[0])
+    while vol < fill and len(lo) < n_boxes:
+        c = rng.uniform(0.28, 0.72, 3)
+        h = rng.uniform(0.02, 0.09, 3)
+        lo.append(c - h); hi.append(c + h)
+        vol += np.prod(2 * h) * 0.6
+    return torch.tensor(np.stack([np.array(lo), np.array(hi)], 1), dtype=torch.float32)
+
+
+def _render_boxes(o, d, boxes, chunk=1 << 20):
+    """analytic RGBA of opaque coloured boxes: nearest slab hit, colour from the hit position."""
+    out = []
+    for s in range(0, o.shape[0], chunk):
+        oo, dd = o[s:s + chunk, None, :], d[s:s + chunk, None, :]
+        inv = 1.0 / torch.where(dd.abs() < 1e-9, torch.full_like(dd, 1e-9), dd)
+        t0 = (boxes[None, :, 0, :] - oo) * inv
+        t1 = (boxes[None, :, 1, :] - oo) * inv
+        tn = torch.minimum(t0, t1).amax(-1)
+        tf = torch.maximum(t0, t1).amin(-1)
+        hit = (tf >= tn) & (tf > 0)
+        tn = torch.where(hit, tn.clamp_min(0), torch.full_like(tn, 1e9))
+        t, _ = tn.min(1)
+        any_hit = t < 1e8
+        p = o[s:s + chunk] + t[:, None].clamp(max=10) * d[s:s + chunk]
+        rgb = (0.5 + 0.5 * torch.sin(p * 37.0)) * any_hit[:, None]
+        out.append(torch.cat([rgb, any_hit[:, None].float()], 1))
+    return torch.cat(out, 0)
+
+
+class Trainer:
+    """One process = one GPU.  Per iteration: hooks (set_iter, batch size) -> batch -> train_step ->
+    backward -> [gradient all-reduce] -> fused Adam(+EMA)."""
+
+    def __init__(self, device, n_img=20, H=800, W=800, seed=0, world_size=1, rank=0, dataset=None, ema=True):
+        torch.manual_seed(seed)                       # identical initial weights on every rank
+        self.device = device
+        self.net = build_network(ngp_lego_model_cfg()).to(device)
+        self.data = dataset or SyntheticLego(device, n_img, H, W, seed=1 + rank)
+        self.net.sampler.set_data(self.data.get_alldata(), self.data.get_info())     # PassDatasetHook
+        self.base_lr = 1e-2
+        self.opt = FusedAdam([p for p in self.net.parameters() if p.numel() > 0], lr=self.base_lr,
+                             betas=(0.9, 0.99), eps=1e-15, weight_decay=1e-6, ema_momentum=0.05 if ema else None)
+        self.iter = 0
+        self.world_size, self.rank = world_size, rank
+        self.rays_done = 0
+        self.samples_done = 0
+
+    def step(self):
+        net, data = self.net, self.data
+        net.sampler.set_iter(self.iter)                                   # PassSamplerIterHook
+        for g in self.opt.param_groups:
+            g['lr'] = step_lr(self.base_lr, self.iter)
+        batch = data.next_batch()
+        n_rays = batch['rays_o'].shape[0]
+        out = net.train_step(batch, self.opt)
+        self.opt.zero_grad(set_to_none=True)
+        out['loss'].backward()
+        if self.world_size > 1:
+            from . import dist as xdist
+            xdist.allreduce_grads([p for p in net.parameters() if p.grad is not None], self.world_size)
+        self.opt.step()
+        data.set_batchsize(net.sampler.n_rays_per_batch)                  # ModifyBatchsizeHook
+        self.iter += 1
+        self.rays_done += n_rays
+        self.samples_done += int(net.sampler.coords.shape[0])
+        return out
+
+
+@torch.no_grad()
+def render_frame(net, pose43, H, W, focal, chunk=None, row0=0, nrows=None, idx=0):
+    """val/test forward of one camera (HashGetRays -> FlattenRays -> HashSetImgids -> batchify_forward;
+    pipelines/create.py:356-425, networks/nerf.py:50-69) with the rays generated on the device.
+    rows [row0,row0+nrows) only -> the image-space shard of one rank."""
+    dev = next(net.parameters()).device
+    nrows = H - row0 if nrows is None else nrows
+    o, d = ops.gen_rays(pose43, H, W, focal, focal, 0.5 * W, 0.5 * H, row0, nrows, device=dev)
+    data = {'rays_o': o, 'rays_d': d, 'img_ids': torch.full((o.shape[0], 1), idx, dtype=torch.int32, device=dev)}
+    old = net.chunk
+    net.chunk = chunk or o.shape[0]
+    try:
+        ret = net.batchify_forward(data, is_test=True)
+    finally:
+        net.chunk = old
+    return ret['rgb'].reshape(nrows, W, 3), ret['alpha'].reshape(nrows, W, 1)
