@@ -184,6 +184,8 @@ class Trainer:
             g['lr'] = step_lr(self.base_lr, self.iter)
         batch = data.next_batch()
         n_rays = batch['rays_o'].shape[0]
+        # the reference's DataLoader(batch_size=1) collates a leading batch axis that train_step unfolds
+        batch = {k: v[None] for k, v in batch.items()}
         out = net.train_step(batch, self.opt)
         self.opt.zero_grad(set_to_none=True)
         out['loss'].backward()
