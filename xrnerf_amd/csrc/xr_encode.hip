@@ -4,11 +4,13 @@
 // reference tree.  fp32 tables, fp32 interpolation.
 //
 // MI355X mapping: one thread per (sample, level).  blockIdx -> (XCD, level slot, sample block)
-// so that a given level's table slice is only ever touched from ONE XCD (block b runs on XCD
-// b % 8): each private 4 MiB L2 then caches 2 of the 16 levels instead of thrashing over all of
-// them.  Features are written FEATURE-MAJOR ([2L][ld]) so that both these stores and the MLP's
+// so that a given level's table slice is only ever touched from ONE XCD (block b is observed to
+// run on XCD b % 8 -- a speed assumption only) and, within the XCD, level-major: an XCD finishes
+// one level before it starts the next, so the 4 MiB slice it is gathering from stays in its
+// private 4 MiB L2 instead of thrashing over all 16 levels.  Features are written FEATURE-MAJOR ([2L][ld]) so that both these stores and the MLP's
 // MFMA operand loads are 256-B coalesced rows.
 #include "xr_common.h"
+#include <cstdlib>
 
 #define EN_BLOCK 256
 #define EN_MAX_LEVELS 16
@@ -18,6 +20,8 @@ struct GridMeta {
     uint32_t res[EN_MAX_LEVELS];
     uint32_t off[EN_MAX_LEVELS + 1];
     int n_levels;
+    uint32_t n_sblocks;   // sample blocks per level
+    int order;            // 0: levels of an XCD interleaved, 1: level-major within the XCD
 };
 
 extern "C" void xr_hashgrid_meta(int n_levels, int log2_hashmap_size, int base_resolution, double per_level_scale,
@@ -51,8 +55,13 @@ __device__ inline uint32_t grid_index(uint32_t cx, uint32_t cy, uint32_t cz, uin
 __device__ inline void level_of_block(const GridMeta& gm, uint32_t* level, uint32_t* sblock) {
     const uint32_t per_xcd = (gm.n_levels + 7) / 8;
     const uint32_t xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    *level = xcd + 8 * (j % per_xcd);
-    *sblock = j / per_xcd;
+    if (gm.order == 0) { *level = xcd + 8 * (j % per_xcd); *sblock = j / per_xcd; }
+    else {
+        // level-major: an XCD finishes one level before it starts the next (finest first), so that
+        // the one 4 MiB table slice it is working on stays resident in its 4 MiB L2
+        const uint32_t slot = j / gm.n_sblocks;
+        *level = xcd + 8 * (per_xcd - 1 - slot); *sblock = j % gm.n_sblocks;
+    }
 }
 
 __global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_fwd(GridMeta gm, uint32_t hashed_mask, const float* __restrict__ table,
@@ -87,36 +96,60 @@ __global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_fwd(GridMeta gm, uint32_t
     enc_t[(size_t)(2 * l + 1) * ld + i] = r1;
 }
 
+// Scatter-add of the feature gradients.
+//
+// Measured on MI355X (tools/atomic_probe.hip): scattered global atomics retire at ~21-24 G
+// REQUESTS/s chip-wide whatever the type (f32/u64/f64/pk_f16), the footprint (32 KB .. 128 MB) or
+// the XCD partitioning -- but lanes of ONE wave instruction that hit adjacent dwords of the same
+// line are merged into one request (pairs 42, quads 84, 16-lane lines 333 G atomics/s).  The
+// kernel is therefore bound by the number of atomic REQUESTS, and is organised around that:
+//   * 16 lanes own the 16 dwords {cz,cy,cx,f} of one (sample stream, level): the four lanes
+//     {cx=0,1} x {f=0,1} of a (cy,cz) corner pair address 16 contiguous bytes for dense levels and,
+//     for hashed levels, idx ^ (x ^ (x+1)) -- the same 64-B line 7 times out of 8 -- so one
+//     instruction issues 4 requests per sample-level instead of 16;
+//   * each 16-lane group walks BW_CH CONSECUTIVE samples (ray order) and keeps the running sum of
+//     its dword in a register while the cell does not change: at the coarse levels a whole ray
+//     segment collapses into one flush (run-length reduction with no shuffles, any run length).
+#define BW_CH 32
+#define BW_SAMPLES_PER_BLOCK (BW_CH * (EN_BLOCK / 16))
 __global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_bwd(GridMeta gm, uint32_t hashed_mask, const float* __restrict__ x,
                                                             uint32_t x_stride, const float* __restrict__ denc_t, uint32_t ld,
                                                             uint32_t n, float* __restrict__ grad_table) {
     uint32_t l, sb;
     level_of_block(gm, &l, &sb);
     if (l >= (uint32_t)gm.n_levels) return;
-    const uint32_t i = sb * EN_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const float d0 = denc_t[(size_t)(2 * l) * ld + i], d1 = denc_t[(size_t)(2 * l + 1) * ld + i];
-    if (d0 == 0.f && d1 == 0.f) return;   // adding +-0 is a no-op
+    const uint32_t q = threadIdx.x & 15, group = threadIdx.x >> 4;
+    const uint32_t f = q & 1, cx = (q >> 1) & 1, cy = (q >> 2) & 1, cz = (q >> 3) & 1;
+    const uint32_t i0 = sb * BW_SAMPLES_PER_BLOCK + group * BW_CH;
+    if (i0 >= n) return;
+    const uint32_t i1 = min(i0 + BW_CH, n);
     const float scale = gm.scale[l];
     const uint32_t res = gm.res[l], hsize = gm.off[l + 1] - gm.off[l];
     const bool hashed = (hashed_mask >> l) & 1;
-    float* __restrict__ tab = grad_table + 2 * (size_t)gm.off[l];
-    const float* xp = x + (size_t)i * x_stride;
-    float w[3]; uint32_t g[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        const float p = xp[d] * scale + 0.5f;
-        const float f = floorf(p);
-        g[d] = (uint32_t)(int)f; w[d] = p - f;
+    float* __restrict__ tab = grad_table + 2 * (size_t)gm.off[l] + f;
+    const float* __restrict__ dsrc = denc_t + (size_t)(2 * l + f) * ld;
+    uint32_t c0 = 0xffffffffu, c1 = 0xffffffffu, c2 = 0xffffffffu;   // current cell
+    float acc = 0.f;
+    float* dst = tab;
+    for (uint32_t i = i0; i < i1; ++i) {
+        const float d = dsrc[i];
+        const float* xp = x + (size_t)i * x_stride;
+        const float p0 = xp[0] * scale + 0.5f, p1 = xp[1] * scale + 0.5f, p2 = xp[2] * scale + 0.5f;
+        const float f0 = floorf(p0), f1 = floorf(p1), f2 = floorf(p2);
+        const uint32_t g0 = (uint32_t)(int)f0, g1 = (uint32_t)(int)f1, g2 = (uint32_t)(int)f2;
+        const float w0 = p0 - f0, w1 = p1 - f1, w2 = p2 - f2;
+        const float wt = (cx ? w0 : 1.f - w0) * (cy ? w1 : 1.f - w1) * (cz ? w2 : 1.f - w2);
+        const float contrib = wt * d;
+        if (g0 == c0 && g1 == c1 && g2 == c2) {
+            acc += contrib;
+        } else {
+            if (acc != 0.f) unsafeAtomicAdd(dst, acc);       // hardware fp32 atomic add, no return
+            c0 = g0; c1 = g1; c2 = g2;
+            dst = tab + 2 * (size_t)grid_index(g0 + cx, g1 + cy, g2 + cz, res, hsize, hashed);
+            acc = contrib;
+        }
     }
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const float wt = ((c & 1) ? w[0] : 1.f - w[0]) * ((c & 2) ? w[1] : 1.f - w[1]) * ((c & 4) ? w[2] : 1.f - w[2]);
-        const uint32_t idx = grid_index(g[0] + (c & 1), g[1] + ((c >> 1) & 1), g[2] + ((c >> 2) & 1), res, hsize, hashed);
-        // hardware fp32 atomic add, result unused (no-return form)
-        unsafeAtomicAdd(tab + 2 * (size_t)idx, wt * d0);
-        unsafeAtomicAdd(tab + 2 * (size_t)idx + 1, wt * d1);
-    }
+    if (acc != 0.f) unsafeAtomicAdd(dst, acc);
 }
 
 static int fill_meta(GridMeta* gm, uint32_t* hashed_mask, int n_levels, const float* scale, const uint32_t* res,
@@ -133,6 +166,7 @@ static int fill_meta(GridMeta* gm, uint32_t* hashed_mask, int n_levels, const fl
         if (hsize < stride) *hashed_mask |= 1u << l;
     }
     gm->off[n_levels] = off[n_levels];
+    gm->order = 1;   // measured: forward gather 0.154 -> 0.115 ms at 2^18 samples
     return 0;
 }
 
@@ -146,6 +180,7 @@ extern "C" int xr_hashgrid_fwd(const float* table, const float* x, uint32_t x_st
     GridMeta gm; uint32_t hm;
     XR_REQUIRE(fill_meta(&gm, &hm, n_levels, scale_host, resolution_host, offset_host) == 0, "bad level metadata");
     const uint32_t per_xcd = (n_levels + 7) / 8;
+    gm.n_sblocks = xr_div_up(n, EN_BLOCK);
     const uint32_t blocks = 8 * per_xcd * xr_div_up(n, EN_BLOCK);
     hipLaunchKernelGGL(k_hashgrid_fwd, dim3(blocks), dim3(EN_BLOCK), 0, (hipStream_t)stream_, gm, hm, table, x, x_stride, n,
                        enc_t, ld);
@@ -162,7 +197,8 @@ extern "C" int xr_hashgrid_bwd(const float* x, uint32_t x_stride, const float* d
     GridMeta gm; uint32_t hm;
     XR_REQUIRE(fill_meta(&gm, &hm, n_levels, scale_host, resolution_host, offset_host) == 0, "bad level metadata");
     const uint32_t per_xcd = (n_levels + 7) / 8;
-    const uint32_t blocks = 8 * per_xcd * xr_div_up(n, EN_BLOCK);
+    gm.n_sblocks = xr_div_up(n, BW_SAMPLES_PER_BLOCK);
+    const uint32_t blocks = 8 * per_xcd * gm.n_sblocks;
     hipLaunchKernelGGL(k_hashgrid_bwd, dim3(blocks), dim3(EN_BLOCK), 0, (hipStream_t)stream_, gm, hm, x, x_stride, denc_t, ld,
                        n, grad_table);
     XR_LAUNCH_CHECK();
