@@ -150,6 +150,8 @@ def main():
     summ = timer.summary()
     dom = max((k for k in summ if k in ALGO), key=lambda k: summ[k][1])
     launches, total_ms, work_units = summ[dom]     # units = samples (rays for K1) summed over the launches
+    if dom in ('xr_hashgrid_fwd', 'xr_hashgrid_bwd', 'xr_nerf_mlp_fwd', 'xr_nerf_mlp_bwd', 'xr_calc_rgb_forward', 'xr_calc_rgb_backward'):
+        work_units += samples      # launches whose row count lives on the device: the marched samples of this rank
     bound, per_sample = ALGO[dom]
     if bound == 'hbm':
         achieved = work_units * per_sample / (total_ms * 1e-3) / 1e9

@@ -77,6 +77,13 @@ int xr_compacted_coord(const float* coords_in, const int32_t* numsteps_in, uint3
                        uint32_t* rays_counter, uint32_t* numstep_counter, void* workspace,
                        size_t workspace_bytes, void* stream);
 
+/* K2 when K1's ray-ordered output is kept in place (no overflow): the compacted coordinates ARE the
+ * first min(total, max_compacted) rows of K1's buffer, so only the clipped per-ray counts are
+ * needed: numsteps_out[i] = (min(max_compacted - min(max_compacted, base), n), base)
+ * (compacted_coord.cu:63-66).  n_valid_dev[0] = min(counter2[1], max_compacted) (device). */
+int xr_clip_numsteps(const int32_t* numsteps_in, const uint32_t* counter2, uint32_t n_rays, uint32_t max_compacted,
+                     int32_t* numsteps_out, uint32_t* n_valid_dev, void* stream);
+
 /* K3  calc_rgb_forward_api (src/calc_rgb.cu:208-264, kernel :6-67) */
 int xr_calc_rgb_forward(const float* network_output /*[S,4]*/, const float* coords /*[S,7]*/,
                         const int32_t* rays_numsteps, const int32_t* rays_numsteps_compacted,
@@ -135,13 +142,15 @@ int xr_bitfield_from_mean(const float* density_grid, const float* density_grid_m
  * stores and the MLP's MFMA operand loads want for coalescing). */
 void xr_hashgrid_meta(int n_levels, int log2_hashmap_size, int base_resolution, double per_level_scale,
                       float* scale_host, uint32_t* resolution_host, uint32_t* offset_host /*[L+1]*/);
-int xr_hashgrid_fwd(const float* table, const float* x, uint32_t x_stride, uint32_t n, int n_levels,
-                    const float* scale_host, const uint32_t* resolution_host, const uint32_t* offset_host,
-                    float* enc_t, uint32_t ld, void* stream);
+/* `n_dev` (nullable, device): when given, only min(n, *n_dev) rows are processed -- the row count
+ * then never has to be read back to the host (n is the launch-sizing upper bound). */
+int xr_hashgrid_fwd(const float* table, const float* x, uint32_t x_stride, uint32_t n, const uint32_t* n_dev,
+                    int n_levels, const float* scale_host, const uint32_t* resolution_host,
+                    const uint32_t* offset_host, float* enc_t, uint32_t ld, void* stream);
 /* grad_table[idx,f] += w * denc_t[2l+f][i]; caller zero-fills grad_table */
-int xr_hashgrid_bwd(const float* x, uint32_t x_stride, const float* denc_t, uint32_t ld, uint32_t n, int n_levels,
-                    const float* scale_host, const uint32_t* resolution_host, const uint32_t* offset_host,
-                    float* grad_table, void* stream);
+int xr_hashgrid_bwd(const float* x, uint32_t x_stride, const float* denc_t, uint32_t ld, uint32_t n,
+                    const uint32_t* n_dev, int n_levels, const float* scale_host, const uint32_t* resolution_host,
+                    const uint32_t* offset_host, float* grad_table, void* stream);
 /* tcnn.Encoding otype=SphericalHarmonics degree 4; dirs in [0,1] (the sampler's warp_direction);
  * out row-major [n,16] */
 int xr_sh4(const float* dirs, uint32_t dir_stride, uint32_t n, float* out, void* stream);
@@ -152,7 +161,7 @@ int xr_sh4(const float* dirs, uint32_t dir_stride, uint32_t n, float* out, void*
  * Weights: tcnn `params` layout = row-major [out,in] matrices in layer order, out padded to 16.
  * dirs may be NULL (run_density, hashnerf_mlp.py:107-111: only raw[:,3] is meaningful then). */
 int xr_nerf_mlp_fwd(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
-                    const float* w_density, const float* w_color, int n_hidden_density, int n_hidden_color,
+                    const uint32_t* n_dev, const float* w_density, const float* w_color, int n_hidden_density, int n_hidden_color,
                     float pad_value, float* raw /*[n,4]*/, void* stream);
 /* backward of the above given dL/draw [n,4]: writes denc_t [32][ld] (for xr_hashgrid_bwd) and
  * ACCUMULATES weight gradients into grad_w_density / grad_w_color (caller zero-fills).
@@ -160,7 +169,7 @@ int xr_nerf_mlp_fwd(const float* enc_t, uint32_t ld, const float* dirs, uint32_t
  * workspace: xr_nerf_mlp_bwd_workspace_bytes(n). */
 size_t xr_nerf_mlp_bwd_workspace_bytes(uint32_t n);
 int xr_nerf_mlp_bwd(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
-                    const float* w_density, const float* w_color, int n_hidden_density, int n_hidden_color,
+                    const uint32_t* n_dev, const float* w_density, const float* w_color, int n_hidden_density, int n_hidden_color,
                     float pad_value, const float* draw /*[n,4]*/, float* denc_t, float* grad_w_density,
                     float* grad_w_color, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -66,10 +66,11 @@ __device__ inline void level_of_block(const GridMeta& gm, uint32_t* level, uint3
 
 __global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_fwd(GridMeta gm, uint32_t hashed_mask, const float* __restrict__ table,
                                                             const float* __restrict__ x, uint32_t x_stride, uint32_t n,
-                                                            float* __restrict__ enc_t, uint32_t ld) {
+                                                            const uint32_t* __restrict__ n_dev, float* __restrict__ enc_t, uint32_t ld) {
     uint32_t l, sb;
     level_of_block(gm, &l, &sb);
     if (l >= (uint32_t)gm.n_levels) return;
+    if (n_dev) n = min(n, *n_dev);
     const uint32_t i = sb * EN_BLOCK + threadIdx.x;
     if (i >= n) return;
     const float scale = gm.scale[l];
@@ -114,10 +115,11 @@ __global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_fwd(GridMeta gm, uint32_t
 #define BW_SAMPLES_PER_BLOCK (BW_CH * (EN_BLOCK / 16))
 __global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_bwd(GridMeta gm, uint32_t hashed_mask, const float* __restrict__ x,
                                                             uint32_t x_stride, const float* __restrict__ denc_t, uint32_t ld,
-                                                            uint32_t n, float* __restrict__ grad_table) {
+                                                            uint32_t n, const uint32_t* __restrict__ n_dev, float* __restrict__ grad_table) {
     uint32_t l, sb;
     level_of_block(gm, &l, &sb);
     if (l >= (uint32_t)gm.n_levels) return;
+    if (n_dev) n = min(n, *n_dev);
     const uint32_t q = threadIdx.x & 15, group = threadIdx.x >> 4;
     const uint32_t f = q & 1, cx = (q >> 1) & 1, cy = (q >> 2) & 1, cz = (q >> 3) & 1;
     const uint32_t i0 = sb * BW_SAMPLES_PER_BLOCK + group * BW_CH;
@@ -170,7 +172,7 @@ static int fill_meta(GridMeta* gm, uint32_t* hashed_mask, int n_levels, const fl
     return 0;
 }
 
-extern "C" int xr_hashgrid_fwd(const float* table, const float* x, uint32_t x_stride, uint32_t n, int n_levels,
+extern "C" int xr_hashgrid_fwd(const float* table, const float* x, uint32_t x_stride, uint32_t n, const uint32_t* n_dev, int n_levels,
                                const float* scale_host, const uint32_t* resolution_host, const uint32_t* offset_host,
                                float* enc_t, uint32_t ld, void* stream_) {
     if (n == 0) return XR_OK;
@@ -183,12 +185,12 @@ extern "C" int xr_hashgrid_fwd(const float* table, const float* x, uint32_t x_st
     gm.n_sblocks = xr_div_up(n, EN_BLOCK);
     const uint32_t blocks = 8 * per_xcd * xr_div_up(n, EN_BLOCK);
     hipLaunchKernelGGL(k_hashgrid_fwd, dim3(blocks), dim3(EN_BLOCK), 0, (hipStream_t)stream_, gm, hm, table, x, x_stride, n,
-                       enc_t, ld);
+                       n_dev, enc_t, ld);
     XR_LAUNCH_CHECK();
     return XR_OK;
 }
 
-extern "C" int xr_hashgrid_bwd(const float* x, uint32_t x_stride, const float* denc_t, uint32_t ld, uint32_t n, int n_levels,
+extern "C" int xr_hashgrid_bwd(const float* x, uint32_t x_stride, const float* denc_t, uint32_t ld, uint32_t n, const uint32_t* n_dev, int n_levels,
                                const float* scale_host, const uint32_t* resolution_host, const uint32_t* offset_host,
                                float* grad_table, void* stream_) {
     if (n == 0) return XR_OK;
@@ -200,7 +202,7 @@ extern "C" int xr_hashgrid_bwd(const float* x, uint32_t x_stride, const float* d
     gm.n_sblocks = xr_div_up(n, BW_SAMPLES_PER_BLOCK);
     const uint32_t blocks = 8 * per_xcd * gm.n_sblocks;
     hipLaunchKernelGGL(k_hashgrid_bwd, dim3(blocks), dim3(EN_BLOCK), 0, (hipStream_t)stream_, gm, hm, x, x_stride, denc_t, ld,
-                       n, grad_table);
+                       n, n_dev, grad_table);
     XR_LAUNCH_CHECK();
     return XR_OK;
 }

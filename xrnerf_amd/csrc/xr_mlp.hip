@@ -232,9 +232,12 @@ __device__ __forceinline__ void build_color_in(const f32x16& dout, const float* 
 template <int NHD, int NHC, bool WITH_COLOR>
 __global__ __launch_bounds__(MLP_THREADS, 2) void k_nerf_mlp_fwd(const float* __restrict__ enc_t, uint32_t ld,
                                                                const float* __restrict__ dirs, uint32_t dir_stride,
-                                                               uint32_t n, const float* __restrict__ w_density,
+                                                               uint32_t n, const uint32_t* __restrict__ n_dev,
+                                                               const float* __restrict__ w_density,
                                                                const float* __restrict__ w_color, float pad_value,
                                                                float4* __restrict__ raw) {
+    if (n_dev) n = min(n, *n_dev);
+    if (n == 0) return;
     using SD = NetShape<NHD>;
     using SC = NetShape<NHC>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -283,8 +286,9 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_nerf_mlp_fwd(const float* __
 // color 32->64->64->16): every activation and all 12 dW accumulator tiles stay in registers.
 __global__ __launch_bounds__(MLP_THREADS, 1) void k_nerf_mlp_bwd_1_2(
     const float* __restrict__ enc_t, uint32_t ld, const float* __restrict__ dirs, uint32_t dir_stride, uint32_t n,
-    const float* __restrict__ w_density, const float* __restrict__ w_color, float pad_value,
-    const float4* __restrict__ draw, float* __restrict__ denc_t, float* __restrict__ partial /*[grid][GW]*/) {
+    const uint32_t* __restrict__ n_dev, const float* __restrict__ w_density, const float* __restrict__ w_color,
+    float pad_value, const float4* __restrict__ draw, float* __restrict__ denc_t, float* __restrict__ partial /*[grid][GW]*/) {
+    if (n_dev) n = min(n, *n_dev);
     using SD = NetShape<1>;
     using SC = NetShape<2>;
     constexpr int GW = SD::glb_floats + SC::glb_floats;                // 3072 + 7168
@@ -398,7 +402,7 @@ extern "C" int xr_device_cus(void) {
 }
 
 template <int NHD, int NHC>
-static int launch_fwd(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
+static int launch_fwd(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n, const uint32_t* n_dev,
                       const float* wd, const float* wc, float pad, float* raw, hipStream_t stream) {
     const int cus = xr_device_cus() > 0 ? xr_device_cus() : 256;
     const uint32_t n_tiles = (n + 31) / 32;
@@ -407,28 +411,28 @@ static int launch_fwd(const float* enc_t, uint32_t ld, const float* dirs, uint32
         const size_t lds = (NetShape<NHD>::lds_floats + NetShape<NHC>::lds_floats) * sizeof(float);
         auto k = k_nerf_mlp_fwd<NHD, NHC, true>;
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XR_EHIP;
-        hipLaunchKernelGGL(k, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, wd, wc, pad, (float4*)raw);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev, wd, wc, pad, (float4*)raw);
     } else {
         const size_t lds = NetShape<NHD>::lds_floats * sizeof(float);
         auto k = k_nerf_mlp_fwd<NHD, NHC, false>;
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XR_EHIP;
-        hipLaunchKernelGGL(k, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, wd, wc, pad, (float4*)raw);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev, wd, wc, pad, (float4*)raw);
     }
     return XR_OK;
 }
 
 extern "C" int xr_nerf_mlp_fwd(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
-                               const float* w_density, const float* w_color, int n_hidden_density, int n_hidden_color,
+                               const uint32_t* n_dev, const float* w_density, const float* w_color, int n_hidden_density, int n_hidden_color,
                                float pad_value, float* raw, void* stream_) {
     if (n == 0) return XR_OK;
     XR_REQUIRE(enc_t && w_density && raw, "null pointer");
     XR_REQUIRE(!dirs || (w_color && dir_stride >= 3), "color path needs w_color and dir_stride >= 3");
     XR_REQUIRE(ld >= n && ((uintptr_t)raw & 15) == 0, "bad ld / raw alignment");
     int rc;
-    if (n_hidden_density == 1 && n_hidden_color == 2) rc = launch_fwd<1, 2>(enc_t, ld, dirs, dir_stride, n, w_density, w_color, pad_value, raw, (hipStream_t)stream_);
-    else if (n_hidden_density == 1 && n_hidden_color == 1) rc = launch_fwd<1, 1>(enc_t, ld, dirs, dir_stride, n, w_density, w_color, pad_value, raw, (hipStream_t)stream_);
-    else if (n_hidden_density == 2 && n_hidden_color == 2) rc = launch_fwd<2, 2>(enc_t, ld, dirs, dir_stride, n, w_density, w_color, pad_value, raw, (hipStream_t)stream_);
-    else if (n_hidden_density == 2 && n_hidden_color == 3) rc = launch_fwd<2, 3>(enc_t, ld, dirs, dir_stride, n, w_density, w_color, pad_value, raw, (hipStream_t)stream_);
+    if (n_hidden_density == 1 && n_hidden_color == 2) rc = launch_fwd<1, 2>(enc_t, ld, dirs, dir_stride, n, n_dev, w_density, w_color, pad_value, raw, (hipStream_t)stream_);
+    else if (n_hidden_density == 1 && n_hidden_color == 1) rc = launch_fwd<1, 1>(enc_t, ld, dirs, dir_stride, n, n_dev, w_density, w_color, pad_value, raw, (hipStream_t)stream_);
+    else if (n_hidden_density == 2 && n_hidden_color == 2) rc = launch_fwd<2, 2>(enc_t, ld, dirs, dir_stride, n, n_dev, w_density, w_color, pad_value, raw, (hipStream_t)stream_);
+    else if (n_hidden_density == 2 && n_hidden_color == 3) rc = launch_fwd<2, 3>(enc_t, ld, dirs, dir_stride, n, n_dev, w_density, w_color, pad_value, raw, (hipStream_t)stream_);
     else { xr_set_error("xr_nerf_mlp_fwd: unsupported hidden-layer counts (%d,%d)", n_hidden_density, n_hidden_color); return XR_EINVAL; }
     if (rc != XR_OK) { xr_set_error("xr_nerf_mlp_fwd: cannot configure dynamic LDS"); return rc; }
     XR_LAUNCH_CHECK();
@@ -447,7 +451,7 @@ extern "C" size_t xr_nerf_mlp_bwd_workspace_bytes(uint32_t n) {
 }
 
 extern "C" int xr_nerf_mlp_bwd(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
-                               const float* w_density, const float* w_color, int n_hidden_density, int n_hidden_color,
+                               const uint32_t* n_dev, const float* w_density, const float* w_color, int n_hidden_density, int n_hidden_color,
                                float pad_value, const float* draw, float* denc_t, float* grad_w_density,
                                float* grad_w_color, void* workspace, size_t workspace_bytes, void* stream_) {
     if (n == 0) return XR_OK;
@@ -466,7 +470,7 @@ extern "C" int xr_nerf_mlp_bwd(const float* enc_t, uint32_t ld, const float* dir
     XR_HIP(hipFuncSetAttribute((const void*)k_nerf_mlp_bwd_1_2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint32_t grid = bwd_grid(n);
     hipLaunchKernelGGL(k_nerf_mlp_bwd_1_2, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n,
-                       w_density, w_color, pad_value, (const float4*)draw, denc_t, (float*)workspace);
+                       n_dev, w_density, w_color, pad_value, (const float4*)draw, denc_t, (float*)workspace);
     hipLaunchKernelGGL(k_reduce_partials, dim3(xr_div_up(GW, 256)), dim3(256), 0, stream, (const float*)workspace, grid,
                        (uint32_t)GW, (uint32_t)NetShape<1>::glb_floats, grad_w_density, grad_w_color);
     XR_LAUNCH_CHECK();

@@ -313,6 +313,25 @@ extern "C" int xr_compacted_coord(const float* coords_in, const int32_t* numstep
     return XR_OK;
 }
 
+__global__ __launch_bounds__(RM_BLOCK) void k2_clip(uint32_t n_rays, uint32_t max_compacted, const int32_t* __restrict__ in,
+                                                     const uint32_t* __restrict__ counter2, int32_t* __restrict__ out,
+                                                     uint32_t* __restrict__ n_valid) {
+    const uint32_t i = blockIdx.x * RM_BLOCK + threadIdx.x;
+    if (i == 0) *n_valid = min(counter2[1], max_compacted);
+    if (i >= n_rays) return;
+    const uint32_t n = (uint32_t)in[2 * i], base = (uint32_t)in[2 * i + 1];
+    out[2 * i] = (int32_t)min(max_compacted - min(max_compacted, base), n);
+    out[2 * i + 1] = (int32_t)base;
+}
+extern "C" int xr_clip_numsteps(const int32_t* numsteps_in, const uint32_t* counter2, uint32_t n_rays, uint32_t max_compacted,
+                                int32_t* numsteps_out, uint32_t* n_valid_dev, void* stream_) {
+    XR_REQUIRE(numsteps_in && counter2 && numsteps_out && n_valid_dev && n_rays > 0, "bad argument");
+    hipLaunchKernelGGL(k2_clip, dim3(xr_div_up(n_rays, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream_, n_rays, max_compacted,
+                       numsteps_in, counter2, numsteps_out, n_valid_dev);
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}
+
 // ------------------------------------------------------------------ K3 / K5 compositor forward
 // one ray per lane, front-to-back (calc_rgb.cu:20-66, :158-205).
 template <bool INFERENCE>

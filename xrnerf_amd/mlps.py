@@ -88,12 +88,13 @@ class _NerfMLPFn(torch.autograd.Function):
     """encode -> density_net -> (SH, color_net) -> raw [n,4]; backward recomputes activations."""
 
     @staticmethod
-    def forward(ctx, table, wd, wc, pts, dirs, mlp):
+    def forward(ctx, table, wd, wc, pts, dirs, mlp, n_dev):
         n = pts.shape[0]
-        enc_t = ops.hashgrid_fwd(table, pts, mlp.embedder_pos.meta)
-        raw = ops.nerf_mlp_fwd(enc_t, dirs, n, wd, wc, mlp.density_net.n_hidden, mlp.color_net.n_hidden, mlp.pad_value)
+        enc_t = ops.hashgrid_fwd(table, pts, mlp.embedder_pos.meta, n_dev=n_dev)
+        raw = ops.nerf_mlp_fwd(enc_t, dirs, n, wd, wc, mlp.density_net.n_hidden, mlp.color_net.n_hidden, mlp.pad_value,
+                               n_dev=n_dev)
         ctx.save_for_backward(table, wd, wc, pts, dirs, enc_t)
-        ctx.mlp = mlp
+        ctx.mlp, ctx.n_dev = mlp, n_dev
         return raw
 
     @staticmethod
@@ -104,10 +105,10 @@ class _NerfMLPFn(torch.autograd.Function):
         draw = draw.contiguous()
         g_wd, g_wc = torch.zeros_like(wd), torch.zeros_like(wc)
         denc_t = ops.nerf_mlp_bwd(enc_t, dirs, n, wd, wc, mlp.density_net.n_hidden, mlp.color_net.n_hidden, draw,
-                                  g_wd, g_wc, mlp.pad_value)
+                                  g_wd, g_wc, mlp.pad_value, n_dev=ctx.n_dev)
         g_table = torch.zeros_like(table)
-        ops.hashgrid_bwd(pts, denc_t, mlp.embedder_pos.meta, g_table)
-        return g_table, g_wd, g_wc, None, None, None
+        ops.hashgrid_bwd(pts, denc_t, mlp.embedder_pos.meta, g_table, n_dev=ctx.n_dev)
+        return g_table, g_wd, g_wc, None, None, None, None
 
 
 @MLPS.register_module()
@@ -154,8 +155,10 @@ class HashNerfMLP(nn.Module):
         dirs = self._rows(viewdirs)
         if pts.shape[0] == 0:
             return torch.zeros((0, 4), dtype=torch.float32, device=pts.device)
+        # `n_valid_dev` (optional, device int32[1]): rows past it are padding of a fixed-size sample buffer
+        # (the reference pads its compacted buffer to target_batch_size rows with zeros and evaluates them)
         return _NerfMLPFn.apply(self.embedder_pos.params, self.density_net.params, self.color_net.params, pts, dirs,
-                                self)
+                                self, data.get('n_valid_dev'))
 
     def run_density(self, pts_flat):
         """hashnerf_mlp.py:107-111: encode + density_net, channel 0 -> [N,1] fp32 (no grad)."""

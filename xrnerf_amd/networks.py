@@ -105,7 +105,12 @@ class HashNerfNetwork(BaseNerfNetwork):
         mse_loss = img2mse(ret['rgb'] * alpha, data['target_s'] * alpha)
         psnr = mse2psnr(mse_loss)
         loss = huber_loss * 5
-        log_vars = {'loss': loss.item(), 'psnr': psnr.item()}
+        if kwargs.get('lazy_log', False):
+            # same values, read back by the caller when it actually logs (the reference's TextLoggerHook
+            # prints every 500 iterations): no per-iteration host synchronisation
+            log_vars = {'loss': loss.detach(), 'psnr': psnr.detach()}
+        else:
+            log_vars = {'loss': loss.item(), 'psnr': psnr.item()}
         return {'loss': loss, 'log_vars': log_vars, 'num_samples': bs}
 
     def val_step(self, data, optimizer=None, **kwargs):

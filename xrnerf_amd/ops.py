@@ -135,7 +135,7 @@ def calc_rgb_forward(raw, coords, numsteps, numsteps_c, bg, rgb_act, density_act
     n = numsteps.shape[0]
     if out is None:
         out = torch.empty((n, 3), dtype=torch.float32, device=raw.device)
-    with _span('xr_calc_rgb_forward', raw.shape[0]):
+    with _span('xr_calc_rgb_forward', 0):
         _lib.check(L.xr_calc_rgb_forward(_ptr(raw), _ptr(coords), _ptr(numsteps), _ptr(numsteps_c), _ptr(bg), n,
                                          int(rgb_act), int(density_act), _ptr(out), _stream()), 'xr_calc_rgb_forward')
     return out
@@ -146,7 +146,7 @@ def calc_rgb_backward(raw, numsteps_c, coords, grad_rgb, rgb_out, density_grid_m
     n = numsteps_c.shape[0]
     if out is None:
         out = torch.zeros_like(raw)
-    with _span('xr_calc_rgb_backward', raw.shape[0]):
+    with _span('xr_calc_rgb_backward', 0):
         _lib.check(L.xr_calc_rgb_backward(_ptr(raw), _ptr(numsteps_c), _ptr(coords), _ptr(grad_rgb), _ptr(rgb_out),
                                           _ptr(density_grid_mean), n, int(rgb_act), int(density_act), _ptr(out),
                                           _stream()), 'xr_calc_rgb_backward')
@@ -248,8 +248,19 @@ def _pos_view(x):
     return x, int(x.stride(0))
 
 
-def hashgrid_fwd(table, x, meta, enc_t=None, ld=None):
-    """x: [n,3] (or a column slice of [n,7] rows) -> enc_t [2L, ld] feature-major."""
+def clip_numsteps(numsteps, counter, max_compacted):
+    """K2 without the copy (K1's output kept in place): clipped per-ray counts + device-side row count."""
+    n = numsteps.shape[0]
+    out = torch.empty_like(numsteps)
+    n_valid = torch.empty((1,), dtype=torch.int32, device=numsteps.device)
+    _lib.check(_lib.load().xr_clip_numsteps(_ptr(numsteps), _ptr(counter), n, max_compacted, _ptr(out), _ptr(n_valid),
+                                            _stream()), 'xr_clip_numsteps')
+    return out, n_valid
+
+
+def hashgrid_fwd(table, x, meta, enc_t=None, ld=None, n_dev=None):
+    """x: [n,3] (or a column slice of [n,7] rows) -> enc_t [2L, ld] feature-major.
+    n_dev: optional device int32[1]; only min(n, n_dev) rows are touched (no host read-back needed)."""
     L = _lib.load()
     x, xs = _pos_view(x)
     n = x.shape[0]
@@ -258,19 +269,19 @@ def hashgrid_fwd(table, x, meta, enc_t=None, ld=None):
     if enc_t is None:
         enc_t = torch.empty((meta.n_output_dims, ld), dtype=torch.float32, device=x.device)
     s, r, o = meta._args()
-    with _span('xr_hashgrid_fwd', n):
-        _lib.check(L.xr_hashgrid_fwd(_ptr(table), C.c_void_p(x.data_ptr()), xs, n, meta.n_levels, s, r, o, _ptr(enc_t), ld,
+    with _span('xr_hashgrid_fwd', 0 if n_dev is not None else n):
+        _lib.check(L.xr_hashgrid_fwd(_ptr(table), C.c_void_p(x.data_ptr()), xs, n, _ptr(n_dev), meta.n_levels, s, r, o, _ptr(enc_t), ld,
                                      _stream()), 'xr_hashgrid_fwd')
     return enc_t
 
 
-def hashgrid_bwd(x, denc_t, meta, grad_table):
+def hashgrid_bwd(x, denc_t, meta, grad_table, n_dev=None):
     L = _lib.load()
     x, xs = _pos_view(x)
     n = x.shape[0]
     s, r, o = meta._args()
-    with _span('xr_hashgrid_bwd', n):
-        _lib.check(L.xr_hashgrid_bwd(C.c_void_p(x.data_ptr()), xs, _ptr(denc_t), denc_t.shape[1], n, meta.n_levels, s, r, o,
+    with _span('xr_hashgrid_bwd', 0 if n_dev is not None else n):
+        _lib.check(L.xr_hashgrid_bwd(C.c_void_p(x.data_ptr()), xs, _ptr(denc_t), denc_t.shape[1], n, _ptr(n_dev), meta.n_levels, s, r, o,
                                      _ptr(grad_table), _stream()), 'xr_hashgrid_bwd')
     return grad_table
 
@@ -283,7 +294,7 @@ def sh4(dirs):
     return out
 
 
-def nerf_mlp_fwd(enc_t, dirs, n, w_density, w_color, nhd, nhc, pad_value=1.0, raw=None):
+def nerf_mlp_fwd(enc_t, dirs, n, w_density, w_color, nhd, nhc, pad_value=1.0, raw=None, n_dev=None):
     L = _lib.load()
     if raw is None:
         raw = torch.empty((n, 4), dtype=torch.float32, device=enc_t.device)
@@ -292,21 +303,22 @@ def nerf_mlp_fwd(enc_t, dirs, n, w_density, w_color, nhd, nhc, pad_value=1.0, ra
         dp = C.c_void_p(dirs.data_ptr())
     else:
         ds, dp = 0, None
-    with _span('xr_nerf_mlp_fwd', n):
-        _lib.check(L.xr_nerf_mlp_fwd(_ptr(enc_t), enc_t.shape[1], dp, ds, n, _ptr(w_density),
+    with _span('xr_nerf_mlp_fwd', 0 if n_dev is not None else n):
+        _lib.check(L.xr_nerf_mlp_fwd(_ptr(enc_t), enc_t.shape[1], dp, ds, n, _ptr(n_dev), _ptr(w_density),
                                      _ptr(w_color) if w_color is not None else None, nhd, nhc, pad_value, _ptr(raw),
                                      _stream()), 'xr_nerf_mlp_fwd')
     return raw
 
 
-def nerf_mlp_bwd(enc_t, dirs, n, w_density, w_color, nhd, nhc, draw, grad_wd, grad_wc, pad_value=1.0, denc_t=None):
+def nerf_mlp_bwd(enc_t, dirs, n, w_density, w_color, nhd, nhc, draw, grad_wd, grad_wc, pad_value=1.0, denc_t=None,
+                 n_dev=None):
     L = _lib.load()
     dirs, ds = _pos_view(dirs)
     if denc_t is None:
         denc_t = torch.empty_like(enc_t)
     ws = _ws(enc_t.device, L.xr_nerf_mlp_bwd_workspace_bytes(n), 'mlpbwd')
-    with _span('xr_nerf_mlp_bwd', n):
-        _lib.check(L.xr_nerf_mlp_bwd(_ptr(enc_t), enc_t.shape[1], C.c_void_p(dirs.data_ptr()), ds, n, _ptr(w_density),
+    with _span('xr_nerf_mlp_bwd', 0 if n_dev is not None else n):
+        _lib.check(L.xr_nerf_mlp_bwd(_ptr(enc_t), enc_t.shape[1], C.c_void_p(dirs.data_ptr()), ds, n, _ptr(n_dev), _ptr(w_density),
                                      _ptr(w_color), nhd, nhc, pad_value, _ptr(draw), _ptr(denc_t), _ptr(grad_wd),
                                      _ptr(grad_wc), _ptr(ws), ws.numel(), _stream()), 'xr_nerf_mlp_bwd')
     return denc_t

@@ -147,36 +147,30 @@ class NGPGridSampler(nn.Module):
             rays_o, rays_d, self.density_grid_bitfield, aabb, self.near_distance, self.cone_angle_constant,
             max_samples, self.k1_calls, coords_out=self._coords_buffer(max_samples))
         self.k1_calls += 1
-        n_valid, samples = counter.tolist()      # the one host read-back (rays_sampler.py:72)
-        if samples > max_samples:                # some rays overflowed and were dropped (ray_sampler.cu:76-82)
-            samples_kept = int(rays_numsteps[:, 0].sum().item())
-        else:
-            samples_kept = samples
-        coords = coords[:min(samples, max_samples)]
         self.rays_index = rays_index
-
         if not is_training:
+            n_valid, samples = counter.tolist()      # one host read-back per call (rays_sampler.py:72)
+            coords = coords[:min(samples, max_samples)]
             self.coords = coords
             self.rays_numsteps = rays_numsteps
             data['pts'], data['viewdirs'] = coords[..., :3], coords[..., 4:]
             return data
 
-        if samples <= max_samples and samples <= self.target_batch_size:
-            # K1's ray-ordered bases are exactly what K2 would assign: alias instead of copying
-            coords_compacted, rays_numsteps_compacted, compacted_total = coords, rays_numsteps, samples
-        else:
-            coords_compacted, rays_numsteps_compacted, _, sc = ops.compacted_coord(
-                coords, rays_numsteps, self.target_batch_size)
-            compacted_total = int(sc.item())
-            coords_compacted = coords_compacted[:min(compacted_total, self.target_batch_size)]
-        self.measured_batch_size += compacted_total        # pre-clip counter (ngp_grid_sampler.py:252)
-        self._measured_host = getattr(self, '_measured_host', 0) + compacted_total
-        self.update_batch_rays(is_training)
-
+        # K2.  K1's bases are the ray-ordered prefix sums, i.e. exactly what K2 would assign, so the
+        # compacted coordinates are the first min(S, target) rows of K1's buffer IN PLACE and only the
+        # clipped per-ray counts have to be produced.  Like the reference, the sample buffer handed to the
+        # MLP has a fixed target_batch_size rows (compacted_coords.py:20-21 pads with zeros); the number of
+        # valid rows stays on the device (`n_valid_dev`) so that no host read-back is needed here.
+        rays_numsteps_compacted, n_valid_dev = ops.clip_numsteps(rays_numsteps, counter, self.target_batch_size)
+        self.measured_batch_size += counter[1:2]           # pre-clip counter (ngp_grid_sampler.py:252)
+        self.update_batch_rays(is_training, max_samples)
+        coords_compacted = coords[:self.target_batch_size]
         self.coords = coords_compacted
         self.rays_numsteps = rays_numsteps
         self.rays_numsteps_compacted = rays_numsteps_compacted
+        self.n_valid_dev = n_valid_dev
         data['pts'], data['viewdirs'] = coords_compacted[..., :3], coords_compacted[..., 4:]
+        data['n_valid_dev'] = n_valid_dev
         return data
 
     def _coords_buffer(self, rows):
@@ -186,13 +180,15 @@ class NGPGridSampler(nn.Module):
             self._coords_buf = buf
         return buf[:rows]
 
-    def update_batch_rays(self, is_training):
+    def update_batch_rays(self, is_training, max_samples=None):
         if is_training and self.iter_n % self.update_grid_freq == (self.update_grid_freq - 1):
-            measured = max(self._measured_host / 16, 1)      # == measured_batch_size.item() / 16, without the sync
-            rays_per_batch = int(self.n_rays_per_batch * self.target_batch_size / measured)
+            total = self.measured_batch_size.item()              # the one read-back per 16 iterations (:271)
+            if max_samples is not None and total > 16 * max_samples:
+                raise RuntimeError('ray marcher overflowed its %d-row sample buffer' % max_samples)
+            measured_batch_size = max(total / 16, 1)
+            rays_per_batch = int(self.n_rays_per_batch * self.target_batch_size / measured_batch_size)
             self.n_rays_per_batch = int(min(self.div_round_up(int(rays_per_batch), 128) * 128, self.target_batch_size))
             self.measured_batch_size.zero_()
-            self._measured_host = 0
 
     def div_round_up(self, val, divisor):
         return (val + divisor - 1) // divisor

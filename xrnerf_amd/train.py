@@ -175,7 +175,8 @@ class Trainer:
         self.iter = 0
         self.world_size, self.rank = world_size, rank
         self.rays_done = 0
-        self.samples_done = 0
+        self._samples_dev = torch.zeros((1,), dtype=torch.int64, device=device)
+        self.lazy_log = True
 
     def step(self):
         net, data = self.net, self.data
@@ -186,7 +187,7 @@ class Trainer:
         n_rays = batch['rays_o'].shape[0]
         # the reference's DataLoader(batch_size=1) collates a leading batch axis that train_step unfolds
         batch = {k: v[None] for k, v in batch.items()}
-        out = net.train_step(batch, self.opt)
+        out = net.train_step(batch, self.opt, lazy_log=self.lazy_log)
         self.opt.zero_grad(set_to_none=True)
         out['loss'].backward()
         if self.world_size > 1:
@@ -196,8 +197,12 @@ class Trainer:
         data.set_batchsize(net.sampler.n_rays_per_batch)                  # ModifyBatchsizeHook
         self.iter += 1
         self.rays_done += n_rays
-        self.samples_done += int(net.sampler.coords.shape[0])
+        self._samples_dev += net.sampler.n_valid_dev          # stays on the device
         return out
+
+    @property
+    def samples_done(self):
+        return int(self._samples_dev.item())
 
 
 @torch.no_grad()
