@@ -379,15 +379,23 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void k_nerf_mlp_bwd_1_2(
     for (int e = threadIdx.x; e < GW; e += MLP_THREADS) out[e] = red[e];
 }
 
-// grad[j] += sum_b partial[b][j], fixed order over b
+// grad[j] += sum_b partial[b][j], fixed order: 64 columns x 4 row groups per block, each thread sums
+// every 4th partial, then the 4 group sums are added in a fixed order through LDS
 __global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict__ partial, uint32_t nb, uint32_t gw,
                                                           uint32_t split, float* __restrict__ g_density,
                                                           float* __restrict__ g_color) {
-    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= gw) return;
+    __shared__ float red[4][64];
+    const uint32_t c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const uint32_t j = blockIdx.x * 64 + c;
     float s = 0.f;
-    for (uint32_t b = 0; b < nb; ++b) s += partial[(size_t)b * gw + j];
-    if (j < split) g_density[j] += s; else g_color[j - split] += s;
+    if (j < gw)
+        for (uint32_t b = rg; b < nb; b += 4) s += partial[(size_t)b * gw + j];
+    red[rg][c] = s;
+    __syncthreads();
+    if (rg == 0 && j < gw) {
+        const float t = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+        if (j < split) g_density[j] += t; else g_color[j - split] += t;
+    }
 }
 
 // ------------------------------------------------------------------ host side
@@ -471,7 +479,7 @@ extern "C" int xr_nerf_mlp_bwd(const float* enc_t, uint32_t ld, const float* dir
     const uint32_t grid = bwd_grid(n);
     hipLaunchKernelGGL(k_nerf_mlp_bwd_1_2, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n,
                        n_dev, w_density, w_color, pad_value, (const float4*)draw, denc_t, (float*)workspace);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(xr_div_up(GW, 256)), dim3(256), 0, stream, (const float*)workspace, grid,
+    hipLaunchKernelGGL(k_reduce_partials, dim3(xr_div_up(GW, 64)), dim3(256), 0, stream, (const float*)workspace, grid,
                        (uint32_t)GW, (uint32_t)NetShape<1>::glb_floats, grad_w_density, grad_w_color);
     XR_LAUNCH_CHECK();
     return XR_OK;

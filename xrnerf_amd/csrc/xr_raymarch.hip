@@ -333,26 +333,46 @@ extern "C" int xr_clip_numsteps(const int32_t* numsteps_in, const uint32_t* coun
 }
 
 // ------------------------------------------------------------------ K3 / K5 compositor forward
-// one ray per lane, front-to-back (calc_rgb.cu:20-66, :158-205).
+// Reference: one thread per ray, front to back (calc_rgb.cu:20-66, :158-205).  A training batch has
+// only ~1e4 rays -- far too few threads for a 256-CU chip -- so here CG = 8 consecutive lanes share a
+// ray: each takes a contiguous chunk of its samples, composites it locally (T_loc, c_loc), and the
+// chunks are stitched with the associativity of the transmittance product:
+//   T_before(chunk m) = prod_{j<m} T_loc(j),   C = sum_m T_before(m) * c_loc(m).
+// Same arithmetic per sample, 8x the parallelism, 1/8 of the serial length.
+#define CG 8
+__device__ inline void cg_chunk(uint32_t n, uint32_t sub, uint32_t* k0, uint32_t* k1) {
+    const uint32_t chunk = (n + CG - 1) / CG;
+    *k0 = min(n, sub * chunk); *k1 = min(n, (sub + 1) * chunk);
+}
+// exclusive prefix over the CG lanes of a ray: T_before and the colour accumulated before this chunk
+__device__ inline void cg_stitch(uint32_t sub, float T_loc, float cr, float cg, float cb, float* Tb, float* Cbr, float* Cbg,
+                                 float* Cbb, float* Ttot, float* Cr, float* Cg, float* Cb) {
+    float tb = 1.f, ar = 0.f, ag = 0.f, ab = 0.f, tt = 1.f, tr = 0.f, tg = 0.f, tbb = 0.f;
+#pragma unroll
+    for (int m = 0; m < CG; ++m) {
+        const float tm = __shfl(T_loc, m, CG), rm = __shfl(cr, m, CG), gm = __shfl(cg, m, CG), bm = __shfl(cb, m, CG);
+        if ((uint32_t)m == sub) { tb = tt; ar = tr; ag = tg; ab = tbb; }
+        tr += tt * rm; tg += tt * gm; tbb += tt * bm;
+        tt *= tm;
+    }
+    *Tb = tb; *Cbr = ar; *Cbg = ag; *Cbb = ab; *Ttot = tt; *Cr = tr; *Cg = tg; *Cb = tbb;
+}
+
 template <bool INFERENCE>
 __global__ __launch_bounds__(RM_BLOCK) void k_composite_fwd(
     uint32_t n_rays, const float4* __restrict__ raw, const float* __restrict__ coords,
     const int32_t* __restrict__ numsteps, const int32_t* __restrict__ numsteps_c, const float* __restrict__ bg,
     float bg_r, float bg_g, float bg_b, int rgb_act, int density_act, float* __restrict__ rgb_out,
     float* __restrict__ alpha_out) {
-    const uint32_t i = blockIdx.x * RM_BLOCK + threadIdx.x;
-    if (i >= n_rays) return;
-    float br, bgc, bb;
-    if (INFERENCE) { br = bg_r; bgc = bg_g; bb = bg_b; }
-    else { br = bg[3 * i]; bgc = bg[3 * i + 1]; bb = bg[3 * i + 2]; }
-    const uint32_t n = (uint32_t)numsteps_c[2 * i], base = (uint32_t)numsteps_c[2 * i + 1];
-    if (n == 0) {
-        rgb_out[3 * i] = br; rgb_out[3 * i + 1] = bgc; rgb_out[3 * i + 2] = bb;
-        if (INFERENCE) alpha_out[i] = 0.f;
-        return;
-    }
+    const uint32_t t = blockIdx.x * RM_BLOCK + threadIdx.x;
+    const uint32_t i = t / CG, sub = t % CG;
+    const bool in = i < n_rays;
+    uint32_t n = 0, base = 0;
+    if (in) { n = (uint32_t)numsteps_c[2 * i]; base = (uint32_t)numsteps_c[2 * i + 1]; }
+    uint32_t k0, k1;
+    cg_chunk(n, sub, &k0, &k1);
     float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f;
-    for (uint32_t k = 0; k < n; ++k) {
+    for (uint32_t k = k0; k < k1; ++k) {
         const float4 o = raw[base + k];
         const float dt = xr_unwarp_dt(coords[7 * (size_t)(base + k) + 3]);
         const float density = xr_act_density(o.w, density_act);
@@ -361,10 +381,21 @@ __global__ __launch_bounds__(RM_BLOCK) void k_composite_fwd(
         cr += w * xr_act_rgb(o.x, rgb_act); cg += w * xr_act_rgb(o.y, rgb_act); cb += w * xr_act_rgb(o.z, rgb_act);
         T *= (1.f - alpha);
     }
+    float Tb, ar, ag, ab, Tt, Cr, Cg, Cb;
+    cg_stitch(sub, T, cr, cg, cb, &Tb, &ar, &ag, &ab, &Tt, &Cr, &Cg, &Cb);
+    if (!in || sub != 0) return;
+    float br, bgc, bb;
+    if (INFERENCE) { br = bg_r; bgc = bg_g; bb = bg_b; }
+    else { br = bg[3 * i]; bgc = bg[3 * i + 1]; bb = bg[3 * i + 2]; }
+    if (n == 0) {                                                          // :28-32 / :167-172
+        rgb_out[3 * i] = br; rgb_out[3 * i + 1] = bgc; rgb_out[3 * i + 2] = bb;
+        if (INFERENCE) alpha_out[i] = 0.f;
+        return;
+    }
     const bool add_bg = INFERENCE ? true : (n == (uint32_t)numsteps[2 * i]);   // :61-64 / :200-203
-    if (add_bg) { cr += T * br; cg += T * bgc; cb += T * bb; }
-    rgb_out[3 * i] = cr; rgb_out[3 * i + 1] = cg; rgb_out[3 * i + 2] = cb;
-    if (INFERENCE) alpha_out[i] = 1.f - T;
+    if (add_bg) { Cr += Tt * br; Cg += Tt * bgc; Cb += Tt * bb; }
+    rgb_out[3 * i] = Cr; rgb_out[3 * i + 1] = Cg; rgb_out[3 * i + 2] = Cb;
+    if (INFERENCE) alpha_out[i] = 1.f - Tt;
 }
 
 extern "C" int xr_calc_rgb_forward(const float* network_output, const float* coords, const int32_t* rays_numsteps,
@@ -373,7 +404,7 @@ extern "C" int xr_calc_rgb_forward(const float* network_output, const float* coo
     XR_REQUIRE(network_output && coords && rays_numsteps && rays_numsteps_compacted && bg_color && rgb_output, "null pointer");
     XR_REQUIRE(((uintptr_t)network_output & 15) == 0, "network_output must be 16-byte aligned");
     XR_REQUIRE(n_rays > 0, "n_rays == 0");
-    hipLaunchKernelGGL(k_composite_fwd<false>, dim3(xr_div_up(n_rays, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream_,
+    hipLaunchKernelGGL(k_composite_fwd<false>, dim3(xr_div_up((uint64_t)n_rays * CG, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream_,
                        n_rays, (const float4*)network_output, coords, rays_numsteps, rays_numsteps_compacted, bg_color,
                        0.f, 0.f, 0.f, rgb_activation, density_activation, rgb_output, (float*)nullptr);
     XR_LAUNCH_CHECK();
@@ -386,7 +417,7 @@ extern "C" int xr_calc_rgb_inference(const float* network_output, const float* c
     XR_REQUIRE(network_output && coords && rays_numsteps && rgb_output && alpha_output, "null pointer");
     XR_REQUIRE(((uintptr_t)network_output & 15) == 0, "network_output must be 16-byte aligned");
     XR_REQUIRE(n_rays > 0, "n_rays == 0");
-    hipLaunchKernelGGL(k_composite_fwd<true>, dim3(xr_div_up(n_rays, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream_,
+    hipLaunchKernelGGL(k_composite_fwd<true>, dim3(xr_div_up((uint64_t)n_rays * CG, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream_,
                        n_rays, (const float4*)network_output, coords, rays_numsteps, rays_numsteps, (const float*)nullptr,
                        bg_r, bg_g, bg_b, rgb_activation, density_activation, rgb_output, alpha_output);
     XR_LAUNCH_CHECK();
@@ -394,20 +425,39 @@ extern "C" int xr_calc_rgb_inference(const float* network_output, const float* c
 }
 
 // ------------------------------------------------------------------ K4 compositor backward (calc_rgb.cu:87-139)
+// Same 8-lanes-per-ray split: pass 1 composites each chunk locally to obtain, after stitching, the
+// transmittance and colour accumulated BEFORE the chunk; pass 2 re-walks the chunk with those as
+// start values and emits the gradients (global T_k = T_before * T_loc,k ; prefix C_k = C_before + T_before * c_loc,k).
 __global__ __launch_bounds__(RM_BLOCK) void k_composite_bwd(
     uint32_t n_rays, const float4* __restrict__ raw, const int32_t* __restrict__ numsteps_c,
     const float* __restrict__ coords, const float* __restrict__ grad_rgb, const float* __restrict__ rgb_final,
     const float* __restrict__ density_grid_mean, int rgb_act, int density_act, float4* __restrict__ dout) {
-    const uint32_t i = blockIdx.x * RM_BLOCK + threadIdx.x;
-    if (i >= n_rays) return;
+    const uint32_t t = blockIdx.x * RM_BLOCK + threadIdx.x;
+    const uint32_t i = t / CG, sub = t % CG;
+    const bool in = i < n_rays;
     float loss_scale = 128.f; loss_scale /= (float)n_rays;                        // :92-93
     const float l2 = rgb_act == XR_ACT_EXPONENTIAL ? 1e-4f : 0.0f;                // :103
     const float l1 = density_grid_mean[0] < 0.01f ? 1e-4f : 0.0f;                 // :104
-    const uint32_t n = (uint32_t)numsteps_c[2 * i], base = (uint32_t)numsteps_c[2 * i + 1];
+    uint32_t n = 0, base = 0;
+    if (in) { n = (uint32_t)numsteps_c[2 * i]; base = (uint32_t)numsteps_c[2 * i + 1]; }
+    uint32_t k0, k1;
+    cg_chunk(n, sub, &k0, &k1);
+    float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f;
+    for (uint32_t k = k0; k < k1; ++k) {
+        const float4 o = raw[base + k];
+        const float dt = xr_unwarp_dt(coords[7 * (size_t)(base + k) + 3]);
+        const float alpha = 1.f - __expf(-xr_act_density(o.w, density_act) * dt);
+        const float w = alpha * T;
+        cr += w * xr_act_rgb(o.x, rgb_act); cg += w * xr_act_rgb(o.y, rgb_act); cb += w * xr_act_rgb(o.z, rgb_act);
+        T *= (1.f - alpha);
+    }
+    float Tb, ar, ag, ab, Tt, Cr, Cg, Cb;
+    cg_stitch(sub, T, cr, cg, cb, &Tb, &ar, &ag, &ab, &Tt, &Cr, &Cg, &Cb);
+    if (!in || k0 >= k1) return;
     const float gr = grad_rgb[3 * i], gg = grad_rgb[3 * i + 1], gb = grad_rgb[3 * i + 2];
     const float fr = rgb_final[3 * i], fg = rgb_final[3 * i + 1], fb = rgb_final[3 * i + 2];
-    float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f;
-    for (uint32_t k = 0; k < n; ++k) {
+    T = Tb; cr = ar; cg = ag; cb = ab;
+    for (uint32_t k = k0; k < k1; ++k) {
         const float4 o = raw[base + k];
         const float r = xr_act_rgb(o.x, rgb_act), g = xr_act_rgb(o.y, rgb_act), b = xr_act_rgb(o.z, rgb_act);
         const float dt = xr_unwarp_dt(coords[7 * (size_t)(base + k) + 3]);
@@ -435,7 +485,7 @@ extern "C" int xr_calc_rgb_backward(const float* network_output, const int32_t* 
                dloss_doutput, "null pointer");
     XR_REQUIRE((((uintptr_t)network_output | (uintptr_t)dloss_doutput) & 15) == 0, "raw/grad buffers must be 16-byte aligned");
     XR_REQUIRE(n_rays > 0, "n_rays == 0");
-    hipLaunchKernelGGL(k_composite_bwd, dim3(xr_div_up(n_rays, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream_,
+    hipLaunchKernelGGL(k_composite_bwd, dim3(xr_div_up((uint64_t)n_rays * CG, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream_,
                        n_rays, (const float4*)network_output, rays_numsteps_compacted, coords, grad_rgb, rgb_output,
                        density_grid_mean, rgb_activation, density_activation, (float4*)dloss_doutput);
     XR_LAUNCH_CHECK();

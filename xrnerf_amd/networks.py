@@ -27,7 +27,25 @@ def mse2psnr(x):
     return -10. * torch.log(x) / torch.log(torch.Tensor([10.]).to(x.device))
 
 
+class _HuberSumFn(torch.autograd.Function):
+    """sum-reduced HuberLoss and its gradient in one launch (xr_huber_loss_grad) instead of ~10 elementwise ops"""
+
+    @staticmethod
+    def forward(ctx, x, y, delta):
+        from . import ops
+        loss, grad = ops.huber_loss_grad(x.contiguous(), y.contiguous(), delta, 1.0)
+        ctx.save_for_backward(grad)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None
+
+
 def HuberLoss(x, y, delta=0.1, reduction='sum'):
+    if reduction == 'sum' and x.is_cuda and x.dtype == torch.float32 and y.dtype == torch.float32 and x.shape == y.shape:
+        return _HuberSumFn.apply(x, y, delta)
     rel = (x - y).abs()
     sqr = 0.5 / delta * rel * rel
     loss = torch.where(rel > delta, rel - 0.5 * delta, sqr)
@@ -102,8 +120,9 @@ class HashNerfNetwork(BaseNerfNetwork):
         bs = ret['rgb'].shape[0]
         alpha = data['alpha'].detach()
         huber_loss = HuberLoss(ret['rgb'], data['target_s'], 0.1, 'sum')
-        mse_loss = img2mse(ret['rgb'] * alpha, data['target_s'] * alpha)
-        psnr = mse2psnr(mse_loss)
+        with torch.no_grad():      # the reference builds (and never uses) an autograd graph for the logged PSNR
+            mse_loss = img2mse(ret['rgb'] * alpha, data['target_s'] * alpha)
+            psnr = mse2psnr(mse_loss)
         loss = huber_loss * 5
         if kwargs.get('lazy_log', False):
             # same values, read back by the caller when it actually logs (the reference's TextLoggerHook
