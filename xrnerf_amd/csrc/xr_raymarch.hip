@@ -9,6 +9,7 @@
 #include <cfloat>
 
 #define RM_BLOCK 256
+#define K1_TL 64          // per-ray t-list capacity; longer rays fall back to a re-march for the tail
 
 // ------------------------------------------------------------------ block-wide exclusive scan
 // 256 threads = 4 wave64.  Returns the exclusive prefix of v; *total gets the block sum.
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(RM_BLOCK) void k1_count(
     uint32_t n_rays, float lo, float hi, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
     const uint8_t* __restrict__ bitfield, float cone, float near_distance, xr_pcg32 rng,
     uint32_t* __restrict__ cnt, uint32_t* __restrict__ local_off, float* __restrict__ start_t,
-    uint32_t* __restrict__ block_tot) {
+    uint32_t* __restrict__ block_tot, float* __restrict__ tlist) {
     __shared__ uint32_t lds4[4];
     const uint32_t i = blockIdx.x * RM_BLOCK + threadIdx.x;
     uint32_t j = 0; float startt = 0.f;
@@ -120,8 +121,12 @@ __global__ __launch_bounds__(RM_BLOCK) void k1_count(
             if (!(rm_contains(lo, hi, px, py, pz) && j < XR_NERF_STEPS)) break;
             float dt = rm_calc_dt(t, cone);
             int mip = rm_mip_from_dt(dt, px, py, pz);
-            if (rm_occupied(px, py, pz, bitfield, mip)) { ++j; t += dt; }
-            else t = rm_advance(t, cone, px, py, pz, r, XR_NERF_GRIDSIZE >> mip);
+            if (rm_occupied(px, py, pz, bitfield, mip)) {
+                // a sample is fully determined by its t: remember the first K1_TL of them so that the
+                // write pass can expand them sample-parallel instead of re-marching
+                if (j < K1_TL) tlist[(size_t)i * K1_TL + j] = t;
+                ++j; t += dt;
+            } else t = rm_advance(t, cone, px, py, pz, r, XR_NERF_GRIDSIZE >> mip);
         }
     }
     uint32_t tot;
@@ -168,7 +173,8 @@ __global__ __launch_bounds__(RM_BLOCK) void k1_write(
     const uint8_t* __restrict__ bitfield, float cone, uint32_t max_samples, const uint32_t* __restrict__ cnt,
     const uint32_t* __restrict__ local_off, const float* __restrict__ start_t,
     const uint32_t* __restrict__ block_base, const uint32_t* __restrict__ info, float* __restrict__ coords_out,
-    int32_t* __restrict__ rays_index, int32_t* __restrict__ numsteps_out, uint32_t* __restrict__ counter2) {
+    int32_t* __restrict__ rays_index, int32_t* __restrict__ numsteps_out, uint32_t* __restrict__ counter2,
+    const float* __restrict__ tlist) {
     __shared__ uint32_t lds4[4];
     const uint32_t b = blockIdx.x, i = b * RM_BLOCK + threadIdx.x;
     const uint32_t cross = info[1], nb = gridDim.x;
@@ -196,14 +202,50 @@ __global__ __launch_bounds__(RM_BLOCK) void k1_write(
         if (b == 0) counter2[1] = info[0];
         if (b == cross || (cross == nb && b == nb - 1)) counter2[0] = valid_before + vtot;
     }
-    if (!valid || n == 0) return;
-    Ray r = rm_load_ray(rays_o, rays_d, i);
-    const float wdx = (r.dx + 1.0f) * 0.5f, wdy = (r.dy + 1.0f) * 0.5f, wdz = (r.dz + 1.0f) * 0.5f; // warp_direction
+    // ---- sample-parallel expansion.  The block's rays own the contiguous row range
+    // [bbase, bbase + block total): all 256 lanes walk it with a stride of 256, find the ray of each
+    // row by binary search over the block's offsets (LDS) and expand (t -> 7 floats).  Consecutive
+    // lanes write consecutive 28-B rows: the stores of a wave cover one contiguous 1.75 KB span.
+    __shared__ uint32_t s_off[RM_BLOCK], s_n[RM_BLOCK];
+    __shared__ float s_ray[RM_BLOCK][6];
+    s_off[threadIdx.x] = in ? local_off[i] : 0xffffffffu;
+    s_n[threadIdx.x] = valid ? n : 0u;
+    if (in) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { s_ray[threadIdx.x][k] = rays_o[3 * i + k]; s_ray[threadIdx.x][3 + k] = rays_d[3 * i + k]; }
+    }
+    __syncthreads();
+    const uint32_t last = min((uint32_t)RM_BLOCK, n_rays - b * RM_BLOCK) - 1;
+    const uint32_t btot = s_off[last] + cnt[b * RM_BLOCK + last];
     const float diag = hi - lo;
-    float t = start_t[i];
-    uint32_t j = 0;
+    for (uint32_t e = threadIdx.x; e < btot; e += RM_BLOCK) {
+        uint32_t lo_r = 0, hi_r = last;                       // last ray with s_off[r] <= e
+        while (lo_r < hi_r) {
+            const uint32_t mid = (lo_r + hi_r + 1) >> 1;
+            if (s_off[mid] <= e) lo_r = mid; else hi_r = mid - 1;
+        }
+        const uint32_t j = e - s_off[lo_r];
+        if (j >= s_n[lo_r] || j >= K1_TL) continue;           // dropped ray, or the tail of a very long ray
+        const float t = tlist[((size_t)b * RM_BLOCK + lo_r) * K1_TL + j];
+        const float ox = s_ray[lo_r][0], oy = s_ray[lo_r][1], oz = s_ray[lo_r][2];
+        const float dx = s_ray[lo_r][3], dy = s_ray[lo_r][4], dz = s_ray[lo_r][5];
+        const float px = ox + t * dx, py = oy + t * dy, pz = oz + t * dz;         // same expression as the march
+        const float dt = rm_calc_dt(t, cone);
+        float* c = coords_out + 7 * ((size_t)bbase + e);
+        c[0] = (px - lo) / diag; c[1] = (py - lo) / diag; c[2] = (pz - lo) / diag;
+        c[3] = (dt - xr_min_step()) / (xr_max_warp_step() - xr_min_step());       // warp_dt
+        c[4] = (dx + 1.0f) * 0.5f; c[5] = (dy + 1.0f) * 0.5f; c[6] = (dz + 1.0f) * 0.5f;   // warp_direction
+    }
+    if (!valid || n <= K1_TL) return;
+    // tail of a ray with more than K1_TL samples: resume the march right after sample K1_TL-1
+    // (t advances by calc_dt(t) after an emitted sample, ray_sampler.cu:107-108) and write rows >= K1_TL
+    Ray r = rm_load_ray(rays_o, rays_d, i);
+    const float wdx = (r.dx + 1.0f) * 0.5f, wdy = (r.dy + 1.0f) * 0.5f, wdz = (r.dz + 1.0f) * 0.5f;
+    float t = tlist[(size_t)i * K1_TL + (K1_TL - 1)];
+    t += rm_calc_dt(t, cone);
+    uint32_t j = K1_TL;
     float* __restrict__ out = coords_out + 7 * (size_t)base;
-    for (;;) {                                                               // :99-115
+    for (;;) {
         float px = r.ox + t * r.dx, py = r.oy + t * r.dy, pz = r.oz + t * r.dz;
         if (!(rm_contains(lo, hi, px, py, pz) && j < n)) break;
         float dt = rm_calc_dt(t, cone);
@@ -211,21 +253,22 @@ __global__ __launch_bounds__(RM_BLOCK) void k1_write(
         if (rm_occupied(px, py, pz, bitfield, mip)) {
             float* c = out + 7 * (size_t)j;
             c[0] = (px - lo) / diag; c[1] = (py - lo) / diag; c[2] = (pz - lo) / diag;
-            c[3] = (dt - xr_min_step()) / (xr_max_warp_step() - xr_min_step());   // warp_dt
+            c[3] = (dt - xr_min_step()) / (xr_max_warp_step() - xr_min_step());
             c[4] = wdx; c[5] = wdy; c[6] = wdz;
             ++j; t += dt;
         } else t = rm_advance(t, cone, px, py, pz, r, XR_NERF_GRIDSIZE >> mip);
     }
 }
 
-struct RmWorkspace { uint32_t *cnt, *local_off, *block_tot, *block_base, *info; float* start_t; };
+struct RmWorkspace { uint32_t *cnt, *local_off, *block_tot, *block_base, *info; float *start_t, *tlist; };
 static size_t rm_ws_layout(uint32_t n_rays, char* base, RmWorkspace* w) {
     const size_t nb = xr_div_up(n_rays, RM_BLOCK);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return base ? base + o : (char*)nullptr; };
     char* p0 = take(4ull * n_rays); char* p1 = take(4ull * n_rays); char* p2 = take(4ull * n_rays);
     char* p3 = take(4 * nb); char* p4 = take(4 * nb); char* p5 = take(16);
-    if (w) { w->cnt = (uint32_t*)p0; w->local_off = (uint32_t*)p1; w->start_t = (float*)p2;
+    char* p6 = take(4ull * n_rays * K1_TL);
+    if (w) { w->tlist = (float*)p6; w->cnt = (uint32_t*)p0; w->local_off = (uint32_t*)p1; w->start_t = (float*)p2;
              w->block_tot = (uint32_t*)p3; w->block_base = (uint32_t*)p4; w->info = (uint32_t*)p5; }
     return off;
 }
@@ -245,11 +288,11 @@ extern "C" int xr_rays_sampler(const float* rays_o, const float* rays_d, const u
     xr_pcg32 rng{rng_state, rng_inc};
     const uint32_t nb = xr_div_up(n_rays, RM_BLOCK);
     hipLaunchKernelGGL(k1_count, dim3(nb), dim3(RM_BLOCK), 0, stream, n_rays, aabb0, aabb1, rays_o, rays_d, bitfield,
-                       cone_angle, near_distance, rng, w.cnt, w.local_off, w.start_t, w.block_tot);
+                       cone_angle, near_distance, rng, w.cnt, w.local_off, w.start_t, w.block_tot, w.tlist);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, nb, w.block_tot, max_samples, w.block_base, w.info);
     hipLaunchKernelGGL(k1_write, dim3(nb), dim3(RM_BLOCK), 0, stream, n_rays, aabb0, aabb1, rays_o, rays_d, bitfield,
                        cone_angle, max_samples, w.cnt, w.local_off, w.start_t, w.block_base, w.info, coords_out,
-                       rays_index, rays_numsteps, counter2);
+                       rays_index, rays_numsteps, counter2, w.tlist);
     XR_LAUNCH_CHECK();
     return XR_OK;
 }
