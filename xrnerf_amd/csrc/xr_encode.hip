@@ -56,7 +56,11 @@ __device__ inline void level_of_block(const GridMeta& gm, uint32_t* level, uint3
     const uint32_t per_xcd = (gm.n_levels + 7) / 8;
     const uint32_t xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     if (gm.order == 0) { *level = xcd + 8 * (j % per_xcd); *sblock = j / per_xcd; }
-    else {
+    else if (gm.order == 2) {
+        // balanced: all XCDs share every level (finest first); used by the scatter, whose atomics
+        // showed no sensitivity to L2 residency but a per-level request count that differs 20x
+        *level = gm.n_levels - 1 - blockIdx.x / gm.n_sblocks; *sblock = blockIdx.x % gm.n_sblocks;
+    } else {
         // level-major: an XCD finishes one level before it starts the next (finest first), so that
         // the one 4 MiB table slice it is working on stays resident in its 4 MiB L2
         const uint32_t slot = j / gm.n_sblocks;
@@ -111,20 +115,20 @@ __global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_fwd(GridMeta gm, uint32_t
 //   * each 16-lane group walks BW_CH CONSECUTIVE samples (ray order) and keeps the running sum of
 //     its dword in a register while the cell does not change: at the coarse levels a whole ray
 //     segment collapses into one flush (run-length reduction with no shuffles, any run length).
-#define BW_CH 32
+#define BW_CH 64
 #define BW_SAMPLES_PER_BLOCK (BW_CH * (EN_BLOCK / 16))
 __global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_bwd(GridMeta gm, uint32_t hashed_mask, const float* __restrict__ x,
                                                             uint32_t x_stride, const float* __restrict__ denc_t, uint32_t ld,
-                                                            uint32_t n, const uint32_t* __restrict__ n_dev, float* __restrict__ grad_table) {
+                                                            uint32_t n, const uint32_t* __restrict__ n_dev, float* __restrict__ grad_table, uint32_t bw_ch) {
     uint32_t l, sb;
     level_of_block(gm, &l, &sb);
     if (l >= (uint32_t)gm.n_levels) return;
     if (n_dev) n = min(n, *n_dev);
     const uint32_t q = threadIdx.x & 15, group = threadIdx.x >> 4;
     const uint32_t f = q & 1, cx = (q >> 1) & 1, cy = (q >> 2) & 1, cz = (q >> 3) & 1;
-    const uint32_t i0 = sb * BW_SAMPLES_PER_BLOCK + group * BW_CH;
+    const uint32_t i0 = sb * (bw_ch * (EN_BLOCK / 16)) + group * bw_ch;
     if (i0 >= n) return;
-    const uint32_t i1 = min(i0 + BW_CH, n);
+    const uint32_t i1 = min(i0 + bw_ch, n);
     const float scale = gm.scale[l];
     const uint32_t res = gm.res[l], hsize = gm.off[l + 1] - gm.off[l];
     const bool hashed = (hashed_mask >> l) & 1;
@@ -199,10 +203,11 @@ extern "C" int xr_hashgrid_bwd(const float* x, uint32_t x_stride, const float* d
     GridMeta gm; uint32_t hm;
     XR_REQUIRE(fill_meta(&gm, &hm, n_levels, scale_host, resolution_host, offset_host) == 0, "bad level metadata");
     const uint32_t per_xcd = (n_levels + 7) / 8;
-    gm.n_sblocks = xr_div_up(n, BW_SAMPLES_PER_BLOCK);
+    const uint32_t bw_ch = BW_CH;      // swept 8..128 on MI355X: 0.71-0.75 ms at 2^18 samples, flat
+    gm.n_sblocks = xr_div_up(n, bw_ch * (EN_BLOCK / 16));
     const uint32_t blocks = 8 * per_xcd * gm.n_sblocks;
     hipLaunchKernelGGL(k_hashgrid_bwd, dim3(blocks), dim3(EN_BLOCK), 0, (hipStream_t)stream_, gm, hm, x, x_stride, denc_t, ld,
-                       n, n_dev, grad_table);
+                       n, n_dev, grad_table, bw_ch);
     XR_LAUNCH_CHECK();
     return XR_OK;
 }
