@@ -183,6 +183,14 @@ int xr_gen_rays(const float* pose43_host, int H, int W, float fx, float fy, floa
  * writes dL/drgb and ADDS the loss into loss_out[0] (caller zero-fills) */
 int xr_huber_loss_grad(const float* rgb, const float* target, uint32_t n_elems, float delta, float scale,
                        float* grad, float* loss_out, void* stream);
+/* the same plus the alpha-masked squared error sum the reference turns into its logged PSNR
+ * (networks/hashnerf.py:40-42): loss_mse_out[0] += loss, loss_mse_out[1] += sum ((rgb-target)*alpha)^2 */
+int xr_huber_loss_grad_mse(const float* rgb, const float* target, const float* alpha /*[n_rays]*/, uint32_t n_rays,
+                           float delta, float scale, float* grad, float* loss_mse_out /*[2]*/, void* stream);
+/* HashBatchSample + RandomBGColor (datasets/pipelines/create.py:153-191, augment.py:290-317) in one launch:
+ * rows [n,11] = (o3, d3, rgba4, img_id) of the device-resident ray table -> batch tensors; bg ~ U[0,1) (PCG32) */
+int xr_make_batch(const float* rays_rgb_rows, uint32_t n, uint64_t rng_state, uint64_t rng_inc, float* rays_o,
+                  float* rays_d, float* target, float* alpha, float* bg, int32_t* img_ids, void* stream);
 /* torch.optim.Adam step with L2 weight decay (configs/instant_ngp/nerf_blender_local01.py:14-18),
  * fused with the optional EMA copy of mmcv's EMAHook (:24): ema = (1-mom)*ema + mom*p. */
 int xr_adam_step(float* p, const float* g, float* m, float* v, size_t n, int step, float lr, float beta1,

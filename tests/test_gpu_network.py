@@ -1,0 +1,55 @@
+"""End-to-end checks behind the registry on the GPU: the fused single-node train step equals the modular
+autograd path (same kernels), training reduces the loss, rendering works, state_dict round-trips."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def make(dev, seed=0):
+    from xrnerf_amd.train import Trainer
+    return Trainer(dev, n_img=2, H=96, W=96, seed=seed, ema=False)
+
+
+def test_fused_step_equals_modular_step(dev, monkeypatch):
+    a, b = make(dev), make(dev)
+    b.net.load_state_dict(a.net.state_dict())
+    out = {}
+    for name, tr, modular in (('fused', a, '0'), ('modular', b, '1')):
+        monkeypatch.setenv('XRNERF_MODULAR_STEP', modular)
+        tr.net.sampler.set_iter(0)
+        batch = {k: v[None] for k, v in tr.data.next_batch().items()}
+        o = tr.net.train_step(batch, tr.opt)
+        o['loss'].backward()
+        out[name] = (float(o['loss']), float(o['log_vars']['psnr']),
+                     [p.grad.clone() for p in tr.net.parameters() if p.grad is not None])
+    lf, pf, gf = out['fused']; lm, pm, gm = out['modular']
+    assert abs(lf - lm) <= 1e-5 * abs(lm) and abs(pf - pm) <= 1e-4
+    assert len(gf) == len(gm) == 3
+    for x, y in zip(gf, gm):
+        assert float((x - y).abs().max()) <= 1e-5 * max(1.0, float(y.abs().max()))
+
+
+def test_training_reduces_loss_and_renders(dev):
+    from xrnerf_amd.train import render_frame
+    tr = make(dev)
+    first = float(tr.step()['log_vars']['loss'])
+    for _ in range(60):
+        out = tr.step()
+    last = float(out['log_vars']['loss'])
+    assert np.isfinite(last) and last < 0.7 * first
+    assert tr.net.sampler.n_rays_per_batch % 128 == 0
+    rgb, alpha = render_frame(tr.net, tr.data.poses[0], 96, 96, tr.data.focal)
+    assert rgb.shape == (96, 96, 3) and alpha.shape == (96, 96, 1)
+    assert torch.isfinite(rgb).all() and 0.0 <= float(alpha.min()) and float(alpha.max()) <= 1.0 + 1e-5
+    # config chunking (networks/nerf.py:50-69) gives the same image as one big chunk
+    rgb2, _ = render_frame(tr.net, tr.data.poses[0], 96, 96, tr.data.focal, chunk=4096)
+    # the per-launch jitter stream advances with every K1 call (hidden RNG of the reference): compare loosely
+    assert float((rgb - rgb2).abs().mean()) < 0.05
+    sd = tr.net.state_dict()
+    tr2 = make(dev, seed=5)
+    tr2.net.load_state_dict(sd)
+    assert torch.equal(tr2.net.mlp.embedder_pos.params, tr.net.mlp.embedder_pos.params)

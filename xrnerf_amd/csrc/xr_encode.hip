@@ -115,11 +115,12 @@ __global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_fwd(GridMeta gm, uint32_t
 //   * each 16-lane group walks BW_CH CONSECUTIVE samples (ray order) and keeps the running sum of
 //     its dword in a register while the cell does not change: at the coarse levels a whole ray
 //     segment collapses into one flush (run-length reduction with no shuffles, any run length).
-#define BW_CH 64
+#define BW_CH 32
 #define BW_SAMPLES_PER_BLOCK (BW_CH * (EN_BLOCK / 16))
 __global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_bwd(GridMeta gm, uint32_t hashed_mask, const float* __restrict__ x,
                                                             uint32_t x_stride, const float* __restrict__ denc_t, uint32_t ld,
-                                                            uint32_t n, const uint32_t* __restrict__ n_dev, float* __restrict__ grad_table, uint32_t bw_ch) {
+                                                            uint32_t n, const uint32_t* __restrict__ n_dev, float* __restrict__ grad_table) {
+    constexpr uint32_t bw_ch = BW_CH;   // compile-time: a runtime chunk length costs 8 % (loop not unrolled)
     uint32_t l, sb;
     level_of_block(gm, &l, &sb);
     if (l >= (uint32_t)gm.n_levels) return;
@@ -203,11 +204,11 @@ extern "C" int xr_hashgrid_bwd(const float* x, uint32_t x_stride, const float* d
     GridMeta gm; uint32_t hm;
     XR_REQUIRE(fill_meta(&gm, &hm, n_levels, scale_host, resolution_host, offset_host) == 0, "bad level metadata");
     const uint32_t per_xcd = (n_levels + 7) / 8;
-    const uint32_t bw_ch = BW_CH;      // swept 8..128 on MI355X: 0.71-0.75 ms at 2^18 samples, flat
+    const uint32_t bw_ch = BW_CH;      // swept 8..128 on MI355X: 0.71-0.75 ms at 2^18 dense-gradient samples, flat
     gm.n_sblocks = xr_div_up(n, bw_ch * (EN_BLOCK / 16));
     const uint32_t blocks = 8 * per_xcd * gm.n_sblocks;
     hipLaunchKernelGGL(k_hashgrid_bwd, dim3(blocks), dim3(EN_BLOCK), 0, (hipStream_t)stream_, gm, hm, x, x_stride, denc_t, ld,
-                       n, n_dev, grad_table, bw_ch);
+                       n, n_dev, grad_table);
     XR_LAUNCH_CHECK();
     return XR_OK;
 }

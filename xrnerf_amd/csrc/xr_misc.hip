@@ -53,27 +53,75 @@ extern "C" int xr_gen_rays(const float* pose43_host, int H, int W, float fx, flo
 }
 
 // ------------------------------------------------------------------ scale * HuberLoss(sum) and its gradient
-__global__ __launch_bounds__(256) void k_huber(const float* __restrict__ rgb, const float* __restrict__ target, uint32_t n,
-                                                float delta, float scale, float* __restrict__ grad, float* __restrict__ loss) {
-    __shared__ float ws[4];
-    float acc = 0.f;
+// (+ optionally the alpha-masked squared error the reference logs as PSNR, networks/hashnerf.py:40-42)
+__global__ __launch_bounds__(256) void k_huber(const float* __restrict__ rgb, const float* __restrict__ target,
+                                                const float* __restrict__ alpha, uint32_t n, float delta, float scale,
+                                                float* __restrict__ grad, float* __restrict__ loss) {
+    __shared__ float ws[4], ws2[4];
+    float acc = 0.f, mse = 0.f;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const float r = rgb[i] - target[i], a = fabsf(r);
         // HuberLoss of the reference (utils/metrics.py:8-16): rel > delta ? rel - delta/2 : 0.5/delta*rel^2
         if (a > delta) { acc += a - 0.5f * delta; grad[i] = scale * (r > 0.f ? 1.f : -1.f); }
         else { acc += 0.5f / delta * a * a; grad[i] = scale * (r / delta); }
+        if (alpha) { const float m = r * alpha[i / 3]; mse += m * m; }
     }
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
-    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+    for (int d = 32; d > 0; d >>= 1) { acc += __shfl_xor(acc, d, 64); mse += __shfl_xor(mse, d, 64); }
+    if ((threadIdx.x & 63) == 0) { ws[threadIdx.x >> 6] = acc; ws2[threadIdx.x >> 6] = mse; }
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(loss, scale * ((ws[0] + ws[1]) + (ws[2] + ws[3])));
+    if (threadIdx.x == 0) {
+        atomicAdd(loss, scale * ((ws[0] + ws[1]) + (ws[2] + ws[3])));
+        if (alpha) atomicAdd(loss + 1, (ws2[0] + ws2[1]) + (ws2[2] + ws2[3]));
+    }
 }
 extern "C" int xr_huber_loss_grad(const float* rgb, const float* target, uint32_t n_elems, float delta, float scale,
                                   float* grad, float* loss_out, void* stream_) {
     XR_REQUIRE(rgb && target && grad && loss_out && n_elems > 0, "bad argument");
     hipLaunchKernelGGL(k_huber, dim3(min(xr_div_up(n_elems, 256), 1024u)), dim3(256), 0, (hipStream_t)stream_, rgb, target,
-                       n_elems, delta, scale, grad, loss_out);
+                       (const float*)nullptr, n_elems, delta, scale, grad, loss_out);
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}
+extern "C" int xr_huber_loss_grad_mse(const float* rgb, const float* target, const float* alpha, uint32_t n_rays, float delta,
+                                      float scale, float* grad, float* loss_mse_out, void* stream_) {
+    XR_REQUIRE(rgb && target && alpha && grad && loss_mse_out && n_rays > 0, "bad argument");
+    hipLaunchKernelGGL(k_huber, dim3(min(xr_div_up(3 * n_rays, 256), 1024u)), dim3(256), 0, (hipStream_t)stream_, rgb, target,
+                       alpha, 3 * n_rays, delta, scale, grad, loss_mse_out);
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}
+
+// ------------------------------------------------------------------ training batch assembly
+// HashBatchSample + RandomBGColor (/root/reference/xrnerf/datasets/pipelines/create.py:153-191,
+// augment.py:290-317) on the device in one launch: slices `n` rows of the [N,11] ray table
+// (o3, d3, rgba4, img_id) and draws the random background with PCG32 (stream position = row).
+__global__ __launch_bounds__(256) void k_make_batch(const float* __restrict__ rows, uint32_t n, xr_pcg32 rng,
+                                                     float* __restrict__ rays_o, float* __restrict__ rays_d,
+                                                     float* __restrict__ target, float* __restrict__ alpha,
+                                                     float* __restrict__ bg, int32_t* __restrict__ img_ids) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* r = rows + 11 * (size_t)i;
+    rng.advance(3ull * i);
+    const float a = r[9];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        rays_o[3 * (size_t)i + k] = r[k];
+        rays_d[3 * (size_t)i + k] = r[3 + k];
+        const float b = rng.next_float();
+        bg[3 * (size_t)i + k] = b;
+        target[3 * (size_t)i + k] = r[6 + k] * a + b * (1.f - a);
+    }
+    alpha[i] = a;
+    img_ids[i] = (int32_t)r[10];
+}
+extern "C" int xr_make_batch(const float* rays_rgb_rows, uint32_t n, uint64_t rng_state, uint64_t rng_inc, float* rays_o,
+                             float* rays_d, float* target, float* alpha, float* bg, int32_t* img_ids, void* stream_) {
+    XR_REQUIRE(rays_rgb_rows && rays_o && rays_d && target && alpha && bg && img_ids && n > 0, "bad argument");
+    xr_pcg32 rng{rng_state, rng_inc};
+    hipLaunchKernelGGL(k_make_batch, dim3(xr_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream_, rays_rgb_rows, n, rng, rays_o,
+                       rays_d, target, alpha, bg, img_ids);
     XR_LAUNCH_CHECK();
     return XR_OK;
 }

@@ -23,8 +23,13 @@ def img2mse(x, y):
     return torch.mean((x - y) ** 2)
 
 
+_LOG10 = float(torch.log(torch.tensor(10.0)))
+
+
 def mse2psnr(x):
-    return -10. * torch.log(x) / torch.log(torch.Tensor([10.]).to(x.device))
+    # the reference divides by torch.log(torch.Tensor([10.]).to(x.device)): a pageable host-to-device copy,
+    # i.e. a full stream synchronisation per call.  Same value, no copy.
+    return -10. * torch.log(x) / _LOG10
 
 
 class _HuberSumFn(torch.autograd.Function):
@@ -66,6 +71,48 @@ def unfold_batching(data):   # networks/utils/batching.py:5-12
 def recover_shape(data, to_shape):   # networks/utils/transforms.py:5-9
     to_shape = list(to_shape[:-1]) + list(data.shape[1:])
     return torch.reshape(data, to_shape)
+
+
+class _FusedTrainStepFn(torch.autograd.Function):
+    """The whole training forward AND backward of HashNerfNetwork as ONE autograd node.
+
+    forward  = sampler.sample -> encode -> fused MLP -> K3 composite -> 5*Huber (+ masked mse)
+               -> K4 -> MLP backward -> hash-grid scatter, all enqueued back to back (10 launches);
+    backward = hand the gradients computed above to autograd (scaled by the incoming gradient).
+    Same kernels and same results as the modular path (mlp(data) -> render -> HuberLoss -> .backward()),
+    without the per-node autograd/Python latency between them (tests/test_gpu_network.py)."""
+
+    @staticmethod
+    def forward(ctx, table, wd, wc, net, data):
+        from . import ops
+        mlp, sampler = net.mlp, net.sampler
+        with torch.no_grad():
+            data = sampler.sample(data, mlp, False)
+            pts, dirs = mlp._rows(data['pts']), mlp._rows(data['viewdirs'])
+            n, n_dev = pts.shape[0], data.get('n_valid_dev')
+            meta, nhd, nhc = mlp.embedder_pos.meta, mlp.density_net.n_hidden, mlp.color_net.n_hidden
+            enc_t = ops.hashgrid_fwd(table, pts, meta, n_dev=n_dev)
+            raw = ops.nerf_mlp_fwd(enc_t, dirs, n, wd, wc, nhd, nhc, mlp.pad_value, n_dev=n_dev)
+            ra, da = int(sampler.rgb_activation), int(sampler.density_activation)
+            rgb = ops.calc_rgb_forward(raw, sampler.coords, sampler.rays_numsteps, sampler.rays_numsteps_compacted,
+                                       data['bg_color'], ra, da)
+            loss_mse, grad_rgb = ops.huber_loss_grad_mse(rgb, data['target_s'].contiguous(), data['alpha'].contiguous(), 0.1, 5.0)
+            draw = torch.zeros_like(raw)
+            ops.calc_rgb_backward(raw, sampler.rays_numsteps_compacted, sampler.coords, grad_rgb, rgb,
+                                  sampler.density_grid_mean, ra, da, out=draw)
+            g_wd, g_wc, g_table = torch.zeros_like(wd), torch.zeros_like(wc), torch.zeros_like(table)
+            denc_t = ops.nerf_mlp_bwd(enc_t, dirs, n, wd, wc, nhd, nhc, draw, g_wd, g_wc, mlp.pad_value, n_dev=n_dev)
+            ops.hashgrid_bwd(pts, denc_t, meta, g_table, n_dev=n_dev)
+        ctx.grads = (g_table, g_wd, g_wc)
+        ctx.mark_non_differentiable(rgb)
+        net._last = {'rgb': rgb, 'loss_mse': loss_mse, 'raw': raw}
+        return loss_mse[0].clone(), rgb
+
+    @staticmethod
+    def backward(ctx, g, _g_rgb):
+        g_table, g_wd, g_wc = ctx.grads
+        ctx.grads = None
+        return g_table.mul_(g), g_wd.mul_(g), g_wc.mul_(g), None, None
 
 
 class BaseNerfNetwork(nn.Module):
@@ -113,9 +160,33 @@ class HashNerfNetwork(BaseNerfNetwork):
                 all_ret.setdefault(k, []).append(ret[k])
         return {k: torch.cat(all_ret[k], 0) for k in all_ret}
 
+    def _fused_ok(self):
+        from .mlps import HashNerfMLP
+        from .renders import HashNerfRender
+        from .samplers import NGPGridSampler
+        import os
+        return (os.environ.get('XRNERF_MODULAR_STEP') != '1' and type(self.sampler) is NGPGridSampler and
+                type(self.mlp) is HashNerfMLP and type(self.render) is HashNerfRender and
+                self.mlp.embedder_pos.params.is_cuda and torch.is_grad_enabled())
+
+    def _train_step_fused(self, data, **kwargs):
+        loss, rgb = _FusedTrainStepFn.apply(self.mlp.embedder_pos.params, self.mlp.density_net.params,
+                                            self.mlp.color_net.params, self, data)
+        bs = rgb.shape[0]
+        with torch.no_grad():
+            mse_loss = self._last['loss_mse'][1] / (3.0 * bs)        # img2mse of the alpha-masked images
+            psnr = mse2psnr(mse_loss)
+        if kwargs.get('lazy_log', False):
+            log_vars = {'loss': loss.detach(), 'psnr': psnr}
+        else:
+            log_vars = {'loss': loss.item(), 'psnr': psnr.item()}
+        return {'loss': loss, 'log_vars': log_vars, 'num_samples': bs}
+
     def train_step(self, data, optimizer, **kwargs):
         for k in data:
             data[k] = unfold_batching(data[k])
+        if self._fused_ok():
+            return self._train_step_fused(data, **kwargs)
         ret = self.forward(data, is_test=False)
         bs = ret['rgb'].shape[0]
         alpha = data['alpha'].detach()

@@ -343,6 +343,27 @@ def huber_loss_grad(rgb, target, delta=0.1, scale=5.0):
     return loss, grad
 
 
+def huber_loss_grad_mse(rgb, target, alpha, delta=0.1, scale=5.0):
+    """-> out[2] = (scale * HuberLoss_sum, sum ((rgb-target)*alpha)^2), dL/drgb"""
+    grad = torch.empty_like(rgb)
+    out = torch.zeros((2,), dtype=torch.float32, device=rgb.device)
+    _lib.check(_lib.load().xr_huber_loss_grad_mse(_ptr(rgb), _ptr(target), _ptr(alpha), rgb.shape[0], delta, scale,
+                                                  _ptr(grad), _ptr(out), _stream()), 'xr_huber_loss_grad_mse')
+    return out, grad
+
+
+def make_batch(rows, n, call_index, seed=20220901):
+    """rows: contiguous [>=n, 11] slice of the device-resident ray table -> dict of batch tensors"""
+    dev = rows.device
+    f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+    o, d, tgt, alpha, bg = f(n, 3), f(n, 3), f(n, 3), f(n, 1), f(n, 3)
+    ids = torch.empty((n, 1), dtype=torch.int32, device=dev)
+    st, inc = pcg32_host_state(call_index, seed)
+    _lib.check(_lib.load().xr_make_batch(_ptr(rows), n, st, inc, _ptr(o), _ptr(d), _ptr(tgt), _ptr(alpha), _ptr(bg),
+                                         _ptr(ids), _stream()), 'xr_make_batch')
+    return {'rays_o': o, 'rays_d': d, 'target_s': tgt, 'alpha': alpha, 'img_ids': ids, 'bg_color': bg}
+
+
 def adam_step(p, g, m, v, step, lr=1e-2, beta1=0.9, beta2=0.99, eps=1e-15, weight_decay=1e-6, ema=None,
               ema_momentum=0.05):
     with _span('xr_adam_step', p.numel()):

@@ -97,7 +97,7 @@ class SyntheticLego:
             self.rays_rgb = self.rays_rgb[perm].contiguous()
         self.cur_i = 0
         self.N_rand = 4096
-        self.gen = torch.Generator(device=device).manual_seed(seed + 100)
+        self.batches_drawn = 0
 
     # HashNerfDataset.get_alldata / get_info
     def get_alldata(self):
@@ -113,17 +113,14 @@ class SyntheticLego:
         self.N_rand = int(bs)
 
     def next_batch(self):
-        """HashBatchSample + RandomBGColor (pipelines/create.py:153-191, augment.py:290-317), on device."""
+        """HashBatchSample + RandomBGColor (pipelines/create.py:153-191, augment.py:290-317), on device, one launch."""
         n = self.N_rand
         if self.cur_i + n >= self.rays_rgb.shape[0]:
             self.cur_i = 0
-        b = self.rays_rgb[self.cur_i:self.cur_i + n]
+        batch = ops.make_batch(self.rays_rgb[self.cur_i:self.cur_i + n], n, self.batches_drawn)
         self.cur_i += n
-        alpha = b[:, 9:10]
-        bg = torch.rand((n, 3), device=self.device, generator=self.gen)
-        target = b[:, 6:9] * alpha + bg * (1 - alpha)
-        return {'rays_o': b[:, 0:3].contiguous(), 'rays_d': b[:, 3:6].contiguous(), 'target_s': target, 'alpha': alpha,
-                'img_ids': b[:, 10:].to(torch.int32), 'bg_color': bg}
+        self.batches_drawn += 1
+        return batch
 
 
 def _lego_boxes(seed=2, fill=0.07, n_boxes=40):
