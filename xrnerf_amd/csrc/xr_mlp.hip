@@ -91,7 +91,7 @@ __device__ inline void load_weights(float* __restrict__ lds, const float* __rest
 
 // ---- building blocks (all tiles in the C/D register layout described above) ------------------
 // out[TO] = W[TO*32][TI*32] . in[TI]
-template <int TI, int TO>
+template <int TI, int TO, bool SB = true>
 __device__ __forceinline__ void layer_fwd(const float* __restrict__ W, const f32x16 (&in)[TI], f32x16 (&out)[TO], int col, int hi) {
     constexpr int ST = TI * 32 + 1;
 #pragma unroll
@@ -103,6 +103,8 @@ __device__ __forceinline__ void layer_fwd(const float* __restrict__ W, const f32
     for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+            // keep the scheduler from hoisting a whole layer's LDS operand reads (64-128 VGPRs) to the top
+            if (SB && (r & 3) == 0) __builtin_amdgcn_sched_barrier(0);
             const float b = in[ti][r];
 #pragma unroll
             for (int to = 0; to < TO; ++to) {
@@ -112,7 +114,7 @@ __device__ __forceinline__ void layer_fwd(const float* __restrict__ W, const f32
         }
 }
 // gin[TI] = W^T . g[TO]     (W is [TO*32][TI*32], stride TI*32+1)
-template <int TO, int TI>
+template <int TO, int TI, bool SB = true>
 __device__ __forceinline__ void layer_bwd(const float* __restrict__ W, const f32x16 (&g)[TO], f32x16 (&gin)[TI], int col, int hi) {
     constexpr int ST = TI * 32 + 1;
 #pragma unroll
@@ -124,6 +126,7 @@ __device__ __forceinline__ void layer_bwd(const float* __restrict__ W, const f32
     for (int to = 0; to < TO; ++to)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+            if (SB && (r & 3) == 0) __builtin_amdgcn_sched_barrier(0);
             const float b = g[to][r];
 #pragma unroll
             for (int ti = 0; ti < TI; ++ti) {
@@ -142,7 +145,7 @@ __device__ __forceinline__ void relu_mask(f32x16& g, const f32x16& h) {
 }
 // acc[to][ti] += g[to] (rows = out neurons) x h[ti]^T (rows = in neurons), contraction over the
 // 32 samples of the tile; `stage` is this wave's private LDS tile [(TO+TI)*32][33].
-template <int TO, int TI>
+template <int TO, int TI, bool SB = true>
 __device__ __forceinline__ void dw_accumulate(f32x16 (&acc)[TO][TI], const f32x16 (&g)[TO], const f32x16 (&h)[TI],
                                               float* __restrict__ stage, int col, int hi) {
 #pragma unroll
@@ -157,6 +160,7 @@ __device__ __forceinline__ void dw_accumulate(f32x16 (&acc)[TO][TI], const f32x1
     const float* sg = stage + col * ST33 + hi;
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
+        if (SB && (t & 3) == 0) __builtin_amdgcn_sched_barrier(0);
         float a[TO], b[TI];
 #pragma unroll
         for (int to = 0; to < TO; ++to) a[to] = sg[(to * 32) * ST33 + 2 * t];
@@ -230,7 +234,7 @@ __device__ __forceinline__ void build_color_in(const f32x16& dout, const float* 
 
 // ------------------------------------------------------------------ forward kernel
 template <int NHD, int NHC, bool WITH_COLOR>
-__global__ __launch_bounds__(MLP_THREADS, 2) void k_nerf_mlp_fwd(const float* __restrict__ enc_t, uint32_t ld,
+__global__ __launch_bounds__(MLP_THREADS, 3) void k_nerf_mlp_fwd(const float* __restrict__ enc_t, uint32_t ld,
                                                                const float* __restrict__ dirs, uint32_t dir_stride,
                                                                uint32_t n, const uint32_t* __restrict__ n_dev,
                                                                const float* __restrict__ w_density,
@@ -320,13 +324,13 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void k_nerf_mlp_bwd_1_2(
         // ---- recompute forward, keep activations
         f32x16 xe[1], hd[2], dout[1], cin[1], hc1[2], hc2[2];
         load_enc_tile(enc_t, ld, sc, xe[0], hi);
-        layer_fwd<1, 2>(wd + SD::lds_off(0), xe, hd, col, hi);
+        layer_fwd<1, 2, false>(wd + SD::lds_off(0), xe, hd, col, hi);
         relu_tile(hd[0]); relu_tile(hd[1]);
-        layer_fwd<2, 1>(wd + SD::lds_off(1), hd, dout, col, hi);
+        layer_fwd<2, 1, false>(wd + SD::lds_off(1), hd, dout, col, hi);
         build_color_in(dout[0], dirs, dir_stride, sc, pad_value, cin[0], hi);
-        layer_fwd<1, 2>(wc + SC::lds_off(0), cin, hc1, col, hi);
+        layer_fwd<1, 2, false>(wc + SC::lds_off(0), cin, hc1, col, hi);
         relu_tile(hc1[0]); relu_tile(hc1[1]);
-        layer_fwd<2, 2>(wc + SC::lds_off(1), hc1, hc2, col, hi);
+        layer_fwd<2, 2, false>(wc + SC::lds_off(1), hc1, hc2, col, hi);
         relu_tile(hc2[0]); relu_tile(hc2[1]);
         // ---- output gradients: rows 0..2 of the color output tile = dL/d(rgb raw), all else 0.
         // dead (ragged) samples get a zero gradient so they contribute nothing to dW.
@@ -337,27 +341,27 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void k_nerf_mlp_bwd_1_2(
         for (int r = 0; r < 16; ++r) g1[0][r] = 0.f;
         g1[0][0] = dr.x; g1[0][1] = dr.y; g1[0][2] = dr.z;             // hi==1 lanes hold zeros
         // color output layer
-        dw_accumulate<1, 2>(a_c2, g1, hc2, stage, col, hi);
-        layer_bwd<1, 2>(wc + SC::lds_off(2), g1, g2, col, hi);
+        dw_accumulate<1, 2, false>(a_c2, g1, hc2, stage, col, hi);
+        layer_bwd<1, 2, false>(wc + SC::lds_off(2), g1, g2, col, hi);
         relu_mask(g2[0], hc2[0]); relu_mask(g2[1], hc2[1]);
         // color hidden layer 2
-        dw_accumulate<2, 2>(a_c1, g2, hc1, stage, col, hi);
-        layer_bwd<2, 2>(wc + SC::lds_off(1), g2, g2b, col, hi);
+        dw_accumulate<2, 2, false>(a_c1, g2, hc1, stage, col, hi);
+        layer_bwd<2, 2, false>(wc + SC::lds_off(1), g2, g2b, col, hi);
         relu_mask(g2b[0], hc1[0]); relu_mask(g2b[1], hc1[1]);
         // color input layer
-        dw_accumulate<2, 1>(a_c0, g2b, cin, stage, col, hi);
-        layer_bwd<2, 1>(wc + SC::lds_off(0), g2b, g1, col, hi);       // g1 = dL/d(color input slots)
+        dw_accumulate<2, 1, false>(a_c0, g2b, cin, stage, col, hi);
+        layer_bwd<2, 1, false>(wc + SC::lds_off(0), g2b, g1, col, hi);       // g1 = dL/d(color input slots)
         // slots 1..15 are density-output rows 1..15; row 0 takes dL/d(sigma raw); rows >= 16 are padding
 #pragma unroll
         for (int r = 8; r < 16; ++r) g1[0][r] = 0.f;
         if (hi == 0) g1[0][0] = dr.w;
         // density output layer
-        dw_accumulate<1, 2>(a_d1, g1, hd, stage, col, hi);
-        layer_bwd<1, 2>(wd + SD::lds_off(1), g1, g2, col, hi);
+        dw_accumulate<1, 2, false>(a_d1, g1, hd, stage, col, hi);
+        layer_bwd<1, 2, false>(wd + SD::lds_off(1), g1, g2, col, hi);
         relu_mask(g2[0], hd[0]); relu_mask(g2[1], hd[1]);
         // density input layer
-        dw_accumulate<2, 1>(a_d0, g2, xe, stage, col, hi);
-        layer_bwd<2, 1>(wd + SD::lds_off(0), g2, g1, col, hi);        // g1 = dL/d(encoded features)
+        dw_accumulate<2, 1, false>(a_d0, g2, xe, stage, col, hi);
+        layer_bwd<2, 1, false>(wd + SD::lds_off(0), g2, g1, col, hi);        // g1 = dL/d(encoded features)
         if (live) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) denc_t[(size_t)(drow(r) + 4 * hi) * ld + s] = g1[0][r];
