@@ -53,3 +53,20 @@ def test_training_reduces_loss_and_renders(dev):
     tr2 = make(dev, seed=5)
     tr2.net.load_state_dict(sd)
     assert torch.equal(tr2.net.mlp.embedder_pos.params, tr.net.mlp.embedder_pos.params)
+
+
+def test_overlapped_march_matches_serial(dev):
+    """K1 of batch i+1 on a side stream under iteration i's backward (Trainer.overlap_march) must not
+    change what is computed: same sample counts exactly, same losses up to atomic-order rounding."""
+    a, b = make(dev), make(dev)
+    b.net.load_state_dict(a.net.state_dict())
+    a.overlap_march, b.overlap_march = True, False
+    la, lb, na, nb = [], [], [], []
+    for _ in range(40):
+        la.append(a.step()['log_vars']['loss']); na.append(a.net.sampler.n_valid_dev.clone())
+        lb.append(b.step()['log_vars']['loss']); nb.append(b.net.sampler.n_valid_dev.clone())
+    torch.cuda.synchronize()
+    assert [int(x) for x in na[:17]] == [int(x) for x in nb[:17]]       # identical marches while the grids agree bit for bit
+    la, lb = torch.stack(la).cpu().numpy(), torch.stack(lb).cpu().numpy()
+    assert np.abs(la - lb).max() <= 2e-2 * np.abs(lb).max()
+    assert a.net.sampler.n_rays_per_batch == b.net.sampler.n_rays_per_batch

@@ -64,6 +64,8 @@ def HuberLoss(x, y, delta=0.1, reduction='sum'):
 def unfold_batching(data):   # networks/utils/batching.py:5-12
     if len(data.shape) > 1:
         bs = data.shape[0]
+        if bs == 1:
+            return data[0]          # same values as the reference's torch.cat of one piece, without the copy
         data = torch.cat([data[b] for b in range(bs)], 0)
     return data
 

@@ -94,7 +94,7 @@ def pcg32_host_state(ncalls, seed=9121):
 
 # ---------------------------------------------------------------- K1 / K2
 def rays_sampler(rays_o, rays_d, bitfield, aabb, near_distance, cone_angle, max_samples, rng_calls,
-                 coords_out=None):
+                 coords_out=None, ws_tag='k1'):
     """returns coords_out [max_samples,7], rays_index [n,1], rays_numsteps [n,2], counter [2] (device)."""
     L = _lib.load()
     n = rays_o.shape[0]
@@ -105,7 +105,7 @@ def rays_sampler(rays_o, rays_d, bitfield, aabb, near_distance, cone_angle, max_
     numsteps = torch.empty((n, 2), dtype=torch.int32, device=dev)
     counter = torch.empty((2,), dtype=torch.int32, device=dev)
     nb = L.xr_rays_sampler_workspace_bytes(n)
-    ws = _ws(dev, nb, 'k1')
+    ws = _ws(dev, nb, ws_tag)
     st, inc = pcg32_host_state(rng_calls)
     with _span('xr_rays_sampler', n):
         _lib.check(L.xr_rays_sampler(_ptr(rays_o), _ptr(rays_d), _ptr(bitfield), n, aabb[0], aabb[1], near_distance,

@@ -64,6 +64,7 @@ class NGPGridSampler(nn.Module):
         self.k1_calls = 0
         self.k6_calls = 0
         self.device = None
+        self._prefetched = None
 
     # ------------------------------------------------------------------ hooks' entry points
     def set_data(self, alldata, datainfo):
@@ -106,6 +107,8 @@ class NGPGridSampler(nn.Module):
         ops.ema_grid_samples(self.density_grid_tmp, n_elements, self.ema_grid_decay, self.density_grid)
         self.density_grid_ema_step += 1
         ops.update_bitfield(self.density_grid, self.density_grid_mean, self.density_grid_bitfield)
+        self._bitfield_event = torch.cuda.Event()
+        self._bitfield_event.record(torch.cuda.current_stream())
 
     def update_density_grid(self, mlp):
         n_cascades = self.max_cascade + 1
@@ -143,10 +146,26 @@ class NGPGridSampler(nn.Module):
         # samplers/utils/rays_sampler.py:20-21); nothing reads rows past the counter, so it is not cleared
         max_samples = max(self.num_coords_elements, n_rays * 64) if is_training else n_rays * self.MAX_STEP
         max_samples = min(max_samples, n_rays * self.MAX_STEP)
-        coords, rays_index, rays_numsteps, counter = ops.rays_sampler(
-            rays_o, rays_d, self.density_grid_bitfield, aabb, self.near_distance, self.cone_angle_constant,
-            max_samples, self.k1_calls, coords_out=self._coords_buffer(max_samples))
-        self.k1_calls += 1
+        pf = self._prefetched
+        self._prefetched = None
+        if (is_training and pf is not None and pf['rays_o'].data_ptr() == data['rays_o'].data_ptr() and
+                pf['rays_o'].shape == data['rays_o'].shape and pf['max_samples'] == max_samples):
+            # K1 of this batch already ran on the side stream while the previous iteration's backward was
+            # executing (prefetch()): order this stream after it and adopt its outputs
+            cur = torch.cuda.current_stream()
+            cur.wait_event(pf['event'])
+            coords, rays_index, rays_numsteps, counter = pf['out']
+            # everything allocated on the side stream is consumed on this one
+            for t in (rays_index, rays_numsteps, counter):
+                t.record_stream(cur)
+            for t in data.values():
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(cur)
+        else:
+            coords, rays_index, rays_numsteps, counter = ops.rays_sampler(
+                rays_o, rays_d, self.density_grid_bitfield, aabb, self.near_distance, self.cone_angle_constant,
+                max_samples, self.k1_calls, coords_out=self._coords_buffer(max_samples))
+            self.k1_calls += 1
         self.rays_index = rays_index
         if not is_training:
             n_valid, samples = counter.tolist()      # one host read-back per call (rays_sampler.py:72)
@@ -174,11 +193,50 @@ class NGPGridSampler(nn.Module):
         return data
 
     def _coords_buffer(self, rows):
-        buf = getattr(self, '_coords_buf', None)
+        # two buffers, alternating per K1 launch: the previous launch's rows are still being read by the
+        # previous iteration's backward when a prefetched launch writes the next ones
+        bufs = getattr(self, '_coords_bufs', None)
+        if bufs is None:
+            bufs = self._coords_bufs = [None, None]
+        k = self.k1_calls & 1
+        buf = bufs[k]
         if buf is None or buf.shape[0] < rows or buf.device != self.device:
-            buf = torch.empty((rows, 7), dtype=torch.float32, device=self.device)
-            self._coords_buf = buf
+            buf = bufs[k] = torch.empty((rows, 7), dtype=torch.float32, device=self.device)
         return buf[:rows]
+
+    # ------------------------------------------------------------------ K1 overlap
+    def can_prefetch(self, next_iter):
+        """K1 depends on the rays and the bitfield only -- not on the parameters -- so the march of iteration
+        i+1 can run on a side stream underneath iteration i's (atomic-bound) backward, unless iteration i+1
+        refreshes the occupancy grid first."""
+        return hasattr(self, 'density_grid') and next_iter % self.update_grid_freq != 0
+
+    def side_stream(self):
+        if getattr(self, '_side', None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
+
+    def prefetch(self, data, buffer_free_event=None):
+        """call inside `with torch.cuda.stream(self.side_stream())`, with the batch created there too.
+        `buffer_free_event`: recorded on the compute stream when the iteration BEFORE the current one (the last
+        reader of the coordinate buffer this launch overwrites) had been enqueued completely."""
+        rays_o, rays_d = data['rays_o'], data['rays_d']
+        n_rays = rays_o.shape[0]
+        aabb = (float(self.aabb_range[0]), float(self.aabb_range[1]))
+        max_samples = min(max(self.num_coords_elements, n_rays * 64), n_rays * self.MAX_STEP)
+        side = torch.cuda.current_stream()
+        ev = getattr(self, '_bitfield_event', None)
+        if ev is not None:
+            side.wait_event(ev)
+        if buffer_free_event is not None:
+            side.wait_event(buffer_free_event)
+        out = ops.rays_sampler(rays_o, rays_d, self.density_grid_bitfield, aabb, self.near_distance,
+                               self.cone_angle_constant, max_samples, self.k1_calls,
+                               coords_out=self._coords_buffer(max_samples), ws_tag='k1_side')
+        self.k1_calls += 1
+        done = torch.cuda.Event()
+        done.record(side)
+        self._prefetched = {'rays_o': rays_o, 'max_samples': max_samples, 'out': out, 'event': done}
 
     def update_batch_rays(self, is_training, max_samples=None):
         if is_training and self.iter_n % self.update_grid_freq == (self.update_grid_freq - 1):

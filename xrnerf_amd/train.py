@@ -174,13 +174,18 @@ class Trainer:
         self.rays_done = 0
         self._samples_dev = torch.zeros((1,), dtype=torch.int64, device=device)
         self.lazy_log = True
+        self.overlap_march = True      # run K1 of the next batch on a side stream under this step's backward
+        self._next_batch = None
+        self._ev_done = [None, None]   # completion events of the last two iterations
 
     def step(self):
         net, data = self.net, self.data
         net.sampler.set_iter(self.iter)                                   # PassSamplerIterHook
         for g in self.opt.param_groups:
             g['lr'] = step_lr(self.base_lr, self.iter)
-        batch = data.next_batch()
+        batch, self._next_batch = self._next_batch, None
+        if batch is None:
+            batch = data.next_batch()
         n_rays = batch['rays_o'].shape[0]
         # the reference's DataLoader(batch_size=1) collates a leading batch axis that train_step unfolds
         batch = {k: v[None] for k, v in batch.items()}
@@ -195,6 +200,17 @@ class Trainer:
         self.iter += 1
         self.rays_done += n_rays
         self._samples_dev += net.sampler.n_valid_dev          # stays on the device
+        if self.overlap_march:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self._ev_done = [self._ev_done[1], ev]
+            if net.sampler.can_prefetch(self.iter):
+                side = net.sampler.side_stream()
+                with torch.cuda.stream(side):
+                    nb = data.next_batch()
+                    # the launch writes the coordinate buffer last read by the PREVIOUS iteration
+                    net.sampler.prefetch(nb, buffer_free_event=self._ev_done[0])
+                self._next_batch = nb
         return out
 
     @property
