@@ -150,6 +150,16 @@ def main():
     json.dump(keep, open(os.path.join(HERE, 'ngp_model_cfg.json'), 'w'), indent=1, sort_keys=True)
     print('ngp_model_cfg.json ok')
 
+    # the pybind surface of the extension module: function -> parameter names (pybind_api.h:4-95)
+    import re
+    src = re.sub(r'//.*', '', open(os.path.join(REF, 'extensions/ngp_raymarch/include/pybind_api.h')).read())
+    api = {}
+    for m in re.finditer(r'void\s+(\w+_api)\s*\((.*?)\)\s*;', src, flags=re.S):
+        params = [q.strip() for q in m.group(2).split(',') if q.strip()]
+        api[m.group(1)] = [re.split(r'[\s&\*]+', q)[-1] for q in params]
+    json.dump(api, open(os.path.join(HERE, 'raymarch_cuda_api.json'), 'w'), indent=1, sort_keys=True)
+    print('raymarch_cuda_api.json ok')
+
 
 if __name__ == '__main__':
     main()

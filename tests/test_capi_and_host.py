@@ -88,6 +88,19 @@ def test_reference_config_builds_unchanged():
         xrnerf_amd.build_network(dict(type='NoSuchNetwork'))
 
 
+def test_raymarch_cuda_shim_matches_reference_pybind_surface():
+    """extension-module boundary: same ten names, same arity and parameter order as pybind_api.h:4-95"""
+    import inspect
+    from xrnerf_amd import raymarch_cuda as rc
+    api = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'raymarch_cuda_api.json')))
+    assert len(api) == 10
+    for name, params in api.items():
+        fn = getattr(rc, name)
+        mine = list(inspect.signature(fn).parameters)
+        assert len(mine) == len(params), (name, mine, params)
+        assert mine == params, (name, mine, params)
+
+
 def test_hidden_layer_key_policy(monkeypatch):
     from xrnerf_amd.mlps import _hidden_layers
     assert _hidden_layers({'num_layers': 2}) == 2 and _hidden_layers({'n_hidden_layers': 3, 'num_layers': 1}) == 3
