@@ -127,21 +127,37 @@ __global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_bwd(GridMeta gm, uint32_t
     if (n_dev) n = min(n, *n_dev);
     const uint32_t q = threadIdx.x & 15, group = threadIdx.x >> 4;
     const uint32_t f = q & 1, cx = (q >> 1) & 1, cy = (q >> 2) & 1, cz = (q >> 3) & 1;
-    const uint32_t i0 = sb * (bw_ch * (EN_BLOCK / 16)) + group * bw_ch;
-    if (i0 >= n) return;
-    const uint32_t i1 = min(i0 + bw_ch, n);
+    const uint32_t b0 = sb * BW_SAMPLES_PER_BLOCK;
+    if (b0 >= n) return;                                     // uniform for the block
+    const uint32_t bn = min((uint32_t)BW_SAMPLES_PER_BLOCK, n - b0);
+    // Stage the block's positions and feature gradients in LDS with coalesced loads.  The walk below
+    // then touches global memory ONLY through atomics: LDS reads count on lgkmcnt, so no vector-memory
+    // wait ever sits between two atomic issues (a global load per sample would order every atomic
+    // behind it -- vmcnt retires in order -- and expose the full atomic latency per sample).
+    __shared__ float s_x[BW_SAMPLES_PER_BLOCK * 3];
+    __shared__ float s_d[2][BW_SAMPLES_PER_BLOCK];
+    for (uint32_t e = threadIdx.x; e < bn * 3; e += EN_BLOCK) {
+        const uint32_t i = e / 3, k = e - 3 * i;
+        s_x[e] = x[(size_t)(b0 + i) * x_stride + k];
+    }
+    for (uint32_t e = threadIdx.x; e < bn; e += EN_BLOCK) {
+        s_d[0][e] = denc_t[(size_t)(2 * l) * ld + b0 + e];
+        s_d[1][e] = denc_t[(size_t)(2 * l + 1) * ld + b0 + e];
+    }
+    __syncthreads();
+    const uint32_t i0 = group * bw_ch;
+    if (i0 >= bn) return;
+    const uint32_t i1 = min(i0 + bw_ch, bn);
     const float scale = gm.scale[l];
     const uint32_t res = gm.res[l], hsize = gm.off[l + 1] - gm.off[l];
     const bool hashed = (hashed_mask >> l) & 1;
     float* __restrict__ tab = grad_table + 2 * (size_t)gm.off[l] + f;
-    const float* __restrict__ dsrc = denc_t + (size_t)(2 * l + f) * ld;
     uint32_t c0 = 0xffffffffu, c1 = 0xffffffffu, c2 = 0xffffffffu;   // current cell
     float acc = 0.f;
     float* dst = tab;
     for (uint32_t i = i0; i < i1; ++i) {
-        const float d = dsrc[i];
-        const float* xp = x + (size_t)i * x_stride;
-        const float p0 = xp[0] * scale + 0.5f, p1 = xp[1] * scale + 0.5f, p2 = xp[2] * scale + 0.5f;
+        const float d = s_d[f][i];
+        const float p0 = s_x[3 * i] * scale + 0.5f, p1 = s_x[3 * i + 1] * scale + 0.5f, p2 = s_x[3 * i + 2] * scale + 0.5f;
         const float f0 = floorf(p0), f1 = floorf(p1), f2 = floorf(p2);
         const uint32_t g0 = (uint32_t)(int)f0, g1 = (uint32_t)(int)f1, g2 = (uint32_t)(int)f2;
         const float w0 = p0 - f0, w1 = p1 - f1, w2 = p2 - f2;
