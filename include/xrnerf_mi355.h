@@ -197,6 +197,12 @@ int xr_adam_step(float* p, const float* g, float* m, float* v, size_t n, int ste
                  float beta2, float eps, float weight_decay, float* ema /*nullable*/, float ema_momentum,
                  void* stream);
 
+/* the same update for up to 4 parameter tensors in ONE launch; arrays are HOST arrays of device pointers /
+ * element counts (ema may be NULL, or hold NULL entries) */
+int xr_adam_step_multi(int n_tensors, float* const* p_host, const float* const* g_host, float* const* m_host,
+                       float* const* v_host, float* const* ema_host, const size_t* n_host, int step, float lr,
+                       float beta1, float beta2, float eps, float weight_decay, float ema_momentum, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

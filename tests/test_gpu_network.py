@@ -66,7 +66,9 @@ def test_overlapped_march_matches_serial(dev):
         la.append(a.step()['log_vars']['loss']); na.append(a.net.sampler.n_valid_dev.clone())
         lb.append(b.step()['log_vars']['loss']); nb.append(b.net.sampler.n_valid_dev.clone())
     torch.cuda.synchronize()
-    assert [int(x) for x in na[:17]] == [int(x) for x in nb[:17]]       # identical marches while the grids agree bit for bit
+    # iterations 0..15 march through the SAME bitfield (built at iteration 0 from identical weights): identical counts.
+    # From the refresh at iteration 16 on, the two runs differ by float-atomic ordering in their gradients.
+    assert [int(x) for x in na[:16]] == [int(x) for x in nb[:16]]
     la, lb = torch.stack(la).cpu().numpy(), torch.stack(lb).cpu().numpy()
     assert np.abs(la - lb).max() <= 2e-2 * np.abs(lb).max()
     assert a.net.sampler.n_rays_per_batch == b.net.sampler.n_rays_per_batch

@@ -162,6 +162,63 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
         if (ema) ema[i] = (1.f - mom) * ema[i] + mom * pp;
     }
 }
+// up to 4 parameter tensors in ONE launch (the three tensors of HashNerfMLP: 12.2 M + 3 K + 7 K floats):
+// block ranges are assigned proportionally, every tensor gets at least one block
+struct AdamTensors { float* p[4]; const float* g[4]; float* m[4]; float* v[4]; float* ema[4]; unsigned long long n[4]; unsigned first_block[5]; };
+__global__ __launch_bounds__(256) void k_adam_multi(AdamTensors t, int nt, float b1, float b2, float step_size, float bc2s,
+                                                     float eps, float wd, float mom) {
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < 4; ++j) if (j < nt && blockIdx.x >= t.first_block[j]) k = j;
+    const unsigned nblk = t.first_block[k + 1] - t.first_block[k], blk = blockIdx.x - t.first_block[k];
+    float* __restrict__ p = t.p[k]; const float* __restrict__ g = t.g[k];
+    float* __restrict__ m = t.m[k]; float* __restrict__ v = t.v[k]; float* __restrict__ ema = t.ema[k];
+    const size_t n = t.n[k], n4 = n / 4;
+    for (size_t i = blk * 256ull + threadIdx.x; i < n4; i += (size_t)nblk * 256) {
+        float4 pp = ((float4*)p)[i], mm = ((float4*)m)[i], vv = ((float4*)v)[i];
+        const float4 gg = ((const float4*)g)[i];
+        adam1(pp.x, gg.x, mm.x, vv.x, b1, b2, step_size, bc2s, eps, wd);
+        adam1(pp.y, gg.y, mm.y, vv.y, b1, b2, step_size, bc2s, eps, wd);
+        adam1(pp.z, gg.z, mm.z, vv.z, b1, b2, step_size, bc2s, eps, wd);
+        adam1(pp.w, gg.w, mm.w, vv.w, b1, b2, step_size, bc2s, eps, wd);
+        ((float4*)p)[i] = pp; ((float4*)m)[i] = mm; ((float4*)v)[i] = vv;
+        if (ema) {
+            float4 e = ((float4*)ema)[i];
+            e.x = (1.f - mom) * e.x + mom * pp.x; e.y = (1.f - mom) * e.y + mom * pp.y;
+            e.z = (1.f - mom) * e.z + mom * pp.z; e.w = (1.f - mom) * e.w + mom * pp.w;
+            ((float4*)ema)[i] = e;
+        }
+    }
+    if (blk == 0 && threadIdx.x < (n & 3)) {
+        const size_t i = n4 * 4 + threadIdx.x;
+        float pp = p[i], mm = m[i], vv = v[i];
+        adam1(pp, g[i], mm, vv, b1, b2, step_size, bc2s, eps, wd);
+        p[i] = pp; m[i] = mm; v[i] = vv;
+        if (ema) ema[i] = (1.f - mom) * ema[i] + mom * pp;
+    }
+}
+extern "C" int xr_adam_step_multi(int n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v,
+                                  float* const* ema, const size_t* n, int step, float lr, float beta1, float beta2, float eps,
+                                  float weight_decay, float ema_momentum, void* stream_) {
+    XR_REQUIRE(n_tensors >= 1 && n_tensors <= 4 && p && g && m && v && n && step >= 1, "bad argument");
+    AdamTensors t; memset(&t, 0, sizeof(t));
+    unsigned blocks = 0;
+    for (int k = 0; k < n_tensors; ++k) {
+        XR_REQUIRE(p[k] && g[k] && m[k] && v[k] && n[k] > 0, "null tensor");
+        XR_REQUIRE((((uintptr_t)p[k] | (uintptr_t)g[k] | (uintptr_t)m[k] | (uintptr_t)v[k] | (uintptr_t)(ema ? ema[k] : nullptr)) & 15) == 0,
+                   "buffers must be 16-byte aligned");
+        t.p[k] = p[k]; t.g[k] = g[k]; t.m[k] = m[k]; t.v[k] = v[k]; t.ema[k] = ema ? ema[k] : nullptr; t.n[k] = n[k];
+        t.first_block[k] = blocks;
+        blocks += min(xr_div_up(n[k] / 4 + 1, 256), 2048u);
+    }
+    for (int k = n_tensors; k <= 4; ++k) t.first_block[k] = blocks;
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(k_adam_multi, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, t, n_tensors, beta1, beta2, lr / bc1,
+                       sqrtf(bc2), eps, weight_decay, ema_momentum);
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}
+
 extern "C" int xr_adam_step(float* p, const float* g, float* m, float* v, size_t n, int step, float lr, float beta1,
                             float beta2, float eps, float weight_decay, float* ema, float ema_momentum, void* stream_) {
     if (n == 0) return XR_OK;

@@ -113,8 +113,10 @@ __device__ __forceinline__ void layer_fwd(const float* __restrict__ W, const f32
             }
         }
 }
-// gin[TI] = W^T . g[TO]     (W is [TO*32][TI*32], stride TI*32+1)
-template <int TO, int TI, bool SB = true>
+// gin[TI] = W^T . g[TO]     (W is [TO*32][TI*32], stride TI*32+1).  RSTEPS < 16: only the first RSTEPS
+// register rows of g can be non-zero (output layers: 16 real neurons -> 8, colour gradient -> 3), the
+// K-steps that would multiply zeros are not issued.
+template <int TO, int TI, bool SB = true, int RSTEPS = 16>
 __device__ __forceinline__ void layer_bwd(const float* __restrict__ W, const f32x16 (&g)[TO], f32x16 (&gin)[TI], int col, int hi) {
     constexpr int ST = TI * 32 + 1;
 #pragma unroll
@@ -125,7 +127,7 @@ __device__ __forceinline__ void layer_bwd(const float* __restrict__ W, const f32
 #pragma unroll
     for (int to = 0; to < TO; ++to)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = 0; r < RSTEPS; ++r) {
             if (SB && (r & 3) == 0) __builtin_amdgcn_sched_barrier(0);
             const float b = g[to][r];
 #pragma unroll
@@ -342,7 +344,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void k_nerf_mlp_bwd_1_2(
         g1[0][0] = dr.x; g1[0][1] = dr.y; g1[0][2] = dr.z;             // hi==1 lanes hold zeros
         // color output layer
         dw_accumulate<1, 2, false>(a_c2, g1, hc2, stage, col, hi);
-        layer_bwd<1, 2, false>(wc + SC::lds_off(2), g1, g2, col, hi);
+        layer_bwd<1, 2, false, 3>(wc + SC::lds_off(2), g1, g2, col, hi);   // rows 0..2 (rgb) only
         relu_mask(g2[0], hc2[0]); relu_mask(g2[1], hc2[1]);
         // color hidden layer 2
         dw_accumulate<2, 2, false>(a_c1, g2, hc1, stage, col, hi);
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void k_nerf_mlp_bwd_1_2(
         if (hi == 0) g1[0][0] = dr.w;
         // density output layer
         dw_accumulate<1, 2, false>(a_d1, g1, hd, stage, col, hi);
-        layer_bwd<1, 2, false>(wd + SD::lds_off(1), g1, g2, col, hi);
+        layer_bwd<1, 2, false, 8>(wd + SD::lds_off(1), g1, g2, col, hi);   // 16 real output neurons
         relu_mask(g2[0], hd[0]); relu_mask(g2[1], hd[1]);
         // density input layer
         dw_accumulate<2, 1, false>(a_d0, g2, xe, stage, col, hi);

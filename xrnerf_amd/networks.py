@@ -117,6 +117,23 @@ class _FusedTrainStepFn(torch.autograd.Function):
         return g_table.mul_(g), g_wd.mul_(g), g_wc.mul_(g), None, None
 
 
+class _LazyPsnr:
+    """PSNR of the alpha-masked prediction (networks/hashnerf.py:40-42), evaluated only when somebody looks
+    (float() / .item()): the three tiny elementwise launches and the read-back stay off the training loop"""
+
+    def __init__(self, loss_mse, bs):
+        self._t, self._bs = loss_mse, bs
+
+    def tensor(self):
+        with torch.no_grad():
+            return mse2psnr(self._t[1] / (3.0 * self._bs))
+
+    def item(self):
+        return float(self.tensor())
+
+    __float__ = item
+
+
 class BaseNerfNetwork(nn.Module):
     def __init__(self, **kwarg):
         super().__init__()
@@ -175,12 +192,12 @@ class HashNerfNetwork(BaseNerfNetwork):
         loss, rgb = _FusedTrainStepFn.apply(self.mlp.embedder_pos.params, self.mlp.density_net.params,
                                             self.mlp.color_net.params, self, data)
         bs = rgb.shape[0]
-        with torch.no_grad():
-            mse_loss = self._last['loss_mse'][1] / (3.0 * bs)        # img2mse of the alpha-masked images
-            psnr = mse2psnr(mse_loss)
         if kwargs.get('lazy_log', False):
-            log_vars = {'loss': loss.detach(), 'psnr': psnr}
+            log_vars = {'loss': loss.detach(), 'psnr': _LazyPsnr(self._last['loss_mse'], bs)}
         else:
+            with torch.no_grad():
+                mse_loss = self._last['loss_mse'][1] / (3.0 * bs)        # img2mse of the alpha-masked images
+                psnr = mse2psnr(mse_loss)
             log_vars = {'loss': loss.item(), 'psnr': psnr.item()}
         return {'loss': loss, 'log_vars': log_vars, 'num_samples': bs}
 

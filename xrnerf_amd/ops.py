@@ -369,3 +369,17 @@ def adam_step(p, g, m, v, step, lr=1e-2, beta1=0.9, beta2=0.99, eps=1e-15, weigh
     with _span('xr_adam_step', p.numel()):
       _lib.check(_lib.load().xr_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), step, lr, beta1, beta2, eps,
                                         weight_decay, _ptr(ema), ema_momentum, _stream()), 'xr_adam_step')
+
+
+def adam_step_multi(ps, gs, ms, vs, step, lr=1e-2, beta1=0.9, beta2=0.99, eps=1e-15, weight_decay=1e-6, emas=None,
+                    ema_momentum=0.05):
+    """one launch for up to 4 tensors"""
+    k = len(ps)
+    arr = lambda ts: (C.c_void_p * k)(*[t.data_ptr() if t is not None else None for t in ts])
+    for t in list(ps) + list(gs) + list(ms) + list(vs):
+        _ptr(t)     # validates device / contiguity
+    ns = (C.c_size_t * k)(*[p.numel() for p in ps])
+    with _span('xr_adam_step', sum(p.numel() for p in ps)):
+        _lib.check(_lib.load().xr_adam_step_multi(k, arr(ps), arr(gs), arr(ms), arr(vs), arr(emas) if emas else None, ns,
+                                                  step, lr, beta1, beta2, eps, weight_decay, ema_momentum, _stream()),
+                   'xr_adam_step_multi')

@@ -51,6 +51,7 @@ class FusedAdam(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         for group in self.param_groups:
+            todo = []
             for p in group['params']:
                 if p.grad is None or p.numel() == 0:
                     continue
@@ -62,9 +63,16 @@ class FusedAdam(torch.optim.Optimizer):
                     if group['ema_momentum'] is not None:
                         st['ema'] = p.detach().clone()
                 st['step'] += 1
-                ops.adam_step(p, p.grad.contiguous(), st['m'], st['v'], st['step'], group['lr'], group['betas'][0],
-                              group['betas'][1], group['eps'], group['weight_decay'], st.get('ema'),
-                              group['ema_momentum'] or 0.0)
+                todo.append((p, p.grad if p.grad.is_contiguous() else p.grad.contiguous(), st))
+            # tensors that share a step count go out in one launch (up to 4 per launch)
+            while todo:
+                chunk = [t for t in todo[:4] if t[2]['step'] == todo[0][2]['step']]
+                todo = [t for t in todo if all(t is not c for c in chunk)]
+                emas = [c[2].get('ema') for c in chunk] if group['ema_momentum'] is not None else None
+                ops.adam_step_multi([c[0] for c in chunk], [c[1] for c in chunk], [c[2]['m'] for c in chunk],
+                                    [c[2]['v'] for c in chunk], chunk[0][2]['step'], group['lr'], group['betas'][0],
+                                    group['betas'][1], group['eps'], group['weight_decay'], emas,
+                                    group['ema_momentum'] or 0.0)
 
 
 def step_lr(base_lr, it, step=10000, gamma=0.2):
