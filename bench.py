@@ -110,7 +110,10 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: there is no CPU path')
-    rank, local, world = xdist.init_from_env('nccl')
+    # XRNERF_DIST_BACKEND=gloo + XRNERF_SHARE_GPU=1: protocol test of the N>1 path on a single-GPU box
+    rank, local, world = xdist.init_from_env(os.environ.get('XRNERF_DIST_BACKEND', 'nccl'))
+    if os.environ.get('XRNERF_SHARE_GPU') == '1':
+        local = 0
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run' % (args.gpus, world))
     torch.cuda.set_device(local)

@@ -145,8 +145,50 @@ def main():
     np.savez_compressed(os.path.join(HERE, 'ref_python.npz'), **py)
     print('ref_python.npz ok')
 
+    # ---------------- vanilla NeRF (BASELINE config #1) through the reference's OWN modules, small widths
+    sys.path.insert(0, HERE)
+    import ref_import
+    R = ref_import.load()
+    torch.manual_seed(0)
+    mcfg = dict(skips=[2], netdepth=4, netwidth=32, output_ch=5, use_viewdirs=True, netchunk=1024 * 32,
+                embedder=dict(type='BaseEmbedder', i_embed=0, multires=10, multires_dirs=4))
+    ref_mlp, ref_fine = R.NerfMLP(**mcfg), R.NerfMLP(**mcfg)
+    ref_render = R.NerfRender(white_bkgd=True, raw_noise_std=0)
+    van = {}
+    n_rays, n_s = 48, 16
+    g = torch.Generator().manual_seed(1)
+    rays_o = torch.randn(n_rays, 3, generator=g) * 0.1 + torch.tensor([0., 0., 4.])
+    rays_d = torch.nn.functional.normalize(torch.randn(n_rays, 3, generator=g) * 0.2 - torch.tensor([0., 0., 1.]), dim=-1) * 1.3
+    viewdirs = rays_d / rays_d.norm(dim=-1, keepdim=True)
+    t = torch.linspace(0., 1., n_s)
+    z = (2. * (1 - t) + 6. * t).expand(n_rays, n_s)
+    t_rand = torch.rand(n_rays, n_s, generator=g)
+    mids = .5 * (z[..., 1:] + z[..., :-1])
+    z = torch.cat([z[..., :1], mids], -1) + (torch.cat([mids, z[..., -1:]], -1) - torch.cat([z[..., :1], mids], -1)) * t_rand
+    pts = rays_o[..., None, :] + rays_d[..., None, :] * z[..., :, None]
+    data = {'pts': pts, 'viewdirs': viewdirs, 'z_vals': z, 'rays_o': rays_o, 'rays_d': rays_d}
+    with torch.no_grad():
+        data = ref_mlp(data)
+        van['coarse_raw'] = data['raw'].numpy().copy()
+        data, ret = ref_render(data, False)
+        van['coarse_rgb'], van['coarse_disp'], van['coarse_acc'] = ret['rgb'].numpy(), ret['disp'].numpy(), ret['acc'].numpy()
+        van['coarse_weights'] = data['weights'].numpy().copy()
+        data = R.sample_pdf(data, 24, False, True)                  # deterministic u
+        van['fine_z'] = data['z_vals'].numpy().copy()
+        data = ref_fine(data)
+        _, fret = ref_render(data, True)
+        van['fine_rgb'] = fret['rgb'].numpy()
+    for k, v in ref_mlp.state_dict().items():
+        van['sd_coarse.' + k] = v.numpy()
+    for k, v in ref_fine.state_dict().items():
+        van['sd_fine.' + k] = v.numpy()
+    van.update(rays_o=rays_o.numpy(), rays_d=rays_d.numpy(), viewdirs=viewdirs.numpy(), z_vals=z.numpy(), t_rand=t_rand.numpy())
+    np.savez_compressed(os.path.join(HERE, 'ref_vanilla_nerf.npz'), **van)
+    print('ref_vanilla_nerf.npz ok', sum(v.nbytes for v in van.values()) // 1024, 'KiB raw')
+
     cfg = runpy.run_path(os.path.join(REF, 'configs/instant_ngp/nerf_blender_local01.py'))
     keep = {k: cfg[k] for k in ('model', 'optimizer', 'lr_config', 'custom_hooks', 'max_iters', 'N_rand_per_sampler')}
+    keep['vanilla_model'] = runpy.run_path(os.path.join(REF, 'configs/nerf/nerf_blender_base01.py'))['model']
     json.dump(keep, open(os.path.join(HERE, 'ngp_model_cfg.json'), 'w'), indent=1, sort_keys=True)
     print('ngp_model_cfg.json ok')
 

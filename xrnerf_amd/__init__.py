@@ -6,6 +6,6 @@ Importing the package registers the reference's type names (`HashNerfNetwork`, `
 """
 from . import builder  # noqa: F401
 from .builder import build_embedder, build_mlp, build_network, build_render, build_sampler  # noqa: F401
-from . import mlps, networks, renders, samplers  # noqa: F401,E402
+from . import mlps, networks, renders, samplers, vanilla  # noqa: F401,E402
 
 __version__ = '0.1.0'

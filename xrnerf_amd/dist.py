@@ -26,7 +26,7 @@ def init_from_env(backend=None):
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-        if backend == 'nccl':
+        if backend == 'nccl' and torch.cuda.is_available():
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
@@ -60,6 +60,11 @@ def gather_image(tile, H, rank, world_size):
     padded = torch.zeros((max_rows, W, Cn), dtype=tile.dtype, device=tile.device)
     padded[:tile.shape[0]] = tile
     out = torch.empty((world_size, max_rows, W, Cn), dtype=tile.dtype, device=tile.device)
-    dist.all_gather_into_tensor(out.view(-1), padded.view(-1))
+    if dist.get_backend() == 'gloo':      # gloo has no all_gather_into_tensor for device tensors
+        parts = [torch.empty_like(padded) for _ in range(world_size)]
+        dist.all_gather(parts, padded)
+        out = torch.stack(parts, 0)
+    else:
+        dist.all_gather_into_tensor(out.view(-1), padded.view(-1))
     rows = [out[r, :row_band(H, r, world_size)[1]] for r in range(world_size)]
     return torch.cat(rows, 0)
