@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 
 from xrnerf_amd import dist as xdist  # noqa: E402
 from xrnerf_amd import ops  # noqa: E402
-from xrnerf_amd.train import Trainer, render_frame  # noqa: E402
+from xrnerf_amd.train import Trainer, render_frame, render_frame_ert  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0         # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # same guide: fp32-input MFMA = the fp32 vector rate
@@ -96,6 +96,40 @@ def cpu_baseline(seconds_budget=20.0):
     return {'value': rays_done / el, 'unit': 'rays/s', 'cores': 1, 'kind': 'port',
             'sample': '%d training iterations of %d rays (K1+encode+MLP+K3+Huber+K4+backward+Adam over 12.2M params), '
                       'oracle/ngp_oracle.c, 1 thread, ray generation excluded' % (it, n_rays)}
+
+
+def cpu_vanilla_nerf(seconds_budget=8.0):
+    """BASELINE config #1 on the host: the vanilla-NeRF pure-PyTorch path (xrnerf_amd/vanilla.py, validated
+    against the reference's own modules in tests/test_vanilla_nerf.py), 1024-ray batch, 64 coarse + 128 fine
+    samples, forward + backward, all host cores."""
+    import xrnerf_amd
+    from xrnerf_amd import vanilla
+    cfg = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'ngp_model_cfg.json')))['vanilla_model']
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    net = xrnerf_amd.build_network(cfg)
+    n = 1024
+    rays_o = torch.tensor([[0., 0., 4.]]).repeat(n, 1)
+    rays_d = torch.nn.functional.normalize(torch.randn(n, 3) * 0.15 - torch.tensor([0., 0., 1.]), dim=-1)
+    tgt = torch.rand(n, 3)
+    its, t0 = 0, None
+    while True:
+        z = vanilla.get_z_vals(rays_o, 2., 6., 64, randomized=True)
+        data = {'rays_o': rays_o[None], 'rays_d': rays_d[None], 'viewdirs': rays_d[None], 'z_vals': z[None],
+                'pts': vanilla.get_pts(rays_o, rays_d, z)[None], 'target_s': tgt[None]}
+        net.zero_grad()
+        net.train_step(data, None)['loss'].backward()
+        if t0 is None:
+            t0 = time.time()          # first iteration = warm-up
+            continue
+        its += 1
+        if time.time() - t0 > seconds_budget or its >= 20:
+            break
+    el = time.time() - t0
+    return {'value': its * n / el, 'unit': 'rays/s', 'cores': threads, 'kind': 'port',
+            'sample': '%d forward+backward iterations of configs/nerf/nerf_blender_base01.py (1024 rays, 64+128 samples, '
+                      '2 x 8x256 MLP), pure PyTorch on the host' % its}
 
 
 def main():
@@ -198,6 +232,19 @@ def main():
         barrier()
         extra['render_ms_per_800x800_frame'] = (time.perf_counter() - t1) * 1e3 / n_frames
         extra['render_samples_per_ray'] = float(tr.net.sampler.coords.shape[0]) / max(1, nrows * W)
+        # optional early-terminated rendering (pixels within 1e-4 of the full evaluation, tests/test_gpu_network.py)
+        for _ in range(2):
+            rgb, alpha = render_frame_ert(tr.net, pose, H, W, tr.data.focal, row0=row0, nrows=nrows)
+            xdist.gather_image(torch.cat([rgb, alpha], -1), H, rank, world)
+        barrier()
+        t1 = time.perf_counter()
+        for f in range(n_frames):
+            rgb, alpha = render_frame_ert(tr.net, tr.data.poses[f % tr.data.n_img], H, W, tr.data.focal, row0=row0, nrows=nrows)
+            img = xdist.gather_image(torch.cat([rgb, alpha], -1), H, rank, world)
+        barrier()
+        extra['render_ms_per_800x800_frame_early_termination_1e-4'] = (time.perf_counter() - t1) * 1e3 / n_frames
+        ev, tot = render_frame_ert.last_evaluated
+        extra['render_early_termination_evaluated_fraction'] = ev / max(tot, 1)
 
     if rank == 0:
         out = {
@@ -217,6 +264,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
             out['cpu_baseline']['host_cores_available'] = os.cpu_count()
+            out['cpu_baseline_vanilla_nerf_config1'] = cpu_vanilla_nerf()
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

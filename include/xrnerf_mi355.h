@@ -103,6 +103,21 @@ int xr_calc_rgb_inference(const float* network_output, const float* coords, cons
                           float bg_r, float bg_g, float bg_b, uint32_t n_rays, int rgb_activation,
                           int density_activation, float* rgb_output, float* alpha_output, void* stream);
 
+/* Optional early-terminated rendering (the reference's K5 walks every sample; its EPSILON is unused,
+ * calc_rgb.cu:178).  A frame is evaluated in depth slices [s0,s1) of per-ray sample indices:
+ *   xr_render_slice_select   : rays with T > eps and more than s0 samples contribute rows
+ *                              base+s0 .. base+min(n,s1)-1 to rows_out (compacted; count_out[0] = rows;
+ *                              ray_offset_out[i] = first slot of ray i or -1)
+ *   (encode + MLP on those rows through the `rows` arguments of xr_hashgrid_fwd / xr_nerf_mlp_fwd)
+ *   xr_render_slice_composite: continues the front-to-back integration of K5 for the selected rays;
+ *                              T [n_rays] and rgb_acc [n_rays,3] carry the state (init 1 and 0).
+ * Final pixel = rgb_acc + T*bg, alpha = 1 - T; differs from K5 by < eps. */
+int xr_render_slice_select(const int32_t* rays_numsteps, const float* T, uint32_t n_rays, uint32_t s0, uint32_t s1,
+                           float eps, uint32_t* rows_out, int32_t* ray_offset_out, uint32_t* count_out, void* stream);
+int xr_render_slice_composite(const float* raw_slice /*[count,4]*/, const float* coords, const int32_t* rays_numsteps,
+                              const int32_t* ray_offset, uint32_t n_rays, uint32_t s0, uint32_t s1, int rgb_activation,
+                              int density_activation, float* T, float* rgb_acc, void* stream);
+
 /* K6  generate_grid_samples_nerf_nonuniform_api (src/generate_grid_samples_nerf_nonuniform.cu:44-87) */
 int xr_generate_grid_samples(const float* density_grid, uint32_t ema_step, uint32_t n_elements,
                              uint32_t n_cascades /* = max_cascade+1 */, float thresh, float aabb0, float aabb1,
@@ -144,8 +159,9 @@ void xr_hashgrid_meta(int n_levels, int log2_hashmap_size, int base_resolution, 
                       float* scale_host, uint32_t* resolution_host, uint32_t* offset_host /*[L+1]*/);
 /* `n_dev` (nullable, device): when given, only min(n, *n_dev) rows are processed -- the row count
  * then never has to be read back to the host (n is the launch-sizing upper bound). */
+/* `rows` (nullable, device): sample i reads its position from row rows[i] of x (render depth slices) */
 int xr_hashgrid_fwd(const float* table, const float* x, uint32_t x_stride, uint32_t n, const uint32_t* n_dev,
-                    int n_levels, const float* scale_host, const uint32_t* resolution_host,
+                    const uint32_t* rows, int n_levels, const float* scale_host, const uint32_t* resolution_host,
                     const uint32_t* offset_host, float* enc_t, uint32_t ld, void* stream);
 /* grad_table[idx,f] += w * denc_t[2l+f][i]; caller zero-fills grad_table */
 int xr_hashgrid_bwd(const float* x, uint32_t x_stride, const float* denc_t, uint32_t ld, uint32_t n,
@@ -161,7 +177,7 @@ int xr_sh4(const float* dirs, uint32_t dir_stride, uint32_t n, float* out, void*
  * Weights: tcnn `params` layout = row-major [out,in] matrices in layer order, out padded to 16.
  * dirs may be NULL (run_density, hashnerf_mlp.py:107-111: only raw[:,3] is meaningful then). */
 int xr_nerf_mlp_fwd(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
-                    const uint32_t* n_dev, const float* w_density, const float* w_color, int n_hidden_density, int n_hidden_color,
+                    const uint32_t* n_dev, const uint32_t* rows /* nullable: dirs row of sample i */, const float* w_density, const float* w_color, int n_hidden_density, int n_hidden_color,
                     float pad_value, float* raw /*[n,4]*/, void* stream);
 /* backward of the above given dL/draw [n,4]: writes denc_t [32][ld] (for xr_hashgrid_bwd) and
  * ACCUMULATES weight gradients into grad_w_density / grad_w_color (caller zero-fills).

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.xr_version() >= 100
     assert lib.xr_rays_sampler_workspace_bytes(4096) > 3 * 4 * 4096
     # an invalid call fails loudly with a message, it does not crash or fall back
-    rc = lib.xr_hashgrid_fwd(None, None, 3, 5, None, 16, None, None, None, None, 5, None)
+    rc = lib.xr_hashgrid_fwd(None, None, 3, 5, None, None, 16, None, None, None, None, 5, None)
     assert rc == -22 and b'null' in lib.xr_last_error()
 
 

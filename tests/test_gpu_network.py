@@ -72,3 +72,22 @@ def test_overlapped_march_matches_serial(dev):
     la, lb = torch.stack(la).cpu().numpy(), torch.stack(lb).cpu().numpy()
     assert np.abs(la - lb).max() <= 2e-2 * np.abs(lb).max()
     assert a.net.sampler.n_rays_per_batch == b.net.sampler.n_rays_per_batch
+
+
+def test_early_terminated_render_within_eps_of_full_render(dev):
+    """optional ERT path: identical to the reference-behaviour render to within eps = 1e-4 (north_star's RGB bar)"""
+    from xrnerf_amd.train import render_frame, render_frame_ert
+    tr = make(dev)
+    for _ in range(150):
+        tr.step()
+    sampler = tr.net.sampler
+    calls = sampler.k1_calls
+    full_rgb, full_a = render_frame(tr.net, tr.data.poses[1], 96, 96, tr.data.focal)
+    sampler.k1_calls = calls                     # same hidden-RNG position -> same jittered samples
+    ert_rgb, ert_a = render_frame_ert(tr.net, tr.data.poses[1], 96, 96, tr.data.focal, eps=1e-4)
+    assert float((full_rgb - ert_rgb).abs().max()) <= 1.5e-4 and float((full_a - ert_a).abs().max()) <= 1.5e-4
+    ev, total = render_frame_ert.last_evaluated
+    assert 0 < ev <= total
+    sampler.k1_calls = calls                     # eps = 0 never terminates: bit-for-bit the same integration order
+    z_rgb, z_a = render_frame_ert(tr.net, tr.data.poses[1], 96, 96, tr.data.focal, eps=-1.0)
+    assert float((full_rgb - z_rgb).abs().max()) <= 2e-6 and render_frame_ert.last_evaluated[0] == total

@@ -21,6 +21,8 @@ SIGNATURES = {
     'xr_rays_sampler': (_i32, [_vp, _vp, _vp, _u32, _f, _f, _f, _f, _u32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'xr_compacted_coord': (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'xr_clip_numsteps': (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _vp]),
+    'xr_render_slice_select': (_i32, [_vp, _vp, _u32, _u32, _u32, _f, _vp, _vp, _vp, _vp]),
+    'xr_render_slice_composite': (_i32, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _i32, _i32, _vp, _vp, _vp]),
     'xr_calc_rgb_forward': (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, _i32, _i32, _vp, _vp]),
     'xr_calc_rgb_backward': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _i32, _i32, _vp, _vp]),
     'xr_calc_rgb_inference': (_i32, [_vp, _vp, _vp, _f, _f, _f, _u32, _i32, _i32, _vp, _vp, _vp]),
@@ -32,10 +34,10 @@ SIGNATURES = {
     'xr_update_bitfield': (_i32, [_vp, _vp, _vp, _vp, _sz, _vp]),
     'xr_bitfield_from_mean': (_i32, [_vp, _vp, _vp, _vp]),
     'xr_hashgrid_meta': (None, [_i32, _i32, _i32, _d, _vp, _vp, _vp]),
-    'xr_hashgrid_fwd': (_i32, [_vp, _vp, _u32, _u32, _vp, _i32, _vp, _vp, _vp, _vp, _u32, _vp]),
+    'xr_hashgrid_fwd': (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _u32, _vp]),
     'xr_hashgrid_bwd': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     'xr_sh4': (_i32, [_vp, _u32, _u32, _vp, _vp]),
-    'xr_nerf_mlp_fwd': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp]),
+    'xr_nerf_mlp_fwd': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp]),
     'xr_nerf_mlp_bwd_workspace_bytes': (_sz, [_u32]),
     'xr_nerf_mlp_bwd': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'xr_gen_rays': (_i32, [_vp, _i32, _i32, _f, _f, _f, _f, _i32, _i32, _vp, _vp, _vp]),

@@ -70,7 +70,8 @@ __device__ inline void level_of_block(const GridMeta& gm, uint32_t* level, uint3
 
 __global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_fwd(GridMeta gm, uint32_t hashed_mask, const float* __restrict__ table,
                                                             const float* __restrict__ x, uint32_t x_stride, uint32_t n,
-                                                            const uint32_t* __restrict__ n_dev, float* __restrict__ enc_t, uint32_t ld) {
+                                                            const uint32_t* __restrict__ n_dev, const uint32_t* __restrict__ rows,
+                                                            float* __restrict__ enc_t, uint32_t ld) {
     uint32_t l, sb;
     level_of_block(gm, &l, &sb);
     if (l >= (uint32_t)gm.n_levels) return;
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_fwd(GridMeta gm, uint32_t
     const uint32_t res = gm.res[l], hsize = gm.off[l + 1] - gm.off[l];
     const bool hashed = (hashed_mask >> l) & 1;
     const float2* __restrict__ tab = (const float2*)table + gm.off[l];
-    const float* xp = x + (size_t)i * x_stride;
+    const float* xp = x + (size_t)(rows ? rows[i] : i) * x_stride;    // optional row indirection (render slices)
     float w[3]; uint32_t g[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
@@ -193,9 +194,9 @@ static int fill_meta(GridMeta* gm, uint32_t* hashed_mask, int n_levels, const fl
     return 0;
 }
 
-extern "C" int xr_hashgrid_fwd(const float* table, const float* x, uint32_t x_stride, uint32_t n, const uint32_t* n_dev, int n_levels,
-                               const float* scale_host, const uint32_t* resolution_host, const uint32_t* offset_host,
-                               float* enc_t, uint32_t ld, void* stream_) {
+extern "C" int xr_hashgrid_fwd(const float* table, const float* x, uint32_t x_stride, uint32_t n, const uint32_t* n_dev,
+                               const uint32_t* rows, int n_levels, const float* scale_host, const uint32_t* resolution_host,
+                               const uint32_t* offset_host, float* enc_t, uint32_t ld, void* stream_) {
     if (n == 0) return XR_OK;
     XR_REQUIRE(table && x && enc_t, "null pointer");
     XR_REQUIRE(x_stride >= 3 && ld >= n, "bad stride");
@@ -206,7 +207,7 @@ extern "C" int xr_hashgrid_fwd(const float* table, const float* x, uint32_t x_st
     gm.n_sblocks = xr_div_up(n, EN_BLOCK);
     const uint32_t blocks = 8 * per_xcd * xr_div_up(n, EN_BLOCK);
     hipLaunchKernelGGL(k_hashgrid_fwd, dim3(blocks), dim3(EN_BLOCK), 0, (hipStream_t)stream_, gm, hm, table, x, x_stride, n,
-                       n_dev, enc_t, ld);
+                       n_dev, rows, enc_t, ld);
     XR_LAUNCH_CHECK();
     return XR_OK;
 }

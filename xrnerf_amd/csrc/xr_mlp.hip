@@ -239,6 +239,7 @@ template <int NHD, int NHC, bool WITH_COLOR>
 __global__ __launch_bounds__(MLP_THREADS, 3) void k_nerf_mlp_fwd(const float* __restrict__ enc_t, uint32_t ld,
                                                                const float* __restrict__ dirs, uint32_t dir_stride,
                                                                uint32_t n, const uint32_t* __restrict__ n_dev,
+                                                               const uint32_t* __restrict__ rows,
                                                                const float* __restrict__ w_density,
                                                                const float* __restrict__ w_color, float pad_value,
                                                                float4* __restrict__ raw) {
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(MLP_THREADS, 3) void k_nerf_mlp_fwd(const float* __
         float4 o = make_float4(0.f, 0.f, 0.f, dout[0][0]);   // hi==0, reg 0 <-> row 0 = sigma
         if (WITH_COLOR) {
             f32x16 cin[1], cout[1];
-            build_color_in(dout[0], dirs, dir_stride, sc, pad_value, cin[0], hi);
+            build_color_in(dout[0], dirs, dir_stride, rows ? rows[sc] : sc, pad_value, cin[0], hi);
             layer_fwd<1, 2>(wc + SC::lds_off(0), cin, h, col, hi);
             relu_tile(h[0]); relu_tile(h[1]);
 #pragma unroll
@@ -417,7 +418,7 @@ extern "C" int xr_device_cus(void) {
 
 template <int NHD, int NHC>
 static int launch_fwd(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n, const uint32_t* n_dev,
-                      const float* wd, const float* wc, float pad, float* raw, hipStream_t stream) {
+                      const uint32_t* rows, const float* wd, const float* wc, float pad, float* raw, hipStream_t stream) {
     const int cus = xr_device_cus() > 0 ? xr_device_cus() : 256;
     const uint32_t n_tiles = (n + 31) / 32;
     const uint32_t grid = min(xr_div_up(n_tiles, MLP_WAVES), (uint32_t)cus * 3u);
@@ -425,28 +426,28 @@ static int launch_fwd(const float* enc_t, uint32_t ld, const float* dirs, uint32
         const size_t lds = (NetShape<NHD>::lds_floats + NetShape<NHC>::lds_floats) * sizeof(float);
         auto k = k_nerf_mlp_fwd<NHD, NHC, true>;
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XR_EHIP;
-        hipLaunchKernelGGL(k, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev, wd, wc, pad, (float4*)raw);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev, rows, wd, wc, pad, (float4*)raw);
     } else {
         const size_t lds = NetShape<NHD>::lds_floats * sizeof(float);
         auto k = k_nerf_mlp_fwd<NHD, NHC, false>;
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XR_EHIP;
-        hipLaunchKernelGGL(k, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev, wd, wc, pad, (float4*)raw);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev, rows, wd, wc, pad, (float4*)raw);
     }
     return XR_OK;
 }
 
 extern "C" int xr_nerf_mlp_fwd(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
-                               const uint32_t* n_dev, const float* w_density, const float* w_color, int n_hidden_density, int n_hidden_color,
+                               const uint32_t* n_dev, const uint32_t* rows, const float* w_density, const float* w_color, int n_hidden_density, int n_hidden_color,
                                float pad_value, float* raw, void* stream_) {
     if (n == 0) return XR_OK;
     XR_REQUIRE(enc_t && w_density && raw, "null pointer");
     XR_REQUIRE(!dirs || (w_color && dir_stride >= 3), "color path needs w_color and dir_stride >= 3");
     XR_REQUIRE(ld >= n && ((uintptr_t)raw & 15) == 0, "bad ld / raw alignment");
     int rc;
-    if (n_hidden_density == 1 && n_hidden_color == 2) rc = launch_fwd<1, 2>(enc_t, ld, dirs, dir_stride, n, n_dev, w_density, w_color, pad_value, raw, (hipStream_t)stream_);
-    else if (n_hidden_density == 1 && n_hidden_color == 1) rc = launch_fwd<1, 1>(enc_t, ld, dirs, dir_stride, n, n_dev, w_density, w_color, pad_value, raw, (hipStream_t)stream_);
-    else if (n_hidden_density == 2 && n_hidden_color == 2) rc = launch_fwd<2, 2>(enc_t, ld, dirs, dir_stride, n, n_dev, w_density, w_color, pad_value, raw, (hipStream_t)stream_);
-    else if (n_hidden_density == 2 && n_hidden_color == 3) rc = launch_fwd<2, 3>(enc_t, ld, dirs, dir_stride, n, n_dev, w_density, w_color, pad_value, raw, (hipStream_t)stream_);
+    if (n_hidden_density == 1 && n_hidden_color == 2) rc = launch_fwd<1, 2>(enc_t, ld, dirs, dir_stride, n, n_dev, rows, w_density, w_color, pad_value, raw, (hipStream_t)stream_);
+    else if (n_hidden_density == 1 && n_hidden_color == 1) rc = launch_fwd<1, 1>(enc_t, ld, dirs, dir_stride, n, n_dev, rows, w_density, w_color, pad_value, raw, (hipStream_t)stream_);
+    else if (n_hidden_density == 2 && n_hidden_color == 2) rc = launch_fwd<2, 2>(enc_t, ld, dirs, dir_stride, n, n_dev, rows, w_density, w_color, pad_value, raw, (hipStream_t)stream_);
+    else if (n_hidden_density == 2 && n_hidden_color == 3) rc = launch_fwd<2, 3>(enc_t, ld, dirs, dir_stride, n, n_dev, rows, w_density, w_color, pad_value, raw, (hipStream_t)stream_);
     else { xr_set_error("xr_nerf_mlp_fwd: unsupported hidden-layer counts (%d,%d)", n_hidden_density, n_hidden_color); return XR_EINVAL; }
     if (rc != XR_OK) { xr_set_error("xr_nerf_mlp_fwd: cannot configure dynamic LDS"); return rc; }
     XR_LAUNCH_CHECK();

@@ -467,6 +467,82 @@ extern "C" int xr_calc_rgb_inference(const float* network_output, const float* c
     return XR_OK;
 }
 
+// ------------------------------------------------------------------ early-terminated rendering (optional)
+// The reference's inference compositor walks every sample (its EPSILON is declared but unused,
+// calc_rgb.cu:178).  For rendering, samples behind an opaque surface are pure waste: with T < eps = 1e-4
+// they can change the pixel by less than 1e-4.  The frame is therefore evaluated in depth slices
+// [s0, s1) of per-ray sample indices; before each slice the still-transparent rays are compacted
+// (wave ballot + one atomic per wave), only their samples go through encode + MLP, and a per-ray
+// state (T, rgb) carries the front-to-back integration across slices.
+__global__ __launch_bounds__(RM_BLOCK) void k_slice_select(uint32_t n_rays, const int32_t* __restrict__ numsteps,
+                                                            const float* __restrict__ T, float eps, uint32_t s0, uint32_t s1,
+                                                            uint32_t* __restrict__ rows, int32_t* __restrict__ ray_off,
+                                                            uint32_t* __restrict__ count) {
+    const uint32_t i = blockIdx.x * RM_BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    uint32_t cnt = 0, base = 0;
+    if (i < n_rays) {
+        const uint32_t n = (uint32_t)numsteps[2 * i];
+        base = (uint32_t)numsteps[2 * i + 1];
+        if (n > s0 && T[i] > eps) cnt = min(n, s1) - s0;
+    }
+    // wave-level exclusive prefix of cnt, one atomic per wave reserves the wave's range
+    uint32_t inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+    const uint32_t wave_total = __shfl(inc, 63, 64);
+    uint32_t wave_base = 0;
+    if (lane == 63 && wave_total) wave_base = atomicAdd(count, wave_total);
+    wave_base = __shfl(wave_base, 63, 64);
+    if (i >= n_rays) return;
+    if (cnt == 0) { ray_off[i] = -1; return; }
+    const uint32_t off = wave_base + inc - cnt;
+    ray_off[i] = (int32_t)off;
+    for (uint32_t j = 0; j < cnt; ++j) rows[off + j] = base + s0 + j;
+}
+__global__ __launch_bounds__(RM_BLOCK) void k_slice_composite(uint32_t n_rays, const float4* __restrict__ raw_s,
+                                                               const float* __restrict__ coords, const int32_t* __restrict__ numsteps,
+                                                               const int32_t* __restrict__ ray_off, uint32_t s0, uint32_t s1,
+                                                               int rgb_act, int density_act, float* __restrict__ T,
+                                                               float* __restrict__ rgb_acc) {
+    const uint32_t i = blockIdx.x * RM_BLOCK + threadIdx.x;
+    if (i >= n_rays) return;
+    const int32_t off = ray_off[i];
+    if (off < 0) return;
+    const uint32_t n = (uint32_t)numsteps[2 * i], base = (uint32_t)numsteps[2 * i + 1];
+    const uint32_t cnt = min(n, s1) - s0;
+    float t = T[i], cr = rgb_acc[3 * i], cg = rgb_acc[3 * i + 1], cb = rgb_acc[3 * i + 2];
+    for (uint32_t j = 0; j < cnt; ++j) {
+        const float4 o = raw_s[(uint32_t)off + j];
+        const float dt = xr_unwarp_dt(coords[7 * (size_t)(base + s0 + j) + 3]);
+        const float alpha = 1.f - __expf(-xr_act_density(o.w, density_act) * dt);
+        const float w = alpha * t;
+        cr += w * xr_act_rgb(o.x, rgb_act); cg += w * xr_act_rgb(o.y, rgb_act); cb += w * xr_act_rgb(o.z, rgb_act);
+        t *= (1.f - alpha);
+    }
+    T[i] = t; rgb_acc[3 * i] = cr; rgb_acc[3 * i + 1] = cg; rgb_acc[3 * i + 2] = cb;
+}
+extern "C" int xr_render_slice_select(const int32_t* rays_numsteps, const float* T, uint32_t n_rays, uint32_t s0, uint32_t s1,
+                                      float eps, uint32_t* rows_out, int32_t* ray_offset_out, uint32_t* count_out, void* stream_) {
+    XR_REQUIRE(rays_numsteps && T && rows_out && ray_offset_out && count_out && n_rays > 0 && s1 > s0, "bad argument");
+    XR_HIP(hipMemsetAsync(count_out, 0, 4, (hipStream_t)stream_));
+    hipLaunchKernelGGL(k_slice_select, dim3(xr_div_up(n_rays, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream_, n_rays,
+                       rays_numsteps, T, eps, s0, s1, rows_out, ray_offset_out, count_out);
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}
+extern "C" int xr_render_slice_composite(const float* raw_slice, const float* coords, const int32_t* rays_numsteps,
+                                         const int32_t* ray_offset, uint32_t n_rays, uint32_t s0, uint32_t s1, int rgb_activation,
+                                         int density_activation, float* T, float* rgb_acc, void* stream_) {
+    XR_REQUIRE(raw_slice && coords && rays_numsteps && ray_offset && T && rgb_acc && n_rays > 0, "bad argument");
+    XR_REQUIRE(((uintptr_t)raw_slice & 15) == 0, "raw must be 16-byte aligned");
+    hipLaunchKernelGGL(k_slice_composite, dim3(xr_div_up(n_rays, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream_, n_rays,
+                       (const float4*)raw_slice, coords, rays_numsteps, ray_offset, s0, s1, rgb_activation, density_activation,
+                       T, rgb_acc);
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}
+
 // ------------------------------------------------------------------ K4 compositor backward (calc_rgb.cu:87-139)
 // Same 8-lanes-per-ray split: pass 1 composites each chunk locally to obtain, after stitching, the
 // transmittance and colour accumulated BEFORE the chunk; pass 2 re-walks the chunk with those as

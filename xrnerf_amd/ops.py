@@ -164,6 +164,17 @@ def calc_rgb_inference(raw, coords, numsteps, bg3, rgb_act, density_act):
     return rgb, alpha
 
 
+def render_slice_select(numsteps, T, s0, s1, eps, rows, ray_off, count):
+    _lib.check(_lib.load().xr_render_slice_select(_ptr(numsteps), _ptr(T), numsteps.shape[0], s0, s1, eps, _ptr(rows),
+                                                  _ptr(ray_off), _ptr(count), _stream()), 'xr_render_slice_select')
+
+
+def render_slice_composite(raw_s, coords, numsteps, ray_off, s0, s1, rgb_act, density_act, T, rgb_acc):
+    _lib.check(_lib.load().xr_render_slice_composite(_ptr(raw_s), _ptr(coords), _ptr(numsteps), _ptr(ray_off),
+                                                     numsteps.shape[0], s0, s1, int(rgb_act), int(density_act), _ptr(T),
+                                                     _ptr(rgb_acc), _stream()), 'xr_render_slice_composite')
+
+
 # ---------------------------------------------------------------- K6 .. K11
 def generate_grid_samples(grid, ema_step, n_elements, n_cascades, thresh, aabb, rng_calls):
     L = _lib.load()
@@ -258,19 +269,19 @@ def clip_numsteps(numsteps, counter, max_compacted):
     return out, n_valid
 
 
-def hashgrid_fwd(table, x, meta, enc_t=None, ld=None, n_dev=None):
+def hashgrid_fwd(table, x, meta, enc_t=None, ld=None, n_dev=None, rows=None):
     """x: [n,3] (or a column slice of [n,7] rows) -> enc_t [2L, ld] feature-major.
     n_dev: optional device int32[1]; only min(n, n_dev) rows are touched (no host read-back needed)."""
     L = _lib.load()
     x, xs = _pos_view(x)
-    n = x.shape[0]
+    n = x.shape[0] if rows is None else rows.shape[0]
     if ld is None:
         ld = (n + 63) // 64 * 64
     if enc_t is None:
         enc_t = torch.empty((meta.n_output_dims, ld), dtype=torch.float32, device=x.device)
     s, r, o = meta._args()
     with _span('xr_hashgrid_fwd', 0 if n_dev is not None else n):
-        _lib.check(L.xr_hashgrid_fwd(_ptr(table), C.c_void_p(x.data_ptr()), xs, n, _ptr(n_dev), meta.n_levels, s, r, o, _ptr(enc_t), ld,
+        _lib.check(L.xr_hashgrid_fwd(_ptr(table), C.c_void_p(x.data_ptr()), xs, n, _ptr(n_dev), _ptr(rows), meta.n_levels, s, r, o, _ptr(enc_t), ld,
                                      _stream()), 'xr_hashgrid_fwd')
     return enc_t
 
@@ -294,7 +305,7 @@ def sh4(dirs):
     return out
 
 
-def nerf_mlp_fwd(enc_t, dirs, n, w_density, w_color, nhd, nhc, pad_value=1.0, raw=None, n_dev=None):
+def nerf_mlp_fwd(enc_t, dirs, n, w_density, w_color, nhd, nhc, pad_value=1.0, raw=None, n_dev=None, rows=None):
     L = _lib.load()
     if raw is None:
         raw = torch.empty((n, 4), dtype=torch.float32, device=enc_t.device)
@@ -304,7 +315,7 @@ def nerf_mlp_fwd(enc_t, dirs, n, w_density, w_color, nhd, nhc, pad_value=1.0, ra
     else:
         ds, dp = 0, None
     with _span('xr_nerf_mlp_fwd', 0 if n_dev is not None else n):
-        _lib.check(L.xr_nerf_mlp_fwd(_ptr(enc_t), enc_t.shape[1], dp, ds, n, _ptr(n_dev), _ptr(w_density),
+        _lib.check(L.xr_nerf_mlp_fwd(_ptr(enc_t), enc_t.shape[1], dp, ds, n, _ptr(n_dev), _ptr(rows), _ptr(w_density),
                                      _ptr(w_color) if w_color is not None else None, nhd, nhc, pad_value, _ptr(raw),
                                      _stream()), 'xr_nerf_mlp_fwd')
     return raw

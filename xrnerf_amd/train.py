@@ -242,3 +242,45 @@ def render_frame(net, pose43, H, W, focal, chunk=None, row0=0, nrows=None, idx=0
     finally:
         net.chunk = old
     return ret['rgb'].reshape(nrows, W, 3), ret['alpha'].reshape(nrows, W, 1)
+
+
+ERT_SLICES = (0, 4, 8, 16, 32, 64, 128, 256, 512, 1024)
+
+
+@torch.no_grad()
+def render_frame_ert(net, pose43, H, W, focal, eps=1e-4, row0=0, nrows=None, bg=None):
+    """Early-terminated rendering of one camera (optional fast path; `render_frame` is the reference
+    behaviour).  The frame is marched once (K1), then evaluated in depth slices: before each slice the rays
+    whose transmittance is still above `eps` are compacted and ONLY their samples go through encode + MLP.
+    Pixels differ from the full evaluation by less than `eps` (everything skipped is weighted by T < eps)."""
+    sampler, mlp, render = net.sampler, net.mlp, net.render
+    dev = next(net.parameters()).device
+    nrows = H - row0 if nrows is None else nrows
+    o, d = ops.gen_rays(pose43, H, W, focal, focal, 0.5 * W, 0.5 * H, row0, nrows, device=dev)
+    data = sampler.sample({'rays_o': o, 'rays_d': d}, mlp, True)          # K1 only; one read-back
+    coords, numsteps = sampler.coords, sampler.rays_numsteps
+    n_rays, total = o.shape[0], coords.shape[0]
+    T = torch.ones((n_rays,), dtype=torch.float32, device=dev)
+    acc = torch.zeros((n_rays, 3), dtype=torch.float32, device=dev)
+    ray_off = torch.empty((n_rays,), dtype=torch.int32, device=dev)
+    count = torch.zeros((1,), dtype=torch.int32, device=dev)
+    rows = torch.empty((max(total, 1),), dtype=torch.int32, device=dev)
+    ra, da = int(sampler.rgb_activation), int(sampler.density_activation)
+    meta, wd, wc = mlp.embedder_pos.meta, mlp.density_net.params, mlp.color_net.params
+    evaluated = 0
+    for s0, s1 in zip(ERT_SLICES[:-1], ERT_SLICES[1:]):
+        ops.render_slice_select(numsteps, T, s0, s1, eps, rows, ray_off, count)
+        m = int(count.item())                                            # slice size decides the launches
+        if m == 0:
+            break
+        evaluated += m
+        r = rows[:m]
+        enc_t = ops.hashgrid_fwd(mlp.embedder_pos.params, coords[:, :3], meta, rows=r)
+        raw = ops.nerf_mlp_fwd(enc_t, coords[:, 4:], m, wd, wc, mlp.density_net.n_hidden, mlp.color_net.n_hidden,
+                               mlp.pad_value, rows=r)
+        ops.render_slice_composite(raw, coords, numsteps, ray_off, s0, s1, ra, da, T, acc)
+    bgc = (render.bg_color if bg is None else torch.as_tensor(bg, dtype=torch.float32)).to(dev)
+    rgb = acc + T[:, None] * bgc[None, :]
+    alpha = (1.0 - T)[:, None]
+    render_frame_ert.last_evaluated = (evaluated, total)
+    return rgb.reshape(nrows, W, 3), alpha.reshape(nrows, W, 1)
