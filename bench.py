@@ -105,7 +105,8 @@ def cpu_vanilla_nerf(seconds_budget=8.0):
     import xrnerf_amd
     from xrnerf_amd import vanilla
     cfg = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'ngp_model_cfg.json')))['vanilla_model']
-    threads = os.cpu_count() or 1
+    # cores actually usable by this process, capped: 256 oversubscribed threads ran this 20x SLOWER on the GPU box
+    threads = min(32, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
     torch.set_num_threads(threads)
     torch.manual_seed(0)
     net = xrnerf_amd.build_network(cfg)
