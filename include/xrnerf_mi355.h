@@ -80,9 +80,12 @@ int xr_compacted_coord(const float* coords_in, const int32_t* numsteps_in, uint3
 /* K2 when K1's ray-ordered output is kept in place (no overflow): the compacted coordinates ARE the
  * first min(total, max_compacted) rows of K1's buffer, so only the clipped per-ray counts are
  * needed: numsteps_out[i] = (min(max_compacted - min(max_compacted, base), n), base)
- * (compacted_coord.cu:63-66).  n_valid_dev[0] = min(counter2[1], max_compacted) (device). */
+ * (compacted_coord.cu:63-66).  n_valid_dev[0] = min(counter2[1], max_compacted) (device); when n_chunks > 0,
+ * n_valid_dev[1+c] = number of valid rows inside row chunk c of chunk_rows rows (for launching the per-sample
+ * kernels chunk by chunk on two streams without a host read-back). */
 int xr_clip_numsteps(const int32_t* numsteps_in, const uint32_t* counter2, uint32_t n_rays, uint32_t max_compacted,
-                     int32_t* numsteps_out, uint32_t* n_valid_dev, void* stream);
+                     int32_t* numsteps_out, uint32_t* n_valid_dev /*[1+n_chunks]*/, uint32_t chunk_rows,
+                     uint32_t n_chunks, void* stream);
 
 /* K3  calc_rgb_forward_api (src/calc_rgb.cu:208-264, kernel :6-67) */
 int xr_calc_rgb_forward(const float* network_output /*[S,4]*/, const float* coords /*[S,7]*/,

@@ -358,19 +358,24 @@ extern "C" int xr_compacted_coord(const float* coords_in, const int32_t* numstep
 
 __global__ __launch_bounds__(RM_BLOCK) void k2_clip(uint32_t n_rays, uint32_t max_compacted, const int32_t* __restrict__ in,
                                                      const uint32_t* __restrict__ counter2, int32_t* __restrict__ out,
-                                                     uint32_t* __restrict__ n_valid) {
+                                                     uint32_t* __restrict__ n_valid, uint32_t chunk_rows, uint32_t n_chunks) {
     const uint32_t i = blockIdx.x * RM_BLOCK + threadIdx.x;
-    if (i == 0) *n_valid = min(counter2[1], max_compacted);
+    if (i == 0) {
+        const uint32_t total = min(counter2[1], max_compacted);
+        n_valid[0] = total;
+        for (uint32_t c = 0; c < n_chunks; ++c)       // rows of chunk c = [c*chunk_rows, (c+1)*chunk_rows) that are valid
+            n_valid[1 + c] = min(chunk_rows, total - min(total, c * chunk_rows));
+    }
     if (i >= n_rays) return;
     const uint32_t n = (uint32_t)in[2 * i], base = (uint32_t)in[2 * i + 1];
     out[2 * i] = (int32_t)min(max_compacted - min(max_compacted, base), n);
     out[2 * i + 1] = (int32_t)base;
 }
 extern "C" int xr_clip_numsteps(const int32_t* numsteps_in, const uint32_t* counter2, uint32_t n_rays, uint32_t max_compacted,
-                                int32_t* numsteps_out, uint32_t* n_valid_dev, void* stream_) {
+                                int32_t* numsteps_out, uint32_t* n_valid_dev, uint32_t chunk_rows, uint32_t n_chunks, void* stream_) {
     XR_REQUIRE(numsteps_in && counter2 && numsteps_out && n_valid_dev && n_rays > 0, "bad argument");
     hipLaunchKernelGGL(k2_clip, dim3(xr_div_up(n_rays, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream_, n_rays, max_compacted,
-                       numsteps_in, counter2, numsteps_out, n_valid_dev);
+                       numsteps_in, counter2, numsteps_out, n_valid_dev, chunk_rows, n_chunks);
     XR_LAUNCH_CHECK();
     return XR_OK;
 }

@@ -93,8 +93,29 @@ class _FusedTrainStepFn(torch.autograd.Function):
             pts, dirs = mlp._rows(data['pts']), mlp._rows(data['viewdirs'])
             n, n_dev = pts.shape[0], data.get('n_valid_dev')
             meta, nhd, nhc = mlp.embedder_pos.meta, mlp.density_net.n_hidden, mlp.color_net.n_hidden
-            enc_t = ops.hashgrid_fwd(table, pts, meta, n_dev=n_dev)
-            raw = ops.nerf_mlp_fwd(enc_t, dirs, n, wd, wc, nhd, nhc, mlp.pad_value, n_dev=n_dev)
+            # Optional two-stream pipeline over N_CHUNKS row chunks (encode of chunk c+1 beside the MLP of chunk
+            # c, MLP backward of chunk c+1 beside the table scatter of chunk c; device-side row counts per
+            # chunk).  It LOSES on MI355X (see ops.N_CHUNKS) and is off (N_CHUNKS = 1: one stream, one launch).
+            chunks = data.get('n_valid_chunks')
+            nch = ops.N_CHUNKS if chunks is not None else 1
+            crow = (n + nch - 1) // nch
+            s0 = torch.cuda.current_stream()
+            s1 = net._aux_stream() if nch > 1 else s0
+            ld = (n + 63) // 64 * 64
+            enc_t = torch.empty((meta.n_output_dims, ld), dtype=torch.float32, device=pts.device)
+            raw = torch.empty((n, 4), dtype=torch.float32, device=pts.device)
+            cnt = lambda c: chunks[1 + c:2 + c] if chunks is not None else n_dev
+            if nch > 1:
+                s1.wait_stream(s0)
+            for c in range(nch):
+                r0, m = c * crow, min(crow, n - c * crow)
+                with torch.cuda.stream(s1):
+                    ops.hashgrid_fwd(table, pts, meta, enc_t=enc_t, ld=ld, n_dev=cnt(c), row0=r0, count=m)
+                    if nch > 1:
+                        ev = torch.cuda.Event(); ev.record(s1)
+                if nch > 1:
+                    s0.wait_event(ev)
+                ops.nerf_mlp_fwd(enc_t, dirs, n, wd, wc, nhd, nhc, mlp.pad_value, raw=raw, n_dev=cnt(c), row0=r0, count=m)
             ra, da = int(sampler.rgb_activation), int(sampler.density_activation)
             rgb = ops.calc_rgb_forward(raw, sampler.coords, sampler.rays_numsteps, sampler.rays_numsteps_compacted,
                                        data['bg_color'], ra, da)
@@ -103,8 +124,21 @@ class _FusedTrainStepFn(torch.autograd.Function):
             ops.calc_rgb_backward(raw, sampler.rays_numsteps_compacted, sampler.coords, grad_rgb, rgb,
                                   sampler.density_grid_mean, ra, da, out=draw)
             g_wd, g_wc, g_table = torch.zeros_like(wd), torch.zeros_like(wc), torch.zeros_like(table)
-            denc_t = ops.nerf_mlp_bwd(enc_t, dirs, n, wd, wc, nhd, nhc, draw, g_wd, g_wc, mlp.pad_value, n_dev=n_dev)
-            ops.hashgrid_bwd(pts, denc_t, meta, g_table, n_dev=n_dev)
+            denc_t = torch.empty_like(enc_t)
+            if nch > 1:
+                s1.wait_stream(s0)                  # the zero-filled table gradient is ready before the first scatter
+            for c in range(nch):
+                r0, m = c * crow, min(crow, n - c * crow)
+                ops.nerf_mlp_bwd(enc_t, dirs, n, wd, wc, nhd, nhc, draw, g_wd, g_wc, mlp.pad_value, denc_t=denc_t,
+                                 n_dev=cnt(c), row0=r0, count=m)
+                if nch > 1:
+                    ev = torch.cuda.Event(); ev.record(s0)
+                with torch.cuda.stream(s1):
+                    if nch > 1:
+                        s1.wait_event(ev)
+                    ops.hashgrid_bwd(pts, denc_t, meta, g_table, n_dev=cnt(c), row0=r0, count=m)
+            if nch > 1:
+                s0.wait_stream(s1)
         ctx.grads = (g_table, g_wd, g_wc)
         ctx.mark_non_differentiable(rgb)
         net._last = {'rgb': rgb, 'loss_mse': loss_mse, 'raw': raw}
@@ -178,6 +212,11 @@ class HashNerfNetwork(BaseNerfNetwork):
             for k in ret:
                 all_ret.setdefault(k, []).append(ret[k])
         return {k: torch.cat(all_ret[k], 0) for k in all_ret}
+
+    def _aux_stream(self):
+        if getattr(self, '_aux', None) is None:
+            self._aux = torch.cuda.Stream(device=self.mlp.embedder_pos.params.device)
+        return self._aux
 
     def _fused_ok(self):
         from .mlps import HashNerfMLP

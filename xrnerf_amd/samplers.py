@@ -187,9 +187,11 @@ class NGPGridSampler(nn.Module):
         self.coords = coords_compacted
         self.rays_numsteps = rays_numsteps
         self.rays_numsteps_compacted = rays_numsteps_compacted
-        self.n_valid_dev = n_valid_dev
+        self.n_valid_dev = n_valid_dev[0:1]
+        self.n_valid_chunks = n_valid_dev
         data['pts'], data['viewdirs'] = coords_compacted[..., :3], coords_compacted[..., 4:]
-        data['n_valid_dev'] = n_valid_dev
+        data['n_valid_dev'] = n_valid_dev[0:1]
+        data['n_valid_chunks'] = n_valid_dev
         return data
 
     def _coords_buffer(self, rows):
