@@ -94,24 +94,30 @@ __device__ inline void load_weights(float* __restrict__ lds, const float* __rest
 template <int TI, int TO, bool SB = true>
 __device__ __forceinline__ void layer_fwd(const float* __restrict__ W, const f32x16 (&in)[TI], f32x16 (&out)[TO], int col, int hi) {
     constexpr int ST = TI * 32 + 1;
+    constexpr int NS = TI * 16;                 // K-steps
+    constexpr int PF = 3;                       // LDS operand prefetch distance (steps); one ds_read ~ 64-128 cycles
 #pragma unroll
     for (int to = 0; to < TO; ++to)
 #pragma unroll
         for (int r = 0; r < 16; ++r) out[to][r] = 0.f;
     const float* wl = W + col * ST + 4 * hi;
+    float a[PF + 1][TO];
 #pragma unroll
-    for (int ti = 0; ti < TI; ++ti)
+    for (int p = 0; p < PF; ++p)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            // keep the scheduler from hoisting a whole layer's LDS operand reads (64-128 VGPRs) to the top
-            if (SB && (r & 3) == 0) __builtin_amdgcn_sched_barrier(0);
-            const float b = in[ti][r];
+        for (int to = 0; to < TO; ++to) a[p][to] = wl[to * 32 * ST + (p / 16) * 32 + drow(p % 16)];
 #pragma unroll
-            for (int to = 0; to < TO; ++to) {
-                const float a = wl[to * 32 * ST + ti * 32 + drow(r)];
-                out[to] = MFMA32(a, b, out[to]);
-            }
+    for (int st = 0; st < NS; ++st) {
+        // keep the scheduler from hoisting a whole layer's LDS operand reads (64-128 VGPRs) to the top
+        if (SB && (st & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+        if (st + PF < NS) {
+#pragma unroll
+            for (int to = 0; to < TO; ++to) a[(st + PF) % (PF + 1)][to] = wl[to * 32 * ST + ((st + PF) / 16) * 32 + drow((st + PF) % 16)];
         }
+        const float b = in[st / 16][st % 16];
+#pragma unroll
+        for (int to = 0; to < TO; ++to) out[to] = MFMA32(a[st % (PF + 1)][to], b, out[to]);
+    }
 }
 // gin[TI] = W^T . g[TO]     (W is [TO*32][TI*32], stride TI*32+1).  RSTEPS < 16: only the first RSTEPS
 // register rows of g can be non-zero (output layers: 16 real neurons -> 8, colour gradient -> 3), the
