@@ -192,6 +192,9 @@ class NGPGridSampler(nn.Module):
         data['pts'], data['viewdirs'] = coords_compacted[..., :3], coords_compacted[..., 4:]
         data['n_valid_dev'] = n_valid_dev[0:1]
         data['n_valid_chunks'] = n_valid_dev
+        cb = getattr(self, 'on_sampled', None)
+        if cb is not None:
+            cb()       # e.g. the trainer issues the NEXT batch's march on a side stream right here
         return data
 
     def _coords_buffer(self, rows):

@@ -174,6 +174,7 @@ class Trainer:
         self.net = build_network(ngp_lego_model_cfg()).to(device)
         self.data = dataset or SyntheticLego(device, n_img, H, W, seed=1 + rank)
         self.net.sampler.set_data(self.data.get_alldata(), self.data.get_info())     # PassDatasetHook
+        self.net.sampler.on_sampled = self._on_sampled
         self.base_lr = 1e-2
         self.opt = FusedAdam([p for p in self.net.parameters() if p.numel() > 0], lr=self.base_lr,
                              betas=(0.9, 0.99), eps=1e-15, weight_decay=1e-6, ema_momentum=0.05 if ema else None)
@@ -212,14 +213,22 @@ class Trainer:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self._ev_done = [self._ev_done[1], ev]
-            if net.sampler.can_prefetch(self.iter):
-                side = net.sampler.side_stream()
-                with torch.cuda.stream(side):
-                    nb = data.next_batch()
-                    # the launch writes the coordinate buffer last read by the PREVIOUS iteration
-                    net.sampler.prefetch(nb, buffer_free_event=self._ev_done[0])
-                self._next_batch = nb
         return out
+
+    def _on_sampled(self):
+        """Called by the sampler as soon as THIS iteration's samples exist: the march of the NEXT batch is
+        issued now, on the side stream, so that it runs beside this iteration's encode / MLP forward and
+        table scatter (it cannot co-reside with the MLP backward, whose waves own whole SIMD register files)
+        and is finished long before the next iteration needs it."""
+        net, data = self.net, self.data
+        if not self.overlap_march or not net.sampler.can_prefetch(self.iter + 1):
+            return
+        side = net.sampler.side_stream()
+        with torch.cuda.stream(side):
+            nb = data.next_batch()
+            # that launch overwrites the coordinate buffer last read by the PREVIOUS iteration
+            net.sampler.prefetch(nb, buffer_free_event=self._ev_done[1])
+        self._next_batch = nb
 
     @property
     def samples_done(self):
