@@ -192,6 +192,17 @@ int xr_nerf_mlp_bwd(const float* enc_t, uint32_t ld, const float* dirs, uint32_t
                     float pad_value, const float* draw /*[n,4]*/, float* denc_t, float* grad_w_density,
                     float* grad_w_color, void* workspace, size_t workspace_bytes, void* stream);
 
+/* tcnn.Network(FullyFusedMLP) on its own (compatibility surface; the hot path uses the fused kernels above):
+ * x [n, n_in] with arbitrary row / column strides (in floats), n_in <= 32, missing input columns = pad_value;
+ * weights in the tcnn layout; y / dy [n,16] row-major (columns >= n_output_dims are padding); dx [n, n_in]
+ * row-major (nullable).  grad_w ACCUMULATES.  n_hidden: forward 1..3, backward 1..2. */
+int xr_mlp_fwd(const float* x, long row_stride, long col_stride, int n_in, float pad_value, uint32_t n, const float* w,
+               int n_hidden, float* y, void* stream);
+size_t xr_mlp_bwd_workspace_bytes(int n_hidden);
+int xr_mlp_bwd(const float* x, long row_stride, long col_stride, int n_in, float pad_value, uint32_t n, const float* w,
+               int n_hidden, const float* dy, float* dx, float* grad_w, void* workspace, size_t workspace_bytes,
+               void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * callers either side of the path
  * ray generation, get_rays_np_hash (xrnerf/datasets/load_data/get_rays.py:35-69) in fp32:

@@ -125,3 +125,44 @@ def test_nerf_mlp_bwd(O, dev, n):
         err = np.abs(got.cpu().numpy() - ref).max()
         # both sides sum n fp32 terms in different orders (the oracle serially): ~sqrt(n)*2^-24 relative
         assert err <= 1e-3 * max(1.0, np.abs(ref).max()), (name, err, np.abs(ref).max())
+
+
+def test_tcnn_module_surface_runs_the_reference_mlp_recipe(O, dev):
+    """xrnerf_amd.tcnn.{Encoding,Network} used exactly as xrnerf/models/mlps/hashnerf_mlp.py:34-45,55-79 uses
+    tinycudann: separate modules, row-major tensors, torch.cat in between, autograd end to end -- and the result
+    equals the fused HashNerfMLP path and the oracle."""
+    from xrnerf_amd import tcnn, ops, synthetic as S
+    from xrnerf_amd.mlps import get_per_level_scale
+    torch.manual_seed(0)
+    emb = tcnn.Encoding(3, dict(otype='HashGrid', n_levels=16, n_features_per_level=2, log2_hashmap_size=19,
+                                base_resolution=16, interpolation='Linear', per_level_scale=get_per_level_scale(1))).to(dev)
+    sh = tcnn.Encoding(3, dict(otype='SphericalHarmonics', degree=4)).to(dev)
+    dnet = tcnn.Network(emb.n_output_dims, 16, dict(otype='FullyFusedMLP', activation='ReLU', output_activation='None',
+                                                    n_neurons=64, num_layers=1)).to(dev)
+    cnet = tcnn.Network(sh.n_output_dims + 16 - 1, 3, dict(otype='FullyFusedMLP', activation='ReLU',
+                                                           output_activation='None', n_neurons=64, num_layers=2)).to(dev)
+    with torch.no_grad():
+        emb.params.copy_(T(S.hash_table(emb.meta.n_params, scale=0.5), dev))
+    n = 3001
+    rng = np.random.default_rng(0)
+    pts = rng.uniform(0, 1, (n, 3)).astype(np.float32); dirs = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    draw = rng.normal(0, 1, (n, 4)).astype(np.float32)
+    # --- the reference's run_mlp, line for line in spirit
+    density_out = dnet(emb(T(pts, dev)))
+    color_out = cnet(torch.cat([density_out[..., 1:], sh(T(dirs, dev))], dim=-1))
+    outputs = torch.cat([color_out, density_out[..., :1]], -1)
+    assert outputs.shape == (n, 4)
+    (outputs * T(draw, dev)).sum().backward()
+    om = O.GridMeta()
+    table, wd, wc = emb.params.detach().cpu().numpy(), dnet.params.detach().cpu().numpy(), cnet.params.detach().cpu().numpy()
+    ref = O.nerf_mlp_fwd(table, wd, wc, pts, dirs, om)
+    assert np.abs(outputs.detach().cpu().numpy() - ref).max() <= 1e-4
+    gt, gd, gc = O.nerf_mlp_bwd(table, wd, wc, pts, dirs, draw, om)
+    for got, want in ((emb.params.grad, gt), (dnet.params.grad, gd), (cnet.params.grad, gc)):
+        err = np.abs(got.cpu().numpy() - want).max()
+        assert err <= 1e-3 * max(1.0, np.abs(want).max()), err
+    # 3 hidden layers forward (strict-default-like depth) against the oracle's generic MLP
+    net3 = tcnn.Network(32, 16, dict(otype='FullyFusedMLP', n_neurons=64, n_hidden_layers=3)).to(dev)
+    x = rng.normal(0, 0.5, (500, 32)).astype(np.float32)
+    y = net3(T(x, dev)).detach().cpu().numpy()
+    assert np.abs(y - O.mlp_fwd(net3.params.detach().cpu().numpy(), x, 32, 64, 3, 16)).max() <= 1e-4

@@ -411,6 +411,122 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict
     }
 }
 
+// ------------------------------------------------------------------ generic single network
+// tcnn.Network(FullyFusedMLP) used on its own: x [n, n_in] (arbitrary row / column strides, n_in <= 32,
+// missing input columns are filled with pad_value like tcnn's Identity-encoded input) -> y [n, 16] row-major.
+// Same building blocks as the fused NeRF kernels; this is the compatibility surface, not the hot path.
+__device__ __forceinline__ void load_x_tile(const float* __restrict__ x, long rs, long cs, uint32_t s, int n_in, float pad,
+                                            f32x16& t, int hi) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int c = drow(r) + 4 * hi;
+        t[r] = c < n_in ? x[(long)s * rs + (long)c * cs] : pad;
+    }
+}
+template <int NH>
+__global__ __launch_bounds__(MLP_THREADS, 2) void k_mlp_fwd(const float* __restrict__ x, long rs, long cs, int n_in, float pad,
+                                                             uint32_t n, const float* __restrict__ w, float* __restrict__ y) {
+    using S = NetShape<NH>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    load_weights<NH>(lds, w, false);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, hi = lane >> 5;
+    const uint32_t n_tiles = (n + 31) / 32;
+    for (uint32_t tile = blockIdx.x * MLP_WAVES + wave; tile < n_tiles; tile += gridDim.x * MLP_WAVES) {
+        const uint32_t s = tile * 32 + col, sc = s < n ? s : n - 1;
+        f32x16 xin[1], h[2], h2[2], out[1];
+        load_x_tile(x, rs, cs, sc, n_in, pad, xin[0], hi);
+        layer_fwd<1, 2>(lds + S::lds_off(0), xin, h, col, hi);
+        relu_tile(h[0]); relu_tile(h[1]);
+#pragma unroll
+        for (int l = 1; l < NH; ++l) {
+            layer_fwd<2, 2>(lds + S::lds_off(l), h, h2, col, hi);
+            relu_tile(h2[0]); relu_tile(h2[1]);
+            h[0] = h2[0]; h[1] = h2[1];
+        }
+        layer_fwd<2, 1>(lds + S::lds_off(NH), h, out, col, hi);
+        if (s < n) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) y[(size_t)s * 16 + drow(r) + 4 * hi] = out[0][r];
+        }
+    }
+}
+// backward: recompute, dX chain, dW (block partials like the fused kernel).  NH in {1, 2}.
+template <int NH>
+__global__ __launch_bounds__(MLP_THREADS, 1) void k_mlp_bwd(const float* __restrict__ x, long rs, long cs, int n_in, float pad,
+                                                             uint32_t n, const float* __restrict__ w, const float* __restrict__ dy,
+                                                             float* __restrict__ dx /*[n, n_in] row-major or null*/,
+                                                             float* __restrict__ partial) {
+    using S = NetShape<NH>;
+    constexpr int GW = S::glb_floats;
+    constexpr int STAGE = 4 * 32 * ST33;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* stage_all = lds + S::lds_floats;
+    load_weights<NH>(lds, w, false);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, hi = lane >> 5;
+    float* stage = stage_all + wave * STAGE;
+    f32x16 a_in[2][1], a_hid[2][2], a_out[1][2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        a_in[0][0][r] = a_in[1][0][r] = 0.f; a_out[0][0][r] = a_out[0][1][r] = 0.f;
+        a_hid[0][0][r] = a_hid[0][1][r] = a_hid[1][0][r] = a_hid[1][1][r] = 0.f;
+    }
+    const uint32_t n_tiles = (n + 31) / 32;
+    for (uint32_t tile = blockIdx.x * MLP_WAVES + wave; tile < n_tiles; tile += gridDim.x * MLP_WAVES) {
+        const uint32_t s = tile * 32 + col;
+        const bool live = s < n;
+        const uint32_t sc = live ? s : n - 1;
+        f32x16 xin[1], h1[2], h2[2], g1[1], ga[2], gb[2];
+        load_x_tile(x, rs, cs, sc, n_in, pad, xin[0], hi);
+        layer_fwd<1, 2, false>(lds + S::lds_off(0), xin, h1, col, hi);
+        relu_tile(h1[0]); relu_tile(h1[1]);
+        if (NH == 2) {
+            layer_fwd<2, 2, false>(lds + S::lds_off(1), h1, h2, col, hi);
+            relu_tile(h2[0]); relu_tile(h2[1]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g1[0][r] = 0.f;
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) g1[0][r] = dy[(size_t)s * 16 + drow(r) + 4 * hi];
+        }
+        if (NH == 2) {
+            dw_accumulate<1, 2, false>(a_out, g1, h2, stage, col, hi);
+            layer_bwd<1, 2, false, 8>(lds + S::lds_off(2), g1, ga, col, hi);
+            relu_mask(ga[0], h2[0]); relu_mask(ga[1], h2[1]);
+            dw_accumulate<2, 2, false>(a_hid, ga, h1, stage, col, hi);
+            layer_bwd<2, 2, false>(lds + S::lds_off(1), ga, gb, col, hi);
+            relu_mask(gb[0], h1[0]); relu_mask(gb[1], h1[1]);
+        } else {
+            dw_accumulate<1, 2, false>(a_out, g1, h1, stage, col, hi);
+            layer_bwd<1, 2, false, 8>(lds + S::lds_off(1), g1, gb, col, hi);
+            relu_mask(gb[0], h1[0]); relu_mask(gb[1], h1[1]);
+        }
+        dw_accumulate<2, 1, false>(a_in, gb, xin, stage, col, hi);
+        if (dx) {
+            layer_bwd<2, 1, false>(lds + S::lds_off(0), gb, g1, col, hi);
+            if (live) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c = drow(r) + 4 * hi;
+                    if (c < n_in) dx[(size_t)s * n_in + c] = g1[0][r];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float* red = stage_all;
+    for (int e = threadIdx.x; e < GW; e += MLP_THREADS) red[e] = 0.f;
+    __syncthreads();
+    dw_flush<2, 1>(a_in, red + S::glb_off(0), 64, 32, false, col, hi);
+    if (NH == 2) dw_flush<2, 2>(a_hid, red + S::glb_off(1), 64, 64, false, col, hi);
+    dw_flush<1, 2>(a_out, red + S::glb_off(NH), 16, 64, false, col, hi);
+    __syncthreads();
+    float* out = partial + (size_t)blockIdx.x * GW;
+    for (int e = threadIdx.x; e < GW; e += MLP_THREADS) out[e] = red[e];
+}
+
 // ------------------------------------------------------------------ host side
 static int g_cus = 0;
 extern "C" int xr_device_cus(void) {
@@ -494,6 +610,60 @@ extern "C" int xr_nerf_mlp_bwd(const float* enc_t, uint32_t ld, const float* dir
                        n_dev, w_density, w_color, pad_value, (const float4*)draw, denc_t, (float*)workspace);
     hipLaunchKernelGGL(k_reduce_partials, dim3(xr_div_up(GW, 64)), dim3(256), 0, stream, (const float*)workspace, grid,
                        (uint32_t)GW, (uint32_t)NetShape<1>::glb_floats, grad_w_density, grad_w_color);
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}
+
+// ---- generic single-network entry points (tcnn.Network compatibility surface)
+extern "C" size_t xr_mlp_bwd_workspace_bytes(int n_hidden) {
+    const int cus = xr_device_cus() > 0 ? xr_device_cus() : 256;
+    return (size_t)cus * (n_hidden == 2 ? NetShape<2>::glb_floats : NetShape<1>::glb_floats) * sizeof(float);
+}
+extern "C" int xr_mlp_fwd(const float* x, long row_stride, long col_stride, int n_in, float pad_value, uint32_t n,
+                          const float* w, int n_hidden, float* y, void* stream_) {
+    if (n == 0) return XR_OK;
+    XR_REQUIRE(x && w && y && n_in >= 1 && n_in <= 32, "bad argument");
+    const int cus = xr_device_cus() > 0 ? xr_device_cus() : 256;
+    const uint32_t grid = min(xr_div_up((n + 31) / 32, MLP_WAVES), (uint32_t)cus * 2u);
+    hipStream_t stream = (hipStream_t)stream_;
+#define XR_FWD_CASE(NH)                                                                                              \
+    case NH: {                                                                                                       \
+        const size_t lds = NetShape<NH>::lds_floats * sizeof(float);                                                 \
+        XR_HIP(hipFuncSetAttribute((const void*)k_mlp_fwd<NH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(k_mlp_fwd<NH>, dim3(grid), dim3(MLP_THREADS), lds, stream, x, row_stride, col_stride, n_in, \
+                           pad_value, n, w, y);                                                                      \
+    } break;
+    switch (n_hidden) {
+        XR_FWD_CASE(1) XR_FWD_CASE(2) XR_FWD_CASE(3)
+        default: xr_set_error("xr_mlp_fwd: n_hidden_layers %d not built (1..3)", n_hidden); return XR_EINVAL;
+    }
+#undef XR_FWD_CASE
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}
+extern "C" int xr_mlp_bwd(const float* x, long row_stride, long col_stride, int n_in, float pad_value, uint32_t n,
+                          const float* w, int n_hidden, const float* dy, float* dx, float* grad_w, void* workspace,
+                          size_t workspace_bytes, void* stream_) {
+    if (n == 0) return XR_OK;
+    XR_REQUIRE(x && w && dy && grad_w && n_in >= 1 && n_in <= 32, "bad argument");
+    XR_REQUIRE(n_hidden == 1 || n_hidden == 2, "backward is built for 1 or 2 hidden layers");
+    XR_REQUIRE(workspace && workspace_bytes >= xr_mlp_bwd_workspace_bytes(n_hidden), "workspace too small");
+    hipStream_t stream = (hipStream_t)stream_;
+    const uint32_t grid = bwd_grid(n);
+    const int gw = n_hidden == 2 ? NetShape<2>::glb_floats : NetShape<1>::glb_floats;
+    if (n_hidden == 1) {
+        const size_t lds = (NetShape<1>::lds_floats + MLP_WAVES * 4 * 32 * ST33) * sizeof(float);
+        XR_HIP(hipFuncSetAttribute((const void*)k_mlp_bwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_mlp_bwd<1>, dim3(grid), dim3(MLP_THREADS), lds, stream, x, row_stride, col_stride, n_in, pad_value,
+                           n, w, dy, dx, (float*)workspace);
+    } else {
+        const size_t lds = (NetShape<2>::lds_floats + MLP_WAVES * 4 * 32 * ST33) * sizeof(float);
+        XR_HIP(hipFuncSetAttribute((const void*)k_mlp_bwd<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_mlp_bwd<2>, dim3(grid), dim3(MLP_THREADS), lds, stream, x, row_stride, col_stride, n_in, pad_value,
+                           n, w, dy, dx, (float*)workspace);
+    }
+    hipLaunchKernelGGL(k_reduce_partials, dim3(xr_div_up(gw, 64)), dim3(256), 0, stream, (const float*)workspace, grid,
+                       (uint32_t)gw, (uint32_t)gw, grad_w, grad_w);
     XR_LAUNCH_CHECK();
     return XR_OK;
 }
