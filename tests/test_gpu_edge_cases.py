@@ -1,0 +1,100 @@
+"""Edge cases of the path through the C-ABI on the GPU: empty and ragged inputs, rays that never hit anything,
+the 1024-step cap of a fully occupied grid, zero-sized launches, argument validation."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import bits
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def test_fully_occupied_grid_hits_the_step_cap(O, dev):
+    """all cells occupied: rays through the box take the maximum NERF_STEPS = 1024 samples (raymarch_shared.h:42);
+    t-list overflow (> 64 samples per ray) and sample-buffer overflow paths are exercised, bit-exact"""
+    from xrnerf_amd import ops, synthetic as S
+    bf = np.full(128 ** 3, 255, np.uint8)
+    poses = S.lego_cameras(3, seed=4)
+    o, d, _ = S.training_rays(poses, 257, seed=2)           # ragged: not a multiple of 64 / 256
+    rc, ri, rn, rcnt = O.rays_sampler(o, d, bf)
+    assert rn[:, 0].max() > 64 and rn[:, 0].max() <= 1024
+    for cap in (257 * 1024, int(rcnt[1]) // 3):
+        rc, ri, rn, rcnt = O.rays_sampler(o, d, bf, max_samples=cap)
+        c, gi, gn, gcnt = ops.rays_sampler(T(o, dev), T(d, dev), T(bf, dev), (0.0, 1.0), 0.05, 1.0 / 256, cap, 0)
+        assert np.array_equal(gcnt.cpu().numpy(), rcnt) and np.array_equal(gn.cpu().numpy(), rn)
+        assert np.array_equal(gi.cpu().numpy(), ri)
+        kept = rn[:, 0] > 0
+        for i in np.nonzero(kept)[0][::7]:
+            b, k = rn[i, 1], rn[i, 0]
+            assert np.array_equal(bits(c[b:b + k].cpu().numpy()), bits(rc[b:b + k]))
+
+
+def test_single_ray_and_all_miss(O, dev):
+    from xrnerf_amd import ops
+    bf = np.zeros(128 ** 3, np.uint8)                        # empty scene: nothing is ever sampled
+    o = np.array([[0.5, 0.5, -1.0]], np.float32); d = np.array([[0.0, 0.0, 1.0]], np.float32)
+    c, gi, gn, gcnt = ops.rays_sampler(T(o, dev), T(d, dev), T(bf, dev), (0.0, 1.0), 0.05, 1.0 / 256, 1024, 0)
+    rc, ri, rn, rcnt = O.rays_sampler(o, d, bf, max_samples=1024)
+    assert gcnt.tolist() == rcnt.tolist() == [1, 0] and gn.tolist() == [[0, 0]] and gi.tolist() == [[-1]]
+    # compositor on rays without samples returns the background (calc_rgb.cu:28-32) and zero alpha (:167-172)
+    raw = torch.zeros((1, 4), device=dev); coords = torch.zeros((1, 7), device=dev)
+    bg = torch.tensor([[0.1, 0.2, 0.3]], device=dev)
+    assert torch.equal(ops.calc_rgb_forward(raw, coords, gn, gn, bg, 2, 3), bg)
+    rgb, a = ops.calc_rgb_inference(raw, coords, gn, [0.4, 0.5, 0.6], 2, 3)
+    assert torch.allclose(rgb, torch.tensor([[0.4, 0.5, 0.6]], device=dev)) and float(a) == 0.0
+    # clip of an all-empty batch: zero valid rows on the device, encode / MLP launches with n_dev = 0 are no-ops
+    nc, nv = ops.clip_numsteps(gn, gcnt, 1 << 18)
+    assert int(nv[0]) == 0 and nc.tolist() == [[0, 0]]
+    meta = ops.GridMeta()
+    table = torch.zeros(meta.n_params, device=dev)
+    enc = torch.full((32, 64), 7.0, device=dev)
+    ops.hashgrid_fwd(table, torch.rand(64, 3, device=dev), meta, enc_t=enc, ld=64, n_dev=nv[0:1])
+    assert float(enc.min()) == 7.0                            # untouched
+
+
+def test_zero_sized_and_invalid_calls(dev):
+    from xrnerf_amd import _lib, ops
+    L = _lib.load()
+    meta = ops.GridMeta()
+    s, r, o = meta._args()
+    # n == 0 is a successful no-op for the per-sample kernels
+    assert L.xr_hashgrid_fwd(None, None, 3, 0, None, None, 16, s, r, o, None, 0, None) == 0
+    assert L.xr_nerf_mlp_fwd(None, 0, None, 0, 0, None, None, None, None, 1, 2, 1.0, None, None) == 0
+    assert L.xr_generate_grid_samples(None, 0, 0, 1, 0.0, 0.0, 1.0, 0, 0, None, None, None) == 0
+    # bad arguments are reported, not executed
+    t = torch.zeros(16, device=dev)
+    assert L.xr_rays_sampler(t.data_ptr(), t.data_ptr(), t.data_ptr(), 4, 0.0, 1.0, 0.05, 0.004, 64, 0, 0, t.data_ptr(),
+                             t.data_ptr(), t.data_ptr(), t.data_ptr(), None, 0, None) == -22
+    assert b'workspace' in L.xr_last_error()
+    assert L.xr_nerf_mlp_bwd(t.data_ptr(), 64, t.data_ptr(), 3, 8, None, t.data_ptr(), t.data_ptr(), 5, 5, 1.0,
+                             t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), 1 << 30, None) == -22
+    assert b'topology' in L.xr_last_error()
+    with pytest.raises(_lib.XrError):
+        ops.ema_grid_samples(torch.zeros(6, device=dev), 6, 0.95, torch.zeros(6, device=dev))   # not a multiple of 4
+
+
+def test_ragged_sample_counts_through_mlp_and_encode(O, dev):
+    """n not a multiple of the 32-sample MFMA tile / 64-lane wave / 256-thread block, incl. n = 1"""
+    from xrnerf_amd import ops, synthetic as S
+    meta, om = ops.GridMeta(), O.GridMeta()
+    table = S.hash_table(meta.n_params, scale=0.5)
+    wd, wc = S.mlp_weights(32, 64, 1, 16, 4), S.mlp_weights(32, 64, 2, 16, 5)
+    tt, twd, twc = T(table, dev), T(wd, dev), T(wc, dev)
+    rng = np.random.default_rng(9)
+    for n in (1, 2, 31, 63, 65, 255, 257, 1023):
+        pts = rng.uniform(0, 1, (n, 3)).astype(np.float32); dirs = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+        draw = rng.normal(0, 1, (n, 4)).astype(np.float32)
+        enc_t = ops.hashgrid_fwd(tt, T(pts, dev), meta)
+        raw = ops.nerf_mlp_fwd(enc_t, T(dirs, dev), n, twd, twc, 1, 2)
+        assert np.abs(raw.cpu().numpy() - O.nerf_mlp_fwd(table, wd, wc, pts, dirs, om)).max() <= 1e-4
+        gwd, gwc = torch.zeros_like(twd), torch.zeros_like(twc)
+        denc = ops.nerf_mlp_bwd(enc_t, T(dirs, dev), n, twd, twc, 1, 2, T(draw, dev), gwd, gwc)
+        gt = torch.zeros(meta.n_params, device=dev)
+        ops.hashgrid_bwd(T(pts, dev), denc, meta, gt)
+        rt, rd, rcg = O.nerf_mlp_bwd(table, wd, wc, pts, dirs, draw, om)
+        for got, want in ((gwd, rd), (gwc, rcg), (gt, rt)):
+            assert np.abs(got.cpu().numpy() - want).max() <= 1e-3 * max(1.0, np.abs(want).max())
