@@ -21,10 +21,13 @@ class KernelTimer:
     current stream IS the stream every kernel of this library is enqueued on).  bench.py uses it to
     get the dominant kernel's average duration live inside the timed region."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.events = {}
+        self.only = only            # record only these entry points (None = all)
 
     def span(self, name, units=0):
+        if self.only is not None and name not in self.only:
+            return _NOSPAN
         return _Span(self, name, units)
 
     def summary(self):

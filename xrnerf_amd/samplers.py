@@ -65,6 +65,7 @@ class NGPGridSampler(nn.Module):
         self.k6_calls = 0
         self.device = None
         self._prefetched = None
+        self._pending_counts = []
 
     # ------------------------------------------------------------------ hooks' entry points
     def set_data(self, alldata, datainfo):
@@ -155,6 +156,7 @@ class NGPGridSampler(nn.Module):
             cur = torch.cuda.current_stream()
             cur.wait_event(pf['event'])
             coords, rays_index, rays_numsteps, counter = pf['out']
+            self._pending_counts.append(pf['host'])
             # everything allocated on the side stream is consumed on this one
             for t in (rays_index, rays_numsteps, counter):
                 t.record_stream(cur)
@@ -166,6 +168,8 @@ class NGPGridSampler(nn.Module):
                 rays_o, rays_d, self.density_grid_bitfield, aabb, self.near_distance, self.cone_angle_constant,
                 max_samples, self.k1_calls, coords_out=self._coords_buffer(max_samples))
             self.k1_calls += 1
+            if is_training:
+                self._pending_counts.append(self._count_to_host(counter))
         self.rays_index = rays_index
         if not is_training:
             n_valid, samples = counter.tolist()      # one host read-back per call (rays_sampler.py:72)
@@ -239,13 +243,31 @@ class NGPGridSampler(nn.Module):
                                self.cone_angle_constant, max_samples, self.k1_calls,
                                coords_out=self._coords_buffer(max_samples), ws_tag='k1_side')
         self.k1_calls += 1
+        host = self._count_to_host(out[3])
         done = torch.cuda.Event()
         done.record(side)
-        self._prefetched = {'rays_o': rays_o, 'max_samples': max_samples, 'out': out, 'event': done}
+        self._prefetched = {'rays_o': rays_o, 'max_samples': max_samples, 'out': out, 'event': done, 'host': host}
+
+    def _count_to_host(self, counter):
+        """asynchronous copy of K1's (rays, samples) counter to pinned host memory, right behind the launch: by
+        the time the batch-size feedback needs the numbers (every 16th iteration) they have long arrived, so
+        reading them does not drain the compute stream the way `measured_batch_size.item()` does"""
+        host = torch.empty((2,), dtype=torch.int32, pin_memory=True)
+        host.copy_(counter, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        return ev, host
 
     def update_batch_rays(self, is_training, max_samples=None):
         if is_training and self.iter_n % self.update_grid_freq == (self.update_grid_freq - 1):
-            total = self.measured_batch_size.item()              # the one read-back per 16 iterations (:271)
+            if self._pending_counts:
+                total = 0
+                for ev, host in self._pending_counts:
+                    ev.synchronize()
+                    total += int(host[1])
+                self._pending_counts = []
+            else:
+                total = self.measured_batch_size.item()          # the one read-back per 16 iterations (:271)
             if max_samples is not None and total > 16 * max_samples:
                 raise RuntimeError('ray marcher overflowed its %d-row sample buffer' % max_samples)
             measured_batch_size = max(total / 16, 1)
