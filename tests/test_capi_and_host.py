@@ -146,6 +146,12 @@ p = torch.nn.Parameter(torch.zeros(1000)); p.grad = torch.full((1000,), float(ra
 q = torch.nn.Parameter(torch.zeros(7)); q.grad = torch.arange(7.) * (rank + 1)
 xd.allreduce_grads([p, q], world)
 assert torch.allclose(p.grad, torch.full((1000,), 1.5)) and torch.allclose(q.grad, torch.arange(7.) * 1.5)
+# bucketed reduction: buckets are slices of one flat gradient, handed over one by one, reduced in place
+flat = torch.arange(100.) * (rank + 1)
+sync = xd.BucketedGradSync(world)
+sync.ready(flat[60:]); sync.ready(flat[:60])
+f = sync.finish()
+assert f == 0.5 and torch.allclose(flat * f, torch.arange(100.) * 1.5) and not sync._works
 # image-space shard + all-gather of uneven row bands
 H, W = 7, 5
 full = torch.arange(H * W * 4, dtype=torch.float32).reshape(H, W, 4)

@@ -33,6 +33,41 @@ def test_fused_step_equals_modular_step(dev, monkeypatch):
         assert float((x - y).abs().max()) <= 1e-5 * max(1.0, float(y.abs().max()))
 
 
+def test_bucketed_gradient_sync_path_covers_every_gradient(dev):
+    """The data-parallel fused step hands its gradients to BucketedGradSync in three buckets while it is
+    still producing them; with a recording stand-in (no peers) the buckets must tile the parameter set and
+    the resulting gradients must equal the single-GPU step's (scaled by the factor finish() returns)."""
+    from xrnerf_amd import dist as xd
+
+    class Recorder(xd.BucketedGradSync):
+        def __init__(self):
+            super().__init__(1)
+            self.sizes = []
+
+        def ready(self, bucket):
+            assert bucket.is_contiguous()
+            self.sizes.append(bucket.numel())
+
+        def finish(self):
+            return 0.5
+
+    a, b = make(dev), make(dev)
+    b.net.load_state_dict(a.net.state_dict())
+    b.net.grad_sync = Recorder()
+    grads = []
+    for tr in (a, b):
+        tr.net.sampler.set_iter(0)
+        batch = {k: v[None] for k, v in tr.data.next_batch().items()}
+        tr.net.train_step(batch, tr.opt)['loss'].backward()
+        grads.append([p.grad.clone() for p in tr.net.parameters() if p.grad is not None])
+    n_mlp = a.net.mlp.density_net.params.numel() + a.net.mlp.color_net.params.numel()
+    n_tab = a.net.mlp.embedder_pos.params.numel()
+    sizes = b.net.grad_sync.sizes
+    assert sizes[0] == n_mlp and sum(sizes[1:]) == n_tab and len(sizes) == 3 and sizes[1] == 8 * 2 * (1 << 19)
+    for x, y in zip(grads[0], grads[1]):
+        assert float((0.5 * x - y).abs().max()) <= 1e-5 * max(1.0, float(x.abs().max()))
+
+
 def test_training_reduces_loss_and_renders(dev):
     from xrnerf_amd.train import render_frame
     tr = make(dev)

@@ -45,6 +45,14 @@ def test_hashgrid_fwd_bwd(O, dev, n):
     ops.hashgrid_bwd(T(x, dev), dt.contiguous(), meta, g)
     err = np.abs(g.cpu().numpy() - ref_g).max()
     assert err <= 1e-4 * max(1.0, np.abs(ref_g).max()), err
+    # level-range launches (data-parallel bucketing: fine half, then coarse half) write exactly their levels
+    g2 = torch.zeros_like(g)
+    ops.hashgrid_bwd(T(x, dev), dt.contiguous(), meta, g2, levels=(8, 16))
+    cut = 2 * int(meta.offset[8])
+    assert float(g2[:cut].abs().max()) == 0.0
+    assert float((g2[cut:] - g[cut:]).abs().max()) <= 1e-5 * max(1.0, float(g.abs().max()))
+    ops.hashgrid_bwd(T(x, dev), dt.contiguous(), meta, g2, levels=(0, 8))
+    assert float((g2 - g).abs().max()) <= 1e-5 * max(1.0, float(g.abs().max()))
 
 
 def test_sh4(O, dev):

@@ -119,11 +119,19 @@ class _FusedTrainStepFn(torch.autograd.Function):
             ra, da = int(sampler.rgb_activation), int(sampler.density_activation)
             rgb = ops.calc_rgb_forward(raw, sampler.coords, sampler.rays_numsteps, sampler.rays_numsteps_compacted,
                                        data['bg_color'], ra, da)
-            loss_mse, grad_rgb = ops.huber_loss_grad_mse(rgb, data['target_s'].contiguous(), data['alpha'].contiguous(), 0.1, 5.0)
-            draw = torch.zeros_like(raw)
+            # one zero-fill for everything that must start at zero: dL/draw rows, the two MLP gradient buffers and
+            # the (loss, mse) accumulators
+            nz = raw.numel() + wd.numel() + wc.numel() + 4
+            zbuf = torch.zeros((nz,), dtype=torch.float32, device=raw.device)
+            draw = zbuf[:raw.numel()].view_as(raw)
+            g_wd = zbuf[raw.numel():raw.numel() + wd.numel()]
+            g_wc = zbuf[raw.numel() + wd.numel():raw.numel() + wd.numel() + wc.numel()]
+            loss_mse = zbuf[nz - 4:nz - 2]
+            grad_rgb = ops.huber_loss_grad_mse(rgb, data['target_s'].contiguous(), data['alpha'].contiguous(), 0.1, 5.0,
+                                               out=loss_mse)[1]
             ops.calc_rgb_backward(raw, sampler.rays_numsteps_compacted, sampler.coords, grad_rgb, rgb,
                                   sampler.density_grid_mean, ra, da, out=draw)
-            g_wd, g_wc, g_table = torch.zeros_like(wd), torch.zeros_like(wc), torch.zeros_like(table)
+            g_table = torch.zeros_like(table)
             denc_t = torch.empty_like(enc_t)
             if nch > 1:
                 s1.wait_stream(s0)                  # the zero-filled table gradient is ready before the first scatter
@@ -133,22 +141,40 @@ class _FusedTrainStepFn(torch.autograd.Function):
                                  n_dev=cnt(c), row0=r0, count=m)
                 if nch > 1:
                     ev = torch.cuda.Event(); ev.record(s0)
+                sync = getattr(net, 'grad_sync', None) if nch == 1 else None
+                if sync is not None and meta.n_levels > 8:
+                    # data parallel: reduce each gradient bucket across ranks while the next one is produced
+                    split = meta.n_levels - 8                      # 8 finest levels = one per XCD
+                    cut = 2 * int(meta.offset[split])
+                    sync.ready(zbuf[raw.numel():raw.numel() + wd.numel() + wc.numel()])       # both MLP gradients
+                    ops.hashgrid_bwd(pts, denc_t, meta, g_table, n_dev=cnt(c), levels=(split, meta.n_levels))
+                    sync.ready(g_table[cut:])
+                    ops.hashgrid_bwd(pts, denc_t, meta, g_table, n_dev=cnt(c), levels=(0, split))
+                    sync.ready(g_table[:cut])
+                    continue
                 with torch.cuda.stream(s1):
                     if nch > 1:
                         s1.wait_event(ev)
                     ops.hashgrid_bwd(pts, denc_t, meta, g_table, n_dev=cnt(c), row0=r0, count=m)
+                if sync is not None:
+                    sync.ready(zbuf[raw.numel():raw.numel() + wd.numel() + wc.numel()])
+                    sync.ready(g_table)
             if nch > 1:
                 s0.wait_stream(s1)
         ctx.grads = (g_table, g_wd, g_wc)
+        ctx.sync = getattr(net, 'grad_sync', None)
         ctx.mark_non_differentiable(rgb)
         net._last = {'rgb': rgb, 'loss_mse': loss_mse, 'raw': raw}
-        return loss_mse[0].clone(), rgb
+        return loss_mse[0:1].reshape(()), rgb
 
     @staticmethod
     def backward(ctx, g, _g_rgb):
-        g_table, g_wd, g_wc = ctx.grads
+        grads = list(ctx.grads)
         ctx.grads = None
-        return g_table.mul_(g), g_wd.mul_(g), g_wc.mul_(g), None, None
+        if ctx.sync is not None:
+            g = g * ctx.sync.finish()            # all buckets reduced; average over the ranks
+        torch._foreach_mul_(grads, g)            # one multi-tensor launch
+        return grads[0], grads[1], grads[2], None, None
 
 
 class _LazyPsnr:

@@ -302,15 +302,24 @@ def hashgrid_fwd(table, x, meta, enc_t=None, ld=None, n_dev=None, rows=None, row
     return enc_t
 
 
-def hashgrid_bwd(x, denc_t, meta, grad_table, n_dev=None, row0=0, count=None):
+def hashgrid_bwd(x, denc_t, meta, grad_table, n_dev=None, row0=0, count=None, levels=None):
+    """scatter dL/denc into dL/dtable.  `levels=(l0, l1)` restricts the launch to that level range (the level
+    metadata arrays are passed from l0 on; table offsets are absolute, so `grad_table` stays the full table):
+    the data-parallel trainer scatters the fine half first and reduces it across ranks under the coarse half."""
     L = _lib.load()
     x, xs = _pos_view(x)
     n = x.shape[0] if count is None else count
     s, r, o = meta._args()
+    l0, l1 = (0, meta.n_levels) if levels is None else levels
+    if not 0 <= l0 < l1 <= meta.n_levels:
+        raise _lib.XrError('bad level range %r' % (levels,))
+    ld = denc_t.shape[1]
     _ptr(denc_t)
     with _span('xr_hashgrid_bwd', 0 if n_dev is not None else n):
-        _lib.check(L.xr_hashgrid_bwd(C.c_void_p(x.data_ptr() + 4 * xs * row0), xs, C.c_void_p(denc_t.data_ptr() + 4 * row0), denc_t.shape[1], n, _ptr(n_dev), meta.n_levels, s, r, o,
-                                     _ptr(grad_table), _stream()), 'xr_hashgrid_bwd')
+        _lib.check(L.xr_hashgrid_bwd(C.c_void_p(x.data_ptr() + 4 * xs * row0), xs,
+                                     C.c_void_p(denc_t.data_ptr() + 4 * (row0 + 2 * l0 * ld)), ld, n, _ptr(n_dev),
+                                     l1 - l0, s + 4 * l0, r + 4 * l0, o + 4 * l0, _ptr(grad_table), _stream()),
+                   'xr_hashgrid_bwd')
     return grad_table
 
 
@@ -379,10 +388,11 @@ def huber_loss_grad(rgb, target, delta=0.1, scale=5.0):
     return loss, grad
 
 
-def huber_loss_grad_mse(rgb, target, alpha, delta=0.1, scale=5.0):
-    """-> out[2] = (scale * HuberLoss_sum, sum ((rgb-target)*alpha)^2), dL/drgb"""
+def huber_loss_grad_mse(rgb, target, alpha, delta=0.1, scale=5.0, out=None):
+    """-> out[2] = (scale * HuberLoss_sum, sum ((rgb-target)*alpha)^2), dL/drgb; `out` must be zero-filled"""
     grad = torch.empty_like(rgb)
-    out = torch.zeros((2,), dtype=torch.float32, device=rgb.device)
+    if out is None:
+        out = torch.zeros((2,), dtype=torch.float32, device=rgb.device)
     _lib.check(_lib.load().xr_huber_loss_grad_mse(_ptr(rgb), _ptr(target), _ptr(alpha), rgb.shape[0], delta, scale,
                                                   _ptr(grad), _ptr(out), _stream()), 'xr_huber_loss_grad_mse')
     return out, grad

@@ -66,6 +66,7 @@ class NGPGridSampler(nn.Module):
         self.device = None
         self._prefetched = None
         self._pending_counts = []
+        self.samples_marched = 0
 
     # ------------------------------------------------------------------ hooks' entry points
     def set_data(self, alldata, datainfo):
@@ -124,7 +125,7 @@ class NGPGridSampler(nn.Module):
         if self.device != device:
             self.device = device
             for attr in ['transforms', 'focal', 'metadata', 'density_grid_mean', 'density_grid_bitfield',
-                         'density_grid_tmp', 'measured_batch_size']:
+                         'density_grid_tmp']:          # measured_batch_size stays on the host
                 if hasattr(self, attr):
                     setattr(self, attr, getattr(self, attr).to(device).contiguous())
             if hasattr(self, 'density_grid'):
@@ -185,7 +186,8 @@ class NGPGridSampler(nn.Module):
         # MLP has a fixed target_batch_size rows (compacted_coords.py:20-21 pads with zeros); the number of
         # valid rows stays on the device (`n_valid_dev`) so that no host read-back is needed here.
         rays_numsteps_compacted, n_valid_dev = ops.clip_numsteps(rays_numsteps, counter, self.target_batch_size)
-        self.measured_batch_size += counter[1:2]           # pre-clip counter (ngp_grid_sampler.py:252)
+        # the pre-clip counter the reference accumulates in `measured_batch_size` (ngp_grid_sampler.py:252) is
+        # accumulated on the host from the asynchronous pinned copies (_pending_counts)
         self.update_batch_rays(is_training, max_samples)
         coords_compacted = coords[:self.target_batch_size]
         self.coords = coords_compacted
@@ -258,16 +260,25 @@ class NGPGridSampler(nn.Module):
         ev.record(torch.cuda.current_stream())
         return ev, host
 
+    def _drain_counts(self):
+        """fold the arrived per-iteration counters into `measured_batch_size` (a HOST tensor here; the reference
+        keeps it on the device and pays a stream drain to read it, ngp_grid_sampler.py:252,271)"""
+        for ev, host in self._pending_counts:
+            ev.synchronize()
+            c = int(host[1])
+            self.measured_batch_size += c
+            self.samples_marched += min(c, self.target_batch_size)      # rows that actually went through the MLP
+        self._pending_counts = []
+
+    def total_valid_samples(self):
+        """samples evaluated by training steps so far (host-side statistic; waits only for counter copies)"""
+        self._drain_counts()
+        return self.samples_marched
+
     def update_batch_rays(self, is_training, max_samples=None):
         if is_training and self.iter_n % self.update_grid_freq == (self.update_grid_freq - 1):
-            if self._pending_counts:
-                total = 0
-                for ev, host in self._pending_counts:
-                    ev.synchronize()
-                    total += int(host[1])
-                self._pending_counts = []
-            else:
-                total = self.measured_batch_size.item()          # the one read-back per 16 iterations (:271)
+            self._drain_counts()
+            total = int(self.measured_batch_size)                # host tensor: no device read-back (:271)
             if max_samples is not None and total > 16 * max_samples:
                 raise RuntimeError('ray marcher overflowed its %d-row sample buffer' % max_samples)
             measured_batch_size = max(total / 16, 1)

@@ -180,8 +180,10 @@ class Trainer:
                              betas=(0.9, 0.99), eps=1e-15, weight_decay=1e-6, ema_momentum=0.05 if ema else None)
         self.iter = 0
         self.world_size, self.rank = world_size, rank
+        if world_size > 1:
+            from . import dist as xdist                 # fused step: bucketed reduction under the table scatter
+            self.net.grad_sync = xdist.BucketedGradSync(world_size)
         self.rays_done = 0
-        self._samples_dev = torch.zeros((1,), dtype=torch.int64, device=device)
         self.lazy_log = True
         self.overlap_march = True      # run K1 of the next batch on a side stream under this step's backward
         self._next_batch = None
@@ -201,14 +203,13 @@ class Trainer:
         out = net.train_step(batch, self.opt, lazy_log=self.lazy_log)
         self.opt.zero_grad(set_to_none=True)
         out['loss'].backward()
-        if self.world_size > 1:
-            from . import dist as xdist
+        if self.world_size > 1 and not net._fused_ok():
+            from . import dist as xdist                 # modular step: reduce after backward (DDP semantics)
             xdist.allreduce_grads([p for p in net.parameters() if p.grad is not None], self.world_size)
         self.opt.step()
         data.set_batchsize(net.sampler.n_rays_per_batch)                  # ModifyBatchsizeHook
         self.iter += 1
         self.rays_done += n_rays
-        self._samples_dev += net.sampler.n_valid_dev          # stays on the device
         if self.overlap_march:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
@@ -232,7 +233,7 @@ class Trainer:
 
     @property
     def samples_done(self):
-        return int(self._samples_dev.item())
+        return self.net.sampler.total_valid_samples()
 
 
 @torch.no_grad()
