@@ -166,10 +166,18 @@ void xr_hashgrid_meta(int n_levels, int log2_hashmap_size, int base_resolution, 
 int xr_hashgrid_fwd(const float* table, const float* x, uint32_t x_stride, uint32_t n, const uint32_t* n_dev,
                     const uint32_t* rows, int n_levels, const float* scale_host, const uint32_t* resolution_host,
                     const uint32_t* offset_host, float* enc_t, uint32_t ld, void* stream);
-/* grad_table[idx,f] += w * denc_t[2l+f][i]; caller zero-fills grad_table */
+/* grad_table[idx,f] += w * denc_t[2l+f][i]; caller zero-fills grad_table.
+ * workspace (nullable; xr_hashgrid_bwd_workspace_bytes(n, n_levels, resolution_host, offset_host), 16-byte
+ * aligned): with it and n >= 16384, the hashed levels (power-of-two slices) are accumulated WITHOUT global
+ * atomics -- contributions are binned by 2^14-entry table partition, then one workgroup per partition sums
+ * its bin in LDS and adds it to the table -- and the dense levels scatter into 8 replicas of their slices
+ * (hot-entry contention) that are folded afterwards; without it every level takes the plain atomic scatter. */
+size_t xr_hashgrid_bwd_workspace_bytes(uint32_t n, int n_levels, const uint32_t* resolution_host,
+                                       const uint32_t* offset_host);
 int xr_hashgrid_bwd(const float* x, uint32_t x_stride, const float* denc_t, uint32_t ld, uint32_t n,
                     const uint32_t* n_dev, int n_levels, const float* scale_host, const uint32_t* resolution_host,
-                    const uint32_t* offset_host, float* grad_table, void* stream);
+                    const uint32_t* offset_host, float* grad_table, void* workspace, size_t workspace_bytes,
+                    void* stream);
 /* tcnn.Encoding otype=SphericalHarmonics degree 4; dirs in [0,1] (the sampler's warp_direction);
  * out row-major [n,16] */
 int xr_sh4(const float* dirs, uint32_t dir_stride, uint32_t n, float* out, void* stream);

@@ -45,6 +45,11 @@ def test_hashgrid_fwd_bwd(O, dev, n):
     ops.hashgrid_bwd(T(x, dev), dt.contiguous(), meta, g)
     err = np.abs(g.cpu().numpy() - ref_g).max()
     assert err <= 1e-4 * max(1.0, np.abs(ref_g).max()), err
+    # the atomic scatter (no workspace) and the LDS-partition scan (n >= 16384, hashed levels) agree
+    g1 = torch.zeros_like(g)
+    ops.hashgrid_bwd(T(x, dev), dt.contiguous(), meta, g1, use_workspace=False)
+    assert float((g1 - g).abs().max()) <= 1e-5 * max(1.0, float(g.abs().max()))
+    assert np.abs(g1.cpu().numpy() - ref_g).max() <= 1e-4 * max(1.0, np.abs(ref_g).max())
     # level-range launches (data-parallel bucketing: fine half, then coarse half) write exactly their levels
     g2 = torch.zeros_like(g)
     ops.hashgrid_bwd(T(x, dev), dt.contiguous(), meta, g2, levels=(8, 16))

@@ -138,7 +138,8 @@ __global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_fwd(GridMeta gm, uint32_t
 #define BW_SAMPLES_PER_BLOCK (BW_CH * (EN_BLOCK / 16))
 __global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_bwd(GridMeta gm, uint32_t hashed_mask, const float* __restrict__ x,
                                                             uint32_t x_stride, const float* __restrict__ denc_t, uint32_t ld,
-                                                            uint32_t n, const uint32_t* __restrict__ n_dev, float* __restrict__ grad_table) {
+                                                            uint32_t n, const uint32_t* __restrict__ n_dev, float* __restrict__ grad_table,
+                                                            float* __restrict__ rep, uint32_t n_rep, uint32_t rep_stride) {
     constexpr uint32_t bw_ch = BW_CH;   // compile-time: a runtime chunk length costs 8 % (loop not unrolled)
     uint32_t l, sb;
     level_of_block(gm, &l, &sb);
@@ -170,7 +171,10 @@ __global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_bwd(GridMeta gm, uint32_t
     const float scale = gm.scale[l];
     const uint32_t res = gm.res[l], hsize = gm.off[l + 1] - gm.off[l];
     const bool hashed = (hashed_mask >> l) & 1;
-    float* __restrict__ tab = grad_table + 2 * (size_t)gm.off[l] + f;
+    // coarse levels: thousands of flushes land on the few hundred entries around the object and same-address
+    // atomics serialise (level 0 alone: 63 us).  With `rep`, workgroup sb adds into replica sb % n_rep of the
+    // slice; k_reduce_replicas folds the replicas into the table afterwards.
+    float* __restrict__ tab = (rep ? rep + (size_t)(sb % n_rep) * rep_stride : grad_table) + 2 * (size_t)gm.off[l] + f;
     uint32_t c0 = 0xffffffffu, c1 = 0xffffffffu, c2 = 0xffffffffu;   // current cell
     float acc = 0.f;
     float* dst = tab;
@@ -192,6 +196,191 @@ __global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_bwd(GridMeta gm, uint32_t
         }
     }
     if (acc != 0.f) unsafeAtomicAdd(dst, acc);
+}
+
+// ---- scatter without global atomics at the hashed levels: bin, then accumulate in LDS ---------------
+// The atomic scatter above is bound by the chip-wide rate of scattered L2 atomic REQUESTS (measured
+// 21-24 G/s whatever the type, footprint or XCD placement): at the fine, hashed levels nothing merges
+// and every sample costs 4-8 requests per level (0.46 ms for the 8 finest levels at 2^18 samples).
+// Here a hashed level's gradient slice (2^19 entries x 2 floats = 4 MiB) is cut into 2^13-entry
+// PARTITIONS (128 KiB of fp64 accumulators) -- what one workgroup can hold in LDS -- and the work is split in two streaming
+// kernels with no global atomic at all:
+//   A  k_scatter_bin    one thread per (sample, level), 4096 samples per workgroup: the 8 corners are
+//      4 x-neighbour PAIRS; the partition of a pair is bits [13,19) of  y*P1 ^ z*P2  (x < 2^13 never
+//      reaches them), so both corners of a pair live in the same partition.  Each pair becomes one
+//      16-byte item {idx0 | idx1 << 13, wy*wz*d0, wy*wz*d1, wx} stored in the workgroup's PRIVATE
+//      sub-bin of its (level, partition); ranks come from an LDS histogram (returning LDS atomics),
+//      the sub-bin's fill count is stored next to it.  Streaming: reads 28 + 8 B, writes 64 B per
+//      (sample, level).
+//   B  k_scatter_accum  one workgroup per (level, partition): walks the sub-bins of all sample blocks
+//      with coalesced 16-B loads, 4 LDS fp64 atomic adds per item, then adds its partition to the table with
+//      plain 16-B accesses -- it is the only writer of that slice.
+// A sub-bin holds 2x its expected load; items beyond that (adversarially clustered inputs) are
+// scattered by A directly with global atomics, so any input stays correct.
+// Measured dead ends, for the record: (1) every partition-owning workgroup scanning ALL samples and
+// filtering by partition: 0.22 ms per 8 levels (32x redundant filter work at 4 cycles per wave64 VALU
+// instruction, latency-bound gathers); (2) shared bins with one returning global atomic per
+// (workgroup, partition): 0.19 ms even for ONE level -- 64 same-address returning atomics serialise
+// at ~3 us each.
+#define SC_THREADS 1024
+#define SC_LOG2 13
+#define SC_ENTRIES (1u << SC_LOG2)
+#define SC_LDS_BYTES (SC_ENTRIES * 2 * sizeof(double))
+#define SC_SPT 4                                   // samples per thread in the binning kernel
+#define SC_BLOCK_SAMPLES (SC_THREADS * SC_SPT)
+#define SC_MAX_PARTS 128
+#define SC_MAX_SB 4096                               // sample blocks per call: n <= 2^24 on the binned path
+#define SC_SUB_ITEMS (2u * 4u * SC_BLOCK_SAMPLES)  // items of all sub-bins of one (workgroup, level): 2x the 4 pairs per sample
+
+__global__ __launch_bounds__(SC_THREADS) void k_scatter_bin(GridMeta gm, uint32_t l_lo, uint32_t l_hi, uint32_t parts, uint32_t nsb,
+                                                            const float* __restrict__ x, uint32_t x_stride,
+                                                            const float* __restrict__ denc_t, uint32_t ld, uint32_t n,
+                                                            const uint32_t* __restrict__ n_dev, uint32_t* __restrict__ counts,
+                                                            float4* __restrict__ bins, float* __restrict__ grad_table) {
+    __shared__ uint32_t s_cnt[SC_MAX_PARTS];
+    const uint32_t nl = l_hi - l_lo;
+    const uint32_t l = l_hi - 1 - blockIdx.x % nl, sb = blockIdx.x / nl;   // finest first; the levels of one sample block are neighbours
+    if (n_dev) n = min(n, *n_dev);
+    const uint32_t b0 = sb * SC_BLOCK_SAMPLES;
+    const uint32_t cap = SC_SUB_ITEMS / parts;                              // capacity of one sub-bin
+    uint32_t* __restrict__ cnt_out = counts + ((size_t)(l - l_lo) * parts) * nsb + sb;      // [level][part][sample block]
+    if (b0 >= n) {                                                          // uniform: an empty sample block has empty sub-bins
+        for (uint32_t p = threadIdx.x; p < parts; p += SC_THREADS) cnt_out[(size_t)p * nsb] = 0;
+        return;
+    }
+    for (uint32_t p = threadIdx.x; p < parts; p += SC_THREADS) s_cnt[p] = 0;
+    __syncthreads();
+    const float scale = gm.scale[l];
+    const uint32_t hsize = gm.off[l + 1] - gm.off[l], hmask = hsize - 1;    // power of two (checked on the host)
+    const float* __restrict__ d0p = denc_t + (size_t)(2 * l) * ld;
+    const float* __restrict__ d1p = d0p + ld;
+    float* __restrict__ tab = grad_table + 2 * (size_t)gm.off[l];
+    // sub-bin (level, part, sample block) at [level][part][sample block][cap]: the reader of one (level, part)
+    // streams nsb * cap contiguous items
+    float4* __restrict__ out = bins + (size_t)(l - l_lo) * nsb * SC_SUB_ITEMS + (size_t)sb * cap;
+    // all 5 x SC_SPT loads of the thread are issued before anything is consumed (one exposed memory latency
+    // per workgroup instead of one per sample)
+    float ld0[SC_SPT], ld1[SC_SPT], lx0[SC_SPT], lx1[SC_SPT], lx2[SC_SPT];
+#pragma unroll
+    for (uint32_t s = 0; s < SC_SPT; ++s) {
+        const uint32_t i = min(b0 + s * SC_THREADS + threadIdx.x, n - 1);
+        const float* xp = x + (size_t)i * x_stride;
+        ld0[s] = d0p[i]; ld1[s] = d1p[i]; lx0[s] = xp[0]; lx1[s] = xp[1]; lx2[s] = xp[2];
+    }
+#pragma unroll
+    for (uint32_t s = 0; s < SC_SPT; ++s) {
+        const uint32_t i = b0 + s * SC_THREADS + threadIdx.x;
+        if (i >= n) continue;
+        const float d0 = ld0[s], d1 = ld1[s], x0 = lx0[s], x1 = lx1[s], x2 = lx2[s];
+        if (d0 == 0.f && d1 == 0.f) continue;                               // rows behind the compositor's early stop add nothing
+        const float p0 = x0 * scale + 0.5f, p1 = x1 * scale + 0.5f, p2 = x2 * scale + 0.5f;
+        const float f0 = floorf(p0), f1 = floorf(p1), f2 = floorf(p2);
+        const uint32_t g0 = (uint32_t)(int)f0, g1 = (uint32_t)(int)f1, g2 = (uint32_t)(int)f2;
+        const float w0 = p0 - f0, w1 = p1 - f1, w2 = p2 - f2;
+        const uint32_t a0 = g1 * 2654435761u, b0h = g2 * 805459861u;
+#pragma unroll
+        for (uint32_t c = 0; c < 4; ++c) {
+            const uint32_t cy = c & 1u, cz = c >> 1;
+            const uint32_t h = (a0 + (cy ? 2654435761u : 0u)) ^ (b0h + (cz ? 805459861u : 0u));
+            const uint32_t i0 = (g0 ^ h) & hmask, i1 = ((g0 + 1u) ^ h) & hmask;
+            const uint32_t part = i0 >> SC_LOG2;                            // == i1 >> SC_LOG2
+            const float wyz = (cy ? w1 : 1.f - w1) * (cz ? w2 : 1.f - w2);
+            const float va = wyz * d0, vb = wyz * d1;
+            const uint32_t rank = atomicAdd(&s_cnt[part], 1u);
+            if (rank < cap) {
+                const uint32_t pr = (i0 & (SC_ENTRIES - 1)) | ((i1 & (SC_ENTRIES - 1)) << SC_LOG2);
+                out[(size_t)part * nsb * cap + rank] = make_float4(__uint_as_float(pr), va, vb, w0);
+            } else {                                                        // overfull sub-bin: scatter this pair directly
+                unsafeAtomicAdd(tab + 2 * (size_t)i0, (1.f - w0) * va);
+                unsafeAtomicAdd(tab + 2 * (size_t)i0 + 1, (1.f - w0) * vb);
+                unsafeAtomicAdd(tab + 2 * (size_t)i1, w0 * va);
+                unsafeAtomicAdd(tab + 2 * (size_t)i1 + 1, w0 * vb);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < parts; p += SC_THREADS) cnt_out[(size_t)p * nsb] = min(s_cnt[p], cap);
+}
+
+// LDS accumulation.  MEASURED on MI355X (tools/lds_probe.hip), ns per wave64 instruction per CU, random addresses:
+//   ds_add_f32 81 (!)   ds_add_f64 8.6   ds_add_u32 3.0   ds_add_u64 4.7   ds_cmpst_rtn_b64 8.9   8-byte read+write 7.2
+// The fp32 LDS atomic add is serialised per lane (~3 cycles each); the fp64 one is not.  (A 64-bit compare-and-
+// swap of the (f0, f1) pair has the throughput but needs the returned value: two exposed LDS latencies per add,
+// 62 us per partition.)  So the partition is accumulated in DOUBLE with returnless ds_add_f64 -- more accurate
+// than the fp32 atomics of the other path -- and rounded to fp32 once, when it is added to the table.
+__global__ __launch_bounds__(SC_THREADS) void k_scatter_accum(GridMeta gm, uint32_t l_lo, uint32_t l_hi, uint32_t parts, uint32_t nsb,
+                                                              const uint32_t* __restrict__ counts, const float4* __restrict__ bins,
+                                                              float* __restrict__ grad_table) {
+    extern __shared__ __attribute__((aligned(16))) double s_acc[];       // [SC_ENTRIES][2]
+    const uint32_t li = blockIdx.x / parts, part = blockIdx.x % parts, l = l_lo + li;
+    const uint32_t hsize = gm.off[l + 1] - gm.off[l];
+    if (part >= (hsize >> SC_LOG2)) return;
+    const uint32_t cap = SC_SUB_ITEMS / parts;
+    const uint32_t* __restrict__ cnt = counts + ((size_t)li * parts + part) * nsb;
+    double2* acc2 = reinterpret_cast<double2*>(s_acc);
+    __shared__ uint32_t s_fill[SC_MAX_SB];                                  // fill counts of this unit's sub-bins
+    for (uint32_t e = threadIdx.x; e < nsb; e += SC_THREADS) s_fill[e] = cnt[e];
+    for (uint32_t e = threadIdx.x; e < SC_ENTRIES; e += SC_THREADS) acc2[e] = make_double2(0.0, 0.0);
+    __syncthreads();
+    // The unit's sub-bins are contiguous ([sample block][cap], cap a power of two): tile k = positions
+    // [k * SC_THREADS, (k+1) * SC_THREADS), a position is live when its offset in its sub-bin is below the fill
+    // count.  The loads of the next U tiles are in flight while the current U are accumulated.
+    const uint32_t cap_log2 = 31 - __builtin_clz(cap), npos = nsb << cap_log2;
+    const float4* __restrict__ src = bins + (size_t)li * nsb * SC_SUB_ITEMS + (size_t)part * npos;
+    constexpr uint32_t U = 8;
+    float4 nx[U];
+    bool non[U];
+    auto fetch = [&](uint32_t k0) {
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+            const uint32_t pos = (k0 + u) * SC_THREADS + threadIdx.x;
+            non[u] = pos < npos && (pos & (cap - 1)) < s_fill[min(pos >> cap_log2, nsb - 1)];
+            if (non[u]) nx[u] = src[pos];
+        }
+    };
+    const uint32_t ntiles = (npos + SC_THREADS - 1) / SC_THREADS;
+    fetch(0);
+    for (uint32_t k0 = 0; k0 < ntiles; k0 += U) {
+        float4 it[U];
+        bool on[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) { it[u] = nx[u]; on[u] = non[u]; }
+        if (k0 + U < ntiles) fetch(k0 + U);
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+            if (!on[u]) continue;
+            const uint32_t pr = __float_as_uint(it[u].x), i0 = pr & (SC_ENTRIES - 1), i1 = pr >> SC_LOG2;
+            const float w0 = it[u].w, a = it[u].y, b = it[u].z;
+            atomicAdd(&s_acc[2 * i0], (double)((1.f - w0) * a));
+            atomicAdd(&s_acc[2 * i0 + 1], (double)((1.f - w0) * b));
+            atomicAdd(&s_acc[2 * i1], (double)(w0 * a));
+            atomicAdd(&s_acc[2 * i1 + 1], (double)(w0 * b));
+        }
+    }
+    __syncthreads();
+    float2* __restrict__ dst = reinterpret_cast<float2*>(grad_table + 2 * ((size_t)gm.off[l] + (size_t)part * SC_ENTRIES));
+    constexpr uint32_t F = SC_ENTRIES / SC_THREADS;                         // all F loads in flight before the first add
+    float2 t[F];
+#pragma unroll
+    for (uint32_t k = 0; k < F; ++k) t[k] = dst[k * SC_THREADS + threadIdx.x];
+#pragma unroll
+    for (uint32_t k = 0; k < F; ++k) {
+        const double2 a = acc2[k * SC_THREADS + threadIdx.x];
+        t[k].x += (float)a.x; t[k].y += (float)a.y;
+        dst[k * SC_THREADS + threadIdx.x] = t[k];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_reduce_replicas(const float4* __restrict__ rep, uint32_t n_rep, uint32_t stride4, uint32_t count4,
+                                                         float4* __restrict__ grad_table) {
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= count4) return;
+    float4 t = grad_table[e];
+    for (uint32_t r = 0; r < n_rep; ++r) {                                  // fixed order
+        const float4 a = rep[(size_t)r * stride4 + e];
+        t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
+    }
+    grad_table[e] = t;
 }
 
 static int fill_meta(GridMeta* gm, uint32_t* hashed_mask, int n_levels, const float* scale, const uint32_t* res,
@@ -230,21 +419,125 @@ extern "C" int xr_hashgrid_fwd(const float* table, const float* x, uint32_t x_st
     return XR_OK;
 }
 
+static int scatter_env(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+// Which levels take which path, and the workspace layout:  [fill counts][bins][replicas of the dense slices]
+#define SC_REPLICAS 8
+struct ScatterPlan {
+    int l_bin;            // levels [l_bin, n_levels) are binned, [0, l_bin) take the atomic kernel
+    uint32_t parts, nsb;
+    size_t counts_bytes, bins_bytes, rep_bytes;
+    uint32_t rep_stride;  // floats per replica
+};
+static ScatterPlan scatter_plan(uint32_t n, int n_levels, const uint32_t* res, const uint32_t* off, uint32_t hashed_mask) {
+    static const int cap_levels = scatter_env("XR_SCAN_LEVELS", EN_MAX_LEVELS);
+    static const int use_rep = scatter_env("XR_REPLICAS", 1);
+    ScatterPlan p{};
+    p.l_bin = n_levels; p.parts = 1; p.nsb = xr_div_up(n, SC_BLOCK_SAMPLES);
+    if (n >= 16384u && p.nsb <= SC_MAX_SB) {
+        while (p.l_bin > 0 && n_levels - p.l_bin < cap_levels) {
+            const int l = p.l_bin - 1;
+            const uint32_t hsize = off[l + 1] - off[l];
+            if (!((hashed_mask >> l) & 1) || (hsize & (hsize - 1)) || hsize < SC_ENTRIES || (hsize >> SC_LOG2) > SC_MAX_PARTS ||
+                res[l] >= SC_ENTRIES || (off[l] & 1)) break;
+            p.parts = p.parts > (hsize >> SC_LOG2) ? p.parts : (hsize >> SC_LOG2);
+            --p.l_bin;
+        }
+    }
+    const uint32_t nl = (uint32_t)(n_levels - p.l_bin);
+    p.counts_bytes = (((size_t)nl * p.parts * p.nsb * sizeof(uint32_t)) + 255) & ~(size_t)255;
+    p.bins_bytes = (size_t)nl * p.nsb * SC_SUB_ITEMS * sizeof(float4);
+    // replicas only for a dense remainder next to a binned range (small tables: <= 2^14-entry... up to 2^19 each)
+    p.rep_stride = (use_rep && n >= 16384u && p.l_bin > 0) ? (2u * off[p.l_bin] + 3u) & ~3u : 0u;
+    p.rep_bytes = (size_t)SC_REPLICAS * p.rep_stride * sizeof(float);
+    return p;
+}
+
+extern "C" size_t xr_hashgrid_bwd_workspace_bytes(uint32_t n, int n_levels, const uint32_t* resolution_host, const uint32_t* offset_host) {
+    if (n_levels < 1 || n_levels > EN_MAX_LEVELS || !resolution_host || !offset_host) return 0;
+    GridMeta gm; uint32_t hm;
+    float dummy[EN_MAX_LEVELS] = {0};
+    if (fill_meta(&gm, &hm, n_levels, dummy, resolution_host, offset_host) != 0) return 0;
+    const ScatterPlan p = scatter_plan(n, n_levels, gm.res, gm.off, hm);
+    return p.counts_bytes + p.bins_bytes + p.rep_bytes;
+}
+
 extern "C" int xr_hashgrid_bwd(const float* x, uint32_t x_stride, const float* denc_t, uint32_t ld, uint32_t n, const uint32_t* n_dev, int n_levels,
                                const float* scale_host, const uint32_t* resolution_host, const uint32_t* offset_host,
-                               float* grad_table, void* stream_) {
+                               float* grad_table, void* workspace, size_t workspace_bytes, void* stream_) {
     if (n == 0) return XR_OK;
     XR_REQUIRE(x && denc_t && grad_table, "null pointer");
     XR_REQUIRE(x_stride >= 3 && ld >= n, "bad stride");
     GridMeta gm; uint32_t hm;
     XR_REQUIRE(fill_meta(&gm, &hm, n_levels, scale_host, resolution_host, offset_host) == 0, "bad level metadata");
-    const uint32_t per_xcd = (n_levels + 7) / 8;
-    const uint32_t bw_ch = BW_CH;      // swept 8..128 on MI355X: 0.71-0.75 ms at 2^18 dense-gradient samples, flat
-    gm.n_sblocks = xr_div_up(n, bw_ch * (EN_BLOCK / 16));
-    const uint32_t blocks = 8 * per_xcd * gm.n_sblocks;
-    hipLaunchKernelGGL(k_hashgrid_bwd, dim3(blocks), dim3(EN_BLOCK), 0, (hipStream_t)stream_, gm, hm, x, x_stride, denc_t, ld,
-                       n, n_dev, grad_table);
-    XR_LAUNCH_CHECK();
+    hipStream_t stream = (hipStream_t)stream_;
+    // Levels [l_bin, n_levels): hashed, power-of-two slices of 2^14..2^21 entries, resolution < 2^14 -> bin +
+    // LDS accumulate (no global atomics).  Levels [0, l_bin): dense / small -> atomic scatter with run-length
+    // merging, into SC_REPLICAS replicas of the slice when a workspace is there.  Without a workspace, or for
+    // small n (fixed cost: 2 x 128 KiB of LDS traffic per partition), every level takes the plain atomic kernel.
+    // XR_SCAN_LEVELS=0 / XR_REPLICAS=0 switch the two mechanisms off (measurement).
+    ScatterPlan p = scatter_plan(n, n_levels, gm.res, gm.off, hm);
+    const bool ws_ok = workspace && ((uintptr_t)grad_table & 15) == 0 && ((uintptr_t)workspace & 15) == 0;
+    if (!ws_ok) { p.l_bin = n_levels; p.rep_stride = 0; }
+    else XR_REQUIRE(workspace_bytes >= p.counts_bytes + p.bins_bytes + p.rep_bytes, "workspace too small");
+    static const int overlap = scatter_env("XR_SCATTER_OVERLAP", 1);
+    static hipStream_t aux = nullptr;
+    static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool forked = false;
+    if (p.l_bin > 0) {
+        // The dense remainder is independent of the binned range (disjoint table slices, read-only inputs) and
+        // both are latency-bound: when both exist the remainder runs on an internal helper stream, forked
+        // from and joined back into the caller's stream with events (created once per process).
+        hipStream_t ds = stream;
+        if (overlap && p.l_bin < n_levels) {
+            if (!aux) {
+                XR_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+                XR_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+                XR_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+            }
+            ds = aux;
+        }
+        GridMeta gd = gm;
+        gd.n_levels = p.l_bin;
+        if (p.l_bin < n_levels || (p.l_bin & 7)) gd.order = 2;   // a partial level range is spread over all XCDs
+        const uint32_t per_xcd = (p.l_bin + 7) / 8;
+        const uint32_t bw_ch = BW_CH;      // swept 8..128 on MI355X: 0.71-0.75 ms at 2^18 dense-gradient samples, flat
+        gd.n_sblocks = xr_div_up(n, bw_ch * (EN_BLOCK / 16));
+        const uint32_t blocks = (gd.order == 2 ? (uint32_t)p.l_bin : 8 * per_xcd) * gd.n_sblocks;
+        float* rep = p.rep_stride ? (float*)((char*)workspace + p.counts_bytes + p.bins_bytes) : nullptr;
+        if (ds != stream) { XR_HIP(hipEventRecord(ev_fork, stream)); XR_HIP(hipStreamWaitEvent(ds, ev_fork, 0)); }
+        if (rep) XR_HIP(hipMemsetAsync(rep, 0, p.rep_bytes, ds));
+        hipLaunchKernelGGL(k_hashgrid_bwd, dim3(blocks), dim3(EN_BLOCK), 0, ds, gd, hm, x, x_stride, denc_t, ld,
+                           n, n_dev, grad_table, rep, (uint32_t)SC_REPLICAS, p.rep_stride);
+        XR_LAUNCH_CHECK();
+        if (rep) {
+            const uint32_t count4 = p.rep_stride / 4;
+            hipLaunchKernelGGL(k_reduce_replicas, dim3(xr_div_up(count4, 256)), dim3(256), 0, ds, (const float4*)rep,
+                               (uint32_t)SC_REPLICAS, count4, count4, (float4*)grad_table);
+            XR_LAUNCH_CHECK();
+        }
+        if (ds != stream) { XR_HIP(hipEventRecord(ev_join, ds)); forked = true; }
+    }
+    if (p.l_bin < n_levels) {
+        const uint32_t nl = (uint32_t)(n_levels - p.l_bin);
+        static bool attr_set = false;
+        if (!attr_set) {
+            XR_HIP(hipFuncSetAttribute((const void*)k_scatter_accum, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC_LDS_BYTES));
+            attr_set = true;
+        }
+        uint32_t* counts = (uint32_t*)workspace;
+        float4* bins = (float4*)((char*)workspace + p.counts_bytes);
+        hipLaunchKernelGGL(k_scatter_bin, dim3(nl * p.nsb), dim3(SC_THREADS), 0, stream, gm, (uint32_t)p.l_bin, (uint32_t)n_levels,
+                           p.parts, p.nsb, x, x_stride, denc_t, ld, n, n_dev, counts, bins, grad_table);
+        XR_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_scatter_accum, dim3(nl * p.parts), dim3(SC_THREADS), SC_LDS_BYTES, stream, gm, (uint32_t)p.l_bin,
+                           (uint32_t)n_levels, p.parts, p.nsb, counts, bins, grad_table);
+        XR_LAUNCH_CHECK();
+    }
+    if (forked) XR_HIP(hipStreamWaitEvent(stream, ev_join, 0));
     return XR_OK;
 }
 

@@ -237,6 +237,7 @@ class GridMeta:
         if per_level_scale is None:
             per_level_scale = float(np.exp2(np.log2(2048 * 1 / 16) / (16 - 1)))  # hashnerf_mlp.py:17-20
         self.n_levels = int(n_levels)
+        self.log2_hashmap_size = int(log2_hashmap_size)
         self.n_features = 2
         self.scale = np.zeros(n_levels, np.float32)
         self.resolution = np.zeros(n_levels, np.uint32)
@@ -302,7 +303,7 @@ def hashgrid_fwd(table, x, meta, enc_t=None, ld=None, n_dev=None, rows=None, row
     return enc_t
 
 
-def hashgrid_bwd(x, denc_t, meta, grad_table, n_dev=None, row0=0, count=None, levels=None):
+def hashgrid_bwd(x, denc_t, meta, grad_table, n_dev=None, row0=0, count=None, levels=None, use_workspace=True):
     """scatter dL/denc into dL/dtable.  `levels=(l0, l1)` restricts the launch to that level range (the level
     metadata arrays are passed from l0 on; table offsets are absolute, so `grad_table` stays the full table):
     the data-parallel trainer scatters the fine half first and reduces it across ranks under the coarse half."""
@@ -315,10 +316,12 @@ def hashgrid_bwd(x, denc_t, meta, grad_table, n_dev=None, row0=0, count=None, le
         raise _lib.XrError('bad level range %r' % (levels,))
     ld = denc_t.shape[1]
     _ptr(denc_t)
+    ws = _ws(x.device, L.xr_hashgrid_bwd_workspace_bytes(n, l1 - l0, r + 4 * l0, o + 4 * l0), 'hgb') if use_workspace else None
     with _span('xr_hashgrid_bwd', 0 if n_dev is not None else n):
         _lib.check(L.xr_hashgrid_bwd(C.c_void_p(x.data_ptr() + 4 * xs * row0), xs,
                                      C.c_void_p(denc_t.data_ptr() + 4 * (row0 + 2 * l0 * ld)), ld, n, _ptr(n_dev),
-                                     l1 - l0, s + 4 * l0, r + 4 * l0, o + 4 * l0, _ptr(grad_table), _stream()),
+                                     l1 - l0, s + 4 * l0, r + 4 * l0, o + 4 * l0, _ptr(grad_table),
+                                     _ptr(ws), ws.numel() if ws is not None else 0, _stream()),
                    'xr_hashgrid_bwd')
     return grad_table
 
