@@ -229,6 +229,11 @@ int xr_huber_loss_grad_mse(const float* rgb, const float* target, const float* a
  * rows [n,11] = (o3, d3, rgba4, img_id) of the device-resident ray table -> batch tensors; bg ~ U[0,1) (PCG32) */
 int xr_make_batch(const float* rays_rgb_rows, uint32_t n, uint64_t rng_state, uint64_t rng_inc, float* rays_o,
                   float* rays_d, float* target, float* alpha, float* bg, int32_t* img_ids, void* stream);
+/* gradients[k] *= (*scale_dev) * host_factor for up to 4 tensors in one launch (scale_dev nullable = 1): the
+ * incoming-gradient scaling of the fused train step (networks/hashnerf.py:24-43 leaves it to autograd) and the
+ * 1/world_size of data-parallel averaging; a factor of exactly 1 costs no memory traffic. */
+int xr_scale_multi(int n_tensors, float* const* tensors, const size_t* n, const float* scale_dev, float host_factor,
+                   void* stream);
 /* torch.optim.Adam step with L2 weight decay (configs/instant_ngp/nerf_blender_local01.py:14-18),
  * fused with the optional EMA copy of mmcv's EMAHook (:24): ema = (1-mom)*ema + mom*p. */
 int xr_adam_step(float* p, const float* g, float* m, float* v, size_t n, int step, float lr, float beta1,

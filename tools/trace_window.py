@@ -1,0 +1,13 @@
+"""print the kernel sequence of the last full training iteration (between the last two k_adam_multi) from a
+rocprofv3 kernel_trace.csv: start offset, duration, queue, name"""
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('k_adam_multi')]
+which = int(sys.argv[2]) if len(sys.argv) > 2 else -2
+a, b = idx[which - 1], idx[which]
+t0 = int(rows[a]['End_Timestamp'])
+for r in rows[a:b + 1]:
+    s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+    print('%9.1f us  +%8.1f us  q%-3s %s' % ((s - t0) / 1e3, (e - s) / 1e3, r.get('Queue_Id', '?'), r['Kernel_Name'][:70]))
+print('iteration span %.1f us' % ((int(rows[b]['End_Timestamp']) - t0) / 1e3))

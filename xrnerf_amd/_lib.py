@@ -49,6 +49,7 @@ SIGNATURES = {
     'xr_huber_loss_grad_mse': (_i32, [_vp, _vp, _vp, _u32, _f, _f, _vp, _vp, _vp]),
     'xr_make_batch': (_i32, [_vp, _u32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'xr_adam_step_multi': (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f, _f, _f, _f, _f, _f, _vp]),
+    'xr_scale_multi': (_i32, [_i32, _vp, _vp, _vp, _f, _vp]),
     'xr_adam_step': (_i32, [_vp, _vp, _vp, _vp, _sz, _i32, _f, _f, _f, _f, _f, _vp, _f, _vp]),
 }
 

@@ -217,6 +217,7 @@ __global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_bwd(GridMeta gm, uint32_t
 //      plain 16-B accesses -- it is the only writer of that slice.
 // A sub-bin holds 2x its expected load; items beyond that (adversarially clustered inputs) are
 // scattered by A directly with global atomics, so any input stays correct.
+// Measured at 2^18 samples, 11 hashed levels: A 79 us (16 us without its 176 MB of item stores), B 105 us.
 // Measured dead ends, for the record: (1) every partition-owning workgroup scanning ALL samples and
 // filtering by partition: 0.22 ms per 8 levels (32x redundant filter work at 4 cycles per wave64 VALU
 // instruction, latency-bound gathers); (2) shared bins with one returning global atomic per
@@ -308,6 +309,12 @@ __global__ __launch_bounds__(SC_THREADS) void k_scatter_bin(GridMeta gm, uint32_
 // swap of the (f0, f1) pair has the throughput but needs the returned value: two exposed LDS latencies per add,
 // 62 us per partition.)  So the partition is accumulated in DOUBLE with returnless ds_add_f64 -- more accurate
 // than the fp32 atomics of the other path -- and rounded to fp32 once, when it is added to the table.
+#ifdef SC_TIMING
+__device__ long long g_sc_t[8];
+#define SC_T(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_sc_t[k] = wall_clock64(); } while (0)
+#else
+#define SC_T(k)
+#endif
 __global__ __launch_bounds__(SC_THREADS) void k_scatter_accum(GridMeta gm, uint32_t l_lo, uint32_t l_hi, uint32_t parts, uint32_t nsb,
                                                               const uint32_t* __restrict__ counts, const float4* __restrict__ bins,
                                                               float* __restrict__ grad_table) {
@@ -318,6 +325,7 @@ __global__ __launch_bounds__(SC_THREADS) void k_scatter_accum(GridMeta gm, uint3
     const uint32_t cap = SC_SUB_ITEMS / parts;
     const uint32_t* __restrict__ cnt = counts + ((size_t)li * parts + part) * nsb;
     double2* acc2 = reinterpret_cast<double2*>(s_acc);
+    SC_T(0);
     __shared__ uint32_t s_fill[SC_MAX_SB];                                  // fill counts of this unit's sub-bins
     for (uint32_t e = threadIdx.x; e < nsb; e += SC_THREADS) s_fill[e] = cnt[e];
     for (uint32_t e = threadIdx.x; e < SC_ENTRIES; e += SC_THREADS) acc2[e] = make_double2(0.0, 0.0);
@@ -339,6 +347,7 @@ __global__ __launch_bounds__(SC_THREADS) void k_scatter_accum(GridMeta gm, uint3
         }
     };
     const uint32_t ntiles = (npos + SC_THREADS - 1) / SC_THREADS;
+    SC_T(1);
     fetch(0);
     for (uint32_t k0 = 0; k0 < ntiles; k0 += U) {
         float4 it[U];
@@ -357,8 +366,10 @@ __global__ __launch_bounds__(SC_THREADS) void k_scatter_accum(GridMeta gm, uint3
             atomicAdd(&s_acc[2 * i1 + 1], (double)(w0 * b));
         }
     }
+    SC_T(2);
     __syncthreads();
     float2* __restrict__ dst = reinterpret_cast<float2*>(grad_table + 2 * ((size_t)gm.off[l] + (size_t)part * SC_ENTRIES));
+    SC_T(3);
     constexpr uint32_t F = SC_ENTRIES / SC_THREADS;                         // all F loads in flight before the first add
     float2 t[F];
 #pragma unroll
@@ -369,6 +380,7 @@ __global__ __launch_bounds__(SC_THREADS) void k_scatter_accum(GridMeta gm, uint3
         t[k].x += (float)a.x; t[k].y += (float)a.y;
         dst[k * SC_THREADS + threadIdx.x] = t[k];
     }
+    SC_T(4);
 }
 
 __global__ __launch_bounds__(256) void k_reduce_replicas(const float4* __restrict__ rep, uint32_t n_rep, uint32_t stride4, uint32_t count4,

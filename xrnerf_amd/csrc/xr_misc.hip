@@ -219,6 +219,35 @@ extern "C" int xr_adam_step_multi(int n_tensors, float* const* p, const float* c
     return XR_OK;
 }
 
+// gradients *= (*scale_dev) * host_factor for up to 4 tensors in one launch; a factor of exactly 1 (what
+// loss.backward() hands to a fused-step autograd node on one GPU) returns without touching memory
+struct ScaleTensors { float* p[4]; unsigned long long n[4]; };
+__global__ __launch_bounds__(256) void k_scale_multi(ScaleTensors t, int nt, const float* __restrict__ scale_dev, float host_factor) {
+    const float f = (scale_dev ? *scale_dev : 1.f) * host_factor;
+    if (f == 1.f) return;
+    for (int k = 0; k < nt; ++k) {
+        float* __restrict__ p = t.p[k];
+        const size_t n = t.n[k], n4 = n / 4;
+        for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+            float4 v = ((float4*)p)[i];
+            v.x *= f; v.y *= f; v.z *= f; v.w *= f;
+            ((float4*)p)[i] = v;
+        }
+        if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[n4 * 4 + threadIdx.x] *= f;
+    }
+}
+extern "C" int xr_scale_multi(int n_tensors, float* const* p, const size_t* n, const float* scale_dev, float host_factor, void* stream_) {
+    XR_REQUIRE(n_tensors >= 1 && n_tensors <= 4 && p && n, "bad argument");
+    ScaleTensors t; memset(&t, 0, sizeof(t));
+    for (int k = 0; k < n_tensors; ++k) {
+        XR_REQUIRE(p[k] && ((uintptr_t)p[k] & 15) == 0, "tensors must be 16-byte aligned");
+        t.p[k] = p[k]; t.n[k] = n[k];
+    }
+    hipLaunchKernelGGL(k_scale_multi, dim3(2048), dim3(256), 0, (hipStream_t)stream_, t, n_tensors, scale_dev, host_factor);
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}
+
 extern "C" int xr_adam_step(float* p, const float* g, float* m, float* v, size_t n, int step, float lr, float beta1,
                             float beta2, float eps, float weight_decay, float* ema, float ema_momentum, void* stream_) {
     if (n == 0) return XR_OK;
