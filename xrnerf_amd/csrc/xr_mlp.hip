@@ -22,7 +22,7 @@
 //     and forms dW = G * H^T on the matrix cores as well; that contraction runs over SAMPLES, i.e.
 //     it needs both operands transposed, which is the one place a per-wave LDS staging tile
 //     ([neuron][33]) is used.  dW accumulates in registers across all tiles a wave processes,
-//     then block-reduces through LDS atomics into one partial per workgroup; a second tiny
+//     then block-reduces through LDS (waves take turns, plain adds) into one partial per workgroup; a second tiny
 //     kernel sums the partials (fixed order).
 //   * the color net's input is cat(density_out[1:16], SH16) + one pad lane (tcnn pads the
 //     Identity-encoded input with 1.0).  In "slot" space m = 0..31 we use column (m+31)%32 of the
@@ -153,9 +153,11 @@ __device__ __forceinline__ void relu_mask(f32x16& g, const f32x16& h) {
 }
 // acc[to][ti] += g[to] (rows = out neurons) x h[ti]^T (rows = in neurons), contraction over the
 // 32 samples of the tile; `stage` is this wave's private LDS tile [(TO+TI)*32][33].
-template <int TO, int TI, bool SB = true>
-__device__ __forceinline__ void dw_accumulate(f32x16 (&acc)[TO][TI], const f32x16 (&g)[TO], const f32x16 (&h)[TI],
-                                              float* __restrict__ stage, int col, int hi) {
+// Split in two so that the caller can put the layer's dX chain (weights from LDS, independent of the staging
+// tile) between the transposing writes and the reads: PMC showed 23 % of the backward's wave cycles waiting
+// on LDS instructions with write -> read back to back.
+template <int TO, int TI>
+__device__ __forceinline__ void dw_stage(const f32x16 (&g)[TO], const f32x16 (&h)[TI], float* __restrict__ stage, int col, int hi) {
 #pragma unroll
     for (int to = 0; to < TO; ++to)
 #pragma unroll
@@ -165,26 +167,49 @@ __device__ __forceinline__ void dw_accumulate(f32x16 (&acc)[TO][TI], const f32x1
 #pragma unroll
         for (int r = 0; r < 16; ++r) stage[((TO + ti) * 32 + drow(r) + 4 * hi) * ST33 + col] = h[ti][r];
     __builtin_amdgcn_wave_barrier();   // same-wave LDS ops complete in order; keep the compiler from reordering
+}
+template <int TO, int TI>
+__device__ __forceinline__ void dw_mfma(f32x16 (&acc)[TO][TI], const float* __restrict__ stage, int col, int hi) {
+    constexpr int PF = 2;              // operand prefetch distance in K-steps
     const float* sg = stage + col * ST33 + hi;
+    float a[PF + 1][TO], b[PF + 1][TI];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+#pragma unroll
+        for (int to = 0; to < TO; ++to) a[p][to] = sg[(to * 32) * ST33 + 2 * p];
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) b[p][ti] = sg[((TO + ti) * 32) * ST33 + 2 * p];
+    }
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
-        if (SB && (t & 3) == 0) __builtin_amdgcn_sched_barrier(0);
-        float a[TO], b[TI];
+        if ((t & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+        if (t + PF < 16) {
 #pragma unroll
-        for (int to = 0; to < TO; ++to) a[to] = sg[(to * 32) * ST33 + 2 * t];
+            for (int to = 0; to < TO; ++to) a[(t + PF) % (PF + 1)][to] = sg[(to * 32) * ST33 + 2 * (t + PF)];
 #pragma unroll
-        for (int ti = 0; ti < TI; ++ti) b[ti] = sg[((TO + ti) * 32) * ST33 + 2 * t];
+            for (int ti = 0; ti < TI; ++ti) b[(t + PF) % (PF + 1)][ti] = sg[((TO + ti) * 32) * ST33 + 2 * (t + PF)];
+        }
 #pragma unroll
         for (int to = 0; to < TO; ++to)
 #pragma unroll
-            for (int ti = 0; ti < TI; ++ti) acc[to][ti] = MFMA32(a[to], b[ti], acc[to][ti]);
+            for (int ti = 0; ti < TI; ++ti) acc[to][ti] = MFMA32(a[t % (PF + 1)][to], b[t % (PF + 1)][ti], acc[to][ti]);
     }
     __builtin_amdgcn_wave_barrier();
 }
-// block-level reduction target: LDS buffer in the GLOBAL (compact, [out][in]) parameter layout
+template <int TO, int TI, bool SB = true>
+__device__ __forceinline__ void dw_accumulate(f32x16 (&acc)[TO][TI], const f32x16 (&g)[TO], const f32x16 (&h)[TI],
+                                              float* __restrict__ stage, int col, int hi) {
+    dw_stage<TO, TI>(g, h, stage, col, hi);
+    dw_mfma<TO, TI>(acc, stage, col, hi);
+}
+// block-level reduction target: LDS buffer in the GLOBAL (compact, [out][in]) parameter layout.
+// The four waves of a workgroup take turns (caller: `for w: if (wave == w) dw_flush(.., first = (w == 0)); barrier`):
+// the first one stores, the others read-add-write with plain LDS accesses.  NOT ds_add_f32: measured on MI355X
+// (tools/lds_probe.hip) an LDS fp32 atomic add costs 81 ns per wave instruction -- ~3 cycles per lane, 27x an
+// integer LDS atomic -- which made this flush (640 of them per workgroup) ~50 us of the 233-us kernel.
 template <int TO, int TI>
 __device__ __forceinline__ void dw_flush(const f32x16 (&acc)[TO][TI], float* __restrict__ dst, int rows, int K, bool rot,
-                                         int col, int hi) {
+                                         int col, int hi, bool first) {
 #pragma unroll
     for (int to = 0; to < TO; ++to)
 #pragma unroll
@@ -194,7 +219,7 @@ __device__ __forceinline__ void dw_flush(const f32x16 (&acc)[TO][TI], float* __r
                 const int o = to * 32 + drow(r) + 4 * hi;
                 int m = ti * 32 + col;
                 if (rot) m = (m + 31) & 31;
-                if (o < rows) atomicAdd(&dst[o * K + m], acc[to][ti][r]);   // ds_add_f32
+                if (o < rows) dst[o * K + m] = first ? acc[to][ti][r] : dst[o * K + m] + acc[to][ti][r];
             }
 }
 
@@ -350,27 +375,32 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void k_nerf_mlp_bwd_1_2(
         for (int r = 0; r < 16; ++r) g1[0][r] = 0.f;
         g1[0][0] = dr.x; g1[0][1] = dr.y; g1[0][2] = dr.z;             // hi==1 lanes hold zeros
         // color output layer
-        dw_accumulate<1, 2, false>(a_c2, g1, hc2, stage, col, hi);
+        dw_stage<1, 2>(g1, hc2, stage, col, hi);
         layer_bwd<1, 2, false, 3>(wc + SC::lds_off(2), g1, g2, col, hi);   // rows 0..2 (rgb) only
+        dw_mfma<1, 2>(a_c2, stage, col, hi);
         relu_mask(g2[0], hc2[0]); relu_mask(g2[1], hc2[1]);
         // color hidden layer 2
-        dw_accumulate<2, 2, false>(a_c1, g2, hc1, stage, col, hi);
+        dw_stage<2, 2>(g2, hc1, stage, col, hi);
         layer_bwd<2, 2, false>(wc + SC::lds_off(1), g2, g2b, col, hi);
+        dw_mfma<2, 2>(a_c1, stage, col, hi);
         relu_mask(g2b[0], hc1[0]); relu_mask(g2b[1], hc1[1]);
         // color input layer
-        dw_accumulate<2, 1, false>(a_c0, g2b, cin, stage, col, hi);
+        dw_stage<2, 1>(g2b, cin, stage, col, hi);
         layer_bwd<2, 1, false>(wc + SC::lds_off(0), g2b, g1, col, hi);       // g1 = dL/d(color input slots)
+        dw_mfma<2, 1>(a_c0, stage, col, hi);
         // slots 1..15 are density-output rows 1..15; row 0 takes dL/d(sigma raw); rows >= 16 are padding
 #pragma unroll
         for (int r = 8; r < 16; ++r) g1[0][r] = 0.f;
         if (hi == 0) g1[0][0] = dr.w;
         // density output layer
-        dw_accumulate<1, 2, false>(a_d1, g1, hd, stage, col, hi);
+        dw_stage<1, 2>(g1, hd, stage, col, hi);
         layer_bwd<1, 2, false, 8>(wd + SD::lds_off(1), g1, g2, col, hi);   // 16 real output neurons
+        dw_mfma<1, 2>(a_d1, stage, col, hi);
         relu_mask(g2[0], hd[0]); relu_mask(g2[1], hd[1]);
         // density input layer
-        dw_accumulate<2, 1, false>(a_d0, g2, xe, stage, col, hi);
+        dw_stage<2, 1>(g2, xe, stage, col, hi);
         layer_bwd<2, 1, false>(wd + SD::lds_off(0), g2, g1, col, hi);        // g1 = dL/d(encoded features)
+        dw_mfma<2, 1>(a_d0, stage, col, hi);
         if (live) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) denc_t[(size_t)(drow(r) + 4 * hi) * ld + s] = g1[0][r];
@@ -379,15 +409,17 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void k_nerf_mlp_bwd_1_2(
     // ---- block reduction of dW through LDS (compact global layout), then one partial per block
     __syncthreads();
     float* red = stage_all;
-    for (int e = threadIdx.x; e < GW; e += MLP_THREADS) red[e] = 0.f;
-    __syncthreads();
-    dw_flush<2, 1>(a_d0, red + SD::glb_off(0), 64, 32, false, col, hi);
-    dw_flush<1, 2>(a_d1, red + SD::glb_off(1), 16, 64, false, col, hi);
     float* redc = red + SD::glb_floats;
-    dw_flush<2, 1>(a_c0, redc + SC::glb_off(0), 64, 32, true, col, hi);
-    dw_flush<2, 2>(a_c1, redc + SC::glb_off(1), 64, 64, false, col, hi);
-    dw_flush<1, 2>(a_c2, redc + SC::glb_off(2), 16, 64, false, col, hi);
-    __syncthreads();
+    for (int w = 0; w < MLP_WAVES; ++w) {                              // fixed order: wave 0 stores, 1..3 add
+        if (wave == w) {
+            dw_flush<2, 1>(a_d0, red + SD::glb_off(0), 64, 32, false, col, hi, w == 0);
+            dw_flush<1, 2>(a_d1, red + SD::glb_off(1), 16, 64, false, col, hi, w == 0);
+            dw_flush<2, 1>(a_c0, redc + SC::glb_off(0), 64, 32, true, col, hi, w == 0);
+            dw_flush<2, 2>(a_c1, redc + SC::glb_off(1), 64, 64, false, col, hi, w == 0);
+            dw_flush<1, 2>(a_c2, redc + SC::glb_off(2), 16, 64, false, col, hi, w == 0);
+        }
+        __syncthreads();
+    }
     float* out = partial + (size_t)blockIdx.x * GW;
     for (int e = threadIdx.x; e < GW; e += MLP_THREADS) out[e] = red[e];
 }
@@ -401,8 +433,18 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict
     const uint32_t c = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const uint32_t j = blockIdx.x * 64 + c;
     float s = 0.f;
-    if (j < gw)
-        for (uint32_t b = rg; b < nb; b += 4) s += partial[(size_t)b * gw + j];
+    if (j < gw) {
+        // 16 loads in flight, summed in the same fixed order (a plain loop exposes one memory latency per term)
+        uint32_t b = rg;
+        for (; b + 4 * 15 < nb; b += 4 * 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = partial[(size_t)(b + 4 * u) * gw + j];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += v[u];
+        }
+        for (; b < nb; b += 4) s += partial[(size_t)b * gw + j];
+    }
     red[rg][c] = s;
     __syncthreads();
     if (rg == 0 && j < gw) {
@@ -519,10 +561,14 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void k_mlp_bwd(const float* __restr
     float* red = stage_all;
     for (int e = threadIdx.x; e < GW; e += MLP_THREADS) red[e] = 0.f;
     __syncthreads();
-    dw_flush<2, 1>(a_in, red + S::glb_off(0), 64, 32, false, col, hi);
-    if (NH == 2) dw_flush<2, 2>(a_hid, red + S::glb_off(1), 64, 64, false, col, hi);
-    dw_flush<1, 2>(a_out, red + S::glb_off(NH), 16, 64, false, col, hi);
-    __syncthreads();
+    for (int w = 0; w < MLP_WAVES; ++w) {                              // wave-serial plain adds into the zero-filled buffer
+        if (wave == w) {
+            dw_flush<2, 1>(a_in, red + S::glb_off(0), 64, 32, false, col, hi, false);
+            if (NH == 2) dw_flush<2, 2>(a_hid, red + S::glb_off(1), 64, 64, false, col, hi, false);
+            dw_flush<1, 2>(a_out, red + S::glb_off(NH), 16, 64, false, col, hi, false);
+        }
+        __syncthreads();
+    }
     float* out = partial + (size_t)blockIdx.x * GW;
     for (int e = threadIdx.x; e < GW; e += MLP_THREADS) out[e] = red[e];
 }

@@ -382,12 +382,14 @@ extern "C" int xr_clip_numsteps(const int32_t* numsteps_in, const uint32_t* coun
 
 // ------------------------------------------------------------------ K3 / K5 compositor forward
 // Reference: one thread per ray, front to back (calc_rgb.cu:20-66, :158-205).  A training batch has
-// only ~1e4 rays -- far too few threads for a 256-CU chip -- so here CG = 8 consecutive lanes share a
+// only ~1e4 rays -- far too few threads for a 256-CU chip -- so here CG = 16 consecutive lanes share a
 // ray: each takes a contiguous chunk of its samples, composites it locally (T_loc, c_loc), and the
 // chunks are stitched with the associativity of the transmittance product:
 //   T_before(chunk m) = prod_{j<m} T_loc(j),   C = sum_m T_before(m) * c_loc(m).
-// Same arithmetic per sample, 8x the parallelism, 1/8 of the serial length.
-#define CG 8
+// Same arithmetic per sample, 16x the parallelism, 1/16 of the serial length; a chunk of up to CG_RC samples is
+// fetched with all its loads in flight together (one exposed memory latency instead of one per sample).
+#define CG 16
+#define CG_RC 4          // chunk lengths up to CG_RC are loaded into registers in one go (rays of <= 64 samples)
 __device__ inline void cg_chunk(uint32_t n, uint32_t sub, uint32_t* k0, uint32_t* k1) {
     const uint32_t chunk = (n + CG - 1) / CG;
     *k0 = min(n, sub * chunk); *k1 = min(n, (sub + 1) * chunk);
@@ -420,14 +422,26 @@ __global__ __launch_bounds__(RM_BLOCK) void k_composite_fwd(
     uint32_t k0, k1;
     cg_chunk(n, sub, &k0, &k1);
     float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f;
-    for (uint32_t k = k0; k < k1; ++k) {
-        const float4 o = raw[base + k];
-        const float dt = xr_unwarp_dt(coords[7 * (size_t)(base + k) + 3]);
+    const uint32_t m = k1 - k0;
+    float4 oc[CG_RC]; float dc[CG_RC];
+    if (m <= CG_RC) {
+#pragma unroll
+        for (uint32_t u = 0; u < CG_RC; ++u)
+            if (u < m) { oc[u] = raw[base + k0 + u]; dc[u] = coords[7 * (size_t)(base + k0 + u) + 3]; }
+    }
+    auto step = [&](const float4 o, float dtw) {
+        const float dt = xr_unwarp_dt(dtw);
         const float density = xr_act_density(o.w, density_act);
         const float alpha = 1.f - __expf(-density * dt);
         const float w = alpha * T;
         cr += w * xr_act_rgb(o.x, rgb_act); cg += w * xr_act_rgb(o.y, rgb_act); cb += w * xr_act_rgb(o.z, rgb_act);
         T *= (1.f - alpha);
+    };
+    if (m <= CG_RC) {
+#pragma unroll
+        for (uint32_t u = 0; u < CG_RC; ++u) if (u < m) step(oc[u], dc[u]);
+    } else {
+        for (uint32_t k = k0; k < k1; ++k) step(raw[base + k], coords[7 * (size_t)(base + k) + 3]);
     }
     float Tb, ar, ag, ab, Tt, Cr, Cg, Cb;
     cg_stitch(sub, T, cr, cg, cb, &Tb, &ar, &ag, &ab, &Tt, &Cr, &Cg, &Cb);
@@ -549,7 +563,7 @@ extern "C" int xr_render_slice_composite(const float* raw_slice, const float* co
 }
 
 // ------------------------------------------------------------------ K4 compositor backward (calc_rgb.cu:87-139)
-// Same 8-lanes-per-ray split: pass 1 composites each chunk locally to obtain, after stitching, the
+// Same CG-lanes-per-ray split: pass 1 composites each chunk locally to obtain, after stitching, the
 // transmittance and colour accumulated BEFORE the chunk; pass 2 re-walks the chunk with those as
 // start values and emits the gradients (global T_k = T_before * T_loc,k ; prefix C_k = C_before + T_before * c_loc,k).
 __global__ __launch_bounds__(RM_BLOCK) void k_composite_bwd(
@@ -567,24 +581,38 @@ __global__ __launch_bounds__(RM_BLOCK) void k_composite_bwd(
     uint32_t k0, k1;
     cg_chunk(n, sub, &k0, &k1);
     float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f;
-    for (uint32_t k = k0; k < k1; ++k) {
-        const float4 o = raw[base + k];
-        const float dt = xr_unwarp_dt(coords[7 * (size_t)(base + k) + 3]);
+    const uint32_t m = k1 - k0;
+    float4 oc[CG_RC]; float dc[CG_RC];
+    float gr = 0.f, gg = 0.f, gb = 0.f, fr = 0.f, fg = 0.f, fb = 0.f;      // issued with the chunk loads, used by pass 2
+    if (in) {
+        gr = grad_rgb[3 * i]; gg = grad_rgb[3 * i + 1]; gb = grad_rgb[3 * i + 2];
+        fr = rgb_final[3 * i]; fg = rgb_final[3 * i + 1]; fb = rgb_final[3 * i + 2];
+    }
+    if (m <= CG_RC) {
+#pragma unroll
+        for (uint32_t u = 0; u < CG_RC; ++u)
+            if (u < m) { oc[u] = raw[base + k0 + u]; dc[u] = coords[7 * (size_t)(base + k0 + u) + 3]; }
+    }
+    auto pass1 = [&](const float4 o, float dtw) {
+        const float dt = xr_unwarp_dt(dtw);
         const float alpha = 1.f - __expf(-xr_act_density(o.w, density_act) * dt);
         const float w = alpha * T;
         cr += w * xr_act_rgb(o.x, rgb_act); cg += w * xr_act_rgb(o.y, rgb_act); cb += w * xr_act_rgb(o.z, rgb_act);
         T *= (1.f - alpha);
+    };
+    if (m <= CG_RC) {
+#pragma unroll
+        for (uint32_t u = 0; u < CG_RC; ++u) if (u < m) pass1(oc[u], dc[u]);
+    } else {
+        for (uint32_t k = k0; k < k1; ++k) pass1(raw[base + k], coords[7 * (size_t)(base + k) + 3]);
     }
     float Tb, ar, ag, ab, Tt, Cr, Cg, Cb;
     cg_stitch(sub, T, cr, cg, cb, &Tb, &ar, &ag, &ab, &Tt, &Cr, &Cg, &Cb);
     if (!in || k0 >= k1) return;
-    const float gr = grad_rgb[3 * i], gg = grad_rgb[3 * i + 1], gb = grad_rgb[3 * i + 2];
-    const float fr = rgb_final[3 * i], fg = rgb_final[3 * i + 1], fb = rgb_final[3 * i + 2];
     T = Tb; cr = ar; cg = ag; cb = ab;
-    for (uint32_t k = k0; k < k1; ++k) {
-        const float4 o = raw[base + k];
+    auto pass2 = [&](const float4 o, float dtw, uint32_t k) {
         const float r = xr_act_rgb(o.x, rgb_act), g = xr_act_rgb(o.y, rgb_act), b = xr_act_rgb(o.z, rgb_act);
-        const float dt = xr_unwarp_dt(coords[7 * (size_t)(base + k) + 3]);
+        const float dt = xr_unwarp_dt(dtw);
         const float density = xr_act_density(o.w, density_act);
         const float alpha = 1.f - __expf(-density * dt);
         const float w = alpha * T;
@@ -598,6 +626,12 @@ __global__ __launch_bounds__(RM_BLOCK) void k_composite_bwd(
         const float dot = gr * (T * r - sr) + gg * (T * g - sg) + gb * (T * b - sb);
         d.w = loss_scale * (xr_dact_density(o.w, density_act) * (dt * dot)) + (o.w < 0.f ? -l1 : 0.0f);
         dout[base + k] = d;
+    };
+    if (m <= CG_RC) {
+#pragma unroll
+        for (uint32_t u = 0; u < CG_RC; ++u) if (u < m) pass2(oc[u], dc[u], k0 + u);
+    } else {
+        for (uint32_t k = k0; k < k1; ++k) pass2(raw[base + k], coords[7 * (size_t)(base + k) + 3], k);
     }
 }
 

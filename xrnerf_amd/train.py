@@ -9,6 +9,8 @@ SURVEY.md section 2a rows 10-16): only what a bench needs to drive `HashNerfNetw
 import math
 
 import numpy as np
+import os
+
 import torch
 
 from . import ops, synthetic
@@ -185,7 +187,8 @@ class Trainer:
             self.net.grad_sync = xdist.BucketedGradSync(world_size)
         self.rays_done = 0
         self.lazy_log = True
-        self.overlap_march = True      # run K1 of the next batch on a side stream under this step's backward
+        # run K1 of the next batch on a side stream under this step's backward (XRNERF_OVERLAP_MARCH=0: serial)
+        self.overlap_march = os.environ.get('XRNERF_OVERLAP_MARCH', '1') != '0'
         self._next_batch = None
         self._ev_done = [None, None]   # completion events of the last two iterations
 
