@@ -26,8 +26,8 @@ def child():
         a.record()
         for _ in range(reps): f()
         b.record(); torch.cuda.synchronize(); return a.elapsed_time(b) / reps
-    out = ['n=%d mode=%s cap=%s' % (n, os.environ.get('XR_BIN_DBG'), os.environ.get('XR_SCAN_LEVELS'))]
-    for lv in ((5, 16), (8, 16)):
+    out = ['n=%d mode=%s cap=%s' % (n, os.environ.get('XR_SCATTER_GROUPS'), os.environ.get('XR_SCAN_LEVELS'))]
+    for lv in ((0, 16), (5, 16), (8, 16)):
         out.append('levels %-8s %.4f ms' % (lv, timeit(lambda: ops.hashgrid_bwd(c[:, :3], denc, meta, g, levels=lv))))
     # correctness of the scan kernel against the atomic kernel is in tests/; here a quick checksum
     g.zero_(); ops.hashgrid_bwd(c[:, :3], denc, meta, g); out.append('sum|g| %.6e' % float(g.abs().sum()))
@@ -38,6 +38,6 @@ if __name__ == '__main__':
     if os.environ.get('XR_CHILD') == '1':
         child()
     else:
-        for mode, cap in (('0', '16'), ('1', '16'), ('3', '16')):
-            env = dict(os.environ, XR_CHILD='1', XR_BIN_DBG=mode, XR_SCATTER_OVERLAP='0', XR_SCAN_LEVELS=cap)
+        for mode, cap in (('1', '16'), ('2', '16'), ('3', '16')):
+            env = dict(os.environ, XR_CHILD='1', XR_SCATTER_GROUPS=mode, XR_SCAN_LEVELS=cap)
             subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, check=False)
