@@ -214,13 +214,11 @@ def main():
         roof = {'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': achieved / MFMA_F32_PEAK_TFLOPS, 'traffic': None}
     # HBM traffic per launch of that kernel from rocprofv3 PMC passes of THIS command (separate --pmc runs of
-    # FETCH_SIZE / WRITE_SIZE, steady-state launches; profiles/r01_pmc_traffic.json; the raw sum -- on gfx950
+    # FETCH_SIZE / WRITE_SIZE, steady-state launches, tools/pmc_traffic.py -> profiles/r01_pmc_traffic.json; raw sum -- on gfx950
     # FETCH_SIZE may under-report wide coalesced reads by up to 2x, the file also carries that upper estimate)
-    kname = {'xr_hashgrid_bwd': 'k_hashgrid_bwd', 'xr_hashgrid_fwd': 'k_hashgrid_fwd', 'xr_nerf_mlp_bwd': 'k_nerf_mlp_bwd_1_2',
-             'xr_nerf_mlp_fwd': 'void k_nerf_mlp_fwd<1, 2, true>', 'xr_calc_rgb_backward': 'k_composite_bwd'}.get(dom)
     try:
         pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
-        roof['traffic'] = pmc[kname]['bytes_raw'] if kname in pmc else None
+        roof['traffic'] = pmc[dom]['bytes_raw'] if dom in pmc else None      # summed over the entry point's kernels
         roof['traffic_unit'] = 'bytes/launch (PMC, 2^18-sample batches)'
     except Exception:  # noqa: BLE001
         roof['traffic'] = None
