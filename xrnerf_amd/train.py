@@ -15,6 +15,7 @@ import torch
 
 from . import ops, synthetic
 from .builder import build_network
+from .datasets import DeviceRayTable
 
 
 def ngp_lego_model_cfg(n_rays=4096):
@@ -82,55 +83,18 @@ def step_lr(base_lr, it, step=10000, gamma=0.2):
     return base_lr * gamma ** (it // step)
 
 
-class SyntheticLego:
+class SyntheticLego(DeviceRayTable):
     """Device-resident stand-in for HashNerfDataset (hashnerf_dataset.py:26-73): cameras on the
     Blender hemisphere in NGP space, all training rays [N*H*W, 11] = (o3, d3, rgba4, img_id)
     precomputed ON THE DEVICE with xr_gen_rays, targets rendered analytically from a union of
     axis-aligned boxes ("Lego-shaped", ~6 % of the level-0 cells), pre-shuffled once like the
-    reference's np.random.shuffle."""
+    reference's np.random.shuffle.  (Real Blender scenes: datasets.HashNerfDataset, same interface.)"""
 
     def __init__(self, device, n_img=20, H=800, W=800, seed=1, shuffle=True):
-        self.device, self.H, self.W, self.n_img = device, H, W, n_img
-        self.focal = float(synthetic.LEGO_FOCAL) * W / 800.0
-        self.poses = synthetic.lego_cameras(n_img, seed=seed)
         self.boxes = _lego_boxes()
-        rows = []
-        for k in range(n_img):
-            o, d = ops.gen_rays(self.poses[k], H, W, self.focal, self.focal, 0.5 * W, 0.5 * H, device=device)
-            rgba = _render_boxes(o, d, self.boxes.to(device))
-            ids = torch.full((o.shape[0], 1), float(k), dtype=torch.float32, device=device)
-            rows.append(torch.cat([o, d, rgba, ids], 1))
-        self.rays_rgb = torch.cat(rows, 0)
-        if shuffle:
-            g = torch.Generator(device='cpu').manual_seed(seed)
-            perm = torch.randperm(self.rays_rgb.shape[0], generator=g).to(device)
-            self.rays_rgb = self.rays_rgb[perm].contiguous()
-        self.cur_i = 0
-        self.N_rand = 4096
-        self.batches_drawn = 0
-
-    # HashNerfDataset.get_alldata / get_info
-    def get_alldata(self):
-        aabb_scale = 1
-        return {'aabb_scale': aabb_scale, 'aabb_range': (0.5 - aabb_scale / 2, 0.5 + aabb_scale / 2),
-                'poses': self.poses, 'focal': np.ones((self.n_img, 2), dtype=float) * self.focal,
-                'metadata': synthetic.metadata_rows(self.n_img, self.focal)}
-
-    def get_info(self):
-        return {'H': self.H, 'W': self.W, 'focal': self.focal}
-
-    def set_batchsize(self, bs):          # ModifyBatchsizeHook
-        self.N_rand = int(bs)
-
-    def next_batch(self):
-        """HashBatchSample + RandomBGColor (pipelines/create.py:153-191, augment.py:290-317), on device, one launch."""
-        n = self.N_rand
-        if self.cur_i + n >= self.rays_rgb.shape[0]:
-            self.cur_i = 0
-        batch = ops.make_batch(self.rays_rgb[self.cur_i:self.cur_i + n], n, self.batches_drawn)
-        self.cur_i += n
-        self.batches_drawn += 1
-        return batch
+        boxes = self.boxes.to(device)
+        super().__init__(device, synthetic.lego_cameras(n_img, seed=seed), lambda k, o, d: _render_boxes(o, d, boxes),
+                         H, W, float(synthetic.LEGO_FOCAL) * W / 800.0, seed=seed, shuffle=shuffle)
 
 
 def _lego_boxes(seed=2, fill=0.07, n_boxes=40):
