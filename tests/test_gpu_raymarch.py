@@ -46,6 +46,23 @@ def test_k1_bit_exact(O, lego, dev, n_rays, calls):
     assert np.array_equal(bits(gc[:S_]), bits(rc[:S_]))
 
 
+def test_k1_multi_cascade_bit_exact(O, dev):
+    """aabb_scale = 16, five active cascades (the reference-generated fixture of tests/golden/make_golden_cascades.py)"""
+    import os, sys
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    sys.path.insert(0, G)
+    from make_golden_cascades import cascade_inputs
+    from xrnerf_amd import ops
+    g = np.load(os.path.join(G, 'ref_raymarch_cascades.npz'))
+    grid, o, d, aabb = cascade_inputs()
+    bf = O.bitfield_given_mean(grid, np.float32(0.5))
+    c, ri, ns, cnt = ops.rays_sampler(T(o, dev), T(d, dev), T(bf, dev), aabb, 0.05, 1 / 256, o.shape[0] * 1024, 0)
+    assert np.array_equal(cnt.cpu().numpy(), g['counter'])
+    assert np.array_equal(ns.cpu().numpy(), g['numsteps']) and np.array_equal(ri.cpu().numpy(), g['index'])
+    s = int(cnt[1])
+    assert np.array_equal(bits(c[:s].cpu().numpy()), bits(g['coords']))
+
+
 def test_k1_overflow_and_k2_clip(O, lego, dev):
     """max_samples smaller than the demand: overflowing rays get (0, base) and no index (ray_sampler.cu:76-82);
     K2 clips at max_compacted (compacted_coord.cu:63-64)."""

@@ -197,3 +197,19 @@ def test_port_vs_reference_kernels_live(O, lego):
         assert np.array_equal(p[2], q[2]) and np.array_equal(p[1], q[1]) and np.array_equal(p[3], q[3])
     assert np.array_equal(O.bitfield_given_mean(lego['grid'], lego['mean']),
                           O.bitfield_given_mean(lego['grid'], lego['mean'], backend='ref'))
+
+
+def test_k1_multi_cascade_golden(O):
+    """aabb_scale = 16 (five active cascades): mip selection from position and step size,
+    coarse-cascade voxel skipping, rays entering the box from outside -- port == the reference's ray_sampler.cu"""
+    import sys
+    sys.path.insert(0, G)
+    from make_golden_cascades import cascade_inputs
+    g = np.load(os.path.join(G, 'ref_raymarch_cascades.npz'))
+    grid, o, d, aabb = cascade_inputs()
+    bf = O.bitfield_given_mean(grid, np.float32(0.5))
+    c, ri, ns, cnt = O.rays_sampler(o, d, bf, aabb=aabb, rng_calls=0)
+    assert np.array_equal(cnt, g['counter']) and np.array_equal(ns, g['numsteps']) and np.array_equal(ri, g['index'])
+    assert np.array_equal(bits(c[:int(cnt[1])]), bits(g['coords']))
+    # the fixture really exercises the coarse cascades: warped dt spans more than the two values of a unit cube
+    assert len(np.unique(g['coords'][:, 3])) > 1000 and int(g['numsteps'][:, 0].max()) > 40
