@@ -117,12 +117,13 @@ class DeviceRayTable:
     def set_batchsize(self, bs):            # ModifyBatchsizeHook (core/hooks/hash_hook.py:33-42)
         self.N_rand = int(bs)
 
-    def next_batch(self):
-        """HashBatchSample + RandomBGColor (pipelines/create.py:153-191, augment.py:290-317), on device, one launch."""
+    def next_batch(self, out=None):
+        """HashBatchSample + RandomBGColor (pipelines/create.py:153-191, augment.py:290-317), on device, one launch.
+        `out`: caller-owned buffers (ops.make_batch_buffers) the batch tensors become views of."""
         n = min(self.N_rand, self.rays_rgb.shape[0])          # a scene smaller than the batch: every ray, every step
         if self.cur_i + n > self.rays_rgb.shape[0]:
             self.cur_i = 0
-        batch = ops.make_batch(self.rays_rgb[self.cur_i:self.cur_i + n], n, self.batches_drawn)
+        batch = ops.make_batch(self.rays_rgb[self.cur_i:self.cur_i + n], n, self.batches_drawn, out=out)
         self.cur_i += n
         self.batches_drawn += 1
         return batch

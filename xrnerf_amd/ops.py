@@ -99,16 +99,20 @@ def pcg32_host_state(ncalls, seed=9121):
 
 # ---------------------------------------------------------------- K1 / K2
 def rays_sampler(rays_o, rays_d, bitfield, aabb, near_distance, cone_angle, max_samples, rng_calls,
-                 coords_out=None, ws_tag='k1'):
-    """returns coords_out [max_samples,7], rays_index [n,1], rays_numsteps [n,2], counter [2] (device)."""
+                 coords_out=None, ws_tag='k1', small_out=None):
+    """returns coords_out [max_samples,7], rays_index [n,1], rays_numsteps [n,2], counter [2] (device).
+    `small_out` = (rays_index, numsteps, counter) caller-owned buffers (persistent double buffers of the trainer)."""
     L = _lib.load()
     n = rays_o.shape[0]
     dev = rays_o.device
     if coords_out is None:
         coords_out = torch.empty((max_samples, 7), dtype=torch.float32, device=dev)
-    rays_index = torch.empty((n, 1), dtype=torch.int32, device=dev)
-    numsteps = torch.empty((n, 2), dtype=torch.int32, device=dev)
-    counter = torch.empty((2,), dtype=torch.int32, device=dev)
+    if small_out is not None:
+        rays_index, numsteps, counter = small_out
+    else:
+        rays_index = torch.empty((n, 1), dtype=torch.int32, device=dev)
+        numsteps = torch.empty((n, 2), dtype=torch.int32, device=dev)
+        counter = torch.empty((2,), dtype=torch.int32, device=dev)
     nb = L.xr_rays_sampler_workspace_bytes(n)
     ws = _ws(dev, nb, ws_tag)
     st, inc = pcg32_host_state(rng_calls)
@@ -403,12 +407,23 @@ def huber_loss_grad_mse(rgb, target, alpha, delta=0.1, scale=5.0, out=None):
     return out, grad
 
 
-def make_batch(rows, n, call_index, seed=20220901):
-    """rows: contiguous [>=n, 11] slice of the device-resident ray table -> dict of batch tensors"""
+def make_batch_buffers(capacity, device):
+    """caller-owned output buffers for make_batch(out=...), `capacity` rays"""
+    f = lambda c: torch.empty((capacity, c), dtype=torch.float32, device=device)
+    return {'rays_o': f(3), 'rays_d': f(3), 'target_s': f(3), 'alpha': f(1), 'bg_color': f(3),
+            'img_ids': torch.empty((capacity, 1), dtype=torch.int32, device=device)}
+
+
+def make_batch(rows, n, call_index, seed=20220901, out=None):
+    """rows: contiguous [>=n, 11] slice of the device-resident ray table -> dict of batch tensors
+    (views of `out`'s buffers when given: no allocation, nothing for the caching allocator to track across streams)"""
     dev = rows.device
-    f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
-    o, d, tgt, alpha, bg = f(n, 3), f(n, 3), f(n, 3), f(n, 1), f(n, 3)
-    ids = torch.empty((n, 1), dtype=torch.int32, device=dev)
+    if out is not None:
+        o, d, tgt, alpha, bg, ids = (out[k][:n] for k in ('rays_o', 'rays_d', 'target_s', 'alpha', 'bg_color', 'img_ids'))
+    else:
+        f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        o, d, tgt, alpha, bg = f(n, 3), f(n, 3), f(n, 3), f(n, 1), f(n, 3)
+        ids = torch.empty((n, 1), dtype=torch.int32, device=dev)
     st, inc = pcg32_host_state(call_index, seed)
     _lib.check(_lib.load().xr_make_batch(_ptr(rows), n, st, inc, _ptr(o), _ptr(d), _ptr(tgt), _ptr(alpha), _ptr(bg),
                                          _ptr(ids), _stream()), 'xr_make_batch')

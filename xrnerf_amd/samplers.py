@@ -19,6 +19,8 @@ Deliberate differences, none of which changes a result:
   * the hidden global RNG (`static pcg32 rng{9121}` per translation unit) becomes two explicit call
     counters on this object.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -158,19 +160,30 @@ class NGPGridSampler(nn.Module):
             cur.wait_event(pf['event'])
             coords, rays_index, rays_numsteps, counter = pf['out']
             self._pending_counts.append(pf['host'])
-            # everything allocated on the side stream is consumed on this one
-            for t in (rays_index, rays_numsteps, counter):
-                t.record_stream(cur)
-            for t in data.values():
-                if torch.is_tensor(t) and t.is_cuda:
-                    t.record_stream(cur)
+            # K1's outputs live in this sampler's persistent double buffers (nothing was allocated on the side
+            # stream).  Batch tensors allocated there by the caller must be handed over to this stream -- unless
+            # the caller owns them persistently too (`persistent_batches`): every record_stream'd tensor costs an
+            # event record on this stream when it is freed, ~6 us of idle GPU each, 9 of them per iteration
+            if not getattr(self, 'persistent_batches', False):
+                for t in data.values():
+                    if torch.is_tensor(t) and t.is_cuda:
+                        t.record_stream(cur)
         else:
+            slot = self._next_slot(is_training)
             coords, rays_index, rays_numsteps, counter = ops.rays_sampler(
                 rays_o, rays_d, self.density_grid_bitfield, aabb, self.near_distance, self.cone_angle_constant,
-                max_samples, self.k1_calls, coords_out=self._coords_buffer(max_samples))
+                max_samples, self.k1_calls, coords_out=self._coords_buffer(max_samples, slot),
+                small_out=self._small_buffers(n_rays, slot))
             self.k1_calls += 1
             if is_training:
-                self._pending_counts.append(self._count_to_host(counter))
+                # the counter's device-to-host copy goes to the side stream: on the compute stream its
+                # system-scope completion would sit between K1 and the first kernel that uses K1's output
+                e = torch.cuda.Event()
+                e.record(torch.cuda.current_stream())
+                side = self.side_stream()
+                with torch.cuda.stream(side):
+                    side.wait_event(e)
+                    self._pending_counts.append(self._count_to_host(counter))
         self.rays_index = rays_index
         if not is_training:
             n_valid, samples = counter.tolist()      # one host read-back per call (rays_sampler.py:72)
@@ -203,17 +216,35 @@ class NGPGridSampler(nn.Module):
             cb()       # e.g. the trainer issues the NEXT batch's march on a side stream right here
         return data
 
-    def _coords_buffer(self, rows):
-        # two buffers, alternating per K1 launch: the previous launch's rows are still being read by the
-        # previous iteration's backward when a prefetched launch writes the next ones
+    # K1 output buffers are persistent and owned by the sampler: slots 0/1 alternate over the TRAINING launches (the
+    # previous launch's rows are still being read by the previous iteration's backward when a prefetched launch
+    # writes the next ones), slot 2 serves test / render launches, which may come in between
+    def _next_slot(self, is_training):
+        if not is_training:
+            return 2
+        self._train_launches = getattr(self, '_train_launches', 0) + 1
+        return self._train_launches & 1
+
+    def _coords_buffer(self, rows, slot):
         bufs = getattr(self, '_coords_bufs', None)
         if bufs is None:
-            bufs = self._coords_bufs = [None, None]
-        k = self.k1_calls & 1
-        buf = bufs[k]
+            bufs = self._coords_bufs = [None, None, None]
+        buf = bufs[slot]
         if buf is None or buf.shape[0] < rows or buf.device != self.device:
-            buf = bufs[k] = torch.empty((rows, 7), dtype=torch.float32, device=self.device)
+            buf = bufs[slot] = torch.empty((rows, 7), dtype=torch.float32, device=self.device)
         return buf[:rows]
+
+    def _small_buffers(self, n_rays, slot):
+        bufs = getattr(self, '_small_bufs', None)
+        if bufs is None:
+            bufs = self._small_bufs = [None, None, None]
+        b = bufs[slot]
+        if b is None or b[0].shape[0] < n_rays or b[0].device != self.device:
+            cap = max(n_rays, 1 << 15)
+            b = bufs[slot] = (torch.empty((cap, 1), dtype=torch.int32, device=self.device),
+                              torch.empty((cap, 2), dtype=torch.int32, device=self.device),
+                              torch.empty((2,), dtype=torch.int32, device=self.device))
+        return b[0][:n_rays], b[1][:n_rays], b[2]
 
     # ------------------------------------------------------------------ K1 overlap
     def can_prefetch(self, next_iter):
@@ -224,7 +255,9 @@ class NGPGridSampler(nn.Module):
 
     def side_stream(self):
         if getattr(self, '_side', None) is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            # high priority (XRNERF_SIDE_PRIORITY, default -1): the march has few waves and long dependent-load chains;
+            # scheduled first it finishes early in the step instead of being stretched to its end
+            self._side = torch.cuda.Stream(device=self.device, priority=int(os.environ.get('XRNERF_SIDE_PRIORITY', '-1')))
         return self._side
 
     def prefetch(self, data, buffer_free_event=None):
@@ -241,20 +274,32 @@ class NGPGridSampler(nn.Module):
             side.wait_event(ev)
         if buffer_free_event is not None:
             side.wait_event(buffer_free_event)
+        slot = self._next_slot(True)
         out = ops.rays_sampler(rays_o, rays_d, self.density_grid_bitfield, aabb, self.near_distance,
                                self.cone_angle_constant, max_samples, self.k1_calls,
-                               coords_out=self._coords_buffer(max_samples), ws_tag='k1_side')
+                               coords_out=self._coords_buffer(max_samples, slot), ws_tag='k1_side',
+                               small_out=self._small_buffers(n_rays, slot))
         self.k1_calls += 1
-        host = self._count_to_host(out[3])
+        # the compute stream waits for the MARCH only: the event sits before the counter's device-to-host copy
+        # (behind it, the waiter also inherits the copy's system-scope completion: measured 45 us of idle compute
+        # stream at the start of every iteration)
         done = torch.cuda.Event()
         done.record(side)
+        host = self._count_to_host(out[3])
         self._prefetched = {'rays_o': rays_o, 'max_samples': max_samples, 'out': out, 'event': done, 'host': host}
 
     def _count_to_host(self, counter):
         """asynchronous copy of K1's (rays, samples) counter to pinned host memory, right behind the launch: by
         the time the batch-size feedback needs the numbers (every 16th iteration) they have long arrived, so
         reading them does not drain the compute stream the way `measured_batch_size.item()` does"""
-        host = torch.empty((2,), dtype=torch.int32, pin_memory=True)
+        # pinned staging buffers come from a small ring allocated once: a fresh pin_memory allocation per iteration
+        # goes through the host allocator (and, on a miss, hipHostMalloc)
+        ring = getattr(self, '_pinned_ring', None)
+        if ring is None:
+            ring = self._pinned_ring = [torch.empty((2,), dtype=torch.int32, pin_memory=True) for _ in range(64)]
+            self._pinned_next = 0
+        host = ring[self._pinned_next % len(ring)]
+        self._pinned_next += 1
         host.copy_(counter, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())

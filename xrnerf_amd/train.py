@@ -155,6 +155,7 @@ class Trainer:
         self.overlap_march = os.environ.get('XRNERF_OVERLAP_MARCH', '1') != '0'
         self._next_batch = None
         self._ev_done = [None, None]   # completion events of the last two iterations
+        self._bbufs = [None, None]
 
     def step(self):
         net, data = self.net, self.data
@@ -193,10 +194,26 @@ class Trainer:
             return
         side = net.sampler.side_stream()
         with torch.cuda.stream(side):
-            nb = data.next_batch()
-            # that launch overwrites the coordinate buffer last read by the PREVIOUS iteration
+            # these launches overwrite the batch / coordinate buffers last read by the PREVIOUS iteration (two
+            # persistent sets, alternating): ordered behind its completion event
+            if self._ev_done[1] is not None:
+                side.wait_event(self._ev_done[1])
+            bufs = self._batch_buffers((self.iter + 1) & 1, data.N_rand)
+            nb = data.next_batch(out=bufs) if bufs is not None else data.next_batch()
             net.sampler.prefetch(nb, buffer_free_event=self._ev_done[1])
         self._next_batch = nb
+
+    def _batch_buffers(self, slot, n):
+        """persistent output buffers of the batch kernel for prefetched batches (None: the dataset cannot use them)"""
+        import inspect
+        if 'out' not in inspect.signature(self.data.next_batch).parameters:
+            self.net.sampler.persistent_batches = False
+            return None
+        if self._bbufs[slot] is None or self._bbufs[slot]['rays_o'].shape[0] < n:
+            cap = max(int(n), self.net.sampler.target_batch_size)
+            self._bbufs[slot] = ops.make_batch_buffers(cap, self.device)
+        self.net.sampler.persistent_batches = True
+        return self._bbufs[slot]
 
     @property
     def samples_done(self):
