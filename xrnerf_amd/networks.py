@@ -165,6 +165,7 @@ class _FusedTrainStepFn(torch.autograd.Function):
         ctx.params = (table, wd, wc)
         ctx.sync = getattr(net, 'grad_sync', None)
         ctx.mark_non_differentiable(rgb)
+        ctx.set_materialize_grads(False)         # no zero-filled dL/drgb tensor for the non-differentiable output
         net._last = {'rgb': rgb, 'loss_mse': loss_mse, 'raw': raw}
         return loss_mse[0:1].reshape(()), rgb
 
@@ -175,6 +176,8 @@ class _FusedTrainStepFn(torch.autograd.Function):
         params = ctx.params
         ctx.grads = ctx.params = None
         factor = ctx.sync.finish() if ctx.sync is not None else 1.0      # all buckets reduced; average over the ranks
+        if g is None:                            # only the non-differentiable output was used downstream
+            return None, None, None, None, None
         g = g.reshape(1) if g.dtype == torch.float32 and g.is_cuda else g.to(grads[0].device, torch.float32).reshape(1)
         ops.scale_multi(grads, g, factor)        # one launch; free when the incoming gradient is exactly 1
         # Hand the gradients to the parameters the way AccumulateGrad would, but without its defensive clone

@@ -156,6 +156,7 @@ class Trainer:
         self._next_batch = None
         self._ev_done = [None, None]   # completion events of the last two iterations
         self._bbufs = [None, None]
+        self._one = None
 
     def step(self):
         net, data = self.net, self.data
@@ -170,7 +171,10 @@ class Trainer:
         batch = {k: v[None] for k, v in batch.items()}
         out = net.train_step(batch, self.opt, lazy_log=self.lazy_log)
         self.opt.zero_grad(set_to_none=True)
-        out['loss'].backward()
+        # root gradient = a persistent ones tensor (loss.backward() would fill a fresh one every step)
+        if self._one is None:
+            self._one = torch.ones((), dtype=torch.float32, device=self.device)
+        torch.autograd.backward(out['loss'], grad_tensors=self._one)
         if self.world_size > 1 and not net._fused_ok():
             from . import dist as xdist                 # modular step: reduce after backward (DDP semantics)
             xdist.allreduce_grads([p for p in net.parameters() if p.grad is not None], self.world_size)
