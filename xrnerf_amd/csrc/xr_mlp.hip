@@ -4,6 +4,9 @@
 // Replaces tcnn.Network(FullyFusedMLP) x2 + tcnn.Encoding(SphericalHarmonics) as called from
 // /root/reference/xrnerf/models/mlps/hashnerf_mlp.py:39-45,55-79,107-111.
 //
+// Measured dead end (round 1): fetching the next tile's 23 inputs during the current tile -- in registers (spills,
+// 0.213 -> 0.255 ms) or straight into LDS with global_load_lds (no gain: 0.199 vs 0.197 ms) -- does not pay.
+//
 // Design (gfx950, wave64):
 //   * everything is computed TRANSPOSED: neurons x samples.  One wave owns a tile of 32 samples;
 //     v_mfma_f32_32x32x2_f32 (fp32 in / fp32 accumulate == an fmaf chain, exact fp32) produces a
