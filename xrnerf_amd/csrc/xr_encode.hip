@@ -495,34 +495,28 @@ extern "C" int xr_hashgrid_bwd(const float* x, uint32_t x_stride, const float* d
     const bool ws_ok = workspace && ((uintptr_t)grad_table & 15) == 0 && ((uintptr_t)workspace & 15) == 0;
     if (!ws_ok) { p.l_bin = n_levels; p.rep_stride = 0; }
     else XR_REQUIRE(workspace_bytes >= p.counts_bytes + p.bins_bytes + p.rep_bytes, "workspace too small");
-    // Independent pieces -- the dense remainder and (optionally, XR_SCATTER_GROUPS > 1) groups of binned levels:
-    // disjoint table slices, read-only inputs -- run concurrently: piece 0 on the caller's stream, the others on internal
-    // helper streams forked from and joined back into it with events (created once per process).  The pieces
-    // are bound by different things (bin: item stores, accumulate: LDS + load latency, dense: atomics).
+    // The dense remainder and the binned range are independent (disjoint table slices, read-only inputs) and bound
+    // by different things (atomics vs item stores / LDS): when both exist the remainder runs on an internal helper
+    // stream, forked from and joined back into the caller's stream with events (created once per process;
+    // XR_SCATTER_OVERLAP=0 keeps everything on the caller's stream).  Measured and rejected: also splitting the
+    // binned levels into 2-3 concurrent bin/accumulate groups (0.283 -> 0.30 ms).
     static const int overlap = scatter_env("XR_SCATTER_OVERLAP", 1);
-    static const int n_groups_env = scatter_env("XR_SCATTER_GROUPS", 1);   // measured: 2 or 3 concurrent bin/accumulate groups LOSE (0.283 -> 0.30 ms)
-    constexpr int MAX_AUX = 4;
-    static hipStream_t aux[MAX_AUX] = {nullptr, nullptr, nullptr, nullptr};
-    static hipEvent_t ev_fork = nullptr, ev_join[MAX_AUX] = {nullptr, nullptr, nullptr, nullptr};
-    int n_aux_used = 0;
-    bool fork_recorded = false;
-    auto side_stream = [&](hipStream_t* out) -> int {          // next helper stream, ordered after the caller's stream
-        if (!overlap || n_aux_used >= MAX_AUX) { *out = stream; return XR_OK; }
-        if (!ev_fork) XR_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-        if (!aux[n_aux_used]) {
-            XR_HIP(hipStreamCreateWithFlags(&aux[n_aux_used], hipStreamNonBlocking));
-            XR_HIP(hipEventCreateWithFlags(&ev_join[n_aux_used], hipEventDisableTiming));
-        }
-        if (!fork_recorded) { XR_HIP(hipEventRecord(ev_fork, stream)); fork_recorded = true; }
-        XR_HIP(hipStreamWaitEvent(aux[n_aux_used], ev_fork, 0));
-        *out = aux[n_aux_used++];
-        return XR_OK;
-    };
-    const int nl_bin = n_levels - p.l_bin;
-    const int n_groups = nl_bin <= 0 ? 0 : (nl_bin < 4 ? 1 : (n_groups_env < 1 ? 1 : (n_groups_env > 3 ? 3 : n_groups_env)));
+    static hipStream_t aux = nullptr;
+    static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool forked = false;
     if (p.l_bin > 0) {
         hipStream_t ds = stream;
-        if (n_groups > 0) { const int rc = side_stream(&ds); if (rc != XR_OK) return rc; }
+        if (overlap && p.l_bin < n_levels) {
+            if (!aux) {
+                XR_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+                XR_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+                XR_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+            }
+            XR_HIP(hipEventRecord(ev_fork, stream));
+            XR_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
+            ds = aux;
+            forked = true;
+        }
         GridMeta gd = gm;
         gd.n_levels = p.l_bin;
         if (p.l_bin < n_levels || (p.l_bin & 7)) gd.order = 2;   // a partial level range is spread over all XCDs
@@ -541,8 +535,10 @@ extern "C" int xr_hashgrid_bwd(const float* x, uint32_t x_stride, const float* d
                                (uint32_t)SC_REPLICAS, count4, count4, (float4*)grad_table);
             XR_LAUNCH_CHECK();
         }
+        if (forked) XR_HIP(hipEventRecord(ev_join, ds));
     }
-    if (n_groups > 0) {
+    if (p.l_bin < n_levels) {
+        const uint32_t nl = (uint32_t)(n_levels - p.l_bin);
         static bool attr_set = false;
         if (!attr_set) {
             XR_HIP(hipFuncSetAttribute((const void*)k_scatter_accum, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC_LDS_BYTES));
@@ -550,28 +546,14 @@ extern "C" int xr_hashgrid_bwd(const float* x, uint32_t x_stride, const float* d
         }
         uint32_t* counts = (uint32_t*)workspace;
         float4* bins = (float4*)((char*)workspace + p.counts_bytes);
-        // groups of consecutive levels, finest first; group 0 (the finest, most expensive) on the caller's stream
-        int hi_l = n_levels;
-        for (int g = 0; g < n_groups; ++g) {
-            const int cnt_l = (nl_bin - (n_levels - hi_l) + (n_groups - g) - 1) / (n_groups - g);
-            const int lo_l = hi_l - cnt_l;
-            hipStream_t gs = stream;
-            if (g > 0) { const int rc = side_stream(&gs); if (rc != XR_OK) return rc; }
-            uint32_t* cg = counts + (size_t)(lo_l - p.l_bin) * p.parts * p.nsb;
-            float4* bg = bins + (size_t)(lo_l - p.l_bin) * p.nsb * SC_SUB_ITEMS;
-            hipLaunchKernelGGL(k_scatter_bin, dim3((uint32_t)cnt_l * p.nsb), dim3(SC_THREADS), 0, gs, gm, (uint32_t)lo_l, (uint32_t)hi_l,
-                               p.parts, p.nsb, x, x_stride, denc_t, ld, n, n_dev, cg, bg, grad_table);
-            XR_LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_scatter_accum, dim3((uint32_t)cnt_l * p.parts), dim3(SC_THREADS), SC_LDS_BYTES, gs, gm, (uint32_t)lo_l,
-                               (uint32_t)hi_l, p.parts, p.nsb, cg, bg, grad_table);
-            XR_LAUNCH_CHECK();
-            hi_l = lo_l;
-        }
+        hipLaunchKernelGGL(k_scatter_bin, dim3(nl * p.nsb), dim3(SC_THREADS), 0, stream, gm, (uint32_t)p.l_bin, (uint32_t)n_levels,
+                           p.parts, p.nsb, x, x_stride, denc_t, ld, n, n_dev, counts, bins, grad_table);
+        XR_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_scatter_accum, dim3(nl * p.parts), dim3(SC_THREADS), SC_LDS_BYTES, stream, gm, (uint32_t)p.l_bin,
+                           (uint32_t)n_levels, p.parts, p.nsb, counts, bins, grad_table);
+        XR_LAUNCH_CHECK();
     }
-    for (int k = 0; k < n_aux_used; ++k) {
-        XR_HIP(hipEventRecord(ev_join[k], aux[k]));
-        XR_HIP(hipStreamWaitEvent(stream, ev_join[k], 0));
-    }
+    if (forked) XR_HIP(hipStreamWaitEvent(stream, ev_join, 0));
     return XR_OK;
 }
 

@@ -93,29 +93,14 @@ class _FusedTrainStepFn(torch.autograd.Function):
             pts, dirs = mlp._rows(data['pts']), mlp._rows(data['viewdirs'])
             n, n_dev = pts.shape[0], data.get('n_valid_dev')
             meta, nhd, nhc = mlp.embedder_pos.meta, mlp.density_net.n_hidden, mlp.color_net.n_hidden
-            # Optional two-stream pipeline over N_CHUNKS row chunks (encode of chunk c+1 beside the MLP of chunk
-            # c, MLP backward of chunk c+1 beside the table scatter of chunk c; device-side row counts per
-            # chunk).  It LOSES on MI355X (see ops.N_CHUNKS) and is off (N_CHUNKS = 1: one stream, one launch).
-            chunks = data.get('n_valid_chunks')
-            nch = ops.N_CHUNKS if chunks is not None else 1
-            crow = (n + nch - 1) // nch
-            s0 = torch.cuda.current_stream()
-            s1 = net._aux_stream() if nch > 1 else s0
+            # One stream, one launch per kernel.  (Measured and removed: a two-stream pipeline over 4 row chunks --
+            # encode of chunk c+1 beside the MLP of chunk c -- 1.55 -> 2.48 ms/step: the MFMA workgroups need a
+            # whole CU each and do not co-schedule with the gather / scatter waves.)
             ld = (n + 63) // 64 * 64
             enc_t = torch.empty((meta.n_output_dims, ld), dtype=torch.float32, device=pts.device)
             raw = torch.empty((n, 4), dtype=torch.float32, device=pts.device)
-            cnt = lambda c: chunks[1 + c:2 + c] if chunks is not None else n_dev
-            if nch > 1:
-                s1.wait_stream(s0)
-            for c in range(nch):
-                r0, m = c * crow, min(crow, n - c * crow)
-                with torch.cuda.stream(s1):
-                    ops.hashgrid_fwd(table, pts, meta, enc_t=enc_t, ld=ld, n_dev=cnt(c), row0=r0, count=m)
-                    if nch > 1:
-                        ev = torch.cuda.Event(); ev.record(s1)
-                if nch > 1:
-                    s0.wait_event(ev)
-                ops.nerf_mlp_fwd(enc_t, dirs, n, wd, wc, nhd, nhc, mlp.pad_value, raw=raw, n_dev=cnt(c), row0=r0, count=m)
+            ops.hashgrid_fwd(table, pts, meta, enc_t=enc_t, ld=ld, n_dev=n_dev)
+            ops.nerf_mlp_fwd(enc_t, dirs, n, wd, wc, nhd, nhc, mlp.pad_value, raw=raw, n_dev=n_dev)
             ra, da = int(sampler.rgb_activation), int(sampler.density_activation)
             rgb = ops.calc_rgb_forward(raw, sampler.coords, sampler.rays_numsteps, sampler.rays_numsteps_compacted,
                                        data['bg_color'], ra, da)
@@ -124,8 +109,8 @@ class _FusedTrainStepFn(torch.autograd.Function):
             nz = raw.numel() + wd.numel() + wc.numel() + 4
             zbuf = torch.zeros((nz,), dtype=torch.float32, device=raw.device)
             draw = zbuf[:raw.numel()].view_as(raw)
-            g_wd = zbuf[raw.numel():raw.numel() + wd.numel()]
-            g_wc = zbuf[raw.numel() + wd.numel():raw.numel() + wd.numel() + wc.numel()]
+            g_mlp = zbuf[raw.numel():raw.numel() + wd.numel() + wc.numel()]          # both MLP gradients, contiguous
+            g_wd, g_wc = g_mlp[:wd.numel()], g_mlp[wd.numel():]
             loss_mse = zbuf[nz - 4:nz - 2]
             grad_rgb = ops.huber_loss_grad_mse(rgb, data['target_s'].contiguous(), data['alpha'].contiguous(), 0.1, 5.0,
                                                out=loss_mse)[1]
@@ -133,34 +118,23 @@ class _FusedTrainStepFn(torch.autograd.Function):
                                   sampler.density_grid_mean, ra, da, out=draw)
             g_table = torch.zeros_like(table)
             denc_t = torch.empty_like(enc_t)
-            if nch > 1:
-                s1.wait_stream(s0)                  # the zero-filled table gradient is ready before the first scatter
-            for c in range(nch):
-                r0, m = c * crow, min(crow, n - c * crow)
-                ops.nerf_mlp_bwd(enc_t, dirs, n, wd, wc, nhd, nhc, draw, g_wd, g_wc, mlp.pad_value, denc_t=denc_t,
-                                 n_dev=cnt(c), row0=r0, count=m)
-                if nch > 1:
-                    ev = torch.cuda.Event(); ev.record(s0)
-                sync = getattr(net, 'grad_sync', None) if nch == 1 else None
-                if sync is not None and meta.n_levels > 8:
-                    # data parallel: reduce each gradient bucket across ranks while the next one is produced
-                    split = meta.n_levels - 8                      # 8 finest levels = one per XCD
-                    cut = 2 * int(meta.offset[split])
-                    sync.ready(zbuf[raw.numel():raw.numel() + wd.numel() + wc.numel()])       # both MLP gradients
-                    ops.hashgrid_bwd(pts, denc_t, meta, g_table, n_dev=cnt(c), levels=(split, meta.n_levels))
-                    sync.ready(g_table[cut:])
-                    ops.hashgrid_bwd(pts, denc_t, meta, g_table, n_dev=cnt(c), levels=(0, split))
-                    sync.ready(g_table[:cut])
-                    continue
-                with torch.cuda.stream(s1):
-                    if nch > 1:
-                        s1.wait_event(ev)
-                    ops.hashgrid_bwd(pts, denc_t, meta, g_table, n_dev=cnt(c), row0=r0, count=m)
-                if sync is not None:
-                    sync.ready(zbuf[raw.numel():raw.numel() + wd.numel() + wc.numel()])
-                    sync.ready(g_table)
-            if nch > 1:
-                s0.wait_stream(s1)
+            ops.nerf_mlp_bwd(enc_t, dirs, n, wd, wc, nhd, nhc, draw, g_wd, g_wc, mlp.pad_value, denc_t=denc_t, n_dev=n_dev)
+            sync = getattr(net, 'grad_sync', None)
+            if sync is None:
+                ops.hashgrid_bwd(pts, denc_t, meta, g_table, n_dev=n_dev)
+            elif meta.n_levels > 8:
+                # data parallel: reduce each gradient bucket across the ranks while the next one is produced
+                split = meta.n_levels - 8
+                cut = 2 * int(meta.offset[split])
+                sync.ready(g_mlp)
+                ops.hashgrid_bwd(pts, denc_t, meta, g_table, n_dev=n_dev, levels=(split, meta.n_levels))
+                sync.ready(g_table[cut:])
+                ops.hashgrid_bwd(pts, denc_t, meta, g_table, n_dev=n_dev, levels=(0, split))
+                sync.ready(g_table[:cut])
+            else:
+                ops.hashgrid_bwd(pts, denc_t, meta, g_table, n_dev=n_dev)
+                sync.ready(g_mlp)
+                sync.ready(g_table)
         ctx.grads = (g_table, g_wd, g_wc)
         ctx.params = (table, wd, wc)
         ctx.sync = getattr(net, 'grad_sync', None)
@@ -252,11 +226,6 @@ class HashNerfNetwork(BaseNerfNetwork):
             for k in ret:
                 all_ret.setdefault(k, []).append(ret[k])
         return {k: torch.cat(all_ret[k], 0) for k in all_ret}
-
-    def _aux_stream(self):
-        if getattr(self, '_aux', None) is None:
-            self._aux = torch.cuda.Stream(device=self.mlp.embedder_pos.params.device)
-        return self._aux
 
     def _fused_ok(self):
         from .mlps import HashNerfMLP

@@ -269,21 +269,14 @@ def _pos_view(x):
     return x, int(x.stride(0))
 
 
-# Row chunks of the sample buffer for a two-stream encode/MLP pipeline.  MEASURED on MI355X with 4 chunks:
-# 1.55 -> 2.48 ms/step -- the MFMA kernels need a whole CU each (118 KB LDS, 512 VGPRs x 4 waves) and do not
-# co-schedule with the gather/scatter waves; kept at 1 (= one launch per kernel, single stream).
-N_CHUNKS = 1
-
-
 def clip_numsteps(numsteps, counter, max_compacted):
-    """K2 without the copy (K1's output kept in place): clipped per-ray counts + device-side row counts
-    n_valid [1 + N_CHUNKS] = (total, rows valid in chunk 0, 1, ...)."""
+    """K2 without the copy (K1's output kept in place): clipped per-ray counts + the device-side count of valid
+    rows n_valid [2] = (total, total)  (the C entry point can also split the count over row chunks)."""
     n = numsteps.shape[0]
     out = torch.empty_like(numsteps)
-    n_valid = torch.empty((1 + N_CHUNKS,), dtype=torch.int32, device=numsteps.device)
-    chunk_rows = (max_compacted + N_CHUNKS - 1) // N_CHUNKS
+    n_valid = torch.empty((2,), dtype=torch.int32, device=numsteps.device)
     _lib.check(_lib.load().xr_clip_numsteps(_ptr(numsteps), _ptr(counter), n, max_compacted, _ptr(out), _ptr(n_valid),
-                                            chunk_rows, N_CHUNKS, _stream()), 'xr_clip_numsteps')
+                                            max_compacted, 1, _stream()), 'xr_clip_numsteps')
     return out, n_valid
 
 

@@ -207,10 +207,8 @@ class NGPGridSampler(nn.Module):
         self.rays_numsteps = rays_numsteps
         self.rays_numsteps_compacted = rays_numsteps_compacted
         self.n_valid_dev = n_valid_dev[0:1]
-        self.n_valid_chunks = n_valid_dev
         data['pts'], data['viewdirs'] = coords_compacted[..., :3], coords_compacted[..., 4:]
         data['n_valid_dev'] = n_valid_dev[0:1]
-        data['n_valid_chunks'] = n_valid_dev
         cb = getattr(self, 'on_sampled', None)
         if cb is not None:
             cb()       # e.g. the trainer issues the NEXT batch's march on a side stream right here
@@ -255,9 +253,7 @@ class NGPGridSampler(nn.Module):
 
     def side_stream(self):
         if getattr(self, '_side', None) is None:
-            # high priority (XRNERF_SIDE_PRIORITY, default -1): the march has few waves and long dependent-load chains;
-            # scheduled first it finishes early in the step instead of being stretched to its end
-            self._side = torch.cuda.Stream(device=self.device, priority=int(os.environ.get('XRNERF_SIDE_PRIORITY', '-1')))
+            self._side = torch.cuda.Stream(device=self.device)        # (a high-priority stream changes nothing: measured)
         return self._side
 
     def prefetch(self, data, buffer_free_event=None):
