@@ -223,14 +223,19 @@ __global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_bwd(GridMeta gm, uint32_t
 // instruction, latency-bound gathers); (2) shared bins with one returning global atomic per
 // (workgroup, partition): 0.19 ms even for ONE level -- 64 same-address returning atomics serialise
 // at ~3 us each.
-#define SC_THREADS 1024
+#define SC_THREADS 1024                            // binning kernel
+#ifndef SC_LOG2
 #define SC_LOG2 13
+#endif
+#ifndef SC_ACC_THREADS
+#define SC_ACC_THREADS 1024                        // accumulate kernel (measured: 2^12-entry partitions with two 512-thread
+#endif                                             // workgroups per CU, 0.287 ms, do not beat 2^13 / 1024 / one per CU, 0.282 ms)
 #define SC_ENTRIES (1u << SC_LOG2)
 #define SC_LDS_BYTES (SC_ENTRIES * 2 * sizeof(double))
 #define SC_SPT 4                                   // samples per thread in the binning kernel
 #define SC_BLOCK_SAMPLES (SC_THREADS * SC_SPT)
-#define SC_MAX_PARTS 128
-#define SC_MAX_SB 4096                               // sample blocks per call: n <= 2^24 on the binned path
+#define SC_MAX_PARTS 256
+#define SC_MAX_SB 1024                               // sample blocks per call: n <= 2^22 on the binned path
 #define SC_SUB_ITEMS (2u * 4u * SC_BLOCK_SAMPLES)  // items of all sub-bins of one (workgroup, level): 2x the 4 pairs per sample
 
 __global__ __launch_bounds__(SC_THREADS) void k_scatter_bin(GridMeta gm, uint32_t l_lo, uint32_t l_hi, uint32_t parts, uint32_t nsb,
@@ -315,7 +320,7 @@ __device__ long long g_sc_t[8];
 #else
 #define SC_T(k)
 #endif
-__global__ __launch_bounds__(SC_THREADS) void k_scatter_accum(GridMeta gm, uint32_t l_lo, uint32_t l_hi, uint32_t parts, uint32_t nsb,
+__global__ __launch_bounds__(SC_ACC_THREADS) void k_scatter_accum(GridMeta gm, uint32_t l_lo, uint32_t l_hi, uint32_t parts, uint32_t nsb,
                                                               const uint32_t* __restrict__ counts, const float4* __restrict__ bins,
                                                               float* __restrict__ grad_table) {
     extern __shared__ __attribute__((aligned(16))) double s_acc[];       // [SC_ENTRIES][2]
@@ -327,11 +332,11 @@ __global__ __launch_bounds__(SC_THREADS) void k_scatter_accum(GridMeta gm, uint3
     double2* acc2 = reinterpret_cast<double2*>(s_acc);
     SC_T(0);
     __shared__ uint32_t s_fill[SC_MAX_SB];                                  // fill counts of this unit's sub-bins
-    for (uint32_t e = threadIdx.x; e < nsb; e += SC_THREADS) s_fill[e] = cnt[e];
-    for (uint32_t e = threadIdx.x; e < SC_ENTRIES; e += SC_THREADS) acc2[e] = make_double2(0.0, 0.0);
+    for (uint32_t e = threadIdx.x; e < nsb; e += SC_ACC_THREADS) s_fill[e] = cnt[e];
+    for (uint32_t e = threadIdx.x; e < SC_ENTRIES; e += SC_ACC_THREADS) acc2[e] = make_double2(0.0, 0.0);
     __syncthreads();
     // The unit's sub-bins are contiguous ([sample block][cap], cap a power of two): tile k = positions
-    // [k * SC_THREADS, (k+1) * SC_THREADS), a position is live when its offset in its sub-bin is below the fill
+    // [k * SC_ACC_THREADS, (k+1) * SC_ACC_THREADS), a position is live when its offset in its sub-bin is below the fill
     // count.  The loads of the next U tiles are in flight while the current U are accumulated.
     const uint32_t cap_log2 = 31 - __builtin_clz(cap), npos = nsb << cap_log2;
     const float4* __restrict__ src = bins + (size_t)li * nsb * SC_SUB_ITEMS + (size_t)part * npos;
@@ -341,12 +346,12 @@ __global__ __launch_bounds__(SC_THREADS) void k_scatter_accum(GridMeta gm, uint3
     auto fetch = [&](uint32_t k0) {
 #pragma unroll
         for (uint32_t u = 0; u < U; ++u) {
-            const uint32_t pos = (k0 + u) * SC_THREADS + threadIdx.x;
+            const uint32_t pos = (k0 + u) * SC_ACC_THREADS + threadIdx.x;
             non[u] = pos < npos && (pos & (cap - 1)) < s_fill[min(pos >> cap_log2, nsb - 1)];
             if (non[u]) nx[u] = src[pos];
         }
     };
-    const uint32_t ntiles = (npos + SC_THREADS - 1) / SC_THREADS;
+    const uint32_t ntiles = (npos + SC_ACC_THREADS - 1) / SC_ACC_THREADS;
     SC_T(1);
     fetch(0);
     for (uint32_t k0 = 0; k0 < ntiles; k0 += U) {
@@ -370,15 +375,15 @@ __global__ __launch_bounds__(SC_THREADS) void k_scatter_accum(GridMeta gm, uint3
     __syncthreads();
     float2* __restrict__ dst = reinterpret_cast<float2*>(grad_table + 2 * ((size_t)gm.off[l] + (size_t)part * SC_ENTRIES));
     SC_T(3);
-    constexpr uint32_t F = SC_ENTRIES / SC_THREADS;                         // all F loads in flight before the first add
+    constexpr uint32_t F = SC_ENTRIES / SC_ACC_THREADS;                         // all F loads in flight before the first add
     float2 t[F];
 #pragma unroll
-    for (uint32_t k = 0; k < F; ++k) t[k] = dst[k * SC_THREADS + threadIdx.x];
+    for (uint32_t k = 0; k < F; ++k) t[k] = dst[k * SC_ACC_THREADS + threadIdx.x];
 #pragma unroll
     for (uint32_t k = 0; k < F; ++k) {
-        const double2 a = acc2[k * SC_THREADS + threadIdx.x];
+        const double2 a = acc2[k * SC_ACC_THREADS + threadIdx.x];
         t[k].x += (float)a.x; t[k].y += (float)a.y;
-        dst[k * SC_THREADS + threadIdx.x] = t[k];
+        dst[k * SC_ACC_THREADS + threadIdx.x] = t[k];
     }
     SC_T(4);
 }
@@ -549,7 +554,7 @@ extern "C" int xr_hashgrid_bwd(const float* x, uint32_t x_stride, const float* d
         hipLaunchKernelGGL(k_scatter_bin, dim3(nl * p.nsb), dim3(SC_THREADS), 0, stream, gm, (uint32_t)p.l_bin, (uint32_t)n_levels,
                            p.parts, p.nsb, x, x_stride, denc_t, ld, n, n_dev, counts, bins, grad_table);
         XR_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_scatter_accum, dim3(nl * p.parts), dim3(SC_THREADS), SC_LDS_BYTES, stream, gm, (uint32_t)p.l_bin,
+        hipLaunchKernelGGL(k_scatter_accum, dim3(nl * p.parts), dim3(SC_ACC_THREADS), SC_LDS_BYTES, stream, gm, (uint32_t)p.l_bin,
                            (uint32_t)n_levels, p.parts, p.nsb, counts, bins, grad_table);
         XR_LAUNCH_CHECK();
     }
