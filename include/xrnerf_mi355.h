@@ -246,6 +246,48 @@ int xr_adam_step_multi(int n_tensors, float* const* p_host, const float* const* 
                        float* const* v_host, float* const* ema_host, const size_t* n_host, int step, float lr,
                        float beta1, float beta2, float eps, float weight_decay, float ema_momentum, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Mip-NeRF (BASELINE config #3; configs/mipnerf/mipnerf_multiscale.py): the sampling / encoding / rendering
+ * stages either side of the 8x256 MLP, one launch each.  Tensors are contiguous fp32; n_z = number of interval
+ * EDGES per ray (config: 129), so a ray has n_z-1 samples.
+ *
+ * GetZvals (xrnerf/datasets/pipelines/create.py:486-531): near/far [n_rays]; z_rand [n_rays,n_z] holds the
+ * uniform draws the reference takes from torch.rand (NULL = not randomized); z_out [n_rays,n_z]. */
+int xr_mip_zvals(const float* near, const float* far, uint32_t n_rays, uint32_t n_z, int lindisp,
+                 const float* z_rand, float* z_out, void* stream);
+/* row width of the encoding: 6*(max_deg-min_deg) + 6*(max_deg_view-min_deg_view) (+3 with append_identity)
+ * (MipNerfEmbedder.get_embed_ch, xrnerf/models/embedders/mipnerf_embedder.py:76-83) */
+uint32_t xr_mip_encode_channels(int min_deg, int max_deg, int min_deg_view, int max_deg_view, int append_identity);
+/* sample_along_rays / cast_rays (xrnerf/models/networks/utils/mip.py:96-148, diag covariance, stable cone
+ * formula) + MipNerfEmbedder.forward (mipnerf_embedder.py:34-99) fused: conical-frustum (ray_shape 0) or cylinder
+ * (1) gaussians -> integrated positional encoding, concatenated with the positional encoding of the ray's view
+ * direction.  out [n_rays*(n_z-1), ld] row-major, ld >= channels (= data['embedded']). */
+int xr_mip_encode(const float* rays_o, const float* rays_d, const float* viewdirs, const float* radii /*[n_rays]*/,
+                  const float* z_vals /*[n_rays,n_z]*/, uint32_t n_rays, uint32_t n_z, int min_deg, int max_deg,
+                  int min_deg_view, int max_deg_view, int append_identity, int ray_shape, float* out, uint32_t ld,
+                  void* stream);
+/* the same from gaussians that already exist (data['samples'] = (means, covs) [n_rays,n_samples,3]) */
+int xr_mip_encode_gaussians(const float* means, const float* covs, const float* viewdirs, uint32_t n_rays,
+                            uint32_t n_samples, int min_deg, int max_deg, int min_deg_view, int max_deg_view,
+                            int append_identity, float* out, uint32_t ld, void* stream);
+/* NerfRender.forward with MipNerfRender's get_weights / get_disp_map (xrnerf/models/renders/nerf_render.py:45-98,
+ * mipnerf_render.py:12-33; raw_noise_std = 0): raw [n_rays,n_z-1,4] -> rgb [n_rays,3], distance ('disp')
+ * [n_rays], acc [n_rays], weights [n_rays,n_z-1].  density_activation: 0 = softplus, 1 = relu. */
+int xr_mip_render_forward(const float* raw, const float* z_vals, const float* rays_d, uint32_t n_rays, uint32_t n_z,
+                          float density_bias, float rgb_padding, int white_bkgd, int density_activation, float* rgb,
+                          float* distance, float* acc, float* weights, void* stream);
+/* dL/draw [n_rays,n_z-1,4] given dL/drgb [n_rays,3] (the reference's losses use the colours only,
+ * networks/mipnerf.py:52-60; weights feed the detached resampling); everything else is recomputed from raw */
+int xr_mip_render_backward(const float* raw, const float* z_vals, const float* rays_d, const float* grad_rgb,
+                           uint32_t n_rays, uint32_t n_z, float density_bias, float rgb_padding, int white_bkgd,
+                           int density_activation, float* grad_raw, void* stream);
+/* resample_along_rays' new z_vals (mip.py:151-176 with sorted_piecewise_constant_pdf :7-62): max-blurred weights
+ * + resample_padding -> pdf -> cdf (fp64 prefix sum like torch's CPU cumsum) -> inverse-cdf sampling at n_z
+ * points.  rand [n_rays,n_z] = the torch.rand draws of the randomized branch (NULL = deterministic linspace).
+ * z_vals must be sorted per ray (they are edges).  n_z <= 2048. */
+int xr_mip_resample(const float* z_vals, const float* weights /*[n_rays,n_z-1]*/, const float* rand,
+                    float resample_padding, uint32_t n_rays, uint32_t n_z, float* z_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

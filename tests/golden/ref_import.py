@@ -57,3 +57,53 @@ def load():
     ns.NerfRender = importlib.import_module('xrnerf.models.renders.nerf_render').NerfRender
     ns.sample_pdf = importlib.import_module('xrnerf.models.networks.utils.hierarchical_sample').sample_pdf
     return ns
+
+
+def load_mip():
+    """-> namespace with the reference's Mip-NeRF pieces (BASELINE config #3): mip.py's functions,
+    MipNerfEmbedder, MipNerfRender, NerfMLP, GetZvals and load_rays_multiscale, imported unmodified.
+    Extra stubs: `turtle` (mipnerf_embedder.py:2 imports it by accident; needs tkinter), `cv2` / `imageio`
+    (module-level imports of datasets/pipelines/create.py, unused by GetZvals), mmcv.parallel."""
+    ns = load()
+    for name in ('turtle', 'cv2', 'imageio'):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.forward = None
+            sys.modules[name] = m
+    mmcv = sys.modules['mmcv']
+    if not hasattr(mmcv, 'parallel'):
+        par = types.ModuleType('mmcv.parallel'); par.collate = None
+        mmcv.parallel = par
+        sys.modules['mmcv.parallel'] = par
+        mmcv.utils.build_from_cfg = lambda cfg, reg, default_args=None: reg.build(cfg)
+        mmcv.utils.digit_version = lambda v: tuple(int(x) for x in v.split('+')[0].split('.')[:3])
+    for pkg in ('xrnerf.datasets', 'xrnerf.datasets.pipelines', 'xrnerf.datasets.load_data'):
+        if pkg not in sys.modules:
+            m = types.ModuleType(pkg)
+            m.__path__ = [os.path.join(REF, *pkg.split('.'))]
+            sys.modules[pkg] = m
+    ns.mip = importlib.import_module('xrnerf.models.networks.utils.mip')
+    ns.MipNerfEmbedder = importlib.import_module('xrnerf.models.embedders.mipnerf_embedder').MipNerfEmbedder
+    ns.MipNerfRender = importlib.import_module('xrnerf.models.renders.mipnerf_render').MipNerfRender
+    sys.modules['xrnerf.datasets'].builder = importlib.import_module('xrnerf.datasets.builder')
+    ns.GetZvals = importlib.import_module('xrnerf.datasets.pipelines.create').GetZvals
+    ns.load_rays_multiscale = importlib.import_module('xrnerf.datasets.load_data.get_rays').load_rays_multiscale
+    # networks/mipnerf.py does `from .utils import (merge_ret, mse2psnr, ...)`; utils/__init__.py would pull in every
+    # model family's dependencies, so the names are placed on the package shell from their leaf modules instead
+    utils = sys.modules['xrnerf.models.networks.utils']
+    for leaf, names in (('transforms', ('merge_ret', 'recover_shape')), ('metrics', ('mse2psnr', 'img2mse', 'HuberLoss')),
+                        ('batching', ('unfold_batching',)), ('mip', ('resample_along_rays', 'sample_along_rays')),
+                        ('hierarchical_sample', ('sample_pdf',))):
+        mod = importlib.import_module('xrnerf.models.networks.utils.' + leaf)
+        for n in names:
+            setattr(utils, n, getattr(mod, n))
+    utils.__all__ = [n for n in vars(utils) if not n.startswith('_')]
+    sys.modules['mmcv.runner'].load_checkpoint = None
+    if 'tqdm' not in sys.modules:
+        try:
+            import tqdm  # noqa: F401
+        except ImportError:
+            t = types.ModuleType('tqdm'); t.tqdm = lambda x, **k: x
+            sys.modules['tqdm'] = t
+    ns.MipNerfNetwork = importlib.import_module('xrnerf.models.networks.mipnerf').MipNerfNetwork
+    return ns

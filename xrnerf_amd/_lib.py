@@ -51,6 +51,13 @@ SIGNATURES = {
     'xr_adam_step_multi': (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f, _f, _f, _f, _f, _f, _vp]),
     'xr_scale_multi': (_i32, [_i32, _vp, _vp, _vp, _f, _vp]),
     'xr_adam_step': (_i32, [_vp, _vp, _vp, _vp, _sz, _i32, _f, _f, _f, _f, _f, _vp, _f, _vp]),
+    'xr_mip_zvals': (_i32, [_vp, _vp, _u32, _u32, _i32, _vp, _vp, _vp]),
+    'xr_mip_encode_channels': (_u32, [_i32, _i32, _i32, _i32, _i32]),
+    'xr_mip_encode': (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _u32, _vp]),
+    'xr_mip_encode_gaussians': (_i32, [_vp, _vp, _vp, _u32, _u32, _i32, _i32, _i32, _i32, _i32, _vp, _u32, _vp]),
+    'xr_mip_render_forward': (_i32, [_vp, _vp, _vp, _u32, _u32, _f, _f, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'xr_mip_render_backward': (_i32, [_vp, _vp, _vp, _vp, _u32, _u32, _f, _f, _i32, _i32, _vp, _vp]),
+    'xr_mip_resample': (_i32, [_vp, _vp, _vp, _f, _u32, _u32, _vp, _vp]),
 }
 
 _lib = None

@@ -23,6 +23,8 @@ SOURCES = {
     'xr_encode.hip': ['-ffp-contract=off'],
     'xr_mlp.hip': [],
     'xr_misc.hip': ['-ffp-contract=off'],
+    # Mip-NeRF stages: fp32 in the reference's operation order (lower + (upper-lower)*rand etc.)
+    'xr_mip.hip': ['-ffp-contract=off'],
 }
 
 
@@ -41,7 +43,7 @@ def _stale(dst, srcs):
 
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, 'xr_common.h'), os.path.join(HERE, '..', 'include', 'xrnerf_mi355.h'),
+    headers = [os.path.join(CSRC, 'xr_common.h'), os.path.join(CSRC, 'xr_mip_math.h'), os.path.join(HERE, '..', 'include', 'xrnerf_mi355.h'),
                os.path.abspath(__file__)]
     have_src = all(os.path.exists(os.path.join(CSRC, s)) for s in SOURCES)
     if not have_src:

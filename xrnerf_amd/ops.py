@@ -452,3 +452,107 @@ def adam_step_multi(ps, gs, ms, vs, step, lr=1e-2, beta1=0.9, beta2=0.99, eps=1e
         _lib.check(_lib.load().xr_adam_step_multi(k, arr(ps), arr(gs), arr(ms), arr(vs), arr(emas) if emas else None, ns,
                                                   step, lr, beta1, beta2, eps, weight_decay, ema_momentum, _stream()),
                    'xr_adam_step_multi')
+
+
+# ---------------------------------------------------------------- Mip-NeRF stages (BASELINE config #3)
+def _f32c(t):
+    if t.dtype != torch.float32:
+        raise _lib.XrError('xrnerf_amd mip ops take float32 tensors (got %s)' % t.dtype)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def mip_zvals(near, far, n_z, lindisp=False, z_rand=None):
+    """GetZvals (create.py:486-531): near/far [R] or [R,1]; z_rand [R,n_z] uniform draws or None -> [R,n_z]"""
+    near, far = _f32c(near.reshape(-1)), _f32c(far.reshape(-1))
+    R = near.shape[0]
+    out = torch.empty((R, n_z), dtype=torch.float32, device=near.device)
+    if z_rand is not None:
+        z_rand = _f32c(z_rand)
+        assert tuple(z_rand.shape) == (R, n_z)
+    _lib.check(_lib.load().xr_mip_zvals(_ptr(near), _ptr(far), R, n_z, int(bool(lindisp)), _ptr(z_rand), _ptr(out),
+                                        _stream()), 'xr_mip_zvals')
+    return out
+
+
+def mip_encode_channels(min_deg, max_deg, min_deg_view, max_deg_view, append_identity=True):
+    return int(_lib.load().xr_mip_encode_channels(min_deg, max_deg, min_deg_view, max_deg_view, int(bool(append_identity))))
+
+
+def mip_encode(rays_o, rays_d, viewdirs, radii, z_vals, min_deg, max_deg, min_deg_view, max_deg_view,
+               append_identity=True, ray_shape='cone', out=None):
+    """cast_rays + integrated_pos_enc + pos_enc + concat in one launch -> [R*(n_z-1), channels]"""
+    L = _lib.load()
+    R, n_z = z_vals.shape
+    ch = mip_encode_channels(min_deg, max_deg, min_deg_view, max_deg_view, append_identity)
+    if out is None:
+        out = torch.empty((R * (n_z - 1), ch), dtype=torch.float32, device=z_vals.device)
+    shape = {'cone': 0, 'cylinder': 1}[ray_shape]
+    with _span('xr_mip_encode', R * (n_z - 1)):
+        _lib.check(L.xr_mip_encode(_ptr(_f32c(rays_o)), _ptr(_f32c(rays_d)), _ptr(_f32c(viewdirs)),
+                                   _ptr(_f32c(radii.reshape(-1))), _ptr(_f32c(z_vals)), R, n_z, min_deg, max_deg,
+                                   min_deg_view, max_deg_view, int(bool(append_identity)), shape, _ptr(out),
+                                   out.stride(0), _stream()), 'xr_mip_encode')
+    return out
+
+
+def mip_encode_gaussians(means, covs, viewdirs, min_deg, max_deg, min_deg_view, max_deg_view, append_identity=True):
+    L = _lib.load()
+    R, S = means.shape[:2]
+    ch = mip_encode_channels(min_deg, max_deg, min_deg_view, max_deg_view, append_identity)
+    out = torch.empty((R * S, ch), dtype=torch.float32, device=means.device)
+    _lib.check(L.xr_mip_encode_gaussians(_ptr(_f32c(means)), _ptr(_f32c(covs)), _ptr(_f32c(viewdirs)), R, S, min_deg,
+                                         max_deg, min_deg_view, max_deg_view, int(bool(append_identity)), _ptr(out),
+                                         ch, _stream()), 'xr_mip_encode_gaussians')
+    return out
+
+
+_MIP_ACT = {'softplus': 0, 'relu': 1}
+
+
+def mip_render_forward(raw, z_vals, rays_d, density_bias, rgb_padding, white_bkgd, density_activation='softplus'):
+    """-> rgb [R,3], distance [R], acc [R], weights [R,S]"""
+    L = _lib.load()
+    R, n_z = z_vals.shape
+    dev = raw.device
+    raw = _f32c(raw)
+    assert tuple(raw.shape) == (R, n_z - 1, 4), 'raw must be [R, n_z-1, 4] (rgb + density)'
+    rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
+    dist = torch.empty((R,), dtype=torch.float32, device=dev)
+    acc = torch.empty((R,), dtype=torch.float32, device=dev)
+    w = torch.empty((R, n_z - 1), dtype=torch.float32, device=dev)
+    with _span('xr_mip_render_forward', R * (n_z - 1)):
+        _lib.check(L.xr_mip_render_forward(_ptr(raw), _ptr(_f32c(z_vals)), _ptr(_f32c(rays_d)), R, n_z,
+                                           float(density_bias), float(rgb_padding), int(bool(white_bkgd)),
+                                           _MIP_ACT[density_activation], _ptr(rgb), _ptr(dist), _ptr(acc), _ptr(w),
+                                           _stream()), 'xr_mip_render_forward')
+    return rgb, dist, acc, w
+
+
+def mip_render_backward(raw, z_vals, rays_d, grad_rgb, density_bias, rgb_padding, white_bkgd,
+                        density_activation='softplus'):
+    L = _lib.load()
+    R, n_z = z_vals.shape
+    raw = _f32c(raw)
+    out = torch.empty_like(raw)
+    with _span('xr_mip_render_backward', R * (n_z - 1)):
+        _lib.check(L.xr_mip_render_backward(_ptr(raw), _ptr(_f32c(z_vals)), _ptr(_f32c(rays_d)), _ptr(_f32c(grad_rgb)),
+                                            R, n_z, float(density_bias), float(rgb_padding), int(bool(white_bkgd)),
+                                            _MIP_ACT[density_activation], _ptr(out), _stream()),
+                   'xr_mip_render_backward')
+    return out
+
+
+def mip_resample(z_vals, weights, resample_padding, rand=None):
+    """resample_along_rays' new (detached) z_vals [R,n_z]; rand [R,n_z] uniform draws (randomized) or None"""
+    L = _lib.load()
+    R, n_z = z_vals.shape
+    z_vals, weights = _f32c(z_vals), _f32c(weights.detach())
+    assert tuple(weights.shape) == (R, n_z - 1)
+    if rand is not None:
+        rand = _f32c(rand)
+        assert tuple(rand.shape) == (R, n_z)
+    out = torch.empty_like(z_vals)
+    with _span('xr_mip_resample', R):
+        _lib.check(L.xr_mip_resample(_ptr(z_vals), _ptr(weights), _ptr(rand), float(resample_padding), R, n_z, _ptr(out),
+                                     _stream()), 'xr_mip_resample')
+    return out
