@@ -133,6 +133,90 @@ def cpu_vanilla_nerf(seconds_budget=8.0):
                       '2 x 8x256 MLP), pure PyTorch on the host' % its}
 
 
+def mipnerf_config3(dev, steps=20, warmup=5, cpu_seconds=10.0):
+    """Secondary line (BASELINE config #3): Mip-NeRF multiscale training step -- 1024 rays,
+    128 + 128 conical-frustum samples, one shared 8x256 MLP -- with the sampling / IPE / render / resample stages as
+    single HIP launches (xrnerf_amd/csrc/xr_mip.hip) and the MLP on rocBLAS; beside it the same step in pure PyTorch on
+    the host cores (oracle/mip_oracle.py::torch_train_step, pinned to the reference's code)."""
+    import xrnerf_amd
+    from xrnerf_amd import mip
+    cfg = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'mip_model_cfg.json')))
+    R, S = cfg['N_rand_per_sampler'], cfg['num_samples']
+    torch.manual_seed(0)
+    net = xrnerf_amd.build_network(cfg['model']).to(dev)
+    opt = torch.optim.Adam(net.parameters(), lr=cfg['optimizer']['lr'])
+    rays = mip.synthetic_multiscale_rays(R, dev, seed=1)
+
+    def step():
+        data = mip.get_z_vals(dict(rays), S + 1, randomized=True)
+        out = net.train_step({k: v[None] for k, v in data.items()}, opt)
+        opt.zero_grad(set_to_none=True)
+        out['loss'].backward()
+        opt.step()
+        return out
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    ops.TIMER = ops.KernelTimer(only={'xr_mip_encode', 'xr_mip_render_forward', 'xr_mip_render_backward', 'xr_mip_resample'})
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    timer, ops.TIMER = ops.TIMER, None
+    summ = timer.summary()
+    ch = net.mlp.input_ch + net.mlp.input_ch_dirs
+    # algorithmic HBM bytes per launch (DESIGN.md section 8): encode writes ch floats per sample and reads 44 B + (S+1)*4 B
+    # per ray; render fwd reads raw 16 B and writes the weight 4 B per sample (+ per ray z 4(S+1), d 12, out 20);
+    # render bwd reads raw 16 B, writes 16 B per sample; resample reads z and weights, writes z per ray
+    algo = {'xr_mip_encode': R * S * ch * 4 + R * (44 + (S + 1) * 4),
+            'xr_mip_render_forward': R * S * 20 + R * ((S + 1) * 4 + 32),
+            'xr_mip_render_backward': R * S * 32 + R * ((S + 1) * 4 + 24),
+            'xr_mip_resample': R * ((S + 1) * 12 + S * 4)}
+    kern = {}
+    for k, (n, ms, _) in summ.items():
+        us = ms * 1e3 / max(n, 1)
+        kern[k] = {'avg_launch_us': us, 'launches': n, 'algorithmic_bytes_per_launch': algo[k],
+                   'achieved_GBs': algo[k] / (us * 1e-6) / 1e9, 'frac_of_hbm_peak': algo[k] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+    res = {'workload': 'Mip-NeRF multiscale (configs/mipnerf/mipnerf_multiscale.py): %d rays x (%d + %d) samples, 8x256 MLP, '
+                       'forward + backward + Adam, synthetic multiscale rays resident in HBM' % (R, S, S),
+           'value': R * steps / el, 'unit': 'rays/s', 'ms_per_step': el * 1e3 / steps, 'steps': steps, 'dtype': 'f32',
+           'final_loss': float(out['log_vars']['loss']), 'kernels': kern}
+    # the same step on the host cores, pure PyTorch
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import mip_oracle as MO
+    from xrnerf_amd import vanilla
+    threads = min(32, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
+    torch.set_num_threads(threads)
+    mcfg = dict(cfg['model']['mlp']); mcfg.pop('type')
+    mlp = vanilla.NerfMLP(**mcfg)
+    copt = torch.optim.Adam(mlp.parameters(), lr=cfg['optimizer']['lr'])
+    cdata = {k: v.cpu() for k, v in rays.items()}
+    r = cfg['model']['render']
+    rkw = dict(density_bias=r['density_bias'], rgb_padding=r['rgb_padding'], white_bkgd=r['white_bkgd'],
+               activation=r['density_activation'])
+    its, t0 = 0, None
+    while True:
+        zr = torch.rand(R, S + 1)
+        cdata['z_vals'] = torch.from_numpy(MO.z_vals(cdata['near'].numpy(), cdata['far'].numpy(), S + 1, False, zr.numpy()))
+        loss, _ = MO.torch_train_step(mlp, cdata, render_kw=rkw)
+        copt.zero_grad(set_to_none=True)
+        loss.backward()
+        copt.step()
+        if t0 is None:
+            t0 = time.perf_counter()          # first iteration = warm-up
+            continue
+        its += 1
+        if time.perf_counter() - t0 > cpu_seconds or its >= 8:
+            break
+    cel = time.perf_counter() - t0
+    res['cpu_baseline'] = {'value': its * R / cel, 'unit': 'rays/s', 'cores': threads, 'kind': 'port',
+                           'sample': '%d iterations of the same step (1024 rays x 256 samples), pure PyTorch on the host '
+                                     '(oracle/mip_oracle.py::torch_train_step)' % its}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -141,6 +225,7 @@ def main():
     ap.add_argument('--n-img', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-render', action='store_true')
+    ap.add_argument('--no-mip', action='store_true', help='skip the secondary Mip-NeRF (config #3) line')
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -280,6 +365,10 @@ def main():
             out['cpu_baseline'] = cpu_baseline()
             out['cpu_baseline']['host_cores_available'] = os.cpu_count()
             out['cpu_baseline_vanilla_nerf_config1'] = cpu_vanilla_nerf()
+        if world == 1 and not args.no_mip:
+            del tr
+            torch.cuda.empty_cache()
+            out['mipnerf_config3'] = mipnerf_config3(dev)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -216,3 +216,91 @@ def render_bwd(raw, z, rays_d, grad_rgb, density_bias=-1., rgb_padding=0.001, wh
     out[..., 3] = d_dd * dists * dsp
     out[..., :3] = g[:, None, :] * w[..., None] * s * (1 - s) * (1 + 2 * rgb_padding)
     return out.astype(np.float32)
+
+
+# ---------------------------------------------------------------- the same path in pure PyTorch (autograd-capable)
+# Used as bench.py's cpu_baseline leg for config #3 (the reference's own code IS pure PyTorch but cannot travel to the
+# GPU box) and as a second statement of the maths in the tests.  Written with searchsorted / cumsum rather than the
+# reference's O(n^2) mask construction; pinned against the same fixture (tests/test_mip_oracle_pinning.py).
+def torch_embed(z, o, d, vd, radii, min_deg=0, max_deg=16, min_deg_view=0, max_deg_view=4, append_identity=True):
+    import torch
+    t0, t1 = z[..., :-1], z[..., 1:]
+    mu, hw = (t0 + t1) / 2, (t1 - t0) / 2
+    den = 3 * mu**2 + hw**2
+    t_mean = mu + (2 * mu * hw**2) / den
+    t_var = hw**2 / 3 - (4 / 15) * ((hw**4 * (12 * mu**2 - hw**2)) / den**2)
+    r_var = radii**2 * (mu**2 / 4 + (5 / 12) * hw**2 - (4 / 15) * hw**4 / den)
+    d2 = d * d
+    mag = d2.sum(-1, keepdim=True).clamp_min(1e-10)
+    mean = d[:, None, :] * t_mean[..., None] + o[:, None, :]
+    cov = t_var[..., None] * d2[:, None, :] + r_var[..., None] * (1 - d2 / mag)[:, None, :]
+    sc = torch.tensor([2.0 ** i for i in range(min_deg, max_deg)], dtype=z.dtype)
+    y = (mean[..., None, :] * sc[:, None]).flatten(-2)
+    yv = (cov[..., None, :] * sc[:, None] ** 2).flatten(-2)
+    ipe = torch.exp(-0.5 * torch.cat([yv, yv], -1)) * torch.sin(torch.cat([y, y + float(HALF_PI)], -1))
+    sv = torch.tensor([2.0 ** i for i in range(min_deg_view, max_deg_view)], dtype=z.dtype)
+    xb = (vd[..., None, :] * sv[:, None]).flatten(-2)
+    pe = torch.sin(torch.cat([xb, xb + float(HALF_PI)], -1))
+    if append_identity:
+        pe = torch.cat([vd, pe], -1)
+    R, S = ipe.shape[:2]
+    return torch.cat([ipe, pe[:, None, :].expand(R, S, pe.shape[-1])], -1).reshape(R * S, -1)
+
+
+def torch_render(raw, z, rays_d, density_bias=-1., rgb_padding=0.001, white_bkgd=True, activation='softplus'):
+    import torch
+    import torch.nn.functional as Fn
+    dists = (z[..., 1:] - z[..., :-1]) * rays_d.norm(dim=-1, keepdim=True)
+    rgb = torch.sigmoid(raw[..., :3]) * (1 + 2 * rgb_padding) - rgb_padding
+    x = raw[..., 3] + density_bias
+    dd = (Fn.softplus(x) if activation == 'softplus' else Fn.relu(x)) * dists
+    before = torch.cat([torch.zeros_like(dd[..., :1]), torch.cumsum(dd[..., :-1], -1)], -1)
+    w = (1 - torch.exp(-dd)) * torch.exp(-before)
+    acc = w.sum(-1)
+    col = (w[..., None] * rgb).sum(-2)
+    depth = (w * (0.5 * (z[..., :-1] + z[..., 1:]))).sum(-1)
+    dist = torch.maximum(torch.minimum(torch.nan_to_num(depth / acc, float('inf')), z[:, -1]), z[:, 0])
+    return (col + (1 - acc[..., None]) if white_bkgd else col), dist, acc, w
+
+
+def torch_resample(z, weights, resample_padding, rand=None):
+    import torch
+    w = weights.detach()
+    pad = torch.cat([w[..., :1], w, w[..., -1:]], -1)
+    wmax = torch.maximum(pad[..., :-1], pad[..., 1:])
+    wb = 0.5 * (wmax[..., :-1] + wmax[..., 1:]) + resample_padding
+    n_z = z.shape[-1]
+    ws = wb.sum(-1, keepdim=True)
+    padding = (1e-5 - ws).clamp_min(0)
+    wb = wb + padding / wb.shape[-1]
+    pdf = wb / (ws + padding)
+    cdf = torch.cumsum(pdf[..., :-1], -1).clamp_max(1)
+    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf, torch.ones_like(cdf[..., :1])], -1)
+    eps = float(EPS32)
+    if rand is not None:
+        u = torch.arange(n_z, dtype=z.dtype) * (1 / n_z) + rand * (1 / n_z - eps)
+        u = u.clamp_max(1. - eps)
+    else:
+        u = torch.linspace(0., 1. - eps, n_z).expand(z.shape[0], n_z)
+    i0 = (torch.searchsorted(cdf.contiguous(), u.contiguous(), right=True) - 1).clamp(0, n_z - 1)
+    i1 = (i0 + 1).clamp_max(n_z - 1)
+    c0, c1, b0, b1 = cdf.gather(-1, i0), cdf.gather(-1, i1), z.gather(-1, i0), z.gather(-1, i1)
+    t = torch.nan_to_num((u - c0) / (c1 - c0), 0.0).clamp(0, 1)
+    return (b0 + t * (b1 - b0)).detach()
+
+
+def torch_train_step(mlp, data, num_levels=2, resample_padding=0.01, coarse_loss_mult=0.1, render_kw=None, rand=None):
+    """networks/mipnerf.py:24-60 with `mlp.run_mlp` (xrnerf_amd.vanilla.NerfMLP or the reference's) on any device"""
+    import torch
+    render_kw = render_kw or {}
+    z, losses, w = data['z_vals'], [], None
+    mask = torch.broadcast_to(data['lossmult'], data['target_s'].shape)
+    for level in range(num_levels):
+        if level > 0:
+            r = rand if rand is not None else torch.rand(z.shape)
+            z = torch_resample(z, w, resample_padding, r)
+        e = torch_embed(z, data['rays_o'], data['rays_d'], data['viewdirs'], data['radii'])
+        raw = mlp.batchify_run_mlp(e).reshape(z.shape[0], z.shape[1] - 1, 4)
+        rgb, _, _, w = torch_render(raw, z, data['rays_d'], **render_kw)
+        losses.append((mask * (rgb - data['target_s']) ** 2).sum() / mask.sum())
+    return losses[-1] + coarse_loss_mult * sum(losses[:-1]), losses

@@ -305,9 +305,9 @@ __global__ void __launch_bounds__(MIP_BLOCK) k_mip_resample(const float* __restr
 // ------------------------------------------------------------------------------------------ C-ABI
 extern "C" int xr_mip_zvals(const float* near, const float* far, uint32_t n_rays, uint32_t n_z, int lindisp,
                             const float* z_rand, float* z_out, void* stream) {
-    XR_REQUIRE(near && far && z_out, "null pointer");
     XR_REQUIRE(n_z >= 2, "n_z must be >= 2");
-    if (n_rays == 0) return XR_OK;
+    if (n_rays == 0) return XR_OK;            // empty batches carry null data pointers
+    XR_REQUIRE(near && far && z_out, "null pointer");
     const uint64_t n = (uint64_t)n_rays * n_z;
     XR_REQUIRE(n < (1ull << 40), "too many samples");
     hipLaunchKernelGGL(k_mip_zvals, dim3(xr_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, near, far, n_rays, n_z,
@@ -327,9 +327,10 @@ static int mip_encode_launch(MipEncArgs a, void* stream) {
     XR_REQUIRE(a.ch > 0, "empty encoding");
     XR_REQUIRE(a.max_deg <= 60 && a.min_deg >= -60 && a.max_deg_view <= 60 && a.min_deg_view >= -60, "degree out of range");
     XR_REQUIRE(a.ld >= a.ch, "ld smaller than the row width");
-    XR_REQUIRE(a.viewdirs && a.out, "null pointer");
     const uint64_t n = (uint64_t)a.n_rays * a.n_s;
     if (n == 0) return XR_OK;
+    XR_REQUIRE(a.viewdirs && a.out, "null pointer");
+    XR_REQUIRE(a.means ? (a.covs != nullptr) : (a.rays_o && a.rays_d && a.radii && a.z_vals), "null pointer");
     XR_REQUIRE(n <= 0xffffffffull * MIP_TILE, "too many samples");
     hipLaunchKernelGGL(k_mip_encode, dim3(xr_div_up(n, MIP_TILE)), dim3(MIP_BLOCK), 0, (hipStream_t)stream, a);
     XR_LAUNCH_CHECK();
@@ -340,7 +341,6 @@ extern "C" int xr_mip_encode(const float* rays_o, const float* rays_d, const flo
                              const float* z_vals, uint32_t n_rays, uint32_t n_z, int min_deg, int max_deg,
                              int min_deg_view, int max_deg_view, int append_identity, int ray_shape, float* out,
                              uint32_t ld, void* stream) {
-    XR_REQUIRE(rays_o && rays_d && radii && z_vals, "null pointer");
     XR_REQUIRE(n_z >= 2, "n_z must be >= 2");
     XR_REQUIRE(ray_shape == 0 || ray_shape == 1, "ray_shape: 0 = cone, 1 = cylinder");
     MipEncArgs a{rays_o, rays_d, viewdirs, radii, z_vals, nullptr, nullptr, n_rays, n_z - 1, min_deg, max_deg,
@@ -351,7 +351,7 @@ extern "C" int xr_mip_encode(const float* rays_o, const float* rays_d, const flo
 extern "C" int xr_mip_encode_gaussians(const float* means, const float* covs, const float* viewdirs, uint32_t n_rays,
                                        uint32_t n_samples, int min_deg, int max_deg, int min_deg_view,
                                        int max_deg_view, int append_identity, float* out, uint32_t ld, void* stream) {
-    XR_REQUIRE(means && covs, "null pointer");
+    XR_REQUIRE(n_rays == 0 || n_samples == 0 || means, "null pointer");
     MipEncArgs a{nullptr, nullptr, viewdirs, nullptr, nullptr, means, covs, n_rays, n_samples, min_deg, max_deg,
                  min_deg_view, max_deg_view, append_identity, 0, 0, ld, out};
     return mip_encode_launch(a, stream);
@@ -360,7 +360,7 @@ extern "C" int xr_mip_encode_gaussians(const float* means, const float* covs, co
 static int mip_render_args(MipRenderArgs& a, const float* raw, const float* z_vals, const float* rays_d,
                            uint32_t n_rays, uint32_t n_z, float density_bias, float rgb_padding, int white_bkgd,
                            int density_activation) {
-    XR_REQUIRE(raw && z_vals && rays_d, "null pointer");
+    XR_REQUIRE(n_rays == 0 || (raw && z_vals && rays_d), "null pointer");
     XR_REQUIRE(n_z >= 2, "n_z must be >= 2");
     XR_REQUIRE(density_activation == 0 || density_activation == 1, "density_activation: 0 = softplus, 1 = relu");
     XR_REQUIRE(((uintptr_t)raw & 15) == 0, "raw must be 16-byte aligned");
@@ -375,8 +375,8 @@ extern "C" int xr_mip_render_forward(const float* raw, const float* z_vals, cons
     MipRenderArgs a;
     int rc = mip_render_args(a, raw, z_vals, rays_d, n_rays, n_z, density_bias, rgb_padding, white_bkgd, density_activation);
     if (rc) return rc;
-    XR_REQUIRE(rgb && distance && acc && weights, "null pointer");
     if (n_rays == 0) return XR_OK;
+    XR_REQUIRE(rgb && distance && acc && weights, "null pointer");
     hipLaunchKernelGGL(k_mip_render_fwd, dim3(xr_div_up(n_rays, MIP_BLOCK / 64)), dim3(MIP_BLOCK), 0, (hipStream_t)stream,
                        a, rgb, distance, acc, weights);
     XR_LAUNCH_CHECK();
@@ -390,9 +390,9 @@ extern "C" int xr_mip_render_backward(const float* raw, const float* z_vals, con
     MipRenderArgs a;
     int rc = mip_render_args(a, raw, z_vals, rays_d, n_rays, n_z, density_bias, rgb_padding, white_bkgd, density_activation);
     if (rc) return rc;
+    if (n_rays == 0) return XR_OK;
     XR_REQUIRE(grad_rgb && grad_raw, "null pointer");
     XR_REQUIRE(((uintptr_t)grad_raw & 15) == 0, "grad_raw must be 16-byte aligned");
-    if (n_rays == 0) return XR_OK;
     hipLaunchKernelGGL(k_mip_render_bwd, dim3(xr_div_up(n_rays, MIP_BLOCK / 64)), dim3(MIP_BLOCK), 0, (hipStream_t)stream,
                        a, grad_rgb, grad_raw);
     XR_LAUNCH_CHECK();
@@ -401,10 +401,10 @@ extern "C" int xr_mip_render_backward(const float* raw, const float* z_vals, con
 
 extern "C" int xr_mip_resample(const float* z_vals, const float* weights, const float* rand, float resample_padding,
                                uint32_t n_rays, uint32_t n_z, float* z_out, void* stream) {
-    XR_REQUIRE(z_vals && weights && z_out, "null pointer");
     XR_REQUIRE(n_z >= 2 && n_z <= MIP_MAX_NZ, "n_z must be in [2, 2048]");
-    XR_REQUIRE(z_out != z_vals, "in-place resampling is not supported");
     if (n_rays == 0) return XR_OK;
+    XR_REQUIRE(z_vals && weights && z_out, "null pointer");
+    XR_REQUIRE(z_out != z_vals, "in-place resampling is not supported");
     // mip.py:31-35: s = 1/num_samples and (s - eps) are python doubles that the tensor ops round to fp32
     const float s32 = (float)(1.0 / (double)n_z);
     const float span32 = (float)(1.0 / (double)n_z - (double)1.1920928955078125e-07);
