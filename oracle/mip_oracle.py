@@ -129,7 +129,8 @@ def sorted_piecewise_constant_pdf(bins, weights, num_samples, rand=None):
     pdf = weights / weight_sum
     # torch.cumsum on the CPU accumulates fp32 inputs in double (at::acc_type<float, false>)
     cdf = np.minimum(F(1), np.cumsum(pdf[..., :-1].astype(np.float64), axis=-1).astype(np.float32))
-    cdf = np.concatenate([np.zeros_like(cdf[..., :1]), cdf, np.ones_like(cdf[..., :1])], -1)
+    lead = list(cdf.shape[:-1]) + [1]                   # (one interval: cdf is empty here, the result is [0, 1])
+    cdf = np.concatenate([np.zeros(lead, np.float32), cdf, np.ones(lead, np.float32)], -1)
     if rand is not None:
         s = F(1 / num_samples)                           # python float 1/n, promoted to fp32 by the tensor op
         u = np.arange(num_samples).astype(np.float32) * s

@@ -1,0 +1,10 @@
+#!/bin/bash
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O
+cd $R
+timeout 300 python -m pytest tests/test_gpu_mip.py -q 2>&1 | tail -40 > $O/mip_pytest.txt; tail -5 $O/mip_pytest.txt
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/prof; timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python $R/tools/profile_mip_step.py 12 > /tmp/b.log 2>&1; tail -2 /tmp/b.log
+cp $(ls /tmp/prof/*/*kernel_stats.csv | head -1) $O/mip_step_kernel_stats.csv; python $R/tools/kstats.py $O/mip_step_kernel_stats.csv | head -30
+rm -rf /tmp/prof2; timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof2 -- python $R/tools/microbench_mip.py 65536 > /tmp/b2.log 2>&1
+cp $(ls /tmp/prof2/*/*kernel_stats.csv | head -1) $O/mip_microbench_kernel_stats.csv; grep k_mip $O/mip_microbench_kernel_stats.csv | cut -c1-60,200-400 | head
