@@ -107,3 +107,19 @@ def load_mip():
             sys.modules['tqdm'] = t
     ns.MipNerfNetwork = importlib.import_module('xrnerf.models.networks.mipnerf').MipNerfNetwork
     return ns
+
+
+def load_kilo():
+    """-> namespace with the reference's in-tree KiloNeRF pieces (BASELINE config #5): reorder_points_and_dirs,
+    convert_to_local_coords_multi, MultiNetworkFourierEmbedding, MultiNetwork, NerfRender.  `kilonerf_cuda` (external,
+    absent) is only imported inside try/except by these files."""
+    ns = load()
+    tr = importlib.import_module('xrnerf.models.networks.utils.transforms')
+    ns.reorder_points_and_dirs = tr.reorder_points_and_dirs
+    ns.convert_to_local_coords_multi = tr.convert_to_local_coords_multi
+    ns.multi_modules = importlib.import_module('xrnerf.models.mlps.multi_modules')
+    ns.MultiNetwork = ns.multi_modules.MultiNetwork
+    emb = importlib.import_module('xrnerf.models.embedders.kilonerf_fourier_embedder')
+    ns.MultiNetworkFourierEmbedding = emb.MultiNetworkFourierEmbedding
+    ns.KiloNerfFourierEmbedder = emb.KiloNerfFourierEmbedder
+    return ns
