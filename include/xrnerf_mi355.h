@@ -288,6 +288,53 @@ int xr_mip_render_backward(const float* raw, const float* z_vals, const float* r
 int xr_mip_resample(const float* z_vals, const float* weights /*[n_rays,n_z-1]*/, const float* rand,
                     float resample_padding, uint32_t n_rays, uint32_t n_z, float* z_out, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * KiloNeRF rendering (BASELINE config #5; configs/kilonerf/kilonerf_finetune_*.py, test / validation path)
+ *
+ * KiloNerfMLP.forward (xrnerf/models/mlps/kilonerf_mlp.py:138-190) in one call: sample -> network assignment with the
+ * occupancy / domain filters and the grouping by network (reorder_points_and_dirs, networks/utils/transforms.py:57-151),
+ * local coordinates (kilonerf_cuda.global_to_local == transforms.py:35-45), Fourier features
+ * (kilonerf_cuda.compute_fourier_features == embedders/kilonerf_fourier_embedder.py:33-52), the per-network MLP
+ * (6 x kilonerf_cuda.multimatmul_magma_grouped_static == MultiNetwork.forward, mlps/multi_modules.py:590-668 with
+ * late_feed_direction, relu, hidden = direction width = 32, no position re-feed) and the scatter back into
+ * raw [n_rays*n_samples, 4] (zeros where no network is evaluated).
+ *   samples: either pts [n_rays*n_samples,3] (data['pts']) or, with pts = NULL, o + d * z from rays_o / rays_d [n_rays,3]
+ *            and z_vals [n_rays,n_samples] (GetPts, datasets/pipelines/create.py:577-601, never materialised);
+ *   viewdirs [n_rays,3]; gmin/gmax/fixed_res/occ_res: HOST arrays of 3 (data['global_domain_min'/'max'], resolution//16,
+ *   resolution); occupancy: device bool grid (1 byte per cell, row-major) or NULL; domain_mins/maxs [N,3] device;
+ *   params [N, param_stride] device: per network the packed block described in xr_kilo_param_floats' source
+ *   (input-major weights = the reference's `multimatmul` layout, kilonerf_mlp.py:104-121);
+ *   counts_out (nullable, device [N]) = batch_size_per_network.
+ * workspace: xr_kilo_workspace_bytes(n_rays*n_samples, N), 256-byte aligned.  No host synchronisation. */
+uint32_t xr_kilo_param_floats(int pos_freqs, int dir_freqs, int n_hidden);
+size_t xr_kilo_workspace_bytes(uint64_t n_samples_total, uint32_t num_networks);
+int xr_kilo_mlp_forward(const float* pts, const float* rays_o, const float* rays_d, const float* z_vals,
+                        const float* viewdirs, uint32_t n_rays, uint32_t n_samples, const float* gmin_host,
+                        const float* gmax_host, const int32_t* fixed_res_host, const int32_t* occ_res_host,
+                        const uint8_t* occupancy, const float* domain_mins, const float* domain_maxs, const float* params,
+                        uint32_t param_stride, uint32_t num_networks, int pos_freqs, int dir_freqs, int n_hidden,
+                        float* raw, uint32_t* counts_out, void* workspace, size_t workspace_bytes, void* stream);
+/* One frame (or chunk) of the reference's KiloNeRF test path in one call, for the real-time bench: GetZvals (not
+ * randomized; datasets/pipelines/create.py:486-531) + GetPts + KiloNerfMLP.forward + NerfRender.forward.  Same values
+ * as xr_mip_zvals -> xr_kilo_mlp_forward -> xr_nerf_render_forward, but no [n_rays, n_samples] tensor other than the
+ * per-sample network id is written or read: z is evaluated where it is needed, rows without a network are neither
+ * zero-filled nor read back (they contribute exactly nothing to NerfRender's sums).  near / far [n_rays] device.
+ * workspace: xr_kilo_render_workspace_bytes(n_rays*n_samples, N) (its raw area is only touched where a network runs). */
+size_t xr_kilo_render_workspace_bytes(uint64_t n_samples_total, uint32_t num_networks);
+int xr_kilo_render_rays(const float* rays_o, const float* rays_d, const float* viewdirs, const float* near,
+                        const float* far, uint32_t n_rays, uint32_t n_samples, int lindisp, const float* gmin_host,
+                        const float* gmax_host, const int32_t* fixed_res_host, const int32_t* occ_res_host,
+                        const uint8_t* occupancy, const float* domain_mins, const float* domain_maxs, const float* params,
+                        uint32_t param_stride, uint32_t num_networks, int pos_freqs, int dir_freqs, int n_hidden,
+                        int white_bkgd, float* rgb, float* disp, float* acc, void* workspace, size_t workspace_bytes,
+                        void* stream);
+/* NerfRender.forward (xrnerf/models/renders/nerf_render.py:45-98; raw_noise_std = 0, relu density, sigmoid colours,
+ * cumprod weights, last interval 1e10): raw [n_rays,n_samples,4], z_vals [n_rays,n_samples] sample positions ->
+ * rgb [n_rays,3], disp [n_rays], acc [n_rays], weights [n_rays,n_samples] (nullable).  Inference only. */
+int xr_nerf_render_forward(const float* raw, const float* z_vals, const float* rays_d, uint32_t n_rays,
+                           uint32_t n_samples, int white_bkgd, float* rgb, float* disp, float* acc, float* weights,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

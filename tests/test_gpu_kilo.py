@@ -1,0 +1,199 @@
+"""KiloNeRF rendering path (BASELINE config #5) on the MI355X, through the C-ABI, against
+  * tests/golden/ref_kilonerf.npz -- outputs of the reference's OWN in-tree PyTorch code (make_golden_kilo.py), and
+  * the numpy oracle (oracle/kilo_oracle.py, pinned to the same code) on the Lego grid (1440 networks, 384 samples/ray).
+Integer work (network assignment, active set, per-network counts) is bit-exact; raw / colours within 1e-4 abs fp32."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+LAYERS = ['pts_linears.0', 'pts_linears.1', 'alpha_linear', 'feature_linear', 'direction_layer', 'rgb_linear']
+EMB = dict(type='KiloNerfFourierEmbedder', num_networks=1, input_ch=3, multires=10, multires_dirs=4)
+
+
+@pytest.fixture(scope='module')
+def K():
+    import kilo_oracle
+    return kilo_oracle
+
+
+@pytest.fixture(scope='module')
+def gold():
+    return np.load(os.path.join(G, 'ref_kilonerf.npz'))
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def mlp_from_gold(gold, dev):
+    from xrnerf_amd import kilo
+    sd = {}
+    for nm in LAYERS:
+        sd[nm + '.weight'], sd[nm + '.bias'] = torch.tensor(gold['w.' + nm]), torch.tensor(gold['b.' + nm])
+    res = [int(v) for v in gold['res']]
+    return kilo.KiloNerfMLP.from_arrays(res, gold['occupancy'], gold['domain_mins'], gold['domain_maxs'], sd, EMB).to(dev)
+
+
+def oracle_nets(K, sd):
+    g = lambda k: sd[k].detach().cpu().numpy()
+    n_hidden = 1 + max(int(k.split('.')[1]) for k in sd if k.startswith('pts_linears.'))
+    return K.TinyNets([g('pts_linears.%d.weight' % l) for l in range(n_hidden)], [g('pts_linears.%d.bias' % l) for l in range(n_hidden)],
+                      g('alpha_linear.weight'), g('alpha_linear.bias'), g('feature_linear.weight'), g('feature_linear.bias'),
+                      g('direction_layer.weight'), g('direction_layer.bias'), g('rgb_linear.weight'), g('rgb_linear.bias'))
+
+
+def test_reference_fixture(dev, gold):
+    from xrnerf_amd import ops
+    mlp = mlp_from_gold(gold, dev)
+    R, S = gold['z_vals'].shape
+    data = {'pts': T(gold['pts'], dev), 'viewdirs': T(gold['viewdirs'], dev), 'global_domain_min': torch.tensor(gold['gmin']),
+            'global_domain_max': torch.tensor(gold['gmax'])}
+    raw = mlp(data)['raw']
+    assert tuple(raw.shape) == (R, S, 4)
+    flat = raw.reshape(-1, 4).cpu().numpy()
+    active = np.zeros(R * S, bool); active[gold['active_samples']] = True
+    assert np.array_equal(flat[~active], np.zeros_like(flat[~active]))           # exact zeros where nothing is evaluated
+    assert np.abs(flat - gold['raw'].reshape(-1, 4)).max() <= 1e-4
+    # per-network counts = the reference's batch_size_per_network, bit-exact; sample positions built on the fly
+    # (o + d*z) give the same rows as the materialised data['pts']
+    fixed = [r // 16 for r in mlp.resolution]
+    raw2, counts = ops.kilo_mlp_forward(data['viewdirs'], gold['gmin'], gold['gmax'], fixed, mlp.resolution, mlp.occupancy_grid,
+                                        mlp.domain_mins, mlp.domain_maxs, mlp.multi_network.packed(), 10, 4, 2,
+                                        rays_o=T(gold['rays_o'], dev), rays_d=T(gold['rays_d'], dev), z_vals=T(gold['z_vals'], dev),
+                                        want_counts=True)
+    assert np.array_equal(counts.cpu().numpy().astype(np.int64), gold['batch_size_per_network'])
+    assert torch.equal(raw2, raw)
+    # NerfRender on the reference's raw: colours, weights, disparity (NaN where the ray is empty, like torch.max)
+    rgb, disp, acc, w = ops.nerf_render_forward(T(gold['raw'], dev), T(gold['z_vals'], dev), T(gold['rays_d'], dev), True)
+    assert np.abs(w.cpu().numpy() - gold['weights']).max() <= 2e-6
+    assert np.abs(rgb.cpu().numpy() - gold['rgb']).max() <= 5e-6 and np.abs(acc.cpu().numpy() - gold['acc']).max() <= 5e-6
+    d, ok = disp.cpu().numpy(), np.isfinite(gold['disp'])
+    assert np.array_equal(ok, np.isfinite(d))
+    assert np.abs(d[ok] - gold['disp'][ok]).max() <= 1e-5 * max(1.0, np.abs(gold['disp'][ok]).max())
+
+
+def test_network_behind_the_registry(dev, gold, tmp_path):
+    """the reference's finetune config model dict (checkpoint paths pointed at files written here) builds and renders"""
+    import copy
+    import json
+    import xrnerf_amd
+    cfg = json.load(open(os.path.join(G, 'kilo_model_cfg.json')))
+    model = copy.deepcopy(cfg['model'])
+    sd = {}
+    for nm in LAYERS:
+        sd[nm + '.weight'], sd[nm + '.bias'] = torch.tensor(gold['w.' + nm]), torch.tensor(gold['b.' + nm])
+    torch.save(torch.tensor(gold['occupancy']), tmp_path / 'occupancy.pth')
+    torch.save({'domain_mins': torch.tensor(gold['domain_mins']), 'domain_maxs': torch.tensor(gold['domain_maxs']), 'state_dict': sd}, tmp_path / 'checkpoint.pth')
+    model['mlp'].update(occupancy_checkpoint=str(tmp_path / 'occupancy.pth'), distilled_checkpoint=str(tmp_path / 'checkpoint.pth'),
+                        resolution=[int(v) for v in gold['res']])        # core/apis/helper.py:57-64 injects the resolution
+    net = xrnerf_amd.build_network(model).to(dev)
+    data = {'pts': T(gold['pts'], dev), 'viewdirs': T(gold['viewdirs'], dev), 'z_vals': T(gold['z_vals'], dev),
+            'rays_o': T(gold['rays_o'], dev), 'rays_d': T(gold['rays_d'], dev),
+            'global_domain_min': T(gold['gmin'], dev), 'global_domain_max': T(gold['gmax'], dev)}
+    with torch.no_grad():
+        ret = net.batchify_forward(data, is_test=True)
+    assert np.abs(ret['rgb'].cpu().numpy() - gold['rgb']).max() <= 1e-4
+    assert np.abs(ret['acc'].cpu().numpy() - gold['acc']).max() <= 1e-4
+    with pytest.raises(NotImplementedError):
+        net.train_step({k: v[None] for k, v in data.items()}, None)
+
+
+@pytest.mark.parametrize('R,S', [(2048, 384), (333, 97)])
+def test_lego_grid_against_oracle(dev, K, R, S):
+    """1440 networks on the 9x16x10 Lego grid, 144x256x160 occupancy, 384 samples per ray (the config's sizes)"""
+    from xrnerf_amd import kilo, ops
+    mlp, gmin, gmax = kilo.synthetic_scene(dev, seed=3)
+    rng = np.random.default_rng(R)
+    cam = rng.normal(0, 1, (R, 3)); cam = (3.2 * cam / np.linalg.norm(cam, axis=-1, keepdims=True)).astype(np.float32)
+    d = (rng.uniform(-0.5, 0.5, (R, 3)) + [0, 0, 0.3] - cam).astype(np.float32)
+    d = (d / np.linalg.norm(d, axis=-1, keepdims=True) * rng.uniform(0.9, 1.1, (R, 1))).astype(np.float32)
+    vd = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32)
+    z = np.tile(np.linspace(1.5, 5.0, S, dtype=np.float32), (R, 1))
+    fixed = [r // 16 for r in mlp.resolution]
+    raw, counts = ops.kilo_mlp_forward(T(vd, dev), gmin.tolist(), gmax.tolist(), fixed, mlp.resolution, mlp.occupancy_grid,
+                                       mlp.domain_mins, mlp.domain_maxs, mlp.multi_network.packed(), 10, 4, 2,
+                                       rays_o=T(cam, dev), rays_d=T(d, dev), z_vals=T(z, dev), want_counts=True)
+    oraw, net, active, ocounts = K.mlp_raw(cam, d, vd, z, gmin.numpy(), gmax.numpy(), fixed, mlp.resolution,
+                                           mlp.occupancy_grid.cpu().numpy(), mlp.domain_mins.cpu().numpy(),
+                                           mlp.domain_maxs.cpu().numpy(), oracle_nets(K, mlp.multi_network.state_dict()))
+    assert active.sum() > 0.01 * R * S
+    assert np.array_equal(counts.cpu().numpy().astype(np.int64), ocounts)
+    g = raw.cpu().numpy()
+    assert np.array_equal((g.reshape(-1, 4) == 0).all(1), ~active) or np.array_equal(g.reshape(-1, 4)[~active], np.zeros((int((~active).sum()), 4), np.float32))
+    assert np.abs(g - oraw).max() <= 1e-4
+    rgb, disp, acc, w = ops.nerf_render_forward(raw, T(z, dev), T(d, dev), True)
+    orgb, odisp, oacc, ow = K.nerf_render(oraw, z, d, True)
+    assert np.abs(w.cpu().numpy() - ow).max() <= 1e-4 and np.abs(rgb.cpu().numpy() - orgb).max() <= 1e-4
+
+
+def test_many_networks_and_other_architectures(dev, K):
+    """> 16384 networks (no LDS histogram: the global-atomic path), 1 hidden layer, 1 / 0 Fourier frequencies"""
+    from xrnerf_amd import ops
+    fixed = [26, 26, 26]
+    N = 26 ** 3
+    gmin, gmax = [-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]
+    nfl = ops.kilo_param_floats(1, 0, 1)
+    assert nfl == (9 * 32 + 32) + 36 + (32 * 32 + 32) + ((32 + 3) * 32 + 32) + 132
+    g = torch.Generator(device='cpu').manual_seed(0)
+    mk = lambda *s: ((torch.rand(*s, generator=g) * 2 - 1) * 0.4)
+    sd = {'pts_linears.0.weight': mk(N, 9, 32), 'pts_linears.0.bias': mk(N, 32), 'alpha_linear.weight': mk(N, 32, 1),
+          'alpha_linear.bias': mk(N, 1), 'feature_linear.weight': mk(N, 32, 32), 'feature_linear.bias': mk(N, 32),
+          'direction_layer.weight': mk(N, 35, 32), 'direction_layer.bias': mk(N, 32), 'rgb_linear.weight': mk(N, 32, 3),
+          'rgb_linear.bias': mk(N, 3)}
+    from xrnerf_amd import kilo
+    mn = kilo.MultiNetwork(N, 9, 3, num_hidden_layers=1)
+    mn.load_state_dict(sd)
+    packed = mn.to(dev).packed()
+    assert packed.shape == (N, nfl)
+    rng = np.random.default_rng(2)
+    R, S = 500, 33
+    pts = rng.uniform(-1.1, 1.1, (R, S, 3)).astype(np.float32)
+    vd = rng.normal(0, 1, (R, 3)).astype(np.float32); vd /= np.linalg.norm(vd, axis=-1, keepdims=True)
+    idx = np.stack(np.meshgrid(*[np.arange(26)] * 3, indexing='ij'), -1).reshape(-1, 3)
+    dmins = (-1.0 + idx * (2.0 / 26)).astype(np.float32); dmaxs = (-1.0 + (idx + 1) * (2.0 / 26)).astype(np.float32)
+    raw, counts = ops.kilo_mlp_forward(T(vd, dev), gmin, gmax, fixed, None, None, T(dmins, dev), T(dmaxs, dev), packed, 1, 0, 1,
+                                       pts=T(pts, dev), want_counts=True)
+    oraw, net, active, ocounts = K.mlp_raw(None, None, vd, np.zeros((R, S), np.float32), np.float32(gmin), np.float32(gmax), fixed,
+                                           None, None, dmins, dmaxs, oracle_nets(K, sd), pos_freqs=1, dir_freqs=0, pts=pts)
+    assert np.array_equal(counts.cpu().numpy().astype(np.int64), ocounts)
+    assert np.abs(raw.cpu().numpy() - oraw).max() <= 1e-4
+
+
+def test_edge_cases_and_validation(dev, gold):
+    from xrnerf_amd import _lib, ops
+    mlp = mlp_from_gold(gold, dev)
+    fixed = [r // 16 for r in mlp.resolution]
+    args = (gold['gmin'], gold['gmax'], fixed, mlp.resolution, mlp.occupancy_grid, mlp.domain_mins, mlp.domain_maxs,
+            mlp.multi_network.packed(), 10, 4, 2)
+    vd = T(gold['viewdirs'], dev)
+    far = torch.full((48, 40, 3), 50.0, device=dev)                           # every sample outside the domain
+    raw, counts = ops.kilo_mlp_forward(vd, *args, pts=far, want_counts=True)
+    assert float(raw.abs().max()) == 0.0 and int(counts.sum()) == 0
+    empty = ops.kilo_mlp_forward(vd[:0], *args, pts=far[:0])
+    assert tuple(empty.shape) == (0, 40, 4)
+    with pytest.raises(_lib.XrError):
+        ops.kilo_mlp_forward(vd.cpu(), *args, pts=far.cpu())                    # no CPU fallback
+    with pytest.raises(_lib.XrError):
+        ops.kilo_mlp_forward(vd, *args[:7], mlp.multi_network.packed()[:, :100].contiguous(), 10, 4, 2, pts=far)   # short blocks
+    # an empty ray: white background, acc 0, disparity NaN (0/0 through torch.max), as NerfRender gives
+    rgb, disp, acc, w = ops.nerf_render_forward(torch.zeros(2, 8, 4, device=dev), torch.linspace(2, 6, 8, device=dev).expand(2, 8).contiguous(),
+                                                torch.ones(2, 3, device=dev), True)
+    assert float((rgb - 1).abs().max()) == 0.0 and float(acc.abs().max()) == 0.0 and bool(torch.isnan(disp).all())
+
+
+def test_fused_frame_path_gives_the_same_pixels(dev):
+    """xr_kilo_render_rays (no per-sample tensor but the network id, empty rows neither filled nor read) against the
+    module-level path (z_vals, dense raw [R,S,4], NerfRender) on a 160x160 view of the Lego-shaped scene: bit-identical"""
+    from xrnerf_amd import kilo
+    mlp, gmin, gmax = kilo.synthetic_scene(dev, seed=1)
+    pose = kilo.orbit_poses(5)[2]
+    H = W = 160
+    a = kilo.render_frame(mlp, gmin, gmax, pose, H, W, 1111.111 * W / 800, fused=True)
+    b = kilo.render_frame(mlp, gmin, gmax, pose, H, W, 1111.111 * W / 800, fused=False)
+    assert float(b[2].max()) > 0.1 and float((b[2] > 0).float().mean()) > 0.02        # the object is in view
+    for x, y in zip(a, b):
+        assert torch.equal(torch.nan_to_num(x, nan=-1.0), torch.nan_to_num(y, nan=-1.0))

@@ -58,6 +58,14 @@ SIGNATURES = {
     'xr_mip_render_forward': (_i32, [_vp, _vp, _vp, _u32, _u32, _f, _f, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     'xr_mip_render_backward': (_i32, [_vp, _vp, _vp, _vp, _u32, _u32, _f, _f, _i32, _i32, _vp, _vp]),
     'xr_mip_resample': (_i32, [_vp, _vp, _vp, _f, _u32, _u32, _vp, _vp]),
+    'xr_kilo_param_floats': (_u32, [_i32, _i32, _i32]),
+    'xr_kilo_workspace_bytes': (_sz, [_u64, _u32]),
+    'xr_kilo_mlp_forward': (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32,
+                                   _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    'xr_nerf_render_forward': (_i32, [_vp, _vp, _vp, _u32, _u32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'xr_kilo_render_workspace_bytes': (_sz, [_u64, _u32]),
+    'xr_kilo_render_rays': (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32,
+                                   _u32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 
 _lib = None

@@ -25,6 +25,9 @@ SOURCES = {
     'xr_misc.hip': ['-ffp-contract=off'],
     # Mip-NeRF stages: fp32 in the reference's operation order (lower + (upper-lower)*rand etc.)
     'xr_mip.hip': ['-ffp-contract=off'],
+    # KiloNeRF: sample positions o + d*z and the cell index arithmetic must round like the reference's tensor ops
+    # (the MLP's FMAs are explicit fmaf calls)
+    'xr_kilo.hip': ['-ffp-contract=off'],
 }
 
 

@@ -1,0 +1,273 @@
+"""Registry entries of the KiloNeRF rendering path (BASELINE config #5, configs/kilonerf/kilonerf_finetune_*.py):
+`KiloNerfNetwork`, `KiloNerfMLP`, `KiloNerfFourierEmbedder` and the `MultiNetwork` parameter container, with the
+constructor signatures, `data` dict keys and parameter names / layouts of
+  /root/reference/xrnerf/models/networks/kilonerf.py:17-154, mlps/kilonerf_mlp.py:27-190,
+  mlps/multi_modules.py:238-392,405-668 (MultiNetworkLinear / MultiNetwork, `multimatmul` weight layout [N, in, out]),
+  embedders/kilonerf_fourier_embedder.py:60-102.
+
+`KiloNerfMLP.forward` is ONE call into the C-ABI (xr_kilo_mlp_forward, xrnerf_amd/csrc/xr_kilo.hip): the reference's
+reorder_points_and_dirs + kilonerf_cuda.global_to_local + compute_fourier_features + six MAGMA grouped GEMMs + two
+scatters.  Inference only in this round: the fine-tuning backward (multimatmul gradients) is the next step and
+`train_step` says so.  No CPU path: host tensors raise.
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import builder, ops
+from .builder import EMBEDDERS, MLPS, NETWORKS
+from .vanilla import NerfNetwork
+
+
+@EMBEDDERS.register_module()
+class KiloNerfFourierEmbedder(nn.Module):
+    """holds the frequency counts; the features themselves ([x | cos(x 2^k) | sin(x 2^k)] per channel,
+    kilonerf_fourier_embedder.py:33-52) are produced in registers inside the MLP kernel"""
+
+    def __init__(self, num_networks, multires=10, multires_dirs=4, input_ch=3, **kwargs):
+        super().__init__()
+        if input_ch != 3:
+            raise NotImplementedError('input_ch must be 3')
+        self.num_networks, self.multires, self.multires_dirs, self.input_ch = num_networks, multires, multires_dirs, input_ch
+        self.embed_ch = (2 * multires + 1) * input_ch
+        self.embed_ch_dirs = (2 * multires_dirs + 1) * input_ch
+
+    def get_embed_ch(self):
+        return self.embed_ch, self.embed_ch_dirs
+
+    def forward(self, data, fourier_embedding_implementation='pytorch'):
+        raise NotImplementedError('the Fourier features are fused into KiloNerfMLP.forward (xr_kilo_mlp_forward)')
+
+
+class MultiNetworkLinear(nn.Module):
+    """parameters of one layer of all networks in the reference's `multimatmul` layout (multi_modules.py:238-340):
+    weight [N, in, out], bias [N, out]; kaiming-uniform(a=sqrt(5)) / fan-in-uniform initialisation"""
+
+    def __init__(self, num_networks, in_features, out_features):
+        super().__init__()
+        self.num_networks, self.in_features, self.out_features = num_networks, in_features, out_features
+        bound = 1.0 / math.sqrt(in_features)                 # gain*sqrt(3/fan_in) with gain = sqrt(2/(1+5)) -> 1/sqrt(fan_in)
+        self.weight = nn.Parameter(torch.empty(num_networks, in_features, out_features).uniform_(-bound, bound))
+        self.bias = nn.Parameter(torch.empty(num_networks, out_features).uniform_(-bound, bound))
+
+
+class MultiNetwork(nn.Module):
+    """the distilled networks' parameters under the reference's names (multi_modules.py:405-565, late_feed_direction,
+    relu): pts_linears.{l}, alpha_linear, feature_linear, direction_layer, rgb_linear"""
+
+    def __init__(self, num_networks, num_position_channels, num_direction_channels, num_output_channels=4,
+                 hidden_layer_size=32, num_hidden_layers=2, refeed_position_index=None, late_feed_direction=True,
+                 direction_layer_size=32, nonlinearity='relu', **kwargs):
+        super().__init__()
+        if not late_feed_direction or refeed_position_index is not None or nonlinearity != 'relu':
+            raise NotImplementedError('only the late_feed_direction / relu / no-refeed architecture of the reference configs')
+        if hidden_layer_size != 32 or direction_layer_size != 32:
+            raise NotImplementedError('hidden_layer_size and direction_layer_size must be 32 (every reference config)')
+        self.num_networks = num_networks
+        self.num_position_channels, self.num_direction_channels = num_position_channels, num_direction_channels
+        self.hidden_layer_size, self.num_hidden_layers = hidden_layer_size, num_hidden_layers
+        self.direction_layer_size = direction_layer_size
+        H = hidden_layer_size
+        self.pts_linears = nn.ModuleList([MultiNetworkLinear(num_networks, num_position_channels if l == 0 else H, H)
+                                          for l in range(num_hidden_layers)])
+        self.alpha_linear = MultiNetworkLinear(num_networks, H, 1)
+        self.feature_linear = MultiNetworkLinear(num_networks, H, H)
+        self.direction_layer = MultiNetworkLinear(num_networks, num_direction_channels + H, direction_layer_size)
+        self.rgb_linear = MultiNetworkLinear(num_networks, direction_layer_size, 3)
+        self.view_dependent_parameters = list(self.direction_layer.parameters()) + list(self.rgb_linear.parameters())
+        self._packed, self._packed_key = None, None
+
+    def packed(self):
+        """[N, stride] parameter blocks in the kernel's order (xr_kilo.hip: kilo_param_floats), rebuilt when a
+        parameter changed"""
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._packed is not None and self._packed_key == key:
+            return self._packed
+        N = self.num_networks
+        with torch.no_grad():
+            parts = []
+            for l in self.pts_linears:
+                parts += [l.weight.reshape(N, -1), l.bias]
+            z = self.alpha_linear.bias.new_zeros
+            parts += [self.alpha_linear.weight.reshape(N, -1), self.alpha_linear.bias, z((N, 3))]
+            parts += [self.feature_linear.weight.reshape(N, -1), self.feature_linear.bias]
+            parts += [self.direction_layer.weight.reshape(N, -1), self.direction_layer.bias]
+            parts += [torch.cat([self.rgb_linear.weight, z((N, self.direction_layer_size, 1))], -1).reshape(N, -1),
+                      self.rgb_linear.bias, z((N, 1))]
+            self._packed = torch.cat(parts, 1).to(torch.float32).contiguous()
+        self._packed_key = key
+        return self._packed
+
+
+@MLPS.register_module()
+class KiloNerfMLP(nn.Module):
+    """kilonerf_mlp.py:27-190.  Checkpoints: `occupancy_checkpoint` is the reference's (a tensor saved with torch.save);
+    `distilled_checkpoint` must be a dict {'domain_mins', 'domain_maxs', 'state_dict'[, 'num_hidden_layers']} with the
+    multi network's state under the reference's parameter names -- the reference's own distillation checkpoint pickles
+    its Node / MultiNetwork classes and cannot be read without that package (conversion: next step)."""
+
+    def __init__(self, resolution=None, distilled_config=None, occupancy_checkpoint=None, distilled_checkpoint=None,
+                 embedder=None):
+        super().__init__()
+        self.resolution = list(resolution)
+        self.distilled_config = distilled_config
+        self.embedder = builder.build_embedder(embedder)
+        occ = torch.load(occupancy_checkpoint) if isinstance(occupancy_checkpoint, str) else occupancy_checkpoint
+        cp = torch.load(distilled_checkpoint) if isinstance(distilled_checkpoint, str) else distilled_checkpoint
+        if not isinstance(cp, dict) or 'state_dict' not in cp:
+            raise NotImplementedError('distilled_checkpoint must be a dict with domain_mins / domain_maxs / state_dict '
+                                      '(the reference pickle of Node objects needs the reference package to load)')
+        self._init_from(occ, cp['domain_mins'], cp['domain_maxs'], cp['state_dict'], cp.get('num_hidden_layers'))
+
+    @classmethod
+    def from_arrays(cls, resolution, occupancy, domain_mins, domain_maxs, state_dict, embedder, num_hidden_layers=None):
+        self = cls.__new__(cls)
+        nn.Module.__init__(self)
+        self.resolution, self.distilled_config = list(resolution), None
+        self.embedder = builder.build_embedder(embedder)
+        self._init_from(occupancy, domain_mins, domain_maxs, state_dict, num_hidden_layers)
+        return self
+
+    def _init_from(self, occupancy, domain_mins, domain_maxs, state_dict, num_hidden_layers):
+        dm = torch.as_tensor(domain_mins, dtype=torch.float32)
+        self.register_buffer('domain_mins', dm.clone())
+        self.register_buffer('domain_maxs', torch.as_tensor(domain_maxs, dtype=torch.float32).clone())
+        if occupancy is not None:
+            self.register_buffer('occupancy_grid', torch.as_tensor(occupancy).reshape(-1).to(torch.bool))
+        else:
+            self.occupancy_grid = None
+        if num_hidden_layers is None:
+            num_hidden_layers = 1 + max(int(k.split('.')[1]) for k in state_dict if k.startswith('pts_linears.'))
+        pos_ch, dir_ch = self.embedder.get_embed_ch()
+        self.multi_network = MultiNetwork(dm.shape[0], pos_ch, dir_ch, 4, 32, num_hidden_layers, None, True, 32, 'relu')
+        self.multi_network.load_state_dict({k: torch.as_tensor(v) for k, v in state_dict.items()}, strict=True)
+        self._host = {}
+
+    def get_view_dependent_parameters(self):
+        return self.multi_network.view_dependent_parameters
+
+    def _host3(self, t):
+        """python floats of a 3-vector that may live on the device (one read-back per distinct tensor, cached)"""
+        if not torch.is_tensor(t):
+            return [float(v) for v in t]
+        key = (t.data_ptr(), t._version, str(t.device))
+        if key not in self._host:
+            if len(self._host) > 8:
+                self._host.clear()
+            self._host[key] = [float(v) for v in t.reshape(-1).tolist()]
+        return self._host[key]
+
+    def forward(self, data):
+        fixed_res = [x // 16 for x in self.resolution]                      # kilonerf_mlp.py:146
+        gmin, gmax = self._host3(data['global_domain_min']), self._host3(data['global_domain_max'])
+        kw = dict(pts=data['pts']) if 'pts' in data else dict(rays_o=data['rays_o'], rays_d=data['rays_d'], z_vals=data['z_vals'])
+        data['raw'] = ops.kilo_mlp_forward(data['viewdirs'], gmin, gmax, fixed_res, self.resolution, self.occupancy_grid,
+                                           self.domain_mins, self.domain_maxs, self.multi_network.packed(),
+                                           self.embedder.multires, self.embedder.multires_dirs,
+                                           self.multi_network.num_hidden_layers, **kw)
+        return data
+
+
+@NETWORKS.register_module()
+class KiloNerfNetwork(NerfNetwork):
+    """networks/kilonerf.py:17-154 (rendering: forward / batchify_forward of NerfNetwork with N_importance = 0)"""
+
+    def __init__(self, cfg, mlp=None, mlp_fine=None, render=None):
+        super().__init__(cfg, mlp=mlp, mlp_fine=mlp_fine, render=render)
+        self.l2_regularization_lambda = dict(cfg).get('l2_regularization_lambda')
+
+    def train_step(self, data, optimizer, **kwargs):
+        raise NotImplementedError('KiloNeRF fine-tuning needs the backward of the grouped tiny-MLP kernel: next step '
+                                  '(this round covers the rendering path the real-time bench measures)')
+
+
+# ------------------------------------------------------------------ synthetic Lego-shaped scene (bench / smoke / tests)
+LEGO_RESOLUTION = [144, 256, 160]             # configs/kilonerf/kilonerf_finetune_Synthetic_NeRF_base01.py:18
+LEGO_GMIN = [-0.67, -1.2, -0.37]              # bounding box of the NSVF Synthetic_NeRF Lego scene
+LEGO_GMAX = [0.67, 1.2, 1.03]
+
+
+def synthetic_scene(device, resolution=None, gmin=None, gmax=None, seed=0, fill=0.07, weight_scale=2.5):
+    """occupancy (union of boxes filling ~`fill` of the cells), node domains exactly as get_nodes_fixed_resolution
+    builds them (datasets/kilonerf_node_dataset.py:108-135) and random weights for resolution//16 networks"""
+    import itertools
+    import numpy as np
+    resolution = list(resolution or LEGO_RESOLUTION)
+    gmin, gmax = np.float32(gmin or LEGO_GMIN), np.float32(gmax or LEGO_GMAX)
+    fixed = [r // 16 for r in resolution]
+    rng = np.random.default_rng(seed)
+    occ = np.zeros(resolution, bool)
+    while occ.mean() < fill:
+        c = rng.uniform(0.25, 0.75, 3) * resolution
+        h = rng.uniform(0.03, 0.12, 3) * resolution
+        lo, hi = np.maximum((c - h).astype(int), 0), np.minimum((c + h).astype(int) + 1, resolution)
+        occ[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]] = True
+    voxel = (gmax.astype(np.float64) - gmin.astype(np.float64)) / np.array(fixed)
+    dmins, dmaxs = [], []
+    for vi in itertools.product(*[range(r) for r in fixed]):
+        dmins.append((gmin.astype(np.float64) + np.array(vi) * voxel).tolist())
+        dmaxs.append((gmin.astype(np.float64) + (np.array(vi) + 1) * voxel).tolist())
+    N = len(dmins)
+    g = torch.Generator().manual_seed(seed)
+    mn = MultiNetwork(N, 63, 27)
+    with torch.no_grad():
+        for p in mn.parameters():
+            p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) * weight_scale / math.sqrt(p.shape[1] if p.dim() == 3 else 32))
+    emb = dict(type='KiloNerfFourierEmbedder', num_networks=1, input_ch=3, multires=10, multires_dirs=4)
+    mlp = KiloNerfMLP.from_arrays(resolution, occ.reshape(-1), torch.tensor(dmins), torch.tensor(dmaxs), mn.state_dict(), emb)
+    return mlp.to(device), torch.tensor(gmin), torch.tensor(gmax)
+
+
+def orbit_poses(n, radius=3.3, elevation=0.5):
+    """camera-to-world matrices [n,4,4] on a circle around the scene, looking at its centre (OpenGL axes like the
+    Blender / NSVF loaders: -z forward, y up)"""
+    out = []
+    for k in range(n):
+        th = 2 * math.pi * k / n
+        cam = torch.tensor([radius * math.cos(elevation) * math.cos(th), radius * math.cos(elevation) * math.sin(th),
+                            radius * math.sin(elevation) + 0.3])
+        fwd = torch.tensor([0., 0., 0.3]) - cam
+        fwd = fwd / fwd.norm()
+        right = torch.linalg.cross(fwd, torch.tensor([0., 0., 1.]))
+        right = right / right.norm()
+        up = torch.linalg.cross(right, fwd)
+        m = torch.eye(4)
+        m[:3, 0], m[:3, 1], m[:3, 2], m[:3, 3] = right, up, -fwd, cam
+        out.append(m)
+    return torch.stack(out)
+
+
+def camera_rays(pose, H, W, focal, device):
+    """KilonerfGetRays (datasets/pipelines/create.py:253-300: kilonerf_cuda.get_rays_d == the commented torch code):
+    dirs = ((i - cx)/fx, -(j - cy)/fy, -1) rotated by c2w[:3,:3], origins = c2w[:3,3]; viewdirs = normalised dirs"""
+    pose = torch.as_tensor(pose, dtype=torch.float32, device=device)
+    j, i = torch.meshgrid(torch.arange(H, dtype=torch.float32, device=device),
+                          torch.arange(W, dtype=torch.float32, device=device), indexing='ij')
+    dirs = torch.stack([(i - 0.5 * W) / focal, -(j - 0.5 * H) / focal, -torch.ones_like(i)], -1)
+    rays_d = torch.sum(dirs[..., None, :] * pose[:3, :3], -1).reshape(-1, 3)
+    rays_o = pose[:3, 3].expand(rays_d.shape).contiguous()
+    return rays_o, rays_d.contiguous(), (rays_d / rays_d.norm(dim=-1, keepdim=True)).contiguous()
+
+
+def render_frame(mlp, gmin, gmax, pose, H, W, focal, near=2.0, far=6.0, n_samples=384, white_bkgd=True, rays=None,
+                 fused=True):
+    """one frame through the reference's test path: rays -> 384 uniform samples (GetZvals, not randomized) ->
+    KiloNerfMLP -> NerfRender.  fused: one C-ABI call that never writes a per-sample tensor except the network id
+    (xr_kilo_render_rays); otherwise the module-level path (z_vals, raw [R,S,4], NerfRender) -- same pixels."""
+    dev = mlp.domain_mins.device
+    rays_o, rays_d, viewdirs = rays if rays is not None else camera_rays(pose, H, W, focal, dev)
+    R = rays_o.shape[0]
+    if fused:
+        nf = torch.empty((2, R), device=dev)
+        nf[0].fill_(near); nf[1].fill_(far)
+        return ops.kilo_render_rays(rays_o, rays_d, viewdirs, nf[0], nf[1], n_samples, mlp._host3(gmin), mlp._host3(gmax),
+                                    [x // 16 for x in mlp.resolution], mlp.resolution, mlp.occupancy_grid, mlp.domain_mins,
+                                    mlp.domain_maxs, mlp.multi_network.packed(), mlp.embedder.multires,
+                                    mlp.embedder.multires_dirs, mlp.multi_network.num_hidden_layers, white_bkgd)
+    z = ops.mip_zvals(torch.full((R,), near, device=dev), torch.full((R,), far, device=dev), n_samples)
+    data = {'rays_o': rays_o, 'rays_d': rays_d, 'viewdirs': viewdirs, 'z_vals': z, 'global_domain_min': gmin,
+            'global_domain_max': gmax}
+    raw = mlp(data)['raw']
+    rgb, disp, acc, _ = ops.nerf_render_forward(raw, z, rays_d, white_bkgd)
+    return rgb, disp, acc

@@ -556,3 +556,92 @@ def mip_resample(z_vals, weights, resample_padding, rand=None):
         _lib.check(L.xr_mip_resample(_ptr(z_vals), _ptr(weights), _ptr(rand), float(resample_padding), R, n_z, _ptr(out),
                                      _stream()), 'xr_mip_resample')
     return out
+
+
+# ---------------------------------------------------------------- KiloNeRF rendering (BASELINE config #5)
+def kilo_param_floats(pos_freqs, dir_freqs, n_hidden):
+    return int(_lib.load().xr_kilo_param_floats(pos_freqs, dir_freqs, n_hidden))
+
+
+def kilo_mlp_forward(viewdirs, gmin, gmax, fixed_res, occ_res, occupancy, domain_mins, domain_maxs, params, pos_freqs,
+                     dir_freqs, n_hidden, pts=None, rays_o=None, rays_d=None, z_vals=None, want_counts=False):
+    """KiloNerfMLP.forward: raw [R,S,4] (zeros where no network is evaluated) (+ batch_size_per_network [N] int32).
+    Samples: pts [R,S,3], or rays_o/rays_d [R,3] + z_vals [R,S] (o + d*z, never materialised).
+    gmin/gmax: 3 python floats; fixed_res/occ_res: 3 ints; occupancy: bool/uint8 device grid or None."""
+    L = _lib.load()
+    if pts is not None:
+        pts = _f32c(pts)
+        R, S = pts.shape[0], pts.shape[1]
+        dev = pts.device
+    else:
+        rays_o, rays_d, z_vals = _f32c(rays_o), _f32c(rays_d), _f32c(z_vals)
+        R, S = z_vals.shape
+        dev = z_vals.device
+    N = params.shape[0]
+    raw = torch.empty((R, S, 4), dtype=torch.float32, device=dev)
+    counts = torch.empty((N,), dtype=torch.int32, device=dev) if want_counts else None
+    ws = _ws(dev, L.xr_kilo_workspace_bytes(R * S, N), 'kilo')
+    if occupancy is not None:
+        occupancy = occupancy.reshape(-1)
+        if occupancy.dtype == torch.bool:
+            occupancy = occupancy.view(torch.uint8)
+        if occupancy.dtype != torch.uint8:
+            raise _lib.XrError('occupancy grid must be bool or uint8')
+    f3 = (C.c_float * 3)
+    i3 = (C.c_int32 * 3)
+    with _span('xr_kilo_mlp_forward', R * S):
+        _lib.check(L.xr_kilo_mlp_forward(_ptr(pts), _ptr(rays_o), _ptr(rays_d), _ptr(z_vals), _ptr(_f32c(viewdirs)), R, S,
+                                         f3(*[float(v) for v in gmin]), f3(*[float(v) for v in gmax]),
+                                         i3(*[int(v) for v in fixed_res]), i3(*[int(v) for v in occ_res]) if occ_res is not None else None,
+                                         _ptr(occupancy), _ptr(_f32c(domain_mins)), _ptr(_f32c(domain_maxs)), _ptr(params),
+                                         params.stride(0), N, int(pos_freqs), int(dir_freqs), int(n_hidden), _ptr(raw),
+                                         _ptr(counts), _ptr(ws), ws.numel(), _stream()), 'xr_kilo_mlp_forward')
+    return (raw, counts) if want_counts else raw
+
+
+def nerf_render_forward(raw, z_vals, rays_d, white_bkgd):
+    """NerfRender.forward (inference): -> rgb [R,3], disp [R], acc [R], weights [R,S]"""
+    L = _lib.load()
+    raw, z_vals = _f32c(raw), _f32c(z_vals)
+    R, S = z_vals.shape
+    assert tuple(raw.shape) == (R, S, 4)
+    dev = raw.device
+    rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
+    disp = torch.empty((R,), dtype=torch.float32, device=dev)
+    acc = torch.empty((R,), dtype=torch.float32, device=dev)
+    w = torch.empty((R, S), dtype=torch.float32, device=dev)
+    with _span('xr_nerf_render_forward', R * S):
+        _lib.check(L.xr_nerf_render_forward(_ptr(raw), _ptr(z_vals), _ptr(_f32c(rays_d)), R, S, int(bool(white_bkgd)),
+                                            _ptr(rgb), _ptr(disp), _ptr(acc), _ptr(w), _stream()), 'xr_nerf_render_forward')
+    return rgb, disp, acc, w
+
+
+def kilo_render_rays(rays_o, rays_d, viewdirs, near, far, n_samples, gmin, gmax, fixed_res, occ_res, occupancy, domain_mins,
+                     domain_maxs, params, pos_freqs, dir_freqs, n_hidden, white_bkgd=True, lindisp=False):
+    """GetZvals(not randomized) + GetPts + KiloNerfMLP.forward + NerfRender.forward in one call (the frame path of the
+    real-time bench): -> rgb [R,3], disp [R], acc [R].  near / far: [R] device tensors."""
+    L = _lib.load()
+    rays_o, rays_d, viewdirs = _f32c(rays_o), _f32c(rays_d), _f32c(viewdirs)
+    near, far = _f32c(near.reshape(-1)), _f32c(far.reshape(-1))
+    R = rays_o.shape[0]
+    dev = rays_o.device
+    N = params.shape[0]
+    rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
+    disp = torch.empty((R,), dtype=torch.float32, device=dev)
+    acc = torch.empty((R,), dtype=torch.float32, device=dev)
+    ws = _ws(dev, L.xr_kilo_render_workspace_bytes(R * n_samples, N), 'kilo_frame')
+    if occupancy is not None:
+        occupancy = occupancy.reshape(-1)
+        if occupancy.dtype == torch.bool:
+            occupancy = occupancy.view(torch.uint8)
+    f3 = (C.c_float * 3)
+    i3 = (C.c_int32 * 3)
+    with _span('xr_kilo_render_rays', R * n_samples):
+        _lib.check(L.xr_kilo_render_rays(_ptr(rays_o), _ptr(rays_d), _ptr(viewdirs), _ptr(near), _ptr(far), R, int(n_samples),
+                                         int(bool(lindisp)), f3(*[float(v) for v in gmin]), f3(*[float(v) for v in gmax]),
+                                         i3(*[int(v) for v in fixed_res]), i3(*[int(v) for v in occ_res]) if occ_res is not None else None,
+                                         _ptr(occupancy), _ptr(_f32c(domain_mins)), _ptr(_f32c(domain_maxs)), _ptr(params),
+                                         params.stride(0), N, int(pos_freqs), int(dir_freqs), int(n_hidden),
+                                         int(bool(white_bkgd)), _ptr(rgb), _ptr(disp), _ptr(acc), _ptr(ws), ws.numel(),
+                                         _stream()), 'xr_kilo_render_rays')
+    return rgb, disp, acc
