@@ -217,6 +217,66 @@ def mipnerf_config3(dev, steps=20, warmup=5, cpu_seconds=10.0):
     return res
 
 
+def kilonerf_config5(dev, frames=8, cpu_seconds=10.0):
+    """Secondary line (BASELINE config #5): KiloNeRF real-time rendering -- 800x800 rays x 384
+    samples through 1440 tiny MLPs on the Lego grid (synthetic occupancy ~7 %, random weights), the reference's test
+    path (GetZvals + GetPts + KiloNerfMLP + NerfRender) as one C-ABI call; beside it the numpy oracle of the same path
+    on a bounded sample of the same rays, one host thread."""
+    from xrnerf_amd import kilo
+    mlp, gmin, gmax = kilo.synthetic_scene(dev, seed=1)
+    H = W = 800
+    focal = 1111.111
+    poses = kilo.orbit_poses(6)
+    for _ in range(2):
+        kilo.render_frame(mlp, gmin, gmax, poses[0], H, W, focal)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for f in range(frames):
+        rgb, disp, acc = kilo.render_frame(mlp, gmin, gmax, poses[f % len(poses)], H, W, focal)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / frames
+    # evaluated samples of one frame (per-network counts of the module-level path) -> flops of the tiny MLPs
+    rays_o, rays_d, viewdirs = kilo.camera_rays(poses[0], H, W, focal, dev)
+    z = ops.mip_zvals(torch.full((H * W,), 2.0, device=dev), torch.full((H * W,), 6.0, device=dev), 384)
+    _, counts = ops.kilo_mlp_forward(viewdirs, mlp._host3(gmin), mlp._host3(gmax), [x // 16 for x in mlp.resolution],
+                                     mlp.resolution, mlp.occupancy_grid, mlp.domain_mins, mlp.domain_maxs,
+                                     mlp.multi_network.packed(), 10, 4, 2, rays_o=rays_o, rays_d=rays_d, z_vals=z, want_counts=True)
+    evaluated = int(counts.sum())
+    flop_per_sample = 2 * (63 * 32 + 32 * 32 + 32 * 33 + 59 * 32 + 32 * 3)
+    res = {'workload': 'KiloNeRF Lego grid (configs/kilonerf/kilonerf_finetune_Synthetic_NeRF_base01.py): 800x800 rays x 384 samples, '
+                       '1440 networks (9x16x10) of 2x32 hidden units, 144x256x160 occupancy, synthetic scene and weights',
+           'value': ms, 'unit': 'ms per 800x800 frame (ray generation included)', 'higher_is_better': False, 'frames': frames,
+           'dtype': 'f32', 'evaluated_samples_per_frame': evaluated, 'networks_used': int((counts > 0).sum()),
+           'tiny_mlp_gflop_per_frame': evaluated * flop_per_sample / 1e9,
+           'reference_published_ms_per_frame_other_hw': 365.16}
+    del z, rays_o, rays_d, viewdirs
+    torch.cuda.empty_cache()
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import kilo_oracle as KO
+    nets = KO.TinyNets(*[[v.cpu().numpy() for v in grp] if isinstance(grp, list) else grp.cpu().numpy() for grp in (
+        [l.weight.detach() for l in mlp.multi_network.pts_linears], [l.bias.detach() for l in mlp.multi_network.pts_linears],
+        mlp.multi_network.alpha_linear.weight.detach(), mlp.multi_network.alpha_linear.bias.detach(),
+        mlp.multi_network.feature_linear.weight.detach(), mlp.multi_network.feature_linear.bias.detach(),
+        mlp.multi_network.direction_layer.weight.detach(), mlp.multi_network.direction_layer.bias.detach(),
+        mlp.multi_network.rgb_linear.weight.detach(), mlp.multi_network.rgb_linear.bias.detach())])
+    ro, rd, vd = (t.cpu().numpy() for t in kilo.camera_rays(poses[0], H, W, focal, 'cpu'))
+    occ, dmn, dmx = mlp.occupancy_grid.cpu().numpy(), mlp.domain_mins.cpu().numpy(), mlp.domain_maxs.cpu().numpy()
+    done, t0 = 0, time.perf_counter()
+    rows = np.arange(0, H * W, 41)                       # a strided sample of the frame's rays, 2048 at a time
+    zc = np.tile(np.linspace(2.0, 6.0, 384, dtype=np.float32), (2048, 1))
+    while done < rows.size and time.perf_counter() - t0 < cpu_seconds:
+        sel = rows[done:done + 2048]
+        raw, _, _, _ = KO.mlp_raw(ro[sel], rd[sel], vd[sel], zc[:sel.size], gmin.numpy(), gmax.numpy(), [9, 16, 10], mlp.resolution,
+                                  occ, dmn, dmx, nets)
+        KO.nerf_render(raw, zc[:sel.size], rd[sel], True)
+        done += sel.size
+    cel = time.perf_counter() - t0
+    res['cpu_baseline'] = {'value': cel / max(done, 1) * H * W * 1e3, 'unit': 'ms per 800x800 frame (extrapolated)', 'cores': 1,
+                           'kind': 'port', 'sample': '%d rays (every 41st of the frame) x 384 samples, oracle/kilo_oracle.py '
+                                                      '(numpy), ray generation excluded' % done}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -226,6 +286,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-render', action='store_true')
     ap.add_argument('--no-mip', action='store_true', help='skip the secondary Mip-NeRF (config #3) line')
+    ap.add_argument('--no-kilo', action='store_true', help='skip the secondary KiloNeRF (config #5) line')
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -365,10 +426,14 @@ def main():
             out['cpu_baseline'] = cpu_baseline()
             out['cpu_baseline']['host_cores_available'] = os.cpu_count()
             out['cpu_baseline_vanilla_nerf_config1'] = cpu_vanilla_nerf()
-        if world == 1 and not args.no_mip:
+        if world == 1 and not (args.no_mip and args.no_kilo):
             del tr
             torch.cuda.empty_cache()
+        if world == 1 and not args.no_mip:
             out['mipnerf_config3'] = mipnerf_config3(dev)
+        if world == 1 and not args.no_kilo:
+            torch.cuda.empty_cache()
+            out['kilonerf_config5'] = kilonerf_config5(dev)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()
