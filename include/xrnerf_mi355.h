@@ -319,8 +319,9 @@ int xr_kilo_mlp_forward(const float* pts, const float* rays_o, const float* rays
  * as xr_mip_zvals -> xr_kilo_mlp_forward -> xr_nerf_render_forward, but no [n_rays, n_samples] tensor other than the
  * per-sample network id is written or read: z is evaluated where it is needed, rows without a network are neither
  * zero-filled nor read back (they contribute exactly nothing to NerfRender's sums).  near / far [n_rays] device.
- * workspace: xr_kilo_render_workspace_bytes(n_rays*n_samples, N) (its raw area is only touched where a network runs). */
-size_t xr_kilo_render_workspace_bytes(uint64_t n_samples_total, uint32_t num_networks);
+ * The lattice passes only visit each ray's span of samples that can lie inside the global domain (slab test).
+ * workspace: xr_kilo_render_workspace_bytes(n_rays, n_samples, N) (its raw area is only touched where a network runs). */
+size_t xr_kilo_render_workspace_bytes(uint32_t n_rays, uint32_t n_samples, uint32_t num_networks);
 int xr_kilo_render_rays(const float* rays_o, const float* rays_d, const float* viewdirs, const float* near,
                         const float* far, uint32_t n_rays, uint32_t n_samples, int lindisp, const float* gmin_host,
                         const float* gmax_host, const int32_t* fixed_res_host, const int32_t* occ_res_host,

@@ -85,9 +85,64 @@ __device__ inline int kilo_network_of(const KiloGrid& g, const float p[3], const
 // NOTE on `net = net * res + idx`: with idx possibly negative on an axis this Horner form still equals
 // sum(idx * strides) exactly (integer arithmetic), which is what the reference compares against [0, num_networks).
 
-__global__ void __launch_bounds__(256) k_kilo_assign(KiloGrid g, KiloRays r, const uint8_t* __restrict__ occupancy,
+// The lattice passes (assign, scatter, render) visit either every sample of a stretch of the flattened [R*S] lattice
+// (spans == NULL: the module-level path with its dense tensors) or, in the fused frame path, only each ray's SPAN:
+// the index range of the un-jittered z lattice that can lie inside the global domain (slab test, widened by two samples
+// per side; axes the ray is nearly parallel to do not constrain).  Samples outside a span fail the reference's domain
+// test, so they are never evaluated, written or read -- about 9 of 10 lattice samples of a Lego frame.
+template <typename F>
+__device__ __forceinline__ void kilo_for_each_sample(const uint32_t* __restrict__ spans, uint32_t n_s, uint64_t n,
+                                                     uint32_t per_block, uint32_t n_rays, F f) {
+    if (spans == nullptr) {
+        const uint64_t i0 = (uint64_t)blockIdx.x * per_block;
+        const uint64_t i1 = i0 + per_block < n ? i0 + per_block : n;
+        for (uint64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) f(i);
+    } else {
+        const uint32_t r0 = blockIdx.x * per_block;                  // per_block counts rays in this mode
+        const uint32_t r1 = r0 + per_block < n_rays ? r0 + per_block : n_rays;
+        const uint32_t lane = threadIdx.x & 63;
+        for (uint32_t ray = r0 + (threadIdx.x >> 6); ray < r1; ray += blockDim.x >> 6) {
+            const uint32_t lo = spans[2 * ray], hi = spans[2 * ray + 1];
+            for (uint32_t s = lo + lane; s < hi; s += 64) f((uint64_t)ray * n_s + s);
+        }
+    }
+}
+
+__global__ void k_kilo_spans(KiloGrid g, KiloRays r, uint32_t* __restrict__ spans) {
+    const uint32_t ray = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ray >= r.n_rays) return;
+    const float near = r.near[ray], far = r.far[ray];
+    float z0 = fminf(near, far), z1 = fmaxf(near, far);
+    bool empty = false;
+    for (int a = 0; a < 3; ++a) {
+        const float o = r.rays_o[ray * 3ull + a], d = r.rays_d[ray * 3ull + a];
+        if (fabsf(d) >= 1e-3f) {
+            const float za = (g.lo_eps[a] - o) / d, zb = (g.hi_eps[a] - o) / d;
+            z0 = fmaxf(z0, fminf(za, zb));
+            z1 = fminf(z1, fmaxf(za, zb));
+        } else if (fabsf(d) == 0.f && (o <= g.lo_eps[a] - 1e-3f || o >= g.hi_eps[a] + 1e-3f)) {
+            empty = true;                               // parallel to the slab and clearly outside of it
+        }
+    }
+    uint32_t lo = 0, hi = 0;
+    if (!empty && z0 <= z1 && far != near && r.lindisp == 0) {
+        const float scale = (float)(r.n_s - 1) / (far - near);
+        float a = (z0 - near) * scale, b = (z1 - near) * scale;
+        if (a > b) { const float t = a; a = b; b = t; }
+        const float fl = floorf(a) - 2.f, fh = ceilf(b) + 3.f;
+        lo = fl <= 0.f ? 0u : (fl >= (float)r.n_s ? r.n_s : (uint32_t)fl);
+        hi = fh <= 0.f ? 0u : (fh >= (float)r.n_s ? r.n_s : (uint32_t)fh);
+        if (hi < lo) hi = lo;
+    } else if (!empty && (far == near || r.lindisp != 0)) {
+        hi = r.n_s;                                     // no closed form used: keep the whole ray
+    }
+    spans[2 * ray] = lo; spans[2 * ray + 1] = hi;
+}
+
+__global__ void __launch_bounds__(1024) k_kilo_assign(KiloGrid g, KiloRays r, const uint8_t* __restrict__ occupancy,
                                                      uint32_t num_networks, uint64_t n, uint32_t per_block,
-                                                     int32_t* __restrict__ net_of, uint32_t* __restrict__ counts,
+                                                     const uint32_t* __restrict__ spans, int32_t* __restrict__ net_of,
+                                                     uint32_t* __restrict__ counts,
                                                      float4* __restrict__ raw /* NULL: rows without a network stay unwritten */) {
     extern __shared__ uint32_t s_hist[];
     const bool lds = num_networks <= KILO_MAX_LDS_BINS;
@@ -95,10 +150,8 @@ __global__ void __launch_bounds__(256) k_kilo_assign(KiloGrid g, KiloRays r, con
         for (uint32_t b = threadIdx.x; b < num_networks; b += blockDim.x) s_hist[b] = 0;
         __syncthreads();
     }
-    const uint64_t i0 = (uint64_t)blockIdx.x * per_block;
-    const uint64_t i1 = i0 + per_block < n ? i0 + per_block : n;
     int any = 0;
-    for (uint64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+    kilo_for_each_sample(spans, r.n_s, n, per_block, r.n_rays, [&](uint64_t i) {
         float p[3];
         kilo_point(r, i, p);
         const int net = kilo_network_of(g, p, occupancy, (int)num_networks);
@@ -106,7 +159,7 @@ __global__ void __launch_bounds__(256) k_kilo_assign(KiloGrid g, KiloRays r, con
         if (net < 0) { if (raw != nullptr) raw[i] = make_float4(0.f, 0.f, 0.f, 0.f); }   // kilonerf_mlp.py:183-189: zeros elsewhere
         else if (lds) { atomicAdd(&s_hist[net], 1u); any = 1; }
         else atomicAdd(&counts[net], 1u);
-    }
+    });
     if (lds && __syncthreads_or(any)) {                 // most workgroups of a frame see no occupied sample at all
         for (uint32_t b = threadIdx.x; b < num_networks; b += blockDim.x)
             if (s_hist[b]) atomicAdd(&counts[b], s_hist[b]);
@@ -146,27 +199,26 @@ __global__ void __launch_bounds__(1024) k_kilo_offsets(const uint32_t* __restric
     if (threadIdx.x == 0) { seg_start[num_networks] = carry_a; tile_start[num_networks] = carry_b; }
 }
 
-__global__ void __launch_bounds__(256) k_kilo_scatter(const int32_t* __restrict__ net_of, uint32_t num_networks, uint64_t n,
-                                                      uint32_t per_block, const uint32_t* __restrict__ seg_start,
+__global__ void __launch_bounds__(1024) k_kilo_scatter(const int32_t* __restrict__ net_of, uint32_t num_networks, uint64_t n,
+                                                      uint32_t per_block, const uint32_t* __restrict__ spans, uint32_t n_s,
+                                                      uint32_t n_rays, const uint32_t* __restrict__ seg_start,
                                                       uint32_t* __restrict__ cursor, uint32_t* __restrict__ order) {
     extern __shared__ uint32_t s_hist[];
     const bool lds = num_networks <= KILO_MAX_LDS_BINS;
-    const uint64_t i0 = (uint64_t)blockIdx.x * per_block;
-    const uint64_t i1 = i0 + per_block < n ? i0 + per_block : n;
     if (!lds) {
-        for (uint64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        kilo_for_each_sample(spans, n_s, n, per_block, n_rays, [&](uint64_t i) {
             const int net = net_of[i];
             if (net >= 0) order[seg_start[net] + atomicAdd(&cursor[net], 1u)] = (uint32_t)i;
-        }
+        });
         return;
     }
     for (uint32_t b = threadIdx.x; b < num_networks; b += blockDim.x) s_hist[b] = 0;
     __syncthreads();
     int any = 0;
-    for (uint64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+    kilo_for_each_sample(spans, n_s, n, per_block, n_rays, [&](uint64_t i) {
         const int net = net_of[i];
         if (net >= 0) { atomicAdd(&s_hist[net], 1u); any = 1; }
-    }
+    });
     if (!__syncthreads_or(any)) return;                 // nothing to place from this stretch of samples
     // reserve this workgroup's range inside every network segment it touches; the bin then holds the next free slot
     for (uint32_t b = threadIdx.x; b < num_networks; b += blockDim.x) {
@@ -174,10 +226,10 @@ __global__ void __launch_bounds__(256) k_kilo_scatter(const int32_t* __restrict_
         if (c) s_hist[b] = seg_start[b] + atomicAdd(&cursor[b], c);
     }
     __syncthreads();
-    for (uint64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+    kilo_for_each_sample(spans, n_s, n, per_block, n_rays, [&](uint64_t i) {
         const int net = net_of[i];
         if (net >= 0) order[atomicAdd(&s_hist[net], 1u)] = (uint32_t)i;
-    }
+    });
 }
 
 // ------------------------------------------------------------------------------------------ the tiny MLPs
@@ -354,7 +406,9 @@ __device__ inline float wave_sum_f(float v) {
 // net_of (nullable): rows with net_of < 0 were never written and count as raw = 0 (exactly what they contribute: alpha = 0,
 // weight = 0, transmittance factor 1) -- the sparse frame path reads 4 bytes per empty sample instead of 16.
 __global__ void __launch_bounds__(256) k_nerf_render(const float4* __restrict__ raw, KiloRays zr,
-                                                     const int32_t* __restrict__ net_of, int white_bkgd,
+                                                     const int32_t* __restrict__ net_of,
+                                                     const uint32_t* __restrict__ spans /* with net_of: only [lo, hi) was assigned */,
+                                                     int white_bkgd,
                                                      float* __restrict__ rgb_out, float* __restrict__ disp_out,
                                                      float* __restrict__ acc_out, float* __restrict__ weights_out) {
     const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -365,9 +419,10 @@ __global__ void __launch_bounds__(256) k_nerf_render(const float4* __restrict__ 
     const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
     double carry = 1.0;                                  // prod_{j < sweep} (1 - alpha_j + 1e-10)
     float a_c[3] = {0.f, 0.f, 0.f}, a_w = 0.f, a_z = 0.f;
-    for (uint32_t base = 0; base < n_s; base += 64) {
+    const uint32_t s_lo = spans != nullptr ? spans[2 * r] : 0u, s_hi = spans != nullptr ? spans[2 * r + 1] : n_s;
+    for (uint32_t base = s_lo & ~63u; base < s_hi; base += 64) {
         const uint32_t i = base + lane;
-        const bool live = i < n_s;
+        const bool live = i >= s_lo && i < s_hi;
         float alpha = 0.f, zi = 0.f;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         double fac = 1.0;
@@ -419,8 +474,8 @@ extern "C" uint32_t xr_kilo_param_floats(int pos_freqs, int dir_freqs, int n_hid
     return kilo_param_floats(pos_freqs, dir_freqs, n_hidden);
 }
 
-struct KiloWs { int32_t* net_of; uint32_t* order; uint32_t* counts; uint32_t* cursor; uint32_t* seg_start; uint32_t* tile_start; };
-static size_t kilo_ws_layout(uint64_t n, uint32_t N, char* base, KiloWs* ws) {
+struct KiloWs { int32_t* net_of; uint32_t* order; uint32_t* counts; uint32_t* cursor; uint32_t* seg_start; uint32_t* tile_start; uint32_t* spans; };
+static size_t kilo_ws_layout(uint64_t n, uint32_t N, uint32_t span_rays, char* base, KiloWs* ws) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return base ? base + o : nullptr; };
     char* p;
@@ -430,11 +485,12 @@ static size_t kilo_ws_layout(uint64_t n, uint32_t N, char* base, KiloWs* ws) {
     p = take((size_t)N * 4); if (ws) ws->cursor = (uint32_t*)p;
     p = take((size_t)(N + 1) * 4); if (ws) ws->seg_start = (uint32_t*)p;
     p = take((size_t)(N + 1) * 4); if (ws) ws->tile_start = (uint32_t*)p;
+    p = take((size_t)span_rays * 8); if (ws) ws->spans = span_rays ? (uint32_t*)p : nullptr;
     return off;
 }
 
 extern "C" size_t xr_kilo_workspace_bytes(uint64_t n_samples, uint32_t num_networks) {
-    return kilo_ws_layout(n_samples, num_networks, nullptr, nullptr);
+    return kilo_ws_layout(n_samples, num_networks, 0, nullptr, nullptr);
 }
 
 // assignment -> offsets -> scatter -> MLP; dense: rows without a network are zero-filled (the reference's raw tensor),
@@ -444,6 +500,8 @@ static int kilo_mlp_launch(const KiloRays& rays, const float* gmin_host, const f
                            const float* domain_maxs, const float* params, uint32_t param_stride, uint32_t num_networks,
                            int pos_freqs, int dir_freqs, int n_hidden, float* raw, bool dense, uint32_t* counts_out,
                            void* workspace, size_t workspace_bytes, hipStream_t st, KiloWs* ws_out) {
+    // per-ray spans: only where the z lattice is evaluated on the fly and nothing dense is promised to the caller
+    const bool use_spans = !dense && rays.pts == nullptr && rays.z_vals == nullptr;
     XR_REQUIRE(gmin_host && gmax_host && fixed_res_host, "null host pointer");
     XR_REQUIRE(num_networks >= 1, "num_networks must be >= 1");
     XR_REQUIRE(pos_freqs >= 0 && pos_freqs <= 16 && dir_freqs >= 0 && dir_freqs <= 16, "frequency count out of range");
@@ -458,8 +516,8 @@ static int kilo_mlp_launch(const KiloRays& rays, const float* gmin_host, const f
     XR_REQUIRE(rays.pts || (rays.rays_o && rays.rays_d && (rays.z_vals || (rays.near && rays.far))),
                "either pts or (rays_o, rays_d, z_vals | near, far) is required");
     XR_REQUIRE(((uintptr_t)raw & 15) == 0 && ((uintptr_t)params & 15) == 0, "raw / params must be 16-byte aligned");
-    XR_REQUIRE(workspace && workspace_bytes >= xr_kilo_workspace_bytes(n, num_networks) && ((uintptr_t)workspace & 255) == 0,
-               "workspace too small or not 256-byte aligned");
+    XR_REQUIRE(workspace && workspace_bytes >= kilo_ws_layout(n, num_networks, use_spans ? rays.n_rays : 0, nullptr, nullptr) &&
+               ((uintptr_t)workspace & 255) == 0, "workspace too small or not 256-byte aligned");
     KiloGrid g;
     for (int a = 0; a < 3; ++a) {
         g.gmin[a] = gmin_host[a]; g.gmax[a] = gmax_host[a]; g.fixed_res[a] = fixed_res_host[a];
@@ -471,20 +529,29 @@ static int kilo_mlp_launch(const KiloRays& rays, const float* gmin_host, const f
         g.lo_eps[a] = lo; g.hi_eps[a] = hi; g.voxel[a] = vx; g.ovoxel[a] = ovx;
     }
     KiloWs ws;
-    kilo_ws_layout(n, num_networks, (char*)workspace, &ws);
+    kilo_ws_layout(n, num_networks, use_spans ? rays.n_rays : 0, (char*)workspace, &ws);
     if (ws_out) *ws_out = ws;
     XR_HIP(hipMemsetAsync(ws.counts, 0, (size_t)num_networks * 4, st));
-    // samples per workgroup: the per-workgroup histogram costs ~3 passes over the bins, so give each one enough samples
-    const uint32_t per_block = n >= (64ull << 20) ? 16384 : 4096;
-    const uint32_t blocks = xr_div_up(n, per_block);
+    // work per workgroup: the per-workgroup histogram costs ~3 passes over the bins, so give each one enough samples
+    // (span mode: per_block counts rays)
+    uint32_t per_block, blocks, threads = 256;
+    if (use_spans) {
+        hipLaunchKernelGGL(k_kilo_spans, dim3(xr_div_up(rays.n_rays, 256)), dim3(256), 0, st, g, rays, ws.spans);
+        XR_LAUNCH_CHECK();
+        per_block = 32;                                  // 4 waves x 8 rays (measured: 128 rays 396 us, 64 rays / 1024 threads 540 us)
+        blocks = xr_div_up(rays.n_rays, per_block);
+    } else {
+        per_block = n >= (64ull << 20) ? 16384 : 4096;
+        blocks = xr_div_up(n, per_block);
+    }
     const size_t hist_lds = num_networks <= KILO_MAX_LDS_BINS ? (size_t)num_networks * 4 : 0;
-    hipLaunchKernelGGL(k_kilo_assign, dim3(blocks), dim3(256), hist_lds, st, g, rays, occupancy, num_networks, n, per_block,
-                       ws.net_of, ws.counts, dense ? reinterpret_cast<float4*>(raw) : nullptr);
+    hipLaunchKernelGGL(k_kilo_assign, dim3(blocks), dim3(threads), hist_lds, st, g, rays, occupancy, num_networks, n, per_block,
+                       ws.spans, ws.net_of, ws.counts, dense ? reinterpret_cast<float4*>(raw) : nullptr);
     XR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_kilo_offsets, dim3(1), dim3(1024), 0, st, ws.counts, num_networks, ws.seg_start, ws.tile_start, ws.cursor);
     XR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_kilo_scatter, dim3(blocks), dim3(256), hist_lds, st, ws.net_of, num_networks, n, per_block,
-                       ws.seg_start, ws.cursor, ws.order);
+    hipLaunchKernelGGL(k_kilo_scatter, dim3(blocks), dim3(threads), hist_lds, st, ws.net_of, num_networks, n, per_block,
+                       ws.spans, rays.n_s, rays.n_rays, ws.seg_start, ws.cursor, ws.order);
     XR_LAUNCH_CHECK();
     KiloMlpArgs a{rays, domain_mins, domain_maxs, params, param_stride, num_networks, pos_freqs, dir_freqs, n_hidden,
                   ws.seg_start, ws.tile_start, ws.order, reinterpret_cast<float4*>(raw)};
@@ -513,8 +580,9 @@ extern "C" int xr_kilo_mlp_forward(const float* pts, const float* rays_o, const 
                            workspace, workspace_bytes, (hipStream_t)stream, nullptr);
 }
 
-extern "C" size_t xr_kilo_render_workspace_bytes(uint64_t n_samples_total, uint32_t num_networks) {
-    return ((n_samples_total * 16 + 255) & ~(size_t)255) + xr_kilo_workspace_bytes(n_samples_total, num_networks);
+extern "C" size_t xr_kilo_render_workspace_bytes(uint32_t n_rays, uint32_t n_samples, uint32_t num_networks) {
+    const uint64_t n = (uint64_t)n_rays * n_samples;
+    return ((n * 16 + 255) & ~(size_t)255) + kilo_ws_layout(n, num_networks, n_rays, nullptr, nullptr);
 }
 
 extern "C" int xr_kilo_render_rays(const float* rays_o, const float* rays_d, const float* viewdirs, const float* near,
@@ -528,8 +596,8 @@ extern "C" int xr_kilo_render_rays(const float* rays_o, const float* rays_d, con
     const uint64_t n = (uint64_t)n_rays * n_samples;
     if (n == 0) return XR_OK;
     XR_REQUIRE(near && far && rgb && disp && acc, "null pointer");
-    XR_REQUIRE(workspace && workspace_bytes >= xr_kilo_render_workspace_bytes(n, num_networks) && ((uintptr_t)workspace & 255) == 0,
-               "workspace too small or not 256-byte aligned");
+    XR_REQUIRE(workspace && workspace_bytes >= xr_kilo_render_workspace_bytes(n_rays, n_samples, num_networks) &&
+               ((uintptr_t)workspace & 255) == 0, "workspace too small or not 256-byte aligned");
     const size_t raw_bytes = (n * 16 + 255) & ~(size_t)255;
     float* raw = (float*)workspace;                      // touched only where a network is evaluated
     KiloRays rays{nullptr, rays_o, rays_d, nullptr, viewdirs, n_rays, n_samples, near, far, lindisp};
@@ -539,7 +607,7 @@ extern "C" int xr_kilo_render_rays(const float* rays_o, const float* rays_d, con
                              (char*)workspace + raw_bytes, workspace_bytes - raw_bytes, (hipStream_t)stream, &ws);
     if (rc) return rc;
     hipLaunchKernelGGL(k_nerf_render, dim3(xr_div_up(n_rays, 4)), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const float4*>(raw), rays, ws.net_of, white_bkgd, rgb, disp, acc, (float*)nullptr);
+                       reinterpret_cast<const float4*>(raw), rays, ws.net_of, ws.spans, white_bkgd, rgb, disp, acc, (float*)nullptr);
     XR_LAUNCH_CHECK();
     return XR_OK;
 }
@@ -553,7 +621,8 @@ extern "C" int xr_nerf_render_forward(const float* raw, const float* z_vals, con
     XR_REQUIRE(((uintptr_t)raw & 15) == 0, "raw must be 16-byte aligned");
     KiloRays zr{nullptr, nullptr, rays_d, z_vals, nullptr, n_rays, n_samples, nullptr, nullptr, 0};
     hipLaunchKernelGGL(k_nerf_render, dim3(xr_div_up(n_rays, 4)), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const float4*>(raw), zr, (const int32_t*)nullptr, white_bkgd, rgb, disp, acc, weights);
+                       reinterpret_cast<const float4*>(raw), zr, (const int32_t*)nullptr, (const uint32_t*)nullptr, white_bkgd, rgb,
+                       disp, acc, weights);
     XR_LAUNCH_CHECK();
     return XR_OK;
 }

@@ -629,7 +629,7 @@ def kilo_render_rays(rays_o, rays_d, viewdirs, near, far, n_samples, gmin, gmax,
     rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
     disp = torch.empty((R,), dtype=torch.float32, device=dev)
     acc = torch.empty((R,), dtype=torch.float32, device=dev)
-    ws = _ws(dev, L.xr_kilo_render_workspace_bytes(R * n_samples, N), 'kilo_frame')
+    ws = _ws(dev, L.xr_kilo_render_workspace_bytes(R, int(n_samples), N), 'kilo_frame')
     if occupancy is not None:
         occupancy = occupancy.reshape(-1)
         if occupancy.dtype == torch.bool:
