@@ -80,3 +80,64 @@ def test_load_blender_data_equals_the_reference_on_its_fixture():
         assert np.allclose(a[2], b[2].numpy(), atol=1e-6)
         assert a[3][:2] == b[3][:2] and abs(a[3][2] - b[3][2]) < 1e-9
         assert all(np.array_equal(x, y) for x, y in zip(a[4], b[4]))
+
+
+def write_llff_scene(root, n=7, H=12, W=16, factor=4):
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    os.makedirs(os.path.join(root, 'images'), exist_ok=True)
+    os.makedirs(os.path.join(root, 'images_%d' % factor), exist_ok=True)
+    rows = []
+    for i in range(n):
+        Image.fromarray(rng.integers(0, 256, (H * factor, W * factor, 3), dtype=np.uint8)).save(os.path.join(root, 'images', 'im_%02d.png' % i))
+        Image.fromarray(rng.integers(0, 256, (H, W, 3), dtype=np.uint8)).save(os.path.join(root, 'images_%d' % factor, 'im_%02d.png' % i))
+        # a forward-facing rig: small rotations around a common look direction, LLFF's [-y, x, z] column convention
+        ang = rng.normal(0, 0.08, 3)
+        Rx = np.array([[1, 0, 0], [0, np.cos(ang[0]), -np.sin(ang[0])], [0, np.sin(ang[0]), np.cos(ang[0])]])
+        Ry = np.array([[np.cos(ang[1]), 0, np.sin(ang[1])], [0, 1, 0], [-np.sin(ang[1]), 0, np.cos(ang[1])]])
+        R = Rx @ Ry
+        t = rng.normal(0, 0.4, 3) + [0, 0, 0.1 * i]
+        pose = np.concatenate([R, t[:, None], np.array([[H * factor], [W * factor], [300.0]])], 1)       # [3,5]
+        rows.append(np.concatenate([pose.reshape(-1), [1.2 + rng.uniform(0, 0.3), 9.0 + rng.uniform(0, 3)]]))
+    np.save(os.path.join(root, 'poses_bounds.npy'), np.array(rows))
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, 'xrnerf')), reason='reference tree absent')
+@pytest.mark.parametrize('kw', [dict(recenter=True, bd_factor=.75, spherify=False, path_zflat=False),
+                                dict(recenter=True, bd_factor=.75, spherify=True, path_zflat=False),
+                                dict(recenter=False, bd_factor=None, spherify=False, path_zflat=False)])
+def test_load_llff_data_equals_the_reference(tmp_path, kw):
+    """the reference's own load_llff_data (imageio replaced by PIL: it is absent here) on a forward-facing rig written
+    on the fly, all three pose-normalisation variants"""
+    from PIL import Image
+    from xrnerf_amd.datasets import load_llff_data
+    write_llff_scene(str(tmp_path))
+    imageio = types.ModuleType('imageio'); imageio.imread = lambda f, **k: np.asarray(Image.open(f))
+    saved = sys.modules.get('imageio')
+    sys.modules['imageio'] = imageio
+    try:
+        spec = importlib.util.spec_from_file_location('ref_load_llff', os.path.join(REF, 'xrnerf/datasets/load_data/load_llff.py'))
+        ref = importlib.util.module_from_spec(spec); spec.loader.exec_module(ref)
+        b = ref.load_llff_data(str(tmp_path), factor=4, **kw)
+    finally:
+        if saved is None: sys.modules.pop('imageio', None)
+        else: sys.modules['imageio'] = saved
+    a = load_llff_data(str(tmp_path), factor=4, **kw)
+    assert a[0].shape == b[0].shape == (7, 12, 16, 3) and np.array_equal(a[0], b[0])
+    for k in (1, 2, 3):
+        assert a[k].shape == b[k].shape and a[k].dtype == np.float32
+        assert np.allclose(a[k], b[k], atol=1e-6 * max(1.0, np.abs(b[k]).max())), k
+    assert a[4] == int(b[4])
+    assert a[1][0, 0, 4] == 12 and a[1][0, 1, 4] == 16 and abs(a[1][0, 2, 4] - 75.0) < 1e-6       # hwf column, focal / factor
+
+
+def test_load_llff_data_needs_the_downscaled_folder(tmp_path):
+    from xrnerf_amd.datasets import load_llff_data
+    write_llff_scene(str(tmp_path))
+    with pytest.raises(FileNotFoundError):
+        load_llff_data(str(tmp_path), factor=8)
+    # path_zflat: the reference's branch divides N_views into a float and np.linspace then raises under numpy >= 1.18
+    # (load_llff.py:318-322), so it has no runnable counterpart; here: 60 views, no z excursion around the average pose
+    imgs, poses, bds, render_poses, i_test = load_llff_data(str(tmp_path), factor=4, path_zflat=True)
+    flat = load_llff_data(str(tmp_path), factor=4, path_zflat=False)
+    assert render_poses.shape == (60, 3, 5) and flat[3].shape == (120, 3, 5) and np.array_equal(poses, flat[1])

@@ -185,3 +185,130 @@ class HashNerfDataset(DeviceRayTable):
         if self.mode == 'train':
             return self.rays_rgb.shape[0] // int(self.cfg.get('N_rand_per_sampler', 4096)) * 4
         return 1 if self.mode == 'val' else self.n_render
+
+
+# ------------------------------------------------------------------------------------------ LLFF (forward-facing) scenes
+def _unit(v):
+    return v / np.linalg.norm(v)
+
+
+def _look_at(z, up, pos):
+    """camera frame with optical axis z (viewmatrix, load_llff.py:131-137): columns [x, y, z, pos]"""
+    z = _unit(z)
+    x = _unit(np.cross(up, z))
+    return np.stack([x, _unit(np.cross(z, x)), z, pos], 1)
+
+
+def _average_pose(poses):
+    """poses_avg (load_llff.py:145-155): mean position, summed z / y axes, hwf column of the first pose"""
+    frame = _look_at(poses[:, :3, 2].sum(0), poses[:, :3, 1].sum(0), poses[:, :3, 3].mean(0))
+    return np.concatenate([frame, poses[0, :3, -1:]], 1)
+
+
+def _recenter(poses):
+    """recenter_poses (load_llff.py:174-187): express every pose in the average pose's frame"""
+    out = poses.copy()
+    bottom = np.array([[0, 0, 0, 1.]])
+    avg = np.concatenate([_average_pose(poses)[:3, :4], bottom], 0)
+    full = np.concatenate([poses[:, :3, :4], np.tile(bottom[None], (poses.shape[0], 1, 1))], 1)
+    out[:, :3, :4] = (np.linalg.inv(avg) @ full)[:, :3, :4]
+    return out
+
+
+def _spiral_path(c2w, up, rads, focal, zdelta, zrate, rots, n):
+    """render_path_spiral (load_llff.py:158-171)"""
+    rads = np.array(list(rads) + [1.])
+    hwf = c2w[:, 4:5]
+    out = []
+    for theta in np.linspace(0., 2. * np.pi * rots, n + 1)[:-1]:
+        c = c2w[:3, :4] @ (np.array([np.cos(theta), -np.sin(theta), -np.sin(theta * zrate), 1.]) * rads)
+        z = _unit(c - c2w[:3, :4] @ np.array([0, 0, -focal, 1.]))
+        out.append(np.concatenate([_look_at(z, up, c), hwf], 1))
+    return out
+
+
+def _spherify(poses, bds):
+    """spherify_poses (load_llff.py:193-265): re-centre on the point closest to all optical axes, unit mean radius,
+    circular render path of 120 views"""
+    def to44(p):
+        return np.concatenate([p, np.tile(np.array([[[0, 0, 0, 1.]]]), (p.shape[0], 1, 1))], 1)
+    d, o = poses[:, :3, 2:3], poses[:, :3, 3:4]
+    A = np.eye(3) - d * np.transpose(d, [0, 2, 1])
+    b = -A @ o
+    center = np.squeeze(-np.linalg.inv((np.transpose(A, [0, 2, 1]) @ A).mean(0)) @ b.mean(0))
+    v0 = _unit((poses[:, :3, 3] - center).mean(0))
+    v1 = _unit(np.cross([.1, .2, .3], v0))
+    v2 = _unit(np.cross(v0, v1))
+    c2w = np.stack([v1, v2, v0, center], 1)
+    reset = np.linalg.inv(to44(c2w[None])) @ to44(poses[:, :3, :4])
+    rad = np.sqrt(np.mean(np.sum(np.square(reset[:, :3, 3]), -1)))
+    sc = 1. / rad
+    reset[:, :3, 3] *= sc
+    bds *= sc
+    rad *= sc
+    zh = np.mean(reset[:, :3, 3], 0)[2]
+    radcircle = np.sqrt(rad ** 2 - zh ** 2)
+    new = []
+    for th in np.linspace(0., 2. * np.pi, 120):
+        cam = np.array([radcircle * np.cos(th), radcircle * np.sin(th), zh])
+        z = _unit(cam)
+        x = _unit(np.cross(z, np.array([0, 0, -1.])))
+        new.append(np.stack([x, _unit(np.cross(z, x)), z, cam], 1))
+    new = np.stack(new, 0)
+    hwf = poses[0, :3, -1:]
+    new = np.concatenate([new, np.broadcast_to(hwf, new[:, :3, -1:].shape)], -1)
+    reset = np.concatenate([reset[:, :3, :4], np.broadcast_to(hwf, reset[:, :3, -1:].shape)], -1)
+    return reset, new, bds
+
+
+def load_llff_data(basedir, factor=8, recenter=True, bd_factor=.75, spherify=False, path_zflat=False):
+    """-> images [N,H,W,3] f32, poses [N,3,5] f32 (hwf in the last column), bds [N,2] f32, render_poses f32, i_test
+    Same contract as load_llff_data / _load_data (load_llff.py:67-128,268-349) for scenes whose down-scaled image folder
+    (`images_<factor>`) already exists -- the reference shells out to ImageMagick's `mogrify` to create it otherwise; that
+    is left to the user (no subprocess here)."""
+    arr = np.load(os.path.join(basedir, 'poses_bounds.npy'))
+    poses = arr[:, :-2].reshape([-1, 3, 5]).transpose([1, 2, 0])          # [3,5,N]
+    bds = arr[:, -2:].transpose([1, 0])
+    sfx = '' if factor is None else '_{}'.format(factor)
+    imgdir = os.path.join(basedir, 'images' + sfx)
+    if not os.path.isdir(imgdir):
+        raise FileNotFoundError('%s does not exist: create the down-scaled images first (the reference runs `mogrify '
+                                '-resize %s%%` over a copy of images/)' % (imgdir, 100. / (factor or 1)))
+    files = [os.path.join(imgdir, f) for f in sorted(os.listdir(imgdir)) if f.endswith(('JPG', 'jpg', 'png'))]
+    if poses.shape[-1] != len(files):
+        raise ValueError('Mismatch between imgs {} and poses {}'.format(len(files), poses.shape[-1]))
+    imgs = [_imread(f)[..., :3] / 255. for f in files]
+    sh = imgs[0].shape
+    poses[:2, 4, :] = np.array(sh[:2]).reshape([2, 1])
+    poses[2, 4, :] = poses[2, 4, :] * 1. / (factor or 1)
+    imgs = np.stack(imgs, -1)
+    # [-y, x, z] column order -> [x, y, z] (load_llff.py:280-285), variable axis first
+    poses = np.concatenate([poses[:, 1:2, :], -poses[:, 0:1, :], poses[:, 2:, :]], 1)
+    poses = np.moveaxis(poses, -1, 0).astype(np.float32)
+    images = np.moveaxis(imgs, -1, 0).astype(np.float32)
+    bds = np.moveaxis(bds, -1, 0).astype(np.float32)
+    sc = 1. if bd_factor is None else 1. / (bds.min() * bd_factor)
+    poses[:, :3, 3] *= sc
+    bds *= sc
+    if recenter:
+        poses = _recenter(poses)
+    if spherify:
+        poses, render_poses, bds = _spherify(poses, bds)
+    else:
+        c2w = _average_pose(poses)
+        up = _unit(poses[:, :3, 1].sum(0))
+        close_depth, inf_depth = bds.min() * .9, bds.max() * 5.
+        dt = .75
+        focal = 1. / ((1. - dt) / close_depth + dt / inf_depth)
+        zdelta = close_depth * .2
+        rads = np.percentile(np.abs(poses[:, :3, 3]), 90, 0)
+        n_views, n_rots = 120, 2
+        if path_zflat:
+            c2w[:3, 3] = c2w[:3, 3] + (-close_depth * .1) * c2w[:3, 2]
+            rads[2] = 0.
+            n_rots, n_views = 1, n_views // 2
+        render_poses = _spiral_path(c2w, up, rads, focal, zdelta, zrate=.5, rots=n_rots, n=n_views)
+    render_poses = np.array(render_poses).astype(np.float32)
+    c2w = _average_pose(poses)
+    i_test = int(np.argmin(np.sum(np.square(c2w[:3, 3] - poses[:, :3, 3]), -1)))
+    return images.astype(np.float32), poses.astype(np.float32), bds, render_poses, i_test
