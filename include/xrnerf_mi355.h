@@ -336,6 +336,25 @@ int xr_nerf_render_forward(const float* raw, const float* z_vals, const float* r
                            uint32_t n_samples, int white_bkgd, float* rgb, float* disp, float* acc, float* weights,
                            void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * fp32 linear layers of the 8x256 NeRF MLP (xrnerf/models/mlps/nerf_mlp.py:27-94: nn.Linear + F.relu) on the fp32
+ * MFMA; row-major tensors, w = nn.Linear.weight [N,K].  K and N must be multiples of 4, pointers 16-byte aligned.
+ *   forward:          y [M,N] = act(x [M,K] . w^T + bias)            (bias nullable, relu 0/1)
+ *   backward, input:  dx [M,K] = (dy [M,N] where mask_src > 0) . w    (mask_src nullable: the layer's relu output)
+ *   backward, weight: dw_partials [splits,N,K] = per-M-range partial sums of (dy masked)^T . x; the caller adds them in
+ *                     order (bit-reproducible); splits = xr_linear_backward_weight_splits(M, N, K)
+ *   backward, bias:   db_partials [splits,N] = per-M-range column sums of (dy masked); splits = xr_linear_backward_bias_splits(M) */
+int xr_linear_forward(const float* x, const float* w, const float* bias, uint32_t M, uint32_t N, uint32_t K, int relu,
+                      float* y, void* stream);
+int xr_linear_backward_input(const float* dy, const float* mask_src, const float* w, uint32_t M, uint32_t N, uint32_t K,
+                             float* dx, void* stream);
+uint32_t xr_linear_backward_weight_splits(uint32_t M, uint32_t N, uint32_t K);
+int xr_linear_backward_weight(const float* dy, const float* mask_src, const float* x, uint32_t M, uint32_t N, uint32_t K,
+                              uint32_t splits, float* dw_partials, void* stream);
+uint32_t xr_linear_backward_bias_splits(uint32_t M);
+int xr_linear_backward_bias(const float* dy, const float* mask_src, uint32_t M, uint32_t N, uint32_t splits,
+                            float* db_partials, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,109 @@
+"""fp32-MFMA linear layers (xr_linear_*) against fp64 matmuls of the same operands: forward with bias / relu, input
+gradient and weight gradient with the relu mask, ragged M / N / K (partial tiles, multi-split weight gradient), and the
+autograd node against torch's own linear + relu."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('M,N,K', [(1000, 256, 96), (4096, 256, 352), (333, 128, 256), (70000, 256, 256), (5, 4, 8), (129, 132, 36)])
+def test_kernels_against_fp64(dev, M, N, K):
+    from xrnerf_amd import ops
+    g = torch.Generator(device='cpu').manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    dy = torch.randn(M, N, generator=g)
+    xd, wd, bd, dyd = x.to(dev), w.to(dev), b.to(dev), dy.to(dev)
+    ref = x.double() @ w.double().t() + b.double()
+    y = ops.linear_forward(xd, wd, bd, False).cpu()
+    assert (y.double() - ref).abs().max() <= 2e-5 * max(1.0, float(ref.abs().max()))
+    yr = ops.linear_forward(xd, wd, bd, True)
+    assert (yr.cpu().double() - ref.clamp_min(0)).abs().max() <= 2e-5 * max(1.0, float(ref.abs().max()))
+    assert (ops.linear_forward(xd, wd, None, False).cpu().double() - (ref - b.double())).abs().max() <= 2e-5 * max(1.0, float(ref.abs().max()))
+    dym = dy.double() * (ref > 0)
+    # mask from the kernel's own relu output (elements within rounding of 0 may differ from the fp64 sign: exclude them)
+    safe = (ref.abs() > 1e-4)
+    dym_k = dy.double() * (yr.cpu() > 0)
+    dx = ops.linear_backward_input(dyd, yr, wd).cpu().double()
+    assert (dx - dym_k @ w.double()).abs().max() <= 5e-5 * max(1.0, float((dym_k @ w.double()).abs().max()))
+    dw = ops.linear_backward_weight(dyd, yr, xd).cpu().double()
+    rw = dym_k.t() @ x.double()
+    assert (dw - rw).abs().max() <= 5e-5 * max(1.0, float(rw.abs().max()))
+    assert ((yr.cpu() > 0) == (ref > 0))[safe].all()
+    db = ops.linear_backward_bias(dyd, yr).cpu().double()
+    assert (db - dym_k.sum(0)).abs().max() <= 5e-5 * max(1.0, float(dym_k.sum(0).abs().max()))
+    assert (ops.linear_backward_bias(dyd, None).cpu().double() - dy.double().sum(0)).abs().max() <= 5e-5 * max(1.0, float(dy.double().sum(0).abs().max()))
+    # no mask
+    dx0 = ops.linear_backward_input(dyd, None, wd).cpu().double()
+    assert (dx0 - dy.double() @ w.double()).abs().max() <= 5e-5 * max(1.0, float((dy.double() @ w.double()).abs().max()))
+
+
+def test_autograd_node_equals_torch_linear(dev):
+    from xrnerf_amd.linear import linear_act
+    torch.manual_seed(0)
+    x = torch.randn(3000, 352, device=dev, requires_grad=True)
+    w = (torch.randn(256, 352, device=dev) / 18).requires_grad_(True)
+    b = torch.randn(256, device=dev, requires_grad=True)
+    g = torch.randn(3000, 256, device=dev)
+    y = linear_act(x, w, b, True)
+    y.backward(g)
+    got = [t.grad.clone() for t in (x, w, b)]
+    for t in (x, w, b):
+        t.grad = None
+    y2 = torch.relu(torch.nn.functional.linear(x, w, b))
+    y2.backward(g)
+    assert (y - y2).abs().max() <= 1e-4
+    for a, r in zip(got, (x.grad, w.grad, b.grad)):
+        assert (a - r).abs().max() <= 1e-4 * max(1.0, float(r.abs().max()))
+    # shapes the kernel does not take fall through to torch (283-wide view layer, 3-wide head)
+    x2 = torch.randn(100, 283, device=dev)
+    w2 = torch.randn(128, 283, device=dev)
+    assert torch.equal(linear_act(x2, w2, None, True), torch.relu(torch.nn.functional.linear(x2, w2)))
+
+
+def test_vanilla_nerf_config1_on_the_device_equals_the_host_path(dev):
+    """BASELINE config #1's model dict (8x256 MLPs, 64 coarse + 128 fine samples): the device path (fp32-MFMA linear
+    layers incl. the padded narrow heads and the shared alpha/feature product, fused NerfRender at inference) against the
+    pure-PyTorch host path with the same weights -- test-mode outputs and one training step's loss and gradients"""
+    import copy
+    import json
+    import os
+    import xrnerf_amd
+    from xrnerf_amd import vanilla
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    cfg = json.load(open(os.path.join(G, 'ngp_model_cfg.json')))['vanilla_model']
+    torch.manual_seed(0)
+    host = xrnerf_amd.build_network(cfg)
+    device = copy.deepcopy(host).to(dev)
+    n = 512
+    rays_o = torch.tensor([[0., 0., 4.]]).repeat(n, 1) + torch.randn(n, 3) * 0.05
+    rays_d = torch.nn.functional.normalize(torch.randn(n, 3) * 0.15 - torch.tensor([0., 0., 1.]), dim=-1)
+    z = vanilla.get_z_vals(rays_o, 2., 6., 64)
+    tgt = torch.rand(n, 3)
+
+    def data(d):
+        return {'rays_o': rays_o.to(d), 'rays_d': rays_d.to(d), 'viewdirs': rays_d.to(d), 'z_vals': z.to(d),
+                'pts': vanilla.get_pts(rays_o, rays_d, z).to(d)}
+    with torch.no_grad():
+        a, b = host.forward(data('cpu'), is_test=True), device.forward(data(dev), is_test=True)
+    for k in ('rgb', 'coarse_rgb', 'acc', 'coarse_acc'):
+        assert (a[k] - b[k].cpu()).abs().max() <= 1e-4, k
+    host.is_perturb = device.is_perturb = False                      # hierarchical sampling without random draws
+    outs = []
+    for net, d in ((host, 'cpu'), (device, dev)):
+        batch = {k: v[None] for k, v in data(d).items()}
+        batch['target_s'] = tgt.to(d)[None]
+        out = net.train_step(batch, None)
+        out['loss'].backward()
+        outs.append(float(out['loss']))
+    assert abs(outs[0] - outs[1]) <= 1e-5 * max(1.0, abs(outs[0]))
+    hp, dp = dict(host.named_parameters()), dict(device.named_parameters())
+    for name in ('mlp.pts_linears.0.weight', 'mlp.pts_linears.5.weight', 'mlp.alpha_linear.weight', 'mlp.alpha_linear.bias',
+                 'mlp.views_linears.0.weight', 'mlp.rgb_linear.weight', 'mlp.rgb_linear.bias', 'mlp_fine.feature_linear.weight',
+                 'mlp_fine.pts_linears.7.bias'):
+        r, g = hp[name].grad, dp[name].grad.cpu()
+        # bias / weight gradients are sums of ~1e5 signed terms: the summation order shows at the 1e-6 level
+        assert (r - g).abs().max() <= 1e-3 * float(r.abs().max()) + 3e-6, name

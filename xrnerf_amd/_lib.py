@@ -63,6 +63,12 @@ SIGNATURES = {
     'xr_kilo_mlp_forward': (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32,
                                    _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     'xr_nerf_render_forward': (_i32, [_vp, _vp, _vp, _u32, _u32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'xr_linear_forward': (_i32, [_vp, _vp, _vp, _u32, _u32, _u32, _i32, _vp, _vp]),
+    'xr_linear_backward_input': (_i32, [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp]),
+    'xr_linear_backward_weight_splits': (_u32, [_u32, _u32, _u32]),
+    'xr_linear_backward_bias_splits': (_u32, [_u32]),
+    'xr_linear_backward_bias': (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp]),
+    'xr_linear_backward_weight': (_i32, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp]),
     'xr_kilo_render_workspace_bytes': (_sz, [_u32, _u32, _u32]),
     'xr_kilo_render_rays': (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32,
                                    _u32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -28,6 +28,7 @@ SOURCES = {
     # KiloNeRF: sample positions o + d*z and the cell index arithmetic must round like the reference's tensor ops
     # (the MLP's FMAs are explicit fmaf calls)
     'xr_kilo.hip': ['-ffp-contract=off'],
+    'xr_gemm.hip': [],
 }
 
 

@@ -1,0 +1,240 @@
+// fp32 linear layers of the 8x256 NeRF MLP (configs #1 and #3: xrnerf/models/mlps/nerf_mlp.py:27-94) on the fp32 MFMA.
+//
+// The reference runs them as nn.Linear; on MI355X that dispatches to hipBLASLt, which reaches 29 TFLOP/s on the shapes
+// of this MLP (M = 32768..131072 samples, N = K = 256: `profiles/r01_mip_step_kernel_stats.csv`, 146 us per
+// 32768x256x256) -- 18 % of the 157.3 TFLOP/s fp32 MFMA peak -- plus separate bias-gradient reductions and relu passes.
+// One LDS-tiled kernel covers the three products of a layer:
+//   forward          y  = act(x w^T + b)        C[M,N]  = A[M,K] . B[N,K]^T        (A row-major, B row-major = nn.Linear.weight)
+//   backward, input  dx = dy w                  C[M,K'] = A[M,N'] . B[N',K']       (B already [contraction, output])
+//   backward, weight dw = dy^T x                C[N',K'] = A[M,N']^T . B[M,K']     (both operands [contraction, output]; split over M)
+// Workgroup = 128 x 128 output tile, 4 waves in 2 x 2, each 64 x 64 = 2 x 2 accumulators of v_mfma_f32_32x32x2_f32
+// (exact fp32, an fmaf chain); operands staged through LDS as [k][m] / [k][n] panels of 32 k (32 KB), the next panel's
+// global loads in flight while the current one is multiplied.  Bias, relu and the relu mask of the incoming gradient are
+// fused into the epilogue / the A-panel load.
+#include "xr_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define GMFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+#define GBM 128
+#define GBN 128
+#ifndef GBK
+#define GBK 16                                   // k per panel (multiple of 8); 2 x 2 x GBK x 128 x 4 B of LDS per workgroup
+#endif
+#define GNJ (GBK / 8)                             // float4 per thread and panel
+#define GPAD 0                                   // [k][row] panels are read and written along `row`: no padding needed (4 x 16 KB = 64 KB of LDS)
+
+struct GemmArgs {
+    const float* A; const float* B; float* C;
+    const float* bias;                           // nullable [Nc]
+    const float* mask_src;                       // nullable, same shape / layout as A: A element counts only where mask_src > 0
+    uint32_t Mc, Nc, Kc;                         // C is [Mc, Nc], contraction length Kc
+    uint32_t lda, ldb, ldc;
+    int a_km, b_kn;                              // A stored [Kc, Mc] (else [Mc, Kc]); B stored [Kc, Nc] (else [Nc, Kc])
+    int relu;
+    uint32_t k_per_split;                        // contraction range of blockIdx.z; C of split z at C + z * c_split_stride
+    size_t c_split_stride;
+};
+
+// one 128 x GBK panel of an operand into registers: GNJ float4 per thread.
+//   row-major [rows, k] source (km == 0): thread -> row (t & 127), GBK/2 consecutive k starting at (t >> 7) * GBK/2
+//   [k, rows] source        (km == 1): thread -> k = (t >> 5) + 8 j, 4 consecutive rows at (t & 31) * 4
+__device__ __forceinline__ void panel_load(const float* __restrict__ P, const float* __restrict__ mask, uint32_t ld, int km,
+                                           uint32_t row0, uint32_t rows, uint32_t k0, uint32_t k_end, float4 (&v)[GNJ]) {
+    const uint32_t t = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < GNJ; ++j) {
+        uint32_t r, k;
+        bool ok;
+        size_t off;
+        if (!km) { r = row0 + (t & 127); k = k0 + (t >> 7) * (GBK / 2) + 4 * j; ok = r < rows && k < k_end; off = (size_t)r * ld + k; }
+        else { k = k0 + (t >> 5) + 8 * j; r = row0 + (t & 31) * 4; ok = r < rows && k < k_end; off = (size_t)k * ld + r; }
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) {
+            x = *reinterpret_cast<const float4*>(P + off);
+            if (mask != nullptr) {
+                const float4 m = *reinterpret_cast<const float4*>(mask + off);
+                x.x = m.x > 0.f ? x.x : 0.f; x.y = m.y > 0.f ? x.y : 0.f; x.z = m.z > 0.f ? x.z : 0.f; x.w = m.w > 0.f ? x.w : 0.f;
+            }
+        }
+        v[j] = x;
+    }
+}
+
+// registers -> LDS panel S[k][row] (row stride GBM + GPAD)
+__device__ __forceinline__ void panel_store(float* __restrict__ S, int km, const float4 (&v)[GNJ]) {
+    const uint32_t t = threadIdx.x;
+    constexpr int ST = GBM + GPAD;
+#pragma unroll
+    for (int j = 0; j < GNJ; ++j) {
+        if (!km) {
+            const uint32_t r = t & 127, k = (t >> 7) * (GBK / 2) + 4 * j;
+            S[(k + 0) * ST + r] = v[j].x; S[(k + 1) * ST + r] = v[j].y; S[(k + 2) * ST + r] = v[j].z; S[(k + 3) * ST + r] = v[j].w;
+        } else {
+            const uint32_t k = (t >> 5) + 8 * j, r = (t & 31) * 4;
+            *reinterpret_cast<float4*>(S + k * ST + r) = v[j];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g) {
+    constexpr int ST = GBM + GPAD;
+    __shared__ float sA[2][GBK * ST];
+    __shared__ float sB[2][GBK * ST];
+    // column tiles vary fastest: the workgroups that share an A row-panel run next to each other (L2 reuse of A)
+    const uint32_t m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+    const uint32_t k_begin = blockIdx.z * g.k_per_split;
+    const uint32_t k_end = k_begin + g.k_per_split < g.Kc ? k_begin + g.k_per_split : g.Kc;
+    const int lane = threadIdx.x & 63, col = lane & 31, hi = lane >> 5;
+    const int wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float4 ra[GNJ], rb[GNJ];
+    if (k_begin < k_end) {
+        panel_load(g.A, g.mask_src, g.lda, g.a_km, m0, g.Mc, k_begin, k_end, ra);
+        panel_load(g.B, nullptr, g.ldb, g.b_kn, n0, g.Nc, k_begin, k_end, rb);
+    }
+    int buf = 0;
+    for (uint32_t k0 = k_begin; k0 < k_end; k0 += GBK) {
+        panel_store(sA[buf], g.a_km, ra);
+        panel_store(sB[buf], g.b_kn, rb);
+        __syncthreads();                                   // panel `buf` complete; the other buffer was consumed one step ago
+        if (k0 + GBK < k_end) {
+            panel_load(g.A, g.mask_src, g.lda, g.a_km, m0, g.Mc, k0 + GBK, k_end, ra);
+            panel_load(g.B, nullptr, g.ldb, g.b_kn, n0, g.Nc, k0 + GBK, k_end, rb);
+        }
+        const float* pa = sA[buf] + hi * ST + wm * 64 + col;
+        const float* pb = sB[buf] + hi * ST + wn * 64 + col;
+#pragma unroll
+        for (int s = 0; s < GBK / 2; ++s) {
+            const float a0 = pa[2 * s * ST], a1 = pa[2 * s * ST + 32];
+            const float b0 = pb[2 * s * ST], b1 = pb[2 * s * ST + 32];
+            acc[0][0] = GMFMA(a0, b0, acc[0][0]);
+            acc[0][1] = GMFMA(a0, b1, acc[0][1]);
+            acc[1][0] = GMFMA(a1, b0, acc[1][0]);
+            acc[1][1] = GMFMA(a1, b1, acc[1][1]);
+        }
+        buf ^= 1;
+    }
+    // epilogue: lane l, register r of a 32x32 accumulator holds row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31
+    float* C = g.C + (size_t)blockIdx.z * g.c_split_stride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t n = n0 + wn * 64 + j * 32 + col;
+            if (n >= g.Nc) continue;
+            const float b = g.bias != nullptr ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (m < g.Mc) {
+                    float v = acc[i][j][r] + b;
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    C[(size_t)m * g.ldc + n] = v;
+                }
+            }
+        }
+}
+
+static int gemm_launch(GemmArgs g, uint32_t splits, void* stream) {
+    XR_REQUIRE(g.A && g.B && g.C, "null pointer");
+    XR_REQUIRE(g.lda % 4 == 0 && g.ldb % 4 == 0, "leading dimensions must be multiples of 4 floats (16-byte vector loads)");
+    XR_REQUIRE(((uintptr_t)g.A & 15) == 0 && ((uintptr_t)g.B & 15) == 0 && (g.mask_src == nullptr || ((uintptr_t)g.mask_src & 15) == 0),
+               "operands must be 16-byte aligned");
+    XR_REQUIRE((g.a_km ? g.Mc : g.Kc) % 4 == 0 && (g.b_kn ? g.Nc : g.Kc) % 4 == 0, "the contiguous dimension of each operand must be a multiple of 4");
+    if (g.Mc == 0 || g.Nc == 0) return XR_OK;
+    XR_REQUIRE(splits >= 1 && splits <= 65535, "bad split count");
+    g.k_per_split = (uint32_t)(((uint64_t)(g.Kc + splits - 1) / splits + GBK - 1) / GBK * GBK);
+    if (g.k_per_split == 0) g.k_per_split = GBK;
+    const dim3 grid(xr_div_up(g.Nc, GBN), xr_div_up(g.Mc, GBM), splits);
+    XR_REQUIRE(grid.y <= 65535, "more than 65535 row tiles (8.3 M rows) in one call");
+    hipLaunchKernelGGL(k_gemm_f32, grid, dim3(256), 0, (hipStream_t)stream, g);
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}
+
+// y [M,N] = act(x [M,K] . w [N,K]^T + bias [N])
+extern "C" int xr_linear_forward(const float* x, const float* w, const float* bias, uint32_t M, uint32_t N, uint32_t K,
+                                 int relu, float* y, void* stream) {
+    GemmArgs g{x, w, y, bias, nullptr, M, N, K, K, K, N, 0, 0, relu, 0, 0};
+    return gemm_launch(g, 1, stream);
+}
+
+// dx [M,K] = (dy [M,N] masked by mask_src [M,N] > 0 when given) . w [N,K]
+extern "C" int xr_linear_backward_input(const float* dy, const float* mask_src, const float* w, uint32_t M, uint32_t N,
+                                        uint32_t K, float* dx, void* stream) {
+    GemmArgs g{dy, w, dx, nullptr, mask_src, M, K, N, N, K, K, 0, 1, 0, 0, 0};
+    return gemm_launch(g, 1, stream);
+}
+
+// dw_partials [splits, N, K]: partial sums of (dy masked)^T . x over `splits` ranges of the M rows; the caller adds
+// the partials (fixed order => bit-reproducible).  splits = xr_linear_backward_weight_splits(M).
+extern "C" uint32_t xr_linear_backward_weight_splits(uint32_t M, uint32_t N, uint32_t K) {
+    // the output is only ceil(N/128) x ceil(K/128) tiles (4 for a 256 x 256 layer): split the M rows until ~1024
+    // workgroups exist, but keep >= 8 k-panels (256 rows) per split (measured: 16 splits of 2048 rows = 64 workgroups
+    // left 3/4 of the chip idle, 110-290 us per 32768-row call)
+    const uint32_t tiles = xr_div_up(N, GBM) * xr_div_up(K, GBN);
+    uint32_t s = 1024 / (tiles ? tiles : 1);
+    const uint32_t by_rows = M / 256;
+    if (s > by_rows) s = by_rows;
+    return s < 1 ? 1 : (s > 4096 ? 4096 : s);
+}
+// db partials [splits, N]: column sums of (dy where mask_src > 0) over `splits` ranges of the M rows.
+// thread = 4 consecutive columns, workgroup = 64 column groups x 4 row phases; 16-byte loads, coalesced along N.
+__global__ void __launch_bounds__(256) k_masked_colsum(const float* __restrict__ dy, const float* __restrict__ mask,
+                                                       uint32_t M, uint32_t N, uint32_t rows_per_split,
+                                                       float* __restrict__ out) {
+    __shared__ float4 s_part[256];
+    const uint32_t cg = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+    const uint32_t r0 = blockIdx.y * rows_per_split;
+    const uint32_t r1 = r0 + rows_per_split < M ? r0 + rows_per_split : M;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cg * 4 < N) {
+        for (uint32_t r = r0 + ph; r < r1; r += 4) {
+            const size_t off = (size_t)r * N + cg * 4;
+            float4 v = *reinterpret_cast<const float4*>(dy + off);
+            if (mask != nullptr) {
+                const float4 m = *reinterpret_cast<const float4*>(mask + off);
+                v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+            }
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    s_part[threadIdx.x] = acc;
+    __syncthreads();
+    if (ph == 0 && cg * 4 < N) {
+        float4 t = s_part[threadIdx.x];
+        for (int p = 1; p < 4; ++p) { const float4 o = s_part[threadIdx.x + 64 * p]; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+        *reinterpret_cast<float4*>(out + (size_t)blockIdx.y * N + cg * 4) = t;
+    }
+}
+
+extern "C" uint32_t xr_linear_backward_bias_splits(uint32_t M) {
+    uint32_t s = M / 128;
+    return s < 1 ? 1 : (s > 512 ? 512 : s);
+}
+extern "C" int xr_linear_backward_bias(const float* dy, const float* mask_src, uint32_t M, uint32_t N, uint32_t splits,
+                                       float* db_partials, void* stream) {
+    XR_REQUIRE(dy && db_partials, "null pointer");
+    XR_REQUIRE(N % 4 == 0 && splits >= 1 && splits <= 65535, "N must be a multiple of 4; bad split count");
+    XR_REQUIRE(((uintptr_t)dy & 15) == 0 && ((uintptr_t)db_partials & 15) == 0 && (mask_src == nullptr || ((uintptr_t)mask_src & 15) == 0),
+               "operands must be 16-byte aligned");
+    if (N == 0) return XR_OK;
+    const uint32_t rows = (M + splits - 1) / splits;
+    hipLaunchKernelGGL(k_masked_colsum, dim3(xr_div_up(N / 4, 64), splits), dim3(256), 0, (hipStream_t)stream, dy, mask_src, M,
+                       N, rows ? rows : 1, db_partials);
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}
+
+extern "C" int xr_linear_backward_weight(const float* dy, const float* mask_src, const float* x, uint32_t M, uint32_t N,
+                                         uint32_t K, uint32_t splits, float* dw_partials, void* stream) {
+    GemmArgs g{dy, x, dw_partials, nullptr, mask_src, N, K, M, N, K, K, 1, 1, 0, 0, (size_t)N * K};
+    return gemm_launch(g, splits, stream);
+}

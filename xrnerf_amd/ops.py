@@ -645,3 +645,59 @@ def kilo_render_rays(rays_o, rays_d, viewdirs, near, far, n_samples, gmin, gmax,
                                          int(bool(white_bkgd)), _ptr(rgb), _ptr(disp), _ptr(acc), _ptr(ws), ws.numel(),
                                          _stream()), 'xr_kilo_render_rays')
     return rgb, disp, acc
+
+
+# ---------------------------------------------------------------- fp32 MFMA linear layers (8x256 NeRF MLP)
+def linear_ok(x, w):
+    """shapes / alignment the MFMA kernel takes: fp32 device tensors, K and N multiples of 4"""
+    return (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.dim() == 2
+            and x.shape[1] % 4 == 0 and w.shape[0] % 4 == 0 and x.shape[0] > 0)
+
+
+def linear_forward(x, w, bias, relu):
+    """y [M,N] = act(x [M,K] . w [N,K]^T + bias)"""
+    x, w = _f32c(x), _f32c(w)
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    with _span('xr_linear_forward', M):
+        _lib.check(_lib.load().xr_linear_forward(_ptr(x), _ptr(w), _ptr(_f32c(bias)) if bias is not None else None, M, N, K,
+                                                 int(bool(relu)), _ptr(y), _stream()), 'xr_linear_forward')
+    return y
+
+
+def linear_backward_input(dy, mask_src, w):
+    """dx [M,K] = (dy where mask_src > 0) . w"""
+    dy, w = _f32c(dy), _f32c(w)
+    M, N = dy.shape
+    K = w.shape[1]
+    dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
+    with _span('xr_linear_backward_input', M):
+        _lib.check(_lib.load().xr_linear_backward_input(_ptr(dy), _ptr(mask_src), _ptr(w), M, N, K, _ptr(dx), _stream()),
+                   'xr_linear_backward_input')
+    return dx
+
+
+def linear_backward_weight(dy, mask_src, x):
+    """dw [N,K] = (dy where mask_src > 0)^T . x   (fixed-order sum of the per-M-range partials)"""
+    L = _lib.load()
+    dy, x = _f32c(dy), _f32c(x)
+    M, N = dy.shape
+    K = x.shape[1]
+    splits = int(L.xr_linear_backward_weight_splits(M, N, K))
+    part = torch.empty((splits, N, K), dtype=torch.float32, device=dy.device)
+    with _span('xr_linear_backward_weight', M):
+        _lib.check(L.xr_linear_backward_weight(_ptr(dy), _ptr(mask_src), _ptr(x), M, N, K, splits, _ptr(part), _stream()),
+                   'xr_linear_backward_weight')
+    return part[0] if splits == 1 else part.sum(0)
+
+
+def linear_backward_bias(dy, mask_src):
+    """db [N] = column sums of (dy where mask_src > 0)   (fixed-order sum of the per-M-range partials)"""
+    L = _lib.load()
+    dy = _f32c(dy)
+    M, N = dy.shape
+    splits = int(L.xr_linear_backward_bias_splits(M))
+    part = torch.empty((splits, N), dtype=torch.float32, device=dy.device)
+    _lib.check(L.xr_linear_backward_bias(_ptr(dy), _ptr(mask_src), M, N, splits, _ptr(part), _stream()), 'xr_linear_backward_bias')
+    return part[0] if splits == 1 else part.sum(0)

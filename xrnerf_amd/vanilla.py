@@ -86,21 +86,39 @@ class NerfMLP(nn.Module):
 
     def run_mlp(self, x):
         x_pts, x_dir = torch.split(x, [self.input_ch, self.input_ch_dirs], dim=-1)
+        if x.is_cuda:
+            # device: linear + bias + relu (and their gradients) on the fp32-MFMA kernels (xrnerf_amd/linear.py); same
+            # maths, summation order aside.  alpha and feature heads share one product (rows of one weight matrix).
+            from .linear import linear_act_padded as lin
+            x_pts = x_pts.contiguous()
+        else:
+            def lin(t, w, b, relu=False):
+                y = F.linear(t, w, b)
+                return F.relu(y) if relu else y
         h = x_pts
         for i, layer in enumerate(self.pts_linears):
-            h = F.relu(layer(h))
+            h = lin(h, layer.weight, layer.bias, True)
             if i in self.skips:
                 h = torch.cat([x_pts, h], -1)
         if not self.use_viewdirs:
-            return self.output_linear(h)
-        alpha = self.alpha_linear(h)
-        h = torch.cat([self.feature_linear(h), x_dir], -1)
+            return lin(h, self.output_linear.weight, self.output_linear.bias)
+        if x.is_cuda:
+            W = self.feature_linear.weight.shape[0]
+            both = lin(h, torch.cat([self.feature_linear.weight, self.alpha_linear.weight], 0),
+                       torch.cat([self.feature_linear.bias, self.alpha_linear.bias], 0))
+            feature, alpha = both[:, :W], both[:, W:W + 1]
+        else:
+            alpha = self.alpha_linear(h)
+            feature = self.feature_linear(h)
+        h = torch.cat([feature, x_dir], -1)
         for layer in self.views_linears:
-            h = F.relu(layer(h))
-        return torch.cat([self.rgb_linear(h), alpha], -1)
+            h = lin(h, layer.weight, layer.bias, True)
+        return torch.cat([lin(h, self.rgb_linear.weight, self.rgb_linear.bias), alpha], -1)
 
     def batchify_run_mlp(self, x):
-        if self.chunk is None:
+        # netchunk only bounds the reference's activation memory; on the device the whole batch goes through in one piece
+        # (same rows, same maths; 288 GB of HBM, and the GEMM tiles fill the chip better)
+        if self.chunk is None or x.is_cuda:
             return self.run_mlp(x)
         return torch.cat([self.run_mlp(x[i:i + self.chunk]) for i in range(0, x.shape[0], self.chunk)], 0)
 
