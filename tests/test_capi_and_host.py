@@ -172,3 +172,41 @@ def test_two_process_gloo_allreduce_and_gather(tmp_path):
     outs = [p.communicate(timeout=120)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all('ok' in o for o in outs)
+
+
+def test_product_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under xrnerf_amd/ may import, load or execute it (only tests/, the smoke
+    check and bench.py's cpu_baseline legs do), and every ops entry point refuses host tensors instead of falling back"""
+    import ast
+    pkg = os.path.join(ROOT, 'xrnerf_amd')
+    offenders = []
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            path = os.path.join(dirpath, f)
+            if f.endswith('.py'):
+                tree = ast.parse(open(path).read())
+                docstrings = {id(n.body[0].value) for n in ast.walk(tree)
+                              if isinstance(n, (ast.Module, ast.FunctionDef, ast.ClassDef)) and n.body
+                              and isinstance(n.body[0], ast.Expr) and isinstance(n.body[0].value, ast.Constant)}
+                for n in ast.walk(tree):
+                    names = []
+                    if isinstance(n, ast.Import):
+                        names = [a.name for a in n.names]
+                    elif isinstance(n, ast.ImportFrom):
+                        names = [n.module or ''] + [a.name for a in n.names]
+                    elif isinstance(n, ast.Constant) and isinstance(n.value, str) and id(n) not in docstrings:
+                        names = [n.value] if ('oracle' in n.value and len(n.value) < 80) else []
+                    offenders += ['%s:%d: %s' % (f, n.lineno, x) for x in names if 'oracle' in x]
+            elif f.endswith(('.hip', '.h')):
+                for ln, line in enumerate(open(path, errors='replace'), 1):
+                    if line.lstrip().startswith('#include') and 'oracle' in line:
+                        offenders.append('%s:%d: %s' % (f, ln, line.strip()))
+    assert not offenders, offenders
+    import torch
+    from xrnerf_amd import _lib, ops
+    for call in (lambda: ops.hashgrid_fwd(torch.zeros(10), torch.zeros(4, 3), ops.GridMeta()),
+                 lambda: ops.mip_zvals(torch.zeros(4), torch.ones(4), 9),
+                 lambda: ops.nerf_render_forward(torch.zeros(2, 4, 4), torch.zeros(2, 4), torch.ones(2, 3), True),
+                 lambda: ops.linear_forward(torch.zeros(8, 8), torch.zeros(8, 8), None, False)):
+        with pytest.raises(_lib.XrError):
+            call()
