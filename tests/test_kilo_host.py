@@ -43,7 +43,7 @@ def test_reference_config5_builds(tmp_path):
     assert {'mlp.multi_network.pts_linears.0.weight', 'mlp.multi_network.direction_layer.bias',
             'mlp.multi_network.rgb_linear.weight', 'mlp.multi_network.alpha_linear.bias'} <= keys
     assert len(net.mlp.get_view_dependent_parameters()) == 4
-    # a reference-style pickled checkpoint (no state_dict) is refused with an explanation, not mis-read
+    # a checkpoint without the multi network's state is refused with an explanation, not mis-read
     torch.save({'root_nodes': []}, tmp_path / 'pickle.pth')
     model['mlp']['distilled_checkpoint'] = str(tmp_path / 'pickle.pth')
     with pytest.raises(NotImplementedError):
@@ -81,3 +81,49 @@ def test_no_cpu_fallback_and_exports():
     data = {'pts': torch.zeros(4, 8, 3), 'viewdirs': torch.ones(4, 3), 'global_domain_min': gmin, 'global_domain_max': gmax}
     with pytest.raises(_lib.XrError):
         mlp(data)
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/xrnerf'), reason='needs the reference classes to write its checkpoint format')
+def test_reference_pickled_distillation_checkpoint_is_read_without_the_reference_package(tmp_path):
+    """a checkpoint written with the reference's OWN classes (Node tree with inner nodes, single-network MultiNetwork
+    leaves, exactly what SaveDistillResultsHook stores) -> load_reference_distilled_checkpoint in a process state where
+    those classes are not used for unpickling; merged weights = KiloNerfMLP.init_mlp's layout (kilonerf_mlp.py:46-127)"""
+    import importlib
+    import sys
+    import types
+    sys.path.insert(0, G)
+    import ref_import
+    ns = ref_import.load_kilo()
+    if 'xrnerf.utils' not in sys.modules:
+        m = types.ModuleType('xrnerf.utils'); m.__path__ = ['/root/reference/xrnerf/utils']; sys.modules['xrnerf.utils'] = m
+    Node = importlib.import_module('xrnerf.utils.data_helper').Node
+    torch.manual_seed(11)
+
+    def leaf(lo, hi):
+        n = Node(); n.domain_min, n.domain_max = lo, hi
+        n.network = ns.MultiNetwork(1, 63, 27, 4, 32, 2, None, True, 32, 'relu', linear_implementation='bmm')
+        return n
+    a, b, c, d = leaf([0., 0, 0], [1., 1, 1]), leaf([1., 0, 0], [2., 1, 1]), leaf([0., 1, 0], [1., 2, 1]), leaf([1., 1, 0], [2., 2, 1])
+    inner = Node(); inner.leq_child, inner.gt_child = c, d           # visited after the roots: order a, b, c, d
+    path = str(tmp_path / 'distill.pth')
+    torch.save({'root_nodes': [a, inner, b]}, path)
+    from xrnerf_amd import kilo
+    cp = kilo.load_reference_distilled_checkpoint(path)
+    order = [a, b, c, d]
+    assert cp['num_hidden_layers'] == 2
+    assert np.array_equal(cp['domain_mins'].numpy(), np.float32([n.domain_min for n in order]))
+    assert np.array_equal(cp['domain_maxs'].numpy(), np.float32([n.domain_max for n in order]))
+    for i, n in enumerate(order):
+        mods = dict(n.network.named_modules())
+        for name in ('pts_linears.0', 'pts_linears.1', 'alpha_linear', 'feature_linear', 'direction_layer', 'rgb_linear'):
+            assert torch.equal(cp['state_dict'][name + '.weight'][i], mods[name].weight.detach()[0].t())
+            assert torch.equal(cp['state_dict'][name + '.bias'][i], mods[name].bias.detach()[0])
+    # and through the registry class with the reference's constructor arguments
+    torch.save(torch.ones(32 * 32 * 16, dtype=torch.bool), tmp_path / 'occupancy.pth')
+    emb = dict(type='KiloNerfFourierEmbedder', num_networks=1, input_ch=3, multires=10, multires_dirs=4)
+    with pytest.raises(NotImplementedError):
+        kilo.KiloNerfMLP(resolution=[32, 32, 16], occupancy_checkpoint=str(tmp_path / 'occupancy.pth'), distilled_checkpoint=path, embedder=emb)
+    mlp = kilo.KiloNerfMLP(resolution=[32, 32, 16], occupancy_checkpoint=str(tmp_path / 'occupancy.pth'), distilled_checkpoint=path,
+                           embedder=emb, trust_pickle=True)
+    assert mlp.multi_network.num_networks == 4 and mlp.multi_network.packed().shape == (4, 6248)
+    assert torch.equal(mlp.multi_network.rgb_linear.weight[2], dict(c.network.named_modules())['rgb_linear'].weight.detach()[0].t())

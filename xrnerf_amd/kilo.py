@@ -100,24 +100,91 @@ class MultiNetwork(nn.Module):
         return self._packed
 
 
+def load_reference_distilled_checkpoint(path):
+    """The reference's distillation checkpoint ({'root_nodes': [Node, ...]}, written by SaveDistillResultsHook,
+    core/hooks/save_distill_results_hook.py:380-420) pickles its own classes (xrnerf.utils.data_helper.Node, each leaf
+    holding a single-network xrnerf.models.mlps.multi_modules.MultiNetwork).  This reads it WITHOUT that package: every
+    `xrnerf.*` class is unpickled as an attribute bag, the tree is walked exactly like KiloNerfMLP.init_mlp
+    (kilonerf_mlp.py:46-66: breadth-first, leq_child before gt_child) and the leaves' weights are merged into the
+    `multimatmul` layout [N, in, out] (:104-121).  -> dict(domain_mins, domain_maxs, state_dict, num_hidden_layers).
+    Like torch.load without weights_only this executes a pickle: only for checkpoints you trust."""
+    import pickle
+    import types
+
+    class _Bag:
+        pass
+
+    bags = {}
+
+    class _Unpickler(pickle.Unpickler):
+        def find_class(self, module, name):
+            if module == 'xrnerf' or module.startswith('xrnerf.'):
+                return bags.setdefault((module, name), type(name, (_Bag,), {'__module__': module}))
+            return super().find_class(module, name)
+
+    shim = types.ModuleType('xrnerf_amd_pickle_shim')
+    shim.Unpickler, shim.load, shim.loads = _Unpickler, pickle.load, pickle.loads
+    shim.__dict__.update({k: getattr(pickle, k) for k in ('HIGHEST_PROTOCOL', 'DEFAULT_PROTOCOL', 'PickleError', 'UnpicklingError')})
+    cp = torch.load(path, map_location='cpu', pickle_module=shim, weights_only=False)
+    queue = list(cp['root_nodes'])
+    leaves = []
+    for node in queue:                                   # the list grows while it is walked, like the reference's
+        if hasattr(node, 'network'):
+            leaves.append(node)
+        else:
+            queue.append(node.leq_child)
+            queue.append(node.gt_child)
+    if not leaves:
+        raise ValueError('no leaf network in the checkpoint')
+
+    def layer(net, *path):
+        m = net
+        for key in path:
+            m = m._modules[key]
+        w, b = m._parameters['weight'].detach(), m._parameters['bias'].detach()
+        return w[0].t().contiguous(), b[0].contiguous()          # 'bmm' layout [1, out, in] -> [in, out]
+
+    p0 = leaves[0].network
+    n_hidden = int(p0.num_hidden_layers)
+    names = [('pts_linears.%d' % l, ('pts_linears', str(l))) for l in range(n_hidden)]
+    names += [(n, (n,)) for n in ('alpha_linear', 'feature_linear', 'direction_layer', 'rgb_linear')]
+    sd = {}
+    for name, path in names:
+        ws, bs = zip(*[layer(leaf.network, *path) for leaf in leaves])
+        sd[name + '.weight'], sd[name + '.bias'] = torch.stack(ws, 0), torch.stack(bs, 0)
+    return {'domain_mins': torch.tensor([list(l.domain_min) for l in leaves], dtype=torch.float32),
+            'domain_maxs': torch.tensor([list(l.domain_max) for l in leaves], dtype=torch.float32),
+            'state_dict': sd, 'num_hidden_layers': n_hidden}
+
+
 @MLPS.register_module()
 class KiloNerfMLP(nn.Module):
     """kilonerf_mlp.py:27-190.  Checkpoints: `occupancy_checkpoint` is the reference's (a tensor saved with torch.save);
-    `distilled_checkpoint` must be a dict {'domain_mins', 'domain_maxs', 'state_dict'[, 'num_hidden_layers']} with the
-    multi network's state under the reference's parameter names -- the reference's own distillation checkpoint pickles
-    its Node / MultiNetwork classes and cannot be read without that package (conversion: next step)."""
+    `distilled_checkpoint` is either a plain dict {'domain_mins', 'domain_maxs', 'state_dict'[, 'num_hidden_layers']} with
+    the multi network's state under the reference's parameter names, or the reference's own distillation checkpoint
+    (a pickle of its Node / MultiNetwork objects), which is read without the reference package by
+    `load_reference_distilled_checkpoint` -- pass `trust_pickle=True` through the mlp config to allow that (it executes
+    a pickle, as the reference's torch.load does)."""
 
     def __init__(self, resolution=None, distilled_config=None, occupancy_checkpoint=None, distilled_checkpoint=None,
-                 embedder=None):
+                 embedder=None, trust_pickle=False):
         super().__init__()
         self.resolution = list(resolution)
         self.distilled_config = distilled_config
         self.embedder = builder.build_embedder(embedder)
         occ = torch.load(occupancy_checkpoint) if isinstance(occupancy_checkpoint, str) else occupancy_checkpoint
-        cp = torch.load(distilled_checkpoint) if isinstance(distilled_checkpoint, str) else distilled_checkpoint
+        cp = distilled_checkpoint
+        if isinstance(cp, str):
+            try:
+                cp = torch.load(cp)                                   # weights_only: plain tensors / dicts
+            except Exception:                                         # noqa: BLE001  the reference's pickled Node tree
+                if not trust_pickle:
+                    raise NotImplementedError(
+                        'distilled_checkpoint is not a plain dict of tensors: the reference pickle of Node objects is read '
+                        'by kilo.load_reference_distilled_checkpoint -- set trust_pickle=True in the mlp config to allow it')
+                cp = load_reference_distilled_checkpoint(cp)
         if not isinstance(cp, dict) or 'state_dict' not in cp:
-            raise NotImplementedError('distilled_checkpoint must be a dict with domain_mins / domain_maxs / state_dict '
-                                      '(the reference pickle of Node objects needs the reference package to load)')
+            raise NotImplementedError('distilled_checkpoint must hold domain_mins / domain_maxs / state_dict')
         self._init_from(occ, cp['domain_mins'], cp['domain_maxs'], cp['state_dict'], cp.get('num_hidden_layers'))
 
     @classmethod
