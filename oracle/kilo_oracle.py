@@ -158,3 +158,66 @@ def nerf_render(raw, z_vals, rays_d, white_bkgd=True):
     if white_bkgd:
         rgb_map = rgb_map + (F(1) - acc[..., None])
     return _f(rgb_map), _f(disp), _f(acc), w
+
+
+# ---------------------------------------------------------------- gradients of the tiny MLPs (fine-tuning)
+def tiny_backward(nets, n, pos_emb, dir_emb, d_raw):
+    """dL/d(parameters of network n) for rows (pos_emb [m,P], dir_emb [m,D]) with dL/draw [m,4] = (rgb3, alpha); float64.
+    MultiNetwork.forward's adjoint (multi_modules.py:590-668; AddMultiMatMul.backward :215-236 = the same products).
+    -> dict name -> gradient in the `multimatmul` layout ([in, out] weights, [out] biases)"""
+    f = lambda a: np.asarray(a, np.float64)
+    x, dv, g = f(pos_emb), f(dir_emb), f(d_raw)
+    acts, h = [], x
+    for w, b in zip(nets.pts_w, nets.pts_b):
+        pre = h @ f(w[n]) + f(b[n])
+        acts.append((h, pre))
+        h = np.maximum(pre, 0)
+    feat = h @ f(nets.feat_w[n]) + f(nets.feat_b[n])
+    din = np.concatenate([feat, dv], -1)
+    pre_d = din @ f(nets.dir_w[n]) + f(nets.dir_b[n])
+    hd = np.maximum(pre_d, 0)
+    out = {}
+    g_rgb, g_a = g[:, :3], g[:, 3:4]
+    out['rgb_linear.weight'], out['rgb_linear.bias'] = hd.T @ g_rgb, g_rgb.sum(0)
+    d_hd = (g_rgb @ f(nets.rgb_w[n]).T) * (pre_d > 0)
+    out['direction_layer.weight'], out['direction_layer.bias'] = din.T @ d_hd, d_hd.sum(0)
+    d_feat = d_hd @ f(nets.dir_w[n])[:feat.shape[1]].T
+    out['feature_linear.weight'], out['feature_linear.bias'] = h.T @ d_feat, d_feat.sum(0)
+    out['alpha_linear.weight'], out['alpha_linear.bias'] = h.T @ g_a, g_a.sum(0)
+    d_h = d_feat @ f(nets.feat_w[n]).T + g_a @ f(nets.alpha_w[n]).T
+    for l in reversed(range(len(nets.pts_w))):
+        hin, pre = acts[l]
+        d_pre = d_h * (pre > 0)
+        out['pts_linears.%d.weight' % l], out['pts_linears.%d.bias' % l] = hin.T @ d_pre, d_pre.sum(0)
+        d_h = d_pre @ f(nets.pts_w[l][n]).T
+    return out
+
+
+def mlp_raw_backward(d_raw, rays_o, rays_d, viewdirs, z_vals, gmin, gmax, fixed_res, res, occupancy, dmins, dmaxs, nets,
+                     pos_freqs=10, dir_freqs=4, pts=None):
+    """gradients of every network's parameters for dL/draw [R,S,4] (rows without a network do not contribute):
+    dict name -> [N, ...] float64 arrays in the `multimatmul` layout"""
+    R, S = np.asarray(z_vals).shape
+    if pts is None:
+        pts = get_pts(rays_o, rays_d, z_vals)
+    flat = _f(pts).reshape(-1, 3)
+    net, active = assign(flat, gmin, gmax, fixed_res, res, occupancy, nets.num_networks)
+    order, counts = group(net, active, nets.num_networks)
+    dirs = np.repeat(_f(viewdirs), S, axis=0)
+    g = np.asarray(d_raw, np.float64).reshape(-1, 4)
+    N = nets.num_networks
+    shapes = {'rgb_linear.weight': nets.rgb_w.shape, 'rgb_linear.bias': nets.rgb_b.shape,
+              'direction_layer.weight': nets.dir_w.shape, 'direction_layer.bias': nets.dir_b.shape,
+              'feature_linear.weight': nets.feat_w.shape, 'feature_linear.bias': nets.feat_b.shape,
+              'alpha_linear.weight': nets.alpha_w.shape, 'alpha_linear.bias': nets.alpha_b.shape}
+    for l, (w, b) in enumerate(zip(nets.pts_w, nets.pts_b)):
+        shapes['pts_linears.%d.weight' % l], shapes['pts_linears.%d.bias' % l] = w.shape, b.shape
+    grads = {k: np.zeros(v, np.float64) for k, v in shapes.items()}
+    start = 0
+    for n in np.nonzero(counts)[0]:
+        rows = order[start:start + counts[n]]
+        start += counts[n]
+        local = to_local(flat[rows], _f(dmins)[n], _f(dmaxs)[n])
+        for k, v in tiny_backward(nets, n, fourier(local, pos_freqs), fourier(dirs[rows], dir_freqs), g[rows]).items():
+            grads[k][n] = v.reshape(grads[k][n].shape)
+    return grads

@@ -98,3 +98,36 @@ def test_live_assignment_and_render_on_a_larger_scene(K):
     dd, ret = ns.NerfRender(white_bkgd=True, raw_noise_std=0)({'raw': T(raw), 'z_vals': T(z), 'rays_d': T(d)}, True)
     rgb, disp, acc, w = K.nerf_render(raw, z, d, True)
     assert np.abs(w - dd['weights'].numpy()).max() <= 1e-6 and np.abs(rgb - ret['rgb'].numpy()).max() <= 5e-6
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/xrnerf'), reason='live check needs /root/reference')
+def test_tiny_mlp_gradients_against_reference_autograd(K, gold):
+    """oracle adjoint of MultiNetwork.forward against torch autograd through the reference's own MultiNetwork('bmm')"""
+    import torch
+    sys.path.insert(0, G)
+    import ref_import
+    ns = ref_import.load_kilo()
+    torch.manual_seed(3)
+    multi = ns.MultiNetwork(1, 63, 27, 4, 32, 2, None, True, 32, 'relu', linear_implementation='bmm')
+    with torch.no_grad():
+        for p in multi.parameters():
+            p.mul_(2.0)
+    mods = dict(multi.named_modules())
+    g = lambda nm: (mods[nm].weight.detach().permute(0, 2, 1).contiguous().numpy(), mods[nm].bias.detach().numpy())
+    (w0, b0), (w1, b1), (wa, ba), (wf, bf), (wd, bd), (wr, br) = (g(n) for n in LAYERS)
+    nets = K.TinyNets([w0, w1], [b0, b1], wa, ba, wf, bf, wd, bd, wr, br)
+    rng = np.random.default_rng(8)
+    m = 200
+    pe = K.fourier(rng.uniform(-1, 1, (m, 3)).astype(np.float32), 10)
+    de = K.fourier(rng.normal(0, 0.6, (m, 3)).astype(np.float32), 4)
+    d_raw = rng.normal(0, 1, (m, 4)).astype(np.float32)
+    out = multi(torch.tensor(np.concatenate([pe, de], -1))[None])
+    (out[0] * torch.tensor(d_raw)).sum().backward()
+    got = K.tiny_backward(nets, 0, pe, de, d_raw)
+    for nm in LAYERS:
+        rw = mods[nm].weight.grad[0].t().numpy()
+        assert np.abs(got[nm + '.weight'] - rw).max() <= 2e-5 * max(1.0, np.abs(rw).max()), nm
+        rb = mods[nm].bias.grad[0].numpy()
+        assert np.abs(got[nm + '.bias'] - rb).max() <= 2e-5 * max(1.0, np.abs(rb).max()), nm
+    # forward of the same network, for completeness
+    assert np.abs(nets.forward(0, pe, de) - out[0].detach().numpy()).max() <= 1e-5
