@@ -314,6 +314,16 @@ int xr_kilo_mlp_forward(const float* pts, const float* rays_o, const float* rays
                         const uint8_t* occupancy, const float* domain_mins, const float* domain_maxs, const float* params,
                         uint32_t param_stride, uint32_t num_networks, int pos_freqs, int dir_freqs, int n_hidden,
                         float* raw, uint32_t* counts_out, void* workspace, size_t workspace_bytes, void* stream);
+/* gradients of the tiny MLPs' parameters for fine-tuning (AddMultiMatMul.backward, mlps/multi_modules.py:215-236, chained
+ * through MultiNetwork.forward): same sample arguments as xr_kilo_mlp_forward; draw [n_rays*n_samples,4] = dL/draw (rows no
+ * network evaluated are ignored); ACCUMULATES into grad_params [N, param_stride] (block layout of params; caller
+ * zero-fills).  n_hidden <= 2, pos_freqs <= 10, dir_freqs <= 4.  workspace: xr_kilo_workspace_bytes. */
+int xr_kilo_mlp_backward(const float* pts, const float* rays_o, const float* rays_d, const float* z_vals,
+                         const float* viewdirs, uint32_t n_rays, uint32_t n_samples, const float* gmin_host,
+                         const float* gmax_host, const int32_t* fixed_res_host, const int32_t* occ_res_host,
+                         const uint8_t* occupancy, const float* domain_mins, const float* domain_maxs, const float* params,
+                         uint32_t param_stride, uint32_t num_networks, int pos_freqs, int dir_freqs, int n_hidden,
+                         const float* draw, float* grad_params, void* workspace, size_t workspace_bytes, void* stream);
 /* One frame (or chunk) of the reference's KiloNeRF test path in one call, for the real-time bench: GetZvals (not
  * randomized; datasets/pipelines/create.py:486-531) + GetPts + KiloNerfMLP.forward + NerfRender.forward.  Same values
  * as xr_mip_zvals -> xr_kilo_mlp_forward -> xr_nerf_render_forward, but no [n_rays, n_samples] tensor other than the

@@ -52,8 +52,9 @@ def test_reference_fixture(dev, gold):
     R, S = gold['z_vals'].shape
     data = {'pts': T(gold['pts'], dev), 'viewdirs': T(gold['viewdirs'], dev), 'global_domain_min': torch.tensor(gold['gmin']),
             'global_domain_max': torch.tensor(gold['gmax'])}
-    raw = mlp(data)['raw']
-    assert tuple(raw.shape) == (R, S, 4)
+    with torch.no_grad():                                   # inference: the plain forward call (no autograd node)
+        raw = mlp(data)['raw']
+    assert tuple(raw.shape) == (R, S, 4) and not raw.requires_grad
     flat = raw.reshape(-1, 4).cpu().numpy()
     active = np.zeros(R * S, bool); active[gold['active_samples']] = True
     assert np.array_equal(flat[~active], np.zeros_like(flat[~active]))           # exact zeros where nothing is evaluated
@@ -98,8 +99,16 @@ def test_network_behind_the_registry(dev, gold, tmp_path):
         ret = net.batchify_forward(data, is_test=True)
     assert np.abs(ret['rgb'].cpu().numpy() - gold['rgb']).max() <= 1e-4
     assert np.abs(ret['acc'].cpu().numpy() - gold['acc']).max() <= 1e-4
-    with pytest.raises(NotImplementedError):
-        net.train_step({k: v[None] for k, v in data.items()}, None)
+    # one fine-tuning step through the registry classes: loss = MSE + lambda * L2(view-dependent parameters)
+    batch = {k: v[None] for k, v in data.items()}
+    batch['target_s'] = T(gold['rgb'], dev)[None] * 0.5
+    out = net.train_step(batch, None)
+    out['loss'].backward()
+    vd = net.mlp.get_view_dependent_parameters()
+    reg = sum(float(p.detach().norm(2)) for p in vd)
+    assert abs(float(out['log_vars']['L2 reg']) - 1e-6 * reg) <= 1e-9 and out['num_samples'] == gold['rgb'].shape[0]
+    grads = [p.grad for p in net.mlp.multi_network.parameters()]
+    assert all(g is not None and torch.isfinite(g).all() for g in grads) and sum(float(g.abs().sum()) for g in grads) > 0
 
 
 @pytest.mark.parametrize('R,S', [(2048, 384), (333, 97)])
@@ -234,3 +243,113 @@ def test_fused_frame_path_spans_on_adversarial_rays(dev):
         assert float((b[2] > 0).float().mean()) > 0.15
         for x, y in zip(a, b):
             assert torch.equal(torch.nan_to_num(x, nan=-1.0), torch.nan_to_num(y, nan=-1.0))
+
+
+def _oracle_grads(K, mlp, cam, d, vd, z, gmin, gmax, draw, pos_freqs=10, dir_freqs=4, pts=None):
+    fixed = [r // 16 for r in mlp.resolution]
+    return K.mlp_raw_backward(draw, cam, d, vd, z, np.float32(gmin), np.float32(gmax), fixed, mlp.resolution,
+                              mlp.occupancy_grid.cpu().numpy() if mlp.occupancy_grid is not None else None,
+                              mlp.domain_mins.cpu().numpy(), mlp.domain_maxs.cpu().numpy(),
+                              oracle_nets(K, mlp.multi_network.state_dict()), pos_freqs, dir_freqs, pts=pts)
+
+
+def test_parameter_gradients_on_the_reference_fixture(dev, K, gold):
+    """xr_kilo_mlp_backward against the oracle's adjoint (pinned to torch autograd through the reference's MultiNetwork):
+    every parameter tensor of all 24 networks, dL/draw random, rows without a network ignored"""
+    from xrnerf_amd import kilo, ops
+    mlp = mlp_from_gold(gold, dev)
+    rng = np.random.default_rng(21)
+    R, S = gold['z_vals'].shape
+    draw = rng.normal(0, 1, (R, S, 4)).astype(np.float32)
+    fixed = [r // 16 for r in mlp.resolution]
+    mn = mlp.multi_network
+    g = ops.kilo_mlp_backward(T(draw, dev), T(gold['viewdirs'], dev), gold['gmin'], gold['gmax'], fixed, mlp.resolution,
+                              mlp.occupancy_grid, mlp.domain_mins, mlp.domain_maxs, mn.packed(), 10, 4, 2, pts=T(gold['pts'], dev))
+    got = kilo.MultiNetwork.unpack_like(g, mn.ordered_parameters())
+    ref = _oracle_grads(K, mlp, None, None, gold['viewdirs'], gold['z_vals'], gold['gmin'], gold['gmax'], draw, pts=gold['pts'])
+    for (name, _), t in zip(mn.named_parameters(), got):
+        r = ref[name]
+        assert np.abs(t.cpu().numpy().astype(np.float64) - r).max() <= 1e-4 * max(1.0, np.abs(r).max()), name
+    # padding slots of the blocks stay untouched
+    pad = torch.cat([g[:, 63 * 32 + 32 + 1056 + 33:63 * 32 + 32 + 1056 + 36], g[:, -1:]], 1)
+    assert float(pad.abs().max()) == 0.0
+
+
+def test_parameter_gradients_on_the_lego_grid_through_autograd(dev, K):
+    """1440 networks, 384 samples per ray: the autograd node (KiloNerfMLP.forward under grad, .backward()) against the
+    oracle's adjoint for every parameter tensor"""
+    from xrnerf_amd import kilo, ops
+    mlp, gmin, gmax = kilo.synthetic_scene(dev, seed=6)
+    rng = np.random.default_rng(5)
+    R, S = 384, 384
+    cam = rng.normal(0, 1, (R, 3)); cam = (3.2 * cam / np.linalg.norm(cam, axis=-1, keepdims=True)).astype(np.float32)
+    d = (rng.uniform(-0.4, 0.4, (R, 3)) + [0, 0, 0.3] - cam).astype(np.float32)
+    d = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32)
+    z = np.tile(np.linspace(1.5, 5.0, S, dtype=np.float32), (R, 1))
+    draw = rng.normal(0, 1, (R, S, 4)).astype(np.float32)
+    mn = mlp.multi_network
+    data = {'rays_o': T(cam, dev), 'rays_d': T(d, dev), 'viewdirs': T(d, dev), 'z_vals': T(z, dev),
+            'global_domain_min': gmin, 'global_domain_max': gmax}
+    raw = mlp(dict(data))['raw']
+    assert raw.requires_grad
+    (raw * T(draw, dev)).sum().backward()
+    ref = _oracle_grads(K, mlp, cam, d, d, z, gmin.numpy(), gmax.numpy(), draw)
+    for name, p in mn.named_parameters():
+        r = ref[name]
+        assert np.abs(p.grad.cpu().numpy().astype(np.float64) - r).max() <= 2e-4 * max(1.0, np.abs(r).max()), name
+
+
+def test_parameter_gradients_other_architecture(dev, K):
+    """one hidden layer, 1 / 0 Fourier frequencies, > 16384 networks (global-atomic assignment path)"""
+    from xrnerf_amd import kilo, ops
+    fixed = [26, 26, 26]
+    N = 26 ** 3
+    g0 = torch.Generator(device='cpu').manual_seed(0)
+    mk = lambda *s: ((torch.rand(*s, generator=g0) * 2 - 1) * 0.4)
+    sd = {'pts_linears.0.weight': mk(N, 9, 32), 'pts_linears.0.bias': mk(N, 32), 'alpha_linear.weight': mk(N, 32, 1),
+          'alpha_linear.bias': mk(N, 1), 'feature_linear.weight': mk(N, 32, 32), 'feature_linear.bias': mk(N, 32),
+          'direction_layer.weight': mk(N, 35, 32), 'direction_layer.bias': mk(N, 32), 'rgb_linear.weight': mk(N, 32, 3),
+          'rgb_linear.bias': mk(N, 3)}
+    mn = kilo.MultiNetwork(N, 9, 3, num_hidden_layers=1)
+    mn.load_state_dict(sd)
+    mn = mn.to(dev)
+    rng = np.random.default_rng(2)
+    R, S = 300, 21
+    pts = rng.uniform(-1.1, 1.1, (R, S, 3)).astype(np.float32)
+    vd = rng.normal(0, 1, (R, 3)).astype(np.float32); vd /= np.linalg.norm(vd, axis=-1, keepdims=True)
+    idx = np.stack(np.meshgrid(*[np.arange(26)] * 3, indexing='ij'), -1).reshape(-1, 3)
+    dmins = (-1.0 + idx * (2.0 / 26)).astype(np.float32); dmaxs = (-1.0 + (idx + 1) * (2.0 / 26)).astype(np.float32)
+    draw = rng.normal(0, 1, (R, S, 4)).astype(np.float32)
+    g = ops.kilo_mlp_backward(T(draw, dev), T(vd, dev), [-1.0] * 3, [1.0] * 3, fixed, None, None, T(dmins, dev), T(dmaxs, dev),
+                              mn.packed(), 1, 0, 1, pts=T(pts, dev))
+    got = kilo.MultiNetwork.unpack_like(g, mn.ordered_parameters())
+    ref = K.mlp_raw_backward(draw, None, None, vd, np.zeros((R, S), np.float32), np.float32([-1] * 3), np.float32([1] * 3), fixed,
+                             None, None, dmins, dmaxs, oracle_nets(K, sd), 1, 0, pts=pts)
+    for (name, _), t in zip(mn.named_parameters(), got):
+        r = ref[name]
+        assert np.abs(t.cpu().numpy().astype(np.float64) - r).max() <= 1e-4 * max(1.0, np.abs(r).max()), name
+
+
+def test_fine_tuning_reduces_the_loss(dev):
+    """Adam on all 1440 networks' parameters through KiloNerfNetwork.train_step: the loss goes down"""
+    import xrnerf_amd
+    from xrnerf_amd import kilo, vanilla
+    mlp, gmin, gmax = kilo.synthetic_scene(dev, seed=7, weight_scale=1.0)
+    net = kilo.KiloNerfNetwork.__new__(kilo.KiloNerfNetwork)
+    torch.nn.Module.__init__(net)
+    net.phase, net.chunk, net.bs_data, net.N_importance, net.is_perturb = 'train', 40000, 'rays_o', 0, True
+    net.mlp, net.render, net.l2_regularization_lambda = mlp, vanilla.NerfRender(white_bkgd=True, raw_noise_std=0), 1e-6
+    rays_o, rays_d, viewdirs = kilo.camera_rays(kilo.orbit_poses(4)[1], 96, 96, 1111.111 * 96 / 800, dev)
+    z = torch.linspace(2.0, 6.0, 192, device=dev).expand(rays_o.shape[0], 192).contiguous()
+    target = torch.rand(rays_o.shape[0], 3, device=dev) * 0.5 + 0.25
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    losses = []
+    for it in range(8):
+        batch = {'rays_o': rays_o[None], 'rays_d': rays_d[None], 'viewdirs': viewdirs[None], 'z_vals': z[None],
+                 'target_s': target[None], 'global_domain_min': gmin, 'global_domain_max': gmax}
+        out = net.train_step(batch, opt)
+        opt.zero_grad(set_to_none=True)
+        out['loss'].backward()
+        opt.step()
+        losses.append(float(out['log_vars']['loss']))
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]

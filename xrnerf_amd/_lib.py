@@ -62,6 +62,8 @@ SIGNATURES = {
     'xr_kilo_workspace_bytes': (_sz, [_u64, _u32]),
     'xr_kilo_mlp_forward': (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32,
                                    _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    'xr_kilo_mlp_backward': (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32,
+                                    _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     'xr_nerf_render_forward': (_i32, [_vp, _vp, _vp, _u32, _u32, _i32, _vp, _vp, _vp, _vp, _vp]),
     'xr_linear_forward': (_i32, [_vp, _vp, _vp, _u32, _u32, _u32, _i32, _vp, _vp]),
     'xr_linear_backward_input': (_i32, [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp]),

@@ -386,6 +386,208 @@ __global__ void __launch_bounds__(256) k_kilo_mlp(KiloMlpArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------ fine-tuning gradients
+// dL/d(parameters) of the tiny MLPs given dL/draw (AddMultiMatMul.backward, multi_modules.py:215-236 = per network
+// grad_biases = column sums, grad_weights = in^T . grad_out, grad_in = grad_out . W^T; chained through
+// MultiNetwork.forward :590-668).  Same tiling as the forward: a wave owns 32 samples in the neurons x samples MFMA
+// layout and first re-runs the forward (nothing is saved).  Back-propagation through a layer is the forward's MFMA idiom
+// with the weight slab read transposed; a weight gradient is an outer product contracted over the wave's 32 samples --
+// both operand tiles ([neurons][samples]) go through a per-wave LDS tile so that the sample index can be the MFMA's K --
+// and is added to the network's block of the packed gradient buffer with coalesced fp32 atomics (32 consecutive floats
+// per row).  Biases: half-wave butterfly sums.  n_hidden <= 2, pos_freqs <= 10, dir_freqs <= 4 (every reference config).
+#define KB_ST 33                                 // LDS tile row stride (floats): conflict-free for row- and column-wise access
+#define KB_WAVE_FLOATS ((64 + 32) * KB_ST)       // per wave: input tile (64 rows) + delta tile (32 rows)
+
+struct KiloBwdArgs { KiloMlpArgs f; const float4* draw; float* grad; };
+
+__device__ __forceinline__ void ktile_to_lds(float* __restrict__ T, const f32x16& v, int col, int hi) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) T[(kdrow(r) + 4 * hi) * KB_ST + col] = v[r];
+}
+// D[k][j] = sum_n tin[k][n] * tdl[j][n]  (n = the wave's 32 samples)
+__device__ __forceinline__ f32x16 kouter(const float* __restrict__ tin, const float* __restrict__ tdl, int col, int hi) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc = KMFMA(tin[col * KB_ST + 2 * s + hi], tdl[col * KB_ST + 2 * s + hi], acc);
+    return acc;
+}
+__device__ __forceinline__ void ktile_atomic_add(float* __restrict__ g, const f32x16& d, int ldw, int n_rows, int n_cols, int col, int hi) {
+    if (col < n_cols) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = kdrow(r) + 4 * hi;
+            if (k < n_rows) atomicAdd(g + k * ldw + col, d[r]);
+        }
+    }
+}
+__device__ __forceinline__ float khalf_sum(float v) {           // over the 32 lanes (samples) of a half-wave
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+// gb[neuron] += sum over the samples of delta[neuron][sample]
+__device__ __forceinline__ void kbias_add(float* __restrict__ gb, const f32x16& d, int col, int hi) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float sum = khalf_sum(d[r]);
+        if (col == 0) atomicAdd(gb + kdrow(r) + 4 * hi, sum);
+    }
+}
+// delta_in[k][n] = sum_j W[k][j] delta_out[j][n] for an input-major [32 k][32 j] slab (read along j: transposed use)
+__device__ __forceinline__ f32x16 kilo_dense32_T(const float* __restrict__ w, const f32x16& d, int col, int hi) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* wl = w + col * KILO_H + 4 * hi;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc = KMFMA(wl[kdrow(s)], d[s], acc);
+    return acc;
+}
+// Fourier features of one scalar into rows [0, 2F+1) of an LDS tile (row = feature, column = sample): same split between
+// the half-waves as kilo_feed_fourier
+__device__ __forceinline__ void kfourier_to_lds(float* __restrict__ T, float x, int n_freq, int col, int hi) {
+    if (hi == 0) T[col] = x;
+    for (int m = 0; 2 * m < n_freq; ++m) {
+        const int k = 2 * m + hi;
+        if (k < n_freq) {
+            float sv, cv;
+            sincosf(ldexpf(x, k), &sv, &cv);
+            T[(1 + k) * KB_ST + col] = cv;
+            T[(1 + n_freq + k) * KB_ST + col] = sv;
+        }
+    }
+}
+
+template <int NH>
+__global__ void __launch_bounds__(128) k_kilo_mlp_bwd(KiloBwdArgs b) {
+    extern __shared__ float s_w[];                      // [parameter block | per-wave tiles]
+    __shared__ uint32_t s_net;
+    const KiloMlpArgs& a = b.f;
+    const uint32_t n_floats = kilo_param_floats(a.pos_freqs, a.dir_freqs, NH);
+    const uint32_t total_tiles = a.tile_start[a.num_networks];
+    const int P = 3 * (2 * a.pos_freqs + 1), D = 3 * (2 * a.dir_freqs + 1);
+    const int lane = threadIdx.x & 63, col = lane & 31, hi = lane >> 5;
+    const uint32_t wave = threadIdx.x >> 6;
+    float* tin = s_w + n_floats + wave * KB_WAVE_FLOATS;
+    float* tdl = tin + 64 * KB_ST;
+    // offsets inside a parameter / gradient block
+    const int o_b0 = P * KILO_H, o_l1 = o_b0 + KILO_H, o_alpha = o_l1 + (NH - 1) * (KILO_H * KILO_H + KILO_H);
+    const int o_feat = o_alpha + KILO_H + 4, o_dir = o_feat + KILO_H * KILO_H + KILO_H;
+    const int o_bd = o_dir + (KILO_H + D) * KILO_H, o_rgb = o_bd + KILO_H;
+    for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t lo = 0, hi_n = a.num_networks - 1;
+            while (lo < hi_n) {
+                const uint32_t mid = (lo + hi_n + 1) >> 1;
+                if (a.tile_start[mid] <= tile) lo = mid; else hi_n = mid - 1;
+            }
+            s_net = lo;
+        }
+        __syncthreads();
+        const uint32_t net = s_net;
+        {
+            const float4* src = reinterpret_cast<const float4*>(a.params + (size_t)net * a.param_stride);
+            float4* dst = reinterpret_cast<float4*>(s_w);
+            for (uint32_t q = threadIdx.x; q < n_floats / 4; q += 128) dst[q] = src[q];
+        }
+        __syncthreads();
+        const float* w = s_w;
+        float* g = b.grad + (size_t)net * a.param_stride;
+        const uint32_t seg0 = a.seg_start[net], seg1 = a.seg_start[net + 1];
+        for (int part = 0; part < 2; ++part) {
+            const uint32_t wave0 = seg0 + (tile - a.tile_start[net]) * KILO_TILE + part * 64 + wave * 32;
+            if (wave0 >= seg1) break;
+            const uint32_t slot = wave0 + col;
+            const bool live = slot < seg1;
+            const uint32_t i = a.order[live ? slot : seg1 - 1];
+            float p[3], x[3], v[3];
+            kilo_point(a.rays, i, p);
+            const uint64_t ray = (uint64_t)i / a.rays.n_s;
+            for (int c = 0; c < 3; ++c) {
+                const float lo = a.domain_mins[net * 3 + c], hi_d = a.domain_maxs[net * 3 + c];
+                x[c] = 2.f * (p[c] - lo) / (hi_d - lo) - 1.f;
+                v[c] = a.rays.viewdirs[ray * 3 + c];
+            }
+            // ---- forward, as k_kilo_mlp
+            f32x16 acc = kilo_bias(w + o_b0, hi);
+            for (int c = 0; c < 3; ++c) acc = kilo_feed_fourier(w + c * (2 * a.pos_freqs + 1) * KILO_H, acc, x[c], a.pos_freqs, col, hi);
+            const f32x16 h0 = kilo_relu(acc);
+            f32x16 hl = h0;
+            if (NH == 2) hl = kilo_relu(kilo_dense32(w + o_l1, kilo_bias(w + o_l1 + KILO_H * KILO_H, hi), h0, col, hi));
+            const f32x16 feat = kilo_dense32(w + o_feat, kilo_bias(w + o_feat + KILO_H * KILO_H, hi), hl, col, hi);
+            acc = kilo_dense32(w + o_dir, kilo_bias(w + o_bd, hi), feat, col, hi);
+            for (int c = 0; c < 3; ++c)
+                acc = kilo_feed_fourier(w + o_dir + (KILO_H + c * (2 * a.dir_freqs + 1)) * KILO_H, acc, v[c], a.dir_freqs, col, hi);
+            const f32x16 hd = kilo_relu(acc);
+            // ---- backward
+            float4 gr = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live) gr = b.draw[i];
+            // rgb head: out_c = b_c + sum_k Wr[k][c] hd[k]
+            f32x16 d;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d[r] = 0.f;
+            if (hi == 0) { d[0] = gr.x; d[1] = gr.y; d[2] = gr.z; }          // rows 0..2 of the delta tile (kdrow(r) = r for r < 4)
+            ktile_to_lds(tin, hd, col, hi);
+            ktile_to_lds(tdl, d, col, hi);
+            ktile_atomic_add(g + o_rgb, kouter(tin, tdl, col, hi), 4, KILO_H, 3, col, hi);
+            {
+                const float s0 = khalf_sum(gr.x), s1 = khalf_sum(gr.y), s2 = khalf_sum(gr.z), s3 = khalf_sum(gr.w);
+                if (lane == 0) {
+                    atomicAdd(g + o_rgb + KILO_H * 4 + 0, s0); atomicAdd(g + o_rgb + KILO_H * 4 + 1, s1);
+                    atomicAdd(g + o_rgb + KILO_H * 4 + 2, s2);
+                    atomicAdd(g + o_alpha + KILO_H, s3);                    // b_alpha
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float4 t = *reinterpret_cast<const float4*>(w + o_rgb + (kdrow(r) + 4 * hi) * 4);
+                d[r] = hd[r] > 0.f ? fmaf(t.x, gr.x, fmaf(t.y, gr.y, t.z * gr.z)) : 0.f;
+            }
+            // direction layer: inputs [feature (32) | Fourier(viewdir) (D)]
+            ktile_to_lds(tdl, d, col, hi);
+            ktile_to_lds(tin, feat, col, hi);
+            ktile_atomic_add(g + o_dir, kouter(tin, tdl, col, hi), KILO_H, KILO_H, KILO_H, col, hi);
+            for (int rr = hi; rr < 32; rr += 2) tin[rr * KB_ST + col] = 0.f;     // rows beyond D stay zero
+            for (int c = 0; c < 3; ++c) kfourier_to_lds(tin + c * (2 * a.dir_freqs + 1) * KB_ST, v[c], a.dir_freqs, col, hi);
+            ktile_atomic_add(g + o_dir + KILO_H * KILO_H, kouter(tin, tdl, col, hi), KILO_H, D, KILO_H, col, hi);
+            kbias_add(g + o_bd, d, col, hi);
+            d = kilo_dense32_T(w + o_dir, d, col, hi);                      // dL/dfeature (no activation)
+            // feature and alpha heads on hl
+            ktile_to_lds(tdl, d, col, hi);
+            ktile_to_lds(tin, hl, col, hi);
+            ktile_atomic_add(g + o_feat, kouter(tin, tdl, col, hi), KILO_H, KILO_H, KILO_H, col, hi);
+            kbias_add(g + o_feat + KILO_H * KILO_H, d, col, hi);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float sum = khalf_sum(hl[r] * gr.w);
+                if (col == 0) atomicAdd(g + o_alpha + kdrow(r) + 4 * hi, sum);
+            }
+            d = kilo_dense32_T(w + o_feat, d, col, hi);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d[r] = hl[r] > 0.f ? fmaf(w[o_alpha + kdrow(r) + 4 * hi], gr.w, d[r]) : 0.f;
+            if (NH == 2) {
+                ktile_to_lds(tdl, d, col, hi);
+                ktile_to_lds(tin, h0, col, hi);
+                ktile_atomic_add(g + o_l1, kouter(tin, tdl, col, hi), KILO_H, KILO_H, KILO_H, col, hi);
+                kbias_add(g + o_l1 + KILO_H * KILO_H, d, col, hi);
+                d = kilo_dense32_T(w + o_l1, d, col, hi);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d[r] = h0[r] > 0.f ? d[r] : 0.f;
+            }
+            // layer 0 on the Fourier features of the local coordinates: two row tiles of the [P x 32] gradient
+            ktile_to_lds(tdl, d, col, hi);
+            for (int rr = hi; rr < 64; rr += 2) tin[rr * KB_ST + col] = 0.f;
+            for (int c = 0; c < 3; ++c) kfourier_to_lds(tin + c * (2 * a.pos_freqs + 1) * KB_ST, x[c], a.pos_freqs, col, hi);
+            ktile_atomic_add(g, kouter(tin, tdl, col, hi), KILO_H, P < 32 ? P : 32, KILO_H, col, hi);
+            if (P > 32) ktile_atomic_add(g + 32 * KILO_H, kouter(tin + 32 * KB_ST, tdl, col, hi), KILO_H, P - 32, KILO_H, col, hi);
+            kbias_add(g + o_b0, d, col, hi);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ NerfRender.forward
 __device__ inline double wave_incl_prod(double v) {
     const int lane = threadIdx.x & 63;
@@ -499,9 +701,11 @@ static int kilo_mlp_launch(const KiloRays& rays, const float* gmin_host, const f
                            const int32_t* occ_res_host, const uint8_t* occupancy, const float* domain_mins,
                            const float* domain_maxs, const float* params, uint32_t param_stride, uint32_t num_networks,
                            int pos_freqs, int dir_freqs, int n_hidden, float* raw, bool dense, uint32_t* counts_out,
-                           void* workspace, size_t workspace_bytes, hipStream_t st, KiloWs* ws_out) {
+                           void* workspace, size_t workspace_bytes, hipStream_t st, KiloWs* ws_out,
+                           const float* draw = nullptr, float* grad = nullptr /* non-null: gradients instead of raw */) {
     // per-ray spans: only where the z lattice is evaluated on the fly and nothing dense is promised to the caller
     const bool use_spans = !dense && rays.pts == nullptr && rays.z_vals == nullptr;
+    const bool backward = grad != nullptr;
     XR_REQUIRE(gmin_host && gmax_host && fixed_res_host, "null host pointer");
     XR_REQUIRE(num_networks >= 1, "num_networks must be >= 1");
     XR_REQUIRE(pos_freqs >= 0 && pos_freqs <= 16 && dir_freqs >= 0 && dir_freqs <= 16, "frequency count out of range");
@@ -512,10 +716,13 @@ static int kilo_mlp_launch(const KiloRays& rays, const float* gmin_host, const f
     XR_REQUIRE(occupancy == nullptr || occ_res_host != nullptr, "occupancy without its resolution");
     const uint64_t n = (uint64_t)rays.n_rays * rays.n_s;
     XR_REQUIRE(n > 0 && n < (1ull << 32), "sample count must be in (0, 2^32)");
-    XR_REQUIRE(rays.viewdirs && domain_mins && domain_maxs && params && raw, "null pointer");
+    XR_REQUIRE(rays.viewdirs && domain_mins && domain_maxs && params && (backward ? draw != nullptr : raw != nullptr), "null pointer");
+    XR_REQUIRE(!backward || (n_hidden <= 2 && pos_freqs <= 10 && dir_freqs <= 4),
+               "gradients: n_hidden <= 2, pos_freqs <= 10, dir_freqs <= 4 (the architectures of the reference configs)");
     XR_REQUIRE(rays.pts || (rays.rays_o && rays.rays_d && (rays.z_vals || (rays.near && rays.far))),
                "either pts or (rays_o, rays_d, z_vals | near, far) is required");
-    XR_REQUIRE(((uintptr_t)raw & 15) == 0 && ((uintptr_t)params & 15) == 0, "raw / params must be 16-byte aligned");
+    XR_REQUIRE(((uintptr_t)raw & 15) == 0 && ((uintptr_t)params & 15) == 0 && ((uintptr_t)draw & 15) == 0,
+               "raw / params / draw must be 16-byte aligned");
     XR_REQUIRE(workspace && workspace_bytes >= kilo_ws_layout(n, num_networks, use_spans ? rays.n_rays : 0, nullptr, nullptr) &&
                ((uintptr_t)workspace & 255) == 0, "workspace too small or not 256-byte aligned");
     KiloGrid g;
@@ -559,7 +766,14 @@ static int kilo_mlp_launch(const KiloRays& rays, const float* gmin_host, const f
     int cus = xr_device_cus();
     if (cus <= 0) cus = 256;
     const uint32_t grid = (uint32_t)(max_tiles < (uint64_t)cus * 8 ? max_tiles : (uint64_t)cus * 8);
-    hipLaunchKernelGGL(k_kilo_mlp, dim3(grid), dim3(256), (size_t)n_floats * 4, st, a);
+    if (!backward) {
+        hipLaunchKernelGGL(k_kilo_mlp, dim3(grid), dim3(256), (size_t)n_floats * 4, st, a);
+    } else {
+        KiloBwdArgs bw{a, reinterpret_cast<const float4*>(draw), grad};
+        const size_t lds = (size_t)n_floats * 4 + 2 * (size_t)KB_WAVE_FLOATS * 4;
+        if (n_hidden == 1) hipLaunchKernelGGL(k_kilo_mlp_bwd<1>, dim3(grid), dim3(128), lds, st, bw);
+        else hipLaunchKernelGGL(k_kilo_mlp_bwd<2>, dim3(grid), dim3(128), lds, st, bw);
+    }
     XR_LAUNCH_CHECK();
     if (counts_out != nullptr)
         XR_HIP(hipMemcpyAsync(counts_out, ws.counts, (size_t)num_networks * 4, hipMemcpyDeviceToDevice, st));
@@ -578,6 +792,23 @@ extern "C" int xr_kilo_mlp_forward(const float* pts, const float* rays_o, const 
     return kilo_mlp_launch(rays, gmin_host, gmax_host, fixed_res_host, occ_res_host, occupancy, domain_mins, domain_maxs,
                            params, param_stride, num_networks, pos_freqs, dir_freqs, n_hidden, raw, true, counts_out,
                            workspace, workspace_bytes, (hipStream_t)stream, nullptr);
+}
+
+// parameter gradients for dL/draw [n_rays*n_samples, 4]; ACCUMULATES into grad_params [N, param_stride] (same block layout
+// as params; caller zero-fills); rows of draw that no network evaluated are ignored
+extern "C" int xr_kilo_mlp_backward(const float* pts, const float* rays_o, const float* rays_d, const float* z_vals,
+                                    const float* viewdirs, uint32_t n_rays, uint32_t n_samples, const float* gmin_host,
+                                    const float* gmax_host, const int32_t* fixed_res_host, const int32_t* occ_res_host,
+                                    const uint8_t* occupancy, const float* domain_mins, const float* domain_maxs,
+                                    const float* params, uint32_t param_stride, uint32_t num_networks, int pos_freqs,
+                                    int dir_freqs, int n_hidden, const float* draw, float* grad_params, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+    if ((uint64_t)n_rays * n_samples == 0) return XR_OK;
+    XR_REQUIRE(grad_params != nullptr, "null pointer");
+    KiloRays rays{pts, rays_o, rays_d, z_vals, viewdirs, n_rays, n_samples, nullptr, nullptr, 0};
+    return kilo_mlp_launch(rays, gmin_host, gmax_host, fixed_res_host, occ_res_host, occupancy, domain_mins, domain_maxs,
+                           params, param_stride, num_networks, pos_freqs, dir_freqs, n_hidden, nullptr, false, nullptr,
+                           workspace, workspace_bytes, (hipStream_t)stream, nullptr, draw, grad_params);
 }
 
 extern "C" size_t xr_kilo_render_workspace_bytes(uint32_t n_rays, uint32_t n_samples, uint32_t num_networks) {

@@ -7,8 +7,8 @@ constructor signatures, `data` dict keys and parameter names / layouts of
 
 `KiloNerfMLP.forward` is ONE call into the C-ABI (xr_kilo_mlp_forward, xrnerf_amd/csrc/xr_kilo.hip): the reference's
 reorder_points_and_dirs + kilonerf_cuda.global_to_local + compute_fourier_features + six MAGMA grouped GEMMs + two
-scatters.  Inference only in this round: the fine-tuning backward (multimatmul gradients) is the next step and
-`train_step` says so.  No CPU path: host tensors raise.
+scatters; fine-tuning gradients (the reference's AddMultiMatMul.backward chain) are one more call
+(xr_kilo_mlp_backward).  No CPU path: host tensors raise.
 """
 import math
 
@@ -78,24 +78,52 @@ class MultiNetwork(nn.Module):
         self.view_dependent_parameters = list(self.direction_layer.parameters()) + list(self.rgb_linear.parameters())
         self._packed, self._packed_key = None, None
 
+    def ordered_parameters(self):
+        """the parameter tensors in block order: (weight, bias) of pts_linears.*, alpha, feature, direction, rgb"""
+        layers = list(self.pts_linears) + [self.alpha_linear, self.feature_linear, self.direction_layer, self.rgb_linear]
+        return [t for l in layers for t in (l.weight, l.bias)]
+
+    @staticmethod
+    def pack(params):
+        """[N, stride] blocks in the kernel's order (xr_kilo.hip: kilo_param_floats) from ordered_parameters()"""
+        N = params[0].shape[0]
+        z = params[1].new_zeros
+        parts = []
+        for w, b in zip(params[0:-8:2], params[1:-8:2]):                  # hidden layers
+            parts += [w.reshape(N, -1), b]
+        aw, ab, fw, fb, dw, db, rw, rb = params[-8:]
+        parts += [aw.reshape(N, -1), ab, z((N, 3)), fw.reshape(N, -1), fb, dw.reshape(N, -1), db,
+                  torch.cat([rw, z((N, rw.shape[1], 1))], -1).reshape(N, -1), rb, z((N, 1))]
+        return torch.cat(parts, 1).to(torch.float32).contiguous()
+
+    @staticmethod
+    def unpack_like(blocks, params):
+        """inverse of pack for a [N, stride] tensor of the same layout (the gradient blocks): one tensor per parameter"""
+        N = params[0].shape[0]
+        out, off = [], 0
+
+        def take(n):
+            nonlocal off
+            t = blocks[:, off:off + n]
+            off += n
+            return t
+        for w, b in zip(params[0:-8:2], params[1:-8:2]):
+            out += [take(w[0].numel()).reshape(w.shape), take(b.shape[1]).reshape(b.shape)]
+        aw, ab, fw, fb, dw, db, rw, rb = params[-8:]
+        out += [take(aw[0].numel()).reshape(aw.shape), take(1).reshape(ab.shape)]
+        take(3)
+        out += [take(fw[0].numel()).reshape(fw.shape), take(fb.shape[1]).reshape(fb.shape)]
+        out += [take(dw[0].numel()).reshape(dw.shape), take(db.shape[1]).reshape(db.shape)]
+        out += [take(rw.shape[1] * 4).reshape(N, rw.shape[1], 4)[..., :3].contiguous(), take(3).reshape(rb.shape)]
+        return out
+
     def packed(self):
-        """[N, stride] parameter blocks in the kernel's order (xr_kilo.hip: kilo_param_floats), rebuilt when a
-        parameter changed"""
+        """cached pack(ordered_parameters()), rebuilt when a parameter changed"""
         key = tuple((p.data_ptr(), p._version) for p in self.parameters())
         if self._packed is not None and self._packed_key == key:
             return self._packed
-        N = self.num_networks
         with torch.no_grad():
-            parts = []
-            for l in self.pts_linears:
-                parts += [l.weight.reshape(N, -1), l.bias]
-            z = self.alpha_linear.bias.new_zeros
-            parts += [self.alpha_linear.weight.reshape(N, -1), self.alpha_linear.bias, z((N, 3))]
-            parts += [self.feature_linear.weight.reshape(N, -1), self.feature_linear.bias]
-            parts += [self.direction_layer.weight.reshape(N, -1), self.direction_layer.bias]
-            parts += [torch.cat([self.rgb_linear.weight, z((N, self.direction_layer_size, 1))], -1).reshape(N, -1),
-                      self.rgb_linear.bias, z((N, 1))]
-            self._packed = torch.cat(parts, 1).to(torch.float32).contiguous()
+            self._packed = self.pack(self.ordered_parameters())
         self._packed_key = key
         return self._packed
 
@@ -229,11 +257,33 @@ class KiloNerfMLP(nn.Module):
         fixed_res = [x // 16 for x in self.resolution]                      # kilonerf_mlp.py:146
         gmin, gmax = self._host3(data['global_domain_min']), self._host3(data['global_domain_max'])
         kw = dict(pts=data['pts']) if 'pts' in data else dict(rays_o=data['rays_o'], rays_d=data['rays_d'], z_vals=data['z_vals'])
-        data['raw'] = ops.kilo_mlp_forward(data['viewdirs'], gmin, gmax, fixed_res, self.resolution, self.occupancy_grid,
-                                           self.domain_mins, self.domain_maxs, self.multi_network.packed(),
-                                           self.embedder.multires, self.embedder.multires_dirs,
-                                           self.multi_network.num_hidden_layers, **kw)
+        mn = self.multi_network
+        args = (data['viewdirs'], gmin, gmax, fixed_res, self.resolution, self.occupancy_grid, self.domain_mins,
+                self.domain_maxs)
+        tail = (self.embedder.multires, self.embedder.multires_dirs, mn.num_hidden_layers)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in mn.parameters()):
+            data['raw'] = _KiloMlpFn.apply(args, tail, kw, *mn.ordered_parameters())      # fine-tuning: gradients flow
+        else:
+            data['raw'] = ops.kilo_mlp_forward(*args, mn.packed(), *tail, **kw)
         return data
+
+
+class _KiloMlpFn(torch.autograd.Function):
+    """KiloNerfMLP.forward with parameter gradients (the reference: AddMultiMatMul, multi_modules.py:198-236, six times):
+    one forward call, one backward call (xr_kilo_mlp_backward) that re-runs the tiny MLPs and accumulates the packed
+    gradient blocks; sample positions / directions carry no gradient (they are data)"""
+
+    @staticmethod
+    def forward(ctx, args, tail, kw, *params):
+        packed = MultiNetwork.pack([p.detach() for p in params])
+        ctx.args, ctx.tail, ctx.kw, ctx.packed, ctx.params = args, tail, kw, packed, params
+        return ops.kilo_mlp_forward(*args, packed, *tail, **kw)
+
+    @staticmethod
+    def backward(ctx, draw):
+        g = ops.kilo_mlp_backward(draw.contiguous(), *ctx.args, ctx.packed, *ctx.tail, **ctx.kw)
+        grads = MultiNetwork.unpack_like(g, ctx.params)
+        return (None, None, None) + tuple(grads)
 
 
 @NETWORKS.register_module()
@@ -245,8 +295,28 @@ class KiloNerfNetwork(NerfNetwork):
         self.l2_regularization_lambda = dict(cfg).get('l2_regularization_lambda')
 
     def train_step(self, data, optimizer, **kwargs):
-        raise NotImplementedError('KiloNeRF fine-tuning needs the backward of the grouped tiny-MLP kernel: next step '
-                                  '(this round covers the rendering path the real-time bench measures)')
+        """networks/kilonerf.py:27-58: MSE on the rendered colours + lambda * sum of the L2 norms of the view-dependent
+        parameters (direction layer and rgb head of all networks)"""
+        from .networks import img2mse, mse2psnr, unfold_batching
+        for k in data:
+            data[k] = unfold_batching(data[k])
+        ret = self.forward(data, is_test=False)
+        img_loss = img2mse(ret['rgb'], data['target_s'])
+        psnr = mse2psnr(img_loss)
+        loss = img_loss
+        l2_loss = img_loss.new_zeros(())
+        if self.l2_regularization_lambda is not None:
+            vd = self.mlp.get_view_dependent_parameters()
+            reg = vd[0].norm(2)
+            for p in vd[1:]:
+                reg = reg + p.norm(2)
+            l2_loss = self.l2_regularization_lambda * reg
+            loss = loss + l2_loss
+        if 'coarse_rgb' in ret:
+            loss = loss + img2mse(ret['coarse_rgb'], data['target_s'])
+        # the reference reads three scalars back per iteration (.item()); here they stay on the device until looked at
+        log_vars = {'loss': loss.detach(), 'psnr': psnr.detach(), 'L2 reg': l2_loss.detach()}
+        return {'loss': loss, 'log_vars': log_vars, 'num_samples': ret['rgb'].shape[0]}
 
 
 # ------------------------------------------------------------------ synthetic Lego-shaped scene (bench / smoke / tests)
@@ -317,6 +387,7 @@ def camera_rays(pose, H, W, focal, device):
     return rays_o, rays_d.contiguous(), (rays_d / rays_d.norm(dim=-1, keepdim=True)).contiguous()
 
 
+@torch.no_grad()
 def render_frame(mlp, gmin, gmax, pose, H, W, focal, near=2.0, far=6.0, n_samples=384, white_bkgd=True, rays=None,
                  fused=True):
     """one frame through the reference's test path: rays -> 384 uniform samples (GetZvals, not randomized) ->

@@ -599,6 +599,37 @@ def kilo_mlp_forward(viewdirs, gmin, gmax, fixed_res, occ_res, occupancy, domain
     return (raw, counts) if want_counts else raw
 
 
+def kilo_mlp_backward(draw, viewdirs, gmin, gmax, fixed_res, occ_res, occupancy, domain_mins, domain_maxs, params, pos_freqs,
+                      dir_freqs, n_hidden, pts=None, rays_o=None, rays_d=None, z_vals=None):
+    """gradient of the packed parameter blocks [N, stride] for dL/draw [R,S,4] (same sample arguments as the forward)"""
+    L = _lib.load()
+    draw = _f32c(draw)
+    if pts is not None:
+        pts = _f32c(pts)
+        R, S = pts.shape[0], pts.shape[1]
+    else:
+        rays_o, rays_d, z_vals = _f32c(rays_o), _f32c(rays_d), _f32c(z_vals)
+        R, S = z_vals.shape
+    dev = draw.device
+    N = params.shape[0]
+    grad = torch.zeros_like(params)
+    ws = _ws(dev, L.xr_kilo_workspace_bytes(R * S, N), 'kilo')
+    if occupancy is not None:
+        occupancy = occupancy.reshape(-1)
+        if occupancy.dtype == torch.bool:
+            occupancy = occupancy.view(torch.uint8)
+    f3 = (C.c_float * 3)
+    i3 = (C.c_int32 * 3)
+    with _span('xr_kilo_mlp_backward', R * S):
+        _lib.check(L.xr_kilo_mlp_backward(_ptr(pts), _ptr(rays_o), _ptr(rays_d), _ptr(z_vals), _ptr(_f32c(viewdirs)), R, S,
+                                          f3(*[float(v) for v in gmin]), f3(*[float(v) for v in gmax]),
+                                          i3(*[int(v) for v in fixed_res]), i3(*[int(v) for v in occ_res]) if occ_res is not None else None,
+                                          _ptr(occupancy), _ptr(_f32c(domain_mins)), _ptr(_f32c(domain_maxs)), _ptr(params),
+                                          params.stride(0), N, int(pos_freqs), int(dir_freqs), int(n_hidden), _ptr(draw),
+                                          _ptr(grad), _ptr(ws), ws.numel(), _stream()), 'xr_kilo_mlp_backward')
+    return grad
+
+
 def nerf_render_forward(raw, z_vals, rays_d, white_bkgd):
     """NerfRender.forward (inference): -> rgb [R,3], disp [R], acc [R], weights [R,S]"""
     L = _lib.load()
