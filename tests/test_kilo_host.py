@@ -127,3 +127,21 @@ def test_reference_pickled_distillation_checkpoint_is_read_without_the_reference
                            embedder=emb, trust_pickle=True)
     assert mlp.multi_network.num_networks == 4 and mlp.multi_network.packed().shape == (4, 6248)
     assert torch.equal(mlp.multi_network.rgb_linear.weight[2], dict(c.network.named_modules())['rgb_linear'].weight.detach()[0].t())
+
+
+def test_pack_and_unpack_round_trip_and_parameter_order():
+    """the gradient blocks the backward kernel fills are cut back into per-parameter tensors by unpack_like: it must be the
+    exact inverse of pack, in the order autograd hands the parameters over (= module registration order)"""
+    from xrnerf_amd import kilo
+    for nh, pc, dc in ((2, 63, 27), (1, 9, 3)):
+        mn = kilo.MultiNetwork(5, pc, dc, num_hidden_layers=nh)
+        ps = mn.ordered_parameters()
+        assert [id(p) for p in ps] == [id(p) for p in mn.parameters()]
+        blocks = kilo.MultiNetwork.pack([p.detach() for p in ps])
+        assert torch.equal(blocks, mn.packed())
+        back = kilo.MultiNetwork.unpack_like(blocks, ps)
+        assert len(back) == len(ps) and all(a.shape == b.shape and torch.equal(a, b.detach()) for a, b in zip(back, ps))
+        # padding slots (3 after b_alpha, the 4th rgb column, 1 after b_rgb) are zero in pack and ignored by unpack_like
+        marked = blocks.clone() + 1.0
+        back2 = kilo.MultiNetwork.unpack_like(marked, ps)
+        assert sum(t.numel() for t in back2) == sum(p.numel() for p in ps) == blocks.numel() - 5 * (3 + 32 + 1)
