@@ -1,0 +1,37 @@
+"""TEST INFRASTRUCTURE ONLY: builds tests/hip_emu/_build/libemu_<name>.so = one kernel source of xrnerf_amd/csrc compiled
+for the HOST through the HIP-on-CPU shim (hip/hip_runtime.h + emu.cpp).  The source is used as it is, except that its
+`extern __shared__ T name[];` declarations (no host spelling exists) become `T* name = (T*)emu::dyn_lds();`."""
+import os
+import re
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, 'xrnerf_amd', 'csrc')
+OUT = os.path.join(HERE, '_build')
+CLANG = '/opt/rocm/lib/llvm/bin/clang++'
+
+
+def build(name, extra=()):
+    """name: 'xr_mip' | 'xr_kilo' | 'xr_gemm' -> path of the shared object (rebuilt when a source is newer)"""
+    os.makedirs(OUT, exist_ok=True)
+    src = os.path.join(CSRC, name + '.hip')
+    so = os.path.join(OUT, 'libemu_%s.so' % name)
+    deps = [src, os.path.join(HERE, 'emu.cpp'), os.path.join(HERE, 'hip', 'hip_runtime.h'), os.path.abspath(__file__)]
+    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    if os.path.exists(so) and all(os.path.getmtime(d) <= os.path.getmtime(so) for d in deps):
+        return so
+    text = open(src).read()
+    text, n = re.subn(r'extern\s+__shared__\s+(\w+)\s+(\w+)\s*\[\s*\]\s*;', r'\1* \2 = (\1*)emu::dyn_lds();', text)
+    cpp = os.path.join(OUT, name + '_host.cpp')
+    open(cpp, 'w').write('// generated from %s by tests/hip_emu/build.py (%d dynamic-LDS declarations rewritten)\n' % (src, n) + text)
+    cmd = [CLANG, '-x', 'c++', '-std=c++17', '-O1', '-g0', '-fPIC', '-shared', '-ffp-contract=off', '-Wno-everything',
+           '-I', HERE, '-I', CSRC, cpp, os.path.join(HERE, 'emu.cpp'), '-o', so] + list(extra)
+    subprocess.check_call(cmd)
+    return so
+
+
+if __name__ == '__main__':
+    import sys
+    for n in sys.argv[1:] or ['xr_mip', 'xr_kilo', 'xr_gemm']:
+        print(build(n))

@@ -1,0 +1,99 @@
+// TEST INFRASTRUCTURE ONLY -- a HIP-on-CPU execution shim: the kernel sources of xrnerf_amd/csrc/*.hip are compiled
+// UNCHANGED for the host (clang++ -x c++; this directory first on the include path) and run by tests/hip_emu/emu.cpp,
+// one cooperative fiber per GPU thread, wave64 semantics: __shfl* / __ballot / v_mfma_f32_32x32x2_f32 are collectives
+// over the 64 lanes of a wave, __syncthreads over the workgroup, LDS = ordinary memory shared by the workgroup's fibers.
+// It checks FUNCTION (indexing, collectives, layouts, edge cases) without a GPU; timing means nothing here and libm's
+// sin/exp stand in for ocml's.  Nothing under xrnerf_amd/ includes or links this.
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <type_traits>
+
+#define __HIP_EMU__ 1
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static            /* kernel-local: one instance, workgroups run one after another */
+#ifndef __restrict__
+#define __restrict__ __restrict
+#endif
+
+struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
+struct uint3e { unsigned x, y, z; };
+typedef void* hipStream_t;
+typedef int hipError_t;
+enum { hipSuccess = 0, hipMemcpyDeviceToDevice = 3 };
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
+inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+
+struct float4 { float x, y, z, w; } __attribute__((aligned(16)));
+inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+struct float2 { float x, y; } __attribute__((aligned(8)));
+inline float2 make_float2(float x, float y) { return float2{x, y}; }
+
+namespace emu {
+struct Lane;                               // one GPU thread
+Lane* cur();
+const uint3e& tid(); const uint3e& bid(); const dim3& bdim(); const dim3& gdim();
+void launch(dim3 grid, dim3 block, size_t dyn_lds, const std::function<void()>& body);
+void block_barrier();
+int block_or(int v);
+// wave collectives on raw 64-bit payloads
+uint64_t wave_exchange(uint64_t mine, int src_lane);          // value deposited by lane src_lane (own value if that lane is gone)
+uint64_t wave_ballot(bool pred);
+void wave_mfma_32x32x2(float a, float b, float* c16);
+void* dyn_lds();
+}
+#define threadIdx (emu::tid())
+#define blockIdx (emu::bid())
+#define blockDim (emu::bdim())
+#define gridDim (emu::gdim())
+
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
+    emu::launch((grid), (block), (lds), [=]() { kernel(__VA_ARGS__); })
+
+inline void __syncthreads() { emu::block_barrier(); }
+inline int __syncthreads_or(int v) { return emu::block_or(v); }
+inline void __threadfence_block() {}
+// on the GPU a wave runs in lockstep, so lanes may hand data to each other through LDS with nothing but a scheduling
+// barrier in between; here lanes are separate fibers, so the same spot has to be a real rendezvous
+namespace emu { void wave_barrier(); }
+inline void __builtin_amdgcn_wave_barrier() { emu::wave_barrier(); }
+inline void __builtin_amdgcn_sched_barrier(int) {}
+
+namespace emu {
+template <typename T> inline uint64_t pack(T v) { uint64_t u = 0; static_assert(sizeof(T) <= 8, ""); memcpy(&u, &v, sizeof(T)); return u; }
+template <typename T> inline T unpack(uint64_t u) { T v; memcpy(&v, &u, sizeof(T)); return v; }
+int lane_id();
+}
+template <typename T> inline T __shfl(T v, int src, int width = 64) { (void)width; return emu::unpack<T>(emu::wave_exchange(emu::pack(v), src & 63)); }
+template <typename T> inline T __shfl_up(T v, unsigned d, int width = 64) { (void)width; int l = emu::lane_id(); return emu::unpack<T>(emu::wave_exchange(emu::pack(v), l >= (int)d ? l - (int)d : l)); }
+template <typename T> inline T __shfl_down(T v, unsigned d, int width = 64) { (void)width; int l = emu::lane_id(); return emu::unpack<T>(emu::wave_exchange(emu::pack(v), l + (int)d < 64 ? l + (int)d : l)); }
+template <typename T> inline T __shfl_xor(T v, int m, int width = 64) { (void)width; return emu::unpack<T>(emu::wave_exchange(emu::pack(v), emu::lane_id() ^ m)); }
+inline unsigned long long __ballot(int p) { return emu::wave_ballot(p != 0); }
+
+typedef float emu_f32x16 __attribute__((ext_vector_type(16)));
+inline emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32_emu(float a, float b, emu_f32x16 c, int, int, int) {
+    float t[16];
+    for (int r = 0; r < 16; ++r) t[r] = c[r];
+    emu::wave_mfma_32x32x2(a, b, t);
+    for (int r = 0; r < 16; ++r) c[r] = t[r];
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x2f32 __builtin_amdgcn_mfma_f32_32x32x2f32_emu
+
+// cooperative fibers never pre-empt each other: plain read-modify-write is atomic here
+template <typename T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+inline unsigned atomicAdd(unsigned* p, int v) { unsigned o = *p; *p = o + (unsigned)v; return o; }
+inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+inline float __expf(float x) { return expf(x); }
+inline void sincosf_emu(float x, float* s, float* c) { *s = sinf(x); *c = cosf(x); }

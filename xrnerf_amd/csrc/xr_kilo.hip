@@ -406,6 +406,9 @@ __device__ __forceinline__ void ktile_to_lds(float* __restrict__ T, const f32x16
 }
 // D[k][j] = sum_n tin[k][n] * tdl[j][n]  (n = the wave's 32 samples)
 __device__ __forceinline__ f32x16 kouter(const float* __restrict__ tin, const float* __restrict__ tdl, int col, int hi) {
+    // the tiles were written by the other lanes of this wave: lockstep execution orders those stores before the loads
+    // below; the barrier pins that order for the compiler (and is the rendezvous of the host emulation, tests/hip_emu)
+    __builtin_amdgcn_wave_barrier();
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -551,6 +554,7 @@ __global__ void __launch_bounds__(128) k_kilo_mlp_bwd(KiloBwdArgs b) {
             ktile_to_lds(tin, feat, col, hi);
             ktile_atomic_add(g + o_dir, kouter(tin, tdl, col, hi), KILO_H, KILO_H, KILO_H, col, hi);
             for (int rr = hi; rr < 32; rr += 2) tin[rr * KB_ST + col] = 0.f;     // rows beyond D stay zero
+            __builtin_amdgcn_wave_barrier();                                   // zero fill (all lanes) before the feature rows
             for (int c = 0; c < 3; ++c) kfourier_to_lds(tin + c * (2 * a.dir_freqs + 1) * KB_ST, v[c], a.dir_freqs, col, hi);
             ktile_atomic_add(g + o_dir + KILO_H * KILO_H, kouter(tin, tdl, col, hi), KILO_H, D, KILO_H, col, hi);
             kbias_add(g + o_bd, d, col, hi);
@@ -580,6 +584,7 @@ __global__ void __launch_bounds__(128) k_kilo_mlp_bwd(KiloBwdArgs b) {
             // layer 0 on the Fourier features of the local coordinates: two row tiles of the [P x 32] gradient
             ktile_to_lds(tdl, d, col, hi);
             for (int rr = hi; rr < 64; rr += 2) tin[rr * KB_ST + col] = 0.f;
+            __builtin_amdgcn_wave_barrier();
             for (int c = 0; c < 3; ++c) kfourier_to_lds(tin + c * (2 * a.pos_freqs + 1) * KB_ST, x[c], a.pos_freqs, col, hi);
             ktile_atomic_add(g, kouter(tin, tdl, col, hi), KILO_H, P < 32 ? P : 32, KILO_H, col, hi);
             if (P > 32) ktile_atomic_add(g + 32 * KILO_H, kouter(tin + 32 * KB_ST, tdl, col, hi), KILO_H, P - 32, KILO_H, col, hi);
