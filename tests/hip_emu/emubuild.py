@@ -22,9 +22,10 @@ def build(name, extra=()):
     if os.path.exists(so) and all(os.path.getmtime(d) <= os.path.getmtime(so) for d in deps):
         return so
     text = open(src).read()
-    text, n = re.subn(r'extern\s+__shared__\s+(\w+)\s+(\w+)\s*\[\s*\]\s*;', r'\1* \2 = (\1*)emu::dyn_lds();', text)
+    text, n = re.subn(r'extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?(\w+)\s+(\w+)\s*\[\s*\]\s*;',
+                      r'\1* \2 = (\1*)emu::dyn_lds();', text)
     cpp = os.path.join(OUT, name + '_host.cpp')
-    open(cpp, 'w').write('// generated from %s by tests/hip_emu/build.py (%d dynamic-LDS declarations rewritten)\n' % (src, n) + text)
+    open(cpp, 'w').write('// generated from %s by tests/hip_emu/emubuild.py (%d dynamic-LDS declarations rewritten)\n' % (src, n) + text)
     cmd = [CLANG, '-x', 'c++', '-std=c++17', '-O1', '-g0', '-fPIC', '-shared', '-ffp-contract=off', '-Wno-everything',
            '-I', HERE, '-I', CSRC, cpp, os.path.join(HERE, 'emu.cpp'), '-o', so] + list(extra)
     subprocess.check_call(cmd)

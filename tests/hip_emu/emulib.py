@@ -1,4 +1,4 @@
-"""TEST INFRASTRUCTURE ONLY: ctypes access to the host-compiled kernel sources (tests/hip_emu/build.py).  The entry points
+"""TEST INFRASTRUCTURE ONLY: ctypes access to the host-compiled kernel sources (tests/hip_emu/emubuild.py).  The entry points
 are the C-ABI of include/xrnerf_mi355.h; "device" pointers are numpy buffers."""
 import ctypes as C
 import os
@@ -8,7 +8,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
-import build as _build  # noqa: E402
+import emubuild as _build  # noqa: E402
 
 _libs = {}
 
@@ -42,3 +42,85 @@ def check(rc, L):
     if rc != 0:
         L.xr_last_error.restype = C.c_char_p
         raise RuntimeError('rc=%d: %s' % (rc, L.xr_last_error().decode()))
+
+
+ALL_SOURCES = ('xr_misc', 'xr_grid', 'xr_raymarch', 'xr_encode', 'xr_mlp', 'xr_mip', 'xr_kilo', 'xr_gemm')
+
+
+class MultiLib:
+    """the host-compiled kernel sources behind one handle: libxrnerf_mi355.so is ONE library, here every source is its own
+    shared object (its internal helpers must not be merged by the linker); a symbol is taken from the object that has it"""
+
+    def __init__(self, names=ALL_SOURCES):
+        self._libs = [C.CDLL(_build.build(n)) for n in names]
+        self._cache = {}
+
+    def __getattr__(self, name):
+        if name.startswith('_'):
+            raise AttributeError(name)
+        if name not in self._cache:
+            for L in self._libs:
+                try:
+                    self._cache[name] = getattr(L, name)
+                    break
+                except AttributeError:
+                    continue
+            else:
+                raise AttributeError(name)
+        return self._cache[name]
+
+    def last_errors(self):
+        out = []
+        for L in self._libs:
+            L.xr_last_error.restype = C.c_char_p
+            m = L.xr_last_error()
+            if m:
+                out.append(m.decode())
+        return ' | '.join(out)
+
+
+class emulated_ops:
+    """context manager: xrnerf_amd.ops runs on the HIP-on-CPU shim with HOST torch tensors -- the GPU tests' bodies can then
+    be executed without a GPU (small sizes).  Only for tests: it swaps the library handle of xrnerf_amd._lib and the three
+    device helpers of xrnerf_amd.ops (pointer check, stream, workspace alignment), and restores them on exit."""
+
+    def __enter__(self):
+        import torch
+        from xrnerf_amd import _lib, ops
+        self._lib, self._ops, self._torch = _lib, ops, torch
+        self.saved = (_lib._lib, ops._ptr, ops._stream, ops._ws, _lib.check, dict(ops._workspaces), ops._on_device)
+        ml = MultiLib()
+        for name, (res, args) in _lib.SIGNATURES.items():
+            fn = getattr(ml, name)
+            fn.restype, fn.argtypes = res, args
+        # xr_last_error: one per object
+        _lib._lib = ml
+
+        def ptr(t):
+            if t is None:
+                return None
+            if not t.is_contiguous():
+                raise _lib.XrError('tensor must be contiguous')
+            return C.c_void_p(t.data_ptr())
+
+        def ws(device, nbytes, tag):
+            raw = torch.empty(max(int(nbytes), 256) + 256, dtype=torch.uint8)
+            off = (-raw.data_ptr()) % 256
+            return raw[off:off + max(int(nbytes), 256)]
+
+        def check(rc, what=''):
+            if rc != 0:
+                raise _lib.XrError('%s failed (%d): %s' % (what, rc, ml.last_errors()))
+        ops._ptr, ops._stream, ops._ws, _lib.check, ops._on_device = ptr, (lambda: None), ws, check, (lambda t: True)
+        ops._workspaces.clear()
+        self._sync = torch.cuda.synchronize
+        torch.cuda.synchronize = lambda *a, **k: None          # the GPU tests' bodies call it; everything is synchronous here
+        return torch.device('cpu')
+
+    def __exit__(self, *exc):
+        _lib, ops = self._lib, self._ops
+        self._torch.cuda.synchronize = self._sync
+        _lib._lib, ops._ptr, ops._stream, ops._ws, _lib.check, wsd, ops._on_device = self.saved
+        ops._workspaces.clear()
+        ops._workspaces.update(wsd)
+        return False

@@ -31,6 +31,16 @@ typedef int hipError_t;
 enum { hipSuccess = 0, hipMemcpyDeviceToDevice = 3 };
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
+typedef void* hipEvent_t;
+enum { hipEventDisableTiming = 2, hipStreamNonBlocking = 1, hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+struct hipDeviceProp_t { int multiProcessorCount; char name[64]; };
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { p->multiProcessorCount = 2; return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
+template <typename F> inline hipError_t hipFuncSetAttribute(F, int, int) { return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memmove(d, s, n); return hipSuccess; }
 
@@ -38,6 +48,32 @@ struct float4 { float x, y, z, w; } __attribute__((aligned(16)));
 inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 struct float2 { float x, y; } __attribute__((aligned(8)));
 inline float2 make_float2(float x, float y) { return float2{x, y}; }
+struct float3 { float x, y, z; };
+inline float3 make_float3(float x, float y, float z) { return float3{x, y, z}; }
+struct uint2 { unsigned x, y; } __attribute__((aligned(8)));
+inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+struct uint4 { unsigned x, y, z, w; } __attribute__((aligned(16)));
+inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+struct int2 { int x, y; } __attribute__((aligned(8)));
+struct double2 { double x, y; } __attribute__((aligned(16)));
+inline double2 make_double2(double x, double y) { return double2{x, y}; }
+// HIP's global min / max overloads
+template <typename T> inline T min(T a, T b) { return b < a ? b : a; }
+template <typename T> inline T max(T a, T b) { return a < b ? b : a; }
+inline unsigned min(unsigned a, int b) { return min(a, (unsigned)b); }
+inline unsigned min(int a, unsigned b) { return min((unsigned)a, b); }
+inline unsigned long min(unsigned long a, unsigned b) { return min(a, (unsigned long)b); }
+inline unsigned long min(unsigned a, unsigned long b) { return min((unsigned long)a, b); }
+inline unsigned max(unsigned a, int b) { return max(a, (unsigned)b); }
+inline unsigned max(int a, unsigned b) { return max((unsigned)a, b); }
+// round-to-nearest single operations that must not be contracted (the build uses -ffp-contract=off anyway)
+inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
+inline float __fdiv_rn(float a, float b) { volatile float r = a / b; return r; }
+inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c); }
+inline float __fsqrt_rn(float a) { return sqrtf(a); }
+inline float __frcp_rn(float a) { volatile float r = 1.0f / a; return r; }
 
 namespace emu {
 struct Lane;                               // one GPU thread
@@ -74,10 +110,23 @@ template <typename T> inline uint64_t pack(T v) { uint64_t u = 0; static_assert(
 template <typename T> inline T unpack(uint64_t u) { T v; memcpy(&v, &u, sizeof(T)); return v; }
 int lane_id();
 }
-template <typename T> inline T __shfl(T v, int src, int width = 64) { (void)width; return emu::unpack<T>(emu::wave_exchange(emu::pack(v), src & 63)); }
-template <typename T> inline T __shfl_up(T v, unsigned d, int width = 64) { (void)width; int l = emu::lane_id(); return emu::unpack<T>(emu::wave_exchange(emu::pack(v), l >= (int)d ? l - (int)d : l)); }
-template <typename T> inline T __shfl_down(T v, unsigned d, int width = 64) { (void)width; int l = emu::lane_id(); return emu::unpack<T>(emu::wave_exchange(emu::pack(v), l + (int)d < 64 ? l + (int)d : l)); }
-template <typename T> inline T __shfl_xor(T v, int m, int width = 64) { (void)width; return emu::unpack<T>(emu::wave_exchange(emu::pack(v), emu::lane_id() ^ m)); }
+// HIP semantics with sub-wave groups: `width` consecutive lanes form a group, source lanes are relative to it
+template <typename T> inline T __shfl(T v, int src, int width = 64) {
+    const int l = emu::lane_id(), g0 = l & ~(width - 1);
+    return emu::unpack<T>(emu::wave_exchange(emu::pack(v), g0 + (src & (width - 1))));
+}
+template <typename T> inline T __shfl_up(T v, unsigned d, int width = 64) {
+    const int l = emu::lane_id(), g0 = l & ~(width - 1);
+    return emu::unpack<T>(emu::wave_exchange(emu::pack(v), l - (int)d >= g0 ? l - (int)d : l));
+}
+template <typename T> inline T __shfl_down(T v, unsigned d, int width = 64) {
+    const int l = emu::lane_id(), g0 = l & ~(width - 1);
+    return emu::unpack<T>(emu::wave_exchange(emu::pack(v), l + (int)d < g0 + width ? l + (int)d : l));
+}
+template <typename T> inline T __shfl_xor(T v, int m, int width = 64) {
+    const int l = emu::lane_id(), g0 = l & ~(width - 1), s = l ^ m;
+    return emu::unpack<T>(emu::wave_exchange(emu::pack(v), s < g0 + width && s >= g0 ? s : l));
+}
 inline unsigned long long __ballot(int p) { return emu::wave_ballot(p != 0); }
 
 typedef float emu_f32x16 __attribute__((ext_vector_type(16)));
@@ -93,6 +142,11 @@ inline emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32_emu(float a, float b, emu
 // cooperative fibers never pre-empt each other: plain read-modify-write is atomic here
 template <typename T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 inline unsigned atomicAdd(unsigned* p, int v) { unsigned o = *p; *p = o + (unsigned)v; return o; }
+template <typename T> inline T unsafeAtomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+template <typename T> inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
+template <typename T> inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 inline float __expf(float x) { return expf(x); }

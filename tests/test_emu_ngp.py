@@ -1,0 +1,79 @@
+"""The Instant-NGP hot path's kernels -- xr_raymarch / xr_grid / xr_encode / xr_mlp / xr_misc .hip, the SAME sources the GPU
+library is built from -- executed on the host by the HIP-on-CPU shim (tests/hip_emu) through the unchanged
+`xrnerf_amd.ops` front-end, by re-running the bodies of the GPU parity tests (tests/test_gpu_*.py) at sizes the emulation
+finishes in seconds: K1 bit-exact against the reference's own kernels (single and five cascades, overflow, step cap), K2,
+compositor forward / backward / inference, K6 / K7, hash-grid gather and binned scatter, SH-4, the fully fused fp32-MFMA
+MLP forward and backward, ray generation / Huber / Adam, edge cases.  `emulated_ops` swaps the library handle and the
+device-pointer helpers of `ops` for the duration of this module only; the product never runs like this."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'tests', 'hip_emu'))
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+
+@pytest.fixture(scope='module')
+def edev():
+    import emulib
+    ctx = emulib.emulated_ops()
+    dev = ctx.__enter__()
+    yield dev
+    ctx.__exit__(None, None, None)
+
+
+@pytest.mark.parametrize('n_rays,calls', [(1000, 3), (4096, 1)])
+def test_k1_bit_exact_on_the_host(O, lego, edev, n_rays, calls):
+    import test_gpu_raymarch as T
+    T.test_k1_bit_exact(O, lego, edev, n_rays, calls)
+
+
+def test_k1_cascades_overflow_and_k2_on_the_host(O, lego, edev):
+    import test_gpu_raymarch as T
+    T.test_k1_multi_cascade_bit_exact(O, edev)
+    T.test_k1_overflow_and_k2_clip(O, lego, edev)
+
+
+def test_compositor_on_the_host(O, lego, edev):
+    import test_gpu_raymarch as T
+    T.test_compositor_fwd_bwd_inference(O, lego, edev, 2, 3)          # the config's activations (16-lane groups per ray)
+    T.test_compositor_zero_sample_rays(O, edev)
+
+
+def test_grid_upkeep_raygen_loss_adam_on_the_host(O, lego, edev):
+    import test_gpu_raymarch as T
+    T.test_k6_grid_samples_bit_exact(O, lego, edev)
+    T.test_k7_mark_untrained(O, lego, edev)
+    T.test_gen_rays_huber_adam(O, lego, edev)
+
+
+@pytest.mark.parametrize('n', [1, 31, 4096])
+def test_hashgrid_gather_and_scatter_on_the_host(O, edev, n):
+    import test_gpu_tcnn as T
+    T.test_hashgrid_fwd_bwd(O, edev, n)
+
+
+def test_fused_mlp_on_the_host(O, edev):
+    import test_gpu_tcnn as T
+    T.test_grid_meta_matches_oracle(O, edev)
+    T.test_sh4(O, edev)
+    for n in (1, 32, 33):
+        T.test_nerf_mlp_fwd(O, edev, n)
+    T.test_nerf_mlp_fwd_asymmetric_weights(O, edev)
+    for n in (32, 100):
+        T.test_nerf_mlp_bwd(O, edev, n)
+
+
+def test_edge_cases_on_the_host(O, edev):
+    import test_gpu_edge_cases as T
+    T.test_fully_occupied_grid_hits_the_step_cap(O, edev)
+    T.test_single_ray_and_all_miss(O, edev)
+    T.test_ragged_sample_counts_through_mlp_and_encode(O, edev)
+
+
+def test_emulation_leaves_the_product_untouched(edev):
+    """after this module the product path is back to: no library for host tensors"""
+    from xrnerf_amd import ops
+    assert ops._on_device(__import__('torch').zeros(1)) is True      # inside the emulation window

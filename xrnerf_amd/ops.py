@@ -72,10 +72,16 @@ def _stream():
     return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
 
 
+def _on_device(t):
+    """the one place that decides whether a tensor may be handed to the library (tests/hip_emu swaps it to run the
+    kernels' host build on CPU tensors)"""
+    return t.is_cuda
+
+
 def _ptr(t):
     if t is None:
         return None
-    if not t.is_cuda:
+    if not _on_device(t):
         raise _lib.XrError('xrnerf_amd ops need ROCm device tensors (got a %s tensor): there is no CPU fallback' % t.device)
     if not t.is_contiguous():
         raise _lib.XrError('tensor must be contiguous')
@@ -208,7 +214,7 @@ def mark_untrained_density_grid(focal, xforms, n_elements, resolutions, grid=Non
 
 def splat_grid_samples(mlp_out, indices, padded_width, n_samples, grid_tmp):
     """mlp_out may be a strided [n,1] view: `padded_width` is its row stride in floats."""
-    if not mlp_out.is_cuda:
+    if not _on_device(mlp_out):
         raise _lib.XrError('xrnerf_amd ops need ROCm device tensors: there is no CPU fallback')
     _lib.check(_lib.load().xr_splat_grid_samples(C.c_void_p(mlp_out.data_ptr()), _ptr(indices), padded_width, n_samples,
                                                  _ptr(grid_tmp), _stream()), 'xr_splat_grid_samples')
@@ -264,7 +270,7 @@ def _pos_view(x):
         raise _lib.XrError('positions must be a 2-D float32 tensor with >= 3 columns')
     if x.stride(1) != 1:
         raise _lib.XrError('positions must have unit column stride')
-    if not x.is_cuda:
+    if not _on_device(x):
         raise _lib.XrError('xrnerf_amd ops need ROCm device tensors (got a %s tensor): there is no CPU fallback' % x.device)
     return x, int(x.stride(0))
 
@@ -681,7 +687,7 @@ def kilo_render_rays(rays_o, rays_d, viewdirs, near, far, n_samples, gmin, gmax,
 # ---------------------------------------------------------------- fp32 MFMA linear layers (8x256 NeRF MLP)
 def linear_ok(x, w):
     """shapes / alignment the MFMA kernel takes: fp32 device tensors, K and N multiples of 4"""
-    return (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.dim() == 2
+    return (_on_device(x) and x.dtype == torch.float32 and w.dtype == torch.float32 and x.dim() == 2
             and x.shape[1] % 4 == 0 and w.shape[0] % 4 == 0 and x.shape[0] > 0)
 
 
