@@ -422,18 +422,26 @@ def main():
                                           for k, v in sorted(warm.items(), key=lambda kv: -kv[1][1])},
         }
         out.update(extra)
+        # secondary measurements must never cost the headline line: a failure is reported in place of the numbers
+        def guarded(key, fn):
+            try:
+                out[key] = fn()
+            except Exception as e:  # noqa: BLE001
+                out[key] = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
+
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline()
-            out['cpu_baseline']['host_cores_available'] = os.cpu_count()
-            out['cpu_baseline_vanilla_nerf_config1'] = cpu_vanilla_nerf()
+            guarded('cpu_baseline', cpu_baseline)
+            if 'error' not in out['cpu_baseline']:
+                out['cpu_baseline']['host_cores_available'] = os.cpu_count()
+            guarded('cpu_baseline_vanilla_nerf_config1', cpu_vanilla_nerf)
         if world == 1 and not (args.no_mip and args.no_kilo):
             del tr
             torch.cuda.empty_cache()
         if world == 1 and not args.no_mip:
-            out['mipnerf_config3'] = mipnerf_config3(dev)
+            guarded('mipnerf_config3', lambda: mipnerf_config3(dev))
         if world == 1 and not args.no_kilo:
             torch.cuda.empty_cache()
-            out['kilonerf_config5'] = kilonerf_config5(dev)
+            guarded('kilonerf_config5', lambda: kilonerf_config5(dev))
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()
