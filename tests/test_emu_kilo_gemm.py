@@ -104,7 +104,8 @@ def test_kilo_forward_backward_and_render_on_the_reference_fixture(E, K, gold):
     assert np.array_equal(ok, np.isfinite(disp)) and np.abs(disp[ok] - gold['disp'][ok]).max() <= 1e-5 * max(1.0, np.abs(gold['disp'][ok]).max())
 
 
-def test_fused_frame_call_equals_the_dense_path_on_the_host(E, gold):
+@pytest.mark.parametrize('lindisp', [0, 1])
+def test_fused_frame_call_equals_the_dense_path_on_the_host(E, gold, lindisp):
     """xr_kilo_render_rays (z on the fly, per-ray spans, rows without a network neither written nor read) against
     xr_mip_zvals -> xr_kilo_mlp_forward -> xr_nerf_render_forward, bit for bit, incl. axis-parallel and missing rays"""
     L, Lm = E.lib('xr_kilo'), E.lib('xr_mip')
@@ -125,16 +126,16 @@ def test_fused_frame_call_equals_the_dense_path_on_the_host(E, gold):
               24, 10, 4, 2)
     rgb, disp, acc = np.zeros((R, 3), np.float32), np.zeros(R, np.float32), np.zeros(R, np.float32)
     ws = E.aligned((int(L.xr_kilo_render_workspace_bytes(R, S, 24)),), np.uint8, fill=0xA5)      # garbage: unwritten rows must not matter
-    E.check(L.xr_kilo_render_rays(E.p(o), E.p(d), E.p(d), E.p(near), E.p(far), R, S, 0, *common, 1, E.p(rgb), E.p(disp), E.p(acc), E.p(ws),
+    E.check(L.xr_kilo_render_rays(E.p(o), E.p(d), E.p(d), E.p(near), E.p(far), R, S, lindisp, *common, 1, E.p(rgb), E.p(disp), E.p(acc), E.p(ws),
                                   C.c_size_t(ws.size), None), L)
     z = np.zeros((R, S), np.float32)
-    E.check(Lm.xr_mip_zvals(E.p(near), E.p(far), R, S, 0, None, E.p(z), None), Lm)
+    E.check(Lm.xr_mip_zvals(E.p(near), E.p(far), R, S, lindisp, None, E.p(z), None), Lm)
     raw = E.aligned((R, S, 4))
     ws2 = E.aligned((int(L.xr_kilo_workspace_bytes(C.c_uint64(R * S), 24)),), np.uint8)
     E.check(L.xr_kilo_mlp_forward(None, E.p(o), E.p(d), E.p(z), E.p(d), R, S, *common, E.p(raw), None, E.p(ws2), C.c_size_t(ws2.size), None), L)
     rgb2, disp2, acc2, w2 = np.zeros((R, 3), np.float32), np.zeros(R, np.float32), np.zeros(R, np.float32), np.zeros((R, S), np.float32)
     E.check(L.xr_nerf_render_forward(E.p(raw), E.p(z), E.p(d), R, S, 1, E.p(rgb2), E.p(disp2), E.p(acc2), E.p(w2), None), L)
-    assert (acc2 > 0).mean() > 0.2
+    assert (acc2 > 0).mean() > (0.2 if not lindisp else 0.05)          # sampling in disparity puts fewer samples in the box
     assert np.array_equal(rgb, rgb2) and np.array_equal(acc, acc2) and np.array_equal(np.nan_to_num(disp, nan=-1), np.nan_to_num(disp2, nan=-1))
 
 
