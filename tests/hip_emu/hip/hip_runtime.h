@@ -19,7 +19,7 @@
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
-#define __shared__ static            /* kernel-local: one instance, workgroups run one after another */
+#define __shared__ static thread_local   /* kernel-local: one instance per host thread (a thread runs one workgroup at a time) */
 #ifndef __restrict__
 #define __restrict__ __restrict
 #endif
@@ -128,6 +128,8 @@ template <typename T> inline T __shfl_xor(T v, int m, int width = 64) {
     return emu::unpack<T>(emu::wave_exchange(emu::pack(v), s < g0 + width && s >= g0 ? s : l));
 }
 inline unsigned long long __ballot(int p) { return emu::wave_ballot(p != 0); }
+// value of the wave's lane 0 (the kernels only use it on wave-uniform values, to tell the compiler they ARE uniform)
+inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 
 typedef float emu_f32x16 __attribute__((ext_vector_type(16)));
 inline emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32_emu(float a, float b, emu_f32x16 c, int, int, int) {

@@ -21,7 +21,14 @@ struct GridMeta {
     uint32_t off[EN_MAX_LEVELS + 1];
     int n_levels;
     uint32_t n_sblocks;   // sample blocks per level
-    int order;            // 0: levels of an XCD interleaved, 1: level-major within the XCD
+    int order;            // 0: levels of an XCD interleaved, 1: level-major within the XCD, 2: all XCDs share every
+                          // level, 3: level-major AND work-balanced over the XCDs (hg_balanced_block)
+    uint8_t wsh[EN_MAX_LEVELS];   // order 3: log2 of the relative cost of one sample block of the level
+    uint32_t wsum;                // order 3: sum of the costs of levels [l_min, n_levels)
+    int l_min;                    // order 3: first level this launch covers (lower ones: k_hashgrid_fwd_lds)
+    int nt;                       // non-temporal (L1-bypassing) table loads at the hashed levels
+    int pairs;                    // round-1 gather: 16-B loads for adjacent x-neighbour pairs (divergent)
+    uint32_t n_hashed;            // order 4: levels [n_levels - n_hashed, n_levels) are the hashed list
 };
 
 extern "C" void xr_hashgrid_meta(int n_levels, int log2_hashmap_size, int base_resolution, double per_level_scale,
@@ -49,6 +56,11 @@ __device__ inline uint32_t grid_index(uint32_t cx, uint32_t cy, uint32_t cz, uin
     else index = cx + cy * res + cz * res * res;
     return index % hsize;
 }
+// the same for a power-of-two slice (every hashed level of the usual geometries): `% hsize` is a mask -- no reciprocal
+// multiply pair (quarter rate) and two corrections per corner
+__device__ inline uint32_t grid_index_pow2(uint32_t cx, uint32_t cy, uint32_t cz, uint32_t hmask) {
+    return (cx ^ (cy * 2654435761u) ^ (cz * 805459861u)) & hmask;
+}
 // tcnn's stride loop (`for dim while stride <= hashmap_size`) followed by `if hashmap_size < stride`
 // reduces, for 3-D inputs, to: hashed iff res^3 > hashmap_size (computed on the host side of the
 // launch in 64-bit, passed as a flag bit per level)
@@ -68,21 +80,91 @@ __device__ inline void level_of_block(const GridMeta& gm, uint32_t* level, uint3
     }
 }
 
-__global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_fwd(GridMeta gm, uint32_t hashed_mask, const float* __restrict__ table,
-                                                            const float* __restrict__ x, uint32_t x_stride, uint32_t n,
-                                                            const uint32_t* __restrict__ n_dev, const uint32_t* __restrict__ rows,
-                                                            float* __restrict__ enc_t, uint32_t ld) {
-    uint32_t l, sb;
-    level_of_block(gm, &l, &sb);
-    if (l >= (uint32_t)gm.n_levels) return;
-    if (n_dev) n = min(n, *n_dev);
-    const uint32_t i = sb * EN_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const float scale = gm.scale[l];
-    const uint32_t res = gm.res[l], hsize = gm.off[l + 1] - gm.off[l];
-    const bool hashed = (hashed_mask >> l) & 1;
-    const float2* __restrict__ tab = (const float2*)table + gm.off[l];
-    const float* xp = x + (size_t)(rows ? rows[i] : i) * x_stride;    // optional row indirection (render slices)
+// Order 3.  Measured with order 1 (XCD x owns levels x and x+8): the 11 hashed levels fall 2-2-2-1-1-1-1-1 on the 8
+// XCDs, so three XCDs gather twice as long as the other five and the kernel takes 2 hashed-level times instead of 11/8.
+// Here the (level, sample block) pairs are laid out finest level first, each weighted with its level's relative cost
+// 2^wsh (hashed levels: one L2 line request per corner pair; dense levels: mostly L1 hits), and cut into 8 contiguous
+// pieces of equal weight -- XCD k (= blockIdx % 8, an observation used for speed only) walks piece k in order.  A level
+// is then shared by at most 2-3 XCDs (its 4 MiB slice is loaded into each of their L2s: +20 MB of fills per launch) and
+// every XCD still works on one level at a time.  Sample block s of visiting slot li sits at weighted position
+// p = nsb * P_li + s * w_li; it belongs to XCD k iff k*W <= 8p < (k+1)*W, W = nsb * wsum.  All uniform (scalar) maths.
+__host__ __device__ inline void hg_xcd_segment(const GridMeta& gm, uint32_t k, uint32_t nsb, uint64_t P, uint32_t sh,
+                                               uint32_t* s_lo, uint32_t* s_hi) {
+    const uint64_t W = (uint64_t)nsb * gm.wsum, base8 = 8ull * P * nsb, lo = (uint64_t)k * W, hi = lo + W;
+    const uint32_t q = 3u + sh;
+    const uint64_t a = lo > base8 ? (lo - base8 + ((1ull << q) - 1)) >> q : 0ull;
+    const uint64_t b = hi > base8 ? (hi - base8 + ((1ull << q) - 1)) >> q : 0ull;
+    *s_lo = (uint32_t)(a < nsb ? a : nsb);
+    *s_hi = (uint32_t)(b < nsb ? b : nsb);
+}
+// -> false when block j of XCD k has no work
+__host__ __device__ inline bool hg_balanced_block(const GridMeta& gm, uint32_t k, uint32_t j, uint32_t nsb, uint32_t* level,
+                                                  uint32_t* sblock) {
+    uint64_t P = 0;
+    for (int l = gm.n_levels - 1; l >= gm.l_min; --l) {
+        uint32_t s_lo, s_hi;
+        hg_xcd_segment(gm, k, nsb, P, gm.wsh[l], &s_lo, &s_hi);
+        const uint32_t cnt = s_hi - s_lo;
+        if (j < cnt) { *level = (uint32_t)l; *sblock = s_lo + j; return true; }
+        j -= cnt;
+        P += 1ull << gm.wsh[l];
+    }
+    return false;
+}
+// Order 4.  What order 3 measured (profiles/r02_microbench_hash_a.txt): run time = (sample blocks of the busiest XCD) x
+// ~44 us per 1012 blocks, the same for dense and hashed blocks -- every block costs the same texture-address time -- while
+// the L2 request load (4 line requests per hashed sample-level, next to none at the dense levels) is what differs.  So:
+// the same NUMBER of blocks on every XCD, and the hashed levels' blocks spread evenly: the (level, sample block) pairs of
+// the hashed levels [n_levels - n_hashed, n_levels), finest first, are cut into 8 equal pieces, the dense levels' pairs
+// likewise; XCD k walks its hashed piece, then its dense piece.
+__host__ __device__ inline bool hg_twolist_block(const GridMeta& gm, uint32_t k, uint32_t j, uint32_t nsb, uint32_t* level,
+                                                 uint32_t* sblock) {
+    const uint32_t nl = (uint32_t)(gm.n_levels - gm.l_min), nh = gm.n_hashed < nl ? gm.n_hashed : nl, nd = nl - nh;
+    // list of m levels x nsb blocks cut at multiples of m*nsb/8 (rounded up): piece k = [k*T/8, (k+1)*T/8)
+    const uint64_t Th = (uint64_t)nh * nsb, Td = (uint64_t)nd * nsb;
+    const uint64_t h0 = (Th * k + 7) / 8, h1 = (Th * (k + 1) + 7) / 8;
+    uint64_t e;
+    if (j < h1 - h0) {
+        e = h0 + j;
+        *level = (uint32_t)gm.n_levels - 1u - (uint32_t)(e / nsb);
+    } else {
+        const uint64_t d0 = (Td * k + 7) / 8, d1 = (Td * (k + 1) + 7) / 8;
+        const uint64_t jj = j - (h1 - h0);
+        if (jj >= d1 - d0) return false;
+        e = d0 + jj;
+        *level = (uint32_t)gm.n_levels - 1u - nh - (uint32_t)(e / nsb);
+    }
+    *sblock = (uint32_t)(e % nsb);
+    return true;
+}
+static uint32_t hg_balanced_blocks_per_xcd(const GridMeta& gm, uint32_t nsb) {
+    uint32_t mx = 0;
+    for (uint32_t k = 0; k < 8; ++k) {
+        uint64_t P = 0; uint32_t c = 0;
+        for (int l = gm.n_levels - 1; l >= gm.l_min; --l) {
+            uint32_t s_lo, s_hi;
+            hg_xcd_segment(gm, k, nsb, P, gm.wsh[l], &s_lo, &s_hi);
+            c += s_hi - s_lo; P += 1ull << gm.wsh[l];
+        }
+        mx = c > mx ? c : mx;
+    }
+    return mx + (uint32_t)gm.n_levels;      // the device recomputes with n_dev <= n: at most one block more per level
+}
+
+typedef float hg_f4 __attribute__((ext_vector_type(4)));
+typedef float hg_f2 __attribute__((ext_vector_type(2)));
+template <bool NT> __device__ inline float4 hg_ld4(const float2* p) {
+    if (NT) { const hg_f4 r = __builtin_nontemporal_load(reinterpret_cast<const hg_f4*>(p)); return make_float4(r.x, r.y, r.z, r.w); }
+    return *reinterpret_cast<const float4*>(p);
+}
+template <bool NT> __device__ inline float2 hg_ld2(const float2* p) {
+    if (NT) { const hg_f2 r = __builtin_nontemporal_load(reinterpret_cast<const hg_f2*>(p)); return make_float2(r.x, r.y); }
+    return *p;
+}
+
+// one (sample, level): 8 corners as 4 x-neighbour pairs -> the level's two features
+template <bool NT, bool POW2, bool PAIRS> __device__ inline void hg_sample_level(const float2* __restrict__ tab, const float* xp, float scale, uint32_t res,
+                                                                      uint32_t hsize, bool hashed, float* r0_, float* r1_) {
     float w[3]; uint32_t g[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
@@ -90,21 +172,27 @@ __global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_fwd(GridMeta gm, uint32_t
         const float f = floorf(p);
         g[d] = (uint32_t)(int)f; w[d] = p - f;
     }
-    // The two x-neighbours of a (y,z) corner pair are adjacent table entries whenever their indices differ
-    // only in bit 0 (dense levels with an even index, hashed levels with an even x: idx ^ 1): one 16-B
-    // load then serves both corners -- 6 instead of 8 cache-line lookups per sample-level on average.
+    // PAIRS (the round-1 kernel): the two x-neighbours of a (y,z) corner pair are adjacent table entries whenever their
+    // indices differ only in bit 0 (dense levels with an even index, hashed levels with an even x: idx ^ 1), and one
+    // 16-B load then serves both corners.  Measured (rocprofv3 PMC, profiles/r02_pmc_hashgrid_fwd_v0_round1_kernel.txt):
+    // the kernel is bound by the texture-address path, ~1 lane-access per clock and CU (TCP_TOTAL_ACCESSES 55.8 M over
+    // 256 CUs x 219 K cycles) -- an issued vector-memory instruction costs its 16 cycles per dword of width whatever its
+    // exec mask, and the adjacent / not-adjacent branch is divergent in nearly every wave, so each pair pays one
+    // dwordx4 AND two dwordx2 (128 cycles) instead of two dwordx2 (64).  Default now: eight plain 8-B loads, issued
+    // together; the second load of a pair finds its line in L1 (or merges with the pending miss) 15 times out of 16.
     float v0x[4], v0y[4], v1x[4], v1y[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const uint32_t gy = g[1] + (p & 1), gz = g[2] + (p >> 1);
-        const uint32_t i0 = grid_index(g[0], gy, gz, res, hsize, hashed), i1 = grid_index(g[0] + 1, gy, gz, res, hsize, hashed);
-        if ((i0 ^ i1) == 1u) {
-            const float4 q = *reinterpret_cast<const float4*>(tab + (i0 & ~1u));
+        const uint32_t i0 = POW2 ? grid_index_pow2(g[0], gy, gz, hsize - 1u) : grid_index(g[0], gy, gz, res, hsize, hashed);
+        const uint32_t i1 = POW2 ? grid_index_pow2(g[0] + 1, gy, gz, hsize - 1u) : grid_index(g[0] + 1, gy, gz, res, hsize, hashed);
+        if (PAIRS && (i0 ^ i1) == 1u) {
+            const float4 q = hg_ld4<NT>(tab + (i0 & ~1u));
             const bool odd = i0 & 1u;
             v0x[p] = odd ? q.z : q.x; v0y[p] = odd ? q.w : q.y;
             v1x[p] = odd ? q.x : q.z; v1y[p] = odd ? q.y : q.w;
         } else {
-            const float2 a = tab[i0], b = tab[i1];
+            const float2 a = hg_ld2<NT>(tab + i0), b = hg_ld2<NT>(tab + i1);
             v0x[p] = a.x; v0y[p] = a.y; v1x[p] = b.x; v1y[p] = b.y;
         }
     }
@@ -116,8 +204,85 @@ __global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_fwd(GridMeta gm, uint32_t
         const float vx = (c & 1) ? v1x[p] : v0x[p], vy = (c & 1) ? v1y[p] : v0y[p];
         r0 += wt * vx; r1 += wt * vy;
     }
+    *r0_ = r0; *r1_ = r1;
+}
+
+__global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_fwd(GridMeta gm, uint32_t hashed_mask, const float* __restrict__ table,
+                                                            const float* __restrict__ x, uint32_t x_stride, uint32_t n,
+                                                            const uint32_t* __restrict__ n_dev, const uint32_t* __restrict__ rows,
+                                                            float* __restrict__ enc_t, uint32_t ld) {
+    uint32_t l, sb;
+    if (n_dev) n = min(n, *n_dev);
+    if (gm.order == 4) {
+        if (!hg_twolist_block(gm, blockIdx.x & 7u, blockIdx.x >> 3, (n + EN_BLOCK - 1) / EN_BLOCK, &l, &sb)) return;
+    } else if (gm.order == 3) {
+        if (!hg_balanced_block(gm, blockIdx.x & 7u, blockIdx.x >> 3, (n + EN_BLOCK - 1) / EN_BLOCK, &l, &sb)) return;
+    } else {
+        level_of_block(gm, &l, &sb);
+        if (l >= (uint32_t)gm.n_levels) return;
+    }
+    const uint32_t i = sb * EN_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float scale = gm.scale[l];
+    const uint32_t res = gm.res[l], hsize = gm.off[l + 1] - gm.off[l];
+    const bool hashed = (hashed_mask >> l) & 1;
+    const float2* __restrict__ tab = (const float2*)table + gm.off[l];
+    const float* xp = x + (size_t)(rows ? rows[i] : i) * x_stride;    // optional row indirection (render slices)
+    float r0, r1;
+    const bool pow2 = hashed && (hsize & (hsize - 1u)) == 0u;           // uniform for the block
+    if (gm.pairs) {
+        if (pow2) hg_sample_level<false, true, true>(tab, xp, scale, res, hsize, hashed, &r0, &r1);
+        else hg_sample_level<false, false, true>(tab, xp, scale, res, hsize, hashed, &r0, &r1);
+    } else if (pow2 && gm.nt) hg_sample_level<true, true, false>(tab, xp, scale, res, hsize, hashed, &r0, &r1);
+    else if (pow2) hg_sample_level<false, true, false>(tab, xp, scale, res, hsize, hashed, &r0, &r1);
+    else hg_sample_level<false, false, false>(tab, xp, scale, res, hsize, hashed, &r0, &r1);
     enc_t[(size_t)(2 * l) * ld + i] = r0;
     enc_t[(size_t)(2 * l + 1) * ld + i] = r1;
+}
+
+// The coarsest levels from LDS (north_star: "LDS staging of per-level feature tiles").  Levels [0, n_lds) -- at the
+// config's geometry levels 0 and 1, 4096 + 12168 entries = 127 KiB -- are copied into the workgroup's LDS with
+// coalesced 16-B loads, then every thread gathers its samples' corners with ds_read_b64 (2 LDS cycles per 64
+// conflict-free lanes, against one L1 tag lookup per distinct line).  One workgroup per CU, grid-strided over samples.
+#define EN_LDS_THREADS 1024
+__global__ __launch_bounds__(EN_LDS_THREADS) void k_hashgrid_fwd_lds(GridMeta gm, int n_lds, const float* __restrict__ table,
+                                                                      const float* __restrict__ x, uint32_t x_stride, uint32_t n,
+                                                                      const uint32_t* __restrict__ n_dev, const uint32_t* __restrict__ rows,
+                                                                      float* __restrict__ enc_t, uint32_t ld) {
+    extern __shared__ __attribute__((aligned(16))) float2 s_tab[];
+    if (n_dev) n = min(n, *n_dev);
+    if (blockIdx.x * EN_LDS_THREADS >= n) return;
+    const uint32_t n_ent = gm.off[n_lds];                       // entries of levels [0, n_lds); a multiple of 8
+    {
+        const float4* __restrict__ src = reinterpret_cast<const float4*>(table);
+        float4* dst = reinterpret_cast<float4*>(s_tab);
+        for (uint32_t e = threadIdx.x; e < n_ent / 2; e += EN_LDS_THREADS) dst[e] = src[e];
+    }
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * EN_LDS_THREADS + threadIdx.x; i < n; i += gridDim.x * EN_LDS_THREADS) {
+        const float* xp = x + (size_t)(rows ? rows[i] : i) * x_stride;
+        const float x0 = xp[0], x1 = xp[1], x2 = xp[2];
+        for (int l = 0; l < n_lds; ++l) {
+            const float scale = gm.scale[l];
+            const uint32_t res = gm.res[l];
+            const float2* tab = s_tab + gm.off[l];
+            const float p0 = x0 * scale + 0.5f, p1 = x1 * scale + 0.5f, p2 = x2 * scale + 0.5f;
+            const float f0 = floorf(p0), f1 = floorf(p1), f2 = floorf(p2);
+            const uint32_t g0 = (uint32_t)(int)f0, g1 = (uint32_t)(int)f1, g2 = (uint32_t)(int)f2;
+            const float w0 = p0 - f0, w1 = p1 - f1, w2 = p2 - f2;
+            const uint32_t hsize = gm.off[l + 1] - gm.off[l];
+            float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {    // the oracle's order: corner 0..7, x fastest
+                const uint32_t idx = grid_index(g0 + (c & 1), g1 + ((c >> 1) & 1), g2 + (c >> 2), res, hsize, false);
+                const float2 v = tab[idx];
+                const float wt = ((c & 1) ? w0 : 1.f - w0) * ((c & 2) ? w1 : 1.f - w1) * ((c & 4) ? w2 : 1.f - w2);
+                r0 += wt * v.x; r1 += wt * v.y;
+            }
+            enc_t[(size_t)(2 * l) * ld + i] = r0;
+            enc_t[(size_t)(2 * l + 1) * ld + i] = r1;
+        }
+    }
 }
 
 // Scatter-add of the feature gradients.
@@ -315,7 +480,7 @@ __global__ __launch_bounds__(SC_THREADS) void k_scatter_bin(GridMeta gm, uint32_
 // 62 us per partition.)  So the partition is accumulated in DOUBLE with returnless ds_add_f64 -- more accurate
 // than the fp32 atomics of the other path -- and rounded to fp32 once, when it is added to the table.
 #ifdef SC_TIMING
-__device__ long long g_sc_t[8];
+__device__ long long g_sc_t[24];
 #define SC_T(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_sc_t[k] = wall_clock64(); } while (0)
 #else
 #define SC_T(k)
@@ -388,6 +553,232 @@ __global__ __launch_bounds__(SC_ACC_THREADS) void k_scatter_accum(GridMeta gm, u
     SC_T(4);
 }
 
+// ---- second generation of the bin / accumulate pair (XR_SC_MODE=1, default) ---------------------------------------
+// Measured on the first pair (rocprofv3, 2^18 samples, 11 hashed levels): k_scatter_bin 90 us, of which 16 us without
+// its item stores -- 11.5 M scattered 16-B stores, each its own L2 write request into a partially written line -- and
+// k_scatter_accum 140 us reading sub-bins that are half empty by construction (capacity 2x the expected fill, lanes
+// past the fill idle in the loads AND in the LDS atomics).  Here:
+//   A' k_scatter_bin2   512 threads, the workgroup's 4096 samples in 4 rounds of 1024: the round's <= 4096 items are
+//      ranked per partition with LDS counters, placed in LDS in partition order (64 KiB), and copied out as contiguous
+//      runs (~64 items = 1 KiB per partition and round): full 16-B-per-lane coalesced stores.  Two workgroups per CU.
+//   B' k_scatter_accum2 sub-bin capacity 1.25x the expected fill; a wave walks whole sub-bins in 64-item chunks,
+//      so only a sub-bin's last chunk has idle lanes; 8 chunk loads in flight per lane while the previous 8 are
+//      accumulated.
+#define SB_THREADS 512
+#define SB_SPT 2
+#define SB_ROUND_SAMPLES (SB_THREADS * SB_SPT)
+#define SB_ROUND_ITEMS (4 * SB_ROUND_SAMPLES)
+#define SB_ROUNDS (SC_BLOCK_SAMPLES / SB_ROUND_SAMPLES)
+#define SC_SUB_ITEMS2 (5u * SC_BLOCK_SAMPLES)      // items of all sub-bins of one (workgroup, level): 1.25x the 4 pairs per sample
+
+__global__ __launch_bounds__(SB_THREADS) void k_scatter_bin2(GridMeta gm, uint32_t l_lo, uint32_t l_hi, uint32_t parts, uint32_t nsb,
+                                                             const float* __restrict__ x, uint32_t x_stride,
+                                                             const float* __restrict__ denc_t, uint32_t ld, uint32_t n,
+                                                             const uint32_t* __restrict__ n_dev, uint32_t* __restrict__ counts,
+                                                             float4* __restrict__ bins, float* __restrict__ grad_table) {
+    __shared__ float4 s_items[SB_ROUND_ITEMS];
+    __shared__ uint8_t s_ipart[SB_ROUND_ITEMS];
+    __shared__ uint32_t s_cnt[SC_MAX_PARTS], s_off[SC_MAX_PARTS + 1], s_base[SC_MAX_PARTS];
+    const uint32_t nl = l_hi - l_lo;
+    const uint32_t l = l_hi - 1 - blockIdx.x % nl, sb = blockIdx.x / nl;   // finest first; the levels of one sample block are neighbours
+    if (n_dev) n = min(n, *n_dev);
+    const uint32_t b0 = sb * SC_BLOCK_SAMPLES;
+    const uint32_t cap = SC_SUB_ITEMS2 / parts;                             // capacity of one sub-bin
+    uint32_t* __restrict__ cnt_out = counts + ((size_t)(l - l_lo) * parts) * nsb + sb;      // [level][part][sample block]
+    if (b0 >= n) {                                                          // uniform: an empty sample block has empty sub-bins
+        for (uint32_t p = threadIdx.x; p < parts; p += SB_THREADS) cnt_out[(size_t)p * nsb] = 0;
+        return;
+    }
+    for (uint32_t p = threadIdx.x; p < parts; p += SB_THREADS) s_base[p] = 0;
+    const float scale = gm.scale[l];
+    const uint32_t hsize = gm.off[l + 1] - gm.off[l], hmask = hsize - 1;    // power of two (checked on the host)
+    const float* __restrict__ d0p = denc_t + (size_t)(2 * l) * ld;
+    const float* __restrict__ d1p = d0p + ld;
+    float* __restrict__ tab = grad_table + 2 * (size_t)gm.off[l];
+    float4* __restrict__ out = bins + (size_t)(l - l_lo) * nsb * SC_SUB_ITEMS2 + (size_t)sb * cap;
+    const uint32_t per = (parts + 63u) / 64u;                               // partitions per lane in the offset scan (<= 4)
+    for (uint32_t r = 0; r < SB_ROUNDS; ++r) {
+        const uint32_t rb0 = b0 + r * SB_ROUND_SAMPLES;
+        if (rb0 >= n) break;                                                // uniform
+        if (r == 0) SC_T(8);
+        for (uint32_t p = threadIdx.x; p < parts; p += SB_THREADS) s_cnt[p] = 0;
+        __syncthreads();
+        float ld0[SB_SPT], ld1[SB_SPT], lx0[SB_SPT], lx1[SB_SPT], lx2[SB_SPT];
+#pragma unroll
+        for (uint32_t s = 0; s < SB_SPT; ++s) {
+            const uint32_t i = min(rb0 + s * SB_THREADS + threadIdx.x, n - 1);
+            const float* xp = x + (size_t)i * x_stride;
+            ld0[s] = d0p[i]; ld1[s] = d1p[i]; lx0[s] = xp[0]; lx1[s] = xp[1]; lx2[s] = xp[2];
+        }
+        uint32_t ipart[SB_SPT * 4], irank[SB_SPT * 4], ipr[SB_SPT * 4];
+        float iva[SB_SPT * 4], ivb[SB_SPT * 4], iw0[SB_SPT];
+        bool live[SB_SPT];
+#pragma unroll
+        for (uint32_t s = 0; s < SB_SPT; ++s) {
+            const uint32_t i = rb0 + s * SB_THREADS + threadIdx.x;
+            const float d0 = ld0[s], d1 = ld1[s];
+            live[s] = i < n && !(d0 == 0.f && d1 == 0.f);                   // rows behind the compositor's early stop add nothing
+            if (!live[s]) continue;
+            const float p0 = lx0[s] * scale + 0.5f, p1 = lx1[s] * scale + 0.5f, p2 = lx2[s] * scale + 0.5f;
+            const float f0 = floorf(p0), f1 = floorf(p1), f2 = floorf(p2);
+            const uint32_t g0 = (uint32_t)(int)f0, g1 = (uint32_t)(int)f1, g2 = (uint32_t)(int)f2;
+            const float w0 = p0 - f0, w1 = p1 - f1, w2 = p2 - f2;
+            const uint32_t a0 = g1 * 2654435761u, b0h = g2 * 805459861u;
+            iw0[s] = w0;
+#pragma unroll
+            for (uint32_t c = 0; c < 4; ++c) {
+                const uint32_t cy = c & 1u, cz = c >> 1, k = s * 4 + c;
+                const uint32_t h = (a0 + (cy ? 2654435761u : 0u)) ^ (b0h + (cz ? 805459861u : 0u));
+                const uint32_t i0 = (g0 ^ h) & hmask, i1 = ((g0 + 1u) ^ h) & hmask;
+                const uint32_t part = i0 >> SC_LOG2;                        // == i1 >> SC_LOG2
+                const float wyz = (cy ? w1 : 1.f - w1) * (cz ? w2 : 1.f - w2);
+                iva[k] = wyz * d0; ivb[k] = wyz * d1;
+                ipart[k] = part;
+                ipr[k] = (i0 & (SC_ENTRIES - 1)) | ((i1 & (SC_ENTRIES - 1)) << SC_LOG2);
+                irank[k] = atomicAdd(&s_cnt[part], 1u);
+            }
+        }
+        if (r == 0) SC_T(9);
+        __syncthreads();
+        if (r == 0) SC_T(10);
+        if (threadIdx.x < 64) {                                             // exclusive scan of the round's partition counts
+            uint32_t loc[4], sum = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) {
+                const uint32_t idx = threadIdx.x * per + q;
+                loc[q] = sum;
+                if (q < per && idx < parts) sum += s_cnt[idx];
+            }
+            uint32_t incl = sum;
+#pragma unroll
+            for (uint32_t d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d);
+                if (threadIdx.x >= d) incl += o;
+            }
+            const uint32_t excl = incl - sum;
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) {
+                const uint32_t idx = threadIdx.x * per + q;
+                if (q < per && idx < parts) s_off[idx] = excl + loc[q];
+            }
+            if (threadIdx.x == 63) s_off[parts] = incl;
+        }
+        __syncthreads();
+        if (r == 0) SC_T(11);
+#pragma unroll
+        for (uint32_t s = 0; s < SB_SPT; ++s) {
+            if (!live[s]) continue;
+#pragma unroll
+            for (uint32_t c = 0; c < 4; ++c) {
+                const uint32_t k = s * 4 + c, q = s_off[ipart[k]] + irank[k];
+                s_items[q] = make_float4(__uint_as_float(ipr[k]), iva[k], ivb[k], iw0[s]);
+                s_ipart[q] = (uint8_t)ipart[k];
+            }
+        }
+        __syncthreads();
+        if (r == 0) SC_T(12);
+        const uint32_t total = s_off[parts];
+        for (uint32_t q = threadIdx.x; q < total; q += SB_THREADS) {
+            const uint32_t p = s_ipart[q], rk = q - s_off[p] + s_base[p];
+            const float4 it = s_items[q];
+            if (rk < cap) {
+                out[(size_t)p * nsb * cap + rk] = it;
+            } else {                                                        // overfull sub-bin: scatter this pair directly
+                const uint32_t pr = __float_as_uint(it.x);
+                const uint32_t i0 = (pr & (SC_ENTRIES - 1)) | (p << SC_LOG2), i1 = (pr >> SC_LOG2) | (p << SC_LOG2);
+                unsafeAtomicAdd(tab + 2 * (size_t)i0, (1.f - it.w) * it.y);
+                unsafeAtomicAdd(tab + 2 * (size_t)i0 + 1, (1.f - it.w) * it.z);
+                unsafeAtomicAdd(tab + 2 * (size_t)i1, it.w * it.y);
+                unsafeAtomicAdd(tab + 2 * (size_t)i1 + 1, it.w * it.z);
+            }
+        }
+        if (r == 0) SC_T(13);
+        __syncthreads();
+        if (r == 0) SC_T(14);
+        for (uint32_t p = threadIdx.x; p < parts; p += SB_THREADS) s_base[p] += s_cnt[p];
+    }
+    SC_T(15);
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < parts; p += SB_THREADS) cnt_out[(size_t)p * nsb] = min(s_base[p], cap);
+}
+
+__global__ __launch_bounds__(SC_ACC_THREADS) void k_scatter_accum2(GridMeta gm, uint32_t l_lo, uint32_t l_hi, uint32_t parts, uint32_t nsb,
+                                                               const uint32_t* __restrict__ counts, const float4* __restrict__ bins,
+                                                               float* __restrict__ grad_table) {
+    extern __shared__ __attribute__((aligned(16))) double s_acc[];       // [SC_ENTRIES][2]
+    const uint32_t li = blockIdx.x / parts, part = blockIdx.x % parts, l = l_lo + li;
+    const uint32_t hsize = gm.off[l + 1] - gm.off[l];
+    if (part >= (hsize >> SC_LOG2)) return;
+    const uint32_t cap = SC_SUB_ITEMS2 / parts;
+    const uint32_t* __restrict__ cnt = counts + ((size_t)li * parts + part) * nsb;
+    double2* acc2 = reinterpret_cast<double2*>(s_acc);
+    SC_T(16);
+    __shared__ uint32_t s_fill[SC_MAX_SB];                                  // fill counts of this unit's sub-bins
+    for (uint32_t e = threadIdx.x; e < nsb; e += SC_ACC_THREADS) s_fill[e] = cnt[e];
+    for (uint32_t e = threadIdx.x; e < SC_ENTRIES; e += SC_ACC_THREADS) acc2[e] = make_double2(0.0, 0.0);
+    __syncthreads();
+    SC_T(17);
+    // the unit's sub-bins: [sample block][cap] contiguous; wave w takes sub-bins w, w + W, ... in 64-item chunks
+    const float4* __restrict__ src = bins + (size_t)li * nsb * SC_SUB_ITEMS2 + (size_t)part * nsb * cap;
+    constexpr uint32_t U = 8, WAVES = SC_ACC_THREADS / 64;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), c = 0;   // next (sub-bin, chunk) of this wave: scalar
+    while (s < nsb && s_fill[s] == 0) s += WAVES;
+    float4 nx[U];
+    bool non[U];
+    auto fetch = [&]() {
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+            non[u] = false;
+            if (s < nsb) {
+                const uint32_t fill = s_fill[s], off = c * 64u + lane;
+                non[u] = off < fill;
+                if (non[u]) nx[u] = src[(size_t)s * cap + off];
+                ++c;
+                if (c * 64u >= fill) {
+                    c = 0; s += WAVES;
+                    while (s < nsb && s_fill[s] == 0) s += WAVES;
+                }
+            }
+        }
+    };
+    fetch();
+    for (;;) {
+        float4 it[U];
+        bool on[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) { it[u] = nx[u]; on[u] = non[u]; }
+        const bool more = s < nsb;                                           // uniform per wave
+        if (more) fetch();
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+            if (!on[u]) continue;
+            const uint32_t pr = __float_as_uint(it[u].x), i0 = pr & (SC_ENTRIES - 1), i1 = pr >> SC_LOG2;
+            const float w0 = it[u].w, a = it[u].y, b = it[u].z;
+            atomicAdd(&s_acc[2 * i0], (double)((1.f - w0) * a));
+            atomicAdd(&s_acc[2 * i0 + 1], (double)((1.f - w0) * b));
+            atomicAdd(&s_acc[2 * i1], (double)(w0 * a));
+            atomicAdd(&s_acc[2 * i1 + 1], (double)(w0 * b));
+        }
+        if (!more) break;
+    }
+    SC_T(18);
+    __syncthreads();
+    SC_T(19);
+    float2* __restrict__ dst = reinterpret_cast<float2*>(grad_table + 2 * ((size_t)gm.off[l] + (size_t)part * SC_ENTRIES));
+    constexpr uint32_t F = SC_ENTRIES / SC_ACC_THREADS;                         // all F loads in flight before the first add
+    float2 t[F];
+#pragma unroll
+    for (uint32_t k = 0; k < F; ++k) t[k] = dst[k * SC_ACC_THREADS + threadIdx.x];
+#pragma unroll
+    for (uint32_t k = 0; k < F; ++k) {
+        const double2 a = acc2[k * SC_ACC_THREADS + threadIdx.x];
+        t[k].x += (float)a.x; t[k].y += (float)a.y;
+        dst[k * SC_ACC_THREADS + threadIdx.x] = t[k];
+    }
+    SC_T(20);
+}
+
 __global__ __launch_bounds__(256) void k_reduce_replicas(const float4* __restrict__ rep, uint32_t n_rep, uint32_t stride4, uint32_t count4,
                                                          float4* __restrict__ grad_table) {
     const uint32_t e = blockIdx.x * 256 + threadIdx.x;
@@ -404,6 +795,8 @@ static int fill_meta(GridMeta* gm, uint32_t* hashed_mask, int n_levels, const fl
                      const uint32_t* off) {
     if (n_levels < 1 || n_levels > EN_MAX_LEVELS || !scale || !res || !off) return -1;
     gm->n_levels = n_levels;
+    gm->l_min = 0; gm->nt = 0; gm->wsum = 0; gm->n_sblocks = 0; gm->pairs = 0; gm->n_hashed = 0;
+    memset(gm->wsh, 0, sizeof(gm->wsh));
     *hashed_mask = 0;
     for (int l = 0; l < n_levels; ++l) {
         gm->scale[l] = scale[l]; gm->res[l] = res[l]; gm->off[l] = off[l];
@@ -418,6 +811,7 @@ static int fill_meta(GridMeta* gm, uint32_t* hashed_mask, int n_levels, const fl
     return 0;
 }
 
+static int scatter_env(const char* name, int dflt);
 extern "C" int xr_hashgrid_fwd(const float* table, const float* x, uint32_t x_stride, uint32_t n, const uint32_t* n_dev,
                                const uint32_t* rows, int n_levels, const float* scale_host, const uint32_t* resolution_host,
                                const uint32_t* offset_host, float* enc_t, uint32_t ld, void* stream_) {
@@ -427,10 +821,66 @@ extern "C" int xr_hashgrid_fwd(const float* table, const float* x, uint32_t x_st
     XR_REQUIRE(((uintptr_t)table & 15) == 0, "table must be 16-byte aligned");
     GridMeta gm; uint32_t hm;
     XR_REQUIRE(fill_meta(&gm, &hm, n_levels, scale_host, resolution_host, offset_host) == 0, "bad level metadata");
-    const uint32_t per_xcd = (n_levels + 7) / 8;
-    gm.n_sblocks = xr_div_up(n, EN_BLOCK);
-    const uint32_t blocks = 8 * per_xcd * xr_div_up(n, EN_BLOCK);
-    hipLaunchKernelGGL(k_hashgrid_fwd, dim3(blocks), dim3(EN_BLOCK), 0, (hipStream_t)stream_, gm, hm, table, x, x_stride, n,
+    hipStream_t stream = (hipStream_t)stream_;
+    // XR_HG_FWD_MODE (measurement switches, read once): bit 4 (16) = two-list balanced XCD mapping (order 4, default),
+    // bit 0 = cost-weighted mapping (order 3), neither = level-major (order 1, round 1); bit 1 = non-temporal table loads
+    // at the hashed levels, bit 2 = coarsest levels from LDS, bit 3 = round-1 pair gathers; XR_HG_WSH = "a,b,c": order 3's
+    // log2 cost of a sample block at dense levels < 2^16 entries, larger dense levels, hashed levels
+    static const int mode = scatter_env("XR_HG_FWD_MODE", 16);
+    static int wsh3[3] = {-1, 0, 0};
+    if (wsh3[0] < 0) {
+        int a = 0, b = 1, c = 2;
+        const char* e = getenv("XR_HG_WSH");
+        if (e) sscanf(e, "%d,%d,%d", &a, &b, &c);
+        wsh3[1] = b; wsh3[2] = c; wsh3[0] = a;
+    }
+    const uint32_t nsb = xr_div_up(n, EN_BLOCK);
+    gm.n_sblocks = nsb;
+    gm.nt = (mode >> 1) & 1;
+    gm.pairs = (mode >> 3) & 1;
+    gm.l_min = 0;
+    static const uint32_t lds_min_n = (uint32_t)scatter_env("XR_HG_LDS_MIN_N", 32768);
+    if ((mode & 4) && n >= lds_min_n) {
+        // levels whose slices fit the LDS together (dense, contiguous from level 0): at most 144 KiB
+        int n_lds = 0;
+        while (n_lds < n_levels && !((hm >> n_lds) & 1) && (size_t)gm.off[n_lds + 1] * 8 <= 144u * 1024u) ++n_lds;
+        if (n_lds > 0 && n_lds < n_levels) {
+            const size_t lds = (size_t)gm.off[n_lds] * 8;
+            static size_t attr_lds = 0;
+            if (lds > attr_lds) {
+                XR_HIP(hipFuncSetAttribute((const void*)k_hashgrid_fwd_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                attr_lds = lds;
+            }
+            const uint32_t g = xr_div_up(n, EN_LDS_THREADS);
+            hipLaunchKernelGGL(k_hashgrid_fwd_lds, dim3(g < 256u ? g : 256u), dim3(EN_LDS_THREADS), lds, stream, gm, n_lds, table, x,
+                               x_stride, n, n_dev, rows, enc_t, ld);
+            XR_LAUNCH_CHECK();
+            gm.l_min = n_lds;
+        }
+    }
+    uint32_t blocks;
+    if (mode & 16) {
+        // hashed levels must be the top of the level range (they are, for a growing resolution)
+        uint32_t nh = 0;
+        while (nh < (uint32_t)(n_levels - gm.l_min) && ((hm >> (n_levels - 1 - nh)) & 1)) ++nh;
+        gm.order = 4;
+        gm.n_hashed = nh;
+        const uint32_t nl = (uint32_t)(n_levels - gm.l_min);
+        blocks = 8 * (xr_div_up((uint64_t)nh * nsb, 8) + xr_div_up((uint64_t)(nl - nh) * nsb, 8) + 2);
+    } else if (mode & 1) {
+        gm.order = 3;
+        gm.wsum = 0;
+        for (int l = 0; l < n_levels; ++l) {
+            const uint32_t hsize = gm.off[l + 1] - gm.off[l];
+            gm.wsh[l] = (uint8_t)(((hm >> l) & 1) ? wsh3[2] : (hsize < 65536u ? wsh3[0] : wsh3[1]));
+            if (l >= gm.l_min) gm.wsum += 1u << gm.wsh[l];
+        }
+        blocks = 8 * hg_balanced_blocks_per_xcd(gm, nsb);
+    } else {
+        XR_REQUIRE(gm.l_min == 0, "the LDS path needs a balanced mapping");
+        blocks = 8 * ((n_levels + 7) / 8) * nsb;
+    }
+    hipLaunchKernelGGL(k_hashgrid_fwd, dim3(blocks), dim3(EN_BLOCK), 0, stream, gm, hm, table, x, x_stride, n,
                        n_dev, rows, enc_t, ld);
     XR_LAUNCH_CHECK();
     return XR_OK;
@@ -441,6 +891,10 @@ static int scatter_env(const char* name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
+static int sc_mode() {          // XR_SC_MODE=0: first-generation bin / accumulate pair (measurement)
+    static const int m = scatter_env("XR_SC_MODE", 1);
+    return m;
+}
 // Which levels take which path, and the workspace layout:  [fill counts][bins][replicas of the dense slices]
 #define SC_REPLICAS 8
 struct ScatterPlan {
@@ -466,7 +920,7 @@ static ScatterPlan scatter_plan(uint32_t n, int n_levels, const uint32_t* res, c
     }
     const uint32_t nl = (uint32_t)(n_levels - p.l_bin);
     p.counts_bytes = (((size_t)nl * p.parts * p.nsb * sizeof(uint32_t)) + 255) & ~(size_t)255;
-    p.bins_bytes = (size_t)nl * p.nsb * SC_SUB_ITEMS * sizeof(float4);
+    p.bins_bytes = (size_t)nl * p.nsb * (sc_mode() ? SC_SUB_ITEMS2 : SC_SUB_ITEMS) * sizeof(float4);
     // replicas only for a dense remainder next to a binned range (small tables: <= 2^14-entry... up to 2^19 each)
     p.rep_stride = (use_rep && n >= 16384u && p.l_bin > 0) ? (2u * off[p.l_bin] + 3u) & ~3u : 0u;
     p.rep_bytes = (size_t)SC_REPLICAS * p.rep_stride * sizeof(float);
@@ -547,16 +1001,26 @@ extern "C" int xr_hashgrid_bwd(const float* x, uint32_t x_stride, const float* d
         static bool attr_set = false;
         if (!attr_set) {
             XR_HIP(hipFuncSetAttribute((const void*)k_scatter_accum, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC_LDS_BYTES));
+            XR_HIP(hipFuncSetAttribute((const void*)k_scatter_accum2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC_LDS_BYTES));
             attr_set = true;
         }
         uint32_t* counts = (uint32_t*)workspace;
         float4* bins = (float4*)((char*)workspace + p.counts_bytes);
-        hipLaunchKernelGGL(k_scatter_bin, dim3(nl * p.nsb), dim3(SC_THREADS), 0, stream, gm, (uint32_t)p.l_bin, (uint32_t)n_levels,
-                           p.parts, p.nsb, x, x_stride, denc_t, ld, n, n_dev, counts, bins, grad_table);
-        XR_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_scatter_accum, dim3(nl * p.parts), dim3(SC_ACC_THREADS), SC_LDS_BYTES, stream, gm, (uint32_t)p.l_bin,
-                           (uint32_t)n_levels, p.parts, p.nsb, counts, bins, grad_table);
-        XR_LAUNCH_CHECK();
+        if (sc_mode()) {
+            hipLaunchKernelGGL(k_scatter_bin2, dim3(nl * p.nsb), dim3(SB_THREADS), 0, stream, gm, (uint32_t)p.l_bin, (uint32_t)n_levels,
+                               p.parts, p.nsb, x, x_stride, denc_t, ld, n, n_dev, counts, bins, grad_table);
+            XR_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_scatter_accum2, dim3(nl * p.parts), dim3(SC_ACC_THREADS), SC_LDS_BYTES, stream, gm, (uint32_t)p.l_bin,
+                               (uint32_t)n_levels, p.parts, p.nsb, counts, bins, grad_table);
+            XR_LAUNCH_CHECK();
+        } else {
+            hipLaunchKernelGGL(k_scatter_bin, dim3(nl * p.nsb), dim3(SC_THREADS), 0, stream, gm, (uint32_t)p.l_bin, (uint32_t)n_levels,
+                               p.parts, p.nsb, x, x_stride, denc_t, ld, n, n_dev, counts, bins, grad_table);
+            XR_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_scatter_accum, dim3(nl * p.parts), dim3(SC_ACC_THREADS), SC_LDS_BYTES, stream, gm, (uint32_t)p.l_bin,
+                               (uint32_t)n_levels, p.parts, p.nsb, counts, bins, grad_table);
+            XR_LAUNCH_CHECK();
+        }
     }
     if (forked) XR_HIP(hipStreamWaitEvent(stream, ev_join, 0));
     return XR_OK;

@@ -21,12 +21,16 @@ class KernelTimer:
     current stream IS the stream every kernel of this library is enqueued on).  bench.py uses it to
     get the dominant kernel's average duration live inside the timed region."""
 
-    def __init__(self, only=None):
+    def __init__(self, only=None, train_only=False):
         self.events = {}
         self.only = only            # record only these entry points (None = all)
+        self.train_only = train_only   # record only the training step's launches (row count on the device), not the
+                                       # occupancy-grid density queries / render launches of the same entry points
 
-    def span(self, name, units=0):
+    def span(self, name, units=0, train=True):
         if self.only is not None and name not in self.only:
+            return _NOSPAN
+        if self.train_only and not train:
             return _NOSPAN
         return _Span(self, name, units)
 
@@ -62,8 +66,13 @@ TIMER = None
 _NOSPAN = _NoSpan()
 
 
-def _span(name, units=0):
-    return TIMER.span(name, units) if TIMER is not None else _NOSPAN
+def _span(name, units=0, train=True):
+    return TIMER.span(name, units, train) if TIMER is not None else _NOSPAN
+
+
+def precision():
+    """arithmetic mode of the hash grid + fused MLP: 'f32' (parity mode, default)"""
+    return 'f32'
 
 
 def _stream():
@@ -301,7 +310,7 @@ def hashgrid_fwd(table, x, meta, enc_t=None, ld=None, n_dev=None, rows=None, row
         n = count
     xp = x.data_ptr() + 4 * xs * row0
     ep = enc_t.data_ptr() + 4 * row0
-    with _span('xr_hashgrid_fwd', 0 if n_dev is not None else n):
+    with _span('xr_hashgrid_fwd', 0 if n_dev is not None else n, train=n_dev is not None):
         _ptr(enc_t)
         _lib.check(L.xr_hashgrid_fwd(_ptr(table), C.c_void_p(xp), xs, n, _ptr(n_dev), _ptr(rows), meta.n_levels, s, r, o, C.c_void_p(ep), ld,
                                      _stream()), 'xr_hashgrid_fwd')
@@ -322,7 +331,7 @@ def hashgrid_bwd(x, denc_t, meta, grad_table, n_dev=None, row0=0, count=None, le
     ld = denc_t.shape[1]
     _ptr(denc_t)
     ws = _ws(x.device, L.xr_hashgrid_bwd_workspace_bytes(n, l1 - l0, r + 4 * l0, o + 4 * l0), 'hgb') if use_workspace else None
-    with _span('xr_hashgrid_bwd', 0 if n_dev is not None else n):
+    with _span('xr_hashgrid_bwd', 0 if n_dev is not None else n, train=n_dev is not None):
         _lib.check(L.xr_hashgrid_bwd(C.c_void_p(x.data_ptr() + 4 * xs * row0), xs,
                                      C.c_void_p(denc_t.data_ptr() + 4 * (row0 + 2 * l0 * ld)), ld, n, _ptr(n_dev),
                                      l1 - l0, s + 4 * l0, r + 4 * l0, o + 4 * l0, _ptr(grad_table),
@@ -352,7 +361,7 @@ def nerf_mlp_fwd(enc_t, dirs, n, w_density, w_color, nhd, nhc, pad_value=1.0, ra
     _ptr(enc_t); _ptr(raw)
     if count is not None:
         n = count
-    with _span('xr_nerf_mlp_fwd', 0 if n_dev is not None else n):
+    with _span('xr_nerf_mlp_fwd', 0 if n_dev is not None else n, train=n_dev is not None):
         _lib.check(L.xr_nerf_mlp_fwd(C.c_void_p(enc_t.data_ptr() + 4 * row0), enc_t.shape[1], dp, ds, n, _ptr(n_dev),
                                      _ptr(rows), _ptr(w_density), _ptr(w_color) if w_color is not None else None, nhd,
                                      nhc, pad_value, C.c_void_p(raw.data_ptr() + 16 * row0), _stream()),
@@ -370,7 +379,7 @@ def nerf_mlp_bwd(enc_t, dirs, n, w_density, w_color, nhd, nhc, draw, grad_wd, gr
     _ptr(enc_t); _ptr(draw); _ptr(denc_t)
     if count is not None:
         n = count
-    with _span('xr_nerf_mlp_bwd', 0 if n_dev is not None else n):
+    with _span('xr_nerf_mlp_bwd', 0 if n_dev is not None else n, train=n_dev is not None):
         _lib.check(L.xr_nerf_mlp_bwd(C.c_void_p(enc_t.data_ptr() + 4 * row0), enc_t.shape[1], C.c_void_p(dirs.data_ptr() + 4 * ds * row0), ds, n, _ptr(n_dev), _ptr(w_density),
                                      _ptr(w_color), nhd, nhc, pad_value, C.c_void_p(draw.data_ptr() + 16 * row0), C.c_void_p(denc_t.data_ptr() + 4 * row0), _ptr(grad_wd),
                                      _ptr(grad_wc), _ptr(ws), ws.numel(), _stream()), 'xr_nerf_mlp_bwd')

@@ -90,11 +90,14 @@ class SyntheticLego(DeviceRayTable):
     axis-aligned boxes ("Lego-shaped", ~6 % of the level-0 cells), pre-shuffled once like the
     reference's np.random.shuffle.  (Real Blender scenes: datasets.HashNerfDataset, same interface.)"""
 
-    def __init__(self, device, n_img=20, H=800, W=800, seed=1, shuffle=True):
+    def __init__(self, device, n_img=20, H=800, W=800, seed=1, shuffle=True, shuffle_seed=None):
+        """`seed` fixes the CAMERAS (identical on every data-parallel rank: K7's visibility mask, hence the density
+        grid and the bitfield, must not depend on the rank); `shuffle_seed` the ray order (per rank)."""
         self.boxes = _lego_boxes()
         boxes = self.boxes.to(device)
         super().__init__(device, synthetic.lego_cameras(n_img, seed=seed), lambda k, o, d: _render_boxes(o, d, boxes),
-                         H, W, float(synthetic.LEGO_FOCAL) * W / 800.0, seed=seed, shuffle=shuffle)
+                         H, W, float(synthetic.LEGO_FOCAL) * W / 800.0, seed=seed if shuffle_seed is None else shuffle_seed,
+                         shuffle=shuffle)
 
 
 def _lego_boxes(seed=2, fill=0.07, n_boxes=40):
@@ -138,7 +141,7 @@ class Trainer:
         torch.manual_seed(seed)                       # identical initial weights on every rank
         self.device = device
         self.net = build_network(ngp_lego_model_cfg()).to(device)
-        self.data = dataset or SyntheticLego(device, n_img, H, W, seed=1 + rank)
+        self.data = dataset or SyntheticLego(device, n_img, H, W, seed=1, shuffle_seed=1 + rank)
         self.net.sampler.set_data(self.data.get_alldata(), self.data.get_info())     # PassDatasetHook
         self.net.sampler.on_sampled = self._on_sampled
         self.base_lr = 1e-2
