@@ -123,3 +123,52 @@ def load_kilo():
     ns.MultiNetworkFourierEmbedding = emb.MultiNetworkFourierEmbedding
     ns.KiloNerfFourierEmbedder = emb.KiloNerfFourierEmbedder
     return ns
+
+
+def load_ngp(raymarch_module, tcnn_module):
+    """-> namespace with the reference's Instant-NGP Python, imported UNMODIFIED from /root/reference with the two
+    extension modules it binds replaced by this repository's drop-ins:
+        sys.modules['raymarch_cuda'] = raymarch_module   (xrnerf_amd.raymarch_cuda)
+        sys.modules['tinycudann']    = tcnn_module       (xrnerf_amd.tcnn, or a test double with the same surface)
+    Loaded: samplers/utils/*.py (the ten autograd-Function wrappers), samplers/ngp_grid_sampler.py (NGPGridSampler),
+    mlps/hashnerf_mlp.py (HashNerfMLP), renders/hashnerf_render.py (HashNerfRender), networks/hashnerf.py
+    (HashNerfNetwork) and the loss helpers they use.  cfg dicts must be `Cfg` (attribute access like mmcv's ConfigDict)."""
+    assert available()
+    _stub_mmcv()
+    sys.modules['raymarch_cuda'] = raymarch_module
+    sys.modules['tinycudann'] = tcnn_module
+    ns = load()
+    for pkg in ('xrnerf.models.samplers',):
+        if pkg not in sys.modules:
+            m = types.ModuleType(pkg)
+            m.__path__ = [os.path.join(REF, *pkg.split('.'))]
+            sys.modules[pkg] = m
+    # a module imported earlier against other extension modules would keep them: (re)import the binding files
+    for name in [n for n in sys.modules if n.startswith('xrnerf.models.samplers.') or n in (
+            'xrnerf.models.renders.hashnerf_render', 'xrnerf.models.mlps.hashnerf_mlp', 'xrnerf.models.networks.hashnerf',
+            'xrnerf.models.networks.nerf')]:
+        del sys.modules[name]
+    ns.sampler_utils = importlib.import_module('xrnerf.models.samplers.utils')
+    ns.NGPGridSampler = importlib.import_module('xrnerf.models.samplers.ngp_grid_sampler').NGPGridSampler
+    ns.HashNerfMLP = importlib.import_module('xrnerf.models.mlps.hashnerf_mlp').HashNerfMLP
+    ns.HashNerfRender = importlib.import_module('xrnerf.models.renders.hashnerf_render').HashNerfRender
+    utils = sys.modules['xrnerf.models.networks.utils']
+    for leaf, names in (('transforms', ('merge_ret', 'recover_shape')), ('metrics', ('mse2psnr', 'img2mse', 'HuberLoss')),
+                        ('batching', ('unfold_batching',)), ('hierarchical_sample', ('sample_pdf',))):
+        mod = importlib.import_module('xrnerf.models.networks.utils.' + leaf)
+        for n in names:
+            setattr(utils, n, getattr(mod, n))
+    utils.__all__ = [n for n in vars(utils) if not n.startswith('_')]
+    if 'tqdm' not in sys.modules:
+        try:
+            import tqdm  # noqa: F401
+        except ImportError:
+            t = types.ModuleType('tqdm'); t.tqdm = lambda x, **k: x
+            sys.modules['tqdm'] = t
+    ns.HashNerfNetwork = importlib.import_module('xrnerf.models.networks.hashnerf').HashNerfNetwork
+    return ns
+
+
+class Cfg(dict):
+    """attribute-style dict (what mmcv's ConfigDict gives the reference's constructors: `cfg.chunk`, `'chunk' in cfg`)"""
+    __getattr__ = dict.__getitem__

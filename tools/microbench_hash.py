@@ -33,6 +33,11 @@ def child(which):
         us = timeit(lambda: ops.hashgrid_fwd(table, c[:, :3], meta, enc_t=enc, ld=ld, n_dev=ndev))
         # the 14 M-sample render-sized launch too (n repeated 16x along fresh rays is not needed: reuse rows)
         print('%-44s n=%d fwd %.1f us  %.0f GB/s algo  frac %.3f' % (tag, n, us, n * 1164 / us / 1e3, n * 1164 / us / 1e3 / 8000), flush=True)
+        if os.environ.get('XR_FWD_ABLATE'):
+            x3 = c[:, :3].contiguous()
+            print('   compact [n,3] positions: %.1f us' % timeit(lambda: ops.hashgrid_fwd(table, x3, meta, enc_t=enc, ld=ld, n_dev=ndev)), flush=True)
+            for lv in ((0, 5), (5, 16), (5, 8), (8, 13), (13, 16), (15, 16), (0, 1), (4, 5)):
+                print('   levels %-8s %.1f us' % (lv, timeit(lambda: ops.hashgrid_fwd(table, c[:, :3], meta, enc_t=enc, ld=ld, n_dev=ndev, levels=lv))), flush=True)
         ref = O.hashgrid_fwd(S.hash_table(meta.n_params), c[:4096, :3].cpu().numpy(), O.GridMeta())
         got = enc[:, :4096].t().cpu().numpy()
         print('   bit-exact vs oracle on 4096 rows:', bool((got == ref).all()), flush=True)

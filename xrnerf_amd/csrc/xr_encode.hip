@@ -733,7 +733,11 @@ __global__ __launch_bounds__(SC_ACC_THREADS) void k_scatter_accum2(GridMeta gm, 
             if (s < nsb) {
                 const uint32_t fill = s_fill[s], off = c * 64u + lane;
                 non[u] = off < fill;
+#ifdef SC_ABL_NOLOAD
+                if (non[u]) nx[u] = make_float4(__uint_as_float((off * 2654435761u) & ((1u << (2 * SC_LOG2)) - 1u)), 1.f, 2.f, 0.25f);
+#else
                 if (non[u]) nx[u] = src[(size_t)s * cap + off];
+#endif
                 ++c;
                 if (c * 64u >= fill) {
                     c = 0; s += WAVES;
@@ -755,10 +759,14 @@ __global__ __launch_bounds__(SC_ACC_THREADS) void k_scatter_accum2(GridMeta gm, 
             if (!on[u]) continue;
             const uint32_t pr = __float_as_uint(it[u].x), i0 = pr & (SC_ENTRIES - 1), i1 = pr >> SC_LOG2;
             const float w0 = it[u].w, a = it[u].y, b = it[u].z;
+#ifdef SC_ABL_NOATOMIC
+            if (w0 * a + b == 1234.5f) s_acc[2 * i0 + i1] = 1.0;
+#else
             atomicAdd(&s_acc[2 * i0], (double)((1.f - w0) * a));
             atomicAdd(&s_acc[2 * i0 + 1], (double)((1.f - w0) * b));
             atomicAdd(&s_acc[2 * i1], (double)(w0 * a));
             atomicAdd(&s_acc[2 * i1 + 1], (double)(w0 * b));
+#endif
         }
         if (!more) break;
     }

@@ -295,9 +295,10 @@ def clip_numsteps(numsteps, counter, max_compacted):
     return out, n_valid
 
 
-def hashgrid_fwd(table, x, meta, enc_t=None, ld=None, n_dev=None, rows=None, row0=0, count=None):
+def hashgrid_fwd(table, x, meta, enc_t=None, ld=None, n_dev=None, rows=None, row0=0, count=None, levels=None):
     """x: [n,3] (or a column slice of [n,7] rows) -> enc_t [2L, ld] feature-major.
-    n_dev: optional device int32[1]; only min(n, n_dev) rows are touched (no host read-back needed)."""
+    n_dev: optional device int32[1]; only min(n, n_dev) rows are touched (no host read-back needed).
+    levels=(l0, l1): only that level range is evaluated (rows 2*l0 .. 2*l1 of enc_t; measurement / partial updates)."""
     L = _lib.load()
     x, xs = _pos_view(x)
     n = x.shape[0] if rows is None else rows.shape[0]
@@ -306,14 +307,17 @@ def hashgrid_fwd(table, x, meta, enc_t=None, ld=None, n_dev=None, rows=None, row
     if enc_t is None:
         enc_t = torch.empty((meta.n_output_dims, ld), dtype=torch.float32, device=x.device)
     s, r, o = meta._args()
+    l0, l1 = (0, meta.n_levels) if levels is None else levels
+    if not 0 <= l0 < l1 <= meta.n_levels:
+        raise _lib.XrError('bad level range %r' % (levels,))
     if count is not None:          # a row chunk [row0, row0+count) of the sample buffer, written to the same columns
         n = count
     xp = x.data_ptr() + 4 * xs * row0
-    ep = enc_t.data_ptr() + 4 * row0
+    ep = enc_t.data_ptr() + 4 * (row0 + 2 * l0 * ld)
     with _span('xr_hashgrid_fwd', 0 if n_dev is not None else n, train=n_dev is not None):
         _ptr(enc_t)
-        _lib.check(L.xr_hashgrid_fwd(_ptr(table), C.c_void_p(xp), xs, n, _ptr(n_dev), _ptr(rows), meta.n_levels, s, r, o, C.c_void_p(ep), ld,
-                                     _stream()), 'xr_hashgrid_fwd')
+        _lib.check(L.xr_hashgrid_fwd(_ptr(table), C.c_void_p(xp), xs, n, _ptr(n_dev), _ptr(rows), l1 - l0, s + 4 * l0, r + 4 * l0,
+                                     o + 4 * l0, C.c_void_p(ep), ld, _stream()), 'xr_hashgrid_fwd')
     return enc_t
 
 

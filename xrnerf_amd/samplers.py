@@ -111,8 +111,9 @@ class NGPGridSampler(nn.Module):
         ops.ema_grid_samples(self.density_grid_tmp, n_elements, self.ema_grid_decay, self.density_grid)
         self.density_grid_ema_step += 1
         ops.update_bitfield(self.density_grid, self.density_grid_mean, self.density_grid_bitfield)
-        self._bitfield_event = torch.cuda.Event()
-        self._bitfield_event.record(torch.cuda.current_stream())
+        if self._streams():
+            self._bitfield_event = torch.cuda.Event()
+            self._bitfield_event.record(torch.cuda.current_stream())
 
     def update_density_grid(self, mlp):
         n_cascades = self.max_cascade + 1
@@ -147,12 +148,23 @@ class NGPGridSampler(nn.Module):
         n_rays = rays_o.shape[0]
         aabb = (float(self.aabb_range[0]), float(self.aabb_range[1]))
         # the reference sizes the buffer n_rays_per_batch*1024 rows (117 MB zero-filled per call,
-        # samplers/utils/rays_sampler.py:20-21); nothing reads rows past the counter, so it is not cleared
-        max_samples = max(self.num_coords_elements, n_rays * 64) if is_training else n_rays * self.MAX_STEP
-        max_samples = min(max_samples, n_rays * self.MAX_STEP)
-        pf = self._prefetched
-        self._prefetched = None
-        if (is_training and pf is not None and pf['rays_o'].data_ptr() == data['rays_o'].data_ptr() and
+        # samplers/utils/rays_sampler.py:20-21) whatever the batch; nothing reads rows past the counter, so it is not
+        # cleared here, and a batch of more than 65536 rays gets 64 rows per ray (the reference's K1 would silently
+        # drop the samples that do not fit; `reference_buffer_rows = True` reproduces exactly that)
+        if is_training:
+            max_samples = self.num_coords_elements if getattr(self, 'reference_buffer_rows', False) else \
+                max(self.num_coords_elements, n_rays * 64)
+            max_samples = min(max_samples, n_rays * self.MAX_STEP)
+        else:
+            # test / render: the worst case is 1024 rows per ray (18 GB for an 800x800 frame marched in one call); the
+            # buffer is sized from the previous test launch (first time: 48 rows per ray) and the launch is repeated with
+            # the exact size -- same RNG call index, identical result -- in the rare case it overflowed
+            est = max(n_rays * 48, int(getattr(self, '_test_rows_seen', 0) * 1.25) + 1024)
+            max_samples = min(n_rays * self.MAX_STEP, est)
+        pf = self._prefetched if is_training else None      # a render / val call in between leaves the prefetch alone
+        if is_training:
+            self._prefetched = None
+        if (pf is not None and pf['rays_o'].data_ptr() == data['rays_o'].data_ptr() and
                 pf['rays_o'].shape == data['rays_o'].shape and pf['max_samples'] == max_samples):
             # K1 of this batch already ran on the side stream while the previous iteration's backward was
             # executing (prefetch()): order this stream after it and adopt its outputs
@@ -169,13 +181,29 @@ class NGPGridSampler(nn.Module):
                     if torch.is_tensor(t) and t.is_cuda:
                         t.record_stream(cur)
         else:
+            if pf is not None:
+                # a prefetched march that does not belong to this batch is dropped (its RNG call stays consumed, like
+                # any other launch); its side-stream writes into the shared buffers must have finished before this
+                # stream's launch touches them
+                torch.cuda.current_stream().wait_event(pf['event'])
             slot = self._next_slot(is_training)
+            k1_index = self.k1_calls
             coords, rays_index, rays_numsteps, counter = ops.rays_sampler(
                 rays_o, rays_d, self.density_grid_bitfield, aabb, self.near_distance, self.cone_angle_constant,
-                max_samples, self.k1_calls, coords_out=self._coords_buffer(max_samples, slot),
+                max_samples, k1_index, coords_out=self._coords_buffer(max_samples, slot),
                 small_out=self._small_buffers(n_rays, slot))
             self.k1_calls += 1
-            if is_training:
+            if not is_training:
+                n_valid, samples = counter.tolist()      # one host read-back per call (rays_sampler.py:72)
+                if samples > max_samples:
+                    max_samples = min(n_rays * self.MAX_STEP, samples)
+                    coords, rays_index, rays_numsteps, counter = ops.rays_sampler(
+                        rays_o, rays_d, self.density_grid_bitfield, aabb, self.near_distance, self.cone_angle_constant,
+                        max_samples, k1_index, coords_out=self._coords_buffer(max_samples, slot),
+                        small_out=self._small_buffers(n_rays, slot))
+                    n_valid, samples = counter.tolist()
+                self._test_rows_seen = samples
+            elif self._streams():
                 # the counter's device-to-host copy goes to the side stream: on the compute stream its
                 # system-scope completion would sit between K1 and the first kernel that uses K1's output
                 e = torch.cuda.Event()
@@ -184,9 +212,10 @@ class NGPGridSampler(nn.Module):
                 with torch.cuda.stream(side):
                     side.wait_event(e)
                     self._pending_counts.append(self._count_to_host(counter))
+            else:
+                self._pending_counts.append((None, counter.clone()))       # host tensors (kernels under tests/hip_emu)
         self.rays_index = rays_index
         if not is_training:
-            n_valid, samples = counter.tolist()      # one host read-back per call (rays_sampler.py:72)
             coords = coords[:min(samples, max_samples)]
             self.coords = coords
             self.rays_numsteps = rays_numsteps
@@ -251,6 +280,11 @@ class NGPGridSampler(nn.Module):
         refreshes the occupancy grid first."""
         return hasattr(self, 'density_grid') and next_iter % self.update_grid_freq != 0
 
+    def _streams(self):
+        """side streams / events / pinned staging only exist on the device (the kernels' host build under tests/hip_emu
+        runs everything in program order)"""
+        return self.device is not None and self.device.type == 'cuda'
+
     def side_stream(self):
         if getattr(self, '_side', None) is None:
             self._side = torch.cuda.Stream(device=self.device)        # (a high-priority stream changes nothing: measured)
@@ -263,7 +297,9 @@ class NGPGridSampler(nn.Module):
         rays_o, rays_d = data['rays_o'], data['rays_d']
         n_rays = rays_o.shape[0]
         aabb = (float(self.aabb_range[0]), float(self.aabb_range[1]))
-        max_samples = min(max(self.num_coords_elements, n_rays * 64), n_rays * self.MAX_STEP)
+        max_samples = self.num_coords_elements if getattr(self, 'reference_buffer_rows', False) else \
+            max(self.num_coords_elements, n_rays * 64)
+        max_samples = min(max_samples, n_rays * self.MAX_STEP)
         side = torch.cuda.current_stream()
         ev = getattr(self, '_bitfield_event', None)
         if ev is not None:
@@ -305,7 +341,8 @@ class NGPGridSampler(nn.Module):
         """fold the arrived per-iteration counters into `measured_batch_size` (a HOST tensor here; the reference
         keeps it on the device and pays a stream drain to read it, ngp_grid_sampler.py:252,271)"""
         for ev, host in self._pending_counts:
-            ev.synchronize()
+            if ev is not None:
+                ev.synchronize()
             c = int(host[1])
             self.measured_batch_size += c
             self.samples_marched += min(c, self.target_batch_size)      # rows that actually went through the MLP

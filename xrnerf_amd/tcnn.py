@@ -79,7 +79,7 @@ class _NetFn(torch.autograd.Function):
         x = x if x.dtype == torch.float32 else x.float()
         n = x.shape[0]
         y = torch.empty((n, 16), dtype=torch.float32, device=x.device)
-        if not x.is_cuda:
+        if not ops._on_device(x):
             raise _lib.XrError('xrnerf_amd.tcnn.Network needs ROCm device tensors: there is no CPU fallback')
         _lib.check(L.xr_mlp_fwd(C.c_void_p(x.data_ptr()), x.stride(0), x.stride(1), net.n_input_dims, net.pad_value, n,
                                 ops._ptr(params), net.n_hidden, ops._ptr(y), ops._stream()), 'xr_mlp_fwd')
