@@ -207,6 +207,44 @@ def kilonerf_config5(dev, frames=8, cpu_seconds=10.0):
            'dtype': 'f32', 'evaluated_samples_per_frame': evaluated, 'networks_used': int((counts > 0).sum()),
            'tiny_mlp_gflop_per_frame': evaluated * flop_per_sample / 1e9,
            'reference_published_ms_per_frame_other_hw': 365.16}
+    # fine-tuning step of configs/kilonerf/kilonerf_finetune_Synthetic_NeRF_base01.py: 8192 rays x 384 samples through
+    # KiloNerfMLP.forward under autograd (xr_kilo_mlp_forward) and its backward (xr_kilo_mlp_backward = the reference's
+    # six AddMultiMatMul.backward's), timed with events on the launch stream
+    try:
+        nft = 8192
+        sel = torch.randperm(H * W, device=dev)[:nft]
+        data = {'rays_o': rays_o[sel].contiguous(), 'rays_d': rays_d[sel].contiguous(), 'viewdirs': viewdirs[sel].contiguous(),
+                'z_vals': z[sel].contiguous(), 'global_domain_min': gmin, 'global_domain_max': gmax}
+        for p_ in mlp.multi_network.parameters():
+            p_.requires_grad_(True)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        tf = tb = 0.0
+        reps = 6
+        for r in range(reps + 2):
+            for p_ in mlp.multi_network.parameters():
+                p_.grad = None
+            ev[0].record()
+            raw = mlp(dict(data))['raw']
+            ev[1].record()
+            raw.backward(torch.ones_like(raw))
+            ev[2].record()
+            torch.cuda.synchronize()
+            if r >= 2:
+                tf += ev[0].elapsed_time(ev[1]); tb += ev[1].elapsed_time(ev[2])
+        _, cft = ops.kilo_mlp_forward(data['viewdirs'], mlp._host3(gmin), mlp._host3(gmax), [x // 16 for x in mlp.resolution],
+                                      mlp.resolution, mlp.occupancy_grid, mlp.domain_mins, mlp.domain_maxs,
+                                      mlp.multi_network.packed(), 10, 4, 2, rays_o=data['rays_o'], rays_d=data['rays_d'],
+                                      z_vals=data['z_vals'], want_counts=True)
+        ev_ft = int(cft.sum())
+        res['finetune_step'] = {'rays': nft, 'samples_per_ray': 384, 'evaluated_samples': ev_ft,
+                                'forward_ms': tf / reps, 'backward_ms': tb / reps,
+                                'backward_includes': 'ones-like dL/draw fill, xr_kilo_mlp_backward, unpacking the packed gradient blocks',
+                                'backward_tflops': ev_ft * 3 * flop_per_sample / (tb / reps * 1e-3) / 1e12,
+                                'forward_tflops': ev_ft * flop_per_sample / (tf / reps * 1e-3) / 1e12}
+        for p_ in mlp.multi_network.parameters():
+            p_.requires_grad_(False); p_.grad = None
+    except Exception as e:  # noqa: BLE001
+        res['finetune_step'] = {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
     del z, rays_o, rays_d, viewdirs
     torch.cuda.empty_cache()
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
@@ -233,6 +271,50 @@ def kilonerf_config5(dev, frames=8, cpu_seconds=10.0):
                            'kind': 'port', 'sample': '%d rays (every 41st of the frame) x 384 samples, oracle/kilo_oracle.py '
                                                       '(numpy), ray generation excluded' % done}
     return res
+
+
+def ngp_config4_unbounded(dev, steps=64):
+    """Secondary line (BASELINE config #4): the same Instant-NGP model on an UNBOUNDED forward-facing scene, 1008 x 756,
+    aabb_scale = 16 (five occupancy cascades: 10.5 M-point grid queries below iteration 256, 2 x 2.6 M after), synthetic
+    fern-shaped cameras and geometry (xrnerf_amd.train.SyntheticFern; the reference ships no such config).  Training
+    rays/s at the adaptive fixed point + ms per 1008x756 frame on this GPU's row band (all rows at N = 1)."""
+    from xrnerf_amd.train import SyntheticFern
+    data = SyntheticFern(dev, n_img=20)
+    tr = Trainer(dev, dataset=data)
+    sampler = tr.net.sampler
+    pre, hist = 0, [sampler.n_rays_per_batch]
+    while pre < PREROLL_MAX:
+        for _ in range(16):
+            tr.step()
+        pre += 16
+        hist.append(sampler.n_rays_per_batch)
+        if pre >= PREROLL_MIN and len(hist) >= 3 and abs(hist[-1] - hist[-2]) <= 0.02 * hist[-2] and abs(hist[-2] - hist[-3]) <= 0.02 * hist[-3]:
+            break
+    torch.cuda.synchronize()
+    r0, s0 = tr.rays_done, tr.samples_done
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    rays, samples = tr.rays_done - r0, tr.samples_done - s0
+    H, W = data.H, data.W
+    for _ in range(2):
+        render_frame(tr.net, data.poses[0], H, W, data.focal)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for f in range(3):
+        rgb, alpha = render_frame(tr.net, data.poses[f], H, W, data.focal)
+    torch.cuda.synchronize()
+    ms_frame = (time.perf_counter() - t1) * 1e3 / 3
+    return {'workload': 'Instant-NGP, unbounded forward-facing synthetic scene (fern-shaped), 1008x756, 20 images, aabb_scale 16 '
+                        '(max_cascade 4), same model / sampler / kernels as the headline; %d timed iterations after %d pre-roll '
+                        'iterations (%d grid refreshes in the window)' % (steps, pre, steps // 16),
+            'value': rays / el, 'unit': 'rays/s', 'ms_per_step': el * 1e3 / steps, 'dtype': 'f32',
+            'rays_per_step': rays / steps, 'samples_per_ray': samples / max(rays, 1), 'rays_per_batch_history': hist,
+            'render_ms_per_1008x756_frame': ms_frame, 'render_samples_per_ray': float(sampler.coords.shape[0]) / (H * W),
+            'occupied_cells_per_cascade': [int(np.unpackbits(sampler.density_grid_bitfield[c * 262144:(c + 1) * 262144].cpu().numpy()).sum())
+                                           for c in range(5)]}
 
 
 def _cpu_worker(seed, seconds_budget):
@@ -300,7 +382,7 @@ def cpu_baseline(seconds_budget=15.0):
                       'ray generation excluded' % (procs, its)}
 
 
-PREROLL_MIN, PREROLL_MAX = 64, 1024
+PREROLL_MIN, PREROLL_MAX = 272, 1024      # past iteration 256: the reference's schedule samples M/4 + M/4 grid cells from there on
 
 
 def _respawn_under_torchrun(n):
@@ -330,6 +412,7 @@ def main():
     ap.add_argument('--no-render', action='store_true')
     ap.add_argument('--no-mip', action='store_true', help='skip the secondary Mip-NeRF (config #3) line')
     ap.add_argument('--no-kilo', action='store_true', help='skip the secondary KiloNeRF (config #5) line')
+    ap.add_argument('--no-unbounded', action='store_true', help='skip the secondary unbounded-scene (config #4) line')
     ap.add_argument('--cpu-worker', type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -379,9 +462,13 @@ def main():
                 break
     for _ in range(args.warmup):
         tr.step()
-    # the timed window starts ON a grid-refresh iteration (iteration % 16 == 0), so K steps contain ceil(K/16) refreshes:
-    # never fewer than the long-run share of 1 in 16
-    align = (-tr.iter) % sampler.update_grid_freq
+    # the window's phase against the every-16th grid refresh is fixed, not left to --warmup: K timed steps contain
+    # round(K / 16) refresh iterations (at least one), the nearest integer to the long-run share; the count is reported
+    freq = sampler.update_grid_freq
+    want = max(1, int(round(args.steps / float(freq))))
+    # the first refresh falls `first_off` steps into the window, the slack split evenly before the first and after the last
+    first_off = max(0, min(freq - 1, (args.steps - 1 - (want - 1) * freq) // 2))
+    align = ((-tr.iter) % freq - first_off) % freq            # un-timed iterations that put the window at that phase
     for _ in range(align):
         tr.step()
     torch.cuda.synchronize()
@@ -493,7 +580,7 @@ def main():
                       'reference tree (parity unpinned)',
             'config': {'workload': 'Instant-NGP Lego, hash L=16 F=2 T=2^19, 64-wide fused MLP (1+2 hidden), 800x800, %d images; '
                                    'full training iterations %d..%d (batch slice + random bg, K1 march, every-16th grid refresh '
-                                   'K6..K11 with its density queries: %d refreshes in the window, encode, MLP, K3, 5*Huber, K4, '
+                                   'K6..K11 with its density queries: %d refreshes in the window = round(steps/16), encode, MLP, K3, 5*Huber, K4, '
                                    'MLP backward, table scatter, %sfused Adam+EMA over 12.2 M parameters) after %d un-timed '
                                    'pre-roll + %d warm-up iterations (adaptive batch at its fixed point: %s rays); the '
                                    'reference\'s dead no-grad MLP pass that only feeds K2\'s dead transmittance loop is skipped'
@@ -518,8 +605,11 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             guarded('cpu_baseline', cpu_baseline)
             guarded('cpu_baseline_vanilla_nerf_config1', cpu_vanilla_nerf)
-        if world == 1 and not (args.no_mip and args.no_kilo):
+        if world == 1 and not (args.no_mip and args.no_kilo and args.no_unbounded):
             del tr
+            torch.cuda.empty_cache()
+        if world == 1 and not args.no_unbounded:
+            guarded('ngp_config4_unbounded', lambda: ngp_config4_unbounded(dev))
             torch.cuda.empty_cache()
         if world == 1 and not args.no_mip:
             guarded('mipnerf_config3', lambda: mipnerf_config3(dev))

@@ -47,6 +47,39 @@ def check(rc, L):
 ALL_SOURCES = ('xr_misc', 'xr_grid', 'xr_raymarch', 'xr_encode', 'xr_mlp', 'xr_mip', 'xr_kilo', 'xr_gemm')
 
 
+# entry points whose workgroups may run on several host threads: no inter-workgroup atomics, no inter-workgroup ordering
+# (xrnerf_amd/csrc/xr_mlp.hip, xr_gemm.hip: per-workgroup partial sums in a workspace + a fixed-order reduce kernel), i.e.
+# the results do not depend on the schedule.  These are the MFMA kernels -- a rendezvous of 64 fibers per MFMA -- which
+# dominate the emulation time.  XR_EMU_THREADS=1 switches it off.
+PARALLEL_OK = ('xr_nerf_mlp_fwd', 'xr_nerf_mlp_bwd', 'xr_mlp_fwd', 'xr_mlp_bwd', 'xr_linear_forward', 'xr_linear_backward_input',
+               'xr_linear_backward_weight')
+EMU_THREADS = max(1, int(os.environ.get('XR_EMU_THREADS', min(8, os.cpu_count() or 1))))
+
+
+class _Threaded:
+    """ctypes function + `emu_set_threads` of the shared object it lives in"""
+
+    def __init__(self, fn, lib):
+        self._fn, self._lib = fn, lib
+
+    def __setattr__(self, k, v):
+        if k in ('restype', 'argtypes'):
+            setattr(self._fn, k, v)
+        else:
+            object.__setattr__(self, k, v)
+
+    @property
+    def __name__(self):
+        return self._fn.__name__
+
+    def __call__(self, *a):
+        self._lib.emu_set_threads(EMU_THREADS)
+        try:
+            return self._fn(*a)
+        finally:
+            self._lib.emu_set_threads(1)
+
+
 class MultiLib:
     """the host-compiled kernel sources behind one handle: libxrnerf_mi355.so is ONE library, here every source is its own
     shared object (its internal helpers must not be merged by the linker); a symbol is taken from the object that has it"""
@@ -61,7 +94,8 @@ class MultiLib:
         if name not in self._cache:
             for L in self._libs:
                 try:
-                    self._cache[name] = getattr(L, name)
+                    fn = getattr(L, name)
+                    self._cache[name] = _Threaded(fn, L) if (name in PARALLEL_OK and EMU_THREADS > 1) else fn
                     break
                 except AttributeError:
                     continue

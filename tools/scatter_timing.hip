@@ -8,7 +8,8 @@
 #include <cmath>
 void xr_set_error(const char*, ...) {}
 int main() {
-    const uint32_t n = 1u << 18, nl = 11, l_lo = 5, l_hi = 16, parts = 64, nsb = n / SC_BLOCK_SAMPLES;
+    const uint32_t n = 1u << 18, nl = 11, l_lo = 5, l_hi = 16, parts = (1u << 19) >> SC_LOG2, nsb = n / SC_BLOCK_SAMPLES;
+    printf("SC_LOG2 %d  SC_ACC_THREADS %d  SB_THREADS %d  SB_SPT %d\n", SC_LOG2, SC_ACC_THREADS, SB_THREADS, SB_SPT);
     float scale[16]; uint32_t res[16], off[17];
     xr_hashgrid_meta(16, 19, 16, std::exp2(std::log2(2048.0 / 16) / 15), scale, res, off);
     GridMeta gm; uint32_t hm; fill_meta(&gm, &hm, 16, scale, res, off);

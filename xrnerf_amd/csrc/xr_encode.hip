@@ -564,8 +564,12 @@ __global__ __launch_bounds__(SC_ACC_THREADS) void k_scatter_accum(GridMeta gm, u
 //   B' k_scatter_accum2 sub-bin capacity 1.25x the expected fill; a wave walks whole sub-bins in 64-item chunks,
 //      so only a sub-bin's last chunk has idle lanes; 8 chunk loads in flight per lane while the previous 8 are
 //      accumulated.
+#ifndef SB_THREADS
 #define SB_THREADS 512
+#endif
+#ifndef SB_SPT
 #define SB_SPT 2
+#endif
 #define SB_ROUND_SAMPLES (SB_THREADS * SB_SPT)
 #define SB_ROUND_ITEMS (4 * SB_ROUND_SAMPLES)
 #define SB_ROUNDS (SC_BLOCK_SAMPLES / SB_ROUND_SAMPLES)

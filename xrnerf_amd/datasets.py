@@ -84,8 +84,12 @@ class DeviceRayTable:
     PassDatasetHook), the batch-size feedback (`set_batchsize`: ModifyBatchsizeHook) and batches
     (`next_batch`: HashBatchSample + RandomBGColor in one launch)."""
 
-    def __init__(self, device, poses_ngp, images, H, W, focal, seed=1, shuffle=True):
+    def __init__(self, device, poses_ngp, images, H, W, focal, seed=1, shuffle=True, aabb_scale=1):
         self.device, self.H, self.W, self.focal = device, int(H), int(W), float(focal)
+        # the reference's HashNerfDataset hard-codes aabb_scale = 1 (hashnerf_dataset.py:57-60); its sampler and kernels
+        # take any power of two up to 128 (ngp_grid_sampler.py:83-85: max_cascade = log2(aabb_scale)) -- BASELINE config #4
+        # (unbounded forward-facing scene) uses 16
+        self.aabb_scale = int(aabb_scale)
         self.poses = np.ascontiguousarray(poses_ngp, dtype=np.float32)          # [n, 4, 3] NGP space
         self.n_img = self.poses.shape[0]
         rows = []
@@ -105,7 +109,7 @@ class DeviceRayTable:
         self.batches_drawn = 0
 
     def get_alldata(self):                  # hashnerf_dataset.py:55-73
-        aabb_scale = 1
+        aabb_scale = self.aabb_scale
         return {'aabb_scale': aabb_scale, 'aabb_range': (0.5 - aabb_scale / 2, 0.5 + aabb_scale / 2),
                 'poses': self.poses, 'focal': np.ones((self.n_img, 2), dtype=float) * self.focal,
                 'metadata': synthetic.metadata_rows(self.n_img, self.focal)}

@@ -200,11 +200,13 @@ class KiloNerfMLP(nn.Module):
         self.resolution = list(resolution)
         self.distilled_config = distilled_config
         self.embedder = builder.build_embedder(embedder)
-        occ = torch.load(occupancy_checkpoint) if isinstance(occupancy_checkpoint, str) else occupancy_checkpoint
+        occ = (torch.load(occupancy_checkpoint, map_location='cpu', weights_only=True) if isinstance(occupancy_checkpoint, str)
+               else occupancy_checkpoint)
         cp = distilled_checkpoint
         if isinstance(cp, str):
             try:
-                cp = torch.load(cp)                                   # weights_only: plain tensors / dicts
+                # weights_only spelled out: torch < 2.6 defaults to a full unpickle, which `trust_pickle=False` must not allow
+                cp = torch.load(cp, map_location='cpu', weights_only=True)
             except Exception:                                         # noqa: BLE001  the reference's pickled Node tree
                 if not trust_pickle:
                     raise NotImplementedError(
@@ -237,21 +239,16 @@ class KiloNerfMLP(nn.Module):
         pos_ch, dir_ch = self.embedder.get_embed_ch()
         self.multi_network = MultiNetwork(dm.shape[0], pos_ch, dir_ch, 4, 32, num_hidden_layers, None, True, 32, 'relu')
         self.multi_network.load_state_dict({k: torch.as_tensor(v) for k, v in state_dict.items()}, strict=True)
-        self._host = {}
 
     def get_view_dependent_parameters(self):
         return self.multi_network.view_dependent_parameters
 
     def _host3(self, t):
-        """python floats of a 3-vector that may live on the device (one read-back per distinct tensor, cached)"""
+        """python floats of a 3-vector.  A device tensor costs one read-back per call: the values are NOT cached by tensor
+        identity (the reference pipeline builds these tensors anew every batch, and a freed address is reused)."""
         if not torch.is_tensor(t):
             return [float(v) for v in t]
-        key = (t.data_ptr(), t._version, str(t.device))
-        if key not in self._host:
-            if len(self._host) > 8:
-                self._host.clear()
-            self._host[key] = [float(v) for v in t.reshape(-1).tolist()]
-        return self._host[key]
+        return [float(v) for v in t.detach().reshape(-1).tolist()]
 
     def forward(self, data):
         fixed_res = [x // 16 for x in self.resolution]                      # kilonerf_mlp.py:146

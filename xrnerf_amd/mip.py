@@ -211,6 +211,8 @@ class MipNerfNetwork(NerfNetwork):
         return rgb, image, disp, idx
 
     def val_step(self, data, optimizer=None, **kwargs):
+        if not self.use_multiscale:                  # networks/mipnerf.py:76-78 (configs/mipnerf/mipnerf_blender.py)
+            return super().val_step(data, **kwargs)
         rank, _ = get_dist_info()
         if rank != 0:
             return {}

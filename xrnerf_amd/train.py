@@ -47,9 +47,9 @@ class FusedAdam(torch.optim.Optimizer):
     mmcv's EMAHook keeps (configs/instant_ngp/nerf_blender_local01.py:14-24), in ONE pass over
     p, g, m, v(, ema) per tensor (xr_adam_step)."""
 
-    def __init__(self, params, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, weight_decay=1e-6, ema_momentum=None):
+    def __init__(self, params, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, weight_decay=1e-6, ema_momentum=None, ema_warm_up=100):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
-                                      ema_momentum=ema_momentum))
+                                      ema_momentum=ema_momentum, ema_warm_up=ema_warm_up))
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -72,10 +72,12 @@ class FusedAdam(torch.optim.Optimizer):
                 chunk = [t for t in todo[:4] if t[2]['step'] == todo[0][2]['step']]
                 todo = [t for t in todo if all(t is not c for c in chunk)]
                 emas = [c[2].get('ema') for c in chunk] if group['ema_momentum'] is not None else None
+                # mmcv's EMAHook warms its momentum up: min(momentum, (1 + iter) / (warm_up + iter)), iter = 0, 1, ...
+                it = chunk[0][2]['step'] - 1
+                mom = min(group['ema_momentum'], (1.0 + it) / (group['ema_warm_up'] + it)) if emas else 0.0
                 ops.adam_step_multi([c[0] for c in chunk], [c[1] for c in chunk], [c[2]['m'] for c in chunk],
                                     [c[2]['v'] for c in chunk], chunk[0][2]['step'], group['lr'], group['betas'][0],
-                                    group['betas'][1], group['eps'], group['weight_decay'], emas,
-                                    group['ema_momentum'] or 0.0)
+                                    group['betas'][1], group['eps'], group['weight_decay'], emas, mom)
 
 
 def step_lr(base_lr, it, step=10000, gamma=0.2):
@@ -98,6 +100,46 @@ class SyntheticLego(DeviceRayTable):
         super().__init__(device, synthetic.lego_cameras(n_img, seed=seed), lambda k, o, d: _render_boxes(o, d, boxes),
                          H, W, float(synthetic.LEGO_FOCAL) * W / 800.0, seed=seed if shuffle_seed is None else shuffle_seed,
                          shuffle=shuffle)
+
+
+class SyntheticFern(DeviceRayTable):
+    """BASELINE config #4 stand-in: an UNBOUNDED forward-facing scene (nerf_llff_data/fern-shaped: 20 cameras on a small
+    patch all looking the same way, 1008 x 756, focal 815 px), aabb_scale = 16 -> five occupancy cascades are active
+    (ngp_grid_sampler.py:83-85; ray_sampler_header.h:37-54 picks the cascade from the step size and the position).  Near
+    geometry sits inside the unit cube around (0.5, 0.5, 0.5), far geometry up to 7 units behind it.  The reference has
+    no such config (configs/instant_ngp/ only holds the bounded Blender one; HashNerfDataset hard-codes aabb_scale = 1):
+    same model, sampler and kernels, only `aabb_scale` differs."""
+
+    def __init__(self, device, n_img=20, H=756, W=1008, seed=6, shuffle=True, shuffle_seed=None):
+        rng = np.random.default_rng(seed)
+        focal = 815.0 * W / 1008.0
+        poses44 = []
+        for _ in range(n_img):
+            c2w = np.eye(4)                                      # NeRF convention: the camera looks down its -z axis
+            c2w[:3, 3] = [rng.uniform(-0.9, 0.9), rng.uniform(-0.6, 0.6), 3.6 + rng.uniform(-0.2, 0.2)]
+            a, b = rng.uniform(-0.05, 0.05, 2)                   # small pan / tilt
+            ry = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+            rx = np.array([[1, 0, 0], [0, np.cos(b), -np.sin(b)], [0, np.sin(b), np.cos(b)]])
+            c2w[:3, :3] = ry @ rx
+            poses44.append(c2w)
+        poses = synthetic.poses_nerf2ngp(np.stack(poses44))
+        # geometry along the common viewing direction, in NGP space: the centre ray of camera 0
+        o0, d0 = synthetic.camera_rays(poses[0], H, W, focal, np.array([(H // 2) * W + W // 2]))
+        fwd = d0[0] / np.linalg.norm(d0[0])
+        centre = np.array([0.5, 0.5, 0.5])
+        lo, hi = [], []
+        for k in range(36):
+            depth = [0.0, 0.1, 0.25, 0.6, 1.2, 2.0, 3.2, 4.8, 6.5][k % 9] + rng.uniform(-0.05, 0.05)
+            size = 0.06 + 0.09 * depth                           # farther boxes are bigger (similar angular size)
+            lateral = rng.uniform(-0.45, 0.45, 3) * (1.0 + 1.1 * depth)
+            lateral -= fwd * lateral.dot(fwd)
+            c = centre + fwd * depth + lateral
+            h = size * rng.uniform(0.5, 1.0, 3)
+            lo.append(c - h); hi.append(c + h)
+        self.boxes = torch.tensor(np.stack([np.array(lo), np.array(hi)], 1), dtype=torch.float32)
+        boxes = self.boxes.to(device)
+        super().__init__(device, poses, lambda k, o, d: _render_boxes(o, d, boxes), H, W, focal,
+                         seed=seed if shuffle_seed is None else shuffle_seed, shuffle=shuffle, aabb_scale=16)
 
 
 def _lego_boxes(seed=2, fill=0.07, n_boxes=40):

@@ -288,7 +288,52 @@ class NerfNetwork(BaseNerfNetwork):
         return {'loss': loss, 'log_vars': {'loss': loss.item(), 'psnr': psnr.item()}, 'num_samples': ret['rgb'].shape[0]}
 
     def val_step(self, data, optimizer=None, **kwargs):
-        raise NotImplementedError('image-level validation loops belong to the dataset / hook layer (out of scope)')
+        """networks/nerf.py:93-142: render the validation poses (timed per frame, pipeline included) and the spiral
+        poses through `val_pipeline` (set by the validation hook) in `chunk`-sized pieces; rank 0 only"""
+        import time
+        from .networks import get_dist_info, recover_shape, unfold_batching
+        if self.phase == 'test':
+            return self.test_step(data, **kwargs)
+        rank, _ = get_dist_info()
+        if rank != 0:
+            return {}
+        for k in data:
+            data[k] = unfold_batching(data[k])
+        poses, images, spiral_poses = data['poses'], data['images'], data['spiral_poses']
+        rgbs, disps, gt_imgs, elapsed = [], [], [], []
+        with torch.no_grad():
+            for i in range(poses.shape[0]):
+                start = time.time()
+                frame = self.val_pipeline({'pose': poses[i]})
+                ret = self.batchify_forward(frame, is_test=True)
+                rgb = recover_shape(ret['rgb'], frame['src_shape']).cpu().numpy()     # the read-back ends the frame
+                elapsed.append(time.time() - start)
+                rgbs.append(rgb)
+                disps.append(recover_shape(ret['disp'], frame['src_shape']).cpu().numpy())
+                gt_imgs.append(images[i].cpu().numpy())
+            spiral_rgbs, spiral_disps = [], []
+            for i in range(spiral_poses.shape[0]):
+                frame = self.val_pipeline({'pose': spiral_poses[i]})
+                ret = self.batchify_forward(frame, is_test=True)
+                spiral_rgbs.append(recover_shape(ret['rgb'], frame['src_shape']).cpu().numpy())
+                spiral_disps.append(recover_shape(ret['disp'], frame['src_shape']).cpu().numpy())
+        return {'spiral_rgbs': spiral_rgbs, 'spiral_disps': spiral_disps, 'rgbs': rgbs, 'disps': disps, 'gt_imgs': gt_imgs,
+                'elapsed_time': elapsed}
+
+    def test_step(self, data, **kwargs):
+        """networks/nerf.py:144-168 (the runner only knows train_step / val_step: val_step + phase == 'test')"""
+        from .networks import get_dist_info, recover_shape, unfold_batching
+        rank, _ = get_dist_info()
+        if rank != 0:
+            return {}
+        for k in data:
+            data[k] = unfold_batching(data[k])
+        image, idx = data['image'], data['idx'].item()
+        with torch.no_grad():
+            frame = self.val_pipeline({'pose': data['pose']})
+            ret = self.batchify_forward(frame, is_test=True)
+        rgb = recover_shape(ret['rgb'], frame['src_shape']).cpu().numpy()
+        return {'rgb': rgb, 'gt_img': image.cpu().numpy(), 'idx': idx}
 
     def set_val_pipeline(self, func):
         self.val_pipeline = func
