@@ -273,6 +273,66 @@ def kilonerf_config5(dev, frames=8, cpu_seconds=10.0):
     return res
 
 
+def ngp_f16_mlp_mode(dev, n_img, steps):
+    """Second line in the reference's own arithmetic (tiny-cuda-nn runs FullyFusedMLP in fp16 with fp32 accumulation,
+    hashnerf_mlp.py:76-77): the same training iterations with the fused MLP on v_mfma_f32_32x32x16_f16 (fp32 tables,
+    parameters, gradients and outputs; xrnerf_amd.ops.set_precision('f16')).  The headline stays the fp32 parity mode."""
+    ops.set_precision('f16')
+    try:
+        tr = Trainer(dev, n_img=n_img)
+        sampler = tr.net.sampler
+        pre, hist = 0, [sampler.n_rays_per_batch]
+        while pre < PREROLL_MAX:
+            for _ in range(16):
+                tr.step()
+            pre += 16
+            hist.append(sampler.n_rays_per_batch)
+            if pre >= PREROLL_MIN and len(hist) >= 3 and abs(hist[-1] - hist[-2]) <= 0.02 * hist[-2] and abs(hist[-2] - hist[-3]) <= 0.02 * hist[-3]:
+                break
+        freq = sampler.update_grid_freq
+        want = max(1, int(round(steps / float(freq))))
+        first_off = max(0, min(freq - 1, (steps - 1 - (want - 1) * freq) // 2))
+        for _ in range(((-tr.iter) % freq - first_off) % freq):
+            tr.step()
+        torch.cuda.synchronize()
+        r0, s0, it0 = tr.rays_done, tr.samples_done, tr.iter
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tr.step()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        rays, samples = tr.rays_done - r0, tr.samples_done - s0
+        s1 = tr.samples_done
+        ops.TIMER = ops.KernelTimer(only={'xr_nerf_mlp_fwd', 'xr_nerf_mlp_bwd'}, train_only=True)
+        for _ in range(32):
+            tr.step()
+        torch.cuda.synchronize()
+        timer, ops.TIMER = ops.TIMER, None
+        s_win = tr.samples_done - s1
+        kern = {}
+        for k, (n_l, ms_l, _) in timer.summary().items():
+            fl = ALGO[k][1] * s_win
+            kern[k] = {'avg_launch_us': ms_l * 1e3 / max(n_l, 1), 'achieved_TFLOPs': fl / (ms_l * 1e-3) / 1e12,
+                       'peak_TFLOPs': MFMA_PEAK['f16'], 'frac': fl / (ms_l * 1e-3) / 1e12 / MFMA_PEAK['f16']}
+        # what the precision costs in the image: the same weights rendered in both modes
+        H = W = 800
+        rgb16, _ = render_frame(tr.net, tr.data.poses[0], H, W, tr.data.focal)
+        k1 = tr.net.sampler.k1_calls
+        ops.set_precision('f32')
+        tr.net.sampler.k1_calls = k1 - 1                    # same jitter as the fp16 frame
+        rgb32, _ = render_frame(tr.net, tr.data.poses[0], H, W, tr.data.focal)
+        dev_rgb = (rgb16 - rgb32).abs()
+        return {'workload': 'the headline iterations with the fused MLP in fp16 (fp32 accumulate), %d timed iterations %d..%d after %d '
+                            'pre-roll iterations' % (steps, it0, it0 + steps - 1, pre),
+                'dtype': 'f16 MLP operands / f32 accumulate, f32 hash tables, parameters, gradients, compositor',
+                'value': rays / el, 'unit': 'rays/s', 'ms_per_step': el * 1e3 / steps, 'rays_per_step': rays / steps,
+                'samples_per_ray': samples / max(rays, 1), 'kernels': kern,
+                'rendered_rgb_deviation_vs_f32': {'max_abs': float(dev_rgb.max()), 'mean_abs': float(dev_rgb.mean())},
+                'final_train_psnr': float(tr.step()['log_vars']['psnr'])}
+    finally:
+        ops.set_precision('f32')
+
+
 def ngp_config4_unbounded(dev, steps=64):
     """Secondary line (BASELINE config #4): the same Instant-NGP model on an UNBOUNDED forward-facing scene, 1008 x 756,
     aabb_scale = 16 (five occupancy cascades: 10.5 M-point grid queries below iteration 256, 2 x 2.6 M after), synthetic
@@ -413,6 +473,7 @@ def main():
     ap.add_argument('--no-mip', action='store_true', help='skip the secondary Mip-NeRF (config #3) line')
     ap.add_argument('--no-kilo', action='store_true', help='skip the secondary KiloNeRF (config #5) line')
     ap.add_argument('--no-unbounded', action='store_true', help='skip the secondary unbounded-scene (config #4) line')
+    ap.add_argument('--no-f16', action='store_true', help='skip the second line in the reference\'s fp16 MLP precision')
     ap.add_argument('--cpu-worker', type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -605,8 +666,11 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             guarded('cpu_baseline', cpu_baseline)
             guarded('cpu_baseline_vanilla_nerf_config1', cpu_vanilla_nerf)
-        if world == 1 and not (args.no_mip and args.no_kilo and args.no_unbounded):
+        if world == 1 and not (args.no_mip and args.no_kilo and args.no_unbounded and args.no_f16):
             del tr
+            torch.cuda.empty_cache()
+        if world == 1 and not args.no_f16:
+            guarded('ngp_f16_mlp_mode', lambda: ngp_f16_mlp_mode(dev, args.n_img, max(args.steps, 32)))
             torch.cuda.empty_cache()
         if world == 1 and not args.no_unbounded:
             guarded('ngp_config4_unbounded', lambda: ngp_config4_unbounded(dev))

@@ -200,6 +200,18 @@ int xr_nerf_mlp_bwd(const float* enc_t, uint32_t ld, const float* dirs, uint32_t
                     float pad_value, const float* draw /*[n,4]*/, float* denc_t, float* grad_w_density,
                     float* grad_w_color, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Reference-precision mode of the two calls above: tiny-cuda-nn computes FullyFusedMLP in fp16 with fp32 accumulation
+ * (the reference casts its half outputs to fp32, hashnerf_mlp.py:76-77).  Same contracts, parameters and gradients stay
+ * fp32 in memory; weights / activations are rounded to fp16 inside the kernel (v_mfma_f32_32x32x16_f16), gradients carry
+ * tcnn's loss scale 128 through the fp16 stages.  Topology (1, 2) only.  The fp32 calls remain the parity mode. */
+int xr_nerf_mlp_fwd_f16(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
+                        const uint32_t* n_dev, const uint32_t* rows, const float* w_density, const float* w_color,
+                        int n_hidden_density, int n_hidden_color, float pad_value, float* raw, void* stream);
+int xr_nerf_mlp_bwd_f16(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
+                        const uint32_t* n_dev, const float* w_density, const float* w_color, int n_hidden_density,
+                        int n_hidden_color, float pad_value, const float* draw, float* denc_t, float* grad_w_density,
+                        float* grad_w_color, void* workspace, size_t workspace_bytes, void* stream);
+
 /* tcnn.Network(FullyFusedMLP) on its own (compatibility surface; the hot path uses the fused kernels above):
  * x [n, n_in] with arbitrary row / column strides (in floats), n_in <= 32, missing input columns = pad_value;
  * weights in the tcnn layout; y / dy [n,16] row-major (columns >= n_output_dims are padding); dx [n, n_in]

@@ -20,6 +20,7 @@ struct Wave {
     uint64_t slot[2][64];
     bool pred[2][64];
     float a[2][64], b[2][64];
+    float a8[2][64][8], b8[2][64][8];
     int stamp[2][64];
 };
 // Context switch: callee-saved registers + stack pointer, x86-64 SysV (glibc's swapcontext makes a sigprocmask system
@@ -164,6 +165,28 @@ void wave_mfma_32x32x2(float a, float b, float* c16) {
             const float av = w.stamp[p][i + 32 * k] == id ? w.a[p][i + 32 * k] : 0.f;
             const float bv = w.stamp[p][j + 32 * k] == id ? w.b[p][j + 32 * k] : 0.f;
             acc = fmaf(av, bv, acc);
+        }
+        c16[r] = acc;
+    }
+}
+
+// v_mfma_f32_32x32x16_f16: A[i = l & 31][k-slot (l >> 5, e)], B[k-slot (l >> 5, e)][j = l & 31], the C/D layout of the 32x32 family;
+// operands arrive already widened to fp32 (products of two halves are exact there), the sum is taken in fp32
+void wave_mfma_32x32x16(const float* a8, const float* b8, float* c16) {
+    Lane* me = S.cur;
+    Wave& w = S.waves[me->wave];
+    const int l = me->lane, id = ++me->coll, p = id & 1;
+    for (int e = 0; e < 8; ++e) { w.a8[p][l][e] = a8[e]; w.b8[p][l][e] = b8[e]; }
+    w.stamp[p][l] = id;
+    wave_sync();
+    const int j = l & 31, hi = l >> 5;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c16[r];
+        for (int h = 0; h < 2; ++h) {
+            const bool pa = w.stamp[p][i + 32 * h] == id, pb = w.stamp[p][j + 32 * h] == id;
+            for (int e = 0; e < 8; ++e)
+                acc += (pa ? w.a8[p][i + 32 * h][e] : 0.f) * (pb ? w.b8[p][j + 32 * h][e] : 0.f);
         }
         c16[r] = acc;
     }

@@ -86,6 +86,7 @@ int block_or(int v);
 uint64_t wave_exchange(uint64_t mine, int src_lane);          // value deposited by lane src_lane (own value if that lane is gone)
 uint64_t wave_ballot(bool pred);
 void wave_mfma_32x32x2(float a, float b, float* c16);
+void wave_mfma_32x32x16(const float* a8, const float* b8, float* c16);
 void* dyn_lds();
 }
 #define threadIdx (emu::tid())
@@ -140,6 +141,17 @@ inline emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32_emu(float a, float b, emu
     return c;
 }
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 __builtin_amdgcn_mfma_f32_32x32x2f32_emu
+// v_mfma_f32_32x32x16_f16: A / B = 8 halves per lane (k-slots (lane >> 5, e)), products exact in fp32, fp32 accumulation
+typedef _Float16 emu_h8 __attribute__((ext_vector_type(8)));
+inline emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16_emu(emu_h8 a, emu_h8 b, emu_f32x16 c, int, int, int) {
+    float fa[8], fb[8], t[16];
+    for (int e = 0; e < 8; ++e) { fa[e] = (float)a[e]; fb[e] = (float)b[e]; }
+    for (int r = 0; r < 16; ++r) t[r] = c[r];
+    emu::wave_mfma_32x32x16(fa, fb, t);
+    for (int r = 0; r < 16; ++r) c[r] = t[r];
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16 __builtin_amdgcn_mfma_f32_32x32x16_f16_emu
 
 // cooperative fibers never pre-empt each other: plain read-modify-write is atomic here
 template <typename T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }

@@ -66,6 +66,13 @@ def test_fused_mlp_on_the_host(O, edev):
         T.test_nerf_mlp_bwd(O, edev, n)
 
 
+def test_reference_precision_mlp_on_the_host(edev):
+    """the fp16-MFMA mode (v_mfma_f32_32x32x16_f16 emulated with its operand layout) against the numpy fp16 statement"""
+    import test_gpu_tcnn as T
+    for n in (32, 100):
+        T.test_nerf_mlp_reference_precision_mode(edev, n)
+
+
 def test_edge_cases_on_the_host(O, edev):
     import test_gpu_edge_cases as T
     T.test_fully_occupied_grid_hits_the_step_cap(O, edev)

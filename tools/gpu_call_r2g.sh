@@ -1,0 +1,15 @@
+#!/bin/bash
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O
+cd $R
+timeout 600 python -m pytest tests/test_gpu_tcnn.py tests/test_gpu_trajectory.py tests/test_gpu_network.py -m gpu -q -x 2>&1 | tail -3
+python tools/microbench_mlp_modes.py 2>&1 | grep -v amdgpu | tee $O/r2g_mlp_modes.txt
+timeout 600 python bench.py --steps 20 --warmup 5 --no-mip --no-kilo --no-unbounded --no-cpu-baseline > $O/r2g_bench.json 2> $O/r2g_bench_err.txt; tail -c 300 $O/r2g_bench_err.txt
+python - <<'PY'
+import json, os
+d = json.loads(open(os.path.join(os.environ.get('GRAFT_REPO_ROOT', '/root/repo'), 'gpurun_out', 'r2g_bench.json')).read().strip().splitlines()[-1])
+print('f32: %.3e rays/s  %.3f ms/step' % (d['value'], d['ms_per_step']))
+for k, v in d['roofline_kernels'].items(): print('  %-22s %8.1f us  frac %.3f' % (k, v['avg_launch_us'], v['frac']))
+f = d.get('ngp_f16_mlp_mode', {})
+print('f16:', {k: v for k, v in f.items() if k not in ('workload',)})
+PY

@@ -40,6 +40,8 @@ SIGNATURES = {
     'xr_sh4': (_i32, [_vp, _u32, _u32, _vp, _vp]),
     'xr_nerf_mlp_fwd': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp]),
     'xr_nerf_mlp_bwd_workspace_bytes': (_sz, [_u32]),
+    'xr_nerf_mlp_fwd_f16': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp]),
+    'xr_nerf_mlp_bwd_f16': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'xr_nerf_mlp_bwd': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'xr_mlp_fwd': (_i32, [_vp, C.c_long, C.c_long, _i32, _f, _u32, _vp, _i32, _vp, _vp]),
     'xr_mlp_bwd_workspace_bytes': (_sz, [_i32]),

@@ -834,11 +834,14 @@ extern "C" int xr_hashgrid_fwd(const float* table, const float* x, uint32_t x_st
     GridMeta gm; uint32_t hm;
     XR_REQUIRE(fill_meta(&gm, &hm, n_levels, scale_host, resolution_host, offset_host) == 0, "bad level metadata");
     hipStream_t stream = (hipStream_t)stream_;
-    // XR_HG_FWD_MODE (measurement switches, read once): bit 4 (16) = two-list balanced XCD mapping (order 4, default),
-    // bit 0 = cost-weighted mapping (order 3), neither = level-major (order 1, round 1); bit 1 = non-temporal table loads
-    // at the hashed levels, bit 2 = coarsest levels from LDS, bit 3 = round-1 pair gathers; XR_HG_WSH = "a,b,c": order 3's
-    // log2 cost of a sample block at dense levels < 2^16 entries, larger dense levels, hashed levels
-    static const int mode = scatter_env("XR_HG_FWD_MODE", 16);
+    // XR_HG_FWD_MODE (measurement switches, read once): bit 4 (16) = two-list balanced XCD mapping (order 4), bit 0 =
+    // cost-weighted mapping (order 3), neither = level-major (order 1); bit 1 = non-temporal table loads at the hashed
+    // levels, bit 2 = coarsest levels from LDS, bit 3 = 16-B pair gathers; XR_HG_WSH = "a,b,c": order 3's log2 cost of a
+    // sample block at dense levels < 2^16 entries, larger dense levels, hashed levels.
+    // Default 8 = level-major + pair gathers, the fastest of the measured set at 2^18 ray-ordered samples
+    // (profiles/r02_microbench_fwd_variants.txt: 8: 88.2 us, 24: 88.6, 0: 92.8, 16: 96.8, 20: 101.6, 18: 254.0; the limiter is
+    // the L2's random-line rate, profiles/r02_gather_probe.txt, which none of the mappings changes).
+    static const int mode = scatter_env("XR_HG_FWD_MODE", 8);
     static int wsh3[3] = {-1, 0, 0};
     if (wsh3[0] < 0) {
         int a = 0, b = 1, c = 2;

@@ -576,6 +576,339 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void k_mlp_bwd(const float* __restr
     for (int e = threadIdx.x; e < GW; e += MLP_THREADS) out[e] = red[e];
 }
 
+// ================================================================== reference-precision mode (fp16 MFMA)
+// tiny-cuda-nn, which the reference calls, runs FullyFusedMLP in fp16 with fp32 accumulation and hands fp16 outputs back
+// (hashnerf_mlp.py:76-77 casts them to fp32).  This is the same arithmetic on v_mfma_f32_32x32x16_f16 (16x the fp32
+// MFMA rate): weights and activations rounded to fp16, products summed in fp32, outputs taken from the fp32 accumulators.
+// Selected by xrnerf_amd.ops.set_precision('f16') / XRNERF_MLP_PRECISION=f16; the fp32 kernels above stay the parity
+// mode and the default.  Topology (1, 2) only (configs/instant_ngp).
+//
+// Same transposed scheme as above: a wave owns 32 samples, tiles are 32 neurons x 32 samples in the C/D layout
+//     lane l: column (sample) = l & 31, row (neuron) = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5).
+// One 32x32x16 step contracts over 16 k's: lane half hi supplies 8 of them to A (8 halves of weight row l & 31) and 8 to
+// B (8 halves of sample column l & 31).  A sum over k is order-free, so step t takes as its k's exactly the neurons the
+// lane ALREADY holds in registers 8 (t & 1) .. 8 (t & 1) + 7 of tile t >> 1:
+//     k-slot (t, hi, e)  <->  neuron hrow(t, hi, e) = 32 (t >> 1) + 16 (t & 1) + 8 (e >> 2) + (e & 3) + 4 hi
+// -- activations go from accumulators to the next layer's B operand by a register-local fp32 -> fp16 conversion, and the
+// weights are stored in LDS pre-permuted ([row][hi][t][8 halves], row stride + 16 B: conflict-free ds_read_b128).  The
+// backward keeps a second, transposed arrangement for the dX chain.  dW contracts over the tile's 32 samples through a
+// per-wave fp16 staging tile [row][32 samples (+8)].  Gradients are scaled by 128 before the fp16 conversion (tcnn's
+// loss scale) and unscaled in fp32.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+#define H16_LOSS_SCALE 128.0f
+
+__host__ __device__ constexpr int hrow(int t, int hi, int e) { return 32 * (t >> 1) + 16 * (t & 1) + 8 * (e >> 2) + (e & 3) + 4 * hi; }
+__host__ __device__ constexpr int h_rs(int k_dim) { return 2 * (k_dim / 16) * 8 + 8; }       // halves per row, 16-B pad
+
+// layer l of a (1 | 2)-hidden network in the two LDS arrangements (halves)
+template <int NH>
+struct HShape {
+    using S = NetShape<NH>;
+    __host__ __device__ static constexpr int f_off(int l) { int o = 0; for (int i = 0; i < l; ++i) o += S::out_rows_lds(i) * h_rs(S::in_dim(i)); return o; }
+    __host__ __device__ static constexpr int b_off(int l) { int o = 0; for (int i = 0; i < l; ++i) o += S::in_dim(i) * h_rs(S::out_rows_lds(i)); return o; }
+    static constexpr int f_halves = f_off(NH + 1);
+    static constexpr int b_halves = b_off(NH + 1);
+};
+
+// global fp32 [out][in] -> LDS fp16, forward arrangement (and the transposed one when `wb` is given).  The loop runs over the
+// SOURCE elements (coalesced global reads); the k-slot of neuron m is the inverse of hrow: e = m[1:0] | m[3] << 2,
+// hi = m[2], t = m >> 4.
+__device__ __forceinline__ int hslot(int m, int ns) {           // offset of neuron m inside a [hi][t][8] row of ns steps
+    const int e = (m & 3) | (((m >> 3) & 1) << 2), hi = (m >> 2) & 1, t = m >> 4;
+    return (hi * ns + t) * 8 + e;
+}
+template <int NH>
+__device__ inline void load_weights_h(_Float16* __restrict__ wf, _Float16* __restrict__ wb, const float* __restrict__ w, bool first_layer_rot) {
+    using S = NetShape<NH>;
+    using H = HShape<NH>;
+#pragma unroll
+    for (int l = 0; l <= NH; ++l) {
+        const int K = S::in_dim(l), rows = S::out_dim(l), prow = S::out_rows_lds(l);
+        const int ns = K / 16, rs = h_rs(K), nso = prow / 16, rsb = h_rs(prow);
+        _Float16* dst = wf + H::f_off(l);
+        _Float16* dstb = wb ? wb + H::b_off(l) : nullptr;
+        const float* src = w + S::glb_off(l);
+        for (int x = threadIdx.x; x < prow * K; x += MLP_THREADS) {
+            const int o = x / K, c = x % K;                                   // global [o][c]
+            const int m = (l == 0 && first_layer_rot) ? ((c + 1) & 31) : c;   // LDS slot of global column c
+            const _Float16 v = (_Float16)(o < rows ? src[x] : 0.f);
+            dst[o * rs + hslot(m, ns)] = v;
+            if (dstb) dstb[m * rsb + hslot(o, nso)] = v;
+        }
+    }
+}
+
+struct HTile { h8 p[2]; };                       // a 32 x 32 tile as the two fp16 B operands of its two K-steps
+__device__ __forceinline__ HTile to_h(const f32x16& t) {
+    HTile r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { r.p[0][e] = (_Float16)t[e]; r.p[1][e] = (_Float16)t[8 + e]; }
+    return r;
+}
+// out[TO] = W . in[TI]
+template <int TI, int TO>
+__device__ __forceinline__ void layer_fwd_h(const _Float16* __restrict__ wf, const HTile (&in)[TI], f32x16 (&out)[TO], int col, int hi) {
+    constexpr int NS = 2 * TI, RS = 2 * NS * 8 + 8;
+#pragma unroll
+    for (int to = 0; to < TO; ++to)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[to][r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+#pragma unroll
+        for (int to = 0; to < TO; ++to) {
+            const h8 a = *reinterpret_cast<const h8*>(wf + (to * 32 + col) * RS + (hi * NS + t) * 8);
+            out[to] = MFMA16(a, in[t >> 1].p[t & 1], out[to]);
+        }
+    }
+}
+// gin[TI] = W^T . g[TO]; only the first NSTEPS K-steps of g can be non-zero
+template <int TO, int TI, int NSTEPS = 2 * TO>
+__device__ __forceinline__ void layer_bwd_h(const _Float16* __restrict__ wb, const HTile (&g)[TO], f32x16 (&gin)[TI], int col, int hi) {
+    constexpr int NSO = 2 * TO, RSB = 2 * NSO * 8 + 8;
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gin[ti][r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NSTEPS; ++t) {
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) {
+            const h8 a = *reinterpret_cast<const h8*>(wb + (ti * 32 + col) * RSB + (hi * NSO + t) * 8);
+            gin[ti] = MFMA16(a, g[t >> 1].p[t & 1], gin[ti]);
+        }
+    }
+}
+#define HST 40                                   // staging row: 32 samples + 8 halves of padding (80 B)
+template <int TO, int TI>
+__device__ __forceinline__ void dw_stage_h(const HTile (&g)[TO], const HTile (&h)[TI], _Float16* __restrict__ stage, int col, int hi) {
+#pragma unroll
+    for (int to = 0; to < TO; ++to)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stage[(to * 32 + drow(r) + 4 * hi) * HST + col] = g[to].p[r >> 3][r & 7];
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stage[((TO + ti) * 32 + drow(r) + 4 * hi) * HST + col] = h[ti].p[r >> 3][r & 7];
+    __builtin_amdgcn_wave_barrier();
+}
+template <int TO, int TI>
+__device__ __forceinline__ void dw_mfma_h(f32x16 (&acc)[TO][TI], const _Float16* __restrict__ stage, int col, int hi) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        h8 a[TO], b[TI];
+#pragma unroll
+        for (int to = 0; to < TO; ++to) a[to] = *reinterpret_cast<const h8*>(stage + (to * 32 + col) * HST + 16 * t + 8 * hi);
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) b[ti] = *reinterpret_cast<const h8*>(stage + ((TO + ti) * 32 + col) * HST + 16 * t + 8 * hi);
+#pragma unroll
+        for (int to = 0; to < TO; ++to)
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti) acc[to][ti] = MFMA16(a[to], b[ti], acc[to][ti]);
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void scale_tile(f32x16& t, float s) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] *= s;
+}
+
+template <bool WITH_COLOR>
+__global__ __launch_bounds__(MLP_THREADS, 2) void k_nerf_mlp_fwd_h(const float* __restrict__ enc_t, uint32_t ld,
+                                                                    const float* __restrict__ dirs, uint32_t dir_stride,
+                                                                    uint32_t n, const uint32_t* __restrict__ n_dev,
+                                                                    const uint32_t* __restrict__ rows,
+                                                                    const float* __restrict__ w_density,
+                                                                    const float* __restrict__ w_color, float pad_value,
+                                                                    float4* __restrict__ raw) {
+    if (n_dev) n = min(n, *n_dev);
+    if (n == 0) return;
+    using HD = HShape<1>;
+    using HC = HShape<2>;
+    extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
+    _Float16* wd = ldsh;
+    _Float16* wc = ldsh + HD::f_halves;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, hi = lane >> 5;
+    const uint32_t n_tiles = (n + 31) / 32, stride = gridDim.x * MLP_WAVES;
+    uint32_t tile = blockIdx.x * MLP_WAVES + wave;
+    // the first tile's inputs are in flight while the workgroup converts the weights
+    f32x16 x;
+    float d3[3] = {0.f, 0.f, 0.f};
+    auto fetch = [&](uint32_t tl, f32x16& xe, float (&dd)[3]) {
+        const uint32_t s = tl * 32 + col, sc = s < n ? s : n - 1;
+        load_enc_tile(enc_t, ld, sc, xe, hi);
+        if (WITH_COLOR) {
+            const float* d = dirs + (size_t)(rows ? rows[sc] : sc) * dir_stride;
+            dd[0] = d[0]; dd[1] = d[1]; dd[2] = d[2];
+        }
+    };
+    if (tile < n_tiles) fetch(tile, x, d3);
+    load_weights_h<1>(wd, nullptr, w_density, false);
+    if (WITH_COLOR) load_weights_h<2>(wc, nullptr, w_color, true);
+    __syncthreads();
+    for (; tile < n_tiles; tile += stride) {
+        const uint32_t s = tile * 32 + col;
+        HTile xin[1] = {to_h(x)};
+        const float dx = d3[0], dy = d3[1], dz = d3[2];
+        if (tile + stride < n_tiles) fetch(tile + stride, x, d3);           // next tile's loads under this tile's MFMAs
+        f32x16 h[2], dout[1];
+        layer_fwd_h<1, 2>(wd + HD::f_off(0), xin, h, col, hi);
+        relu_tile(h[0]); relu_tile(h[1]);
+        HTile hh[2] = {to_h(h[0]), to_h(h[1])};
+        layer_fwd_h<2, 1>(wd + HD::f_off(1), hh, dout, col, hi);
+        float4 o = make_float4(0.f, 0.f, 0.f, dout[0][0]);
+        if (WITH_COLOR) {
+            f32x16 cin, cout[1];
+            const float dd[3] = {dx, dy, dz};
+            build_color_in(dout[0], dd, 3, 0, pad_value, cin, hi);
+            HTile ci[1] = {to_h(cin)};
+            layer_fwd_h<1, 2>(wc + HC::f_off(0), ci, h, col, hi);
+            relu_tile(h[0]); relu_tile(h[1]);
+            hh[0] = to_h(h[0]); hh[1] = to_h(h[1]);
+            layer_fwd_h<2, 2>(wc + HC::f_off(1), hh, h, col, hi);
+            relu_tile(h[0]); relu_tile(h[1]);
+            hh[0] = to_h(h[0]); hh[1] = to_h(h[1]);
+            layer_fwd_h<2, 1>(wc + HC::f_off(2), hh, cout, col, hi);
+            o.x = cout[0][0]; o.y = cout[0][1]; o.z = cout[0][2];
+        }
+        if (hi == 0 && s < n) raw[s] = o;
+    }
+}
+
+__global__ __launch_bounds__(MLP_THREADS, 1) void k_nerf_mlp_bwd_h(
+    const float* __restrict__ enc_t, uint32_t ld, const float* __restrict__ dirs, uint32_t dir_stride, uint32_t n,
+    const uint32_t* __restrict__ n_dev, const float* __restrict__ w_density, const float* __restrict__ w_color,
+    float pad_value, const float4* __restrict__ draw, float* __restrict__ denc_t, float* __restrict__ partial /*[grid][GW]*/) {
+    if (n_dev) n = min(n, *n_dev);
+    using SD = NetShape<1>;
+    using SC = NetShape<2>;
+    using HD = HShape<1>;
+    using HC = HShape<2>;
+    constexpr int GW = SD::glb_floats + SC::glb_floats;
+    constexpr int STAGE = 4 * 32 * HST;                                  // halves per wave
+    extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
+    _Float16* wdf = ldsh;
+    _Float16* wcf = wdf + HD::f_halves;
+    _Float16* wdb = wcf + HC::f_halves;
+    _Float16* wcb = wdb + HD::b_halves;
+    _Float16* stage_all = wcb + HC::b_halves;                           // MLP_WAVES * STAGE halves; doubles as the fp32 reduction buffer
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, hi = lane >> 5;
+    _Float16* stage = stage_all + wave * STAGE;
+    const uint32_t n_tiles = (n + 31) / 32, tstride = gridDim.x * MLP_WAVES;
+    // (measured: fetching the NEXT tile's 23 inputs under the current tile costs 40 more spilled registers in this
+    // one-wave-per-SIMD kernel: 86 -> 136 us at 2^18 samples; the forward kernel, with registers to spare, gains 28 -> 20 us)
+    load_weights_h<1>(wdf, wdb, w_density, false);
+    load_weights_h<2>(wcf, wcb, w_color, true);
+    __syncthreads();
+
+    f32x16 a_d0[2][1], a_d1[1][2], a_c0[2][1], a_c1[2][2], a_c2[1][2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        a_d0[0][0][r] = a_d0[1][0][r] = 0.f; a_d1[0][0][r] = a_d1[0][1][r] = 0.f;
+        a_c0[0][0][r] = a_c0[1][0][r] = 0.f;
+        a_c1[0][0][r] = a_c1[0][1][r] = a_c1[1][0][r] = a_c1[1][1][r] = 0.f;
+        a_c2[0][0][r] = a_c2[0][1][r] = 0.f;
+    }
+    for (uint32_t tile = blockIdx.x * MLP_WAVES + wave; tile < n_tiles; tile += tstride) {
+        const uint32_t s = tile * 32 + col;
+        const bool live = s < n;
+        const uint32_t sc = live ? s : n - 1;
+        // ---- recompute the forward; every activation is kept in the fp16 form the forward used
+        f32x16 t0, t2[2], dout[1];
+        load_enc_tile(enc_t, ld, sc, t0, hi);
+        HTile xe[1] = {to_h(t0)};
+        layer_fwd_h<1, 2>(wdf + HD::f_off(0), xe, t2, col, hi);
+        relu_tile(t2[0]); relu_tile(t2[1]);
+        HTile hd[2] = {to_h(t2[0]), to_h(t2[1])};
+        layer_fwd_h<2, 1>(wdf + HD::f_off(1), hd, dout, col, hi);
+        build_color_in(dout[0], dirs, dir_stride, sc, pad_value, t0, hi);
+        HTile cin[1] = {to_h(t0)};
+        layer_fwd_h<1, 2>(wcf + HC::f_off(0), cin, t2, col, hi);
+        relu_tile(t2[0]); relu_tile(t2[1]);
+        HTile hc1[2] = {to_h(t2[0]), to_h(t2[1])};
+        layer_fwd_h<2, 2>(wcf + HC::f_off(1), hc1, t2, col, hi);
+        relu_tile(t2[0]); relu_tile(t2[1]);
+        HTile hc2[2] = {to_h(t2[0]), to_h(t2[1])};
+        // ---- output gradients (x loss scale)
+        float4 drc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live && hi == 0) drc = draw[s];
+        f32x16 g1, g2[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g1[r] = 0.f;
+        g1[0] = drc.x * H16_LOSS_SCALE; g1[1] = drc.y * H16_LOSS_SCALE; g1[2] = drc.z * H16_LOSS_SCALE;
+        HTile gh1[1] = {to_h(g1)};
+        // color output layer
+        dw_stage_h<1, 2>(gh1, hc2, stage, col, hi);
+        layer_bwd_h<1, 2, 1>(wcb + HC::b_off(2), gh1, g2, col, hi);          // rows 0..2: the first K-step only
+        dw_mfma_h<1, 2>(a_c2, stage, col, hi);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {                                        // relu mask by the fp16 activation's sign
+            g2[0][r] = (float)hc2[0].p[r >> 3][r & 7] > 0.f ? g2[0][r] : 0.f;
+            g2[1][r] = (float)hc2[1].p[r >> 3][r & 7] > 0.f ? g2[1][r] : 0.f;
+        }
+        HTile gh2[2] = {to_h(g2[0]), to_h(g2[1])};
+        // color hidden layer 2
+        dw_stage_h<2, 2>(gh2, hc1, stage, col, hi);
+        layer_bwd_h<2, 2>(wcb + HC::b_off(1), gh2, g2, col, hi);
+        dw_mfma_h<2, 2>(a_c1, stage, col, hi);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            g2[0][r] = (float)hc1[0].p[r >> 3][r & 7] > 0.f ? g2[0][r] : 0.f;
+            g2[1][r] = (float)hc1[1].p[r >> 3][r & 7] > 0.f ? g2[1][r] : 0.f;
+        }
+        gh2[0] = to_h(g2[0]); gh2[1] = to_h(g2[1]);
+        // color input layer
+        dw_stage_h<2, 1>(gh2, cin, stage, col, hi);
+        f32x16 gi[1];
+        layer_bwd_h<2, 1>(wcb + HC::b_off(0), gh2, gi, col, hi);             // dL/d(color input slots)
+        dw_mfma_h<2, 1>(a_c0, stage, col, hi);
+#pragma unroll
+        for (int r = 8; r < 16; ++r) gi[0][r] = 0.f;                          // slots >= 16 are SH / padding, not density outputs
+        if (hi == 0) gi[0][0] = drc.w * H16_LOSS_SCALE;                       // row 0 = sigma
+        gh1[0] = to_h(gi[0]);
+        // density output layer
+        dw_stage_h<1, 2>(gh1, hd, stage, col, hi);
+        layer_bwd_h<1, 2, 1>(wdb + HD::b_off(1), gh1, g2, col, hi);          // 16 real output neurons: the first K-step
+        dw_mfma_h<1, 2>(a_d1, stage, col, hi);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            g2[0][r] = (float)hd[0].p[r >> 3][r & 7] > 0.f ? g2[0][r] : 0.f;
+            g2[1][r] = (float)hd[1].p[r >> 3][r & 7] > 0.f ? g2[1][r] : 0.f;
+        }
+        gh2[0] = to_h(g2[0]); gh2[1] = to_h(g2[1]);
+        // density input layer
+        dw_stage_h<2, 1>(gh2, xe, stage, col, hi);
+        layer_bwd_h<2, 1>(wdb + HD::b_off(0), gh2, gi, col, hi);             // dL/d(encoded features) x loss scale
+        dw_mfma_h<2, 1>(a_d0, stage, col, hi);
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) denc_t[(size_t)(drow(r) + 4 * hi) * ld + s] = gi[0][r] * (1.0f / H16_LOSS_SCALE);
+        }
+    }
+    constexpr float inv = 1.0f / H16_LOSS_SCALE;
+    scale_tile(a_d0[0][0], inv); scale_tile(a_d0[1][0], inv); scale_tile(a_d1[0][0], inv); scale_tile(a_d1[0][1], inv);
+    scale_tile(a_c0[0][0], inv); scale_tile(a_c0[1][0], inv);
+    scale_tile(a_c1[0][0], inv); scale_tile(a_c1[0][1], inv); scale_tile(a_c1[1][0], inv); scale_tile(a_c1[1][1], inv);
+    scale_tile(a_c2[0][0], inv); scale_tile(a_c2[0][1], inv);
+    // ---- block reduction of dW through LDS (fp32, compact global layout), then one partial per block
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(stage_all);
+    float* redc = red + SD::glb_floats;
+    for (int w = 0; w < MLP_WAVES; ++w) {
+        if (wave == w) {
+            dw_flush<2, 1>(a_d0, red + SD::glb_off(0), 64, 32, false, col, hi, w == 0);
+            dw_flush<1, 2>(a_d1, red + SD::glb_off(1), 16, 64, false, col, hi, w == 0);
+            dw_flush<2, 1>(a_c0, redc + SC::glb_off(0), 64, 32, true, col, hi, w == 0);
+            dw_flush<2, 2>(a_c1, redc + SC::glb_off(1), 64, 64, false, col, hi, w == 0);
+            dw_flush<1, 2>(a_c2, redc + SC::glb_off(2), 16, 64, false, col, hi, w == 0);
+        }
+        __syncthreads();
+    }
+    float* out = partial + (size_t)blockIdx.x * GW;
+    for (int e = threadIdx.x; e < GW; e += MLP_THREADS) out[e] = red[e];
+}
+
 // ------------------------------------------------------------------ host side
 static int g_cus = 0;
 extern "C" int xr_device_cus(void) {
@@ -713,6 +1046,55 @@ extern "C" int xr_mlp_bwd(const float* x, long row_stride, long col_stride, int 
     }
     hipLaunchKernelGGL(k_reduce_partials, dim3(xr_div_up(gw, 64)), dim3(256), 0, stream, (const float*)workspace, grid,
                        (uint32_t)gw, (uint32_t)gw, grad_w, grad_w);
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}
+
+// ---- reference-precision mode entry points (same contracts as xr_nerf_mlp_fwd / xr_nerf_mlp_bwd)
+extern "C" int xr_nerf_mlp_fwd_f16(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
+                                   const uint32_t* n_dev, const uint32_t* rows, const float* w_density, const float* w_color,
+                                   int n_hidden_density, int n_hidden_color, float pad_value, float* raw, void* stream_) {
+    if (n == 0) return XR_OK;
+    XR_REQUIRE(enc_t && w_density && raw, "null pointer");
+    XR_REQUIRE(!dirs || (w_color && dir_stride >= 3), "color path needs w_color and dir_stride >= 3");
+    XR_REQUIRE(ld >= n && ((uintptr_t)raw & 15) == 0, "bad ld / raw alignment");
+    XR_REQUIRE(n_hidden_density == 1 && n_hidden_color == 2, "the fp16 mode is built for the (1,2) hidden-layer topology");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int cus = xr_device_cus() > 0 ? xr_device_cus() : 256;
+    const uint32_t grid = min(xr_div_up((n + 31) / 32, MLP_WAVES), (uint32_t)cus * 2u);     // resident: 2 workgroups per CU
+    if (dirs) {
+        const size_t lds = (size_t)(HShape<1>::f_halves + HShape<2>::f_halves) * 2;
+        hipLaunchKernelGGL(k_nerf_mlp_fwd_h<true>, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev,
+                           rows, w_density, w_color, pad_value, (float4*)raw);
+    } else {
+        const size_t lds = (size_t)HShape<1>::f_halves * 2;
+        hipLaunchKernelGGL(k_nerf_mlp_fwd_h<false>, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev,
+                           rows, w_density, w_color, pad_value, (float4*)raw);
+    }
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}
+
+extern "C" int xr_nerf_mlp_bwd_f16(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
+                                   const uint32_t* n_dev, const float* w_density, const float* w_color, int n_hidden_density,
+                                   int n_hidden_color, float pad_value, const float* draw, float* denc_t, float* grad_w_density,
+                                   float* grad_w_color, void* workspace, size_t workspace_bytes, void* stream_) {
+    if (n == 0) return XR_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    XR_REQUIRE(enc_t && dirs && w_density && w_color && draw && denc_t && grad_w_density && grad_w_color, "null pointer");
+    XR_REQUIRE(ld >= n && dir_stride >= 3 && ((uintptr_t)draw & 15) == 0, "bad ld / stride / alignment");
+    XR_REQUIRE(n_hidden_density == 1 && n_hidden_color == 2, "the fp16 mode is built for the (1,2) hidden-layer topology");
+    XR_REQUIRE(workspace && workspace_bytes >= xr_nerf_mlp_bwd_workspace_bytes(n), "workspace too small");
+    constexpr int GW = NetShape<1>::glb_floats + NetShape<2>::glb_floats;
+    constexpr size_t stage_bytes = (size_t)MLP_WAVES * 4 * 32 * HST * 2;
+    static_assert(stage_bytes >= GW * sizeof(float), "stage area doubles as the dW reduction buffer");
+    const size_t lds = (size_t)(HShape<1>::f_halves + HShape<2>::f_halves + HShape<1>::b_halves + HShape<2>::b_halves) * 2 + stage_bytes;
+    XR_HIP(hipFuncSetAttribute((const void*)k_nerf_mlp_bwd_h, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const uint32_t grid = bwd_grid(n);
+    hipLaunchKernelGGL(k_nerf_mlp_bwd_h, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev, w_density,
+                       w_color, pad_value, (const float4*)draw, denc_t, (float*)workspace);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(xr_div_up(GW, 64)), dim3(256), 0, stream, (const float*)workspace, grid, (uint32_t)GW,
+                       (uint32_t)NetShape<1>::glb_floats, grad_w_density, grad_w_color);
     XR_LAUNCH_CHECK();
     return XR_OK;
 }

@@ -4,6 +4,7 @@ Every function takes contiguous CUDA(ROCm) tensors, enqueues on torch's current 
 NOT synchronise.  There is no CPU path: a non-CUDA tensor is an error.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -70,9 +71,21 @@ def _span(name, units=0, train=True):
     return TIMER.span(name, units, train) if TIMER is not None else _NOSPAN
 
 
+_PRECISION = os.environ.get('XRNERF_MLP_PRECISION', 'f32')
+
+
 def precision():
-    """arithmetic mode of the hash grid + fused MLP: 'f32' (parity mode, default)"""
-    return 'f32'
+    """arithmetic mode of the fused MLP: 'f32' (parity mode, default: v_mfma_f32_32x32x2_f32, exact fp32) or 'f16'
+    (the reference's own precision -- tiny-cuda-nn computes FullyFusedMLP in fp16 with fp32 accumulation:
+    v_mfma_f32_32x32x16_f16, fp32 parameters / gradients in memory, fp32 outputs)"""
+    return _PRECISION
+
+
+def set_precision(p):
+    global _PRECISION
+    if p not in ('f32', 'f16'):
+        raise ValueError("precision must be 'f32' or 'f16'")
+    _PRECISION = p
 
 
 def _stream():
@@ -365,8 +378,9 @@ def nerf_mlp_fwd(enc_t, dirs, n, w_density, w_color, nhd, nhc, pad_value=1.0, ra
     _ptr(enc_t); _ptr(raw)
     if count is not None:
         n = count
+    fn = L.xr_nerf_mlp_fwd_f16 if (_PRECISION == 'f16' and nhd == 1 and nhc == 2) else L.xr_nerf_mlp_fwd
     with _span('xr_nerf_mlp_fwd', 0 if n_dev is not None else n, train=n_dev is not None):
-        _lib.check(L.xr_nerf_mlp_fwd(C.c_void_p(enc_t.data_ptr() + 4 * row0), enc_t.shape[1], dp, ds, n, _ptr(n_dev),
+        _lib.check(fn(C.c_void_p(enc_t.data_ptr() + 4 * row0), enc_t.shape[1], dp, ds, n, _ptr(n_dev),
                                      _ptr(rows), _ptr(w_density), _ptr(w_color) if w_color is not None else None, nhd,
                                      nhc, pad_value, C.c_void_p(raw.data_ptr() + 16 * row0), _stream()),
                    'xr_nerf_mlp_fwd')
@@ -383,8 +397,9 @@ def nerf_mlp_bwd(enc_t, dirs, n, w_density, w_color, nhd, nhc, draw, grad_wd, gr
     _ptr(enc_t); _ptr(draw); _ptr(denc_t)
     if count is not None:
         n = count
+    fn = L.xr_nerf_mlp_bwd_f16 if (_PRECISION == 'f16' and nhd == 1 and nhc == 2) else L.xr_nerf_mlp_bwd
     with _span('xr_nerf_mlp_bwd', 0 if n_dev is not None else n, train=n_dev is not None):
-        _lib.check(L.xr_nerf_mlp_bwd(C.c_void_p(enc_t.data_ptr() + 4 * row0), enc_t.shape[1], C.c_void_p(dirs.data_ptr() + 4 * ds * row0), ds, n, _ptr(n_dev), _ptr(w_density),
+        _lib.check(fn(C.c_void_p(enc_t.data_ptr() + 4 * row0), enc_t.shape[1], C.c_void_p(dirs.data_ptr() + 4 * ds * row0), ds, n, _ptr(n_dev), _ptr(w_density),
                                      _ptr(w_color), nhd, nhc, pad_value, C.c_void_p(draw.data_ptr() + 16 * row0), C.c_void_p(denc_t.data_ptr() + 4 * row0), _ptr(grad_wd),
                                      _ptr(grad_wc), _ptr(ws), ws.numel(), _stream()), 'xr_nerf_mlp_bwd')
     return denc_t
