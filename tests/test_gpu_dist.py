@@ -1,0 +1,72 @@
+"""Data-parallel training path on the GPU box: two ranks (gloo transport, both on cuda:0 -- the driver's test box has one
+GPU; RCCL over xGMI is the same code path with backend 'nccl') run the fused training step with the bucketed gradient
+all-reduce for 18 iterations (grid refreshes at 0 and 16).  The replicas must stay identical -- parameters after every
+Adam step, occupancy grid / bitfield after every refresh (the refresh is a deterministic function of the parameters, the
+shared cameras and the explicit K6 RNG counters: no exchange) -- while marching DIFFERENT rays.  Also: `bench.py --gpus 2`
+started by plain python (it spawns its own ranks)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import hashlib, os, sys, torch
+sys.path.insert(0, %r)
+import torch.distributed as dist
+from xrnerf_amd import dist as xd
+from xrnerf_amd.train import Trainer
+rank, local, world = xd.init_from_env('gloo')
+dev = torch.device('cuda', 0)
+torch.cuda.set_device(dev)
+tr = Trainer(dev, n_img=3, H=128, W=128, world_size=world, rank=rank, ema=False)
+assert tr.net._fused_ok() and tr.net.grad_sync is not None
+sig = []
+for it in range(18):
+    tr.step()
+    if it in (0, 15, 16, 17):
+        torch.cuda.synchronize()
+        p = torch.cat([q.detach().reshape(-1)[:4096] for q in tr.net.parameters() if q.numel() > 0])
+        sig.append((hashlib.sha1(tr.net.sampler.density_grid_bitfield.cpu().numpy().tobytes()).hexdigest(),
+                    hashlib.sha1(tr.net.sampler.density_grid.cpu().numpy().tobytes()).hexdigest(),
+                    hashlib.sha1(p.cpu().numpy().tobytes()).hexdigest(),
+                    float(tr.data.rays_rgb[:64].sum())))
+objs = [None] * world
+dist.all_gather_object(objs, sig)
+if rank == 0:
+    a, b = objs
+    for (bf0, g0, p0, r0), (bf1, g1, p1, r1) in zip(a, b):
+        assert bf0 == bf1, 'bitfields differ across ranks'
+        assert g0 == g1, 'density grids differ across ranks'
+        assert p0 == p1, 'parameters differ across ranks'
+        assert r0 != r1, 'both ranks march the same rays'
+    print('replicas identical over', len(a), 'checkpoints')
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_two_ranks_stay_identical_replicas(tmp_path):
+    script = tmp_path / 'w.py'
+    script.write_text(WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29731', WORLD_SIZE='2', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert 'replicas identical' in outs[0]
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher (here: gloo transport, both ranks on the one GPU of the test box)"""
+    env = dict(os.environ, XRNERF_DIST_BACKEND='gloo', XRNERF_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('WORLD_SIZE', None); env.pop('RANK', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '16', '--warmup', '0', '--n-img', '2'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = [l for l in r.stdout.decode().splitlines() if l.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['n_gpus'] == 2 and d['value'] > 0 and 'roofline' in d and d['scaling'] == 'weak'

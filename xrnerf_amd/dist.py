@@ -59,7 +59,9 @@ class BucketedGradSync:
 
     def ready(self, bucket):
         if self.world_size > 1:
-            self._works.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, async_op=True))
+            # `.data`: the bucket is a slice of a buffer other outputs of the fused step are views of (the loss scalar);
+            # the in-place reduction must not bump THEIR autograd version counter ("a view ... has been modified inplace")
+            self._works.append(dist.all_reduce(bucket.data, op=dist.ReduceOp.SUM, async_op=True))
 
     def finish(self):
         for w in self._works:
