@@ -23,10 +23,11 @@ H = W = 800
 N_IMG = 6
 
 
-def scene(n_img=N_IMG):
-    """what PassDatasetHook hands to the sampler (hashnerf_dataset.py:55-86), for synthetic Lego cameras"""
+def scene(n_img=N_IMG, aabb_scale=1):
+    """what PassDatasetHook hands to the sampler (hashnerf_dataset.py:55-86), for synthetic Lego cameras; aabb_scale > 1:
+    the unbounded setting of BASELINE config #4 (log2(aabb_scale) + 1 occupancy cascades)"""
     poses = S.lego_cameras(n_img, seed=1)
-    alldata = {'aabb_scale': 1, 'aabb_range': (0.0, 1.0), 'poses': poses,
+    alldata = {'aabb_scale': aabb_scale, 'aabb_range': (0.5 - aabb_scale / 2, 0.5 + aabb_scale / 2), 'poses': poses,
                'focal': np.ones((n_img, 2), dtype=float) * float(S.LEGO_FOCAL), 'metadata': S.metadata_rows(n_img, float(S.LEGO_FOCAL))}
     return poses, alldata, {'H': H, 'W': W}
 

@@ -79,6 +79,36 @@ def test_reference_sampler_and_wrappers_run_unmodified_and_match_ours(edev, ref)
     assert np.array_equal(ra['pts'].numpy(), oa['pts'].numpy()) and np.array_equal(ra['viewdirs'].numpy(), oa['viewdirs'].numpy())
 
 
+def test_reference_sampler_unbounded_scene_five_cascades(edev, ref):
+    """BASELINE config #4's setting, aabb_scale = 16 (max_cascade = 4: K6 samples 5 x 128^3 cells per refresh, K1 picks the
+    cascade from step size and position, positions are warped into the 16-unit box): the reference's sampler on the
+    `raymarch_cuda` drop-in against ours, refresh + 3 marches (+ a test-mode march)."""
+    import ngp_ref_harness as Hn
+    import xrnerf_amd.raymarch_cuda as rc
+    from xrnerf_amd.samplers import NGPGridSampler as Ours
+    poses, alldata, info = Hn.scene(aabb_scale=16)
+    kw = dict(update_grid_freq=16, n_rays_per_batch=512, target_batch_size=1 << 15)
+    mlp = Hn.OracleMlp(seed=1)
+    rs, os_ = ref.NGPGridSampler(**kw), Ours(**kw)
+    rs.set_data(alldata, info); os_.set_data(alldata, info)
+    assert rs.max_cascade == os_.max_cascade == 4
+    rc.reset_rng()
+    for it in range(3):
+        b = Hn.batch(poses, rs.n_rays_per_batch, it, edev)
+        rs.set_iter(it); os_.set_iter(it)
+        rs.sample({k: v.clone() for k, v in b.items()}, mlp, False)
+        os_.sample({k: v.clone() for k, v in b.items()}, mlp, False)
+        a, o = Hn.sampler_state(rs), Hn.sampler_state(os_)
+        Hn.compare_states(a, o, it)
+    per_cascade = [int(np.unpackbits(a['bitfield'][c * 262144:(c + 1) * 262144]).sum()) for c in range(8)]
+    assert all(v > 0 for v in per_cascade[:5]), per_cascade          # (cascades 5..7 only hold K11's max-pooled copies)
+    assert a['coords'][:, :3].min() >= 0 and a['coords'][:, :3].max() <= 1          # warped positions
+    b = Hn.batch(poses, 300, 50, edev)
+    ra = rs.sample({k: v.clone() for k, v in b.items()}, mlp, True)
+    oa = os_.sample({k: v.clone() for k, v in b.items()}, mlp, True)
+    assert np.array_equal(rs.rays_numsteps.numpy(), os_.rays_numsteps.numpy()) and np.array_equal(ra['pts'].numpy(), oa['pts'].numpy())
+
+
 def _preset_grid(sampler, edev):
     """occupancy state of a trained scene (the synthetic Lego boxes) instead of a 2 M-point density query through the
     emulated MLP: density grid -> mean / bitfield by the real K10 / K11"""
