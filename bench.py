@@ -532,9 +532,16 @@ def main():
     align = ((-tr.iter) % freq - first_off) % freq            # un-timed iterations that put the window at that phase
     for _ in range(align):
         tr.step()
+    # which entry point dominates the step?  16 un-timed iterations with events around every training launch (the phase
+    # alignment above is redone afterwards); the timed region then carries events around THAT kernel only
+    ops.TIMER = ops.KernelTimer(only=set(ALGO), train_only=True)
+    for _ in range(freq):
+        tr.step()
     torch.cuda.synchronize()
-    dom_pick = 'xr_hashgrid_bwd'            # the entry point with the largest share of the step (roofline_kernels below)
-
+    pre_summ, ops.TIMER = ops.TIMER.summary(), None
+    cand = {k: v[1] for k, v in pre_summ.items() if k != 'xr_rays_sampler'}      # K1 runs overlapped on the side stream
+    dom_pick = max(cand, key=cand.get) if cand else 'xr_hashgrid_bwd'
+    torch.cuda.synchronize()
     ops.TIMER = ops.KernelTimer(only={dom_pick}, train_only=True)
     rays0, samples0, it0 = tr.rays_done, tr.samples_done, tr.iter
     barrier()
@@ -571,13 +578,13 @@ def main():
     # ---- roofline of the dominant kernel: HIP events on the launch stream around every TRAINING launch of that entry
     # point inside the timed region (the occupancy-grid density queries use other entry points / are not counted)
     summ = timer.summary()
-    launches, total_ms, _ = summ[dom_pick]
-    roof = roof_of(dom_pick, launches, total_ms, samples)
+    launches, total_ms, units = summ[dom_pick]
+    roof = roof_of(dom_pick, launches, total_ms, units if units > 0 else samples)
     roof['traffic'] = None
     try:   # HBM bytes per launch from separate rocprofv3 --pmc passes of THIS command (tools/pmc_traffic.py)
         pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')))
         if dom_pick in pmc:
-            roof['traffic'] = pmc[dom_pick]['bytes_corrected']
+            roof['traffic'] = pmc[dom_pick]['bytes_fetch_x2']
             roof['traffic_unit'] = 'bytes/launch (PMC FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, 2^18-sample batches)'
     except Exception:  # noqa: BLE001
         pass

@@ -9,7 +9,7 @@ once per training step), plus the sums over the kernels that make up one C-ABI e
 import collections, csv, json, sys
 
 ENTRY = {   # entry point -> kernels launched by it (include/xrnerf_mi355.h)
-    'xr_hashgrid_bwd': ['k_scatter_bin', 'k_scatter_accum', 'k_hashgrid_bwd', 'k_reduce_replicas'],
+    'xr_hashgrid_bwd': ['k_scatter_bin2', 'k_scatter_accum2', 'k_scatter_bin', 'k_scatter_accum', 'k_hashgrid_bwd', 'k_reduce_replicas'],
     'xr_hashgrid_fwd': ['k_hashgrid_fwd'],
     'xr_nerf_mlp_bwd': ['k_nerf_mlp_bwd_1_2', 'k_reduce_partials'],
     'xr_nerf_mlp_fwd': ['void k_nerf_mlp_fwd<1, 2, true>'],

@@ -63,7 +63,7 @@ def build(force=False, verbose=False):
 
     def cc(job):
         s, o, extra = job
-        cmd = [_hipcc()] + COMMON + extra + ['-c', s, '-o', o]
+        cmd = [_hipcc()] + COMMON + extra + os.environ.get('XR_EXTRA_HIPCC_FLAGS', '').split() + ['-c', s, '-o', o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('hipcc failed: %s\n%s' % (' '.join(cmd), r.stdout + r.stderr))
