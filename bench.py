@@ -544,14 +544,21 @@ def main():
     torch.cuda.synchronize()
     ops.TIMER = ops.KernelTimer(only={dom_pick}, train_only=True)
     rays0, samples0, it0 = tr.rays_done, tr.samples_done, tr.iter
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # one event per iteration boundary
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in range(args.steps):
+        step_ev[k].record()
         tr.step()
+    step_ev[args.steps].record()
     barrier()
     elapsed = time.perf_counter() - t0
     timer, ops.TIMER = ops.TIMER, None
     it1 = tr.iter
+    step_ms = [step_ev[k].elapsed_time(step_ev[k + 1]) for k in range(args.steps)]
+    is_refresh = [(it0 + k) % sampler.update_grid_freq == 0 for k in range(args.steps)]
+    ms_refresh = [m for m, r in zip(step_ms, is_refresh) if r]
+    ms_normal = [m for m, r in zip(step_ms, is_refresh) if not r]
 
     rays = tr.rays_done - rays0
     samples = tr.samples_done - samples0
@@ -657,6 +664,8 @@ def main():
                        'rays_per_step': rays_all / args.steps / world, 'samples_per_ray': samples_all / max(rays_all, 1),
                        'samples_per_s': samples_all / elapsed_max, 'n_images': args.n_img,
                        'preroll_iterations': preroll, 'timed_iterations': [it0, it1 - 1], 'grid_refreshes_in_window': n_refresh,
+                       'device_ms_normal_iteration': sum(ms_normal) / max(len(ms_normal), 1),
+                       'device_ms_refresh_iteration': sum(ms_refresh) / max(len(ms_refresh), 1) if ms_refresh else None,
                        'rays_per_batch_history': hist,
                        'parallelism': 'ray-sharded data parallel x%d, gradient all-reduce (RCCL)' % world if world > 1 else 'single GPU'},
             'roofline': roof,
