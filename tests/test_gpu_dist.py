@@ -50,13 +50,17 @@ dist.barrier(); dist.destroy_process_group()
 
 
 def test_two_ranks_stay_identical_replicas(tmp_path):
+    import socket
     script = tmp_path / 'w.py'
     script.write_text(WORKER % ROOT)
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29731', WORLD_SIZE='2', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE='2', HSA_ENABLE_IPC_MODE_LEGACY='0')
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
-    assert all(p.returncode == 0 for p in procs), outs
+    assert all(p.returncode == 0 for p in procs), [o[-1500:] for o in outs]
     assert 'replicas identical' in outs[0]
 
 

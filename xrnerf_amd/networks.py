@@ -89,7 +89,15 @@ class _FusedTrainStepFn(torch.autograd.Function):
         from . import ops
         mlp, sampler = net.mlp, net.sampler
         with torch.no_grad():
-            data = sampler.sample(data, mlp, False)
+            # the sampler's `on_sampled` hook (the trainer issues the NEXT batch's march on a side stream from it: ~10
+            # Python-side launches, events, pinned copies) is deferred until this step's encode and MLP forward are
+            # enqueued: in the kernel trace the main stream sat idle ~90 us between K2 and the encode while the host was
+            # busy issuing that prefetch (profiles/r02_trace_normal_iteration.txt)
+            cb, sampler.on_sampled = getattr(sampler, 'on_sampled', None), None
+            try:
+                data = sampler.sample(data, mlp, False)
+            finally:
+                sampler.on_sampled = cb
             pts, dirs = mlp._rows(data['pts']), mlp._rows(data['viewdirs'])
             n, n_dev = pts.shape[0], data.get('n_valid_dev')
             meta, nhd, nhc = mlp.embedder_pos.meta, mlp.density_net.n_hidden, mlp.color_net.n_hidden
@@ -101,6 +109,8 @@ class _FusedTrainStepFn(torch.autograd.Function):
             raw = torch.empty((n, 4), dtype=torch.float32, device=pts.device)
             ops.hashgrid_fwd(table, pts, meta, enc_t=enc_t, ld=ld, n_dev=n_dev)
             ops.nerf_mlp_fwd(enc_t, dirs, n, wd, wc, nhd, nhc, mlp.pad_value, raw=raw, n_dev=n_dev)
+            if cb is not None:
+                cb()
             ra, da = int(sampler.rgb_activation), int(sampler.density_activation)
             rgb = ops.calc_rgb_forward(raw, sampler.coords, sampler.rays_numsteps, sampler.rays_numsteps_compacted,
                                        data['bg_color'], ra, da)
