@@ -149,9 +149,10 @@ def test_k6_grid_samples_bit_exact(O, lego, dev):
     grid = (lego['grid'] * rng.uniform(0.0, 0.05, lego['grid'].shape)).astype(np.float32)
     grid[rng.uniform(0, 1, grid.shape) < 0.1] = -1.0
     g = T(grid, dev)
-    for (n, step, casc, thr, calls) in [(100000, 0, 1, -0.01, 0), (100000, 7, 1, 0.01, 1), (65536, 3, 5, 0.01, 4)]:
-        rp, ri = O.generate_grid_samples(grid, step, n, casc - 1, thr, rng_calls=calls)
-        gp, gi = ops.generate_grid_samples(g, step, n, casc, thr, (0.0, 1.0), calls)
+    for (n, step, casc, thr, calls, aabb) in [(100000, 0, 1, -0.01, 0, (0.0, 1.0)), (100000, 7, 1, 0.01, 1, (0.0, 1.0)),
+                                              (65536, 3, 5, 0.01, 4, (0.0, 1.0)), (65536, 3, 5, 0.01, 4, (-7.5, 8.5))]:
+        rp, ri = O.generate_grid_samples(grid, step, n, casc - 1, thr, aabb=aabb, rng_calls=calls)
+        gp, gi = ops.generate_grid_samples(g, step, n, casc, thr, aabb, calls)
         assert np.array_equal(gi.cpu().numpy(), ri)
         assert np.array_equal(bits(gp.cpu().numpy()), bits(rp))
 

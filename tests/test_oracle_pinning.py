@@ -213,3 +213,19 @@ def test_k1_multi_cascade_golden(O):
     assert np.array_equal(bits(c[:int(cnt[1])]), bits(g['coords']))
     # the fixture really exercises the coarse cascades: warped dt spans more than the two values of a unit cube
     assert len(np.unique(g['coords'][:, 3])) > 1000 and int(g['numsteps'][:, 0].max()) > 40
+
+
+@pytest.mark.skipif(not __import__('oracle').have_ref(), reason='needs oracle/_ref (the reference kernels compiled for the CPU)')
+def test_k6_unbounded_boxes_bit_exact_against_the_reference_kernels(O, lego):
+    """BASELINE config #4's setting: K6 (generate_grid_samples_nerf_nonuniform) with aabb = [-7.5, 8.5] (aabb_scale 16, five
+    cascades) and an intermediate box -- the restatement against the reference's own kernel, positions bit for bit (they are
+    warped into the box: inside [0, 1])."""
+    rng = np.random.default_rng(3)
+    grid = (lego['grid'] * rng.uniform(0.0, 0.05, lego['grid'].shape)).astype(np.float32)
+    grid[rng.uniform(0, 1, grid.shape) < 0.1] = -1.0
+    for aabb in ((-7.5, 8.5), (-1.5, 2.5)):
+        for casc, thr, calls in ((5, 0.01, 4), (5, -0.01, 0), (3, 0.01, 2)):
+            rp, ri = O.generate_grid_samples(grid, 3, 50000, casc - 1, thr, aabb=aabb, rng_calls=calls, backend='ref')
+            pp, pi = O.generate_grid_samples(grid, 3, 50000, casc - 1, thr, aabb=aabb, rng_calls=calls, backend='port')
+            assert np.array_equal(ri, pi) and np.array_equal(rp.view(np.uint32), pp.view(np.uint32)), (aabb, casc, thr)
+    assert 0.0 <= rp.min() and rp.max() <= 1.0
