@@ -48,6 +48,8 @@ ALGO = {
     # per sample: 16 B raw + 4 B dt read (+ per ray 40 B, folded in as 3 B/sample at ~14 samples/ray)
     'xr_calc_rgb_forward': ('hbm', 20 + 3),
     'xr_calc_rgb_backward': ('hbm', 36 + 2),
+    # K3 + Huber + K4 in one launch: per sample 16 B raw + 4 B dt read, 16 B written (+ per ray ~70 B folded as 3 B/sample)
+    'xr_composite_train': ('hbm', 36 + 3),
     # per emitted sample 28 B written + per ray 36 B (folded: ~3 B/sample)
     # per RAY: 36 B in/out + 28 B per emitted sample at ~14 samples/ray
     'xr_rays_sampler': ('hbm', 36 + 28 * 14),

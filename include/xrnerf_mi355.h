@@ -100,6 +100,17 @@ int xr_calc_rgb_backward(const float* network_output, const int32_t* rays_numste
                          const float* density_grid_mean /*device, [0] read*/, uint32_t n_rays,
                          int rgb_activation, int density_activation, float* dloss_doutput /*[S,4]*/,
                          void* stream);
+
+/* K3 + scale * HuberLoss(delta, sum) with its gradient + the alpha-masked squared error + K4 in ONE launch (the training
+ * step's compositor sequence, networks/hashnerf.py:32-44 around renders/hashnerf_render.py:60-135): rgb_output [n_rays,3]
+ * and dloss_doutput [S,4] are exactly what xr_calc_rgb_forward / xr_calc_rgb_backward produce; loss_mse_out[2] is ADDED
+ * to (caller zero-fills): [0] += scale * sum huber, [1] += sum ((rgb - target) * alpha)^2.  Rows of dloss_doutput behind
+ * the last sample are not written (caller zero-fills). */
+int xr_composite_train(const float* network_output, const float* coords, const int32_t* rays_numsteps,
+                       const int32_t* rays_numsteps_compacted, const float* bg_color, const float* target,
+                       const float* alpha_mask, const float* density_grid_mean, uint32_t n_rays, int rgb_activation,
+                       int density_activation, float delta, float scale, float* rgb_output, float* loss_mse_out,
+                       float* dloss_doutput, void* stream);
 /* K5  calc_rgb_influence_api (src/calc_rgb.cu:330-389, kernel :144-206); bg is by value like the
  * reference's host tensor */
 int xr_calc_rgb_inference(const float* network_output, const float* coords, const int32_t* rays_numsteps,

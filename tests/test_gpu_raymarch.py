@@ -225,3 +225,33 @@ def test_gen_rays_huber_adam(O, lego, dev):
         O.adam(p, g, m, v, step)
         ops.adam_step(tp, T(g, dev), tm, tv, step)
     assert np.abs(tp.cpu().numpy() - p).max() <= 1e-5 and np.abs(tv.cpu().numpy() - v).max() <= 1e-9
+
+
+def test_fused_compositor_train_equals_k3_huber_k4(O, lego, dev):
+    """xr_composite_train (K3 + 5*Huber + masked MSE + K4 in one launch) against the three separate entry points on marched
+    Lego samples incl. clipped tails and rays without samples: rgb and dL/draw bit for bit, the two loss scalars to 1e-6"""
+    from xrnerf_amd import ops, synthetic as S
+    rng = np.random.default_rng(21)
+    n_rays = 3000
+    o, d, _ = S.training_rays(lego['poses'], n_rays, seed=9)
+    coords, _, ns, cnt = ops.rays_sampler(T(o, dev), T(d, dev), T(lego['bitfield'], dev), (0., 1.), 0.05, 1 / 256, n_rays * 64, 0)
+    total = int(cnt[1])
+    cap = int(total * 0.8)                                            # clip: some rays lose their tail, some everything
+    nsc, _ = ops.clip_numsteps(ns, cnt, cap)
+    raw = T(rng.normal(0, 1.5, (cap, 4)).astype(np.float32), dev)
+    bg = T(rng.uniform(0, 1, (n_rays, 3)).astype(np.float32), dev)
+    tgt = T(rng.uniform(0, 1, (n_rays, 3)).astype(np.float32), dev)
+    alpha = T((rng.uniform(0, 1, (n_rays, 1)) > 0.3).astype(np.float32), dev)
+    mean = torch.tensor([0.005] + [0.0] * 15, dtype=torch.float32, device=dev)
+    c = coords[:cap].contiguous()
+    for ra, da in ((2, 3), (3, 1)):
+        rgb_a = ops.calc_rgb_forward(raw, c, ns, nsc, bg, ra, da)
+        lm_a, grad = ops.huber_loss_grad_mse(rgb_a, tgt, alpha, 0.1, 5.0)
+        draw_a = ops.calc_rgb_backward(raw, nsc, c, grad, rgb_a, mean, ra, da)
+        lm_b = torch.zeros(2, dtype=torch.float32, device=dev)
+        draw_b = torch.zeros_like(raw)
+        rgb_b = ops.composite_train(raw, c, ns, nsc, bg, tgt, alpha, mean, ra, da, lm_b, draw_b)
+        assert torch.equal(rgb_a, rgb_b)
+        assert torch.equal(draw_a, draw_b)
+        assert torch.allclose(lm_a, lm_b, rtol=1e-5, atol=0)
+    assert int((nsc[:, 0] == 0).sum()) > 0 and int((nsc[:, 0] < ns[:, 0]).sum()) > 0

@@ -25,6 +25,7 @@ SIGNATURES = {
     'xr_render_slice_composite': (_i32, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _i32, _i32, _vp, _vp, _vp]),
     'xr_calc_rgb_forward': (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, _i32, _i32, _vp, _vp]),
     'xr_calc_rgb_backward': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _i32, _i32, _vp, _vp]),
+    'xr_composite_train': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _i32, _i32, _f, _f, _vp, _vp, _vp, _vp]),
     'xr_calc_rgb_inference': (_i32, [_vp, _vp, _vp, _f, _f, _f, _u32, _i32, _i32, _vp, _vp, _vp]),
     'xr_generate_grid_samples': (_i32, [_vp, _u32, _u32, _u32, _f, _f, _f, _u64, _u64, _vp, _vp, _vp]),
     'xr_mark_untrained_density_grid': (_i32, [_vp, _vp, _u32, _u32, _i32, _i32, _vp, _vp]),

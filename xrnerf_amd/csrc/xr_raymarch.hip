@@ -655,3 +655,131 @@ extern "C" int xr_calc_rgb_backward(const float* network_output, const int32_t* 
     XR_LAUNCH_CHECK();
     return XR_OK;
 }
+
+// ------------------------------------------------------------------ K3 + 5*Huber (+ masked MSE) + K4 in one launch
+// The training step composites (K3), takes scale * HuberLoss(rgb, target) and the alpha-masked squared error the reference
+// logs (networks/hashnerf.py:36-44), and runs K4 on dL/drgb -- three launches of 13 + 7 + 29 us with two 1.5-MB round trips
+// (rgb, dL/drgb) in between.  K4's first pass IS the forward composite (same chunking, same stitch), so one kernel does all
+// three: pass 1 + stitch -> final colour (+ background rule of K3) -> Huber gradient per ray in registers (lane 0 of the ray
+// adds the ray's loss terms to a block sum) -> pass 2.  rgb_out, the loss accumulators and dout are what the three kernels
+// produce (rgb and dout bit for bit; the two scalars up to the order of the block sums).
+__global__ __launch_bounds__(RM_BLOCK) void k_composite_train(
+    uint32_t n_rays, const float4* __restrict__ raw, const float* __restrict__ coords, const int32_t* __restrict__ numsteps,
+    const int32_t* __restrict__ numsteps_c, const float* __restrict__ bg, const float* __restrict__ target,
+    const float* __restrict__ alpha_mask, const float* __restrict__ density_grid_mean, int rgb_act, int density_act, float delta,
+    float scale, float* __restrict__ rgb_out, float* __restrict__ loss_mse, float4* __restrict__ dout) {
+    __shared__ float ws[RM_BLOCK / 64], ws2[RM_BLOCK / 64];
+    const uint32_t t = blockIdx.x * RM_BLOCK + threadIdx.x;
+    const uint32_t i = t / CG, sub = t % CG;
+    const bool in = i < n_rays;
+    float loss_scale = 128.f; loss_scale /= (float)n_rays;                        // calc_rgb.cu:92-93
+    const float l2 = rgb_act == XR_ACT_EXPONENTIAL ? 1e-4f : 0.0f;
+    const float l1 = density_grid_mean[0] < 0.01f ? 1e-4f : 0.0f;
+    uint32_t n = 0, base = 0, n_full = 0;
+    float br = 0.f, bgc = 0.f, bb = 0.f, tr = 0.f, tg = 0.f, tb = 0.f, am = 0.f;
+    if (in) {
+        n = (uint32_t)numsteps_c[2 * i]; base = (uint32_t)numsteps_c[2 * i + 1]; n_full = (uint32_t)numsteps[2 * i];
+        br = bg[3 * i]; bgc = bg[3 * i + 1]; bb = bg[3 * i + 2];
+        tr = target[3 * i]; tg = target[3 * i + 1]; tb = target[3 * i + 2];
+        am = alpha_mask[i];
+    }
+    uint32_t k0, k1;
+    cg_chunk(n, sub, &k0, &k1);
+    float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f;
+    const uint32_t m = k1 - k0;
+    float4 oc[CG_RC]; float dc[CG_RC];
+    if (m <= CG_RC) {
+#pragma unroll
+        for (uint32_t u = 0; u < CG_RC; ++u)
+            if (u < m) { oc[u] = raw[base + k0 + u]; dc[u] = coords[7 * (size_t)(base + k0 + u) + 3]; }
+    }
+    auto pass1 = [&](const float4 o, float dtw) {
+        const float dt = xr_unwarp_dt(dtw);
+        const float alpha = 1.f - __expf(-xr_act_density(o.w, density_act) * dt);
+        const float w = alpha * T;
+        cr += w * xr_act_rgb(o.x, rgb_act); cg += w * xr_act_rgb(o.y, rgb_act); cb += w * xr_act_rgb(o.z, rgb_act);
+        T *= (1.f - alpha);
+    };
+    if (m <= CG_RC) {
+#pragma unroll
+        for (uint32_t u = 0; u < CG_RC; ++u) if (u < m) pass1(oc[u], dc[u]);
+    } else {
+        for (uint32_t k = k0; k < k1; ++k) pass1(raw[base + k], coords[7 * (size_t)(base + k) + 3]);
+    }
+    float Tb, ar, ag, ab, Tt, Cr, Cg, Cb;
+    cg_stitch(sub, T, cr, cg, cb, &Tb, &ar, &ag, &ab, &Tt, &Cr, &Cg, &Cb);
+    // K3's result (:28-32, :61-64)
+    float fr, fg, fb;
+    if (n == 0) { fr = br; fg = bgc; fb = bb; }
+    else { fr = Cr; fg = Cg; fb = Cb; if (n == n_full) { fr += Tt * br; fg += Tt * bgc; fb += Tt * bb; } }
+    // scale * HuberLoss and its gradient (utils/metrics.py:8-16), masked squared error
+    float gr, gg, gb, acc = 0.f, mse = 0.f;
+    {
+        const float d3[3] = {fr - tr, fg - tg, fb - tb};
+        float g3[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float a = fabsf(d3[c]);
+            if (a > delta) { acc += a - 0.5f * delta; g3[c] = scale * (d3[c] > 0.f ? 1.f : -1.f); }
+            else { acc += 0.5f / delta * a * a; g3[c] = scale * (d3[c] / delta); }
+            const float mm = d3[c] * am; mse += mm * mm;
+        }
+        gr = g3[0]; gg = g3[1]; gb = g3[2];
+    }
+    if (!(in && sub == 0)) { acc = 0.f; mse = 0.f; }
+    else { rgb_out[3 * i] = fr; rgb_out[3 * i + 1] = fg; rgb_out[3 * i + 2] = fb; }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { acc += __shfl_xor(acc, d, 64); mse += __shfl_xor(mse, d, 64); }
+    if ((threadIdx.x & 63) == 0) { ws[threadIdx.x >> 6] = acc; ws2[threadIdx.x >> 6] = mse; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int w = 0; w < RM_BLOCK / 64; ++w) { a += ws[w]; b += ws2[w]; }
+        if (a != 0.f) atomicAdd(loss_mse, scale * a);
+        if (b != 0.f) atomicAdd(loss_mse + 1, b);
+    }
+    if (!in || k0 >= k1) return;
+    T = Tb; cr = ar; cg = ag; cb = ab;
+    auto pass2 = [&](const float4 o, float dtw, uint32_t k) {
+        const float r = xr_act_rgb(o.x, rgb_act), g = xr_act_rgb(o.y, rgb_act), b = xr_act_rgb(o.z, rgb_act);
+        const float dt = xr_unwarp_dt(dtw);
+        const float density = xr_act_density(o.w, density_act);
+        const float alpha = 1.f - __expf(-density * dt);
+        const float w = alpha * T;
+        cr += w * r; cg += w * g; cb += w * b;
+        T *= (1.f - alpha);
+        const float sr = fr - cr, sg = fg - cg, sb = fb - cb;                     // suffix
+        float4 d;
+        d.x = loss_scale * ((w * gr) * xr_dact_rgb(o.x, rgb_act) + fmaxf(0.0f, l2 * o.x));
+        d.y = loss_scale * ((w * gg) * xr_dact_rgb(o.y, rgb_act) + fmaxf(0.0f, l2 * o.y));
+        d.z = loss_scale * ((w * gb) * xr_dact_rgb(o.z, rgb_act) + fmaxf(0.0f, l2 * o.z));
+        const float dot = gr * (T * r - sr) + gg * (T * g - sg) + gb * (T * b - sb);
+        d.w = loss_scale * (xr_dact_density(o.w, density_act) * (dt * dot)) + (o.w < 0.f ? -l1 : 0.0f);
+        dout[base + k] = d;
+    };
+    if (m <= CG_RC) {
+#pragma unroll
+        for (uint32_t u = 0; u < CG_RC; ++u) if (u < m) pass2(oc[u], dc[u], k0 + u);
+    } else {
+        for (uint32_t k = k0; k < k1; ++k) pass2(raw[base + k], coords[7 * (size_t)(base + k) + 3], k);
+    }
+}
+
+extern "C" int xr_composite_train(const float* network_output, const float* coords, const int32_t* rays_numsteps,
+                                  const int32_t* rays_numsteps_compacted, const float* bg_color, const float* target,
+                                  const float* alpha_mask, const float* density_grid_mean, uint32_t n_rays, int rgb_activation,
+                                  int density_activation, float delta, float scale, float* rgb_output, float* loss_mse_out,
+                                  float* dloss_doutput, void* stream_) {
+    XR_REQUIRE(network_output && coords && rays_numsteps && rays_numsteps_compacted && bg_color && target && alpha_mask &&
+               density_grid_mean && rgb_output && loss_mse_out && dloss_doutput, "null pointer");
+    XR_REQUIRE((((uintptr_t)network_output | (uintptr_t)dloss_doutput) & 15) == 0, "raw/grad buffers must be 16-byte aligned");
+    XR_REQUIRE(n_rays > 0, "n_rays == 0");
+    hipLaunchKernelGGL(k_composite_train, dim3(xr_div_up((uint64_t)n_rays * CG, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream_,
+                       n_rays, (const float4*)network_output, coords, rays_numsteps, rays_numsteps_compacted, bg_color, target,
+                       alpha_mask, density_grid_mean, rgb_activation, density_activation, delta, scale, rgb_output, loss_mse_out,
+                       (float4*)dloss_doutput);
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}
+

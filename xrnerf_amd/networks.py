@@ -112,20 +112,19 @@ class _FusedTrainStepFn(torch.autograd.Function):
             if cb is not None:
                 cb()
             ra, da = int(sampler.rgb_activation), int(sampler.density_activation)
-            rgb = ops.calc_rgb_forward(raw, sampler.coords, sampler.rays_numsteps, sampler.rays_numsteps_compacted,
-                                       data['bg_color'], ra, da)
-            # one zero-fill for everything that must start at zero: dL/draw rows, the two MLP gradient buffers and
-            # the (loss, mse) accumulators
-            nz = raw.numel() + wd.numel() + wc.numel() + 4
+            # one small zero-fill for what must start at zero: the two MLP gradient buffers and the (loss, mse)
+            # accumulators.  dL/draw needs none when the valid row count is on the device: rows [0, n_valid) are exactly
+            # the rays' (base, count) ranges, all written by K4, and nothing downstream reads a row behind n_valid
+            nz = wd.numel() + wc.numel() + 4
             zbuf = torch.zeros((nz,), dtype=torch.float32, device=raw.device)
-            draw = zbuf[:raw.numel()].view_as(raw)
-            g_mlp = zbuf[raw.numel():raw.numel() + wd.numel() + wc.numel()]          # both MLP gradients, contiguous
+            draw = torch.empty_like(raw) if n_dev is not None else torch.zeros_like(raw)
+            g_mlp = zbuf[:wd.numel() + wc.numel()]                                    # both MLP gradients, contiguous
             g_wd, g_wc = g_mlp[:wd.numel()], g_mlp[wd.numel():]
             loss_mse = zbuf[nz - 4:nz - 2]
-            grad_rgb = ops.huber_loss_grad_mse(rgb, data['target_s'].contiguous(), data['alpha'].contiguous(), 0.1, 5.0,
-                                               out=loss_mse)[1]
-            ops.calc_rgb_backward(raw, sampler.rays_numsteps_compacted, sampler.coords, grad_rgb, rgb,
-                                  sampler.density_grid_mean, ra, da, out=draw)
+            # K3 -> 5 * Huber (+ masked MSE for the logged PSNR) -> K4 as ONE launch (xr_composite_train)
+            rgb = ops.composite_train(raw, sampler.coords, sampler.rays_numsteps, sampler.rays_numsteps_compacted,
+                                      data['bg_color'], data['target_s'].contiguous(), data['alpha'].contiguous(),
+                                      sampler.density_grid_mean, ra, da, loss_mse, draw, delta=0.1, scale=5.0)
             g_table = torch.zeros_like(table)
             denc_t = torch.empty_like(enc_t)
             ops.nerf_mlp_bwd(enc_t, dirs, n, wd, wc, nhd, nhc, draw, g_wd, g_wc, mlp.pad_value, denc_t=denc_t, n_dev=n_dev)

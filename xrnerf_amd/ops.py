@@ -190,6 +190,21 @@ def calc_rgb_backward(raw, numsteps_c, coords, grad_rgb, rgb_out, density_grid_m
     return out
 
 
+def composite_train(raw, coords, numsteps, numsteps_c, bg, target, alpha, density_grid_mean, rgb_act, density_act, loss_mse, draw,
+                    delta=0.1, scale=5.0, rgb=None):
+    """K3 + scale * Huber (+ masked MSE) + K4 in one launch -> rgb [n,3]; `loss_mse` [2] and `draw` [S,4] must be zero-filled
+    (loss terms are added, rows behind the last sample are not written)"""
+    n = numsteps.shape[0]
+    if rgb is None:
+        rgb = torch.empty((n, 3), dtype=torch.float32, device=raw.device)
+    with _span('xr_composite_train', 0):
+        _lib.check(_lib.load().xr_composite_train(_ptr(raw), _ptr(coords), _ptr(numsteps), _ptr(numsteps_c), _ptr(bg), _ptr(target),
+                                                  _ptr(alpha), _ptr(density_grid_mean), n, int(rgb_act), int(density_act),
+                                                  float(delta), float(scale), _ptr(rgb), _ptr(loss_mse), _ptr(draw), _stream()),
+                   'xr_composite_train')
+    return rgb
+
+
 def calc_rgb_inference(raw, coords, numsteps, bg3, rgb_act, density_act):
     L = _lib.load()
     n = numsteps.shape[0]
