@@ -223,6 +223,34 @@ int xr_nerf_mlp_bwd_f16(const float* enc_t, uint32_t ld, const float* dirs, uint
                         int n_hidden_color, float pad_value, const float* draw, float* denc_t, float* grad_w_density,
                         float* grad_w_color, void* workspace, size_t workspace_bytes, void* stream);
 
+/* One training step's device work of HashNerfNetwork.train_step (networks/hashnerf.py:32-52, optimiser excluded) as ONE call:
+ * xr_hashgrid_fwd -> xr_nerf_mlp_fwd[_f16] -> zero-fill of `zero_block` (which must contain grad_w_density, grad_w_color and
+ * loss_mse) -> xr_composite_train -> zero-fill of grad_table -> xr_nerf_mlp_bwd[_f16] -> xr_hashgrid_bwd, on `stream`.
+ * coords: K1's [n_rows,7] rows (positions / directions consumed in place); n_dev: device count of valid rows; every buffer
+ * is caller-owned (enc_t / denc_t [32][ld], raw / draw [n_rows,4], rgb_out [n_rays,3]); zero_draw != 0 also clears draw
+ * (needed only without n_dev).  Same kernels and results as the separate calls -- this exists because issuing them one by
+ * one from an interpreter costs as much host time as the kernels take on the device. */
+int xr_ngp_train_step(const float* table, const float* w_density, const float* w_color, int n_hidden_density, int n_hidden_color,
+                      float pad_value, int f16_mlp, int n_levels, const float* scale_host, const uint32_t* resolution_host,
+                      const uint32_t* offset_host, const float* coords, uint32_t n_rows, const uint32_t* n_dev,
+                      const int32_t* rays_numsteps, const int32_t* rays_numsteps_compacted, uint32_t n_rays, const float* bg_color,
+                      const float* target, const float* alpha_mask, const float* density_grid_mean, int rgb_activation,
+                      int density_activation, float huber_delta, float loss_scale, float* enc_t, uint32_t ld, float* raw,
+                      float* draw, float* denc_t, float* rgb_out, float* zero_block, size_t zero_floats, float* grad_w_density,
+                      float* grad_w_color, float* loss_mse, float* grad_table, size_t table_floats, int zero_draw,
+                      void* ws_mlp_bwd, size_t ws_mlp_bwd_bytes, void* ws_scatter, size_t ws_scatter_bytes, void* stream);
+
+/* The next batch's side-stream work as ONE call: xr_make_batch (rows = [n_rays,11] slice of the device-resident ray table;
+ * generator = pcg32 seeded `batch_seed`, advanced `batch_call_index` calls) -> xr_rays_sampler (the reference's hidden
+ * `static pcg32 rng{9121}`, advanced `k1_call_index` calls) -> xr_clip_numsteps(max_compacted) -> asynchronous copy of
+ * counter2 to `counter_host_pinned` (nullable; pinned host memory).  Buffers as in the three calls. */
+int xr_ngp_prefetch(const float* rays_rgb_rows, uint32_t n_rays, uint64_t batch_seed, uint64_t batch_call_index, float* rays_o,
+                    float* rays_d, float* target, float* alpha, float* bg, int32_t* img_ids, const uint8_t* bitfield, float aabb0,
+                    float aabb1, float near_distance, float cone_angle, uint32_t max_samples, uint64_t k1_call_index,
+                    float* coords_out, int32_t* rays_index, int32_t* rays_numsteps, uint32_t* counter2, void* workspace,
+                    size_t workspace_bytes, uint32_t max_compacted, int32_t* numsteps_clipped, uint32_t* n_valid_dev,
+                    uint32_t* counter_host_pinned, void* stream);
+
 /* tcnn.Network(FullyFusedMLP) on its own (compatibility surface; the hot path uses the fused kernels above):
  * x [n, n_in] with arbitrary row / column strides (in floats), n_in <= 32, missing input columns = pad_value;
  * weights in the tcnn layout; y / dy [n,16] row-major (columns >= n_output_dims are padding); dx [n, n_in]

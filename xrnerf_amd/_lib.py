@@ -41,6 +41,11 @@ SIGNATURES = {
     'xr_sh4': (_i32, [_vp, _u32, _u32, _vp, _vp]),
     'xr_nerf_mlp_fwd': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp]),
     'xr_nerf_mlp_bwd_workspace_bytes': (_sz, [_u32]),
+    'xr_ngp_prefetch': (_i32, [_vp, _u32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _u32, _u64, _vp, _vp, _vp, _vp,
+                               _vp, _sz, _u32, _vp, _vp, _vp, _vp]),
+    'xr_ngp_train_step': (_i32, [_vp, _vp, _vp, _i32, _i32, _f, _i32, _i32, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _u32, _vp, _vp, _vp,
+                                 _vp, _i32, _i32, _f, _f, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _sz, _i32, _vp, _sz,
+                                 _vp, _sz, _vp]),
     'xr_nerf_mlp_fwd_f16': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp]),
     'xr_nerf_mlp_bwd_f16': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'xr_nerf_mlp_bwd': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -1,0 +1,73 @@
+// One call = one training step's device work of HashNerfNetwork (networks/hashnerf.py:32-52 without the optimiser):
+// hash-grid encode -> fused MLP -> K3 + 5*Huber + masked MSE + K4 -> MLP backward -> table scatter, enqueued back to back on
+// one stream from native code.  Measured on the GPU box (tools/hosttime2.py): issued from Python -- ten ctypes calls, a dozen
+// tensor allocations, ~1400 interpreter-level calls per iteration -- the step costs 0.64 ms of HOST time against 0.66 ms of
+// kernels, i.e. the trainer was about to be bound by the interpreter rather than by the MI355X.  Everything here is the
+// existing entry points of this library called in sequence (same kernels, same results); buffers are caller-owned, nothing
+// is allocated or synchronised.
+#include "xr_common.h"
+
+extern "C" int xr_ngp_train_step(
+    const float* table, const float* w_density, const float* w_color, int n_hidden_density, int n_hidden_color, float pad_value,
+    int f16_mlp, int n_levels, const float* scale_host, const uint32_t* resolution_host, const uint32_t* offset_host,
+    const float* coords, uint32_t n_rows, const uint32_t* n_dev, const int32_t* rays_numsteps, const int32_t* rays_numsteps_compacted,
+    uint32_t n_rays, const float* bg_color, const float* target, const float* alpha_mask, const float* density_grid_mean,
+    int rgb_activation, int density_activation, float huber_delta, float loss_scale,
+    float* enc_t, uint32_t ld, float* raw, float* draw, float* denc_t, float* rgb_out,
+    float* zero_block, size_t zero_floats, float* grad_w_density, float* grad_w_color, float* loss_mse,
+    float* grad_table, size_t table_floats, int zero_draw,
+    void* ws_mlp_bwd, size_t ws_mlp_bwd_bytes, void* ws_scatter, size_t ws_scatter_bytes, void* stream_) {
+    XR_REQUIRE(table && w_density && w_color && coords && rays_numsteps && rays_numsteps_compacted && bg_color && target &&
+               alpha_mask && density_grid_mean && enc_t && raw && draw && denc_t && rgb_out && zero_block && grad_w_density &&
+               grad_w_color && loss_mse && grad_table, "null pointer");
+    XR_REQUIRE(n_rows > 0 && n_rays > 0 && ld >= n_rows, "bad sizes");
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc;
+    // coordinate rows {pos3, dt, dir3}: positions and directions are consumed in place (row stride 7)
+    rc = xr_hashgrid_fwd(table, coords, 7, n_rows, n_dev, nullptr, n_levels, scale_host, resolution_host, offset_host, enc_t, ld, stream_);
+    if (rc != XR_OK) return rc;
+    rc = f16_mlp ? xr_nerf_mlp_fwd_f16(enc_t, ld, coords + 4, 7, n_rows, n_dev, nullptr, w_density, w_color, n_hidden_density,
+                                       n_hidden_color, pad_value, raw, stream_)
+                 : xr_nerf_mlp_fwd(enc_t, ld, coords + 4, 7, n_rows, n_dev, nullptr, w_density, w_color, n_hidden_density,
+                                   n_hidden_color, pad_value, raw, stream_);
+    if (rc != XR_OK) return rc;
+    XR_HIP(hipMemsetAsync(zero_block, 0, zero_floats * sizeof(float), stream));         // MLP gradients + loss accumulators
+    if (zero_draw) XR_HIP(hipMemsetAsync(draw, 0, (size_t)n_rows * 4 * sizeof(float), stream));
+    rc = xr_composite_train(raw, coords, rays_numsteps, rays_numsteps_compacted, bg_color, target, alpha_mask, density_grid_mean,
+                            n_rays, rgb_activation, density_activation, huber_delta, loss_scale, rgb_out, loss_mse, draw, stream_);
+    if (rc != XR_OK) return rc;
+    XR_HIP(hipMemsetAsync(grad_table, 0, table_floats * sizeof(float), stream));
+    rc = f16_mlp ? xr_nerf_mlp_bwd_f16(enc_t, ld, coords + 4, 7, n_rows, n_dev, w_density, w_color, n_hidden_density, n_hidden_color,
+                                       pad_value, draw, denc_t, grad_w_density, grad_w_color, ws_mlp_bwd, ws_mlp_bwd_bytes, stream_)
+                 : xr_nerf_mlp_bwd(enc_t, ld, coords + 4, 7, n_rows, n_dev, w_density, w_color, n_hidden_density, n_hidden_color,
+                                   pad_value, draw, denc_t, grad_w_density, grad_w_color, ws_mlp_bwd, ws_mlp_bwd_bytes, stream_);
+    if (rc != XR_OK) return rc;
+    return xr_hashgrid_bwd(coords, 7, denc_t, ld, n_rows, n_dev, n_levels, scale_host, resolution_host, offset_host, grad_table,
+                           ws_scatter, ws_scatter_bytes, stream_);
+}
+
+// The next batch's side-stream work as one call: HashBatchSample + RandomBGColor (xr_make_batch) -> K1 (xr_rays_sampler) ->
+// K2's clipped counts (xr_clip_numsteps) -> asynchronous copy of K1's (rays, samples) counter to pinned host memory.  The two
+// hidden generators of the reference (`static pcg32 rng{9121}` per translation unit) and the batch generator are advanced
+// here from their call indices.  From Python this sequence cost ~200 us of interpreter time per iteration.
+extern "C" int xr_ngp_prefetch(const float* rays_rgb_rows, uint32_t n_rays, uint64_t batch_seed, uint64_t batch_call_index,
+                               float* rays_o, float* rays_d, float* target, float* alpha, float* bg, int32_t* img_ids,
+                               const uint8_t* bitfield, float aabb0, float aabb1, float near_distance, float cone_angle,
+                               uint32_t max_samples, uint64_t k1_call_index, float* coords_out, int32_t* rays_index,
+                               int32_t* rays_numsteps, uint32_t* counter2, void* workspace, size_t workspace_bytes,
+                               uint32_t max_compacted, int32_t* numsteps_clipped, uint32_t* n_valid_dev,
+                               uint32_t* counter_host_pinned, void* stream_) {
+    uint64_t st, inc;
+    xr_pcg32_host_state(batch_seed, batch_call_index, &st, &inc);
+    int rc = xr_make_batch(rays_rgb_rows, n_rays, st, inc, rays_o, rays_d, target, alpha, bg, img_ids, stream_);
+    if (rc != XR_OK) return rc;
+    xr_pcg32_host_state(9121, k1_call_index, &st, &inc);
+    rc = xr_rays_sampler(rays_o, rays_d, bitfield, n_rays, aabb0, aabb1, near_distance, cone_angle, max_samples, st, inc, coords_out,
+                         rays_index, rays_numsteps, counter2, workspace, workspace_bytes, stream_);
+    if (rc != XR_OK) return rc;
+    rc = xr_clip_numsteps(rays_numsteps, counter2, n_rays, max_compacted, numsteps_clipped, n_valid_dev, max_compacted, 1, stream_);
+    if (rc != XR_OK) return rc;
+    if (counter_host_pinned)
+        XR_HIP(hipMemcpyAsync(counter_host_pinned, counter2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream_));
+    return XR_OK;
+}

@@ -1,6 +1,7 @@
 """`HashNerfNetwork`: sampler -> mlp -> render, the registered type of
 /root/reference/xrnerf/models/networks/hashnerf.py:16-112 (base class behaviour from
 networks/nerf.py:23-69,171-173 and networks/base.py:9-37)."""
+import os
 import time
 
 import torch
@@ -98,6 +99,36 @@ class _FusedTrainStepFn(torch.autograd.Function):
                 data = sampler.sample(data, mlp, False)
             finally:
                 sampler.on_sampled = cb
+            sync = getattr(net, 'grad_sync', None)
+            if sync is None and table.is_cuda and mlp.density_net.n_hidden == 1 and mlp.color_net.n_hidden == 2 and \
+                    os.environ.get('XRNERF_PY_STEP') != '1':
+                # single GPU: the whole device side of the step as ONE native call (csrc/xr_step.hip) -- the same entry points
+                # in the same order as the Python sequence below, which stays for the data-parallel path (gradient buckets
+                # are handed to RCCL between the scatter halves) and for the kernels' host build
+                n_rows = sampler.coords.shape[0]
+                sets = getattr(net, '_step_bufs', None)
+                n_rays = sampler.rays_numsteps.shape[0]
+                if (sets is None or sets[0].n_rows != n_rows or sets[0].ray_cap < n_rays or sets[0].g_table.shape != table.shape
+                        or sets[0].g_table.device != table.device):
+                    sets = net._step_bufs = [ops.TrainStepBuffers(table.device, n_rows, max(n_rays, 1 << 15), table.numel(), wd.numel(),
+                                                                  wc.numel(), mlp.embedder_pos.meta) for _ in range(2)]
+                    net._step_turn = 0
+                net._step_turn ^= 1                 # two sets alternate: the one the optimiser still holds as .grad is not reused
+                b = sets[net._step_turn]
+                rgb = ops.ngp_train_step(table, wd, wc, 1, 2, mlp.pad_value, mlp.embedder_pos.meta, sampler.coords, data.get('n_valid_dev'),
+                                         sampler.rays_numsteps, sampler.rays_numsteps_compacted, data['bg_color'],
+                                         data['target_s'].contiguous(), data['alpha'].contiguous(), sampler.density_grid_mean,
+                                         int(sampler.rgb_activation), int(sampler.density_activation), b)
+                if cb is not None:
+                    cb()
+                ctx.grads = (b.g_table, b.g_wd, b.g_wc)
+                ctx.params = (table, wd, wc)
+                ctx.sync = None
+                ctx.unit_root_grad = getattr(net, '_unit_root_grad', None)
+                ctx.mark_non_differentiable(rgb)
+                ctx.set_materialize_grads(False)
+                net._last = {'rgb': rgb, 'loss_mse': b.loss_mse, 'raw': b.raw}
+                return b.loss_mse[0:1].reshape(()), rgb
             pts, dirs = mlp._rows(data['pts']), mlp._rows(data['viewdirs'])
             n, n_dev = pts.shape[0], data.get('n_valid_dev')
             meta, nhd, nhc = mlp.embedder_pos.meta, mlp.density_net.n_hidden, mlp.color_net.n_hidden
@@ -147,6 +178,7 @@ class _FusedTrainStepFn(torch.autograd.Function):
         ctx.grads = (g_table, g_wd, g_wc)
         ctx.params = (table, wd, wc)
         ctx.sync = getattr(net, 'grad_sync', None)
+        ctx.unit_root_grad = getattr(net, '_unit_root_grad', None)
         ctx.mark_non_differentiable(rgb)
         ctx.set_materialize_grads(False)         # no zero-filled dL/drgb tensor for the non-differentiable output
         net._last = {'rgb': rgb, 'loss_mse': loss_mse, 'raw': raw}
@@ -161,8 +193,12 @@ class _FusedTrainStepFn(torch.autograd.Function):
         factor = ctx.sync.finish() if ctx.sync is not None else 1.0      # all buckets reduced; average over the ranks
         if g is None:                            # only the non-differentiable output was used downstream
             return None, None, None, None, None
-        g = g.reshape(1) if g.dtype == torch.float32 and g.is_cuda else g.to(grads[0].device, torch.float32).reshape(1)
-        ops.scale_multi(grads, g, factor)        # one launch; free when the incoming gradient is exactly 1
+        unit = ctx.unit_root_grad
+        if not (factor == 1.0 and unit is not None and g.data_ptr() == unit.data_ptr()):
+            # (the trainer back-propagates from a persistent all-ones root gradient it registers as
+            # `net._unit_root_grad`: the scaling launch -- which would read that 1.0 and do nothing -- is skipped then)
+            g = g.reshape(1) if g.dtype == torch.float32 and g.is_cuda else g.to(grads[0].device, torch.float32).reshape(1)
+            ops.scale_multi(grads, g, factor)        # one launch; no memory traffic when the factor is exactly 1
         # Hand the gradients to the parameters the way AccumulateGrad would, but without its defensive clone
         # (a Python-created gradient is never "stolen": 48.8 MB copied per step): first gradient -> becomes
         # .grad, otherwise accumulate in place.

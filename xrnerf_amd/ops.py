@@ -205,6 +205,65 @@ def composite_train(raw, coords, numsteps, numsteps_c, bg, target, alpha, densit
     return rgb
 
 
+def ngp_prefetch(rows, n, batch_call_index, batch_out, bitfield, aabb, near_distance, cone_angle, max_samples, k1_call_index,
+                 coords_out, small_out, clip_out, max_compacted, counter_host, batch_seed=20220901, ws_tag='k1_side'):
+    """make_batch + K1 + K2 clip + counter copy to pinned host memory as one native call (xr_ngp_prefetch) on the current stream.
+    -> (batch dict of views, (coords_out, rays_index, numsteps, counter), (numsteps_clipped, n_valid))"""
+    L = _lib.load()
+    o, d, tgt, alpha, bg, ids = (batch_out[k][:n] for k in ('rays_o', 'rays_d', 'target_s', 'alpha', 'bg_color', 'img_ids'))
+    rays_index, numsteps, counter = small_out
+    clipped, n_valid = clip_out
+    ws = _ws(rows.device, L.xr_rays_sampler_workspace_bytes(n), ws_tag)
+    with _span('xr_rays_sampler', n):
+        _lib.check(L.xr_ngp_prefetch(_ptr(rows), n, batch_seed, batch_call_index, _ptr(o), _ptr(d), _ptr(tgt), _ptr(alpha), _ptr(bg),
+                                     _ptr(ids), _ptr(bitfield), aabb[0], aabb[1], near_distance, cone_angle, max_samples,
+                                     k1_call_index, _ptr(coords_out), _ptr(rays_index), _ptr(numsteps), _ptr(counter), _ptr(ws),
+                                     ws.numel(), max_compacted, _ptr(clipped), _ptr(n_valid),
+                                     C.c_void_p(counter_host.data_ptr()) if counter_host is not None else None, _stream()),
+                   'xr_ngp_prefetch')
+    batch = {'rays_o': o, 'rays_d': d, 'target_s': tgt, 'alpha': alpha, 'img_ids': ids, 'bg_color': bg}
+    return batch, (coords_out, rays_index, numsteps, counter), (clipped, n_valid)
+
+
+class TrainStepBuffers:
+    """caller-owned buffers of xr_ngp_train_step for `n_rows` sample rows and up to `ray_cap` rays"""
+
+    def __init__(self, device, n_rows, ray_cap, table_floats, wd_floats, wc_floats, meta):
+        f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=device)
+        self.n_rows, self.ray_cap, self.ld = n_rows, ray_cap, (n_rows + 63) // 64 * 64
+        self.enc_t, self.denc_t = f(meta.n_output_dims, self.ld), f(meta.n_output_dims, self.ld)
+        self.raw, self.draw, self.rgb = f(n_rows, 4), f(n_rows, 4), f(ray_cap, 3)
+        self.zero_block = f(wd_floats + wc_floats + 4)
+        self.g_wd, self.g_wc = self.zero_block[:wd_floats], self.zero_block[wd_floats:wd_floats + wc_floats]
+        self.g_mlp = self.zero_block[:wd_floats + wc_floats]
+        self.loss_mse = self.zero_block[wd_floats + wc_floats:wd_floats + wc_floats + 2]
+        self.g_table = f(table_floats)
+
+
+def ngp_train_step(table, wd, wc, nhd, nhc, pad_value, meta, coords, n_dev, numsteps, numsteps_c, bg, target, alpha,
+                   density_grid_mean, rgb_act, density_act, bufs, huber_delta=0.1, loss_scale=5.0):
+    """the device work of one HashNerfNetwork training step as one native call (xr_ngp_train_step): encode -> MLP -> K3 +
+    Huber + K4 -> MLP backward -> table scatter into `bufs` (TrainStepBuffers).  Returns rgb [n_rays,3] (a view of bufs.rgb)."""
+    L = _lib.load()
+    n_rays = numsteps.shape[0]
+    n_rows = bufs.n_rows
+    if coords.shape[0] < n_rows or coords.shape[1] != 7 or not coords.is_contiguous():
+        raise _lib.XrError('coords must be contiguous [>= n_rows, 7] rows')
+    s, r, o = meta._args()
+    ws_mlp = _ws(coords.device, L.xr_nerf_mlp_bwd_workspace_bytes(n_rows), 'mlpbwd')
+    ws_sc = _ws(coords.device, L.xr_hashgrid_bwd_workspace_bytes(n_rows, meta.n_levels, r, o), 'hgb')
+    with _span('xr_ngp_train_step', 0):
+        _lib.check(L.xr_ngp_train_step(
+            _ptr(table), _ptr(wd), _ptr(wc), nhd, nhc, pad_value, 1 if _PRECISION == 'f16' else 0, meta.n_levels, s, r, o,
+            _ptr(coords), n_rows, _ptr(n_dev), _ptr(numsteps), _ptr(numsteps_c), n_rays, _ptr(bg), _ptr(target), _ptr(alpha),
+            _ptr(density_grid_mean), int(rgb_act), int(density_act), float(huber_delta), float(loss_scale),
+            _ptr(bufs.enc_t), bufs.ld, _ptr(bufs.raw), _ptr(bufs.draw), _ptr(bufs.denc_t), _ptr(bufs.rgb),
+            _ptr(bufs.zero_block), bufs.zero_block.numel(), _ptr(bufs.g_wd), _ptr(bufs.g_wc), _ptr(bufs.loss_mse),
+            _ptr(bufs.g_table), bufs.g_table.numel(), 0 if n_dev is not None else 1,
+            _ptr(ws_mlp), ws_mlp.numel(), _ptr(ws_sc), ws_sc.numel(), _stream()), 'xr_ngp_train_step')
+    return bufs.rgb[:n_rays]
+
+
 def calc_rgb_inference(raw, coords, numsteps, bg3, rgb_act, density_act):
     L = _lib.load()
     n = numsteps.shape[0]
@@ -312,12 +371,16 @@ def _pos_view(x):
     return x, int(x.stride(0))
 
 
-def clip_numsteps(numsteps, counter, max_compacted):
+def clip_numsteps(numsteps, counter, max_compacted, out=None):
     """K2 without the copy (K1's output kept in place): clipped per-ray counts + the device-side count of valid
-    rows n_valid [2] = (total, total)  (the C entry point can also split the count over row chunks)."""
+    rows n_valid [2] = (total, total)  (the C entry point can also split the count over row chunks).
+    `out` = caller-owned (clipped [n,2] int32, n_valid [2] int32) buffers."""
     n = numsteps.shape[0]
-    out = torch.empty_like(numsteps)
-    n_valid = torch.empty((2,), dtype=torch.int32, device=numsteps.device)
+    if out is not None:
+        out, n_valid = out
+    else:
+        out = torch.empty_like(numsteps)
+        n_valid = torch.empty((2,), dtype=torch.int32, device=numsteps.device)
     _lib.check(_lib.load().xr_clip_numsteps(_ptr(numsteps), _ptr(counter), n, max_compacted, _ptr(out), _ptr(n_valid),
                                             max_compacted, 1, _stream()), 'xr_clip_numsteps')
     return out, n_valid

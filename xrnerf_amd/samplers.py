@@ -171,6 +171,7 @@ class NGPGridSampler(nn.Module):
             cur = torch.cuda.current_stream()
             cur.wait_event(pf['event'])
             coords, rays_index, rays_numsteps, counter = pf['out']
+            clipped = pf.get('clipped')
             self._pending_counts.append(pf['host'])
             # K1's outputs live in this sampler's persistent double buffers (nothing was allocated on the side
             # stream).  Batch tensors allocated there by the caller must be handed over to this stream -- unless
@@ -181,6 +182,7 @@ class NGPGridSampler(nn.Module):
                     if torch.is_tensor(t) and t.is_cuda:
                         t.record_stream(cur)
         else:
+            clipped = None
             if pf is not None:
                 # a prefetched march that does not belong to this batch is dropped (its RNG call stays consumed, like
                 # any other launch); its side-stream writes into the shared buffers must have finished before this
@@ -227,7 +229,9 @@ class NGPGridSampler(nn.Module):
         # clipped per-ray counts have to be produced.  Like the reference, the sample buffer handed to the
         # MLP has a fixed target_batch_size rows (compacted_coords.py:20-21 pads with zeros); the number of
         # valid rows stays on the device (`n_valid_dev`) so that no host read-back is needed here.
-        rays_numsteps_compacted, n_valid_dev = ops.clip_numsteps(rays_numsteps, counter, self.target_batch_size)
+        if clipped is None:
+            clipped = ops.clip_numsteps(rays_numsteps, counter, self.target_batch_size)
+        rays_numsteps_compacted, n_valid_dev = clipped
         # the pre-clip counter the reference accumulates in `measured_batch_size` (ngp_grid_sampler.py:252) is
         # accumulated on the host from the asynchronous pinned copies (_pending_counts)
         self.update_batch_rays(is_training, max_samples)
@@ -273,6 +277,18 @@ class NGPGridSampler(nn.Module):
                               torch.empty((2,), dtype=torch.int32, device=self.device))
         return b[0][:n_rays], b[1][:n_rays], b[2]
 
+    def _clip_buffers(self, n_rays, slot):
+        """persistent outputs of the prefetched K2 clip (nothing allocated on the side stream)"""
+        bufs = getattr(self, '_clip_bufs', None)
+        if bufs is None:
+            bufs = self._clip_bufs = [None, None, None]
+        b = bufs[slot]
+        if b is None or b[0].shape[0] < n_rays or b[0].device != self.device:
+            cap = max(n_rays, 1 << 15)
+            b = bufs[slot] = (torch.empty((cap, 2), dtype=torch.int32, device=self.device),
+                              torch.empty((2,), dtype=torch.int32, device=self.device))
+        return b[0][:n_rays], b[1]
+
     # ------------------------------------------------------------------ K1 overlap
     def can_prefetch(self, next_iter):
         """K1 depends on the rays and the bitfield only -- not on the parameters -- so the march of iteration
@@ -312,13 +328,43 @@ class NGPGridSampler(nn.Module):
                                coords_out=self._coords_buffer(max_samples, slot), ws_tag='k1_side',
                                small_out=self._small_buffers(n_rays, slot))
         self.k1_calls += 1
+        # K2's clipped per-ray counts and the device-side valid-row count only depend on this launch's outputs: computed
+        # here, on the side stream, instead of in front of the next iteration's encode
+        clipped = ops.clip_numsteps(out[2], out[3], self.target_batch_size, out=self._clip_buffers(n_rays, slot))
         # the compute stream waits for the MARCH only: the event sits before the counter's device-to-host copy
         # (behind it, the waiter also inherits the copy's system-scope completion: measured 45 us of idle compute
         # stream at the start of every iteration)
         done = torch.cuda.Event()
         done.record(side)
         host = self._count_to_host(out[3])
-        self._prefetched = {'rays_o': rays_o, 'max_samples': max_samples, 'out': out, 'event': done, 'host': host}
+        self._prefetched = {'rays_o': rays_o, 'max_samples': max_samples, 'out': out, 'event': done, 'host': host, 'clipped': clipped}
+
+    def prefetch_native(self, rows, n_rays, batch_call_index, batch_out, buffer_free_event=None):
+        """`prefetch` with the batch assembly folded in, as ONE native call (xr_ngp_prefetch: make_batch + K1 + K2 clip + counter
+        copy) on the current (side) stream.  -> the batch dict (views of `batch_out`)."""
+        aabb = (float(self.aabb_range[0]), float(self.aabb_range[1]))
+        max_samples = self.num_coords_elements if getattr(self, 'reference_buffer_rows', False) else \
+            max(self.num_coords_elements, n_rays * 64)
+        max_samples = min(max_samples, n_rays * self.MAX_STEP)
+        side = self.side_stream()
+        ev = getattr(self, '_bitfield_event', None)
+        if ev is not None:
+            side.wait_event(ev)
+        if buffer_free_event is not None:
+            side.wait_event(buffer_free_event)
+        slot = self._next_slot(True)
+        batch, out, clipped = ops.ngp_prefetch(rows, n_rays, batch_call_index, batch_out, self.density_grid_bitfield, aabb,
+                                               self.near_distance, self.cone_angle_constant, max_samples, self.k1_calls,
+                                               self._coords_buffer(max_samples, slot), self._small_buffers(n_rays, slot),
+                                               self._clip_buffers(n_rays, slot), self.target_batch_size, None)
+        self.__dict__['k1_calls'] = self.k1_calls + 1
+        # the compute stream waits for the march only: its event sits BEFORE the counter's device-to-host copy (see prefetch)
+        done = torch.cuda.Event()
+        done.record(side)
+        host = self._count_to_host(out[3])
+        self.__dict__['_prefetched'] = {'rays_o': batch['rays_o'], 'max_samples': max_samples, 'out': out, 'event': done,
+                                        'host': host, 'clipped': clipped}
+        return batch
 
     def _count_to_host(self, counter):
         """asynchronous copy of K1's (rays, samples) counter to pinned host memory, right behind the launch: by

@@ -219,6 +219,7 @@ class Trainer:
         # root gradient = a persistent ones tensor (loss.backward() would fill a fresh one every step)
         if self._one is None:
             self._one = torch.ones((), dtype=torch.float32, device=self.device)
+            net._unit_root_grad = self._one        # lets the fused step skip its gradient-scaling launch
         torch.autograd.backward(out['loss'], grad_tensors=self._one)
         if self.world_size > 1 and not net._fused_ok():
             from . import dist as xdist                 # modular step: reduce after backward (DDP semantics)
@@ -242,20 +243,34 @@ class Trainer:
         if not self.overlap_march or not net.sampler.can_prefetch(self.iter + 1):
             return
         side = net.sampler.side_stream()
+        bufs = self._batch_buffers((self.iter + 1) & 1, data.N_rand)
+        if bufs is not None and hasattr(data, 'rays_rgb') and os.environ.get('XRNERF_PY_STEP') != '1':
+            # the whole side-stream sequence (batch assembly, K1, K2 clip, counter copy) as one native call
+            n = min(data.N_rand, data.rays_rgb.shape[0])
+            if data.cur_i + n > data.rays_rgb.shape[0]:
+                data.cur_i = 0
+            with torch.cuda.stream(side):
+                nb = net.sampler.prefetch_native(data.rays_rgb[data.cur_i:data.cur_i + n], n, data.batches_drawn, bufs,
+                                                 buffer_free_event=self._ev_done[1])
+            data.cur_i += n
+            data.batches_drawn += 1
+            self._next_batch = nb
+            return
         with torch.cuda.stream(side):
             # these launches overwrite the batch / coordinate buffers last read by the PREVIOUS iteration (two
             # persistent sets, alternating): ordered behind its completion event
             if self._ev_done[1] is not None:
                 side.wait_event(self._ev_done[1])
-            bufs = self._batch_buffers((self.iter + 1) & 1, data.N_rand)
             nb = data.next_batch(out=bufs) if bufs is not None else data.next_batch()
             net.sampler.prefetch(nb, buffer_free_event=self._ev_done[1])
         self._next_batch = nb
 
     def _batch_buffers(self, slot, n):
         """persistent output buffers of the batch kernel for prefetched batches (None: the dataset cannot use them)"""
-        import inspect
-        if 'out' not in inspect.signature(self.data.next_batch).parameters:
+        if getattr(self, '_data_takes_out', None) is None:
+            import inspect
+            self._data_takes_out = 'out' in inspect.signature(self.data.next_batch).parameters
+        if not self._data_takes_out:
             self.net.sampler.persistent_batches = False
             return None
         if self._bbufs[slot] is None or self._bbufs[slot]['rays_o'].shape[0] < n:
