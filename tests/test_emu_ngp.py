@@ -67,6 +67,14 @@ def test_fused_mlp_on_the_host(O, edev):
         T.test_nerf_mlp_bwd(O, edev, n)
 
 
+def test_mlp_backward_on_live_rows_on_the_host(O, edev):
+    """the live-row compaction in front of the backward (both precisions), ragged / clipped / single-live-row launches"""
+    import test_gpu_tcnn as T
+    for n, nv in ((31, None), (100, None), (1500, 1200), (1100, 0)):
+        for precision in ('f32', 'f16'):
+            T.test_nerf_mlp_bwd_live_rows(O, edev, n, nv, precision)
+
+
 def test_reference_precision_mlp_on_the_host(edev):
     """the fp16-MFMA mode (v_mfma_f32_32x32x16_f16 emulated with its operand layout) against the numpy fp16 statement"""
     import test_gpu_tcnn as T

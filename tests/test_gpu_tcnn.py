@@ -140,6 +140,71 @@ def test_nerf_mlp_bwd(O, dev, n):
         assert err <= 1e-3 * max(1.0, np.abs(ref).max()), (name, err, np.abs(ref).max())
 
 
+def sparse_draw(rng, n, dead_fraction=0.55):
+    """dL/d(raw) the way the compositor produces it: runs of exactly-zero rows (samples behind an opaque surface), a few
+    isolated zero rows, rows with a single non-zero component, -0.0 entries"""
+    draw = rng.normal(0, 1, (n, 4)).astype(np.float32)
+    pos = 0
+    while pos < n:
+        run = int(rng.integers(1, 90))
+        if rng.uniform() < dead_fraction:
+            draw[pos:pos + run] = 0.0
+        pos += run
+    draw[rng.integers(0, n, max(1, n // 50))] = 0.0
+    one = rng.integers(0, n, max(1, n // 50))
+    draw[one] = 0.0
+    draw[one, rng.integers(0, 4, one.size)] = 0.5
+    draw[rng.integers(0, n, max(1, n // 100)), 1] = -0.0
+    return draw
+
+
+@pytest.mark.parametrize('n,n_valid', [(31, None), (100, None), (5000, 4100), (40001, None), (3000, 0)])
+@pytest.mark.parametrize('precision', ['f32', 'f16'])
+def test_nerf_mlp_bwd_live_rows(O, dev, n, n_valid, precision):
+    """the backward runs on the compaction of the rows with a non-zero dL/d(raw) (xr_mlp.hip: k_live_count / k_live_fill):
+    same dW, and an exactly-zero dL/d(encoding) for the dead rows, as the run over every row (XR_MLP_LIVE=0 is that run;
+    here the check is against the oracle and, for dead rows, exact)"""
+    from xrnerf_amd import ops, synthetic as S
+    meta = ops.GridMeta(); om = O.GridMeta()
+    rng = np.random.default_rng(7 * n + 1)
+    table = S.hash_table(meta.n_params, scale=0.5)
+    wd, wc = nets(S)
+    pts = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    dirs = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    draw = sparse_draw(rng, n)
+    if n == 31:
+        draw[:] = 0.0; draw[17, 3] = 1.0                   # one live row in the whole launch
+    if precision == 'f16':
+        draw *= 1e-2                                       # the magnitude the loss-scaled fp16 chain is built for
+    nv = n if n_valid is None else n_valid
+    dref = draw.copy(); dref[nv:] = 0.0
+    gt, gd, gc = O.nerf_mlp_bwd(table, wd, wc, pts, dirs, dref, om)
+    tt, tp = T(table, dev), T(pts, dev)
+    enc_t = ops.hashgrid_fwd(tt, tp, meta)
+    g_wd = torch.zeros(wd.size, dtype=torch.float32, device=dev)
+    g_wc = torch.zeros(wc.size, dtype=torch.float32, device=dev)
+    n_dev = None if n_valid is None else torch.tensor([nv], dtype=torch.int32, device=dev)
+    old = ops.precision()
+    ops.set_precision(precision)
+    try:
+        denc_t = ops.nerf_mlp_bwd(enc_t, T(dirs, dev), n, T(wd, dev), T(wc, dev), 1, 2, T(draw, dev), g_wd, g_wc, n_dev=n_dev)
+    finally:
+        ops.set_precision(old)
+    d = denc_t.cpu().numpy()[:, :nv]
+    dead = ~(dref[:nv] != 0).any(1)
+    assert dead.sum() > 0 or nv == 0
+    assert not d[:, dead].any(), 'dead rows must get an exactly-zero encoding gradient'
+    if nv == 0:
+        assert not g_wd.cpu().numpy().any() and not g_wc.cpu().numpy().any()
+        return
+    g_t = torch.zeros(meta.n_params, dtype=torch.float32, device=dev)
+    ops.hashgrid_bwd(tp, denc_t, meta, g_t, n_dev=n_dev)
+    tol = 1e-3 if precision == 'f32' else 3e-2             # fp16 operands: tests/f16_reference.py has the tight model
+    for name, got, ref in (('wd', g_wd, gd), ('wc', g_wc, gc), ('table', g_t, gt)):
+        err = np.abs(got.cpu().numpy() - ref).max()
+        assert err <= tol * max(1.0, np.abs(ref).max()), (name, err, np.abs(ref).max())
+
+
 def test_tcnn_module_surface_runs_the_reference_mlp_recipe(O, dev):
     """xrnerf_amd.tcnn.{Encoding,Network} used exactly as xrnerf/models/mlps/hashnerf_mlp.py:34-45,55-79 uses
     tinycudann: separate modules, row-major tensors, torch.cat in between, autograd end to end -- and the result

@@ -33,6 +33,7 @@
 //     output row m for m<16, so density_out registers feed the color net in place and its input
 //     gradient lands back on the density-output registers with no data movement either.
 #include "xr_common.h"
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
@@ -76,20 +77,50 @@ struct NetShape {
 
 // copy a network's weights global -> LDS (padded stride, zero-padded output rows).
 // first_layer_rot: apply the color-net slot permutation  LDS[o][m] = W[o][(m+31)&31].
+// Two phases: EVERY global load of the network is issued before the first LDS store (up to 32 registers per thread).
+// A plain load -> store loop compiles to one exposed L2 round trip per iteration, 40 of them in a row per workgroup:
+// measured as ~25 us of fixed time in a backward launch whose tile work is 80-160 us.
+template <int NH, int L>
+__device__ __forceinline__ void fetch_layer(float (&v)[NetShape<NH>::out_rows_lds(L) * NetShape<NH>::in_dim(L) / MLP_THREADS],
+                                            const float* __restrict__ w, bool first_layer_rot) {
+    using S = NetShape<NH>;
+    constexpr int K = S::in_dim(L), rows = S::out_dim(L), prow = S::out_rows_lds(L);
+    static_assert(prow * K % MLP_THREADS == 0, "layer size must be a multiple of the workgroup size");
+    const float* src = w + S::glb_off(L);
+#pragma unroll
+    for (int i = 0; i < prow * K / MLP_THREADS; ++i) {
+        const int e = threadIdx.x + i * MLP_THREADS, o = e / K, m = e % K;
+        const int col = (L == 0 && first_layer_rot) ? ((m + 31) & 31) : m;
+        v[i] = src[(o < rows ? o : rows - 1) * K + col];                  // padded rows: any valid address, zeroed on store
+    }
+}
+template <int NH, int L>
+__device__ __forceinline__ void store_layer(const float (&v)[NetShape<NH>::out_rows_lds(L) * NetShape<NH>::in_dim(L) / MLP_THREADS],
+                                            float* __restrict__ lds) {
+    using S = NetShape<NH>;
+    constexpr int K = S::in_dim(L), rows = S::out_dim(L), prow = S::out_rows_lds(L), st = S::stride(L);
+    float* dst = lds + S::lds_off(L);
+#pragma unroll
+    for (int i = 0; i < prow * K / MLP_THREADS; ++i) {
+        const int e = threadIdx.x + i * MLP_THREADS, o = e / K, m = e % K;
+        dst[o * st + m] = o < rows ? v[i] : 0.f;
+    }
+}
 template <int NH>
 __device__ inline void load_weights(float* __restrict__ lds, const float* __restrict__ w, bool first_layer_rot) {
     using S = NetShape<NH>;
-#pragma unroll
-    for (int l = 0; l <= NH; ++l) {
-        const int K = S::in_dim(l), rows = S::out_dim(l), prow = S::out_rows_lds(l), st = S::stride(l);
-        float* dst = lds + S::lds_off(l);
-        const float* src = w + S::glb_off(l);
-        for (int e = threadIdx.x; e < prow * K; e += MLP_THREADS) {
-            const int o = e / K, m = e % K;
-            const int col = (l == 0 && first_layer_rot) ? ((m + 31) & 31) : m;
-            dst[o * st + m] = o < rows ? src[o * K + col] : 0.f;
-        }
-    }
+    static_assert(NH >= 1 && NH <= 3, "1..3 hidden layers");
+    float v0[S::out_rows_lds(0) * S::in_dim(0) / MLP_THREADS], v1[S::out_rows_lds(1) * S::in_dim(1) / MLP_THREADS];
+    float v2[NH >= 2 ? S::out_rows_lds(NH >= 2 ? 2 : 0) * S::in_dim(NH >= 2 ? 2 : 0) / MLP_THREADS : 1];
+    float v3[NH >= 3 ? S::out_rows_lds(NH >= 3 ? 3 : 0) * S::in_dim(NH >= 3 ? 3 : 0) / MLP_THREADS : 1];
+    fetch_layer<NH, 0>(v0, w, first_layer_rot);
+    fetch_layer<NH, 1>(v1, w, false);
+    if constexpr (NH >= 2) fetch_layer<NH, 2>(v2, w, false);
+    if constexpr (NH >= 3) fetch_layer<NH, 3>(v3, w, false);
+    store_layer<NH, 0>(v0, lds);
+    store_layer<NH, 1>(v1, lds);
+    if constexpr (NH >= 2) store_layer<NH, 2>(v2, lds);
+    if constexpr (NH >= 3) store_layer<NH, 3>(v3, lds);
 }
 
 // ---- building blocks (all tiles in the C/D register layout described above) ------------------
@@ -322,14 +353,92 @@ __global__ __launch_bounds__(MLP_THREADS, 3) void k_nerf_mlp_fwd(const float* __
     }
 }
 
+// ------------------------------------------------------------------ live rows of a backward pass
+// A sample whose dL/d(raw) row is exactly (0,0,0,0) contributes exactly nothing to dW and gets an exactly-zero
+// dL/d(encoding): behind an opaque surface the compositor's transmittance is exactly 0 in fp32, and in steady-state
+// training that is MORE THAN HALF of the marched samples (tools/zero_grad_fraction.py: 0.53-0.55 at the bench
+// workload).  The backward therefore runs on the stable compaction of the live rows: k_live_count counts them per
+// 1024-row segment, k_live_fill writes the ordered row list (and the zero rows of denc_t), the MLP backward kernels
+// take tile t, column c from live_rows[32 t + c].  Stable order + fixed partition: bit-reproducible run to run.
+#define LIVE_SEG 1024
+#define LIVE_THREADS 256
+__device__ __forceinline__ bool row_live(const float4 d) { return d.x != 0.f || d.y != 0.f || d.z != 0.f || d.w != 0.f; }
+
+__global__ __launch_bounds__(LIVE_THREADS) void k_live_count(const float4* __restrict__ draw, uint32_t n, const uint32_t* __restrict__ n_dev,
+                                                            uint32_t* __restrict__ seg_count) {
+    if (n_dev) n = min(n, *n_dev);
+    __shared__ uint32_t ws[LIVE_THREADS / 64];
+    const uint32_t r0 = blockIdx.x * LIVE_SEG + threadIdx.x * 4;
+    uint32_t c = 0;
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u)
+        if (r0 + u < n) c += row_live(draw[r0 + u]) ? 1u : 0u;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) seg_count[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
+__global__ __launch_bounds__(LIVE_THREADS) void k_live_fill(const float4* __restrict__ draw, uint32_t n, const uint32_t* __restrict__ n_dev,
+                                                           const uint32_t* __restrict__ seg_count, uint32_t n_seg,
+                                                           uint32_t* __restrict__ live_rows, uint32_t* __restrict__ n_live,
+                                                           float* __restrict__ denc_t, uint32_t ld) {
+    if (n_dev) n = min(n, *n_dev);
+    __shared__ uint32_t ws[LIVE_THREADS / 64], wbase[LIVE_THREADS / 64 + 1];
+    // rows before this segment: sum of the earlier segments' counts
+    uint32_t before = 0;
+    for (uint32_t s = threadIdx.x; s < blockIdx.x; s += LIVE_THREADS) before += seg_count[s];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = before;
+    __syncthreads();
+    before = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+    __syncthreads();
+    const uint32_t r0 = blockIdx.x * LIVE_SEG + threadIdx.x * 4;
+    bool lv[4]; uint32_t c = 0;
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) { lv[u] = r0 + u < n && row_live(draw[r0 + u]); c += lv[u] ? 1u : 0u; }
+    // exclusive scan of c over the block (wave scan, then the four wave totals)
+    uint32_t inc = c;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+    if (lane == 63) ws[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t a = 0;
+        for (int w = 0; w < LIVE_THREADS / 64; ++w) { wbase[w] = a; a += ws[w]; }
+        wbase[LIVE_THREADS / 64] = a;
+    }
+    __syncthreads();
+    uint32_t pos = before + wbase[threadIdx.x >> 6] + inc - c;
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) if (lv[u]) live_rows[pos++] = r0 + u;
+    if (blockIdx.x == n_seg - 1 && threadIdx.x == 0) *n_live = before + wbase[LIVE_THREADS / 64];
+    // dead rows inside [0, n): their dL/d(encoding) is exactly zero (what the full backward would have written)
+    if (c == 0 && r0 + 3 < n && (ld & 3) == 0 && (((uintptr_t)denc_t) & 15) == 0) {
+#pragma unroll
+        for (int f = 0; f < ENC_DIM; ++f) *reinterpret_cast<float4*>(denc_t + (size_t)f * ld + r0) = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u)
+            if (!lv[u] && r0 + u < n)
+                for (int f = 0; f < ENC_DIM; ++f) denc_t[(size_t)f * ld + r0 + u] = 0.f;
+    }
+}
+
 // ------------------------------------------------------------------ backward kernel
 // Specialised for the reference topology family NHD = 1, NHC = 2 (density 32->64->16,
 // color 32->64->64->16): every activation and all 12 dW accumulator tiles stay in registers.
+template <bool LIVE>
 __global__ __launch_bounds__(MLP_THREADS, 1) void k_nerf_mlp_bwd_1_2(
     const float* __restrict__ enc_t, uint32_t ld, const float* __restrict__ dirs, uint32_t dir_stride, uint32_t n,
     const uint32_t* __restrict__ n_dev, const float* __restrict__ w_density, const float* __restrict__ w_color,
-    float pad_value, const float4* __restrict__ draw, float* __restrict__ denc_t, float* __restrict__ partial /*[grid][GW]*/) {
+    float pad_value, const float4* __restrict__ draw, float* __restrict__ denc_t, float* __restrict__ partial /*[grid][GW]*/,
+    const uint32_t* __restrict__ live_rows, const uint32_t* __restrict__ n_live) {
     if (n_dev) n = min(n, *n_dev);
+    if (LIVE) n = *n_live;                                             // rows of the compacted space
     using SD = NetShape<1>;
     using SC = NetShape<2>;
     constexpr int GW = SD::glb_floats + SC::glb_floats;                // 3072 + 7168
@@ -355,9 +464,10 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void k_nerf_mlp_bwd_1_2(
 
     const uint32_t n_tiles = (n + 31) / 32;
     for (uint32_t tile = blockIdx.x * MLP_WAVES + wave; tile < n_tiles; tile += gridDim.x * MLP_WAVES) {
-        const uint32_t s = tile * 32 + col;
-        const bool live = s < n;
-        const uint32_t sc = live ? s : n - 1;
+        const uint32_t s0 = tile * 32 + col;
+        const bool live = s0 < n;
+        const uint32_t s = LIVE ? live_rows[live ? s0 : n - 1] : s0;
+        const uint32_t sc = LIVE ? s : (live ? s : n - 1);
         // ---- recompute forward, keep activations
         f32x16 xe[1], hd[2], dout[1], cin[1], hc1[2], hc2[2];
         load_enc_tile(enc_t, ld, sc, xe[0], hi);
@@ -618,25 +728,38 @@ __device__ __forceinline__ int hslot(int m, int ns) {           // offset of neu
     const int e = (m & 3) | (((m >> 3) & 1) << 2), hi = (m >> 2) & 1, t = m >> 4;
     return (hi * ns + t) * 8 + e;
 }
+template <int NH, int L>
+__device__ __forceinline__ void store_layer_h(const float (&v)[NetShape<NH>::out_rows_lds(L) * NetShape<NH>::in_dim(L) / MLP_THREADS],
+                                              _Float16* __restrict__ wf, _Float16* __restrict__ wb, bool first_layer_rot) {
+    using S = NetShape<NH>;
+    using H = HShape<NH>;
+    constexpr int K = S::in_dim(L), rows = S::out_dim(L), prow = S::out_rows_lds(L);
+    constexpr int ns = K / 16, rs = h_rs(K), nso = prow / 16, rsb = h_rs(prow);
+    _Float16* dst = wf + H::f_off(L);
+    _Float16* dstb = wb ? wb + H::b_off(L) : nullptr;
+#pragma unroll
+    for (int i = 0; i < prow * K / MLP_THREADS; ++i) {
+        const int x = threadIdx.x + i * MLP_THREADS, o = x / K, c = x % K;        // global [o][c]
+        const int m = (L == 0 && first_layer_rot) ? ((c + 1) & 31) : c;             // LDS slot of global column c
+        const _Float16 h = (_Float16)(o < rows ? v[i] : 0.f);
+        dst[o * rs + hslot(m, ns)] = h;
+        if (dstb) dstb[m * rsb + hslot(o, nso)] = h;
+    }
+}
+// same two-phase scheme as load_weights (all global loads in flight, then the converting LDS stores); the fetch reads
+// the SOURCE elements in order (coalesced), i.e. fetch_layer without the slot rotation
 template <int NH>
 __device__ inline void load_weights_h(_Float16* __restrict__ wf, _Float16* __restrict__ wb, const float* __restrict__ w, bool first_layer_rot) {
     using S = NetShape<NH>;
-    using H = HShape<NH>;
-#pragma unroll
-    for (int l = 0; l <= NH; ++l) {
-        const int K = S::in_dim(l), rows = S::out_dim(l), prow = S::out_rows_lds(l);
-        const int ns = K / 16, rs = h_rs(K), nso = prow / 16, rsb = h_rs(prow);
-        _Float16* dst = wf + H::f_off(l);
-        _Float16* dstb = wb ? wb + H::b_off(l) : nullptr;
-        const float* src = w + S::glb_off(l);
-        for (int x = threadIdx.x; x < prow * K; x += MLP_THREADS) {
-            const int o = x / K, c = x % K;                                   // global [o][c]
-            const int m = (l == 0 && first_layer_rot) ? ((c + 1) & 31) : c;   // LDS slot of global column c
-            const _Float16 v = (_Float16)(o < rows ? src[x] : 0.f);
-            dst[o * rs + hslot(m, ns)] = v;
-            if (dstb) dstb[m * rsb + hslot(o, nso)] = v;
-        }
-    }
+    static_assert(NH == 1 || NH == 2, "the fp16 mode is built for 1 or 2 hidden layers");
+    float v0[S::out_rows_lds(0) * S::in_dim(0) / MLP_THREADS], v1[S::out_rows_lds(1) * S::in_dim(1) / MLP_THREADS];
+    float v2[NH >= 2 ? S::out_rows_lds(NH >= 2 ? 2 : 0) * S::in_dim(NH >= 2 ? 2 : 0) / MLP_THREADS : 1];
+    fetch_layer<NH, 0>(v0, w, false);
+    fetch_layer<NH, 1>(v1, w, false);
+    if constexpr (NH >= 2) fetch_layer<NH, 2>(v2, w, false);
+    store_layer_h<NH, 0>(v0, wf, wb, first_layer_rot);
+    store_layer_h<NH, 1>(v1, wf, wb, false);
+    if constexpr (NH >= 2) store_layer_h<NH, 2>(v2, wf, wb, false);
 }
 
 struct HTile { h8 p[2]; };                       // a 32 x 32 tile as the two fp16 B operands of its two K-steps
@@ -646,37 +769,83 @@ __device__ __forceinline__ HTile to_h(const f32x16& t) {
     for (int e = 0; e < 8; ++e) { r.p[0][e] = (_Float16)t[e]; r.p[1][e] = (_Float16)t[8 + e]; }
     return r;
 }
-// out[TO] = W . in[TI]
-template <int TI, int TO>
+// out[TO] = W . in[TI].  SB: explicit operand prefetch (distance HPF K-steps) fenced by scheduling barriers -- the
+// backward kernel runs one wave per SIMD at the register limit, and a scheduler free to hoist every ds_read_b128 of a
+// layer (4 VGPRs each) to the top pushes its accumulators into scratch.
+#ifndef HPF
+#define HPF 2
+#endif
+#ifndef HSB
+#define HSB false
+#endif
+template <int TI, int TO, bool SB = false>
 __device__ __forceinline__ void layer_fwd_h(const _Float16* __restrict__ wf, const HTile (&in)[TI], f32x16 (&out)[TO], int col, int hi) {
     constexpr int NS = 2 * TI, RS = 2 * NS * 8 + 8;
 #pragma unroll
     for (int to = 0; to < TO; ++to)
 #pragma unroll
         for (int r = 0; r < 16; ++r) out[to][r] = 0.f;
+    if (!SB) {
 #pragma unroll
-    for (int t = 0; t < NS; ++t) {
+        for (int t = 0; t < NS; ++t) {
 #pragma unroll
-        for (int to = 0; to < TO; ++to) {
-            const h8 a = *reinterpret_cast<const h8*>(wf + (to * 32 + col) * RS + (hi * NS + t) * 8);
-            out[to] = MFMA16(a, in[t >> 1].p[t & 1], out[to]);
+            for (int to = 0; to < TO; ++to) {
+                const h8 a = *reinterpret_cast<const h8*>(wf + (to * 32 + col) * RS + (hi * NS + t) * 8);
+                out[to] = MFMA16(a, in[t >> 1].p[t & 1], out[to]);
+            }
+        }
+    } else {
+        const _Float16* wl = wf + col * RS + hi * NS * 8;
+        h8 a[HPF + 1][TO];
+#pragma unroll
+        for (int p = 0; p < HPF && p < NS; ++p)
+#pragma unroll
+            for (int to = 0; to < TO; ++to) a[p][to] = *reinterpret_cast<const h8*>(wl + to * 32 * RS + p * 8);
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + HPF < NS) {
+#pragma unroll
+                for (int to = 0; to < TO; ++to) a[(t + HPF) % (HPF + 1)][to] = *reinterpret_cast<const h8*>(wl + to * 32 * RS + (t + HPF) * 8);
+            }
+#pragma unroll
+            for (int to = 0; to < TO; ++to) out[to] = MFMA16(a[t % (HPF + 1)][to], in[t >> 1].p[t & 1], out[to]);
         }
     }
 }
 // gin[TI] = W^T . g[TO]; only the first NSTEPS K-steps of g can be non-zero
-template <int TO, int TI, int NSTEPS = 2 * TO>
+template <int TO, int TI, int NSTEPS = 2 * TO, bool SB = false>
 __device__ __forceinline__ void layer_bwd_h(const _Float16* __restrict__ wb, const HTile (&g)[TO], f32x16 (&gin)[TI], int col, int hi) {
     constexpr int NSO = 2 * TO, RSB = 2 * NSO * 8 + 8;
 #pragma unroll
     for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
         for (int r = 0; r < 16; ++r) gin[ti][r] = 0.f;
+    if (!SB) {
 #pragma unroll
-    for (int t = 0; t < NSTEPS; ++t) {
+        for (int t = 0; t < NSTEPS; ++t) {
 #pragma unroll
-        for (int ti = 0; ti < TI; ++ti) {
-            const h8 a = *reinterpret_cast<const h8*>(wb + (ti * 32 + col) * RSB + (hi * NSO + t) * 8);
-            gin[ti] = MFMA16(a, g[t >> 1].p[t & 1], gin[ti]);
+            for (int ti = 0; ti < TI; ++ti) {
+                const h8 a = *reinterpret_cast<const h8*>(wb + (ti * 32 + col) * RSB + (hi * NSO + t) * 8);
+                gin[ti] = MFMA16(a, g[t >> 1].p[t & 1], gin[ti]);
+            }
+        }
+    } else {
+        const _Float16* wl = wb + col * RSB + hi * NSO * 8;
+        h8 a[HPF + 1][TI];
+#pragma unroll
+        for (int p = 0; p < HPF && p < NSTEPS; ++p)
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti) a[p][ti] = *reinterpret_cast<const h8*>(wl + ti * 32 * RSB + p * 8);
+#pragma unroll
+        for (int t = 0; t < NSTEPS; ++t) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + HPF < NSTEPS) {
+#pragma unroll
+                for (int ti = 0; ti < TI; ++ti) a[(t + HPF) % (HPF + 1)][ti] = *reinterpret_cast<const h8*>(wl + ti * 32 * RSB + (t + HPF) * 8);
+            }
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti) gin[ti] = MFMA16(a[t % (HPF + 1)][ti], g[t >> 1].p[t & 1], gin[ti]);
         }
     }
 }
@@ -776,11 +945,14 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_nerf_mlp_fwd_h(const float* 
     }
 }
 
+template <bool LIVE>
 __global__ __launch_bounds__(MLP_THREADS, 1) void k_nerf_mlp_bwd_h(
     const float* __restrict__ enc_t, uint32_t ld, const float* __restrict__ dirs, uint32_t dir_stride, uint32_t n,
     const uint32_t* __restrict__ n_dev, const float* __restrict__ w_density, const float* __restrict__ w_color,
-    float pad_value, const float4* __restrict__ draw, float* __restrict__ denc_t, float* __restrict__ partial /*[grid][GW]*/) {
+    float pad_value, const float4* __restrict__ draw, float* __restrict__ denc_t, float* __restrict__ partial /*[grid][GW]*/,
+    const uint32_t* __restrict__ live_rows, const uint32_t* __restrict__ n_live) {
     if (n_dev) n = min(n, *n_dev);
+    if (LIVE) n = *n_live;
     using SD = NetShape<1>;
     using SC = NetShape<2>;
     using HD = HShape<1>;
@@ -811,23 +983,24 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void k_nerf_mlp_bwd_h(
         a_c2[0][0][r] = a_c2[0][1][r] = 0.f;
     }
     for (uint32_t tile = blockIdx.x * MLP_WAVES + wave; tile < n_tiles; tile += tstride) {
-        const uint32_t s = tile * 32 + col;
-        const bool live = s < n;
-        const uint32_t sc = live ? s : n - 1;
+        const uint32_t s0 = tile * 32 + col;
+        const bool live = s0 < n;
+        const uint32_t s = LIVE ? live_rows[live ? s0 : n - 1] : s0;
+        const uint32_t sc = LIVE ? s : (live ? s : n - 1);
         // ---- recompute the forward; every activation is kept in the fp16 form the forward used
         f32x16 t0, t2[2], dout[1];
         load_enc_tile(enc_t, ld, sc, t0, hi);
         HTile xe[1] = {to_h(t0)};
-        layer_fwd_h<1, 2>(wdf + HD::f_off(0), xe, t2, col, hi);
+        layer_fwd_h<1, 2, HSB>(wdf + HD::f_off(0), xe, t2, col, hi);
         relu_tile(t2[0]); relu_tile(t2[1]);
         HTile hd[2] = {to_h(t2[0]), to_h(t2[1])};
-        layer_fwd_h<2, 1>(wdf + HD::f_off(1), hd, dout, col, hi);
+        layer_fwd_h<2, 1, HSB>(wdf + HD::f_off(1), hd, dout, col, hi);
         build_color_in(dout[0], dirs, dir_stride, sc, pad_value, t0, hi);
         HTile cin[1] = {to_h(t0)};
-        layer_fwd_h<1, 2>(wcf + HC::f_off(0), cin, t2, col, hi);
+        layer_fwd_h<1, 2, HSB>(wcf + HC::f_off(0), cin, t2, col, hi);
         relu_tile(t2[0]); relu_tile(t2[1]);
         HTile hc1[2] = {to_h(t2[0]), to_h(t2[1])};
-        layer_fwd_h<2, 2>(wcf + HC::f_off(1), hc1, t2, col, hi);
+        layer_fwd_h<2, 2, HSB>(wcf + HC::f_off(1), hc1, t2, col, hi);
         relu_tile(t2[0]); relu_tile(t2[1]);
         HTile hc2[2] = {to_h(t2[0]), to_h(t2[1])};
         // ---- output gradients (x loss scale)
@@ -840,7 +1013,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void k_nerf_mlp_bwd_h(
         HTile gh1[1] = {to_h(g1)};
         // color output layer
         dw_stage_h<1, 2>(gh1, hc2, stage, col, hi);
-        layer_bwd_h<1, 2, 1>(wcb + HC::b_off(2), gh1, g2, col, hi);          // rows 0..2: the first K-step only
+        layer_bwd_h<1, 2, 1, HSB>(wcb + HC::b_off(2), gh1, g2, col, hi);          // rows 0..2: the first K-step only
         dw_mfma_h<1, 2>(a_c2, stage, col, hi);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {                                        // relu mask by the fp16 activation's sign
@@ -850,7 +1023,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void k_nerf_mlp_bwd_h(
         HTile gh2[2] = {to_h(g2[0]), to_h(g2[1])};
         // color hidden layer 2
         dw_stage_h<2, 2>(gh2, hc1, stage, col, hi);
-        layer_bwd_h<2, 2>(wcb + HC::b_off(1), gh2, g2, col, hi);
+        layer_bwd_h<2, 2, 4, HSB>(wcb + HC::b_off(1), gh2, g2, col, hi);
         dw_mfma_h<2, 2>(a_c1, stage, col, hi);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -861,7 +1034,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void k_nerf_mlp_bwd_h(
         // color input layer
         dw_stage_h<2, 1>(gh2, cin, stage, col, hi);
         f32x16 gi[1];
-        layer_bwd_h<2, 1>(wcb + HC::b_off(0), gh2, gi, col, hi);             // dL/d(color input slots)
+        layer_bwd_h<2, 1, 4, HSB>(wcb + HC::b_off(0), gh2, gi, col, hi);             // dL/d(color input slots)
         dw_mfma_h<2, 1>(a_c0, stage, col, hi);
 #pragma unroll
         for (int r = 8; r < 16; ++r) gi[0][r] = 0.f;                          // slots >= 16 are SH / padding, not density outputs
@@ -869,7 +1042,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void k_nerf_mlp_bwd_h(
         gh1[0] = to_h(gi[0]);
         // density output layer
         dw_stage_h<1, 2>(gh1, hd, stage, col, hi);
-        layer_bwd_h<1, 2, 1>(wdb + HD::b_off(1), gh1, g2, col, hi);          // 16 real output neurons: the first K-step
+        layer_bwd_h<1, 2, 1, HSB>(wdb + HD::b_off(1), gh1, g2, col, hi);          // 16 real output neurons: the first K-step
         dw_mfma_h<1, 2>(a_d1, stage, col, hi);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -879,7 +1052,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void k_nerf_mlp_bwd_h(
         gh2[0] = to_h(g2[0]); gh2[1] = to_h(g2[1]);
         // density input layer
         dw_stage_h<2, 1>(gh2, xe, stage, col, hi);
-        layer_bwd_h<2, 1>(wdb + HD::b_off(0), gh2, gi, col, hi);             // dL/d(encoded features) x loss scale
+        layer_bwd_h<2, 1, 4, HSB>(wdb + HD::b_off(0), gh2, gi, col, hi);             // dL/d(encoded features) x loss scale
         dw_mfma_h<2, 1>(a_d0, stage, col, hi);
         if (live) {
 #pragma unroll
@@ -963,10 +1136,31 @@ static uint32_t bwd_grid(uint32_t n) {
     const uint32_t n_tiles = (n + 31) / 32;
     return min(xr_div_up(n_tiles, MLP_WAVES), (uint32_t)cus);
 }
-extern "C" size_t xr_nerf_mlp_bwd_workspace_bytes(uint32_t n) {
-    (void)n;
+// workspace: [cus][GW] dW partials | live_rows[n] | seg_count[ceil(n / LIVE_SEG)] | n_live
+static size_t bwd_partial_bytes() {
     const int cus = xr_device_cus() > 0 ? xr_device_cus() : 256;
     return (size_t)cus * (NetShape<1>::glb_floats + NetShape<2>::glb_floats) * sizeof(float);
+}
+extern "C" size_t xr_nerf_mlp_bwd_workspace_bytes(uint32_t n) {
+    return bwd_partial_bytes() + ((size_t)n + xr_div_up(n, LIVE_SEG) + 4) * sizeof(uint32_t);
+}
+static bool live_rows_enabled() {          // XR_MLP_LIVE=0: run the backward over every row (measurement)
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("XR_MLP_LIVE"); on = (e && e[0] == '0') ? 0 : 1; }
+    return on == 1;
+}
+// builds the live-row list of `draw` in the workspace (and zeroes the dead rows of denc_t); -> list / count pointers
+static int build_live_rows(const float* draw, uint32_t n, const uint32_t* n_dev, float* denc_t, uint32_t ld, void* workspace,
+                           hipStream_t stream, const uint32_t** rows, const uint32_t** n_live) {
+    uint32_t* list = reinterpret_cast<uint32_t*>((char*)workspace + bwd_partial_bytes());
+    const uint32_t n_seg = xr_div_up(n, LIVE_SEG);
+    uint32_t* seg = list + n;
+    uint32_t* cnt = seg + n_seg;
+    hipLaunchKernelGGL(k_live_count, dim3(n_seg), dim3(LIVE_THREADS), 0, stream, (const float4*)draw, n, n_dev, seg);
+    hipLaunchKernelGGL(k_live_fill, dim3(n_seg), dim3(LIVE_THREADS), 0, stream, (const float4*)draw, n, n_dev, (const uint32_t*)seg, n_seg,
+                       list, cnt, denc_t, ld);
+    *rows = list; *n_live = cnt;
+    return XR_OK;
 }
 
 extern "C" int xr_nerf_mlp_bwd(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
@@ -986,10 +1180,13 @@ extern "C" int xr_nerf_mlp_bwd(const float* enc_t, uint32_t ld, const float* dir
     constexpr int GW = NetShape<1>::glb_floats + NetShape<2>::glb_floats;
     const size_t lds = (NetShape<1>::lds_floats + NetShape<2>::lds_floats + MLP_WAVES * 4 * 32 * ST33) * sizeof(float);
     static_assert(MLP_WAVES * 4 * 32 * ST33 >= GW, "stage area doubles as the dW reduction buffer");
-    XR_HIP(hipFuncSetAttribute((const void*)k_nerf_mlp_bwd_1_2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint32_t grid = bwd_grid(n);
-    hipLaunchKernelGGL(k_nerf_mlp_bwd_1_2, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n,
-                       n_dev, w_density, w_color, pad_value, (const float4*)draw, denc_t, (float*)workspace);
+    const uint32_t *rows = nullptr, *n_live = nullptr;
+    if (live_rows_enabled()) build_live_rows(draw, n, n_dev, denc_t, ld, workspace, stream, &rows, &n_live);
+    auto kern = rows ? k_nerf_mlp_bwd_1_2<true> : k_nerf_mlp_bwd_1_2<false>;
+    XR_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n,
+                       n_dev, w_density, w_color, pad_value, (const float4*)draw, denc_t, (float*)workspace, rows, n_live);
     hipLaunchKernelGGL(k_reduce_partials, dim3(xr_div_up(GW, 64)), dim3(256), 0, stream, (const float*)workspace, grid,
                        (uint32_t)GW, (uint32_t)NetShape<1>::glb_floats, grad_w_density, grad_w_color);
     XR_LAUNCH_CHECK();
@@ -1089,10 +1286,13 @@ extern "C" int xr_nerf_mlp_bwd_f16(const float* enc_t, uint32_t ld, const float*
     constexpr size_t stage_bytes = (size_t)MLP_WAVES * 4 * 32 * HST * 2;
     static_assert(stage_bytes >= GW * sizeof(float), "stage area doubles as the dW reduction buffer");
     const size_t lds = (size_t)(HShape<1>::f_halves + HShape<2>::f_halves + HShape<1>::b_halves + HShape<2>::b_halves) * 2 + stage_bytes;
-    XR_HIP(hipFuncSetAttribute((const void*)k_nerf_mlp_bwd_h, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint32_t grid = bwd_grid(n);
-    hipLaunchKernelGGL(k_nerf_mlp_bwd_h, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev, w_density,
-                       w_color, pad_value, (const float4*)draw, denc_t, (float*)workspace);
+    const uint32_t *rows = nullptr, *n_live = nullptr;
+    if (live_rows_enabled()) build_live_rows(draw, n, n_dev, denc_t, ld, workspace, stream, &rows, &n_live);
+    auto kern = rows ? k_nerf_mlp_bwd_h<true> : k_nerf_mlp_bwd_h<false>;
+    XR_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev, w_density,
+                       w_color, pad_value, (const float4*)draw, denc_t, (float*)workspace, rows, n_live);
     hipLaunchKernelGGL(k_reduce_partials, dim3(xr_div_up(GW, 64)), dim3(256), 0, stream, (const float*)workspace, grid, (uint32_t)GW,
                        (uint32_t)NetShape<1>::glb_floats, grad_w_density, grad_w_color);
     XR_LAUNCH_CHECK();
