@@ -185,8 +185,10 @@ int xr_hashgrid_fwd(const float* table, const float* x, uint32_t x_stride, uint3
  * (hot-entry contention) that are folded afterwards; without it every level takes the plain atomic scatter. */
 size_t xr_hashgrid_bwd_workspace_bytes(uint32_t n, int n_levels, const uint32_t* resolution_host,
                                        const uint32_t* offset_host);
+/* rows (nullable, with n_dev): launch sample j is row rows[j] of x / denc_t and *n_dev the list's length -- the live-row
+ * list of xr_live_rows, so that the scatter never touches the rows whose gradient is exactly zero. */
 int xr_hashgrid_bwd(const float* x, uint32_t x_stride, const float* denc_t, uint32_t ld, uint32_t n,
-                    const uint32_t* n_dev, int n_levels, const float* scale_host, const uint32_t* resolution_host,
+                    const uint32_t* n_dev, const uint32_t* rows, int n_levels, const float* scale_host, const uint32_t* resolution_host,
                     const uint32_t* offset_host, float* grad_table, void* workspace, size_t workspace_bytes,
                     void* stream);
 /* tcnn.Encoding otype=SphericalHarmonics degree 4; dirs in [0,1] (the sampler's warp_direction);
@@ -206,10 +208,26 @@ int xr_nerf_mlp_fwd(const float* enc_t, uint32_t ld, const float* dirs, uint32_t
  * Activations are recomputed in-kernel (nothing saved by the forward).
  * workspace: xr_nerf_mlp_bwd_workspace_bytes(n). */
 size_t xr_nerf_mlp_bwd_workspace_bytes(uint32_t n);
+/* live_rows / n_live (both or neither): the list xr_live_rows built from `draw`.  The backward then computes exactly the
+ * listed rows and leaves the other rows of denc_t UNTOUCHED (pass the same list to xr_hashgrid_bwd).  Without a list
+ * the call builds its own in the workspace and writes exact zeros to the dead rows of denc_t (same results as the
+ * backward over every row, which XR_MLP_LIVE=0 still runs for measurement). */
 int xr_nerf_mlp_bwd(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
                     const uint32_t* n_dev, const float* w_density, const float* w_color, int n_hidden_density, int n_hidden_color,
                     float pad_value, const float* draw /*[n,4]*/, float* denc_t, float* grad_w_density,
-                    float* grad_w_color, void* workspace, size_t workspace_bytes, void* stream);
+                    float* grad_w_color, void* workspace, size_t workspace_bytes, const uint32_t* live_rows,
+                    const uint32_t* n_live, void* stream);
+/* Rows of dL/d(raw) [n,4] that are not exactly (0,0,0,0), in order: live_rows[0 .. *n_live).  A sample behind an opaque
+ * surface has transmittance exactly 0 in fp32 (calc_rgb.cu:36-52 multiplies it into every term of the gradient), so its
+ * row is exactly zero and contributes exactly nothing to dW or to the table gradient -- in steady-state training more
+ * than half of the marched samples.  seg_count: scratch of xr_live_rows_segments(n) words.  zero_denc_t (nullable,
+ * [32][ld]): the dead rows of it are set to zero.  Stable order and a fixed partition: reproducible run to run. */
+size_t xr_live_rows_segments(uint32_t n);
+/* the list area inside an xr_nerf_mlp_bwd workspace of n rows (unused by a backward that is handed a list) */
+int xr_nerf_mlp_bwd_list_slots(void* workspace, size_t workspace_bytes, uint32_t n, uint32_t** live_rows, uint32_t** seg_count,
+                               uint32_t** n_live);
+int xr_live_rows(const float* dloss_doutput, uint32_t n, const uint32_t* n_dev, uint32_t* seg_count, uint32_t* live_rows,
+                 uint32_t* n_live, float* zero_denc_t, uint32_t ld, void* stream);
 
 /* Reference-precision mode of the two calls above: tiny-cuda-nn computes FullyFusedMLP in fp16 with fp32 accumulation
  * (the reference casts its half outputs to fp32, hashnerf_mlp.py:76-77).  Same contracts, parameters and gradients stay
@@ -221,7 +239,8 @@ int xr_nerf_mlp_fwd_f16(const float* enc_t, uint32_t ld, const float* dirs, uint
 int xr_nerf_mlp_bwd_f16(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
                         const uint32_t* n_dev, const float* w_density, const float* w_color, int n_hidden_density,
                         int n_hidden_color, float pad_value, const float* draw, float* denc_t, float* grad_w_density,
-                        float* grad_w_color, void* workspace, size_t workspace_bytes, void* stream);
+                        float* grad_w_color, void* workspace, size_t workspace_bytes, const uint32_t* live_rows,
+                        const uint32_t* n_live, void* stream);
 
 /* One training step's device work of HashNerfNetwork.train_step (networks/hashnerf.py:32-52, optimiser excluded) as ONE call:
  * xr_hashgrid_fwd -> xr_nerf_mlp_fwd[_f16] -> zero-fill of `zero_block` (which must contain grad_w_density, grad_w_color and

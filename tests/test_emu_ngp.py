@@ -73,6 +73,8 @@ def test_mlp_backward_on_live_rows_on_the_host(O, edev):
     for n, nv in ((31, None), (100, None), (1500, 1200), (1100, 0)):
         for precision in ('f32', 'f16'):
             T.test_nerf_mlp_bwd_live_rows(O, edev, n, nv, precision)
+    for n, nv in ((100, None), (17000, 16500), (900, 0)):
+        T.test_shared_live_row_list_through_backward_and_scatter(O, edev, n, nv)
 
 
 def test_reference_precision_mlp_on_the_host(edev):

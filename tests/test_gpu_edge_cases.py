@@ -71,7 +71,7 @@ def test_zero_sized_and_invalid_calls(dev):
                              t.data_ptr(), t.data_ptr(), t.data_ptr(), None, 0, None) == -22
     assert b'workspace' in L.xr_last_error()
     assert L.xr_nerf_mlp_bwd(t.data_ptr(), 64, t.data_ptr(), 3, 8, None, t.data_ptr(), t.data_ptr(), 5, 5, 1.0,
-                             t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), 1 << 30, None) == -22
+                             t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), 1 << 30, None, None, None) == -22
     assert b'topology' in L.xr_last_error()
     with pytest.raises(_lib.XrError):
         ops.ema_grid_samples(torch.zeros(6, device=dev), 6, 0.95, torch.zeros(6, device=dev))   # not a multiple of 4

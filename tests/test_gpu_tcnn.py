@@ -205,6 +205,44 @@ def test_nerf_mlp_bwd_live_rows(O, dev, n, n_valid, precision):
         assert err <= tol * max(1.0, np.abs(ref).max()), (name, err, np.abs(ref).max())
 
 
+@pytest.mark.parametrize('n,n_valid', [(100, None), (20000, 17000), (40001, None), (3000, 0)])
+def test_shared_live_row_list_through_backward_and_scatter(O, dev, n, n_valid):
+    """the training step's arrangement: ONE list (ops.live_rows) drives the MLP backward and the table scatter, rows outside
+    it are never read or written (denc_t is poisoned with NaN to prove it); n >= 16384 takes the binned scatter"""
+    from xrnerf_amd import ops, synthetic as S
+    meta = ops.GridMeta(); om = O.GridMeta()
+    rng = np.random.default_rng(11 * n + 3)
+    table = S.hash_table(meta.n_params, scale=0.5)
+    wd, wc = nets(S)
+    # ray-like positions: runs of consecutive rows walk through the volume (the dense levels' run-length merging sees runs)
+    pts = np.clip(np.cumsum(rng.normal(0, 0.004, (n, 3)), 0) % 1.0, 0, 1).astype(np.float32)
+    dirs = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    draw = sparse_draw(rng, n)
+    nv = n if n_valid is None else n_valid
+    dref = draw.copy(); dref[nv:] = 0.0
+    gt, gd, gc = O.nerf_mlp_bwd(table, wd, wc, pts, dirs, dref, om)
+    tt, tp, tdraw = T(table, dev), T(pts, dev), T(draw, dev)
+    enc_t = ops.hashgrid_fwd(tt, tp, meta)
+    g_wd = torch.zeros(wd.size, dtype=torch.float32, device=dev)
+    g_wc = torch.zeros(wc.size, dtype=torch.float32, device=dev)
+    n_dev = None if n_valid is None else torch.tensor([nv], dtype=torch.int32, device=dev)
+    live = ops.live_rows(tdraw, n, n_dev=n_dev)
+    rows, n_live = live[0].cpu().numpy(), int(live[1].cpu().numpy()[0])
+    want = np.nonzero((dref != 0).any(1))[0]
+    assert n_live == want.size and np.array_equal(rows[:n_live], want)          # stable compaction
+    denc_t = torch.full_like(enc_t, float('nan'))
+    ops.nerf_mlp_bwd(enc_t, T(dirs, dev), n, T(wd, dev), T(wc, dev), 1, 2, tdraw, g_wd, g_wc, denc_t=denc_t, n_dev=n_dev, live=live)
+    d = denc_t.cpu().numpy()
+    assert np.isfinite(d[:, want]).all() and np.isnan(np.delete(d[:, :n], want, axis=1)).all()
+    g_t = torch.zeros(meta.n_params, dtype=torch.float32, device=dev)
+    ops.hashgrid_bwd(tp, denc_t, meta, g_t, live=live)
+    for name, got, ref in (('wd', g_wd, gd), ('wc', g_wc, gc), ('table', g_t, gt)):
+        g = got.cpu().numpy()
+        assert np.isfinite(g).all(), name
+        err = np.abs(g - ref).max()
+        assert err <= 1e-3 * max(1.0, np.abs(ref).max()), (name, err, np.abs(ref).max())
+
+
 def test_tcnn_module_surface_runs_the_reference_mlp_recipe(O, dev):
     """xrnerf_amd.tcnn.{Encoding,Network} used exactly as xrnerf/models/mlps/hashnerf_mlp.py:34-45,55-79 uses
     tinycudann: separate modules, row-major tensors, torch.cat in between, autograd end to end -- and the result

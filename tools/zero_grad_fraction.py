@@ -22,4 +22,12 @@ def spy(enc_t, dirs, n, wd, wc, nhd, nhc, draw, *a, **k):
     return orig(enc_t, dirs, n, wd, wc, nhd, nhc, draw, *a, **k)
 ops.nerf_mlp_bwd = spy
 for _ in range(8): tr.step()
+try:
+    smp = tr.sampler if hasattr(tr, 'sampler') else tr.net.sampler
+    c = smp.rays_numsteps_compacted[:, 0].float()
+    qs = torch.tensor([0.5, 0.9, 0.99, 1.0], device=c.device)
+    print('samples per ray: mean %.1f  rays with 0: %.2f  > 64: %.3f  quantiles 0.5/0.9/0.99/max %s' % (
+        float(c.mean()), float((c == 0).float().mean()), float((c > 64).float().mean()), [int(v) for v in torch.quantile(c, qs)]))
+except Exception as e:
+    print('ray-length statistics unavailable:', e)
 for s in seen: print('valid rows %d  zero-gradient rows %.3f  all-zero 32-row tiles %.3f  rows with |g| < 1e-25 %.3f' % s)

@@ -37,7 +37,7 @@ SIGNATURES = {
     'xr_hashgrid_meta': (None, [_i32, _i32, _i32, _d, _vp, _vp, _vp]),
     'xr_hashgrid_fwd': (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _u32, _vp]),
     'xr_hashgrid_bwd_workspace_bytes': (_sz, [_u32, _i32, _vp, _vp]),
-    'xr_hashgrid_bwd': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'xr_hashgrid_bwd': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'xr_sh4': (_i32, [_vp, _u32, _u32, _vp, _vp]),
     'xr_nerf_mlp_fwd': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp]),
     'xr_nerf_mlp_bwd_workspace_bytes': (_sz, [_u32]),
@@ -47,8 +47,11 @@ SIGNATURES = {
                                  _vp, _i32, _i32, _f, _f, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _sz, _i32, _vp, _sz,
                                  _vp, _sz, _vp]),
     'xr_nerf_mlp_fwd_f16': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp]),
-    'xr_nerf_mlp_bwd_f16': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    'xr_nerf_mlp_bwd': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'xr_nerf_mlp_bwd_f16': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
+    'xr_nerf_mlp_bwd': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
+    'xr_live_rows_segments': (_sz, [_u32]),
+    'xr_live_rows': (_i32, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _u32, _vp]),
+    'xr_nerf_mlp_bwd_list_slots': (_i32, [_vp, _sz, _u32, _vp, _vp, _vp]),
     'xr_mlp_fwd': (_i32, [_vp, C.c_long, C.c_long, _i32, _f, _u32, _vp, _i32, _vp, _vp]),
     'xr_mlp_bwd_workspace_bytes': (_sz, [_i32]),
     'xr_mlp_bwd': (_i32, [_vp, C.c_long, C.c_long, _i32, _f, _u32, _vp, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),

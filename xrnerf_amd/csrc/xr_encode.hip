@@ -303,8 +303,8 @@ __global__ __launch_bounds__(EN_LDS_THREADS) void k_hashgrid_fwd_lds(GridMeta gm
 #define BW_SAMPLES_PER_BLOCK (BW_CH * (EN_BLOCK / 16))
 __global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_bwd(GridMeta gm, uint32_t hashed_mask, const float* __restrict__ x,
                                                             uint32_t x_stride, const float* __restrict__ denc_t, uint32_t ld,
-                                                            uint32_t n, const uint32_t* __restrict__ n_dev, float* __restrict__ grad_table,
-                                                            float* __restrict__ rep, uint32_t n_rep, uint32_t rep_stride) {
+                                                            uint32_t n, const uint32_t* __restrict__ n_dev, const uint32_t* __restrict__ rows,
+                                                            float* __restrict__ grad_table, float* __restrict__ rep, uint32_t n_rep, uint32_t rep_stride) {
     constexpr uint32_t bw_ch = BW_CH;   // compile-time: a runtime chunk length costs 8 % (loop not unrolled)
     uint32_t l, sb;
     level_of_block(gm, &l, &sb);
@@ -323,11 +323,12 @@ __global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_bwd(GridMeta gm, uint32_t
     __shared__ float s_d[2][BW_SAMPLES_PER_BLOCK];
     for (uint32_t e = threadIdx.x; e < bn * 3; e += EN_BLOCK) {
         const uint32_t i = e / 3, k = e - 3 * i;
-        s_x[e] = x[(size_t)(b0 + i) * x_stride + k];
+        s_x[e] = x[(size_t)(rows ? rows[b0 + i] : b0 + i) * x_stride + k];
     }
     for (uint32_t e = threadIdx.x; e < bn; e += EN_BLOCK) {
-        s_d[0][e] = denc_t[(size_t)(2 * l) * ld + b0 + e];
-        s_d[1][e] = denc_t[(size_t)(2 * l + 1) * ld + b0 + e];
+        const uint32_t r = rows ? rows[b0 + e] : b0 + e;
+        s_d[0][e] = denc_t[(size_t)(2 * l) * ld + r];
+        s_d[1][e] = denc_t[(size_t)(2 * l + 1) * ld + r];
     }
     __syncthreads();
     const uint32_t i0 = group * bw_ch;
@@ -406,7 +407,8 @@ __global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_bwd(GridMeta gm, uint32_t
 __global__ __launch_bounds__(SC_THREADS) void k_scatter_bin(GridMeta gm, uint32_t l_lo, uint32_t l_hi, uint32_t parts, uint32_t nsb,
                                                             const float* __restrict__ x, uint32_t x_stride,
                                                             const float* __restrict__ denc_t, uint32_t ld, uint32_t n,
-                                                            const uint32_t* __restrict__ n_dev, uint32_t* __restrict__ counts,
+                                                            const uint32_t* __restrict__ n_dev, const uint32_t* __restrict__ rows,
+                                                            uint32_t* __restrict__ counts,
                                                             float4* __restrict__ bins, float* __restrict__ grad_table) {
     __shared__ uint32_t s_cnt[SC_MAX_PARTS];
     const uint32_t nl = l_hi - l_lo;
@@ -434,7 +436,8 @@ __global__ __launch_bounds__(SC_THREADS) void k_scatter_bin(GridMeta gm, uint32_
     float ld0[SC_SPT], ld1[SC_SPT], lx0[SC_SPT], lx1[SC_SPT], lx2[SC_SPT];
 #pragma unroll
     for (uint32_t s = 0; s < SC_SPT; ++s) {
-        const uint32_t i = min(b0 + s * SC_THREADS + threadIdx.x, n - 1);
+        uint32_t i = min(b0 + s * SC_THREADS + threadIdx.x, n - 1);
+        if (rows) i = rows[i];
         const float* xp = x + (size_t)i * x_stride;
         ld0[s] = d0p[i]; ld1[s] = d1p[i]; lx0[s] = xp[0]; lx1[s] = xp[1]; lx2[s] = xp[2];
     }
@@ -578,7 +581,8 @@ __global__ __launch_bounds__(SC_ACC_THREADS) void k_scatter_accum(GridMeta gm, u
 __global__ __launch_bounds__(SB_THREADS) void k_scatter_bin2(GridMeta gm, uint32_t l_lo, uint32_t l_hi, uint32_t parts, uint32_t nsb,
                                                              const float* __restrict__ x, uint32_t x_stride,
                                                              const float* __restrict__ denc_t, uint32_t ld, uint32_t n,
-                                                             const uint32_t* __restrict__ n_dev, uint32_t* __restrict__ counts,
+                                                             const uint32_t* __restrict__ n_dev, const uint32_t* __restrict__ rows,
+                                                             uint32_t* __restrict__ counts,
                                                              float4* __restrict__ bins, float* __restrict__ grad_table) {
     __shared__ float4 s_items[SB_ROUND_ITEMS];
     __shared__ uint8_t s_ipart[SB_ROUND_ITEMS];
@@ -610,7 +614,8 @@ __global__ __launch_bounds__(SB_THREADS) void k_scatter_bin2(GridMeta gm, uint32
         float ld0[SB_SPT], ld1[SB_SPT], lx0[SB_SPT], lx1[SB_SPT], lx2[SB_SPT];
 #pragma unroll
         for (uint32_t s = 0; s < SB_SPT; ++s) {
-            const uint32_t i = min(rb0 + s * SB_THREADS + threadIdx.x, n - 1);
+            uint32_t i = min(rb0 + s * SB_THREADS + threadIdx.x, n - 1);
+            if (rows) i = rows[i];
             const float* xp = x + (size_t)i * x_stride;
             ld0[s] = d0p[i]; ld1[s] = d1p[i]; lx0[s] = xp[0]; lx1[s] = xp[1]; lx2[s] = xp[2];
         }
@@ -951,12 +956,14 @@ extern "C" size_t xr_hashgrid_bwd_workspace_bytes(uint32_t n, int n_levels, cons
     return p.counts_bytes + p.bins_bytes + p.rep_bytes;
 }
 
-extern "C" int xr_hashgrid_bwd(const float* x, uint32_t x_stride, const float* denc_t, uint32_t ld, uint32_t n, const uint32_t* n_dev, int n_levels,
+extern "C" int xr_hashgrid_bwd(const float* x, uint32_t x_stride, const float* denc_t, uint32_t ld, uint32_t n, const uint32_t* n_dev,
+                               const uint32_t* rows, int n_levels,
                                const float* scale_host, const uint32_t* resolution_host, const uint32_t* offset_host,
                                float* grad_table, void* workspace, size_t workspace_bytes, void* stream_) {
     if (n == 0) return XR_OK;
     XR_REQUIRE(x && denc_t && grad_table, "null pointer");
     XR_REQUIRE(x_stride >= 3 && ld >= n, "bad stride");
+    XR_REQUIRE(!rows || n_dev, "a row list comes with its device-side length (n_dev)");
     GridMeta gm; uint32_t hm;
     XR_REQUIRE(fill_meta(&gm, &hm, n_levels, scale_host, resolution_host, offset_host) == 0, "bad level metadata");
     hipStream_t stream = (hipStream_t)stream_;
@@ -1001,7 +1008,7 @@ extern "C" int xr_hashgrid_bwd(const float* x, uint32_t x_stride, const float* d
         float* rep = p.rep_stride ? (float*)((char*)workspace + p.counts_bytes + p.bins_bytes) : nullptr;
         if (rep) XR_HIP(hipMemsetAsync(rep, 0, p.rep_bytes, ds));
         hipLaunchKernelGGL(k_hashgrid_bwd, dim3(blocks), dim3(EN_BLOCK), 0, ds, gd, hm, x, x_stride, denc_t, ld,
-                           n, n_dev, grad_table, rep, (uint32_t)SC_REPLICAS, p.rep_stride);
+                           n, n_dev, rows, grad_table, rep, (uint32_t)SC_REPLICAS, p.rep_stride);
         XR_LAUNCH_CHECK();
         if (rep) {
             const uint32_t count4 = p.rep_stride / 4;
@@ -1023,14 +1030,14 @@ extern "C" int xr_hashgrid_bwd(const float* x, uint32_t x_stride, const float* d
         float4* bins = (float4*)((char*)workspace + p.counts_bytes);
         if (sc_mode()) {
             hipLaunchKernelGGL(k_scatter_bin2, dim3(nl * p.nsb), dim3(SB_THREADS), 0, stream, gm, (uint32_t)p.l_bin, (uint32_t)n_levels,
-                               p.parts, p.nsb, x, x_stride, denc_t, ld, n, n_dev, counts, bins, grad_table);
+                               p.parts, p.nsb, x, x_stride, denc_t, ld, n, n_dev, rows, counts, bins, grad_table);
             XR_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_scatter_accum2, dim3(nl * p.parts), dim3(SC_ACC_THREADS), SC_LDS_BYTES, stream, gm, (uint32_t)p.l_bin,
                                (uint32_t)n_levels, p.parts, p.nsb, counts, bins, grad_table);
             XR_LAUNCH_CHECK();
         } else {
             hipLaunchKernelGGL(k_scatter_bin, dim3(nl * p.nsb), dim3(SC_THREADS), 0, stream, gm, (uint32_t)p.l_bin, (uint32_t)n_levels,
-                               p.parts, p.nsb, x, x_stride, denc_t, ld, n, n_dev, counts, bins, grad_table);
+                               p.parts, p.nsb, x, x_stride, denc_t, ld, n, n_dev, rows, counts, bins, grad_table);
             XR_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_scatter_accum, dim3(nl * p.parts), dim3(SC_ACC_THREADS), SC_LDS_BYTES, stream, gm, (uint32_t)p.l_bin,
                                (uint32_t)n_levels, p.parts, p.nsb, counts, bins, grad_table);

@@ -417,6 +417,7 @@ __global__ __launch_bounds__(LIVE_THREADS) void k_live_fill(const float4* __rest
     for (uint32_t u = 0; u < 4; ++u) if (lv[u]) live_rows[pos++] = r0 + u;
     if (blockIdx.x == n_seg - 1 && threadIdx.x == 0) *n_live = before + wbase[LIVE_THREADS / 64];
     // dead rows inside [0, n): their dL/d(encoding) is exactly zero (what the full backward would have written)
+    if (!denc_t) return;
     if (c == 0 && r0 + 3 < n && (ld & 3) == 0 && (((uintptr_t)denc_t) & 15) == 0) {
 #pragma unroll
         for (int f = 0; f < ENC_DIM; ++f) *reinterpret_cast<float4*>(denc_t + (size_t)f * ld + r0) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1149,24 +1150,47 @@ static bool live_rows_enabled() {          // XR_MLP_LIVE=0: run the backward ov
     if (on < 0) { const char* e = getenv("XR_MLP_LIVE"); on = (e && e[0] == '0') ? 0 : 1; }
     return on == 1;
 }
-// builds the live-row list of `draw` in the workspace (and zeroes the dead rows of denc_t); -> list / count pointers
+extern "C" size_t xr_live_rows_segments(uint32_t n) { return xr_div_up(n, LIVE_SEG); }
+extern "C" int xr_live_rows(const float* dloss_doutput, uint32_t n, const uint32_t* n_dev, uint32_t* seg_count, uint32_t* live_rows,
+                            uint32_t* n_live, float* zero_denc_t, uint32_t ld, void* stream_) {
+    XR_REQUIRE(dloss_doutput && seg_count && live_rows && n_live, "null pointer");
+    XR_REQUIRE(((uintptr_t)dloss_doutput & 15) == 0, "dloss_doutput must be 16-byte aligned");
+    XR_REQUIRE(!zero_denc_t || ld >= n, "bad ld");
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n == 0) { XR_HIP(hipMemsetAsync(n_live, 0, sizeof(uint32_t), stream)); return XR_OK; }
+    const uint32_t n_seg = xr_div_up(n, LIVE_SEG);
+    hipLaunchKernelGGL(k_live_count, dim3(n_seg), dim3(LIVE_THREADS), 0, stream, (const float4*)dloss_doutput, n, n_dev, seg_count);
+    hipLaunchKernelGGL(k_live_fill, dim3(n_seg), dim3(LIVE_THREADS), 0, stream, (const float4*)dloss_doutput, n, n_dev,
+                       (const uint32_t*)seg_count, n_seg, live_rows, n_live, zero_denc_t, ld);
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}
+// where a list of n rows sits in an xr_nerf_mlp_bwd workspace (behind the dW partials): callers that build the list
+// themselves to share it with xr_hashgrid_bwd use these slots instead of allocating
+extern "C" int xr_nerf_mlp_bwd_list_slots(void* workspace, size_t workspace_bytes, uint32_t n, uint32_t** live_rows,
+                                          uint32_t** seg_count, uint32_t** n_live) {
+    XR_REQUIRE(workspace && live_rows && seg_count && n_live, "null pointer");
+    XR_REQUIRE(workspace_bytes >= xr_nerf_mlp_bwd_workspace_bytes(n), "workspace too small");
+    *live_rows = reinterpret_cast<uint32_t*>((char*)workspace + bwd_partial_bytes());
+    *seg_count = *live_rows + n;
+    *n_live = *seg_count + xr_div_up(n, LIVE_SEG);
+    return XR_OK;
+}
+// the backward's own list, in its workspace (callers that did not bring one): dead rows of denc_t are zeroed
 static int build_live_rows(const float* draw, uint32_t n, const uint32_t* n_dev, float* denc_t, uint32_t ld, void* workspace,
                            hipStream_t stream, const uint32_t** rows, const uint32_t** n_live) {
     uint32_t* list = reinterpret_cast<uint32_t*>((char*)workspace + bwd_partial_bytes());
-    const uint32_t n_seg = xr_div_up(n, LIVE_SEG);
     uint32_t* seg = list + n;
-    uint32_t* cnt = seg + n_seg;
-    hipLaunchKernelGGL(k_live_count, dim3(n_seg), dim3(LIVE_THREADS), 0, stream, (const float4*)draw, n, n_dev, seg);
-    hipLaunchKernelGGL(k_live_fill, dim3(n_seg), dim3(LIVE_THREADS), 0, stream, (const float4*)draw, n, n_dev, (const uint32_t*)seg, n_seg,
-                       list, cnt, denc_t, ld);
+    uint32_t* cnt = seg + xr_div_up(n, LIVE_SEG);
     *rows = list; *n_live = cnt;
-    return XR_OK;
+    return xr_live_rows(draw, n, n_dev, seg, list, cnt, denc_t, ld, stream);
 }
 
 extern "C" int xr_nerf_mlp_bwd(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
                                const uint32_t* n_dev, const float* w_density, const float* w_color, int n_hidden_density, int n_hidden_color,
                                float pad_value, const float* draw, float* denc_t, float* grad_w_density,
-                               float* grad_w_color, void* workspace, size_t workspace_bytes, void* stream_) {
+                               float* grad_w_color, void* workspace, size_t workspace_bytes, const uint32_t* live_rows,
+        const uint32_t* n_live, void* stream_) {
     if (n == 0) return XR_OK;
     hipStream_t stream = (hipStream_t)stream_;
     XR_REQUIRE(enc_t && dirs && w_density && w_color && draw && denc_t && grad_w_density && grad_w_color, "null pointer");
@@ -1181,8 +1205,9 @@ extern "C" int xr_nerf_mlp_bwd(const float* enc_t, uint32_t ld, const float* dir
     const size_t lds = (NetShape<1>::lds_floats + NetShape<2>::lds_floats + MLP_WAVES * 4 * 32 * ST33) * sizeof(float);
     static_assert(MLP_WAVES * 4 * 32 * ST33 >= GW, "stage area doubles as the dW reduction buffer");
     const uint32_t grid = bwd_grid(n);
-    const uint32_t *rows = nullptr, *n_live = nullptr;
-    if (live_rows_enabled()) build_live_rows(draw, n, n_dev, denc_t, ld, workspace, stream, &rows, &n_live);
+    XR_REQUIRE(!live_rows == !n_live, "live_rows and n_live come together");
+    const uint32_t* rows = live_rows;                    // the caller's list (xr_live_rows), else the backward's own
+    if (!rows && live_rows_enabled()) { const int rc = build_live_rows(draw, n, n_dev, denc_t, ld, workspace, stream, &rows, &n_live); if (rc != XR_OK) return rc; }
     auto kern = rows ? k_nerf_mlp_bwd_1_2<true> : k_nerf_mlp_bwd_1_2<false>;
     XR_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n,
@@ -1275,7 +1300,8 @@ extern "C" int xr_nerf_mlp_fwd_f16(const float* enc_t, uint32_t ld, const float*
 extern "C" int xr_nerf_mlp_bwd_f16(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
                                    const uint32_t* n_dev, const float* w_density, const float* w_color, int n_hidden_density,
                                    int n_hidden_color, float pad_value, const float* draw, float* denc_t, float* grad_w_density,
-                                   float* grad_w_color, void* workspace, size_t workspace_bytes, void* stream_) {
+                                   float* grad_w_color, void* workspace, size_t workspace_bytes, const uint32_t* live_rows,
+        const uint32_t* n_live, void* stream_) {
     if (n == 0) return XR_OK;
     hipStream_t stream = (hipStream_t)stream_;
     XR_REQUIRE(enc_t && dirs && w_density && w_color && draw && denc_t && grad_w_density && grad_w_color, "null pointer");
@@ -1287,8 +1313,9 @@ extern "C" int xr_nerf_mlp_bwd_f16(const float* enc_t, uint32_t ld, const float*
     static_assert(stage_bytes >= GW * sizeof(float), "stage area doubles as the dW reduction buffer");
     const size_t lds = (size_t)(HShape<1>::f_halves + HShape<2>::f_halves + HShape<1>::b_halves + HShape<2>::b_halves) * 2 + stage_bytes;
     const uint32_t grid = bwd_grid(n);
-    const uint32_t *rows = nullptr, *n_live = nullptr;
-    if (live_rows_enabled()) build_live_rows(draw, n, n_dev, denc_t, ld, workspace, stream, &rows, &n_live);
+    XR_REQUIRE(!live_rows == !n_live, "live_rows and n_live come together");
+    const uint32_t* rows = live_rows;                    // the caller's list (xr_live_rows), else the backward's own
+    if (!rows && live_rows_enabled()) { const int rc = build_live_rows(draw, n, n_dev, denc_t, ld, workspace, stream, &rows, &n_live); if (rc != XR_OK) return rc; }
     auto kern = rows ? k_nerf_mlp_bwd_h<true> : k_nerf_mlp_bwd_h<false>;
     XR_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev, w_density,

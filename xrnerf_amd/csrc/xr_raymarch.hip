@@ -663,13 +663,17 @@ extern "C" int xr_calc_rgb_backward(const float* network_output, const int32_t* 
 // three: pass 1 + stitch -> final colour (+ background rule of K3) -> Huber gradient per ray in registers (lane 0 of the ray
 // adds the ray's loss terms to a block sum) -> pass 2.  rgb_out, the loss accumulators and dout are what the three kernels
 // produce (rgb and dout bit for bit; the two scalars up to the order of the block sums).
-__global__ __launch_bounds__(RM_BLOCK) void k_composite_train(
+// CT_BLOCK = 1024: every workgroup ends with two fp32 atomics on the SAME cache line (loss, mse), and same-address L2 atomics
+// retire one per ~13.5 ns -- measured: a launch with every ray EMPTY took 23.7 us at 786 workgroups of 256 threads, 42.6 us at
+// 1572 and 13-15 us at 196 workgroups of 1024 (tools/microbench_composite.py).
+#define CT_BLOCK 1024
+__global__ __launch_bounds__(CT_BLOCK) void k_composite_train(
     uint32_t n_rays, const float4* __restrict__ raw, const float* __restrict__ coords, const int32_t* __restrict__ numsteps,
     const int32_t* __restrict__ numsteps_c, const float* __restrict__ bg, const float* __restrict__ target,
     const float* __restrict__ alpha_mask, const float* __restrict__ density_grid_mean, int rgb_act, int density_act, float delta,
     float scale, float* __restrict__ rgb_out, float* __restrict__ loss_mse, float4* __restrict__ dout) {
-    __shared__ float ws[RM_BLOCK / 64], ws2[RM_BLOCK / 64];
-    const uint32_t t = blockIdx.x * RM_BLOCK + threadIdx.x;
+    __shared__ float ws[CT_BLOCK / 64], ws2[CT_BLOCK / 64];
+    const uint32_t t = blockIdx.x * CT_BLOCK + threadIdx.x;
     const uint32_t i = t / CG, sub = t % CG;
     const bool in = i < n_rays;
     float loss_scale = 128.f; loss_scale /= (float)n_rays;                        // calc_rgb.cu:92-93
@@ -735,7 +739,7 @@ __global__ __launch_bounds__(RM_BLOCK) void k_composite_train(
     if (threadIdx.x == 0) {
         float a = 0.f, b = 0.f;
 #pragma unroll
-        for (int w = 0; w < RM_BLOCK / 64; ++w) { a += ws[w]; b += ws2[w]; }
+        for (int w = 0; w < CT_BLOCK / 64; ++w) { a += ws[w]; b += ws2[w]; }
         if (a != 0.f) atomicAdd(loss_mse, scale * a);
         if (b != 0.f) atomicAdd(loss_mse + 1, b);
     }
@@ -775,7 +779,7 @@ extern "C" int xr_composite_train(const float* network_output, const float* coor
                density_grid_mean && rgb_output && loss_mse_out && dloss_doutput, "null pointer");
     XR_REQUIRE((((uintptr_t)network_output | (uintptr_t)dloss_doutput) & 15) == 0, "raw/grad buffers must be 16-byte aligned");
     XR_REQUIRE(n_rays > 0, "n_rays == 0");
-    hipLaunchKernelGGL(k_composite_train, dim3(xr_div_up((uint64_t)n_rays * CG, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream_,
+    hipLaunchKernelGGL(k_composite_train, dim3(xr_div_up((uint64_t)n_rays * CG, CT_BLOCK)), dim3(CT_BLOCK), 0, (hipStream_t)stream_,
                        n_rays, (const float4*)network_output, coords, rays_numsteps, rays_numsteps_compacted, bg_color, target,
                        alpha_mask, density_grid_mean, rgb_activation, density_activation, delta, scale, rgb_output, loss_mse_out,
                        (float4*)dloss_doutput);

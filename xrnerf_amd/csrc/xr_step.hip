@@ -37,12 +37,18 @@ extern "C" int xr_ngp_train_step(
                             n_rays, rgb_activation, density_activation, huber_delta, loss_scale, rgb_out, loss_mse, draw, stream_);
     if (rc != XR_OK) return rc;
     XR_HIP(hipMemsetAsync(grad_table, 0, table_floats * sizeof(float), stream));
-    rc = f16_mlp ? xr_nerf_mlp_bwd_f16(enc_t, ld, coords + 4, 7, n_rows, n_dev, w_density, w_color, n_hidden_density, n_hidden_color,
-                                       pad_value, draw, denc_t, grad_w_density, grad_w_color, ws_mlp_bwd, ws_mlp_bwd_bytes, stream_)
-                 : xr_nerf_mlp_bwd(enc_t, ld, coords + 4, 7, n_rows, n_dev, w_density, w_color, n_hidden_density, n_hidden_color,
-                                   pad_value, draw, denc_t, grad_w_density, grad_w_color, ws_mlp_bwd, ws_mlp_bwd_bytes, stream_);
+    // rows with an exactly-zero dL/d(raw) (T == 0 behind a surface) are skipped by the MLP backward AND the scatter: one list
+    uint32_t *rows, *seg, *n_live;
+    rc = xr_nerf_mlp_bwd_list_slots(ws_mlp_bwd, ws_mlp_bwd_bytes, n_rows, &rows, &seg, &n_live);
     if (rc != XR_OK) return rc;
-    return xr_hashgrid_bwd(coords, 7, denc_t, ld, n_rows, n_dev, n_levels, scale_host, resolution_host, offset_host, grad_table,
+    rc = xr_live_rows(draw, n_rows, n_dev, seg, rows, n_live, nullptr, ld, stream_);
+    if (rc != XR_OK) return rc;
+    rc = f16_mlp ? xr_nerf_mlp_bwd_f16(enc_t, ld, coords + 4, 7, n_rows, n_dev, w_density, w_color, n_hidden_density, n_hidden_color,
+                                       pad_value, draw, denc_t, grad_w_density, grad_w_color, ws_mlp_bwd, ws_mlp_bwd_bytes, rows, n_live, stream_)
+                 : xr_nerf_mlp_bwd(enc_t, ld, coords + 4, 7, n_rows, n_dev, w_density, w_color, n_hidden_density, n_hidden_color,
+                                   pad_value, draw, denc_t, grad_w_density, grad_w_color, ws_mlp_bwd, ws_mlp_bwd_bytes, rows, n_live, stream_);
+    if (rc != XR_OK) return rc;
+    return xr_hashgrid_bwd(coords, 7, denc_t, ld, n_rows, n_live, rows, n_levels, scale_host, resolution_host, offset_host, grad_table,
                            ws_scatter, ws_scatter_bytes, stream_);
 }
 

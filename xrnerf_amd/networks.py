@@ -160,21 +160,24 @@ class _FusedTrainStepFn(torch.autograd.Function):
                                       sampler.density_grid_mean, ra, da, loss_mse, draw, delta=0.1, scale=5.0)
             g_table = torch.zeros_like(table)
             denc_t = torch.empty_like(enc_t)
-            ops.nerf_mlp_bwd(enc_t, dirs, n, wd, wc, nhd, nhc, draw, g_wd, g_wc, mlp.pad_value, denc_t=denc_t, n_dev=n_dev)
+            # samples behind an opaque surface have an exactly-zero dL/d(raw) row (T == 0): the MLP backward and the scatter
+            # run on the list of the others (more than half of the rows are dead in steady state)
+            live = ops.live_rows(draw, n, n_dev=n_dev)
+            ops.nerf_mlp_bwd(enc_t, dirs, n, wd, wc, nhd, nhc, draw, g_wd, g_wc, mlp.pad_value, denc_t=denc_t, n_dev=n_dev, live=live)
             sync = getattr(net, 'grad_sync', None)
             if sync is None:
-                ops.hashgrid_bwd(pts, denc_t, meta, g_table, n_dev=n_dev)
+                ops.hashgrid_bwd(pts, denc_t, meta, g_table, live=live)
             elif meta.n_levels > 8:
                 # data parallel: reduce each gradient bucket across the ranks while the next one is produced
                 split = meta.n_levels - 8
                 cut = 2 * int(meta.offset[split])
                 sync.ready(g_mlp)
-                ops.hashgrid_bwd(pts, denc_t, meta, g_table, n_dev=n_dev, levels=(split, meta.n_levels))
+                ops.hashgrid_bwd(pts, denc_t, meta, g_table, live=live, levels=(split, meta.n_levels))
                 sync.ready(g_table[cut:])
-                ops.hashgrid_bwd(pts, denc_t, meta, g_table, n_dev=n_dev, levels=(0, split))
+                ops.hashgrid_bwd(pts, denc_t, meta, g_table, live=live, levels=(0, split))
                 sync.ready(g_table[:cut])
             else:
-                ops.hashgrid_bwd(pts, denc_t, meta, g_table, n_dev=n_dev)
+                ops.hashgrid_bwd(pts, denc_t, meta, g_table, live=live)
                 sync.ready(g_mlp)
                 sync.ready(g_table)
         ctx.grads = (g_table, g_wd, g_wc)

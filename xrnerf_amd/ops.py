@@ -412,10 +412,11 @@ def hashgrid_fwd(table, x, meta, enc_t=None, ld=None, n_dev=None, rows=None, row
     return enc_t
 
 
-def hashgrid_bwd(x, denc_t, meta, grad_table, n_dev=None, row0=0, count=None, levels=None, use_workspace=True):
+def hashgrid_bwd(x, denc_t, meta, grad_table, n_dev=None, row0=0, count=None, levels=None, use_workspace=True, live=None):
     """scatter dL/denc into dL/dtable.  `levels=(l0, l1)` restricts the launch to that level range (the level
     metadata arrays are passed from l0 on; table offsets are absolute, so `grad_table` stays the full table):
-    the data-parallel trainer scatters the fine half first and reduces it across ranks under the coarse half."""
+    the data-parallel trainer scatters the fine half first and reduces it across ranks under the coarse half.
+    `live=(rows, n_live)` (ops.live_rows): only the listed rows are scattered."""
     L = _lib.load()
     x, xs = _pos_view(x)
     n = x.shape[0] if count is None else count
@@ -426,9 +427,14 @@ def hashgrid_bwd(x, denc_t, meta, grad_table, n_dev=None, row0=0, count=None, le
     ld = denc_t.shape[1]
     _ptr(denc_t)
     ws = _ws(x.device, L.xr_hashgrid_bwd_workspace_bytes(n, l1 - l0, r + 4 * l0, o + 4 * l0), 'hgb') if use_workspace else None
+    rows = None
+    if live is not None:
+        if row0:
+            raise _lib.XrError('a live-row list addresses rows from 0')
+        rows, n_dev = live
     with _span('xr_hashgrid_bwd', 0 if n_dev is not None else n, train=n_dev is not None):
         _lib.check(L.xr_hashgrid_bwd(C.c_void_p(x.data_ptr() + 4 * xs * row0), xs,
-                                     C.c_void_p(denc_t.data_ptr() + 4 * (row0 + 2 * l0 * ld)), ld, n, _ptr(n_dev),
+                                     C.c_void_p(denc_t.data_ptr() + 4 * (row0 + 2 * l0 * ld)), ld, n, _ptr(n_dev), _ptr(rows),
                                      l1 - l0, s + 4 * l0, r + 4 * l0, o + 4 * l0, _ptr(grad_table),
                                      _ptr(ws), ws.numel() if ws is not None else 0, _stream()),
                    'xr_hashgrid_bwd')
@@ -465,8 +471,27 @@ def nerf_mlp_fwd(enc_t, dirs, n, w_density, w_color, nhd, nhc, pad_value=1.0, ra
     return raw
 
 
+def live_rows(draw, n, n_dev=None, zero_denc_t=None):
+    """-> (rows int32 [n], n_live int32 [1]) on the device: the rows of dL/d(raw) [n,4] that are not exactly zero, in
+    order (xr_live_rows).  Handed to nerf_mlp_bwd and hashgrid_bwd as `live=`; the buffers are reused by the next call."""
+    L = _lib.load()
+    dev = draw.device
+    segs = L.xr_live_rows_segments(n)
+    buf = _ws(dev, 4 * (n + segs + 1), 'liverows')
+    base = buf.data_ptr()
+    rows = buf[:4 * n].view(torch.int32)
+    n_live = buf[4 * (n + segs):4 * (n + segs + 1)].view(torch.int32)
+    with _span('xr_live_rows', 0 if n_dev is not None else n, train=n_dev is not None):
+        _lib.check(L.xr_live_rows(_ptr(draw), n, _ptr(n_dev), C.c_void_p(base + 4 * n), _ptr(rows), _ptr(n_live),
+                                  _ptr(zero_denc_t), zero_denc_t.shape[1] if zero_denc_t is not None else 0, _stream()), 'xr_live_rows')
+    return rows, n_live
+
+
 def nerf_mlp_bwd(enc_t, dirs, n, w_density, w_color, nhd, nhc, draw, grad_wd, grad_wc, pad_value=1.0, denc_t=None,
-                 n_dev=None, row0=0, count=None):
+                 n_dev=None, row0=0, count=None, live=None):
+    """`live=(rows, n_live)` (ops.live_rows(draw, ...)): the backward computes the listed rows only and leaves the other
+    rows of denc_t untouched -- pass the same list to hashgrid_bwd.  Without it the call builds its own list and writes
+    exact zeros to the dead rows (identical results to the backward over every row)."""
     L = _lib.load()
     dirs, ds = _pos_view(dirs)
     if denc_t is None:
@@ -479,7 +504,8 @@ def nerf_mlp_bwd(enc_t, dirs, n, w_density, w_color, nhd, nhc, draw, grad_wd, gr
     with _span('xr_nerf_mlp_bwd', 0 if n_dev is not None else n, train=n_dev is not None):
         _lib.check(fn(C.c_void_p(enc_t.data_ptr() + 4 * row0), enc_t.shape[1], C.c_void_p(dirs.data_ptr() + 4 * ds * row0), ds, n, _ptr(n_dev), _ptr(w_density),
                                      _ptr(w_color), nhd, nhc, pad_value, C.c_void_p(draw.data_ptr() + 16 * row0), C.c_void_p(denc_t.data_ptr() + 4 * row0), _ptr(grad_wd),
-                                     _ptr(grad_wc), _ptr(ws), ws.numel(), _stream()), 'xr_nerf_mlp_bwd')
+                                     _ptr(grad_wc), _ptr(ws), ws.numel(), _ptr(live[0]) if live is not None else None,
+                                     _ptr(live[1]) if live is not None else None, _stream()), 'xr_nerf_mlp_bwd')
     return denc_t
 
 
