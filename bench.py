@@ -55,6 +55,8 @@ ALGO = {
     'xr_rays_sampler': ('hbm', 36 + 28 * 14),
     # per PARAMETER: read p, g, m, v, ema (20 B) + write p, m, v, ema (16 B)
     'xr_adam_step': ('hbm', 36),
+    # live-row list of the backward: dL/d(raw) [16 B] read by the count and by the fill pass, 4 B of list per live row (~0.46)
+    'xr_live_rows': ('hbm', 16 + 16 + 2),
 }
 
 
@@ -545,6 +547,8 @@ def main():
     dom_pick = max(cand, key=cand.get) if cand else 'xr_hashgrid_bwd'
     torch.cuda.synchronize()
     ops.TIMER = ops.KernelTimer(only={dom_pick}, train_only=True)
+    if ops.LIVE_STATS is not None:
+        ops.LIVE_STATS[1:3].zero_()            # running (live rows, valid rows) totals of the backward's row list
     rays0, samples0, it0 = tr.rays_done, tr.samples_done, tr.iter
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # one event per iteration boundary
     barrier()
@@ -573,22 +577,39 @@ def main():
     else:
         elapsed_max, rays_all, samples_all = elapsed, float(rays), float(samples)
 
-    def roof_of(name, launches, total_ms, units):
+    # The two backward entry points run on the rows whose dL/d(raw) is not exactly zero (ops.live_rows): the units ONE LAUNCH
+    # PROCESSES are the live rows, and only those are priced -- the fraction is read from the device-side running totals.
+    def live_fraction():
+        if ops.LIVE_STATS is None:
+            return 1.0
+        live, valid = (int(v) & 0xffffffff for v in ops.LIVE_STATS[1:3].tolist())
+        return live / valid if valid else 1.0
+
+    LIVE_KERNELS = ('xr_nerf_mlp_bwd', 'xr_hashgrid_bwd')
+    live_frac_timed = live_fraction()
+
+    def roof_of(name, launches, total_ms, units, live_frac=1.0):
         bound, per_unit = ALGO[name]
+        if name in LIVE_KERNELS:
+            units = units * live_frac
         work = units * per_unit
         if bound == 'hbm':
             achieved, peak, unit = work / (total_ms * 1e-3) / 1e9, HBM_PEAK_GBS, 'GB/s'
         else:
             achieved, peak, unit = work / (total_ms * 1e-3) / 1e12, MFMA_PEAK[ops.precision()], 'TFLOP/s'
-        return {'kernel': name, 'bound': bound, 'achieved': achieved, 'peak': peak, 'unit': unit, 'frac': achieved / peak,
-                'avg_launch_us': total_ms * 1e3 / max(launches, 1), 'launches': launches,
-                'algorithmic_per_sample': per_unit, 'algorithmic_bytes_or_flops_per_launch': work / max(launches, 1)}
+        out = {'kernel': name, 'bound': bound, 'achieved': achieved, 'peak': peak, 'unit': unit, 'frac': achieved / peak,
+               'avg_launch_us': total_ms * 1e3 / max(launches, 1), 'launches': launches,
+               'algorithmic_per_sample': per_unit, 'algorithmic_bytes_or_flops_per_launch': work / max(launches, 1)}
+        if name in LIVE_KERNELS:
+            out['live_row_fraction'] = live_frac
+            out['units'] = 'samples with a non-zero output gradient (the rows the launch processes); the others are exact zeros'
+        return out
 
     # ---- roofline of the dominant kernel: HIP events on the launch stream around every TRAINING launch of that entry
     # point inside the timed region (the occupancy-grid density queries use other entry points / are not counted)
     summ = timer.summary()
     launches, total_ms, units = summ[dom_pick]
-    roof = roof_of(dom_pick, launches, total_ms, units if units > 0 else samples)
+    roof = roof_of(dom_pick, launches, total_ms, units if units > 0 else samples, live_frac_timed)
     roof['traffic'] = None
     try:   # HBM bytes per launch from separate rocprofv3 --pmc passes of THIS command (tools/pmc_traffic.py)
         pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')))
@@ -602,17 +623,20 @@ def main():
     # launches (kept out of the timed region: the events cost ~0.07 ms/step)
     s0 = tr.samples_done
     ops.TIMER = ops.KernelTimer(only=set(ALGO), train_only=True)
+    if ops.LIVE_STATS is not None:
+        ops.LIVE_STATS[1:3].zero_()
     for _ in range(32):
         tr.step()
     torch.cuda.synchronize()
     timer2, ops.TIMER = ops.TIMER, None
+    live_frac_win = live_fraction()
     s_win = tr.samples_done - s0
     r_win = None
     roofs = {}
     for k, (n_l, ms_l, u_l) in timer2.summary().items():
         if k == 'xr_rays_sampler':
             continue          # runs on the side stream beside other kernels: its span is not its duration
-        roofs[k] = roof_of(k, n_l, ms_l, u_l if u_l > 0 else s_win)      # Adam counts parameters, the rest samples
+        roofs[k] = roof_of(k, n_l, ms_l, u_l if u_l > 0 else s_win, live_frac_win)      # Adam counts parameters, the rest samples
 
     extra = {}
     if not args.no_render:
@@ -672,6 +696,10 @@ def main():
                        'parallelism': 'ray-sharded data parallel x%d, gradient all-reduce (RCCL)' % world if world > 1 else 'single GPU'},
             'roofline': roof,
             'roofline_kernels': roofs,
+            'backward_live_row_fraction': {'timed_window': live_frac_timed, 'kernel_window': live_frac_win,
+                                           'note': 'share of the marched samples whose dL/d(raw) is not exactly zero (T == 0 behind opaque '
+                                                   'surfaces makes the rest exact zeros); the MLP backward and the table scatter process '
+                                                   'these rows only, results are identical to the backward over every row'},
         }
         out.update(extra)
         # secondary measurements must never cost the headline line: a failure is reported in place of the numbers

@@ -220,7 +220,9 @@ int xr_nerf_mlp_bwd(const float* enc_t, uint32_t ld, const float* dirs, uint32_t
 /* Rows of dL/d(raw) [n,4] that are not exactly (0,0,0,0), in order: live_rows[0 .. *n_live).  A sample behind an opaque
  * surface has transmittance exactly 0 in fp32 (calc_rgb.cu:36-52 multiplies it into every term of the gradient), so its
  * row is exactly zero and contributes exactly nothing to dW or to the table gradient -- in steady-state training more
- * than half of the marched samples.  seg_count: scratch of xr_live_rows_segments(n) words.  zero_denc_t (nullable,
+ * than half of the marched samples.  n_live: FOUR words -- [0] the list's length, [1] / [2] running totals of live / valid rows
+ * over the calls since the caller last cleared them (statistics: bench.py reports the live fraction from them), [3] spare.
+ * seg_count: scratch of xr_live_rows_segments(n) words.  zero_denc_t (nullable,
  * [32][ld]): the dead rows of it are set to zero.  Stable order and a fixed partition: reproducible run to run. */
 size_t xr_live_rows_segments(uint32_t n);
 /* the list area inside an xr_nerf_mlp_bwd workspace of n rows (unused by a backward that is handed a list) */

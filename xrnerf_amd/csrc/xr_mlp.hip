@@ -415,7 +415,11 @@ __global__ __launch_bounds__(LIVE_THREADS) void k_live_fill(const float4* __rest
     uint32_t pos = before + wbase[threadIdx.x >> 6] + inc - c;
 #pragma unroll
     for (uint32_t u = 0; u < 4; ++u) if (lv[u]) live_rows[pos++] = r0 + u;
-    if (blockIdx.x == n_seg - 1 && threadIdx.x == 0) *n_live = before + wbase[LIVE_THREADS / 64];
+    if (blockIdx.x == n_seg - 1 && threadIdx.x == 0) {
+        const uint32_t total = before + wbase[LIVE_THREADS / 64];
+        n_live[0] = total;
+        n_live[1] += total; n_live[2] += n;        // running totals (live rows, valid rows) since the caller last cleared them
+    }
     // dead rows inside [0, n): their dL/d(encoding) is exactly zero (what the full backward would have written)
     if (!denc_t) return;
     if (c == 0 && r0 + 3 < n && (ld & 3) == 0 && (((uintptr_t)denc_t) & 15) == 0) {
@@ -1143,7 +1147,7 @@ static size_t bwd_partial_bytes() {
     return (size_t)cus * (NetShape<1>::glb_floats + NetShape<2>::glb_floats) * sizeof(float);
 }
 extern "C" size_t xr_nerf_mlp_bwd_workspace_bytes(uint32_t n) {
-    return bwd_partial_bytes() + ((size_t)n + xr_div_up(n, LIVE_SEG) + 4) * sizeof(uint32_t);
+    return bwd_partial_bytes() + ((size_t)n + xr_div_up(n, LIVE_SEG) + 4) * sizeof(uint32_t);   // n_live is 4 words
 }
 static bool live_rows_enabled() {          // XR_MLP_LIVE=0: run the backward over every row (measurement)
     static int on = -1;

@@ -471,16 +471,24 @@ def nerf_mlp_fwd(enc_t, dirs, n, w_density, w_color, nhd, nhc, pad_value=1.0, ra
     return raw
 
 
+LIVE_STATS = None      # the 4-word count block of the last ops.live_rows call (words 1, 2: running totals; clear to restart)
+
+
 def live_rows(draw, n, n_dev=None, zero_denc_t=None):
     """-> (rows int32 [n], n_live int32 [1]) on the device: the rows of dL/d(raw) [n,4] that are not exactly zero, in
     order (xr_live_rows).  Handed to nerf_mlp_bwd and hashgrid_bwd as `live=`; the buffers are reused by the next call."""
     L = _lib.load()
     dev = draw.device
     segs = L.xr_live_rows_segments(n)
-    buf = _ws(dev, 4 * (n + segs + 1), 'liverows')
+    fresh = (str(dev), 'liverows') not in _workspaces or _workspaces[(str(dev), 'liverows')].numel() < 4 * (n + segs + 4)
+    buf = _ws(dev, 4 * (n + segs + 4), 'liverows')
     base = buf.data_ptr()
     rows = buf[:4 * n].view(torch.int32)
-    n_live = buf[4 * (n + segs):4 * (n + segs + 1)].view(torch.int32)
+    n_live = buf[4 * (n + segs):4 * (n + segs + 4)].view(torch.int32)    # [count, running live total, running valid total, spare]
+    if fresh:
+        n_live.zero_()
+    global LIVE_STATS
+    LIVE_STATS = n_live
     with _span('xr_live_rows', 0 if n_dev is not None else n, train=n_dev is not None):
         _lib.check(L.xr_live_rows(_ptr(draw), n, _ptr(n_dev), C.c_void_p(base + 4 * n), _ptr(rows), _ptr(n_live),
                                   _ptr(zero_denc_t), zero_denc_t.shape[1] if zero_denc_t is not None else 0, _stream()), 'xr_live_rows')
