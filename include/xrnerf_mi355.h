@@ -218,7 +218,7 @@ int xr_nerf_mlp_bwd(const float* enc_t, uint32_t ld, const float* dirs, uint32_t
                     float* grad_w_color, void* workspace, size_t workspace_bytes, const uint32_t* live_rows,
                     const uint32_t* n_live, void* stream);
 /* Rows of dL/d(raw) [n,4] that are not exactly (0,0,0,0), in order: live_rows[0 .. *n_live).  A sample behind an opaque
- * surface has transmittance exactly 0 in fp32 (calc_rgb.cu:36-52 multiplies it into every term of the gradient), so its
+ * surface has transmittance exactly 0 in fp32 (calc_rgb.cu:108-135: every term of the row carries the weight alpha*T, or T times a suffix colour that is exactly 0 there), so its
  * row is exactly zero and contributes exactly nothing to dW or to the table gradient -- in steady-state training more
  * than half of the marched samples.  n_live: FOUR words -- [0] the list's length, [1] / [2] running totals of live / valid rows
  * over the calls since the caller last cleared them (statistics: bench.py reports the live fraction from them), [3] spare.
