@@ -525,21 +525,26 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void k_nerf_mlp_bwd_1_2(
         }
     }
     // ---- block reduction of dW through LDS (compact global layout), then one partial per block
+    // Every wave is past its last tile: weights and staging are dead, the whole dynamic LDS holds TWO copies of the gradient.
+    // Waves 0 / 1 store into copy A / B side by side, waves 2 / 3 add, the write-out sums the copies: two turns instead of
+    // four (fixed order (w0 + w2) + (w1 + w3)).
     __syncthreads();
-    float* red = stage_all;
-    float* redc = red + SD::glb_floats;
-    for (int w = 0; w < MLP_WAVES; ++w) {                              // fixed order: wave 0 stores, 1..3 add
-        if (wave == w) {
-            dw_flush<2, 1>(a_d0, red + SD::glb_off(0), 64, 32, false, col, hi, w == 0);
-            dw_flush<1, 2>(a_d1, red + SD::glb_off(1), 16, 64, false, col, hi, w == 0);
-            dw_flush<2, 1>(a_c0, redc + SC::glb_off(0), 64, 32, true, col, hi, w == 0);
-            dw_flush<2, 2>(a_c1, redc + SC::glb_off(1), 64, 64, false, col, hi, w == 0);
-            dw_flush<1, 2>(a_c2, redc + SC::glb_off(2), 16, 64, false, col, hi, w == 0);
+    static_assert(2 * GW <= SD::lds_floats + SC::lds_floats + MLP_WAVES * STAGE, "two reduction copies must fit the launch's LDS");
+    float* redA = lds;
+    for (int ph = 0; ph < 2; ++ph) {
+        if ((wave >> 1) == ph) {
+            float* red = redA + (wave & 1) * GW;
+            float* redc = red + SD::glb_floats;
+            dw_flush<2, 1>(a_d0, red + SD::glb_off(0), 64, 32, false, col, hi, ph == 0);
+            dw_flush<1, 2>(a_d1, red + SD::glb_off(1), 16, 64, false, col, hi, ph == 0);
+            dw_flush<2, 1>(a_c0, redc + SC::glb_off(0), 64, 32, true, col, hi, ph == 0);
+            dw_flush<2, 2>(a_c1, redc + SC::glb_off(1), 64, 64, false, col, hi, ph == 0);
+            dw_flush<1, 2>(a_c2, redc + SC::glb_off(2), 16, 64, false, col, hi, ph == 0);
         }
         __syncthreads();
     }
     float* out = partial + (size_t)blockIdx.x * GW;
-    for (int e = threadIdx.x; e < GW; e += MLP_THREADS) out[e] = red[e];
+    for (int e = threadIdx.x; e < GW; e += MLP_THREADS) out[e] = redA[e] + redA[GW + e];
 }
 
 // grad[j] += sum_b partial[b][j], fixed order: 64 columns x 4 row groups per block, each thread sums
@@ -1070,21 +1075,25 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void k_nerf_mlp_bwd_h(
     scale_tile(a_c1[0][0], inv); scale_tile(a_c1[0][1], inv); scale_tile(a_c1[1][0], inv); scale_tile(a_c1[1][1], inv);
     scale_tile(a_c2[0][0], inv); scale_tile(a_c2[0][1], inv);
     // ---- block reduction of dW through LDS (fp32, compact global layout), then one partial per block
+    // two copies over the whole (now dead) dynamic LDS, two turns: see k_nerf_mlp_bwd_1_2
     __syncthreads();
-    float* red = reinterpret_cast<float*>(stage_all);
-    float* redc = red + SD::glb_floats;
-    for (int w = 0; w < MLP_WAVES; ++w) {
-        if (wave == w) {
-            dw_flush<2, 1>(a_d0, red + SD::glb_off(0), 64, 32, false, col, hi, w == 0);
-            dw_flush<1, 2>(a_d1, red + SD::glb_off(1), 16, 64, false, col, hi, w == 0);
-            dw_flush<2, 1>(a_c0, redc + SC::glb_off(0), 64, 32, true, col, hi, w == 0);
-            dw_flush<2, 2>(a_c1, redc + SC::glb_off(1), 64, 64, false, col, hi, w == 0);
-            dw_flush<1, 2>(a_c2, redc + SC::glb_off(2), 16, 64, false, col, hi, w == 0);
+    static_assert(2 * GW * sizeof(float) <= (size_t)(HD::f_halves + HC::f_halves + HD::b_halves + HC::b_halves + MLP_WAVES * STAGE) * 2,
+                  "two reduction copies must fit the launch's LDS");
+    float* redA = reinterpret_cast<float*>(ldsh);
+    for (int ph = 0; ph < 2; ++ph) {
+        if ((wave >> 1) == ph) {
+            float* red = redA + (wave & 1) * GW;
+            float* redc = red + SD::glb_floats;
+            dw_flush<2, 1>(a_d0, red + SD::glb_off(0), 64, 32, false, col, hi, ph == 0);
+            dw_flush<1, 2>(a_d1, red + SD::glb_off(1), 16, 64, false, col, hi, ph == 0);
+            dw_flush<2, 1>(a_c0, redc + SC::glb_off(0), 64, 32, true, col, hi, ph == 0);
+            dw_flush<2, 2>(a_c1, redc + SC::glb_off(1), 64, 64, false, col, hi, ph == 0);
+            dw_flush<1, 2>(a_c2, redc + SC::glb_off(2), 16, 64, false, col, hi, ph == 0);
         }
         __syncthreads();
     }
     float* out = partial + (size_t)blockIdx.x * GW;
-    for (int e = threadIdx.x; e < GW; e += MLP_THREADS) out[e] = red[e];
+    for (int e = threadIdx.x; e < GW; e += MLP_THREADS) out[e] = redA[e] + redA[GW + e];
 }
 
 // ------------------------------------------------------------------ host side
