@@ -259,7 +259,18 @@ int xr_ngp_train_step(const float* table, const float* w_density, const float* w
                       int density_activation, float huber_delta, float loss_scale, float* enc_t, uint32_t ld, float* raw,
                       float* draw, float* denc_t, float* rgb_out, float* zero_block, size_t zero_floats, float* grad_w_density,
                       float* grad_w_color, float* loss_mse, float* grad_table, size_t table_floats, int zero_draw,
-                      void* ws_mlp_bwd, size_t ws_mlp_bwd_bytes, void* ws_scatter, size_t ws_scatter_bytes, void* stream);
+                      void* ws_mlp_bwd, size_t ws_mlp_bwd_bytes, void* ws_scatter, size_t ws_scatter_bytes,
+                      const char* timed_entry, void* timing_begin, void* timing_end, void* stream);
+/* timed_entry (nullable): the name of ONE of the entry points the step runs ("xr_hashgrid_fwd", "xr_nerf_mlp_fwd",
+ * "xr_composite_train", "xr_live_rows", "xr_nerf_mlp_bwd", "xr_hashgrid_bwd"): its launches are bracketed on `stream` by the two
+ * events (xr_timing_event_create) -- bench.py's live duration of the dominant kernel inside the timed region.
+ * XR_STEP_OVERLAP=1 moves the zero-fill of grad_table and the reduction of the MLP backward's partials to a helper stream
+ * (measured slower on the MI355X, kept as a switch). */
+void* xr_timing_event_create(void);
+int xr_timing_event_destroy(void* event);
+int xr_timing_event_elapsed_ms(void* begin, void* end, float* ms);
+/* the second half of xr_nerf_mlp_bwd[_f16] on its own (sum of the per-workgroup dW partials in `workspace` into the gradients) */
+int xr_nerf_mlp_bwd_reduce(const void* workspace, uint32_t n, float* grad_w_density, float* grad_w_color, void* stream);
 
 /* The next batch's side-stream work as ONE call: xr_make_batch (rows = [n_rays,11] slice of the device-resident ray table;
  * generator = pcg32 seeded `batch_seed`, advanced `batch_call_index` calls) -> xr_rays_sampler (the reference's hidden

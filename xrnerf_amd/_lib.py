@@ -45,7 +45,11 @@ SIGNATURES = {
                                _vp, _sz, _u32, _vp, _vp, _vp, _vp]),
     'xr_ngp_train_step': (_i32, [_vp, _vp, _vp, _i32, _i32, _f, _i32, _i32, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _u32, _vp, _vp, _vp,
                                  _vp, _i32, _i32, _f, _f, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _sz, _i32, _vp, _sz,
-                                 _vp, _sz, _vp]),
+                                 _vp, _sz, C.c_char_p, _vp, _vp, _vp]),
+    'xr_timing_event_create': (_vp, []),
+    'xr_timing_event_destroy': (_i32, [_vp]),
+    'xr_timing_event_elapsed_ms': (_i32, [_vp, _vp, _vp]),
+    'xr_nerf_mlp_bwd_reduce': (_i32, [_vp, _u32, _vp, _vp, _vp]),
     'xr_nerf_mlp_fwd_f16': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp]),
     'xr_nerf_mlp_bwd_f16': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     'xr_nerf_mlp_bwd': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),

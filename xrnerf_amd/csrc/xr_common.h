@@ -114,3 +114,6 @@ __device__ inline float xr_dact_density(float v, int a) {
 __host__ __device__ inline float xr_unwarp_dt(float dt) {   // ray_sampler_header.h:388-392
     return dt * (xr_max_warp_step() - xr_min_step()) + xr_min_step();
 }
+
+// library-internal (not part of the C ABI): see xr_mlp.hip
+void xr_internal_defer_mlp_reduce(bool on);

@@ -1200,6 +1200,19 @@ static int build_live_rows(const float* draw, uint32_t n, const uint32_t* n_dev,
     return xr_live_rows(draw, n, n_dev, seg, list, cnt, denc_t, ld, stream);
 }
 
+// xr_ngp_train_step runs the partial reduce on its helper stream beside the table scatter (only the optimiser reads the MLP
+// gradients): it sets this flag around its backward call and issues xr_nerf_mlp_bwd_reduce itself
+static thread_local bool g_defer_reduce = false;
+void xr_internal_defer_mlp_reduce(bool on) { g_defer_reduce = on; }
+extern "C" int xr_nerf_mlp_bwd_reduce(const void* workspace, uint32_t n, float* grad_w_density, float* grad_w_color, void* stream_) {
+    XR_REQUIRE(workspace && grad_w_density && grad_w_color, "null pointer");
+    constexpr int GW = NetShape<1>::glb_floats + NetShape<2>::glb_floats;
+    hipLaunchKernelGGL(k_reduce_partials, dim3(xr_div_up(GW, 64)), dim3(256), 0, (hipStream_t)stream_, (const float*)workspace, bwd_grid(n),
+                       (uint32_t)GW, (uint32_t)NetShape<1>::glb_floats, grad_w_density, grad_w_color);
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}
+
 extern "C" int xr_nerf_mlp_bwd(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
                                const uint32_t* n_dev, const float* w_density, const float* w_color, int n_hidden_density, int n_hidden_color,
                                float pad_value, const float* draw, float* denc_t, float* grad_w_density,
@@ -1226,8 +1239,9 @@ extern "C" int xr_nerf_mlp_bwd(const float* enc_t, uint32_t ld, const float* dir
     XR_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n,
                        n_dev, w_density, w_color, pad_value, (const float4*)draw, denc_t, (float*)workspace, rows, n_live);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(xr_div_up(GW, 64)), dim3(256), 0, stream, (const float*)workspace, grid,
-                       (uint32_t)GW, (uint32_t)NetShape<1>::glb_floats, grad_w_density, grad_w_color);
+    if (!g_defer_reduce)
+        hipLaunchKernelGGL(k_reduce_partials, dim3(xr_div_up(GW, 64)), dim3(256), 0, stream, (const float*)workspace, grid,
+                           (uint32_t)GW, (uint32_t)NetShape<1>::glb_floats, grad_w_density, grad_w_color);
     XR_LAUNCH_CHECK();
     return XR_OK;
 }
@@ -1334,8 +1348,9 @@ extern "C" int xr_nerf_mlp_bwd_f16(const float* enc_t, uint32_t ld, const float*
     XR_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev, w_density,
                        w_color, pad_value, (const float4*)draw, denc_t, (float*)workspace, rows, n_live);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(xr_div_up(GW, 64)), dim3(256), 0, stream, (const float*)workspace, grid, (uint32_t)GW,
-                       (uint32_t)NetShape<1>::glb_floats, grad_w_density, grad_w_color);
+    if (!g_defer_reduce)
+        hipLaunchKernelGGL(k_reduce_partials, dim3(xr_div_up(GW, 64)), dim3(256), 0, stream, (const float*)workspace, grid, (uint32_t)GW,
+                           (uint32_t)NetShape<1>::glb_floats, grad_w_density, grad_w_color);
     XR_LAUNCH_CHECK();
     return XR_OK;
 }

@@ -6,6 +6,22 @@
 // existing entry points of this library called in sequence (same kernels, same results); buffers are caller-owned, nothing
 // is allocated or synchronised.
 #include "xr_common.h"
+#include <cstdlib>
+#include <initializer_list>
+
+// Timing events for callers without a HIP binding of their own (bench.py brackets one stage of the native step with them)
+extern "C" void* xr_timing_event_create(void) {
+    hipEvent_t e = nullptr;
+    return hipEventCreate(&e) == hipSuccess ? (void*)e : nullptr;
+}
+extern "C" int xr_timing_event_destroy(void* e) { return e && hipEventDestroy((hipEvent_t)e) != hipSuccess ? XR_EHIP : XR_OK; }
+extern "C" int xr_timing_event_elapsed_ms(void* a, void* b, float* ms) {
+    XR_REQUIRE(a && b && ms, "null pointer");
+    XR_HIP(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+    return XR_OK;
+}
+
+static bool stage_is(const char* timed, const char* name) { return timed && strcmp(timed, name) == 0; }
 
 extern "C" int xr_ngp_train_step(
     const float* table, const float* w_density, const float* w_color, int n_hidden_density, int n_hidden_color, float pad_value,
@@ -16,40 +32,86 @@ extern "C" int xr_ngp_train_step(
     float* enc_t, uint32_t ld, float* raw, float* draw, float* denc_t, float* rgb_out,
     float* zero_block, size_t zero_floats, float* grad_w_density, float* grad_w_color, float* loss_mse,
     float* grad_table, size_t table_floats, int zero_draw,
-    void* ws_mlp_bwd, size_t ws_mlp_bwd_bytes, void* ws_scatter, size_t ws_scatter_bytes, void* stream_) {
+    void* ws_mlp_bwd, size_t ws_mlp_bwd_bytes, void* ws_scatter, size_t ws_scatter_bytes,
+    const char* timed_entry, void* timing_begin, void* timing_end, void* stream_) {
     XR_REQUIRE(table && w_density && w_color && coords && rays_numsteps && rays_numsteps_compacted && bg_color && target &&
                alpha_mask && density_grid_mean && enc_t && raw && draw && denc_t && rgb_out && zero_block && grad_w_density &&
                grad_w_color && loss_mse && grad_table, "null pointer");
     XR_REQUIRE(n_rows > 0 && n_rays > 0 && ld >= n_rows, "bad sizes");
+    XR_REQUIRE(!timed_entry || (timing_begin && timing_end), "a timed entry point needs its two events");
     hipStream_t stream = (hipStream_t)stream_;
+    // XR_STEP_OVERLAP=1 (measurement; default off): work that only LATER stages need goes to a helper stream --
+    //   * the 48.8-MB zero-fill of the table gradient beside the encode (first read by the scatter),
+    //   * the reduction of the MLP backward's per-workgroup partials beside the scatter (first read by the optimiser),
+    // forked from / joined into the caller's stream with events.  Measured on the MI355X (tools/iter_times.py, steady state):
+    // a normal iteration takes 0.562 ms WITH it against 0.542 ms on one stream (fp16 mode: 0.66 against 0.50) -- the two
+    // cross-queue joins cost more than the 13 us of kernels they take off the stream.
+    static hipStream_t aux = nullptr;
+    static hipEvent_t ev_fork0 = nullptr, ev_zero = nullptr, ev_fork1 = nullptr, ev_red = nullptr;
+    static const bool overlap = []() { const char* e = getenv("XR_STEP_OVERLAP"); return e && e[0] == '1'; }();
+    if (overlap && !aux) {
+        XR_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+        for (hipEvent_t* e : {&ev_fork0, &ev_zero, &ev_fork1, &ev_red}) XR_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
+    auto begin = [&](const char* name) -> int { if (stage_is(timed_entry, name)) XR_HIP(hipEventRecord((hipEvent_t)timing_begin, stream)); return XR_OK; };
+    auto end = [&](const char* name) -> int { if (stage_is(timed_entry, name)) XR_HIP(hipEventRecord((hipEvent_t)timing_end, stream)); return XR_OK; };
     int rc;
+    if (overlap) {
+        XR_HIP(hipEventRecord(ev_fork0, stream));                      // behind everything that still reads the old gradient (the optimiser)
+        XR_HIP(hipStreamWaitEvent(aux, ev_fork0, 0));
+        XR_HIP(hipMemsetAsync(grad_table, 0, table_floats * sizeof(float), aux));
+        XR_HIP(hipEventRecord(ev_zero, aux));
+    }
     // coordinate rows {pos3, dt, dir3}: positions and directions are consumed in place (row stride 7)
+    if ((rc = begin("xr_hashgrid_fwd")) != XR_OK) return rc;
     rc = xr_hashgrid_fwd(table, coords, 7, n_rows, n_dev, nullptr, n_levels, scale_host, resolution_host, offset_host, enc_t, ld, stream_);
     if (rc != XR_OK) return rc;
+    if ((rc = end("xr_hashgrid_fwd")) != XR_OK || (rc = begin("xr_nerf_mlp_fwd")) != XR_OK) return rc;
     rc = f16_mlp ? xr_nerf_mlp_fwd_f16(enc_t, ld, coords + 4, 7, n_rows, n_dev, nullptr, w_density, w_color, n_hidden_density,
                                        n_hidden_color, pad_value, raw, stream_)
                  : xr_nerf_mlp_fwd(enc_t, ld, coords + 4, 7, n_rows, n_dev, nullptr, w_density, w_color, n_hidden_density,
                                    n_hidden_color, pad_value, raw, stream_);
     if (rc != XR_OK) return rc;
+    if ((rc = end("xr_nerf_mlp_fwd")) != XR_OK) return rc;
     XR_HIP(hipMemsetAsync(zero_block, 0, zero_floats * sizeof(float), stream));         // MLP gradients + loss accumulators
     if (zero_draw) XR_HIP(hipMemsetAsync(draw, 0, (size_t)n_rows * 4 * sizeof(float), stream));
+    if ((rc = begin("xr_composite_train")) != XR_OK) return rc;
     rc = xr_composite_train(raw, coords, rays_numsteps, rays_numsteps_compacted, bg_color, target, alpha_mask, density_grid_mean,
                             n_rays, rgb_activation, density_activation, huber_delta, loss_scale, rgb_out, loss_mse, draw, stream_);
     if (rc != XR_OK) return rc;
-    XR_HIP(hipMemsetAsync(grad_table, 0, table_floats * sizeof(float), stream));
+    if ((rc = end("xr_composite_train")) != XR_OK) return rc;
+    if (!overlap) XR_HIP(hipMemsetAsync(grad_table, 0, table_floats * sizeof(float), stream));
     // rows with an exactly-zero dL/d(raw) (T == 0 behind a surface) are skipped by the MLP backward AND the scatter: one list
     uint32_t *rows, *seg, *n_live;
     rc = xr_nerf_mlp_bwd_list_slots(ws_mlp_bwd, ws_mlp_bwd_bytes, n_rows, &rows, &seg, &n_live);
     if (rc != XR_OK) return rc;
+    if ((rc = begin("xr_live_rows")) != XR_OK) return rc;
     rc = xr_live_rows(draw, n_rows, n_dev, seg, rows, n_live, nullptr, ld, stream_);
     if (rc != XR_OK) return rc;
+    if ((rc = end("xr_live_rows")) != XR_OK || (rc = begin("xr_nerf_mlp_bwd")) != XR_OK) return rc;
+    xr_internal_defer_mlp_reduce(overlap);
     rc = f16_mlp ? xr_nerf_mlp_bwd_f16(enc_t, ld, coords + 4, 7, n_rows, n_dev, w_density, w_color, n_hidden_density, n_hidden_color,
                                        pad_value, draw, denc_t, grad_w_density, grad_w_color, ws_mlp_bwd, ws_mlp_bwd_bytes, rows, n_live, stream_)
                  : xr_nerf_mlp_bwd(enc_t, ld, coords + 4, 7, n_rows, n_dev, w_density, w_color, n_hidden_density, n_hidden_color,
                                    pad_value, draw, denc_t, grad_w_density, grad_w_color, ws_mlp_bwd, ws_mlp_bwd_bytes, rows, n_live, stream_);
+    xr_internal_defer_mlp_reduce(false);
     if (rc != XR_OK) return rc;
-    return xr_hashgrid_bwd(coords, 7, denc_t, ld, n_rows, n_live, rows, n_levels, scale_host, resolution_host, offset_host, grad_table,
-                           ws_scatter, ws_scatter_bytes, stream_);
+    if ((rc = end("xr_nerf_mlp_bwd")) != XR_OK) return rc;
+    if (overlap) {
+        XR_HIP(hipEventRecord(ev_fork1, stream));
+        XR_HIP(hipStreamWaitEvent(aux, ev_fork1, 0));
+        rc = xr_nerf_mlp_bwd_reduce(ws_mlp_bwd, n_rows, grad_w_density, grad_w_color, aux);
+        if (rc != XR_OK) return rc;
+        XR_HIP(hipEventRecord(ev_red, aux));
+        XR_HIP(hipStreamWaitEvent(stream, ev_zero, 0));                // the table gradient is zero from here on
+    }
+    if ((rc = begin("xr_hashgrid_bwd")) != XR_OK) return rc;
+    rc = xr_hashgrid_bwd(coords, 7, denc_t, ld, n_rows, n_live, rows, n_levels, scale_host, resolution_host, offset_host, grad_table,
+                         ws_scatter, ws_scatter_bytes, stream_);
+    if (rc != XR_OK) return rc;
+    if ((rc = end("xr_hashgrid_bwd")) != XR_OK) return rc;
+    if (overlap) XR_HIP(hipStreamWaitEvent(stream, ev_red, 0));
+    return XR_OK;
 }
 
 // The next batch's side-stream work as one call: HashBatchSample + RandomBGColor (xr_make_batch) -> K1 (xr_rays_sampler) ->

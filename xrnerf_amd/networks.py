@@ -101,7 +101,7 @@ class _FusedTrainStepFn(torch.autograd.Function):
                 sampler.on_sampled = cb
             sync = getattr(net, 'grad_sync', None)
             if sync is None and table.is_cuda and mlp.density_net.n_hidden == 1 and mlp.color_net.n_hidden == 2 and \
-                    os.environ.get('XRNERF_PY_STEP') != '1' and ops.TIMER is None:
+                    os.environ.get('XRNERF_PY_STEP') != '1' and (ops.TIMER is None or ops.TIMER.native_stage()[0]):
                 # single GPU: the whole device side of the step as ONE native call (csrc/xr_step.hip) -- the same entry points
                 # in the same order as the Python sequence below, which stays for the data-parallel path (gradient buckets
                 # are handed to RCCL between the scatter halves), for the kernels' host build, and whenever a KernelTimer

@@ -35,6 +35,17 @@ class KernelTimer:
             return _NOSPAN
         return _Span(self, name, units)
 
+    # the entry points xr_ngp_train_step runs (it can bracket ONE of them with a pair of events): a timer that asks for
+    # nothing else inside the step leaves the native path usable
+    STEP_STAGES = ('xr_hashgrid_fwd', 'xr_nerf_mlp_fwd', 'xr_composite_train', 'xr_live_rows', 'xr_nerf_mlp_bwd', 'xr_hashgrid_bwd')
+
+    def native_stage(self):
+        """-> (ok, stage): ok if the native step can serve this timer; stage = the one step stage to bracket (or None)"""
+        if self.only is None:
+            return False, None
+        inside = [k for k in self.only if k in self.STEP_STAGES]
+        return len(inside) <= 1, (inside[0] if inside else None)
+
     def summary(self):
         """name -> (launches, total_ms, total_units); call after torch.cuda.synchronize()"""
         return {k: (len(v), sum(a.elapsed_time(b) for a, b, _ in v), sum(u for _, _, u in v))
@@ -53,6 +64,26 @@ class _Span:
     def __exit__(self, *exc):
         self.b.record()
         self.timer.events.setdefault(self.name, []).append((self.a, self.b, self.units))
+
+
+class _CEvent:
+    """a timing event of the library (xr_timing_event_*): what xr_ngp_train_step records around one of its stages"""
+
+    def __init__(self):
+        self.h = _lib.load().xr_timing_event_create()
+        if not self.h:
+            raise _lib.XrError('cannot create a timing event')
+
+    def elapsed_time(self, other):
+        ms = C.c_float()
+        _lib.check(_lib.load().xr_timing_event_elapsed_ms(self.h, other.h, C.byref(ms)), 'xr_timing_event_elapsed_ms')
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            _lib.load().xr_timing_event_destroy(self.h)
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
 
 
 class _NoSpan:
@@ -252,6 +283,17 @@ def ngp_train_step(table, wd, wc, nhd, nhc, pad_value, meta, coords, n_dev, nums
     s, r, o = meta._args()
     ws_mlp = _ws(coords.device, L.xr_nerf_mlp_bwd_workspace_bytes(n_rows), 'mlpbwd')
     ws_sc = _ws(coords.device, L.xr_hashgrid_bwd_workspace_bytes(n_rows, meta.n_levels, r, o), 'hgb')
+    # the backward's (count, running live total, running valid total) block sits in the MLP workspace on this path
+    global LIVE_STATS
+    ws_mlp, _, _, LIVE_STATS = _list_slots(coords.device, n_rows)
+    stage, ev = None, (None, None)
+    if TIMER is not None:
+        ok, stage = TIMER.native_stage()
+        if not ok:
+            raise _lib.XrError('this KernelTimer needs the per-entry-point launch sequence (XRNERF_PY_STEP=1)')
+        if stage is not None:
+            ev = (_CEvent(), _CEvent())
+            TIMER.events.setdefault(stage, []).append((ev[0], ev[1], 0))
     with _span('xr_ngp_train_step', 0):
         _lib.check(L.xr_ngp_train_step(
             _ptr(table), _ptr(wd), _ptr(wc), nhd, nhc, pad_value, 1 if _PRECISION == 'f16' else 0, meta.n_levels, s, r, o,
@@ -260,7 +302,8 @@ def ngp_train_step(table, wd, wc, nhd, nhc, pad_value, meta, coords, n_dev, nums
             _ptr(bufs.enc_t), bufs.ld, _ptr(bufs.raw), _ptr(bufs.draw), _ptr(bufs.denc_t), _ptr(bufs.rgb),
             _ptr(bufs.zero_block), bufs.zero_block.numel(), _ptr(bufs.g_wd), _ptr(bufs.g_wc), _ptr(bufs.loss_mse),
             _ptr(bufs.g_table), bufs.g_table.numel(), 0 if n_dev is not None else 1,
-            _ptr(ws_mlp), ws_mlp.numel(), _ptr(ws_sc), ws_sc.numel(), _stream()), 'xr_ngp_train_step')
+            _ptr(ws_mlp), ws_mlp.numel(), _ptr(ws_sc), ws_sc.numel(), stage.encode() if stage else None,
+            ev[0].h if stage else None, ev[1].h if stage else None, _stream()), 'xr_ngp_train_step')
     return bufs.rgb[:n_rays]
 
 
@@ -471,27 +514,32 @@ def nerf_mlp_fwd(enc_t, dirs, n, w_density, w_color, nhd, nhc, pad_value=1.0, ra
     return raw
 
 
-LIVE_STATS = None      # the 4-word count block of the last ops.live_rows call (words 1, 2: running totals; clear to restart)
+LIVE_STATS = None      # the backward's 4-word count block (words 1, 2: running live / valid row totals; clear to restart)
+
+
+def _list_slots(dev, n):
+    """the list area of the MLP backward's workspace for n rows -> (workspace, rows view, seg pointer, count-block view)"""
+    L = _lib.load()
+    ws = _ws(dev, L.xr_nerf_mlp_bwd_workspace_bytes(n), 'mlpbwd')
+    p_rows, p_seg, p_cnt = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    _lib.check(L.xr_nerf_mlp_bwd_list_slots(_ptr(ws), ws.numel(), n, C.byref(p_rows), C.byref(p_seg), C.byref(p_cnt)),
+               'xr_nerf_mlp_bwd_list_slots')
+    base = ws.data_ptr()
+    rows = ws[p_rows.value - base:p_rows.value - base + 4 * n].view(torch.int32)
+    cnt = ws[p_cnt.value - base:p_cnt.value - base + 16].view(torch.int32)   # [count, running live total, running valid total, spare]
+    return ws, rows, p_seg, cnt
 
 
 def live_rows(draw, n, n_dev=None, zero_denc_t=None):
-    """-> (rows int32 [n], n_live int32 [1]) on the device: the rows of dL/d(raw) [n,4] that are not exactly zero, in
-    order (xr_live_rows).  Handed to nerf_mlp_bwd and hashgrid_bwd as `live=`; the buffers are reused by the next call."""
-    L = _lib.load()
-    dev = draw.device
-    segs = L.xr_live_rows_segments(n)
-    fresh = (str(dev), 'liverows') not in _workspaces or _workspaces[(str(dev), 'liverows')].numel() < 4 * (n + segs + 4)
-    buf = _ws(dev, 4 * (n + segs + 4), 'liverows')
-    base = buf.data_ptr()
-    rows = buf[:4 * n].view(torch.int32)
-    n_live = buf[4 * (n + segs):4 * (n + segs + 4)].view(torch.int32)    # [count, running live total, running valid total, spare]
-    if fresh:
-        n_live.zero_()
+    """-> (rows int32 [n], n_live int32 [4]) on the device: the rows of dL/d(raw) [n,4] that are not exactly zero, in
+    order (xr_live_rows); n_live[0] is the count.  Handed to nerf_mlp_bwd and hashgrid_bwd as `live=`.  The list sits in
+    the MLP backward's workspace (where xr_ngp_train_step keeps it too) and is overwritten by the next call."""
     global LIVE_STATS
+    _, rows, p_seg, n_live = _list_slots(draw.device, n)
     LIVE_STATS = n_live
     with _span('xr_live_rows', 0 if n_dev is not None else n, train=n_dev is not None):
-        _lib.check(L.xr_live_rows(_ptr(draw), n, _ptr(n_dev), C.c_void_p(base + 4 * n), _ptr(rows), _ptr(n_live),
-                                  _ptr(zero_denc_t), zero_denc_t.shape[1] if zero_denc_t is not None else 0, _stream()), 'xr_live_rows')
+        _lib.check(_lib.load().xr_live_rows(_ptr(draw), n, _ptr(n_dev), p_seg, _ptr(rows), _ptr(n_live),
+                                            _ptr(zero_denc_t), zero_denc_t.shape[1] if zero_denc_t is not None else 0, _stream()), 'xr_live_rows')
     return rows, n_live
 
 
