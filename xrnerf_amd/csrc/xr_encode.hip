@@ -304,7 +304,8 @@ __global__ __launch_bounds__(EN_LDS_THREADS) void k_hashgrid_fwd_lds(GridMeta gm
 __global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_bwd(GridMeta gm, uint32_t hashed_mask, const float* __restrict__ x,
                                                             uint32_t x_stride, const float* __restrict__ denc_t, uint32_t ld,
                                                             uint32_t n, const uint32_t* __restrict__ n_dev, const uint32_t* __restrict__ rows,
-                                                            float* __restrict__ grad_table, float* __restrict__ rep, uint32_t n_rep, uint32_t rep_stride) {
+                                                            float* __restrict__ grad_table, float* __restrict__ rep, uint32_t n_rep, uint32_t rep_stride,
+                                                            uint32_t rep_levels) {
     constexpr uint32_t bw_ch = BW_CH;   // compile-time: a runtime chunk length costs 8 % (loop not unrolled)
     uint32_t l, sb;
     level_of_block(gm, &l, &sb);
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_bwd(GridMeta gm, uint32_t
     // coarse levels: thousands of flushes land on the few hundred entries around the object and same-address
     // atomics serialise (level 0 alone: 63 us).  With `rep`, workgroup sb adds into replica sb % n_rep of the
     // slice; k_reduce_replicas folds the replicas into the table afterwards.
-    float* __restrict__ tab = (rep ? rep + (size_t)(sb % n_rep) * rep_stride : grad_table) + 2 * (size_t)gm.off[l] + f;
+    float* __restrict__ tab = (rep && l < rep_levels ? rep + (size_t)(sb % n_rep) * rep_stride : grad_table) + 2 * (size_t)gm.off[l] + f;
     uint32_t c0 = 0xffffffffu, c1 = 0xffffffffu, c2 = 0xffffffffu;   // current cell
     float acc = 0.f;
     float* dst = tab;
@@ -922,6 +923,7 @@ struct ScatterPlan {
     uint32_t parts, nsb;
     size_t counts_bytes, bins_bytes, rep_bytes;
     uint32_t rep_stride;  // floats per replica
+    uint32_t rep_levels;  // levels [0, rep_levels) of the dense remainder go through the replicas
 };
 static ScatterPlan scatter_plan(uint32_t n, int n_levels, const uint32_t* res, const uint32_t* off, uint32_t hashed_mask) {
     static const int cap_levels = scatter_env("XR_SCAN_LEVELS", EN_MAX_LEVELS);
@@ -942,7 +944,11 @@ static ScatterPlan scatter_plan(uint32_t n, int n_levels, const uint32_t* res, c
     p.counts_bytes = (((size_t)nl * p.parts * p.nsb * sizeof(uint32_t)) + 255) & ~(size_t)255;
     p.bins_bytes = (size_t)nl * p.nsb * (sc_mode() ? SC_SUB_ITEMS2 : SC_SUB_ITEMS) * sizeof(float4);
     // replicas only for a dense remainder next to a binned range (small tables: <= 2^14-entry... up to 2^19 each)
-    p.rep_stride = (use_rep && n >= 16384u && p.l_bin > 0) ? (2u * off[p.l_bin] + 3u) & ~3u : 0u;
+    // XR_REPLICA_LEVELS: how many of the coarsest levels are replicated (default: all of the dense remainder).  Measured in the
+    // bench's training loop (entry span): all 5 -> 151 us, 3 -> 149, 2 -> 147, 1 -> 156, 0 -> 157: flat, the default stays
+    static const int rep_lv = scatter_env("XR_REPLICA_LEVELS", EN_MAX_LEVELS);
+    p.rep_levels = (uint32_t)(rep_lv < p.l_bin ? (rep_lv < 0 ? 0 : rep_lv) : p.l_bin);
+    p.rep_stride = (use_rep && n >= 16384u && p.rep_levels > 0) ? (2u * off[p.rep_levels] + 3u) & ~3u : 0u;
     p.rep_bytes = (size_t)SC_REPLICAS * p.rep_stride * sizeof(float);
     return p;
 }
@@ -974,7 +980,7 @@ extern "C" int xr_hashgrid_bwd(const float* x, uint32_t x_stride, const float* d
     // XR_SCAN_LEVELS=0 / XR_REPLICAS=0 switch the two mechanisms off (measurement).
     ScatterPlan p = scatter_plan(n, n_levels, gm.res, gm.off, hm);
     const bool ws_ok = workspace && ((uintptr_t)grad_table & 15) == 0 && ((uintptr_t)workspace & 15) == 0;
-    if (!ws_ok) { p.l_bin = n_levels; p.rep_stride = 0; }
+    if (!ws_ok) { p.l_bin = n_levels; p.rep_stride = 0; p.rep_levels = 0; }
     else XR_REQUIRE(workspace_bytes >= p.counts_bytes + p.bins_bytes + p.rep_bytes, "workspace too small");
     // The dense remainder and the binned range are independent (disjoint table slices, read-only inputs) and bound
     // by different things (atomics vs item stores / LDS): when both exist the remainder runs on an internal helper
@@ -1013,7 +1019,7 @@ extern "C" int xr_hashgrid_bwd(const float* x, uint32_t x_stride, const float* d
         float* rep = p.rep_stride ? (float*)((char*)workspace + p.counts_bytes + p.bins_bytes) : nullptr;
         if (rep) XR_HIP(hipMemsetAsync(rep, 0, p.rep_bytes, ds));
         hipLaunchKernelGGL(k_hashgrid_bwd, dim3(blocks), dim3(EN_BLOCK), 0, ds, gd, hm, x, x_stride, denc_t, ld,
-                           n, n_dev, rows, grad_table, rep, (uint32_t)SC_REPLICAS, p.rep_stride);
+                           n, n_dev, rows, grad_table, rep, (uint32_t)SC_REPLICAS, p.rep_stride, p.rep_levels);
         XR_LAUNCH_CHECK();
         if (rep) {
             const uint32_t count4 = p.rep_stride / 4;
