@@ -202,7 +202,7 @@ class _FusedTrainStepFn(torch.autograd.Function):
         if not (factor == 1.0 and unit is not None and g.data_ptr() == unit.data_ptr()):
             # (the trainer back-propagates from a persistent all-ones root gradient it registers as
             # `net._unit_root_grad`: the scaling launch -- which would read that 1.0 and do nothing -- is skipped then)
-            g = g.reshape(1) if g.dtype == torch.float32 and g.is_cuda else g.to(grads[0].device, torch.float32).reshape(1)
+            g = g.reshape(1) if g.dtype == torch.float32 and ops._on_device(g) else g.to(grads[0].device, torch.float32).reshape(1)
             ops.scale_multi(grads, g, factor)        # one launch; no memory traffic when the factor is exactly 1
         # Hand the gradients to the parameters the way AccumulateGrad would, but without its defensive clone
         # (a Python-created gradient is never "stolen": 48.8 MB copied per step): first gradient -> becomes
@@ -281,10 +281,11 @@ class HashNerfNetwork(BaseNerfNetwork):
         from .mlps import HashNerfMLP
         from .renders import HashNerfRender
         from .samplers import NGPGridSampler
+        from . import ops
         import os
         return (os.environ.get('XRNERF_MODULAR_STEP') != '1' and type(self.sampler) is NGPGridSampler and
                 type(self.mlp) is HashNerfMLP and type(self.render) is HashNerfRender and
-                self.mlp.embedder_pos.params.is_cuda and torch.is_grad_enabled())
+                ops._on_device(self.mlp.embedder_pos.params) and torch.is_grad_enabled())
 
     def _train_step_fused(self, data, **kwargs):
         loss, rgb = _FusedTrainStepFn.apply(self.mlp.embedder_pos.params, self.mlp.density_net.params,
