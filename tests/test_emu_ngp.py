@@ -89,6 +89,7 @@ def test_edge_cases_on_the_host(O, edev):
     T.test_fully_occupied_grid_hits_the_step_cap(O, edev)
     T.test_single_ray_and_all_miss(O, edev)
     T.test_ragged_sample_counts_through_mlp_and_encode(O, edev)
+    T.test_live_row_list_edge_cases(O, edev)
 
 
 def test_emulation_leaves_the_product_untouched(edev):

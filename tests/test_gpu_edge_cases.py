@@ -98,3 +98,49 @@ def test_ragged_sample_counts_through_mlp_and_encode(O, dev):
         rt, rd, rcg = O.nerf_mlp_bwd(table, wd, wc, pts, dirs, draw, om)
         for got, want in ((gwd, rd), (gwc, rcg), (gt, rt)):
             assert np.abs(got.cpu().numpy() - want).max() <= 1e-3 * max(1.0, np.abs(want).max())
+
+
+def test_live_row_list_edge_cases(O, dev):
+    """xr_live_rows / the row-list arguments of the backward pair: no live row at all, one live row at either end, a count
+    that is not a multiple of the 4-row / 1024-row granules, a device-side count below n, and the argument checks"""
+    from xrnerf_amd import _lib, ops, synthetic as S
+    meta, om = ops.GridMeta(), O.GridMeta()
+    table = S.hash_table(meta.n_params, scale=0.5)
+    wd, wc = S.mlp_weights(32, 64, 1, 16, 4), S.mlp_weights(32, 64, 2, 16, 5)
+    tt, twd, twc = T(table, dev), T(wd, dev), T(wc, dev)
+    rng = np.random.default_rng(21)
+    for n, live_idx, n_valid in ((1, [], None), (1, [0], None), (1027, [], None), (1027, [0], None), (1027, [1026], None),
+                                 (2051, [0, 1023, 1024, 2050], None), (2051, [5, 1030, 2049], 1031), (4100, list(range(1000, 1100)), 1050)):
+        pts = rng.uniform(0, 1, (n, 3)).astype(np.float32); dirs = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+        draw = np.zeros((n, 4), np.float32)
+        draw[live_idx] = rng.normal(0, 1, (len(live_idx), 4)).astype(np.float32)
+        nv = n if n_valid is None else n_valid
+        n_dev = None if n_valid is None else torch.tensor([nv], dtype=torch.int32, device=dev)
+        tdraw = T(draw, dev)
+        live = ops.live_rows(tdraw, n, n_dev=n_dev)
+        want = [i for i in live_idx if i < nv]
+        assert int(live[1][0]) == len(want) and live[0][:len(want)].cpu().tolist() == want, (n, live_idx, n_valid)
+        enc_t = ops.hashgrid_fwd(tt, T(pts, dev), meta)
+        gwd, gwc = torch.zeros_like(twd), torch.zeros_like(twc)
+        denc = torch.full_like(enc_t, float('nan'))
+        ops.nerf_mlp_bwd(enc_t, T(dirs, dev), n, twd, twc, 1, 2, tdraw, gwd, gwc, denc_t=denc, n_dev=n_dev, live=live)
+        gt = torch.zeros(meta.n_params, device=dev)
+        ops.hashgrid_bwd(T(pts, dev), denc, meta, gt, live=live)
+        dref = draw.copy(); dref[nv:] = 0
+        rt, rd, rcg = O.nerf_mlp_bwd(table, wd, wc, pts, dirs, dref, om)
+        for got, ref in ((gwd, rd), (gwc, rcg), (gt, rt)):
+            g = got.cpu().numpy()
+            assert np.isfinite(g).all() and np.abs(g - ref).max() <= 1e-3 * max(1.0, np.abs(ref).max()), (n, live_idx, n_valid)
+        if not want:
+            assert not gwd.any() and not gwc.any() and not gt.any()
+    # a row list needs its device-side length; the two list arguments of the MLP backward come together
+    L = _lib.load()
+    t = torch.zeros(64, device=dev)
+    s, r, o = meta._args()
+    assert L.xr_hashgrid_bwd(t.data_ptr(), 3, t.data_ptr(), 8, 8, None, t.data_ptr(), meta.n_levels, s, r, o, t.data_ptr(), None, 0, None) == -22
+    one_lib = torch.device(dev).type == 'cuda'        # (the host build of the kernels is one library per source file)
+    assert not one_lib or b'row list' in L.xr_last_error()
+    assert L.xr_nerf_mlp_bwd(t.data_ptr(), 64, t.data_ptr(), 3, 8, None, t.data_ptr(), t.data_ptr(), 1, 2, 1.0, t.data_ptr(), t.data_ptr(),
+                             t.data_ptr(), t.data_ptr(), t.data_ptr(), 1 << 30, t.data_ptr(), None, None) == -22
+    assert not one_lib or b'come together' in L.xr_last_error()
+    assert L.xr_live_rows(None, 8, None, t.data_ptr(), t.data_ptr(), t.data_ptr(), None, 0, None) == -22
