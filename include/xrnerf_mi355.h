@@ -249,7 +249,10 @@ int xr_nerf_mlp_bwd_f16(const float* enc_t, uint32_t ld, const float* dirs, uint
  * loss_mse) -> xr_composite_train -> zero-fill of grad_table -> xr_nerf_mlp_bwd[_f16] -> xr_hashgrid_bwd, on `stream`.
  * coords: K1's [n_rows,7] rows (positions / directions consumed in place); n_dev: device count of valid rows; every buffer
  * is caller-owned (enc_t / denc_t [32][ld], raw / draw [n_rows,4], rgb_out [n_rays,3]); zero_draw != 0 also clears draw
- * (needed only without n_dev).  Same kernels and results as the separate calls -- this exists because issuing them one by
+ * (needed only without n_dev).  scatter_level0: the step scatters hash levels [scatter_level0, n_levels) only (0 = all) -- a
+ * data-parallel caller hands that slice of grad_table to its gradient collective and then scatters the coarser levels with
+ * xr_hashgrid_bwd on the same row list (xr_nerf_mlp_bwd_list_slots), so the exchange runs under the rest of the backward.
+ * Same kernels and results as the separate calls -- this exists because issuing them one by
  * one from an interpreter costs as much host time as the kernels take on the device. */
 int xr_ngp_train_step(const float* table, const float* w_density, const float* w_color, int n_hidden_density, int n_hidden_color,
                       float pad_value, int f16_mlp, int n_levels, const float* scale_host, const uint32_t* resolution_host,
@@ -259,7 +262,7 @@ int xr_ngp_train_step(const float* table, const float* w_density, const float* w
                       int density_activation, float huber_delta, float loss_scale, float* enc_t, uint32_t ld, float* raw,
                       float* draw, float* denc_t, float* rgb_out, float* zero_block, size_t zero_floats, float* grad_w_density,
                       float* grad_w_color, float* loss_mse, float* grad_table, size_t table_floats, int zero_draw,
-                      void* ws_mlp_bwd, size_t ws_mlp_bwd_bytes, void* ws_scatter, size_t ws_scatter_bytes,
+                      void* ws_mlp_bwd, size_t ws_mlp_bwd_bytes, void* ws_scatter, size_t ws_scatter_bytes, int scatter_level0,
                       const char* timed_entry, void* timing_begin, void* timing_end, void* stream);
 /* timed_entry (nullable): the name of ONE of the entry points the step runs ("xr_hashgrid_fwd", "xr_nerf_mlp_fwd",
  * "xr_composite_train", "xr_live_rows", "xr_nerf_mlp_bwd", "xr_hashgrid_bwd"): its launches are bracketed on `stream` by the two
@@ -324,10 +327,13 @@ int xr_adam_step(float* p, const float* g, float* m, float* v, size_t n, int ste
                  void* stream);
 
 /* the same update for up to 4 parameter tensors in ONE launch; arrays are HOST arrays of device pointers /
- * element counts (ema may be NULL, or hold NULL entries) */
+ * element counts (ema may be NULL, or hold NULL entries).  grad_scale: factor on the gradients as they are read (1 = none;
+ * 1/world_size after a summing all-reduce -- bit for bit the update of `g *= grad_scale` followed by this call, without
+ * that pass over the gradients; the gradient buffers themselves are not modified). */
 int xr_adam_step_multi(int n_tensors, float* const* p_host, const float* const* g_host, float* const* m_host,
                        float* const* v_host, float* const* ema_host, const size_t* n_host, int step, float lr,
-                       float beta1, float beta2, float eps, float weight_decay, float ema_momentum, void* stream);
+                       float beta1, float beta2, float eps, float weight_decay, float ema_momentum, float grad_scale,
+                       void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Mip-NeRF (BASELINE config #3; configs/mipnerf/mipnerf_multiscale.py): the sampling / encoding / rendering

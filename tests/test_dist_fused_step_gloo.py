@@ -46,21 +46,33 @@ with emulib.emulated_ops() as edev:
         ops.update_bitfield(net.sampler.density_grid, net.sampler.density_grid_mean, net.sampler.density_grid_bitfield)
         net.sampler.density_grid_ema_step = 1
         return net
-    dp, solo = build(), build()
+    dp, solo, dp2 = build(), build(), build()
     dp.grad_sync = xd.BucketedGradSync(world)
     opt = FusedAdam([p for p in dp.parameters() if p.numel() > 0], lr=1e-2, betas=(0.9, 0.99), eps=1e-15, weight_decay=1e-6)
+    # the trainer's form of the same step (xrnerf_amd/train.py): unit root gradient, .grad keeps the all-reduced SUM and
+    # the optimiser applies the 1/world_size while reading it (FusedAdam.step(grad_scale=...))
+    dp2.grad_sync = xd.BucketedGradSync(world)
+    dp2._defer_grad_scale = True
+    dp2._unit_root_grad = one = torch.ones(())
+    opt2 = FusedAdam([p for p in dp2.parameters() if p.numel() > 0], lr=1e-2, betas=(0.9, 0.99), eps=1e-15, weight_decay=1e-6)
     names = ('embedder_pos', 'density_net', 'color_net')
     for it in (1, 2):
         b = Hn.batch(poses, N_RAYS, 100 * rank + it, edev)          # every rank its own rays
         grads = {}
-        for tag, net in (('solo', solo), ('dp', dp)):
+        for tag, net in (('solo', solo), ('dp', dp), ('dp2', dp2)):
             net.sampler.set_iter(it)
             net.sampler.k1_calls = 7 * it + rank                    # same march jitter for both networks of this rank
             o = net.train_step({k: v.clone()[None] for k, v in b.items()}, None)
             for n in names:
                 getattr(net.mlp, n).params.grad = None
-            o['loss'].backward()
+            if net is dp2:
+                torch.autograd.backward(o['loss'], grad_tensors=one)
+            else:
+                o['loss'].backward()
             grads[tag] = {n: getattr(net.mlp, n).params.grad.detach().clone() for n in names}
+        assert dp2._pending_grad_scale == 0.5
+        for n in names:                                              # the deferred form holds the SUM: mean = sum / 2 exactly
+            assert torch.equal(grads['dp2'][n] * 0.5, grads['dp'][n]), (rank, it, n)
         for n in names:
             mine = grads['solo'][n]
             both = [torch.empty_like(mine) for _ in range(world)]
@@ -71,6 +83,10 @@ with emulib.emulated_ops() as edev:
             assert scale > 0 and err <= 2e-6 * scale, (rank, it, n, err, scale)
             assert float((both[0] - both[1]).abs().max()) > 1e-3 * scale        # the ranks really saw different rays
         opt.step()
+        opt2.step(grad_scale=dp2._pending_grad_scale)
+        dp2._pending_grad_scale = 1.0
+        for n in names:                                              # same update, bit for bit, without the scaling pass
+            assert torch.equal(getattr(dp2.mlp, n).params.detach(), getattr(dp.mlp, n).params.detach()), (rank, it, n)
         with torch.no_grad():                                        # keep the un-synchronised twin on the same weights
             for n in names:
                 getattr(solo.mlp, n).params.copy_(getattr(dp.mlp, n).params)

@@ -48,6 +48,7 @@ def test_grid_upkeep_raygen_loss_adam_on_the_host(O, lego, edev):
     T.test_k6_grid_samples_bit_exact(O, lego, edev)
     T.test_k7_mark_untrained(O, lego, edev)
     T.test_gen_rays_huber_adam(O, lego, edev)
+    T.test_adam_multi_grad_scale_equals_scaling_pass_then_adam(O, edev)
 
 
 @pytest.mark.parametrize('n', [1, 31, 4096])

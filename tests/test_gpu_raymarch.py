@@ -227,6 +227,38 @@ def test_gen_rays_huber_adam(O, lego, dev):
     assert np.abs(tp.cpu().numpy() - p).max() <= 1e-5 and np.abs(tv.cpu().numpy() - v).max() <= 1e-9
 
 
+def test_adam_multi_grad_scale_equals_scaling_pass_then_adam(O, dev):
+    """xr_adam_step_multi(grad_scale = 1/world) -- what the data-parallel trainer runs on the all-reduced SUM of the gradients --
+    against xr_scale_multi(1/world) followed by the same update: parameters, moments and EMA bit for bit, gradients untouched;
+    and against the oracle's Adam on the averaged gradients"""
+    from xrnerf_amd import ops
+    rng = np.random.default_rng(5)
+    sizes = (100003, 3072, 7168)
+    mk = lambda sc: [rng.normal(0, sc, n).astype(np.float32) for n in sizes]
+    p0, g0 = mk(1.0), mk(3e-2)
+    for world in (2, 3, 8):
+        fac = 1.0 / world
+        # (.clone(): on the host-emulated device T() shares the numpy buffer)
+        A = dict(p=[T(a, dev).clone() for a in p0], g=[T(a, dev).clone() for a in g0], m=[T(np.zeros_like(a), dev) for a in p0],
+                 v=[T(np.zeros_like(a), dev) for a in p0], e=[T(a, dev).clone() for a in p0])
+        B = {k: [t.clone() for t in v] for k, v in A.items()}
+        ref = [(a.copy(), np.zeros_like(a), np.zeros_like(a)) for a in p0]
+        for step in (1, 2, 3):
+            ops.adam_step_multi(A['p'], A['g'], A['m'], A['v'], step, emas=A['e'], ema_momentum=0.05, grad_scale=fac)
+            gs = [t.clone() for t in B['g']]
+            ops.scale_multi(gs, None, fac)
+            ops.adam_step_multi(B['p'], gs, B['m'], B['v'], step, emas=B['e'], ema_momentum=0.05)
+            for (rp, rm, rv), g in zip(ref, g0):
+                O.adam(rp, (g * np.float32(fac)).astype(np.float32), rm, rv, step)
+        for k in 'pmve':
+            for a, b in zip(A[k], B[k]):
+                assert torch.equal(a, b), (world, k)
+        for a, g in zip(A['g'], g0):
+            assert np.array_equal(a.cpu().numpy(), g)
+        for a, (rp, _, _) in zip(A['p'], ref):
+            assert np.abs(a.cpu().numpy() - rp).max() <= 1e-5
+
+
 def test_fused_compositor_train_equals_k3_huber_k4(O, lego, dev):
     """xr_composite_train (K3 + 5*Huber + masked MSE + K4 in one launch) against the three separate entry points on marched
     Lego samples incl. clipped tails and rays without samples: rgb and dL/draw bit for bit, the two loss scalars to 1e-6"""

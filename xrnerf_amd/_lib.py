@@ -45,7 +45,7 @@ SIGNATURES = {
                                _vp, _sz, _u32, _vp, _vp, _vp, _vp]),
     'xr_ngp_train_step': (_i32, [_vp, _vp, _vp, _i32, _i32, _f, _i32, _i32, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _u32, _vp, _vp, _vp,
                                  _vp, _i32, _i32, _f, _f, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _sz, _i32, _vp, _sz,
-                                 _vp, _sz, C.c_char_p, _vp, _vp, _vp]),
+                                 _vp, _sz, _i32, C.c_char_p, _vp, _vp, _vp]),
     'xr_timing_event_create': (_vp, []),
     'xr_timing_event_destroy': (_i32, [_vp]),
     'xr_timing_event_elapsed_ms': (_i32, [_vp, _vp, _vp]),
@@ -63,7 +63,7 @@ SIGNATURES = {
     'xr_huber_loss_grad': (_i32, [_vp, _vp, _u32, _f, _f, _vp, _vp, _vp]),
     'xr_huber_loss_grad_mse': (_i32, [_vp, _vp, _vp, _u32, _f, _f, _vp, _vp, _vp]),
     'xr_make_batch': (_i32, [_vp, _u32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    'xr_adam_step_multi': (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f, _f, _f, _f, _f, _f, _vp]),
+    'xr_adam_step_multi': (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f, _f, _f, _f, _f, _f, _f, _vp]),
     'xr_scale_multi': (_i32, [_i32, _vp, _vp, _vp, _f, _vp]),
     'xr_adam_step': (_i32, [_vp, _vp, _vp, _vp, _sz, _i32, _f, _f, _f, _f, _f, _vp, _f, _vp]),
     'xr_mip_zvals': (_i32, [_vp, _vp, _u32, _u32, _i32, _vp, _vp, _vp]),

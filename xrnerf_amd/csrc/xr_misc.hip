@@ -128,8 +128,11 @@ extern "C" int xr_make_batch(const float* rays_rgb_rows, uint32_t n, uint64_t rn
 
 // ------------------------------------------------------------------ fused Adam (+L2 weight decay, + optional EMA)
 // torch.optim.Adam semantics; one pass over p,g,m,v(,ema): 16 B per lane per stream.
+// gs: a factor on the incoming gradient (1/world_size of data-parallel averaging, applied here instead of in a pass of its
+// own over the 48.8-MB gradient); rounded on its own first, so the update is bit for bit the one of `g *= gs` + this kernel
 __device__ inline void adam1(float& p, float g, float& m, float& v, float b1, float b2, float step_size, float bc2s,
-                             float eps, float wd) {
+                             float eps, float wd, float gs = 1.f) {
+    g = __fmul_rn(g, gs);
     g = g + wd * p;
     m = b1 * m + (1.f - b1) * g;
     v = b2 * v + (1.f - b2) * g * g;
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
 // block ranges are assigned proportionally, every tensor gets at least one block
 struct AdamTensors { float* p[4]; const float* g[4]; float* m[4]; float* v[4]; float* ema[4]; unsigned long long n[4]; unsigned first_block[5]; };
 __global__ __launch_bounds__(256) void k_adam_multi(AdamTensors t, int nt, float b1, float b2, float step_size, float bc2s,
-                                                     float eps, float wd, float mom) {
+                                                     float eps, float wd, float mom, float gs) {
     int k = 0;
 #pragma unroll
     for (int j = 1; j < 4; ++j) if (j < nt && blockIdx.x >= t.first_block[j]) k = j;
@@ -177,10 +180,10 @@ __global__ __launch_bounds__(256) void k_adam_multi(AdamTensors t, int nt, float
     for (size_t i = blk * 256ull + threadIdx.x; i < n4; i += (size_t)nblk * 256) {
         float4 pp = ((float4*)p)[i], mm = ((float4*)m)[i], vv = ((float4*)v)[i];
         const float4 gg = ((const float4*)g)[i];
-        adam1(pp.x, gg.x, mm.x, vv.x, b1, b2, step_size, bc2s, eps, wd);
-        adam1(pp.y, gg.y, mm.y, vv.y, b1, b2, step_size, bc2s, eps, wd);
-        adam1(pp.z, gg.z, mm.z, vv.z, b1, b2, step_size, bc2s, eps, wd);
-        adam1(pp.w, gg.w, mm.w, vv.w, b1, b2, step_size, bc2s, eps, wd);
+        adam1(pp.x, gg.x, mm.x, vv.x, b1, b2, step_size, bc2s, eps, wd, gs);
+        adam1(pp.y, gg.y, mm.y, vv.y, b1, b2, step_size, bc2s, eps, wd, gs);
+        adam1(pp.z, gg.z, mm.z, vv.z, b1, b2, step_size, bc2s, eps, wd, gs);
+        adam1(pp.w, gg.w, mm.w, vv.w, b1, b2, step_size, bc2s, eps, wd, gs);
         ((float4*)p)[i] = pp; ((float4*)m)[i] = mm; ((float4*)v)[i] = vv;
         if (ema) {
             float4 e = ((float4*)ema)[i];
@@ -192,14 +195,14 @@ __global__ __launch_bounds__(256) void k_adam_multi(AdamTensors t, int nt, float
     if (blk == 0 && threadIdx.x < (n & 3)) {
         const size_t i = n4 * 4 + threadIdx.x;
         float pp = p[i], mm = m[i], vv = v[i];
-        adam1(pp, g[i], mm, vv, b1, b2, step_size, bc2s, eps, wd);
+        adam1(pp, g[i], mm, vv, b1, b2, step_size, bc2s, eps, wd, gs);
         p[i] = pp; m[i] = mm; v[i] = vv;
         if (ema) ema[i] = (1.f - mom) * ema[i] + mom * pp;
     }
 }
 extern "C" int xr_adam_step_multi(int n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v,
                                   float* const* ema, const size_t* n, int step, float lr, float beta1, float beta2, float eps,
-                                  float weight_decay, float ema_momentum, void* stream_) {
+                                  float weight_decay, float ema_momentum, float grad_scale, void* stream_) {
     XR_REQUIRE(n_tensors >= 1 && n_tensors <= 4 && p && g && m && v && n && step >= 1, "bad argument");
     AdamTensors t; memset(&t, 0, sizeof(t));
     unsigned blocks = 0;
@@ -214,7 +217,7 @@ extern "C" int xr_adam_step_multi(int n_tensors, float* const* p, const float* c
     for (int k = n_tensors; k <= 4; ++k) t.first_block[k] = blocks;
     const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
     hipLaunchKernelGGL(k_adam_multi, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, t, n_tensors, beta1, beta2, lr / bc1,
-                       sqrtf(bc2), eps, weight_decay, ema_momentum);
+                       sqrtf(bc2), eps, weight_decay, ema_momentum, grad_scale);
     XR_LAUNCH_CHECK();
     return XR_OK;
 }

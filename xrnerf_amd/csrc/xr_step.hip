@@ -32,12 +32,13 @@ extern "C" int xr_ngp_train_step(
     float* enc_t, uint32_t ld, float* raw, float* draw, float* denc_t, float* rgb_out,
     float* zero_block, size_t zero_floats, float* grad_w_density, float* grad_w_color, float* loss_mse,
     float* grad_table, size_t table_floats, int zero_draw,
-    void* ws_mlp_bwd, size_t ws_mlp_bwd_bytes, void* ws_scatter, size_t ws_scatter_bytes,
+    void* ws_mlp_bwd, size_t ws_mlp_bwd_bytes, void* ws_scatter, size_t ws_scatter_bytes, int scatter_level0,
     const char* timed_entry, void* timing_begin, void* timing_end, void* stream_) {
     XR_REQUIRE(table && w_density && w_color && coords && rays_numsteps && rays_numsteps_compacted && bg_color && target &&
                alpha_mask && density_grid_mean && enc_t && raw && draw && denc_t && rgb_out && zero_block && grad_w_density &&
                grad_w_color && loss_mse && grad_table, "null pointer");
     XR_REQUIRE(n_rows > 0 && n_rays > 0 && ld >= n_rows, "bad sizes");
+    XR_REQUIRE(scatter_level0 >= 0 && scatter_level0 < n_levels, "scatter_level0 outside [0, n_levels)");
     XR_REQUIRE(!timed_entry || (timing_begin && timing_end), "a timed entry point needs its two events");
     hipStream_t stream = (hipStream_t)stream_;
     // XR_STEP_OVERLAP=1 (measurement; default off): work that only LATER stages need goes to a helper stream --
@@ -106,7 +107,11 @@ extern "C" int xr_ngp_train_step(
         XR_HIP(hipStreamWaitEvent(stream, ev_zero, 0));                // the table gradient is zero from here on
     }
     if ((rc = begin("xr_hashgrid_bwd")) != XR_OK) return rc;
-    rc = xr_hashgrid_bwd(coords, 7, denc_t, ld, n_rows, n_live, rows, n_levels, scale_host, resolution_host, offset_host, grad_table,
+    // data-parallel callers scatter the levels below scatter_level0 themselves (xr_hashgrid_bwd with the same row list, found
+    // through xr_nerf_mlp_bwd_list_slots) AFTER handing the finer levels' gradient slice to the collective: table offsets are
+    // absolute, so the level metadata is simply passed from that level on
+    rc = xr_hashgrid_bwd(coords, 7, denc_t + (size_t)2 * scatter_level0 * ld, ld, n_rows, n_live, rows, n_levels - scatter_level0,
+                         scale_host + scatter_level0, resolution_host + scatter_level0, offset_host + scatter_level0, grad_table,
                          ws_scatter, ws_scatter_bytes, stream_);
     if (rc != XR_OK) return rc;
     if ((rc = end("xr_hashgrid_bwd")) != XR_OK) return rc;

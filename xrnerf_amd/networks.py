@@ -100,13 +100,14 @@ class _FusedTrainStepFn(torch.autograd.Function):
             finally:
                 sampler.on_sampled = cb
             sync = getattr(net, 'grad_sync', None)
-            if sync is None and table.is_cuda and mlp.density_net.n_hidden == 1 and mlp.color_net.n_hidden == 2 and \
+            if table.is_cuda and mlp.density_net.n_hidden == 1 and mlp.color_net.n_hidden == 2 and \
                     os.environ.get('XRNERF_PY_STEP') != '1' and (ops.TIMER is None or ops.TIMER.native_stage()[0]):
-                # single GPU: the whole device side of the step as ONE native call (csrc/xr_step.hip) -- the same entry points
-                # in the same order as the Python sequence below, which stays for the data-parallel path (gradient buckets
-                # are handed to RCCL between the scatter halves), for the kernels' host build, and whenever a KernelTimer
-                # wants events around the individual entry points (bench.py's roofline windows; the step is bound by the
-                # device either way: 0.736-0.740 ms with both)
+                # the whole device side of the step as ONE native call (csrc/xr_step.hip) -- the same entry points in the same
+                # order as the Python sequence below, which stays for the kernels' host build and whenever a KernelTimer wants
+                # events around the individual entry points (bench.py's roofline windows).  Data parallel: the native call
+                # stops after the scatter of the 8 finest hash levels; their 32-MB gradient slice goes to the collective, which
+                # then runs under the scatter of the coarser levels (one more native call) -- the same bucket protocol as the
+                # Python sequence, without ~0.5 ms of interpreter time per iteration on every rank
                 n_rows = sampler.coords.shape[0]
                 sets = getattr(net, '_step_bufs', None)
                 n_rays = sampler.rays_numsteps.shape[0]
@@ -117,16 +118,28 @@ class _FusedTrainStepFn(torch.autograd.Function):
                     net._step_turn = 0
                 net._step_turn ^= 1                 # two sets alternate: the one the optimiser still holds as .grad is not reused
                 b = sets[net._step_turn]
-                rgb = ops.ngp_train_step(table, wd, wc, 1, 2, mlp.pad_value, mlp.embedder_pos.meta, sampler.coords, data.get('n_valid_dev'),
+                meta = mlp.embedder_pos.meta
+                split = meta.n_levels - 8 if (sync is not None and meta.n_levels > 8) else 0
+                rgb = ops.ngp_train_step(table, wd, wc, 1, 2, mlp.pad_value, meta, sampler.coords, data.get('n_valid_dev'),
                                          sampler.rays_numsteps, sampler.rays_numsteps_compacted, data['bg_color'],
                                          data['target_s'].contiguous(), data['alpha'].contiguous(), sampler.density_grid_mean,
-                                         int(sampler.rgb_activation), int(sampler.density_activation), b)
+                                         int(sampler.rgb_activation), int(sampler.density_activation), b, scatter_level0=split)
+                if sync is not None:
+                    sync.ready(b.g_mlp)
+                    if split:
+                        cut = 2 * int(meta.offset[split])
+                        sync.ready(b.g_table[cut:])
+                        ops.hashgrid_bwd(sampler.coords[:n_rows], b.denc_t, meta, b.g_table, live=b.live, levels=(0, split))
+                        sync.ready(b.g_table[:cut])
+                    else:
+                        sync.ready(b.g_table)
                 if cb is not None:
                     cb()
                 ctx.grads = (b.g_table, b.g_wd, b.g_wc)
                 ctx.params = (table, wd, wc)
-                ctx.sync = None
+                ctx.sync = sync
                 ctx.unit_root_grad = getattr(net, '_unit_root_grad', None)
+                ctx.net = net
                 ctx.mark_non_differentiable(rgb)
                 ctx.set_materialize_grads(False)
                 net._last = {'rgb': rgb, 'loss_mse': b.loss_mse, 'raw': b.raw}
@@ -184,6 +197,7 @@ class _FusedTrainStepFn(torch.autograd.Function):
         ctx.params = (table, wd, wc)
         ctx.sync = getattr(net, 'grad_sync', None)
         ctx.unit_root_grad = getattr(net, '_unit_root_grad', None)
+        ctx.net = net
         ctx.mark_non_differentiable(rgb)
         ctx.set_materialize_grads(False)         # no zero-filled dL/drgb tensor for the non-differentiable output
         net._last = {'rgb': rgb, 'loss_mse': loss_mse, 'raw': raw}
@@ -199,7 +213,14 @@ class _FusedTrainStepFn(torch.autograd.Function):
         if g is None:                            # only the non-differentiable output was used downstream
             return None, None, None, None, None
         unit = ctx.unit_root_grad
-        if not (factor == 1.0 and unit is not None and g.data_ptr() == unit.data_ptr()):
+        is_unit = unit is not None and g.data_ptr() == unit.data_ptr()
+        net = ctx.net
+        ctx.net = None
+        if factor != 1.0 and is_unit and getattr(net, '_defer_grad_scale', False):
+            # data parallel, trainer-owned optimiser: .grad keeps the all-reduced SUM and the optimiser multiplies by
+            # 1/world_size while it reads the gradient (xr_adam_step_multi's grad_scale) -- no scaling pass over 48.8 MB
+            net._pending_grad_scale = getattr(net, '_pending_grad_scale', 1.0) * factor
+        elif not (factor == 1.0 and is_unit):
             # (the trainer back-propagates from a persistent all-ones root gradient it registers as
             # `net._unit_root_grad`: the scaling launch -- which would read that 1.0 and do nothing -- is skipped then)
             g = g.reshape(1) if g.dtype == torch.float32 and ops._on_device(g) else g.to(grads[0].device, torch.float32).reshape(1)

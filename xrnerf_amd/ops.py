@@ -272,9 +272,11 @@ class TrainStepBuffers:
 
 
 def ngp_train_step(table, wd, wc, nhd, nhc, pad_value, meta, coords, n_dev, numsteps, numsteps_c, bg, target, alpha,
-                   density_grid_mean, rgb_act, density_act, bufs, huber_delta=0.1, loss_scale=5.0):
+                   density_grid_mean, rgb_act, density_act, bufs, huber_delta=0.1, loss_scale=5.0, scatter_level0=0):
     """the device work of one HashNerfNetwork training step as one native call (xr_ngp_train_step): encode -> MLP -> K3 +
-    Huber + K4 -> MLP backward -> table scatter into `bufs` (TrainStepBuffers).  Returns rgb [n_rays,3] (a view of bufs.rgb)."""
+    Huber + K4 -> MLP backward -> table scatter into `bufs` (TrainStepBuffers).  Returns rgb [n_rays,3] (a view of bufs.rgb).
+    scatter_level0 > 0 (data parallel): only hash levels [scatter_level0, n_levels) are scattered; the caller finishes with
+    hashgrid_bwd(..., live=bufs.live, levels=(0, scatter_level0)) after handing the finer slice to its collective."""
     L = _lib.load()
     n_rays = numsteps.shape[0]
     n_rows = bufs.n_rows
@@ -285,7 +287,8 @@ def ngp_train_step(table, wd, wc, nhd, nhc, pad_value, meta, coords, n_dev, nums
     ws_sc = _ws(coords.device, L.xr_hashgrid_bwd_workspace_bytes(n_rows, meta.n_levels, r, o), 'hgb')
     # the backward's (count, running live total, running valid total) block sits in the MLP workspace on this path
     global LIVE_STATS
-    ws_mlp, _, _, LIVE_STATS = _list_slots(coords.device, n_rows)
+    ws_mlp, live_list, _, LIVE_STATS = _list_slots(coords.device, n_rows)
+    bufs.live = (live_list, LIVE_STATS)
     stage, ev = None, (None, None)
     if TIMER is not None:
         ok, stage = TIMER.native_stage()
@@ -302,7 +305,7 @@ def ngp_train_step(table, wd, wc, nhd, nhc, pad_value, meta, coords, n_dev, nums
             _ptr(bufs.enc_t), bufs.ld, _ptr(bufs.raw), _ptr(bufs.draw), _ptr(bufs.denc_t), _ptr(bufs.rgb),
             _ptr(bufs.zero_block), bufs.zero_block.numel(), _ptr(bufs.g_wd), _ptr(bufs.g_wc), _ptr(bufs.loss_mse),
             _ptr(bufs.g_table), bufs.g_table.numel(), 0 if n_dev is not None else 1,
-            _ptr(ws_mlp), ws_mlp.numel(), _ptr(ws_sc), ws_sc.numel(), stage.encode() if stage else None,
+            _ptr(ws_mlp), ws_mlp.numel(), _ptr(ws_sc), ws_sc.numel(), int(scatter_level0), stage.encode() if stage else None,
             ev[0].h if stage else None, ev[1].h if stage else None, _stream()), 'xr_ngp_train_step')
     return bufs.rgb[:n_rays]
 
@@ -635,8 +638,8 @@ def scale_multi(ts, scale_dev=None, host_factor=1.0):
 
 
 def adam_step_multi(ps, gs, ms, vs, step, lr=1e-2, beta1=0.9, beta2=0.99, eps=1e-15, weight_decay=1e-6, emas=None,
-                    ema_momentum=0.05):
-    """one launch for up to 4 tensors"""
+                    ema_momentum=0.05, grad_scale=1.0):
+    """one launch for up to 4 tensors; `grad_scale` multiplies the gradients as they are read (the buffers stay as they are)"""
     k = len(ps)
     arr = lambda ts: (C.c_void_p * k)(*[t.data_ptr() if t is not None else None for t in ts])
     for t in list(ps) + list(gs) + list(ms) + list(vs):
@@ -644,7 +647,8 @@ def adam_step_multi(ps, gs, ms, vs, step, lr=1e-2, beta1=0.9, beta2=0.99, eps=1e
     ns = (C.c_size_t * k)(*[p.numel() for p in ps])
     with _span('xr_adam_step', sum(p.numel() for p in ps)):
         _lib.check(_lib.load().xr_adam_step_multi(k, arr(ps), arr(gs), arr(ms), arr(vs), arr(emas) if emas else None, ns,
-                                                  step, lr, beta1, beta2, eps, weight_decay, ema_momentum, _stream()),
+                                                  step, lr, beta1, beta2, eps, weight_decay, ema_momentum, float(grad_scale),
+                                                  _stream()),
                    'xr_adam_step_multi')
 
 

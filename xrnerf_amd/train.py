@@ -52,7 +52,9 @@ class FusedAdam(torch.optim.Optimizer):
                                       ema_momentum=ema_momentum, ema_warm_up=ema_warm_up))
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, grad_scale=1.0):
+        """`grad_scale`: factor on every gradient as the update reads it (the data-parallel trainer passes the 1/world_size
+        its fused step left out: same update as scaling the gradients first, one 98-MB pass over them less)"""
         for group in self.param_groups:
             todo = []
             for p in group['params']:
@@ -77,7 +79,7 @@ class FusedAdam(torch.optim.Optimizer):
                 mom = min(group['ema_momentum'], (1.0 + it) / (group['ema_warm_up'] + it)) if emas else 0.0
                 ops.adam_step_multi([c[0] for c in chunk], [c[1] for c in chunk], [c[2]['m'] for c in chunk],
                                     [c[2]['v'] for c in chunk], chunk[0][2]['step'], group['lr'], group['betas'][0],
-                                    group['betas'][1], group['eps'], group['weight_decay'], emas, mom)
+                                    group['betas'][1], group['eps'], group['weight_decay'], emas, mom, grad_scale=grad_scale)
 
 
 def step_lr(base_lr, it, step=10000, gamma=0.2):
@@ -194,6 +196,9 @@ class Trainer:
         if world_size > 1:
             from . import dist as xdist                 # fused step: bucketed reduction under the table scatter
             self.net.grad_sync = xdist.BucketedGradSync(world_size)
+            # this trainer's optimiser applies the 1/world_size itself (FusedAdam.step(grad_scale=...)): the fused step leaves
+            # the SUMMED gradients in .grad and reports the factor in net._pending_grad_scale
+            self.net._defer_grad_scale = os.environ.get('XRNERF_DEFER_GRAD_SCALE', '1') != '0'
         self.rays_done = 0
         self.lazy_log = True
         # run K1 of the next batch on a side stream under this step's backward (XRNERF_OVERLAP_MARCH=0: serial)
@@ -224,7 +229,8 @@ class Trainer:
         if self.world_size > 1 and not net._fused_ok():
             from . import dist as xdist                 # modular step: reduce after backward (DDP semantics)
             xdist.allreduce_grads([p for p in net.parameters() if p.grad is not None], self.world_size)
-        self.opt.step()
+        self.opt.step(grad_scale=getattr(net, '_pending_grad_scale', 1.0))
+        net._pending_grad_scale = 1.0
         data.set_batchsize(net.sampler.n_rays_per_batch)                  # ModifyBatchsizeHook
         self.iter += 1
         self.rays_done += n_rays
