@@ -598,9 +598,18 @@ def main():
             achieved, peak, unit = work / (total_ms * 1e-3) / 1e9, HBM_PEAK_GBS, 'GB/s'
         else:
             achieved, peak, unit = work / (total_ms * 1e-3) / 1e12, MFMA_PEAK[ops.precision()], 'TFLOP/s'
+        split = name == 'xr_nerf_mlp_fwd' and ops._mlp_mode() == 2
+        if split:
+            peak = MFMA_PEAK['f16']              # the kernel runs on the bf16 matrix cores (same dense peak as fp16)
         out = {'kernel': name, 'bound': bound, 'achieved': achieved, 'peak': peak, 'unit': unit, 'frac': achieved / peak,
                'avg_launch_us': total_ms * 1e3 / max(launches, 1), 'launches': launches,
                'algorithmic_per_sample': per_unit, 'algorithmic_bytes_or_flops_per_launch': work / max(launches, 1)}
+        if split:
+            out['arithmetic'] = ('xr_nerf_mlp_fwd_bf16x3: fp32 operands split exactly into 3 bf16 parts, 6 v_mfma_f32_32x32x16_bf16 per '
+                                 'product block, fp32 accumulate (fp32-rounding accuracy); priced on the ALGORITHMIC flops against the '
+                                 'bf16 MFMA peak -- the matrix cores execute 6x these flops (issued_frac)')
+            out['issued_frac'] = 6.0 * achieved / peak
+            out['frac_of_fp32_mfma_peak'] = achieved / MFMA_F32_PEAK_TFLOPS
         if name in LIVE_KERNELS:
             out['live_row_fraction'] = live_frac
             out['units'] = 'samples with a non-zero output gradient (the rows the launch processes); the others are exact zeros'
@@ -685,9 +694,12 @@ def main():
                                    'K6..K11 with its density queries: %d refreshes in the window = round(steps/16), encode, MLP, K3, 5*Huber, K4, '
                                    'MLP backward, table scatter, %sfused Adam+EMA over 12.2 M parameters) after %d un-timed '
                                    'pre-roll + %d warm-up iterations (adaptive batch at its fixed point: %s rays); the '
-                                   'reference\'s dead no-grad MLP pass that only feeds K2\'s dead transmittance loop is skipped'
+                                   'reference\'s dead no-grad MLP pass that only feeds K2\'s dead transmittance loop is skipped; fused-MLP '
+                                   'forward: %s'
                                    % (args.n_img, it0, it1 - 1, n_refresh, 'gradient all-reduce, ' if world > 1 else '',
-                                      preroll, args.warmup + align, hist[-1]),
+                                      preroll, args.warmup + align, hist[-1],
+                                      'fp32 via exact 3-way bf16 operand split on the bf16 MFMA (xr_nerf_mlp_fwd_bf16x3)' if ops._mlp_mode() == 2
+                                      else 'fp32 MFMA'),
                        'rays_per_step': rays_all / args.steps / world, 'samples_per_ray': samples_all / max(rays_all, 1),
                        'samples_per_s': samples_all / elapsed_max, 'n_images': args.n_img,
                        'preroll_iterations': preroll, 'timed_iterations': [it0, it1 - 1], 'grid_refreshes_in_window': n_refresh,

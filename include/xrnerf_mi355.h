@@ -244,18 +244,27 @@ int xr_nerf_mlp_bwd_f16(const float* enc_t, uint32_t ld, const float* dirs, uint
                         float* grad_w_color, void* workspace, size_t workspace_bytes, const uint32_t* live_rows,
                         const uint32_t* n_live, void* stream);
 
+/* The fp32 forward on the bf16 matrix cores: every fp32 operand is split EXACTLY into three bf16 numbers (8 + 8 + 8
+ * significand bits) and a product is carried by the six bf16 x bf16 MFMA terms above 2^-23 of it (fp32 accumulate) --
+ * fp32-rounding accuracy at 0.375 of the fp32-MFMA matrix-core time.  Same contract as xr_nerf_mlp_fwd (parity mode: same
+ * 1e-4 bar against the oracle); results differ from it the way two fp32 summation orders differ.  Topology (1, 2) only. */
+int xr_nerf_mlp_fwd_bf16x3(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
+                           const uint32_t* n_dev, const uint32_t* rows, const float* w_density, const float* w_color,
+                           int n_hidden_density, int n_hidden_color, float pad_value, float* raw, void* stream);
+
 /* One training step's device work of HashNerfNetwork.train_step (networks/hashnerf.py:32-52, optimiser excluded) as ONE call:
  * xr_hashgrid_fwd -> xr_nerf_mlp_fwd[_f16] -> zero-fill of `zero_block` (which must contain grad_w_density, grad_w_color and
  * loss_mse) -> xr_composite_train -> zero-fill of grad_table -> xr_nerf_mlp_bwd[_f16] -> xr_hashgrid_bwd, on `stream`.
  * coords: K1's [n_rows,7] rows (positions / directions consumed in place); n_dev: device count of valid rows; every buffer
  * is caller-owned (enc_t / denc_t [32][ld], raw / draw [n_rows,4], rgb_out [n_rays,3]); zero_draw != 0 also clears draw
- * (needed only without n_dev).  scatter_level0: the step scatters hash levels [scatter_level0, n_levels) only (0 = all) -- a
+ * (needed only without n_dev).  mlp_mode: 0 = xr_nerf_mlp_fwd / _bwd (fp32 MFMA), 1 = the _f16 pair, 2 = xr_nerf_mlp_fwd_bf16x3
+ * + xr_nerf_mlp_bwd.  scatter_level0: the step scatters hash levels [scatter_level0, n_levels) only (0 = all) -- a
  * data-parallel caller hands that slice of grad_table to its gradient collective and then scatters the coarser levels with
  * xr_hashgrid_bwd on the same row list (xr_nerf_mlp_bwd_list_slots), so the exchange runs under the rest of the backward.
  * Same kernels and results as the separate calls -- this exists because issuing them one by
  * one from an interpreter costs as much host time as the kernels take on the device. */
 int xr_ngp_train_step(const float* table, const float* w_density, const float* w_color, int n_hidden_density, int n_hidden_color,
-                      float pad_value, int f16_mlp, int n_levels, const float* scale_host, const uint32_t* resolution_host,
+                      float pad_value, int mlp_mode, int n_levels, const float* scale_host, const uint32_t* resolution_host,
                       const uint32_t* offset_host, const float* coords, uint32_t n_rows, const uint32_t* n_dev,
                       const int32_t* rays_numsteps, const int32_t* rays_numsteps_compacted, uint32_t n_rays, const float* bg_color,
                       const float* target, const float* alpha_mask, const float* density_grid_mean, int rgb_activation,

@@ -152,6 +152,18 @@ inline emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16_emu(emu_h8 a, emu_h8 b,
     return c;
 }
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16 __builtin_amdgcn_mfma_f32_32x32x16_f16_emu
+// v_mfma_f32_32x32x16_bf16: the same operand / accumulator layout with bf16 operands (host __bf16: round-to-nearest-even
+// conversions like v_cvt_pk_bf16_f32)
+typedef __bf16 emu_b8 __attribute__((ext_vector_type(8)));
+inline emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16_emu(emu_b8 a, emu_b8 b, emu_f32x16 c, int, int, int) {
+    float fa[8], fb[8], t[16];
+    for (int e = 0; e < 8; ++e) { fa[e] = (float)a[e]; fb[e] = (float)b[e]; }
+    for (int r = 0; r < 16; ++r) t[r] = c[r];
+    emu::wave_mfma_32x32x16(fa, fb, t);
+    for (int r = 0; r < 16; ++r) c[r] = t[r];
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16 __builtin_amdgcn_mfma_f32_32x32x16_bf16_emu
 
 // cooperative fibers never pre-empt each other: plain read-modify-write is atomic here
 template <typename T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }

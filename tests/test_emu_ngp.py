@@ -61,9 +61,18 @@ def test_fused_mlp_on_the_host(O, edev):
     import test_gpu_tcnn as T
     T.test_grid_meta_matches_oracle(O, edev)
     T.test_sh4(O, edev)
-    for n in (1, 32, 33):
-        T.test_nerf_mlp_fwd(O, edev, n)
-    T.test_nerf_mlp_fwd_asymmetric_weights(O, edev)
+    from xrnerf_amd import ops
+    old = ops.f32_forward()
+    try:
+        for kind in ('bf16x3', 'mfma'):                 # the fixture of the GPU tests, by hand
+            ops.set_f32_forward(kind)
+            for n in (1, 32, 33):
+                T.test_nerf_mlp_fwd(O, edev, n, kind)
+            T.test_nerf_mlp_fwd_asymmetric_weights(O, edev, kind)
+    finally:
+        ops.set_f32_forward(old)
+    for n, nv in ((1, None), (33, None), (300, 250), (70, 0)):   # 8-wave workgroups: ragged tiles, device-side count
+        T.test_nerf_mlp_fwd_split_operands_equal_fp32_mfma(edev, n, nv)
     for n in (32, 100):
         T.test_nerf_mlp_bwd(O, edev, n)
 

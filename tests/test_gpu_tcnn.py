@@ -72,8 +72,18 @@ def nets(S):
     return wd, wc
 
 
+@pytest.fixture(params=['bf16x3', 'mfma'])
+def f32_forward(request):
+    """both forwards of the fp32 mode: bf16x3 = exact 3-way bf16 operand split on the bf16 matrix cores (default), mfma = fp32 MFMA"""
+    from xrnerf_amd import ops
+    old = ops.f32_forward()
+    ops.set_f32_forward(request.param)
+    yield request.param
+    ops.set_f32_forward(old)
+
+
 @pytest.mark.parametrize('n', [1, 32, 33, 1000, 40000])
-def test_nerf_mlp_fwd(O, dev, n):
+def test_nerf_mlp_fwd(O, dev, n, f32_forward):
     from xrnerf_amd import ops, synthetic as S
     meta = ops.GridMeta(); om = O.GridMeta()
     rng = np.random.default_rng(n)
@@ -91,7 +101,44 @@ def test_nerf_mlp_fwd(O, dev, n):
     assert np.abs(rd[:, 3] - ref[:, 3]).max() <= 1e-4
 
 
-def test_nerf_mlp_fwd_asymmetric_weights(O, dev):
+@pytest.mark.parametrize('n,n_valid', [(1, None), (33, None), (8191, 8000), (70001, None), (5000, 0)])
+def test_nerf_mlp_fwd_split_operands_equal_fp32_mfma(dev, n, n_valid):
+    """xr_nerf_mlp_fwd_bf16x3 against xr_nerf_mlp_fwd on the same inputs: activations spanning 1e-6 .. 1e2, weights of
+    mixed magnitude, a device-side row count, row-indirect directions.  Both are fp32-accurate evaluations of the same sums,
+    so they agree to a few ulp of the largest partial sum (here: 3e-6 of max|raw|), far inside the 1e-4 parity bar."""
+    from xrnerf_amd import ops, synthetic as S
+    rng = np.random.default_rng(7 * n + 1)
+    wd, wc = nets(S)
+    wd = (wd * rng.choice([0.01, 1.0, 4.0], wd.shape)).astype(np.float32)
+    ld = (n + 63) // 64 * 64
+    enc = np.zeros((32, ld), np.float32)
+    enc[:, :n] = (rng.normal(0, 1, (32, n)) * np.exp(rng.uniform(np.log(1e-6), np.log(1e1), (1, n)))).astype(np.float32)
+    dirs = rng.uniform(0, 1, (n + 7, 3)).astype(np.float32)
+    rows = rng.permutation(n + 7)[:n].astype(np.int32)
+    n_dev = None if n_valid is None else torch.tensor([n_valid], dtype=torch.int32, device=dev)
+    out = {}
+    old = ops.f32_forward()
+    try:
+        for kind in ('mfma', 'bf16x3'):
+            ops.set_f32_forward(kind)
+            raw = torch.full((n, 4), 7.0, dtype=torch.float32, device=dev)
+            ops.nerf_mlp_fwd(T(enc, dev), T(dirs, dev), n, T(wd, dev), T(wc, dev), 1, 2, raw=raw, n_dev=n_dev, rows=T(rows, dev))
+            dens = torch.full((n, 4), 7.0, dtype=torch.float32, device=dev)
+            ops.nerf_mlp_fwd(T(enc, dev), None, n, T(wd, dev), None, 1, 2, raw=dens, n_dev=n_dev)
+            out[kind] = (raw.cpu().numpy(), dens.cpu().numpy())
+    finally:
+        ops.set_f32_forward(old)
+    m = n if n_valid is None else n_valid
+    for a, b in zip(out['mfma'], out['bf16x3']):
+        assert np.all(a[m:] == 7.0) and np.all(b[m:] == 7.0)                   # rows behind the device-side count untouched
+        if m:
+            scale = np.abs(a[:m]).max()
+            assert np.isfinite(b[:m]).all() and np.abs(a[:m] - b[:m]).max() <= 3e-6 * scale, (np.abs(a[:m] - b[:m]).max(), scale)
+    if m:
+        assert np.array_equal(out['bf16x3'][0][:m, 3], out['bf16x3'][1][:m, 3])   # sigma: same arithmetic with and without the color net
+
+
+def test_nerf_mlp_fwd_asymmetric_weights(O, dev, f32_forward):
     """transpose / permutation detector: one-hot weights so that each output picks a known input."""
     from xrnerf_amd import ops
     n = 64

@@ -1096,6 +1096,195 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void k_nerf_mlp_bwd_h(
     for (int e = threadIdx.x; e < GW; e += MLP_THREADS) out[e] = redA[e] + redA[GW + e];
 }
 
+// ==================================================================================================================
+// fp32 results on the bf16 matrix cores: 3-way operand splitting
+// ==================================================================================================================
+// v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 rate (157 vs 2500 TFLOP/s).  A fp32 number is EXACTLY the sum of three
+// bf16 numbers (8 + 8 + 8 significand bits, same exponent range): x = xh + xm + xl with xh = bf16(x), xm = bf16(x - xh),
+// xl = bf16(x - xh - xm), both differences exact in fp32.  A product of two fp32 operands is then
+//     w.x = wh.xh + (wh.xm + wm.xh) + (wh.xl + wl.xh + wm.xm) + [wm.xl + wl.xm + wl.xl],
+// each bf16 x bf16 product exact in fp32; the bracket is below 2^-23 of |w||x| and is dropped, i.e. the six kept products
+// carry the product to fp32 rounding accuracy.  Six v_mfma_f32_32x32x16_bf16 (fp32 accumulate, smallest terms first)
+// replace eight v_mfma_f32_32x32x2_f32: 6 x 8 passes instead of 8 x 16 -- 0.375 of the matrix-core time -- and the operand
+// traffic from LDS drops 4x (three 16-B reads per 16 k's and 32 rows instead of eight 4-B reads per 2 k's).  This is the
+// forward of the fp32 parity mode (same 1e-4 bar against the oracle, tests/test_gpu_tcnn.py); the result differs from the
+// fp32-MFMA kernel at the level two fp32 summation orders differ.  Same tile / k-slot scheme as the fp16 kernels above:
+// activations go from the accumulators to the next layer's B operands by a register-local split, the weights sit in LDS
+// pre-split and pre-permuted (three copies of the fp16 kernels' [row][hi][t][8] arrangement: 84 KiB for both networks,
+// hence ONE workgroup of 8 waves per CU sharing them).  Topology (1, 2) only.
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+#define MFMA16B(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#define BX_WAVES 8
+#define BX_THREADS (BX_WAVES * 64)
+
+__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
+    h = (__bf16)x;
+    const float r1 = x - (float)h;          // exact
+    m = (__bf16)r1;
+    const float r2 = r1 - (float)m;         // exact
+    l = (__bf16)r2;
+}
+struct BTile { b8 p[3][2]; };                // a 32 x 32 tile as B operands: [hi | mid | lo part][K-step]
+__device__ __forceinline__ BTile to_b3(const f32x16& t) {
+    BTile r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        __bf16 h, m, l;
+        split3(t[e], h, m, l);     r.p[0][0][e] = h; r.p[1][0][e] = m; r.p[2][0][e] = l;
+        split3(t[8 + e], h, m, l); r.p[0][1][e] = h; r.p[1][1][e] = m; r.p[2][1][e] = l;
+    }
+    return r;
+}
+// global fp32 [out][in] -> LDS, three bf16 parts `ps` halves apart, each in the forward arrangement of store_layer_h
+template <int NH, int L>
+__device__ __forceinline__ void fetch_layer_b3(float (&v)[NetShape<NH>::out_rows_lds(L) * NetShape<NH>::in_dim(L) / BX_THREADS],
+                                               const float* __restrict__ w) {
+    using S = NetShape<NH>;
+    constexpr int K = S::in_dim(L), rows = S::out_dim(L), prow = S::out_rows_lds(L);
+    static_assert(prow * K % BX_THREADS == 0, "layer size must be a multiple of the workgroup size");
+    const float* src = w + S::glb_off(L);
+#pragma unroll
+    for (int i = 0; i < prow * K / BX_THREADS; ++i) {
+        const int x = threadIdx.x + i * BX_THREADS, o = x / K, c = x % K;
+        v[i] = src[(o < rows ? o : rows - 1) * K + c];                    // padded rows: any valid address, zeroed on store
+    }
+}
+template <int NH, int L>
+__device__ __forceinline__ void store_layer_b3(const float (&v)[NetShape<NH>::out_rows_lds(L) * NetShape<NH>::in_dim(L) / BX_THREADS],
+                                               __bf16* __restrict__ wf, int ps, bool first_layer_rot) {
+    using S = NetShape<NH>;
+    using H = HShape<NH>;
+    constexpr int K = S::in_dim(L), rows = S::out_dim(L), prow = S::out_rows_lds(L), ns = K / 16, rs = h_rs(K);
+    __bf16* dst = wf + H::f_off(L);
+#pragma unroll
+    for (int i = 0; i < prow * K / BX_THREADS; ++i) {
+        const int x = threadIdx.x + i * BX_THREADS, o = x / K, c = x % K;        // global [o][c]
+        const int m = (L == 0 && first_layer_rot) ? ((c + 1) & 31) : c;           // LDS slot of global column c
+        __bf16 h, mi, lo;
+        split3(o < rows ? v[i] : 0.f, h, mi, lo);
+        __bf16* d = dst + o * rs + hslot(m, ns);
+        d[0] = h; d[ps] = mi; d[2 * ps] = lo;
+    }
+}
+template <int NH>
+__device__ inline void load_weights_b3(__bf16* __restrict__ wf, int ps, const float* __restrict__ w, bool first_layer_rot) {
+    using S = NetShape<NH>;
+    static_assert(NH == 1 || NH == 2, "the split forward is built for 1 or 2 hidden layers");
+    float v0[S::out_rows_lds(0) * S::in_dim(0) / BX_THREADS], v1[S::out_rows_lds(1) * S::in_dim(1) / BX_THREADS];
+    float v2[NH >= 2 ? S::out_rows_lds(NH >= 2 ? 2 : 0) * S::in_dim(NH >= 2 ? 2 : 0) / BX_THREADS : 1];
+    fetch_layer_b3<NH, 0>(v0, w);                  // every global load in flight before the first LDS store
+    fetch_layer_b3<NH, 1>(v1, w);
+    if constexpr (NH >= 2) fetch_layer_b3<NH, 2>(v2, w);
+    store_layer_b3<NH, 0>(v0, wf, ps, first_layer_rot);
+    store_layer_b3<NH, 1>(v1, wf, ps, false);
+    if constexpr (NH >= 2) store_layer_b3<NH, 2>(v2, wf, ps, false);
+}
+// out[TO] = W . in[TI] to fp32 accuracy: per K-step and output tile three 16-B operand reads and six MFMAs.  The operand
+// reads of step t + 1 are issued before the MFMAs of step t, fenced by scheduling barriers: a scheduler free to hoist every
+// ds_read_b128 of a layer (12 VGPRs per step and output tile) to the top spills the accumulators (165 VGPRs of scratch).
+template <int TI, int TO>
+__device__ __forceinline__ void layer_fwd_b3(const __bf16* __restrict__ wf, int ps, const BTile (&in)[TI], f32x16 (&out)[TO], int col, int hi) {
+    constexpr int NS = 2 * TI, RS = 2 * NS * 8 + 8;
+#pragma unroll
+    for (int to = 0; to < TO; ++to)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[to][r] = 0.f;
+    const __bf16* wl = wf + col * RS + hi * NS * 8;
+    b8 a[2][TO][3];
+    auto load = [&](int t, b8 (&d)[TO][3]) {
+#pragma unroll
+        for (int to = 0; to < TO; ++to) {
+            const __bf16* p = wl + to * 32 * RS + t * 8;
+            d[to][0] = *reinterpret_cast<const b8*>(p);
+            d[to][1] = *reinterpret_cast<const b8*>(p + ps);
+            d[to][2] = *reinterpret_cast<const b8*>(p + 2 * ps);
+        }
+    };
+    load(0, a[0]);
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < NS) load(t + 1, a[(t + 1) & 1]);
+        const BTile& x = in[t >> 1];
+        const int k = t & 1;
+#pragma unroll
+        for (int to = 0; to < TO; ++to) {
+            const b8 ah = a[t & 1][to][0], am = a[t & 1][to][1], al = a[t & 1][to][2];
+            out[to] = MFMA16B(al, x.p[0][k], out[to]);
+            out[to] = MFMA16B(ah, x.p[2][k], out[to]);
+            out[to] = MFMA16B(am, x.p[1][k], out[to]);
+            out[to] = MFMA16B(am, x.p[0][k], out[to]);
+            out[to] = MFMA16B(ah, x.p[1][k], out[to]);
+            out[to] = MFMA16B(ah, x.p[0][k], out[to]);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <bool WITH_COLOR>
+__global__ __launch_bounds__(BX_THREADS, 1) void k_nerf_mlp_fwd_b3(const float* __restrict__ enc_t, uint32_t ld,
+                                                                    const float* __restrict__ dirs, uint32_t dir_stride,
+                                                                    uint32_t n, const uint32_t* __restrict__ n_dev,
+                                                                    const uint32_t* __restrict__ rows,
+                                                                    const float* __restrict__ w_density,
+                                                                    const float* __restrict__ w_color, float pad_value,
+                                                                    float4* __restrict__ raw) {
+    if (n_dev) n = min(n, *n_dev);
+    if (n == 0) return;
+    using HD = HShape<1>;
+    using HC = HShape<2>;
+    constexpr int PD = HD::f_halves, PC = HC::f_halves;             // halves per part
+    static_assert(PD % 8 == 0 && PC % 8 == 0, "parts must keep the 16-byte alignment of the operand reads");
+    extern __shared__ __attribute__((aligned(16))) __bf16 ldsb[];
+    __bf16* wd = ldsb;
+    __bf16* wc = ldsb + 3 * PD;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, hi = lane >> 5;
+    const uint32_t n_tiles = (n + 31) / 32, stride = gridDim.x * BX_WAVES;
+    uint32_t tile = blockIdx.x * BX_WAVES + wave;
+    // the first tile's inputs are in flight while the workgroup splits the weights
+    f32x16 x;
+    float d3[3] = {0.f, 0.f, 0.f};
+    auto fetch = [&](uint32_t tl, f32x16& xe, float (&dd)[3]) {
+        const uint32_t s = tl * 32 + col, sc = s < n ? s : n - 1;
+        load_enc_tile(enc_t, ld, sc, xe, hi);
+        if (WITH_COLOR) {
+            const float* d = dirs + (size_t)(rows ? rows[sc] : sc) * dir_stride;
+            dd[0] = d[0]; dd[1] = d[1]; dd[2] = d[2];
+        }
+    };
+    if (tile < n_tiles) fetch(tile, x, d3);
+    load_weights_b3<1>(wd, PD, w_density, false);
+    if (WITH_COLOR) load_weights_b3<2>(wc, PC, w_color, true);
+    __syncthreads();
+    for (; tile < n_tiles; tile += stride) {
+        const uint32_t s = tile * 32 + col;
+        BTile xin[1] = {to_b3(x)};
+        const float dx = d3[0], dy = d3[1], dz = d3[2];
+        if (tile + stride < n_tiles) fetch(tile + stride, x, d3);           // next tile's loads under this tile's MFMAs
+        f32x16 h[2], dout[1];
+        layer_fwd_b3<1, 2>(wd + HD::f_off(0), PD, xin, h, col, hi);
+        relu_tile(h[0]); relu_tile(h[1]);
+        BTile hh[2] = {to_b3(h[0]), to_b3(h[1])};
+        layer_fwd_b3<2, 1>(wd + HD::f_off(1), PD, hh, dout, col, hi);
+        float4 o = make_float4(0.f, 0.f, 0.f, dout[0][0]);
+        if (WITH_COLOR) {
+            f32x16 cin, cout[1];
+            const float dd[3] = {dx, dy, dz};
+            build_color_in(dout[0], dd, 3, 0, pad_value, cin, hi);
+            BTile ci[1] = {to_b3(cin)};
+            layer_fwd_b3<1, 2>(wc + HC::f_off(0), PC, ci, h, col, hi);
+            relu_tile(h[0]); relu_tile(h[1]);
+            hh[0] = to_b3(h[0]); hh[1] = to_b3(h[1]);
+            layer_fwd_b3<2, 2>(wc + HC::f_off(1), PC, hh, h, col, hi);
+            relu_tile(h[0]); relu_tile(h[1]);
+            hh[0] = to_b3(h[0]); hh[1] = to_b3(h[1]);
+            layer_fwd_b3<2, 1>(wc + HC::f_off(2), PC, hh, cout, col, hi);
+            o.x = cout[0][0]; o.y = cout[0][1]; o.z = cout[0][2];
+        }
+        if (hi == 0 && s < n) raw[s] = o;
+    }
+}
+
 // ------------------------------------------------------------------ host side
 static int g_cus = 0;
 extern "C" int xr_device_cus(void) {
@@ -1319,6 +1508,32 @@ extern "C" int xr_nerf_mlp_fwd_f16(const float* enc_t, uint32_t ld, const float*
     } else {
         const size_t lds = (size_t)HShape<1>::f_halves * 2;
         hipLaunchKernelGGL(k_nerf_mlp_fwd_h<false>, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev,
+                           rows, w_density, w_color, pad_value, (float4*)raw);
+    }
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}
+
+// fp32-accuracy forward on the bf16 matrix cores (3-way operand split; same contract as xr_nerf_mlp_fwd, topology (1, 2))
+extern "C" int xr_nerf_mlp_fwd_bf16x3(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
+                                      const uint32_t* n_dev, const uint32_t* rows, const float* w_density, const float* w_color,
+                                      int n_hidden_density, int n_hidden_color, float pad_value, float* raw, void* stream_) {
+    if (n == 0) return XR_OK;
+    XR_REQUIRE(enc_t && w_density && raw, "null pointer");
+    XR_REQUIRE(!dirs || (w_color && dir_stride >= 3), "color path needs w_color and dir_stride >= 3");
+    XR_REQUIRE(ld >= n && ((uintptr_t)raw & 15) == 0, "bad ld / raw alignment");
+    XR_REQUIRE(n_hidden_density == 1 && n_hidden_color == 2, "the split forward is built for the (1,2) hidden-layer topology");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int cus = xr_device_cus() > 0 ? xr_device_cus() : 256;
+    const uint32_t grid = min(xr_div_up((n + 31) / 32, BX_WAVES), (uint32_t)cus);          // resident: one 8-wave workgroup per CU
+    if (dirs) {
+        const size_t lds = (size_t)3 * (HShape<1>::f_halves + HShape<2>::f_halves) * 2;
+        XR_HIP(hipFuncSetAttribute((const void*)k_nerf_mlp_fwd_b3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_nerf_mlp_fwd_b3<true>, dim3(grid), dim3(BX_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev,
+                           rows, w_density, w_color, pad_value, (float4*)raw);
+    } else {
+        const size_t lds = (size_t)3 * HShape<1>::f_halves * 2;
+        hipLaunchKernelGGL(k_nerf_mlp_fwd_b3<false>, dim3(grid), dim3(BX_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev,
                            rows, w_density, w_color, pad_value, (float4*)raw);
     }
     XR_LAUNCH_CHECK();

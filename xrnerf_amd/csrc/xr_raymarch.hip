@@ -66,23 +66,6 @@ __device__ inline bool rm_occupied(float px, float py, float pz, const uint8_t* 
     uint32_t idx = xr_morton3d((uint32_t)ix, (uint32_t)iy, (uint32_t)iz);
     return (bf[(idx >> 3) + (uint32_t)mip * (XR_GRID_CELLS / 8)] >> (idx & 7)) & 1;
 }
-// The same test through a one-word register cache: the bit of Morton cell idx at cascade mip is bit (idx & 31) of the 32-bit
-// word (idx >> 5) + mip * cells/32 (little endian; the bitfield is 4-byte aligned, checked on the host), and 32 consecutive
-// Morton indices are one 4x4x2 block of cells.  A march revisits the word it just read most of the time -- 4-5 samples fall
-// into one occupied cell at the minimum step, and an empty-space step moves to a face neighbour, which is inside the same
-// block two times out of three -- so the dependent ~0.6-us load of the per-step chain is only issued when the word changes.
-// Same decisions bit for bit.
-__device__ inline bool rm_occupied_cached(float px, float py, float pz, const uint32_t* __restrict__ bf32, int mip,
-                                          uint32_t& c_idx, uint32_t& c_word) {
-    float s = scalbnf(1.0f, -mip);
-    float qx = (px - 0.5f) * s + 0.5f, qy = (py - 0.5f) * s + 0.5f, qz = (pz - 0.5f) * s + 0.5f;
-    int ix = (int)(qx * 128.0f), iy = (int)(qy * 128.0f), iz = (int)(qz * 128.0f);
-    ix = min(max(ix, 0), 127); iy = min(max(iy, 0), 127); iz = min(max(iz, 0), 127);
-    const uint32_t idx = xr_morton3d((uint32_t)ix, (uint32_t)iy, (uint32_t)iz);
-    const uint32_t wi = (idx >> 5) + (uint32_t)mip * (XR_GRID_CELLS / 32);
-    if (wi != c_idx) { c_word = bf32[wi]; c_idx = wi; }
-    return (c_word >> (idx & 31u)) & 1u;
-}
 __device__ inline float rm_lt_min(float a, float b) { return a < b ? a : b; }  // reference `min` = a<b?a:b
 __device__ inline float rm_advance(float t, float cone, float px, float py, float pz, const Ray& r, uint32_t res) { // :271-296
     float rf = (float)res;
@@ -122,10 +105,13 @@ __device__ inline Ray rm_load_ray(const float* __restrict__ o, const float* __re
 
 // ------------------------------------------------------------------ K1 pass A: count (ray_sampler.cu:26-74)
 // One ray per lane: a chain of dependent bitfield-byte loads (~0.6 us each from L2) plus ~150 VALU instructions per
-// visited lattice point.  Measured dead end: marching 4 rays per lane in lock step (4 loads in flight per lane)
+// visited lattice point.  The arithmetic is the bound, not the load: keeping the last 32-bit word of the bitfield in a
+// register (32 consecutive Morton indices = one 4x4x2 block of cells, so most steps re-use it and skip the load) made the
+// pass 5 % SLOWER (12.5 K rays: 176 -> 184 us, profiles/r02_k1_word_cache_ab.txt) -- the compare / branch per step costs
+// more than the loads it saves.  Measured dead end: marching 4 rays per lane in lock step (4 loads in flight per lane)
 // is 3.5x SLOWER (172 -> 612 us on 12.5 K rays) -- the per-point arithmetic at 4 cycles per wave64 instruction
 // then dominates and a wave lasts as long as the longest of 256 rays instead of 64.
-template <bool WORD_CACHE> __global__ __launch_bounds__(RM_BLOCK) void k1_count(
+__global__ __launch_bounds__(RM_BLOCK) void k1_count(
     uint32_t n_rays, float lo, float hi, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
     const uint8_t* __restrict__ bitfield, float cone, float near_distance, xr_pcg32 rng,
     uint32_t* __restrict__ cnt, uint32_t* __restrict__ local_off, float* __restrict__ start_t,
@@ -140,14 +126,12 @@ template <bool WORD_CACHE> __global__ __launch_bounds__(RM_BLOCK) void k1_count(
         startt = tmin;
         startt += rm_calc_dt(startt, cone) * rng.next_float();               // :50
         float t = startt;
-        uint32_t c_idx = 0xffffffffu, c_word = 0u;
         for (;;) {                                                           // :58-72
             float px = r.ox + t * r.dx, py = r.oy + t * r.dy, pz = r.oz + t * r.dz;
             if (!(rm_contains(lo, hi, px, py, pz) && j < XR_NERF_STEPS)) break;
             float dt = rm_calc_dt(t, cone);
             int mip = rm_mip_from_dt(dt, px, py, pz);
-            if (WORD_CACHE ? rm_occupied_cached(px, py, pz, reinterpret_cast<const uint32_t*>(bitfield), mip, c_idx, c_word)
-                           : rm_occupied(px, py, pz, bitfield, mip)) {
+            if (rm_occupied(px, py, pz, bitfield, mip)) {
                 // a sample is fully determined by its t: remember the first K1_TL of them so that the
                 // write pass can expand them sample-parallel instead of re-marching
                 if (j < K1_TL) tlist[(size_t)i * K1_TL + j] = t;
@@ -313,14 +297,8 @@ extern "C" int xr_rays_sampler(const float* rays_o, const float* rays_d, const u
     RmWorkspace w; rm_ws_layout(n_rays, (char*)workspace, &w);
     xr_pcg32 rng{rng_state, rng_inc};
     const uint32_t nb = xr_div_up(n_rays, RM_BLOCK);
-    // XR_K1_WORD_CACHE=0: one byte load per visited lattice point (measurement); an unaligned bitfield takes that path too
-    static const bool word_cache = []() { const char* e = getenv("XR_K1_WORD_CACHE"); return !(e && e[0] == '0'); }();
-    if (word_cache && ((uintptr_t)bitfield & 3) == 0)
-        hipLaunchKernelGGL(k1_count<true>, dim3(nb), dim3(RM_BLOCK), 0, stream, n_rays, aabb0, aabb1, rays_o, rays_d, bitfield,
-                           cone_angle, near_distance, rng, w.cnt, w.local_off, w.start_t, w.block_tot, w.tlist);
-    else
-        hipLaunchKernelGGL(k1_count<false>, dim3(nb), dim3(RM_BLOCK), 0, stream, n_rays, aabb0, aabb1, rays_o, rays_d, bitfield,
-                           cone_angle, near_distance, rng, w.cnt, w.local_off, w.start_t, w.block_tot, w.tlist);
+    hipLaunchKernelGGL(k1_count, dim3(nb), dim3(RM_BLOCK), 0, stream, n_rays, aabb0, aabb1, rays_o, rays_d, bitfield,
+                       cone_angle, near_distance, rng, w.cnt, w.local_off, w.start_t, w.block_tot, w.tlist);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, nb, w.block_tot, max_samples, w.block_base, w.info);
     hipLaunchKernelGGL(k1_write, dim3(nb), dim3(RM_BLOCK), 0, stream, n_rays, aabb0, aabb1, rays_o, rays_d, bitfield,
                        cone_angle, max_samples, w.cnt, w.local_off, w.start_t, w.block_base, w.info, coords_out,

@@ -25,7 +25,7 @@ static bool stage_is(const char* timed, const char* name) { return timed && strc
 
 extern "C" int xr_ngp_train_step(
     const float* table, const float* w_density, const float* w_color, int n_hidden_density, int n_hidden_color, float pad_value,
-    int f16_mlp, int n_levels, const float* scale_host, const uint32_t* resolution_host, const uint32_t* offset_host,
+    int mlp_mode, int n_levels, const float* scale_host, const uint32_t* resolution_host, const uint32_t* offset_host,
     const float* coords, uint32_t n_rows, const uint32_t* n_dev, const int32_t* rays_numsteps, const int32_t* rays_numsteps_compacted,
     uint32_t n_rays, const float* bg_color, const float* target, const float* alpha_mask, const float* density_grid_mean,
     int rgb_activation, int density_activation, float huber_delta, float loss_scale,
@@ -38,6 +38,7 @@ extern "C" int xr_ngp_train_step(
                alpha_mask && density_grid_mean && enc_t && raw && draw && denc_t && rgb_out && zero_block && grad_w_density &&
                grad_w_color && loss_mse && grad_table, "null pointer");
     XR_REQUIRE(n_rows > 0 && n_rays > 0 && ld >= n_rows, "bad sizes");
+    XR_REQUIRE(mlp_mode >= 0 && mlp_mode <= 2, "mlp_mode is 0 (fp32 MFMA), 1 (fp16) or 2 (fp32 forward on split bf16 operands)");
     XR_REQUIRE(scatter_level0 >= 0 && scatter_level0 < n_levels, "scatter_level0 outside [0, n_levels)");
     XR_REQUIRE(!timed_entry || (timing_begin && timing_end), "a timed entry point needs its two events");
     hipStream_t stream = (hipStream_t)stream_;
@@ -68,10 +69,10 @@ extern "C" int xr_ngp_train_step(
     rc = xr_hashgrid_fwd(table, coords, 7, n_rows, n_dev, nullptr, n_levels, scale_host, resolution_host, offset_host, enc_t, ld, stream_);
     if (rc != XR_OK) return rc;
     if ((rc = end("xr_hashgrid_fwd")) != XR_OK || (rc = begin("xr_nerf_mlp_fwd")) != XR_OK) return rc;
-    rc = f16_mlp ? xr_nerf_mlp_fwd_f16(enc_t, ld, coords + 4, 7, n_rows, n_dev, nullptr, w_density, w_color, n_hidden_density,
-                                       n_hidden_color, pad_value, raw, stream_)
-                 : xr_nerf_mlp_fwd(enc_t, ld, coords + 4, 7, n_rows, n_dev, nullptr, w_density, w_color, n_hidden_density,
-                                   n_hidden_color, pad_value, raw, stream_);
+    const bool f16_mlp = mlp_mode == 1;
+    auto mlp_fwd = mlp_mode == 1 ? xr_nerf_mlp_fwd_f16 : mlp_mode == 2 ? xr_nerf_mlp_fwd_bf16x3 : xr_nerf_mlp_fwd;
+    rc = mlp_fwd(enc_t, ld, coords + 4, 7, n_rows, n_dev, nullptr, w_density, w_color, n_hidden_density, n_hidden_color, pad_value, raw,
+                 stream_);
     if (rc != XR_OK) return rc;
     if ((rc = end("xr_nerf_mlp_fwd")) != XR_OK) return rc;
     XR_HIP(hipMemsetAsync(zero_block, 0, zero_floats * sizeof(float), stream));         // MLP gradients + loss accumulators

@@ -105,6 +105,33 @@ def _span(name, units=0, train=True):
 _PRECISION = os.environ.get('XRNERF_MLP_PRECISION', 'f32')
 
 
+# forward of the 'f32' mode on the (1, 2) topology: 'bf16x3' = xr_nerf_mlp_fwd_bf16x3 (fp32 operands split exactly into three
+# bf16 numbers, six bf16 MFMAs per product block, fp32 accumulate: fp32-rounding accuracy on the 16x faster matrix-core
+# path), 'mfma' = xr_nerf_mlp_fwd (v_mfma_f32_32x32x2_f32).  Other topologies always take the latter.
+_F32_FORWARD = os.environ.get('XRNERF_F32_FORWARD', 'bf16x3')
+
+
+def f32_forward():
+    return _F32_FORWARD
+
+
+def set_f32_forward(kind):
+    global _F32_FORWARD
+    if kind not in ('bf16x3', 'mfma'):
+        raise ValueError("the fp32 forward is 'bf16x3' or 'mfma'")
+    _F32_FORWARD = kind
+
+
+def _mlp_mode(nhd=1, nhc=2):
+    """xr_ngp_train_step's mlp_mode for the current settings"""
+    if nhd == 1 and nhc == 2:
+        if _PRECISION == 'f16':
+            return 1
+        if _F32_FORWARD == 'bf16x3':
+            return 2
+    return 0
+
+
 def precision():
     """arithmetic mode of the fused MLP: 'f32' (parity mode, default: v_mfma_f32_32x32x2_f32, exact fp32) or 'f16'
     (the reference's own precision -- tiny-cuda-nn computes FullyFusedMLP in fp16 with fp32 accumulation:
@@ -299,7 +326,7 @@ def ngp_train_step(table, wd, wc, nhd, nhc, pad_value, meta, coords, n_dev, nums
             TIMER.events.setdefault(stage, []).append((ev[0], ev[1], 0))
     with _span('xr_ngp_train_step', 0):
         _lib.check(L.xr_ngp_train_step(
-            _ptr(table), _ptr(wd), _ptr(wc), nhd, nhc, pad_value, 1 if _PRECISION == 'f16' else 0, meta.n_levels, s, r, o,
+            _ptr(table), _ptr(wd), _ptr(wc), nhd, nhc, pad_value, _mlp_mode(nhd, nhc), meta.n_levels, s, r, o,
             _ptr(coords), n_rows, _ptr(n_dev), _ptr(numsteps), _ptr(numsteps_c), n_rays, _ptr(bg), _ptr(target), _ptr(alpha),
             _ptr(density_grid_mean), int(rgb_act), int(density_act), float(huber_delta), float(loss_scale),
             _ptr(bufs.enc_t), bufs.ld, _ptr(bufs.raw), _ptr(bufs.draw), _ptr(bufs.denc_t), _ptr(bufs.rgb),
@@ -508,7 +535,7 @@ def nerf_mlp_fwd(enc_t, dirs, n, w_density, w_color, nhd, nhc, pad_value=1.0, ra
     _ptr(enc_t); _ptr(raw)
     if count is not None:
         n = count
-    fn = L.xr_nerf_mlp_fwd_f16 if (_PRECISION == 'f16' and nhd == 1 and nhc == 2) else L.xr_nerf_mlp_fwd
+    fn = (L.xr_nerf_mlp_fwd, L.xr_nerf_mlp_fwd_f16, L.xr_nerf_mlp_fwd_bf16x3)[_mlp_mode(nhd, nhc)]
     with _span('xr_nerf_mlp_fwd', 0 if n_dev is not None else n, train=n_dev is not None):
         _lib.check(fn(C.c_void_p(enc_t.data_ptr() + 4 * row0), enc_t.shape[1], dp, ds, n, _ptr(n_dev),
                                      _ptr(rows), _ptr(w_density), _ptr(w_color) if w_color is not None else None, nhd,
