@@ -100,6 +100,7 @@ void* dyn_lds();
 inline void __syncthreads() { emu::block_barrier(); }
 inline int __syncthreads_or(int v) { return emu::block_or(v); }
 inline void __threadfence_block() {}
+inline void __threadfence() {}
 // on the GPU a wave runs in lockstep, so lanes may hand data to each other through LDS with nothing but a scheduling
 // barrier in between; here lanes are separate fibers, so the same spot has to be a real rendezvous
 namespace emu { void wave_barrier(); }
