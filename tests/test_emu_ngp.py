@@ -73,7 +73,6 @@ def test_fused_mlp_on_the_host(O, edev):
         ops.set_f32_forward(old)
     for n, nv in ((1, None), (33, None), (300, 250), (70, 0)):   # 8-wave workgroups: ragged tiles, device-side count
         T.test_nerf_mlp_fwd_split_operands_equal_fp32_mfma(edev, n, nv)
-    T.test_nerf_mlp_fwd_split_ticket_slots_are_recycled(edev)
     for n in (32, 100):
         T.test_nerf_mlp_bwd(O, edev, n)
 

@@ -138,30 +138,6 @@ def test_nerf_mlp_fwd_split_operands_equal_fp32_mfma(dev, n, n_valid):
         assert np.array_equal(out['bf16x3'][0][:m, 3], out['bf16x3'][1][:m, 3])   # sigma: same arithmetic with and without the color net
 
 
-def test_nerf_mlp_fwd_split_ticket_slots_are_recycled(dev):
-    """the split forward hands its tiles out through one of 64 ticket pairs, cleared by the launch's last wave: 150 launches
-    (every slot used more than twice; sizes with fewer tiles than waves, with exactly one tile per wave, with many) give
-    the same rows every time"""
-    from xrnerf_amd import ops, synthetic as S
-    rng = np.random.default_rng(3)
-    wd, wc = nets(S)
-    old = ops.f32_forward()
-    ops.set_f32_forward('bf16x3')
-    try:
-        n_max = 2500 if dev.type == 'cuda' else 300
-        ld = (n_max + 63) // 64 * 64
-        enc = T(rng.normal(0, 0.5, (32, ld)).astype(np.float32), dev)
-        dirs = T(rng.uniform(0, 1, (n_max, 3)).astype(np.float32), dev)
-        twd, twc = T(wd, dev), T(wc, dev)
-        ref = ops.nerf_mlp_fwd(enc, dirs, n_max, twd, twc, 1, 2).clone()
-        for it in range(150):
-            n = (1, 31, 256, n_max)[it % 4] if it % 5 else n_max
-            raw = ops.nerf_mlp_fwd(enc, dirs[:n], n, twd, twc, 1, 2)
-            assert torch.equal(raw, ref[:n]), (it, n)
-    finally:
-        ops.set_f32_forward(old)
-
-
 def test_nerf_mlp_fwd_asymmetric_weights(O, dev, f32_forward):
     """transpose / permutation detector: one-hot weights so that each output picks a known input."""
     from xrnerf_amd import ops

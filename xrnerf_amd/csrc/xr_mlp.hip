@@ -33,7 +33,6 @@
 //     output row m for m<16, so density_out registers feed the color net in place and its input
 //     gradient lands back on the density-output registers with no data movement either.
 #include "xr_common.h"
-#include <atomic>
 #include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -1222,15 +1221,10 @@ __device__ __forceinline__ void layer_fwd_b3(const __bf16* __restrict__ wf, int 
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// Tiles are handed out DYNAMICALLY: a wave's first tile is its launch index, every further one comes from a ticket counter.
-// In the training loop the next batch's ray march runs beside this kernel on a side stream (VALU-bound waves on ~50 of the
-// 256 CUs); with a static partition the launch lasts as long as its slowest SIMD (measured: 44 us alone, 60 us in the
-// loop).  The outputs are per-sample, so the assignment does not change any result.  Ticket slots: a launch takes the next
-// of B3_SLOTS {next tile, finished waves} pairs (host-side round robin) and the last wave to finish clears the pair, so
-// launches that overlap on different streams do not share a counter unless B3_SLOTS of them are in flight.
-#define B3_SLOTS 64
-__device__ uint32_t g_b3_ticket[B3_SLOTS][2];
-
+// Measured and dropped: handing the tiles out dynamically (a ticket counter, because the next batch's ray march co-runs on
+// ~50 CUs in the training loop and a static partition lasts as long as its slowest SIMD: 44 us alone, 60 us in the loop).
+// One returning atomic per 32-sample tile is 8100 same-address atomics per launch, and those retire one per ~13.5 ns: the
+// launch took 130 us (profiles/r02_mlp_fwd_bf16x3_dynamic_tickets_negative.txt).
 template <bool WITH_COLOR>
 __global__ __launch_bounds__(BX_THREADS, 1) void k_nerf_mlp_fwd_b3(const float* __restrict__ enc_t, uint32_t ld,
                                                                     const float* __restrict__ dirs, uint32_t dir_stride,
@@ -1238,9 +1232,9 @@ __global__ __launch_bounds__(BX_THREADS, 1) void k_nerf_mlp_fwd_b3(const float* 
                                                                     const uint32_t* __restrict__ rows,
                                                                     const float* __restrict__ w_density,
                                                                     const float* __restrict__ w_color, float pad_value,
-                                                                    float4* __restrict__ raw, uint32_t slot) {
+                                                                    float4* __restrict__ raw) {
     if (n_dev) n = min(n, *n_dev);
-    if (n == 0) return;                              // uniform for the launch: nobody touches the ticket
+    if (n == 0) return;
     using HD = HShape<1>;
     using HC = HShape<2>;
     constexpr int PD = HD::f_halves, PC = HC::f_halves;             // halves per part
@@ -1249,15 +1243,8 @@ __global__ __launch_bounds__(BX_THREADS, 1) void k_nerf_mlp_fwd_b3(const float* 
     __bf16* wd = ldsb;
     __bf16* wc = ldsb + 3 * PD;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, hi = lane >> 5;
-    const uint32_t n_tiles = (n + 31) / 32, n_waves = gridDim.x * BX_WAVES;
-    uint32_t* const ticket = g_b3_ticket[slot];
-    auto grab = [&]() -> uint32_t {                  // the next unassigned tile (>= n_tiles: none left); wave-uniform
-        uint32_t v = 0;
-        if (lane == 0) v = atomicAdd(&ticket[0], 1u);
-        return n_waves + (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-    };
+    const uint32_t n_tiles = (n + 31) / 32, stride = gridDim.x * BX_WAVES;
     uint32_t tile = blockIdx.x * BX_WAVES + wave;
-    uint32_t next = tile < n_tiles ? grab() : n_tiles;
     // the first tile's inputs are in flight while the workgroup splits the weights
     f32x16 x;
     float d3[3] = {0.f, 0.f, 0.f};
@@ -1273,15 +1260,11 @@ __global__ __launch_bounds__(BX_THREADS, 1) void k_nerf_mlp_fwd_b3(const float* 
     load_weights_b3<1>(wd, PD, w_density, false);
     if (WITH_COLOR) load_weights_b3<2>(wc, PC, w_color, true);
     __syncthreads();
-    while (tile < n_tiles) {
+    for (; tile < n_tiles; tile += stride) {
         const uint32_t s = tile * 32 + col;
         BTile xin[1] = {to_b3(x)};
         const float dx = d3[0], dy = d3[1], dz = d3[2];
-        uint32_t after = n_tiles;
-        if (next < n_tiles) {
-            fetch(next, x, d3);                      // next tile's loads (and the ticket after it) under this tile's MFMAs
-            after = grab();
-        }
+        if (tile + stride < n_tiles) fetch(tile + stride, x, d3);           // next tile's loads under this tile's MFMAs
         f32x16 h[2], dout[1];
         layer_fwd_b3<1, 2>(wd + HD::f_off(0), PD, xin, h, col, hi);
         relu_tile(h[0]); relu_tile(h[1]);
@@ -1303,12 +1286,6 @@ __global__ __launch_bounds__(BX_THREADS, 1) void k_nerf_mlp_fwd_b3(const float* 
             o.x = cout[0][0]; o.y = cout[0][1]; o.z = cout[0][2];
         }
         if (hi == 0 && s < n) raw[s] = o;
-        tile = next; next = after;
-    }
-    // the last wave of the launch to get here leaves the pair cleared for the slot's next user
-    if (lane == 0 && atomicAdd(&ticket[1], 1u) == n_waves - 1u) {
-        __threadfence();
-        ticket[0] = 0u; ticket[1] = 0u;
     }
 }
 
@@ -1553,17 +1530,15 @@ extern "C" int xr_nerf_mlp_fwd_bf16x3(const float* enc_t, uint32_t ld, const flo
     hipStream_t stream = (hipStream_t)stream_;
     const int cus = xr_device_cus() > 0 ? xr_device_cus() : 256;
     const uint32_t grid = min(xr_div_up((n + 31) / 32, BX_WAVES), (uint32_t)cus);          // resident: one 8-wave workgroup per CU
-    static std::atomic<uint32_t> next_slot{0};
-    const uint32_t slot = next_slot.fetch_add(1u, std::memory_order_relaxed) % B3_SLOTS;
     if (dirs) {
         const size_t lds = (size_t)3 * (HShape<1>::f_halves + HShape<2>::f_halves) * 2;
         XR_HIP(hipFuncSetAttribute((const void*)k_nerf_mlp_fwd_b3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_nerf_mlp_fwd_b3<true>, dim3(grid), dim3(BX_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev,
-                           rows, w_density, w_color, pad_value, (float4*)raw, slot);
+                           rows, w_density, w_color, pad_value, (float4*)raw);
     } else {
         const size_t lds = (size_t)3 * HShape<1>::f_halves * 2;
         hipLaunchKernelGGL(k_nerf_mlp_fwd_b3<false>, dim3(grid), dim3(BX_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev,
-                           rows, w_density, w_color, pad_value, (float4*)raw, slot);
+                           rows, w_density, w_color, pad_value, (float4*)raw);
     }
     XR_LAUNCH_CHECK();
     return XR_OK;
