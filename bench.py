@@ -665,6 +665,14 @@ def main():
         barrier()
         extra['render_ms_per_800x800_frame'] = (time.perf_counter() - t1) * 1e3 / n_frames
         extra['render_samples_per_ray'] = float(tr.net.sampler.coords.shape[0]) / max(1, nrows * W)
+        # the same entry points in their RENDER launches (one launch = every marched sample of the frame / row band, ~14 M):
+        # events on the launch stream around each launch of two more frames, outside the frame timer
+        ops.TIMER = ops.KernelTimer(only={'xr_hashgrid_fwd', 'xr_nerf_mlp_fwd'}, train_only=False)
+        for f in range(2):
+            render_frame(tr.net, tr.data.poses[f % tr.data.n_img], H, W, tr.data.focal, row0=row0, nrows=nrows)
+        torch.cuda.synchronize()
+        timer_r, ops.TIMER = ops.TIMER, None
+        extra['roofline_kernels_render'] = {k: roof_of(k, n_l, ms_l, u_l) for k, (n_l, ms_l, u_l) in timer_r.summary().items() if u_l > 0}
         # optional early-terminated rendering (pixels within 1e-4 of the full evaluation, tests/test_gpu_network.py)
         for _ in range(2):
             rgb, alpha = render_frame_ert(tr.net, pose, H, W, tr.data.focal, row0=row0, nrows=nrows)

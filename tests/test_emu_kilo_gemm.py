@@ -139,8 +139,15 @@ def test_fused_frame_call_equals_the_dense_path_on_the_host(E, gold, lindisp):
     assert np.array_equal(rgb, rgb2) and np.array_equal(acc, acc2) and np.array_equal(np.nan_to_num(disp, nan=-1), np.nan_to_num(disp2, nan=-1))
 
 
+@pytest.fixture(params=['bf16x3', 'mfma'])
+def gemm_kernel(request, monkeypatch):
+    """both kernels behind the linear entry points: fp32 results on the bf16 MFMA (3-way operand split, default) / fp32 MFMA"""
+    monkeypatch.setenv('XR_GEMM_F32', request.param)
+    return request.param
+
+
 @pytest.mark.parametrize('M,N,K', [(300, 256, 96), (257, 128, 284), (130, 260, 256), (5, 4, 8), (1000, 132, 36)])
-def test_linear_kernels_on_the_host(E, M, N, K):
+def test_linear_kernels_on_the_host(E, M, N, K, gemm_kernel):
     L = E.lib('xr_gemm')
     rng = np.random.default_rng(M + N + K)
     x, w, b = E.aligned((M, K), fill=rng.normal(0, 1, (M, K))), E.aligned((N, K), fill=rng.normal(0, 1, (N, K)) / K ** 0.5), E.f32(rng.normal(0, 1, N))

@@ -8,8 +8,15 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=['bf16x3', 'mfma'])
+def gemm_kernel(request, monkeypatch):
+    """both kernels behind the linear entry points: fp32 results on the bf16 MFMA (3-way operand split, default) / fp32 MFMA"""
+    monkeypatch.setenv('XR_GEMM_F32', request.param)
+    return request.param
+
+
 @pytest.mark.parametrize('M,N,K', [(1000, 256, 96), (4096, 256, 352), (333, 128, 256), (70000, 256, 256), (5, 4, 8), (129, 132, 36)])
-def test_kernels_against_fp64(dev, M, N, K):
+def test_kernels_against_fp64(dev, M, N, K, gemm_kernel):
     from xrnerf_amd import ops
     g = torch.Generator(device='cpu').manual_seed(M + N + K)
     x = torch.randn(M, K, generator=g)

@@ -12,6 +12,7 @@
 // global loads in flight while the current one is multiplied.  Bias, relu and the relu mask of the incoming gradient are
 // fused into the epilogue / the A-panel load.
 #include "xr_common.h"
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define GMFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
@@ -142,6 +143,153 @@ __global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g) {
         }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same three products on the bf16 matrix cores, to fp32 accuracy (csrc/xr_mlp.hip, "3-way operand splitting"): every
+// fp32 operand element is split EXACTLY into three bf16 numbers while its panel is staged into LDS, and a 32 x 32 x 16 block
+// of products is carried by the six bf16 x bf16 MFMA terms above 2^-23 of it (fp32 accumulate): 6 x 8 passes instead of the
+// 8 x 16 passes of eight v_mfma_f32_32x32x2_f32.  Same tiling (128 x 128 per workgroup, 4 waves in 2 x 2, 2 x 2 accumulators
+// each), same epilogue; panels are 32 k deep, stored [part][row][k] with 80-byte rows so that a lane's 8 consecutive k of
+// one part are one conflict-free ds_read_b128 (60 KB per workgroup, two workgroups per CU; the next panel's global loads
+// are in flight while the current one is multiplied).
+typedef __bf16 gb8 __attribute__((ext_vector_type(8)));
+typedef __bf16 gb4 __attribute__((ext_vector_type(4)));
+#define GMFMAB(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#define G3K 32                                   // k per panel: two MFMA k-steps
+#define G3RS (G3K + 8)                           // halves per LDS row (80 B)
+#define G3PART (GBM * G3RS)                      // halves per part of one operand panel
+#define G3NJ (G3K / 8)                           // float4 per thread and panel
+
+__device__ __forceinline__ void g3_split(float x, __bf16& h, __bf16& m, __bf16& l) {
+    h = (__bf16)x;
+    const float r1 = x - (float)h;               // exact
+    m = (__bf16)r1;
+    const float r2 = r1 - (float)m;              // exact
+    l = (__bf16)r2;
+}
+// panel_load for 32-k panels (same thread mapping as above with GBK = 32)
+__device__ __forceinline__ void g3_panel_load(const float* __restrict__ P, const float* __restrict__ mask, uint32_t ld, int km,
+                                              uint32_t row0, uint32_t rows, uint32_t k0, uint32_t k_end, float4 (&v)[G3NJ]) {
+    const uint32_t t = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < G3NJ; ++j) {
+        uint32_t r, k;
+        bool ok;
+        size_t off;
+        if (!km) { r = row0 + (t & 127); k = k0 + (t >> 7) * (G3K / 2) + 4 * j; ok = r < rows && k < k_end; off = (size_t)r * ld + k; }
+        else { k = k0 + (t >> 5) + 8 * j; r = row0 + (t & 31) * 4; ok = r < rows && k < k_end; off = (size_t)k * ld + r; }
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) {
+            x = *reinterpret_cast<const float4*>(P + off);
+            if (mask != nullptr) {
+                const float4 m = *reinterpret_cast<const float4*>(mask + off);
+                x.x = m.x > 0.f ? x.x : 0.f; x.y = m.y > 0.f ? x.y : 0.f; x.z = m.z > 0.f ? x.z : 0.f; x.w = m.w > 0.f ? x.w : 0.f;
+            }
+        }
+        v[j] = x;
+    }
+}
+// registers -> LDS: S[part][row][k] (row stride G3RS halves)
+__device__ __forceinline__ void g3_panel_store(__bf16* __restrict__ S, int km, const float4 (&v)[G3NJ]) {
+    const uint32_t t = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < G3NJ; ++j) {
+        const float x[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+        if (!km) {                               // 4 consecutive k of one row: one 8-byte store per part
+            const uint32_t r = t & 127, k = (t >> 7) * (G3K / 2) + 4 * j;
+            gb4 h, m, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { __bf16 a, b, c; g3_split(x[e], a, b, c); h[e] = a; m[e] = b; l[e] = c; }
+            __bf16* d = S + r * G3RS + k;
+            *reinterpret_cast<gb4*>(d) = h;
+            *reinterpret_cast<gb4*>(d + G3PART) = m;
+            *reinterpret_cast<gb4*>(d + 2 * G3PART) = l;
+        } else {                                 // 4 consecutive rows at one k
+            const uint32_t k = (t >> 5) + 8 * j, r = (t & 31) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                __bf16 a, b, c;
+                g3_split(x[e], a, b, c);
+                __bf16* d = S + (r + e) * G3RS + k;
+                d[0] = a; d[G3PART] = b; d[2 * G3PART] = c;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256, 2) k_gemm_b3(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) __bf16 sA[3 * G3PART];
+    __shared__ __attribute__((aligned(16))) __bf16 sB[3 * G3PART];
+    const uint32_t m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+    const uint32_t k_begin = blockIdx.z * g.k_per_split;
+    const uint32_t k_end = k_begin + g.k_per_split < g.Kc ? k_begin + g.k_per_split : g.Kc;
+    const int lane = threadIdx.x & 63, col = lane & 31, hi = lane >> 5;
+    const int wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float4 ra[G3NJ], rb[G3NJ];
+    if (k_begin < k_end) {
+        g3_panel_load(g.A, g.mask_src, g.lda, g.a_km, m0, g.Mc, k_begin, k_end, ra);
+        g3_panel_load(g.B, nullptr, g.ldb, g.b_kn, n0, g.Nc, k_begin, k_end, rb);
+    }
+    for (uint32_t k0 = k_begin; k0 < k_end; k0 += G3K) {
+        __syncthreads();                                   // the previous panel has been consumed
+        g3_panel_store(sA, g.a_km, ra);
+        g3_panel_store(sB, g.b_kn, rb);
+        __syncthreads();
+        if (k0 + G3K < k_end) {
+            g3_panel_load(g.A, g.mask_src, g.lda, g.a_km, m0, g.Mc, k0 + G3K, k_end, ra);
+            g3_panel_load(g.B, nullptr, g.ldb, g.b_kn, n0, g.Nc, k0 + G3K, k_end, rb);
+        }
+        const __bf16* pa = sA + (wm * 64 + col) * G3RS + hi * 8;
+        const __bf16* pb = sB + (wn * 64 + col) * G3RS + hi * 8;
+#pragma unroll
+        for (int s = 0; s < G3K / 16; ++s) {
+            gb8 a[2][3], b[2][3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    a[i][p] = *reinterpret_cast<const gb8*>(pa + p * G3PART + i * 32 * G3RS + s * 16);
+                    b[i][p] = *reinterpret_cast<const gb8*>(pb + p * G3PART + i * 32 * G3RS + s * 16);
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {              // smallest terms first
+                    acc[i][j] = GMFMAB(a[i][2], b[j][0], acc[i][j]);
+                    acc[i][j] = GMFMAB(a[i][0], b[j][2], acc[i][j]);
+                    acc[i][j] = GMFMAB(a[i][1], b[j][1], acc[i][j]);
+                    acc[i][j] = GMFMAB(a[i][1], b[j][0], acc[i][j]);
+                    acc[i][j] = GMFMAB(a[i][0], b[j][1], acc[i][j]);
+                    acc[i][j] = GMFMAB(a[i][0], b[j][0], acc[i][j]);
+                }
+        }
+    }
+    float* C = g.C + (size_t)blockIdx.z * g.c_split_stride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t n = n0 + wn * 64 + j * 32 + col;
+            if (n >= g.Nc) continue;
+            const float b = g.bias != nullptr ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (m < g.Mc) {
+                    float v = acc[i][j][r] + b;
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    C[(size_t)m * g.ldc + n] = v;
+                }
+            }
+        }
+}
+
 static int gemm_launch(GemmArgs g, uint32_t splits, void* stream) {
     XR_REQUIRE(g.A && g.B && g.C, "null pointer");
     XR_REQUIRE(g.lda % 4 == 0 && g.ldb % 4 == 0, "leading dimensions must be multiples of 4 floats (16-byte vector loads)");
@@ -150,11 +298,16 @@ static int gemm_launch(GemmArgs g, uint32_t splits, void* stream) {
     XR_REQUIRE((g.a_km ? g.Mc : g.Kc) % 4 == 0 && (g.b_kn ? g.Nc : g.Kc) % 4 == 0, "the contiguous dimension of each operand must be a multiple of 4");
     if (g.Mc == 0 || g.Nc == 0) return XR_OK;
     XR_REQUIRE(splits >= 1 && splits <= 65535, "bad split count");
-    g.k_per_split = (uint32_t)(((uint64_t)(g.Kc + splits - 1) / splits + GBK - 1) / GBK * GBK);
-    if (g.k_per_split == 0) g.k_per_split = GBK;
+    // XR_GEMM_F32=mfma: the fp32-MFMA kernel; default: fp32 results on the bf16 matrix cores (exact 3-way operand split)
+    const char* env = getenv("XR_GEMM_F32");       // read per call: a test (or a measurement) can switch between two launches
+    const bool split = !(env && env[0] == 'm');
+    const uint32_t kb = split ? (uint32_t)G3K : (uint32_t)GBK;
+    g.k_per_split = (uint32_t)(((uint64_t)(g.Kc + splits - 1) / splits + kb - 1) / kb * kb);
+    if (g.k_per_split == 0) g.k_per_split = kb;
     const dim3 grid(xr_div_up(g.Nc, GBN), xr_div_up(g.Mc, GBM), splits);
     XR_REQUIRE(grid.y <= 65535, "more than 65535 row tiles (8.3 M rows) in one call");
-    hipLaunchKernelGGL(k_gemm_f32, grid, dim3(256), 0, (hipStream_t)stream, g);
+    if (split) hipLaunchKernelGGL(k_gemm_b3, grid, dim3(256), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(k_gemm_f32, grid, dim3(256), 0, (hipStream_t)stream, g);
     XR_LAUNCH_CHECK();
     return XR_OK;
 }
