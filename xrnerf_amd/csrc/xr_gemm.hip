@@ -13,6 +13,7 @@
 // fused into the epilogue / the A-panel load.
 #include "xr_common.h"
 #include <cstdlib>
+#include <cstring>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define GMFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
@@ -35,6 +36,7 @@ struct GemmArgs {
     int relu;
     uint32_t k_per_split;                        // contraction range of blockIdx.z; C of split z at C + z * c_split_stride
     size_t c_split_stride;
+    int tload;                                   // k_gemm_b3: [k, rows] operands are read with per-k dword loads (k-contiguous in registers)
 };
 
 // one 128 x GBK panel of an operand into registers: GNJ float4 per thread.
@@ -188,6 +190,29 @@ __device__ __forceinline__ void g3_panel_load(const float* __restrict__ P, const
         v[j] = x;
     }
 }
+// a [k, rows] source read the other way round: thread -> row (t & 127), 16 k's starting at (t >> 7) * 16, one dword per k
+// (a wave's 64 rows are 256 contiguous bytes per k) -> the SAME register layout as the row-major case, so the panel goes
+// to LDS with one 8-byte store per part and 4 k's instead of twelve 2-byte stores (measured with the float4-along-rows
+// loads: dX 0.9x, dW 0.55x of the fp32-MFMA kernel, profiles/r02_gemm_bf16x3_vs_fp32_mfma_v1.txt)
+__device__ __forceinline__ void g3_panel_load_t(const float* __restrict__ P, const float* __restrict__ mask, uint32_t ld,
+                                                uint32_t row0, uint32_t rows, uint32_t k0, uint32_t k_end, float4 (&v)[G3NJ]) {
+    const uint32_t t = threadIdx.x, r = row0 + (t & 127);
+#pragma unroll
+    for (int j = 0; j < G3NJ; ++j) {
+        float x[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t k = k0 + (t >> 7) * (G3K / 2) + 4 * j + e;
+            x[e] = 0.f;
+            if (r < rows && k < k_end) {
+                const size_t off = (size_t)k * ld + r;
+                x[e] = P[off];
+                if (mask != nullptr && !(mask[off] > 0.f)) x[e] = 0.f;
+            }
+        }
+        v[j] = make_float4(x[0], x[1], x[2], x[3]);
+    }
+}
 // registers -> LDS: S[part][row][k] (row stride G3RS halves)
 __device__ __forceinline__ void g3_panel_store(__bf16* __restrict__ S, int km, const float4 (&v)[G3NJ]) {
     const uint32_t t = threadIdx.x;
@@ -232,19 +257,20 @@ __global__ void __launch_bounds__(256, 2) k_gemm_b3(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     float4 ra[G3NJ], rb[G3NJ];
-    if (k_begin < k_end) {
-        g3_panel_load(g.A, g.mask_src, g.lda, g.a_km, m0, g.Mc, k_begin, k_end, ra);
-        g3_panel_load(g.B, nullptr, g.ldb, g.b_kn, n0, g.Nc, k_begin, k_end, rb);
-    }
+    const bool ta = g.a_km && g.tload, tb = g.b_kn && g.tload;             // uniform
+    auto load = [&](uint32_t k0) {
+        if (ta) g3_panel_load_t(g.A, g.mask_src, g.lda, m0, g.Mc, k0, k_end, ra);
+        else g3_panel_load(g.A, g.mask_src, g.lda, g.a_km, m0, g.Mc, k0, k_end, ra);
+        if (tb) g3_panel_load_t(g.B, nullptr, g.ldb, n0, g.Nc, k0, k_end, rb);
+        else g3_panel_load(g.B, nullptr, g.ldb, g.b_kn, n0, g.Nc, k0, k_end, rb);
+    };
+    if (k_begin < k_end) load(k_begin);
     for (uint32_t k0 = k_begin; k0 < k_end; k0 += G3K) {
         __syncthreads();                                   // the previous panel has been consumed
-        g3_panel_store(sA, g.a_km, ra);
-        g3_panel_store(sB, g.b_kn, rb);
+        g3_panel_store(sA, ta ? 0 : g.a_km, ra);
+        g3_panel_store(sB, tb ? 0 : g.b_kn, rb);
         __syncthreads();
-        if (k0 + G3K < k_end) {
-            g3_panel_load(g.A, g.mask_src, g.lda, g.a_km, m0, g.Mc, k0 + G3K, k_end, ra);
-            g3_panel_load(g.B, nullptr, g.ldb, g.b_kn, n0, g.Nc, k0 + G3K, k_end, rb);
-        }
+        if (k0 + G3K < k_end) load(k0 + G3K);
         const __bf16* pa = sA + (wm * 64 + col) * G3RS + hi * 8;
         const __bf16* pb = sB + (wn * 64 + col) * G3RS + hi * 8;
 #pragma unroll
@@ -299,8 +325,15 @@ static int gemm_launch(GemmArgs g, uint32_t splits, void* stream) {
     if (g.Mc == 0 || g.Nc == 0) return XR_OK;
     XR_REQUIRE(splits >= 1 && splits <= 65535, "bad split count");
     // XR_GEMM_F32=mfma: the fp32-MFMA kernel; default: fp32 results on the bf16 matrix cores (exact 3-way operand split)
-    const char* env = getenv("XR_GEMM_F32");       // read per call: a test (or a measurement) can switch between two launches
-    const bool split = !(env && env[0] == 'm');
+    // XR_GEMM_F32 (read per call: a test or a measurement can switch between two launches):
+    //   unset / bf16x3 : the split kernel for products whose operands are both row-major [rows, k] (the forward; measured
+    //                    1.05-1.3x the fp32-MFMA kernel), the fp32-MFMA kernel for the two backward products
+    //   bf16x3all      : the split kernel for all three products ([k, rows] operands read with per-k dword loads)
+    //   mfma           : the fp32-MFMA kernel throughout
+    const char* env = getenv("XR_GEMM_F32");
+    const bool all = env && strcmp(env, "bf16x3all") == 0;
+    const bool split = !(env && env[0] == 'm') && (all || (!g.a_km && !g.b_kn));
+    g.tload = all ? 1 : 0;
     const uint32_t kb = split ? (uint32_t)G3K : (uint32_t)GBK;
     g.k_per_split = (uint32_t)(((uint64_t)(g.Kc + splits - 1) / splits + kb - 1) / kb * kb);
     if (g.k_per_split == 0) g.k_per_split = kb;
