@@ -591,6 +591,9 @@ def main():
 
     def roof_of(name, launches, total_ms, units, live_frac=1.0):
         bound, per_unit = ALGO[name]
+        halves = world > 1 and name == 'xr_hashgrid_bwd'
+        if halves:
+            launches = max(1, launches // 2)      # data parallel: fine / coarse halves around the gradient collective = one step's scatter
         if name in LIVE_KERNELS:
             units = units * live_frac
         work = units * per_unit
@@ -610,6 +613,8 @@ def main():
                                  'bf16 MFMA peak -- the matrix cores execute 6x these flops (issued_frac)')
             out['issued_frac'] = 6.0 * achieved / peak
             out['frac_of_fp32_mfma_peak'] = achieved / MFMA_F32_PEAK_TFLOPS
+        if halves:
+            out['note'] = 'entry point called twice per step (levels 8..15, then 0..7, each handed to the all-reduce): figures are per step'
         if name in LIVE_KERNELS:
             out['live_row_fraction'] = live_frac
             out['units'] = 'samples with a non-zero output gradient (the rows the launch processes); the others are exact zeros'
