@@ -654,6 +654,31 @@ def main():
         roofs[k] = roof_of(k, n_l, ms_l, u_l if u_l > 0 else s_win, live_frac_win)      # Adam counts parameters, the rest samples
 
     extra = {}
+    if ops._mlp_mode() == 2:
+        # live evidence that the split forward is an fp32-accurate evaluation: the trained weights, the current batch's
+        # marched samples, both forwards (never inside a timed region; a failure here must not cost the line)
+        try:
+            mlp = tr.net.mlp
+            coords = sampler.coords
+            n_chk = int(min(coords.shape[0], int(sampler.n_valid_dev[0]), 1 << 18))      # rows behind the count are stale
+            enc_chk = ops.hashgrid_fwd(mlp.embedder_pos.params.detach(), coords[:n_chk, :3], mlp.embedder_pos.meta)
+            outs = {}
+            for kind in ('mfma', 'bf16x3'):
+                ops.set_f32_forward(kind)
+                outs[kind] = ops.nerf_mlp_fwd(enc_chk, coords[:n_chk, 4:], n_chk, mlp.density_net.params.detach(),
+                                              mlp.color_net.params.detach(), 1, 2, mlp.pad_value).clone()
+            dev_max = float((outs['mfma'] - outs['bf16x3']).abs().max())
+            if not (dev_max == dev_max and dev_max < float('inf')):
+                raise ValueError('non-finite deviation')
+            extra['mlp_forward_check'] = {
+                'samples': n_chk, 'max_abs_raw_fp32_mfma': float(outs['mfma'].abs().max()),
+                'max_abs_deviation_bf16x3_vs_fp32_mfma': dev_max,
+                'note': 'xr_nerf_mlp_fwd_bf16x3 (exact 3-way bf16 operand split, 6 bf16 MFMAs per product block, fp32 accumulate) '
+                        'against xr_nerf_mlp_fwd (fp32 MFMA) on the trained weights and the current training batch; parity bar on raw: 1e-4'}
+        except Exception as e:  # noqa: BLE001
+            extra['mlp_forward_check'] = {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
+        finally:
+            ops.set_f32_forward('bf16x3')
     if not args.no_render:
         H = W = 800
         pose = tr.data.poses[0]
