@@ -108,6 +108,26 @@ def test_hidden_layer_key_policy(monkeypatch):
     assert _hidden_layers({'num_layers': 2}) == 5
 
 
+def test_mlp_mode_selection():
+    """which fused-MLP kernels a launch takes (xr_ngp_train_step's mlp_mode): the (1, 2) topology of configs/instant_ngp runs its
+    fp32 forward on split bf16 operands unless told otherwise, the fp16 mode takes the fp16 pair, other topologies the fp32 MFMA"""
+    from xrnerf_amd import ops
+    old_p, old_f = ops.precision(), ops.f32_forward()
+    try:
+        ops.set_precision('f32'); ops.set_f32_forward('bf16x3')
+        assert ops._mlp_mode(1, 2) == 2 and ops._mlp_mode(2, 2) == 0 and ops._mlp_mode(1, 1) == 0
+        ops.set_f32_forward('mfma')
+        assert ops._mlp_mode(1, 2) == 0
+        ops.set_precision('f16')
+        assert ops._mlp_mode(1, 2) == 1 and ops._mlp_mode(2, 3) == 0
+        with pytest.raises(ValueError):
+            ops.set_f32_forward('bf16')
+        with pytest.raises(ValueError):
+            ops.set_precision('bf16')
+    finally:
+        ops.set_precision(old_p); ops.set_f32_forward(old_f)
+
+
 def test_batch_size_adaptation_matches_reference_formula():
     """ngp_grid_sampler.py:268-281"""
     from xrnerf_amd.samplers import NGPGridSampler
