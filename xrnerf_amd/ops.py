@@ -103,12 +103,16 @@ def _span(name, units=0, train=True):
 
 
 _PRECISION = os.environ.get('XRNERF_MLP_PRECISION', 'f32')
+if _PRECISION not in ('f32', 'f16'):
+    raise ValueError("XRNERF_MLP_PRECISION must be 'f32' or 'f16' (got %r)" % _PRECISION)
 
 
 # forward of the 'f32' mode on the (1, 2) topology: 'bf16x3' = xr_nerf_mlp_fwd_bf16x3 (fp32 operands split exactly into three
 # bf16 numbers, six bf16 MFMAs per product block, fp32 accumulate: fp32-rounding accuracy on the 16x faster matrix-core
 # path), 'mfma' = xr_nerf_mlp_fwd (v_mfma_f32_32x32x2_f32).  Other topologies always take the latter.
 _F32_FORWARD = os.environ.get('XRNERF_F32_FORWARD', 'bf16x3')
+if _F32_FORWARD not in ('bf16x3', 'mfma'):
+    raise ValueError("XRNERF_F32_FORWARD must be 'bf16x3' or 'mfma' (got %r)" % _F32_FORWARD)
 
 
 def f32_forward():
