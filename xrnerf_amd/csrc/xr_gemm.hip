@@ -348,14 +348,14 @@ static int gemm_launch(GemmArgs g, uint32_t splits, void* stream) {
 // y [M,N] = act(x [M,K] . w [N,K]^T + bias [N])
 extern "C" int xr_linear_forward(const float* x, const float* w, const float* bias, uint32_t M, uint32_t N, uint32_t K,
                                  int relu, float* y, void* stream) {
-    GemmArgs g{x, w, y, bias, nullptr, M, N, K, K, K, N, 0, 0, relu, 0, 0};
+    GemmArgs g{x, w, y, bias, nullptr, M, N, K, K, K, N, 0, 0, relu, 0, 0, 0};
     return gemm_launch(g, 1, stream);
 }
 
 // dx [M,K] = (dy [M,N] masked by mask_src [M,N] > 0 when given) . w [N,K]
 extern "C" int xr_linear_backward_input(const float* dy, const float* mask_src, const float* w, uint32_t M, uint32_t N,
                                         uint32_t K, float* dx, void* stream) {
-    GemmArgs g{dy, w, dx, nullptr, mask_src, M, K, N, N, K, K, 0, 1, 0, 0, 0};
+    GemmArgs g{dy, w, dx, nullptr, mask_src, M, K, N, N, K, K, 0, 1, 0, 0, 0, 0};
     return gemm_launch(g, 1, stream);
 }
 
@@ -421,6 +421,6 @@ extern "C" int xr_linear_backward_bias(const float* dy, const float* mask_src, u
 
 extern "C" int xr_linear_backward_weight(const float* dy, const float* mask_src, const float* x, uint32_t M, uint32_t N,
                                          uint32_t K, uint32_t splits, float* dw_partials, void* stream) {
-    GemmArgs g{dy, x, dw_partials, nullptr, mask_src, N, K, M, N, K, K, 1, 1, 0, 0, (size_t)N * K};
+    GemmArgs g{dy, x, dw_partials, nullptr, mask_src, N, K, M, N, K, K, 1, 1, 0, 0, (size_t)N * K, 0};
     return gemm_launch(g, splits, stream);
 }
