@@ -20,7 +20,7 @@ from .datasets import DeviceRayTable
 
 def ngp_lego_model_cfg(n_rays=4096):
     """The `model` dict of /root/reference/configs/instant_ngp/nerf_blender_local01.py:78-138,
-    restated (the reference tree does not exist on the GPU box; tests/test_config.py checks this
+    restated (the reference tree does not exist on the GPU box; tests/test_capi_and_host.py::test_reference_config_builds_unchanged checks this
     against the real file when it is present and against tests/golden/ngp_model_cfg.json)."""
     return dict(
         type='HashNerfNetwork',
