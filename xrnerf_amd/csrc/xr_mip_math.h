@@ -1,5 +1,5 @@
 // Per-element arithmetic of the Mip-NeRF kernels (xr_mip.hip), fp32 in the reference's operation order.
-// __host__ __device__ so that tools/mip_math_host_check.cpp can run the very same expressions on the CPU
+// __host__ __device__ so that tests/host_harness/mip_math_host.cpp (tests/test_mip_host_math.py) can run the very same expressions on the CPU
 // against the numpy oracle before a kernel ever reaches a GPU (compile BOTH with -ffp-contract=off).
 //
 // Reference (relative to /root/reference/):
