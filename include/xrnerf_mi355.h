@@ -177,12 +177,16 @@ void xr_hashgrid_meta(int n_levels, int log2_hashmap_size, int base_resolution, 
 int xr_hashgrid_fwd(const float* table, const float* x, uint32_t x_stride, uint32_t n, const uint32_t* n_dev,
                     const uint32_t* rows, int n_levels, const float* scale_host, const uint32_t* resolution_host,
                     const uint32_t* offset_host, float* enc_t, uint32_t ld, void* stream);
-/* grad_table[idx,f] += w * denc_t[2l+f][i]; caller zero-fills grad_table.
+/* Backward of the encoding above (tcnn's kernel_grid_backward as reached from hashnerf_mlp.py:59-61 under autograd):
+ * grad_table[idx,f] += w * denc_t[2l+f][i]; the caller zero-fills grad_table (xr_hashgrid_bwd2 + XR_SCATTER_OVERWRITE: no).
  * workspace (nullable; xr_hashgrid_bwd_workspace_bytes(n, n_levels, resolution_host, offset_host), 16-byte
- * aligned): with it and n >= 16384, the hashed levels (power-of-two slices) are accumulated WITHOUT global
- * atomics -- contributions are binned by 2^14-entry table partition, then one workgroup per partition sums
- * its bin in LDS and adds it to the table -- and the dense levels scatter into 8 replicas of their slices
- * (hot-entry contention) that are folded afterwards; without it every level takes the plain atomic scatter. */
+ * aligned): with it and n >= 16384 NO level touches the table with an atomic -- hashed levels and the larger dense levels
+ * are binned by table partition (16-byte items in workgroup-private sub-bins, overflow lists for clustered inputs) and
+ * one workgroup per partition sums its bins in fp64 in LDS; dense levels up to 2^16 entries are run-length reduced per
+ * thread into workgroup-private LDS partitions whose per-chunk partials are folded in fixed order (csrc/xr_scatter.hip).
+ * Without a workspace, for small n and for table shapes outside those rules a level takes the atomic scatter.
+ * Positions must lie in the unit cube (the sampler's aabb): a hashed level's x-neighbour pair is kept in one partition
+ * by x < 2^13. */
 size_t xr_hashgrid_bwd_workspace_bytes(uint32_t n, int n_levels, const uint32_t* resolution_host,
                                        const uint32_t* offset_host);
 /* rows (nullable, with n_dev): launch sample j is row rows[j] of x / denc_t and *n_dev the list's length -- the live-row
@@ -191,6 +195,14 @@ int xr_hashgrid_bwd(const float* x, uint32_t x_stride, const float* denc_t, uint
                     const uint32_t* n_dev, const uint32_t* rows, int n_levels, const float* scale_host, const uint32_t* resolution_host,
                     const uint32_t* offset_host, float* grad_table, void* workspace, size_t workspace_bytes,
                     void* stream);
+/* the same with flags.  XR_SCATTER_OVERWRITE: the table slices of the call's levels are WRITTEN (grad = scatter result)
+ * instead of added to -- the caller needs no zero-fill (the training step saves a 48.8-MB one); with n == 0 the slices
+ * are zero-filled. */
+#define XR_SCATTER_OVERWRITE 1
+int xr_hashgrid_bwd2(const float* x, uint32_t x_stride, const float* denc_t, uint32_t ld, uint32_t n,
+                     const uint32_t* n_dev, const uint32_t* rows, int n_levels, const float* scale_host, const uint32_t* resolution_host,
+                     const uint32_t* offset_host, float* grad_table, void* workspace, size_t workspace_bytes, int flags,
+                     void* stream);
 /* tcnn.Encoding otype=SphericalHarmonics degree 4; dirs in [0,1] (the sampler's warp_direction);
  * out row-major [n,16] */
 int xr_sh4(const float* dirs, uint32_t dir_stride, uint32_t n, float* out, void* stream);
@@ -254,13 +266,15 @@ int xr_nerf_mlp_fwd_bf16x3(const float* enc_t, uint32_t ld, const float* dirs, u
 
 /* One training step's device work of HashNerfNetwork.train_step (networks/hashnerf.py:32-52, optimiser excluded) as ONE call:
  * xr_hashgrid_fwd -> xr_nerf_mlp_fwd[_f16] -> zero-fill of `zero_block` (which must contain grad_w_density, grad_w_color and
- * loss_mse) -> xr_composite_train -> zero-fill of grad_table -> xr_nerf_mlp_bwd[_f16] -> xr_hashgrid_bwd, on `stream`.
+ * loss_mse) -> xr_composite_train -> xr_live_rows -> xr_nerf_mlp_bwd[_f16] -> xr_hashgrid_bwd2(XR_SCATTER_OVERWRITE), on `stream`:
+ * grad_table's slices of the scattered levels are WRITTEN (no zero-fill; whatever they held is gone).
  * coords: K1's [n_rows,7] rows (positions / directions consumed in place); n_dev: device count of valid rows; every buffer
  * is caller-owned (enc_t / denc_t [32][ld], raw / draw [n_rows,4], rgb_out [n_rays,3]); zero_draw != 0 also clears draw
  * (needed only without n_dev).  mlp_mode: 0 = xr_nerf_mlp_fwd / _bwd (fp32 MFMA), 1 = the _f16 pair, 2 = xr_nerf_mlp_fwd_bf16x3
  * + xr_nerf_mlp_bwd.  scatter_level0: the step scatters hash levels [scatter_level0, n_levels) only (0 = all) -- a
  * data-parallel caller hands that slice of grad_table to its gradient collective and then scatters the coarser levels with
- * xr_hashgrid_bwd on the same row list (xr_nerf_mlp_bwd_list_slots), so the exchange runs under the rest of the backward.
+ * xr_hashgrid_bwd2(XR_SCATTER_OVERWRITE) on the same row list (xr_nerf_mlp_bwd_list_slots), so the exchange runs under the rest
+ * of the backward.
  * Same kernels and results as the separate calls -- this exists because issuing them one by
  * one from an interpreter costs as much host time as the kernels take on the device. */
 int xr_ngp_train_step(const float* table, const float* w_density, const float* w_color, int n_hidden_density, int n_hidden_color,
@@ -276,8 +290,8 @@ int xr_ngp_train_step(const float* table, const float* w_density, const float* w
 /* timed_entry (nullable): the name of ONE of the entry points the step runs ("xr_hashgrid_fwd", "xr_nerf_mlp_fwd",
  * "xr_composite_train", "xr_live_rows", "xr_nerf_mlp_bwd", "xr_hashgrid_bwd"): its launches are bracketed on `stream` by the two
  * events (xr_timing_event_create) -- bench.py's live duration of the dominant kernel inside the timed region.
- * XR_STEP_OVERLAP=1 moves the zero-fill of grad_table and the reduction of the MLP backward's partials to a helper stream
- * (measured slower on the MI355X, kept as a switch). */
+ * XR_STEP_OVERLAP=1 moves the reduction of the MLP backward's partials to a helper stream (measured slower on the MI355X,
+ * kept as a switch). */
 void* xr_timing_event_create(void);
 int xr_timing_event_destroy(void* event);
 int xr_timing_event_elapsed_ms(void* begin, void* end, float* ms);

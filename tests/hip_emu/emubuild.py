@@ -10,6 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, 'xrnerf_amd', 'csrc')
 OUT = os.path.join(HERE, '_build')
 CLANG = '/opt/rocm/lib/llvm/bin/clang++'
+# translation units that call into another one (library-internal C++ interfaces): built into the same shared object
+COMPANIONS = {'xr_encode': ('xr_scatter',)}
 
 
 def build(name, extra=()):
@@ -17,17 +19,21 @@ def build(name, extra=()):
     os.makedirs(OUT, exist_ok=True)
     src = os.path.join(CSRC, name + '.hip')
     so = os.path.join(OUT, 'libemu_%s.so' % name)
-    deps = [src, os.path.join(HERE, 'emu.cpp'), os.path.join(HERE, 'hip', 'hip_runtime.h'), os.path.abspath(__file__)]
+    deps = [src] + [os.path.join(CSRC, u + '.hip') for u in COMPANIONS.get(name, ())] + [os.path.join(HERE, 'emu.cpp'), os.path.join(HERE, 'hip', 'hip_runtime.h'), os.path.abspath(__file__)]
     deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
     if os.path.exists(so) and all(os.path.getmtime(d) <= os.path.getmtime(so) for d in deps):
         return so
-    text = open(src).read()
-    text, n = re.subn(r'extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?(\w+)\s+(\w+)\s*\[\s*\]\s*;',
-                      r'\1* \2 = (\1*)emu::dyn_lds();', text)
-    cpp = os.path.join(OUT, name + '_host.cpp')
-    open(cpp, 'w').write('// generated from %s by tests/hip_emu/emubuild.py (%d dynamic-LDS declarations rewritten)\n' % (src, n) + text)
+    cpps = []
+    for unit in (name,) + COMPANIONS.get(name, ()):
+        usrc = os.path.join(CSRC, unit + '.hip')
+        text = open(usrc).read()
+        text, n = re.subn(r'extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?(\w+)\s+(\w+)\s*\[\s*\]\s*;',
+                          r'\1* \2 = (\1*)emu::dyn_lds();', text)
+        cpp = os.path.join(OUT, unit + '_host.cpp')
+        open(cpp, 'w').write('// generated from %s by tests/hip_emu/emubuild.py (%d dynamic-LDS declarations rewritten)\n' % (usrc, n) + text)
+        cpps.append(cpp)
     cmd = [CLANG, '-x', 'c++', '-std=c++17', '-O1', '-g0', '-fPIC', '-shared', '-ffp-contract=off', '-Wno-everything',
-           '-I', HERE, '-I', CSRC, cpp, os.path.join(HERE, 'emu.cpp'), '-o', so] + list(extra)
+           '-I', HERE, '-I', CSRC] + cpps + [os.path.join(HERE, 'emu.cpp'), '-o', so] + list(extra)
     subprocess.check_call(cmd)
     return so
 

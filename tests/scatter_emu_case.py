@@ -1,0 +1,92 @@
+"""TEST INFRASTRUCTURE: one process = one setting of the scatter's process-wide switches (XR_SC_MODE / XR_SC_BLOCK / XR_SC_RL /
+XR_SC_RL_CHUNKS / XR_SC_MIN_N are read once).  Runs xr_hashgrid_bwd2 of the kernels' host build (tests/hip_emu) against
+oracle/ngp_oracle.c on `n` positions drawn as `mode` and prints one line per check; exit code 0 = all within tolerance.
+usage: python tests/scatter_emu_case.py <n> <rand|rays|cluster>"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'tests', 'hip_emu'), os.path.join(ROOT, 'oracle')):
+    sys.path.insert(0, p)
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+
+
+def positions(n, mode, rng):
+    x = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    if mode == 'cluster':            # every sample in one cell: sub-bins overflow into the overflow lists
+        x[:] = np.array([0.4371, 0.5113, 0.6207], np.float32)
+        x[: n // 3] += rng.uniform(0, 1e-3, (n // 3, 3)).astype(np.float32)
+    elif mode == 'rays':             # 20 consecutive samples per ray, sqrt(3)/1024 apart: the run-length paths
+        nr = n // 20
+        o3 = rng.uniform(0.2, 0.8, (nr, 3)).astype(np.float32)
+        d3 = rng.normal(0, 1, (nr, 3)).astype(np.float32)
+        d3 /= np.linalg.norm(d3, axis=1, keepdims=True)
+        k = np.arange(nr * 20)
+        x[:nr * 20] = np.clip(o3[k // 20] + (np.float32(0.0017) * (k % 20).astype(np.float32))[:, None] * d3[k // 20], 0, 1)
+    x[0] = [0.0, 1.0, 0.5]
+    x[1] = [1.0, 1.0, 1.0]           # index wrap-around at the upper corner of the domain
+    return x
+
+
+def main(n, mode):
+    import emulib
+    import oracle as O
+    ok = True
+    with emulib.emulated_ops():
+        from xrnerf_amd import ops
+        meta, om = ops.GridMeta(), O.GridMeta()
+        rng = np.random.default_rng(n)
+        x = positions(n, mode, rng)
+        dy = rng.normal(0, 1, (n, 32)).astype(np.float32)
+        dy[5:9] = 0
+        ref = O.hashgrid_bwd(x, dy, om)
+        ld = (n + 63) // 64 * 64
+        dt = torch.zeros((32, ld))
+        dt[:, :n] = torch.from_numpy(dy).t()
+        dt = dt.contiguous()
+        tx = torch.from_numpy(x)
+
+        def report(tag, g, refv):
+            nonlocal ok
+            err = np.abs(g.numpy() - refv)
+            tol = 2e-5 * max(1.0, float(np.abs(refv).max()))
+            bad = [lv for lv in range(16) if err[2 * int(meta.offset[lv]):2 * int(meta.offset[lv + 1])].max() > tol]
+            ok = ok and not bad
+            print('%-26s max err %.3e (|ref| max %.3e) levels out of tolerance: %s' % (tag, err.max(), np.abs(refv).max(), bad))
+
+        for ow in (False, True):
+            g = torch.full((meta.n_params,), 7.0) if ow else torch.zeros(meta.n_params)
+            ops.hashgrid_bwd(tx, dt, meta, g, overwrite=ow)
+            report('overwrite=%s' % ow, g, ref)
+        g = torch.zeros(meta.n_params)
+        ops.hashgrid_bwd(tx, dt, meta, g, levels=(8, 16))
+        ops.hashgrid_bwd(tx, dt, meta, g, levels=(0, 8))
+        report('levels 8-16, then 0-8', g, ref)
+        g = torch.full((meta.n_params,), 3.0)
+        ops.hashgrid_bwd(tx, dt, meta, g, levels=(3, 16), overwrite=True)
+        ops.hashgrid_bwd(tx, dt, meta, g, levels=(0, 3), overwrite=True)
+        report('overwrite 3-16, then 0-3', g, ref)
+        live = np.flatnonzero(rng.uniform(size=n) < 0.45).astype(np.int32)
+        dy2 = np.zeros_like(dy)
+        dy2[live] = dy[live]
+        rows = torch.zeros(n, dtype=torch.int32)
+        rows[:len(live)] = torch.from_numpy(live)
+        dtp = dt.clone()
+        dtp[:, np.setdiff1d(np.arange(n), live)] = float('nan')       # rows outside the list must never be read
+        g = torch.full((meta.n_params,), 5.0)
+        ops.hashgrid_bwd(tx, dtp.contiguous(), meta, g, live=(rows, torch.tensor([len(live), 0, 0, 0], dtype=torch.int32)), overwrite=True)
+        report('live-row list', g, O.hashgrid_bwd(x, dy2, om))
+        dy3 = dy.copy()
+        dy3[n // 3:] = 0
+        g = torch.zeros(meta.n_params)
+        ops.hashgrid_bwd(tx, dt, meta, g, n_dev=torch.tensor([n // 3], dtype=torch.int32))
+        report('device-side count n/3', g, O.hashgrid_bwd(x, dy3, om))
+        g = torch.full((meta.n_params,), 9.0)
+        ops.hashgrid_bwd(tx, dt, meta, g, n_dev=torch.tensor([0], dtype=torch.int32), overwrite=True)
+        report('device-side count 0', g, np.zeros_like(ref))
+    return 0 if ok else 1
+
+
+if __name__ == '__main__':
+    sys.exit(main(int(sys.argv[1]), sys.argv[2]))

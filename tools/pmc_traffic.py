@@ -9,7 +9,9 @@ once per training step), plus the sums over the kernels that make up one C-ABI e
 import collections, csv, json, sys
 
 ENTRY = {   # entry point -> kernels launched by it (include/xrnerf_mi355.h)
-    'xr_hashgrid_bwd': ['k_scatter_bin2', 'k_scatter_accum2', 'k_scatter_bin', 'k_scatter_accum', 'k_hashgrid_bwd', 'k_reduce_replicas'],
+    'xr_hashgrid_bwd': ['k_scatter_bin2', 'k_scatter_accum2', 'k_scatter_bin', 'k_scatter_accum', 'k_hashgrid_bwd', 'k_reduce_replicas',
+                        'void k_scatter_bin3<4096>', 'void k_scatter_bin3<2048>', 'void k_scatter_bin3<1024>', 'k_scatter_accum3', 'k_scatter_dense_rl',
+                        'k_scatter_fold'],
     'xr_hashgrid_fwd': ['k_hashgrid_fwd'],
     'xr_nerf_mlp_bwd': ['k_nerf_mlp_bwd_1_2', 'void k_nerf_mlp_bwd_1_2<true>', 'void k_nerf_mlp_bwd_1_2<false>', 'k_reduce_partials'],
     'xr_live_rows': ['k_live_count', 'k_live_fill'],
@@ -35,7 +37,16 @@ def per_kernel(path):
     return out
 
 
+def show(path):
+    d = json.load(open(path))
+    for k in ('xr_hashgrid_bwd', 'xr_hashgrid_fwd', 'xr_nerf_mlp_bwd', 'xr_nerf_mlp_fwd', 'xr_adam_step', 'xr_live_rows', 'xr_composite_train'):
+        if k in d:
+            print(k, {a: (round(b / 1e6, 1) if isinstance(b, float) and b > 1e4 else b) for a, b in d[k].items()})
+
+
 def main():
+    if sys.argv[1] == '--print':
+        return show(sys.argv[2])
     fetch, write = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
     hm = per_kernel(sys.argv[3]) if len(sys.argv) > 3 else {}
     res = {}

@@ -21,6 +21,8 @@ SOURCES = {
     'xr_grid.hip': ['-ffp-contract=off'],
     # the hash-grid cell index is floor(x*scale+0.5): an index decision at scale up to 2047
     'xr_encode.hip': ['-ffp-contract=off'],
+    # same index decisions and the same weight products as the gather
+    'xr_scatter.hip': ['-ffp-contract=off'],
     'xr_mlp.hip': [],
     'xr_misc.hip': ['-ffp-contract=off'],
     # Mip-NeRF stages: fp32 in the reference's operation order (lower + (upper-lower)*rand etc.)
@@ -49,7 +51,8 @@ def _stale(dst, srcs):
 
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, 'xr_common.h'), os.path.join(CSRC, 'xr_mip_math.h'), os.path.join(HERE, '..', 'include', 'xrnerf_mi355.h'),
+    headers = [os.path.join(CSRC, 'xr_common.h'), os.path.join(CSRC, 'xr_mip_math.h'), os.path.join(CSRC, 'xr_hashgrid.h'),
+               os.path.join(CSRC, 'xr_scatter.h'), os.path.join(HERE, '..', 'include', 'xrnerf_mi355.h'),
                os.path.abspath(__file__)]
     have_src = all(os.path.exists(os.path.join(CSRC, s)) for s in SOURCES)
     if not have_src:

@@ -9,27 +9,9 @@
 // one level before it starts the next, so the 4 MiB slice it is gathering from stays in its
 // private 4 MiB L2 instead of thrashing over all 16 levels.  Features are written FEATURE-MAJOR ([2L][ld]) so that both these stores and the MLP's
 // MFMA operand loads are 256-B coalesced rows.
-#include "xr_common.h"
+#include "xr_hashgrid.h"
+#include "xr_scatter.h"
 #include <cstdlib>
-
-#define EN_BLOCK 256
-#define EN_MAX_LEVELS 16
-
-struct GridMeta {
-    float scale[EN_MAX_LEVELS];
-    uint32_t res[EN_MAX_LEVELS];
-    uint32_t off[EN_MAX_LEVELS + 1];
-    int n_levels;
-    uint32_t n_sblocks;   // sample blocks per level
-    int order;            // 0: levels of an XCD interleaved, 1: level-major within the XCD, 2: all XCDs share every
-                          // level, 3: level-major AND work-balanced over the XCDs (hg_balanced_block)
-    uint8_t wsh[EN_MAX_LEVELS];   // order 3: log2 of the relative cost of one sample block of the level
-    uint32_t wsum;                // order 3: sum of the costs of levels [l_min, n_levels)
-    int l_min;                    // order 3: first level this launch covers (lower ones: k_hashgrid_fwd_lds)
-    int nt;                       // non-temporal (L1-bypassing) table loads at the hashed levels
-    int pairs;                    // round-1 gather: 16-B loads for adjacent x-neighbour pairs (divergent)
-    uint32_t n_hashed;            // order 4: levels [n_levels - n_hashed, n_levels) are the hashed list
-};
 
 extern "C" void xr_hashgrid_meta(int n_levels, int log2_hashmap_size, int base_resolution, double per_level_scale,
                                  float* scale, uint32_t* resolution, uint32_t* offset) {
@@ -50,17 +32,6 @@ extern "C" void xr_hashgrid_meta(int n_levels, int log2_hashmap_size, int base_r
     offset[n_levels] = off;
 }
 
-__device__ inline uint32_t grid_index(uint32_t cx, uint32_t cy, uint32_t cz, uint32_t res, uint32_t hsize, bool hashed) {
-    uint32_t index;
-    if (hashed) index = cx ^ (cy * 2654435761u) ^ (cz * 805459861u);
-    else index = cx + cy * res + cz * res * res;
-    return index % hsize;
-}
-// the same for a power-of-two slice (every hashed level of the usual geometries): `% hsize` is a mask -- no reciprocal
-// multiply pair (quarter rate) and two corrections per corner
-__device__ inline uint32_t grid_index_pow2(uint32_t cx, uint32_t cy, uint32_t cz, uint32_t hmask) {
-    return (cx ^ (cy * 2654435761u) ^ (cz * 805459861u)) & hmask;
-}
 // tcnn's stride loop (`for dim while stride <= hashmap_size`) followed by `if hashmap_size < stride`
 // reduces, for 3-D inputs, to: hashed iff res^3 > hashmap_size (computed on the host side of the
 // launch in 64-bit, passed as a flag bit per level)
@@ -809,26 +780,6 @@ __global__ __launch_bounds__(256) void k_reduce_replicas(const float4* __restric
     grad_table[e] = t;
 }
 
-static int fill_meta(GridMeta* gm, uint32_t* hashed_mask, int n_levels, const float* scale, const uint32_t* res,
-                     const uint32_t* off) {
-    if (n_levels < 1 || n_levels > EN_MAX_LEVELS || !scale || !res || !off) return -1;
-    gm->n_levels = n_levels;
-    gm->l_min = 0; gm->nt = 0; gm->wsum = 0; gm->n_sblocks = 0; gm->pairs = 0; gm->n_hashed = 0;
-    memset(gm->wsh, 0, sizeof(gm->wsh));
-    *hashed_mask = 0;
-    for (int l = 0; l < n_levels; ++l) {
-        gm->scale[l] = scale[l]; gm->res[l] = res[l]; gm->off[l] = off[l];
-        const uint64_t hsize = off[l + 1] - off[l];
-        // tcnn: stride accumulates while stride <= hsize; hashed iff hsize < final stride
-        uint64_t stride = 1;
-        for (int d = 0; d < 3 && stride <= hsize; ++d) stride *= res[l];
-        if (hsize < stride) *hashed_mask |= 1u << l;
-    }
-    gm->off[n_levels] = off[n_levels];
-    gm->order = 1;   // measured: forward gather 0.154 -> 0.115 ms at 2^18 samples
-    return 0;
-}
-
 static int scatter_env(const char* name, int dflt);
 extern "C" int xr_hashgrid_fwd(const float* table, const float* x, uint32_t x_stride, uint32_t n, const uint32_t* n_dev,
                                const uint32_t* rows, int n_levels, const float* scale_host, const uint32_t* resolution_host,
@@ -912,8 +863,8 @@ static int scatter_env(const char* name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
-static int sc_mode() {          // XR_SC_MODE=0: first-generation bin / accumulate pair (measurement)
-    static const int m = scatter_env("XR_SC_MODE", 1);
+static int sc_mode() {          // XR_SC_MODE: 2 = third generation (xr_scatter.hip, default); 1 / 0 = the second / first bin /
+    static const int m = scatter_env("XR_SC_MODE", 2);   // accumulate pair with the atomic kernel for the dense levels (measurement)
     return m;
 }
 // Which levels take which path, and the workspace layout:  [fill counts][bins][replicas of the dense slices]
@@ -958,18 +909,15 @@ extern "C" size_t xr_hashgrid_bwd_workspace_bytes(uint32_t n, int n_levels, cons
     GridMeta gm; uint32_t hm;
     float dummy[EN_MAX_LEVELS] = {0};
     if (fill_meta(&gm, &hm, n_levels, dummy, resolution_host, offset_host) != 0) return 0;
+    if (sc_mode() == 2) return xr_scatter3_workspace_bytes(n, gm, hm);
     const ScatterPlan p = scatter_plan(n, n_levels, gm.res, gm.off, hm);
     return p.counts_bytes + p.bins_bytes + p.rep_bytes;
 }
 
-extern "C" int xr_hashgrid_bwd(const float* x, uint32_t x_stride, const float* denc_t, uint32_t ld, uint32_t n, const uint32_t* n_dev,
+static int hashgrid_bwd_gen12(const float* x, uint32_t x_stride, const float* denc_t, uint32_t ld, uint32_t n, const uint32_t* n_dev,
                                const uint32_t* rows, int n_levels,
                                const float* scale_host, const uint32_t* resolution_host, const uint32_t* offset_host,
                                float* grad_table, void* workspace, size_t workspace_bytes, void* stream_) {
-    if (n == 0) return XR_OK;
-    XR_REQUIRE(x && denc_t && grad_table, "null pointer");
-    XR_REQUIRE(x_stride >= 3 && ld >= n, "bad stride");
-    XR_REQUIRE(!rows || n_dev, "a row list comes with its device-side length (n_dev)");
     GridMeta gm; uint32_t hm;
     XR_REQUIRE(fill_meta(&gm, &hm, n_levels, scale_host, resolution_host, offset_host) == 0, "bad level metadata");
     hipStream_t stream = (hipStream_t)stream_;
@@ -1062,6 +1010,66 @@ extern "C" int xr_hashgrid_bwd(const float* x, uint32_t x_stride, const float* d
     }
     if (forked) XR_HIP(hipStreamWaitEvent(stream, ev_join, 0));
     return XR_OK;
+}
+
+// Levels of `mask` through the atomic kernel (small n, tiny or oddly shaped tables): one launch per run of consecutive levels
+static int hashgrid_bwd_atomic_levels(const GridMeta& gm, uint32_t hm, uint32_t mask, const float* x, uint32_t x_stride, const float* denc_t,
+                                      uint32_t ld, uint32_t n, const uint32_t* n_dev, const uint32_t* rows, float* grad_table, int overwrite,
+                                      hipStream_t stream) {
+    int l = 0;
+    while (l < gm.n_levels) {
+        if (!((mask >> l) & 1)) { ++l; continue; }
+        int e = l;
+        while (e < gm.n_levels && ((mask >> e) & 1)) ++e;
+        GridMeta gd = gm;
+        gd.n_levels = e - l;
+        for (int i = 0; i < gd.n_levels; ++i) { gd.scale[i] = gm.scale[l + i]; gd.res[i] = gm.res[l + i]; gd.off[i] = gm.off[l + i]; }
+        gd.off[gd.n_levels] = gm.off[e];
+        if (gd.n_levels & 7) gd.order = 2;
+        gd.n_sblocks = xr_div_up(n, BW_CH * (EN_BLOCK / 16));
+        const uint32_t blocks = (gd.order == 2 ? (uint32_t)gd.n_levels : 8u * ((gd.n_levels + 7) / 8)) * gd.n_sblocks;
+        if (overwrite) XR_HIP(hipMemsetAsync(grad_table + 2 * (size_t)gm.off[l], 0, 2 * (size_t)(gm.off[e] - gm.off[l]) * sizeof(float), stream));
+        hipLaunchKernelGGL(k_hashgrid_bwd, dim3(blocks), dim3(EN_BLOCK), 0, stream, gd, hm >> l, x, x_stride, denc_t + (size_t)2 * l * ld, ld,
+                           n, n_dev, rows, grad_table, (float*)nullptr, 0u, 0u, 0u);
+        XR_LAUNCH_CHECK();
+        l = e;
+    }
+    return XR_OK;
+}
+
+extern "C" int xr_hashgrid_bwd2(const float* x, uint32_t x_stride, const float* denc_t, uint32_t ld, uint32_t n, const uint32_t* n_dev,
+                                const uint32_t* rows, int n_levels, const float* scale_host, const uint32_t* resolution_host,
+                                const uint32_t* offset_host, float* grad_table, void* workspace, size_t workspace_bytes, int flags,
+                                void* stream_) {
+    XR_REQUIRE(grad_table && scale_host && resolution_host && offset_host, "null pointer");
+    XR_REQUIRE((flags & ~XR_SCATTER_OVERWRITE) == 0, "unknown flag");
+    const int overwrite = (flags & XR_SCATTER_OVERWRITE) ? 1 : 0;
+    hipStream_t stream = (hipStream_t)stream_;
+    GridMeta gm; uint32_t hm;
+    XR_REQUIRE(fill_meta(&gm, &hm, n_levels, scale_host, resolution_host, offset_host) == 0, "bad level metadata");
+    if (n == 0) {
+        if (overwrite) XR_HIP(hipMemsetAsync(grad_table + 2 * (size_t)gm.off[0], 0, 2 * (size_t)(gm.off[n_levels] - gm.off[0]) * sizeof(float), stream));
+        return XR_OK;
+    }
+    XR_REQUIRE(x && denc_t, "null pointer");
+    XR_REQUIRE(x_stride >= 3 && ld >= n, "bad stride");
+    XR_REQUIRE(!rows || n_dev, "a row list comes with its device-side length (n_dev)");
+    if (sc_mode() != 2) {
+        if (overwrite) XR_HIP(hipMemsetAsync(grad_table + 2 * (size_t)gm.off[0], 0, 2 * (size_t)(gm.off[n_levels] - gm.off[0]) * sizeof(float), stream));
+        return hashgrid_bwd_gen12(x, x_stride, denc_t, ld, n, n_dev, rows, n_levels, scale_host, resolution_host, offset_host, grad_table,
+                                  workspace, workspace_bytes, stream_);
+    }
+    uint32_t amask = 0;
+    const int rc = xr_scatter3(x, x_stride, denc_t, ld, n, n_dev, rows, gm, hm, grad_table, workspace, workspace_bytes, overwrite, &amask, stream);
+    if (rc != XR_OK) return rc;
+    return amask ? hashgrid_bwd_atomic_levels(gm, hm, amask, x, x_stride, denc_t, ld, n, n_dev, rows, grad_table, overwrite, stream) : XR_OK;
+}
+
+extern "C" int xr_hashgrid_bwd(const float* x, uint32_t x_stride, const float* denc_t, uint32_t ld, uint32_t n, const uint32_t* n_dev,
+                               const uint32_t* rows, int n_levels, const float* scale_host, const uint32_t* resolution_host,
+                               const uint32_t* offset_host, float* grad_table, void* workspace, size_t workspace_bytes, void* stream_) {
+    return xr_hashgrid_bwd2(x, x_stride, denc_t, ld, n, n_dev, rows, n_levels, scale_host, resolution_host, offset_host, grad_table, workspace,
+                            workspace_bytes, 0, stream_);
 }
 
 // ------------------------------------------------------------------ SH degree 4 (tcnn SphericalHarmonics)

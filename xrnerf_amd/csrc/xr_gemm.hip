@@ -330,9 +330,14 @@ static int gemm_launch(GemmArgs g, uint32_t splits, void* stream) {
     //                    1.05-1.3x the fp32-MFMA kernel), the fp32-MFMA kernel for the two backward products
     //   bf16x3all      : the split kernel for all three products ([k, rows] operands read with per-k dword loads)
     //   mfma           : the fp32-MFMA kernel throughout
+    // Anything else is an error.  NOTE the split kernels' operand range: an Inf (or a magnitude within 2^-8 of FLT_MAX, whose
+    // bf16 head rounds to Inf) turns into NaN inside the split (Inf - Inf); the fp32-MFMA kernel propagates it like an fmaf chain.
     const char* env = getenv("XR_GEMM_F32");
+    const bool dflt = !env || !env[0] || strcmp(env, "bf16x3") == 0;
     const bool all = env && strcmp(env, "bf16x3all") == 0;
-    const bool split = !(env && env[0] == 'm') && (all || (!g.a_km && !g.b_kn));
+    const bool mfma = env && strcmp(env, "mfma") == 0;
+    XR_REQUIRE(dflt || all || mfma, "XR_GEMM_F32 must be bf16x3, bf16x3all or mfma");
+    const bool split = !mfma && (all || (!g.a_km && !g.b_kn));
     g.tload = all ? 1 : 0;
     const uint32_t kb = split ? (uint32_t)G3K : (uint32_t)GBK;
     g.k_per_split = (uint32_t)(((uint64_t)(g.Kc + splits - 1) / splits + kb - 1) / kb * kb);

@@ -1,0 +1,55 @@
+// Level geometry of the multiresolution hash grid shared by the gather (xr_encode.hip) and the scatter (xr_encode.hip,
+// xr_scatter.hip) translation units.  tcnn surface: /root/reference/xrnerf/models/mlps/hashnerf_mlp.py:34-37.
+#pragma once
+#include "xr_common.h"
+
+#define EN_BLOCK 256
+#define EN_MAX_LEVELS 16
+
+struct GridMeta {
+    float scale[EN_MAX_LEVELS];
+    uint32_t res[EN_MAX_LEVELS];
+    uint32_t off[EN_MAX_LEVELS + 1];
+    int n_levels;
+    uint32_t n_sblocks;   // sample blocks per level
+    int order;            // 0: levels of an XCD interleaved, 1: level-major within the XCD, 2: all XCDs share every
+                          // level, 3: level-major AND work-balanced over the XCDs (hg_balanced_block)
+    uint8_t wsh[EN_MAX_LEVELS];   // order 3: log2 of the relative cost of one sample block of the level
+    uint32_t wsum;                // order 3: sum of the costs of levels [l_min, n_levels)
+    int l_min;                    // order 3: first level this launch covers (lower ones: k_hashgrid_fwd_lds)
+    int nt;                       // non-temporal (L1-bypassing) table loads at the hashed levels
+    int pairs;                    // round-1 gather: 16-B loads for adjacent x-neighbour pairs (divergent)
+    uint32_t n_hashed;            // order 4: levels [n_levels - n_hashed, n_levels) are the hashed list
+};
+
+__device__ inline uint32_t grid_index(uint32_t cx, uint32_t cy, uint32_t cz, uint32_t res, uint32_t hsize, bool hashed) {
+    uint32_t index;
+    if (hashed) index = cx ^ (cy * 2654435761u) ^ (cz * 805459861u);
+    else index = cx + cy * res + cz * res * res;
+    return index % hsize;
+}
+// the same for a power-of-two slice (every hashed level of the usual geometries): `% hsize` is a mask -- no reciprocal
+// multiply pair (quarter rate) and two corrections per corner
+__device__ inline uint32_t grid_index_pow2(uint32_t cx, uint32_t cy, uint32_t cz, uint32_t hmask) {
+    return (cx ^ (cy * 2654435761u) ^ (cz * 805459861u)) & hmask;
+}
+static inline int fill_meta(GridMeta* gm, uint32_t* hashed_mask, int n_levels, const float* scale, const uint32_t* res,
+                     const uint32_t* off) {
+    if (n_levels < 1 || n_levels > EN_MAX_LEVELS || !scale || !res || !off) return -1;
+    gm->n_levels = n_levels;
+    gm->l_min = 0; gm->nt = 0; gm->wsum = 0; gm->n_sblocks = 0; gm->pairs = 0; gm->n_hashed = 0;
+    memset(gm->wsh, 0, sizeof(gm->wsh));
+    *hashed_mask = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        gm->scale[l] = scale[l]; gm->res[l] = res[l]; gm->off[l] = off[l];
+        const uint64_t hsize = off[l + 1] - off[l];
+        // tcnn: stride accumulates while stride <= hsize; hashed iff hsize < final stride
+        uint64_t stride = 1;
+        for (int d = 0; d < 3 && stride <= hsize; ++d) stride *= res[l];
+        if (hsize < stride) *hashed_mask |= 1u << l;
+    }
+    gm->off[n_levels] = off[n_levels];
+    gm->order = 1;   // measured: forward gather 0.154 -> 0.115 ms at 2^18 samples
+    return 0;
+}
+

@@ -1,0 +1,11 @@
+// library-internal interface of the third-generation scatter (xr_scatter.hip), called from xr_hashgrid_bwd2 (xr_encode.hip)
+#pragma once
+#include "xr_hashgrid.h"
+
+// bytes of workspace xr_scatter3 needs for n rows (0: this n / geometry takes the atomic kernel for every level)
+size_t xr_scatter3_workspace_bytes(uint32_t n, const GridMeta& gm, uint32_t hashed_mask);
+// scatters every level it has a non-atomic path for and reports the others in *atomic_mask (the caller runs the atomic
+// kernel on those).  overwrite != 0: the levels' table slices are written, not added to.
+int xr_scatter3(const float* x, uint32_t x_stride, const float* denc_t, uint32_t ld, uint32_t n, const uint32_t* n_dev,
+                const uint32_t* rows, const GridMeta& gm, uint32_t hashed_mask, float* grad_table, void* workspace,
+                size_t workspace_bytes, int overwrite, uint32_t* atomic_mask, hipStream_t stream);

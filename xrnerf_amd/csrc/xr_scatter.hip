@@ -1,0 +1,608 @@
+// Third generation of the hash-grid scatter (backward of tcnn's HashGrid encoding as called from
+// /root/reference/xrnerf/models/mlps/hashnerf_mlp.py:34-37,59-61): EVERY level without a global atomic, no helper
+// stream, results independent of the launch schedule up to the order of fp64 additions inside one workgroup.
+//
+// What round 2 measured on the second generation (profiles/r02_scatter_phase_timing.txt):
+//   * the dense levels' atomic kernel (55 us alone) beside the bin / accumulate pair stretches that pair from 39 + 56 to
+//     73 + 64 us -- the overlap costs what it hides;
+//   * inside k_scatter_accum2 the item stream (11.5 us per workgroup) and the LDS atomics (12 us) do NOT overlap (23.8 us
+//     together): the loop reads the sub-bin fill counts from LDS, LDS operations retire in order, so the read -- and the
+//     global loads of the next items behind it -- waits for every queued atomic;
+//   * the accumulate kernel reads the 46 MB of the hashed levels' gradient slices only to add to the zeros a 48.8-MB
+//     zero-fill wrote a few kernels earlier.
+// Here:
+//   kind H  hashed levels (power-of-two slices >= 2^13 entries): bin by bits [13, ..) of y*P1 ^ z*P2 as before;
+//   kind D  dense levels above 2^16 entries: the same bin / accumulate pair, partition = (16-entry block) mod P with P = 32
+//           or 64 -- neighbouring cells land in different partitions, so the load is as even as a hash's; an x-neighbour pair
+//           that straddles two blocks (x & 15 == 15 ... 1 in 16) becomes two single-entry items;
+//   kind R  dense levels up to 2^16 entries (levels 0-2 of the Lego geometry: 4 096 + 12 168 + 29 792 entries, where a
+//           ray's 20 samples fall into two or three cells): one THREAD walks 16 consecutive rows with the 16 corner sums of
+//           the current cell in registers and flushes them into a workgroup-private fp64 LDS copy of its 2^13-entry
+//           partition on a cell change (run-length reduction: ~10x fewer LDS atomics, lanes of a wave sit on different
+//           rays, so no same-address serialisation); per-chunk partials are folded in fixed order by k_scatter_fold;
+//   items that do not fit their sub-bin (capacity 1.5x the expected fill) go to the workgroup's private overflow list and
+//   are picked up by the accumulate workgroup of their partition -- any input stays correct, nothing ever touches the
+//   table with an atomic, and the table slice can therefore be WRITTEN instead of added to (flag XR_SCATTER_OVERWRITE:
+//   the training step drops its 48.8-MB zero-fill);
+//   the accumulate loop keeps its sub-bin fill counts in a VGPR (lane i of wave w: sub-bin w + 16 i, read with
+//   v_readlane): no LDS read sits between the item loads and the returnless LDS atomics.
+#include "xr_hashgrid.h"
+#include "xr_scatter.h"
+#include <cstdlib>
+
+#define S3_LOG2 13
+#define S3_ENTRIES (1u << S3_LOG2)
+#define S3_LDS_BYTES (S3_ENTRIES * 2 * sizeof(double))
+#define S3_MAX_PARTS 256
+#define S3_MAX_SB 1024
+#define S3_BIN_THREADS 512
+#define S3_ACC_THREADS 1024
+#define S3_ACC_WAVES (S3_ACC_THREADS / 64)
+#define S3_ROUND_ITEMS 4096                          // items staged in LDS per binning round
+#define S3_R_MAX_ENTRIES 65536u                      // dense levels up to this size take the run-length kernel
+#define S3_R_ROWS 16                                 // consecutive rows per thread there
+#define S3_R_THREADS 1024
+
+enum { S3_H = 0, S3_D = 1 };
+
+struct S3Level {
+    float scale;
+    uint32_t res, hsize, toff;       // table offset in entries
+    uint32_t kind, parts, plog2;     // partitions (kind D: a power of two, plog2 its log2)
+    uint32_t cap;                    // items per sub-bin
+    uint32_t drow;                   // row of the level's feature 0 in denc_t
+    uint32_t counts_off;             // words into counts: [part][nsb]
+    uint32_t acc_block0;             // first workgroup of this level in the accumulate grid
+    uint32_t pad_;
+    uint64_t bins_off;               // items into bins: [part][sb][cap]
+    uint64_t ovf_off;                // records into the overflow area: [sb][ovf_cap]
+};
+struct S3Plan {
+    S3Level lv[EN_MAX_LEVELS];
+    uint32_t n_lv, nsb, ovf_cap, overwrite;
+    uint32_t ovfcnt_off;             // words into counts: [lv][nsb]
+    uint32_t acc_blocks;
+};
+struct S3RLevel {
+    float scale;
+    uint32_t res, hsize, toff, parts, drow;
+    uint32_t poff;                   // entries before this level in a partial slab
+    uint32_t block0;                 // first workgroup of this level: [part][chunk]
+};
+struct S3RPlan {
+    S3RLevel lv[EN_MAX_LEVELS];
+    uint32_t n_lv, chunks, slab_entries, overwrite, blocks;
+};
+
+// index % hsize of a dense level: inside the unit cube the index is below 2 hsize (x + y res + z res^2 with coordinates <= res)
+__device__ __forceinline__ uint32_t s3_wrap(uint32_t i, uint32_t hsize) {
+    if (i >= hsize) { i -= hsize; if (i >= hsize) i %= hsize; }
+    return i;
+}
+#ifdef __HIP_EMU__
+__device__ inline uint32_t s3_readlane(uint32_t v, uint32_t lane) { return __shfl(v, (int)lane); }
+#else
+__device__ inline uint32_t s3_readlane(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
+#endif
+
+// ------------------------------------------------------------------------------------------------ binning
+// One workgroup = (level, block of BS samples).  Per round of <= 1024 samples: items ranked per partition with LDS counters,
+// placed in LDS in partition order, copied out as contiguous runs (full-line stores).  The inputs of round r + 1 are
+// fetched before round r is ranked and copied out.
+template <int KIND> struct S3Bin {
+    static constexpr int SPT = KIND == S3_H ? 2 : 1;            // samples per thread and round
+    static constexpr int IPS = KIND == S3_H ? 4 : 8;            // items per sample, worst case
+    static constexpr int ROUND = S3_BIN_THREADS * SPT;
+};
+
+template <int KIND, int BS>
+__device__ __forceinline__ void s3_bin_block(const S3Level& L, uint32_t nsb, uint32_t ovf_cap, uint32_t sb, const float* __restrict__ x,
+                                             uint32_t x_stride, const float* __restrict__ denc_t, uint32_t ld, uint32_t n,
+                                             const uint32_t* __restrict__ rows, uint32_t* __restrict__ cnt_out,
+                                             uint32_t* __restrict__ ovfcnt_out, float4* __restrict__ bins, float4* __restrict__ ovf,
+                                             float4* s_items, uint8_t* s_ipart, uint32_t* s_cnt, uint32_t* s_off, uint32_t* s_base,
+                                             uint32_t* s_ovf) {
+    using B = S3Bin<KIND>;
+    constexpr int SPT = B::SPT, IPS = B::IPS, NI = SPT * IPS, ROUND = B::ROUND, ROUNDS = BS / ROUND;
+    static_assert(ROUND * IPS <= S3_ROUND_ITEMS, "a round's items must fit the LDS staging area");
+    const uint32_t parts = L.parts, cap = L.cap, b0 = sb * BS;
+    for (uint32_t p = threadIdx.x; p < parts; p += S3_BIN_THREADS) s_base[p] = 0;
+    if (threadIdx.x == 0) *s_ovf = 0;
+    const float scale = L.scale;
+    const uint32_t res = L.res, hsize = L.hsize, hmask = hsize - 1u, plog2 = L.plog2, pmask = parts - 1u;
+    const float* __restrict__ d0p = denc_t + (size_t)L.drow * ld;
+    const float* __restrict__ d1p = d0p + ld;
+    float4* __restrict__ out = bins + L.bins_off + (size_t)sb * cap;         // [part][sb][cap]
+    float4* __restrict__ ovo = ovf + L.ovf_off + (size_t)sb * ovf_cap;
+    const uint32_t per = (parts + 63u) / 64u;                                // partitions per lane in the offset scan (<= 4)
+    float ld0[SPT], ld1[SPT], lx0[SPT], lx1[SPT], lx2[SPT];
+    auto fetch = [&](uint32_t rb0) {
+#pragma unroll
+        for (int s = 0; s < SPT; ++s) {
+            uint32_t i = min(rb0 + s * S3_BIN_THREADS + threadIdx.x, n - 1);
+            if (rows) i = rows[i];
+            const float* xp = x + (size_t)i * x_stride;
+            ld0[s] = d0p[i]; ld1[s] = d1p[i]; lx0[s] = xp[0]; lx1[s] = xp[1]; lx2[s] = xp[2];
+        }
+    };
+    fetch(b0);
+    for (uint32_t r = 0; r < (uint32_t)ROUNDS; ++r) {
+        const uint32_t rb0 = b0 + r * ROUND;
+        if (rb0 >= n) break;                                                // uniform
+        for (uint32_t p = threadIdx.x; p < parts; p += S3_BIN_THREADS) s_cnt[p] = 0;
+        __syncthreads();
+        uint32_t ipart[NI], irank[NI], ipr[NI];
+        float iva[NI], ivb[NI], iw[NI];
+        bool ion[NI];
+#pragma unroll
+        for (int k = 0; k < NI; ++k) ion[k] = false;
+#pragma unroll
+        for (int s = 0; s < SPT; ++s) {
+            const uint32_t i = rb0 + s * S3_BIN_THREADS + threadIdx.x;
+            const float d0 = ld0[s], d1 = ld1[s];
+            if (!(i < n) || (d0 == 0.f && d1 == 0.f)) continue;             // rows with a zero gradient add nothing
+            const float p0 = lx0[s] * scale + 0.5f, p1 = lx1[s] * scale + 0.5f, p2 = lx2[s] * scale + 0.5f;
+            const float f0 = floorf(p0), f1 = floorf(p1), f2 = floorf(p2);
+            const uint32_t g0 = (uint32_t)(int)f0, g1 = (uint32_t)(int)f1, g2 = (uint32_t)(int)f2;
+            const float w0 = p0 - f0, w1 = p1 - f1, w2 = p2 - f2;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t cy = c & 1u, cz = c >> 1;
+                const float wyz = (cy ? w1 : 1.f - w1) * (cz ? w2 : 1.f - w2);
+                const float va = wyz * d0, vb = wyz * d1;
+                if (KIND == S3_H) {
+                    const int k = s * IPS + c;
+                    const uint32_t h = ((g1 + cy) * 2654435761u) ^ ((g2 + cz) * 805459861u);
+                    const uint32_t i0 = (g0 ^ h) & hmask, i1 = ((g0 + 1u) ^ h) & hmask;
+                    ipart[k] = i0 >> S3_LOG2;                               // == i1 >> S3_LOG2: x < 2^13 never reaches these bits
+                    ipr[k] = (i0 & (S3_ENTRIES - 1)) | ((i1 & (S3_ENTRIES - 1)) << S3_LOG2);
+                    iva[k] = va; ivb[k] = vb; iw[k] = w0; ion[k] = true;
+                } else {
+                    const int k = s * IPS + 2 * c;
+                    const uint32_t base = g0 + (g1 + cy) * res + (g2 + cz) * res * res;
+                    const uint32_t i0 = s3_wrap(base, hsize), i1 = s3_wrap(base + 1u, hsize);
+                    const uint32_t q0 = i0 >> 4, q1 = i1 >> 4;
+                    const uint32_t e0 = ((q0 >> plog2) << 4) | (i0 & 15u), e1 = ((q1 >> plog2) << 4) | (i1 & 15u);
+                    if (q0 == q1) {
+                        ipart[k] = q0 & pmask; ipr[k] = e0 | (e1 << S3_LOG2);
+                        iva[k] = va; ivb[k] = vb; iw[k] = w0; ion[k] = true;
+                    } else {                                                // the pair straddles two blocks: two single-entry items
+                        ipart[k] = q0 & pmask; ipr[k] = e0 | (e0 << S3_LOG2);
+                        iva[k] = (1.f - w0) * va; ivb[k] = (1.f - w0) * vb; iw[k] = 0.f; ion[k] = true;
+                        ipart[k + 1] = q1 & pmask; ipr[k + 1] = e1 | (e1 << S3_LOG2);
+                        iva[k + 1] = w0 * va; ivb[k + 1] = w0 * vb; iw[k + 1] = 0.f; ion[k + 1] = true;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NI; ++k)
+            if (ion[k]) irank[k] = atomicAdd(&s_cnt[ipart[k]], 1u);
+        if (r + 1 < (uint32_t)ROUNDS && rb0 + ROUND < n) fetch(rb0 + ROUND);   // next round's inputs under this round's ranking
+        __syncthreads();
+        if (threadIdx.x < 64) {                                             // exclusive scan of the round's partition counts
+            uint32_t loc[4], sum = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) {
+                const uint32_t idx = threadIdx.x * per + q;
+                loc[q] = sum;
+                if (q < per && idx < parts) sum += s_cnt[idx];
+            }
+            uint32_t incl = sum;
+#pragma unroll
+            for (uint32_t d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d);
+                if (threadIdx.x >= d) incl += o;
+            }
+            const uint32_t excl = incl - sum;
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) {
+                const uint32_t idx = threadIdx.x * per + q;
+                if (q < per && idx < parts) s_off[idx] = excl + loc[q];
+            }
+            if (threadIdx.x == 63) s_off[parts] = incl;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            if (!ion[k]) continue;
+            const uint32_t q = s_off[ipart[k]] + irank[k];
+            s_items[q] = make_float4(__uint_as_float(ipr[k]), iva[k], ivb[k], iw[k]);
+            s_ipart[q] = (uint8_t)ipart[k];
+        }
+        __syncthreads();
+        const uint32_t total = s_off[parts];
+        for (uint32_t q = threadIdx.x; q < total; q += S3_BIN_THREADS) {
+            const uint32_t p = s_ipart[q], rk = q - s_off[p] + s_base[p];
+            const float4 it = s_items[q];
+            if (rk < cap) {
+                out[(size_t)p * nsb * cap + rk] = it;
+            } else {                                                        // overfull sub-bin: two single-entry records
+                const uint32_t pr = __float_as_uint(it.x), e0 = pr & (S3_ENTRIES - 1), e1 = pr >> S3_LOG2;
+                if (e0 == e1) {                                             // a single-entry item (weight 0): one record
+                    const uint32_t o = atomicAdd(s_ovf, 1u);
+                    ovo[o] = make_float4(__uint_as_float(e0 | (p << S3_LOG2)), (1.f - it.w) * it.y, (1.f - it.w) * it.z, 0.f);
+                } else {
+                    const uint32_t o = atomicAdd(s_ovf, 2u);
+                    ovo[o] = make_float4(__uint_as_float(e0 | (p << S3_LOG2)), (1.f - it.w) * it.y, (1.f - it.w) * it.z, 0.f);
+                    ovo[o + 1] = make_float4(__uint_as_float(e1 | (p << S3_LOG2)), it.w * it.y, it.w * it.z, 0.f);
+                }
+            }
+        }
+        __syncthreads();
+        for (uint32_t p = threadIdx.x; p < parts; p += S3_BIN_THREADS) s_base[p] += s_cnt[p];
+    }
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < parts; p += S3_BIN_THREADS) cnt_out[(size_t)p * nsb] = min(s_base[p], cap);
+    if (threadIdx.x == 0) *ovfcnt_out = *s_ovf;
+}
+
+template <int BS>
+__global__ __launch_bounds__(S3_BIN_THREADS) void k_scatter_bin3(S3Plan pl, const float* __restrict__ x, uint32_t x_stride,
+                                                                 const float* __restrict__ denc_t, uint32_t ld, uint32_t n,
+                                                                 const uint32_t* __restrict__ n_dev, const uint32_t* __restrict__ rows,
+                                                                 uint32_t* __restrict__ counts, float4* __restrict__ bins,
+                                                                 float4* __restrict__ ovf) {
+    __shared__ float4 s_items[S3_ROUND_ITEMS];
+    __shared__ uint8_t s_ipart[S3_ROUND_ITEMS];
+    __shared__ uint32_t s_cnt[S3_MAX_PARTS], s_off[S3_MAX_PARTS + 1], s_base[S3_MAX_PARTS], s_ovf;
+    const uint32_t e = pl.n_lv - 1u - blockIdx.x % pl.n_lv, sb = blockIdx.x / pl.n_lv;   // the levels of one sample block are neighbours
+    const S3Level& L = pl.lv[e];
+    if (n_dev) n = min(n, *n_dev);
+    uint32_t* __restrict__ cnt_out = counts + L.counts_off + sb;            // [part][sample block]
+    uint32_t* __restrict__ ovfcnt_out = counts + pl.ovfcnt_off + e * pl.nsb + sb;
+    if (sb * BS >= n) {                                                     // uniform: an empty sample block has empty sub-bins
+        for (uint32_t p = threadIdx.x; p < L.parts; p += S3_BIN_THREADS) cnt_out[(size_t)p * pl.nsb] = 0;
+        if (threadIdx.x == 0) *ovfcnt_out = 0;
+        return;
+    }
+    if (L.kind == S3_H)
+        s3_bin_block<S3_H, BS>(L, pl.nsb, pl.ovf_cap, sb, x, x_stride, denc_t, ld, n, rows, cnt_out, ovfcnt_out, bins, ovf, s_items, s_ipart,
+                               s_cnt, s_off, s_base, &s_ovf);
+    else
+        s3_bin_block<S3_D, BS>(L, pl.nsb, pl.ovf_cap, sb, x, x_stride, denc_t, ld, n, rows, cnt_out, ovfcnt_out, bins, ovf, s_items, s_ipart,
+                               s_cnt, s_off, s_base, &s_ovf);
+}
+
+// ------------------------------------------------------------------------------------------------ accumulate
+// One workgroup = (level, partition): fp64 LDS accumulators (returnless ds_add_f64: 8.6 ns per wave instruction, against 81 ns
+// for ds_add_f32 -- tools/lds_probe.hip), rounded to fp32 once when the partition is written to the table.
+__global__ __launch_bounds__(S3_ACC_THREADS) void k_scatter_accum3(S3Plan pl, const uint32_t* __restrict__ counts,
+                                                                   const float4* __restrict__ bins, const float4* __restrict__ ovf,
+                                                                   float* __restrict__ grad_table) {
+    extern __shared__ __attribute__((aligned(16))) double s_acc[];       // [S3_ENTRIES][2]
+    uint32_t e = 0;
+    while (e + 1 < pl.n_lv && blockIdx.x >= pl.lv[e + 1].acc_block0) ++e;   // levels in accumulate order (heaviest first)
+    const S3Level& L = pl.lv[e];
+    const uint32_t part = blockIdx.x - L.acc_block0, nsb = pl.nsb, cap = L.cap;
+    double2* acc2 = reinterpret_cast<double2*>(s_acc);
+    // entries this partition owns
+    uint32_t n_loc;
+    if (L.kind == S3_H) n_loc = S3_ENTRIES;
+    else { const uint32_t nblk = (L.hsize + 15u) >> 4; n_loc = ((nblk + L.parts - 1u - part) >> L.plog2) << 4; }
+    for (uint32_t q = threadIdx.x; q < n_loc; q += S3_ACC_THREADS) acc2[q] = make_double2(0.0, 0.0);
+    // this wave's sub-bins w, w + 16, ...: their fill counts in one VGPR, the overflow counts of the level's sample blocks too
+    const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t* __restrict__ cnt = counts + L.counts_off + (size_t)part * nsb;
+    const uint32_t my_sb = wave + S3_ACC_WAVES * lane;
+    const uint32_t vfill = my_sb < nsb ? cnt[my_sb] : 0u;
+    const uint32_t vovf = my_sb < nsb ? counts[pl.ovfcnt_off + e * nsb + my_sb] : 0u;
+    __syncthreads();
+    const float4* __restrict__ src = bins + L.bins_off + (size_t)part * nsb * cap;
+    constexpr uint32_t U = 8;
+    const uint32_t n_mine = nsb > wave ? (nsb - wave + S3_ACC_WAVES - 1u) / S3_ACC_WAVES : 0u;   // sub-bins of this wave
+    uint32_t si = 0, c = 0;                                                 // next (sub-bin slot, 64-item chunk): wave-uniform
+    uint32_t fill = n_mine ? s3_readlane(vfill, 0) : 0u;
+    auto skip_empty = [&]() {
+        while (si < n_mine && fill == 0u) { ++si; fill = si < n_mine ? s3_readlane(vfill, si) : 0u; }
+    };
+    skip_empty();
+    float4 nx[U];
+    bool non[U];
+    auto fetch = [&]() {
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+            non[u] = false;
+            if (si < n_mine) {
+                const uint32_t off = c * 64u + lane;
+                non[u] = off < fill;
+                if (non[u]) nx[u] = src[(size_t)(wave + S3_ACC_WAVES * si) * cap + off];
+                ++c;
+                if (c * 64u >= fill) {
+                    c = 0; ++si;
+                    fill = si < n_mine ? s3_readlane(vfill, si) : 0u;
+                    skip_empty();
+                }
+            }
+        }
+    };
+    fetch();
+    for (;;) {
+        float4 it[U];
+        bool on[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) { it[u] = nx[u]; on[u] = non[u]; }
+        const bool more = si < n_mine;                                      // uniform per wave
+        if (more) fetch();
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+            if (!on[u]) continue;
+            const uint32_t pr = __float_as_uint(it[u].x), i0 = pr & (S3_ENTRIES - 1), i1 = pr >> S3_LOG2;
+            const float w0 = it[u].w, a = it[u].y, b = it[u].z;
+            atomicAdd(&s_acc[2 * i0], (double)((1.f - w0) * a));
+            atomicAdd(&s_acc[2 * i0 + 1], (double)((1.f - w0) * b));
+            atomicAdd(&s_acc[2 * i1], (double)(w0 * a));
+            atomicAdd(&s_acc[2 * i1 + 1], (double)(w0 * b));
+        }
+        if (!more) break;
+    }
+    // overflow records of the level's sample blocks (none unless the samples cluster): every partition scans them all
+    if (__ballot(vovf != 0u) != 0ull) {
+        for (uint32_t k = 0; k < n_mine; ++k) {
+            const uint32_t cntk = s3_readlane(vovf, k);
+            const float4* __restrict__ ov = ovf + L.ovf_off + (size_t)(wave + S3_ACC_WAVES * k) * pl.ovf_cap;
+            for (uint32_t q = lane; q < cntk; q += 64u) {
+                const float4 rcd = ov[q];
+                const uint32_t key = __float_as_uint(rcd.x);
+                if ((key >> S3_LOG2) != part) continue;
+                atomicAdd(&s_acc[2 * (key & (S3_ENTRIES - 1))], (double)rcd.y);
+                atomicAdd(&s_acc[2 * (key & (S3_ENTRIES - 1)) + 1], (double)rcd.z);
+            }
+        }
+    }
+    __syncthreads();
+    float2* __restrict__ tab = reinterpret_cast<float2*>(grad_table) + L.toff;
+    const bool add = pl.overwrite == 0u;
+    if (L.kind == S3_H) {
+        float2* __restrict__ dst = tab + (size_t)part * S3_ENTRIES;
+        constexpr uint32_t F = S3_ENTRIES / S3_ACC_THREADS;
+        float2 t[F];
+#pragma unroll
+        for (uint32_t k = 0; k < F; ++k) t[k] = add ? dst[k * S3_ACC_THREADS + threadIdx.x] : make_float2(0.f, 0.f);
+#pragma unroll
+        for (uint32_t k = 0; k < F; ++k) {
+            const double2 a = acc2[k * S3_ACC_THREADS + threadIdx.x];
+            t[k].x += (float)a.x; t[k].y += (float)a.y;
+            dst[k * S3_ACC_THREADS + threadIdx.x] = t[k];
+        }
+    } else {
+        for (uint32_t q = threadIdx.x; q < n_loc; q += S3_ACC_THREADS) {
+            const uint32_t idx = ((((q >> 4) << L.plog2) | part) << 4) | (q & 15u);
+            if (idx >= L.hsize) continue;
+            const double2 a = acc2[q];
+            float2 t = add ? tab[idx] : make_float2(0.f, 0.f);
+            t.x += (float)a.x; t.y += (float)a.y;
+            tab[idx] = t;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ small dense levels
+// kind R.  Workgroup = (level, 2^13-entry partition, chunk of the rows): thread t walks rows [16 t, 16 t + 16) of its chunk
+// keeping the 8 corners x 2 features of the CURRENT cell in registers; on a cell change the 16 sums go to the workgroup's
+// fp64 LDS copy of the partition (only the corners that fall into it).  The chunk's partition is then written as fp32 into
+// slab `chunk` of the workspace; k_scatter_fold adds the slabs in fixed order.
+__device__ __forceinline__ void s3_r_flush(double* s_acc, const float (&acc)[16], uint32_t g0, uint32_t g1, uint32_t g2, uint32_t res,
+                                           uint32_t hsize, uint32_t part) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const uint32_t idx = s3_wrap((g0 + (c & 1)) + (g1 + ((c >> 1) & 1)) * res + (g2 + (c >> 2)) * res * res, hsize);
+        if ((idx >> S3_LOG2) != part) continue;
+        const uint32_t q = idx & (S3_ENTRIES - 1);
+        if (acc[2 * c] != 0.f) atomicAdd(&s_acc[2 * q], (double)acc[2 * c]);
+        if (acc[2 * c + 1] != 0.f) atomicAdd(&s_acc[2 * q + 1], (double)acc[2 * c + 1]);
+    }
+}
+
+__global__ __launch_bounds__(S3_R_THREADS) void k_scatter_dense_rl(S3RPlan pl, const float* __restrict__ x, uint32_t x_stride,
+                                                                   const float* __restrict__ denc_t, uint32_t ld, uint32_t n,
+                                                                   const uint32_t* __restrict__ n_dev, const uint32_t* __restrict__ rows,
+                                                                   float2* __restrict__ slabs) {
+    extern __shared__ __attribute__((aligned(16))) double s_acc[];       // [<= S3_ENTRIES][2]
+    uint32_t e = 0;
+    while (e + 1 < pl.n_lv && blockIdx.x >= pl.lv[e + 1].block0) ++e;
+    const S3RLevel& L = pl.lv[e];
+    const uint32_t rel = blockIdx.x - L.block0, part = rel / pl.chunks, chunk = rel % pl.chunks;
+    if (n_dev) n = min(n, *n_dev);
+    const uint32_t p_lo = part << S3_LOG2, n_loc = min(S3_ENTRIES, L.hsize - p_lo);
+    double2* acc2 = reinterpret_cast<double2*>(s_acc);
+    for (uint32_t q = threadIdx.x; q < n_loc; q += S3_R_THREADS) acc2[q] = make_double2(0.0, 0.0);
+    __syncthreads();
+    // chunk = rows [lo, hi) in units of S3_R_ROWS-row segments, the same number of segments per chunk
+    const uint32_t n_seg = (n + S3_R_ROWS - 1) / S3_R_ROWS, seg_per = (n_seg + pl.chunks - 1) / pl.chunks;
+    const uint32_t seg_lo = min(chunk * seg_per, n_seg), seg_hi = min(seg_lo + seg_per, n_seg);
+    const float scale = L.scale;
+    const uint32_t res = L.res, hsize = L.hsize;
+    const float* __restrict__ d0p = denc_t + (size_t)L.drow * ld;
+    const float* __restrict__ d1p = d0p + ld;
+    for (uint32_t seg = seg_lo + threadIdx.x; seg < seg_hi; seg += S3_R_THREADS) {
+        const uint32_t r0 = seg * S3_R_ROWS;
+        uint32_t c0 = 0xffffffffu, c1 = 0xffffffffu, c2 = 0xffffffffu;     // current cell
+        float acc[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+#pragma unroll
+        for (int h = 0; h < S3_R_ROWS / 8; ++h) {                           // 8 rows' loads in flight
+            float vx[8][3], vd0[8], vd1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                uint32_t i = min(r0 + h * 8 + u, n - 1);
+                if (rows) i = rows[i];
+                const float* xp = x + (size_t)i * x_stride;
+                vx[u][0] = xp[0]; vx[u][1] = xp[1]; vx[u][2] = xp[2]; vd0[u] = d0p[i]; vd1[u] = d1p[i];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (r0 + h * 8 + u >= n) continue;
+                const float d0 = vd0[u], d1 = vd1[u];
+                if (d0 == 0.f && d1 == 0.f) continue;
+                const float p0 = vx[u][0] * scale + 0.5f, p1 = vx[u][1] * scale + 0.5f, p2 = vx[u][2] * scale + 0.5f;
+                const float f0 = floorf(p0), f1 = floorf(p1), f2 = floorf(p2);
+                const uint32_t g0 = (uint32_t)(int)f0, g1 = (uint32_t)(int)f1, g2 = (uint32_t)(int)f2;
+                const float w0 = p0 - f0, w1 = p1 - f1, w2 = p2 - f2;
+                if (!(g0 == c0 && g1 == c1 && g2 == c2)) {
+                    if (c0 != 0xffffffffu) s3_r_flush(s_acc, acc, c0, c1, c2, res, hsize, part);
+                    c0 = g0; c1 = g1; c2 = g2;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+                }
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float wt = ((c & 1) ? w0 : 1.f - w0) * ((c & 2) ? w1 : 1.f - w1) * ((c & 4) ? w2 : 1.f - w2);
+                    acc[2 * c] += wt * d0; acc[2 * c + 1] += wt * d1;
+                }
+            }
+        }
+        if (c0 != 0xffffffffu) s3_r_flush(s_acc, acc, c0, c1, c2, res, hsize, part);
+    }
+    __syncthreads();
+    float2* __restrict__ dst = slabs + (size_t)chunk * pl.slab_entries + L.poff + p_lo;
+    for (uint32_t q = threadIdx.x; q < n_loc; q += S3_R_THREADS) {
+        const double2 a = acc2[q];
+        dst[q] = make_float2((float)a.x, (float)a.y);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_scatter_fold(S3RPlan pl, const float2* __restrict__ slabs, float* __restrict__ grad_table) {
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= pl.slab_entries) return;
+    uint32_t e = 0;
+    while (e + 1 < pl.n_lv && q >= pl.lv[e + 1].poff) ++e;
+    float2* __restrict__ dst = reinterpret_cast<float2*>(grad_table) + pl.lv[e].toff + (q - pl.lv[e].poff);
+    float2 t = pl.overwrite ? make_float2(0.f, 0.f) : *dst;
+    for (uint32_t c = 0; c < pl.chunks; ++c) {                              // fixed order
+        const float2 a = slabs[(size_t)c * pl.slab_entries + q];
+        t.x += a.x; t.y += a.y;
+    }
+    *dst = t;
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static int s3_env(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+static uint32_t s3_block_samples() {          // XR_SC_BLOCK: samples per binning workgroup (4096 | 2048 | 1024)
+    static const int bs = []() { const int v = s3_env("XR_SC_BLOCK", 4096); return v == 1024 || v == 2048 ? v : 4096; }();
+    return (uint32_t)bs;
+}
+static uint32_t s3_chunks() {                 // XR_SC_RL_CHUNKS: row chunks per partition of the run-length kernel
+    static const int c = []() { const int v = s3_env("XR_SC_RL_CHUNKS", 16); return v >= 1 && v <= 64 ? v : 16; }();
+    return (uint32_t)c;
+}
+
+struct S3Layout {
+    S3Plan bin; S3RPlan rl;
+    uint32_t atomic_mask;            // levels that take the atomic kernel (xr_encode.hip)
+    size_t counts_bytes, bins_bytes, ovf_bytes, slabs_bytes;
+};
+
+static bool s3_layout(uint32_t n, const GridMeta& gm, uint32_t hashed_mask, int overwrite, S3Layout* out) {
+    S3Layout& P = *out;
+    memset(&P, 0, sizeof(P));
+    const uint32_t bs = s3_block_samples();
+    const uint32_t nsb = xr_div_up(n, bs);
+    // below XR_SC_MIN_N rows (default 16384) the fixed costs -- 128 KiB of LDS per partition zeroed and written back -- exceed
+    // what the atomic kernel needs; the tests lower it to run this path at sizes the host emulation finishes quickly
+    static const uint32_t min_n = (uint32_t)s3_env("XR_SC_MIN_N", 16384);
+    if (n < min_n || nsb > S3_MAX_SB) { P.atomic_mask = (1u << gm.n_levels) - 1u; return false; }
+    P.bin.nsb = nsb; P.bin.overwrite = (uint32_t)overwrite; P.bin.ovf_cap = 8u * bs;
+    P.rl.chunks = s3_chunks(); P.rl.overwrite = (uint32_t)overwrite;
+    static const int use_rl = s3_env("XR_SC_RL", 1);      // 0: small dense levels through the binned path too (measurement)
+    uint64_t bins_off = 0, ovf_off = 0;
+    uint32_t counts_off = 0;
+    // accumulate order: dense binned levels first (32 partitions carry twice a hashed partition's items)
+    for (int pass = 0; pass < 2; ++pass)
+        for (int l = gm.n_levels - 1; l >= 0; --l) {
+            const uint32_t hsize = gm.off[l + 1] - gm.off[l], res = gm.res[l];
+            const bool hashed = (hashed_mask >> l) & 1;
+            const bool kindH = hashed && (hsize & (hsize - 1)) == 0 && hsize >= S3_ENTRIES && (hsize >> S3_LOG2) <= S3_MAX_PARTS &&
+                               res < S3_ENTRIES && (gm.off[l] & 1) == 0;
+            const bool kindR = !hashed && hsize <= S3_R_MAX_ENTRIES && use_rl;
+            const bool kindD = !hashed && !kindR && hsize >= 1024u && hsize <= 64u * S3_ENTRIES;
+            if (pass == 0 && !kindH && !kindD && !kindR) P.atomic_mask |= 1u << l;
+            if (pass == 0 && kindR) {
+                S3RLevel& R = P.rl.lv[P.rl.n_lv++];
+                R.scale = gm.scale[l]; R.res = res; R.hsize = hsize; R.toff = gm.off[l]; R.parts = xr_div_up(hsize, S3_ENTRIES);
+                R.drow = 2u * (uint32_t)l; R.poff = P.rl.slab_entries; R.block0 = P.rl.blocks;
+                P.rl.slab_entries += hsize; P.rl.blocks += R.parts * P.rl.chunks;
+            }
+            if (!((pass == 0 && kindD) || (pass == 1 && kindH))) continue;
+            S3Level& L = P.bin.lv[P.bin.n_lv++];
+            L.scale = gm.scale[l]; L.res = res; L.hsize = hsize; L.toff = gm.off[l]; L.drow = 2u * (uint32_t)l;
+            L.kind = kindH ? S3_H : S3_D;
+            if (kindH) { L.parts = hsize >> S3_LOG2; L.plog2 = 0; }
+            else {
+                // a partition holds ceil(blocks / P) 16-entry blocks <= 2^13 entries
+                L.parts = hsize <= 32u * (S3_ENTRIES - 16u) ? 32u : 64u;
+                if (hsize < 32u * 64u) L.parts = 8u;
+                L.plog2 = L.parts == 64u ? 6u : L.parts == 32u ? 5u : 3u;
+            }
+            const uint32_t ips = kindH ? 4u : 5u;                             // items per sample (dense: 1 in 16 pairs splits; generous)
+            L.cap = ((3u * ips * bs / 2u + L.parts - 1u) / L.parts + 15u) & ~15u;   // 1.5x the expected fill
+            L.counts_off = counts_off; counts_off += L.parts * nsb;
+            L.bins_off = bins_off; bins_off += (uint64_t)L.parts * nsb * L.cap;
+            L.ovf_off = ovf_off; ovf_off += (uint64_t)nsb * P.bin.ovf_cap;
+            L.acc_block0 = P.bin.acc_blocks; P.bin.acc_blocks += L.parts;
+        }
+    P.bin.ovfcnt_off = counts_off; counts_off += P.bin.n_lv * nsb;
+    P.counts_bytes = (((size_t)counts_off * sizeof(uint32_t)) + 255) & ~(size_t)255;
+    P.bins_bytes = (size_t)bins_off * sizeof(float4);
+    P.ovf_bytes = (size_t)ovf_off * sizeof(float4);
+    P.rl.blocks = P.rl.blocks;
+    P.slabs_bytes = (size_t)P.rl.chunks * P.rl.slab_entries * sizeof(float2);
+    return true;
+}
+
+size_t xr_scatter3_workspace_bytes(uint32_t n, const GridMeta& gm, uint32_t hashed_mask) {
+    S3Layout P;
+    if (!s3_layout(n, gm, hashed_mask, 0, &P)) return 0;
+    return P.counts_bytes + P.bins_bytes + P.ovf_bytes + P.slabs_bytes;
+}
+
+int xr_scatter3(const float* x, uint32_t x_stride, const float* denc_t, uint32_t ld, uint32_t n, const uint32_t* n_dev,
+                const uint32_t* rows, const GridMeta& gm, uint32_t hashed_mask, float* grad_table, void* workspace,
+                size_t workspace_bytes, int overwrite, uint32_t* atomic_mask, hipStream_t stream) {
+    S3Layout P;
+    if (!s3_layout(n, gm, hashed_mask, overwrite, &P) || !workspace || ((uintptr_t)workspace & 15) || ((uintptr_t)grad_table & 15)) {
+        *atomic_mask = (1u << gm.n_levels) - 1u;
+        return XR_OK;
+    }
+    XR_REQUIRE(workspace_bytes >= P.counts_bytes + P.bins_bytes + P.ovf_bytes + P.slabs_bytes, "workspace too small");
+    *atomic_mask = P.atomic_mask;
+    uint32_t* counts = (uint32_t*)workspace;
+    float4* bins = (float4*)((char*)workspace + P.counts_bytes);
+    float4* ovf = (float4*)((char*)workspace + P.counts_bytes + P.bins_bytes);
+    float2* slabs = (float2*)((char*)workspace + P.counts_bytes + P.bins_bytes + P.ovf_bytes);
+    static bool attr_set = false;
+    if (!attr_set) {
+        XR_HIP(hipFuncSetAttribute((const void*)k_scatter_accum3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES));
+        XR_HIP(hipFuncSetAttribute((const void*)k_scatter_dense_rl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES));
+        attr_set = true;
+    }
+    // XR_SC_RL_FIRST=0: the small dense levels AFTER the bin / accumulate pair instead of before it (measurement)
+    static const int rl_first = s3_env("XR_SC_RL_FIRST", 1);
+    auto launch_rl = [&]() -> int {
+        if (P.rl.n_lv == 0) return XR_OK;
+        hipLaunchKernelGGL(k_scatter_dense_rl, dim3(P.rl.blocks), dim3(S3_R_THREADS), S3_LDS_BYTES, stream, P.rl, x, x_stride, denc_t, ld, n,
+                           n_dev, rows, slabs);
+        XR_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_scatter_fold, dim3(xr_div_up(P.rl.slab_entries, 256)), dim3(256), 0, stream, P.rl, (const float2*)slabs, grad_table);
+        XR_LAUNCH_CHECK();
+        return XR_OK;
+    };
+    if (rl_first) { const int rc = launch_rl(); if (rc != XR_OK) return rc; }
+    if (P.bin.n_lv) {
+        const uint32_t bs = s3_block_samples();
+        const dim3 grid(P.bin.n_lv * P.bin.nsb), block(S3_BIN_THREADS);
+        if (bs == 4096) hipLaunchKernelGGL(k_scatter_bin3<4096>, grid, block, 0, stream, P.bin, x, x_stride, denc_t, ld, n, n_dev, rows, counts, bins, ovf);
+        else if (bs == 2048) hipLaunchKernelGGL(k_scatter_bin3<2048>, grid, block, 0, stream, P.bin, x, x_stride, denc_t, ld, n, n_dev, rows, counts, bins, ovf);
+        else hipLaunchKernelGGL(k_scatter_bin3<1024>, grid, block, 0, stream, P.bin, x, x_stride, denc_t, ld, n, n_dev, rows, counts, bins, ovf);
+        XR_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_scatter_accum3, dim3(P.bin.acc_blocks), dim3(S3_ACC_THREADS), S3_LDS_BYTES, stream, P.bin, (const uint32_t*)counts,
+                           (const float4*)bins, (const float4*)ovf, grad_table);
+        XR_LAUNCH_CHECK();
+    }
+    if (!rl_first) { const int rc = launch_rl(); if (rc != XR_OK) return rc; }
+    return XR_OK;
+}

@@ -42,28 +42,22 @@ extern "C" int xr_ngp_train_step(
     XR_REQUIRE(scatter_level0 >= 0 && scatter_level0 < n_levels, "scatter_level0 outside [0, n_levels)");
     XR_REQUIRE(!timed_entry || (timing_begin && timing_end), "a timed entry point needs its two events");
     hipStream_t stream = (hipStream_t)stream_;
-    // XR_STEP_OVERLAP=1 (measurement; default off): work that only LATER stages need goes to a helper stream --
-    //   * the 48.8-MB zero-fill of the table gradient beside the encode (first read by the scatter),
-    //   * the reduction of the MLP backward's per-workgroup partials beside the scatter (first read by the optimiser),
-    // forked from / joined into the caller's stream with events.  Measured on the MI355X (tools/iter_times.py, steady state):
-    // a normal iteration takes 0.562 ms WITH it against 0.542 ms on one stream (fp16 mode: 0.66 against 0.50) -- the two
-    // cross-queue joins cost more than the 13 us of kernels they take off the stream.
+    // XR_STEP_OVERLAP=1 (measurement; default off): the reduction of the MLP backward's per-workgroup partials (first read by
+    // the optimiser) goes to a helper stream beside the scatter, forked from / joined into the caller's stream with events.
+    // Measured on the MI355X in round 2 together with the then 48.8-MB zero-fill of the table gradient beside the encode
+    // (tools/iter_times.py, steady state): a normal iteration took 0.562 ms WITH it against 0.542 ms on one stream (fp16 mode:
+    // 0.66 against 0.50) -- the cross-queue joins cost more than the 13 us of kernels they took off the stream.  The zero-fill
+    // itself is gone: the scatter WRITES the table gradient (XR_SCATTER_OVERWRITE, csrc/xr_scatter.hip).
     static hipStream_t aux = nullptr;
-    static hipEvent_t ev_fork0 = nullptr, ev_zero = nullptr, ev_fork1 = nullptr, ev_red = nullptr;
+    static hipEvent_t ev_fork1 = nullptr, ev_red = nullptr;
     static const bool overlap = []() { const char* e = getenv("XR_STEP_OVERLAP"); return e && e[0] == '1'; }();
     if (overlap && !aux) {
         XR_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
-        for (hipEvent_t* e : {&ev_fork0, &ev_zero, &ev_fork1, &ev_red}) XR_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        for (hipEvent_t* e : {&ev_fork1, &ev_red}) XR_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
     auto begin = [&](const char* name) -> int { if (stage_is(timed_entry, name)) XR_HIP(hipEventRecord((hipEvent_t)timing_begin, stream)); return XR_OK; };
     auto end = [&](const char* name) -> int { if (stage_is(timed_entry, name)) XR_HIP(hipEventRecord((hipEvent_t)timing_end, stream)); return XR_OK; };
     int rc;
-    if (overlap) {
-        XR_HIP(hipEventRecord(ev_fork0, stream));                      // behind everything that still reads the old gradient (the optimiser)
-        XR_HIP(hipStreamWaitEvent(aux, ev_fork0, 0));
-        XR_HIP(hipMemsetAsync(grad_table, 0, table_floats * sizeof(float), aux));
-        XR_HIP(hipEventRecord(ev_zero, aux));
-    }
     // coordinate rows {pos3, dt, dir3}: positions and directions are consumed in place (row stride 7)
     if ((rc = begin("xr_hashgrid_fwd")) != XR_OK) return rc;
     rc = xr_hashgrid_fwd(table, coords, 7, n_rows, n_dev, nullptr, n_levels, scale_host, resolution_host, offset_host, enc_t, ld, stream_);
@@ -82,7 +76,6 @@ extern "C" int xr_ngp_train_step(
                             n_rays, rgb_activation, density_activation, huber_delta, loss_scale, rgb_out, loss_mse, draw, stream_);
     if (rc != XR_OK) return rc;
     if ((rc = end("xr_composite_train")) != XR_OK) return rc;
-    if (!overlap) XR_HIP(hipMemsetAsync(grad_table, 0, table_floats * sizeof(float), stream));
     // rows with an exactly-zero dL/d(raw) (T == 0 behind a surface) are skipped by the MLP backward AND the scatter: one list
     uint32_t *rows, *seg, *n_live;
     rc = xr_nerf_mlp_bwd_list_slots(ws_mlp_bwd, ws_mlp_bwd_bytes, n_rows, &rows, &seg, &n_live);
@@ -105,15 +98,15 @@ extern "C" int xr_ngp_train_step(
         rc = xr_nerf_mlp_bwd_reduce(ws_mlp_bwd, n_rows, grad_w_density, grad_w_color, aux);
         if (rc != XR_OK) return rc;
         XR_HIP(hipEventRecord(ev_red, aux));
-        XR_HIP(hipStreamWaitEvent(stream, ev_zero, 0));                // the table gradient is zero from here on
     }
     if ((rc = begin("xr_hashgrid_bwd")) != XR_OK) return rc;
     // data-parallel callers scatter the levels below scatter_level0 themselves (xr_hashgrid_bwd with the same row list, found
     // through xr_nerf_mlp_bwd_list_slots) AFTER handing the finer levels' gradient slice to the collective: table offsets are
     // absolute, so the level metadata is simply passed from that level on
-    rc = xr_hashgrid_bwd(coords, 7, denc_t + (size_t)2 * scatter_level0 * ld, ld, n_rows, n_live, rows, n_levels - scatter_level0,
-                         scale_host + scatter_level0, resolution_host + scatter_level0, offset_host + scatter_level0, grad_table,
-                         ws_scatter, ws_scatter_bytes, stream_);
+    // the gradient slices of the scattered levels are written, not added to: no zero-fill of the 48.8-MB table gradient
+    rc = xr_hashgrid_bwd2(coords, 7, denc_t + (size_t)2 * scatter_level0 * ld, ld, n_rows, n_live, rows, n_levels - scatter_level0,
+                          scale_host + scatter_level0, resolution_host + scatter_level0, offset_host + scatter_level0, grad_table,
+                          ws_scatter, ws_scatter_bytes, XR_SCATTER_OVERWRITE, stream_);
     if (rc != XR_OK) return rc;
     if ((rc = end("xr_hashgrid_bwd")) != XR_OK) return rc;
     if (overlap) XR_HIP(hipStreamWaitEvent(stream, ev_red, 0));

@@ -116,8 +116,19 @@ class _FusedTrainStepFn(torch.autograd.Function):
                     sets = net._step_bufs = [ops.TrainStepBuffers(table.device, n_rows, max(n_rays, 1 << 15), table.numel(), wd.numel(),
                                                                   wc.numel(), mlp.embedder_pos.meta) for _ in range(2)]
                     net._step_turn = 0
-                net._step_turn ^= 1                 # two sets alternate: the one the optimiser still holds as .grad is not reused
-                b = sets[net._step_turn]
+                # two sets alternate: the one the optimiser still holds as .grad is not reused.  A caller that keeps gradients
+                # alive across steps (zero_grad(set_to_none=False), accumulation over several backward passes) may still hold
+                # EITHER set as .grad: the step WRITES its gradient buffers, so such a set is skipped, and when both are held a
+                # fresh one takes the place of the older
+                held = {p_.grad.data_ptr() for p_ in (table, wd, wc) if p_.grad is not None}
+                for _ in range(2):
+                    net._step_turn ^= 1
+                    b = sets[net._step_turn]
+                    if not held & {b.g_table.data_ptr(), b.g_wd.data_ptr(), b.g_wc.data_ptr()}:
+                        break
+                else:
+                    b = sets[net._step_turn] = ops.TrainStepBuffers(table.device, n_rows, sets[0].ray_cap, table.numel(), wd.numel(),
+                                                                     wc.numel(), mlp.embedder_pos.meta)
                 meta = mlp.embedder_pos.meta
                 split = meta.n_levels - 8 if (sync is not None and meta.n_levels > 8) else 0
                 rgb = ops.ngp_train_step(table, wd, wc, 1, 2, mlp.pad_value, meta, sampler.coords, data.get('n_valid_dev'),
@@ -129,7 +140,7 @@ class _FusedTrainStepFn(torch.autograd.Function):
                     if split:
                         cut = 2 * int(meta.offset[split])
                         sync.ready(b.g_table[cut:])
-                        ops.hashgrid_bwd(sampler.coords[:n_rows], b.denc_t, meta, b.g_table, live=b.live, levels=(0, split))
+                        ops.hashgrid_bwd(sampler.coords[:n_rows], b.denc_t, meta, b.g_table, live=b.live, levels=(0, split), overwrite=True)
                         sync.ready(b.g_table[:cut])
                     else:
                         sync.ready(b.g_table)
@@ -142,6 +153,8 @@ class _FusedTrainStepFn(torch.autograd.Function):
                 ctx.net = net
                 ctx.mark_non_differentiable(rgb)
                 ctx.set_materialize_grads(False)
+                # LIFETIME: loss, rgb and raw are views of the recycled buffer set -- valid until the step after next writes it.
+                # train_step reads its log scalars at once unless the caller opts into lazy_log, whose contract says so.
                 net._last = {'rgb': rgb, 'loss_mse': b.loss_mse, 'raw': b.raw}
                 return b.loss_mse[0:1].reshape(()), rgb
             pts, dirs = mlp._rows(data['pts']), mlp._rows(data['viewdirs'])
@@ -219,7 +232,9 @@ class _FusedTrainStepFn(torch.autograd.Function):
         if factor != 1.0 and is_unit and getattr(net, '_defer_grad_scale', False):
             # data parallel, trainer-owned optimiser: .grad keeps the all-reduced SUM and the optimiser multiplies by
             # 1/world_size while it reads the gradient (xr_adam_step_multi's grad_scale) -- no scaling pass over 48.8 MB
-            net._pending_grad_scale = getattr(net, '_pending_grad_scale', 1.0) * factor
+            # (set, not compounded: the factor belongs to the SUM the collective left in .grad; the trainer's optimiser consumes
+            # and clears it -- a second backward before that adds another all-reduced sum with the same 1 / world_size)
+            net._pending_grad_scale = factor
         elif not (factor == 1.0 and is_unit):
             # (the trainer back-propagates from a persistent all-ones root gradient it registers as
             # `net._unit_root_grad`: the scaling launch -- which would read that 1.0 and do nothing -- is skipped then)
@@ -229,8 +244,8 @@ class _FusedTrainStepFn(torch.autograd.Function):
         # (a Python-created gradient is never "stolen": 48.8 MB copied per step): first gradient -> becomes
         # .grad, otherwise accumulate in place.
         for p_, g_ in zip(params, grads):
-            if p_.grad is None:
-                p_.grad = g_
+            if p_.grad is None or p_.grad.data_ptr() == g_.data_ptr():
+                p_.grad = g_                    # (same storage: the step already wrote this gradient into it)
             else:
                 p_.grad.add_(g_)
         return None, None, None, None, None
@@ -313,6 +328,9 @@ class HashNerfNetwork(BaseNerfNetwork):
                                             self.mlp.color_net.params, self, data)
         bs = rgb.shape[0]
         if kwargs.get('lazy_log', False):
+            # lazy_log contract: the two values are device-side views of the step's recycled buffers and must be read (float())
+            # before the step after next runs -- xrnerf_amd.train.Trainer reads them when it logs that very iteration.  A
+            # logger that keeps them for longer (an averaging LogBuffer) must not ask for lazy_log.
             log_vars = {'loss': loss.detach(), 'psnr': _LazyPsnr(self._last['loss_mse'], bs)}
         else:
             with torch.no_grad():

@@ -177,6 +177,10 @@ def _ws(device, nbytes, tag):
     w = _workspaces.get(key)
     if w is None or w.numel() < nbytes:
         w = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        if tag == 'mlpbwd':
+            # holds the live-row count block, whose words 1-2 are RUNNING totals (k_live_fill adds to them): they start at zero.
+            # (uint32: a reader -- bench.py prices the backward kernels from them -- clears them per measurement window)
+            w.zero_()
         _workspaces[key] = w
     return w
 
@@ -489,11 +493,13 @@ def hashgrid_fwd(table, x, meta, enc_t=None, ld=None, n_dev=None, rows=None, row
     return enc_t
 
 
-def hashgrid_bwd(x, denc_t, meta, grad_table, n_dev=None, row0=0, count=None, levels=None, use_workspace=True, live=None):
+def hashgrid_bwd(x, denc_t, meta, grad_table, n_dev=None, row0=0, count=None, levels=None, use_workspace=True, live=None,
+                 overwrite=False):
     """scatter dL/denc into dL/dtable.  `levels=(l0, l1)` restricts the launch to that level range (the level
     metadata arrays are passed from l0 on; table offsets are absolute, so `grad_table` stays the full table):
     the data-parallel trainer scatters the fine half first and reduces it across ranks under the coarse half.
-    `live=(rows, n_live)` (ops.live_rows): only the listed rows are scattered."""
+    `live=(rows, n_live)` (ops.live_rows): only the listed rows are scattered.
+    `overwrite=True` (XR_SCATTER_OVERWRITE): the levels' slices of grad_table are written instead of added to."""
     L = _lib.load()
     x, xs = _pos_view(x)
     n = x.shape[0] if count is None else count
@@ -510,10 +516,10 @@ def hashgrid_bwd(x, denc_t, meta, grad_table, n_dev=None, row0=0, count=None, le
             raise _lib.XrError('a live-row list addresses rows from 0')
         rows, n_dev = live
     with _span('xr_hashgrid_bwd', 0 if n_dev is not None else n, train=n_dev is not None):
-        _lib.check(L.xr_hashgrid_bwd(C.c_void_p(x.data_ptr() + 4 * xs * row0), xs,
-                                     C.c_void_p(denc_t.data_ptr() + 4 * (row0 + 2 * l0 * ld)), ld, n, _ptr(n_dev), _ptr(rows),
-                                     l1 - l0, s + 4 * l0, r + 4 * l0, o + 4 * l0, _ptr(grad_table),
-                                     _ptr(ws), ws.numel() if ws is not None else 0, _stream()),
+        _lib.check(L.xr_hashgrid_bwd2(C.c_void_p(x.data_ptr() + 4 * xs * row0), xs,
+                                      C.c_void_p(denc_t.data_ptr() + 4 * (row0 + 2 * l0 * ld)), ld, n, _ptr(n_dev), _ptr(rows),
+                                      l1 - l0, s + 4 * l0, r + 4 * l0, o + 4 * l0, _ptr(grad_table),
+                                      _ptr(ws), ws.numel() if ws is not None else 0, 1 if overwrite else 0, _stream()),
                    'xr_hashgrid_bwd')
     return grad_table
 
