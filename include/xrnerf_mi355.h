@@ -65,6 +65,13 @@ int xr_rays_sampler(const float* rays_o, const float* rays_d, const uint8_t* bit
                     uint64_t rng_state, uint64_t rng_inc, float* coords_out, int32_t* rays_index,
                     int32_t* rays_numsteps, uint32_t* counter2, void* workspace, size_t workspace_bytes,
                     void* stream);
+/* the same; xyz_planes (nullable): the three position columns of coords_out once more as planes of plane_stride
+ * (>= max_samples) floats each -- what xr_hashgrid_fwd2 reads with coalesced loads */
+int xr_rays_sampler2(const float* rays_o, const float* rays_d, const uint8_t* bitfield, uint32_t n_rays,
+                     float aabb0, float aabb1, float near_distance, float cone_angle, uint32_t max_samples,
+                     uint64_t rng_state, uint64_t rng_inc, float* coords_out, int32_t* rays_index,
+                     int32_t* rays_numsteps, uint32_t* counter2, float* xyz_planes, uint32_t plane_stride,
+                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* K2  compacted_coord_api (src/compacted_coord.cu:79-143, kernel :6-77).  The reference's
  * transmittance loop cannot influence any output (its `break` is commented out, :41-44), so
@@ -177,6 +184,12 @@ void xr_hashgrid_meta(int n_levels, int log2_hashmap_size, int base_resolution, 
 int xr_hashgrid_fwd(const float* table, const float* x, uint32_t x_stride, uint32_t n, const uint32_t* n_dev,
                     const uint32_t* rows, int n_levels, const float* scale_host, const uint32_t* resolution_host,
                     const uint32_t* offset_host, float* enc_t, uint32_t ld, void* stream);
+/* the same with a component stride: coordinate d of sample i is x[i * x_stride + d * x_comp_stride].  x_comp_stride = 1 is the
+ * call above; x_stride = 1 with x_comp_stride = plane size reads positions stored as three planes (structure of arrays):
+ * three coalesced dword loads per sample instead of three strided ones out of 28-byte rows. */
+int xr_hashgrid_fwd2(const float* table, const float* x, uint32_t x_stride, uint32_t x_comp_stride, uint32_t n, const uint32_t* n_dev,
+                     const uint32_t* rows, int n_levels, const float* scale_host, const uint32_t* resolution_host,
+                     const uint32_t* offset_host, float* enc_t, uint32_t ld, void* stream);
 /* Backward of the encoding above (tcnn's kernel_grid_backward as reached from hashnerf_mlp.py:59-61 under autograd):
  * grad_table[idx,f] += w * denc_t[2l+f][i]; the caller zero-fills grad_table (xr_hashgrid_bwd2 + XR_SCATTER_OVERWRITE: no).
  * workspace (nullable; xr_hashgrid_bwd_workspace_bytes(n, n_levels, resolution_host, offset_host), 16-byte
@@ -286,7 +299,10 @@ int xr_ngp_train_step(const float* table, const float* w_density, const float* w
                       float* draw, float* denc_t, float* rgb_out, float* zero_block, size_t zero_floats, float* grad_w_density,
                       float* grad_w_color, float* loss_mse, float* grad_table, size_t table_floats, int zero_draw,
                       void* ws_mlp_bwd, size_t ws_mlp_bwd_bytes, void* ws_scatter, size_t ws_scatter_bytes, int scatter_level0,
+                      const float* xyz_planes, uint32_t plane_stride,
                       const char* timed_entry, void* timing_begin, void* timing_end, void* stream);
+/* xyz_planes (nullable): the positions of `coords` once more as three planes of plane_stride floats (xr_rays_sampler2 /
+ * xr_ngp_prefetch write them); the encoder then reads them with coalesced loads (xr_hashgrid_fwd2). */
 /* timed_entry (nullable): the name of ONE of the entry points the step runs ("xr_hashgrid_fwd", "xr_nerf_mlp_fwd",
  * "xr_composite_train", "xr_live_rows", "xr_nerf_mlp_bwd", "xr_hashgrid_bwd"): its launches are bracketed on `stream` by the two
  * events (xr_timing_event_create) -- bench.py's live duration of the dominant kernel inside the timed region.
@@ -307,7 +323,7 @@ int xr_ngp_prefetch(const float* rays_rgb_rows, uint32_t n_rays, uint64_t batch_
                     float aabb1, float near_distance, float cone_angle, uint32_t max_samples, uint64_t k1_call_index,
                     float* coords_out, int32_t* rays_index, int32_t* rays_numsteps, uint32_t* counter2, void* workspace,
                     size_t workspace_bytes, uint32_t max_compacted, int32_t* numsteps_clipped, uint32_t* n_valid_dev,
-                    uint32_t* counter_host_pinned, void* stream);
+                    uint32_t* counter_host_pinned, float* xyz_planes, uint32_t plane_stride, void* stream);
 
 /* tcnn.Network(FullyFusedMLP) on its own (compatibility surface; the hot path uses the fused kernels above):
  * x [n, n_in] with arbitrary row / column strides (in floats), n_in <= 32, missing input columns = pad_value;

@@ -40,6 +40,10 @@ def child():
         b.record(); torch.cuda.synchronize(); return a.elapsed_time(b) / reps * 1e3
     tag = ' '.join('%s=%s' % (k[3:], os.environ[k]) for k in sorted(os.environ) if k.startswith('XR_SC'))
     out = []
+    if os.environ.get('XR_ONLY'):          # one configuration only (clean rocprofv3 kernel averages): levels 0-16, live list, overwrite
+        us = timeit(lambda: ops.hashgrid_bwd(c[:, :3], denc, meta, g, live=(rows, nl), overwrite=True), 50)
+        print('%-34s ONLY levels (0, 16) live list (%d): %.1f us' % (tag, len(live), us), flush=True)
+        return
     for lv in ((0, 16), (5, 16), (3, 16), (0, 3), (0, 5), (8, 16), (0, 8)):
         if os.environ.get('XR_QUICK') and lv not in ((0, 16), (5, 16), (0, 5)): continue
         us_all = timeit(lambda: ops.hashgrid_bwd(c[:, :3], denc, meta, g, levels=lv, overwrite=True))
@@ -61,9 +65,8 @@ if __name__ == '__main__':
         child()
     else:
         quick = len(sys.argv) > 1 and sys.argv[1] == 'quick'
-        runs = [dict(XR_SC_MODE='1'), dict(XR_SC_MODE='2'), dict(XR_SC_MODE='2', XR_SC_BLOCK='2048'), dict(XR_SC_MODE='2', XR_SC_BLOCK='1024'),
-                dict(XR_SC_MODE='2', XR_SC_RL='0'), dict(XR_SC_MODE='2', XR_SC_RL_CHUNKS='8'), dict(XR_SC_MODE='2', XR_SC_RL_CHUNKS='32'),
-                dict(XR_SC_MODE='2', XR_SC_RL_FIRST='0')]
+        runs = [dict(XR_SC_MODE='1'), dict(XR_SC_MODE='2'), dict(XR_SC_MODE='2', XR_SC_RL_ASYNC='0'), dict(XR_SC_MODE='2', XR_SC_DENSE_ATOMIC='1'),
+                dict(XR_SC_MODE='2', XR_SC_BLOCK='2048'), dict(XR_SC_MODE='2', XR_SC_RL_FIRST='0')]
         for env in runs:
             e = dict(os.environ, XR_CHILD='1', **env)
             if quick: e['XR_QUICK'] = '1'

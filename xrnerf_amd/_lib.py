@@ -19,6 +19,7 @@ SIGNATURES = {
     'xr_pcg32_host_state': (None, [_u64, _u64, _vp, _vp]),
     'xr_rays_sampler_workspace_bytes': (_sz, [_u32]),
     'xr_rays_sampler': (_i32, [_vp, _vp, _vp, _u32, _f, _f, _f, _f, _u32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'xr_rays_sampler2': (_i32, [_vp, _vp, _vp, _u32, _f, _f, _f, _f, _u32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _sz, _vp]),
     'xr_compacted_coord': (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'xr_clip_numsteps': (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _u32, _u32, _vp]),
     'xr_render_slice_select': (_i32, [_vp, _vp, _u32, _u32, _u32, _f, _vp, _vp, _vp, _vp]),
@@ -36,6 +37,7 @@ SIGNATURES = {
     'xr_bitfield_from_mean': (_i32, [_vp, _vp, _vp, _vp]),
     'xr_hashgrid_meta': (None, [_i32, _i32, _i32, _d, _vp, _vp, _vp]),
     'xr_hashgrid_fwd': (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _u32, _vp]),
+    'xr_hashgrid_fwd2': (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _u32, _vp]),
     'xr_hashgrid_bwd_workspace_bytes': (_sz, [_u32, _i32, _vp, _vp]),
     'xr_hashgrid_bwd': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'xr_hashgrid_bwd2': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp]),
@@ -43,10 +45,10 @@ SIGNATURES = {
     'xr_nerf_mlp_fwd': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp]),
     'xr_nerf_mlp_bwd_workspace_bytes': (_sz, [_u32]),
     'xr_ngp_prefetch': (_i32, [_vp, _u32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _u32, _u64, _vp, _vp, _vp, _vp,
-                               _vp, _sz, _u32, _vp, _vp, _vp, _vp]),
+                               _vp, _sz, _u32, _vp, _vp, _vp, _vp, _u32, _vp]),
     'xr_ngp_train_step': (_i32, [_vp, _vp, _vp, _i32, _i32, _f, _i32, _i32, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _u32, _vp, _vp, _vp,
                                  _vp, _i32, _i32, _f, _f, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _sz, _i32, _vp, _sz,
-                                 _vp, _sz, _i32, C.c_char_p, _vp, _vp, _vp]),
+                                 _vp, _sz, _i32, _vp, _u32, C.c_char_p, _vp, _vp, _vp]),
     'xr_timing_event_create': (_vp, []),
     'xr_timing_event_destroy': (_i32, [_vp]),
     'xr_timing_event_elapsed_ms': (_i32, [_vp, _vp, _vp]),

@@ -134,12 +134,12 @@ template <bool NT> __device__ inline float2 hg_ld2(const float2* p) {
 }
 
 // one (sample, level): 8 corners as 4 x-neighbour pairs -> the level's two features
-template <bool NT, bool POW2, bool PAIRS> __device__ inline void hg_sample_level(const float2* __restrict__ tab, const float* xp, float scale, uint32_t res,
-                                                                      uint32_t hsize, bool hashed, float* r0_, float* r1_) {
+template <bool NT, bool POW2, bool PAIRS> __device__ inline void hg_sample_level(const float2* __restrict__ tab, const float* xp, uint32_t x_cs, float scale,
+                                                                      uint32_t res, uint32_t hsize, bool hashed, float* r0_, float* r1_) {
     float w[3]; uint32_t g[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        const float p = xp[d] * scale + 0.5f;
+        const float p = xp[(size_t)d * x_cs] * scale + 0.5f;
         const float f = floorf(p);
         g[d] = (uint32_t)(int)f; w[d] = p - f;
     }
@@ -178,13 +178,31 @@ template <bool NT, bool POW2, bool PAIRS> __device__ inline void hg_sample_level
     *r0_ = r0; *r1_ = r1;
 }
 
-__global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_fwd(GridMeta gm, uint32_t hashed_mask, const float* __restrict__ table,
-                                                            const float* __restrict__ x, uint32_t x_stride, uint32_t n,
+// Order 5: an explicit map.  XCD k (= blockIdx % 8, an observation used for speed only) walks its list of segments
+// (level, sample blocks [lo, hi)) in order -- whole levels first, then its share of the levels that are split.  The map is
+// built on the host from one measured cost per level (hg_build_map): every XCD gets the same cost, the eight most expensive
+// levels stay whole on one XCD each (their 4-MiB slices are faulted into ONE L2), only the cheap remainder is shared.
+#define HG_MAP_SEGS 6
+struct XcdMap {
+    uint8_t level[8][HG_MAP_SEGS];
+    uint8_t nseg[8];
+    uint32_t lo[8][HG_MAP_SEGS], hi[8][HG_MAP_SEGS];
+};
+
+__global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_fwd(GridMeta gm, XcdMap xm, uint32_t hashed_mask, const float* __restrict__ table,
+                                                            const float* __restrict__ x, uint32_t x_stride, uint32_t x_cs, uint32_t n,
                                                             const uint32_t* __restrict__ n_dev, const uint32_t* __restrict__ rows,
                                                             float* __restrict__ enc_t, uint32_t ld) {
     uint32_t l, sb;
     if (n_dev) n = min(n, *n_dev);
-    if (gm.order == 4) {
+    if (gm.order == 5) {
+        const uint32_t k = blockIdx.x & 7u;
+        uint32_t j = blockIdx.x >> 3, sg = 0;
+        const uint32_t ns = xm.nseg[k];
+        while (sg < ns && j >= xm.hi[k][sg] - xm.lo[k][sg]) { j -= xm.hi[k][sg] - xm.lo[k][sg]; ++sg; }
+        if (sg >= ns) return;
+        l = xm.level[k][sg]; sb = xm.lo[k][sg] + j;
+    } else if (gm.order == 4) {
         if (!hg_twolist_block(gm, blockIdx.x & 7u, blockIdx.x >> 3, (n + EN_BLOCK - 1) / EN_BLOCK, &l, &sb)) return;
     } else if (gm.order == 3) {
         if (!hg_balanced_block(gm, blockIdx.x & 7u, blockIdx.x >> 3, (n + EN_BLOCK - 1) / EN_BLOCK, &l, &sb)) return;
@@ -202,11 +220,11 @@ __global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_fwd(GridMeta gm, uint32_t
     float r0, r1;
     const bool pow2 = hashed && (hsize & (hsize - 1u)) == 0u;           // uniform for the block
     if (gm.pairs) {
-        if (pow2) hg_sample_level<false, true, true>(tab, xp, scale, res, hsize, hashed, &r0, &r1);
-        else hg_sample_level<false, false, true>(tab, xp, scale, res, hsize, hashed, &r0, &r1);
-    } else if (pow2 && gm.nt) hg_sample_level<true, true, false>(tab, xp, scale, res, hsize, hashed, &r0, &r1);
-    else if (pow2) hg_sample_level<false, true, false>(tab, xp, scale, res, hsize, hashed, &r0, &r1);
-    else hg_sample_level<false, false, false>(tab, xp, scale, res, hsize, hashed, &r0, &r1);
+        if (pow2) hg_sample_level<false, true, true>(tab, xp, x_cs, scale, res, hsize, hashed, &r0, &r1);
+        else hg_sample_level<false, false, true>(tab, xp, x_cs, scale, res, hsize, hashed, &r0, &r1);
+    } else if (pow2 && gm.nt) hg_sample_level<true, true, false>(tab, xp, x_cs, scale, res, hsize, hashed, &r0, &r1);
+    else if (pow2) hg_sample_level<false, true, false>(tab, xp, x_cs, scale, res, hsize, hashed, &r0, &r1);
+    else hg_sample_level<false, false, false>(tab, xp, x_cs, scale, res, hsize, hashed, &r0, &r1);
     enc_t[(size_t)(2 * l) * ld + i] = r0;
     enc_t[(size_t)(2 * l + 1) * ld + i] = r1;
 }
@@ -781,24 +799,91 @@ __global__ __launch_bounds__(256) void k_reduce_replicas(const float4* __restric
 }
 
 static int scatter_env(const char* name, int dflt);
-extern "C" int xr_hashgrid_fwd(const float* table, const float* x, uint32_t x_stride, uint32_t n, const uint32_t* n_dev,
-                               const uint32_t* rows, int n_levels, const float* scale_host, const uint32_t* resolution_host,
-                               const uint32_t* offset_host, float* enc_t, uint32_t ld, void* stream_) {
+// Host side of order 5.  cost[l] = time of level l alone on one XCD (any unit); a level goes to the XCD with the most budget left,
+// whole when it fits (within 5 %), otherwise in pieces of sample blocks -- most expensive levels first, so the fine hashed levels
+// stay whole and only the cheap remainder is shared between XCDs.  -> blocks per XCD (max over the XCDs), 0 = no map possible.
+static uint32_t hg_build_map(XcdMap* xm, const float* cost, int n_levels, uint32_t nsb) {
+    memset(xm, 0, sizeof(*xm));
+    double T = 0;
+    for (int l = 0; l < n_levels; ++l) T += cost[l] > 0.f ? cost[l] : 1e-3;
+    T /= 8.0;
+    int idx[EN_MAX_LEVELS];
+    for (int l = 0; l < n_levels; ++l) idx[l] = l;
+    for (int i = 1; i < n_levels; ++i)                       // insertion sort, cost descending (finer level first on ties)
+        for (int j = i; j > 0 && (cost[idx[j]] > cost[idx[j - 1]] || (cost[idx[j]] == cost[idx[j - 1]] && idx[j] > idx[j - 1])); --j) {
+            const int t = idx[j]; idx[j] = idx[j - 1]; idx[j - 1] = t;
+        }
+    double load[8] = {0};
+    uint32_t blocks[8] = {0};
+    for (int i = 0; i < n_levels; ++i) {
+        const int l = idx[i];
+        const double c = cost[l] > 0.f ? cost[l] : 1e-3, w = c / nsb;     // cost per sample block
+        uint32_t next = 0;
+        while (next < nsb) {
+            int k = -1;
+            for (int q = 0; q < 8; ++q)
+                if (xm->nseg[q] < HG_MAP_SEGS && (k < 0 || T - load[q] > T - load[k])) k = q;
+            if (k < 0) return 0;
+            const double capk = T - load[k], rem = w * (nsb - next);
+            uint32_t take = nsb - next;
+            if (capk > 0 && capk < 0.95 * rem) { take = (uint32_t)(capk / w); if (take == 0) take = 1; }
+            const uint32_t sg = xm->nseg[k]++;
+            xm->level[k][sg] = (uint8_t)l; xm->lo[k][sg] = next; xm->hi[k][sg] = next + take;
+            load[k] += w * take; blocks[k] += take; next += take;
+        }
+    }
+    uint32_t mx = 0;
+    for (int q = 0; q < 8; ++q) mx = blocks[q] > mx ? blocks[q] : mx;
+    return mx;
+}
+// XR_HG_COST="c0,c1,...": measured single-level times (tools/microbench_fwd3.py prints the line); fewer values than levels: the
+// last one repeats.  Default: the Lego geometry's figures at 2.6e5 ray-ordered samples on the MI355X.
+static void hg_level_costs(float* cost, int n_levels, uint32_t hashed_mask) {
+    static float env_cost[EN_MAX_LEVELS];
+    static int n_env = -1;
+    if (n_env < 0) {
+        n_env = 0;
+        const char* e = getenv("XR_HG_COST");
+        while (e && *e && n_env < EN_MAX_LEVELS) {
+            char* end = nullptr;
+            const float v = strtof(e, &end);
+            if (end == e) break;
+            env_cost[n_env++] = v;
+            e = *end == ',' ? end + 1 : end;
+        }
+    }
+    // measured (profiles/r03_microbench_fwd3.txt): a level alone on one XCD, 2.6e5 ray-ordered samples, us: dense levels 23-24
+    // (bound by the texture-address rate of their 13 lane accesses per sample, all cache hits), hashed levels 27.6, 32.0, 38.9,
+    // 47.3, 50.5, 51.4, 51.6 ... from the coarsest on (the coarse ones still share lines between neighbouring samples)
+    static const float hashed_cost[] = {27.6f, 32.0f, 38.9f, 47.3f, 50.5f, 51.4f, 51.7f};
+    int h = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        if (n_env > 0) cost[l] = env_cost[l < n_env ? l : n_env - 1];
+        else if ((hashed_mask >> l) & 1) { cost[l] = hashed_cost[h < 6 ? h : 6]; ++h; }
+        else cost[l] = 23.6f;
+    }
+}
+
+extern "C" int xr_hashgrid_fwd2(const float* table, const float* x, uint32_t x_stride, uint32_t x_comp_stride, uint32_t n, const uint32_t* n_dev,
+                                const uint32_t* rows, int n_levels, const float* scale_host, const uint32_t* resolution_host,
+                                const uint32_t* offset_host, float* enc_t, uint32_t ld, void* stream_) {
     if (n == 0) return XR_OK;
     XR_REQUIRE(table && x && enc_t, "null pointer");
-    XR_REQUIRE(x_stride >= 3 && ld >= n, "bad stride");
+    XR_REQUIRE(ld >= n && x_comp_stride >= 1 && (x_comp_stride > 1 ? x_stride >= 1 : x_stride >= 3), "bad stride");
     XR_REQUIRE(((uintptr_t)table & 15) == 0, "table must be 16-byte aligned");
     GridMeta gm; uint32_t hm;
     XR_REQUIRE(fill_meta(&gm, &hm, n_levels, scale_host, resolution_host, offset_host) == 0, "bad level metadata");
     hipStream_t stream = (hipStream_t)stream_;
-    // XR_HG_FWD_MODE (measurement switches, read once): bit 4 (16) = two-list balanced XCD mapping (order 4), bit 0 =
-    // cost-weighted mapping (order 3), neither = level-major (order 1); bit 1 = non-temporal table loads at the hashed
-    // levels, bit 2 = coarsest levels from LDS, bit 3 = 16-B pair gathers; XR_HG_WSH = "a,b,c": order 3's log2 cost of a
-    // sample block at dense levels < 2^16 entries, larger dense levels, hashed levels.
-    // Default 8 = level-major + pair gathers, the fastest of the measured set at 2^18 ray-ordered samples
-    // (profiles/r02_microbench_fwd_variants.txt: 8: 88.2 us, 24: 88.6, 0: 92.8, 16: 96.8, 20: 101.6, 18: 254.0; the limiter is
-    // the L2's random-line rate, profiles/r02_gather_probe.txt, which none of the mappings changes).
-    static const int mode = scatter_env("XR_HG_FWD_MODE", 8);
+    // XR_HG_FWD_MODE (measurement switches, read once): bit 5 (32) = explicit cost-balanced XCD map (order 5), bit 4 (16) = two-list
+    // balanced XCD mapping (order 4), bit 0 = cost-weighted mapping (order 3), none of them = level-major (order 1); bit 1 =
+    // non-temporal table loads at the hashed levels, bit 2 = coarsest levels from LDS, bit 3 = 16-B pair gathers; XR_HG_WSH =
+    // "a,b,c": order 3's log2 cost of a sample block at dense levels < 2^16 entries, larger dense levels, hashed levels.
+    // Round 2 (profiles/r02_microbench_fwd_variants.txt, 2^18 ray-ordered samples): 8: 88.2 us, 24: 88.6, 0: 92.8, 16: 96.8,
+    // 20: 101.6, 18: 254.0.
+    // Round 3 (profiles/r03_microbench_fwd3.txt): 8: 91.2 us, 0: 96.8, 40 (map from the measured per-level costs + pair gathers):
+    // 83.3, 32 (map, plain gathers): 86.5; with positions as three planes (x_comp_stride > 1): 82.9 / 85.0 / 76.1 / 77.6.
+    // Default 40.
+    static const int mode = scatter_env("XR_HG_FWD_MODE", 40);
     static int wsh3[3] = {-1, 0, 0};
     if (wsh3[0] < 0) {
         int a = 0, b = 1, c = 2;
@@ -811,8 +896,10 @@ extern "C" int xr_hashgrid_fwd(const float* table, const float* x, uint32_t x_st
     gm.nt = (mode >> 1) & 1;
     gm.pairs = (mode >> 3) & 1;
     gm.l_min = 0;
+    XcdMap xm;
+    memset(&xm, 0, sizeof(xm));
     static const uint32_t lds_min_n = (uint32_t)scatter_env("XR_HG_LDS_MIN_N", 32768);
-    if ((mode & 4) && n >= lds_min_n) {
+    if ((mode & 4) && n >= lds_min_n && x_comp_stride == 1 && !(mode & 32)) {
         // levels whose slices fit the LDS together (dense, contiguous from level 0): at most 144 KiB
         int n_lds = 0;
         while (n_lds < n_levels && !((hm >> n_lds) & 1) && (size_t)gm.off[n_lds + 1] * 8 <= 144u * 1024u) ++n_lds;
@@ -830,8 +917,15 @@ extern "C" int xr_hashgrid_fwd(const float* table, const float* x, uint32_t x_st
             gm.l_min = n_lds;
         }
     }
-    uint32_t blocks;
-    if (mode & 16) {
+    uint32_t blocks = 0;
+    if (mode & 32) {
+        float cost[EN_MAX_LEVELS];
+        hg_level_costs(cost, n_levels, hm);
+        const uint32_t per_xcd = hg_build_map(&xm, cost, n_levels, nsb);
+        if (per_xcd) { gm.order = 5; blocks = 8 * per_xcd; }
+    }
+    if (blocks) {
+    } else if (mode & 16) {
         // hashed levels must be the top of the level range (they are, for a growing resolution)
         uint32_t nh = 0;
         while (nh < (uint32_t)(n_levels - gm.l_min) && ((hm >> (n_levels - 1 - nh)) & 1)) ++nh;
@@ -852,10 +946,17 @@ extern "C" int xr_hashgrid_fwd(const float* table, const float* x, uint32_t x_st
         XR_REQUIRE(gm.l_min == 0, "the LDS path needs a balanced mapping");
         blocks = 8 * ((n_levels + 7) / 8) * nsb;
     }
-    hipLaunchKernelGGL(k_hashgrid_fwd, dim3(blocks), dim3(EN_BLOCK), 0, stream, gm, hm, table, x, x_stride, n,
+    hipLaunchKernelGGL(k_hashgrid_fwd, dim3(blocks), dim3(EN_BLOCK), 0, stream, gm, xm, hm, table, x, x_stride, x_comp_stride, n,
                        n_dev, rows, enc_t, ld);
     XR_LAUNCH_CHECK();
     return XR_OK;
+}
+
+extern "C" int xr_hashgrid_fwd(const float* table, const float* x, uint32_t x_stride, uint32_t n, const uint32_t* n_dev,
+                               const uint32_t* rows, int n_levels, const float* scale_host, const uint32_t* resolution_host,
+                               const uint32_t* offset_host, float* enc_t, uint32_t ld, void* stream_) {
+    XR_REQUIRE(x_stride >= 3, "bad stride");
+    return xr_hashgrid_fwd2(table, x, x_stride, 1, n, n_dev, rows, n_levels, scale_host, resolution_host, offset_host, enc_t, ld, stream_);
 }
 
 static int scatter_env(const char* name, int dflt) {
@@ -1059,10 +1160,34 @@ extern "C" int xr_hashgrid_bwd2(const float* x, uint32_t x_stride, const float* 
         return hashgrid_bwd_gen12(x, x_stride, denc_t, ld, n, n_dev, rows, n_levels, scale_host, resolution_host, offset_host, grad_table,
                                   workspace, workspace_bytes, stream_);
     }
-    uint32_t amask = 0;
-    const int rc = xr_scatter3(x, x_stride, denc_t, ld, n, n_dev, rows, gm, hm, grad_table, workspace, workspace_bytes, overwrite, &amask, stream);
-    if (rc != XR_OK) return rc;
-    return amask ? hashgrid_bwd_atomic_levels(gm, hm, amask, x, x_stride, denc_t, ld, n, n_dev, rows, grad_table, overwrite, stream) : XR_OK;
+    // levels without a non-atomic path (tiny / oddly shaped tables, small n) take the atomic kernel -- beside the binned levels on a
+    // helper stream when both exist (disjoint table slices)
+    uint32_t amask = xr_scatter3_atomic_mask(n, gm, hm, workspace && ((uintptr_t)workspace & 15) == 0 && ((uintptr_t)grad_table & 15) == 0);
+    const uint32_t all = (1u << n_levels) - 1u;
+    static hipStream_t aux = nullptr;
+    static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    const bool fork = amask != 0 && amask != all;
+    if (fork) {
+        if (!aux) {
+            XR_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+            XR_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+            XR_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        }
+        XR_HIP(hipEventRecord(ev_fork, stream));
+        XR_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
+    }
+    if (amask) {
+        const int rc = hashgrid_bwd_atomic_levels(gm, hm, amask, x, x_stride, denc_t, ld, n, n_dev, rows, grad_table, overwrite, fork ? aux : stream);
+        if (rc != XR_OK) return rc;
+        if (fork) XR_HIP(hipEventRecord(ev_join, aux));
+    }
+    if (amask != all) {
+        uint32_t amask2 = 0;
+        const int rc = xr_scatter3(x, x_stride, denc_t, ld, n, n_dev, rows, gm, hm, grad_table, workspace, workspace_bytes, overwrite, &amask2, stream);
+        if (rc != XR_OK) return rc;
+    }
+    if (fork) XR_HIP(hipStreamWaitEvent(stream, ev_join, 0));
+    return XR_OK;
 }
 
 extern "C" int xr_hashgrid_bwd(const float* x, uint32_t x_stride, const float* denc_t, uint32_t ld, uint32_t n, const uint32_t* n_dev,

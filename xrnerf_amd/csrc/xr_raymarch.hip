@@ -184,7 +184,7 @@ __global__ __launch_bounds__(RM_BLOCK) void k1_write(
     const uint32_t* __restrict__ local_off, const float* __restrict__ start_t,
     const uint32_t* __restrict__ block_base, const uint32_t* __restrict__ info, float* __restrict__ coords_out,
     int32_t* __restrict__ rays_index, int32_t* __restrict__ numsteps_out, uint32_t* __restrict__ counter2,
-    const float* __restrict__ tlist) {
+    const float* __restrict__ tlist, float* __restrict__ xyz_planes, uint32_t plane_stride) {
     __shared__ uint32_t lds4[4];
     const uint32_t b = blockIdx.x, i = b * RM_BLOCK + threadIdx.x;
     const uint32_t cross = info[1], nb = gridDim.x;
@@ -245,6 +245,10 @@ __global__ __launch_bounds__(RM_BLOCK) void k1_write(
         c[0] = (px - lo) / diag; c[1] = (py - lo) / diag; c[2] = (pz - lo) / diag;
         c[3] = (dt - xr_min_step()) / (xr_max_warp_step() - xr_min_step());       // warp_dt
         c[4] = (dx + 1.0f) * 0.5f; c[5] = (dy + 1.0f) * 0.5f; c[6] = (dz + 1.0f) * 0.5f;   // warp_direction
+        if (xyz_planes) {        // the same positions once more as three planes: the encoder reads them with coalesced loads
+            const size_t q = (size_t)bbase + e;
+            xyz_planes[q] = c[0]; xyz_planes[plane_stride + q] = c[1]; xyz_planes[2 * (size_t)plane_stride + q] = c[2];
+        }
     }
     if (!valid || n <= K1_TL) return;
     // tail of a ray with more than K1_TL samples: resume the march right after sample K1_TL-1
@@ -265,6 +269,10 @@ __global__ __launch_bounds__(RM_BLOCK) void k1_write(
             c[0] = (px - lo) / diag; c[1] = (py - lo) / diag; c[2] = (pz - lo) / diag;
             c[3] = (dt - xr_min_step()) / (xr_max_warp_step() - xr_min_step());
             c[4] = wdx; c[5] = wdy; c[6] = wdz;
+            if (xyz_planes) {
+                const size_t q = (size_t)base + j;
+                xyz_planes[q] = c[0]; xyz_planes[plane_stride + q] = c[1]; xyz_planes[2 * (size_t)plane_stride + q] = c[2];
+            }
             ++j; t += dt;
         } else t = rm_advance(t, cone, px, py, pz, r, XR_NERF_GRIDSIZE >> mip);
     }
@@ -285,13 +293,14 @@ static size_t rm_ws_layout(uint32_t n_rays, char* base, RmWorkspace* w) {
 
 extern "C" size_t xr_rays_sampler_workspace_bytes(uint32_t n_rays) { return rm_ws_layout(n_rays, nullptr, nullptr); }
 
-extern "C" int xr_rays_sampler(const float* rays_o, const float* rays_d, const uint8_t* bitfield, uint32_t n_rays,
-                               float aabb0, float aabb1, float near_distance, float cone_angle, uint32_t max_samples,
-                               uint64_t rng_state, uint64_t rng_inc, float* coords_out, int32_t* rays_index,
-                               int32_t* rays_numsteps, uint32_t* counter2, void* workspace, size_t workspace_bytes,
-                               void* stream_) {
+extern "C" int xr_rays_sampler2(const float* rays_o, const float* rays_d, const uint8_t* bitfield, uint32_t n_rays,
+                                float aabb0, float aabb1, float near_distance, float cone_angle, uint32_t max_samples,
+                                uint64_t rng_state, uint64_t rng_inc, float* coords_out, int32_t* rays_index,
+                                int32_t* rays_numsteps, uint32_t* counter2, float* xyz_planes, uint32_t plane_stride,
+                                void* workspace, size_t workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     XR_REQUIRE(rays_o && rays_d && bitfield && coords_out && rays_index && rays_numsteps && counter2, "null pointer");
+    XR_REQUIRE(!xyz_planes || plane_stride >= max_samples, "a position plane holds max_samples values");
     XR_REQUIRE(n_rays > 0 && n_rays <= (1u << 28), "n_rays out of range");
     XR_REQUIRE(workspace && workspace_bytes >= xr_rays_sampler_workspace_bytes(n_rays), "workspace too small");
     RmWorkspace w; rm_ws_layout(n_rays, (char*)workspace, &w);
@@ -302,9 +311,18 @@ extern "C" int xr_rays_sampler(const float* rays_o, const float* rays_d, const u
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, nb, w.block_tot, max_samples, w.block_base, w.info);
     hipLaunchKernelGGL(k1_write, dim3(nb), dim3(RM_BLOCK), 0, stream, n_rays, aabb0, aabb1, rays_o, rays_d, bitfield,
                        cone_angle, max_samples, w.cnt, w.local_off, w.start_t, w.block_base, w.info, coords_out,
-                       rays_index, rays_numsteps, counter2, w.tlist);
+                       rays_index, rays_numsteps, counter2, w.tlist, xyz_planes, plane_stride);
     XR_LAUNCH_CHECK();
     return XR_OK;
+}
+
+extern "C" int xr_rays_sampler(const float* rays_o, const float* rays_d, const uint8_t* bitfield, uint32_t n_rays,
+                               float aabb0, float aabb1, float near_distance, float cone_angle, uint32_t max_samples,
+                               uint64_t rng_state, uint64_t rng_inc, float* coords_out, int32_t* rays_index,
+                               int32_t* rays_numsteps, uint32_t* counter2, void* workspace, size_t workspace_bytes,
+                               void* stream_) {
+    return xr_rays_sampler2(rays_o, rays_d, bitfield, n_rays, aabb0, aabb1, near_distance, cone_angle, max_samples, rng_state, rng_inc,
+                            coords_out, rays_index, rays_numsteps, counter2, nullptr, 0, workspace, workspace_bytes, stream_);
 }
 
 // ------------------------------------------------------------------ K2 re-pack (compacted_coord.cu:22-76)

@@ -509,6 +509,7 @@ static bool s3_layout(uint32_t n, const GridMeta& gm, uint32_t hashed_mask, int 
     P.bin.nsb = nsb; P.bin.overwrite = (uint32_t)overwrite; P.bin.ovf_cap = 8u * bs;
     P.rl.chunks = s3_chunks(); P.rl.overwrite = (uint32_t)overwrite;
     static const int use_rl = s3_env("XR_SC_RL", 1);      // 0: small dense levels through the binned path too (measurement)
+    static const int dense_atomic = s3_env("XR_SC_DENSE_ATOMIC", 0);   // 1: every dense level through the atomic kernel (measurement)
     uint64_t bins_off = 0, ovf_off = 0;
     uint32_t counts_off = 0;
     // accumulate order: dense binned levels first (32 partitions carry twice a hashed partition's items)
@@ -518,8 +519,8 @@ static bool s3_layout(uint32_t n, const GridMeta& gm, uint32_t hashed_mask, int 
             const bool hashed = (hashed_mask >> l) & 1;
             const bool kindH = hashed && (hsize & (hsize - 1)) == 0 && hsize >= S3_ENTRIES && (hsize >> S3_LOG2) <= S3_MAX_PARTS &&
                                res < S3_ENTRIES && (gm.off[l] & 1) == 0;
-            const bool kindR = !hashed && hsize <= S3_R_MAX_ENTRIES && use_rl;
-            const bool kindD = !hashed && !kindR && hsize >= 1024u && hsize <= 64u * S3_ENTRIES;
+            const bool kindR = !hashed && hsize <= S3_R_MAX_ENTRIES && use_rl && !dense_atomic;
+            const bool kindD = !hashed && !kindR && hsize >= 1024u && hsize <= 64u * S3_ENTRIES && !dense_atomic;
             if (pass == 0 && !kindH && !kindD && !kindR) P.atomic_mask |= 1u << l;
             if (pass == 0 && kindR) {
                 S3RLevel& R = P.rl.lv[P.rl.n_lv++];
@@ -560,6 +561,12 @@ size_t xr_scatter3_workspace_bytes(uint32_t n, const GridMeta& gm, uint32_t hash
     return P.counts_bytes + P.bins_bytes + P.ovf_bytes + P.slabs_bytes;
 }
 
+uint32_t xr_scatter3_atomic_mask(uint32_t n, const GridMeta& gm, uint32_t hashed_mask, bool workspace_ok) {
+    S3Layout P;
+    if (!workspace_ok || !s3_layout(n, gm, hashed_mask, 0, &P)) return (1u << gm.n_levels) - 1u;
+    return P.atomic_mask;
+}
+
 int xr_scatter3(const float* x, uint32_t x_stride, const float* denc_t, uint32_t ld, uint32_t n, const uint32_t* n_dev,
                 const uint32_t* rows, const GridMeta& gm, uint32_t hashed_mask, float* grad_table, void* workspace,
                 size_t workspace_bytes, int overwrite, uint32_t* atomic_mask, hipStream_t stream) {
@@ -581,14 +588,32 @@ int xr_scatter3(const float* x, uint32_t x_stride, const float* denc_t, uint32_t
         attr_set = true;
     }
     // XR_SC_RL_FIRST=0: the small dense levels AFTER the bin / accumulate pair instead of before it (measurement)
+    // XR_SC_RL_ASYNC=1: ... on an internal helper stream beside the pair (disjoint table slices, read-only inputs), forked from
+    // and joined back into the caller's stream with events
     static const int rl_first = s3_env("XR_SC_RL_FIRST", 1);
+    static const int rl_async = s3_env("XR_SC_RL_ASYNC", 1);
+    static hipStream_t aux = nullptr;
+    static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    const bool fork = rl_async && P.rl.n_lv > 0 && P.bin.n_lv > 0;
+    if (fork && !aux) {
+        XR_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+        XR_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        XR_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    }
     auto launch_rl = [&]() -> int {
         if (P.rl.n_lv == 0) return XR_OK;
-        hipLaunchKernelGGL(k_scatter_dense_rl, dim3(P.rl.blocks), dim3(S3_R_THREADS), S3_LDS_BYTES, stream, P.rl, x, x_stride, denc_t, ld, n,
+        hipStream_t rs = stream;
+        if (fork) {
+            XR_HIP(hipEventRecord(ev_fork, stream));
+            XR_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
+            rs = aux;
+        }
+        hipLaunchKernelGGL(k_scatter_dense_rl, dim3(P.rl.blocks), dim3(S3_R_THREADS), S3_LDS_BYTES, rs, P.rl, x, x_stride, denc_t, ld, n,
                            n_dev, rows, slabs);
         XR_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_scatter_fold, dim3(xr_div_up(P.rl.slab_entries, 256)), dim3(256), 0, stream, P.rl, (const float2*)slabs, grad_table);
+        hipLaunchKernelGGL(k_scatter_fold, dim3(xr_div_up(P.rl.slab_entries, 256)), dim3(256), 0, rs, P.rl, (const float2*)slabs, grad_table);
         XR_LAUNCH_CHECK();
+        if (fork) XR_HIP(hipEventRecord(ev_join, aux));
         return XR_OK;
     };
     if (rl_first) { const int rc = launch_rl(); if (rc != XR_OK) return rc; }
@@ -604,5 +629,6 @@ int xr_scatter3(const float* x, uint32_t x_stride, const float* denc_t, uint32_t
         XR_LAUNCH_CHECK();
     }
     if (!rl_first) { const int rc = launch_rl(); if (rc != XR_OK) return rc; }
+    if (fork) XR_HIP(hipStreamWaitEvent(stream, ev_join, 0));
     return XR_OK;
 }

@@ -88,9 +88,10 @@ class _NerfMLPFn(torch.autograd.Function):
     """encode -> density_net -> (SH, color_net) -> raw [n,4]; backward recomputes activations."""
 
     @staticmethod
-    def forward(ctx, table, wd, wc, pts, dirs, mlp, n_dev):
+    def forward(ctx, table, wd, wc, pts, dirs, mlp, n_dev, planes=None):
         n = pts.shape[0]
-        enc_t = ops.hashgrid_fwd(table, pts, mlp.embedder_pos.meta, n_dev=n_dev)
+        # `planes` [3, n]: the same positions as three planes when the sampler has them (coalesced loads in the gather)
+        enc_t = ops.hashgrid_fwd(table, planes if planes is not None else pts, mlp.embedder_pos.meta, n_dev=n_dev)
         raw = ops.nerf_mlp_fwd(enc_t, dirs, n, wd, wc, mlp.density_net.n_hidden, mlp.color_net.n_hidden, mlp.pad_value,
                                n_dev=n_dev)
         ctx.save_for_backward(table, wd, wc, pts, dirs, enc_t)
@@ -108,7 +109,7 @@ class _NerfMLPFn(torch.autograd.Function):
                                   g_wd, g_wc, mlp.pad_value, n_dev=ctx.n_dev)
         g_table = torch.zeros_like(table)
         ops.hashgrid_bwd(pts, denc_t, mlp.embedder_pos.meta, g_table, n_dev=ctx.n_dev)
-        return g_table, g_wd, g_wc, None, None, None, None
+        return g_table, g_wd, g_wc, None, None, None, None, None
 
 
 @MLPS.register_module()
@@ -157,8 +158,11 @@ class HashNerfMLP(nn.Module):
             return torch.zeros((0, 4), dtype=torch.float32, device=pts.device)
         # `n_valid_dev` (optional, device int32[1]): rows past it are padding of a fixed-size sample buffer
         # (the reference pads its compacted buffer to target_batch_size rows with zeros and evaluates them)
+        planes = data.get('pts_planes')
+        if planes is not None and (planes.dim() != 2 or planes.shape[0] != 3 or planes.shape[1] != pts.shape[0] or pts.shape[0] == 3):
+            planes = None
         return _NerfMLPFn.apply(self.embedder_pos.params, self.density_net.params, self.color_net.params, pts, dirs,
-                                self, data.get('n_valid_dev'))
+                                self, data.get('n_valid_dev'), planes)
 
     def run_density(self, pts_flat):
         """hashnerf_mlp.py:107-111: encode + density_net, channel 0 -> [N,1] fp32 (no grad)."""

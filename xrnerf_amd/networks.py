@@ -134,7 +134,8 @@ class _FusedTrainStepFn(torch.autograd.Function):
                 rgb = ops.ngp_train_step(table, wd, wc, 1, 2, mlp.pad_value, meta, sampler.coords, data.get('n_valid_dev'),
                                          sampler.rays_numsteps, sampler.rays_numsteps_compacted, data['bg_color'],
                                          data['target_s'].contiguous(), data['alpha'].contiguous(), sampler.density_grid_mean,
-                                         int(sampler.rgb_activation), int(sampler.density_activation), b, scatter_level0=split)
+                                         int(sampler.rgb_activation), int(sampler.density_activation), b, scatter_level0=split,
+                                         xyz=getattr(sampler, 'xyz', None))
                 if sync is not None:
                     sync.ready(b.g_mlp)
                     if split:

@@ -193,9 +193,10 @@ def pcg32_host_state(ncalls, seed=9121):
 
 # ---------------------------------------------------------------- K1 / K2
 def rays_sampler(rays_o, rays_d, bitfield, aabb, near_distance, cone_angle, max_samples, rng_calls,
-                 coords_out=None, ws_tag='k1', small_out=None):
+                 coords_out=None, ws_tag='k1', small_out=None, xyz_out=None):
     """returns coords_out [max_samples,7], rays_index [n,1], rays_numsteps [n,2], counter [2] (device).
-    `small_out` = (rays_index, numsteps, counter) caller-owned buffers (persistent double buffers of the trainer)."""
+    `small_out` = (rays_index, numsteps, counter) caller-owned buffers (persistent double buffers of the trainer).
+    `xyz_out` = [3, >= max_samples] float32: the sample positions once more as three planes (hashgrid_fwd's fast input)."""
     L = _lib.load()
     n = rays_o.shape[0]
     dev = rays_o.device
@@ -211,9 +212,10 @@ def rays_sampler(rays_o, rays_d, bitfield, aabb, near_distance, cone_angle, max_
     ws = _ws(dev, nb, ws_tag)
     st, inc = pcg32_host_state(rng_calls)
     with _span('xr_rays_sampler', n):
-        _lib.check(L.xr_rays_sampler(_ptr(rays_o), _ptr(rays_d), _ptr(bitfield), n, aabb[0], aabb[1], near_distance,
-                                     cone_angle, max_samples, st, inc, _ptr(coords_out), _ptr(rays_index),
-                                     _ptr(numsteps), _ptr(counter), _ptr(ws), ws.numel(), _stream()), 'xr_rays_sampler')
+        _lib.check(L.xr_rays_sampler2(_ptr(rays_o), _ptr(rays_d), _ptr(bitfield), n, aabb[0], aabb[1], near_distance,
+                                      cone_angle, max_samples, st, inc, _ptr(coords_out), _ptr(rays_index),
+                                      _ptr(numsteps), _ptr(counter), _ptr(xyz_out), xyz_out.shape[1] if xyz_out is not None else 0,
+                                      _ptr(ws), ws.numel(), _stream()), 'xr_rays_sampler')
     return coords_out, rays_index, numsteps, counter
 
 
@@ -272,7 +274,7 @@ def composite_train(raw, coords, numsteps, numsteps_c, bg, target, alpha, densit
 
 
 def ngp_prefetch(rows, n, batch_call_index, batch_out, bitfield, aabb, near_distance, cone_angle, max_samples, k1_call_index,
-                 coords_out, small_out, clip_out, max_compacted, counter_host, batch_seed=20220901, ws_tag='k1_side'):
+                 coords_out, small_out, clip_out, max_compacted, counter_host, batch_seed=20220901, ws_tag='k1_side', xyz_out=None):
     """make_batch + K1 + K2 clip + counter copy to pinned host memory as one native call (xr_ngp_prefetch) on the current stream.
     -> (batch dict of views, (coords_out, rays_index, numsteps, counter), (numsteps_clipped, n_valid))"""
     L = _lib.load()
@@ -285,7 +287,8 @@ def ngp_prefetch(rows, n, batch_call_index, batch_out, bitfield, aabb, near_dist
                                      _ptr(ids), _ptr(bitfield), aabb[0], aabb[1], near_distance, cone_angle, max_samples,
                                      k1_call_index, _ptr(coords_out), _ptr(rays_index), _ptr(numsteps), _ptr(counter), _ptr(ws),
                                      ws.numel(), max_compacted, _ptr(clipped), _ptr(n_valid),
-                                     C.c_void_p(counter_host.data_ptr()) if counter_host is not None else None, _stream()),
+                                     C.c_void_p(counter_host.data_ptr()) if counter_host is not None else None,
+                                     _ptr(xyz_out), xyz_out.shape[1] if xyz_out is not None else 0, _stream()),
                    'xr_ngp_prefetch')
     batch = {'rays_o': o, 'rays_d': d, 'target_s': tgt, 'alpha': alpha, 'img_ids': ids, 'bg_color': bg}
     return batch, (coords_out, rays_index, numsteps, counter), (clipped, n_valid)
@@ -307,7 +310,7 @@ class TrainStepBuffers:
 
 
 def ngp_train_step(table, wd, wc, nhd, nhc, pad_value, meta, coords, n_dev, numsteps, numsteps_c, bg, target, alpha,
-                   density_grid_mean, rgb_act, density_act, bufs, huber_delta=0.1, loss_scale=5.0, scatter_level0=0):
+                   density_grid_mean, rgb_act, density_act, bufs, huber_delta=0.1, loss_scale=5.0, scatter_level0=0, xyz=None):
     """the device work of one HashNerfNetwork training step as one native call (xr_ngp_train_step): encode -> MLP -> K3 +
     Huber + K4 -> MLP backward -> table scatter into `bufs` (TrainStepBuffers).  Returns rgb [n_rays,3] (a view of bufs.rgb).
     scatter_level0 > 0 (data parallel): only hash levels [scatter_level0, n_levels) are scattered; the caller finishes with
@@ -340,7 +343,8 @@ def ngp_train_step(table, wd, wc, nhd, nhc, pad_value, meta, coords, n_dev, nums
             _ptr(bufs.enc_t), bufs.ld, _ptr(bufs.raw), _ptr(bufs.draw), _ptr(bufs.denc_t), _ptr(bufs.rgb),
             _ptr(bufs.zero_block), bufs.zero_block.numel(), _ptr(bufs.g_wd), _ptr(bufs.g_wc), _ptr(bufs.loss_mse),
             _ptr(bufs.g_table), bufs.g_table.numel(), 0 if n_dev is not None else 1,
-            _ptr(ws_mlp), ws_mlp.numel(), _ptr(ws_sc), ws_sc.numel(), int(scatter_level0), stage.encode() if stage else None,
+            _ptr(ws_mlp), ws_mlp.numel(), _ptr(ws_sc), ws_sc.numel(), int(scatter_level0),
+            _ptr(xyz), xyz.shape[1] if xyz is not None else 0, stage.encode() if stage else None,
             ev[0].h if stage else None, ev[1].h if stage else None, _stream()), 'xr_ngp_train_step')
     return bufs.rgb[:n_rays]
 
@@ -468,12 +472,19 @@ def clip_numsteps(numsteps, counter, max_compacted, out=None):
 
 
 def hashgrid_fwd(table, x, meta, enc_t=None, ld=None, n_dev=None, rows=None, row0=0, count=None, levels=None):
-    """x: [n,3] (or a column slice of [n,7] rows) -> enc_t [2L, ld] feature-major.
+    """x: [n,3] (or a column slice of [n,7] rows), or positions as three planes [3, m] (m >= n: structure of arrays, three
+    coalesced loads per sample) -> enc_t [2L, ld] feature-major.
     n_dev: optional device int32[1]; only min(n, n_dev) rows are touched (no host read-back needed).
     levels=(l0, l1): only that level range is evaluated (rows 2*l0 .. 2*l1 of enc_t; measurement / partial updates)."""
     L = _lib.load()
-    x, xs = _pos_view(x)
-    n = x.shape[0] if rows is None else rows.shape[0]
+    if x.dim() == 2 and x.shape[0] == 3 and x.shape[1] != 3 and x.stride(1) == 1:      # planes [3, m]
+        if x.dtype != torch.float32 or not _on_device(x):
+            raise _lib.XrError('positions must be float32 device tensors')
+        xs, xcs, n_x = 1, int(x.stride(0)), x.shape[1]
+    else:
+        x, xs = _pos_view(x)
+        xcs, n_x = 1, x.shape[0]
+    n = n_x if rows is None else rows.shape[0]
     if ld is None:
         ld = (n + 63) // 64 * 64
     if enc_t is None:
@@ -488,8 +499,8 @@ def hashgrid_fwd(table, x, meta, enc_t=None, ld=None, n_dev=None, rows=None, row
     ep = enc_t.data_ptr() + 4 * (row0 + 2 * l0 * ld)
     with _span('xr_hashgrid_fwd', 0 if n_dev is not None else n, train=n_dev is not None):
         _ptr(enc_t)
-        _lib.check(L.xr_hashgrid_fwd(_ptr(table), C.c_void_p(xp), xs, n, _ptr(n_dev), _ptr(rows), l1 - l0, s + 4 * l0, r + 4 * l0,
-                                     o + 4 * l0, C.c_void_p(ep), ld, _stream()), 'xr_hashgrid_fwd')
+        _lib.check(L.xr_hashgrid_fwd2(_ptr(table), C.c_void_p(xp), xs, xcs, n, _ptr(n_dev), _ptr(rows), l1 - l0, s + 4 * l0, r + 4 * l0,
+                                      o + 4 * l0, C.c_void_p(ep), ld, _stream()), 'xr_hashgrid_fwd')
     return enc_t
 
 

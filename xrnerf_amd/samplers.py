@@ -171,6 +171,7 @@ class NGPGridSampler(nn.Module):
             cur = torch.cuda.current_stream()
             cur.wait_event(pf['event'])
             coords, rays_index, rays_numsteps, counter = pf['out']
+            xyz = pf.get('xyz')
             clipped = pf.get('clipped')
             self._pending_counts.append(pf['host'])
             # K1's outputs live in this sampler's persistent double buffers (nothing was allocated on the side
@@ -190,19 +191,21 @@ class NGPGridSampler(nn.Module):
                 torch.cuda.current_stream().wait_event(pf['event'])
             slot = self._next_slot(is_training)
             k1_index = self.k1_calls
+            xyz = self._xyz_buffer(max_samples, slot)
             coords, rays_index, rays_numsteps, counter = ops.rays_sampler(
                 rays_o, rays_d, self.density_grid_bitfield, aabb, self.near_distance, self.cone_angle_constant,
                 max_samples, k1_index, coords_out=self._coords_buffer(max_samples, slot),
-                small_out=self._small_buffers(n_rays, slot))
+                small_out=self._small_buffers(n_rays, slot), xyz_out=xyz)
             self.k1_calls += 1
             if not is_training:
                 n_valid, samples = counter.tolist()      # one host read-back per call (rays_sampler.py:72)
                 if samples > max_samples:
                     max_samples = min(n_rays * self.MAX_STEP, samples)
+                    xyz = self._xyz_buffer(max_samples, slot)
                     coords, rays_index, rays_numsteps, counter = ops.rays_sampler(
                         rays_o, rays_d, self.density_grid_bitfield, aabb, self.near_distance, self.cone_angle_constant,
                         max_samples, k1_index, coords_out=self._coords_buffer(max_samples, slot),
-                        small_out=self._small_buffers(n_rays, slot))
+                        small_out=self._small_buffers(n_rays, slot), xyz_out=xyz)
                     n_valid, samples = counter.tolist()
                 self._test_rows_seen = samples
             elif self._streams():
@@ -220,8 +223,11 @@ class NGPGridSampler(nn.Module):
         if not is_training:
             coords = coords[:min(samples, max_samples)]
             self.coords = coords
+            self.xyz = xyz
             self.rays_numsteps = rays_numsteps
             data['pts'], data['viewdirs'] = coords[..., :3], coords[..., 4:]
+            if xyz is not None:
+                data['pts_planes'] = xyz[:, :coords.shape[0]]      # the same positions as planes [3, n] (K1 wrote both)
             return data
 
         # K2.  K1's bases are the ray-ordered prefix sums, i.e. exactly what K2 would assign, so the
@@ -237,6 +243,9 @@ class NGPGridSampler(nn.Module):
         self.update_batch_rays(is_training, max_samples)
         coords_compacted = coords[:self.target_batch_size]
         self.coords = coords_compacted
+        self.xyz = xyz
+        if xyz is not None:
+            data['pts_planes'] = xyz[:, :coords_compacted.shape[0]]
         self.rays_numsteps = rays_numsteps
         self.rays_numsteps_compacted = rays_numsteps_compacted
         self.n_valid_dev = n_valid_dev[0:1]
@@ -264,6 +273,19 @@ class NGPGridSampler(nn.Module):
         if buf is None or buf.shape[0] < rows or buf.device != self.device:
             buf = bufs[slot] = torch.empty((rows, 7), dtype=torch.float32, device=self.device)
         return buf[:rows]
+
+    def _xyz_buffer(self, rows, slot):
+        """[3, rows] planes holding the positions of the slot's coordinate rows once more (K1 writes both): the encoder's
+        coalesced input.  Device only (the host build of the kernels reads the rows)."""
+        if not self._streams() or os.environ.get('XRNERF_XYZ_PLANES', '1') == '0':
+            return None
+        bufs = getattr(self, '_xyz_bufs', None)
+        if bufs is None:
+            bufs = self._xyz_bufs = [None, None, None]
+        buf = bufs[slot]
+        if buf is None or buf.shape[1] < rows or buf.device != self.device:
+            buf = bufs[slot] = torch.empty((3, rows), dtype=torch.float32, device=self.device)
+        return buf
 
     def _small_buffers(self, n_rays, slot):
         bufs = getattr(self, '_small_bufs', None)
@@ -323,10 +345,11 @@ class NGPGridSampler(nn.Module):
         if buffer_free_event is not None:
             side.wait_event(buffer_free_event)
         slot = self._next_slot(True)
+        xyz = self._xyz_buffer(max_samples, slot)
         out = ops.rays_sampler(rays_o, rays_d, self.density_grid_bitfield, aabb, self.near_distance,
                                self.cone_angle_constant, max_samples, self.k1_calls,
                                coords_out=self._coords_buffer(max_samples, slot), ws_tag='k1_side',
-                               small_out=self._small_buffers(n_rays, slot))
+                               small_out=self._small_buffers(n_rays, slot), xyz_out=xyz)
         self.k1_calls += 1
         # K2's clipped per-ray counts and the device-side valid-row count only depend on this launch's outputs: computed
         # here, on the side stream, instead of in front of the next iteration's encode
@@ -337,7 +360,8 @@ class NGPGridSampler(nn.Module):
         done = torch.cuda.Event()
         done.record(side)
         host = self._count_to_host(out[3])
-        self._prefetched = {'rays_o': rays_o, 'max_samples': max_samples, 'out': out, 'event': done, 'host': host, 'clipped': clipped}
+        self._prefetched = {'rays_o': rays_o, 'max_samples': max_samples, 'out': out, 'event': done, 'host': host, 'clipped': clipped,
+                            'xyz': xyz}
 
     def prefetch_native(self, rows, n_rays, batch_call_index, batch_out, buffer_free_event=None):
         """`prefetch` with the batch assembly folded in, as ONE native call (xr_ngp_prefetch: make_batch + K1 + K2 clip + counter
@@ -353,17 +377,18 @@ class NGPGridSampler(nn.Module):
         if buffer_free_event is not None:
             side.wait_event(buffer_free_event)
         slot = self._next_slot(True)
+        xyz = self._xyz_buffer(max_samples, slot)
         batch, out, clipped = ops.ngp_prefetch(rows, n_rays, batch_call_index, batch_out, self.density_grid_bitfield, aabb,
                                                self.near_distance, self.cone_angle_constant, max_samples, self.k1_calls,
                                                self._coords_buffer(max_samples, slot), self._small_buffers(n_rays, slot),
-                                               self._clip_buffers(n_rays, slot), self.target_batch_size, None)
+                                               self._clip_buffers(n_rays, slot), self.target_batch_size, None, xyz_out=xyz)
         self.__dict__['k1_calls'] = self.k1_calls + 1
         # the compute stream waits for the march only: its event sits BEFORE the counter's device-to-host copy (see prefetch)
         done = torch.cuda.Event()
         done.record(side)
         host = self._count_to_host(out[3])
         self.__dict__['_prefetched'] = {'rays_o': batch['rays_o'], 'max_samples': max_samples, 'out': out, 'event': done,
-                                        'host': host, 'clipped': clipped}
+                                        'host': host, 'clipped': clipped, 'xyz': xyz}
         return batch
 
     def _count_to_host(self, counter):
