@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE: one process = one setting of the scatter's process-wide switches (XR_SC_MODE / XR_SC_BLOCK / XR_SC_RL /
 XR_SC_RL_CHUNKS / XR_SC_MIN_N are read once).  Runs xr_hashgrid_bwd2 of the kernels' host build (tests/hip_emu) against
 oracle/ngp_oracle.c on `n` positions drawn as `mode` and prints one line per check; exit code 0 = all within tolerance.
-usage: python tests/scatter_emu_case.py <n> <rand|rays|cluster>"""
+usage: python tests/scatter_emu_case.py <n> <rand|rays|cluster|faces>"""
 import os
 import sys
 
@@ -24,6 +24,10 @@ def positions(n, mode, rng):
         d3 /= np.linalg.norm(d3, axis=1, keepdims=True)
         k = np.arange(nr * 20)
         x[:nr * 20] = np.clip(o3[k // 20] + (np.float32(0.0017) * (k % 20).astype(np.float32))[:, None] * d3[k // 20], 0, 1)
+    elif mode == 'faces':            # piled on the domain's upper faces: tcnn's linear index leaves the lattice row / wraps around
+        x[:, 0] = 1.0
+        x[: n // 2, 1] = 1.0
+        x[: n // 4, 2] = 1.0
     x[0] = [0.0, 1.0, 0.5]
     x[1] = [1.0, 1.0, 1.0]           # index wrap-around at the upper corner of the domain
     return x

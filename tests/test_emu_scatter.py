@@ -19,14 +19,14 @@ def run(n, mode, **env):
     return r.stdout
 
 
-@pytest.mark.parametrize('n,mode', [(3000, 'rand'), (9000, 'rays'), (5000, 'cluster')])
+@pytest.mark.parametrize('n,mode', [(3000, 'rand'), (9000, 'rays'), (5000, 'cluster'), (3000, 'faces')])
 def test_scatter_generation_3_against_the_oracle(n, mode):
     out = run(n, mode)
     assert out.count('levels out of tolerance: []') == 7, out
 
 
-@pytest.mark.parametrize('env', [dict(XR_SC_BLOCK='1024'), dict(XR_SC_BLOCK='2048'), dict(XR_SC_RL='0'), dict(XR_SC_RL_CHUNKS='3'),
-                                 dict(XR_SC_MODE='1')])
-def test_scatter_switches_give_the_same_gradients(env):
-    run(9000, 'rays', **env)
-    run(5000, 'cluster', **env)
+@pytest.mark.parametrize('n,mode,env', [(5000, 'cluster', dict(XR_SC_BLOCK='1024')), (9000, 'rays', dict(XR_SC_BLOCK='2048')),
+                                        (3000, 'faces', dict(XR_SC_RL='0')), (9000, 'rays', dict(XR_SC_RL_CHUNKS='3')),
+                                        (5000, 'cluster', dict(XR_SC_MODE='1')), (9000, 'rays', dict(XR_SC_DENSE_ATOMIC='1'))])
+def test_scatter_switches_give_the_same_gradients(n, mode, env):
+    run(n, mode, **env)

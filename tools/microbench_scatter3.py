@@ -44,8 +44,8 @@ def child():
         us = timeit(lambda: ops.hashgrid_bwd(c[:, :3], denc, meta, g, live=(rows, nl), overwrite=True), 50)
         print('%-34s ONLY levels (0, 16) live list (%d): %.1f us' % (tag, len(live), us), flush=True)
         return
-    for lv in ((0, 16), (5, 16), (3, 16), (0, 3), (0, 5), (8, 16), (0, 8)):
-        if os.environ.get('XR_QUICK') and lv not in ((0, 16), (5, 16), (0, 5)): continue
+    for lv in ((0, 16), (5, 16), (3, 16), (0, 3), (0, 5), (8, 16), (0, 8), (5, 9), (12, 16), (3, 5)):
+        if os.environ.get('XR_QUICK') and lv not in ((0, 16), (5, 16), (0, 5), (5, 9), (12, 16), (3, 5)): continue
         us_all = timeit(lambda: ops.hashgrid_bwd(c[:, :3], denc, meta, g, levels=lv, overwrite=True))
         us_live = timeit(lambda: ops.hashgrid_bwd(c[:, :3], denc, meta, g, levels=lv, live=(rows, nl), overwrite=True))
         out.append('%-34s levels %-8s  all rows (%d) %.1f us   live list (%d) %.1f us' % (tag, lv, n, us_all, len(live), us_live))
@@ -65,8 +65,8 @@ if __name__ == '__main__':
         child()
     else:
         quick = len(sys.argv) > 1 and sys.argv[1] == 'quick'
-        runs = [dict(XR_SC_MODE='1'), dict(XR_SC_MODE='2'), dict(XR_SC_MODE='2', XR_SC_RL_ASYNC='0'), dict(XR_SC_MODE='2', XR_SC_DENSE_ATOMIC='1'),
-                dict(XR_SC_MODE='2', XR_SC_BLOCK='2048'), dict(XR_SC_MODE='2', XR_SC_RL_FIRST='0')]
+        runs = [dict(XR_SC_MODE='2'), dict(XR_SC_MODE='2', XR_SC_LOG2='12'), dict(XR_SC_MODE='2', XR_SC_LOG2='12', XR_SC_BLOCK='2048'),
+                dict(XR_SC_MODE='2', XR_SC_BLOCK='2048'), dict(XR_SC_MODE='2', XR_SC_RL_ASYNC='0')]
         for env in runs:
             e = dict(os.environ, XR_CHILD='1', **env)
             if quick: e['XR_QUICK'] = '1'

@@ -1,0 +1,79 @@
+// phase timing of the third-generation accumulate kernel (k_scatter_accum3<13>) on ray-like samples (20 consecutive steps of
+// sqrt(3)/1024 per ray), all 16 levels of the Lego geometry: wall_clock64 (100 MHz) stamps of workgroups 0, 96, 192, ... + event
+// times of the kernels.  build + run on the GPU box:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -ffp-contract=off -mllvm -simplifycfg-sink-common=false -DS3_TIMING \
+//         tools/scatter3_timing.hip -o tools/scatter3_timing && tools/scatter3_timing [n]
+#include "../xrnerf_amd/csrc/xr_scatter.hip"
+#include <vector>
+#include <cstdio>
+#include <cmath>
+void xr_set_error(const char*, ...) {}
+extern "C" void xr_hashgrid_meta(int n_levels, int log2_hashmap_size, int base_resolution, double per_level_scale, float* scale,
+                                 uint32_t* resolution, uint32_t* offset) {
+    const float log2b = log2f((float)per_level_scale);
+    uint32_t off = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        const float s = exp2f((float)l * log2b) * (float)base_resolution - 1.0f;
+        const uint32_t res = (uint32_t)ceilf(s) + 1u;
+        scale[l] = s; resolution[l] = res; offset[l] = off;
+        const double cube = (double)res * res * res;
+        uint32_t n = cube > 2147483647.0 ? 2147483647u : (uint32_t)cube;
+        n = (n + 7u) / 8u * 8u;
+        if (n > (1u << log2_hashmap_size)) n = 1u << log2_hashmap_size;
+        off += n;
+    }
+    offset[n_levels] = off;
+}
+int main(int argc, char** argv) {
+    const uint32_t n = argc > 1 ? (uint32_t)atoi(argv[1]) : 121776u;
+    float scale[16]; uint32_t res[16], off[17];
+    xr_hashgrid_meta(16, 19, 16, std::exp2(std::log2(2048.0 / 16) / 15), scale, res, off);
+    GridMeta gm; uint32_t hm; fill_meta(&gm, &hm, 16, scale, res, off);
+    std::vector<float> x((size_t)n * 3), d((size_t)32 * n);
+    uint32_t h = 1; auto rnd = [&]() { h = h * 1664525u + 1013904223u; return (h >> 8) * (1.f / 16777216.f); };
+    float o[3] = {0, 0, 0}, dir[3] = {0, 0, 1};
+    for (uint32_t i = 0; i < n; ++i) {
+        if (i % 20 == 0) {
+            float nn = 0;
+            for (int k = 0; k < 3; ++k) { o[k] = 0.25f + 0.5f * rnd(); dir[k] = rnd() - 0.5f; nn += dir[k] * dir[k]; }
+            nn = 1.f / sqrtf(nn + 1e-9f);
+            for (int k = 0; k < 3; ++k) dir[k] *= nn;
+        }
+        for (int k = 0; k < 3; ++k) { float v = o[k] + 0.0016915f * (i % 20) * dir[k]; x[3 * (size_t)i + k] = v < 0 ? 0 : (v > 1 ? 1 : v); }
+    }
+    for (auto& v : d) v = rnd() - 0.5f;
+    S3Layout P;
+    if (!s3_layout(1u << 18, gm, hm, 1, &P)) { printf("no layout\n"); return 1; }
+    printf("n %u  binned levels %u  accumulate workgroups %u  nsb %u  run-length levels %u\n", n, P.bin.n_lv, P.bin.acc_blocks, P.bin.nsb, P.rl.n_lv);
+    float *dx, *dd, *tab; void* ws; uint32_t* ndev;
+    hipMalloc(&dx, x.size() * 4); hipMalloc(&dd, d.size() * 4); hipMalloc(&tab, (size_t)off[16] * 8); hipMalloc(&ndev, 4);
+    const size_t wsb = P.counts_bytes + P.bins_bytes + P.ovf_bytes + P.slabs_bytes;
+    hipMalloc(&ws, wsb);
+    hipMemcpy(dx, x.data(), x.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dd, d.data(), d.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(ndev, &n, 4, hipMemcpyHostToDevice);
+    uint32_t* counts = (uint32_t*)ws;
+    float4* bins = (float4*)((char*)ws + P.counts_bytes);
+    float4* ovf = (float4*)((char*)ws + P.counts_bytes + P.bins_bytes);
+    hipFuncSetAttribute((const void*)k_scatter_accum3<13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES);
+    hipEvent_t a, b, c; hipEventCreate(&a); hipEventCreate(&b); hipEventCreate(&c);
+    for (int rep = 0; rep < 4; ++rep) {
+        hipEventRecord(a);
+        hipLaunchKernelGGL(k_scatter_bin3<4096>, dim3(P.bin.n_lv * P.bin.nsb), dim3(S3_BIN_THREADS), 0, 0, P.bin, dx, 3u, dd, n, 1u << 18, ndev,
+                           (const uint32_t*)nullptr, counts, bins, ovf);
+        hipEventRecord(b);
+        hipLaunchKernelGGL(k_scatter_accum3<13>, dim3(P.bin.acc_blocks), dim3(1024), S3_LDS_BYTES, 0, P.bin, (const uint32_t*)counts,
+                           (const float4*)bins, (const float4*)ovf, tab);
+        hipEventRecord(c); hipEventSynchronize(c);
+        float m1, m2; hipEventElapsedTime(&m1, a, b); hipEventElapsedTime(&m2, b, c);
+        long long t[S3_T_BLOCKS][8]; hipMemcpyFromSymbol(t, HIP_SYMBOL(g_s3_t), sizeof(t));
+        printf("bin3 %.1f us  accum3 %.1f us\n", m1 * 1e3, m2 * 1e3);
+        if (rep < 3) continue;
+        long long t0 = t[0][0];
+        for (int w = 0; w < S3_T_BLOCKS; ++w) {
+            auto us = [&](int i, int j) { return (t[w][j] - t[w][i]) / 100.0; };
+            printf("  wg %3d: start +%6.2f | fills %.2f  first fetch issued %.2f  zero+sync %.2f  loop %.2f  overflow check %.2f+sync  write %.2f | whole %.2f us\n",
+                   w * 96, (t[w][0] - t0) / 100.0, us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(5, 6), us(0, 6));
+        }
+    }
+    return 0;
+}

@@ -22,7 +22,9 @@ SOURCES = {
     # the hash-grid cell index is floor(x*scale+0.5): an index decision at scale up to 2047
     'xr_encode.hip': ['-ffp-contract=off'],
     # same index decisions and the same weight products as the gather
-    'xr_scatter.hip': ['-ffp-contract=off'],
+    # (-simplifycfg-sink-common=false: LLVM otherwise merges the `rank slot k` stores of different unrolled items into one
+    # block with a dynamic slot index, which turns the per-thread rank registers of k_scatter_bin3 into scratch memory)
+    'xr_scatter.hip': ['-ffp-contract=off', '-mllvm', '-simplifycfg-sink-common=false'],
     'xr_mlp.hip': [],
     'xr_misc.hip': ['-ffp-contract=off'],
     # Mip-NeRF stages: fp32 in the reference's operation order (lower + (upper-lower)*rand etc.)

@@ -12,9 +12,10 @@
 //     zero-fill wrote a few kernels earlier.
 // Here:
 //   kind H  hashed levels (power-of-two slices >= 2^13 entries): bin by bits [13, ..) of y*P1 ^ z*P2 as before;
-//   kind D  dense levels above 2^16 entries: the same bin / accumulate pair, partition = (16-entry block) mod P with P = 32
-//           or 64 -- neighbouring cells land in different partitions, so the load is as even as a hash's; an x-neighbour pair
-//           that straddles two blocks (x & 15 == 15 ... 1 in 16) becomes two single-entry items;
+//   kind D  dense levels above 2^16 entries: the same bin / accumulate pair, partition = (grid row y + z res) mod P with P = 32
+//           or 64 -- neighbouring rows land in different partitions, so the load is as even as a hash's, and the two
+//           x-neighbours of a pair always share a row (pairs that leave the res^3 lattice at the domain's upper faces, where
+//           tcnn's linear index runs into the next row or wraps, become two single-entry items);
 //   kind R  dense levels up to 2^16 entries (levels 0-2 of the Lego geometry: 4 096 + 12 168 + 29 792 entries, where a
 //           ray's 20 samples fall into two or three cells): one THREAD walks 16 consecutive rows with the 16 corner sums of
 //           the current cell in registers and flushes them into a workgroup-private fp64 LDS copy of its 2^13-entry
@@ -29,6 +30,15 @@
 #include "xr_hashgrid.h"
 #include "xr_scatter.h"
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
+
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{}) -- indices that name
+// registers of a per-thread array must be constants for the array to stay out of scratch memory
+template <typename F, int... I>
+__device__ __forceinline__ void s3_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void s3_static_for(F&& f) { s3_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 #define S3_LOG2 13
 #define S3_ENTRIES (1u << S3_LOG2)
@@ -44,6 +54,20 @@
 #define S3_R_THREADS 1024
 
 enum { S3_H = 0, S3_D = 1 };
+#ifndef S3_PERMUTE
+#define S3_PERMUTE 1
+#endif
+#ifndef S3_MERGE
+#define S3_MERGE S3_PERMUTE
+#endif
+
+#ifdef S3_TIMING          // tools/scatter3_timing.hip: wall_clock64 (100 MHz) stamps of a few accumulate workgroups
+#define S3_T_BLOCKS 8
+__device__ long long g_s3_t[S3_T_BLOCKS][8];
+#define S3_T(k) do { if (threadIdx.x == 0 && (blockIdx.x % 96u) == 0u && blockIdx.x / 96u < S3_T_BLOCKS) g_s3_t[blockIdx.x / 96u][k] = wall_clock64(); } while (0)
+#else
+#define S3_T(k)
+#endif
 
 struct S3Level {
     float scale;
@@ -62,6 +86,7 @@ struct S3Plan {
     uint32_t n_lv, nsb, ovf_cap, overwrite;
     uint32_t ovfcnt_off;             // words into counts: [lv][nsb]
     uint32_t acc_blocks;
+    uint32_t lg;                     // log2 of the entries of one partition (13, or 12: two accumulate workgroups per CU)
 };
 struct S3RLevel {
     float scale;
@@ -79,6 +104,20 @@ __device__ __forceinline__ uint32_t s3_wrap(uint32_t i, uint32_t hsize) {
     if (i >= hsize) { i -= hsize; if (i >= hsize) i %= hsize; }
     return i;
 }
+// kind D: entry idx of a dense level -> (partition, local entry).  Row r = idx / res of the res^3 lattice belongs to partition
+// r mod P and sits at local row r / P; the (at most 7) padding entries behind the lattice close partition 0.
+__device__ __forceinline__ uint32_t s3_dense_rows(uint32_t res, uint32_t plog2, uint32_t part) {
+    return (res * res + (1u << plog2) - 1u - part) >> plog2;                // rows r < res^2 with r mod P == part
+}
+__device__ __forceinline__ void s3_dense_local(uint32_t idx, uint32_t res, uint32_t plog2, uint32_t pmask, uint32_t* part, uint32_t* e) {
+    const uint32_t cells = res * res * res;
+    if (idx < cells) {
+        const uint32_t r = idx / res, xx = idx - r * res;
+        *part = r & pmask; *e = (r >> plog2) * res + xx;
+    } else {
+        *part = 0u; *e = s3_dense_rows(res, plog2, 0u) * res + (idx - cells);
+    }
+}
 #ifdef __HIP_EMU__
 __device__ inline uint32_t s3_readlane(uint32_t v, uint32_t lane) { return __shfl(v, (int)lane); }
 #else
@@ -90,13 +129,13 @@ __device__ inline uint32_t s3_readlane(uint32_t v, uint32_t lane) { return (uint
 // placed in LDS in partition order, copied out as contiguous runs (full-line stores).  The inputs of round r + 1 are
 // fetched before round r is ranked and copied out.
 template <int KIND> struct S3Bin {
-    static constexpr int SPT = KIND == S3_H ? 2 : 1;            // samples per thread and round
-    static constexpr int IPS = KIND == S3_H ? 4 : 8;            // items per sample, worst case
+    static constexpr int SPT = 2;                               // samples per thread and round
+    static constexpr int IPS = KIND == S3_H ? 4 : 8;            // items per sample, worst case (kind D: every pair split)
     static constexpr int ROUND = S3_BIN_THREADS * SPT;
 };
 
 template <int KIND, int BS>
-__device__ __forceinline__ void s3_bin_block(const S3Level& L, uint32_t nsb, uint32_t ovf_cap, uint32_t sb, const float* __restrict__ x,
+__device__ __forceinline__ void s3_bin_block(const S3Level& L, uint32_t lg, uint32_t nsb, uint32_t ovf_cap, uint32_t sb, const float* __restrict__ x,
                                              uint32_t x_stride, const float* __restrict__ denc_t, uint32_t ld, uint32_t n,
                                              const uint32_t* __restrict__ rows, uint32_t* __restrict__ cnt_out,
                                              uint32_t* __restrict__ ovfcnt_out, float4* __restrict__ bins, float4* __restrict__ ovf,
@@ -104,80 +143,81 @@ __device__ __forceinline__ void s3_bin_block(const S3Level& L, uint32_t nsb, uin
                                              uint32_t* s_ovf) {
     using B = S3Bin<KIND>;
     constexpr int SPT = B::SPT, IPS = B::IPS, NI = SPT * IPS, ROUND = B::ROUND, ROUNDS = BS / ROUND;
-    static_assert(ROUND * IPS <= S3_ROUND_ITEMS, "a round's items must fit the LDS staging area");
+    static_assert(ROUND * 4 <= S3_ROUND_ITEMS, "a round's expected items must fit the LDS staging area");
     const uint32_t parts = L.parts, cap = L.cap, b0 = sb * BS;
     for (uint32_t p = threadIdx.x; p < parts; p += S3_BIN_THREADS) s_base[p] = 0;
     if (threadIdx.x == 0) *s_ovf = 0;
     const float scale = L.scale;
-    const uint32_t res = L.res, hsize = L.hsize, hmask = hsize - 1u, plog2 = L.plog2, pmask = parts - 1u;
+    const uint32_t res = L.res, hsize = L.hsize, hmask = hsize - 1u, plog2 = L.plog2, pmask = parts - 1u, emask = (1u << lg) - 1u;
     const float* __restrict__ d0p = denc_t + (size_t)L.drow * ld;
     const float* __restrict__ d1p = d0p + ld;
     float4* __restrict__ out = bins + L.bins_off + (size_t)sb * cap;         // [part][sb][cap]
     float4* __restrict__ ovo = ovf + L.ovf_off + (size_t)sb * ovf_cap;
     const uint32_t per = (parts + 63u) / 64u;                                // partitions per lane in the offset scan (<= 4)
-    float ld0[SPT], ld1[SPT], lx0[SPT], lx1[SPT], lx2[SPT];
+    // inputs of the current round and, in flight, of the next one
+    float ld0[SPT], ld1[SPT], lx0[SPT], lx1[SPT], lx2[SPT], nd0[SPT], nd1[SPT], nx0[SPT], nx1[SPT], nx2[SPT];
     auto fetch = [&](uint32_t rb0) {
 #pragma unroll
         for (int s = 0; s < SPT; ++s) {
             uint32_t i = min(rb0 + s * S3_BIN_THREADS + threadIdx.x, n - 1);
             if (rows) i = rows[i];
             const float* xp = x + (size_t)i * x_stride;
-            ld0[s] = d0p[i]; ld1[s] = d1p[i]; lx0[s] = xp[0]; lx1[s] = xp[1]; lx2[s] = xp[2];
+            nd0[s] = d0p[i]; nd1[s] = d1p[i]; nx0[s] = xp[0]; nx1[s] = xp[1]; nx2[s] = xp[2];
         }
     };
     fetch(b0);
     for (uint32_t r = 0; r < (uint32_t)ROUNDS; ++r) {
         const uint32_t rb0 = b0 + r * ROUND;
         if (rb0 >= n) break;                                                // uniform
+#pragma unroll
+        for (int s = 0; s < SPT; ++s) { ld0[s] = nd0[s]; ld1[s] = nd1[s]; lx0[s] = nx0[s]; lx1[s] = nx1[s]; lx2[s] = nx2[s]; }
         for (uint32_t p = threadIdx.x; p < parts; p += S3_BIN_THREADS) s_cnt[p] = 0;
         __syncthreads();
-        uint32_t ipart[NI], irank[NI], ipr[NI];
-        float iva[NI], ivb[NI], iw[NI];
-        bool ion[NI];
-#pragma unroll
-        for (int k = 0; k < NI; ++k) ion[k] = false;
-#pragma unroll
-        for (int s = 0; s < SPT; ++s) {
-            const uint32_t i = rb0 + s * S3_BIN_THREADS + threadIdx.x;
-            const float d0 = ld0[s], d1 = ld1[s];
-            if (!(i < n) || (d0 == 0.f && d1 == 0.f)) continue;             // rows with a zero gradient add nothing
-            const float p0 = lx0[s] * scale + 0.5f, p1 = lx1[s] * scale + 0.5f, p2 = lx2[s] * scale + 0.5f;
-            const float f0 = floorf(p0), f1 = floorf(p1), f2 = floorf(p2);
-            const uint32_t g0 = (uint32_t)(int)f0, g1 = (uint32_t)(int)f1, g2 = (uint32_t)(int)f2;
-            const float w0 = p0 - f0, w1 = p1 - f1, w2 = p2 - f2;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const uint32_t cy = c & 1u, cz = c >> 1;
-                const float wyz = (cy ? w1 : 1.f - w1) * (cz ? w2 : 1.f - w2);
-                const float va = wyz * d0, vb = wyz * d1;
-                if (KIND == S3_H) {
-                    const int k = s * IPS + c;
-                    const uint32_t h = ((g1 + cy) * 2654435761u) ^ ((g2 + cz) * 805459861u);
-                    const uint32_t i0 = (g0 ^ h) & hmask, i1 = ((g0 + 1u) ^ h) & hmask;
-                    ipart[k] = i0 >> S3_LOG2;                               // == i1 >> S3_LOG2: x < 2^13 never reaches these bits
-                    ipr[k] = (i0 & (S3_ENTRIES - 1)) | ((i1 & (S3_ENTRIES - 1)) << S3_LOG2);
-                    iva[k] = va; ivb[k] = vb; iw[k] = w0; ion[k] = true;
-                } else {
-                    const int k = s * IPS + 2 * c;
-                    const uint32_t base = g0 + (g1 + cy) * res + (g2 + cz) * res * res;
-                    const uint32_t i0 = s3_wrap(base, hsize), i1 = s3_wrap(base + 1u, hsize);
-                    const uint32_t q0 = i0 >> 4, q1 = i1 >> 4;
-                    const uint32_t e0 = ((q0 >> plog2) << 4) | (i0 & 15u), e1 = ((q1 >> plog2) << 4) | (i1 & 15u);
-                    if (q0 == q1) {
-                        ipart[k] = q0 & pmask; ipr[k] = e0 | (e1 << S3_LOG2);
-                        iva[k] = va; ivb[k] = vb; iw[k] = w0; ion[k] = true;
-                    } else {                                                // the pair straddles two blocks: two single-entry items
-                        ipart[k] = q0 & pmask; ipr[k] = e0 | (e0 << S3_LOG2);
-                        iva[k] = (1.f - w0) * va; ivb[k] = (1.f - w0) * vb; iw[k] = 0.f; ion[k] = true;
-                        ipart[k + 1] = q1 & pmask; ipr[k + 1] = e1 | (e1 << S3_LOG2);
-                        iva[k + 1] = w0 * va; ivb[k + 1] = w0 * vb; iw[k + 1] = 0.f; ion[k + 1] = true;
+        // The thread's items are GENERATED twice -- once to rank them per partition, once to place them -- instead of being
+        // kept in registers in between: 16 item slots (kind D, every pair split) x 6 values cost 181 VGPRs, i.e. one workgroup
+        // per CU instead of two.  f(k, partition, packed local entries, va, vb, w): slot k is a compile-time constant.
+        auto items = [&](auto&& f) __attribute__((always_inline)) {
+            s3_static_for<SPT>([&](auto S_) __attribute__((always_inline)) {
+                constexpr int s = decltype(S_)::value;
+                const uint32_t i = rb0 + s * S3_BIN_THREADS + threadIdx.x;
+                const float d0 = ld0[s], d1 = ld1[s];
+                if (!(i < n) || (d0 == 0.f && d1 == 0.f)) return;           // rows with a zero gradient add nothing
+                const float p0 = lx0[s] * scale + 0.5f, p1 = lx1[s] * scale + 0.5f, p2 = lx2[s] * scale + 0.5f;
+                const float f0 = floorf(p0), f1 = floorf(p1), f2 = floorf(p2);
+                const uint32_t g0 = (uint32_t)(int)f0, g1 = (uint32_t)(int)f1, g2 = (uint32_t)(int)f2;
+                const float w0 = p0 - f0, w1 = p1 - f1, w2 = p2 - f2;
+                s3_static_for<4>([&](auto C_) __attribute__((always_inline)) {
+                    constexpr int c = decltype(C_)::value;
+                    constexpr uint32_t cy = c & 1u, cz = c >> 1;
+                    const float wyz = (cy ? w1 : 1.f - w1) * (cz ? w2 : 1.f - w2);
+                    const float va = wyz * d0, vb = wyz * d1;
+                    if constexpr (KIND == S3_H) {
+                        const uint32_t h = ((g1 + cy) * 2654435761u) ^ ((g2 + cz) * 805459861u);
+                        const uint32_t i0 = (g0 ^ h) & hmask, i1 = ((g0 + 1u) ^ h) & hmask;
+                        // partition = i0 >> lg == i1 >> lg: x < 2^lg never reaches these bits
+                        f(std::integral_constant<int, s * IPS + c>{}, i0 >> lg, (i0 & emask) | ((i1 & emask) << S3_LOG2), va, vb, w0);
+                    } else {
+                        constexpr int k = s * IPS + 2 * c;
+                        const uint32_t rr = (g1 + cy) + (g2 + cz) * res;    // grid row of the pair
+                        // slot k: the pair (or its first half), slot k + 1: the second half of a split pair -- each slot is
+                        // filled at ONE place in the code (a slot index merged over two branches would become a dynamic
+                        // register-array index, i.e. scratch memory)
+                        const bool whole = g0 + 1u < res && rr < res * res;   // both x-neighbours in row rr of the res^3 lattice
+                        uint32_t pa = rr & pmask, ea = (rr >> plog2) * res + g0, eb = ea + 1u, pb = 0u;
+                        if (!whole) {                                       // upper faces of the domain / positions outside it
+                            const uint32_t base = g0 + rr * res;            // == g0 + y res + z res^2 (mod 2^32), tcnn's linear index
+                            s3_dense_local(s3_wrap(base, hsize), res, plog2, pmask, &pa, &ea);
+                            s3_dense_local(s3_wrap(base + 1u, hsize), res, plog2, pmask, &pb, &eb);
+                        }
+                        f(std::integral_constant<int, k>{}, pa, ea | ((whole ? eb : ea) << S3_LOG2), whole ? va : (1.f - w0) * va,
+                          whole ? vb : (1.f - w0) * vb, whole ? w0 : 0.f);
+                        if (!whole) f(std::integral_constant<int, k + 1>{}, pb, eb | (eb << S3_LOG2), w0 * va, w0 * vb, 0.f);
                     }
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < NI; ++k)
-            if (ion[k]) irank[k] = atomicAdd(&s_cnt[ipart[k]], 1u);
+                });
+            });
+        };
+        uint32_t irank[NI];
+        items([&](auto K_, uint32_t part, uint32_t, float, float, float) __attribute__((always_inline)) { irank[decltype(K_)::value] = atomicAdd(&s_cnt[part], 1u); });
         if (r + 1 < (uint32_t)ROUNDS && rb0 + ROUND < n) fetch(rb0 + ROUND);   // next round's inputs under this round's ranking
         __syncthreads();
         if (threadIdx.x < 64) {                                             // exclusive scan of the round's partition counts
@@ -203,15 +243,20 @@ __device__ __forceinline__ void s3_bin_block(const S3Level& L, uint32_t nsb, uin
             if (threadIdx.x == 63) s_off[parts] = incl;
         }
         __syncthreads();
-#pragma unroll
-        for (int k = 0; k < NI; ++k) {
-            if (!ion[k]) continue;
-            const uint32_t q = s_off[ipart[k]] + irank[k];
-            s_items[q] = make_float4(__uint_as_float(ipr[k]), iva[k], ivb[k], iw[k]);
-            s_ipart[q] = (uint8_t)ipart[k];
-        }
+        items([&](auto K_, uint32_t part, uint32_t pr, float va, float vb, float w) __attribute__((always_inline)) {
+            const uint32_t q = s_off[part] + irank[decltype(K_)::value];
+            if (KIND == S3_H || q < S3_ROUND_ITEMS) {
+                s_items[q] = make_float4(__uint_as_float(pr), va, vb, w);
+                s_ipart[q] = (uint8_t)part;
+            } else {          // kind D, more than 4 items per sample on average (samples piled on the domain's upper faces): overflow records
+                const uint32_t e0 = pr & (S3_ENTRIES - 1), e1 = pr >> S3_LOG2;
+                const uint32_t o = atomicAdd(s_ovf, e0 == e1 ? 1u : 2u);
+                ovo[o] = make_float4(__uint_as_float(e0 | (part << S3_LOG2)), (1.f - w) * va, (1.f - w) * vb, 0.f);
+                if (e0 != e1) ovo[o + 1] = make_float4(__uint_as_float(e1 | (part << S3_LOG2)), w * va, w * vb, 0.f);
+            }
+        });
         __syncthreads();
-        const uint32_t total = s_off[parts];
+        const uint32_t total = KIND == S3_H ? s_off[parts] : min(s_off[parts], (uint32_t)S3_ROUND_ITEMS);
         for (uint32_t q = threadIdx.x; q < total; q += S3_BIN_THREADS) {
             const uint32_t p = s_ipart[q], rk = q - s_off[p] + s_base[p];
             const float4 it = s_items[q];
@@ -230,7 +275,9 @@ __device__ __forceinline__ void s3_bin_block(const S3Level& L, uint32_t nsb, uin
             }
         }
         __syncthreads();
-        for (uint32_t p = threadIdx.x; p < parts; p += S3_BIN_THREADS) s_base[p] += s_cnt[p];
+        // (kind D: items of a partition that went straight to the overflow list do not take sub-bin slots)
+        for (uint32_t p = threadIdx.x; p < parts; p += S3_BIN_THREADS)
+            s_base[p] += KIND == S3_H ? s_cnt[p] : min(s_off[p] + s_cnt[p], (uint32_t)S3_ROUND_ITEMS) - min(s_off[p], (uint32_t)S3_ROUND_ITEMS);
     }
     __syncthreads();
     for (uint32_t p = threadIdx.x; p < parts; p += S3_BIN_THREADS) cnt_out[(size_t)p * nsb] = min(s_base[p], cap);
@@ -257,46 +304,48 @@ __global__ __launch_bounds__(S3_BIN_THREADS) void k_scatter_bin3(S3Plan pl, cons
         return;
     }
     if (L.kind == S3_H)
-        s3_bin_block<S3_H, BS>(L, pl.nsb, pl.ovf_cap, sb, x, x_stride, denc_t, ld, n, rows, cnt_out, ovfcnt_out, bins, ovf, s_items, s_ipart,
+        s3_bin_block<S3_H, BS>(L, pl.lg, pl.nsb, pl.ovf_cap, sb, x, x_stride, denc_t, ld, n, rows, cnt_out, ovfcnt_out, bins, ovf, s_items, s_ipart,
                                s_cnt, s_off, s_base, &s_ovf);
     else
-        s3_bin_block<S3_D, BS>(L, pl.nsb, pl.ovf_cap, sb, x, x_stride, denc_t, ld, n, rows, cnt_out, ovfcnt_out, bins, ovf, s_items, s_ipart,
+        s3_bin_block<S3_D, BS>(L, pl.lg, pl.nsb, pl.ovf_cap, sb, x, x_stride, denc_t, ld, n, rows, cnt_out, ovfcnt_out, bins, ovf, s_items, s_ipart,
                                s_cnt, s_off, s_base, &s_ovf);
 }
 
 // ------------------------------------------------------------------------------------------------ accumulate
 // One workgroup = (level, partition): fp64 LDS accumulators (returnless ds_add_f64: 8.6 ns per wave instruction, against 81 ns
 // for ds_add_f32 -- tools/lds_probe.hip), rounded to fp32 once when the partition is written to the table.
-__global__ __launch_bounds__(S3_ACC_THREADS) void k_scatter_accum3(S3Plan pl, const uint32_t* __restrict__ counts,
-                                                                   const float4* __restrict__ bins, const float4* __restrict__ ovf,
-                                                                   float* __restrict__ grad_table) {
-    extern __shared__ __attribute__((aligned(16))) double s_acc[];       // [S3_ENTRIES][2]
+template <int LG>
+__global__ __launch_bounds__(1 << (LG - 3)) void k_scatter_accum3(S3Plan pl, const uint32_t* __restrict__ counts,
+                                                                  const float4* __restrict__ bins, const float4* __restrict__ ovf,
+                                                                  float* __restrict__ grad_table) {
+    constexpr uint32_t ENTRIES = 1u << LG, THREADS = 1u << (LG - 3), WAVES = THREADS / 64;
+    extern __shared__ __attribute__((aligned(16))) double s_acc[];       // [ENTRIES][2]
     uint32_t e = 0;
     while (e + 1 < pl.n_lv && blockIdx.x >= pl.lv[e + 1].acc_block0) ++e;   // levels in accumulate order (heaviest first)
     const S3Level& L = pl.lv[e];
     const uint32_t part = blockIdx.x - L.acc_block0, nsb = pl.nsb, cap = L.cap;
     double2* acc2 = reinterpret_cast<double2*>(s_acc);
+    S3_T(0);
     // entries this partition owns
     uint32_t n_loc;
-    if (L.kind == S3_H) n_loc = S3_ENTRIES;
-    else { const uint32_t nblk = (L.hsize + 15u) >> 4; n_loc = ((nblk + L.parts - 1u - part) >> L.plog2) << 4; }
-    for (uint32_t q = threadIdx.x; q < n_loc; q += S3_ACC_THREADS) acc2[q] = make_double2(0.0, 0.0);
+    if (L.kind == S3_H) n_loc = ENTRIES;
+    else n_loc = s3_dense_rows(L.res, L.plog2, part) * L.res + (part == 0u ? L.hsize - L.res * L.res * L.res : 0u);
     // this wave's sub-bins w, w + 16, ...: their fill counts in one VGPR, the overflow counts of the level's sample blocks too
     const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t* __restrict__ cnt = counts + L.counts_off + (size_t)part * nsb;
-    const uint32_t my_sb = wave + S3_ACC_WAVES * lane;
+    const uint32_t my_sb = wave + WAVES * lane;
     const uint32_t vfill = my_sb < nsb ? cnt[my_sb] : 0u;
     const uint32_t vovf = my_sb < nsb ? counts[pl.ovfcnt_off + e * nsb + my_sb] : 0u;
-    __syncthreads();
     const float4* __restrict__ src = bins + L.bins_off + (size_t)part * nsb * cap;
     constexpr uint32_t U = 8;
-    const uint32_t n_mine = nsb > wave ? (nsb - wave + S3_ACC_WAVES - 1u) / S3_ACC_WAVES : 0u;   // sub-bins of this wave
+    const uint32_t n_mine = nsb > wave ? (nsb - wave + WAVES - 1u) / WAVES : 0u;   // sub-bins of this wave
     uint32_t si = 0, c = 0;                                                 // next (sub-bin slot, 64-item chunk): wave-uniform
     uint32_t fill = n_mine ? s3_readlane(vfill, 0) : 0u;
     auto skip_empty = [&]() {
         while (si < n_mine && fill == 0u) { ++si; fill = si < n_mine ? s3_readlane(vfill, si) : 0u; }
     };
     skip_empty();
+    S3_T(1);
     float4 nx[U];
     bool non[U];
     auto fetch = [&]() {
@@ -304,9 +353,13 @@ __global__ __launch_bounds__(S3_ACC_THREADS) void k_scatter_accum3(S3Plan pl, co
         for (uint32_t u = 0; u < U; ++u) {
             non[u] = false;
             if (si < n_mine) {
-                const uint32_t off = c * 64u + lane;
+                // lane l of chunk c takes item l * nch + c of the sub-bin (nch = its number of chunks), not c * 64 + l: consecutive
+                // items come from consecutive samples of a ray, which at the coarse levels sit in the same cell -- side by side
+                // in one wave instruction their LDS atomics hit the same addresses and serialise (measured with
+                // tools/scatter3_timing.hip: 18 us of atomics per workgroup at levels 5-6 against 7 us at level 15)
+                const uint32_t nch = (fill + 63u) >> 6, off = S3_PERMUTE ? lane * nch + c : c * 64u + lane;
                 non[u] = off < fill;
-                if (non[u]) nx[u] = src[(size_t)(wave + S3_ACC_WAVES * si) * cap + off];
+                if (non[u]) nx[u] = src[(size_t)(wave + WAVES * si) * cap + off];
                 ++c;
                 if (c * 64u >= fill) {
                     c = 0; ++si;
@@ -317,6 +370,13 @@ __global__ __launch_bounds__(S3_ACC_THREADS) void k_scatter_accum3(S3Plan pl, co
         }
     };
     fetch();
+    S3_T(2);
+    // the accumulators are cleared while the first items are in flight
+    for (uint32_t q = threadIdx.x; q < n_loc; q += THREADS) acc2[q] = make_double2(0.0, 0.0);
+    __syncthreads();
+    S3_T(3);
+    uint32_t run_pr = 0xffffffffu;                                          // entry pair of the lane's current run (no item packs to all ones)
+    double r00 = 0.0, r01 = 0.0, r10 = 0.0, r11 = 0.0;
     for (;;) {
         float4 it[U];
         bool on[U];
@@ -327,20 +387,43 @@ __global__ __launch_bounds__(S3_ACC_THREADS) void k_scatter_accum3(S3Plan pl, co
 #pragma unroll
         for (uint32_t u = 0; u < U; ++u) {
             if (!on[u]) continue;
-            const uint32_t pr = __float_as_uint(it[u].x), i0 = pr & (S3_ENTRIES - 1), i1 = pr >> S3_LOG2;
+            const uint32_t pr = __float_as_uint(it[u].x);
             const float w0 = it[u].w, a = it[u].y, b = it[u].z;
-            atomicAdd(&s_acc[2 * i0], (double)((1.f - w0) * a));
-            atomicAdd(&s_acc[2 * i0 + 1], (double)((1.f - w0) * b));
-            atomicAdd(&s_acc[2 * i1], (double)(w0 * a));
-            atomicAdd(&s_acc[2 * i1 + 1], (double)(w0 * b));
+            if (S3_MERGE) {
+                // a lane's successive items are successive items of its sub-bins (the permuted mapping): while they name the same
+                // entry pair -- samples of one ray inside one cell -- their four products are summed in registers (in fp64, like
+                // the LDS accumulators) and go to the LDS once per run
+                if (pr != run_pr) {
+                    if (run_pr != 0xffffffffu) {
+                        const uint32_t i0 = run_pr & (S3_ENTRIES - 1), i1 = run_pr >> S3_LOG2;
+                        atomicAdd(&s_acc[2 * i0], r00); atomicAdd(&s_acc[2 * i0 + 1], r01);
+                        atomicAdd(&s_acc[2 * i1], r10); atomicAdd(&s_acc[2 * i1 + 1], r11);
+                    }
+                    run_pr = pr; r00 = r01 = r10 = r11 = 0.0;
+                }
+                r00 += (double)((1.f - w0) * a); r01 += (double)((1.f - w0) * b);
+                r10 += (double)(w0 * a); r11 += (double)(w0 * b);
+            } else {
+                const uint32_t i0 = pr & (S3_ENTRIES - 1), i1 = pr >> S3_LOG2;
+                atomicAdd(&s_acc[2 * i0], (double)((1.f - w0) * a));
+                atomicAdd(&s_acc[2 * i0 + 1], (double)((1.f - w0) * b));
+                atomicAdd(&s_acc[2 * i1], (double)(w0 * a));
+                atomicAdd(&s_acc[2 * i1 + 1], (double)(w0 * b));
+            }
         }
         if (!more) break;
     }
+    if (S3_MERGE && run_pr != 0xffffffffu) {
+        const uint32_t i0 = run_pr & (S3_ENTRIES - 1), i1 = run_pr >> S3_LOG2;
+        atomicAdd(&s_acc[2 * i0], r00); atomicAdd(&s_acc[2 * i0 + 1], r01);
+        atomicAdd(&s_acc[2 * i1], r10); atomicAdd(&s_acc[2 * i1 + 1], r11);
+    }
+    S3_T(4);
     // overflow records of the level's sample blocks (none unless the samples cluster): every partition scans them all
     if (__ballot(vovf != 0u) != 0ull) {
         for (uint32_t k = 0; k < n_mine; ++k) {
             const uint32_t cntk = s3_readlane(vovf, k);
-            const float4* __restrict__ ov = ovf + L.ovf_off + (size_t)(wave + S3_ACC_WAVES * k) * pl.ovf_cap;
+            const float4* __restrict__ ov = ovf + L.ovf_off + (size_t)(wave + WAVES * k) * pl.ovf_cap;
             for (uint32_t q = lane; q < cntk; q += 64u) {
                 const float4 rcd = ov[q];
                 const uint32_t key = __float_as_uint(rcd.x);
@@ -351,30 +434,34 @@ __global__ __launch_bounds__(S3_ACC_THREADS) void k_scatter_accum3(S3Plan pl, co
         }
     }
     __syncthreads();
+    S3_T(5);
     float2* __restrict__ tab = reinterpret_cast<float2*>(grad_table) + L.toff;
     const bool add = pl.overwrite == 0u;
     if (L.kind == S3_H) {
-        float2* __restrict__ dst = tab + (size_t)part * S3_ENTRIES;
-        constexpr uint32_t F = S3_ENTRIES / S3_ACC_THREADS;
+        float2* __restrict__ dst = tab + (size_t)part * ENTRIES;
+        constexpr uint32_t F = ENTRIES / THREADS;
         float2 t[F];
 #pragma unroll
-        for (uint32_t k = 0; k < F; ++k) t[k] = add ? dst[k * S3_ACC_THREADS + threadIdx.x] : make_float2(0.f, 0.f);
+        for (uint32_t k = 0; k < F; ++k) t[k] = add ? dst[k * THREADS + threadIdx.x] : make_float2(0.f, 0.f);
 #pragma unroll
         for (uint32_t k = 0; k < F; ++k) {
-            const double2 a = acc2[k * S3_ACC_THREADS + threadIdx.x];
+            const double2 a = acc2[k * THREADS + threadIdx.x];
             t[k].x += (float)a.x; t[k].y += (float)a.y;
-            dst[k * S3_ACC_THREADS + threadIdx.x] = t[k];
+            dst[k * THREADS + threadIdx.x] = t[k];
         }
     } else {
-        for (uint32_t q = threadIdx.x; q < n_loc; q += S3_ACC_THREADS) {
-            const uint32_t idx = ((((q >> 4) << L.plog2) | part) << 4) | (q & 15u);
-            if (idx >= L.hsize) continue;
+        const uint32_t res = L.res, lat = s3_dense_rows(res, L.plog2, part) * res;       // lattice entries of this partition
+        for (uint32_t q = threadIdx.x; q < n_loc; q += THREADS) {
+            uint32_t idx;
+            if (q < lat) { const uint32_t rl = q / res; idx = ((rl << L.plog2) | part) * res + (q - rl * res); }
+            else idx = res * res * res + (q - lat);                          // padding entries behind the lattice (partition 0)
             const double2 a = acc2[q];
             float2 t = add ? tab[idx] : make_float2(0.f, 0.f);
             t.x += (float)a.x; t.y += (float)a.y;
             tab[idx] = t;
         }
     }
+    S3_T(6);
 }
 
 // ------------------------------------------------------------------------------------------------ small dense levels
@@ -506,7 +593,10 @@ static bool s3_layout(uint32_t n, const GridMeta& gm, uint32_t hashed_mask, int 
     // what the atomic kernel needs; the tests lower it to run this path at sizes the host emulation finishes quickly
     static const uint32_t min_n = (uint32_t)s3_env("XR_SC_MIN_N", 16384);
     if (n < min_n || nsb > S3_MAX_SB) { P.atomic_mask = (1u << gm.n_levels) - 1u; return false; }
-    P.bin.nsb = nsb; P.bin.overwrite = (uint32_t)overwrite; P.bin.ovf_cap = 8u * bs;
+    // XR_SC_LOG2=12: 2^12-entry partitions accumulated by 512-thread workgroups in 64 KiB of LDS, two per CU (measurement)
+    static const uint32_t lg = s3_env("XR_SC_LOG2", 13) == 12 ? 12u : 13u;
+    const uint32_t entries = 1u << lg;
+    P.bin.nsb = nsb; P.bin.overwrite = (uint32_t)overwrite; P.bin.ovf_cap = 8u * bs; P.bin.lg = lg;
     P.rl.chunks = s3_chunks(); P.rl.overwrite = (uint32_t)overwrite;
     static const int use_rl = s3_env("XR_SC_RL", 1);      // 0: small dense levels through the binned path too (measurement)
     static const int dense_atomic = s3_env("XR_SC_DENSE_ATOMIC", 0);   // 1: every dense level through the atomic kernel (measurement)
@@ -517,10 +607,10 @@ static bool s3_layout(uint32_t n, const GridMeta& gm, uint32_t hashed_mask, int 
         for (int l = gm.n_levels - 1; l >= 0; --l) {
             const uint32_t hsize = gm.off[l + 1] - gm.off[l], res = gm.res[l];
             const bool hashed = (hashed_mask >> l) & 1;
-            const bool kindH = hashed && (hsize & (hsize - 1)) == 0 && hsize >= S3_ENTRIES && (hsize >> S3_LOG2) <= S3_MAX_PARTS &&
-                               res < S3_ENTRIES && (gm.off[l] & 1) == 0;
+            const bool kindH = hashed && (hsize & (hsize - 1)) == 0 && hsize >= entries && (hsize >> lg) <= S3_MAX_PARTS &&
+                               res < entries && (gm.off[l] & 1) == 0;
             const bool kindR = !hashed && hsize <= S3_R_MAX_ENTRIES && use_rl && !dense_atomic;
-            const bool kindD = !hashed && !kindR && hsize >= 1024u && hsize <= 64u * S3_ENTRIES && !dense_atomic;
+            const bool kindD = !hashed && !kindR && res >= 8u && res <= 128u && (uint64_t)res * res * res <= hsize && !dense_atomic;
             if (pass == 0 && !kindH && !kindD && !kindR) P.atomic_mask |= 1u << l;
             if (pass == 0 && kindR) {
                 S3RLevel& R = P.rl.lv[P.rl.n_lv++];
@@ -532,14 +622,14 @@ static bool s3_layout(uint32_t n, const GridMeta& gm, uint32_t hashed_mask, int 
             S3Level& L = P.bin.lv[P.bin.n_lv++];
             L.scale = gm.scale[l]; L.res = res; L.hsize = hsize; L.toff = gm.off[l]; L.drow = 2u * (uint32_t)l;
             L.kind = kindH ? S3_H : S3_D;
-            if (kindH) { L.parts = hsize >> S3_LOG2; L.plog2 = 0; }
+            if (kindH) { L.parts = hsize >> lg; L.plog2 = 0; }
             else {
-                // a partition holds ceil(blocks / P) 16-entry blocks <= 2^13 entries
-                L.parts = hsize <= 32u * (S3_ENTRIES - 16u) ? 32u : 64u;
-                if (hsize < 32u * 64u) L.parts = 8u;
-                L.plog2 = L.parts == 64u ? 6u : L.parts == 32u ? 5u : 3u;
+                // a partition holds ceil(res^2 / P) grid rows of res entries (+ the padding entries behind the lattice) <= 2^13
+                L.parts = 32u; L.plog2 = 5u;
+                if (lg == 12) { L.parts = 64u; L.plog2 = 6u; }
+                while (((res * res + L.parts - 1u) / L.parts) * res + 8u > entries && L.parts < S3_MAX_PARTS) { L.parts *= 2u; ++L.plog2; }
             }
-            const uint32_t ips = kindH ? 4u : 5u;                             // items per sample (dense: 1 in 16 pairs splits; generous)
+            const uint32_t ips = 4u;                                          // items per sample
             L.cap = ((3u * ips * bs / 2u + L.parts - 1u) / L.parts + 15u) & ~15u;   // 1.5x the expected fill
             L.counts_off = counts_off; counts_off += L.parts * nsb;
             L.bins_off = bins_off; bins_off += (uint64_t)L.parts * nsb * L.cap;
@@ -583,7 +673,8 @@ int xr_scatter3(const float* x, uint32_t x_stride, const float* denc_t, uint32_t
     float2* slabs = (float2*)((char*)workspace + P.counts_bytes + P.bins_bytes + P.ovf_bytes);
     static bool attr_set = false;
     if (!attr_set) {
-        XR_HIP(hipFuncSetAttribute((const void*)k_scatter_accum3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES));
+        XR_HIP(hipFuncSetAttribute((const void*)k_scatter_accum3<13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES));
+        XR_HIP(hipFuncSetAttribute((const void*)k_scatter_accum3<12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES / 2));
         XR_HIP(hipFuncSetAttribute((const void*)k_scatter_dense_rl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES));
         attr_set = true;
     }
@@ -624,8 +715,12 @@ int xr_scatter3(const float* x, uint32_t x_stride, const float* denc_t, uint32_t
         else if (bs == 2048) hipLaunchKernelGGL(k_scatter_bin3<2048>, grid, block, 0, stream, P.bin, x, x_stride, denc_t, ld, n, n_dev, rows, counts, bins, ovf);
         else hipLaunchKernelGGL(k_scatter_bin3<1024>, grid, block, 0, stream, P.bin, x, x_stride, denc_t, ld, n, n_dev, rows, counts, bins, ovf);
         XR_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_scatter_accum3, dim3(P.bin.acc_blocks), dim3(S3_ACC_THREADS), S3_LDS_BYTES, stream, P.bin, (const uint32_t*)counts,
-                           (const float4*)bins, (const float4*)ovf, grad_table);
+        if (P.bin.lg == 13)
+            hipLaunchKernelGGL(k_scatter_accum3<13>, dim3(P.bin.acc_blocks), dim3(1024), S3_LDS_BYTES, stream, P.bin, (const uint32_t*)counts,
+                               (const float4*)bins, (const float4*)ovf, grad_table);
+        else
+            hipLaunchKernelGGL(k_scatter_accum3<12>, dim3(P.bin.acc_blocks), dim3(512), S3_LDS_BYTES / 2, stream, P.bin, (const uint32_t*)counts,
+                               (const float4*)bins, (const float4*)ovf, grad_table);
         XR_LAUNCH_CHECK();
     }
     if (!rl_first) { const int rc = launch_rl(); if (rc != XR_OK) return rc; }
