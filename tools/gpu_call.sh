@@ -2,7 +2,7 @@
 # One parametrised GPU-box script (replaces the per-call scripts of rounds 1-2):
 #   gpurun --timeout T -- 'bash tools/gpu_call.sh TAG stage [stage ...]'
 # Every stage writes under gpurun_out/ with the TAG prefix; summaries worth keeping are copied to profiles/ by hand.
-# Stages: tests | smoke | bench[:args] | kstats[:args] | pmc[:args] | scatter[:quick] | fwd | mlp | py:<script and args>
+# Stages: tests | smoke | bench[:args] | kstats[:args] | trace[:args] | pmc[:args] | scatter[:quick] | fwd | py:<script and args>
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O
 TAG=$1; shift
@@ -24,6 +24,9 @@ for st in "$@"; do
              done
              python tools/pmc_traffic.py $(ls /tmp/pmc_FETCH_SIZE/*/*counter_collection.csv | head -1) $(ls /tmp/pmc_WRITE_SIZE/*/*counter_collection.csv | head -1) > $O/${TAG}_pmc_traffic.json
              python tools/pmc_traffic.py --print $O/${TAG}_pmc_traffic.json ;;
+    trace)   (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/proft && timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/proft -- \
+               python $R/bench.py ${arg:---steps 40 --warmup 5 --no-cpu-baseline --no-mip --no-kilo --no-unbounded --no-render --no-f16} > /tmp/bt.log 2>&1; tail -c 300 /tmp/bt.log)
+             python tools/trace_window.py $(ls /tmp/proft/*/*kernel_trace.csv | head -1) -3 | tee $O/${TAG}_trace_normal_iteration.txt ;;
     scatter) timeout 900 python tools/microbench_scatter3.py $arg 2>&1 | tee $O/${TAG}_microbench_scatter3.txt ;;
     fwd)     timeout 900 python tools/microbench_fwd3.py $arg 2>&1 | tee $O/${TAG}_microbench_fwd3.txt ;;
     py)      timeout 1200 python $arg 2>&1 | tee -a $O/${TAG}_py.txt ;;

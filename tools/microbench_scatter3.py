@@ -33,11 +33,19 @@ def child():
     nl = torch.tensor([len(live), 0, 0, 0], dtype=torch.int32, device=dev)
 
     def timeit(f, reps=30):
+        # ONE call between two events, the device idle before it (median): what the entry costs inside a training step.  Timing a
+        # train of calls (XR_B2B=1) lets the next call's helper-stream work start under the previous call's tail and reads
+        # ~25 us lower -- the figures of profiles/r03_scatter3_*variants.txt before this note were taken that way.
         for _ in range(5): f()
         torch.cuda.synchronize(); a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(reps): f()
-        b.record(); torch.cuda.synchronize(); return a.elapsed_time(b) / reps * 1e3
+        if os.environ.get('XR_B2B'):
+            a.record()
+            for _ in range(reps): f()
+            b.record(); torch.cuda.synchronize(); return a.elapsed_time(b) / reps * 1e3
+        ts = []
+        for _ in range(reps):
+            a.record(); f(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b) * 1e3)
+        return float(np.median(ts))
     tag = ' '.join('%s=%s' % (k[3:], os.environ[k]) for k in sorted(os.environ) if k.startswith('XR_SC'))
     out = []
     if os.environ.get('XR_ONLY'):          # one configuration only (clean rocprofv3 kernel averages): levels 0-16, live list, overwrite
@@ -65,8 +73,10 @@ if __name__ == '__main__':
         child()
     else:
         quick = len(sys.argv) > 1 and sys.argv[1] == 'quick'
-        runs = [dict(XR_SC_MODE='2'), dict(XR_SC_MODE='2', XR_SC_LOG2='12'), dict(XR_SC_MODE='2', XR_SC_LOG2='12', XR_SC_BLOCK='2048'),
-                dict(XR_SC_MODE='2', XR_SC_BLOCK='2048'), dict(XR_SC_MODE='2', XR_SC_RL_ASYNC='0')]
+        runs = [dict(XR_SC_MODE='2', XR_SC_RL='1', XR_SC_RL_CHUNKS='16', XR_SC_BLOCK='2048'), dict(XR_SC_MODE='2', XR_SC_RL='1', XR_SC_RL_CHUNKS='8', XR_SC_BLOCK='2048'),
+                dict(XR_SC_MODE='2', XR_SC_RL='1', XR_SC_RL_CHUNKS='16', XR_SC_BLOCK='2048', XR_SC_RL_ASYNC='0'),
+                dict(XR_SC_MODE='2', XR_SC_RL='1', XR_SC_RL_CHUNKS='16', XR_SC_BLOCK='2048', XR_SC_LOG2='12'),
+                dict(XR_SC_MODE='2', XR_SC_RL='1', XR_SC_RL_CHUNKS='16', XR_SC_BLOCK='1024')]
         for env in runs:
             e = dict(os.environ, XR_CHILD='1', **env)
             if quick: e['XR_QUICK'] = '1'

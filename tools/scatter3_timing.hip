@@ -58,7 +58,7 @@ int main(int argc, char** argv) {
     hipEvent_t a, b, c; hipEventCreate(&a); hipEventCreate(&b); hipEventCreate(&c);
     for (int rep = 0; rep < 4; ++rep) {
         hipEventRecord(a);
-        hipLaunchKernelGGL(k_scatter_bin3<4096>, dim3(P.bin.n_lv * P.bin.nsb), dim3(S3_BIN_THREADS), 0, 0, P.bin, dx, 3u, dd, n, 1u << 18, ndev,
+        hipLaunchKernelGGL(k_scatter_bin3<2048>, dim3(P.bin.n_lv * P.bin.nsb), dim3(S3_BIN_THREADS), 0, 0, P.bin, dx, 3u, dd, n, 1u << 18, ndev,
                            (const uint32_t*)nullptr, counts, bins, ovf);
         hipEventRecord(b);
         hipLaunchKernelGGL(k_scatter_accum3<13>, dim3(P.bin.acc_blocks), dim3(1024), S3_LDS_BYTES, 0, P.bin, (const uint32_t*)counts,

@@ -469,6 +469,9 @@ __global__ __launch_bounds__(1 << (LG - 3)) void k_scatter_accum3(S3Plan pl, con
 // keeping the 8 corners x 2 features of the CURRENT cell in registers; on a cell change the 16 sums go to the workgroup's
 // fp64 LDS copy of the partition (only the corners that fall into it).  The chunk's partition is then written as fp32 into
 // slab `chunk` of the workspace; k_scatter_fold adds the slabs in fixed order.
+// Measured and dropped (round 3): a variant that reads the rows with coalesced loads (lane = row) and transposes them through
+// a per-wave LDS tile so that lane l can walk rows 16 l .. 16 l + 15 -- 46.6 us against 36.8: with any lane of a wave flushing at
+// nearly every step, the kernel issues its 16 LDS atomic instructions per step either way, and those, not the loads, set its time.
 __device__ __forceinline__ void s3_r_flush(double* s_acc, const float (&acc)[16], uint32_t g0, uint32_t g1, uint32_t g2, uint32_t res,
                                            uint32_t hsize, uint32_t part) {
 #pragma unroll
@@ -569,8 +572,8 @@ static int s3_env(const char* name, int dflt) {
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
 }
-static uint32_t s3_block_samples() {          // XR_SC_BLOCK: samples per binning workgroup (4096 | 2048 | 1024)
-    static const int bs = []() { const int v = s3_env("XR_SC_BLOCK", 4096); return v == 1024 || v == 2048 ? v : 4096; }();
+static uint32_t s3_block_samples() {          // XR_SC_BLOCK: samples per binning workgroup (4096 | 2048 | 1024); measured 152 / 139 / 155 us
+    static const int bs = []() { const int v = s3_env("XR_SC_BLOCK", 2048); return v == 1024 || v == 4096 ? v : 2048; }();
     return (uint32_t)bs;
 }
 static uint32_t s3_chunks() {                 // XR_SC_RL_CHUNKS: row chunks per partition of the run-length kernel
@@ -593,12 +596,14 @@ static bool s3_layout(uint32_t n, const GridMeta& gm, uint32_t hashed_mask, int 
     // what the atomic kernel needs; the tests lower it to run this path at sizes the host emulation finishes quickly
     static const uint32_t min_n = (uint32_t)s3_env("XR_SC_MIN_N", 16384);
     if (n < min_n || nsb > S3_MAX_SB) { P.atomic_mask = (1u << gm.n_levels) - 1u; return false; }
-    // XR_SC_LOG2=12: 2^12-entry partitions accumulated by 512-thread workgroups in 64 KiB of LDS, two per CU (measurement)
-    static const uint32_t lg = s3_env("XR_SC_LOG2", 13) == 12 ? 12u : 13u;
-    const uint32_t entries = 1u << lg;
+    // (measured and dropped: 2^12-entry partitions accumulated by 512-thread workgroups in 64 KiB of LDS, two per CU:
+    // 172.8 us against 138.7 for the whole entry point, profiles/r03_scatter3_defaults.txt)
+    const uint32_t lg = S3_LOG2, entries = S3_ENTRIES;
     P.bin.nsb = nsb; P.bin.overwrite = (uint32_t)overwrite; P.bin.ovf_cap = 8u * bs; P.bin.lg = lg;
     P.rl.chunks = s3_chunks(); P.rl.overwrite = (uint32_t)overwrite;
-    static const int use_rl = s3_env("XR_SC_RL", 1);      // 0: small dense levels through the binned path too (measurement)
+    // XR_SC_RL=0: the small dense levels through the binned path too (measurement: 277 us instead of 41 before the accumulate
+    // kernel merged runs in registers)
+    static const int use_rl = s3_env("XR_SC_RL", 1) != 0;
     static const int dense_atomic = s3_env("XR_SC_DENSE_ATOMIC", 0);   // 1: every dense level through the atomic kernel (measurement)
     uint64_t bins_off = 0, ovf_off = 0;
     uint32_t counts_off = 0;
@@ -626,7 +631,6 @@ static bool s3_layout(uint32_t n, const GridMeta& gm, uint32_t hashed_mask, int 
             else {
                 // a partition holds ceil(res^2 / P) grid rows of res entries (+ the padding entries behind the lattice) <= 2^13
                 L.parts = 32u; L.plog2 = 5u;
-                if (lg == 12) { L.parts = 64u; L.plog2 = 6u; }
                 while (((res * res + L.parts - 1u) / L.parts) * res + 8u > entries && L.parts < S3_MAX_PARTS) { L.parts *= 2u; ++L.plog2; }
             }
             const uint32_t ips = 4u;                                          // items per sample
@@ -673,8 +677,7 @@ int xr_scatter3(const float* x, uint32_t x_stride, const float* denc_t, uint32_t
     float2* slabs = (float2*)((char*)workspace + P.counts_bytes + P.bins_bytes + P.ovf_bytes);
     static bool attr_set = false;
     if (!attr_set) {
-        XR_HIP(hipFuncSetAttribute((const void*)k_scatter_accum3<13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES));
-        XR_HIP(hipFuncSetAttribute((const void*)k_scatter_accum3<12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES / 2));
+        XR_HIP(hipFuncSetAttribute((const void*)k_scatter_accum3<S3_LOG2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES));
         XR_HIP(hipFuncSetAttribute((const void*)k_scatter_dense_rl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES));
         attr_set = true;
     }
@@ -715,12 +718,8 @@ int xr_scatter3(const float* x, uint32_t x_stride, const float* denc_t, uint32_t
         else if (bs == 2048) hipLaunchKernelGGL(k_scatter_bin3<2048>, grid, block, 0, stream, P.bin, x, x_stride, denc_t, ld, n, n_dev, rows, counts, bins, ovf);
         else hipLaunchKernelGGL(k_scatter_bin3<1024>, grid, block, 0, stream, P.bin, x, x_stride, denc_t, ld, n, n_dev, rows, counts, bins, ovf);
         XR_LAUNCH_CHECK();
-        if (P.bin.lg == 13)
-            hipLaunchKernelGGL(k_scatter_accum3<13>, dim3(P.bin.acc_blocks), dim3(1024), S3_LDS_BYTES, stream, P.bin, (const uint32_t*)counts,
-                               (const float4*)bins, (const float4*)ovf, grad_table);
-        else
-            hipLaunchKernelGGL(k_scatter_accum3<12>, dim3(P.bin.acc_blocks), dim3(512), S3_LDS_BYTES / 2, stream, P.bin, (const uint32_t*)counts,
-                               (const float4*)bins, (const float4*)ovf, grad_table);
+        hipLaunchKernelGGL(k_scatter_accum3<S3_LOG2>, dim3(P.bin.acc_blocks), dim3(1024), S3_LDS_BYTES, stream, P.bin, (const uint32_t*)counts,
+                           (const float4*)bins, (const float4*)ovf, grad_table);
         XR_LAUNCH_CHECK();
     }
     if (!rl_first) { const int rc = launch_rl(); if (rc != XR_OK) return rc; }
