@@ -55,17 +55,24 @@ with emulib.emulated_ops() as edev:
     dp2._defer_grad_scale = True
     dp2._unit_root_grad = one = torch.ones(())
     opt2 = FusedAdam([p for p in dp2.parameters() if p.numel() > 0], lr=1e-2, betas=(0.9, 0.99), eps=1e-15, weight_decay=1e-6)
+    # SURVEY.md section 8e's form (XRNERF_DP=zero1): reduce-scatter -> Adam on this rank's shard of the table -> all-gather
+    dp3 = build()
+    dp3.grad_sync = z1 = xd.Zero1GradSync(world, rank)
+    dp3._defer_grad_scale = True
+    dp3._unit_root_grad = one
+    shard = z1.attach(dp3.mlp.embedder_pos.params)
+    opt3 = FusedAdam([shard, dp3.mlp.density_net.params, dp3.mlp.color_net.params], lr=1e-2, betas=(0.9, 0.99), eps=1e-15, weight_decay=1e-6)
     names = ('embedder_pos', 'density_net', 'color_net')
     for it in (1, 2):
         b = Hn.batch(poses, N_RAYS, 100 * rank + it, edev)          # every rank its own rays
         grads = {}
-        for tag, net in (('solo', solo), ('dp', dp), ('dp2', dp2)):
+        for tag, net in (('solo', solo), ('dp', dp), ('dp2', dp2), ('dp3', dp3)):
             net.sampler.set_iter(it)
             net.sampler.k1_calls = 7 * it + rank                    # same march jitter for both networks of this rank
             o = net.train_step({k: v.clone()[None] for k, v in b.items()}, None)
             for n in names:
                 getattr(net.mlp, n).params.grad = None
-            if net is dp2:
+            if net is dp2 or net is dp3:
                 torch.autograd.backward(o['loss'], grad_tensors=one)
             else:
                 o['loss'].backward()
@@ -85,16 +92,51 @@ with emulib.emulated_ops() as edev:
         opt.step()
         opt2.step(grad_scale=dp2._pending_grad_scale)
         dp2._pending_grad_scale = 1.0
+        # zero1: this rank's shard of the reduce-scattered SUM equals the all-reduced sum's slice; after Adam on the shard and
+        # the all-gather the whole table equals the replicated-optimiser result bit for bit (two ranks: a + b is one rounding)
+        lo, hi = rank * z1.shard, min((rank + 1) * z1.shard, z1.n)
+        assert torch.equal(z1.shard_grad[:hi - lo], grads['dp2']['embedder_pos'][lo:hi]), (rank, it)
+        assert dp3._pending_grad_scale == 0.5
+        opt3.step(grad_scale=dp3._pending_grad_scale)
+        dp3._pending_grad_scale = 1.0
+        z1.gather_params()
+        for n in names:
+            assert torch.equal(getattr(dp3.mlp, n).params.detach(), getattr(dp2.mlp, n).params.detach()), (rank, it, n, 'zero1')
         for n in names:                                              # same update, bit for bit, without the scaling pass
             assert torch.equal(getattr(dp2.mlp, n).params.detach(), getattr(dp.mlp, n).params.detach()), (rank, it, n)
         with torch.no_grad():                                        # keep the un-synchronised twin on the same weights
             for n in names:
                 getattr(solo.mlp, n).params.copy_(getattr(dp.mlp, n).params)
+        assert z1.bytes_reduced > 0 and z1.bytes_gathered == it * 4 * z1.param_padded.numel()
         for n in names:
             p = getattr(dp.mlp, n).params.detach()
             both = [torch.empty_like(p) for _ in range(world)]
             dist.all_gather(both, p.contiguous())
             assert torch.equal(both[0], both[1]), (rank, it, n)      # replicas stay bit-identical
+    # validation frames: every rank renders its band of image rows, one all-gather puts the image together (networks._render_rows)
+    Hh, Ww = 9, 8                                                     # 9 rows over 2 ranks: bands of 5 and 4 rows
+    o, d = ops.gen_rays(poses[0], Hh, Ww, 11.0, 11.0, 0.5 * Ww, 0.5 * Hh, device=edev)
+    frame = lambda: {'rays_o': o.clone(), 'rays_d': d.clone(), 'img_ids': torch.zeros((Hh * Ww, 1), dtype=torch.int32),
+                     'src_shape': np.array([Hh, Ww, 3])}
+    dp.set_val_pipeline(lambda q: frame())
+    dp.sampler.k1_calls = 1000                                        # same march jitter stream on both ranks
+    with torch.no_grad():
+        out = dp.val_step({'poses': torch.zeros((1, 1, 4, 3)), 'images': torch.ones((1, 1, Hh, Ww, 4))})
+    row0, nrows = xd.row_band(Hh, rank, world)
+    dp.sampler.k1_calls = 1000
+    with torch.no_grad():                                             # this rank's band on its own, same sampler state
+        fr = frame()
+        band = {k: (v[row0 * Ww:(row0 + nrows) * Ww] if torch.is_tensor(v) else v) for k, v in fr.items()}
+        mine = dp.batchify_forward(band, is_test=True)['rgb'].reshape(nrows, Ww, 3)
+    both = [torch.empty((5, Ww, 3)) for _ in range(world)]
+    pad = torch.zeros((5, Ww, 3)); pad[:nrows] = mine
+    dist.all_gather(both, pad)
+    if rank == 0:
+        img = torch.from_numpy(out['rgbs'][0])
+        assert img.shape == (Hh, Ww, 3) and len(out['elapsed_time']) == 1
+        assert torch.equal(img[:5], both[0][:5]) and torch.equal(img[5:], both[1][:4])      # rows 5.. came from rank 1
+    else:
+        assert out == {}
 dist.barrier(); dist.destroy_process_group()
 print('ok', rank)
 '''

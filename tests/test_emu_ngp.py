@@ -77,6 +77,13 @@ def test_fused_mlp_on_the_host(O, edev):
         T.test_nerf_mlp_bwd(O, edev, n)
 
 
+def test_deeper_topologies_on_the_host(O, edev):
+    """(5, 5) -- tiny-cuda-nn's default depth -- and (3, 4): the layer-by-layer path on the emulated linear kernels"""
+    import test_gpu_tcnn as T
+    T.test_deeper_topologies_run_layer_by_layer(O, edev, 5, 5, 100, 80)
+    T.test_deeper_topologies_run_layer_by_layer(O, edev, 3, 4, 65, None)
+
+
 def test_mlp_backward_on_live_rows_on_the_host(O, edev):
     """the live-row compaction in front of the backward (both precisions), ragged / clipped / single-live-row launches"""
     import test_gpu_tcnn as T

@@ -187,6 +187,40 @@ def test_nerf_mlp_bwd(O, dev, n):
         assert err <= 1e-3 * max(1.0, np.abs(ref).max()), (name, err, np.abs(ref).max())
 
 
+@pytest.mark.parametrize('nhd,nhc,n,n_valid', [(5, 5, 300, None), (5, 5, 5000, 4100), (3, 4, 257, None), (2, 2, 100, None)])
+def test_deeper_topologies_run_layer_by_layer(O, dev, nhd, nhc, n, n_valid):
+    """tiny-cuda-nn's own default depth (5 hidden layers: what the reference's unchanged config builds if tcnn ignores its
+    `num_layers` key) and any other depth the fused kernels are not built for: forward and backward
+    against the oracle, through the same ops entry points (layer-by-layer path on the linear kernels)"""
+    from xrnerf_amd import ops, synthetic as S
+    meta = ops.GridMeta(); om = O.GridMeta()
+    rng = np.random.default_rng(nhd * 10 + nhc + n)
+    table = S.hash_table(meta.n_params, scale=0.5)
+    wd, wc = S.mlp_weights(32, 64, nhd, 16, 4), S.mlp_weights(32, 64, nhc, 16, 5)
+    pts = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    dirs = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    draw = rng.normal(0, 1, (n, 4)).astype(np.float32)
+    nv = n if n_valid is None else n_valid
+    draw_ref = draw.copy(); draw_ref[nv:] = 0
+    ref = O.nerf_mlp_fwd(table, wd, wc, pts, dirs, om, nhd, nhc)
+    gt, gd, gc = O.nerf_mlp_bwd(table, wd, wc, pts, dirs, draw_ref, om, nhd, nhc)
+    tt, tp, td = T(table, dev), T(pts, dev), T(dirs, dev)
+    n_dev = None if n_valid is None else torch.tensor([n_valid], dtype=torch.int32, device=dev)
+    enc_t = ops.hashgrid_fwd(tt, tp, meta)
+    raw = ops.nerf_mlp_fwd(enc_t, td, n, T(wd, dev), T(wc, dev), nhd, nhc, n_dev=n_dev)
+    assert np.abs(raw.cpu().numpy()[:nv] - ref[:nv]).max() <= 1e-4
+    dens = ops.nerf_mlp_fwd(enc_t, None, n, T(wd, dev), None, nhd, nhc)
+    assert np.abs(dens.cpu().numpy()[:, 3] - ref[:, 3]).max() <= 1e-4 and float(dens[:, :3].abs().max()) == 0.0
+    g_wd = torch.zeros(wd.size, dtype=torch.float32, device=dev)
+    g_wc = torch.zeros(wc.size, dtype=torch.float32, device=dev)
+    denc_t = ops.nerf_mlp_bwd(enc_t, td, n, T(wd, dev), T(wc, dev), nhd, nhc, T(draw, dev), g_wd, g_wc, n_dev=n_dev)
+    g_t = torch.zeros(meta.n_params, dtype=torch.float32, device=dev)
+    ops.hashgrid_bwd(tp, denc_t, meta, g_t, n_dev=n_dev)
+    for name, got, refg in (('wd', g_wd, gd), ('wc', g_wc, gc), ('table', g_t, gt)):
+        err = np.abs(got.cpu().numpy() - refg).max()
+        assert err <= 1e-3 * max(1.0, np.abs(refg).max()), (name, err, np.abs(refg).max())
+
+
 def sparse_draw(rng, n, dead_fraction=0.55):
     """dL/d(raw) the way the compositor produces it: runs of exactly-zero rows (samples behind an opaque surface), a few
     isolated zero rows, rows with a single non-zero component, -0.0 entries"""

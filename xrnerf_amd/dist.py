@@ -70,6 +70,106 @@ class BucketedGradSync:
         return 1.0 / self.world_size
 
 
+class Zero1GradSync:
+    """SURVEY.md section 8e's gradient exchange as it says it: reduce-scatter -> fused Adam on the rank's shard -> all-gather of
+    the updated parameters (the reference's equivalent is DDP's all-reduce + a replicated optimiser, core/apis/train.py:28-38).
+    Selected with XRNERF_DP=zero1.  Same bytes on the links as the all-reduce (a ring all-reduce IS reduce-scatter + all-gather),
+    but the 71-us Adam + EMA pass over the 12.2 M table parameters -- 12 % of a step, run N times over by the replicated form
+    -- shrinks to 1/N per rank, and so do its m / v / EMA states.
+
+    Geometry: the table's storage is padded to `world * shard` floats (shard a multiple of 4: 16-byte aligned for the fused
+    Adam's float4 accesses); rank r owns [r * shard, (r + 1) * shard).  `attach` re-seats the parameter (and `pad_grad` the
+    step's gradient buffers) on padded storage once, so the collectives run in place: no staging copies.
+    Protocol per step, same interface as BucketedGradSync: `ready(mlp gradients)` -> async all-reduce (41 KB, replicated
+    Adam); `ready(table gradient)` -> async reduce-scatter into `shard_grad`; `finish()` waits and returns 1 / world;
+    the trainer then steps its optimiser on (`shard_param`, wd, wc) and calls `gather_params()`."""
+
+    split_levels = False           # one table bucket: shards cut across the level slices
+
+    def __init__(self, world_size, rank):
+        self.world_size, self.rank = int(world_size), int(rank)
+        self._works, self._padded = [], {}
+        self.shard = self.n = 0
+        self.bytes_reduced = self.bytes_gathered = 0
+
+    def attach(self, table_param):
+        """pad the table parameter's storage to world * shard floats, in place -> the nn.Parameter of this rank's shard (a view)"""
+        n = table_param.numel()
+        self.n = n
+        self.shard = (-(-n // self.world_size) + 3) // 4 * 4
+        buf = torch.zeros(self.shard * self.world_size, dtype=table_param.dtype, device=table_param.device)
+        buf[:n] = table_param.data
+        table_param.data = buf[:n]
+        self.param_padded = buf
+        self.shard_param = torch.nn.Parameter(buf[self.rank * self.shard:(self.rank + 1) * self.shard])
+        self.shard_grad = torch.zeros_like(self.shard_param.data)
+        return self.shard_param
+
+    def pad_grad(self, device):
+        """storage for one table-gradient buffer of the fused step: (padded [world * shard], its leading [n] view)"""
+        buf = torch.zeros(self.shard * self.world_size, dtype=torch.float32, device=device)
+        self._padded[buf.data_ptr()] = buf
+        return buf, buf[:self.n]
+
+    def ready(self, bucket):
+        if self.world_size <= 1:
+            return
+        padded = self._padded.get(bucket.data_ptr()) if bucket.numel() == self.n else None
+        if padded is None:                                   # the MLP gradients: replicated
+            self._works.append(dist.all_reduce(bucket.data, op=dist.ReduceOp.SUM, async_op=True))
+            self.bytes_reduced += 4 * bucket.numel()
+            return
+        self.bytes_reduced += 4 * padded.numel()
+        if dist.get_backend() == 'gloo':                     # gloo has no reduce-scatter: all-reduce, keep this rank's shard
+            self._works.append(dist.all_reduce(padded, op=dist.ReduceOp.SUM, async_op=True))
+            self._take = padded
+        else:
+            self._works.append(dist.reduce_scatter_tensor(self.shard_grad, padded, op=dist.ReduceOp.SUM, async_op=True))
+            self._take = None
+
+    def finish(self):
+        for w in self._works:
+            w.wait()
+        self._works = []
+        if getattr(self, '_take', None) is not None:
+            self.shard_grad.copy_(self._take[self.rank * self.shard:(self.rank + 1) * self.shard])
+            self._take = None
+        self.shard_param.grad = self.shard_grad
+        return 1.0 / self.world_size
+
+    def gather_params(self):
+        """all-gather of the updated shards, in place in the padded parameter storage"""
+        if self.world_size <= 1:
+            return
+        self.bytes_gathered += 4 * self.param_padded.numel()
+        if dist.get_backend() == 'gloo':
+            parts = [torch.empty_like(self.shard_param.data) for _ in range(self.world_size)]
+            dist.all_gather(parts, self.shard_param.data.contiguous())
+            for r, t in enumerate(parts):
+                if r != self.rank:
+                    self.param_padded[r * self.shard:(r + 1) * self.shard].copy_(t)
+        else:
+            dist.all_gather_into_tensor(self.param_padded, self.shard_param.data)
+
+
+def comm_model(world_size, table_floats=12196240, mlp_floats=10240, link_GBs=153.0, links=7, step_ms=0.59):
+    """what one training step puts on xGMI, and what a ring over it costs (one-GPU boxes only: nothing here is measured).
+    xGMI is point-to-point, 7 links x ~153 GB/s per GPU; an N-rank ring collective is bound by ONE link per hop:
+    all-reduce = 2 (N - 1) / N x bytes over one link (reduce-scatter + all-gather, (N - 1) / N each)."""
+    n = int(world_size)
+    if n <= 1:
+        return {'world_size': n, 'bytes_per_step': 0, 'ring_ms': 0.0}
+    b = 4.0 * (table_floats + mlp_floats)
+    wire = 2.0 * (n - 1) / n * b
+    ring_ms = wire / (link_GBs * 1e9) * 1e3
+    return {'world_size': n, 'gradient_bytes_per_rank': b, 'bytes_on_each_link_per_step': wire, 'assumed_link_GBs': link_GBs,
+            'ring_ms': ring_ms, 'step_ms_single_gpu': step_ms,
+            'overlappable_ms': 'all-reduce form: the 32-MB fine bucket runs under the coarse levels\' scatter (~0.06 ms); zero1 form: none '
+                               '(one bucket), but Adam drops from 0.071 ms to 0.071 / N',
+            'efficiency_if_fully_exposed': step_ms / (step_ms + ring_ms),
+            'note': 'model, not a measurement: RCCL over xGMI has never run in this repository (single-GPU boxes)'}
+
+
 def row_band(H, rank, world_size):
     """contiguous band of image rows of rank `rank`: (row0, nrows); bands differ by at most one row"""
     base, rem = divmod(H, world_size)

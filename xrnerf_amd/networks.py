@@ -114,7 +114,8 @@ class _FusedTrainStepFn(torch.autograd.Function):
                 if (sets is None or sets[0].n_rows != n_rows or sets[0].ray_cap < n_rays or sets[0].g_table.shape != table.shape
                         or sets[0].g_table.device != table.device):
                     sets = net._step_bufs = [ops.TrainStepBuffers(table.device, n_rows, max(n_rays, 1 << 15), table.numel(), wd.numel(),
-                                                                  wc.numel(), mlp.embedder_pos.meta) for _ in range(2)]
+                                                                  wc.numel(), mlp.embedder_pos.meta, getattr(sync, 'pad_grad', None))
+                                             for _ in range(2)]
                     net._step_turn = 0
                 # two sets alternate: the one the optimiser still holds as .grad is not reused.  A caller that keeps gradients
                 # alive across steps (zero_grad(set_to_none=False), accumulation over several backward passes) may still hold
@@ -128,9 +129,9 @@ class _FusedTrainStepFn(torch.autograd.Function):
                         break
                 else:
                     b = sets[net._step_turn] = ops.TrainStepBuffers(table.device, n_rows, sets[0].ray_cap, table.numel(), wd.numel(),
-                                                                     wc.numel(), mlp.embedder_pos.meta)
+                                                                     wc.numel(), mlp.embedder_pos.meta, getattr(sync, 'pad_grad', None))
                 meta = mlp.embedder_pos.meta
-                split = meta.n_levels - 8 if (sync is not None and meta.n_levels > 8) else 0
+                split = meta.n_levels - 8 if (sync is not None and meta.n_levels > 8 and getattr(sync, 'split_levels', True)) else 0
                 rgb = ops.ngp_train_step(table, wd, wc, 1, 2, mlp.pad_value, meta, sampler.coords, data.get('n_valid_dev'),
                                          sampler.rays_numsteps, sampler.rays_numsteps_compacted, data['bg_color'],
                                          data['target_s'].contiguous(), data['alpha'].contiguous(), sampler.density_grid_mean,
@@ -194,7 +195,7 @@ class _FusedTrainStepFn(torch.autograd.Function):
             sync = getattr(net, 'grad_sync', None)
             if sync is None:
                 ops.hashgrid_bwd(pts, denc_t, meta, g_table, live=live)
-            elif meta.n_levels > 8:
+            elif meta.n_levels > 8 and getattr(sync, 'split_levels', True):
                 # data parallel: reduce each gradient bucket across the ranks while the next one is produced
                 split = meta.n_levels - 8
                 cut = 2 * int(meta.offset[split])
@@ -204,6 +205,8 @@ class _FusedTrainStepFn(torch.autograd.Function):
                 ops.hashgrid_bwd(pts, denc_t, meta, g_table, live=live, levels=(0, split))
                 sync.ready(g_table[:cut])
             else:
+                if hasattr(sync, 'pad_grad'):          # padded storage for the reduce-scatter
+                    g_table = sync.pad_grad(table.device)[1]
                 ops.hashgrid_bwd(pts, denc_t, meta, g_table, live=live)
                 sync.ready(g_mlp)
                 sync.ready(g_table)
@@ -361,11 +364,33 @@ class HashNerfNetwork(BaseNerfNetwork):
             log_vars = {'loss': loss.item(), 'psnr': psnr.item()}
         return {'loss': loss, 'log_vars': log_vars, 'num_samples': bs}
 
+    def _render_rows(self, frame, is_test=True):
+        """batchify_forward of one frame's flattened rays.  One rank: the whole frame, like the reference (which renders on
+        rank 0 only, networks/hashnerf.py:58-59,97-98, while the other ranks idle).  Several ranks: every rank marches and
+        evaluates ITS contiguous band of image rows and ONE all-gather puts the RGBA image together on every rank (north_star:
+        image-space ray sharding + all-gather of the rendered tiles); XRNERF_VAL_RANK0_ONLY=1 restores the reference's form.
+        -> {'rgb': [H*W,3], 'alpha': [H*W,1]} of the full frame (None on ranks > 0 in the rank-0-only form)."""
+        from . import dist as xdist
+        rank, world = get_dist_info()
+        if world == 1 or os.environ.get('XRNERF_VAL_RANK0_ONLY') == '1':
+            return self.batchify_forward(frame, is_test=is_test) if rank == 0 else None
+        shape = tuple(int(v) for v in frame['src_shape'])
+        H, W = shape[0], shape[1]
+        N = frame[self.bs_data].shape[0]
+        assert N == H * W, 'row-band sharding needs the frame as H*W flattened rays'
+        row0, nrows = xdist.row_band(H, rank, world)
+        band = {k: (v[row0 * W:(row0 + nrows) * W] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == N else v) for k, v in frame.items()}
+        ret = self.batchify_forward(band, is_test=is_test)
+        tile = torch.cat([ret['rgb'].reshape(nrows, W, 3), ret['alpha'].reshape(nrows, W, 1)], -1)
+        img = xdist.gather_image(tile, H, rank, world)
+        return {'rgb': img[..., :3].reshape(N, 3), 'alpha': img[..., 3:].reshape(N, 1)}
+
     def val_step(self, data, optimizer=None, **kwargs):
         if self.phase == 'test':
             return self.test_step(data, **kwargs)
         rank, world_size = get_dist_info()
-        if rank != 0:
+        sharded = world_size > 1 and os.environ.get('XRNERF_VAL_RANK0_ONLY') != '1'
+        if rank != 0 and not sharded:
             return {}
         for k in data:
             data[k] = unfold_batching(data[k])
@@ -374,7 +399,9 @@ class HashNerfNetwork(BaseNerfNetwork):
         for i in range(poses.shape[0]):
             start = time.time()
             frame = self.val_pipeline({'pose': poses[i], 'idx': i})
-            ret = self.batchify_forward(frame, is_test=True)
+            ret = self._render_rows(frame)
+            if rank != 0:
+                continue
             rgb = recover_shape(ret['rgb'], frame['src_shape'])
             rgb = rgb.cpu().numpy()           # D2H inside the timer ends the frame, as the reference's does
             elapsed_time_list.append(time.time() - start)
@@ -382,16 +409,21 @@ class HashNerfNetwork(BaseNerfNetwork):
             gt_img = images[i].cpu().numpy()[:, :, :3]
             rgbs.append(rgb * alpha)
             gt_imgs.append(gt_img * alpha)
+        if rank != 0:
+            return {}
         return {'rgbs': rgbs, 'disps': disps, 'gt_imgs': gt_imgs, 'elapsed_time': elapsed_time_list}
 
     def test_step(self, data, **kwargs):
         rank, world_size = get_dist_info()
-        if rank != 0:
+        sharded = world_size > 1 and os.environ.get('XRNERF_VAL_RANK0_ONLY') != '1'
+        if rank != 0 and not sharded:
             return {}
         for k in data:
             data[k] = unfold_batching(data[k])
         idx = data['idx'].item()
-        ret = self.batchify_forward(data, is_test=True)
+        ret = self._render_rows(data)
+        if rank != 0:
+            return {}
         rgb = recover_shape(ret['rgb'], data['src_shape']).cpu().numpy()
         alpha = recover_shape(ret['alpha'], data['src_shape']).cpu().numpy()
         return {'spiral_rgb': rgb, 'spiral_alpha': alpha, 'idx': idx}

@@ -297,7 +297,7 @@ def ngp_prefetch(rows, n, batch_call_index, batch_out, bitfield, aabb, near_dist
 class TrainStepBuffers:
     """caller-owned buffers of xr_ngp_train_step for `n_rows` sample rows and up to `ray_cap` rays"""
 
-    def __init__(self, device, n_rows, ray_cap, table_floats, wd_floats, wc_floats, meta):
+    def __init__(self, device, n_rows, ray_cap, table_floats, wd_floats, wc_floats, meta, table_grad_storage=None):
         f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=device)
         self.n_rows, self.ray_cap, self.ld = n_rows, ray_cap, (n_rows + 63) // 64 * 64
         self.enc_t, self.denc_t = f(meta.n_output_dims, self.ld), f(meta.n_output_dims, self.ld)
@@ -306,7 +306,9 @@ class TrainStepBuffers:
         self.g_wd, self.g_wc = self.zero_block[:wd_floats], self.zero_block[wd_floats:wd_floats + wc_floats]
         self.g_mlp = self.zero_block[:wd_floats + wc_floats]
         self.loss_mse = self.zero_block[wd_floats + wc_floats:wd_floats + wc_floats + 2]
-        self.g_table = f(table_floats)
+        # `table_grad_storage`: -> (padded buffer, leading [table_floats] view) when the gradient collective wants padded storage
+        # (dist.Zero1GradSync.pad_grad); the step writes the view
+        self.g_table = table_grad_storage(device)[1] if table_grad_storage is not None else f(table_floats)
 
 
 def ngp_train_step(table, wd, wc, nhd, nhc, pad_value, meta, coords, n_dev, numsteps, numsteps_c, bg, target, alpha,
@@ -543,9 +545,66 @@ def sh4(dirs):
     return out
 
 
+# ---- deeper tiny MLPs than the fused kernels are built for --------------------------------------------------------
+# tiny-cuda-nn's key for the depth is `n_hidden_layers` (default 5); the reference config writes `num_layers`
+# (configs/instant_ngp/nerf_blender_local01.py:106-124, passed unchanged by xrnerf/models/mlps/hashnerf_mlp.py:39-45), so a
+# checkpoint of the real reference may hold 5-hidden-layer nets (19 456 floats each; SURVEY.md section 2c, XRNERF_TCNN_STRICT_DEFAULTS).
+# The fused kernels keep every activation of both nets in registers and both weight sets in LDS: (1, 2), (1, 1), (2, 2), (2, 3)
+# forward, (1, 2) backward.  Any other depth runs layer by layer on the fp32 linear kernels of csrc/xr_gemm.hip (the 8x256
+# MLP's: bias-free here, relu in the epilogue, relu mask applied while the gradient is loaded) -- same arithmetic, activations
+# through HBM.
+_FUSED_FWD = ((1, 2), (1, 1), (2, 2), (2, 3))
+_FUSED_BWD = ((1, 2),)
+
+
+def _net_layers(w_flat, n_hidden, n_in=32, width=64, n_out=16):
+    """views [out, in] of a flat FullyFusedMLP parameter vector (row-major matrices in layer order)"""
+    dims = [n_in] + [width] * n_hidden + [n_out]
+    out, o = [], 0
+    for a, b in zip(dims[:-1], dims[1:]):
+        out.append(w_flat[o:o + a * b].view(b, a))
+        o += a * b
+    if o != w_flat.numel():
+        raise _lib.XrError('parameter vector of %d floats does not hold %d hidden layers' % (w_flat.numel(), n_hidden))
+    return out
+
+
+def _layered_net(x, w_flat, n_hidden):
+    from .linear import linear_act
+    ws = _net_layers(w_flat, n_hidden)
+    h = x
+    for w in ws[:-1]:
+        h = linear_act(h, w, None, True)
+    return linear_act(h, ws[-1], None, False)
+
+
+def _layered_nerf_mlp(enc, dirs, w_density, w_color, nhd, nhc, pad_value):
+    """enc [n,32] (, dirs [n,3]) -> raw [n,4] = [rgb raw, sigma raw]; differentiable w.r.t. enc, w_density, w_color"""
+    dout = _layered_net(enc, w_density, nhd)
+    if dirs is None:
+        z = torch.zeros((enc.shape[0], 3), dtype=torch.float32, device=enc.device)
+        return torch.cat([z, dout[:, :1]], 1)
+    cin = torch.cat([dout[:, 1:16], sh4(dirs), torch.full((enc.shape[0], 1), float(pad_value), dtype=torch.float32, device=enc.device)], 1)
+    cout = _layered_net(cin, w_color, nhc)
+    return torch.cat([cout[:, :3], dout[:, :1]], 1)
+
+
 def nerf_mlp_fwd(enc_t, dirs, n, w_density, w_color, nhd, nhc, pad_value=1.0, raw=None, n_dev=None, rows=None, row0=0,
                  count=None):
     L = _lib.load()
+    if (nhd, nhc) not in _FUSED_FWD:
+        if rows is not None:
+            raise _lib.XrError('row lists are served by the fused kernels only (hidden layers %d, %d)' % (nhd, nhc))
+        m = n if count is None else count
+        with torch.no_grad(), _span('xr_nerf_mlp_fwd', 0 if n_dev is not None else m, train=n_dev is not None):
+            enc = enc_t[:, row0:row0 + m].t().contiguous()
+            d = _pos_view(dirs)[0][row0:row0 + m] if dirs is not None else None
+            out = _layered_nerf_mlp(enc, d.contiguous() if d is not None and d.stride(0) != 3 else d, w_density.detach(),
+                                    w_color.detach() if w_color is not None else None, nhd, nhc, pad_value)
+        if raw is None:
+            raw = torch.empty((n, 4), dtype=torch.float32, device=enc_t.device)
+        raw[row0:row0 + m] = out
+        return raw
     if raw is None:
         raw = torch.empty((n, 4), dtype=torch.float32, device=enc_t.device)
     if dirs is not None:
@@ -600,6 +659,27 @@ def nerf_mlp_bwd(enc_t, dirs, n, w_density, w_color, nhd, nhc, draw, grad_wd, gr
     rows of denc_t untouched -- pass the same list to hashgrid_bwd.  Without it the call builds its own list and writes
     exact zeros to the dead rows (identical results to the backward over every row)."""
     L = _lib.load()
+    if (nhd, nhc) not in _FUSED_BWD:
+        # layer by layer: recompute the forward under autograd, back-propagate dL/d(raw); rows outside a live list have an
+        # exactly-zero dL/d(raw) and get an exactly-zero dL/d(encoding) (a superset of the fused contract, which leaves them alone)
+        m = n if count is None else count
+        if denc_t is None:
+            denc_t = torch.empty_like(enc_t)
+        with _span('xr_nerf_mlp_bwd', 0 if n_dev is not None else m, train=n_dev is not None):
+            d = _pos_view(dirs)[0][row0:row0 + m]
+            d = d.contiguous() if d.stride(0) != 3 else d
+            with torch.enable_grad():
+                enc = enc_t[:, row0:row0 + m].t().contiguous().requires_grad_(True)
+                wd, wc = w_density.detach().requires_grad_(True), w_color.detach().requires_grad_(True)
+                out = _layered_nerf_mlp(enc, d, wd, wc, nhd, nhc, pad_value)
+                g = draw[row0:row0 + m]
+                if n_dev is not None:       # rows behind the device-side count are padding: no gradient
+                    g = g * (torch.arange(m, device=g.device)[:, None] < n_dev.reshape(-1)[:1].to(torch.int64)).to(g.dtype)
+                ge, gwd, gwc = torch.autograd.grad(out, [enc, wd, wc], grad_outputs=g.contiguous())
+            denc_t[:, row0:row0 + m] = ge.t()
+            grad_wd.add_(gwd)
+            grad_wc.add_(gwc)
+        return denc_t
     dirs, ds = _pos_view(dirs)
     if denc_t is None:
         denc_t = torch.empty_like(enc_t)

@@ -125,4 +125,11 @@ class Network(nn.Module):
         self.params = nn.Parameter(torch.cat(ws))
 
     def forward(self, x):
+        if self.n_hidden > 2:
+            # deeper than the fused single-network kernels (forward 1..3 hidden layers, backward 1..2): layer by layer on the
+            # linear kernels (ops._layered_net) -- tiny-cuda-nn's own default depth, 5, takes this path
+            x = x if x.dtype == torch.float32 else x.float()
+            if x.shape[1] < 32:
+                x = torch.cat([x, torch.full((x.shape[0], 32 - x.shape[1]), self.pad_value, dtype=torch.float32, device=x.device)], 1)
+            return ops._layered_net(x.contiguous(), self.params, self.n_hidden)[:, :self.n_output_dims]
         return _NetFn.apply(self.params, x, self)

@@ -189,13 +189,25 @@ class Trainer:
         self.net.sampler.set_data(self.data.get_alldata(), self.data.get_info())     # PassDatasetHook
         self.net.sampler.on_sampled = self._on_sampled
         self.base_lr = 1e-2
-        self.opt = FusedAdam([p for p in self.net.parameters() if p.numel() > 0], lr=self.base_lr,
-                             betas=(0.9, 0.99), eps=1e-15, weight_decay=1e-6, ema_momentum=0.05 if ema else None)
         self.iter = 0
         self.world_size, self.rank = world_size, rank
-        if world_size > 1:
+        self.dp_mode = os.environ.get('XRNERF_DP', 'allreduce')
+        if self.dp_mode not in ('allreduce', 'zero1'):
+            raise ValueError("XRNERF_DP must be 'allreduce' or 'zero1' (got %r)" % self.dp_mode)
+        opt_params = [p for p in self.net.parameters() if p.numel() > 0]
+        if world_size > 1 and self.dp_mode == 'zero1':
+            # reduce-scatter -> Adam on this rank's shard of the table -> all-gather
+            from . import dist as xdist
+            self.net.grad_sync = xdist.Zero1GradSync(world_size, rank)
+            table = self.net.mlp.embedder_pos.params
+            shard = self.net.grad_sync.attach(table)
+            opt_params = [shard] + [p for p in opt_params if p is not table]
+        self.opt = FusedAdam(opt_params, lr=self.base_lr, betas=(0.9, 0.99), eps=1e-15, weight_decay=1e-6,
+                             ema_momentum=0.05 if ema else None)
+        if world_size > 1 and self.dp_mode == 'allreduce':
             from . import dist as xdist                 # fused step: bucketed reduction under the table scatter
             self.net.grad_sync = xdist.BucketedGradSync(world_size)
+        if world_size > 1:
             # this trainer's optimiser applies the 1/world_size itself (FusedAdam.step(grad_scale=...)): the fused step leaves
             # the SUMMED gradients in .grad and reports the factor in net._pending_grad_scale
             self.net._defer_grad_scale = os.environ.get('XRNERF_DEFER_GRAD_SCALE', '1') != '0'
@@ -231,6 +243,8 @@ class Trainer:
             xdist.allreduce_grads([p for p in net.parameters() if p.grad is not None], self.world_size)
         self.opt.step(grad_scale=getattr(net, '_pending_grad_scale', 1.0))
         net._pending_grad_scale = 1.0
+        if self.world_size > 1 and self.dp_mode == 'zero1':
+            net.grad_sync.gather_params()               # every rank's updated shard -> the full table, in place
         data.set_batchsize(net.sampler.n_rays_per_batch)                  # ModifyBatchsizeHook
         self.iter += 1
         self.rays_done += n_rays
