@@ -337,6 +337,124 @@ def ngp_f16_mlp_mode(dev, n_img, steps):
         ops.set_precision('f32')
 
 
+def ngp_tcnn_strict_defaults(dev, n_img, steps):
+    """The topology tiny-cuda-nn would build from the reference's UNCHANGED config if it ignores the config's `num_layers` key
+    (its key is `n_hidden_layers`, default 5): 5-hidden-layer density and colour nets, 77 824 flop per
+    sample forward.  Runs layer by layer on the fp32 linear kernels (ops._layered_nerf_mlp): priced, not tuned."""
+    os.environ['XRNERF_TCNN_STRICT_DEFAULTS'] = '1'
+    try:
+        tr = Trainer(dev, n_img=n_img)
+        assert tr.net.mlp.density_net.n_hidden == 5 and tr.net.mlp.color_net.n_hidden == 5
+        sampler = tr.net.sampler
+        for _ in range(96):
+            tr.step()
+        for _ in range((-tr.iter) % sampler.update_grid_freq + 1):
+            tr.step()
+        torch.cuda.synchronize()
+        r0, s0, it0 = tr.rays_done, tr.samples_done, tr.iter
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tr.step()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        rays, samples = tr.rays_done - r0, tr.samples_done - s0
+        s1 = tr.samples_done
+        ops.TIMER = ops.KernelTimer(only={'xr_nerf_mlp_fwd', 'xr_nerf_mlp_bwd'}, train_only=True)
+        for _ in range(16):
+            tr.step()
+        torch.cuda.synchronize()
+        timer, ops.TIMER = ops.TIMER, None
+        s_win = tr.samples_done - s1
+        flop = {'xr_nerf_mlp_fwd': 2 * (32 * 64 + 4 * 64 * 64 + 64 * 16) * 2, 'xr_nerf_mlp_bwd': 3 * 2 * (32 * 64 + 4 * 64 * 64 + 64 * 16) * 2}
+        kern = {}
+        for k, (n_l, ms_l, _) in timer.summary().items():
+            fl = flop[k] * s_win
+            kern[k] = {'avg_launch_us': ms_l * 1e3 / max(n_l, 1), 'achieved_TFLOPs': fl / (ms_l * 1e-3) / 1e12,
+                       'peak_TFLOPs': MFMA_F32_PEAK_TFLOPS, 'frac': fl / (ms_l * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                       'flop_per_sample': flop[k]}
+        return {'workload': 'the headline iterations with 5 + 5 hidden layers (XRNERF_TCNN_STRICT_DEFAULTS=1: what tcnn builds if it ignores '
+                            'the config\'s num_layers key), %d timed iterations %d..%d after %d pre-roll iterations; fused MLP replaced by '
+                            'layer-by-layer fp32 linear kernels (activations through HBM)' % (steps, it0, it0 + steps - 1, it0),
+                'value': rays / el, 'unit': 'rays/s', 'ms_per_step': el * 1e3 / steps, 'rays_per_step': rays / steps,
+                'samples_per_ray': samples / max(rays, 1), 'kernels': kern, 'final_train_psnr': float(tr.step()['log_vars']['psnr'])}
+    finally:
+        os.environ.pop('XRNERF_TCNN_STRICT_DEFAULTS', None)
+
+
+def ngp_real_lego_fixture(dev, steps=64):
+    """The reference's own 5-image Lego fixture (4 training views; staged under oracle/_ref/data by tools/stage_ref_lego.py): does the
+    headline hinge on the synthetic boxes?  Rays/s and the share of live backward rows on real pixels after 512 iterations."""
+    from xrnerf_amd import datasets
+    datadir = os.path.join(ROOT, 'oracle', '_ref', 'data', 'lego')
+    if not os.path.isdir(datadir):
+        return {'skipped': 'fixture not staged (%s)' % datadir}
+    ds = datasets.HashNerfDataset(dict(datadir=datadir, half_res=False, testskip=1, white_bkgd=False, load_alpha=True,
+                                       N_rand_per_sampler=4096, mode='train', val_n=2), device=dev)
+    tr = Trainer(dev, dataset=ds)
+    for _ in range(512):
+        tr.step()
+    for _ in range((-tr.iter) % tr.net.sampler.update_grid_freq + 1):
+        tr.step()
+    if ops.LIVE_STATS is not None:
+        ops.LIVE_STATS[1:3].zero_()
+    torch.cuda.synchronize()
+    r0, s0 = tr.rays_done, tr.samples_done
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    live, valid = (int(v) & 0xffffffff for v in ops.LIVE_STATS[1:3].tolist()) if ops.LIVE_STATS is not None else (0, 0)
+    rays, samples = tr.rays_done - r0, tr.samples_done - s0
+    return {'workload': 'reference test fixture nerf_synthetic/lego, %d training views 800x800, iterations %d..%d' % (ds.n_img, tr.iter - steps, tr.iter - 1),
+            'value': rays / el, 'unit': 'rays/s', 'ms_per_step': el * 1e3 / steps, 'rays_per_step': rays / steps,
+            'samples_per_ray': samples / max(rays, 1), 'live_row_fraction': live / valid if valid else None,
+            'train_psnr_batch': float(tr.step()['log_vars']['psnr']),
+            'note': 'a 4-view over-fit check of the pipeline on real pixels, not comparable with the reference\'s 100-view 35.1 dB'}
+
+
+def registry_frame_ms(tr, H=800, W=800, frames=3):
+    """The frame time a user of the unchanged config gets: HashNerfNetwork.val_step (networks/hashnerf.py:54-93 semantics: per frame
+    the pipeline's ray generation, batchify_forward in chunk = 4096 pieces -- 157 chunks -- and the device-to-host copy of the image
+    inside the timer)."""
+    net, data = tr.net, tr.data
+    focal = data.focal * H / data.H
+
+    def pipeline(q):
+        o, d = ops.gen_rays(q['pose'], H, W, focal, focal, 0.5 * W, 0.5 * H, device=tr.device)
+        return {'rays_o': o, 'rays_d': d, 'img_ids': torch.full((o.shape[0], 1), float(q['idx']), dtype=torch.float32, device=tr.device),
+                'src_shape': np.array([H, W, 3])}
+    net.set_val_pipeline(pipeline)
+    poses = np.stack([data.poses[k % data.n_img] for k in range(frames + 1)])[None]
+    images = torch.ones((1, frames + 1, H, W, 4), dtype=torch.float32)
+    out = {}
+    for key, env in (('render_ms_per_800x800_frame_registry_chunk4096', '1'), ('render_ms_per_800x800_frame_registry_chunk4096_readback_per_chunk', '0')):
+        os.environ['XRNERF_ASYNC_CHUNKS'] = env
+        try:
+            with torch.no_grad():
+                r = net.val_step({'poses': poses, 'images': images})
+            out[key] = float(np.mean(r['elapsed_time'][1:])) * 1e3
+        finally:
+            os.environ.pop('XRNERF_ASYNC_CHUNKS', None)
+    out['registry_chunk'] = int(net.chunk)
+    return out
+
+
+def value_all_rows(args):
+    """the headline once more with the backward over EVERY marched row (XR_MLP_LIVE=0, read once per process: a child process)"""
+    import subprocess
+    env = dict(os.environ, XR_MLP_LIVE='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), '--steps', str(args.steps), '--warmup', str(args.warmup), '--n-img', str(args.n_img),
+                        '--headline-only'], env=env, capture_output=True, text=True, timeout=1200)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    if r.returncode != 0 or not line:
+        raise RuntimeError('child failed: %s' % r.stderr[-300:])
+    d = json.loads(line[-1])
+    return {'value': d['value'], 'ms_per_step': d['ms_per_step'], 'note': 'MLP backward and table scatter over every marched row (XR_MLP_LIVE=0), same results'}
+
+
 def ngp_config4_unbounded(dev, steps=64):
     """Secondary line (BASELINE config #4): the same Instant-NGP model on an UNBOUNDED forward-facing scene, 1008 x 756,
     aabb_scale = 16 (five occupancy cascades: 10.5 M-point grid queries below iteration 256, 2 x 2.6 M after), synthetic
@@ -470,7 +588,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=256)
     ap.add_argument('--warmup', type=int, default=16)
-    ap.add_argument('--n-img', type=int, default=20)
+    ap.add_argument('--n-img', type=int, default=100, help='training cameras of the synthetic scene (SURVEY.md section 8d: 100; the ray table is 28 MB per image)')
     ap.add_argument('--no-preroll', action='store_true', help='time right after --warmup (the occupancy grid is still dense '
                     'and the adaptive batch has not converged: NOT the steady state)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -479,6 +597,9 @@ def main():
     ap.add_argument('--no-kilo', action='store_true', help='skip the secondary KiloNeRF (config #5) line')
     ap.add_argument('--no-unbounded', action='store_true', help='skip the secondary unbounded-scene (config #4) line')
     ap.add_argument('--no-f16', action='store_true', help='skip the second line in the reference\'s fp16 MLP precision')
+    ap.add_argument('--no-strict', action='store_true', help='skip the secondary line with tcnn\'s default 5 + 5 hidden layers')
+    ap.add_argument('--no-extra', action='store_true', help='skip value_all_rows, the real-Lego fixture line and the registry frame time')
+    ap.add_argument('--headline-only', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--cpu-worker', type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -578,6 +699,13 @@ def main():
     else:
         elapsed_max, rays_all, samples_all = elapsed, float(rays), float(samples)
 
+    if args.headline_only:
+        if rank == 0:
+            print(json.dumps({'value': rays_all / elapsed_max, 'ms_per_step': elapsed_max * 1e3 / args.steps, 'steps': args.steps}))
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
     # The two backward entry points run on the rows whose dL/d(raw) is not exactly zero (ops.live_rows): the units ONE LAUNCH
     # PROCESSES are the live rows, and only those are priced -- the fraction is read from the device-side running totals.
     def live_fraction():
@@ -627,10 +755,11 @@ def main():
     roof = roof_of(dom_pick, launches, total_ms, units if units > 0 else samples, live_frac_timed)
     roof['traffic'] = None
     try:   # HBM bytes per launch from separate rocprofv3 --pmc passes of THIS command (tools/pmc_traffic.py)
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')))
+        pmc_path = next(p for p in (os.path.join(ROOT, 'profiles', n) for n in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json')) if os.path.exists(p))
+        pmc = json.load(open(pmc_path))
         if dom_pick in pmc:
             roof['traffic'] = pmc[dom_pick]['bytes_fetch_x2']
-            roof['traffic_unit'] = 'bytes/launch (PMC FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, 2^18-sample batches)'
+            roof['traffic_unit'] = 'bytes/launch (PMC FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, 2^18-sample batches; %s)' % os.path.basename(pmc_path)
     except Exception:  # noqa: BLE001
         pass
 
@@ -716,6 +845,21 @@ def main():
         extra['render_ms_per_800x800_frame_early_termination_1e-4'] = (time.perf_counter() - t1) * 1e3 / n_frames
         ev, tot = render_frame_ert.last_evaluated
         extra['render_early_termination_evaluated_fraction'] = ev / max(tot, 1)
+        if world == 1 and not args.no_extra:
+            try:
+                extra.update(registry_frame_ms(tr))
+            except Exception as e:  # noqa: BLE001
+                extra['render_ms_per_800x800_frame_registry_chunk4096'] = {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
+    # north_star's named kernel as top-level scalars (the driver's record truncates nested objects)
+    if 'xr_hashgrid_fwd' in roofs:
+        extra['hash_lookup_frac_of_hbm_training_launches'] = roofs['xr_hashgrid_fwd']['frac']
+    if 'xr_hashgrid_fwd' in extra.get('roofline_kernels_render', {}):
+        extra['hash_lookup_frac_of_hbm_frame_launches'] = extra['roofline_kernels_render']['xr_hashgrid_fwd']['frac']
+    if world > 1:
+        sync = getattr(tr.net, 'grad_sync', None)
+        extra['collective'] = {'mode': tr.dp_mode, 'model': xdist.comm_model(world, step_ms=elapsed_max * 1e3 / args.steps),
+                               'bytes_reduced_per_rank_total': getattr(sync, 'bytes_reduced', None),
+                               'bytes_gathered_per_rank_total': getattr(sync, 'bytes_gathered', None)}
 
     if rank == 0:
         n_refresh = sum(1 for i in range(it0, it1) if i % sampler.update_grid_freq == 0)
@@ -763,11 +907,18 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             guarded('cpu_baseline', cpu_baseline)
             guarded('cpu_baseline_vanilla_nerf_config1', cpu_vanilla_nerf)
-        if world == 1 and not (args.no_mip and args.no_kilo and args.no_unbounded and args.no_f16):
+        if world == 1 and not (args.no_mip and args.no_kilo and args.no_unbounded and args.no_f16 and args.no_extra and args.no_strict):
             del tr
             torch.cuda.empty_cache()
         if world == 1 and not args.no_f16:
             guarded('ngp_f16_mlp_mode', lambda: ngp_f16_mlp_mode(dev, args.n_img, max(args.steps, 32)))
+            torch.cuda.empty_cache()
+        if world == 1 and not args.no_extra:
+            guarded('value_all_rows', lambda: value_all_rows(args))
+            guarded('ngp_real_lego_fixture', lambda: ngp_real_lego_fixture(dev))
+            torch.cuda.empty_cache()
+        if world == 1 and not args.no_strict:
+            guarded('ngp_tcnn_strict_defaults', lambda: ngp_tcnn_strict_defaults(dev, args.n_img, max(args.steps, 32)))
             torch.cuda.empty_cache()
         if world == 1 and not args.no_unbounded:
             guarded('ngp_config4_unbounded', lambda: ngp_config4_unbounded(dev))

@@ -49,19 +49,63 @@ dist.barrier(); dist.destroy_process_group()
 '''
 
 
-def test_two_ranks_stay_identical_replicas(tmp_path):
+@pytest.mark.parametrize('dp_mode', ['allreduce', 'zero1'])
+def test_two_ranks_stay_identical_replicas(tmp_path, dp_mode):
+    """dp_mode zero1: reduce-scatter -> Adam on the rank's shard -> all-gather (dist.Zero1GradSync; over gloo the reduce-scatter
+    is an all-reduce + slice: the protocol, the padded storage and the sharded optimiser are what runs here)"""
     import socket
     script = tmp_path / 'w.py'
     script.write_text(WORKER % ROOT)
     with socket.socket() as sk:
         sk.bind(('127.0.0.1', 0))
         port = sk.getsockname()[1]
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE='2', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE='2', HSA_ENABLE_IPC_MODE_LEGACY='0', XRNERF_DP=dp_mode)
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), [o[-1500:] for o in outs]
     assert 'replicas identical' in outs[0]
+
+
+NCCL_WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, %r)
+import torch.distributed as dist
+from xrnerf_amd import dist as xd
+rank, local, world = xd.init_from_env('nccl')          # world_size 1: RCCL is loaded and initialised, the collectives are self-copies
+if not dist.is_initialized():
+    dist.init_process_group(backend='nccl', rank=0, world_size=1)
+dev = torch.device('cuda', 0)
+a = torch.arange(1024, dtype=torch.float32, device=dev)
+dist.all_reduce(a)
+out = torch.empty(1024, dtype=torch.float32, device=dev)
+dist.reduce_scatter_tensor(out, a.clone())
+g = torch.empty(1024, dtype=torch.float32, device=dev)
+dist.all_gather_into_tensor(g, out)
+torch.cuda.synchronize()
+assert torch.equal(g, torch.arange(1024, dtype=torch.float32, device=dev))
+z = xd.Zero1GradSync(1, 0)
+p = torch.nn.Parameter(torch.ones(1001, device=dev))
+sh = z.attach(p)
+assert sh.numel() == 1004 and p.numel() == 1001 and p.data_ptr() == sh.data_ptr()
+print('rccl ok', dist.get_backend())
+dist.destroy_process_group()
+'''
+
+
+def test_rccl_backend_initialises_and_runs_the_three_collectives(tmp_path):
+    """backend 'nccl' (= RCCL on ROCm) with world_size 1 on the test box's one GPU: library load, communicator init, and the three
+    collectives the data-parallel paths use (all-reduce, reduce-scatter, all-gather) -- everything short of a second GPU"""
+    import socket
+    script = tmp_path / 'n.py'
+    script.write_text(NCCL_WORKER % ROOT)
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE='1', RANK='0', LOCAL_RANK='0',
+               HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0 and b'rccl ok nccl' in r.stdout, r.stdout.decode()[-2000:]
 
 
 def test_bench_spawns_its_own_ranks():

@@ -177,3 +177,91 @@ def test_blender_scene_directory_trains_through_the_device_ray_table(dev, O, tmp
     for _ in range(3):
         out = tr.step()
     assert np.isfinite(float(out['log_vars']['loss']))
+
+
+def test_gradient_buffers_survive_callers_that_keep_their_gradients(dev):
+    """The native fused step WRITES its gradients into two recycled buffer sets that become `.grad`.  A caller that keeps `.grad`
+    alive -- `zero_grad(set_to_none=False)`, or accumulation over several backward passes -- must still see torch semantics:
+    three accumulated steps equal the sum of the three steps' gradients taken one by one (the launch sequence XRNERF_PY_STEP=1
+    allocates fresh gradient tensors every step and is the reference here)."""
+    import os
+    from xrnerf_amd.train import Trainer
+
+    def grads_of(tr, n_steps, accumulate, keep):
+        net, out = tr.net, []
+        params = [p for p in net.parameters() if p.numel() > 0]
+        for p in params:
+            p.grad = None
+        for _ in range(n_steps):
+            net.sampler.set_iter(3)                                  # no grid refresh, no batch-size change
+            b = tr.data.next_batch()
+            o = net.train_step({k: v[None] for k, v in b.items()}, None)
+            if not accumulate:
+                if keep:
+                    for p in params:
+                        if p.grad is not None:
+                            p.grad.zero_()                           # optimizer.zero_grad(set_to_none=False)
+                else:
+                    for p in params:
+                        p.grad = None
+            o['loss'].backward()
+            out.append([p.grad.detach().clone() for p in params])
+        return out
+
+    def fresh(py):
+        if py:
+            os.environ['XRNERF_PY_STEP'] = '1'
+        else:
+            os.environ.pop('XRNERF_PY_STEP', None)
+        tr = Trainer(dev, n_img=3, H=128, W=128, ema=False)
+        tr.overlap_march = False
+        tr.net.sampler.on_sampled = None
+        for _ in range(2):
+            tr.step()                                                # past the first refresh: a real occupancy grid
+        tr.data.cur_i = 0
+        tr.data.batches_drawn = 0
+        tr.net.sampler.k1_calls = 100
+        return tr
+    try:
+        ref = grads_of(fresh(True), 3, accumulate=False, keep=False)
+        want_acc = [sum(g[i] for g in ref) for i in range(len(ref[0]))]
+        kept = grads_of(fresh(False), 3, accumulate=False, keep=True)    # zero_grad(set_to_none=False) between the steps
+        acc = grads_of(fresh(False), 3, accumulate=True, keep=True)
+    finally:
+        os.environ.pop('XRNERF_PY_STEP', None)
+    for i in range(len(want_acc)):
+        scale = float(want_acc[i].abs().max())
+        for s in range(3):
+            assert float((kept[s][i] - ref[s][i]).abs().max()) <= 1e-4 * scale, (i, s)
+        assert float((acc[2][i] - want_acc[i]).abs().max()) <= 1e-4 * scale, i
+
+
+@pytest.mark.parametrize('trained_steps', [0, 40])
+def test_chunked_frame_without_per_chunk_readback_gives_the_same_pixels(dev, trained_steps, monkeypatch):
+    """The registry's frame path (val_step -> batchify_forward in chunk = 4096 pieces, networks/nerf.py:50-69) marched without a
+    host read-back per chunk: identical pixels to the synchronous form.  trained_steps = 0: the dense initial occupancy grid
+    gives > 48 samples per ray, so chunks OVERFLOW their estimated buffers and are done again (same RNG call index)."""
+    from xrnerf_amd.train import Trainer, render_frame
+    tr = Trainer(dev, n_img=3, H=128, W=128, ema=False)
+    for _ in range(max(trained_steps, 1)):
+        tr.step()
+    net, pose = tr.net, tr.data.poses[1]
+    H = W = 160                                                    # 25 600 rays = 7 chunks of 4096
+    k1 = net.sampler.k1_calls
+    monkeypatch.setenv('XRNERF_ASYNC_CHUNKS', '0')
+    rgb_s, a_s = render_frame(net, pose, H, W, tr.data.focal * H / 128, chunk=4096)
+    calls = net.sampler.k1_calls - k1
+    for attempt in range(2):                                       # second attempt: buffers sized from the first frame's rows per ray
+        monkeypatch.setenv('XRNERF_ASYNC_CHUNKS', '1')
+        net.sampler.k1_calls = k1
+        rgb_a, a_a = render_frame(net, pose, H, W, tr.data.focal * H / 128, chunk=4096)
+        assert net.sampler.k1_calls - k1 == calls == 7
+        assert torch.equal(rgb_a, rgb_s) and torch.equal(a_a, a_s), attempt
+    assert float(a_s.max()) > 0.5
+    # a chunk whose rays all miss the occupied cells (sky rows): zero samples, background pixels, both forms
+    up = np.array(pose, dtype=np.float32).copy()
+    up[3] = [0.5, -5.0, 0.5]                                       # camera far outside, looking away: no ray enters the cube
+    for env in ('0', '1'):
+        monkeypatch.setenv('XRNERF_ASYNC_CHUNKS', env)
+        rgb_e, a_e = render_frame(net, up, 96, 96, tr.data.focal, chunk=4096)
+        assert float(a_e.abs().max()) == 0.0

@@ -79,13 +79,17 @@ extern "C" int xr_ngp_train_step(
                             n_rays, rgb_activation, density_activation, huber_delta, loss_scale, rgb_out, loss_mse, draw, stream_);
     if (rc != XR_OK) return rc;
     if ((rc = end("xr_composite_train")) != XR_OK) return rc;
-    // rows with an exactly-zero dL/d(raw) (T == 0 behind a surface) are skipped by the MLP backward AND the scatter: one list
-    uint32_t *rows, *seg, *n_live;
-    rc = xr_nerf_mlp_bwd_list_slots(ws_mlp_bwd, ws_mlp_bwd_bytes, n_rows, &rows, &seg, &n_live);
-    if (rc != XR_OK) return rc;
+    // rows with an exactly-zero dL/d(raw) (T == 0 behind a surface) are skipped by the MLP backward AND the scatter: one list.
+    // XR_MLP_LIVE=0 (measurement, read once): no list -- both run over every marched row, same results.
+    static const bool live_on = []() { const char* e = getenv("XR_MLP_LIVE"); return !(e && e[0] == '0'); }();
+    uint32_t *rows = nullptr, *seg = nullptr, *n_live = nullptr;
     if ((rc = begin("xr_live_rows")) != XR_OK) return rc;
-    rc = xr_live_rows(draw, n_rows, n_dev, seg, rows, n_live, nullptr, ld, stream_);
-    if (rc != XR_OK) return rc;
+    if (live_on) {
+        rc = xr_nerf_mlp_bwd_list_slots(ws_mlp_bwd, ws_mlp_bwd_bytes, n_rows, &rows, &seg, &n_live);
+        if (rc != XR_OK) return rc;
+        rc = xr_live_rows(draw, n_rows, n_dev, seg, rows, n_live, nullptr, ld, stream_);
+        if (rc != XR_OK) return rc;
+    }
     if ((rc = end("xr_live_rows")) != XR_OK || (rc = begin("xr_nerf_mlp_bwd")) != XR_OK) return rc;
     xr_internal_defer_mlp_reduce(overlap);
     rc = f16_mlp ? xr_nerf_mlp_bwd_f16(enc_t, ld, coords + 4, 7, n_rows, n_dev, w_density, w_color, n_hidden_density, n_hidden_color,
@@ -107,7 +111,7 @@ extern "C" int xr_ngp_train_step(
     // through xr_nerf_mlp_bwd_list_slots) AFTER handing the finer levels' gradient slice to the collective: table offsets are
     // absolute, so the level metadata is simply passed from that level on
     // the gradient slices of the scattered levels are written, not added to: no zero-fill of the 48.8-MB table gradient
-    rc = xr_hashgrid_bwd2(coords, 7, denc_t + (size_t)2 * scatter_level0 * ld, ld, n_rows, n_live, rows, n_levels - scatter_level0,
+    rc = xr_hashgrid_bwd2(coords, 7, denc_t + (size_t)2 * scatter_level0 * ld, ld, n_rows, live_on ? n_live : n_dev, rows, n_levels - scatter_level0,
                           scale_host + scatter_level0, resolution_host + scatter_level0, offset_host + scatter_level0, grad_table,
                           ws_scatter, ws_scatter_bytes, XR_SCATTER_OVERWRITE, stream_);
     if (rc != XR_OK) return rc;

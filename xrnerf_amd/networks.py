@@ -142,7 +142,8 @@ class _FusedTrainStepFn(torch.autograd.Function):
                     if split:
                         cut = 2 * int(meta.offset[split])
                         sync.ready(b.g_table[cut:])
-                        ops.hashgrid_bwd(sampler.coords[:n_rows], b.denc_t, meta, b.g_table, live=b.live, levels=(0, split), overwrite=True)
+                        ops.hashgrid_bwd(sampler.coords[:n_rows], b.denc_t, meta, b.g_table, live=b.live, n_dev=data.get('n_valid_dev'),
+                                         levels=(0, split), overwrite=True)
                         sync.ready(b.g_table[:cut])
                     else:
                         sync.ready(b.g_table)
@@ -302,17 +303,33 @@ class HashNerfNetwork(BaseNerfNetwork):
         return ret
 
     def batchify_forward(self, data, is_test=False):
-        """forward in smaller minibatches (networks/nerf.py:50-69)."""
+        """forward in smaller minibatches (networks/nerf.py:50-69).  A test-mode frame cut into several chunks (the config's
+        chunk = 4096: 157 chunks per 800x800 frame) is marched WITHOUT a host read-back per chunk (samplers.begin_async_test):
+        one check at the end of the frame, chunks whose sample buffer overflowed are done again -- same pixels as the
+        synchronous form (XRNERF_ASYNC_CHUNKS=0), which costs one device-to-host round trip per chunk."""
         N = data[self.bs_data].shape[0]
-        all_ret = {}
+        pieces = []
         for i in range(0, N, self.chunk):
             data_chunk = {}
             for k in data:
-                if data[k].shape[0] == N:
+                if torch.is_tensor(data[k]) and data[k].dim() > 0 and data[k].shape[0] == N:
                     data_chunk[k] = data[k][i:i + self.chunk]
                 else:
                     data_chunk[k] = data[k]
-            ret = self.forward(data_chunk, is_test)
+            pieces.append(data_chunk)
+        use_async = (is_test and len(pieces) > 1 and hasattr(self.sampler, 'begin_async_test') and self.sampler._streams()
+                     and os.environ.get('XRNERF_ASYNC_CHUNKS', '1') != '0')
+        if use_async:
+            self.sampler.begin_async_test()
+        rets = [self.forward(dict(c), is_test) for c in pieces]
+        if use_async:
+            for ci, k1_index in self.sampler.end_async_test():
+                after = self.sampler.k1_calls
+                self.sampler.k1_calls = k1_index                 # same jitter stream as the first attempt
+                rets[ci] = self.forward(dict(pieces[ci]), is_test)
+                self.sampler.k1_calls = after
+        all_ret = {}
+        for ret in rets:
             for k in ret:
                 all_ret.setdefault(k, []).append(ret[k])
         return {k: torch.cat(all_ret[k], 0) for k in all_ret}

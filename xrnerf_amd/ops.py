@@ -328,7 +328,7 @@ def ngp_train_step(table, wd, wc, nhd, nhc, pad_value, meta, coords, n_dev, nums
     # the backward's (count, running live total, running valid total) block sits in the MLP workspace on this path
     global LIVE_STATS
     ws_mlp, live_list, _, LIVE_STATS = _list_slots(coords.device, n_rows)
-    bufs.live = (live_list, LIVE_STATS)
+    bufs.live = (live_list, LIVE_STATS) if os.environ.get('XR_MLP_LIVE') != '0' else None     # (the native step reads the same switch)
     stage, ev = None, (None, None)
     if TIMER is not None:
         ok, stage = TIMER.native_stage()
@@ -356,6 +356,11 @@ def calc_rgb_inference(raw, coords, numsteps, bg3, rgb_act, density_act):
     n = numsteps.shape[0]
     rgb = torch.empty((n, 3), dtype=torch.float32, device=raw.device)
     alpha = torch.empty((n, 1), dtype=torch.float32, device=raw.device)
+    if raw.shape[0] == 0 or coords.shape[0] == 0:
+        # a chunk of rays that all miss the occupied cells (the sky rows of a frame marched in chunk = 4096 pieces): every
+        # per-ray count is 0 and nothing is read, but the entry point wants non-null buffers
+        raw = torch.zeros((1, 4), dtype=torch.float32, device=numsteps.device)
+        coords = torch.zeros((1, 7), dtype=torch.float32, device=numsteps.device)
     _lib.check(L.xr_calc_rgb_inference(_ptr(raw), _ptr(coords), _ptr(numsteps), float(bg3[0]), float(bg3[1]),
                                        float(bg3[2]), n, int(rgb_act), int(density_act), _ptr(rgb), _ptr(alpha),
                                        _stream()), 'xr_calc_rgb_inference')

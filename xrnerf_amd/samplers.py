@@ -191,12 +191,30 @@ class NGPGridSampler(nn.Module):
                 torch.cuda.current_stream().wait_event(pf['event'])
             slot = self._next_slot(is_training)
             k1_index = self.k1_calls
+            async_test = (not is_training) and getattr(self, '_async_test', None) is not None and self._streams()
+            if async_test:
+                # a frame marched in chunks (batchify_forward): no read-back per chunk.  The buffer is sized from the rows per
+                # ray the previous frame needed (x1.5; first frame: 48), the valid row count stays on the device, and the
+                # chunk's counter is kept for ONE check at the end of the frame (end_async_test: a chunk that overflowed its
+                # buffer is marched again with the exact size and the same RNG call index -- identical samples)
+                max_samples = min(n_rays * self.MAX_STEP, max(n_rays * 48, int(getattr(self, '_test_rows_per_ray', 0.0) * n_rays * 1.5) + 1024))
             xyz = self._xyz_buffer(max_samples, slot)
             coords, rays_index, rays_numsteps, counter = ops.rays_sampler(
                 rays_o, rays_d, self.density_grid_bitfield, aabb, self.near_distance, self.cone_angle_constant,
                 max_samples, k1_index, coords_out=self._coords_buffer(max_samples, slot),
-                small_out=self._small_buffers(n_rays, slot), xyz_out=xyz)
+                small_out=None if async_test else self._small_buffers(n_rays, slot), xyz_out=xyz)
             self.k1_calls += 1
+            if async_test:
+                self._async_test.append((counter, max_samples, k1_index, n_rays))
+                self.rays_index = rays_index
+                self.coords = coords[:max_samples]
+                self.xyz = xyz
+                self.rays_numsteps = rays_numsteps
+                data['pts'], data['viewdirs'] = self.coords[..., :3], self.coords[..., 4:]
+                data['n_valid_dev'] = counter[1:2]            # rows behind it are stale; an overflowing count is clamped by the kernels
+                if xyz is not None:
+                    data['pts_planes'] = xyz[:, :max_samples]
+                return data
             if not is_training:
                 n_valid, samples = counter.tolist()      # one host read-back per call (rays_sampler.py:72)
                 if samples > max_samples:
@@ -273,6 +291,20 @@ class NGPGridSampler(nn.Module):
         if buf is None or buf.shape[0] < rows or buf.device != self.device:
             buf = bufs[slot] = torch.empty((rows, 7), dtype=torch.float32, device=self.device)
         return buf[:rows]
+
+    def begin_async_test(self):
+        """batchify_forward(is_test=True) over several chunks: no host read-back per chunk until end_async_test"""
+        self._async_test = []
+
+    def end_async_test(self):
+        """one read-back for the whole frame -> [(chunk index, K1 call index)] of the chunks whose samples did not fit their
+        buffer (the caller renders those again through the synchronous path)"""
+        pend, self._async_test = self._async_test, None
+        if not pend:
+            return []
+        counts = torch.stack([c for c, _, _, _ in pend]).cpu().numpy()
+        self._test_rows_per_ray = max(float(counts[i, 1]) / max(pend[i][3], 1) for i in range(len(pend)))
+        return [(i, pend[i][2]) for i in range(len(pend)) if int(counts[i, 1]) > pend[i][1]]
 
     def _xyz_buffer(self, rows, slot):
         """[3, rows] planes holding the positions of the slot's coordinate rows once more (K1 writes both): the encoder's
