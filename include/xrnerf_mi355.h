@@ -66,12 +66,15 @@ int xr_rays_sampler(const float* rays_o, const float* rays_d, const uint8_t* bit
                     int32_t* rays_numsteps, uint32_t* counter2, void* workspace, size_t workspace_bytes,
                     void* stream);
 /* the same; xyz_planes (nullable): the three position columns of coords_out once more as planes of plane_stride
- * (>= max_samples) floats each -- what xr_hashgrid_fwd2 reads with coalesced loads */
+ * (>= max_samples) floats each -- what xr_hashgrid_fwd2 reads with coalesced loads.
+ * rng_chunk (0 = off): ray i draws its jitter as ray i % rng_chunk of launch number i / rng_chunk of a series of launches over
+ * rng_chunk rays each, starting at (rng_state, rng_inc) -- a frame that the reference marches in `chunk`-sized launches
+ * (networks/nerf.py:50-69; the hidden generator advances by 2^32 per launch, ray_sampler.cu:198) in ONE launch, same samples */
 int xr_rays_sampler2(const float* rays_o, const float* rays_d, const uint8_t* bitfield, uint32_t n_rays,
                      float aabb0, float aabb1, float near_distance, float cone_angle, uint32_t max_samples,
                      uint64_t rng_state, uint64_t rng_inc, float* coords_out, int32_t* rays_index,
                      int32_t* rays_numsteps, uint32_t* counter2, float* xyz_planes, uint32_t plane_stride,
-                     void* workspace, size_t workspace_bytes, void* stream);
+                     uint32_t rng_chunk, void* workspace, size_t workspace_bytes, void* stream);
 
 /* K2  compacted_coord_api (src/compacted_coord.cu:79-143, kernel :6-77).  The reference's
  * transmittance loop cannot influence any output (its `break` is commented out, :41-44), so

@@ -36,6 +36,28 @@ def test_k1_cascades_overflow_and_k2_on_the_host(O, lego, edev):
     T.test_k1_overflow_and_k2_clip(O, lego, edev)
 
 
+def test_k1_one_launch_stands_for_a_series_of_chunk_launches(lego, edev):
+    """rng_chunk: rays i of ONE launch draw the jitter they would draw as ray i % chunk of launch i / chunk of a series (the
+    reference marches a frame in `chunk`-sized launches, advancing its hidden generator once per launch): same samples"""
+    import numpy as np
+    import torch
+    from xrnerf_amd import ops, synthetic as S
+    bf = torch.from_numpy(lego['bitfield'])
+    o, d, _ = S.training_rays(S.lego_cameras(3), 700, seed=5, H=64, W=64, focal=S.LEGO_FOCAL * 64 / 800)
+    to, td = torch.from_numpy(o), torch.from_numpy(d)
+    chunk, base = 256, 11
+    c1, i1, n1, cnt1 = ops.rays_sampler(to, td, bf, (0.0, 1.0), 0.05, 1.0 / 256, 700 * 64, base, rng_chunk=chunk)
+    row = 0
+    for k, s0 in enumerate(range(0, 700, chunk)):
+        ck, ik, nk, cntk = ops.rays_sampler(to[s0:s0 + chunk].contiguous(), td[s0:s0 + chunk].contiguous(), bf, (0.0, 1.0), 0.05, 1.0 / 256,
+                                            chunk * 64, base + k)
+        m = int(cntk[1])
+        assert np.array_equal(nk[:, 0].numpy(), n1[s0:s0 + chunk, 0].numpy())
+        assert np.array_equal(ck[:m].numpy().view(np.uint32), c1[row:row + m].numpy().view(np.uint32))
+        row += m
+    assert row == int(cnt1[1]) and row > 0
+
+
 def test_compositor_on_the_host(O, lego, edev):
     import test_gpu_raymarch as T
     T.test_compositor_fwd_bwd_inference(O, lego, edev, 2, 3)          # the config's activations (16-lane groups per ray)

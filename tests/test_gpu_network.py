@@ -248,8 +248,9 @@ def test_chunked_frame_without_per_chunk_readback_gives_the_same_pixels(dev, tra
     net, pose = tr.net, tr.data.poses[1]
     H = W = 160                                                    # 25 600 rays = 7 chunks of 4096
     k1 = net.sampler.k1_calls
+    monkeypatch.setenv('XRNERF_FRAME_ONE_LAUNCH', '0')
     monkeypatch.setenv('XRNERF_ASYNC_CHUNKS', '0')
-    rgb_s, a_s = render_frame(net, pose, H, W, tr.data.focal * H / 128, chunk=4096)
+    rgb_s, a_s = render_frame(net, pose, H, W, tr.data.focal * H / 128, chunk=4096)             # the reference's loop, one read-back per chunk
     calls = net.sampler.k1_calls - k1
     for attempt in range(2):                                       # second attempt: buffers sized from the first frame's rows per ray
         monkeypatch.setenv('XRNERF_ASYNC_CHUNKS', '1')
@@ -257,6 +258,13 @@ def test_chunked_frame_without_per_chunk_readback_gives_the_same_pixels(dev, tra
         rgb_a, a_a = render_frame(net, pose, H, W, tr.data.focal * H / 128, chunk=4096)
         assert net.sampler.k1_calls - k1 == calls == 7
         assert torch.equal(rgb_a, rgb_s) and torch.equal(a_a, a_s), attempt
+    # the default: the whole frame as one launch per kernel, K1 drawing each ray's jitter as its chunk's launch would
+    monkeypatch.delenv('XRNERF_FRAME_ONE_LAUNCH')
+    net.sampler.k1_calls = k1
+    rgb_1, a_1 = render_frame(net, pose, H, W, tr.data.focal * H / 128, chunk=4096)
+    assert net.sampler.k1_calls - k1 == 7
+    assert torch.equal(rgb_1, rgb_s) and torch.equal(a_1, a_s)
+    monkeypatch.setenv('XRNERF_FRAME_ONE_LAUNCH', '0')
     assert float(a_s.max()) > 0.5
     # a chunk whose rays all miss the occupied cells (sky rows): zero samples, background pixels, both forms
     up = np.array(pose, dtype=np.float32).copy()

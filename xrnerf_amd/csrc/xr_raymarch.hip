@@ -113,14 +113,18 @@ __device__ inline Ray rm_load_ray(const float* __restrict__ o, const float* __re
 // then dominates and a wave lasts as long as the longest of 256 rays instead of 64.
 __global__ __launch_bounds__(RM_BLOCK) void k1_count(
     uint32_t n_rays, float lo, float hi, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
-    const uint8_t* __restrict__ bitfield, float cone, float near_distance, xr_pcg32 rng,
+    const uint8_t* __restrict__ bitfield, float cone, float near_distance, xr_pcg32 rng, uint32_t rng_chunk,
     uint32_t* __restrict__ cnt, uint32_t* __restrict__ local_off, float* __restrict__ start_t,
     uint32_t* __restrict__ block_tot, float* __restrict__ tlist) {
     __shared__ uint32_t lds4[4];
     const uint32_t i = blockIdx.x * RM_BLOCK + threadIdx.x;
     uint32_t j = 0; float startt = 0.f;
     if (i < n_rays) {
-        rng.advance((uint64_t)(i * 8u));                                     // :31
+        // :31.  rng_chunk > 0: ray i draws what it would draw as ray i % rng_chunk of launch i / rng_chunk of a series of
+        // launches over rng_chunk rays each (the generator moves on by 2^32 per launch, :198) -- a frame the reference marches
+        // in chunk-sized launches (networks/nerf.py:50-69) becomes ONE launch with the same samples
+        if (rng_chunk) rng.advance(((uint64_t)(i / rng_chunk) << 32) + (uint64_t)((i % rng_chunk) * 8u));
+        else rng.advance((uint64_t)(i * 8u));
         Ray r = rm_load_ray(rays_o, rays_d, i);
         float tmin = fmaxf(rm_aabb_tmin(lo, hi, r), near_distance);          // :42-46
         startt = tmin;
@@ -297,7 +301,7 @@ extern "C" int xr_rays_sampler2(const float* rays_o, const float* rays_d, const 
                                 float aabb0, float aabb1, float near_distance, float cone_angle, uint32_t max_samples,
                                 uint64_t rng_state, uint64_t rng_inc, float* coords_out, int32_t* rays_index,
                                 int32_t* rays_numsteps, uint32_t* counter2, float* xyz_planes, uint32_t plane_stride,
-                                void* workspace, size_t workspace_bytes, void* stream_) {
+                                uint32_t rng_chunk, void* workspace, size_t workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     XR_REQUIRE(rays_o && rays_d && bitfield && coords_out && rays_index && rays_numsteps && counter2, "null pointer");
     XR_REQUIRE(!xyz_planes || plane_stride >= max_samples, "a position plane holds max_samples values");
@@ -307,7 +311,7 @@ extern "C" int xr_rays_sampler2(const float* rays_o, const float* rays_d, const 
     xr_pcg32 rng{rng_state, rng_inc};
     const uint32_t nb = xr_div_up(n_rays, RM_BLOCK);
     hipLaunchKernelGGL(k1_count, dim3(nb), dim3(RM_BLOCK), 0, stream, n_rays, aabb0, aabb1, rays_o, rays_d, bitfield,
-                       cone_angle, near_distance, rng, w.cnt, w.local_off, w.start_t, w.block_tot, w.tlist);
+                       cone_angle, near_distance, rng, rng_chunk, w.cnt, w.local_off, w.start_t, w.block_tot, w.tlist);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, nb, w.block_tot, max_samples, w.block_base, w.info);
     hipLaunchKernelGGL(k1_write, dim3(nb), dim3(RM_BLOCK), 0, stream, n_rays, aabb0, aabb1, rays_o, rays_d, bitfield,
                        cone_angle, max_samples, w.cnt, w.local_off, w.start_t, w.block_base, w.info, coords_out,
@@ -322,7 +326,7 @@ extern "C" int xr_rays_sampler(const float* rays_o, const float* rays_d, const u
                                int32_t* rays_numsteps, uint32_t* counter2, void* workspace, size_t workspace_bytes,
                                void* stream_) {
     return xr_rays_sampler2(rays_o, rays_d, bitfield, n_rays, aabb0, aabb1, near_distance, cone_angle, max_samples, rng_state, rng_inc,
-                            coords_out, rays_index, rays_numsteps, counter2, nullptr, 0, workspace, workspace_bytes, stream_);
+                            coords_out, rays_index, rays_numsteps, counter2, nullptr, 0, 0, workspace, workspace_bytes, stream_);
 }
 
 // ------------------------------------------------------------------ K2 re-pack (compacted_coord.cu:22-76)

@@ -137,7 +137,7 @@ extern "C" int xr_ngp_prefetch(const float* rays_rgb_rows, uint32_t n_rays, uint
     if (rc != XR_OK) return rc;
     xr_pcg32_host_state(9121, k1_call_index, &st, &inc);
     rc = xr_rays_sampler2(rays_o, rays_d, bitfield, n_rays, aabb0, aabb1, near_distance, cone_angle, max_samples, st, inc, coords_out,
-                          rays_index, rays_numsteps, counter2, xyz_planes, plane_stride, workspace, workspace_bytes, stream_);
+                          rays_index, rays_numsteps, counter2, xyz_planes, plane_stride, 0, workspace, workspace_bytes, stream_);
     if (rc != XR_OK) return rc;
     rc = xr_clip_numsteps(rays_numsteps, counter2, n_rays, max_compacted, numsteps_clipped, n_valid_dev, max_compacted, 1, stream_);
     if (rc != XR_OK) return rc;

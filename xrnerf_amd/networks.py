@@ -308,6 +308,17 @@ class HashNerfNetwork(BaseNerfNetwork):
         one check at the end of the frame, chunks whose sample buffer overflowed are done again -- same pixels as the
         synchronous form (XRNERF_ASYNC_CHUNKS=0), which costs one device-to-host round trip per chunk."""
         N = data[self.bs_data].shape[0]
+        from .samplers import NGPGridSampler
+        if (is_test and N > self.chunk and type(self.sampler) is NGPGridSampler and os.environ.get('XRNERF_FRAME_ONE_LAUNCH', '1') != '0'):
+            # The whole frame as ONE launch per kernel with the SAME pixels as the chunk loop: encode, MLP and compositor are
+            # per-sample / per-ray maps, and K1 -- whose hidden generator the loop would advance once per chunk -- draws every
+            # ray's jitter as the ray's chunk-th launch would (`frame_chunk`).  61 ms -> 6 ms per 800x800 frame at chunk = 4096
+            # (157 chunks x ~0.4 ms of launches); XRNERF_FRAME_ONE_LAUNCH=0 runs the loop.
+            self.sampler.frame_chunk = int(self.chunk)
+            try:
+                return self.forward(dict(data), is_test)
+            finally:
+                self.sampler.frame_chunk = 0
         pieces = []
         for i in range(0, N, self.chunk):
             data_chunk = {}

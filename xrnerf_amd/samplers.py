@@ -199,11 +199,14 @@ class NGPGridSampler(nn.Module):
                 # buffer is marched again with the exact size and the same RNG call index -- identical samples)
                 max_samples = min(n_rays * self.MAX_STEP, max(n_rays * 48, int(getattr(self, '_test_rows_per_ray', 0.0) * n_rays * 1.5) + 1024))
             xyz = self._xyz_buffer(max_samples, slot)
+            # test mode, `frame_chunk` set by the network: this launch stands for ceil(n_rays / frame_chunk) launches of the
+            # reference's chunked frame loop -- same jitter per ray, the hidden generator moves on by as many launches
+            rng_chunk = 0 if is_training else int(getattr(self, 'frame_chunk', 0) or 0)
             coords, rays_index, rays_numsteps, counter = ops.rays_sampler(
                 rays_o, rays_d, self.density_grid_bitfield, aabb, self.near_distance, self.cone_angle_constant,
                 max_samples, k1_index, coords_out=self._coords_buffer(max_samples, slot),
-                small_out=None if async_test else self._small_buffers(n_rays, slot), xyz_out=xyz)
-            self.k1_calls += 1
+                small_out=None if async_test else self._small_buffers(n_rays, slot), xyz_out=xyz, rng_chunk=rng_chunk)
+            self.k1_calls += (n_rays + rng_chunk - 1) // rng_chunk if rng_chunk else 1
             if async_test:
                 self._async_test.append((counter, max_samples, k1_index, n_rays))
                 self.rays_index = rays_index
@@ -223,7 +226,7 @@ class NGPGridSampler(nn.Module):
                     coords, rays_index, rays_numsteps, counter = ops.rays_sampler(
                         rays_o, rays_d, self.density_grid_bitfield, aabb, self.near_distance, self.cone_angle_constant,
                         max_samples, k1_index, coords_out=self._coords_buffer(max_samples, slot),
-                        small_out=self._small_buffers(n_rays, slot), xyz_out=xyz)
+                        small_out=self._small_buffers(n_rays, slot), xyz_out=xyz, rng_chunk=rng_chunk)
                     n_valid, samples = counter.tolist()
                 self._test_rows_seen = samples
             elif self._streams():
