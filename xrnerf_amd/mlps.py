@@ -161,6 +161,19 @@ class HashNerfMLP(nn.Module):
         planes = data.get('pts_planes')
         if planes is not None and (planes.dim() != 2 or planes.shape[0] != 3 or planes.shape[1] != pts.shape[0] or pts.shape[0] == 3):
             planes = None
+        if not torch.is_grad_enabled() and ops._on_device(pts) and torch.is_tensor(pts) and pts.is_cuda:
+            # inference (frames): no autograd node, intermediates in grow-only persistent buffers (ops._buf).  `raw` is valid until
+            # the next inference call of this process -- the renderer consumes it right away.
+            n = pts.shape[0]
+            ld = (n + 63) // 64 * 64
+            nhd, nhc = self.density_net.n_hidden, self.color_net.n_hidden
+            n_dev = data.get('n_valid_dev')
+            enc_t = ops._buf(pts.device, (self.embedder_pos.meta.n_output_dims, ld), 'infer_enc')
+            raw = ops._buf(pts.device, (n, 4), 'infer_raw')
+            ops.hashgrid_fwd(self.embedder_pos.params.detach(), planes if planes is not None else pts, self.embedder_pos.meta, enc_t=enc_t,
+                             ld=ld, n_dev=n_dev)
+            return ops.nerf_mlp_fwd(enc_t, dirs, n, self.density_net.params.detach(), self.color_net.params.detach(), nhd, nhc,
+                                    self.pad_value, raw=raw, n_dev=n_dev)
         return _NerfMLPFn.apply(self.embedder_pos.params, self.density_net.params, self.color_net.params, pts, dirs,
                                 self, data.get('n_valid_dev'), planes)
 

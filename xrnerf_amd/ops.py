@@ -185,6 +185,22 @@ def _ws(device, nbytes, tag):
     return w
 
 
+def _buf(device, shape, tag):
+    """grow-only fp32 scratch of the given shape (a view of a persistent buffer per tag): frame-sized intermediates whose size
+    changes from frame to frame (13-15 M samples: 1.7 GB of encoded features) would otherwise send the caching allocator to
+    hipMalloc / hipFree -- device-synchronising calls of ~10 ms -- on most frames"""
+    n = 1
+    for v in shape:
+        n *= int(v)
+    key = (str(device), tag)
+    have = _workspaces.get(key)
+    need = 4 * max(n, 1) + 256
+    # grow with 25 % headroom: frames of one sequence differ by a few per cent in their sample counts
+    w = _ws(device, need if (have is not None and have.numel() >= need) else need + need // 4, tag)
+    off = (-w.data_ptr()) % 16
+    return w[off:off + 4 * n].view(torch.float32).view(*shape)
+
+
 def pcg32_host_state(ncalls, seed=9121):
     s, i = C.c_uint64(), C.c_uint64()
     _lib.load().xr_pcg32_host_state(seed, ncalls, C.byref(s), C.byref(i))
