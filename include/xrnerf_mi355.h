@@ -302,7 +302,7 @@ int xr_ngp_train_step(const float* table, const float* w_density, const float* w
                       float* draw, float* denc_t, float* rgb_out, float* zero_block, size_t zero_floats, float* grad_w_density,
                       float* grad_w_color, float* loss_mse, float* grad_table, size_t table_floats, int zero_draw,
                       void* ws_mlp_bwd, size_t ws_mlp_bwd_bytes, void* ws_scatter, size_t ws_scatter_bytes, int scatter_level0,
-                      const float* xyz_planes, uint32_t plane_stride,
+                      const float* xyz_planes, uint32_t plane_stride, const char* mark_entry, void* mark_event,
                       const char* timed_entry, void* timing_begin, void* timing_end, void* stream);
 /* xyz_planes (nullable): the positions of `coords` once more as three planes of plane_stride floats (xr_rays_sampler2 /
  * xr_ngp_prefetch write them); the encoder then reads them with coalesced loads (xr_hashgrid_fwd2). */
@@ -311,7 +311,10 @@ int xr_ngp_train_step(const float* table, const float* w_density, const float* w
  * events (xr_timing_event_create) -- bench.py's live duration of the dominant kernel inside the timed region.
  * XR_STEP_OVERLAP=1 moves the reduction of the MLP backward's partials to a helper stream (measured slower on the MI355X,
  * kept as a switch). */
+/* mark_entry / mark_event (nullable): mark_event is recorded on `stream` right behind the launches of the named entry point, so
+ * that work on another stream can be started from that point of the step (xr_stream_wait_event). */
 void* xr_timing_event_create(void);
+int xr_stream_wait_event(void* stream, void* event);
 int xr_timing_event_destroy(void* event);
 int xr_timing_event_elapsed_ms(void* begin, void* end, float* ms);
 /* the second half of xr_nerf_mlp_bwd[_f16] on its own (sum of the per-workgroup dW partials in `workspace` into the gradients) */

@@ -48,8 +48,9 @@ SIGNATURES = {
                                _vp, _sz, _u32, _vp, _vp, _vp, _vp, _u32, _vp]),
     'xr_ngp_train_step': (_i32, [_vp, _vp, _vp, _i32, _i32, _f, _i32, _i32, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _u32, _vp, _vp, _vp,
                                  _vp, _i32, _i32, _f, _f, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _sz, _i32, _vp, _sz,
-                                 _vp, _sz, _i32, _vp, _u32, C.c_char_p, _vp, _vp, _vp]),
+                                 _vp, _sz, _i32, _vp, _u32, C.c_char_p, _vp, C.c_char_p, _vp, _vp, _vp]),
     'xr_timing_event_create': (_vp, []),
+    'xr_stream_wait_event': (_i32, [_vp, _vp]),
     'xr_timing_event_destroy': (_i32, [_vp]),
     'xr_timing_event_elapsed_ms': (_i32, [_vp, _vp, _vp]),
     'xr_nerf_mlp_bwd_reduce': (_i32, [_vp, _u32, _vp, _vp, _vp]),

@@ -21,6 +21,13 @@ extern "C" int xr_timing_event_elapsed_ms(void* a, void* b, float* ms) {
     return XR_OK;
 }
 
+// order `stream` behind a recorded event (a caller without a HIP binding holds events from xr_timing_event_create)
+extern "C" int xr_stream_wait_event(void* stream, void* event) {
+    XR_REQUIRE(event, "null event");
+    XR_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+    return XR_OK;
+}
+
 static bool stage_is(const char* timed, const char* name) { return timed && strcmp(timed, name) == 0; }
 
 extern "C" int xr_ngp_train_step(
@@ -33,7 +40,7 @@ extern "C" int xr_ngp_train_step(
     float* zero_block, size_t zero_floats, float* grad_w_density, float* grad_w_color, float* loss_mse,
     float* grad_table, size_t table_floats, int zero_draw,
     void* ws_mlp_bwd, size_t ws_mlp_bwd_bytes, void* ws_scatter, size_t ws_scatter_bytes, int scatter_level0,
-    const float* xyz_planes, uint32_t plane_stride,
+    const float* xyz_planes, uint32_t plane_stride, const char* mark_entry, void* mark_event,
     const char* timed_entry, void* timing_begin, void* timing_end, void* stream_) {
     XR_REQUIRE(table && w_density && w_color && coords && rays_numsteps && rays_numsteps_compacted && bg_color && target &&
                alpha_mask && density_grid_mean && enc_t && raw && draw && denc_t && rgb_out && zero_block && grad_w_density &&
@@ -42,6 +49,7 @@ extern "C" int xr_ngp_train_step(
     XR_REQUIRE(mlp_mode >= 0 && mlp_mode <= 2, "mlp_mode is 0 (fp32 MFMA), 1 (fp16) or 2 (fp32 forward on split bf16 operands)");
     XR_REQUIRE(scatter_level0 >= 0 && scatter_level0 < n_levels, "scatter_level0 outside [0, n_levels)");
     XR_REQUIRE(!timed_entry || (timing_begin && timing_end), "a timed entry point needs its two events");
+    XR_REQUIRE(!mark_entry || mark_event, "a marked entry point needs its event");
     hipStream_t stream = (hipStream_t)stream_;
     // XR_STEP_OVERLAP=1 (measurement; default off): the reduction of the MLP backward's per-workgroup partials (first read by
     // the optimiser) goes to a helper stream beside the scatter, forked from / joined into the caller's stream with events.
@@ -57,7 +65,13 @@ extern "C" int xr_ngp_train_step(
         for (hipEvent_t* e : {&ev_fork1, &ev_red}) XR_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
     auto begin = [&](const char* name) -> int { if (stage_is(timed_entry, name)) XR_HIP(hipEventRecord((hipEvent_t)timing_begin, stream)); return XR_OK; };
-    auto end = [&](const char* name) -> int { if (stage_is(timed_entry, name)) XR_HIP(hipEventRecord((hipEvent_t)timing_end, stream)); return XR_OK; };
+    // mark_entry / mark_event: the event is recorded on `stream` right behind the named entry point's launches (the trainer
+    // starts the next batch's side-stream march from there instead of beside the fused-MLP forward)
+    auto end = [&](const char* name) -> int {
+        if (stage_is(timed_entry, name)) XR_HIP(hipEventRecord((hipEvent_t)timing_end, stream));
+        if (mark_event && stage_is(mark_entry, name)) XR_HIP(hipEventRecord((hipEvent_t)mark_event, stream));
+        return XR_OK;
+    };
     int rc;
     // coordinate rows {pos3, dt, dir3}: positions and directions are consumed in place (row stride 7)
     if ((rc = begin("xr_hashgrid_fwd")) != XR_OK) return rc;

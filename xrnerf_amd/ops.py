@@ -330,7 +330,7 @@ class TrainStepBuffers:
 
 
 def ngp_train_step(table, wd, wc, nhd, nhc, pad_value, meta, coords, n_dev, numsteps, numsteps_c, bg, target, alpha,
-                   density_grid_mean, rgb_act, density_act, bufs, huber_delta=0.1, loss_scale=5.0, scatter_level0=0, xyz=None):
+                   density_grid_mean, rgb_act, density_act, bufs, huber_delta=0.1, loss_scale=5.0, scatter_level0=0, xyz=None, mark=None):
     """the device work of one HashNerfNetwork training step as one native call (xr_ngp_train_step): encode -> MLP -> K3 +
     Huber + K4 -> MLP backward -> table scatter into `bufs` (TrainStepBuffers).  Returns rgb [n_rays,3] (a view of bufs.rgb).
     scatter_level0 > 0 (data parallel): only hash levels [scatter_level0, n_levels) are scattered; the caller finishes with
@@ -364,9 +364,15 @@ def ngp_train_step(table, wd, wc, nhd, nhc, pad_value, meta, coords, n_dev, nums
             _ptr(bufs.zero_block), bufs.zero_block.numel(), _ptr(bufs.g_wd), _ptr(bufs.g_wc), _ptr(bufs.loss_mse),
             _ptr(bufs.g_table), bufs.g_table.numel(), 0 if n_dev is not None else 1,
             _ptr(ws_mlp), ws_mlp.numel(), _ptr(ws_sc), ws_sc.numel(), int(scatter_level0),
-            _ptr(xyz), xyz.shape[1] if xyz is not None else 0, stage.encode() if stage else None,
+            _ptr(xyz), xyz.shape[1] if xyz is not None else 0, mark[0].encode() if mark else None, mark[1].h if mark else None,
+            stage.encode() if stage else None,
             ev[0].h if stage else None, ev[1].h if stage else None, _stream()), 'xr_ngp_train_step')
     return bufs.rgb[:n_rays]
+
+
+def stream_wait_event(stream, cevent):
+    """order a torch stream behind a library event (_CEvent)"""
+    _lib.check(_lib.load().xr_stream_wait_event(C.c_void_p(stream.cuda_stream), cevent.h), 'xr_stream_wait_event')
 
 
 def calc_rgb_inference(raw, coords, numsteps, bg3, rgb_act, density_act):

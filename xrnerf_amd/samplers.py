@@ -398,7 +398,7 @@ class NGPGridSampler(nn.Module):
         self._prefetched = {'rays_o': rays_o, 'max_samples': max_samples, 'out': out, 'event': done, 'host': host, 'clipped': clipped,
                             'xyz': xyz}
 
-    def prefetch_native(self, rows, n_rays, batch_call_index, batch_out, buffer_free_event=None):
+    def prefetch_native(self, rows, n_rays, batch_call_index, batch_out, buffer_free_event=None, start_event=None):
         """`prefetch` with the batch assembly folded in, as ONE native call (xr_ngp_prefetch: make_batch + K1 + K2 clip + counter
         copy) on the current (side) stream.  -> the batch dict (views of `batch_out`)."""
         aabb = (float(self.aabb_range[0]), float(self.aabb_range[1]))
@@ -411,6 +411,8 @@ class NGPGridSampler(nn.Module):
             side.wait_event(ev)
         if buffer_free_event is not None:
             side.wait_event(buffer_free_event)
+        if start_event is not None:
+            ops.stream_wait_event(side, start_event)        # a point inside the current step (library event)
         slot = self._next_slot(True)
         xyz = self._xyz_buffer(max_samples, slot)
         batch, out, clipped = ops.ngp_prefetch(rows, n_rays, batch_call_index, batch_out, self.density_grid_bitfield, aabb,

@@ -216,6 +216,15 @@ class Trainer:
         # run K1 of the next batch on a side stream under this step's backward (XRNERF_OVERLAP_MARCH=0: serial)
         self.overlap_march = os.environ.get('XRNERF_OVERLAP_MARCH', '1') != '0'
         self._next_batch = None
+        # where in the step the next batch's side-stream march may start: behind the named entry point of the fused step
+        # (XRNERF_PREFETCH_AFTER; default none = as soon as the step is enqueued).  Measured (profiles/r03_prefetch_start_point.txt,
+        # ms/step): none 0.548, behind the encode 0.554, behind the fused-MLP forward 0.552, behind the compositor 0.582, behind
+        # the MLP backward 0.620 -- the 200-us march beside the forward costs that kernel ~10 us, but started any later it is not
+        # finished when the next iteration's encode needs its rows
+        after = os.environ.get('XRNERF_PREFETCH_AFTER', 'none')
+        if after not in ('none', 'xr_hashgrid_fwd', 'xr_nerf_mlp_fwd', 'xr_composite_train', 'xr_live_rows', 'xr_nerf_mlp_bwd'):
+            raise ValueError('XRNERF_PREFETCH_AFTER: unknown entry point %r' % after)
+        self.net._step_mark = (after, ops._CEvent()) if (after != 'none' and device.type == 'cuda') else None
         self._ev_done = [None, None]   # completion events of the last two iterations
         self._bbufs = [None, None]
         self._one = None
@@ -271,7 +280,8 @@ class Trainer:
                 data.cur_i = 0
             with torch.cuda.stream(side):
                 nb = net.sampler.prefetch_native(data.rays_rgb[data.cur_i:data.cur_i + n], n, data.batches_drawn, bufs,
-                                                 buffer_free_event=self._ev_done[1])
+                                                 buffer_free_event=self._ev_done[1],
+                                                 start_event=net._step_mark[1] if getattr(net, '_step_mark', None) else None)
             data.cur_i += n
             data.batches_drawn += 1
             self._next_batch = nb
