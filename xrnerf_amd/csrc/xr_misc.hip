@@ -1,6 +1,7 @@
 // Library plumbing (error string, version, RNG host helper) and the small kernels on either side
 // of the path: ray generation, Huber loss gradient, fused Adam(+EMA).
 #include "xr_common.h"
+#include <cstdlib>
 #include <cstdarg>
 
 static thread_local char g_err[512] = "";
@@ -168,6 +169,20 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
 // up to 4 parameter tensors in ONE launch (the three tensors of HashNerfMLP: 12.2 M + 3 K + 7 K floats):
 // block ranges are assigned proportionally, every tensor gets at least one block
 struct AdamTensors { float* p[4]; const float* g[4]; float* m[4]; float* v[4]; float* ema[4]; unsigned long long n[4]; unsigned first_block[5]; };
+// NT: the optimiser states (m, v, EMA copy) and the gradient -- 390 of the 439 MB this launch moves, each byte touched once per
+// step -- go through non-temporal loads / stores so that the parameters, which the next step's gather reads right away, are
+// what the caches keep (XR_ADAM_NT=0 switches it off; measured in the training loop, profiles/r03_adam_nontemporal.txt:
+// 0.534 -> 0.520 ms per step: the gather 93 -> 89 us, the scatter 113 -> 108 us, this launch 71 -> 70 us)
+typedef float am_f4 __attribute__((ext_vector_type(4)));
+template <bool NT> __device__ __forceinline__ float4 am_ld(const float* p, size_t i) {
+    if (NT) { const am_f4 r = __builtin_nontemporal_load(reinterpret_cast<const am_f4*>(p) + i); return make_float4(r.x, r.y, r.z, r.w); }
+    return reinterpret_cast<const float4*>(p)[i];
+}
+template <bool NT> __device__ __forceinline__ void am_st(float* p, size_t i, const float4 v) {
+    if (NT) { am_f4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; __builtin_nontemporal_store(r, reinterpret_cast<am_f4*>(p) + i); }
+    else reinterpret_cast<float4*>(p)[i] = v;
+}
+template <bool NT>
 __global__ __launch_bounds__(256) void k_adam_multi(AdamTensors t, int nt, float b1, float b2, float step_size, float bc2s,
                                                      float eps, float wd, float mom, float gs) {
     int k = 0;
@@ -178,18 +193,18 @@ __global__ __launch_bounds__(256) void k_adam_multi(AdamTensors t, int nt, float
     float* __restrict__ m = t.m[k]; float* __restrict__ v = t.v[k]; float* __restrict__ ema = t.ema[k];
     const size_t n = t.n[k], n4 = n / 4;
     for (size_t i = blk * 256ull + threadIdx.x; i < n4; i += (size_t)nblk * 256) {
-        float4 pp = ((float4*)p)[i], mm = ((float4*)m)[i], vv = ((float4*)v)[i];
-        const float4 gg = ((const float4*)g)[i];
+        float4 pp = ((float4*)p)[i], mm = am_ld<NT>(m, i), vv = am_ld<NT>(v, i);
+        const float4 gg = am_ld<NT>(g, i);
         adam1(pp.x, gg.x, mm.x, vv.x, b1, b2, step_size, bc2s, eps, wd, gs);
         adam1(pp.y, gg.y, mm.y, vv.y, b1, b2, step_size, bc2s, eps, wd, gs);
         adam1(pp.z, gg.z, mm.z, vv.z, b1, b2, step_size, bc2s, eps, wd, gs);
         adam1(pp.w, gg.w, mm.w, vv.w, b1, b2, step_size, bc2s, eps, wd, gs);
-        ((float4*)p)[i] = pp; ((float4*)m)[i] = mm; ((float4*)v)[i] = vv;
+        ((float4*)p)[i] = pp; am_st<NT>(m, i, mm); am_st<NT>(v, i, vv);
         if (ema) {
-            float4 e = ((float4*)ema)[i];
+            float4 e = am_ld<NT>(ema, i);
             e.x = (1.f - mom) * e.x + mom * pp.x; e.y = (1.f - mom) * e.y + mom * pp.y;
             e.z = (1.f - mom) * e.z + mom * pp.z; e.w = (1.f - mom) * e.w + mom * pp.w;
-            ((float4*)ema)[i] = e;
+            am_st<NT>(ema, i, e);
         }
     }
     if (blk == 0 && threadIdx.x < (n & 3)) {
@@ -216,8 +231,11 @@ extern "C" int xr_adam_step_multi(int n_tensors, float* const* p, const float* c
     }
     for (int k = n_tensors; k <= 4; ++k) t.first_block[k] = blocks;
     const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
-    hipLaunchKernelGGL(k_adam_multi, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, t, n_tensors, beta1, beta2, lr / bc1,
-                       sqrtf(bc2), eps, weight_decay, ema_momentum, grad_scale);
+    static const bool nt = []() { const char* e = getenv("XR_ADAM_NT"); return !(e && e[0] == '0'); }();     // default on
+    if (nt) hipLaunchKernelGGL(k_adam_multi<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, t, n_tensors, beta1, beta2, lr / bc1,
+                               sqrtf(bc2), eps, weight_decay, ema_momentum, grad_scale);
+    else hipLaunchKernelGGL(k_adam_multi<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, t, n_tensors, beta1, beta2, lr / bc1,
+                            sqrtf(bc2), eps, weight_decay, ema_momentum, grad_scale);
     XR_LAUNCH_CHECK();
     return XR_OK;
 }
