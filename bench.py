@@ -433,10 +433,15 @@ def registry_frame_ms(tr, H=800, W=800, frames=6):
         try:
             with torch.no_grad():
                 r = net.val_step({'poses': poses, 'images': images})
-            out[key] = float(np.mean(r['elapsed_time'][2:])) * 1e3          # the first two frames size the persistent buffers
+            ts = np.array(r['elapsed_time'][2:]) * 1e3                      # the first two frames size the persistent buffers
+            out[key] = float(np.median(ts))
+            out[key + '_mean_min_max'] = [float(ts.mean()), float(ts.min()), float(ts.max())]
         finally:
             os.environ.pop('XRNERF_FRAME_ONE_LAUNCH', None)
     out['registry_chunk'] = int(net.chunk)
+    out['registry_frame_note'] = ('median over %d frames of val_step\'s own per-frame timer (pipeline + batchify_forward + device-to-host copy); between two '
+                                  'frames val_step multiplies the image by its alpha on the host (~5 ms of numpy, outside the timer, as in the reference), '
+                                  'the GPU idles meanwhile and single frames take up to 4x the median (clock ramp)' % frames)
     return out
 
 

@@ -147,6 +147,12 @@ int xr_generate_grid_samples(const float* density_grid, uint32_t ema_step, uint3
                              uint32_t n_cascades /* = max_cascade+1 */, float thresh, float aabb0, float aabb1,
                              uint64_t rng_state, uint64_t rng_inc, float* positions /*[n,3]*/,
                              int32_t* indices /*[n]*/, void* stream);
+/* the same with strides on the positions: coordinate d of point i goes to positions[i * pos_row_stride + d * pos_comp_stride]
+ * ((3, 1): the rows above; (1, plane size): three planes, the layout xr_hashgrid_fwd2 reads with coalesced loads -- the sampler
+ * writes both K6 calls of a grid refresh into one plane buffer and queries the density without a concatenation) */
+int xr_generate_grid_samples2(const float* density_grid, uint32_t ema_step, uint32_t n_elements, uint32_t n_cascades,
+                              float thresh, float aabb0, float aabb1, uint64_t rng_state, uint64_t rng_inc,
+                              float* positions, uint32_t pos_row_stride, uint32_t pos_comp_stride, int32_t* indices, void* stream);
 /* K7  mark_untrained_density_grid_api (src/mark_untrained_density_grid.cu:54-82): writes 0 where
  * the cell is visible from any training camera, -1 elsewhere (the reference leaves visible cells of
  * its UNINITIALISED buffer untouched when they happen to be >= 0) */

@@ -32,6 +32,29 @@ def test_training_trajectory_follows_the_reference_python_stack(dev):
     assert net._fused_ok()
     rec = {k: [] for k in ('n_rays', 'marched', 'loss', 'psnr', 'popcount')}
     bitfields = {}
+    # The first refresh depends on the initial weights only, and differs from the fixture's in a few hundred of 2 M bits (device exp
+    # against libm's at the occupancy threshold).  Right behind it -- before iteration 0 marches -- cascade 0 of the bitfield is
+    # replaced by the fixture's: iterations 0..15 then march the SAME occupancy with the same rays and the same jitter stream,
+    # so their sample counts (and the batch size adapted from them at iteration 15) must equal the fixture's exactly.
+    from xrnerf_amd import ops
+    real_update, seeded = ops.update_bitfield, {}
+
+    def update_then_seed(grid, mean, bitfield):
+        out = real_update(grid, mean, bitfield)
+        if not seeded:
+            seeded['own'] = bitfield[:128 ** 3 // 8].cpu().numpy().copy()
+            bitfield[:128 ** 3 // 8].copy_(torch.from_numpy(fx['bitfield_it0']).to(bitfield.device))
+        return out
+    ops.update_bitfield = update_then_seed
+    try:
+        rec, bitfields = _run(net, opt, poses, fx, dev, Hn, rec, bitfields)
+    finally:
+        ops.update_bitfield = real_update
+    bitfields[0] = seeded['own']
+    _check(rec, bitfields, fx, net)
+
+
+def _run(net, opt, poses, fx, dev, Hn, rec, bitfields):
     for it in range(int(fx['n_iters'])):
         n_rays = int(net.sampler.n_rays_per_batch)
         b = Hn.batch(poses, n_rays, it, dev)
@@ -48,6 +71,10 @@ def test_training_trajectory_follows_the_reference_python_stack(dev):
         rec['popcount'].append(int(np.unpackbits(bf).sum()))
         if it % 16 == 0:
             bitfields[it] = bf[:128 ** 3 // 8].copy()
+    return rec, bitfields
+
+
+def _check(rec, bitfields, fx, net):
     print('rays/batch', rec['n_rays'][::8], 'ref', fx['n_rays'][::8].tolist())
     print('marched   ', rec['marched'][::8], 'ref', fx['marched'][::8].tolist())
     print('loss      ', [round(v, 4) for v in rec['loss'][::8]], 'ref', [round(float(v), 4) for v in fx['loss'][::8]])
@@ -55,8 +82,10 @@ def test_training_trajectory_follows_the_reference_python_stack(dev):
     # occupancy threshold
     ham0 = int(np.unpackbits(bitfields[0] ^ fx['bitfield_it0']).sum())
     assert ham0 <= 2e-4 * 128 ** 3, ham0
-    assert abs(rec['marched'][0] - int(fx['marched'][0])) <= 2e-3 * int(fx['marched'][0])
-    assert rec['n_rays'][:16] == fx['n_rays'][:16].tolist()
+    # iterations 0..15 on the fixture's first bitfield: exact sample counts, hence the exact batch size from iteration 16 on
+    assert rec['marched'][:16] == fx['marched'][:16].tolist(), (rec['marched'][:16], fx['marched'][:16].tolist())
+    assert rec['n_rays'][:17] == fx['n_rays'][:17].tolist()
+    # (from the refresh at iteration 16 on the occupancy depends on 16 optimiser steps of weights: the looser bounds below)
     # whole trajectory
     for it in range(int(fx['n_iters'])):
         assert abs(rec['n_rays'][it] - int(fx['n_rays'][it])) <= 128, (it, rec['n_rays'][it], int(fx['n_rays'][it]))

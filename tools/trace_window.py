@@ -3,7 +3,7 @@ rocprofv3 kernel_trace.csv: start offset, duration, queue, name"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('k_adam_multi')]
+idx = [i for i, r in enumerate(rows) if 'k_adam_multi' in r['Kernel_Name']]
 which = int(sys.argv[2]) if len(sys.argv) > 2 else -2
 a, b = idx[which - 1], idx[which]
 t0 = int(rows[a]['End_Timestamp'])

@@ -29,6 +29,7 @@ SIGNATURES = {
     'xr_composite_train': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _i32, _i32, _f, _f, _vp, _vp, _vp, _vp]),
     'xr_calc_rgb_inference': (_i32, [_vp, _vp, _vp, _f, _f, _f, _u32, _i32, _i32, _vp, _vp, _vp]),
     'xr_generate_grid_samples': (_i32, [_vp, _u32, _u32, _u32, _f, _f, _f, _u64, _u64, _vp, _vp, _vp]),
+    'xr_generate_grid_samples2': (_i32, [_vp, _u32, _u32, _u32, _f, _f, _f, _u64, _u64, _vp, _u32, _u32, _vp, _vp]),
     'xr_mark_untrained_density_grid': (_i32, [_vp, _vp, _u32, _u32, _i32, _i32, _vp, _vp]),
     'xr_splat_grid_samples': (_i32, [_vp, _vp, _u32, _u32, _vp, _vp]),
     'xr_ema_grid_samples': (_i32, [_vp, _u32, _f, _vp, _vp]),

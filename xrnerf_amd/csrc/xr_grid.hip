@@ -10,8 +10,8 @@
 // ------------------------------------------------------------------ K6 (generate_grid_samples...cu:11-41)
 __global__ __launch_bounds__(GR_BLOCK) void k6_generate(uint32_t n_elements, xr_pcg32 rng, uint32_t step, float lo,
                                                          float hi, const float* __restrict__ grid,
-                                                         float* __restrict__ out, int32_t* __restrict__ indices,
-                                                         uint32_t n_cascades, float thresh) {
+                                                         float* __restrict__ out, uint32_t out_rs, uint32_t out_cs,
+                                                         int32_t* __restrict__ indices, uint32_t n_cascades, float thresh) {
     const uint32_t i = blockIdx.x * GR_BLOCK + threadIdx.x;
     if (i >= n_elements) return;
     rng.advance((uint64_t)(i * 4u));
@@ -30,22 +30,32 @@ __global__ __launch_bounds__(GR_BLOCK) void k6_generate(uint32_t n_elements, xr_
     const float px = ((x + u0) / 128.0f - 0.5f) * sc + 0.5f;
     const float py = ((y + u1) / 128.0f - 0.5f) * sc + 0.5f;
     const float pz = ((z + u2) / 128.0f - 0.5f) * sc + 0.5f;
-    out[3 * (size_t)i] = (px - lo) / diag; out[3 * (size_t)i + 1] = (py - lo) / diag; out[3 * (size_t)i + 2] = (pz - lo) / diag;
+    float* o = out + (size_t)i * out_rs;          // rows [n,3] (out_rs = 3, out_cs = 1) or three planes (out_rs = 1, out_cs = plane size)
+    o[0] = (px - lo) / diag; o[out_cs] = (py - lo) / diag; o[2 * (size_t)out_cs] = (pz - lo) / diag;
     indices[i] = (int32_t)idx;
 }
 
+extern "C" int xr_generate_grid_samples2(const float* density_grid, uint32_t ema_step, uint32_t n_elements,
+                                         uint32_t n_cascades, float thresh, float aabb0, float aabb1,
+                                         uint64_t rng_state, uint64_t rng_inc, float* positions, uint32_t pos_row_stride,
+                                         uint32_t pos_comp_stride, int32_t* indices, void* stream_) {
+    if (n_elements == 0) return XR_OK;
+    XR_REQUIRE(density_grid && positions && indices, "null pointer");
+    XR_REQUIRE(n_cascades >= 1 && n_cascades <= XR_NERF_CASCADES, "n_cascades out of range");
+    XR_REQUIRE(pos_row_stride >= 1 && pos_comp_stride >= 1, "bad stride");
+    xr_pcg32 rng{rng_state, rng_inc};
+    hipLaunchKernelGGL(k6_generate, dim3(xr_div_up(n_elements, GR_BLOCK)), dim3(GR_BLOCK), 0, (hipStream_t)stream_,
+                       n_elements, rng, ema_step, aabb0, aabb1, density_grid, positions, pos_row_stride, pos_comp_stride, indices,
+                       n_cascades, thresh);
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}
 extern "C" int xr_generate_grid_samples(const float* density_grid, uint32_t ema_step, uint32_t n_elements,
                                         uint32_t n_cascades, float thresh, float aabb0, float aabb1,
                                         uint64_t rng_state, uint64_t rng_inc, float* positions, int32_t* indices,
                                         void* stream_) {
-    if (n_elements == 0) return XR_OK;
-    XR_REQUIRE(density_grid && positions && indices, "null pointer");
-    XR_REQUIRE(n_cascades >= 1 && n_cascades <= XR_NERF_CASCADES, "n_cascades out of range");
-    xr_pcg32 rng{rng_state, rng_inc};
-    hipLaunchKernelGGL(k6_generate, dim3(xr_div_up(n_elements, GR_BLOCK)), dim3(GR_BLOCK), 0, (hipStream_t)stream_,
-                       n_elements, rng, ema_step, aabb0, aabb1, density_grid, positions, indices, n_cascades, thresh);
-    XR_LAUNCH_CHECK();
-    return XR_OK;
+    return xr_generate_grid_samples2(density_grid, ema_step, n_elements, n_cascades, thresh, aabb0, aabb1, rng_state, rng_inc, positions,
+                                     3, 1, indices, stream_);
 }
 
 // ------------------------------------------------------------------ K7 (mark_untrained_density_grid.cu:6-52)

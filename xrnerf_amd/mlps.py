@@ -177,6 +177,17 @@ class HashNerfMLP(nn.Module):
         return _NerfMLPFn.apply(self.embedder_pos.params, self.density_net.params, self.color_net.params, pts, dirs,
                                 self, data.get('n_valid_dev'), planes)
 
+    def run_density_planes(self, planes):
+        """run_density for positions stored as three planes [3, n] (the sampler's grid refresh): -> [n,1] view, row stride 4"""
+        n = planes.shape[1]
+        with torch.no_grad():
+            enc_t = ops._buf(planes.device, (self.embedder_pos.meta.n_output_dims, (n + 63) // 64 * 64), 'density_enc')
+            raw = ops._buf(planes.device, (n, 4), 'density_raw')
+            ops.hashgrid_fwd(self.embedder_pos.params.detach(), planes, self.embedder_pos.meta, enc_t=enc_t, ld=enc_t.shape[1])
+            ops.nerf_mlp_fwd(enc_t, None, n, self.density_net.params.detach(), None, self.density_net.n_hidden, self.color_net.n_hidden,
+                             self.pad_value, raw=raw)
+        return raw[:, 3:4]
+
     def run_density(self, pts_flat):
         """hashnerf_mlp.py:107-111: encode + density_net, channel 0 -> [N,1] fp32 (no grad)."""
         pts = self._rows(pts_flat)

@@ -403,12 +403,22 @@ def render_slice_composite(raw_s, coords, numsteps, ray_off, s0, s1, rgb_act, de
 
 
 # ---------------------------------------------------------------- K6 .. K11
-def generate_grid_samples(grid, ema_step, n_elements, n_cascades, thresh, aabb, rng_calls):
+def generate_grid_samples(grid, ema_step, n_elements, n_cascades, thresh, aabb, rng_calls, planes_out=None, idx_out=None, offset=0):
+    """K6.  Default: -> (positions [n,3], indices [n]).  `planes_out` [3, m] + `idx_out` [m]: the n points go to columns
+    [offset, offset + n) of the planes (and of idx_out) instead -- both calls of a grid refresh fill one buffer, no concatenation,
+    and the density query reads the planes with coalesced loads."""
     L = _lib.load()
     dev = grid.device
+    st, inc = pcg32_host_state(rng_calls)
+    if planes_out is not None:
+        if n_elements:
+            _ptr(planes_out); _ptr(idx_out)
+            _lib.check(L.xr_generate_grid_samples2(_ptr(grid), ema_step, n_elements, n_cascades, thresh, aabb[0], aabb[1], st, inc,
+                                                   C.c_void_p(planes_out.data_ptr() + 4 * offset), 1, planes_out.stride(0),
+                                                   C.c_void_p(idx_out.data_ptr() + 4 * offset), _stream()), 'xr_generate_grid_samples')
+        return planes_out[:, offset:offset + n_elements], idx_out[offset:offset + n_elements]
     pos = torch.empty((n_elements, 3), dtype=torch.float32, device=dev)
     idx = torch.empty((n_elements,), dtype=torch.int32, device=dev)
-    st, inc = pcg32_host_state(rng_calls)
     _lib.check(L.xr_generate_grid_samples(_ptr(grid), ema_step, n_elements, n_cascades, thresh, aabb[0], aabb[1],
                                           st, inc, _ptr(pos), _ptr(idx), _stream()), 'xr_generate_grid_samples')
     return pos, idx

@@ -93,21 +93,40 @@ class NGPGridSampler(nn.Module):
         if not hasattr(self, 'density_grid'):
             self.density_grid = ops.mark_untrained_density_grid(self.focal, self.transforms, n_elements,
                                                                 self.resolutions)
+        planes = hasattr(mlp, 'run_density_planes') and self._streams() and os.environ.get('XRNERF_XYZ_PLANES', '1') != '0'
+        if planes:
+            # both K6 calls write ONE [3, n] plane buffer (+ one index vector): no concatenation, coalesced reads in the query
+            n_tot = n_uniform + n_nonuniform
+            buf = getattr(self, '_k6_bufs', None)
+            if buf is None or buf[0].shape[1] < n_tot or buf[0].device != self.density_grid.device:
+                buf = self._k6_bufs = (torch.empty((3, n_tot), dtype=torch.float32, device=self.density_grid.device),
+                                       torch.empty((n_tot,), dtype=torch.int32, device=self.density_grid.device))
+            po, io = buf
+        else:
+            po = io = None
         pos_u, idx_u = ops.generate_grid_samples(self.density_grid, self.density_grid_ema_step, n_uniform,
-                                                 self.max_cascade + 1, -0.01, aabb, self.k6_calls)
+                                                 self.max_cascade + 1, -0.01, aabb, self.k6_calls, po, io, 0)
         self.k6_calls += 1
         pos_n, idx_n = ops.generate_grid_samples(self.density_grid, self.density_grid_ema_step, n_nonuniform,
                                                  self.max_cascade + 1, self.NERF_MIN_OPTICAL_THICKNESS, aabb,
-                                                 self.k6_calls)
+                                                 self.k6_calls, po, io, n_uniform)
         self.k6_calls += 1     # the reference's rng advances on every call, also for n == 0
-        positions = torch.cat([pos_u, pos_n]) if n_nonuniform > 0 else pos_u
-        indices = torch.cat([idx_u, idx_n]) if n_nonuniform > 0 else idx_u
         self.density_grid_tmp.zero_()
-        with torch.no_grad():
-            for i in range(0, positions.shape[0], self.update_block_size):
-                density = mlp.run_density(positions[i:i + self.update_block_size])   # [m,1] view, row stride 4
-                ops.splat_grid_samples(density, indices[i:i + self.update_block_size], density.stride(0),
-                                       density.shape[0], self.density_grid_tmp)
+        if planes:
+            positions, indices = po[:, :n_tot], io[:n_tot]
+            with torch.no_grad():
+                for i in range(0, n_tot, self.update_block_size):
+                    density = mlp.run_density_planes(positions[:, i:i + self.update_block_size])
+                    ops.splat_grid_samples(density, indices[i:i + self.update_block_size], density.stride(0), density.shape[0],
+                                           self.density_grid_tmp)
+        else:
+            positions = torch.cat([pos_u, pos_n]) if n_nonuniform > 0 else pos_u
+            indices = torch.cat([idx_u, idx_n]) if n_nonuniform > 0 else idx_u
+            with torch.no_grad():
+                for i in range(0, positions.shape[0], self.update_block_size):
+                    density = mlp.run_density(positions[i:i + self.update_block_size])   # [m,1] view, row stride 4
+                    ops.splat_grid_samples(density, indices[i:i + self.update_block_size], density.stride(0),
+                                           density.shape[0], self.density_grid_tmp)
         ops.ema_grid_samples(self.density_grid_tmp, n_elements, self.ema_grid_decay, self.density_grid)
         self.density_grid_ema_step += 1
         ops.update_bitfield(self.density_grid, self.density_grid_mean, self.density_grid_bitfield)
