@@ -121,6 +121,21 @@ int xr_composite_train(const float* network_output, const float* coords, const i
                        const float* alpha_mask, const float* density_grid_mean, uint32_t n_rays, int rgb_activation,
                        int density_activation, float delta, float scale, float* rgb_output, float* loss_mse_out,
                        float* dloss_doutput, void* stream);
+/* the same work, which can also count the live rows it writes: live_seg_count (nullable; xr_live_rows_segments(S) words the
+ * caller zero-fills) gets, per segment of 1024 rows of dloss_doutput, the number of rows that are not exactly zero ADDED --
+ * the counting pass of xr_live_rows; follow with xr_live_rows2(..., seg_counts_ready = 1).
+ * loss_mse_out is nullable here: without it the launch is the wave-per-ray kernel (64 chunks per ray instead of 16: rgb_output
+ * and dloss_doutput differ from xr_composite_train's like two fp32 summation orders) and the two loss scalars are left to
+ * xr_train_loss_scalars. */
+int xr_composite_train2(const float* network_output, const float* coords, const int32_t* rays_numsteps,
+                        const int32_t* rays_numsteps_compacted, const float* bg_color, const float* target,
+                        const float* alpha_mask, const float* density_grid_mean, uint32_t n_rays, int rgb_activation,
+                        int density_activation, float delta, float scale, float* rgb_output, float* loss_mse_out,
+                        float* dloss_doutput, uint32_t* live_seg_count, void* stream);
+/* loss_mse_out[0] = scale * sum HuberLoss(rgb - target), [1] = sum ((rgb - target) * alpha)^2 (utils/metrics.py:8-16,
+ * networks/hashnerf.py:36-44), WRITTEN, one workgroup's fixed-order sum: bit-reproducible run to run */
+int xr_train_loss_scalars(const float* rgb, const float* target, const float* alpha_mask, uint32_t n_rays, float delta,
+                          float scale, float* loss_mse_out, void* stream);
 /* K5  calc_rgb_influence_api (src/calc_rgb.cu:330-389, kernel :144-206); bg is by value like the
  * reference's host tensor */
 int xr_calc_rgb_inference(const float* network_output, const float* coords, const int32_t* rays_numsteps,
@@ -264,6 +279,9 @@ int xr_nerf_mlp_bwd_list_slots(void* workspace, size_t workspace_bytes, uint32_t
                                uint32_t** n_live);
 int xr_live_rows(const float* dloss_doutput, uint32_t n, const uint32_t* n_dev, uint32_t* seg_count, uint32_t* live_rows,
                  uint32_t* n_live, float* zero_denc_t, uint32_t ld, void* stream);
+/* seg_counts_ready != 0: seg_count already holds the per-segment counts (xr_composite_train2): the ranking pass only */
+int xr_live_rows2(const float* dloss_doutput, uint32_t n, const uint32_t* n_dev, uint32_t* seg_count, uint32_t* live_rows,
+                  uint32_t* n_live, float* zero_denc_t, uint32_t ld, int seg_counts_ready, void* stream);
 
 /* Reference-precision mode of the two calls above: tiny-cuda-nn computes FullyFusedMLP in fp16 with fp32 accumulation
  * (the reference casts its half outputs to fp32, hashnerf_mlp.py:76-77).  Same contracts, parameters and gradients stay
@@ -288,8 +306,11 @@ int xr_nerf_mlp_fwd_bf16x3(const float* enc_t, uint32_t ld, const float* dirs, u
 
 /* One training step's device work of HashNerfNetwork.train_step (networks/hashnerf.py:32-52, optimiser excluded) as ONE call:
  * xr_hashgrid_fwd -> xr_nerf_mlp_fwd[_f16] -> zero-fill of `zero_block` (which must contain grad_w_density, grad_w_color and
- * loss_mse) -> xr_composite_train -> xr_live_rows -> xr_nerf_mlp_bwd[_f16] -> xr_hashgrid_bwd2(XR_SCATTER_OVERWRITE), on `stream`:
+ * loss_mse) -> xr_composite_train2 (which counts the live rows per segment) -> xr_live_rows2 -> xr_nerf_mlp_bwd[_f16] ->
+ * xr_hashgrid_bwd2(XR_SCATTER_OVERWRITE), on `stream`:
  * grad_table's slices of the scattered levels are WRITTEN (no zero-fill; whatever they held is gone).
+ * live_seg_count (nullable): xr_live_rows_segments(n_rows) words for the per-segment counts; placed inside zero_block they are
+ * cleared by the one zero-fill, elsewhere (or null: the slot in ws_mlp_bwd) by one more.
  * coords: K1's [n_rows,7] rows (positions / directions consumed in place); n_dev: device count of valid rows; every buffer
  * is caller-owned (enc_t / denc_t [32][ld], raw / draw [n_rows,4], rgb_out [n_rays,3]); zero_draw != 0 also clears draw
  * (needed only without n_dev).  mlp_mode: 0 = xr_nerf_mlp_fwd / _bwd (fp32 MFMA), 1 = the _f16 pair, 2 = xr_nerf_mlp_fwd_bf16x3
@@ -306,7 +327,7 @@ int xr_ngp_train_step(const float* table, const float* w_density, const float* w
                       const float* target, const float* alpha_mask, const float* density_grid_mean, int rgb_activation,
                       int density_activation, float huber_delta, float loss_scale, float* enc_t, uint32_t ld, float* raw,
                       float* draw, float* denc_t, float* rgb_out, float* zero_block, size_t zero_floats, float* grad_w_density,
-                      float* grad_w_color, float* loss_mse, float* grad_table, size_t table_floats, int zero_draw,
+                      float* grad_w_color, float* loss_mse, uint32_t* live_seg_count, float* grad_table, size_t table_floats, int zero_draw,
                       void* ws_mlp_bwd, size_t ws_mlp_bwd_bytes, void* ws_scatter, size_t ws_scatter_bytes, int scatter_level0,
                       const float* xyz_planes, uint32_t plane_stride, const char* mark_entry, void* mark_event,
                       const char* timed_entry, void* timing_begin, void* timing_end, void* stream);

@@ -276,6 +276,7 @@ def test_fused_compositor_train_equals_k3_huber_k4(O, lego, dev):
     alpha = T((rng.uniform(0, 1, (n_rays, 1)) > 0.3).astype(np.float32), dev)
     mean = torch.tensor([0.005] + [0.0] * 15, dtype=torch.float32, device=dev)
     c = coords[:cap].contiguous()
+    dead_seen = False
     for ra, da in ((2, 3), (3, 1)):
         rgb_a = ops.calc_rgb_forward(raw, c, ns, nsc, bg, ra, da)
         lm_a, grad = ops.huber_loss_grad_mse(rgb_a, tgt, alpha, 0.1, 5.0)
@@ -286,4 +287,42 @@ def test_fused_compositor_train_equals_k3_huber_k4(O, lego, dev):
         assert torch.equal(rgb_a, rgb_b)
         assert torch.equal(draw_a, draw_b)
         assert torch.allclose(lm_a, lm_b, rtol=1e-5, atol=0)
+        # the same launch counting the live rows per 1024-row segment (xr_composite_train2) + the ranking pass alone
+        # (xr_live_rows2) = the two-pass list: same rows, same count; some rows are dead (exact zeros behind T == 0)
+        raw_dead = raw.clone()
+        raw_dead[::3, 3] = 200.0                                     # opaque samples: everything behind them has T == 0
+        draw_c, draw_d = torch.zeros_like(raw), torch.zeros_like(raw)
+        lm_c = torch.zeros(2, dtype=torch.float32, device=dev)
+        ops.composite_train(raw_dead, c, ns, nsc, bg, tgt, alpha, mean, ra, da, lm_c, draw_c)
+        rows_2, n_2 = ops.live_rows(draw_c, cap)
+        rows_2, n_2 = rows_2.clone(), n_2.clone()
+        lm_c.zero_()
+        seg = torch.zeros(ops.live_segments(cap), dtype=torch.int32, device=dev)
+        ops.composite_train(raw_dead, c, ns, nsc, bg, tgt, alpha, mean, ra, da, lm_c, draw_d, live_seg=seg)
+        rows_1, n_1 = ops.live_rows(draw_d, cap, seg_counts=seg)
+        live = (draw_c != 0).any(1)
+        assert seg.tolist() == [int(live[k:k + 1024].sum()) for k in range(0, cap, 1024)]
+        assert torch.equal(draw_c, draw_d)
+        nl = int(n_2[0])
+        assert nl == int(n_1[0]) == int((draw_c != 0).any(1).sum()) and 0 < nl <= cap
+        dead_seen = dead_seen or nl < cap
+        assert torch.equal(rows_1[:nl], rows_2[:nl])
+        # the wave-per-ray form (no loss accumulator handed in): another association of the same products; loss scalars from
+        # xr_train_loss_scalars; its own live-row counts are exact for its own rows
+        draw_w = torch.zeros_like(raw)
+        seg_w = torch.zeros(ops.live_segments(cap), dtype=torch.int32, device=dev)
+        rgb_w = ops.composite_train(raw, c, ns, nsc, bg, tgt, alpha, mean, ra, da, None, draw_w)
+        assert float((rgb_w - rgb_a).abs().max()) <= 2e-6
+        assert float((draw_w - draw_a).abs().max()) <= 2e-5 * float(draw_a.abs().max())
+        lm_w = ops.train_loss_scalars(rgb_w, tgt, alpha, 0.1, 5.0)
+        assert torch.allclose(lm_w, lm_a, rtol=1e-5, atol=0)
+        # (opaque samples: the suffix colour behind them is a difference of nearly equal sums times exp(15) -- only the zero
+        # pattern and the counts are compared on that input)
+        draw_w.zero_()
+        ops.composite_train(raw_dead, c, ns, nsc, bg, tgt, alpha, mean, ra, da, None, draw_w, live_seg=seg_w)
+        live_w = (draw_w != 0).any(1)
+        assert seg_w.tolist() == [int(live_w[k:k + 1024].sum()) for k in range(0, cap, 1024)]
+        assert not bool((live_w & ~live).any())   # exact zeros (T == 0 behind an opaque sample) of the 16-lane form are zeros here too
     assert int((nsc[:, 0] == 0).sum()) > 0 and int((nsc[:, 0] < ns[:, 0]).sum()) > 0
+    assert int(nsc[:, 0].max()) > 64                                  # chunks longer than the in-register fast path
+    assert dead_seen

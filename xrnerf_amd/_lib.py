@@ -27,6 +27,8 @@ SIGNATURES = {
     'xr_calc_rgb_forward': (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, _i32, _i32, _vp, _vp]),
     'xr_calc_rgb_backward': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _i32, _i32, _vp, _vp]),
     'xr_composite_train': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _i32, _i32, _f, _f, _vp, _vp, _vp, _vp]),
+    'xr_train_loss_scalars': (_i32, [_vp, _vp, _vp, _u32, _f, _f, _vp, _vp]),
+    'xr_composite_train2': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _i32, _i32, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     'xr_calc_rgb_inference': (_i32, [_vp, _vp, _vp, _f, _f, _f, _u32, _i32, _i32, _vp, _vp, _vp]),
     'xr_generate_grid_samples': (_i32, [_vp, _u32, _u32, _u32, _f, _f, _f, _u64, _u64, _vp, _vp, _vp]),
     'xr_generate_grid_samples2': (_i32, [_vp, _u32, _u32, _u32, _f, _f, _f, _u64, _u64, _vp, _u32, _u32, _vp, _vp]),
@@ -48,7 +50,7 @@ SIGNATURES = {
     'xr_ngp_prefetch': (_i32, [_vp, _u32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _u32, _u64, _vp, _vp, _vp, _vp,
                                _vp, _sz, _u32, _vp, _vp, _vp, _vp, _u32, _vp]),
     'xr_ngp_train_step': (_i32, [_vp, _vp, _vp, _i32, _i32, _f, _i32, _i32, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _u32, _vp, _vp, _vp,
-                                 _vp, _i32, _i32, _f, _f, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _sz, _i32, _vp, _sz,
+                                 _vp, _i32, _i32, _f, _f, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp, _sz,
                                  _vp, _sz, _i32, _vp, _u32, C.c_char_p, _vp, C.c_char_p, _vp, _vp, _vp]),
     'xr_timing_event_create': (_vp, []),
     'xr_stream_wait_event': (_i32, [_vp, _vp]),
@@ -61,6 +63,7 @@ SIGNATURES = {
     'xr_nerf_mlp_bwd': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     'xr_live_rows_segments': (_sz, [_u32]),
     'xr_live_rows': (_i32, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _u32, _vp]),
+    'xr_live_rows2': (_i32, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _u32, _i32, _vp]),
     'xr_nerf_mlp_bwd_list_slots': (_i32, [_vp, _sz, _u32, _vp, _vp, _vp]),
     'xr_mlp_fwd': (_i32, [_vp, C.c_long, C.c_long, _i32, _f, _u32, _vp, _i32, _vp, _vp]),
     'xr_mlp_bwd_workspace_bytes': (_sz, [_i32]),

@@ -115,5 +115,12 @@ __host__ __device__ inline float xr_unwarp_dt(float dt) {   // ray_sampler_heade
     return dt * (xr_max_warp_step() - xr_min_step()) + xr_min_step();
 }
 
+// rows per segment of the live-row compaction (xr_live_rows counts / ranks per segment; xr_composite_train2 can produce the counts)
+#define XR_LIVE_SEG 1024u
+
 // library-internal (not part of the C ABI): see xr_mlp.hip
 void xr_internal_defer_mlp_reduce(bool on);
+// see xr_scatter.hip: work the next xr_scatter3 call of this thread enqueues on its helper stream right after forking it (in
+// front of its own helper-stream kernels); `done` tells the caller whether a fork happened.  nullptr clears.
+struct XrAuxPrologue { int (*fn)(hipStream_t, void*); void* arg; bool done; };
+void xr_internal_scatter_aux_prologue(XrAuxPrologue* p);

@@ -360,7 +360,7 @@ __global__ __launch_bounds__(MLP_THREADS, 3) void k_nerf_mlp_fwd(const float* __
 // workload).  The backward therefore runs on the stable compaction of the live rows: k_live_count counts them per
 // 1024-row segment, k_live_fill writes the ordered row list (and the zero rows of denc_t), the MLP backward kernels
 // take tile t, column c from live_rows[32 t + c].  Stable order + fixed partition: bit-reproducible run to run.
-#define LIVE_SEG 1024
+#define LIVE_SEG XR_LIVE_SEG
 #define LIVE_THREADS 256
 __device__ __forceinline__ bool row_live(const float4 d) { return d.x != 0.f || d.y != 0.f || d.z != 0.f || d.w != 0.f; }
 
@@ -1358,19 +1358,26 @@ static bool live_rows_enabled() {          // XR_MLP_LIVE=0: run the backward ov
     return on == 1;
 }
 extern "C" size_t xr_live_rows_segments(uint32_t n) { return xr_div_up(n, LIVE_SEG); }
-extern "C" int xr_live_rows(const float* dloss_doutput, uint32_t n, const uint32_t* n_dev, uint32_t* seg_count, uint32_t* live_rows,
-                            uint32_t* n_live, float* zero_denc_t, uint32_t ld, void* stream_) {
+// seg_counts_ready != 0: seg_count already holds the live rows per segment (xr_composite_train2 counted them while writing
+// the rows) -- only the ranking / list pass runs
+extern "C" int xr_live_rows2(const float* dloss_doutput, uint32_t n, const uint32_t* n_dev, uint32_t* seg_count, uint32_t* live_rows,
+                             uint32_t* n_live, float* zero_denc_t, uint32_t ld, int seg_counts_ready, void* stream_) {
     XR_REQUIRE(dloss_doutput && seg_count && live_rows && n_live, "null pointer");
     XR_REQUIRE(((uintptr_t)dloss_doutput & 15) == 0, "dloss_doutput must be 16-byte aligned");
     XR_REQUIRE(!zero_denc_t || ld >= n, "bad ld");
     hipStream_t stream = (hipStream_t)stream_;
     if (n == 0) { XR_HIP(hipMemsetAsync(n_live, 0, sizeof(uint32_t), stream)); return XR_OK; }
     const uint32_t n_seg = xr_div_up(n, LIVE_SEG);
-    hipLaunchKernelGGL(k_live_count, dim3(n_seg), dim3(LIVE_THREADS), 0, stream, (const float4*)dloss_doutput, n, n_dev, seg_count);
+    if (!seg_counts_ready)
+        hipLaunchKernelGGL(k_live_count, dim3(n_seg), dim3(LIVE_THREADS), 0, stream, (const float4*)dloss_doutput, n, n_dev, seg_count);
     hipLaunchKernelGGL(k_live_fill, dim3(n_seg), dim3(LIVE_THREADS), 0, stream, (const float4*)dloss_doutput, n, n_dev,
                        (const uint32_t*)seg_count, n_seg, live_rows, n_live, zero_denc_t, ld);
     XR_LAUNCH_CHECK();
     return XR_OK;
+}
+extern "C" int xr_live_rows(const float* dloss_doutput, uint32_t n, const uint32_t* n_dev, uint32_t* seg_count, uint32_t* live_rows,
+                            uint32_t* n_live, float* zero_denc_t, uint32_t ld, void* stream_) {
+    return xr_live_rows2(dloss_doutput, n, n_dev, seg_count, live_rows, n_live, zero_denc_t, ld, 0, stream_);
 }
 // where a list of n rows sits in an xr_nerf_mlp_bwd workspace (behind the dW partials): callers that build the list
 // themselves to share it with xr_hashgrid_bwd use these slots instead of allocating

@@ -440,6 +440,25 @@ __device__ inline void cg_stitch(uint32_t sub, float T_loc, float cr, float cg, 
     *Tb = tb; *Cbr = ar; *Cbg = ag; *Cbb = ab; *Ttot = tt; *Cr = tr; *Cg = tg; *Cb = tbb;
 }
 
+// a chunk longer than CG_RC: batches of CG_LB samples, each batch's loads in flight together.  The per-sample loop this replaces
+// exposed one memory latency per sample, and the launch lasts as long as its longest ray: 16 % of a training batch's rays have
+// more than 64 samples (max ~150: 9-10 per lane, twice over in the fused kernel) -- tools/microbench_composite.py, 36.9 us as
+// captured against 21.8 us with every ray cut to 64.  Same samples in the same order per lane: results unchanged bit for bit.
+#define CG_LB 8
+template <class F>
+__device__ __forceinline__ void cg_long(const float4* __restrict__ raw, const float* __restrict__ coords, uint32_t base, uint32_t k0,
+                                        uint32_t k1, F&& f) {
+    for (uint32_t b = k0; b < k1; b += CG_LB) {
+        float4 o[CG_LB]; float d[CG_LB];
+        const uint32_t mm = min((uint32_t)CG_LB, k1 - b);
+#pragma unroll
+        for (uint32_t u = 0; u < CG_LB; ++u)
+            if (u < mm) { o[u] = raw[base + b + u]; d[u] = coords[7 * (size_t)(base + b + u) + 3]; }
+#pragma unroll
+        for (uint32_t u = 0; u < CG_LB; ++u) if (u < mm) f(o[u], d[u], b + u);
+    }
+}
+
 template <bool INFERENCE>
 __global__ __launch_bounds__(RM_BLOCK) void k_composite_fwd(
     uint32_t n_rays, const float4* __restrict__ raw, const float* __restrict__ coords,
@@ -473,7 +492,7 @@ __global__ __launch_bounds__(RM_BLOCK) void k_composite_fwd(
 #pragma unroll
         for (uint32_t u = 0; u < CG_RC; ++u) if (u < m) step(oc[u], dc[u]);
     } else {
-        for (uint32_t k = k0; k < k1; ++k) step(raw[base + k], coords[7 * (size_t)(base + k) + 3]);
+        cg_long(raw, coords, base, k0, k1, [&](const float4 o, float dtw, uint32_t) { step(o, dtw); });
     }
     float Tb, ar, ag, ab, Tt, Cr, Cg, Cb;
     cg_stitch(sub, T, cr, cg, cb, &Tb, &ar, &ag, &ab, &Tt, &Cr, &Cg, &Cb);
@@ -636,7 +655,7 @@ __global__ __launch_bounds__(RM_BLOCK) void k_composite_bwd(
 #pragma unroll
         for (uint32_t u = 0; u < CG_RC; ++u) if (u < m) pass1(oc[u], dc[u]);
     } else {
-        for (uint32_t k = k0; k < k1; ++k) pass1(raw[base + k], coords[7 * (size_t)(base + k) + 3]);
+        cg_long(raw, coords, base, k0, k1, [&](const float4 o, float dtw, uint32_t) { pass1(o, dtw); });
     }
     float Tb, ar, ag, ab, Tt, Cr, Cg, Cb;
     cg_stitch(sub, T, cr, cg, cb, &Tb, &ar, &ag, &ab, &Tt, &Cr, &Cg, &Cb);
@@ -663,7 +682,7 @@ __global__ __launch_bounds__(RM_BLOCK) void k_composite_bwd(
 #pragma unroll
         for (uint32_t u = 0; u < CG_RC; ++u) if (u < m) pass2(oc[u], dc[u], k0 + u);
     } else {
-        for (uint32_t k = k0; k < k1; ++k) pass2(raw[base + k], coords[7 * (size_t)(base + k) + 3], k);
+        cg_long(raw, coords, base, k0, k1, pass2);
     }
 }
 
@@ -692,13 +711,31 @@ extern "C" int xr_calc_rgb_backward(const float* network_output, const int32_t* 
 // CT_BLOCK = 1024: every workgroup ends with two fp32 atomics on the SAME cache line (loss, mse), and same-address L2 atomics
 // retire one per ~13.5 ns -- measured: a launch with every ray EMPTY took 23.7 us at 786 workgroups of 256 threads, 42.6 us at
 // 1572 and 13-15 us at 196 workgroups of 1024 (tools/microbench_composite.py).
+// Round 3: what bounded the launch after that was the texture-address path of the ONE compute unit a workgroup sits on -- every lane
+// reads its own contiguous chunk (16-B rows 64+ B apart across lanes: nothing coalesces) and a workgroup whose 64 rays are long
+// issues ~35 such instructions per wave (tools/microbench_composite.py: 32 us as captured, 17 us with every ray cut to 64 samples,
+// although only a quarter of the samples go away).  The workgroup's rays own ONE contiguous row range (K1's bases ascend), so it
+// is staged through LDS: coalesced 16-B-per-lane loads of raw / dt rows in, each lane composites its chunk out of LDS exactly as
+// before (same values, same order: same bits), dL/draw rows go back into the slots and leave with coalesced stores.  Ranges
+// above CT_CAP rows (the first iterations, when every ray is long) take the direct path.
 #define CT_BLOCK 1024
+#define CT_SEGS 68
+#define CT_CAP 6144u                          // rows: 96 KB of raw / dL/draw slots + 24 KB of dt
+#define CT_MARK 0x7fc0a5a5u                   // dt slot of a row whose dL/draw slot has been written (a NaN payload K1 never stores)
+#define CT_LDS_BYTES (CT_CAP * 20u)
 __global__ __launch_bounds__(CT_BLOCK) void k_composite_train(
     uint32_t n_rays, const float4* __restrict__ raw, const float* __restrict__ coords, const int32_t* __restrict__ numsteps,
     const int32_t* __restrict__ numsteps_c, const float* __restrict__ bg, const float* __restrict__ target,
     const float* __restrict__ alpha_mask, const float* __restrict__ density_grid_mean, int rgb_act, int density_act, float delta,
-    float scale, float* __restrict__ rgb_out, float* __restrict__ loss_mse, float4* __restrict__ dout) {
+    float scale, float* __restrict__ rgb_out, float* __restrict__ loss_mse, float4* __restrict__ dout,
+    uint32_t* __restrict__ live_seg_count, int stage) {
+    extern __shared__ __attribute__((aligned(16))) float4 ct_rows[];
     __shared__ float ws[CT_BLOCK / 64], ws2[CT_BLOCK / 64];
+    // live rows (dL/d(raw) != 0) per XR_LIVE_SEG-row segment, counted while the rows are written: the workgroup's 64 rays own a
+    // contiguous row range, i.e. <= CT_SEGS segments from its first row's on (rays of <= 1024 samples; beyond: global adds)
+    __shared__ uint32_t seg_hist[CT_SEGS], seg_first, row_lo, row_hi;
+    if (live_seg_count && threadIdx.x < CT_SEGS) seg_hist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { row_lo = 0xffffffffu; row_hi = 0u; }
     const uint32_t t = blockIdx.x * CT_BLOCK + threadIdx.x;
     const uint32_t i = t / CG, sub = t % CG;
     const bool in = i < n_rays;
@@ -713,17 +750,40 @@ __global__ __launch_bounds__(CT_BLOCK) void k_composite_train(
         tr = target[3 * i]; tg = target[3 * i + 1]; tb = target[3 * i + 2];
         am = alpha_mask[i];
     }
+    // the rows of this workgroup's rays: [row_lo, row_hi)
+    __syncthreads();
+    if (stage && in && sub == 0 && n > 0) { atomicMin(&row_lo, base); atomicMax(&row_hi, base + n); }
+    __syncthreads();
+    const uint32_t lo = row_lo, hi = row_hi;
+    const bool staged = stage && hi > lo && hi - lo <= CT_CAP;                   // uniform over the workgroup
+    float* const ct_dt = reinterpret_cast<float*>(ct_rows + CT_CAP);
+    if (staged) {
+        for (uint32_t r = threadIdx.x; r < hi - lo; r += CT_BLOCK) {
+            ct_rows[r] = raw[lo + r];
+            ct_dt[r] = coords[7 * (size_t)(lo + r) + 3];
+        }
+        __syncthreads();
+    }
     uint32_t k0, k1;
     cg_chunk(n, sub, &k0, &k1);
     float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f;
     const uint32_t m = k1 - k0;
+    const uint32_t slot0 = base - lo;                                            // LDS slot of the ray's first row (staged)
     float4 oc[CG_RC]; float dc[CG_RC];
     if (m <= CG_RC) {
 #pragma unroll
         for (uint32_t u = 0; u < CG_RC; ++u)
-            if (u < m) { oc[u] = raw[base + k0 + u]; dc[u] = coords[7 * (size_t)(base + k0 + u) + 3]; }
+            if (u < m) {
+                if (staged) { oc[u] = ct_rows[slot0 + k0 + u]; dc[u] = ct_dt[slot0 + k0 + u]; }
+                else { oc[u] = raw[base + k0 + u]; dc[u] = coords[7 * (size_t)(base + k0 + u) + 3]; }
+            }
     }
-    auto pass1 = [&](const float4 o, float dtw) {
+    // a chunk longer than CG_RC: rows out of LDS one by one (no memory latency to batch), else cg_long's batches
+    auto long_chunk = [&](auto&& f) {
+        if (staged) { for (uint32_t k = k0; k < k1; ++k) f(ct_rows[slot0 + k], ct_dt[slot0 + k], k); }
+        else cg_long(raw, coords, base, k0, k1, f);
+    };
+    auto pass1 = [&](const float4 o, float dtw, uint32_t) {
         const float dt = xr_unwarp_dt(dtw);
         const float alpha = 1.f - __expf(-xr_act_density(o.w, density_act) * dt);
         const float w = alpha * T;
@@ -732,9 +792,9 @@ __global__ __launch_bounds__(CT_BLOCK) void k_composite_train(
     };
     if (m <= CG_RC) {
 #pragma unroll
-        for (uint32_t u = 0; u < CG_RC; ++u) if (u < m) pass1(oc[u], dc[u]);
+        for (uint32_t u = 0; u < CG_RC; ++u) if (u < m) pass1(oc[u], dc[u], 0u);
     } else {
-        for (uint32_t k = k0; k < k1; ++k) pass1(raw[base + k], coords[7 * (size_t)(base + k) + 3]);
+        long_chunk(pass1);
     }
     float Tb, ar, ag, ab, Tt, Cr, Cg, Cb;
     cg_stitch(sub, T, cr, cg, cb, &Tb, &ar, &ag, &ab, &Tt, &Cr, &Cg, &Cb);
@@ -761,55 +821,261 @@ __global__ __launch_bounds__(CT_BLOCK) void k_composite_train(
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { acc += __shfl_xor(acc, d, 64); mse += __shfl_xor(mse, d, 64); }
     if ((threadIdx.x & 63) == 0) { ws[threadIdx.x >> 6] = acc; ws2[threadIdx.x >> 6] = mse; }
+    if (threadIdx.x == 0) seg_first = base / XR_LIVE_SEG;          // ray bases ascend with the ray index (K1's prefix)
     __syncthreads();
     if (threadIdx.x == 0) {
         float a = 0.f, b = 0.f;
 #pragma unroll
         for (int w = 0; w < CT_BLOCK / 64; ++w) { a += ws[w]; b += ws2[w]; }
-        if (a != 0.f) atomicAdd(loss_mse, scale * a);
-        if (b != 0.f) atomicAdd(loss_mse + 1, b);
+        if (loss_mse && a != 0.f) atomicAdd(loss_mse, scale * a);
+        if (loss_mse && b != 0.f) atomicAdd(loss_mse + 1, b);
     }
-    if (!in || k0 >= k1) return;
-    T = Tb; cr = ar; cg = ag; cb = ab;
-    auto pass2 = [&](const float4 o, float dtw, uint32_t k) {
-        const float r = xr_act_rgb(o.x, rgb_act), g = xr_act_rgb(o.y, rgb_act), b = xr_act_rgb(o.z, rgb_act);
-        const float dt = xr_unwarp_dt(dtw);
-        const float density = xr_act_density(o.w, density_act);
-        const float alpha = 1.f - __expf(-density * dt);
-        const float w = alpha * T;
-        cr += w * r; cg += w * g; cb += w * b;
-        T *= (1.f - alpha);
-        const float sr = fr - cr, sg = fg - cg, sb = fb - cb;                     // suffix
-        float4 d;
-        d.x = loss_scale * ((w * gr) * xr_dact_rgb(o.x, rgb_act) + fmaxf(0.0f, l2 * o.x));
-        d.y = loss_scale * ((w * gg) * xr_dact_rgb(o.y, rgb_act) + fmaxf(0.0f, l2 * o.y));
-        d.z = loss_scale * ((w * gb) * xr_dact_rgb(o.z, rgb_act) + fmaxf(0.0f, l2 * o.z));
-        const float dot = gr * (T * r - sr) + gg * (T * g - sg) + gb * (T * b - sb);
-        d.w = loss_scale * (xr_dact_density(o.w, density_act) * (dt * dot)) + (o.w < 0.f ? -l1 : 0.0f);
-        dout[base + k] = d;
-    };
-    if (m <= CG_RC) {
+    if (in && k0 < k1) {
+        T = Tb; cr = ar; cg = ag; cb = ab;
+        auto pass2 = [&](const float4 o, float dtw, uint32_t k) {
+            const float r = xr_act_rgb(o.x, rgb_act), g = xr_act_rgb(o.y, rgb_act), b = xr_act_rgb(o.z, rgb_act);
+            const float dt = xr_unwarp_dt(dtw);
+            const float density = xr_act_density(o.w, density_act);
+            const float alpha = 1.f - __expf(-density * dt);
+            const float w = alpha * T;
+            cr += w * r; cg += w * g; cb += w * b;
+            T *= (1.f - alpha);
+            const float sr = fr - cr, sg = fg - cg, sb = fb - cb;                     // suffix
+            float4 d;
+            d.x = loss_scale * ((w * gr) * xr_dact_rgb(o.x, rgb_act) + fmaxf(0.0f, l2 * o.x));
+            d.y = loss_scale * ((w * gg) * xr_dact_rgb(o.y, rgb_act) + fmaxf(0.0f, l2 * o.y));
+            d.z = loss_scale * ((w * gb) * xr_dact_rgb(o.z, rgb_act) + fmaxf(0.0f, l2 * o.z));
+            const float dot = gr * (T * r - sr) + gg * (T * g - sg) + gb * (T * b - sb);
+            d.w = loss_scale * (xr_dact_density(o.w, density_act) * (dt * dot)) + (o.w < 0.f ? -l1 : 0.0f);
+            if (staged) { ct_rows[slot0 + k] = d; ct_dt[slot0 + k] = __uint_as_float(CT_MARK); }
+            else dout[base + k] = d;
+            if (live_seg_count && (d.x != 0.f || d.y != 0.f || d.z != 0.f || d.w != 0.f)) {
+                const uint32_t sg_ = (base + k) / XR_LIVE_SEG, rel = sg_ - seg_first;
+                if (rel < CT_SEGS) atomicAdd(&seg_hist[rel], 1u); else atomicAdd(&live_seg_count[sg_], 1u);
+            }
+        };
+        if (m <= CG_RC) {
 #pragma unroll
-        for (uint32_t u = 0; u < CG_RC; ++u) if (u < m) pass2(oc[u], dc[u], k0 + u);
-    } else {
-        for (uint32_t k = k0; k < k1; ++k) pass2(raw[base + k], coords[7 * (size_t)(base + k) + 3], k);
+            for (uint32_t u = 0; u < CG_RC; ++u) if (u < m) pass2(oc[u], dc[u], k0 + u);
+        } else {
+            long_chunk(pass2);
+        }
     }
+    if (!live_seg_count && !staged) return;
+    __syncthreads();
+    if (live_seg_count && threadIdx.x < CT_SEGS && seg_hist[threadIdx.x])
+        atomicAdd(&live_seg_count[seg_first + threadIdx.x], seg_hist[threadIdx.x]);
+    if (staged)
+        for (uint32_t r = threadIdx.x; r < hi - lo; r += CT_BLOCK)
+            if (__float_as_uint(ct_dt[r]) == CT_MARK) dout[lo + r] = ct_rows[r];
 }
 
+// ---- the fused compositor, one WAVE per ray (the default of xr_composite_train2; XR_CT_WAVE=0 restores the 16-lane kernel above)
+// What bounds the 16-lane form is neither memory nor the loss atomics alone but the lock step: a wave's time is its LONGEST
+// chunk (rays of 143 samples: 9 samples per lane, twice over) times ~390 issue cycles per sample (13 transcendentals), with 59 %
+// of the lanes sitting on rays without samples, and a workgroup per compute unit makes that 4 waves per SIMD back to back --
+// tools/microbench_composite.py follows 11.5 us + 1.3 us x (longest chunk) closely.  Here every ray gets a wave: chunks of
+// ceil(n / 64) <= 3 samples (one for the typical ray: consecutive lanes read consecutive 16-B rows), 12.5 K waves over 1024 SIMDs,
+// an empty ray costs its numsteps load.  The 64 chunks are stitched by ordered prefixes (16 lanes, then the 4 groups) under
+//   (T_l, c_l) o (T_r, c_r) = (T_l T_r, c_l + T_l c_r),
+// i.e. another association of the same products than the 16-lane kernels use (results differ from them like two fp32
+// summation orders; each is held to the oracle separately).
+// No loss accumulation here: the two scalars are a pure function of rgb_out (xr_train_loss_scalars: one fixed-order sum instead
+// of 2 x 784 same-line atomics at 13.5 ns each -- reproducible run to run, and off this launch).
+#define CW_RAYS 4                          // rays = waves per workgroup
+#define CW_RC 2                            // chunk lengths kept in registers (rays of <= 128 samples)
+#define CW_SEGS 8
+__global__ __launch_bounds__(64 * CW_RAYS) void k_composite_train_w(
+    uint32_t n_rays, const float4* __restrict__ raw, const float* __restrict__ coords, const int32_t* __restrict__ numsteps,
+    const int32_t* __restrict__ numsteps_c, const float* __restrict__ bg, const float* __restrict__ target,
+    const float* __restrict__ density_grid_mean, int rgb_act, int density_act, float delta, float scale,
+    float* __restrict__ rgb_out, float4* __restrict__ dout, uint32_t* __restrict__ live_seg_count) {
+    __shared__ uint32_t seg_hist[CW_SEGS], seg_first;
+    const uint32_t lane = threadIdx.x & 63, i = blockIdx.x * CW_RAYS + (threadIdx.x >> 6);
+    const bool in = i < n_rays;
+    if (live_seg_count) {
+        if (threadIdx.x < CW_SEGS) seg_hist[threadIdx.x] = 0;
+        if (threadIdx.x == 0) seg_first = (uint32_t)numsteps_c[2 * i + 1] / XR_LIVE_SEG;    // (the grid has no workgroup without a ray)
+        __syncthreads();
+    }
+    float loss_scale = 128.f; loss_scale /= (float)n_rays;                        // calc_rgb.cu:92-93
+    const float l2 = rgb_act == XR_ACT_EXPONENTIAL ? 1e-4f : 0.0f;
+    const float l1 = density_grid_mean[0] < 0.01f ? 1e-4f : 0.0f;
+    uint32_t n = 0, base = 0, n_full = 0;
+    if (in) { n = (uint32_t)numsteps_c[2 * i]; base = (uint32_t)numsteps_c[2 * i + 1]; n_full = (uint32_t)numsteps[2 * i]; }
+    if (n > 0) {                                                                   // wave-uniform
+        const uint32_t chunk = (n + 63) / 64;
+        const uint32_t k0 = min(n, lane * chunk), k1 = min(n, (lane + 1) * chunk), m = k1 - k0;
+        float4 oc[CW_RC]; float dc[CW_RC];
+        if (chunk <= CW_RC) {
+#pragma unroll
+            for (uint32_t u = 0; u < CW_RC; ++u)
+                if (u < m) { oc[u] = raw[base + k0 + u]; dc[u] = coords[7 * (size_t)(base + k0 + u) + 3]; }
+        }
+        const float br = bg[3 * i], bgc = bg[3 * i + 1], bb = bg[3 * i + 2];
+        const float tr = target[3 * i], tg = target[3 * i + 1], tb = target[3 * i + 2];
+        float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f;
+        auto pass1 = [&](const float4 o, float dtw, uint32_t) {
+            const float dt = xr_unwarp_dt(dtw);
+            const float alpha = 1.f - __expf(-xr_act_density(o.w, density_act) * dt);
+            const float w = alpha * T;
+            cr += w * xr_act_rgb(o.x, rgb_act); cg += w * xr_act_rgb(o.y, rgb_act); cb += w * xr_act_rgb(o.z, rgb_act);
+            T *= (1.f - alpha);
+        };
+        if (chunk <= CW_RC) {
+#pragma unroll
+            for (uint32_t u = 0; u < CW_RC; ++u) if (u < m) pass1(oc[u], dc[u], 0u);
+        } else {
+            cg_long(raw, coords, base, k0, k1, pass1);
+        }
+        // stitch: the 16-step ordered prefix of cg_stitch inside each group of 16 lanes, then an ordered prefix over the 4 groups.
+        // (Not a log-step scan: behind an opaque sample -- T exactly 0 -- every later prefix and the ray's total must be the SAME
+        // fp32 number, so that the suffix colour, and with it the whole dL/draw row, is exactly zero there: those rows are what
+        // the live-row list drops.  An ordered prefix stops changing once T is 0; a tree combines different partial sums per lane.)
+        float Tb1, ar1, ag1, ab1, Tg, Cgr, Cgg, Cgb;
+        cg_stitch(lane & 15, T, cr, cg, cb, &Tb1, &ar1, &ag1, &ab1, &Tg, &Cgr, &Cgg, &Cgb);
+        float GT = 1.f, Gr = 0.f, Gg = 0.f, Gb = 0.f, Tb = 1.f, ar = 0.f, ag = 0.f, ab = 0.f;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const float th = __shfl(Tg, 16 * h, 64), rh = __shfl(Cgr, 16 * h, 64), gh = __shfl(Cgg, 16 * h, 64), bh = __shfl(Cgb, 16 * h, 64);
+            if ((int)(lane >> 4) == h) { Tb = GT * Tb1; ar = Gr + GT * ar1; ag = Gg + GT * ag1; ab = Gb + GT * ab1; }
+            Gr += GT * rh; Gg += GT * gh; Gb += GT * bh;
+            GT *= th;
+        }
+        const float Tt = GT;
+        float fr = Gr, fg = Gg, fb = Gb;
+        if (n == n_full) { fr += Tt * br; fg += Tt * bgc; fb += Tt * bb; }       // K3 (:61-64)
+        if (lane == 0) { rgb_out[3 * i] = fr; rgb_out[3 * i + 1] = fg; rgb_out[3 * i + 2] = fb; }
+        // gradient of scale * HuberLoss (utils/metrics.py:8-16)
+        float g3[3];
+        {
+            const float d3[3] = {fr - tr, fg - tg, fb - tb};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) g3[c] = fabsf(d3[c]) > delta ? scale * (d3[c] > 0.f ? 1.f : -1.f) : scale * (d3[c] / delta);
+        }
+        const float gr = g3[0], gg = g3[1], gb = g3[2];
+        if (k0 < k1) {
+            T = Tb; cr = ar; cg = ag; cb = ab;
+            uint32_t live_lo = 0, live_hi = 0;                                    // live rows of this chunk in its first / next segment
+            const uint32_t seg_lo = (base + k0) / XR_LIVE_SEG;
+            auto pass2 = [&](const float4 o, float dtw, uint32_t k) {
+                const float r = xr_act_rgb(o.x, rgb_act), g = xr_act_rgb(o.y, rgb_act), b = xr_act_rgb(o.z, rgb_act);
+                const float dt = xr_unwarp_dt(dtw);
+                const float density = xr_act_density(o.w, density_act);
+                const float alpha = 1.f - __expf(-density * dt);
+                const float w = alpha * T;
+                cr += w * r; cg += w * g; cb += w * b;
+                T *= (1.f - alpha);
+                const float ur = fr - cr, ug = fg - cg, ub = fb - cb;                 // suffix
+                float4 d;
+                d.x = loss_scale * ((w * gr) * xr_dact_rgb(o.x, rgb_act) + fmaxf(0.0f, l2 * o.x));
+                d.y = loss_scale * ((w * gg) * xr_dact_rgb(o.y, rgb_act) + fmaxf(0.0f, l2 * o.y));
+                d.z = loss_scale * ((w * gb) * xr_dact_rgb(o.z, rgb_act) + fmaxf(0.0f, l2 * o.z));
+                const float dot = gr * (T * r - ur) + gg * (T * g - ug) + gb * (T * b - ub);
+                d.w = loss_scale * (xr_dact_density(o.w, density_act) * (dt * dot)) + (o.w < 0.f ? -l1 : 0.0f);
+                dout[base + k] = d;
+                if (d.x != 0.f || d.y != 0.f || d.z != 0.f || d.w != 0.f) {
+                    if ((base + k) / XR_LIVE_SEG == seg_lo) ++live_lo; else ++live_hi;   // a chunk of <= 16 rows spans <= 2 segments
+                }
+            };
+            if (chunk <= CW_RC) {
+#pragma unroll
+                for (uint32_t u = 0; u < CW_RC; ++u) if (u < m) pass2(oc[u], dc[u], k0 + u);
+            } else {
+                cg_long(raw, coords, base, k0, k1, pass2);
+            }
+            if (live_seg_count) {
+                const uint32_t rel = seg_lo - seg_first;
+                if (live_lo) { if (rel < CW_SEGS) atomicAdd(&seg_hist[rel], live_lo); else atomicAdd(&live_seg_count[seg_lo], live_lo); }
+                if (live_hi) { if (rel + 1 < CW_SEGS) atomicAdd(&seg_hist[rel + 1], live_hi); else atomicAdd(&live_seg_count[seg_lo + 1], live_hi); }
+            }
+        }
+    } else if (in && lane == 0) {                                                  // K3 (:28-32): no samples -> the background
+        rgb_out[3 * i] = bg[3 * i]; rgb_out[3 * i + 1] = bg[3 * i + 1]; rgb_out[3 * i + 2] = bg[3 * i + 2];
+    }
+    if (!live_seg_count) return;
+    __syncthreads();
+    if (threadIdx.x < CW_SEGS && seg_hist[threadIdx.x]) atomicAdd(&live_seg_count[seg_first + threadIdx.x], seg_hist[threadIdx.x]);
+}
+
+// scale * sum HuberLoss(rgb - target) and sum ((rgb - target) * alpha)^2 as ONE workgroup's fixed-order sum: out[0], out[1] are
+// WRITTEN (utils/metrics.py:8-16, networks/hashnerf.py:36-44)
+#define LS_THREADS 1024
+__global__ __launch_bounds__(LS_THREADS) void k_train_loss_scalars(const float* __restrict__ rgb, const float* __restrict__ target,
+                                                                  const float* __restrict__ alpha_mask, uint32_t n_rays, float delta,
+                                                                  float scale, float* __restrict__ out) {
+    __shared__ float ws[LS_THREADS / 64], ws2[LS_THREADS / 64];
+    float acc = 0.f, mse = 0.f;
+    for (uint32_t i = threadIdx.x; i < n_rays; i += LS_THREADS) {
+        const float am = alpha_mask[i];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float d = rgb[3 * i + c] - target[3 * i + c], a = fabsf(d);
+            acc += a > delta ? a - 0.5f * delta : 0.5f / delta * a * a;
+            const float mm = d * am; mse += mm * mm;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { acc += __shfl_xor(acc, d, 64); mse += __shfl_xor(mse, d, 64); }
+    if ((threadIdx.x & 63) == 0) { ws[threadIdx.x >> 6] = acc; ws2[threadIdx.x >> 6] = mse; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int w = 0; w < LS_THREADS / 64; ++w) { a += ws[w]; b += ws2[w]; }
+        out[0] = scale * a; out[1] = b;
+    }
+}
+extern "C" int xr_train_loss_scalars(const float* rgb, const float* target, const float* alpha_mask, uint32_t n_rays, float delta,
+                                     float scale, float* loss_mse_out, void* stream_) {
+    XR_REQUIRE(rgb && target && alpha_mask && loss_mse_out && n_rays > 0, "bad argument");
+    hipLaunchKernelGGL(k_train_loss_scalars, dim3(1), dim3(LS_THREADS), 0, (hipStream_t)stream_, rgb, target, alpha_mask, n_rays, delta,
+                       scale, loss_mse_out);
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}
+
+// loss_mse_out == nullptr: the wave-per-ray kernel; the two loss scalars are left to xr_train_loss_scalars (a function of
+// rgb_output).  With loss_mse_out: the 16-lanes-per-ray kernel, which ADDS them (block sums + two atomics per workgroup).
+extern "C" int xr_composite_train2(const float* network_output, const float* coords, const int32_t* rays_numsteps,
+                                   const int32_t* rays_numsteps_compacted, const float* bg_color, const float* target,
+                                   const float* alpha_mask, const float* density_grid_mean, uint32_t n_rays, int rgb_activation,
+                                   int density_activation, float delta, float scale, float* rgb_output, float* loss_mse_out,
+                                   float* dloss_doutput, uint32_t* live_seg_count, void* stream_) {
+    XR_REQUIRE(network_output && coords && rays_numsteps && rays_numsteps_compacted && bg_color && target && alpha_mask &&
+               density_grid_mean && rgb_output && dloss_doutput, "null pointer");
+    XR_REQUIRE((((uintptr_t)network_output | (uintptr_t)dloss_doutput) & 15) == 0, "raw/grad buffers must be 16-byte aligned");
+    XR_REQUIRE(n_rays > 0, "n_rays == 0");
+    // XR_CT_WAVE=0 (measurement, read once): the 16-lanes-per-ray kernel also when the caller takes the loss scalars separately
+    static const int wave = []() { const char* e = getenv("XR_CT_WAVE"); return (e && e[0] == '0') ? 0 : 1; }();
+    if (!loss_mse_out && wave) {
+        hipLaunchKernelGGL(k_composite_train_w, dim3(xr_div_up(n_rays, CW_RAYS)), dim3(64 * CW_RAYS), 0, (hipStream_t)stream_, n_rays,
+                           (const float4*)network_output, coords, rays_numsteps, rays_numsteps_compacted, bg_color, target,
+                           density_grid_mean, rgb_activation, density_activation, delta, scale, rgb_output, (float4*)dloss_doutput,
+                           live_seg_count);
+        XR_LAUNCH_CHECK();
+        return XR_OK;
+    }
+    // XR_CT_STAGE=0 (measurement, read once): every workgroup on the direct path
+    static const int stage = []() { const char* e = getenv("XR_CT_STAGE"); return (e && e[0] == '0') ? 0 : 1; }();
+    static bool attr_set = false;
+    if (!attr_set) {
+        XR_HIP(hipFuncSetAttribute((const void*)k_composite_train, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CT_LDS_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_composite_train, dim3(xr_div_up((uint64_t)n_rays * CG, CT_BLOCK)), dim3(CT_BLOCK), CT_LDS_BYTES, (hipStream_t)stream_,
+                       n_rays, (const float4*)network_output, coords, rays_numsteps, rays_numsteps_compacted, bg_color, target,
+                       alpha_mask, density_grid_mean, rgb_activation, density_activation, delta, scale, rgb_output, loss_mse_out,
+                       (float4*)dloss_doutput, live_seg_count, stage);
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}
 extern "C" int xr_composite_train(const float* network_output, const float* coords, const int32_t* rays_numsteps,
                                   const int32_t* rays_numsteps_compacted, const float* bg_color, const float* target,
                                   const float* alpha_mask, const float* density_grid_mean, uint32_t n_rays, int rgb_activation,
                                   int density_activation, float delta, float scale, float* rgb_output, float* loss_mse_out,
                                   float* dloss_doutput, void* stream_) {
-    XR_REQUIRE(network_output && coords && rays_numsteps && rays_numsteps_compacted && bg_color && target && alpha_mask &&
-               density_grid_mean && rgb_output && loss_mse_out && dloss_doutput, "null pointer");
-    XR_REQUIRE((((uintptr_t)network_output | (uintptr_t)dloss_doutput) & 15) == 0, "raw/grad buffers must be 16-byte aligned");
-    XR_REQUIRE(n_rays > 0, "n_rays == 0");
-    hipLaunchKernelGGL(k_composite_train, dim3(xr_div_up((uint64_t)n_rays * CG, CT_BLOCK)), dim3(CT_BLOCK), 0, (hipStream_t)stream_,
-                       n_rays, (const float4*)network_output, coords, rays_numsteps, rays_numsteps_compacted, bg_color, target,
-                       alpha_mask, density_grid_mean, rgb_activation, density_activation, delta, scale, rgb_output, loss_mse_out,
-                       (float4*)dloss_doutput);
-    XR_LAUNCH_CHECK();
-    return XR_OK;
+    return xr_composite_train2(network_output, coords, rays_numsteps, rays_numsteps_compacted, bg_color, target, alpha_mask,
+                               density_grid_mean, n_rays, rgb_activation, density_activation, delta, scale, rgb_output, loss_mse_out,
+                               dloss_doutput, nullptr, stream_);
 }
-

@@ -661,6 +661,9 @@ uint32_t xr_scatter3_atomic_mask(uint32_t n, const GridMeta& gm, uint32_t hashed
     return P.atomic_mask;
 }
 
+static thread_local XrAuxPrologue* g_aux_prologue = nullptr;
+void xr_internal_scatter_aux_prologue(XrAuxPrologue* p) { g_aux_prologue = p; }
+
 int xr_scatter3(const float* x, uint32_t x_stride, const float* denc_t, uint32_t ld, uint32_t n, const uint32_t* n_dev,
                 const uint32_t* rows, const GridMeta& gm, uint32_t hashed_mask, float* grad_table, void* workspace,
                 size_t workspace_bytes, int overwrite, uint32_t* atomic_mask, hipStream_t stream) {
@@ -701,6 +704,11 @@ int xr_scatter3(const float* x, uint32_t x_stride, const float* denc_t, uint32_t
             XR_HIP(hipEventRecord(ev_fork, stream));
             XR_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
             rs = aux;
+            if (g_aux_prologue && !g_aux_prologue->done) {            // a caller's small kernel that only has to finish by the join
+                g_aux_prologue->done = true;
+                const int rc = g_aux_prologue->fn(aux, g_aux_prologue->arg);
+                if (rc != XR_OK) return rc;
+            }
         }
         hipLaunchKernelGGL(k_scatter_dense_rl, dim3(P.rl.blocks), dim3(S3_R_THREADS), S3_LDS_BYTES, rs, P.rl, x, x_stride, denc_t, ld, n,
                            n_dev, rows, slabs);

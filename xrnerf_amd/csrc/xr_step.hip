@@ -37,7 +37,7 @@ extern "C" int xr_ngp_train_step(
     uint32_t n_rays, const float* bg_color, const float* target, const float* alpha_mask, const float* density_grid_mean,
     int rgb_activation, int density_activation, float huber_delta, float loss_scale,
     float* enc_t, uint32_t ld, float* raw, float* draw, float* denc_t, float* rgb_out,
-    float* zero_block, size_t zero_floats, float* grad_w_density, float* grad_w_color, float* loss_mse,
+    float* zero_block, size_t zero_floats, float* grad_w_density, float* grad_w_color, float* loss_mse, uint32_t* live_seg_count,
     float* grad_table, size_t table_floats, int zero_draw,
     void* ws_mlp_bwd, size_t ws_mlp_bwd_bytes, void* ws_scatter, size_t ws_scatter_bytes, int scatter_level0,
     const float* xyz_planes, uint32_t plane_stride, const char* mark_entry, void* mark_event,
@@ -51,19 +51,12 @@ extern "C" int xr_ngp_train_step(
     XR_REQUIRE(!timed_entry || (timing_begin && timing_end), "a timed entry point needs its two events");
     XR_REQUIRE(!mark_entry || mark_event, "a marked entry point needs its event");
     hipStream_t stream = (hipStream_t)stream_;
-    // XR_STEP_OVERLAP=1 (measurement; default off): the reduction of the MLP backward's per-workgroup partials (first read by
-    // the optimiser) goes to a helper stream beside the scatter, forked from / joined into the caller's stream with events.
-    // Measured on the MI355X in round 2 together with the then 48.8-MB zero-fill of the table gradient beside the encode
-    // (tools/iter_times.py, steady state): a normal iteration took 0.562 ms WITH it against 0.542 ms on one stream (fp16 mode:
-    // 0.66 against 0.50) -- the cross-queue joins cost more than the 13 us of kernels they took off the stream.  The zero-fill
-    // itself is gone: the scatter WRITES the table gradient (XR_SCATTER_OVERWRITE, csrc/xr_scatter.hip).
-    static hipStream_t aux = nullptr;
-    static hipEvent_t ev_fork1 = nullptr, ev_red = nullptr;
-    static const bool overlap = []() { const char* e = getenv("XR_STEP_OVERLAP"); return e && e[0] == '1'; }();
-    if (overlap && !aux) {
-        XR_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
-        for (hipEvent_t* e : {&ev_fork1, &ev_red}) XR_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
-    }
+    // The reduction of the MLP backward's per-workgroup partials (first read by the optimiser) rides on the helper stream the
+    // table scatter forks anyway for its small dense levels, in front of them: one launch and one dependent-kernel boundary
+    // (~5 us each on this part) less on the caller's stream, no event of its own.  XR_STEP_REDUCE_AUX=0: on the caller's stream.
+    // (Round 2 measured a SEPARATE fork / join for it: 0.562 ms against 0.542 ms per iteration -- the extra cross-queue joins
+    // cost more than the kernel.)  The zero-fill of the table gradient is gone: the scatter WRITES it (XR_SCATTER_OVERWRITE).
+    static const bool reduce_aux = []() { const char* e = getenv("XR_STEP_REDUCE_AUX"); return !(e && e[0] == '0'); }();
     auto begin = [&](const char* name) -> int { if (stage_is(timed_entry, name)) XR_HIP(hipEventRecord((hipEvent_t)timing_begin, stream)); return XR_OK; };
     // mark_entry / mark_event: the event is recorded on `stream` right behind the named entry point's launches (the trainer
     // starts the next batch's side-stream march from there instead of beside the fused-MLP forward)
@@ -88,24 +81,33 @@ extern "C" int xr_ngp_train_step(
     if ((rc = end("xr_nerf_mlp_fwd")) != XR_OK) return rc;
     XR_HIP(hipMemsetAsync(zero_block, 0, zero_floats * sizeof(float), stream));         // MLP gradients + loss accumulators
     if (zero_draw) XR_HIP(hipMemsetAsync(draw, 0, (size_t)n_rows * 4 * sizeof(float), stream));
-    if ((rc = begin("xr_composite_train")) != XR_OK) return rc;
-    rc = xr_composite_train(raw, coords, rays_numsteps, rays_numsteps_compacted, bg_color, target, alpha_mask, density_grid_mean,
-                            n_rays, rgb_activation, density_activation, huber_delta, loss_scale, rgb_out, loss_mse, draw, stream_);
-    if (rc != XR_OK) return rc;
-    if ((rc = end("xr_composite_train")) != XR_OK) return rc;
     // rows with an exactly-zero dL/d(raw) (T == 0 behind a surface) are skipped by the MLP backward AND the scatter: one list.
+    // The compositor counts the live rows per 1024-row segment while it writes them (no separate counting launch).
     // XR_MLP_LIVE=0 (measurement, read once): no list -- both run over every marched row, same results.
     static const bool live_on = []() { const char* e = getenv("XR_MLP_LIVE"); return !(e && e[0] == '0'); }();
     uint32_t *rows = nullptr, *seg = nullptr, *n_live = nullptr;
-    if ((rc = begin("xr_live_rows")) != XR_OK) return rc;
     if (live_on) {
         rc = xr_nerf_mlp_bwd_list_slots(ws_mlp_bwd, ws_mlp_bwd_bytes, n_rows, &rows, &seg, &n_live);
         if (rc != XR_OK) return rc;
-        rc = xr_live_rows(draw, n_rows, n_dev, seg, rows, n_live, nullptr, ld, stream_);
+        // the per-segment counts start at zero: a caller that placed them inside zero_block had them cleared just above
+        const bool in_block = live_seg_count && (float*)live_seg_count >= zero_block &&
+                              (float*)(live_seg_count + xr_live_rows_segments(n_rows)) <= zero_block + zero_floats;
+        if (live_seg_count) seg = live_seg_count;
+        if (!in_block) XR_HIP(hipMemsetAsync(seg, 0, xr_live_rows_segments(n_rows) * sizeof(uint32_t), stream));
+    }
+    if ((rc = begin("xr_composite_train")) != XR_OK) return rc;
+    // (the two loss scalars are a function of rgb_out: one fixed-order sum on the scatter's helper stream, see below)
+    rc = xr_composite_train2(raw, coords, rays_numsteps, rays_numsteps_compacted, bg_color, target, alpha_mask, density_grid_mean,
+                             n_rays, rgb_activation, density_activation, huber_delta, loss_scale, rgb_out, nullptr, draw, seg, stream_);
+    if (rc != XR_OK) return rc;
+    if ((rc = end("xr_composite_train")) != XR_OK) return rc;
+    if ((rc = begin("xr_live_rows")) != XR_OK) return rc;
+    if (live_on) {
+        rc = xr_live_rows2(draw, n_rows, n_dev, seg, rows, n_live, nullptr, ld, 1, stream_);
         if (rc != XR_OK) return rc;
     }
     if ((rc = end("xr_live_rows")) != XR_OK || (rc = begin("xr_nerf_mlp_bwd")) != XR_OK) return rc;
-    xr_internal_defer_mlp_reduce(overlap);
+    xr_internal_defer_mlp_reduce(true);                 // (the reduce is issued below: helper stream, or this one)
     rc = f16_mlp ? xr_nerf_mlp_bwd_f16(enc_t, ld, coords + 4, 7, n_rows, n_dev, w_density, w_color, n_hidden_density, n_hidden_color,
                                        pad_value, draw, denc_t, grad_w_density, grad_w_color, ws_mlp_bwd, ws_mlp_bwd_bytes, rows, n_live, stream_)
                  : xr_nerf_mlp_bwd(enc_t, ld, coords + 4, 7, n_rows, n_dev, w_density, w_color, n_hidden_density, n_hidden_color,
@@ -113,13 +115,15 @@ extern "C" int xr_ngp_train_step(
     xr_internal_defer_mlp_reduce(false);
     if (rc != XR_OK) return rc;
     if ((rc = end("xr_nerf_mlp_bwd")) != XR_OK) return rc;
-    if (overlap) {
-        XR_HIP(hipEventRecord(ev_fork1, stream));
-        XR_HIP(hipStreamWaitEvent(aux, ev_fork1, 0));
-        rc = xr_nerf_mlp_bwd_reduce(ws_mlp_bwd, n_rows, grad_w_density, grad_w_color, aux);
-        if (rc != XR_OK) return rc;
-        XR_HIP(hipEventRecord(ev_red, aux));
-    }
+    struct TailArgs { void* ws; uint32_t n; float *gd, *gc; const float *rgb, *target, *alpha; uint32_t n_rays; float delta, scale; float* loss; }
+        ta = {ws_mlp_bwd, n_rows, grad_w_density, grad_w_color, rgb_out, target, alpha_mask, n_rays, huber_delta, loss_scale, loss_mse};
+    XrAuxPrologue pro = {[](hipStream_t st, void* a) -> int {
+                             auto* r = (TailArgs*)a;
+                             const int rc1 = xr_nerf_mlp_bwd_reduce(r->ws, r->n, r->gd, r->gc, st);
+                             if (rc1 != XR_OK) return rc1;
+                             return xr_train_loss_scalars(r->rgb, r->target, r->alpha, r->n_rays, r->delta, r->scale, r->loss, st);
+                         }, &ta, false};
+    if (reduce_aux) xr_internal_scatter_aux_prologue(&pro);
     if ((rc = begin("xr_hashgrid_bwd")) != XR_OK) return rc;
     // data-parallel callers scatter the levels below scatter_level0 themselves (xr_hashgrid_bwd with the same row list, found
     // through xr_nerf_mlp_bwd_list_slots) AFTER handing the finer levels' gradient slice to the collective: table offsets are
@@ -128,9 +132,10 @@ extern "C" int xr_ngp_train_step(
     rc = xr_hashgrid_bwd2(coords, 7, denc_t + (size_t)2 * scatter_level0 * ld, ld, n_rows, live_on ? n_live : n_dev, rows, n_levels - scatter_level0,
                           scale_host + scatter_level0, resolution_host + scatter_level0, offset_host + scatter_level0, grad_table,
                           ws_scatter, ws_scatter_bytes, XR_SCATTER_OVERWRITE, stream_);
+    xr_internal_scatter_aux_prologue(nullptr);
     if (rc != XR_OK) return rc;
+    if (!pro.done && (rc = pro.fn(stream, pro.arg)) != XR_OK) return rc;     // the scatter did not fork (or XR_STEP_REDUCE_AUX=0)
     if ((rc = end("xr_hashgrid_bwd")) != XR_OK) return rc;
-    if (overlap) XR_HIP(hipStreamWaitEvent(stream, ev_red, 0));
     return XR_OK;
 }
 

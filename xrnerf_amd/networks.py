@@ -177,21 +177,24 @@ class _FusedTrainStepFn(torch.autograd.Function):
             # one small zero-fill for what must start at zero: the two MLP gradient buffers and the (loss, mse)
             # accumulators.  dL/draw needs none when the valid row count is on the device: rows [0, n_valid) are exactly
             # the rays' (base, count) ranges, all written by K4, and nothing downstream reads a row behind n_valid
-            nz = wd.numel() + wc.numel() + 4
+            n_seg = ops.live_segments(n)
+            nz = wd.numel() + wc.numel() + 4 + n_seg
             zbuf = torch.zeros((nz,), dtype=torch.float32, device=raw.device)
             draw = torch.empty_like(raw) if n_dev is not None else torch.zeros_like(raw)
             g_mlp = zbuf[:wd.numel() + wc.numel()]                                    # both MLP gradients, contiguous
             g_wd, g_wc = g_mlp[:wd.numel()], g_mlp[wd.numel():]
-            loss_mse = zbuf[nz - 4:nz - 2]
+            loss_mse = zbuf[nz - n_seg - 4:nz - n_seg - 2]
+            live_seg = zbuf[nz - n_seg:].view(torch.int32)       # per-segment live-row counts, filled by the compositor
             # K3 -> 5 * Huber (+ masked MSE for the logged PSNR) -> K4 as ONE launch (xr_composite_train)
             rgb = ops.composite_train(raw, sampler.coords, sampler.rays_numsteps, sampler.rays_numsteps_compacted,
                                       data['bg_color'], data['target_s'].contiguous(), data['alpha'].contiguous(),
-                                      sampler.density_grid_mean, ra, da, loss_mse, draw, delta=0.1, scale=5.0)
+                                      sampler.density_grid_mean, ra, da, None, draw, delta=0.1, scale=5.0, live_seg=live_seg)
+            ops.train_loss_scalars(rgb, data['target_s'].contiguous(), data['alpha'].contiguous(), 0.1, 5.0, out=loss_mse)
             g_table = torch.zeros_like(table)
             denc_t = torch.empty_like(enc_t)
             # samples behind an opaque surface have an exactly-zero dL/d(raw) row (T == 0): the MLP backward and the scatter
             # run on the list of the others (more than half of the rows are dead in steady state)
-            live = ops.live_rows(draw, n, n_dev=n_dev)
+            live = ops.live_rows(draw, n, n_dev=n_dev, seg_counts=live_seg)       # (the compositor counted them per segment)
             ops.nerf_mlp_bwd(enc_t, dirs, n, wd, wc, nhd, nhc, draw, g_wd, g_wc, mlp.pad_value, denc_t=denc_t, n_dev=n_dev, live=live)
             sync = getattr(net, 'grad_sync', None)
             if sync is None:

@@ -277,16 +277,21 @@ def calc_rgb_backward(raw, numsteps_c, coords, grad_rgb, rgb_out, density_grid_m
 
 
 def composite_train(raw, coords, numsteps, numsteps_c, bg, target, alpha, density_grid_mean, rgb_act, density_act, loss_mse, draw,
-                    delta=0.1, scale=5.0, rgb=None):
+                    delta=0.1, scale=5.0, rgb=None, live_seg=None):
     """K3 + scale * Huber (+ masked MSE) + K4 in one launch -> rgb [n,3]; `loss_mse` [2] and `draw` [S,4] must be zero-filled
-    (loss terms are added, rows behind the last sample are not written)"""
+    (loss terms are added, rows behind the last sample are not written).
+    live_seg (int32 [live_segments(S)], zero-filled by the caller): the launch also counts the non-zero rows of `draw` per
+    1024-row segment into it (xr_composite_train2); follow with live_rows(..., seg_counts=live_seg).
+    loss_mse=None: the wave-per-ray kernel (rgb / draw differ from the 16-lane kernels' like two fp32 summation orders); the loss
+    scalars then come from train_loss_scalars(rgb, ...)."""
     n = numsteps.shape[0]
     if rgb is None:
         rgb = torch.empty((n, 3), dtype=torch.float32, device=raw.device)
+    p_seg = _ptr(live_seg)
     with _span('xr_composite_train', 0):
-        _lib.check(_lib.load().xr_composite_train(_ptr(raw), _ptr(coords), _ptr(numsteps), _ptr(numsteps_c), _ptr(bg), _ptr(target),
-                                                  _ptr(alpha), _ptr(density_grid_mean), n, int(rgb_act), int(density_act),
-                                                  float(delta), float(scale), _ptr(rgb), _ptr(loss_mse), _ptr(draw), _stream()),
+        _lib.check(_lib.load().xr_composite_train2(_ptr(raw), _ptr(coords), _ptr(numsteps), _ptr(numsteps_c), _ptr(bg), _ptr(target),
+                                                   _ptr(alpha), _ptr(density_grid_mean), n, int(rgb_act), int(density_act),
+                                                   float(delta), float(scale), _ptr(rgb), _ptr(loss_mse), _ptr(draw), p_seg, _stream()),
                    'xr_composite_train')
     return rgb
 
@@ -320,7 +325,10 @@ class TrainStepBuffers:
         self.n_rows, self.ray_cap, self.ld = n_rows, ray_cap, (n_rows + 63) // 64 * 64
         self.enc_t, self.denc_t = f(meta.n_output_dims, self.ld), f(meta.n_output_dims, self.ld)
         self.raw, self.draw, self.rgb = f(n_rows, 4), f(n_rows, 4), f(ray_cap, 3)
-        self.zero_block = f(wd_floats + wc_floats + 4)
+        # one zero-fill per step covers the MLP gradients, the (loss, mse) accumulators and the compositor's live-row counts
+        n_seg = int(_lib.load().xr_live_rows_segments(n_rows))
+        self.zero_block = f(wd_floats + wc_floats + 4 + n_seg)
+        self.live_seg = self.zero_block[wd_floats + wc_floats + 4:]
         self.g_wd, self.g_wc = self.zero_block[:wd_floats], self.zero_block[wd_floats:wd_floats + wc_floats]
         self.g_mlp = self.zero_block[:wd_floats + wc_floats]
         self.loss_mse = self.zero_block[wd_floats + wc_floats:wd_floats + wc_floats + 2]
@@ -361,7 +369,7 @@ def ngp_train_step(table, wd, wc, nhd, nhc, pad_value, meta, coords, n_dev, nums
             _ptr(coords), n_rows, _ptr(n_dev), _ptr(numsteps), _ptr(numsteps_c), n_rays, _ptr(bg), _ptr(target), _ptr(alpha),
             _ptr(density_grid_mean), int(rgb_act), int(density_act), float(huber_delta), float(loss_scale),
             _ptr(bufs.enc_t), bufs.ld, _ptr(bufs.raw), _ptr(bufs.draw), _ptr(bufs.denc_t), _ptr(bufs.rgb),
-            _ptr(bufs.zero_block), bufs.zero_block.numel(), _ptr(bufs.g_wd), _ptr(bufs.g_wc), _ptr(bufs.loss_mse),
+            _ptr(bufs.zero_block), bufs.zero_block.numel(), _ptr(bufs.g_wd), _ptr(bufs.g_wc), _ptr(bufs.loss_mse), _ptr(bufs.live_seg),
             _ptr(bufs.g_table), bufs.g_table.numel(), 0 if n_dev is not None else 1,
             _ptr(ws_mlp), ws_mlp.numel(), _ptr(ws_sc), ws_sc.numel(), int(scatter_level0),
             _ptr(xyz), xyz.shape[1] if xyz is not None else 0, mark[0].encode() if mark else None, mark[1].h if mark else None,
@@ -679,16 +687,32 @@ def _list_slots(dev, n):
     return ws, rows, p_seg, cnt
 
 
-def live_rows(draw, n, n_dev=None, zero_denc_t=None):
+def train_loss_scalars(rgb, target, alpha, delta=0.1, scale=5.0, out=None):
+    """-> out[2] = (scale * sum HuberLoss(rgb - target), sum ((rgb - target) * alpha)^2), written by one fixed-order sum"""
+    if out is None:
+        out = torch.empty((2,), dtype=torch.float32, device=rgb.device)
+    _lib.check(_lib.load().xr_train_loss_scalars(_ptr(rgb), _ptr(target), _ptr(alpha), rgb.shape[0], float(delta), float(scale),
+                                                 _ptr(out), _stream()), 'xr_train_loss_scalars')
+    return out
+
+
+def live_segments(n):
+    """number of 1024-row segments of n rows (length of the compositor's live-row count array)"""
+    return int(_lib.load().xr_live_rows_segments(n))
+
+
+def live_rows(draw, n, n_dev=None, zero_denc_t=None, seg_counts=None):
     """-> (rows int32 [n], n_live int32 [4]) on the device: the rows of dL/d(raw) [n,4] that are not exactly zero, in
     order (xr_live_rows); n_live[0] is the count.  Handed to nerf_mlp_bwd and hashgrid_bwd as `live=`.  The list sits in
-    the MLP backward's workspace (where xr_ngp_train_step keeps it too) and is overwritten by the next call."""
+    the MLP backward's workspace (where xr_ngp_train_step keeps it too) and is overwritten by the next call.
+    seg_counts: the per-segment counts composite_train(..., live_seg=) left (one launch less: the ranking pass only)."""
     global LIVE_STATS
     _, rows, p_seg, n_live = _list_slots(draw.device, n)
     LIVE_STATS = n_live
     with _span('xr_live_rows', 0 if n_dev is not None else n, train=n_dev is not None):
-        _lib.check(_lib.load().xr_live_rows(_ptr(draw), n, _ptr(n_dev), p_seg, _ptr(rows), _ptr(n_live),
-                                            _ptr(zero_denc_t), zero_denc_t.shape[1] if zero_denc_t is not None else 0, _stream()), 'xr_live_rows')
+        _lib.check(_lib.load().xr_live_rows2(_ptr(draw), n, _ptr(n_dev), p_seg if seg_counts is None else _ptr(seg_counts), _ptr(rows),
+                                             _ptr(n_live), _ptr(zero_denc_t), zero_denc_t.shape[1] if zero_denc_t is not None else 0,
+                                             0 if seg_counts is None else 1, _stream()), 'xr_live_rows')
     return rows, n_live
 
 
