@@ -722,7 +722,7 @@ def main():
     LIVE_KERNELS = ('xr_nerf_mlp_bwd', 'xr_hashgrid_bwd')
     live_frac_timed = live_fraction()
 
-    def roof_of(name, launches, total_ms, units, live_frac=1.0):
+    def roof_of(name, launches, total_ms, units, live_frac=1.0, native=True):
         bound, per_unit = ALGO[name]
         halves = world > 1 and name == 'xr_hashgrid_bwd'
         if halves:
@@ -730,6 +730,11 @@ def main():
         if name in LIVE_KERNELS:
             units = units * live_frac
         work = units * per_unit
+        fused_adam = native and name == 'xr_hashgrid_bwd' and getattr(tr, 'fuse_adam', False) and world == 1
+        if fused_adam:
+            # the scatter applies the optimiser's update to the table itself (xr_hashgrid_bwd_adam): per launch and table
+            # parameter it reads p, m, v, ema and writes them back (32 B; the gradient never exists in memory)
+            work += launches * tr.net.mlp.embedder_pos.params.numel() * 32
         if bound == 'hbm':
             achieved, peak, unit = work / (total_ms * 1e-3) / 1e9, HBM_PEAK_GBS, 'GB/s'
         else:
@@ -748,6 +753,8 @@ def main():
             out['frac_of_fp32_mfma_peak'] = achieved / MFMA_F32_PEAK_TFLOPS
         if halves:
             out['note'] = 'entry point called twice per step (levels 8..15, then 0..7, each handed to the all-reduce): figures are per step'
+        if fused_adam:
+            out['includes'] = 'Adam + L2 + EMA update of the %d table parameters, applied where each entry\'s gradient completes (32 B per parameter per launch on top of the per-sample figure)' % tr.net.mlp.embedder_pos.params.numel()
         if name in LIVE_KERNELS:
             out['live_row_fraction'] = live_frac
             out['units'] = 'samples with a non-zero output gradient (the rows the launch processes); the others are exact zeros'
@@ -768,24 +775,29 @@ def main():
     except Exception:  # noqa: BLE001
         pass
 
-    # ---- every hot kernel's roofline, from a second window of 32 more iterations with events around all training
-    # launches (kept out of the timed region: the events cost ~0.07 ms/step)
-    s0 = tr.samples_done
-    ops.TIMER = ops.KernelTimer(only=set(ALGO), train_only=True)
-    if ops.LIVE_STATS is not None:
-        ops.LIVE_STATS[1:3].zero_()
-    for _ in range(32):
-        tr.step()
-    torch.cuda.synchronize()
-    timer2, ops.TIMER = ops.TIMER, None
-    live_frac_win = live_fraction()
-    s_win = tr.samples_done - s0
-    r_win = None
+    # ---- every hot kernel's roofline: 16 more iterations per entry point with events around THAT entry point only, so that every
+    # window runs the product's native step (a timer that wants several stages of the step at once forces the per-entry-point
+    # Python sequence, which has neither the fused optimiser update nor the helper-stream tail).  Out of the timed region.
     roofs = {}
-    for k, (n_l, ms_l, u_l) in timer2.summary().items():
-        if k == 'xr_rays_sampler':
-            continue          # runs on the side stream beside other kernels: its span is not its duration
-        roofs[k] = roof_of(k, n_l, ms_l, u_l if u_l > 0 else s_win, live_frac_win)      # Adam counts parameters, the rest samples
+    s_win = 0
+    for k in ALGO:
+        if k in ('xr_rays_sampler', 'xr_calc_rgb_forward', 'xr_calc_rgb_backward'):
+            continue          # K1 runs on the side stream beside other kernels (its span is not its duration); K3 / K4 alone are not on the training path
+        s0 = tr.samples_done
+        ops.TIMER = ops.KernelTimer(only={k}, train_only=True)
+        if ops.LIVE_STATS is not None:
+            ops.LIVE_STATS[1:3].zero_()
+        for _ in range(16):
+            tr.step()
+        torch.cuda.synchronize()
+        timer2, ops.TIMER = ops.TIMER, None
+        live_frac_win = live_fraction()
+        s_win = tr.samples_done - s0
+        summ2 = timer2.summary()
+        if k in summ2:
+            n_l, ms_l, u_l = summ2[k]
+            roofs[k] = roof_of(k, n_l, ms_l, u_l if u_l > 0 else s_win, live_frac_win)      # Adam counts parameters, the rest samples
+    r_win = None
 
     extra = {}
     if ops._mlp_mode() == 2:

@@ -283,6 +283,24 @@ int xr_live_rows(const float* dloss_doutput, uint32_t n, const uint32_t* n_dev, 
 int xr_live_rows2(const float* dloss_doutput, uint32_t n, const uint32_t* n_dev, uint32_t* seg_count, uint32_t* live_rows,
                   uint32_t* n_live, float* zero_denc_t, uint32_t ld, int seg_counts_ready, void* stream);
 
+/* The table scatter with the optimiser's update applied in place of the gradient write: the scatter owns every entry of its
+ * levels exactly once per launch, so it can run Adam (+ L2 weight decay, + the EMA copy) on (param, m, v, ema) where an entry's
+ * gradient is complete -- same update, bit for bit, as xr_hashgrid_bwd2(XR_SCATTER_OVERWRITE) followed by xr_adam_step_multi
+ * on the table, without the 48.8-MB gradient write + read and without the separate HBM-bound launch.  No gradient is produced.
+ * Single-GPU training only (a data-parallel step must reduce the gradient first).  xr_hashgrid_bwd_adam_supported: 1 when every
+ * level of this geometry / row capacity has a non-atomic path (otherwise the call fails before launching anything). */
+typedef struct xr_adam_fuse {
+    float* param; float* m; float* v; float* ema;   /* whole tensors, 16-byte aligned; ema nullable */
+    int step;                                       /* 1, 2, ... (this update's bias correction) */
+    float lr, beta1, beta2, eps, weight_decay, ema_momentum, grad_scale;
+} xr_adam_fuse;
+int xr_hashgrid_bwd_adam_supported(uint32_t n, int n_levels, const float* scale_host, const uint32_t* resolution_host,
+                                   const uint32_t* offset_host);
+int xr_hashgrid_bwd_adam(const float* x, uint32_t x_stride, const float* denc_t, uint32_t ld, uint32_t n, const uint32_t* n_dev,
+                         const uint32_t* rows, int n_levels, const float* scale_host, const uint32_t* resolution_host,
+                         const uint32_t* offset_host, void* workspace, size_t workspace_bytes, const xr_adam_fuse* adam,
+                         void* stream);
+
 /* Reference-precision mode of the two calls above: tiny-cuda-nn computes FullyFusedMLP in fp16 with fp32 accumulation
  * (the reference casts its half outputs to fp32, hashnerf_mlp.py:76-77).  Same contracts, parameters and gradients stay
  * fp32 in memory; weights / activations are rounded to fp16 inside the kernel (v_mfma_f32_32x32x16_f16), gradients carry
@@ -309,6 +327,8 @@ int xr_nerf_mlp_fwd_bf16x3(const float* enc_t, uint32_t ld, const float* dirs, u
  * loss_mse) -> xr_composite_train2 (which counts the live rows per segment) -> xr_live_rows2 -> xr_nerf_mlp_bwd[_f16] ->
  * xr_hashgrid_bwd2(XR_SCATTER_OVERWRITE), on `stream`:
  * grad_table's slices of the scattered levels are WRITTEN (no zero-fill; whatever they held is gone).
+ * table_adam (nullable): the scatter becomes xr_hashgrid_bwd_adam -- the table is UPDATED by this call and grad_table (then
+ * nullable) is not written; single GPU, scatter_level0 == 0.
  * live_seg_count (nullable): xr_live_rows_segments(n_rows) words for the per-segment counts; placed inside zero_block they are
  * cleared by the one zero-fill, elsewhere (or null: the slot in ws_mlp_bwd) by one more.
  * coords: K1's [n_rows,7] rows (positions / directions consumed in place); n_dev: device count of valid rows; every buffer
@@ -329,8 +349,8 @@ int xr_ngp_train_step(const float* table, const float* w_density, const float* w
                       float* draw, float* denc_t, float* rgb_out, float* zero_block, size_t zero_floats, float* grad_w_density,
                       float* grad_w_color, float* loss_mse, uint32_t* live_seg_count, float* grad_table, size_t table_floats, int zero_draw,
                       void* ws_mlp_bwd, size_t ws_mlp_bwd_bytes, void* ws_scatter, size_t ws_scatter_bytes, int scatter_level0,
-                      const float* xyz_planes, uint32_t plane_stride, const char* mark_entry, void* mark_event,
-                      const char* timed_entry, void* timing_begin, void* timing_end, void* stream);
+                      const float* xyz_planes, uint32_t plane_stride, const xr_adam_fuse* table_adam, const char* mark_entry,
+                      void* mark_event, const char* timed_entry, void* timing_begin, void* timing_end, void* stream);
 /* xyz_planes (nullable): the positions of `coords` once more as three planes of plane_stride floats (xr_rays_sampler2 /
  * xr_ngp_prefetch write them); the encoder then reads them with coalesced loads (xr_hashgrid_fwd2). */
 /* timed_entry (nullable): the name of ONE of the entry points the step runs ("xr_hashgrid_fwd", "xr_nerf_mlp_fwd",

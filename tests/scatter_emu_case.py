@@ -89,6 +89,29 @@ def main(n, mode):
         g = torch.full((meta.n_params,), 9.0)
         ops.hashgrid_bwd(tx, dt, meta, g, n_dev=torch.tensor([0], dtype=torch.int32), overwrite=True)
         report('device-side count 0', g, np.zeros_like(ref))
+        # the optimiser's update applied by the scatter itself (xr_hashgrid_bwd_adam) = scatter (overwrite) + xr_adam_step_multi,
+        # bit for bit, on a live-row list; two steps so that m / v / ema carry over
+        if ops.hashgrid_bwd_adam_supported(n, meta):
+            P = [torch.from_numpy(rng.uniform(-1e-4, 1e-4, meta.n_params).astype(np.float32)) for _ in range(2)]
+            P[1] = P[0].clone()
+            M, V, E = ([torch.zeros(meta.n_params) for _ in range(2)] for _ in range(3))
+            for k in range(2):
+                E[k].copy_(P[k])
+            live_t = (rows, torch.tensor([len(live), 0, 0, 0], dtype=torch.int32))
+            same = True
+            for step in (1, 2):
+                mom = min(0.05, step / (100.0 + step - 1))
+                g = torch.full((meta.n_params,), 5.0)
+                ops.hashgrid_bwd(tx, dtp.contiguous(), meta, g, live=live_t, overwrite=True)
+                ops.adam_step_multi([P[0]], [g], [M[0]], [V[0]], step, 1e-2, 0.9, 0.99, 1e-15, 1e-6, [E[0]], mom)
+                ops.hashgrid_bwd_adam(tx, dtp.contiguous(), meta, ops.adam_fuse(P[1], M[1], V[1], E[1], step, 1e-2, 0.9, 0.99, 1e-15, 1e-6, mom),
+                                      live=live_t)
+                same = same and all(torch.equal(a[0], a[1]) for a in (P, M, V, E))
+            moved = float((P[0] - E[0]).abs().max()) > 0
+            ok = ok and same and moved
+            print('%-26s parameters / m / v / ema identical to scatter + optimiser launch: %s' % ('fused optimiser update', same and moved))
+        else:
+            print('%-26s not available with these switches' % 'fused optimiser update')
     return 0 if ok else 1
 
 

@@ -23,6 +23,7 @@ def run(n, mode, **env):
 def test_scatter_generation_3_against_the_oracle(n, mode):
     out = run(n, mode)
     assert out.count('levels out of tolerance: []') == 7, out
+    assert 'identical to scatter + optimiser launch: True' in out, out
 
 
 @pytest.mark.parametrize('n,mode,env', [(5000, 'cluster', dict(XR_SC_BLOCK='1024')), (9000, 'rays', dict(XR_SC_BLOCK='4096')),

@@ -273,3 +273,25 @@ def test_chunked_frame_without_per_chunk_readback_gives_the_same_pixels(dev, tra
         monkeypatch.setenv('XRNERF_ASYNC_CHUNKS', env)
         rgb_e, a_e = render_frame(net, up, 96, 96, tr.data.focal, chunk=4096)
         assert float(a_e.abs().max()) == 0.0
+
+
+def test_table_update_inside_the_scatter_equals_scatter_plus_optimiser_launch(dev, monkeypatch):
+    """One GPU: the trainer lets the table scatter apply FusedAdam's update to the hash table (xr_hashgrid_bwd_adam) instead of
+    writing a gradient the optimiser launch reads back.  20 iterations (two grid refreshes) with and without: parameters, Adam
+    moments and EMA copies bit for bit, and no table gradient is produced on the fused path."""
+    from xrnerf_amd.train import Trainer
+    out = []
+    for fuse in ('1', '0'):
+        monkeypatch.setenv('XRNERF_FUSE_ADAM', fuse)
+        tr = Trainer(dev, n_img=3, H=128, W=128, seed=3)
+        assert tr.fuse_adam == (fuse == '1')
+        for _ in range(20):
+            tr.step()
+        torch.cuda.synchronize()
+        table = tr.net.mlp.embedder_pos.params
+        st = tr.opt.state[table]
+        assert (table.grad is None) == (fuse == '1')
+        out.append([p.detach().clone() for p in tr.net.parameters()] + [st['m'].clone(), st['v'].clone(), st['ema'].clone(), st['step']])
+    for a, b in zip(out[0][:-1], out[1][:-1]):
+        assert torch.equal(a, b)
+    assert out[0][-1] == out[1][-1] == 20

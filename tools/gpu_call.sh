@@ -26,7 +26,8 @@ for st in "$@"; do
              python tools/pmc_traffic.py --print $O/${TAG}_pmc_traffic.json ;;
     trace)   (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/proft && timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/proft -- \
                python $R/bench.py ${arg:---steps 40 --warmup 5 --no-cpu-baseline --no-mip --no-kilo --no-unbounded --no-render --no-f16 --no-strict --no-extra} > /tmp/bt.log 2>&1; tail -c 300 /tmp/bt.log)
-             python tools/trace_window.py $(ls /tmp/proft/*/*kernel_trace.csv | head -1) -3 | tee $O/${TAG}_trace_normal_iteration.txt ;;
+             python tools/trace_window.py $(ls /tmp/proft/*/*kernel_trace.csv | head -1) spans > $O/${TAG}_trace_spans.txt
+             python tools/trace_window.py $(ls /tmp/proft/*/*kernel_trace.csv | head -1) ${TRACE_WIN:-0.55} | tee $O/${TAG}_trace_normal_iteration.txt ;;
     scatter) timeout 900 python tools/microbench_scatter3.py $arg 2>&1 | tee $O/${TAG}_microbench_scatter3.txt ;;
     fwd)     timeout 900 python tools/microbench_fwd3.py $arg 2>&1 | tee $O/${TAG}_microbench_fwd3.txt ;;
     py)      timeout 1200 python $arg 2>&1 | tee -a $O/${TAG}_py.txt ;;

@@ -4,7 +4,16 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if 'k_adam_multi' in r['Kernel_Name']]
-which = int(sys.argv[2]) if len(sys.argv) > 2 else -2
+arg = sys.argv[2] if len(sys.argv) > 2 else '-2'
+if arg == 'spans':            # one line per window: its span and the longest kernel in it (to find the steady state)
+    for w in range(1, len(idx)):
+        a, b = idx[w - 1], idx[w]
+        span = (int(rows[b]['End_Timestamp']) - int(rows[a]['End_Timestamp'])) / 1e3
+        print('%4d %8.1f us  %d kernels' % (w, span, b - a))
+    sys.exit(0)
+which = int(float(arg) * len(idx)) if '.' in arg else int(arg)
+which = max(1, min(len(idx) - 1, which)) if which >= 0 else which
+print('# window %d of %d' % (which, len(idx)))
 a, b = idx[which - 1], idx[which]
 t0 = int(rows[a]['End_Timestamp'])
 for r in rows[a:b + 1]:

@@ -12,6 +12,13 @@ LIB_PATH = os.path.join(HERE, 'libxrnerf_mi355.so')
 _vp, _u32, _i32, _f, _u64, _sz, _d = C.c_void_p, C.c_uint32, C.c_int, C.c_float, C.c_uint64, C.c_size_t, C.c_double
 
 # name -> (restype, argtypes); mirrors include/xrnerf_mi355.h one to one
+class AdamFuse(C.Structure):
+    """xr_adam_fuse (include/xrnerf_mi355.h)"""
+    _fields_ = [('param', C.c_void_p), ('m', C.c_void_p), ('v', C.c_void_p), ('ema', C.c_void_p), ('step', C.c_int),
+                ('lr', C.c_float), ('beta1', C.c_float), ('beta2', C.c_float), ('eps', C.c_float), ('weight_decay', C.c_float),
+                ('ema_momentum', C.c_float), ('grad_scale', C.c_float)]
+
+
 SIGNATURES = {
     'xr_last_error': (C.c_char_p, []),
     'xr_version': (_i32, []),
@@ -27,6 +34,8 @@ SIGNATURES = {
     'xr_calc_rgb_forward': (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, _i32, _i32, _vp, _vp]),
     'xr_calc_rgb_backward': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _i32, _i32, _vp, _vp]),
     'xr_composite_train': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _i32, _i32, _f, _f, _vp, _vp, _vp, _vp]),
+    'xr_hashgrid_bwd_adam_supported': (_i32, [_u32, _i32, _vp, _vp, _vp]),
+    'xr_hashgrid_bwd_adam': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     'xr_train_loss_scalars': (_i32, [_vp, _vp, _vp, _u32, _f, _f, _vp, _vp]),
     'xr_composite_train2': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _i32, _i32, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     'xr_calc_rgb_inference': (_i32, [_vp, _vp, _vp, _f, _f, _f, _u32, _i32, _i32, _vp, _vp, _vp]),
@@ -51,7 +60,7 @@ SIGNATURES = {
                                _vp, _sz, _u32, _vp, _vp, _vp, _vp, _u32, _vp]),
     'xr_ngp_train_step': (_i32, [_vp, _vp, _vp, _i32, _i32, _f, _i32, _i32, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _u32, _vp, _vp, _vp,
                                  _vp, _i32, _i32, _f, _f, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp, _sz,
-                                 _vp, _sz, _i32, _vp, _u32, C.c_char_p, _vp, C.c_char_p, _vp, _vp, _vp]),
+                                 _vp, _sz, _i32, _vp, _u32, _vp, C.c_char_p, _vp, C.c_char_p, _vp, _vp, _vp]),
     'xr_timing_event_create': (_vp, []),
     'xr_stream_wait_event': (_i32, [_vp, _vp]),
     'xr_timing_event_destroy': (_i32, [_vp]),

@@ -54,7 +54,7 @@ def _stale(dst, srcs):
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, 'xr_common.h'), os.path.join(CSRC, 'xr_mip_math.h'), os.path.join(CSRC, 'xr_hashgrid.h'),
-               os.path.join(CSRC, 'xr_scatter.h'), os.path.join(HERE, '..', 'include', 'xrnerf_mi355.h'),
+               os.path.join(CSRC, 'xr_scatter.h'), os.path.join(CSRC, 'xr_adam.h'), os.path.join(HERE, '..', 'include', 'xrnerf_mi355.h'),
                os.path.abspath(__file__)]
     have_src = all(os.path.exists(os.path.join(CSRC, s)) for s in SOURCES)
     if not have_src:

@@ -11,6 +11,7 @@
 // MFMA operand loads are 256-B coalesced rows.
 #include "xr_hashgrid.h"
 #include "xr_scatter.h"
+#include "xr_adam.h"
 #include <cstdlib>
 
 extern "C" void xr_hashgrid_meta(int n_levels, int log2_hashmap_size, int base_resolution, double per_level_scale,
@@ -1188,6 +1189,36 @@ extern "C" int xr_hashgrid_bwd2(const float* x, uint32_t x_stride, const float* 
     }
     if (fork) XR_HIP(hipStreamWaitEvent(stream, ev_join, 0));
     return XR_OK;
+}
+
+extern "C" int xr_hashgrid_bwd_adam_supported(uint32_t n, int n_levels, const float* scale_host, const uint32_t* resolution_host,
+                                              const uint32_t* offset_host) {
+    GridMeta gm; uint32_t hm;
+    if (!scale_host || !resolution_host || !offset_host || n == 0 || sc_mode() != 2) return 0;
+    if (fill_meta(&gm, &hm, n_levels, scale_host, resolution_host, offset_host) != 0) return 0;
+    return xr_scatter3_atomic_mask(n, gm, hm, true) == 0 ? 1 : 0;
+}
+extern "C" int xr_hashgrid_bwd_adam(const float* x, uint32_t x_stride, const float* denc_t, uint32_t ld, uint32_t n, const uint32_t* n_dev,
+                                    const uint32_t* rows, int n_levels, const float* scale_host, const uint32_t* resolution_host,
+                                    const uint32_t* offset_host, void* workspace, size_t workspace_bytes, const xr_adam_fuse* adam,
+                                    void* stream_) {
+    XR_REQUIRE(x && denc_t && scale_host && resolution_host && offset_host && workspace && adam, "null pointer");
+    XR_REQUIRE(adam->param && adam->m && adam->v && adam->step >= 1, "bad optimiser state");
+    XR_REQUIRE((((uintptr_t)adam->param | (uintptr_t)adam->m | (uintptr_t)adam->v | (uintptr_t)adam->ema | (uintptr_t)workspace) & 15) == 0,
+               "buffers must be 16-byte aligned");
+    XR_REQUIRE(n > 0 && x_stride >= 3 && ld >= n, "bad sizes");
+    XR_REQUIRE(!rows || n_dev, "a row list comes with its device-side length (n_dev)");
+    XR_REQUIRE(xr_hashgrid_bwd_adam_supported(n, n_levels, scale_host, resolution_host, offset_host),
+               "a level of this geometry / row count has no non-atomic path (or XR_SC_MODE != 2): scatter and step separately");
+    GridMeta gm; uint32_t hm;
+    XR_REQUIRE(fill_meta(&gm, &hm, n_levels, scale_host, resolution_host, offset_host) == 0, "bad level metadata");
+    // the constants exactly as xr_adam_step_multi hands them to its kernel
+    const float bc1 = 1.f - powf(adam->beta1, (float)adam->step), bc2 = 1.f - powf(adam->beta2, (float)adam->step);
+    XrAdamArgs A = {adam->param, adam->m, adam->v, adam->ema, adam->beta1, adam->beta2, adam->lr / bc1, sqrtf(bc2), adam->eps,
+                    adam->weight_decay, adam->ema_momentum, adam->grad_scale};
+    uint32_t amask = 0;
+    return xr_scatter3(x, x_stride, denc_t, ld, n, n_dev, rows, gm, hm, adam->param /* alignment check only */, workspace, workspace_bytes,
+                       1, &amask, (hipStream_t)stream_, &A);
 }
 
 extern "C" int xr_hashgrid_bwd(const float* x, uint32_t x_stride, const float* denc_t, uint32_t ld, uint32_t n, const uint32_t* n_dev,

@@ -1,6 +1,7 @@
 // Library plumbing (error string, version, RNG host helper) and the small kernels on either side
 // of the path: ray generation, Huber loss gradient, fused Adam(+EMA).
 #include "xr_common.h"
+#include "xr_adam.h"
 #include <cstdlib>
 #include <cstdarg>
 
@@ -128,17 +129,7 @@ extern "C" int xr_make_batch(const float* rays_rgb_rows, uint32_t n, uint64_t rn
 }
 
 // ------------------------------------------------------------------ fused Adam (+L2 weight decay, + optional EMA)
-// torch.optim.Adam semantics; one pass over p,g,m,v(,ema): 16 B per lane per stream.
-// gs: a factor on the incoming gradient (1/world_size of data-parallel averaging, applied here instead of in a pass of its
-// own over the 48.8-MB gradient); rounded on its own first, so the update is bit for bit the one of `g *= gs` + this kernel
-__device__ inline void adam1(float& p, float g, float& m, float& v, float b1, float b2, float step_size, float bc2s,
-                             float eps, float wd, float gs = 1.f) {
-    g = __fmul_rn(g, gs);
-    g = g + wd * p;
-    m = b1 * m + (1.f - b1) * g;
-    v = b2 * v + (1.f - b2) * g * g;
-    p = p - step_size * (m / (sqrtf(v) / bc2s + eps));
-}
+// torch.optim.Adam semantics (adam1, xr_adam.h); one pass over p,g,m,v(,ema): 16 B per lane per stream.
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                float* __restrict__ v, size_t n, float b1, float b2, float step_size,
                                                float bc2s, float eps, float wd, float* __restrict__ ema, float mom) {

@@ -29,6 +29,7 @@
 //   v_readlane): no LDS read sits between the item loads and the returnless LDS atomics.
 #include "xr_hashgrid.h"
 #include "xr_scatter.h"
+#include "xr_adam.h"
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -87,6 +88,8 @@ struct S3Plan {
     uint32_t ovfcnt_off;             // words into counts: [lv][nsb]
     uint32_t acc_blocks;
     uint32_t lg;                     // log2 of the entries of one partition (13, or 12: two accumulate workgroups per CU)
+    uint32_t fuse;                   // != 0: the accumulate kernel applies Adam to the entries instead of writing their gradient
+    XrAdamArgs ad;
 };
 struct S3RLevel {
     float scale;
@@ -97,6 +100,8 @@ struct S3RLevel {
 struct S3RPlan {
     S3RLevel lv[EN_MAX_LEVELS];
     uint32_t n_lv, chunks, slab_entries, overwrite, blocks;
+    uint32_t fuse;                   // != 0: the fold kernel applies Adam instead of writing the gradient
+    XrAdamArgs ad;
 };
 
 // index % hsize of a dense level: inside the unit cube the index is below 2 hsize (x + y res + z res^2 with coordinates <= res)
@@ -314,6 +319,48 @@ __global__ __launch_bounds__(S3_BIN_THREADS) void k_scatter_bin3(S3Plan pl, cons
 // ------------------------------------------------------------------------------------------------ accumulate
 // One workgroup = (level, partition): fp64 LDS accumulators (returnless ds_add_f64: 8.6 ns per wave instruction, against 81 ns
 // for ds_add_f32 -- tools/lds_probe.hip), rounded to fp32 once when the partition is written to the table.
+// ---- Adam applied where the gradient of an entry is complete (XrAdamArgs, xr_adam.h): the scatter owns every table entry of
+// its levels exactly once per launch (what XR_SCATTER_OVERWRITE relies on), so instead of writing 48.8 MB of gradient that the
+// optimiser launch reads back next, the accumulate / fold kernels run the optimiser's update on (p, m, v, ema) themselves:
+// 98 MB and one 70-us HBM-bound launch less per step, its streams spread under the LDS-bound phases of other workgroups.
+// Same adam1 / ema1 as k_adam_multi, same operand order: parameters bit for bit those of scatter + xr_adam_step_multi.
+typedef float s3_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 s3_ldnt(const float* base, size_t e) {
+    const s3_f2 r = __builtin_nontemporal_load(reinterpret_cast<const s3_f2*>(base) + e);
+    return make_float2(r.x, r.y);
+}
+__device__ __forceinline__ void s3_stnt(float* base, size_t e, float2 v) {
+    s3_f2 r; r.x = v.x; r.y = v.y;
+    __builtin_nontemporal_store(r, reinterpret_cast<s3_f2*>(base) + e);
+}
+typedef float s3_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 s3_ld4nt(const float* base, size_t i4) {
+    const s3_f4 r = __builtin_nontemporal_load(reinterpret_cast<const s3_f4*>(base) + i4);
+    return make_float4(r.x, r.y, r.z, r.w);
+}
+__device__ __forceinline__ void s3_st4nt(float* base, size_t i4, float4 v) {
+    s3_f4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
+    __builtin_nontemporal_store(r, reinterpret_cast<s3_f4*>(base) + i4);
+}
+template <int N>
+__device__ __forceinline__ void s3_adam_entries(const XrAdamArgs& A, const size_t (&e)[N], const float2 (&g)[N], const bool (&on)[N]) {
+    float2 p[N], m[N], v[N], q[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+        if (on[k]) {
+            p[k] = reinterpret_cast<const float2*>(A.p)[e[k]]; m[k] = s3_ldnt(A.m, e[k]); v[k] = s3_ldnt(A.v, e[k]);
+            if (A.ema) q[k] = s3_ldnt(A.ema, e[k]);
+        }
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+        if (on[k]) {
+            adam1(p[k].x, g[k].x, m[k].x, v[k].x, A.b1, A.b2, A.step_size, A.bc2s, A.eps, A.wd, A.gs);
+            adam1(p[k].y, g[k].y, m[k].y, v[k].y, A.b1, A.b2, A.step_size, A.bc2s, A.eps, A.wd, A.gs);
+            reinterpret_cast<float2*>(A.p)[e[k]] = p[k]; s3_stnt(A.m, e[k], m[k]); s3_stnt(A.v, e[k], v[k]);
+            if (A.ema) { q[k].x = ema1(q[k].x, p[k].x, A.mom); q[k].y = ema1(q[k].y, p[k].y, A.mom); s3_stnt(A.ema, e[k], q[k]); }
+        }
+}
+
 template <int LG>
 __global__ __launch_bounds__(1 << (LG - 3)) void k_scatter_accum3(S3Plan pl, const uint32_t* __restrict__ counts,
                                                                   const float4* __restrict__ bins, const float4* __restrict__ ovf,
@@ -433,11 +480,72 @@ __global__ __launch_bounds__(1 << (LG - 3)) void k_scatter_accum3(S3Plan pl, con
             }
         }
     }
+    // fused optimiser update, hashed levels: this thread's 8 entries are 4 pairs of neighbours (16 B of p / m / v / ema each), taken
+    // in two rounds of two pairs; the first round's loads go out before the barrier that waits for every wave's LDS atomics
+    constexpr uint32_t FP = ENTRIES / (2 * THREADS), FH = FP / 2;
+    static_assert(FP == 4, "two rounds of two pairs");
+    const bool fuse_h = pl.fuse != 0u && L.kind == S3_H;
+    float4 fp_[FH], fm_[FH], fv_[FH], fq_[FH];
+    const size_t f4_0 = ((size_t)L.toff + (size_t)part * ENTRIES) / 2;      // float4 index of the partition's first pair (offsets are even)
+    auto adam_load = [&](uint32_t k0) {
+#pragma unroll
+        for (uint32_t k = 0; k < FH; ++k) {
+            const size_t i4 = f4_0 + (k0 + k) * THREADS + threadIdx.x;
+            fp_[k] = reinterpret_cast<const float4*>(pl.ad.p)[i4]; fm_[k] = s3_ld4nt(pl.ad.m, i4); fv_[k] = s3_ld4nt(pl.ad.v, i4);
+            if (pl.ad.ema) fq_[k] = s3_ld4nt(pl.ad.ema, i4);
+        }
+    };
+    if (fuse_h) adam_load(0);
     __syncthreads();
     S3_T(5);
     float2* __restrict__ tab = reinterpret_cast<float2*>(grad_table) + L.toff;
     const bool add = pl.overwrite == 0u;
-    if (L.kind == S3_H) {
+    if (fuse_h) {
+        const XrAdamArgs& A = pl.ad;
+#pragma unroll
+        for (uint32_t r = 0; r < 2; ++r) {
+            double2 a0[FH], a1[FH];
+#pragma unroll
+            for (uint32_t k = 0; k < FH; ++k) { const uint32_t q = 2u * ((r * FH + k) * THREADS + threadIdx.x); a0[k] = acc2[q]; a1[k] = acc2[q + 1]; }
+#pragma unroll
+            for (uint32_t k = 0; k < FH; ++k) {
+                adam1(fp_[k].x, (float)a0[k].x, fm_[k].x, fv_[k].x, A.b1, A.b2, A.step_size, A.bc2s, A.eps, A.wd, A.gs);
+                adam1(fp_[k].y, (float)a0[k].y, fm_[k].y, fv_[k].y, A.b1, A.b2, A.step_size, A.bc2s, A.eps, A.wd, A.gs);
+                adam1(fp_[k].z, (float)a1[k].x, fm_[k].z, fv_[k].z, A.b1, A.b2, A.step_size, A.bc2s, A.eps, A.wd, A.gs);
+                adam1(fp_[k].w, (float)a1[k].y, fm_[k].w, fv_[k].w, A.b1, A.b2, A.step_size, A.bc2s, A.eps, A.wd, A.gs);
+                const size_t i4 = f4_0 + (r * FH + k) * THREADS + threadIdx.x;
+                reinterpret_cast<float4*>(A.p)[i4] = fp_[k]; s3_st4nt(A.m, i4, fm_[k]); s3_st4nt(A.v, i4, fv_[k]);
+                if (A.ema) {
+                    fq_[k].x = ema1(fq_[k].x, fp_[k].x, A.mom); fq_[k].y = ema1(fq_[k].y, fp_[k].y, A.mom);
+                    fq_[k].z = ema1(fq_[k].z, fp_[k].z, A.mom); fq_[k].w = ema1(fq_[k].w, fp_[k].w, A.mom);
+                    s3_st4nt(A.ema, i4, fq_[k]);
+                }
+            }
+            if (r == 0) adam_load(FH);
+        }
+    } else if (pl.fuse) {
+        // (dense levels: strided rows) the partition's entries, 4 per thread and round: (p, m, v, ema) of all four in flight together
+        constexpr int AB = 4;
+        const uint32_t res = L.res, lat = L.kind == S3_H ? 0u : s3_dense_rows(res, L.plog2, part) * res;
+        for (uint32_t q0 = 0; q0 < n_loc; q0 += AB * THREADS) {
+            size_t e[AB]; float2 g[AB]; bool on[AB];
+#pragma unroll
+            for (int k = 0; k < AB; ++k) {
+                const uint32_t q = q0 + k * THREADS + threadIdx.x;
+                on[k] = q < n_loc;
+                uint32_t idx = 0;
+                if (on[k]) {
+                    if (L.kind == S3_H) idx = part * ENTRIES + q;
+                    else if (q < lat) { const uint32_t rl = q / res; idx = ((rl << L.plog2) | part) * res + (q - rl * res); }
+                    else idx = res * res * res + (q - lat);
+                    const double2 a = acc2[q];
+                    g[k] = make_float2((float)a.x, (float)a.y);
+                }
+                e[k] = (size_t)L.toff + idx;
+            }
+            s3_adam_entries<AB>(pl.ad, e, g, on);
+        }
+    } else if (L.kind == S3_H) {
         float2* __restrict__ dst = tab + (size_t)part * ENTRIES;
         constexpr uint32_t F = ENTRIES / THREADS;
         float2 t[F];
@@ -559,12 +667,17 @@ __global__ __launch_bounds__(256) void k_scatter_fold(S3RPlan pl, const float2* 
     uint32_t e = 0;
     while (e + 1 < pl.n_lv && q >= pl.lv[e + 1].poff) ++e;
     float2* __restrict__ dst = reinterpret_cast<float2*>(grad_table) + pl.lv[e].toff + (q - pl.lv[e].poff);
-    float2 t = pl.overwrite ? make_float2(0.f, 0.f) : *dst;
+    float2 t = (pl.overwrite || pl.fuse) ? make_float2(0.f, 0.f) : *dst;
     for (uint32_t c = 0; c < pl.chunks; ++c) {                              // fixed order
         const float2 a = slabs[(size_t)c * pl.slab_entries + q];
         t.x += a.x; t.y += a.y;
     }
-    *dst = t;
+    if (pl.fuse) {
+        const size_t ee[1] = {(size_t)pl.lv[e].toff + (q - pl.lv[e].poff)};
+        const float2 gg[1] = {t};
+        const bool on[1] = {true};
+        s3_adam_entries<1>(pl.ad, ee, gg, on);
+    } else *dst = t;
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -666,11 +779,17 @@ void xr_internal_scatter_aux_prologue(XrAuxPrologue* p) { g_aux_prologue = p; }
 
 int xr_scatter3(const float* x, uint32_t x_stride, const float* denc_t, uint32_t ld, uint32_t n, const uint32_t* n_dev,
                 const uint32_t* rows, const GridMeta& gm, uint32_t hashed_mask, float* grad_table, void* workspace,
-                size_t workspace_bytes, int overwrite, uint32_t* atomic_mask, hipStream_t stream) {
+                size_t workspace_bytes, int overwrite, uint32_t* atomic_mask, hipStream_t stream, const XrAdamArgs* adam) {
     S3Layout P;
     if (!s3_layout(n, gm, hashed_mask, overwrite, &P) || !workspace || ((uintptr_t)workspace & 15) || ((uintptr_t)grad_table & 15)) {
+        XR_REQUIRE(!adam, "the fused optimiser update needs every level on the non-atomic path");
         *atomic_mask = (1u << gm.n_levels) - 1u;
         return XR_OK;
+    }
+    if (adam) {
+        XR_REQUIRE(P.atomic_mask == 0, "the fused optimiser update needs every level on the non-atomic path");
+        P.bin.fuse = P.rl.fuse = 1u;
+        P.bin.ad = P.rl.ad = *adam;
     }
     XR_REQUIRE(workspace_bytes >= P.counts_bytes + P.bins_bytes + P.ovf_bytes + P.slabs_bytes, "workspace too small");
     *atomic_mask = P.atomic_mask;

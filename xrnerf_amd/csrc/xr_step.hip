@@ -40,11 +40,16 @@ extern "C" int xr_ngp_train_step(
     float* zero_block, size_t zero_floats, float* grad_w_density, float* grad_w_color, float* loss_mse, uint32_t* live_seg_count,
     float* grad_table, size_t table_floats, int zero_draw,
     void* ws_mlp_bwd, size_t ws_mlp_bwd_bytes, void* ws_scatter, size_t ws_scatter_bytes, int scatter_level0,
-    const float* xyz_planes, uint32_t plane_stride, const char* mark_entry, void* mark_event,
+    const float* xyz_planes, uint32_t plane_stride, const xr_adam_fuse* table_adam, const char* mark_entry, void* mark_event,
     const char* timed_entry, void* timing_begin, void* timing_end, void* stream_) {
     XR_REQUIRE(table && w_density && w_color && coords && rays_numsteps && rays_numsteps_compacted && bg_color && target &&
                alpha_mask && density_grid_mean && enc_t && raw && draw && denc_t && rgb_out && zero_block && grad_w_density &&
-               grad_w_color && loss_mse && grad_table, "null pointer");
+               grad_w_color && loss_mse && (grad_table || table_adam), "null pointer");
+    // table_adam: the scatter applies the optimiser's update to the table instead of writing its gradient (xr_hashgrid_bwd_adam);
+    // checked before anything is enqueued
+    XR_REQUIRE(!table_adam || (scatter_level0 == 0 && table_adam->param == table), "the fused table update takes the whole table of this step");
+    XR_REQUIRE(!table_adam || xr_hashgrid_bwd_adam_supported(n_rows, n_levels, scale_host, resolution_host, offset_host),
+               "the fused table update needs a non-atomic scatter path for every level at this row capacity");
     XR_REQUIRE(n_rows > 0 && n_rays > 0 && ld >= n_rows, "bad sizes");
     XR_REQUIRE(mlp_mode >= 0 && mlp_mode <= 2, "mlp_mode is 0 (fp32 MFMA), 1 (fp16) or 2 (fp32 forward on split bf16 operands)");
     XR_REQUIRE(scatter_level0 >= 0 && scatter_level0 < n_levels, "scatter_level0 outside [0, n_levels)");
@@ -129,9 +134,13 @@ extern "C" int xr_ngp_train_step(
     // through xr_nerf_mlp_bwd_list_slots) AFTER handing the finer levels' gradient slice to the collective: table offsets are
     // absolute, so the level metadata is simply passed from that level on
     // the gradient slices of the scattered levels are written, not added to: no zero-fill of the 48.8-MB table gradient
-    rc = xr_hashgrid_bwd2(coords, 7, denc_t + (size_t)2 * scatter_level0 * ld, ld, n_rows, live_on ? n_live : n_dev, rows, n_levels - scatter_level0,
-                          scale_host + scatter_level0, resolution_host + scatter_level0, offset_host + scatter_level0, grad_table,
-                          ws_scatter, ws_scatter_bytes, XR_SCATTER_OVERWRITE, stream_);
+    if (table_adam)
+        rc = xr_hashgrid_bwd_adam(coords, 7, denc_t, ld, n_rows, live_on ? n_live : n_dev, rows, n_levels, scale_host, resolution_host, offset_host,
+                                  ws_scatter, ws_scatter_bytes, table_adam, stream_);
+    else
+        rc = xr_hashgrid_bwd2(coords, 7, denc_t + (size_t)2 * scatter_level0 * ld, ld, n_rows, live_on ? n_live : n_dev, rows, n_levels - scatter_level0,
+                              scale_host + scatter_level0, resolution_host + scatter_level0, offset_host + scatter_level0, grad_table,
+                              ws_scatter, ws_scatter_bytes, XR_SCATTER_OVERWRITE, stream_);
     xr_internal_scatter_aux_prologue(nullptr);
     if (rc != XR_OK) return rc;
     if (!pro.done && (rc = pro.fn(stream, pro.arg)) != XR_OK) return rc;     // the scatter did not fork (or XR_STEP_REDUCE_AUX=0)

@@ -132,11 +132,22 @@ class _FusedTrainStepFn(torch.autograd.Function):
                                                                      wc.numel(), mlp.embedder_pos.meta, getattr(sync, 'pad_grad', None))
                 meta = mlp.embedder_pos.meta
                 split = meta.n_levels - 8 if (sync is not None and meta.n_levels > 8 and getattr(sync, 'split_levels', True)) else 0
+                # one GPU, a trainer that opted in (net._fuse_table_update: unit root gradient, gradients cleared every step) and
+                # an optimiser that can hand its update over (FusedAdam.fused_table_update): the scatter updates the table itself
+                adam = None
+                opt = getattr(net, '_step_optimizer', None)
+                if (sync is None and getattr(net, '_fuse_table_update', False) and hasattr(opt, 'fused_table_update')
+                        and getattr(net, '_unit_root_grad', None) is not None):
+                    key = (n_rows, id(meta))
+                    if getattr(net, '_fuse_ok_key', None) != key:
+                        net._fuse_ok_key, net._fuse_ok = key, ops.hashgrid_bwd_adam_supported(n_rows, meta)
+                    if net._fuse_ok:
+                        adam = opt.fused_table_update(table)
                 rgb = ops.ngp_train_step(table, wd, wc, 1, 2, mlp.pad_value, meta, sampler.coords, data.get('n_valid_dev'),
                                          sampler.rays_numsteps, sampler.rays_numsteps_compacted, data['bg_color'],
                                          data['target_s'].contiguous(), data['alpha'].contiguous(), sampler.density_grid_mean,
                                          int(sampler.rgb_activation), int(sampler.density_activation), b, scatter_level0=split,
-                                         xyz=getattr(sampler, 'xyz', None), mark=getattr(net, '_step_mark', None))
+                                         xyz=getattr(sampler, 'xyz', None), mark=getattr(net, '_step_mark', None), adam=adam)
                 if sync is not None:
                     sync.ready(b.g_mlp)
                     if split:
@@ -149,8 +160,9 @@ class _FusedTrainStepFn(torch.autograd.Function):
                         sync.ready(b.g_table)
                 if cb is not None:
                     cb()
-                ctx.grads = (b.g_table, b.g_wd, b.g_wc)
-                ctx.params = (table, wd, wc)
+                ctx.grads = (b.g_table, b.g_wd, b.g_wc) if adam is None else (b.g_wd, b.g_wc)
+                ctx.params = (table, wd, wc) if adam is None else (wd, wc)
+                ctx.table_updated = adam is not None
                 ctx.sync = sync
                 ctx.unit_root_grad = getattr(net, '_unit_root_grad', None)
                 ctx.net = net
@@ -235,6 +247,9 @@ class _FusedTrainStepFn(torch.autograd.Function):
             return None, None, None, None, None
         unit = ctx.unit_root_grad
         is_unit = unit is not None and g.data_ptr() == unit.data_ptr()
+        if getattr(ctx, 'table_updated', False) and not (is_unit and factor == 1.0):
+            raise RuntimeError('this step already applied the table update for a unit root gradient (net._fuse_table_update): '
+                               'back-propagate the registered unit gradient, or switch the fused update off')
         net = ctx.net
         ctx.net = None
         if factor != 1.0 and is_unit and getattr(net, '_defer_grad_scale', False):
@@ -378,7 +393,11 @@ class HashNerfNetwork(BaseNerfNetwork):
         for k in data:
             data[k] = unfold_batching(data[k])
         if self._fused_ok():
-            return self._train_step_fused(data, **kwargs)
+            self._step_optimizer = optimizer           # (a FusedAdam can hand the table's update to the step, see _FusedTrainStepFn)
+            try:
+                return self._train_step_fused(data, **kwargs)
+            finally:
+                self._step_optimizer = None
         ret = self.forward(data, is_test=False)
         bs = ret['rgb'].shape[0]
         alpha = data['alpha'].detach()

@@ -338,11 +338,14 @@ class TrainStepBuffers:
 
 
 def ngp_train_step(table, wd, wc, nhd, nhc, pad_value, meta, coords, n_dev, numsteps, numsteps_c, bg, target, alpha,
-                   density_grid_mean, rgb_act, density_act, bufs, huber_delta=0.1, loss_scale=5.0, scatter_level0=0, xyz=None, mark=None):
+                   density_grid_mean, rgb_act, density_act, bufs, huber_delta=0.1, loss_scale=5.0, scatter_level0=0, xyz=None, mark=None,
+                   adam=None):
     """the device work of one HashNerfNetwork training step as one native call (xr_ngp_train_step): encode -> MLP -> K3 +
     Huber + K4 -> MLP backward -> table scatter into `bufs` (TrainStepBuffers).  Returns rgb [n_rays,3] (a view of bufs.rgb).
     scatter_level0 > 0 (data parallel): only hash levels [scatter_level0, n_levels) are scattered; the caller finishes with
-    hashgrid_bwd(..., live=bufs.live, levels=(0, scatter_level0)) after handing the finer slice to its collective."""
+    hashgrid_bwd(..., live=bufs.live, levels=(0, scatter_level0)) after handing the finer slice to its collective.
+    adam (ops.adam_fuse of the table, single GPU): the scatter applies the optimiser's update to the table itself; bufs.g_table
+    is not written."""
     L = _lib.load()
     n_rays = numsteps.shape[0]
     n_rows = bufs.n_rows
@@ -372,7 +375,8 @@ def ngp_train_step(table, wd, wc, nhd, nhc, pad_value, meta, coords, n_dev, nums
             _ptr(bufs.zero_block), bufs.zero_block.numel(), _ptr(bufs.g_wd), _ptr(bufs.g_wc), _ptr(bufs.loss_mse), _ptr(bufs.live_seg),
             _ptr(bufs.g_table), bufs.g_table.numel(), 0 if n_dev is not None else 1,
             _ptr(ws_mlp), ws_mlp.numel(), _ptr(ws_sc), ws_sc.numel(), int(scatter_level0),
-            _ptr(xyz), xyz.shape[1] if xyz is not None else 0, mark[0].encode() if mark else None, mark[1].h if mark else None,
+            _ptr(xyz), xyz.shape[1] if xyz is not None else 0, C.byref(adam) if adam is not None else None,
+            mark[0].encode() if mark else None, mark[1].h if mark else None,
             stage.encode() if stage else None,
             ev[0].h if stage else None, ev[1].h if stage else None, _stream()), 'xr_ngp_train_step')
     return bufs.rgb[:n_rays]
@@ -582,6 +586,39 @@ def hashgrid_bwd(x, denc_t, meta, grad_table, n_dev=None, row0=0, count=None, le
                                       _ptr(ws), ws.numel() if ws is not None else 0, 1 if overwrite else 0, _stream()),
                    'xr_hashgrid_bwd')
     return grad_table
+
+
+def adam_fuse(param, m, v, ema, step, lr, beta1, beta2, eps, weight_decay, ema_momentum=0.0, grad_scale=1.0):
+    """-> xr_adam_fuse for hashgrid_bwd_adam / ngp_train_step(adam=): whole tensors + this update's constants (keeps the tensors alive)"""
+    a = _lib.AdamFuse(param.data_ptr(), m.data_ptr(), v.data_ptr(), ema.data_ptr() if ema is not None else None, int(step), float(lr),
+                      float(beta1), float(beta2), float(eps), float(weight_decay), float(ema_momentum), float(grad_scale))
+    a._keep = (param, m, v, ema)
+    for t in a._keep:
+        if t is not None:
+            _ptr(t)                       # device / contiguity check
+    return a
+
+
+def hashgrid_bwd_adam_supported(n, meta):
+    """every level of `meta` has a non-atomic scatter path at a capacity of n rows (what the fused update needs)"""
+    s, r, o = meta._args()
+    return bool(_lib.load().xr_hashgrid_bwd_adam_supported(int(n), meta.n_levels, s, r, o))
+
+
+def hashgrid_bwd_adam(x, denc_t, meta, adam, n_dev=None, live=None, count=None):
+    """the table scatter with the optimiser's update in place of the gradient write (xr_hashgrid_bwd_adam): the tensors named
+    by `adam` (ops.adam_fuse) are updated exactly as hashgrid_bwd(overwrite=True) + adam_step_multi would; no gradient is produced"""
+    L = _lib.load()
+    x, xs = _pos_view(x)
+    n = x.shape[0] if count is None else count
+    s, r, o = meta._args()
+    ws = _ws(x.device, L.xr_hashgrid_bwd_workspace_bytes(n, meta.n_levels, r, o), 'hgb')
+    rows = None
+    if live is not None:
+        rows, n_dev = live
+    with _span('xr_hashgrid_bwd', 0 if n_dev is not None else n, train=n_dev is not None):
+        _lib.check(L.xr_hashgrid_bwd_adam(C.c_void_p(x.data_ptr()), xs, _ptr(denc_t), denc_t.shape[1], n, _ptr(n_dev), _ptr(rows),
+                                          meta.n_levels, s, r, o, _ptr(ws), ws.numel(), C.byref(adam), _stream()), 'xr_hashgrid_bwd_adam')
 
 
 def sh4(dirs):

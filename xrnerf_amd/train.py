@@ -51,6 +51,38 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
                                       ema_momentum=ema_momentum, ema_warm_up=ema_warm_up))
 
+    def _state(self, p, group):
+        st = self.state[p]
+        if not st:
+            st['step'] = 0
+            st['m'] = torch.zeros_like(p)
+            st['v'] = torch.zeros_like(p)
+            if group['ema_momentum'] is not None:
+                st['ema'] = p.detach().clone()
+        return st
+
+    @staticmethod
+    def _ema_momentum(group, step):
+        # mmcv's EMAHook warms its momentum up: min(momentum, (1 + iter) / (warm_up + iter)), iter = 0, 1, ...
+        it = step - 1
+        return min(group['ema_momentum'], (1.0 + it) / (group['ema_warm_up'] + it))
+
+    @torch.no_grad()
+    def fused_table_update(self, p):
+        """Hands THIS step's update of `p` to a kernel that applies it where it completes the gradient (the table scatter,
+        ops.ngp_train_step(adam=...)): -> ops.adam_fuse with the state tensors and this update's constants, or None when `p` is
+        not one of this optimiser's parameters.  The step counter advances here; the following step() finds no .grad on `p` and
+        leaves it alone."""
+        for group in self.param_groups:
+            if any(q is p for q in group['params']):
+                st = self._state(p, group)
+                st['step'] += 1
+                ema = st.get('ema') if group['ema_momentum'] is not None else None
+                mom = self._ema_momentum(group, st['step']) if ema is not None else 0.0
+                return ops.adam_fuse(p.data, st['m'], st['v'], ema, st['step'], group['lr'], group['betas'][0], group['betas'][1],
+                                     group['eps'], group['weight_decay'], mom, 1.0)
+        return None
+
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0):
         """`grad_scale`: factor on every gradient as the update reads it (the data-parallel trainer passes the 1/world_size
@@ -60,13 +92,7 @@ class FusedAdam(torch.optim.Optimizer):
             for p in group['params']:
                 if p.grad is None or p.numel() == 0:
                     continue
-                st = self.state[p]
-                if not st:
-                    st['step'] = 0
-                    st['m'] = torch.zeros_like(p)
-                    st['v'] = torch.zeros_like(p)
-                    if group['ema_momentum'] is not None:
-                        st['ema'] = p.detach().clone()
+                st = self._state(p, group)
                 st['step'] += 1
                 todo.append((p, p.grad if p.grad.is_contiguous() else p.grad.contiguous(), st))
             # tensors that share a step count go out in one launch (up to 4 per launch)
@@ -74,9 +100,7 @@ class FusedAdam(torch.optim.Optimizer):
                 chunk = [t for t in todo[:4] if t[2]['step'] == todo[0][2]['step']]
                 todo = [t for t in todo if all(t is not c for c in chunk)]
                 emas = [c[2].get('ema') for c in chunk] if group['ema_momentum'] is not None else None
-                # mmcv's EMAHook warms its momentum up: min(momentum, (1 + iter) / (warm_up + iter)), iter = 0, 1, ...
-                it = chunk[0][2]['step'] - 1
-                mom = min(group['ema_momentum'], (1.0 + it) / (group['ema_warm_up'] + it)) if emas else 0.0
+                mom = self._ema_momentum(group, chunk[0][2]['step']) if emas else 0.0
                 ops.adam_step_multi([c[0] for c in chunk], [c[1] for c in chunk], [c[2]['m'] for c in chunk],
                                     [c[2]['v'] for c in chunk], chunk[0][2]['step'], group['lr'], group['betas'][0],
                                     group['betas'][1], group['eps'], group['weight_decay'], emas, mom, grad_scale=grad_scale)
@@ -211,6 +235,10 @@ class Trainer:
             # this trainer's optimiser applies the 1/world_size itself (FusedAdam.step(grad_scale=...)): the fused step leaves
             # the SUMMED gradients in .grad and reports the factor in net._pending_grad_scale
             self.net._defer_grad_scale = os.environ.get('XRNERF_DEFER_GRAD_SCALE', '1') != '0'
+        # one GPU: the table scatter applies this optimiser's update to the table itself (XRNERF_FUSE_ADAM=0: separate launches).
+        # Valid because this trainer back-propagates a unit root gradient and clears the gradients every step.
+        # (the switch is raised around this trainer's own train_step calls only: anyone else calling net.train_step gets gradients)
+        self.fuse_adam = world_size == 1 and os.environ.get('XRNERF_FUSE_ADAM', '1') != '0'
         self.rays_done = 0
         self.lazy_log = True
         # run K1 of the next batch on a side stream under this step's backward (XRNERF_OVERLAP_MARCH=0: serial)
@@ -240,7 +268,11 @@ class Trainer:
         n_rays = batch['rays_o'].shape[0]
         # the reference's DataLoader(batch_size=1) collates a leading batch axis that train_step unfolds
         batch = {k: v[None] for k, v in batch.items()}
-        out = net.train_step(batch, self.opt, lazy_log=self.lazy_log)
+        net._fuse_table_update = self.fuse_adam and self._one is not None
+        try:
+            out = net.train_step(batch, self.opt, lazy_log=self.lazy_log)
+        finally:
+            net._fuse_table_update = False
         self.opt.zero_grad(set_to_none=True)
         # root gradient = a persistent ones tensor (loss.backward() would fill a fresh one every step)
         if self._one is None:
