@@ -293,6 +293,7 @@ typedef struct xr_adam_fuse {
     float* param; float* m; float* v; float* ema;   /* whole tensors, 16-byte aligned; ema nullable */
     int step;                                       /* 1, 2, ... (this update's bias correction) */
     float lr, beta1, beta2, eps, weight_decay, ema_momentum, grad_scale;
+    uint64_t n;                                     /* floats in the tensor (read where the caller cannot know it: xr_ngp_train_step's mlp_adam) */
 } xr_adam_fuse;
 int xr_hashgrid_bwd_adam_supported(uint32_t n, int n_levels, const float* scale_host, const uint32_t* resolution_host,
                                    const uint32_t* offset_host);
@@ -329,6 +330,8 @@ int xr_nerf_mlp_fwd_bf16x3(const float* enc_t, uint32_t ld, const float* dirs, u
  * grad_table's slices of the scattered levels are WRITTEN (no zero-fill; whatever they held is gone).
  * table_adam (nullable): the scatter becomes xr_hashgrid_bwd_adam -- the table is UPDATED by this call and grad_table (then
  * nullable) is not written; single GPU, scatter_level0 == 0.
+ * w_density_adam / w_color_adam (both or neither, same step and constants): xr_adam_step_multi on the two MLP tensors right behind
+ * the reduction of their gradients, on the helper stream the scatter forks (joined before the call's work ends on `stream`).
  * live_seg_count (nullable): xr_live_rows_segments(n_rows) words for the per-segment counts; placed inside zero_block they are
  * cleared by the one zero-fill, elsewhere (or null: the slot in ws_mlp_bwd) by one more.
  * coords: K1's [n_rows,7] rows (positions / directions consumed in place); n_dev: device count of valid rows; every buffer
@@ -349,8 +352,9 @@ int xr_ngp_train_step(const float* table, const float* w_density, const float* w
                       float* draw, float* denc_t, float* rgb_out, float* zero_block, size_t zero_floats, float* grad_w_density,
                       float* grad_w_color, float* loss_mse, uint32_t* live_seg_count, float* grad_table, size_t table_floats, int zero_draw,
                       void* ws_mlp_bwd, size_t ws_mlp_bwd_bytes, void* ws_scatter, size_t ws_scatter_bytes, int scatter_level0,
-                      const float* xyz_planes, uint32_t plane_stride, const xr_adam_fuse* table_adam, const char* mark_entry,
-                      void* mark_event, const char* timed_entry, void* timing_begin, void* timing_end, void* stream);
+                      const float* xyz_planes, uint32_t plane_stride, const xr_adam_fuse* table_adam, const xr_adam_fuse* w_density_adam,
+                      const xr_adam_fuse* w_color_adam, const char* mark_entry, void* mark_event, const char* timed_entry,
+                      void* timing_begin, void* timing_end, void* stream);
 /* xyz_planes (nullable): the positions of `coords` once more as three planes of plane_stride floats (xr_rays_sampler2 /
  * xr_ngp_prefetch write them); the encoder then reads them with coalesced loads (xr_hashgrid_fwd2). */
 /* timed_entry (nullable): the name of ONE of the entry points the step runs ("xr_hashgrid_fwd", "xr_nerf_mlp_fwd",

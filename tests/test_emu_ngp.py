@@ -135,3 +135,4 @@ def test_emulation_leaves_the_product_untouched(edev):
     """after this module the product path is back to: no library for host tensors"""
     from xrnerf_amd import ops
     assert ops._on_device(__import__('torch').zeros(1)) is True      # inside the emulation window
+

@@ -26,6 +26,7 @@ extern "C" void xr_hashgrid_meta(int n_levels, int log2_hashmap_size, int base_r
 }
 int main(int argc, char** argv) {
     const uint32_t n = argc > 1 ? (uint32_t)atoi(argv[1]) : 121776u;
+    const bool fuse = argc > 2 && atoi(argv[2]) != 0;          // the optimiser update inside the accumulate kernel
     float scale[16]; uint32_t res[16], off[17];
     xr_hashgrid_meta(16, 19, 16, std::exp2(std::log2(2048.0 / 16) / 15), scale, res, off);
     GridMeta gm; uint32_t hm; fill_meta(&gm, &hm, 16, scale, res, off);
@@ -54,6 +55,13 @@ int main(int argc, char** argv) {
     uint32_t* counts = (uint32_t*)ws;
     float4* bins = (float4*)((char*)ws + P.counts_bytes);
     float4* ovf = (float4*)((char*)ws + P.counts_bytes + P.bins_bytes);
+    if (fuse) {
+        float* st[4];
+        for (auto& q : st) { hipMalloc(&q, (size_t)off[16] * 8); hipMemset(q, 0, (size_t)off[16] * 8); }
+        P.bin.fuse = 1u;
+        P.bin.ad = XrAdamArgs{st[0], st[1], st[2], st[3], 0.9f, 0.99f, 1e-2f, 0.1f, 1e-15f, 1e-6f, 0.05f, 1.f};
+        printf("fused optimiser update ON\n");
+    }
     hipFuncSetAttribute((const void*)k_scatter_accum3<13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES);
     hipEvent_t a, b, c; hipEventCreate(&a); hipEventCreate(&b); hipEventCreate(&c);
     for (int rep = 0; rep < 4; ++rep) {

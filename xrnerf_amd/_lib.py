@@ -16,7 +16,7 @@ class AdamFuse(C.Structure):
     """xr_adam_fuse (include/xrnerf_mi355.h)"""
     _fields_ = [('param', C.c_void_p), ('m', C.c_void_p), ('v', C.c_void_p), ('ema', C.c_void_p), ('step', C.c_int),
                 ('lr', C.c_float), ('beta1', C.c_float), ('beta2', C.c_float), ('eps', C.c_float), ('weight_decay', C.c_float),
-                ('ema_momentum', C.c_float), ('grad_scale', C.c_float)]
+                ('ema_momentum', C.c_float), ('grad_scale', C.c_float), ('n', C.c_uint64)]
 
 
 SIGNATURES = {
@@ -60,7 +60,7 @@ SIGNATURES = {
                                _vp, _sz, _u32, _vp, _vp, _vp, _vp, _u32, _vp]),
     'xr_ngp_train_step': (_i32, [_vp, _vp, _vp, _i32, _i32, _f, _i32, _i32, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _u32, _vp, _vp, _vp,
                                  _vp, _i32, _i32, _f, _f, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp, _sz,
-                                 _vp, _sz, _i32, _vp, _u32, _vp, C.c_char_p, _vp, C.c_char_p, _vp, _vp, _vp]),
+                                 _vp, _sz, _i32, _vp, _u32, _vp, _vp, _vp, C.c_char_p, _vp, C.c_char_p, _vp, _vp, _vp]),
     'xr_timing_event_create': (_vp, []),
     'xr_stream_wait_event': (_i32, [_vp, _vp]),
     'xr_timing_event_destroy': (_i32, [_vp]),

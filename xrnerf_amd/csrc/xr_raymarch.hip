@@ -111,6 +111,13 @@ __device__ inline Ray rm_load_ray(const float* __restrict__ o, const float* __re
 // more than the loads it saves.  Measured dead end: marching 4 rays per lane in lock step (4 loads in flight per lane)
 // is 3.5x SLOWER (172 -> 612 us on 12.5 K rays) -- the per-point arithmetic at 4 cycles per wave64 instruction
 // then dominates and a wave lasts as long as the longest of 256 rays instead of 64.
+// Round 3, also measured and removed: one WAVE per ray.  The lattice t_0, t_1, ... of a ray is a chain of `t += calc_dt(t)` that
+// does not depend on the occupancy (samples and the do-while of advance_to_next_voxel step along the same chain), so 64 lanes can
+// evaluate 64 consecutive lattice points at once and replay the reference's control flow with ballots -- bit-exact (it passed the
+// K1 tests here and on the GPU).  But every lane has to walk the chain to its own point with the same fp32 additions (63 dependent
+// steps per window, ~2000 of the ~3000 issue cycles of a window), 12.5 K waves x ~8 windows make it as long as this kernel
+// (173 us either way, tools/microbench_k1.py) while occupying every SIMD: beside the training step on the side stream it slowed
+// the encode from 81 to 143 us and the iteration from 0.447 to 0.488 ms (profiles/r03_k1_wave_per_ray_ab.txt).
 __global__ __launch_bounds__(RM_BLOCK) void k1_count(
     uint32_t n_rays, float lo, float hi, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
     const uint8_t* __restrict__ bitfield, float cone, float near_distance, xr_pcg32 rng, uint32_t rng_chunk,

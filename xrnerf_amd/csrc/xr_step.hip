@@ -40,7 +40,8 @@ extern "C" int xr_ngp_train_step(
     float* zero_block, size_t zero_floats, float* grad_w_density, float* grad_w_color, float* loss_mse, uint32_t* live_seg_count,
     float* grad_table, size_t table_floats, int zero_draw,
     void* ws_mlp_bwd, size_t ws_mlp_bwd_bytes, void* ws_scatter, size_t ws_scatter_bytes, int scatter_level0,
-    const float* xyz_planes, uint32_t plane_stride, const xr_adam_fuse* table_adam, const char* mark_entry, void* mark_event,
+    const float* xyz_planes, uint32_t plane_stride, const xr_adam_fuse* table_adam, const xr_adam_fuse* w_density_adam,
+    const xr_adam_fuse* w_color_adam, const char* mark_entry, void* mark_event,
     const char* timed_entry, void* timing_begin, void* timing_end, void* stream_) {
     XR_REQUIRE(table && w_density && w_color && coords && rays_numsteps && rays_numsteps_compacted && bg_color && target &&
                alpha_mask && density_grid_mean && enc_t && raw && draw && denc_t && rgb_out && zero_block && grad_w_density &&
@@ -48,6 +49,10 @@ extern "C" int xr_ngp_train_step(
     // table_adam: the scatter applies the optimiser's update to the table instead of writing its gradient (xr_hashgrid_bwd_adam);
     // checked before anything is enqueued
     XR_REQUIRE(!table_adam || (scatter_level0 == 0 && table_adam->param == table), "the fused table update takes the whole table of this step");
+    XR_REQUIRE(!w_density_adam == !w_color_adam, "the two MLP tensors' updates come together");
+    XR_REQUIRE(!w_density_adam || (w_density_adam->param == w_density && w_color_adam->param == w_color && w_density_adam->step == w_color_adam->step &&
+                                   w_density_adam->n > 0 && w_color_adam->n > 0),
+               "mlp_adam: the step's own weight tensors, one step count");
     XR_REQUIRE(!table_adam || xr_hashgrid_bwd_adam_supported(n_rows, n_levels, scale_host, resolution_host, offset_host),
                "the fused table update needs a non-atomic scatter path for every level at this row capacity");
     XR_REQUIRE(n_rows > 0 && n_rays > 0 && ld >= n_rows, "bad sizes");
@@ -120,12 +125,22 @@ extern "C" int xr_ngp_train_step(
     xr_internal_defer_mlp_reduce(false);
     if (rc != XR_OK) return rc;
     if ((rc = end("xr_nerf_mlp_bwd")) != XR_OK) return rc;
-    struct TailArgs { void* ws; uint32_t n; float *gd, *gc; const float *rgb, *target, *alpha; uint32_t n_rays; float delta, scale; float* loss; }
-        ta = {ws_mlp_bwd, n_rows, grad_w_density, grad_w_color, rgb_out, target, alpha_mask, n_rays, huber_delta, loss_scale, loss_mse};
+    struct TailArgs { void* ws; uint32_t n; float *gd, *gc; const float *rgb, *target, *alpha; uint32_t n_rays; float delta, scale; float* loss;
+                      const xr_adam_fuse *ad, *ac; }
+        ta = {ws_mlp_bwd, n_rows, grad_w_density, grad_w_color, rgb_out, target, alpha_mask, n_rays, huber_delta, loss_scale, loss_mse,
+              w_density_adam, w_color_adam};
     XrAuxPrologue pro = {[](hipStream_t st, void* a) -> int {
                              auto* r = (TailArgs*)a;
-                             const int rc1 = xr_nerf_mlp_bwd_reduce(r->ws, r->n, r->gd, r->gc, st);
+                             int rc1 = xr_nerf_mlp_bwd_reduce(r->ws, r->n, r->gd, r->gc, st);
                              if (rc1 != XR_OK) return rc1;
+                             if (r->ad) {                      // the MLP tensors' optimiser update, right behind their gradients
+                                 float* p[2] = {r->ad->param, r->ac->param}; const float* g[2] = {r->gd, r->gc};
+                                 float* m[2] = {r->ad->m, r->ac->m}; float* v[2] = {r->ad->v, r->ac->v}; float* e[2] = {r->ad->ema, r->ac->ema};
+                                 const size_t nn[2] = {(size_t)r->ad->n, (size_t)r->ac->n};
+                                 rc1 = xr_adam_step_multi(2, p, g, m, v, (e[0] && e[1]) ? e : nullptr, nn, r->ad->step, r->ad->lr, r->ad->beta1, r->ad->beta2,
+                                                          r->ad->eps, r->ad->weight_decay, r->ad->ema_momentum, r->ad->grad_scale, st);
+                                 if (rc1 != XR_OK) return rc1;
+                             }
                              return xr_train_loss_scalars(r->rgb, r->target, r->alpha, r->n_rays, r->delta, r->scale, r->loss, st);
                          }, &ta, false};
     if (reduce_aux) xr_internal_scatter_aux_prologue(&pro);

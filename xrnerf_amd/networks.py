@@ -133,21 +133,25 @@ class _FusedTrainStepFn(torch.autograd.Function):
                 meta = mlp.embedder_pos.meta
                 split = meta.n_levels - 8 if (sync is not None and meta.n_levels > 8 and getattr(sync, 'split_levels', True)) else 0
                 # one GPU, a trainer that opted in (net._fuse_table_update: unit root gradient, gradients cleared every step) and
-                # an optimiser that can hand its update over (FusedAdam.fused_table_update): the scatter updates the table itself
-                adam = None
+                # an optimiser that can hand its updates over (FusedAdam.fused_update): the step applies them itself -- the table's
+                # inside the scatter, the MLP tensors' behind the reduction of their gradients
+                adam = mlp_adam = None
                 opt = getattr(net, '_step_optimizer', None)
-                if (sync is None and getattr(net, '_fuse_table_update', False) and hasattr(opt, 'fused_table_update')
+                if (sync is None and getattr(net, '_fuse_table_update', False) and hasattr(opt, 'fused_update')
                         and getattr(net, '_unit_root_grad', None) is not None):
                     key = (n_rows, id(meta))
                     if getattr(net, '_fuse_ok_key', None) != key:
                         net._fuse_ok_key, net._fuse_ok = key, ops.hashgrid_bwd_adam_supported(n_rows, meta)
                     if net._fuse_ok:
-                        adam = opt.fused_table_update(table)
+                        adam = opt.fused_update(table)
+                        mlp_adam = (opt.fused_update(wd), opt.fused_update(wc)) if adam is not None else None
+                        if mlp_adam is not None and (mlp_adam[0] is None or mlp_adam[1] is None or mlp_adam[0].step != mlp_adam[1].step):
+                            raise RuntimeError('the optimiser handed over the table update but not a joint update of the two MLP tensors')
                 rgb = ops.ngp_train_step(table, wd, wc, 1, 2, mlp.pad_value, meta, sampler.coords, data.get('n_valid_dev'),
                                          sampler.rays_numsteps, sampler.rays_numsteps_compacted, data['bg_color'],
                                          data['target_s'].contiguous(), data['alpha'].contiguous(), sampler.density_grid_mean,
                                          int(sampler.rgb_activation), int(sampler.density_activation), b, scatter_level0=split,
-                                         xyz=getattr(sampler, 'xyz', None), mark=getattr(net, '_step_mark', None), adam=adam)
+                                         xyz=getattr(sampler, 'xyz', None), mark=getattr(net, '_step_mark', None), adam=adam, mlp_adam=mlp_adam)
                 if sync is not None:
                     sync.ready(b.g_mlp)
                     if split:
@@ -160,8 +164,8 @@ class _FusedTrainStepFn(torch.autograd.Function):
                         sync.ready(b.g_table)
                 if cb is not None:
                     cb()
-                ctx.grads = (b.g_table, b.g_wd, b.g_wc) if adam is None else (b.g_wd, b.g_wc)
-                ctx.params = (table, wd, wc) if adam is None else (wd, wc)
+                ctx.grads = (b.g_table, b.g_wd, b.g_wc) if adam is None else ()
+                ctx.params = (table, wd, wc) if adam is None else ()
                 ctx.table_updated = adam is not None
                 ctx.sync = sync
                 ctx.unit_root_grad = getattr(net, '_unit_root_grad', None)

@@ -339,13 +339,13 @@ class TrainStepBuffers:
 
 def ngp_train_step(table, wd, wc, nhd, nhc, pad_value, meta, coords, n_dev, numsteps, numsteps_c, bg, target, alpha,
                    density_grid_mean, rgb_act, density_act, bufs, huber_delta=0.1, loss_scale=5.0, scatter_level0=0, xyz=None, mark=None,
-                   adam=None):
+                   adam=None, mlp_adam=None):
     """the device work of one HashNerfNetwork training step as one native call (xr_ngp_train_step): encode -> MLP -> K3 +
     Huber + K4 -> MLP backward -> table scatter into `bufs` (TrainStepBuffers).  Returns rgb [n_rays,3] (a view of bufs.rgb).
     scatter_level0 > 0 (data parallel): only hash levels [scatter_level0, n_levels) are scattered; the caller finishes with
     hashgrid_bwd(..., live=bufs.live, levels=(0, scatter_level0)) after handing the finer slice to its collective.
     adam (ops.adam_fuse of the table, single GPU): the scatter applies the optimiser's update to the table itself; bufs.g_table
-    is not written."""
+    is not written.  mlp_adam = (adam_fuse of wd, adam_fuse of wc): their update runs behind the reduction of their gradients."""
     L = _lib.load()
     n_rays = numsteps.shape[0]
     n_rows = bufs.n_rows
@@ -376,6 +376,7 @@ def ngp_train_step(table, wd, wc, nhd, nhc, pad_value, meta, coords, n_dev, nums
             _ptr(bufs.g_table), bufs.g_table.numel(), 0 if n_dev is not None else 1,
             _ptr(ws_mlp), ws_mlp.numel(), _ptr(ws_sc), ws_sc.numel(), int(scatter_level0),
             _ptr(xyz), xyz.shape[1] if xyz is not None else 0, C.byref(adam) if adam is not None else None,
+            C.byref(mlp_adam[0]) if mlp_adam else None, C.byref(mlp_adam[1]) if mlp_adam else None,
             mark[0].encode() if mark else None, mark[1].h if mark else None,
             stage.encode() if stage else None,
             ev[0].h if stage else None, ev[1].h if stage else None, _stream()), 'xr_ngp_train_step')
@@ -591,7 +592,7 @@ def hashgrid_bwd(x, denc_t, meta, grad_table, n_dev=None, row0=0, count=None, le
 def adam_fuse(param, m, v, ema, step, lr, beta1, beta2, eps, weight_decay, ema_momentum=0.0, grad_scale=1.0):
     """-> xr_adam_fuse for hashgrid_bwd_adam / ngp_train_step(adam=): whole tensors + this update's constants (keeps the tensors alive)"""
     a = _lib.AdamFuse(param.data_ptr(), m.data_ptr(), v.data_ptr(), ema.data_ptr() if ema is not None else None, int(step), float(lr),
-                      float(beta1), float(beta2), float(eps), float(weight_decay), float(ema_momentum), float(grad_scale))
+                      float(beta1), float(beta2), float(eps), float(weight_decay), float(ema_momentum), float(grad_scale), param.numel())
     a._keep = (param, m, v, ema)
     for t in a._keep:
         if t is not None:

@@ -68,9 +68,10 @@ class FusedAdam(torch.optim.Optimizer):
         return min(group['ema_momentum'], (1.0 + it) / (group['ema_warm_up'] + it))
 
     @torch.no_grad()
-    def fused_table_update(self, p):
-        """Hands THIS step's update of `p` to a kernel that applies it where it completes the gradient (the table scatter,
-        ops.ngp_train_step(adam=...)): -> ops.adam_fuse with the state tensors and this update's constants, or None when `p` is
+    def fused_update(self, p):
+        """Hands THIS step's update of `p` to the native training step, which applies it where the gradient is complete (the
+        table: inside the scatter; the MLP tensors: behind the reduction of their gradients -- ops.ngp_train_step(adam=,
+        mlp_adam=)): -> ops.adam_fuse with the state tensors and this update's constants, or None when `p` is
         not one of this optimiser's parameters.  The step counter advances here; the following step() finds no .grad on `p` and
         leaves it alone."""
         for group in self.param_groups:
