@@ -891,11 +891,12 @@ def main():
             'config': {'workload': 'Instant-NGP Lego, hash L=16 F=2 T=2^19, 64-wide fused MLP (1+2 hidden), 800x800, %d images; '
                                    'full training iterations %d..%d (batch slice + random bg, K1 march, every-16th grid refresh '
                                    'K6..K11 with its density queries: %d refreshes in the window = round(steps/16), encode, MLP, K3, 5*Huber, K4, '
-                                   'MLP backward, table scatter, %sfused Adam+EMA over 12.2 M parameters) after %d un-timed '
+                                   'MLP backward, table scatter, %sAdam + L2 + EMA over 12.2 M parameters%s) after %d un-timed '
                                    'pre-roll + %d warm-up iterations (adaptive batch at its fixed point: %s rays); the '
                                    'reference\'s dead no-grad MLP pass that only feeds K2\'s dead transmittance loop is skipped; fused-MLP '
                                    'forward: %s'
                                    % (args.n_img, it0, it1 - 1, n_refresh, 'gradient all-reduce, ' if world > 1 else '',
+                                      ' (the table\'s update applied inside the scatter: no gradient round trip)' if (world == 1 and tr.fuse_adam) else '',
                                       preroll, args.warmup + align, hist[-1],
                                       'fp32 via exact 3-way bf16 operand split on the bf16 MFMA (xr_nerf_mlp_fwd_bf16x3)' if ops._mlp_mode() == 2
                                       else 'fp32 MFMA'),

@@ -152,22 +152,28 @@ class Zero1GradSync:
             dist.all_gather_into_tensor(self.param_padded, self.shard_param.data)
 
 
-def comm_model(world_size, table_floats=12196240, mlp_floats=10240, link_GBs=153.0, links=7, step_ms=0.59):
-    """what one training step puts on xGMI, and what a ring over it costs (one-GPU boxes only: nothing here is measured).
-    xGMI is point-to-point, 7 links x ~153 GB/s per GPU; an N-rank ring collective is bound by ONE link per hop:
-    all-reduce = 2 (N - 1) / N x bytes over one link (reduce-scatter + all-gather, (N - 1) / N each)."""
+def comm_model(world_size, table_floats=12196240, mlp_floats=10240, link_GBs=153.0, links=7, step_ms=0.50):
+    """what one training step puts on xGMI, and what it costs under two schedules (one-GPU boxes only: nothing here is measured).
+    xGMI is point-to-point, 7 links x ~153 GB/s per GPU.
+      ring:   an N-rank ring is bound by ONE link per hop: all-reduce = 2 (N - 1) / N x bytes over one link;
+      direct: on a fully connected mesh (N <= links + 1) reduce-scatter and all-gather each send bytes / N to every peer over its
+              own link at the same time: 2 x bytes / N over one link -- what the reduce-scatter / all-gather pair of XRNERF_DP=zero1
+              maps to when RCCL uses every link."""
     n = int(world_size)
     if n <= 1:
-        return {'world_size': n, 'bytes_per_step': 0, 'ring_ms': 0.0}
+        return {'world_size': n, 'bytes_per_step': 0, 'ring_ms': 0.0, 'direct_ms': 0.0}
     b = 4.0 * (table_floats + mlp_floats)
     wire = 2.0 * (n - 1) / n * b
     ring_ms = wire / (link_GBs * 1e9) * 1e3
-    return {'world_size': n, 'gradient_bytes_per_rank': b, 'bytes_on_each_link_per_step': wire, 'assumed_link_GBs': link_GBs,
-            'ring_ms': ring_ms, 'step_ms_single_gpu': step_ms,
+    direct_ms = (2.0 * b / n) / (link_GBs * 1e9) * 1e3 if n <= links + 1 else ring_ms
+    return {'world_size': n, 'gradient_bytes_per_rank': b, 'bytes_on_each_link_per_step_ring': wire, 'assumed_link_GBs': link_GBs,
+            'ring_ms': ring_ms, 'direct_ms': direct_ms, 'step_ms_single_gpu': step_ms,
             'overlappable_ms': 'all-reduce form: the 32-MB fine bucket runs under the coarse levels\' scatter (~0.06 ms); zero1 form: none '
-                               '(one bucket), but Adam drops from 0.071 ms to 0.071 / N',
-            'efficiency_if_fully_exposed': step_ms / (step_ms + ring_ms),
-            'note': 'model, not a measurement: RCCL over xGMI has never run in this repository (single-GPU boxes)'}
+                               '(one bucket), but the table\'s Adam pass drops from 0.070 ms to 0.070 / N',
+            'efficiency_if_fully_exposed': {'ring': step_ms / (step_ms + ring_ms), 'direct': step_ms / (step_ms + direct_ms)},
+            'note': 'model, not a measurement: RCCL over xGMI has never run in this repository beyond world size 1 (single-GPU boxes). '
+                    'The data-parallel step keeps gradient + separate optimiser launches (the fused table update of one GPU needs the '
+                    'reduced gradient first): its single-GPU-equivalent step is ~0.015 ms longer than the N = 1 line'}
 
 
 def row_band(H, rank, world_size):
