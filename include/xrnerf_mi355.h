@@ -324,16 +324,17 @@ int xr_nerf_mlp_fwd_bf16x3(const float* enc_t, uint32_t ld, const float* dirs, u
                            int n_hidden_density, int n_hidden_color, float pad_value, float* raw, void* stream);
 
 /* One training step's device work of HashNerfNetwork.train_step (networks/hashnerf.py:32-52, optimiser excluded) as ONE call:
- * xr_hashgrid_fwd -> xr_nerf_mlp_fwd[_f16] -> zero-fill of `zero_block` (which must contain grad_w_density, grad_w_color and
- * loss_mse) -> xr_composite_train2 (which counts the live rows per segment) -> xr_live_rows2 -> xr_nerf_mlp_bwd[_f16] ->
+ * xr_hashgrid_fwd -> xr_nerf_mlp_fwd[_f16] -> xr_composite_train2 (which counts the live rows per segment) -> xr_live_rows2 -> xr_nerf_mlp_bwd[_f16] ->
  * xr_hashgrid_bwd2(XR_SCATTER_OVERWRITE), on `stream`:
  * grad_table's slices of the scattered levels are WRITTEN (no zero-fill; whatever they held is gone).
  * table_adam (nullable): the scatter becomes xr_hashgrid_bwd_adam -- the table is UPDATED by this call and grad_table (then
  * nullable) is not written; single GPU, scatter_level0 == 0.
  * w_density_adam / w_color_adam (both or neither, same step and constants): xr_adam_step_multi on the two MLP tensors right behind
  * the reduction of their gradients, on the helper stream the scatter forks (joined before the call's work ends on `stream`).
- * live_seg_count (nullable): xr_live_rows_segments(n_rows) words for the per-segment counts; placed inside zero_block they are
- * cleared by the one zero-fill, elsewhere (or null: the slot in ws_mlp_bwd) by one more.
+ * live_seg_count (nullable): xr_live_rows_segments(n_rows) words for the per-segment counts, ZERO on entry; the call leaves them
+ * zero again (cleared on its helper stream after use).  Null: the slot in ws_mlp_bwd, cleared by a fill on `stream`.
+ * zero_block / zero_floats: kept for the layout (grad_w_density, grad_w_color, loss_mse live in it); nothing in it is zero-filled
+ * any more -- the two gradient buffers and loss_mse[0..1] are WRITTEN.
  * coords: K1's [n_rows,7] rows (positions / directions consumed in place); n_dev: device count of valid rows; every buffer
  * is caller-owned (enc_t / denc_t [32][ld], raw / draw [n_rows,4], rgb_out [n_rays,3]); zero_draw != 0 also clears draw
  * (needed only without n_dev).  mlp_mode: 0 = xr_nerf_mlp_fwd / _bwd (fp32 MFMA), 1 = the _f16 pair, 2 = xr_nerf_mlp_fwd_bf16x3

@@ -551,7 +551,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void k_nerf_mlp_bwd_1_2(
 // every 4th partial, then the 4 group sums are added in a fixed order through LDS
 __global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict__ partial, uint32_t nb, uint32_t gw,
                                                           uint32_t split, float* __restrict__ g_density,
-                                                          float* __restrict__ g_color) {
+                                                          float* __restrict__ g_color, int overwrite = 0) {
     __shared__ float red[4][64];
     const uint32_t c = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const uint32_t j = blockIdx.x * 64 + c;
@@ -572,7 +572,8 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict
     __syncthreads();
     if (rg == 0 && j < gw) {
         const float t = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
-        if (j < split) g_density[j] += t; else g_color[j - split] += t;
+        // overwrite: the sums REPLACE what the buffers held (xr_ngp_train_step: no zero-fill of its gradient buffers)
+        if (j < split) g_density[j] = overwrite ? t : g_density[j] + t; else g_color[j - split] = overwrite ? t : g_color[j - split] + t;
     }
 }
 
@@ -1404,13 +1405,16 @@ static int build_live_rows(const float* draw, uint32_t n, const uint32_t* n_dev,
 // gradients): it sets this flag around its backward call and issues xr_nerf_mlp_bwd_reduce itself
 static thread_local bool g_defer_reduce = false;
 void xr_internal_defer_mlp_reduce(bool on) { g_defer_reduce = on; }
-extern "C" int xr_nerf_mlp_bwd_reduce(const void* workspace, uint32_t n, float* grad_w_density, float* grad_w_color, void* stream_) {
+int xr_internal_mlp_bwd_reduce(const void* workspace, uint32_t n, float* grad_w_density, float* grad_w_color, int overwrite, void* stream_) {
     XR_REQUIRE(workspace && grad_w_density && grad_w_color, "null pointer");
     constexpr int GW = NetShape<1>::glb_floats + NetShape<2>::glb_floats;
     hipLaunchKernelGGL(k_reduce_partials, dim3(xr_div_up(GW, 64)), dim3(256), 0, (hipStream_t)stream_, (const float*)workspace, bwd_grid(n),
-                       (uint32_t)GW, (uint32_t)NetShape<1>::glb_floats, grad_w_density, grad_w_color);
+                       (uint32_t)GW, (uint32_t)NetShape<1>::glb_floats, grad_w_density, grad_w_color, overwrite);
     XR_LAUNCH_CHECK();
     return XR_OK;
+}
+extern "C" int xr_nerf_mlp_bwd_reduce(const void* workspace, uint32_t n, float* grad_w_density, float* grad_w_color, void* stream_) {
+    return xr_internal_mlp_bwd_reduce(workspace, n, grad_w_density, grad_w_color, 0, stream_);
 }
 
 extern "C" int xr_nerf_mlp_bwd(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,

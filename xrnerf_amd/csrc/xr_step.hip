@@ -89,7 +89,9 @@ extern "C" int xr_ngp_train_step(
                  stream_);
     if (rc != XR_OK) return rc;
     if ((rc = end("xr_nerf_mlp_fwd")) != XR_OK) return rc;
-    XR_HIP(hipMemsetAsync(zero_block, 0, zero_floats * sizeof(float), stream));         // MLP gradients + loss accumulators
+    // nothing of zero_block is zero-filled any more: the MLP gradients are WRITTEN by the reduction of their partials, the loss
+    // scalars by xr_train_loss_scalars, and the live-row counts are handed over zeroed and zeroed again after use (below)
+    (void)zero_block; (void)zero_floats;
     if (zero_draw) XR_HIP(hipMemsetAsync(draw, 0, (size_t)n_rows * 4 * sizeof(float), stream));
     // rows with an exactly-zero dL/d(raw) (T == 0 behind a surface) are skipped by the MLP backward AND the scatter: one list.
     // The compositor counts the live rows per 1024-row segment while it writes them (no separate counting launch).
@@ -99,11 +101,11 @@ extern "C" int xr_ngp_train_step(
     if (live_on) {
         rc = xr_nerf_mlp_bwd_list_slots(ws_mlp_bwd, ws_mlp_bwd_bytes, n_rows, &rows, &seg, &n_live);
         if (rc != XR_OK) return rc;
-        // the per-segment counts start at zero: a caller that placed them inside zero_block had them cleared just above
-        const bool in_block = live_seg_count && (float*)live_seg_count >= zero_block &&
-                              (float*)(live_seg_count + xr_live_rows_segments(n_rows)) <= zero_block + zero_floats;
+        // the per-segment counts start at zero.  A caller's own array (live_seg_count) is zero on entry by contract and is cleared
+        // again on the scatter's helper stream once the ranking pass has read it: no fill on this stream.  Without one: the
+        // slot in the backward's workspace, cleared here.
         if (live_seg_count) seg = live_seg_count;
-        if (!in_block) XR_HIP(hipMemsetAsync(seg, 0, xr_live_rows_segments(n_rows) * sizeof(uint32_t), stream));
+        else XR_HIP(hipMemsetAsync(seg, 0, xr_live_rows_segments(n_rows) * sizeof(uint32_t), stream));
     }
     if ((rc = begin("xr_composite_train")) != XR_OK) return rc;
     // (the two loss scalars are a function of rgb_out: one fixed-order sum on the scatter's helper stream, see below)
@@ -126,13 +128,14 @@ extern "C" int xr_ngp_train_step(
     if (rc != XR_OK) return rc;
     if ((rc = end("xr_nerf_mlp_bwd")) != XR_OK) return rc;
     struct TailArgs { void* ws; uint32_t n; float *gd, *gc; const float *rgb, *target, *alpha; uint32_t n_rays; float delta, scale; float* loss;
-                      const xr_adam_fuse *ad, *ac; }
+                      const xr_adam_fuse *ad, *ac; uint32_t* seg_clear; size_t seg_bytes; }
         ta = {ws_mlp_bwd, n_rows, grad_w_density, grad_w_color, rgb_out, target, alpha_mask, n_rays, huber_delta, loss_scale, loss_mse,
-              w_density_adam, w_color_adam};
+              w_density_adam, w_color_adam, (live_on && live_seg_count) ? live_seg_count : nullptr, xr_live_rows_segments(n_rows) * sizeof(uint32_t)};
     XrAuxPrologue pro = {[](hipStream_t st, void* a) -> int {
                              auto* r = (TailArgs*)a;
-                             int rc1 = xr_nerf_mlp_bwd_reduce(r->ws, r->n, r->gd, r->gc, st);
+                             int rc1 = xr_internal_mlp_bwd_reduce(r->ws, r->n, r->gd, r->gc, 1, st);      // writes the two gradient buffers
                              if (rc1 != XR_OK) return rc1;
+                             if (r->seg_clear) XR_HIP(hipMemsetAsync(r->seg_clear, 0, r->seg_bytes, st));      // read by the ranking pass long ago
                              if (r->ad) {                      // the MLP tensors' optimiser update, right behind their gradients
                                  float* p[2] = {r->ad->param, r->ac->param}; const float* g[2] = {r->gd, r->gc};
                                  float* m[2] = {r->ad->m, r->ac->m}; float* v[2] = {r->ad->v, r->ac->v}; float* e[2] = {r->ad->ema, r->ac->ema};

@@ -325,9 +325,10 @@ class TrainStepBuffers:
         self.n_rows, self.ray_cap, self.ld = n_rows, ray_cap, (n_rows + 63) // 64 * 64
         self.enc_t, self.denc_t = f(meta.n_output_dims, self.ld), f(meta.n_output_dims, self.ld)
         self.raw, self.draw, self.rgb = f(n_rows, 4), f(n_rows, 4), f(ray_cap, 3)
-        # one zero-fill per step covers the MLP gradients, the (loss, mse) accumulators and the compositor's live-row counts
+        # MLP gradients, the (loss, mse) scalars and the compositor's live-row counts in one block; the step writes the first two and
+        # hands the counts back zeroed (no fill on the step's stream)
         n_seg = int(_lib.load().xr_live_rows_segments(n_rows))
-        self.zero_block = f(wd_floats + wc_floats + 4 + n_seg)
+        self.zero_block = torch.zeros((wd_floats + wc_floats + 4 + n_seg,), dtype=torch.float32, device=device)     # (the counts start at zero)
         self.live_seg = self.zero_block[wd_floats + wc_floats + 4:]
         self.g_wd, self.g_wc = self.zero_block[:wd_floats], self.zero_block[wd_floats:wd_floats + wc_floats]
         self.g_mlp = self.zero_block[:wd_floats + wc_floats]
