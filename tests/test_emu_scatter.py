@@ -26,8 +26,8 @@ def test_scatter_generation_3_against_the_oracle(n, mode):
     assert 'identical to scatter + optimiser launch: True' in out, out
 
 
-@pytest.mark.parametrize('n,mode,env', [(5000, 'cluster', dict(XR_SC_BLOCK='1024')), (9000, 'rays', dict(XR_SC_BLOCK='4096')),
-                                        (3000, 'faces', dict(XR_SC_RL='0')), (9000, 'rays', dict(XR_SC_RL_CHUNKS='3')),
-                                        (5000, 'cluster', dict(XR_SC_MODE='1')), (9000, 'rays', dict(XR_SC_DENSE_ATOMIC='1'))])
+@pytest.mark.parametrize('n,mode,env', [(5000, 'cluster', dict(XR_SC_BLOCK='1024')), (5000, 'rays', dict(XR_SC_BLOCK='4096')),
+                                        (3000, 'faces', dict(XR_SC_RL='0')), (5000, 'rays', dict(XR_SC_RL_CHUNKS='3')),
+                                        (5000, 'cluster', dict(XR_SC_MODE='1')), (5000, 'rays', dict(XR_SC_DENSE_ATOMIC='1'))])
 def test_scatter_switches_give_the_same_gradients(n, mode, env):
     run(n, mode, **env)
