@@ -111,7 +111,11 @@ class NGPGridSampler(nn.Module):
                                                  self.max_cascade + 1, self.NERF_MIN_OPTICAL_THICKNESS, aabb,
                                                  self.k6_calls, po, io, n_uniform)
         self.k6_calls += 1     # the reference's rng advances on every call, also for n == 0
-        self.density_grid_tmp.zero_()
+        # K6 draws cells of cascades 0..max_cascade only, so K8 touches, and K9 can change, only that leading part of the two grids:
+        # the other cascades' cells hold K7's 0 / -1, which max(p * decay, 0) and the p < 0 rule both leave as they are.  The
+        # reference clears and walks all 8 cascades (134 + 200 MB per refresh at aabb_scale 1); same values here from 1/8 of that.
+        n_used = (self.max_cascade + 1) * (self.density_n_elements // self.NERF_CASCADES)
+        self.density_grid_tmp[:n_used].zero_()
         if planes:
             positions, indices = po[:, :n_tot], io[:n_tot]
             with torch.no_grad():
@@ -127,7 +131,7 @@ class NGPGridSampler(nn.Module):
                     density = mlp.run_density(positions[i:i + self.update_block_size])   # [m,1] view, row stride 4
                     ops.splat_grid_samples(density, indices[i:i + self.update_block_size], density.stride(0),
                                            density.shape[0], self.density_grid_tmp)
-        ops.ema_grid_samples(self.density_grid_tmp, n_elements, self.ema_grid_decay, self.density_grid)
+        ops.ema_grid_samples(self.density_grid_tmp, n_used, self.ema_grid_decay, self.density_grid)
         self.density_grid_ema_step += 1
         ops.update_bitfield(self.density_grid, self.density_grid_mean, self.density_grid_bitfield)
         if self._streams():
