@@ -62,7 +62,8 @@ def test_compositor_on_the_host(O, lego, edev):
     import test_gpu_raymarch as T
     T.test_compositor_fwd_bwd_inference(O, lego, edev, 2, 3)          # the config's activations (16-lane groups per ray)
     T.test_compositor_zero_sample_rays(O, edev)
-    T.test_fused_compositor_train_equals_k3_huber_k4(O, lego, edev)
+    T.test_fused_compositor_train_equals_k3_huber_k4(O, lego, edev, 3000)
+    T.test_fused_compositor_train_equals_k3_huber_k4(O, lego, edev, 1001)
 
 
 def test_grid_upkeep_raygen_loss_adam_on_the_host(O, lego, edev):

@@ -259,13 +259,13 @@ def test_adam_multi_grad_scale_equals_scaling_pass_then_adam(O, dev):
             assert np.abs(a.cpu().numpy() - rp).max() <= 1e-5
 
 
-def test_fused_compositor_train_equals_k3_huber_k4(O, lego, dev):
+@pytest.mark.parametrize('n_rays', [3000, 1001])
+def test_fused_compositor_train_equals_k3_huber_k4(O, lego, dev, n_rays):
     """xr_composite_train (K3 + 5*Huber + masked MSE + K4 in one launch) against the three separate entry points on marched
     Lego samples incl. clipped tails and rays without samples: rgb and dL/draw bit for bit, the two loss scalars to 1e-6"""
     from xrnerf_amd import ops, synthetic as S
     rng = np.random.default_rng(21)
-    n_rays = 3000
-    o, d, _ = S.training_rays(lego['poses'], n_rays, seed=9)
+    o, d, _ = S.training_rays(lego['poses'], n_rays, seed=9)           # (1001: the last workgroups of both kernels are partly empty)
     coords, _, ns, cnt = ops.rays_sampler(T(o, dev), T(d, dev), T(lego['bitfield'], dev), (0., 1.), 0.05, 1 / 256, n_rays * 64, 0)
     total = int(cnt[1])
     cap = int(total * 0.8)                                            # clip: some rays lose their tail, some everything
