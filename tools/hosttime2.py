@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT)
 import torch
 from xrnerf_amd.train import Trainer
 dev = torch.device('cuda:0')
-tr = Trainer(dev, n_img=20)
+tr = Trainer(dev, n_img=int(os.environ.get("N_IMG", "100")))
 for _ in range(320): tr.step()
 torch.cuda.synchronize()
 for rep in range(3):

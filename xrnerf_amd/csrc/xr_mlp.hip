@@ -1340,6 +1340,17 @@ extern "C" int xr_nerf_mlp_fwd(const float* enc_t, uint32_t ld, const float* dir
     return XR_OK;
 }
 
+// hipFuncSetAttribute is a driver call (~3-5 us of host time): once per kernel and size, not once per launch
+static int mlp_set_lds(const void* kernel, size_t lds) {
+    static const void* seen_k[16];
+    static size_t seen_b[16];
+    static int n_seen = 0;
+    for (int i = 0; i < n_seen; ++i) if (seen_k[i] == kernel && seen_b[i] >= lds) return XR_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XR_EHIP;
+    for (int i = 0; i < n_seen; ++i) if (seen_k[i] == kernel) { seen_b[i] = lds; return XR_OK; }
+    if (n_seen < 16) { seen_k[n_seen] = kernel; seen_b[n_seen] = lds; ++n_seen; }
+    return XR_OK;
+}
 static uint32_t bwd_grid(uint32_t n) {
     const int cus = xr_device_cus() > 0 ? xr_device_cus() : 256;
     const uint32_t n_tiles = (n + 31) / 32;
@@ -1440,7 +1451,7 @@ extern "C" int xr_nerf_mlp_bwd(const float* enc_t, uint32_t ld, const float* dir
     const uint32_t* rows = live_rows;                    // the caller's list (xr_live_rows), else the backward's own
     if (!rows && live_rows_enabled()) { const int rc = build_live_rows(draw, n, n_dev, denc_t, ld, workspace, stream, &rows, &n_live); if (rc != XR_OK) return rc; }
     auto kern = rows ? k_nerf_mlp_bwd_1_2<true> : k_nerf_mlp_bwd_1_2<false>;
-    XR_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (mlp_set_lds((const void*)kern, lds) != XR_OK) { xr_set_error("hipFuncSetAttribute failed"); return XR_EHIP; }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n,
                        n_dev, w_density, w_color, pad_value, (const float4*)draw, denc_t, (float*)workspace, rows, n_live);
     if (!g_defer_reduce)
@@ -1543,7 +1554,7 @@ extern "C" int xr_nerf_mlp_fwd_bf16x3(const float* enc_t, uint32_t ld, const flo
     const uint32_t grid = min(xr_div_up((n + 31) / 32, BX_WAVES), (uint32_t)cus);          // resident: one 8-wave workgroup per CU
     if (dirs) {
         const size_t lds = (size_t)3 * (HShape<1>::f_halves + HShape<2>::f_halves) * 2;
-        XR_HIP(hipFuncSetAttribute((const void*)k_nerf_mlp_fwd_b3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (mlp_set_lds((const void*)k_nerf_mlp_fwd_b3<true>, lds) != XR_OK) { xr_set_error("hipFuncSetAttribute failed"); return XR_EHIP; }
         hipLaunchKernelGGL(k_nerf_mlp_fwd_b3<true>, dim3(grid), dim3(BX_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev,
                            rows, w_density, w_color, pad_value, (float4*)raw);
     } else {
@@ -1575,7 +1586,7 @@ extern "C" int xr_nerf_mlp_bwd_f16(const float* enc_t, uint32_t ld, const float*
     const uint32_t* rows = live_rows;                    // the caller's list (xr_live_rows), else the backward's own
     if (!rows && live_rows_enabled()) { const int rc = build_live_rows(draw, n, n_dev, denc_t, ld, workspace, stream, &rows, &n_live); if (rc != XR_OK) return rc; }
     auto kern = rows ? k_nerf_mlp_bwd_h<true> : k_nerf_mlp_bwd_h<false>;
-    XR_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (mlp_set_lds((const void*)kern, lds) != XR_OK) { xr_set_error("hipFuncSetAttribute failed"); return XR_EHIP; }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev, w_density,
                        w_color, pad_value, (const float4*)draw, denc_t, (float*)workspace, rows, n_live);
     if (!g_defer_reduce)

@@ -76,6 +76,20 @@ def recover_shape(data, to_shape):   # networks/utils/transforms.py:5-9
     return torch.reshape(data, to_shape)
 
 
+from ._fastattr import _FastAttr
+
+
+class _DirectCtx:
+    """stands in for the autograd context when the trainer runs the fused step without autograd (HashNerfNetwork.train_step(...,
+    direct=True)): the step either applies the updates itself or hands its gradients straight to `.grad`"""
+
+    def mark_non_differentiable(self, *a):
+        pass
+
+    def set_materialize_grads(self, v):
+        pass
+
+
 class _FusedTrainStepFn(torch.autograd.Function):
     """The whole training forward AND backward of HashNerfNetwork as ONE autograd node.
 
@@ -242,13 +256,20 @@ class _FusedTrainStepFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, _g_rgb):
+        _FusedTrainStepFn.deliver(ctx, g)
+        return None, None, None, None, None
+
+    @staticmethod
+    def deliver(ctx, g):
+        """hands the step's gradients to the parameters' .grad (the body of backward; also called directly by the autograd-free
+        step with the registered unit root gradient)"""
         from . import ops
         grads = list(ctx.grads)
         params = ctx.params
         ctx.grads = ctx.params = None
         factor = ctx.sync.finish() if ctx.sync is not None else 1.0      # all buckets reduced; average over the ranks
         if g is None:                            # only the non-differentiable output was used downstream
-            return None, None, None, None, None
+            return
         unit = ctx.unit_root_grad
         is_unit = unit is not None and g.data_ptr() == unit.data_ptr()
         if getattr(ctx, 'table_updated', False) and not (is_unit and factor == 1.0):
@@ -275,7 +296,6 @@ class _FusedTrainStepFn(torch.autograd.Function):
                 p_.grad = g_                    # (same storage: the step already wrote this gradient into it)
             else:
                 p_.grad.add_(g_)
-        return None, None, None, None, None
 
 
 class _LazyPsnr:
@@ -307,7 +327,10 @@ class BaseNerfNetwork(nn.Module):
 
 
 @NETWORKS.register_module()
-class HashNerfNetwork(BaseNerfNetwork):
+class HashNerfNetwork(_FastAttr, BaseNerfNetwork):
+    _FAST_ATTRS = frozenset(('_fuse_table_update', '_step_optimizer', '_step_turn', '_last', '_pending_grad_scale', '_direct_step',
+                             '_fuse_ok_key', '_fuse_ok'))
+
     def __init__(self, cfg, sampler=None, mlp=None, render=None):
         super().__init__()
         cfg = builder.ConfigDict.wrap(dict(cfg))
@@ -378,8 +401,22 @@ class HashNerfNetwork(BaseNerfNetwork):
                 ops._on_device(self.mlp.embedder_pos.params) and torch.is_grad_enabled())
 
     def _train_step_fused(self, data, **kwargs):
-        loss, rgb = _FusedTrainStepFn.apply(self.mlp.embedder_pos.params, self.mlp.density_net.params,
-                                            self.mlp.color_net.params, self, data)
+        direct = kwargs.get('direct', False) and getattr(self, 'grad_sync', None) is None and getattr(self, '_unit_root_grad', None) is not None
+        if direct:
+            # no autograd graph: the caller promises what the graph would have been used for -- one backward pass from a unit root
+            # gradient with cleared .grads (xrnerf_amd.train.Trainer).  ~80 us of engine, Function.apply and optimiser-wrapper time per
+            # iteration that the host does not have: at 0.45 ms per step the loop was bound by the interpreter, not by the GPU
+            ctx = _DirectCtx()
+            with torch.no_grad():
+                loss, rgb = _FusedTrainStepFn.forward(ctx, self.mlp.embedder_pos.params, self.mlp.density_net.params,
+                                                      self.mlp.color_net.params, self, data)
+            applied = getattr(ctx, 'table_updated', False)
+            if not applied:
+                _FusedTrainStepFn.deliver(ctx, self._unit_root_grad)
+        else:
+            applied = False
+            loss, rgb = _FusedTrainStepFn.apply(self.mlp.embedder_pos.params, self.mlp.density_net.params,
+                                                self.mlp.color_net.params, self, data)
         bs = rgb.shape[0]
         if kwargs.get('lazy_log', False):
             # lazy_log contract: the two values are device-side views of the step's recycled buffers and must be read (float())
@@ -391,7 +428,11 @@ class HashNerfNetwork(BaseNerfNetwork):
                 mse_loss = self._last['loss_mse'][1] / (3.0 * bs)        # img2mse of the alpha-masked images
                 psnr = mse2psnr(mse_loss)
             log_vars = {'loss': loss.item(), 'psnr': psnr.item()}
-        return {'loss': loss, 'log_vars': log_vars, 'num_samples': bs}
+        out = {'loss': loss, 'log_vars': log_vars, 'num_samples': bs}
+        if direct:
+            out['grads_ready'] = True                   # .grad holds the gradients (or nothing: updates_applied) -- no backward() needed
+            out['updates_applied'] = applied
+        return out
 
     def train_step(self, data, optimizer, **kwargs):
         for k in data:

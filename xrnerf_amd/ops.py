@@ -346,19 +346,45 @@ def ngp_train_step(table, wd, wc, nhd, nhc, pad_value, meta, coords, n_dev, nums
     scatter_level0 > 0 (data parallel): only hash levels [scatter_level0, n_levels) are scattered; the caller finishes with
     hashgrid_bwd(..., live=bufs.live, levels=(0, scatter_level0)) after handing the finer slice to its collective.
     adam (ops.adam_fuse of the table, single GPU): the scatter applies the optimiser's update to the table itself; bufs.g_table
-    is not written.  mlp_adam = (adam_fuse of wd, adam_fuse of wc): their update runs behind the reduction of their gradients."""
+    is not written.  mlp_adam = (adam_fuse of wd, adam_fuse of wc): their update runs behind the reduction of their gradients.
+
+    The ~45 pointer / size arguments are validated and converted once per set of buffers (keyed by the data pointers of the
+    tensors that alternate between iterations): at 0.45 ms per iteration the interpreter time of this call -- 30 pointer checks,
+    four workspace queries -- was what the GPU waited for (tools/hosttime2.py)."""
+    global LIVE_STATS
     L = _lib.load()
     n_rays = numsteps.shape[0]
-    n_rows = bufs.n_rows
-    if coords.shape[0] < n_rows or coords.shape[1] != 7 or not coords.is_contiguous():
-        raise _lib.XrError('coords must be contiguous [>= n_rows, 7] rows')
-    s, r, o = meta._args()
-    ws_mlp = _ws(coords.device, L.xr_nerf_mlp_bwd_workspace_bytes(n_rows), 'mlpbwd')
-    ws_sc = _ws(coords.device, L.xr_hashgrid_bwd_workspace_bytes(n_rows, meta.n_levels, r, o), 'hgb')
-    # the backward's (count, running live total, running valid total) block sits in the MLP workspace on this path
-    global LIVE_STATS
-    ws_mlp, live_list, _, LIVE_STATS = _list_slots(coords.device, n_rows)
-    bufs.live = (live_list, LIVE_STATS) if os.environ.get('XR_MLP_LIVE') != '0' else None     # (the native step reads the same switch)
+    mode = _mlp_mode(nhd, nhc)
+    key = (table.data_ptr(), wd.data_ptr(), wc.data_ptr(), coords.data_ptr(), coords.shape[0], n_dev.data_ptr() if n_dev is not None else 0,
+           numsteps.data_ptr(), numsteps_c.data_ptr(), bg.data_ptr(), target.data_ptr(), alpha.data_ptr(), density_grid_mean.data_ptr(),
+           xyz.data_ptr() if xyz is not None else 0, xyz.shape[1] if xyz is not None else 0, nhd, nhc, pad_value, mode, id(meta),
+           int(rgb_act), int(density_act), huber_delta, loss_scale, int(scatter_level0))
+    cache = bufs.__dict__.setdefault('_step_args', {})
+    ent = cache.get(key)
+    if ent is None:
+        n_rows = bufs.n_rows
+        if coords.shape[0] < n_rows or coords.shape[1] != 7 or not coords.is_contiguous():
+            raise _lib.XrError('coords must be contiguous [>= n_rows, 7] rows')
+        s, r, o = meta._args()
+        _ws(coords.device, L.xr_nerf_mlp_bwd_workspace_bytes(n_rows), 'mlpbwd')
+        ws_sc = _ws(coords.device, L.xr_hashgrid_bwd_workspace_bytes(n_rows, meta.n_levels, r, o), 'hgb')
+        # the backward's (count, running live total, running valid total) block sits in the MLP workspace on this path
+        ws_mlp, live_list, _, live_stats = _list_slots(coords.device, n_rows)
+        live = (live_list, live_stats) if os.environ.get('XR_MLP_LIVE') != '0' else None     # (the native step reads the same switch)
+        head = (_ptr(table), _ptr(wd), _ptr(wc), nhd, nhc, pad_value, mode, meta.n_levels, s, r, o,
+                _ptr(coords), n_rows, _ptr(n_dev), _ptr(numsteps), _ptr(numsteps_c))
+        mid = (_ptr(bg), _ptr(target), _ptr(alpha),
+               _ptr(density_grid_mean), int(rgb_act), int(density_act), float(huber_delta), float(loss_scale),
+               _ptr(bufs.enc_t), bufs.ld, _ptr(bufs.raw), _ptr(bufs.draw), _ptr(bufs.denc_t), _ptr(bufs.rgb),
+               _ptr(bufs.zero_block), bufs.zero_block.numel(), _ptr(bufs.g_wd), _ptr(bufs.g_wc), _ptr(bufs.loss_mse), _ptr(bufs.live_seg),
+               _ptr(bufs.g_table), bufs.g_table.numel(), 0 if n_dev is not None else 1,
+               _ptr(ws_mlp), ws_mlp.numel(), _ptr(ws_sc), ws_sc.numel(), int(scatter_level0),
+               _ptr(xyz), xyz.shape[1] if xyz is not None else 0)
+        if len(cache) > 16:
+            cache.clear()
+        ent = cache[key] = (head, mid, live, live_stats, (ws_mlp, ws_sc, meta, table, wd, wc))     # (keeps what the pointers name alive)
+    head, mid, live, LIVE_STATS = ent[0], ent[1], ent[2], ent[3]
+    bufs.live = live
     stage, ev = None, (None, None)
     if TIMER is not None:
         ok, stage = TIMER.native_stage()
@@ -367,20 +393,12 @@ def ngp_train_step(table, wd, wc, nhd, nhc, pad_value, meta, coords, n_dev, nums
         if stage is not None:
             ev = (_CEvent(), _CEvent())
             TIMER.events.setdefault(stage, []).append((ev[0], ev[1], 0))
-    with _span('xr_ngp_train_step', 0):
-        _lib.check(L.xr_ngp_train_step(
-            _ptr(table), _ptr(wd), _ptr(wc), nhd, nhc, pad_value, _mlp_mode(nhd, nhc), meta.n_levels, s, r, o,
-            _ptr(coords), n_rows, _ptr(n_dev), _ptr(numsteps), _ptr(numsteps_c), n_rays, _ptr(bg), _ptr(target), _ptr(alpha),
-            _ptr(density_grid_mean), int(rgb_act), int(density_act), float(huber_delta), float(loss_scale),
-            _ptr(bufs.enc_t), bufs.ld, _ptr(bufs.raw), _ptr(bufs.draw), _ptr(bufs.denc_t), _ptr(bufs.rgb),
-            _ptr(bufs.zero_block), bufs.zero_block.numel(), _ptr(bufs.g_wd), _ptr(bufs.g_wc), _ptr(bufs.loss_mse), _ptr(bufs.live_seg),
-            _ptr(bufs.g_table), bufs.g_table.numel(), 0 if n_dev is not None else 1,
-            _ptr(ws_mlp), ws_mlp.numel(), _ptr(ws_sc), ws_sc.numel(), int(scatter_level0),
-            _ptr(xyz), xyz.shape[1] if xyz is not None else 0, C.byref(adam) if adam is not None else None,
-            C.byref(mlp_adam[0]) if mlp_adam else None, C.byref(mlp_adam[1]) if mlp_adam else None,
-            mark[0].encode() if mark else None, mark[1].h if mark else None,
-            stage.encode() if stage else None,
-            ev[0].h if stage else None, ev[1].h if stage else None, _stream()), 'xr_ngp_train_step')
+    rc = L.xr_ngp_train_step(*head, n_rays, *mid, C.byref(adam) if adam is not None else None,
+                             C.byref(mlp_adam[0]) if mlp_adam else None, C.byref(mlp_adam[1]) if mlp_adam else None,
+                             mark[0].encode() if mark else None, mark[1].h if mark else None,
+                             stage.encode() if stage else None, ev[0].h if stage else None, ev[1].h if stage else None, _stream())
+    if rc != 0:
+        _lib.check(rc, 'xr_ngp_train_step')
     return bufs.rgb[:n_rays]
 
 

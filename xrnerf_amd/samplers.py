@@ -25,11 +25,16 @@ import torch
 from torch import nn
 
 from . import ops
+from ._fastattr import _FastAttr
 from .builder import SAMPLERS
 
 
 @SAMPLERS.register_module()
-class NGPGridSampler(nn.Module):
+class NGPGridSampler(_FastAttr, nn.Module):
+    # per-step state (never a Parameter, a registered buffer or a sub-module): assigned ~15 times per training iteration
+    _FAST_ATTRS = frozenset(('iter_n', 'on_sampled', '_prefetched', 'rays_index', 'coords', 'xyz', 'rays_numsteps', 'rays_numsteps_compacted',
+                             'n_valid_dev', 'persistent_batches', '_train_launches', '_pinned_next', 'k1_calls', '_test_rows_seen',
+                             'frame_chunk', '_pending_counts', 'n_rays_per_batch'))
     def __init__(self, update_grid_freq=16, update_block_size=5000000, n_rays_per_batch=4096,
                  cone_angle_constant=0.00390625, near_distance=0.2, target_batch_size=1 << 18, rgb_activation=2,
                  density_activation=3):
@@ -191,8 +196,7 @@ class NGPGridSampler(nn.Module):
                 pf['rays_o'].shape == data['rays_o'].shape and pf['max_samples'] == max_samples):
             # K1 of this batch already ran on the side stream while the previous iteration's backward was
             # executing (prefetch()): order this stream after it and adopt its outputs
-            cur = torch.cuda.current_stream()
-            cur.wait_event(pf['event'])
+            pf['event'].wait()                          # the current stream waits (no torch.cuda.current_stream(): ~10 us of Python)
             coords, rays_index, rays_numsteps, counter = pf['out']
             xyz = pf.get('xyz')
             clipped = pf.get('clipped')
@@ -202,6 +206,7 @@ class NGPGridSampler(nn.Module):
             # the caller owns them persistently too (`persistent_batches`): every record_stream'd tensor costs an
             # event record on this stream when it is freed, ~6 us of idle GPU each, 9 of them per iteration
             if not getattr(self, 'persistent_batches', False):
+                cur = torch.cuda.current_stream()
                 for t in data.values():
                     if torch.is_tensor(t) and t.is_cuda:
                         t.record_stream(cur)
@@ -465,7 +470,7 @@ class NGPGridSampler(nn.Module):
         self._pinned_next += 1
         host.copy_(counter, non_blocking=True)
         ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
+        ev.record()                                  # on the current stream
         return ev, host
 
     def _drain_counts(self):

@@ -240,6 +240,8 @@ class Trainer:
         # Valid because this trainer back-propagates a unit root gradient and clears the gradients every step.
         # (the switch is raised around this trainer's own train_step calls only: anyone else calling net.train_step gets gradients)
         self.fuse_adam = world_size == 1 and os.environ.get('XRNERF_FUSE_ADAM', '1') != '0'
+        self.direct_step = world_size == 1 and os.environ.get('XRNERF_DIRECT_STEP', '1') != '0'
+        self._opt_params = opt_params
         self.rays_done = 0
         self.lazy_log = True
         # run K1 of the next batch on a side stream under this step's backward (XRNERF_OVERLAP_MARCH=0: serial)
@@ -269,22 +271,34 @@ class Trainer:
         n_rays = batch['rays_o'].shape[0]
         # the reference's DataLoader(batch_size=1) collates a leading batch axis that train_step unfolds
         batch = {k: v[None] for k, v in batch.items()}
-        net._fuse_table_update = self.fuse_adam and self._one is not None
-        try:
-            out = net.train_step(batch, self.opt, lazy_log=self.lazy_log)
-        finally:
-            net._fuse_table_update = False
-        self.opt.zero_grad(set_to_none=True)
         # root gradient = a persistent ones tensor (loss.backward() would fill a fresh one every step)
         if self._one is None:
             self._one = torch.ones((), dtype=torch.float32, device=self.device)
             net._unit_root_grad = self._one        # lets the fused step skip its gradient-scaling launch
-        torch.autograd.backward(out['loss'], grad_tensors=self._one)
-        if self.world_size > 1 and not net._fused_ok():
-            from . import dist as xdist                 # modular step: reduce after backward (DDP semantics)
-            xdist.allreduce_grads([p for p in net.parameters() if p.grad is not None], self.world_size)
-        self.opt.step(grad_scale=getattr(net, '_pending_grad_scale', 1.0))
-        net._pending_grad_scale = 1.0
+        # one GPU: the fused step without autograd (`direct`): this loop back-propagates a unit root gradient into cleared .grads and
+        # nothing else, which the step can do itself -- it applies the updates (fuse_adam) or leaves its gradients in .grad.  The
+        # engine pass, Function.apply and the optimiser wrappers were ~0.1 ms of the ~0.43 ms of interpreter time per iteration,
+        # and the interpreter, not the GPU, set the pace (tools/hosttime2.py).  XRNERF_DIRECT_STEP=0: through autograd.
+        direct = self.direct_step
+        if direct:
+            for p_ in self._opt_params:
+                p_.grad = None
+        net._fuse_table_update = self.fuse_adam
+        try:
+            out = net.train_step(batch, self.opt, lazy_log=self.lazy_log, direct=direct)
+        finally:
+            net._fuse_table_update = False
+        if out.get('grads_ready'):
+            if not out['updates_applied']:
+                self.opt.step()
+        else:
+            self.opt.zero_grad(set_to_none=True)
+            torch.autograd.backward(out['loss'], grad_tensors=self._one)
+            if self.world_size > 1 and not net._fused_ok():
+                from . import dist as xdist                 # modular step: reduce after backward (DDP semantics)
+                xdist.allreduce_grads([p for p in net.parameters() if p.grad is not None], self.world_size)
+            self.opt.step(grad_scale=getattr(net, '_pending_grad_scale', 1.0))
+            net._pending_grad_scale = 1.0
         if self.world_size > 1 and self.dp_mode == 'zero1':
             net.grad_sync.gather_params()               # every rank's updated shard -> the full table, in place
         data.set_batchsize(net.sampler.n_rays_per_batch)                  # ModifyBatchsizeHook
@@ -292,7 +306,7 @@ class Trainer:
         self.rays_done += n_rays
         if self.overlap_march:
             ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
+            ev.record()                                   # (the current stream; torch.cuda.current_stream() alone costs ~10 us)
             self._ev_done = [self._ev_done[1], ev]
         return out
 
