@@ -1,4 +1,4 @@
-// phase timing of the third-generation accumulate kernel (k_scatter_accum3<13>) on ray-like samples (20 consecutive steps of
+// phase timing of the third-generation accumulate kernel (k_scatter_accum3<13, 1024>) on ray-like samples (20 consecutive steps of
 // sqrt(3)/1024 per ray), all 16 levels of the Lego geometry: wall_clock64 (100 MHz) stamps of workgroups 0, 96, 192, ... + event
 // times of the kernels.  build + run on the GPU box:
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -ffp-contract=off -mllvm -simplifycfg-sink-common=false -DS3_TIMING \
@@ -62,14 +62,14 @@ int main(int argc, char** argv) {
         P.bin.ad = XrAdamArgs{st[0], st[1], st[2], st[3], 0.9f, 0.99f, 1e-2f, 0.1f, 1e-15f, 1e-6f, 0.05f, 1.f};
         printf("fused optimiser update ON\n");
     }
-    hipFuncSetAttribute((const void*)k_scatter_accum3<13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES);
+    hipFuncSetAttribute((const void*)k_scatter_accum3<13, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES);
     hipEvent_t a, b, c; hipEventCreate(&a); hipEventCreate(&b); hipEventCreate(&c);
     for (int rep = 0; rep < 4; ++rep) {
         hipEventRecord(a);
         hipLaunchKernelGGL(k_scatter_bin3<2048>, dim3(P.bin.n_lv * P.bin.nsb), dim3(S3_BIN_THREADS), 0, 0, P.bin, dx, 3u, dd, n, 1u << 18, ndev,
                            (const uint32_t*)nullptr, counts, bins, ovf);
         hipEventRecord(b);
-        hipLaunchKernelGGL(k_scatter_accum3<13>, dim3(P.bin.acc_blocks), dim3(1024), S3_LDS_BYTES, 0, P.bin, (const uint32_t*)counts,
+        hipLaunchKernelGGL((k_scatter_accum3<13, 1024>), dim3(P.bin.acc_blocks), dim3(1024), S3_LDS_BYTES, 0, P.bin, (const uint32_t*)counts,
                            (const float4*)bins, (const float4*)ovf, tab);
         hipEventRecord(c); hipEventSynchronize(c);
         float m1, m2; hipEventElapsedTime(&m1, a, b); hipEventElapsedTime(&m2, b, c);

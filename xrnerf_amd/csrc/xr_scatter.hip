@@ -361,11 +361,13 @@ __device__ __forceinline__ void s3_adam_entries(const XrAdamArgs& A, const size_
         }
 }
 
-template <int LG>
-__global__ __launch_bounds__(1 << (LG - 3)) void k_scatter_accum3(S3Plan pl, const uint32_t* __restrict__ counts,
+// TH: threads per workgroup.  1024 (16 waves) or 512 (8 waves: the same time, profiles/r03_accumulate_512_threads_ab.txt, with half
+// the register file left to whatever else is resident -- the side-stream march, for one).
+template <int LG, int TH = (1 << (LG - 3))>
+__global__ __launch_bounds__(TH) void k_scatter_accum3(S3Plan pl, const uint32_t* __restrict__ counts,
                                                                   const float4* __restrict__ bins, const float4* __restrict__ ovf,
                                                                   float* __restrict__ grad_table) {
-    constexpr uint32_t ENTRIES = 1u << LG, THREADS = 1u << (LG - 3), WAVES = THREADS / 64;
+    constexpr uint32_t ENTRIES = 1u << LG, THREADS = (uint32_t)TH, WAVES = THREADS / 64;
     extern __shared__ __attribute__((aligned(16))) double s_acc[];       // [ENTRIES][2]
     uint32_t e = 0;
     while (e + 1 < pl.n_lv && blockIdx.x >= pl.lv[e + 1].acc_block0) ++e;   // levels in accumulate order (heaviest first)
@@ -482,8 +484,8 @@ __global__ __launch_bounds__(1 << (LG - 3)) void k_scatter_accum3(S3Plan pl, con
     }
     // fused optimiser update, hashed levels: this thread's 8 entries are 4 pairs of neighbours (16 B of p / m / v / ema each), taken
     // in two rounds of two pairs; the first round's loads go out before the barrier that waits for every wave's LDS atomics
-    constexpr uint32_t FP = ENTRIES / (2 * THREADS), FH = FP / 2;
-    static_assert(FP == 4, "two rounds of two pairs");
+    constexpr uint32_t FP = ENTRIES / (2 * THREADS), FH = 2, ROUNDS = FP / FH;
+    static_assert(FP % FH == 0 && ROUNDS >= 1, "rounds of two pairs");
     const bool fuse_h = pl.fuse != 0u && L.kind == S3_H;
     float4 fp_[FH], fm_[FH], fv_[FH], fq_[FH];
     const size_t f4_0 = ((size_t)L.toff + (size_t)part * ENTRIES) / 2;      // float4 index of the partition's first pair (offsets are even)
@@ -503,7 +505,7 @@ __global__ __launch_bounds__(1 << (LG - 3)) void k_scatter_accum3(S3Plan pl, con
     if (fuse_h) {
         const XrAdamArgs& A = pl.ad;
 #pragma unroll
-        for (uint32_t r = 0; r < 2; ++r) {
+        for (uint32_t r = 0; r < ROUNDS; ++r) {
             double2 a0[FH], a1[FH];
 #pragma unroll
             for (uint32_t k = 0; k < FH; ++k) { const uint32_t q = 2u * ((r * FH + k) * THREADS + threadIdx.x); a0[k] = acc2[q]; a1[k] = acc2[q + 1]; }
@@ -521,7 +523,7 @@ __global__ __launch_bounds__(1 << (LG - 3)) void k_scatter_accum3(S3Plan pl, con
                     s3_st4nt(A.ema, i4, fq_[k]);
                 }
             }
-            if (r == 0) adam_load(FH);
+            if (r + 1 < ROUNDS) adam_load((r + 1) * FH);
         }
     } else if (pl.fuse) {
         // (dense levels: strided rows) the partition's entries, 4 per thread and round: (p, m, v, ema) of all four in flight together
@@ -799,7 +801,8 @@ int xr_scatter3(const float* x, uint32_t x_stride, const float* denc_t, uint32_t
     float2* slabs = (float2*)((char*)workspace + P.counts_bytes + P.bins_bytes + P.ovf_bytes);
     static bool attr_set = false;
     if (!attr_set) {
-        XR_HIP(hipFuncSetAttribute((const void*)k_scatter_accum3<S3_LOG2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES));
+        XR_HIP(hipFuncSetAttribute((const void*)k_scatter_accum3<S3_LOG2, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES));
+        XR_HIP(hipFuncSetAttribute((const void*)k_scatter_accum3<S3_LOG2, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES));
         XR_HIP(hipFuncSetAttribute((const void*)k_scatter_dense_rl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES));
         attr_set = true;
     }
@@ -845,8 +848,15 @@ int xr_scatter3(const float* x, uint32_t x_stride, const float* denc_t, uint32_t
         else if (bs == 2048) hipLaunchKernelGGL(k_scatter_bin3<2048>, grid, block, 0, stream, P.bin, x, x_stride, denc_t, ld, n, n_dev, rows, counts, bins, ovf);
         else hipLaunchKernelGGL(k_scatter_bin3<1024>, grid, block, 0, stream, P.bin, x, x_stride, denc_t, ld, n, n_dev, rows, counts, bins, ovf);
         XR_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_scatter_accum3<S3_LOG2>, dim3(P.bin.acc_blocks), dim3(1024), S3_LDS_BYTES, stream, P.bin, (const uint32_t*)counts,
-                           (const float4*)bins, (const float4*)ovf, grad_table);
+        // XR_SC_ACC_THREADS (read once): 512 (default) | 1024 threads per accumulate workgroup -- the same time alone; with 8 waves the
+        // march that the trainer now runs beside this kernel (prefetch depth 2) finds registers on every SIMD
+        static const int acc_threads = s3_env("XR_SC_ACC_THREADS", 512);
+        if (acc_threads == 512)
+            hipLaunchKernelGGL((k_scatter_accum3<S3_LOG2, 512>), dim3(P.bin.acc_blocks), dim3(512), S3_LDS_BYTES, stream, P.bin, (const uint32_t*)counts,
+                               (const float4*)bins, (const float4*)ovf, grad_table);
+        else
+            hipLaunchKernelGGL((k_scatter_accum3<S3_LOG2, 1024>), dim3(P.bin.acc_blocks), dim3(1024), S3_LDS_BYTES, stream, P.bin, (const uint32_t*)counts,
+                               (const float4*)bins, (const float4*)ovf, grad_table);
         XR_LAUNCH_CHECK();
     }
     if (!rl_first) { const int rc = launch_rl(); if (rc != XR_OK) return rc; }

@@ -32,7 +32,7 @@ from .builder import SAMPLERS
 @SAMPLERS.register_module()
 class NGPGridSampler(_FastAttr, nn.Module):
     # per-step state (never a Parameter, a registered buffer or a sub-module): assigned ~15 times per training iteration
-    _FAST_ATTRS = frozenset(('iter_n', 'on_sampled', '_prefetched', 'rays_index', 'coords', 'xyz', 'rays_numsteps', 'rays_numsteps_compacted',
+    _FAST_ATTRS = frozenset(('iter_n', 'on_sampled', '_prefetched_q', 'rays_index', 'coords', 'xyz', 'rays_numsteps', 'rays_numsteps_compacted',
                              'n_valid_dev', 'persistent_batches', '_train_launches', '_pinned_next', 'k1_calls', '_test_rows_seen',
                              'frame_chunk', '_pending_counts', 'n_rays_per_batch'))
     def __init__(self, update_grid_freq=16, update_block_size=5000000, n_rays_per_batch=4096,
@@ -71,7 +71,7 @@ class NGPGridSampler(_FastAttr, nn.Module):
         self.k1_calls = 0
         self.k6_calls = 0
         self.device = None
-        self._prefetched = None
+        self._prefetched_q = []
         self._pending_counts = []
         self.samples_marched = 0
 
@@ -189,9 +189,10 @@ class NGPGridSampler(_FastAttr, nn.Module):
             # the exact size -- same RNG call index, identical result -- in the rare case it overflowed
             est = max(n_rays * 48, int(getattr(self, '_test_rows_seen', 0) * 1.25) + 1024)
             max_samples = min(n_rays * self.MAX_STEP, est)
-        pf = self._prefetched if is_training else None      # a render / val call in between leaves the prefetch alone
-        if is_training:
-            self._prefetched = None
+        # prefetched marches wait in issue order (up to two: the next iteration's and the one after); a render / val call in
+        # between leaves them alone
+        q = self.__dict__.get('_prefetched_q')
+        pf = q.pop(0) if (is_training and q) else None
         if (pf is not None and pf['rays_o'].data_ptr() == data['rays_o'].data_ptr() and
                 pf['rays_o'].shape == data['rays_o'].shape and pf['max_samples'] == max_samples):
             # K1 of this batch already ran on the side stream while the previous iteration's backward was
@@ -216,7 +217,11 @@ class NGPGridSampler(_FastAttr, nn.Module):
                 # a prefetched march that does not belong to this batch is dropped (its RNG call stays consumed, like
                 # any other launch); its side-stream writes into the shared buffers must have finished before this
                 # stream's launch touches them
-                torch.cuda.current_stream().wait_event(pf['event'])
+                cur = torch.cuda.current_stream()
+                cur.wait_event(pf['event'])
+                for other in q:                     # (whatever was marched behind it is as stale as it is)
+                    cur.wait_event(other['event'])
+                del q[:]
             slot = self._next_slot(is_training)
             k1_index = self.k1_calls
             async_test = (not is_training) and getattr(self, '_async_test', None) is not None and self._streams()
@@ -305,19 +310,21 @@ class NGPGridSampler(_FastAttr, nn.Module):
             cb()       # e.g. the trainer issues the NEXT batch's march on a side stream right here
         return data
 
-    # K1 output buffers are persistent and owned by the sampler: slots 0/1 alternate over the TRAINING launches (the
-    # previous launch's rows are still being read by the previous iteration's backward when a prefetched launch
-    # writes the next ones), slot 2 serves test / render launches, which may come in between
+    # K1 output buffers are persistent and owned by the sampler: slots 0..2 rotate over the TRAINING launches (a march may be
+    # issued two iterations ahead -- Trainer, prefetch depth 2 -- while the two iterations before it still read their rows),
+    # slot 3 serves test / render launches, which may come in between
+    N_SLOTS = 4
+
     def _next_slot(self, is_training):
         if not is_training:
-            return 2
+            return 3
         self._train_launches = getattr(self, '_train_launches', 0) + 1
-        return self._train_launches & 1
+        return self._train_launches % 3
 
     def _coords_buffer(self, rows, slot):
         bufs = getattr(self, '_coords_bufs', None)
         if bufs is None:
-            bufs = self._coords_bufs = [None, None, None]
+            bufs = self._coords_bufs = [None] * self.N_SLOTS
         buf = bufs[slot]
         if buf is None or buf.shape[0] < rows or buf.device != self.device:
             buf = bufs[slot] = torch.empty((rows, 7), dtype=torch.float32, device=self.device)
@@ -344,7 +351,7 @@ class NGPGridSampler(_FastAttr, nn.Module):
             return None
         bufs = getattr(self, '_xyz_bufs', None)
         if bufs is None:
-            bufs = self._xyz_bufs = [None, None, None]
+            bufs = self._xyz_bufs = [None] * self.N_SLOTS
         buf = bufs[slot]
         if buf is None or buf.shape[1] < rows or buf.device != self.device:
             buf = bufs[slot] = torch.empty((3, rows), dtype=torch.float32, device=self.device)
@@ -353,7 +360,7 @@ class NGPGridSampler(_FastAttr, nn.Module):
     def _small_buffers(self, n_rays, slot):
         bufs = getattr(self, '_small_bufs', None)
         if bufs is None:
-            bufs = self._small_bufs = [None, None, None]
+            bufs = self._small_bufs = [None] * self.N_SLOTS
         b = bufs[slot]
         if b is None or b[0].shape[0] < n_rays or b[0].device != self.device:
             cap = max(n_rays, 1 << 15)
@@ -366,7 +373,7 @@ class NGPGridSampler(_FastAttr, nn.Module):
         """persistent outputs of the prefetched K2 clip (nothing allocated on the side stream)"""
         bufs = getattr(self, '_clip_bufs', None)
         if bufs is None:
-            bufs = self._clip_bufs = [None, None, None]
+            bufs = self._clip_bufs = [None] * self.N_SLOTS
         b = bufs[slot]
         if b is None or b[0].shape[0] < n_rays or b[0].device != self.device:
             cap = max(n_rays, 1 << 15)
@@ -423,8 +430,8 @@ class NGPGridSampler(_FastAttr, nn.Module):
         done = torch.cuda.Event()
         done.record(side)
         host = self._count_to_host(out[3])
-        self._prefetched = {'rays_o': rays_o, 'max_samples': max_samples, 'out': out, 'event': done, 'host': host, 'clipped': clipped,
-                            'xyz': xyz}
+        self.__dict__.setdefault('_prefetched_q', []).append({'rays_o': rays_o, 'max_samples': max_samples, 'out': out, 'event': done,
+                                                              'host': host, 'clipped': clipped, 'xyz': xyz})
 
     def prefetch_native(self, rows, n_rays, batch_call_index, batch_out, buffer_free_event=None, start_event=None):
         """`prefetch` with the batch assembly folded in, as ONE native call (xr_ngp_prefetch: make_batch + K1 + K2 clip + counter
@@ -452,8 +459,8 @@ class NGPGridSampler(_FastAttr, nn.Module):
         done = torch.cuda.Event()
         done.record(side)
         host = self._count_to_host(out[3])
-        self.__dict__['_prefetched'] = {'rays_o': batch['rays_o'], 'max_samples': max_samples, 'out': out, 'event': done,
-                                        'host': host, 'clipped': clipped, 'xyz': xyz}
+        self.__dict__.setdefault('_prefetched_q', []).append({'rays_o': batch['rays_o'], 'max_samples': max_samples, 'out': out,
+                                                              'event': done, 'host': host, 'clipped': clipped, 'xyz': xyz})
         return batch
 
     def _count_to_host(self, counter):

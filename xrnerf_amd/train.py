@@ -246,7 +246,6 @@ class Trainer:
         self.lazy_log = True
         # run K1 of the next batch on a side stream under this step's backward (XRNERF_OVERLAP_MARCH=0: serial)
         self.overlap_march = os.environ.get('XRNERF_OVERLAP_MARCH', '1') != '0'
-        self._next_batch = None
         # where in the step the next batch's side-stream march may start: behind the named entry point of the fused step
         # (XRNERF_PREFETCH_AFTER; default none = as soon as the step is enqueued).  Measured (profiles/r03_prefetch_start_point.txt,
         # ms/step): none 0.548, behind the encode 0.554, behind the fused-MLP forward 0.552, behind the compositor 0.582, behind
@@ -256,8 +255,18 @@ class Trainer:
         if after not in ('none', 'xr_hashgrid_fwd', 'xr_nerf_mlp_fwd', 'xr_composite_train', 'xr_live_rows', 'xr_nerf_mlp_bwd'):
             raise ValueError('XRNERF_PREFETCH_AFTER: unknown entry point %r' % after)
         self.net._step_mark = (after, ops._CEvent()) if (after != 'none' and device.type == 'cuda') else None
+        # XRNERF_PREFETCH_DEPTH (default 2): the march of iteration i + 2 is issued during iteration i and starts behind i's MLP
+        # backward, so that it runs beside the table scatter and the next encode instead of beside the two fused-MLP kernels --
+        # the backward's waves own whole SIMD register files and cannot be placed on a CU that hosts a marching wave, the forward
+        # shares its SIMDs with them: 87 -> 74 us and 62 -> 47 us when the march is elsewhere (profiles/r03_k1_placement_ab.txt).
+        # With one iteration of lead that start point leaves the march unfinished when its rows are needed; with two it has a
+        # whole iteration.  1 = the previous scheme (iteration i + 1, started as soon as i is enqueued).
+        self.prefetch_depth = 2 if os.environ.get('XRNERF_PREFETCH_DEPTH', '2') != '1' else 1
+        if self.prefetch_depth == 2 and self.net._step_mark is None and device.type == 'cuda':
+            self.net._step_mark = ('xr_nerf_mlp_bwd', ops._CEvent())
         self._ev_done = [None, None]   # completion events of the last two iterations
-        self._bbufs = [None, None]
+        self._bbufs = [None, None, None]
+        self._queue = []               # [(iteration, batch)] marched ahead, in order
         self._one = None
 
     def step(self):
@@ -265,7 +274,7 @@ class Trainer:
         net.sampler.set_iter(self.iter)                                   # PassSamplerIterHook
         for g in self.opt.param_groups:
             g['lr'] = step_lr(self.base_lr, self.iter)
-        batch, self._next_batch = self._next_batch, None
+        batch = self._queue.pop(0)[1] if (self._queue and self._queue[0][0] == self.iter) else None
         if batch is None:
             batch = data.next_batch()
         n_rays = batch['rays_o'].shape[0]
@@ -311,15 +320,32 @@ class Trainer:
         return out
 
     def _on_sampled(self):
-        """Called by the sampler as soon as THIS iteration's samples exist: the march of the NEXT batch is
-        issued now, on the side stream, so that it runs beside this iteration's encode / MLP forward and
-        table scatter (it cannot co-reside with the MLP backward, whose waves own whole SIMD register files)
-        and is finished long before the next iteration needs it."""
-        net, data = self.net, self.data
-        if not self.overlap_march or not net.sampler.can_prefetch(self.iter + 1):
+        """Called by the sampler as soon as THIS iteration's samples exist (and the step is enqueued): marches of later
+        iterations are issued now, on the side stream.  Depth 2 (default): iteration i + 2, behind this step's MLP backward; the
+        iterations that scheme cannot cover (i + 1 right after a grid refresh) are marched at once, as with depth 1.
+        A march reads the rays and the occupancy bitfield only: it must not be issued across a grid refresh (iterations = 0 mod
+        update_grid_freq), and its batch must be drawn with the batch size its iteration will have (the size changes after
+        iterations = update_grid_freq - 1 mod update_grid_freq, i.e. together with the refresh)."""
+        net = self.net
+        if not self.overlap_march:
             return
+        it, f = self.iter, net.sampler.update_grid_freq
+        queued = self._queue[-1][0] if self._queue else it            # the last iteration that already has its march
+        mark = getattr(net, '_step_mark', None)
+        if self.prefetch_depth == 2 and mark is not None and mark[0] == 'xr_nerf_mlp_bwd':
+            if queued < it + 1 and net.sampler.can_prefetch(it + 1):
+                self._issue(it + 1, None)                             # not covered two iterations ago: at once
+                queued = it + 1
+            if queued == it + 1 and (it + 1) % f != 0 and (it + 2) % f != 0:
+                self._issue(it + 2, mark[1])
+        elif queued < it + 1 and net.sampler.can_prefetch(it + 1):
+            self._issue(it + 1, mark[1] if mark else None)
+
+    def _issue(self, target_iter, start_event):
+        """draw the batch of iteration `target_iter` and march it on the side stream (behind `start_event` when given)"""
+        net, data = self.net, self.data
         side = net.sampler.side_stream()
-        bufs = self._batch_buffers((self.iter + 1) & 1, data.N_rand)
+        bufs = self._batch_buffers(target_iter % 3, data.N_rand)
         if bufs is not None and hasattr(data, 'rays_rgb') and os.environ.get('XRNERF_PY_STEP') != '1':
             # the whole side-stream sequence (batch assembly, K1, K2 clip, counter copy) as one native call
             n = min(data.N_rand, data.rays_rgb.shape[0])
@@ -327,20 +353,21 @@ class Trainer:
                 data.cur_i = 0
             with torch.cuda.stream(side):
                 nb = net.sampler.prefetch_native(data.rays_rgb[data.cur_i:data.cur_i + n], n, data.batches_drawn, bufs,
-                                                 buffer_free_event=self._ev_done[1],
-                                                 start_event=net._step_mark[1] if getattr(net, '_step_mark', None) else None)
+                                                 buffer_free_event=self._ev_done[1], start_event=start_event)
             data.cur_i += n
             data.batches_drawn += 1
-            self._next_batch = nb
+            self._queue.append((target_iter, nb))
             return
         with torch.cuda.stream(side):
-            # these launches overwrite the batch / coordinate buffers last read by the PREVIOUS iteration (two
-            # persistent sets, alternating): ordered behind its completion event
+            # these launches overwrite batch / coordinate buffers last read three iterations before their own (three persistent
+            # sets, rotating): ordered behind the completion event of the previous iteration
             if self._ev_done[1] is not None:
                 side.wait_event(self._ev_done[1])
+            if start_event is not None:
+                ops.stream_wait_event(side, start_event)
             nb = data.next_batch(out=bufs) if bufs is not None else data.next_batch()
             net.sampler.prefetch(nb, buffer_free_event=self._ev_done[1])
-        self._next_batch = nb
+        self._queue.append((target_iter, nb))
 
     def _batch_buffers(self, slot, n):
         """persistent output buffers of the batch kernel for prefetched batches (None: the dataset cannot use them)"""
