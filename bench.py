@@ -346,7 +346,9 @@ def ngp_tcnn_strict_defaults(dev, n_img, steps):
         tr = Trainer(dev, n_img=n_img)
         assert tr.net.mlp.density_net.n_hidden == 5 and tr.net.mlp.color_net.n_hidden == 5
         sampler = tr.net.sampler
-        for _ in range(96):
+        # (the first ~100 iterations of this topology are erratic -- when the occupancy grid thins out varies from run to run by
+        # dozens of iterations, and with it the rays per batch by 5x -- so the window sits behind 224 of them)
+        for _ in range(224):
             tr.step()
         for _ in range((-tr.iter) % sampler.update_grid_freq + 1):
             tr.step()
