@@ -295,3 +295,28 @@ def test_table_update_inside_the_scatter_equals_scatter_plus_optimiser_launch(de
     for a, b in zip(out[0][:-1], out[1][:-1]):
         assert torch.equal(a, b)
     assert out[0][-1] == out[1][-1] == 20
+
+
+def test_march_two_iterations_ahead_leaves_the_trajectory_alone(dev, monkeypatch):
+    """Prefetch depth 2 (the march of iteration i + 2 issued during iteration i, started behind its MLP backward; three rotating buffer
+    sets) against depth 1 over 40 iterations -- two grid refreshes, two batch-size updates, the iterations that cannot be marched
+    two ahead in between: the same batches, the same RNG call order, bit-identical parameters and sampler state."""
+    from xrnerf_amd.train import Trainer
+    out = []
+    for depth in ('2', '1'):
+        monkeypatch.setenv('XRNERF_PREFETCH_DEPTH', depth)
+        tr = Trainer(dev, n_img=3, H=128, W=128, seed=5)
+        assert tr.prefetch_depth == int(depth)
+        hist = []
+        for _ in range(40):
+            tr.step()
+            hist.append((tr.net.sampler.n_rays_per_batch, tr.net.sampler.k1_calls, tr.data.batches_drawn if hasattr(tr.data, 'batches_drawn') else 0))
+        torch.cuda.synchronize()
+        out.append(([p.detach().clone() for p in tr.net.parameters()], tr.net.sampler.density_grid.clone(),
+                    tr.net.sampler.density_grid_bitfield.clone(), hist))
+    (pa, ga, ba, ha), (pb, gb, bb, hb) = out
+    assert [h[0] for h in ha] == [h[0] for h in hb]                  # rays per batch, iteration by iteration
+    assert ha[-1][1] == hb[-1][1] + 1                                 # one more march in flight, nothing else
+    for a, b in zip(pa, pb):
+        assert torch.equal(a, b)
+    assert torch.equal(ga, gb) and torch.equal(ba, bb)

@@ -246,11 +246,11 @@ class Trainer:
         self.lazy_log = True
         # run K1 of the next batch on a side stream under this step's backward (XRNERF_OVERLAP_MARCH=0: serial)
         self.overlap_march = os.environ.get('XRNERF_OVERLAP_MARCH', '1') != '0'
-        # where in the step the next batch's side-stream march may start: behind the named entry point of the fused step
-        # (XRNERF_PREFETCH_AFTER; default none = as soon as the step is enqueued).  Measured (profiles/r03_prefetch_start_point.txt,
-        # ms/step): none 0.548, behind the encode 0.554, behind the fused-MLP forward 0.552, behind the compositor 0.582, behind
-        # the MLP backward 0.620 -- the 200-us march beside the forward costs that kernel ~10 us, but started any later it is not
-        # finished when the next iteration's encode needs its rows
+        # where in the step the side-stream march may start: behind the named entry point of the fused step (XRNERF_PREFETCH_AFTER;
+        # 'none' = as soon as the step is enqueued).  Setting it by hand selects the one-iteration-ahead scheme with that start
+        # point; at depth 1 every later start point lost (profiles/r03_prefetch_start_point.txt, ms/step at that time: none 0.548,
+        # behind the encode 0.554, the fused-MLP forward 0.552, the compositor 0.582, the MLP backward 0.620 -- started late the
+        # march is not finished when the next iteration's encode needs its rows).  Left unset, depth 2 below picks its own.
         after = os.environ.get('XRNERF_PREFETCH_AFTER', 'none')
         if after not in ('none', 'xr_hashgrid_fwd', 'xr_nerf_mlp_fwd', 'xr_composite_train', 'xr_live_rows', 'xr_nerf_mlp_bwd'):
             raise ValueError('XRNERF_PREFETCH_AFTER: unknown entry point %r' % after)
