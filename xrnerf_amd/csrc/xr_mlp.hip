@@ -236,6 +236,180 @@ __device__ __forceinline__ void dw_accumulate(f32x16 (&acc)[TO][TI], const f32x1
     dw_stage<TO, TI>(g, h, stage, col, hi);
     dw_mfma<TO, TI>(acc, stage, col, hi);
 }
+// ---- 16-bit operand arrangements in LDS (shared by the fp16 kernels and the bf16-split ones below)
+__host__ __device__ constexpr int hrow(int t, int hi, int e) { return 32 * (t >> 1) + 16 * (t & 1) + 8 * (e >> 2) + (e & 3) + 4 * hi; }
+__host__ __device__ constexpr int h_rs(int k_dim) { return 2 * (k_dim / 16) * 8 + 8; }       // halves per row, 16-B pad
+
+// layer l of a (1 | 2)-hidden network in the two LDS arrangements (halves)
+template <int NH>
+struct HShape {
+    using S = NetShape<NH>;
+    __host__ __device__ static constexpr int f_off(int l) { int o = 0; for (int i = 0; i < l; ++i) o += S::out_rows_lds(i) * h_rs(S::in_dim(i)); return o; }
+    __host__ __device__ static constexpr int b_off(int l) { int o = 0; for (int i = 0; i < l; ++i) o += S::in_dim(i) * h_rs(S::out_rows_lds(i)); return o; }
+    static constexpr int f_halves = f_off(NH + 1);
+    static constexpr int b_halves = b_off(NH + 1);
+};
+
+// global fp32 [out][in] -> LDS fp16, forward arrangement (and the transposed one when `wb` is given).  The loop runs over the
+// SOURCE elements (coalesced global reads); the k-slot of neuron m is the inverse of hrow: e = m[1:0] | m[3] << 2,
+// hi = m[2], t = m >> 4.
+__device__ __forceinline__ int hslot(int m, int ns) {           // offset of neuron m inside a [hi][t][8] row of ns steps
+    const int e = (m & 3) | (((m >> 3) & 1) << 2), hi = (m >> 2) & 1, t = m >> 4;
+    return (hi * ns + t) * 8 + e;
+}
+// dW on the bf16 matrix cores (XR_MLP_BWD_DW=b2, review item 3 of round 2): the same staging tile, each operand read as 8
+// consecutive samples of one neuron and split in registers into two bf16 parts x = xh + xl (xh = bf16(x) round-to-nearest,
+// xl = bf16(x - xh), the difference exact in fp32).  Three v_mfma_f32_32x32x16_bf16 per 16 samples keep
+// gh*hh + gh*hl + gl*hh (every bf16 x bf16 product exact, fp32 accumulate, small terms first); the dropped gl*hl term and the
+// rounding of the low parts are below 2^-16 of |g||h| per term -- inside the 1e-3 * max bar the gradients are tested to
+// (tests/test_gpu_tcnn.py::test_nerf_mlp_bwd*).  6 matrix instructions of 8 passes instead of 16 of 16 per output tile.
+typedef __bf16 bw8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split2x8(const float* __restrict__ p, bw8& h, bw8& l) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float v = p[e];
+        const __bf16 hh = (__bf16)v;
+        h[e] = hh;
+        l[e] = (__bf16)(v - (float)hh);
+    }
+}
+template <int TO, int TI>
+__device__ __forceinline__ void dw_mfma_b2(f32x16 (&acc)[TO][TI], const float* __restrict__ stage, int col, int hi) {
+    const float* sg = stage + col * ST33 + 8 * hi;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        bw8 ah[TO], al[TO], bh[TI], bl[TI];
+#pragma unroll
+        for (int to = 0; to < TO; ++to) split2x8(sg + (to * 32) * ST33 + 16 * t, ah[to], al[to]);
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) split2x8(sg + ((TO + ti) * 32) * ST33 + 16 * t, bh[ti], bl[ti]);
+#pragma unroll
+        for (int to = 0; to < TO; ++to)
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti) {
+                acc[to][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[to], bh[ti], acc[to][ti], 0, 0, 0);
+                acc[to][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[to], bl[ti], acc[to][ti], 0, 0, 0);
+                acc[to][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[to], bh[ti], acc[to][ti], 0, 0, 0);
+            }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+template <bool B2, int TO, int TI>
+__device__ __forceinline__ void dw_product(f32x16 (&acc)[TO][TI], const float* __restrict__ stage, int col, int hi) {
+    if constexpr (B2) dw_mfma_b2<TO, TI>(acc, stage, col, hi);
+    else dw_mfma<TO, TI>(acc, stage, col, hi);
+}
+// one H tile at a time (the c1 layer under the 3-tile staging area of the bf16 dX mode): acc[.][TIX] += G (tiles 0..TO-1 of the
+// staging area) x H (tile TO)
+template <int TO, int TIA, int TIX>
+__device__ __forceinline__ void dw_mfma_b2_col(f32x16 (&acc)[TO][TIA], const float* __restrict__ stage, int col, int hi) {
+    const float* sg = stage + col * ST33 + 8 * hi;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        bw8 ah[TO], al[TO], bh, bl;
+#pragma unroll
+        for (int to = 0; to < TO; ++to) split2x8(sg + (to * 32) * ST33 + 16 * t, ah[to], al[to]);
+        split2x8(sg + (TO * 32) * ST33 + 16 * t, bh, bl);
+#pragma unroll
+        for (int to = 0; to < TO; ++to) {
+            acc[to][TIX] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[to], bh, acc[to][TIX], 0, 0, 0);
+            acc[to][TIX] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[to], bl, acc[to][TIX], 0, 0, 0);
+            acc[to][TIX] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[to], bh, acc[to][TIX], 0, 0, 0);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+// staging-area tile `slot` <- one tile (transposing write, as dw_stage)
+__device__ __forceinline__ void dw_stage_one(const f32x16& h, int slot, float* __restrict__ stage, int col, int hi) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) stage[(slot * 32 + drow(r) + 4 * hi) * ST33 + col] = h[r];
+    __builtin_amdgcn_wave_barrier();
+}
+
+// dX chain on the bf16 matrix cores (XR_MLP_BWD_DW=b2x): W^T sits in LDS pre-split into two bf16 parts, each in the
+// [in neuron][hi][K-step][8] arrangement of the fp16 kernels; a gradient tile goes from the accumulator layout to the B
+// operands of its two K-steps by a register-local 2-way split (the k-slot permutation is the accumulator layout's own row
+// order, so nothing is transposed).  Per K-step and output tile: two 16-B operand reads and three MFMAs (gl*wh, gh*wl, gh*wh).
+struct B2Tile { bw8 p[2][2]; };                                  // [part][K-step]
+__device__ __forceinline__ B2Tile to_b2(const f32x16& t) {
+    B2Tile r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 h0 = (__bf16)t[e], h1 = (__bf16)t[8 + e];
+        r.p[0][0][e] = h0; r.p[1][0][e] = (__bf16)(t[e] - (float)h0);
+        r.p[0][1][e] = h1; r.p[1][1][e] = (__bf16)(t[8 + e] - (float)h1);
+    }
+    return r;
+}
+template <int NH, int L>
+__device__ __forceinline__ void store_layer_bt2(const float (&v)[NetShape<NH>::out_rows_lds(L) * NetShape<NH>::in_dim(L) / MLP_THREADS],
+                                                __bf16* __restrict__ wb, int ps, bool first_layer_rot) {
+    using S = NetShape<NH>;
+    using H = HShape<NH>;
+    constexpr int K = S::in_dim(L), rows = S::out_dim(L), prow = S::out_rows_lds(L), nso = prow / 16, rsb = h_rs(prow);
+    __bf16* dstb = wb + H::b_off(L);
+#pragma unroll
+    for (int i = 0; i < prow * K / MLP_THREADS; ++i) {
+        const int x = threadIdx.x + i * MLP_THREADS, o = x / K, c = x % K;        // global [o][c]
+        const int m = (L == 0 && first_layer_rot) ? ((c + 1) & 31) : c;             // LDS slot of global column c
+        const float w = o < rows ? v[i] : 0.f;
+        const __bf16 h = (__bf16)w;
+        __bf16* d = dstb + m * rsb + hslot(o, nso);
+        d[0] = h; d[ps] = (__bf16)(w - (float)h);
+    }
+}
+template <int NH>
+__device__ inline void load_weights_bt2(__bf16* __restrict__ wb, int ps, const float* __restrict__ w, bool first_layer_rot) {
+    using S = NetShape<NH>;
+    static_assert(NH == 1 || NH == 2, "built for 1 or 2 hidden layers");
+    float v0[S::out_rows_lds(0) * S::in_dim(0) / MLP_THREADS], v1[S::out_rows_lds(1) * S::in_dim(1) / MLP_THREADS];
+    float v2[NH >= 2 ? S::out_rows_lds(NH >= 2 ? 2 : 0) * S::in_dim(NH >= 2 ? 2 : 0) / MLP_THREADS : 1];
+    fetch_layer<NH, 0>(v0, w, false);              // source order; the slot rotation is applied on store
+    fetch_layer<NH, 1>(v1, w, false);
+    if constexpr (NH >= 2) fetch_layer<NH, 2>(v2, w, false);
+    store_layer_bt2<NH, 0>(v0, wb, ps, first_layer_rot);
+    store_layer_bt2<NH, 1>(v1, wb, ps, false);
+    if constexpr (NH >= 2) store_layer_bt2<NH, 2>(v2, wb, ps, false);
+}
+// gin[TI] = W^T . g[TO]; only the first NSTEPS K-steps of g can be non-zero
+template <int TO, int TI, int NSTEPS = 2 * TO>
+__device__ __forceinline__ void layer_bwd_b2(const __bf16* __restrict__ wb, int ps, const B2Tile (&g)[TO], f32x16 (&gin)[TI], int col, int hi) {
+    constexpr int NSO = 2 * TO, RSB = 2 * NSO * 8 + 8;
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gin[ti][r] = 0.f;
+    const __bf16* wl = wb + col * RSB + hi * NSO * 8;
+#ifndef B2X_PF
+#define B2X_PF 1
+#endif
+    bw8 a[B2X_PF + 1][TI][2];
+    auto load = [&](int t, bw8 (&d)[TI][2]) {
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) {
+            const __bf16* p = wl + ti * 32 * RSB + t * 8;
+            d[ti][0] = *reinterpret_cast<const bw8*>(p);
+            d[ti][1] = *reinterpret_cast<const bw8*>(p + ps);
+        }
+    };
+    if (B2X_PF) load(0, a[0]);
+#pragma unroll
+    for (int t = 0; t < NSTEPS; ++t) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (B2X_PF) { if (t + 1 < NSTEPS) load(t + 1, a[(t + 1) & 1]); }
+        else load(t, a[0]);
+        const B2Tile& x = g[t >> 1];
+        const int k = t & 1;
+        const int cur = B2X_PF ? (t & 1) : 0;
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) {
+            gin[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][ti][1], x.p[0][k], gin[ti], 0, 0, 0);
+            gin[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][ti][0], x.p[1][k], gin[ti], 0, 0, 0);
+            gin[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][ti][0], x.p[0][k], gin[ti], 0, 0, 0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
 // block-level reduction target: LDS buffer in the GLOBAL (compact, [out][in]) parameter layout.
 // The four waves of a workgroup take turns (caller: `for w: if (wave == w) dw_flush(.., first = (w == 0)); barrier`):
 // the first one stores, the others read-add-write with plain LDS accesses.  NOT ds_add_f32: measured on MI355X
@@ -279,9 +453,21 @@ __device__ __forceinline__ void sh4_eval(float x, float y, float z, float* o) {
 }
 
 // ---- per-tile pieces ---------------------------------------------------------------------------
+// Row r of the tile sits at enc_t + (drow(r) + 4 hi) * ld + s.  Written as a wave-uniform row base (scalar registers) plus ONE
+// 32-bit per-lane byte offset, so that the 16 accesses are `global_load_dword v, v_off, s[base]`: as sixteen per-lane 64-bit
+// addresses the compiler hoists 32 VGPRs of them out of the tile loop, and in the one-wave-per-SIMD backward those are the
+// registers that end up in scratch (11 serialized reloads per tile, ~+7 us per launch).  Hosts check (5 ld) * 4 < 2^32.
 __device__ __forceinline__ void load_enc_tile(const float* __restrict__ enc_t, uint32_t ld, uint32_t s, f32x16& xe, int hi) {
+    const uint32_t voff = (4u * (uint32_t)hi * ld + s) * 4u;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) xe[r] = enc_t[(size_t)(drow(r) + 4 * hi) * ld + s];
+    for (int r = 0; r < 16; ++r)
+        xe[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(enc_t + (size_t)drow(r) * ld) + voff);
+}
+__device__ __forceinline__ void store_enc_tile(float* __restrict__ denc_t, uint32_t ld, uint32_t s, const f32x16& g, int hi, float scale = 1.0f) {
+    const uint32_t voff = (4u * (uint32_t)hi * ld + s) * 4u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        *reinterpret_cast<float*>(reinterpret_cast<char*>(denc_t + (size_t)drow(r) * ld) + voff) = scale == 1.0f ? g[r] : g[r] * scale;
 }
 // color-net input tile in slot space from the density output tile + SH of the view direction
 __device__ __forceinline__ void build_color_in(const f32x16& dout, const float* __restrict__ dirs, uint32_t dir_stride,
@@ -436,7 +622,8 @@ __global__ __launch_bounds__(LIVE_THREADS) void k_live_fill(const float4* __rest
 // ------------------------------------------------------------------ backward kernel
 // Specialised for the reference topology family NHD = 1, NHC = 2 (density 32->64->16,
 // color 32->64->64->16): every activation and all 12 dW accumulator tiles stay in registers.
-template <bool LIVE>
+// MODE 0: fp32 MFMA throughout; 1: dW products on the bf16 matrix cores (2-way split); 2: the dX chain as well
+template <bool LIVE, int MODE>
 __global__ __launch_bounds__(MLP_THREADS, 1) void k_nerf_mlp_bwd_1_2(
     const float* __restrict__ enc_t, uint32_t ld, const float* __restrict__ dirs, uint32_t dir_stride, uint32_t n,
     const uint32_t* __restrict__ n_dev, const float* __restrict__ w_density, const float* __restrict__ w_color,
@@ -447,13 +634,24 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void k_nerf_mlp_bwd_1_2(
     using SD = NetShape<1>;
     using SC = NetShape<2>;
     constexpr int GW = SD::glb_floats + SC::glb_floats;                // 3072 + 7168
-    constexpr int STAGE = 4 * 32 * ST33;                               // floats per wave
+    constexpr bool DWB = MODE >= 1, DXB = MODE >= 2;
+    using HD = HShape<1>;
+    using HC = HShape<2>;
+    constexpr int PD = HD::b_halves, PC = HC::b_halves;                // halves per part of W^T
+    constexpr int STAGE = (DXB ? 3 : 4) * 32 * ST33;                   // floats per wave
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* wd = lds;
     float* wc = wd + SD::lds_floats;
-    float* stage_all = wc + SC::lds_floats;                            // MLP_WAVES * STAGE floats (>= GW)
+    __bf16* wbd = reinterpret_cast<__bf16*>(wc + SC::lds_floats);      // DXB: W^T of both networks, two bf16 parts each
+    __bf16* wbc = wbd + 2 * PD;
+    float* stage_all = DXB ? reinterpret_cast<float*>(wbc + 2 * PC) : wc + SC::lds_floats;   // MLP_WAVES * STAGE floats
+    static_assert(PD % 8 == 0 && PC % 8 == 0 && (SD::lds_floats + SC::lds_floats) % 4 == 0, "16-byte alignment of the operand reads");
     load_weights<1>(wd, w_density, false);
     load_weights<2>(wc, w_color, true);
+    if constexpr (DXB) {
+        load_weights_bt2<1>(wbd, PD, w_density, false);
+        load_weights_bt2<2>(wbc, PC, w_color, true);
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, hi = lane >> 5;
     float* stage = stage_all + wave * STAGE;
@@ -494,34 +692,55 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void k_nerf_mlp_bwd_1_2(
         g1[0][0] = dr.x; g1[0][1] = dr.y; g1[0][2] = dr.z;             // hi==1 lanes hold zeros
         // color output layer
         dw_stage<1, 2>(g1, hc2, stage, col, hi);
-        layer_bwd<1, 2, false, 3>(wc + SC::lds_off(2), g1, g2, col, hi);   // rows 0..2 (rgb) only
-        dw_mfma<1, 2>(a_c2, stage, col, hi);
+        if constexpr (DXB) { const B2Tile gb[1] = {to_b2(g1[0])}; layer_bwd_b2<1, 2, 1>(wbc + HC::b_off(2), PC, gb, g2, col, hi); }
+        else layer_bwd<1, 2, false, 3>(wc + SC::lds_off(2), g1, g2, col, hi);   // rows 0..2 (rgb) only
+        dw_product<DWB, 1, 2>(a_c2, stage, col, hi);
         relu_mask(g2[0], hc2[0]); relu_mask(g2[1], hc2[1]);
         // color hidden layer 2
-        dw_stage<2, 2>(g2, hc1, stage, col, hi);
-        layer_bwd<2, 2, false>(wc + SC::lds_off(1), g2, g2b, col, hi);
-        dw_mfma<2, 2>(a_c1, stage, col, hi);
+        if constexpr (DXB) {
+            // 3-tile staging area: both G tiles and one H tile at a time
+            const f32x16 h0[1] = {hc1[0]};
+            dw_stage<2, 1>(g2, h0, stage, col, hi);
+            const B2Tile gb[2] = {to_b2(g2[0]), to_b2(g2[1])};
+            layer_bwd_b2<2, 2>(wbc + HC::b_off(1), PC, gb, g2b, col, hi);
+            dw_mfma_b2_col<2, 2, 0>(a_c1, stage, col, hi);
+            dw_stage_one(hc1[1], 2, stage, col, hi);
+            dw_mfma_b2_col<2, 2, 1>(a_c1, stage, col, hi);
+        } else {
+            dw_stage<2, 2>(g2, hc1, stage, col, hi);
+            layer_bwd<2, 2, false>(wc + SC::lds_off(1), g2, g2b, col, hi);
+            dw_product<DWB, 2, 2>(a_c1, stage, col, hi);
+        }
         relu_mask(g2b[0], hc1[0]); relu_mask(g2b[1], hc1[1]);
         // color input layer
         dw_stage<2, 1>(g2b, cin, stage, col, hi);
-        layer_bwd<2, 1, false>(wc + SC::lds_off(0), g2b, g1, col, hi);       // g1 = dL/d(color input slots)
-        dw_mfma<2, 1>(a_c0, stage, col, hi);
+        if constexpr (DXB) { const B2Tile gb[2] = {to_b2(g2b[0]), to_b2(g2b[1])}; layer_bwd_b2<2, 1>(wbc + HC::b_off(0), PC, gb, g1, col, hi); }
+        else layer_bwd<2, 1, false>(wc + SC::lds_off(0), g2b, g1, col, hi);       // g1 = dL/d(color input slots)
+        dw_product<DWB, 2, 1>(a_c0, stage, col, hi);
         // slots 1..15 are density-output rows 1..15; row 0 takes dL/d(sigma raw); rows >= 16 are padding
 #pragma unroll
         for (int r = 8; r < 16; ++r) g1[0][r] = 0.f;
         if (hi == 0) g1[0][0] = dr.w;
         // density output layer
+        if constexpr (DXB) {
+            // the encoded features are not kept across the tile (16 registers this kernel does not have: they went to scratch,
+            // nine serialized reloads per tile); they are fetched again here, two layers before their use -- L2 hits
+            uint32_t sc2 = sc;
+            asm volatile("" : "+v"(sc2));                                  // a second load, not the first one kept alive
+            load_enc_tile(enc_t, ld, sc2, xe[0], hi);
+        }
         dw_stage<1, 2>(g1, hd, stage, col, hi);
-        layer_bwd<1, 2, false, 8>(wd + SD::lds_off(1), g1, g2, col, hi);   // 16 real output neurons
-        dw_mfma<1, 2>(a_d1, stage, col, hi);
+        if constexpr (DXB) { const B2Tile gb[1] = {to_b2(g1[0])}; layer_bwd_b2<1, 2, 1>(wbd + HD::b_off(1), PD, gb, g2, col, hi); }
+        else layer_bwd<1, 2, false, 8>(wd + SD::lds_off(1), g1, g2, col, hi);   // 16 real output neurons
+        dw_product<DWB, 1, 2>(a_d1, stage, col, hi);
         relu_mask(g2[0], hd[0]); relu_mask(g2[1], hd[1]);
         // density input layer
         dw_stage<2, 1>(g2, xe, stage, col, hi);
-        layer_bwd<2, 1, false>(wd + SD::lds_off(0), g2, g1, col, hi);        // g1 = dL/d(encoded features)
-        dw_mfma<2, 1>(a_d0, stage, col, hi);
+        if constexpr (DXB) { const B2Tile gb[2] = {to_b2(g2[0]), to_b2(g2[1])}; layer_bwd_b2<2, 1>(wbd + HD::b_off(0), PD, gb, g1, col, hi); }
+        else layer_bwd<2, 1, false>(wd + SD::lds_off(0), g2, g1, col, hi);        // g1 = dL/d(encoded features)
+        dw_product<DWB, 2, 1>(a_d0, stage, col, hi);
         if (live) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) denc_t[(size_t)(drow(r) + 4 * hi) * ld + s] = g1[0][r];
+            store_enc_tile(denc_t, ld, s, g1[0], hi);
         }
     }
     // ---- block reduction of dW through LDS (compact global layout), then one partial per block
@@ -529,7 +748,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void k_nerf_mlp_bwd_1_2(
     // Waves 0 / 1 store into copy A / B side by side, waves 2 / 3 add, the write-out sums the copies: two turns instead of
     // four (fixed order (w0 + w2) + (w1 + w3)).
     __syncthreads();
-    static_assert(2 * GW <= SD::lds_floats + SC::lds_floats + MLP_WAVES * STAGE, "two reduction copies must fit the launch's LDS");
+    static_assert(2 * GW <= SD::lds_floats + SC::lds_floats + (DXB ? PD + PC : 0) + MLP_WAVES * STAGE, "two reduction copies must fit the launch's LDS");
     float* redA = lds;
     for (int ph = 0; ph < 2; ++ph) {
         if ((wave >> 1) == ph) {
@@ -719,26 +938,6 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 #define H16_LOSS_SCALE 128.0f
 
-__host__ __device__ constexpr int hrow(int t, int hi, int e) { return 32 * (t >> 1) + 16 * (t & 1) + 8 * (e >> 2) + (e & 3) + 4 * hi; }
-__host__ __device__ constexpr int h_rs(int k_dim) { return 2 * (k_dim / 16) * 8 + 8; }       // halves per row, 16-B pad
-
-// layer l of a (1 | 2)-hidden network in the two LDS arrangements (halves)
-template <int NH>
-struct HShape {
-    using S = NetShape<NH>;
-    __host__ __device__ static constexpr int f_off(int l) { int o = 0; for (int i = 0; i < l; ++i) o += S::out_rows_lds(i) * h_rs(S::in_dim(i)); return o; }
-    __host__ __device__ static constexpr int b_off(int l) { int o = 0; for (int i = 0; i < l; ++i) o += S::in_dim(i) * h_rs(S::out_rows_lds(i)); return o; }
-    static constexpr int f_halves = f_off(NH + 1);
-    static constexpr int b_halves = b_off(NH + 1);
-};
-
-// global fp32 [out][in] -> LDS fp16, forward arrangement (and the transposed one when `wb` is given).  The loop runs over the
-// SOURCE elements (coalesced global reads); the k-slot of neuron m is the inverse of hrow: e = m[1:0] | m[3] << 2,
-// hi = m[2], t = m >> 4.
-__device__ __forceinline__ int hslot(int m, int ns) {           // offset of neuron m inside a [hi][t][8] row of ns steps
-    const int e = (m & 3) | (((m >> 3) & 1) << 2), hi = (m >> 2) & 1, t = m >> 4;
-    return (hi * ns + t) * 8 + e;
-}
 template <int NH, int L>
 __device__ __forceinline__ void store_layer_h(const float (&v)[NetShape<NH>::out_rows_lds(L) * NetShape<NH>::in_dim(L) / MLP_THREADS],
                                               _Float16* __restrict__ wf, _Float16* __restrict__ wb, bool first_layer_rot) {
@@ -1066,8 +1265,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void k_nerf_mlp_bwd_h(
         layer_bwd_h<2, 1, 4, HSB>(wdb + HD::b_off(0), gh2, gi, col, hi);             // dL/d(encoded features) x loss scale
         dw_mfma_h<2, 1>(a_d0, stage, col, hi);
         if (live) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) denc_t[(size_t)(drow(r) + 4 * hi) * ld + s] = gi[0][r] * (1.0f / H16_LOSS_SCALE);
+            store_enc_tile(denc_t, ld, s, gi[0], hi, 1.0f / H16_LOSS_SCALE);
         }
     }
     constexpr float inv = 1.0f / H16_LOSS_SCALE;
@@ -1444,13 +1642,17 @@ extern "C" int xr_nerf_mlp_bwd(const float* enc_t, uint32_t ld, const float* dir
     }
     XR_REQUIRE(workspace && workspace_bytes >= xr_nerf_mlp_bwd_workspace_bytes(n), "workspace too small");
     constexpr int GW = NetShape<1>::glb_floats + NetShape<2>::glb_floats;
-    const size_t lds = (NetShape<1>::lds_floats + NetShape<2>::lds_floats + MLP_WAVES * 4 * 32 * ST33) * sizeof(float);
-    static_assert(MLP_WAVES * 4 * 32 * ST33 >= GW, "stage area doubles as the dW reduction buffer");
+    size_t lds = (NetShape<1>::lds_floats + NetShape<2>::lds_floats + MLP_WAVES * 4 * 32 * ST33) * sizeof(float);
     const uint32_t grid = bwd_grid(n);
     XR_REQUIRE(!live_rows == !n_live, "live_rows and n_live come together");
     const uint32_t* rows = live_rows;                    // the caller's list (xr_live_rows), else the backward's own
     if (!rows && live_rows_enabled()) { const int rc = build_live_rows(draw, n, n_dev, denc_t, ld, workspace, stream, &rows, &n_live); if (rc != XR_OK) return rc; }
-    auto kern = rows ? k_nerf_mlp_bwd_1_2<true> : k_nerf_mlp_bwd_1_2<false>;
+    // XR_MLP_BWD_DW: f32 = fp32 MFMA throughout, b2 = dW products on the bf16 matrix cores, b2x (default) = the dX chain too
+    static const int mode = [] { const char* e = getenv("XR_MLP_BWD_DW"); return !e ? 2 : strcmp(e, "f32") == 0 ? 0 : strcmp(e, "b2") == 0 ? 1 : 2; }();
+    auto kern = rows ? (mode == 2 ? k_nerf_mlp_bwd_1_2<true, 2> : mode == 1 ? k_nerf_mlp_bwd_1_2<true, 1> : k_nerf_mlp_bwd_1_2<true, 0>)
+                     : (mode == 2 ? k_nerf_mlp_bwd_1_2<false, 2> : mode == 1 ? k_nerf_mlp_bwd_1_2<false, 1> : k_nerf_mlp_bwd_1_2<false, 0>);
+    if (mode == 2) lds = (NetShape<1>::lds_floats + NetShape<2>::lds_floats + MLP_WAVES * 3 * 32 * ST33) * sizeof(float)
+                         + (size_t)2 * (HShape<1>::b_halves + HShape<2>::b_halves) * sizeof(__bf16);
     if (mlp_set_lds((const void*)kern, lds) != XR_OK) { xr_set_error("hipFuncSetAttribute failed"); return XR_EHIP; }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n,
                        n_dev, w_density, w_color, pad_value, (const float4*)draw, denc_t, (float*)workspace, rows, n_live);
