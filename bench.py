@@ -753,6 +753,20 @@ def main():
                                  'bf16 MFMA peak -- the matrix cores execute 6x these flops (issued_frac)')
             out['issued_frac'] = 6.0 * achieved / peak
             out['frac_of_fp32_mfma_peak'] = achieved / MFMA_F32_PEAK_TFLOPS
+        if name == 'xr_nerf_mlp_bwd' and ops.precision() == 'f32' and bound == 'mfma':
+            # mixed arithmetic (XR_MLP_BWD_DW, default b2x): the forward recompute (18432 of the 59392 flop / sample) on the fp32
+            # MFMA, the dW products and the dX chain on the bf16 matrix cores with 2-way split operands (3 matrix products per
+            # algorithmic one).  The peak quoted is the rate at which the matrix cores could finish exactly this mix.
+            arith = os.environ.get('XR_MLP_BWD_DW', 'b2x')
+            f_fwd, f_dx, f_dw = 18432.0, 20480.0, 20480.0
+            on_f32 = {'f32': f_fwd + f_dx + f_dw, 'b2': f_fwd + f_dx, 'b2x': f_fwd, 'b2f': 0.0}.get(arith, f_fwd)
+            on_b16 = (f_fwd + f_dx + f_dw) - on_f32
+            t_unit = on_f32 / (MFMA_F32_PEAK_TFLOPS * 1e12) + 3.0 * on_b16 / (MFMA_PEAK['f16'] * 1e12)
+            peak = (on_f32 + on_b16) / t_unit / 1e12
+            out['peak'], out['frac'] = peak, achieved / peak
+            out['arithmetic'] = ('XR_MLP_BWD_DW=%s: %.0f flop/sample on the fp32 MFMA (157.3 TFLOP/s), %.0f on the bf16 matrix cores as 3 products '
+                                 'each (2-way operand split, 2500 TFLOP/s dense); peak = the rate of this mix' % (arith, on_f32, on_b16))
+            out['frac_of_fp32_mfma_peak'] = achieved / MFMA_F32_PEAK_TFLOPS
         if halves:
             out['note'] = 'entry point called twice per step (levels 8..15, then 0..7, each handed to the all-reduce): figures are per step'
         if fused_adam:

@@ -107,6 +107,17 @@ def test_deeper_topologies_on_the_host(O, edev):
     T.test_deeper_topologies_run_layer_by_layer(O, edev, 3, 4, 65, None)
 
 
+def test_mlp_backward_arithmetic_modes_on_the_host(O, edev, monkeypatch):
+    """the bf16-split products of the backward (dW, dX chain, and the opt-in split recompute) on the host build"""
+    import test_gpu_tcnn as T
+    for arith in ('f32', 'b2'):
+        monkeypatch.setenv('XR_MLP_BWD_DW', arith)
+        T.test_nerf_mlp_bwd(O, edev, 100)
+        T.test_nerf_mlp_bwd_live_rows(O, edev, 100, None, 'f32')
+    monkeypatch.delenv('XR_MLP_BWD_DW')
+    T.test_nerf_mlp_bwd_split_recompute_differs_by_relu_kinks_only(edev, 1200, monkeypatch)
+
+
 def test_mlp_backward_on_live_rows_on_the_host(O, edev):
     """the live-row compaction in front of the backward (both precisions), ragged / clipped / single-live-row launches"""
     import test_gpu_tcnn as T

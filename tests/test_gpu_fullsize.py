@@ -153,7 +153,9 @@ def test_mlp_backward_properties_at_2p18(O, dev, frame):
     dyd = np.zeros((4096, 16), np.float32); dyd[:, 0] = dr[:, 3]; dyd[:, 1:] = dcin[:, :15]
     _, denc = O.mlp_bwd(wdn, en, acts, dyd, 32, 64, 1, 16)
     err = np.abs(e1[:, idx.to(dev)].t().cpu().numpy() - denc).max(1)
-    assert (err > 1e-4).sum() <= 2 and np.median(err) <= 1e-6
+    # the dX chain runs on the bf16 matrix cores with 2-way split operands (2^-16 relative per product, xr_mlp.hip
+    # layer_bwd_b2): median 2e-6 here against 4e-7 with every product on the fp32 MFMA (XR_MLP_BWD_DW=f32)
+    assert (err > 1e-4).sum() <= 2 and np.median(err) <= 5e-6 * max(1.0, float(np.abs(denc).max())), (np.median(err), np.abs(denc).max())
 
 
 def test_raymarch_cuda_shim_like_the_reference_wrappers(O, lego, dev):

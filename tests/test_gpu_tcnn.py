@@ -187,6 +187,47 @@ def test_nerf_mlp_bwd(O, dev, n):
         assert err <= 1e-3 * max(1.0, np.abs(ref).max()), (name, err, np.abs(ref).max())
 
 
+@pytest.mark.parametrize('arith', ['f32', 'b2', 'b2x'])
+def test_nerf_mlp_bwd_arithmetic_modes(O, dev, arith, monkeypatch):
+    """XR_MLP_BWD_DW: the backward with every product on the fp32 MFMA, with the dW products on the bf16 matrix cores (2-way
+    operand split), and (the default) with the dX chain there too -- each against the oracle at the same 1e-3 * max bar"""
+    monkeypatch.setenv('XR_MLP_BWD_DW', arith)
+    test_nerf_mlp_bwd(O, dev, 5000)
+    test_nerf_mlp_bwd_live_rows(O, dev, 5000, 4100, 'f32')
+    test_nerf_mlp_bwd_live_rows(O, dev, 31, None, 'f32')
+
+
+@pytest.mark.parametrize('n', [3000])
+def test_nerf_mlp_bwd_split_recompute_differs_by_relu_kinks_only(dev, n, monkeypatch):
+    """XR_MLP_BWD_DW=b2f also recomputes the forward with 2-way split operands (2^-16 relative).  A hidden unit whose
+    pre-activation is that close to zero can land on the other side of its ReLU than in the fp32 recompute; apart from those
+    unit-samples the two backward passes agree closely: per sample the encoding gradient is either within 1e-3 of its scale or
+    the sample is one of a few with a flipped unit, and the weight gradients agree in the 2-norm."""
+    from xrnerf_amd import ops, synthetic as S
+    rng = np.random.default_rng(n)
+    wd, wc = nets(S)
+    enc_t = T(rng.normal(0, 0.5, (32, n)).astype(np.float32), dev)
+    dirs = T(rng.uniform(0, 1, (n, 3)).astype(np.float32), dev)
+    draw = T(rng.normal(0, 1, (n, 4)).astype(np.float32), dev)
+    out = {}
+    for arith in ('b2x', 'b2f'):
+        monkeypatch.setenv('XR_MLP_BWD_DW', arith)
+        g_wd = torch.zeros(wd.size, dtype=torch.float32, device=dev_of(enc_t))
+        g_wc = torch.zeros(wc.size, dtype=torch.float32, device=dev_of(enc_t))
+        denc_t = ops.nerf_mlp_bwd(enc_t, dirs, n, T(wd, dev), T(wc, dev), 1, 2, draw, g_wd, g_wc)
+        out[arith] = (denc_t[:, :n].cpu().numpy().astype(np.float64), g_wd.cpu().numpy().astype(np.float64), g_wc.cpu().numpy().astype(np.float64))
+    (da, wda, wca), (db, wdb, wcb) = out['b2x'], out['b2f']
+    row_err = np.abs(da - db).max(0) / max(np.abs(da).max(0).mean(), 1e-30)
+    assert np.median(row_err) <= 1e-4, np.median(row_err)
+    assert (row_err > 1e-3).mean() <= 0.05, (row_err > 1e-3).mean()          # samples with a flipped unit
+    for a, b in ((wda, wdb), (wca, wcb)):
+        assert np.linalg.norm(a - b) <= 2e-2 * np.linalg.norm(a), np.linalg.norm(a - b) / np.linalg.norm(a)
+
+
+def dev_of(t):
+    return t.device
+
+
 @pytest.mark.parametrize('nhd,nhc,n,n_valid', [(5, 5, 300, None), (5, 5, 5000, 4100), (3, 4, 257, None), (2, 2, 100, None)])
 def test_deeper_topologies_run_layer_by_layer(O, dev, nhd, nhc, n, n_valid):
     """tiny-cuda-nn's own default depth (5 hidden layers: what the reference's unchanged config builds if tcnn ignores its

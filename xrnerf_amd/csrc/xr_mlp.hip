@@ -43,6 +43,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define W_HID 64          // n_neurons of the reference config (nerf_blender_local01.py:106-124)
 #define ENC_DIM 32        // 16 levels x 2 features
 #define ST33 33
+#define XR_MLP_MAX_LD 200000000u   // load_enc_tile / store_enc_tile: the per-lane byte offset (5 ld) * 4 stays below 2^32
 
 __device__ __forceinline__ constexpr int drow(int r) { return (r & 3) + 8 * (r >> 2); }
 
@@ -410,6 +411,87 @@ __device__ __forceinline__ void layer_bwd_b2(const __bf16* __restrict__ wb, int 
     }
     __builtin_amdgcn_sched_barrier(0);
 }
+// Forward recompute of the backward on the bf16 matrix cores (XR_MLP_BWD_DW=b2f): W in the forward arrangement
+// [out neuron][hi][K-step][8], two bf16 parts.  Only what the backward's recompute reads is kept: the colour net's output
+// layer is never recomputed, and the density net's output layer keeps its 16 real rows (lanes 16..31 read rows 0..15 again;
+// their accumulator rows are not used) -- with W^T beside it the weights take 98.6 KiB and no fp32 copy is needed.
+template <int NH>
+struct F2Shape {
+    __host__ __device__ static constexpr int rows(int l) { return l == NH ? (NH == 1 ? 16 : 0) : W_HID; }
+    __host__ __device__ static constexpr int off(int l) { int o = 0; for (int i = 0; i < l; ++i) o += rows(i) * h_rs(net_in_dim(i)); return o; }
+    static constexpr int halves = off(NH + 1);
+};
+template <int NH, int L>
+__device__ __forceinline__ void store_layer_fb2(const float (&v)[NetShape<NH>::out_rows_lds(L) * NetShape<NH>::in_dim(L) / MLP_THREADS],
+                                                __bf16* __restrict__ wf, int psf, __bf16* __restrict__ wb, int psb, bool first_layer_rot) {
+    using S = NetShape<NH>;
+    using H = HShape<NH>;
+    using F = F2Shape<NH>;
+    constexpr int K = S::in_dim(L), rows = S::out_dim(L), prow = S::out_rows_lds(L);
+    constexpr int ns = K / 16, rs = h_rs(K), nso = prow / 16, rsb = h_rs(prow), frows = F::rows(L);
+    __bf16* dstf = wf + F::off(L);
+    __bf16* dstb = wb + H::b_off(L);
+#pragma unroll
+    for (int i = 0; i < prow * K / MLP_THREADS; ++i) {
+        const int x = threadIdx.x + i * MLP_THREADS, o = x / K, c = x % K;        // global [o][c]
+        const int m = (L == 0 && first_layer_rot) ? ((c + 1) & 31) : c;             // LDS slot of global column c
+        const float w = o < rows ? v[i] : 0.f;
+        const __bf16 h = (__bf16)w, l = (__bf16)(w - (float)h);
+        if (frows > 0 && o < frows) { __bf16* d = dstf + o * rs + hslot(m, ns); d[0] = h; d[psf] = l; }
+        __bf16* d = dstb + m * rsb + hslot(o, nso);
+        d[0] = h; d[psb] = l;
+    }
+}
+template <int NH>
+__device__ inline void load_weights_fb2(__bf16* __restrict__ wf, int psf, __bf16* __restrict__ wb, int psb, const float* __restrict__ w,
+                                        bool first_layer_rot) {
+    using S = NetShape<NH>;
+    static_assert(NH == 1 || NH == 2, "built for 1 or 2 hidden layers");
+    float v0[S::out_rows_lds(0) * S::in_dim(0) / MLP_THREADS], v1[S::out_rows_lds(1) * S::in_dim(1) / MLP_THREADS];
+    float v2[NH >= 2 ? S::out_rows_lds(NH >= 2 ? 2 : 0) * S::in_dim(NH >= 2 ? 2 : 0) / MLP_THREADS : 1];
+    fetch_layer<NH, 0>(v0, w, false);
+    fetch_layer<NH, 1>(v1, w, false);
+    if constexpr (NH >= 2) fetch_layer<NH, 2>(v2, w, false);
+    store_layer_fb2<NH, 0>(v0, wf, psf, wb, psb, first_layer_rot);
+    store_layer_fb2<NH, 1>(v1, wf, psf, wb, psb, false);
+    if constexpr (NH >= 2) store_layer_fb2<NH, 2>(v2, wf, psf, wb, psb, false);
+}
+// out[TO] = W . in[TI]; ROW16: the layer has 16 rows in LDS (lanes 16..31 repeat them)
+template <int TI, int TO, bool ROW16 = false>
+__device__ __forceinline__ void layer_fwd_b2(const __bf16* __restrict__ wf, int ps, const B2Tile (&in)[TI], f32x16 (&out)[TO], int col, int hi) {
+    constexpr int NS = 2 * TI, RS = 2 * NS * 8 + 8;
+#pragma unroll
+    for (int to = 0; to < TO; ++to)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[to][r] = 0.f;
+    const __bf16* wl = wf + (ROW16 ? (col & 15) : col) * RS + hi * NS * 8;
+    bw8 a[B2X_PF + 1][TO][2];
+    auto load = [&](int t, bw8 (&d)[TO][2]) {
+#pragma unroll
+        for (int to = 0; to < TO; ++to) {
+            const __bf16* p = wl + to * 32 * RS + t * 8;
+            d[to][0] = *reinterpret_cast<const bw8*>(p);
+            d[to][1] = *reinterpret_cast<const bw8*>(p + ps);
+        }
+    };
+    if (B2X_PF) load(0, a[0]);
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (B2X_PF) { if (t + 1 < NS) load(t + 1, a[(t + 1) & 1]); }
+        else load(t, a[0]);
+        const B2Tile& x = in[t >> 1];
+        const int k = t & 1;
+        const int cur = B2X_PF ? (t & 1) : 0;
+#pragma unroll
+        for (int to = 0; to < TO; ++to) {
+            out[to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][to][1], x.p[0][k], out[to], 0, 0, 0);
+            out[to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][to][0], x.p[1][k], out[to], 0, 0, 0);
+            out[to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][to][0], x.p[0][k], out[to], 0, 0, 0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
 // block-level reduction target: LDS buffer in the GLOBAL (compact, [out][in]) parameter layout.
 // The four waves of a workgroup take turns (caller: `for w: if (wave == w) dw_flush(.., first = (w == 0)); barrier`):
 // the first one stores, the others read-add-write with plain LDS accesses.  NOT ds_add_f32: measured on MI355X
@@ -634,23 +716,36 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void k_nerf_mlp_bwd_1_2(
     using SD = NetShape<1>;
     using SC = NetShape<2>;
     constexpr int GW = SD::glb_floats + SC::glb_floats;                // 3072 + 7168
-    constexpr bool DWB = MODE >= 1, DXB = MODE >= 2;
+    constexpr bool DWB = MODE >= 1, DXB = MODE >= 2, FWB = MODE >= 3;
     using HD = HShape<1>;
     using HC = HShape<2>;
+    using FD = F2Shape<1>;
+    using FC = F2Shape<2>;
     constexpr int PD = HD::b_halves, PC = HC::b_halves;                // halves per part of W^T
+    constexpr int PFD = FD::halves, PFC = FC::halves;                  // halves per part of W (FWB)
     constexpr int STAGE = (DXB ? 3 : 4) * 32 * ST33;                   // floats per wave
+    constexpr int W32 = FWB ? 0 : SD::lds_floats + SC::lds_floats;     // fp32 weights (none when the recompute is on bf16 too)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* wd = lds;
     float* wc = wd + SD::lds_floats;
-    __bf16* wbd = reinterpret_cast<__bf16*>(wc + SC::lds_floats);      // DXB: W^T of both networks, two bf16 parts each
+    __bf16* wfd = reinterpret_cast<__bf16*>(lds + W32);                // FWB: W of both networks, two bf16 parts each
+    __bf16* wfc = wfd + (FWB ? 2 * PFD : 0);
+    __bf16* wbd = wfc + (FWB ? 2 * PFC : 0);                           // DXB: W^T of both networks, two bf16 parts each
     __bf16* wbc = wbd + 2 * PD;
-    float* stage_all = DXB ? reinterpret_cast<float*>(wbc + 2 * PC) : wc + SC::lds_floats;   // MLP_WAVES * STAGE floats
-    static_assert(PD % 8 == 0 && PC % 8 == 0 && (SD::lds_floats + SC::lds_floats) % 4 == 0, "16-byte alignment of the operand reads");
-    load_weights<1>(wd, w_density, false);
-    load_weights<2>(wc, w_color, true);
-    if constexpr (DXB) {
-        load_weights_bt2<1>(wbd, PD, w_density, false);
-        load_weights_bt2<2>(wbc, PC, w_color, true);
+    float* stage_all = DXB ? reinterpret_cast<float*>(wbc + 2 * PC) : lds + W32;             // MLP_WAVES * STAGE floats
+    constexpr int LDS_FLOATS = W32 + (FWB ? PFD + PFC : 0) + (DXB ? PD + PC : 0) + MLP_WAVES * STAGE;
+    static_assert(PD % 8 == 0 && PC % 8 == 0 && PFD % 8 == 0 && PFC % 8 == 0 && (SD::lds_floats + SC::lds_floats) % 4 == 0,
+                  "16-byte alignment of the operand reads");
+    if constexpr (FWB) {
+        load_weights_fb2<1>(wfd, PFD, wbd, PD, w_density, false);
+        load_weights_fb2<2>(wfc, PFC, wbc, PC, w_color, true);
+    } else {
+        load_weights<1>(wd, w_density, false);
+        load_weights<2>(wc, w_color, true);
+        if constexpr (DXB) {
+            load_weights_bt2<1>(wbd, PD, w_density, false);
+            load_weights_bt2<2>(wbc, PC, w_color, true);
+        }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, hi = lane >> 5;
@@ -674,14 +769,25 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void k_nerf_mlp_bwd_1_2(
         // ---- recompute forward, keep activations
         f32x16 xe[1], hd[2], dout[1], cin[1], hc1[2], hc2[2];
         load_enc_tile(enc_t, ld, sc, xe[0], hi);
-        layer_fwd<1, 2, false>(wd + SD::lds_off(0), xe, hd, col, hi);
-        relu_tile(hd[0]); relu_tile(hd[1]);
-        layer_fwd<2, 1, false>(wd + SD::lds_off(1), hd, dout, col, hi);
-        build_color_in(dout[0], dirs, dir_stride, sc, pad_value, cin[0], hi);
-        layer_fwd<1, 2, false>(wc + SC::lds_off(0), cin, hc1, col, hi);
-        relu_tile(hc1[0]); relu_tile(hc1[1]);
-        layer_fwd<2, 2, false>(wc + SC::lds_off(1), hc1, hc2, col, hi);
-        relu_tile(hc2[0]); relu_tile(hc2[1]);
+        if constexpr (FWB) {
+            { const B2Tile xb[1] = {to_b2(xe[0])}; layer_fwd_b2<1, 2>(wfd + FD::off(0), PFD, xb, hd, col, hi); }
+            relu_tile(hd[0]); relu_tile(hd[1]);
+            { const B2Tile hb[2] = {to_b2(hd[0]), to_b2(hd[1])}; layer_fwd_b2<2, 1, true>(wfd + FD::off(1), PFD, hb, dout, col, hi); }
+            build_color_in(dout[0], dirs, dir_stride, sc, pad_value, cin[0], hi);
+            { const B2Tile cb[1] = {to_b2(cin[0])}; layer_fwd_b2<1, 2>(wfc + FC::off(0), PFC, cb, hc1, col, hi); }
+            relu_tile(hc1[0]); relu_tile(hc1[1]);
+            { const B2Tile hb[2] = {to_b2(hc1[0]), to_b2(hc1[1])}; layer_fwd_b2<2, 2>(wfc + FC::off(1), PFC, hb, hc2, col, hi); }
+            relu_tile(hc2[0]); relu_tile(hc2[1]);
+        } else {
+            layer_fwd<1, 2, false>(wd + SD::lds_off(0), xe, hd, col, hi);
+            relu_tile(hd[0]); relu_tile(hd[1]);
+            layer_fwd<2, 1, false>(wd + SD::lds_off(1), hd, dout, col, hi);
+            build_color_in(dout[0], dirs, dir_stride, sc, pad_value, cin[0], hi);
+            layer_fwd<1, 2, false>(wc + SC::lds_off(0), cin, hc1, col, hi);
+            relu_tile(hc1[0]); relu_tile(hc1[1]);
+            layer_fwd<2, 2, false>(wc + SC::lds_off(1), hc1, hc2, col, hi);
+            relu_tile(hc2[0]); relu_tile(hc2[1]);
+        }
         // ---- output gradients: rows 0..2 of the color output tile = dL/d(rgb raw), all else 0.
         // dead (ragged) samples get a zero gradient so they contribute nothing to dW.
         float4 dr = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -748,7 +854,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void k_nerf_mlp_bwd_1_2(
     // Waves 0 / 1 store into copy A / B side by side, waves 2 / 3 add, the write-out sums the copies: two turns instead of
     // four (fixed order (w0 + w2) + (w1 + w3)).
     __syncthreads();
-    static_assert(2 * GW <= SD::lds_floats + SC::lds_floats + (DXB ? PD + PC : 0) + MLP_WAVES * STAGE, "two reduction copies must fit the launch's LDS");
+    static_assert(2 * GW <= LDS_FLOATS, "two reduction copies must fit the launch's LDS");
     float* redA = lds;
     for (int ph = 0; ph < 2; ++ph) {
         if ((wave >> 1) == ph) {
@@ -1526,7 +1632,7 @@ extern "C" int xr_nerf_mlp_fwd(const float* enc_t, uint32_t ld, const float* dir
     if (n == 0) return XR_OK;
     XR_REQUIRE(enc_t && w_density && raw, "null pointer");
     XR_REQUIRE(!dirs || (w_color && dir_stride >= 3), "color path needs w_color and dir_stride >= 3");
-    XR_REQUIRE(ld >= n && ((uintptr_t)raw & 15) == 0, "bad ld / raw alignment");
+    XR_REQUIRE(ld >= n && ld <= XR_MLP_MAX_LD && ((uintptr_t)raw & 15) == 0, "bad ld / raw alignment");
     int rc;
     if (n_hidden_density == 1 && n_hidden_color == 2) rc = launch_fwd<1, 2>(enc_t, ld, dirs, dir_stride, n, n_dev, rows, w_density, w_color, pad_value, raw, (hipStream_t)stream_);
     else if (n_hidden_density == 1 && n_hidden_color == 1) rc = launch_fwd<1, 1>(enc_t, ld, dirs, dir_stride, n, n_dev, rows, w_density, w_color, pad_value, raw, (hipStream_t)stream_);
@@ -1634,7 +1740,7 @@ extern "C" int xr_nerf_mlp_bwd(const float* enc_t, uint32_t ld, const float* dir
     if (n == 0) return XR_OK;
     hipStream_t stream = (hipStream_t)stream_;
     XR_REQUIRE(enc_t && dirs && w_density && w_color && draw && denc_t && grad_w_density && grad_w_color, "null pointer");
-    XR_REQUIRE(ld >= n && dir_stride >= 3 && ((uintptr_t)draw & 15) == 0, "bad ld / stride / alignment");
+    XR_REQUIRE(ld >= n && ld <= XR_MLP_MAX_LD && dir_stride >= 3 && ((uintptr_t)draw & 15) == 0, "bad ld / stride / alignment");
     if (!(n_hidden_density == 1 && n_hidden_color == 2)) {
         xr_set_error("xr_nerf_mlp_bwd: only the (1,2) hidden-layer topology of configs/instant_ngp is built (got %d,%d)",
                      n_hidden_density, n_hidden_color);
@@ -1647,12 +1753,25 @@ extern "C" int xr_nerf_mlp_bwd(const float* enc_t, uint32_t ld, const float* dir
     XR_REQUIRE(!live_rows == !n_live, "live_rows and n_live come together");
     const uint32_t* rows = live_rows;                    // the caller's list (xr_live_rows), else the backward's own
     if (!rows && live_rows_enabled()) { const int rc = build_live_rows(draw, n, n_dev, denc_t, ld, workspace, stream, &rows, &n_live); if (rc != XR_OK) return rc; }
-    // XR_MLP_BWD_DW: f32 = fp32 MFMA throughout, b2 = dW products on the bf16 matrix cores, b2x (default) = the dX chain too
-    static const int mode = [] { const char* e = getenv("XR_MLP_BWD_DW"); return !e ? 2 : strcmp(e, "f32") == 0 ? 0 : strcmp(e, "b2") == 0 ? 1 : 2; }();
-    auto kern = rows ? (mode == 2 ? k_nerf_mlp_bwd_1_2<true, 2> : mode == 1 ? k_nerf_mlp_bwd_1_2<true, 1> : k_nerf_mlp_bwd_1_2<true, 0>)
-                     : (mode == 2 ? k_nerf_mlp_bwd_1_2<false, 2> : mode == 1 ? k_nerf_mlp_bwd_1_2<false, 1> : k_nerf_mlp_bwd_1_2<false, 0>);
-    if (mode == 2) lds = (NetShape<1>::lds_floats + NetShape<2>::lds_floats + MLP_WAVES * 3 * 32 * ST33) * sizeof(float)
-                         + (size_t)2 * (HShape<1>::b_halves + HShape<2>::b_halves) * sizeof(__bf16);
+    // XR_MLP_BWD_DW (read per call): f32 = fp32 MFMA throughout; b2 = the dW products on the bf16 matrix cores (2-way split);
+    // b2x (default) = the dX chain too; b2f = the forward recompute as well.  b2f is not the default: a recompute at 2^-16
+    // relative accuracy puts a hidden unit whose pre-activation is within ~1e-5 of zero on the other side of its ReLU than
+    // the forward had it (a few hundred unit-samples per training step, ~1 with the fp32 recompute) -- harmless to the
+    // optimiser, but each such flip is one sample's whole contribution to a weight row, which a 1e-3 * max parity bar on a
+    // small batch sees.
+    const char* bwd_env = getenv("XR_MLP_BWD_DW");
+    const int mode = !bwd_env ? 2 : strcmp(bwd_env, "f32") == 0 ? 0 : strcmp(bwd_env, "b2") == 0 ? 1 : strcmp(bwd_env, "b2f") == 0 ? 3 : 2;
+    using KernT = void (*)(const float*, uint32_t, const float*, uint32_t, uint32_t, const uint32_t*, const float*, const float*, float,
+                           const float4*, float*, float*, const uint32_t*, const uint32_t*);
+    static const KernT kerns[2][4] = {{k_nerf_mlp_bwd_1_2<false, 0>, k_nerf_mlp_bwd_1_2<false, 1>, k_nerf_mlp_bwd_1_2<false, 2>, k_nerf_mlp_bwd_1_2<false, 3>},
+                                      {k_nerf_mlp_bwd_1_2<true, 0>, k_nerf_mlp_bwd_1_2<true, 1>, k_nerf_mlp_bwd_1_2<true, 2>, k_nerf_mlp_bwd_1_2<true, 3>}};
+    KernT kern = kerns[rows ? 1 : 0][mode];
+    constexpr size_t bt2 = (size_t)2 * (HShape<1>::b_halves + HShape<2>::b_halves) * sizeof(__bf16);
+    constexpr size_t ft2 = (size_t)2 * (F2Shape<1>::halves + F2Shape<2>::halves) * sizeof(__bf16);
+    constexpr size_t w32 = (NetShape<1>::lds_floats + NetShape<2>::lds_floats) * sizeof(float);
+    constexpr size_t st3 = (size_t)MLP_WAVES * 3 * 32 * ST33 * sizeof(float);
+    if (mode == 2) lds = w32 + bt2 + st3;
+    if (mode == 3) lds = ft2 + bt2 + st3;
     if (mlp_set_lds((const void*)kern, lds) != XR_OK) { xr_set_error("hipFuncSetAttribute failed"); return XR_EHIP; }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n,
                        n_dev, w_density, w_color, pad_value, (const float4*)draw, denc_t, (float*)workspace, rows, n_live);
@@ -1724,7 +1843,7 @@ extern "C" int xr_nerf_mlp_fwd_f16(const float* enc_t, uint32_t ld, const float*
     if (n == 0) return XR_OK;
     XR_REQUIRE(enc_t && w_density && raw, "null pointer");
     XR_REQUIRE(!dirs || (w_color && dir_stride >= 3), "color path needs w_color and dir_stride >= 3");
-    XR_REQUIRE(ld >= n && ((uintptr_t)raw & 15) == 0, "bad ld / raw alignment");
+    XR_REQUIRE(ld >= n && ld <= XR_MLP_MAX_LD && ((uintptr_t)raw & 15) == 0, "bad ld / raw alignment");
     XR_REQUIRE(n_hidden_density == 1 && n_hidden_color == 2, "the fp16 mode is built for the (1,2) hidden-layer topology");
     hipStream_t stream = (hipStream_t)stream_;
     const int cus = xr_device_cus() > 0 ? xr_device_cus() : 256;
@@ -1749,7 +1868,7 @@ extern "C" int xr_nerf_mlp_fwd_bf16x3(const float* enc_t, uint32_t ld, const flo
     if (n == 0) return XR_OK;
     XR_REQUIRE(enc_t && w_density && raw, "null pointer");
     XR_REQUIRE(!dirs || (w_color && dir_stride >= 3), "color path needs w_color and dir_stride >= 3");
-    XR_REQUIRE(ld >= n && ((uintptr_t)raw & 15) == 0, "bad ld / raw alignment");
+    XR_REQUIRE(ld >= n && ld <= XR_MLP_MAX_LD && ((uintptr_t)raw & 15) == 0, "bad ld / raw alignment");
     XR_REQUIRE(n_hidden_density == 1 && n_hidden_color == 2, "the split forward is built for the (1,2) hidden-layer topology");
     hipStream_t stream = (hipStream_t)stream_;
     const int cus = xr_device_cus() > 0 ? xr_device_cus() : 256;
@@ -1776,7 +1895,7 @@ extern "C" int xr_nerf_mlp_bwd_f16(const float* enc_t, uint32_t ld, const float*
     if (n == 0) return XR_OK;
     hipStream_t stream = (hipStream_t)stream_;
     XR_REQUIRE(enc_t && dirs && w_density && w_color && draw && denc_t && grad_w_density && grad_w_color, "null pointer");
-    XR_REQUIRE(ld >= n && dir_stride >= 3 && ((uintptr_t)draw & 15) == 0, "bad ld / stride / alignment");
+    XR_REQUIRE(ld >= n && ld <= XR_MLP_MAX_LD && dir_stride >= 3 && ((uintptr_t)draw & 15) == 0, "bad ld / stride / alignment");
     XR_REQUIRE(n_hidden_density == 1 && n_hidden_color == 2, "the fp16 mode is built for the (1,2) hidden-layer topology");
     XR_REQUIRE(workspace && workspace_bytes >= xr_nerf_mlp_bwd_workspace_bytes(n), "workspace too small");
     constexpr int GW = NetShape<1>::glb_floats + NetShape<2>::glb_floats;
