@@ -119,11 +119,20 @@ def _preset_grid(sampler, edev):
     sampler.density_grid_ema_step = 1
 
 
-def test_reference_network_mlp_render_on_the_tcnn_and_raymarch_shims_match_ours(edev, ref):
+@pytest.mark.parametrize('arith', ['b2', 'b2x'])
+def test_reference_network_mlp_render_on_the_tcnn_and_raymarch_shims_match_ours(edev, ref, arith, monkeypatch):
     """HashNerfNetwork.train_step of the reference (its sampler, its HashNerfMLP on `tinycudann` = xrnerf_amd.tcnn, its
     HashNerfRender autograd Functions on `raymarch_cuda`, its HuberLoss) against this package's network from the same
     weights, for three iterations with an Adam step in between: rgb, loss, PSNR, every parameter gradient, the parameters
-    after the steps."""
+    after the steps.
+
+    The reference's module-by-module route reaches the single-network kernels (fp32 MFMA throughout), this package's fused
+    backward runs its dX chain on the bf16 matrix cores with 2-way split operands by default (XR_MLP_BWD_DW=b2x: 2^-16
+    relative per product instead of 2^-24).  Gradients agree to 2e-5 of their scale either way.  After three Adam steps
+    (eps = 1e-15: a table entry whose gradient is rounding noise moves by +-lr per step whatever the noise's size) the
+    parameters agree to 1e-4 everywhere with the dX chain on fp32-grade products (arith = b2), and everywhere but on
+    < 1e-5 of the table entries with the default (arith = b2x)."""
+    monkeypatch.setenv('XR_MLP_BWD_DW', arith)
     import ngp_ref_harness as Hn
     import xrnerf_amd
     import xrnerf_amd.raymarch_cuda as rc
@@ -174,7 +183,11 @@ def test_reference_network_mlp_render_on_the_tcnn_and_raymarch_shims_match_ours(
     for n in ('embedder_pos', 'density_net', 'color_net'):
         a, c = getattr(theirs.mlp, n).params.detach(), getattr(mine.mlp, n).params.detach()
         # Adam divides by sqrt(v): entries whose gradients differ at summation-order level move apart by more than that
-        assert float((a - c).abs().max()) <= 1e-4, (n, float((a - c).abs().max()))
+        d = (a - c).abs()
+        if arith == 'b2':
+            assert float(d.max()) <= 1e-4, (n, float(d.max()))
+        else:
+            assert float(d.max()) <= 3.5e-2 and int((d > 1e-4).sum()) <= 1e-5 * d.numel(), (n, float(d.max()), int((d > 1e-4).sum()))
     # validation forward (is_test=True: K1 without clipping, K5 compositor) through both
     b = Hn.batch(poses, 300, 77, edev)
     with torch.no_grad():

@@ -11,6 +11,8 @@ if arg == 'spans':            # one line per window: its span and the longest ke
         span = (int(rows[b]['End_Timestamp']) - int(rows[a]['End_Timestamp'])) / 1e3
         print('%4d %8.1f us  %d kernels' % (w, span, b - a))
     sys.exit(0)
+if arg == 'refresh':          # the last window that holds a grid refresh (k9_ema)
+    arg = str(max(w for w in range(1, len(idx)) if any('k9_ema' in r['Kernel_Name'] for r in rows[idx[w - 1]:idx[w]])))
 which = int(float(arg) * len(idx)) if '.' in arg else int(arg)
 which = max(1, min(len(idx) - 1, which)) if which >= 0 else which
 print('# window %d of %d' % (which, len(idx)))

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libxrnerf_mi355.so')
+# XRNERF_LIB: another build of the same library (kernel A/Bs that need a compile-time constant changed: tools/build_variant.sh)
+LIB_PATH = os.environ.get('XRNERF_LIB') or os.path.join(HERE, 'libxrnerf_mi355.so')
 
 _vp, _u32, _i32, _f, _u64, _sz, _d = C.c_void_p, C.c_uint32, C.c_int, C.c_float, C.c_uint64, C.c_size_t, C.c_double
 

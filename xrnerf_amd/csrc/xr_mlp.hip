@@ -1419,7 +1419,15 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void k_nerf_mlp_bwd_h(
 // hence ONE workgroup of 8 waves per CU sharing them).  Topology (1, 2) only.
 typedef __bf16 b8 __attribute__((ext_vector_type(8)));
 #define MFMA16B(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#ifndef BX_WAVES
 #define BX_WAVES 8
+#endif
+#ifndef BX_PF_OP
+#define BX_PF_OP 1        // LDS operand double buffer (1 step ahead)
+#endif
+#ifndef BX_PF_TILE
+#define BX_PF_TILE 1      // next tile's inputs fetched under the current tile
+#endif
 #define BX_THREADS (BX_WAVES * 64)
 
 __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
@@ -1495,7 +1503,7 @@ __device__ __forceinline__ void layer_fwd_b3(const __bf16* __restrict__ wf, int 
 #pragma unroll
         for (int r = 0; r < 16; ++r) out[to][r] = 0.f;
     const __bf16* wl = wf + col * RS + hi * NS * 8;
-    b8 a[2][TO][3];
+    b8 a[BX_PF_OP + 1][TO][3];
     auto load = [&](int t, b8 (&d)[TO][3]) {
 #pragma unroll
         for (int to = 0; to < TO; ++to) {
@@ -1505,16 +1513,18 @@ __device__ __forceinline__ void layer_fwd_b3(const __bf16* __restrict__ wf, int 
             d[to][2] = *reinterpret_cast<const b8*>(p + 2 * ps);
         }
     };
-    load(0, a[0]);
+    if (BX_PF_OP) load(0, a[0]);
 #pragma unroll
     for (int t = 0; t < NS; ++t) {
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < NS) load(t + 1, a[(t + 1) & 1]);
+        if (BX_PF_OP) { if (t + 1 < NS) load(t + 1, a[(t + 1) & 1]); }
+        else load(t, a[0]);
         const BTile& x = in[t >> 1];
         const int k = t & 1;
+        const int cur = BX_PF_OP ? (t & 1) : 0;
 #pragma unroll
         for (int to = 0; to < TO; ++to) {
-            const b8 ah = a[t & 1][to][0], am = a[t & 1][to][1], al = a[t & 1][to][2];
+            const b8 ah = a[cur][to][0], am = a[cur][to][1], al = a[cur][to][2];
             out[to] = MFMA16B(al, x.p[0][k], out[to]);
             out[to] = MFMA16B(ah, x.p[2][k], out[to]);
             out[to] = MFMA16B(am, x.p[1][k], out[to]);
@@ -1567,9 +1577,10 @@ __global__ __launch_bounds__(BX_THREADS, 1) void k_nerf_mlp_fwd_b3(const float* 
     __syncthreads();
     for (; tile < n_tiles; tile += stride) {
         const uint32_t s = tile * 32 + col;
+        if (!BX_PF_TILE && tile >= (blockIdx.x + gridDim.x) * BX_WAVES) fetch(tile, x, d3);      // (the first tile came before the weight split)
         BTile xin[1] = {to_b3(x)};
         const float dx = d3[0], dy = d3[1], dz = d3[2];
-        if (tile + stride < n_tiles) fetch(tile + stride, x, d3);           // next tile's loads under this tile's MFMAs
+        if (BX_PF_TILE && tile + stride < n_tiles) fetch(tile + stride, x, d3);   // next tile's loads under this tile's MFMAs
         f32x16 h[2], dout[1];
         layer_fwd_b3<1, 2>(wd + HD::f_off(0), PD, xin, h, col, hi);
         relu_tile(h[0]); relu_tile(h[1]);
