@@ -366,6 +366,8 @@ int xr_ngp_train_step(const float* table, const float* w_density, const float* w
 /* mark_entry / mark_event (nullable): mark_event is recorded on `stream` right behind the launches of the named entry point, so
  * that work on another stream can be started from that point of the step (xr_stream_wait_event). */
 void* xr_timing_event_create(void);
+/* an event for ordering only (no timestamp taken: cheaper to record); destroy / wait with the calls of the timing events */
+void* xr_order_event_create(void);
 int xr_stream_wait_event(void* stream, void* event);
 int xr_timing_event_destroy(void* event);
 int xr_timing_event_elapsed_ms(void* begin, void* end, float* ms);

@@ -63,6 +63,7 @@ SIGNATURES = {
                                  _vp, _i32, _i32, _f, _f, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp, _sz,
                                  _vp, _sz, _i32, _vp, _u32, _vp, _vp, _vp, C.c_char_p, _vp, C.c_char_p, _vp, _vp, _vp]),
     'xr_timing_event_create': (_vp, []),
+    'xr_order_event_create': (_vp, []),
     'xr_stream_wait_event': (_i32, [_vp, _vp]),
     'xr_timing_event_destroy': (_i32, [_vp]),
     'xr_timing_event_elapsed_ms': (_i32, [_vp, _vp, _vp]),

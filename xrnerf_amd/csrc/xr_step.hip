@@ -14,6 +14,11 @@ extern "C" void* xr_timing_event_create(void) {
     hipEvent_t e = nullptr;
     return hipEventCreate(&e) == hipSuccess ? (void*)e : nullptr;
 }
+// an event for ordering only (hipEventDisableTiming: no timestamp is taken when it completes); same destroy / wait calls
+extern "C" void* xr_order_event_create(void) {
+    hipEvent_t e = nullptr;
+    return hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess ? (void*)e : nullptr;
+}
 extern "C" int xr_timing_event_destroy(void* e) { return e && hipEventDestroy((hipEvent_t)e) != hipSuccess ? XR_EHIP : XR_OK; }
 extern "C" int xr_timing_event_elapsed_ms(void* a, void* b, float* ms) {
     XR_REQUIRE(a && b && ms, "null pointer");

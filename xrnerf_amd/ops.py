@@ -69,8 +69,9 @@ class _Span:
 class _CEvent:
     """a timing event of the library (xr_timing_event_*): what xr_ngp_train_step records around one of its stages"""
 
-    def __init__(self):
-        self.h = _lib.load().xr_timing_event_create()
+    def __init__(self, timing=True):
+        # timing=False: an event for ordering only (xr_order_event_create, hipEventDisableTiming)
+        self.h = _lib.load().xr_timing_event_create() if timing else _lib.load().xr_order_event_create()
         if not self.h:
             raise _lib.XrError('cannot create a timing event')
 

@@ -254,7 +254,7 @@ class Trainer:
         after = os.environ.get('XRNERF_PREFETCH_AFTER', 'none')
         if after not in ('none', 'xr_hashgrid_fwd', 'xr_nerf_mlp_fwd', 'xr_composite_train', 'xr_live_rows', 'xr_nerf_mlp_bwd'):
             raise ValueError('XRNERF_PREFETCH_AFTER: unknown entry point %r' % after)
-        self.net._step_mark = (after, ops._CEvent()) if (after != 'none' and device.type == 'cuda') else None
+        self.net._step_mark = (after, ops._CEvent(timing=False)) if (after != 'none' and device.type == 'cuda') else None
         # XRNERF_PREFETCH_DEPTH (default 2): the march of iteration i + 2 is issued during iteration i and starts behind i's MLP
         # backward, so that it runs beside the table scatter and the next encode instead of beside the two fused-MLP kernels --
         # the backward's waves own whole SIMD register files and cannot be placed on a CU that hosts a marching wave, the forward
@@ -263,7 +263,7 @@ class Trainer:
         # whole iteration.  1 = the previous scheme (iteration i + 1, started as soon as i is enqueued).
         self.prefetch_depth = 2 if os.environ.get('XRNERF_PREFETCH_DEPTH', '2') != '1' else 1
         if self.prefetch_depth == 2 and self.net._step_mark is None and device.type == 'cuda':
-            self.net._step_mark = ('xr_nerf_mlp_bwd', ops._CEvent())
+            self.net._step_mark = ('xr_nerf_mlp_bwd', ops._CEvent(timing=False))
         self._ev_done = [None, None]   # completion events of the last two iterations
         self._bbufs = [None, None, None]
         self._queue = []               # [(iteration, batch)] marched ahead, in order
