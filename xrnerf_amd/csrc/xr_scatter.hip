@@ -41,7 +41,9 @@ __device__ __forceinline__ void s3_static_for_impl(F&& f, std::integer_sequence<
 template <int N, typename F>
 __device__ __forceinline__ void s3_static_for(F&& f) { s3_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
-#define S3_LOG2 13
+#ifndef S3_LOG2
+#define S3_LOG2 13      // (tools/build_variant.sh lg12 xr_scatter.hip "-DS3_LOG2=12": measured, slower)
+#endif
 #define S3_ENTRIES (1u << S3_LOG2)
 #define S3_LDS_BYTES (S3_ENTRIES * 2 * sizeof(double))
 #define S3_MAX_PARTS 256
