@@ -297,6 +297,27 @@ def test_table_update_inside_the_scatter_equals_scatter_plus_optimiser_launch(de
     assert out[0][-1] == out[1][-1] == 20
 
 
+def test_refresh_samples_generated_one_iteration_early_leave_the_trajectory_alone(dev, monkeypatch):
+    """XRNERF_PREFETCH_K6 (default on): K6 and the clear of the temporary grid of a refresh run on the side stream during the
+    iteration before it.  40 iterations (refreshes at 0, 16, 32) with and without: bit-identical parameters, grids, RNG counters."""
+    from xrnerf_amd.train import Trainer
+    out = []
+    for on in ('1', '0'):
+        monkeypatch.setenv('XRNERF_PREFETCH_K6', on)
+        tr = Trainer(dev, n_img=3, H=128, W=128, seed=5)
+        assert tr.prefetch_k6 == (on == '1')
+        for _ in range(40):
+            tr.step()
+        torch.cuda.synchronize()
+        out.append(([p.detach().clone() for p in tr.net.parameters()], tr.net.sampler.density_grid.clone(),
+                    tr.net.sampler.density_grid_bitfield.clone(), tr.net.sampler.k6_calls, tr.net.sampler.n_rays_per_batch))
+    (pa, ga, ba, ka, na), (pb, gb, bb, kb, nb) = out
+    assert ka == kb and na == nb
+    for a, b in zip(pa, pb):
+        assert torch.equal(a, b)
+    assert torch.equal(ga, gb) and torch.equal(ba, bb)
+
+
 def test_march_two_iterations_ahead_leaves_the_trajectory_alone(dev, monkeypatch):
     """Prefetch depth 2 (the march of iteration i + 2 issued during iteration i, started behind its MLP backward; three rotating buffer
     sets) against depth 1 over 40 iterations -- two grid refreshes, two batch-size updates, the iterations that cannot be marched

@@ -99,28 +99,17 @@ class NGPGridSampler(_FastAttr, nn.Module):
             self.density_grid = ops.mark_untrained_density_grid(self.focal, self.transforms, n_elements,
                                                                 self.resolutions)
         planes = hasattr(mlp, 'run_density_planes') and self._streams() and os.environ.get('XRNERF_XYZ_PLANES', '1') != '0'
-        if planes:
-            # both K6 calls write ONE [3, n] plane buffer (+ one index vector): no concatenation, coalesced reads in the query
-            n_tot = n_uniform + n_nonuniform
-            buf = getattr(self, '_k6_bufs', None)
-            if buf is None or buf[0].shape[1] < n_tot or buf[0].device != self.density_grid.device:
-                buf = self._k6_bufs = (torch.empty((3, n_tot), dtype=torch.float32, device=self.density_grid.device),
-                                       torch.empty((n_tot,), dtype=torch.int32, device=self.density_grid.device))
-            po, io = buf
+        pre = self.__dict__.pop('_k6_prefetched', None)
+        if pre is not None and planes and pre['key'] == (n_uniform, n_nonuniform, self.density_grid_ema_step):
+            # K6 and the clear of the temporary grid ran on the side stream during the previous iteration (prefetch_grid_samples)
+            pre['event'].wait()
+            po, io = self._k6_bufs
+            n_tot, n_used = n_uniform + n_nonuniform, pre['n_used']
         else:
-            po = io = None
-        pos_u, idx_u = ops.generate_grid_samples(self.density_grid, self.density_grid_ema_step, n_uniform,
-                                                 self.max_cascade + 1, -0.01, aabb, self.k6_calls, po, io, 0)
-        self.k6_calls += 1
-        pos_n, idx_n = ops.generate_grid_samples(self.density_grid, self.density_grid_ema_step, n_nonuniform,
-                                                 self.max_cascade + 1, self.NERF_MIN_OPTICAL_THICKNESS, aabb,
-                                                 self.k6_calls, po, io, n_uniform)
-        self.k6_calls += 1     # the reference's rng advances on every call, also for n == 0
-        # K6 draws cells of cascades 0..max_cascade only, so K8 touches, and K9 can change, only that leading part of the two grids:
-        # the other cascades' cells hold K7's 0 / -1, which max(p * decay, 0) and the p < 0 rule both leave as they are.  The
-        # reference clears and walks all 8 cascades (134 + 200 MB per refresh at aabb_scale 1); same values here from 1/8 of that.
-        n_used = (self.max_cascade + 1) * (self.density_n_elements // self.NERF_CASCADES)
-        self.density_grid_tmp[:n_used].zero_()
+            if pre is not None:
+                self.k6_calls = pre['k6_calls']                 # a guess that does not apply: as if it had not been made
+            po, io, pos_u, idx_u, pos_n, idx_n, n_used = self._grid_samples(n_uniform, n_nonuniform, planes)
+            n_tot = n_uniform + n_nonuniform
         if planes:
             positions, indices = po[:, :n_tot], io[:n_tot]
             with torch.no_grad():
@@ -143,13 +132,55 @@ class NGPGridSampler(_FastAttr, nn.Module):
             self._bitfield_event = torch.cuda.Event()
             self._bitfield_event.record(torch.cuda.current_stream())
 
-    def update_density_grid(self, mlp):
-        n_cascades = self.max_cascade + 1
-        M = self.NERF_GRIDSIZE ** 3 * n_cascades
-        if self.iter_n < 256:
-            self.update_density_grid_func(M, 0, mlp)
+    def _grid_samples(self, n_uniform, n_nonuniform, planes):
+        """K6 twice (uniform, then among the occupied cells) + the clear of the temporary grid's part in use"""
+        aabb = (float(self.aabb_range[0]), float(self.aabb_range[1]))
+        if planes:
+            # both K6 calls write ONE [3, n] plane buffer (+ one index vector): no concatenation, coalesced reads in the query
+            n_tot = n_uniform + n_nonuniform
+            buf = getattr(self, '_k6_bufs', None)
+            if buf is None or buf[0].shape[1] < n_tot or buf[0].device != self.density_grid.device:
+                buf = self._k6_bufs = (torch.empty((3, n_tot), dtype=torch.float32, device=self.density_grid.device),
+                                       torch.empty((n_tot,), dtype=torch.int32, device=self.density_grid.device))
+            po, io = buf
         else:
-            self.update_density_grid_func(M // 4, M // 4, mlp)
+            po = io = None
+        pos_u, idx_u = ops.generate_grid_samples(self.density_grid, self.density_grid_ema_step, n_uniform,
+                                                 self.max_cascade + 1, -0.01, aabb, self.k6_calls, po, io, 0)
+        self.k6_calls += 1
+        pos_n, idx_n = ops.generate_grid_samples(self.density_grid, self.density_grid_ema_step, n_nonuniform,
+                                                 self.max_cascade + 1, self.NERF_MIN_OPTICAL_THICKNESS, aabb,
+                                                 self.k6_calls, po, io, n_uniform)
+        self.k6_calls += 1     # the reference's rng advances on every call, also for n == 0
+        # K6 draws cells of cascades 0..max_cascade only, so K8 touches, and K9 can change, only that leading part of the two grids:
+        # the other cascades' cells hold K7's 0 / -1, which max(p * decay, 0) and the p < 0 rule both leave as they are.  The
+        # reference clears and walks all 8 cascades (134 + 200 MB per refresh at aabb_scale 1); same values here from 1/8 of that.
+        n_used = (self.max_cascade + 1) * (self.density_n_elements // self.NERF_CASCADES)
+        self.density_grid_tmp[:n_used].zero_()
+        return po, io, pos_u, idx_u, pos_n, idx_n, n_used
+
+    def _refresh_counts(self, iter_n):
+        M = self.NERF_GRIDSIZE ** 3 * (self.max_cascade + 1)
+        return (M, 0) if iter_n < 256 else (M // 4, M // 4)
+
+    def prefetch_grid_samples(self, next_iter_n):
+        """call inside `with torch.cuda.stream(self.side_stream())` during the iteration BEFORE one that starts with a grid refresh:
+        K6 (both calls) and the clear of the temporary grid read the density grid and the RNG call counter only -- neither changes
+        until that refresh -- so they leave its critical path (~45 us of the refresh's 0.8 ms).  Same values, same call counters."""
+        if not (self._streams() and hasattr(self, 'density_grid') and os.environ.get('XRNERF_XYZ_PLANES', '1') != '0'):
+            return
+        n_uniform, n_nonuniform = self._refresh_counts(next_iter_n)
+        side = torch.cuda.current_stream()
+        if getattr(self, '_bitfield_event', None) is not None:
+            side.wait_event(self._bitfield_event)               # the last refresh (writer of the density grid, reader of the buffers)
+        k6_calls = self.k6_calls
+        out = self._grid_samples(n_uniform, n_nonuniform, True)
+        ev = torch.cuda.Event()
+        ev.record(side)
+        self._k6_prefetched = dict(key=(n_uniform, n_nonuniform, self.density_grid_ema_step), n_used=out[6], event=ev, k6_calls=k6_calls)
+
+    def update_density_grid(self, mlp):
+        self.update_density_grid_func(*self._refresh_counts(self.iter_n), mlp)
 
     def check_device(self, data):
         device = data['rays_o'].device

@@ -264,6 +264,7 @@ class Trainer:
         self.prefetch_depth = 2 if os.environ.get('XRNERF_PREFETCH_DEPTH', '2') != '1' else 1
         if self.prefetch_depth == 2 and self.net._step_mark is None and device.type == 'cuda':
             self.net._step_mark = ('xr_nerf_mlp_bwd', ops._CEvent(timing=False))
+        self.prefetch_k6 = os.environ.get('XRNERF_PREFETCH_K6', '1') != '0'      # the refresh's K6 one iteration early, on the side stream
         self._ev_done = [None, None]   # completion events of the last two iterations
         self._bbufs = [None, None, None]
         self._queue = []               # [(iteration, batch)] marched ahead, in order
@@ -340,6 +341,11 @@ class Trainer:
                 self._issue(it + 2, mark[1])
         elif queued < it + 1 and net.sampler.can_prefetch(it + 1):
             self._issue(it + 1, mark[1] if mark else None)
+        if (it + 1) % f == 0 and self.prefetch_k6 and hasattr(net.sampler, 'prefetch_grid_samples'):
+            # the next iteration starts with a grid refresh, which no march can be issued across: the side stream is idle, and the
+            # refresh's sample generation (K6 twice + the clear of the temporary grid) depends on nothing this iteration changes
+            with torch.cuda.stream(net.sampler.side_stream()):
+                net.sampler.prefetch_grid_samples(it + 1)
 
     def _issue(self, target_iter, start_event):
         """draw the batch of iteration `target_iter` and march it on the side stream (behind `start_event` when given)"""
