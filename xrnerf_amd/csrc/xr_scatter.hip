@@ -821,6 +821,10 @@ int xr_scatter3(const float* x, uint32_t x_stride, const float* denc_t, uint32_t
         XR_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
         XR_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
     }
+    // the caller's small kernels (xr_ngp_train_step: reduction of the MLP partials, MLP Adam, loss scalars, a clear) run on the helper
+    // stream BEHIND the dense levels' two kernels: those then start beside the bin kernel instead of 40 us into the accumulate
+    // kernel, whose HBM streams they disturb (scatter 181 -> 172 us, profiles/r03_aux_kernels_last_ab.txt).  XR_SC_AUX_LAST=0: before.
+    static const bool aux_last = s3_env("XR_SC_AUX_LAST", 1) != 0;
     auto launch_rl = [&]() -> int {
         if (P.rl.n_lv == 0) return XR_OK;
         hipStream_t rs = stream;
@@ -828,7 +832,7 @@ int xr_scatter3(const float* x, uint32_t x_stride, const float* denc_t, uint32_t
             XR_HIP(hipEventRecord(ev_fork, stream));
             XR_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
             rs = aux;
-            if (g_aux_prologue && !g_aux_prologue->done) {            // a caller's small kernel that only has to finish by the join
+            if (!aux_last && g_aux_prologue && !g_aux_prologue->done) {   // a caller's small kernels that only have to finish by the join
                 g_aux_prologue->done = true;
                 const int rc = g_aux_prologue->fn(aux, g_aux_prologue->arg);
                 if (rc != XR_OK) return rc;
@@ -839,6 +843,11 @@ int xr_scatter3(const float* x, uint32_t x_stride, const float* denc_t, uint32_t
         XR_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_scatter_fold, dim3(xr_div_up(P.rl.slab_entries, 256)), dim3(256), 0, rs, P.rl, (const float2*)slabs, grad_table);
         XR_LAUNCH_CHECK();
+        if (fork && aux_last && g_aux_prologue && !g_aux_prologue->done) {
+            g_aux_prologue->done = true;
+            const int rc = g_aux_prologue->fn(aux, g_aux_prologue->arg);
+            if (rc != XR_OK) return rc;
+        }
         if (fork) XR_HIP(hipEventRecord(ev_join, aux));
         return XR_OK;
     };
