@@ -13,7 +13,8 @@ ENTRY = {   # entry point -> kernels launched by it (include/xrnerf_mi355.h)
                         'void k_scatter_bin3<4096>', 'void k_scatter_bin3<2048>', 'void k_scatter_bin3<1024>', 'void k_scatter_accum3<13>', 'void k_scatter_accum3<13, 512>', 'void k_scatter_accum3<13, 1024>', 'k_scatter_dense_rl',
                         'k_scatter_fold'],
     'xr_hashgrid_fwd': ['k_hashgrid_fwd'],
-    'xr_nerf_mlp_bwd': ['k_nerf_mlp_bwd_1_2', 'void k_nerf_mlp_bwd_1_2<true>', 'void k_nerf_mlp_bwd_1_2<false>', 'k_reduce_partials'],
+    'xr_nerf_mlp_bwd': ['k_nerf_mlp_bwd_1_2', 'void k_nerf_mlp_bwd_1_2<true>', 'void k_nerf_mlp_bwd_1_2<false>', 'k_reduce_partials'] +
+                       ['void k_nerf_mlp_bwd_1_2<%s, %d>' % (l, m) for l in ('true', 'false') for m in range(4)],
     'xr_live_rows': ['k_live_count', 'k_live_fill'],
     'xr_composite_train': ['k_composite_train', 'k_composite_train_w'],
     'xr_nerf_mlp_fwd': ['void k_nerf_mlp_fwd<1, 2, true>', 'void k_nerf_mlp_fwd_b3<true>'],
