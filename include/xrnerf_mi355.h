@@ -260,7 +260,12 @@ size_t xr_nerf_mlp_bwd_workspace_bytes(uint32_t n);
 /* live_rows / n_live (both or neither): the list xr_live_rows built from `draw`.  The backward then computes exactly the
  * listed rows and leaves the other rows of denc_t UNTOUCHED (pass the same list to xr_hashgrid_bwd).  Without a list
  * the call builds its own in the workspace and writes exact zeros to the dead rows of denc_t (same results as the
- * backward over every row, which XR_MLP_LIVE=0 still runs for measurement). */
+ * backward over every row, which XR_MLP_LIVE=0 still runs for measurement).
+ * Arithmetic (topology (1, 2); XR_MLP_BWD_DW, read per call): the activations are recomputed on the fp32 MFMA; the weight-gradient
+ * products and the gradient chain run on v_mfma_f32_32x32x16_bf16 with every fp32 operand split into two bf16 parts (x = xh + xl,
+ * three products kept: 2^-16 relative per product, gradients within 2e-5 of their scale of the all-fp32 kernel).  "f32": every
+ * product on the fp32 MFMA; "b2": only the weight-gradient products split; "b2x": the default; "b2f": the recompute split as
+ * well (faster, but a hidden unit within ~1e-5 of zero can land on the other side of its ReLU than in the forward). */
 int xr_nerf_mlp_bwd(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
                     const uint32_t* n_dev, const float* w_density, const float* w_color, int n_hidden_density, int n_hidden_color,
                     float pad_value, const float* draw /*[n,4]*/, float* denc_t, float* grad_w_density,
