@@ -331,6 +331,9 @@ __device__ __forceinline__ void dw_stage_one(const f32x16& h, int slot, float* _
 // [in neuron][hi][K-step][8] arrangement of the fp16 kernels; a gradient tile goes from the accumulator layout to the B
 // operands of its two K-steps by a register-local 2-way split (the k-slot permutation is the accumulator layout's own row
 // order, so nothing is transposed).  Per K-step and output tile: two 16-B operand reads and three MFMAs (gl*wh, gh*wl, gh*wh).
+#ifndef B2X_PF
+#define B2X_PF 1            // LDS operand double buffer of the split layers (one K-step ahead); 0 measured the same
+#endif
 struct B2Tile { bw8 p[2][2]; };                                  // [part][K-step]
 __device__ __forceinline__ B2Tile to_b2(const f32x16& t) {
     B2Tile r;
@@ -381,9 +384,6 @@ __device__ __forceinline__ void layer_bwd_b2(const __bf16* __restrict__ wb, int 
 #pragma unroll
         for (int r = 0; r < 16; ++r) gin[ti][r] = 0.f;
     const __bf16* wl = wb + col * RSB + hi * NSO * 8;
-#ifndef B2X_PF
-#define B2X_PF 1
-#endif
     bw8 a[B2X_PF + 1][TI][2];
     auto load = [&](int t, bw8 (&d)[TI][2]) {
 #pragma unroll
