@@ -152,6 +152,11 @@ extern "C" int xr_ngp_train_step(
                              return xr_train_loss_scalars(r->rgb, r->target, r->alpha, r->n_rays, r->delta, r->scale, r->loss, st);
                          }, &ta, false};
     if (reduce_aux) xr_internal_scatter_aux_prologue(&pro);
+    // the mark behind the MLP backward is the last thing on `stream`: the scatter orders its helper stream behind that event instead
+    // of recording one of its own (XR_STEP_SHARE_FORK=0: its own)
+    static const bool share_fork = []() { const char* e = getenv("XR_STEP_SHARE_FORK"); return !(e && e[0] == '0'); }();
+    if (share_fork && mark_event && stage_is(mark_entry, "xr_nerf_mlp_bwd") && !stage_is(timed_entry, "xr_hashgrid_bwd"))
+        xr_internal_scatter_fork_event(mark_event);
     if ((rc = begin("xr_hashgrid_bwd")) != XR_OK) return rc;
     // data-parallel callers scatter the levels below scatter_level0 themselves (xr_hashgrid_bwd with the same row list, found
     // through xr_nerf_mlp_bwd_list_slots) AFTER handing the finer levels' gradient slice to the collective: table offsets are
@@ -165,6 +170,7 @@ extern "C" int xr_ngp_train_step(
                               scale_host + scatter_level0, resolution_host + scatter_level0, offset_host + scatter_level0, grad_table,
                               ws_scatter, ws_scatter_bytes, XR_SCATTER_OVERWRITE, stream_);
     xr_internal_scatter_aux_prologue(nullptr);
+    xr_internal_scatter_fork_event(nullptr);
     if (rc != XR_OK) return rc;
     if (!pro.done && (rc = pro.fn(stream, pro.arg)) != XR_OK) return rc;     // the scatter did not fork (or XR_STEP_REDUCE_AUX=0)
     if ((rc = end("xr_hashgrid_bwd")) != XR_OK) return rc;
