@@ -114,6 +114,9 @@ def test_mlp_backward_arithmetic_modes_on_the_host(O, edev, monkeypatch):
         monkeypatch.setenv('XR_MLP_BWD_DW', arith)
         T.test_nerf_mlp_bwd(O, edev, 100)
         T.test_nerf_mlp_bwd_live_rows(O, edev, 100, None, 'f32')
+    monkeypatch.setenv('XR_MLP_BWD_DW', 'bf16')                 # not a mode: an error, not a silent default
+    with pytest.raises(Exception, match='XR_MLP_BWD_DW'):
+        T.test_nerf_mlp_bwd(O, edev, 32)
     monkeypatch.delenv('XR_MLP_BWD_DW')
     T.test_nerf_mlp_bwd_split_recompute_differs_by_relu_kinks_only(edev, 1200, monkeypatch)
 

@@ -191,6 +191,9 @@ def test_nerf_mlp_bwd(O, dev, n):
 def test_nerf_mlp_bwd_arithmetic_modes(O, dev, arith, monkeypatch):
     """XR_MLP_BWD_DW: the backward with every product on the fp32 MFMA, with the dW products on the bf16 matrix cores (2-way
     operand split), and (the default) with the dX chain there too -- each against the oracle at the same 1e-3 * max bar"""
+    monkeypatch.setenv('XR_MLP_BWD_DW', 'bf16')                 # not a mode: an error, not a silent default
+    with pytest.raises(Exception, match='XR_MLP_BWD_DW'):
+        test_nerf_mlp_bwd(O, dev, 32)
     monkeypatch.setenv('XR_MLP_BWD_DW', arith)
     test_nerf_mlp_bwd(O, dev, 5000)
     test_nerf_mlp_bwd_live_rows(O, dev, 5000, 4100, 'f32')

@@ -1771,7 +1771,9 @@ extern "C" int xr_nerf_mlp_bwd(const float* enc_t, uint32_t ld, const float* dir
     // optimiser, but each such flip is one sample's whole contribution to a weight row, which a 1e-3 * max parity bar on a
     // small batch sees.
     const char* bwd_env = getenv("XR_MLP_BWD_DW");
-    const int mode = !bwd_env ? 2 : strcmp(bwd_env, "f32") == 0 ? 0 : strcmp(bwd_env, "b2") == 0 ? 1 : strcmp(bwd_env, "b2f") == 0 ? 3 : 2;
+    const int mode = !bwd_env ? 2 : strcmp(bwd_env, "f32") == 0 ? 0 : strcmp(bwd_env, "b2") == 0 ? 1 : strcmp(bwd_env, "b2x") == 0 ? 2
+                   : strcmp(bwd_env, "b2f") == 0 ? 3 : -1;
+    if (mode < 0) { xr_set_error("XR_MLP_BWD_DW=%s: expected f32, b2, b2x or b2f", bwd_env); return XR_EINVAL; }
     using KernT = void (*)(const float*, uint32_t, const float*, uint32_t, uint32_t, const uint32_t*, const float*, const float*, float,
                            const float4*, float*, float*, const uint32_t*, const uint32_t*);
     static const KernT kerns[2][4] = {{k_nerf_mlp_bwd_1_2<false, 0>, k_nerf_mlp_bwd_1_2<false, 1>, k_nerf_mlp_bwd_1_2<false, 2>, k_nerf_mlp_bwd_1_2<false, 3>},
