@@ -332,7 +332,7 @@ __device__ __forceinline__ void dw_stage_one(const f32x16& h, int slot, float* _
 // operands of its two K-steps by a register-local 2-way split (the k-slot permutation is the accumulator layout's own row
 // order, so nothing is transposed).  Per K-step and output tile: two 16-B operand reads and three MFMAs (gl*wh, gh*wl, gh*wh).
 #ifndef B2X_PF
-#define B2X_PF 1            // LDS operand double buffer of the split layers (one K-step ahead); 0 measured the same
+#define B2X_PF 1            // LDS operand double buffer of the split layers (one K-step ahead); 0 = none (same register count, not timed)
 #endif
 struct B2Tile { bw8 p[2][2]; };                                  // [part][K-step]
 __device__ __forceinline__ B2Tile to_b2(const f32x16& t) {
