@@ -705,9 +705,9 @@ __global__ __launch_bounds__(LIVE_THREADS) void k_live_fill(const float4* __rest
 // Specialised for the reference topology family NHD = 1, NHC = 2 (density 32->64->16,
 // color 32->64->64->16): every activation and all 12 dW accumulator tiles stay in registers.
 // MODE 0: fp32 MFMA throughout; 1: dW products on the bf16 matrix cores (2-way split); 2 (default): the dX chain as well; 3: and the
-// forward recompute (no fp32 copy of the weights).  LDS per workgroup: fp32 weights 50.2 KB (modes 0-2) | W in two bf16 parts 43.5 KB
-// (mode 3); W^T in two bf16 parts 57.3 KB (modes 2-3); per-wave transposing stage 4 x 16.9 KB (modes 0-1) | 4 x 12.7 KB (modes 2-3):
-// 117.8 / 158.2 / 151.5 KB of the 160.
+// forward recompute (no fp32 copy of the weights).  LDS per workgroup, bytes: fp32 weights 50 176 (modes 0-2) | W in two bf16 parts
+// 43 520 (mode 3); W^T in two bf16 parts 57 344 (modes 2-3); per-wave transposing stage 4 x 16 896 (modes 0-1) | 4 x 12 672 (modes 2-3):
+// 117 760 / 158 208 / 151 552 of the 163 840.
 template <bool LIVE, int MODE>
 __global__ __launch_bounds__(MLP_THREADS, 1) void k_nerf_mlp_bwd_1_2(
     const float* __restrict__ enc_t, uint32_t ld, const float* __restrict__ dirs, uint32_t dir_stride, uint32_t n,
