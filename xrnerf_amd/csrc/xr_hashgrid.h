@@ -22,10 +22,24 @@ struct GridMeta {
     uint32_t n_hashed;            // order 4: levels [n_levels - n_hashed, n_levels) are the hashed list
 };
 
+#ifndef HG_FAST_MOD
+#define HG_FAST_MOD 1
+#endif
 __device__ inline uint32_t grid_index(uint32_t cx, uint32_t cy, uint32_t cz, uint32_t res, uint32_t hsize, bool hashed) {
     uint32_t index;
     if (hashed) index = cx ^ (cy * 2654435761u) ^ (cz * 805459861u);
-    else index = cx + cy * res + cz * res * res;
+    else {
+        index = cx + cy * res + cz * res * res;
+#if HG_FAST_MOD
+        // Dense level: the corner coordinates of a point of the unit cube are <= res, so index <= res^3 + res^2 + res < 2 hsize and
+        // ONE conditional subtraction is the modulo.  A `%` by a runtime value is ~18 instructions per corner, two of them
+        // quarter-rate multiplies -- 150 per (sample, level) on levels whose table sits in the L2, i.e. what those levels cost.
+        // Anything else (a point outside the cube wraps through the unsigned arithmetic) takes the division below: same value.
+        // (Measured: the lookup's span in the loop does not move, 80 vs 81 us -- the dense levels are not bound by this arithmetic.)
+        const uint32_t r = index >= hsize ? index - hsize : index;
+        if (__builtin_expect(r < hsize, 1)) return r;
+#endif
+    }
     return index % hsize;
 }
 // the same for a power-of-two slice (every hashed level of the usual geometries): `% hsize` is a mask -- no reciprocal
