@@ -265,6 +265,10 @@ __device__ __forceinline__ int hslot(int m, int ns) {           // offset of neu
 // rounding of the low parts are below 2^-16 of |g||h| per term -- inside the 1e-3 * max bar the gradients are tested to
 // (tests/test_gpu_tcnn.py::test_nerf_mlp_bwd*).  6 matrix instructions of 8 passes instead of 16 of 16 per output tile.
 typedef __bf16 bw8 __attribute__((ext_vector_type(8)));
+// 2-vectors for the forward's 3-way split (split3_pair below).  The 2-way splits of this kernel stay element by element: written
+// on pairs they are 181 instructions fewer per tile and the kernel is 3 us SLOWER (66 vs 63 us in the loop, one measurement).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split2x8(const float* __restrict__ p, bw8& h, bw8& l) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -1441,14 +1445,28 @@ __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l)
     l = (__bf16)r2;
 }
 struct BTile { b8 p[3][2]; };                // a 32 x 32 tile as B operands: [hi | mid | lo part][K-step]
+// the same split on two values at a time: written on 2-vectors so that every conversion is ONE v_cvt_pk_bf16_f32 for the pair
+// and the differences are packed subtractions (element by element the compiler paired only some of them: 6.1 vector
+// instructions per element against 4.5 -- in a kernel bound by how many instructions a SIMD can issue)
+__device__ __forceinline__ void split3_pair(f32x2 x, bf16x2& h, bf16x2& m, bf16x2& l) {
+    h = __builtin_convertvector(x, bf16x2);
+    const f32x2 r1 = x - __builtin_convertvector(h, f32x2);          // exact
+    m = __builtin_convertvector(r1, bf16x2);
+    const f32x2 r2 = r1 - __builtin_convertvector(m, f32x2);         // exact
+    l = __builtin_convertvector(r2, bf16x2);
+}
 __device__ __forceinline__ BTile to_b3(const f32x16& t) {
     BTile r;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        __bf16 h, m, l;
-        split3(t[e], h, m, l);     r.p[0][0][e] = h; r.p[1][0][e] = m; r.p[2][0][e] = l;
-        split3(t[8 + e], h, m, l); r.p[0][1][e] = h; r.p[1][1][e] = m; r.p[2][1][e] = l;
-    }
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            bf16x2 h, m, l;
+            split3_pair(f32x2{t[8 * k + e], t[8 * k + e + 1]}, h, m, l);
+            r.p[0][k][e] = h[0]; r.p[0][k][e + 1] = h[1];
+            r.p[1][k][e] = m[0]; r.p[1][k][e + 1] = m[1];
+            r.p[2][k][e] = l[0]; r.p[2][k][e + 1] = l[1];
+        }
     return r;
 }
 // global fp32 [out][in] -> LDS, three bf16 parts `ps` halves apart, each in the forward arrangement of store_layer_h
