@@ -366,14 +366,14 @@ int xr_ngp_train_step(const float* table, const float* w_density, const float* w
 /* timed_entry (nullable): the name of ONE of the entry points the step runs ("xr_hashgrid_fwd", "xr_nerf_mlp_fwd",
  * "xr_composite_train", "xr_live_rows", "xr_nerf_mlp_bwd", "xr_hashgrid_bwd"): its launches are bracketed on `stream` by the two
  * events (xr_timing_event_create) -- bench.py's live duration of the dominant kernel inside the timed region.
- * XR_STEP_OVERLAP=1 moves the reduction of the MLP backward's partials to a helper stream (measured slower on the MI355X,
- * kept as a switch). */
+ */
 /* mark_entry / mark_event (nullable): mark_event is recorded on `stream` right behind the launches of the named entry point, so
  * that work on another stream can be started from that point of the step (xr_stream_wait_event). */
 void* xr_timing_event_create(void);
 /* an event for ordering only (no timestamp taken: cheaper to record); destroy / wait with the calls of the timing events */
 void* xr_order_event_create(void);
 int xr_stream_wait_event(void* stream, void* event);
+int xr_event_record(void* event, void* stream);
 int xr_timing_event_destroy(void* event);
 int xr_timing_event_elapsed_ms(void* begin, void* end, float* ms);
 /* the second half of xr_nerf_mlp_bwd[_f16] on its own (sum of the per-workgroup dW partials in `workspace` into the gradients) */
@@ -389,6 +389,70 @@ int xr_ngp_prefetch(const float* rays_rgb_rows, uint32_t n_rays, uint64_t batch_
                     float* coords_out, int32_t* rays_index, int32_t* rays_numsteps, uint32_t* counter2, void* workspace,
                     size_t workspace_bytes, uint32_t max_compacted, int32_t* numsteps_clipped, uint32_t* n_valid_dev,
                     uint32_t* counter_host_pinned, float* xyz_planes, uint32_t plane_stride, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * The training LOOP between two grid refreshes as one call.  The reference's loop is mmcv's IterBasedRunner calling
+ * HashNerfNetwork.train_step once per iteration (xrnerf/core/apis/train.py:58-66, networks/hashnerf.py:32-52) with three hooks
+ * around it (core/hooks/hash_hook.py:12-42).  Driven from an interpreter the enqueue of one iteration costs 0.36 ms of host
+ * time against 0.42 ms of device work; xr_ngp_loop_run enqueues k iterations -- batch draw (xr_make_batch), the march of
+ * iteration i + 2 on the side stream (xr_ngp_prefetch, started behind iteration i's MLP backward), the step with the
+ * optimiser's updates inside (xr_ngp_train_step with its three xr_adam_fuse) -- from native code: same entry points, same
+ * order per stream, same RNG call indices, hence the same parameters bit for bit as k single calls.
+ * It never crosses a grid refresh: an iteration = 0 (mod update_grid_freq) is the caller's (it changes the occupancy bitfield
+ * the marches read and the batch size); marches are not issued across it either, so the queue is empty when the caller takes
+ * over.  Everything is caller-owned; the library keeps only a few events per handle. */
+typedef struct xr_ngp_march_set {      /* one of the THREE rotating sets a marched batch lives in */
+    float *rays_o, *rays_d, *target, *alpha, *bg; int32_t* img_ids;        /* xr_make_batch outputs, >= n_rays rows */
+    float* coords; int32_t *rays_index, *rays_numsteps; uint32_t* counter2; /* K1 outputs (coords: >= max_samples rows of 7) */
+    int32_t* numsteps_clipped; uint32_t* n_valid;                           /* K2's clipped counts, device count of valid rows */
+    float* xyz_planes; uint32_t plane_stride;                               /* nullable: positions as planes */
+} xr_ngp_march_set;
+typedef struct xr_ngp_step_set {       /* one of the TWO alternating sets of step buffers (see xr_ngp_train_step) */
+    float *enc_t, *raw, *draw, *denc_t, *rgb_out, *zero_block; size_t zero_floats;
+    float *grad_w_density, *grad_w_color, *loss_mse; uint32_t* live_seg_count;
+} xr_ngp_step_set;
+typedef struct xr_ngp_loop_desc {
+    float *table, *w_density, *w_color; int n_hidden_density, n_hidden_color; float pad_value; int mlp_mode;
+    int n_levels; const float* scale_host; const uint32_t *resolution_host, *offset_host;
+    xr_adam_fuse adam_table, adam_w_density, adam_w_color;  /* tensors and constants; step / lr / ema_momentum are set per iteration */
+    const float* rays_rgb_rows; uint64_t n_table_rays; uint64_t batch_seed;   /* device-resident [n_table_rays, 11] ray table */
+    const uint8_t* bitfield; float aabb0, aabb1, near_distance, cone_angle;
+    uint32_t max_samples, max_compacted;                   /* K1's row capacity, K2's clip (= n_rows of the step) */
+    const float* density_grid_mean; int rgb_activation, density_activation; float huber_delta, loss_scale;
+    uint32_t n_rows, ld;
+    xr_ngp_march_set march[3]; xr_ngp_step_set step[2];
+    void* ws_k1; size_t ws_k1_bytes; void* ws_mlp_bwd; size_t ws_mlp_bwd_bytes; void* ws_scatter; size_t ws_scatter_bytes;
+    uint32_t* counter_host_pinned; uint32_t n_pinned;      /* ring of n_pinned (rays, samples) pairs in pinned host memory */
+    void *stream, *side_stream;
+    void* bitfield_event;                                  /* nullable: recorded behind the last writer of `bitfield` */
+    void* mark_event;                                      /* xr_order_event_create: recorded behind every step's MLP backward */
+} xr_ngp_loop_desc;
+typedef struct xr_ngp_loop_state {     /* the counters the loop shares with its caller (read AND written) */
+    uint64_t iter;                     /* next iteration */
+    uint64_t k1_calls, batches_drawn, cur_ray;   /* RNG call indices of K1 / the batch generator, cursor into the ray table */
+    uint32_t march_launches;           /* training launches of K1 so far: the next one takes set (march_launches + 1) % 3 */
+    uint32_t step_turn;                /* the next step takes set step_turn ^ 1 */
+    int32_t adam_step;                 /* updates applied so far */
+    uint32_t pinned_next;              /* next slot of the pinned ring */
+    uint32_t queued;                   /* marches issued ahead: iterations iter .. iter + queued - 1 (0, 1 or 2) */
+    uint32_t queue_set[2];             /* ... and the sets they live in */
+    uint32_t last_march_set, last_step_set;   /* (out) the sets iteration iter - 1 used */
+} xr_ngp_loop_state;
+void* xr_ngp_loop_create(void);
+int xr_ngp_loop_destroy(void* loop);
+/* k iterations iter .. iter + k - 1, none of them = 0 (mod update_grid_freq); n_rays = this window's batch size;
+ * lr / ema_momentum: k values each (the schedules are the caller's).  ext_done_prev2 / ext_done_prev1 (nullable): events the
+ * CALLER recorded on `stream` at the end of iterations iter - 2 / iter - 1 when it ran those itself (a march overwrites the set
+ * iteration i - 3 read: it is ordered behind the end of i - 1); null = the loop's own record of that iteration.
+ * timed_entry + timing_events [2k] (nullable): one entry point of every step bracketed by a pair of timing events;
+ * iter_events [k + 1] (nullable): timing events recorded on `stream` in front of every iteration and behind the last. */
+/* hand-over with a caller that issues marches itself: the event behind the march in `set` (to wait on), and its record on the side
+ * stream for a march the caller enqueued there earlier */
+void* xr_ngp_loop_march_event(void* loop, uint32_t set);
+int xr_ngp_loop_adopt_march(void* loop, uint32_t set, void* side_stream);
+int xr_ngp_loop_run(void* loop, const xr_ngp_loop_desc* desc, xr_ngp_loop_state* state, uint32_t k, uint32_t n_rays,
+                    uint32_t update_grid_freq, const float* lr, const float* ema_momentum, void* ext_done_prev2, void* ext_done_prev1,
+                    const char* timed_entry, void* const* timing_events, void* const* iter_events);
 
 /* tcnn.Network(FullyFusedMLP) on its own (compatibility surface; the hot path uses the fused kernels above):
  * x [n, n_in] with arbitrary row / column strides (in floats), n_in <= 32, missing input columns = pad_value;

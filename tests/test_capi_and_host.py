@@ -230,3 +230,26 @@ def test_product_never_touches_the_oracle():
                  lambda: ops.linear_forward(torch.zeros(8, 8), torch.zeros(8, 8), None, False)):
         with pytest.raises(_lib.XrError):
             call()
+
+
+def test_struct_layouts_of_the_loop_api_match_the_header(tmp_path):
+    """the ctypes mirrors of xr_adam_fuse / xr_ngp_march_set / xr_ngp_step_set / xr_ngp_loop_desc / xr_ngp_loop_state have the C
+    compiler's size and field offsets (gcc on include/xrnerf_mi355.h; a mismatch would hand the native loop garbage pointers)"""
+    from xrnerf_amd import _lib
+    structs = {'xr_adam_fuse': _lib.AdamFuse, 'xr_ngp_march_set': _lib.MarchSet, 'xr_ngp_step_set': _lib.StepSet,
+               'xr_ngp_loop_desc': _lib.LoopDesc, 'xr_ngp_loop_state': _lib.LoopState}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "xrnerf_mi355.h"', 'int main(void) {']
+    for cname, cls in structs.items():
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines.append('return 0; }')
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in structs.items():
+        assert int(got[cname]) == __import__('ctypes').sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got['%s.%s' % (cname, fname)]) == getattr(cls, fname).offset, '%s.%s' % (cname, fname)

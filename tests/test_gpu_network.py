@@ -341,3 +341,80 @@ def test_march_two_iterations_ahead_leaves_the_trajectory_alone(dev, monkeypatch
     for a, b in zip(pa, pb):
         assert torch.equal(a, b)
     assert torch.equal(ga, gb) and torch.equal(ba, bb)
+
+
+def _trainer_state(tr):
+    table = tr.net.mlp.embedder_pos.params
+    st = tr.opt.state[table]
+    return ([p.detach().clone() for p in tr.net.parameters()] + [st['m'].clone(), st['v'].clone(), st['ema'].clone()],
+            (st['step'], tr.iter, tr.net.sampler.k1_calls, tr.net.sampler.k6_calls, tr.data.batches_drawn, tr.data.cur_i,
+             tr.net.sampler.n_rays_per_batch, tr.rays_done, tr.samples_done),
+            tr.net.sampler.density_grid.clone(), tr.net.sampler.density_grid_bitfield.clone())
+
+
+def test_native_loop_between_refreshes_equals_the_per_iteration_path(dev, monkeypatch):
+    """xr_ngp_loop_run enqueues the iterations between two grid refreshes from native code (batch draw, march two iterations ahead,
+    step with the updates inside).  41 iterations -- refreshes at 0, 16, 32, two batch-size updates -- as (a) per-iteration Python
+    path, (b) Trainer.run over whole windows, (c) single step() calls that go through the native loop one iteration at a time,
+    (d) windows cut at odd places with a multi-stage KernelTimer forcing the per-iteration path in between (marched batches are
+    handed over in both directions): parameters, Adam moments, EMA copies, occupancy grids, every RNG / batch counter and the
+    logged loss of the last iteration bit for bit."""
+    from xrnerf_amd import ops
+    from xrnerf_amd.train import Trainer
+    out = []
+    for mode in ('python', 'run', 'step', 'mixed'):
+        monkeypatch.setenv('XRNERF_NATIVE_LOOP', '0' if mode == 'python' else '1')
+        tr = Trainer(dev, n_img=3, H=128, W=128, seed=7)
+        assert tr.native_loop == (mode != 'python')
+        if mode in ('python', 'step'):
+            for _ in range(41):
+                last = tr.step()
+        elif mode == 'run':
+            tr.run(7)
+            tr.run(30)
+            last = tr.run(4)
+        else:
+            tr.run(5)                                         # 0 (Python) + 1..4 native: marches for 5, 6 are queued natively
+            ops.TIMER = ops.KernelTimer(only={'xr_hashgrid_fwd', 'xr_nerf_mlp_fwd'}, train_only=True)     # two stages: per-iteration path
+            try:
+                tr.run(3)                                     # 5, 6, 7 through Python (takes the native queue over, issues 8, 9 itself)
+            finally:
+                ops.TIMER = None
+            tr.run(2)                                         # 8, 9 native again (adopts the Python queue)
+            ops.TIMER = ops.KernelTimer(only={'xr_hashgrid_bwd'}, train_only=True)                         # one stage: stays native
+            try:
+                tr.run(20)
+                torch.cuda.synchronize()
+                n_timed, ms, _ = ops.TIMER.summary()['xr_hashgrid_bwd']
+                assert n_timed == 20 and 0.0 < ms < 200.0
+            finally:
+                ops.TIMER = None
+            for _ in range(10):
+                tr.step()
+            last = tr.step()
+        if mode != 'python':
+            assert tr._loop is not None
+        torch.cuda.synchronize()
+        out.append(_trainer_state(tr) + (float(last['loss']), float(last['log_vars']['psnr'])))
+    ref = out[0]
+    assert ref[1][1] == 41
+    for o in out[1:]:
+        assert o[1] == ref[1]
+        for a, b in zip(o[0], ref[0]):
+            assert torch.equal(a, b)
+        assert torch.equal(o[2], ref[2]) and torch.equal(o[3], ref[3])
+        assert o[4] == ref[4] and o[5] == ref[5]
+
+
+def test_native_loop_iteration_events_bracket_every_iteration(dev):
+    """Trainer.run(k, iter_events=...) records one timing event in front of every iteration and one behind the last, on both paths"""
+    from xrnerf_amd import ops
+    from xrnerf_amd.train import Trainer
+    tr = Trainer(dev, n_img=3, H=128, W=128, seed=2)
+    tr.run(14)
+    ev = [ops._CEvent() for _ in range(6)]
+    tr.run(5, iter_events=ev)                                # 14, 15 native, 16 per-iteration (refresh), 17, 18 native
+    torch.cuda.synchronize()
+    ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(5)]
+    assert all(0.0 < m < 100.0 for m in ms)
+    assert ms[2] > max(ms[0], ms[1])                          # the refresh iteration is the long one

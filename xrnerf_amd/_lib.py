@@ -20,6 +20,43 @@ class AdamFuse(C.Structure):
                 ('ema_momentum', C.c_float), ('grad_scale', C.c_float), ('n', C.c_uint64)]
 
 
+class MarchSet(C.Structure):
+    """xr_ngp_march_set"""
+    _fields_ = [(k, C.c_void_p) for k in ('rays_o', 'rays_d', 'target', 'alpha', 'bg', 'img_ids', 'coords', 'rays_index', 'rays_numsteps',
+                                          'counter2', 'numsteps_clipped', 'n_valid', 'xyz_planes')] + [('plane_stride', C.c_uint32)]
+
+
+class StepSet(C.Structure):
+    """xr_ngp_step_set"""
+    _fields_ = [(k, C.c_void_p) for k in ('enc_t', 'raw', 'draw', 'denc_t', 'rgb_out', 'zero_block')] + [('zero_floats', C.c_size_t)] + \
+               [(k, C.c_void_p) for k in ('grad_w_density', 'grad_w_color', 'loss_mse', 'live_seg_count')]
+
+
+class LoopDesc(C.Structure):
+    """xr_ngp_loop_desc"""
+    _fields_ = [('table', C.c_void_p), ('w_density', C.c_void_p), ('w_color', C.c_void_p), ('n_hidden_density', C.c_int),
+                ('n_hidden_color', C.c_int), ('pad_value', C.c_float), ('mlp_mode', C.c_int), ('n_levels', C.c_int),
+                ('scale_host', C.c_void_p), ('resolution_host', C.c_void_p), ('offset_host', C.c_void_p),
+                ('adam_table', AdamFuse), ('adam_w_density', AdamFuse), ('adam_w_color', AdamFuse),
+                ('rays_rgb_rows', C.c_void_p), ('n_table_rays', C.c_uint64), ('batch_seed', C.c_uint64),
+                ('bitfield', C.c_void_p), ('aabb0', C.c_float), ('aabb1', C.c_float), ('near_distance', C.c_float), ('cone_angle', C.c_float),
+                ('max_samples', C.c_uint32), ('max_compacted', C.c_uint32),
+                ('density_grid_mean', C.c_void_p), ('rgb_activation', C.c_int), ('density_activation', C.c_int),
+                ('huber_delta', C.c_float), ('loss_scale', C.c_float), ('n_rows', C.c_uint32), ('ld', C.c_uint32),
+                ('march', MarchSet * 3), ('step', StepSet * 2),
+                ('ws_k1', C.c_void_p), ('ws_k1_bytes', C.c_size_t), ('ws_mlp_bwd', C.c_void_p), ('ws_mlp_bwd_bytes', C.c_size_t),
+                ('ws_scatter', C.c_void_p), ('ws_scatter_bytes', C.c_size_t),
+                ('counter_host_pinned', C.c_void_p), ('n_pinned', C.c_uint32),
+                ('stream', C.c_void_p), ('side_stream', C.c_void_p), ('bitfield_event', C.c_void_p), ('mark_event', C.c_void_p)]
+
+
+class LoopState(C.Structure):
+    """xr_ngp_loop_state"""
+    _fields_ = [('iter', C.c_uint64), ('k1_calls', C.c_uint64), ('batches_drawn', C.c_uint64), ('cur_ray', C.c_uint64),
+                ('march_launches', C.c_uint32), ('step_turn', C.c_uint32), ('adam_step', C.c_int32), ('pinned_next', C.c_uint32),
+                ('queued', C.c_uint32), ('queue_set', C.c_uint32 * 2), ('last_march_set', C.c_uint32), ('last_step_set', C.c_uint32)]
+
+
 SIGNATURES = {
     'xr_last_error': (C.c_char_p, []),
     'xr_version': (_i32, []),
@@ -62,6 +99,12 @@ SIGNATURES = {
     'xr_ngp_train_step': (_i32, [_vp, _vp, _vp, _i32, _i32, _f, _i32, _i32, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _u32, _vp, _vp, _vp,
                                  _vp, _i32, _i32, _f, _f, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp, _sz,
                                  _vp, _sz, _i32, _vp, _u32, _vp, _vp, _vp, C.c_char_p, _vp, C.c_char_p, _vp, _vp, _vp]),
+    'xr_ngp_loop_create': (_vp, []),
+    'xr_ngp_loop_destroy': (_i32, [_vp]),
+    'xr_ngp_loop_march_event': (_vp, [_vp, _u32]),
+    'xr_ngp_loop_adopt_march': (_i32, [_vp, _u32, _vp]),
+    'xr_event_record': (_i32, [_vp, _vp]),
+    'xr_ngp_loop_run': (_i32, [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, C.c_char_p, _vp, _vp]),
     'xr_timing_event_create': (_vp, []),
     'xr_order_event_create': (_vp, []),
     'xr_stream_wait_event': (_i32, [_vp, _vp]),

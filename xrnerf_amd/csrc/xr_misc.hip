@@ -12,11 +12,11 @@ void xr_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* xr_last_error(void) { return g_err; }
-extern "C" int xr_version(void) { return 100; }
+extern "C" int xr_version(void) { return 110; }    // 110: xr_ngp_loop_* added, xr_ngp_train_step / xr_ngp_prefetch signatures of round 3
 
 extern "C" void xr_pcg32_host_state(uint64_t seed, uint64_t ncalls, uint64_t* state_host, uint64_t* inc_host) {
     xr_pcg32 r; r.seed(seed, 1u);
-    for (uint64_t c = 0; c < ncalls; ++c) r.advance(1ull << 32);
+    r.advance(ncalls << 32);      // (one advance by the summed distance: the generator is a group action, 2^64 its period)
     *state_host = r.state; *inc_host = r.inc;
 }
 

@@ -33,6 +33,13 @@ extern "C" int xr_stream_wait_event(void* stream, void* event) {
     return XR_OK;
 }
 
+// record an event of this library on a stream (callers without a HIP binding: bench.py's per-iteration boundary events)
+extern "C" int xr_event_record(void* event, void* stream) {
+    XR_REQUIRE(event, "null event");
+    XR_HIP(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+    return XR_OK;
+}
+
 static bool stage_is(const char* timed, const char* name) { return timed && strcmp(timed, name) == 0; }
 
 extern "C" int xr_ngp_train_step(
@@ -200,5 +207,133 @@ extern "C" int xr_ngp_prefetch(const float* rays_rgb_rows, uint32_t n_rays, uint
     if (rc != XR_OK) return rc;
     if (counter_host_pinned)
         XR_HIP(hipMemcpyAsync(counter_host_pinned, counter2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream_));
+    return XR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ the loop between two refreshes
+// k iterations of the trainer's steady state as one call (contract: include/xrnerf_mi355.h, xr_ngp_loop_run).  What one iteration
+// enqueues, and where -- the same as xrnerf_amd.train.Trainer.step drives through Python (the trajectory test compares the two):
+//   main stream   wait(march of `it` done) -> xr_ngp_train_step(updates inside; mark behind the MLP backward) -> record done(it)
+//   side stream   [wait(bitfield), wait(done(it - 1)), wait(mark(it))] -> xr_ngp_prefetch for it + 2 -> record march-done
+//                 -> copy of K1's counter to the pinned ring
+// A march is never issued across a refresh (iterations = 0 mod f re-write the bitfield it reads and change the batch size): the
+// first iteration after a refresh is marched as soon as it is known ("at once"), the second behind the mark of the iteration the
+// caller just ran, all others two iterations ahead.
+struct XrLoop {
+    hipEvent_t march_done[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t iter_done[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t done_prev[2] = {nullptr, nullptr};          // end of iterations iter - 2, iter - 1 (own or the caller's)
+};
+
+extern "C" void* xr_ngp_loop_create(void) {
+    XrLoop* L = new XrLoop();
+    for (int i = 0; i < 3; ++i)
+        if (hipEventCreateWithFlags(&L->march_done[i], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&L->iter_done[i], hipEventDisableTiming) != hipSuccess) { delete L; return nullptr; }
+    return L;
+}
+extern "C" int xr_ngp_loop_destroy(void* loop) {
+    if (!loop) return XR_OK;
+    XrLoop* L = (XrLoop*)loop;
+    for (int i = 0; i < 3; ++i) { if (L->march_done[i]) (void)hipEventDestroy(L->march_done[i]); if (L->iter_done[i]) (void)hipEventDestroy(L->iter_done[i]); }
+    delete L;
+    return XR_OK;
+}
+
+// Hand-over between this loop and a caller that issues marches itself (Trainer's per-iteration path): the event the main stream waits
+// on for a march in `set` -- (a) handed out so that the caller can wait for a march this loop issued, (b) recorded on the side
+// stream NOW for a march the caller issued there earlier (the stream is in order: the record sits behind that march).
+extern "C" void* xr_ngp_loop_march_event(void* loop, uint32_t set) { return (loop && set < 3u) ? (void*)((XrLoop*)loop)->march_done[set] : nullptr; }
+extern "C" int xr_ngp_loop_adopt_march(void* loop, uint32_t set, void* side_stream) {
+    XR_REQUIRE(loop && set < 3u, "bad set");
+    XR_HIP(hipEventRecord(((XrLoop*)loop)->march_done[set], (hipStream_t)side_stream));
+    return XR_OK;
+}
+
+// the march of iteration `target` on the side stream: mirror of NGPGridSampler.prefetch_native + Trainer._issue
+static int xr_loop_issue_march(XrLoop* L, const xr_ngp_loop_desc& D, xr_ngp_loop_state& S, uint32_t n_rays, hipEvent_t buffer_free, hipEvent_t start) {
+    hipStream_t side = (hipStream_t)D.side_stream;
+    if (D.bitfield_event) XR_HIP(hipStreamWaitEvent(side, (hipEvent_t)D.bitfield_event, 0));
+    if (buffer_free) XR_HIP(hipStreamWaitEvent(side, buffer_free, 0));
+    if (start) XR_HIP(hipStreamWaitEvent(side, start, 0));
+    const uint32_t set = (++S.march_launches) % 3u;
+    const xr_ngp_march_set& M = D.march[set];
+    if (S.cur_ray + n_rays > D.n_table_rays) S.cur_ray = 0;
+    int rc = xr_ngp_prefetch(D.rays_rgb_rows + (size_t)S.cur_ray * 11, n_rays, D.batch_seed, S.batches_drawn, M.rays_o, M.rays_d, M.target, M.alpha,
+                             M.bg, M.img_ids, D.bitfield, D.aabb0, D.aabb1, D.near_distance, D.cone_angle, D.max_samples, S.k1_calls, M.coords,
+                             M.rays_index, M.rays_numsteps, M.counter2, D.ws_k1, D.ws_k1_bytes, D.max_compacted, M.numsteps_clipped, M.n_valid,
+                             nullptr, M.xyz_planes, M.plane_stride, side);
+    if (rc != XR_OK) return rc;
+    S.cur_ray += n_rays; S.batches_drawn += 1; S.k1_calls += 1;
+    // the main stream waits for the MARCH only: the event sits in front of the counter's device-to-host copy
+    XR_HIP(hipEventRecord(L->march_done[set], side));
+    if (D.counter_host_pinned) {
+        XR_HIP(hipMemcpyAsync(D.counter_host_pinned + 2u * (S.pinned_next % D.n_pinned), M.counter2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, side));
+        S.pinned_next += 1;
+    }
+    S.queue_set[S.queued] = set;
+    S.queued += 1;
+    return XR_OK;
+}
+
+extern "C" int xr_ngp_loop_run(void* loop, const xr_ngp_loop_desc* desc, xr_ngp_loop_state* state, uint32_t k, uint32_t n_rays,
+                               uint32_t update_grid_freq, const float* lr, const float* ema_momentum, void* ext_done_prev2, void* ext_done_prev1,
+                               const char* timed_entry, void* const* timing_events, void* const* iter_events) {
+    XR_REQUIRE(loop && desc && state && lr && ema_momentum, "null pointer");
+    XrLoop* L = (XrLoop*)loop;
+    const xr_ngp_loop_desc& D = *desc;
+    xr_ngp_loop_state& S = *state;
+    const uint32_t f = update_grid_freq;
+    XR_REQUIRE(f >= 2 && k >= 1 && n_rays >= 1 && n_rays <= D.n_table_rays, "bad sizes");
+    XR_REQUIRE(S.iter % f != 0 && (S.iter % f) + (uint64_t)k <= (uint64_t)f, "the window crosses a grid refresh (an iteration = 0 mod update_grid_freq is the caller's)");
+    XR_REQUIRE(S.queued <= 2 && D.mark_event && D.stream != D.side_stream && D.n_pinned >= 1, "bad loop state");
+    XR_REQUIRE(!timed_entry || timing_events, "a timed entry point needs its events");
+    XR_REQUIRE(D.adam_table.param == D.table && D.adam_w_density.param == D.w_density && D.adam_w_color.param == D.w_color, "the updates name the step's tensors");
+    hipStream_t stream = (hipStream_t)D.stream;
+    if (ext_done_prev1) { L->done_prev[0] = ext_done_prev2 ? (hipEvent_t)ext_done_prev2 : L->done_prev[1]; L->done_prev[1] = (hipEvent_t)ext_done_prev1; }
+    else if (ext_done_prev2) L->done_prev[0] = (hipEvent_t)ext_done_prev2;
+    int rc;
+    // marches the caller's iteration left to this loop (it runs refresh iterations without issuing any: see Trainer): iteration `iter`
+    // at once (ordered behind the end of iter - 2, as if issued during iter - 1), iter + 1 behind the mark of iter - 1
+    if (S.queued == 0) {
+        if ((rc = xr_loop_issue_march(L, D, S, n_rays, L->done_prev[0], nullptr)) != XR_OK) return rc;
+        if ((S.iter + 1) % f != 0 && k >= 1)
+            if ((rc = xr_loop_issue_march(L, D, S, n_rays, L->done_prev[0], (hipEvent_t)D.mark_event)) != XR_OK) return rc;
+    }
+    xr_adam_fuse at = D.adam_table, ad = D.adam_w_density, ac = D.adam_w_color;
+    for (uint32_t j = 0; j < k; ++j) {
+        const uint64_t it = S.iter;
+        if (iter_events) XR_HIP(hipEventRecord((hipEvent_t)iter_events[j], stream));
+        XR_REQUIRE(S.queued >= 1, "no march queued for this iteration");
+        const uint32_t mset = S.queue_set[0];
+        S.queue_set[0] = S.queue_set[1]; S.queued -= 1;
+        const xr_ngp_march_set& M = D.march[mset];
+        XR_HIP(hipStreamWaitEvent(stream, L->march_done[mset], 0));
+        S.step_turn ^= 1u;
+        const xr_ngp_step_set& B = D.step[S.step_turn & 1u];
+        S.adam_step += 1;
+        at.step = ad.step = ac.step = S.adam_step;
+        at.lr = ad.lr = ac.lr = lr[j];
+        at.ema_momentum = ad.ema_momentum = ac.ema_momentum = ema_momentum[j];
+        rc = xr_ngp_train_step(D.table, D.w_density, D.w_color, D.n_hidden_density, D.n_hidden_color, D.pad_value, D.mlp_mode, D.n_levels, D.scale_host,
+                               D.resolution_host, D.offset_host, M.coords, D.n_rows, M.n_valid, M.rays_numsteps, M.numsteps_clipped, n_rays, M.bg, M.target,
+                               M.alpha, D.density_grid_mean, D.rgb_activation, D.density_activation, D.huber_delta, D.loss_scale, B.enc_t, D.ld, B.raw,
+                               B.draw, B.denc_t, B.rgb_out, B.zero_block, B.zero_floats, B.grad_w_density, B.grad_w_color, B.loss_mse, B.live_seg_count,
+                               nullptr, 0, 0, D.ws_mlp_bwd, D.ws_mlp_bwd_bytes, D.ws_scatter, D.ws_scatter_bytes, 0, M.xyz_planes, M.plane_stride, &at,
+                               &ad, &ac, "xr_nerf_mlp_bwd", D.mark_event, timed_entry, timed_entry ? timing_events[2 * j] : nullptr,
+                               timed_entry ? timing_events[2 * j + 1] : nullptr, D.stream);
+        if (rc != XR_OK) return rc;
+        // Trainer._on_sampled, depth 2: iteration it + 1 at once if nothing is queued for it, then it + 2 behind this step's mark
+        if (S.queued == 0 && (it + 1) % f != 0)
+            if ((rc = xr_loop_issue_march(L, D, S, n_rays, L->done_prev[1], nullptr)) != XR_OK) return rc;
+        if (S.queued == 1 && (it + 1) % f != 0 && (it + 2) % f != 0)
+            if ((rc = xr_loop_issue_march(L, D, S, n_rays, L->done_prev[1], (hipEvent_t)D.mark_event)) != XR_OK) return rc;
+        hipEvent_t done = L->iter_done[it % 3u];
+        XR_HIP(hipEventRecord(done, stream));
+        L->done_prev[0] = L->done_prev[1]; L->done_prev[1] = done;
+        S.last_march_set = mset; S.last_step_set = S.step_turn & 1u;
+        S.iter = it + 1;
+    }
+    if (iter_events) XR_HIP(hipEventRecord((hipEvent_t)iter_events[k], stream));
     return XR_OK;
 }

@@ -403,6 +403,11 @@ def ngp_train_step(table, wd, wc, nhd, nhc, pad_value, meta, coords, n_dev, nums
     return bufs.rgb[:n_rays]
 
 
+def record_event(cevent):
+    """record a library event (_CEvent) on the current stream"""
+    _lib.check(_lib.load().xr_event_record(cevent.h, _stream()), 'xr_event_record')
+
+
 def stream_wait_event(stream, cevent):
     """order a torch stream behind a library event (_CEvent)"""
     _lib.check(_lib.load().xr_stream_wait_event(C.c_void_p(stream.cuda_stream), cevent.h), 'xr_stream_wait_event')

@@ -491,7 +491,7 @@ class NGPGridSampler(_FastAttr, nn.Module):
         done.record(side)
         host = self._count_to_host(out[3])
         self.__dict__.setdefault('_prefetched_q', []).append({'rays_o': batch['rays_o'], 'max_samples': max_samples, 'out': out,
-                                                              'event': done, 'host': host, 'clipped': clipped, 'xyz': xyz})
+                                                              'event': done, 'host': host, 'clipped': clipped, 'xyz': xyz, 'slot': slot})
         return batch
 
     def _count_to_host(self, counter):

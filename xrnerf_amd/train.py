@@ -11,9 +11,11 @@ import math
 import numpy as np
 import os
 
+import ctypes as C
+
 import torch
 
-from . import ops, synthetic
+from . import _lib, ops, synthetic
 from .builder import build_network
 from .datasets import DeviceRayTable
 
@@ -265,13 +267,77 @@ class Trainer:
         if self.prefetch_depth == 2 and self.net._step_mark is None and device.type == 'cuda':
             self.net._step_mark = ('xr_nerf_mlp_bwd', ops._CEvent(timing=False))
         self.prefetch_k6 = os.environ.get('XRNERF_PREFETCH_K6', '1') != '0'      # the refresh's K6 one iteration early, on the side stream
-        self._ev_done = [None, None]   # completion events of the last two iterations
+        self._ev_done = [None, None]   # completion events of the last two iterations (None: the native loop ran it and holds the event)
+        # the iterations between two grid refreshes as native calls (xr_ngp_loop_run: batch draw, march two iterations ahead, step with the
+        # updates inside, enqueued from C++ -- the interpreter had been pacing the loop at 0.36 ms of host work per 0.42-ms iteration).
+        # Needs what the fast Python path needs (one GPU, fused updates, the direct step, the native side-stream march, a device-resident
+        # ray table); anything else keeps the per-iteration path.  XRNERF_NATIVE_LOOP=0: off.
+        self.native_loop = os.environ.get('XRNERF_NATIVE_LOOP', '1') != '0'
+        self._loop = None
         self._bbufs = [None, None, None]
         self._queue = []               # [(iteration, batch)] marched ahead, in order
         self._one = None
 
     def step(self):
+        if self._native_ok() and self.iter % self.net.sampler.update_grid_freq != 0 and hasattr(self.net.sampler, 'density_grid'):
+            return self._run_native(1)
+        return self._step_py()
+
+    def run(self, k, iter_events=None):
+        """k iterations.  `iter_events` (k + 1 ops._CEvent timing events, optional): recorded on the compute stream in front of every
+        iteration and behind the last (bench.py's per-iteration device times)."""
+        out, done = None, 0
+        f = self.net.sampler.update_grid_freq
+        while done < k:
+            if self._native_ok() and self.iter % f != 0 and hasattr(self.net.sampler, 'density_grid'):
+                n = min(k - done, f - self.iter % f)
+                out = self._run_native(n, iter_events[done:done + n + 1] if iter_events is not None else None)
+            else:
+                n = 1
+                if iter_events is not None:
+                    ops.record_event(iter_events[done])
+                out = self._step_py()
+                if iter_events is not None:
+                    ops.record_event(iter_events[done + 1])
+            done += n
+        return out
+
+    def _native_ok(self):
+        st = getattr(self, '_native_static', None)
+        if st is None:
+            from .mlps import HashNerfMLP
+            from .renders import HashNerfRender
+            from .samplers import NGPGridSampler
+            net = self.net
+            st = self._native_static = bool(
+                self.native_loop and self.world_size == 1 and self.fuse_adam and self.direct_step and self.overlap_march and
+                self.prefetch_depth == 2 and self.device.type == 'cuda' and hasattr(self.data, 'rays_rgb') and
+                type(net.sampler) is NGPGridSampler and type(net.mlp) is HashNerfMLP and type(net.render) is HashNerfRender and
+                net.mlp.density_net.n_hidden == 1 and net.mlp.color_net.n_hidden == 2 and self._data_takes_batches() and
+                isinstance(self.opt, FusedAdam) and os.environ.get('XRNERF_XYZ_PLANES', '1') != '0')
+        if not st or getattr(self.net, 'grad_sync', None) is not None:
+            return False
+        if os.environ.get('XRNERF_PY_STEP') == '1' or os.environ.get('XRNERF_MODULAR_STEP') == '1':
+            return False
+        if ops.TIMER is not None and not ops.TIMER.native_stage()[0]:
+            return False
+        return True
+
+    def _data_takes_batches(self):
+        if getattr(self, '_data_takes_out', None) is None:
+            import inspect
+            self._data_takes_out = 'out' in inspect.signature(self.data.next_batch).parameters
+        return self._data_takes_out
+
+    def _run_native(self, k, iter_events=None):
+        if self._loop is None:
+            self._loop = _NativeLoop(self)
+        return self._loop.run(k, iter_events)
+
+    def _step_py(self):
         net, data = self.net, self.data
+        if self._loop is not None and self._loop.state.queued:
+            self._loop.release_to_python()                                # marches the native loop issued ahead: this path's queue now
         net.sampler.set_iter(self.iter)                                   # PassSamplerIterHook
         for g in self.opt.param_groups:
             g['lr'] = step_lr(self.base_lr, self.iter)
@@ -318,6 +384,7 @@ class Trainer:
             ev = torch.cuda.Event()
             ev.record()                                   # (the current stream; torch.cuda.current_stream() alone costs ~10 us)
             self._ev_done = [self._ev_done[1], ev]
+            self._ev_last = ev
         return out
 
     def _on_sampled(self):
@@ -331,6 +398,10 @@ class Trainer:
         if not self.overlap_march:
             return
         it, f = self.iter, net.sampler.update_grid_freq
+        if self._native_ok() and hasattr(net.sampler, 'density_grid') and not self._queue and (it + 1) % f != 0:
+            # the native loop runs the next iteration: it issues the marches of it + 1 (at once) and it + 2 (behind this step's mark)
+            # itself when it starts -- the same launches in the same order on the side stream, enqueued a few microseconds later
+            return
         queued = self._queue[-1][0] if self._queue else it            # the last iteration that already has its march
         mark = getattr(net, '_step_mark', None)
         if self.prefetch_depth == 2 and mark is not None and mark[0] == 'xr_nerf_mlp_bwd':
@@ -351,7 +422,9 @@ class Trainer:
         """draw the batch of iteration `target_iter` and march it on the side stream (behind `start_event` when given)"""
         net, data = self.net, self.data
         side = net.sampler.side_stream()
-        bufs = self._batch_buffers(target_iter % 3, data.N_rand)
+        # the batch lives in the set the sampler's next training launch of K1 writes (one ring of three sets for both, shared with the
+        # native loop: a marched batch is handed between the two paths by its set index)
+        bufs = self._batch_buffers((getattr(net.sampler, '_train_launches', 0) + 1) % 3, data.N_rand)
         if bufs is not None and hasattr(data, 'rays_rgb') and os.environ.get('XRNERF_PY_STEP') != '1':
             # the whole side-stream sequence (batch assembly, K1, K2 clip, counter copy) as one native call
             n = min(data.N_rand, data.rays_rgb.shape[0])
@@ -359,7 +432,7 @@ class Trainer:
                 data.cur_i = 0
             with torch.cuda.stream(side):
                 nb = net.sampler.prefetch_native(data.rays_rgb[data.cur_i:data.cur_i + n], n, data.batches_drawn, bufs,
-                                                 buffer_free_event=self._ev_done[1], start_event=start_event)
+                                                 buffer_free_event=self._last_done(), start_event=start_event)
             data.cur_i += n
             data.batches_drawn += 1
             self._queue.append((target_iter, nb))
@@ -367,13 +440,17 @@ class Trainer:
         with torch.cuda.stream(side):
             # these launches overwrite batch / coordinate buffers last read three iterations before their own (three persistent
             # sets, rotating): ordered behind the completion event of the previous iteration
-            if self._ev_done[1] is not None:
-                side.wait_event(self._ev_done[1])
+            if self._last_done() is not None:
+                side.wait_event(self._last_done())
             if start_event is not None:
                 ops.stream_wait_event(side, start_event)
             nb = data.next_batch(out=bufs) if bufs is not None else data.next_batch()
-            net.sampler.prefetch(nb, buffer_free_event=self._ev_done[1])
+            net.sampler.prefetch(nb, buffer_free_event=self._last_done())
         self._queue.append((target_iter, nb))
+
+    def _last_done(self):
+        """event at the end of the latest iteration, whichever path ran it (`_ev_done` holds None for the native loop's iterations)"""
+        return self._ev_done[1] if self._ev_done[1] is not None else getattr(self, '_ev_last', None)
 
     def _batch_buffers(self, slot, n):
         """persistent output buffers of the batch kernel for prefetched batches (None: the dataset cannot use them)"""
@@ -392,6 +469,250 @@ class Trainer:
     @property
     def samples_done(self):
         return self.net.sampler.total_valid_samples()
+
+
+class _LibEvent:
+    """a library-owned event seen through the two methods the sampler uses on a torch event"""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    def wait(self):
+        _lib.check(_lib.load().xr_stream_wait_event(ops._stream(), self.h), 'xr_stream_wait_event')
+
+
+class _NativeLoop:
+    """Host side of xr_ngp_loop_run (include/xrnerf_mi355.h): builds the descriptor from the trainer's, the sampler's and the
+    optimiser's persistent buffers, mirrors the counters both paths share, and hands marched batches over when the per-iteration
+    path takes an iteration in between (a grid refresh, a timer that wants events around several entry points)."""
+
+    N_PINNED = 64
+
+    def __init__(self, tr):
+        L = _lib.load()
+        self.tr, self.h = tr, L.xr_ngp_loop_create()
+        if not self.h:
+            raise _lib.XrError('xr_ngp_loop_create failed')
+        self.state = _lib.LoopState()
+        self.pinned = torch.zeros((self.N_PINNED, 2), dtype=torch.int32).pin_memory()
+        self.issued = []                   # (object with .synchronize(), host [2] view) of the marches issued and not yet consumed, in order
+        self._keep = None
+
+    def __del__(self):
+        try:
+            _lib.load().xr_ngp_loop_destroy(self.h)
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
+    # ------------------------------------------------------------------ counters shared with the per-iteration path
+    def _pull(self):
+        tr, S = self.tr, self.state
+        sampler, data, net = tr.net.sampler, tr.data, tr.net
+        S.iter, S.k1_calls, S.batches_drawn, S.cur_ray = tr.iter, sampler.k1_calls, data.batches_drawn, data.cur_i
+        S.march_launches = getattr(sampler, '_train_launches', 0) % 3
+        S.step_turn = getattr(net, '_step_turn', 0) & 1
+        S.adam_step = self._adam_steps()[0]
+
+    def _push(self, k, n_rays):
+        tr, S = self.tr, self.state
+        sampler, data, net = tr.net.sampler, tr.data, tr.net
+        tr.iter, data.batches_drawn, data.cur_i = int(S.iter), int(S.batches_drawn), int(S.cur_ray)
+        sampler.__dict__['k1_calls'] = int(S.k1_calls)
+        sampler._train_launches = int(S.march_launches)
+        net._step_turn = int(S.step_turn)
+        for st in self._adam_states():
+            st['step'] = int(S.adam_step)
+        tr.rays_done += k * n_rays
+        tr._ev_done = [None, None] if k >= 2 else [tr._ev_done[1], None]
+        tr._ev_last = torch.cuda.Event()
+        tr._ev_last.record()                        # (for a march the per-iteration path may issue next)
+
+    def _adam_states(self):
+        tr = self.tr
+        mlp = tr.net.mlp
+        out = []
+        for p in (mlp.embedder_pos.params, mlp.density_net.params, mlp.color_net.params):
+            grp = [g for g in tr.opt.param_groups if any(q is p for q in g['params'])]
+            if not grp:
+                raise _lib.XrError('the native loop needs the three NGP tensors in the trainer\'s FusedAdam')
+            out.append(tr.opt._state(p, grp[0]))
+        self._group = grp[0]
+        return out
+
+    def _adam_steps(self):
+        steps = [st['step'] for st in self._adam_states()]
+        if len(set(steps)) != 1:
+            raise _lib.XrError('the three NGP tensors have different optimiser step counts: %r' % (steps,))
+        return steps
+
+    # ------------------------------------------------------------------ hand-over of marched batches
+    def _sets(self, n_rays, max_samples):
+        """the three rotating sets as the per-iteration path sees them: [(batch buffers, coords, (rays_index, numsteps, counter), (clipped, n_valid), xyz)]"""
+        tr = self.tr
+        sampler = tr.net.sampler
+        return [(tr._batch_buffers(i, n_rays), sampler._coords_buffer(max_samples, i), sampler._small_buffers(n_rays, i),
+                 sampler._clip_buffers(n_rays, i), sampler._xyz_buffer(max_samples, i)) for i in range(3)]
+
+    def _max_samples(self, n_rays):
+        sampler = self.tr.net.sampler
+        m = sampler.num_coords_elements if getattr(sampler, 'reference_buffer_rows', False) else max(sampler.num_coords_elements, n_rays * 64)
+        return min(m, n_rays * sampler.MAX_STEP)
+
+    def adopt_from_python(self):
+        """marches the per-iteration path issued ahead become this loop's"""
+        tr, S = self.tr, self.state
+        sampler = tr.net.sampler
+        q = sampler.__dict__.get('_prefetched_q') or []
+        if len(q) != len(tr._queue) or len(q) > 2 or any('slot' not in pf for pf in q):
+            raise _lib.XrError('cannot hand these marched batches to the native loop')
+        side = sampler.side_stream()
+        for i, pf in enumerate(q):
+            S.queue_set[i] = pf['slot']
+            _lib.check(_lib.load().xr_ngp_loop_adopt_march(self.h, pf['slot'], C.c_void_p(side.cuda_stream)), 'xr_ngp_loop_adopt_march')
+            self.issued.append(pf['host'])
+        S.queued = len(q)
+        del q[:]
+        del tr._queue[:]
+
+    def release_to_python(self):
+        """marches this loop issued ahead become the per-iteration path's (same buffers: the rings are shared)"""
+        tr, S = self.tr, self.state
+        sampler, data = tr.net.sampler, tr.data
+        n = min(data.N_rand, data.rays_rgb.shape[0])
+        ms = self._max_samples(n)
+        sets = self._sets(n, ms)
+        L = _lib.load()
+        for i in range(int(S.queued)):
+            si = int(S.queue_set[i])
+            bb, coords, small, clip, xyz = sets[si]
+            batch = {'rays_o': bb['rays_o'][:n], 'rays_d': bb['rays_d'][:n], 'target_s': bb['target_s'][:n], 'alpha': bb['alpha'][:n],
+                     'img_ids': bb['img_ids'][:n], 'bg_color': bb['bg_color'][:n]}
+            sampler.__dict__.setdefault('_prefetched_q', []).append(
+                {'rays_o': batch['rays_o'], 'max_samples': ms, 'out': (coords, small[0], small[1], small[2]),
+                 'event': _LibEvent(L.xr_ngp_loop_march_event(self.h, si)), 'host': self.issued[i], 'clipped': clip, 'xyz': xyz, 'slot': si})
+            tr._queue.append((tr.iter + i, batch))
+        del self.issued[:int(S.queued)]
+        S.queued = 0
+
+    # ------------------------------------------------------------------ one window
+    def run(self, k, iter_events=None):
+        tr, S, L = self.tr, self.state, _lib.load()
+        net, data = tr.net, tr.data
+        sampler, mlp = net.sampler, net.mlp
+        f = sampler.update_grid_freq
+        if tr.iter % f == 0 or tr.iter % f + k > f:
+            raise _lib.XrError('a native window never crosses a grid refresh')
+        dev = tr.device
+        self._pull()
+        if tr._queue or sampler.__dict__.get('_prefetched_q'):
+            self.adopt_from_python()
+        n_rays = min(data.N_rand, data.rays_rgb.shape[0])
+        max_samples = self._max_samples(n_rays)
+        n_rows = min(sampler.target_batch_size, max_samples)
+        table, wd, wc = mlp.embedder_pos.params, mlp.density_net.params, mlp.color_net.params
+        meta = mlp.embedder_pos.meta
+        sets = getattr(net, '_step_bufs', None)
+        if (sets is None or sets[0].n_rows != n_rows or sets[0].ray_cap < n_rays or sets[0].g_table.shape != table.shape
+                or sets[0].g_table.device != table.device):
+            sets = net._step_bufs = [ops.TrainStepBuffers(dev, n_rows, max(n_rays, 1 << 15), table.numel(), wd.numel(), wc.numel(), meta)
+                                     for _ in range(2)]
+            net._step_turn = S.step_turn = 0
+        if not ops.hashgrid_bwd_adam_supported(n_rows, meta):
+            raise _lib.XrError('the fused table update has no non-atomic scatter path at this row capacity')
+        D = _lib.LoopDesc()
+        vp = lambda t: t.data_ptr() if t is not None else None
+        D.table, D.w_density, D.w_color = vp(table), vp(wd), vp(wc)
+        D.n_hidden_density, D.n_hidden_color, D.pad_value, D.mlp_mode = 1, 2, float(mlp.pad_value), ops._mlp_mode(1, 2)
+        s_, r_, o_ = meta._args()
+        D.n_levels, D.scale_host, D.resolution_host, D.offset_host = meta.n_levels, s_, r_, o_
+        states = self._adam_states()
+        g = self._group
+        for name, p, st in zip(('adam_table', 'adam_w_density', 'adam_w_color'), (table, wd, wc), states):
+            ema = st.get('ema') if g['ema_momentum'] is not None else None
+            a = ops.adam_fuse(p.data, st['m'], st['v'], ema, 0, 0.0, g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], 0.0, 1.0)
+            setattr(D, name, a)
+        rows = data.rays_rgb
+        D.rays_rgb_rows, D.n_table_rays, D.batch_seed = vp(rows), rows.shape[0], 20220901
+        D.bitfield = vp(sampler.density_grid_bitfield)
+        D.aabb0, D.aabb1 = float(sampler.aabb_range[0]), float(sampler.aabb_range[1])
+        D.near_distance, D.cone_angle = float(sampler.near_distance), float(sampler.cone_angle_constant)
+        D.max_samples, D.max_compacted = max_samples, sampler.target_batch_size
+        D.density_grid_mean = vp(sampler.density_grid_mean)
+        D.rgb_activation, D.density_activation, D.huber_delta, D.loss_scale = int(sampler.rgb_activation), int(sampler.density_activation), 0.1, 5.0
+        D.n_rows, D.ld = n_rows, sets[0].ld
+        msets = self._sets(n_rays, max_samples)
+        for i, (bb, coords, small, clip, xyz) in enumerate(msets):
+            M = D.march[i]
+            M.rays_o, M.rays_d, M.target, M.alpha, M.bg, M.img_ids = (vp(bb[q]) for q in ('rays_o', 'rays_d', 'target_s', 'alpha', 'bg_color', 'img_ids'))
+            M.coords, M.rays_index, M.rays_numsteps, M.counter2 = vp(coords), vp(small[0]), vp(small[1]), vp(small[2])
+            M.numsteps_clipped, M.n_valid = vp(clip[0]), vp(clip[1])
+            M.xyz_planes, M.plane_stride = vp(xyz), (xyz.shape[1] if xyz is not None else 0)
+        for i, b in enumerate(sets):
+            B = D.step[i]
+            B.enc_t, B.raw, B.draw, B.denc_t, B.rgb_out, B.zero_block = vp(b.enc_t), vp(b.raw), vp(b.draw), vp(b.denc_t), vp(b.rgb), vp(b.zero_block)
+            B.zero_floats = b.zero_block.numel()
+            B.grad_w_density, B.grad_w_color, B.loss_mse, B.live_seg_count = vp(b.g_wd), vp(b.g_wc), vp(b.loss_mse), vp(b.live_seg)
+        with torch.cuda.stream(sampler.side_stream()):                   # (allocated in the side stream's pool, like the per-iteration path's)
+            ws_k1 = ops._ws(dev, L.xr_rays_sampler_workspace_bytes(n_rays), 'k1_side')
+        ws_mlp, live_list, _, live_stats = ops._list_slots(dev, n_rows)
+        ws_sc = ops._ws(dev, L.xr_hashgrid_bwd_workspace_bytes(n_rows, meta.n_levels, r_, o_), 'hgb')
+        D.ws_k1, D.ws_k1_bytes, D.ws_mlp_bwd, D.ws_mlp_bwd_bytes = vp(ws_k1), ws_k1.numel(), vp(ws_mlp), ws_mlp.numel()
+        D.ws_scatter, D.ws_scatter_bytes = vp(ws_sc), ws_sc.numel()
+        D.counter_host_pinned, D.n_pinned = self.pinned.data_ptr(), self.N_PINNED
+        side = sampler.side_stream()
+        D.stream, D.side_stream = ops._stream(), side.cuda_stream
+        bev = getattr(sampler, '_bitfield_event', None)
+        D.bitfield_event = bev.cuda_event if bev is not None else None
+        mark = getattr(net, '_step_mark', None)
+        if mark is None or mark[0] != 'xr_nerf_mlp_bwd':
+            raise _lib.XrError('the native loop marches two iterations ahead (XRNERF_PREFETCH_DEPTH=2)')
+        D.mark_event = mark[1].h
+        self._keep = (D, msets, sets, ws_k1, ws_mlp, ws_sc, bev)
+        # the schedules are this trainer's: lr per iteration, the EMA momentum of mmcv's EMAHook per update
+        lr = (C.c_float * k)(*[step_lr(tr.base_lr, tr.iter + j) for j in range(k)])
+        mom = (C.c_float * k)(*[(FusedAdam._ema_momentum(g, int(S.adam_step) + 1 + j) if g['ema_momentum'] is not None else 0.0) for j in range(k)])
+        ext = [e.cuda_event if e is not None else None for e in tr._ev_done]
+        stage, tev, tarr = None, None, None
+        if ops.TIMER is not None:
+            ok, stage = ops.TIMER.native_stage()
+            if not ok:
+                raise _lib.XrError('this KernelTimer needs the per-entry-point launch sequence')
+            if stage is not None:
+                tev = [ops._CEvent() for _ in range(2 * k)]
+                tarr = (C.c_void_p * (2 * k))(*[e.h for e in tev])
+        iarr = (C.c_void_p * (k + 1))(*[e.h for e in iter_events]) if iter_events is not None else None
+        pinned0 = int(S.pinned_next)
+        ops.LIVE_STATS = live_stats
+        sets[0].live = sets[1].live = (live_list, live_stats) if os.environ.get('XR_MLP_LIVE') != '0' else None
+        rc = L.xr_ngp_loop_run(self.h, C.byref(D), C.byref(S), k, n_rays, f, lr, mom, ext[0], ext[1], stage.encode() if stage else None, tarr, iarr)
+        if rc != 0:
+            _lib.check(rc, 'xr_ngp_loop_run')
+        if stage is not None:
+            ops.TIMER.events.setdefault(stage, []).extend((tev[2 * j], tev[2 * j + 1], 0) for j in range(k))
+        for q in range(pinned0, int(S.pinned_next)):
+            self.issued.append((side, self.pinned[q % self.N_PINNED]))
+        sampler._pending_counts.extend(self.issued[:k])       # the k iterations consumed the k oldest marches
+        del self.issued[:k]
+        self._push(k, n_rays)
+        # the sampler's public state = the last iteration's (what a reader between two steps sees on the per-iteration path too)
+        last = tr.iter - 1
+        bb, coords, small, clip, xyz = msets[int(S.last_march_set)]
+        sampler.iter_n = last
+        sampler.coords, sampler.xyz = coords[:n_rows], xyz
+        sampler.rays_index, sampler.rays_numsteps, sampler.rays_numsteps_compacted = small[0], small[1], clip[0]
+        sampler.n_valid_dev = clip[1][0:1]
+        b = sets[int(S.last_step_set)]
+        net._last = {'rgb': b.rgb[:n_rays], 'loss_mse': b.loss_mse, 'raw': b.raw}
+        if last % f == f - 1:
+            sampler.update_batch_rays(True, max_samples)                  # drains the 16 counters (waits for the side stream's copies)
+            if tr.prefetch_k6 and hasattr(sampler, 'prefetch_grid_samples'):
+                with torch.cuda.stream(side):
+                    sampler.prefetch_grid_samples(last + 1)
+        data.set_batchsize(sampler.n_rays_per_batch)                      # ModifyBatchsizeHook
+        from .networks import _LazyPsnr
+        loss = b.loss_mse[0:1].reshape(())
+        return {'loss': loss, 'log_vars': {'loss': loss, 'psnr': _LazyPsnr(b.loss_mse, n_rays)}, 'num_samples': n_rays,
+                'grads_ready': True, 'updates_applied': True}
 
 
 @torch.no_grad()
