@@ -287,8 +287,7 @@ def ngp_f16_mlp_mode(dev, n_img, steps):
         sampler = tr.net.sampler
         pre, hist = 0, [sampler.n_rays_per_batch]
         while pre < PREROLL_MAX:
-            for _ in range(16):
-                tr.step()
+            tr.run(16)
             pre += 16
             hist.append(sampler.n_rays_per_batch)
             if pre >= PREROLL_MIN and len(hist) >= 3 and abs(hist[-1] - hist[-2]) <= 0.02 * hist[-2] and abs(hist[-2] - hist[-3]) <= 0.02 * hist[-3]:
@@ -296,13 +295,13 @@ def ngp_f16_mlp_mode(dev, n_img, steps):
         freq = sampler.update_grid_freq
         want = max(1, int(round(steps / float(freq))))
         first_off = max(0, min(freq - 1, (steps - 1 - (want - 1) * freq) // 2))
-        for _ in range(((-tr.iter) % freq - first_off) % freq):
-            tr.step()
+        align = ((-tr.iter) % freq - first_off) % freq
+        if align:
+            tr.run(align)
         torch.cuda.synchronize()
         r0, s0, it0 = tr.rays_done, tr.samples_done, tr.iter
         t0 = time.perf_counter()
-        for _ in range(steps):
-            tr.step()
+        tr.run(steps)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         rays, samples = tr.rays_done - r0, tr.samples_done - s0
@@ -393,17 +392,14 @@ def ngp_real_lego_fixture(dev, steps=64):
     ds = datasets.HashNerfDataset(dict(datadir=datadir, half_res=False, testskip=1, white_bkgd=False, load_alpha=True,
                                        N_rand_per_sampler=4096, mode='train', val_n=2), device=dev)
     tr = Trainer(dev, dataset=ds)
-    for _ in range(512):
-        tr.step()
-    for _ in range((-tr.iter) % tr.net.sampler.update_grid_freq + 1):
-        tr.step()
+    tr.run(512)
+    tr.run((-tr.iter) % tr.net.sampler.update_grid_freq + 1)
     if ops.LIVE_STATS is not None:
         ops.LIVE_STATS[1:3].zero_()
     torch.cuda.synchronize()
     r0, s0 = tr.rays_done, tr.samples_done
     t0 = time.perf_counter()
-    for _ in range(steps):
-        tr.step()
+    tr.run(steps)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     live, valid = (int(v) & 0xffffffff for v in ops.LIVE_STATS[1:3].tolist()) if ops.LIVE_STATS is not None else (0, 0)
@@ -643,8 +639,7 @@ def main():
     preroll, hist = 0, [sampler.n_rays_per_batch]
     if not args.no_preroll:
         while preroll < PREROLL_MAX:
-            for _ in range(16):
-                tr.step()
+            tr.run(16)
             preroll += 16
             hist.append(sampler.n_rays_per_batch)
             stable = (len(hist) >= 3 and abs(hist[-1] - hist[-2]) <= 0.02 * hist[-2]
@@ -654,8 +649,8 @@ def main():
                 torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
             if float(flag) > 0:
                 break
-    for _ in range(args.warmup):
-        tr.step()
+    if args.warmup:
+        tr.run(args.warmup)
     # the window's phase against the every-16th grid refresh is fixed, not left to --warmup: K timed steps contain
     # round(K / 16) refresh iterations (at least one), the nearest integer to the long-run share; the count is reported
     freq = sampler.update_grid_freq
@@ -663,8 +658,8 @@ def main():
     # the first refresh falls `first_off` steps into the window, the slack split evenly before the first and after the last
     first_off = max(0, min(freq - 1, (args.steps - 1 - (want - 1) * freq) // 2))
     align = ((-tr.iter) % freq - first_off) % freq            # un-timed iterations that put the window at that phase
-    for _ in range(align):
-        tr.step()
+    if align:
+        tr.run(align)
     # which entry point dominates the step?  16 un-timed iterations with events around every training launch (the phase
     # alignment above is redone afterwards); the timed region then carries events around THAT kernel only
     ops.TIMER = ops.KernelTimer(only=set(ALGO), train_only=True)
@@ -679,13 +674,12 @@ def main():
     if ops.LIVE_STATS is not None:
         ops.LIVE_STATS[1:3].zero_()            # running (live rows, valid rows) totals of the backward's row list
     rays0, samples0, it0 = tr.rays_done, tr.samples_done, tr.iter
-    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # one event per iteration boundary
+    step_ev = [ops._CEvent() for _ in range(args.steps + 1)]     # one event per iteration boundary
     barrier()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        step_ev[k].record()
-        tr.step()
-    step_ev[args.steps].record()
+    # (Trainer.run: the iterations between two grid refreshes are enqueued by one native call each, xr_ngp_loop_run -- the events in
+    # front of every iteration and around the dominant entry point are recorded by that call)
+    tr.run(args.steps, iter_events=step_ev)
     barrier()
     elapsed = time.perf_counter() - t0
     timer, ops.TIMER = ops.TIMER, None

@@ -13,11 +13,16 @@ for rep in range(3):
     while tr.iter % 16 != 1: tr.step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(N): tr.step()
+    if os.environ.get('HT_STEP') == '1':
+        for _ in range(N): tr.step()        # one call per iteration (still the native loop unless XRNERF_NATIVE_LOOP=0)
+    else:
+        tr.run(N)                           # one native window
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     print('host enqueue %.3f ms/step   total (host + drain) %.3f ms/step' % ((t1 - t0) * 1e3 / N, (t2 - t0) * 1e3 / N), flush=True)
+if os.environ.get('HT_PROFILE') != '1':
+    sys.exit(0)
 import cProfile, pstats
 while tr.iter % 16 != 1: tr.step()
 torch.cuda.synchronize()
