@@ -20,7 +20,10 @@ for rep in range(3):
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
-    print('host enqueue %.3f ms/step   total (host + drain) %.3f ms/step' % ((t1 - t0) * 1e3 / N, (t2 - t0) * 1e3 / N), flush=True)
+    print('host (incl. the window-end counter drain, which waits for the side stream) %.3f ms/step   total (host + drain) %.3f ms/step' % ((t1 - t0) * 1e3 / N, (t2 - t0) * 1e3 / N), flush=True)
+    if tr._loop is not None and tr._loop.enqueued:
+        print('   inside xr_ngp_loop_run: %.4f ms/iteration over %d iterations' % (tr._loop.enqueue_s * 1e3 / tr._loop.enqueued, tr._loop.enqueued), flush=True)
+        tr._loop.enqueue_s, tr._loop.enqueued = 0.0, 0
 if os.environ.get('HT_PROFILE') != '1':
     sys.exit(0)
 import cProfile, pstats

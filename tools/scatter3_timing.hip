@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cmath>
 void xr_set_error(const char*, ...) {}
+extern "C" int xr_device_cus(void) { return 256; }
 extern "C" void xr_hashgrid_meta(int n_levels, int log2_hashmap_size, int base_resolution, double per_level_scale, float* scale,
                                  uint32_t* resolution, uint32_t* offset) {
     const float log2b = log2f((float)per_level_scale);
@@ -63,25 +64,47 @@ int main(int argc, char** argv) {
         printf("fused optimiser update ON\n");
     }
     hipFuncSetAttribute((const void*)k_scatter_accum3<13, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES);
+    hipFuncSetAttribute((const void*)k_scatter_accum3<13, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES);
+    hipFuncSetAttribute((const void*)k_scatter_accum4<13, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES);
     hipEvent_t a, b, c; hipEventCreate(&a); hipEventCreate(&b); hipEventCreate(&c);
-    for (int rep = 0; rep < 4; ++rep) {
-        hipEventRecord(a);
-        hipLaunchKernelGGL(k_scatter_bin3<2048>, dim3(P.bin.n_lv * P.bin.nsb), dim3(S3_BIN_THREADS), 0, 0, P.bin, dx, 3u, dd, n, 1u << 18, ndev,
-                           (const uint32_t*)nullptr, counts, bins, ovf);
-        hipEventRecord(b);
-        hipLaunchKernelGGL((k_scatter_accum3<13, 1024>), dim3(P.bin.acc_blocks), dim3(1024), S3_LDS_BYTES, 0, P.bin, (const uint32_t*)counts,
-                           (const float4*)bins, (const float4*)ovf, tab);
-        hipEventRecord(c); hipEventSynchronize(c);
-        float m1, m2; hipEventElapsedTime(&m1, a, b); hipEventElapsedTime(&m2, b, c);
-        long long t[S3_T_BLOCKS][8]; hipMemcpyFromSymbol(t, HIP_SYMBOL(g_s3_t), sizeof(t));
-        printf("bin3 %.1f us  accum3 %.1f us\n", m1 * 1e3, m2 * 1e3);
-        if (rep < 3) continue;
-        long long t0 = t[0][0];
-        for (int w = 0; w < S3_T_BLOCKS; ++w) {
-            auto us = [&](int i, int j) { return (t[w][j] - t[w][i]) / 100.0; };
-            printf("  wg %3d: start +%6.2f | fills %.2f  first fetch issued %.2f  zero+sync %.2f  loop %.2f  overflow check %.2f+sync  write %.2f | whole %.2f us\n",
-                   w * 96, (t[w][0] - t0) / 100.0, us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(5, 6), us(0, 6));
+    // kind 3: one workgroup per partition (1024 threads, then 512); kind 4 / 5: the persistent kernel, static round robin / tickets,
+    // with 256 (one per CU) workgroups
+    struct Form { const char* name; int kind, threads; } forms[] = {{"accum3 x1024", 3, 1024}, {"accum3 x512", 3, 512},
+                                                                      {"accum4 static", 4, 512}, {"accum4 tickets", 5, 512}};
+    for (const Form& f : forms) {
+        float best1 = 1e9f, best2 = 1e9f;
+        for (int rep = 0; rep < 6; ++rep) {
+            S3Plan pb = P.bin;
+            pb.ticket_off = f.kind == 5 ? P.ticket_word : 0xffffffffu;
+            hipEventRecord(a);
+            hipLaunchKernelGGL(k_scatter_bin3<2048>, dim3(pb.n_lv * pb.nsb), dim3(S3_BIN_THREADS), 0, 0, pb, dx, 3u, dd, n, 1u << 18, ndev,
+                               (const uint32_t*)nullptr, counts, bins, ovf);
+            hipEventRecord(b);
+            if (f.kind == 3 && f.threads == 1024)
+                hipLaunchKernelGGL((k_scatter_accum3<13, 1024>), dim3(pb.acc_blocks), dim3(1024), S3_LDS_BYTES, 0, pb, (const uint32_t*)counts,
+                                   (const float4*)bins, (const float4*)ovf, tab);
+            else if (f.kind == 3)
+                hipLaunchKernelGGL((k_scatter_accum3<13, 512>), dim3(pb.acc_blocks), dim3(512), S3_LDS_BYTES, 0, pb, (const uint32_t*)counts,
+                                   (const float4*)bins, (const float4*)ovf, tab);
+            else
+                hipLaunchKernelGGL((k_scatter_accum4<13, 512>), dim3(pb.acc_blocks < 256u ? pb.acc_blocks : 256u), dim3(512), S3_LDS_BYTES, 0, pb, counts,
+                                   (const float4*)bins, (const float4*)ovf, tab);
+            hipEventRecord(c); hipEventSynchronize(c);
+            float m1, m2; hipEventElapsedTime(&m1, a, b); hipEventElapsedTime(&m2, b, c);
+            if (rep >= 2) { best1 = m1 < best1 ? m1 : best1; best2 = m2 < best2 ? m2 : best2; }
         }
+        printf("%-16s bin3 %.1f us  accumulate %.1f us (best of 4)\n", f.name, best1 * 1e3, best2 * 1e3);
+#ifdef S3_TIMING
+        if (f.kind == 3 && f.threads == 1024) {
+            long long t[S3_T_BLOCKS][8]; hipMemcpyFromSymbol(t, HIP_SYMBOL(g_s3_t), sizeof(t));
+            long long t0 = t[0][0];
+            for (int w = 0; w < S3_T_BLOCKS; ++w) {
+                auto us = [&](int i, int j) { return (t[w][j] - t[w][i]) / 100.0; };
+                printf("  wg %3d: start +%6.2f | fills %.2f  first fetch issued %.2f  zero+sync %.2f  loop %.2f  overflow check %.2f+sync  write %.2f | whole %.2f us\n",
+                       w * 96, (t[w][0] - t0) / 100.0, us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(5, 6), us(0, 6));
+            }
+        }
+#endif
     }
     return 0;
 }

@@ -12,6 +12,7 @@ import numpy as np
 import os
 
 import ctypes as C
+import time
 
 import torch
 
@@ -495,6 +496,7 @@ class _NativeLoop:
             raise _lib.XrError('xr_ngp_loop_create failed')
         self.state = _lib.LoopState()
         self.pinned = torch.zeros((self.N_PINNED, 2), dtype=torch.int32).pin_memory()
+        self.enqueue_s, self.enqueued = 0.0, 0
         self.issued = []                   # (object with .synchronize(), host [2] view) of the marches issued and not yet consumed, in order
         self._keep = None
 
@@ -684,7 +686,10 @@ class _NativeLoop:
         pinned0 = int(S.pinned_next)
         ops.LIVE_STATS = live_stats
         sets[0].live = sets[1].live = (live_list, live_stats) if os.environ.get('XR_MLP_LIVE') != '0' else None
+        t_enq = time.perf_counter()
         rc = L.xr_ngp_loop_run(self.h, C.byref(D), C.byref(S), k, n_rays, f, lr, mom, ext[0], ext[1], stage.encode() if stage else None, tarr, iarr)
+        self.enqueue_s += time.perf_counter() - t_enq                    # host time inside the native call (tools/hosttime2.py)
+        self.enqueued += k
         if rc != 0:
             _lib.check(rc, 'xr_ngp_loop_run')
         if stage is not None:
