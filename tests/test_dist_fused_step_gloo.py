@@ -76,6 +76,9 @@ with emulib.emulated_ops() as edev:
                 torch.autograd.backward(o['loss'], grad_tensors=one)
             else:
                 o['loss'].backward()
+            if net is dp3:                                           # zero1: the table gradient goes to the reduce-scatter, not to .grad
+                assert net.mlp.embedder_pos.params.grad is None
+                continue
             grads[tag] = {n: getattr(net.mlp, n).params.grad.detach().clone() for n in names}
         assert dp2._pending_grad_scale == 0.5
         for n in names:                                              # the deferred form holds the SUM: mean = sum / 2 exactly

@@ -32,13 +32,3 @@ def test_scatter_generation_3_against_the_oracle(n, mode):
 def test_scatter_switches_give_the_same_gradients(n, mode, env):
     run(n, mode, **env)
 
-
-@pytest.mark.parametrize('n,mode,env', [(5000, 'rays', dict(XR_SC_ACC='3')), (5000, 'cluster', dict(XR_SC_ACC='5')),
-                                        (9000, 'rays', dict(XR_SC_ACC='5', XR_SC_ACC_PER_CU='3'))])
-def test_accumulate_kernel_forms_give_the_same_gradients(n, mode, env):
-    """XR_SC_ACC: 4 (default, the cases above) = the persistent accumulate kernel with a static round robin over the partitions -- the
-    emulated device has 2 CUs, so every workgroup walks hundreds of partitions --, 5 = tickets from a device counter, 3 = one workgroup
-    per partition (round 3's kernel)"""
-    out = run(n, mode, **env)
-    assert out.count('levels out of tolerance: []') == 7, out
-    assert 'identical to scatter + optimiser launch: True' in out, out

@@ -1,4 +1,4 @@
-// phase timing of the third-generation accumulate kernel (k_scatter_accum3<13, 1024>) on ray-like samples (20 consecutive steps of
+// phase timing of the third-generation accumulate kernel (k_scatter_accum3<S3_LOG2, 1024>) on ray-like samples (20 consecutive steps of
 // sqrt(3)/1024 per ray), all 16 levels of the Lego geometry: wall_clock64 (100 MHz) stamps of workgroups 0, 96, 192, ... + event
 // times of the kernels.  build + run on the GPU box:
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -ffp-contract=off -mllvm -simplifycfg-sink-common=false -DS3_TIMING \
@@ -63,31 +63,24 @@ int main(int argc, char** argv) {
         P.bin.ad = XrAdamArgs{st[0], st[1], st[2], st[3], 0.9f, 0.99f, 1e-2f, 0.1f, 1e-15f, 1e-6f, 0.05f, 1.f};
         printf("fused optimiser update ON\n");
     }
-    hipFuncSetAttribute((const void*)k_scatter_accum3<13, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES);
-    hipFuncSetAttribute((const void*)k_scatter_accum3<13, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES);
-    hipFuncSetAttribute((const void*)k_scatter_accum4<13, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES);
+    hipFuncSetAttribute((const void*)k_scatter_accum3<S3_LOG2, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES);
+    hipFuncSetAttribute((const void*)k_scatter_accum3<S3_LOG2, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES);
     hipEvent_t a, b, c; hipEventCreate(&a); hipEventCreate(&b); hipEventCreate(&c);
-    // kind 3: one workgroup per partition (1024 threads, then 512); kind 4 / 5: the persistent kernel, static round robin / tickets,
-    // with 256 (one per CU) workgroups
-    struct Form { const char* name; int kind, threads; } forms[] = {{"accum3 x1024", 3, 1024}, {"accum3 x512", 3, 512},
-                                                                      {"accum4 static", 4, 512}, {"accum4 tickets", 5, 512}};
+    // one workgroup per partition, 1024 threads, then 512 (the persistent forms of round 4: commit "Scatter: persistent accumulate kernel")
+    struct Form { const char* name; int kind, threads; } forms[] = {{"accum3 x1024", 3, 1024}, {"accum3 x512", 3, 512}};
     for (const Form& f : forms) {
         float best1 = 1e9f, best2 = 1e9f;
         for (int rep = 0; rep < 6; ++rep) {
             S3Plan pb = P.bin;
-            pb.ticket_off = f.kind == 5 ? P.ticket_word : 0xffffffffu;
             hipEventRecord(a);
             hipLaunchKernelGGL(k_scatter_bin3<2048>, dim3(pb.n_lv * pb.nsb), dim3(S3_BIN_THREADS), 0, 0, pb, dx, 3u, dd, n, 1u << 18, ndev,
                                (const uint32_t*)nullptr, counts, bins, ovf);
             hipEventRecord(b);
             if (f.kind == 3 && f.threads == 1024)
-                hipLaunchKernelGGL((k_scatter_accum3<13, 1024>), dim3(pb.acc_blocks), dim3(1024), S3_LDS_BYTES, 0, pb, (const uint32_t*)counts,
-                                   (const float4*)bins, (const float4*)ovf, tab);
-            else if (f.kind == 3)
-                hipLaunchKernelGGL((k_scatter_accum3<13, 512>), dim3(pb.acc_blocks), dim3(512), S3_LDS_BYTES, 0, pb, (const uint32_t*)counts,
+                hipLaunchKernelGGL((k_scatter_accum3<S3_LOG2, 1024>), dim3(pb.acc_blocks), dim3(1024), S3_LDS_BYTES, 0, pb, (const uint32_t*)counts,
                                    (const float4*)bins, (const float4*)ovf, tab);
             else
-                hipLaunchKernelGGL((k_scatter_accum4<13, 512>), dim3(pb.acc_blocks < 256u ? pb.acc_blocks : 256u), dim3(512), S3_LDS_BYTES, 0, pb, counts,
+                hipLaunchKernelGGL((k_scatter_accum3<S3_LOG2, 512>), dim3(pb.acc_blocks), dim3(512), S3_LDS_BYTES, 0, pb, (const uint32_t*)counts,
                                    (const float4*)bins, (const float4*)ovf, tab);
             hipEventRecord(c); hipEventSynchronize(c);
             float m1, m2; hipEventElapsedTime(&m1, a, b); hipEventElapsedTime(&m2, b, c);

@@ -91,7 +91,6 @@ struct S3Plan {
     uint32_t acc_blocks;
     uint32_t lg;                     // log2 of the entries of one partition (13, or 12: two accumulate workgroups per CU)
     uint32_t fuse;                   // != 0: the accumulate kernel applies Adam to the entries instead of writing their gradient
-    uint32_t ticket_off;             // word into counts: the persistent accumulate kernel's ticket counter (0xffffffff: static round robin)
     XrAdamArgs ad;
 };
 struct S3RLevel {
@@ -303,7 +302,6 @@ __global__ __launch_bounds__(S3_BIN_THREADS) void k_scatter_bin3(S3Plan pl, cons
     __shared__ uint32_t s_cnt[S3_MAX_PARTS], s_off[S3_MAX_PARTS + 1], s_base[S3_MAX_PARTS], s_ovf;
     const uint32_t e = pl.n_lv - 1u - blockIdx.x % pl.n_lv, sb = blockIdx.x / pl.n_lv;   // the levels of one sample block are neighbours
     const S3Level& L = pl.lv[e];
-    if (pl.ticket_off != 0xffffffffu && blockIdx.x == 0 && threadIdx.x == 0) counts[pl.ticket_off] = 0u;   // (the accumulate kernel's tickets)
     if (n_dev) n = min(n, *n_dev);
     uint32_t* __restrict__ cnt_out = counts + L.counts_off + sb;            // [part][sample block]
     uint32_t* __restrict__ ovfcnt_out = counts + pl.ovfcnt_off + e * pl.nsb + sb;
@@ -578,234 +576,11 @@ __global__ __launch_bounds__(TH) void k_scatter_accum3(S3Plan pl, const uint32_t
     S3_T(6);
 }
 
-// ---- the accumulate kernel as a PERSISTENT grid (round 4).  What the phase stamps of k_scatter_accum3 showed with the optimiser's
-// update inside (profiles/r03_accumulate_kernel_phase_study.txt): a workgroup lasts 19-28 us but a CU takes a new one only every
-// ~37 us -- its 256 KB of update stores drain before the 128 KB of LDS are handed on, and the next workgroup starts with two
-// dependent memory latencies (fill counts -> first items, 3.5 us) on an idle CU.  Here one workgroup per CU walks its partitions
-// (static round robin, or tickets from a device counter): the stores of partition k drain under the item stream of partition
-// k + 1, the fill counts of k + 1 are fetched before the barrier that ends k's atomics and its first items behind that barrier
-// (both latencies under k's update phase), and the accumulators are cleared by the pass that reads them (no separate zero pass,
-// one barrier less per partition).  Same items, same fp64 LDS accumulation, same adam1 / ema1: results as k_scatter_accum3's up
-// to the order of the fp64 additions inside one partition.
-template <int LG, int TH>
-__global__ __launch_bounds__(TH) void k_scatter_accum4(S3Plan pl, uint32_t* __restrict__ counts, const float4* __restrict__ bins,
-                                                        const float4* __restrict__ ovf, float* __restrict__ grad_table) {
-    constexpr uint32_t ENTRIES = 1u << LG, THREADS = (uint32_t)TH, WAVES = THREADS / 64;
-    extern __shared__ __attribute__((aligned(16))) double s_acc[];       // [ENTRIES][2]
-    __shared__ uint32_t s_ticket;
-    double2* acc2 = reinterpret_cast<double2*>(s_acc);
-    const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t nsb = pl.nsb, my_sb = wave + WAVES * lane;
-    const uint32_t n_mine = nsb > wave ? (nsb - wave + WAVES - 1u) / WAVES : 0u;   // sub-bins of this wave (the same for every partition)
-    const bool tickets = pl.ticket_off != 0xffffffffu;
-    constexpr uint32_t U = 8;
-    // ---- state of the partition whose items are in flight
-    uint32_t b = blockIdx.x;                                               // accumulate block = (level, partition)
-    uint32_t e = 0, part = 0, cap = 0, si = 0, c = 0, fill = 0, vfill = 0, vovf = 0;
-    const float4* __restrict__ src = bins;
-    auto locate = [&](uint32_t blk) {
-        e = 0;
-        while (e + 1 < pl.n_lv && blk >= pl.lv[e + 1].acc_block0) ++e;
-        part = blk - pl.lv[e].acc_block0; cap = pl.lv[e].cap;
-        src = bins + pl.lv[e].bins_off + (size_t)part * nsb * cap;
-    };
-    auto load_fills = [&]() {                                               // (global loads: issue only)
-        const uint32_t* __restrict__ cnt = counts + pl.lv[e].counts_off + (size_t)part * nsb;
-        vfill = my_sb < nsb ? cnt[my_sb] : 0u;
-        vovf = my_sb < nsb ? counts[pl.ovfcnt_off + e * nsb + my_sb] : 0u;
-    };
-    auto skip_empty = [&]() {
-        while (si < n_mine && fill == 0u) { ++si; fill = si < n_mine ? s3_readlane(vfill, si) : 0u; }
-    };
-    auto start_items = [&]() { si = 0; c = 0; fill = n_mine ? s3_readlane(vfill, 0) : 0u; skip_empty(); };
-    float4 nx[U];
-    bool non[U];
-    auto fetch = [&]() {
-#pragma unroll
-        for (uint32_t u = 0; u < U; ++u) {
-            non[u] = false;
-            if (si < n_mine) {
-                const uint32_t nch = (fill + 63u) >> 6, off = S3_PERMUTE ? lane * nch + c : c * 64u + lane;     // (see k_scatter_accum3)
-                non[u] = off < fill;
-                if (non[u]) nx[u] = src[(size_t)(wave + WAVES * si) * cap + off];
-                ++c;
-                if (c * 64u >= fill) {
-                    c = 0; ++si;
-                    fill = si < n_mine ? s3_readlane(vfill, si) : 0u;
-                    skip_empty();
-                }
-            }
-        }
-    };
-    const bool have = b < pl.acc_blocks;                                    // uniform
-    if (have) { locate(b); load_fills(); }
-    if (tickets && threadIdx.x == 0) s_ticket = 0xffffffffu;
-    for (uint32_t q = threadIdx.x; q < ENTRIES; q += THREADS) acc2[q] = make_double2(0.0, 0.0);
-    if (have) { start_items(); fetch(); }
-    // the block after this one is known one partition ahead (so that its fill counts can be fetched before the barrier that ends this
-    // partition's atomics): the second block of a workgroup is static, tickets start at 2 gridDim.x
-    uint32_t nb = b + gridDim.x;
-    __syncthreads();
-    while (b < pl.acc_blocks) {                                             // uniform
-        const S3Level& L = pl.lv[e];
-        uint32_t n_loc;
-        if (L.kind == S3_H) n_loc = ENTRIES;
-        else n_loc = s3_dense_rows(L.res, L.plog2, part) * L.res + (part == 0u ? L.hsize - L.res * L.res * L.res : 0u);
-        const uint32_t cur_part = part, cur_kind = L.kind, cur_res = L.res, cur_plog2 = L.plog2, cur_toff = L.toff;
-        const uint64_t cur_ovf_off = L.ovf_off;
-        // the block after the next: a ticket drawn now (one returning device atomic per partition, its latency under the item stream)
-        if (tickets && threadIdx.x == 0) s_ticket = atomicAdd(counts + pl.ticket_off, 1u);
-        // ---- items -> LDS atomics
-        uint32_t run_pr = 0xffffffffu;
-        double r00 = 0.0, r01 = 0.0, r10 = 0.0, r11 = 0.0;
-        for (;;) {
-            float4 it[U];
-            bool on[U];
-#pragma unroll
-            for (uint32_t u = 0; u < U; ++u) { it[u] = nx[u]; on[u] = non[u]; }
-            const bool more = si < n_mine;                                  // uniform per wave
-            if (more) fetch();
-#pragma unroll
-            for (uint32_t u = 0; u < U; ++u) {
-                if (!on[u]) continue;
-                const uint32_t pr = __float_as_uint(it[u].x);
-                const float w0 = it[u].w, a = it[u].y, bb = it[u].z;
-                if (pr != run_pr) {
-                    if (run_pr != 0xffffffffu) {
-                        const uint32_t i0 = run_pr & (S3_ENTRIES - 1), i1 = run_pr >> S3_LOG2;
-                        atomicAdd(&s_acc[2 * i0], r00); atomicAdd(&s_acc[2 * i0 + 1], r01);
-                        atomicAdd(&s_acc[2 * i1], r10); atomicAdd(&s_acc[2 * i1 + 1], r11);
-                    }
-                    run_pr = pr; r00 = r01 = r10 = r11 = 0.0;
-                }
-                r00 += (double)((1.f - w0) * a); r01 += (double)((1.f - w0) * bb);
-                r10 += (double)(w0 * a); r11 += (double)(w0 * bb);
-            }
-            if (!more) break;
-        }
-        if (run_pr != 0xffffffffu) {
-            const uint32_t i0 = run_pr & (S3_ENTRIES - 1), i1 = run_pr >> S3_LOG2;
-            atomicAdd(&s_acc[2 * i0], r00); atomicAdd(&s_acc[2 * i0 + 1], r01);
-            atomicAdd(&s_acc[2 * i1], r10); atomicAdd(&s_acc[2 * i1 + 1], r11);
-        }
-        // overflow records of the level's sample blocks (none unless the samples cluster): every partition scans them all
-        if (__ballot(vovf != 0u) != 0ull) {
-            for (uint32_t k = 0; k < n_mine; ++k) {
-                const uint32_t cntk = s3_readlane(vovf, k);
-                const float4* __restrict__ ov = ovf + cur_ovf_off + (size_t)(wave + WAVES * k) * pl.ovf_cap;
-                for (uint32_t q = lane; q < cntk; q += 64u) {
-                    const float4 rcd = ov[q];
-                    const uint32_t key = __float_as_uint(rcd.x);
-                    if ((key >> S3_LOG2) != cur_part) continue;
-                    atomicAdd(&s_acc[2 * (key & (S3_ENTRIES - 1))], (double)rcd.y);
-                    atomicAdd(&s_acc[2 * (key & (S3_ENTRIES - 1)) + 1], (double)rcd.z);
-                }
-            }
-        }
-        // ---- update phase of THIS partition (kept in cur_*); the NEXT one's fill counts go out before the barrier, its first items behind it
-        constexpr uint32_t FP = ENTRIES / (2 * THREADS), FH = 2, ROUNDS = FP / FH;
-        static_assert(FP % FH == 0 && ROUNDS >= 1, "rounds of two pairs");
-        const bool fuse_h = pl.fuse != 0u && cur_kind == S3_H;
-        float4 fp_[FH], fm_[FH], fv_[FH], fq_[FH];
-        const size_t f4_0 = ((size_t)cur_toff + (size_t)cur_part * ENTRIES) / 2;
-        auto adam_load = [&](uint32_t k0) {
-#pragma unroll
-            for (uint32_t k = 0; k < FH; ++k) {
-                const size_t i4 = f4_0 + (k0 + k) * THREADS + threadIdx.x;
-                fp_[k] = reinterpret_cast<const float4*>(pl.ad.p)[i4]; fm_[k] = s3_ld4nt(pl.ad.m, i4); fv_[k] = s3_ld4nt(pl.ad.v, i4);
-                if (pl.ad.ema) fq_[k] = s3_ld4nt(pl.ad.ema, i4);
-            }
-        };
-        const bool next = nb < pl.acc_blocks;                               // uniform
-        if (next) { locate(nb); load_fills(); }
-        if (fuse_h) adam_load(0);
-        __syncthreads();                                                    // every wave's LDS atomics have landed; the ticket is there
-        const uint32_t nnb = tickets ? s_ticket + 2u * gridDim.x : nb + gridDim.x;
-        if (next) { start_items(); fetch(); }                               // first items of the next partition: in flight under the update
-        float2* __restrict__ tab = reinterpret_cast<float2*>(grad_table) + cur_toff;
-        const bool add = pl.overwrite == 0u;
-        const double2 zero2 = make_double2(0.0, 0.0);
-        if (fuse_h) {
-            const XrAdamArgs& A = pl.ad;
-#pragma unroll
-            for (uint32_t r = 0; r < ROUNDS; ++r) {
-                double2 a0[FH], a1[FH];
-#pragma unroll
-                for (uint32_t k = 0; k < FH; ++k) {
-                    const uint32_t q = 2u * ((r * FH + k) * THREADS + threadIdx.x);
-                    a0[k] = acc2[q]; a1[k] = acc2[q + 1];
-                    acc2[q] = zero2; acc2[q + 1] = zero2;
-                }
-#pragma unroll
-                for (uint32_t k = 0; k < FH; ++k) {
-                    adam1(fp_[k].x, (float)a0[k].x, fm_[k].x, fv_[k].x, A.b1, A.b2, A.step_size, A.bc2s, A.eps, A.wd, A.gs);
-                    adam1(fp_[k].y, (float)a0[k].y, fm_[k].y, fv_[k].y, A.b1, A.b2, A.step_size, A.bc2s, A.eps, A.wd, A.gs);
-                    adam1(fp_[k].z, (float)a1[k].x, fm_[k].z, fv_[k].z, A.b1, A.b2, A.step_size, A.bc2s, A.eps, A.wd, A.gs);
-                    adam1(fp_[k].w, (float)a1[k].y, fm_[k].w, fv_[k].w, A.b1, A.b2, A.step_size, A.bc2s, A.eps, A.wd, A.gs);
-                    const size_t i4 = f4_0 + (r * FH + k) * THREADS + threadIdx.x;
-                    reinterpret_cast<float4*>(A.p)[i4] = fp_[k]; s3_st4nt(A.m, i4, fm_[k]); s3_st4nt(A.v, i4, fv_[k]);
-                    if (A.ema) {
-                        fq_[k].x = ema1(fq_[k].x, fp_[k].x, A.mom); fq_[k].y = ema1(fq_[k].y, fp_[k].y, A.mom);
-                        fq_[k].z = ema1(fq_[k].z, fp_[k].z, A.mom); fq_[k].w = ema1(fq_[k].w, fp_[k].w, A.mom);
-                        s3_st4nt(A.ema, i4, fq_[k]);
-                    }
-                }
-                if (r + 1 < ROUNDS) adam_load((r + 1) * FH);
-            }
-        } else {
-            if (pl.fuse) {
-                // (dense levels: strided rows) the partition's entries, 4 per thread and round: (p, m, v, ema) of all four in flight together
-                constexpr int AB = 4;
-                const uint32_t lat = s3_dense_rows(cur_res, cur_plog2, cur_part) * cur_res;
-                for (uint32_t q0 = 0; q0 < n_loc; q0 += AB * THREADS) {
-                    size_t ee[AB]; float2 g[AB]; bool on[AB];
-#pragma unroll
-                    for (int k = 0; k < AB; ++k) {
-                        const uint32_t q = q0 + k * THREADS + threadIdx.x;
-                        on[k] = q < n_loc;
-                        uint32_t idx = 0;
-                        if (on[k]) {
-                            if (q < lat) { const uint32_t rl = q / cur_res; idx = ((rl << cur_plog2) | cur_part) * cur_res + (q - rl * cur_res); }
-                            else idx = cur_res * cur_res * cur_res + (q - lat);
-                            const double2 a = acc2[q];
-                            acc2[q] = zero2;
-                            g[k] = make_float2((float)a.x, (float)a.y);
-                        }
-                        ee[k] = (size_t)cur_toff + idx;
-                    }
-                    s3_adam_entries<AB>(pl.ad, ee, g, on);
-                }
-            } else if (cur_kind == S3_H) {
-                float2* __restrict__ dst = tab + (size_t)cur_part * ENTRIES;
-                constexpr uint32_t F = ENTRIES / THREADS;
-                float2 t[F];
-#pragma unroll
-                for (uint32_t k = 0; k < F; ++k) t[k] = add ? dst[k * THREADS + threadIdx.x] : make_float2(0.f, 0.f);
-#pragma unroll
-                for (uint32_t k = 0; k < F; ++k) {
-                    const double2 a = acc2[k * THREADS + threadIdx.x];
-                    acc2[k * THREADS + threadIdx.x] = zero2;
-                    t[k].x += (float)a.x; t[k].y += (float)a.y;
-                    dst[k * THREADS + threadIdx.x] = t[k];
-                }
-            } else {
-                const uint32_t lat = s3_dense_rows(cur_res, cur_plog2, cur_part) * cur_res;     // lattice entries of this partition
-                for (uint32_t q = threadIdx.x; q < n_loc; q += THREADS) {
-                    uint32_t idx;
-                    if (q < lat) { const uint32_t rl = q / cur_res; idx = ((rl << cur_plog2) | cur_part) * cur_res + (q - rl * cur_res); }
-                    else idx = cur_res * cur_res * cur_res + (q - lat);      // padding entries behind the lattice (partition 0)
-                    const double2 a = acc2[q];
-                    acc2[q] = zero2;
-                    float2 t = add ? tab[idx] : make_float2(0.f, 0.f);
-                    t.x += (float)a.x; t.y += (float)a.y;
-                    tab[idx] = t;
-                }
-            }
-        }
-        b = nb; nb = nnb;
-        __syncthreads();                                                    // the accumulators are read and clear: the next partition's atomics may start
-    }
-}
+// (Round 4 built this kernel as a PERSISTENT grid too -- one workgroup per CU walking its partitions, next partition's counts and
+// first items fetched under the update phase, accumulators cleared by the pass that reads them: 102 us against 106 alone, 191-200
+// against 172 in the training loop, where the march of iteration i + 2 shares ~50 CUs with it and a static or ticketed assignment
+// ends with its slowest workgroup.  profiles/r04_persistent_accumulate_kernel_ab.txt; the kernel is in the history, commit "Scatter:
+// persistent accumulate kernel".)
 
 // ------------------------------------------------------------------------------------------------ small dense levels
 // kind R.  Workgroup = (level, 2^13-entry partition, chunk of the rows): thread t walks rows [16 t, 16 t + 16) of its chunk
@@ -932,7 +707,6 @@ static uint32_t s3_chunks() {                 // XR_SC_RL_CHUNKS: row chunks per
 struct S3Layout {
     S3Plan bin; S3RPlan rl;
     uint32_t atomic_mask;            // levels that take the atomic kernel (xr_encode.hip)
-    uint32_t ticket_word;
     size_t counts_bytes, bins_bytes, ovf_bytes, slabs_bytes;
 };
 
@@ -990,8 +764,6 @@ static bool s3_layout(uint32_t n, const GridMeta& gm, uint32_t hashed_mask, int 
             L.acc_block0 = P.bin.acc_blocks; P.bin.acc_blocks += L.parts;
         }
     P.bin.ovfcnt_off = counts_off; counts_off += P.bin.n_lv * nsb;
-    P.bin.ticket_off = 0xffffffffu;
-    P.ticket_word = counts_off; counts_off += 1;          // the persistent accumulate kernel's ticket counter (cleared by the bin kernel)
     P.counts_bytes = (((size_t)counts_off * sizeof(uint32_t)) + 255) & ~(size_t)255;
     P.bins_bytes = (size_t)bins_off * sizeof(float4);
     P.ovf_bytes = (size_t)ovf_off * sizeof(float4);
@@ -1044,7 +816,6 @@ int xr_scatter3(const float* x, uint32_t x_stride, const float* denc_t, uint32_t
     if (!attr_set) {
         XR_HIP(hipFuncSetAttribute((const void*)k_scatter_accum3<S3_LOG2, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES));
         XR_HIP(hipFuncSetAttribute((const void*)k_scatter_accum3<S3_LOG2, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES));
-        XR_HIP(hipFuncSetAttribute((const void*)k_scatter_accum4<S3_LOG2, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES));
         XR_HIP(hipFuncSetAttribute((const void*)k_scatter_dense_rl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES));
         attr_set = true;
     }
@@ -1096,29 +867,16 @@ int xr_scatter3(const float* x, uint32_t x_stride, const float* denc_t, uint32_t
     };
     if (rl_first) { const int rc = launch_rl(); if (rc != XR_OK) return rc; }
     if (P.bin.n_lv) {
-        static const int acc_kind0 = s3_env("XR_SC_ACC", 4);
-        if (acc_kind0 == 5) P.bin.ticket_off = P.ticket_word;
         const uint32_t bs = s3_block_samples();
         const dim3 grid(P.bin.n_lv * P.bin.nsb), block(S3_BIN_THREADS);
         if (bs == 4096) hipLaunchKernelGGL(k_scatter_bin3<4096>, grid, block, 0, stream, P.bin, x, x_stride, denc_t, ld, n, n_dev, rows, counts, bins, ovf);
         else if (bs == 2048) hipLaunchKernelGGL(k_scatter_bin3<2048>, grid, block, 0, stream, P.bin, x, x_stride, denc_t, ld, n, n_dev, rows, counts, bins, ovf);
         else hipLaunchKernelGGL(k_scatter_bin3<1024>, grid, block, 0, stream, P.bin, x, x_stride, denc_t, ld, n, n_dev, rows, counts, bins, ovf);
         XR_LAUNCH_CHECK();
-        // XR_SC_ACC (read once): 4 (default) = the persistent accumulate kernel, one workgroup per CU walking its partitions in static
-        // round robin; 5 = the same with tickets from a device counter; 3 = one workgroup per partition (round 3's kernel).
-        // XR_SC_ACC_THREADS: 512 (default) | 1024 threads per accumulate workgroup -- the same time alone; with 8 waves the march that
-        // the trainer runs beside this kernel (prefetch depth 2) finds registers on every SIMD
+        // XR_SC_ACC_THREADS (read once): 512 (default) | 1024 threads per accumulate workgroup -- the same time alone; with 8 waves the
+        // march that the trainer runs beside this kernel (prefetch depth 2) finds registers on every SIMD
         static const int acc_threads = s3_env("XR_SC_ACC_THREADS", 512);
-        static const int acc_kind = s3_env("XR_SC_ACC", 4);
-        if (acc_kind >= 4) {
-            static const int cus = xr_device_cus();
-            static const int per_cu = s3_env("XR_SC_ACC_PER_CU", 1);
-            const uint32_t grid_p = min(P.bin.acc_blocks, (uint32_t)(cus > 0 ? cus : 256) * (uint32_t)(per_cu > 0 ? per_cu : 1));
-            S3Plan pp = P.bin;              // (the bin kernel above was launched with ticket_off of the same value: it clears the word)
-            // (8 waves: two per SIMD with 256 registers each -- the 16-wave form of this kernel spills)
-            hipLaunchKernelGGL((k_scatter_accum4<S3_LOG2, 512>), dim3(grid_p), dim3(512), S3_LDS_BYTES, stream, pp, counts, (const float4*)bins,
-                               (const float4*)ovf, grad_table);
-        } else if (acc_threads == 512)
+        if (acc_threads == 512)
             hipLaunchKernelGGL((k_scatter_accum3<S3_LOG2, 512>), dim3(P.bin.acc_blocks), dim3(512), S3_LDS_BYTES, stream, P.bin, (const uint32_t*)counts,
                                (const float4*)bins, (const float4*)ovf, grad_table);
         else

@@ -88,7 +88,7 @@ class Zero1GradSync:
 
     def __init__(self, world_size, rank):
         self.world_size, self.rank = int(world_size), int(rank)
-        self._works, self._padded = [], {}
+        self._works = []
         self.shard = self.n = 0
         self.bytes_reduced = self.bytes_gathered = 0
 
@@ -106,15 +106,25 @@ class Zero1GradSync:
         return self.shard_param
 
     def pad_grad(self, device):
-        """storage for one table-gradient buffer of the fused step: (padded [world * shard], its leading [n] view)"""
+        """storage for one table-gradient buffer of the fused step: (padded [world * shard], its leading [n] view).  Nothing is kept
+        here: `ready` finds the padded extent through the view's own storage, so a buffer set the step replaces is freed with it."""
         buf = torch.zeros(self.shard * self.world_size, dtype=torch.float32, device=device)
-        self._padded[buf.data_ptr()] = buf
         return buf, buf[:self.n]
+
+    def _padded_of(self, bucket):
+        """the whole padded buffer behind a table-gradient view made by pad_grad (None: not one of those)"""
+        total = self.shard * self.world_size
+        if bucket.numel() != self.n or bucket.storage_offset() != 0 or bucket.dtype != torch.float32:
+            return None
+        st = bucket.untyped_storage()
+        if st.nbytes() < 4 * total:
+            return None
+        return torch.empty(0, dtype=torch.float32, device=bucket.device).set_(st, 0, (total,))
 
     def ready(self, bucket):
         if self.world_size <= 1:
             return
-        padded = self._padded.get(bucket.data_ptr()) if bucket.numel() == self.n else None
+        padded = self._padded_of(bucket)
         if padded is None:                                   # the MLP gradients: replicated
             self._works.append(dist.all_reduce(bucket.data, op=dist.ReduceOp.SUM, async_op=True))
             self.bytes_reduced += 4 * bucket.numel()

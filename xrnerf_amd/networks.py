@@ -135,7 +135,9 @@ class _FusedTrainStepFn(torch.autograd.Function):
                 # alive across steps (zero_grad(set_to_none=False), accumulation over several backward passes) may still hold
                 # EITHER set as .grad: the step WRITES its gradient buffers, so such a set is skipped, and when both are held a
                 # fresh one takes the place of the older
-                held = {p_.grad.data_ptr() for p_ in (table, wd, wc) if p_.grad is not None}
+                # (zero1: the full table is not the optimiser's -- its shard is -- so no gradient is delivered to it, see below)
+                deliver_table = not hasattr(sync, 'shard_param')
+                held = {p_.grad.data_ptr() for p_ in ((table, wd, wc) if deliver_table else (wd, wc)) if p_.grad is not None}
                 for _ in range(2):
                     net._step_turn ^= 1
                     b = sets[net._step_turn]
@@ -178,8 +180,11 @@ class _FusedTrainStepFn(torch.autograd.Function):
                         sync.ready(b.g_table)
                 if cb is not None:
                     cb()
-                ctx.grads = (b.g_table, b.g_wd, b.g_wc) if adam is None else ()
-                ctx.params = (table, wd, wc) if adam is None else ()
+                # XRNERF_DP=zero1: the table gradient's consumer is the reduce-scatter (sync.ready above) and the optimiser owns this rank's
+                # SHARD, whose .grad sync.finish() sets; a .grad on the full table would never be cleared by that optimiser's zero_grad
+                # and would pin a 48.8-MB buffer set per step
+                ctx.grads = () if adam is not None else (b.g_table, b.g_wd, b.g_wc) if deliver_table else (b.g_wd, b.g_wc)
+                ctx.params = () if adam is not None else (table, wd, wc) if deliver_table else (wd, wc)
                 ctx.table_updated = adam is not None
                 ctx.sync = sync
                 ctx.unit_root_grad = getattr(net, '_unit_root_grad', None)
@@ -244,8 +249,9 @@ class _FusedTrainStepFn(torch.autograd.Function):
                 ops.hashgrid_bwd(pts, denc_t, meta, g_table, live=live)
                 sync.ready(g_mlp)
                 sync.ready(g_table)
-        ctx.grads = (g_table, g_wd, g_wc)
-        ctx.params = (table, wd, wc)
+        deliver_table = not hasattr(sync, 'shard_param')
+        ctx.grads = (g_table, g_wd, g_wc) if deliver_table else (g_wd, g_wc)
+        ctx.params = (table, wd, wc) if deliver_table else (wd, wc)
         ctx.sync = getattr(net, 'grad_sync', None)
         ctx.unit_root_grad = getattr(net, '_unit_root_grad', None)
         ctx.net = net
