@@ -75,6 +75,14 @@ int xr_rays_sampler2(const float* rays_o, const float* rays_d, const uint8_t* bi
                      uint64_t rng_state, uint64_t rng_inc, float* coords_out, int32_t* rays_index,
                      int32_t* rays_numsteps, uint32_t* counter2, float* xyz_planes, uint32_t plane_stride,
                      uint32_t rng_chunk, void* workspace, size_t workspace_bytes, void* stream);
+/* the same; rng_ray0 (used with rng_chunk > 0): the launch's ray i is ray rng_ray0 + i of the frame that series of launches covers -- a
+ * rank that renders a band of image rows draws exactly the jitter the whole-frame loop would give those rays (image-space sharding
+ * of validation frames: pixels independent of the world size) */
+int xr_rays_sampler3(const float* rays_o, const float* rays_d, const uint8_t* bitfield, uint32_t n_rays,
+                     float aabb0, float aabb1, float near_distance, float cone_angle, uint32_t max_samples,
+                     uint64_t rng_state, uint64_t rng_inc, float* coords_out, int32_t* rays_index,
+                     int32_t* rays_numsteps, uint32_t* counter2, float* xyz_planes, uint32_t plane_stride,
+                     uint32_t rng_chunk, uint32_t rng_ray0, void* workspace, size_t workspace_bytes, void* stream);
 
 /* K2  compacted_coord_api (src/compacted_coord.cu:79-143, kernel :6-77).  The reference's
  * transmittance loop cannot influence any output (its `break` is commented out, :41-44), so

@@ -418,3 +418,38 @@ def test_native_loop_iteration_events_bracket_every_iteration(dev):
     ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(5)]
     assert all(0.0 < m < 100.0 for m in ms)
     assert ms[2] > max(ms[0], ms[1])                          # the refresh iteration is the long one
+
+
+def test_row_bands_of_a_frame_give_the_whole_frames_pixels(dev):
+    """Image-space sharding of a validation frame (HashNerfNetwork._render_rows with several ranks): every rank marches a band of
+    image rows, and the band's rays draw the jitter they have in the WHOLE frame's chunk series (sampler.frame_ray0 ->
+    xr_rays_sampler3's rng_ray0), so the all-gathered image is the one-GPU frame bit for bit -- bands that do not start on a chunk
+    boundary included -- and the hidden generator's call counter ends where the whole frame leaves it."""
+    from xrnerf_amd import ops
+    from xrnerf_amd.dist import row_band
+    from xrnerf_amd.train import Trainer
+    tr = Trainer(dev, n_img=3, H=128, W=128, ema=False)
+    tr.run(20)
+    net, H, W = tr.net, 150, 160                                    # 24 000 rays = 6 chunks of 4096 (the last one partial)
+    o, d = ops.gen_rays(tr.data.poses[1], H, W, tr.data.focal * H / 128, tr.data.focal * H / 128, 0.5 * W, 0.5 * H, device=dev)
+    frame = {'rays_o': o, 'rays_d': d, 'img_ids': torch.zeros((H * W, 1), dtype=torch.int32, device=dev)}
+    net.chunk = 4096
+    k1 = net.sampler.k1_calls
+    with torch.no_grad():
+        whole = net.batchify_forward(dict(frame), is_test=True)
+        whole = {k: v.clone() for k, v in whole.items()}
+        assert net.sampler.k1_calls - k1 == 6
+        for world in (2, 3):
+            parts = []
+            for rank in range(world):
+                row0, nrows = row_band(H, rank, world)
+                band = {k: v[row0 * W:(row0 + nrows) * W] for k, v in frame.items()}
+                net.sampler.k1_calls = k1
+                net.sampler.frame_ray0 = row0 * W
+                try:
+                    parts.append({k: v.clone() for k, v in net.batchify_forward(band, is_test=True).items()})
+                finally:
+                    net.sampler.frame_ray0 = 0
+            for key in ('rgb', 'alpha'):
+                assert torch.equal(torch.cat([p[key] for p in parts], 0), whole[key]), (world, key)
+    assert float(whole['alpha'].max()) > 0.5

@@ -120,7 +120,7 @@ __device__ inline Ray rm_load_ray(const float* __restrict__ o, const float* __re
 // the encode from 81 to 143 us and the iteration from 0.447 to 0.488 ms (profiles/r03_k1_wave_per_ray_ab.txt).
 __global__ __launch_bounds__(RM_BLOCK) void k1_count(
     uint32_t n_rays, float lo, float hi, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
-    const uint8_t* __restrict__ bitfield, float cone, float near_distance, xr_pcg32 rng, uint32_t rng_chunk,
+    const uint8_t* __restrict__ bitfield, float cone, float near_distance, xr_pcg32 rng, uint32_t rng_chunk, uint32_t rng_ray0,
     uint32_t* __restrict__ cnt, uint32_t* __restrict__ local_off, float* __restrict__ start_t,
     uint32_t* __restrict__ block_tot, float* __restrict__ tlist) {
     __shared__ uint32_t lds4[4];
@@ -130,7 +130,8 @@ __global__ __launch_bounds__(RM_BLOCK) void k1_count(
         // :31.  rng_chunk > 0: ray i draws what it would draw as ray i % rng_chunk of launch i / rng_chunk of a series of
         // launches over rng_chunk rays each (the generator moves on by 2^32 per launch, :198) -- a frame the reference marches
         // in chunk-sized launches (networks/nerf.py:50-69) becomes ONE launch with the same samples
-        if (rng_chunk) rng.advance(((uint64_t)(i / rng_chunk) << 32) + (uint64_t)((i % rng_chunk) * 8u));
+        // rng_ray0: this launch holds rays rng_ray0 .. of that series' frame (a rank's band of image rows)
+        if (rng_chunk) { const uint32_t g = rng_ray0 + i; rng.advance(((uint64_t)(g / rng_chunk) << 32) + (uint64_t)((g % rng_chunk) * 8u)); }
         else rng.advance((uint64_t)(i * 8u));
         Ray r = rm_load_ray(rays_o, rays_d, i);
         float tmin = fmaxf(rm_aabb_tmin(lo, hi, r), near_distance);          // :42-46
@@ -304,11 +305,11 @@ static size_t rm_ws_layout(uint32_t n_rays, char* base, RmWorkspace* w) {
 
 extern "C" size_t xr_rays_sampler_workspace_bytes(uint32_t n_rays) { return rm_ws_layout(n_rays, nullptr, nullptr); }
 
-extern "C" int xr_rays_sampler2(const float* rays_o, const float* rays_d, const uint8_t* bitfield, uint32_t n_rays,
+extern "C" int xr_rays_sampler3(const float* rays_o, const float* rays_d, const uint8_t* bitfield, uint32_t n_rays,
                                 float aabb0, float aabb1, float near_distance, float cone_angle, uint32_t max_samples,
                                 uint64_t rng_state, uint64_t rng_inc, float* coords_out, int32_t* rays_index,
                                 int32_t* rays_numsteps, uint32_t* counter2, float* xyz_planes, uint32_t plane_stride,
-                                uint32_t rng_chunk, void* workspace, size_t workspace_bytes, void* stream_) {
+                                uint32_t rng_chunk, uint32_t rng_ray0, void* workspace, size_t workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     XR_REQUIRE(rays_o && rays_d && bitfield && coords_out && rays_index && rays_numsteps && counter2, "null pointer");
     XR_REQUIRE(!xyz_planes || plane_stride >= max_samples, "a position plane holds max_samples values");
@@ -318,13 +319,22 @@ extern "C" int xr_rays_sampler2(const float* rays_o, const float* rays_d, const 
     xr_pcg32 rng{rng_state, rng_inc};
     const uint32_t nb = xr_div_up(n_rays, RM_BLOCK);
     hipLaunchKernelGGL(k1_count, dim3(nb), dim3(RM_BLOCK), 0, stream, n_rays, aabb0, aabb1, rays_o, rays_d, bitfield,
-                       cone_angle, near_distance, rng, rng_chunk, w.cnt, w.local_off, w.start_t, w.block_tot, w.tlist);
+                       cone_angle, near_distance, rng, rng_chunk, rng_ray0, w.cnt, w.local_off, w.start_t, w.block_tot, w.tlist);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, nb, w.block_tot, max_samples, w.block_base, w.info);
     hipLaunchKernelGGL(k1_write, dim3(nb), dim3(RM_BLOCK), 0, stream, n_rays, aabb0, aabb1, rays_o, rays_d, bitfield,
                        cone_angle, max_samples, w.cnt, w.local_off, w.start_t, w.block_base, w.info, coords_out,
                        rays_index, rays_numsteps, counter2, w.tlist, xyz_planes, plane_stride);
     XR_LAUNCH_CHECK();
     return XR_OK;
+}
+
+extern "C" int xr_rays_sampler2(const float* rays_o, const float* rays_d, const uint8_t* bitfield, uint32_t n_rays,
+                                float aabb0, float aabb1, float near_distance, float cone_angle, uint32_t max_samples,
+                                uint64_t rng_state, uint64_t rng_inc, float* coords_out, int32_t* rays_index,
+                                int32_t* rays_numsteps, uint32_t* counter2, float* xyz_planes, uint32_t plane_stride,
+                                uint32_t rng_chunk, void* workspace, size_t workspace_bytes, void* stream_) {
+    return xr_rays_sampler3(rays_o, rays_d, bitfield, n_rays, aabb0, aabb1, near_distance, cone_angle, max_samples, rng_state, rng_inc,
+                            coords_out, rays_index, rays_numsteps, counter2, xyz_planes, plane_stride, rng_chunk, 0, workspace, workspace_bytes, stream_);
 }
 
 extern "C" int xr_rays_sampler(const float* rays_o, const float* rays_d, const uint8_t* bitfield, uint32_t n_rays,

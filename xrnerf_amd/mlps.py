@@ -162,14 +162,17 @@ class HashNerfMLP(nn.Module):
         if planes is not None and (planes.dim() != 2 or planes.shape[0] != 3 or planes.shape[1] != pts.shape[0] or pts.shape[0] == 3):
             planes = None
         if not torch.is_grad_enabled() and ops._on_device(pts) and torch.is_tensor(pts) and pts.is_cuda:
-            # inference (frames): no autograd node, intermediates in grow-only persistent buffers (ops._buf).  `raw` is valid until
-            # the next inference call of this process -- the renderer consumes it right away.
+            # inference (frames): no autograd node; the encoded features (consumed inside this call) live in a grow-only persistent
+            # buffer (ops._buf).  The RESULT is a fresh tensor unless the caller opts in with data['reuse_buffers'] (HashNerfNetwork's
+            # own forward does: its renderer consumes `raw` right away): then it is a view of this module's persistent buffer, valid
+            # until this module's next such call -- a caller that keeps two results would otherwise get aliased data.
             n = pts.shape[0]
             ld = (n + 63) // 64 * 64
             nhd, nhc = self.density_net.n_hidden, self.color_net.n_hidden
             n_dev = data.get('n_valid_dev')
             enc_t = ops._buf(pts.device, (self.embedder_pos.meta.n_output_dims, ld), 'infer_enc')
-            raw = ops._buf(pts.device, (n, 4), 'infer_raw')
+            raw = ops._buf(pts.device, (n, 4), 'infer_raw_%x' % id(self)) if data.get('reuse_buffers') else \
+                torch.empty((n, 4), dtype=torch.float32, device=pts.device)
             ops.hashgrid_fwd(self.embedder_pos.params.detach(), planes if planes is not None else pts, self.embedder_pos.meta, enc_t=enc_t,
                              ld=ld, n_dev=n_dev)
             return ops.nerf_mlp_fwd(enc_t, dirs, n, self.density_net.params.detach(), self.color_net.params.detach(), nhd, nhc,
@@ -178,11 +181,12 @@ class HashNerfMLP(nn.Module):
                                 self, data.get('n_valid_dev'), planes)
 
     def run_density_planes(self, planes):
-        """run_density for positions stored as three planes [3, n] (the sampler's grid refresh): -> [n,1] view, row stride 4"""
+        """run_density for positions stored as three planes [3, n] (the sampler's grid refresh): -> [n,1] view, row stride 4, of this
+        module's persistent buffer: valid until this module's next call of this method"""
         n = planes.shape[1]
         with torch.no_grad():
             enc_t = ops._buf(planes.device, (self.embedder_pos.meta.n_output_dims, (n + 63) // 64 * 64), 'density_enc')
-            raw = ops._buf(planes.device, (n, 4), 'density_raw')
+            raw = ops._buf(planes.device, (n, 4), 'density_raw_%x' % id(self))       # (consumed by the caller's splat launch before the next query)
             ops.hashgrid_fwd(self.embedder_pos.params.detach(), planes, self.embedder_pos.meta, enc_t=enc_t, ld=enc_t.shape[1])
             ops.nerf_mlp_fwd(enc_t, None, n, self.density_net.params.detach(), None, self.density_net.n_hidden, self.color_net.n_hidden,
                              self.pad_value, raw=raw)

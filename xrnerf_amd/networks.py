@@ -349,6 +349,8 @@ class HashNerfNetwork(_FastAttr, BaseNerfNetwork):
 
     def forward(self, data, is_test=False):
         data = self.sampler.sample(data, self.mlp, is_test)
+        if is_test:
+            data['reuse_buffers'] = True          # (the renderer below consumes `raw` at once: HashNerfMLP may hand out its persistent buffer)
         data = self.mlp(data)
         data, ret = self.render(data, self.sampler, is_test)
         return ret
@@ -360,7 +362,8 @@ class HashNerfNetwork(_FastAttr, BaseNerfNetwork):
         synchronous form (XRNERF_ASYNC_CHUNKS=0), which costs one device-to-host round trip per chunk."""
         N = data[self.bs_data].shape[0]
         from .samplers import NGPGridSampler
-        if (is_test and N > self.chunk and type(self.sampler) is NGPGridSampler and os.environ.get('XRNERF_FRAME_ONE_LAUNCH', '1') != '0'):
+        if (is_test and (N > self.chunk or getattr(self.sampler, 'frame_ray0', 0)) and type(self.sampler) is NGPGridSampler
+                and os.environ.get('XRNERF_FRAME_ONE_LAUNCH', '1') != '0'):
             # The whole frame as ONE launch per kernel with the SAME pixels as the chunk loop: encode, MLP and compositor are
             # per-sample / per-ray maps, and K1 -- whose hidden generator the loop would advance once per chunk -- draws every
             # ray's jitter as the ray's chunk-th launch would (`frame_chunk`).  61 ms -> 6 ms per 800x800 frame at chunk = 4096
@@ -481,7 +484,20 @@ class HashNerfNetwork(_FastAttr, BaseNerfNetwork):
         assert N == H * W, 'row-band sharding needs the frame as H*W flattened rays'
         row0, nrows = xdist.row_band(H, rank, world)
         band = {k: (v[row0 * W:(row0 + nrows) * W] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == N else v) for k, v in frame.items()}
-        ret = self.batchify_forward(band, is_test=is_test)
+        # the band's rays draw the march jitter they have in the WHOLE frame's chunk series (frame_ray0: xr_rays_sampler3), and every rank's
+        # hidden-generator counter moves on by the whole frame's launches: the pixels are those of the one-GPU / reference frame whatever
+        # the world size, and the ranks' training RNG streams stay in step
+        from .samplers import NGPGridSampler
+        exact = type(self.sampler) is NGPGridSampler and os.environ.get('XRNERF_FRAME_ONE_LAUNCH', '1') != '0' and N > self.chunk
+        k1_before = getattr(self.sampler, 'k1_calls', 0)
+        if exact:
+            self.sampler.frame_ray0 = row0 * W
+        try:
+            ret = self.batchify_forward(band, is_test=is_test)
+        finally:
+            if exact:
+                self.sampler.frame_ray0 = 0
+                self.sampler.k1_calls = k1_before + (N + self.chunk - 1) // self.chunk
         tile = torch.cat([ret['rgb'].reshape(nrows, W, 3), ret['alpha'].reshape(nrows, W, 1)], -1)
         img = xdist.gather_image(tile, H, rank, world)
         return {'rgb': img[..., :3].reshape(N, 3), 'alpha': img[..., 3:].reshape(N, 1)}

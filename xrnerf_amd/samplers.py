@@ -34,7 +34,7 @@ class NGPGridSampler(_FastAttr, nn.Module):
     # per-step state (never a Parameter, a registered buffer or a sub-module): assigned ~15 times per training iteration
     _FAST_ATTRS = frozenset(('iter_n', 'on_sampled', '_prefetched_q', 'rays_index', 'coords', 'xyz', 'rays_numsteps', 'rays_numsteps_compacted',
                              'n_valid_dev', 'persistent_batches', '_train_launches', '_pinned_next', 'k1_calls', '_test_rows_seen',
-                             'frame_chunk', '_pending_counts', 'n_rays_per_batch'))
+                             'frame_chunk', 'frame_ray0', '_pending_counts', 'n_rays_per_batch'))
     def __init__(self, update_grid_freq=16, update_block_size=5000000, n_rays_per_batch=4096,
                  cone_angle_constant=0.00390625, near_distance=0.2, target_batch_size=1 << 18, rgb_activation=2,
                  density_activation=3):
@@ -108,6 +108,7 @@ class NGPGridSampler(_FastAttr, nn.Module):
         else:
             if pre is not None:
                 self.k6_calls = pre['k6_calls']                 # a guess that does not apply: as if it had not been made
+                pre['event'].wait()                             # ... but its side-stream launches write the buffers this stream is about to write
             po, io, pos_u, idx_u, pos_n, idx_n, n_used = self._grid_samples(n_uniform, n_nonuniform, planes)
             n_tot = n_uniform + n_nonuniform
         if planes:
@@ -266,11 +267,14 @@ class NGPGridSampler(_FastAttr, nn.Module):
             # test mode, `frame_chunk` set by the network: this launch stands for ceil(n_rays / frame_chunk) launches of the
             # reference's chunked frame loop -- same jitter per ray, the hidden generator moves on by as many launches
             rng_chunk = 0 if is_training else int(getattr(self, 'frame_chunk', 0) or 0)
+            # ... and `frame_ray0`: these rays are rays frame_ray0.. of the frame (a rank's band of image rows)
+            rng_ray0 = int(getattr(self, 'frame_ray0', 0) or 0) if rng_chunk else 0
             coords, rays_index, rays_numsteps, counter = ops.rays_sampler(
                 rays_o, rays_d, self.density_grid_bitfield, aabb, self.near_distance, self.cone_angle_constant,
                 max_samples, k1_index, coords_out=self._coords_buffer(max_samples, slot),
-                small_out=None if async_test else self._small_buffers(n_rays, slot), xyz_out=xyz, rng_chunk=rng_chunk)
-            self.k1_calls += (n_rays + rng_chunk - 1) // rng_chunk if rng_chunk else 1
+                small_out=None if async_test else self._small_buffers(n_rays, slot), xyz_out=xyz, rng_chunk=rng_chunk, rng_ray0=rng_ray0)
+            # (a band: the launches of the chunk series its rays fall into; the network puts the whole frame's count back afterwards)
+            self.k1_calls += ((rng_ray0 + n_rays + rng_chunk - 1) // rng_chunk - rng_ray0 // rng_chunk) if rng_chunk else 1
             if async_test:
                 self._async_test.append((counter, max_samples, k1_index, n_rays))
                 self.rays_index = rays_index
@@ -290,7 +294,7 @@ class NGPGridSampler(_FastAttr, nn.Module):
                     coords, rays_index, rays_numsteps, counter = ops.rays_sampler(
                         rays_o, rays_d, self.density_grid_bitfield, aabb, self.near_distance, self.cone_angle_constant,
                         max_samples, k1_index, coords_out=self._coords_buffer(max_samples, slot),
-                        small_out=self._small_buffers(n_rays, slot), xyz_out=xyz, rng_chunk=rng_chunk)
+                        small_out=self._small_buffers(n_rays, slot), xyz_out=xyz, rng_chunk=rng_chunk, rng_ray0=rng_ray0)
                     n_valid, samples = counter.tolist()
                 self._test_rows_seen = samples
             elif self._streams():
