@@ -426,8 +426,8 @@ def registry_frame_ms(tr, H=800, W=800, frames=6):
     poses = np.stack([data.poses[k % data.n_img] for k in range(frames + 2)])[None]
     images = torch.ones((1, frames + 2, H, W, 4), dtype=torch.float32)
     out = {}
-    for key, env in (('render_ms_per_800x800_frame_registry_chunk4096', '1'), ('render_ms_per_800x800_frame_registry_chunk4096_loop_of_157_chunks', '0')):
-        os.environ['XRNERF_FRAME_ONE_LAUNCH'] = env
+    for key, env in (('render_ms_per_800x800_frame_registry_chunk4096', 'one_launch'), ('render_ms_per_800x800_frame_registry_chunk4096_loop_of_157_chunks', 'async')):
+        os.environ['XRNERF_FRAME'] = env
         try:
             with torch.no_grad():
                 r = net.val_step({'poses': poses, 'images': images})
@@ -435,7 +435,7 @@ def registry_frame_ms(tr, H=800, W=800, frames=6):
             out[key] = float(np.median(ts))
             out[key + '_mean_min_max'] = [float(ts.mean()), float(ts.min()), float(ts.max())]
         finally:
-            os.environ.pop('XRNERF_FRAME_ONE_LAUNCH', None)
+            os.environ.pop('XRNERF_FRAME', None)
     out['registry_chunk'] = int(net.chunk)
     out['registry_frame_note'] = ('median over %d frames of val_step\'s own per-frame timer (pipeline + batchify_forward + device-to-host copy); between two '
                                   'frames val_step multiplies the image by its alpha on the host (~5 ms of numpy, outside the timer, as in the reference), '

@@ -18,8 +18,8 @@ def test_fused_step_equals_modular_step(dev, monkeypatch):
     a, b = make(dev), make(dev)
     b.net.load_state_dict(a.net.state_dict())
     out = {}
-    for name, tr, modular in (('fused', a, '0'), ('modular', b, '1')):
-        monkeypatch.setenv('XRNERF_MODULAR_STEP', modular)
+    for name, tr in (('fused', a), ('modular', b)):
+        monkeypatch.setenv('XRNERF_STEP', name)
         tr.net.sampler.set_iter(0)
         batch = {k: v[None] for k, v in tr.data.next_batch().items()}
         o = tr.net.train_step(batch, tr.opt)
@@ -182,7 +182,7 @@ def test_blender_scene_directory_trains_through_the_device_ray_table(dev, O, tmp
 def test_gradient_buffers_survive_callers_that_keep_their_gradients(dev):
     """The native fused step WRITES its gradients into two recycled buffer sets that become `.grad`.  A caller that keeps `.grad`
     alive -- `zero_grad(set_to_none=False)`, or accumulation over several backward passes -- must still see torch semantics:
-    three accumulated steps equal the sum of the three steps' gradients taken one by one (the launch sequence XRNERF_PY_STEP=1
+    three accumulated steps equal the sum of the three steps' gradients taken one by one (the launch sequence XRNERF_STEP=py
     allocates fresh gradient tensors every step and is the reference here)."""
     import os
     from xrnerf_amd.train import Trainer
@@ -210,9 +210,9 @@ def test_gradient_buffers_survive_callers_that_keep_their_gradients(dev):
 
     def fresh(py):
         if py:
-            os.environ['XRNERF_PY_STEP'] = '1'
+            os.environ['XRNERF_STEP'] = 'py'
         else:
-            os.environ.pop('XRNERF_PY_STEP', None)
+            os.environ.pop('XRNERF_STEP', None)
         tr = Trainer(dev, n_img=3, H=128, W=128, ema=False)
         tr.overlap_march = False
         tr.net.sampler.on_sampled = None
@@ -228,7 +228,7 @@ def test_gradient_buffers_survive_callers_that_keep_their_gradients(dev):
         kept = grads_of(fresh(False), 3, accumulate=False, keep=True)    # zero_grad(set_to_none=False) between the steps
         acc = grads_of(fresh(False), 3, accumulate=True, keep=True)
     finally:
-        os.environ.pop('XRNERF_PY_STEP', None)
+        os.environ.pop('XRNERF_STEP', None)
     for i in range(len(want_acc)):
         scale = float(want_acc[i].abs().max())
         for s in range(3):
@@ -248,29 +248,27 @@ def test_chunked_frame_without_per_chunk_readback_gives_the_same_pixels(dev, tra
     net, pose = tr.net, tr.data.poses[1]
     H = W = 160                                                    # 25 600 rays = 7 chunks of 4096
     k1 = net.sampler.k1_calls
-    monkeypatch.setenv('XRNERF_FRAME_ONE_LAUNCH', '0')
-    monkeypatch.setenv('XRNERF_ASYNC_CHUNKS', '0')
+    monkeypatch.setenv('XRNERF_FRAME', 'sync')
     rgb_s, a_s = render_frame(net, pose, H, W, tr.data.focal * H / 128, chunk=4096)             # the reference's loop, one read-back per chunk
     calls = net.sampler.k1_calls - k1
     for attempt in range(2):                                       # second attempt: buffers sized from the first frame's rows per ray
-        monkeypatch.setenv('XRNERF_ASYNC_CHUNKS', '1')
+        monkeypatch.setenv('XRNERF_FRAME', 'async')
         net.sampler.k1_calls = k1
         rgb_a, a_a = render_frame(net, pose, H, W, tr.data.focal * H / 128, chunk=4096)
         assert net.sampler.k1_calls - k1 == calls == 7
         assert torch.equal(rgb_a, rgb_s) and torch.equal(a_a, a_s), attempt
     # the default: the whole frame as one launch per kernel, K1 drawing each ray's jitter as its chunk's launch would
-    monkeypatch.delenv('XRNERF_FRAME_ONE_LAUNCH')
+    monkeypatch.delenv('XRNERF_FRAME')
     net.sampler.k1_calls = k1
     rgb_1, a_1 = render_frame(net, pose, H, W, tr.data.focal * H / 128, chunk=4096)
     assert net.sampler.k1_calls - k1 == 7
     assert torch.equal(rgb_1, rgb_s) and torch.equal(a_1, a_s)
-    monkeypatch.setenv('XRNERF_FRAME_ONE_LAUNCH', '0')
     assert float(a_s.max()) > 0.5
     # a chunk whose rays all miss the occupied cells (sky rows): zero samples, background pixels, both forms
     up = np.array(pose, dtype=np.float32).copy()
     up[3] = [0.5, -5.0, 0.5]                                       # camera far outside, looking away: no ray enters the cube
-    for env in ('0', '1'):
-        monkeypatch.setenv('XRNERF_ASYNC_CHUNKS', env)
+    for env in ('sync', 'async'):
+        monkeypatch.setenv('XRNERF_FRAME', env)
         rgb_e, a_e = render_frame(net, up, 96, 96, tr.data.focal, chunk=4096)
         assert float(a_e.abs().max()) == 0.0
 
@@ -282,8 +280,7 @@ def test_table_update_inside_the_scatter_equals_scatter_plus_optimiser_launch(de
     from xrnerf_amd.train import Trainer
     out = []
     for fuse in ('1', '0'):
-        monkeypatch.setenv('XRNERF_FUSE_ADAM', fuse)
-        tr = Trainer(dev, n_img=3, H=128, W=128, seed=3)
+        tr = Trainer(dev, n_img=3, H=128, W=128, seed=3, fuse_adam=fuse == '1')
         assert tr.fuse_adam == (fuse == '1')
         for _ in range(20):
             tr.step()
@@ -298,13 +295,12 @@ def test_table_update_inside_the_scatter_equals_scatter_plus_optimiser_launch(de
 
 
 def test_refresh_samples_generated_one_iteration_early_leave_the_trajectory_alone(dev, monkeypatch):
-    """XRNERF_PREFETCH_K6 (default on): K6 and the clear of the temporary grid of a refresh run on the side stream during the
+    """prefetch_k6 (default on): K6 and the clear of the temporary grid of a refresh run on the side stream during the
     iteration before it.  40 iterations (refreshes at 0, 16, 32) with and without: bit-identical parameters, grids, RNG counters."""
     from xrnerf_amd.train import Trainer
     out = []
     for on in ('1', '0'):
-        monkeypatch.setenv('XRNERF_PREFETCH_K6', on)
-        tr = Trainer(dev, n_img=3, H=128, W=128, seed=5)
+        tr = Trainer(dev, n_img=3, H=128, W=128, seed=5, prefetch_k6=on == '1')
         assert tr.prefetch_k6 == (on == '1')
         for _ in range(40):
             tr.step()
@@ -325,8 +321,7 @@ def test_march_two_iterations_ahead_leaves_the_trajectory_alone(dev, monkeypatch
     from xrnerf_amd.train import Trainer
     out = []
     for depth in ('2', '1'):
-        monkeypatch.setenv('XRNERF_PREFETCH_DEPTH', depth)
-        tr = Trainer(dev, n_img=3, H=128, W=128, seed=5)
+        tr = Trainer(dev, n_img=3, H=128, W=128, seed=5, prefetch_depth=int(depth))
         assert tr.prefetch_depth == int(depth)
         hist = []
         for _ in range(40):
@@ -363,7 +358,7 @@ def test_native_loop_between_refreshes_equals_the_per_iteration_path(dev, monkey
     from xrnerf_amd.train import Trainer
     out = []
     for mode in ('python', 'run', 'step', 'mixed'):
-        monkeypatch.setenv('XRNERF_NATIVE_LOOP', '0' if mode == 'python' else '1')
+        monkeypatch.setenv('XRNERF_TRAINER', 'native_loop=%d' % (mode != 'python'))       # (through the environment override, once)
         tr = Trainer(dev, n_img=3, H=128, W=128, seed=7)
         assert tr.native_loop == (mode != 'python')
         if mode in ('python', 'step'):

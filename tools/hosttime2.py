@@ -14,7 +14,7 @@ for rep in range(3):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     if os.environ.get('HT_STEP') == '1':
-        for _ in range(N): tr.step()        # one call per iteration (still the native loop unless XRNERF_NATIVE_LOOP=0)
+        for _ in range(N): tr.step()        # one call per iteration (still the native loop unless XRNERF_TRAINER=native_loop=0)
     else:
         tr.run(N)                           # one native window
     t1 = time.perf_counter()

@@ -3,7 +3,7 @@ most 16 / 64 samples, and with the ray list sorted by length (what bounds the la
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ['XRNERF_PY_STEP'] = '1'
+os.environ['XRNERF_STEP'] = 'py'
 import torch
 from xrnerf_amd.train import Trainer
 from xrnerf_amd import ops

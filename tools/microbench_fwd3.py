@@ -1,7 +1,7 @@
-"""Round-3 forward-gather micro-benchmark on marched Lego samples (ray-ordered, ~2.6e5 rows, and a 16x larger frame-sized launch):
-(1) every level alone -> the cost line XR_HG_COST; (2) level-major (round 2) against the cost-balanced XCD map (XR_HG_FWD_MODE bit 5)
-built from those costs, with 28-byte coordinate rows and with positions as three planes.  Switches are read once per process: the script
-re-executes itself per setting.  usage: python tools/microbench_fwd3.py"""
+"""Forward-gather micro-benchmark on marched Lego samples (ray-ordered, ~2.6e5 rows, and a 16x larger frame-sized launch): every level
+alone (the per-level cost line the cost-balanced XCD map in xr_encode.hip is built from), then the whole lookup with 28-byte
+coordinate rows and with positions as three planes, checked bit-exactly against the oracle.  XRNERF_LIB selects another build
+(tools/build_variant.sh) for A/Bs.  usage: python tools/microbench_fwd3.py"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
@@ -39,7 +39,7 @@ def child(which):
         cs = [timeit(torch, lambda: ops.hashgrid_fwd(table, c[:, :3], meta, enc_t=enc, ld=ld, n_dev=ndev, levels=(l, l + 1)), 20) for l in range(16)]
         print('COST ' + ','.join('%.1f' % v for v in cs), flush=True)
         return
-    tag = 'MODE=%s COST=%s' % (os.environ.get('XR_HG_FWD_MODE'), (os.environ.get('XR_HG_COST') or '')[:40])
+    tag = 'lib=%s' % os.path.basename(os.environ.get('XRNERF_LIB', 'default'))
     us = timeit(torch, lambda: ops.hashgrid_fwd(table, c[:, :3], meta, enc_t=enc, ld=ld, n_dev=ndev))
     soa = c[:, :3].t().contiguous()                              # planes [3, n]
     e2 = torch.empty_like(enc)
@@ -63,11 +63,6 @@ if __name__ == '__main__':
         child(os.environ['XR_CHILD'])
     else:
         me = [sys.executable, os.path.abspath(__file__)]
-        r = subprocess.run(me, env=dict(os.environ, XR_CHILD='costs', XR_HG_FWD_MODE='8'), capture_output=True, text=True)
+        r = subprocess.run(me, env=dict(os.environ, XR_CHILD='costs'), capture_output=True, text=True)
         print(r.stdout, r.stderr[-400:])
-        cost = [ln[5:] for ln in r.stdout.splitlines() if ln.startswith('COST ')]
-        cost = cost[0] if cost else ''
-        runs = [dict(XR_HG_FWD_MODE='8'), dict(XR_HG_FWD_MODE='0'), dict(XR_HG_FWD_MODE='40', XR_HG_COST=cost), dict(XR_HG_FWD_MODE='32', XR_HG_COST=cost),
-                dict(XR_HG_FWD_MODE='40'), dict(XR_HG_FWD_MODE='40', XR_HG_COST='3,3,3,4,5,30,34,38,48')]
-        for env in runs:
-            subprocess.run(me, env=dict(os.environ, XR_CHILD='run', **env), check=False)
+        subprocess.run(me, env=dict(os.environ, XR_CHILD='run'), check=False)

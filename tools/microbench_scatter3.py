@@ -1,7 +1,7 @@
-"""Round-3 scatter micro-benchmark: the third generation (xr_scatter.hip, XR_SC_MODE=2) against the second (XR_SC_MODE=1) on
-marched Lego samples (ray-ordered, ~2.6e5 rows), over every row and on a live-row list shaped like the training step's
-(per ray: the leading ~47 % of its samples), with and without XR_SCATTER_OVERWRITE.  The switches are read once per process,
-so the script re-executes itself per setting.  usage: python tools/microbench_scatter3.py [quick]"""
+"""Scatter micro-benchmark (xr_scatter.hip) on marched Lego samples (ray-ordered, ~2.6e5 rows), over every row and on a live-row list
+shaped like the training step's (per ray: the leading ~47 % of its samples), by level range, with and without XR_SCATTER_OVERWRITE,
+and the agreement with the atomic kernel.  XR_SC_TEST (layout parameters) is read once per process, so the script re-executes
+itself per setting; XRNERF_LIB selects another build.  usage: python tools/microbench_scatter3.py [quick]"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
@@ -73,10 +73,7 @@ if __name__ == '__main__':
         child()
     else:
         quick = len(sys.argv) > 1 and sys.argv[1] == 'quick'
-        runs = [dict(XR_SC_MODE='2', XR_SC_RL='1', XR_SC_RL_CHUNKS='16', XR_SC_BLOCK='2048'), dict(XR_SC_MODE='2', XR_SC_RL='1', XR_SC_RL_CHUNKS='8', XR_SC_BLOCK='2048'),
-                dict(XR_SC_MODE='2', XR_SC_RL='1', XR_SC_RL_CHUNKS='16', XR_SC_BLOCK='2048', XR_SC_RL_ASYNC='0'),
-                dict(XR_SC_MODE='2', XR_SC_RL='1', XR_SC_RL_CHUNKS='16', XR_SC_BLOCK='2048', XR_SC_LOG2='12'),
-                dict(XR_SC_MODE='2', XR_SC_RL='1', XR_SC_RL_CHUNKS='16', XR_SC_BLOCK='1024')]
+        runs = [dict(), dict(XR_SC_TEST='rl_chunks=8'), dict(XR_SC_TEST='block=1024')]
         for env in runs:
             e = dict(os.environ, XR_CHILD='1', **env)
             if quick: e['XR_QUICK'] = '1'

@@ -3,7 +3,7 @@ scatter's binning pass; a compaction in front of the MLP backward would skip the
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ['XRNERF_PY_STEP'] = '1'
+os.environ['XRNERF_STEP'] = 'py'
 import torch
 from xrnerf_amd.train import Trainer
 from xrnerf_amd import ops

@@ -52,91 +52,13 @@ __device__ inline void level_of_block(const GridMeta& gm, uint32_t* level, uint3
     }
 }
 
-// Order 3.  Measured with order 1 (XCD x owns levels x and x+8): the 11 hashed levels fall 2-2-2-1-1-1-1-1 on the 8
-// XCDs, so three XCDs gather twice as long as the other five and the kernel takes 2 hashed-level times instead of 11/8.
-// Here the (level, sample block) pairs are laid out finest level first, each weighted with its level's relative cost
-// 2^wsh (hashed levels: one L2 line request per corner pair; dense levels: mostly L1 hits), and cut into 8 contiguous
-// pieces of equal weight -- XCD k (= blockIdx % 8, an observation used for speed only) walks piece k in order.  A level
-// is then shared by at most 2-3 XCDs (its 4 MiB slice is loaded into each of their L2s: +20 MB of fills per launch) and
-// every XCD still works on one level at a time.  Sample block s of visiting slot li sits at weighted position
-// p = nsb * P_li + s * w_li; it belongs to XCD k iff k*W <= 8p < (k+1)*W, W = nsb * wsum.  All uniform (scalar) maths.
-__host__ __device__ inline void hg_xcd_segment(const GridMeta& gm, uint32_t k, uint32_t nsb, uint64_t P, uint32_t sh,
-                                               uint32_t* s_lo, uint32_t* s_hi) {
-    const uint64_t W = (uint64_t)nsb * gm.wsum, base8 = 8ull * P * nsb, lo = (uint64_t)k * W, hi = lo + W;
-    const uint32_t q = 3u + sh;
-    const uint64_t a = lo > base8 ? (lo - base8 + ((1ull << q) - 1)) >> q : 0ull;
-    const uint64_t b = hi > base8 ? (hi - base8 + ((1ull << q) - 1)) >> q : 0ull;
-    *s_lo = (uint32_t)(a < nsb ? a : nsb);
-    *s_hi = (uint32_t)(b < nsb ? b : nsb);
-}
-// -> false when block j of XCD k has no work
-__host__ __device__ inline bool hg_balanced_block(const GridMeta& gm, uint32_t k, uint32_t j, uint32_t nsb, uint32_t* level,
-                                                  uint32_t* sblock) {
-    uint64_t P = 0;
-    for (int l = gm.n_levels - 1; l >= gm.l_min; --l) {
-        uint32_t s_lo, s_hi;
-        hg_xcd_segment(gm, k, nsb, P, gm.wsh[l], &s_lo, &s_hi);
-        const uint32_t cnt = s_hi - s_lo;
-        if (j < cnt) { *level = (uint32_t)l; *sblock = s_lo + j; return true; }
-        j -= cnt;
-        P += 1ull << gm.wsh[l];
-    }
-    return false;
-}
-// Order 4.  What order 3 measured (profiles/r02_microbench_hash_a.txt): run time = (sample blocks of the busiest XCD) x
-// ~44 us per 1012 blocks, the same for dense and hashed blocks -- every block costs the same texture-address time -- while
-// the L2 request load (4 line requests per hashed sample-level, next to none at the dense levels) is what differs.  So:
-// the same NUMBER of blocks on every XCD, and the hashed levels' blocks spread evenly: the (level, sample block) pairs of
-// the hashed levels [n_levels - n_hashed, n_levels), finest first, are cut into 8 equal pieces, the dense levels' pairs
-// likewise; XCD k walks its hashed piece, then its dense piece.
-__host__ __device__ inline bool hg_twolist_block(const GridMeta& gm, uint32_t k, uint32_t j, uint32_t nsb, uint32_t* level,
-                                                 uint32_t* sblock) {
-    const uint32_t nl = (uint32_t)(gm.n_levels - gm.l_min), nh = gm.n_hashed < nl ? gm.n_hashed : nl, nd = nl - nh;
-    // list of m levels x nsb blocks cut at multiples of m*nsb/8 (rounded up): piece k = [k*T/8, (k+1)*T/8)
-    const uint64_t Th = (uint64_t)nh * nsb, Td = (uint64_t)nd * nsb;
-    const uint64_t h0 = (Th * k + 7) / 8, h1 = (Th * (k + 1) + 7) / 8;
-    uint64_t e;
-    if (j < h1 - h0) {
-        e = h0 + j;
-        *level = (uint32_t)gm.n_levels - 1u - (uint32_t)(e / nsb);
-    } else {
-        const uint64_t d0 = (Td * k + 7) / 8, d1 = (Td * (k + 1) + 7) / 8;
-        const uint64_t jj = j - (h1 - h0);
-        if (jj >= d1 - d0) return false;
-        e = d0 + jj;
-        *level = (uint32_t)gm.n_levels - 1u - nh - (uint32_t)(e / nsb);
-    }
-    *sblock = (uint32_t)(e % nsb);
-    return true;
-}
-static uint32_t hg_balanced_blocks_per_xcd(const GridMeta& gm, uint32_t nsb) {
-    uint32_t mx = 0;
-    for (uint32_t k = 0; k < 8; ++k) {
-        uint64_t P = 0; uint32_t c = 0;
-        for (int l = gm.n_levels - 1; l >= gm.l_min; --l) {
-            uint32_t s_lo, s_hi;
-            hg_xcd_segment(gm, k, nsb, P, gm.wsh[l], &s_lo, &s_hi);
-            c += s_hi - s_lo; P += 1ull << gm.wsh[l];
-        }
-        mx = c > mx ? c : mx;
-    }
-    return mx + (uint32_t)gm.n_levels;      // the device recomputes with n_dev <= n: at most one block more per level
-}
-
-typedef float hg_f4 __attribute__((ext_vector_type(4)));
-typedef float hg_f2 __attribute__((ext_vector_type(2)));
-template <bool NT> __device__ inline float4 hg_ld4(const float2* p) {
-    if (NT) { const hg_f4 r = __builtin_nontemporal_load(reinterpret_cast<const hg_f4*>(p)); return make_float4(r.x, r.y, r.z, r.w); }
-    return *reinterpret_cast<const float4*>(p);
-}
-template <bool NT> __device__ inline float2 hg_ld2(const float2* p) {
-    if (NT) { const hg_f2 r = __builtin_nontemporal_load(reinterpret_cast<const hg_f2*>(p)); return make_float2(r.x, r.y); }
-    return *p;
-}
-
-// one (sample, level): 8 corners as 4 x-neighbour pairs -> the level's two features
-template <bool NT, bool POW2, bool PAIRS> __device__ inline void hg_sample_level(const float2* __restrict__ tab, const float* xp, uint32_t x_cs, float scale,
-                                                                      uint32_t res, uint32_t hsize, bool hashed, float* r0_, float* r1_) {
+// one (sample, level): 8 corners as 4 x-neighbour pairs -> the level's two features.  The two x-neighbours of a (y,z) corner pair are
+// adjacent table entries whenever their indices differ only in bit 0 (dense levels with an even index, hashed levels with an even
+// x: idx ^ 1): one 16-B load then serves both corners.  (Rounds 2-3 measured the alternatives -- eight plain 8-B loads, non-temporal
+// loads at the hashed levels, the two coarsest levels from LDS, four other block-to-XCD orders -- and kept this form with the
+// cost-balanced map below: profiles/r02_microbench_fwd_variants.txt, profiles/r03_microbench_fwd3.txt.)
+template <bool POW2> __device__ inline void hg_sample_level(const float2* __restrict__ tab, const float* xp, uint32_t x_cs, float scale,
+                                                            uint32_t res, uint32_t hsize, bool hashed, float* r0_, float* r1_) {
     float w[3]; uint32_t g[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
@@ -144,27 +66,19 @@ template <bool NT, bool POW2, bool PAIRS> __device__ inline void hg_sample_level
         const float f = floorf(p);
         g[d] = (uint32_t)(int)f; w[d] = p - f;
     }
-    // PAIRS (the round-1 kernel): the two x-neighbours of a (y,z) corner pair are adjacent table entries whenever their
-    // indices differ only in bit 0 (dense levels with an even index, hashed levels with an even x: idx ^ 1), and one
-    // 16-B load then serves both corners.  Measured (rocprofv3 PMC, profiles/r02_pmc_hashgrid_fwd_v0_round1_kernel.txt):
-    // the kernel is bound by the texture-address path, ~1 lane-access per clock and CU (TCP_TOTAL_ACCESSES 55.8 M over
-    // 256 CUs x 219 K cycles) -- an issued vector-memory instruction costs its 16 cycles per dword of width whatever its
-    // exec mask, and the adjacent / not-adjacent branch is divergent in nearly every wave, so each pair pays one
-    // dwordx4 AND two dwordx2 (128 cycles) instead of two dwordx2 (64).  Default now: eight plain 8-B loads, issued
-    // together; the second load of a pair finds its line in L1 (or merges with the pending miss) 15 times out of 16.
     float v0x[4], v0y[4], v1x[4], v1y[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const uint32_t gy = g[1] + (p & 1), gz = g[2] + (p >> 1);
         const uint32_t i0 = POW2 ? grid_index_pow2(g[0], gy, gz, hsize - 1u) : grid_index(g[0], gy, gz, res, hsize, hashed);
         const uint32_t i1 = POW2 ? grid_index_pow2(g[0] + 1, gy, gz, hsize - 1u) : grid_index(g[0] + 1, gy, gz, res, hsize, hashed);
-        if (PAIRS && (i0 ^ i1) == 1u) {
-            const float4 q = hg_ld4<NT>(tab + (i0 & ~1u));
+        if ((i0 ^ i1) == 1u) {
+            const float4 q = *reinterpret_cast<const float4*>(tab + (i0 & ~1u));
             const bool odd = i0 & 1u;
             v0x[p] = odd ? q.z : q.x; v0y[p] = odd ? q.w : q.y;
             v1x[p] = odd ? q.x : q.z; v1y[p] = odd ? q.y : q.w;
         } else {
-            const float2 a = hg_ld2<NT>(tab + i0), b = hg_ld2<NT>(tab + i1);
+            const float2 a = tab[i0], b = tab[i1];
             v0x[p] = a.x; v0y[p] = a.y; v1x[p] = b.x; v1y[p] = b.y;
         }
     }
@@ -203,10 +117,6 @@ __global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_fwd(GridMeta gm, XcdMap x
         while (sg < ns && j >= xm.hi[k][sg] - xm.lo[k][sg]) { j -= xm.hi[k][sg] - xm.lo[k][sg]; ++sg; }
         if (sg >= ns) return;
         l = xm.level[k][sg]; sb = xm.lo[k][sg] + j;
-    } else if (gm.order == 4) {
-        if (!hg_twolist_block(gm, blockIdx.x & 7u, blockIdx.x >> 3, (n + EN_BLOCK - 1) / EN_BLOCK, &l, &sb)) return;
-    } else if (gm.order == 3) {
-        if (!hg_balanced_block(gm, blockIdx.x & 7u, blockIdx.x >> 3, (n + EN_BLOCK - 1) / EN_BLOCK, &l, &sb)) return;
     } else {
         level_of_block(gm, &l, &sb);
         if (l >= (uint32_t)gm.n_levels) return;
@@ -220,62 +130,14 @@ __global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_fwd(GridMeta gm, XcdMap x
     const float* xp = x + (size_t)(rows ? rows[i] : i) * x_stride;    // optional row indirection (render slices)
     float r0, r1;
     const bool pow2 = hashed && (hsize & (hsize - 1u)) == 0u;           // uniform for the block
-    if (gm.pairs) {
-        if (pow2) hg_sample_level<false, true, true>(tab, xp, x_cs, scale, res, hsize, hashed, &r0, &r1);
-        else hg_sample_level<false, false, true>(tab, xp, x_cs, scale, res, hsize, hashed, &r0, &r1);
-    } else if (pow2 && gm.nt) hg_sample_level<true, true, false>(tab, xp, x_cs, scale, res, hsize, hashed, &r0, &r1);
-    else if (pow2) hg_sample_level<false, true, false>(tab, xp, x_cs, scale, res, hsize, hashed, &r0, &r1);
-    else hg_sample_level<false, false, false>(tab, xp, x_cs, scale, res, hsize, hashed, &r0, &r1);
+    if (pow2) hg_sample_level<true>(tab, xp, x_cs, scale, res, hsize, hashed, &r0, &r1);
+    else hg_sample_level<false>(tab, xp, x_cs, scale, res, hsize, hashed, &r0, &r1);
     enc_t[(size_t)(2 * l) * ld + i] = r0;
     enc_t[(size_t)(2 * l + 1) * ld + i] = r1;
 }
 
-// The coarsest levels from LDS (north_star: "LDS staging of per-level feature tiles").  Levels [0, n_lds) -- at the
-// config's geometry levels 0 and 1, 4096 + 12168 entries = 127 KiB -- are copied into the workgroup's LDS with
-// coalesced 16-B loads, then every thread gathers its samples' corners with ds_read_b64 (2 LDS cycles per 64
-// conflict-free lanes, against one L1 tag lookup per distinct line).  One workgroup per CU, grid-strided over samples.
-#define EN_LDS_THREADS 1024
-__global__ __launch_bounds__(EN_LDS_THREADS) void k_hashgrid_fwd_lds(GridMeta gm, int n_lds, const float* __restrict__ table,
-                                                                      const float* __restrict__ x, uint32_t x_stride, uint32_t n,
-                                                                      const uint32_t* __restrict__ n_dev, const uint32_t* __restrict__ rows,
-                                                                      float* __restrict__ enc_t, uint32_t ld) {
-    extern __shared__ __attribute__((aligned(16))) float2 s_tab[];
-    if (n_dev) n = min(n, *n_dev);
-    if (blockIdx.x * EN_LDS_THREADS >= n) return;
-    const uint32_t n_ent = gm.off[n_lds];                       // entries of levels [0, n_lds); a multiple of 8
-    {
-        const float4* __restrict__ src = reinterpret_cast<const float4*>(table);
-        float4* dst = reinterpret_cast<float4*>(s_tab);
-        for (uint32_t e = threadIdx.x; e < n_ent / 2; e += EN_LDS_THREADS) dst[e] = src[e];
-    }
-    __syncthreads();
-    for (uint32_t i = blockIdx.x * EN_LDS_THREADS + threadIdx.x; i < n; i += gridDim.x * EN_LDS_THREADS) {
-        const float* xp = x + (size_t)(rows ? rows[i] : i) * x_stride;
-        const float x0 = xp[0], x1 = xp[1], x2 = xp[2];
-        for (int l = 0; l < n_lds; ++l) {
-            const float scale = gm.scale[l];
-            const uint32_t res = gm.res[l];
-            const float2* tab = s_tab + gm.off[l];
-            const float p0 = x0 * scale + 0.5f, p1 = x1 * scale + 0.5f, p2 = x2 * scale + 0.5f;
-            const float f0 = floorf(p0), f1 = floorf(p1), f2 = floorf(p2);
-            const uint32_t g0 = (uint32_t)(int)f0, g1 = (uint32_t)(int)f1, g2 = (uint32_t)(int)f2;
-            const float w0 = p0 - f0, w1 = p1 - f1, w2 = p2 - f2;
-            const uint32_t hsize = gm.off[l + 1] - gm.off[l];
-            float r0 = 0.f, r1 = 0.f;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {    // the oracle's order: corner 0..7, x fastest
-                const uint32_t idx = grid_index(g0 + (c & 1), g1 + ((c >> 1) & 1), g2 + (c >> 2), res, hsize, false);
-                const float2 v = tab[idx];
-                const float wt = ((c & 1) ? w0 : 1.f - w0) * ((c & 2) ? w1 : 1.f - w1) * ((c & 4) ? w2 : 1.f - w2);
-                r0 += wt * v.x; r1 += wt * v.y;
-            }
-            enc_t[(size_t)(2 * l) * ld + i] = r0;
-            enc_t[(size_t)(2 * l + 1) * ld + i] = r1;
-        }
-    }
-}
-
-// Scatter-add of the feature gradients.
+// Scatter-add of the feature gradients with global atomics: the path for small row counts and for levels the binned scatter
+// (xr_scatter.hip) has no layout for.  (Generations 1 and 2 of the bin / accumulate pair lived here until round 4: history.)
 //
 // Measured on MI355X (tools/atomic_probe.hip): scattered global atomics retire at ~21-24 G
 // REQUESTS/s chip-wide whatever the type (f32/u64/f64/pk_f16), the footprint (32 KB .. 128 MB) or
@@ -294,8 +156,7 @@ __global__ __launch_bounds__(EN_LDS_THREADS) void k_hashgrid_fwd_lds(GridMeta gm
 __global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_bwd(GridMeta gm, uint32_t hashed_mask, const float* __restrict__ x,
                                                             uint32_t x_stride, const float* __restrict__ denc_t, uint32_t ld,
                                                             uint32_t n, const uint32_t* __restrict__ n_dev, const uint32_t* __restrict__ rows,
-                                                            float* __restrict__ grad_table, float* __restrict__ rep, uint32_t n_rep, uint32_t rep_stride,
-                                                            uint32_t rep_levels) {
+                                                            float* __restrict__ grad_table) {
     constexpr uint32_t bw_ch = BW_CH;   // compile-time: a runtime chunk length costs 8 % (loop not unrolled)
     uint32_t l, sb;
     level_of_block(gm, &l, &sb);
@@ -328,10 +189,7 @@ __global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_bwd(GridMeta gm, uint32_t
     const float scale = gm.scale[l];
     const uint32_t res = gm.res[l], hsize = gm.off[l + 1] - gm.off[l];
     const bool hashed = (hashed_mask >> l) & 1;
-    // coarse levels: thousands of flushes land on the few hundred entries around the object and same-address
-    // atomics serialise (level 0 alone: 63 us).  With `rep`, workgroup sb adds into replica sb % n_rep of the
-    // slice; k_reduce_replicas folds the replicas into the table afterwards.
-    float* __restrict__ tab = (rep && l < rep_levels ? rep + (size_t)(sb % n_rep) * rep_stride : grad_table) + 2 * (size_t)gm.off[l] + f;
+    float* __restrict__ tab = grad_table + 2 * (size_t)gm.off[l] + f;
     uint32_t c0 = 0xffffffffu, c1 = 0xffffffffu, c2 = 0xffffffffu;   // current cell
     float acc = 0.f;
     float* dst = tab;
@@ -355,451 +213,6 @@ __global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_bwd(GridMeta gm, uint32_t
     if (acc != 0.f) unsafeAtomicAdd(dst, acc);
 }
 
-// ---- scatter without global atomics at the hashed levels: bin, then accumulate in LDS ---------------
-// The atomic scatter above is bound by the chip-wide rate of scattered L2 atomic REQUESTS (measured
-// 21-24 G/s whatever the type, footprint or XCD placement): at the fine, hashed levels nothing merges
-// and every sample costs 4-8 requests per level (0.46 ms for the 8 finest levels at 2^18 samples).
-// Here a hashed level's gradient slice (2^19 entries x 2 floats = 4 MiB) is cut into 2^13-entry
-// PARTITIONS (128 KiB of fp64 accumulators) -- what one workgroup can hold in LDS -- and the work is split in two streaming
-// kernels with no global atomic at all:
-//   A  k_scatter_bin    one thread per (sample, level), 4096 samples per workgroup: the 8 corners are
-//      4 x-neighbour PAIRS; the partition of a pair is bits [13,19) of  y*P1 ^ z*P2  (x < 2^13 never
-//      reaches them), so both corners of a pair live in the same partition.  Each pair becomes one
-//      16-byte item {idx0 | idx1 << 13, wy*wz*d0, wy*wz*d1, wx} stored in the workgroup's PRIVATE
-//      sub-bin of its (level, partition); ranks come from an LDS histogram (returning LDS atomics),
-//      the sub-bin's fill count is stored next to it.  Streaming: reads 28 + 8 B, writes 64 B per
-//      (sample, level).
-//   B  k_scatter_accum  one workgroup per (level, partition): walks the sub-bins of all sample blocks
-//      with coalesced 16-B loads, 4 LDS fp64 atomic adds per item, then adds its partition to the table with
-//      plain 16-B accesses -- it is the only writer of that slice.
-// A sub-bin holds 2x its expected load; items beyond that (adversarially clustered inputs) are
-// scattered by A directly with global atomics, so any input stays correct.
-// Measured at 2^18 samples, 11 hashed levels: A 79 us (16 us without its 176 MB of item stores), B 105 us.
-// Measured dead ends, for the record: (1) every partition-owning workgroup scanning ALL samples and
-// filtering by partition: 0.22 ms per 8 levels (32x redundant filter work at 4 cycles per wave64 VALU
-// instruction, latency-bound gathers); (2) shared bins with one returning global atomic per
-// (workgroup, partition): 0.19 ms even for ONE level -- 64 same-address returning atomics serialise
-// at ~3 us each.
-#define SC_THREADS 1024                            // binning kernel
-#ifndef SC_LOG2
-#define SC_LOG2 13
-#endif
-#ifndef SC_ACC_THREADS
-#define SC_ACC_THREADS 1024                        // accumulate kernel (measured: 2^12-entry partitions with two 512-thread
-#endif                                             // workgroups per CU, 0.287 ms, do not beat 2^13 / 1024 / one per CU, 0.282 ms)
-#define SC_ENTRIES (1u << SC_LOG2)
-#define SC_LDS_BYTES (SC_ENTRIES * 2 * sizeof(double))
-#define SC_SPT 4                                   // samples per thread in the binning kernel
-#define SC_BLOCK_SAMPLES (SC_THREADS * SC_SPT)
-#define SC_MAX_PARTS 256
-#define SC_MAX_SB 1024                               // sample blocks per call: n <= 2^22 on the binned path
-#define SC_SUB_ITEMS (2u * 4u * SC_BLOCK_SAMPLES)  // items of all sub-bins of one (workgroup, level): 2x the 4 pairs per sample
-
-__global__ __launch_bounds__(SC_THREADS) void k_scatter_bin(GridMeta gm, uint32_t l_lo, uint32_t l_hi, uint32_t parts, uint32_t nsb,
-                                                            const float* __restrict__ x, uint32_t x_stride,
-                                                            const float* __restrict__ denc_t, uint32_t ld, uint32_t n,
-                                                            const uint32_t* __restrict__ n_dev, const uint32_t* __restrict__ rows,
-                                                            uint32_t* __restrict__ counts,
-                                                            float4* __restrict__ bins, float* __restrict__ grad_table) {
-    __shared__ uint32_t s_cnt[SC_MAX_PARTS];
-    const uint32_t nl = l_hi - l_lo;
-    const uint32_t l = l_hi - 1 - blockIdx.x % nl, sb = blockIdx.x / nl;   // finest first; the levels of one sample block are neighbours
-    if (n_dev) n = min(n, *n_dev);
-    const uint32_t b0 = sb * SC_BLOCK_SAMPLES;
-    const uint32_t cap = SC_SUB_ITEMS / parts;                              // capacity of one sub-bin
-    uint32_t* __restrict__ cnt_out = counts + ((size_t)(l - l_lo) * parts) * nsb + sb;      // [level][part][sample block]
-    if (b0 >= n) {                                                          // uniform: an empty sample block has empty sub-bins
-        for (uint32_t p = threadIdx.x; p < parts; p += SC_THREADS) cnt_out[(size_t)p * nsb] = 0;
-        return;
-    }
-    for (uint32_t p = threadIdx.x; p < parts; p += SC_THREADS) s_cnt[p] = 0;
-    __syncthreads();
-    const float scale = gm.scale[l];
-    const uint32_t hsize = gm.off[l + 1] - gm.off[l], hmask = hsize - 1;    // power of two (checked on the host)
-    const float* __restrict__ d0p = denc_t + (size_t)(2 * l) * ld;
-    const float* __restrict__ d1p = d0p + ld;
-    float* __restrict__ tab = grad_table + 2 * (size_t)gm.off[l];
-    // sub-bin (level, part, sample block) at [level][part][sample block][cap]: the reader of one (level, part)
-    // streams nsb * cap contiguous items
-    float4* __restrict__ out = bins + (size_t)(l - l_lo) * nsb * SC_SUB_ITEMS + (size_t)sb * cap;
-    // all 5 x SC_SPT loads of the thread are issued before anything is consumed (one exposed memory latency
-    // per workgroup instead of one per sample)
-    float ld0[SC_SPT], ld1[SC_SPT], lx0[SC_SPT], lx1[SC_SPT], lx2[SC_SPT];
-#pragma unroll
-    for (uint32_t s = 0; s < SC_SPT; ++s) {
-        uint32_t i = min(b0 + s * SC_THREADS + threadIdx.x, n - 1);
-        if (rows) i = rows[i];
-        const float* xp = x + (size_t)i * x_stride;
-        ld0[s] = d0p[i]; ld1[s] = d1p[i]; lx0[s] = xp[0]; lx1[s] = xp[1]; lx2[s] = xp[2];
-    }
-#pragma unroll
-    for (uint32_t s = 0; s < SC_SPT; ++s) {
-        const uint32_t i = b0 + s * SC_THREADS + threadIdx.x;
-        if (i >= n) continue;
-        const float d0 = ld0[s], d1 = ld1[s], x0 = lx0[s], x1 = lx1[s], x2 = lx2[s];
-        if (d0 == 0.f && d1 == 0.f) continue;                               // rows behind the compositor's early stop add nothing
-        const float p0 = x0 * scale + 0.5f, p1 = x1 * scale + 0.5f, p2 = x2 * scale + 0.5f;
-        const float f0 = floorf(p0), f1 = floorf(p1), f2 = floorf(p2);
-        const uint32_t g0 = (uint32_t)(int)f0, g1 = (uint32_t)(int)f1, g2 = (uint32_t)(int)f2;
-        const float w0 = p0 - f0, w1 = p1 - f1, w2 = p2 - f2;
-        const uint32_t a0 = g1 * 2654435761u, b0h = g2 * 805459861u;
-#pragma unroll
-        for (uint32_t c = 0; c < 4; ++c) {
-            const uint32_t cy = c & 1u, cz = c >> 1;
-            const uint32_t h = (a0 + (cy ? 2654435761u : 0u)) ^ (b0h + (cz ? 805459861u : 0u));
-            const uint32_t i0 = (g0 ^ h) & hmask, i1 = ((g0 + 1u) ^ h) & hmask;
-            const uint32_t part = i0 >> SC_LOG2;                            // == i1 >> SC_LOG2
-            const float wyz = (cy ? w1 : 1.f - w1) * (cz ? w2 : 1.f - w2);
-            const float va = wyz * d0, vb = wyz * d1;
-            const uint32_t rank = atomicAdd(&s_cnt[part], 1u);
-            if (rank < cap) {
-                const uint32_t pr = (i0 & (SC_ENTRIES - 1)) | ((i1 & (SC_ENTRIES - 1)) << SC_LOG2);
-                out[(size_t)part * nsb * cap + rank] = make_float4(__uint_as_float(pr), va, vb, w0);
-            } else {                                                        // overfull sub-bin: scatter this pair directly
-                unsafeAtomicAdd(tab + 2 * (size_t)i0, (1.f - w0) * va);
-                unsafeAtomicAdd(tab + 2 * (size_t)i0 + 1, (1.f - w0) * vb);
-                unsafeAtomicAdd(tab + 2 * (size_t)i1, w0 * va);
-                unsafeAtomicAdd(tab + 2 * (size_t)i1 + 1, w0 * vb);
-            }
-        }
-    }
-    __syncthreads();
-    for (uint32_t p = threadIdx.x; p < parts; p += SC_THREADS) cnt_out[(size_t)p * nsb] = min(s_cnt[p], cap);
-}
-
-// LDS accumulation.  MEASURED on MI355X (tools/lds_probe.hip), ns per wave64 instruction per CU, random addresses:
-//   ds_add_f32 81 (!)   ds_add_f64 8.6   ds_add_u32 3.0   ds_add_u64 4.7   ds_cmpst_rtn_b64 8.9   8-byte read+write 7.2
-// The fp32 LDS atomic add is serialised per lane (~3 cycles each); the fp64 one is not.  (A 64-bit compare-and-
-// swap of the (f0, f1) pair has the throughput but needs the returned value: two exposed LDS latencies per add,
-// 62 us per partition.)  So the partition is accumulated in DOUBLE with returnless ds_add_f64 -- more accurate
-// than the fp32 atomics of the other path -- and rounded to fp32 once, when it is added to the table.
-#ifdef SC_TIMING
-__device__ long long g_sc_t[24];
-#define SC_T(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_sc_t[k] = wall_clock64(); } while (0)
-#else
-#define SC_T(k)
-#endif
-__global__ __launch_bounds__(SC_ACC_THREADS) void k_scatter_accum(GridMeta gm, uint32_t l_lo, uint32_t l_hi, uint32_t parts, uint32_t nsb,
-                                                              const uint32_t* __restrict__ counts, const float4* __restrict__ bins,
-                                                              float* __restrict__ grad_table) {
-    extern __shared__ __attribute__((aligned(16))) double s_acc[];       // [SC_ENTRIES][2]
-    const uint32_t li = blockIdx.x / parts, part = blockIdx.x % parts, l = l_lo + li;
-    const uint32_t hsize = gm.off[l + 1] - gm.off[l];
-    if (part >= (hsize >> SC_LOG2)) return;
-    const uint32_t cap = SC_SUB_ITEMS / parts;
-    const uint32_t* __restrict__ cnt = counts + ((size_t)li * parts + part) * nsb;
-    double2* acc2 = reinterpret_cast<double2*>(s_acc);
-    SC_T(0);
-    __shared__ uint32_t s_fill[SC_MAX_SB];                                  // fill counts of this unit's sub-bins
-    for (uint32_t e = threadIdx.x; e < nsb; e += SC_ACC_THREADS) s_fill[e] = cnt[e];
-    for (uint32_t e = threadIdx.x; e < SC_ENTRIES; e += SC_ACC_THREADS) acc2[e] = make_double2(0.0, 0.0);
-    __syncthreads();
-    // The unit's sub-bins are contiguous ([sample block][cap], cap a power of two): tile k = positions
-    // [k * SC_ACC_THREADS, (k+1) * SC_ACC_THREADS), a position is live when its offset in its sub-bin is below the fill
-    // count.  The loads of the next U tiles are in flight while the current U are accumulated.
-    const uint32_t cap_log2 = 31 - __builtin_clz(cap), npos = nsb << cap_log2;
-    const float4* __restrict__ src = bins + (size_t)li * nsb * SC_SUB_ITEMS + (size_t)part * npos;
-    constexpr uint32_t U = 8;
-    float4 nx[U];
-    bool non[U];
-    auto fetch = [&](uint32_t k0) {
-#pragma unroll
-        for (uint32_t u = 0; u < U; ++u) {
-            const uint32_t pos = (k0 + u) * SC_ACC_THREADS + threadIdx.x;
-            non[u] = pos < npos && (pos & (cap - 1)) < s_fill[min(pos >> cap_log2, nsb - 1)];
-            if (non[u]) nx[u] = src[pos];
-        }
-    };
-    const uint32_t ntiles = (npos + SC_ACC_THREADS - 1) / SC_ACC_THREADS;
-    SC_T(1);
-    fetch(0);
-    for (uint32_t k0 = 0; k0 < ntiles; k0 += U) {
-        float4 it[U];
-        bool on[U];
-#pragma unroll
-        for (uint32_t u = 0; u < U; ++u) { it[u] = nx[u]; on[u] = non[u]; }
-        if (k0 + U < ntiles) fetch(k0 + U);
-#pragma unroll
-        for (uint32_t u = 0; u < U; ++u) {
-            if (!on[u]) continue;
-            const uint32_t pr = __float_as_uint(it[u].x), i0 = pr & (SC_ENTRIES - 1), i1 = pr >> SC_LOG2;
-            const float w0 = it[u].w, a = it[u].y, b = it[u].z;
-            atomicAdd(&s_acc[2 * i0], (double)((1.f - w0) * a));
-            atomicAdd(&s_acc[2 * i0 + 1], (double)((1.f - w0) * b));
-            atomicAdd(&s_acc[2 * i1], (double)(w0 * a));
-            atomicAdd(&s_acc[2 * i1 + 1], (double)(w0 * b));
-        }
-    }
-    SC_T(2);
-    __syncthreads();
-    float2* __restrict__ dst = reinterpret_cast<float2*>(grad_table + 2 * ((size_t)gm.off[l] + (size_t)part * SC_ENTRIES));
-    SC_T(3);
-    constexpr uint32_t F = SC_ENTRIES / SC_ACC_THREADS;                         // all F loads in flight before the first add
-    float2 t[F];
-#pragma unroll
-    for (uint32_t k = 0; k < F; ++k) t[k] = dst[k * SC_ACC_THREADS + threadIdx.x];
-#pragma unroll
-    for (uint32_t k = 0; k < F; ++k) {
-        const double2 a = acc2[k * SC_ACC_THREADS + threadIdx.x];
-        t[k].x += (float)a.x; t[k].y += (float)a.y;
-        dst[k * SC_ACC_THREADS + threadIdx.x] = t[k];
-    }
-    SC_T(4);
-}
-
-// ---- second generation of the bin / accumulate pair (XR_SC_MODE=1, default) ---------------------------------------
-// Measured on the first pair (rocprofv3, 2^18 samples, 11 hashed levels): k_scatter_bin 90 us, of which 16 us without
-// its item stores -- 11.5 M scattered 16-B stores, each its own L2 write request into a partially written line -- and
-// k_scatter_accum 140 us reading sub-bins that are half empty by construction (capacity 2x the expected fill, lanes
-// past the fill idle in the loads AND in the LDS atomics).  Here:
-//   A' k_scatter_bin2   512 threads, the workgroup's 4096 samples in 4 rounds of 1024: the round's <= 4096 items are
-//      ranked per partition with LDS counters, placed in LDS in partition order (64 KiB), and copied out as contiguous
-//      runs (~64 items = 1 KiB per partition and round): full 16-B-per-lane coalesced stores.  Two workgroups per CU.
-//   B' k_scatter_accum2 sub-bin capacity 1.25x the expected fill; a wave walks whole sub-bins in 64-item chunks,
-//      so only a sub-bin's last chunk has idle lanes; 8 chunk loads in flight per lane while the previous 8 are
-//      accumulated.
-#ifndef SB_THREADS
-#define SB_THREADS 512
-#endif
-#ifndef SB_SPT
-#define SB_SPT 2
-#endif
-#define SB_ROUND_SAMPLES (SB_THREADS * SB_SPT)
-#define SB_ROUND_ITEMS (4 * SB_ROUND_SAMPLES)
-#define SB_ROUNDS (SC_BLOCK_SAMPLES / SB_ROUND_SAMPLES)
-#define SC_SUB_ITEMS2 (5u * SC_BLOCK_SAMPLES)      // items of all sub-bins of one (workgroup, level): 1.25x the 4 pairs per sample
-
-__global__ __launch_bounds__(SB_THREADS) void k_scatter_bin2(GridMeta gm, uint32_t l_lo, uint32_t l_hi, uint32_t parts, uint32_t nsb,
-                                                             const float* __restrict__ x, uint32_t x_stride,
-                                                             const float* __restrict__ denc_t, uint32_t ld, uint32_t n,
-                                                             const uint32_t* __restrict__ n_dev, const uint32_t* __restrict__ rows,
-                                                             uint32_t* __restrict__ counts,
-                                                             float4* __restrict__ bins, float* __restrict__ grad_table) {
-    __shared__ float4 s_items[SB_ROUND_ITEMS];
-    __shared__ uint8_t s_ipart[SB_ROUND_ITEMS];
-    __shared__ uint32_t s_cnt[SC_MAX_PARTS], s_off[SC_MAX_PARTS + 1], s_base[SC_MAX_PARTS];
-    const uint32_t nl = l_hi - l_lo;
-    const uint32_t l = l_hi - 1 - blockIdx.x % nl, sb = blockIdx.x / nl;   // finest first; the levels of one sample block are neighbours
-    if (n_dev) n = min(n, *n_dev);
-    const uint32_t b0 = sb * SC_BLOCK_SAMPLES;
-    const uint32_t cap = SC_SUB_ITEMS2 / parts;                             // capacity of one sub-bin
-    uint32_t* __restrict__ cnt_out = counts + ((size_t)(l - l_lo) * parts) * nsb + sb;      // [level][part][sample block]
-    if (b0 >= n) {                                                          // uniform: an empty sample block has empty sub-bins
-        for (uint32_t p = threadIdx.x; p < parts; p += SB_THREADS) cnt_out[(size_t)p * nsb] = 0;
-        return;
-    }
-    for (uint32_t p = threadIdx.x; p < parts; p += SB_THREADS) s_base[p] = 0;
-    const float scale = gm.scale[l];
-    const uint32_t hsize = gm.off[l + 1] - gm.off[l], hmask = hsize - 1;    // power of two (checked on the host)
-    const float* __restrict__ d0p = denc_t + (size_t)(2 * l) * ld;
-    const float* __restrict__ d1p = d0p + ld;
-    float* __restrict__ tab = grad_table + 2 * (size_t)gm.off[l];
-    float4* __restrict__ out = bins + (size_t)(l - l_lo) * nsb * SC_SUB_ITEMS2 + (size_t)sb * cap;
-    const uint32_t per = (parts + 63u) / 64u;                               // partitions per lane in the offset scan (<= 4)
-    for (uint32_t r = 0; r < SB_ROUNDS; ++r) {
-        const uint32_t rb0 = b0 + r * SB_ROUND_SAMPLES;
-        if (rb0 >= n) break;                                                // uniform
-        if (r == 0) SC_T(8);
-        for (uint32_t p = threadIdx.x; p < parts; p += SB_THREADS) s_cnt[p] = 0;
-        __syncthreads();
-        float ld0[SB_SPT], ld1[SB_SPT], lx0[SB_SPT], lx1[SB_SPT], lx2[SB_SPT];
-#pragma unroll
-        for (uint32_t s = 0; s < SB_SPT; ++s) {
-            uint32_t i = min(rb0 + s * SB_THREADS + threadIdx.x, n - 1);
-            if (rows) i = rows[i];
-            const float* xp = x + (size_t)i * x_stride;
-            ld0[s] = d0p[i]; ld1[s] = d1p[i]; lx0[s] = xp[0]; lx1[s] = xp[1]; lx2[s] = xp[2];
-        }
-        uint32_t ipart[SB_SPT * 4], irank[SB_SPT * 4], ipr[SB_SPT * 4];
-        float iva[SB_SPT * 4], ivb[SB_SPT * 4], iw0[SB_SPT];
-        bool live[SB_SPT];
-#pragma unroll
-        for (uint32_t s = 0; s < SB_SPT; ++s) {
-            const uint32_t i = rb0 + s * SB_THREADS + threadIdx.x;
-            const float d0 = ld0[s], d1 = ld1[s];
-            live[s] = i < n && !(d0 == 0.f && d1 == 0.f);                   // rows behind the compositor's early stop add nothing
-            if (!live[s]) continue;
-            const float p0 = lx0[s] * scale + 0.5f, p1 = lx1[s] * scale + 0.5f, p2 = lx2[s] * scale + 0.5f;
-            const float f0 = floorf(p0), f1 = floorf(p1), f2 = floorf(p2);
-            const uint32_t g0 = (uint32_t)(int)f0, g1 = (uint32_t)(int)f1, g2 = (uint32_t)(int)f2;
-            const float w0 = p0 - f0, w1 = p1 - f1, w2 = p2 - f2;
-            const uint32_t a0 = g1 * 2654435761u, b0h = g2 * 805459861u;
-            iw0[s] = w0;
-#pragma unroll
-            for (uint32_t c = 0; c < 4; ++c) {
-                const uint32_t cy = c & 1u, cz = c >> 1, k = s * 4 + c;
-                const uint32_t h = (a0 + (cy ? 2654435761u : 0u)) ^ (b0h + (cz ? 805459861u : 0u));
-                const uint32_t i0 = (g0 ^ h) & hmask, i1 = ((g0 + 1u) ^ h) & hmask;
-                const uint32_t part = i0 >> SC_LOG2;                        // == i1 >> SC_LOG2
-                const float wyz = (cy ? w1 : 1.f - w1) * (cz ? w2 : 1.f - w2);
-                iva[k] = wyz * d0; ivb[k] = wyz * d1;
-                ipart[k] = part;
-                ipr[k] = (i0 & (SC_ENTRIES - 1)) | ((i1 & (SC_ENTRIES - 1)) << SC_LOG2);
-                irank[k] = atomicAdd(&s_cnt[part], 1u);
-            }
-        }
-        if (r == 0) SC_T(9);
-        __syncthreads();
-        if (r == 0) SC_T(10);
-        if (threadIdx.x < 64) {                                             // exclusive scan of the round's partition counts
-            uint32_t loc[4], sum = 0;
-#pragma unroll
-            for (uint32_t q = 0; q < 4; ++q) {
-                const uint32_t idx = threadIdx.x * per + q;
-                loc[q] = sum;
-                if (q < per && idx < parts) sum += s_cnt[idx];
-            }
-            uint32_t incl = sum;
-#pragma unroll
-            for (uint32_t d = 1; d < 64; d <<= 1) {
-                const uint32_t o = __shfl_up(incl, d);
-                if (threadIdx.x >= d) incl += o;
-            }
-            const uint32_t excl = incl - sum;
-#pragma unroll
-            for (uint32_t q = 0; q < 4; ++q) {
-                const uint32_t idx = threadIdx.x * per + q;
-                if (q < per && idx < parts) s_off[idx] = excl + loc[q];
-            }
-            if (threadIdx.x == 63) s_off[parts] = incl;
-        }
-        __syncthreads();
-        if (r == 0) SC_T(11);
-#pragma unroll
-        for (uint32_t s = 0; s < SB_SPT; ++s) {
-            if (!live[s]) continue;
-#pragma unroll
-            for (uint32_t c = 0; c < 4; ++c) {
-                const uint32_t k = s * 4 + c, q = s_off[ipart[k]] + irank[k];
-                s_items[q] = make_float4(__uint_as_float(ipr[k]), iva[k], ivb[k], iw0[s]);
-                s_ipart[q] = (uint8_t)ipart[k];
-            }
-        }
-        __syncthreads();
-        if (r == 0) SC_T(12);
-        const uint32_t total = s_off[parts];
-        for (uint32_t q = threadIdx.x; q < total; q += SB_THREADS) {
-            const uint32_t p = s_ipart[q], rk = q - s_off[p] + s_base[p];
-            const float4 it = s_items[q];
-            if (rk < cap) {
-                out[(size_t)p * nsb * cap + rk] = it;
-            } else {                                                        // overfull sub-bin: scatter this pair directly
-                const uint32_t pr = __float_as_uint(it.x);
-                const uint32_t i0 = (pr & (SC_ENTRIES - 1)) | (p << SC_LOG2), i1 = (pr >> SC_LOG2) | (p << SC_LOG2);
-                unsafeAtomicAdd(tab + 2 * (size_t)i0, (1.f - it.w) * it.y);
-                unsafeAtomicAdd(tab + 2 * (size_t)i0 + 1, (1.f - it.w) * it.z);
-                unsafeAtomicAdd(tab + 2 * (size_t)i1, it.w * it.y);
-                unsafeAtomicAdd(tab + 2 * (size_t)i1 + 1, it.w * it.z);
-            }
-        }
-        if (r == 0) SC_T(13);
-        __syncthreads();
-        if (r == 0) SC_T(14);
-        for (uint32_t p = threadIdx.x; p < parts; p += SB_THREADS) s_base[p] += s_cnt[p];
-    }
-    SC_T(15);
-    __syncthreads();
-    for (uint32_t p = threadIdx.x; p < parts; p += SB_THREADS) cnt_out[(size_t)p * nsb] = min(s_base[p], cap);
-}
-
-__global__ __launch_bounds__(SC_ACC_THREADS) void k_scatter_accum2(GridMeta gm, uint32_t l_lo, uint32_t l_hi, uint32_t parts, uint32_t nsb,
-                                                               const uint32_t* __restrict__ counts, const float4* __restrict__ bins,
-                                                               float* __restrict__ grad_table) {
-    extern __shared__ __attribute__((aligned(16))) double s_acc[];       // [SC_ENTRIES][2]
-    const uint32_t li = blockIdx.x / parts, part = blockIdx.x % parts, l = l_lo + li;
-    const uint32_t hsize = gm.off[l + 1] - gm.off[l];
-    if (part >= (hsize >> SC_LOG2)) return;
-    const uint32_t cap = SC_SUB_ITEMS2 / parts;
-    const uint32_t* __restrict__ cnt = counts + ((size_t)li * parts + part) * nsb;
-    double2* acc2 = reinterpret_cast<double2*>(s_acc);
-    SC_T(16);
-    __shared__ uint32_t s_fill[SC_MAX_SB];                                  // fill counts of this unit's sub-bins
-    for (uint32_t e = threadIdx.x; e < nsb; e += SC_ACC_THREADS) s_fill[e] = cnt[e];
-    for (uint32_t e = threadIdx.x; e < SC_ENTRIES; e += SC_ACC_THREADS) acc2[e] = make_double2(0.0, 0.0);
-    __syncthreads();
-    SC_T(17);
-    // the unit's sub-bins: [sample block][cap] contiguous; wave w takes sub-bins w, w + W, ... in 64-item chunks
-    const float4* __restrict__ src = bins + (size_t)li * nsb * SC_SUB_ITEMS2 + (size_t)part * nsb * cap;
-    constexpr uint32_t U = 8, WAVES = SC_ACC_THREADS / 64;
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), c = 0;   // next (sub-bin, chunk) of this wave: scalar
-    while (s < nsb && s_fill[s] == 0) s += WAVES;
-    float4 nx[U];
-    bool non[U];
-    auto fetch = [&]() {
-#pragma unroll
-        for (uint32_t u = 0; u < U; ++u) {
-            non[u] = false;
-            if (s < nsb) {
-                const uint32_t fill = s_fill[s], off = c * 64u + lane;
-                non[u] = off < fill;
-#ifdef SC_ABL_NOLOAD
-                if (non[u]) nx[u] = make_float4(__uint_as_float((off * 2654435761u) & ((1u << (2 * SC_LOG2)) - 1u)), 1.f, 2.f, 0.25f);
-#else
-                if (non[u]) nx[u] = src[(size_t)s * cap + off];
-#endif
-                ++c;
-                if (c * 64u >= fill) {
-                    c = 0; s += WAVES;
-                    while (s < nsb && s_fill[s] == 0) s += WAVES;
-                }
-            }
-        }
-    };
-    fetch();
-    for (;;) {
-        float4 it[U];
-        bool on[U];
-#pragma unroll
-        for (uint32_t u = 0; u < U; ++u) { it[u] = nx[u]; on[u] = non[u]; }
-        const bool more = s < nsb;                                           // uniform per wave
-        if (more) fetch();
-#pragma unroll
-        for (uint32_t u = 0; u < U; ++u) {
-            if (!on[u]) continue;
-            const uint32_t pr = __float_as_uint(it[u].x), i0 = pr & (SC_ENTRIES - 1), i1 = pr >> SC_LOG2;
-            const float w0 = it[u].w, a = it[u].y, b = it[u].z;
-#ifdef SC_ABL_NOATOMIC
-            if (w0 * a + b == 1234.5f) s_acc[2 * i0 + i1] = 1.0;
-#else
-            atomicAdd(&s_acc[2 * i0], (double)((1.f - w0) * a));
-            atomicAdd(&s_acc[2 * i0 + 1], (double)((1.f - w0) * b));
-            atomicAdd(&s_acc[2 * i1], (double)(w0 * a));
-            atomicAdd(&s_acc[2 * i1 + 1], (double)(w0 * b));
-#endif
-        }
-        if (!more) break;
-    }
-    SC_T(18);
-    __syncthreads();
-    SC_T(19);
-    float2* __restrict__ dst = reinterpret_cast<float2*>(grad_table + 2 * ((size_t)gm.off[l] + (size_t)part * SC_ENTRIES));
-    constexpr uint32_t F = SC_ENTRIES / SC_ACC_THREADS;                         // all F loads in flight before the first add
-    float2 t[F];
-#pragma unroll
-    for (uint32_t k = 0; k < F; ++k) t[k] = dst[k * SC_ACC_THREADS + threadIdx.x];
-#pragma unroll
-    for (uint32_t k = 0; k < F; ++k) {
-        const double2 a = acc2[k * SC_ACC_THREADS + threadIdx.x];
-        t[k].x += (float)a.x; t[k].y += (float)a.y;
-        dst[k * SC_ACC_THREADS + threadIdx.x] = t[k];
-    }
-    SC_T(20);
-}
-
-__global__ __launch_bounds__(256) void k_reduce_replicas(const float4* __restrict__ rep, uint32_t n_rep, uint32_t stride4, uint32_t count4,
-                                                         float4* __restrict__ grad_table) {
-    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= count4) return;
-    float4 t = grad_table[e];
-    for (uint32_t r = 0; r < n_rep; ++r) {                                  // fixed order
-        const float4 a = rep[(size_t)r * stride4 + e];
-        t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
-    }
-    grad_table[e] = t;
-}
-
-static int scatter_env(const char* name, int dflt);
 // Host side of order 5.  cost[l] = time of level l alone on one XCD (any unit); a level goes to the XCD with the most budget left,
 // whole when it fits (within 5 %), otherwise in pieces of sample blocks -- most expensive levels first, so the fine hashed levels
 // stay whole and only the cheap remainder is shared between XCDs.  -> blocks per XCD (max over the XCDs), 0 = no map possible.
@@ -837,30 +250,15 @@ static uint32_t hg_build_map(XcdMap* xm, const float* cost, int n_levels, uint32
     for (int q = 0; q < 8; ++q) mx = blocks[q] > mx ? blocks[q] : mx;
     return mx;
 }
-// XR_HG_COST="c0,c1,...": measured single-level times (tools/microbench_fwd3.py prints the line); fewer values than levels: the
-// last one repeats.  Default: the Lego geometry's figures at 2.6e5 ray-ordered samples on the MI355X.
+// single-level times (a level alone on one XCD, 2.6e5 ray-ordered samples of the Lego geometry on the MI355X, us; tools/microbench_fwd3.py
+// re-measures them, profiles/r03_microbench_fwd3.txt): dense levels 23-24 (bound by the texture-address rate of their 13 lane accesses
+// per sample, all cache hits), hashed levels 27.6, 32.0, 38.9, 47.3, 50.5, 51.4, 51.6 ... from the coarsest on (the coarse ones still
+// share lines between neighbouring samples)
 static void hg_level_costs(float* cost, int n_levels, uint32_t hashed_mask) {
-    static float env_cost[EN_MAX_LEVELS];
-    static int n_env = -1;
-    if (n_env < 0) {
-        n_env = 0;
-        const char* e = getenv("XR_HG_COST");
-        while (e && *e && n_env < EN_MAX_LEVELS) {
-            char* end = nullptr;
-            const float v = strtof(e, &end);
-            if (end == e) break;
-            env_cost[n_env++] = v;
-            e = *end == ',' ? end + 1 : end;
-        }
-    }
-    // measured (profiles/r03_microbench_fwd3.txt): a level alone on one XCD, 2.6e5 ray-ordered samples, us: dense levels 23-24
-    // (bound by the texture-address rate of their 13 lane accesses per sample, all cache hits), hashed levels 27.6, 32.0, 38.9,
-    // 47.3, 50.5, 51.4, 51.6 ... from the coarsest on (the coarse ones still share lines between neighbouring samples)
     static const float hashed_cost[] = {27.6f, 32.0f, 38.9f, 47.3f, 50.5f, 51.4f, 51.7f};
     int h = 0;
     for (int l = 0; l < n_levels; ++l) {
-        if (n_env > 0) cost[l] = env_cost[l < n_env ? l : n_env - 1];
-        else if ((hashed_mask >> l) & 1) { cost[l] = hashed_cost[h < 6 ? h : 6]; ++h; }
+        if ((hashed_mask >> l) & 1) { cost[l] = hashed_cost[h < 6 ? h : 6]; ++h; }
         else cost[l] = 23.6f;
     }
 }
@@ -875,78 +273,16 @@ extern "C" int xr_hashgrid_fwd2(const float* table, const float* x, uint32_t x_s
     GridMeta gm; uint32_t hm;
     XR_REQUIRE(fill_meta(&gm, &hm, n_levels, scale_host, resolution_host, offset_host) == 0, "bad level metadata");
     hipStream_t stream = (hipStream_t)stream_;
-    // XR_HG_FWD_MODE (measurement switches, read once): bit 5 (32) = explicit cost-balanced XCD map (order 5), bit 4 (16) = two-list
-    // balanced XCD mapping (order 4), bit 0 = cost-weighted mapping (order 3), none of them = level-major (order 1); bit 1 =
-    // non-temporal table loads at the hashed levels, bit 2 = coarsest levels from LDS, bit 3 = 16-B pair gathers; XR_HG_WSH =
-    // "a,b,c": order 3's log2 cost of a sample block at dense levels < 2^16 entries, larger dense levels, hashed levels.
-    // Round 2 (profiles/r02_microbench_fwd_variants.txt, 2^18 ray-ordered samples): 8: 88.2 us, 24: 88.6, 0: 92.8, 16: 96.8,
-    // 20: 101.6, 18: 254.0.
-    // Round 3 (profiles/r03_microbench_fwd3.txt): 8: 91.2 us, 0: 96.8, 40 (map from the measured per-level costs + pair gathers):
-    // 83.3, 32 (map, plain gathers): 86.5; with positions as three planes (x_comp_stride > 1): 82.9 / 85.0 / 76.1 / 77.6.
-    // Default 40.
-    static const int mode = scatter_env("XR_HG_FWD_MODE", 40);
-    static int wsh3[3] = {-1, 0, 0};
-    if (wsh3[0] < 0) {
-        int a = 0, b = 1, c = 2;
-        const char* e = getenv("XR_HG_WSH");
-        if (e) sscanf(e, "%d,%d,%d", &a, &b, &c);
-        wsh3[1] = b; wsh3[2] = c; wsh3[0] = a;
-    }
+    // block -> (level, sample block): the cost-balanced XCD map (hg_build_map); level-major when no map fits (more than 6 segments on an XCD)
     const uint32_t nsb = xr_div_up(n, EN_BLOCK);
     gm.n_sblocks = nsb;
-    gm.nt = (mode >> 1) & 1;
-    gm.pairs = (mode >> 3) & 1;
-    gm.l_min = 0;
     XcdMap xm;
-    memset(&xm, 0, sizeof(xm));
-    static const uint32_t lds_min_n = (uint32_t)scatter_env("XR_HG_LDS_MIN_N", 32768);
-    if ((mode & 4) && n >= lds_min_n && x_comp_stride == 1 && !(mode & 32)) {
-        // levels whose slices fit the LDS together (dense, contiguous from level 0): at most 144 KiB
-        int n_lds = 0;
-        while (n_lds < n_levels && !((hm >> n_lds) & 1) && (size_t)gm.off[n_lds + 1] * 8 <= 144u * 1024u) ++n_lds;
-        if (n_lds > 0 && n_lds < n_levels) {
-            const size_t lds = (size_t)gm.off[n_lds] * 8;
-            static size_t attr_lds = 0;
-            if (lds > attr_lds) {
-                XR_HIP(hipFuncSetAttribute((const void*)k_hashgrid_fwd_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                attr_lds = lds;
-            }
-            const uint32_t g = xr_div_up(n, EN_LDS_THREADS);
-            hipLaunchKernelGGL(k_hashgrid_fwd_lds, dim3(g < 256u ? g : 256u), dim3(EN_LDS_THREADS), lds, stream, gm, n_lds, table, x,
-                               x_stride, n, n_dev, rows, enc_t, ld);
-            XR_LAUNCH_CHECK();
-            gm.l_min = n_lds;
-        }
-    }
-    uint32_t blocks = 0;
-    if (mode & 32) {
-        float cost[EN_MAX_LEVELS];
-        hg_level_costs(cost, n_levels, hm);
-        const uint32_t per_xcd = hg_build_map(&xm, cost, n_levels, nsb);
-        if (per_xcd) { gm.order = 5; blocks = 8 * per_xcd; }
-    }
-    if (blocks) {
-    } else if (mode & 16) {
-        // hashed levels must be the top of the level range (they are, for a growing resolution)
-        uint32_t nh = 0;
-        while (nh < (uint32_t)(n_levels - gm.l_min) && ((hm >> (n_levels - 1 - nh)) & 1)) ++nh;
-        gm.order = 4;
-        gm.n_hashed = nh;
-        const uint32_t nl = (uint32_t)(n_levels - gm.l_min);
-        blocks = 8 * (xr_div_up((uint64_t)nh * nsb, 8) + xr_div_up((uint64_t)(nl - nh) * nsb, 8) + 2);
-    } else if (mode & 1) {
-        gm.order = 3;
-        gm.wsum = 0;
-        for (int l = 0; l < n_levels; ++l) {
-            const uint32_t hsize = gm.off[l + 1] - gm.off[l];
-            gm.wsh[l] = (uint8_t)(((hm >> l) & 1) ? wsh3[2] : (hsize < 65536u ? wsh3[0] : wsh3[1]));
-            if (l >= gm.l_min) gm.wsum += 1u << gm.wsh[l];
-        }
-        blocks = 8 * hg_balanced_blocks_per_xcd(gm, nsb);
-    } else {
-        XR_REQUIRE(gm.l_min == 0, "the LDS path needs a balanced mapping");
-        blocks = 8 * ((n_levels + 7) / 8) * nsb;
-    }
+    float cost[EN_MAX_LEVELS];
+    hg_level_costs(cost, n_levels, hm);
+    const uint32_t per_xcd = hg_build_map(&xm, cost, n_levels, nsb);
+    uint32_t blocks;
+    if (per_xcd) { gm.order = 5; blocks = 8 * per_xcd; }
+    else { memset(&xm, 0, sizeof(xm)); blocks = 8 * ((n_levels + 7) / 8) * nsb; }
     hipLaunchKernelGGL(k_hashgrid_fwd, dim3(blocks), dim3(EN_BLOCK), 0, stream, gm, xm, hm, table, x, x_stride, x_comp_stride, n,
                        n_dev, rows, enc_t, ld);
     XR_LAUNCH_CHECK();
@@ -960,158 +296,12 @@ extern "C" int xr_hashgrid_fwd(const float* table, const float* x, uint32_t x_st
     return xr_hashgrid_fwd2(table, x, x_stride, 1, n, n_dev, rows, n_levels, scale_host, resolution_host, offset_host, enc_t, ld, stream_);
 }
 
-static int scatter_env(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
-
-static int sc_mode() {          // XR_SC_MODE: 2 = third generation (xr_scatter.hip, default); 1 / 0 = the second / first bin /
-    static const int m = scatter_env("XR_SC_MODE", 2);   // accumulate pair with the atomic kernel for the dense levels (measurement)
-    return m;
-}
-// Which levels take which path, and the workspace layout:  [fill counts][bins][replicas of the dense slices]
-#define SC_REPLICAS 8
-struct ScatterPlan {
-    int l_bin;            // levels [l_bin, n_levels) are binned, [0, l_bin) take the atomic kernel
-    uint32_t parts, nsb;
-    size_t counts_bytes, bins_bytes, rep_bytes;
-    uint32_t rep_stride;  // floats per replica
-    uint32_t rep_levels;  // levels [0, rep_levels) of the dense remainder go through the replicas
-};
-static ScatterPlan scatter_plan(uint32_t n, int n_levels, const uint32_t* res, const uint32_t* off, uint32_t hashed_mask) {
-    static const int cap_levels = scatter_env("XR_SCAN_LEVELS", EN_MAX_LEVELS);
-    static const int use_rep = scatter_env("XR_REPLICAS", 1);
-    ScatterPlan p{};
-    p.l_bin = n_levels; p.parts = 1; p.nsb = xr_div_up(n, SC_BLOCK_SAMPLES);
-    if (n >= 16384u && p.nsb <= SC_MAX_SB) {
-        while (p.l_bin > 0 && n_levels - p.l_bin < cap_levels) {
-            const int l = p.l_bin - 1;
-            const uint32_t hsize = off[l + 1] - off[l];
-            if (!((hashed_mask >> l) & 1) || (hsize & (hsize - 1)) || hsize < SC_ENTRIES || (hsize >> SC_LOG2) > SC_MAX_PARTS ||
-                res[l] >= SC_ENTRIES || (off[l] & 1)) break;
-            p.parts = p.parts > (hsize >> SC_LOG2) ? p.parts : (hsize >> SC_LOG2);
-            --p.l_bin;
-        }
-    }
-    const uint32_t nl = (uint32_t)(n_levels - p.l_bin);
-    p.counts_bytes = (((size_t)nl * p.parts * p.nsb * sizeof(uint32_t)) + 255) & ~(size_t)255;
-    p.bins_bytes = (size_t)nl * p.nsb * (sc_mode() ? SC_SUB_ITEMS2 : SC_SUB_ITEMS) * sizeof(float4);
-    // replicas only for a dense remainder next to a binned range (small tables: <= 2^14-entry... up to 2^19 each)
-    // XR_REPLICA_LEVELS: how many of the coarsest levels are replicated (default: all of the dense remainder).  Measured in the
-    // bench's training loop (entry span): all 5 -> 151 us, 3 -> 149, 2 -> 147, 1 -> 156, 0 -> 157: flat, the default stays
-    static const int rep_lv = scatter_env("XR_REPLICA_LEVELS", EN_MAX_LEVELS);
-    p.rep_levels = (uint32_t)(rep_lv < p.l_bin ? (rep_lv < 0 ? 0 : rep_lv) : p.l_bin);
-    p.rep_stride = (use_rep && n >= 16384u && p.rep_levels > 0) ? (2u * off[p.rep_levels] + 3u) & ~3u : 0u;
-    p.rep_bytes = (size_t)SC_REPLICAS * p.rep_stride * sizeof(float);
-    return p;
-}
-
 extern "C" size_t xr_hashgrid_bwd_workspace_bytes(uint32_t n, int n_levels, const uint32_t* resolution_host, const uint32_t* offset_host) {
     if (n_levels < 1 || n_levels > EN_MAX_LEVELS || !resolution_host || !offset_host) return 0;
     GridMeta gm; uint32_t hm;
     float dummy[EN_MAX_LEVELS] = {0};
     if (fill_meta(&gm, &hm, n_levels, dummy, resolution_host, offset_host) != 0) return 0;
-    if (sc_mode() == 2) return xr_scatter3_workspace_bytes(n, gm, hm);
-    const ScatterPlan p = scatter_plan(n, n_levels, gm.res, gm.off, hm);
-    return p.counts_bytes + p.bins_bytes + p.rep_bytes;
-}
-
-static int hashgrid_bwd_gen12(const float* x, uint32_t x_stride, const float* denc_t, uint32_t ld, uint32_t n, const uint32_t* n_dev,
-                               const uint32_t* rows, int n_levels,
-                               const float* scale_host, const uint32_t* resolution_host, const uint32_t* offset_host,
-                               float* grad_table, void* workspace, size_t workspace_bytes, void* stream_) {
-    GridMeta gm; uint32_t hm;
-    XR_REQUIRE(fill_meta(&gm, &hm, n_levels, scale_host, resolution_host, offset_host) == 0, "bad level metadata");
-    hipStream_t stream = (hipStream_t)stream_;
-    // Levels [l_bin, n_levels): hashed, power-of-two slices of 2^14..2^21 entries, resolution < 2^14 -> bin +
-    // LDS accumulate (no global atomics).  Levels [0, l_bin): dense / small -> atomic scatter with run-length
-    // merging, into SC_REPLICAS replicas of the slice when a workspace is there.  Without a workspace, or for
-    // small n (fixed cost: 2 x 128 KiB of LDS traffic per partition), every level takes the plain atomic kernel.
-    // XR_SCAN_LEVELS=0 / XR_REPLICAS=0 switch the two mechanisms off (measurement).
-    ScatterPlan p = scatter_plan(n, n_levels, gm.res, gm.off, hm);
-    const bool ws_ok = workspace && ((uintptr_t)grad_table & 15) == 0 && ((uintptr_t)workspace & 15) == 0;
-    if (!ws_ok) { p.l_bin = n_levels; p.rep_stride = 0; p.rep_levels = 0; }
-    else XR_REQUIRE(workspace_bytes >= p.counts_bytes + p.bins_bytes + p.rep_bytes, "workspace too small");
-    // The dense remainder and the binned range are independent (disjoint table slices, read-only inputs) and bound
-    // by different things (atomics vs item stores / LDS): when both exist the remainder runs on an internal helper
-    // stream, forked from and joined back into the caller's stream with events (created once per process;
-    // XR_SCATTER_OVERLAP=0 keeps everything on the caller's stream).  Measured and rejected: also splitting the
-    // binned levels into 2-3 concurrent bin/accumulate groups (0.283 -> 0.30 ms).
-    static const int overlap = scatter_env("XR_SCATTER_OVERLAP", 1);
-    static hipStream_t aux = nullptr;
-    static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    bool forked = false;
-    // XR_SCATTER_ORDER=1: the dense remainder is forked AFTER the binning kernel, i.e. it runs beside the LDS-bound accumulate
-    // kernel instead of beside the store-bound binning kernel.  Measured in the bench's training loop: 150 vs 153 us entry span,
-    // no difference -- the default stays 0 (forked first).
-    static const int order = scatter_env("XR_SCATTER_ORDER", 0);
-    auto launch_dense = [&]() -> int {
-    if (p.l_bin > 0) {
-        hipStream_t ds = stream;
-        if (overlap && p.l_bin < n_levels) {
-            if (!aux) {
-                XR_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
-                XR_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-                XR_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-            }
-            XR_HIP(hipEventRecord(ev_fork, stream));
-            XR_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
-            ds = aux;
-            forked = true;
-        }
-        GridMeta gd = gm;
-        gd.n_levels = p.l_bin;
-        if (p.l_bin < n_levels || (p.l_bin & 7)) gd.order = 2;   // a partial level range is spread over all XCDs
-        const uint32_t per_xcd = (p.l_bin + 7) / 8;
-        const uint32_t bw_ch = BW_CH;      // swept 8..128 on MI355X: 0.71-0.75 ms at 2^18 dense-gradient samples, flat
-        gd.n_sblocks = xr_div_up(n, bw_ch * (EN_BLOCK / 16));
-        const uint32_t blocks = (gd.order == 2 ? (uint32_t)p.l_bin : 8 * per_xcd) * gd.n_sblocks;
-        float* rep = p.rep_stride ? (float*)((char*)workspace + p.counts_bytes + p.bins_bytes) : nullptr;
-        if (rep) XR_HIP(hipMemsetAsync(rep, 0, p.rep_bytes, ds));
-        hipLaunchKernelGGL(k_hashgrid_bwd, dim3(blocks), dim3(EN_BLOCK), 0, ds, gd, hm, x, x_stride, denc_t, ld,
-                           n, n_dev, rows, grad_table, rep, (uint32_t)SC_REPLICAS, p.rep_stride, p.rep_levels);
-        XR_LAUNCH_CHECK();
-        if (rep) {
-            const uint32_t count4 = p.rep_stride / 4;
-            hipLaunchKernelGGL(k_reduce_replicas, dim3(xr_div_up(count4, 256)), dim3(256), 0, ds, (const float4*)rep,
-                               (uint32_t)SC_REPLICAS, count4, count4, (float4*)grad_table);
-            XR_LAUNCH_CHECK();
-        }
-        if (forked) XR_HIP(hipEventRecord(ev_join, ds));
-    }
-    return XR_OK;
-    };
-    if (order == 0 || p.l_bin >= n_levels) { const int rc = launch_dense(); if (rc != XR_OK) return rc; }
-    if (p.l_bin < n_levels) {
-        const uint32_t nl = (uint32_t)(n_levels - p.l_bin);
-        static bool attr_set = false;
-        if (!attr_set) {
-            XR_HIP(hipFuncSetAttribute((const void*)k_scatter_accum, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC_LDS_BYTES));
-            XR_HIP(hipFuncSetAttribute((const void*)k_scatter_accum2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC_LDS_BYTES));
-            attr_set = true;
-        }
-        uint32_t* counts = (uint32_t*)workspace;
-        float4* bins = (float4*)((char*)workspace + p.counts_bytes);
-        if (sc_mode()) {
-            hipLaunchKernelGGL(k_scatter_bin2, dim3(nl * p.nsb), dim3(SB_THREADS), 0, stream, gm, (uint32_t)p.l_bin, (uint32_t)n_levels,
-                               p.parts, p.nsb, x, x_stride, denc_t, ld, n, n_dev, rows, counts, bins, grad_table);
-            XR_LAUNCH_CHECK();
-            if (order != 0) { const int rc = launch_dense(); if (rc != XR_OK) return rc; }
-            hipLaunchKernelGGL(k_scatter_accum2, dim3(nl * p.parts), dim3(SC_ACC_THREADS), SC_LDS_BYTES, stream, gm, (uint32_t)p.l_bin,
-                               (uint32_t)n_levels, p.parts, p.nsb, counts, bins, grad_table);
-            XR_LAUNCH_CHECK();
-        } else {
-            hipLaunchKernelGGL(k_scatter_bin, dim3(nl * p.nsb), dim3(SC_THREADS), 0, stream, gm, (uint32_t)p.l_bin, (uint32_t)n_levels,
-                               p.parts, p.nsb, x, x_stride, denc_t, ld, n, n_dev, rows, counts, bins, grad_table);
-            XR_LAUNCH_CHECK();
-            if (order != 0) { const int rc = launch_dense(); if (rc != XR_OK) return rc; }
-            hipLaunchKernelGGL(k_scatter_accum, dim3(nl * p.parts), dim3(SC_ACC_THREADS), SC_LDS_BYTES, stream, gm, (uint32_t)p.l_bin,
-                               (uint32_t)n_levels, p.parts, p.nsb, counts, bins, grad_table);
-            XR_LAUNCH_CHECK();
-        }
-    }
-    if (forked) XR_HIP(hipStreamWaitEvent(stream, ev_join, 0));
-    return XR_OK;
+    return xr_scatter3_workspace_bytes(n, gm, hm);
 }
 
 // Levels of `mask` through the atomic kernel (small n, tiny or oddly shaped tables): one launch per run of consecutive levels
@@ -1132,7 +322,7 @@ static int hashgrid_bwd_atomic_levels(const GridMeta& gm, uint32_t hm, uint32_t 
         const uint32_t blocks = (gd.order == 2 ? (uint32_t)gd.n_levels : 8u * ((gd.n_levels + 7) / 8)) * gd.n_sblocks;
         if (overwrite) XR_HIP(hipMemsetAsync(grad_table + 2 * (size_t)gm.off[l], 0, 2 * (size_t)(gm.off[e] - gm.off[l]) * sizeof(float), stream));
         hipLaunchKernelGGL(k_hashgrid_bwd, dim3(blocks), dim3(EN_BLOCK), 0, stream, gd, hm >> l, x, x_stride, denc_t + (size_t)2 * l * ld, ld,
-                           n, n_dev, rows, grad_table, (float*)nullptr, 0u, 0u, 0u);
+                           n, n_dev, rows, grad_table);
         XR_LAUNCH_CHECK();
         l = e;
     }
@@ -1156,11 +346,6 @@ extern "C" int xr_hashgrid_bwd2(const float* x, uint32_t x_stride, const float* 
     XR_REQUIRE(x && denc_t, "null pointer");
     XR_REQUIRE(x_stride >= 3 && ld >= n, "bad stride");
     XR_REQUIRE(!rows || n_dev, "a row list comes with its device-side length (n_dev)");
-    if (sc_mode() != 2) {
-        if (overwrite) XR_HIP(hipMemsetAsync(grad_table + 2 * (size_t)gm.off[0], 0, 2 * (size_t)(gm.off[n_levels] - gm.off[0]) * sizeof(float), stream));
-        return hashgrid_bwd_gen12(x, x_stride, denc_t, ld, n, n_dev, rows, n_levels, scale_host, resolution_host, offset_host, grad_table,
-                                  workspace, workspace_bytes, stream_);
-    }
     // levels without a non-atomic path (tiny / oddly shaped tables, small n) take the atomic kernel -- beside the binned levels on a
     // helper stream when both exist (disjoint table slices)
     uint32_t amask = xr_scatter3_atomic_mask(n, gm, hm, workspace && ((uintptr_t)workspace & 15) == 0 && ((uintptr_t)grad_table & 15) == 0);
@@ -1194,7 +379,7 @@ extern "C" int xr_hashgrid_bwd2(const float* x, uint32_t x_stride, const float* 
 extern "C" int xr_hashgrid_bwd_adam_supported(uint32_t n, int n_levels, const float* scale_host, const uint32_t* resolution_host,
                                               const uint32_t* offset_host) {
     GridMeta gm; uint32_t hm;
-    if (!scale_host || !resolution_host || !offset_host || n == 0 || sc_mode() != 2) return 0;
+    if (!scale_host || !resolution_host || !offset_host || n == 0) return 0;
     if (fill_meta(&gm, &hm, n_levels, scale_host, resolution_host, offset_host) != 0) return 0;
     return xr_scatter3_atomic_mask(n, gm, hm, true) == 0 ? 1 : 0;
 }
@@ -1209,7 +394,7 @@ extern "C" int xr_hashgrid_bwd_adam(const float* x, uint32_t x_stride, const flo
     XR_REQUIRE(n > 0 && x_stride >= 3 && ld >= n, "bad sizes");
     XR_REQUIRE(!rows || n_dev, "a row list comes with its device-side length (n_dev)");
     XR_REQUIRE(xr_hashgrid_bwd_adam_supported(n, n_levels, scale_host, resolution_host, offset_host),
-               "a level of this geometry / row count has no non-atomic path (or XR_SC_MODE != 2): scatter and step separately");
+               "a level of this geometry / row count has no non-atomic path: scatter and step separately");
     GridMeta gm; uint32_t hm;
     XR_REQUIRE(fill_meta(&gm, &hm, n_levels, scale_host, resolution_host, offset_host) == 0, "bad level metadata");
     // the constants exactly as xr_adam_step_multi hands them to its kernel

@@ -12,14 +12,8 @@ struct GridMeta {
     uint32_t off[EN_MAX_LEVELS + 1];
     int n_levels;
     uint32_t n_sblocks;   // sample blocks per level
-    int order;            // 0: levels of an XCD interleaved, 1: level-major within the XCD, 2: all XCDs share every
-                          // level, 3: level-major AND work-balanced over the XCDs (hg_balanced_block)
-    uint8_t wsh[EN_MAX_LEVELS];   // order 3: log2 of the relative cost of one sample block of the level
-    uint32_t wsum;                // order 3: sum of the costs of levels [l_min, n_levels)
-    int l_min;                    // order 3: first level this launch covers (lower ones: k_hashgrid_fwd_lds)
-    int nt;                       // non-temporal (L1-bypassing) table loads at the hashed levels
-    int pairs;                    // round-1 gather: 16-B loads for adjacent x-neighbour pairs (divergent)
-    uint32_t n_hashed;            // order 4: levels [n_levels - n_hashed, n_levels) are the hashed list
+    int order;            // block -> (level, sample block): 1 = level-major within the XCD (XCD x owns levels x, x + 8), 2 = all XCDs share every
+                          // level (partial level ranges of the atomic scatter), 5 = the forward's explicit cost-balanced map (XcdMap)
 };
 
 #ifndef HG_FAST_MOD
@@ -51,8 +45,7 @@ static inline int fill_meta(GridMeta* gm, uint32_t* hashed_mask, int n_levels, c
                      const uint32_t* off) {
     if (n_levels < 1 || n_levels > EN_MAX_LEVELS || !scale || !res || !off) return -1;
     gm->n_levels = n_levels;
-    gm->l_min = 0; gm->nt = 0; gm->wsum = 0; gm->n_sblocks = 0; gm->pairs = 0; gm->n_hashed = 0;
-    memset(gm->wsh, 0, sizeof(gm->wsh));
+    gm->n_sblocks = 0;
     *hashed_mask = 0;
     for (int l = 0; l < n_levels; ++l) {
         gm->scale[l] = scale[l]; gm->res[l] = res[l]; gm->off[l] = off[l];

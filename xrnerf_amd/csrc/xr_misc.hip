@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
 struct AdamTensors { float* p[4]; const float* g[4]; float* m[4]; float* v[4]; float* ema[4]; unsigned long long n[4]; unsigned first_block[5]; };
 // NT: the optimiser states (m, v, EMA copy) and the gradient -- 390 of the 439 MB this launch moves, each byte touched once per
 // step -- go through non-temporal loads / stores so that the parameters, which the next step's gather reads right away, are
-// what the caches keep (XR_ADAM_NT=0 switches it off; measured in the training loop, profiles/r03_adam_nontemporal.txt:
+// what the caches keep (build with -DXR_ADAM_NT=0 to switch it off -- tools/build_variant.sh; measured in the training loop, profiles/r03_adam_nontemporal.txt:
 // 0.534 -> 0.520 ms per step: the gather 93 -> 89 us, the scatter 113 -> 108 us, this launch 71 -> 70 us)
 typedef float am_f4 __attribute__((ext_vector_type(4)));
 template <bool NT> __device__ __forceinline__ float4 am_ld(const float* p, size_t i) {
@@ -222,11 +222,11 @@ extern "C" int xr_adam_step_multi(int n_tensors, float* const* p, const float* c
     }
     for (int k = n_tensors; k <= 4; ++k) t.first_block[k] = blocks;
     const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
-    static const bool nt = []() { const char* e = getenv("XR_ADAM_NT"); return !(e && e[0] == '0'); }();     // default on
-    if (nt) hipLaunchKernelGGL(k_adam_multi<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, t, n_tensors, beta1, beta2, lr / bc1,
-                               sqrtf(bc2), eps, weight_decay, ema_momentum, grad_scale);
-    else hipLaunchKernelGGL(k_adam_multi<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, t, n_tensors, beta1, beta2, lr / bc1,
-                            sqrtf(bc2), eps, weight_decay, ema_momentum, grad_scale);
+#ifndef XR_ADAM_NT
+#define XR_ADAM_NT 1
+#endif
+    hipLaunchKernelGGL(k_adam_multi<XR_ADAM_NT != 0>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, t, n_tensors, beta1, beta2, lr / bc1,
+                       sqrtf(bc2), eps, weight_decay, ema_momentum, grad_scale);
     XR_LAUNCH_CHECK();
     return XR_OK;
 }

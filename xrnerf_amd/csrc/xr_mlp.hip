@@ -1642,7 +1642,10 @@ static int launch_fwd(const float* enc_t, uint32_t ld, const float* dirs, uint32
                       const uint32_t* rows, const float* wd, const float* wc, float pad, float* raw, hipStream_t stream) {
     const int cus = xr_device_cus() > 0 ? xr_device_cus() : 256;
     const uint32_t n_tiles = (n + 31) / 32;
-    static const int per_cu = []() { const char* e = getenv("XR_MLP_FWD_WGS_PER_CU"); const int v = e ? atoi(e) : 3; return v >= 1 && v <= 3 ? v : 3; }();
+#ifndef XR_MLP_FWD_WGS_PER_CU
+#define XR_MLP_FWD_WGS_PER_CU 3       // 1..3 (tools/build_variant.sh)
+#endif
+    const int per_cu = XR_MLP_FWD_WGS_PER_CU;
     const uint32_t grid = min(xr_div_up(n_tiles, MLP_WAVES), (uint32_t)cus * (uint32_t)per_cu);
     if (dirs) {
         const size_t lds = (NetShape<NHD>::lds_floats + NetShape<NHC>::lds_floats) * sizeof(float);

@@ -887,7 +887,8 @@ __global__ __launch_bounds__(CT_BLOCK) void k_composite_train(
             if (__float_as_uint(ct_dt[r]) == CT_MARK) dout[lo + r] = ct_rows[r];
 }
 
-// ---- the fused compositor, one WAVE per ray (the default of xr_composite_train2; XR_CT_WAVE=0 restores the 16-lane kernel above)
+// ---- the fused compositor, one WAVE per ray (what xr_composite_train2 runs when the caller takes the loss scalars separately; build with
+// -DXR_CT_WAVE=0 for the 16-lane kernel above in that case too -- tools/build_variant.sh)
 // What bounds the 16-lane form is neither memory nor the loss atomics alone but the lock step: a wave's time is its LONGEST
 // chunk (rays of 143 samples: 9 samples per lane, twice over) times ~390 issue cycles per sample (13 transcendentals), with 59 %
 // of the lanes sitting on rays without samples, and a workgroup per compute unit makes that 4 waves per SIMD back to back --
@@ -1063,9 +1064,13 @@ extern "C" int xr_composite_train2(const float* network_output, const float* coo
                density_grid_mean && rgb_output && dloss_doutput, "null pointer");
     XR_REQUIRE((((uintptr_t)network_output | (uintptr_t)dloss_doutput) & 15) == 0, "raw/grad buffers must be 16-byte aligned");
     XR_REQUIRE(n_rays > 0, "n_rays == 0");
-    // XR_CT_WAVE=0 (measurement, read once): the 16-lanes-per-ray kernel also when the caller takes the loss scalars separately
-    static const int wave = []() { const char* e = getenv("XR_CT_WAVE"); return (e && e[0] == '0') ? 0 : 1; }();
-    if (!loss_mse_out && wave) {
+#ifndef XR_CT_WAVE
+#define XR_CT_WAVE 1
+#endif
+#ifndef XR_CT_STAGE
+#define XR_CT_STAGE 1       // 0: every workgroup of the 16-lane kernel on the direct path (no LDS staging of its row range)
+#endif
+    if (!loss_mse_out && XR_CT_WAVE) {
         hipLaunchKernelGGL(k_composite_train_w, dim3(xr_div_up(n_rays, CW_RAYS)), dim3(64 * CW_RAYS), 0, (hipStream_t)stream_, n_rays,
                            (const float4*)network_output, coords, rays_numsteps, rays_numsteps_compacted, bg_color, target,
                            density_grid_mean, rgb_activation, density_activation, delta, scale, rgb_output, (float4*)dloss_doutput,
@@ -1073,8 +1078,7 @@ extern "C" int xr_composite_train2(const float* network_output, const float* coo
         XR_LAUNCH_CHECK();
         return XR_OK;
     }
-    // XR_CT_STAGE=0 (measurement, read once): every workgroup on the direct path
-    static const int stage = []() { const char* e = getenv("XR_CT_STAGE"); return (e && e[0] == '0') ? 0 : 1; }();
+    const int stage = XR_CT_STAGE;
     static bool attr_set = false;
     if (!attr_set) {
         XR_HIP(hipFuncSetAttribute((const void*)k_composite_train, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CT_LDS_BYTES));

@@ -691,18 +691,37 @@ __global__ __launch_bounds__(256) void k_scatter_fold(S3RPlan pl, const float2* 
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-static int s3_env(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
+// XR_SC_TEST="min_n=256,block=1024,rl_chunks=3,rl=0" (read once per process): the layout parameters the tests vary -- the row
+// threshold below which every level takes the atomic kernel (tests run the binned path at sizes the host emulation finishes
+// quickly), samples per binning workgroup (1024 | 2048 | 4096), row chunks per partition of the run-length kernel, rl=0 the small
+// dense levels through the bins.  Measurement-only alternatives of earlier rounds are compile-time now (S3_LOG2, S3_ACC_THREADS,
+// S3_RL_ASYNC: tools/build_variant.sh) or gone with their records under profiles/.
+struct S3Test { int min_n = 16384, block = 2048, rl_chunks = 16, rl = 1; };
+static const S3Test& s3_test() {
+    static const S3Test t = []() {
+        S3Test v;
+        const char* e = getenv("XR_SC_TEST");
+        while (e && *e) {
+            int val = 0;
+            if (sscanf(e, "min_n=%d", &val) == 1) v.min_n = val;
+            else if (sscanf(e, "block=%d", &val) == 1) v.block = (val == 1024 || val == 4096) ? val : 2048;
+            else if (sscanf(e, "rl_chunks=%d", &val) == 1) v.rl_chunks = (val >= 1 && val <= 64) ? val : 16;
+            else if (sscanf(e, "rl=%d", &val) == 1) v.rl = val != 0;
+            const char* c = strchr(e, ',');
+            e = c ? c + 1 : nullptr;
+        }
+        return v;
+    }();
+    return t;
 }
-static uint32_t s3_block_samples() {          // XR_SC_BLOCK: samples per binning workgroup (4096 | 2048 | 1024); measured 152 / 139 / 155 us
-    static const int bs = []() { const int v = s3_env("XR_SC_BLOCK", 2048); return v == 1024 || v == 4096 ? v : 2048; }();
-    return (uint32_t)bs;
-}
-static uint32_t s3_chunks() {                 // XR_SC_RL_CHUNKS: row chunks per partition of the run-length kernel
-    static const int c = []() { const int v = s3_env("XR_SC_RL_CHUNKS", 16); return v >= 1 && v <= 64 ? v : 16; }();
-    return (uint32_t)c;
-}
+static uint32_t s3_block_samples() { return (uint32_t)s3_test().block; }     // measured 152 / 139 / 155 us for 4096 / 2048 / 1024
+static uint32_t s3_chunks() { return (uint32_t)s3_test().rl_chunks; }
+#ifndef S3_ACC_THREADS_DEFAULT
+#define S3_ACC_THREADS_DEFAULT 512      // 512 | 1024 threads per accumulate workgroup: the same time alone; with 8 waves the march the trainer
+#endif                                  // runs beside this kernel finds registers on every SIMD (profiles/r03_accumulate_512_threads_ab.txt)
+#ifndef S3_RL_ASYNC
+#define S3_RL_ASYNC 1                   // the small dense levels on an internal helper stream beside the bin / accumulate pair
+#endif
 
 struct S3Layout {
     S3Plan bin; S3RPlan rl;
@@ -715,19 +734,18 @@ static bool s3_layout(uint32_t n, const GridMeta& gm, uint32_t hashed_mask, int 
     memset(&P, 0, sizeof(P));
     const uint32_t bs = s3_block_samples();
     const uint32_t nsb = xr_div_up(n, bs);
-    // below XR_SC_MIN_N rows (default 16384) the fixed costs -- 128 KiB of LDS per partition zeroed and written back -- exceed
+    // below min_n rows (default 16384; XR_SC_TEST) the fixed costs -- 128 KiB of LDS per partition zeroed and written back -- exceed
     // what the atomic kernel needs; the tests lower it to run this path at sizes the host emulation finishes quickly
-    static const uint32_t min_n = (uint32_t)s3_env("XR_SC_MIN_N", 16384);
+    const uint32_t min_n = (uint32_t)s3_test().min_n;
     if (n < min_n || nsb > S3_MAX_SB) { P.atomic_mask = (1u << gm.n_levels) - 1u; return false; }
     // (measured and dropped: 2^12-entry partitions accumulated by 512-thread workgroups in 64 KiB of LDS, two per CU:
     // 172.8 us against 138.7 for the whole entry point, profiles/r03_scatter3_defaults.txt)
     const uint32_t lg = S3_LOG2, entries = S3_ENTRIES;
     P.bin.nsb = nsb; P.bin.overwrite = (uint32_t)overwrite; P.bin.ovf_cap = 8u * bs; P.bin.lg = lg;
     P.rl.chunks = s3_chunks(); P.rl.overwrite = (uint32_t)overwrite;
-    // XR_SC_RL=0: the small dense levels through the binned path too (measurement: 277 us instead of 41 before the accumulate
-    // kernel merged runs in registers)
-    static const int use_rl = s3_env("XR_SC_RL", 1) != 0;
-    static const int dense_atomic = s3_env("XR_SC_DENSE_ATOMIC", 0);   // 1: every dense level through the atomic kernel (measurement)
+    // rl=0 (XR_SC_TEST): the small dense levels through the binned path too (277 us instead of 41 before the accumulate kernel merged
+    // runs in registers; kept as a test of the kind-D layout at small resolutions)
+    const int use_rl = s3_test().rl;
     uint64_t bins_off = 0, ovf_off = 0;
     uint32_t counts_off = 0;
     // accumulate order: dense binned levels first (32 partitions carry twice a hashed partition's items)
@@ -737,8 +755,8 @@ static bool s3_layout(uint32_t n, const GridMeta& gm, uint32_t hashed_mask, int 
             const bool hashed = (hashed_mask >> l) & 1;
             const bool kindH = hashed && (hsize & (hsize - 1)) == 0 && hsize >= entries && (hsize >> lg) <= S3_MAX_PARTS &&
                                res < entries && (gm.off[l] & 1) == 0;
-            const bool kindR = !hashed && hsize <= S3_R_MAX_ENTRIES && use_rl && !dense_atomic;
-            const bool kindD = !hashed && !kindR && res >= 8u && res <= 128u && (uint64_t)res * res * res <= hsize && !dense_atomic;
+            const bool kindR = !hashed && hsize <= S3_R_MAX_ENTRIES && use_rl;
+            const bool kindD = !hashed && !kindR && res >= 8u && res <= 128u && (uint64_t)res * res * res <= hsize;
             if (pass == 0 && !kindH && !kindD && !kindR) P.atomic_mask |= 1u << l;
             if (pass == 0 && kindR) {
                 S3RLevel& R = P.rl.lv[P.rl.n_lv++];
@@ -819,11 +837,9 @@ int xr_scatter3(const float* x, uint32_t x_stride, const float* denc_t, uint32_t
         XR_HIP(hipFuncSetAttribute((const void*)k_scatter_dense_rl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES));
         attr_set = true;
     }
-    // XR_SC_RL_FIRST=0: the small dense levels AFTER the bin / accumulate pair instead of before it (measurement)
-    // XR_SC_RL_ASYNC=1: ... on an internal helper stream beside the pair (disjoint table slices, read-only inputs), forked from
-    // and joined back into the caller's stream with events
-    static const int rl_first = s3_env("XR_SC_RL_FIRST", 1);
-    static const int rl_async = s3_env("XR_SC_RL_ASYNC", 1);
+    // the small dense levels' two kernels are enqueued first, on an internal helper stream beside the bin / accumulate pair (disjoint
+    // table slices, read-only inputs), forked from and joined back into the caller's stream with events
+    const int rl_first = 1, rl_async = S3_RL_ASYNC;
     static hipStream_t aux = nullptr;
     static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     const bool fork = rl_async && P.rl.n_lv > 0 && P.bin.n_lv > 0;
@@ -834,8 +850,8 @@ int xr_scatter3(const float* x, uint32_t x_stride, const float* denc_t, uint32_t
     }
     // the caller's small kernels (xr_ngp_train_step: reduction of the MLP partials, MLP Adam, loss scalars, a clear) run on the helper
     // stream BEHIND the dense levels' two kernels: those then start beside the bin kernel instead of 40 us into the accumulate
-    // kernel, whose HBM streams they disturb (scatter 181 -> 172 us, profiles/r03_aux_kernels_last_ab.txt).  XR_SC_AUX_LAST=0: before.
-    static const bool aux_last = s3_env("XR_SC_AUX_LAST", 1) != 0;
+    // kernel, whose HBM streams they disturb (scatter 181 -> 172 us, profiles/r03_aux_kernels_last_ab.txt)
+    const bool aux_last = true;
     auto launch_rl = [&]() -> int {
         if (P.rl.n_lv == 0) return XR_OK;
         hipStream_t rs = stream;
@@ -873,9 +889,7 @@ int xr_scatter3(const float* x, uint32_t x_stride, const float* denc_t, uint32_t
         else if (bs == 2048) hipLaunchKernelGGL(k_scatter_bin3<2048>, grid, block, 0, stream, P.bin, x, x_stride, denc_t, ld, n, n_dev, rows, counts, bins, ovf);
         else hipLaunchKernelGGL(k_scatter_bin3<1024>, grid, block, 0, stream, P.bin, x, x_stride, denc_t, ld, n, n_dev, rows, counts, bins, ovf);
         XR_LAUNCH_CHECK();
-        // XR_SC_ACC_THREADS (read once): 512 (default) | 1024 threads per accumulate workgroup -- the same time alone; with 8 waves the
-        // march that the trainer runs beside this kernel (prefetch depth 2) finds registers on every SIMD
-        static const int acc_threads = s3_env("XR_SC_ACC_THREADS", 512);
+        const int acc_threads = S3_ACC_THREADS_DEFAULT;
         if (acc_threads == 512)
             hipLaunchKernelGGL((k_scatter_accum3<S3_LOG2, 512>), dim3(P.bin.acc_blocks), dim3(512), S3_LDS_BYTES, stream, P.bin, (const uint32_t*)counts,
                                (const float4*)bins, (const float4*)ovf, grad_table);

@@ -75,10 +75,16 @@ extern "C" int xr_ngp_train_step(
     hipStream_t stream = (hipStream_t)stream_;
     // The reduction of the MLP backward's per-workgroup partials (first read by the optimiser) rides on the helper stream the
     // table scatter forks anyway for its small dense levels, in front of them: one launch and one dependent-kernel boundary
-    // (~5 us each on this part) less on the caller's stream, no event of its own.  XR_STEP_REDUCE_AUX=0: on the caller's stream.
+    // (~5 us each on this part) less on the caller's stream, no event of its own.  -DXR_STEP_REDUCE_AUX=0: on the caller's stream.
     // (Round 2 measured a SEPARATE fork / join for it: 0.562 ms against 0.542 ms per iteration -- the extra cross-queue joins
     // cost more than the kernel.)  The zero-fill of the table gradient is gone: the scatter WRITES it (XR_SCATTER_OVERWRITE).
-    static const bool reduce_aux = []() { const char* e = getenv("XR_STEP_REDUCE_AUX"); return !(e && e[0] == '0'); }();
+#ifndef XR_STEP_REDUCE_AUX
+#define XR_STEP_REDUCE_AUX 1
+#endif
+#ifndef XR_STEP_SHARE_FORK
+#define XR_STEP_SHARE_FORK 1
+#endif
+    const bool reduce_aux = XR_STEP_REDUCE_AUX != 0;
     auto begin = [&](const char* name) -> int { if (stage_is(timed_entry, name)) XR_HIP(hipEventRecord((hipEvent_t)timing_begin, stream)); return XR_OK; };
     // mark_entry / mark_event: the event is recorded on `stream` right behind the named entry point's launches (the trainer
     // starts the next batch's side-stream march from there instead of beside the fused-MLP forward)
@@ -160,8 +166,8 @@ extern "C" int xr_ngp_train_step(
                          }, &ta, false};
     if (reduce_aux) xr_internal_scatter_aux_prologue(&pro);
     // the mark behind the MLP backward is the last thing on `stream`: the scatter orders its helper stream behind that event instead
-    // of recording one of its own (XR_STEP_SHARE_FORK=0: its own)
-    static const bool share_fork = []() { const char* e = getenv("XR_STEP_SHARE_FORK"); return !(e && e[0] == '0'); }();
+    // of recording one of its own (-DXR_STEP_SHARE_FORK=0: its own)
+    const bool share_fork = XR_STEP_SHARE_FORK != 0;
     if (share_fork && mark_event && stage_is(mark_entry, "xr_nerf_mlp_bwd") && !stage_is(timed_entry, "xr_hashgrid_bwd"))
         xr_internal_scatter_fork_event(mark_event);
     if ((rc = begin("xr_hashgrid_bwd")) != XR_OK) return rc;
@@ -179,7 +185,7 @@ extern "C" int xr_ngp_train_step(
     xr_internal_scatter_aux_prologue(nullptr);
     xr_internal_scatter_fork_event(nullptr);
     if (rc != XR_OK) return rc;
-    if (!pro.done && (rc = pro.fn(stream, pro.arg)) != XR_OK) return rc;     // the scatter did not fork (or XR_STEP_REDUCE_AUX=0)
+    if (!pro.done && (rc = pro.fn(stream, pro.arg)) != XR_OK) return rc;     // the scatter did not fork (or the build keeps them on this stream)
     if ((rc = end("xr_hashgrid_bwd")) != XR_OK) return rc;
     return XR_OK;
 }

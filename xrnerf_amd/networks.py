@@ -7,7 +7,7 @@ import time
 import torch
 from torch import nn
 
-from . import builder
+from . import builder, switches
 from .builder import NETWORKS
 
 
@@ -115,7 +115,7 @@ class _FusedTrainStepFn(torch.autograd.Function):
                 sampler.on_sampled = cb
             sync = getattr(net, 'grad_sync', None)
             if table.is_cuda and mlp.density_net.n_hidden == 1 and mlp.color_net.n_hidden == 2 and \
-                    os.environ.get('XRNERF_PY_STEP') != '1' and (ops.TIMER is None or ops.TIMER.native_stage()[0]):
+                    switches.step_mode() == 'fused' and (ops.TIMER is None or ops.TIMER.native_stage()[0]):
                 # the whole device side of the step as ONE native call (csrc/xr_step.hip) -- the same entry points in the same
                 # order as the Python sequence below, which stays for the kernels' host build and whenever a KernelTimer wants
                 # events around the individual entry points (bench.py's roofline windows).  Data parallel: the native call
@@ -359,15 +359,15 @@ class HashNerfNetwork(_FastAttr, BaseNerfNetwork):
         """forward in smaller minibatches (networks/nerf.py:50-69).  A test-mode frame cut into several chunks (the config's
         chunk = 4096: 157 chunks per 800x800 frame) is marched WITHOUT a host read-back per chunk (samplers.begin_async_test):
         one check at the end of the frame, chunks whose sample buffer overflowed are done again -- same pixels as the
-        synchronous form (XRNERF_ASYNC_CHUNKS=0), which costs one device-to-host round trip per chunk."""
+        synchronous form (XRNERF_FRAME=sync), which costs one device-to-host round trip per chunk."""
         N = data[self.bs_data].shape[0]
         from .samplers import NGPGridSampler
         if (is_test and (N > self.chunk or getattr(self.sampler, 'frame_ray0', 0)) and type(self.sampler) is NGPGridSampler
-                and os.environ.get('XRNERF_FRAME_ONE_LAUNCH', '1') != '0'):
+                and switches.frame_mode() == 'one_launch'):
             # The whole frame as ONE launch per kernel with the SAME pixels as the chunk loop: encode, MLP and compositor are
             # per-sample / per-ray maps, and K1 -- whose hidden generator the loop would advance once per chunk -- draws every
             # ray's jitter as the ray's chunk-th launch would (`frame_chunk`).  61 ms -> 6 ms per 800x800 frame at chunk = 4096
-            # (157 chunks x ~0.4 ms of launches); XRNERF_FRAME_ONE_LAUNCH=0 runs the loop.
+            # (157 chunks x ~0.4 ms of launches); XRNERF_FRAME=async | sync runs the loop.
             self.sampler.frame_chunk = int(self.chunk)
             try:
                 return self.forward(dict(data), is_test)
@@ -383,7 +383,7 @@ class HashNerfNetwork(_FastAttr, BaseNerfNetwork):
                     data_chunk[k] = data[k]
             pieces.append(data_chunk)
         use_async = (is_test and len(pieces) > 1 and hasattr(self.sampler, 'begin_async_test') and self.sampler._streams()
-                     and os.environ.get('XRNERF_ASYNC_CHUNKS', '1') != '0')
+                     and switches.frame_mode() != 'sync')
         if use_async:
             self.sampler.begin_async_test()
         rets = [self.forward(dict(c), is_test) for c in pieces]
@@ -405,7 +405,7 @@ class HashNerfNetwork(_FastAttr, BaseNerfNetwork):
         from .samplers import NGPGridSampler
         from . import ops
         import os
-        return (os.environ.get('XRNERF_MODULAR_STEP') != '1' and type(self.sampler) is NGPGridSampler and
+        return (switches.step_mode() != 'modular' and type(self.sampler) is NGPGridSampler and
                 type(self.mlp) is HashNerfMLP and type(self.render) is HashNerfRender and
                 ops._on_device(self.mlp.embedder_pos.params) and torch.is_grad_enabled())
 
@@ -488,7 +488,7 @@ class HashNerfNetwork(_FastAttr, BaseNerfNetwork):
         # hidden-generator counter moves on by the whole frame's launches: the pixels are those of the one-GPU / reference frame whatever
         # the world size, and the ranks' training RNG streams stay in step
         from .samplers import NGPGridSampler
-        exact = type(self.sampler) is NGPGridSampler and os.environ.get('XRNERF_FRAME_ONE_LAUNCH', '1') != '0' and N > self.chunk
+        exact = type(self.sampler) is NGPGridSampler and switches.frame_mode() == 'one_launch' and N > self.chunk
         k1_before = getattr(self.sampler, 'k1_calls', 0)
         if exact:
             self.sampler.frame_ray0 = row0 * W

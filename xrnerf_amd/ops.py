@@ -111,9 +111,7 @@ if _PRECISION not in ('f32', 'f16'):
 # forward of the 'f32' mode on the (1, 2) topology: 'bf16x3' = xr_nerf_mlp_fwd_bf16x3 (fp32 operands split exactly into three
 # bf16 numbers, six bf16 MFMAs per product block, fp32 accumulate: fp32-rounding accuracy on the 16x faster matrix-core
 # path), 'mfma' = xr_nerf_mlp_fwd (v_mfma_f32_32x32x2_f32).  Other topologies always take the latter.
-_F32_FORWARD = os.environ.get('XRNERF_F32_FORWARD', 'bf16x3')
-if _F32_FORWARD not in ('bf16x3', 'mfma'):
-    raise ValueError("XRNERF_F32_FORWARD must be 'bf16x3' or 'mfma' (got %r)" % _F32_FORWARD)
+_F32_FORWARD = 'bf16x3'          # (set_f32_forward)
 
 
 def f32_forward():
@@ -390,7 +388,7 @@ def ngp_train_step(table, wd, wc, nhd, nhc, pad_value, meta, coords, n_dev, nums
     if TIMER is not None:
         ok, stage = TIMER.native_stage()
         if not ok:
-            raise _lib.XrError('this KernelTimer needs the per-entry-point launch sequence (XRNERF_PY_STEP=1)')
+            raise _lib.XrError('this KernelTimer needs the per-entry-point launch sequence (XRNERF_STEP=py)')
         if stage is not None:
             ev = (_CEvent(), _CEvent())
             TIMER.events.setdefault(stage, []).append((ev[0], ev[1], 0))

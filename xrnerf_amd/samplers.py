@@ -98,7 +98,7 @@ class NGPGridSampler(_FastAttr, nn.Module):
         if not hasattr(self, 'density_grid'):
             self.density_grid = ops.mark_untrained_density_grid(self.focal, self.transforms, n_elements,
                                                                 self.resolutions)
-        planes = hasattr(mlp, 'run_density_planes') and self._streams() and os.environ.get('XRNERF_XYZ_PLANES', '1') != '0'
+        planes = hasattr(mlp, 'run_density_planes') and self._streams()
         pre = self.__dict__.pop('_k6_prefetched', None)
         if pre is not None and planes and pre['key'] == (n_uniform, n_nonuniform, self.density_grid_ema_step):
             # K6 and the clear of the temporary grid ran on the side stream during the previous iteration (prefetch_grid_samples)
@@ -168,7 +168,7 @@ class NGPGridSampler(_FastAttr, nn.Module):
         """call inside `with torch.cuda.stream(self.side_stream())` during the iteration BEFORE one that starts with a grid refresh:
         K6 (both calls) and the clear of the temporary grid read the density grid and the RNG call counter only -- neither changes
         until that refresh -- so they leave its critical path (~45 us of the refresh's 0.8 ms).  Same values, same call counters."""
-        if not (self._streams() and hasattr(self, 'density_grid') and os.environ.get('XRNERF_XYZ_PLANES', '1') != '0'):
+        if not (self._streams() and hasattr(self, 'density_grid')):
             return
         n_uniform, n_nonuniform = self._refresh_counts(next_iter_n)
         side = torch.cuda.current_stream()
@@ -382,7 +382,7 @@ class NGPGridSampler(_FastAttr, nn.Module):
     def _xyz_buffer(self, rows, slot):
         """[3, rows] planes holding the positions of the slot's coordinate rows once more (K1 writes both): the encoder's
         coalesced input.  Device only (the host build of the kernels reads the rows)."""
-        if not self._streams() or os.environ.get('XRNERF_XYZ_PLANES', '1') == '0':
+        if not self._streams():
             return None
         bufs = getattr(self, '_xyz_bufs', None)
         if bufs is None:

@@ -1,0 +1,46 @@
+"""The runtime switches of the host side, in one place (the C library reads XR_MLP_BWD_DW, XR_MLP_LIVE, XR_GEMM_F32 and XR_SC_TEST
+itself).  tools/README.md lists every switch with the test that covers it; everything else that earlier rounds A/B-tested is either
+a compile-time constant of one source (tools/build_variant.sh + XRNERF_LIB) or gone, with its record under profiles/.
+
+  XRNERF_LIB                   path of another build of the library (_lib.py)
+  XRNERF_MLP_PRECISION         f32 (default, parity mode) | f16 (the reference's tcnn arithmetic) -- ops.set_precision
+  XRNERF_DP                    allreduce (default) | zero1 -- the data-parallel gradient exchange (train.Trainer)
+  XRNERF_TRAINER               "k=v,..." overrides of Trainer's keyword switches: native_loop, fuse_adam, direct_step, overlap_march,
+                               prefetch_depth, prefetch_k6 (A/B runs of bench.py / tools without editing code)
+  XRNERF_STEP                  fused (default: one native call per training step) | py (the same entry points issued one by one from
+                               Python: per-entry-point timers, the kernels' host build) | modular (sampler -> mlp -> render -> autograd)
+  XRNERF_FRAME                 one_launch (default: a chunked test frame as one launch per kernel, same pixels) | async (the chunk loop
+                               without a read-back per chunk) | sync (the reference's loop)
+  XRNERF_TCNN_STRICT_DEFAULTS  1: tcnn's default 5 hidden layers where the config's `num_layers` is not a tcnn key (mlps.py)
+  XRNERF_VAL_RANK0_ONLY        1: validation frames on rank 0 only, like the reference (networks.py)
+"""
+import os
+
+
+def step_mode():
+    m = os.environ.get('XRNERF_STEP', 'fused')
+    if m not in ('fused', 'py', 'modular'):
+        raise ValueError("XRNERF_STEP must be 'fused', 'py' or 'modular' (got %r)" % m)
+    return m
+
+
+def frame_mode():
+    m = os.environ.get('XRNERF_FRAME', 'one_launch')
+    if m not in ('one_launch', 'async', 'sync'):
+        raise ValueError("XRNERF_FRAME must be 'one_launch', 'async' or 'sync' (got %r)" % m)
+    return m
+
+
+TRAINER_KEYS = {'native_loop': bool, 'fuse_adam': bool, 'direct_step': bool, 'overlap_march': bool, 'prefetch_depth': int, 'prefetch_k6': bool}
+
+
+def trainer_overrides():
+    """XRNERF_TRAINER="fuse_adam=0,prefetch_depth=1" -> {'fuse_adam': False, 'prefetch_depth': 1}"""
+    out = {}
+    for item in filter(None, os.environ.get('XRNERF_TRAINER', '').split(',')):
+        k, _, v = item.partition('=')
+        k = k.strip()
+        if k not in TRAINER_KEYS:
+            raise ValueError('XRNERF_TRAINER: unknown key %r (known: %s)' % (k, ', '.join(sorted(TRAINER_KEYS))))
+        out[k] = bool(int(v)) if TRAINER_KEYS[k] is bool else int(v)
+    return out

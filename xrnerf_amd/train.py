@@ -16,7 +16,7 @@ import time
 
 import torch
 
-from . import _lib, ops, synthetic
+from . import _lib, ops, switches, synthetic
 from .builder import build_network
 from .datasets import DeviceRayTable
 
@@ -209,7 +209,20 @@ class Trainer:
     """One process = one GPU.  Per iteration: hooks (set_iter, batch size) -> batch -> train_step ->
     backward -> [gradient all-reduce] -> fused Adam(+EMA)."""
 
-    def __init__(self, device, n_img=20, H=800, W=800, seed=0, world_size=1, rank=0, dataset=None, ema=True):
+    def __init__(self, device, n_img=20, H=800, W=800, seed=0, world_size=1, rank=0, dataset=None, ema=True, native_loop=True,
+                 fuse_adam=True, direct_step=True, overlap_march=True, prefetch_depth=2, prefetch_k6=True):
+        """The keyword switches (each overridable from the environment: XRNERF_TRAINER="fuse_adam=0,..."; xrnerf_amd/switches.py):
+        native_loop     the iterations between two grid refreshes as native calls (xr_ngp_loop_run); False: one Python-driven step each
+        fuse_adam       one GPU: the table scatter applies this optimiser's update itself (False: scatter, then the optimiser's launches)
+        direct_step     one GPU: the fused step without an autograd graph (False: loss.backward() + optimizer.step())
+        overlap_march   K1 of later batches on a side stream under the current step (False: in order on the compute stream)
+        prefetch_depth  2: the march of iteration i + 2 is issued during iteration i, behind its MLP backward; 1: iteration i + 1 at once
+        prefetch_k6     the refresh's sample generation one iteration early, on the side stream"""
+        opts = dict(native_loop=native_loop, fuse_adam=fuse_adam, direct_step=direct_step, overlap_march=overlap_march,
+                    prefetch_depth=prefetch_depth, prefetch_k6=prefetch_k6)
+        opts.update(switches.trainer_overrides())
+        if opts['prefetch_depth'] not in (1, 2):
+            raise ValueError('prefetch_depth is 1 or 2')
         torch.manual_seed(seed)                       # identical initial weights on every rank
         self.device = device
         self.net = build_network(ngp_lego_model_cfg()).to(device)
@@ -238,42 +251,31 @@ class Trainer:
         if world_size > 1:
             # this trainer's optimiser applies the 1/world_size itself (FusedAdam.step(grad_scale=...)): the fused step leaves
             # the SUMMED gradients in .grad and reports the factor in net._pending_grad_scale
-            self.net._defer_grad_scale = os.environ.get('XRNERF_DEFER_GRAD_SCALE', '1') != '0'
-        # one GPU: the table scatter applies this optimiser's update to the table itself (XRNERF_FUSE_ADAM=0: separate launches).
-        # Valid because this trainer back-propagates a unit root gradient and clears the gradients every step.
-        # (the switch is raised around this trainer's own train_step calls only: anyone else calling net.train_step gets gradients)
-        self.fuse_adam = world_size == 1 and os.environ.get('XRNERF_FUSE_ADAM', '1') != '0'
-        self.direct_step = world_size == 1 and os.environ.get('XRNERF_DIRECT_STEP', '1') != '0'
+            self.net._defer_grad_scale = True
+        # one GPU: the table scatter applies this optimiser's update to the table itself.  Valid because this trainer back-propagates
+        # a unit root gradient and clears the gradients every step.  (The switch is raised around this trainer's own train_step
+        # calls only: anyone else calling net.train_step gets gradients.)
+        self.fuse_adam = world_size == 1 and opts['fuse_adam']
+        self.direct_step = world_size == 1 and opts['direct_step']
         self._opt_params = opt_params
         self.rays_done = 0
         self.lazy_log = True
-        # run K1 of the next batch on a side stream under this step's backward (XRNERF_OVERLAP_MARCH=0: serial)
-        self.overlap_march = os.environ.get('XRNERF_OVERLAP_MARCH', '1') != '0'
-        # where in the step the side-stream march may start: behind the named entry point of the fused step (XRNERF_PREFETCH_AFTER;
-        # 'none' = as soon as the step is enqueued).  Setting it by hand selects the one-iteration-ahead scheme with that start
-        # point; at depth 1 every later start point lost (profiles/r03_prefetch_start_point.txt, ms/step at that time: none 0.548,
-        # behind the encode 0.554, the fused-MLP forward 0.552, the compositor 0.582, the MLP backward 0.620 -- started late the
-        # march is not finished when the next iteration's encode needs its rows).  Left unset, depth 2 below picks its own.
-        after = os.environ.get('XRNERF_PREFETCH_AFTER', 'none')
-        if after not in ('none', 'xr_hashgrid_fwd', 'xr_nerf_mlp_fwd', 'xr_composite_train', 'xr_live_rows', 'xr_nerf_mlp_bwd'):
-            raise ValueError('XRNERF_PREFETCH_AFTER: unknown entry point %r' % after)
-        self.net._step_mark = (after, ops._CEvent(timing=False)) if (after != 'none' and device.type == 'cuda') else None
-        # XRNERF_PREFETCH_DEPTH (default 2): the march of iteration i + 2 is issued during iteration i and starts behind i's MLP
-        # backward, so that it runs beside the table scatter and the next encode instead of beside the two fused-MLP kernels --
-        # the backward's waves own whole SIMD register files and cannot be placed on a CU that hosts a marching wave, the forward
-        # shares its SIMDs with them: 87 -> 74 us and 62 -> 47 us when the march is elsewhere (profiles/r03_k1_placement_ab.txt).
-        # With one iteration of lead that start point leaves the march unfinished when its rows are needed; with two it has a
-        # whole iteration.  1 = the previous scheme (iteration i + 1, started as soon as i is enqueued).
-        self.prefetch_depth = 2 if os.environ.get('XRNERF_PREFETCH_DEPTH', '2') != '1' else 1
-        if self.prefetch_depth == 2 and self.net._step_mark is None and device.type == 'cuda':
-            self.net._step_mark = ('xr_nerf_mlp_bwd', ops._CEvent(timing=False))
-        self.prefetch_k6 = os.environ.get('XRNERF_PREFETCH_K6', '1') != '0'      # the refresh's K6 one iteration early, on the side stream
+        self.overlap_march = opts['overlap_march']
+        # prefetch_depth 2: the march of iteration i + 2 is issued during iteration i and starts behind i's MLP backward (the event the
+        # native step records there), so that it runs beside the table scatter and the next encode instead of beside the two fused-MLP
+        # kernels -- the backward's waves own whole SIMD register files and cannot be placed on a CU that hosts a marching wave, the
+        # forward shares its SIMDs with them: 87 -> 74 us and 62 -> 47 us when the march is elsewhere (profiles/r03_k1_placement_ab.txt).
+        # With one iteration of lead that start point leaves the march unfinished when its rows are needed (start points of the
+        # depth-1 scheme, all measured: profiles/r03_prefetch_start_point.txt); with two it has a whole iteration.
+        self.prefetch_depth = opts['prefetch_depth']
+        self.net._step_mark = ('xr_nerf_mlp_bwd', ops._CEvent(timing=False)) if (self.prefetch_depth == 2 and device.type == 'cuda') else None
+        self.prefetch_k6 = opts['prefetch_k6']      # the refresh's K6 one iteration early, on the side stream
         self._ev_done = [None, None]   # completion events of the last two iterations (None: the native loop ran it and holds the event)
         # the iterations between two grid refreshes as native calls (xr_ngp_loop_run: batch draw, march two iterations ahead, step with the
         # updates inside, enqueued from C++ -- the interpreter had been pacing the loop at 0.36 ms of host work per 0.42-ms iteration).
         # Needs what the fast Python path needs (one GPU, fused updates, the direct step, the native side-stream march, a device-resident
-        # ray table); anything else keeps the per-iteration path.  XRNERF_NATIVE_LOOP=0: off.
-        self.native_loop = os.environ.get('XRNERF_NATIVE_LOOP', '1') != '0'
+        # ray table); anything else keeps the per-iteration path.
+        self.native_loop = opts['native_loop']
         self._loop = None
         self._bbufs = [None, None, None]
         self._queue = []               # [(iteration, batch)] marched ahead, in order
@@ -315,10 +317,10 @@ class Trainer:
                 self.prefetch_depth == 2 and self.device.type == 'cuda' and hasattr(self.data, 'rays_rgb') and
                 type(net.sampler) is NGPGridSampler and type(net.mlp) is HashNerfMLP and type(net.render) is HashNerfRender and
                 net.mlp.density_net.n_hidden == 1 and net.mlp.color_net.n_hidden == 2 and self._data_takes_batches() and
-                isinstance(self.opt, FusedAdam) and os.environ.get('XRNERF_XYZ_PLANES', '1') != '0')
+                isinstance(self.opt, FusedAdam))
         if not st or getattr(self.net, 'grad_sync', None) is not None:
             return False
-        if os.environ.get('XRNERF_PY_STEP') == '1' or os.environ.get('XRNERF_MODULAR_STEP') == '1':
+        if switches.step_mode() != 'fused':
             return False
         if ops.TIMER is not None and not ops.TIMER.native_stage()[0]:
             return False
@@ -355,7 +357,7 @@ class Trainer:
         # one GPU: the fused step without autograd (`direct`): this loop back-propagates a unit root gradient into cleared .grads and
         # nothing else, which the step can do itself -- it applies the updates (fuse_adam) or leaves its gradients in .grad.  The
         # engine pass, Function.apply and the optimiser wrappers were ~0.1 ms of the ~0.43 ms of interpreter time per iteration,
-        # and the interpreter, not the GPU, set the pace (tools/hosttime2.py).  XRNERF_DIRECT_STEP=0: through autograd.
+        # and the interpreter, not the GPU, set the pace (tools/hosttime2.py).  direct_step=False: through autograd.
         direct = self.direct_step
         if direct:
             for p_ in self._opt_params:
@@ -426,7 +428,7 @@ class Trainer:
         # the batch lives in the set the sampler's next training launch of K1 writes (one ring of three sets for both, shared with the
         # native loop: a marched batch is handed between the two paths by its set index)
         bufs = self._batch_buffers((getattr(net.sampler, '_train_launches', 0) + 1) % 3, data.N_rand)
-        if bufs is not None and hasattr(data, 'rays_rgb') and os.environ.get('XRNERF_PY_STEP') != '1':
+        if bufs is not None and hasattr(data, 'rays_rgb') and switches.step_mode() == 'fused':
             # the whole side-stream sequence (batch assembly, K1, K2 clip, counter copy) as one native call
             n = min(data.N_rand, data.rays_rgb.shape[0])
             if data.cur_i + n > data.rays_rgb.shape[0]:
@@ -667,7 +669,7 @@ class _NativeLoop:
         D.bitfield_event = bev.cuda_event if bev is not None else None
         mark = getattr(net, '_step_mark', None)
         if mark is None or mark[0] != 'xr_nerf_mlp_bwd':
-            raise _lib.XrError('the native loop marches two iterations ahead (XRNERF_PREFETCH_DEPTH=2)')
+            raise _lib.XrError('the native loop marches two iterations ahead (prefetch_depth=2)')
         D.mark_event = mark[1].h
         self._keep = (D, msets, sets, ws_k1, ws_mlp, ws_sc, bev)
         # the schedules are this trainer's: lr per iteration, the EMA momentum of mmcv's EMAHook per update
