@@ -675,6 +675,9 @@ def main():
         ops.LIVE_STATS[1:3].zero_()            # running (live rows, valid rows) totals of the backward's row list
     rays0, samples0, it0 = tr.rays_done, tr.samples_done, tr.iter
     step_ev = [ops._CEvent() for _ in range(args.steps + 1)]     # one event per iteration boundary
+    if getattr(tr.net, 'grad_sync', None) is not None:
+        tr.net.grad_sync.exposed.summary()                       # (drop what earlier iterations recorded)
+        tr.net.grad_sync.exposed.on = True
     barrier()
     t0 = time.perf_counter()
     # (Trainer.run: the iterations between two grid refreshes are enqueued by one native call each, xr_ngp_loop_run -- the events in
@@ -884,7 +887,17 @@ def main():
         extra['hash_lookup_frac_of_hbm_frame_launches'] = extra['roofline_kernels_render']['xr_hashgrid_fwd']['frac']
     if world > 1:
         sync = getattr(tr.net, 'grad_sync', None)
-        extra['collective'] = {'mode': tr.dp_mode, 'model': xdist.comm_model(world, step_ms=elapsed_max * 1e3 / args.steps),
+        # MEASURED: how long this rank's compute stream waited for the step's collectives inside the timed region (events around the
+        # waits of grad_sync.finish(); what did not overlap), gathered from every rank; the model stays beside it
+        exposed = sync.exposed.summary() if sync is not None else {}
+        per_rank = [None] * world
+        torch.distributed.all_gather_object(per_rank, exposed)
+        extra['collective'] = {'mode': tr.dp_mode, 'exposed_collective_ms_per_rank': [e.get('mean_ms') for e in per_rank],
+                               'exposed_collective_ms': max((e.get('mean_ms') or 0.0) for e in per_rank),
+                               'exposed_collective_ms_max_step': max((e.get('max_ms') or 0.0) for e in per_rank),
+                               'exposed_steps_measured': exposed.get('steps'),
+                               'model': xdist.comm_model(world, step_ms=elapsed_max * 1e3 / args.steps, wire_bytes_per_float=2.0 if tr.dp_mode == 'allreduce_bf16' else 4.0),
+                               'bytes_on_wire_per_rank_total': getattr(sync, 'bytes_on_wire', None),
                                'bytes_reduced_per_rank_total': getattr(sync, 'bytes_reduced', None),
                                'bytes_gathered_per_rank_total': getattr(sync, 'bytes_gathered', None)}
 

@@ -265,6 +265,47 @@ def test_deeper_topologies_run_layer_by_layer(O, dev, nhd, nhc, n, n_valid):
         assert err <= 1e-3 * max(1.0, np.abs(refg).max()), (name, err, np.abs(refg).max())
 
 
+def test_layer_by_layer_path_equals_the_fused_kernels_at_full_size(dev, monkeypatch):
+    """The layer-by-layer path (what any topology but (1, 2) trains on, e.g. tcnn's default 5 + 5) at the training step's size: 2^18
+    rows of which 2.3e5 are valid, the rows behind the count holding NaN bit patterns in the encoded features and in dL/d(raw) (what
+    fresh memory may hold).  On the (1, 2) topology both paths exist: forward and all three gradients of the layered path against the
+    fused kernels' (fp32 MFMA forward and backward, the parity arithmetic), which the oracle pins at small sizes."""
+    from xrnerf_amd import ops, synthetic as S
+    monkeypatch.setenv('XR_MLP_BWD_DW', 'f32')
+    n, nv = 1 << 18, 230000
+    meta = ops.GridMeta()
+    g = torch.Generator(device='cpu').manual_seed(5)
+    table = T(S.hash_table(meta.n_params, scale=0.5), dev)
+    wd, wc = T(S.mlp_weights(32, 64, 1, 16, 4), dev), T(S.mlp_weights(32, 64, 2, 16, 5), dev)
+    pts = torch.rand((n, 3), generator=g).to(dev)
+    dirs = torch.rand((n, 3), generator=g).to(dev)
+    draw = torch.randn((n, 4), generator=g).to(dev)
+    draw[torch.rand((n,), generator=g).to(dev) < 0.5] = 0.0                # dead rows, as the compositor leaves them
+    n_dev = torch.tensor([nv], dtype=torch.int32, device=dev)
+    enc_t = ops.hashgrid_fwd(table, pts, meta)
+    enc_t[:, nv:] = float('nan')
+    draw[nv:] = float('nan')
+    old_f = ops.f32_forward()
+    ops.set_f32_forward('mfma')
+    try:
+        out = {}
+        for kind in ('fused', 'layered'):
+            monkeypatch.setattr(ops, '_FUSED_FWD', ((1, 2),) if kind == 'fused' else ())
+            monkeypatch.setattr(ops, '_FUSED_BWD', ((1, 2),) if kind == 'fused' else ())
+            raw = ops.nerf_mlp_fwd(enc_t, dirs, n, wd, wc, 1, 2, n_dev=n_dev)
+            g_wd, g_wc = torch.zeros_like(wd), torch.zeros_like(wc)
+            denc_t = ops.nerf_mlp_bwd(enc_t, dirs, n, wd, wc, 1, 2, draw, g_wd, g_wc, n_dev=n_dev)
+            g_t = torch.zeros(meta.n_params, dtype=torch.float32, device=dev)
+            ops.hashgrid_bwd(pts, denc_t, meta, g_t, n_dev=n_dev)
+            out[kind] = (raw[:nv].clone(), g_wd, g_wc, g_t, denc_t[:, :nv].clone())
+    finally:
+        ops.set_f32_forward(old_f)
+    for name, a, b in zip(('raw', 'g_wd', 'g_wc', 'g_table', 'denc'), out['layered'], out['fused']):
+        assert bool(torch.isfinite(a).all()) and bool(torch.isfinite(b).all()), name
+        err, scale = float((a - b).abs().max()), float(b.abs().max())
+        assert scale > 0 and err <= (1e-5 if name == 'raw' else 2e-5) * max(1.0, scale), (name, err, scale)
+
+
 def sparse_draw(rng, n, dead_fraction=0.55):
     """dL/d(raw) the way the compositor produces it: runs of exactly-zero rows (samples behind an opaque surface), a few
     isolated zero rows, rows with a single non-zero component, -0.0 entries"""

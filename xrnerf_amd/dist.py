@@ -43,6 +43,43 @@ def allreduce_grads(params, world_size):
         p.grad.mul_(1.0 / world_size)
 
 
+class _ExposedTimer:
+    """How long the compute stream WAITS for the collectives of a step: one event in front of the waits and one behind them, on the
+    compute stream -- the span between the two is what the exchange adds to the step after everything that overlapped (measured,
+    per rank; `dist.comm_model` is the model beside it).  Host tensors (gloo protocol tests on CPU): wall clock around the waits."""
+
+    def __init__(self):
+        self.on = False
+        self._pairs, self._host_ms = [], []
+
+    def begin(self, device_is_cuda):
+        if not self.on:
+            return None
+        if device_is_cuda:
+            a = torch.cuda.Event(enable_timing=True)
+            a.record()
+            return a
+        import time
+        return time.perf_counter()
+
+    def end(self, token):
+        if token is None:
+            return
+        if isinstance(token, float):
+            import time
+            self._host_ms.append((time.perf_counter() - token) * 1e3)
+        else:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            self._pairs.append((token, b))
+
+    def summary(self):
+        """-> {'steps', 'mean_ms', 'max_ms'} (call after a device synchronisation); clears the record"""
+        ms = [a.elapsed_time(b) for a, b in self._pairs] + self._host_ms
+        self._pairs, self._host_ms = [], []
+        return {'steps': len(ms), 'mean_ms': sum(ms) / len(ms) if ms else None, 'max_ms': max(ms) if ms else None}
+
+
 class BucketedGradSync:
     """Gradient reduction overlapped with the backward pass that produces the gradients.
 
@@ -53,21 +90,44 @@ class BucketedGradSync:
     them and returns the factor (1/world) the caller folds into its own gradient scaling.  Three
     collectives per iteration, 10 KB + 32 MB + 16.8 MB: few and large, as xGMI's point-to-point rings want."""
 
-    def __init__(self, world_size):
+    def __init__(self, world_size, wire_dtype=None):
+        """wire_dtype=torch.bfloat16 (XRNERF_DP=allreduce_bf16): buckets above 1 MB cross the links as bf16 -- half the bytes of the
+        48.8-MB table gradient; the reference's tcnn gradients are fp16 (hashnerf_mlp.py:76-77 casts its half outputs up).  Each rank
+        rounds its gradient to bf16 (2^-9 relative), the sum is taken in bf16 by the collective and widened back to fp32 in place:
+        the replicas stay bit-identical (every rank gets the same sum), the trajectory differs from the fp32 exchange by that rounding
+        (tests/test_capi_and_host.py::test_bf16_gradient_exchange_two_ranks bounds it)."""
         self.world_size = int(world_size)
-        self._works = []
+        self.wire_dtype = wire_dtype
+        self._works, self._staged = [], []
+        self.exposed = _ExposedTimer()
+        self.bytes_on_wire = 0
 
     def ready(self, bucket):
         if self.world_size > 1:
             # `.data`: the bucket is a slice of a buffer other outputs of the fused step are views of (the loss scalar);
             # the in-place reduction must not bump THEIR autograd version counter ("a view ... has been modified inplace")
-            self._works.append(dist.all_reduce(bucket.data, op=dist.ReduceOp.SUM, async_op=True))
+            b = bucket.data
+            self._on_device = b.is_cuda
+            if self.wire_dtype is not None and b.numel() * 4 >= (1 << 20):
+                wire = b.to(self.wire_dtype)
+                self._works.append(dist.all_reduce(wire, op=dist.ReduceOp.SUM, async_op=True))
+                self._staged.append((b, wire))
+                self.bytes_on_wire += wire.numel() * wire.element_size()
+            else:
+                self._works.append(dist.all_reduce(b, op=dist.ReduceOp.SUM, async_op=True))
+                self.bytes_on_wire += 4 * b.numel()
 
     def finish(self):
+        tok = self.exposed.begin(self._on_device) if self._works else None
         for w in self._works:
             w.wait()
-        self._works = []
+        self.exposed.end(tok)
+        for b, wire in self._staged:
+            b.copy_(wire)                         # widened back in place: .grad holds the (bf16-rounded) sum as fp32
+        self._works, self._staged = [], []
         return 1.0 / self.world_size
+
+    _on_device = False
 
 
 class Zero1GradSync:
@@ -91,6 +151,8 @@ class Zero1GradSync:
         self._works = []
         self.shard = self.n = 0
         self.bytes_reduced = self.bytes_gathered = 0
+        self.exposed = _ExposedTimer()
+        self._on_device = False
 
     def attach(self, table_param):
         """pad the table parameter's storage to world * shard floats, in place -> the nn.Parameter of this rank's shard (a view)"""
@@ -124,6 +186,7 @@ class Zero1GradSync:
     def ready(self, bucket):
         if self.world_size <= 1:
             return
+        self._on_device = bucket.is_cuda
         padded = self._padded_of(bucket)
         if padded is None:                                   # the MLP gradients: replicated
             self._works.append(dist.all_reduce(bucket.data, op=dist.ReduceOp.SUM, async_op=True))
@@ -138,8 +201,10 @@ class Zero1GradSync:
             self._take = None
 
     def finish(self):
+        tok = self.exposed.begin(self._on_device) if self._works else None
         for w in self._works:
             w.wait()
+        self.exposed.end(tok)
         self._works = []
         if getattr(self, '_take', None) is not None:
             self.shard_grad.copy_(self._take[self.rank * self.shard:(self.rank + 1) * self.shard])
@@ -162,7 +227,7 @@ class Zero1GradSync:
             dist.all_gather_into_tensor(self.param_padded, self.shard_param.data)
 
 
-def comm_model(world_size, table_floats=12196240, mlp_floats=10240, link_GBs=153.0, links=7, step_ms=0.50):
+def comm_model(world_size, table_floats=12196240, mlp_floats=10240, link_GBs=153.0, links=7, step_ms=0.50, wire_bytes_per_float=4.0):
     """what one training step puts on xGMI, and what it costs under two schedules (one-GPU boxes only: nothing here is measured).
     xGMI is point-to-point, 7 links x ~153 GB/s per GPU.
       ring:   an N-rank ring is bound by ONE link per hop: all-reduce = 2 (N - 1) / N x bytes over one link;
@@ -172,7 +237,7 @@ def comm_model(world_size, table_floats=12196240, mlp_floats=10240, link_GBs=153
     n = int(world_size)
     if n <= 1:
         return {'world_size': n, 'bytes_per_step': 0, 'ring_ms': 0.0, 'direct_ms': 0.0}
-    b = 4.0 * (table_floats + mlp_floats)
+    b = wire_bytes_per_float * table_floats + 4.0 * mlp_floats
     wire = 2.0 * (n - 1) / n * b
     ring_ms = wire / (link_GBs * 1e9) * 1e3
     direct_ms = (2.0 * b / n) / (link_GBs * 1e9) * 1e3 if n <= links + 1 else ring_ms

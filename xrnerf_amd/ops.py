@@ -686,6 +686,14 @@ def _layered_net(x, w_flat, n_hidden):
     return linear_act(h, ws[-1], None, False)
 
 
+def _valid_rows(x, n_dev):
+    """contiguous copy of the row-major [m, c] tensor `x` with the rows behind the device-side count n_dev[0] set to zero"""
+    if n_dev is None:
+        return x.contiguous()
+    keep = torch.arange(x.shape[0], device=x.device)[:, None] < n_dev.reshape(-1)[:1].to(torch.int64)
+    return torch.where(keep, x, torch.zeros((), dtype=x.dtype, device=x.device)).contiguous()
+
+
 def _layered_nerf_mlp(enc, dirs, w_density, w_color, nhd, nhc, pad_value):
     """enc [n,32] (, dirs [n,3]) -> raw [n,4] = [rgb raw, sigma raw]; differentiable w.r.t. enc, w_density, w_color"""
     dout = _layered_net(enc, w_density, nhd)
@@ -705,7 +713,7 @@ def nerf_mlp_fwd(enc_t, dirs, n, w_density, w_color, nhd, nhc, pad_value=1.0, ra
             raise _lib.XrError('row lists are served by the fused kernels only (hidden layers %d, %d)' % (nhd, nhc))
         m = n if count is None else count
         with torch.no_grad(), _span('xr_nerf_mlp_fwd', 0 if n_dev is not None else m, train=n_dev is not None):
-            enc = enc_t[:, row0:row0 + m].t().contiguous()
+            enc = _valid_rows(enc_t[:, row0:row0 + m].t(), n_dev)
             d = _pos_view(dirs)[0][row0:row0 + m] if dirs is not None else None
             out = _layered_nerf_mlp(enc, d.contiguous() if d is not None and d.stride(0) != 3 else d, w_density.detach(),
                                     w_color.detach() if w_color is not None else None, nhd, nhc, pad_value)
@@ -793,13 +801,14 @@ def nerf_mlp_bwd(enc_t, dirs, n, w_density, w_color, nhd, nhc, draw, grad_wd, gr
             d = _pos_view(dirs)[0][row0:row0 + m]
             d = d.contiguous() if d.stride(0) != 3 else d
             with torch.enable_grad():
-                enc = enc_t[:, row0:row0 + m].t().contiguous().requires_grad_(True)
+                # rows behind the device-side count are padding of a fixed-size buffer that nothing wrote this step (the encode and the
+                # compositor stop at the count): whatever they hold -- stale rows, NaN bit patterns of fresh memory -- is replaced by
+                # zeros, not multiplied by zero (0 * NaN), in the features AND in the incoming gradient
+                enc = _valid_rows(enc_t[:, row0:row0 + m].t(), n_dev).requires_grad_(True)
                 wd, wc = w_density.detach().requires_grad_(True), w_color.detach().requires_grad_(True)
                 out = _layered_nerf_mlp(enc, d, wd, wc, nhd, nhc, pad_value)
-                g = draw[row0:row0 + m]
-                if n_dev is not None:       # rows behind the device-side count are padding: no gradient
-                    g = g * (torch.arange(m, device=g.device)[:, None] < n_dev.reshape(-1)[:1].to(torch.int64)).to(g.dtype)
-                ge, gwd, gwc = torch.autograd.grad(out, [enc, wd, wc], grad_outputs=g.contiguous())
+                g = _valid_rows(draw[row0:row0 + m], n_dev)
+                ge, gwd, gwc = torch.autograd.grad(out, [enc, wd, wc], grad_outputs=g)
             denc_t[:, row0:row0 + m] = ge.t()
             grad_wd.add_(gwd)
             grad_wc.add_(gwc)

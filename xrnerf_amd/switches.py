@@ -4,7 +4,8 @@ a compile-time constant of one source (tools/build_variant.sh + XRNERF_LIB) or g
 
   XRNERF_LIB                   path of another build of the library (_lib.py)
   XRNERF_MLP_PRECISION         f32 (default, parity mode) | f16 (the reference's tcnn arithmetic) -- ops.set_precision
-  XRNERF_DP                    allreduce (default) | zero1 -- the data-parallel gradient exchange (train.Trainer)
+  XRNERF_DP                    allreduce (default) | allreduce_bf16 (the table gradient crosses the links as bf16) | zero1 -- the
+                               data-parallel gradient exchange (train.Trainer, dist.py)
   XRNERF_TRAINER               "k=v,..." overrides of Trainer's keyword switches: native_loop, fuse_adam, direct_step, overlap_march,
                                prefetch_depth, prefetch_k6 (A/B runs of bench.py / tools without editing code)
   XRNERF_STEP                  fused (default: one native call per training step) | py (the same entry points issued one by one from

@@ -233,8 +233,8 @@ class Trainer:
         self.iter = 0
         self.world_size, self.rank = world_size, rank
         self.dp_mode = os.environ.get('XRNERF_DP', 'allreduce')
-        if self.dp_mode not in ('allreduce', 'zero1'):
-            raise ValueError("XRNERF_DP must be 'allreduce' or 'zero1' (got %r)" % self.dp_mode)
+        if self.dp_mode not in ('allreduce', 'allreduce_bf16', 'zero1'):
+            raise ValueError("XRNERF_DP must be 'allreduce', 'allreduce_bf16' or 'zero1' (got %r)" % self.dp_mode)
         opt_params = [p for p in self.net.parameters() if p.numel() > 0]
         if world_size > 1 and self.dp_mode == 'zero1':
             # reduce-scatter -> Adam on this rank's shard of the table -> all-gather
@@ -245,9 +245,9 @@ class Trainer:
             opt_params = [shard] + [p for p in opt_params if p is not table]
         self.opt = FusedAdam(opt_params, lr=self.base_lr, betas=(0.9, 0.99), eps=1e-15, weight_decay=1e-6,
                              ema_momentum=0.05 if ema else None)
-        if world_size > 1 and self.dp_mode == 'allreduce':
+        if world_size > 1 and self.dp_mode in ('allreduce', 'allreduce_bf16'):
             from . import dist as xdist                 # fused step: bucketed reduction under the table scatter
-            self.net.grad_sync = xdist.BucketedGradSync(world_size)
+            self.net.grad_sync = xdist.BucketedGradSync(world_size, torch.bfloat16 if self.dp_mode == 'allreduce_bf16' else None)
         if world_size > 1:
             # this trainer's optimiser applies the 1/world_size itself (FusedAdam.step(grad_scale=...)): the fused step leaves
             # the SUMMED gradients in .grad and reports the factor in net._pending_grad_scale
