@@ -380,9 +380,6 @@ int xr_ngp_train_step(const float* table, const float* w_density, const float* w
 void* xr_timing_event_create(void);
 /* an event for ordering only (no timestamp taken: cheaper to record); destroy / wait with the calls of the timing events */
 void* xr_order_event_create(void);
-/* a stream restricted to the compute units named by `mask` (mask_words x 32 bits, bit i = CU i); null on failure.  Never destroyed
- * by the library (wrap it: torch.cuda.ExternalStream). */
-void* xr_stream_create_cu_mask(const uint32_t* mask, uint32_t mask_words);
 int xr_stream_wait_event(void* stream, void* event);
 int xr_event_record(void* event, void* stream);
 int xr_timing_event_destroy(void* event);

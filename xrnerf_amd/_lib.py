@@ -105,7 +105,6 @@ SIGNATURES = {
     'xr_ngp_loop_march_event': (_vp, [_vp, _u32]),
     'xr_ngp_loop_adopt_march': (_i32, [_vp, _u32, _vp]),
     'xr_event_record': (_i32, [_vp, _vp]),
-    'xr_stream_create_cu_mask': (_vp, [_vp, _u32]),
     'xr_ngp_loop_run': (_i32, [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, C.c_char_p, _vp, _vp]),
     'xr_timing_event_create': (_vp, []),
     'xr_order_event_create': (_vp, []),

@@ -40,15 +40,6 @@ extern "C" int xr_event_record(void* event, void* stream) {
     return XR_OK;
 }
 
-// A stream whose kernels may only be placed on a subset of the compute units (hipExtStreamCreateWithCUMask): the trainer's side stream
-// -- the march of iteration i + 2 is ~290 us of latency-bound waves per iteration that otherwise spread over ~50 CUs and slow down
-// whatever HBM- or LDS-bound kernel of the step runs beside them.  mask_words x 32 bits, bit i = CU i of the device's enumeration.
-extern "C" void* xr_stream_create_cu_mask(const uint32_t* mask, uint32_t mask_words) {
-    hipStream_t s = nullptr;
-    if (!mask || !mask_words || hipExtStreamCreateWithCUMask(&s, mask_words, mask) != hipSuccess) return nullptr;
-    return (void*)s;
-}
-
 static bool stage_is(const char* timed, const char* name) { return timed && strcmp(timed, name) == 0; }
 
 extern "C" int xr_ngp_train_step(

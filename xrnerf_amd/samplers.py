@@ -29,27 +29,6 @@ from ._fastattr import _FastAttr
 from .builder import SAMPLERS
 
 
-def _masked_stream(device):
-    """XR_SIDE_CUS="n[,stride[,first]]" (experiment): the side stream may only use n compute units, CU first + k * stride"""
-    spec = os.environ.get('XR_SIDE_CUS')
-    if not spec:
-        return None
-    import ctypes as C
-    from . import _lib
-    v = [int(t) for t in spec.split(',')]
-    n, stride, first = v[0], (v[1] if len(v) > 1 else 1), (v[2] if len(v) > 2 else 0)
-    L = _lib.load()
-    total = max(L.xr_device_cus(), 1)
-    words = (C.c_uint32 * ((total + 31) // 32))()
-    for k in range(n):
-        cu = (first + k * stride) % total
-        words[cu // 32] |= 1 << (cu % 32)
-    h = L.xr_stream_create_cu_mask(words, len(words))
-    if not h:
-        raise _lib.XrError('hipExtStreamCreateWithCUMask failed')
-    return torch.cuda.ExternalStream(h, device=device)
-
-
 @SAMPLERS.register_module()
 class NGPGridSampler(_FastAttr, nn.Module):
     # per-step state (never a Parameter, a registered buffer or a sub-module): assigned ~15 times per training iteration
@@ -451,7 +430,8 @@ class NGPGridSampler(_FastAttr, nn.Module):
 
     def side_stream(self):
         if getattr(self, '_side', None) is None:
-            self._side = _masked_stream(self.device) or torch.cuda.Stream(device=self.device)   # (a high-priority stream changes nothing: measured)
+            # (a high-priority stream changes nothing; a CU-masked stream doubles the iteration: profiles/r04_side_stream_cu_mask_ab.txt)
+            self._side = torch.cuda.Stream(device=self.device)
         return self._side
 
     def prefetch(self, data, buffer_free_event=None):
