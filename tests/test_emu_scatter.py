@@ -27,9 +27,8 @@ def test_scatter_generation_3_against_the_oracle(n, mode):
 
 
 @pytest.mark.parametrize('n,mode,test', [(5000, 'cluster', 'block=1024'), (5000, 'rays', 'block=4096'), (3000, 'faces', 'rl=0'),
-                                         (5000, 'rays', 'rl_chunks=3'), (20000, 'rays', 'block=1024')])
+                                         (5000, 'rays', 'rl_chunks=3')])
 def test_scatter_layout_parameters_give_the_same_gradients(n, mode, test):
-    """XR_SC_TEST: samples per binning workgroup, the small dense levels through the bins, row chunks of the run-length kernel; the last
-    case has 20 sample blocks, i.e. accumulate waves that walk several sub-bins at a time with 16 lanes each at the coarse levels"""
+    """XR_SC_TEST: samples per binning workgroup, the small dense levels through the bins, row chunks of the run-length kernel"""
     run(n, mode, test)
 

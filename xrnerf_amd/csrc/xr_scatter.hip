@@ -57,11 +57,11 @@ __device__ __forceinline__ void s3_static_for(F&& f) { s3_static_for_impl(f, std
 #define S3_R_THREADS 1024
 
 enum { S3_H = 0, S3_D = 1 };
-#ifndef S3_MERGE
-#define S3_MERGE 1
+#ifndef S3_PERMUTE
+#define S3_PERMUTE 1
 #endif
-#ifndef S3_GROUP_RES
-#define S3_GROUP_RES 300      // levels up to this resolution: 16 lanes per sub-bin, 4 sub-bins per wave step (0: always 64 lanes per sub-bin)
+#ifndef S3_MERGE
+#define S3_MERGE S3_PERMUTE
 #endif
 
 #ifdef S3_TIMING          // tools/scatter3_timing.hip: wall_clock64 (100 MHz) stamps of a few accumulate workgroups
@@ -390,30 +390,11 @@ __global__ __launch_bounds__(TH) void k_scatter_accum3(S3Plan pl, const uint32_t
     const float4* __restrict__ src = bins + L.bins_off + (size_t)part * nsb * cap;
     constexpr uint32_t U = 8;
     const uint32_t n_mine = nsb > wave ? (nsb - wave + WAVES - 1u) / WAVES : 0u;   // sub-bins of this wave
-    // Item -> lane mapping.  A sub-bin's items are consecutive samples of a sample block in ray order: at the coarse levels several
-    // consecutive items name the same entry pair (a ray's samples inside one cell).  A lane therefore walks CONSECUTIVE items (its runs
-    // are merged in registers below), and the lanes of one wave instruction should sit on different runs: with all 64 lanes on one
-    // sub-bin of ~128 items a lane gets 2 items and a run of 3-7 spans neighbouring lanes, whose LDS atomics then hit the same address
-    // in the same instruction and serialise (tools/scatter3_timing.hip: 14 us of atomics per workgroup at level 5 against 6 at level
-    // 15).  Levels up to S3_GROUP_RES cells per axis give a sub-bin 16 lanes and a wave 4 sub-bins at a time: 8 consecutive items
-    // per lane, a run inside one lane.  Finer levels (no two samples in a cell) keep 64 lanes per sub-bin.
-    const uint32_t G = (S3_GROUP_RES && L.res <= (uint32_t)S3_GROUP_RES) ? 4u : 1u, lps = 64u / G;     // sub-bins per wave step, lanes per sub-bin
-    const uint32_t grp = lane / lps, jl = lane % lps;
-    uint32_t si = 0, c = 0, qn = 0, myfill = 0, mynch = 0;                 // si, c, qn: wave-uniform (first sub-bin slot of the step, chunk, chunks)
-    auto load_step = [&]() {
-        qn = 0; myfill = 0;
-        for (uint32_t g = 0; g < G; ++g) {
-            const uint32_t f = si + g < n_mine ? s3_readlane(vfill, si + g) : 0u;
-            const uint32_t nchg = (f + lps - 1u) / lps;
-            qn = nchg > qn ? nchg : qn;
-            if (grp == g) myfill = f;
-        }
-        mynch = (myfill + lps - 1u) / lps;
-    };
+    uint32_t si = 0, c = 0;                                                 // next (sub-bin slot, 64-item chunk): wave-uniform
+    uint32_t fill = n_mine ? s3_readlane(vfill, 0) : 0u;
     auto skip_empty = [&]() {
-        while (si < n_mine && qn == 0u) { si += G; if (si < n_mine) load_step(); }
+        while (si < n_mine && fill == 0u) { ++si; fill = si < n_mine ? s3_readlane(vfill, si) : 0u; }
     };
-    if (n_mine) load_step();
     skip_empty();
     S3_T(1);
     float4 nx[U];
@@ -423,13 +404,17 @@ __global__ __launch_bounds__(TH) void k_scatter_accum3(S3Plan pl, const uint32_t
         for (uint32_t u = 0; u < U; ++u) {
             non[u] = false;
             if (si < n_mine) {
-                const uint32_t off = jl * mynch + c;                        // chunk c of the lane's mynch consecutive items
-                non[u] = c < mynch && off < myfill;
-                if (non[u]) nx[u] = src[(size_t)(wave + WAVES * (si + grp)) * cap + off];
+                // lane l of chunk c takes item l * nch + c of the sub-bin (nch = its number of chunks), not c * 64 + l: consecutive
+                // items come from consecutive samples of a ray, which at the coarse levels sit in the same cell -- side by side
+                // in one wave instruction their LDS atomics hit the same addresses and serialise (measured with
+                // tools/scatter3_timing.hip: 18 us of atomics per workgroup at levels 5-6 against 7 us at level 15)
+                const uint32_t nch = (fill + 63u) >> 6, off = S3_PERMUTE ? lane * nch + c : c * 64u + lane;
+                non[u] = off < fill;
+                if (non[u]) nx[u] = src[(size_t)(wave + WAVES * si) * cap + off];
                 ++c;
-                if (c >= qn) {
-                    c = 0; si += G; qn = 0;
-                    if (si < n_mine) load_step();
+                if (c * 64u >= fill) {
+                    c = 0; ++si;
+                    fill = si < n_mine ? s3_readlane(vfill, si) : 0u;
                     skip_empty();
                 }
             }
