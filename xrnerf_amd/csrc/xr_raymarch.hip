@@ -10,6 +10,9 @@
 #include <cstdlib>
 
 #define RM_BLOCK 256
+#ifndef K1W_MAX_RAYS
+#define K1W_MAX_RAYS 65536  // launches of up to this many rays march with 8 lanes per ray (k1_count_w); 0: always one ray per lane
+#endif
 #define K1_TL 128         // per-ray t-list capacity (4*n_rays*K1_TL bytes of workspace); longer rays -- 3 of 12.5 K in a
                           // training batch, 9 % at 64 -- fall back to a re-march of their tail in the write pass
                           // (measured: K1 223 -> 172 us on 12.5 K rays)
@@ -67,14 +70,17 @@ __device__ inline bool rm_occupied(float px, float py, float pz, const uint8_t* 
     return (bf[(idx >> 3) + (uint32_t)mip * (XR_GRID_CELLS / 8)] >> (idx & 7)) & 1;
 }
 __device__ inline float rm_lt_min(float a, float b) { return a < b ? a : b; }  // reference `min` = a<b?a:b
-__device__ inline float rm_advance(float t, float cone, float px, float py, float pz, const Ray& r, uint32_t res) { // :271-296
+__device__ inline float rm_advance_target(float t, float px, float py, float pz, const Ray& r, uint32_t res) { // :271-293
     float rf = (float)res;
     float ppx = rf * px, ppy = rf * py, ppz = rf * pz;
     float tx = (floorf(ppx + 0.5f + 0.5f * copysignf(1.0f, r.dx)) - ppx) * r.ix;
     float ty = (floorf(ppy + 0.5f + 0.5f * copysignf(1.0f, r.dy)) - ppy) * r.iy;
     float tz = (floorf(ppz + 0.5f + 0.5f * copysignf(1.0f, r.dz)) - ppz) * r.iz;
     float tt = rm_lt_min(rm_lt_min(tx, ty), tz);
-    float target = t + fmaxf(tt / rf, 0.0f);
+    return t + fmaxf(tt / rf, 0.0f);
+}
+__device__ inline float rm_advance(float t, float cone, float px, float py, float pz, const Ray& r, uint32_t res) { // :271-296
+    const float target = rm_advance_target(t, px, py, pz, r, res);
     do { t += rm_calc_dt(t, cone); } while (t < target);
     return t;
 }
@@ -154,6 +160,86 @@ __global__ __launch_bounds__(RM_BLOCK) void k1_count(
     uint32_t tot;
     uint32_t off = block_excl_scan(j, &tot, lds4);
     if (i < n_rays) { cnt[i] = j; local_off[i] = off; start_t[i] = startt; }
+    if (threadIdx.x == 0) block_tot[blockIdx.x] = tot;
+}
+
+// ------------------------------------------------------------------ K1 pass A with K1W lanes per ray (training-sized batches)
+// A training batch is ~12.8 K rays: one ray per lane makes 200 waves on 1024 SIMDs, each a serial chain of ~150 VALU instructions per
+// visited lattice point -- 172-222 us however idle the chip is.  The lattice t_0, t_1 = t_0 + calc_dt(t_0), ... does not depend on
+// the occupancy (a sample steps `t += dt`, advance_to_next_voxel steps `do t += calc_dt(t) while (t < target)`: the same chain), so
+// the K1W lanes of a ray evaluate K1W consecutive lattice points at once -- lane i reaches its point with i of those additions, the
+// same fp32 operations in the same order as the serial walk -- and then replay the reference's control flow over the window with
+// group ballots / shuffles: a tested point is either a sample (next point: the following one) or empty (next point: the first one
+// not below its voxel-exit target, possibly in a later window).  Points the walk jumps over were evaluated for nothing; with 8
+// lanes a window costs ~7 chain steps + one point evaluation + <= 8 replay steps instead of 8 point evaluations in a row.
+// (Round 3 tried 64 lanes per ray: 63 chain steps per window and 12.5 K waves made it no faster than the serial kernel.)
+// Same counts, same sample t's (bit for bit), same RNG draw; cnt / start_t / tlist as k1_count, the block scan is k1_block_scan.
+#define K1W 8
+__global__ __launch_bounds__(RM_BLOCK) void k1_count_w(
+    uint32_t n_rays, float lo, float hi, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+    const uint8_t* __restrict__ bitfield, float cone, float near_distance, xr_pcg32 rng, uint32_t rng_chunk, uint32_t rng_ray0,
+    uint32_t* __restrict__ cnt, float* __restrict__ start_t, float* __restrict__ tlist) {
+    const uint32_t ray = (blockIdx.x * RM_BLOCK + threadIdx.x) / K1W;
+    const int li = threadIdx.x & (K1W - 1), g0 = (threadIdx.x & 63) & ~(K1W - 1);      // lane inside its ray's group, the group's first lane of the wave
+    if (ray >= n_rays) return;                                                          // (whole groups leave)
+    if (rng_chunk) { const uint32_t g = rng_ray0 + ray; rng.advance(((uint64_t)(g / rng_chunk) << 32) + (uint64_t)((g % rng_chunk) * 8u)); }
+    else rng.advance((uint64_t)(ray * 8u));
+    const Ray r = rm_load_ray(rays_o, rays_d, ray);
+    float startt = fmaxf(rm_aabb_tmin(lo, hi, r), near_distance);
+    startt += rm_calc_dt(startt, cone) * rng.next_float();
+    float t0 = startt, target = 0.f;
+    uint32_t j = 0;
+    bool seek = false;                                   // the walk is inside a voxel advance: the next tested point is the first one not below `target`
+    for (;;) {
+        float t = t0;
+#pragma unroll
+        for (int s = 0; s < K1W - 1; ++s)
+            if (s < li) t += rm_calc_dt(t, cone);
+        const float px = r.ox + t * r.dx, py = r.oy + t * r.dy, pz = r.oz + t * r.dz;
+        const bool inb = rm_contains(lo, hi, px, py, pz);
+        bool occ = false;
+        float tgt = 0.f;
+        if (inb) {
+            const float dt = rm_calc_dt(t, cone);
+            const int mip = rm_mip_from_dt(dt, px, py, pz);
+            occ = rm_occupied(px, py, pz, bitfield, mip);
+            if (!occ) tgt = rm_advance_target(t, px, py, pz, r, XR_NERF_GRIDSIZE >> mip);
+        }
+        // ---- replay of the reference's walk over the window (every lane of the group takes the same decisions)
+        uint32_t cur = 0;
+        if (seek) {                                      // do { t += dt } while (t < target): the first lattice point with !(t < target)
+            const uint32_t m = (uint32_t)(__ballot(!(t < target)) >> g0) & ((1u << K1W) - 1u);
+            cur = m ? (uint32_t)__ffs((int)m) - 1u : (uint32_t)K1W;
+        }
+        bool done = false;
+        while (cur < (uint32_t)K1W) {
+            const int c_inb = __shfl((int)inb, (int)cur, K1W);
+            if (!(c_inb && j < XR_NERF_STEPS)) { done = true; break; }
+            seek = false;
+            if (__shfl((int)occ, (int)cur, K1W)) {
+                if ((uint32_t)li == cur && j < K1_TL) tlist[(size_t)ray * K1_TL + j] = t;
+                ++j; ++cur;
+            } else {
+                const float c_tgt = __shfl(tgt, (int)cur, K1W);
+                const uint32_t m = ((uint32_t)(__ballot(!(t < c_tgt)) >> g0) & ((1u << K1W) - 1u)) & ~((2u << cur) - 1u);   // lanes behind `cur`
+                if (m) cur = (uint32_t)__ffs((int)m) - 1u;
+                else { seek = true; target = c_tgt; cur = (uint32_t)K1W; }
+            }
+        }
+        if (done) break;
+        const float tl = __shfl(t, K1W - 1, K1W);
+        t0 = tl + rm_calc_dt(tl, cone);
+    }
+    if (li == 0) { cnt[ray] = j; start_t[ray] = startt; }
+}
+// per 256-ray block: exclusive prefix of the counts (ray order) and the block total -- what k1_count produces on the fly
+__global__ __launch_bounds__(RM_BLOCK) void k1_block_scan(uint32_t n_rays, const uint32_t* __restrict__ cnt, uint32_t* __restrict__ local_off,
+                                                          uint32_t* __restrict__ block_tot) {
+    __shared__ uint32_t lds4[4];
+    const uint32_t i = blockIdx.x * RM_BLOCK + threadIdx.x;
+    uint32_t tot;
+    const uint32_t off = block_excl_scan(i < n_rays ? cnt[i] : 0u, &tot, lds4);
+    if (i < n_rays) local_off[i] = off;
     if (threadIdx.x == 0) block_tot[blockIdx.x] = tot;
 }
 
@@ -318,8 +404,15 @@ extern "C" int xr_rays_sampler3(const float* rays_o, const float* rays_d, const 
     RmWorkspace w; rm_ws_layout(n_rays, (char*)workspace, &w);
     xr_pcg32 rng{rng_state, rng_inc};
     const uint32_t nb = xr_div_up(n_rays, RM_BLOCK);
-    hipLaunchKernelGGL(k1_count, dim3(nb), dim3(RM_BLOCK), 0, stream, n_rays, aabb0, aabb1, rays_o, rays_d, bitfield,
-                       cone_angle, near_distance, rng, rng_chunk, rng_ray0, w.cnt, w.local_off, w.start_t, w.block_tot, w.tlist);
+    // up to K1W_MAX_RAYS rays (a training batch): K1W lanes per ray -- 8x the waves, each ~1/4 as long; above it (frames: 640 K rays = 10 K
+    // waves of the one-ray-per-lane kernel) the chip is full either way and the lanes are better spent on rays
+    if (K1W_MAX_RAYS && n_rays <= (uint32_t)K1W_MAX_RAYS) {
+        hipLaunchKernelGGL(k1_count_w, dim3(xr_div_up(n_rays * K1W, RM_BLOCK)), dim3(RM_BLOCK), 0, stream, n_rays, aabb0, aabb1, rays_o, rays_d,
+                           bitfield, cone_angle, near_distance, rng, rng_chunk, rng_ray0, w.cnt, w.start_t, w.tlist);
+        hipLaunchKernelGGL(k1_block_scan, dim3(nb), dim3(RM_BLOCK), 0, stream, n_rays, (const uint32_t*)w.cnt, w.local_off, w.block_tot);
+    } else
+        hipLaunchKernelGGL(k1_count, dim3(nb), dim3(RM_BLOCK), 0, stream, n_rays, aabb0, aabb1, rays_o, rays_d, bitfield,
+                           cone_angle, near_distance, rng, rng_chunk, rng_ray0, w.cnt, w.local_off, w.start_t, w.block_tot, w.tlist);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, nb, w.block_tot, max_samples, w.block_base, w.info);
     hipLaunchKernelGGL(k1_write, dim3(nb), dim3(RM_BLOCK), 0, stream, n_rays, aabb0, aabb1, rays_o, rays_d, bitfield,
                        cone_angle, max_samples, w.cnt, w.local_off, w.start_t, w.block_base, w.info, coords_out,
