@@ -82,7 +82,10 @@ int xr_rays_sampler3(const float* rays_o, const float* rays_d, const uint8_t* bi
                      float aabb0, float aabb1, float near_distance, float cone_angle, uint32_t max_samples,
                      uint64_t rng_state, uint64_t rng_inc, float* coords_out, int32_t* rays_index,
                      int32_t* rays_numsteps, uint32_t* counter2, float* xyz_planes, uint32_t plane_stride,
-                     uint32_t rng_chunk, uint32_t rng_ray0, void* workspace, size_t workspace_bytes, void* stream);
+                     uint32_t rng_chunk, uint32_t rng_ray0, uint32_t flags, void* workspace, size_t workspace_bytes, void* stream);
+/* flags: XR_K1_WIDE = nothing else is running on the device (the march in place at a grid refresh): launches of up to 32 768 rays
+ * use 8 lanes per ray (same samples bit for bit, a shorter critical path, 8x the waves) */
+#define XR_K1_WIDE 1u
 
 /* K2  compacted_coord_api (src/compacted_coord.cu:79-143, kernel :6-77).  The reference's
  * transmittance loop cannot influence any output (its `break` is commented out, :41-44), so

@@ -23,8 +23,8 @@ def edge_rays():
     return np.array(o, np.float32), np.array(d, np.float32)
 
 
-def run_k1(ops, dev, o, d, bf, max_samples, calls):
-    c, ri, ns, cnt = ops.rays_sampler(T(o, dev), T(d, dev), T(bf, dev), (0.0, 1.0), 0.05, 1.0 / 256, max_samples, calls)
+def run_k1(ops, dev, o, d, bf, max_samples, calls, wide=False):
+    c, ri, ns, cnt = ops.rays_sampler(T(o, dev), T(d, dev), T(bf, dev), (0.0, 1.0), 0.05, 1.0 / 256, max_samples, calls, wide=wide)
     torch.cuda.synchronize()
     return c.cpu().numpy(), ri.cpu().numpy(), ns.cpu().numpy(), cnt.cpu().numpy()
 
@@ -37,13 +37,15 @@ def test_k1_bit_exact(O, lego, dev, n_rays, calls):
     o, d = np.concatenate([eo, o]), np.concatenate([ed, d])
     n = o.shape[0]
     rc, ri, rn, rcnt = O.rays_sampler(o, d, lego['bitfield'], rng_calls=calls, max_samples=n * 64)
-    gc, gi, gn, gcnt = run_k1(ops, dev, o, d, lego['bitfield'], n * 64, calls)
-    assert np.array_equal(gcnt, rcnt), (gcnt, rcnt)
-    assert np.array_equal(gn, rn)
-    assert np.array_equal(gi, ri)
-    S_ = int(rcnt[1])
-    assert S_ > n   # the scene is actually hit
-    assert np.array_equal(bits(gc[:S_]), bits(rc[:S_]))
+    # wide: XR_K1_WIDE, the count pass with 8 lanes per ray (launches of up to 32 768 rays; the 70 000-ray case stays on one ray per lane)
+    for wide in (False, True):
+        gc, gi, gn, gcnt = run_k1(ops, dev, o, d, lego['bitfield'], n * 64, calls, wide=wide)
+        assert np.array_equal(gcnt, rcnt), (gcnt, rcnt, wide)
+        assert np.array_equal(gn, rn), wide
+        assert np.array_equal(gi, ri), wide
+        S_ = int(rcnt[1])
+        assert S_ > n   # the scene is actually hit
+        assert np.array_equal(bits(gc[:S_]), bits(rc[:S_])), wide
 
 
 def test_k1_multi_cascade_bit_exact(O, dev):
@@ -56,11 +58,12 @@ def test_k1_multi_cascade_bit_exact(O, dev):
     g = np.load(os.path.join(G, 'ref_raymarch_cascades.npz'))
     grid, o, d, aabb = cascade_inputs()
     bf = O.bitfield_given_mean(grid, np.float32(0.5))
-    c, ri, ns, cnt = ops.rays_sampler(T(o, dev), T(d, dev), T(bf, dev), aabb, 0.05, 1 / 256, o.shape[0] * 1024, 0)
-    assert np.array_equal(cnt.cpu().numpy(), g['counter'])
-    assert np.array_equal(ns.cpu().numpy(), g['numsteps']) and np.array_equal(ri.cpu().numpy(), g['index'])
-    s = int(cnt[1])
-    assert np.array_equal(bits(c[:s].cpu().numpy()), bits(g['coords']))
+    for wide in (False, True):
+        c, ri, ns, cnt = ops.rays_sampler(T(o, dev), T(d, dev), T(bf, dev), aabb, 0.05, 1 / 256, o.shape[0] * 1024, 0, wide=wide)
+        assert np.array_equal(cnt.cpu().numpy(), g['counter']), wide
+        assert np.array_equal(ns.cpu().numpy(), g['numsteps']) and np.array_equal(ri.cpu().numpy(), g['index']), wide
+        s = int(cnt[1])
+        assert np.array_equal(bits(c[:s].cpu().numpy()), bits(g['coords'])), wide
 
 
 def test_k1_overflow_and_k2_clip(O, lego, dev):

@@ -65,7 +65,7 @@ SIGNATURES = {
     'xr_rays_sampler_workspace_bytes': (_sz, [_u32]),
     'xr_rays_sampler': (_i32, [_vp, _vp, _vp, _u32, _f, _f, _f, _f, _u32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'xr_rays_sampler2': (_i32, [_vp, _vp, _vp, _u32, _f, _f, _f, _f, _u32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _sz, _vp]),
-    'xr_rays_sampler3': (_i32, [_vp, _vp, _vp, _u32, _f, _f, _f, _f, _u32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp, _sz, _vp]),
+    'xr_rays_sampler3': (_i32, [_vp, _vp, _vp, _u32, _f, _f, _f, _f, _u32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _sz, _vp]),
     'xr_compacted_coord': (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'xr_clip_numsteps': (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _u32, _u32, _vp]),
     'xr_render_slice_select': (_i32, [_vp, _vp, _u32, _u32, _u32, _f, _vp, _vp, _vp, _vp]),

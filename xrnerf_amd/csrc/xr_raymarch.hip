@@ -11,7 +11,7 @@
 
 #define RM_BLOCK 256
 #ifndef K1W_MAX_RAYS
-#define K1W_MAX_RAYS 65536  // launches of up to this many rays march with 8 lanes per ray (k1_count_w); 0: always one ray per lane
+#define K1W_MAX_RAYS 32768  // XR_K1_WIDE launches of up to this many rays march with 8 lanes per ray (k1_count_w); 0: always one ray per lane
 #endif
 #define K1_TL 128         // per-ray t-list capacity (4*n_rays*K1_TL bytes of workspace); longer rays -- 3 of 12.5 K in a
                           // training batch, 9 % at 64 -- fall back to a re-march of their tail in the write pass
@@ -395,8 +395,9 @@ extern "C" int xr_rays_sampler3(const float* rays_o, const float* rays_d, const 
                                 float aabb0, float aabb1, float near_distance, float cone_angle, uint32_t max_samples,
                                 uint64_t rng_state, uint64_t rng_inc, float* coords_out, int32_t* rays_index,
                                 int32_t* rays_numsteps, uint32_t* counter2, float* xyz_planes, uint32_t plane_stride,
-                                uint32_t rng_chunk, uint32_t rng_ray0, void* workspace, size_t workspace_bytes, void* stream_) {
+                                uint32_t rng_chunk, uint32_t rng_ray0, uint32_t flags, void* workspace, size_t workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    XR_REQUIRE((flags & ~XR_K1_WIDE) == 0, "unknown flag");
     XR_REQUIRE(rays_o && rays_d && bitfield && coords_out && rays_index && rays_numsteps && counter2, "null pointer");
     XR_REQUIRE(!xyz_planes || plane_stride >= max_samples, "a position plane holds max_samples values");
     XR_REQUIRE(n_rays > 0 && n_rays <= (1u << 28), "n_rays out of range");
@@ -404,9 +405,11 @@ extern "C" int xr_rays_sampler3(const float* rays_o, const float* rays_d, const 
     RmWorkspace w; rm_ws_layout(n_rays, (char*)workspace, &w);
     xr_pcg32 rng{rng_state, rng_inc};
     const uint32_t nb = xr_div_up(n_rays, RM_BLOCK);
-    // up to K1W_MAX_RAYS rays (a training batch): K1W lanes per ray -- 8x the waves, each ~1/4 as long; above it (frames: 640 K rays = 10 K
-    // waves of the one-ray-per-lane kernel) the chip is full either way and the lanes are better spent on rays
-    if (K1W_MAX_RAYS && n_rays <= (uint32_t)K1W_MAX_RAYS) {
+    // XR_K1_WIDE (the caller says nothing else is running: the march in place at a grid refresh) and at most K1W_MAX_RAYS rays: K1W lanes
+    // per ray -- 8x the waves, each shorter: 174 -> 143 us at 12.5 K rays, 170 -> 121 at 4 K (profiles/r04_k1_lanes_per_ray_ab.txt).
+    // Not beside the training step (the side-stream marches): 8x the waves slow the scatter they run beside by more than the march
+    // gains (iteration 0.408 -> 0.424 ms); not for frames (65 K rays: 173 -> 280 us, the chip is full of rays either way).
+    if ((flags & XR_K1_WIDE) && K1W_MAX_RAYS && n_rays <= (uint32_t)K1W_MAX_RAYS) {
         hipLaunchKernelGGL(k1_count_w, dim3(xr_div_up(n_rays * K1W, RM_BLOCK)), dim3(RM_BLOCK), 0, stream, n_rays, aabb0, aabb1, rays_o, rays_d,
                            bitfield, cone_angle, near_distance, rng, rng_chunk, rng_ray0, w.cnt, w.start_t, w.tlist);
         hipLaunchKernelGGL(k1_block_scan, dim3(nb), dim3(RM_BLOCK), 0, stream, n_rays, (const uint32_t*)w.cnt, w.local_off, w.block_tot);
@@ -427,7 +430,7 @@ extern "C" int xr_rays_sampler2(const float* rays_o, const float* rays_d, const 
                                 int32_t* rays_numsteps, uint32_t* counter2, float* xyz_planes, uint32_t plane_stride,
                                 uint32_t rng_chunk, void* workspace, size_t workspace_bytes, void* stream_) {
     return xr_rays_sampler3(rays_o, rays_d, bitfield, n_rays, aabb0, aabb1, near_distance, cone_angle, max_samples, rng_state, rng_inc,
-                            coords_out, rays_index, rays_numsteps, counter2, xyz_planes, plane_stride, rng_chunk, 0, workspace, workspace_bytes, stream_);
+                            coords_out, rays_index, rays_numsteps, counter2, xyz_planes, plane_stride, rng_chunk, 0, 0, workspace, workspace_bytes, stream_);
 }
 
 extern "C" int xr_rays_sampler(const float* rays_o, const float* rays_d, const uint8_t* bitfield, uint32_t n_rays,

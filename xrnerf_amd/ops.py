@@ -208,12 +208,13 @@ def pcg32_host_state(ncalls, seed=9121):
 
 # ---------------------------------------------------------------- K1 / K2
 def rays_sampler(rays_o, rays_d, bitfield, aabb, near_distance, cone_angle, max_samples, rng_calls,
-                 coords_out=None, ws_tag='k1', small_out=None, xyz_out=None, rng_chunk=0, rng_ray0=0):
+                 coords_out=None, ws_tag='k1', small_out=None, xyz_out=None, rng_chunk=0, rng_ray0=0, wide=False):
     """returns coords_out [max_samples,7], rays_index [n,1], rays_numsteps [n,2], counter [2] (device).
     `small_out` = (rays_index, numsteps, counter) caller-owned buffers (persistent double buffers of the trainer).
     `xyz_out` = [3, >= max_samples] float32: the sample positions once more as three planes (hashgrid_fwd's fast input).
     `rng_chunk` > 0: the jitter of ceil(n / rng_chunk) consecutive launches over rng_chunk rays each (call indices rng_calls,
-    rng_calls + 1, ...) in this one launch; `rng_ray0`: the launch's rays are rays rng_ray0.. of that series' frame."""
+    rng_calls + 1, ...) in this one launch; `rng_ray0`: the launch's rays are rays rng_ray0.. of that series' frame.
+    `wide`: nothing else runs on the device (XR_K1_WIDE): up to 32 768 rays march with 8 lanes per ray, same samples."""
     L = _lib.load()
     n = rays_o.shape[0]
     dev = rays_o.device
@@ -232,7 +233,7 @@ def rays_sampler(rays_o, rays_d, bitfield, aabb, near_distance, cone_angle, max_
         _lib.check(L.xr_rays_sampler3(_ptr(rays_o), _ptr(rays_d), _ptr(bitfield), n, aabb[0], aabb[1], near_distance,
                                       cone_angle, max_samples, st, inc, _ptr(coords_out), _ptr(rays_index),
                                       _ptr(numsteps), _ptr(counter), _ptr(xyz_out), xyz_out.shape[1] if xyz_out is not None else 0,
-                                      int(rng_chunk), int(rng_ray0), _ptr(ws), ws.numel(), _stream()), 'xr_rays_sampler')
+                                      int(rng_chunk), int(rng_ray0), 1 if wide else 0, _ptr(ws), ws.numel(), _stream()), 'xr_rays_sampler')
     return coords_out, rays_index, numsteps, counter
 
 

@@ -272,7 +272,8 @@ class NGPGridSampler(_FastAttr, nn.Module):
             coords, rays_index, rays_numsteps, counter = ops.rays_sampler(
                 rays_o, rays_d, self.density_grid_bitfield, aabb, self.near_distance, self.cone_angle_constant,
                 max_samples, k1_index, coords_out=self._coords_buffer(max_samples, slot),
-                small_out=None if async_test else self._small_buffers(n_rays, slot), xyz_out=xyz, rng_chunk=rng_chunk, rng_ray0=rng_ray0)
+                small_out=None if async_test else self._small_buffers(n_rays, slot), xyz_out=xyz, rng_chunk=rng_chunk, rng_ray0=rng_ray0,
+                wide=is_training)       # (a training march in place = the iteration of a grid refresh: nothing runs beside it)
             # (a band: the launches of the chunk series its rays fall into; the network puts the whole frame's count back afterwards)
             self.k1_calls += ((rng_ray0 + n_rays + rng_chunk - 1) // rng_chunk - rng_ray0 // rng_chunk) if rng_chunk else 1
             if async_test:
