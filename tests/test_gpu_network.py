@@ -126,6 +126,18 @@ def test_early_terminated_render_within_eps_of_full_render(dev):
     sampler.k1_calls = calls                     # eps = 0 never terminates: bit-for-bit the same integration order
     z_rgb, z_a = render_frame_ert(tr.net, tr.data.poses[1], 96, 96, tr.data.focal, eps=-1.0)
     assert float((full_rgb - z_rgb).abs().max()) <= 2e-6 and render_frame_ert.last_evaluated[0] == total
+    # the same path behind the registry's frame entry point (XRNERF_FRAME=ert: HashNerfNetwork.batchify_forward, i.e. val_step / test_step)
+    import os
+    from xrnerf_amd import ops
+    o, d = ops.gen_rays(tr.data.poses[1], 96, 96, tr.data.focal, tr.data.focal, 48.0, 48.0, device=dev)
+    os.environ['XRNERF_FRAME'] = 'ert'
+    try:
+        sampler.k1_calls = calls
+        with torch.no_grad():
+            ret = tr.net.batchify_forward({'rays_o': o, 'rays_d': d, 'img_ids': torch.zeros((o.shape[0], 1), dtype=torch.int32, device=dev)}, is_test=True)
+    finally:
+        os.environ.pop('XRNERF_FRAME', None)
+    assert torch.equal(ret['rgb'].reshape(96, 96, 3), ert_rgb) and torch.equal(ret['alpha'].reshape(96, 96, 1), ert_a)
 
 
 def test_training_converges_on_the_synthetic_scene(dev):

@@ -362,6 +362,11 @@ class HashNerfNetwork(_FastAttr, BaseNerfNetwork):
         synchronous form (XRNERF_FRAME=sync), which costs one device-to-host round trip per chunk."""
         N = data[self.bs_data].shape[0]
         from .samplers import NGPGridSampler
+        if is_test and switches.frame_mode() == 'ert' and type(self.sampler) is NGPGridSampler and self._fused_types():
+            # optional (the reference evaluates every marched sample): early ray termination behind the registry's val / test steps
+            from .train import render_rays_ert
+            rgb, alpha = render_rays_ert(self, data['rays_o'].contiguous().float(), data['rays_d'].contiguous().float())
+            return {'rgb': rgb, 'alpha': alpha}
         if (is_test and (N > self.chunk or getattr(self.sampler, 'frame_ray0', 0)) and type(self.sampler) is NGPGridSampler
                 and switches.frame_mode() == 'one_launch'):
             # The whole frame as ONE launch per kernel with the SAME pixels as the chunk loop: encode, MLP and compositor are
@@ -398,6 +403,11 @@ class HashNerfNetwork(_FastAttr, BaseNerfNetwork):
             for k in ret:
                 all_ret.setdefault(k, []).append(ret[k])
         return {k: torch.cat(all_ret[k], 0) for k in all_ret}
+
+    def _fused_types(self):
+        from .mlps import HashNerfMLP
+        from .renders import HashNerfRender
+        return type(self.mlp) is HashNerfMLP and type(self.render) is HashNerfRender and self.mlp.density_net.n_hidden <= 2
 
     def _fused_ok(self):
         from .mlps import HashNerfMLP

@@ -11,7 +11,8 @@ a compile-time constant of one source (tools/build_variant.sh + XRNERF_LIB) or g
   XRNERF_STEP                  fused (default: one native call per training step) | py (the same entry points issued one by one from
                                Python: per-entry-point timers, the kernels' host build) | modular (sampler -> mlp -> render -> autograd)
   XRNERF_FRAME                 one_launch (default: a chunked test frame as one launch per kernel, same pixels) | async (the chunk loop
-                               without a read-back per chunk) | sync (the reference's loop)
+                               without a read-back per chunk) | sync (the reference's loop) | ert (early ray termination: samples behind
+                               T < 1e-4 are not evaluated; pixels within 1e-4 of the default -- the reference has no such path)
   XRNERF_TCNN_STRICT_DEFAULTS  1: tcnn's default 5 hidden layers where the config's `num_layers` is not a tcnn key (mlps.py)
   XRNERF_VAL_RANK0_ONLY        1: validation frames on rank 0 only, like the reference (networks.py)
 """
@@ -27,8 +28,8 @@ def step_mode():
 
 def frame_mode():
     m = os.environ.get('XRNERF_FRAME', 'one_launch')
-    if m not in ('one_launch', 'async', 'sync'):
-        raise ValueError("XRNERF_FRAME must be 'one_launch', 'async' or 'sync' (got %r)" % m)
+    if m not in ('one_launch', 'async', 'sync', 'ert'):
+        raise ValueError("XRNERF_FRAME must be 'one_launch', 'async', 'sync' or 'ert' (got %r)" % m)
     return m
 
 

@@ -744,15 +744,14 @@ ERT_SLICES = (0, 4, 8, 16, 32, 64, 128, 256, 512, 1024)
 
 
 @torch.no_grad()
-def render_frame_ert(net, pose43, H, W, focal, eps=1e-4, row0=0, nrows=None, bg=None):
-    """Early-terminated rendering of one camera (optional fast path; `render_frame` is the reference
-    behaviour).  The frame is marched once (K1), then evaluated in depth slices: before each slice the rays
-    whose transmittance is still above `eps` are compacted and ONLY their samples go through encode + MLP.
-    Pixels differ from the full evaluation by less than `eps` (everything skipped is weighted by T < eps)."""
+def render_rays_ert(net, o, d, eps=1e-4, bg=None):
+    """Early-terminated rendering of a set of rays (the optional fast path behind XRNERF_FRAME=ert and `render_frame_ert`; the reference
+    has no early termination -- its K5 leaves EPSILON unused, calc_rgb.cu:144-206 -- so the default frame path evaluates every marched
+    sample).  The rays are marched once (K1), then evaluated in depth slices: before each slice the rays whose transmittance is
+    still above `eps` are compacted (wave ballots) and ONLY their samples go through encode + MLP.  Pixels differ from the full
+    evaluation by less than `eps` (everything skipped is weighted by T < eps).  -> (rgb [n,3], alpha [n,1])"""
     sampler, mlp, render = net.sampler, net.mlp, net.render
-    dev = next(net.parameters()).device
-    nrows = H - row0 if nrows is None else nrows
-    o, d = ops.gen_rays(pose43, H, W, focal, focal, 0.5 * W, 0.5 * H, row0, nrows, device=dev)
+    dev = o.device
     data = sampler.sample({'rays_o': o, 'rays_d': d}, mlp, True)          # K1 only; one read-back
     coords, numsteps = sampler.coords, sampler.rays_numsteps
     n_rays, total = o.shape[0], coords.shape[0]
@@ -776,7 +775,16 @@ def render_frame_ert(net, pose43, H, W, focal, eps=1e-4, row0=0, nrows=None, bg=
                                mlp.pad_value, rows=r)
         ops.render_slice_composite(raw, coords, numsteps, ray_off, s0, s1, ra, da, T, acc)
     bgc = (render.bg_color if bg is None else torch.as_tensor(bg, dtype=torch.float32)).to(dev)
-    rgb = acc + T[:, None] * bgc[None, :]
-    alpha = (1.0 - T)[:, None]
-    render_frame_ert.last_evaluated = (evaluated, total)
+    render_rays_ert.last_evaluated = (evaluated, total)
+    return acc + T[:, None] * bgc[None, :], (1.0 - T)[:, None]
+
+
+@torch.no_grad()
+def render_frame_ert(net, pose43, H, W, focal, eps=1e-4, row0=0, nrows=None, bg=None):
+    """`render_rays_ert` for one camera (rows [row0, row0 + nrows) of its image)"""
+    dev = next(net.parameters()).device
+    nrows = H - row0 if nrows is None else nrows
+    o, d = ops.gen_rays(pose43, H, W, focal, focal, 0.5 * W, 0.5 * H, row0, nrows, device=dev)
+    rgb, alpha = render_rays_ert(net, o, d, eps, bg)
+    render_frame_ert.last_evaluated = render_rays_ert.last_evaluated
     return rgb.reshape(nrows, W, 3), alpha.reshape(nrows, W, 1)
