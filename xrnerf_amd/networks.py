@@ -532,12 +532,17 @@ class HashNerfNetwork(_FastAttr, BaseNerfNetwork):
             rgb = recover_shape(ret['rgb'], frame['src_shape'])
             rgb = rgb.cpu().numpy()           # D2H inside the timer ends the frame, as the reference's does
             elapsed_time_list.append(time.time() - start)
-            alpha = images[i].cpu().numpy()[:, :, 3:]
-            gt_img = images[i].cpu().numpy()[:, :, :3]
-            rgbs.append(rgb * alpha)
-            gt_imgs.append(gt_img * alpha)
+            rgbs.append(rgb)
         if rank != 0:
             return {}
+        # the alpha-masked images the reference builds between two frames (networks/hashnerf.py:78-83), built behind the LAST frame
+        # instead: ~5 ms of host-side numpy per frame during which the GPU idles and clocks down -- the next frame's timer then read
+        # 14 ms for 6 ms of device work (profiles/r04_registry_frame_host_time.txt).  Same arrays.
+        for i in range(len(rgbs)):
+            img = images[i].cpu().numpy()
+            alpha = img[:, :, 3:]
+            gt_imgs.append(img[:, :, :3] * alpha)
+            rgbs[i] = rgbs[i] * alpha
         return {'rgbs': rgbs, 'disps': disps, 'gt_imgs': gt_imgs, 'elapsed_time': elapsed_time_list}
 
     def test_step(self, data, **kwargs):
