@@ -130,8 +130,9 @@ class NGPGridSampler(_FastAttr, nn.Module):
         self.density_grid_ema_step += 1
         ops.update_bitfield(self.density_grid, self.density_grid_mean, self.density_grid_bitfield)
         if self._streams():
-            self._bitfield_event = torch.cuda.Event()
-            self._bitfield_event.record(torch.cuda.current_stream())
+            if getattr(self, '_bitfield_event', None) is None:
+                self._bitfield_event = torch.cuda.Event()        # ONE event, recorded again at every refresh (waits capture the record
+            self._bitfield_event.record(torch.cuda.current_stream())   # they follow; the native loop's descriptor keeps naming it)
 
     def _grid_samples(self, n_uniform, n_nonuniform, planes):
         """K6 twice (uniform, then among the occupied cells) + the clear of the temporary grid's part in use"""

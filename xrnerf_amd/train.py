@@ -598,29 +598,13 @@ class _NativeLoop:
         del self.issued[:int(S.queued)]
         S.queued = 0
 
-    # ------------------------------------------------------------------ one window
-    def run(self, k, iter_events=None):
-        tr, S, L = self.tr, self.state, _lib.load()
+    def _descriptor(self, n_rays, max_samples, n_rows, sets, states, g, side, bev):
+        tr, L = self.tr, _lib.load()
         net, data = tr.net, tr.data
         sampler, mlp = net.sampler, net.mlp
-        f = sampler.update_grid_freq
-        if tr.iter % f == 0 or tr.iter % f + k > f:
-            raise _lib.XrError('a native window never crosses a grid refresh')
         dev = tr.device
-        self._pull()
-        if tr._queue or sampler.__dict__.get('_prefetched_q'):
-            self.adopt_from_python()
-        n_rays = min(data.N_rand, data.rays_rgb.shape[0])
-        max_samples = self._max_samples(n_rays)
-        n_rows = min(sampler.target_batch_size, max_samples)
         table, wd, wc = mlp.embedder_pos.params, mlp.density_net.params, mlp.color_net.params
         meta = mlp.embedder_pos.meta
-        sets = getattr(net, '_step_bufs', None)
-        if (sets is None or sets[0].n_rows != n_rows or sets[0].ray_cap < n_rays or sets[0].g_table.shape != table.shape
-                or sets[0].g_table.device != table.device):
-            sets = net._step_bufs = [ops.TrainStepBuffers(dev, n_rows, max(n_rays, 1 << 15), table.numel(), wd.numel(), wc.numel(), meta)
-                                     for _ in range(2)]
-            net._step_turn = S.step_turn = 0
         if not ops.hashgrid_bwd_adam_supported(n_rows, meta):
             raise _lib.XrError('the fused table update has no non-atomic scatter path at this row capacity')
         D = _lib.LoopDesc()
@@ -629,8 +613,6 @@ class _NativeLoop:
         D.n_hidden_density, D.n_hidden_color, D.pad_value, D.mlp_mode = 1, 2, float(mlp.pad_value), ops._mlp_mode(1, 2)
         s_, r_, o_ = meta._args()
         D.n_levels, D.scale_host, D.resolution_host, D.offset_host = meta.n_levels, s_, r_, o_
-        states = self._adam_states()
-        g = self._group
         for name, p, st in zip(('adam_table', 'adam_w_density', 'adam_w_color'), (table, wd, wc), states):
             ema = st.get('ema') if g['ema_momentum'] is not None else None
             a = ops.adam_fuse(p.data, st['m'], st['v'], ema, 0, 0.0, g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], 0.0, 1.0)
@@ -663,15 +645,56 @@ class _NativeLoop:
         D.ws_k1, D.ws_k1_bytes, D.ws_mlp_bwd, D.ws_mlp_bwd_bytes = vp(ws_k1), ws_k1.numel(), vp(ws_mlp), ws_mlp.numel()
         D.ws_scatter, D.ws_scatter_bytes = vp(ws_sc), ws_sc.numel()
         D.counter_host_pinned, D.n_pinned = self.pinned.data_ptr(), self.N_PINNED
-        side = sampler.side_stream()
         D.stream, D.side_stream = ops._stream(), side.cuda_stream
-        bev = getattr(sampler, '_bitfield_event', None)
         D.bitfield_event = bev.cuda_event if bev is not None else None
         mark = getattr(net, '_step_mark', None)
         if mark is None or mark[0] != 'xr_nerf_mlp_bwd':
             raise _lib.XrError('the native loop marches two iterations ahead (prefetch_depth=2)')
         D.mark_event = mark[1].h
-        self._keep = (D, msets, sets, ws_k1, ws_mlp, ws_sc, bev)
+        self._hold = (sets, ws_k1, ws_mlp, ws_sc, bev, states)          # (what the pointers name stays alive)
+        return D, msets, live_list, live_stats
+
+    # ------------------------------------------------------------------ one window
+    def run(self, k, iter_events=None):
+        tr, S, L = self.tr, self.state, _lib.load()
+        net, data = tr.net, tr.data
+        sampler, mlp = net.sampler, net.mlp
+        f = sampler.update_grid_freq
+        if tr.iter % f == 0 or tr.iter % f + k > f:
+            raise _lib.XrError('a native window never crosses a grid refresh')
+        dev = tr.device
+        self._pull()
+        if tr._queue or sampler.__dict__.get('_prefetched_q'):
+            self.adopt_from_python()
+        n_rays = min(data.N_rand, data.rays_rgb.shape[0])
+        max_samples = self._max_samples(n_rays)
+        n_rows = min(sampler.target_batch_size, max_samples)
+        table, wd, wc = mlp.embedder_pos.params, mlp.density_net.params, mlp.color_net.params
+        meta = mlp.embedder_pos.meta
+        sets = getattr(net, '_step_bufs', None)
+        if (sets is None or sets[0].n_rows != n_rows or sets[0].ray_cap < n_rays or sets[0].g_table.shape != table.shape
+                or sets[0].g_table.device != table.device):
+            sets = net._step_bufs = [ops.TrainStepBuffers(dev, n_rows, max(n_rays, 1 << 15), table.numel(), wd.numel(), wc.numel(), meta)
+                                     for _ in range(2)]
+            net._step_turn = S.step_turn = 0
+        side = sampler.side_stream()
+        bev = getattr(sampler, '_bitfield_event', None)
+        states = self._adam_states()
+        g = self._group
+        # the descriptor is rebuilt only when something it names has changed (a buffer that grew, a new refresh event, another
+        # precision mode): ~60 pointer conversions and four workspace queries otherwise sit in front of every window's first kernel
+        key = (n_rays, max_samples, n_rows, id(sets[0]), id(sets[1]), table.data_ptr(), wd.data_ptr(), wc.data_ptr(), data.rays_rgb.data_ptr(),
+               sampler.density_grid_bitfield.data_ptr(), sampler.density_grid_mean.data_ptr(), ops._mlp_mode(1, 2), id(bev), ops._stream().value,
+               tuple(id(x) for x in (getattr(sampler, '_coords_bufs', None) or ())), tuple(id(x) for x in (getattr(sampler, '_small_bufs', None) or ())),
+               tuple(id(x) for x in (getattr(sampler, '_clip_bufs', None) or ())), tuple(id(x) for x in (getattr(sampler, '_xyz_bufs', None) or ())),
+               tuple(id(x) for x in tr._bbufs), tuple(id(st['m']) for st in states), id(ops._workspaces.get((str(dev), 'k1_side'))),
+               id(ops._workspaces.get((str(dev), 'mlpbwd'))), id(ops._workspaces.get((str(dev), 'hgb'))))
+        if self._keep is not None and self._keep[0] == key:
+            _, D, msets, live_list, live_stats = self._keep
+        else:
+            D, msets, live_list, live_stats = self._descriptor(n_rays, max_samples, n_rows, sets, states, g, side, bev)
+            key = key[:-3] + (id(ops._workspaces.get((str(dev), 'k1_side'))), id(ops._workspaces.get((str(dev), 'mlpbwd'))), id(ops._workspaces.get((str(dev), 'hgb'))))
+            self._keep = (key, D, msets, live_list, live_stats)
         # the schedules are this trainer's: lr per iteration, the EMA momentum of mmcv's EMAHook per update
         lr = (C.c_float * k)(*[step_lr(tr.base_lr, tr.iter + j) for j in range(k)])
         mom = (C.c_float * k)(*[(FusedAdam._ema_momentum(g, int(S.adam_step) + 1 + j) if g['ema_momentum'] is not None else 0.0) for j in range(k)])
