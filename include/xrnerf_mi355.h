@@ -436,7 +436,10 @@ typedef struct xr_ngp_loop_desc {
     uint32_t* counter_host_pinned; uint32_t n_pinned;      /* ring of n_pinned (rays, samples) pairs in pinned host memory */
     void *stream, *side_stream;
     void* bitfield_event;                                  /* nullable: recorded behind the last writer of `bitfield` */
-    void* mark_event;                                      /* xr_order_event_create: recorded behind every step's MLP backward */
+    void* mark_event;                                      /* xr_order_event_create: recorded behind `mark_entry` of every step */
+    const char* mark_entry;                                /* the entry point of the step behind which the march of iteration i + 2 may start
+                                                              ("xr_nerf_mlp_bwd": beside the scatter and the next lookup; null: behind the end of
+                                                              iteration i - 1 only, i.e. from the start of iteration i) */
 } xr_ngp_loop_desc;
 typedef struct xr_ngp_loop_state {     /* the counters the loop shares with its caller (read AND written) */
     uint64_t iter;                     /* next iteration */

@@ -409,7 +409,7 @@ extern "C" int xr_rays_sampler3(const float* rays_o, const float* rays_d, const 
     // per ray -- 8x the waves, each shorter: 174 -> 143 us at 12.5 K rays, 170 -> 121 at 4 K (profiles/r04_k1_lanes_per_ray_ab.txt).
     // Not beside the training step (the side-stream marches): 8x the waves slow the scatter they run beside by more than the march
     // gains (iteration 0.408 -> 0.424 ms); not for frames (65 K rays: 173 -> 280 us, the chip is full of rays either way).
-    if ((flags & XR_K1_WIDE) && K1W_MAX_RAYS && n_rays <= (uint32_t)K1W_MAX_RAYS) {
+    if ((flags & XR_K1_WIDE) != 0u && (uint32_t)K1W_MAX_RAYS != 0u && n_rays <= (uint32_t)K1W_MAX_RAYS) {
         hipLaunchKernelGGL(k1_count_w, dim3(xr_div_up(n_rays * K1W, RM_BLOCK)), dim3(RM_BLOCK), 0, stream, n_rays, aabb0, aabb1, rays_o, rays_d,
                            bitfield, cone_angle, near_distance, rng, rng_chunk, rng_ray0, w.cnt, w.start_t, w.tlist);
         hipLaunchKernelGGL(k1_block_scan, dim3(nb), dim3(RM_BLOCK), 0, stream, n_rays, (const uint32_t*)w.cnt, w.local_off, w.block_tot);

@@ -304,7 +304,7 @@ extern "C" int xr_ngp_loop_run(void* loop, const xr_ngp_loop_desc* desc, xr_ngp_
     if (S.queued == 0) {
         if ((rc = xr_loop_issue_march(L, D, S, n_rays, L->done_prev[0], nullptr)) != XR_OK) return rc;
         if ((S.iter + 1) % f != 0 && k >= 1)
-            if ((rc = xr_loop_issue_march(L, D, S, n_rays, L->done_prev[0], (hipEvent_t)D.mark_event)) != XR_OK) return rc;
+            if ((rc = xr_loop_issue_march(L, D, S, n_rays, L->done_prev[0], D.mark_entry ? (hipEvent_t)D.mark_event : nullptr)) != XR_OK) return rc;
     }
     xr_adam_fuse at = D.adam_table, ad = D.adam_w_density, ac = D.adam_w_color;
     for (uint32_t j = 0; j < k; ++j) {
@@ -326,14 +326,14 @@ extern "C" int xr_ngp_loop_run(void* loop, const xr_ngp_loop_desc* desc, xr_ngp_
                                M.alpha, D.density_grid_mean, D.rgb_activation, D.density_activation, D.huber_delta, D.loss_scale, B.enc_t, D.ld, B.raw,
                                B.draw, B.denc_t, B.rgb_out, B.zero_block, B.zero_floats, B.grad_w_density, B.grad_w_color, B.loss_mse, B.live_seg_count,
                                nullptr, 0, 0, D.ws_mlp_bwd, D.ws_mlp_bwd_bytes, D.ws_scatter, D.ws_scatter_bytes, 0, M.xyz_planes, M.plane_stride, &at,
-                               &ad, &ac, "xr_nerf_mlp_bwd", D.mark_event, timed_entry, timed_entry ? timing_events[2 * j] : nullptr,
+                               &ad, &ac, D.mark_entry, D.mark_entry ? D.mark_event : nullptr, timed_entry, timed_entry ? timing_events[2 * j] : nullptr,
                                timed_entry ? timing_events[2 * j + 1] : nullptr, D.stream);
         if (rc != XR_OK) return rc;
         // Trainer._on_sampled, depth 2: iteration it + 1 at once if nothing is queued for it, then it + 2 behind this step's mark
         if (S.queued == 0 && (it + 1) % f != 0)
             if ((rc = xr_loop_issue_march(L, D, S, n_rays, L->done_prev[1], nullptr)) != XR_OK) return rc;
         if (S.queued == 1 && (it + 1) % f != 0 && (it + 2) % f != 0)
-            if ((rc = xr_loop_issue_march(L, D, S, n_rays, L->done_prev[1], (hipEvent_t)D.mark_event)) != XR_OK) return rc;
+            if ((rc = xr_loop_issue_march(L, D, S, n_rays, L->done_prev[1], D.mark_entry ? (hipEvent_t)D.mark_event : nullptr)) != XR_OK) return rc;
         hipEvent_t done = L->iter_done[it % 3u];
         XR_HIP(hipEventRecord(done, stream));
         L->done_prev[0] = L->done_prev[1]; L->done_prev[1] = done;

@@ -33,7 +33,8 @@ def frame_mode():
     return m
 
 
-TRAINER_KEYS = {'native_loop': bool, 'fuse_adam': bool, 'direct_step': bool, 'overlap_march': bool, 'prefetch_depth': int, 'prefetch_k6': bool}
+TRAINER_KEYS = {'native_loop': bool, 'fuse_adam': bool, 'direct_step': bool, 'overlap_march': bool, 'prefetch_depth': int, 'prefetch_k6': bool,
+                'march_after': str}
 
 
 def trainer_overrides():
@@ -44,5 +45,5 @@ def trainer_overrides():
         k = k.strip()
         if k not in TRAINER_KEYS:
             raise ValueError('XRNERF_TRAINER: unknown key %r (known: %s)' % (k, ', '.join(sorted(TRAINER_KEYS))))
-        out[k] = bool(int(v)) if TRAINER_KEYS[k] is bool else int(v)
+        out[k] = bool(int(v)) if TRAINER_KEYS[k] is bool else TRAINER_KEYS[k](v)
     return out

@@ -210,16 +210,19 @@ class Trainer:
     backward -> [gradient all-reduce] -> fused Adam(+EMA)."""
 
     def __init__(self, device, n_img=20, H=800, W=800, seed=0, world_size=1, rank=0, dataset=None, ema=True, native_loop=True,
-                 fuse_adam=True, direct_step=True, overlap_march=True, prefetch_depth=2, prefetch_k6=True):
+                 fuse_adam=True, direct_step=True, overlap_march=True, prefetch_depth=2, prefetch_k6=True, march_after='xr_nerf_mlp_bwd'):
         """The keyword switches (each overridable from the environment: XRNERF_TRAINER="fuse_adam=0,..."; xrnerf_amd/switches.py):
         native_loop     the iterations between two grid refreshes as native calls (xr_ngp_loop_run); False: one Python-driven step each
         fuse_adam       one GPU: the table scatter applies this optimiser's update itself (False: scatter, then the optimiser's launches)
         direct_step     one GPU: the fused step without an autograd graph (False: loss.backward() + optimizer.step())
         overlap_march   K1 of later batches on a side stream under the current step (False: in order on the compute stream)
         prefetch_depth  2: the march of iteration i + 2 is issued during iteration i, behind its MLP backward; 1: iteration i + 1 at once
-        prefetch_k6     the refresh's sample generation one iteration early, on the side stream"""
+        prefetch_k6     the refresh's sample generation one iteration early, on the side stream
+        march_after     (prefetch_depth 2) the entry point of step i behind which the march of iteration i + 2 starts: 'xr_nerf_mlp_bwd'
+                        (default: beside the scatter and the next lookup), 'xr_hashgrid_fwd', 'xr_nerf_mlp_fwd', 'xr_composite_train',
+                        'xr_live_rows', or 'start' (from the start of step i)"""
         opts = dict(native_loop=native_loop, fuse_adam=fuse_adam, direct_step=direct_step, overlap_march=overlap_march,
-                    prefetch_depth=prefetch_depth, prefetch_k6=prefetch_k6)
+                    prefetch_depth=prefetch_depth, prefetch_k6=prefetch_k6, march_after=march_after)
         opts.update(switches.trainer_overrides())
         if opts['prefetch_depth'] not in (1, 2):
             raise ValueError('prefetch_depth is 1 or 2')
@@ -268,7 +271,11 @@ class Trainer:
         # With one iteration of lead that start point leaves the march unfinished when its rows are needed (start points of the
         # depth-1 scheme, all measured: profiles/r03_prefetch_start_point.txt); with two it has a whole iteration.
         self.prefetch_depth = opts['prefetch_depth']
-        self.net._step_mark = ('xr_nerf_mlp_bwd', ops._CEvent(timing=False)) if (self.prefetch_depth == 2 and device.type == 'cuda') else None
+        if opts['march_after'] not in ('start', 'xr_hashgrid_fwd', 'xr_nerf_mlp_fwd', 'xr_composite_train', 'xr_live_rows', 'xr_nerf_mlp_bwd'):
+            raise ValueError('march_after: unknown entry point %r' % opts['march_after'])
+        self.march_after = opts['march_after']
+        self.net._step_mark = ((self.march_after, ops._CEvent(timing=False))
+                               if (self.prefetch_depth == 2 and self.march_after != 'start' and device.type == 'cuda') else None)
         self.prefetch_k6 = opts['prefetch_k6']      # the refresh's K6 one iteration early, on the side stream
         self._ev_done = [None, None]   # completion events of the last two iterations (None: the native loop ran it and holds the event)
         # the iterations between two grid refreshes as native calls (xr_ngp_loop_run: batch draw, march two iterations ahead, step with the
@@ -407,12 +414,12 @@ class Trainer:
             return
         queued = self._queue[-1][0] if self._queue else it            # the last iteration that already has its march
         mark = getattr(net, '_step_mark', None)
-        if self.prefetch_depth == 2 and mark is not None and mark[0] == 'xr_nerf_mlp_bwd':
+        if self.prefetch_depth == 2 and (mark is not None or self.march_after == 'start'):
             if queued < it + 1 and net.sampler.can_prefetch(it + 1):
                 self._issue(it + 1, None)                             # not covered two iterations ago: at once
                 queued = it + 1
             if queued == it + 1 and (it + 1) % f != 0 and (it + 2) % f != 0:
-                self._issue(it + 2, mark[1])
+                self._issue(it + 2, mark[1] if mark is not None else None)
         elif queued < it + 1 and net.sampler.can_prefetch(it + 1):
             self._issue(it + 1, mark[1] if mark else None)
         if (it + 1) % f == 0 and self.prefetch_k6 and hasattr(net.sampler, 'prefetch_grid_samples'):
@@ -499,6 +506,7 @@ class _NativeLoop:
         self.state = _lib.LoopState()
         self.pinned = torch.zeros((self.N_PINNED, 2), dtype=torch.int32).pin_memory()
         self.enqueue_s, self.enqueued = 0.0, 0
+        self._mark_dummy = None
         self.issued = []                   # (object with .synchronize(), host [2] view) of the marches issued and not yet consumed, in order
         self._keep = None
 
@@ -648,9 +656,12 @@ class _NativeLoop:
         D.stream, D.side_stream = ops._stream(), side.cuda_stream
         D.bitfield_event = bev.cuda_event if bev is not None else None
         mark = getattr(net, '_step_mark', None)
-        if mark is None or mark[0] != 'xr_nerf_mlp_bwd':
+        if mark is None and tr.march_after != 'start':
             raise _lib.XrError('the native loop marches two iterations ahead (prefetch_depth=2)')
-        D.mark_event = mark[1].h
+        if self._mark_dummy is None:
+            self._mark_dummy = ops._CEvent(timing=False)
+        D.mark_event = mark[1].h if mark is not None else self._mark_dummy.h
+        D.mark_entry = mark[0].encode() if mark is not None else None
         self._hold = (sets, ws_k1, ws_mlp, ws_sc, bev, states)          # (what the pointers name stays alive)
         return D, msets, live_list, live_stats
 
