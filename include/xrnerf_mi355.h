@@ -438,7 +438,7 @@ typedef struct xr_ngp_loop_desc {
     void* bitfield_event;                                  /* nullable: recorded behind the last writer of `bitfield` */
     void* mark_event;                                      /* xr_order_event_create: recorded behind `mark_entry` of every step */
     const char* mark_entry;                                /* the entry point of the step behind which the march of iteration i + 2 may start
-                                                              ("xr_nerf_mlp_bwd": beside the scatter and the next lookup; null: behind the end of
+                                                              ("xr_live_rows": beside the MLP backward and the scatter; null: behind the end of
                                                               iteration i - 1 only, i.e. from the start of iteration i) */
 } xr_ngp_loop_desc;
 typedef struct xr_ngp_loop_state {     /* the counters the loop shares with its caller (read AND written) */

@@ -1793,7 +1793,7 @@ extern "C" int xr_nerf_mlp_bwd(const float* enc_t, uint32_t ld, const float* dir
     // relative accuracy puts a hidden unit whose pre-activation is within ~1e-5 of zero on the other side of its ReLU than
     // the forward had it (a few hundred unit-samples per training step, ~1 with the fp32 recompute) -- harmless to the
     // optimiser, but each such flip is one sample's whole contribution to a weight row, which a 1e-3 * max parity bar on a
-    // small batch sees.
+    // small batch sees (profiles/NOTES_r01_r03.md 5f).
     const char* bwd_env = getenv("XR_MLP_BWD_DW");
     const int mode = !bwd_env ? 2 : strcmp(bwd_env, "f32") == 0 ? 0 : strcmp(bwd_env, "b2") == 0 ? 1 : strcmp(bwd_env, "b2x") == 0 ? 2
                    : strcmp(bwd_env, "b2f") == 0 ? 3 : -1;

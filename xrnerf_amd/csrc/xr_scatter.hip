@@ -2,7 +2,7 @@
 // /root/reference/xrnerf/models/mlps/hashnerf_mlp.py:34-37,59-61): EVERY level without a global atomic, no helper
 // stream, results independent of the launch schedule up to the order of fp64 additions inside one workgroup.
 //
-// What round 2 measured on the second generation (profiles/r02_scatter_phase_timing.txt):
+// What round 2 measured on the second generation (profiles/r02_scatter_phase_timing.txt, profiles/NOTES_r01_r03.md 5b):
 //   * the dense levels' atomic kernel (55 us alone) beside the bin / accumulate pair stretches that pair from 39 + 56 to
 //     73 + 64 us -- the overlap costs what it hides;
 //   * inside k_scatter_accum2 the item stream (11.5 us per workgroup) and the LDS atomics (12 us) do NOT overlap (23.8 us

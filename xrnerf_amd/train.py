@@ -210,7 +210,7 @@ class Trainer:
     backward -> [gradient all-reduce] -> fused Adam(+EMA)."""
 
     def __init__(self, device, n_img=20, H=800, W=800, seed=0, world_size=1, rank=0, dataset=None, ema=True, native_loop=True,
-                 fuse_adam=True, direct_step=True, overlap_march=True, prefetch_depth=2, prefetch_k6=True, march_after='xr_nerf_mlp_bwd'):
+                 fuse_adam=True, direct_step=True, overlap_march=True, prefetch_depth=2, prefetch_k6=True, march_after='xr_live_rows'):
         """The keyword switches (each overridable from the environment: XRNERF_TRAINER="fuse_adam=0,..."; xrnerf_amd/switches.py):
         native_loop     the iterations between two grid refreshes as native calls (xr_ngp_loop_run); False: one Python-driven step each
         fuse_adam       one GPU: the table scatter applies this optimiser's update itself (False: scatter, then the optimiser's launches)
@@ -218,9 +218,10 @@ class Trainer:
         overlap_march   K1 of later batches on a side stream under the current step (False: in order on the compute stream)
         prefetch_depth  2: the march of iteration i + 2 is issued during iteration i, behind its MLP backward; 1: iteration i + 1 at once
         prefetch_k6     the refresh's sample generation one iteration early, on the side stream
-        march_after     (prefetch_depth 2) the entry point of step i behind which the march of iteration i + 2 starts: 'xr_nerf_mlp_bwd'
-                        (default: beside the scatter and the next lookup), 'xr_hashgrid_fwd', 'xr_nerf_mlp_fwd', 'xr_composite_train',
-                        'xr_live_rows', or 'start' (from the start of step i)"""
+        march_after     (prefetch_depth 2) the entry point of step i behind which the march of iteration i + 2 starts: 'xr_live_rows'
+                        (default: beside the MLP backward and the scatter; a normal iteration 0.401 ms against 0.408-0.410 behind the
+                        MLP backward, 0.423 from the step's start or behind the lookup / MLP forward: profiles/r04_march_start_point_ab.txt),
+                        'xr_hashgrid_fwd', 'xr_nerf_mlp_fwd', 'xr_composite_train', 'xr_nerf_mlp_bwd', or 'start'"""
         opts = dict(native_loop=native_loop, fuse_adam=fuse_adam, direct_step=direct_step, overlap_march=overlap_march,
                     prefetch_depth=prefetch_depth, prefetch_k6=prefetch_k6, march_after=march_after)
         opts.update(switches.trainer_overrides())
@@ -264,12 +265,12 @@ class Trainer:
         self.rays_done = 0
         self.lazy_log = True
         self.overlap_march = opts['overlap_march']
-        # prefetch_depth 2: the march of iteration i + 2 is issued during iteration i and starts behind i's MLP backward (the event the
-        # native step records there), so that it runs beside the table scatter and the next encode instead of beside the two fused-MLP
-        # kernels -- the backward's waves own whole SIMD register files and cannot be placed on a CU that hosts a marching wave, the
-        # forward shares its SIMDs with them: 87 -> 74 us and 62 -> 47 us when the march is elsewhere (profiles/r03_k1_placement_ab.txt).
-        # With one iteration of lead that start point leaves the march unfinished when its rows are needed (start points of the
-        # depth-1 scheme, all measured: profiles/r03_prefetch_start_point.txt); with two it has a whole iteration.
+        # prefetch_depth 2: the march of iteration i + 2 is issued during iteration i and starts behind an entry point of step i (the event
+        # the native step records there; `march_after`), so that its ~290 us of latency-bound waves run beside the backward half of
+        # the step -- round 3 started it behind the MLP backward (profiles/r03_k1_placement_ab.txt: beside the fused-MLP forward it
+        # costs that kernel 15 us), round 4 measured every start point under the native loop and moved it behind the live-row list:
+        # the march then ends before the next step's MLP forward begins.  With one iteration of lead a late start point leaves the
+        # march unfinished when its rows are needed (profiles/r03_prefetch_start_point.txt); with two it has a whole iteration.
         self.prefetch_depth = opts['prefetch_depth']
         if opts['march_after'] not in ('start', 'xr_hashgrid_fwd', 'xr_nerf_mlp_fwd', 'xr_composite_train', 'xr_live_rows', 'xr_nerf_mlp_bwd'):
             raise ValueError('march_after: unknown entry point %r' % opts['march_after'])
