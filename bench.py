@@ -780,7 +780,7 @@ def main():
     roof = roof_of(dom_pick, launches, total_ms, units if units > 0 else samples, live_frac_timed)
     roof['traffic'] = None
     try:   # HBM bytes per launch from separate rocprofv3 --pmc passes of THIS command (tools/pmc_traffic.py)
-        pmc_path = next(p for p in (os.path.join(ROOT, 'profiles', n) for n in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json')) if os.path.exists(p))
+        pmc_path = next(p for p in (os.path.join(ROOT, 'profiles', n) for n in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json')) if os.path.exists(p))
         pmc = json.load(open(pmc_path))
         if dom_pick in pmc:
             roof['traffic'] = pmc[dom_pick]['bytes_fetch_x2']
