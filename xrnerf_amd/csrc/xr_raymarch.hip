@@ -280,13 +280,27 @@ __global__ __launch_bounds__(RM_BLOCK) void k1_write(
     uint32_t n_rays, float lo, float hi, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
     const uint8_t* __restrict__ bitfield, float cone, uint32_t max_samples, const uint32_t* __restrict__ cnt,
     const uint32_t* __restrict__ local_off, const float* __restrict__ start_t,
-    const uint32_t* __restrict__ block_base, const uint32_t* __restrict__ info, float* __restrict__ coords_out,
+    const uint32_t* __restrict__ block_base, const uint32_t* __restrict__ info, const uint32_t* __restrict__ block_tot,
+    float* __restrict__ coords_out,
     int32_t* __restrict__ rays_index, int32_t* __restrict__ numsteps_out, uint32_t* __restrict__ counter2,
     const float* __restrict__ tlist, float* __restrict__ xyz_planes, uint32_t plane_stride) {
     __shared__ uint32_t lds4[4];
     const uint32_t b = blockIdx.x, i = b * RM_BLOCK + threadIdx.x;
-    const uint32_t cross = info[1], nb = gridDim.x;
-    const uint32_t bbase = block_base[b];
+    const uint32_t nb = gridDim.x;
+    uint32_t cross, bbase, grand;
+    if (block_tot) {
+        // up to RM_BLOCK blocks (65 536 rays: every training batch): each workgroup scans the block totals itself -- the one-workgroup
+        // k_scan_blocks launch between the two passes is gone (5 us alone, 20-40 us of the side stream's chain beside the training
+        // step, where a one-workgroup kernel waits for a slot: profiles/r04_trace_normal_iteration.txt)
+        __shared__ uint32_t s_cross, s_bbase;
+        if (threadIdx.x == 0) s_cross = nb;
+        const uint32_t v = threadIdx.x < nb ? block_tot[threadIdx.x] : 0u;
+        const uint32_t ex = block_excl_scan(v, &grand, lds4);
+        if (threadIdx.x < nb && (uint64_t)ex + v > (uint64_t)max_samples) atomicMin(&s_cross, threadIdx.x);
+        if (threadIdx.x == b) s_bbase = ex;
+        __syncthreads();
+        cross = s_cross; bbase = s_bbase;
+    } else { cross = info[1]; bbase = block_base[b]; grand = info[0]; }
     uint32_t n = 0, base = 0; bool in = i < n_rays;
     if (in) { n = cnt[i]; base = bbase + local_off[i]; }
     // a ray is "valid" unless its range would overflow the sample buffer (:76-82)
@@ -307,7 +321,7 @@ __global__ __launch_bounds__(RM_BLOCK) void k1_write(
     // counters: samples = grand total (the atomicAdd of :75 runs for every ray, overflowing or
     // not); rays = number of valid rays
     if (threadIdx.x == 0) {
-        if (b == 0) counter2[1] = info[0];
+        if (b == 0) counter2[1] = grand;
         if (b == cross || (cross == nb && b == nb - 1)) counter2[0] = valid_before + vtot;
     }
     // ---- sample-parallel expansion.  The block's rays own the contiguous row range
@@ -416,9 +430,14 @@ extern "C" int xr_rays_sampler3(const float* rays_o, const float* rays_d, const 
     } else
         hipLaunchKernelGGL(k1_count, dim3(nb), dim3(RM_BLOCK), 0, stream, n_rays, aabb0, aabb1, rays_o, rays_d, bitfield,
                            cone_angle, near_distance, rng, rng_chunk, rng_ray0, w.cnt, w.local_off, w.start_t, w.block_tot, w.tlist);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, nb, w.block_tot, max_samples, w.block_base, w.info);
+#ifndef K1_INLINE_SCAN
+#define K1_INLINE_SCAN 1
+#endif
+    const bool inline_scan = K1_INLINE_SCAN && nb <= (uint32_t)RM_BLOCK;
+    if (!inline_scan) hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, nb, w.block_tot, max_samples, w.block_base, w.info);
     hipLaunchKernelGGL(k1_write, dim3(nb), dim3(RM_BLOCK), 0, stream, n_rays, aabb0, aabb1, rays_o, rays_d, bitfield,
-                       cone_angle, max_samples, w.cnt, w.local_off, w.start_t, w.block_base, w.info, coords_out,
+                       cone_angle, max_samples, w.cnt, w.local_off, w.start_t, w.block_base, w.info,
+                       inline_scan ? (const uint32_t*)w.block_tot : (const uint32_t*)nullptr, coords_out,
                        rays_index, rays_numsteps, counter2, w.tlist, xyz_planes, plane_stride);
     XR_LAUNCH_CHECK();
     return XR_OK;

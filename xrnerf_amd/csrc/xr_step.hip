@@ -256,19 +256,30 @@ extern "C" int xr_ngp_loop_adopt_march(void* loop, uint32_t set, void* side_stre
     return XR_OK;
 }
 
+#ifndef XR_LOOP_BATCH_FIRST
+#define XR_LOOP_BATCH_FIRST 1     // the batch assembly ahead of the march's start point (0: behind it, as one xr_ngp_prefetch would)
+#endif
 // the march of iteration `target` on the side stream: mirror of NGPGridSampler.prefetch_native + Trainer._issue
 static int xr_loop_issue_march(XrLoop* L, const xr_ngp_loop_desc& D, xr_ngp_loop_state& S, uint32_t n_rays, hipEvent_t buffer_free, hipEvent_t start) {
     hipStream_t side = (hipStream_t)D.side_stream;
     if (D.bitfield_event) XR_HIP(hipStreamWaitEvent(side, (hipEvent_t)D.bitfield_event, 0));
     if (buffer_free) XR_HIP(hipStreamWaitEvent(side, buffer_free, 0));
-    if (start) XR_HIP(hipStreamWaitEvent(side, start, 0));
     const uint32_t set = (++S.march_launches) % 3u;
     const xr_ngp_march_set& M = D.march[set];
     if (S.cur_ray + n_rays > D.n_table_rays) S.cur_ray = 0;
-    int rc = xr_ngp_prefetch(D.rays_rgb_rows + (size_t)S.cur_ray * 11, n_rays, D.batch_seed, S.batches_drawn, M.rays_o, M.rays_d, M.target, M.alpha,
-                             M.bg, M.img_ids, D.bitfield, D.aabb0, D.aabb1, D.near_distance, D.cone_angle, D.max_samples, S.k1_calls, M.coords,
-                             M.rays_index, M.rays_numsteps, M.counter2, D.ws_k1, D.ws_k1_bytes, D.max_compacted, M.numsteps_clipped, M.n_valid,
-                             nullptr, M.xyz_planes, M.plane_stride, side);
+    // xr_ngp_prefetch's three calls, with the batch assembly AHEAD of the start point: it needs the set's buffers only, and behind the
+    // mark it sat in front of the march for up to 50 us (a 12-us kernel waiting for slots beside the MLP backward)
+    uint64_t st, inc;
+    xr_pcg32_host_state(D.batch_seed, S.batches_drawn, &st, &inc);
+    if (!XR_LOOP_BATCH_FIRST && start) XR_HIP(hipStreamWaitEvent(side, start, 0));
+    int rc = xr_make_batch(D.rays_rgb_rows + (size_t)S.cur_ray * 11, n_rays, st, inc, M.rays_o, M.rays_d, M.target, M.alpha, M.bg, M.img_ids, side);
+    if (rc != XR_OK) return rc;
+    if (XR_LOOP_BATCH_FIRST && start) XR_HIP(hipStreamWaitEvent(side, start, 0));
+    xr_pcg32_host_state(9121, S.k1_calls, &st, &inc);
+    rc = xr_rays_sampler2(M.rays_o, M.rays_d, D.bitfield, n_rays, D.aabb0, D.aabb1, D.near_distance, D.cone_angle, D.max_samples, st, inc, M.coords,
+                          M.rays_index, M.rays_numsteps, M.counter2, M.xyz_planes, M.plane_stride, 0, D.ws_k1, D.ws_k1_bytes, side);
+    if (rc != XR_OK) return rc;
+    rc = xr_clip_numsteps(M.rays_numsteps, M.counter2, n_rays, D.max_compacted, M.numsteps_clipped, M.n_valid, D.max_compacted, 1, side);
     if (rc != XR_OK) return rc;
     S.cur_ray += n_rays; S.batches_drawn += 1; S.k1_calls += 1;
     // the main stream waits for the MARCH only: the event sits in front of the counter's device-to-host copy
