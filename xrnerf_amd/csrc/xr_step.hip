@@ -257,7 +257,7 @@ extern "C" int xr_ngp_loop_adopt_march(void* loop, uint32_t set, void* side_stre
 }
 
 #ifndef XR_LOOP_BATCH_FIRST
-#define XR_LOOP_BATCH_FIRST 1     // the batch assembly ahead of the march's start point (0: behind it, as one xr_ngp_prefetch would)
+#define XR_LOOP_BATCH_FIRST 0     // 1: the batch assembly ahead of the march's start point (measured equal: the march then covers the whole MLP backward, 61 -> 77 us, and less of the scatter)
 #endif
 // the march of iteration `target` on the side stream: mirror of NGPGridSampler.prefetch_native + Trainer._issue
 static int xr_loop_issue_march(XrLoop* L, const xr_ngp_loop_desc& D, xr_ngp_loop_state& S, uint32_t n_rays, hipEvent_t buffer_free, hipEvent_t start) {
@@ -267,8 +267,8 @@ static int xr_loop_issue_march(XrLoop* L, const xr_ngp_loop_desc& D, xr_ngp_loop
     const uint32_t set = (++S.march_launches) % 3u;
     const xr_ngp_march_set& M = D.march[set];
     if (S.cur_ray + n_rays > D.n_table_rays) S.cur_ray = 0;
-    // xr_ngp_prefetch's three calls, with the batch assembly AHEAD of the start point: it needs the set's buffers only, and behind the
-    // mark it sat in front of the march for up to 50 us (a 12-us kernel waiting for slots beside the MLP backward)
+    // xr_ngp_prefetch's three calls (XR_LOOP_BATCH_FIRST=1 puts the batch assembly ahead of the start point -- it needs the set's buffers
+    // only; measured equal, profiles/r04_march_chain_ab.txt)
     uint64_t st, inc;
     xr_pcg32_host_state(D.batch_seed, S.batches_drawn, &st, &inc);
     if (!XR_LOOP_BATCH_FIRST && start) XR_HIP(hipStreamWaitEvent(side, start, 0));
