@@ -339,36 +339,6 @@ int xr_nerf_mlp_fwd_bf16x3(const float* enc_t, uint32_t ld, const float* dirs, u
                            const uint32_t* n_dev, const uint32_t* rows, const float* w_density, const float* w_color,
                            int n_hidden_density, int n_hidden_color, float pad_value, float* raw, void* stream);
 
-/* The lookup and the fused forward on a row LIST, in place: for i < *n_dev (at most n) row r = rows[i] is read (position row / column r
- * of enc_t, direction row r) and written (column r of enc_t, raw[r]); rows not listed are not touched.  (xr_hashgrid_fwd2 /
- * xr_nerf_mlp_fwd with a row list write the COMPACT index i: the render slices' layout.)  mlp_mode as in xr_ngp_train_step. */
-int xr_hashgrid_fwd_rows(const float* table, const float* x, uint32_t x_stride, uint32_t x_comp_stride, uint32_t n, const uint32_t* n_dev,
-                         const uint32_t* rows, int n_levels, const float* scale_host, const uint32_t* resolution_host,
-                         const uint32_t* offset_host, float* enc_t, uint32_t ld, void* stream);
-int xr_nerf_mlp_fwd_rows(int mlp_mode, const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
-                         const uint32_t* n_dev, const uint32_t* rows, const float* w_density, const float* w_color,
-                         int n_hidden_density, int n_hidden_color, float pad_value, float* raw, void* stream);
-/* The training step's forward in two depth slices (north_star: "wavefront ballot/prefix-sum for sample compaction and early ray
- * termination"; the reference has none: K2's transmittance loop is dead code, compacted_coord.cu:41-44).  head: the first k rows of
- * every ray, rounded up to a multiple of ceil(count / 64) -- the rows one lane of xr_composite_train2's wave-per-ray kernel takes; tail:
- * the rest of the rays that kernel does NOT see end inside the head: its transmittance prefix in front of the first tail row -- the
- * same ordered products of the same per-lane chunk products, from the head rows' network outputs in `raw` -- has no exactly-zero
- * factor.  Every ray goes on while one of the reference's per-sample regularisers is in force (density_grid_mean < 0.01 or an
- * exponential rgb activation, calc_rgb.cu:103-104) or the density activation is XR_ACT_NONE.  The rows on neither list then carry exact
- * zeros in the compositor's weights and in dL/draw whatever `raw` holds there (finite values: keep the buffer initialised).
- * rows_out [cap]; *n_out = the list's length (cleared by the call). */
-int xr_slice_rows_head(const int32_t* numsteps_compacted, uint32_t n_rays, uint32_t k, uint32_t* rows_out, uint32_t cap, uint32_t* n_out,
-                       void* stream);
-int xr_slice_rows_tail(const int32_t* numsteps_compacted, uint32_t n_rays, uint32_t k, const float* raw, const float* coords,
-                       const float* density_grid_mean, int rgb_activation, int density_activation, uint32_t* rows_out, uint32_t cap,
-                       uint32_t* n_out, void* stream);
-typedef struct xr_fwd_slices {         /* xr_ngp_train_step's sliced forward (nullable there: every row in one launch per kernel) */
-    uint32_t k;                        /* rows per ray in the head slice */
-    uint32_t* head_rows; uint32_t* head_n; uint32_t head_cap;
-    int head_ready;                    /* != 0: the caller built the head list (xr_slice_rows_head, e.g. on its side stream); 0: the step builds it */
-    uint32_t* tail_rows; uint32_t* tail_n; uint32_t tail_cap;
-} xr_fwd_slices;
-
 /* One training step's device work of HashNerfNetwork.train_step (networks/hashnerf.py:32-52, optimiser excluded) as ONE call:
  * xr_hashgrid_fwd -> xr_nerf_mlp_fwd[_f16] -> xr_composite_train2 (which counts the live rows per segment) -> xr_live_rows2 -> xr_nerf_mlp_bwd[_f16] ->
  * xr_hashgrid_bwd2(XR_SCATTER_OVERWRITE), on `stream`:
@@ -399,13 +369,9 @@ int xr_ngp_train_step(const float* table, const float* w_density, const float* w
                       float* draw, float* denc_t, float* rgb_out, float* zero_block, size_t zero_floats, float* grad_w_density,
                       float* grad_w_color, float* loss_mse, uint32_t* live_seg_count, float* grad_table, size_t table_floats, int zero_draw,
                       void* ws_mlp_bwd, size_t ws_mlp_bwd_bytes, void* ws_scatter, size_t ws_scatter_bytes, int scatter_level0,
-                      const float* xyz_planes, uint32_t plane_stride, const xr_fwd_slices* slices, const xr_adam_fuse* table_adam,
-                      const xr_adam_fuse* w_density_adam, const xr_adam_fuse* w_color_adam, const char* mark_entry, void* mark_event,
-                      const char* timed_entry, void* timing_begin, void* timing_end, void* stream);
-/* slices (nullable): the forward in two depth slices (xr_fwd_slices): same rgb, losses, gradients and updates (rows it does not
- * evaluate carry a transmittance that is exactly zero -- at worst the smallest denormal, 1.4e-45 -- in the compositor); `raw` must not
- * hold NaN / Inf bit patterns in rows it never wrote (allocate it zeroed).  A timed "xr_hashgrid_fwd" then spans both lookups and
- * the head slice's MLP launch, a timed "xr_nerf_mlp_fwd" the tail slice's MLP launch only. */
+                      const float* xyz_planes, uint32_t plane_stride, const xr_adam_fuse* table_adam, const xr_adam_fuse* w_density_adam,
+                      const xr_adam_fuse* w_color_adam, const char* mark_entry, void* mark_event, const char* timed_entry,
+                      void* timing_begin, void* timing_end, void* stream);
 /* xyz_planes (nullable): the positions of `coords` once more as three planes of plane_stride floats (xr_rays_sampler2 /
  * xr_ngp_prefetch write them); the encoder then reads them with coalesced loads (xr_hashgrid_fwd2). */
 /* timed_entry (nullable): the name of ONE of the entry points the step runs ("xr_hashgrid_fwd", "xr_nerf_mlp_fwd",
@@ -451,12 +417,10 @@ typedef struct xr_ngp_march_set {      /* one of the THREE rotating sets a march
     float* coords; int32_t *rays_index, *rays_numsteps; uint32_t* counter2; /* K1 outputs (coords: >= max_samples rows of 7) */
     int32_t* numsteps_clipped; uint32_t* n_valid;                           /* K2's clipped counts, device count of valid rows */
     float* xyz_planes; uint32_t plane_stride;                               /* nullable: positions as planes */
-    uint32_t* head_rows; uint32_t* head_n;                                  /* sliced forward (desc.slice_k > 0): the head list, built behind K2 */
 } xr_ngp_march_set;
 typedef struct xr_ngp_step_set {       /* one of the TWO alternating sets of step buffers (see xr_ngp_train_step) */
     float *enc_t, *raw, *draw, *denc_t, *rgb_out, *zero_block; size_t zero_floats;
     float *grad_w_density, *grad_w_color, *loss_mse; uint32_t* live_seg_count;
-    uint32_t* tail_rows; uint32_t* tail_n;                                  /* sliced forward: the tail list */
 } xr_ngp_step_set;
 typedef struct xr_ngp_loop_desc {
     float *table, *w_density, *w_color; int n_hidden_density, n_hidden_color; float pad_value; int mlp_mode;
@@ -473,7 +437,6 @@ typedef struct xr_ngp_loop_desc {
     void *stream, *side_stream;
     void* bitfield_event;                                  /* nullable: recorded behind the last writer of `bitfield` */
     void* mark_event;                                      /* xr_order_event_create: recorded behind `mark_entry` of every step */
-    uint32_t slice_k, head_cap, tail_cap;                  /* slice_k > 0: the forward in two depth slices (xr_fwd_slices) */
     const char* mark_entry;                                /* the entry point of the step behind which the march of iteration i + 2 may start
                                                               ("xr_live_rows": beside the MLP backward and the scatter; null: behind the end of
                                                               iteration i - 1 only, i.e. from the start of iteration i) */

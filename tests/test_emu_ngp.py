@@ -66,12 +66,6 @@ def test_compositor_on_the_host(O, lego, edev):
     T.test_fused_compositor_train_equals_k3_huber_k4(O, lego, edev, 1001)
 
 
-def test_forward_in_two_depth_slices_on_the_host(lego, edev):
-    import test_gpu_raymarch as T
-    T.test_forward_in_two_depth_slices_gives_the_unsliced_outputs(lego, edev, 700, 4, 8.0)
-    T.test_forward_in_two_depth_slices_gives_the_unsliced_outputs(lego, edev, 700, 7, 6.0)
-
-
 def test_grid_upkeep_raygen_loss_adam_on_the_host(O, lego, edev):
     import test_gpu_raymarch as T
     T.test_k6_grid_samples_bit_exact(O, lego, edev)

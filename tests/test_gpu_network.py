@@ -460,4 +460,3 @@ def test_row_bands_of_a_frame_give_the_whole_frames_pixels(dev):
             for key in ('rgb', 'alpha'):
                 assert torch.equal(torch.cat([p[key] for p in parts], 0), whole[key]), (world, key)
     assert float(whole['alpha'].max()) > 0.5
-

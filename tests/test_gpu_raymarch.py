@@ -329,65 +329,3 @@ def test_fused_compositor_train_equals_k3_huber_k4(O, lego, dev, n_rays):
     assert int((nsc[:, 0] == 0).sum()) > 0 and int((nsc[:, 0] < ns[:, 0]).sum()) > 0
     assert int(nsc[:, 0].max()) > 64                                  # chunks longer than the in-register fast path
     assert dead_seen
-
-
-@pytest.mark.parametrize('n_rays,k,wscale', [(700, 4, 8.0), (1500, 16, 8.0), (1500, 16, 5.5), (1500, 7, 6.5)])
-def test_forward_in_two_depth_slices_gives_the_unsliced_outputs(lego, dev, n_rays, k, wscale):
-    """xr_slice_rows_head / xr_slice_rows_tail + the in-place row-list lookup and network (xr_hashgrid_fwd_rows,
-    xr_nerf_mlp_fwd_rows) = xr_ngp_train_step's sliced forward: every evaluated row carries the unsliced forward's network output
-    bit for bit, the rows left out sit behind an exactly-zero transmittance, so the compositor returns the same pixels and the same
-    dL/draw (all zero on the rows left out); with a per-sample regulariser in force (density_grid_mean < 0.01) no row is left out.
-    (wscale: how dense the random network is -- at 8 rays end on one opaque sample, at 5.5 / 6.5 mostly by a transmittance that
-    underflows over several samples, where the decision has to follow the compositor's own order of multiplication.)"""
-    from xrnerf_amd import ops, synthetic as S
-    rng = np.random.default_rng(5)
-    meta = ops.GridMeta()
-    o, d, _ = S.training_rays(lego['poses'], n_rays, seed=3)
-    coords, _, ns, cnt = ops.rays_sampler(T(o, dev), T(d, dev), T(lego['bitfield'], dev), (0., 1.), 0.05, 1 / 256, n_rays * 48, 0)
-    cap = int(int(cnt[1]) * 0.9)                                      # some rays lose their tail, some everything
-    nsc, _ = ops.clip_numsteps(ns, cnt, cap)
-    c = coords[:cap].contiguous()
-    table = T(S.hash_table(meta.n_params, scale=1.0), dev)
-    wd = T(S.mlp_weights(32, 64, 1, 16, seed=4) * wscale, dev)        # (two linear layers: log densities x wscale^2 -> opaque samples exist)
-    wc = T(S.mlp_weights(32, 64, 2, 16, seed=5), dev)
-    bg = T(rng.uniform(0, 1, (n_rays, 3)).astype(np.float32), dev)
-    tgt = T(rng.uniform(0, 1, (n_rays, 3)).astype(np.float32), dev)
-    alpha = torch.ones((n_rays, 1), dtype=torch.float32, device=dev)
-    ld = (cap + 63) // 64 * 64
-    enc_full = ops.hashgrid_fwd(table, c[:, :3], meta, ld=ld)
-    raw_full = ops.nerf_mlp_fwd(enc_full, c[:, 4:7], cap, wd, wc, 1, 2)
-    head, tail = (torch.empty((cap,), dtype=torch.int32, device=dev) for _ in range(2))
-    n_list = torch.zeros((2,), dtype=torch.int32, device=dev)
-    for mean0, ra, da in ((0.5, 2, 3), (0.005, 2, 3), (0.5, 3, 3)):
-        mean = torch.tensor([mean0] + [0.0] * 15, dtype=torch.float32, device=dev)
-        enc = torch.full_like(enc_full, 7.0)
-        raw = torch.zeros_like(raw_full)
-        ops.slice_rows_head(nsc, k, head, n_list[0:1])
-        ops.hashgrid_fwd_rows(table, c[:, :3], meta, head, n_list[0:1], enc)
-        ops.nerf_mlp_fwd_rows(enc, c[:, 4:7], head, n_list[0:1], wd, wc, 1, 2, 1.0, raw)
-        ops.slice_rows_tail(nsc, k, raw, c, mean, ra, da, tail, n_list[1:2])
-        ops.hashgrid_fwd_rows(table, c[:, :3], meta, tail, n_list[1:2], enc)
-        ops.nerf_mlp_fwd_rows(enc, c[:, 4:7], tail, n_list[1:2], wd, wc, 1, 2, 1.0, raw)
-        torch.cuda.synchronize()
-        nh, nt = (int(v) for v in n_list.cpu())
-        cnt_c = nsc[:, 0].cpu().numpy().astype(np.int64)
-        chunk = np.maximum((cnt_c + 63) // 64, 1)                     # the head ends on a boundary of the compositor's per-lane chunks
-        assert nh == int(np.minimum(cnt_c, (k + chunk - 1) // chunk * chunk).sum())
-        rows_h, rows_t = head[:nh].cpu().numpy().astype(np.int64), tail[:nt].cpu().numpy().astype(np.int64)
-        seen = np.zeros(cap, np.int32)
-        np.add.at(seen, rows_h, 1); np.add.at(seen, rows_t, 1)
-        assert seen.max() == 1                                         # no row twice
-        ev = torch.from_numpy(seen.astype(bool)).to(dev)
-        assert torch.equal(raw[ev], raw_full[ev]) and torch.equal(enc[:, :cap][:, ev], enc_full[:, :cap][:, ev])
-        assert float(raw[~ev].abs().max() if int((~ev).sum()) else 0.0) == 0.0 and bool((enc[:, :cap][:, ~ev] == 7.0).all())
-        if mean0 < 0.01 or ra == 3:
-            assert nh + nt == int(cnt_c.sum())                         # a regulariser on every sample: every row evaluated
-        else:
-            assert 0 < nt and (nt < int(cnt_c.sum()) - nh or wscale < 8)   # some rays went opaque inside their head rows, some did not
-        outs = []
-        for r in (raw_full, raw):
-            draw = torch.zeros_like(r)
-            rgb = ops.composite_train(r, c, ns, nsc, bg, tgt, alpha, mean, ra, da, None, draw)
-            outs.append((rgb.clone(), draw))
-        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-        assert float(outs[0][1][~ev].abs().max() if int((~ev).sum()) else 0.0) == 0.0

@@ -20,23 +20,16 @@ class AdamFuse(C.Structure):
                 ('ema_momentum', C.c_float), ('grad_scale', C.c_float), ('n', C.c_uint64)]
 
 
-class FwdSlices(C.Structure):
-    """xr_fwd_slices"""
-    _fields_ = [('k', C.c_uint32), ('head_rows', C.c_void_p), ('head_n', C.c_void_p), ('head_cap', C.c_uint32), ('head_ready', C.c_int),
-                ('tail_rows', C.c_void_p), ('tail_n', C.c_void_p), ('tail_cap', C.c_uint32)]
-
-
 class MarchSet(C.Structure):
     """xr_ngp_march_set"""
     _fields_ = [(k, C.c_void_p) for k in ('rays_o', 'rays_d', 'target', 'alpha', 'bg', 'img_ids', 'coords', 'rays_index', 'rays_numsteps',
-                                          'counter2', 'numsteps_clipped', 'n_valid', 'xyz_planes')] + [('plane_stride', C.c_uint32), ('head_rows', C.c_void_p),
-                                                                                              ('head_n', C.c_void_p)]
+                                          'counter2', 'numsteps_clipped', 'n_valid', 'xyz_planes')] + [('plane_stride', C.c_uint32)]
 
 
 class StepSet(C.Structure):
     """xr_ngp_step_set"""
     _fields_ = [(k, C.c_void_p) for k in ('enc_t', 'raw', 'draw', 'denc_t', 'rgb_out', 'zero_block')] + [('zero_floats', C.c_size_t)] + \
-               [(k, C.c_void_p) for k in ('grad_w_density', 'grad_w_color', 'loss_mse', 'live_seg_count', 'tail_rows', 'tail_n')]
+               [(k, C.c_void_p) for k in ('grad_w_density', 'grad_w_color', 'loss_mse', 'live_seg_count')]
 
 
 class LoopDesc(C.Structure):
@@ -55,7 +48,7 @@ class LoopDesc(C.Structure):
                 ('ws_scatter', C.c_void_p), ('ws_scatter_bytes', C.c_size_t),
                 ('counter_host_pinned', C.c_void_p), ('n_pinned', C.c_uint32),
                 ('stream', C.c_void_p), ('side_stream', C.c_void_p), ('bitfield_event', C.c_void_p), ('mark_event', C.c_void_p),
-                ('slice_k', C.c_uint32), ('head_cap', C.c_uint32), ('tail_cap', C.c_uint32), ('mark_entry', C.c_char_p)]
+                ('mark_entry', C.c_char_p)]
 
 
 class LoopState(C.Structure):
@@ -107,11 +100,7 @@ SIGNATURES = {
                                _vp, _sz, _u32, _vp, _vp, _vp, _vp, _u32, _vp]),
     'xr_ngp_train_step': (_i32, [_vp, _vp, _vp, _i32, _i32, _f, _i32, _i32, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _u32, _vp, _vp, _vp,
                                  _vp, _i32, _i32, _f, _f, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp, _sz,
-                                 _vp, _sz, _i32, _vp, _u32, _vp, _vp, _vp, _vp, C.c_char_p, _vp, C.c_char_p, _vp, _vp, _vp]),
-    'xr_hashgrid_fwd_rows': (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _u32, _vp]),
-    'xr_nerf_mlp_fwd_rows': (_i32, [_i32, _vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp]),
-    'xr_slice_rows_head': (_i32, [_vp, _u32, _u32, _vp, _u32, _vp, _vp]),
-    'xr_slice_rows_tail': (_i32, [_vp, _u32, _u32, _vp, _vp, _vp, _i32, _i32, _vp, _u32, _vp, _vp]),
+                                 _vp, _sz, _i32, _vp, _u32, _vp, _vp, _vp, C.c_char_p, _vp, C.c_char_p, _vp, _vp, _vp]),
     'xr_ngp_loop_create': (_vp, []),
     'xr_ngp_loop_destroy': (_i32, [_vp]),
     'xr_ngp_loop_march_event': (_vp, [_vp, _u32]),

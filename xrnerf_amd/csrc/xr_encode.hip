@@ -107,32 +107,16 @@ struct XcdMap {
 __global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_fwd(GridMeta gm, XcdMap xm, uint32_t hashed_mask, const float* __restrict__ table,
                                                             const float* __restrict__ x, uint32_t x_stride, uint32_t x_cs, uint32_t n,
                                                             const uint32_t* __restrict__ n_dev, const uint32_t* __restrict__ rows,
-                                                            float* __restrict__ enc_t, uint32_t ld, uint32_t inplace) {
+                                                            float* __restrict__ enc_t, uint32_t ld) {
     uint32_t l, sb;
     if (n_dev) n = min(n, *n_dev);
     if (gm.order == 5) {
-        // inplace != 0 (xr_hashgrid_fwd_rows): sample i of the launch IS row rows[i] (its features go to column rows[i]), and the
-        // launch is sized for a capacity its device-side count may be far below: the map's sample-block ranges -- built for the
-        // capacity's gm.n_sblocks blocks -- are scaled to the count's blocks here, so that every XCD keeps its share of the rows that
-        // exist and neighbouring workgroups keep neighbouring rows (an XCD whose range lies behind the count would idle otherwise)
-        const uint32_t nbd = (n + EN_BLOCK - 1u) / EN_BLOCK, nsb = gm.n_sblocks;
-        const float ratio = (float)nbd / (float)nsb;
         const uint32_t k = blockIdx.x & 7u;
-        uint32_t j = blockIdx.x >> 3, sg = 0, lo = 0, len = 0;
+        uint32_t j = blockIdx.x >> 3, sg = 0;
         const uint32_t ns = xm.nseg[k];
-        for (; sg < ns; ++sg) {
-            lo = xm.lo[k][sg];
-            uint32_t hi = xm.hi[k][sg];
-            if (inplace) {                   // any monotone f with f(0) = 0, f(nsb) = nbd keeps the ranges a partition: no integer division here
-                lo = min(nbd, (uint32_t)((float)lo * ratio));
-                hi = hi == nsb ? nbd : min(nbd, (uint32_t)((float)hi * ratio));
-            }
-            len = hi - lo;
-            if (j < len) break;
-            j -= len;
-        }
+        while (sg < ns && j >= xm.hi[k][sg] - xm.lo[k][sg]) { j -= xm.hi[k][sg] - xm.lo[k][sg]; ++sg; }
         if (sg >= ns) return;
-        l = xm.level[k][sg]; sb = lo + j;
+        l = xm.level[k][sg]; sb = xm.lo[k][sg] + j;
     } else {
         level_of_block(gm, &l, &sb);
         if (l >= (uint32_t)gm.n_levels) return;
@@ -143,15 +127,13 @@ __global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_fwd(GridMeta gm, XcdMap x
     const uint32_t res = gm.res[l], hsize = gm.off[l + 1] - gm.off[l];
     const bool hashed = (hashed_mask >> l) & 1;
     const float2* __restrict__ tab = (const float2*)table + gm.off[l];
-    const uint32_t rw = rows ? rows[i] : i;                             // optional row indirection (render slices, sliced forward)
-    const float* xp = x + (size_t)rw * x_stride;
+    const float* xp = x + (size_t)(rows ? rows[i] : i) * x_stride;    // optional row indirection (render slices)
     float r0, r1;
     const bool pow2 = hashed && (hsize & (hsize - 1u)) == 0u;           // uniform for the block
     if (pow2) hg_sample_level<true>(tab, xp, x_cs, scale, res, hsize, hashed, &r0, &r1);
     else hg_sample_level<false>(tab, xp, x_cs, scale, res, hsize, hashed, &r0, &r1);
-    const uint32_t oc = inplace ? rw : i;
-    enc_t[(size_t)(2 * l) * ld + oc] = r0;
-    enc_t[(size_t)(2 * l + 1) * ld + oc] = r1;
+    enc_t[(size_t)(2 * l) * ld + i] = r0;
+    enc_t[(size_t)(2 * l + 1) * ld + i] = r1;
 }
 
 // Scatter-add of the feature gradients with global atomics: the path for small row counts and for levels the binned scatter
@@ -281,7 +263,6 @@ static void hg_level_costs(float* cost, int n_levels, uint32_t hashed_mask) {
     }
 }
 
-static thread_local bool g_fwd_rows_inplace = false;
 extern "C" int xr_hashgrid_fwd2(const float* table, const float* x, uint32_t x_stride, uint32_t x_comp_stride, uint32_t n, const uint32_t* n_dev,
                                 const uint32_t* rows, int n_levels, const float* scale_host, const uint32_t* resolution_host,
                                 const uint32_t* offset_host, float* enc_t, uint32_t ld, void* stream_) {
@@ -302,23 +283,10 @@ extern "C" int xr_hashgrid_fwd2(const float* table, const float* x, uint32_t x_s
     uint32_t blocks;
     if (per_xcd) { gm.order = 5; blocks = 8 * per_xcd; }
     else { memset(&xm, 0, sizeof(xm)); blocks = 8 * ((n_levels + 7) / 8) * nsb; }
-    const uint32_t perm = g_fwd_rows_inplace ? 1u : 0u;      // (in place: the kernel scales the map's block ranges to the device-side count)
     hipLaunchKernelGGL(k_hashgrid_fwd, dim3(blocks), dim3(EN_BLOCK), 0, stream, gm, xm, hm, table, x, x_stride, x_comp_stride, n,
-                       n_dev, rows, enc_t, ld, perm);
+                       n_dev, rows, enc_t, ld);
     XR_LAUNCH_CHECK();
     return XR_OK;
-}
-
-// The lookup on a row LIST, in place: for i < *n_dev (at most n), row r = rows[i]: position x[r] -> column r of enc_t (ld >= every r + 1).
-// The columns not listed are not touched.  (xr_hashgrid_fwd2 with a row list writes column i: the render slices' compact layout.)
-extern "C" int xr_hashgrid_fwd_rows(const float* table, const float* x, uint32_t x_stride, uint32_t x_comp_stride, uint32_t n, const uint32_t* n_dev,
-                                    const uint32_t* rows, int n_levels, const float* scale_host, const uint32_t* resolution_host,
-                                    const uint32_t* offset_host, float* enc_t, uint32_t ld, void* stream_) {
-    XR_REQUIRE(rows && n_dev, "a row list comes with its device-side length");
-    g_fwd_rows_inplace = true;
-    const int rc = xr_hashgrid_fwd2(table, x, x_stride, x_comp_stride, n, n_dev, rows, n_levels, scale_host, resolution_host, offset_host, enc_t, ld, stream_);
-    g_fwd_rows_inplace = false;
-    return rc;
 }
 
 extern "C" int xr_hashgrid_fwd(const float* table, const float* x, uint32_t x_stride, uint32_t n, const uint32_t* n_dev,

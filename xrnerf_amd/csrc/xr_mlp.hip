@@ -579,7 +579,7 @@ __global__ __launch_bounds__(MLP_THREADS, 3) void k_nerf_mlp_fwd(const float* __
                                                                const uint32_t* __restrict__ rows,
                                                                const float* __restrict__ w_density,
                                                                const float* __restrict__ w_color, float pad_value,
-                                                               float4* __restrict__ raw, uint32_t inplace) {
+                                                               float4* __restrict__ raw) {
     if (n_dev) n = min(n, *n_dev);
     if (n == 0) return;
     using SD = NetShape<NHD>;
@@ -596,10 +596,7 @@ __global__ __launch_bounds__(MLP_THREADS, 3) void k_nerf_mlp_fwd(const float* __
         const uint32_t s = tile * 32 + col;
         const uint32_t sc = s < n ? s : n - 1;             // clamp loads of the ragged last tile
         f32x16 x[1], h[2], h2[2], dout[1];
-        // inplace (with a row list): sample i of the launch IS row rows[i] -- its features are read from and its output written to that
-        // row (the sliced forward of a training step: xr_ngp_train_step's head / tail lists); otherwise rows[] only names the direction row
-        const uint32_t so = (inplace && rows) ? rows[sc] : s;
-        load_enc_tile(enc_t, ld, (inplace && rows) ? so : sc, x[0], hi);
+        load_enc_tile(enc_t, ld, sc, x[0], hi);
         layer_fwd<1, 2>(wd + SD::lds_off(0), x, h, col, hi);
         relu_tile(h[0]); relu_tile(h[1]);
 #pragma unroll
@@ -624,7 +621,7 @@ __global__ __launch_bounds__(MLP_THREADS, 3) void k_nerf_mlp_fwd(const float* __
             layer_fwd<2, 1>(wc + SC::lds_off(NHC), h, cout, col, hi);
             o.x = cout[0][0]; o.y = cout[0][1]; o.z = cout[0][2];   // rows 0,1,2 in the hi==0 half
         }
-        if (hi == 0 && s < n) raw[so] = o;
+        if (hi == 0 && s < n) raw[s] = o;
     }
 }
 
@@ -1216,7 +1213,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_nerf_mlp_fwd_h(const float* 
                                                                     const uint32_t* __restrict__ rows,
                                                                     const float* __restrict__ w_density,
                                                                     const float* __restrict__ w_color, float pad_value,
-                                                                    float4* __restrict__ raw, uint32_t inplace) {
+                                                                    float4* __restrict__ raw) {
     if (n_dev) n = min(n, *n_dev);
     if (n == 0) return;
     using HD = HShape<1>;
@@ -1232,10 +1229,9 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_nerf_mlp_fwd_h(const float* 
     float d3[3] = {0.f, 0.f, 0.f};
     auto fetch = [&](uint32_t tl, f32x16& xe, float (&dd)[3]) {
         const uint32_t s = tl * 32 + col, sc = s < n ? s : n - 1;
-        const uint32_t rw = rows ? rows[sc] : sc;
-        load_enc_tile(enc_t, ld, inplace ? rw : sc, xe, hi);             // (inplace: see k_nerf_mlp_fwd)
+        load_enc_tile(enc_t, ld, sc, xe, hi);
         if (WITH_COLOR) {
-            const float* d = dirs + (size_t)rw * dir_stride;
+            const float* d = dirs + (size_t)(rows ? rows[sc] : sc) * dir_stride;
             dd[0] = d[0]; dd[1] = d[1]; dd[2] = d[2];
         }
     };
@@ -1268,7 +1264,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_nerf_mlp_fwd_h(const float* 
             layer_fwd_h<2, 1>(wc + HC::f_off(2), hh, cout, col, hi);
             o.x = cout[0][0]; o.y = cout[0][1]; o.z = cout[0][2];
         }
-        if (hi == 0 && s < n) raw[(inplace && rows) ? rows[s] : s] = o;
+        if (hi == 0 && s < n) raw[s] = o;
     }
 }
 
@@ -1572,7 +1568,7 @@ __global__ __launch_bounds__(BX_THREADS, 1) void k_nerf_mlp_fwd_b3(const float* 
                                                                     const uint32_t* __restrict__ rows,
                                                                     const float* __restrict__ w_density,
                                                                     const float* __restrict__ w_color, float pad_value,
-                                                                    float4* __restrict__ raw, uint32_t inplace) {
+                                                                    float4* __restrict__ raw) {
     if (n_dev) n = min(n, *n_dev);
     if (n == 0) return;
     using HD = HShape<1>;
@@ -1590,10 +1586,9 @@ __global__ __launch_bounds__(BX_THREADS, 1) void k_nerf_mlp_fwd_b3(const float* 
     float d3[3] = {0.f, 0.f, 0.f};
     auto fetch = [&](uint32_t tl, f32x16& xe, float (&dd)[3]) {
         const uint32_t s = tl * 32 + col, sc = s < n ? s : n - 1;
-        const uint32_t rw = rows ? rows[sc] : sc;
-        load_enc_tile(enc_t, ld, inplace ? rw : sc, xe, hi);             // (inplace: see k_nerf_mlp_fwd)
+        load_enc_tile(enc_t, ld, sc, xe, hi);
         if (WITH_COLOR) {
-            const float* d = dirs + (size_t)rw * dir_stride;
+            const float* d = dirs + (size_t)(rows ? rows[sc] : sc) * dir_stride;
             dd[0] = d[0]; dd[1] = d[1]; dd[2] = d[2];
         }
     };
@@ -1627,14 +1622,11 @@ __global__ __launch_bounds__(BX_THREADS, 1) void k_nerf_mlp_fwd_b3(const float* 
             layer_fwd_b3<2, 1>(wc + HC::f_off(2), PC, hh, cout, col, hi);
             o.x = cout[0][0]; o.y = cout[0][1]; o.z = cout[0][2];
         }
-        if (hi == 0 && s < n) raw[(inplace && rows) ? rows[s] : s] = o;
+        if (hi == 0 && s < n) raw[s] = o;
     }
 }
 
 // ------------------------------------------------------------------ host side
-// xr_nerf_mlp_fwd_rows: the forward on a row LIST, in place (sample i of the launch is row rows[i]: features read from, output
-// written to that row).  The three forward entry points read this flag when they launch.
-static thread_local uint32_t g_fwd_inplace = 0u;
 static int g_cus = 0;
 extern "C" int xr_device_cus(void) {
     if (g_cus == 0) {
@@ -1659,12 +1651,12 @@ static int launch_fwd(const float* enc_t, uint32_t ld, const float* dirs, uint32
         const size_t lds = (NetShape<NHD>::lds_floats + NetShape<NHC>::lds_floats) * sizeof(float);
         auto k = k_nerf_mlp_fwd<NHD, NHC, true>;
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XR_EHIP;
-        hipLaunchKernelGGL(k, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev, rows, wd, wc, pad, (float4*)raw, g_fwd_inplace);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev, rows, wd, wc, pad, (float4*)raw);
     } else {
         const size_t lds = NetShape<NHD>::lds_floats * sizeof(float);
         auto k = k_nerf_mlp_fwd<NHD, NHC, false>;
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XR_EHIP;
-        hipLaunchKernelGGL(k, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev, rows, wd, wc, pad, (float4*)raw, g_fwd_inplace);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev, rows, wd, wc, pad, (float4*)raw);
     }
     return XR_OK;
 }
@@ -1896,11 +1888,11 @@ extern "C" int xr_nerf_mlp_fwd_f16(const float* enc_t, uint32_t ld, const float*
     if (dirs) {
         const size_t lds = (size_t)(HShape<1>::f_halves + HShape<2>::f_halves) * 2;
         hipLaunchKernelGGL(k_nerf_mlp_fwd_h<true>, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev,
-                           rows, w_density, w_color, pad_value, (float4*)raw, g_fwd_inplace);
+                           rows, w_density, w_color, pad_value, (float4*)raw);
     } else {
         const size_t lds = (size_t)HShape<1>::f_halves * 2;
         hipLaunchKernelGGL(k_nerf_mlp_fwd_h<false>, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev,
-                           rows, w_density, w_color, pad_value, (float4*)raw, g_fwd_inplace);
+                           rows, w_density, w_color, pad_value, (float4*)raw);
     }
     XR_LAUNCH_CHECK();
     return XR_OK;
@@ -1922,29 +1914,14 @@ extern "C" int xr_nerf_mlp_fwd_bf16x3(const float* enc_t, uint32_t ld, const flo
         const size_t lds = (size_t)3 * (HShape<1>::f_halves + HShape<2>::f_halves) * 2;
         if (mlp_set_lds((const void*)k_nerf_mlp_fwd_b3<true>, lds) != XR_OK) { xr_set_error("hipFuncSetAttribute failed"); return XR_EHIP; }
         hipLaunchKernelGGL(k_nerf_mlp_fwd_b3<true>, dim3(grid), dim3(BX_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev,
-                           rows, w_density, w_color, pad_value, (float4*)raw, g_fwd_inplace);
+                           rows, w_density, w_color, pad_value, (float4*)raw);
     } else {
         const size_t lds = (size_t)3 * HShape<1>::f_halves * 2;
         hipLaunchKernelGGL(k_nerf_mlp_fwd_b3<false>, dim3(grid), dim3(BX_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev,
-                           rows, w_density, w_color, pad_value, (float4*)raw, g_fwd_inplace);
+                           rows, w_density, w_color, pad_value, (float4*)raw);
     }
     XR_LAUNCH_CHECK();
     return XR_OK;
-}
-
-// The fused forward on a row list, IN PLACE: for i < *n_dev (at most n), row r = rows[i] of enc_t (column r) / dirs (row r) gives raw[r].
-// mlp_mode as in xr_ngp_train_step (0 fp32 MFMA, 1 fp16, 2 split bf16).  The rows not listed are not touched.
-extern "C" int xr_nerf_mlp_fwd_rows(int mlp_mode, const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
-                                    const uint32_t* n_dev, const uint32_t* rows, const float* w_density, const float* w_color,
-                                    int n_hidden_density, int n_hidden_color, float pad_value, float* raw, void* stream_) {
-    XR_REQUIRE(rows && n_dev, "a row list comes with its device-side length");
-    XR_REQUIRE(mlp_mode >= 0 && mlp_mode <= 2, "mlp_mode is 0, 1 or 2");
-    g_fwd_inplace = 1u;
-    auto fn = mlp_mode == 1 ? xr_nerf_mlp_fwd_f16 : mlp_mode == 2 ? xr_nerf_mlp_fwd_bf16x3 : xr_nerf_mlp_fwd;
-    // (ld bounds the ROW INDICES here, n only the list length)
-    const int rc = fn(enc_t, ld, dirs, dir_stride, n, n_dev, rows, w_density, w_color, n_hidden_density, n_hidden_color, pad_value, raw, stream_);
-    g_fwd_inplace = 0u;
-    return rc;
 }
 
 extern "C" int xr_nerf_mlp_bwd_f16(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,

@@ -461,111 +461,6 @@ extern "C" int xr_rays_sampler(const float* rays_o, const float* rays_d, const u
                             coords_out, rays_index, rays_numsteps, counter2, nullptr, 0, 0, workspace, workspace_bytes, stream_);
 }
 
-// ------------------------------------------------------------------ the training step's forward in two depth slices
-// Behind an opaque surface the transmittance is exactly zero: the compositor gives those samples a zero weight and -- without the
-// reference's L1 / L2 regularisers, which act on every sample (calc_rgb.cu:103-104: only while density_grid_mean < 0.01, or with an
-// exponential rgb activation) -- an exactly-zero dL/d(raw).  The backward already skips them (the live-row list); these two
-// kernels let the FORWARD skip them too: `head` lists the first k rows of every ray (rounded up to the compositor's per-lane chunk),
-// `tail` -- run when the head's network outputs exist -- lists the remaining rows of the rays the compositor does not see end
-// inside the head (below; a regulariser in force keeps every ray).  The lookup and the fused MLP then run on the two lists in place
-// (xr_hashgrid_fwd_rows, xr_nerf_mlp_fwd_rows); rows on neither list keep whatever raw they held (finite: the buffer starts zeroed
-// and only ever receives network outputs), which the compositor multiplies by exact zeros.  Row order inside a list is the order of the
-// ray blocks' atomic tickets: per-row work, results independent of it.
-// workgroup = 256 rays: lengths -> block scan -> ONE atomic for the block's place in the list -> cooperative expansion (binary
-// search over the block's offsets, consecutive lanes write consecutive rows)
-//
-// Which rays are over behind their head rows is the COMPOSITOR's decision (k_composite_train_w), restated here so that a ray declared
-// over has exact zeros on every later row whatever the network would have said there.  The compositor gives lane m of the ray's wave
-// the rows [m * chunk, (m + 1) * chunk), chunk = ceil(n / 64); its transmittance in front of lane L is GT * tt: tt = the ordered
-// product of the chunk products of the lanes of L's group of 16 in front of L, GT = the ordered product of the earlier groups' totals.
-// Once tt or GT is EXACTLY zero every later prefix is 0 * finite = 0: the rows' weights, the colour they add to any partial sum and
-// their dL/draw are exact zeros.  (A product that merely underflows in one association need not in another: the head therefore ends
-// on a chunk boundary -- slice_head_len -- and the test is made on the compositor's own two factors, not on a row-by-row product.)
-#ifndef XR_CT_WAVE
-#define XR_CT_WAVE 1
-#endif
-__device__ inline uint32_t slice_head_len(uint32_t cnt, uint32_t k) {
-    const uint32_t chunk = (cnt + 63u) / 64u;
-    return chunk ? min(cnt, (k + chunk - 1u) / chunk * chunk) : 0u;
-}
-template <bool TAIL>
-__global__ __launch_bounds__(RM_BLOCK) void k_slice_rows(uint32_t n_rays, const int32_t* __restrict__ numsteps_c, uint32_t k,
-                                                         const float4* __restrict__ raw, const float* __restrict__ coords,
-                                                         const float* __restrict__ density_grid_mean, int rgb_act, int density_act,
-                                                         uint32_t* __restrict__ rows_out, uint32_t* __restrict__ n_out, uint32_t cap) {
-    __shared__ uint32_t lds4[4];
-    __shared__ uint32_t s_off[RM_BLOCK], s_start[RM_BLOCK], s_base;
-    const uint32_t i = blockIdx.x * RM_BLOCK + threadIdx.x;
-    uint32_t start = 0, len = 0;
-    if (i < n_rays) {
-        const uint32_t cnt = (uint32_t)numsteps_c[2 * i], base = (uint32_t)numsteps_c[2 * i + 1];
-        const uint32_t hl = slice_head_len(cnt, k);
-        if (!TAIL) { start = base; len = hl; }
-        else if (cnt > hl) {
-            // every ray goes on while a regulariser touches every sample (calc_rgb.cu:103-104), while the density activation can be
-            // negative (a transmittance factor above 1), and under the 16-lane compositor (-DXR_CT_WAVE=0: other chunk shapes)
-            bool alive = density_grid_mean[0] < 0.01f || rgb_act == XR_ACT_EXPONENTIAL || density_act == XR_ACT_NONE || !XR_CT_WAVE;
-            if (!alive) {
-                const uint32_t chunk = (cnt + 63u) / 64u, L = hl / chunk;           // hl is a multiple of chunk here (hl < cnt)
-                float GT = 1.f, tt = 1.f;
-                for (uint32_t m = 0; m < L; ++m) {
-                    if (m && (m & 15u) == 0u) { GT *= tt; tt = 1.f; }
-                    float T = 1.f;
-                    for (uint32_t u = 0; u < chunk; ++u) {
-                        const uint32_t j = base + m * chunk + u;
-                        const float dt = xr_unwarp_dt(coords[7 * (size_t)j + 3]);
-                        const float alpha = 1.f - __expf(-xr_act_density(raw[j].w, density_act) * dt);
-                        T *= (1.f - alpha);
-                    }
-                    tt *= T;
-                }
-                if (L && (L & 15u) == 0u) { GT *= tt; tt = 1.f; }
-                alive = !(GT == 0.f || tt == 0.f);                                   // (NaN counts as alive)
-            }
-            if (alive) { start = base + hl; len = cnt - hl; }
-        }
-    }
-    uint32_t tot;
-    const uint32_t off = block_excl_scan(len, &tot, lds4);
-    s_off[threadIdx.x] = off; s_start[threadIdx.x] = start;
-    if (threadIdx.x == 0) s_base = tot ? atomicAdd(n_out, tot) : 0u;
-    __syncthreads();
-    const uint32_t gbase = s_base;
-    for (uint32_t e = threadIdx.x; e < tot; e += RM_BLOCK) {
-        uint32_t lo = 0, hi = RM_BLOCK - 1;                  // last ray of the block with s_off[r] <= e (empty rays share their successor's offset)
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi + 1) >> 1;
-            if (s_off[mid] <= e) lo = mid; else hi = mid - 1;
-        }
-        if (gbase + e < cap) rows_out[gbase + e] = s_start[lo] + (e - s_off[lo]);
-    }
-}
-
-// head list (first k rows of every ray): rows_out [cap], *n_out = its length (cleared here).  Side-stream work: it needs K2's counts only.
-extern "C" int xr_slice_rows_head(const int32_t* numsteps_compacted, uint32_t n_rays, uint32_t k, uint32_t* rows_out, uint32_t cap,
-                                  uint32_t* n_out, void* stream_) {
-    XR_REQUIRE(numsteps_compacted && rows_out && n_out && n_rays > 0 && k > 0, "bad argument");
-    hipStream_t stream = (hipStream_t)stream_;
-    XR_HIP(hipMemsetAsync(n_out, 0, sizeof(uint32_t), stream));
-    hipLaunchKernelGGL(k_slice_rows<false>, dim3(xr_div_up(n_rays, RM_BLOCK)), dim3(RM_BLOCK), 0, stream, n_rays, numsteps_compacted, k,
-                       (const float4*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, 0, rows_out, n_out, cap);
-    XR_LAUNCH_CHECK();
-    return XR_OK;
-}
-// tail list (rows k.. of the rays still transparent behind row k - 1), given the network outputs of the head rows in `raw`
-extern "C" int xr_slice_rows_tail(const int32_t* numsteps_compacted, uint32_t n_rays, uint32_t k, const float* raw, const float* coords,
-                                  const float* density_grid_mean, int rgb_activation, int density_activation, uint32_t* rows_out, uint32_t cap,
-                                  uint32_t* n_out, void* stream_) {
-    XR_REQUIRE(numsteps_compacted && raw && coords && density_grid_mean && rows_out && n_out && n_rays > 0 && k > 0, "bad argument");
-    XR_REQUIRE(((uintptr_t)raw & 15) == 0, "raw must be 16-byte aligned");
-    hipStream_t stream = (hipStream_t)stream_;
-    XR_HIP(hipMemsetAsync(n_out, 0, sizeof(uint32_t), stream));
-    hipLaunchKernelGGL(k_slice_rows<true>, dim3(xr_div_up(n_rays, RM_BLOCK)), dim3(RM_BLOCK), 0, stream, n_rays, numsteps_compacted, k,
-                       (const float4*)raw, coords, density_grid_mean, rgb_activation, density_activation, rows_out, n_out, cap);
-    XR_LAUNCH_CHECK();
-    return XR_OK;
-}
-
 // ------------------------------------------------------------------ K2 re-pack (compacted_coord.cu:22-76)
 __global__ __launch_bounds__(RM_BLOCK) void k2_count(uint32_t n_rays, const int32_t* __restrict__ numsteps_in,
                                                       uint32_t* __restrict__ local_off, uint32_t* __restrict__ block_tot) {
@@ -1284,6 +1179,9 @@ extern "C" int xr_composite_train2(const float* network_output, const float* coo
                density_grid_mean && rgb_output && dloss_doutput, "null pointer");
     XR_REQUIRE((((uintptr_t)network_output | (uintptr_t)dloss_doutput) & 15) == 0, "raw/grad buffers must be 16-byte aligned");
     XR_REQUIRE(n_rays > 0, "n_rays == 0");
+#ifndef XR_CT_WAVE
+#define XR_CT_WAVE 1
+#endif
 #ifndef XR_CT_STAGE
 #define XR_CT_STAGE 1       // 0: every workgroup of the 16-lane kernel on the direct path (no LDS staging of its row range)
 #endif

@@ -52,7 +52,7 @@ extern "C" int xr_ngp_train_step(
     float* zero_block, size_t zero_floats, float* grad_w_density, float* grad_w_color, float* loss_mse, uint32_t* live_seg_count,
     float* grad_table, size_t table_floats, int zero_draw,
     void* ws_mlp_bwd, size_t ws_mlp_bwd_bytes, void* ws_scatter, size_t ws_scatter_bytes, int scatter_level0,
-    const float* xyz_planes, uint32_t plane_stride, const xr_fwd_slices* slices, const xr_adam_fuse* table_adam, const xr_adam_fuse* w_density_adam,
+    const float* xyz_planes, uint32_t plane_stride, const xr_adam_fuse* table_adam, const xr_adam_fuse* w_density_adam,
     const xr_adam_fuse* w_color_adam, const char* mark_entry, void* mark_event,
     const char* timed_entry, void* timing_begin, void* timing_end, void* stream_) {
     XR_REQUIRE(table && w_density && w_color && coords && rays_numsteps && rays_numsteps_compacted && bg_color && target &&
@@ -72,8 +72,6 @@ extern "C" int xr_ngp_train_step(
     XR_REQUIRE(scatter_level0 >= 0 && scatter_level0 < n_levels, "scatter_level0 outside [0, n_levels)");
     XR_REQUIRE(!timed_entry || (timing_begin && timing_end), "a timed entry point needs its two events");
     XR_REQUIRE(!mark_entry || mark_event, "a marked entry point needs its event");
-    XR_REQUIRE(!slices || (slices->k > 0 && slices->head_rows && slices->head_n && slices->tail_rows && slices->tail_n && slices->head_cap > 0 &&
-                           slices->tail_cap > 0 && n_dev), "sliced forward: the two row lists with their device-side lengths, on a step with a device-side row count");
     hipStream_t stream = (hipStream_t)stream_;
     // The reduction of the MLP backward's per-workgroup partials (first read by the optimiser) rides on the helper stream the
     // table scatter forks anyway for its small dense levels, in front of them: one launch and one dependent-kernel boundary
@@ -98,40 +96,17 @@ extern "C" int xr_ngp_train_step(
     int rc;
     // coordinate rows {pos3, dt, dir3}: positions and directions are consumed in place (row stride 7)
     if ((rc = begin("xr_hashgrid_fwd")) != XR_OK) return rc;
-    const bool f16_mlp = mlp_mode == 1;
-    if (slices) {
-        // the forward in two depth slices (include/xrnerf_mi355.h, xr_fwd_slices): head rows -> which rays are still transparent -> their tails
-        auto lookup = [&](const uint32_t* rows, const uint32_t* n_list, uint32_t cap) -> int {
-            if (xyz_planes) return xr_hashgrid_fwd_rows(table, xyz_planes, 1, plane_stride, cap, n_list, rows, n_levels, scale_host, resolution_host, offset_host, enc_t, ld, stream_);
-            return xr_hashgrid_fwd_rows(table, coords, 7, 1, cap, n_list, rows, n_levels, scale_host, resolution_host, offset_host, enc_t, ld, stream_);
-        };
-        auto mlp = [&](const uint32_t* rows, const uint32_t* n_list, uint32_t cap) -> int {
-            return xr_nerf_mlp_fwd_rows(mlp_mode, enc_t, ld, coords + 4, 7, cap, n_list, rows, w_density, w_color, n_hidden_density, n_hidden_color, pad_value, raw, stream_);
-        };
-        const uint32_t hcap = slices->head_cap < n_rows ? slices->head_cap : n_rows, tcap = slices->tail_cap < n_rows ? slices->tail_cap : n_rows;
-        if (!slices->head_ready &&
-            (rc = xr_slice_rows_head(rays_numsteps_compacted, n_rays, slices->k, slices->head_rows, hcap, slices->head_n, stream_)) != XR_OK) return rc;
-        if ((rc = lookup(slices->head_rows, slices->head_n, hcap)) != XR_OK) return rc;
-        if ((rc = mlp(slices->head_rows, slices->head_n, hcap)) != XR_OK) return rc;
-        rc = xr_slice_rows_tail(rays_numsteps_compacted, n_rays, slices->k, raw, coords, density_grid_mean, rgb_activation, density_activation,
-                                slices->tail_rows, tcap, slices->tail_n, stream_);
-        if (rc != XR_OK) return rc;
-        if ((rc = lookup(slices->tail_rows, slices->tail_n, tcap)) != XR_OK) return rc;
-        if ((rc = end("xr_hashgrid_fwd")) != XR_OK || (rc = begin("xr_nerf_mlp_fwd")) != XR_OK) return rc;
-        if ((rc = mlp(slices->tail_rows, slices->tail_n, tcap)) != XR_OK) return rc;
-        if ((rc = end("xr_nerf_mlp_fwd")) != XR_OK) return rc;
-    } else {
     // positions: K1's three planes when the caller has them (coalesced loads: 91 -> 83 us at 2.6e5 samples), else the rows
     if (xyz_planes) rc = xr_hashgrid_fwd2(table, xyz_planes, 1, plane_stride, n_rows, n_dev, nullptr, n_levels, scale_host, resolution_host, offset_host, enc_t, ld, stream_);
     else rc = xr_hashgrid_fwd(table, coords, 7, n_rows, n_dev, nullptr, n_levels, scale_host, resolution_host, offset_host, enc_t, ld, stream_);
     if (rc != XR_OK) return rc;
     if ((rc = end("xr_hashgrid_fwd")) != XR_OK || (rc = begin("xr_nerf_mlp_fwd")) != XR_OK) return rc;
+    const bool f16_mlp = mlp_mode == 1;
     auto mlp_fwd = mlp_mode == 1 ? xr_nerf_mlp_fwd_f16 : mlp_mode == 2 ? xr_nerf_mlp_fwd_bf16x3 : xr_nerf_mlp_fwd;
     rc = mlp_fwd(enc_t, ld, coords + 4, 7, n_rows, n_dev, nullptr, w_density, w_color, n_hidden_density, n_hidden_color, pad_value, raw,
                  stream_);
     if (rc != XR_OK) return rc;
     if ((rc = end("xr_nerf_mlp_fwd")) != XR_OK) return rc;
-    }
     // nothing of zero_block is zero-filled any more: the MLP gradients are WRITTEN by the reduction of their partials, the loss
     // scalars by xr_train_loss_scalars, and the live-row counts are handed over zeroed and zeroed again after use (below)
     (void)zero_block; (void)zero_floats;
@@ -306,10 +281,6 @@ static int xr_loop_issue_march(XrLoop* L, const xr_ngp_loop_desc& D, xr_ngp_loop
     if (rc != XR_OK) return rc;
     rc = xr_clip_numsteps(M.rays_numsteps, M.counter2, n_rays, D.max_compacted, M.numsteps_clipped, M.n_valid, D.max_compacted, 1, side);
     if (rc != XR_OK) return rc;
-    if (D.slice_k) {          // the head list of the sliced forward depends on K2's counts only: built here, off the step's stream
-        rc = xr_slice_rows_head(M.numsteps_clipped, n_rays, D.slice_k, M.head_rows, D.head_cap < D.n_rows ? D.head_cap : D.n_rows, M.head_n, side);
-        if (rc != XR_OK) return rc;
-    }
     S.cur_ray += n_rays; S.batches_drawn += 1; S.k1_calls += 1;
     // the main stream waits for the MARCH only: the event sits in front of the counter's device-to-host copy
     XR_HIP(hipEventRecord(L->march_done[set], side));
@@ -335,11 +306,6 @@ extern "C" int xr_ngp_loop_run(void* loop, const xr_ngp_loop_desc* desc, xr_ngp_
     XR_REQUIRE(S.queued <= 2 && D.mark_event && D.stream != D.side_stream && D.n_pinned >= 1, "bad loop state");
     XR_REQUIRE(!timed_entry || timing_events, "a timed entry point needs its events");
     XR_REQUIRE(D.adam_table.param == D.table && D.adam_w_density.param == D.w_density && D.adam_w_color.param == D.w_color, "the updates name the step's tensors");
-    if (D.slice_k) {
-        XR_REQUIRE(D.head_cap > 0 && D.tail_cap > 0, "sliced forward: list capacities");
-        for (int i = 0; i < 3; ++i) XR_REQUIRE(D.march[i].head_rows && D.march[i].head_n, "sliced forward: a head list per march set");
-        for (int i = 0; i < 2; ++i) XR_REQUIRE(D.step[i].tail_rows && D.step[i].tail_n, "sliced forward: a tail list per step set");
-    }
     hipStream_t stream = (hipStream_t)D.stream;
     if (ext_done_prev1) { L->done_prev[0] = ext_done_prev2 ? (hipEvent_t)ext_done_prev2 : L->done_prev[1]; L->done_prev[1] = (hipEvent_t)ext_done_prev1; }
     else if (ext_done_prev2) L->done_prev[0] = (hipEvent_t)ext_done_prev2;
@@ -363,7 +329,6 @@ extern "C" int xr_ngp_loop_run(void* loop, const xr_ngp_loop_desc* desc, xr_ngp_
         S.step_turn ^= 1u;
         const xr_ngp_step_set& B = D.step[S.step_turn & 1u];
         S.adam_step += 1;
-        xr_fwd_slices sl = {D.slice_k, M.head_rows, M.head_n, D.head_cap, 1, B.tail_rows, B.tail_n, D.tail_cap};
         at.step = ad.step = ac.step = S.adam_step;
         at.lr = ad.lr = ac.lr = lr[j];
         at.ema_momentum = ad.ema_momentum = ac.ema_momentum = ema_momentum[j];
@@ -371,8 +336,7 @@ extern "C" int xr_ngp_loop_run(void* loop, const xr_ngp_loop_desc* desc, xr_ngp_
                                D.resolution_host, D.offset_host, M.coords, D.n_rows, M.n_valid, M.rays_numsteps, M.numsteps_clipped, n_rays, M.bg, M.target,
                                M.alpha, D.density_grid_mean, D.rgb_activation, D.density_activation, D.huber_delta, D.loss_scale, B.enc_t, D.ld, B.raw,
                                B.draw, B.denc_t, B.rgb_out, B.zero_block, B.zero_floats, B.grad_w_density, B.grad_w_color, B.loss_mse, B.live_seg_count,
-                               nullptr, 0, 0, D.ws_mlp_bwd, D.ws_mlp_bwd_bytes, D.ws_scatter, D.ws_scatter_bytes, 0, M.xyz_planes, M.plane_stride,
-                               D.slice_k ? &sl : nullptr, &at,
+                               nullptr, 0, 0, D.ws_mlp_bwd, D.ws_mlp_bwd_bytes, D.ws_scatter, D.ws_scatter_bytes, 0, M.xyz_planes, M.plane_stride, &at,
                                &ad, &ac, D.mark_entry, D.mark_entry ? D.mark_event : nullptr, timed_entry, timed_entry ? timing_events[2 * j] : nullptr,
                                timed_entry ? timing_events[2 * j + 1] : nullptr, D.stream);
         if (rc != XR_OK) return rc;

@@ -324,12 +324,7 @@ class TrainStepBuffers:
         f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=device)
         self.n_rows, self.ray_cap, self.ld = n_rows, ray_cap, (n_rows + 63) // 64 * 64
         self.enc_t, self.denc_t = f(meta.n_output_dims, self.ld), f(meta.n_output_dims, self.ld)
-        # raw starts ZEROED: the sliced forward (ngp_train_step(slice_k=)) leaves the rows behind an exactly-zero transmittance unwritten, and
-        # what the compositor multiplies by that zero must be finite
-        self.raw, self.draw, self.rgb = torch.zeros((n_rows, 4), dtype=torch.float32, device=device), f(n_rows, 4), f(ray_cap, 3)
-        # row lists of the sliced forward: head (first k rows of every ray) and tail (the rest of the rays still transparent), + their lengths
-        self.head_rows, self.tail_rows = (torch.empty((n_rows,), dtype=torch.int32, device=device) for _ in range(2))
-        self.slice_n = torch.zeros((2,), dtype=torch.int32, device=device)
+        self.raw, self.draw, self.rgb = f(n_rows, 4), f(n_rows, 4), f(ray_cap, 3)
         # MLP gradients, the (loss, mse) scalars and the compositor's live-row counts in one block; the step writes the first two and
         # hands the counts back zeroed (no fill on the step's stream)
         n_seg = int(_lib.load().xr_live_rows_segments(n_rows))
@@ -345,13 +340,11 @@ class TrainStepBuffers:
 
 def ngp_train_step(table, wd, wc, nhd, nhc, pad_value, meta, coords, n_dev, numsteps, numsteps_c, bg, target, alpha,
                    density_grid_mean, rgb_act, density_act, bufs, huber_delta=0.1, loss_scale=5.0, scatter_level0=0, xyz=None, mark=None,
-                   adam=None, mlp_adam=None, slice_k=0):
+                   adam=None, mlp_adam=None):
     """the device work of one HashNerfNetwork training step as one native call (xr_ngp_train_step): encode -> MLP -> K3 +
     Huber + K4 -> MLP backward -> table scatter into `bufs` (TrainStepBuffers).  Returns rgb [n_rays,3] (a view of bufs.rgb).
     scatter_level0 > 0 (data parallel): only hash levels [scatter_level0, n_levels) are scattered; the caller finishes with
     hashgrid_bwd(..., live=bufs.live, levels=(0, scatter_level0)) after handing the finer slice to its collective.
-    slice_k > 0: the forward in two depth slices (xr_fwd_slices: the first slice_k rows of every ray, then the rest of the rays whose
-    transmittance is not yet exactly zero) -- same results, the rows behind an opaque surface are not evaluated.
     adam (ops.adam_fuse of the table, single GPU): the scatter applies the optimiser's update to the table itself; bufs.g_table
     is not written.  mlp_adam = (adam_fuse of wd, adam_fuse of wc): their update runs behind the reduction of their gradients.
 
@@ -400,11 +393,7 @@ def ngp_train_step(table, wd, wc, nhd, nhc, pad_value, meta, coords, n_dev, nums
         if stage is not None:
             ev = (_CEvent(), _CEvent())
             TIMER.events.setdefault(stage, []).append((ev[0], ev[1], 0))
-    sl = None
-    if slice_k:
-        sl = _lib.FwdSlices(int(slice_k), bufs.head_rows.data_ptr(), bufs.slice_n.data_ptr(), bufs.n_rows, 0, bufs.tail_rows.data_ptr(),
-                            bufs.slice_n.data_ptr() + 4, bufs.n_rows)
-    rc = L.xr_ngp_train_step(*head, n_rays, *mid, C.byref(sl) if sl is not None else None, C.byref(adam) if adam is not None else None,
+    rc = L.xr_ngp_train_step(*head, n_rays, *mid, C.byref(adam) if adam is not None else None,
                              C.byref(mlp_adam[0]) if mlp_adam else None, C.byref(mlp_adam[1]) if mlp_adam else None,
                              mark[0].encode() if mark else None, mark[1].h if mark else None,
                              stage.encode() if stage else None, ev[0].h if stage else None, ev[1].h if stage else None, _stream())
@@ -416,40 +405,6 @@ def ngp_train_step(table, wd, wc, nhd, nhc, pad_value, meta, coords, n_dev, nums
 def record_event(cevent):
     """record a library event (_CEvent) on the current stream"""
     _lib.check(_lib.load().xr_event_record(cevent.h, _stream()), 'xr_event_record')
-
-
-def slice_rows_head(numsteps_c, k, rows_out, n_out):
-    """head list of the sliced forward: the first k rows of every ray -> rows_out (int32 [cap]), n_out (int32 [1]) on the device"""
-    _lib.check(_lib.load().xr_slice_rows_head(_ptr(numsteps_c), numsteps_c.shape[0], int(k), _ptr(rows_out), rows_out.shape[0], _ptr(n_out), _stream()),
-               'xr_slice_rows_head')
-
-
-def slice_rows_tail(numsteps_c, k, raw, coords, density_grid_mean, rgb_act, density_act, rows_out, n_out):
-    """tail list: rows k.. of the rays whose transmittance behind row k - 1 (from `raw`'s head rows) is not exactly zero"""
-    _lib.check(_lib.load().xr_slice_rows_tail(_ptr(numsteps_c), numsteps_c.shape[0], int(k), _ptr(raw), _ptr(coords), _ptr(density_grid_mean),
-                                              int(rgb_act), int(density_act), _ptr(rows_out), rows_out.shape[0], _ptr(n_out), _stream()),
-               'xr_slice_rows_tail')
-
-
-def hashgrid_fwd_rows(table, x, meta, rows, n_list, enc_t, cap=None):
-    """the lookup on a row list, in place: row r = rows[i] (i < n_list[0]) of `x` ([n,>=3] rows or [3,n] planes) -> column r of enc_t"""
-    s, r, o = meta._args()
-    planes = x.dim() == 2 and x.shape[0] == 3 and x.shape[1] != 3
-    xs, xcs = (1, x.stride(0)) if planes else (x.stride(0), 1)
-    cap = rows.shape[0] if cap is None else cap
-    with _span('xr_hashgrid_fwd', 0):
-        _lib.check(_lib.load().xr_hashgrid_fwd_rows(_ptr(table), C.c_void_p(x.data_ptr()), xs, xcs, cap, _ptr(n_list), _ptr(rows), meta.n_levels, s, r, o,
-                                                    _ptr(enc_t), enc_t.shape[1], _stream()), 'xr_hashgrid_fwd_rows')
-
-
-def nerf_mlp_fwd_rows(enc_t, dirs, rows, n_list, w_density, w_color, nhd, nhc, pad_value, raw, cap=None):
-    """the fused forward on a row list, in place: column r of enc_t, direction row r -> raw[r] for r = rows[i], i < n_list[0]"""
-    dirs, ds = _pos_view(dirs)
-    cap = rows.shape[0] if cap is None else cap
-    with _span('xr_nerf_mlp_fwd', 0):
-        _lib.check(_lib.load().xr_nerf_mlp_fwd_rows(_mlp_mode(nhd, nhc), _ptr(enc_t), enc_t.shape[1], C.c_void_p(dirs.data_ptr()), ds, cap, _ptr(n_list),
-                                                    _ptr(rows), _ptr(w_density), _ptr(w_color), nhd, nhc, float(pad_value), _ptr(raw), _stream()),
-                   'xr_nerf_mlp_fwd_rows')
 
 
 def stream_wait_event(stream, cevent):

@@ -210,7 +210,7 @@ class Trainer:
     backward -> [gradient all-reduce] -> fused Adam(+EMA)."""
 
     def __init__(self, device, n_img=20, H=800, W=800, seed=0, world_size=1, rank=0, dataset=None, ema=True, native_loop=True,
-                 fuse_adam=True, direct_step=True, overlap_march=True, prefetch_depth=2, prefetch_k6=True, march_after='xr_live_rows', forward_slice=0):
+                 fuse_adam=True, direct_step=True, overlap_march=True, prefetch_depth=2, prefetch_k6=True, march_after='xr_live_rows'):
         """The keyword switches (each overridable from the environment: XRNERF_TRAINER="fuse_adam=0,..."; xrnerf_amd/switches.py):
         native_loop     the iterations between two grid refreshes as native calls (xr_ngp_loop_run); False: one Python-driven step each
         fuse_adam       one GPU: the table scatter applies this optimiser's update itself (False: scatter, then the optimiser's launches)
@@ -223,7 +223,7 @@ class Trainer:
                         MLP backward, 0.423 from the step's start or behind the lookup / MLP forward: profiles/r04_march_start_point_ab.txt),
                         'xr_hashgrid_fwd', 'xr_nerf_mlp_fwd', 'xr_composite_train', 'xr_nerf_mlp_bwd', or 'start'"""
         opts = dict(native_loop=native_loop, fuse_adam=fuse_adam, direct_step=direct_step, overlap_march=overlap_march,
-                    prefetch_depth=prefetch_depth, prefetch_k6=prefetch_k6, march_after=march_after, forward_slice=forward_slice)
+                    prefetch_depth=prefetch_depth, prefetch_k6=prefetch_k6, march_after=march_after)
         opts.update(switches.trainer_overrides())
         if opts['prefetch_depth'] not in (1, 2):
             raise ValueError('prefetch_depth is 1 or 2')
@@ -278,10 +278,6 @@ class Trainer:
         self.net._step_mark = ((self.march_after, ops._CEvent(timing=False))
                                if (self.prefetch_depth == 2 and self.march_after != 'start' and device.type == 'cuda') else None)
         self.prefetch_k6 = opts['prefetch_k6']      # the refresh's K6 one iteration early, on the side stream
-        # forward_slice = k > 0: the step's forward in two depth slices (the first k rows of every ray, then the rest of the rays that are
-        # still transparent): the rows behind an opaque surface -- two thirds of them on the synthetic scene -- are not evaluated
-        self.forward_slice = int(opts['forward_slice'])
-        self.net._forward_slice_k = self.forward_slice
         self._ev_done = [None, None]   # completion events of the last two iterations (None: the native loop ran it and holds the event)
         # the iterations between two grid refreshes as native calls (xr_ngp_loop_run: batch draw, march two iterations ahead, step with the
         # updates inside, enqueued from C++ -- the interpreter had been pacing the loop at 0.36 ms of host work per 0.42-ms iteration).
@@ -512,7 +508,6 @@ class _NativeLoop:
         self.pinned = torch.zeros((self.N_PINNED, 2), dtype=torch.int32).pin_memory()
         self.enqueue_s, self.enqueued = 0.0, 0
         self._mark_dummy = None
-        self._head = None
         self.issued = []                   # (object with .synchronize(), host [2] view) of the marches issued and not yet consumed, in order
         self._keep = None
 
@@ -647,15 +642,8 @@ class _NativeLoop:
             M.coords, M.rays_index, M.rays_numsteps, M.counter2 = vp(coords), vp(small[0]), vp(small[1]), vp(small[2])
             M.numsteps_clipped, M.n_valid = vp(clip[0]), vp(clip[1])
             M.xyz_planes, M.plane_stride = vp(xyz), (xyz.shape[1] if xyz is not None else 0)
-        D.slice_k, D.head_cap, D.tail_cap = tr.forward_slice, n_rows, n_rows
-        if tr.forward_slice:
-            if self._head is None or self._head[0][0].shape[0] < n_rows:
-                self._head = [(torch.empty((n_rows,), dtype=torch.int32, device=dev), torch.zeros((1,), dtype=torch.int32, device=dev)) for _ in range(3)]
-            for i in range(3):
-                D.march[i].head_rows, D.march[i].head_n = self._head[i][0].data_ptr(), self._head[i][1].data_ptr()
         for i, b in enumerate(sets):
             B = D.step[i]
-            B.tail_rows, B.tail_n = vp(b.tail_rows), b.slice_n.data_ptr() + 4
             B.enc_t, B.raw, B.draw, B.denc_t, B.rgb_out, B.zero_block = vp(b.enc_t), vp(b.raw), vp(b.draw), vp(b.denc_t), vp(b.rgb), vp(b.zero_block)
             B.zero_floats = b.zero_block.numel()
             B.grad_w_density, B.grad_w_color, B.loss_mse, B.live_seg_count = vp(b.g_wd), vp(b.g_wc), vp(b.loss_mse), vp(b.live_seg)
@@ -707,7 +695,7 @@ class _NativeLoop:
         g = self._group
         # the descriptor is rebuilt only when something it names has changed (a buffer that grew, a new refresh event, another
         # precision mode): ~60 pointer conversions and four workspace queries otherwise sit in front of every window's first kernel
-        key = (n_rays, max_samples, n_rows, tr.forward_slice, id(sets[0]), id(sets[1]), table.data_ptr(), wd.data_ptr(), wc.data_ptr(), data.rays_rgb.data_ptr(),
+        key = (n_rays, max_samples, n_rows, id(sets[0]), id(sets[1]), table.data_ptr(), wd.data_ptr(), wc.data_ptr(), data.rays_rgb.data_ptr(),
                sampler.density_grid_bitfield.data_ptr(), sampler.density_grid_mean.data_ptr(), ops._mlp_mode(1, 2), id(bev), ops._stream().value,
                tuple(id(x) for x in (getattr(sampler, '_coords_bufs', None) or ())), tuple(id(x) for x in (getattr(sampler, '_small_bufs', None) or ())),
                tuple(id(x) for x in (getattr(sampler, '_clip_bufs', None) or ())), tuple(id(x) for x in (getattr(sampler, '_xyz_bufs', None) or ())),
