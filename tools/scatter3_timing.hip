@@ -25,6 +25,21 @@ extern "C" void xr_hashgrid_meta(int n_levels, int log2_hashmap_size, int base_r
     }
     offset[n_levels] = off;
 }
+// co-run probe (argv[3] = 1): the accumulate kernel WITHOUT the update on one stream, a plain optimiser sweep over the same 12.2 M parameters
+// (reads g p m v ema, writes p m v ema: 36 B per parameter) on a second stream, both started together: what an accumulate kernel whose
+// update phase runs under the next partition's atomics could reach at best
+__global__ __launch_bounds__(256) void k_adam_probe(const float4* __restrict__ g, float4* __restrict__ p, float4* __restrict__ m, float4* __restrict__ v,
+                                                    float4* __restrict__ e, size_t n4) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 G = g[i], P = p[i], M = m[i], V = v[i], E = e[i];
+        auto one = [](float g_, float& p_, float& m_, float& v_, float& e_) {
+            m_ = 0.9f * m_ + 0.1f * g_; v_ = 0.99f * v_ + 0.01f * g_ * g_;
+            p_ -= 1e-2f * m_ / (sqrtf(v_) + 1e-15f); e_ = 0.95f * e_ + 0.05f * p_;
+        };
+        one(G.x, P.x, M.x, V.x, E.x); one(G.y, P.y, M.y, V.y, E.y); one(G.z, P.z, M.z, V.z, E.z); one(G.w, P.w, M.w, V.w, E.w);
+        p[i] = P; m[i] = M; v[i] = V; e[i] = E;
+    }
+}
 int main(int argc, char** argv) {
     const uint32_t n = argc > 1 ? (uint32_t)atoi(argv[1]) : 121776u;
     const bool fuse = argc > 2 && atoi(argv[2]) != 0;          // the optimiser update inside the accumulate kernel
@@ -98,6 +113,36 @@ int main(int argc, char** argv) {
             }
         }
 #endif
+    }
+    if (argc > 3 && atoi(argv[3]) != 0 && !fuse) {
+        float4* st[5]; const size_t n4 = (size_t)off[16] * 2 / 4;
+        for (auto& q : st) { hipMalloc(&q, n4 * 16); hipMemset(q, 0, n4 * 16); }
+        hipStream_t s1, s2; hipStreamCreateWithFlags(&s1, hipStreamNonBlocking); hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+        hipEvent_t e0, e1, e2, f1, f2; for (auto* ev : {&e0, &e1, &e2, &f1, &f2}) hipEventCreate(ev);
+        S3Plan pb = P.bin;
+        for (int grid : {512, 1024, 2048, 8192}) {
+            float alone_acc = 1e9f, alone_adam = 1e9f, both = 1e9f, both_acc = 1e9f, both_adam = 1e9f;
+            for (int rep = 0; rep < 6; ++rep) {
+                for (int mode = 0; mode < 3; ++mode) {          // 0: accumulate alone, 1: sweep alone, 2: together
+                    hipDeviceSynchronize();
+                    hipEventRecord(e0, s1); hipStreamWaitEvent(s2, e0, 0);
+                    hipEventRecord(f1, s2);
+                    if (mode != 1) hipLaunchKernelGGL((k_scatter_accum3<S3_LOG2, 512>), dim3(pb.acc_blocks), dim3(512), S3_LDS_BYTES, s1, pb, (const uint32_t*)counts,
+                                                      (const float4*)bins, (const float4*)ovf, tab);
+                    hipEventRecord(e1, s1);
+                    if (mode != 0) hipLaunchKernelGGL(k_adam_probe, dim3(grid), dim3(256), 0, s2, (const float4*)st[0], st[1], st[2], st[3], st[4], n4);
+                    hipEventRecord(f2, s2);
+                    hipStreamWaitEvent(s1, f2, 0); hipEventRecord(e2, s1); hipEventSynchronize(e2);
+                    float ta, tb, tw; hipEventElapsedTime(&ta, e0, e1); hipEventElapsedTime(&tb, f1, f2); hipEventElapsedTime(&tw, e0, e2);
+                    if (rep < 2) continue;
+                    if (mode == 0) alone_acc = fminf(alone_acc, ta);
+                    if (mode == 1) alone_adam = fminf(alone_adam, tb);
+                    if (mode == 2) { both = fminf(both, tw); both_acc = fminf(both_acc, ta); both_adam = fminf(both_adam, tb); }
+                }
+            }
+            printf("co-run, sweep grid %5d x 256: accumulate alone %.1f us  sweep alone %.1f us  together %.1f us (accumulate %.1f, sweep %.1f)\n", grid,
+                   alone_acc * 1e3, alone_adam * 1e3, both * 1e3, both_acc * 1e3, both_adam * 1e3);
+        }
     }
     return 0;
 }
