@@ -636,19 +636,6 @@ uint32_t xr_linear_backward_bias_splits(uint32_t M);
 int xr_linear_backward_bias(const float* dy, const float* mask_src, uint32_t M, uint32_t N, uint32_t splits,
                             float* db_partials, void* stream);
 
-/* The same layers with the operands kept SPLIT in HBM (csrc/xr_gemm3.hip): a tensor that feeds a product is three bf16 planes
- * [3][rows][ld] (plane i at planes + i * plane_stride, in 2-byte elements; rows 16-byte aligned, ld a multiple of 8) whose sum is the
- * fp32 value exactly; it is split once, by the kernel that produces it.  Products: six bf16 MFMA terms, fp32 accumulate (fp32
- * rounding accuracy, same bar as the kernels above).  Padded columns (K .. K_padded - 1) hold zeros; K of a product is a multiple of 32.
- *   xr_p3_split:   planes = split(x [M,K] fp32, where mask_src > 0 when given)
- *   xr_p3_gemm_nt: C [M,N] = act(A [M,K] . B [N,K]^T + bias), zeroed where mask_hi (the HIGH plane of a relu layer's output at the
- *                  same [m][n]) is not positive; written as planes (C_planes, N % 8 == 0) and / or fp32 (C, N % 4 == 0) */
-int xr_p3_split(const float* x, uint32_t M, uint32_t K, uint32_t ldx, const float* mask_src, uint32_t ld_mask, void* planes,
-                uint32_t ld_planes, size_t plane_stride, uint32_t K_padded, void* stream);
-int xr_p3_gemm_nt(const void* A, uint32_t lda, size_t psa, const void* B, uint32_t ldb, size_t psb, uint32_t M, uint32_t N, uint32_t K,
-                  const float* bias, int relu, const void* mask_hi, uint32_t ld_mask, void* C_planes, uint32_t ldcp, size_t pscp,
-                  float* C, uint32_t ldc, void* stream);
-
 #ifdef __cplusplus
 }
 #endif

@@ -151,8 +151,6 @@ SIGNATURES = {
     'xr_linear_backward_bias_splits': (_u32, [_u32]),
     'xr_linear_backward_bias': (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp]),
     'xr_linear_backward_weight': (_i32, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp]),
-    'xr_p3_split': (_i32, [_vp, _u32, _u32, _u32, _vp, _u32, _vp, _u32, _sz, _u32, _vp]),
-    'xr_p3_gemm_nt': (_i32, [_vp, _u32, _sz, _vp, _u32, _sz, _u32, _u32, _u32, _vp, _i32, _vp, _u32, _vp, _u32, _sz, _vp, _u32, _vp]),
     'xr_kilo_render_workspace_bytes': (_sz, [_u32, _u32, _u32]),
     'xr_kilo_render_rays': (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32,
                                    _u32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -33,7 +33,6 @@ SOURCES = {
     # (the MLP's FMAs are explicit fmaf calls)
     'xr_kilo.hip': ['-ffp-contract=off'],
     'xr_gemm.hip': [],
-    'xr_gemm3.hip': [],
     # host-side step executor (calls the entry points above in sequence)
     'xr_step.hip': [],
 }

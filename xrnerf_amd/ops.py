@@ -1192,49 +1192,3 @@ def linear_backward_bias(dy, mask_src):
     part = torch.empty((splits, N), dtype=torch.float32, device=dy.device)
     _lib.check(L.xr_linear_backward_bias(_ptr(dy), _ptr(mask_src), M, N, splits, _ptr(part), _stream()), 'xr_linear_backward_bias')
     return part[0] if splits == 1 else part.sum(0)
-
-
-# ------------------------------------------------------------------ linear layers on split operands (csrc/xr_gemm3.hip)
-def p3_planes(M, K, device):
-    """an empty plane tensor [3, M, ld] (bf16; ld = K rounded up to 32: the products' k-steps)"""
-    return torch.empty((3, M, (K + 31) // 32 * 32), dtype=torch.bfloat16, device=device)
-
-
-def p3_split(x, out=None, col0=0, k_pad=None, mask_src=None):
-    """fp32 [M,K] -> three bf16 planes whose sum is x exactly, into columns col0 .. col0 + k_pad of `out` ([3, M, ld]; columns K .. k_pad
-    are zero-filled).  mask_src: fp32 [M,K], x counts where it is > 0."""
-    M, K = x.shape
-    if x.dtype != torch.float32 or x.stride(1) != 1 or not _on_device(x):
-        raise _lib.XrError('p3_split: fp32 device rows')
-    if k_pad is None:
-        k_pad = (K + 31) // 32 * 32 if out is None else min((K + 7) // 8 * 8, out.shape[2] - col0)
-    if out is None:
-        out = torch.empty((3, M, k_pad), dtype=torch.bfloat16, device=x.device)
-    if mask_src is not None and (mask_src.shape != x.shape or mask_src.stride(1) != 1):
-        raise _lib.XrError('p3_split: mask shape')
-    _lib.check(_lib.load().xr_p3_split(_ptr_any(x), M, K, x.stride(0), _ptr_any(mask_src), mask_src.stride(0) if mask_src is not None else 0,
-                                       C.c_void_p(out.data_ptr() + 2 * col0), out.stride(1), out.stride(0), k_pad, _stream()), 'xr_p3_split')
-    return out
-
-
-def _ptr_any(t):
-    return None if t is None else C.c_void_p(t.data_ptr())
-
-
-def p3_gemm_nt(A, B, N, K=None, bias=None, relu=False, mask_hi=None, out_planes=None, out_col0=0, out_f32=None, a_col0=0):
-    """C [M,N] = act(A [M,K] . B [N,K]^T + bias) on split operands (A, B: [3, rows, ld] bf16 planes; K a multiple of 32, default B's width),
-    zeroed where mask_hi ([M, ld] bf16: the high plane of a relu output) is not positive.  -> planes written at column out_col0 of
-    out_planes and / or fp32 out_f32 [M, >= N]."""
-    M = A.shape[1]
-    K = B.shape[2] if K is None else K
-    if out_planes is None and out_f32 is None:
-        out_planes = torch.empty((3, M, (N + 31) // 32 * 32), dtype=torch.bfloat16, device=A.device)
-        if out_planes.shape[2] != N:
-            out_planes[:, :, N:].zero_()
-    L = _lib.load()
-    _lib.check(L.xr_p3_gemm_nt(C.c_void_p(A.data_ptr() + 2 * a_col0), A.stride(1), A.stride(0), _ptr_any(B), B.stride(1), B.stride(0), M, N, K,
-                               _ptr_any(bias), 1 if relu else 0, _ptr_any(mask_hi), mask_hi.stride(0) if mask_hi is not None else 0,
-                               C.c_void_p(out_planes.data_ptr() + 2 * out_col0) if out_planes is not None else None,
-                               out_planes.stride(1) if out_planes is not None else 0, out_planes.stride(0) if out_planes is not None else 0,
-                               _ptr_any(out_f32), out_f32.stride(0) if out_f32 is not None else 0, _stream()), 'xr_p3_gemm_nt')
-    return out_planes if out_planes is not None else out_f32
