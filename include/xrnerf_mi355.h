@@ -629,9 +629,16 @@ int xr_linear_forward(const float* x, const float* w, const float* bias, uint32_
                       float* y, void* stream);
 int xr_linear_backward_input(const float* dy, const float* mask_src, const float* w, uint32_t M, uint32_t N, uint32_t K,
                              float* dx, void* stream);
+/* the same with the weight transposed by the caller (w_t [K,N] row-major): served by the forward's split-operand kernel */
+int xr_linear_backward_input_t(const float* dy, const float* mask_src, const float* w_t, uint32_t M, uint32_t N, uint32_t K,
+                               float* dx, void* stream);
 uint32_t xr_linear_backward_weight_splits(uint32_t M, uint32_t N, uint32_t K);
 int xr_linear_backward_weight(const float* dy, const float* mask_src, const float* x, uint32_t M, uint32_t N, uint32_t K,
                               uint32_t splits, float* dw_partials, void* stream);
+/* weight and bias gradient in one launch: db_partials [splits,N] over the SAME M ranges as dw_partials (taken from the operand panels
+ * the product stages anyway; no pass of its own over dy and the mask) */
+int xr_linear_backward_weight_bias(const float* dy, const float* mask_src, const float* x, uint32_t M, uint32_t N, uint32_t K,
+                                   uint32_t splits, float* dw_partials, float* db_partials, void* stream);
 uint32_t xr_linear_backward_bias_splits(uint32_t M);
 int xr_linear_backward_bias(const float* dy, const float* mask_src, uint32_t M, uint32_t N, uint32_t splits,
                             float* db_partials, void* stream);

@@ -43,6 +43,10 @@ def test_kernels_against_fp64(dev, M, N, K, gemm_kernel):
     db = ops.linear_backward_bias(dyd, yr).cpu().double()
     assert (db - dym_k.sum(0)).abs().max() <= 5e-5 * max(1.0, float(dym_k.sum(0).abs().max()))
     assert (ops.linear_backward_bias(dyd, None).cpu().double() - dy.double().sum(0)).abs().max() <= 5e-5 * max(1.0, float(dy.double().sum(0).abs().max()))
+    # weight and bias gradient from one launch (the column sums ride on the weight-gradient product's operand panels)
+    dw2, db2 = ops.linear_backward_weight_bias(dyd, yr, xd)
+    assert torch.equal(dw2.cpu().double(), dw)
+    assert (db2.cpu().double() - dym_k.sum(0)).abs().max() <= 5e-5 * max(1.0, float(dym_k.sum(0).abs().max()))
     # no mask
     dx0 = ops.linear_backward_input(dyd, None, wd).cpu().double()
     assert (dx0 - dy.double() @ w.double()).abs().max() <= 5e-5 * max(1.0, float((dy.double() @ w.double()).abs().max()))

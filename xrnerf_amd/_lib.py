@@ -147,7 +147,9 @@ SIGNATURES = {
     'xr_nerf_render_forward': (_i32, [_vp, _vp, _vp, _u32, _u32, _i32, _vp, _vp, _vp, _vp, _vp]),
     'xr_linear_forward': (_i32, [_vp, _vp, _vp, _u32, _u32, _u32, _i32, _vp, _vp]),
     'xr_linear_backward_input': (_i32, [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp]),
+    'xr_linear_backward_input_t': (_i32, [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp]),
     'xr_linear_backward_weight_splits': (_u32, [_u32, _u32, _u32]),
+    'xr_linear_backward_weight_bias': (_i32, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
     'xr_linear_backward_bias_splits': (_u32, [_u32]),
     'xr_linear_backward_bias': (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp]),
     'xr_linear_backward_weight': (_i32, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp]),

@@ -37,6 +37,7 @@ struct GemmArgs {
     uint32_t k_per_split;                        // contraction range of blockIdx.z; C of split z at C + z * c_split_stride
     size_t c_split_stride;
     int tload;                                   // k_gemm_b3: [k, rows] operands are read with per-k dword loads (k-contiguous in registers)
+    float* colsum;                               // k_gemm_f32 with a_km: nullable [splits, Mc]: sums of A's (masked) rows over the split's k range
 };
 
 // one 128 x GBK panel of an operand into registers: GNJ float4 per thread.
@@ -98,9 +99,19 @@ __global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     float4 ra[GNJ], rb[GNJ];
+    // the bias gradient rides on the weight-gradient product: A = (dy masked)^T is staged as [k = sample][row = output neuron] panels, a
+    // thread's panel registers are always the same 4 neurons, so their running sum over the split's samples is 4 adds per float4 -- in
+    // the first column tile's workgroups only; no second pass over dy and the relu mask (k_masked_colsum: 43 us per layer)
+    const bool cs = g.colsum != nullptr && g.a_km && blockIdx.x == 0;                     // uniform
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto cs_add = [&]() {
+#pragma unroll
+        for (int j = 0; j < GNJ; ++j) { csum.x += ra[j].x; csum.y += ra[j].y; csum.z += ra[j].z; csum.w += ra[j].w; }
+    };
     if (k_begin < k_end) {
         panel_load(g.A, g.mask_src, g.lda, g.a_km, m0, g.Mc, k_begin, k_end, ra);
         panel_load(g.B, nullptr, g.ldb, g.b_kn, n0, g.Nc, k_begin, k_end, rb);
+        if (cs) cs_add();
     }
     int buf = 0;
     for (uint32_t k0 = k_begin; k0 < k_end; k0 += GBK) {
@@ -110,6 +121,7 @@ __global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g) {
         if (k0 + GBK < k_end) {
             panel_load(g.A, g.mask_src, g.lda, g.a_km, m0, g.Mc, k0 + GBK, k_end, ra);
             panel_load(g.B, nullptr, g.ldb, g.b_kn, n0, g.Nc, k0 + GBK, k_end, rb);
+            if (cs) cs_add();
         }
         const float* pa = sA[buf] + hi * ST + wm * 64 + col;
         const float* pb = sB[buf] + hi * ST + wn * 64 + col;
@@ -143,6 +155,18 @@ __global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g) {
                 }
             }
         }
+    if (cs) {                                              // the 8 k-phases of a neuron's running sums, added in a fixed order
+        __syncthreads();
+        float* red = &sA[0][0];
+        *reinterpret_cast<float4*>(red + (threadIdx.x >> 5) * GBM + (threadIdx.x & 31) * 4) = csum;
+        __syncthreads();
+        if (threadIdx.x < GBM) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += red[i * GBM + threadIdx.x];
+            if (m0 + threadIdx.x < g.Mc) g.colsum[(size_t)blockIdx.z * g.Mc + m0 + threadIdx.x] = s;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -353,14 +377,22 @@ static int gemm_launch(GemmArgs g, uint32_t splits, void* stream) {
 // y [M,N] = act(x [M,K] . w [N,K]^T + bias [N])
 extern "C" int xr_linear_forward(const float* x, const float* w, const float* bias, uint32_t M, uint32_t N, uint32_t K,
                                  int relu, float* y, void* stream) {
-    GemmArgs g{x, w, y, bias, nullptr, M, N, K, K, K, N, 0, 0, relu, 0, 0, 0};
+    GemmArgs g{x, w, y, bias, nullptr, M, N, K, K, K, N, 0, 0, relu, 0, 0, 0, nullptr};
     return gemm_launch(g, 1, stream);
 }
 
 // dx [M,K] = (dy [M,N] masked by mask_src [M,N] > 0 when given) . w [N,K]
 extern "C" int xr_linear_backward_input(const float* dy, const float* mask_src, const float* w, uint32_t M, uint32_t N,
                                         uint32_t K, float* dx, void* stream) {
-    GemmArgs g{dy, w, dx, nullptr, mask_src, M, K, N, N, K, K, 0, 1, 0, 0, 0, 0};
+    GemmArgs g{dy, w, dx, nullptr, mask_src, M, K, N, N, K, K, 0, 1, 0, 0, 0, 0, nullptr};
+    return gemm_launch(g, 1, stream);
+}
+
+// the same product with the weight handed over TRANSPOSED (w_t [K,N] row-major): both operands are then [rows, contraction] like the
+// forward's, and the product runs on the split-operand kernel (163 us against 267 us on the fp32 MFMA at 131072 x 256 x 256)
+extern "C" int xr_linear_backward_input_t(const float* dy, const float* mask_src, const float* w_t, uint32_t M, uint32_t N,
+                                          uint32_t K, float* dx, void* stream) {
+    GemmArgs g{dy, w_t, dx, nullptr, mask_src, M, K, N, N, N, K, 0, 0, 0, 0, 0, 0, nullptr};
     return gemm_launch(g, 1, stream);
 }
 
@@ -426,6 +458,26 @@ extern "C" int xr_linear_backward_bias(const float* dy, const float* mask_src, u
 
 extern "C" int xr_linear_backward_weight(const float* dy, const float* mask_src, const float* x, uint32_t M, uint32_t N,
                                          uint32_t K, uint32_t splits, float* dw_partials, void* stream) {
-    GemmArgs g{dy, x, dw_partials, nullptr, mask_src, N, K, M, N, K, K, 1, 1, 0, 0, (size_t)N * K, 0};
+    GemmArgs g{dy, x, dw_partials, nullptr, mask_src, N, K, M, N, K, K, 1, 1, 0, 0, (size_t)N * K, 0, nullptr};
+    return gemm_launch(g, splits, stream);
+}
+
+// weight AND bias gradient of a layer in one launch: db_partials [splits, N] = the same M-range column sums of (dy masked) that
+// xr_linear_backward_bias computes with a pass of its own, taken from the panels the weight-gradient product stages anyway
+extern "C" int xr_linear_backward_weight_bias(const float* dy, const float* mask_src, const float* x, uint32_t M, uint32_t N,
+                                              uint32_t K, uint32_t splits, float* dw_partials, float* db_partials, void* stream) {
+    XR_REQUIRE(db_partials, "null pointer");
+    const char* env = getenv("XR_GEMM_F32");
+    if (env && strcmp(env, "bf16x3all") == 0) {            // that measurement mode has no column sums in its kernel: two launches
+        const int rc = xr_linear_backward_weight(dy, mask_src, x, M, N, K, splits, dw_partials, stream);
+        if (rc != XR_OK) return rc;
+        // per-split column sums over the same M ranges: k_masked_colsum with `splits` row ranges of k_per_split rows
+        const uint32_t rows = (uint32_t)(((uint64_t)(M + splits - 1) / splits + GBK - 1) / GBK * GBK);
+        hipLaunchKernelGGL(k_masked_colsum, dim3(xr_div_up(N / 4, 64), splits), dim3(256), 0, (hipStream_t)stream, dy, mask_src, M, N, rows ? rows : 1,
+                           db_partials);
+        XR_LAUNCH_CHECK();
+        return XR_OK;
+    }
+    GemmArgs g{dy, x, dw_partials, nullptr, mask_src, N, K, M, N, K, K, 1, 1, 0, 0, (size_t)N * K, 0, db_partials};
     return gemm_launch(g, splits, stream);
 }

@@ -24,10 +24,13 @@ class _LinearAct(torch.autograd.Function):
         dy = dy.contiguous()
         mask = y if ctx.relu else None
         dx = ops.linear_backward_input(dy, mask, w) if ctx.needs_input_grad[0] else None
-        dw = ops.linear_backward_weight(dy, mask, x) if ctx.needs_input_grad[1] else None
-        db = None
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = ops.linear_backward_bias(dy, mask)
+        dw = db = None
+        if ctx.has_bias and ctx.needs_input_grad[2] and ctx.needs_input_grad[1]:
+            dw, db = ops.linear_backward_weight_bias(dy, mask, x)      # (the bias gradient rides on the weight-gradient product)
+        else:
+            dw = ops.linear_backward_weight(dy, mask, x) if ctx.needs_input_grad[1] else None
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = ops.linear_backward_bias(dy, mask)
         return dx, dw, db, None
 
 

@@ -1158,14 +1158,16 @@ def linear_forward(x, w, bias, relu):
 
 
 def linear_backward_input(dy, mask_src, w):
-    """dx [M,K] = (dy where mask_src > 0) . w"""
+    """dx [M,K] = (dy where mask_src > 0) . w.  The weight goes in transposed (one 64 K-element copy): both operands of the product are
+    then [rows, contraction] like the forward's and it runs on the forward's split-operand kernel instead of the fp32 MFMA (1.6x)."""
     dy, w = _f32c(dy), _f32c(w)
     M, N = dy.shape
     K = w.shape[1]
     dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
+    w_t = w.t().contiguous()
     with _span('xr_linear_backward_input', M):
-        _lib.check(_lib.load().xr_linear_backward_input(_ptr(dy), _ptr(mask_src), _ptr(w), M, N, K, _ptr(dx), _stream()),
-                   'xr_linear_backward_input')
+        _lib.check(_lib.load().xr_linear_backward_input_t(_ptr(dy), _ptr(mask_src), _ptr(w_t), M, N, K, _ptr(dx), _stream()),
+                   'xr_linear_backward_input_t')
     return dx
 
 
@@ -1181,6 +1183,22 @@ def linear_backward_weight(dy, mask_src, x):
         _lib.check(L.xr_linear_backward_weight(_ptr(dy), _ptr(mask_src), _ptr(x), M, N, K, splits, _ptr(part), _stream()),
                    'xr_linear_backward_weight')
     return part[0] if splits == 1 else part.sum(0)
+
+
+def linear_backward_weight_bias(dy, mask_src, x):
+    """(dw [N,K], db [N]) of one layer from ONE launch: the bias gradient's column sums ride on the weight-gradient product"""
+    L = _lib.load()
+    dy, x = _f32c(dy), _f32c(x)
+    M, N = dy.shape
+    K = x.shape[1]
+    splits = int(L.xr_linear_backward_weight_splits(M, N, K))
+    dwp, dbp = torch.empty((splits, N, K), dtype=torch.float32, device=dy.device), torch.empty((splits, N), dtype=torch.float32, device=dy.device)
+    with _span('xr_linear_backward_weight', M):
+        _lib.check(L.xr_linear_backward_weight_bias(_ptr(dy), _ptr(mask_src), _ptr(x), M, N, K, splits, _ptr(dwp), _ptr(dbp), _stream()),
+                   'xr_linear_backward_weight_bias')
+    if splits == 1:
+        return dwp[0], dbp[0]
+    return dwp.sum(0), dbp.sum(0)
 
 
 def linear_backward_bias(dy, mask_src):
