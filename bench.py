@@ -917,12 +917,18 @@ def main():
                                    'MLP backward, table scatter, %sAdam + L2 + EMA over 12.2 M parameters%s) after %d un-timed '
                                    'pre-roll + %d warm-up iterations (adaptive batch at its fixed point: %s rays); the '
                                    'reference\'s dead no-grad MLP pass that only feeds K2\'s dead transmittance loop is skipped; fused-MLP '
-                                   'forward: %s'
+                                   'forward: %s; fused-MLP backward: %s'
                                    % (args.n_img, it0, it1 - 1, n_refresh, 'gradient all-reduce, ' if world > 1 else '',
                                       ' (the table\'s update applied inside the scatter: no gradient round trip)' if (world == 1 and tr.fuse_adam) else '',
                                       preroll, args.warmup + align, hist[-1],
                                       'fp32 via exact 3-way bf16 operand split on the bf16 MFMA (xr_nerf_mlp_fwd_bf16x3)' if ops._mlp_mode() == 2
-                                      else 'fp32 MFMA'),
+                                      else 'fp32 MFMA',
+                                      {'f32': 'fp32 MFMA throughout', 'b2': 'dW on 2-way-split bf16 operands (2^-16 per product), dX chain on the fp32 MFMA',
+                                       'b2x': 'dW and the dX chain on 2-way-split bf16 operands (2^-16 relative per product, fp32 accumulate; '
+                                              '1.0e-5 of max against a float64 statement away from ReLU kinks: profiles/r04_mlp_bwd_denc_outlier.txt), '
+                                              'forward recompute in fp32 (3-way split)',
+                                       'b2f': 'as b2x with the forward recompute on 2-way-split operands'}.get(os.environ.get('XR_MLP_BWD_DW', 'b2x'), 'see XR_MLP_BWD_DW')
+                                      if ops._mlp_mode() != 1 else 'fp16 operands, fp32 accumulate'),
                        'rays_per_step': rays_all / args.steps / world, 'samples_per_ray': samples_all / max(rays_all, 1),
                        'samples_per_s': samples_all / elapsed_max, 'n_images': args.n_img,
                        'preroll_iterations': preroll, 'timed_iterations': [it0, it1 - 1], 'grid_refreshes_in_window': n_refresh,

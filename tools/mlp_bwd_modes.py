@@ -42,3 +42,13 @@ def timeit(reps=30):
     for _ in range(reps): f()
     b.record(); torch.cuda.synchronize(); return a.elapsed_time(b) / reps * 1e3
 print('XR_MLP_BWD_DW=%-4s  %.1f us on %d rows   max |err| / max |grad|:  %s' % (os.environ.get('XR_MLP_BWD_DW', 'b2x'), timeit(), n, '   '.join(line)), flush=True)
+# where does the largest dL/d enc deviation come from?  A hidden unit whose pre-activation is within rounding of 0 has its ReLU on in
+# one arithmetic and off in the other: that row's gradient then differs by a whole weight column, whatever the precision of the products.
+with torch.no_grad():
+    z0 = x @ W0.t(); zc0 = cin @ C0.t(); zc1 = torch.relu(zc0) @ C1.t()
+    zmin = torch.cat([z0.abs(), zc0.abs(), zc1.abs()], 1).min(1).values.cpu().numpy()        # per row: the pre-activation closest to its kink
+err_row = np.abs(got[2] - ref[2]).max(0) / np.abs(ref[2]).max()
+bad = np.nonzero(err_row > 1e-4)[0]
+print('   dL/d enc: %d of %d rows deviate by more than 1e-4 of max; their closest |pre-activation| (float64): max %.2e (median over all rows %.2e); '
+      'max deviation over the rows whose closest |pre-activation| exceeds 1e-5: %.2e of max'
+      % (len(bad), n, zmin[bad].max() if len(bad) else 0.0, np.median(zmin), err_row[zmin > 1e-5].max()), flush=True)
