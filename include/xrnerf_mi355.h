@@ -440,6 +440,11 @@ typedef struct xr_ngp_loop_desc {
     const char* mark_entry;                                /* the entry point of the step behind which the march of iteration i + 2 may start
                                                               ("xr_live_rows": beside the MLP backward and the scatter; null: behind the end of
                                                               iteration i - 1 only, i.e. from the start of iteration i) */
+    uint32_t* mark_word;                                   /* nullable device word (zero-initialised).  With mark_entry "xr_live_rows": the steps of a
+                                                              window store their iteration number + 1 to it from the live-row list kernel instead of
+                                                              recording mark_event, and the side stream polls it (one wave, with a deadline) in front of
+                                                              the march: the start point is a preference about time, and an event record holds the
+                                                              step's queue for several microseconds per iteration */
 } xr_ngp_loop_desc;
 typedef struct xr_ngp_loop_state {     /* the counters the loop shares with its caller (read AND written) */
     uint64_t iter;                     /* next iteration */

@@ -48,7 +48,7 @@ class LoopDesc(C.Structure):
                 ('ws_scatter', C.c_void_p), ('ws_scatter_bytes', C.c_size_t),
                 ('counter_host_pinned', C.c_void_p), ('n_pinned', C.c_uint32),
                 ('stream', C.c_void_p), ('side_stream', C.c_void_p), ('bitfield_event', C.c_void_p), ('mark_event', C.c_void_p),
-                ('mark_entry', C.c_char_p)]
+                ('mark_entry', C.c_char_p), ('mark_word', C.c_void_p)]
 
 
 class LoopState(C.Structure):

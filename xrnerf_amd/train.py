@@ -210,7 +210,7 @@ class Trainer:
     backward -> [gradient all-reduce] -> fused Adam(+EMA)."""
 
     def __init__(self, device, n_img=20, H=800, W=800, seed=0, world_size=1, rank=0, dataset=None, ema=True, native_loop=True,
-                 fuse_adam=True, direct_step=True, overlap_march=True, prefetch_depth=2, prefetch_k6=True, march_after='xr_live_rows'):
+                 fuse_adam=True, direct_step=True, overlap_march=True, prefetch_depth=2, prefetch_k6=True, march_after='xr_live_rows', mark_by_word=True):
         """The keyword switches (each overridable from the environment: XRNERF_TRAINER="fuse_adam=0,..."; xrnerf_amd/switches.py):
         native_loop     the iterations between two grid refreshes as native calls (xr_ngp_loop_run); False: one Python-driven step each
         fuse_adam       one GPU: the table scatter applies this optimiser's update itself (False: scatter, then the optimiser's launches)
@@ -223,7 +223,7 @@ class Trainer:
                         MLP backward, 0.423 from the step's start or behind the lookup / MLP forward: profiles/r04_march_start_point_ab.txt),
                         'xr_hashgrid_fwd', 'xr_nerf_mlp_fwd', 'xr_composite_train', 'xr_nerf_mlp_bwd', or 'start'"""
         opts = dict(native_loop=native_loop, fuse_adam=fuse_adam, direct_step=direct_step, overlap_march=overlap_march,
-                    prefetch_depth=prefetch_depth, prefetch_k6=prefetch_k6, march_after=march_after)
+                    prefetch_depth=prefetch_depth, prefetch_k6=prefetch_k6, march_after=march_after, mark_by_word=mark_by_word)
         opts.update(switches.trainer_overrides())
         if opts['prefetch_depth'] not in (1, 2):
             raise ValueError('prefetch_depth is 1 or 2')
@@ -275,6 +275,9 @@ class Trainer:
         if opts['march_after'] not in ('start', 'xr_hashgrid_fwd', 'xr_nerf_mlp_fwd', 'xr_composite_train', 'xr_live_rows', 'xr_nerf_mlp_bwd'):
             raise ValueError('march_after: unknown entry point %r' % opts['march_after'])
         self.march_after = opts['march_after']
+        # the native loop's start point as a word the step's list kernel stores and the side stream polls, instead of an event record on
+        # the step's stream (csrc/xr_step.hip, xr_loop_issue_march); only with march_after = 'xr_live_rows'
+        self.mark_by_word = bool(opts['mark_by_word'])
         self.net._step_mark = ((self.march_after, ops._CEvent(timing=False))
                                if (self.prefetch_depth == 2 and self.march_after != 'start' and device.type == 'cuda') else None)
         self.prefetch_k6 = opts['prefetch_k6']      # the refresh's K6 one iteration early, on the side stream
@@ -508,6 +511,7 @@ class _NativeLoop:
         self.pinned = torch.zeros((self.N_PINNED, 2), dtype=torch.int32).pin_memory()
         self.enqueue_s, self.enqueued = 0.0, 0
         self._mark_dummy = None
+        self._mark_word = None
         self.issued = []                   # (object with .synchronize(), host [2] view) of the marches issued and not yet consumed, in order
         self._keep = None
 
@@ -663,6 +667,9 @@ class _NativeLoop:
             self._mark_dummy = ops._CEvent(timing=False)
         D.mark_event = mark[1].h if mark is not None else self._mark_dummy.h
         D.mark_entry = mark[0].encode() if mark is not None else None
+        if self._mark_word is None:
+            self._mark_word = torch.zeros((1,), dtype=torch.int32, device=dev)
+        D.mark_word = self._mark_word.data_ptr() if tr.mark_by_word else None
         self._hold = (sets, ws_k1, ws_mlp, ws_sc, bev, states)          # (what the pointers name stays alive)
         return D, msets, live_list, live_stats
 
