@@ -238,6 +238,7 @@ struct XrLoop {
     hipEvent_t march_done[3] = {nullptr, nullptr, nullptr};
     hipEvent_t iter_done[3] = {nullptr, nullptr, nullptr};
     hipEvent_t done_prev[2] = {nullptr, nullptr};          // end of iterations iter - 2, iter - 1 (own or the caller's)
+    hipEvent_t join_covers = nullptr;                      // the march event the last step's helper-stream join waited for (inside a window)
 };
 
 extern "C" void* xr_ngp_loop_create(void) {
@@ -332,6 +333,9 @@ static int xr_loop_issue_march(XrLoop* L, const xr_ngp_loop_desc& D, xr_ngp_loop
     return XR_OK;
 }
 
+#ifndef XR_LOOP_MERGE_WAITS
+#define XR_LOOP_MERGE_WAITS 1        // the wait for the next march rides on the helper stream's join of the step in front (0: a wait of its own)
+#endif
 #ifndef XR_LOOP_DONE_EVERY
 #define XR_LOOP_DONE_EVERY 0         // 1: record the end-of-iteration event in every iteration (the A/B of tools/build_variant.sh)
 #endif
@@ -352,6 +356,7 @@ extern "C" int xr_ngp_loop_run(void* loop, const xr_ngp_loop_desc* desc, xr_ngp_
     if (ext_done_prev1) { L->done_prev[0] = ext_done_prev2 ? (hipEvent_t)ext_done_prev2 : L->done_prev[1]; L->done_prev[1] = (hipEvent_t)ext_done_prev1; }
     else if (ext_done_prev2) L->done_prev[0] = (hipEvent_t)ext_done_prev2;
     int rc;
+    L->join_covers = nullptr;
     // marches the caller's iteration left to this loop (it runs refresh iterations without issuing any: see Trainer): iteration `iter`
     // at once (ordered behind the end of iter - 2, as if issued during iter - 1), iter + 1 behind the mark of iter - 1
     if (S.queued == 0) {
@@ -367,7 +372,10 @@ extern "C" int xr_ngp_loop_run(void* loop, const xr_ngp_loop_desc* desc, xr_ngp_
         const uint32_t mset = S.queue_set[0];
         S.queue_set[0] = S.queue_set[1]; S.queued -= 1;
         const xr_ngp_march_set& M = D.march[mset];
-        XR_HIP(hipStreamWaitEvent(stream, L->march_done[mset], 0));
+        // (the previous step's scatter may have put this wait on its helper stream, in front of the join this stream waits for anyway)
+        if (L->join_covers != L->march_done[mset]) XR_HIP(hipStreamWaitEvent(stream, L->march_done[mset], 0));
+        L->join_covers = nullptr;
+        hipEvent_t next_march = (XR_LOOP_MERGE_WAITS && S.queued >= 1) ? L->march_done[S.queue_set[0]] : nullptr;
         S.step_turn ^= 1u;
         const xr_ngp_step_set& B = D.step[S.step_turn & 1u];
         S.adam_step += 1;
@@ -377,6 +385,7 @@ extern "C" int xr_ngp_loop_run(void* loop, const xr_ngp_loop_desc* desc, xr_ngp_
         const bool by_word = D.mark_word != nullptr && D.mark_entry && strcmp(D.mark_entry, "xr_live_rows") == 0;
         const uint32_t word_value = (uint32_t)(it + 1);
         g_step_mark_word = by_word ? D.mark_word : nullptr; g_step_mark_value = word_value;
+        xr_internal_scatter_join_also(next_march);
         rc = xr_ngp_train_step(D.table, D.w_density, D.w_color, D.n_hidden_density, D.n_hidden_color, D.pad_value, D.mlp_mode, D.n_levels, D.scale_host,
                                D.resolution_host, D.offset_host, M.coords, D.n_rows, M.n_valid, M.rays_numsteps, M.numsteps_clipped, n_rays, M.bg, M.target,
                                M.alpha, D.density_grid_mean, D.rgb_activation, D.density_activation, D.huber_delta, D.loss_scale, B.enc_t, D.ld, B.raw,
@@ -385,6 +394,8 @@ extern "C" int xr_ngp_loop_run(void* loop, const xr_ngp_loop_desc* desc, xr_ngp_
                                &ad, &ac, D.mark_entry, D.mark_entry ? D.mark_event : nullptr, timed_entry, timed_entry ? timing_events[2 * j] : nullptr,
                                timed_entry ? timing_events[2 * j + 1] : nullptr, D.stream);
         g_step_mark_word = nullptr;
+        if (next_march && xr_internal_scatter_join_also_taken()) L->join_covers = next_march;
+        xr_internal_scatter_join_also(nullptr);
         if (rc != XR_OK) return rc;
         // Trainer._on_sampled, depth 2: iteration it + 1 at once if nothing is queued for it, then it + 2 behind this step's mark
         if (S.queued == 0 && (it + 1) % f != 0)
