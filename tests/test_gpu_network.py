@@ -460,3 +460,26 @@ def test_row_bands_of_a_frame_give_the_whole_frames_pixels(dev):
             for key in ('rgb', 'alpha'):
                 assert torch.equal(torch.cat([p[key] for p in parts], 0), whole[key]), (world, key)
     assert float(whole['alpha'].max()) > 0.5
+
+def test_backward_over_every_row_mode_through_the_native_loop(dev):
+    """XR_MLP_LIVE=0 (read once per process: a child process here) runs the MLP backward and the scatter over every marched row -- same
+    results as the live-row list -- and has no list kernel: the native loop must then start its marches from the mark EVENT, not from the
+    word the list kernel would store (a march waiting for a word nobody stores runs into its 1.5-ms deadline every iteration)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import json, torch, sys; sys.path.insert(0, %r)\n"
+            "from xrnerf_amd.train import Trainer\n"
+            "tr = Trainer(torch.device('cuda:0'), n_img=3, H=128, W=128, seed=7)\n"
+            "tr.run(20); torch.cuda.synchronize()\n"
+            "a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)\n"
+            "a.record(); tr.run(3); tr.run(8); b.record(); torch.cuda.synchronize()\n"          # 20..30: no refresh inside
+            "t = tr.net.mlp.embedder_pos.params\n"
+            "print(json.dumps({'ms': a.elapsed_time(b) / 11, 'sum': float(t.double().sum()), 'abs': float(t.double().abs().sum())}))\n" % root)
+    out = {}
+    for live in ('1', '0'):
+        env = dict(os.environ, XR_MLP_LIVE=live)
+        r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[live] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out['0']['ms'] < 1.0 and out['1']['ms'] < 1.0, out
+    assert abs(out['0']['sum'] - out['1']['sum']) <= 1e-6 * out['1']['abs'], out

@@ -382,7 +382,9 @@ extern "C" int xr_ngp_loop_run(void* loop, const xr_ngp_loop_desc* desc, xr_ngp_
         at.step = ad.step = ac.step = S.adam_step;
         at.lr = ad.lr = ac.lr = lr[j];
         at.ema_momentum = ad.ema_momentum = ac.ema_momentum = ema_momentum[j];
-        const bool by_word = D.mark_word != nullptr && D.mark_entry && strcmp(D.mark_entry, "xr_live_rows") == 0;
+        // (XR_MLP_LIVE=0, the measurement mode without a live-row list, has no list kernel to store the word: event as before)
+        static const bool live_list = []() { const char* e = getenv("XR_MLP_LIVE"); return !(e && e[0] == '0'); }();
+        const bool by_word = live_list && D.mark_word != nullptr && D.mark_entry && strcmp(D.mark_entry, "xr_live_rows") == 0;
         const uint32_t word_value = (uint32_t)(it + 1);
         g_step_mark_word = by_word ? D.mark_word : nullptr; g_step_mark_value = word_value;
         xr_internal_scatter_join_also(next_march);
