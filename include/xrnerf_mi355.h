@@ -339,6 +339,14 @@ int xr_nerf_mlp_fwd_bf16x3(const float* enc_t, uint32_t ld, const float* dirs, u
                            const uint32_t* n_dev, const uint32_t* rows, const float* w_density, const float* w_color,
                            int n_hidden_density, int n_hidden_color, float pad_value, float* raw, void* stream);
 
+/* K9's density query and K8 in one launch (grid refresh: ngp_grid_sampler.py:103-137 -> hashnerf_mlp.py:107-111 +
+ * splat_grid_samples_nerf_max_nearest_neighbor.cu:7-28): the density network over n encoded points (enc_t as xr_hashgrid_fwd writes it),
+ * each result's optical thickness exp(density) * min_step merged into density_grid_tmp[indices[i]] by an order-free maximum from the
+ * forward kernel's epilogue -- the same values xr_splat_grid_samples would merge, without the [n,4] network output in HBM and without
+ * the 2^20-thread launch.  mlp_mode as in xr_ngp_train_step; topology (1, 2) only. */
+int xr_nerf_density_splat(int mlp_mode, const float* enc_t, uint32_t ld, uint32_t n, const float* w_density, int n_hidden_density,
+                          int n_hidden_color, const int32_t* indices, float* density_grid_tmp, void* stream);
+
 /* One training step's device work of HashNerfNetwork.train_step (networks/hashnerf.py:32-52, optimiser excluded) as ONE call:
  * xr_hashgrid_fwd -> xr_nerf_mlp_fwd[_f16] -> xr_composite_train2 (which counts the live rows per segment) -> xr_live_rows2 -> xr_nerf_mlp_bwd[_f16] ->
  * xr_hashgrid_bwd2(XR_SCATTER_OVERWRITE), on `stream`:

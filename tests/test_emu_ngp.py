@@ -100,6 +100,18 @@ def test_fused_mlp_on_the_host(O, edev):
         T.test_nerf_mlp_bwd(O, edev, n)
 
 
+def test_density_query_with_the_splat_inside_on_the_host(edev):
+    import test_gpu_tcnn as T
+    from xrnerf_amd import ops
+    for kind in ('bf16x3', 'mfma'):
+        old = ops.f32_forward()
+        ops.set_f32_forward(kind)
+        try:
+            T.test_density_query_with_the_splat_inside_equals_query_plus_splat(edev, 1000, kind)
+        finally:
+            ops.set_f32_forward(old)
+
+
 def test_deeper_topologies_on_the_host(O, edev):
     """(5, 5) -- tiny-cuda-nn's default depth -- and (3, 4): the layer-by-layer path on the emulated linear kernels"""
     import test_gpu_tcnn as T

@@ -496,3 +496,33 @@ def test_nerf_mlp_reference_precision_mode(dev, n):
         # one |g h| term (measured on the MI355X: none at n = 5000 / 8193 / 33000, one or two at 32768 / 40001 / 100000; the
         # colour output layer, which has no mask behind it, always agrees to 1e-4).  Bounded and rare:
         assert np.quantile(err, 0.99) <= 2e-3 * big and err.max() <= 0.2 * big, (name, err.max(), np.quantile(err, 0.99), big)
+
+
+@pytest.mark.parametrize('n', [1000, 40001])
+def test_density_query_with_the_splat_inside_equals_query_plus_splat(dev, n, f32_forward):
+    """xr_nerf_density_splat (K9's density query with K8 in the forward kernel's epilogue) against xr_nerf_mlp_fwd (density only) +
+    xr_splat_grid_samples: the same order-free maxima, cell for cell and bit for bit, heavy collisions included; in the fp16 mode too"""
+    from xrnerf_amd import ops, synthetic as S
+    meta = ops.GridMeta()
+    rng = np.random.default_rng(n)
+    table = T(S.hash_table(meta.n_params, scale=1.0), dev)
+    wd = T(S.mlp_weights(32, 64, 1, 16, seed=4) * 3.0, dev)
+    pts = T(rng.uniform(0, 1, (n, 3)).astype(np.float32), dev)
+    idx = rng.integers(0, 128 ** 3, n).astype(np.int32)
+    idx[:200] = idx[0]
+    idx_d = T(idx, dev)
+    modes = ['f32'] + (['f16'] if f32_forward == 'mfma' else [])
+    for mode in modes:
+        old = ops.precision()
+        ops.set_precision(mode)
+        try:
+            enc_t = ops.hashgrid_fwd(table, pts, meta)
+            raw = ops.nerf_mlp_fwd(enc_t, None, n, wd, None, 1, 2)
+            a = torch.zeros(128 ** 3, dtype=torch.float32, device=dev)
+            ops.splat_grid_samples(raw[:, 3:4], idx_d, raw.stride(0), n, a)
+            b = torch.zeros_like(a)
+            ops.nerf_density_splat(enc_t, n, wd, 1, 2, idx_d, b)
+        finally:
+            ops.set_precision(old)
+        assert torch.equal(a, b) and float(a.max()) > 0
+        assert int((a > 0).sum()) == len(np.unique(idx))

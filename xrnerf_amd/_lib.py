@@ -145,6 +145,7 @@ SIGNATURES = {
     'xr_kilo_mlp_backward': (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32,
                                     _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     'xr_nerf_render_forward': (_i32, [_vp, _vp, _vp, _u32, _u32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'xr_nerf_density_splat': (_i32, [_i32, _vp, _u32, _u32, _vp, _i32, _i32, _vp, _vp, _vp]),
     'xr_linear_forward': (_i32, [_vp, _vp, _vp, _u32, _u32, _u32, _i32, _vp, _vp]),
     'xr_linear_backward_input': (_i32, [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp]),
     'xr_linear_backward_input_t': (_i32, [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp]),

@@ -579,7 +579,8 @@ __global__ __launch_bounds__(MLP_THREADS, 3) void k_nerf_mlp_fwd(const float* __
                                                                const uint32_t* __restrict__ rows,
                                                                const float* __restrict__ w_density,
                                                                const float* __restrict__ w_color, float pad_value,
-                                                               float4* __restrict__ raw) {
+                                                               float4* __restrict__ raw, const int32_t* __restrict__ splat_idx,
+                                                               float* __restrict__ splat_grid) {
     if (n_dev) n = min(n, *n_dev);
     if (n == 0) return;
     using SD = NetShape<NHD>;
@@ -621,7 +622,12 @@ __global__ __launch_bounds__(MLP_THREADS, 3) void k_nerf_mlp_fwd(const float* __
             layer_fwd<2, 1>(wc + SC::lds_off(NHC), h, cout, col, hi);
             o.x = cout[0][0]; o.y = cout[0][1]; o.z = cout[0][2];   // rows 0,1,2 in the hi==0 half
         }
-        if (hi == 0 && s < n) raw[s] = o;
+        if (hi == 0 && s < n) {
+            // density-only launches of the grid refresh: K8 (splat_grid_samples_nerf_max_nearest_neighbor.cu:7-28) in the epilogue -- the
+            // sample's optical thickness at the smallest step goes straight into its cell's maximum, `raw` is not written
+            if (!WITH_COLOR && splat_idx != nullptr) atomicMax((uint32_t*)&splat_grid[(uint32_t)splat_idx[s]], __float_as_uint(expf(o.w) * xr_min_step()));
+            else raw[s] = o;
+        }
     }
 }
 
@@ -1216,7 +1222,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_nerf_mlp_fwd_h(const float* 
                                                                     const uint32_t* __restrict__ rows,
                                                                     const float* __restrict__ w_density,
                                                                     const float* __restrict__ w_color, float pad_value,
-                                                                    float4* __restrict__ raw) {
+                                                                    float4* __restrict__ raw, const int32_t* __restrict__ splat_idx,
+                                                                    float* __restrict__ splat_grid) {
     if (n_dev) n = min(n, *n_dev);
     if (n == 0) return;
     using HD = HShape<1>;
@@ -1267,7 +1274,12 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_nerf_mlp_fwd_h(const float* 
             layer_fwd_h<2, 1>(wc + HC::f_off(2), hh, cout, col, hi);
             o.x = cout[0][0]; o.y = cout[0][1]; o.z = cout[0][2];
         }
-        if (hi == 0 && s < n) raw[s] = o;
+        if (hi == 0 && s < n) {
+            // density-only launches of the grid refresh: K8 (splat_grid_samples_nerf_max_nearest_neighbor.cu:7-28) in the epilogue -- the
+            // sample's optical thickness at the smallest step goes straight into its cell's maximum, `raw` is not written
+            if (!WITH_COLOR && splat_idx != nullptr) atomicMax((uint32_t*)&splat_grid[(uint32_t)splat_idx[s]], __float_as_uint(expf(o.w) * xr_min_step()));
+            else raw[s] = o;
+        }
     }
 }
 
@@ -1571,7 +1583,8 @@ __global__ __launch_bounds__(BX_THREADS, 1) void k_nerf_mlp_fwd_b3(const float* 
                                                                     const uint32_t* __restrict__ rows,
                                                                     const float* __restrict__ w_density,
                                                                     const float* __restrict__ w_color, float pad_value,
-                                                                    float4* __restrict__ raw) {
+                                                                    float4* __restrict__ raw, const int32_t* __restrict__ splat_idx,
+                                                                    float* __restrict__ splat_grid) {
     if (n_dev) n = min(n, *n_dev);
     if (n == 0) return;
     using HD = HShape<1>;
@@ -1625,11 +1638,19 @@ __global__ __launch_bounds__(BX_THREADS, 1) void k_nerf_mlp_fwd_b3(const float* 
             layer_fwd_b3<2, 1>(wc + HC::f_off(2), PC, hh, cout, col, hi);
             o.x = cout[0][0]; o.y = cout[0][1]; o.z = cout[0][2];
         }
-        if (hi == 0 && s < n) raw[s] = o;
+        if (hi == 0 && s < n) {
+            // density-only launches of the grid refresh: K8 (splat_grid_samples_nerf_max_nearest_neighbor.cu:7-28) in the epilogue -- the
+            // sample's optical thickness at the smallest step goes straight into its cell's maximum, `raw` is not written
+            if (!WITH_COLOR && splat_idx != nullptr) atomicMax((uint32_t*)&splat_grid[(uint32_t)splat_idx[s]], __float_as_uint(expf(o.w) * xr_min_step()));
+            else raw[s] = o;
+        }
     }
 }
 
 // ------------------------------------------------------------------ host side
+// set around a density-only forward by xr_nerf_density_splat: the launch splats instead of writing `raw`
+static thread_local const int32_t* g_fwd_splat_idx = nullptr;
+static thread_local float* g_fwd_splat_grid = nullptr;
 static int g_cus = 0;
 extern "C" int xr_device_cus(void) {
     if (g_cus == 0) {
@@ -1654,12 +1675,12 @@ static int launch_fwd(const float* enc_t, uint32_t ld, const float* dirs, uint32
         const size_t lds = (NetShape<NHD>::lds_floats + NetShape<NHC>::lds_floats) * sizeof(float);
         auto k = k_nerf_mlp_fwd<NHD, NHC, true>;
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XR_EHIP;
-        hipLaunchKernelGGL(k, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev, rows, wd, wc, pad, (float4*)raw);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev, rows, wd, wc, pad, (float4*)raw, (const int32_t*)nullptr, (float*)nullptr);
     } else {
         const size_t lds = NetShape<NHD>::lds_floats * sizeof(float);
         auto k = k_nerf_mlp_fwd<NHD, NHC, false>;
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XR_EHIP;
-        hipLaunchKernelGGL(k, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev, rows, wd, wc, pad, (float4*)raw);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev, rows, wd, wc, pad, (float4*)raw, g_fwd_splat_idx, g_fwd_splat_grid);
     }
     return XR_OK;
 }
@@ -1895,11 +1916,11 @@ extern "C" int xr_nerf_mlp_fwd_f16(const float* enc_t, uint32_t ld, const float*
     if (dirs) {
         const size_t lds = (size_t)(HShape<1>::f_halves + HShape<2>::f_halves) * 2;
         hipLaunchKernelGGL(k_nerf_mlp_fwd_h<true>, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev,
-                           rows, w_density, w_color, pad_value, (float4*)raw);
+                           rows, w_density, w_color, pad_value, (float4*)raw, (const int32_t*)nullptr, (float*)nullptr);
     } else {
         const size_t lds = (size_t)HShape<1>::f_halves * 2;
         hipLaunchKernelGGL(k_nerf_mlp_fwd_h<false>, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev,
-                           rows, w_density, w_color, pad_value, (float4*)raw);
+                           rows, w_density, w_color, pad_value, (float4*)raw, g_fwd_splat_idx, g_fwd_splat_grid);
     }
     XR_LAUNCH_CHECK();
     return XR_OK;
@@ -1921,11 +1942,11 @@ extern "C" int xr_nerf_mlp_fwd_bf16x3(const float* enc_t, uint32_t ld, const flo
         const size_t lds = (size_t)3 * (HShape<1>::f_halves + HShape<2>::f_halves) * 2;
         if (mlp_set_lds((const void*)k_nerf_mlp_fwd_b3<true>, lds) != XR_OK) { xr_set_error("hipFuncSetAttribute failed"); return XR_EHIP; }
         hipLaunchKernelGGL(k_nerf_mlp_fwd_b3<true>, dim3(grid), dim3(BX_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev,
-                           rows, w_density, w_color, pad_value, (float4*)raw);
+                           rows, w_density, w_color, pad_value, (float4*)raw, (const int32_t*)nullptr, (float*)nullptr);
     } else {
         const size_t lds = (size_t)3 * HShape<1>::f_halves * 2;
         hipLaunchKernelGGL(k_nerf_mlp_fwd_b3<false>, dim3(grid), dim3(BX_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev,
-                           rows, w_density, w_color, pad_value, (float4*)raw);
+                           rows, w_density, w_color, pad_value, (float4*)raw, g_fwd_splat_idx, g_fwd_splat_grid);
     }
     XR_LAUNCH_CHECK();
     return XR_OK;
@@ -1959,4 +1980,22 @@ extern "C" int xr_nerf_mlp_bwd_f16(const float* enc_t, uint32_t ld, const float*
                            (uint32_t)NetShape<1>::glb_floats, grad_w_density, grad_w_color);
     XR_LAUNCH_CHECK();
     return XR_OK;
+}
+
+// K9's density query and K8 in one launch (grid refresh, ngp_grid_sampler.py:103-137 -> hashnerf_mlp.py:107-111 + splat_grid_samples...cu):
+// the density network over n encoded points (enc_t feature-major, as xr_hashgrid_fwd writes it), each result's optical thickness
+// exp(density) * min_step merged into density_grid_tmp[indices[i]] by an order-free maximum from the forward kernel's epilogue -- no
+// [n,4] network output through HBM, no separate 2^20-thread launch.  mlp_mode as in xr_ngp_train_step; topology (1, 2) only.
+extern "C" int xr_nerf_density_splat(int mlp_mode, const float* enc_t, uint32_t ld, uint32_t n, const float* w_density, int n_hidden_density,
+                                     int n_hidden_color, const int32_t* indices, float* density_grid_tmp, void* stream) {
+    if (n == 0) return XR_OK;
+    XR_REQUIRE(indices && density_grid_tmp, "null pointer");
+    XR_REQUIRE(n_hidden_density == 1 && n_hidden_color == 2, "the fused density query is built for the (1,2) hidden-layer topology");
+    g_fwd_splat_idx = indices; g_fwd_splat_grid = density_grid_tmp;
+    auto fwd = mlp_mode == 1 ? xr_nerf_mlp_fwd_f16 : mlp_mode == 2 ? xr_nerf_mlp_fwd_bf16x3 : xr_nerf_mlp_fwd;
+    // (`raw` is not written in this mode; the argument only has to pass the alignment check)
+    const int rc = fwd(enc_t, ld, nullptr, 0, n, nullptr, nullptr, w_density, nullptr, n_hidden_density, n_hidden_color, 1.0f,
+                       (float*)(((uintptr_t)density_grid_tmp + 15) & ~(uintptr_t)15), stream);
+    g_fwd_splat_idx = nullptr; g_fwd_splat_grid = nullptr;
+    return rc;
 }

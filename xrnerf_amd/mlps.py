@@ -192,6 +192,19 @@ class HashNerfMLP(nn.Module):
                              self.pad_value, raw=raw)
         return raw[:, 3:4]
 
+    def density_splat_planes(self, planes, indices, grid_tmp):
+        """the grid refresh's density query with K8 inside (ops.nerf_density_splat): positions as planes [3, n], each point's optical
+        thickness merged into grid_tmp[indices[i]]; False when this topology has no fused forward (the caller then queries and splats)"""
+        nhd, nhc = self.density_net.n_hidden, self.color_net.n_hidden
+        if not ops.density_splat_supported(nhd, nhc):
+            return False
+        n = planes.shape[1]
+        with torch.no_grad():
+            enc_t = ops._buf(planes.device, (self.embedder_pos.meta.n_output_dims, (n + 63) // 64 * 64), 'density_enc')
+            ops.hashgrid_fwd(self.embedder_pos.params.detach(), planes, self.embedder_pos.meta, enc_t=enc_t, ld=enc_t.shape[1])
+            ops.nerf_density_splat(enc_t, n, self.density_net.params.detach(), nhd, nhc, indices, grid_tmp)
+        return True
+
     def run_density(self, pts_flat):
         """hashnerf_mlp.py:107-111: encode + density_net, channel 0 -> [N,1] fp32 (no grad)."""
         pts = self._rows(pts_flat)

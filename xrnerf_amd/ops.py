@@ -741,6 +741,20 @@ def nerf_mlp_fwd(enc_t, dirs, n, w_density, w_color, nhd, nhc, pad_value=1.0, ra
     return raw
 
 
+def nerf_density_splat(enc_t, n, w_density, nhd, nhc, indices, grid_tmp):
+    """K9's density query + K8 in one launch: the density network over the n encoded points of enc_t, exp(density) * min_step merged into
+    grid_tmp[indices[i]] by maximum from the forward kernel's epilogue (fused topologies only: see density_splat_supported)"""
+    if indices.dtype != torch.int32 or grid_tmp.dtype != torch.float32:
+        raise _lib.XrError('nerf_density_splat: int32 indices, float32 grid')
+    with _span('xr_nerf_mlp_fwd', n, train=False):
+        _lib.check(_lib.load().xr_nerf_density_splat(_mlp_mode(nhd, nhc), _ptr(enc_t), enc_t.shape[1], n, _ptr(w_density), nhd, nhc, _ptr(indices),
+                                                     _ptr(grid_tmp), _stream()), 'xr_nerf_density_splat')
+
+
+def density_splat_supported(nhd, nhc):
+    return (nhd, nhc) in _FUSED_FWD and (nhd, nhc) == (1, 2)
+
+
 LIVE_STATS = None      # the backward's 4-word count block (words 1, 2: running live / valid row totals; clear to restart)
 
 

@@ -115,9 +115,12 @@ class NGPGridSampler(_FastAttr, nn.Module):
             positions, indices = po[:, :n_tot], io[:n_tot]
             with torch.no_grad():
                 for i in range(0, n_tot, self.update_block_size):
-                    density = mlp.run_density_planes(positions[:, i:i + self.update_block_size])
-                    ops.splat_grid_samples(density, indices[i:i + self.update_block_size], density.stride(0), density.shape[0],
-                                           self.density_grid_tmp)
+                    pos_i, idx_i = positions[:, i:i + self.update_block_size], indices[i:i + self.update_block_size]
+                    # K8 inside the density network's forward where the topology has a fused kernel (same maxima, one launch less)
+                    if hasattr(mlp, 'density_splat_planes') and mlp.density_splat_planes(pos_i, idx_i, self.density_grid_tmp):
+                        continue
+                    density = mlp.run_density_planes(pos_i)
+                    ops.splat_grid_samples(density, idx_i, density.stride(0), density.shape[0], self.density_grid_tmp)
         else:
             positions = torch.cat([pos_u, pos_n]) if n_nonuniform > 0 else pos_u
             indices = torch.cat([idx_u, idx_n]) if n_nonuniform > 0 else idx_u
