@@ -174,7 +174,9 @@ __global__ __launch_bounds__(RM_BLOCK) void k1_count(
 // lanes a window costs ~7 chain steps + one point evaluation + <= 8 replay steps instead of 8 point evaluations in a row.
 // (Round 3 tried 64 lanes per ray: 63 chain steps per window and 12.5 K waves made it no faster than the serial kernel.)
 // Same counts, same sample t's (bit for bit), same RNG draw; cnt / start_t / tlist as k1_count, the block scan is k1_block_scan.
+#ifndef K1W
 #define K1W 8
+#endif
 __global__ __launch_bounds__(RM_BLOCK) void k1_count_w(
     uint32_t n_rays, float lo, float hi, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
     const uint8_t* __restrict__ bitfield, float cone, float near_distance, xr_pcg32 rng, uint32_t rng_chunk, uint32_t rng_ray0,
@@ -423,7 +425,10 @@ extern "C" int xr_rays_sampler3(const float* rays_o, const float* rays_d, const 
     // per ray -- 8x the waves, each shorter: 174 -> 143 us at 12.5 K rays, 170 -> 121 at 4 K (profiles/r04_k1_lanes_per_ray_ab.txt).
     // Not beside the training step (the side-stream marches): 8x the waves slow the scatter they run beside by more than the march
     // gains (iteration 0.408 -> 0.424 ms); not for frames (65 K rays: 173 -> 280 us, the chip is full of rays either way).
-    if ((flags & XR_K1_WIDE) != 0u && (uint32_t)K1W_MAX_RAYS != 0u && n_rays <= (uint32_t)K1W_MAX_RAYS) {
+#ifndef K1W_ALWAYS
+#define K1W_ALWAYS 0           // 1: every launch of up to K1W_MAX_RAYS rays takes the K1W-lane kernel (A/B of K1W = 2 / 4 beside the training step)
+#endif
+    if (((flags & XR_K1_WIDE) != 0u || K1W_ALWAYS != 0) && (uint32_t)K1W_MAX_RAYS != 0u && n_rays <= (uint32_t)K1W_MAX_RAYS) {
         hipLaunchKernelGGL(k1_count_w, dim3(xr_div_up(n_rays * K1W, RM_BLOCK)), dim3(RM_BLOCK), 0, stream, n_rays, aabb0, aabb1, rays_o, rays_d,
                            bitfield, cone_angle, near_distance, rng, rng_chunk, rng_ray0, w.cnt, w.start_t, w.tlist);
         hipLaunchKernelGGL(k1_block_scan, dim3(nb), dim3(RM_BLOCK), 0, stream, n_rays, (const uint32_t*)w.cnt, w.local_off, w.block_tot);
