@@ -430,6 +430,9 @@ typedef struct xr_ngp_step_set {       /* one of the TWO alternating sets of ste
     float *enc_t, *raw, *draw, *denc_t, *rgb_out, *zero_block; size_t zero_floats;
     float *grad_w_density, *grad_w_color, *loss_mse; uint32_t* live_seg_count;
 } xr_ngp_step_set;
+/* rotating sets of batch / K1 buffers: the march runs two iterations ahead of the step that consumes it (three sets would do; the fourth
+ * measured 1 % faster with the event-ordered start, profiles/r04_event_cost_probe.txt) */
+#define XR_NGP_MARCH_SETS 4
 typedef struct xr_ngp_loop_desc {
     float *table, *w_density, *w_color; int n_hidden_density, n_hidden_color; float pad_value; int mlp_mode;
     int n_levels; const float* scale_host; const uint32_t *resolution_host, *offset_host;
@@ -439,7 +442,7 @@ typedef struct xr_ngp_loop_desc {
     uint32_t max_samples, max_compacted;                   /* K1's row capacity, K2's clip (= n_rows of the step) */
     const float* density_grid_mean; int rgb_activation, density_activation; float huber_delta, loss_scale;
     uint32_t n_rows, ld;
-    xr_ngp_march_set march[3]; xr_ngp_step_set step[2];
+    xr_ngp_march_set march[XR_NGP_MARCH_SETS]; xr_ngp_step_set step[2];
     void* ws_k1; size_t ws_k1_bytes; void* ws_mlp_bwd; size_t ws_mlp_bwd_bytes; void* ws_scatter; size_t ws_scatter_bytes;
     uint32_t* counter_host_pinned; uint32_t n_pinned;      /* ring of n_pinned (rays, samples) pairs in pinned host memory */
     void *stream, *side_stream;
@@ -448,16 +451,11 @@ typedef struct xr_ngp_loop_desc {
     const char* mark_entry;                                /* the entry point of the step behind which the march of iteration i + 2 may start
                                                               ("xr_live_rows": beside the MLP backward and the scatter; null: behind the end of
                                                               iteration i - 1 only, i.e. from the start of iteration i) */
-    uint32_t* mark_word;                                   /* nullable device word (zero-initialised).  With mark_entry "xr_live_rows": the steps of a
-                                                              window store their iteration number + 1 to it from the live-row list kernel instead of
-                                                              recording mark_event, and the side stream polls it (one wave, with a deadline) in front of
-                                                              the march: the start point is a preference about time, and an event record holds the
-                                                              step's queue for several microseconds per iteration */
 } xr_ngp_loop_desc;
 typedef struct xr_ngp_loop_state {     /* the counters the loop shares with its caller (read AND written) */
     uint64_t iter;                     /* next iteration */
     uint64_t k1_calls, batches_drawn, cur_ray;   /* RNG call indices of K1 / the batch generator, cursor into the ray table */
-    uint32_t march_launches;           /* training launches of K1 so far: the next one takes set (march_launches + 1) % 3 */
+    uint32_t march_launches;           /* training launches of K1 so far: the next one takes set (march_launches + 1) % XR_NGP_MARCH_SETS */
     uint32_t step_turn;                /* the next step takes set step_turn ^ 1 */
     int32_t adam_step;                 /* updates applied so far */
     uint32_t pinned_next;              /* next slot of the pinned ring */

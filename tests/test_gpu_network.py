@@ -463,8 +463,8 @@ def test_row_bands_of_a_frame_give_the_whole_frames_pixels(dev):
 
 def test_backward_over_every_row_mode_through_the_native_loop(dev):
     """XR_MLP_LIVE=0 (read once per process: a child process here) runs the MLP backward and the scatter over every marched row -- same
-    results as the live-row list -- and has no list kernel: the native loop must then start its marches from the mark EVENT, not from the
-    word the list kernel would store (a march waiting for a word nobody stores runs into its 1.5-ms deadline every iteration)."""
+    results as the live-row list -- through the native loop, at the speed of the list-less step (a start point of the march that depends
+    on a kernel this mode does not launch once cost it 1.5 ms per iteration)."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ("import json, torch, sys; sys.path.insert(0, %r)\n"

@@ -32,6 +32,9 @@ class StepSet(C.Structure):
                [(k, C.c_void_p) for k in ('grad_w_density', 'grad_w_color', 'loss_mse', 'live_seg_count')]
 
 
+MARCH_SETS = 4          # XR_NGP_MARCH_SETS
+
+
 class LoopDesc(C.Structure):
     """xr_ngp_loop_desc"""
     _fields_ = [('table', C.c_void_p), ('w_density', C.c_void_p), ('w_color', C.c_void_p), ('n_hidden_density', C.c_int),
@@ -43,12 +46,12 @@ class LoopDesc(C.Structure):
                 ('max_samples', C.c_uint32), ('max_compacted', C.c_uint32),
                 ('density_grid_mean', C.c_void_p), ('rgb_activation', C.c_int), ('density_activation', C.c_int),
                 ('huber_delta', C.c_float), ('loss_scale', C.c_float), ('n_rows', C.c_uint32), ('ld', C.c_uint32),
-                ('march', MarchSet * 3), ('step', StepSet * 2),
+                ('march', MarchSet * MARCH_SETS), ('step', StepSet * 2),
                 ('ws_k1', C.c_void_p), ('ws_k1_bytes', C.c_size_t), ('ws_mlp_bwd', C.c_void_p), ('ws_mlp_bwd_bytes', C.c_size_t),
                 ('ws_scatter', C.c_void_p), ('ws_scatter_bytes', C.c_size_t),
                 ('counter_host_pinned', C.c_void_p), ('n_pinned', C.c_uint32),
                 ('stream', C.c_void_p), ('side_stream', C.c_void_p), ('bitfield_event', C.c_void_p), ('mark_event', C.c_void_p),
-                ('mark_entry', C.c_char_p), ('mark_word', C.c_void_p)]
+                ('mark_entry', C.c_char_p)]
 
 
 class LoopState(C.Structure):

@@ -120,7 +120,6 @@ __host__ __device__ inline float xr_unwarp_dt(float dt) {   // ray_sampler_heade
 
 // library-internal (not part of the C ABI): see xr_mlp.hip
 void xr_internal_defer_mlp_reduce(bool on);
-void xr_internal_live_signal(uint32_t* word, uint32_t value);   // the next xr_live_rows2 of this thread stores value to word (a time hint)
 int xr_internal_mlp_bwd_reduce(const void* workspace, uint32_t n, float* grad_w_density, float* grad_w_color, int overwrite, void* stream);
 // see xr_scatter.hip: work the next xr_scatter3 call of this thread enqueues on its helper stream right after forking it (in
 // front of its own helper-stream kernels); `done` tells the caller whether a fork happened.  nullptr clears.

@@ -661,10 +661,7 @@ __global__ __launch_bounds__(LIVE_THREADS) void k_live_count(const float4* __res
 __global__ __launch_bounds__(LIVE_THREADS) void k_live_fill(const float4* __restrict__ draw, uint32_t n, const uint32_t* __restrict__ n_dev,
                                                            const uint32_t* __restrict__ seg_count, uint32_t n_seg,
                                                            uint32_t* __restrict__ live_rows, uint32_t* __restrict__ n_live,
-                                                           float* __restrict__ denc_t, uint32_t ld, uint32_t* signal, uint32_t signal_value) {
-    // "the step has reached its live-row list": a word another stream may poll (xr_step.hip, the march's start point) -- a hint about
-    // time, nothing is ordered by it
-    if (signal && blockIdx.x == 0 && threadIdx.x == 0) __atomic_store_n(signal, signal_value, __ATOMIC_RELAXED);
+                                                           float* __restrict__ denc_t, uint32_t ld) {
     if (n_dev) n = min(n, *n_dev);
     __shared__ uint32_t ws[LIVE_THREADS / 64], wbase[LIVE_THREADS / 64 + 1];
     // rows before this segment: sum of the earlier segments' counts
@@ -1733,10 +1730,6 @@ static bool live_rows_enabled() {          // XR_MLP_LIVE=0: run the backward ov
     return on == 1;
 }
 extern "C" size_t xr_live_rows_segments(uint32_t n) { return xr_div_up(n, LIVE_SEG); }
-// library-internal: the next xr_live_rows2 of this thread stores `value` to `word` from its list kernel (nullptr clears)
-static thread_local uint32_t* g_live_signal = nullptr;
-static thread_local uint32_t g_live_signal_value = 0;
-void xr_internal_live_signal(uint32_t* word, uint32_t value) { g_live_signal = word; g_live_signal_value = value; }
 // seg_counts_ready != 0: seg_count already holds the live rows per segment (xr_composite_train2 counted them while writing
 // the rows) -- only the ranking / list pass runs
 extern "C" int xr_live_rows2(const float* dloss_doutput, uint32_t n, const uint32_t* n_dev, uint32_t* seg_count, uint32_t* live_rows,
@@ -1750,7 +1743,7 @@ extern "C" int xr_live_rows2(const float* dloss_doutput, uint32_t n, const uint3
     if (!seg_counts_ready)
         hipLaunchKernelGGL(k_live_count, dim3(n_seg), dim3(LIVE_THREADS), 0, stream, (const float4*)dloss_doutput, n, n_dev, seg_count);
     hipLaunchKernelGGL(k_live_fill, dim3(n_seg), dim3(LIVE_THREADS), 0, stream, (const float4*)dloss_doutput, n, n_dev,
-                       (const uint32_t*)seg_count, n_seg, live_rows, n_live, zero_denc_t, ld, g_live_signal, g_live_signal_value);
+                       (const uint32_t*)seg_count, n_seg, live_rows, n_live, zero_denc_t, ld);
     XR_LAUNCH_CHECK();
     return XR_OK;
 }

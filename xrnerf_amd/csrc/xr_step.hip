@@ -42,10 +42,6 @@ extern "C" int xr_event_record(void* event, void* stream) {
 
 static bool stage_is(const char* timed, const char* name) { return timed && strcmp(timed, name) == 0; }
 
-// set by xr_ngp_loop_run around its steps: the start hint for the next march goes out as a word stored by the live-row list kernel
-// (see xr_loop_issue_march) instead of a record of mark_event
-static thread_local uint32_t* g_step_mark_word = nullptr;    // set by xr_ngp_loop_run around its steps
-static thread_local uint32_t g_step_mark_value = 0;
 extern "C" int xr_ngp_train_step(
     const float* table, const float* w_density, const float* w_color, int n_hidden_density, int n_hidden_color, float pad_value,
     int mlp_mode, int n_levels, const float* scale_host, const uint32_t* resolution_host, const uint32_t* offset_host,
@@ -94,8 +90,7 @@ extern "C" int xr_ngp_train_step(
     // starts the next batch's side-stream march from there instead of beside the fused-MLP forward)
     auto end = [&](const char* name) -> int {
         if (stage_is(timed_entry, name)) XR_HIP(hipEventRecord((hipEvent_t)timing_end, stream));
-        if (mark_event && stage_is(mark_entry, name) && !(g_step_mark_word && strcmp(name, "xr_live_rows") == 0))
-            XR_HIP(hipEventRecord((hipEvent_t)mark_event, stream));
+        if (mark_event && stage_is(mark_entry, name)) XR_HIP(hipEventRecord((hipEvent_t)mark_event, stream));
         return XR_OK;
     };
     int rc;
@@ -138,11 +133,7 @@ extern "C" int xr_ngp_train_step(
     if ((rc = end("xr_composite_train")) != XR_OK) return rc;
     if ((rc = begin("xr_live_rows")) != XR_OK) return rc;
     if (live_on) {
-        // (a caller that starts its next march "behind the live-row list" may take the hint from a word the list kernel stores instead
-        // of an event record on this stream: xr_loop_issue_march)
-        if (g_step_mark_word && stage_is(mark_entry, "xr_live_rows")) xr_internal_live_signal(g_step_mark_word, g_step_mark_value);
         rc = xr_live_rows2(draw, n_rows, n_dev, seg, rows, n_live, nullptr, ld, 1, stream_);
-        xr_internal_live_signal(nullptr, 0);
         if (rc != XR_OK) return rc;
     }
     if ((rc = end("xr_live_rows")) != XR_OK || (rc = begin("xr_nerf_mlp_bwd")) != XR_OK) return rc;
@@ -235,15 +226,15 @@ extern "C" int xr_ngp_prefetch(const float* rays_rgb_rows, uint32_t n_rays, uint
 // first iteration after a refresh is marched as soon as it is known ("at once"), the second behind the mark of the iteration the
 // caller just ran, all others two iterations ahead.
 struct XrLoop {
-    hipEvent_t march_done[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t iter_done[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t march_done[XR_NGP_MARCH_SETS] = {};
+    hipEvent_t iter_done[XR_NGP_MARCH_SETS] = {};
     hipEvent_t done_prev[2] = {nullptr, nullptr};          // end of iterations iter - 2, iter - 1 (own or the caller's)
     hipEvent_t join_covers = nullptr;                      // the march event the last step's helper-stream join waited for (inside a window)
 };
 
 extern "C" void* xr_ngp_loop_create(void) {
     XrLoop* L = new XrLoop();
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < XR_NGP_MARCH_SETS; ++i)
         if (hipEventCreateWithFlags(&L->march_done[i], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&L->iter_done[i], hipEventDisableTiming) != hipSuccess) { delete L; return nullptr; }
     return L;
@@ -251,7 +242,7 @@ extern "C" void* xr_ngp_loop_create(void) {
 extern "C" int xr_ngp_loop_destroy(void* loop) {
     if (!loop) return XR_OK;
     XrLoop* L = (XrLoop*)loop;
-    for (int i = 0; i < 3; ++i) { if (L->march_done[i]) (void)hipEventDestroy(L->march_done[i]); if (L->iter_done[i]) (void)hipEventDestroy(L->iter_done[i]); }
+    for (int i = 0; i < XR_NGP_MARCH_SETS; ++i) { if (L->march_done[i]) (void)hipEventDestroy(L->march_done[i]); if (L->iter_done[i]) (void)hipEventDestroy(L->iter_done[i]); }
     delete L;
     return XR_OK;
 }
@@ -259,9 +250,9 @@ extern "C" int xr_ngp_loop_destroy(void* loop) {
 // Hand-over between this loop and a caller that issues marches itself (Trainer's per-iteration path): the event the main stream waits
 // on for a march in `set` -- (a) handed out so that the caller can wait for a march this loop issued, (b) recorded on the side
 // stream NOW for a march the caller issued there earlier (the stream is in order: the record sits behind that march).
-extern "C" void* xr_ngp_loop_march_event(void* loop, uint32_t set) { return (loop && set < 3u) ? (void*)((XrLoop*)loop)->march_done[set] : nullptr; }
+extern "C" void* xr_ngp_loop_march_event(void* loop, uint32_t set) { return (loop && set < (uint32_t)XR_NGP_MARCH_SETS) ? (void*)((XrLoop*)loop)->march_done[set] : nullptr; }
 extern "C" int xr_ngp_loop_adopt_march(void* loop, uint32_t set, void* side_stream) {
-    XR_REQUIRE(loop && set < 3u, "bad set");
+    XR_REQUIRE(loop && set < (uint32_t)XR_NGP_MARCH_SETS, "bad set");
     XR_HIP(hipEventRecord(((XrLoop*)loop)->march_done[set], (hipStream_t)side_stream));
     return XR_OK;
 }
@@ -270,37 +261,11 @@ extern "C" int xr_ngp_loop_adopt_march(void* loop, uint32_t set, void* side_stre
 #define XR_LOOP_BATCH_FIRST 0     // 1: the batch assembly ahead of the march's start point (measured equal: the march then covers the whole MLP backward, 61 -> 77 us, and less of the scatter)
 #endif
 // the march of iteration `target` on the side stream: mirror of NGPGridSampler.prefetch_native + Trainer._issue
-// The march of iteration i + 2 should START when step i has reached its live-row list (beside the MLP backward and the scatter: measured
-// best, profiles/r04_march_start_point_ab.txt).  That is a preference about time, not an ordering requirement -- the march needs the buffer
-// set (buffer_free) and the bitfield, nothing of step i -- and an event record for it holds the step's queue for 7-8 us per iteration
-// (profiles/r04_trace_normal_iteration.txt: the only kernel boundaries of the iteration that are not back to back are the ones with an
-// event record or wait in them; tools/event_cost_probe.hip: ~3 us per record even between two kernels that do nothing else).  So the
-// step's list kernel stores the iteration number to a word (k_live_fill), and the side stream polls it with one wave, with a deadline:
-// a missed hint makes one march start early or XR_LOOP_WORD_TIMEOUT_US late, never wrong.
-#ifndef XR_LOOP_WORD_TIMEOUT_US
-#define XR_LOOP_WORD_TIMEOUT_US 1500u
-#endif
-#ifndef XR_LOOP_WORD_DELAY_US
-#define XR_LOOP_WORD_DELAY_US 15u       // the march starts this long after the hint (0 / 15 / 30 / 60 us measured: profiles/r04_event_cost_probe.txt)
-#endif
-__global__ void k_wait_word(const uint32_t* word, uint32_t value, unsigned long long ticks) {
-    if (threadIdx.x != 0) return;
-    const unsigned long long t0 = wall_clock64();           // 100 MHz
-    while ((int32_t)(__atomic_load_n(word, __ATOMIC_RELAXED) - value) < 0) {
-        if (wall_clock64() - t0 > ticks) return;
-        __builtin_amdgcn_s_sleep(64);
-    }
-    if (XR_LOOP_WORD_DELAY_US) {
-        const unsigned long long t1 = wall_clock64();
-        while (wall_clock64() - t1 < (unsigned long long)XR_LOOP_WORD_DELAY_US * 100ull) __builtin_amdgcn_s_sleep(32);
-    }
-}
-static int xr_loop_issue_march(XrLoop* L, const xr_ngp_loop_desc& D, xr_ngp_loop_state& S, uint32_t n_rays, hipEvent_t buffer_free, hipEvent_t start,
-                               const uint32_t* word = nullptr, uint32_t word_value = 0) {
+static int xr_loop_issue_march(XrLoop* L, const xr_ngp_loop_desc& D, xr_ngp_loop_state& S, uint32_t n_rays, hipEvent_t buffer_free, hipEvent_t start) {
     hipStream_t side = (hipStream_t)D.side_stream;
     if (D.bitfield_event) XR_HIP(hipStreamWaitEvent(side, (hipEvent_t)D.bitfield_event, 0));
     if (buffer_free) XR_HIP(hipStreamWaitEvent(side, buffer_free, 0));
-    const uint32_t set = (++S.march_launches) % 3u;
+    const uint32_t set = (++S.march_launches) % (uint32_t)XR_NGP_MARCH_SETS;
     const xr_ngp_march_set& M = D.march[set];
     if (S.cur_ray + n_rays > D.n_table_rays) S.cur_ray = 0;
     // xr_ngp_prefetch's three calls (XR_LOOP_BATCH_FIRST=1 puts the batch assembly ahead of the start point -- it needs the set's buffers
@@ -308,10 +273,6 @@ static int xr_loop_issue_march(XrLoop* L, const xr_ngp_loop_desc& D, xr_ngp_loop
     uint64_t st, inc;
     xr_pcg32_host_state(D.batch_seed, S.batches_drawn, &st, &inc);
     if (!XR_LOOP_BATCH_FIRST && start) XR_HIP(hipStreamWaitEvent(side, start, 0));
-    if (word) {                         // start point as a polled word (see k_wait_word): no event record on the step's stream
-        hipLaunchKernelGGL(k_wait_word, dim3(1), dim3(64), 0, side, (const uint32_t*)word, word_value, (unsigned long long)XR_LOOP_WORD_TIMEOUT_US * 100ull);
-        XR_LAUNCH_CHECK();
-    }
     int rc = xr_make_batch(D.rays_rgb_rows + (size_t)S.cur_ray * 11, n_rays, st, inc, M.rays_o, M.rays_d, M.target, M.alpha, M.bg, M.img_ids, side);
     if (rc != XR_OK) return rc;
     if (XR_LOOP_BATCH_FIRST && start) XR_HIP(hipStreamWaitEvent(side, start, 0));
@@ -382,12 +343,6 @@ extern "C" int xr_ngp_loop_run(void* loop, const xr_ngp_loop_desc* desc, xr_ngp_
         at.step = ad.step = ac.step = S.adam_step;
         at.lr = ad.lr = ac.lr = lr[j];
         at.ema_momentum = ad.ema_momentum = ac.ema_momentum = ema_momentum[j];
-        // (XR_MLP_LIVE=0, the measurement mode without a live-row list, has no list kernel to store the word: event as before)
-        static const bool live_list = []() { const char* e = getenv("XR_MLP_LIVE"); return !(e && e[0] == '0'); }();
-        const bool by_word = live_list && D.mark_word != nullptr && D.mark_entry && strcmp(D.mark_entry, "xr_live_rows") == 0;
-        const uint32_t word_value = (uint32_t)(it + 1);
-        g_step_mark_word = by_word ? D.mark_word : nullptr; g_step_mark_value = word_value;
-        xr_internal_scatter_join_also(next_march);
         rc = xr_ngp_train_step(D.table, D.w_density, D.w_color, D.n_hidden_density, D.n_hidden_color, D.pad_value, D.mlp_mode, D.n_levels, D.scale_host,
                                D.resolution_host, D.offset_host, M.coords, D.n_rows, M.n_valid, M.rays_numsteps, M.numsteps_clipped, n_rays, M.bg, M.target,
                                M.alpha, D.density_grid_mean, D.rgb_activation, D.density_activation, D.huber_delta, D.loss_scale, B.enc_t, D.ld, B.raw,
@@ -395,24 +350,20 @@ extern "C" int xr_ngp_loop_run(void* loop, const xr_ngp_loop_desc* desc, xr_ngp_
                                nullptr, 0, 0, D.ws_mlp_bwd, D.ws_mlp_bwd_bytes, D.ws_scatter, D.ws_scatter_bytes, 0, M.xyz_planes, M.plane_stride, &at,
                                &ad, &ac, D.mark_entry, D.mark_entry ? D.mark_event : nullptr, timed_entry, timed_entry ? timing_events[2 * j] : nullptr,
                                timed_entry ? timing_events[2 * j + 1] : nullptr, D.stream);
-        g_step_mark_word = nullptr;
         if (next_march && xr_internal_scatter_join_also_taken()) L->join_covers = next_march;
         xr_internal_scatter_join_also(nullptr);
         if (rc != XR_OK) return rc;
         // Trainer._on_sampled, depth 2: iteration it + 1 at once if nothing is queued for it, then it + 2 behind this step's mark
         if (S.queued == 0 && (it + 1) % f != 0)
             if ((rc = xr_loop_issue_march(L, D, S, n_rays, L->done_prev[1], nullptr)) != XR_OK) return rc;
-        if (S.queued == 1 && (it + 1) % f != 0 && (it + 2) % f != 0) {
-            if (by_word) rc = xr_loop_issue_march(L, D, S, n_rays, L->done_prev[1], nullptr, D.mark_word, word_value);
-            else rc = xr_loop_issue_march(L, D, S, n_rays, L->done_prev[1], D.mark_entry ? (hipEvent_t)D.mark_event : nullptr);
-            if (rc != XR_OK) return rc;
-        }
+        if (S.queued == 1 && (it + 1) % f != 0 && (it + 2) % f != 0)
+            if ((rc = xr_loop_issue_march(L, D, S, n_rays, L->done_prev[1], D.mark_entry ? (hipEvent_t)D.mark_event : nullptr)) != XR_OK) return rc;
         // "iteration `it` is over" orders the marches that are issued AT ONCE (the first ones of a window, the caller's after a refresh) behind
         // the steps that last read their buffer sets.  Inside a window every march starts behind the mark of a LATER step on this in-order
         // stream, which implies it: only the last two iterations of the window record the event (an event record holds the queue for ~3 us,
         // profiles/r04_event_cost_probe.txt).  Without a mark (march_after = start) every iteration records it.
         if (XR_LOOP_DONE_EVERY || !D.mark_entry || j + 2 >= k) {
-            hipEvent_t done = L->iter_done[it % 3u];
+            hipEvent_t done = L->iter_done[it % (uint64_t)XR_NGP_MARCH_SETS];
             XR_HIP(hipEventRecord(done, stream));
             L->done_prev[0] = L->done_prev[1]; L->done_prev[1] = done;
         }

@@ -353,13 +353,14 @@ class NGPGridSampler(_FastAttr, nn.Module):
     # K1 output buffers are persistent and owned by the sampler: slots 0..2 rotate over the TRAINING launches (a march may be
     # issued two iterations ahead -- Trainer, prefetch depth 2 -- while the two iterations before it still read their rows),
     # slot 3 serves test / render launches, which may come in between
-    N_SLOTS = 4
+    TRAIN_SLOTS = 4          # = XR_NGP_MARCH_SETS (include/xrnerf_mi355.h)
+    N_SLOTS = TRAIN_SLOTS + 1
 
     def _next_slot(self, is_training):
         if not is_training:
-            return 3
+            return self.TRAIN_SLOTS
         self._train_launches = getattr(self, '_train_launches', 0) + 1
-        return self._train_launches % 3
+        return self._train_launches % self.TRAIN_SLOTS
 
     def _coords_buffer(self, rows, slot):
         bufs = getattr(self, '_coords_bufs', None)

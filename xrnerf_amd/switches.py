@@ -7,7 +7,7 @@ a compile-time constant of one source (tools/build_variant.sh + XRNERF_LIB) or g
   XRNERF_DP                    allreduce (default) | allreduce_bf16 (the table gradient crosses the links as bf16) | zero1 -- the
                                data-parallel gradient exchange (train.Trainer, dist.py)
   XRNERF_TRAINER               "k=v,..." overrides of Trainer's keyword switches: native_loop, fuse_adam, direct_step, overlap_march,
-                               prefetch_depth, prefetch_k6, march_after, mark_by_word (A/B runs of bench.py / tools without editing code)
+                               prefetch_depth, prefetch_k6, march_after (A/B runs of bench.py / tools without editing code)
   XRNERF_STEP                  fused (default: one native call per training step) | py (the same entry points issued one by one from
                                Python: per-entry-point timers, the kernels' host build) | modular (sampler -> mlp -> render -> autograd)
   XRNERF_FRAME                 one_launch (default: a chunked test frame as one launch per kernel, same pixels) | async (the chunk loop
@@ -34,7 +34,7 @@ def frame_mode():
 
 
 TRAINER_KEYS = {'native_loop': bool, 'fuse_adam': bool, 'direct_step': bool, 'overlap_march': bool, 'prefetch_depth': int, 'prefetch_k6': bool,
-                'march_after': str, 'mark_by_word': bool}
+                'march_after': str}
 
 
 def trainer_overrides():

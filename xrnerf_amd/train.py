@@ -210,7 +210,7 @@ class Trainer:
     backward -> [gradient all-reduce] -> fused Adam(+EMA)."""
 
     def __init__(self, device, n_img=20, H=800, W=800, seed=0, world_size=1, rank=0, dataset=None, ema=True, native_loop=True,
-                 fuse_adam=True, direct_step=True, overlap_march=True, prefetch_depth=2, prefetch_k6=True, march_after='xr_live_rows', mark_by_word=True):
+                 fuse_adam=True, direct_step=True, overlap_march=True, prefetch_depth=2, prefetch_k6=True, march_after='xr_live_rows'):
         """The keyword switches (each overridable from the environment: XRNERF_TRAINER="fuse_adam=0,..."; xrnerf_amd/switches.py):
         native_loop     the iterations between two grid refreshes as native calls (xr_ngp_loop_run); False: one Python-driven step each
         fuse_adam       one GPU: the table scatter applies this optimiser's update itself (False: scatter, then the optimiser's launches)
@@ -223,7 +223,7 @@ class Trainer:
                         MLP backward, 0.423 from the step's start or behind the lookup / MLP forward: profiles/r04_march_start_point_ab.txt),
                         'xr_hashgrid_fwd', 'xr_nerf_mlp_fwd', 'xr_composite_train', 'xr_nerf_mlp_bwd', or 'start'"""
         opts = dict(native_loop=native_loop, fuse_adam=fuse_adam, direct_step=direct_step, overlap_march=overlap_march,
-                    prefetch_depth=prefetch_depth, prefetch_k6=prefetch_k6, march_after=march_after, mark_by_word=mark_by_word)
+                    prefetch_depth=prefetch_depth, prefetch_k6=prefetch_k6, march_after=march_after)
         opts.update(switches.trainer_overrides())
         if opts['prefetch_depth'] not in (1, 2):
             raise ValueError('prefetch_depth is 1 or 2')
@@ -275,9 +275,6 @@ class Trainer:
         if opts['march_after'] not in ('start', 'xr_hashgrid_fwd', 'xr_nerf_mlp_fwd', 'xr_composite_train', 'xr_live_rows', 'xr_nerf_mlp_bwd'):
             raise ValueError('march_after: unknown entry point %r' % opts['march_after'])
         self.march_after = opts['march_after']
-        # the native loop's start point as a word the step's list kernel stores and the side stream polls, instead of an event record on
-        # the step's stream (csrc/xr_step.hip, xr_loop_issue_march); only with march_after = 'xr_live_rows'
-        self.mark_by_word = bool(opts['mark_by_word'])
         self.net._step_mark = ((self.march_after, ops._CEvent(timing=False))
                                if (self.prefetch_depth == 2 and self.march_after != 'start' and device.type == 'cuda') else None)
         self.prefetch_k6 = opts['prefetch_k6']      # the refresh's K6 one iteration early, on the side stream
@@ -288,7 +285,7 @@ class Trainer:
         # ray table); anything else keeps the per-iteration path.
         self.native_loop = opts['native_loop']
         self._loop = None
-        self._bbufs = [None, None, None]
+        self._bbufs = [None] * 4                    # one per rotating set (samplers.NGPGridSampler.TRAIN_SLOTS)
         self._queue = []               # [(iteration, batch)] marched ahead, in order
         self._one = None
 
@@ -436,9 +433,9 @@ class Trainer:
         """draw the batch of iteration `target_iter` and march it on the side stream (behind `start_event` when given)"""
         net, data = self.net, self.data
         side = net.sampler.side_stream()
-        # the batch lives in the set the sampler's next training launch of K1 writes (one ring of three sets for both, shared with the
+        # the batch lives in the set the sampler's next training launch of K1 writes (one ring of four sets for both, shared with the
         # native loop: a marched batch is handed between the two paths by its set index)
-        bufs = self._batch_buffers((getattr(net.sampler, '_train_launches', 0) + 1) % 3, data.N_rand)
+        bufs = self._batch_buffers((getattr(net.sampler, '_train_launches', 0) + 1) % net.sampler.TRAIN_SLOTS, data.N_rand)
         if bufs is not None and hasattr(data, 'rays_rgb') and switches.step_mode() == 'fused':
             # the whole side-stream sequence (batch assembly, K1, K2 clip, counter copy) as one native call
             n = min(data.N_rand, data.rays_rgb.shape[0])
@@ -452,7 +449,7 @@ class Trainer:
             self._queue.append((target_iter, nb))
             return
         with torch.cuda.stream(side):
-            # these launches overwrite batch / coordinate buffers last read three iterations before their own (three persistent
+            # these launches overwrite batch / coordinate buffers last read four iterations before their own (four persistent
             # sets, rotating): ordered behind the completion event of the previous iteration
             if self._last_done() is not None:
                 side.wait_event(self._last_done())
@@ -511,7 +508,6 @@ class _NativeLoop:
         self.pinned = torch.zeros((self.N_PINNED, 2), dtype=torch.int32).pin_memory()
         self.enqueue_s, self.enqueued = 0.0, 0
         self._mark_dummy = None
-        self._mark_word = None
         self.issued = []                   # (object with .synchronize(), host [2] view) of the marches issued and not yet consumed, in order
         self._keep = None
 
@@ -526,7 +522,7 @@ class _NativeLoop:
         tr, S = self.tr, self.state
         sampler, data, net = tr.net.sampler, tr.data, tr.net
         S.iter, S.k1_calls, S.batches_drawn, S.cur_ray = tr.iter, sampler.k1_calls, data.batches_drawn, data.cur_i
-        S.march_launches = getattr(sampler, '_train_launches', 0) % 3
+        S.march_launches = getattr(sampler, '_train_launches', 0) % sampler.TRAIN_SLOTS
         S.step_turn = getattr(net, '_step_turn', 0) & 1
         S.adam_step = self._adam_steps()[0]
 
@@ -564,11 +560,11 @@ class _NativeLoop:
 
     # ------------------------------------------------------------------ hand-over of marched batches
     def _sets(self, n_rays, max_samples):
-        """the three rotating sets as the per-iteration path sees them: [(batch buffers, coords, (rays_index, numsteps, counter), (clipped, n_valid), xyz)]"""
+        """the rotating sets as the per-iteration path sees them: [(batch buffers, coords, (rays_index, numsteps, counter), (clipped, n_valid), xyz)]"""
         tr = self.tr
         sampler = tr.net.sampler
         return [(tr._batch_buffers(i, n_rays), sampler._coords_buffer(max_samples, i), sampler._small_buffers(n_rays, i),
-                 sampler._clip_buffers(n_rays, i), sampler._xyz_buffer(max_samples, i)) for i in range(3)]
+                 sampler._clip_buffers(n_rays, i), sampler._xyz_buffer(max_samples, i)) for i in range(sampler.TRAIN_SLOTS)]
 
     def _max_samples(self, n_rays):
         sampler = self.tr.net.sampler
@@ -667,9 +663,6 @@ class _NativeLoop:
             self._mark_dummy = ops._CEvent(timing=False)
         D.mark_event = mark[1].h if mark is not None else self._mark_dummy.h
         D.mark_entry = mark[0].encode() if mark is not None else None
-        if self._mark_word is None:
-            self._mark_word = torch.zeros((1,), dtype=torch.int32, device=dev)
-        D.mark_word = self._mark_word.data_ptr() if tr.mark_by_word else None
         self._hold = (sets, ws_k1, ws_mlp, ws_sc, bev, states)          # (what the pointers name stays alive)
         return D, msets, live_list, live_stats
 
