@@ -24,7 +24,7 @@ import os
 import torch
 from torch import nn
 
-from . import ops
+from . import _lib, ops
 from ._fastattr import _FastAttr
 from .builder import SAMPLERS
 
@@ -353,7 +353,7 @@ class NGPGridSampler(_FastAttr, nn.Module):
     # K1 output buffers are persistent and owned by the sampler: slots 0..2 rotate over the TRAINING launches (a march may be
     # issued two iterations ahead -- Trainer, prefetch depth 2 -- while the two iterations before it still read their rows),
     # slot 3 serves test / render launches, which may come in between
-    TRAIN_SLOTS = 4          # = XR_NGP_MARCH_SETS (include/xrnerf_mi355.h)
+    TRAIN_SLOTS = _lib.MARCH_SETS          # = XR_NGP_MARCH_SETS (include/xrnerf_mi355.h)
     N_SLOTS = TRAIN_SLOTS + 1
 
     def _next_slot(self, is_training):

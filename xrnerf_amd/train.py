@@ -285,7 +285,7 @@ class Trainer:
         # ray table); anything else keeps the per-iteration path.
         self.native_loop = opts['native_loop']
         self._loop = None
-        self._bbufs = [None] * 4                    # one per rotating set (samplers.NGPGridSampler.TRAIN_SLOTS)
+        self._bbufs = [None] * _lib.MARCH_SETS      # one per rotating set (samplers.NGPGridSampler.TRAIN_SLOTS)
         self._queue = []               # [(iteration, batch)] marched ahead, in order
         self._one = None
 
