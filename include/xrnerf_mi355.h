@@ -420,7 +420,7 @@ int xr_ngp_prefetch(const float* rays_rgb_rows, uint32_t n_rays, uint64_t batch_
  * It never crosses a grid refresh: an iteration = 0 (mod update_grid_freq) is the caller's (it changes the occupancy bitfield
  * the marches read and the batch size); marches are not issued across it either, so the queue is empty when the caller takes
  * over.  Everything is caller-owned; the library keeps only a few events per handle. */
-typedef struct xr_ngp_march_set {      /* one of the THREE rotating sets a marched batch lives in */
+typedef struct xr_ngp_march_set {      /* one of the rotating sets (XR_NGP_MARCH_SETS) a marched batch lives in */
     float *rays_o, *rays_d, *target, *alpha, *bg; int32_t* img_ids;        /* xr_make_batch outputs, >= n_rays rows */
     float* coords; int32_t *rays_index, *rays_numsteps; uint32_t* counter2; /* K1 outputs (coords: >= max_samples rows of 7) */
     int32_t* numsteps_clipped; uint32_t* n_valid;                           /* K2's clipped counts, device count of valid rows */
