@@ -9,7 +9,7 @@ import csv, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
 for r in csv.DictReader(open(sys.argv[1])):
     k = r['Kernel_Name'][:24]
-    if 'mlp_bwd' not in k: continue
+    if 'mlp_bwd' not in k and 'mlp_fwd' not in k: continue
     acc[k][r['Counter_Name']] += float(r['Counter_Value']); cnt[(k, r['Counter_Name'])] += 1
 for k in acc:
     print(k, {c: '%.4g' % (v / cnt[(k, c)]) for c, v in acc[k].items()})
