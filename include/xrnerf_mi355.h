@@ -86,6 +86,17 @@ int xr_rays_sampler3(const float* rays_o, const float* rays_d, const uint8_t* bi
 /* flags: XR_K1_WIDE = nothing else is running on the device (the march in place at a grid refresh): launches of up to 32 768 rays
  * use 8 lanes per ray (same samples bit for bit, a shorter critical path, 8x the waves) */
 #define XR_K1_WIDE 1u
+/* n_series launches of K1 over n_rays rays each as ONE launch per pass (blockIdx.y = launch): launch c reads rays_o / rays_d at row
+ * c * ray_stride, draws the jitter of the hidden generator's call (first + c) -- (rng_state, rng_inc) = the state of call `first`; the
+ * generator moves on by 2^32 per launch, ray_sampler.cu:198 -- and writes coords_out + 7 * c * coords_stride, rays_index / rays_numsteps at
+ * row c * ray_stride, counter2 + 2 * c and the three planes at xyz_planes + 3 * c * plane_stride: bit for bit what n_series calls of
+ * xr_rays_sampler2 write.  Launches of more than 65 536 rays are enqueued one after the other. */
+size_t xr_rays_sampler_series_workspace_bytes(uint32_t n_rays, uint32_t n_series);
+int xr_rays_sampler_series(const float* rays_o, const float* rays_d, uint32_t ray_stride, const uint8_t* bitfield, uint32_t n_rays,
+                           uint32_t n_series, float aabb0, float aabb1, float near_distance, float cone_angle, uint32_t max_samples,
+                           uint64_t rng_state, uint64_t rng_inc, float* coords_out, size_t coords_stride, int32_t* rays_index,
+                           int32_t* rays_numsteps, uint32_t* counter2, float* xyz_planes, uint32_t plane_stride, void* workspace,
+                           size_t workspace_bytes, void* stream);
 
 /* K2  compacted_coord_api (src/compacted_coord.cu:79-143, kernel :6-77).  The reference's
  * transmittance loop cannot influence any output (its `break` is commented out, :41-44), so
@@ -107,6 +118,10 @@ int xr_compacted_coord(const float* coords_in, const int32_t* numsteps_in, uint3
 int xr_clip_numsteps(const int32_t* numsteps_in, const uint32_t* counter2, uint32_t n_rays, uint32_t max_compacted,
                      int32_t* numsteps_out, uint32_t* n_valid_dev /*[1+n_chunks]*/, uint32_t chunk_rows,
                      uint32_t n_chunks, void* stream);
+/* ... for the n_series launches of xr_rays_sampler_series in one launch: numsteps arrays with ray_stride rows per launch, counter2
+ * [n_series][2], n_valid_dev [n_series][2] (both words = the launch's valid row count) */
+int xr_clip_numsteps_series(const int32_t* numsteps_in, const uint32_t* counter2, uint32_t n_rays, uint32_t n_series, uint32_t ray_stride,
+                            uint32_t max_compacted, int32_t* numsteps_out, uint32_t* n_valid_dev, void* stream);
 
 /* K3  calc_rgb_forward_api (src/calc_rgb.cu:208-264, kernel :6-67) */
 int xr_calc_rgb_forward(const float* network_output /*[S,4]*/, const float* coords /*[S,7]*/,
@@ -378,16 +393,13 @@ int xr_ngp_train_step(const float* table, const float* w_density, const float* w
                       float* grad_w_color, float* loss_mse, uint32_t* live_seg_count, float* grad_table, size_t table_floats, int zero_draw,
                       void* ws_mlp_bwd, size_t ws_mlp_bwd_bytes, void* ws_scatter, size_t ws_scatter_bytes, int scatter_level0,
                       const float* xyz_planes, uint32_t plane_stride, const xr_adam_fuse* table_adam, const xr_adam_fuse* w_density_adam,
-                      const xr_adam_fuse* w_color_adam, const char* mark_entry, void* mark_event, const char* timed_entry,
-                      void* timing_begin, void* timing_end, void* stream);
+                      const xr_adam_fuse* w_color_adam, const char* timed_entry, void* timing_begin, void* timing_end, void* stream);
 /* xyz_planes (nullable): the positions of `coords` once more as three planes of plane_stride floats (xr_rays_sampler2 /
- * xr_ngp_prefetch write them); the encoder then reads them with coalesced loads (xr_hashgrid_fwd2). */
+ * xr_ngp_window_march write them); the encoder then reads them with coalesced loads (xr_hashgrid_fwd2). */
 /* timed_entry (nullable): the name of ONE of the entry points the step runs ("xr_hashgrid_fwd", "xr_nerf_mlp_fwd",
  * "xr_composite_train", "xr_live_rows", "xr_nerf_mlp_bwd", "xr_hashgrid_bwd"): its launches are bracketed on `stream` by the two
  * events (xr_timing_event_create) -- bench.py's live duration of the dominant kernel inside the timed region.
  */
-/* mark_entry / mark_event (nullable): mark_event is recorded on `stream` right behind the launches of the named entry point, so
- * that work on another stream can be started from that point of the step (xr_stream_wait_event). */
 void* xr_timing_event_create(void);
 /* an event for ordering only (no timestamp taken: cheaper to record); destroy / wait with the calls of the timing events */
 void* xr_order_event_create(void);
@@ -398,86 +410,70 @@ int xr_timing_event_elapsed_ms(void* begin, void* end, float* ms);
 /* the second half of xr_nerf_mlp_bwd[_f16] on its own (sum of the per-workgroup dW partials in `workspace` into the gradients) */
 int xr_nerf_mlp_bwd_reduce(const void* workspace, uint32_t n, float* grad_w_density, float* grad_w_color, void* stream);
 
-/* The next batch's side-stream work as ONE call: xr_make_batch (rows = [n_rays,11] slice of the device-resident ray table;
- * generator = pcg32 seeded `batch_seed`, advanced `batch_call_index` calls) -> xr_rays_sampler (the reference's hidden
- * `static pcg32 rng{9121}`, advanced `k1_call_index` calls) -> xr_clip_numsteps(max_compacted) -> asynchronous copy of
- * counter2 to `counter_host_pinned` (nullable; pinned host memory).  Buffers as in the three calls. */
-int xr_ngp_prefetch(const float* rays_rgb_rows, uint32_t n_rays, uint64_t batch_seed, uint64_t batch_call_index, float* rays_o,
-                    float* rays_d, float* target, float* alpha, float* bg, int32_t* img_ids, const uint8_t* bitfield, float aabb0,
-                    float aabb1, float near_distance, float cone_angle, uint32_t max_samples, uint64_t k1_call_index,
-                    float* coords_out, int32_t* rays_index, int32_t* rays_numsteps, uint32_t* counter2, void* workspace,
-                    size_t workspace_bytes, uint32_t max_compacted, int32_t* numsteps_clipped, uint32_t* n_valid_dev,
-                    uint32_t* counter_host_pinned, float* xyz_planes, uint32_t plane_stride, void* stream);
-
 /* ------------------------------------------------------------------------------------------
- * The training LOOP between two grid refreshes as one call.  The reference's loop is mmcv's IterBasedRunner calling
- * HashNerfNetwork.train_step once per iteration (xrnerf/core/apis/train.py:58-66, networks/hashnerf.py:32-52) with three hooks
- * around it (core/hooks/hash_hook.py:12-42).  Driven from an interpreter the enqueue of one iteration costs 0.36 ms of host
- * time against 0.42 ms of device work; xr_ngp_loop_run enqueues k iterations -- batch draw (xr_make_batch), the march of
- * iteration i + 2 on the side stream (xr_ngp_prefetch, started behind iteration i's MLP backward), the step with the
- * optimiser's updates inside (xr_ngp_train_step with its three xr_adam_fuse) -- from native code: same entry points, same
- * order per stream, same RNG call indices, hence the same parameters bit for bit as k single calls.
- * It never crosses a grid refresh: an iteration = 0 (mod update_grid_freq) is the caller's (it changes the occupancy bitfield
- * the marches read and the batch size); marches are not issued across it either, so the queue is empty when the caller takes
- * over.  Everything is caller-owned; the library keeps only a few events per handle. */
-typedef struct xr_ngp_march_set {      /* one of the rotating sets (XR_NGP_MARCH_SETS) a marched batch lives in */
-    float *rays_o, *rays_d, *target, *alpha, *bg; int32_t* img_ids;        /* xr_make_batch outputs, >= n_rays rows */
-    float* coords; int32_t *rays_index, *rays_numsteps; uint32_t* counter2; /* K1 outputs (coords: >= max_samples rows of 7) */
-    int32_t* numsteps_clipped; uint32_t* n_valid;                           /* K2's clipped counts, device count of valid rows */
-    float* xyz_planes; uint32_t plane_stride;                               /* nullable: positions as planes */
-} xr_ngp_march_set;
+ * The marches of a refresh WINDOW as one series of launches, and the training LOOP between two grid refreshes as one call.
+ * The reference's loop is mmcv's IterBasedRunner calling HashNerfNetwork.train_step once per iteration
+ * (xrnerf/core/apis/train.py:58-66, networks/hashnerf.py:32-52) with three hooks around it (core/hooks/hash_hook.py:12-42); its
+ * sampler refreshes the occupancy bitfield at iterations = 0 (mod update_grid_freq = 16) only (samplers/ngp_grid_sampler.py:194-197) and
+ * changes the batch size at iterations = 15 (mod 16) only (:268-281), and K1 reads no weights (ray_sampler.cu:5-116).  So right behind a
+ * refresh every batch of the window can be drawn and marched: xr_ngp_window_march does that for up to XR_NGP_WINDOW iterations with ONE
+ * launch per kernel (batch assembly, K1 count, K1 write, K2 clip) and one copy of the (rays, samples) counters to pinned host memory --
+ * bit for bit the batches, samples and RNG call indices of one xr_make_batch / xr_rays_sampler2 / xr_clip_numsteps sequence per iteration.
+ * The window's buffers are caller-owned: chunk c (iteration it lives in chunk it % XR_NGP_WINDOW) sits at fixed strides. */
+#define XR_NGP_WINDOW 16
+typedef struct xr_ngp_window {
+    float *rays_o, *rays_d, *target, *alpha, *bg; int32_t* img_ids;   /* xr_make_batch outputs; chunk c at row c * ray_stride */
+    int32_t *rays_index, *rays_numsteps, *numsteps_clipped;           /* K1 / K2 per-ray outputs ([.,1], [.,2], [.,2]); chunk c at row c * ray_stride */
+    uint32_t ray_stride;                                              /* rows per chunk of the per-ray arrays (>= n_rays) */
+    float* coords; size_t coords_stride;                              /* chunk c: coords + 7 * c * coords_stride, coords_stride >= max_samples rows */
+    float* xyz_planes; uint32_t plane_stride;                         /* nullable; chunk c's plane k: xyz_planes + (3 c + k) * plane_stride */
+    uint32_t *counter2, *n_valid;                                     /* [XR_NGP_WINDOW][2] each: K1's (rays, samples), K2's valid row count (twice) */
+} xr_ngp_window;
+/* chunks [first_chunk, first_chunk + n_chunks): the first `batches_ready` of them already hold their batch (the caller drew it with
+ * xr_make_batch into the chunk's rows), the others are drawn here from the device-resident [n_table_rays, 11] table with the cursor
+ * *cur_ray (in / out; a batch that would run over the end starts at row 0) and the batch generator's call indices batch_call_index ...;
+ * K1 runs for all n_chunks with call indices k1_call_index ...; counter_host_pinned (nullable): [XR_NGP_WINDOW][2] pinned words,
+ * the chunks' pairs are copied to their slots.  workspace: xr_rays_sampler_series_workspace_bytes(n_rays, n_chunks). */
+int xr_ngp_window_march(const xr_ngp_window* window, uint32_t first_chunk, uint32_t n_chunks, uint32_t batches_ready, uint32_t n_rays,
+                        const float* rays_rgb_rows, uint64_t n_table_rays, uint64_t* cur_ray, uint64_t batch_seed, uint64_t batch_call_index,
+                        const uint8_t* bitfield, float aabb0, float aabb1, float near_distance, float cone_angle, uint32_t max_samples,
+                        uint64_t k1_call_index, uint32_t max_compacted, void* workspace, size_t workspace_bytes,
+                        uint32_t* counter_host_pinned, void* stream);
+/* n_series <= XR_NGP_WINDOW batches in one launch (the batch assembly of xr_ngp_window_march on its own) */
+int xr_make_batch_series(const float* rays_rgb_rows, const uint64_t* row0_host, uint32_t n, uint32_t n_series, uint32_t ray_stride,
+                         uint64_t rng_state, uint64_t rng_inc, float* rays_o, float* rays_d, float* target, float* alpha, float* bg,
+                         int32_t* img_ids, void* stream);
+
+/* Driven from an interpreter the enqueue of one iteration costs 0.36 ms of host time against 0.4 ms of device work; xr_ngp_loop_run
+ * enqueues k iterations -- each one xr_ngp_train_step on its chunk of the marched window, with the optimiser's updates inside (three
+ * xr_adam_fuse) -- from native code on ONE in-order stream: same entry points, same order, hence the same parameters bit for bit as k
+ * single calls.  The caller orders `stream` behind the window's marches once; nothing is allocated, recorded or waited for here. */
 typedef struct xr_ngp_step_set {       /* one of the TWO alternating sets of step buffers (see xr_ngp_train_step) */
     float *enc_t, *raw, *draw, *denc_t, *rgb_out, *zero_block; size_t zero_floats;
     float *grad_w_density, *grad_w_color, *loss_mse; uint32_t* live_seg_count;
 } xr_ngp_step_set;
-/* rotating sets of batch / K1 buffers: the march runs two iterations ahead of the step that consumes it (three sets would do; the fourth
- * measured 1 % faster with the event-ordered start, profiles/r04_event_cost_probe.txt) */
-#define XR_NGP_MARCH_SETS 4
 typedef struct xr_ngp_loop_desc {
     float *table, *w_density, *w_color; int n_hidden_density, n_hidden_color; float pad_value; int mlp_mode;
     int n_levels; const float* scale_host; const uint32_t *resolution_host, *offset_host;
     xr_adam_fuse adam_table, adam_w_density, adam_w_color;  /* tensors and constants; step / lr / ema_momentum are set per iteration */
-    const float* rays_rgb_rows; uint64_t n_table_rays; uint64_t batch_seed;   /* device-resident [n_table_rays, 11] ray table */
-    const uint8_t* bitfield; float aabb0, aabb1, near_distance, cone_angle;
-    uint32_t max_samples, max_compacted;                   /* K1's row capacity, K2's clip (= n_rows of the step) */
     const float* density_grid_mean; int rgb_activation, density_activation; float huber_delta, loss_scale;
-    uint32_t n_rows, ld;
-    xr_ngp_march_set march[XR_NGP_MARCH_SETS]; xr_ngp_step_set step[2];
-    void* ws_k1; size_t ws_k1_bytes; void* ws_mlp_bwd; size_t ws_mlp_bwd_bytes; void* ws_scatter; size_t ws_scatter_bytes;
-    uint32_t* counter_host_pinned; uint32_t n_pinned;      /* ring of n_pinned (rays, samples) pairs in pinned host memory */
-    void *stream, *side_stream;
-    void* bitfield_event;                                  /* nullable: recorded behind the last writer of `bitfield` */
-    void* mark_event;                                      /* xr_order_event_create: recorded behind `mark_entry` of every step */
-    const char* mark_entry;                                /* the entry point of the step behind which the march of iteration i + 2 may start
-                                                              ("xr_live_rows": beside the MLP backward and the scatter; null: behind the end of
-                                                              iteration i - 1 only, i.e. from the start of iteration i) */
+    uint32_t n_rows, ld;                                   /* rows of the step (= K2's clip), leading dimension of the feature planes */
+    xr_ngp_window window; xr_ngp_step_set step[2];
+    void* ws_mlp_bwd; size_t ws_mlp_bwd_bytes; void* ws_scatter; size_t ws_scatter_bytes;
+    void* stream;
 } xr_ngp_loop_desc;
 typedef struct xr_ngp_loop_state {     /* the counters the loop shares with its caller (read AND written) */
     uint64_t iter;                     /* next iteration */
-    uint64_t k1_calls, batches_drawn, cur_ray;   /* RNG call indices of K1 / the batch generator, cursor into the ray table */
-    uint32_t march_launches;           /* training launches of K1 so far: the next one takes set (march_launches + 1) % XR_NGP_MARCH_SETS */
     uint32_t step_turn;                /* the next step takes set step_turn ^ 1 */
     int32_t adam_step;                 /* updates applied so far */
-    uint32_t pinned_next;              /* next slot of the pinned ring */
-    uint32_t queued;                   /* marches issued ahead: iterations iter .. iter + queued - 1 (0, 1 or 2) */
-    uint32_t queue_set[2];             /* ... and the sets they live in */
-    uint32_t last_march_set, last_step_set;   /* (out) the sets iteration iter - 1 used */
+    uint32_t last_step_set;            /* (out) the set iteration iter - 1 used */
 } xr_ngp_loop_state;
-void* xr_ngp_loop_create(void);
-int xr_ngp_loop_destroy(void* loop);
-/* k iterations iter .. iter + k - 1, none of them = 0 (mod update_grid_freq); n_rays = this window's batch size;
- * lr / ema_momentum: k values each (the schedules are the caller's).  ext_done_prev2 / ext_done_prev1 (nullable): events the
- * CALLER recorded on `stream` at the end of iterations iter - 2 / iter - 1 when it ran those itself (a march overwrites the set
- * iteration i - 3 read: it is ordered behind the end of i - 1); null = the loop's own record of that iteration.
+/* k <= XR_NGP_WINDOW iterations iter .. iter + k - 1, all of them marched (chunks iter % XR_NGP_WINDOW ...); n_rays = the window's batch
+ * size; lr / ema_momentum: k values each (the schedules are the caller's).
  * timed_entry + timing_events [2k] (nullable): one entry point of every step bracketed by a pair of timing events;
  * iter_events [k + 1] (nullable): timing events recorded on `stream` in front of every iteration and behind the last. */
-/* hand-over with a caller that issues marches itself: the event behind the march in `set` (to wait on), and its record on the side
- * stream for a march the caller enqueued there earlier */
-void* xr_ngp_loop_march_event(void* loop, uint32_t set);
-int xr_ngp_loop_adopt_march(void* loop, uint32_t set, void* side_stream);
-int xr_ngp_loop_run(void* loop, const xr_ngp_loop_desc* desc, xr_ngp_loop_state* state, uint32_t k, uint32_t n_rays,
-                    uint32_t update_grid_freq, const float* lr, const float* ema_momentum, void* ext_done_prev2, void* ext_done_prev1,
-                    const char* timed_entry, void* const* timing_events, void* const* iter_events);
+int xr_ngp_loop_run(const xr_ngp_loop_desc* desc, xr_ngp_loop_state* state, uint32_t k, uint32_t n_rays, const float* lr,
+                    const float* ema_momentum, const char* timed_entry, void* const* timing_events, void* const* iter_events);
 
 /* tcnn.Network(FullyFusedMLP) on its own (compatibility surface; the hot path uses the fused kernels above):
  * x [n, n_in] with arbitrary row / column strides (in floats), n_in <= 32, missing input columns = pad_value;

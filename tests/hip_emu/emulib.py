@@ -44,9 +44,8 @@ def check(rc, L):
         raise RuntimeError('rc=%d: %s' % (rc, L.xr_last_error().decode()))
 
 
-HOST_ONLY = ('xr_ngp_train_step', 'xr_ngp_prefetch', 'xr_timing_event_create', 'xr_order_event_create', 'xr_timing_event_destroy', 'xr_timing_event_elapsed_ms',
-             'xr_stream_wait_event', 'xr_event_record', 'xr_ngp_loop_create', 'xr_ngp_loop_destroy', 'xr_ngp_loop_run', 'xr_ngp_loop_march_event',
-             'xr_ngp_loop_adopt_march')
+HOST_ONLY = ('xr_ngp_train_step', 'xr_ngp_window_march', 'xr_timing_event_create', 'xr_order_event_create', 'xr_timing_event_destroy',
+             'xr_timing_event_elapsed_ms', 'xr_stream_wait_event', 'xr_event_record', 'xr_ngp_loop_run')
 ALL_SOURCES = ('xr_misc', 'xr_grid', 'xr_raymarch', 'xr_encode', 'xr_mlp', 'xr_mip', 'xr_kilo', 'xr_gemm')
 
 

@@ -36,6 +36,12 @@ def test_k1_cascades_overflow_and_k2_on_the_host(O, lego, edev):
     T.test_k1_overflow_and_k2_clip(O, lego, edev)
 
 
+def test_window_march_equals_one_launch_per_iteration_on_the_host(lego, edev):
+    """the series kernels (blockIdx.y = iteration of a refresh window) against one launch per iteration, on the host"""
+    import test_gpu_raymarch as T
+    T.test_window_march_equals_one_launch_per_iteration(lego, edev)
+
+
 def test_k1_one_launch_stands_for_a_series_of_chunk_launches(lego, edev):
     """rng_chunk: rays i of ONE launch draw the jitter they would draw as ray i % chunk of launch i / chunk of a series (the
     reference marches a frame in `chunk`-sized launches, advancing its hidden generator once per launch): same samples"""

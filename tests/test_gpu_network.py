@@ -90,12 +90,13 @@ def test_training_reduces_loss_and_renders(dev):
     assert torch.equal(tr2.net.mlp.embedder_pos.params, tr.net.mlp.embedder_pos.params)
 
 
-def test_overlapped_march_matches_serial(dev):
-    """K1 of batch i+1 on a side stream under iteration i's backward (Trainer.overlap_march) must not
-    change what is computed: same sample counts exactly, same losses up to atomic-order rounding."""
+def test_window_march_matches_marches_in_place(dev):
+    """The marches of a refresh window issued right behind the refresh as one series of launches on a side stream
+    (Trainer.march_window = 'side') must not change what is computed: same sample counts exactly, same losses up to
+    summation-order rounding."""
     a, b = make(dev), make(dev)
     b.net.load_state_dict(a.net.state_dict())
-    a.overlap_march, b.overlap_march = True, False
+    a.march_window, b.march_window = 'side', 'off'
     la, lb, na, nb = [], [], [], []
     for _ in range(40):
         la.append(a.step()['log_vars']['loss']); na.append(a.net.sampler.n_valid_dev.clone())
@@ -116,6 +117,7 @@ def test_early_terminated_render_within_eps_of_full_render(dev):
     for _ in range(150):
         tr.step()
     sampler = tr.net.sampler
+    sampler.rewind_marches()                     # (what the first test-mode launch would do: the window's marches ahead are taken back)
     calls = sampler.k1_calls
     full_rgb, full_a = render_frame(tr.net, tr.data.poses[1], 96, 96, tr.data.focal)
     sampler.k1_calls = calls                     # same hidden-RNG position -> same jittered samples
@@ -226,7 +228,7 @@ def test_gradient_buffers_survive_callers_that_keep_their_gradients(dev):
         else:
             os.environ.pop('XRNERF_STEP', None)
         tr = Trainer(dev, n_img=3, H=128, W=128, ema=False)
-        tr.overlap_march = False
+        tr.march_window = 'off'
         tr.net.sampler.on_sampled = None
         for _ in range(2):
             tr.step()                                                # past the first refresh: a real occupancy grid
@@ -259,6 +261,7 @@ def test_chunked_frame_without_per_chunk_readback_gives_the_same_pixels(dev, tra
         tr.step()
     net, pose = tr.net, tr.data.poses[1]
     H = W = 160                                                    # 25 600 rays = 7 chunks of 4096
+    net.sampler.rewind_marches()                                   # (a test-mode launch takes the marches issued ahead back first)
     k1 = net.sampler.k1_calls
     monkeypatch.setenv('XRNERF_FRAME', 'sync')
     rgb_s, a_s = render_frame(net, pose, H, W, tr.data.focal * H / 128, chunk=4096)             # the reference's loop, one read-back per chunk
@@ -326,28 +329,58 @@ def test_refresh_samples_generated_one_iteration_early_leave_the_trajectory_alon
     assert torch.equal(ga, gb) and torch.equal(ba, bb)
 
 
-def test_march_two_iterations_ahead_leaves_the_trajectory_alone(dev, monkeypatch):
-    """Prefetch depth 2 (the march of iteration i + 2 issued during iteration i, started behind its MLP backward; three rotating buffer
-    sets) against depth 1 over 40 iterations -- two grid refreshes, two batch-size updates, the iterations that cannot be marched
-    two ahead in between: the same batches, the same RNG call order, bit-identical parameters and sampler state."""
+def test_window_march_leaves_the_trajectory_alone(dev, monkeypatch):
+    """march_window = 'side' (the rest of a refresh window drawn and marched as one series of launches on a side stream, beside the
+    refresh iteration's step), 'main' (the same series on the compute stream) and 'off' (every iteration marches in place) over 40
+    iterations -- three grid refreshes, two batch-size updates: the same batches, the same RNG call indices per iteration,
+    bit-identical parameters and sampler state; the window forms have marched the iterations up to the next refresh already."""
     from xrnerf_amd.train import Trainer
     out = []
-    for depth in ('2', '1'):
-        tr = Trainer(dev, n_img=3, H=128, W=128, seed=5, prefetch_depth=int(depth))
-        assert tr.prefetch_depth == int(depth)
+    for mode in ('side', 'main', 'off'):
+        tr = Trainer(dev, n_img=3, H=128, W=128, seed=5, march_window=mode, native_loop=False)
+        assert tr.march_window == mode
         hist = []
         for _ in range(40):
             tr.step()
-            hist.append((tr.net.sampler.n_rays_per_batch, tr.net.sampler.k1_calls, tr.data.batches_drawn if hasattr(tr.data, 'batches_drawn') else 0))
+            hist.append((tr.net.sampler.n_rays_per_batch, tr.net.sampler.k1_calls, tr.data.batches_drawn))
         torch.cuda.synchronize()
         out.append(([p.detach().clone() for p in tr.net.parameters()], tr.net.sampler.density_grid.clone(),
-                    tr.net.sampler.density_grid_bitfield.clone(), hist))
-    (pa, ga, ba, ha), (pb, gb, bb, hb) = out
-    assert [h[0] for h in ha] == [h[0] for h in hb]                  # rays per batch, iteration by iteration
-    assert ha[-1][1] == hb[-1][1] + 1                                 # one more march in flight, nothing else
-    for a, b in zip(pa, pb):
-        assert torch.equal(a, b)
-    assert torch.equal(ga, gb) and torch.equal(ba, bb)
+                    tr.net.sampler.density_grid_bitfield.clone(), hist, tr.samples_done))
+    ref = out[2]
+    for o in out[:2]:
+        assert [h[0] for h in o[3]] == [h[0] for h in ref[3]]              # rays per batch, iteration by iteration
+        assert o[3][-1][1] == ref[3][-1][1] + 8 and o[3][-1][2] == ref[3][-1][2] + 8     # iterations 40..47 are marched already
+        assert o[3][15][1] == ref[3][15][1] and o[3][31][1] == ref[3][31][1]            # nothing is marched across a refresh
+        for a, b in zip(o[0], ref[0]):
+            assert torch.equal(a, b)
+        assert torch.equal(o[1], ref[1]) and torch.equal(o[2], ref[2]) and o[4] == ref[4]
+
+
+def test_frame_rendered_inside_a_window_rewinds_the_marches(dev):
+    """The reference's hidden K1 generator is shared by training and test launches: a frame rendered between iterations j - 1 and j
+    moves the jitter of iteration j on.  With the window marched ahead, a test-mode launch takes the marches of j.. back (RNG call
+    index, batch cursor) and the trainer marches what is left of the window again: bit-identical trajectory to marching in place,
+    on the per-iteration path and through the native loop."""
+    from xrnerf_amd.train import Trainer, render_frame
+    out = []
+    for mode, native in (('off', False), ('side', False), ('side', True), ('main', True)):
+        tr = Trainer(dev, n_img=3, H=128, W=128, seed=9, march_window=mode, native_loop=native)
+        frames = []
+        for stop in (5, 16, 23, 31, 36):
+            tr.run(stop - tr.iter)
+            rgb, _ = render_frame(tr.net, tr.data.poses[1], 48, 48, tr.data.focal * 48 / 128)
+            frames.append(rgb.clone())
+        tr.run(40 - tr.iter)
+        torch.cuda.synchronize()
+        out.append(([p.detach().clone() for p in tr.net.parameters()], frames, tr.net.sampler.density_grid_bitfield.clone(),
+                    tr.net.sampler.n_rays_per_batch, tr.rays_done, tr.samples_done))
+    ref = out[0]
+    for o in out[1:]:
+        for a, b in zip(o[0], ref[0]):
+            assert torch.equal(a, b)
+        for a, b in zip(o[1], ref[1]):
+            assert torch.equal(a, b)
+        assert torch.equal(o[2], ref[2]) and o[3:] == ref[3:]
 
 
 def _trainer_state(tr):
@@ -360,8 +393,8 @@ def _trainer_state(tr):
 
 
 def test_native_loop_between_refreshes_equals_the_per_iteration_path(dev, monkeypatch):
-    """xr_ngp_loop_run enqueues the iterations between two grid refreshes from native code (batch draw, march two iterations ahead,
-    step with the updates inside).  41 iterations -- refreshes at 0, 16, 32, two batch-size updates -- as (a) per-iteration Python
+    """xr_ngp_loop_run enqueues the iterations between two grid refreshes from native code (the steps on the marched window, with the
+    updates inside).  41 iterations -- refreshes at 0, 16, 32, two batch-size updates -- as (a) per-iteration Python
     path, (b) Trainer.run over whole windows, (c) single step() calls that go through the native loop one iteration at a time,
     (d) windows cut at odd places with a multi-stage KernelTimer forcing the per-iteration path in between (marched batches are
     handed over in both directions): parameters, Adam moments, EMA copies, occupancy grids, every RNG / batch counter and the
@@ -381,13 +414,13 @@ def test_native_loop_between_refreshes_equals_the_per_iteration_path(dev, monkey
             tr.run(30)
             last = tr.run(4)
         else:
-            tr.run(5)                                         # 0 (Python) + 1..4 native: marches for 5, 6 are queued natively
+            tr.run(5)                                         # 0 (Python, marches 1..15) + 1..4 native
             ops.TIMER = ops.KernelTimer(only={'xr_hashgrid_fwd', 'xr_nerf_mlp_fwd'}, train_only=True)     # two stages: per-iteration path
             try:
-                tr.run(3)                                     # 5, 6, 7 through Python (takes the native queue over, issues 8, 9 itself)
+                tr.run(3)                                     # 5, 6, 7 through Python (the same queue of marched iterations)
             finally:
                 ops.TIMER = None
-            tr.run(2)                                         # 8, 9 native again (adopts the Python queue)
+            tr.run(2)                                         # 8, 9 native again
             ops.TIMER = ops.KernelTimer(only={'xr_hashgrid_bwd'}, train_only=True)                         # one stage: stays native
             try:
                 tr.run(20)
@@ -441,6 +474,7 @@ def test_row_bands_of_a_frame_give_the_whole_frames_pixels(dev):
     o, d = ops.gen_rays(tr.data.poses[1], H, W, tr.data.focal * H / 128, tr.data.focal * H / 128, 0.5 * W, 0.5 * H, device=dev)
     frame = {'rays_o': o, 'rays_d': d, 'img_ids': torch.zeros((H * W, 1), dtype=torch.int32, device=dev)}
     net.chunk = 4096
+    net.sampler.rewind_marches()                                    # (a test-mode launch takes the marches issued ahead back first)
     k1 = net.sampler.k1_calls
     with torch.no_grad():
         whole = net.batchify_forward(dict(frame), is_test=True)

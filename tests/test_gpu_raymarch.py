@@ -93,6 +93,58 @@ def test_k1_overflow_and_k2_clip(O, lego, dev):
         assert np.array_equal(bits(gc.cpu().numpy()[:kept]), bits(oc[:kept]))
 
 
+def test_window_march_equals_one_launch_per_iteration(lego, dev):
+    """xr_ngp_window_march: the batches and marches of several iterations as ONE series of launches (blockIdx.y = iteration) are bit for
+    bit the batches, samples, counters and clipped counts of one xr_make_batch / xr_rays_sampler / xr_clip_numsteps sequence per
+    iteration with consecutive RNG call indices -- a batch size that is not a multiple of the 256-ray block, the table cursor wrapping
+    inside the series, a launch whose samples overflow its buffer, a series that starts in the middle of the window."""
+    from xrnerf_amd import ops, synthetic as S
+    n, n_table = 300, 1000
+    o, d, _ = S.training_rays(lego['poses'], n_table, seed=3)
+    rng = np.random.default_rng(0)
+    table = np.concatenate([o, d, rng.uniform(0, 1, (n_table, 4)), rng.integers(0, 20, (n_table, 1))], 1).astype(np.float32)
+    tt, bf = T(table, dev), T(lego['bitfield'], dev)
+    planes = dev.type == 'cuda'
+    for max_samples, first, chunks, ready in ((n * 64, 3, 5, 0), (2500, 0, 4, 0), (n * 64, 11, 5, 1)):
+        win = ops.MarchWindow(dev, 384, max(max_samples, 4096), planes=planes)
+        cur0, b0, k0, clip = 450, 7, 21, 2000
+        if ready:          # the first chunk's batch is already in place (drawn by the caller)
+            ops.make_batch(tt[cur0:cur0 + n], n, b0, out=win.batch_out(first))
+            end = ops.ngp_window_march(win, first, chunks, 1, n, tt, cur0 + n, b0 + 1, bf, (0.0, 1.0), 0.05, 1.0 / 256, max_samples, k0, clip)
+        else:
+            end = ops.ngp_window_march(win, first, chunks, 0, n, tt, cur0, b0, bf, (0.0, 1.0), 0.05, 1.0 / 256, max_samples, k0, clip)
+        torch.cuda.synchronize()
+        cur, overflowed = cur0, 0
+        for j in range(chunks):
+            if cur + n > n_table:
+                cur = 0
+            b = ops.make_batch(tt[cur:cur + n], n, b0 + j)
+            cur += n
+            c, ri, ns, cnt = ops.rays_sampler(b['rays_o'], b['rays_d'], bf, (0.0, 1.0), 0.05, 1.0 / 256, max_samples, k0 + j)
+            cl, nv = ops.clip_numsteps(ns, cnt, clip)
+            torch.cuda.synchronize()
+            w = win.batch(first + j, n)
+            for key in b:
+                assert torch.equal(w[key], b[key]), (key, j)
+            s = min(int(cnt[1]), max_samples)
+            overflowed += int(cnt[1]) > max_samples
+            assert torch.equal(win.counter2[first + j], cnt) and torch.equal(win.numsteps[first + j, :n], ns), j
+            assert torch.equal(win.rays_index[first + j, :n], ri) and torch.equal(win.clipped[first + j, :n], cl), j
+            assert torch.equal(win.n_valid[first + j], nv), j
+            assert s > 0
+            # rows of rays that were dropped for overflow are not written by either form: compare the rows the counts name
+            keep = ns[:, 0] > 0
+            for i in torch.nonzero(keep)[:, 0].tolist()[:400]:
+                b_, k_ = int(ns[i, 1]), int(ns[i, 0])
+                assert torch.equal(win.coords[first + j, b_:b_ + k_].view(torch.int32), c[b_:b_ + k_].view(torch.int32)), (j, i)
+                if win.xyz is not None:
+                    assert torch.equal(win.xyz[first + j][:, b_:b_ + k_].t().contiguous().view(torch.int32), c[b_:b_ + k_, :3].contiguous().view(torch.int32))
+            if win.pinned is not None:
+                assert win.pinned[first + j].tolist() == cnt.tolist()
+        assert end == cur
+        assert (overflowed > 0) == (max_samples == 2500)
+
+
 def make_samples(O, lego, n_rays, seed):
     from xrnerf_amd import synthetic as S
     o, d, _ = S.training_rays(lego['poses'], n_rays, seed=seed)

@@ -31,8 +31,8 @@ def test_trainer_overrides(monkeypatch):
     from xrnerf_amd import switches
     monkeypatch.delenv('XRNERF_TRAINER', raising=False)
     assert switches.trainer_overrides() == {}
-    monkeypatch.setenv('XRNERF_TRAINER', 'fuse_adam=0,prefetch_depth=1,native_loop=1,march_after=xr_nerf_mlp_bwd')
-    assert switches.trainer_overrides() == {'fuse_adam': False, 'prefetch_depth': 1, 'native_loop': True, 'march_after': 'xr_nerf_mlp_bwd'}
+    monkeypatch.setenv('XRNERF_TRAINER', 'fuse_adam=0,native_loop=1,march_window=main')
+    assert switches.trainer_overrides() == {'fuse_adam': False, 'native_loop': True, 'march_window': 'main'}
     monkeypatch.setenv('XRNERF_TRAINER', 'fused_adam=0')
     with pytest.raises(ValueError):
         switches.trainer_overrides()

@@ -20,10 +20,12 @@ class AdamFuse(C.Structure):
                 ('ema_momentum', C.c_float), ('grad_scale', C.c_float), ('n', C.c_uint64)]
 
 
-class MarchSet(C.Structure):
-    """xr_ngp_march_set"""
-    _fields_ = [(k, C.c_void_p) for k in ('rays_o', 'rays_d', 'target', 'alpha', 'bg', 'img_ids', 'coords', 'rays_index', 'rays_numsteps',
-                                          'counter2', 'numsteps_clipped', 'n_valid', 'xyz_planes')] + [('plane_stride', C.c_uint32)]
+class Window(C.Structure):
+    """xr_ngp_window"""
+    _fields_ = [(k, C.c_void_p) for k in ('rays_o', 'rays_d', 'target', 'alpha', 'bg', 'img_ids', 'rays_index', 'rays_numsteps',
+                                          'numsteps_clipped')] + \
+               [('ray_stride', C.c_uint32), ('coords', C.c_void_p), ('coords_stride', C.c_size_t), ('xyz_planes', C.c_void_p),
+                ('plane_stride', C.c_uint32), ('counter2', C.c_void_p), ('n_valid', C.c_void_p)]
 
 
 class StepSet(C.Structure):
@@ -32,7 +34,7 @@ class StepSet(C.Structure):
                [(k, C.c_void_p) for k in ('grad_w_density', 'grad_w_color', 'loss_mse', 'live_seg_count')]
 
 
-MARCH_SETS = 4          # XR_NGP_MARCH_SETS
+WINDOW = 16             # XR_NGP_WINDOW
 
 
 class LoopDesc(C.Structure):
@@ -41,24 +43,16 @@ class LoopDesc(C.Structure):
                 ('n_hidden_color', C.c_int), ('pad_value', C.c_float), ('mlp_mode', C.c_int), ('n_levels', C.c_int),
                 ('scale_host', C.c_void_p), ('resolution_host', C.c_void_p), ('offset_host', C.c_void_p),
                 ('adam_table', AdamFuse), ('adam_w_density', AdamFuse), ('adam_w_color', AdamFuse),
-                ('rays_rgb_rows', C.c_void_p), ('n_table_rays', C.c_uint64), ('batch_seed', C.c_uint64),
-                ('bitfield', C.c_void_p), ('aabb0', C.c_float), ('aabb1', C.c_float), ('near_distance', C.c_float), ('cone_angle', C.c_float),
-                ('max_samples', C.c_uint32), ('max_compacted', C.c_uint32),
                 ('density_grid_mean', C.c_void_p), ('rgb_activation', C.c_int), ('density_activation', C.c_int),
                 ('huber_delta', C.c_float), ('loss_scale', C.c_float), ('n_rows', C.c_uint32), ('ld', C.c_uint32),
-                ('march', MarchSet * MARCH_SETS), ('step', StepSet * 2),
-                ('ws_k1', C.c_void_p), ('ws_k1_bytes', C.c_size_t), ('ws_mlp_bwd', C.c_void_p), ('ws_mlp_bwd_bytes', C.c_size_t),
-                ('ws_scatter', C.c_void_p), ('ws_scatter_bytes', C.c_size_t),
-                ('counter_host_pinned', C.c_void_p), ('n_pinned', C.c_uint32),
-                ('stream', C.c_void_p), ('side_stream', C.c_void_p), ('bitfield_event', C.c_void_p), ('mark_event', C.c_void_p),
-                ('mark_entry', C.c_char_p)]
+                ('window', Window), ('step', StepSet * 2),
+                ('ws_mlp_bwd', C.c_void_p), ('ws_mlp_bwd_bytes', C.c_size_t), ('ws_scatter', C.c_void_p), ('ws_scatter_bytes', C.c_size_t),
+                ('stream', C.c_void_p)]
 
 
 class LoopState(C.Structure):
     """xr_ngp_loop_state"""
-    _fields_ = [('iter', C.c_uint64), ('k1_calls', C.c_uint64), ('batches_drawn', C.c_uint64), ('cur_ray', C.c_uint64),
-                ('march_launches', C.c_uint32), ('step_turn', C.c_uint32), ('adam_step', C.c_int32), ('pinned_next', C.c_uint32),
-                ('queued', C.c_uint32), ('queue_set', C.c_uint32 * 2), ('last_march_set', C.c_uint32), ('last_step_set', C.c_uint32)]
+    _fields_ = [('iter', C.c_uint64), ('step_turn', C.c_uint32), ('adam_step', C.c_int32), ('last_step_set', C.c_uint32)]
 
 
 SIGNATURES = {
@@ -72,6 +66,13 @@ SIGNATURES = {
     'xr_rays_sampler3': (_i32, [_vp, _vp, _vp, _u32, _f, _f, _f, _f, _u32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _sz, _vp]),
     'xr_compacted_coord': (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'xr_clip_numsteps': (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _u32, _u32, _vp]),
+    'xr_rays_sampler_series_workspace_bytes': (_sz, [_u32, _u32]),
+    'xr_rays_sampler_series': (_i32, [_vp, _vp, _u32, _vp, _u32, _u32, _f, _f, _f, _f, _u32, _u64, _u64, _vp, _sz, _vp, _vp, _vp, _vp, _u32, _vp,
+                                      _sz, _vp]),
+    'xr_clip_numsteps_series': (_i32, [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
+    'xr_make_batch_series': (_i32, [_vp, _vp, _u32, _u32, _u32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'xr_ngp_window_march': (_i32, [_vp, _u32, _u32, _u32, _u32, _vp, _u64, _vp, _u64, _u64, _vp, _f, _f, _f, _f, _u32, _u64, _u32, _vp, _sz,
+                                   _vp, _vp]),
     'xr_render_slice_select': (_i32, [_vp, _vp, _u32, _u32, _u32, _f, _vp, _vp, _vp, _vp]),
     'xr_render_slice_composite': (_i32, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _i32, _i32, _vp, _vp, _vp]),
     'xr_calc_rgb_forward': (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, _i32, _i32, _vp, _vp]),
@@ -99,17 +100,11 @@ SIGNATURES = {
     'xr_sh4': (_i32, [_vp, _u32, _u32, _vp, _vp]),
     'xr_nerf_mlp_fwd': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp]),
     'xr_nerf_mlp_bwd_workspace_bytes': (_sz, [_u32]),
-    'xr_ngp_prefetch': (_i32, [_vp, _u32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _u32, _u64, _vp, _vp, _vp, _vp,
-                               _vp, _sz, _u32, _vp, _vp, _vp, _vp, _u32, _vp]),
     'xr_ngp_train_step': (_i32, [_vp, _vp, _vp, _i32, _i32, _f, _i32, _i32, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _u32, _vp, _vp, _vp,
                                  _vp, _i32, _i32, _f, _f, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp, _sz,
-                                 _vp, _sz, _i32, _vp, _u32, _vp, _vp, _vp, C.c_char_p, _vp, C.c_char_p, _vp, _vp, _vp]),
-    'xr_ngp_loop_create': (_vp, []),
-    'xr_ngp_loop_destroy': (_i32, [_vp]),
-    'xr_ngp_loop_march_event': (_vp, [_vp, _u32]),
-    'xr_ngp_loop_adopt_march': (_i32, [_vp, _u32, _vp]),
+                                 _vp, _sz, _i32, _vp, _u32, _vp, _vp, _vp, C.c_char_p, _vp, _vp, _vp]),
     'xr_event_record': (_i32, [_vp, _vp]),
-    'xr_ngp_loop_run': (_i32, [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, C.c_char_p, _vp, _vp]),
+    'xr_ngp_loop_run': (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, C.c_char_p, _vp, _vp]),
     'xr_timing_event_create': (_vp, []),
     'xr_order_event_create': (_vp, []),
     'xr_stream_wait_event': (_i32, [_vp, _vp]),

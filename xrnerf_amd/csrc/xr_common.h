@@ -125,6 +125,3 @@ int xr_internal_mlp_bwd_reduce(const void* workspace, uint32_t n, float* grad_w_
 // front of its own helper-stream kernels); `done` tells the caller whether a fork happened.  nullptr clears.
 struct XrAuxPrologue { int (*fn)(hipStream_t, void*); void* arg; bool done; };
 void xr_internal_scatter_aux_prologue(XrAuxPrologue* p);
-void xr_internal_scatter_fork_event(void* recorded_event);   // see xr_scatter.hip
-void xr_internal_scatter_join_also(void* event_of_another_stream);   // see xr_scatter.hip
-bool xr_internal_scatter_join_also_taken();

@@ -98,32 +98,52 @@ extern "C" int xr_huber_loss_grad_mse(const float* rgb, const float* target, con
 // HashBatchSample + RandomBGColor (/root/reference/xrnerf/datasets/pipelines/create.py:153-191,
 // augment.py:290-317) on the device in one launch: slices `n` rows of the [N,11] ray table
 // (o3, d3, rgba4, img_id) and draws the random background with PCG32 (stream position = row).
+// blockIdx.y = batch c of a series (xr_make_batch_series): table rows from row0[c], the generator of call index (first + c)
+// (it moves on by 2^32 per call: xr_pcg32_host_state), outputs at c * ray_stride rows.
+struct XrBatchRows { uint64_t row0[XR_NGP_WINDOW]; };
 __global__ __launch_bounds__(256) void k_make_batch(const float* __restrict__ rows, uint32_t n, xr_pcg32 rng,
                                                      float* __restrict__ rays_o, float* __restrict__ rays_d,
                                                      float* __restrict__ target, float* __restrict__ alpha,
-                                                     float* __restrict__ bg, int32_t* __restrict__ img_ids) {
+                                                     float* __restrict__ bg, int32_t* __restrict__ img_ids, XrBatchRows at, uint32_t ray_stride) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const float* r = rows + 11 * (size_t)i;
-    rng.advance(3ull * i);
+    const float* r = rows + 11 * ((size_t)at.row0[blockIdx.y] + i);
+    rng.advance(((uint64_t)blockIdx.y << 32) + 3ull * i);
+    const size_t q = (size_t)blockIdx.y * ray_stride + i;
     const float a = r[9];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        rays_o[3 * (size_t)i + k] = r[k];
-        rays_d[3 * (size_t)i + k] = r[3 + k];
+        rays_o[3 * q + k] = r[k];
+        rays_d[3 * q + k] = r[3 + k];
         const float b = rng.next_float();
-        bg[3 * (size_t)i + k] = b;
-        target[3 * (size_t)i + k] = r[6 + k] * a + b * (1.f - a);
+        bg[3 * q + k] = b;
+        target[3 * q + k] = r[6 + k] * a + b * (1.f - a);
     }
-    alpha[i] = a;
-    img_ids[i] = (int32_t)r[10];
+    alpha[q] = a;
+    img_ids[q] = (int32_t)r[10];
 }
 extern "C" int xr_make_batch(const float* rays_rgb_rows, uint32_t n, uint64_t rng_state, uint64_t rng_inc, float* rays_o,
                              float* rays_d, float* target, float* alpha, float* bg, int32_t* img_ids, void* stream_) {
     XR_REQUIRE(rays_rgb_rows && rays_o && rays_d && target && alpha && bg && img_ids && n > 0, "bad argument");
     xr_pcg32 rng{rng_state, rng_inc};
+    XrBatchRows at = {};
     hipLaunchKernelGGL(k_make_batch, dim3(xr_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream_, rays_rgb_rows, n, rng, rays_o,
-                       rays_d, target, alpha, bg, img_ids);
+                       rays_d, target, alpha, bg, img_ids, at, 0u);
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}
+// n_series <= XR_NGP_WINDOW batches in one launch: batch c = rows [row0[c], row0[c] + n) of the table, drawn with the generator of call index
+// (first + c) (rng_state / rng_inc = xr_pcg32_host_state(seed, first)), written at rows c * ray_stride of the six outputs
+extern "C" int xr_make_batch_series(const float* rays_rgb_rows, const uint64_t* row0_host, uint32_t n, uint32_t n_series, uint32_t ray_stride,
+                                    uint64_t rng_state, uint64_t rng_inc, float* rays_o, float* rays_d, float* target, float* alpha, float* bg,
+                                    int32_t* img_ids, void* stream_) {
+    XR_REQUIRE(rays_rgb_rows && row0_host && rays_o && rays_d && target && alpha && bg && img_ids && n > 0, "bad argument");
+    XR_REQUIRE(n_series >= 1 && n_series <= (uint32_t)XR_NGP_WINDOW && ray_stride >= n, "bad series");
+    xr_pcg32 rng{rng_state, rng_inc};
+    XrBatchRows at = {};
+    for (uint32_t c = 0; c < n_series; ++c) at.row0[c] = row0_host[c];
+    hipLaunchKernelGGL(k_make_batch, dim3(xr_div_up(n, 256), n_series), dim3(256), 0, (hipStream_t)stream_, rays_rgb_rows, n, rng, rays_o,
+                       rays_d, target, alpha, bg, img_ids, at, ray_stride);
     XR_LAUNCH_CHECK();
     return XR_OK;
 }

@@ -124,13 +124,20 @@ __device__ inline Ray rm_load_ray(const float* __restrict__ o, const float* __re
 // steps per window, ~2000 of the ~3000 issue cycles of a window), 12.5 K waves x ~8 windows make it as long as this kernel
 // (173 us either way, tools/microbench_k1.py) while occupying every SIMD: beside the training step on the side stream it slowed
 // the encode from 81 to 143 us and the iteration from 0.447 to 0.488 ms (profiles/r03_k1_wave_per_ray_ab.txt).
+// A SERIES of launches in one (round 5): blockIdx.y = launch c of a series of gridDim.y launches over n_rays rays each -- the marches of
+// a whole refresh window (ngp_grid_sampler.py:194-197,268-281: the bitfield and the batch size do not change between two refreshes and
+// K1 reads no weights).  Launch c reads rays c * ray_stride .., draws the jitter of hidden-generator call index (first + c) -- the
+// generator moves on by 2^32 per launch, ray_sampler.cu:198 -- and owns workspace blocks [c * gridDim.x, (c + 1) * gridDim.x).
 __global__ __launch_bounds__(RM_BLOCK) void k1_count(
     uint32_t n_rays, float lo, float hi, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
     const uint8_t* __restrict__ bitfield, float cone, float near_distance, xr_pcg32 rng, uint32_t rng_chunk, uint32_t rng_ray0,
     uint32_t* __restrict__ cnt, uint32_t* __restrict__ local_off, float* __restrict__ start_t,
-    uint32_t* __restrict__ block_tot, float* __restrict__ tlist) {
+    uint32_t* __restrict__ block_tot, float* __restrict__ tlist, uint32_t ray_stride) {
     __shared__ uint32_t lds4[4];
-    const uint32_t i = blockIdx.x * RM_BLOCK + threadIdx.x;
+    const uint32_t i = blockIdx.x * RM_BLOCK + threadIdx.x;                     // ray of this launch
+    const uint32_t wb = blockIdx.y * gridDim.x + blockIdx.x, wi = wb * RM_BLOCK + threadIdx.x;   // workspace block / slot
+    rays_o += 3 * (size_t)blockIdx.y * ray_stride; rays_d += 3 * (size_t)blockIdx.y * ray_stride;
+    rng.advance((uint64_t)blockIdx.y << 32);
     uint32_t j = 0; float startt = 0.f;
     if (i < n_rays) {
         // :31.  rng_chunk > 0: ray i draws what it would draw as ray i % rng_chunk of launch i / rng_chunk of a series of
@@ -152,15 +159,15 @@ __global__ __launch_bounds__(RM_BLOCK) void k1_count(
             if (rm_occupied(px, py, pz, bitfield, mip)) {
                 // a sample is fully determined by its t: remember the first K1_TL of them so that the
                 // write pass can expand them sample-parallel instead of re-marching
-                if (j < K1_TL) tlist[(size_t)i * K1_TL + j] = t;
+                if (j < K1_TL) tlist[(size_t)wi * K1_TL + j] = t;
                 ++j; t += dt;
             } else t = rm_advance(t, cone, px, py, pz, r, XR_NERF_GRIDSIZE >> mip);
         }
     }
     uint32_t tot;
     uint32_t off = block_excl_scan(j, &tot, lds4);
-    if (i < n_rays) { cnt[i] = j; local_off[i] = off; start_t[i] = startt; }
-    if (threadIdx.x == 0) block_tot[blockIdx.x] = tot;
+    if (i < n_rays) { cnt[wi] = j; local_off[wi] = off; start_t[wi] = startt; }
+    if (threadIdx.x == 0) block_tot[wb] = tot;
 }
 
 // ------------------------------------------------------------------ K1 pass A with K1W lanes per ray (training-sized batches)
@@ -285,10 +292,20 @@ __global__ __launch_bounds__(RM_BLOCK) void k1_write(
     const uint32_t* __restrict__ block_base, const uint32_t* __restrict__ info, const uint32_t* __restrict__ block_tot,
     float* __restrict__ coords_out,
     int32_t* __restrict__ rays_index, int32_t* __restrict__ numsteps_out, uint32_t* __restrict__ counter2,
-    const float* __restrict__ tlist, float* __restrict__ xyz_planes, uint32_t plane_stride) {
+    const float* __restrict__ tlist, float* __restrict__ xyz_planes, uint32_t plane_stride, uint32_t ray_stride, size_t coords_stride) {
     __shared__ uint32_t lds4[4];
     const uint32_t b = blockIdx.x, i = b * RM_BLOCK + threadIdx.x;
     const uint32_t nb = gridDim.x;
+    // launch blockIdx.y of a series (see k1_count): its rays, its output buffers, its blocks of the workspace
+    {
+        const size_t c = blockIdx.y;
+        rays_o += 3 * c * ray_stride; rays_d += 3 * c * ray_stride;
+        rays_index += c * ray_stride; numsteps_out += 2 * c * ray_stride; counter2 += 2 * c;
+        coords_out += 7 * c * coords_stride;
+        if (xyz_planes) xyz_planes += 3 * c * (size_t)plane_stride;
+        if (block_tot) block_tot += c * nb;
+        cnt += c * nb * RM_BLOCK; local_off += c * nb * RM_BLOCK; start_t += c * nb * RM_BLOCK; tlist += c * nb * RM_BLOCK * (size_t)K1_TL;
+    }
     uint32_t cross, bbase, grand;
     if (block_tot) {
         // up to RM_BLOCK blocks (65 536 rays: every training batch): each workgroup scans the block totals itself -- the one-workgroup
@@ -393,58 +410,100 @@ __global__ __launch_bounds__(RM_BLOCK) void k1_write(
 }
 
 struct RmWorkspace { uint32_t *cnt, *local_off, *block_tot, *block_base, *info; float *start_t, *tlist; };
-static size_t rm_ws_layout(uint32_t n_rays, char* base, RmWorkspace* w) {
-    const size_t nb = xr_div_up(n_rays, RM_BLOCK);
+// `n_series` launches over n_rays rays each (xr_rays_sampler_series): every launch owns whole 256-ray blocks of the per-ray arrays
+static size_t rm_ws_layout(uint32_t n_rays, char* base, RmWorkspace* w, uint32_t n_series = 1) {
+    const size_t nb = (size_t)xr_div_up(n_rays, RM_BLOCK) * n_series;
+    const size_t slots = n_series > 1 ? nb * RM_BLOCK : (size_t)n_rays;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return base ? base + o : (char*)nullptr; };
-    char* p0 = take(4ull * n_rays); char* p1 = take(4ull * n_rays); char* p2 = take(4ull * n_rays);
+    char* p0 = take(4ull * slots); char* p1 = take(4ull * slots); char* p2 = take(4ull * slots);
     char* p3 = take(4 * nb); char* p4 = take(4 * nb); char* p5 = take(16);
-    char* p6 = take(4ull * n_rays * K1_TL);
+    char* p6 = take(4ull * slots * K1_TL);
     if (w) { w->tlist = (float*)p6; w->cnt = (uint32_t*)p0; w->local_off = (uint32_t*)p1; w->start_t = (float*)p2;
              w->block_tot = (uint32_t*)p3; w->block_base = (uint32_t*)p4; w->info = (uint32_t*)p5; }
     return off;
 }
 
 extern "C" size_t xr_rays_sampler_workspace_bytes(uint32_t n_rays) { return rm_ws_layout(n_rays, nullptr, nullptr); }
+extern "C" size_t xr_rays_sampler_series_workspace_bytes(uint32_t n_rays, uint32_t n_series) {
+    return rm_ws_layout(n_rays, nullptr, nullptr, n_series ? n_series : 1);
+}
+
+// the launches behind xr_rays_sampler3 / xr_rays_sampler_series
+static int rm_launch(const float* rays_o, const float* rays_d, const uint8_t* bitfield, uint32_t n_rays, uint32_t n_series, uint32_t ray_stride,
+                     float aabb0, float aabb1, float near_distance, float cone_angle, uint32_t max_samples, xr_pcg32 rng,
+                     float* coords_out, size_t coords_stride, int32_t* rays_index, int32_t* rays_numsteps, uint32_t* counter2, float* xyz_planes,
+                     uint32_t plane_stride, uint32_t rng_chunk, uint32_t rng_ray0, uint32_t flags, void* workspace, hipStream_t stream) {
+    RmWorkspace w; rm_ws_layout(n_rays, (char*)workspace, &w, n_series);
+    const uint32_t nb = xr_div_up(n_rays, RM_BLOCK);
+    // XR_K1_WIDE (the caller says nothing else is running: the march in place at a grid refresh) and at most K1W_MAX_RAYS rays: K1W lanes
+    // per ray -- 8x the waves, each shorter: 174 -> 143 us at 12.5 K rays, 170 -> 121 at 4 K (profiles/r04_k1_lanes_per_ray_ab.txt).
+    // Not beside the training step: 8x the waves slow the scatter they run beside by more than the march
+    // gains (iteration 0.408 -> 0.424 ms); not for frames (65 K rays: 173 -> 280 us, the chip is full of rays either way).
+#ifndef K1W_ALWAYS
+#define K1W_ALWAYS 0           // 1: every launch of up to K1W_MAX_RAYS rays takes the K1W-lane kernel (A/B of K1W = 2 / 4 beside the training step)
+#endif
+    if (n_series == 1 && ((flags & XR_K1_WIDE) != 0u || K1W_ALWAYS != 0) && (uint32_t)K1W_MAX_RAYS != 0u && n_rays <= (uint32_t)K1W_MAX_RAYS) {
+        hipLaunchKernelGGL(k1_count_w, dim3(xr_div_up(n_rays * K1W, RM_BLOCK)), dim3(RM_BLOCK), 0, stream, n_rays, aabb0, aabb1, rays_o, rays_d,
+                           bitfield, cone_angle, near_distance, rng, rng_chunk, rng_ray0, w.cnt, w.start_t, w.tlist);
+        hipLaunchKernelGGL(k1_block_scan, dim3(nb), dim3(RM_BLOCK), 0, stream, n_rays, (const uint32_t*)w.cnt, w.local_off, w.block_tot);
+    } else
+        hipLaunchKernelGGL(k1_count, dim3(nb, n_series), dim3(RM_BLOCK), 0, stream, n_rays, aabb0, aabb1, rays_o, rays_d, bitfield,
+                           cone_angle, near_distance, rng, rng_chunk, rng_ray0, w.cnt, w.local_off, w.start_t, w.block_tot, w.tlist, ray_stride);
+#ifndef K1_INLINE_SCAN
+#define K1_INLINE_SCAN 1
+#endif
+    const bool inline_scan = (K1_INLINE_SCAN || n_series > 1) && nb <= (uint32_t)RM_BLOCK;
+    if (!inline_scan) hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, nb, w.block_tot, max_samples, w.block_base, w.info);
+    hipLaunchKernelGGL(k1_write, dim3(nb, n_series), dim3(RM_BLOCK), 0, stream, n_rays, aabb0, aabb1, rays_o, rays_d, bitfield,
+                       cone_angle, max_samples, w.cnt, w.local_off, w.start_t, w.block_base, w.info,
+                       inline_scan ? (const uint32_t*)w.block_tot : (const uint32_t*)nullptr, coords_out,
+                       rays_index, rays_numsteps, counter2, w.tlist, xyz_planes, plane_stride, ray_stride, coords_stride);
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}
 
 extern "C" int xr_rays_sampler3(const float* rays_o, const float* rays_d, const uint8_t* bitfield, uint32_t n_rays,
                                 float aabb0, float aabb1, float near_distance, float cone_angle, uint32_t max_samples,
                                 uint64_t rng_state, uint64_t rng_inc, float* coords_out, int32_t* rays_index,
                                 int32_t* rays_numsteps, uint32_t* counter2, float* xyz_planes, uint32_t plane_stride,
                                 uint32_t rng_chunk, uint32_t rng_ray0, uint32_t flags, void* workspace, size_t workspace_bytes, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
     XR_REQUIRE((flags & ~XR_K1_WIDE) == 0, "unknown flag");
     XR_REQUIRE(rays_o && rays_d && bitfield && coords_out && rays_index && rays_numsteps && counter2, "null pointer");
     XR_REQUIRE(!xyz_planes || plane_stride >= max_samples, "a position plane holds max_samples values");
     XR_REQUIRE(n_rays > 0 && n_rays <= (1u << 28), "n_rays out of range");
     XR_REQUIRE(workspace && workspace_bytes >= xr_rays_sampler_workspace_bytes(n_rays), "workspace too small");
-    RmWorkspace w; rm_ws_layout(n_rays, (char*)workspace, &w);
-    xr_pcg32 rng{rng_state, rng_inc};
+    return rm_launch(rays_o, rays_d, bitfield, n_rays, 1, 0, aabb0, aabb1, near_distance, cone_angle, max_samples, xr_pcg32{rng_state, rng_inc},
+                     coords_out, 0, rays_index, rays_numsteps, counter2, xyz_planes, plane_stride, rng_chunk, rng_ray0, flags, workspace,
+                     (hipStream_t)stream_);
+}
+
+// n_series launches of K1 over n_rays rays each as ONE (contract: include/xrnerf_mi355.h).  Launch c is bit for bit the launch
+// xr_rays_sampler3 would make with the hidden generator's call index (first + c) on rays c * ray_stride .. and the c-th output buffers.
+extern "C" int xr_rays_sampler_series(const float* rays_o, const float* rays_d, uint32_t ray_stride, const uint8_t* bitfield, uint32_t n_rays,
+                                      uint32_t n_series, float aabb0, float aabb1, float near_distance, float cone_angle, uint32_t max_samples,
+                                      uint64_t rng_state, uint64_t rng_inc, float* coords_out, size_t coords_stride, int32_t* rays_index,
+                                      int32_t* rays_numsteps, uint32_t* counter2, float* xyz_planes, uint32_t plane_stride, void* workspace,
+                                      size_t workspace_bytes, void* stream_) {
+    XR_REQUIRE(rays_o && rays_d && bitfield && coords_out && rays_index && rays_numsteps && counter2, "null pointer");
+    XR_REQUIRE(n_series >= 1 && n_series <= 65535u && n_rays > 0 && n_rays <= (1u << 28) && ray_stride >= n_rays, "bad series");
+    XR_REQUIRE(coords_stride >= max_samples && (!xyz_planes || plane_stride >= max_samples), "a launch's buffers hold max_samples rows");
+    XR_REQUIRE(workspace && workspace_bytes >= xr_rays_sampler_series_workspace_bytes(n_rays, n_series), "workspace too small");
     const uint32_t nb = xr_div_up(n_rays, RM_BLOCK);
-    // XR_K1_WIDE (the caller says nothing else is running: the march in place at a grid refresh) and at most K1W_MAX_RAYS rays: K1W lanes
-    // per ray -- 8x the waves, each shorter: 174 -> 143 us at 12.5 K rays, 170 -> 121 at 4 K (profiles/r04_k1_lanes_per_ray_ab.txt).
-    // Not beside the training step (the side-stream marches): 8x the waves slow the scatter they run beside by more than the march
-    // gains (iteration 0.408 -> 0.424 ms); not for frames (65 K rays: 173 -> 280 us, the chip is full of rays either way).
-#ifndef K1W_ALWAYS
-#define K1W_ALWAYS 0           // 1: every launch of up to K1W_MAX_RAYS rays takes the K1W-lane kernel (A/B of K1W = 2 / 4 beside the training step)
-#endif
-    if (((flags & XR_K1_WIDE) != 0u || K1W_ALWAYS != 0) && (uint32_t)K1W_MAX_RAYS != 0u && n_rays <= (uint32_t)K1W_MAX_RAYS) {
-        hipLaunchKernelGGL(k1_count_w, dim3(xr_div_up(n_rays * K1W, RM_BLOCK)), dim3(RM_BLOCK), 0, stream, n_rays, aabb0, aabb1, rays_o, rays_d,
-                           bitfield, cone_angle, near_distance, rng, rng_chunk, rng_ray0, w.cnt, w.start_t, w.tlist);
-        hipLaunchKernelGGL(k1_block_scan, dim3(nb), dim3(RM_BLOCK), 0, stream, n_rays, (const uint32_t*)w.cnt, w.local_off, w.block_tot);
-    } else
-        hipLaunchKernelGGL(k1_count, dim3(nb), dim3(RM_BLOCK), 0, stream, n_rays, aabb0, aabb1, rays_o, rays_d, bitfield,
-                           cone_angle, near_distance, rng, rng_chunk, rng_ray0, w.cnt, w.local_off, w.start_t, w.block_tot, w.tlist);
-#ifndef K1_INLINE_SCAN
-#define K1_INLINE_SCAN 1
-#endif
-    const bool inline_scan = K1_INLINE_SCAN && nb <= (uint32_t)RM_BLOCK;
-    if (!inline_scan) hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, nb, w.block_tot, max_samples, w.block_base, w.info);
-    hipLaunchKernelGGL(k1_write, dim3(nb), dim3(RM_BLOCK), 0, stream, n_rays, aabb0, aabb1, rays_o, rays_d, bitfield,
-                       cone_angle, max_samples, w.cnt, w.local_off, w.start_t, w.block_base, w.info,
-                       inline_scan ? (const uint32_t*)w.block_tot : (const uint32_t*)nullptr, coords_out,
-                       rays_index, rays_numsteps, counter2, w.tlist, xyz_planes, plane_stride);
-    XR_LAUNCH_CHECK();
+    if (nb <= (uint32_t)RM_BLOCK || n_series == 1)
+        return rm_launch(rays_o, rays_d, bitfield, n_rays, n_series, ray_stride, aabb0, aabb1, near_distance, cone_angle, max_samples,
+                         xr_pcg32{rng_state, rng_inc}, coords_out, coords_stride, rays_index, rays_numsteps, counter2, xyz_planes, plane_stride,
+                         0, 0, 0, workspace, (hipStream_t)stream_);
+    // launches of more than 65 536 rays need the one-workgroup scan between the two passes: one after the other
+    xr_pcg32 rng{rng_state, rng_inc};
+    for (uint32_t c = 0; c < n_series; ++c) {
+        int rc = rm_launch(rays_o + 3 * (size_t)c * ray_stride, rays_d + 3 * (size_t)c * ray_stride, bitfield, n_rays, 1, 0, aabb0, aabb1, near_distance,
+                           cone_angle, max_samples, rng, coords_out + 7 * c * coords_stride, 0, rays_index + (size_t)c * ray_stride,
+                           rays_numsteps + 2 * (size_t)c * ray_stride, counter2 + 2 * c, xyz_planes ? xyz_planes + 3 * (size_t)c * plane_stride : nullptr,
+                           plane_stride, 0, 0, 0, workspace, (hipStream_t)stream_);
+        if (rc != XR_OK) return rc;
+        rng.advance(1ull << 32);
+    }
     return XR_OK;
 }
 
@@ -527,8 +586,12 @@ extern "C" int xr_compacted_coord(const float* coords_in, const int32_t* numstep
 
 __global__ __launch_bounds__(RM_BLOCK) void k2_clip(uint32_t n_rays, uint32_t max_compacted, const int32_t* __restrict__ in,
                                                      const uint32_t* __restrict__ counter2, int32_t* __restrict__ out,
-                                                     uint32_t* __restrict__ n_valid, uint32_t chunk_rows, uint32_t n_chunks) {
+                                                     uint32_t* __restrict__ n_valid, uint32_t chunk_rows, uint32_t n_chunks,
+                                                     uint32_t ray_stride) {
     const uint32_t i = blockIdx.x * RM_BLOCK + threadIdx.x;
+    // launch blockIdx.y of a series (xr_clip_numsteps_series): its rays, its counter pair, its (1 + n_chunks) valid-row counts
+    in += 2 * (size_t)blockIdx.y * ray_stride; out += 2 * (size_t)blockIdx.y * ray_stride;
+    counter2 += 2 * blockIdx.y; n_valid += (size_t)(1 + n_chunks) * blockIdx.y;
     if (i == 0) {
         const uint32_t total = min(counter2[1], max_compacted);
         n_valid[0] = total;
@@ -544,7 +607,17 @@ extern "C" int xr_clip_numsteps(const int32_t* numsteps_in, const uint32_t* coun
                                 int32_t* numsteps_out, uint32_t* n_valid_dev, uint32_t chunk_rows, uint32_t n_chunks, void* stream_) {
     XR_REQUIRE(numsteps_in && counter2 && numsteps_out && n_valid_dev && n_rays > 0, "bad argument");
     hipLaunchKernelGGL(k2_clip, dim3(xr_div_up(n_rays, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream_, n_rays, max_compacted,
-                       numsteps_in, counter2, numsteps_out, n_valid_dev, chunk_rows, n_chunks);
+                       numsteps_in, counter2, numsteps_out, n_valid_dev, chunk_rows, n_chunks, 0u);
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}
+// K2's clip for the n_series launches of xr_rays_sampler_series: numsteps arrays with ray_stride rows per launch, counter2 [n_series][2],
+// n_valid_dev [n_series][2] = (valid rows, valid rows) like xr_clip_numsteps(chunk_rows = max_compacted, n_chunks = 1)
+extern "C" int xr_clip_numsteps_series(const int32_t* numsteps_in, const uint32_t* counter2, uint32_t n_rays, uint32_t n_series, uint32_t ray_stride,
+                                       uint32_t max_compacted, int32_t* numsteps_out, uint32_t* n_valid_dev, void* stream_) {
+    XR_REQUIRE(numsteps_in && counter2 && numsteps_out && n_valid_dev && n_rays > 0 && n_series >= 1 && n_series <= 65535u && ray_stride >= n_rays, "bad argument");
+    hipLaunchKernelGGL(k2_clip, dim3(xr_div_up(n_rays, RM_BLOCK), n_series), dim3(RM_BLOCK), 0, (hipStream_t)stream_, n_rays, max_compacted,
+                       numsteps_in, counter2, numsteps_out, n_valid_dev, max_compacted, 1u, ray_stride);
     XR_LAUNCH_CHECK();
     return XR_OK;
 }

@@ -803,19 +803,7 @@ uint32_t xr_scatter3_atomic_mask(uint32_t n, const GridMeta& gm, uint32_t hashed
 }
 
 static thread_local XrAuxPrologue* g_aux_prologue = nullptr;
-// an event the caller has ALREADY recorded on the stream with nothing launched on it since (xr_ngp_train_step's mark behind the MLP
-// backward): the helper stream is ordered behind that one instead of behind a fork event of this call's own -- one event record
-// less between two dependent kernels of the critical stream
-static thread_local hipEvent_t g_fork_event = nullptr;
-void xr_internal_scatter_fork_event(void* e) { g_fork_event = (hipEvent_t)e; }
 void xr_internal_scatter_aux_prologue(XrAuxPrologue* p) { g_aux_prologue = p; }
-// an event of ANOTHER stream the caller would otherwise wait for on its own stream right behind this call: the helper stream waits for it
-// in front of the join instead -- the caller's stream then carries one wait, not two (each holds the queue for a few microseconds,
-// profiles/r04_event_cost_probe.txt).  `taken` tells whether the call forked at all.
-static thread_local hipEvent_t g_join_also = nullptr;
-static thread_local bool g_join_also_taken = false;
-void xr_internal_scatter_join_also(void* e) { g_join_also = (hipEvent_t)e; g_join_also_taken = false; }
-bool xr_internal_scatter_join_also_taken() { return g_join_also_taken; }
 
 int xr_scatter3(const float* x, uint32_t x_stride, const float* denc_t, uint32_t ld, uint32_t n, const uint32_t* n_dev,
                 const uint32_t* rows, const GridMeta& gm, uint32_t hashed_mask, float* grad_table, void* workspace,
@@ -863,11 +851,8 @@ int xr_scatter3(const float* x, uint32_t x_stride, const float* denc_t, uint32_t
         if (P.rl.n_lv == 0) return XR_OK;
         hipStream_t rs = stream;
         if (fork) {
-            if (g_fork_event) XR_HIP(hipStreamWaitEvent(aux, g_fork_event, 0));
-            else {
-                XR_HIP(hipEventRecord(ev_fork, stream));
-                XR_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
-            }
+            XR_HIP(hipEventRecord(ev_fork, stream));
+            XR_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
             rs = aux;
             if (!aux_last && g_aux_prologue && !g_aux_prologue->done) {   // a caller's small kernels that only have to finish by the join
                 g_aux_prologue->done = true;
@@ -885,7 +870,6 @@ int xr_scatter3(const float* x, uint32_t x_stride, const float* denc_t, uint32_t
             const int rc = g_aux_prologue->fn(aux, g_aux_prologue->arg);
             if (rc != XR_OK) return rc;
         }
-        if (fork && g_join_also) { XR_HIP(hipStreamWaitEvent(aux, g_join_also, 0)); g_join_also_taken = true; }
         if (fork) XR_HIP(hipEventRecord(ev_join, aux));
         return XR_OK;
     };

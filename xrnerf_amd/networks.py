@@ -167,7 +167,7 @@ class _FusedTrainStepFn(torch.autograd.Function):
                                          sampler.rays_numsteps, sampler.rays_numsteps_compacted, data['bg_color'],
                                          data['target_s'].contiguous(), data['alpha'].contiguous(), sampler.density_grid_mean,
                                          int(sampler.rgb_activation), int(sampler.density_activation), b, scatter_level0=split,
-                                         xyz=getattr(sampler, 'xyz', None), mark=getattr(net, '_step_mark', None), adam=adam, mlp_adam=mlp_adam)
+                                         xyz=getattr(sampler, 'xyz', None), adam=adam, mlp_adam=mlp_adam)
                 if sync is not None:
                     sync.ready(b.g_mlp)
                     if split:

@@ -296,25 +296,86 @@ def composite_train(raw, coords, numsteps, numsteps_c, bg, target, alpha, densit
     return rgb
 
 
-def ngp_prefetch(rows, n, batch_call_index, batch_out, bitfield, aabb, near_distance, cone_angle, max_samples, k1_call_index,
-                 coords_out, small_out, clip_out, max_compacted, counter_host, batch_seed=20220901, ws_tag='k1_side', xyz_out=None):
-    """make_batch + K1 + K2 clip + counter copy to pinned host memory as one native call (xr_ngp_prefetch) on the current stream.
-    -> (batch dict of views, (coords_out, rays_index, numsteps, counter), (numsteps_clipped, n_valid))"""
+class MarchWindow:
+    """Caller-owned buffers of a marched refresh window (xr_ngp_window, include/xrnerf_mi355.h): XR_NGP_WINDOW chunks at fixed strides.
+    Iteration `it` lives in chunk it % WINDOW.  One allocation per array; `chunk(c)` hands out the views a single march / step takes."""
+
+    N = _lib.WINDOW
+
+    def __init__(self, device, ray_stride, coords_stride, planes=True):
+        W = self.N
+        f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=device)
+        i = lambda *shape: torch.empty(shape, dtype=torch.int32, device=device)
+        self.device, self.ray_stride, self.coords_stride = device, int(ray_stride), int(coords_stride)
+        self.rays_o, self.rays_d, self.target, self.bg = f(W, ray_stride, 3), f(W, ray_stride, 3), f(W, ray_stride, 3), f(W, ray_stride, 3)
+        self.alpha, self.img_ids = f(W, ray_stride, 1), i(W, ray_stride, 1)
+        self.rays_index, self.numsteps, self.clipped = i(W, ray_stride, 1), i(W, ray_stride, 2), i(W, ray_stride, 2)
+        self.coords = f(W, coords_stride, 7)
+        self.xyz = f(W, 3, coords_stride) if planes else None
+        self.counter2, self.n_valid = i(W, 2), i(W, 2)
+        self.pinned = torch.zeros((W, 2), dtype=torch.int32).pin_memory() if device.type == 'cuda' else None
+        c = _lib.Window()
+        vp = lambda t: t.data_ptr() if t is not None else None
+        c.rays_o, c.rays_d, c.target, c.alpha, c.bg, c.img_ids = vp(self.rays_o), vp(self.rays_d), vp(self.target), vp(self.alpha), vp(self.bg), vp(self.img_ids)
+        c.rays_index, c.rays_numsteps, c.numsteps_clipped = vp(self.rays_index), vp(self.numsteps), vp(self.clipped)
+        c.ray_stride, c.coords, c.coords_stride = self.ray_stride, vp(self.coords), self.coords_stride
+        c.xyz_planes, c.plane_stride = vp(self.xyz), (self.coords_stride if planes else 0)
+        c.counter2, c.n_valid = vp(self.counter2), vp(self.n_valid)
+        self.c = c
+
+    def batch(self, c, n):
+        """the batch dict of chunk c (views; what HashBatchSample + RandomBGColor hand to train_step)"""
+        return {'rays_o': self.rays_o[c, :n], 'rays_d': self.rays_d[c, :n], 'target_s': self.target[c, :n], 'alpha': self.alpha[c, :n],
+                'img_ids': self.img_ids[c, :n], 'bg_color': self.bg[c, :n]}
+
+    def batch_out(self, c):
+        """chunk c's buffers in the form make_batch(out=...) takes"""
+        return {'rays_o': self.rays_o[c], 'rays_d': self.rays_d[c], 'target_s': self.target[c], 'alpha': self.alpha[c],
+                'img_ids': self.img_ids[c], 'bg_color': self.bg[c]}
+
+
+def ngp_window_march(win, first_chunk, n_chunks, batches_ready, n, rows_table, cur_ray, batch_call_index, bitfield, aabb, near_distance,
+                     cone_angle, max_samples, k1_call_index, max_compacted, batch_seed=20220901, ws_tag='k1_window'):
+    """the batches and marches of window chunks [first_chunk, first_chunk + n_chunks) as one series of launches on the current stream
+    (xr_ngp_window_march): batch assembly for all but the first `batches_ready` chunks, K1, K2's clip, counters to win.pinned.
+    -> the table cursor behind the last batch drawn"""
     L = _lib.load()
-    o, d, tgt, alpha, bg, ids = (batch_out[k][:n] for k in ('rays_o', 'rays_d', 'target_s', 'alpha', 'bg_color', 'img_ids'))
-    rays_index, numsteps, counter = small_out
-    clipped, n_valid = clip_out
-    ws = _ws(rows.device, L.xr_rays_sampler_workspace_bytes(n), ws_tag)
-    with _span('xr_rays_sampler', n):
-        _lib.check(L.xr_ngp_prefetch(_ptr(rows), n, batch_seed, batch_call_index, _ptr(o), _ptr(d), _ptr(tgt), _ptr(alpha), _ptr(bg),
-                                     _ptr(ids), _ptr(bitfield), aabb[0], aabb[1], near_distance, cone_angle, max_samples,
-                                     k1_call_index, _ptr(coords_out), _ptr(rays_index), _ptr(numsteps), _ptr(counter), _ptr(ws),
-                                     ws.numel(), max_compacted, _ptr(clipped), _ptr(n_valid),
-                                     C.c_void_p(counter_host.data_ptr()) if counter_host is not None else None,
-                                     _ptr(xyz_out), xyz_out.shape[1] if xyz_out is not None else 0, _stream()),
-                   'xr_ngp_prefetch')
-    batch = {'rays_o': o, 'rays_d': d, 'target_s': tgt, 'alpha': alpha, 'img_ids': ids, 'bg_color': bg}
-    return batch, (coords_out, rays_index, numsteps, counter), (clipped, n_valid)
+    ws = _ws(win.device, L.xr_rays_sampler_series_workspace_bytes(n, n_chunks), ws_tag)
+    try:
+        native = L.xr_ngp_window_march
+    except AttributeError:
+        native = None            # the kernels' host build (tests/hip_emu) has no native executors: the same series calls from here
+    if native is not None:
+        cur = C.c_uint64(int(cur_ray))
+        with _span('xr_rays_sampler', n * n_chunks):
+            _lib.check(native(C.byref(win.c), first_chunk, n_chunks, batches_ready, n, _ptr(rows_table),
+                              rows_table.shape[0] if rows_table is not None else 0, C.byref(cur), batch_seed, batch_call_index,
+                              _ptr(bitfield), aabb[0], aabb[1], near_distance, cone_angle, max_samples, k1_call_index, max_compacted,
+                              _ptr(ws), ws.numel(), C.c_void_p(win.pinned.data_ptr()) if win.pinned is not None else None, _stream()),
+                       'xr_ngp_window_march')
+        return int(cur.value)
+    c0, c1, cur = first_chunk, first_chunk + n_chunks, int(cur_ray)
+    if batches_ready < n_chunks:
+        row0 = []
+        for _ in range(batches_ready, n_chunks):
+            if cur + n > rows_table.shape[0]:
+                cur = 0
+            row0.append(cur)
+            cur += n
+        b0 = c0 + batches_ready
+        st, inc = pcg32_host_state(batch_call_index, batch_seed)
+        _lib.check(L.xr_make_batch_series(_ptr(rows_table), (C.c_uint64 * len(row0))(*row0), n, len(row0), win.ray_stride, st, inc, _ptr(win.rays_o[b0:c1]),
+                                          _ptr(win.rays_d[b0:c1]), _ptr(win.target[b0:c1]), _ptr(win.alpha[b0:c1]), _ptr(win.bg[b0:c1]),
+                                          _ptr(win.img_ids[b0:c1]), _stream()), 'xr_make_batch_series')
+    st, inc = pcg32_host_state(k1_call_index)
+    _lib.check(L.xr_rays_sampler_series(_ptr(win.rays_o[c0:c1]), _ptr(win.rays_d[c0:c1]), win.ray_stride, _ptr(bitfield), n, n_chunks, aabb[0], aabb[1],
+                                        near_distance, cone_angle, max_samples, st, inc, _ptr(win.coords[c0:c1]), win.coords_stride,
+                                        _ptr(win.rays_index[c0:c1]), _ptr(win.numsteps[c0:c1]), _ptr(win.counter2[c0:c1]),
+                                        _ptr(win.xyz[c0:c1]) if win.xyz is not None else None, win.coords_stride if win.xyz is not None else 0,
+                                        _ptr(ws), ws.numel(), _stream()), 'xr_rays_sampler_series')
+    _lib.check(L.xr_clip_numsteps_series(_ptr(win.numsteps[c0:c1]), _ptr(win.counter2[c0:c1]), n, n_chunks, win.ray_stride, max_compacted,
+                                         _ptr(win.clipped[c0:c1]), _ptr(win.n_valid[c0:c1]), _stream()), 'xr_clip_numsteps_series')
+    return cur
 
 
 class TrainStepBuffers:
@@ -339,7 +400,7 @@ class TrainStepBuffers:
 
 
 def ngp_train_step(table, wd, wc, nhd, nhc, pad_value, meta, coords, n_dev, numsteps, numsteps_c, bg, target, alpha,
-                   density_grid_mean, rgb_act, density_act, bufs, huber_delta=0.1, loss_scale=5.0, scatter_level0=0, xyz=None, mark=None,
+                   density_grid_mean, rgb_act, density_act, bufs, huber_delta=0.1, loss_scale=5.0, scatter_level0=0, xyz=None,
                    adam=None, mlp_adam=None):
     """the device work of one HashNerfNetwork training step as one native call (xr_ngp_train_step): encode -> MLP -> K3 +
     Huber + K4 -> MLP backward -> table scatter into `bufs` (TrainStepBuffers).  Returns rgb [n_rays,3] (a view of bufs.rgb).
@@ -395,7 +456,6 @@ def ngp_train_step(table, wd, wc, nhd, nhc, pad_value, meta, coords, n_dev, nums
             TIMER.events.setdefault(stage, []).append((ev[0], ev[1], 0))
     rc = L.xr_ngp_train_step(*head, n_rays, *mid, C.byref(adam) if adam is not None else None,
                              C.byref(mlp_adam[0]) if mlp_adam else None, C.byref(mlp_adam[1]) if mlp_adam else None,
-                             mark[0].encode() if mark else None, mark[1].h if mark else None,
                              stage.encode() if stage else None, ev[0].h if stage else None, ev[1].h if stage else None, _stream())
     if rc != 0:
         _lib.check(rc, 'xr_ngp_train_step')

@@ -16,6 +16,9 @@ Deliberate differences, none of which changes a result:
   * sample bases are the exclusive prefix sum in ray order (deterministic) instead of atomicAdd
     order, so when nothing is clipped K1's output already IS the compacted layout and K2 is a no-op
     alias (it runs only when S > target_batch_size or K1 overflowed);
+  * the occupancy bitfield and the batch size only change at a grid refresh and K1 reads no weights, so the
+    marches of the iterations up to the next refresh can be issued right behind a refresh as ONE series of
+    launches (`march_window`): same batches, same samples, same RNG call indices as one launch per iteration;
   * the hidden global RNG (`static pcg32 rng{9121}` per translation unit) becomes two explicit call
     counters on this object.
 """
@@ -32,9 +35,9 @@ from .builder import SAMPLERS
 @SAMPLERS.register_module()
 class NGPGridSampler(_FastAttr, nn.Module):
     # per-step state (never a Parameter, a registered buffer or a sub-module): assigned ~15 times per training iteration
-    _FAST_ATTRS = frozenset(('iter_n', 'on_sampled', '_prefetched_q', 'rays_index', 'coords', 'xyz', 'rays_numsteps', 'rays_numsteps_compacted',
-                             'n_valid_dev', 'persistent_batches', '_train_launches', '_pinned_next', 'k1_calls', '_test_rows_seen',
-                             'frame_chunk', 'frame_ray0', '_pending_counts', 'n_rays_per_batch'))
+    _FAST_ATTRS = frozenset(('iter_n', 'on_sampled', 'on_rewind', '_prefetched_q', 'rays_index', 'coords', 'xyz', 'rays_numsteps', 'rays_numsteps_compacted',
+                             'n_valid_dev', '_pinned_next', 'k1_calls', '_test_rows_seen',
+                             'frame_chunk', 'frame_ray0', '_pending_counts', 'n_rays_per_batch', '_window'))
     def __init__(self, update_grid_freq=16, update_block_size=5000000, n_rays_per_batch=4096,
                  cone_angle_constant=0.00390625, near_distance=0.2, target_batch_size=1 << 18, rgb_activation=2,
                  density_activation=3):
@@ -216,49 +219,45 @@ class NGPGridSampler(_FastAttr, nn.Module):
         # cleared here, and a batch of more than 65536 rays gets 64 rows per ray (the reference's K1 would silently
         # drop the samples that do not fit; `reference_buffer_rows = True` reproduces exactly that)
         if is_training:
-            max_samples = self.num_coords_elements if getattr(self, 'reference_buffer_rows', False) else \
-                max(self.num_coords_elements, n_rays * 64)
-            max_samples = min(max_samples, n_rays * self.MAX_STEP)
+            max_samples = self.train_max_samples(n_rays)
         else:
             # test / render: the worst case is 1024 rows per ray (18 GB for an 800x800 frame marched in one call); the
             # buffer is sized from the previous test launch (first time: 48 rows per ray) and the launch is repeated with
             # the exact size -- same RNG call index, identical result -- in the rare case it overflowed
             est = max(n_rays * 48, int(getattr(self, '_test_rows_seen', 0) * 1.25) + 1024)
             max_samples = min(n_rays * self.MAX_STEP, est)
-        # prefetched marches wait in issue order (up to two: the next iteration's and the one after); a render / val call in
-        # between leaves them alone
+        # marches issued ahead (march_window: the rest of a refresh window) wait in iteration order.  A test / render launch in between
+        # takes them back first: the reference's hidden generator is shared by training and test launches (one `static pcg32` per
+        # translation unit), so a frame rendered between iterations j - 1 and j moves the jitter of iteration j on -- the marches of j..
+        # are dropped and their RNG / batch counters rewound, and the trainer marches what is left of the window again afterwards
         q = self.__dict__.get('_prefetched_q')
+        if q and not is_training:
+            self.rewind_marches()
         pf = q.pop(0) if (is_training and q) else None
         if (pf is not None and pf['rays_o'].data_ptr() == data['rays_o'].data_ptr() and
                 pf['rays_o'].shape == data['rays_o'].shape and pf['max_samples'] == max_samples):
-            # K1 of this batch already ran on the side stream while the previous iteration's backward was
-            # executing (prefetch()): order this stream after it and adopt its outputs
-            pf['event'].wait()                          # the current stream waits (no torch.cuda.current_stream(): ~10 us of Python)
+            # K1 of this batch already ran (march_window, right behind the window's grid refresh): order this stream after it -- once
+            # per window -- and adopt its outputs
+            self._wait_march(pf)
             coords, rays_index, rays_numsteps, counter = pf['out']
             xyz = pf.get('xyz')
             clipped = pf.get('clipped')
             self._pending_counts.append(pf['host'])
-            # K1's outputs live in this sampler's persistent double buffers (nothing was allocated on the side
-            # stream).  Batch tensors allocated there by the caller must be handed over to this stream -- unless
-            # the caller owns them persistently too (`persistent_batches`): every record_stream'd tensor costs an
-            # event record on this stream when it is freed, ~6 us of idle GPU each, 9 of them per iteration
-            if not getattr(self, 'persistent_batches', False):
-                cur = torch.cuda.current_stream()
-                for t in data.values():
-                    if torch.is_tensor(t) and t.is_cuda:
-                        t.record_stream(cur)
+            # (K1's outputs and the batch tensors are views of the sampler's persistent window buffers: nothing was allocated on the
+            # side stream, nothing has to be handed between the streams' allocator pools)
         else:
             clipped = None
             if pf is not None:
-                # a prefetched march that does not belong to this batch is dropped (its RNG call stays consumed, like
+                # a march issued ahead that does not belong to this batch is dropped (its RNG call stays consumed, like
                 # any other launch); its side-stream writes into the shared buffers must have finished before this
                 # stream's launch touches them
-                cur = torch.cuda.current_stream()
-                cur.wait_event(pf['event'])
+                self._wait_march(pf)
                 for other in q:                     # (whatever was marched behind it is as stale as it is)
-                    cur.wait_event(other['event'])
+                    self._wait_march(other)
                 del q[:]
-            slot = self._next_slot(is_training)
+            slot = (self.iter_n % self.WINDOW) if is_training else self.TEST_SLOT
+            if is_training:
+                self.window_for(n_rays, max_samples)
             k1_index = self.k1_calls
             async_test = (not is_training) and getattr(self, '_async_test', None) is not None and self._streams()
             if async_test:
@@ -277,7 +276,9 @@ class NGPGridSampler(_FastAttr, nn.Module):
                 rays_o, rays_d, self.density_grid_bitfield, aabb, self.near_distance, self.cone_angle_constant,
                 max_samples, k1_index, coords_out=self._coords_buffer(max_samples, slot),
                 small_out=None if async_test else self._small_buffers(n_rays, slot), xyz_out=xyz, rng_chunk=rng_chunk, rng_ray0=rng_ray0,
-                wide=is_training)       # (a training march in place = the iteration of a grid refresh: nothing runs beside it)
+                # 8 lanes per ray where nothing runs beside the march: the iteration of a grid refresh (every other in-place march may
+                # run beside a collective or the K6 prefetch: one ray per lane, same samples)
+                wide=is_training and self.iter_n % self.update_grid_freq == 0 and getattr(self, 'wide_in_place', True))
             # (a band: the launches of the chunk series its rays fall into; the network puts the whole frame's count back afterwards)
             self.k1_calls += ((rng_ray0 + n_rays + rng_chunk - 1) // rng_chunk - rng_ray0 // rng_chunk) if rng_chunk else 1
             if async_test:
@@ -330,7 +331,7 @@ class NGPGridSampler(_FastAttr, nn.Module):
         # MLP has a fixed target_batch_size rows (compacted_coords.py:20-21 pads with zeros); the number of
         # valid rows stays on the device (`n_valid_dev`) so that no host read-back is needed here.
         if clipped is None:
-            clipped = ops.clip_numsteps(rays_numsteps, counter, self.target_batch_size)
+            clipped = ops.clip_numsteps(rays_numsteps, counter, self.target_batch_size, out=self._clip_buffers(n_rays, slot))
         rays_numsteps_compacted, n_valid_dev = clipped
         # the pre-clip counter the reference accumulates in `measured_batch_size` (ngp_grid_sampler.py:252) is
         # accumulated on the host from the asynchronous pinned copies (_pending_counts)
@@ -350,25 +351,33 @@ class NGPGridSampler(_FastAttr, nn.Module):
             cb()       # e.g. the trainer issues the NEXT batch's march on a side stream right here
         return data
 
-    # K1 output buffers are persistent and owned by the sampler: slots 0..2 rotate over the TRAINING launches (a march may be
-    # issued two iterations ahead -- Trainer, prefetch depth 2 -- while the two iterations before it still read their rows),
-    # slot 3 serves test / render launches, which may come in between
-    TRAIN_SLOTS = _lib.MARCH_SETS          # = XR_NGP_MARCH_SETS (include/xrnerf_mi355.h)
-    N_SLOTS = TRAIN_SLOTS + 1
+    # K1's output buffers are persistent and owned by the sampler.  Training: the XR_NGP_WINDOW chunks of ONE window allocation
+    # (ops.MarchWindow) -- iteration `it` lives in chunk it % WINDOW, whether it was marched ahead with the rest of its refresh window
+    # (march_window) or in place.  Test / render launches, which may come in between, have a slot of their own.
+    WINDOW = ops.MarchWindow.N               # = XR_NGP_WINDOW (include/xrnerf_mi355.h)
+    TEST_SLOT = WINDOW
 
-    def _next_slot(self, is_training):
-        if not is_training:
-            return self.TRAIN_SLOTS
-        self._train_launches = getattr(self, '_train_launches', 0) + 1
-        return self._train_launches % self.TRAIN_SLOTS
+    def train_max_samples(self, n_rays):
+        """rows of a training launch's sample buffer.  The reference sizes it n_rays_per_batch(ctor) * 1024 rows whatever the batch
+        (117 MB zero-filled per call, samplers/utils/rays_sampler.py:20-21); nothing reads rows past the counter, so it is not cleared
+        here, and a batch of more than 65536 rays gets 64 rows per ray (the reference's K1 would silently drop the samples that do not
+        fit; `reference_buffer_rows = True` reproduces exactly that)"""
+        m = self.num_coords_elements if getattr(self, 'reference_buffer_rows', False) else max(self.num_coords_elements, n_rays * 64)
+        return min(m, n_rays * self.MAX_STEP)
+
+    def window_for(self, n_rays, max_samples):
+        """the window allocation, grown when a batch size / row capacity does not fit (marches issued ahead keep their old views)"""
+        w = self.__dict__.get('_window')
+        if w is None or w.ray_stride < n_rays or w.coords_stride < max_samples or w.device != self.device:
+            w = self._window = ops.MarchWindow(self.device, max((n_rays + 127) // 128 * 128, 1 << 15), max_samples, planes=self._streams())
+        return w
 
     def _coords_buffer(self, rows, slot):
-        bufs = getattr(self, '_coords_bufs', None)
-        if bufs is None:
-            bufs = self._coords_bufs = [None] * self.N_SLOTS
-        buf = bufs[slot]
+        if slot < self.WINDOW:
+            return self._window.coords[slot][:rows]
+        buf = getattr(self, '_test_coords', None)
         if buf is None or buf.shape[0] < rows or buf.device != self.device:
-            buf = bufs[slot] = torch.empty((rows, 7), dtype=torch.float32, device=self.device)
+            buf = self._test_coords = torch.empty((rows, 7), dtype=torch.float32, device=self.device)
         return buf[:rows]
 
     def begin_async_test(self):
@@ -390,43 +399,34 @@ class NGPGridSampler(_FastAttr, nn.Module):
         coalesced input.  Device only (the host build of the kernels reads the rows)."""
         if not self._streams():
             return None
-        bufs = getattr(self, '_xyz_bufs', None)
-        if bufs is None:
-            bufs = self._xyz_bufs = [None] * self.N_SLOTS
-        buf = bufs[slot]
+        if slot < self.WINDOW:
+            return self._window.xyz[slot]
+        buf = getattr(self, '_test_xyz', None)
         if buf is None or buf.shape[1] < rows or buf.device != self.device:
-            buf = bufs[slot] = torch.empty((3, rows), dtype=torch.float32, device=self.device)
+            buf = self._test_xyz = torch.empty((3, rows), dtype=torch.float32, device=self.device)
         return buf
 
     def _small_buffers(self, n_rays, slot):
-        bufs = getattr(self, '_small_bufs', None)
-        if bufs is None:
-            bufs = self._small_bufs = [None] * self.N_SLOTS
-        b = bufs[slot]
+        if slot < self.WINDOW:
+            w = self._window
+            return w.rays_index[slot][:n_rays], w.numsteps[slot][:n_rays], w.counter2[slot]
+        b = getattr(self, '_test_small', None)
         if b is None or b[0].shape[0] < n_rays or b[0].device != self.device:
             cap = max(n_rays, 1 << 15)
-            b = bufs[slot] = (torch.empty((cap, 1), dtype=torch.int32, device=self.device),
-                              torch.empty((cap, 2), dtype=torch.int32, device=self.device),
-                              torch.empty((2,), dtype=torch.int32, device=self.device))
+            b = self._test_small = (torch.empty((cap, 1), dtype=torch.int32, device=self.device),
+                                    torch.empty((cap, 2), dtype=torch.int32, device=self.device),
+                                    torch.empty((2,), dtype=torch.int32, device=self.device))
         return b[0][:n_rays], b[1][:n_rays], b[2]
 
     def _clip_buffers(self, n_rays, slot):
-        """persistent outputs of the prefetched K2 clip (nothing allocated on the side stream)"""
-        bufs = getattr(self, '_clip_bufs', None)
-        if bufs is None:
-            bufs = self._clip_bufs = [None] * self.N_SLOTS
-        b = bufs[slot]
-        if b is None or b[0].shape[0] < n_rays or b[0].device != self.device:
-            cap = max(n_rays, 1 << 15)
-            b = bufs[slot] = (torch.empty((cap, 2), dtype=torch.int32, device=self.device),
-                              torch.empty((2,), dtype=torch.int32, device=self.device))
-        return b[0][:n_rays], b[1]
+        """persistent outputs of K2's clip"""
+        w = self._window
+        return w.clipped[slot][:n_rays], w.n_valid[slot]
 
-    # ------------------------------------------------------------------ K1 overlap
-    def can_prefetch(self, next_iter):
-        """K1 depends on the rays and the bitfield only -- not on the parameters -- so the march of iteration
-        i+1 can run on a side stream underneath iteration i's (atomic-bound) backward, unless iteration i+1
-        refreshes the occupancy grid first."""
+    # ------------------------------------------------------------------ the window's marches
+    def can_march_ahead(self, next_iter):
+        """K1 depends on the rays and the bitfield only -- not on the parameters -- so an iteration can be marched ahead of its step
+        unless it refreshes the occupancy grid first"""
         return hasattr(self, 'density_grid') and next_iter % self.update_grid_freq != 0
 
     def _streams(self):
@@ -441,70 +441,93 @@ class NGPGridSampler(_FastAttr, nn.Module):
             self._side = torch.cuda.Stream(device=self.device)
         return self._side
 
-    def prefetch(self, data, buffer_free_event=None):
-        """call inside `with torch.cuda.stream(self.side_stream())`, with the batch created there too.
-        `buffer_free_event`: recorded on the compute stream when the iteration BEFORE the current one (the last
-        reader of the coordinate buffer this launch overwrites) had been enqueued completely."""
-        rays_o, rays_d = data['rays_o'], data['rays_d']
-        n_rays = rays_o.shape[0]
-        aabb = (float(self.aabb_range[0]), float(self.aabb_range[1]))
-        max_samples = self.num_coords_elements if getattr(self, 'reference_buffer_rows', False) else \
-            max(self.num_coords_elements, n_rays * 64)
-        max_samples = min(max_samples, n_rays * self.MAX_STEP)
-        side = torch.cuda.current_stream()
-        ev = getattr(self, '_bitfield_event', None)
-        if ev is not None:
-            side.wait_event(ev)
-        if buffer_free_event is not None:
-            side.wait_event(buffer_free_event)
-        slot = self._next_slot(True)
-        xyz = self._xyz_buffer(max_samples, slot)
-        out = ops.rays_sampler(rays_o, rays_d, self.density_grid_bitfield, aabb, self.near_distance,
-                               self.cone_angle_constant, max_samples, self.k1_calls,
-                               coords_out=self._coords_buffer(max_samples, slot), ws_tag='k1_side',
-                               small_out=self._small_buffers(n_rays, slot), xyz_out=xyz)
-        self.k1_calls += 1
-        # K2's clipped per-ray counts and the device-side valid-row count only depend on this launch's outputs: computed
-        # here, on the side stream, instead of in front of the next iteration's encode
-        clipped = ops.clip_numsteps(out[2], out[3], self.target_batch_size, out=self._clip_buffers(n_rays, slot))
-        # the compute stream waits for the MARCH only: the event sits before the counter's device-to-host copy
-        # (behind it, the waiter also inherits the copy's system-scope completion: measured 45 us of idle compute
-        # stream at the start of every iteration)
-        done = torch.cuda.Event()
-        done.record(side)
-        host = self._count_to_host(out[3])
-        self.__dict__.setdefault('_prefetched_q', []).append({'rays_o': rays_o, 'max_samples': max_samples, 'out': out, 'event': done,
-                                                              'host': host, 'clipped': clipped, 'xyz': xyz})
+    def _wait_march(self, pf):
+        """order the current stream behind the march `pf` came from -- once per series of marches (they share one event)"""
+        ev, gate = pf.get('event'), pf.get('gate')
+        if ev is not None and not (gate is not None and gate['waited']):
+            ev.wait()                                   # the current stream waits (no torch.cuda.current_stream(): ~10 us of Python)
+            if gate is not None:
+                gate['waited'] = True
 
-    def prefetch_native(self, rows, n_rays, batch_call_index, batch_out, buffer_free_event=None, start_event=None):
-        """`prefetch` with the batch assembly folded in, as ONE native call (xr_ngp_prefetch: make_batch + K1 + K2 clip + counter
-        copy) on the current (side) stream.  -> the batch dict (views of `batch_out`)."""
+    def march_window(self, rows_table, cur_ray, batch_call_index, first_iter, n_iters, n_rays, batches_ready=0, on_side=True):
+        """Draw and march iterations first_iter .. first_iter + n_iters - 1 -- the rest of a refresh window: same bitfield, same batch
+        size (ngp_grid_sampler.py:194-197,268-281) -- as ONE series of launches (xr_ngp_window_march).  rows_table = the device-resident
+        [N, 11] ray table, cur_ray / batch_call_index = HashBatchSample's cursor and the batch generator's call index for the first
+        batch drawn here (the first `batches_ready` iterations already hold their batch in their chunk).  on_side: on the side stream,
+        behind the last refresh (beside the refresh iteration's own step); else on the current stream.
+        -> (cursor behind the last batch, [batch dict per iteration])"""
+        n = int(n_rays)
+        max_samples = self.train_max_samples(n)
+        win = self.window_for(n, max_samples)
+        W = self.WINDOW
+        c0 = first_iter % W
+        if n_iters < 1 or c0 + n_iters > W:
+            raise ValueError('iterations %d..%d are not inside one window of %d' % (first_iter, first_iter + n_iters - 1, W))
         aabb = (float(self.aabb_range[0]), float(self.aabb_range[1]))
-        max_samples = self.num_coords_elements if getattr(self, 'reference_buffer_rows', False) else \
-            max(self.num_coords_elements, n_rays * 64)
-        max_samples = min(max_samples, n_rays * self.MAX_STEP)
-        side = self.side_stream()
-        ev = getattr(self, '_bitfield_event', None)
-        if ev is not None:
-            side.wait_event(ev)
-        if buffer_free_event is not None:
-            side.wait_event(buffer_free_event)
-        if start_event is not None:
-            ops.stream_wait_event(side, start_event)        # a point inside the current step (library event)
-        slot = self._next_slot(True)
-        xyz = self._xyz_buffer(max_samples, slot)
-        batch, out, clipped = ops.ngp_prefetch(rows, n_rays, batch_call_index, batch_out, self.density_grid_bitfield, aabb,
-                                               self.near_distance, self.cone_angle_constant, max_samples, self.k1_calls,
-                                               self._coords_buffer(max_samples, slot), self._small_buffers(n_rays, slot),
-                                               self._clip_buffers(n_rays, slot), self.target_batch_size, None, xyz_out=xyz)
-        self.__dict__['k1_calls'] = self.k1_calls + 1
-        # the compute stream waits for the march only: its event sits BEFORE the counter's device-to-host copy (see prefetch)
-        done = torch.cuda.Event()
-        done.record(side)
-        host = self._count_to_host(out[3])
-        self.__dict__.setdefault('_prefetched_q', []).append({'rays_o': batch['rays_o'], 'max_samples': max_samples, 'out': out,
-                                                              'event': done, 'host': host, 'clipped': clipped, 'xyz': xyz, 'slot': slot})
-        return batch
+        k1_0 = self.k1_calls
+        # the cursor of every batch drawn here (what a rewind puts back: rewind_marches)
+        cursors, cur = [], int(cur_ray)
+        for j in range(n_iters):
+            if j >= batches_ready and cur + n > rows_table.shape[0]:
+                cur = 0
+            cursors.append(cur)
+            if j >= batches_ready:
+                cur += n
+        on_side = bool(on_side and self._streams())
+        ev = host_ev = None
+        if on_side:
+            side, main_ev = self.side_stream(), getattr(self, '_bitfield_event', None)
+            if main_ev is None:
+                main_ev = torch.cuda.Event()
+                main_ev.record()
+            with torch.cuda.stream(side):
+                # behind the last refresh: the last writer of the bitfield, and behind every step of the window before (the last readers
+                # of the chunks this series overwrites)
+                side.wait_event(main_ev)
+                end = ops.ngp_window_march(win, c0, n_iters, batches_ready, n, rows_table, cur_ray, batch_call_index, self.density_grid_bitfield,
+                                           aabb, self.near_distance, self.cone_angle_constant, max_samples, k1_0, self.target_batch_size)
+                ev = torch.cuda.Event()
+                ev.record(side)
+                host_ev = ev
+        else:
+            end = ops.ngp_window_march(win, c0, n_iters, batches_ready, n, rows_table, cur_ray, batch_call_index, self.density_grid_bitfield,
+                                       aabb, self.near_distance, self.cone_angle_constant, max_samples, k1_0, self.target_batch_size)
+            if self._streams():
+                host_ev = torch.cuda.Event()
+                host_ev.record()
+        assert end == cur
+        self.k1_calls = k1_0 + n_iters
+        gate = {'waited': ev is None}
+        q = self.__dict__.setdefault('_prefetched_q', [])
+        batches = []
+        for j in range(n_iters):
+            c = c0 + j
+            b = win.batch(c, n)
+            host = (host_ev, win.pinned[c]) if win.pinned is not None else (None, win.counter2[c])
+            q.append({'rays_o': b['rays_o'], 'max_samples': max_samples,
+                      'out': (win.coords[c][:max_samples], win.rays_index[c][:n], win.numsteps[c][:n], win.counter2[c]),
+                      'event': ev, 'gate': gate, 'host': host, 'clipped': (win.clipped[c][:n], win.n_valid[c]),
+                      'xyz': win.xyz[c] if win.xyz is not None else None, 'slot': c, 'window': win, 'iter': first_iter + j,
+                      'k1_index': k1_0 + j, 'cur_ray': cursors[j], 'batch_index': batch_call_index + max(j - batches_ready, 0),
+                      'drawn_here': j >= batches_ready})
+            batches.append(b)
+        return end, batches
+
+    def rewind_marches(self):
+        """Take back the marches issued ahead and not consumed yet: the hidden generator's call counter goes back to the first of them
+        (`on_rewind(entry)` lets the owner of the batch cursor do the same), the current stream is ordered behind their launches."""
+        q = self.__dict__.get('_prefetched_q')
+        if not q:
+            return
+        for pf in q:
+            self._wait_march(pf)
+        first = q[0]
+        if 'k1_index' in first:
+            self.k1_calls = first['k1_index']
+        cb = getattr(self, 'on_rewind', None)
+        del q[:]
+        if cb is not None:
+            cb(first)
 
     def _count_to_host(self, counter):
         """asynchronous copy of K1's (rays, samples) counter to pinned host memory, right behind the launch: by

@@ -6,8 +6,8 @@ a compile-time constant of one source (tools/build_variant.sh + XRNERF_LIB) or g
   XRNERF_MLP_PRECISION         f32 (default, parity mode) | f16 (the reference's tcnn arithmetic) -- ops.set_precision
   XRNERF_DP                    allreduce (default) | allreduce_bf16 (the table gradient crosses the links as bf16) | zero1 -- the
                                data-parallel gradient exchange (train.Trainer, dist.py)
-  XRNERF_TRAINER               "k=v,..." overrides of Trainer's keyword switches: native_loop, fuse_adam, direct_step, overlap_march,
-                               prefetch_depth, prefetch_k6, march_after (A/B runs of bench.py / tools without editing code)
+  XRNERF_TRAINER               "k=v,..." overrides of Trainer's keyword switches: native_loop, fuse_adam, direct_step, march_window
+                               (side | main | off), prefetch_k6 (A/B runs of bench.py / tools without editing code)
   XRNERF_STEP                  fused (default: one native call per training step) | py (the same entry points issued one by one from
                                Python: per-entry-point timers, the kernels' host build) | modular (sampler -> mlp -> render -> autograd)
   XRNERF_FRAME                 one_launch (default: a chunked test frame as one launch per kernel, same pixels) | async (the chunk loop
@@ -33,12 +33,11 @@ def frame_mode():
     return m
 
 
-TRAINER_KEYS = {'native_loop': bool, 'fuse_adam': bool, 'direct_step': bool, 'overlap_march': bool, 'prefetch_depth': int, 'prefetch_k6': bool,
-                'march_after': str}
+TRAINER_KEYS = {'native_loop': bool, 'fuse_adam': bool, 'direct_step': bool, 'march_window': str, 'prefetch_k6': bool}
 
 
 def trainer_overrides():
-    """XRNERF_TRAINER="fuse_adam=0,prefetch_depth=1" -> {'fuse_adam': False, 'prefetch_depth': 1}"""
+    """XRNERF_TRAINER="fuse_adam=0,march_window=off" -> {'fuse_adam': False, 'march_window': 'off'}"""
     out = {}
     for item in filter(None, os.environ.get('XRNERF_TRAINER', '').split(',')):
         k, _, v = item.partition('=')

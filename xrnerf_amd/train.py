@@ -210,29 +210,28 @@ class Trainer:
     backward -> [gradient all-reduce] -> fused Adam(+EMA)."""
 
     def __init__(self, device, n_img=20, H=800, W=800, seed=0, world_size=1, rank=0, dataset=None, ema=True, native_loop=True,
-                 fuse_adam=True, direct_step=True, overlap_march=True, prefetch_depth=2, prefetch_k6=True, march_after='xr_live_rows'):
+                 fuse_adam=True, direct_step=True, march_window='side', prefetch_k6=True):
         """The keyword switches (each overridable from the environment: XRNERF_TRAINER="fuse_adam=0,..."; xrnerf_amd/switches.py):
         native_loop     the iterations between two grid refreshes as native calls (xr_ngp_loop_run); False: one Python-driven step each
         fuse_adam       one GPU: the table scatter applies this optimiser's update itself (False: scatter, then the optimiser's launches)
         direct_step     one GPU: the fused step without an autograd graph (False: loss.backward() + optimizer.step())
-        overlap_march   K1 of later batches on a side stream under the current step (False: in order on the compute stream)
-        prefetch_depth  2: the march of iteration i + 2 is issued during iteration i, behind its MLP backward; 1: iteration i + 1 at once
-        prefetch_k6     the refresh's sample generation one iteration early, on the side stream
-        march_after     (prefetch_depth 2) the entry point of step i behind which the march of iteration i + 2 starts: 'xr_live_rows'
-                        (default: beside the MLP backward and the scatter; a normal iteration 0.401 ms against 0.408-0.410 behind the
-                        MLP backward, 0.423 from the step's start or behind the lookup / MLP forward: profiles/r04_march_start_point_ab.txt),
-                        'xr_hashgrid_fwd', 'xr_nerf_mlp_fwd', 'xr_composite_train', 'xr_nerf_mlp_bwd', or 'start'"""
-        opts = dict(native_loop=native_loop, fuse_adam=fuse_adam, direct_step=direct_step, overlap_march=overlap_march,
-                    prefetch_depth=prefetch_depth, prefetch_k6=prefetch_k6, march_after=march_after)
+        march_window    'side' (default): right behind a grid refresh the batches of the iterations up to the next refresh are drawn and
+                        marched as ONE series of launches (the bitfield and the batch size do not change in between, K1 reads no
+                        weights) on a side stream, beside the refresh iteration's own step -- the other iterations then run on one
+                        in-order stream with nothing beside them; 'main': the same series on the compute stream; 'off': every
+                        iteration marches in place
+        prefetch_k6     the refresh's sample generation one iteration early, on the side stream"""
+        opts = dict(native_loop=native_loop, fuse_adam=fuse_adam, direct_step=direct_step, march_window=march_window, prefetch_k6=prefetch_k6)
         opts.update(switches.trainer_overrides())
-        if opts['prefetch_depth'] not in (1, 2):
-            raise ValueError('prefetch_depth is 1 or 2')
+        if opts['march_window'] not in ('side', 'main', 'off'):
+            raise ValueError("march_window is 'side', 'main' or 'off'")
         torch.manual_seed(seed)                       # identical initial weights on every rank
         self.device = device
         self.net = build_network(ngp_lego_model_cfg()).to(device)
         self.data = dataset or SyntheticLego(device, n_img, H, W, seed=1, shuffle_seed=1 + rank)
         self.net.sampler.set_data(self.data.get_alldata(), self.data.get_info())     # PassDatasetHook
         self.net.sampler.on_sampled = self._on_sampled
+        self.net.sampler.on_rewind = self._on_rewind
         self.base_lr = 1e-2
         self.iter = 0
         self.world_size, self.rank = world_size, rank
@@ -264,33 +263,19 @@ class Trainer:
         self._opt_params = opt_params
         self.rays_done = 0
         self.lazy_log = True
-        self.overlap_march = opts['overlap_march']
-        # prefetch_depth 2: the march of iteration i + 2 is issued during iteration i and starts behind an entry point of step i (the event
-        # the native step records there; `march_after`), so that its ~290 us of latency-bound waves run beside the backward half of
-        # the step -- round 3 started it behind the MLP backward (profiles/r03_k1_placement_ab.txt: beside the fused-MLP forward it
-        # costs that kernel 15 us), round 4 measured every start point under the native loop and moved it behind the live-row list:
-        # the march then ends before the next step's MLP forward begins.  With one iteration of lead a late start point leaves the
-        # march unfinished when its rows are needed (profiles/r03_prefetch_start_point.txt); with two it has a whole iteration.
-        self.prefetch_depth = opts['prefetch_depth']
-        if opts['march_after'] not in ('start', 'xr_hashgrid_fwd', 'xr_nerf_mlp_fwd', 'xr_composite_train', 'xr_live_rows', 'xr_nerf_mlp_bwd'):
-            raise ValueError('march_after: unknown entry point %r' % opts['march_after'])
-        self.march_after = opts['march_after']
-        self.net._step_mark = ((self.march_after, ops._CEvent(timing=False))
-                               if (self.prefetch_depth == 2 and self.march_after != 'start' and device.type == 'cuda') else None)
+        self.march_window = opts['march_window']
         self.prefetch_k6 = opts['prefetch_k6']      # the refresh's K6 one iteration early, on the side stream
-        self._ev_done = [None, None]   # completion events of the last two iterations (None: the native loop ran it and holds the event)
-        # the iterations between two grid refreshes as native calls (xr_ngp_loop_run: batch draw, march two iterations ahead, step with the
-        # updates inside, enqueued from C++ -- the interpreter had been pacing the loop at 0.36 ms of host work per 0.42-ms iteration).
-        # Needs what the fast Python path needs (one GPU, fused updates, the direct step, the native side-stream march, a device-resident
+        # the iterations between two grid refreshes as native calls (xr_ngp_loop_run: the steps of the marched window with the updates
+        # inside, enqueued from C++ -- the interpreter had been pacing the loop at 0.36 ms of host work per 0.42-ms iteration).
+        # Needs what the fast Python path needs (one GPU, fused updates, the direct step, a marched window, a device-resident
         # ray table); anything else keeps the per-iteration path.
         self.native_loop = opts['native_loop']
         self._loop = None
-        self._bbufs = [None] * _lib.MARCH_SETS      # one per rotating set (samplers.NGPGridSampler.TRAIN_SLOTS)
         self._queue = []               # [(iteration, batch)] marched ahead, in order
         self._one = None
 
     def step(self):
-        if self._native_ok() and self.iter % self.net.sampler.update_grid_freq != 0 and hasattr(self.net.sampler, 'density_grid'):
+        if self._native_span(1):
             return self._run_native(1)
         return self._step_py()
 
@@ -298,10 +283,9 @@ class Trainer:
         """k iterations.  `iter_events` (k + 1 ops._CEvent timing events, optional): recorded on the compute stream in front of every
         iteration and behind the last (bench.py's per-iteration device times)."""
         out, done = None, 0
-        f = self.net.sampler.update_grid_freq
         while done < k:
-            if self._native_ok() and self.iter % f != 0 and hasattr(self.net.sampler, 'density_grid'):
-                n = min(k - done, f - self.iter % f)
+            n = self._native_span(k - done)
+            if n:
                 out = self._run_native(n, iter_events[done:done + n + 1] if iter_events is not None else None)
             else:
                 n = 1
@@ -321,10 +305,9 @@ class Trainer:
             from .samplers import NGPGridSampler
             net = self.net
             st = self._native_static = bool(
-                self.native_loop and self.world_size == 1 and self.fuse_adam and self.direct_step and self.overlap_march and
-                self.prefetch_depth == 2 and self.device.type == 'cuda' and hasattr(self.data, 'rays_rgb') and
-                type(net.sampler) is NGPGridSampler and type(net.mlp) is HashNerfMLP and type(net.render) is HashNerfRender and
-                net.mlp.density_net.n_hidden == 1 and net.mlp.color_net.n_hidden == 2 and self._data_takes_batches() and
+                self.native_loop and self.world_size == 1 and self.fuse_adam and self.direct_step and self.march_window != 'off' and
+                self.device.type == 'cuda' and self._window_ok() and type(net.sampler) is NGPGridSampler and type(net.mlp) is HashNerfMLP and
+                type(net.render) is HashNerfRender and net.mlp.density_net.n_hidden == 1 and net.mlp.color_net.n_hidden == 2 and
                 isinstance(self.opt, FusedAdam))
         if not st or getattr(self.net, 'grad_sync', None) is not None:
             return False
@@ -333,6 +316,28 @@ class Trainer:
         if ops.TIMER is not None and not ops.TIMER.native_stage()[0]:
             return False
         return True
+
+    def _native_span(self, want):
+        """-> how many of the next `want` iterations the native loop can run in one call: marched ahead (in this trainer's queue and the
+        sampler's, in the sampler's current window allocation), none of them a grid refresh"""
+        if not self._queue or self._queue[0][0] != self.iter or not self._native_ok():
+            return 0
+        sampler = self.net.sampler
+        q = sampler.__dict__.get('_prefetched_q') or []
+        win = sampler.__dict__.get('_window')
+        n = 0
+        while (n < want and n < len(self._queue) and n < len(q) and self._queue[n][0] == self.iter + n and q[n].get('iter') == self.iter + n
+               and q[n].get('window') is win and (self.iter + n) % sampler.update_grid_freq != 0):
+            n += 1
+        return n
+
+    def _window_ok(self):
+        """the marches of a window are drawn from a device-resident ray table by the sampler that owns the window's buffers"""
+        ok = getattr(self, '_window_static', None)
+        if ok is None:
+            from .samplers import NGPGridSampler
+            ok = self._window_static = hasattr(self.data, 'rays_rgb') and isinstance(self.net.sampler, NGPGridSampler) and self._data_takes_batches()
+        return ok
 
     def _data_takes_batches(self):
         if getattr(self, '_data_takes_out', None) is None:
@@ -345,16 +350,25 @@ class Trainer:
             self._loop = _NativeLoop(self)
         return self._loop.run(k, iter_events)
 
+    def _draw(self):
+        """this iteration's batch, drawn now: into its chunk of the sampler's window where there is one (persistent buffers)"""
+        data, sampler = self.data, self.net.sampler
+        if self._window_ok() and sampler.device is not None:
+            n = min(data.N_rand, data.rays_rgb.shape[0])
+            win = sampler.window_for(n, sampler.train_max_samples(n))
+            return data.next_batch(out=win.batch_out(self.iter % sampler.WINDOW))
+        return data.next_batch()
+
     def _step_py(self):
         net, data = self.net, self.data
-        if self._loop is not None and self._loop.state.queued:
-            self._loop.release_to_python()                                # marches the native loop issued ahead: this path's queue now
         net.sampler.set_iter(self.iter)                                   # PassSamplerIterHook
         for g in self.opt.param_groups:
             g['lr'] = step_lr(self.base_lr, self.iter)
-        batch = self._queue.pop(0)[1] if (self._queue and self._queue[0][0] == self.iter) else None
+        if self._queue and self._queue[0][0] != self.iter:
+            net.sampler.rewind_marches()                                  # marched for other iterations than the one that runs now
+        batch = self._queue.pop(0)[1] if self._queue else None
         if batch is None:
-            batch = data.next_batch()
+            batch = self._draw()
         n_rays = batch['rays_o'].shape[0]
         # the reference's DataLoader(batch_size=1) collates a leading batch axis that train_step unfolds
         batch = {k: v[None] for k, v in batch.items()}
@@ -391,155 +405,57 @@ class Trainer:
         data.set_batchsize(net.sampler.n_rays_per_batch)                  # ModifyBatchsizeHook
         self.iter += 1
         self.rays_done += n_rays
-        if self.overlap_march:
-            ev = torch.cuda.Event()
-            ev.record()                                   # (the current stream; torch.cuda.current_stream() alone costs ~10 us)
-            self._ev_done = [self._ev_done[1], ev]
-            self._ev_last = ev
         return out
 
     def _on_sampled(self):
-        """Called by the sampler as soon as THIS iteration's samples exist (and the step is enqueued): marches of later
-        iterations are issued now, on the side stream.  Depth 2 (default): iteration i + 2, behind this step's MLP backward; the
-        iterations that scheme cannot cover (i + 1 right after a grid refresh) are marched at once, as with depth 1.
-        A march reads the rays and the occupancy bitfield only: it must not be issued across a grid refresh (iterations = 0 mod
-        update_grid_freq), and its batch must be drawn with the batch size its iteration will have (the size changes after
+        """Called by the sampler as soon as THIS iteration's samples exist (and the step is enqueued).  Nothing marched ahead: the
+        iterations up to the next grid refresh are drawn and marched now, as one series of launches (NGPGridSampler.march_window) --
+        normally right behind a refresh, beside the refresh iteration's own step; also after a rewind (a frame rendered in the middle
+        of a window took the marches back).  A march reads the rays and the occupancy bitfield only: it is never issued across a grid
+        refresh (iterations = 0 mod update_grid_freq), and its batches have the size their iterations will have (the size changes after
         iterations = update_grid_freq - 1 mod update_grid_freq, i.e. together with the refresh)."""
         net = self.net
-        if not self.overlap_march:
-            return
-        it, f = self.iter, net.sampler.update_grid_freq
-        if self._native_ok() and hasattr(net.sampler, 'density_grid') and not self._queue and (it + 1) % f != 0:
-            # the native loop runs the next iteration: it issues the marches of it + 1 (at once) and it + 2 (behind this step's mark)
-            # itself when it starts -- the same launches in the same order on the side stream, enqueued a few microseconds later
-            return
-        queued = self._queue[-1][0] if self._queue else it            # the last iteration that already has its march
-        mark = getattr(net, '_step_mark', None)
-        if self.prefetch_depth == 2 and (mark is not None or self.march_after == 'start'):
-            if queued < it + 1 and net.sampler.can_prefetch(it + 1):
-                self._issue(it + 1, None)                             # not covered two iterations ago: at once
-                queued = it + 1
-            if queued == it + 1 and (it + 1) % f != 0 and (it + 2) % f != 0:
-                self._issue(it + 2, mark[1] if mark is not None else None)
-        elif queued < it + 1 and net.sampler.can_prefetch(it + 1):
-            self._issue(it + 1, mark[1] if mark else None)
-        if (it + 1) % f == 0 and self.prefetch_k6 and hasattr(net.sampler, 'prefetch_grid_samples'):
-            # the next iteration starts with a grid refresh, which no march can be issued across: the side stream is idle, and the
-            # refresh's sample generation (K6 twice + the clear of the temporary grid) depends on nothing this iteration changes
-            with torch.cuda.stream(net.sampler.side_stream()):
-                net.sampler.prefetch_grid_samples(it + 1)
-
-    def _issue(self, target_iter, start_event):
-        """draw the batch of iteration `target_iter` and march it on the side stream (behind `start_event` when given)"""
-        net, data = self.net, self.data
-        side = net.sampler.side_stream()
-        # the batch lives in the set the sampler's next training launch of K1 writes (one ring of four sets for both, shared with the
-        # native loop: a marched batch is handed between the two paths by its set index)
-        bufs = self._batch_buffers((getattr(net.sampler, '_train_launches', 0) + 1) % net.sampler.TRAIN_SLOTS, data.N_rand)
-        if bufs is not None and hasattr(data, 'rays_rgb') and switches.step_mode() == 'fused':
-            # the whole side-stream sequence (batch assembly, K1, K2 clip, counter copy) as one native call
+        sampler = net.sampler
+        it, f = self.iter, sampler.update_grid_freq
+        if (self.march_window != 'off' and not self._queue and not sampler.__dict__.get('_prefetched_q') and self._window_ok()
+                and sampler.can_march_ahead(it + 1)):
+            W = sampler.WINDOW
+            n_iters = min(f - (it + 1) % f, W - (it + 1) % W)             # up to the next refresh, inside the window's chunks
+            data = self.data
             n = min(data.N_rand, data.rays_rgb.shape[0])
-            if data.cur_i + n > data.rays_rgb.shape[0]:
-                data.cur_i = 0
-            with torch.cuda.stream(side):
-                nb = net.sampler.prefetch_native(data.rays_rgb[data.cur_i:data.cur_i + n], n, data.batches_drawn, bufs,
-                                                 buffer_free_event=self._last_done(), start_event=start_event)
-            data.cur_i += n
-            data.batches_drawn += 1
-            self._queue.append((target_iter, nb))
-            return
-        with torch.cuda.stream(side):
-            # these launches overwrite batch / coordinate buffers last read four iterations before their own (four persistent
-            # sets, rotating): ordered behind the completion event of the previous iteration
-            if self._last_done() is not None:
-                side.wait_event(self._last_done())
-            if start_event is not None:
-                ops.stream_wait_event(side, start_event)
-            nb = data.next_batch(out=bufs) if bufs is not None else data.next_batch()
-            net.sampler.prefetch(nb, buffer_free_event=self._last_done())
-        self._queue.append((target_iter, nb))
+            end, batches = sampler.march_window(data.rays_rgb, data.cur_i, data.batches_drawn, it + 1, n_iters, n,
+                                                on_side=self.march_window == 'side')
+            data.cur_i, data.batches_drawn = end, data.batches_drawn + n_iters
+            self._queue.extend((it + 1 + j, b) for j, b in enumerate(batches))
+        if (it + 1) % f == 0 and self.prefetch_k6 and hasattr(sampler, 'prefetch_grid_samples') and sampler._streams():
+            # the next iteration starts with a grid refresh: its sample generation (K6 twice + the clear of the temporary grid) depends
+            # on nothing this iteration changes
+            with torch.cuda.stream(sampler.side_stream()):
+                sampler.prefetch_grid_samples(it + 1)
 
-    def _last_done(self):
-        """event at the end of the latest iteration, whichever path ran it (`_ev_done` holds None for the native loop's iterations)"""
-        return self._ev_done[1] if self._ev_done[1] is not None else getattr(self, '_ev_last', None)
-
-    def _batch_buffers(self, slot, n):
-        """persistent output buffers of the batch kernel for prefetched batches (None: the dataset cannot use them)"""
-        if getattr(self, '_data_takes_out', None) is None:
-            import inspect
-            self._data_takes_out = 'out' in inspect.signature(self.data.next_batch).parameters
-        if not self._data_takes_out:
-            self.net.sampler.persistent_batches = False
-            return None
-        if self._bbufs[slot] is None or self._bbufs[slot]['rays_o'].shape[0] < n:
-            cap = max(int(n), self.net.sampler.target_batch_size)
-            self._bbufs[slot] = ops.make_batch_buffers(cap, self.device)
-        self.net.sampler.persistent_batches = True
-        return self._bbufs[slot]
+    def _on_rewind(self, first):
+        """the sampler took back the marches issued ahead (a test-mode launch in between): the batch cursor and the batch generator's
+        call index go back to the first of them"""
+        self.data.cur_i, self.data.batches_drawn = int(first['cur_ray']), int(first['batch_index'])
+        del self._queue[:]
 
     @property
     def samples_done(self):
         return self.net.sampler.total_valid_samples()
 
 
-class _LibEvent:
-    """a library-owned event seen through the two methods the sampler uses on a torch event"""
-
-    def __init__(self, handle):
-        self.h = handle
-
-    def wait(self):
-        _lib.check(_lib.load().xr_stream_wait_event(ops._stream(), self.h), 'xr_stream_wait_event')
-
-
 class _NativeLoop:
     """Host side of xr_ngp_loop_run (include/xrnerf_mi355.h): builds the descriptor from the trainer's, the sampler's and the
-    optimiser's persistent buffers, mirrors the counters both paths share, and hands marched batches over when the per-iteration
-    path takes an iteration in between (a grid refresh, a timer that wants events around several entry points)."""
-
-    N_PINNED = 64
+    optimiser's persistent buffers, mirrors the counters both paths share, and consumes the marched iterations from the queues the
+    per-iteration path would consume them from."""
 
     def __init__(self, tr):
-        L = _lib.load()
-        self.tr, self.h = tr, L.xr_ngp_loop_create()
-        if not self.h:
-            raise _lib.XrError('xr_ngp_loop_create failed')
+        self.tr = tr
         self.state = _lib.LoopState()
-        self.pinned = torch.zeros((self.N_PINNED, 2), dtype=torch.int32).pin_memory()
         self.enqueue_s, self.enqueued = 0.0, 0
-        self._mark_dummy = None
-        self.issued = []                   # (object with .synchronize(), host [2] view) of the marches issued and not yet consumed, in order
         self._keep = None
 
-    def __del__(self):
-        try:
-            _lib.load().xr_ngp_loop_destroy(self.h)
-        except Exception:  # noqa: BLE001  (interpreter shutdown)
-            pass
-
     # ------------------------------------------------------------------ counters shared with the per-iteration path
-    def _pull(self):
-        tr, S = self.tr, self.state
-        sampler, data, net = tr.net.sampler, tr.data, tr.net
-        S.iter, S.k1_calls, S.batches_drawn, S.cur_ray = tr.iter, sampler.k1_calls, data.batches_drawn, data.cur_i
-        S.march_launches = getattr(sampler, '_train_launches', 0) % sampler.TRAIN_SLOTS
-        S.step_turn = getattr(net, '_step_turn', 0) & 1
-        S.adam_step = self._adam_steps()[0]
-
-    def _push(self, k, n_rays):
-        tr, S = self.tr, self.state
-        sampler, data, net = tr.net.sampler, tr.data, tr.net
-        tr.iter, data.batches_drawn, data.cur_i = int(S.iter), int(S.batches_drawn), int(S.cur_ray)
-        sampler.__dict__['k1_calls'] = int(S.k1_calls)
-        sampler._train_launches = int(S.march_launches)
-        net._step_turn = int(S.step_turn)
-        for st in self._adam_states():
-            st['step'] = int(S.adam_step)
-        tr.rays_done += k * n_rays
-        tr._ev_done = [None, None] if k >= 2 else [tr._ev_done[1], None]
-        tr._ev_last = torch.cuda.Event()
-        tr._ev_last.record()                        # (for a march the per-iteration path may issue next)
-
     def _adam_states(self):
         tr = self.tr
         mlp = tr.net.mlp
@@ -552,64 +468,9 @@ class _NativeLoop:
         self._group = grp[0]
         return out
 
-    def _adam_steps(self):
-        steps = [st['step'] for st in self._adam_states()]
-        if len(set(steps)) != 1:
-            raise _lib.XrError('the three NGP tensors have different optimiser step counts: %r' % (steps,))
-        return steps
-
-    # ------------------------------------------------------------------ hand-over of marched batches
-    def _sets(self, n_rays, max_samples):
-        """the rotating sets as the per-iteration path sees them: [(batch buffers, coords, (rays_index, numsteps, counter), (clipped, n_valid), xyz)]"""
-        tr = self.tr
-        sampler = tr.net.sampler
-        return [(tr._batch_buffers(i, n_rays), sampler._coords_buffer(max_samples, i), sampler._small_buffers(n_rays, i),
-                 sampler._clip_buffers(n_rays, i), sampler._xyz_buffer(max_samples, i)) for i in range(sampler.TRAIN_SLOTS)]
-
-    def _max_samples(self, n_rays):
-        sampler = self.tr.net.sampler
-        m = sampler.num_coords_elements if getattr(sampler, 'reference_buffer_rows', False) else max(sampler.num_coords_elements, n_rays * 64)
-        return min(m, n_rays * sampler.MAX_STEP)
-
-    def adopt_from_python(self):
-        """marches the per-iteration path issued ahead become this loop's"""
-        tr, S = self.tr, self.state
-        sampler = tr.net.sampler
-        q = sampler.__dict__.get('_prefetched_q') or []
-        if len(q) != len(tr._queue) or len(q) > 2 or any('slot' not in pf for pf in q):
-            raise _lib.XrError('cannot hand these marched batches to the native loop')
-        side = sampler.side_stream()
-        for i, pf in enumerate(q):
-            S.queue_set[i] = pf['slot']
-            _lib.check(_lib.load().xr_ngp_loop_adopt_march(self.h, pf['slot'], C.c_void_p(side.cuda_stream)), 'xr_ngp_loop_adopt_march')
-            self.issued.append(pf['host'])
-        S.queued = len(q)
-        del q[:]
-        del tr._queue[:]
-
-    def release_to_python(self):
-        """marches this loop issued ahead become the per-iteration path's (same buffers: the rings are shared)"""
-        tr, S = self.tr, self.state
-        sampler, data = tr.net.sampler, tr.data
-        n = min(data.N_rand, data.rays_rgb.shape[0])
-        ms = self._max_samples(n)
-        sets = self._sets(n, ms)
-        L = _lib.load()
-        for i in range(int(S.queued)):
-            si = int(S.queue_set[i])
-            bb, coords, small, clip, xyz = sets[si]
-            batch = {'rays_o': bb['rays_o'][:n], 'rays_d': bb['rays_d'][:n], 'target_s': bb['target_s'][:n], 'alpha': bb['alpha'][:n],
-                     'img_ids': bb['img_ids'][:n], 'bg_color': bb['bg_color'][:n]}
-            sampler.__dict__.setdefault('_prefetched_q', []).append(
-                {'rays_o': batch['rays_o'], 'max_samples': ms, 'out': (coords, small[0], small[1], small[2]),
-                 'event': _LibEvent(L.xr_ngp_loop_march_event(self.h, si)), 'host': self.issued[i], 'clipped': clip, 'xyz': xyz, 'slot': si})
-            tr._queue.append((tr.iter + i, batch))
-        del self.issued[:int(S.queued)]
-        S.queued = 0
-
-    def _descriptor(self, n_rays, max_samples, n_rows, sets, states, g, side, bev):
+    def _descriptor(self, win, n_rows, sets, states, g):
         tr, L = self.tr, _lib.load()
-        net, data = tr.net, tr.data
+        net = tr.net
         sampler, mlp = net.sampler, net.mlp
         dev = tr.device
         table, wd, wc = mlp.embedder_pos.params, mlp.density_net.params, mlp.color_net.params
@@ -626,60 +487,37 @@ class _NativeLoop:
             ema = st.get('ema') if g['ema_momentum'] is not None else None
             a = ops.adam_fuse(p.data, st['m'], st['v'], ema, 0, 0.0, g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], 0.0, 1.0)
             setattr(D, name, a)
-        rows = data.rays_rgb
-        D.rays_rgb_rows, D.n_table_rays, D.batch_seed = vp(rows), rows.shape[0], 20220901
-        D.bitfield = vp(sampler.density_grid_bitfield)
-        D.aabb0, D.aabb1 = float(sampler.aabb_range[0]), float(sampler.aabb_range[1])
-        D.near_distance, D.cone_angle = float(sampler.near_distance), float(sampler.cone_angle_constant)
-        D.max_samples, D.max_compacted = max_samples, sampler.target_batch_size
         D.density_grid_mean = vp(sampler.density_grid_mean)
         D.rgb_activation, D.density_activation, D.huber_delta, D.loss_scale = int(sampler.rgb_activation), int(sampler.density_activation), 0.1, 5.0
         D.n_rows, D.ld = n_rows, sets[0].ld
-        msets = self._sets(n_rays, max_samples)
-        for i, (bb, coords, small, clip, xyz) in enumerate(msets):
-            M = D.march[i]
-            M.rays_o, M.rays_d, M.target, M.alpha, M.bg, M.img_ids = (vp(bb[q]) for q in ('rays_o', 'rays_d', 'target_s', 'alpha', 'bg_color', 'img_ids'))
-            M.coords, M.rays_index, M.rays_numsteps, M.counter2 = vp(coords), vp(small[0]), vp(small[1]), vp(small[2])
-            M.numsteps_clipped, M.n_valid = vp(clip[0]), vp(clip[1])
-            M.xyz_planes, M.plane_stride = vp(xyz), (xyz.shape[1] if xyz is not None else 0)
+        D.window = win.c
         for i, b in enumerate(sets):
             B = D.step[i]
             B.enc_t, B.raw, B.draw, B.denc_t, B.rgb_out, B.zero_block = vp(b.enc_t), vp(b.raw), vp(b.draw), vp(b.denc_t), vp(b.rgb), vp(b.zero_block)
             B.zero_floats = b.zero_block.numel()
             B.grad_w_density, B.grad_w_color, B.loss_mse, B.live_seg_count = vp(b.g_wd), vp(b.g_wc), vp(b.loss_mse), vp(b.live_seg)
-        with torch.cuda.stream(sampler.side_stream()):                   # (allocated in the side stream's pool, like the per-iteration path's)
-            ws_k1 = ops._ws(dev, L.xr_rays_sampler_workspace_bytes(n_rays), 'k1_side')
         ws_mlp, live_list, _, live_stats = ops._list_slots(dev, n_rows)
         ws_sc = ops._ws(dev, L.xr_hashgrid_bwd_workspace_bytes(n_rows, meta.n_levels, r_, o_), 'hgb')
-        D.ws_k1, D.ws_k1_bytes, D.ws_mlp_bwd, D.ws_mlp_bwd_bytes = vp(ws_k1), ws_k1.numel(), vp(ws_mlp), ws_mlp.numel()
+        D.ws_mlp_bwd, D.ws_mlp_bwd_bytes = vp(ws_mlp), ws_mlp.numel()
         D.ws_scatter, D.ws_scatter_bytes = vp(ws_sc), ws_sc.numel()
-        D.counter_host_pinned, D.n_pinned = self.pinned.data_ptr(), self.N_PINNED
-        D.stream, D.side_stream = ops._stream(), side.cuda_stream
-        D.bitfield_event = bev.cuda_event if bev is not None else None
-        mark = getattr(net, '_step_mark', None)
-        if mark is None and tr.march_after != 'start':
-            raise _lib.XrError('the native loop marches two iterations ahead (prefetch_depth=2)')
-        if self._mark_dummy is None:
-            self._mark_dummy = ops._CEvent(timing=False)
-        D.mark_event = mark[1].h if mark is not None else self._mark_dummy.h
-        D.mark_entry = mark[0].encode() if mark is not None else None
-        self._hold = (sets, ws_k1, ws_mlp, ws_sc, bev, states)          # (what the pointers name stays alive)
-        return D, msets, live_list, live_stats
+        D.stream = ops._stream()
+        self._hold = (win, sets, ws_mlp, ws_sc, states)          # (what the pointers name stays alive)
+        return D, live_list, live_stats
 
-    # ------------------------------------------------------------------ one window
+    # ------------------------------------------------------------------ k marched iterations
     def run(self, k, iter_events=None):
         tr, S, L = self.tr, self.state, _lib.load()
         net, data = tr.net, tr.data
         sampler, mlp = net.sampler, net.mlp
         f = sampler.update_grid_freq
+        q = sampler._prefetched_q
+        if k < 1 or len(q) < k or len(tr._queue) < k or q[0].get('iter') != tr.iter:
+            raise _lib.XrError('the native loop runs marched iterations only')
         if tr.iter % f == 0 or tr.iter % f + k > f:
             raise _lib.XrError('a native window never crosses a grid refresh')
         dev = tr.device
-        self._pull()
-        if tr._queue or sampler.__dict__.get('_prefetched_q'):
-            self.adopt_from_python()
-        n_rays = min(data.N_rand, data.rays_rgb.shape[0])
-        max_samples = self._max_samples(n_rays)
+        pfs = q[:k]
+        win, n_rays, max_samples = pfs[0]['window'], pfs[0]['rays_o'].shape[0], pfs[0]['max_samples']
         n_rows = min(sampler.target_batch_size, max_samples)
         table, wd, wc = mlp.embedder_pos.params, mlp.density_net.params, mlp.color_net.params
         meta = mlp.embedder_pos.meta
@@ -688,29 +526,31 @@ class _NativeLoop:
                 or sets[0].g_table.device != table.device):
             sets = net._step_bufs = [ops.TrainStepBuffers(dev, n_rows, max(n_rays, 1 << 15), table.numel(), wd.numel(), wc.numel(), meta)
                                      for _ in range(2)]
-            net._step_turn = S.step_turn = 0
-        side = sampler.side_stream()
-        bev = getattr(sampler, '_bitfield_event', None)
+            net._step_turn = 0
         states = self._adam_states()
         g = self._group
-        # the descriptor is rebuilt only when something it names has changed (a buffer that grew, a new refresh event, another
-        # precision mode): ~60 pointer conversions and four workspace queries otherwise sit in front of every window's first kernel
-        key = (n_rays, max_samples, n_rows, id(sets[0]), id(sets[1]), table.data_ptr(), wd.data_ptr(), wc.data_ptr(), data.rays_rgb.data_ptr(),
-               sampler.density_grid_bitfield.data_ptr(), sampler.density_grid_mean.data_ptr(), ops._mlp_mode(1, 2), id(bev), ops._stream().value,
-               tuple(id(x) for x in (getattr(sampler, '_coords_bufs', None) or ())), tuple(id(x) for x in (getattr(sampler, '_small_bufs', None) or ())),
-               tuple(id(x) for x in (getattr(sampler, '_clip_bufs', None) or ())), tuple(id(x) for x in (getattr(sampler, '_xyz_bufs', None) or ())),
-               tuple(id(x) for x in tr._bbufs), tuple(id(st['m']) for st in states), id(ops._workspaces.get((str(dev), 'k1_side'))),
-               id(ops._workspaces.get((str(dev), 'mlpbwd'))), id(ops._workspaces.get((str(dev), 'hgb'))))
+        steps = [st['step'] for st in states]
+        if len(set(steps)) != 1:
+            raise _lib.XrError('the three NGP tensors have different optimiser step counts: %r' % (steps,))
+        S.iter, S.step_turn, S.adam_step = tr.iter, getattr(net, '_step_turn', 0) & 1, steps[0]
+        # the descriptor is rebuilt only when something it names has changed (a buffer that grew, another precision mode): ~40 pointer
+        # conversions and three workspace queries otherwise sit in front of every window's first kernel.  Keyed on what the pointers
+        # ARE (data pointers and sizes), not on object identities
+        dp = lambda t: (t.data_ptr(), t.numel()) if t is not None else (0, 0)
+        key = (n_rows, dp(win.coords), dp(win.rays_o), dp(win.xyz), win.ray_stride, win.coords_stride,
+               tuple(dp(b.enc_t) + dp(b.zero_block) + dp(b.rgb) for b in sets), dp(table), dp(wd), dp(wc),
+               dp(sampler.density_grid_mean), ops._mlp_mode(1, 2), ops._stream().value,
+               tuple(dp(st['m']) + dp(st['v']) + dp(st.get('ema')) for st in states),
+               dp(ops._workspaces.get((str(dev), 'mlpbwd'))), dp(ops._workspaces.get((str(dev), 'hgb'))))
         if self._keep is not None and self._keep[0] == key:
-            _, D, msets, live_list, live_stats = self._keep
+            _, D, live_list, live_stats = self._keep
         else:
-            D, msets, live_list, live_stats = self._descriptor(n_rays, max_samples, n_rows, sets, states, g, side, bev)
-            key = key[:-3] + (id(ops._workspaces.get((str(dev), 'k1_side'))), id(ops._workspaces.get((str(dev), 'mlpbwd'))), id(ops._workspaces.get((str(dev), 'hgb'))))
-            self._keep = (key, D, msets, live_list, live_stats)
+            D, live_list, live_stats = self._descriptor(win, n_rows, sets, states, g)
+            key = key[:-2] + (dp(ops._workspaces.get((str(dev), 'mlpbwd'))), dp(ops._workspaces.get((str(dev), 'hgb'))))
+            self._keep = (key, D, live_list, live_stats)
         # the schedules are this trainer's: lr per iteration, the EMA momentum of mmcv's EMAHook per update
         lr = (C.c_float * k)(*[step_lr(tr.base_lr, tr.iter + j) for j in range(k)])
         mom = (C.c_float * k)(*[(FusedAdam._ema_momentum(g, int(S.adam_step) + 1 + j) if g['ema_momentum'] is not None else 0.0) for j in range(k)])
-        ext = [e.cuda_event if e is not None else None for e in tr._ev_done]
         stage, tev, tarr = None, None, None
         if ops.TIMER is not None:
             ok, stage = ops.TIMER.native_stage()
@@ -720,35 +560,37 @@ class _NativeLoop:
                 tev = [ops._CEvent() for _ in range(2 * k)]
                 tarr = (C.c_void_p * (2 * k))(*[e.h for e in tev])
         iarr = (C.c_void_p * (k + 1))(*[e.h for e in iter_events]) if iter_events is not None else None
-        pinned0 = int(S.pinned_next)
         ops.LIVE_STATS = live_stats
         sets[0].live = sets[1].live = (live_list, live_stats) if os.environ.get('XR_MLP_LIVE') != '0' else None
+        sampler._wait_march(pfs[0])                       # the compute stream behind the window's marches: once per window
         t_enq = time.perf_counter()
-        rc = L.xr_ngp_loop_run(self.h, C.byref(D), C.byref(S), k, n_rays, f, lr, mom, ext[0], ext[1], stage.encode() if stage else None, tarr, iarr)
+        rc = L.xr_ngp_loop_run(C.byref(D), C.byref(S), k, n_rays, lr, mom, stage.encode() if stage else None, tarr, iarr)
         self.enqueue_s += time.perf_counter() - t_enq                    # host time inside the native call (tools/hosttime2.py)
         self.enqueued += k
         if rc != 0:
             _lib.check(rc, 'xr_ngp_loop_run')
         if stage is not None:
             ops.TIMER.events.setdefault(stage, []).extend((tev[2 * j], tev[2 * j + 1], 0) for j in range(k))
-        for q in range(pinned0, int(S.pinned_next)):
-            self.issued.append((side, self.pinned[q % self.N_PINNED]))
-        sampler._pending_counts.extend(self.issued[:k])       # the k iterations consumed the k oldest marches
-        del self.issued[:k]
-        self._push(k, n_rays)
+        sampler._pending_counts.extend(pf['host'] for pf in pfs)
+        del q[:k]
+        del tr._queue[:k]
+        tr.iter = int(S.iter)
+        net._step_turn = int(S.step_turn)
+        for st in states:
+            st['step'] = int(S.adam_step)
+        tr.rays_done += k * n_rays
         # the sampler's public state = the last iteration's (what a reader between two steps sees on the per-iteration path too)
-        last = tr.iter - 1
-        bb, coords, small, clip, xyz = msets[int(S.last_march_set)]
+        last, pf = tr.iter - 1, pfs[-1]
         sampler.iter_n = last
-        sampler.coords, sampler.xyz = coords[:n_rows], xyz
-        sampler.rays_index, sampler.rays_numsteps, sampler.rays_numsteps_compacted = small[0], small[1], clip[0]
-        sampler.n_valid_dev = clip[1][0:1]
+        sampler.coords, sampler.xyz = pf['out'][0][:n_rows], pf['xyz']
+        sampler.rays_index, sampler.rays_numsteps, sampler.rays_numsteps_compacted = pf['out'][1], pf['out'][2], pf['clipped'][0]
+        sampler.n_valid_dev = pf['clipped'][1][0:1]
         b = sets[int(S.last_step_set)]
         net._last = {'rgb': b.rgb[:n_rays], 'loss_mse': b.loss_mse, 'raw': b.raw}
         if last % f == f - 1:
-            sampler.update_batch_rays(True, max_samples)                  # drains the 16 counters (waits for the side stream's copies)
+            sampler.update_batch_rays(True, max_samples)                  # drains the window's counters (waits for the side stream's copy)
             if tr.prefetch_k6 and hasattr(sampler, 'prefetch_grid_samples'):
-                with torch.cuda.stream(side):
+                with torch.cuda.stream(sampler.side_stream()):
                     sampler.prefetch_grid_samples(last + 1)
         data.set_batchsize(sampler.n_rays_per_batch)                      # ModifyBatchsizeHook
         from .networks import _LazyPsnr
