@@ -99,14 +99,14 @@ def test_window_march_matches_marches_in_place(dev):
     a.march_window, b.march_window = 'side', 'off'
     la, lb, na, nb = [], [], [], []
     for _ in range(40):
-        la.append(a.step()['log_vars']['loss']); na.append(a.net.sampler.n_valid_dev.clone())
-        lb.append(b.step()['log_vars']['loss']); nb.append(b.net.sampler.n_valid_dev.clone())
+        # (read at once: the logged loss is a view of the step's recycled buffers)
+        la.append(float(a.step()['log_vars']['loss'])); na.append(int(a.net.sampler.n_valid_dev))
+        lb.append(float(b.step()['log_vars']['loss'])); nb.append(int(b.net.sampler.n_valid_dev))
     torch.cuda.synchronize()
-    # iterations 0..15 march through the SAME bitfield (built at iteration 0 from identical weights): identical counts.
-    # From the refresh at iteration 16 on, the two runs differ by float-atomic ordering in their gradients.
-    assert [int(x) for x in na[:16]] == [int(x) for x in nb[:16]]
-    la, lb = torch.stack(la).cpu().numpy(), torch.stack(lb).cpu().numpy()
-    assert np.abs(la - lb).max() <= 2e-2 * np.abs(lb).max()
+    # the same batches, the same samples, the same (atomic-free, fixed-order) arithmetic: the whole trajectory agrees
+    assert na == nb
+    la, lb = np.array(la), np.array(lb)
+    assert np.abs(la - lb).max() <= 1e-5 * np.abs(lb).max()
     assert a.net.sampler.n_rays_per_batch == b.net.sampler.n_rays_per_batch
 
 

@@ -35,7 +35,7 @@ from .builder import SAMPLERS
 @SAMPLERS.register_module()
 class NGPGridSampler(_FastAttr, nn.Module):
     # per-step state (never a Parameter, a registered buffer or a sub-module): assigned ~15 times per training iteration
-    _FAST_ATTRS = frozenset(('iter_n', 'on_sampled', 'on_rewind', '_prefetched_q', 'rays_index', 'coords', 'xyz', 'rays_numsteps', 'rays_numsteps_compacted',
+    _FAST_ATTRS = frozenset(('iter_n', 'on_sampled', 'on_rewind', 'on_refreshed', '_prefetched_q', 'rays_index', 'coords', 'xyz', 'rays_numsteps', 'rays_numsteps_compacted',
                              'n_valid_dev', '_pinned_next', 'k1_calls', '_test_rows_seen',
                              'frame_chunk', 'frame_ray0', '_pending_counts', 'n_rays_per_batch', '_window'))
     def __init__(self, update_grid_freq=16, update_block_size=5000000, n_rays_per_batch=4096,
@@ -205,8 +205,18 @@ class NGPGridSampler(_FastAttr, nn.Module):
     def sample(self, data, mlp, is_test=False):
         is_training = not is_test
         self.check_device(data)
+        k1_reserved = None
         if is_training and (self.iter_n % self.update_grid_freq == 0 or not hasattr(self, 'density_grid')):
             self.update_density_grid(mlp)
+            cb = getattr(self, 'on_refreshed', None)
+            if cb is not None:
+                # the trainer marches the rest of the window from here, beside this iteration's own march in place -- which keeps the
+                # hidden generator's call index it has in the reference's order (this iteration first); nothing marched ahead crosses a
+                # refresh, so whatever is still queued is stale
+                self.rewind_marches()
+                k1_reserved = self.k1_calls
+                self.k1_calls += 1
+                cb()
 
         rays_o = data['rays_o'].contiguous().float()
         rays_d = data['rays_d'].contiguous().float()
@@ -233,7 +243,8 @@ class NGPGridSampler(_FastAttr, nn.Module):
         q = self.__dict__.get('_prefetched_q')
         if q and not is_training:
             self.rewind_marches()
-        pf = q.pop(0) if (is_training and q) else None
+        # (marches for LATER iterations -- issued a moment ago from on_refreshed -- stay queued)
+        pf = q.pop(0) if (is_training and q and q[0].get('iter', self.iter_n) <= self.iter_n) else None
         if (pf is not None and pf['rays_o'].data_ptr() == data['rays_o'].data_ptr() and
                 pf['rays_o'].shape == data['rays_o'].shape and pf['max_samples'] == max_samples):
             # K1 of this batch already ran (march_window, right behind the window's grid refresh): order this stream after it -- once
@@ -258,7 +269,7 @@ class NGPGridSampler(_FastAttr, nn.Module):
             slot = (self.iter_n % self.WINDOW) if is_training else self.TEST_SLOT
             if is_training:
                 self.window_for(n_rays, max_samples)
-            k1_index = self.k1_calls
+            k1_index = self.k1_calls if k1_reserved is None else k1_reserved
             async_test = (not is_training) and getattr(self, '_async_test', None) is not None and self._streams()
             if async_test:
                 # a frame marched in chunks (batchify_forward): no read-back per chunk.  The buffer is sized from the rows per
@@ -280,7 +291,8 @@ class NGPGridSampler(_FastAttr, nn.Module):
                 # run beside a collective or the K6 prefetch: one ray per lane, same samples)
                 wide=is_training and self.iter_n % self.update_grid_freq == 0 and getattr(self, 'wide_in_place', True))
             # (a band: the launches of the chunk series its rays fall into; the network puts the whole frame's count back afterwards)
-            self.k1_calls += ((rng_ray0 + n_rays + rng_chunk - 1) // rng_chunk - rng_ray0 // rng_chunk) if rng_chunk else 1
+            if k1_reserved is None:
+                self.k1_calls += ((rng_ray0 + n_rays + rng_chunk - 1) // rng_chunk - rng_ray0 // rng_chunk) if rng_chunk else 1
             if async_test:
                 self._async_test.append((counter, max_samples, k1_index, n_rays))
                 self.rays_index = rays_index

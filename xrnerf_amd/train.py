@@ -232,6 +232,7 @@ class Trainer:
         self.net.sampler.set_data(self.data.get_alldata(), self.data.get_info())     # PassDatasetHook
         self.net.sampler.on_sampled = self._on_sampled
         self.net.sampler.on_rewind = self._on_rewind
+        self.net.sampler.on_refreshed = self._march_ahead
         self.base_lr = 1e-2
         self.iter = 0
         self.world_size, self.rank = world_size, rank
@@ -364,9 +365,9 @@ class Trainer:
         net.sampler.set_iter(self.iter)                                   # PassSamplerIterHook
         for g in self.opt.param_groups:
             g['lr'] = step_lr(self.base_lr, self.iter)
-        if self._queue and self._queue[0][0] != self.iter:
-            net.sampler.rewind_marches()                                  # marched for other iterations than the one that runs now
-        batch = self._queue.pop(0)[1] if self._queue else None
+        if self._queue and self._queue[0][0] < self.iter:
+            net.sampler.rewind_marches()                                  # marched for iterations that are over
+        batch = self._queue.pop(0)[1] if (self._queue and self._queue[0][0] == self.iter) else None
         if batch is None:
             batch = self._draw()
         n_rays = batch['rays_o'].shape[0]
@@ -407,26 +408,33 @@ class Trainer:
         self.rays_done += n_rays
         return out
 
-    def _on_sampled(self):
-        """Called by the sampler as soon as THIS iteration's samples exist (and the step is enqueued).  Nothing marched ahead: the
-        iterations up to the next grid refresh are drawn and marched now, as one series of launches (NGPGridSampler.march_window) --
-        normally right behind a refresh, beside the refresh iteration's own step; also after a rewind (a frame rendered in the middle
-        of a window took the marches back).  A march reads the rays and the occupancy bitfield only: it is never issued across a grid
-        refresh (iterations = 0 mod update_grid_freq), and its batches have the size their iterations will have (the size changes after
-        iterations = update_grid_freq - 1 mod update_grid_freq, i.e. together with the refresh)."""
-        net = self.net
-        sampler = net.sampler
+    def _march_ahead(self):
+        """Nothing marched ahead: the iterations up to the next grid refresh are drawn and marched now, as one series of launches
+        (NGPGridSampler.march_window).  Called by the sampler right behind a grid refresh (the series then starts beside this
+        iteration's own march in place and runs on beside its step) and once more when this iteration's samples exist -- which is
+        where it happens after a rewind (a frame rendered in the middle of a window took the marches back).  A march reads the rays
+        and the occupancy bitfield only: it is never issued across a grid refresh (iterations = 0 mod update_grid_freq), and its
+        batches have the size their iterations will have (the size changes after iterations = update_grid_freq - 1 mod
+        update_grid_freq, i.e. together with the refresh)."""
+        sampler = self.net.sampler
         it, f = self.iter, sampler.update_grid_freq
-        if (self.march_window != 'off' and not self._queue and not sampler.__dict__.get('_prefetched_q') and self._window_ok()
-                and sampler.can_march_ahead(it + 1)):
-            W = sampler.WINDOW
-            n_iters = min(f - (it + 1) % f, W - (it + 1) % W)             # up to the next refresh, inside the window's chunks
-            data = self.data
-            n = min(data.N_rand, data.rays_rgb.shape[0])
-            end, batches = sampler.march_window(data.rays_rgb, data.cur_i, data.batches_drawn, it + 1, n_iters, n,
-                                                on_side=self.march_window == 'side')
-            data.cur_i, data.batches_drawn = end, data.batches_drawn + n_iters
-            self._queue.extend((it + 1 + j, b) for j, b in enumerate(batches))
+        if (self.march_window == 'off' or self._queue or sampler.__dict__.get('_prefetched_q') or not self._window_ok()
+                or not sampler.can_march_ahead(it + 1)):
+            return
+        W = sampler.WINDOW
+        n_iters = min(f - (it + 1) % f, W - (it + 1) % W)             # up to the next refresh, inside the window's chunks
+        data = self.data
+        n = min(data.N_rand, data.rays_rgb.shape[0])
+        end, batches = sampler.march_window(data.rays_rgb, data.cur_i, data.batches_drawn, it + 1, n_iters, n,
+                                            on_side=self.march_window == 'side')
+        data.cur_i, data.batches_drawn = end, data.batches_drawn + n_iters
+        self._queue.extend((it + 1 + j, b) for j, b in enumerate(batches))
+
+    def _on_sampled(self):
+        """Called by the sampler as soon as THIS iteration's samples exist (and the step is enqueued)"""
+        sampler = self.net.sampler
+        it, f = self.iter, sampler.update_grid_freq
+        self._march_ahead()
         if (it + 1) % f == 0 and self.prefetch_k6 and hasattr(sampler, 'prefetch_grid_samples') and sampler._streams():
             # the next iteration starts with a grid refresh: its sample generation (K6 twice + the clear of the temporary grid) depends
             # on nothing this iteration changes
