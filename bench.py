@@ -339,45 +339,59 @@ def ngp_f16_mlp_mode(dev, n_img, steps):
 def ngp_tcnn_strict_defaults(dev, n_img, steps):
     """The topology tiny-cuda-nn would build from the reference's UNCHANGED config if it ignores the config's `num_layers` key
     (its key is `n_hidden_layers`, default 5): 5-hidden-layer density and colour nets, 77 824 flop per
-    sample forward.  Runs layer by layer on the fp32 linear kernels (ops._layered_nerf_mlp): priced, not tuned."""
+    sample forward.  Round 5: the streamed fused kernels (k_nerf_mlp_fwd_deep / _bwd_deep: the layers' weights pass through LDS) inside
+    the same native step and loop as the headline; timed at THIS network's adaptive fixed point (pre-roll like the headline's)."""
     os.environ['XRNERF_TCNN_STRICT_DEFAULTS'] = '1'
     try:
         tr = Trainer(dev, n_img=n_img)
         assert tr.net.mlp.density_net.n_hidden == 5 and tr.net.mlp.color_net.n_hidden == 5
         sampler = tr.net.sampler
-        # (the first ~100 iterations of this topology are erratic -- when the occupancy grid thins out varies from run to run by
-        # dozens of iterations, and with it the rays per batch by 5x -- so the window sits behind 224 of them)
-        for _ in range(224):
-            tr.step()
-        for _ in range((-tr.iter) % sampler.update_grid_freq + 1):
-            tr.step()
+        pre, hist = 0, [sampler.n_rays_per_batch]
+        while pre < PREROLL_MAX:
+            tr.run(16)
+            pre += 16
+            hist.append(sampler.n_rays_per_batch)
+            if pre >= PREROLL_MIN and len(hist) >= 3 and abs(hist[-1] - hist[-2]) <= 0.02 * hist[-2] and abs(hist[-2] - hist[-3]) <= 0.02 * hist[-3]:
+                break
+        tr.run((-tr.iter) % sampler.update_grid_freq + 1)
         torch.cuda.synchronize()
+        if ops.LIVE_STATS is not None:
+            ops.LIVE_STATS[1:3].zero_()
         r0, s0, it0 = tr.rays_done, tr.samples_done, tr.iter
         t0 = time.perf_counter()
-        for _ in range(steps):
-            tr.step()
+        tr.run(steps)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         rays, samples = tr.rays_done - r0, tr.samples_done - s0
-        s1 = tr.samples_done
-        ops.TIMER = ops.KernelTimer(only={'xr_nerf_mlp_fwd', 'xr_nerf_mlp_bwd'}, train_only=True)
-        for _ in range(16):
-            tr.step()
-        torch.cuda.synchronize()
-        timer, ops.TIMER = ops.TIMER, None
-        s_win = tr.samples_done - s1
-        flop = {'xr_nerf_mlp_fwd': 2 * (32 * 64 + 4 * 64 * 64 + 64 * 16) * 2, 'xr_nerf_mlp_bwd': 3 * 2 * (32 * 64 + 4 * 64 * 64 + 64 * 16) * 2}
+        live_frac = 1.0
+        if ops.LIVE_STATS is not None:
+            lv, vd = (int(v) & 0xffffffff for v in ops.LIVE_STATS[1:3].tolist())
+            live_frac = lv / vd if vd else 1.0
+        native = tr._loop is not None and tr._loop.enqueued > 0
+        mac = 32 * 64 + 4 * 64 * 64 + 64 * 16
+        flop = {'xr_nerf_mlp_fwd': 2 * mac * 2, 'xr_nerf_mlp_bwd': 3 * 2 * mac * 2 - 2 * 64 * 16}
         kern = {}
-        for k, (n_l, ms_l, _) in timer.summary().items():
-            fl = flop[k] * s_win
-            kern[k] = {'avg_launch_us': ms_l * 1e3 / max(n_l, 1), 'achieved_TFLOPs': fl / (ms_l * 1e-3) / 1e12,
-                       'peak_TFLOPs': MFMA_F32_PEAK_TFLOPS, 'frac': fl / (ms_l * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                       'flop_per_sample': flop[k]}
+        for name in ('xr_nerf_mlp_fwd', 'xr_nerf_mlp_bwd'):
+            ops.TIMER = ops.KernelTimer(only={name}, train_only=True)
+            tr.run((-tr.iter) % sampler.update_grid_freq + 1)      # (past the next refresh: the timed launches are the training step's)
+            tr.run(15)
+            torch.cuda.synchronize()
+            timer, ops.TIMER = ops.TIMER, None
+            n_l, ms_l, _ = timer.summary()[name]
+            units = (samples / steps) * (live_frac if name == 'xr_nerf_mlp_bwd' else 1.0) * n_l
+            fl = flop[name] * units
+            kern[name] = {'avg_launch_us': ms_l * 1e3 / max(n_l, 1), 'launches': n_l, 'achieved_TFLOPs': fl / (ms_l * 1e-3) / 1e12,
+                          'peak_TFLOPs': MFMA_PEAK['f16'], 'frac': fl / (ms_l * 1e-3) / 1e12 / MFMA_PEAK['f16'],
+                          'frac_of_fp32_mfma_peak': fl / (ms_l * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 'flop_per_sample': flop[name],
+                          'units': 'marched samples' if name == 'xr_nerf_mlp_fwd' else 'live rows (fraction %.3f)' % live_frac}
         return {'workload': 'the headline iterations with 5 + 5 hidden layers (XRNERF_TCNN_STRICT_DEFAULTS=1: what tcnn builds if it ignores '
-                            'the config\'s num_layers key), %d timed iterations %d..%d after %d pre-roll iterations; fused MLP replaced by '
-                            'layer-by-layer fp32 linear kernels (activations through HBM)' % (steps, it0, it0 + steps - 1, it0),
+                            'the config\'s num_layers key), %d timed iterations %d..%d after %d pre-roll iterations at this network\'s own '
+                            'adaptive fixed point; streamed fused MLP kernels (fp32 results on the bf16 matrix cores: forward and recompute '
+                            'on exact 3-way split operands, gradients on 2-way split operands), native step and loop: %s'
+                            % (steps, it0, it0 + steps - 1, it0, 'yes' if native else 'NO'),
                 'value': rays / el, 'unit': 'rays/s', 'ms_per_step': el * 1e3 / steps, 'rays_per_step': rays / steps,
-                'samples_per_ray': samples / max(rays, 1), 'kernels': kern, 'final_train_psnr': float(tr.step()['log_vars']['psnr'])}
+                'samples_per_ray': samples / max(rays, 1), 'backward_live_row_fraction': live_frac, 'rays_per_batch_history': hist[-6:],
+                'kernels': kern, 'final_train_psnr': float(tr.step()['log_vars']['psnr'])}
     finally:
         os.environ.pop('XRNERF_TCNN_STRICT_DEFAULTS', None)
 

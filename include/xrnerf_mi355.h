@@ -274,15 +274,25 @@ int xr_sh4(const float* dirs, uint32_t dir_stride, uint32_t n, float* out, void*
  * features, SH-4 of the view direction, color_net (15+16 (+1 pad = pad_value) -> nhc x 64 -> 16),
  * raw [n,4] = [r,g,b,sigma].  fp32 MFMA (v_mfma_f32_32x32x2_f32 == an fmaf chain, exact fp32).
  * Weights: tcnn `params` layout = row-major [out,in] matrices in layer order, out padded to 16.
- * dirs may be NULL (run_density, hashnerf_mlp.py:107-111: only raw[:,3] is meaningful then). */
+ * dirs may be NULL (run_density, hashnerf_mlp.py:107-111: only raw[:,3] is meaningful then).
+ * Depths: (1, 2) -- what the config's `num_layers` says --, (1, 1), (2, 2), (2, 3) keep every activation in registers and both
+ * weight sets in LDS; ANY other 1..8 + 1..8 hidden layers, tcnn's own default 5 + 5 first of all (tcnn reads `n_hidden_layers`
+ * and ignores the `num_layers` key of configs/instant_ngp/nerf_blender_local01.py:106-124), runs on the streamed kernels: a
+ * workgroup takes its sample tiles through one layer at a time, the layers' weights pass through LDS; fp32 results on the bf16
+ * matrix cores (exact 3-way operand split), same 1e-4 bar. */
 int xr_nerf_mlp_fwd(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
                     const uint32_t* n_dev, const uint32_t* rows /* nullable: dirs row of sample i */, const float* w_density, const float* w_color, int n_hidden_density, int n_hidden_color,
                     float pad_value, float* raw /*[n,4]*/, void* stream);
 /* backward of the above given dL/draw [n,4]: writes denc_t [32][ld] (for xr_hashgrid_bwd) and
  * ACCUMULATES weight gradients into grad_w_density / grad_w_color (caller zero-fills).
  * Activations are recomputed in-kernel (nothing saved by the forward).
- * workspace: xr_nerf_mlp_bwd_workspace_bytes(n). */
+ * workspace: xr_nerf_mlp_bwd_workspace_bytes2(n, n_hidden_density, n_hidden_color) -- list of live rows first (its position does
+ * not depend on the depths), then the per-workgroup weight-gradient partials, then (streamed depths) the activation scratch area;
+ * xr_nerf_mlp_bwd_workspace_bytes(n) = the (1, 2) size.
+ * Streamed depths (anything but (1, 2)): the forward is recomputed with the forward's own arithmetic (3-way split: the same ReLU
+ * decisions bit for bit), the gradient chain and the weight-gradient products on 2-way split operands like the default below. */
 size_t xr_nerf_mlp_bwd_workspace_bytes(uint32_t n);
+size_t xr_nerf_mlp_bwd_workspace_bytes2(uint32_t n, int n_hidden_density, int n_hidden_color);
 /* live_rows / n_live (both or neither): the list xr_live_rows built from `draw`.  The backward then computes exactly the
  * listed rows and leaves the other rows of denc_t UNTOUCHED (pass the same list to xr_hashgrid_bwd).  Without a list
  * the call builds its own in the workspace and writes exact zeros to the dead rows of denc_t (same results as the

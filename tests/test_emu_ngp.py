@@ -118,11 +118,13 @@ def test_density_query_with_the_splat_inside_on_the_host(edev):
             ops.set_f32_forward(old)
 
 
-def test_deeper_topologies_on_the_host(O, edev):
-    """(5, 5) -- tiny-cuda-nn's default depth -- and (3, 4): the layer-by-layer path on the emulated linear kernels"""
+def test_deeper_topologies_on_the_host(O, edev, monkeypatch):
+    """(5, 5) -- tiny-cuda-nn's default depth -- and other depths: the streamed fused kernels (weights through LDS layer by layer, the
+    activation scratch area, the ReLU bits, the per-layer dW reduction) and the layer-by-layer path, both on the host build"""
     import test_gpu_tcnn as T
-    T.test_deeper_topologies_run_layer_by_layer(O, edev, 5, 5, 100, 80)
-    T.test_deeper_topologies_run_layer_by_layer(O, edev, 3, 4, 65, None)
+    T.test_deeper_topologies_against_the_oracle(O, edev, 5, 5, 300, 270, 'streamed', monkeypatch)
+    T.test_deeper_topologies_against_the_oracle(O, edev, 2, 1, 65, None, 'streamed', monkeypatch)
+    T.test_deeper_topologies_against_the_oracle(O, edev, 3, 4, 65, None, 'layered', monkeypatch)
 
 
 def test_mlp_backward_arithmetic_modes_on_the_host(O, edev, monkeypatch):

@@ -70,9 +70,12 @@ def test_zero_sized_and_invalid_calls(dev):
     assert L.xr_rays_sampler(t.data_ptr(), t.data_ptr(), t.data_ptr(), 4, 0.0, 1.0, 0.05, 0.004, 64, 0, 0, t.data_ptr(),
                              t.data_ptr(), t.data_ptr(), t.data_ptr(), None, 0, None) == -22
     assert b'workspace' in L.xr_last_error()
-    assert L.xr_nerf_mlp_bwd(t.data_ptr(), 64, t.data_ptr(), 3, 8, None, t.data_ptr(), t.data_ptr(), 5, 5, 1.0,
+    assert L.xr_nerf_mlp_bwd(t.data_ptr(), 64, t.data_ptr(), 3, 8, None, t.data_ptr(), t.data_ptr(), 9, 5, 1.0,
                              t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), 1 << 30, None, None, None) == -22
-    assert b'topology' in L.xr_last_error()
+    assert b'hidden layers' in L.xr_last_error()              # (1..8 per network; 5 + 5 = tcnn's default runs on the streamed kernels)
+    assert L.xr_nerf_mlp_bwd(t.data_ptr(), 64, t.data_ptr(), 3, 8, None, t.data_ptr(), t.data_ptr(), 5, 5, 1.0,
+                             t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), 1 << 20, None, None, None) == -22
+    assert b'workspace' in L.xr_last_error()
     with pytest.raises(_lib.XrError):
         ops.ema_grid_samples(torch.zeros(6, device=dev), 6, 0.95, torch.zeros(6, device=dev))   # not a multiple of 4
 

@@ -231,12 +231,18 @@ def dev_of(t):
     return t.device
 
 
-@pytest.mark.parametrize('nhd,nhc,n,n_valid', [(5, 5, 300, None), (5, 5, 5000, 4100), (3, 4, 257, None), (2, 2, 100, None)])
-def test_deeper_topologies_run_layer_by_layer(O, dev, nhd, nhc, n, n_valid):
+@pytest.mark.parametrize('path', ['streamed', 'layered'])
+@pytest.mark.parametrize('nhd,nhc,n,n_valid', [(5, 5, 300, None), (5, 5, 5000, 4100), (3, 4, 257, None), (2, 2, 100, None), (1, 1, 33, None),
+                                               (8, 8, 700, 650), (2, 1, 1000, None)])
+def test_deeper_topologies_against_the_oracle(O, dev, nhd, nhc, n, n_valid, path, monkeypatch):
     """tiny-cuda-nn's own default depth (5 hidden layers: what the reference's unchanged config builds if tcnn ignores its
-    `num_layers` key) and any other depth the fused kernels are not built for: forward and backward
-    against the oracle, through the same ops entry points (layer-by-layer path on the linear kernels)"""
+    `num_layers` key) and any other depth: forward and backward against the oracle through the same ops entry
+    points -- on the STREAMED fused kernels (k_nerf_mlp_fwd_deep / _bwd_deep: the layers' weights pass through LDS, round 5) and on
+    the layer-by-layer path over the linear kernels (the independent statement of rounds 3-4)"""
     from xrnerf_amd import ops, synthetic as S
+    if path == 'layered':
+        monkeypatch.setattr(ops, '_FUSED_FWD', ((1, 2),))
+        monkeypatch.setattr(ops, '_FUSED_BWD', ((1, 2),))
     meta = ops.GridMeta(); om = O.GridMeta()
     rng = np.random.default_rng(nhd * 10 + nhc + n)
     table = S.hash_table(meta.n_params, scale=0.5)
@@ -263,6 +269,54 @@ def test_deeper_topologies_run_layer_by_layer(O, dev, nhd, nhc, n, n_valid):
     for name, got, refg in (('wd', g_wd, gd), ('wc', g_wc, gc), ('table', g_t, gt)):
         err = np.abs(got.cpu().numpy() - refg).max()
         assert err <= 1e-3 * max(1.0, np.abs(refg).max()), (name, err, np.abs(refg).max())
+
+
+def test_streamed_kernels_equal_the_layer_by_layer_path_at_full_size(dev, monkeypatch):
+    """tcnn's default 5 + 5 hidden layers at the training step's size: 2^18 rows of which 2.3e5 are valid, the rows behind the count
+    holding NaN bit patterns in the encoded features and in dL/d(raw), half of the valid rows dead (exactly zero gradient) and the
+    backward on the live-row list.  The streamed fused kernels against the layer-by-layer path (fp32 linear kernels, activations
+    through HBM), which the oracle pins at small sizes: forward, dL/d(encoding) and both weight gradients."""
+    from xrnerf_amd import ops, synthetic as S
+    n, nv, nhd, nhc = 1 << 18, 230000, 5, 5
+    g = torch.Generator(device='cpu').manual_seed(7)
+    wd, wc = T(S.mlp_weights(32, 64, nhd, 16, 4), dev), T(S.mlp_weights(32, 64, nhc, 16, 5), dev)
+    enc_t = (torch.randn((32, n), generator=g) * 0.5).to(dev)
+    dirs = torch.rand((n, 3), generator=g).to(dev)
+    draw = torch.randn((n, 4), generator=g).to(dev)
+    draw[torch.rand((n,), generator=g).to(dev) < 0.5] = 0.0                # dead rows, as the compositor leaves them
+    n_dev = torch.tensor([nv], dtype=torch.int32, device=dev)
+    enc_t[:, nv:] = float('nan')
+    draw[nv:] = float('nan')
+    out = {}
+    for kind in ('streamed', 'streamed_live', 'layered'):
+        if kind == 'layered':
+            monkeypatch.setattr(ops, '_FUSED_FWD', ((1, 2),))
+            monkeypatch.setattr(ops, '_FUSED_BWD', ((1, 2),))
+        raw = ops.nerf_mlp_fwd(enc_t, dirs, n, wd, wc, nhd, nhc, n_dev=n_dev)
+        g_wd, g_wc = torch.zeros_like(wd), torch.zeros_like(wc)
+        live = ops.live_rows(draw, n, n_dev=n_dev) if kind == 'streamed_live' else None
+        denc_t = torch.zeros_like(enc_t)
+        ops.nerf_mlp_bwd(enc_t, dirs, n, wd, wc, nhd, nhc, draw, g_wd, g_wc, denc_t=denc_t, n_dev=n_dev, live=live)
+        out[kind] = (raw[:nv].clone(), g_wd, g_wc, denc_t[:, :nv].clone())
+    # Both sides recompute the forward to fp32 rounding accuracy in different summation orders, so a hidden unit whose pre-activation is
+    # within an ulp or two of zero can sit on the other side of its ReLU (~1e2 of the 1.5e8 unit-samples here).  Such a flip is one
+    # sample's whole contribution to a weight row and one sample's encoding gradient: the weight gradients are compared in the 2-norm
+    # (and loosely entry by entry), the encoding gradient row by row.
+    for kind in ('streamed', 'streamed_live'):
+        raw, g_wd, g_wc, denc = out[kind]
+        lraw, lg_wd, lg_wc, ldenc = out['layered']
+        for t in (raw, g_wd, g_wc, denc, lraw, lg_wd, lg_wc, ldenc):
+            assert bool(torch.isfinite(t).all()), kind
+        assert float((raw - lraw).abs().max()) <= 2e-5 * max(1.0, float(lraw.abs().max())), kind
+        for name, a, b in (('g_wd', g_wd, lg_wd), ('g_wc', g_wc, lg_wc)):
+            a, b = a.double(), b.double()
+            assert float((a - b).norm()) <= 1e-3 * float(b.norm()), (kind, name, float((a - b).norm()) / float(b.norm()))
+            assert float((a - b).abs().max()) <= 1e-2 * float(b.abs().max()), (kind, name)
+        row_err = (denc - ldenc).abs().amax(0) / float(ldenc.abs().amax(0).mean())
+        assert float(row_err.median()) <= 1e-4 and float((row_err > 1e-3).float().mean()) <= 0.01, (kind, float(row_err.median()), float((row_err > 1e-3).float().mean()))
+    # the live-row list changes nothing: same kernel, same rows in the same order within a tile batch... up to the batches' composition
+    a, b = out['streamed'], out['streamed_live']
+    assert float((a[3] - b[3]).abs().max()) <= 1e-6 * float(a[3].abs().max()) and float((a[1] - b[1]).abs().max()) <= 1e-4 * float(a[1].abs().max())
 
 
 def test_layer_by_layer_path_equals_the_fused_kernels_at_full_size(dev, monkeypatch):

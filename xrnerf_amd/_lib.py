@@ -100,6 +100,7 @@ SIGNATURES = {
     'xr_sh4': (_i32, [_vp, _u32, _u32, _vp, _vp]),
     'xr_nerf_mlp_fwd': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp]),
     'xr_nerf_mlp_bwd_workspace_bytes': (_sz, [_u32]),
+    'xr_nerf_mlp_bwd_workspace_bytes2': (_sz, [_u32, _i32, _i32]),
     'xr_ngp_train_step': (_i32, [_vp, _vp, _vp, _i32, _i32, _f, _i32, _i32, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _u32, _vp, _vp, _vp,
                                  _vp, _i32, _i32, _f, _f, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp, _sz,
                                  _vp, _sz, _i32, _vp, _u32, _vp, _vp, _vp, C.c_char_p, _vp, _vp, _vp]),

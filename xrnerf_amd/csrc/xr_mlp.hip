@@ -1644,6 +1644,394 @@ __global__ __launch_bounds__(BX_THREADS, 1) void k_nerf_mlp_fwd_b3(const float* 
     }
 }
 
+// ==================================================================================================================
+// Any depth: the layers' weights STREAMED through LDS
+// ==================================================================================================================
+// tiny-cuda-nn reads `n_hidden_layers` (default 5) and ignores keys it does not know; the reference's config writes `num_layers`
+// (configs/instant_ngp/nerf_blender_local01.py:106-124), so the networks hashnerf_mlp.py:39-45 builds are very probably 5 + 5 hidden
+// layers of 64 -- 77 824 flop per sample instead of 20 480.  Twelve 64-wide layers do not fit the 160 KB of LDS in any operand format
+// the kernels above use (fp32: 164 KB, three bf16 parts: 280 KB), and their activations and weight-gradient accumulators do not fit
+// a wave's registers.  So the loop nest is turned inside out: a workgroup takes a batch of sample tiles through ONE layer at a time.
+//   * the layer's weights are fetched from global memory (L2-resident: 80 KB per network) into registers while the previous layer
+//     computes, split and permuted into LDS behind it (two alternating buffers, one barrier per layer);
+//   * every wave keeps the activations (forward) / gradients (backward) of its tile of 32 samples in registers from layer to layer
+//     -- the transposed neurons x samples scheme of the kernels above, nothing goes through LDS between layers;
+//   * forward arithmetic = the 3-way bf16 operand split of k_nerf_mlp_fwd_b3 (fp32-rounding accuracy, layer_fwd_b3);
+//   * the backward recomputes the forward with the SAME arithmetic (its ReLU decisions are the forward's bit for bit), leaves each
+//     layer's input tile in a per-workgroup global scratch area as [neuron][32 samples] -- the layout the weight gradient's
+//     contraction over samples reads its H operand from directly, 32 B per lane, no transposing LDS tile -- and the ReLU decisions as
+//     one bit per value in LDS; then walks the layers backwards with W^T streamed in the 2-way split arrangement of layer_bwd_b2,
+//     one layer's dW accumulators (<= 4 tiles) alive at a time, reduced across the waves through LDS into the workgroup's partial.
+// All hidden layers are 64 x 64, so the depth is a RUNTIME loop count (any 1 <= n_hidden <= XR_MLP_MAX_HIDDEN per network).
+#define DP_PS 4608                     // halves per bf16 part of a streamed layer: 64 rows x h_rs(64)
+#define DP_FW 8                        // waves per workgroup, forward
+#define DP_BW 8                        // waves per workgroup, backward
+#define XR_MLP_MAX_HIDDEN 8
+
+struct DeepLayer { int K, kshift, rows, prow, goff; };
+__host__ __device__ inline int deep_glb_floats(int nh) { return 32 * W_HID + (nh - 1) * W_HID * W_HID + W_HID * 16; }
+__device__ __forceinline__ DeepLayer deep_layer(int nh, int l) {
+    DeepLayer d;
+    d.K = l == 0 ? 32 : W_HID; d.kshift = l == 0 ? 5 : 6;
+    d.rows = l == nh ? 16 : W_HID; d.prow = l == nh ? 32 : W_HID;
+    d.goff = l == 0 ? 0 : 32 * W_HID + (l - 1) * W_HID * W_HID;
+    return d;
+}
+// a layer's weights, global -> registers in SOURCE order (coalesced); padded rows read as zero
+template <int THREADS>
+__device__ __forceinline__ void deep_fetch(float (&v)[W_HID * W_HID / THREADS], const float* __restrict__ w, const DeepLayer L) {
+#pragma unroll
+    for (int i = 0; i < W_HID * W_HID / THREADS; ++i) {
+        const int e = threadIdx.x + i * THREADS, o = e >> L.kshift, c = e & (L.K - 1);
+        v[i] = (e < L.prow * L.K && o < L.rows) ? w[L.goff + o * L.K + c] : 0.f;
+    }
+}
+// registers -> LDS, forward arrangement [out row][hi][K-step][8] in three bf16 parts (store_layer_b3)
+template <int THREADS>
+__device__ __forceinline__ void deep_commit_f3(const float (&v)[W_HID * W_HID / THREADS], __bf16* __restrict__ buf, const DeepLayer L, bool rot) {
+    const int ns = L.K / 16, rs = 2 * ns * 8 + 8;
+#pragma unroll
+    for (int i = 0; i < W_HID * W_HID / THREADS; ++i) {
+        const int e = threadIdx.x + i * THREADS, o = e >> L.kshift, c = e & (L.K - 1);
+        if (e < L.prow * L.K) {
+            const int m = rot ? ((c + 1) & 31) : c;
+            __bf16 h, mi, lo;
+            split3(v[i], h, mi, lo);
+            __bf16* d = buf + o * rs + hslot(m, ns);
+            d[0] = h; d[DP_PS] = mi; d[2 * DP_PS] = lo;
+        }
+    }
+}
+// registers -> LDS, transposed arrangement [in slot][hi][K-step][8] in two bf16 parts (store_layer_bt2)
+template <int THREADS>
+__device__ __forceinline__ void deep_commit_b2(const float (&v)[W_HID * W_HID / THREADS], __bf16* __restrict__ buf, const DeepLayer L, bool rot) {
+    const int nso = L.prow / 16, rsb = 2 * nso * 8 + 8;
+#pragma unroll
+    for (int i = 0; i < W_HID * W_HID / THREADS; ++i) {
+        const int e = threadIdx.x + i * THREADS, o = e >> L.kshift, c = e & (L.K - 1);
+        if (e < L.prow * L.K) {
+            const int m = rot ? ((c + 1) & 31) : c;
+            const __bf16 h = (__bf16)v[i];
+            __bf16* d = buf + m * rsb + hslot(o, nso);
+            d[0] = h; d[DP_PS] = (__bf16)(v[i] - (float)h);
+        }
+    }
+}
+__device__ __forceinline__ uint32_t relu_tile_bits(f32x16& t) {           // relu in place -> one bit per value that stayed
+    uint32_t m = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const bool on = t[r] > 0.f; m |= on ? (1u << r) : 0u; t[r] = on ? t[r] : 0.f; }
+    return m;
+}
+__device__ __forceinline__ void mask_tile_bits(f32x16& g, uint32_t m) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g[r] = ((m >> r) & 1u) ? g[r] : 0.f;
+}
+
+template <bool WITH_COLOR>
+__global__ __launch_bounds__(DP_FW * 64, 1) void k_nerf_mlp_fwd_deep(const float* __restrict__ enc_t, uint32_t ld,
+                                                                     const float* __restrict__ dirs, uint32_t dir_stride,
+                                                                     uint32_t n, const uint32_t* __restrict__ n_dev,
+                                                                     const uint32_t* __restrict__ rows,
+                                                                     const float* __restrict__ w_density, const float* __restrict__ w_color,
+                                                                     int nhd, int nhc, float pad_value, float4* __restrict__ raw,
+                                                                     const int32_t* __restrict__ splat_idx, float* __restrict__ splat_grid) {
+    if (n_dev) n = min(n, *n_dev);
+    if (n == 0) return;
+    constexpr int THREADS = DP_FW * 64;
+    extern __shared__ __attribute__((aligned(16))) __bf16 ldsb[];        // two layer buffers of three parts each
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, hi = lane >> 5;
+    const int n_stage = (nhd + 1) + (WITH_COLOR ? nhc + 1 : 0);
+    // stage g of a pass: layer (net, l)
+    float v[W_HID * W_HID / THREADS];
+    int k = 0;                                                          // stages done so far (buffer parity)
+    auto fetch_stage = [&](int g) {
+        const int net = g > nhd ? 1 : 0, l = net ? g - (nhd + 1) : g;
+        deep_fetch<THREADS>(v, net ? w_color : w_density, deep_layer(net ? nhc : nhd, l));
+    };
+    auto commit_stage = [&](int g, int slot) {
+        const int net = g > nhd ? 1 : 0, l = net ? g - (nhd + 1) : g;
+        deep_commit_f3<THREADS>(v, ldsb + slot * 3 * DP_PS, deep_layer(net ? nhc : nhd, l), net == 1 && l == 0);
+    };
+    fetch_stage(0);
+    commit_stage(0, 0);
+    const uint32_t per_pass = DP_FW * 32;
+    for (uint32_t base = blockIdx.x * per_pass; base < n; base += gridDim.x * per_pass) {
+        const bool last_pass = base + gridDim.x * per_pass >= n;
+        const uint32_t s = base + wave * 32 + col, sc = s < n ? s : n - 1;
+        f32x16 x, h[2];
+        float d3[3] = {0.f, 0.f, 0.f};
+        load_enc_tile(enc_t, ld, sc, x, hi);
+        if (WITH_COLOR) {
+            const float* d = dirs + (size_t)(rows ? rows[sc] : sc) * dir_stride;
+            d3[0] = d[0]; d3[1] = d[1]; d3[2] = d[2];
+        }
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int g = 0; g < n_stage; ++g) {
+            const bool has_next = !(last_pass && g + 1 == n_stage);
+            const int gn = g + 1 == n_stage ? 0 : g + 1;
+            __syncthreads();                       // stage g's weights are in place; everyone is done with the other buffer
+            if (has_next) fetch_stage(gn);
+            const __bf16* wf = ldsb + (k & 1) * 3 * DP_PS;
+            const int net = g > nhd ? 1 : 0, l = net ? g - (nhd + 1) : g, nh = net ? nhc : nhd;
+            if (l == 0) {
+                const BTile xin[1] = {to_b3(x)};
+                layer_fwd_b3<1, 2>(wf, DP_PS, xin, h, col, hi);
+                relu_tile(h[0]); relu_tile(h[1]);
+            } else if (l < nh) {
+                const BTile hh[2] = {to_b3(h[0]), to_b3(h[1])};
+                layer_fwd_b3<2, 2>(wf, DP_PS, hh, h, col, hi);
+                relu_tile(h[0]); relu_tile(h[1]);
+            } else {
+                const BTile hh[2] = {to_b3(h[0]), to_b3(h[1])};
+                f32x16 dout[1];
+                layer_fwd_b3<2, 1>(wf, DP_PS, hh, dout, col, hi);
+                if (net == 0) {
+                    o.w = dout[0][0];                                        // hi == 0, register 0 <-> row 0 = sigma
+                    if (WITH_COLOR) build_color_in(dout[0], d3, 3, 0, pad_value, x, hi);     // x: the colour net's input tile
+                } else { o.x = dout[0][0]; o.y = dout[0][1]; o.z = dout[0][2]; }
+            }
+            if (has_next) commit_stage(gn, (k + 1) & 1);
+            ++k;
+        }
+        if (hi == 0 && s < n) {
+            if (!WITH_COLOR && splat_idx != nullptr) atomicMax((uint32_t*)&splat_grid[(uint32_t)splat_idx[s]], __float_as_uint(expf(o.w) * xr_min_step()));
+            else raw[s] = o;
+        }
+    }
+}
+
+template <int TO>
+__device__ __forceinline__ void dw_stage_g(const f32x16 (&g)[TO], float* __restrict__ stage, int col, int hi) {
+#pragma unroll
+    for (int to = 0; to < TO; ++to)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stage[(to * 32 + drow(r) + 4 * hi) * ST33 + col] = g[to][r];
+    __builtin_amdgcn_wave_barrier();
+}
+// a tile in the accumulator layout -> the scratch area's [neuron][32 samples]
+__device__ __forceinline__ void scr_store_tile(float* __restrict__ hs, int tile, const f32x16& h, int col, int hi) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hs[(tile * 32 + drow(r) + 4 * hi) * 32 + col] = h[r];
+}
+template <int N>
+__device__ __forceinline__ void zero_tiles(f32x16 (&a)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[i][r] = 0.f;
+}
+// the dW of the layer just walked: the eight waves' accumulators -> four LDS copies (two turns) -> summed into the workgroup's partial.
+// `old`: the partial's values of the passes before, fetched at the top of the stage (the read-modify-write's load latency would
+// otherwise sit exposed at the end of every stage).
+template <int TO, int TI>
+__device__ __forceinline__ void deep_flush(const f32x16 (&acc)[TO][TI], float* __restrict__ red, float* __restrict__ dst, int rows, int K, bool rot,
+                                           const float (&old)[W_HID * W_HID / (DP_BW * 64)], int wave, int col, int hi) {
+    __syncthreads();                               // every wave is done with its staging tile (the copies alias the staging area)
+    if (wave < 4) dw_flush<TO, TI>(acc, red + wave * W_HID * W_HID, rows, K, rot, col, hi, true);
+    __syncthreads();
+    if (wave >= 4) dw_flush<TO, TI>(acc, red + (wave & 3) * W_HID * W_HID, rows, K, rot, col, hi, false);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < W_HID * W_HID / (DP_BW * 64); ++i) {
+        const int e = threadIdx.x + i * DP_BW * 64;
+        if (e < rows * K) dst[e] = old[i] + ((red[e] + red[W_HID * W_HID + e]) + (red[2 * W_HID * W_HID + e] + red[3 * W_HID * W_HID + e]));
+    }
+}
+// a layer's input tile(s) from the scratch area as the H operand of the weight gradient: fetched at the top of the stage, used behind the
+// dX chain (two waves per SIMD do not hide a memory round trip issued right in front of its use)
+template <int TI>
+struct HOperand { float4 q[TI][2][2]; };
+template <int TI>
+__device__ __forceinline__ void fetch_h(HOperand<TI>& H, const float* __restrict__ hs, int col, int hi) {
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            H.q[ti][t][0] = *reinterpret_cast<const float4*>(hs + (ti * 32 + col) * 32 + 16 * t + 8 * hi);
+            H.q[ti][t][1] = *reinterpret_cast<const float4*>(hs + (ti * 32 + col) * 32 + 16 * t + 8 * hi + 4);
+        }
+}
+template <int TO, int TI>
+__device__ __forceinline__ void dw_mfma_b2_h(f32x16 (&acc)[TO][TI], const float* __restrict__ stage, const HOperand<TI>& H, int col, int hi) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        bw8 ah[TO], al[TO], bh[TI], bl[TI];
+#pragma unroll
+        for (int to = 0; to < TO; ++to) split2x8(stage + (to * 32 + col) * ST33 + 16 * t + 8 * hi, ah[to], al[to]);
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) {
+            const float4 a = H.q[ti][t][0], b = H.q[ti][t][1];
+            const float q[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            split2x8(q, bh[ti], bl[ti]);
+        }
+#pragma unroll
+        for (int to = 0; to < TO; ++to)
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti) {
+                acc[to][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[to], bh[ti], acc[to][ti], 0, 0, 0);
+                acc[to][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[to], bl[ti], acc[to][ti], 0, 0, 0);
+                acc[to][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[to], bh[ti], acc[to][ti], 0, 0, 0);
+            }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <bool LIVE>
+__global__ __launch_bounds__(DP_BW * 64, 1) void k_nerf_mlp_bwd_deep(
+    const float* __restrict__ enc_t, uint32_t ld, const float* __restrict__ dirs, uint32_t dir_stride, uint32_t n,
+    const uint32_t* __restrict__ n_dev, const float* __restrict__ w_density, const float* __restrict__ w_color, int nhd, int nhc,
+    float pad_value, const float4* __restrict__ draw, float* __restrict__ denc_t, float* __restrict__ partial /*[grid][GW]*/,
+    float* __restrict__ scratch /*[grid][slots][waves][64][32]*/, const uint32_t* __restrict__ live_rows,
+    const uint32_t* __restrict__ n_live) {
+    if (n_dev) n = min(n, *n_dev);
+    if (LIVE) n = *n_live;                                             // rows of the compacted space
+    constexpr int THREADS = DP_BW * 64;
+    const int gwd = deep_glb_floats(nhd), GW = gwd + deep_glb_floats(nhc);
+    const int n_slot = nhd + nhc + 2;                                   // density: features, hidden 1..nhd; colour: input slots, hidden 1..nhc
+    extern __shared__ __attribute__((aligned(16))) __bf16 ldsb[];
+    __bf16* wbuf = ldsb;                                                // two layer buffers (three parts each; the backward uses two)
+    float* stage_all = reinterpret_cast<float*>(ldsb + 2 * 3 * DP_PS);  // per wave [64][33]; between layers: four copies of a layer's dW
+    uint32_t* bits = reinterpret_cast<uint32_t*>(stage_all + DP_BW * 64 * ST33);   // [slot][wave][64 lanes]: the ReLU decisions of a lane's 32 values
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, hi = lane >> 5;
+    float* stage = stage_all + wave * 64 * ST33;
+    float* part = partial + (size_t)blockIdx.x * GW;
+    float* scr0 = scratch + ((size_t)blockIdx.x * n_slot * DP_BW + wave) * 2048;
+    auto scr = [&](int slot) { return scr0 + (size_t)slot * DP_BW * 2048; };
+    auto bit = [&](int slot) -> uint32_t& { return bits[(slot * DP_BW + wave) * 64 + lane]; };
+    // stages of a pass.  Forward recompute: density l = 0..nhd, colour l = 0..nhc-1 (its output is not needed).  Backward: colour
+    // l = nhc..0, density l = nhd..0.
+    const int nF = (nhd + 1) + nhc, n_stage = nF + (nhc + 1) + (nhd + 1);
+    auto net_of = [&](int g) { return g < nF ? (g > nhd ? 1 : 0) : (g - nF <= nhc ? 1 : 0); };
+    auto lay_of = [&](int g) { return g < nF ? (g > nhd ? g - (nhd + 1) : g) : (g - nF <= nhc ? nhc - (g - nF) : nhd - (g - nF - (nhc + 1))); };
+    float v[W_HID * W_HID / THREADS];
+    int k = 0;
+    auto fetch_stage = [&](int g) {
+        const int net = net_of(g);
+        deep_fetch<THREADS>(v, net ? w_color : w_density, deep_layer(net ? nhc : nhd, lay_of(g)));
+    };
+    auto commit_stage = [&](int g, int slot) {
+        const int net = net_of(g), l = lay_of(g);
+        const DeepLayer L = deep_layer(net ? nhc : nhd, l);
+        if (g < nF) deep_commit_f3<THREADS>(v, wbuf + slot * 3 * DP_PS, L, net == 1 && l == 0);
+        else deep_commit_b2<THREADS>(v, wbuf + slot * 3 * DP_PS, L, net == 1 && l == 0);
+    };
+    bool first_pass = true;
+    fetch_stage(0);
+    commit_stage(0, 0);
+    const uint32_t per_pass = DP_BW * 32;
+    for (uint32_t base = blockIdx.x * per_pass; base < n || first_pass; base += gridDim.x * per_pass) {
+        const bool last_pass = base + gridDim.x * per_pass >= n;
+        const uint32_t s0 = base + wave * 32 + col;
+        const bool live = s0 < n;
+        const uint32_t si = n ? (live ? s0 : n - 1) : 0;
+        const uint32_t s = LIVE ? (n ? live_rows[si] : 0) : si;
+        float4 dr = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live && hi == 0) dr = draw[s];
+        {
+            // ---- forward recompute (its own scope: the activations are dead behind it, the gradients not alive in it)
+            f32x16 x, h[2];
+            load_enc_tile(enc_t, ld, s, x, hi);
+            scr_store_tile(scr(0), 0, x, col, hi);
+            for (int g = 0; g < nF; ++g) {
+                __syncthreads();
+                fetch_stage(g + 1);
+                const __bf16* wl = wbuf + (k & 1) * 3 * DP_PS;
+                const int net = net_of(g), l = lay_of(g), nh = net ? nhc : nhd, slot0 = net ? nhd + 1 : 0;
+                if (l == 0) {
+                    const BTile xin[1] = {to_b3(x)};
+                    layer_fwd_b3<1, 2>(wl, DP_PS, xin, h, col, hi);
+                } else if (l < nh) {
+                    const BTile hh[2] = {to_b3(h[0]), to_b3(h[1])};
+                    layer_fwd_b3<2, 2>(wl, DP_PS, hh, h, col, hi);
+                } else {                                              // density output layer -> the colour net's input slots
+                    const BTile hh[2] = {to_b3(h[0]), to_b3(h[1])};
+                    f32x16 dout[1];
+                    layer_fwd_b3<2, 1>(wl, DP_PS, hh, dout, col, hi);
+                    build_color_in(dout[0], dirs, dir_stride, s, pad_value, x, hi);
+                    scr_store_tile(scr(nhd + 1), 0, x, col, hi);
+                }
+                if (l < nh) {
+                    const uint32_t b0 = relu_tile_bits(h[0]), b1 = relu_tile_bits(h[1]);
+                    bit(slot0 + l + 1) = b0 | (b1 << 16);
+                    float* hs = scr(slot0 + l + 1);
+                    scr_store_tile(hs, 0, h[0], col, hi); scr_store_tile(hs, 1, h[1], col, hi);
+                }
+                commit_stage(g + 1, (k + 1) & 1);
+                ++k;
+            }
+        }
+        // ---- backward through the layers
+        f32x16 g2[2], g1[1];
+        for (int g = nF; g < n_stage; ++g) {
+            const bool has_next = !(last_pass && g + 1 == n_stage);
+            const int gn = g + 1 == n_stage ? 0 : g + 1;
+            __syncthreads();
+            if (has_next) fetch_stage(gn);
+            const __bf16* wl = wbuf + (k & 1) * 3 * DP_PS;
+            const int net = net_of(g), l = lay_of(g), nh = net ? nhc : nhd, slot0 = net ? nhd + 1 : 0;
+            const DeepLayer LL = deep_layer(nh, l);
+            float* dst = part + (net ? gwd : 0) + LL.goff;
+            float old[W_HID * W_HID / THREADS];
+#pragma unroll
+            for (int i = 0; i < W_HID * W_HID / THREADS; ++i) {
+                const int e = threadIdx.x + i * THREADS;
+                old[i] = (!first_pass && e < LL.rows * LL.K) ? dst[e] : 0.f;
+            }
+            if (l == nh) {
+                // ---------------------------------------------------------------- output layer of a network
+                if (net == 1) {
+                    zero_tiles(g1);
+                    g1[0][0] = dr.x; g1[0][1] = dr.y; g1[0][2] = dr.z;          // hi == 1 lanes hold zeros
+                }
+                HOperand<2> H;
+                fetch_h<2>(H, scr(slot0 + nh), col, hi);
+                dw_stage_g<1>(g1, stage, col, hi);
+                { const B2Tile gb[1] = {to_b2(g1[0])}; layer_bwd_b2<1, 2, 1>(wl, DP_PS, gb, g2, col, hi); }
+                f32x16 acc[1][2];
+                zero_tiles(acc[0]);
+                dw_mfma_b2_h<1, 2>(acc, stage, H, col, hi);
+                const uint32_t b = bit(slot0 + nh);
+                mask_tile_bits(g2[0], b); mask_tile_bits(g2[1], b >> 16);
+                deep_flush<1, 2>(acc, stage_all, dst, 16, 64, false, old, wave, col, hi);
+            } else if (l > 0) {
+                // ---------------------------------------------------------------- hidden layer
+                HOperand<2> H;
+                fetch_h<2>(H, scr(slot0 + l), col, hi);
+                dw_stage_g<2>(g2, stage, col, hi);
+                { const B2Tile gb[2] = {to_b2(g2[0]), to_b2(g2[1])}; layer_bwd_b2<2, 2>(wl, DP_PS, gb, g2, col, hi); }
+                const uint32_t b = bit(slot0 + l);
+                mask_tile_bits(g2[0], b); mask_tile_bits(g2[1], b >> 16);
+                __builtin_amdgcn_sched_barrier(0);               // (the accumulators of the weight gradient come alive behind the dX chain)
+                f32x16 acc[2][2];
+                zero_tiles(acc[0]); zero_tiles(acc[1]);
+                dw_mfma_b2_h<2, 2>(acc, stage, H, col, hi);
+                deep_flush<2, 2>(acc, stage_all, dst, 64, 64, false, old, wave, col, hi);
+            } else {
+                // ---------------------------------------------------------------- input layer of a network
+                HOperand<1> H;
+                fetch_h<1>(H, scr(slot0), col, hi);
+                dw_stage_g<2>(g2, stage, col, hi);
+                { const B2Tile gb[2] = {to_b2(g2[0]), to_b2(g2[1])}; layer_bwd_b2<2, 1>(wl, DP_PS, gb, g1, col, hi); }
+                __builtin_amdgcn_sched_barrier(0);
+                f32x16 acc[2][1];
+                zero_tiles(acc[0]); zero_tiles(acc[1]);
+                dw_mfma_b2_h<2, 1>(acc, stage, H, col, hi);
+                if (net == 1) {
+                    // slots 1..15 are density-output rows 1..15; row 0 takes dL/d(sigma raw); rows >= 16 (SH, pad) end here
+#pragma unroll
+                    for (int r = 8; r < 16; ++r) g1[0][r] = 0.f;
+                    if (hi == 0) g1[0][0] = dr.w;
+                } else if (live) store_enc_tile(denc_t, ld, s, g1[0], hi);
+                deep_flush<2, 1>(acc, stage_all, dst, 64, 32, net == 1, old, wave, col, hi);
+            }
+            if (has_next) commit_stage(gn, (k + 1) & 1);
+            ++k;
+        }
+        first_pass = false;
+    }
+}
+
 // ------------------------------------------------------------------ host side
 // set around a density-only forward by xr_nerf_density_splat: the launch splats instead of writing `raw`
 static thread_local const int32_t* g_fwd_splat_idx = nullptr;
@@ -1682,6 +2070,37 @@ static int launch_fwd(const float* enc_t, uint32_t ld, const float* dirs, uint32
     return XR_OK;
 }
 
+// hipFuncSetAttribute is a driver call (~3-5 us of host time): once per kernel and size, not once per launch
+static int mlp_set_lds(const void* kernel, size_t lds) {
+    static const void* seen_k[16];
+    static size_t seen_b[16];
+    static int n_seen = 0;
+    for (int i = 0; i < n_seen; ++i) if (seen_k[i] == kernel && seen_b[i] >= lds) return XR_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XR_EHIP;
+    for (int i = 0; i < n_seen; ++i) if (seen_k[i] == kernel) { seen_b[i] = lds; return XR_OK; }
+    if (n_seen < 16) { seen_k[n_seen] = kernel; seen_b[n_seen] = lds; ++n_seen; }
+    return XR_OK;
+}
+// any depth: the streamed kernel (fp32 results on the bf16 matrix cores, 3-way operand split)
+static int launch_fwd_deep(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n, const uint32_t* n_dev,
+                           const uint32_t* rows, const float* wd, const float* wc, int nhd, int nhc, float pad, float* raw, hipStream_t stream) {
+    XR_REQUIRE(nhd >= 1 && nhd <= XR_MLP_MAX_HIDDEN && nhc >= 1 && nhc <= XR_MLP_MAX_HIDDEN, "1..8 hidden layers per network");
+    const int cus = xr_device_cus() > 0 ? xr_device_cus() : 256;
+    const uint32_t grid = min(xr_div_up(n, DP_FW * 32), (uint32_t)cus);
+    const size_t lds = (size_t)2 * 3 * DP_PS * sizeof(__bf16);
+    if (dirs) {
+        if (mlp_set_lds((const void*)k_nerf_mlp_fwd_deep<true>, lds) != XR_OK) { xr_set_error("hipFuncSetAttribute failed"); return XR_EHIP; }
+        hipLaunchKernelGGL(k_nerf_mlp_fwd_deep<true>, dim3(grid), dim3(DP_FW * 64), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev, rows, wd, wc,
+                           nhd, nhc, pad, (float4*)raw, (const int32_t*)nullptr, (float*)nullptr);
+    } else {
+        if (mlp_set_lds((const void*)k_nerf_mlp_fwd_deep<false>, lds) != XR_OK) { xr_set_error("hipFuncSetAttribute failed"); return XR_EHIP; }
+        hipLaunchKernelGGL(k_nerf_mlp_fwd_deep<false>, dim3(grid), dim3(DP_FW * 64), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev, rows, wd, wc,
+                           nhd, nhc, pad, (float4*)raw, g_fwd_splat_idx, g_fwd_splat_grid);
+    }
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}
+
 extern "C" int xr_nerf_mlp_fwd(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
                                const uint32_t* n_dev, const uint32_t* rows, const float* w_density, const float* w_color, int n_hidden_density, int n_hidden_color,
                                float pad_value, float* raw, void* stream_) {
@@ -1694,36 +2113,40 @@ extern "C" int xr_nerf_mlp_fwd(const float* enc_t, uint32_t ld, const float* dir
     else if (n_hidden_density == 1 && n_hidden_color == 1) rc = launch_fwd<1, 1>(enc_t, ld, dirs, dir_stride, n, n_dev, rows, w_density, w_color, pad_value, raw, (hipStream_t)stream_);
     else if (n_hidden_density == 2 && n_hidden_color == 2) rc = launch_fwd<2, 2>(enc_t, ld, dirs, dir_stride, n, n_dev, rows, w_density, w_color, pad_value, raw, (hipStream_t)stream_);
     else if (n_hidden_density == 2 && n_hidden_color == 3) rc = launch_fwd<2, 3>(enc_t, ld, dirs, dir_stride, n, n_dev, rows, w_density, w_color, pad_value, raw, (hipStream_t)stream_);
-    else { xr_set_error("xr_nerf_mlp_fwd: unsupported hidden-layer counts (%d,%d)", n_hidden_density, n_hidden_color); return XR_EINVAL; }
+    // any other depth (tcnn's default 5 + 5): the layers' weights streamed through LDS
+    else return launch_fwd_deep(enc_t, ld, dirs, dir_stride, n, n_dev, rows, w_density, w_color, n_hidden_density, n_hidden_color, pad_value, raw, (hipStream_t)stream_);
     if (rc != XR_OK) { xr_set_error("xr_nerf_mlp_fwd: cannot configure dynamic LDS"); return rc; }
     XR_LAUNCH_CHECK();
     return XR_OK;
 }
 
-// hipFuncSetAttribute is a driver call (~3-5 us of host time): once per kernel and size, not once per launch
-static int mlp_set_lds(const void* kernel, size_t lds) {
-    static const void* seen_k[16];
-    static size_t seen_b[16];
-    static int n_seen = 0;
-    for (int i = 0; i < n_seen; ++i) if (seen_k[i] == kernel && seen_b[i] >= lds) return XR_OK;
-    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XR_EHIP;
-    for (int i = 0; i < n_seen; ++i) if (seen_k[i] == kernel) { seen_b[i] = lds; return XR_OK; }
-    if (n_seen < 16) { seen_k[n_seen] = kernel; seen_b[n_seen] = lds; ++n_seen; }
-    return XR_OK;
-}
 static uint32_t bwd_grid(uint32_t n) {
     const int cus = xr_device_cus() > 0 ? xr_device_cus() : 256;
     const uint32_t n_tiles = (n + 31) / 32;
     return min(xr_div_up(n_tiles, MLP_WAVES), (uint32_t)cus);
 }
-// workspace: [cus][GW] dW partials | live_rows[n] | seg_count[ceil(n / LIVE_SEG)] | n_live
-static size_t bwd_partial_bytes() {
+static uint32_t bwd_grid_deep(uint32_t n) {
     const int cus = xr_device_cus() > 0 ? xr_device_cus() : 256;
-    return (size_t)cus * (NetShape<1>::glb_floats + NetShape<2>::glb_floats) * sizeof(float);
+    return max(1u, min(xr_div_up(n, DP_BW * 32), (uint32_t)cus));
 }
-extern "C" size_t xr_nerf_mlp_bwd_workspace_bytes(uint32_t n) {
-    return bwd_partial_bytes() + ((size_t)n + xr_div_up(n, LIVE_SEG) + 4) * sizeof(uint32_t);   // n_live is 4 words
+static bool bwd_is_deep(int nhd, int nhc) { return !(nhd == 1 && nhc == 2); }
+// workspace of a backward over n rows: live_rows[n] | seg_count[ceil(n / LIVE_SEG)] | n_live (4 words) | -> 256 B | dW partials
+// [cus][GW] | streamed kernels: the activation scratch area [cus][nhd + nhc + 2][waves][64][32]
+static size_t bwd_list_bytes(uint32_t n) { return ((((size_t)n + xr_div_up(n, LIVE_SEG) + 4) * sizeof(uint32_t)) + 255) & ~(size_t)255; }
+static size_t bwd_partial_bytes(int nhd, int nhc) {
+    const int cus = xr_device_cus() > 0 ? xr_device_cus() : 256;
+    const size_t gw = bwd_is_deep(nhd, nhc) ? (size_t)deep_glb_floats(nhd) + deep_glb_floats(nhc) : (size_t)NetShape<1>::glb_floats + NetShape<2>::glb_floats;
+    return ((size_t)cus * gw * sizeof(float) + 255) & ~(size_t)255;
 }
+static size_t bwd_scratch_bytes(int nhd, int nhc) {
+    const int cus = xr_device_cus() > 0 ? xr_device_cus() : 256;
+    return bwd_is_deep(nhd, nhc) ? (size_t)cus * (nhd + nhc + 2) * DP_BW * 2048 * sizeof(float) : 0;
+}
+static float* bwd_partials(const void* workspace, uint32_t n) { return reinterpret_cast<float*>((char*)workspace + bwd_list_bytes(n)); }
+extern "C" size_t xr_nerf_mlp_bwd_workspace_bytes2(uint32_t n, int n_hidden_density, int n_hidden_color) {
+    return bwd_list_bytes(n) + bwd_partial_bytes(n_hidden_density, n_hidden_color) + bwd_scratch_bytes(n_hidden_density, n_hidden_color);
+}
+extern "C" size_t xr_nerf_mlp_bwd_workspace_bytes(uint32_t n) { return xr_nerf_mlp_bwd_workspace_bytes2(n, 1, 2); }
 static bool live_rows_enabled() {          // XR_MLP_LIVE=0: run the backward over every row (measurement)
     static int on = -1;
     if (on < 0) { const char* e = getenv("XR_MLP_LIVE"); on = (e && e[0] == '0') ? 0 : 1; }
@@ -1751,13 +2174,13 @@ extern "C" int xr_live_rows(const float* dloss_doutput, uint32_t n, const uint32
                             uint32_t* n_live, float* zero_denc_t, uint32_t ld, void* stream_) {
     return xr_live_rows2(dloss_doutput, n, n_dev, seg_count, live_rows, n_live, zero_denc_t, ld, 0, stream_);
 }
-// where a list of n rows sits in an xr_nerf_mlp_bwd workspace (behind the dW partials): callers that build the list
+// where a list of n rows sits in an xr_nerf_mlp_bwd workspace (at its start, whatever the topology): callers that build the list
 // themselves to share it with xr_hashgrid_bwd use these slots instead of allocating
 extern "C" int xr_nerf_mlp_bwd_list_slots(void* workspace, size_t workspace_bytes, uint32_t n, uint32_t** live_rows,
                                           uint32_t** seg_count, uint32_t** n_live) {
     XR_REQUIRE(workspace && live_rows && seg_count && n_live, "null pointer");
     XR_REQUIRE(workspace_bytes >= xr_nerf_mlp_bwd_workspace_bytes(n), "workspace too small");
-    *live_rows = reinterpret_cast<uint32_t*>((char*)workspace + bwd_partial_bytes());
+    *live_rows = reinterpret_cast<uint32_t*>(workspace);
     *seg_count = *live_rows + n;
     *n_live = *seg_count + xr_div_up(n, LIVE_SEG);
     return XR_OK;
@@ -1765,7 +2188,7 @@ extern "C" int xr_nerf_mlp_bwd_list_slots(void* workspace, size_t workspace_byte
 // the backward's own list, in its workspace (callers that did not bring one): dead rows of denc_t are zeroed
 static int build_live_rows(const float* draw, uint32_t n, const uint32_t* n_dev, float* denc_t, uint32_t ld, void* workspace,
                            hipStream_t stream, const uint32_t** rows, const uint32_t** n_live) {
-    uint32_t* list = reinterpret_cast<uint32_t*>((char*)workspace + bwd_partial_bytes());
+    uint32_t* list = reinterpret_cast<uint32_t*>(workspace);
     uint32_t* seg = list + n;
     uint32_t* cnt = seg + xr_div_up(n, LIVE_SEG);
     *rows = list; *n_live = cnt;
@@ -1776,16 +2199,18 @@ static int build_live_rows(const float* draw, uint32_t n, const uint32_t* n_dev,
 // gradients): it sets this flag around its backward call and issues xr_nerf_mlp_bwd_reduce itself
 static thread_local bool g_defer_reduce = false;
 void xr_internal_defer_mlp_reduce(bool on) { g_defer_reduce = on; }
-int xr_internal_mlp_bwd_reduce(const void* workspace, uint32_t n, float* grad_w_density, float* grad_w_color, int overwrite, void* stream_) {
+int xr_internal_mlp_bwd_reduce(const void* workspace, uint32_t n, int nhd, int nhc, float* grad_w_density, float* grad_w_color, int overwrite, void* stream_) {
     XR_REQUIRE(workspace && grad_w_density && grad_w_color, "null pointer");
-    constexpr int GW = NetShape<1>::glb_floats + NetShape<2>::glb_floats;
-    hipLaunchKernelGGL(k_reduce_partials, dim3(xr_div_up(GW, 64)), dim3(256), 0, (hipStream_t)stream_, (const float*)workspace, bwd_grid(n),
-                       (uint32_t)GW, (uint32_t)NetShape<1>::glb_floats, grad_w_density, grad_w_color, overwrite);
+    const bool deep = bwd_is_deep(nhd, nhc);
+    const uint32_t gwd = deep ? (uint32_t)deep_glb_floats(nhd) : (uint32_t)NetShape<1>::glb_floats;
+    const uint32_t GW = gwd + (deep ? (uint32_t)deep_glb_floats(nhc) : (uint32_t)NetShape<2>::glb_floats);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(xr_div_up(GW, 64)), dim3(256), 0, (hipStream_t)stream_, (const float*)bwd_partials(workspace, n),
+                       deep ? bwd_grid_deep(n) : bwd_grid(n), GW, gwd, grad_w_density, grad_w_color, overwrite);
     XR_LAUNCH_CHECK();
     return XR_OK;
 }
 extern "C" int xr_nerf_mlp_bwd_reduce(const void* workspace, uint32_t n, float* grad_w_density, float* grad_w_color, void* stream_) {
-    return xr_internal_mlp_bwd_reduce(workspace, n, grad_w_density, grad_w_color, 0, stream_);
+    return xr_internal_mlp_bwd_reduce(workspace, n, 1, 2, grad_w_density, grad_w_color, 0, stream_);
 }
 
 extern "C" int xr_nerf_mlp_bwd(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
@@ -1797,18 +2222,34 @@ extern "C" int xr_nerf_mlp_bwd(const float* enc_t, uint32_t ld, const float* dir
     hipStream_t stream = (hipStream_t)stream_;
     XR_REQUIRE(enc_t && dirs && w_density && w_color && draw && denc_t && grad_w_density && grad_w_color, "null pointer");
     XR_REQUIRE(ld >= n && ld <= XR_MLP_MAX_LD && dir_stride >= 3 && ((uintptr_t)draw & 15) == 0, "bad ld / stride / alignment");
-    if (!(n_hidden_density == 1 && n_hidden_color == 2)) {
-        xr_set_error("xr_nerf_mlp_bwd: only the (1,2) hidden-layer topology of configs/instant_ngp is built (got %d,%d)",
-                     n_hidden_density, n_hidden_color);
-        return XR_EINVAL;
-    }
-    XR_REQUIRE(workspace && workspace_bytes >= xr_nerf_mlp_bwd_workspace_bytes(n), "workspace too small");
-    constexpr int GW = NetShape<1>::glb_floats + NetShape<2>::glb_floats;
-    size_t lds = (NetShape<1>::lds_floats + NetShape<2>::lds_floats + MLP_WAVES * 4 * 32 * ST33) * sizeof(float);
-    const uint32_t grid = bwd_grid(n);
+    XR_REQUIRE(n_hidden_density >= 1 && n_hidden_density <= XR_MLP_MAX_HIDDEN && n_hidden_color >= 1 && n_hidden_color <= XR_MLP_MAX_HIDDEN,
+               "1..8 hidden layers per network");
+    XR_REQUIRE(workspace && workspace_bytes >= xr_nerf_mlp_bwd_workspace_bytes2(n, n_hidden_density, n_hidden_color), "workspace too small");
     XR_REQUIRE(!live_rows == !n_live, "live_rows and n_live come together");
     const uint32_t* rows = live_rows;                    // the caller's list (xr_live_rows), else the backward's own
     if (!rows && live_rows_enabled()) { const int rc = build_live_rows(draw, n, n_dev, denc_t, ld, workspace, stream, &rows, &n_live); if (rc != XR_OK) return rc; }
+    float* partials = bwd_partials(workspace, n);
+    if (bwd_is_deep(n_hidden_density, n_hidden_color)) {
+        // any depth but the reference config's (1, 2): the streamed kernel (k_nerf_mlp_bwd_deep)
+        const int nhd = n_hidden_density, nhc = n_hidden_color;
+        const uint32_t gwd = (uint32_t)deep_glb_floats(nhd), GWD = gwd + (uint32_t)deep_glb_floats(nhc);
+        const uint32_t gridd = bwd_grid_deep(n);
+        const size_t ldsd = (size_t)2 * 3 * DP_PS * sizeof(__bf16) + (size_t)DP_BW * 64 * ST33 * sizeof(float) +
+                            (size_t)(nhd + nhc + 2) * DP_BW * 64 * sizeof(uint32_t);
+        float* scratch = reinterpret_cast<float*>((char*)partials + bwd_partial_bytes(nhd, nhc));
+        auto kd = rows ? k_nerf_mlp_bwd_deep<true> : k_nerf_mlp_bwd_deep<false>;
+        if (mlp_set_lds((const void*)kd, ldsd) != XR_OK) { xr_set_error("hipFuncSetAttribute failed"); return XR_EHIP; }
+        hipLaunchKernelGGL(kd, dim3(gridd), dim3(DP_BW * 64), ldsd, stream, enc_t, ld, dirs, dir_stride, n, n_dev, w_density, w_color, nhd, nhc, pad_value,
+                           (const float4*)draw, denc_t, partials, scratch, rows, n_live);
+        if (!g_defer_reduce)
+            hipLaunchKernelGGL(k_reduce_partials, dim3(xr_div_up(GWD, 64)), dim3(256), 0, stream, (const float*)partials, gridd, GWD, gwd,
+                               grad_w_density, grad_w_color, 0);
+        XR_LAUNCH_CHECK();
+        return XR_OK;
+    }
+    constexpr int GW = NetShape<1>::glb_floats + NetShape<2>::glb_floats;
+    size_t lds = (NetShape<1>::lds_floats + NetShape<2>::lds_floats + MLP_WAVES * 4 * 32 * ST33) * sizeof(float);
+    const uint32_t grid = bwd_grid(n);
     // XR_MLP_BWD_DW (read per call): f32 = fp32 MFMA throughout; b2 = the dW products on the bf16 matrix cores (2-way split);
     // b2x (default) = the dX chain too; b2f = the forward recompute as well.  b2f is not the default: a recompute at 2^-16
     // relative accuracy puts a hidden unit whose pre-activation is within ~1e-5 of zero on the other side of its ReLU than
@@ -1832,9 +2273,9 @@ extern "C" int xr_nerf_mlp_bwd(const float* enc_t, uint32_t ld, const float* dir
     if (mode == 3) lds = ft2 + bt2 + st3;
     if (mlp_set_lds((const void*)kern, lds) != XR_OK) { xr_set_error("hipFuncSetAttribute failed"); return XR_EHIP; }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n,
-                       n_dev, w_density, w_color, pad_value, (const float4*)draw, denc_t, (float*)workspace, rows, n_live);
+                       n_dev, w_density, w_color, pad_value, (const float4*)draw, denc_t, partials, rows, n_live);
     if (!g_defer_reduce)
-        hipLaunchKernelGGL(k_reduce_partials, dim3(xr_div_up(GW, 64)), dim3(256), 0, stream, (const float*)workspace, grid,
+        hipLaunchKernelGGL(k_reduce_partials, dim3(xr_div_up(GW, 64)), dim3(256), 0, stream, (const float*)partials, grid,
                            (uint32_t)GW, (uint32_t)NetShape<1>::glb_floats, grad_w_density, grad_w_color);
     XR_LAUNCH_CHECK();
     return XR_OK;
@@ -1927,8 +2368,9 @@ extern "C" int xr_nerf_mlp_fwd_bf16x3(const float* enc_t, uint32_t ld, const flo
     XR_REQUIRE(enc_t && w_density && raw, "null pointer");
     XR_REQUIRE(!dirs || (w_color && dir_stride >= 3), "color path needs w_color and dir_stride >= 3");
     XR_REQUIRE(ld >= n && ld <= XR_MLP_MAX_LD && ((uintptr_t)raw & 15) == 0, "bad ld / raw alignment");
-    XR_REQUIRE(n_hidden_density == 1 && n_hidden_color == 2, "the split forward is built for the (1,2) hidden-layer topology");
     hipStream_t stream = (hipStream_t)stream_;
+    if (!(n_hidden_density == 1 && n_hidden_color == 2))      // the same arithmetic at any depth: the layers' weights streamed through LDS
+        return launch_fwd_deep(enc_t, ld, dirs, dir_stride, n, n_dev, rows, w_density, w_color, n_hidden_density, n_hidden_color, pad_value, raw, stream);
     const int cus = xr_device_cus() > 0 ? xr_device_cus() : 256;
     const uint32_t grid = min(xr_div_up((n + 31) / 32, BX_WAVES), (uint32_t)cus);          // resident: one 8-wave workgroup per CU
     if (dirs) {
@@ -1967,9 +2409,9 @@ extern "C" int xr_nerf_mlp_bwd_f16(const float* enc_t, uint32_t ld, const float*
     auto kern = rows ? k_nerf_mlp_bwd_h<true> : k_nerf_mlp_bwd_h<false>;
     if (mlp_set_lds((const void*)kern, lds) != XR_OK) { xr_set_error("hipFuncSetAttribute failed"); return XR_EHIP; }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev, w_density,
-                       w_color, pad_value, (const float4*)draw, denc_t, (float*)workspace, rows, n_live);
+                       w_color, pad_value, (const float4*)draw, denc_t, bwd_partials(workspace, n), rows, n_live);
     if (!g_defer_reduce)
-        hipLaunchKernelGGL(k_reduce_partials, dim3(xr_div_up(GW, 64)), dim3(256), 0, stream, (const float*)workspace, grid, (uint32_t)GW,
+        hipLaunchKernelGGL(k_reduce_partials, dim3(xr_div_up(GW, 64)), dim3(256), 0, stream, (const float*)bwd_partials(workspace, n), grid, (uint32_t)GW,
                            (uint32_t)NetShape<1>::glb_floats, grad_w_density, grad_w_color);
     XR_LAUNCH_CHECK();
     return XR_OK;
@@ -1983,7 +2425,7 @@ extern "C" int xr_nerf_density_splat(int mlp_mode, const float* enc_t, uint32_t 
                                      int n_hidden_color, const int32_t* indices, float* density_grid_tmp, void* stream) {
     if (n == 0) return XR_OK;
     XR_REQUIRE(indices && density_grid_tmp, "null pointer");
-    XR_REQUIRE(n_hidden_density == 1 && n_hidden_color == 2, "the fused density query is built for the (1,2) hidden-layer topology");
+    XR_REQUIRE(mlp_mode != 1 || (n_hidden_density == 1 && n_hidden_color == 2), "the fp16 mode is built for the (1,2) hidden-layer topology");
     g_fwd_splat_idx = indices; g_fwd_splat_grid = density_grid_tmp;
     auto fwd = mlp_mode == 1 ? xr_nerf_mlp_fwd_f16 : mlp_mode == 2 ? xr_nerf_mlp_fwd_bf16x3 : xr_nerf_mlp_fwd;
     // (`raw` is not written in this mode; the argument only has to pass the alignment check)

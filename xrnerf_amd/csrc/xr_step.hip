@@ -137,13 +137,13 @@ extern "C" int xr_ngp_train_step(
     xr_internal_defer_mlp_reduce(false);
     if (rc != XR_OK) return rc;
     if ((rc = end("xr_nerf_mlp_bwd")) != XR_OK) return rc;
-    struct TailArgs { void* ws; uint32_t n; float *gd, *gc; const float *rgb, *target, *alpha; uint32_t n_rays; float delta, scale; float* loss;
+    struct TailArgs { void* ws; uint32_t n; int nhd, nhc; float *gd, *gc; const float *rgb, *target, *alpha; uint32_t n_rays; float delta, scale; float* loss;
                       const xr_adam_fuse *ad, *ac; uint32_t* seg_clear; size_t seg_bytes; }
-        ta = {ws_mlp_bwd, n_rows, grad_w_density, grad_w_color, rgb_out, target, alpha_mask, n_rays, huber_delta, loss_scale, loss_mse,
+        ta = {ws_mlp_bwd, n_rows, n_hidden_density, n_hidden_color, grad_w_density, grad_w_color, rgb_out, target, alpha_mask, n_rays, huber_delta, loss_scale, loss_mse,
               w_density_adam, w_color_adam, (live_on && live_seg_count) ? live_seg_count : nullptr, xr_live_rows_segments(n_rows) * sizeof(uint32_t)};
     XrAuxPrologue pro = {[](hipStream_t st, void* a) -> int {
                              auto* r = (TailArgs*)a;
-                             int rc1 = xr_internal_mlp_bwd_reduce(r->ws, r->n, r->gd, r->gc, 1, st);      // writes the two gradient buffers
+                             int rc1 = xr_internal_mlp_bwd_reduce(r->ws, r->n, r->nhd, r->nhc, r->gd, r->gc, 1, st);      // writes the two gradient buffers
                              if (rc1 != XR_OK) return rc1;
                              if (r->seg_clear) XR_HIP(hipMemsetAsync(r->seg_clear, 0, r->seg_bytes, st));      // read by the ranking pass long ago
                              if (r->ad) {                      // the MLP tensors' optimiser update, right behind their gradients

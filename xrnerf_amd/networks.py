@@ -114,7 +114,7 @@ class _FusedTrainStepFn(torch.autograd.Function):
             finally:
                 sampler.on_sampled = cb
             sync = getattr(net, 'grad_sync', None)
-            if table.is_cuda and mlp.density_net.n_hidden == 1 and mlp.color_net.n_hidden == 2 and \
+            if table.is_cuda and (mlp.density_net.n_hidden, mlp.color_net.n_hidden) in ops._FUSED_BWD and \
                     switches.step_mode() == 'fused' and (ops.TIMER is None or ops.TIMER.native_stage()[0]):
                 # the whole device side of the step as ONE native call (csrc/xr_step.hip) -- the same entry points in the same
                 # order as the Python sequence below, which stays for the kernels' host build and whenever a KernelTimer wants
@@ -163,7 +163,7 @@ class _FusedTrainStepFn(torch.autograd.Function):
                         mlp_adam = (opt.fused_update(wd), opt.fused_update(wc)) if adam is not None else None
                         if mlp_adam is not None and (mlp_adam[0] is None or mlp_adam[1] is None or mlp_adam[0].step != mlp_adam[1].step):
                             raise RuntimeError('the optimiser handed over the table update but not a joint update of the two MLP tensors')
-                rgb = ops.ngp_train_step(table, wd, wc, 1, 2, mlp.pad_value, meta, sampler.coords, data.get('n_valid_dev'),
+                rgb = ops.ngp_train_step(table, wd, wc, mlp.density_net.n_hidden, mlp.color_net.n_hidden, mlp.pad_value, meta, sampler.coords, data.get('n_valid_dev'),
                                          sampler.rays_numsteps, sampler.rays_numsteps_compacted, data['bg_color'],
                                          data['target_s'].contiguous(), data['alpha'].contiguous(), sampler.density_grid_mean,
                                          int(sampler.rgb_activation), int(sampler.density_activation), b, scatter_level0=split,
@@ -407,7 +407,7 @@ class HashNerfNetwork(_FastAttr, BaseNerfNetwork):
     def _fused_types(self):
         from .mlps import HashNerfMLP
         from .renders import HashNerfRender
-        return type(self.mlp) is HashNerfMLP and type(self.render) is HashNerfRender and self.mlp.density_net.n_hidden <= 2
+        return type(self.mlp) is HashNerfMLP and type(self.render) is HashNerfRender
 
     def _fused_ok(self):
         from .mlps import HashNerfMLP

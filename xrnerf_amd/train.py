@@ -308,7 +308,7 @@ class Trainer:
             st = self._native_static = bool(
                 self.native_loop and self.world_size == 1 and self.fuse_adam and self.direct_step and self.march_window != 'off' and
                 self.device.type == 'cuda' and self._window_ok() and type(net.sampler) is NGPGridSampler and type(net.mlp) is HashNerfMLP and
-                type(net.render) is HashNerfRender and net.mlp.density_net.n_hidden == 1 and net.mlp.color_net.n_hidden == 2 and
+                type(net.render) is HashNerfRender and (net.mlp.density_net.n_hidden, net.mlp.color_net.n_hidden) in ops._FUSED_BWD and
                 isinstance(self.opt, FusedAdam))
         if not st or getattr(self.net, 'grad_sync', None) is not None:
             return False
@@ -488,7 +488,8 @@ class _NativeLoop:
         D = _lib.LoopDesc()
         vp = lambda t: t.data_ptr() if t is not None else None
         D.table, D.w_density, D.w_color = vp(table), vp(wd), vp(wc)
-        D.n_hidden_density, D.n_hidden_color, D.pad_value, D.mlp_mode = 1, 2, float(mlp.pad_value), ops._mlp_mode(1, 2)
+        nhd, nhc = mlp.density_net.n_hidden, mlp.color_net.n_hidden
+        D.n_hidden_density, D.n_hidden_color, D.pad_value, D.mlp_mode = nhd, nhc, float(mlp.pad_value), ops._mlp_mode(nhd, nhc)
         s_, r_, o_ = meta._args()
         D.n_levels, D.scale_host, D.resolution_host, D.offset_host = meta.n_levels, s_, r_, o_
         for name, p, st in zip(('adam_table', 'adam_w_density', 'adam_w_color'), (table, wd, wc), states):
@@ -504,7 +505,7 @@ class _NativeLoop:
             B.enc_t, B.raw, B.draw, B.denc_t, B.rgb_out, B.zero_block = vp(b.enc_t), vp(b.raw), vp(b.draw), vp(b.denc_t), vp(b.rgb), vp(b.zero_block)
             B.zero_floats = b.zero_block.numel()
             B.grad_w_density, B.grad_w_color, B.loss_mse, B.live_seg_count = vp(b.g_wd), vp(b.g_wc), vp(b.loss_mse), vp(b.live_seg)
-        ws_mlp, live_list, _, live_stats = ops._list_slots(dev, n_rows)
+        ws_mlp, live_list, _, live_stats = ops._list_slots(dev, n_rows, nhd, nhc)
         ws_sc = ops._ws(dev, L.xr_hashgrid_bwd_workspace_bytes(n_rows, meta.n_levels, r_, o_), 'hgb')
         D.ws_mlp_bwd, D.ws_mlp_bwd_bytes = vp(ws_mlp), ws_mlp.numel()
         D.ws_scatter, D.ws_scatter_bytes = vp(ws_sc), ws_sc.numel()
@@ -547,7 +548,7 @@ class _NativeLoop:
         dp = lambda t: (t.data_ptr(), t.numel()) if t is not None else (0, 0)
         key = (n_rows, dp(win.coords), dp(win.rays_o), dp(win.xyz), win.ray_stride, win.coords_stride,
                tuple(dp(b.enc_t) + dp(b.zero_block) + dp(b.rgb) for b in sets), dp(table), dp(wd), dp(wc),
-               dp(sampler.density_grid_mean), ops._mlp_mode(1, 2), ops._stream().value,
+               dp(sampler.density_grid_mean), ops._mlp_mode(mlp.density_net.n_hidden, mlp.color_net.n_hidden), ops._stream().value,
                tuple(dp(st['m']) + dp(st['v']) + dp(st.get('ema')) for st in states),
                dp(ops._workspaces.get((str(dev), 'mlpbwd'))), dp(ops._workspaces.get((str(dev), 'hgb'))))
         if self._keep is not None and self._keep[0] == key:
