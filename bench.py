@@ -689,9 +689,18 @@ def main():
         ops.LIVE_STATS[1:3].zero_()            # running (live rows, valid rows) totals of the backward's row list
     rays0, samples0, it0 = tr.rays_done, tr.samples_done, tr.iter
     step_ev = [ops._CEvent() for _ in range(args.steps + 1)]     # one event per iteration boundary
-    if getattr(tr.net, 'grad_sync', None) is not None:
-        tr.net.grad_sync.exposed.summary()                       # (drop what earlier iterations recorded)
-        tr.net.grad_sync.exposed.on = True
+    def exposure_timers():
+        """what measures the compute stream's waits for the step's collectives: the per-iteration path's (grad_sync) and, when the native
+        loop carries the exchange, the exchange's own (callbacks: in finish(); RCCL from native code: events recorded in xr_dist.hip)"""
+        out = []
+        if getattr(tr.net, 'grad_sync', None) is not None:
+            out.append(tr.net.grad_sync.exposed)
+        if tr._loop is not None and tr._loop.exchange is not None:
+            out.append(tr._loop.exchange.exposed)
+        return out
+    for ex_t in exposure_timers():
+        ex_t.summary()                                           # (drop what earlier iterations recorded)
+        ex_t.on = True
     barrier()
     t0 = time.perf_counter()
     # (Trainer.run: the iterations between two grid refreshes are enqueued by one native call each, xr_ngp_loop_run -- the events in
@@ -903,13 +912,23 @@ def main():
         sync = getattr(tr.net, 'grad_sync', None)
         # MEASURED: how long this rank's compute stream waited for the step's collectives inside the timed region (events around the
         # waits of grad_sync.finish(); what did not overlap), gathered from every rank; the model stays beside it
-        exposed = sync.exposed.summary() if sync is not None else {}
+        parts = [t.summary() for t in exposure_timers()]
+        n_exp = sum(p_['steps'] for p_ in parts)
+        exposed = {'steps': n_exp, 'mean_ms': (sum((p_['mean_ms'] or 0.0) * p_['steps'] for p_ in parts) / n_exp) if n_exp else None,
+                   'max_ms': max([p_['max_ms'] or 0.0 for p_ in parts] + [0.0]) if n_exp else None}
         per_rank = [None] * world
         torch.distributed.all_gather_object(per_rank, exposed)
+        per_rank_iter = [None] * world
+        torch.distributed.all_gather_object(per_rank_iter, (sum(ms_normal) / max(len(ms_normal), 1), sum(ms_refresh) / max(len(ms_refresh), 1)))
         extra['collective'] = {'mode': tr.dp_mode, 'exposed_collective_ms_per_rank': [e.get('mean_ms') for e in per_rank],
                                'exposed_collective_ms': max((e.get('mean_ms') or 0.0) for e in per_rank),
                                'exposed_collective_ms_max_step': max((e.get('max_ms') or 0.0) for e in per_rank),
                                'exposed_steps_measured': exposed.get('steps'),
+                               'device_ms_normal_iteration_per_rank': [a for a, _ in per_rank_iter],
+                               'device_ms_refresh_iteration_per_rank': [b for _, b in per_rank_iter],
+                               'native_loop': bool(tr._loop is not None and tr._loop.enqueued > 0),
+                               'exchange': type(tr._loop.exchange).__name__ if (tr._loop is not None and tr._loop.exchange is not None) else 'per-iteration path (torch.distributed)',
+                               'host_enqueue_ms_per_iteration_native_loop': (tr._loop.enqueue_s * 1e3 / tr._loop.enqueued) if (tr._loop is not None and tr._loop.enqueued) else None,
                                'model': xdist.comm_model(world, step_ms=elapsed_max * 1e3 / args.steps, wire_bytes_per_float=2.0 if tr.dp_mode == 'allreduce_bf16' else 4.0),
                                'bytes_on_wire_per_rank_total': getattr(sync, 'bytes_on_wire', None),
                                'bytes_reduced_per_rank_total': getattr(sync, 'bytes_reduced', None),

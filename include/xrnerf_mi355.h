@@ -461,7 +461,20 @@ int xr_make_batch_series(const float* rays_rgb_rows, const uint64_t* row0_host, 
 typedef struct xr_ngp_step_set {       /* one of the TWO alternating sets of step buffers (see xr_ngp_train_step) */
     float *enc_t, *raw, *draw, *denc_t, *rgb_out, *zero_block; size_t zero_floats;
     float *grad_w_density, *grad_w_color, *loss_mse; uint32_t* live_seg_count;
+    float* grad_table;                 /* data parallel only: the table gradient of this set (zero1: padded to world * shard floats) */
 } xr_ngp_step_set;
+/* The gradient exchange of a data-parallel loop (N > 1 ranks; the reference: MMDistributedDataParallel's all-reduce behind the
+ * backward pass, xrnerf/core/apis/train.py:28-38).  Each call enqueues ONE collective ordered behind everything enqueued on `stream`
+ * so far and returns at once (the collective runs on the implementation's own stream, under what the caller enqueues next); `finish`
+ * orders `stream` behind every collective begun since the last finish.  Implementations: xr_rccl_exchange (RCCL driven from native
+ * code) or caller-provided function pointers (e.g. a ctypes callback issuing torch.distributed collectives: the gloo tests). */
+typedef struct xr_grad_exchange {
+    int (*all_reduce)(void* ctx, float* buf, size_t n, void* stream);                                   /* in-place sum */
+    int (*reduce_scatter)(void* ctx, const float* send, float* recv, size_t n_recv, void* stream);      /* zero1 only */
+    int (*all_gather)(void* ctx, const float* send, float* recv, size_t n_send, void* stream);          /* zero1 only */
+    int (*finish)(void* ctx, void* stream);
+    void* ctx; int world_size, rank;
+} xr_grad_exchange;
 typedef struct xr_ngp_loop_desc {
     float *table, *w_density, *w_color; int n_hidden_density, n_hidden_color; float pad_value; int mlp_mode;
     int n_levels; const float* scale_host; const uint32_t *resolution_host, *offset_host;
@@ -471,6 +484,13 @@ typedef struct xr_ngp_loop_desc {
     xr_ngp_window window; xr_ngp_step_set step[2];
     void* ws_mlp_bwd; size_t ws_mlp_bwd_bytes; void* ws_scatter; size_t ws_scatter_bytes;
     void* stream;
+    /* data parallel (null exchange = one GPU: the three updates inside the step).  Per iteration: the step writes its gradients
+     * (hash levels >= split_level first), the buckets go to the exchange as they complete (MLP gradients, fine levels, then the coarse
+     * levels scattered underneath the fine bucket's collective), `finish`, then ONE xr_adam_step_multi with grad_scale = 1 / world.
+     * dp_mode 1 (zero1): reduce-scatter of the padded table gradient into shard_grad, the optimiser on this rank's
+     * shard (adam_table then describes the SHARD: param = table_padded + rank * shard_floats), all-gather of the updated shards. */
+    const xr_grad_exchange* exchange; int dp_mode; int split_level;
+    float *shard_grad, *table_padded; uint64_t shard_floats;
 } xr_ngp_loop_desc;
 typedef struct xr_ngp_loop_state {     /* the counters the loop shares with its caller (read AND written) */
     uint64_t iter;                     /* next iteration */
@@ -484,6 +504,18 @@ typedef struct xr_ngp_loop_state {     /* the counters the loop shares with its 
  * iter_events [k + 1] (nullable): timing events recorded on `stream` in front of every iteration and behind the last. */
 int xr_ngp_loop_run(const xr_ngp_loop_desc* desc, xr_ngp_loop_state* state, uint32_t k, uint32_t n_rays, const float* lr,
                     const float* ema_momentum, const char* timed_entry, void* const* timing_events, void* const* iter_events);
+/* RCCL driven from native code (csrc/xr_dist.hip): librccl is dlopen'ed on first use (librccl_path nullable: a copy the process
+ * already mapped, else the system library).  xr_rccl_unique_id on ONE rank -> 128 bytes the caller hands to every rank ->
+ * xr_rccl_create on every rank (collective; the current device) -> xr_rccl_exchange fills the hooks.  This is the one handle the
+ * library creates (a communicator cannot live in caller-provided memory). */
+int xr_rccl_unique_id(const char* librccl_path, void* id128);
+void* xr_rccl_create(const char* librccl_path, const void* id128, int world_size, int rank);
+int xr_rccl_destroy(void* handle);
+int xr_rccl_exchange(void* handle, xr_grad_exchange* out);
+/* measured exposure of the exchange: with timing on, every `finish` that waits for something brackets the wait with two events on the
+ * caller's stream; xr_rccl_exposed_ms (after a device synchronisation) -> mean / max of the last <= 64 of them and the total count */
+int xr_rccl_timing(void* handle, int on);
+int xr_rccl_exposed_ms(void* handle, float* mean_ms, float* max_ms, int* count);
 
 /* tcnn.Network(FullyFusedMLP) on its own (compatibility surface; the hot path uses the fused kernels above):
  * x [n, n_in] with arbitrary row / column strides (in floats), n_in <= 32, missing input columns = pad_value;

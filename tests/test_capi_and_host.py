@@ -236,7 +236,7 @@ def test_struct_layouts_of_the_loop_api_match_the_header(tmp_path):
     """the ctypes mirrors of xr_adam_fuse / xr_ngp_window / xr_ngp_step_set / xr_ngp_loop_desc / xr_ngp_loop_state have the C
     compiler's size and field offsets (gcc on include/xrnerf_mi355.h; a mismatch would hand the native loop garbage pointers)"""
     from xrnerf_amd import _lib
-    structs = {'xr_adam_fuse': _lib.AdamFuse, 'xr_ngp_window': _lib.Window, 'xr_ngp_step_set': _lib.StepSet,
+    structs = {'xr_adam_fuse': _lib.AdamFuse, 'xr_ngp_window': _lib.Window, 'xr_ngp_step_set': _lib.StepSet, 'xr_grad_exchange': _lib.GradExchange,
                'xr_ngp_loop_desc': _lib.LoopDesc, 'xr_ngp_loop_state': _lib.LoopState}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "xrnerf_mi355.h"', 'int main(void) {']
     for cname, cls in structs.items():

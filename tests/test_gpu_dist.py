@@ -23,12 +23,18 @@ from xrnerf_amd.train import Trainer
 rank, local, world = xd.init_from_env('gloo')
 dev = torch.device('cuda', 0)
 torch.cuda.set_device(dev)
-tr = Trainer(dev, n_img=3, H=128, W=128, world_size=world, rank=rank, ema=False)
+native = os.environ.get('DP_NATIVE', '1') == '1'
+tr = Trainer(dev, n_img=3, H=128, W=128, world_size=world, rank=rank, ema=False, native_loop=native)
 assert tr.net._fused_ok() and tr.net.grad_sync is not None
 sig = []
 bufs_seen, mem = set(), []
 for it in range(18):
-    tr.step()
+    if it == 9 and native:
+        tr.run(4); continue_from = 13            # a window of several iterations in one native call
+    elif it in (10, 11, 12) and native:
+        continue
+    else:
+        tr.step()
     bufs_seen |= {id(b) for b in tr.net._step_bufs}
     if it in (5, 17):
         torch.cuda.synchronize(); mem.append(torch.cuda.memory_allocated())
@@ -45,6 +51,13 @@ for it in range(18):
 # clears used to pin a set per step: 48.8 MB of growth per iteration under zero1)
 assert len(bufs_seen) == 2, len(bufs_seen)
 assert mem[1] - mem[0] < (8 << 20), mem
+assert tr.iter == 18
+if native:
+    # the iterations between the refreshes went through xr_ngp_loop_run with the exchange hooks (callbacks into torch.distributed here)
+    assert tr._loop is not None and tr._loop.enqueued == 16 and tr._loop.exchange is not None, (tr._loop and tr._loop.enqueued)
+else:
+    assert tr._loop is None
+print('SIG', rank, ' '.join(a + b + c for a, b, c, _ in sig), flush=True)
 objs = [None] * world
 dist.all_gather_object(objs, sig)
 if rank == 0:
@@ -59,22 +72,33 @@ dist.barrier(); dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize('dp_mode', ['allreduce', 'zero1'])
-def test_two_ranks_stay_identical_replicas(tmp_path, dp_mode):
-    """dp_mode zero1: reduce-scatter -> Adam on the rank's shard -> all-gather (dist.Zero1GradSync; over gloo the reduce-scatter
-    is an all-reduce + slice: the protocol, the padded storage and the sharded optimiser are what runs here)"""
+def _two_ranks(tmp_path, dp_mode, native):
     import socket
-    script = tmp_path / 'w.py'
+    script = tmp_path / ('w%d.py' % native)
     script.write_text(WORKER % ROOT)
     with socket.socket() as sk:
         sk.bind(('127.0.0.1', 0))
         port = sk.getsockname()[1]
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE='2', HSA_ENABLE_IPC_MODE_LEGACY='0', XRNERF_DP=dp_mode)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE='2', HSA_ENABLE_IPC_MODE_LEGACY='0', XRNERF_DP=dp_mode,
+               DP_NATIVE='1' if native else '0')
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), [o[-1500:] for o in outs]
     assert 'replicas identical' in outs[0]
+    return [[l for l in o.splitlines() if l.startswith('SIG')][-1].split()[2:] for o in outs]
+
+
+@pytest.mark.parametrize('dp_mode', ['allreduce', 'zero1'])
+def test_two_ranks_stay_identical_replicas(tmp_path, dp_mode):
+    """dp_mode zero1: reduce-scatter -> Adam on the rank's shard -> all-gather (dist.Zero1GradSync; over gloo the reduce-scatter
+    is an all-reduce + slice: the protocol, the padded storage and the sharded optimiser are what runs here).  Twice: through the
+    NATIVE loop (xr_ngp_loop_run with the gradient-exchange hooks: the buckets go to the collectives from C++, one optimiser launch
+    on the summed gradients per iteration) and through the per-iteration path -- same grids, bitfields and parameters at every
+    checkpoint, bit for bit."""
+    nat = _two_ranks(tmp_path, dp_mode, True)
+    per = _two_ranks(tmp_path, dp_mode, False)
+    assert nat[0] == per[0] and nat[1] == per[1]
 
 
 NCCL_WORKER = r'''
@@ -116,6 +140,40 @@ def test_rccl_backend_initialises_and_runs_the_three_collectives(tmp_path):
                HSA_ENABLE_IPC_MODE_LEGACY='0')
     r = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert r.returncode == 0 and b'rccl ok nccl' in r.stdout, r.stdout.decode()[-2000:]
+
+
+RCCL_NATIVE = r'''
+import ctypes as C, sys, torch
+sys.path.insert(0, %r)
+from xrnerf_amd import _lib, dist as xd
+torch.cuda.set_device(0)
+ex = xd.RcclExchange(1, 0)                       # librccl dlopen'ed, a one-rank communicator on cuda:0, its stream and events
+st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+a = torch.arange(4096, dtype=torch.float32, device='cuda')
+ref = a.clone()
+assert ex.c.all_reduce(ex.c.ctx, a.data_ptr(), a.numel(), st) == 0
+out = torch.zeros(4096, dtype=torch.float32, device='cuda')
+assert ex.c.reduce_scatter(ex.c.ctx, a.data_ptr(), out.data_ptr(), 4096, st) == 0
+assert ex.c.finish(ex.c.ctx, st) == 0
+g = torch.zeros(4096, dtype=torch.float32, device='cuda')
+assert ex.c.all_gather(ex.c.ctx, out.data_ptr(), g.data_ptr(), 4096, st) == 0
+assert ex.c.finish(ex.c.ctx, st) == 0
+torch.cuda.synchronize()
+assert torch.equal(a, ref) and torch.equal(out, ref) and torch.equal(g, ref)
+del ex
+print('native rccl ok')
+'''
+
+
+def test_rccl_driven_from_native_code_at_world_size_one(tmp_path):
+    """csrc/xr_dist.hip: librccl dlopen'ed, a communicator from a unique id, the three collectives of the data-parallel loop enqueued
+    from native code on the communicator's own stream, `finish` ordering the caller's stream behind them -- everything short of a
+    second GPU (what `bench.py --gpus N` uses under backend nccl)"""
+    script = tmp_path / 'r.py'
+    script.write_text(RCCL_NATIVE % ROOT)
+    r = subprocess.run([sys.executable, str(script)], env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'), stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0 and b'native rccl ok' in r.stdout, r.stdout.decode()[-2000:]
 
 
 def test_bench_spawns_its_own_ranks():

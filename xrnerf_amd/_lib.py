@@ -31,10 +31,20 @@ class Window(C.Structure):
 class StepSet(C.Structure):
     """xr_ngp_step_set"""
     _fields_ = [(k, C.c_void_p) for k in ('enc_t', 'raw', 'draw', 'denc_t', 'rgb_out', 'zero_block')] + [('zero_floats', C.c_size_t)] + \
-               [(k, C.c_void_p) for k in ('grad_w_density', 'grad_w_color', 'loss_mse', 'live_seg_count')]
+               [(k, C.c_void_p) for k in ('grad_w_density', 'grad_w_color', 'loss_mse', 'live_seg_count', 'grad_table')]
 
 
 WINDOW = 16             # XR_NGP_WINDOW
+
+EX_ALL_REDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+EX_SCATTER_GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+EX_FINISH = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+
+
+class GradExchange(C.Structure):
+    """xr_grad_exchange"""
+    _fields_ = [('all_reduce', EX_ALL_REDUCE), ('reduce_scatter', EX_SCATTER_GATHER), ('all_gather', EX_SCATTER_GATHER),
+                ('finish', EX_FINISH), ('ctx', C.c_void_p), ('world_size', C.c_int), ('rank', C.c_int)]
 
 
 class LoopDesc(C.Structure):
@@ -47,7 +57,9 @@ class LoopDesc(C.Structure):
                 ('huber_delta', C.c_float), ('loss_scale', C.c_float), ('n_rows', C.c_uint32), ('ld', C.c_uint32),
                 ('window', Window), ('step', StepSet * 2),
                 ('ws_mlp_bwd', C.c_void_p), ('ws_mlp_bwd_bytes', C.c_size_t), ('ws_scatter', C.c_void_p), ('ws_scatter_bytes', C.c_size_t),
-                ('stream', C.c_void_p)]
+                ('stream', C.c_void_p),
+                ('exchange', C.POINTER(GradExchange)), ('dp_mode', C.c_int), ('split_level', C.c_int),
+                ('shard_grad', C.c_void_p), ('table_padded', C.c_void_p), ('shard_floats', C.c_uint64)]
 
 
 class LoopState(C.Structure):
@@ -106,6 +118,12 @@ SIGNATURES = {
                                  _vp, _sz, _i32, _vp, _u32, _vp, _vp, _vp, C.c_char_p, _vp, _vp, _vp]),
     'xr_event_record': (_i32, [_vp, _vp]),
     'xr_ngp_loop_run': (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, C.c_char_p, _vp, _vp]),
+    'xr_rccl_unique_id': (_i32, [C.c_char_p, _vp]),
+    'xr_rccl_create': (_vp, [C.c_char_p, _vp, _i32, _i32]),
+    'xr_rccl_destroy': (_i32, [_vp]),
+    'xr_rccl_exchange': (_i32, [_vp, _vp]),
+    'xr_rccl_timing': (_i32, [_vp, _i32]),
+    'xr_rccl_exposed_ms': (_i32, [_vp, _vp, _vp, _vp]),
     'xr_timing_event_create': (_vp, []),
     'xr_order_event_create': (_vp, []),
     'xr_stream_wait_event': (_i32, [_vp, _vp]),

@@ -35,6 +35,8 @@ SOURCES = {
     'xr_gemm.hip': [],
     # host-side step executor (calls the entry points above in sequence)
     'xr_step.hip': [],
+    # RCCL driven from native code (dlopen'ed on first use): the data-parallel loop's gradient exchange
+    'xr_dist.hip': [],
 }
 
 
@@ -83,7 +85,7 @@ def build(force=False, verbose=False):
             list(ex.map(cc, jobs))
     objs = [os.path.join(OBJ, s.replace('.hip', '.o')) for s in SOURCES]
     if force or jobs or _stale(OUT, objs):
-        cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs
+        cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs + ['-ldl']
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('link failed: %s\n%s' % (' '.join(cmd), r.stdout + r.stderr))

@@ -1665,6 +1665,9 @@ __global__ __launch_bounds__(BX_THREADS, 1) void k_nerf_mlp_fwd_b3(const float* 
 // All hidden layers are 64 x 64, so the depth is a RUNTIME loop count (any 1 <= n_hidden <= XR_MLP_MAX_HIDDEN per network).
 #define DP_PS 4608                     // halves per bf16 part of a streamed layer: 64 rows x h_rs(64)
 #define DP_FW 8                        // waves per workgroup, forward
+#ifndef DEEP_CUT
+#define DEEP_CUT 0          // measurement builds only (wrong results): 1 no dW flush, 2 no dW products, 4 no scratch stores, 8 no dX chain
+#endif
 #define DP_BW 8                        // waves per workgroup, backward
 #define XR_MLP_MAX_HIDDEN 8
 
@@ -1811,6 +1814,7 @@ __device__ __forceinline__ void dw_stage_g(const f32x16 (&g)[TO], float* __restr
 }
 // a tile in the accumulator layout -> the scratch area's [neuron][32 samples]
 __device__ __forceinline__ void scr_store_tile(float* __restrict__ hs, int tile, const f32x16& h, int col, int hi) {
+    if (DEEP_CUT & 4) return;
 #pragma unroll
     for (int r = 0; r < 16; ++r) hs[(tile * 32 + drow(r) + 4 * hi) * 32 + col] = h[r];
 }
@@ -1827,6 +1831,7 @@ __device__ __forceinline__ void zero_tiles(f32x16 (&a)[N]) {
 template <int TO, int TI>
 __device__ __forceinline__ void deep_flush(const f32x16 (&acc)[TO][TI], float* __restrict__ red, float* __restrict__ dst, int rows, int K, bool rot,
                                            const float (&old)[W_HID * W_HID / (DP_BW * 64)], int wave, int col, int hi) {
+    if (DEEP_CUT & 1) return;
     __syncthreads();                               // every wave is done with its staging tile (the copies alias the staging area)
     if (wave < 4) dw_flush<TO, TI>(acc, red + wave * W_HID * W_HID, rows, K, rot, col, hi, true);
     __syncthreads();
@@ -1854,6 +1859,7 @@ __device__ __forceinline__ void fetch_h(HOperand<TI>& H, const float* __restrict
 }
 template <int TO, int TI>
 __device__ __forceinline__ void dw_mfma_b2_h(f32x16 (&acc)[TO][TI], const float* __restrict__ stage, const HOperand<TI>& H, int col, int hi) {
+    if (DEEP_CUT & 2) return;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         bw8 ah[TO], al[TO], bh[TI], bl[TI];

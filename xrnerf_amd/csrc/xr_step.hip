@@ -241,7 +241,14 @@ extern "C" int xr_ngp_loop_run(const xr_ngp_loop_desc* desc, xr_ngp_loop_state* 
     const xr_ngp_window& W = D.window;
     XR_REQUIRE(k >= 1 && k <= (uint32_t)XR_NGP_WINDOW && n_rays >= 1 && n_rays <= W.ray_stride, "bad sizes");
     XR_REQUIRE(!timed_entry || timing_events, "a timed entry point needs its events");
-    XR_REQUIRE(D.adam_table.param == D.table && D.adam_w_density.param == D.w_density && D.adam_w_color.param == D.w_color, "the updates name the step's tensors");
+    const xr_grad_exchange* X = D.exchange;
+    XR_REQUIRE(D.adam_w_density.param == D.w_density && D.adam_w_color.param == D.w_color, "the updates name the step's tensors");
+    XR_REQUIRE(X ? (D.dp_mode == 1 ? (D.shard_grad && D.table_padded && D.shard_floats > 0 && D.adam_table.n == D.shard_floats &&
+                                        D.adam_table.param == D.table_padded + (uint64_t)X->rank * D.shard_floats && X->reduce_scatter && X->all_gather)
+                                    : (D.dp_mode == 0 && D.adam_table.param == D.table))
+                 : D.adam_table.param == D.table, "the table update names the step's table (zero1: this rank's shard of it)");
+    XR_REQUIRE(!X || (X->all_reduce && X->finish && X->world_size >= 1 && D.step[0].grad_table && D.step[1].grad_table &&
+                      D.split_level >= 0 && D.split_level < D.n_levels && (D.dp_mode == 0 || D.split_level == 0)), "bad exchange");
     XR_REQUIRE(W.coords && W.rays_numsteps && W.numsteps_clipped && W.n_valid && W.bg && W.target && W.alpha && W.coords_stride >= D.n_rows, "bad window");
     hipStream_t stream = (hipStream_t)D.stream;
     int rc;
@@ -256,14 +263,50 @@ extern "C" int xr_ngp_loop_run(const xr_ngp_loop_desc* desc, xr_ngp_loop_state* 
         at.step = ad.step = ac.step = S.adam_step;
         at.lr = ad.lr = ac.lr = lr[j];
         at.ema_momentum = ad.ema_momentum = ac.ema_momentum = ema_momentum[j];
+        const float* coords = W.coords + 7 * c * W.coords_stride;
+        const size_t table_floats = 2 * (size_t)D.offset_host[D.n_levels];
         rc = xr_ngp_train_step(D.table, D.w_density, D.w_color, D.n_hidden_density, D.n_hidden_color, D.pad_value, D.mlp_mode, D.n_levels, D.scale_host,
-                               D.resolution_host, D.offset_host, W.coords + 7 * c * W.coords_stride, D.n_rows, W.n_valid + 2 * c, W.rays_numsteps + 2 * r0,
+                               D.resolution_host, D.offset_host, coords, D.n_rows, W.n_valid + 2 * c, W.rays_numsteps + 2 * r0,
                                W.numsteps_clipped + 2 * r0, n_rays, W.bg + 3 * r0, W.target + 3 * r0, W.alpha + r0, D.density_grid_mean, D.rgb_activation,
                                D.density_activation, D.huber_delta, D.loss_scale, B.enc_t, D.ld, B.raw, B.draw, B.denc_t, B.rgb_out, B.zero_block,
-                               B.zero_floats, B.grad_w_density, B.grad_w_color, B.loss_mse, B.live_seg_count, nullptr, 0, 0, D.ws_mlp_bwd, D.ws_mlp_bwd_bytes,
-                               D.ws_scatter, D.ws_scatter_bytes, 0, W.xyz_planes ? W.xyz_planes + 3 * c * W.plane_stride : nullptr, W.plane_stride, &at, &ad, &ac,
-                               timed_entry, timed_entry ? timing_events[2 * j] : nullptr, timed_entry ? timing_events[2 * j + 1] : nullptr, D.stream);
+                               B.zero_floats, B.grad_w_density, B.grad_w_color, B.loss_mse, B.live_seg_count, X ? B.grad_table : nullptr,
+                               X ? table_floats : 0, 0, D.ws_mlp_bwd, D.ws_mlp_bwd_bytes, D.ws_scatter, D.ws_scatter_bytes, X ? D.split_level : 0,
+                               W.xyz_planes ? W.xyz_planes + 3 * c * W.plane_stride : nullptr, W.plane_stride, X ? nullptr : &at, X ? nullptr : &ad,
+                               X ? nullptr : &ac, timed_entry, timed_entry ? timing_events[2 * j] : nullptr,
+                               timed_entry ? timing_events[2 * j + 1] : nullptr, D.stream);
         if (rc != XR_OK) return rc;
+        if (X) {
+            // ---- data parallel: the buckets to the exchange as they complete, then one optimiser launch on the summed gradients
+            // (the two MLP gradients are adjacent in the set's block: one bucket)
+            XR_REQUIRE(B.grad_w_color == B.grad_w_density + D.adam_w_density.n, "the two MLP gradients form one bucket");
+            if ((rc = X->all_reduce(X->ctx, B.grad_w_density, (size_t)(D.adam_w_density.n + D.adam_w_color.n), D.stream)) != XR_OK) return rc;
+            if (D.dp_mode == 1) {
+                if ((rc = X->reduce_scatter(X->ctx, B.grad_table, D.shard_grad, (size_t)D.shard_floats, D.stream)) != XR_OK) return rc;
+            } else if (D.split_level > 0) {
+                const size_t cut = 2 * (size_t)D.offset_host[D.split_level];
+                if ((rc = X->all_reduce(X->ctx, B.grad_table + cut, table_floats - cut, D.stream)) != XR_OK) return rc;
+                // the coarser levels underneath that collective, on the step's own row list
+                uint32_t *rows = nullptr, *seg = nullptr, *n_live = nullptr;
+                static const bool live_on = []() { const char* e = getenv("XR_MLP_LIVE"); return !(e && e[0] == '0'); }();
+                if (live_on && (rc = xr_nerf_mlp_bwd_list_slots(D.ws_mlp_bwd, D.ws_mlp_bwd_bytes, D.n_rows, &rows, &seg, &n_live)) != XR_OK) return rc;
+                rc = xr_hashgrid_bwd2(coords, 7, B.denc_t, D.ld, D.n_rows, live_on ? n_live : W.n_valid + 2 * c, live_on ? rows : nullptr, D.split_level,
+                                      D.scale_host, D.resolution_host, D.offset_host, B.grad_table, D.ws_scatter, D.ws_scatter_bytes, XR_SCATTER_OVERWRITE, D.stream);
+                if (rc != XR_OK) return rc;
+                if ((rc = X->all_reduce(X->ctx, B.grad_table, cut, D.stream)) != XR_OK) return rc;
+            } else if ((rc = X->all_reduce(X->ctx, B.grad_table, table_floats, D.stream)) != XR_OK) return rc;
+            if ((rc = X->finish(X->ctx, D.stream)) != XR_OK) return rc;
+            float* p[3] = {at.param, ad.param, ac.param};
+            const float* g[3] = {D.dp_mode == 1 ? D.shard_grad : B.grad_table, B.grad_w_density, B.grad_w_color};
+            float* m[3] = {at.m, ad.m, ac.m}; float* v[3] = {at.v, ad.v, ac.v}; float* e[3] = {at.ema, ad.ema, ac.ema};
+            const size_t nn[3] = {(size_t)at.n, (size_t)ad.n, (size_t)ac.n};
+            rc = xr_adam_step_multi(3, p, g, m, v, (e[0] && e[1] && e[2]) ? e : nullptr, nn, at.step, at.lr, at.beta1, at.beta2, at.eps, at.weight_decay,
+                                    at.ema_momentum, 1.0f / (float)X->world_size, D.stream);
+            if (rc != XR_OK) return rc;
+            if (D.dp_mode == 1) {          // every rank's updated shard -> the full table, in place
+                if ((rc = X->all_gather(X->ctx, at.param, D.table_padded, (size_t)D.shard_floats, D.stream)) != XR_OK) return rc;
+                if ((rc = X->finish(X->ctx, D.stream)) != XR_OK) return rc;
+            }
+        }
         S.last_step_set = S.step_turn & 1u;
         S.iter = it + 1;
     }

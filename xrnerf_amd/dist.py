@@ -227,6 +227,147 @@ class Zero1GradSync:
             dist.all_gather_into_tensor(self.param_padded, self.shard_param.data)
 
 
+class CallbackExchange:
+    """xr_grad_exchange (include/xrnerf_mi355.h) served by torch.distributed through ctypes callbacks: the native loop calls back for
+    each collective (~30 us of interpreter time each instead of the ~360 us of a whole Python-driven iteration).  Any backend: this is
+    what the gloo tests use (two ranks sharing one GPU); RCCL jobs take `RcclExchange`, which never enters the interpreter.
+    Buffers are found by address among the registered base tensors (the native loop hands slices of them)."""
+
+    def __init__(self, world_size, rank):
+        import ctypes as C
+        from . import _lib
+        self.world_size, self.rank = int(world_size), int(rank)
+        self._bases, self._works = [], []
+        self.exposed = _ExposedTimer()
+        self._on_device = False
+        self.error = None
+
+        def guard(fn):
+            def run(*a):
+                try:
+                    fn(*a)
+                    return 0
+                except Exception as e:      # noqa: BLE001  (an exception must not unwind through the C frames)
+                    self.error = e
+                    return -5
+            return run
+
+        def all_reduce(ctx, buf, n, stream):
+            t = self._view(buf, n)
+            self._on_device = t.is_cuda
+            self._works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
+
+        def reduce_scatter(ctx, send, recv, n_recv, stream):
+            src, dst = self._view(send, n_recv * self.world_size), self._view(recv, n_recv)
+            self._on_device = dst.is_cuda
+            if dist.get_backend() == 'gloo':                 # gloo has no reduce-scatter: all-reduce, keep this rank's shard
+                dist.all_reduce(src, op=dist.ReduceOp.SUM)
+                dst.copy_(src[self.rank * n_recv:(self.rank + 1) * n_recv])
+            else:
+                self._works.append(dist.reduce_scatter_tensor(dst, src, op=dist.ReduceOp.SUM, async_op=True))
+
+        def all_gather(ctx, send, recv, n_send, stream):
+            src, dst = self._view(send, n_send), self._view(recv, n_send * self.world_size)
+            if dist.get_backend() == 'gloo':
+                parts = [torch.empty_like(src) for _ in range(self.world_size)]
+                dist.all_gather(parts, src.contiguous())
+                for r, t in enumerate(parts):
+                    if r != self.rank:
+                        dst[r * n_send:(r + 1) * n_send].copy_(t)
+            else:
+                self._works.append(dist.all_gather_into_tensor(dst, src, async_op=True))
+
+        def finish(ctx, stream):
+            tok = self.exposed.begin(self._on_device) if self._works else None
+            for w in self._works:
+                w.wait()
+            self.exposed.end(tok)
+            self._works = []
+
+        self._cbs = (_lib.EX_ALL_REDUCE(guard(all_reduce)), _lib.EX_SCATTER_GATHER(guard(reduce_scatter)),
+                     _lib.EX_SCATTER_GATHER(guard(all_gather)), _lib.EX_FINISH(guard(finish)))
+        self.c = _lib.GradExchange(self._cbs[0], self._cbs[1], self._cbs[2], self._cbs[3], None, self.world_size, self.rank)
+
+    def register(self, *tensors):
+        """base tensors the loop's buckets are slices of (kept alive here)"""
+        for t in tensors:
+            if t is not None and not any(b.data_ptr() == t.data_ptr() and b.numel() >= t.numel() for b in self._bases):
+                self._bases.append(t.detach().reshape(-1) if t.is_contiguous() else t)
+
+    def _view(self, ptr, n):
+        ptr, n = int(ptr), int(n)
+        for b in self._bases:
+            off = ptr - b.data_ptr()
+            if 0 <= off and off + 4 * n <= 4 * b.numel() and off % 4 == 0:
+                return b[off // 4:off // 4 + n]
+        raise RuntimeError('the native loop handed the exchange a buffer that was not registered (%#x, %d floats)' % (ptr, n))
+
+
+class RcclExchange:
+    """xr_grad_exchange served by RCCL driven from native code (csrc/xr_dist.hip): the communicator is created from a unique id made on
+    rank 0 and broadcast through torch.distributed's existing process group; the collectives then never enter the interpreter."""
+
+    def __init__(self, world_size, rank):
+        import ctypes as C
+        from . import _lib
+        L = _lib.load()
+        self.world_size, self.rank = int(world_size), int(rank)
+        lib = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')          # the copy torch.distributed itself uses
+        path = lib.encode() if os.path.exists(lib) else None
+        uid = (C.c_char * 128)()
+        if self.rank == 0:
+            _lib.check(L.xr_rccl_unique_id(path, uid), 'xr_rccl_unique_id')
+        box = [bytes(uid.raw) if self.rank == 0 else None]
+        if self.world_size > 1:
+            dist.broadcast_object_list(box, src=0)
+        uid = (C.c_char * 128).from_buffer_copy(box[0])
+        self.h = L.xr_rccl_create(path, uid, self.world_size, self.rank)
+        if not self.h:
+            raise _lib.XrError('xr_rccl_create failed: %s' % L.xr_last_error().decode())
+        self.c = _lib.GradExchange()
+        _lib.check(L.xr_rccl_exchange(self.h, C.byref(self.c)), 'xr_rccl_exchange')
+        self.exposed = self                         # (same two calls as _ExposedTimer: `on`, `summary()`; measured in native code)
+        self._on = False
+
+    def register(self, *tensors):
+        pass
+
+    error = None
+
+    @property
+    def on(self):
+        return self._on
+
+    @on.setter
+    def on(self, v):
+        from . import _lib
+        self._on = bool(v)
+        _lib.check(_lib.load().xr_rccl_timing(self.h, 1 if v else 0), 'xr_rccl_timing')
+
+    def summary(self):
+        """-> {'steps', 'mean_ms', 'max_ms'} of the waits the compute stream spent in `finish` (call after a device synchronisation)"""
+        import ctypes as C
+        from . import _lib
+        mean, mx, n = C.c_float(), C.c_float(), C.c_int()
+        _lib.check(_lib.load().xr_rccl_exposed_ms(self.h, C.byref(mean), C.byref(mx), C.byref(n)), 'xr_rccl_exposed_ms')
+        return {'steps': int(n.value), 'mean_ms': float(mean.value) if n.value else None, 'max_ms': float(mx.value) if n.value else None}
+
+    def __del__(self):
+        try:
+            from . import _lib
+            _lib.load().xr_rccl_destroy(self.h)
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
+def native_exchange(world_size, rank):
+    """the exchange implementation of the native loop for this job: RCCL from native code under backend 'nccl'
+    (XRNERF_NATIVE_RCCL=0: callbacks into torch.distributed instead), callbacks otherwise"""
+    if dist.get_backend() == 'nccl' and os.environ.get('XRNERF_NATIVE_RCCL', '1') != '0':
+        return RcclExchange(world_size, rank)
+    return CallbackExchange(world_size, rank)
+
+
 def comm_model(world_size, table_floats=12196240, mlp_floats=10240, link_GBs=153.0, links=7, step_ms=0.50, wire_bytes_per_float=4.0):
     """what one training step puts on xGMI, and what it costs under two schedules (one-GPU boxes only: nothing here is measured).
     xGMI is point-to-point, 7 links x ~153 GB/s per GPU.

@@ -305,12 +305,16 @@ class Trainer:
             from .renders import HashNerfRender
             from .samplers import NGPGridSampler
             net = self.net
+            one_gpu = self.world_size == 1 and self.fuse_adam and self.direct_step
+            # data parallel: the loop hands the gradient buckets to an exchange (dist.native_exchange) and runs ONE optimiser launch on the
+            # summed gradients per iteration -- fp32 on the wire (allreduce, zero1); the bf16 wire format keeps the per-iteration path
+            dp = self.world_size > 1 and self.dp_mode in ('allreduce', 'zero1') and getattr(net, 'grad_sync', None) is not None
             st = self._native_static = bool(
-                self.native_loop and self.world_size == 1 and self.fuse_adam and self.direct_step and self.march_window != 'off' and
+                self.native_loop and (one_gpu or dp) and self.march_window != 'off' and
                 self.device.type == 'cuda' and self._window_ok() and type(net.sampler) is NGPGridSampler and type(net.mlp) is HashNerfMLP and
                 type(net.render) is HashNerfRender and (net.mlp.density_net.n_hidden, net.mlp.color_net.n_hidden) in ops._FUSED_BWD and
                 isinstance(self.opt, FusedAdam))
-        if not st or getattr(self.net, 'grad_sync', None) is not None:
+        if not st or (self.world_size == 1 and getattr(self.net, 'grad_sync', None) is not None):
             return False
         if switches.step_mode() != 'fused':
             return False
@@ -462,13 +466,16 @@ class _NativeLoop:
         self.state = _lib.LoopState()
         self.enqueue_s, self.enqueued = 0.0, 0
         self._keep = None
+        self.exchange = None               # data parallel: dist.native_exchange, created with the first descriptor
 
     # ------------------------------------------------------------------ counters shared with the per-iteration path
     def _adam_states(self):
         tr = self.tr
         mlp = tr.net.mlp
         out = []
-        for p in (mlp.embedder_pos.params, mlp.density_net.params, mlp.color_net.params):
+        sync = getattr(tr.net, 'grad_sync', None)
+        first = sync.shard_param if hasattr(sync, 'shard_param') else mlp.embedder_pos.params     # zero1: the optimiser owns this rank's shard
+        for p in (first, mlp.density_net.params, mlp.color_net.params):
             grp = [g for g in tr.opt.param_groups if any(q is p for q in g['params'])]
             if not grp:
                 raise _lib.XrError('the native loop needs the three NGP tensors in the trainer\'s FusedAdam')
@@ -492,10 +499,26 @@ class _NativeLoop:
         D.n_hidden_density, D.n_hidden_color, D.pad_value, D.mlp_mode = nhd, nhc, float(mlp.pad_value), ops._mlp_mode(nhd, nhc)
         s_, r_, o_ = meta._args()
         D.n_levels, D.scale_host, D.resolution_host, D.offset_host = meta.n_levels, s_, r_, o_
-        for name, p, st in zip(('adam_table', 'adam_w_density', 'adam_w_color'), (table, wd, wc), states):
+        sync = getattr(net, 'grad_sync', None)
+        zero1 = hasattr(sync, 'shard_param')
+        for name, p, st in zip(('adam_table', 'adam_w_density', 'adam_w_color'), (sync.shard_param if zero1 else table, wd, wc), states):
             ema = st.get('ema') if g['ema_momentum'] is not None else None
             a = ops.adam_fuse(p.data, st['m'], st['v'], ema, 0, 0.0, g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], 0.0, 1.0)
             setattr(D, name, a)
+        if sync is not None:
+            from . import dist as xdist
+            if self.exchange is None:
+                self.exchange = xdist.native_exchange(tr.world_size, tr.rank)
+            ex = self.exchange
+            ex.register(*[b.zero_block for b in sets])
+            D.exchange = C.pointer(ex.c)
+            D.dp_mode = 1 if zero1 else 0
+            D.split_level = meta.n_levels - 8 if (not zero1 and meta.n_levels > 8 and getattr(sync, 'split_levels', True)) else 0
+            if zero1:
+                D.shard_grad, D.table_padded, D.shard_floats = vp(sync.shard_grad), vp(sync.param_padded), sync.shard
+                ex.register(sync.shard_grad, sync.param_padded, *[sync._padded_of(b.g_table) for b in sets])
+            else:
+                ex.register(*[b.g_table for b in sets])
         D.density_grid_mean = vp(sampler.density_grid_mean)
         D.rgb_activation, D.density_activation, D.huber_delta, D.loss_scale = int(sampler.rgb_activation), int(sampler.density_activation), 0.1, 5.0
         D.n_rows, D.ld = n_rows, sets[0].ld
@@ -505,6 +528,7 @@ class _NativeLoop:
             B.enc_t, B.raw, B.draw, B.denc_t, B.rgb_out, B.zero_block = vp(b.enc_t), vp(b.raw), vp(b.draw), vp(b.denc_t), vp(b.rgb), vp(b.zero_block)
             B.zero_floats = b.zero_block.numel()
             B.grad_w_density, B.grad_w_color, B.loss_mse, B.live_seg_count = vp(b.g_wd), vp(b.g_wc), vp(b.loss_mse), vp(b.live_seg)
+            B.grad_table = vp(b.g_table) if sync is not None else None
         ws_mlp, live_list, _, live_stats = ops._list_slots(dev, n_rows, nhd, nhc)
         ws_sc = ops._ws(dev, L.xr_hashgrid_bwd_workspace_bytes(n_rows, meta.n_levels, r_, o_), 'hgb')
         D.ws_mlp_bwd, D.ws_mlp_bwd_bytes = vp(ws_mlp), ws_mlp.numel()
@@ -533,8 +557,8 @@ class _NativeLoop:
         sets = getattr(net, '_step_bufs', None)
         if (sets is None or sets[0].n_rows != n_rows or sets[0].ray_cap < n_rays or sets[0].g_table.shape != table.shape
                 or sets[0].g_table.device != table.device):
-            sets = net._step_bufs = [ops.TrainStepBuffers(dev, n_rows, max(n_rays, 1 << 15), table.numel(), wd.numel(), wc.numel(), meta)
-                                     for _ in range(2)]
+            sets = net._step_bufs = [ops.TrainStepBuffers(dev, n_rows, max(n_rays, 1 << 15), table.numel(), wd.numel(), wc.numel(), meta,
+                                                          getattr(getattr(net, 'grad_sync', None), 'pad_grad', None)) for _ in range(2)]
             net._step_turn = 0
         states = self._adam_states()
         g = self._group
@@ -549,6 +573,7 @@ class _NativeLoop:
         key = (n_rows, dp(win.coords), dp(win.rays_o), dp(win.xyz), win.ray_stride, win.coords_stride,
                tuple(dp(b.enc_t) + dp(b.zero_block) + dp(b.rgb) for b in sets), dp(table), dp(wd), dp(wc),
                dp(sampler.density_grid_mean), ops._mlp_mode(mlp.density_net.n_hidden, mlp.color_net.n_hidden), ops._stream().value,
+               tuple(dp(b.g_table) for b in sets), id(getattr(net, 'grad_sync', None)),
                tuple(dp(st['m']) + dp(st['v']) + dp(st.get('ema')) for st in states),
                dp(ops._workspaces.get((str(dev), 'mlpbwd'))), dp(ops._workspaces.get((str(dev), 'hgb'))))
         if self._keep is not None and self._keep[0] == key:
@@ -577,6 +602,9 @@ class _NativeLoop:
         self.enqueue_s += time.perf_counter() - t_enq                    # host time inside the native call (tools/hosttime2.py)
         self.enqueued += k
         if rc != 0:
+            if self.exchange is not None and self.exchange.error is not None:
+                err, self.exchange.error = self.exchange.error, None
+                raise err
             _lib.check(rc, 'xr_ngp_loop_run')
         if stage is not None:
             ops.TIMER.events.setdefault(stage, []).extend((tev[2 * j], tev[2 * j + 1], 0) for j in range(k))
@@ -604,6 +632,8 @@ class _NativeLoop:
         data.set_batchsize(sampler.n_rays_per_batch)                      # ModifyBatchsizeHook
         from .networks import _LazyPsnr
         loss = b.loss_mse[0:1].reshape(())
+        for p_ in tr._opt_params:
+            p_.grad = None                  # (the summed gradients were consumed by the loop's own optimiser launches)
         return {'loss': loss, 'log_vars': {'loss': loss, 'psnr': _LazyPsnr(b.loss_mse, n_rays)}, 'num_samples': n_rays,
                 'grads_ready': True, 'updates_applied': True}
 
