@@ -321,3 +321,61 @@ def test_bf16_gradient_exchange_two_ranks(tmp_path):
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all('ok' in o for o in outs)
+
+
+EXCHANGE_WORKER = r'''
+import ctypes as C, os, sys, torch
+sys.path.insert(0, %r)
+import torch.distributed as dist
+from xrnerf_amd import dist as xd
+rank, local, world = xd.init_from_env('gloo')
+ex = xd.native_exchange(world, rank)
+assert type(ex).__name__ == 'CallbackExchange' and ex.c.world_size == 2 and ex.c.rank == rank
+shard = 1000
+grad = torch.arange(2 * shard, dtype=torch.float32) * (rank + 1)              # a padded table gradient: world * shard floats
+mlp = torch.full((64,), float(rank + 1))
+shard_grad = torch.zeros(shard)
+padded = torch.zeros(2 * shard)
+ex.register(grad, mlp, shard_grad, padded)
+ex.exposed.on = True
+f = ex.c
+# all-reduce of a SLICE of a registered buffer (the loop hands over the fine / coarse halves of the table gradient), and of the MLP bucket
+assert f.all_reduce(f.ctx, grad.data_ptr() + 4 * 500, 1500, None) == 0
+assert f.all_reduce(f.ctx, mlp.data_ptr(), 64, None) == 0
+assert f.finish(f.ctx, None) == 0
+ref = torch.arange(2 * shard, dtype=torch.float32)
+assert torch.equal(grad[500:], 3 * ref[500:]) and torch.equal(grad[:500], (rank + 1) * ref[:500]) and torch.equal(mlp, torch.full((64,), 3.0))
+# zero1: reduce-scatter of the padded gradient into this rank's shard, all-gather of the updated shards in place
+g2 = ref * (rank + 1)
+ex.register(g2)
+assert f.reduce_scatter(f.ctx, g2.data_ptr(), shard_grad.data_ptr(), shard, None) == 0 and f.finish(f.ctx, None) == 0
+assert torch.equal(shard_grad, 3 * ref[rank * shard:(rank + 1) * shard])
+padded[rank * shard:(rank + 1) * shard] = 10.0 + rank
+assert f.all_gather(f.ctx, padded.data_ptr() + 4 * rank * shard, padded.data_ptr(), shard, None) == 0 and f.finish(f.ctx, None) == 0
+assert torch.equal(padded[:shard], torch.full((shard,), 10.0)) and torch.equal(padded[shard:], torch.full((shard,), 11.0))
+# a buffer nobody registered is an error carried back through the C frames, not a crash
+stray = torch.zeros(8)
+assert f.all_reduce(f.ctx, stray.data_ptr(), 8, None) != 0 and 'not registered' in str(ex.error)
+s = ex.exposed.summary()
+assert s['steps'] >= 1
+dist.barrier(); dist.destroy_process_group()
+print('ok')
+'''
+
+
+def test_gradient_exchange_hooks_two_ranks(tmp_path):
+    """dist.CallbackExchange -- the xr_grad_exchange the native loop gets where RCCL is not driven from native code -- on two gloo ranks
+    (host tensors): all-reduce of slices of registered buffers, the zero1 reduce-scatter / all-gather pair, the exposure record, and an
+    unregistered buffer reported as an error code with the exception kept."""
+    import socket
+    script = tmp_path / 'ex.py'
+    script.write_text(EXCHANGE_WORKER % ROOT)
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE='2')
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all('ok' in o for o in outs)
