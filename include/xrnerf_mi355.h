@@ -58,31 +58,22 @@ void xr_pcg32_host_state(uint64_t seed, uint64_t ncalls, uint64_t* state_host, u
  *      (metadata / img_ids / xforms of the reference are loaded-but-dead there, :34-38)
  * out: coords_out [max_samples,7] f32 rows {pos3, warped dt, warped dir3}; rays_index [n_rays]
  *      i32; rays_numsteps [n_rays,2] i32 = (n, base); counter2 [2] u32 = (rays, samples).
- * counter2 is zeroed by this call.  workspace: xr_rays_sampler_workspace_bytes(n_rays). */
-size_t xr_rays_sampler_workspace_bytes(uint32_t n_rays);
+ * counter2 is zeroed by this call.  workspace: xr_rays_sampler_workspace_bytes(n_rays, 1). */
+size_t xr_rays_sampler_workspace_bytes(uint32_t n_rays, uint32_t n_series /* 1: a single launch */);
+/* xyz_planes (nullable): the three position columns of coords_out once more as planes of plane_stride (>= max_samples) floats each --
+ * what xr_hashgrid_fwd reads with coalesced loads.
+ * rng_chunk (0 = off): ray i draws its jitter as ray i % rng_chunk of launch number i / rng_chunk of a series of launches over
+ * rng_chunk rays each, starting at (rng_state, rng_inc) -- a frame that the reference marches in `chunk`-sized launches
+ * (networks/nerf.py:50-69; the hidden generator advances by 2^32 per launch, ray_sampler.cu:198) in ONE launch, same samples.
+ * rng_ray0 (used with rng_chunk > 0): the launch's ray i is ray rng_ray0 + i of the frame that series of launches covers -- a
+ * rank that renders a band of image rows draws exactly the jitter the whole-frame loop would give those rays (image-space sharding
+ * of validation frames: pixels independent of the world size).
+ * (xr_version 120 retired the two earlier generations of this entry point: the form without planes and the `2` form; this is the former xr_rays_sampler3.) */
 int xr_rays_sampler(const float* rays_o, const float* rays_d, const uint8_t* bitfield, uint32_t n_rays,
                     float aabb0, float aabb1, float near_distance, float cone_angle, uint32_t max_samples,
                     uint64_t rng_state, uint64_t rng_inc, float* coords_out, int32_t* rays_index,
-                    int32_t* rays_numsteps, uint32_t* counter2, void* workspace, size_t workspace_bytes,
-                    void* stream);
-/* the same; xyz_planes (nullable): the three position columns of coords_out once more as planes of plane_stride
- * (>= max_samples) floats each -- what xr_hashgrid_fwd2 reads with coalesced loads.
- * rng_chunk (0 = off): ray i draws its jitter as ray i % rng_chunk of launch number i / rng_chunk of a series of launches over
- * rng_chunk rays each, starting at (rng_state, rng_inc) -- a frame that the reference marches in `chunk`-sized launches
- * (networks/nerf.py:50-69; the hidden generator advances by 2^32 per launch, ray_sampler.cu:198) in ONE launch, same samples */
-int xr_rays_sampler2(const float* rays_o, const float* rays_d, const uint8_t* bitfield, uint32_t n_rays,
-                     float aabb0, float aabb1, float near_distance, float cone_angle, uint32_t max_samples,
-                     uint64_t rng_state, uint64_t rng_inc, float* coords_out, int32_t* rays_index,
-                     int32_t* rays_numsteps, uint32_t* counter2, float* xyz_planes, uint32_t plane_stride,
-                     uint32_t rng_chunk, void* workspace, size_t workspace_bytes, void* stream);
-/* the same; rng_ray0 (used with rng_chunk > 0): the launch's ray i is ray rng_ray0 + i of the frame that series of launches covers -- a
- * rank that renders a band of image rows draws exactly the jitter the whole-frame loop would give those rays (image-space sharding
- * of validation frames: pixels independent of the world size) */
-int xr_rays_sampler3(const float* rays_o, const float* rays_d, const uint8_t* bitfield, uint32_t n_rays,
-                     float aabb0, float aabb1, float near_distance, float cone_angle, uint32_t max_samples,
-                     uint64_t rng_state, uint64_t rng_inc, float* coords_out, int32_t* rays_index,
-                     int32_t* rays_numsteps, uint32_t* counter2, float* xyz_planes, uint32_t plane_stride,
-                     uint32_t rng_chunk, uint32_t rng_ray0, uint32_t flags, void* workspace, size_t workspace_bytes, void* stream);
+                    int32_t* rays_numsteps, uint32_t* counter2, float* xyz_planes, uint32_t plane_stride,
+                    uint32_t rng_chunk, uint32_t rng_ray0, uint32_t flags, void* workspace, size_t workspace_bytes, void* stream);
 /* flags: XR_K1_WIDE = nothing else is running on the device (the march in place at a grid refresh): launches of up to 32 768 rays
  * use 8 lanes per ray (same samples bit for bit, a shorter critical path, 8x the waves) */
 #define XR_K1_WIDE 1u
@@ -90,8 +81,8 @@ int xr_rays_sampler3(const float* rays_o, const float* rays_d, const uint8_t* bi
  * c * ray_stride, draws the jitter of the hidden generator's call (first + c) -- (rng_state, rng_inc) = the state of call `first`; the
  * generator moves on by 2^32 per launch, ray_sampler.cu:198 -- and writes coords_out + 7 * c * coords_stride, rays_index / rays_numsteps at
  * row c * ray_stride, counter2 + 2 * c and the three planes at xyz_planes + 3 * c * plane_stride: bit for bit what n_series calls of
- * xr_rays_sampler2 write.  Launches of more than 65 536 rays are enqueued one after the other. */
-size_t xr_rays_sampler_series_workspace_bytes(uint32_t n_rays, uint32_t n_series);
+ * xr_rays_sampler write.  Launches of more than 65 536 rays are enqueued one after the other.
+ * workspace: xr_rays_sampler_workspace_bytes(n_rays, n_series). */
 int xr_rays_sampler_series(const float* rays_o, const float* rays_d, uint32_t ray_stride, const uint8_t* bitfield, uint32_t n_rays,
                            uint32_t n_series, float aabb0, float aabb1, float near_distance, float cone_angle, uint32_t max_samples,
                            uint64_t rng_state, uint64_t rng_inc, float* coords_out, size_t coords_stride, int32_t* rays_index,
@@ -112,16 +103,11 @@ int xr_compacted_coord(const float* coords_in, const int32_t* numsteps_in, uint3
 /* K2 when K1's ray-ordered output is kept in place (no overflow): the compacted coordinates ARE the
  * first min(total, max_compacted) rows of K1's buffer, so only the clipped per-ray counts are
  * needed: numsteps_out[i] = (min(max_compacted - min(max_compacted, base), n), base)
- * (compacted_coord.cu:63-66).  n_valid_dev[0] = min(counter2[1], max_compacted) (device); when n_chunks > 0,
- * n_valid_dev[1+c] = number of valid rows inside row chunk c of chunk_rows rows (for launching the per-sample
- * kernels chunk by chunk on two streams without a host read-back). */
-int xr_clip_numsteps(const int32_t* numsteps_in, const uint32_t* counter2, uint32_t n_rays, uint32_t max_compacted,
-                     int32_t* numsteps_out, uint32_t* n_valid_dev /*[1+n_chunks]*/, uint32_t chunk_rows,
-                     uint32_t n_chunks, void* stream);
-/* ... for the n_series launches of xr_rays_sampler_series in one launch: numsteps arrays with ray_stride rows per launch, counter2
- * [n_series][2], n_valid_dev [n_series][2] (both words = the launch's valid row count) */
-int xr_clip_numsteps_series(const int32_t* numsteps_in, const uint32_t* counter2, uint32_t n_rays, uint32_t n_series, uint32_t ray_stride,
-                            uint32_t max_compacted, int32_t* numsteps_out, uint32_t* n_valid_dev, void* stream);
+ * (compacted_coord.cu:63-66), and the device-side count of valid rows n_valid_dev[0] = n_valid_dev[1] = min(counter2[1], max_compacted).
+ * For the n_series launches of xr_rays_sampler_series in one launch: numsteps arrays with ray_stride rows per launch, counter2 and
+ * n_valid_dev [n_series][2]; a single launch: n_series = 1, ray_stride = n_rays. */
+int xr_clip_numsteps(const int32_t* numsteps_in, const uint32_t* counter2, uint32_t n_rays, uint32_t n_series, uint32_t ray_stride,
+                     uint32_t max_compacted, int32_t* numsteps_out, uint32_t* n_valid_dev, void* stream);
 
 /* K3  calc_rgb_forward_api (src/calc_rgb.cu:208-264, kernel :6-67) */
 int xr_calc_rgb_forward(const float* network_output /*[S,4]*/, const float* coords /*[S,7]*/,
@@ -137,27 +123,20 @@ int xr_calc_rgb_backward(const float* network_output, const int32_t* rays_numste
                          int rgb_activation, int density_activation, float* dloss_doutput /*[S,4]*/,
                          void* stream);
 
-/* K3 + scale * HuberLoss(delta, sum) with its gradient + the alpha-masked squared error + K4 in ONE launch (the training
- * step's compositor sequence, networks/hashnerf.py:32-44 around renders/hashnerf_render.py:60-135): rgb_output [n_rays,3]
- * and dloss_doutput [S,4] are exactly what xr_calc_rgb_forward / xr_calc_rgb_backward produce; loss_mse_out[2] is ADDED
- * to (caller zero-fills): [0] += scale * sum huber, [1] += sum ((rgb - target) * alpha)^2.  Rows of dloss_doutput behind
- * the last sample are not written (caller zero-fills). */
+/* K3 + scale * HuberLoss(delta, sum) with its gradient + K4 in ONE launch (the training step's compositor sequence,
+ * networks/hashnerf.py:32-44 around renders/hashnerf_render.py:60-135): rgb_output [n_rays,3] and dloss_doutput [S,4] are what
+ * xr_calc_rgb_forward / xr_calc_rgb_backward produce.  Rows of dloss_doutput behind the last sample are not written.
+ * live_seg_count (nullable; xr_live_rows_segments(S) words the caller zero-fills) gets, per segment of 1024 rows of dloss_doutput,
+ * the number of rows that are not exactly zero ADDED -- the counting pass of xr_live_rows (follow with seg_counts_ready = 1).
+ * loss_mse_out (nullable): without it the launch is the wave-per-ray kernel and the two loss scalars are left to
+ * xr_train_loss_scalars; with it (caller zero-fills) the 16-lanes-per-ray kernel, which also ADDS [0] += scale * sum huber,
+ * [1] += sum ((rgb - target) * alpha)^2 -- the two kernels' rgb_output / dloss_doutput differ like two fp32 summation orders.
+ * (xr_version 120: this is the former `...train2`; the form without live_seg_count is retired.) */
 int xr_composite_train(const float* network_output, const float* coords, const int32_t* rays_numsteps,
                        const int32_t* rays_numsteps_compacted, const float* bg_color, const float* target,
                        const float* alpha_mask, const float* density_grid_mean, uint32_t n_rays, int rgb_activation,
                        int density_activation, float delta, float scale, float* rgb_output, float* loss_mse_out,
-                       float* dloss_doutput, void* stream);
-/* the same work, which can also count the live rows it writes: live_seg_count (nullable; xr_live_rows_segments(S) words the
- * caller zero-fills) gets, per segment of 1024 rows of dloss_doutput, the number of rows that are not exactly zero ADDED --
- * the counting pass of xr_live_rows; follow with xr_live_rows2(..., seg_counts_ready = 1).
- * loss_mse_out is nullable here: without it the launch is the wave-per-ray kernel (64 chunks per ray instead of 16: rgb_output
- * and dloss_doutput differ from xr_composite_train's like two fp32 summation orders) and the two loss scalars are left to
- * xr_train_loss_scalars. */
-int xr_composite_train2(const float* network_output, const float* coords, const int32_t* rays_numsteps,
-                        const int32_t* rays_numsteps_compacted, const float* bg_color, const float* target,
-                        const float* alpha_mask, const float* density_grid_mean, uint32_t n_rays, int rgb_activation,
-                        int density_activation, float delta, float scale, float* rgb_output, float* loss_mse_out,
-                        float* dloss_doutput, uint32_t* live_seg_count, void* stream);
+                       float* dloss_doutput, uint32_t* live_seg_count, void* stream);
 /* loss_mse_out[0] = scale * sum HuberLoss(rgb - target), [1] = sum ((rgb - target) * alpha)^2 (utils/metrics.py:8-16,
  * networks/hashnerf.py:36-44), WRITTEN, one workgroup's fixed-order sum: bit-reproducible run to run */
 int xr_train_loss_scalars(const float* rgb, const float* target, const float* alpha_mask, uint32_t n_rays, float delta,
@@ -183,17 +162,13 @@ int xr_render_slice_composite(const float* raw_slice /*[count,4]*/, const float*
                               const int32_t* ray_offset, uint32_t n_rays, uint32_t s0, uint32_t s1, int rgb_activation,
                               int density_activation, float* T, float* rgb_acc, void* stream);
 
-/* K6  generate_grid_samples_nerf_nonuniform_api (src/generate_grid_samples_nerf_nonuniform.cu:44-87) */
-int xr_generate_grid_samples(const float* density_grid, uint32_t ema_step, uint32_t n_elements,
-                             uint32_t n_cascades /* = max_cascade+1 */, float thresh, float aabb0, float aabb1,
-                             uint64_t rng_state, uint64_t rng_inc, float* positions /*[n,3]*/,
-                             int32_t* indices /*[n]*/, void* stream);
-/* the same with strides on the positions: coordinate d of point i goes to positions[i * pos_row_stride + d * pos_comp_stride]
- * ((3, 1): the rows above; (1, plane size): three planes, the layout xr_hashgrid_fwd2 reads with coalesced loads -- the sampler
- * writes both K6 calls of a grid refresh into one plane buffer and queries the density without a concatenation) */
-int xr_generate_grid_samples2(const float* density_grid, uint32_t ema_step, uint32_t n_elements, uint32_t n_cascades,
-                              float thresh, float aabb0, float aabb1, uint64_t rng_state, uint64_t rng_inc,
-                              float* positions, uint32_t pos_row_stride, uint32_t pos_comp_stride, int32_t* indices, void* stream);
+/* K6  generate_grid_samples_nerf_nonuniform_api (src/generate_grid_samples_nerf_nonuniform.cu:44-87).  Coordinate d of point i goes
+ * to positions[i * pos_row_stride + d * pos_comp_stride]: (3, 1) = the reference's [n,3] rows; (1, plane size) = three planes, the
+ * layout xr_hashgrid_fwd reads with coalesced loads -- the sampler writes both K6 calls of a grid refresh into one plane buffer and
+ * queries the density without a concatenation.  (xr_version 120: the former xr_generate_grid_samples2.) */
+int xr_generate_grid_samples(const float* density_grid, uint32_t ema_step, uint32_t n_elements, uint32_t n_cascades /* = max_cascade+1 */,
+                             float thresh, float aabb0, float aabb1, uint64_t rng_state, uint64_t rng_inc,
+                             float* positions, uint32_t pos_row_stride, uint32_t pos_comp_stride, int32_t* indices /*[n]*/, void* stream);
 /* K7  mark_untrained_density_grid_api (src/mark_untrained_density_grid.cu:54-82): writes 0 where
  * the cell is visible from any training camera, -1 elsewhere (the reference leaves visible cells of
  * its UNINITIALISED buffer untouched when they happen to be >= 0) */
@@ -231,17 +206,14 @@ void xr_hashgrid_meta(int n_levels, int log2_hashmap_size, int base_resolution, 
 /* `n_dev` (nullable, device): when given, only min(n, *n_dev) rows are processed -- the row count
  * then never has to be read back to the host (n is the launch-sizing upper bound). */
 /* `rows` (nullable, device): sample i reads its position from row rows[i] of x (render depth slices) */
-int xr_hashgrid_fwd(const float* table, const float* x, uint32_t x_stride, uint32_t n, const uint32_t* n_dev,
+/* Coordinate d of sample i is x[i * x_stride + d * x_comp_stride]: (7, 1) consumes K1's [S,7] coordinate rows in place, (3, 1) plain
+ * [n,3] rows; x_stride = 1 with x_comp_stride = plane size reads positions stored as three planes (structure of arrays): three
+ * coalesced dword loads per sample instead of three strided ones out of 28-byte rows.  (xr_version 120: the former `..._fwd2`.) */
+int xr_hashgrid_fwd(const float* table, const float* x, uint32_t x_stride, uint32_t x_comp_stride, uint32_t n, const uint32_t* n_dev,
                     const uint32_t* rows, int n_levels, const float* scale_host, const uint32_t* resolution_host,
                     const uint32_t* offset_host, float* enc_t, uint32_t ld, void* stream);
-/* the same with a component stride: coordinate d of sample i is x[i * x_stride + d * x_comp_stride].  x_comp_stride = 1 is the
- * call above; x_stride = 1 with x_comp_stride = plane size reads positions stored as three planes (structure of arrays):
- * three coalesced dword loads per sample instead of three strided ones out of 28-byte rows. */
-int xr_hashgrid_fwd2(const float* table, const float* x, uint32_t x_stride, uint32_t x_comp_stride, uint32_t n, const uint32_t* n_dev,
-                     const uint32_t* rows, int n_levels, const float* scale_host, const uint32_t* resolution_host,
-                     const uint32_t* offset_host, float* enc_t, uint32_t ld, void* stream);
 /* Backward of the encoding above (tcnn's kernel_grid_backward as reached from hashnerf_mlp.py:59-61 under autograd):
- * grad_table[idx,f] += w * denc_t[2l+f][i]; the caller zero-fills grad_table (xr_hashgrid_bwd2 + XR_SCATTER_OVERWRITE: no).
+ * grad_table[idx,f] += w * denc_t[2l+f][i]; the caller zero-fills grad_table (with XR_SCATTER_OVERWRITE: no).
  * workspace (nullable; xr_hashgrid_bwd_workspace_bytes(n, n_levels, resolution_host, offset_host), 16-byte
  * aligned): with it and n >= 16384 NO level touches the table with an atomic -- hashed levels and the larger dense levels
  * are binned by table partition (16-byte items in workgroup-private sub-bins, overflow lists for clustered inputs) and
@@ -253,19 +225,15 @@ int xr_hashgrid_fwd2(const float* table, const float* x, uint32_t x_stride, uint
 size_t xr_hashgrid_bwd_workspace_bytes(uint32_t n, int n_levels, const uint32_t* resolution_host,
                                        const uint32_t* offset_host);
 /* rows (nullable, with n_dev): launch sample j is row rows[j] of x / denc_t and *n_dev the list's length -- the live-row
- * list of xr_live_rows, so that the scatter never touches the rows whose gradient is exactly zero. */
+ * list of xr_live_rows, so that the scatter never touches the rows whose gradient is exactly zero.
+ * flags: 0 = grad_table is ADDED to (caller zero-fills); XR_SCATTER_OVERWRITE: the table slices of the call's levels are WRITTEN
+ * (grad = scatter result) -- the caller needs no zero-fill (the training step saves a 48.8-MB one); with n == 0 the slices are
+ * zero-filled.  (xr_version 120: the former `..._bwd2`.) */
+#define XR_SCATTER_OVERWRITE 1
 int xr_hashgrid_bwd(const float* x, uint32_t x_stride, const float* denc_t, uint32_t ld, uint32_t n,
                     const uint32_t* n_dev, const uint32_t* rows, int n_levels, const float* scale_host, const uint32_t* resolution_host,
-                    const uint32_t* offset_host, float* grad_table, void* workspace, size_t workspace_bytes,
+                    const uint32_t* offset_host, float* grad_table, void* workspace, size_t workspace_bytes, int flags,
                     void* stream);
-/* the same with flags.  XR_SCATTER_OVERWRITE: the table slices of the call's levels are WRITTEN (grad = scatter result)
- * instead of added to -- the caller needs no zero-fill (the training step saves a 48.8-MB one); with n == 0 the slices
- * are zero-filled. */
-#define XR_SCATTER_OVERWRITE 1
-int xr_hashgrid_bwd2(const float* x, uint32_t x_stride, const float* denc_t, uint32_t ld, uint32_t n,
-                     const uint32_t* n_dev, const uint32_t* rows, int n_levels, const float* scale_host, const uint32_t* resolution_host,
-                     const uint32_t* offset_host, float* grad_table, void* workspace, size_t workspace_bytes, int flags,
-                     void* stream);
 /* tcnn.Encoding otype=SphericalHarmonics degree 4; dirs in [0,1] (the sampler's warp_direction);
  * out row-major [n,16] */
 int xr_sh4(const float* dirs, uint32_t dir_stride, uint32_t n, float* out, void* stream);
@@ -286,13 +254,11 @@ int xr_nerf_mlp_fwd(const float* enc_t, uint32_t ld, const float* dirs, uint32_t
 /* backward of the above given dL/draw [n,4]: writes denc_t [32][ld] (for xr_hashgrid_bwd) and
  * ACCUMULATES weight gradients into grad_w_density / grad_w_color (caller zero-fills).
  * Activations are recomputed in-kernel (nothing saved by the forward).
- * workspace: xr_nerf_mlp_bwd_workspace_bytes2(n, n_hidden_density, n_hidden_color) -- list of live rows first (its position does
- * not depend on the depths), then the per-workgroup weight-gradient partials, then (streamed depths) the activation scratch area;
- * xr_nerf_mlp_bwd_workspace_bytes(n) = the (1, 2) size.
+ * workspace: xr_nerf_mlp_bwd_workspace_bytes(n, n_hidden_density, n_hidden_color) -- list of live rows first (its position does
+ * not depend on the depths), then the per-workgroup weight-gradient partials, then (streamed depths) the activation scratch area.
  * Streamed depths (anything but (1, 2)): the forward is recomputed with the forward's own arithmetic (3-way split: the same ReLU
  * decisions bit for bit), the gradient chain and the weight-gradient products on 2-way split operands like the default below. */
-size_t xr_nerf_mlp_bwd_workspace_bytes(uint32_t n);
-size_t xr_nerf_mlp_bwd_workspace_bytes2(uint32_t n, int n_hidden_density, int n_hidden_color);
+size_t xr_nerf_mlp_bwd_workspace_bytes(uint32_t n, int n_hidden_density, int n_hidden_color);
 /* live_rows / n_live (both or neither): the list xr_live_rows built from `draw`.  The backward then computes exactly the
  * listed rows and leaves the other rows of denc_t UNTOUCHED (pass the same list to xr_hashgrid_bwd).  Without a list
  * the call builds its own in the workspace and writes exact zeros to the dead rows of denc_t (same results as the
@@ -318,15 +284,13 @@ size_t xr_live_rows_segments(uint32_t n);
 /* the list area inside an xr_nerf_mlp_bwd workspace of n rows (unused by a backward that is handed a list) */
 int xr_nerf_mlp_bwd_list_slots(void* workspace, size_t workspace_bytes, uint32_t n, uint32_t** live_rows, uint32_t** seg_count,
                                uint32_t** n_live);
+/* seg_counts_ready != 0: seg_count already holds the per-segment counts (xr_composite_train counted them): the ranking pass only */
 int xr_live_rows(const float* dloss_doutput, uint32_t n, const uint32_t* n_dev, uint32_t* seg_count, uint32_t* live_rows,
-                 uint32_t* n_live, float* zero_denc_t, uint32_t ld, void* stream);
-/* seg_counts_ready != 0: seg_count already holds the per-segment counts (xr_composite_train2): the ranking pass only */
-int xr_live_rows2(const float* dloss_doutput, uint32_t n, const uint32_t* n_dev, uint32_t* seg_count, uint32_t* live_rows,
-                  uint32_t* n_live, float* zero_denc_t, uint32_t ld, int seg_counts_ready, void* stream);
+                 uint32_t* n_live, float* zero_denc_t, uint32_t ld, int seg_counts_ready, void* stream);
 
 /* The table scatter with the optimiser's update applied in place of the gradient write: the scatter owns every entry of its
  * levels exactly once per launch, so it can run Adam (+ L2 weight decay, + the EMA copy) on (param, m, v, ema) where an entry's
- * gradient is complete -- same update, bit for bit, as xr_hashgrid_bwd2(XR_SCATTER_OVERWRITE) followed by xr_adam_step_multi
+ * gradient is complete -- same update, bit for bit, as xr_hashgrid_bwd(XR_SCATTER_OVERWRITE) followed by xr_adam_step_multi
  * on the table, without the 48.8-MB gradient write + read and without the separate HBM-bound launch.  No gradient is produced.
  * Single-GPU training only (a data-parallel step must reduce the gradient first).  xr_hashgrid_bwd_adam_supported: 1 when every
  * level of this geometry / row capacity has a non-atomic path (otherwise the call fails before launching anything). */
@@ -373,8 +337,8 @@ int xr_nerf_density_splat(int mlp_mode, const float* enc_t, uint32_t ld, uint32_
                           int n_hidden_color, const int32_t* indices, float* density_grid_tmp, void* stream);
 
 /* One training step's device work of HashNerfNetwork.train_step (networks/hashnerf.py:32-52, optimiser excluded) as ONE call:
- * xr_hashgrid_fwd -> xr_nerf_mlp_fwd[_f16] -> xr_composite_train2 (which counts the live rows per segment) -> xr_live_rows2 -> xr_nerf_mlp_bwd[_f16] ->
- * xr_hashgrid_bwd2(XR_SCATTER_OVERWRITE), on `stream`:
+ * xr_hashgrid_fwd -> xr_nerf_mlp_fwd[_f16] -> xr_composite_train (which counts the live rows per segment) -> xr_live_rows -> xr_nerf_mlp_bwd[_f16] ->
+ * xr_hashgrid_bwd(XR_SCATTER_OVERWRITE), on `stream`:
  * grad_table's slices of the scattered levels are WRITTEN (no zero-fill; whatever they held is gone).
  * table_adam (nullable): the scatter becomes xr_hashgrid_bwd_adam -- the table is UPDATED by this call and grad_table (then
  * nullable) is not written; single GPU, scatter_level0 == 0.
@@ -389,7 +353,7 @@ int xr_nerf_density_splat(int mlp_mode, const float* enc_t, uint32_t ld, uint32_
  * (needed only without n_dev).  mlp_mode: 0 = xr_nerf_mlp_fwd / _bwd (fp32 MFMA), 1 = the _f16 pair, 2 = xr_nerf_mlp_fwd_bf16x3
  * + xr_nerf_mlp_bwd.  scatter_level0: the step scatters hash levels [scatter_level0, n_levels) only (0 = all) -- a
  * data-parallel caller hands that slice of grad_table to its gradient collective and then scatters the coarser levels with
- * xr_hashgrid_bwd2(XR_SCATTER_OVERWRITE) on the same row list (xr_nerf_mlp_bwd_list_slots), so the exchange runs under the rest
+ * xr_hashgrid_bwd(XR_SCATTER_OVERWRITE) on the same row list (xr_nerf_mlp_bwd_list_slots), so the exchange runs under the rest
  * of the backward.
  * Same kernels and results as the separate calls -- this exists because issuing them one by
  * one from an interpreter costs as much host time as the kernels take on the device. */
@@ -404,21 +368,16 @@ int xr_ngp_train_step(const float* table, const float* w_density, const float* w
                       void* ws_mlp_bwd, size_t ws_mlp_bwd_bytes, void* ws_scatter, size_t ws_scatter_bytes, int scatter_level0,
                       const float* xyz_planes, uint32_t plane_stride, const xr_adam_fuse* table_adam, const xr_adam_fuse* w_density_adam,
                       const xr_adam_fuse* w_color_adam, const char* timed_entry, void* timing_begin, void* timing_end, void* stream);
-/* xyz_planes (nullable): the positions of `coords` once more as three planes of plane_stride floats (xr_rays_sampler2 /
- * xr_ngp_window_march write them); the encoder then reads them with coalesced loads (xr_hashgrid_fwd2). */
+/* xyz_planes (nullable): the positions of `coords` once more as three planes of plane_stride floats (xr_rays_sampler /
+ * xr_ngp_window_march write them); the encoder then reads them with coalesced loads (xr_hashgrid_fwd). */
 /* timed_entry (nullable): the name of ONE of the entry points the step runs ("xr_hashgrid_fwd", "xr_nerf_mlp_fwd",
  * "xr_composite_train", "xr_live_rows", "xr_nerf_mlp_bwd", "xr_hashgrid_bwd"): its launches are bracketed on `stream` by the two
  * events (xr_timing_event_create) -- bench.py's live duration of the dominant kernel inside the timed region.
  */
 void* xr_timing_event_create(void);
-/* an event for ordering only (no timestamp taken: cheaper to record); destroy / wait with the calls of the timing events */
-void* xr_order_event_create(void);
-int xr_stream_wait_event(void* stream, void* event);
 int xr_event_record(void* event, void* stream);
 int xr_timing_event_destroy(void* event);
 int xr_timing_event_elapsed_ms(void* begin, void* end, float* ms);
-/* the second half of xr_nerf_mlp_bwd[_f16] on its own (sum of the per-workgroup dW partials in `workspace` into the gradients) */
-int xr_nerf_mlp_bwd_reduce(const void* workspace, uint32_t n, float* grad_w_density, float* grad_w_color, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * The marches of a refresh WINDOW as one series of launches, and the training LOOP between two grid refreshes as one call.
@@ -428,7 +387,7 @@ int xr_nerf_mlp_bwd_reduce(const void* workspace, uint32_t n, float* grad_w_dens
  * changes the batch size at iterations = 15 (mod 16) only (:268-281), and K1 reads no weights (ray_sampler.cu:5-116).  So right behind a
  * refresh every batch of the window can be drawn and marched: xr_ngp_window_march does that for up to XR_NGP_WINDOW iterations with ONE
  * launch per kernel (batch assembly, K1 count, K1 write, K2 clip) and one copy of the (rays, samples) counters to pinned host memory --
- * bit for bit the batches, samples and RNG call indices of one xr_make_batch / xr_rays_sampler2 / xr_clip_numsteps sequence per iteration.
+ * bit for bit the batches, samples and RNG call indices of one xr_make_batch / xr_rays_sampler / xr_clip_numsteps sequence per iteration.
  * The window's buffers are caller-owned: chunk c (iteration it lives in chunk it % XR_NGP_WINDOW) sits at fixed strides. */
 #define XR_NGP_WINDOW 16
 typedef struct xr_ngp_window {
@@ -443,7 +402,7 @@ typedef struct xr_ngp_window {
  * xr_make_batch into the chunk's rows), the others are drawn here from the device-resident [n_table_rays, 11] table with the cursor
  * *cur_ray (in / out; a batch that would run over the end starts at row 0) and the batch generator's call indices batch_call_index ...;
  * K1 runs for all n_chunks with call indices k1_call_index ...; counter_host_pinned (nullable): [XR_NGP_WINDOW][2] pinned words,
- * the chunks' pairs are copied to their slots.  workspace: xr_rays_sampler_series_workspace_bytes(n_rays, n_chunks). */
+ * the chunks' pairs are copied to their slots.  workspace: xr_rays_sampler_workspace_bytes(n_rays, n_chunks). */
 int xr_ngp_window_march(const xr_ngp_window* window, uint32_t first_chunk, uint32_t n_chunks, uint32_t batches_ready, uint32_t n_rays,
                         const float* rays_rgb_rows, uint64_t n_table_rays, uint64_t* cur_ray, uint64_t batch_seed, uint64_t batch_call_index,
                         const uint8_t* bitfield, float aabb0, float aabb1, float near_distance, float cone_angle, uint32_t max_samples,

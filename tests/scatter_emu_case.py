@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE: one process = one setting of the scatter's test switch (XR_SC_TEST = "min_n=..,block=..,rl=..,rl_chunks=.."
-is read once per process).  Runs xr_hashgrid_bwd2 of the kernels' host build (tests/hip_emu) against
+is read once per process).  Runs xr_hashgrid_bwd of the kernels' host build (tests/hip_emu) against
 oracle/ngp_oracle.c on `n` positions drawn as `mode` and prints one line per check; exit code 0 = all within tolerance.
 usage: python tests/scatter_emu_case.py <n> <rand|rays|cluster|faces>"""
 import os

@@ -31,9 +31,9 @@ def test_library_exports_every_declared_symbol():
         assert n in _lib.SIGNATURES, 'no ctypes signature for %s' % n
     assert sorted(_lib.SIGNATURES) == names
     assert lib.xr_version() >= 100
-    assert lib.xr_rays_sampler_workspace_bytes(4096) > 3 * 4 * 4096
+    assert lib.xr_rays_sampler_workspace_bytes(4096, 1) > 3 * 4 * 4096
     # an invalid call fails loudly with a message, it does not crash or fall back
-    rc = lib.xr_hashgrid_fwd(None, None, 3, 5, None, None, 16, None, None, None, None, 5, None)
+    rc = lib.xr_hashgrid_fwd(None, None, 3, 1, 5, None, None, 16, None, None, None, None, 5, None)
     assert rc == -22 and b'null' in lib.xr_last_error()
 
 

@@ -76,14 +76,19 @@ def _two_ranks(tmp_path, dp_mode, native):
     import socket
     script = tmp_path / ('w%d.py' % native)
     script.write_text(WORKER % ROOT)
-    with socket.socket() as sk:
-        sk.bind(('127.0.0.1', 0))
-        port = sk.getsockname()[1]
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE='2', HSA_ENABLE_IPC_MODE_LEGACY='0', XRNERF_DP=dp_mode,
-               DP_NATIVE='1' if native else '0')
-    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
-    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    outs = None
+    for attempt in range(2):          # (one retry: the rendezvous port is picked by bind-and-release, which another process can win)
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE='2', HSA_ENABLE_IPC_MODE_LEGACY='0', XRNERF_DP=dp_mode,
+                   DP_NATIVE='1' if native else '0')
+        procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+        outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+        if all(p.returncode == 0 for p in procs):
+            break
+        print('attempt %d failed:\n%s' % (attempt, '\n'.join(o[-1500:] for o in outs)))
     assert all(p.returncode == 0 for p in procs), [o[-1500:] for o in outs]
     assert 'replicas identical' in outs[0]
     return [[l for l in o.splitlines() if l.startswith('SIG')][-1].split()[2:] for o in outs]

@@ -463,7 +463,7 @@ def test_native_loop_iteration_events_bracket_every_iteration(dev):
 def test_row_bands_of_a_frame_give_the_whole_frames_pixels(dev):
     """Image-space sharding of a validation frame (HashNerfNetwork._render_rows with several ranks): every rank marches a band of
     image rows, and the band's rays draw the jitter they have in the WHOLE frame's chunk series (sampler.frame_ray0 ->
-    xr_rays_sampler3's rng_ray0), so the all-gathered image is the one-GPU frame bit for bit -- bands that do not start on a chunk
+    xr_rays_sampler's rng_ray0), so the all-gathered image is the one-GPU frame bit for bit -- bands that do not start on a chunk
     boundary included -- and the hidden generator's call counter ends where the whole frame leaves it."""
     from xrnerf_amd import ops
     from xrnerf_amd.dist import row_band

@@ -342,8 +342,8 @@ def test_fused_compositor_train_equals_k3_huber_k4(O, lego, dev, n_rays):
         assert torch.equal(rgb_a, rgb_b)
         assert torch.equal(draw_a, draw_b)
         assert torch.allclose(lm_a, lm_b, rtol=1e-5, atol=0)
-        # the same launch counting the live rows per 1024-row segment (xr_composite_train2) + the ranking pass alone
-        # (xr_live_rows2) = the two-pass list: same rows, same count; some rows are dead (exact zeros behind T == 0)
+        # the same launch counting the live rows per 1024-row segment (live_seg_count) + the ranking pass alone
+        # (seg_counts_ready) = the two-pass list: same rows, same count; some rows are dead (exact zeros behind T == 0)
         raw_dead = raw.clone()
         raw_dead[::3, 3] = 200.0                                     # opaque samples: everything behind them has T == 0
         draw_c, draw_d = torch.zeros_like(raw), torch.zeros_like(raw)

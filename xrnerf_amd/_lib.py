@@ -72,16 +72,12 @@ SIGNATURES = {
     'xr_version': (_i32, []),
     'xr_device_cus': (_i32, []),
     'xr_pcg32_host_state': (None, [_u64, _u64, _vp, _vp]),
-    'xr_rays_sampler_workspace_bytes': (_sz, [_u32]),
-    'xr_rays_sampler': (_i32, [_vp, _vp, _vp, _u32, _f, _f, _f, _f, _u32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    'xr_rays_sampler2': (_i32, [_vp, _vp, _vp, _u32, _f, _f, _f, _f, _u32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _sz, _vp]),
-    'xr_rays_sampler3': (_i32, [_vp, _vp, _vp, _u32, _f, _f, _f, _f, _u32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _sz, _vp]),
+    'xr_rays_sampler': (_i32, [_vp, _vp, _vp, _u32, _f, _f, _f, _f, _u32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _sz, _vp]),
     'xr_compacted_coord': (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    'xr_clip_numsteps': (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _u32, _u32, _vp]),
-    'xr_rays_sampler_series_workspace_bytes': (_sz, [_u32, _u32]),
+    'xr_rays_sampler_workspace_bytes': (_sz, [_u32, _u32]),
     'xr_rays_sampler_series': (_i32, [_vp, _vp, _u32, _vp, _u32, _u32, _f, _f, _f, _f, _u32, _u64, _u64, _vp, _sz, _vp, _vp, _vp, _vp, _u32, _vp,
                                       _sz, _vp]),
-    'xr_clip_numsteps_series': (_i32, [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
+    'xr_clip_numsteps': (_i32, [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
     'xr_make_batch_series': (_i32, [_vp, _vp, _u32, _u32, _u32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'xr_ngp_window_march': (_i32, [_vp, _u32, _u32, _u32, _u32, _vp, _u64, _vp, _u64, _u64, _vp, _f, _f, _f, _f, _u32, _u64, _u32, _vp, _sz,
                                    _vp, _vp]),
@@ -89,14 +85,12 @@ SIGNATURES = {
     'xr_render_slice_composite': (_i32, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _i32, _i32, _vp, _vp, _vp]),
     'xr_calc_rgb_forward': (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, _i32, _i32, _vp, _vp]),
     'xr_calc_rgb_backward': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _i32, _i32, _vp, _vp]),
-    'xr_composite_train': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _i32, _i32, _f, _f, _vp, _vp, _vp, _vp]),
     'xr_hashgrid_bwd_adam_supported': (_i32, [_u32, _i32, _vp, _vp, _vp]),
     'xr_hashgrid_bwd_adam': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     'xr_train_loss_scalars': (_i32, [_vp, _vp, _vp, _u32, _f, _f, _vp, _vp]),
-    'xr_composite_train2': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _i32, _i32, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    'xr_composite_train': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _i32, _i32, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     'xr_calc_rgb_inference': (_i32, [_vp, _vp, _vp, _f, _f, _f, _u32, _i32, _i32, _vp, _vp, _vp]),
-    'xr_generate_grid_samples': (_i32, [_vp, _u32, _u32, _u32, _f, _f, _f, _u64, _u64, _vp, _vp, _vp]),
-    'xr_generate_grid_samples2': (_i32, [_vp, _u32, _u32, _u32, _f, _f, _f, _u64, _u64, _vp, _u32, _u32, _vp, _vp]),
+    'xr_generate_grid_samples': (_i32, [_vp, _u32, _u32, _u32, _f, _f, _f, _u64, _u64, _vp, _u32, _u32, _vp, _vp]),
     'xr_mark_untrained_density_grid': (_i32, [_vp, _vp, _u32, _u32, _i32, _i32, _vp, _vp]),
     'xr_splat_grid_samples': (_i32, [_vp, _vp, _u32, _u32, _vp, _vp]),
     'xr_ema_grid_samples': (_i32, [_vp, _u32, _f, _vp, _vp]),
@@ -104,15 +98,12 @@ SIGNATURES = {
     'xr_update_bitfield': (_i32, [_vp, _vp, _vp, _vp, _sz, _vp]),
     'xr_bitfield_from_mean': (_i32, [_vp, _vp, _vp, _vp]),
     'xr_hashgrid_meta': (None, [_i32, _i32, _i32, _d, _vp, _vp, _vp]),
-    'xr_hashgrid_fwd': (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _u32, _vp]),
-    'xr_hashgrid_fwd2': (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _u32, _vp]),
+    'xr_hashgrid_fwd': (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _u32, _vp]),
     'xr_hashgrid_bwd_workspace_bytes': (_sz, [_u32, _i32, _vp, _vp]),
-    'xr_hashgrid_bwd': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    'xr_hashgrid_bwd2': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp]),
+    'xr_hashgrid_bwd': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp]),
     'xr_sh4': (_i32, [_vp, _u32, _u32, _vp, _vp]),
     'xr_nerf_mlp_fwd': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp]),
-    'xr_nerf_mlp_bwd_workspace_bytes': (_sz, [_u32]),
-    'xr_nerf_mlp_bwd_workspace_bytes2': (_sz, [_u32, _i32, _i32]),
+    'xr_nerf_mlp_bwd_workspace_bytes': (_sz, [_u32, _i32, _i32]),
     'xr_ngp_train_step': (_i32, [_vp, _vp, _vp, _i32, _i32, _f, _i32, _i32, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _u32, _vp, _vp, _vp,
                                  _vp, _i32, _i32, _f, _f, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp, _sz,
                                  _vp, _sz, _i32, _vp, _u32, _vp, _vp, _vp, C.c_char_p, _vp, _vp, _vp]),
@@ -125,18 +116,14 @@ SIGNATURES = {
     'xr_rccl_timing': (_i32, [_vp, _i32]),
     'xr_rccl_exposed_ms': (_i32, [_vp, _vp, _vp, _vp]),
     'xr_timing_event_create': (_vp, []),
-    'xr_order_event_create': (_vp, []),
-    'xr_stream_wait_event': (_i32, [_vp, _vp]),
     'xr_timing_event_destroy': (_i32, [_vp]),
     'xr_timing_event_elapsed_ms': (_i32, [_vp, _vp, _vp]),
-    'xr_nerf_mlp_bwd_reduce': (_i32, [_vp, _u32, _vp, _vp, _vp]),
     'xr_nerf_mlp_fwd_bf16x3': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp]),
     'xr_nerf_mlp_fwd_f16': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp]),
     'xr_nerf_mlp_bwd_f16': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     'xr_nerf_mlp_bwd': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     'xr_live_rows_segments': (_sz, [_u32]),
-    'xr_live_rows': (_i32, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _u32, _vp]),
-    'xr_live_rows2': (_i32, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _u32, _i32, _vp]),
+    'xr_live_rows': (_i32, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _u32, _i32, _vp]),
     'xr_nerf_mlp_bwd_list_slots': (_i32, [_vp, _sz, _u32, _vp, _vp, _vp]),
     'xr_mlp_fwd': (_i32, [_vp, C.c_long, C.c_long, _i32, _f, _u32, _vp, _i32, _vp, _vp]),
     'xr_mlp_bwd_workspace_bytes': (_sz, [_i32]),

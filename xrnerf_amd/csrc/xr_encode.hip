@@ -263,7 +263,7 @@ static void hg_level_costs(float* cost, int n_levels, uint32_t hashed_mask) {
     }
 }
 
-extern "C" int xr_hashgrid_fwd2(const float* table, const float* x, uint32_t x_stride, uint32_t x_comp_stride, uint32_t n, const uint32_t* n_dev,
+extern "C" int xr_hashgrid_fwd(const float* table, const float* x, uint32_t x_stride, uint32_t x_comp_stride, uint32_t n, const uint32_t* n_dev,
                                 const uint32_t* rows, int n_levels, const float* scale_host, const uint32_t* resolution_host,
                                 const uint32_t* offset_host, float* enc_t, uint32_t ld, void* stream_) {
     if (n == 0) return XR_OK;
@@ -287,13 +287,6 @@ extern "C" int xr_hashgrid_fwd2(const float* table, const float* x, uint32_t x_s
                        n_dev, rows, enc_t, ld);
     XR_LAUNCH_CHECK();
     return XR_OK;
-}
-
-extern "C" int xr_hashgrid_fwd(const float* table, const float* x, uint32_t x_stride, uint32_t n, const uint32_t* n_dev,
-                               const uint32_t* rows, int n_levels, const float* scale_host, const uint32_t* resolution_host,
-                               const uint32_t* offset_host, float* enc_t, uint32_t ld, void* stream_) {
-    XR_REQUIRE(x_stride >= 3, "bad stride");
-    return xr_hashgrid_fwd2(table, x, x_stride, 1, n, n_dev, rows, n_levels, scale_host, resolution_host, offset_host, enc_t, ld, stream_);
 }
 
 extern "C" size_t xr_hashgrid_bwd_workspace_bytes(uint32_t n, int n_levels, const uint32_t* resolution_host, const uint32_t* offset_host) {
@@ -329,7 +322,7 @@ static int hashgrid_bwd_atomic_levels(const GridMeta& gm, uint32_t hm, uint32_t 
     return XR_OK;
 }
 
-extern "C" int xr_hashgrid_bwd2(const float* x, uint32_t x_stride, const float* denc_t, uint32_t ld, uint32_t n, const uint32_t* n_dev,
+extern "C" int xr_hashgrid_bwd(const float* x, uint32_t x_stride, const float* denc_t, uint32_t ld, uint32_t n, const uint32_t* n_dev,
                                 const uint32_t* rows, int n_levels, const float* scale_host, const uint32_t* resolution_host,
                                 const uint32_t* offset_host, float* grad_table, void* workspace, size_t workspace_bytes, int flags,
                                 void* stream_) {
@@ -404,13 +397,6 @@ extern "C" int xr_hashgrid_bwd_adam(const float* x, uint32_t x_stride, const flo
     uint32_t amask = 0;
     return xr_scatter3(x, x_stride, denc_t, ld, n, n_dev, rows, gm, hm, adam->param /* alignment check only */, workspace, workspace_bytes,
                        1, &amask, (hipStream_t)stream_, &A);
-}
-
-extern "C" int xr_hashgrid_bwd(const float* x, uint32_t x_stride, const float* denc_t, uint32_t ld, uint32_t n, const uint32_t* n_dev,
-                               const uint32_t* rows, int n_levels, const float* scale_host, const uint32_t* resolution_host,
-                               const uint32_t* offset_host, float* grad_table, void* workspace, size_t workspace_bytes, void* stream_) {
-    return xr_hashgrid_bwd2(x, x_stride, denc_t, ld, n, n_dev, rows, n_levels, scale_host, resolution_host, offset_host, grad_table, workspace,
-                            workspace_bytes, 0, stream_);
 }
 
 // ------------------------------------------------------------------ SH degree 4 (tcnn SphericalHarmonics)

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(GR_BLOCK) void k6_generate(uint32_t n_elements, xr_
     indices[i] = (int32_t)idx;
 }
 
-extern "C" int xr_generate_grid_samples2(const float* density_grid, uint32_t ema_step, uint32_t n_elements,
+extern "C" int xr_generate_grid_samples(const float* density_grid, uint32_t ema_step, uint32_t n_elements,
                                          uint32_t n_cascades, float thresh, float aabb0, float aabb1,
                                          uint64_t rng_state, uint64_t rng_inc, float* positions, uint32_t pos_row_stride,
                                          uint32_t pos_comp_stride, int32_t* indices, void* stream_) {
@@ -49,13 +49,6 @@ extern "C" int xr_generate_grid_samples2(const float* density_grid, uint32_t ema
                        n_cascades, thresh);
     XR_LAUNCH_CHECK();
     return XR_OK;
-}
-extern "C" int xr_generate_grid_samples(const float* density_grid, uint32_t ema_step, uint32_t n_elements,
-                                        uint32_t n_cascades, float thresh, float aabb0, float aabb1,
-                                        uint64_t rng_state, uint64_t rng_inc, float* positions, int32_t* indices,
-                                        void* stream_) {
-    return xr_generate_grid_samples2(density_grid, ema_step, n_elements, n_cascades, thresh, aabb0, aabb1, rng_state, rng_inc, positions,
-                                     3, 1, indices, stream_);
 }
 
 // ------------------------------------------------------------------ K7 (mark_untrained_density_grid.cu:6-52)

@@ -12,7 +12,8 @@ void xr_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* xr_last_error(void) { return g_err; }
-extern "C" int xr_version(void) { return 110; }    // 110: xr_ngp_loop_* added, xr_ngp_train_step / xr_ngp_prefetch signatures of round 3
+extern "C" int xr_version(void) { return 120; }    // 120 (round 5): one generation per entry point (xr_rays_sampler, xr_hashgrid_fwd / _bwd, xr_composite_train,
+                                                   // xr_live_rows, xr_generate_grid_samples, xr_clip_numsteps take their newest signatures), window march, loop without a handle
 
 extern "C" void xr_pcg32_host_state(uint64_t seed, uint64_t ncalls, uint64_t* state_host, uint64_t* inc_host) {
     xr_pcg32 r; r.seed(seed, 1u);

@@ -2149,10 +2149,9 @@ static size_t bwd_scratch_bytes(int nhd, int nhc) {
     return bwd_is_deep(nhd, nhc) ? (size_t)cus * (nhd + nhc + 2) * DP_BW * 2048 * sizeof(float) : 0;
 }
 static float* bwd_partials(const void* workspace, uint32_t n) { return reinterpret_cast<float*>((char*)workspace + bwd_list_bytes(n)); }
-extern "C" size_t xr_nerf_mlp_bwd_workspace_bytes2(uint32_t n, int n_hidden_density, int n_hidden_color) {
+extern "C" size_t xr_nerf_mlp_bwd_workspace_bytes(uint32_t n, int n_hidden_density, int n_hidden_color) {
     return bwd_list_bytes(n) + bwd_partial_bytes(n_hidden_density, n_hidden_color) + bwd_scratch_bytes(n_hidden_density, n_hidden_color);
 }
-extern "C" size_t xr_nerf_mlp_bwd_workspace_bytes(uint32_t n) { return xr_nerf_mlp_bwd_workspace_bytes2(n, 1, 2); }
 static bool live_rows_enabled() {          // XR_MLP_LIVE=0: run the backward over every row (measurement)
     static int on = -1;
     if (on < 0) { const char* e = getenv("XR_MLP_LIVE"); on = (e && e[0] == '0') ? 0 : 1; }
@@ -2161,7 +2160,7 @@ static bool live_rows_enabled() {          // XR_MLP_LIVE=0: run the backward ov
 extern "C" size_t xr_live_rows_segments(uint32_t n) { return xr_div_up(n, LIVE_SEG); }
 // seg_counts_ready != 0: seg_count already holds the live rows per segment (xr_composite_train2 counted them while writing
 // the rows) -- only the ranking / list pass runs
-extern "C" int xr_live_rows2(const float* dloss_doutput, uint32_t n, const uint32_t* n_dev, uint32_t* seg_count, uint32_t* live_rows,
+extern "C" int xr_live_rows(const float* dloss_doutput, uint32_t n, const uint32_t* n_dev, uint32_t* seg_count, uint32_t* live_rows,
                              uint32_t* n_live, float* zero_denc_t, uint32_t ld, int seg_counts_ready, void* stream_) {
     XR_REQUIRE(dloss_doutput && seg_count && live_rows && n_live, "null pointer");
     XR_REQUIRE(((uintptr_t)dloss_doutput & 15) == 0, "dloss_doutput must be 16-byte aligned");
@@ -2176,16 +2175,12 @@ extern "C" int xr_live_rows2(const float* dloss_doutput, uint32_t n, const uint3
     XR_LAUNCH_CHECK();
     return XR_OK;
 }
-extern "C" int xr_live_rows(const float* dloss_doutput, uint32_t n, const uint32_t* n_dev, uint32_t* seg_count, uint32_t* live_rows,
-                            uint32_t* n_live, float* zero_denc_t, uint32_t ld, void* stream_) {
-    return xr_live_rows2(dloss_doutput, n, n_dev, seg_count, live_rows, n_live, zero_denc_t, ld, 0, stream_);
-}
 // where a list of n rows sits in an xr_nerf_mlp_bwd workspace (at its start, whatever the topology): callers that build the list
 // themselves to share it with xr_hashgrid_bwd use these slots instead of allocating
 extern "C" int xr_nerf_mlp_bwd_list_slots(void* workspace, size_t workspace_bytes, uint32_t n, uint32_t** live_rows,
                                           uint32_t** seg_count, uint32_t** n_live) {
     XR_REQUIRE(workspace && live_rows && seg_count && n_live, "null pointer");
-    XR_REQUIRE(workspace_bytes >= xr_nerf_mlp_bwd_workspace_bytes(n), "workspace too small");
+    XR_REQUIRE(workspace_bytes >= xr_nerf_mlp_bwd_workspace_bytes(n, 1, 2), "workspace too small");
     *live_rows = reinterpret_cast<uint32_t*>(workspace);
     *seg_count = *live_rows + n;
     *n_live = *seg_count + xr_div_up(n, LIVE_SEG);
@@ -2198,7 +2193,7 @@ static int build_live_rows(const float* draw, uint32_t n, const uint32_t* n_dev,
     uint32_t* seg = list + n;
     uint32_t* cnt = seg + xr_div_up(n, LIVE_SEG);
     *rows = list; *n_live = cnt;
-    return xr_live_rows(draw, n, n_dev, seg, list, cnt, denc_t, ld, stream);
+    return xr_live_rows(draw, n, n_dev, seg, list, cnt, denc_t, ld, 0, stream);
 }
 
 // xr_ngp_train_step runs the partial reduce on its helper stream beside the table scatter (only the optimiser reads the MLP
@@ -2215,9 +2210,6 @@ int xr_internal_mlp_bwd_reduce(const void* workspace, uint32_t n, int nhd, int n
     XR_LAUNCH_CHECK();
     return XR_OK;
 }
-extern "C" int xr_nerf_mlp_bwd_reduce(const void* workspace, uint32_t n, float* grad_w_density, float* grad_w_color, void* stream_) {
-    return xr_internal_mlp_bwd_reduce(workspace, n, 1, 2, grad_w_density, grad_w_color, 0, stream_);
-}
 
 extern "C" int xr_nerf_mlp_bwd(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
                                const uint32_t* n_dev, const float* w_density, const float* w_color, int n_hidden_density, int n_hidden_color,
@@ -2230,7 +2222,7 @@ extern "C" int xr_nerf_mlp_bwd(const float* enc_t, uint32_t ld, const float* dir
     XR_REQUIRE(ld >= n && ld <= XR_MLP_MAX_LD && dir_stride >= 3 && ((uintptr_t)draw & 15) == 0, "bad ld / stride / alignment");
     XR_REQUIRE(n_hidden_density >= 1 && n_hidden_density <= XR_MLP_MAX_HIDDEN && n_hidden_color >= 1 && n_hidden_color <= XR_MLP_MAX_HIDDEN,
                "1..8 hidden layers per network");
-    XR_REQUIRE(workspace && workspace_bytes >= xr_nerf_mlp_bwd_workspace_bytes2(n, n_hidden_density, n_hidden_color), "workspace too small");
+    XR_REQUIRE(workspace && workspace_bytes >= xr_nerf_mlp_bwd_workspace_bytes(n, n_hidden_density, n_hidden_color), "workspace too small");
     XR_REQUIRE(!live_rows == !n_live, "live_rows and n_live come together");
     const uint32_t* rows = live_rows;                    // the caller's list (xr_live_rows), else the backward's own
     if (!rows && live_rows_enabled()) { const int rc = build_live_rows(draw, n, n_dev, denc_t, ld, workspace, stream, &rows, &n_live); if (rc != XR_OK) return rc; }
@@ -2403,7 +2395,7 @@ extern "C" int xr_nerf_mlp_bwd_f16(const float* enc_t, uint32_t ld, const float*
     XR_REQUIRE(enc_t && dirs && w_density && w_color && draw && denc_t && grad_w_density && grad_w_color, "null pointer");
     XR_REQUIRE(ld >= n && ld <= XR_MLP_MAX_LD && dir_stride >= 3 && ((uintptr_t)draw & 15) == 0, "bad ld / stride / alignment");
     XR_REQUIRE(n_hidden_density == 1 && n_hidden_color == 2, "the fp16 mode is built for the (1,2) hidden-layer topology");
-    XR_REQUIRE(workspace && workspace_bytes >= xr_nerf_mlp_bwd_workspace_bytes(n), "workspace too small");
+    XR_REQUIRE(workspace && workspace_bytes >= xr_nerf_mlp_bwd_workspace_bytes(n, 1, 2), "workspace too small");
     constexpr int GW = NetShape<1>::glb_floats + NetShape<2>::glb_floats;
     constexpr size_t stage_bytes = (size_t)MLP_WAVES * 4 * 32 * HST * 2;
     static_assert(stage_bytes >= GW * sizeof(float), "stage area doubles as the dW reduction buffer");

@@ -424,8 +424,7 @@ static size_t rm_ws_layout(uint32_t n_rays, char* base, RmWorkspace* w, uint32_t
     return off;
 }
 
-extern "C" size_t xr_rays_sampler_workspace_bytes(uint32_t n_rays) { return rm_ws_layout(n_rays, nullptr, nullptr); }
-extern "C" size_t xr_rays_sampler_series_workspace_bytes(uint32_t n_rays, uint32_t n_series) {
+extern "C" size_t xr_rays_sampler_workspace_bytes(uint32_t n_rays, uint32_t n_series) {
     return rm_ws_layout(n_rays, nullptr, nullptr, n_series ? n_series : 1);
 }
 
@@ -463,7 +462,7 @@ static int rm_launch(const float* rays_o, const float* rays_d, const uint8_t* bi
     return XR_OK;
 }
 
-extern "C" int xr_rays_sampler3(const float* rays_o, const float* rays_d, const uint8_t* bitfield, uint32_t n_rays,
+extern "C" int xr_rays_sampler(const float* rays_o, const float* rays_d, const uint8_t* bitfield, uint32_t n_rays,
                                 float aabb0, float aabb1, float near_distance, float cone_angle, uint32_t max_samples,
                                 uint64_t rng_state, uint64_t rng_inc, float* coords_out, int32_t* rays_index,
                                 int32_t* rays_numsteps, uint32_t* counter2, float* xyz_planes, uint32_t plane_stride,
@@ -472,7 +471,7 @@ extern "C" int xr_rays_sampler3(const float* rays_o, const float* rays_d, const 
     XR_REQUIRE(rays_o && rays_d && bitfield && coords_out && rays_index && rays_numsteps && counter2, "null pointer");
     XR_REQUIRE(!xyz_planes || plane_stride >= max_samples, "a position plane holds max_samples values");
     XR_REQUIRE(n_rays > 0 && n_rays <= (1u << 28), "n_rays out of range");
-    XR_REQUIRE(workspace && workspace_bytes >= xr_rays_sampler_workspace_bytes(n_rays), "workspace too small");
+    XR_REQUIRE(workspace && workspace_bytes >= xr_rays_sampler_workspace_bytes(n_rays, 1), "workspace too small");
     return rm_launch(rays_o, rays_d, bitfield, n_rays, 1, 0, aabb0, aabb1, near_distance, cone_angle, max_samples, xr_pcg32{rng_state, rng_inc},
                      coords_out, 0, rays_index, rays_numsteps, counter2, xyz_planes, plane_stride, rng_chunk, rng_ray0, flags, workspace,
                      (hipStream_t)stream_);
@@ -488,7 +487,7 @@ extern "C" int xr_rays_sampler_series(const float* rays_o, const float* rays_d, 
     XR_REQUIRE(rays_o && rays_d && bitfield && coords_out && rays_index && rays_numsteps && counter2, "null pointer");
     XR_REQUIRE(n_series >= 1 && n_series <= 65535u && n_rays > 0 && n_rays <= (1u << 28) && ray_stride >= n_rays, "bad series");
     XR_REQUIRE(coords_stride >= max_samples && (!xyz_planes || plane_stride >= max_samples), "a launch's buffers hold max_samples rows");
-    XR_REQUIRE(workspace && workspace_bytes >= xr_rays_sampler_series_workspace_bytes(n_rays, n_series), "workspace too small");
+    XR_REQUIRE(workspace && workspace_bytes >= xr_rays_sampler_workspace_bytes(n_rays, n_series), "workspace too small");
     const uint32_t nb = xr_div_up(n_rays, RM_BLOCK);
     if (nb <= (uint32_t)RM_BLOCK || n_series == 1)
         return rm_launch(rays_o, rays_d, bitfield, n_rays, n_series, ray_stride, aabb0, aabb1, near_distance, cone_angle, max_samples,
@@ -505,24 +504,6 @@ extern "C" int xr_rays_sampler_series(const float* rays_o, const float* rays_d, 
         rng.advance(1ull << 32);
     }
     return XR_OK;
-}
-
-extern "C" int xr_rays_sampler2(const float* rays_o, const float* rays_d, const uint8_t* bitfield, uint32_t n_rays,
-                                float aabb0, float aabb1, float near_distance, float cone_angle, uint32_t max_samples,
-                                uint64_t rng_state, uint64_t rng_inc, float* coords_out, int32_t* rays_index,
-                                int32_t* rays_numsteps, uint32_t* counter2, float* xyz_planes, uint32_t plane_stride,
-                                uint32_t rng_chunk, void* workspace, size_t workspace_bytes, void* stream_) {
-    return xr_rays_sampler3(rays_o, rays_d, bitfield, n_rays, aabb0, aabb1, near_distance, cone_angle, max_samples, rng_state, rng_inc,
-                            coords_out, rays_index, rays_numsteps, counter2, xyz_planes, plane_stride, rng_chunk, 0, 0, workspace, workspace_bytes, stream_);
-}
-
-extern "C" int xr_rays_sampler(const float* rays_o, const float* rays_d, const uint8_t* bitfield, uint32_t n_rays,
-                               float aabb0, float aabb1, float near_distance, float cone_angle, uint32_t max_samples,
-                               uint64_t rng_state, uint64_t rng_inc, float* coords_out, int32_t* rays_index,
-                               int32_t* rays_numsteps, uint32_t* counter2, void* workspace, size_t workspace_bytes,
-                               void* stream_) {
-    return xr_rays_sampler2(rays_o, rays_d, bitfield, n_rays, aabb0, aabb1, near_distance, cone_angle, max_samples, rng_state, rng_inc,
-                            coords_out, rays_index, rays_numsteps, counter2, nullptr, 0, 0, workspace, workspace_bytes, stream_);
 }
 
 // ------------------------------------------------------------------ K2 re-pack (compacted_coord.cu:22-76)
@@ -572,7 +553,7 @@ extern "C" int xr_compacted_coord(const float* coords_in, const int32_t* numstep
     hipStream_t stream = (hipStream_t)stream_;
     XR_REQUIRE(coords_in && numsteps_in && coords_out && numsteps_out && rays_counter && numstep_counter, "null pointer");
     XR_REQUIRE(n_rays > 0, "n_rays == 0");
-    XR_REQUIRE(workspace && workspace_bytes >= xr_rays_sampler_workspace_bytes(n_rays), "workspace too small");
+    XR_REQUIRE(workspace && workspace_bytes >= xr_rays_sampler_workspace_bytes(n_rays, 1), "workspace too small");
     RmWorkspace w; rm_ws_layout(n_rays, (char*)workspace, &w);
     const uint32_t nb = xr_div_up(n_rays, RM_BLOCK);
     XR_HIP(hipMemsetAsync(rays_counter, 0, 4, stream));
@@ -603,17 +584,9 @@ __global__ __launch_bounds__(RM_BLOCK) void k2_clip(uint32_t n_rays, uint32_t ma
     out[2 * i] = (int32_t)min(max_compacted - min(max_compacted, base), n);
     out[2 * i + 1] = (int32_t)base;
 }
-extern "C" int xr_clip_numsteps(const int32_t* numsteps_in, const uint32_t* counter2, uint32_t n_rays, uint32_t max_compacted,
-                                int32_t* numsteps_out, uint32_t* n_valid_dev, uint32_t chunk_rows, uint32_t n_chunks, void* stream_) {
-    XR_REQUIRE(numsteps_in && counter2 && numsteps_out && n_valid_dev && n_rays > 0, "bad argument");
-    hipLaunchKernelGGL(k2_clip, dim3(xr_div_up(n_rays, RM_BLOCK)), dim3(RM_BLOCK), 0, (hipStream_t)stream_, n_rays, max_compacted,
-                       numsteps_in, counter2, numsteps_out, n_valid_dev, chunk_rows, n_chunks, 0u);
-    XR_LAUNCH_CHECK();
-    return XR_OK;
-}
 // K2's clip for the n_series launches of xr_rays_sampler_series: numsteps arrays with ray_stride rows per launch, counter2 [n_series][2],
 // n_valid_dev [n_series][2] = (valid rows, valid rows) like xr_clip_numsteps(chunk_rows = max_compacted, n_chunks = 1)
-extern "C" int xr_clip_numsteps_series(const int32_t* numsteps_in, const uint32_t* counter2, uint32_t n_rays, uint32_t n_series, uint32_t ray_stride,
+extern "C" int xr_clip_numsteps(const int32_t* numsteps_in, const uint32_t* counter2, uint32_t n_rays, uint32_t n_series, uint32_t ray_stride,
                                        uint32_t max_compacted, int32_t* numsteps_out, uint32_t* n_valid_dev, void* stream_) {
     XR_REQUIRE(numsteps_in && counter2 && numsteps_out && n_valid_dev && n_rays > 0 && n_series >= 1 && n_series <= 65535u && ray_stride >= n_rays, "bad argument");
     hipLaunchKernelGGL(k2_clip, dim3(xr_div_up(n_rays, RM_BLOCK), n_series), dim3(RM_BLOCK), 0, (hipStream_t)stream_, n_rays, max_compacted,
@@ -1248,7 +1221,7 @@ extern "C" int xr_train_loss_scalars(const float* rgb, const float* target, cons
 
 // loss_mse_out == nullptr: the wave-per-ray kernel; the two loss scalars are left to xr_train_loss_scalars (a function of
 // rgb_output).  With loss_mse_out: the 16-lanes-per-ray kernel, which ADDS them (block sums + two atomics per workgroup).
-extern "C" int xr_composite_train2(const float* network_output, const float* coords, const int32_t* rays_numsteps,
+extern "C" int xr_composite_train(const float* network_output, const float* coords, const int32_t* rays_numsteps,
                                    const int32_t* rays_numsteps_compacted, const float* bg_color, const float* target,
                                    const float* alpha_mask, const float* density_grid_mean, uint32_t n_rays, int rgb_activation,
                                    int density_activation, float delta, float scale, float* rgb_output, float* loss_mse_out,
@@ -1283,13 +1256,4 @@ extern "C" int xr_composite_train2(const float* network_output, const float* coo
                        (float4*)dloss_doutput, live_seg_count, stage);
     XR_LAUNCH_CHECK();
     return XR_OK;
-}
-extern "C" int xr_composite_train(const float* network_output, const float* coords, const int32_t* rays_numsteps,
-                                  const int32_t* rays_numsteps_compacted, const float* bg_color, const float* target,
-                                  const float* alpha_mask, const float* density_grid_mean, uint32_t n_rays, int rgb_activation,
-                                  int density_activation, float delta, float scale, float* rgb_output, float* loss_mse_out,
-                                  float* dloss_doutput, void* stream_) {
-    return xr_composite_train2(network_output, coords, rays_numsteps, rays_numsteps_compacted, bg_color, target, alpha_mask,
-                               density_grid_mean, n_rays, rgb_activation, density_activation, delta, scale, rgb_output, loss_mse_out,
-                               dloss_doutput, nullptr, stream_);
 }

@@ -14,22 +14,10 @@ extern "C" void* xr_timing_event_create(void) {
     hipEvent_t e = nullptr;
     return hipEventCreate(&e) == hipSuccess ? (void*)e : nullptr;
 }
-// an event for ordering only (hipEventDisableTiming: no timestamp is taken when it completes); same destroy / wait calls
-extern "C" void* xr_order_event_create(void) {
-    hipEvent_t e = nullptr;
-    return hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess ? (void*)e : nullptr;
-}
 extern "C" int xr_timing_event_destroy(void* e) { return e && hipEventDestroy((hipEvent_t)e) != hipSuccess ? XR_EHIP : XR_OK; }
 extern "C" int xr_timing_event_elapsed_ms(void* a, void* b, float* ms) {
     XR_REQUIRE(a && b && ms, "null pointer");
     XR_HIP(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
-    return XR_OK;
-}
-
-// order `stream` behind a recorded event (a caller without a HIP binding holds events from xr_timing_event_create)
-extern "C" int xr_stream_wait_event(void* stream, void* event) {
-    XR_REQUIRE(event, "null event");
-    XR_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
     return XR_OK;
 }
 
@@ -89,8 +77,8 @@ extern "C" int xr_ngp_train_step(
     // coordinate rows {pos3, dt, dir3}: positions and directions are consumed in place (row stride 7)
     if ((rc = begin("xr_hashgrid_fwd")) != XR_OK) return rc;
     // positions: K1's three planes when the caller has them (coalesced loads: 91 -> 83 us at 2.6e5 samples), else the rows
-    if (xyz_planes) rc = xr_hashgrid_fwd2(table, xyz_planes, 1, plane_stride, n_rows, n_dev, nullptr, n_levels, scale_host, resolution_host, offset_host, enc_t, ld, stream_);
-    else rc = xr_hashgrid_fwd(table, coords, 7, n_rows, n_dev, nullptr, n_levels, scale_host, resolution_host, offset_host, enc_t, ld, stream_);
+    if (xyz_planes) rc = xr_hashgrid_fwd(table, xyz_planes, 1, plane_stride, n_rows, n_dev, nullptr, n_levels, scale_host, resolution_host, offset_host, enc_t, ld, stream_);
+    else rc = xr_hashgrid_fwd(table, coords, 7, 1, n_rows, n_dev, nullptr, n_levels, scale_host, resolution_host, offset_host, enc_t, ld, stream_);
     if (rc != XR_OK) return rc;
     if ((rc = end("xr_hashgrid_fwd")) != XR_OK || (rc = begin("xr_nerf_mlp_fwd")) != XR_OK) return rc;
     const bool f16_mlp = mlp_mode == 1;
@@ -119,13 +107,13 @@ extern "C" int xr_ngp_train_step(
     }
     if ((rc = begin("xr_composite_train")) != XR_OK) return rc;
     // (the two loss scalars are a function of rgb_out: one fixed-order sum on the scatter's helper stream, see below)
-    rc = xr_composite_train2(raw, coords, rays_numsteps, rays_numsteps_compacted, bg_color, target, alpha_mask, density_grid_mean,
+    rc = xr_composite_train(raw, coords, rays_numsteps, rays_numsteps_compacted, bg_color, target, alpha_mask, density_grid_mean,
                              n_rays, rgb_activation, density_activation, huber_delta, loss_scale, rgb_out, nullptr, draw, seg, stream_);
     if (rc != XR_OK) return rc;
     if ((rc = end("xr_composite_train")) != XR_OK) return rc;
     if ((rc = begin("xr_live_rows")) != XR_OK) return rc;
     if (live_on) {
-        rc = xr_live_rows2(draw, n_rows, n_dev, seg, rows, n_live, nullptr, ld, 1, stream_);
+        rc = xr_live_rows(draw, n_rows, n_dev, seg, rows, n_live, nullptr, ld, 1, stream_);
         if (rc != XR_OK) return rc;
     }
     if ((rc = end("xr_live_rows")) != XR_OK || (rc = begin("xr_nerf_mlp_bwd")) != XR_OK) return rc;
@@ -166,7 +154,7 @@ extern "C" int xr_ngp_train_step(
         rc = xr_hashgrid_bwd_adam(coords, 7, denc_t, ld, n_rows, live_on ? n_live : n_dev, rows, n_levels, scale_host, resolution_host, offset_host,
                                   ws_scatter, ws_scatter_bytes, table_adam, stream_);
     else
-        rc = xr_hashgrid_bwd2(coords, 7, denc_t + (size_t)2 * scatter_level0 * ld, ld, n_rows, live_on ? n_live : n_dev, rows, n_levels - scatter_level0,
+        rc = xr_hashgrid_bwd(coords, 7, denc_t + (size_t)2 * scatter_level0 * ld, ld, n_rows, live_on ? n_live : n_dev, rows, n_levels - scatter_level0,
                               scale_host + scatter_level0, resolution_host + scatter_level0, offset_host + scatter_level0, grad_table,
                               ws_scatter, ws_scatter_bytes, XR_SCATTER_OVERWRITE, stream_);
     xr_internal_scatter_aux_prologue(nullptr);
@@ -220,7 +208,7 @@ extern "C" int xr_ngp_window_march(const xr_ngp_window* W, uint32_t first_chunk,
                                 W->xyz_planes ? W->xyz_planes + 3 * (size_t)first_chunk * W->plane_stride : nullptr, W->plane_stride, workspace,
                                 workspace_bytes, stream_);
     if (rc != XR_OK) return rc;
-    rc = xr_clip_numsteps_series(W->rays_numsteps + 2 * r0, W->counter2 + 2 * first_chunk, n_rays, n_chunks, W->ray_stride, max_compacted,
+    rc = xr_clip_numsteps(W->rays_numsteps + 2 * r0, W->counter2 + 2 * first_chunk, n_rays, n_chunks, W->ray_stride, max_compacted,
                                  W->numsteps_clipped + 2 * r0, W->n_valid + 2 * first_chunk, stream_);
     if (rc != XR_OK) return rc;
     if (counter_host_pinned)
@@ -289,7 +277,7 @@ extern "C" int xr_ngp_loop_run(const xr_ngp_loop_desc* desc, xr_ngp_loop_state* 
                 uint32_t *rows = nullptr, *seg = nullptr, *n_live = nullptr;
                 static const bool live_on = []() { const char* e = getenv("XR_MLP_LIVE"); return !(e && e[0] == '0'); }();
                 if (live_on && (rc = xr_nerf_mlp_bwd_list_slots(D.ws_mlp_bwd, D.ws_mlp_bwd_bytes, D.n_rows, &rows, &seg, &n_live)) != XR_OK) return rc;
-                rc = xr_hashgrid_bwd2(coords, 7, B.denc_t, D.ld, D.n_rows, live_on ? n_live : W.n_valid + 2 * c, live_on ? rows : nullptr, D.split_level,
+                rc = xr_hashgrid_bwd(coords, 7, B.denc_t, D.ld, D.n_rows, live_on ? n_live : W.n_valid + 2 * c, live_on ? rows : nullptr, D.split_level,
                                       D.scale_host, D.resolution_host, D.offset_host, B.grad_table, D.ws_scatter, D.ws_scatter_bytes, XR_SCATTER_OVERWRITE, D.stream);
                 if (rc != XR_OK) return rc;
                 if ((rc = X->all_reduce(X->ctx, B.grad_table, cut, D.stream)) != XR_OK) return rc;

@@ -361,9 +361,9 @@ class RcclExchange:
 
 
 def native_exchange(world_size, rank):
-    """the exchange implementation of the native loop for this job: RCCL from native code under backend 'nccl'
-    (XRNERF_NATIVE_RCCL=0: callbacks into torch.distributed instead), callbacks otherwise"""
-    if dist.get_backend() == 'nccl' and os.environ.get('XRNERF_NATIVE_RCCL', '1') != '0':
+    """the exchange implementation of the native loop for this job: RCCL from native code under backend 'nccl', callbacks into
+    torch.distributed otherwise (gloo)"""
+    if dist.get_backend() == 'nccl':
         return RcclExchange(world_size, rank)
     return CallbackExchange(world_size, rank)
 

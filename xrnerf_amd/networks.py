@@ -494,7 +494,7 @@ class HashNerfNetwork(_FastAttr, BaseNerfNetwork):
         assert N == H * W, 'row-band sharding needs the frame as H*W flattened rays'
         row0, nrows = xdist.row_band(H, rank, world)
         band = {k: (v[row0 * W:(row0 + nrows) * W] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == N else v) for k, v in frame.items()}
-        # the band's rays draw the march jitter they have in the WHOLE frame's chunk series (frame_ray0: xr_rays_sampler3), and every rank's
+        # the band's rays draw the march jitter they have in the WHOLE frame's chunk series (frame_ray0: xr_rays_sampler's rng_ray0), and every rank's
         # hidden-generator counter moves on by the whole frame's launches: the pixels are those of the one-GPU / reference frame whatever
         # the world size, and the ranks' training RNG streams stay in step
         from .samplers import NGPGridSampler

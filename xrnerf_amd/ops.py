@@ -70,8 +70,7 @@ class _CEvent:
     """a timing event of the library (xr_timing_event_*): what xr_ngp_train_step records around one of its stages"""
 
     def __init__(self, timing=True):
-        # timing=False: an event for ordering only (xr_order_event_create, hipEventDisableTiming)
-        self.h = _lib.load().xr_timing_event_create() if timing else _lib.load().xr_order_event_create()
+        self.h = _lib.load().xr_timing_event_create()
         if not self.h:
             raise _lib.XrError('cannot create a timing event')
 
@@ -226,11 +225,11 @@ def rays_sampler(rays_o, rays_d, bitfield, aabb, near_distance, cone_angle, max_
         rays_index = torch.empty((n, 1), dtype=torch.int32, device=dev)
         numsteps = torch.empty((n, 2), dtype=torch.int32, device=dev)
         counter = torch.empty((2,), dtype=torch.int32, device=dev)
-    nb = L.xr_rays_sampler_workspace_bytes(n)
+    nb = L.xr_rays_sampler_workspace_bytes(n, 1)
     ws = _ws(dev, nb, ws_tag)
     st, inc = pcg32_host_state(rng_calls)
     with _span('xr_rays_sampler', n):
-        _lib.check(L.xr_rays_sampler3(_ptr(rays_o), _ptr(rays_d), _ptr(bitfield), n, aabb[0], aabb[1], near_distance,
+        _lib.check(L.xr_rays_sampler(_ptr(rays_o), _ptr(rays_d), _ptr(bitfield), n, aabb[0], aabb[1], near_distance,
                                       cone_angle, max_samples, st, inc, _ptr(coords_out), _ptr(rays_index),
                                       _ptr(numsteps), _ptr(counter), _ptr(xyz_out), xyz_out.shape[1] if xyz_out is not None else 0,
                                       int(rng_chunk), int(rng_ray0), 1 if wide else 0, _ptr(ws), ws.numel(), _stream()), 'xr_rays_sampler')
@@ -246,7 +245,7 @@ def compacted_coord(coords_in, numsteps, max_compacted, coords_out=None):
     nc = torch.empty((n, 2), dtype=torch.int32, device=dev)
     rc = torch.empty((1,), dtype=torch.int32, device=dev)
     sc = torch.empty((1,), dtype=torch.int32, device=dev)
-    ws = _ws(dev, L.xr_rays_sampler_workspace_bytes(n), 'k1')
+    ws = _ws(dev, L.xr_rays_sampler_workspace_bytes(n, 1), 'k1')
     _lib.check(L.xr_compacted_coord(_ptr(coords_in), _ptr(numsteps), n, max_compacted, _ptr(coords_out), _ptr(nc),
                                     _ptr(rc), _ptr(sc), _ptr(ws), ws.numel(), _stream()), 'xr_compacted_coord')
     return coords_out, nc, rc, sc
@@ -281,7 +280,7 @@ def composite_train(raw, coords, numsteps, numsteps_c, bg, target, alpha, densit
     """K3 + scale * Huber (+ masked MSE) + K4 in one launch -> rgb [n,3]; `loss_mse` [2] and `draw` [S,4] must be zero-filled
     (loss terms are added, rows behind the last sample are not written).
     live_seg (int32 [live_segments(S)], zero-filled by the caller): the launch also counts the non-zero rows of `draw` per
-    1024-row segment into it (xr_composite_train2); follow with live_rows(..., seg_counts=live_seg).
+    1024-row segment into it; follow with live_rows(..., seg_counts=live_seg).
     loss_mse=None: the wave-per-ray kernel (rgb / draw differ from the 16-lane kernels' like two fp32 summation orders); the loss
     scalars then come from train_loss_scalars(rgb, ...)."""
     n = numsteps.shape[0]
@@ -289,7 +288,7 @@ def composite_train(raw, coords, numsteps, numsteps_c, bg, target, alpha, densit
         rgb = torch.empty((n, 3), dtype=torch.float32, device=raw.device)
     p_seg = _ptr(live_seg)
     with _span('xr_composite_train', 0):
-        _lib.check(_lib.load().xr_composite_train2(_ptr(raw), _ptr(coords), _ptr(numsteps), _ptr(numsteps_c), _ptr(bg), _ptr(target),
+        _lib.check(_lib.load().xr_composite_train(_ptr(raw), _ptr(coords), _ptr(numsteps), _ptr(numsteps_c), _ptr(bg), _ptr(target),
                                                    _ptr(alpha), _ptr(density_grid_mean), n, int(rgb_act), int(density_act),
                                                    float(delta), float(scale), _ptr(rgb), _ptr(loss_mse), _ptr(draw), p_seg, _stream()),
                    'xr_composite_train')
@@ -340,7 +339,7 @@ def ngp_window_march(win, first_chunk, n_chunks, batches_ready, n, rows_table, c
     (xr_ngp_window_march): batch assembly for all but the first `batches_ready` chunks, K1, K2's clip, counters to win.pinned.
     -> the table cursor behind the last batch drawn"""
     L = _lib.load()
-    ws = _ws(win.device, L.xr_rays_sampler_series_workspace_bytes(n, n_chunks), ws_tag)
+    ws = _ws(win.device, L.xr_rays_sampler_workspace_bytes(n, n_chunks), ws_tag)
     try:
         native = L.xr_ngp_window_march
     except AttributeError:
@@ -373,8 +372,8 @@ def ngp_window_march(win, first_chunk, n_chunks, batches_ready, n, rows_table, c
                                         _ptr(win.rays_index[c0:c1]), _ptr(win.numsteps[c0:c1]), _ptr(win.counter2[c0:c1]),
                                         _ptr(win.xyz[c0:c1]) if win.xyz is not None else None, win.coords_stride if win.xyz is not None else 0,
                                         _ptr(ws), ws.numel(), _stream()), 'xr_rays_sampler_series')
-    _lib.check(L.xr_clip_numsteps_series(_ptr(win.numsteps[c0:c1]), _ptr(win.counter2[c0:c1]), n, n_chunks, win.ray_stride, max_compacted,
-                                         _ptr(win.clipped[c0:c1]), _ptr(win.n_valid[c0:c1]), _stream()), 'xr_clip_numsteps_series')
+    _lib.check(L.xr_clip_numsteps(_ptr(win.numsteps[c0:c1]), _ptr(win.counter2[c0:c1]), n, n_chunks, win.ray_stride, max_compacted,
+                                         _ptr(win.clipped[c0:c1]), _ptr(win.n_valid[c0:c1]), _stream()), 'xr_clip_numsteps')
     return cur
 
 
@@ -427,7 +426,7 @@ def ngp_train_step(table, wd, wc, nhd, nhc, pad_value, meta, coords, n_dev, nums
         if coords.shape[0] < n_rows or coords.shape[1] != 7 or not coords.is_contiguous():
             raise _lib.XrError('coords must be contiguous [>= n_rows, 7] rows')
         s, r, o = meta._args()
-        _ws(coords.device, L.xr_nerf_mlp_bwd_workspace_bytes2(n_rows, nhd, nhc), 'mlpbwd')
+        _ws(coords.device, L.xr_nerf_mlp_bwd_workspace_bytes(n_rows, nhd, nhc), 'mlpbwd')
         ws_sc = _ws(coords.device, L.xr_hashgrid_bwd_workspace_bytes(n_rows, meta.n_levels, r, o), 'hgb')
         # the backward's (count, running live total, running valid total) block sits in the MLP workspace on this path
         ws_mlp, live_list, _, live_stats = _list_slots(coords.device, n_rows, nhd, nhc)
@@ -465,11 +464,6 @@ def ngp_train_step(table, wd, wc, nhd, nhc, pad_value, meta, coords, n_dev, nums
 def record_event(cevent):
     """record a library event (_CEvent) on the current stream"""
     _lib.check(_lib.load().xr_event_record(cevent.h, _stream()), 'xr_event_record')
-
-
-def stream_wait_event(stream, cevent):
-    """order a torch stream behind a library event (_CEvent)"""
-    _lib.check(_lib.load().xr_stream_wait_event(C.c_void_p(stream.cuda_stream), cevent.h), 'xr_stream_wait_event')
 
 
 def calc_rgb_inference(raw, coords, numsteps, bg3, rgb_act, density_act):
@@ -510,14 +504,14 @@ def generate_grid_samples(grid, ema_step, n_elements, n_cascades, thresh, aabb, 
     if planes_out is not None:
         if n_elements:
             _ptr(planes_out); _ptr(idx_out)
-            _lib.check(L.xr_generate_grid_samples2(_ptr(grid), ema_step, n_elements, n_cascades, thresh, aabb[0], aabb[1], st, inc,
+            _lib.check(L.xr_generate_grid_samples(_ptr(grid), ema_step, n_elements, n_cascades, thresh, aabb[0], aabb[1], st, inc,
                                                    C.c_void_p(planes_out.data_ptr() + 4 * offset), 1, planes_out.stride(0),
                                                    C.c_void_p(idx_out.data_ptr() + 4 * offset), _stream()), 'xr_generate_grid_samples')
         return planes_out[:, offset:offset + n_elements], idx_out[offset:offset + n_elements]
     pos = torch.empty((n_elements, 3), dtype=torch.float32, device=dev)
     idx = torch.empty((n_elements,), dtype=torch.int32, device=dev)
     _lib.check(L.xr_generate_grid_samples(_ptr(grid), ema_step, n_elements, n_cascades, thresh, aabb[0], aabb[1],
-                                          st, inc, _ptr(pos), _ptr(idx), _stream()), 'xr_generate_grid_samples')
+                                          st, inc, _ptr(pos), 3, 1, _ptr(idx), _stream()), 'xr_generate_grid_samples')
     return pos, idx
 
 
@@ -604,8 +598,8 @@ def clip_numsteps(numsteps, counter, max_compacted, out=None):
     else:
         out = torch.empty_like(numsteps)
         n_valid = torch.empty((2,), dtype=torch.int32, device=numsteps.device)
-    _lib.check(_lib.load().xr_clip_numsteps(_ptr(numsteps), _ptr(counter), n, max_compacted, _ptr(out), _ptr(n_valid),
-                                            max_compacted, 1, _stream()), 'xr_clip_numsteps')
+    _lib.check(_lib.load().xr_clip_numsteps(_ptr(numsteps), _ptr(counter), n, 1, n, max_compacted, _ptr(out), _ptr(n_valid),
+                                            _stream()), 'xr_clip_numsteps')
     return out, n_valid
 
 
@@ -637,7 +631,7 @@ def hashgrid_fwd(table, x, meta, enc_t=None, ld=None, n_dev=None, rows=None, row
     ep = enc_t.data_ptr() + 4 * (row0 + 2 * l0 * ld)
     with _span('xr_hashgrid_fwd', 0 if n_dev is not None else n, train=n_dev is not None):
         _ptr(enc_t)
-        _lib.check(L.xr_hashgrid_fwd2(_ptr(table), C.c_void_p(xp), xs, xcs, n, _ptr(n_dev), _ptr(rows), l1 - l0, s + 4 * l0, r + 4 * l0,
+        _lib.check(L.xr_hashgrid_fwd(_ptr(table), C.c_void_p(xp), xs, xcs, n, _ptr(n_dev), _ptr(rows), l1 - l0, s + 4 * l0, r + 4 * l0,
                                       o + 4 * l0, C.c_void_p(ep), ld, _stream()), 'xr_hashgrid_fwd')
     return enc_t
 
@@ -665,7 +659,7 @@ def hashgrid_bwd(x, denc_t, meta, grad_table, n_dev=None, row0=0, count=None, le
             raise _lib.XrError('a live-row list addresses rows from 0')
         rows, n_dev = live
     with _span('xr_hashgrid_bwd', 0 if n_dev is not None else n, train=n_dev is not None):
-        _lib.check(L.xr_hashgrid_bwd2(C.c_void_p(x.data_ptr() + 4 * xs * row0), xs,
+        _lib.check(L.xr_hashgrid_bwd(C.c_void_p(x.data_ptr() + 4 * xs * row0), xs,
                                       C.c_void_p(denc_t.data_ptr() + 4 * (row0 + 2 * l0 * ld)), ld, n, _ptr(n_dev), _ptr(rows),
                                       l1 - l0, s + 4 * l0, r + 4 * l0, o + 4 * l0, _ptr(grad_table),
                                       _ptr(ws), ws.numel() if ws is not None else 0, 1 if overwrite else 0, _stream()),
@@ -824,7 +818,7 @@ def _list_slots(dev, n, nhd=1, nhc=2):
     """the list area of the MLP backward's workspace for n rows (at its start, whatever the topology the workspace is sized for)
     -> (workspace, rows view, seg pointer, count-block view)"""
     L = _lib.load()
-    ws = _ws(dev, L.xr_nerf_mlp_bwd_workspace_bytes2(n, nhd, nhc), 'mlpbwd')
+    ws = _ws(dev, L.xr_nerf_mlp_bwd_workspace_bytes(n, nhd, nhc), 'mlpbwd')
     p_rows, p_seg, p_cnt = C.c_void_p(), C.c_void_p(), C.c_void_p()
     _lib.check(L.xr_nerf_mlp_bwd_list_slots(_ptr(ws), ws.numel(), n, C.byref(p_rows), C.byref(p_seg), C.byref(p_cnt)),
                'xr_nerf_mlp_bwd_list_slots')
@@ -857,7 +851,7 @@ def live_rows(draw, n, n_dev=None, zero_denc_t=None, seg_counts=None):
     _, rows, p_seg, n_live = _list_slots(draw.device, n)
     LIVE_STATS = n_live
     with _span('xr_live_rows', 0 if n_dev is not None else n, train=n_dev is not None):
-        _lib.check(_lib.load().xr_live_rows2(_ptr(draw), n, _ptr(n_dev), p_seg if seg_counts is None else _ptr(seg_counts), _ptr(rows),
+        _lib.check(_lib.load().xr_live_rows(_ptr(draw), n, _ptr(n_dev), p_seg if seg_counts is None else _ptr(seg_counts), _ptr(rows),
                                              _ptr(n_live), _ptr(zero_denc_t), zero_denc_t.shape[1] if zero_denc_t is not None else 0,
                                              0 if seg_counts is None else 1, _stream()), 'xr_live_rows')
     return rows, n_live
@@ -894,7 +888,7 @@ def nerf_mlp_bwd(enc_t, dirs, n, w_density, w_color, nhd, nhc, draw, grad_wd, gr
     dirs, ds = _pos_view(dirs)
     if denc_t is None:
         denc_t = torch.empty_like(enc_t)
-    ws = _ws(enc_t.device, L.xr_nerf_mlp_bwd_workspace_bytes2(n, nhd, nhc), 'mlpbwd')
+    ws = _ws(enc_t.device, L.xr_nerf_mlp_bwd_workspace_bytes(n, nhd, nhc), 'mlpbwd')
     _ptr(enc_t); _ptr(draw); _ptr(denc_t)
     if count is not None:
         n = count

@@ -41,12 +41,12 @@ def rays_sampler_api(rays_o, rays_d, density_grid_bitfield, metadata, imgs_id, x
                      cone_angle_constant, coords_out, rays_index, rays_numsteps, ray_numstep_counter):
     L = _lib.load()
     n = rays_o.shape[0]
-    ws = ops._ws(rays_o.device, L.xr_rays_sampler_workspace_bytes(n), 'k1')
+    ws = ops._ws(rays_o.device, L.xr_rays_sampler_workspace_bytes(n, 1), 'k1')
     st, inc = ops.pcg32_host_state(_calls['rays_sampler'])
     _calls['rays_sampler'] += 1
     _lib.check(L.xr_rays_sampler(_p(rays_o), _p(rays_d), _p(density_grid_bitfield), n, float(aabb0), float(aabb1),
                                  float(near_distance), float(cone_angle_constant), coords_out.shape[0], st, inc,
-                                 _p(coords_out), _p(rays_index), _p(rays_numsteps), _p(ray_numstep_counter), _p(ws),
+                                 _p(coords_out), _p(rays_index), _p(rays_numsteps), _p(ray_numstep_counter), None, 0, 0, 0, 0, _p(ws),
                                  ws.numel(), ops._stream()), 'rays_sampler_api')
     _sync()
 
@@ -56,7 +56,7 @@ def compacted_coord_api(network_output, coords_in, rays_numsteps, bg_color_in, r
                         compacted_numstep_counter):
     L = _lib.load()
     n = rays_numsteps.shape[0]
-    ws = ops._ws(coords_in.device, L.xr_rays_sampler_workspace_bytes(n), 'k1')
+    ws = ops._ws(coords_in.device, L.xr_rays_sampler_workspace_bytes(n, 1), 'k1')
     _lib.check(L.xr_compacted_coord(_p(coords_in), _p(rays_numsteps), n, coords_out.shape[0], _p(coords_out),
                                     _p(rays_numsteps_compacted), _p(compacted_rays_counter),
                                     _p(compacted_numstep_counter), _p(ws), ws.numel(), ops._stream()),
@@ -97,7 +97,7 @@ def generate_grid_samples_nerf_nonuniform_api(density_grid, density_grid_ema_ste
     if n_elements > 0:
         _lib.check(_lib.load().xr_generate_grid_samples(_p(density_grid), int(density_grid_ema_step), int(n_elements),
                                                         int(max_cascade) + 1, float(thresh), float(aabb0),
-                                                        float(aabb1), st, inc, _p(density_grid_positions_uniform),
+                                                        float(aabb1), st, inc, _p(density_grid_positions_uniform), 3, 1,
                                                         _p(density_grid_indices_uniform), ops._stream()),
                    'generate_grid_samples_nerf_nonuniform_api')
     _sync()

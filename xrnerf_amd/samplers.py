@@ -32,6 +32,53 @@ from ._fastattr import _FastAttr
 from .builder import SAMPLERS
 
 
+class _Marched:
+    """One iteration of a marched window (NGPGridSampler.march_window), as the sampler's / trainer's queues hold it.  Read like the dict
+    it replaces (`pf['out']`, `pf.get('xyz')`), but the tensor views are made when somebody asks: building ~20 views for each of 15
+    iterations cost the refresh iteration ~150 us of host time in front of its own march (profiles/r05_trace_refresh_iteration*.txt),
+    and the native loop needs none of them."""
+    __slots__ = ('window', 'slot', 'n', 'max_samples', 'iter', 'k1_index', 'cur_ray', 'batch_index', 'event', 'gate', 'host_ev')
+    _SCALARS = frozenset(__slots__)
+
+    def __init__(self, **kw):
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+    def matches(self, rays_o, max_samples):
+        """is `rays_o` this iteration's batch (the chunk's rows of the window, by address)?"""
+        w = self.window
+        return (rays_o.data_ptr() == w.rays_o.data_ptr() + 12 * self.slot * w.ray_stride and rays_o.shape[0] == self.n
+                and self.max_samples == max_samples)
+
+    def batch(self):
+        return self.window.batch(self.slot, self.n)
+
+    def __getitem__(self, k):
+        if k in self._SCALARS:
+            return getattr(self, k)
+        w, c, n = self.window, self.slot, self.n
+        if k == 'rays_o':
+            return w.rays_o[c, :n]
+        if k == 'out':
+            return (w.coords[c][:self.max_samples], w.rays_index[c][:n], w.numsteps[c][:n], w.counter2[c])
+        if k == 'clipped':
+            return (w.clipped[c][:n], w.n_valid[c])
+        if k == 'xyz':
+            return w.xyz[c] if w.xyz is not None else None
+        if k == 'host':
+            return (self.host_ev, w.pinned[c]) if w.pinned is not None else (None, w.counter2[c])
+        raise KeyError(k)
+
+    def get(self, k, default=None):
+        try:
+            return self[k]
+        except KeyError:
+            return default
+
+    def __contains__(self, k):
+        return k in self._SCALARS or k in ('rays_o', 'out', 'clipped', 'xyz', 'host')
+
+
 @SAMPLERS.register_module()
 class NGPGridSampler(_FastAttr, nn.Module):
     # per-step state (never a Parameter, a registered buffer or a sub-module): assigned ~15 times per training iteration
@@ -245,8 +292,7 @@ class NGPGridSampler(_FastAttr, nn.Module):
             self.rewind_marches()
         # (marches for LATER iterations -- issued a moment ago from on_refreshed -- stay queued)
         pf = q.pop(0) if (is_training and q and q[0].get('iter', self.iter_n) <= self.iter_n) else None
-        if (pf is not None and pf['rays_o'].data_ptr() == data['rays_o'].data_ptr() and
-                pf['rays_o'].shape == data['rays_o'].shape and pf['max_samples'] == max_samples):
+        if pf is not None and pf.matches(data['rays_o'], max_samples):
             # K1 of this batch already ran (march_window, right behind the window's grid refresh): order this stream after it -- once
             # per window -- and adopt its outputs
             self._wait_march(pf)
@@ -467,7 +513,7 @@ class NGPGridSampler(_FastAttr, nn.Module):
         [N, 11] ray table, cur_ray / batch_call_index = HashBatchSample's cursor and the batch generator's call index for the first
         batch drawn here (the first `batches_ready` iterations already hold their batch in their chunk).  on_side: on the side stream,
         behind the last refresh (beside the refresh iteration's own step); else on the current stream.
-        -> (cursor behind the last batch, [batch dict per iteration])"""
+        -> (cursor behind the last batch, [the queued entry per iteration: `.batch()` gives its batch dict])"""
         n = int(n_rays)
         max_samples = self.train_max_samples(n)
         win = self.window_for(n, max_samples)
@@ -511,19 +557,10 @@ class NGPGridSampler(_FastAttr, nn.Module):
         self.k1_calls = k1_0 + n_iters
         gate = {'waited': ev is None}
         q = self.__dict__.setdefault('_prefetched_q', [])
-        batches = []
-        for j in range(n_iters):
-            c = c0 + j
-            b = win.batch(c, n)
-            host = (host_ev, win.pinned[c]) if win.pinned is not None else (None, win.counter2[c])
-            q.append({'rays_o': b['rays_o'], 'max_samples': max_samples,
-                      'out': (win.coords[c][:max_samples], win.rays_index[c][:n], win.numsteps[c][:n], win.counter2[c]),
-                      'event': ev, 'gate': gate, 'host': host, 'clipped': (win.clipped[c][:n], win.n_valid[c]),
-                      'xyz': win.xyz[c] if win.xyz is not None else None, 'slot': c, 'window': win, 'iter': first_iter + j,
-                      'k1_index': k1_0 + j, 'cur_ray': cursors[j], 'batch_index': batch_call_index + max(j - batches_ready, 0),
-                      'drawn_here': j >= batches_ready})
-            batches.append(b)
-        return end, batches
+        made = [_Marched(window=win, slot=c0 + j, n=n, max_samples=max_samples, iter=first_iter + j, k1_index=k1_0 + j, cur_ray=cursors[j],
+                         batch_index=batch_call_index + max(j - batches_ready, 0), event=ev, gate=gate, host_ev=host_ev) for j in range(n_iters)]
+        q.extend(made)
+        return end, made
 
     def rewind_marches(self):
         """Take back the marches issued ahead and not consumed yet: the hidden generator's call counter goes back to the first of them

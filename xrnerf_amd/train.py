@@ -272,7 +272,7 @@ class Trainer:
         # ray table); anything else keeps the per-iteration path.
         self.native_loop = opts['native_loop']
         self._loop = None
-        self._queue = []               # [(iteration, batch)] marched ahead, in order
+        self._queue = []               # [(iteration, the sampler's queued entry)] marched ahead, in order (entry.batch(): its batch dict)
         self._one = None
 
     def step(self):
@@ -371,7 +371,7 @@ class Trainer:
             g['lr'] = step_lr(self.base_lr, self.iter)
         if self._queue and self._queue[0][0] < self.iter:
             net.sampler.rewind_marches()                                  # marched for iterations that are over
-        batch = self._queue.pop(0)[1] if (self._queue and self._queue[0][0] == self.iter) else None
+        batch = self._queue.pop(0)[1].batch() if (self._queue and self._queue[0][0] == self.iter) else None
         if batch is None:
             batch = self._draw()
         n_rays = batch['rays_o'].shape[0]
@@ -429,10 +429,10 @@ class Trainer:
         n_iters = min(f - (it + 1) % f, W - (it + 1) % W)             # up to the next refresh, inside the window's chunks
         data = self.data
         n = min(data.N_rand, data.rays_rgb.shape[0])
-        end, batches = sampler.march_window(data.rays_rgb, data.cur_i, data.batches_drawn, it + 1, n_iters, n,
-                                            on_side=self.march_window == 'side')
+        end, made = sampler.march_window(data.rays_rgb, data.cur_i, data.batches_drawn, it + 1, n_iters, n,
+                                         on_side=self.march_window == 'side')
         data.cur_i, data.batches_drawn = end, data.batches_drawn + n_iters
-        self._queue.extend((it + 1 + j, b) for j, b in enumerate(batches))
+        self._queue.extend((it + 1 + j, pf) for j, pf in enumerate(made))
 
     def _on_sampled(self):
         """Called by the sampler as soon as THIS iteration's samples exist (and the step is enqueued)"""
@@ -550,7 +550,7 @@ class _NativeLoop:
             raise _lib.XrError('a native window never crosses a grid refresh')
         dev = tr.device
         pfs = q[:k]
-        win, n_rays, max_samples = pfs[0]['window'], pfs[0]['rays_o'].shape[0], pfs[0]['max_samples']
+        win, n_rays, max_samples = pfs[0]['window'], pfs[0]['n'], pfs[0]['max_samples']
         n_rows = min(sampler.target_batch_size, max_samples)
         table, wd, wc = mlp.embedder_pos.params, mlp.density_net.params, mlp.color_net.params
         meta = mlp.embedder_pos.meta
