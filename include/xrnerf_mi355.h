@@ -234,6 +234,11 @@ int xr_hashgrid_bwd(const float* x, uint32_t x_stride, const float* denc_t, uint
                     const uint32_t* n_dev, const uint32_t* rows, int n_levels, const float* scale_host, const uint32_t* resolution_host,
                     const uint32_t* offset_host, float* grad_table, void* workspace, size_t workspace_bytes, int flags,
                     void* stream);
+/* The scatter (and with it xr_ngp_train_step / xr_ngp_loop_run) can run its small dense levels, the reduction of the MLP gradients and
+ * the small optimiser launches on a HELPER stream beside its two large kernels.  The library creates no stream or event: the caller
+ * hands over one stream and two events (fork / join; plain hipEvent_t, timing not needed) once per host thread; null stream = none,
+ * everything then runs in order on the caller's stream (same results). */
+int xr_set_helper_stream(void* stream, void* fork_event, void* join_event);
 /* tcnn.Encoding otype=SphericalHarmonics degree 4; dirs in [0,1] (the sampler's warp_direction);
  * out row-major [n,16] */
 int xr_sh4(const float* dirs, uint32_t dir_stride, uint32_t n, float* out, void* stream);

@@ -118,6 +118,9 @@ __host__ __device__ inline float xr_unwarp_dt(float dt) {   // ray_sampler_heade
 // rows per segment of the live-row compaction (xr_live_rows counts / ranks per segment; xr_composite_train2 can produce the counts)
 #define XR_LIVE_SEG 1024u
 
+// the caller-provided helper stream of this thread (xr_set_helper_stream), or nullptr: see xr_scatter.hip
+struct XrHelper { hipStream_t stream; hipEvent_t fork, join; };
+const XrHelper* xr_internal_helper();
 // library-internal (not part of the C ABI): see xr_mlp.hip
 void xr_internal_defer_mlp_reduce(bool on);
 int xr_internal_mlp_bwd_reduce(const void* workspace, uint32_t n, int n_hidden_density, int n_hidden_color, float* grad_w_density, float* grad_w_color, int overwrite, void* stream);

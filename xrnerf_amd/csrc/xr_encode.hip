@@ -343,15 +343,11 @@ extern "C" int xr_hashgrid_bwd(const float* x, uint32_t x_stride, const float* d
     // helper stream when both exist (disjoint table slices)
     uint32_t amask = xr_scatter3_atomic_mask(n, gm, hm, workspace && ((uintptr_t)workspace & 15) == 0 && ((uintptr_t)grad_table & 15) == 0);
     const uint32_t all = (1u << n_levels) - 1u;
-    static hipStream_t aux = nullptr;
-    static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    const bool fork = amask != 0 && amask != all;
+    const XrHelper* hp = xr_internal_helper();            // the caller's helper stream (xr_set_helper_stream); none: in order on `stream`
+    const bool fork = hp && amask != 0 && amask != all;
+    const hipStream_t aux = hp ? hp->stream : nullptr;
+    const hipEvent_t ev_fork = hp ? hp->fork : nullptr, ev_join = hp ? hp->join : nullptr;
     if (fork) {
-        if (!aux) {
-            XR_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
-            XR_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-            XR_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-        }
         XR_HIP(hipEventRecord(ev_fork, stream));
         XR_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
     }

@@ -1245,7 +1245,7 @@ extern "C" int xr_composite_train(const float* network_output, const float* coor
         return XR_OK;
     }
     const int stage = XR_CT_STAGE;
-    static bool attr_set = false;
+    static thread_local bool attr_set = false;
     if (!attr_set) {
         XR_HIP(hipFuncSetAttribute((const void*)k_composite_train, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CT_LDS_BYTES));
         attr_set = true;

@@ -803,6 +803,16 @@ uint32_t xr_scatter3_atomic_mask(uint32_t n, const GridMeta& gm, uint32_t hashed
 }
 
 static thread_local XrAuxPrologue* g_aux_prologue = nullptr;
+// The scatter runs its small dense levels (and a training step's reductions / small updates) on a HELPER stream beside the bin /
+// accumulate pair.  The stream and the two events that fork it from and join it into the caller's stream are the CALLER's
+// (xr_set_helper_stream, per host thread): the library creates nothing.  Without them everything runs on the caller's stream.
+static thread_local XrHelper g_helper = {nullptr, nullptr, nullptr};
+const XrHelper* xr_internal_helper() { return g_helper.stream ? &g_helper : nullptr; }
+extern "C" int xr_set_helper_stream(void* stream, void* fork_event, void* join_event) {
+    XR_REQUIRE(!stream || (fork_event && join_event), "a helper stream comes with its fork and join events");
+    g_helper.stream = (hipStream_t)stream; g_helper.fork = (hipEvent_t)fork_event; g_helper.join = (hipEvent_t)join_event;
+    return XR_OK;
+}
 void xr_internal_scatter_aux_prologue(XrAuxPrologue* p) { g_aux_prologue = p; }
 
 int xr_scatter3(const float* x, uint32_t x_stride, const float* denc_t, uint32_t ld, uint32_t n, const uint32_t* n_dev,
@@ -825,7 +835,7 @@ int xr_scatter3(const float* x, uint32_t x_stride, const float* denc_t, uint32_t
     float4* bins = (float4*)((char*)workspace + P.counts_bytes);
     float4* ovf = (float4*)((char*)workspace + P.counts_bytes + P.bins_bytes);
     float2* slabs = (float2*)((char*)workspace + P.counts_bytes + P.bins_bytes + P.ovf_bytes);
-    static bool attr_set = false;
+    static thread_local bool attr_set = false;        // (idempotent: a second thread setting it again is harmless)
     if (!attr_set) {
         XR_HIP(hipFuncSetAttribute((const void*)k_scatter_accum3<S3_LOG2, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES));
         XR_HIP(hipFuncSetAttribute((const void*)k_scatter_accum3<S3_LOG2, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES));
@@ -835,14 +845,10 @@ int xr_scatter3(const float* x, uint32_t x_stride, const float* denc_t, uint32_t
     // the small dense levels' two kernels are enqueued first, on an internal helper stream beside the bin / accumulate pair (disjoint
     // table slices, read-only inputs), forked from and joined back into the caller's stream with events
     const int rl_first = 1, rl_async = S3_RL_ASYNC;
-    static hipStream_t aux = nullptr;
-    static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    const bool fork = rl_async && P.rl.n_lv > 0 && P.bin.n_lv > 0;
-    if (fork && !aux) {
-        XR_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
-        XR_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-        XR_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-    }
+    const XrHelper* hp = xr_internal_helper();
+    const bool fork = rl_async && hp && P.rl.n_lv > 0 && P.bin.n_lv > 0;
+    const hipStream_t aux = hp ? hp->stream : nullptr;
+    const hipEvent_t ev_fork = hp ? hp->fork : nullptr, ev_join = hp ? hp->join : nullptr;
     // the caller's small kernels (xr_ngp_train_step: reduction of the MLP partials, MLP Adam, loss scalars, a clear) run on the helper
     // stream BEHIND the dense levels' two kernels: those then start beside the bin kernel instead of 40 us into the accumulate
     // kernel, whose HBM streams they disturb (scatter 181 -> 172 us, profiles/r03_aux_kernels_last_ab.txt)

@@ -199,6 +199,25 @@ def _buf(device, shape, tag):
     return w[off:off + 4 * n].view(torch.float32).view(*shape)
 
 
+_helpers = {}
+
+
+def _ensure_helper(device):
+    """hand the library this thread's helper stream (xr_set_helper_stream): one stream + fork / join events per device and host thread,
+    created HERE -- the library itself creates nothing.  Without it the scatter's side work runs in order on the compute stream."""
+    import threading
+    key = (str(device), threading.get_ident())
+    if key in _helpers or device.type != 'cuda':
+        return
+    st = torch.cuda.Stream(device=device)
+    evs = (torch.cuda.Event(), torch.cuda.Event())
+    for e in evs:
+        e.record(st)                               # (torch creates the underlying event at its first record)
+    _lib.check(_lib.load().xr_set_helper_stream(C.c_void_p(st.cuda_stream), C.c_void_p(evs[0].cuda_event), C.c_void_p(evs[1].cuda_event)),
+               'xr_set_helper_stream')
+    _helpers[key] = (st, evs)
+
+
 def pcg32_host_state(ncalls, seed=9121):
     s, i = C.c_uint64(), C.c_uint64()
     _lib.load().xr_pcg32_host_state(seed, ncalls, C.byref(s), C.byref(i))
@@ -426,6 +445,7 @@ def ngp_train_step(table, wd, wc, nhd, nhc, pad_value, meta, coords, n_dev, nums
         if coords.shape[0] < n_rows or coords.shape[1] != 7 or not coords.is_contiguous():
             raise _lib.XrError('coords must be contiguous [>= n_rows, 7] rows')
         s, r, o = meta._args()
+        _ensure_helper(coords.device)
         _ws(coords.device, L.xr_nerf_mlp_bwd_workspace_bytes(n_rows, nhd, nhc), 'mlpbwd')
         ws_sc = _ws(coords.device, L.xr_hashgrid_bwd_workspace_bytes(n_rows, meta.n_levels, r, o), 'hgb')
         # the backward's (count, running live total, running valid total) block sits in the MLP workspace on this path
@@ -644,6 +664,7 @@ def hashgrid_bwd(x, denc_t, meta, grad_table, n_dev=None, row0=0, count=None, le
     `live=(rows, n_live)` (ops.live_rows): only the listed rows are scattered.
     `overwrite=True` (XR_SCATTER_OVERWRITE): the levels' slices of grad_table are written instead of added to."""
     L = _lib.load()
+    _ensure_helper(denc_t.device)
     x, xs = _pos_view(x)
     n = x.shape[0] if count is None else count
     s, r, o = meta._args()
@@ -688,6 +709,7 @@ def hashgrid_bwd_adam(x, denc_t, meta, adam, n_dev=None, live=None, count=None):
     """the table scatter with the optimiser's update in place of the gradient write (xr_hashgrid_bwd_adam): the tensors named
     by `adam` (ops.adam_fuse) are updated exactly as hashgrid_bwd(overwrite=True) + adam_step_multi would; no gradient is produced"""
     L = _lib.load()
+    _ensure_helper(denc_t.device)
     x, xs = _pos_view(x)
     n = x.shape[0] if count is None else count
     s, r, o = meta._args()
