@@ -941,6 +941,7 @@ def main():
             'value': rays_all / elapsed_max, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': elapsed_max * 1e3 / args.steps, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'library_build': __import__('xrnerf_amd.build', fromlist=['info']).info(),
             'parity': 'partial: sampling / compositing / grid upkeep pinned to the reference kernels (bit-exact indices and '
                       'counts, <=1e-4 fp32); hash grid + SH + fused MLP restate tiny-cuda-nn, which is absent from the '
                       'reference tree (parity unpinned)',

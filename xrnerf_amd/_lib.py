@@ -176,13 +176,20 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    from . import build as _build
+    stale = False
+    if not os.environ.get('XRNERF_LIB') and os.path.exists(LIB_PATH) and os.path.isdir(_build.CSRC):
+        # the binary beside the sources must be the build OF those sources (build.py stamps every build with both hashes)
+        i = _build.info()
+        stale = i.get('stamp') == 'missing' or not i.get('binary_is_the_stamped_build') or i.get('sources_match_the_stamped_build') is False
+    if not os.path.exists(LIB_PATH) or stale:
         try:
-            from . import build as _build
-            _build.build()
+            _build.build(force=stale)
         except Exception as e:  # noqa: BLE001
-            raise XrError('libxrnerf_mi355.so is missing and could not be built: %s. '
-                          'Run `python -m xrnerf_amd.build` (needs hipcc).' % e)
+            if not os.path.exists(LIB_PATH):
+                raise XrError('libxrnerf_mi355.so is missing and could not be built: %s. '
+                              'Run `python -m xrnerf_amd.build` (needs hipcc).' % e)
+            raise XrError('libxrnerf_mi355.so is not the build of the sources beside it and could not be rebuilt: %s' % e)
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError here = header/library mismatch: fail loudly

@@ -46,6 +46,27 @@ def _hipcc():
             return c
 
 
+def sources_hash():
+    """sha256 over the library's sources (csrc/*, the public header, this recipe) in a fixed order"""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.h')))
+    for f in files + [os.path.join(HERE, '..', 'include', 'xrnerf_mi355.h'), os.path.abspath(__file__)]:
+        h.update(os.path.basename(f).encode() + b'\0')
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+STAMP = OUT + '.stamp'          # "<sources hash> <library hash>" written by the build that produced OUT
+
+
+def _file_hash(path):
+    import hashlib
+    with open(path, 'rb') as fh:
+        return hashlib.sha256(fh.read()).hexdigest()
+
+
 def _stale(dst, srcs):
     if not os.path.exists(dst):
         return True
@@ -89,7 +110,28 @@ def build(force=False, verbose=False):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('link failed: %s\n%s' % (' '.join(cmd), r.stdout + r.stderr))
+        with open(STAMP, 'w') as fh:
+            fh.write('%s %s\n' % (sources_hash(), _file_hash(OUT)))
+        global BUILT_HERE
+        BUILT_HERE = True
     return OUT
+
+
+BUILT_HERE = False
+
+
+def info():
+    """where the loaded binary comes from: was it compiled in this process, and is it the build of exactly the sources beside it?"""
+    out = {'library': os.path.basename(OUT), 'compiled_in_this_process': BUILT_HERE}
+    try:
+        src, lib = open(STAMP).read().split()
+        out['library_sha16'] = _file_hash(OUT)[:16]
+        out['binary_is_the_stamped_build'] = lib == _file_hash(OUT)
+        out['sources_match_the_stamped_build'] = src == sources_hash() if os.path.isdir(CSRC) else None
+        out['sources_sha16'] = src[:16]
+    except (OSError, ValueError):
+        out['stamp'] = 'missing'
+    return out
 
 
 if __name__ == '__main__':
