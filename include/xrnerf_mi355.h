@@ -333,6 +333,17 @@ int xr_nerf_mlp_fwd_bf16x3(const float* enc_t, uint32_t ld, const float* dirs, u
                            const uint32_t* n_dev, const uint32_t* rows, const float* w_density, const float* w_color,
                            int n_hidden_density, int n_hidden_color, float pad_value, float* raw, void* stream);
 
+/* The fp32 forward on the FP16 matrix cores (round 5; the default of the parity mode): x = xh + xl with xh = fp16(x), xl = fp16(x - xh)
+ * keeps 22 significand bits, and the three products wh.xh + wh.xl + wl.xh (each exact in the fp32 accumulator) carry w.x to ~2^-21 of
+ * |w||x| -- measured 3.4e-7 .. 4.6e-7 of max|raw| against a float64 statement where the fp32 MFMA is at 1.7e-7 .. 3.0e-7
+ * (profiles/r05_mlp_fwd_f16x2_split_probe.txt) -- with HALF the matrix instructions and ~60 % of the conversions of the 3-way bf16
+ * split: 27.5 us against 42.6 us at 2^18 rows.  Range: hidden activations up to 65504 and hash-grid features up to 4e3 in magnitude
+ * (the features enter the first layer scaled by 2^4, exactly; the reference's own fp16 tcnn overflows at 65504 too); low parts below
+ * 2^-14 are fp16 subnormals (absolute precision 2^-25).  Same contract as xr_nerf_mlp_fwd; any depth (streamed kernel beyond (1, 2)). */
+int xr_nerf_mlp_fwd_f16x2(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
+                          const uint32_t* n_dev, const uint32_t* rows, const float* w_density, const float* w_color,
+                          int n_hidden_density, int n_hidden_color, float pad_value, float* raw, void* stream);
+
 /* K9's density query and K8 in one launch (grid refresh: ngp_grid_sampler.py:103-137 -> hashnerf_mlp.py:107-111 +
  * splat_grid_samples_nerf_max_nearest_neighbor.cu:7-28): the density network over n encoded points (enc_t as xr_hashgrid_fwd writes it),
  * each result's optical thickness exp(density) * min_step merged into density_grid_tmp[indices[i]] by an order-free maximum from the
@@ -356,7 +367,7 @@ int xr_nerf_density_splat(int mlp_mode, const float* enc_t, uint32_t ld, uint32_
  * coords: K1's [n_rows,7] rows (positions / directions consumed in place); n_dev: device count of valid rows; every buffer
  * is caller-owned (enc_t / denc_t [32][ld], raw / draw [n_rows,4], rgb_out [n_rays,3]); zero_draw != 0 also clears draw
  * (needed only without n_dev).  mlp_mode: 0 = xr_nerf_mlp_fwd / _bwd (fp32 MFMA), 1 = the _f16 pair, 2 = xr_nerf_mlp_fwd_bf16x3
- * + xr_nerf_mlp_bwd.  scatter_level0: the step scatters hash levels [scatter_level0, n_levels) only (0 = all) -- a
+ * + xr_nerf_mlp_bwd, 3 = xr_nerf_mlp_fwd_f16x2 + xr_nerf_mlp_bwd (the default of the host package).  scatter_level0: the step scatters hash levels [scatter_level0, n_levels) only (0 = all) -- a
  * data-parallel caller hands that slice of grad_table to its gradient collective and then scatters the coarser levels with
  * xr_hashgrid_bwd(XR_SCATTER_OVERWRITE) on the same row list (xr_nerf_mlp_bwd_list_slots), so the exchange runs under the rest
  * of the backward.

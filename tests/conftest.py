@@ -44,3 +44,30 @@ def dev():
 
 def bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def grad_close(got, ref, what='', kinks=None):
+    """Gradient parity against the oracle.  The bar is max|got - ref| <= 1e-3 * max(1, max|ref|).
+
+    The default backward recomputes the hidden activations with the forward's arithmetic (fp16 2-way operand split,
+    ~4e-7 relative -- see profiles/r05_mlp_fwd_f16x2_split_probe.txt) while the oracle recomputes them in float64: a hidden
+    unit whose pre-activation lies within that distance of zero can land on the other side of the ReLU, and then ONE sample's
+    contribution to a weight entry appears or disappears.  That is a property of ReLU under any two summation orders, not of the
+    kernel (tests/test_gpu_tcnn.py::test_nerf_mlp_bwd_split_recompute_differs_by_relu_kinks_only shows these are the only
+    differences), so where the recompute is the split one (`kinks`, default: XR_MLP_BWD_DW unset or 'h2f') a SMALL number of
+    entries may exceed the bar, bounded three ways: at most 5 % of the entries, none beyond 1e-2 * max, and the whole difference
+    within 5e-3 of the reference in the 2-norm.  With the fp32 recompute (f32 / b2 / b2x) the plain bar applies."""
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape and np.isfinite(got).all(), what
+    if kinks is None:
+        kinks = os.environ.get('XR_MLP_BWD_DW', 'h2f') == 'h2f'
+    scale = max(1.0, float(np.abs(ref).max())) if ref.size else 1.0
+    err = np.abs(got - ref)
+    worst = float(err.max()) if err.size else 0.0
+    if worst <= 1e-3 * scale:
+        return
+    assert kinks, (what, worst, scale)
+    over = float((err > 1e-3 * scale).mean())
+    rel2 = float(np.linalg.norm(got - ref)) / max(float(np.linalg.norm(ref)), 1e-30)
+    assert over <= 0.05 and worst <= 1e-2 * scale and rel2 <= 5e-3, (what, worst, scale, over, rel2)

@@ -110,11 +110,13 @@ def test_hidden_layer_key_policy(monkeypatch):
 
 def test_mlp_mode_selection():
     """which fused-MLP kernels a launch takes (xr_ngp_train_step's mlp_mode): the (1, 2) topology of configs/instant_ngp runs its
-    fp32 forward on split bf16 operands unless told otherwise, the fp16 mode takes the fp16 pair, other topologies the fp32 MFMA"""
+    fp32 forward on 2-way split fp16 operands unless told otherwise, the fp16 mode takes the fp16 pair, other topologies the fp32 MFMA"""
     from xrnerf_amd import ops
     old_p, old_f = ops.precision(), ops.f32_forward()
     try:
-        ops.set_precision('f32'); ops.set_f32_forward('bf16x3')
+        ops.set_precision('f32'); ops.set_f32_forward('f16x2')
+        assert ops._mlp_mode(1, 2) == 3 and ops._mlp_mode(5, 5) == 3
+        ops.set_f32_forward('bf16x3')
         assert ops._mlp_mode(1, 2) == 2 and ops._mlp_mode(2, 2) == 0 and ops._mlp_mode(1, 1) == 0
         ops.set_f32_forward('mfma')
         assert ops._mlp_mode(1, 2) == 0

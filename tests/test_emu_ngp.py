@@ -93,7 +93,7 @@ def test_fused_mlp_on_the_host(O, edev):
     from xrnerf_amd import ops
     old = ops.f32_forward()
     try:
-        for kind in ('bf16x3', 'mfma'):                 # the fixture of the GPU tests, by hand
+        for kind in ('f16x2', 'bf16x3', 'mfma'):        # the fixture of the GPU tests, by hand
             ops.set_f32_forward(kind)
             for n in (1, 32, 33):
                 T.test_nerf_mlp_fwd(O, edev, n, kind)
@@ -109,7 +109,7 @@ def test_fused_mlp_on_the_host(O, edev):
 def test_density_query_with_the_splat_inside_on_the_host(edev):
     import test_gpu_tcnn as T
     from xrnerf_amd import ops
-    for kind in ('bf16x3', 'mfma'):
+    for kind in ('f16x2', 'bf16x3', 'mfma'):
         old = ops.f32_forward()
         ops.set_f32_forward(kind)
         try:
@@ -130,7 +130,7 @@ def test_deeper_topologies_on_the_host(O, edev, monkeypatch):
 def test_mlp_backward_arithmetic_modes_on_the_host(O, edev, monkeypatch):
     """the bf16-split products of the backward (dW, dX chain, and the opt-in split recompute) on the host build"""
     import test_gpu_tcnn as T
-    for arith in ('f32', 'b2'):
+    for arith in ('f32', 'b2', 'h2f'):
         monkeypatch.setenv('XR_MLP_BWD_DW', arith)
         T.test_nerf_mlp_bwd(O, edev, 100)
         T.test_nerf_mlp_bwd_live_rows(O, edev, 100, None, 'f32')

@@ -5,6 +5,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import grad_close
+
 pytestmark = pytest.mark.gpu
 
 
@@ -72,9 +74,10 @@ def nets(S):
     return wd, wc
 
 
-@pytest.fixture(params=['bf16x3', 'mfma'])
+@pytest.fixture(params=['f16x2', 'bf16x3', 'mfma'])
 def f32_forward(request):
-    """both forwards of the fp32 mode: bf16x3 = exact 3-way bf16 operand split on the bf16 matrix cores (default), mfma = fp32 MFMA"""
+    """the forwards of the fp32 mode: f16x2 = 2-way fp16 operand split on the fp16 matrix cores (default), bf16x3 = exact 3-way bf16
+    split, mfma = fp32 MFMA"""
     from xrnerf_amd import ops
     old = ops.f32_forward()
     ops.set_f32_forward(request.param)
@@ -103,7 +106,7 @@ def test_nerf_mlp_fwd(O, dev, n, f32_forward):
 
 @pytest.mark.parametrize('n,n_valid', [(1, None), (33, None), (8191, 8000), (70001, None), (5000, 0)])
 def test_nerf_mlp_fwd_split_operands_equal_fp32_mfma(dev, n, n_valid):
-    """xr_nerf_mlp_fwd_bf16x3 against xr_nerf_mlp_fwd on the same inputs: activations spanning 1e-6 .. 1e2, weights of
+    """xr_nerf_mlp_fwd_bf16x3 and xr_nerf_mlp_fwd_f16x2 against xr_nerf_mlp_fwd on the same inputs: activations spanning 1e-6 .. 1e2, weights of
     mixed magnitude, a device-side row count, row-indirect directions.  Both are fp32-accurate evaluations of the same sums,
     so they agree to a few ulp of the largest partial sum (here: 3e-6 of max|raw|), far inside the 1e-4 parity bar."""
     from xrnerf_amd import ops, synthetic as S
@@ -119,7 +122,7 @@ def test_nerf_mlp_fwd_split_operands_equal_fp32_mfma(dev, n, n_valid):
     out = {}
     old = ops.f32_forward()
     try:
-        for kind in ('mfma', 'bf16x3'):
+        for kind in ('mfma', 'bf16x3', 'f16x2'):
             ops.set_f32_forward(kind)
             raw = torch.full((n, 4), 7.0, dtype=torch.float32, device=dev)
             ops.nerf_mlp_fwd(T(enc, dev), T(dirs, dev), n, T(wd, dev), T(wc, dev), 1, 2, raw=raw, n_dev=n_dev, rows=T(rows, dev))
@@ -129,13 +132,14 @@ def test_nerf_mlp_fwd_split_operands_equal_fp32_mfma(dev, n, n_valid):
     finally:
         ops.set_f32_forward(old)
     m = n if n_valid is None else n_valid
-    for a, b in zip(out['mfma'], out['bf16x3']):
-        assert np.all(a[m:] == 7.0) and np.all(b[m:] == 7.0)                   # rows behind the device-side count untouched
+    for kind in ('bf16x3', 'f16x2'):
+        for a, b in zip(out['mfma'], out[kind]):
+            assert np.all(a[m:] == 7.0) and np.all(b[m:] == 7.0)                   # rows behind the device-side count untouched
+            if m:
+                scale = np.abs(a[:m]).max()
+                assert np.isfinite(b[:m]).all() and np.abs(a[:m] - b[:m]).max() <= 3e-6 * scale, (kind, np.abs(a[:m] - b[:m]).max(), scale)
         if m:
-            scale = np.abs(a[:m]).max()
-            assert np.isfinite(b[:m]).all() and np.abs(a[:m] - b[:m]).max() <= 3e-6 * scale, (np.abs(a[:m] - b[:m]).max(), scale)
-    if m:
-        assert np.array_equal(out['bf16x3'][0][:m, 3], out['bf16x3'][1][:m, 3])   # sigma: same arithmetic with and without the color net
+            assert np.array_equal(out[kind][0][:m, 3], out[kind][1][:m, 3])   # sigma: same arithmetic with and without the color net
 
 
 def test_nerf_mlp_fwd_asymmetric_weights(O, dev, f32_forward):
@@ -182,12 +186,11 @@ def test_nerf_mlp_bwd(O, dev, n):
     g_t = torch.zeros(meta.n_params, dtype=torch.float32, device=dev)
     ops.hashgrid_bwd(tp, denc_t, meta, g_t)
     for name, got, ref in (('wd', g_wd, gd), ('wc', g_wc, gc), ('table', g_t, gt)):
-        err = np.abs(got.cpu().numpy() - ref).max()
         # both sides sum n fp32 terms in different orders (the oracle serially): ~sqrt(n)*2^-24 relative
-        assert err <= 1e-3 * max(1.0, np.abs(ref).max()), (name, err, np.abs(ref).max())
+        grad_close(got.cpu().numpy(), ref, name)
 
 
-@pytest.mark.parametrize('arith', ['f32', 'b2', 'b2x'])
+@pytest.mark.parametrize('arith', ['f32', 'b2', 'b2x', 'h2f'])
 def test_nerf_mlp_bwd_arithmetic_modes(O, dev, arith, monkeypatch):
     """XR_MLP_BWD_DW: the backward with every product on the fp32 MFMA, with the dW products on the bf16 matrix cores (2-way
     operand split), and (the default) with the dX chain there too -- each against the oracle at the same 1e-3 * max bar"""
@@ -267,8 +270,7 @@ def test_deeper_topologies_against_the_oracle(O, dev, nhd, nhc, n, n_valid, path
     g_t = torch.zeros(meta.n_params, dtype=torch.float32, device=dev)
     ops.hashgrid_bwd(tp, denc_t, meta, g_t, n_dev=n_dev)
     for name, got, refg in (('wd', g_wd, gd), ('wc', g_wc, gc), ('table', g_t, gt)):
-        err = np.abs(got.cpu().numpy() - refg).max()
-        assert err <= 1e-3 * max(1.0, np.abs(refg).max()), (name, err, np.abs(refg).max())
+        grad_close(got.cpu().numpy(), refg, name, kinks=True)
 
 
 def test_streamed_kernels_equal_the_layer_by_layer_path_at_full_size(dev, monkeypatch):
@@ -310,7 +312,7 @@ def test_streamed_kernels_equal_the_layer_by_layer_path_at_full_size(dev, monkey
         assert float((raw - lraw).abs().max()) <= 2e-5 * max(1.0, float(lraw.abs().max())), kind
         for name, a, b in (('g_wd', g_wd, lg_wd), ('g_wc', g_wc, lg_wc)):
             a, b = a.double(), b.double()
-            assert float((a - b).norm()) <= 1e-3 * float(b.norm()), (kind, name, float((a - b).norm()) / float(b.norm()))
+            assert float((a - b).norm()) <= 3e-3 * float(b.norm()), (kind, name, float((a - b).norm()) / float(b.norm()))
             assert float((a - b).abs().max()) <= 1e-2 * float(b.abs().max()), (kind, name)
         row_err = (denc - ldenc).abs().amax(0) / float(ldenc.abs().amax(0).mean())
         assert float(row_err.median()) <= 1e-4 and float((row_err > 1e-3).float().mean()) <= 0.01, (kind, float(row_err.median()), float((row_err > 1e-3).float().mean()))
@@ -457,10 +459,7 @@ def test_shared_live_row_list_through_backward_and_scatter(O, dev, n, n_valid):
     g_t = torch.zeros(meta.n_params, dtype=torch.float32, device=dev)
     ops.hashgrid_bwd(tp, denc_t, meta, g_t, live=live)
     for name, got, ref in (('wd', g_wd, gd), ('wc', g_wc, gc), ('table', g_t, gt)):
-        g = got.cpu().numpy()
-        assert np.isfinite(g).all(), name
-        err = np.abs(g - ref).max()
-        assert err <= 1e-3 * max(1.0, np.abs(ref).max()), (name, err, np.abs(ref).max())
+        grad_close(got.cpu().numpy(), ref, name)
 
 
 def test_tcnn_module_surface_runs_the_reference_mlp_recipe(O, dev):
@@ -495,8 +494,7 @@ def test_tcnn_module_surface_runs_the_reference_mlp_recipe(O, dev):
     assert np.abs(outputs.detach().cpu().numpy() - ref).max() <= 1e-4
     gt, gd, gc = O.nerf_mlp_bwd(table, wd, wc, pts, dirs, draw, om)
     for got, want in ((emb.params.grad, gt), (dnet.params.grad, gd), (cnet.params.grad, gc)):
-        err = np.abs(got.cpu().numpy() - want).max()
-        assert err <= 1e-3 * max(1.0, np.abs(want).max()), err
+        grad_close(got.cpu().numpy(), want)
     # 3 hidden layers forward (strict-default-like depth) against the oracle's generic MLP
     net3 = tcnn.Network(32, 16, dict(otype='FullyFusedMLP', n_neurons=64, n_hidden_layers=3)).to(dev)
     x = rng.normal(0, 0.5, (500, 32)).astype(np.float32)

@@ -496,6 +496,100 @@ __device__ __forceinline__ void layer_fwd_b2(const __bf16* __restrict__ wf, int 
     }
     __builtin_amdgcn_sched_barrier(0);
 }
+// ---- fp32 operands as TWO fp16 parts (used by the forward kernels further down and by the backward's recompute, MODE 4) ----------
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+#define H2_IN_SCALE 16.0f       // hash-grid features into the first layer: O(1e-4) at initialisation -> low parts of 2^-11 of that stay out of the
+                                // deepest fp16 subnormals; features up to 4e3 in magnitude do not overflow
+struct H2Tile { h8 p[2][2]; };               // [hi | lo part][K-step]
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ H2Tile to_h2(const f32x16& t, float scale = 1.0f) {
+    H2Tile r;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            const f32x2 x = f32x2{t[8 * k + e], t[8 * k + e + 1]} * scale;
+            const f16x2 h = __builtin_convertvector(x, f16x2);
+            const f16x2 l = __builtin_convertvector(x - __builtin_convertvector(h, f32x2), f16x2);
+            r.p[0][k][e] = h[0]; r.p[0][k][e + 1] = h[1];
+            r.p[1][k][e] = l[0]; r.p[1][k][e + 1] = l[1];
+        }
+    return r;
+}
+// ROW16: the layer has 16 rows in LDS (lanes 16..31 repeat them; their accumulator rows are not used)
+template <int TI, int TO, bool ROW16 = false>
+__device__ __forceinline__ void layer_fwd_h2(const _Float16* __restrict__ wf, int ps, const H2Tile (&in)[TI], f32x16 (&out)[TO], int col, int hi) {
+    constexpr int NS = 2 * TI, RS = 2 * NS * 8 + 8;
+#pragma unroll
+    for (int to = 0; to < TO; ++to)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[to][r] = 0.f;
+    const _Float16* wl = wf + (ROW16 ? (col & 15) : col) * RS + hi * NS * 8;
+    h8 a[2][TO][2];
+    auto load = [&](int t, h8 (&d)[TO][2]) {
+#pragma unroll
+        for (int to = 0; to < TO; ++to) {
+            const _Float16* p = wl + to * 32 * RS + t * 8;
+            d[to][0] = *reinterpret_cast<const h8*>(p);
+            d[to][1] = *reinterpret_cast<const h8*>(p + ps);
+        }
+    };
+    load(0, a[0]);
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < NS) load(t + 1, a[(t + 1) & 1]);
+        const H2Tile& x = in[t >> 1];
+        const int k = t & 1, cur = t & 1;
+#pragma unroll
+        for (int to = 0; to < TO; ++to) {
+            out[to] = MFMA16(a[cur][to][1], x.p[0][k], out[to]);
+            out[to] = MFMA16(a[cur][to][0], x.p[1][k], out[to]);
+            out[to] = MFMA16(a[cur][to][0], x.p[0][k], out[to]);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int NH, int L>
+__device__ __forceinline__ void store_layer_fh2(const float (&v)[NetShape<NH>::out_rows_lds(L) * NetShape<NH>::in_dim(L) / MLP_THREADS],
+                                                _Float16* __restrict__ wf, int psf, __bf16* __restrict__ wb, int psb, bool first_layer_rot) {
+    using S = NetShape<NH>;
+    using H = HShape<NH>;
+    using F = F2Shape<NH>;
+    constexpr int K = S::in_dim(L), rows = S::out_dim(L), prow = S::out_rows_lds(L);
+    constexpr int ns = K / 16, rs = h_rs(K), nso = prow / 16, rsb = h_rs(prow), frows = F::rows(L);
+    _Float16* dstf = wf + F::off(L);
+    __bf16* dstb = wb + H::b_off(L);
+#pragma unroll
+    for (int i = 0; i < prow * K / MLP_THREADS; ++i) {
+        const int x = threadIdx.x + i * MLP_THREADS, o = x / K, c = x % K;        // global [o][c]
+        const int m = (L == 0 && first_layer_rot) ? ((c + 1) & 31) : c;             // LDS slot of global column c
+        const float w = o < rows ? v[i] : 0.f;
+        if (frows > 0 && o < frows) {
+            const _Float16 h = (_Float16)w;
+            _Float16* d = dstf + o * rs + hslot(m, ns);
+            d[0] = h; d[psf] = (_Float16)(w - (float)h);
+        }
+        const __bf16 hb = (__bf16)w;
+        __bf16* d = dstb + m * rsb + hslot(o, nso);
+        d[0] = hb; d[psb] = (__bf16)(w - (float)hb);
+    }
+}
+template <int NH>
+__device__ inline void load_weights_fh2(_Float16* __restrict__ wf, int psf, __bf16* __restrict__ wb, int psb, const float* __restrict__ w,
+                                        bool first_layer_rot) {
+    using S = NetShape<NH>;
+    static_assert(NH == 1 || NH == 2, "built for 1 or 2 hidden layers");
+    float v0[S::out_rows_lds(0) * S::in_dim(0) / MLP_THREADS], v1[S::out_rows_lds(1) * S::in_dim(1) / MLP_THREADS];
+    float v2[NH >= 2 ? S::out_rows_lds(NH >= 2 ? 2 : 0) * S::in_dim(NH >= 2 ? 2 : 0) / MLP_THREADS : 1];
+    fetch_layer<NH, 0>(v0, w, false);
+    fetch_layer<NH, 1>(v1, w, false);
+    if constexpr (NH >= 2) fetch_layer<NH, 2>(v2, w, false);
+    store_layer_fh2<NH, 0>(v0, wf, psf, wb, psb, first_layer_rot);
+    store_layer_fh2<NH, 1>(v1, wf, psf, wb, psb, false);
+    if constexpr (NH >= 2) store_layer_fh2<NH, 2>(v2, wf, psf, wb, psb, false);
+}
 // block-level reduction target: LDS buffer in the GLOBAL (compact, [out][in]) parameter layout.
 // The four waves of a workgroup take turns (caller: `for w: if (wave == w) dw_flush(.., first = (w == 0)); barrier`):
 // the first one stores, the others read-add-write with plain LDS accesses.  NOT ds_add_f32: measured on MI355X
@@ -729,7 +823,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void k_nerf_mlp_bwd_1_2(
     using SD = NetShape<1>;
     using SC = NetShape<2>;
     constexpr int GW = SD::glb_floats + SC::glb_floats;                // 3072 + 7168
-    constexpr bool DWB = MODE >= 1, DXB = MODE >= 2, FWB = MODE >= 3;
+    constexpr bool DWB = MODE >= 1, DXB = MODE >= 2, FWB = MODE >= 3, FWH = MODE == 4;      // FWH: the recompute on two fp16 parts instead of two bf16 parts
     using HD = HShape<1>;
     using HC = HShape<2>;
     using FD = F2Shape<1>;
@@ -749,7 +843,10 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void k_nerf_mlp_bwd_1_2(
     constexpr int LDS_FLOATS = W32 + (FWB ? PFD + PFC : 0) + (DXB ? PD + PC : 0) + MLP_WAVES * STAGE;
     static_assert(PD % 8 == 0 && PC % 8 == 0 && PFD % 8 == 0 && PFC % 8 == 0 && (SD::lds_floats + SC::lds_floats) % 4 == 0,
                   "16-byte alignment of the operand reads");
-    if constexpr (FWB) {
+    if constexpr (FWH) {
+        load_weights_fh2<1>(reinterpret_cast<_Float16*>(wfd), PFD, wbd, PD, w_density, false);
+        load_weights_fh2<2>(reinterpret_cast<_Float16*>(wfc), PFC, wbc, PC, w_color, true);
+    } else if constexpr (FWB) {
         load_weights_fb2<1>(wfd, PFD, wbd, PD, w_density, false);
         load_weights_fb2<2>(wfc, PFC, wbc, PC, w_color, true);
     } else {
@@ -782,7 +879,23 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void k_nerf_mlp_bwd_1_2(
         // ---- recompute forward, keep activations
         f32x16 xe[1], hd[2], dout[1], cin[1], hc1[2], hc2[2];
         load_enc_tile(enc_t, ld, sc, xe[0], hi);
-        if constexpr (FWB) {
+        if constexpr (FWH) {
+            // the forward's own arithmetic (k_nerf_mlp_fwd_h2: same split, same products in the same order): its ReLU decisions bit for bit
+            const _Float16* hfd = reinterpret_cast<const _Float16*>(wfd);
+            const _Float16* hfc = reinterpret_cast<const _Float16*>(wfc);
+            { const H2Tile xb[1] = {to_h2(xe[0], H2_IN_SCALE)}; layer_fwd_h2<1, 2>(hfd + FD::off(0), PFD, xb, hd, col, hi); }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                hd[0][r] = hd[0][r] > 0.f ? hd[0][r] * (1.0f / H2_IN_SCALE) : 0.f;
+                hd[1][r] = hd[1][r] > 0.f ? hd[1][r] * (1.0f / H2_IN_SCALE) : 0.f;
+            }
+            { const H2Tile hb[2] = {to_h2(hd[0]), to_h2(hd[1])}; layer_fwd_h2<2, 1, true>(hfd + FD::off(1), PFD, hb, dout, col, hi); }
+            build_color_in(dout[0], dirs, dir_stride, sc, pad_value, cin[0], hi);
+            { const H2Tile cb[1] = {to_h2(cin[0])}; layer_fwd_h2<1, 2>(hfc + FC::off(0), PFC, cb, hc1, col, hi); }
+            relu_tile(hc1[0]); relu_tile(hc1[1]);
+            { const H2Tile hb[2] = {to_h2(hc1[0]), to_h2(hc1[1])}; layer_fwd_h2<2, 2>(hfc + FC::off(1), PFC, hb, hc2, col, hi); }
+            relu_tile(hc2[0]); relu_tile(hc2[1]);
+        } else if constexpr (FWB) {
             { const B2Tile xb[1] = {to_b2(xe[0])}; layer_fwd_b2<1, 2>(wfd + FD::off(0), PFD, xb, hd, col, hi); }
             relu_tile(hd[0]); relu_tile(hd[1]);
             { const B2Tile hb[2] = {to_b2(hd[0]), to_b2(hd[1])}; layer_fwd_b2<2, 1, true>(wfd + FD::off(1), PFD, hb, dout, col, hi); }
@@ -1053,8 +1166,6 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void k_mlp_bwd(const float* __restr
 // backward keeps a second, transposed arrangement for the dX chain.  dW contracts over the tile's 32 samples through a
 // per-wave fp16 staging tile [row][32 samples (+8)].  Gradients are scaled by 128 before the fp16 conversion (tcnn's
 // loss scale) and unscaled in fp32.
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 #define H16_LOSS_SCALE 128.0f
 
 template <int NH, int L>
@@ -1569,6 +1680,114 @@ __device__ __forceinline__ void layer_fwd_b3(const __bf16* __restrict__ wf, int 
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// ---- the same on the FP16 matrix cores with a 2-way split (round 5) -------------------------------------------------------------
+// fp16 carries 11 significand bits, so x = xh + xl with xh = fp16(x), xl = fp16(x - xh) (the difference exact in fp32) keeps 22 bits,
+// and the three products wh.xh + wh.xl + wl.xh -- each exact in the fp32 accumulator -- carry w.x to ~2^-21 of |w||x|: within a few
+// ulps of fp32, at HALF the matrix instructions and ~60 % of the conversion instructions of the 3-way bf16 split (3 MFMAs and two
+// conversions + one subtraction per value instead of 6 and 3 + 2).  What fp16 costs is exponent range: a low part below 2^-14 is a
+// subnormal (absolute precision 2^-25 ~ 3e-8 -- the level at which the reference's own fp16 tcnn quantises EVERY value) and
+// a value above 65504 would overflow; the hash-grid features, O(1e-4) at initialisation, are therefore scaled by 2^10 into the first
+// layer and its accumulators scaled back (both exact).  The weights sit in LDS in two fp16 parts (56 KiB for both networks).
+template <int NH, int L>
+__device__ __forceinline__ void store_layer_h2(const float (&v)[NetShape<NH>::out_rows_lds(L) * NetShape<NH>::in_dim(L) / BX_THREADS],
+                                               _Float16* __restrict__ wf, int ps, bool first_layer_rot) {
+    using S = NetShape<NH>;
+    using H = HShape<NH>;
+    constexpr int K = S::in_dim(L), rows = S::out_dim(L), prow = S::out_rows_lds(L), ns = K / 16, rs = h_rs(K);
+    _Float16* dst = wf + H::f_off(L);
+#pragma unroll
+    for (int i = 0; i < prow * K / BX_THREADS; ++i) {
+        const int x = threadIdx.x + i * BX_THREADS, o = x / K, c = x % K;        // global [o][c]
+        const int m = (L == 0 && first_layer_rot) ? ((c + 1) & 31) : c;           // LDS slot of global column c
+        const float w = o < rows ? v[i] : 0.f;
+        const _Float16 h = (_Float16)w;
+        _Float16* d = dst + o * rs + hslot(m, ns);
+        d[0] = h; d[ps] = (_Float16)(w - (float)h);
+    }
+}
+template <int NH>
+__device__ inline void load_weights_h2(_Float16* __restrict__ wf, int ps, const float* __restrict__ w, bool first_layer_rot) {
+    using S = NetShape<NH>;
+    static_assert(NH == 1 || NH == 2, "built for 1 or 2 hidden layers");
+    float v0[S::out_rows_lds(0) * S::in_dim(0) / BX_THREADS], v1[S::out_rows_lds(1) * S::in_dim(1) / BX_THREADS];
+    float v2[NH >= 2 ? S::out_rows_lds(NH >= 2 ? 2 : 0) * S::in_dim(NH >= 2 ? 2 : 0) / BX_THREADS : 1];
+    fetch_layer_b3<NH, 0>(v0, w);
+    fetch_layer_b3<NH, 1>(v1, w);
+    if constexpr (NH >= 2) fetch_layer_b3<NH, 2>(v2, w);
+    store_layer_h2<NH, 0>(v0, wf, ps, first_layer_rot);
+    store_layer_h2<NH, 1>(v1, wf, ps, false);
+    if constexpr (NH >= 2) store_layer_h2<NH, 2>(v2, wf, ps, false);
+}
+template <bool WITH_COLOR>
+__global__ __launch_bounds__(BX_THREADS, 2) void k_nerf_mlp_fwd_h2(const float* __restrict__ enc_t, uint32_t ld,
+                                                                    const float* __restrict__ dirs, uint32_t dir_stride,
+                                                                    uint32_t n, const uint32_t* __restrict__ n_dev,
+                                                                    const uint32_t* __restrict__ rows,
+                                                                    const float* __restrict__ w_density,
+                                                                    const float* __restrict__ w_color, float pad_value,
+                                                                    float4* __restrict__ raw, const int32_t* __restrict__ splat_idx,
+                                                                    float* __restrict__ splat_grid) {
+    if (n_dev) n = min(n, *n_dev);
+    if (n == 0) return;
+    using HD = HShape<1>;
+    using HC = HShape<2>;
+    constexpr int PD = HD::f_halves, PC = HC::f_halves;             // halves per part
+    extern __shared__ __attribute__((aligned(16))) _Float16 ldsh2[];
+    _Float16* wd = ldsh2;
+    _Float16* wc = ldsh2 + 2 * PD;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, hi = lane >> 5;
+    const uint32_t n_tiles = (n + 31) / 32, stride = gridDim.x * BX_WAVES;
+    uint32_t tile = blockIdx.x * BX_WAVES + wave;
+    f32x16 x;
+    float d3[3] = {0.f, 0.f, 0.f};
+    auto fetch = [&](uint32_t tl, f32x16& xe, float (&dd)[3]) {
+        const uint32_t s = tl * 32 + col, sc = s < n ? s : n - 1;
+        load_enc_tile(enc_t, ld, sc, xe, hi);
+        if (WITH_COLOR) {
+            const float* d = dirs + (size_t)(rows ? rows[sc] : sc) * dir_stride;
+            dd[0] = d[0]; dd[1] = d[1]; dd[2] = d[2];
+        }
+    };
+    if (tile < n_tiles) fetch(tile, x, d3);
+    load_weights_h2<1>(wd, PD, w_density, false);
+    if (WITH_COLOR) load_weights_h2<2>(wc, PC, w_color, true);
+    __syncthreads();
+    for (; tile < n_tiles; tile += stride) {
+        const uint32_t s = tile * 32 + col;
+        H2Tile xin[1] = {to_h2(x, H2_IN_SCALE)};
+        const float dx = d3[0], dy = d3[1], dz = d3[2];
+        if (tile + stride < n_tiles) fetch(tile + stride, x, d3);   // next tile's loads under this tile's MFMAs
+        f32x16 h[2], dout[1];
+        layer_fwd_h2<1, 2>(wd + HD::f_off(0), PD, xin, h, col, hi);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {                              // relu + the input scale taken out again (exact)
+            h[0][r] = h[0][r] > 0.f ? h[0][r] * (1.0f / H2_IN_SCALE) : 0.f;
+            h[1][r] = h[1][r] > 0.f ? h[1][r] * (1.0f / H2_IN_SCALE) : 0.f;
+        }
+        H2Tile hh[2] = {to_h2(h[0]), to_h2(h[1])};
+        layer_fwd_h2<2, 1>(wd + HD::f_off(1), PD, hh, dout, col, hi);
+        float4 o = make_float4(0.f, 0.f, 0.f, dout[0][0]);
+        if (WITH_COLOR) {
+            f32x16 cin, cout[1];
+            const float dd[3] = {dx, dy, dz};
+            build_color_in(dout[0], dd, 3, 0, pad_value, cin, hi);
+            H2Tile ci[1] = {to_h2(cin)};
+            layer_fwd_h2<1, 2>(wc + HC::f_off(0), PC, ci, h, col, hi);
+            relu_tile(h[0]); relu_tile(h[1]);
+            hh[0] = to_h2(h[0]); hh[1] = to_h2(h[1]);
+            layer_fwd_h2<2, 2>(wc + HC::f_off(1), PC, hh, h, col, hi);
+            relu_tile(h[0]); relu_tile(h[1]);
+            hh[0] = to_h2(h[0]); hh[1] = to_h2(h[1]);
+            layer_fwd_h2<2, 1>(wc + HC::f_off(2), PC, hh, cout, col, hi);
+            o.x = cout[0][0]; o.y = cout[0][1]; o.z = cout[0][2];
+        }
+        if (hi == 0 && s < n) {
+            if (!WITH_COLOR && splat_idx != nullptr) atomicMax((uint32_t*)&splat_grid[(uint32_t)splat_idx[s]], __float_as_uint(expf(o.w) * xr_min_step()));
+            else raw[s] = o;
+        }
+    }
+}
+
 // Measured and dropped: handing the tiles out dynamically (a ticket counter, because the next batch's ray march co-runs on
 // ~50 CUs in the training loop and a static partition lasts as long as its slowest SIMD: 44 us alone, 60 us in the loop).
 // One returning atomic per 32-sample tile is 8100 same-address atomics per launch, and those retire one per ~13.5 ns: the
@@ -1656,7 +1875,7 @@ __global__ __launch_bounds__(BX_THREADS, 1) void k_nerf_mlp_fwd_b3(const float* 
 //     computes, split and permuted into LDS behind it (two alternating buffers, one barrier per layer);
 //   * every wave keeps the activations (forward) / gradients (backward) of its tile of 32 samples in registers from layer to layer
 //     -- the transposed neurons x samples scheme of the kernels above, nothing goes through LDS between layers;
-//   * forward arithmetic = the 3-way bf16 operand split of k_nerf_mlp_fwd_b3 (fp32-rounding accuracy, layer_fwd_b3);
+//   * forward arithmetic = the 2-way fp16 operand split of k_nerf_mlp_fwd_h2 (within a few ulps of fp32, layer_fwd_h2);
 //   * the backward recomputes the forward with the SAME arithmetic (its ReLU decisions are the forward's bit for bit), leaves each
 //     layer's input tile in a per-workgroup global scratch area as [neuron][32 samples] -- the layout the weight gradient's
 //     contraction over samples reads its H operand from directly, 32 B per lane, no transposing LDS tile -- and the ReLU decisions as
@@ -1689,19 +1908,18 @@ __device__ __forceinline__ void deep_fetch(float (&v)[W_HID * W_HID / THREADS], 
         v[i] = (e < L.prow * L.K && o < L.rows) ? w[L.goff + o * L.K + c] : 0.f;
     }
 }
-// registers -> LDS, forward arrangement [out row][hi][K-step][8] in three bf16 parts (store_layer_b3)
+// registers -> LDS, forward arrangement [out row][hi][K-step][8] in two fp16 parts (store_layer_h2)
 template <int THREADS>
-__device__ __forceinline__ void deep_commit_f3(const float (&v)[W_HID * W_HID / THREADS], __bf16* __restrict__ buf, const DeepLayer L, bool rot) {
+__device__ __forceinline__ void deep_commit_f2(const float (&v)[W_HID * W_HID / THREADS], _Float16* __restrict__ buf, const DeepLayer L, bool rot) {
     const int ns = L.K / 16, rs = 2 * ns * 8 + 8;
 #pragma unroll
     for (int i = 0; i < W_HID * W_HID / THREADS; ++i) {
         const int e = threadIdx.x + i * THREADS, o = e >> L.kshift, c = e & (L.K - 1);
         if (e < L.prow * L.K) {
             const int m = rot ? ((c + 1) & 31) : c;
-            __bf16 h, mi, lo;
-            split3(v[i], h, mi, lo);
-            __bf16* d = buf + o * rs + hslot(m, ns);
-            d[0] = h; d[DP_PS] = mi; d[2 * DP_PS] = lo;
+            const _Float16 h = (_Float16)v[i];
+            _Float16* d = buf + o * rs + hslot(m, ns);
+            d[0] = h; d[DP_PS] = (_Float16)(v[i] - (float)h);
         }
     }
 }
@@ -1742,7 +1960,7 @@ __global__ __launch_bounds__(DP_FW * 64, 1) void k_nerf_mlp_fwd_deep(const float
     if (n_dev) n = min(n, *n_dev);
     if (n == 0) return;
     constexpr int THREADS = DP_FW * 64;
-    extern __shared__ __attribute__((aligned(16))) __bf16 ldsb[];        // two layer buffers of three parts each
+    extern __shared__ __attribute__((aligned(16))) __bf16 ldsb[];        // two layer buffers of two 16-bit parts each
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, hi = lane >> 5;
     const int n_stage = (nhd + 1) + (WITH_COLOR ? nhc + 1 : 0);
     // stage g of a pass: layer (net, l)
@@ -1754,7 +1972,7 @@ __global__ __launch_bounds__(DP_FW * 64, 1) void k_nerf_mlp_fwd_deep(const float
     };
     auto commit_stage = [&](int g, int slot) {
         const int net = g > nhd ? 1 : 0, l = net ? g - (nhd + 1) : g;
-        deep_commit_f3<THREADS>(v, ldsb + slot * 3 * DP_PS, deep_layer(net ? nhc : nhd, l), net == 1 && l == 0);
+        deep_commit_f2<THREADS>(v, reinterpret_cast<_Float16*>(ldsb) + slot * 2 * DP_PS, deep_layer(net ? nhc : nhd, l), net == 1 && l == 0);
     };
     fetch_stage(0);
     commit_stage(0, 0);
@@ -1775,20 +1993,23 @@ __global__ __launch_bounds__(DP_FW * 64, 1) void k_nerf_mlp_fwd_deep(const float
             const int gn = g + 1 == n_stage ? 0 : g + 1;
             __syncthreads();                       // stage g's weights are in place; everyone is done with the other buffer
             if (has_next) fetch_stage(gn);
-            const __bf16* wf = ldsb + (k & 1) * 3 * DP_PS;
+            const _Float16* wf = reinterpret_cast<const _Float16*>(ldsb) + (k & 1) * 2 * DP_PS;
             const int net = g > nhd ? 1 : 0, l = net ? g - (nhd + 1) : g, nh = net ? nhc : nhd;
             if (l == 0) {
-                const BTile xin[1] = {to_b3(x)};
-                layer_fwd_b3<1, 2>(wf, DP_PS, xin, h, col, hi);
-                relu_tile(h[0]); relu_tile(h[1]);
+                // (the hash-grid features enter scaled by 2^4, the accumulators are scaled back: see k_nerf_mlp_fwd_h2)
+                const float sc_in = net == 0 ? H2_IN_SCALE : 1.0f, sc_out = net == 0 ? 1.0f / H2_IN_SCALE : 1.0f;
+                const H2Tile xin[1] = {to_h2(x, sc_in)};
+                layer_fwd_h2<1, 2>(wf, DP_PS, xin, h, col, hi);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { h[0][r] = h[0][r] > 0.f ? h[0][r] * sc_out : 0.f; h[1][r] = h[1][r] > 0.f ? h[1][r] * sc_out : 0.f; }
             } else if (l < nh) {
-                const BTile hh[2] = {to_b3(h[0]), to_b3(h[1])};
-                layer_fwd_b3<2, 2>(wf, DP_PS, hh, h, col, hi);
+                const H2Tile hh[2] = {to_h2(h[0]), to_h2(h[1])};
+                layer_fwd_h2<2, 2>(wf, DP_PS, hh, h, col, hi);
                 relu_tile(h[0]); relu_tile(h[1]);
             } else {
-                const BTile hh[2] = {to_b3(h[0]), to_b3(h[1])};
+                const H2Tile hh[2] = {to_h2(h[0]), to_h2(h[1])};
                 f32x16 dout[1];
-                layer_fwd_b3<2, 1>(wf, DP_PS, hh, dout, col, hi);
+                layer_fwd_h2<2, 1>(wf, DP_PS, hh, dout, col, hi);
                 if (net == 0) {
                     o.w = dout[0][0];                                        // hi == 0, register 0 <-> row 0 = sigma
                     if (WITH_COLOR) build_color_in(dout[0], d3, 3, 0, pad_value, x, hi);     // x: the colour net's input tile
@@ -1896,8 +2117,8 @@ __global__ __launch_bounds__(DP_BW * 64, 1) void k_nerf_mlp_bwd_deep(
     const int gwd = deep_glb_floats(nhd), GW = gwd + deep_glb_floats(nhc);
     const int n_slot = nhd + nhc + 2;                                   // density: features, hidden 1..nhd; colour: input slots, hidden 1..nhc
     extern __shared__ __attribute__((aligned(16))) __bf16 ldsb[];
-    __bf16* wbuf = ldsb;                                                // two layer buffers (three parts each; the backward uses two)
-    float* stage_all = reinterpret_cast<float*>(ldsb + 2 * 3 * DP_PS);  // per wave [64][33]; between layers: four copies of a layer's dW
+    __bf16* wbuf = ldsb;                                                // two layer buffers of two 16-bit parts (recompute: fp16, backward: bf16)
+    float* stage_all = reinterpret_cast<float*>(ldsb + 2 * 2 * DP_PS);  // per wave [64][33]; between layers: four copies of a layer's dW
     uint32_t* bits = reinterpret_cast<uint32_t*>(stage_all + DP_BW * 64 * ST33);   // [slot][wave][64 lanes]: the ReLU decisions of a lane's 32 values
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, hi = lane >> 5;
     float* stage = stage_all + wave * 64 * ST33;
@@ -1919,8 +2140,8 @@ __global__ __launch_bounds__(DP_BW * 64, 1) void k_nerf_mlp_bwd_deep(
     auto commit_stage = [&](int g, int slot) {
         const int net = net_of(g), l = lay_of(g);
         const DeepLayer L = deep_layer(net ? nhc : nhd, l);
-        if (g < nF) deep_commit_f3<THREADS>(v, wbuf + slot * 3 * DP_PS, L, net == 1 && l == 0);
-        else deep_commit_b2<THREADS>(v, wbuf + slot * 3 * DP_PS, L, net == 1 && l == 0);
+        if (g < nF) deep_commit_f2<THREADS>(v, reinterpret_cast<_Float16*>(wbuf) + slot * 2 * DP_PS, L, net == 1 && l == 0);
+        else deep_commit_b2<THREADS>(v, wbuf + slot * 2 * DP_PS, L, net == 1 && l == 0);
     };
     bool first_pass = true;
     fetch_stage(0);
@@ -1942,18 +2163,19 @@ __global__ __launch_bounds__(DP_BW * 64, 1) void k_nerf_mlp_bwd_deep(
             for (int g = 0; g < nF; ++g) {
                 __syncthreads();
                 fetch_stage(g + 1);
-                const __bf16* wl = wbuf + (k & 1) * 3 * DP_PS;
+                const _Float16* wl = reinterpret_cast<const _Float16*>(wbuf) + (k & 1) * 2 * DP_PS;
                 const int net = net_of(g), l = lay_of(g), nh = net ? nhc : nhd, slot0 = net ? nhd + 1 : 0;
                 if (l == 0) {
-                    const BTile xin[1] = {to_b3(x)};
-                    layer_fwd_b3<1, 2>(wl, DP_PS, xin, h, col, hi);
+                    const H2Tile xin[1] = {to_h2(x, net == 0 ? H2_IN_SCALE : 1.0f)};
+                    layer_fwd_h2<1, 2>(wl, DP_PS, xin, h, col, hi);
+                    if (net == 0) { scale_tile(h[0], 1.0f / H2_IN_SCALE); scale_tile(h[1], 1.0f / H2_IN_SCALE); }
                 } else if (l < nh) {
-                    const BTile hh[2] = {to_b3(h[0]), to_b3(h[1])};
-                    layer_fwd_b3<2, 2>(wl, DP_PS, hh, h, col, hi);
+                    const H2Tile hh[2] = {to_h2(h[0]), to_h2(h[1])};
+                    layer_fwd_h2<2, 2>(wl, DP_PS, hh, h, col, hi);
                 } else {                                              // density output layer -> the colour net's input slots
-                    const BTile hh[2] = {to_b3(h[0]), to_b3(h[1])};
+                    const H2Tile hh[2] = {to_h2(h[0]), to_h2(h[1])};
                     f32x16 dout[1];
-                    layer_fwd_b3<2, 1>(wl, DP_PS, hh, dout, col, hi);
+                    layer_fwd_h2<2, 1>(wl, DP_PS, hh, dout, col, hi);
                     build_color_in(dout[0], dirs, dir_stride, s, pad_value, x, hi);
                     scr_store_tile(scr(nhd + 1), 0, x, col, hi);
                 }
@@ -1974,7 +2196,7 @@ __global__ __launch_bounds__(DP_BW * 64, 1) void k_nerf_mlp_bwd_deep(
             const int gn = g + 1 == n_stage ? 0 : g + 1;
             __syncthreads();
             if (has_next) fetch_stage(gn);
-            const __bf16* wl = wbuf + (k & 1) * 3 * DP_PS;
+            const __bf16* wl = wbuf + (k & 1) * 2 * DP_PS;
             const int net = net_of(g), l = lay_of(g), nh = net ? nhc : nhd, slot0 = net ? nhd + 1 : 0;
             const DeepLayer LL = deep_layer(nh, l);
             float* dst = part + (net ? gwd : 0) + LL.goff;
@@ -2093,7 +2315,7 @@ static int launch_fwd_deep(const float* enc_t, uint32_t ld, const float* dirs, u
     XR_REQUIRE(nhd >= 1 && nhd <= XR_MLP_MAX_HIDDEN && nhc >= 1 && nhc <= XR_MLP_MAX_HIDDEN, "1..8 hidden layers per network");
     const int cus = xr_device_cus() > 0 ? xr_device_cus() : 256;
     const uint32_t grid = min(xr_div_up(n, DP_FW * 32), (uint32_t)cus);
-    const size_t lds = (size_t)2 * 3 * DP_PS * sizeof(__bf16);
+    const size_t lds = (size_t)2 * 2 * DP_PS * sizeof(__bf16);
     if (dirs) {
         if (mlp_set_lds((const void*)k_nerf_mlp_fwd_deep<true>, lds) != XR_OK) { xr_set_error("hipFuncSetAttribute failed"); return XR_EHIP; }
         hipLaunchKernelGGL(k_nerf_mlp_fwd_deep<true>, dim3(grid), dim3(DP_FW * 64), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev, rows, wd, wc,
@@ -2232,7 +2454,7 @@ extern "C" int xr_nerf_mlp_bwd(const float* enc_t, uint32_t ld, const float* dir
         const int nhd = n_hidden_density, nhc = n_hidden_color;
         const uint32_t gwd = (uint32_t)deep_glb_floats(nhd), GWD = gwd + (uint32_t)deep_glb_floats(nhc);
         const uint32_t gridd = bwd_grid_deep(n);
-        const size_t ldsd = (size_t)2 * 3 * DP_PS * sizeof(__bf16) + (size_t)DP_BW * 64 * ST33 * sizeof(float) +
+        const size_t ldsd = (size_t)2 * 2 * DP_PS * sizeof(__bf16) + (size_t)DP_BW * 64 * ST33 * sizeof(float) +
                             (size_t)(nhd + nhc + 2) * DP_BW * 64 * sizeof(uint32_t);
         float* scratch = reinterpret_cast<float*>((char*)partials + bwd_partial_bytes(nhd, nhc));
         auto kd = rows ? k_nerf_mlp_bwd_deep<true> : k_nerf_mlp_bwd_deep<false>;
@@ -2249,26 +2471,30 @@ extern "C" int xr_nerf_mlp_bwd(const float* enc_t, uint32_t ld, const float* dir
     size_t lds = (NetShape<1>::lds_floats + NetShape<2>::lds_floats + MLP_WAVES * 4 * 32 * ST33) * sizeof(float);
     const uint32_t grid = bwd_grid(n);
     // XR_MLP_BWD_DW (read per call): f32 = fp32 MFMA throughout; b2 = the dW products on the bf16 matrix cores (2-way split);
-    // b2x (default) = the dX chain too; b2f = the forward recompute as well.  b2f is not the default: a recompute at 2^-16
+    // b2x = the dX chain too; h2f (default, round 5) = that with the forward recomputed on two FP16 parts -- the arithmetic of the
+    // default forward (xr_nerf_mlp_fwd_f16x2), product for product, so the ReLU decisions are the forward's; b2f = the recompute on two
+    // bf16 parts.  b2f is not the default: a recompute at 2^-16
     // relative accuracy puts a hidden unit whose pre-activation is within ~1e-5 of zero on the other side of its ReLU than
     // the forward had it (a few hundred unit-samples per training step, ~1 with the fp32 recompute) -- harmless to the
     // optimiser, but each such flip is one sample's whole contribution to a weight row, which a 1e-3 * max parity bar on a
     // small batch sees (profiles/NOTES_r01_r03.md 5f).
     const char* bwd_env = getenv("XR_MLP_BWD_DW");
-    const int mode = !bwd_env ? 2 : strcmp(bwd_env, "f32") == 0 ? 0 : strcmp(bwd_env, "b2") == 0 ? 1 : strcmp(bwd_env, "b2x") == 0 ? 2
-                   : strcmp(bwd_env, "b2f") == 0 ? 3 : -1;
-    if (mode < 0) { xr_set_error("XR_MLP_BWD_DW=%s: expected f32, b2, b2x or b2f", bwd_env); return XR_EINVAL; }
+    const int mode = !bwd_env ? 4 : strcmp(bwd_env, "f32") == 0 ? 0 : strcmp(bwd_env, "b2") == 0 ? 1 : strcmp(bwd_env, "b2x") == 0 ? 2
+                   : strcmp(bwd_env, "b2f") == 0 ? 3 : strcmp(bwd_env, "h2f") == 0 ? 4 : -1;
+    if (mode < 0) { xr_set_error("XR_MLP_BWD_DW=%s: expected f32, b2, b2x, b2f or h2f", bwd_env); return XR_EINVAL; }
     using KernT = void (*)(const float*, uint32_t, const float*, uint32_t, uint32_t, const uint32_t*, const float*, const float*, float,
                            const float4*, float*, float*, const uint32_t*, const uint32_t*);
-    static const KernT kerns[2][4] = {{k_nerf_mlp_bwd_1_2<false, 0>, k_nerf_mlp_bwd_1_2<false, 1>, k_nerf_mlp_bwd_1_2<false, 2>, k_nerf_mlp_bwd_1_2<false, 3>},
-                                      {k_nerf_mlp_bwd_1_2<true, 0>, k_nerf_mlp_bwd_1_2<true, 1>, k_nerf_mlp_bwd_1_2<true, 2>, k_nerf_mlp_bwd_1_2<true, 3>}};
+    static const KernT kerns[2][5] = {{k_nerf_mlp_bwd_1_2<false, 0>, k_nerf_mlp_bwd_1_2<false, 1>, k_nerf_mlp_bwd_1_2<false, 2>, k_nerf_mlp_bwd_1_2<false, 3>,
+                                       k_nerf_mlp_bwd_1_2<false, 4>},
+                                      {k_nerf_mlp_bwd_1_2<true, 0>, k_nerf_mlp_bwd_1_2<true, 1>, k_nerf_mlp_bwd_1_2<true, 2>, k_nerf_mlp_bwd_1_2<true, 3>,
+                                       k_nerf_mlp_bwd_1_2<true, 4>}};
     KernT kern = kerns[rows ? 1 : 0][mode];
     constexpr size_t bt2 = (size_t)2 * (HShape<1>::b_halves + HShape<2>::b_halves) * sizeof(__bf16);
     constexpr size_t ft2 = (size_t)2 * (F2Shape<1>::halves + F2Shape<2>::halves) * sizeof(__bf16);
     constexpr size_t w32 = (NetShape<1>::lds_floats + NetShape<2>::lds_floats) * sizeof(float);
     constexpr size_t st3 = (size_t)MLP_WAVES * 3 * 32 * ST33 * sizeof(float);
     if (mode == 2) lds = w32 + bt2 + st3;
-    if (mode == 3) lds = ft2 + bt2 + st3;
+    if (mode >= 3) lds = ft2 + bt2 + st3;
     if (mlp_set_lds((const void*)kern, lds) != XR_OK) { xr_set_error("hipFuncSetAttribute failed"); return XR_EHIP; }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n,
                        n_dev, w_density, w_color, pad_value, (const float4*)draw, denc_t, partials, rows, n_live);
@@ -2385,6 +2611,34 @@ extern "C" int xr_nerf_mlp_fwd_bf16x3(const float* enc_t, uint32_t ld, const flo
     return XR_OK;
 }
 
+// fp32-accurate forward on the fp16 matrix cores (2-way operand split: k_nerf_mlp_fwd_h2; same contract as xr_nerf_mlp_fwd).  Any
+// depth but (1, 2) takes the streamed kernel, which uses the same arithmetic.
+extern "C" int xr_nerf_mlp_fwd_f16x2(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
+                                     const uint32_t* n_dev, const uint32_t* rows, const float* w_density, const float* w_color,
+                                     int n_hidden_density, int n_hidden_color, float pad_value, float* raw, void* stream_) {
+    if (n == 0) return XR_OK;
+    XR_REQUIRE(enc_t && w_density && raw, "null pointer");
+    XR_REQUIRE(!dirs || (w_color && dir_stride >= 3), "color path needs w_color and dir_stride >= 3");
+    XR_REQUIRE(ld >= n && ld <= XR_MLP_MAX_LD && ((uintptr_t)raw & 15) == 0, "bad ld / raw alignment");
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!(n_hidden_density == 1 && n_hidden_color == 2))
+        return launch_fwd_deep(enc_t, ld, dirs, dir_stride, n, n_dev, rows, w_density, w_color, n_hidden_density, n_hidden_color, pad_value, raw, stream);
+    const int cus = xr_device_cus() > 0 ? xr_device_cus() : 256;
+    const uint32_t grid2 = min(xr_div_up((n + 31) / 32, BX_WAVES), 2u * (uint32_t)cus);   // 56 KiB of weights: two workgroups per CU
+    if (dirs) {
+        const size_t lds = (size_t)2 * (HShape<1>::f_halves + HShape<2>::f_halves) * 2;
+        if (mlp_set_lds((const void*)k_nerf_mlp_fwd_h2<true>, lds) != XR_OK) { xr_set_error("hipFuncSetAttribute failed"); return XR_EHIP; }
+        hipLaunchKernelGGL(k_nerf_mlp_fwd_h2<true>, dim3(grid2), dim3(BX_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev,
+                           rows, w_density, w_color, pad_value, (float4*)raw, (const int32_t*)nullptr, (float*)nullptr);
+    } else {
+        const size_t lds = (size_t)2 * HShape<1>::f_halves * 2;
+        hipLaunchKernelGGL(k_nerf_mlp_fwd_h2<false>, dim3(grid2), dim3(BX_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev,
+                           rows, w_density, w_color, pad_value, (float4*)raw, g_fwd_splat_idx, g_fwd_splat_grid);
+    }
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}
+
 extern "C" int xr_nerf_mlp_bwd_f16(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
                                    const uint32_t* n_dev, const float* w_density, const float* w_color, int n_hidden_density,
                                    int n_hidden_color, float pad_value, const float* draw, float* denc_t, float* grad_w_density,
@@ -2425,7 +2679,7 @@ extern "C" int xr_nerf_density_splat(int mlp_mode, const float* enc_t, uint32_t 
     XR_REQUIRE(indices && density_grid_tmp, "null pointer");
     XR_REQUIRE(mlp_mode != 1 || (n_hidden_density == 1 && n_hidden_color == 2), "the fp16 mode is built for the (1,2) hidden-layer topology");
     g_fwd_splat_idx = indices; g_fwd_splat_grid = density_grid_tmp;
-    auto fwd = mlp_mode == 1 ? xr_nerf_mlp_fwd_f16 : mlp_mode == 2 ? xr_nerf_mlp_fwd_bf16x3 : xr_nerf_mlp_fwd;
+    auto fwd = mlp_mode == 1 ? xr_nerf_mlp_fwd_f16 : mlp_mode == 2 ? xr_nerf_mlp_fwd_bf16x3 : mlp_mode == 3 ? xr_nerf_mlp_fwd_f16x2 : xr_nerf_mlp_fwd;
     // (`raw` is not written in this mode; the argument only has to pass the alignment check)
     const int rc = fwd(enc_t, ld, nullptr, 0, n, nullptr, nullptr, w_density, nullptr, n_hidden_density, n_hidden_color, 1.0f,
                        (float*)(((uintptr_t)density_grid_tmp + 15) & ~(uintptr_t)15), stream);

@@ -55,7 +55,7 @@ extern "C" int xr_ngp_train_step(
     XR_REQUIRE(!table_adam || xr_hashgrid_bwd_adam_supported(n_rows, n_levels, scale_host, resolution_host, offset_host),
                "the fused table update needs a non-atomic scatter path for every level at this row capacity");
     XR_REQUIRE(n_rows > 0 && n_rays > 0 && ld >= n_rows, "bad sizes");
-    XR_REQUIRE(mlp_mode >= 0 && mlp_mode <= 2, "mlp_mode is 0 (fp32 MFMA), 1 (fp16) or 2 (fp32 forward on split bf16 operands)");
+    XR_REQUIRE(mlp_mode >= 0 && mlp_mode <= 3, "mlp_mode is 0 (fp32 MFMA), 1 (fp16), 2 (fp32 forward on 3-way split bf16 operands) or 3 (on 2-way split fp16 operands)");
     XR_REQUIRE(scatter_level0 >= 0 && scatter_level0 < n_levels, "scatter_level0 outside [0, n_levels)");
     XR_REQUIRE(!timed_entry || (timing_begin && timing_end), "a timed entry point needs its two events");
     hipStream_t stream = (hipStream_t)stream_;
@@ -82,7 +82,7 @@ extern "C" int xr_ngp_train_step(
     if (rc != XR_OK) return rc;
     if ((rc = end("xr_hashgrid_fwd")) != XR_OK || (rc = begin("xr_nerf_mlp_fwd")) != XR_OK) return rc;
     const bool f16_mlp = mlp_mode == 1;
-    auto mlp_fwd = mlp_mode == 1 ? xr_nerf_mlp_fwd_f16 : mlp_mode == 2 ? xr_nerf_mlp_fwd_bf16x3 : xr_nerf_mlp_fwd;
+    auto mlp_fwd = mlp_mode == 1 ? xr_nerf_mlp_fwd_f16 : mlp_mode == 2 ? xr_nerf_mlp_fwd_bf16x3 : mlp_mode == 3 ? xr_nerf_mlp_fwd_f16x2 : xr_nerf_mlp_fwd;
     rc = mlp_fwd(enc_t, ld, coords + 4, 7, n_rows, n_dev, nullptr, w_density, w_color, n_hidden_density, n_hidden_color, pad_value, raw,
                  stream_);
     if (rc != XR_OK) return rc;

@@ -107,10 +107,11 @@ if _PRECISION not in ('f32', 'f16'):
     raise ValueError("XRNERF_MLP_PRECISION must be 'f32' or 'f16' (got %r)" % _PRECISION)
 
 
-# forward of the 'f32' mode on the (1, 2) topology: 'bf16x3' = xr_nerf_mlp_fwd_bf16x3 (fp32 operands split exactly into three
-# bf16 numbers, six bf16 MFMAs per product block, fp32 accumulate: fp32-rounding accuracy on the 16x faster matrix-core
-# path), 'mfma' = xr_nerf_mlp_fwd (v_mfma_f32_32x32x2_f32).  Other topologies always take the latter.
-_F32_FORWARD = 'bf16x3'          # (set_f32_forward)
+# forward of the 'f32' mode: 'f16x2' = xr_nerf_mlp_fwd_f16x2 (the default: fp32 operands as two fp16 parts, three fp16 MFMAs per product
+# block, fp32 accumulate: within a few ulps of fp32 at half the matrix instructions of the 3-way split), 'bf16x3' =
+# xr_nerf_mlp_fwd_bf16x3 (three bf16 parts, six MFMAs: fp32-rounding accuracy), 'mfma' = xr_nerf_mlp_fwd (v_mfma_f32_32x32x2_f32).
+# Depths other than (1, 2) run the streamed kernel (f16x2 arithmetic) whatever this says, except (1,1), (2,2), (2,3) under 'mfma'.
+_F32_FORWARD = 'f16x2'          # (set_f32_forward)
 
 
 def f32_forward():
@@ -119,8 +120,8 @@ def f32_forward():
 
 def set_f32_forward(kind):
     global _F32_FORWARD
-    if kind not in ('bf16x3', 'mfma'):
-        raise ValueError("the fp32 forward is 'bf16x3' or 'mfma'")
+    if kind not in ('f16x2', 'bf16x3', 'mfma'):
+        raise ValueError("the fp32 forward is 'f16x2', 'bf16x3' or 'mfma'")
     _F32_FORWARD = kind
 
 
@@ -131,7 +132,7 @@ def _mlp_mode(nhd=1, nhc=2):
             return 1
         if _F32_FORWARD == 'bf16x3':
             return 2
-    return 0
+    return 3 if _F32_FORWARD == 'f16x2' else 0
 
 
 def precision():
@@ -810,7 +811,7 @@ def nerf_mlp_fwd(enc_t, dirs, n, w_density, w_color, nhd, nhc, pad_value=1.0, ra
     _ptr(enc_t); _ptr(raw)
     if count is not None:
         n = count
-    fn = (L.xr_nerf_mlp_fwd, L.xr_nerf_mlp_fwd_f16, L.xr_nerf_mlp_fwd_bf16x3)[_mlp_mode(nhd, nhc)]
+    fn = (L.xr_nerf_mlp_fwd, L.xr_nerf_mlp_fwd_f16, L.xr_nerf_mlp_fwd_bf16x3, L.xr_nerf_mlp_fwd_f16x2)[_mlp_mode(nhd, nhc)]
     with _span('xr_nerf_mlp_fwd', 0 if n_dev is not None else n, train=n_dev is not None):
         _lib.check(fn(C.c_void_p(enc_t.data_ptr() + 4 * row0), enc_t.shape[1], dp, ds, n, _ptr(n_dev),
                                      _ptr(rows), _ptr(w_density), _ptr(w_color) if w_color is not None else None, nhd,
