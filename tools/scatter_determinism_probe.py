@@ -1,0 +1,91 @@
+"""Is the table scatter bit-for-bit repeatable when another process shares the GPU?  The bin kernel ranks a sub-bin's items with LDS
+atomics (their order follows the wave schedule) and the accumulate kernel sums them in fp64 -- exact, hence order-free, only while the
+addends of an entry span < 2^(29 - log2 count).  Takes the scatter's inputs from the second step of a small training job, repeats
+the launch K times with and without a second process training on the same GPU, and counts (launch, level) pairs whose slice differs
+from the first launch's.   usage: python tools/scatter_determinism_probe.py [K]"""
+import os, subprocess, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from xrnerf_amd import ops
+from xrnerf_amd.train import Trainer
+
+dev = torch.device('cuda', 0)
+if len(sys.argv) > 1 and sys.argv[1] == 'noise':
+    tr = Trainer(dev, n_img=3, H=128, W=128, ema=False)
+    t0 = time.time()
+    while time.time() - t0 < float(sys.argv[2]):
+        tr.run(16); torch.cuda.synchronize()
+    sys.exit(0)
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+tr = Trainer(dev, n_img=3, H=128, W=128, ema=False, native_loop=False, fuse_adam=False)
+for _ in range(2):
+    tr.step()
+torch.cuda.synchronize()
+net = tr.net
+b = net._step_bufs[net._step_turn]
+meta = net.mlp.embedder_pos.meta
+coords = net.sampler.coords[:b.n_rows]
+off = [2 * int(o) for o in meta.offset]
+print('rows', b.n_rows, 'live', int(b.live[1][0]) if b.live is not None else None)
+
+
+def sweep(tag, alternate=False):
+    """alternate: launches k and k + 1 scatter different gradients (the second one negated), each compared with its own first result --
+    a launch that picked up anything left behind by the launch before it shows, which identical launches would hide"""
+    refs, bad, worst = [None, None], [0] * meta.n_levels, 0.0
+    dencs = [b.denc_t, -b.denc_t] if alternate else [b.denc_t, b.denc_t]
+    for k in range(K):
+        ref = refs[k & 1]
+        g = torch.full((meta.n_params,), float('nan'), device=dev)
+        ops.hashgrid_bwd(coords, dencs[k & 1], meta, g, live=b.live, overwrite=True)
+        if ref is None:
+            refs[k & 1] = g
+            continue
+        ne = g.view(torch.int32) != ref.view(torch.int32)
+        if bool(ne.any()):
+            worst = max(worst, float(((g - ref).abs() / ref.abs().clamp_min(1e-30))[ne].max()))
+            for l in range(meta.n_levels):
+                m = ne[off[l]:off[l + 1]]
+                if bool(m.any()):
+                    bad[l] += 1
+                    a, r = g[off[l]:off[l + 1]][m], ref[off[l]:off[l + 1]][m]
+                    idx = torch.nonzero(m).reshape(-1)
+                    print('   launch %d level %d: %d entries differ (first at %d, last at %d of %d), max |diff| %.3g where |ref| max %.3g (level max %.3g), nan %d'
+                          % (k, l, int(m.sum()), int(idx[0]), int(idx[-1]), m.numel(), float((a - r).abs().nan_to_num(0).max()), float(r.abs().max()),
+                             float(ref[off[l]:off[l + 1]].abs().max()), int(torch.isnan(a).sum())), flush=True)
+    print(tag, 'launches', K, 'levels that differed from the first launch (count per level):', bad, 'worst relative difference %.3g' % worst, flush=True)
+
+
+def sweep_others(tag):
+    """the same question for the other kernels of the step: gather, fused MLP forward and backward (live rows)"""
+    mlp = net.mlp
+    table, wd, wc = mlp.embedder_pos.params.detach(), mlp.density_net.params.detach(), mlp.color_net.params.detach()
+    n = b.n_rows
+    dirs = net.sampler.coords[:n, 4:7]
+    ref, bad = None, {}
+    for k in range(K):
+        enc = ops.hashgrid_fwd(table, coords, meta)
+        raw = ops.nerf_mlp_fwd(enc, dirs, n, wd, wc, 1, 2)
+        gd, gc = torch.zeros_like(wd), torch.zeros_like(wc)
+        de = torch.zeros_like(enc)
+        ops.nerf_mlp_bwd(enc, dirs, n, wd, wc, 1, 2, b.draw, gd, gc, denc_t=de, live=b.live)
+        cur = dict(gather=enc, mlp_forward=raw, mlp_backward_dw=torch.cat([gd, gc]), mlp_backward_dx=de)
+        if ref is None:
+            ref = cur
+            continue
+        for name in cur:
+            ne = cur[name].view(torch.int32) != ref[name].view(torch.int32)
+            if bool(ne.any()):
+                bad[name] = bad.get(name, 0) + 1
+                print('   launch %d %s: %d values differ, max |diff| %.3g (max |ref| %.3g)' % (k, name, int(ne.sum()), float((cur[name] - ref[name]).abs().max()), float(ref[name].abs().max())), flush=True)
+    print(tag, 'launches', K, 'kernels that differed from the first launch:', bad or 'none', flush=True)
+
+
+sweep('alone, same input every launch        ')
+sweep('alone, alternating inputs             ', True)
+p = subprocess.Popen([sys.executable, os.path.abspath(__file__), 'noise', '110'])
+time.sleep(15)
+sweep('GPU shared, same input every launch   ')
+sweep('GPU shared, alternating inputs        ', True)
+p.wait()
