@@ -386,8 +386,8 @@ def ngp_tcnn_strict_defaults(dev, n_img, steps):
                           'units': 'marched samples' if name == 'xr_nerf_mlp_fwd' else 'live rows (fraction %.3f)' % live_frac}
         return {'workload': 'the headline iterations with 5 + 5 hidden layers (XRNERF_TCNN_STRICT_DEFAULTS=1: what tcnn builds if it ignores '
                             'the config\'s num_layers key), %d timed iterations %d..%d after %d pre-roll iterations at this network\'s own '
-                            'adaptive fixed point; streamed fused MLP kernels (fp32 results on the bf16 matrix cores: forward and recompute '
-                            'on exact 3-way split operands, gradients on 2-way split operands), native step and loop: %s'
+                            'adaptive fixed point; streamed fused MLP kernels (fp32 results on the 16-bit matrix cores: forward and recompute '
+                            'on 2-way split fp16 operands, gradients on 2-way split bf16 operands), native step and loop: %s'
                             % (steps, it0, it0 + steps - 1, it0, 'yes' if native else 'NO'),
                 'value': rays / el, 'unit': 'rays/s', 'ms_per_step': el * 1e3 / steps, 'rays_per_step': rays / steps,
                 'samples_per_ray': samples / max(rays, 1), 'backward_live_row_fraction': live_frac, 'rays_per_batch_history': hist[-6:],
@@ -761,30 +761,38 @@ def main():
             achieved, peak, unit = work / (total_ms * 1e-3) / 1e9, HBM_PEAK_GBS, 'GB/s'
         else:
             achieved, peak, unit = work / (total_ms * 1e-3) / 1e12, MFMA_PEAK[ops.precision()], 'TFLOP/s'
-        split = name == 'xr_nerf_mlp_fwd' and ops._mlp_mode() == 2
+        split = name == 'xr_nerf_mlp_fwd' and ops._mlp_mode() in (2, 3)
         if split:
-            peak = MFMA_PEAK['f16']              # the kernel runs on the bf16 matrix cores (same dense peak as fp16)
+            peak = MFMA_PEAK['f16']              # the kernel runs on the 16-bit matrix cores (fp16 and bf16: the same dense peak)
         out = {'kernel': name, 'bound': bound, 'achieved': achieved, 'peak': peak, 'unit': unit, 'frac': achieved / peak,
                'avg_launch_us': total_ms * 1e3 / max(launches, 1), 'launches': launches,
                'algorithmic_per_sample': per_unit, 'algorithmic_bytes_or_flops_per_launch': work / max(launches, 1)}
-        if split:
+        if split and ops._mlp_mode() == 3:
+            out['arithmetic'] = ('xr_nerf_mlp_fwd_f16x2: fp32 operands split into 2 fp16 parts (hi + lo, ~22 bits), 3 v_mfma_f32_32x32x16_f16 per '
+                                 'product block, fp32 accumulate (4e-7 relative against float64, the fp32 MFMA path: 2e-7 -- '
+                                 'profiles/r05_mlp_fwd_f16x2_split_probe.txt); priced on the ALGORITHMIC flops against the fp16 MFMA peak -- the '
+                                 'matrix cores execute 3x these flops (issued_frac)')
+            out['issued_frac'] = 3.0 * achieved / peak
+            out['frac_of_fp32_mfma_peak'] = achieved / MFMA_F32_PEAK_TFLOPS
+        elif split:
             out['arithmetic'] = ('xr_nerf_mlp_fwd_bf16x3: fp32 operands split exactly into 3 bf16 parts, 6 v_mfma_f32_32x32x16_bf16 per '
                                  'product block, fp32 accumulate (fp32-rounding accuracy); priced on the ALGORITHMIC flops against the '
                                  'bf16 MFMA peak -- the matrix cores execute 6x these flops (issued_frac)')
             out['issued_frac'] = 6.0 * achieved / peak
             out['frac_of_fp32_mfma_peak'] = achieved / MFMA_F32_PEAK_TFLOPS
         if name == 'xr_nerf_mlp_bwd' and ops.precision() == 'f32' and bound == 'mfma':
-            # mixed arithmetic (XR_MLP_BWD_DW, default b2x): the forward recompute (18432 of the 59392 flop / sample) on the fp32
-            # MFMA, the dW products and the dX chain on the bf16 matrix cores with 2-way split operands (3 matrix products per
-            # algorithmic one).  The peak quoted is the rate at which the matrix cores could finish exactly this mix.
-            arith = os.environ.get('XR_MLP_BWD_DW', 'b2x')
+            # mixed arithmetic (XR_MLP_BWD_DW, default h2f): the forward recompute (18432 of the 59392 flop / sample) with the forward's
+            # own arithmetic (fp16 2-way split; b2x: on the fp32 MFMA), the dW products and the dX chain on the bf16 matrix cores with
+            # 2-way split operands -- 3 matrix products per algorithmic one each.  The peak quoted is the rate at which the matrix
+            # cores could finish exactly this mix.
+            arith = os.environ.get('XR_MLP_BWD_DW', 'h2f')
             f_fwd, f_dx, f_dw = 18432.0, 20480.0, 20480.0
-            on_f32 = {'f32': f_fwd + f_dx + f_dw, 'b2': f_fwd + f_dx, 'b2x': f_fwd, 'b2f': 0.0}.get(arith, f_fwd)
+            on_f32 = {'f32': f_fwd + f_dx + f_dw, 'b2': f_fwd + f_dx, 'b2x': f_fwd, 'b2f': 0.0, 'h2f': 0.0}.get(arith, f_fwd)
             on_b16 = (f_fwd + f_dx + f_dw) - on_f32
             t_unit = on_f32 / (MFMA_F32_PEAK_TFLOPS * 1e12) + 3.0 * on_b16 / (MFMA_PEAK['f16'] * 1e12)
             peak = (on_f32 + on_b16) / t_unit / 1e12
             out['peak'], out['frac'] = peak, achieved / peak
-            out['arithmetic'] = ('XR_MLP_BWD_DW=%s: %.0f flop/sample on the fp32 MFMA (157.3 TFLOP/s), %.0f on the bf16 matrix cores as 3 products '
+            out['arithmetic'] = ('XR_MLP_BWD_DW=%s: %.0f flop/sample on the fp32 MFMA (157.3 TFLOP/s), %.0f on the 16-bit matrix cores as 3 products '
                                  'each (2-way operand split, 2500 TFLOP/s dense); peak = the rate of this mix' % (arith, on_f32, on_b16))
             out['frac_of_fp32_mfma_peak'] = achieved / MFMA_F32_PEAK_TFLOPS
         if halves:
@@ -803,7 +811,7 @@ def main():
     roof = roof_of(dom_pick, launches, total_ms, units if units > 0 else samples, live_frac_timed)
     roof['traffic'] = None
     try:   # HBM bytes per launch from separate rocprofv3 --pmc passes of THIS command (tools/pmc_traffic.py)
-        pmc_path = next(p for p in (os.path.join(ROOT, 'profiles', n) for n in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json')) if os.path.exists(p))
+        pmc_path = next(p for p in (os.path.join(ROOT, 'profiles', n) for n in ('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json')) if os.path.exists(p))
         pmc = json.load(open(pmc_path))
         if dom_pick in pmc:
             roof['traffic'] = pmc[dom_pick]['bytes_fetch_x2']
@@ -836,31 +844,33 @@ def main():
     r_win = None
 
     extra = {}
-    if ops._mlp_mode() == 2:
+    if ops._mlp_mode() in (2, 3):
         # live evidence that the split forward is an fp32-accurate evaluation: the trained weights, the current batch's
         # marched samples, both forwards (never inside a timed region; a failure here must not cost the line)
+        split_kind = ops.f32_forward()
         try:
             mlp = tr.net.mlp
             coords = sampler.coords
             n_chk = int(min(coords.shape[0], int(sampler.n_valid_dev[0]), 1 << 18))      # rows behind the count are stale
             enc_chk = ops.hashgrid_fwd(mlp.embedder_pos.params.detach(), coords[:n_chk, :3], mlp.embedder_pos.meta)
             outs = {}
-            for kind in ('mfma', 'bf16x3'):
+            for kind in ('mfma', split_kind):
                 ops.set_f32_forward(kind)
                 outs[kind] = ops.nerf_mlp_fwd(enc_chk, coords[:n_chk, 4:], n_chk, mlp.density_net.params.detach(),
                                               mlp.color_net.params.detach(), 1, 2, mlp.pad_value).clone()
-            dev_max = float((outs['mfma'] - outs['bf16x3']).abs().max())
+            dev_max = float((outs['mfma'] - outs[split_kind]).abs().max())
             if not (dev_max == dev_max and dev_max < float('inf')):
                 raise ValueError('non-finite deviation')
             extra['mlp_forward_check'] = {
                 'samples': n_chk, 'max_abs_raw_fp32_mfma': float(outs['mfma'].abs().max()),
-                'max_abs_deviation_bf16x3_vs_fp32_mfma': dev_max,
-                'note': 'xr_nerf_mlp_fwd_bf16x3 (exact 3-way bf16 operand split, 6 bf16 MFMAs per product block, fp32 accumulate) '
-                        'against xr_nerf_mlp_fwd (fp32 MFMA) on the trained weights and the current training batch; parity bar on raw: 1e-4'}
+                'max_abs_deviation_%s_vs_fp32_mfma' % split_kind: dev_max,
+                'note': 'xr_nerf_mlp_fwd_%s (fp32 operands split into %s, fp32 accumulate) against xr_nerf_mlp_fwd (fp32 MFMA) on the trained '
+                        'weights and the current training batch; parity bar on raw: 1e-4'
+                        % (split_kind, '2 fp16 parts, 3 fp16 MFMAs per product block' if split_kind == 'f16x2' else '3 bf16 parts, 6 bf16 MFMAs per product block')}
         except Exception as e:  # noqa: BLE001
             extra['mlp_forward_check'] = {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
         finally:
-            ops.set_f32_forward('bf16x3')
+            ops.set_f32_forward(split_kind)
     if not args.no_render:
         H = W = 800
         pose = tr.data.poses[0]
@@ -956,12 +966,15 @@ def main():
                                       ' (the table\'s update applied inside the scatter: no gradient round trip)' if (world == 1 and tr.fuse_adam) else '',
                                       preroll, args.warmup + align, hist[-1],
                                       'fp32 via exact 3-way bf16 operand split on the bf16 MFMA (xr_nerf_mlp_fwd_bf16x3)' if ops._mlp_mode() == 2
-                                      else 'fp32 MFMA',
+                                      else 'fp32 results via 2-way fp16 operand split on the fp16 MFMA (xr_nerf_mlp_fwd_f16x2; 4e-7 relative against float64)'
+                                      if ops._mlp_mode() == 3 else 'fp32 MFMA',
                                       {'f32': 'fp32 MFMA throughout', 'b2': 'dW on 2-way-split bf16 operands (2^-16 per product), dX chain on the fp32 MFMA',
                                        'b2x': 'dW and the dX chain on 2-way-split bf16 operands (2^-16 relative per product, fp32 accumulate; '
                                               '1.0e-5 of max against a float64 statement away from ReLU kinks: profiles/r04_mlp_bwd_denc_outlier.txt), '
                                               'forward recompute in fp32 (3-way split)',
-                                       'b2f': 'as b2x with the forward recompute on 2-way-split operands'}.get(os.environ.get('XR_MLP_BWD_DW', 'b2x'), 'see XR_MLP_BWD_DW')
+                                       'b2f': 'as b2x with the forward recompute on 2-way-split bf16 operands',
+                                       'h2f': 'forward recompute with the forward\'s own arithmetic (2-way fp16 split), dW and the dX chain on 2-way-split '
+                                              'bf16 operands (2^-16 relative per product), fp32 accumulate'}.get(os.environ.get('XR_MLP_BWD_DW', 'h2f'), 'see XR_MLP_BWD_DW')
                                       if ops._mlp_mode() != 1 else 'fp16 operands, fp32 accumulate'),
                        'rays_per_step': rays_all / args.steps / world, 'samples_per_ray': samples_all / max(rays_all, 1),
                        'samples_per_s': samples_all / elapsed_max, 'n_images': args.n_img,

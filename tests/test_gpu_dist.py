@@ -193,7 +193,8 @@ def test_bench_spawns_its_own_ranks():
     """`python bench.py --gpus 2` without a launcher (here: gloo transport, both ranks on the one GPU of the test box)"""
     env = dict(os.environ, XRNERF_DIST_BACKEND='gloo', XRNERF_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     env.pop('WORLD_SIZE', None); env.pop('RANK', None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '16', '--warmup', '0', '--n-img', '2'],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '16', '--warmup', '0', '--n-img', '2',
+                        '--no-preroll', '--no-cpu-baseline', '--no-mip', '--no-kilo', '--no-unbounded', '--no-f16', '--no-strict', '--no-extra'],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     line = [l for l in r.stdout.decode().splitlines() if l.startswith('{')][-1]

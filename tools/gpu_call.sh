@@ -11,7 +11,7 @@ for st in "$@"; do
   name=${st%%:*}; arg=""; [ "$st" != "$name" ] && arg=${st#*:}
   echo "=== stage $st"
   case $name in
-    tests)   timeout 1200 python -m pytest tests -m gpu -q -x $arg 2>&1 | tail -15 | tee $O/${TAG}_pytest_gpu.txt ;;
+    tests)   timeout 1200 python -m pytest tests -m gpu -q -x --durations=8 $arg 2>&1 | tail -30 | tee $O/${TAG}_pytest_gpu.txt ;;
     smoke)   timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 | tee $O/${TAG}_smoke.txt ;;
     bench)   timeout 1200 python bench.py ${arg:---steps 20 --warmup 5} > $O/${TAG}_bench.json 2> $O/${TAG}_bench_err.txt; tail -c 300 $O/${TAG}_bench_err.txt
              python tools/benchsum.py $O/${TAG}_bench.json ;;
