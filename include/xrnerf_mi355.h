@@ -94,7 +94,7 @@ int xr_rays_sampler_series(const float* rays_o, const float* rays_d, uint32_t ra
  * network_output is not an argument.  counters are zeroed by this call.
  * out: coords_out [max_compacted,7]; numsteps_out [n_rays,2] = (n_clipped, base_c);
  *      rays_counter [1], numstep_counter [1] u32 (numstep_counter = UNCLIPPED total).
- * workspace: xr_rays_sampler_workspace_bytes(n_rays). */
+ * workspace: xr_rays_sampler_workspace_bytes(n_rays, 1). */
 int xr_compacted_coord(const float* coords_in, const int32_t* numsteps_in, uint32_t n_rays,
                        uint32_t max_compacted, float* coords_out, int32_t* numsteps_out,
                        uint32_t* rays_counter, uint32_t* numstep_counter, void* workspace,
