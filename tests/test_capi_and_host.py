@@ -381,3 +381,21 @@ def test_gradient_exchange_hooks_two_ranks(tmp_path):
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all('ok' in o for o in outs)
+
+
+def test_bf16_wire_sum_error_by_world_size():
+    """XRNERF_DP=allreduce_bf16 lets the collective add in bf16: a ring over N ranks rounds N - 1 times in sequence.  The bound the
+    docstring of dist.BucketedGradSync quotes, on gradients of mixed sign and a wide magnitude range (a statement about the wire
+    format, so plain torch on the host: no process group needed)."""
+    import torch
+    g = torch.Generator().manual_seed(11)
+    for world, bound in ((2, 2 * 2.0 ** -8), (8, 8 * 2.0 ** -8)):
+        grads = [torch.randn(1 << 16, generator=g) * torch.exp(3.0 * torch.randn(1 << 16, generator=g)) for _ in range(world)]
+        exact = torch.stack(grads).to(torch.float64).sum(0)
+        wire = grads[0].to(torch.bfloat16)
+        for t in grads[1:]:
+            wire = wire + t.to(torch.bfloat16)                    # the ring's running sum, rounded to bf16 at every hop
+        err = (wire.to(torch.float64) - exact).abs()
+        mass = torch.stack(grads).to(torch.float64).abs().sum(0)
+        assert float((err / mass).max()) <= bound, (world, float((err / mass).max()))
+        assert float((err / mass).max()) > 2.0 ** -12              # and it is a real rounding, not an fp32 sum in disguise

@@ -95,7 +95,12 @@ class BucketedGradSync:
         48.8-MB table gradient; the reference's tcnn gradients are fp16 (hashnerf_mlp.py:76-77 casts its half outputs up).  Each rank
         rounds its gradient to bf16 (2^-9 relative), the sum is taken in bf16 by the collective and widened back to fp32 in place:
         the replicas stay bit-identical (every rank gets the same sum), the trajectory differs from the fp32 exchange by that rounding
-        (tests/test_capi_and_host.py::test_bf16_gradient_exchange_two_ranks bounds it)."""
+        (tests/test_capi_and_host.py::test_bf16_gradient_exchange_two_ranks bounds it).
+        NOT a parity mode: tcnn's fp16 gradients are accumulated in fp32 on one GPU and the reference's DDP sums fp32 across ranks, while
+        here the collective itself adds in bf16 -- each rank's rounding plus up to world - 1 sequential roundings on a ring, 2^-8 (half an
+        ulp of bf16) each, so the error of the sum grows with the world size (test_bf16_wire_sum_error_by_world_size: <= world * 2^-8 of
+        sum|g|, i.e. 2^-7 at 2 ranks, 2^-5 at 8).  It is an
+        opt-in bandwidth trade on the per-iteration path only; the native loop serves the two exact exchanges."""
         self.world_size = int(world_size)
         self.wire_dtype = wire_dtype
         self._works, self._staged = [], []
