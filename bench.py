@@ -768,14 +768,14 @@ def main():
                'avg_launch_us': total_ms * 1e3 / max(launches, 1), 'launches': launches,
                'algorithmic_per_sample': per_unit, 'algorithmic_bytes_or_flops_per_launch': work / max(launches, 1)}
         if split and ops._mlp_mode() == 3:
-            out['arithmetic'] = ('xr_nerf_mlp_fwd_f16x2: fp32 operands split into 2 fp16 parts (hi + lo, ~22 bits), 3 v_mfma_f32_32x32x16_f16 per '
+            out['arithmetic'] = ('xr_nerf_mlp_fwd(XR_MLP_F16X2): fp32 operands split into 2 fp16 parts (hi + lo, ~22 bits), 3 v_mfma_f32_32x32x16_f16 per '
                                  'product block, fp32 accumulate (4e-7 relative against float64, the fp32 MFMA path: 2e-7 -- '
                                  'profiles/r05_mlp_fwd_f16x2_split_probe.txt); priced on the ALGORITHMIC flops against the fp16 MFMA peak -- the '
                                  'matrix cores execute 3x these flops (issued_frac)')
             out['issued_frac'] = 3.0 * achieved / peak
             out['frac_of_fp32_mfma_peak'] = achieved / MFMA_F32_PEAK_TFLOPS
         elif split:
-            out['arithmetic'] = ('xr_nerf_mlp_fwd_bf16x3: fp32 operands split exactly into 3 bf16 parts, 6 v_mfma_f32_32x32x16_bf16 per '
+            out['arithmetic'] = ('xr_nerf_mlp_fwd(XR_MLP_BF16X3): fp32 operands split exactly into 3 bf16 parts, 6 v_mfma_f32_32x32x16_bf16 per '
                                  'product block, fp32 accumulate (fp32-rounding accuracy); priced on the ALGORITHMIC flops against the '
                                  'bf16 MFMA peak -- the matrix cores execute 6x these flops (issued_frac)')
             out['issued_frac'] = 6.0 * achieved / peak
@@ -864,7 +864,7 @@ def main():
             extra['mlp_forward_check'] = {
                 'samples': n_chk, 'max_abs_raw_fp32_mfma': float(outs['mfma'].abs().max()),
                 'max_abs_deviation_%s_vs_fp32_mfma' % split_kind: dev_max,
-                'note': 'xr_nerf_mlp_fwd_%s (fp32 operands split into %s, fp32 accumulate) against xr_nerf_mlp_fwd (fp32 MFMA) on the trained '
+                'note': 'xr_nerf_mlp_fwd in the %s arithmetic (fp32 operands split into %s, fp32 accumulate) against XR_MLP_F32 (fp32 MFMA) on the trained '
                         'weights and the current training batch; parity bar on raw: 1e-4'
                         % (split_kind, '2 fp16 parts, 3 fp16 MFMAs per product block' if split_kind == 'f16x2' else '3 bf16 parts, 6 bf16 MFMAs per product block')}
         except Exception as e:  # noqa: BLE001
@@ -965,8 +965,8 @@ def main():
                                    % (args.n_img, it0, it1 - 1, n_refresh, 'gradient all-reduce, ' if world > 1 else '',
                                       ' (the table\'s update applied inside the scatter: no gradient round trip)' if (world == 1 and tr.fuse_adam) else '',
                                       preroll, args.warmup + align, hist[-1],
-                                      'fp32 via exact 3-way bf16 operand split on the bf16 MFMA (xr_nerf_mlp_fwd_bf16x3)' if ops._mlp_mode() == 2
-                                      else 'fp32 results via 2-way fp16 operand split on the fp16 MFMA (xr_nerf_mlp_fwd_f16x2; 4e-7 relative against float64)'
+                                      'fp32 via exact 3-way bf16 operand split on the bf16 MFMA (xr_nerf_mlp_fwd, XR_MLP_BF16X3)' if ops._mlp_mode() == 2
+                                      else 'fp32 results via 2-way fp16 operand split on the fp16 MFMA (xr_nerf_mlp_fwd, XR_MLP_F16X2; 4e-7 relative against float64)'
                                       if ops._mlp_mode() == 3 else 'fp32 MFMA',
                                       {'f32': 'fp32 MFMA throughout', 'b2': 'dW on 2-way-split bf16 operands (2^-16 per product), dX chain on the fp32 MFMA',
                                        'b2x': 'dW and the dX chain on 2-way-split bf16 operands (2^-16 relative per product, fp32 accumulate; '

@@ -45,8 +45,6 @@ enum { XR_ACT_NONE = 0, XR_ACT_RELU = 1, XR_ACT_LOGISTIC = 2, XR_ACT_EXPONENTIAL
 
 const char* xr_last_error(void);
 int xr_version(void);
-/* number of compute units of the current device (for persistent-grid sizing by callers) */
-int xr_device_cus(void);
 
 /* host helper: state of `pcg32 rng{seed}` after `ncalls` launches (each launch ends with
  * rng.advance() = 2^32; ray_sampler.cu:198, generate_grid_samples_nerf_nonuniform.cu:84) */
@@ -126,7 +124,7 @@ int xr_calc_rgb_backward(const float* network_output, const int32_t* rays_numste
 /* K3 + scale * HuberLoss(delta, sum) with its gradient + K4 in ONE launch (the training step's compositor sequence,
  * networks/hashnerf.py:32-44 around renders/hashnerf_render.py:60-135): rgb_output [n_rays,3] and dloss_doutput [S,4] are what
  * xr_calc_rgb_forward / xr_calc_rgb_backward produce.  Rows of dloss_doutput behind the last sample are not written.
- * live_seg_count (nullable; xr_live_rows_segments(S) words the caller zero-fills) gets, per segment of 1024 rows of dloss_doutput,
+ * live_seg_count (nullable; XR_LIVE_ROWS_SEGMENTS(S) words the caller zero-fills) gets, per segment of 1024 rows of dloss_doutput,
  * the number of rows that are not exactly zero ADDED -- the counting pass of xr_live_rows (follow with seg_counts_ready = 1).
  * loss_mse_out (nullable): without it the launch is the wave-per-ray kernel and the two loss scalars are left to
  * xr_train_loss_scalars; with it (caller zero-fills) the 16-lanes-per-ray kernel, which also ADDS [0] += scale * sum huber,
@@ -245,15 +243,37 @@ int xr_sh4(const float* dirs, uint32_t dir_stride, uint32_t n, float* out, void*
 
 /* HashNerfMLP.run_mlp fused (hashnerf_mlp.py:55-79): density_net (32 -> nhd x 64 -> 16) on the encoded
  * features, SH-4 of the view direction, color_net (15+16 (+1 pad = pad_value) -> nhc x 64 -> 16),
- * raw [n,4] = [r,g,b,sigma].  fp32 MFMA (v_mfma_f32_32x32x2_f32 == an fmaf chain, exact fp32).
+ * raw [n,4] = [r,g,b,sigma].
  * Weights: tcnn `params` layout = row-major [out,in] matrices in layer order, out padded to 16.
  * dirs may be NULL (run_density, hashnerf_mlp.py:107-111: only raw[:,3] is meaningful then).
- * Depths: (1, 2) -- what the config's `num_layers` says --, (1, 1), (2, 2), (2, 3) keep every activation in registers and both
- * weight sets in LDS; ANY other 1..8 + 1..8 hidden layers, tcnn's own default 5 + 5 first of all (tcnn reads `n_hidden_layers`
- * and ignores the `num_layers` key of configs/instant_ngp/nerf_blender_local01.py:106-124), runs on the streamed kernels: a
- * workgroup takes its sample tiles through one layer at a time, the layers' weights pass through LDS; fp32 results on the bf16
- * matrix cores (exact 3-way operand split), same 1e-4 bar. */
-int xr_nerf_mlp_fwd(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
+ * Depths: (1, 2) -- what the config's `num_layers` says -- keeps every activation in registers and both weight sets in LDS (so do
+ * (1, 1), (2, 2), (2, 3) under XR_MLP_F32); ANY other 1..8 + 1..8 hidden layers, tcnn's own default 5 + 5 first of all (tcnn reads
+ * `n_hidden_layers` and ignores the `num_layers` key of configs/instant_ngp/nerf_blender_local01.py:106-124), runs on the streamed
+ * kernels: a workgroup takes its sample tiles through one layer at a time, the layers' weights pass through LDS (arithmetic of
+ * XR_MLP_F16X2; XR_MLP_F16 is built for (1, 2) only).
+ * `arithmetic` -- ONE entry point, four kernel families; the first, third and fourth are the fp32 "parity mode" (1e-4 on raw):
+ *   XR_MLP_F32     v_mfma_f32_32x32x2_f32 == an fmaf chain, exact fp32 products.
+ *   XR_MLP_F16     the reference's precision: tiny-cuda-nn computes FullyFusedMLP in fp16 with fp32 accumulation (the reference casts
+ *                  its half outputs to fp32, hashnerf_mlp.py:76-77).  Parameters and gradients stay fp32 in memory; weights /
+ *                  activations are rounded to fp16 inside the kernel (v_mfma_f32_32x32x16_f16), gradients carry tcnn's loss scale 128
+ *                  through the fp16 stages.
+ *   XR_MLP_BF16X3  every fp32 operand split EXACTLY into three bf16 numbers (8 + 8 + 8 significand bits), a product carried by the six
+ *                  bf16 x bf16 MFMA terms above 2^-23 of it, fp32 accumulate: fp32-rounding accuracy at 0.375 of the fp32-MFMA
+ *                  matrix-core time; results differ from XR_MLP_F32 the way two fp32 summation orders differ.  (1, 2) only.
+ *   XR_MLP_F16X2   (round 5; what the host side selects by default) x = xh + xl with xh = fp16(x), xl = fp16(x - xh) keeps 22 significand
+ *                  bits, and the three products wh.xh + wh.xl + wl.xh (each exact in the fp32 accumulator) carry w.x to ~2^-21 of
+ *                  |w||x| -- measured 3.4e-7 .. 4.6e-7 of max|raw| against a float64 statement where the fp32 MFMA is at 1.7e-7 ..
+ *                  3.0e-7 (profiles/r05_mlp_fwd_f16x2_split_probe.txt) -- with HALF the matrix instructions and ~60 % of the
+ *                  conversions of the 3-way bf16 split: 27.5 us against 42.6 us at 2^18 rows.  Range: hidden activations up to 65504
+ *                  and hash-grid features up to 4e3 in magnitude (the features enter the first layer scaled by 2^4, exactly; the
+ *                  reference's own fp16 tcnn overflows at 65504 too); low parts below 2^-14 are fp16 subnormals (absolute precision
+ *                  2^-25).  Any depth.
+ * (xr_version 120 -> 121: the four arithmetics used to be four entry points, xr_nerf_mlp_fwd / _f16 / _bf16x3 / _f16x2.) */
+#define XR_MLP_F32 0
+#define XR_MLP_F16 1
+#define XR_MLP_BF16X3 2
+#define XR_MLP_F16X2 3
+int xr_nerf_mlp_fwd(int arithmetic, const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
                     const uint32_t* n_dev, const uint32_t* rows /* nullable: dirs row of sample i */, const float* w_density, const float* w_color, int n_hidden_density, int n_hidden_color,
                     float pad_value, float* raw /*[n,4]*/, void* stream);
 /* backward of the above given dL/draw [n,4]: writes denc_t [32][ld] (for xr_hashgrid_bwd) and
@@ -261,19 +281,22 @@ int xr_nerf_mlp_fwd(const float* enc_t, uint32_t ld, const float* dirs, uint32_t
  * Activations are recomputed in-kernel (nothing saved by the forward).
  * workspace: xr_nerf_mlp_bwd_workspace_bytes(n, n_hidden_density, n_hidden_color) -- list of live rows first (its position does
  * not depend on the depths), then the per-workgroup weight-gradient partials, then (streamed depths) the activation scratch area.
- * Streamed depths (anything but (1, 2)): the forward is recomputed with the forward's own arithmetic (3-way split: the same ReLU
- * decisions bit for bit), the gradient chain and the weight-gradient products on 2-way split operands like the default below. */
+ * Streamed depths (anything but (1, 2)): the forward is recomputed with the forward's own arithmetic (2-way fp16 split: the same ReLU
+ * decisions bit for bit), the gradient chain and the weight-gradient products on 2-way split bf16 operands like the default below. */
 size_t xr_nerf_mlp_bwd_workspace_bytes(uint32_t n, int n_hidden_density, int n_hidden_color);
 /* live_rows / n_live (both or neither): the list xr_live_rows built from `draw`.  The backward then computes exactly the
  * listed rows and leaves the other rows of denc_t UNTOUCHED (pass the same list to xr_hashgrid_bwd).  Without a list
  * the call builds its own in the workspace and writes exact zeros to the dead rows of denc_t (same results as the
  * backward over every row, which XR_MLP_LIVE=0 still runs for measurement).
- * Arithmetic (topology (1, 2); XR_MLP_BWD_DW, read per call): the activations are recomputed on the fp32 MFMA; the weight-gradient
- * products and the gradient chain run on v_mfma_f32_32x32x16_bf16 with every fp32 operand split into two bf16 parts (x = xh + xl,
- * three products kept: 2^-16 relative per product, gradients within 2e-5 of their scale of the all-fp32 kernel).  "f32": every
- * product on the fp32 MFMA; "b2": only the weight-gradient products split; "b2x": the default; "b2f": the recompute split as
- * well (faster, but a hidden unit within ~1e-5 of zero can land on the other side of its ReLU than in the forward). */
-int xr_nerf_mlp_bwd(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
+ * `arithmetic`: XR_MLP_F16 = the reference-precision backward (topology (1, 2)); the three fp32 forwards share ONE backward, whose
+ * products are chosen by XR_MLP_BWD_DW (environment, read per call; topology (1, 2)): the weight-gradient products and the gradient chain
+ * run on v_mfma_f32_32x32x16_bf16 with every fp32 operand split into two bf16 parts (x = xh + xl, three products kept: 2^-16 relative per
+ * product, gradients within 2e-5 of their scale of the all-fp32 kernel), and the activations are recomputed
+ *   "h2f" (default) with XR_MLP_F16X2's arithmetic, product for product -- the ReLU decisions of the default forward, bit for bit;
+ *   "b2x" on the fp32 MFMA (the ReLU decisions of XR_MLP_F32);   "b2f" on 2-way split bf16 operands (a hidden unit within ~1e-5 of zero can
+ *   land on the other side of its ReLU than in the forward);   "b2": only the weight-gradient products split;   "f32": every product on the
+ *   fp32 MFMA. */
+int xr_nerf_mlp_bwd(int arithmetic, const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
                     const uint32_t* n_dev, const float* w_density, const float* w_color, int n_hidden_density, int n_hidden_color,
                     float pad_value, const float* draw /*[n,4]*/, float* denc_t, float* grad_w_density,
                     float* grad_w_color, void* workspace, size_t workspace_bytes, const uint32_t* live_rows,
@@ -283,9 +306,10 @@ int xr_nerf_mlp_bwd(const float* enc_t, uint32_t ld, const float* dirs, uint32_t
  * row is exactly zero and contributes exactly nothing to dW or to the table gradient -- in steady-state training more
  * than half of the marched samples.  n_live: FOUR words -- [0] the list's length, [1] / [2] running totals of live / valid rows
  * over the calls since the caller last cleared them (statistics: bench.py reports the live fraction from them), [3] spare.
- * seg_count: scratch of xr_live_rows_segments(n) words.  zero_denc_t (nullable,
+ * seg_count: scratch of XR_LIVE_ROWS_SEGMENTS(n) words.  zero_denc_t (nullable,
  * [32][ld]): the dead rows of it are set to zero.  Stable order and a fixed partition: reproducible run to run. */
-size_t xr_live_rows_segments(uint32_t n);
+#define XR_LIVE_SEGMENT_ROWS 1024u
+#define XR_LIVE_ROWS_SEGMENTS(n) (((n) + XR_LIVE_SEGMENT_ROWS - 1u) / XR_LIVE_SEGMENT_ROWS)
 /* the list area inside an xr_nerf_mlp_bwd workspace of n rows (unused by a backward that is handed a list) */
 int xr_nerf_mlp_bwd_list_slots(void* workspace, size_t workspace_bytes, uint32_t n, uint32_t** live_rows, uint32_t** seg_count,
                                uint32_t** n_live);
@@ -297,58 +321,25 @@ int xr_live_rows(const float* dloss_doutput, uint32_t n, const uint32_t* n_dev, 
  * levels exactly once per launch, so it can run Adam (+ L2 weight decay, + the EMA copy) on (param, m, v, ema) where an entry's
  * gradient is complete -- same update, bit for bit, as xr_hashgrid_bwd(XR_SCATTER_OVERWRITE) followed by xr_adam_step_multi
  * on the table, without the 48.8-MB gradient write + read and without the separate HBM-bound launch.  No gradient is produced.
- * Single-GPU training only (a data-parallel step must reduce the gradient first).  xr_hashgrid_bwd_adam_supported: 1 when every
- * level of this geometry / row capacity has a non-atomic path (otherwise the call fails before launching anything). */
+ * Single-GPU training only (a data-parallel step must reduce the gradient first).  Needs a non-atomic path for every level of this
+ * geometry / row capacity, else the call fails before launching anything; adam == NULL is the dry run of exactly that check (XR_OK =
+ * supported; nothing else is read, nothing is launched). */
 typedef struct xr_adam_fuse {
     float* param; float* m; float* v; float* ema;   /* whole tensors, 16-byte aligned; ema nullable */
     int step;                                       /* 1, 2, ... (this update's bias correction) */
     float lr, beta1, beta2, eps, weight_decay, ema_momentum, grad_scale;
     uint64_t n;                                     /* floats in the tensor (read where the caller cannot know it: xr_ngp_train_step's mlp_adam) */
 } xr_adam_fuse;
-int xr_hashgrid_bwd_adam_supported(uint32_t n, int n_levels, const float* scale_host, const uint32_t* resolution_host,
-                                   const uint32_t* offset_host);
 int xr_hashgrid_bwd_adam(const float* x, uint32_t x_stride, const float* denc_t, uint32_t ld, uint32_t n, const uint32_t* n_dev,
                          const uint32_t* rows, int n_levels, const float* scale_host, const uint32_t* resolution_host,
                          const uint32_t* offset_host, void* workspace, size_t workspace_bytes, const xr_adam_fuse* adam,
                          void* stream);
 
-/* Reference-precision mode of the two calls above: tiny-cuda-nn computes FullyFusedMLP in fp16 with fp32 accumulation
- * (the reference casts its half outputs to fp32, hashnerf_mlp.py:76-77).  Same contracts, parameters and gradients stay
- * fp32 in memory; weights / activations are rounded to fp16 inside the kernel (v_mfma_f32_32x32x16_f16), gradients carry
- * tcnn's loss scale 128 through the fp16 stages.  Topology (1, 2) only.  The fp32 calls remain the parity mode. */
-int xr_nerf_mlp_fwd_f16(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
-                        const uint32_t* n_dev, const uint32_t* rows, const float* w_density, const float* w_color,
-                        int n_hidden_density, int n_hidden_color, float pad_value, float* raw, void* stream);
-int xr_nerf_mlp_bwd_f16(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
-                        const uint32_t* n_dev, const float* w_density, const float* w_color, int n_hidden_density,
-                        int n_hidden_color, float pad_value, const float* draw, float* denc_t, float* grad_w_density,
-                        float* grad_w_color, void* workspace, size_t workspace_bytes, const uint32_t* live_rows,
-                        const uint32_t* n_live, void* stream);
-
-/* The fp32 forward on the bf16 matrix cores: every fp32 operand is split EXACTLY into three bf16 numbers (8 + 8 + 8
- * significand bits) and a product is carried by the six bf16 x bf16 MFMA terms above 2^-23 of it (fp32 accumulate) --
- * fp32-rounding accuracy at 0.375 of the fp32-MFMA matrix-core time.  Same contract as xr_nerf_mlp_fwd (parity mode: same
- * 1e-4 bar against the oracle); results differ from it the way two fp32 summation orders differ.  Topology (1, 2) only. */
-int xr_nerf_mlp_fwd_bf16x3(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
-                           const uint32_t* n_dev, const uint32_t* rows, const float* w_density, const float* w_color,
-                           int n_hidden_density, int n_hidden_color, float pad_value, float* raw, void* stream);
-
-/* The fp32 forward on the FP16 matrix cores (round 5; the default of the parity mode): x = xh + xl with xh = fp16(x), xl = fp16(x - xh)
- * keeps 22 significand bits, and the three products wh.xh + wh.xl + wl.xh (each exact in the fp32 accumulator) carry w.x to ~2^-21 of
- * |w||x| -- measured 3.4e-7 .. 4.6e-7 of max|raw| against a float64 statement where the fp32 MFMA is at 1.7e-7 .. 3.0e-7
- * (profiles/r05_mlp_fwd_f16x2_split_probe.txt) -- with HALF the matrix instructions and ~60 % of the conversions of the 3-way bf16
- * split: 27.5 us against 42.6 us at 2^18 rows.  Range: hidden activations up to 65504 and hash-grid features up to 4e3 in magnitude
- * (the features enter the first layer scaled by 2^4, exactly; the reference's own fp16 tcnn overflows at 65504 too); low parts below
- * 2^-14 are fp16 subnormals (absolute precision 2^-25).  Same contract as xr_nerf_mlp_fwd; any depth (streamed kernel beyond (1, 2)). */
-int xr_nerf_mlp_fwd_f16x2(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
-                          const uint32_t* n_dev, const uint32_t* rows, const float* w_density, const float* w_color,
-                          int n_hidden_density, int n_hidden_color, float pad_value, float* raw, void* stream);
-
 /* K9's density query and K8 in one launch (grid refresh: ngp_grid_sampler.py:103-137 -> hashnerf_mlp.py:107-111 +
  * splat_grid_samples_nerf_max_nearest_neighbor.cu:7-28): the density network over n encoded points (enc_t as xr_hashgrid_fwd writes it),
  * each result's optical thickness exp(density) * min_step merged into density_grid_tmp[indices[i]] by an order-free maximum from the
  * forward kernel's epilogue -- the same values xr_splat_grid_samples would merge, without the [n,4] network output in HBM and without
- * the 2^20-thread launch.  mlp_mode as in xr_ngp_train_step; topology (1, 2) only. */
+ * the 2^20-thread launch.  mlp_mode = the `arithmetic` of xr_nerf_mlp_fwd. */
 int xr_nerf_density_splat(int mlp_mode, const float* enc_t, uint32_t ld, uint32_t n, const float* w_density, int n_hidden_density,
                           int n_hidden_color, const int32_t* indices, float* density_grid_tmp, void* stream);
 
@@ -360,14 +351,14 @@ int xr_nerf_density_splat(int mlp_mode, const float* enc_t, uint32_t ld, uint32_
  * nullable) is not written; single GPU, scatter_level0 == 0.
  * w_density_adam / w_color_adam (both or neither, same step and constants): xr_adam_step_multi on the two MLP tensors right behind
  * the reduction of their gradients, on the helper stream the scatter forks (joined before the call's work ends on `stream`).
- * live_seg_count (nullable): xr_live_rows_segments(n_rows) words for the per-segment counts, ZERO on entry; the call leaves them
+ * live_seg_count (nullable): XR_LIVE_ROWS_SEGMENTS(n_rows) words for the per-segment counts, ZERO on entry; the call leaves them
  * zero again (cleared on its helper stream after use).  Null: the slot in ws_mlp_bwd, cleared by a fill on `stream`.
  * zero_block / zero_floats: kept for the layout (grad_w_density, grad_w_color, loss_mse live in it); nothing in it is zero-filled
  * any more -- the two gradient buffers and loss_mse[0..1] are WRITTEN.
  * coords: K1's [n_rows,7] rows (positions / directions consumed in place); n_dev: device count of valid rows; every buffer
  * is caller-owned (enc_t / denc_t [32][ld], raw / draw [n_rows,4], rgb_out [n_rays,3]); zero_draw != 0 also clears draw
- * (needed only without n_dev).  mlp_mode: 0 = xr_nerf_mlp_fwd / _bwd (fp32 MFMA), 1 = the _f16 pair, 2 = xr_nerf_mlp_fwd_bf16x3
- * + xr_nerf_mlp_bwd, 3 = xr_nerf_mlp_fwd_f16x2 + xr_nerf_mlp_bwd (the default of the host package).  scatter_level0: the step scatters hash levels [scatter_level0, n_levels) only (0 = all) -- a
+ * (needed only without n_dev).  mlp_mode: the `arithmetic` of xr_nerf_mlp_fwd / _bwd (XR_MLP_F16X2 is the default of the host
+ * package).  scatter_level0: the step scatters hash levels [scatter_level0, n_levels) only (0 = all) -- a
  * data-parallel caller hands that slice of grad_table to its gradient collective and then scatters the coarser levels with
  * xr_hashgrid_bwd(XR_SCATTER_OVERWRITE) on the same row list (xr_nerf_mlp_bwd_list_slots), so the exchange runs under the rest
  * of the backward.
@@ -388,12 +379,9 @@ int xr_ngp_train_step(const float* table, const float* w_density, const float* w
  * xr_ngp_window_march write them); the encoder then reads them with coalesced loads (xr_hashgrid_fwd). */
 /* timed_entry (nullable): the name of ONE of the entry points the step runs ("xr_hashgrid_fwd", "xr_nerf_mlp_fwd",
  * "xr_composite_train", "xr_live_rows", "xr_nerf_mlp_bwd", "xr_hashgrid_bwd"): its launches are bracketed on `stream` by the two
- * events (xr_timing_event_create) -- bench.py's live duration of the dominant kernel inside the timed region.
+ * caller's events (hipEvent_t created with timing enabled; the library creates none) -- bench.py's live duration of the dominant kernel
+ * inside the timed region.
  */
-void* xr_timing_event_create(void);
-int xr_event_record(void* event, void* stream);
-int xr_timing_event_destroy(void* event);
-int xr_timing_event_elapsed_ms(void* begin, void* end, float* ms);
 
 /* ------------------------------------------------------------------------------------------
  * The marches of a refresh WINDOW as one series of launches, and the training LOOP between two grid refreshes as one call.
@@ -488,9 +476,9 @@ void* xr_rccl_create(const char* librccl_path, const void* id128, int world_size
 int xr_rccl_destroy(void* handle);
 int xr_rccl_exchange(void* handle, xr_grad_exchange* out);
 /* measured exposure of the exchange: with timing on, every `finish` that waits for something brackets the wait with two events on the
- * caller's stream; xr_rccl_exposed_ms (after a device synchronisation) -> mean / max of the last <= 64 of them and the total count */
-int xr_rccl_timing(void* handle, int on);
-int xr_rccl_exposed_ms(void* handle, float* mean_ms, float* max_ms, int* count);
+ * caller's stream.  The call reports (three non-null results; after a device synchronisation) mean / max of the last <= 64 of them and
+ * the total count, THEN sets the recording state: timing_on != 0 starts a new record, 0 stops recording. */
+int xr_rccl_exposed_ms(void* handle, int timing_on, float* mean_ms /*nullable*/, float* max_ms, int* count);
 
 /* tcnn.Network(FullyFusedMLP) on its own (compatibility surface; the hot path uses the fused kernels above):
  * x [n, n_in] with arbitrary row / column strides (in floats), n_in <= 32, missing input columns = pad_value;
@@ -509,30 +497,20 @@ int xr_mlp_bwd(const float* x, long row_stride, long col_stride, int n_in, float
  * rows [row0, row0+nrows) of an H x W image; pose_host = the python [4,3] matrix. */
 int xr_gen_rays(const float* pose43_host, int H, int W, float fx, float fy, float cx, float cy, int row0,
                 int nrows, float* rays_o, float* rays_d, void* stream);
-/* loss = scale * sum huber_delta(rgb - target) (networks/hashnerf.py:37-44, utils/metrics.py);
- * writes dL/drgb and ADDS the loss into loss_out[0] (caller zero-fills) */
-int xr_huber_loss_grad(const float* rgb, const float* target, uint32_t n_elems, float delta, float scale,
+/* loss = scale * sum huber_delta(rgb - target) (networks/hashnerf.py:37-44, utils/metrics.py); writes dL/drgb and ADDS the loss into
+ * loss_out[0] (caller zero-fills).  alpha (nullable, [n_elems / 3]): also the alpha-masked squared error sum the reference turns into its
+ * logged PSNR (networks/hashnerf.py:40-42): loss_out[1] += sum ((rgb - target) * alpha)^2 -- loss_out then has two floats. */
+int xr_huber_loss_grad(const float* rgb, const float* target, const float* alpha, uint32_t n_elems, float delta, float scale,
                        float* grad, float* loss_out, void* stream);
-/* the same plus the alpha-masked squared error sum the reference turns into its logged PSNR
- * (networks/hashnerf.py:40-42): loss_mse_out[0] += loss, loss_mse_out[1] += sum ((rgb-target)*alpha)^2 */
-int xr_huber_loss_grad_mse(const float* rgb, const float* target, const float* alpha /*[n_rays]*/, uint32_t n_rays,
-                           float delta, float scale, float* grad, float* loss_mse_out /*[2]*/, void* stream);
-/* HashBatchSample + RandomBGColor (datasets/pipelines/create.py:153-191, augment.py:290-317) in one launch:
- * rows [n,11] = (o3, d3, rgba4, img_id) of the device-resident ray table -> batch tensors; bg ~ U[0,1) (PCG32) */
-int xr_make_batch(const float* rays_rgb_rows, uint32_t n, uint64_t rng_state, uint64_t rng_inc, float* rays_o,
-                  float* rays_d, float* target, float* alpha, float* bg, int32_t* img_ids, void* stream);
+/* HashBatchSample + RandomBGColor (datasets/pipelines/create.py:153-191, augment.py:290-317): xr_make_batch_series below, one launch for
+ * 1..XR_NGP_WINDOW batches -- rows [n,11] = (o3, d3, rgba4, img_id) of the device-resident ray table -> batch tensors; bg ~ U[0,1) (PCG32) */
 /* gradients[k] *= (*scale_dev) * host_factor for up to 4 tensors in one launch (scale_dev nullable = 1): the
  * incoming-gradient scaling of the fused train step (networks/hashnerf.py:24-43 leaves it to autograd) and the
  * 1/world_size of data-parallel averaging; a factor of exactly 1 costs no memory traffic. */
 int xr_scale_multi(int n_tensors, float* const* tensors, const size_t* n, const float* scale_dev, float host_factor,
                    void* stream);
-/* torch.optim.Adam step with L2 weight decay (configs/instant_ngp/nerf_blender_local01.py:14-18),
- * fused with the optional EMA copy of mmcv's EMAHook (:24): ema = (1-mom)*ema + mom*p. */
-int xr_adam_step(float* p, const float* g, float* m, float* v, size_t n, int step, float lr, float beta1,
-                 float beta2, float eps, float weight_decay, float* ema /*nullable*/, float ema_momentum,
-                 void* stream);
-
-/* the same update for up to 4 parameter tensors in ONE launch; arrays are HOST arrays of device pointers /
+/* torch.optim.Adam step with L2 weight decay (configs/instant_ngp/nerf_blender_local01.py:14-18), fused with the optional EMA copy of
+ * mmcv's EMAHook (:24): ema = (1-mom)*ema + mom*p -- for 1..4 parameter tensors in ONE launch; arrays are HOST arrays of device pointers /
  * element counts (ema may be NULL, or hold NULL entries).  grad_scale: factor on the gradients as they are read (1 = none;
  * 1/world_size after a summing all-reduce -- bit for bit the update of `g *= grad_scale` followed by this call, without
  * that pass over the gradients; the gradient buffers themselves are not modified). */
@@ -647,23 +625,19 @@ int xr_nerf_render_forward(const float* raw, const float* z_vals, const float* r
  *   forward:          y [M,N] = act(x [M,K] . w^T + bias)            (bias nullable, relu 0/1)
  *   backward, input:  dx [M,K] = (dy [M,N] where mask_src > 0) . w    (mask_src nullable: the layer's relu output)
  *   backward, weight: dw_partials [splits,N,K] = per-M-range partial sums of (dy masked)^T . x; the caller adds them in
- *                     order (bit-reproducible); splits = xr_linear_backward_weight_splits(M, N, K)
- *   backward, bias:   db_partials [splits,N] = per-M-range column sums of (dy masked); splits = xr_linear_backward_bias_splits(M) */
+ *                     order (bit-reproducible); splits = xr_linear_backward_splits(M, N, K)
+ *   backward, bias:   db_partials [splits,N] = per-M-range column sums of (dy masked); splits = xr_linear_backward_splits(M, 0, 0) */
 int xr_linear_forward(const float* x, const float* w, const float* bias, uint32_t M, uint32_t N, uint32_t K, int relu,
                       float* y, void* stream);
-int xr_linear_backward_input(const float* dy, const float* mask_src, const float* w, uint32_t M, uint32_t N, uint32_t K,
+/* w_transposed != 0: the weight is handed over transposed by the caller (w_t [K,N] row-major): served by the forward's split-operand kernel */
+int xr_linear_backward_input(const float* dy, const float* mask_src, const float* w, int w_transposed, uint32_t M, uint32_t N, uint32_t K,
                              float* dx, void* stream);
-/* the same with the weight transposed by the caller (w_t [K,N] row-major): served by the forward's split-operand kernel */
-int xr_linear_backward_input_t(const float* dy, const float* mask_src, const float* w_t, uint32_t M, uint32_t N, uint32_t K,
-                               float* dx, void* stream);
-uint32_t xr_linear_backward_weight_splits(uint32_t M, uint32_t N, uint32_t K);
+/* M ranges of the weight gradient of an N x K layer; N == K == 0: of the bias gradient alone (xr_linear_backward_bias) */
+uint32_t xr_linear_backward_splits(uint32_t M, uint32_t N, uint32_t K);
+/* db_partials (nullable): weight and bias gradient in one launch: db_partials [splits,N] over the SAME M ranges as dw_partials (taken from
+ * the operand panels the product stages anyway; no pass of its own over dy and the mask) */
 int xr_linear_backward_weight(const float* dy, const float* mask_src, const float* x, uint32_t M, uint32_t N, uint32_t K,
-                              uint32_t splits, float* dw_partials, void* stream);
-/* weight and bias gradient in one launch: db_partials [splits,N] over the SAME M ranges as dw_partials (taken from the operand panels
- * the product stages anyway; no pass of its own over dy and the mask) */
-int xr_linear_backward_weight_bias(const float* dy, const float* mask_src, const float* x, uint32_t M, uint32_t N, uint32_t K,
-                                   uint32_t splits, float* dw_partials, float* db_partials, void* stream);
-uint32_t xr_linear_backward_bias_splits(uint32_t M);
+                              uint32_t splits, float* dw_partials, float* db_partials, void* stream);
 int xr_linear_backward_bias(const float* dy, const float* mask_src, uint32_t M, uint32_t N, uint32_t splits,
                             float* db_partials, void* stream);
 

@@ -158,23 +158,23 @@ def test_linear_kernels_on_the_host(E, M, N, K, gemm_kernel):
     assert np.abs(y - np.maximum(ref, 0)).max() <= 2e-5 * max(1.0, np.abs(ref).max())
     dym = dy.astype(np.float64) * (y > 0)
     dx = E.aligned((M, K))
-    E.check(L.xr_linear_backward_input(E.p(dy), E.p(y), E.p(w), M, N, K, E.p(dx), None), L)
+    E.check(L.xr_linear_backward_input(E.p(dy), E.p(y), E.p(w), 0, M, N, K, E.p(dx), None), L)
     assert np.abs(dx - dym @ w.astype(np.float64)).max() <= 5e-5 * max(1.0, np.abs(dym @ w).max())
-    splits = int(L.xr_linear_backward_weight_splits(M, N, K))
+    splits = int(L.xr_linear_backward_splits(M, N, K))
     part = E.aligned((splits, N, K))
-    E.check(L.xr_linear_backward_weight(E.p(dy), E.p(y), E.p(x), M, N, K, splits, E.p(part), None), L)
+    E.check(L.xr_linear_backward_weight(E.p(dy), E.p(y), E.p(x), M, N, K, splits, E.p(part), None, None), L)
     rw = dym.T @ x.astype(np.float64)
     assert np.abs(part.sum(0) - rw).max() <= 5e-5 * max(1.0, np.abs(rw).max())
-    bs = int(L.xr_linear_backward_bias_splits(M))
+    bs = int(L.xr_linear_backward_splits(M, 0, 0))
     pb = E.aligned((bs, N))
     E.check(L.xr_linear_backward_bias(E.p(dy), E.p(y), M, N, bs, E.p(pb), None), L)
     assert np.abs(pb.sum(0) - dym.sum(0)).max() <= 5e-5 * max(1.0, np.abs(dym.sum(0)).max())
     # the input gradient with the weight handed over transposed (the forward's kernel), and weight + bias gradient in one launch
     wt = E.aligned((K, N), fill=np.ascontiguousarray(w.T))
     dx2 = E.aligned((M, K))
-    E.check(L.xr_linear_backward_input_t(E.p(dy), E.p(y), E.p(wt), M, N, K, E.p(dx2), None), L)
+    E.check(L.xr_linear_backward_input(E.p(dy), E.p(y), E.p(wt), 1, M, N, K, E.p(dx2), None), L)
     assert np.abs(dx2 - dym @ w.astype(np.float64)).max() <= 5e-5 * max(1.0, np.abs(dym @ w).max())
     part2, pb2 = E.aligned((splits, N, K)), E.aligned((splits, N))
-    E.check(L.xr_linear_backward_weight_bias(E.p(dy), E.p(y), E.p(x), M, N, K, splits, E.p(part2), E.p(pb2), None), L)
+    E.check(L.xr_linear_backward_weight(E.p(dy), E.p(y), E.p(x), M, N, K, splits, E.p(part2), E.p(pb2), None), L)
     assert np.array_equal(part2, part)
     assert np.abs(pb2.sum(0) - dym.sum(0)).max() <= 5e-5 * max(1.0, np.abs(dym.sum(0)).max())

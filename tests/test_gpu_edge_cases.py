@@ -63,19 +63,21 @@ def test_zero_sized_and_invalid_calls(dev):
     s, r, o = meta._args()
     # n == 0 is a successful no-op for the per-sample kernels
     assert L.xr_hashgrid_fwd(None, None, 3, 1, 0, None, None, 16, s, r, o, None, 0, None) == 0
-    assert L.xr_nerf_mlp_fwd(None, 0, None, 0, 0, None, None, None, None, 1, 2, 1.0, None, None) == 0
+    assert L.xr_nerf_mlp_fwd(0, None, 0, None, 0, 0, None, None, None, None, 1, 2, 1.0, None, None) == 0
     assert L.xr_generate_grid_samples(None, 0, 0, 1, 0.0, 0.0, 1.0, 0, 0, None, 3, 1, None, None) == 0
     # bad arguments are reported, not executed
     t = torch.zeros(16, device=dev)
     assert L.xr_rays_sampler(t.data_ptr(), t.data_ptr(), t.data_ptr(), 4, 0.0, 1.0, 0.05, 0.004, 64, 0, 0, t.data_ptr(),
                              t.data_ptr(), t.data_ptr(), t.data_ptr(), None, 0, 0, 0, 0, None, 0, None) == -22
     assert b'workspace' in L.xr_last_error()
-    assert L.xr_nerf_mlp_bwd(t.data_ptr(), 64, t.data_ptr(), 3, 8, None, t.data_ptr(), t.data_ptr(), 9, 5, 1.0,
+    assert L.xr_nerf_mlp_bwd(0, t.data_ptr(), 64, t.data_ptr(), 3, 8, None, t.data_ptr(), t.data_ptr(), 9, 5, 1.0,
                              t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), 1 << 30, None, None, None) == -22
     assert b'hidden layers' in L.xr_last_error()              # (1..8 per network; 5 + 5 = tcnn's default runs on the streamed kernels)
-    assert L.xr_nerf_mlp_bwd(t.data_ptr(), 64, t.data_ptr(), 3, 8, None, t.data_ptr(), t.data_ptr(), 5, 5, 1.0,
+    assert L.xr_nerf_mlp_bwd(0, t.data_ptr(), 64, t.data_ptr(), 3, 8, None, t.data_ptr(), t.data_ptr(), 5, 5, 1.0,
                              t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), 1 << 20, None, None, None) == -22
     assert b'workspace' in L.xr_last_error()
+    assert L.xr_nerf_mlp_fwd(7, t.data_ptr(), 64, None, 0, 8, None, None, t.data_ptr(), None, 1, 2, 1.0, t.data_ptr(), None) == -22
+    assert b'arithmetic' in L.xr_last_error()
     with pytest.raises(_lib.XrError):
         ops.ema_grid_samples(torch.zeros(6, device=dev), 6, 0.95, torch.zeros(6, device=dev))   # not a multiple of 4
 
@@ -149,7 +151,7 @@ def test_live_row_list_edge_cases(O, dev):
     assert L.xr_hashgrid_bwd(t.data_ptr(), 3, t.data_ptr(), 8, 8, None, t.data_ptr(), meta.n_levels, s, r, o, t.data_ptr(), None, 0, 0, None) == -22
     one_lib = torch.device(dev).type == 'cuda'        # (the host build of the kernels is one library per source file)
     assert not one_lib or b'row list' in L.xr_last_error()
-    assert L.xr_nerf_mlp_bwd(t.data_ptr(), 64, t.data_ptr(), 3, 8, None, t.data_ptr(), t.data_ptr(), 1, 2, 1.0, t.data_ptr(), t.data_ptr(),
+    assert L.xr_nerf_mlp_bwd(0, t.data_ptr(), 64, t.data_ptr(), 3, 8, None, t.data_ptr(), t.data_ptr(), 1, 2, 1.0, t.data_ptr(), t.data_ptr(),
                              t.data_ptr(), t.data_ptr(), t.data_ptr(), 1 << 30, t.data_ptr(), None, None) == -22
     assert not one_lib or b'come together' in L.xr_last_error()
     assert L.xr_live_rows(None, 8, None, t.data_ptr(), t.data_ptr(), t.data_ptr(), None, 0, 0, None) == -22

@@ -34,7 +34,8 @@ class StepSet(C.Structure):
                [(k, C.c_void_p) for k in ('grad_w_density', 'grad_w_color', 'loss_mse', 'live_seg_count', 'grad_table')]
 
 
-WINDOW = 16             # XR_NGP_WINDOW
+WINDOW = 16                      # XR_NGP_WINDOW
+LIVE_SEGMENT_ROWS = 1024         # XR_LIVE_SEGMENT_ROWS
 
 EX_ALL_REDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 EX_SCATTER_GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
@@ -70,7 +71,6 @@ class LoopState(C.Structure):
 SIGNATURES = {
     'xr_last_error': (C.c_char_p, []),
     'xr_version': (_i32, []),
-    'xr_device_cus': (_i32, []),
     'xr_pcg32_host_state': (None, [_u64, _u64, _vp, _vp]),
     'xr_rays_sampler': (_i32, [_vp, _vp, _vp, _u32, _f, _f, _f, _f, _u32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _sz, _vp]),
     'xr_compacted_coord': (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -85,7 +85,6 @@ SIGNATURES = {
     'xr_render_slice_composite': (_i32, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _i32, _i32, _vp, _vp, _vp]),
     'xr_calc_rgb_forward': (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, _i32, _i32, _vp, _vp]),
     'xr_calc_rgb_backward': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _i32, _i32, _vp, _vp]),
-    'xr_hashgrid_bwd_adam_supported': (_i32, [_u32, _i32, _vp, _vp, _vp]),
     'xr_hashgrid_bwd_adam': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     'xr_train_loss_scalars': (_i32, [_vp, _vp, _vp, _u32, _f, _f, _vp, _vp]),
     'xr_composite_train': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _i32, _i32, _f, _f, _vp, _vp, _vp, _vp, _vp]),
@@ -103,40 +102,27 @@ SIGNATURES = {
     'xr_hashgrid_bwd': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp]),
     'xr_set_helper_stream': (_i32, [_vp, _vp, _vp]),
     'xr_sh4': (_i32, [_vp, _u32, _u32, _vp, _vp]),
-    'xr_nerf_mlp_fwd': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp]),
+    'xr_nerf_mlp_fwd': (_i32, [_i32, _vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp]),
     'xr_nerf_mlp_bwd_workspace_bytes': (_sz, [_u32, _i32, _i32]),
     'xr_ngp_train_step': (_i32, [_vp, _vp, _vp, _i32, _i32, _f, _i32, _i32, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _u32, _vp, _vp, _vp,
                                  _vp, _i32, _i32, _f, _f, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp, _sz,
                                  _vp, _sz, _i32, _vp, _u32, _vp, _vp, _vp, C.c_char_p, _vp, _vp, _vp]),
-    'xr_event_record': (_i32, [_vp, _vp]),
     'xr_ngp_loop_run': (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, C.c_char_p, _vp, _vp]),
     'xr_rccl_unique_id': (_i32, [C.c_char_p, _vp]),
     'xr_rccl_create': (_vp, [C.c_char_p, _vp, _i32, _i32]),
     'xr_rccl_destroy': (_i32, [_vp]),
     'xr_rccl_exchange': (_i32, [_vp, _vp]),
-    'xr_rccl_timing': (_i32, [_vp, _i32]),
-    'xr_rccl_exposed_ms': (_i32, [_vp, _vp, _vp, _vp]),
-    'xr_timing_event_create': (_vp, []),
-    'xr_timing_event_destroy': (_i32, [_vp]),
-    'xr_timing_event_elapsed_ms': (_i32, [_vp, _vp, _vp]),
-    'xr_nerf_mlp_fwd_bf16x3': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp]),
-    'xr_nerf_mlp_fwd_f16x2': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp]),
-    'xr_nerf_mlp_fwd_f16': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp]),
-    'xr_nerf_mlp_bwd_f16': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
-    'xr_nerf_mlp_bwd': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
-    'xr_live_rows_segments': (_sz, [_u32]),
+    'xr_rccl_exposed_ms': (_i32, [_vp, _i32, _vp, _vp, _vp]),
+    'xr_nerf_mlp_bwd': (_i32, [_i32, _vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     'xr_live_rows': (_i32, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _u32, _i32, _vp]),
     'xr_nerf_mlp_bwd_list_slots': (_i32, [_vp, _sz, _u32, _vp, _vp, _vp]),
     'xr_mlp_fwd': (_i32, [_vp, C.c_long, C.c_long, _i32, _f, _u32, _vp, _i32, _vp, _vp]),
     'xr_mlp_bwd_workspace_bytes': (_sz, [_i32]),
     'xr_mlp_bwd': (_i32, [_vp, C.c_long, C.c_long, _i32, _f, _u32, _vp, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     'xr_gen_rays': (_i32, [_vp, _i32, _i32, _f, _f, _f, _f, _i32, _i32, _vp, _vp, _vp]),
-    'xr_huber_loss_grad': (_i32, [_vp, _vp, _u32, _f, _f, _vp, _vp, _vp]),
-    'xr_huber_loss_grad_mse': (_i32, [_vp, _vp, _vp, _u32, _f, _f, _vp, _vp, _vp]),
-    'xr_make_batch': (_i32, [_vp, _u32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'xr_huber_loss_grad': (_i32, [_vp, _vp, _vp, _u32, _f, _f, _vp, _vp, _vp]),
     'xr_adam_step_multi': (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f, _f, _f, _f, _f, _f, _f, _vp]),
     'xr_scale_multi': (_i32, [_i32, _vp, _vp, _vp, _f, _vp]),
-    'xr_adam_step': (_i32, [_vp, _vp, _vp, _vp, _sz, _i32, _f, _f, _f, _f, _f, _vp, _f, _vp]),
     'xr_mip_zvals': (_i32, [_vp, _vp, _u32, _u32, _i32, _vp, _vp, _vp]),
     'xr_mip_encode_channels': (_u32, [_i32, _i32, _i32, _i32, _i32]),
     'xr_mip_encode': (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _u32, _vp]),
@@ -153,13 +139,10 @@ SIGNATURES = {
     'xr_nerf_render_forward': (_i32, [_vp, _vp, _vp, _u32, _u32, _i32, _vp, _vp, _vp, _vp, _vp]),
     'xr_nerf_density_splat': (_i32, [_i32, _vp, _u32, _u32, _vp, _i32, _i32, _vp, _vp, _vp]),
     'xr_linear_forward': (_i32, [_vp, _vp, _vp, _u32, _u32, _u32, _i32, _vp, _vp]),
-    'xr_linear_backward_input': (_i32, [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp]),
-    'xr_linear_backward_input_t': (_i32, [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp]),
-    'xr_linear_backward_weight_splits': (_u32, [_u32, _u32, _u32]),
-    'xr_linear_backward_weight_bias': (_i32, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
-    'xr_linear_backward_bias_splits': (_u32, [_u32]),
+    'xr_linear_backward_input': (_i32, [_vp, _vp, _vp, _i32, _u32, _u32, _u32, _vp, _vp]),
+    'xr_linear_backward_splits': (_u32, [_u32, _u32, _u32]),
     'xr_linear_backward_bias': (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp]),
-    'xr_linear_backward_weight': (_i32, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp]),
+    'xr_linear_backward_weight': (_i32, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
     'xr_kilo_render_workspace_bytes': (_sz, [_u32, _u32, _u32]),
     'xr_kilo_render_rays': (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32,
                                    _u32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),

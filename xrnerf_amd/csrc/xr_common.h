@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include "../../include/xrnerf_mi355.h"
+extern "C" __attribute__((visibility("hidden"))) int xr_device_cus(void);        // compute units of the current device (xr_mlp.hip); not exported
 
 #define XR_WAVE 64
 
@@ -121,6 +122,9 @@ __host__ __device__ inline float xr_unwarp_dt(float dt) {   // ray_sampler_heade
 // the caller-provided helper stream of this thread (xr_set_helper_stream), or nullptr: see xr_scatter.hip
 struct XrHelper { hipStream_t stream; hipEvent_t fork, join; };
 const XrHelper* xr_internal_helper();
+// every level of this geometry has a non-atomic scatter path at a capacity of n rows (what the update inside the scatter needs): xr_encode.hip
+int xr_internal_hashgrid_bwd_adam_supported(uint32_t n, int n_levels, const float* scale_host, const uint32_t* resolution_host,
+                                            const uint32_t* offset_host);
 // library-internal (not part of the C ABI): see xr_mlp.hip
 void xr_internal_defer_mlp_reduce(bool on);
 int xr_internal_mlp_bwd_reduce(const void* workspace, uint32_t n, int n_hidden_density, int n_hidden_color, float* grad_w_density, float* grad_w_color, int overwrite, void* stream);

@@ -141,27 +141,26 @@ extern "C" int xr_rccl_destroy(void* handle) {
     delete C;
     return XR_OK;
 }
-// measured exposure: on != 0 starts a new record; xr_rccl_exposed_ms (after the caller synchronised the device) -> the mean / max wait
-// of the last <= 64 finishes that waited for something, and how many
-extern "C" int xr_rccl_timing(void* handle, int on) {
+// measured exposure.  Reports (mean_ms / max_ms / count non-null; after the caller synchronised the device) the mean / max wait of the last
+// <= 64 finishes that waited for something and how many there were, THEN sets the recording state: timing_on != 0 starts a new record
+// (events created at the first use), 0 stops recording.
+extern "C" int xr_rccl_exposed_ms(void* handle, int timing_on, float* mean_ms, float* max_ms, int* count) {
     XR_REQUIRE(handle, "null handle");
+    XR_REQUIRE((mean_ms && max_ms && count) || (!mean_ms && !max_ms && !count), "the three results come together");
     XrRccl* C = (XrRccl*)handle;
-    if (on && !C->t0[0])
-        for (int i = 0; i < XrRccl::RING; ++i) { XR_HIP(hipEventCreate(&C->t0[i])); XR_HIP(hipEventCreate(&C->t1[i])); }
-    C->timing = on != 0; C->n_timed = 0;
-    return XR_OK;
-}
-extern "C" int xr_rccl_exposed_ms(void* handle, float* mean_ms, float* max_ms, int* count) {
-    XR_REQUIRE(handle && mean_ms && max_ms && count, "null pointer");
-    XrRccl* C = (XrRccl*)handle;
-    const unsigned n = C->n_timed < (unsigned)XrRccl::RING ? C->n_timed : (unsigned)XrRccl::RING;
-    float sum = 0.f, mx = 0.f;
-    for (unsigned i = 0; i < n; ++i) {
-        float ms = 0.f;
-        XR_HIP(hipEventElapsedTime(&ms, C->t0[i], C->t1[i]));
-        sum += ms; mx = ms > mx ? ms : mx;
+    if (mean_ms) {
+        const unsigned n = C->n_timed < (unsigned)XrRccl::RING ? C->n_timed : (unsigned)XrRccl::RING;
+        float sum = 0.f, mx = 0.f;
+        for (unsigned i = 0; i < n; ++i) {
+            float ms = 0.f;
+            XR_HIP(hipEventElapsedTime(&ms, C->t0[i], C->t1[i]));
+            sum += ms; mx = ms > mx ? ms : mx;
+        }
+        *mean_ms = n ? sum / n : 0.f; *max_ms = mx; *count = (int)C->n_timed;
     }
-    *mean_ms = n ? sum / n : 0.f; *max_ms = mx; *count = (int)C->n_timed;
+    if (timing_on && !C->t0[0])
+        for (int i = 0; i < XrRccl::RING; ++i) { XR_HIP(hipEventCreate(&C->t0[i])); XR_HIP(hipEventCreate(&C->t1[i])); }
+    C->timing = timing_on != 0; C->n_timed = 0;
     return XR_OK;
 }
 // the exchange hooks of xr_ngp_loop_desc served by this communicator

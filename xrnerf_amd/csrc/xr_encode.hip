@@ -365,8 +365,8 @@ extern "C" int xr_hashgrid_bwd(const float* x, uint32_t x_stride, const float* d
     return XR_OK;
 }
 
-extern "C" int xr_hashgrid_bwd_adam_supported(uint32_t n, int n_levels, const float* scale_host, const uint32_t* resolution_host,
-                                              const uint32_t* offset_host) {
+int xr_internal_hashgrid_bwd_adam_supported(uint32_t n, int n_levels, const float* scale_host, const uint32_t* resolution_host,
+                                            const uint32_t* offset_host) {
     GridMeta gm; uint32_t hm;
     if (!scale_host || !resolution_host || !offset_host || n == 0) return 0;
     if (fill_meta(&gm, &hm, n_levels, scale_host, resolution_host, offset_host) != 0) return 0;
@@ -376,13 +376,18 @@ extern "C" int xr_hashgrid_bwd_adam(const float* x, uint32_t x_stride, const flo
                                     const uint32_t* rows, int n_levels, const float* scale_host, const uint32_t* resolution_host,
                                     const uint32_t* offset_host, void* workspace, size_t workspace_bytes, const xr_adam_fuse* adam,
                                     void* stream_) {
-    XR_REQUIRE(x && denc_t && scale_host && resolution_host && offset_host && workspace && adam, "null pointer");
+    if (!adam) {                     // dry run: is there a non-atomic path for every level at this row capacity?
+        XR_REQUIRE(xr_internal_hashgrid_bwd_adam_supported(n, n_levels, scale_host, resolution_host, offset_host),
+                   "a level of this geometry / row count has no non-atomic path: scatter and step separately");
+        return XR_OK;
+    }
+    XR_REQUIRE(x && denc_t && scale_host && resolution_host && offset_host && workspace, "null pointer");
     XR_REQUIRE(adam->param && adam->m && adam->v && adam->step >= 1, "bad optimiser state");
     XR_REQUIRE((((uintptr_t)adam->param | (uintptr_t)adam->m | (uintptr_t)adam->v | (uintptr_t)adam->ema | (uintptr_t)workspace) & 15) == 0,
                "buffers must be 16-byte aligned");
     XR_REQUIRE(n > 0 && x_stride >= 3 && ld >= n, "bad sizes");
     XR_REQUIRE(!rows || n_dev, "a row list comes with its device-side length (n_dev)");
-    XR_REQUIRE(xr_hashgrid_bwd_adam_supported(n, n_levels, scale_host, resolution_host, offset_host),
+    XR_REQUIRE(xr_internal_hashgrid_bwd_adam_supported(n, n_levels, scale_host, resolution_host, offset_host),
                "a level of this geometry / row count has no non-atomic path: scatter and step separately");
     GridMeta gm; uint32_t hm;
     XR_REQUIRE(fill_meta(&gm, &hm, n_levels, scale_host, resolution_host, offset_host) == 0, "bad level metadata");

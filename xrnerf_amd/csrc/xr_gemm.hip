@@ -381,24 +381,23 @@ extern "C" int xr_linear_forward(const float* x, const float* w, const float* bi
     return gemm_launch(g, 1, stream);
 }
 
-// dx [M,K] = (dy [M,N] masked by mask_src [M,N] > 0 when given) . w [N,K]
-extern "C" int xr_linear_backward_input(const float* dy, const float* mask_src, const float* w, uint32_t M, uint32_t N,
+// dx [M,K] = (dy [M,N] masked by mask_src [M,N] > 0 when given) . w [N,K].  w_transposed != 0: the weight is handed over TRANSPOSED
+// (w_t [K,N] row-major): both operands are then [rows, contraction] like the forward's, and the product runs on the split-operand kernel
+// (163 us against 267 us on the fp32 MFMA at 131072 x 256 x 256)
+extern "C" int xr_linear_backward_input(const float* dy, const float* mask_src, const float* w, int w_transposed, uint32_t M, uint32_t N,
                                         uint32_t K, float* dx, void* stream) {
+    if (w_transposed) {
+        GemmArgs g{dy, w, dx, nullptr, mask_src, M, K, N, N, N, K, 0, 0, 0, 0, 0, 0, nullptr};
+        return gemm_launch(g, 1, stream);
+    }
     GemmArgs g{dy, w, dx, nullptr, mask_src, M, K, N, N, K, K, 0, 1, 0, 0, 0, 0, nullptr};
     return gemm_launch(g, 1, stream);
 }
 
-// the same product with the weight handed over TRANSPOSED (w_t [K,N] row-major): both operands are then [rows, contraction] like the
-// forward's, and the product runs on the split-operand kernel (163 us against 267 us on the fp32 MFMA at 131072 x 256 x 256)
-extern "C" int xr_linear_backward_input_t(const float* dy, const float* mask_src, const float* w_t, uint32_t M, uint32_t N,
-                                          uint32_t K, float* dx, void* stream) {
-    GemmArgs g{dy, w_t, dx, nullptr, mask_src, M, K, N, N, N, K, 0, 0, 0, 0, 0, 0, nullptr};
-    return gemm_launch(g, 1, stream);
-}
-
 // dw_partials [splits, N, K]: partial sums of (dy masked)^T . x over `splits` ranges of the M rows; the caller adds
-// the partials (fixed order => bit-reproducible).  splits = xr_linear_backward_weight_splits(M).
-extern "C" uint32_t xr_linear_backward_weight_splits(uint32_t M, uint32_t N, uint32_t K) {
+// the partials (fixed order => bit-reproducible).  splits = xr_linear_backward_splits(M, N, K); N == K == 0: the bias gradient's.
+extern "C" uint32_t xr_linear_backward_splits(uint32_t M, uint32_t N, uint32_t K) {
+    if (N == 0 && K == 0) { const uint32_t b = M / 128; return b < 1 ? 1 : (b > 512 ? 512 : b); }
     // the output is only ceil(N/128) x ceil(K/128) tiles (4 for a 256 x 256 layer): split the M rows until ~1024
     // workgroups exist, but keep >= 8 k-panels (256 rows) per split (measured: 16 splits of 2048 rows = 64 workgroups
     // left 3/4 of the chip idle, 110-290 us per 32768-row call)
@@ -438,10 +437,6 @@ __global__ void __launch_bounds__(256) k_masked_colsum(const float* __restrict__
     }
 }
 
-extern "C" uint32_t xr_linear_backward_bias_splits(uint32_t M) {
-    uint32_t s = M / 128;
-    return s < 1 ? 1 : (s > 512 ? 512 : s);
-}
 extern "C" int xr_linear_backward_bias(const float* dy, const float* mask_src, uint32_t M, uint32_t N, uint32_t splits,
                                        float* db_partials, void* stream) {
     XR_REQUIRE(dy && db_partials, "null pointer");
@@ -456,20 +451,14 @@ extern "C" int xr_linear_backward_bias(const float* dy, const float* mask_src, u
     return XR_OK;
 }
 
-extern "C" int xr_linear_backward_weight(const float* dy, const float* mask_src, const float* x, uint32_t M, uint32_t N,
-                                         uint32_t K, uint32_t splits, float* dw_partials, void* stream) {
-    GemmArgs g{dy, x, dw_partials, nullptr, mask_src, N, K, M, N, K, K, 1, 1, 0, 0, (size_t)N * K, 0, nullptr};
-    return gemm_launch(g, splits, stream);
-}
-
-// weight AND bias gradient of a layer in one launch: db_partials [splits, N] = the same M-range column sums of (dy masked) that
+// db_partials (nullable) [splits, N]: weight AND bias gradient of a layer in one launch -- the same M-range column sums of (dy masked) that
 // xr_linear_backward_bias computes with a pass of its own, taken from the panels the weight-gradient product stages anyway
-extern "C" int xr_linear_backward_weight_bias(const float* dy, const float* mask_src, const float* x, uint32_t M, uint32_t N,
-                                              uint32_t K, uint32_t splits, float* dw_partials, float* db_partials, void* stream) {
-    XR_REQUIRE(db_partials, "null pointer");
+extern "C" int xr_linear_backward_weight(const float* dy, const float* mask_src, const float* x, uint32_t M, uint32_t N, uint32_t K,
+                                         uint32_t splits, float* dw_partials, float* db_partials, void* stream) {
     const char* env = getenv("XR_GEMM_F32");
-    if (env && strcmp(env, "bf16x3all") == 0) {            // that measurement mode has no column sums in its kernel: two launches
-        const int rc = xr_linear_backward_weight(dy, mask_src, x, M, N, K, splits, dw_partials, stream);
+    if (db_partials && env && strcmp(env, "bf16x3all") == 0) {   // that measurement mode has no column sums in its kernel: two launches
+        GemmArgs g0{dy, x, dw_partials, nullptr, mask_src, N, K, M, N, K, K, 1, 1, 0, 0, (size_t)N * K, 0, nullptr};
+        const int rc = gemm_launch(g0, splits, stream);
         if (rc != XR_OK) return rc;
         // per-split column sums over the same M ranges: k_masked_colsum with `splits` row ranges of k_per_split rows
         const uint32_t rows = (uint32_t)(((uint64_t)(M + splits - 1) / splits + GBK - 1) / GBK * GBK);

@@ -12,7 +12,7 @@ void xr_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* xr_last_error(void) { return g_err; }
-extern "C" int xr_version(void) { return 120; }    // 120 (round 5): one generation per entry point (xr_rays_sampler, xr_hashgrid_fwd / _bwd, xr_composite_train,
+extern "C" int xr_version(void) { return 121; }    // 121: xr_nerf_mlp_fwd / _bwd take their arithmetic as an argument; small merges.  120 (round 5): one generation per entry point (xr_rays_sampler, xr_hashgrid_fwd / _bwd, xr_composite_train,
                                                    // xr_live_rows, xr_generate_grid_samples, xr_clip_numsteps take their newest signatures), window march, loop without a handle
 
 extern "C" void xr_pcg32_host_state(uint64_t seed, uint64_t ncalls, uint64_t* state_host, uint64_t* inc_host) {
@@ -78,19 +78,12 @@ __global__ __launch_bounds__(256) void k_huber(const float* __restrict__ rgb, co
         if (alpha) atomicAdd(loss + 1, (ws2[0] + ws2[1]) + (ws2[2] + ws2[3]));
     }
 }
-extern "C" int xr_huber_loss_grad(const float* rgb, const float* target, uint32_t n_elems, float delta, float scale,
+extern "C" int xr_huber_loss_grad(const float* rgb, const float* target, const float* alpha, uint32_t n_elems, float delta, float scale,
                                   float* grad, float* loss_out, void* stream_) {
     XR_REQUIRE(rgb && target && grad && loss_out && n_elems > 0, "bad argument");
-    hipLaunchKernelGGL(k_huber, dim3(min(xr_div_up(n_elems, 256), 1024u)), dim3(256), 0, (hipStream_t)stream_, rgb, target,
-                       (const float*)nullptr, n_elems, delta, scale, grad, loss_out);
-    XR_LAUNCH_CHECK();
-    return XR_OK;
-}
-extern "C" int xr_huber_loss_grad_mse(const float* rgb, const float* target, const float* alpha, uint32_t n_rays, float delta,
-                                      float scale, float* grad, float* loss_mse_out, void* stream_) {
-    XR_REQUIRE(rgb && target && alpha && grad && loss_mse_out && n_rays > 0, "bad argument");
-    hipLaunchKernelGGL(k_huber, dim3(min(xr_div_up(3 * n_rays, 256), 1024u)), dim3(256), 0, (hipStream_t)stream_, rgb, target,
-                       alpha, 3 * n_rays, delta, scale, grad, loss_mse_out);
+    XR_REQUIRE(!alpha || n_elems % 3 == 0, "the masked error takes rgb triples");
+    hipLaunchKernelGGL(k_huber, dim3(min(xr_div_up(n_elems, 256), 1024u)), dim3(256), 0, (hipStream_t)stream_, rgb, target, alpha, n_elems,
+                       delta, scale, grad, loss_out);
     XR_LAUNCH_CHECK();
     return XR_OK;
 }
@@ -123,16 +116,6 @@ __global__ __launch_bounds__(256) void k_make_batch(const float* __restrict__ ro
     alpha[q] = a;
     img_ids[q] = (int32_t)r[10];
 }
-extern "C" int xr_make_batch(const float* rays_rgb_rows, uint32_t n, uint64_t rng_state, uint64_t rng_inc, float* rays_o,
-                             float* rays_d, float* target, float* alpha, float* bg, int32_t* img_ids, void* stream_) {
-    XR_REQUIRE(rays_rgb_rows && rays_o && rays_d && target && alpha && bg && img_ids && n > 0, "bad argument");
-    xr_pcg32 rng{rng_state, rng_inc};
-    XrBatchRows at = {};
-    hipLaunchKernelGGL(k_make_batch, dim3(xr_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream_, rays_rgb_rows, n, rng, rays_o,
-                       rays_d, target, alpha, bg, img_ids, at, 0u);
-    XR_LAUNCH_CHECK();
-    return XR_OK;
-}
 // n_series <= XR_NGP_WINDOW batches in one launch: batch c = rows [row0[c], row0[c] + n) of the table, drawn with the generator of call index
 // (first + c) (rng_state / rng_inc = xr_pcg32_host_state(seed, first)), written at rows c * ray_stride of the six outputs
 extern "C" int xr_make_batch_series(const float* rays_rgb_rows, const uint64_t* row0_host, uint32_t n, uint32_t n_series, uint32_t ray_stride,
@@ -150,34 +133,7 @@ extern "C" int xr_make_batch_series(const float* rays_rgb_rows, const uint64_t* 
 }
 
 // ------------------------------------------------------------------ fused Adam (+L2 weight decay, + optional EMA)
-// torch.optim.Adam semantics (adam1, xr_adam.h); one pass over p,g,m,v(,ema): 16 B per lane per stream.
-__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                               float* __restrict__ v, size_t n, float b1, float b2, float step_size,
-                                               float bc2s, float eps, float wd, float* __restrict__ ema, float mom) {
-    const size_t n4 = n / 4;
-    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        float4 pp = ((float4*)p)[i], mm = ((float4*)m)[i], vv = ((float4*)v)[i];
-        const float4 gg = ((const float4*)g)[i];
-        adam1(pp.x, gg.x, mm.x, vv.x, b1, b2, step_size, bc2s, eps, wd);
-        adam1(pp.y, gg.y, mm.y, vv.y, b1, b2, step_size, bc2s, eps, wd);
-        adam1(pp.z, gg.z, mm.z, vv.z, b1, b2, step_size, bc2s, eps, wd);
-        adam1(pp.w, gg.w, mm.w, vv.w, b1, b2, step_size, bc2s, eps, wd);
-        ((float4*)p)[i] = pp; ((float4*)m)[i] = mm; ((float4*)v)[i] = vv;
-        if (ema) {
-            float4 e = ((float4*)ema)[i];
-            e.x = (1.f - mom) * e.x + mom * pp.x; e.y = (1.f - mom) * e.y + mom * pp.y;
-            e.z = (1.f - mom) * e.z + mom * pp.z; e.w = (1.f - mom) * e.w + mom * pp.w;
-            ((float4*)ema)[i] = e;
-        }
-    }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
-        const size_t i = n4 * 4 + threadIdx.x;
-        float pp = p[i], mm = m[i], vv = v[i];
-        adam1(pp, g[i], mm, vv, b1, b2, step_size, bc2s, eps, wd);
-        p[i] = pp; m[i] = mm; v[i] = vv;
-        if (ema) ema[i] = (1.f - mom) * ema[i] + mom * pp;
-    }
-}
+// torch.optim.Adam semantics (adam1, xr_adam.h); one pass over p, g, m, v (, ema): 16 B per lane per stream.
 // up to 4 parameter tensors in ONE launch (the three tensors of HashNerfMLP: 12.2 M + 3 K + 7 K floats):
 // block ranges are assigned proportionally, every tensor gets at least one block
 struct AdamTensors { float* p[4]; const float* g[4]; float* m[4]; float* v[4]; float* ema[4]; unsigned long long n[4]; unsigned first_block[5]; };
@@ -281,15 +237,3 @@ extern "C" int xr_scale_multi(int n_tensors, float* const* p, const size_t* n, c
     return XR_OK;
 }
 
-extern "C" int xr_adam_step(float* p, const float* g, float* m, float* v, size_t n, int step, float lr, float beta1,
-                            float beta2, float eps, float weight_decay, float* ema, float ema_momentum, void* stream_) {
-    if (n == 0) return XR_OK;
-    XR_REQUIRE(p && g && m && v && step >= 1, "bad argument");
-    XR_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)ema) & 15) == 0, "buffers must be 16-byte aligned");
-    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
-    const uint32_t blocks = min(xr_div_up(n / 4 + 1, 256), 2048u);
-    hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, p, g, m, v, n, beta1, beta2, lr / bc1,
-                       sqrtf(bc2), eps, weight_decay, ema, ema_momentum);
-    XR_LAUNCH_CHECK();
-    return XR_OK;
-}

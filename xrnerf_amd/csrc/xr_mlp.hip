@@ -2265,7 +2265,7 @@ __global__ __launch_bounds__(DP_BW * 64, 1) void k_nerf_mlp_bwd_deep(
 static thread_local const int32_t* g_fwd_splat_idx = nullptr;
 static thread_local float* g_fwd_splat_grid = nullptr;
 static int g_cus = 0;
-extern "C" int xr_device_cus(void) {
+extern "C" int xr_device_cus(void) {       // (internal, hidden: xr_common.h)
     if (g_cus == 0) {
         int dev = 0; hipDeviceProp_t p;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
@@ -2329,7 +2329,7 @@ static int launch_fwd_deep(const float* enc_t, uint32_t ld, const float* dirs, u
     return XR_OK;
 }
 
-extern "C" int xr_nerf_mlp_fwd(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
+static int mlp_fwd_f32(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
                                const uint32_t* n_dev, const uint32_t* rows, const float* w_density, const float* w_color, int n_hidden_density, int n_hidden_color,
                                float pad_value, float* raw, void* stream_) {
     if (n == 0) return XR_OK;
@@ -2379,7 +2379,7 @@ static bool live_rows_enabled() {          // XR_MLP_LIVE=0: run the backward ov
     if (on < 0) { const char* e = getenv("XR_MLP_LIVE"); on = (e && e[0] == '0') ? 0 : 1; }
     return on == 1;
 }
-extern "C" size_t xr_live_rows_segments(uint32_t n) { return xr_div_up(n, LIVE_SEG); }
+static_assert(LIVE_SEG == XR_LIVE_SEGMENT_ROWS, "the header names the segment size");
 // seg_counts_ready != 0: seg_count already holds the live rows per segment (xr_composite_train2 counted them while writing
 // the rows) -- only the ranking / list pass runs
 extern "C" int xr_live_rows(const float* dloss_doutput, uint32_t n, const uint32_t* n_dev, uint32_t* seg_count, uint32_t* live_rows,
@@ -2433,7 +2433,7 @@ int xr_internal_mlp_bwd_reduce(const void* workspace, uint32_t n, int nhd, int n
     return XR_OK;
 }
 
-extern "C" int xr_nerf_mlp_bwd(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
+static int mlp_bwd_f32(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
                                const uint32_t* n_dev, const float* w_density, const float* w_color, int n_hidden_density, int n_hidden_color,
                                float pad_value, const float* draw, float* denc_t, float* grad_w_density,
                                float* grad_w_color, void* workspace, size_t workspace_bytes, const uint32_t* live_rows,
@@ -2560,7 +2560,7 @@ extern "C" int xr_mlp_bwd(const float* x, long row_stride, long col_stride, int 
 }
 
 // ---- reference-precision mode entry points (same contracts as xr_nerf_mlp_fwd / xr_nerf_mlp_bwd)
-extern "C" int xr_nerf_mlp_fwd_f16(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
+static int mlp_fwd_f16(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
                                    const uint32_t* n_dev, const uint32_t* rows, const float* w_density, const float* w_color,
                                    int n_hidden_density, int n_hidden_color, float pad_value, float* raw, void* stream_) {
     if (n == 0) return XR_OK;
@@ -2585,7 +2585,7 @@ extern "C" int xr_nerf_mlp_fwd_f16(const float* enc_t, uint32_t ld, const float*
 }
 
 // fp32-accuracy forward on the bf16 matrix cores (3-way operand split; same contract as xr_nerf_mlp_fwd, topology (1, 2))
-extern "C" int xr_nerf_mlp_fwd_bf16x3(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
+static int mlp_fwd_bf16x3(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
                                       const uint32_t* n_dev, const uint32_t* rows, const float* w_density, const float* w_color,
                                       int n_hidden_density, int n_hidden_color, float pad_value, float* raw, void* stream_) {
     if (n == 0) return XR_OK;
@@ -2613,7 +2613,7 @@ extern "C" int xr_nerf_mlp_fwd_bf16x3(const float* enc_t, uint32_t ld, const flo
 
 // fp32-accurate forward on the fp16 matrix cores (2-way operand split: k_nerf_mlp_fwd_h2; same contract as xr_nerf_mlp_fwd).  Any
 // depth but (1, 2) takes the streamed kernel, which uses the same arithmetic.
-extern "C" int xr_nerf_mlp_fwd_f16x2(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
+static int mlp_fwd_f16x2(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
                                      const uint32_t* n_dev, const uint32_t* rows, const float* w_density, const float* w_color,
                                      int n_hidden_density, int n_hidden_color, float pad_value, float* raw, void* stream_) {
     if (n == 0) return XR_OK;
@@ -2639,7 +2639,7 @@ extern "C" int xr_nerf_mlp_fwd_f16x2(const float* enc_t, uint32_t ld, const floa
     return XR_OK;
 }
 
-extern "C" int xr_nerf_mlp_bwd_f16(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
+static int mlp_bwd_f16(const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
                                    const uint32_t* n_dev, const float* w_density, const float* w_color, int n_hidden_density,
                                    int n_hidden_color, float pad_value, const float* draw, float* denc_t, float* grad_w_density,
                                    float* grad_w_color, void* workspace, size_t workspace_bytes, const uint32_t* live_rows,
@@ -2669,6 +2669,24 @@ extern "C" int xr_nerf_mlp_bwd_f16(const float* enc_t, uint32_t ld, const float*
     return XR_OK;
 }
 
+// ---- the two entry points: `arithmetic` selects the kernel family (include/xrnerf_mi355.h: XR_MLP_F32 / _F16 / _BF16X3 / _F16X2)
+extern "C" int xr_nerf_mlp_fwd(int arithmetic, const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
+                               const uint32_t* n_dev, const uint32_t* rows, const float* w_density, const float* w_color, int n_hidden_density,
+                               int n_hidden_color, float pad_value, float* raw, void* stream) {
+    XR_REQUIRE(arithmetic >= XR_MLP_F32 && arithmetic <= XR_MLP_F16X2, "unknown arithmetic");
+    auto fwd = arithmetic == XR_MLP_F16 ? mlp_fwd_f16 : arithmetic == XR_MLP_BF16X3 ? mlp_fwd_bf16x3 : arithmetic == XR_MLP_F16X2 ? mlp_fwd_f16x2 : mlp_fwd_f32;
+    return fwd(enc_t, ld, dirs, dir_stride, n, n_dev, rows, w_density, w_color, n_hidden_density, n_hidden_color, pad_value, raw, stream);
+}
+extern "C" int xr_nerf_mlp_bwd(int arithmetic, const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
+                               const uint32_t* n_dev, const float* w_density, const float* w_color, int n_hidden_density, int n_hidden_color,
+                               float pad_value, const float* draw, float* denc_t, float* grad_w_density, float* grad_w_color, void* workspace,
+                               size_t workspace_bytes, const uint32_t* live_rows, const uint32_t* n_live, void* stream) {
+    XR_REQUIRE(arithmetic >= XR_MLP_F32 && arithmetic <= XR_MLP_F16X2, "unknown arithmetic");
+    auto bwd = arithmetic == XR_MLP_F16 ? mlp_bwd_f16 : mlp_bwd_f32;          // (the three fp32 forwards share one backward: XR_MLP_BWD_DW)
+    return bwd(enc_t, ld, dirs, dir_stride, n, n_dev, w_density, w_color, n_hidden_density, n_hidden_color, pad_value, draw, denc_t, grad_w_density,
+               grad_w_color, workspace, workspace_bytes, live_rows, n_live, stream);
+}
+
 // K9's density query and K8 in one launch (grid refresh, ngp_grid_sampler.py:103-137 -> hashnerf_mlp.py:107-111 + splat_grid_samples...cu):
 // the density network over n encoded points (enc_t feature-major, as xr_hashgrid_fwd writes it), each result's optical thickness
 // exp(density) * min_step merged into density_grid_tmp[indices[i]] by an order-free maximum from the forward kernel's epilogue -- no
@@ -2679,10 +2697,9 @@ extern "C" int xr_nerf_density_splat(int mlp_mode, const float* enc_t, uint32_t 
     XR_REQUIRE(indices && density_grid_tmp, "null pointer");
     XR_REQUIRE(mlp_mode != 1 || (n_hidden_density == 1 && n_hidden_color == 2), "the fp16 mode is built for the (1,2) hidden-layer topology");
     g_fwd_splat_idx = indices; g_fwd_splat_grid = density_grid_tmp;
-    auto fwd = mlp_mode == 1 ? xr_nerf_mlp_fwd_f16 : mlp_mode == 2 ? xr_nerf_mlp_fwd_bf16x3 : mlp_mode == 3 ? xr_nerf_mlp_fwd_f16x2 : xr_nerf_mlp_fwd;
     // (`raw` is not written in this mode; the argument only has to pass the alignment check)
-    const int rc = fwd(enc_t, ld, nullptr, 0, n, nullptr, nullptr, w_density, nullptr, n_hidden_density, n_hidden_color, 1.0f,
-                       (float*)(((uintptr_t)density_grid_tmp + 15) & ~(uintptr_t)15), stream);
+    const int rc = xr_nerf_mlp_fwd(mlp_mode, enc_t, ld, nullptr, 0, n, nullptr, nullptr, w_density, nullptr, n_hidden_density, n_hidden_color, 1.0f,
+                                   (float*)(((uintptr_t)density_grid_tmp + 15) & ~(uintptr_t)15), stream);
     g_fwd_splat_idx = nullptr; g_fwd_splat_grid = nullptr;
     return rc;
 }

@@ -9,25 +9,6 @@
 #include <cstdlib>
 #include <initializer_list>
 
-// Timing events for callers without a HIP binding of their own (bench.py brackets one stage of the native step with them)
-extern "C" void* xr_timing_event_create(void) {
-    hipEvent_t e = nullptr;
-    return hipEventCreate(&e) == hipSuccess ? (void*)e : nullptr;
-}
-extern "C" int xr_timing_event_destroy(void* e) { return e && hipEventDestroy((hipEvent_t)e) != hipSuccess ? XR_EHIP : XR_OK; }
-extern "C" int xr_timing_event_elapsed_ms(void* a, void* b, float* ms) {
-    XR_REQUIRE(a && b && ms, "null pointer");
-    XR_HIP(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
-    return XR_OK;
-}
-
-// record an event of this library on a stream (callers without a HIP binding: bench.py's per-iteration boundary events)
-extern "C" int xr_event_record(void* event, void* stream) {
-    XR_REQUIRE(event, "null event");
-    XR_HIP(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
-    return XR_OK;
-}
-
 static bool stage_is(const char* timed, const char* name) { return timed && strcmp(timed, name) == 0; }
 
 extern "C" int xr_ngp_train_step(
@@ -52,7 +33,7 @@ extern "C" int xr_ngp_train_step(
     XR_REQUIRE(!w_density_adam || (w_density_adam->param == w_density && w_color_adam->param == w_color && w_density_adam->step == w_color_adam->step &&
                                    w_density_adam->n > 0 && w_color_adam->n > 0),
                "mlp_adam: the step's own weight tensors, one step count");
-    XR_REQUIRE(!table_adam || xr_hashgrid_bwd_adam_supported(n_rows, n_levels, scale_host, resolution_host, offset_host),
+    XR_REQUIRE(!table_adam || xr_internal_hashgrid_bwd_adam_supported(n_rows, n_levels, scale_host, resolution_host, offset_host),
                "the fused table update needs a non-atomic scatter path for every level at this row capacity");
     XR_REQUIRE(n_rows > 0 && n_rays > 0 && ld >= n_rows, "bad sizes");
     XR_REQUIRE(mlp_mode >= 0 && mlp_mode <= 3, "mlp_mode is 0 (fp32 MFMA), 1 (fp16), 2 (fp32 forward on 3-way split bf16 operands) or 3 (on 2-way split fp16 operands)");
@@ -82,9 +63,8 @@ extern "C" int xr_ngp_train_step(
     if (rc != XR_OK) return rc;
     if ((rc = end("xr_hashgrid_fwd")) != XR_OK || (rc = begin("xr_nerf_mlp_fwd")) != XR_OK) return rc;
     const bool f16_mlp = mlp_mode == 1;
-    auto mlp_fwd = mlp_mode == 1 ? xr_nerf_mlp_fwd_f16 : mlp_mode == 2 ? xr_nerf_mlp_fwd_bf16x3 : mlp_mode == 3 ? xr_nerf_mlp_fwd_f16x2 : xr_nerf_mlp_fwd;
-    rc = mlp_fwd(enc_t, ld, coords + 4, 7, n_rows, n_dev, nullptr, w_density, w_color, n_hidden_density, n_hidden_color, pad_value, raw,
-                 stream_);
+    rc = xr_nerf_mlp_fwd(mlp_mode, enc_t, ld, coords + 4, 7, n_rows, n_dev, nullptr, w_density, w_color, n_hidden_density, n_hidden_color, pad_value,
+                         raw, stream_);
     if (rc != XR_OK) return rc;
     if ((rc = end("xr_nerf_mlp_fwd")) != XR_OK) return rc;
     // nothing of zero_block is zero-filled any more: the MLP gradients are WRITTEN by the reduction of their partials, the loss
@@ -103,7 +83,7 @@ extern "C" int xr_ngp_train_step(
         // again on the scatter's helper stream once the ranking pass has read it: no fill on this stream.  Without one: the
         // slot in the backward's workspace, cleared here.
         if (live_seg_count) seg = live_seg_count;
-        else XR_HIP(hipMemsetAsync(seg, 0, xr_live_rows_segments(n_rows) * sizeof(uint32_t), stream));
+        else XR_HIP(hipMemsetAsync(seg, 0, XR_LIVE_ROWS_SEGMENTS(n_rows) * sizeof(uint32_t), stream));
     }
     if ((rc = begin("xr_composite_train")) != XR_OK) return rc;
     // (the two loss scalars are a function of rgb_out: one fixed-order sum on the scatter's helper stream, see below)
@@ -118,17 +98,15 @@ extern "C" int xr_ngp_train_step(
     }
     if ((rc = end("xr_live_rows")) != XR_OK || (rc = begin("xr_nerf_mlp_bwd")) != XR_OK) return rc;
     xr_internal_defer_mlp_reduce(true);                 // (the reduce is issued below: helper stream, or this one)
-    rc = f16_mlp ? xr_nerf_mlp_bwd_f16(enc_t, ld, coords + 4, 7, n_rows, n_dev, w_density, w_color, n_hidden_density, n_hidden_color,
-                                       pad_value, draw, denc_t, grad_w_density, grad_w_color, ws_mlp_bwd, ws_mlp_bwd_bytes, rows, n_live, stream_)
-                 : xr_nerf_mlp_bwd(enc_t, ld, coords + 4, 7, n_rows, n_dev, w_density, w_color, n_hidden_density, n_hidden_color,
-                                   pad_value, draw, denc_t, grad_w_density, grad_w_color, ws_mlp_bwd, ws_mlp_bwd_bytes, rows, n_live, stream_);
+    rc = xr_nerf_mlp_bwd(mlp_mode, enc_t, ld, coords + 4, 7, n_rows, n_dev, w_density, w_color, n_hidden_density, n_hidden_color, pad_value, draw, denc_t,
+                         grad_w_density, grad_w_color, ws_mlp_bwd, ws_mlp_bwd_bytes, rows, n_live, stream_);
     xr_internal_defer_mlp_reduce(false);
     if (rc != XR_OK) return rc;
     if ((rc = end("xr_nerf_mlp_bwd")) != XR_OK) return rc;
     struct TailArgs { void* ws; uint32_t n; int nhd, nhc; float *gd, *gc; const float *rgb, *target, *alpha; uint32_t n_rays; float delta, scale; float* loss;
                       const xr_adam_fuse *ad, *ac; uint32_t* seg_clear; size_t seg_bytes; }
         ta = {ws_mlp_bwd, n_rows, n_hidden_density, n_hidden_color, grad_w_density, grad_w_color, rgb_out, target, alpha_mask, n_rays, huber_delta, loss_scale, loss_mse,
-              w_density_adam, w_color_adam, (live_on && live_seg_count) ? live_seg_count : nullptr, xr_live_rows_segments(n_rows) * sizeof(uint32_t)};
+              w_density_adam, w_color_adam, (live_on && live_seg_count) ? live_seg_count : nullptr, XR_LIVE_ROWS_SEGMENTS(n_rows) * sizeof(uint32_t)};
     XrAuxPrologue pro = {[](hipStream_t st, void* a) -> int {
                              auto* r = (TailArgs*)a;
                              int rc1 = xr_internal_mlp_bwd_reduce(r->ws, r->n, r->nhd, r->nhc, r->gd, r->gc, 1, st);      // writes the two gradient buffers

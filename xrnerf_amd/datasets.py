@@ -8,7 +8,7 @@ Mirrors, for Blender-format scenes, what the reference spreads over
   /root/reference/xrnerf/datasets/pipelines/create.py:153-191, augment.py:290-317 (HashBatchSample, RandomBGColor)
 with two MI355X-first changes: the [N*H*W, 11] ray table (o3, d3, rgba4, img_id) is generated ON THE DEVICE
 with xr_gen_rays and stays there (the reference builds it with numpy, shuffles it on the host and slices +
-H2D-copies a batch every iteration), and a training batch is one kernel launch (xr_make_batch).
+H2D-copies a batch every iteration), and a training batch is one kernel launch (xr_make_batch_series).
 
 PNG decoding uses PIL (the reference: imageio; cv2.INTER_AREA for half_res -- for the exact factor 2 that is
 the mean of each 2x2 block, which is what `_half_res` computes).

@@ -347,14 +347,15 @@ class RcclExchange:
     def on(self, v):
         from . import _lib
         self._on = bool(v)
-        _lib.check(_lib.load().xr_rccl_timing(self.h, 1 if v else 0), 'xr_rccl_timing')
+        _lib.check(_lib.load().xr_rccl_exposed_ms(self.h, 1 if v else 0, None, None, None), 'xr_rccl_exposed_ms')
 
     def summary(self):
-        """-> {'steps', 'mean_ms', 'max_ms'} of the waits the compute stream spent in `finish` (call after a device synchronisation)"""
+        """-> {'steps', 'mean_ms', 'max_ms'} of the waits the compute stream spent in `finish` (call after a device synchronisation);
+        clears the record"""
         import ctypes as C
         from . import _lib
         mean, mx, n = C.c_float(), C.c_float(), C.c_int()
-        _lib.check(_lib.load().xr_rccl_exposed_ms(self.h, C.byref(mean), C.byref(mx), C.byref(n)), 'xr_rccl_exposed_ms')
+        _lib.check(_lib.load().xr_rccl_exposed_ms(self.h, 1 if self._on else 0, C.byref(mean), C.byref(mx), C.byref(n)), 'xr_rccl_exposed_ms')
         return {'steps': int(n.value), 'mean_ms': float(mean.value) if n.value else None, 'max_ms': float(mx.value) if n.value else None}
 
     def __del__(self):

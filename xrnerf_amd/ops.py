@@ -67,23 +67,16 @@ class _Span:
 
 
 class _CEvent:
-    """a timing event of the library (xr_timing_event_*): what xr_ngp_train_step records around one of its stages"""
+    """a timing event handed to the library by its raw handle (xr_ngp_train_step / xr_ngp_loop_run record it around a stage or in front
+    of an iteration).  The event is the caller's: torch creates the underlying HIP event at its first record, hence the record here."""
 
-    def __init__(self, timing=True):
-        self.h = _lib.load().xr_timing_event_create()
-        if not self.h:
-            raise _lib.XrError('cannot create a timing event')
+    def __init__(self):
+        self.ev = torch.cuda.Event(enable_timing=True)
+        self.ev.record()
+        self.h = C.c_void_p(self.ev.cuda_event)
 
     def elapsed_time(self, other):
-        ms = C.c_float()
-        _lib.check(_lib.load().xr_timing_event_elapsed_ms(self.h, other.h, C.byref(ms)), 'xr_timing_event_elapsed_ms')
-        return float(ms.value)
-
-    def __del__(self):
-        try:
-            _lib.load().xr_timing_event_destroy(self.h)
-        except Exception:  # noqa: BLE001  (interpreter shutdown)
-            pass
+        return self.ev.elapsed_time(other.ev)
 
 
 class _NoSpan:
@@ -107,9 +100,9 @@ if _PRECISION not in ('f32', 'f16'):
     raise ValueError("XRNERF_MLP_PRECISION must be 'f32' or 'f16' (got %r)" % _PRECISION)
 
 
-# forward of the 'f32' mode: 'f16x2' = xr_nerf_mlp_fwd_f16x2 (the default: fp32 operands as two fp16 parts, three fp16 MFMAs per product
+# forward of the 'f32' mode (the `arithmetic` argument of xr_nerf_mlp_fwd): 'f16x2' = XR_MLP_F16X2 (the default: fp32 operands as two fp16 parts, three fp16 MFMAs per product
 # block, fp32 accumulate: within a few ulps of fp32 at half the matrix instructions of the 3-way split), 'bf16x3' =
-# xr_nerf_mlp_fwd_bf16x3 (three bf16 parts, six MFMAs: fp32-rounding accuracy), 'mfma' = xr_nerf_mlp_fwd (v_mfma_f32_32x32x2_f32).
+# XR_MLP_BF16X3 (three bf16 parts, six MFMAs: fp32-rounding accuracy), 'mfma' = XR_MLP_F32 (v_mfma_f32_32x32x2_f32).
 # Depths other than (1, 2) run the streamed kernel (f16x2 arithmetic) whatever this says, except (1,1), (2,2), (2,3) under 'mfma'.
 _F32_FORWARD = 'f16x2'          # (set_f32_forward)
 
@@ -407,7 +400,7 @@ class TrainStepBuffers:
         self.raw, self.draw, self.rgb = f(n_rows, 4), f(n_rows, 4), f(ray_cap, 3)
         # MLP gradients, the (loss, mse) scalars and the compositor's live-row counts in one block; the step writes the first two and
         # hands the counts back zeroed (no fill on the step's stream)
-        n_seg = int(_lib.load().xr_live_rows_segments(n_rows))
+        n_seg = live_segments(n_rows)
         self.zero_block = torch.zeros((wd_floats + wc_floats + 4 + n_seg,), dtype=torch.float32, device=device)     # (the counts start at zero)
         self.live_seg = self.zero_block[wd_floats + wc_floats + 4:]
         self.g_wd, self.g_wc = self.zero_block[:wd_floats], self.zero_block[wd_floats:wd_floats + wc_floats]
@@ -483,8 +476,8 @@ def ngp_train_step(table, wd, wc, nhd, nhc, pad_value, meta, coords, n_dev, nums
 
 
 def record_event(cevent):
-    """record a library event (_CEvent) on the current stream"""
-    _lib.check(_lib.load().xr_event_record(cevent.h, _stream()), 'xr_event_record')
+    """record a timing event (_CEvent) on the current stream"""
+    cevent.ev.record()
 
 
 def calc_rgb_inference(raw, coords, numsteps, bg3, rgb_act, density_act):
@@ -703,7 +696,7 @@ def adam_fuse(param, m, v, ema, step, lr, beta1, beta2, eps, weight_decay, ema_m
 def hashgrid_bwd_adam_supported(n, meta):
     """every level of `meta` has a non-atomic scatter path at a capacity of n rows (what the fused update needs)"""
     s, r, o = meta._args()
-    return bool(_lib.load().xr_hashgrid_bwd_adam_supported(int(n), meta.n_levels, s, r, o))
+    return _lib.load().xr_hashgrid_bwd_adam(None, 0, None, 0, int(n), None, None, meta.n_levels, s, r, o, None, 0, None, None) == 0       # (adam = NULL: the dry run)
 
 
 def hashgrid_bwd_adam(x, denc_t, meta, adam, n_dev=None, live=None, count=None):
@@ -811,9 +804,8 @@ def nerf_mlp_fwd(enc_t, dirs, n, w_density, w_color, nhd, nhc, pad_value=1.0, ra
     _ptr(enc_t); _ptr(raw)
     if count is not None:
         n = count
-    fn = (L.xr_nerf_mlp_fwd, L.xr_nerf_mlp_fwd_f16, L.xr_nerf_mlp_fwd_bf16x3, L.xr_nerf_mlp_fwd_f16x2)[_mlp_mode(nhd, nhc)]
     with _span('xr_nerf_mlp_fwd', 0 if n_dev is not None else n, train=n_dev is not None):
-        _lib.check(fn(C.c_void_p(enc_t.data_ptr() + 4 * row0), enc_t.shape[1], dp, ds, n, _ptr(n_dev),
+        _lib.check(L.xr_nerf_mlp_fwd(_mlp_mode(nhd, nhc), C.c_void_p(enc_t.data_ptr() + 4 * row0), enc_t.shape[1], dp, ds, n, _ptr(n_dev),
                                      _ptr(rows), _ptr(w_density), _ptr(w_color) if w_color is not None else None, nhd,
                                      nhc, pad_value, C.c_void_p(raw.data_ptr() + 16 * row0), _stream()),
                    'xr_nerf_mlp_fwd')
@@ -862,7 +854,7 @@ def train_loss_scalars(rgb, target, alpha, delta=0.1, scale=5.0, out=None):
 
 def live_segments(n):
     """number of 1024-row segments of n rows (length of the compositor's live-row count array)"""
-    return int(_lib.load().xr_live_rows_segments(n))
+    return (int(n) + _lib.LIVE_SEGMENT_ROWS - 1) // _lib.LIVE_SEGMENT_ROWS
 
 
 def live_rows(draw, n, n_dev=None, zero_denc_t=None, seg_counts=None):
@@ -915,9 +907,8 @@ def nerf_mlp_bwd(enc_t, dirs, n, w_density, w_color, nhd, nhc, draw, grad_wd, gr
     _ptr(enc_t); _ptr(draw); _ptr(denc_t)
     if count is not None:
         n = count
-    fn = L.xr_nerf_mlp_bwd_f16 if (_PRECISION == 'f16' and nhd == 1 and nhc == 2) else L.xr_nerf_mlp_bwd
     with _span('xr_nerf_mlp_bwd', 0 if n_dev is not None else n, train=n_dev is not None):
-        _lib.check(fn(C.c_void_p(enc_t.data_ptr() + 4 * row0), enc_t.shape[1], C.c_void_p(dirs.data_ptr() + 4 * ds * row0), ds, n, _ptr(n_dev), _ptr(w_density),
+        _lib.check(L.xr_nerf_mlp_bwd(_mlp_mode(nhd, nhc), C.c_void_p(enc_t.data_ptr() + 4 * row0), enc_t.shape[1], C.c_void_p(dirs.data_ptr() + 4 * ds * row0), ds, n, _ptr(n_dev), _ptr(w_density),
                                      _ptr(w_color), nhd, nhc, pad_value, C.c_void_p(draw.data_ptr() + 16 * row0), C.c_void_p(denc_t.data_ptr() + 4 * row0), _ptr(grad_wd),
                                      _ptr(grad_wc), _ptr(ws), ws.numel(), _ptr(live[0]) if live is not None else None,
                                      _ptr(live[1]) if live is not None else None, _stream()), 'xr_nerf_mlp_bwd')
@@ -938,7 +929,7 @@ def gen_rays(pose43, H, W, fx, fy, cx, cy, row0=0, nrows=None, device='cuda'):
 def huber_loss_grad(rgb, target, delta=0.1, scale=5.0):
     grad = torch.empty_like(rgb)
     loss = torch.zeros((1,), dtype=torch.float32, device=rgb.device)
-    _lib.check(_lib.load().xr_huber_loss_grad(_ptr(rgb), _ptr(target), rgb.numel(), delta, scale, _ptr(grad),
+    _lib.check(_lib.load().xr_huber_loss_grad(_ptr(rgb), _ptr(target), None, rgb.numel(), delta, scale, _ptr(grad),
                                               _ptr(loss), _stream()), 'xr_huber_loss_grad')
     return loss, grad
 
@@ -948,8 +939,8 @@ def huber_loss_grad_mse(rgb, target, alpha, delta=0.1, scale=5.0, out=None):
     grad = torch.empty_like(rgb)
     if out is None:
         out = torch.zeros((2,), dtype=torch.float32, device=rgb.device)
-    _lib.check(_lib.load().xr_huber_loss_grad_mse(_ptr(rgb), _ptr(target), _ptr(alpha), rgb.shape[0], delta, scale,
-                                                  _ptr(grad), _ptr(out), _stream()), 'xr_huber_loss_grad_mse')
+    _lib.check(_lib.load().xr_huber_loss_grad(_ptr(rgb), _ptr(target), _ptr(alpha), 3 * rgb.shape[0], delta, scale,
+                                              _ptr(grad), _ptr(out), _stream()), 'xr_huber_loss_grad')
     return out, grad
 
 
@@ -971,16 +962,15 @@ def make_batch(rows, n, call_index, seed=20220901, out=None):
         o, d, tgt, alpha, bg = f(n, 3), f(n, 3), f(n, 3), f(n, 1), f(n, 3)
         ids = torch.empty((n, 1), dtype=torch.int32, device=dev)
     st, inc = pcg32_host_state(call_index, seed)
-    _lib.check(_lib.load().xr_make_batch(_ptr(rows), n, st, inc, _ptr(o), _ptr(d), _ptr(tgt), _ptr(alpha), _ptr(bg),
-                                         _ptr(ids), _stream()), 'xr_make_batch')
+    # (one batch = a series of one: rows from the slice's first row, the generator of call `call_index`)
+    _lib.check(_lib.load().xr_make_batch_series(_ptr(rows), (C.c_uint64 * 1)(0), n, 1, n, st, inc, _ptr(o), _ptr(d), _ptr(tgt), _ptr(alpha),
+                                                _ptr(bg), _ptr(ids), _stream()), 'xr_make_batch_series')
     return {'rays_o': o, 'rays_d': d, 'target_s': tgt, 'alpha': alpha, 'img_ids': ids, 'bg_color': bg}
 
 
 def adam_step(p, g, m, v, step, lr=1e-2, beta1=0.9, beta2=0.99, eps=1e-15, weight_decay=1e-6, ema=None,
               ema_momentum=0.05):
-    with _span('xr_adam_step', p.numel()):
-      _lib.check(_lib.load().xr_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), step, lr, beta1, beta2, eps,
-                                        weight_decay, _ptr(ema), ema_momentum, _stream()), 'xr_adam_step')
+    adam_step_multi([p], [g], [m], [v], step, lr, beta1, beta2, eps, weight_decay, [ema] if ema is not None else None, ema_momentum)
 
 
 def scale_multi(ts, scale_dev=None, host_factor=1.0):
@@ -1260,8 +1250,8 @@ def linear_backward_input(dy, mask_src, w):
     dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
     w_t = w.t().contiguous()
     with _span('xr_linear_backward_input', M):
-        _lib.check(_lib.load().xr_linear_backward_input_t(_ptr(dy), _ptr(mask_src), _ptr(w_t), M, N, K, _ptr(dx), _stream()),
-                   'xr_linear_backward_input_t')
+        _lib.check(_lib.load().xr_linear_backward_input(_ptr(dy), _ptr(mask_src), _ptr(w_t), 1, M, N, K, _ptr(dx), _stream()),
+                   'xr_linear_backward_input')
     return dx
 
 
@@ -1271,10 +1261,10 @@ def linear_backward_weight(dy, mask_src, x):
     dy, x = _f32c(dy), _f32c(x)
     M, N = dy.shape
     K = x.shape[1]
-    splits = int(L.xr_linear_backward_weight_splits(M, N, K))
+    splits = int(L.xr_linear_backward_splits(M, N, K))
     part = torch.empty((splits, N, K), dtype=torch.float32, device=dy.device)
     with _span('xr_linear_backward_weight', M):
-        _lib.check(L.xr_linear_backward_weight(_ptr(dy), _ptr(mask_src), _ptr(x), M, N, K, splits, _ptr(part), _stream()),
+        _lib.check(L.xr_linear_backward_weight(_ptr(dy), _ptr(mask_src), _ptr(x), M, N, K, splits, _ptr(part), None, _stream()),
                    'xr_linear_backward_weight')
     return part[0] if splits == 1 else part.sum(0)
 
@@ -1285,11 +1275,11 @@ def linear_backward_weight_bias(dy, mask_src, x):
     dy, x = _f32c(dy), _f32c(x)
     M, N = dy.shape
     K = x.shape[1]
-    splits = int(L.xr_linear_backward_weight_splits(M, N, K))
+    splits = int(L.xr_linear_backward_splits(M, N, K))
     dwp, dbp = torch.empty((splits, N, K), dtype=torch.float32, device=dy.device), torch.empty((splits, N), dtype=torch.float32, device=dy.device)
     with _span('xr_linear_backward_weight', M):
-        _lib.check(L.xr_linear_backward_weight_bias(_ptr(dy), _ptr(mask_src), _ptr(x), M, N, K, splits, _ptr(dwp), _ptr(dbp), _stream()),
-                   'xr_linear_backward_weight_bias')
+        _lib.check(L.xr_linear_backward_weight(_ptr(dy), _ptr(mask_src), _ptr(x), M, N, K, splits, _ptr(dwp), _ptr(dbp), _stream()),
+                   'xr_linear_backward_weight')
     if splits == 1:
         return dwp[0], dbp[0]
     return dwp.sum(0), dbp.sum(0)
@@ -1300,7 +1290,7 @@ def linear_backward_bias(dy, mask_src):
     L = _lib.load()
     dy = _f32c(dy)
     M, N = dy.shape
-    splits = int(L.xr_linear_backward_bias_splits(M))
+    splits = int(L.xr_linear_backward_splits(M, 0, 0))
     part = torch.empty((splits, N), dtype=torch.float32, device=dy.device)
     _lib.check(L.xr_linear_backward_bias(_ptr(dy), _ptr(mask_src), M, N, splits, _ptr(part), _stream()), 'xr_linear_backward_bias')
     return part[0] if splits == 1 else part.sum(0)

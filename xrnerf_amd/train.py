@@ -48,7 +48,7 @@ def ngp_lego_model_cfg(n_rays=4096):
 class FusedAdam(torch.optim.Optimizer):
     """torch.optim.Adam semantics (L2 weight decay folded into the gradient) + the EMA copy that
     mmcv's EMAHook keeps (configs/instant_ngp/nerf_blender_local01.py:14-24), in ONE pass over
-    p, g, m, v(, ema) per tensor (xr_adam_step)."""
+    p, g, m, v(, ema) per tensor (xr_adam_step_multi)."""
 
     def __init__(self, params, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, weight_decay=1e-6, ema_momentum=None, ema_warm_up=100):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
