@@ -938,6 +938,7 @@ def main():
                                'device_ms_refresh_iteration_per_rank': [b for _, b in per_rank_iter],
                                'native_loop': bool(tr._loop is not None and tr._loop.enqueued > 0),
                                'exchange': type(tr._loop.exchange).__name__ if (tr._loop is not None and tr._loop.exchange is not None) else 'per-iteration path (torch.distributed)',
+                               'exchange_fallback_reason': getattr(tr._loop.exchange, 'fallback_reason', None) if (tr._loop is not None and tr._loop.exchange is not None) else None,
                                'host_enqueue_ms_per_iteration_native_loop': (tr._loop.enqueue_s * 1e3 / tr._loop.enqueued) if (tr._loop is not None and tr._loop.enqueued) else None,
                                'model': xdist.comm_model(world, step_ms=elapsed_max * 1e3 / args.steps, wire_bytes_per_float=2.0 if tr.dp_mode == 'allreduce_bf16' else 4.0),
                                'bytes_on_wire_per_rank_total': getattr(sync, 'bytes_on_wire', None),

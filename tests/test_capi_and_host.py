@@ -360,6 +360,13 @@ stray = torch.zeros(8)
 assert f.all_reduce(f.ctx, stray.data_ptr(), 8, None) != 0 and 'not registered' in str(ex.error)
 s = ex.exposed.summary()
 assert s['steps'] >= 1
+# the agreed fall-back: the native RCCL exchange cannot be made here (no GPU, gloo transport) -- every rank must come out with the callback
+# form and the reason, none may be left waiting in a collective
+import warnings
+with warnings.catch_warnings(record=True) as caught:
+    warnings.simplefilter('always')
+    ex2 = xd.native_exchange(world, rank, prefer_rccl=True)
+assert type(ex2).__name__ == 'CallbackExchange' and 'could not be created on' in ex2.fallback_reason and caught
 dist.barrier(); dist.destroy_process_group()
 print('ok')
 '''
@@ -368,7 +375,8 @@ print('ok')
 def test_gradient_exchange_hooks_two_ranks(tmp_path):
     """dist.CallbackExchange -- the xr_grad_exchange the native loop gets where RCCL is not driven from native code -- on two gloo ranks
     (host tensors): all-reduce of slices of registered buffers, the zero1 reduce-scatter / all-gather pair, the exposure record, and an
-    unregistered buffer reported as an error code with the exception kept."""
+    unregistered buffer reported as an error code with the exception kept; then dist.native_exchange asked for the native RCCL form where
+    it cannot exist: both ranks agree on the callback form and carry the reason."""
     import socket
     script = tmp_path / 'ex.py'
     script.write_text(EXCHANGE_WORKER % ROOT)

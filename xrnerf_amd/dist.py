@@ -320,11 +320,16 @@ class RcclExchange:
         lib = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')          # the copy torch.distributed itself uses
         path = lib.encode() if os.path.exists(lib) else None
         uid = (C.c_char * 128)()
+        # rank 0 makes the id; a failure there is broadcast too (an empty id), so that no rank is left waiting in a collective
+        box = [None]
         if self.rank == 0:
-            _lib.check(L.xr_rccl_unique_id(path, uid), 'xr_rccl_unique_id')
-        box = [bytes(uid.raw) if self.rank == 0 else None]
+            rc = L.xr_rccl_unique_id(path, uid)
+            box = [bytes(uid.raw) if rc == 0 else b'']
+            self._id_error = None if rc == 0 else L.xr_last_error().decode()
         if self.world_size > 1:
             dist.broadcast_object_list(box, src=0)
+        if not box[0]:
+            raise _lib.XrError('xr_rccl_unique_id failed on rank 0%s' % (': ' + self._id_error if self.rank == 0 else ''))
         uid = (C.c_char * 128).from_buffer_copy(box[0])
         self.h = L.xr_rccl_create(path, uid, self.world_size, self.rank)
         if not self.h:
@@ -366,12 +371,36 @@ class RcclExchange:
             pass
 
 
-def native_exchange(world_size, rank):
-    """the exchange implementation of the native loop for this job: RCCL from native code under backend 'nccl', callbacks into
-    torch.distributed otherwise (gloo)"""
-    if dist.get_backend() == 'nccl':
-        return RcclExchange(world_size, rank)
-    return CallbackExchange(world_size, rank)
+def native_exchange(world_size, rank, prefer_rccl=None):
+    """the exchange implementation of the native loop for this job: RCCL from native code under backend 'nccl' (prefer_rccl: force the
+    attempt / skip it), callbacks into torch.distributed otherwise (gloo).  The ranks AGREE on the outcome: if the native communicator
+    cannot be made on any rank (librccl not loadable, ncclCommInitRank failing), every rank takes the callback form -- the same RCCL
+    collectives issued by torch.distributed, ~30 us of interpreter time each -- and says so (`fallback_reason`, echoed in bench.py's
+    `collective` block).  Nothing here computes on the host."""
+    if prefer_rccl is None:
+        prefer_rccl = dist.get_backend() == 'nccl'
+    if not prefer_rccl:
+        return CallbackExchange(world_size, rank)
+    ex, err = None, None
+    try:
+        ex = RcclExchange(world_size, rank)
+    except Exception as e:  # noqa: BLE001  (whatever went wrong, the other ranks must hear of it)
+        err = e
+    if world_size > 1:
+        flag = torch.tensor([0 if ex is not None else 1], dtype=torch.int32,
+                            device=torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(flag)
+        failed = int(flag[0])
+    else:
+        failed = 0 if ex is not None else 1
+    if failed == 0:
+        return ex
+    import warnings
+    reason = 'the native RCCL exchange could not be created on %d of %d ranks%s' % (failed, world_size, ' (here: %s)' % err if err is not None else '')
+    warnings.warn(reason + ': the native loop calls back into torch.distributed for its collectives')
+    ex = CallbackExchange(world_size, rank)
+    ex.fallback_reason = reason
+    return ex
 
 
 def comm_model(world_size, table_floats=12196240, mlp_floats=10240, link_GBs=153.0, links=7, step_ms=0.50, wire_bytes_per_float=4.0):
