@@ -166,6 +166,21 @@ inline emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16_emu(emu_b8 a, emu_b8 b
 }
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 __builtin_amdgcn_mfma_f32_32x32x16_bf16_emu
 
+// ds_read_b64_tr_b16 (gfx950's transposing LDS load): inside every group of 16 lanes, lane j receives element (j & 3) of the four 8-byte
+// rows addressed by lanes (j >> 2) + 4 e, e = 0..3 -- the mapping measured on the MI355X (profiles/r02_ds_read_tr_b16_lane_mapping.txt)
+typedef short emu_s4 __attribute__((ext_vector_type(4)));
+inline emu_s4 emu_ds_read_tr16_b64(const void* my_row) {
+    const int l = emu::lane_id(), g0 = l & ~15, j = l & 15;
+    emu_s4 out;
+    for (int e = 0; e < 4; ++e) {
+        const uint64_t addr = emu::wave_exchange((uint64_t)(uintptr_t)my_row, g0 + (j >> 2) + 4 * e);
+        out[e] = reinterpret_cast<const short*>((uintptr_t)addr)[j & 3];
+    }
+    return out;
+}
+#define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) emu_ds_read_tr16_b64((const void*)(p))
+#define XR_LDS_PTR(T, p) ((T*)(p))
+
 // cooperative fibers never pre-empt each other: plain read-modify-write is atomic here
 template <typename T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 inline unsigned atomicAdd(unsigned* p, int v) { unsigned o = *p; *p = o + (unsigned)v; return o; }

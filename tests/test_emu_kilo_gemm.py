@@ -139,7 +139,7 @@ def test_fused_frame_call_equals_the_dense_path_on_the_host(E, gold, lindisp):
     assert np.array_equal(rgb, rgb2) and np.array_equal(acc, acc2) and np.array_equal(np.nan_to_num(disp, nan=-1), np.nan_to_num(disp2, nan=-1))
 
 
-@pytest.fixture(params=['bf16x3', 'bf16x3all', 'mfma'])
+@pytest.fixture(params=['split2', 'bf16x3', 'bf16x3all', 'mfma'])
 def gemm_kernel(request, monkeypatch):
     """the kernels behind the linear entry points: fp32 results on the bf16 MFMA (3-way operand split) for the forward product only (default) / for all three products / fp32 MFMA throughout"""
     monkeypatch.setenv('XR_GEMM_F32', request.param)

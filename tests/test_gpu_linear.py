@@ -8,9 +8,9 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=['bf16x3', 'bf16x3all', 'mfma'])
+@pytest.fixture(params=['split2', 'bf16x3', 'bf16x3all', 'mfma'])
 def gemm_kernel(request, monkeypatch):
-    """the kernels behind the linear entry points: fp32 results on the bf16 MFMA (3-way operand split) for the forward product only (default) / for all three products / fp32 MFMA throughout"""
+    """the kernels behind the linear entry points: the row-major products on 2-way split operands (fp16 parts forward, bf16 parts for gradients: the default) / on exact 3-way bf16 operands / that for all three products / fp32 MFMA throughout"""
     monkeypatch.setenv('XR_GEMM_F32', request.param)
     return request.param
 

@@ -5,6 +5,11 @@
 #include <cstdio>
 #include <cstring>
 #include "../../include/xrnerf_mi355.h"
+// a generic pointer into LDS as the LDS-address-space pointer the ds_* builtins take (the host build of the kernels, tests/hip_emu, defines it
+// as a plain cast before this header is read)
+#ifndef XR_LDS_PTR
+#define XR_LDS_PTR(T, p) ((T __attribute__((address_space(3)))*)(p))
+#endif
 extern "C" __attribute__((visibility("hidden"))) int xr_device_cus(void);        // compute units of the current device (xr_mlp.hip); not exported
 
 #define XR_WAVE 64

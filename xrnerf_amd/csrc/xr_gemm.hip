@@ -36,8 +36,9 @@ struct GemmArgs {
     int relu;
     uint32_t k_per_split;                        // contraction range of blockIdx.z; C of split z at C + z * c_split_stride
     size_t c_split_stride;
-    int tload;                                   // k_gemm_b3: [k, rows] operands are read with per-k dword loads (k-contiguous in registers)
+    int tload;                                   // k_gemm_split: [k, rows] operands are read with per-k dword loads (k-contiguous in registers)
     float* colsum;                               // k_gemm_f32 with a_km: nullable [splits, Mc]: sums of A's (masked) rows over the split's k range
+    int a_gradient = 0;                          // A holds gradients (any magnitude): a 16-bit split of it must keep the fp32 range (bf16 parts)
 };
 
 // one 128 x GBK panel of an operand into registers: GNJ float4 per thread.
@@ -185,13 +186,37 @@ typedef __bf16 gb4 __attribute__((ext_vector_type(4)));
 #define G3PART (GBM * G3RS)                      // halves per part of one operand panel
 #define G3NJ (G3K / 8)                           // float4 per thread and panel
 
-__device__ __forceinline__ void g3_split(float x, __bf16& h, __bf16& m, __bf16& l) {
-    h = (__bf16)x;
-    const float r1 = x - (float)h;               // exact
-    m = (__bf16)r1;
-    const float r2 = r1 - (float)m;              // exact
-    l = (__bf16)r2;
-}
+// The split kernel's three arithmetics (one template, `GSplit<KIND>`):
+//   G_B3  three bf16 parts, exact (8 + 8 + 8 significand bits), six product terms: fp32-rounding accuracy       (round 2)
+//   G_H2  two fp16 parts (hi + lo ~ 22 bits), three terms: ~2^-21 of |a||b| per product, |operand| < 65504         (round 5: forward)
+//   G_B2  two bf16 parts (16 bits), three terms: 2^-16 relative per product, fp32 range                           (round 5: dy . w)
+enum { G_B3 = 0, G_H2 = 1, G_B2 = 2 };
+typedef _Float16 gh8 __attribute__((ext_vector_type(8)));
+typedef _Float16 gh4 __attribute__((ext_vector_type(4)));
+template <int KIND> struct GSplit;
+template <> struct GSplit<G_B3> {
+    typedef __bf16 T; typedef gb4 V4; typedef gb8 V8;
+    static constexpr int P = 3;
+    static __device__ __forceinline__ void split(float x, T (&p)[3]) {
+        p[0] = (__bf16)x;
+        const float r1 = x - (float)p[0];        // exact
+        p[1] = (__bf16)r1;
+        p[2] = (__bf16)(r1 - (float)p[1]);       // exact remainder, rounded once
+    }
+    static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct GSplit<G_H2> {
+    typedef _Float16 T; typedef gh4 V4; typedef gh8 V8;
+    static constexpr int P = 2;
+    static __device__ __forceinline__ void split(float x, T (&p)[2]) { p[0] = (_Float16)x; p[1] = (_Float16)(x - (float)p[0]); }
+    static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct GSplit<G_B2> {
+    typedef __bf16 T; typedef gb4 V4; typedef gb8 V8;
+    static constexpr int P = 2;
+    static __device__ __forceinline__ void split(float x, T (&p)[2]) { p[0] = (__bf16)x; p[1] = (__bf16)(x - (float)p[0]); }
+    static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
 // panel_load for 32-k panels (same thread mapping as above with GBK = 32)
 __device__ __forceinline__ void g3_panel_load(const float* __restrict__ P, const float* __restrict__ mask, uint32_t ld, int km,
                                               uint32_t row0, uint32_t rows, uint32_t k0, uint32_t k_end, float4 (&v)[G3NJ]) {
@@ -238,36 +263,50 @@ __device__ __forceinline__ void g3_panel_load_t(const float* __restrict__ P, con
     }
 }
 // registers -> LDS: S[part][row][k] (row stride G3RS halves)
-__device__ __forceinline__ void g3_panel_store(__bf16* __restrict__ S, int km, const float4 (&v)[G3NJ]) {
+template <int KIND>
+__device__ __forceinline__ void g3_panel_store(typename GSplit<KIND>::T* __restrict__ S, int km, const float4 (&v)[G3NJ]) {
+    using G = GSplit<KIND>;
+    typedef typename G::T T;
+    constexpr int P = G::P;
     const uint32_t t = threadIdx.x;
 #pragma unroll
     for (int j = 0; j < G3NJ; ++j) {
         const float x[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
         if (!km) {                               // 4 consecutive k of one row: one 8-byte store per part
             const uint32_t r = t & 127, k = (t >> 7) * (G3K / 2) + 4 * j;
-            gb4 h, m, l;
+            typename G::V4 q[P];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { __bf16 a, b, c; g3_split(x[e], a, b, c); h[e] = a; m[e] = b; l[e] = c; }
-            __bf16* d = S + r * G3RS + k;
-            *reinterpret_cast<gb4*>(d) = h;
-            *reinterpret_cast<gb4*>(d + G3PART) = m;
-            *reinterpret_cast<gb4*>(d + 2 * G3PART) = l;
+            for (int e = 0; e < 4; ++e) {
+                T parts[P];
+                G::split(x[e], parts);
+#pragma unroll
+                for (int p = 0; p < P; ++p) q[p][e] = parts[p];
+            }
+            T* d = S + r * G3RS + k;
+#pragma unroll
+            for (int p = 0; p < P; ++p) *reinterpret_cast<typename G::V4*>(d + p * G3PART) = q[p];
         } else {                                 // 4 consecutive rows at one k
             const uint32_t k = (t >> 5) + 8 * j, r = (t & 31) * 4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                __bf16 a, b, c;
-                g3_split(x[e], a, b, c);
-                __bf16* d = S + (r + e) * G3RS + k;
-                d[0] = a; d[G3PART] = b; d[2 * G3PART] = c;
+                T parts[P];
+                G::split(x[e], parts);
+                T* d = S + (r + e) * G3RS + k;
+#pragma unroll
+                for (int p = 0; p < P; ++p) d[p * G3PART] = parts[p];
             }
         }
     }
 }
 
-__global__ void __launch_bounds__(256, 2) k_gemm_b3(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) __bf16 sA[3 * G3PART];
-    __shared__ __attribute__((aligned(16))) __bf16 sB[3 * G3PART];
+template <int KIND>
+__global__ void __launch_bounds__(256, 2) k_gemm_split(GemmArgs g) {
+    using G = GSplit<KIND>;
+    typedef typename G::T T;
+    typedef typename G::V8 V8;
+    constexpr int P = G::P;
+    __shared__ __attribute__((aligned(16))) T sA[P * G3PART];
+    __shared__ __attribute__((aligned(16))) T sB[P * G3PART];
     const uint32_t m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
     const uint32_t k_begin = blockIdx.z * g.k_per_split;
     const uint32_t k_end = k_begin + g.k_per_split < g.Kc ? k_begin + g.k_per_split : g.Kc;
@@ -291,32 +330,34 @@ __global__ void __launch_bounds__(256, 2) k_gemm_b3(GemmArgs g) {
     if (k_begin < k_end) load(k_begin);
     for (uint32_t k0 = k_begin; k0 < k_end; k0 += G3K) {
         __syncthreads();                                   // the previous panel has been consumed
-        g3_panel_store(sA, ta ? 0 : g.a_km, ra);
-        g3_panel_store(sB, tb ? 0 : g.b_kn, rb);
+        g3_panel_store<KIND>(sA, ta ? 0 : g.a_km, ra);
+        g3_panel_store<KIND>(sB, tb ? 0 : g.b_kn, rb);
         __syncthreads();
         if (k0 + G3K < k_end) load(k0 + G3K);
-        const __bf16* pa = sA + (wm * 64 + col) * G3RS + hi * 8;
-        const __bf16* pb = sB + (wn * 64 + col) * G3RS + hi * 8;
+        const T* pa = sA + (wm * 64 + col) * G3RS + hi * 8;
+        const T* pb = sB + (wn * 64 + col) * G3RS + hi * 8;
 #pragma unroll
         for (int s = 0; s < G3K / 16; ++s) {
-            gb8 a[2][3], b[2][3];
+            V8 a[2][P], b[2][P];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    a[i][p] = *reinterpret_cast<const gb8*>(pa + p * G3PART + i * 32 * G3RS + s * 16);
-                    b[i][p] = *reinterpret_cast<const gb8*>(pb + p * G3PART + i * 32 * G3RS + s * 16);
+                for (int p = 0; p < P; ++p) {
+                    a[i][p] = *reinterpret_cast<const V8*>(pa + p * G3PART + i * 32 * G3RS + s * 16);
+                    b[i][p] = *reinterpret_cast<const V8*>(pb + p * G3PART + i * 32 * G3RS + s * 16);
                 }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {              // smallest terms first
-                    acc[i][j] = GMFMAB(a[i][2], b[j][0], acc[i][j]);
-                    acc[i][j] = GMFMAB(a[i][0], b[j][2], acc[i][j]);
-                    acc[i][j] = GMFMAB(a[i][1], b[j][1], acc[i][j]);
-                    acc[i][j] = GMFMAB(a[i][1], b[j][0], acc[i][j]);
-                    acc[i][j] = GMFMAB(a[i][0], b[j][1], acc[i][j]);
-                    acc[i][j] = GMFMAB(a[i][0], b[j][0], acc[i][j]);
+                    if constexpr (P == 3) {
+                        acc[i][j] = G::mfma(a[i][2], b[j][0], acc[i][j]);
+                        acc[i][j] = G::mfma(a[i][0], b[j][2], acc[i][j]);
+                        acc[i][j] = G::mfma(a[i][1], b[j][1], acc[i][j]);
+                    }
+                    acc[i][j] = G::mfma(a[i][1], b[j][0], acc[i][j]);
+                    acc[i][j] = G::mfma(a[i][0], b[j][1], acc[i][j]);
+                    acc[i][j] = G::mfma(a[i][0], b[j][0], acc[i][j]);
                 }
         }
     }
@@ -340,6 +381,145 @@ __global__ void __launch_bounds__(256, 2) k_gemm_b3(GemmArgs g) {
         }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The weight gradient (both operands [k = sample][row]) on the split kernel's arithmetic, round 5.  Its operands arrive k-major: a
+// float4 of global memory is 4 consecutive ROWS at one k, while the MFMA wants 8 consecutive K of one row per lane.  Round 2 turned the
+// panel around on its way INTO LDS (twelve 2-byte stores per float4) or read it with per-k dword loads; both lost to the fp32-MFMA
+// kernel.  gfx950's transposing LDS load does the turn on the way OUT: the panel is stored as it arrives -- S[part][k][row], one 8-byte
+// store per part and float4 -- and ds_read_b64_tr_b16 hands lane j of every 16-lane group element (j & 3) of the four 8-byte rows
+// addressed by lanes (j >> 2) + 4 e (profiles/r02_ds_read_tr_b16_lane_mapping.txt): with lane a pointing at &S[k0 + (a >> 2)][i0 + 4 (a & 3)]
+// lane j receives row i0 + j at k0 .. k0 + 3, i.e. two such loads are one 32 x 32 x 16 operand.  The bias gradient's column sums ride
+// on the A panels exactly as in k_gemm_f32.
+#define GKT_RS (GBM + 16)                        // halves per k-row (288 B): four consecutive k-rows start 8 banks apart
+#define GKT_PART (G3K * GKT_RS)
+typedef short gs4 __attribute__((ext_vector_type(4)));
+typedef short gs8 __attribute__((ext_vector_type(8)));
+
+template <int KIND>
+__device__ __forceinline__ void gkt_panel_store(typename GSplit<KIND>::T* __restrict__ S, const float4 (&v)[G3NJ]) {
+    using G = GSplit<KIND>;
+    typedef typename G::T T;
+    constexpr int P = G::P;
+    const uint32_t t = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < G3NJ; ++j) {
+        const float x[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+        const uint32_t k = (t >> 5) + 8 * j, r = (t & 31) * 4;          // the [k, rows] mapping of g3_panel_load
+        typename G::V4 q[P];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            T parts[P];
+            G::split(x[e], parts);
+#pragma unroll
+            for (int p = 0; p < P; ++p) q[p][e] = parts[p];
+        }
+#pragma unroll
+        for (int p = 0; p < P; ++p) *reinterpret_cast<typename G::V4*>(S + p * GKT_PART + k * GKT_RS + r) = q[p];
+    }
+}
+// the MFMA operand of rows row0 .. row0 + 31 at k = kbase .. kbase + 15 out of one part of a k-major panel
+template <int KIND>
+__device__ __forceinline__ typename GSplit<KIND>::V8 gkt_operand(const typename GSplit<KIND>::T* __restrict__ S, int row0, int kbase) {
+    const int lane = threadIdx.x & 63, grp = lane >> 4, j = lane & 15;
+    const typename GSplit<KIND>::T* p = S + (kbase + (grp >> 1) * 8 + (j >> 2)) * GKT_RS + row0 + 16 * (grp & 1) + 4 * (j & 3);
+    const gs4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(XR_LDS_PTR(gs4, p));
+    const gs4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(XR_LDS_PTR(gs4, p + 4 * GKT_RS));
+    const gs8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    typename GSplit<KIND>::V8 out;
+    __builtin_memcpy(&out, &v, sizeof(out));
+    return out;
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(256, 2) k_gemm_split_kt(GemmArgs g) {
+    using G = GSplit<KIND>;
+    typedef typename G::T T;
+    typedef typename G::V8 V8;
+    constexpr int P = G::P;
+    __shared__ __attribute__((aligned(16))) T sA[P * GKT_PART];
+    __shared__ __attribute__((aligned(16))) T sB[P * GKT_PART];
+    const uint32_t m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+    const uint32_t k_begin = blockIdx.z * g.k_per_split;
+    const uint32_t k_end = k_begin + g.k_per_split < g.Kc ? k_begin + g.k_per_split : g.Kc;
+    const int lane = threadIdx.x & 63, col = lane & 31, hi = lane >> 5;
+    const int wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float4 ra[G3NJ], rb[G3NJ];
+    const bool cs = g.colsum != nullptr && blockIdx.x == 0;                // uniform: the bias gradient, first column tile only
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load = [&](uint32_t k0) {
+        g3_panel_load(g.A, g.mask_src, g.lda, 1, m0, g.Mc, k0, k_end, ra);
+        g3_panel_load(g.B, nullptr, g.ldb, 1, n0, g.Nc, k0, k_end, rb);
+        if (cs) {
+#pragma unroll
+            for (int j = 0; j < G3NJ; ++j) { csum.x += ra[j].x; csum.y += ra[j].y; csum.z += ra[j].z; csum.w += ra[j].w; }
+        }
+    };
+    if (k_begin < k_end) load(k_begin);
+    for (uint32_t k0 = k_begin; k0 < k_end; k0 += G3K) {
+        __syncthreads();                                   // the previous panel has been consumed
+        gkt_panel_store<KIND>(sA, ra);
+        gkt_panel_store<KIND>(sB, rb);
+        __syncthreads();
+        if (k0 + G3K < k_end) load(k0 + G3K);
+#pragma unroll
+        for (int s = 0; s < G3K / 16; ++s) {
+            V8 a[2][P], b[2][P];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    a[i][p] = gkt_operand<KIND>(sA + p * GKT_PART, wm * 64 + i * 32, s * 16);
+                    b[i][p] = gkt_operand<KIND>(sB + p * GKT_PART, wn * 64 + i * 32, s * 16);
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {              // smallest terms first
+                    if constexpr (P == 3) {
+                        acc[i][j] = G::mfma(a[i][2], b[j][0], acc[i][j]);
+                        acc[i][j] = G::mfma(a[i][0], b[j][2], acc[i][j]);
+                        acc[i][j] = G::mfma(a[i][1], b[j][1], acc[i][j]);
+                    }
+                    acc[i][j] = G::mfma(a[i][1], b[j][0], acc[i][j]);
+                    acc[i][j] = G::mfma(a[i][0], b[j][1], acc[i][j]);
+                    acc[i][j] = G::mfma(a[i][0], b[j][0], acc[i][j]);
+                }
+        }
+    }
+    float* C = g.C + (size_t)blockIdx.z * g.c_split_stride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t n = n0 + wn * 64 + j * 32 + col;
+            if (n >= g.Nc) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (m < g.Mc) C[(size_t)m * g.ldc + n] = acc[i][j][r];
+            }
+        }
+    if (cs) {                                              // the 8 k-phases of a neuron's running sums, added in a fixed order
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(sA);
+        *reinterpret_cast<float4*>(red + (threadIdx.x >> 5) * GBM + (threadIdx.x & 31) * 4) = csum;
+        __syncthreads();
+        if (threadIdx.x < GBM) {
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sum += red[i * GBM + threadIdx.x];
+            if (m0 + threadIdx.x < g.Mc) g.colsum[(size_t)blockIdx.z * g.Mc + m0 + threadIdx.x] = sum;
+        }
+    }
+}
+
 static int gemm_launch(GemmArgs g, uint32_t splits, void* stream) {
     XR_REQUIRE(g.A && g.B && g.C, "null pointer");
     XR_REQUIRE(g.lda % 4 == 0 && g.ldb % 4 == 0, "leading dimensions must be multiples of 4 floats (16-byte vector loads)");
@@ -348,27 +528,36 @@ static int gemm_launch(GemmArgs g, uint32_t splits, void* stream) {
     XR_REQUIRE((g.a_km ? g.Mc : g.Kc) % 4 == 0 && (g.b_kn ? g.Nc : g.Kc) % 4 == 0, "the contiguous dimension of each operand must be a multiple of 4");
     if (g.Mc == 0 || g.Nc == 0) return XR_OK;
     XR_REQUIRE(splits >= 1 && splits <= 65535, "bad split count");
-    // XR_GEMM_F32=mfma: the fp32-MFMA kernel; default: fp32 results on the bf16 matrix cores (exact 3-way operand split)
     // XR_GEMM_F32 (read per call: a test or a measurement can switch between two launches):
-    //   unset / bf16x3 : the split kernel for products whose operands are both row-major [rows, k] (the forward; measured
-    //                    1.05-1.3x the fp32-MFMA kernel), the fp32-MFMA kernel for the two backward products
-    //   bf16x3all      : the split kernel for all three products ([k, rows] operands read with per-k dword loads)
+    //   unset / split2 : products whose operands are both row-major [rows, k] -- the forward, and the input gradient with the weight handed
+    //                    over transposed -- on the 16-bit matrix cores with 2-way split operands, three MFMAs per product block: fp16 parts for
+    //                    the forward (~2^-21 of |x||w| per product; |operand| < 65504), bf16 parts where A holds gradients (2^-16 relative per
+    //                    product, fp32 range); the weight gradient -- both operands k-major -- on bf16 parts as well, its panels turned around by
+    //                    the transposing LDS load (k_gemm_split_kt)
+    //   bf16x3         : the same products on EXACT 3-way bf16 operands, six MFMAs per product block (fp32-rounding accuracy; round 2-4's default)
+    //   bf16x3all      : the 3-way split kernel for all three products ([k, rows] operands read with per-k dword loads)
     //   mfma           : the fp32-MFMA kernel throughout
     // Anything else is an error.  NOTE the split kernels' operand range: an Inf (or a magnitude within 2^-8 of FLT_MAX, whose
-    // bf16 head rounds to Inf) turns into NaN inside the split (Inf - Inf); the fp32-MFMA kernel propagates it like an fmaf chain.
+    // bf16 head rounds to Inf; beyond 65504 for fp16 parts) turns into NaN inside the split (Inf - Inf); the fp32-MFMA kernel propagates it
+    // like an fmaf chain.
     const char* env = getenv("XR_GEMM_F32");
-    const bool dflt = !env || !env[0] || strcmp(env, "bf16x3") == 0;
+    const bool dflt = !env || !env[0] || strcmp(env, "split2") == 0;
+    const bool b3 = env && strcmp(env, "bf16x3") == 0;
     const bool all = env && strcmp(env, "bf16x3all") == 0;
     const bool mfma = env && strcmp(env, "mfma") == 0;
-    XR_REQUIRE(dflt || all || mfma, "XR_GEMM_F32 must be bf16x3, bf16x3all or mfma");
-    const bool split = !mfma && (all || (!g.a_km && !g.b_kn));
+    XR_REQUIRE(dflt || b3 || all || mfma, "XR_GEMM_F32 must be split2, bf16x3, bf16x3all or mfma");
+    const bool kt = dflt && g.a_km && g.b_kn;                 // the weight gradient: k-major operands through the transposing LDS load
+    const bool split = !mfma && (all || kt || (!g.a_km && !g.b_kn));
     g.tload = all ? 1 : 0;
     const uint32_t kb = split ? (uint32_t)G3K : (uint32_t)GBK;
     g.k_per_split = (uint32_t)(((uint64_t)(g.Kc + splits - 1) / splits + kb - 1) / kb * kb);
     if (g.k_per_split == 0) g.k_per_split = kb;
     const dim3 grid(xr_div_up(g.Nc, GBN), xr_div_up(g.Mc, GBM), splits);
     XR_REQUIRE(grid.y <= 65535, "more than 65535 row tiles (8.3 M rows) in one call");
-    if (split) hipLaunchKernelGGL(k_gemm_b3, grid, dim3(256), 0, (hipStream_t)stream, g);
+    if (kt) hipLaunchKernelGGL(k_gemm_split_kt<G_B2>, grid, dim3(256), 0, (hipStream_t)stream, g);
+    else if (split && dflt && g.a_gradient) hipLaunchKernelGGL(k_gemm_split<G_B2>, grid, dim3(256), 0, (hipStream_t)stream, g);
+    else if (split && dflt) hipLaunchKernelGGL(k_gemm_split<G_H2>, grid, dim3(256), 0, (hipStream_t)stream, g);
+    else if (split) hipLaunchKernelGGL(k_gemm_split<G_B3>, grid, dim3(256), 0, (hipStream_t)stream, g);
     else hipLaunchKernelGGL(k_gemm_f32, grid, dim3(256), 0, (hipStream_t)stream, g);
     XR_LAUNCH_CHECK();
     return XR_OK;
@@ -388,9 +577,11 @@ extern "C" int xr_linear_backward_input(const float* dy, const float* mask_src, 
                                         uint32_t K, float* dx, void* stream) {
     if (w_transposed) {
         GemmArgs g{dy, w, dx, nullptr, mask_src, M, K, N, N, N, K, 0, 0, 0, 0, 0, 0, nullptr};
+        g.a_gradient = 1;
         return gemm_launch(g, 1, stream);
     }
     GemmArgs g{dy, w, dx, nullptr, mask_src, M, K, N, N, K, K, 0, 1, 0, 0, 0, 0, nullptr};
+    g.a_gradient = 1;
     return gemm_launch(g, 1, stream);
 }
 
