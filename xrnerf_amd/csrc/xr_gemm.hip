@@ -1,4 +1,5 @@
-// fp32 linear layers of the 8x256 NeRF MLP (configs #1 and #3: xrnerf/models/mlps/nerf_mlp.py:27-94) on the fp32 MFMA.
+// fp32 linear layers of the 8x256 NeRF MLP (configs #1 and #3: xrnerf/models/mlps/nerf_mlp.py:27-94): the fp32-MFMA kernel (k_gemm_f32, round 1)
+// and, below it, the split-operand kernels that serve the products by default (k_gemm_split, k_gemm_split_kt: fp32 results on the 16-bit matrix cores).
 //
 // The reference runs them as nn.Linear; on MI355X that dispatches to hipBLASLt, which reaches 29 TFLOP/s on the shapes
 // of this MLP (M = 32768..131072 samples, N = K = 256: `profiles/r01_mip_step_kernel_stats.csv`, 146 us per
@@ -299,57 +300,64 @@ __device__ __forceinline__ void g3_panel_store(typename GSplit<KIND>::T* __restr
     }
 }
 
-template <int KIND>
+// NB = 128-column blocks of the output tile: 1 = a 128 x 128 tile; 2 = 128 x 256 -- a layer's whole output width in one workgroup, so that
+// the A panels (x; dy AND its relu mask in the input gradient) are read once instead of once per column tile (round 5)
+template <int KIND, int NB = 1>
 __global__ void __launch_bounds__(256, 2) k_gemm_split(GemmArgs g) {
     using G = GSplit<KIND>;
     typedef typename G::T T;
     typedef typename G::V8 V8;
-    constexpr int P = G::P;
+    constexpr int P = G::P, NJ = 2 * NB;
     __shared__ __attribute__((aligned(16))) T sA[P * G3PART];
-    __shared__ __attribute__((aligned(16))) T sB[P * G3PART];
-    const uint32_t m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+    __shared__ __attribute__((aligned(16))) T sB[NB * P * G3PART];
+    const uint32_t m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN * NB;
     const uint32_t k_begin = blockIdx.z * g.k_per_split;
     const uint32_t k_end = k_begin + g.k_per_split < g.Kc ? k_begin + g.k_per_split : g.Kc;
     const int lane = threadIdx.x & 63, col = lane & 31, hi = lane >> 5;
     const int wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
-    f32x16 acc[2][2];
+    f32x16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    float4 ra[G3NJ], rb[G3NJ];
+    float4 ra[G3NJ], rb[NB][G3NJ];
     const bool ta = g.a_km && g.tload, tb = g.b_kn && g.tload;             // uniform
     auto load = [&](uint32_t k0) {
         if (ta) g3_panel_load_t(g.A, g.mask_src, g.lda, m0, g.Mc, k0, k_end, ra);
         else g3_panel_load(g.A, g.mask_src, g.lda, g.a_km, m0, g.Mc, k0, k_end, ra);
-        if (tb) g3_panel_load_t(g.B, nullptr, g.ldb, n0, g.Nc, k0, k_end, rb);
-        else g3_panel_load(g.B, nullptr, g.ldb, g.b_kn, n0, g.Nc, k0, k_end, rb);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            if (tb) g3_panel_load_t(g.B, nullptr, g.ldb, n0 + nb * GBN, g.Nc, k0, k_end, rb[nb]);
+            else g3_panel_load(g.B, nullptr, g.ldb, g.b_kn, n0 + nb * GBN, g.Nc, k0, k_end, rb[nb]);
+        }
     };
     if (k_begin < k_end) load(k_begin);
     for (uint32_t k0 = k_begin; k0 < k_end; k0 += G3K) {
         __syncthreads();                                   // the previous panel has been consumed
         g3_panel_store<KIND>(sA, ta ? 0 : g.a_km, ra);
-        g3_panel_store<KIND>(sB, tb ? 0 : g.b_kn, rb);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) g3_panel_store<KIND>(sB + nb * P * G3PART, tb ? 0 : g.b_kn, rb[nb]);
         __syncthreads();
         if (k0 + G3K < k_end) load(k0 + G3K);
         const T* pa = sA + (wm * 64 + col) * G3RS + hi * 8;
-        const T* pb = sB + (wn * 64 + col) * G3RS + hi * 8;
+        // this wave's 64 * NB columns: rows wn * 64 * NB + j * 32 + col of the B panel (block = row / 128)
+        const T* pb = sB + (NB == 2 ? wn * P * G3PART + col * G3RS : (wn * 64 + col) * G3RS) + hi * 8;
 #pragma unroll
         for (int s = 0; s < G3K / 16; ++s) {
-            V8 a[2][P], b[2][P];
+            V8 a[2][P], b[NJ][P];
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[i][p] = *reinterpret_cast<const V8*>(pa + p * G3PART + i * 32 * G3RS + s * 16);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) b[j][p] = *reinterpret_cast<const V8*>(pb + p * G3PART + j * 32 * G3RS + s * 16);
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    a[i][p] = *reinterpret_cast<const V8*>(pa + p * G3PART + i * 32 * G3RS + s * 16);
-                    b[i][p] = *reinterpret_cast<const V8*>(pb + p * G3PART + i * 32 * G3RS + s * 16);
-                }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {              // smallest terms first
+                for (int j = 0; j < NJ; ++j) {             // smallest terms first
                     if constexpr (P == 3) {
                         acc[i][j] = G::mfma(a[i][2], b[j][0], acc[i][j]);
                         acc[i][j] = G::mfma(a[i][0], b[j][2], acc[i][j]);
@@ -365,8 +373,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm_split(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const uint32_t n = n0 + wn * 64 + j * 32 + col;
+        for (int j = 0; j < NJ; ++j) {
+            const uint32_t n = n0 + wn * 64 * NB + j * 32 + col;
             if (n >= g.Nc) continue;
             const float b = g.bias != nullptr ? g.bias[n] : 0.f;
 #pragma unroll
@@ -430,32 +438,33 @@ __device__ __forceinline__ typename GSplit<KIND>::V8 gkt_operand(const typename 
     return out;
 }
 
-template <int KIND>
+template <int KIND, int NB = 1>
 __global__ void __launch_bounds__(256, 2) k_gemm_split_kt(GemmArgs g) {
     using G = GSplit<KIND>;
     typedef typename G::T T;
     typedef typename G::V8 V8;
-    constexpr int P = G::P;
+    constexpr int P = G::P, NJ = 2 * NB;
     __shared__ __attribute__((aligned(16))) T sA[P * GKT_PART];
-    __shared__ __attribute__((aligned(16))) T sB[P * GKT_PART];
-    const uint32_t m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+    __shared__ __attribute__((aligned(16))) T sB[NB * P * GKT_PART];
+    const uint32_t m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN * NB;
     const uint32_t k_begin = blockIdx.z * g.k_per_split;
     const uint32_t k_end = k_begin + g.k_per_split < g.Kc ? k_begin + g.k_per_split : g.Kc;
     const int lane = threadIdx.x & 63, col = lane & 31, hi = lane >> 5;
     const int wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
-    f32x16 acc[2][2];
+    f32x16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    float4 ra[G3NJ], rb[G3NJ];
+    float4 ra[G3NJ], rb[NB][G3NJ];
     const bool cs = g.colsum != nullptr && blockIdx.x == 0;                // uniform: the bias gradient, first column tile only
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
     auto load = [&](uint32_t k0) {
         g3_panel_load(g.A, g.mask_src, g.lda, 1, m0, g.Mc, k0, k_end, ra);
-        g3_panel_load(g.B, nullptr, g.ldb, 1, n0, g.Nc, k0, k_end, rb);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) g3_panel_load(g.B, nullptr, g.ldb, 1, n0 + nb * GBN, g.Nc, k0, k_end, rb[nb]);
         if (cs) {
 #pragma unroll
             for (int j = 0; j < G3NJ; ++j) { csum.x += ra[j].x; csum.y += ra[j].y; csum.z += ra[j].z; csum.w += ra[j].w; }
@@ -465,23 +474,27 @@ __global__ void __launch_bounds__(256, 2) k_gemm_split_kt(GemmArgs g) {
     for (uint32_t k0 = k_begin; k0 < k_end; k0 += G3K) {
         __syncthreads();                                   // the previous panel has been consumed
         gkt_panel_store<KIND>(sA, ra);
-        gkt_panel_store<KIND>(sB, rb);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) gkt_panel_store<KIND>(sB + nb * P * GKT_PART, rb[nb]);
         __syncthreads();
         if (k0 + G3K < k_end) load(k0 + G3K);
+        // this wave's 64 * NB columns of the B panel: block wn (NB == 2), or rows wn * 64 .. of the one block
+        const T* pbw = sB + (NB == 2 ? wn * P * GKT_PART : 0);
+        const int rowb = NB == 2 ? 0 : wn * 64;
 #pragma unroll
         for (int s = 0; s < G3K / 16; ++s) {
-            V8 a[2][P], b[2][P];
+            V8 a[2][P], b[NJ][P];
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[i][p] = gkt_operand<KIND>(sA + p * GKT_PART, wm * 64 + i * 32, s * 16);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) b[j][p] = gkt_operand<KIND>(pbw + p * GKT_PART, rowb + j * 32, s * 16);
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    a[i][p] = gkt_operand<KIND>(sA + p * GKT_PART, wm * 64 + i * 32, s * 16);
-                    b[i][p] = gkt_operand<KIND>(sB + p * GKT_PART, wn * 64 + i * 32, s * 16);
-                }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {              // smallest terms first
+                for (int j = 0; j < NJ; ++j) {             // smallest terms first
                     if constexpr (P == 3) {
                         acc[i][j] = G::mfma(a[i][2], b[j][0], acc[i][j]);
                         acc[i][j] = G::mfma(a[i][0], b[j][2], acc[i][j]);
@@ -497,8 +510,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm_split_kt(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const uint32_t n = n0 + wn * 64 + j * 32 + col;
+        for (int j = 0; j < NJ; ++j) {
+            const uint32_t n = n0 + wn * 64 * NB + j * 32 + col;
             if (n >= g.Nc) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -552,9 +565,16 @@ static int gemm_launch(GemmArgs g, uint32_t splits, void* stream) {
     const uint32_t kb = split ? (uint32_t)G3K : (uint32_t)GBK;
     g.k_per_split = (uint32_t)(((uint64_t)(g.Kc + splits - 1) / splits + kb - 1) / kb * kb);
     if (g.k_per_split == 0) g.k_per_split = kb;
-    const dim3 grid(xr_div_up(g.Nc, GBN), xr_div_up(g.Mc, GBM), splits);
+    dim3 grid(xr_div_up(g.Nc, GBN), xr_div_up(g.Mc, GBM), splits);
     XR_REQUIRE(grid.y <= 65535, "more than 65535 row tiles (8.3 M rows) in one call");
-    if (kt) hipLaunchKernelGGL(k_gemm_split_kt<G_B2>, grid, dim3(256), 0, (hipStream_t)stream, g);
+    // 128 x 256 tiles: the A panels (x; dy and its mask) are read once per 256 output columns.  The weight gradient takes them only when the
+    // last 256-column block is more than half full (N' x 352: 273 us wide against 242 us narrow; 256 x 256: 131 against 185)
+    const bool wide = split && dflt && g.Nc > GBN && (!kt || xr_div_up(g.Nc, 2 * GBN) * 2 * GBN - g.Nc < GBN);
+    if (wide) grid.x = xr_div_up(g.Nc, 2 * GBN);
+    if (kt && wide) hipLaunchKernelGGL((k_gemm_split_kt<G_B2, 2>), grid, dim3(256), 0, (hipStream_t)stream, g);
+    else if (kt) hipLaunchKernelGGL(k_gemm_split_kt<G_B2>, grid, dim3(256), 0, (hipStream_t)stream, g);
+    else if (wide && g.a_gradient) hipLaunchKernelGGL((k_gemm_split<G_B2, 2>), grid, dim3(256), 0, (hipStream_t)stream, g);
+    else if (wide) hipLaunchKernelGGL((k_gemm_split<G_H2, 2>), grid, dim3(256), 0, (hipStream_t)stream, g);
     else if (split && dflt && g.a_gradient) hipLaunchKernelGGL(k_gemm_split<G_B2>, grid, dim3(256), 0, (hipStream_t)stream, g);
     else if (split && dflt) hipLaunchKernelGGL(k_gemm_split<G_H2>, grid, dim3(256), 0, (hipStream_t)stream, g);
     else if (split) hipLaunchKernelGGL(k_gemm_split<G_B3>, grid, dim3(256), 0, (hipStream_t)stream, g);
