@@ -66,17 +66,50 @@ class _Span:
         self.timer.events.setdefault(self.name, []).append((self.a, self.b, self.units))
 
 
+_HIP = None
+
+
+def _hip():
+    """the HIP runtime this process already runs on (the copy torch mapped), for the four event calls below"""
+    global _HIP
+    if _HIP is None:
+        path = None
+        with open('/proc/self/maps') as f:
+            for line in f:
+                if 'libamdhip64' in line:
+                    path = line.split()[-1]
+                    break
+        h = C.CDLL(path or 'libamdhip64.so')
+        h.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
+        h.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
+        h.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+        h.hipEventDestroy.argtypes = [C.c_void_p]
+        _HIP = h
+    return _HIP
+
+
 class _CEvent:
     """a timing event handed to the library by its raw handle (xr_ngp_train_step / xr_ngp_loop_run record it around a stage or in front
-    of an iteration).  The event is the caller's: torch creates the underlying HIP event at its first record, hence the record here."""
+    of an iteration).  The event is the caller's, made with the HIP runtime directly: a torch.cuda.Event only exists as a HIP event after
+    its first record, and a record per event at creation -- 30 per refresh window with a kernel timer on -- put 4 ms of release fences in
+    front of every refresh iteration (round 5, the one bench run that had them)."""
 
     def __init__(self):
-        self.ev = torch.cuda.Event(enable_timing=True)
-        self.ev.record()
-        self.h = C.c_void_p(self.ev.cuda_event)
+        self.h = C.c_void_p()
+        if _hip().hipEventCreate(C.byref(self.h)) != 0 or not self.h:
+            raise _lib.XrError('hipEventCreate failed')
 
     def elapsed_time(self, other):
-        return self.ev.elapsed_time(other.ev)
+        ms = C.c_float()
+        if _hip().hipEventElapsedTime(C.byref(ms), self.h, other.h) != 0:
+            raise _lib.XrError('hipEventElapsedTime failed (both events recorded and complete?)')
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            _hip().hipEventDestroy(self.h)
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
 
 
 class _NoSpan:
@@ -477,7 +510,8 @@ def ngp_train_step(table, wd, wc, nhd, nhc, pad_value, meta, coords, n_dev, nums
 
 def record_event(cevent):
     """record a timing event (_CEvent) on the current stream"""
-    cevent.ev.record()
+    if _hip().hipEventRecord(cevent.h, _stream()) != 0:
+        raise _lib.XrError('hipEventRecord failed')
 
 
 def calc_rgb_inference(raw, coords, numsteps, bg3, rgb_act, density_act):
