@@ -379,9 +379,13 @@ int xr_ngp_train_step(const float* table, const float* w_density, const float* w
  * xr_ngp_window_march write them); the encoder then reads them with coalesced loads (xr_hashgrid_fwd). */
 /* timed_entry (nullable): the name of ONE of the entry points the step runs ("xr_hashgrid_fwd", "xr_nerf_mlp_fwd",
  * "xr_composite_train", "xr_live_rows", "xr_nerf_mlp_bwd", "xr_hashgrid_bwd"): its launches are bracketed on `stream` by the two
- * caller's events (hipEvent_t created with timing enabled; the library creates none) -- bench.py's live duration of the dominant kernel
- * inside the timed region.
+ * events -- bench.py's live duration of the dominant kernel inside the timed region.  A caller with a HIP binding of its own passes its own
+ * hipEvent_t (timing enabled); for callers without one (ctypes) the four calls below make, record, read and destroy such events.
  */
+void* xr_timing_event_create(void);
+int xr_event_record(void* event, void* stream);
+int xr_timing_event_destroy(void* event);
+int xr_timing_event_elapsed_ms(void* begin, void* end, float* ms);
 
 /* ------------------------------------------------------------------------------------------
  * The marches of a refresh WINDOW as one series of launches, and the training LOOP between two grid refreshes as one call.

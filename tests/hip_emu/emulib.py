@@ -44,7 +44,8 @@ def check(rc, L):
         raise RuntimeError('rc=%d: %s' % (rc, L.xr_last_error().decode()))
 
 
-HOST_ONLY = ('xr_ngp_train_step', 'xr_ngp_window_march', 'xr_ngp_loop_run', 'xr_rccl_unique_id', 'xr_rccl_create', 'xr_rccl_destroy',
+HOST_ONLY = ('xr_ngp_train_step', 'xr_ngp_window_march', 'xr_timing_event_create', 'xr_timing_event_destroy', 'xr_timing_event_elapsed_ms',
+             'xr_event_record', 'xr_ngp_loop_run', 'xr_rccl_unique_id', 'xr_rccl_create', 'xr_rccl_destroy',
              'xr_rccl_exchange', 'xr_rccl_exposed_ms')
 ALL_SOURCES = ('xr_misc', 'xr_grid', 'xr_raymarch', 'xr_encode', 'xr_mlp', 'xr_mip', 'xr_kilo', 'xr_gemm')
 

@@ -71,6 +71,10 @@ class LoopState(C.Structure):
 SIGNATURES = {
     'xr_last_error': (C.c_char_p, []),
     'xr_version': (_i32, []),
+    'xr_event_record': (_i32, [_vp, _vp]),
+    'xr_timing_event_create': (_vp, []),
+    'xr_timing_event_destroy': (_i32, [_vp]),
+    'xr_timing_event_elapsed_ms': (_i32, [_vp, _vp, _vp]),
     'xr_pcg32_host_state': (None, [_u64, _u64, _vp, _vp]),
     'xr_rays_sampler': (_i32, [_vp, _vp, _vp, _u32, _f, _f, _f, _f, _u32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _sz, _vp]),
     'xr_compacted_coord': (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -9,6 +9,23 @@
 #include <cstdlib>
 #include <initializer_list>
 
+// Timing events for callers without a HIP binding of their own (bench.py brackets one stage of the native step with them)
+extern "C" void* xr_timing_event_create(void) {
+    hipEvent_t e = nullptr;
+    return hipEventCreate(&e) == hipSuccess ? (void*)e : nullptr;
+}
+extern "C" int xr_timing_event_destroy(void* e) { return e && hipEventDestroy((hipEvent_t)e) != hipSuccess ? XR_EHIP : XR_OK; }
+extern "C" int xr_timing_event_elapsed_ms(void* a, void* b, float* ms) {
+    XR_REQUIRE(a && b && ms, "null pointer");
+    XR_HIP(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+    return XR_OK;
+}
+extern "C" int xr_event_record(void* event, void* stream) {
+    XR_REQUIRE(event, "null event");
+    XR_HIP(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+    return XR_OK;
+}
+
 static bool stage_is(const char* timed, const char* name) { return timed && strcmp(timed, name) == 0; }
 
 extern "C" int xr_ngp_train_step(

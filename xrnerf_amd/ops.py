@@ -66,48 +66,23 @@ class _Span:
         self.timer.events.setdefault(self.name, []).append((self.a, self.b, self.units))
 
 
-_HIP = None
-
-
-def _hip():
-    """the HIP runtime this process already runs on (the copy torch mapped), for the four event calls below"""
-    global _HIP
-    if _HIP is None:
-        path = None
-        with open('/proc/self/maps') as f:
-            for line in f:
-                if 'libamdhip64' in line:
-                    path = line.split()[-1]
-                    break
-        h = C.CDLL(path or 'libamdhip64.so')
-        h.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
-        h.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
-        h.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
-        h.hipEventDestroy.argtypes = [C.c_void_p]
-        _HIP = h
-    return _HIP
-
-
 class _CEvent:
-    """a timing event handed to the library by its raw handle (xr_ngp_train_step / xr_ngp_loop_run record it around a stage or in front
-    of an iteration).  The event is the caller's, made with the HIP runtime directly: a torch.cuda.Event only exists as a HIP event after
-    its first record, and a record per event at creation -- 30 per refresh window with a kernel timer on -- put 4 ms of release fences in
-    front of every refresh iteration (round 5, the one bench run that had them)."""
+    """a timing event of the library (xr_timing_event_*): what xr_ngp_train_step / xr_ngp_loop_run record around a stage or in front of an
+    iteration"""
 
     def __init__(self):
-        self.h = C.c_void_p()
-        if _hip().hipEventCreate(C.byref(self.h)) != 0 or not self.h:
-            raise _lib.XrError('hipEventCreate failed')
+        self.h = _lib.load().xr_timing_event_create()
+        if not self.h:
+            raise _lib.XrError('cannot create a timing event')
 
     def elapsed_time(self, other):
         ms = C.c_float()
-        if _hip().hipEventElapsedTime(C.byref(ms), self.h, other.h) != 0:
-            raise _lib.XrError('hipEventElapsedTime failed (both events recorded and complete?)')
+        _lib.check(_lib.load().xr_timing_event_elapsed_ms(self.h, other.h, C.byref(ms)), 'xr_timing_event_elapsed_ms')
         return float(ms.value)
 
     def __del__(self):
         try:
-            _hip().hipEventDestroy(self.h)
+            _lib.load().xr_timing_event_destroy(self.h)
         except Exception:  # noqa: BLE001  (interpreter shutdown)
             pass
 
@@ -510,8 +485,7 @@ def ngp_train_step(table, wd, wc, nhd, nhc, pad_value, meta, coords, n_dev, nums
 
 def record_event(cevent):
     """record a timing event (_CEvent) on the current stream"""
-    if _hip().hipEventRecord(cevent.h, _stream()) != 0:
-        raise _lib.XrError('hipEventRecord failed')
+    _lib.check(_lib.load().xr_event_record(cevent.h, _stream()), 'xr_event_record')
 
 
 def calc_rgb_inference(raw, coords, numsteps, bg3, rgb_act, density_act):
