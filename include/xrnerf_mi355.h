@@ -395,11 +395,11 @@ int xr_timing_event_elapsed_ms(void* begin, void* end, float* ms);
  * changes the batch size at iterations = 15 (mod 16) only (:268-281), and K1 reads no weights (ray_sampler.cu:5-116).  So right behind a
  * refresh every batch of the window can be drawn and marched: xr_ngp_window_march does that for up to XR_NGP_WINDOW iterations with ONE
  * launch per kernel (batch assembly, K1 count, K1 write, K2 clip) and one copy of the (rays, samples) counters to pinned host memory --
- * bit for bit the batches, samples and RNG call indices of one xr_make_batch / xr_rays_sampler / xr_clip_numsteps sequence per iteration.
+ * bit for bit the batches, samples and RNG call indices of one xr_make_batch_series(1) / xr_rays_sampler / xr_clip_numsteps sequence per iteration.
  * The window's buffers are caller-owned: chunk c (iteration it lives in chunk it % XR_NGP_WINDOW) sits at fixed strides. */
 #define XR_NGP_WINDOW 16
 typedef struct xr_ngp_window {
-    float *rays_o, *rays_d, *target, *alpha, *bg; int32_t* img_ids;   /* xr_make_batch outputs; chunk c at row c * ray_stride */
+    float *rays_o, *rays_d, *target, *alpha, *bg; int32_t* img_ids;   /* xr_make_batch_series outputs; chunk c at row c * ray_stride */
     int32_t *rays_index, *rays_numsteps, *numsteps_clipped;           /* K1 / K2 per-ray outputs ([.,1], [.,2], [.,2]); chunk c at row c * ray_stride */
     uint32_t ray_stride;                                              /* rows per chunk of the per-ray arrays (>= n_rays) */
     float* coords; size_t coords_stride;                              /* chunk c: coords + 7 * c * coords_stride, coords_stride >= max_samples rows */
@@ -407,7 +407,7 @@ typedef struct xr_ngp_window {
     uint32_t *counter2, *n_valid;                                     /* [XR_NGP_WINDOW][2] each: K1's (rays, samples), K2's valid row count (twice) */
 } xr_ngp_window;
 /* chunks [first_chunk, first_chunk + n_chunks): the first `batches_ready` of them already hold their batch (the caller drew it with
- * xr_make_batch into the chunk's rows), the others are drawn here from the device-resident [n_table_rays, 11] table with the cursor
+ * xr_make_batch_series into the chunk's rows), the others are drawn here from the device-resident [n_table_rays, 11] table with the cursor
  * *cur_ray (in / out; a batch that would run over the end starts at row 0) and the batch generator's call indices batch_call_index ...;
  * K1 runs for all n_chunks with call indices k1_call_index ...; counter_host_pinned (nullable): [XR_NGP_WINDOW][2] pinned words,
  * the chunks' pairs are copied to their slots.  workspace: xr_rays_sampler_workspace_bytes(n_rays, n_chunks). */

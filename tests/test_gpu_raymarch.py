@@ -95,7 +95,7 @@ def test_k1_overflow_and_k2_clip(O, lego, dev):
 
 def test_window_march_equals_one_launch_per_iteration(lego, dev):
     """xr_ngp_window_march: the batches and marches of several iterations as ONE series of launches (blockIdx.y = iteration) are bit for
-    bit the batches, samples, counters and clipped counts of one xr_make_batch / xr_rays_sampler / xr_clip_numsteps sequence per
+    bit the batches, samples, counters and clipped counts of one xr_make_batch_series(1) / xr_rays_sampler / xr_clip_numsteps sequence per
     iteration with consecutive RNG call indices -- a batch size that is not a multiple of the 256-ray block, the table cursor wrapping
     inside the series, a launch whose samples overflow its buffer, a series that starts in the middle of the window."""
     from xrnerf_amd import ops, synthetic as S

@@ -106,7 +106,7 @@ def test_nerf_mlp_fwd(O, dev, n, f32_forward):
 
 @pytest.mark.parametrize('n,n_valid', [(1, None), (33, None), (8191, 8000), (70001, None), (5000, 0)])
 def test_nerf_mlp_fwd_split_operands_equal_fp32_mfma(dev, n, n_valid):
-    """xr_nerf_mlp_fwd_bf16x3 and xr_nerf_mlp_fwd_f16x2 against xr_nerf_mlp_fwd on the same inputs: activations spanning 1e-6 .. 1e2, weights of
+    """xr_nerf_mlp_fwd in the XR_MLP_BF16X3 and XR_MLP_F16X2 arithmetics against XR_MLP_F32 on the same inputs: activations spanning 1e-6 .. 1e2, weights of
     mixed magnitude, a device-side row count, row-indirect directions.  Both are fp32-accurate evaluations of the same sums,
     so they agree to a few ulp of the largest partial sum (here: 3e-6 of max|raw|), far inside the 1e-4 parity bar."""
     from xrnerf_amd import ops, synthetic as S

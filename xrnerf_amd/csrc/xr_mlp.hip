@@ -2472,7 +2472,7 @@ static int mlp_bwd_f32(const float* enc_t, uint32_t ld, const float* dirs, uint3
     const uint32_t grid = bwd_grid(n);
     // XR_MLP_BWD_DW (read per call): f32 = fp32 MFMA throughout; b2 = the dW products on the bf16 matrix cores (2-way split);
     // b2x = the dX chain too; h2f (default, round 5) = that with the forward recomputed on two FP16 parts -- the arithmetic of the
-    // default forward (xr_nerf_mlp_fwd_f16x2), product for product, so the ReLU decisions are the forward's; b2f = the recompute on two
+    // default forward (XR_MLP_F16X2), product for product, so the ReLU decisions are the forward's; b2f = the recompute on two
     // bf16 parts.  b2f is not the default: a recompute at 2^-16
     // relative accuracy puts a hidden unit whose pre-activation is within ~1e-5 of zero on the other side of its ReLU than
     // the forward had it (a few hundred unit-samples per training step, ~1 with the fp32 recompute) -- harmless to the

@@ -79,7 +79,6 @@ extern "C" int xr_ngp_train_step(
     else rc = xr_hashgrid_fwd(table, coords, 7, 1, n_rows, n_dev, nullptr, n_levels, scale_host, resolution_host, offset_host, enc_t, ld, stream_);
     if (rc != XR_OK) return rc;
     if ((rc = end("xr_hashgrid_fwd")) != XR_OK || (rc = begin("xr_nerf_mlp_fwd")) != XR_OK) return rc;
-    const bool f16_mlp = mlp_mode == 1;
     rc = xr_nerf_mlp_fwd(mlp_mode, enc_t, ld, coords + 4, 7, n_rows, n_dev, nullptr, w_density, w_color, n_hidden_density, n_hidden_color, pad_value,
                          raw, stream_);
     if (rc != XR_OK) return rc;
