@@ -146,7 +146,7 @@ def gemm_kernel(request, monkeypatch):
     return request.param
 
 
-@pytest.mark.parametrize('M,N,K', [(300, 256, 96), (257, 128, 284), (130, 260, 256), (5, 4, 8), (1000, 132, 36)])
+@pytest.mark.parametrize('M,N,K', [(300, 256, 96), (257, 128, 284), (130, 260, 256), (5, 4, 8), (1000, 132, 36), (200, 384, 256), (321, 512, 132)])
 def test_linear_kernels_on_the_host(E, M, N, K, gemm_kernel):
     L = E.lib('xr_gemm')
     rng = np.random.default_rng(M + N + K)
