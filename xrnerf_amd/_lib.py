@@ -165,19 +165,33 @@ def load():
     if _lib is not None:
         return _lib
     from . import build as _build
-    stale = False
-    if not os.environ.get('XRNERF_LIB') and os.path.exists(LIB_PATH) and os.path.isdir(_build.CSRC):
-        # the binary beside the sources must be the build OF those sources (build.py stamps every build with both hashes)
-        i = _build.info()
-        stale = i.get('stamp') == 'missing' or not i.get('binary_is_the_stamped_build') or i.get('sources_match_the_stamped_build') is False
+
+    def is_stale():
+        if not os.environ.get('XRNERF_LIB') and os.path.exists(LIB_PATH) and os.path.isdir(_build.CSRC):
+            # the binary beside the sources must be the build OF those sources (build.py stamps every build with both hashes)
+            i = _build.info()
+            return i.get('stamp') == 'missing' or not i.get('binary_is_the_stamped_build') or i.get('sources_match_the_stamped_build') is False
+        return False
+
+    stale = is_stale()
     if not os.path.exists(LIB_PATH) or stale:
-        try:
-            _build.build(force=stale)
-        except Exception as e:  # noqa: BLE001
-            if not os.path.exists(LIB_PATH):
-                raise XrError('libxrnerf_mi355.so is missing and could not be built: %s. '
-                              'Run `python -m xrnerf_amd.build` (needs hipcc).' % e)
-            raise XrError('libxrnerf_mi355.so is not the build of the sources beside it and could not be rebuilt: %s' % e)
+        # one builder per tree: the ranks of a multi-GPU job start together (torch.distributed.run), and N compilers writing the same
+        # objects would hand every rank a broken library.  The others wait for the lock and find the finished build.
+        import fcntl
+        with open(LIB_PATH + '.lock', 'w') as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                stale = is_stale()
+                if not os.path.exists(LIB_PATH) or stale:
+                    try:
+                        _build.build(force=stale)
+                    except Exception as e:  # noqa: BLE001
+                        if not os.path.exists(LIB_PATH):
+                            raise XrError('libxrnerf_mi355.so is missing and could not be built: %s. '
+                                          'Run `python -m xrnerf_amd.build` (needs hipcc).' % e)
+                        raise XrError('libxrnerf_mi355.so is not the build of the sources beside it and could not be rebuilt: %s' % e)
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError here = header/library mismatch: fail loudly
