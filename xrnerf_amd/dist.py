@@ -46,19 +46,28 @@ def allreduce_grads(params, world_size):
 class _ExposedTimer:
     """How long the compute stream WAITS for the collectives of a step: one event in front of the waits and one behind them, on the
     compute stream -- the span between the two is what the exchange adds to the step after everything that overlapped (measured,
-    per rank; `dist.comm_model` is the model beside it).  Host tensors (gloo protocol tests on CPU): wall clock around the waits."""
+    per rank; `dist.comm_model` is the model beside it).  Host tensors (gloo protocol tests on CPU): wall clock around the waits.
+    A ring of RING event pairs, re-recorded in turn (like the native exchange's, csrc/xr_dist.hip): the record covers the last RING
+    steps, and the number of live timing events stays bounded (round 5: with several hundred timing events alive, event records took
+    ~100 us each -- profiles/NOTES in DESIGN.md section 0, item 8)."""
+
+    RING = 64
 
     def __init__(self):
         self.on = False
         self._pairs, self._host_ms = [], []
+        self._n = 0
 
     def begin(self, device_is_cuda):
         if not self.on:
             return None
         if device_is_cuda:
-            a = torch.cuda.Event(enable_timing=True)
+            slot = self._n % self.RING
+            if slot >= len(self._pairs):
+                self._pairs.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+            a = self._pairs[slot][0]
             a.record()
-            return a
+            return slot
         import time
         return time.perf_counter()
 
@@ -69,15 +78,17 @@ class _ExposedTimer:
             import time
             self._host_ms.append((time.perf_counter() - token) * 1e3)
         else:
-            b = torch.cuda.Event(enable_timing=True)
-            b.record()
-            self._pairs.append((token, b))
+            self._pairs[token][1].record()
+            self._n += 1
 
     def summary(self):
-        """-> {'steps', 'mean_ms', 'max_ms'} (call after a device synchronisation); clears the record"""
-        ms = [a.elapsed_time(b) for a, b in self._pairs] + self._host_ms
-        self._pairs, self._host_ms = [], []
-        return {'steps': len(ms), 'mean_ms': sum(ms) / len(ms) if ms else None, 'max_ms': max(ms) if ms else None}
+        """-> {'steps', 'mean_ms', 'max_ms'} (call after a device synchronisation) over the last <= RING device-side steps (all host-side
+        ones); 'steps' counts every step since the last call; clears the record"""
+        k = min(self._n, len(self._pairs))
+        ms = [a.elapsed_time(b) for a, b in self._pairs[:k]] + self._host_ms
+        steps = self._n + len(self._host_ms)
+        self._host_ms, self._n = [], 0
+        return {'steps': steps, 'mean_ms': sum(ms) / len(ms) if ms else None, 'max_ms': max(ms) if ms else None}
 
 
 class BucketedGradSync:
