@@ -681,7 +681,7 @@ def main():
         tr.step()
     torch.cuda.synchronize()
     pre_summ, ops.TIMER = ops.TIMER.summary(), None
-    cand = {k: v[1] for k, v in pre_summ.items() if k != 'xr_rays_sampler'}      # K1 runs overlapped on the side stream
+    cand = {k: v[1] for k, v in pre_summ.items() if k != 'xr_rays_sampler'}      # (K1 runs once per refresh window, beside the refresh iteration: not a per-step kernel)
     dom_pick = max(cand, key=cand.get) if cand else 'xr_hashgrid_bwd'
     torch.cuda.synchronize()
     ops.TIMER = ops.KernelTimer(only={dom_pick}, train_only=True)
@@ -710,6 +710,9 @@ def main():
     elapsed = time.perf_counter() - t0
     timer, ops.TIMER = ops.TIMER, None
     it1 = tr.iter
+    # operands the default MLP arithmetic had to saturate at fp16's range, over everything this process has run so far (pre-roll, warm-up,
+    # timed window): waves counted by the forward kernels in the range word (xr_set_mlp_range_word); 0 = the fp16 x 2 split was exact
+    mlp_range_events = ops.mlp_range_events(dev)
     step_ms = [step_ev[k].elapsed_time(step_ev[k + 1]) for k in range(args.steps)]
     is_refresh = [(it0 + k) % sampler.update_grid_freq == 0 for k in range(args.steps)]
     ms_refresh = [m for m, r in zip(step_ms, is_refresh) if r]
@@ -811,11 +814,14 @@ def main():
     roof = roof_of(dom_pick, launches, total_ms, units if units > 0 else samples, live_frac_timed)
     roof['traffic'] = None
     try:   # HBM bytes per launch from separate rocprofv3 --pmc passes of THIS command (tools/pmc_traffic.py)
-        pmc_path = next(p for p in (os.path.join(ROOT, 'profiles', n) for n in ('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json')) if os.path.exists(p))
+        # (hardware counters cannot be read from inside this process: the figure is the committed record of the last `rocprofv3 --pmc` passes
+        # of this command -- `traffic_from_file` names it -- not a measurement of this run)
+        pmc_path = next(p for p in (os.path.join(ROOT, 'profiles', n) for n in ('r06_pmc_traffic.json', 'r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json')) if os.path.exists(p))
         pmc = json.load(open(pmc_path))
         if dom_pick in pmc:
             roof['traffic'] = pmc[dom_pick]['bytes_fetch_x2']
-            roof['traffic_unit'] = 'bytes/launch (PMC FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, 2^18-sample batches; %s)' % os.path.basename(pmc_path)
+            roof['traffic_from_file'] = 'profiles/' + os.path.basename(pmc_path)
+            roof['traffic_unit'] = 'bytes/launch (PMC FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, 2^18-sample batches; read from %s, collected by tools/gpu_call.sh pmc)' % os.path.basename(pmc_path)
     except Exception:  # noqa: BLE001
         pass
 
@@ -985,6 +991,7 @@ def main():
                        'rays_per_batch_history': hist,
                        'parallelism': 'ray-sharded data parallel x%d, gradient all-reduce (RCCL)' % world if world > 1 else 'single GPU'},
             'roofline': roof,
+            'mlp_range_events': mlp_range_events,
             'roofline_kernels': roofs,
             'backward_live_row_fraction': {'timed_window': live_frac_timed, 'kernel_window': live_frac_win,
                                            'note': 'share of the marched samples whose dL/d(raw) is not exactly zero (T == 0 behind opaque '

@@ -267,12 +267,20 @@ int xr_sh4(const float* dirs, uint32_t dir_stride, uint32_t n, float* out, void*
  *                  conversions of the 3-way bf16 split: 27.5 us against 42.6 us at 2^18 rows.  Range: hidden activations up to 65504
  *                  and hash-grid features up to 4e3 in magnitude (the features enter the first layer scaled by 2^4, exactly; the
  *                  reference's own fp16 tcnn overflows at 65504 too); low parts below 2^-14 are fp16 subnormals (absolute precision
- *                  2^-25).  Any depth.
+ *                  2^-25).  Any depth.  Out of range is SATURATED, not inf: every operand is clamped to +-65504 before it is split
+ *                  (hidden activations in the ReLU's own instruction), forward and backward alike, and the forward counts the waves
+ *                  that met such an operand in the caller's range word (xr_set_mlp_range_word below).
  * (xr_version 120 -> 121: the four arithmetics used to be four entry points, xr_nerf_mlp_fwd / _f16 / _bf16x3 / _f16x2.) */
 #define XR_MLP_F32 0
 #define XR_MLP_F16 1
 #define XR_MLP_BF16X3 2
 #define XR_MLP_F16X2 3
+/* XR_MLP_F16X2's range word: one uint32 in device memory, the caller's (per host thread, like the helper stream; NULL = none).  Every
+ * XR_MLP_F16X2 forward launched by this thread afterwards -- xr_nerf_mlp_fwd, xr_nerf_density_splat, and inside xr_ngp_train_step /
+ * xr_ngp_loop_run / the frame entry points -- adds one per wave that split an operand (feature x 2^4, activation, colour input or weight)
+ * above 65504 in magnitude.  Nothing reads it on the device; the host reads it when it synchronises anyway (the trainer: at the grid
+ * refresh) and XR_MLP_F32 is the escape when it is not zero. */
+int xr_set_mlp_range_word(uint32_t* word);
 int xr_nerf_mlp_fwd(int arithmetic, const float* enc_t, uint32_t ld, const float* dirs, uint32_t dir_stride, uint32_t n,
                     const uint32_t* n_dev, const uint32_t* rows /* nullable: dirs row of sample i */, const float* w_density, const float* w_color, int n_hidden_density, int n_hidden_color,
                     float pad_value, float* raw /*[n,4]*/, void* stream);

@@ -680,6 +680,43 @@ void xo_nerf_mlp_fwd(const float* table, const float* Wd, const float* Wc, const
     }
     free(enc); free(sh); free(dout); free(cin); free(cout);
 }
+/* Test infrastructure for the gradient tests: how close does a sample come to a ReLU kink?  margin[i] = min over the hidden
+ * units of this network of |z| / sum_k |w_k x_k| (z = the unit's pre-activation, evaluated as xo_mlp_fwd does), MIN-merged into
+ * margin (caller fills it with a large value).  A backward that recomputes z in another arithmetic can only disagree with this
+ * one about relu'(z) on samples whose margin is below that arithmetic's relative error. */
+void xo_mlp_kink_margin(const float* W, const float* x, int n, int in_pad, int width, int n_hidden, float* margin) {
+    for (int i = 0; i < n; ++i) {
+        float a[2][256];
+        const float* in = x + (size_t)i * in_pad; int nin = in_pad; const float* w = W; int cur = 0;
+        for (int l = 0; l < n_hidden; ++l) {
+            for (int o = 0; o < width; ++o) {
+                float s = 0.f; double mag = 0.0;
+                for (int k = 0; k < nin; ++k) { s += w[(size_t)o * nin + k] * in[k]; mag += fabs((double)w[(size_t)o * nin + k] * (double)in[k]); }
+                a[cur][o] = s > 0.f ? s : 0.f;
+                if (mag > 0.0) { const float r = (float)(fabs((double)s) / mag); if (r < margin[i]) margin[i] = r; }
+            }
+            w += (size_t)width * nin; in = a[cur]; nin = width; cur ^= 1;
+        }
+    }
+}
+void xo_nerf_mlp_kink_margin(const float* table, const float* Wd, const float* Wc, const float* pts, const float* dirs,
+                             int n, int n_levels, const float* scale, const uint32_t* resolution, const uint32_t* offset,
+                             int n_hidden_d, int n_hidden_c, float pad_value, float* margin) {
+    float* enc = (float*)malloc(sizeof(float) * 32);
+    float sh[16], dout[16], cin[32];
+    for (int i = 0; i < n; ++i) {
+        margin[i] = 1e30f;
+        xo_hashgrid_fwd(table, pts + 3 * (size_t)i, 1, n_levels, scale, resolution, offset, enc);
+        xo_mlp_kink_margin(Wd, enc, 1, 2 * n_levels, 64, n_hidden_d, margin + i);
+        xo_mlp_fwd(Wd, enc, 1, 2 * n_levels, 64, n_hidden_d, 16, dout, NULL);
+        xo_sh4(dirs + 3 * (size_t)i, 1, sh);
+        for (int k = 0; k < 15; ++k) cin[k] = dout[1 + k];
+        for (int k = 0; k < 16; ++k) cin[15 + k] = sh[k];
+        cin[31] = pad_value;
+        xo_mlp_kink_margin(Wc, cin, 1, 32, 64, n_hidden_c, margin + i);
+    }
+    free(enc);
+}
 /* backward of the above w.r.t. table, Wd, Wc given dL/draw [N,4]; gradients ACCUMULATE. */
 void xo_nerf_mlp_bwd(const float* table, const float* Wd, const float* Wc, const float* pts, const float* dirs,
                      const float* draw, int n, int n_levels, const float* scale, const uint32_t* resolution,

@@ -333,6 +333,17 @@ def nerf_mlp_fwd(table, Wd, Wc, pts, dirs, meta, n_hidden_d=1, n_hidden_c=2, pad
     return raw
 
 
+def nerf_mlp_kink_margin(table, Wd, Wc, pts, dirs, meta, n_hidden_d=1, n_hidden_c=2, pad_value=1.0):
+    """per sample: the smallest |pre-activation| / sum |w x| over the hidden units of both networks (xo_nerf_mlp_kink_margin)"""
+    table, Wd, Wc, pts, dirs = _f32(table), _f32(Wd), _f32(Wc), _f32(pts), _f32(dirs)
+    n = pts.shape[0]
+    margin = np.zeros((n,), np.float32)
+    port().xo_nerf_mlp_kink_margin(_p(table), _p(Wd), _p(Wc), _p(pts), _p(dirs), C.c_int(n), C.c_int(meta.n_levels),
+                                   _p(meta.scale), _p(meta.resolution), _p(meta.offset), C.c_int(n_hidden_d),
+                                   C.c_int(n_hidden_c), C.c_float(pad_value), _p(margin))
+    return margin
+
+
 def nerf_mlp_bwd(table, Wd, Wc, pts, dirs, draw, meta, n_hidden_d=1, n_hidden_c=2, pad_value=1.0):
     table, Wd, Wc, pts, dirs, draw = _f32(table), _f32(Wd), _f32(Wc), _f32(pts), _f32(dirs), _f32(draw)
     gt, gd, gc = np.zeros_like(table), np.zeros_like(Wd), np.zeros_like(Wc)

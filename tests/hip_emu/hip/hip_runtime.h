@@ -130,6 +130,9 @@ template <typename T> inline T __shfl_xor(T v, int m, int width = 64) {
     return emu::unpack<T>(emu::wave_exchange(emu::pack(v), s < g0 + width && s >= g0 ? s : l));
 }
 inline unsigned long long __ballot(int p) { return emu::wave_ballot(p != 0); }
+inline int __any(int p) { return emu::wave_ballot(p != 0) != 0; }
+// v_med3_f32 (no NaN operands in the kernels' uses)
+inline float __builtin_amdgcn_fmed3f(float a, float b, float c) { return a < b ? (b < c ? b : (a < c ? c : a)) : (a < c ? a : (b < c ? c : b)); }
 // value of the wave's lane 0 (the kernels only use it on wave-uniform values, to tell the compiler they ARE uniform)
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 

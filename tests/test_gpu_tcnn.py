@@ -142,6 +142,127 @@ def test_nerf_mlp_fwd_split_operands_equal_fp32_mfma(dev, n, n_valid):
             assert np.array_equal(out[kind][0][:m, 3], out[kind][1][:m, 3])   # sigma: same arithmetic with and without the color net
 
 
+def _chain_oracle(O, wd, wc, enc, dirs, sat=False, draw=None):
+    """the (1, 2) network over explicit encoded features through the oracle's layer functions (xo_mlp_fwd / xo_mlp_bwd); sat: with
+    XR_MLP_F16X2's saturation applied to the operands (features x 16, colour inputs -- hidden activations are checked, not clamped)"""
+    enc = np.ascontiguousarray(enc, np.float32)
+    if sat:
+        enc = np.clip(enc * 16.0, -65504.0, 65504.0).astype(np.float32) / np.float32(16.0)
+    dout, actd = O.mlp_fwd(wd, enc, 32, 64, 1, 16, want_acts=True)
+    cin = np.concatenate([dout[:, 1:16], O.sh4(dirs), np.ones((enc.shape[0], 1), np.float32)], 1)
+    if sat:
+        cin = np.clip(cin, -65504.0, 65504.0)
+    cout, actc = O.mlp_fwd(wc, cin, 32, 64, 2, 16, want_acts=True)
+    raw = np.concatenate([cout[:, :3], dout[:, :1]], 1)
+    if draw is None:
+        return raw, max(float(actd.max()), float(actc.max()))
+    dyc = np.zeros((enc.shape[0], 16), np.float32); dyc[:, :3] = draw[:, :3]
+    gwc, dcin = O.mlp_bwd(wc, cin, actc, dyc, 32, 64, 2, 16)
+    dyd = np.zeros((enc.shape[0], 16), np.float32); dyd[:, 0] = draw[:, 3]; dyd[:, 1:16] = dcin[:, :15]
+    gwd, denc = O.mlp_bwd(wd, enc, actd, dyd, 32, 64, 1, 16)
+    return raw, gwd, gwc, denc
+
+
+def test_default_forward_and_backward_at_the_edge_of_the_fp16_range(O, dev):
+    """XR_MLP_F16X2 (the default forward) and the h2f backward at the documented boundary: hash-grid features up to +-4000 (x 2^4 = 64000 <
+    65504) and hidden activations up to ~6e4 are carried like any other value -- forward within 3e-6 of max|raw| of the oracle, gradients
+    at the plain bar -- and the range word stays 0.  Beyond the boundary (features of 1e4, activations above 65504) the operands
+    saturate: every output is finite, equal to the oracle's evaluation of the saturated operands where only the inputs saturate, and the
+    range word counts the event (`mlp_range_events` in the bench line reads the same word)."""
+    from xrnerf_amd import ops, synthetic as S
+    assert ops.f32_forward() == 'f16x2'
+    rng = np.random.default_rng(65504)
+    n = 4096
+    wd, wc = nets(S)
+    dirs = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    draw = rng.normal(0, 1, (n, 4)).astype(np.float32)
+
+    def run(enc, wd_, wc_, backward):
+        ops.mlp_range_events(dev, reset=True)
+        enc_t = T(np.ascontiguousarray(enc.T), dev)
+        raw = ops.nerf_mlp_fwd(enc_t, T(dirs, dev), n, T(wd_, dev), T(wc_, dev), 1, 2).cpu().numpy()
+        ev = ops.mlp_range_events(dev, reset=True)
+        if not backward:
+            return raw, ev
+        g_wd = torch.zeros(wd_.size, dtype=torch.float32, device=dev); g_wc = torch.zeros(wc_.size, dtype=torch.float32, device=dev)
+        denc_t = ops.nerf_mlp_bwd(enc_t, T(dirs, dev), n, T(wd_, dev), T(wc_, dev), 1, 2, T(draw, dev), g_wd, g_wc)
+        return raw, ev, g_wd.cpu().numpy(), g_wc.cpu().numpy(), denc_t[:, :n].t().cpu().numpy()
+
+    # (a) at the boundary, inside: features +-4000, first-layer weights scaled so that the hidden activations reach ~3.6e4
+    enc = rng.uniform(-4000, 4000, (n, 32)).astype(np.float32)
+    enc[0, :] = 4000.0; enc[1, :] = -4000.0
+    wd_a = wd.copy(); wd_a[:2048] *= 4.0; wd_a[2048:] *= 1e-4         # hidden activations to ~3.6e4; the density output (the colour net's input) back to O(1)
+    ref, gwd, gwc, denc = _chain_oracle(O, wd_a, wc, enc, dirs, draw=draw)
+    _, hmax = _chain_oracle(O, wd_a, wc, enc, dirs)
+    assert 2e4 < hmax < 65504.0, hmax
+    raw, ev, g_wd, g_wc, d_enc = run(enc, wd_a, wc, True)
+    assert ev == 0
+    scale = np.abs(ref).max()
+    assert np.isfinite(raw).all() and np.abs(raw - ref).max() <= 3e-6 * scale, (np.abs(raw - ref).max(), scale)
+    for name, got, want in (('wd', g_wd, gwd), ('wc', g_wc, gwc), ('denc', d_enc, denc)):
+        assert np.isfinite(got).all(), name
+        grad_close(got / max(np.abs(want).max(), 1e-30), want / max(np.abs(want).max(), 1e-30), name)
+    # (b) features beyond 4094: saturated to 65504 / 16 on the way in, counted, == the oracle on the saturated features
+    enc_b = enc.copy(); enc_b[5, :] = 1e4; enc_b[6, 3] = -3e5
+    ref_b, _ = _chain_oracle(O, wd_a, wc, enc_b, dirs, sat=True)
+    raw_b, ev_b = run(enc_b, wd_a, wc, False)
+    assert ev_b >= 1 and np.isfinite(raw_b).all()
+    assert np.abs(raw_b - ref_b).max() <= 3e-6 * np.abs(ref_b).max(), (np.abs(raw_b - ref_b).max(), np.abs(ref_b).max())
+    # (c) hidden activations beyond 65504 (a first layer twice as large on the same features): finite everywhere, counted; forward and backward
+    wd_c = wd.copy(); wd_c[:2048] *= 8.0; wd_c[2048:] *= 1e-4
+    _, hmax_c = _chain_oracle(O, wd_c, wc, enc, dirs)
+    assert hmax_c > 65504.0, hmax_c
+    raw_c, ev_c, g_wd_c, g_wc_c, d_enc_c = run(enc, wd_c, wc, True)
+    assert ev_c >= 1
+    assert np.isfinite(raw_c).all() and np.isfinite(g_wd_c).all() and np.isfinite(g_wc_c).all() and np.isfinite(d_enc_c).all()
+    ok = _chain_oracle(O, wd_c, wc, enc, dirs)[0]
+    rows = np.abs(ok).max(1) > 0                                       # (every row; the saturated ones differ, boundedly)
+    assert np.abs(raw_c[rows]).max() <= 2.0 * np.abs(ok).max()
+    # (d) weights beyond the range are saturated and counted as well
+    wd_d = wd_a.copy(); wd_d[7] = 1e5
+    raw_d, ev_d = run(enc * 1e-6, wd_d, wc, False)
+    assert ev_d >= 1 and np.isfinite(raw_d).all()
+    # the fp32 MFMA forward is the escape: no saturation, no count
+    ops.set_f32_forward('mfma')
+    try:
+        raw_e, ev_e = run(enc_b, wd_a, wc, False)
+    finally:
+        ops.set_f32_forward('f16x2')
+    ref_e, _ = _chain_oracle(O, wd_a, wc, enc_b, dirs)
+    assert ev_e == 0 and np.abs(raw_e - ref_e).max() <= 3e-6 * np.abs(ref_e).max()
+
+
+@pytest.mark.parametrize('n', [5000, 40000])
+def test_default_backward_on_kink_free_rows_at_the_plain_bar(O, dev, n, monkeypatch):
+    """The DEFAULT backward (recompute on split fp16 operands, XR_MLP_BWD_DW=h2f) against the oracle at the bar of the exact modes
+    (1e-3 * max, no kink allowance): the oracle reports per sample how close its nearest hidden pre-activation comes to zero
+    (xo_nerf_mlp_kink_margin: |z| / sum |w x|); samples within 1e-5 -- where two correct evaluations may disagree about relu'(z) --
+    get a zero dL/d(raw) on both sides, everything else is compared in full."""
+    from xrnerf_amd import ops, synthetic as S
+    monkeypatch.delenv('XR_MLP_BWD_DW', raising=False)
+    meta = ops.GridMeta(); om = O.GridMeta()
+    rng = np.random.default_rng(n + 11)
+    table = S.hash_table(meta.n_params, scale=0.5)
+    wd, wc = nets(S)
+    pts = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    dirs = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    draw = rng.normal(0, 1, (n, 4)).astype(np.float32)
+    margin = O.nerf_mlp_kink_margin(table, wd, wc, pts, dirs, om)
+    near = margin < 1e-5
+    assert near.mean() < 0.02, near.mean()
+    draw[near] = 0.0
+    gt, gd, gc = O.nerf_mlp_bwd(table, wd, wc, pts, dirs, draw, om)
+    tt, tp = T(table, dev), T(pts, dev)
+    enc_t = ops.hashgrid_fwd(tt, tp, meta)
+    g_wd = torch.zeros(wd.size, dtype=torch.float32, device=dev)
+    g_wc = torch.zeros(wc.size, dtype=torch.float32, device=dev)
+    denc_t = ops.nerf_mlp_bwd(enc_t, T(dirs, dev), n, T(wd, dev), T(wc, dev), 1, 2, T(draw, dev), g_wd, g_wc)
+    g_t = torch.zeros(meta.n_params, dtype=torch.float32, device=dev)
+    ops.hashgrid_bwd(tp, denc_t, meta, g_t)
+    for name, got, ref in (('wd', g_wd, gd), ('wc', g_wc, gc), ('table', g_t, gt)):
+        grad_close(got.cpu().numpy(), ref, name, kinks=False)
+
+
 def test_nerf_mlp_fwd_asymmetric_weights(O, dev, f32_forward):
     """transpose / permutation detector: one-hot weights so that each output picks a known input."""
     from xrnerf_amd import ops

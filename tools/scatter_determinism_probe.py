@@ -27,6 +27,8 @@ b = net._step_bufs[net._step_turn]
 meta = net.mlp.embedder_pos.meta
 coords = net.sampler.coords[:b.n_rows]
 off = [2 * int(o) for o in meta.offset]
+# words of the workspace head that hold sub-bin fill counts only: 13 binned levels x >= 32 partitions x (rows / 2048) sample blocks
+COUNT_WORDS = 13 * 32 * max(1, (b.n_rows + 2047) // 2048)
 print('rows', b.n_rows, 'live', int(b.live[1][0]) if b.live is not None else None)
 
 
@@ -35,10 +37,23 @@ def sweep(tag, alternate=False):
     a launch that picked up anything left behind by the launch before it shows, which identical launches would hide"""
     refs, bad, worst = [None, None], [0] * meta.n_levels, 0.0
     dencs = [b.denc_t, -b.denc_t] if alternate else [b.denc_t, b.denc_t]
+    cref, cbad = None, 0
     for k in range(K):
         ref = refs[k & 1]
         g = torch.full((meta.n_params,), float('nan'), device=dev)
         ops.hashgrid_bwd(coords, dencs[k & 1], meta, g, live=b.live, overwrite=True)
+        # the BIN kernel's outputs that do not depend on the wave schedule: the fill counts of every (level, partition, sample block)
+        # sub-bin, at the head of the scatter's workspace (the item -> partition map is a function of the inputs: +-denc give the same counts)
+        ws = ops._workspaces.get((str(dev), 'hgb'))
+        if ws is not None:
+            cnt = ws[:min(ws.numel(), 4 * COUNT_WORDS)].view(torch.int32).clone()
+            if cref is None:
+                cref = cnt
+            elif not torch.equal(cnt, cref):
+                cbad += 1
+                d = torch.nonzero(cnt != cref).reshape(-1)
+                print('   launch %d: %d sub-bin fill counts differ from the first launch (words %d..%d; first: %d instead of %d)'
+                      % (k, d.numel(), int(d[0]), int(d[-1]), int(cnt[d[0]]), int(cref[d[0]])), flush=True)
         if ref is None:
             refs[k & 1] = g
             continue
@@ -54,7 +69,8 @@ def sweep(tag, alternate=False):
                     print('   launch %d level %d: %d entries differ (first at %d, last at %d of %d), max |diff| %.3g where |ref| max %.3g (level max %.3g), nan %d'
                           % (k, l, int(m.sum()), int(idx[0]), int(idx[-1]), m.numel(), float((a - r).abs().nan_to_num(0).max()), float(r.abs().max()),
                              float(ref[off[l]:off[l + 1]].abs().max()), int(torch.isnan(a).sum())), flush=True)
-    print(tag, 'launches', K, 'levels that differed from the first launch (count per level):', bad, 'worst relative difference %.3g' % worst, flush=True)
+    print(tag, 'launches', K, 'levels that differed from the first launch (count per level):', bad, 'worst relative difference %.3g' % worst,
+          '| launches whose sub-bin fill counts differed:', cbad, flush=True)
 
 
 def sweep_others(tag):

@@ -105,6 +105,7 @@ SIGNATURES = {
     'xr_hashgrid_bwd_workspace_bytes': (_sz, [_u32, _i32, _vp, _vp]),
     'xr_hashgrid_bwd': (_i32, [_vp, _u32, _vp, _u32, _u32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp]),
     'xr_set_helper_stream': (_i32, [_vp, _vp, _vp]),
+    'xr_set_mlp_range_word': (_i32, [_vp]),
     'xr_sh4': (_i32, [_vp, _u32, _u32, _vp, _vp]),
     'xr_nerf_mlp_fwd': (_i32, [_i32, _vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _i32, _i32, _f, _vp, _vp]),
     'xr_nerf_mlp_bwd_workspace_bytes': (_sz, [_u32, _i32, _i32]),

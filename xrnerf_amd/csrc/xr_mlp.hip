@@ -500,22 +500,53 @@ __device__ __forceinline__ void layer_fwd_b2(const __bf16* __restrict__ wf, int 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 #define H2_IN_SCALE 16.0f       // hash-grid features into the first layer: O(1e-4) at initialisation -> low parts of 2^-11 of that stay out of the
-                                // deepest fp16 subnormals; features up to 4e3 in magnitude do not overflow
+                                // deepest fp16 subnormals; features up to 4094 in magnitude are carried exactly, larger ones saturate (below)
+// Range of the split.  fp16 ends at 65504: an operand above it would convert to inf and poison the row with NaN.  Every operand of
+// this arithmetic is therefore SATURATED to +-65504 before it is split (the first layer's input after its scale, the colour net's
+// input, every hidden activation -- there in the ReLU's own instruction, v_med3_f32(h, 0, 65504) -- and the weights), so the error of an
+// out-of-range value is bounded, and the forward kernels COUNT the waves that saw one in the caller's range word
+// (xr_set_mlp_range_word): the trainer reads it at the grid refresh's host read-back and the bench line prints it
+// (`mlp_range_events`).  The backward's recompute saturates the same way (same ReLU decisions, same operands) and does not count.
+#define H2_MAX 65504.0f
 struct H2Tile { h8 p[2][2]; };               // [hi | lo part][K-step]
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ H2Tile to_h2(const f32x16& t, float scale = 1.0f) {
+__device__ __forceinline__ float h2_sat(float x) { return __builtin_amdgcn_fmed3f(x, -H2_MAX, H2_MAX); }
+// an INPUT tile (any sign): x * scale, saturated.  TRACK: mx = max(mx, |x * scale|) before the saturation
+template <bool SAT = true, bool TRACK = false>
+__device__ __forceinline__ H2Tile to_h2(const f32x16& t, float scale, float& mx) {
     H2Tile r;
 #pragma unroll
     for (int k = 0; k < 2; ++k)
 #pragma unroll
         for (int e = 0; e < 8; e += 2) {
-            const f32x2 x = f32x2{t[8 * k + e], t[8 * k + e + 1]} * scale;
+            f32x2 x = f32x2{t[8 * k + e], t[8 * k + e + 1]} * scale;
+            if (TRACK) mx = fmaxf(fmaxf(mx, fabsf(x[0])), fabsf(x[1]));
+            if (SAT) { x[0] = h2_sat(x[0]); x[1] = h2_sat(x[1]); }
             const f16x2 h = __builtin_convertvector(x, f16x2);
             const f16x2 l = __builtin_convertvector(x - __builtin_convertvector(h, f32x2), f16x2);
             r.p[0][k][e] = h[0]; r.p[0][k][e + 1] = h[1];
             r.p[1][k][e] = l[0]; r.p[1][k][e + 1] = l[1];
         }
     return r;
+}
+__device__ __forceinline__ H2Tile to_h2(const f32x16& t, float scale = 1.0f) { float d = 0.f; return to_h2<true, false>(t, scale, d); }
+// a hidden activation tile already through h2_relu_sat: in range by construction
+__device__ __forceinline__ H2Tile to_h2_act(const f32x16& t) { float d = 0.f; return to_h2<false, false>(t, 1.0f, d); }
+// ReLU + the saturation in one instruction per value: t = med3(t * s, 0, 65504)
+template <bool TRACK = false>
+__device__ __forceinline__ void h2_relu_sat(f32x16& t, float s, float& mx) {
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const f32x2 x = f32x2{t[r], t[r + 1]} * s;
+        const float a = x[0], b = x[1];
+        if (TRACK) mx = fmaxf(fmaxf(mx, a), b);
+        t[r] = __builtin_amdgcn_fmed3f(a, 0.f, H2_MAX); t[r + 1] = __builtin_amdgcn_fmed3f(b, 0.f, H2_MAX);
+    }
+}
+__device__ __forceinline__ void h2_relu_sat(f32x16& t, float s = 1.0f) { float d = 0.f; h2_relu_sat<false>(t, s, d); }
+// one count per wave that saw an operand out of range (word: the caller's, nullable)
+__device__ __forceinline__ void h2_range_report(float mx, uint32_t* __restrict__ word) {
+    if (word != nullptr && __any(mx > H2_MAX) && (threadIdx.x & 63) == 0) atomicAdd(word, 1u);
 }
 // ROW16: the layer has 16 rows in LDS (lanes 16..31 repeat them; their accumulator rows are not used)
 template <int TI, int TO, bool ROW16 = false>
@@ -567,9 +598,10 @@ __device__ __forceinline__ void store_layer_fh2(const float (&v)[NetShape<NH>::o
         const int m = (L == 0 && first_layer_rot) ? ((c + 1) & 31) : c;             // LDS slot of global column c
         const float w = o < rows ? v[i] : 0.f;
         if (frows > 0 && o < frows) {
-            const _Float16 h = (_Float16)w;
+            const float ws = h2_sat(w);                                                 // (as store_layer_h2)
+            const _Float16 h = (_Float16)ws;
             _Float16* d = dstf + o * rs + hslot(m, ns);
-            d[0] = h; d[psf] = (_Float16)(w - (float)h);
+            d[0] = h; d[psf] = (_Float16)(ws - (float)h);
         }
         const __bf16 hb = (__bf16)w;
         __bf16* d = dstb + m * rsb + hslot(o, nso);
@@ -883,18 +915,15 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void k_nerf_mlp_bwd_1_2(
             // the forward's own arithmetic (k_nerf_mlp_fwd_h2: same split, same products in the same order): its ReLU decisions bit for bit
             const _Float16* hfd = reinterpret_cast<const _Float16*>(wfd);
             const _Float16* hfc = reinterpret_cast<const _Float16*>(wfc);
+            // (and its saturation: h2_relu_sat / to_h2)
             { const H2Tile xb[1] = {to_h2(xe[0], H2_IN_SCALE)}; layer_fwd_h2<1, 2>(hfd + FD::off(0), PFD, xb, hd, col, hi); }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                hd[0][r] = hd[0][r] > 0.f ? hd[0][r] * (1.0f / H2_IN_SCALE) : 0.f;
-                hd[1][r] = hd[1][r] > 0.f ? hd[1][r] * (1.0f / H2_IN_SCALE) : 0.f;
-            }
-            { const H2Tile hb[2] = {to_h2(hd[0]), to_h2(hd[1])}; layer_fwd_h2<2, 1, true>(hfd + FD::off(1), PFD, hb, dout, col, hi); }
+            h2_relu_sat(hd[0], 1.0f / H2_IN_SCALE); h2_relu_sat(hd[1], 1.0f / H2_IN_SCALE);     // relu + the input scale taken out again (exact)
+            { const H2Tile hb[2] = {to_h2_act(hd[0]), to_h2_act(hd[1])}; layer_fwd_h2<2, 1, true>(hfd + FD::off(1), PFD, hb, dout, col, hi); }
             build_color_in(dout[0], dirs, dir_stride, sc, pad_value, cin[0], hi);
             { const H2Tile cb[1] = {to_h2(cin[0])}; layer_fwd_h2<1, 2>(hfc + FC::off(0), PFC, cb, hc1, col, hi); }
-            relu_tile(hc1[0]); relu_tile(hc1[1]);
-            { const H2Tile hb[2] = {to_h2(hc1[0]), to_h2(hc1[1])}; layer_fwd_h2<2, 2>(hfc + FC::off(1), PFC, hb, hc2, col, hi); }
-            relu_tile(hc2[0]); relu_tile(hc2[1]);
+            h2_relu_sat(hc1[0]); h2_relu_sat(hc1[1]);
+            { const H2Tile hb[2] = {to_h2_act(hc1[0]), to_h2_act(hc1[1])}; layer_fwd_h2<2, 2>(hfc + FC::off(1), PFC, hb, hc2, col, hi); }
+            h2_relu_sat(hc2[0]); h2_relu_sat(hc2[1]);
         } else if constexpr (FWB) {
             { const B2Tile xb[1] = {to_b2(xe[0])}; layer_fwd_b2<1, 2>(wfd + FD::off(0), PFD, xb, hd, col, hi); }
             relu_tile(hd[0]); relu_tile(hd[1]);
@@ -1686,11 +1715,11 @@ __device__ __forceinline__ void layer_fwd_b3(const __bf16* __restrict__ wf, int 
 // ulps of fp32, at HALF the matrix instructions and ~60 % of the conversion instructions of the 3-way bf16 split (3 MFMAs and two
 // conversions + one subtraction per value instead of 6 and 3 + 2).  What fp16 costs is exponent range: a low part below 2^-14 is a
 // subnormal (absolute precision 2^-25 ~ 3e-8 -- the level at which the reference's own fp16 tcnn quantises EVERY value) and
-// a value above 65504 would overflow; the hash-grid features, O(1e-4) at initialisation, are therefore scaled by 2^10 into the first
-// layer and its accumulators scaled back (both exact).  The weights sit in LDS in two fp16 parts (56 KiB for both networks).
+// a value above 65504 would overflow (it is saturated and counted instead: H2_MAX above); the hash-grid features, O(1e-4) at
+// initialisation, are therefore scaled by H2_IN_SCALE = 2^4 into the first layer and its accumulators scaled back (both exact).  The weights sit in LDS in two fp16 parts (56 KiB for both networks).
 template <int NH, int L>
 __device__ __forceinline__ void store_layer_h2(const float (&v)[NetShape<NH>::out_rows_lds(L) * NetShape<NH>::in_dim(L) / BX_THREADS],
-                                               _Float16* __restrict__ wf, int ps, bool first_layer_rot) {
+                                               _Float16* __restrict__ wf, int ps, bool first_layer_rot, float& mx) {
     using S = NetShape<NH>;
     using H = HShape<NH>;
     constexpr int K = S::in_dim(L), rows = S::out_dim(L), prow = S::out_rows_lds(L), ns = K / 16, rs = h_rs(K);
@@ -1699,14 +1728,15 @@ __device__ __forceinline__ void store_layer_h2(const float (&v)[NetShape<NH>::ou
     for (int i = 0; i < prow * K / BX_THREADS; ++i) {
         const int x = threadIdx.x + i * BX_THREADS, o = x / K, c = x % K;        // global [o][c]
         const int m = (L == 0 && first_layer_rot) ? ((c + 1) & 31) : c;           // LDS slot of global column c
-        const float w = o < rows ? v[i] : 0.f;
+        mx = fmaxf(mx, fabsf(v[i]));
+        const float w = o < rows ? h2_sat(v[i]) : 0.f;
         const _Float16 h = (_Float16)w;
         _Float16* d = dst + o * rs + hslot(m, ns);
         d[0] = h; d[ps] = (_Float16)(w - (float)h);
     }
 }
 template <int NH>
-__device__ inline void load_weights_h2(_Float16* __restrict__ wf, int ps, const float* __restrict__ w, bool first_layer_rot) {
+__device__ inline void load_weights_h2(_Float16* __restrict__ wf, int ps, const float* __restrict__ w, bool first_layer_rot, float& mx) {
     using S = NetShape<NH>;
     static_assert(NH == 1 || NH == 2, "built for 1 or 2 hidden layers");
     float v0[S::out_rows_lds(0) * S::in_dim(0) / BX_THREADS], v1[S::out_rows_lds(1) * S::in_dim(1) / BX_THREADS];
@@ -1714,9 +1744,9 @@ __device__ inline void load_weights_h2(_Float16* __restrict__ wf, int ps, const 
     fetch_layer_b3<NH, 0>(v0, w);
     fetch_layer_b3<NH, 1>(v1, w);
     if constexpr (NH >= 2) fetch_layer_b3<NH, 2>(v2, w);
-    store_layer_h2<NH, 0>(v0, wf, ps, first_layer_rot);
-    store_layer_h2<NH, 1>(v1, wf, ps, false);
-    if constexpr (NH >= 2) store_layer_h2<NH, 2>(v2, wf, ps, false);
+    store_layer_h2<NH, 0>(v0, wf, ps, first_layer_rot, mx);
+    store_layer_h2<NH, 1>(v1, wf, ps, false, mx);
+    if constexpr (NH >= 2) store_layer_h2<NH, 2>(v2, wf, ps, false, mx);
 }
 template <bool WITH_COLOR>
 __global__ __launch_bounds__(BX_THREADS, 2) void k_nerf_mlp_fwd_h2(const float* __restrict__ enc_t, uint32_t ld,
@@ -1726,12 +1756,13 @@ __global__ __launch_bounds__(BX_THREADS, 2) void k_nerf_mlp_fwd_h2(const float* 
                                                                     const float* __restrict__ w_density,
                                                                     const float* __restrict__ w_color, float pad_value,
                                                                     float4* __restrict__ raw, const int32_t* __restrict__ splat_idx,
-                                                                    float* __restrict__ splat_grid) {
+                                                                    float* __restrict__ splat_grid, uint32_t* __restrict__ range_word) {
     if (n_dev) n = min(n, *n_dev);
     if (n == 0) return;
     using HD = HShape<1>;
     using HC = HShape<2>;
     constexpr int PD = HD::f_halves, PC = HC::f_halves;             // halves per part
+    float mx = 0.f;                                                 // largest operand magnitude this thread split (h2_range_report)
     extern __shared__ __attribute__((aligned(16))) _Float16 ldsh2[];
     _Float16* wd = ldsh2;
     _Float16* wc = ldsh2 + 2 * PD;
@@ -1749,35 +1780,32 @@ __global__ __launch_bounds__(BX_THREADS, 2) void k_nerf_mlp_fwd_h2(const float* 
         }
     };
     if (tile < n_tiles) fetch(tile, x, d3);
-    load_weights_h2<1>(wd, PD, w_density, false);
-    if (WITH_COLOR) load_weights_h2<2>(wc, PC, w_color, true);
+    load_weights_h2<1>(wd, PD, w_density, false, mx);
+    if (WITH_COLOR) load_weights_h2<2>(wc, PC, w_color, true, mx);
     __syncthreads();
     for (; tile < n_tiles; tile += stride) {
         const uint32_t s = tile * 32 + col;
-        H2Tile xin[1] = {to_h2(x, H2_IN_SCALE)};
+        H2Tile xin[1] = {to_h2<true, true>(x, H2_IN_SCALE, mx)};
         const float dx = d3[0], dy = d3[1], dz = d3[2];
         if (tile + stride < n_tiles) fetch(tile + stride, x, d3);   // next tile's loads under this tile's MFMAs
         f32x16 h[2], dout[1];
         layer_fwd_h2<1, 2>(wd + HD::f_off(0), PD, xin, h, col, hi);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {                              // relu + the input scale taken out again (exact)
-            h[0][r] = h[0][r] > 0.f ? h[0][r] * (1.0f / H2_IN_SCALE) : 0.f;
-            h[1][r] = h[1][r] > 0.f ? h[1][r] * (1.0f / H2_IN_SCALE) : 0.f;
-        }
-        H2Tile hh[2] = {to_h2(h[0]), to_h2(h[1])};
+        h2_relu_sat<true>(h[0], 1.0f / H2_IN_SCALE, mx);            // relu + the input scale taken out again (exact) + the saturation
+        h2_relu_sat<true>(h[1], 1.0f / H2_IN_SCALE, mx);
+        H2Tile hh[2] = {to_h2_act(h[0]), to_h2_act(h[1])};
         layer_fwd_h2<2, 1>(wd + HD::f_off(1), PD, hh, dout, col, hi);
         float4 o = make_float4(0.f, 0.f, 0.f, dout[0][0]);
         if (WITH_COLOR) {
             f32x16 cin, cout[1];
             const float dd[3] = {dx, dy, dz};
             build_color_in(dout[0], dd, 3, 0, pad_value, cin, hi);
-            H2Tile ci[1] = {to_h2(cin)};
+            H2Tile ci[1] = {to_h2<true, true>(cin, 1.0f, mx)};
             layer_fwd_h2<1, 2>(wc + HC::f_off(0), PC, ci, h, col, hi);
-            relu_tile(h[0]); relu_tile(h[1]);
-            hh[0] = to_h2(h[0]); hh[1] = to_h2(h[1]);
+            h2_relu_sat<true>(h[0], 1.0f, mx); h2_relu_sat<true>(h[1], 1.0f, mx);
+            hh[0] = to_h2_act(h[0]); hh[1] = to_h2_act(h[1]);
             layer_fwd_h2<2, 2>(wc + HC::f_off(1), PC, hh, h, col, hi);
-            relu_tile(h[0]); relu_tile(h[1]);
-            hh[0] = to_h2(h[0]); hh[1] = to_h2(h[1]);
+            h2_relu_sat<true>(h[0], 1.0f, mx); h2_relu_sat<true>(h[1], 1.0f, mx);
+            hh[0] = to_h2_act(h[0]); hh[1] = to_h2_act(h[1]);
             layer_fwd_h2<2, 1>(wc + HC::f_off(2), PC, hh, cout, col, hi);
             o.x = cout[0][0]; o.y = cout[0][1]; o.z = cout[0][2];
         }
@@ -1786,6 +1814,7 @@ __global__ __launch_bounds__(BX_THREADS, 2) void k_nerf_mlp_fwd_h2(const float* 
             else raw[s] = o;
         }
     }
+    h2_range_report(mx, range_word);
 }
 
 // Measured and dropped: handing the tiles out dynamically (a ticket counter, because the next batch's ray march co-runs on
@@ -1917,9 +1946,10 @@ __device__ __forceinline__ void deep_commit_f2(const float (&v)[W_HID * W_HID / 
         const int e = threadIdx.x + i * THREADS, o = e >> L.kshift, c = e & (L.K - 1);
         if (e < L.prow * L.K) {
             const int m = rot ? ((c + 1) & 31) : c;
-            const _Float16 h = (_Float16)v[i];
+            const float ws = h2_sat(v[i]);
+            const _Float16 h = (_Float16)ws;
             _Float16* d = buf + o * rs + hslot(m, ns);
-            d[0] = h; d[DP_PS] = (_Float16)(v[i] - (float)h);
+            d[0] = h; d[DP_PS] = (_Float16)(ws - (float)h);
         }
     }
 }
@@ -1941,7 +1971,7 @@ __device__ __forceinline__ void deep_commit_b2(const float (&v)[W_HID * W_HID / 
 __device__ __forceinline__ uint32_t relu_tile_bits(f32x16& t) {           // relu in place -> one bit per value that stayed
     uint32_t m = 0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { const bool on = t[r] > 0.f; m |= on ? (1u << r) : 0u; t[r] = on ? t[r] : 0.f; }
+    for (int r = 0; r < 16; ++r) { const bool on = t[r] > 0.f; m |= on ? (1u << r) : 0u; t[r] = on ? fminf(t[r], H2_MAX) : 0.f; }   // (saturated as h2_relu_sat)
     return m;
 }
 __device__ __forceinline__ void mask_tile_bits(f32x16& g, uint32_t m) {
@@ -1956,9 +1986,11 @@ __global__ __launch_bounds__(DP_FW * 64, 1) void k_nerf_mlp_fwd_deep(const float
                                                                      const uint32_t* __restrict__ rows,
                                                                      const float* __restrict__ w_density, const float* __restrict__ w_color,
                                                                      int nhd, int nhc, float pad_value, float4* __restrict__ raw,
-                                                                     const int32_t* __restrict__ splat_idx, float* __restrict__ splat_grid) {
+                                                                     const int32_t* __restrict__ splat_idx, float* __restrict__ splat_grid,
+                                                                     uint32_t* __restrict__ range_word) {
     if (n_dev) n = min(n, *n_dev);
     if (n == 0) return;
+    float mx = 0.f;                                                     // (h2_range_report; the weights' range is the (1, 2) kernel's and the trainer's check)
     constexpr int THREADS = DP_FW * 64;
     extern __shared__ __attribute__((aligned(16))) __bf16 ldsb[];        // two layer buffers of two 16-bit parts each
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, hi = lane >> 5;
@@ -1998,16 +2030,15 @@ __global__ __launch_bounds__(DP_FW * 64, 1) void k_nerf_mlp_fwd_deep(const float
             if (l == 0) {
                 // (the hash-grid features enter scaled by 2^4, the accumulators are scaled back: see k_nerf_mlp_fwd_h2)
                 const float sc_in = net == 0 ? H2_IN_SCALE : 1.0f, sc_out = net == 0 ? 1.0f / H2_IN_SCALE : 1.0f;
-                const H2Tile xin[1] = {to_h2(x, sc_in)};
+                const H2Tile xin[1] = {to_h2<true, true>(x, sc_in, mx)};
                 layer_fwd_h2<1, 2>(wf, DP_PS, xin, h, col, hi);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { h[0][r] = h[0][r] > 0.f ? h[0][r] * sc_out : 0.f; h[1][r] = h[1][r] > 0.f ? h[1][r] * sc_out : 0.f; }
+                h2_relu_sat<true>(h[0], sc_out, mx); h2_relu_sat<true>(h[1], sc_out, mx);
             } else if (l < nh) {
-                const H2Tile hh[2] = {to_h2(h[0]), to_h2(h[1])};
+                const H2Tile hh[2] = {to_h2_act(h[0]), to_h2_act(h[1])};
                 layer_fwd_h2<2, 2>(wf, DP_PS, hh, h, col, hi);
-                relu_tile(h[0]); relu_tile(h[1]);
+                h2_relu_sat<true>(h[0], 1.0f, mx); h2_relu_sat<true>(h[1], 1.0f, mx);
             } else {
-                const H2Tile hh[2] = {to_h2(h[0]), to_h2(h[1])};
+                const H2Tile hh[2] = {to_h2_act(h[0]), to_h2_act(h[1])};
                 f32x16 dout[1];
                 layer_fwd_h2<2, 1>(wf, DP_PS, hh, dout, col, hi);
                 if (net == 0) {
@@ -2023,6 +2054,7 @@ __global__ __launch_bounds__(DP_FW * 64, 1) void k_nerf_mlp_fwd_deep(const float
             else raw[s] = o;
         }
     }
+    h2_range_report(mx, range_word);
 }
 
 template <int TO>
@@ -2170,10 +2202,10 @@ __global__ __launch_bounds__(DP_BW * 64, 1) void k_nerf_mlp_bwd_deep(
                     layer_fwd_h2<1, 2>(wl, DP_PS, xin, h, col, hi);
                     if (net == 0) { scale_tile(h[0], 1.0f / H2_IN_SCALE); scale_tile(h[1], 1.0f / H2_IN_SCALE); }
                 } else if (l < nh) {
-                    const H2Tile hh[2] = {to_h2(h[0]), to_h2(h[1])};
+                    const H2Tile hh[2] = {to_h2_act(h[0]), to_h2_act(h[1])};
                     layer_fwd_h2<2, 2>(wl, DP_PS, hh, h, col, hi);
                 } else {                                              // density output layer -> the colour net's input slots
-                    const H2Tile hh[2] = {to_h2(h[0]), to_h2(h[1])};
+                    const H2Tile hh[2] = {to_h2_act(h[0]), to_h2_act(h[1])};
                     f32x16 dout[1];
                     layer_fwd_h2<2, 1>(wl, DP_PS, hh, dout, col, hi);
                     build_color_in(dout[0], dirs, dir_stride, s, pad_value, x, hi);
@@ -2264,6 +2296,9 @@ __global__ __launch_bounds__(DP_BW * 64, 1) void k_nerf_mlp_bwd_deep(
 // set around a density-only forward by xr_nerf_density_splat: the launch splats instead of writing `raw`
 static thread_local const int32_t* g_fwd_splat_idx = nullptr;
 static thread_local float* g_fwd_splat_grid = nullptr;
+// the caller's range word (xr_set_mlp_range_word, per host thread like the helper stream): the XR_MLP_F16X2 forwards count into it
+static thread_local uint32_t* g_range_word = nullptr;
+extern "C" int xr_set_mlp_range_word(uint32_t* word) { g_range_word = word; return XR_OK; }
 static int g_cus = 0;
 extern "C" int xr_device_cus(void) {       // (internal, hidden: xr_common.h)
     if (g_cus == 0) {
@@ -2319,11 +2354,11 @@ static int launch_fwd_deep(const float* enc_t, uint32_t ld, const float* dirs, u
     if (dirs) {
         if (mlp_set_lds((const void*)k_nerf_mlp_fwd_deep<true>, lds) != XR_OK) { xr_set_error("hipFuncSetAttribute failed"); return XR_EHIP; }
         hipLaunchKernelGGL(k_nerf_mlp_fwd_deep<true>, dim3(grid), dim3(DP_FW * 64), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev, rows, wd, wc,
-                           nhd, nhc, pad, (float4*)raw, (const int32_t*)nullptr, (float*)nullptr);
+                           nhd, nhc, pad, (float4*)raw, (const int32_t*)nullptr, (float*)nullptr, g_range_word);
     } else {
         if (mlp_set_lds((const void*)k_nerf_mlp_fwd_deep<false>, lds) != XR_OK) { xr_set_error("hipFuncSetAttribute failed"); return XR_EHIP; }
         hipLaunchKernelGGL(k_nerf_mlp_fwd_deep<false>, dim3(grid), dim3(DP_FW * 64), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev, rows, wd, wc,
-                           nhd, nhc, pad, (float4*)raw, g_fwd_splat_idx, g_fwd_splat_grid);
+                           nhd, nhc, pad, (float4*)raw, g_fwd_splat_idx, g_fwd_splat_grid, g_range_word);
     }
     XR_LAUNCH_CHECK();
     return XR_OK;
@@ -2629,11 +2664,11 @@ static int mlp_fwd_f16x2(const float* enc_t, uint32_t ld, const float* dirs, uin
         const size_t lds = (size_t)2 * (HShape<1>::f_halves + HShape<2>::f_halves) * 2;
         if (mlp_set_lds((const void*)k_nerf_mlp_fwd_h2<true>, lds) != XR_OK) { xr_set_error("hipFuncSetAttribute failed"); return XR_EHIP; }
         hipLaunchKernelGGL(k_nerf_mlp_fwd_h2<true>, dim3(grid2), dim3(BX_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev,
-                           rows, w_density, w_color, pad_value, (float4*)raw, (const int32_t*)nullptr, (float*)nullptr);
+                           rows, w_density, w_color, pad_value, (float4*)raw, (const int32_t*)nullptr, (float*)nullptr, g_range_word);
     } else {
         const size_t lds = (size_t)2 * HShape<1>::f_halves * 2;
         hipLaunchKernelGGL(k_nerf_mlp_fwd_h2<false>, dim3(grid2), dim3(BX_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev,
-                           rows, w_density, w_color, pad_value, (float4*)raw, g_fwd_splat_idx, g_fwd_splat_grid);
+                           rows, w_density, w_color, pad_value, (float4*)raw, g_fwd_splat_idx, g_fwd_splat_grid, g_range_word);
     }
     XR_LAUNCH_CHECK();
     return XR_OK;

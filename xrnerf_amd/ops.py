@@ -202,22 +202,64 @@ def _buf(device, shape, tag):
 
 
 _helpers = {}
+_helper_current = {}            # host thread -> the device whose helper the library's (per-thread) slot holds right now
 
 
 def _ensure_helper(device):
     """hand the library this thread's helper stream (xr_set_helper_stream): one stream + fork / join events per device and host thread,
-    created HERE -- the library itself creates nothing.  Without it the scatter's side work runs in order on the compute stream."""
+    created HERE -- the library itself creates nothing.  Without it the scatter's side work runs in order on the compute stream.
+    The library's slot is one per host thread: a thread that moves to another device hands over that device's stream again."""
     import threading
-    key = (str(device), threading.get_ident())
-    if key in _helpers or device.type != 'cuda':
+    if device.type != 'cuda':
         return
-    st = torch.cuda.Stream(device=device)
-    evs = (torch.cuda.Event(), torch.cuda.Event())
-    for e in evs:
-        e.record(st)                               # (torch creates the underlying event at its first record)
+    tid = threading.get_ident()
+    key = (str(device), tid)
+    if _helper_current.get(tid) == key:
+        return
+    h = _helpers.get(key)
+    if h is None:
+        with torch.cuda.device(device):
+            st = torch.cuda.Stream(device=device)
+            evs = (torch.cuda.Event(), torch.cuda.Event())
+            for e in evs:
+                e.record(st)                           # (torch creates the underlying event at its first record, on the current device)
+        h = _helpers[key] = (st, evs)
+    st, evs = h
     _lib.check(_lib.load().xr_set_helper_stream(C.c_void_p(st.cuda_stream), C.c_void_p(evs[0].cuda_event), C.c_void_p(evs[1].cuda_event)),
                'xr_set_helper_stream')
-    _helpers[key] = (st, evs)
+    _helper_current[tid] = key
+
+
+# ---- range of the default MLP arithmetic (XR_MLP_F16X2 saturates its operands at +-65504 and counts the waves that saw one out of
+# range in the caller's word: include/xrnerf_mi355.h).  One uint32 word per device; the library's slot is per host thread.
+_range_words = {}
+_range_current = {}
+
+
+def mlp_range_word(device):
+    """this device's range word (a [1] int32 tensor, allocated once), handed to the library for the calling thread"""
+    import threading
+    if device.type != 'cuda':
+        return None
+    w = _range_words.get(str(device))
+    if w is None:
+        w = _range_words[str(device)] = torch.zeros((1,), dtype=torch.int32, device=device)
+    tid = threading.get_ident()
+    if _range_current.get(tid) != str(device):
+        _lib.check(_lib.load().xr_set_mlp_range_word(C.c_void_p(w.data_ptr())), 'xr_set_mlp_range_word')
+        _range_current[tid] = str(device)
+    return w
+
+
+def mlp_range_events(device, reset=False):
+    """waves of the default forward that met an operand above fp16's range since the last reset (a host read-back: synchronises)"""
+    w = mlp_range_word(device)
+    if w is None:
+        return 0
+    v = int(w.item())
+    if reset and v:
+        w.zero_()
+    return v
 
 
 def pcg32_host_state(ncalls, seed=9121):
@@ -436,6 +478,7 @@ def ngp_train_step(table, wd, wc, nhd, nhc, pad_value, meta, coords, n_dev, nums
     L = _lib.load()
     n_rays = numsteps.shape[0]
     mode = _mlp_mode(nhd, nhc)
+    mlp_range_word(coords.device)
     key = (table.data_ptr(), wd.data_ptr(), wc.data_ptr(), coords.data_ptr(), coords.shape[0], n_dev.data_ptr() if n_dev is not None else 0,
            numsteps.data_ptr(), numsteps_c.data_ptr(), bg.data_ptr(), target.data_ptr(), alpha.data_ptr(), density_grid_mean.data_ptr(),
            xyz.data_ptr() if xyz is not None else 0, xyz.shape[1] if xyz is not None else 0, nhd, nhc, pad_value, mode, id(meta),
@@ -812,6 +855,7 @@ def nerf_mlp_fwd(enc_t, dirs, n, w_density, w_color, nhd, nhc, pad_value=1.0, ra
     _ptr(enc_t); _ptr(raw)
     if count is not None:
         n = count
+    mlp_range_word(enc_t.device)
     with _span('xr_nerf_mlp_fwd', 0 if n_dev is not None else n, train=n_dev is not None):
         _lib.check(L.xr_nerf_mlp_fwd(_mlp_mode(nhd, nhc), C.c_void_p(enc_t.data_ptr() + 4 * row0), enc_t.shape[1], dp, ds, n, _ptr(n_dev),
                                      _ptr(rows), _ptr(w_density), _ptr(w_color) if w_color is not None else None, nhd,
@@ -825,6 +869,7 @@ def nerf_density_splat(enc_t, n, w_density, nhd, nhc, indices, grid_tmp):
     grid_tmp[indices[i]] by maximum from the forward kernel's epilogue (fused topologies only: see density_splat_supported)"""
     if indices.dtype != torch.int32 or grid_tmp.dtype != torch.float32:
         raise _lib.XrError('nerf_density_splat: int32 indices, float32 grid')
+    mlp_range_word(enc_t.device)
     with _span('xr_nerf_mlp_fwd', n, train=False):
         _lib.check(_lib.load().xr_nerf_density_splat(_mlp_mode(nhd, nhc), _ptr(enc_t), enc_t.shape[1], n, _ptr(w_density), nhd, nhc, _ptr(indices),
                                                      _ptr(grid_tmp), _stream()), 'xr_nerf_density_splat')

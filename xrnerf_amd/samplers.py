@@ -611,9 +611,36 @@ class NGPGridSampler(_FastAttr, nn.Module):
         self._drain_counts()
         return self.samples_marched
 
+    def poll_mlp_range(self):
+        """The default MLP arithmetic (XR_MLP_F16X2) saturates operands above fp16's range and counts them in a device word
+        (ops.mlp_range_word).  Once per refresh window, where the host waits for the sample counters anyway: look at the copy of the
+        word issued one window ago (arrived long since -- no stall), warn the first time it is not zero, issue the next copy.
+        `mlp_range_events` = the count as of one window ago."""
+        if not self._streams():
+            return
+        word = ops.mlp_range_word(self.device)
+        pend = self.__dict__.get('_range_pending')
+        if pend is not None:
+            ev, host = pend
+            ev.synchronize()
+            v = int(host[0])
+            if v and not getattr(self, 'mlp_range_events', 0):
+                import warnings
+                warnings.warn('the fused MLP met operands above the fp16 range (%d wave events so far): they were saturated at 65504; '
+                              'ops.set_f32_forward("mfma") / XR_MLP_BWD_DW=b2x run the fp32 MFMA kernels instead' % v)
+            self.mlp_range_events = v
+        host = self.__dict__.get('_range_host')
+        if host is None:
+            host = self._range_host = torch.empty((1,), dtype=torch.int32, pin_memory=True)
+        host.copy_(word, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._range_pending = (ev, host)
+
     def update_batch_rays(self, is_training, max_samples=None):
         if is_training and self.iter_n % self.update_grid_freq == (self.update_grid_freq - 1):
             self._drain_counts()
+            self.poll_mlp_range()
             total = int(self.measured_batch_size)                # host tensor: no device read-back (:271)
             if max_samples is not None and total > 16 * max_samples:
                 raise RuntimeError('ray marcher overflowed its %d-row sample buffer' % max_samples)

@@ -493,6 +493,7 @@ class _NativeLoop:
         if not ops.hashgrid_bwd_adam_supported(n_rows, meta):
             raise _lib.XrError('the fused table update has no non-atomic scatter path at this row capacity')
         ops._ensure_helper(dev)
+        ops.mlp_range_word(dev)
         D = _lib.LoopDesc()
         vp = lambda t: t.data_ptr() if t is not None else None
         D.table, D.w_density, D.w_color = vp(table), vp(wd), vp(wc)
