@@ -191,7 +191,11 @@ def test_default_forward_and_backward_at_the_edge_of_the_fp16_range(O, dev):
     # (a) at the boundary, inside: features +-4000, first-layer weights scaled so that the hidden activations reach ~3.6e4
     enc = rng.uniform(-4000, 4000, (n, 32)).astype(np.float32)
     enc[0, :] = 4000.0; enc[1, :] = -4000.0
-    wd_a = wd.copy(); wd_a[:2048] *= 4.0; wd_a[2048:] *= 1e-4         # hidden activations to ~3.6e4; the density output (the colour net's input) back to O(1)
+    # hidden activations to ~3.6e4; the density outputs (the colour net's inputs) ~8.5e3, the colour net's own activations ~6e2.  (The
+    # weights stay O(0.01 .. 1): the split carries an operand below 2^-3 to 2^-25 ABSOLUTE -- its low part is an fp16 subnormal -- so
+    # weights of 1e-5 against activations of 1e4 would be a test of that documented floor, not of the range.)
+    wd_a = wd.copy(); wd_a[:2048] *= 4.0; wd_a[2048:] *= 0.25
+    wc = wc.copy(); wc[:2048] *= 0.125
     ref, gwd, gwc, denc = _chain_oracle(O, wd_a, wc, enc, dirs, draw=draw)
     _, hmax = _chain_oracle(O, wd_a, wc, enc, dirs)
     assert 2e4 < hmax < 65504.0, hmax
@@ -209,7 +213,7 @@ def test_default_forward_and_backward_at_the_edge_of_the_fp16_range(O, dev):
     assert ev_b >= 1 and np.isfinite(raw_b).all()
     assert np.abs(raw_b - ref_b).max() <= 3e-6 * np.abs(ref_b).max(), (np.abs(raw_b - ref_b).max(), np.abs(ref_b).max())
     # (c) hidden activations beyond 65504 (a first layer twice as large on the same features): finite everywhere, counted; forward and backward
-    wd_c = wd.copy(); wd_c[:2048] *= 8.0; wd_c[2048:] *= 1e-4
+    wd_c = wd.copy(); wd_c[:2048] *= 8.0; wd_c[2048:] *= 0.25
     _, hmax_c = _chain_oracle(O, wd_c, wc, enc, dirs)
     assert hmax_c > 65504.0, hmax_c
     raw_c, ev_c, g_wd_c, g_wc_c, d_enc_c = run(enc, wd_c, wc, True)

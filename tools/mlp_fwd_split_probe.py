@@ -45,15 +45,20 @@ def case(label, enc, wd_, wc_=wc, sat=False):
 
 for scale in (1e-4, 1e-2, 0.5, 20.0):
     case('features ~ N(0, %g)' % scale, (torch.randn((32, n), generator=g) * scale).to(dev), wd)
-# the documented boundary: features up to +-4000 (x 2^4 = 64000 < 65504), hidden activations up to ~3.6e4 (first layer x 4, its output layer x 1e-4)
+# the documented boundary: features up to +-4000 (x 2^4 = 64000 < 65504), hidden activations up to ~3.6e4 (first layer x 4, its output layer x 0.25, the colour net's first layer x 0.125)
 enc_b = ((torch.rand((32, n), generator=g) * 2 - 1) * 4000.0).to(dev); enc_b[:, 0] = 4000.0; enc_b[:, 1] = -4000.0
-wd_b = wd.copy(); wd_b[:2048] *= 4.0; wd_b[2048:] *= 1e-4
-case('boundary: features +-4000, hidden ~3.6e4', enc_b, wd_b)
+wd_b = wd.copy(); wd_b[:2048] *= 4.0; wd_b[2048:] *= 0.25
+wc_b = wc.copy(); wc_b[:2048] *= 0.125
+case('boundary: features +-4000, hidden ~3.6e4', enc_b, wd_b, wc_b)
+# the floor of the split, for the record: an operand below 2^-3 has an fp16-subnormal low part, i.e. it is carried to 2^-25 ABSOLUTE;
+# output-layer weights of ~2e-5 against activations of 3.6e4 show it (every realistic regime above does not)
+wd_s = wd.copy(); wd_s[:2048] *= 4.0; wd_s[2048:] *= 1e-4
+case('floor: weights ~2e-5 x activations 3.6e4', enc_b, wd_s)
 # beyond it: features of 1e4 (saturate at 4094), first layer x 8 (hidden activations above 65504 saturate)
 enc_o = enc_b.clone(); enc_o[:, 5] = 1e4; enc_o[3, 6] = -3e5
-case('beyond: features 1e4 / -3e5', enc_o, wd_b, sat=True)
-wd_o = wd.copy(); wd_o[:2048] *= 8.0; wd_o[2048:] *= 1e-4
-case('beyond: hidden activations > 65504', enc_b, wd_o, sat=True)
+case('beyond: features 1e4 / -3e5', enc_o, wd_b, wc_b, sat=True)
+wd_o = wd.copy(); wd_o[:2048] *= 8.0; wd_o[2048:] *= 0.25
+case('beyond: hidden activations > 65504', enc_b, wd_o, wc_b, sat=True)
 
 enc = (torch.randn((32, n), generator=g) * 0.1).to(dev); raw = torch.empty((n, 4), device=dev)
 twd, twc = torch.from_numpy(wd).to(dev), torch.from_numpy(wc).to(dev)

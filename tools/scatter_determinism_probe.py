@@ -66,6 +66,12 @@ def sweep(tag, alternate=False):
                     bad[l] += 1
                     a, r = g[off[l]:off[l + 1]][m], ref[off[l]:off[l + 1]][m]
                     idx = torch.nonzero(m).reshape(-1)
+                    # where inside the level: accumulate workgroups (2^13 entries = 16384 floats each) hit, floats per workgroup, features
+                    wg = idx // 16384
+                    uw, cw = torch.unique(wg, return_counts=True)
+                    print('      %d accumulate workgroups hit (floats per workgroup: max %d, min %d); feature-0 / feature-1 floats %d / %d; '
+                          'diff / ref of the first five: %s' % (uw.numel(), int(cw.max()), int(cw.min()), int((idx % 2 == 0).sum()), int((idx % 2 == 1).sum()),
+                                                                 ' '.join('%.4g' % float(v) for v in ((a - r) / r.abs().clamp_min(1e-30))[:5])), flush=True)
                     print('   launch %d level %d: %d entries differ (first at %d, last at %d of %d), max |diff| %.3g where |ref| max %.3g (level max %.3g), nan %d'
                           % (k, l, int(m.sum()), int(idx[0]), int(idx[-1]), m.numel(), float((a - r).abs().nan_to_num(0).max()), float(r.abs().max()),
                              float(ref[off[l]:off[l + 1]].abs().max()), int(torch.isnan(a).sum())), flush=True)
@@ -98,10 +104,14 @@ def sweep_others(tag):
     print(tag, 'launches', K, 'kernels that differed from the first launch:', bad or 'none', flush=True)
 
 
-sweep('alone, same input every launch        ')
-sweep('alone, alternating inputs             ', True)
-p = subprocess.Popen([sys.executable, os.path.abspath(__file__), 'noise', '110'])
+NOISE = int(os.environ.get('NOISE_PROCS', '1'))
+if not os.environ.get('SHARED_ONLY'):
+    sweep('alone, same input every launch        ')
+    sweep('alone, alternating inputs             ', True)
+ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), 'noise', os.environ.get('NOISE_SECONDS', '110')]) for _ in range(NOISE)]
 time.sleep(15)
-sweep('GPU shared, same input every launch   ')
-sweep('GPU shared, alternating inputs        ', True)
-p.wait()
+sweep('GPU shared (%d other), same input every launch   ' % NOISE)
+if not os.environ.get('SHARED_ONLY'):
+    sweep('GPU shared, alternating inputs        ', True)
+for p in ps:
+    p.wait()

@@ -93,6 +93,29 @@ template <bool POW2> __device__ inline void hg_sample_level(const float2* __rest
     *r0_ = r0; *r1_ = r1;
 }
 
+#ifdef HG_CELL_MAJOR_PROBE
+// TIMING PROBE ONLY (tools/build_variant.sh cellmajor xr_encode.hip -DHG_CELL_MAJOR_PROBE; results are NOT the encoding): what would the
+// dense levels cost if the 8 corners of a cell sat side by side (one 64-B chunk = one line instead of four)?  The chunk is read from
+// inside the table allocation at (8 off[l] + 8 cell) mod (entries - 8): the footprint and the access pattern of a real cell-major
+// copy (21 MB over levels 0-4 of the Lego geometry), without building one.  profiles/r06_lookup_cell_major_probe.txt
+__device__ inline void hg_sample_level_cm_probe(const float2* __restrict__ table_all, uint32_t total, uint32_t off_l, const float* xp, uint32_t x_cs,
+                                                float scale, uint32_t res, float* r0_, float* r1_) {
+    float w[3]; uint32_t g[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { const float p = xp[(size_t)d * x_cs] * scale + 0.5f; const float f = floorf(p); g[d] = (uint32_t)(int)f; w[d] = p - f; }
+    const uint32_t cell = g[0] + g[1] * res + g[2] * res * res;
+    const float4* __restrict__ q = reinterpret_cast<const float4*>(table_all + ((8u * off_l + 8u * cell) % (total - 8u) & ~1u));
+    float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float4 v = q[p];
+        const float wyz = ((p & 1) ? w[1] : 1.f - w[1]) * ((p >> 1) ? w[2] : 1.f - w[2]);
+        r0 += wyz * ((1.f - w[0]) * v.x + w[0] * v.z); r1 += wyz * ((1.f - w[0]) * v.y + w[0] * v.w);
+    }
+    *r0_ = r0; *r1_ = r1;
+}
+#endif
+
 // Order 5: an explicit map.  XCD k (= blockIdx % 8, an observation used for speed only) walks its list of segments
 // (level, sample blocks [lo, hi)) in order -- whole levels first, then its share of the levels that are split.  The map is
 // built on the host from one measured cost per level (hg_build_map): every XCD gets the same cost, the eight most expensive
@@ -131,6 +154,9 @@ __global__ __launch_bounds__(EN_BLOCK) void k_hashgrid_fwd(GridMeta gm, XcdMap x
     float r0, r1;
     const bool pow2 = hashed && (hsize & (hsize - 1u)) == 0u;           // uniform for the block
     if (pow2) hg_sample_level<true>(tab, xp, x_cs, scale, res, hsize, hashed, &r0, &r1);
+#ifdef HG_CELL_MAJOR_PROBE
+    else if (!hashed) hg_sample_level_cm_probe((const float2*)table, gm.off[gm.n_levels], gm.off[l], xp, x_cs, scale, res, &r0, &r1);
+#endif
     else hg_sample_level<false>(tab, xp, x_cs, scale, res, hsize, hashed, &r0, &r1);
     enc_t[(size_t)(2 * l) * ld + i] = r0;
     enc_t[(size_t)(2 * l + 1) * ld + i] = r1;

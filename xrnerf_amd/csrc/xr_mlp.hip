@@ -1748,7 +1748,10 @@ __device__ inline void load_weights_h2(_Float16* __restrict__ wf, int ps, const 
     store_layer_h2<NH, 1>(v1, wf, ps, false, mx);
     if constexpr (NH >= 2) store_layer_h2<NH, 2>(v2, wf, ps, false, mx);
 }
-template <bool WITH_COLOR>
+// TRACK: with the range count (a launch that was handed a range word); without it the saturation alone (one v_med3 per value, in the
+// ReLU's place: free) -- the max chain behind the count is 0.5 VALU instruction per operand on a kernel that is bound by exactly those
+// (27.5 -> 31.9 us at 2^18 rows), so the training loop's normal iterations run untracked and the refresh iterations tracked.
+template <bool WITH_COLOR, bool TRACK>
 __global__ __launch_bounds__(BX_THREADS, 2) void k_nerf_mlp_fwd_h2(const float* __restrict__ enc_t, uint32_t ld,
                                                                     const float* __restrict__ dirs, uint32_t dir_stride,
                                                                     uint32_t n, const uint32_t* __restrict__ n_dev,
@@ -1785,13 +1788,13 @@ __global__ __launch_bounds__(BX_THREADS, 2) void k_nerf_mlp_fwd_h2(const float* 
     __syncthreads();
     for (; tile < n_tiles; tile += stride) {
         const uint32_t s = tile * 32 + col;
-        H2Tile xin[1] = {to_h2<true, true>(x, H2_IN_SCALE, mx)};
+        H2Tile xin[1] = {to_h2<true, TRACK>(x, H2_IN_SCALE, mx)};
         const float dx = d3[0], dy = d3[1], dz = d3[2];
         if (tile + stride < n_tiles) fetch(tile + stride, x, d3);   // next tile's loads under this tile's MFMAs
         f32x16 h[2], dout[1];
         layer_fwd_h2<1, 2>(wd + HD::f_off(0), PD, xin, h, col, hi);
-        h2_relu_sat<true>(h[0], 1.0f / H2_IN_SCALE, mx);            // relu + the input scale taken out again (exact) + the saturation
-        h2_relu_sat<true>(h[1], 1.0f / H2_IN_SCALE, mx);
+        h2_relu_sat<TRACK>(h[0], 1.0f / H2_IN_SCALE, mx);            // relu + the input scale taken out again (exact) + the saturation
+        h2_relu_sat<TRACK>(h[1], 1.0f / H2_IN_SCALE, mx);
         H2Tile hh[2] = {to_h2_act(h[0]), to_h2_act(h[1])};
         layer_fwd_h2<2, 1>(wd + HD::f_off(1), PD, hh, dout, col, hi);
         float4 o = make_float4(0.f, 0.f, 0.f, dout[0][0]);
@@ -1799,12 +1802,12 @@ __global__ __launch_bounds__(BX_THREADS, 2) void k_nerf_mlp_fwd_h2(const float* 
             f32x16 cin, cout[1];
             const float dd[3] = {dx, dy, dz};
             build_color_in(dout[0], dd, 3, 0, pad_value, cin, hi);
-            H2Tile ci[1] = {to_h2<true, true>(cin, 1.0f, mx)};
+            H2Tile ci[1] = {to_h2<true, TRACK>(cin, 1.0f, mx)};
             layer_fwd_h2<1, 2>(wc + HC::f_off(0), PC, ci, h, col, hi);
-            h2_relu_sat<true>(h[0], 1.0f, mx); h2_relu_sat<true>(h[1], 1.0f, mx);
+            h2_relu_sat<TRACK>(h[0], 1.0f, mx); h2_relu_sat<TRACK>(h[1], 1.0f, mx);
             hh[0] = to_h2_act(h[0]); hh[1] = to_h2_act(h[1]);
             layer_fwd_h2<2, 2>(wc + HC::f_off(1), PC, hh, h, col, hi);
-            h2_relu_sat<true>(h[0], 1.0f, mx); h2_relu_sat<true>(h[1], 1.0f, mx);
+            h2_relu_sat<TRACK>(h[0], 1.0f, mx); h2_relu_sat<TRACK>(h[1], 1.0f, mx);
             hh[0] = to_h2_act(h[0]); hh[1] = to_h2_act(h[1]);
             layer_fwd_h2<2, 1>(wc + HC::f_off(2), PC, hh, cout, col, hi);
             o.x = cout[0][0]; o.y = cout[0][1]; o.z = cout[0][2];
@@ -1814,7 +1817,7 @@ __global__ __launch_bounds__(BX_THREADS, 2) void k_nerf_mlp_fwd_h2(const float* 
             else raw[s] = o;
         }
     }
-    h2_range_report(mx, range_word);
+    if (TRACK) h2_range_report(mx, range_word);
 }
 
 // Measured and dropped: handing the tiles out dynamically (a ticket counter, because the next batch's ray march co-runs on
@@ -1979,7 +1982,7 @@ __device__ __forceinline__ void mask_tile_bits(f32x16& g, uint32_t m) {
     for (int r = 0; r < 16; ++r) g[r] = ((m >> r) & 1u) ? g[r] : 0.f;
 }
 
-template <bool WITH_COLOR>
+template <bool WITH_COLOR, bool TRACK>
 __global__ __launch_bounds__(DP_FW * 64, 1) void k_nerf_mlp_fwd_deep(const float* __restrict__ enc_t, uint32_t ld,
                                                                      const float* __restrict__ dirs, uint32_t dir_stride,
                                                                      uint32_t n, const uint32_t* __restrict__ n_dev,
@@ -2030,13 +2033,13 @@ __global__ __launch_bounds__(DP_FW * 64, 1) void k_nerf_mlp_fwd_deep(const float
             if (l == 0) {
                 // (the hash-grid features enter scaled by 2^4, the accumulators are scaled back: see k_nerf_mlp_fwd_h2)
                 const float sc_in = net == 0 ? H2_IN_SCALE : 1.0f, sc_out = net == 0 ? 1.0f / H2_IN_SCALE : 1.0f;
-                const H2Tile xin[1] = {to_h2<true, true>(x, sc_in, mx)};
+                const H2Tile xin[1] = {to_h2<true, TRACK>(x, sc_in, mx)};
                 layer_fwd_h2<1, 2>(wf, DP_PS, xin, h, col, hi);
-                h2_relu_sat<true>(h[0], sc_out, mx); h2_relu_sat<true>(h[1], sc_out, mx);
+                h2_relu_sat<TRACK>(h[0], sc_out, mx); h2_relu_sat<TRACK>(h[1], sc_out, mx);
             } else if (l < nh) {
                 const H2Tile hh[2] = {to_h2_act(h[0]), to_h2_act(h[1])};
                 layer_fwd_h2<2, 2>(wf, DP_PS, hh, h, col, hi);
-                h2_relu_sat<true>(h[0], 1.0f, mx); h2_relu_sat<true>(h[1], 1.0f, mx);
+                h2_relu_sat<TRACK>(h[0], 1.0f, mx); h2_relu_sat<TRACK>(h[1], 1.0f, mx);
             } else {
                 const H2Tile hh[2] = {to_h2_act(h[0]), to_h2_act(h[1])};
                 f32x16 dout[1];
@@ -2054,7 +2057,7 @@ __global__ __launch_bounds__(DP_FW * 64, 1) void k_nerf_mlp_fwd_deep(const float
             else raw[s] = o;
         }
     }
-    h2_range_report(mx, range_word);
+    if (TRACK) h2_range_report(mx, range_word);
 }
 
 template <int TO>
@@ -2335,13 +2338,13 @@ static int launch_fwd(const float* enc_t, uint32_t ld, const float* dirs, uint32
 
 // hipFuncSetAttribute is a driver call (~3-5 us of host time): once per kernel and size, not once per launch
 static int mlp_set_lds(const void* kernel, size_t lds) {
-    static const void* seen_k[16];
-    static size_t seen_b[16];
+    static const void* seen_k[32];
+    static size_t seen_b[32];
     static int n_seen = 0;
     for (int i = 0; i < n_seen; ++i) if (seen_k[i] == kernel && seen_b[i] >= lds) return XR_OK;
     if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XR_EHIP;
     for (int i = 0; i < n_seen; ++i) if (seen_k[i] == kernel) { seen_b[i] = lds; return XR_OK; }
-    if (n_seen < 16) { seen_k[n_seen] = kernel; seen_b[n_seen] = lds; ++n_seen; }
+    if (n_seen < 32) { seen_k[n_seen] = kernel; seen_b[n_seen] = lds; ++n_seen; }
     return XR_OK;
 }
 // any depth: the streamed kernel (fp32 results on the bf16 matrix cores, 3-way operand split)
@@ -2351,15 +2354,11 @@ static int launch_fwd_deep(const float* enc_t, uint32_t ld, const float* dirs, u
     const int cus = xr_device_cus() > 0 ? xr_device_cus() : 256;
     const uint32_t grid = min(xr_div_up(n, DP_FW * 32), (uint32_t)cus);
     const size_t lds = (size_t)2 * 2 * DP_PS * sizeof(__bf16);
-    if (dirs) {
-        if (mlp_set_lds((const void*)k_nerf_mlp_fwd_deep<true>, lds) != XR_OK) { xr_set_error("hipFuncSetAttribute failed"); return XR_EHIP; }
-        hipLaunchKernelGGL(k_nerf_mlp_fwd_deep<true>, dim3(grid), dim3(DP_FW * 64), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev, rows, wd, wc,
-                           nhd, nhc, pad, (float4*)raw, (const int32_t*)nullptr, (float*)nullptr, g_range_word);
-    } else {
-        if (mlp_set_lds((const void*)k_nerf_mlp_fwd_deep<false>, lds) != XR_OK) { xr_set_error("hipFuncSetAttribute failed"); return XR_EHIP; }
-        hipLaunchKernelGGL(k_nerf_mlp_fwd_deep<false>, dim3(grid), dim3(DP_FW * 64), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev, rows, wd, wc,
-                           nhd, nhc, pad, (float4*)raw, g_fwd_splat_idx, g_fwd_splat_grid, g_range_word);
-    }
+    auto k = dirs ? (g_range_word ? k_nerf_mlp_fwd_deep<true, true> : k_nerf_mlp_fwd_deep<true, false>)
+                  : (g_range_word ? k_nerf_mlp_fwd_deep<false, true> : k_nerf_mlp_fwd_deep<false, false>);
+    if (mlp_set_lds((const void*)k, lds) != XR_OK) { xr_set_error("hipFuncSetAttribute failed"); return XR_EHIP; }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(DP_FW * 64), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev, rows, wd, wc, nhd, nhc, pad, (float4*)raw,
+                       dirs ? (const int32_t*)nullptr : g_fwd_splat_idx, dirs ? (float*)nullptr : g_fwd_splat_grid, g_range_word);
     XR_LAUNCH_CHECK();
     return XR_OK;
 }
@@ -2660,16 +2659,12 @@ static int mlp_fwd_f16x2(const float* enc_t, uint32_t ld, const float* dirs, uin
         return launch_fwd_deep(enc_t, ld, dirs, dir_stride, n, n_dev, rows, w_density, w_color, n_hidden_density, n_hidden_color, pad_value, raw, stream);
     const int cus = xr_device_cus() > 0 ? xr_device_cus() : 256;
     const uint32_t grid2 = min(xr_div_up((n + 31) / 32, BX_WAVES), 2u * (uint32_t)cus);   // 56 KiB of weights: two workgroups per CU
-    if (dirs) {
-        const size_t lds = (size_t)2 * (HShape<1>::f_halves + HShape<2>::f_halves) * 2;
-        if (mlp_set_lds((const void*)k_nerf_mlp_fwd_h2<true>, lds) != XR_OK) { xr_set_error("hipFuncSetAttribute failed"); return XR_EHIP; }
-        hipLaunchKernelGGL(k_nerf_mlp_fwd_h2<true>, dim3(grid2), dim3(BX_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev,
-                           rows, w_density, w_color, pad_value, (float4*)raw, (const int32_t*)nullptr, (float*)nullptr, g_range_word);
-    } else {
-        const size_t lds = (size_t)2 * HShape<1>::f_halves * 2;
-        hipLaunchKernelGGL(k_nerf_mlp_fwd_h2<false>, dim3(grid2), dim3(BX_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev,
-                           rows, w_density, w_color, pad_value, (float4*)raw, g_fwd_splat_idx, g_fwd_splat_grid, g_range_word);
-    }
+    const size_t lds = (size_t)2 * (HShape<1>::f_halves + (dirs ? HShape<2>::f_halves : 0)) * 2;
+    auto k = dirs ? (g_range_word ? k_nerf_mlp_fwd_h2<true, true> : k_nerf_mlp_fwd_h2<true, false>)
+                  : (g_range_word ? k_nerf_mlp_fwd_h2<false, true> : k_nerf_mlp_fwd_h2<false, false>);
+    if (mlp_set_lds((const void*)k, lds) != XR_OK) { xr_set_error("hipFuncSetAttribute failed"); return XR_EHIP; }
+    hipLaunchKernelGGL(k, dim3(grid2), dim3(BX_THREADS), lds, stream, enc_t, ld, dirs, dir_stride, n, n_dev, rows, w_density, w_color, pad_value, (float4*)raw,
+                       dirs ? (const int32_t*)nullptr : g_fwd_splat_idx, dirs ? (float*)nullptr : g_fwd_splat_grid, g_range_word);
     XR_LAUNCH_CHECK();
     return XR_OK;
 }

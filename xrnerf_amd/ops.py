@@ -234,10 +234,13 @@ def _ensure_helper(device):
 # range in the caller's word: include/xrnerf_mi355.h).  One uint32 word per device; the library's slot is per host thread.
 _range_words = {}
 _range_current = {}
+_range_off = set()              # host threads whose launches run untracked right now (mlp_range_tracking)
 
 
 def mlp_range_word(device):
-    """this device's range word (a [1] int32 tensor, allocated once), handed to the library for the calling thread"""
+    """this device's range word (a [1] int32 tensor, allocated once), handed to the library for the calling thread -- unless the thread
+    has tracking switched off (mlp_range_tracking), in which case the library is told `none`: the forwards then run without the max
+    chain behind the count (4 us of a 32-us launch), the saturation itself stays"""
     import threading
     if device.type != 'cuda':
         return None
@@ -245,10 +248,24 @@ def mlp_range_word(device):
     if w is None:
         w = _range_words[str(device)] = torch.zeros((1,), dtype=torch.int32, device=device)
     tid = threading.get_ident()
-    if _range_current.get(tid) != str(device):
-        _lib.check(_lib.load().xr_set_mlp_range_word(C.c_void_p(w.data_ptr())), 'xr_set_mlp_range_word')
-        _range_current[tid] = str(device)
+    want = None if tid in _range_off else str(device)
+    if _range_current.get(tid, 0) != want:
+        _lib.check(_lib.load().xr_set_mlp_range_word(C.c_void_p(w.data_ptr()) if want is not None else None), 'xr_set_mlp_range_word')
+        _range_current[tid] = want
     return w
+
+
+def mlp_range_tracking(device, on):
+    """Switch the range count of the calling thread's XR_MLP_F16X2 forwards on (default) or off.  The trainer runs the iterations
+    between two grid refreshes untracked (train._NativeLoop) and everything else -- the refresh iterations with their 2^20-point
+    density queries, frames, direct calls -- tracked: one iteration in 16 looks, which is where growing weights or features show up"""
+    import threading
+    tid = threading.get_ident()
+    if on:
+        _range_off.discard(tid)
+    else:
+        _range_off.add(tid)
+    mlp_range_word(device)
 
 
 def mlp_range_events(device, reset=False):

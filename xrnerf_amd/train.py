@@ -493,7 +493,6 @@ class _NativeLoop:
         if not ops.hashgrid_bwd_adam_supported(n_rows, meta):
             raise _lib.XrError('the fused table update has no non-atomic scatter path at this row capacity')
         ops._ensure_helper(dev)
-        ops.mlp_range_word(dev)
         D = _lib.LoopDesc()
         vp = lambda t: t.data_ptr() if t is not None else None
         D.table, D.w_density, D.w_color = vp(table), vp(wd), vp(wc)
@@ -599,9 +598,13 @@ class _NativeLoop:
         ops.LIVE_STATS = live_stats
         sets[0].live = sets[1].live = (live_list, live_stats) if os.environ.get('XR_MLP_LIVE') != '0' else None
         sampler._wait_march(pfs[0])                       # the compute stream behind the window's marches: once per window
+        ops.mlp_range_tracking(dev, False)                # the iterations between two refreshes run the forward without its range count
         t_enq = time.perf_counter()
-        rc = L.xr_ngp_loop_run(C.byref(D), C.byref(S), k, n_rays, lr, mom, stage.encode() if stage else None, tarr, iarr)
-        self.enqueue_s += time.perf_counter() - t_enq                    # host time inside the native call (tools/hosttime2.py)
+        try:
+            rc = L.xr_ngp_loop_run(C.byref(D), C.byref(S), k, n_rays, lr, mom, stage.encode() if stage else None, tarr, iarr)
+        finally:
+            self.enqueue_s += time.perf_counter() - t_enq                # host time inside the native call (tools/hosttime2.py)
+            ops.mlp_range_tracking(dev, True)
         self.enqueued += k
         if rc != 0:
             if self.exchange is not None and self.exchange.error is not None:
