@@ -185,6 +185,13 @@ int xr_ema_grid_samples(const float* density_grid_tmp, uint32_t n_elements, floa
 size_t xr_update_bitfield_workspace_bytes(void);
 int xr_update_bitfield(const float* density_grid, float* density_grid_mean, uint8_t* bitfield, void* workspace,
                        size_t workspace_bytes, void* stream);
+/* K9 + K10 + K11 of one grid refresh as THREE launches (the refresh tail of NGPGridSampler.update_density_grid,
+ * ngp_grid_sampler.py:150-174): xr_ema_grid_samples over the first n_elements cells followed by xr_update_bitfield -- the same density
+ * grid, mean and bitfield bit for bit (K10's partial sums are taken where K9 walks cascade 0, every workgroup of the bits kernel folds
+ * the partials itself, and the seven dependent max-pool launches become one: csrc/xr_grid.hip).  Same workspace as
+ * xr_update_bitfield (which runs the last two of these launches behind K10's partial sums). */
+int xr_ema_update_bitfield(const float* density_grid_tmp, uint32_t n_elements, float decay, float* density_grid,
+                           float* density_grid_mean, uint8_t* bitfield, void* workspace, size_t workspace_bytes, void* stream);
 /* K11 alone with the mean supplied (device pointer) -- for bit-exact tests against the reference */
 int xr_bitfield_from_mean(const float* density_grid, const float* density_grid_mean, uint8_t* bitfield,
                           void* stream);

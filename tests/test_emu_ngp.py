@@ -80,6 +80,13 @@ def test_grid_upkeep_raygen_loss_adam_on_the_host(O, lego, edev):
     T.test_adam_multi_grad_scale_equals_scaling_pass_then_adam(O, edev)
 
 
+def test_refresh_tail_three_launches_on_the_host(O, lego, edev):
+    """K9 + K10 + K11 as three launches (xr_ema_update_bitfield) against the two separate entry points and the oracle, the kernels'
+    own sources on the host"""
+    import test_gpu_raymarch as T
+    T.test_refresh_tail_in_three_launches(O, lego, edev, 8)
+
+
 @pytest.mark.parametrize('n', [1, 31, 4096])
 def test_hashgrid_gather_and_scatter_on_the_host(O, edev, n):
     import test_gpu_tcnn as T

@@ -259,6 +259,47 @@ def test_k8_k9_k10_k11(O, lego, dev):
     assert float(mean2[0]) == float(mean[0]) and torch.equal(bf, bf2)
 
 
+@pytest.mark.parametrize('n_casc', [1, 8, 3])
+def test_refresh_tail_in_three_launches(O, lego, dev, n_casc):
+    """xr_ema_update_bitfield (K9 + K10's partial sums in one pass, the bits kernel folding the partials itself and emitting every
+    cascade's own pool bytes from a wave ballot, the seven dependent max-pool launches as one chain kernel) == xr_ema_grid_samples
+    followed by xr_update_bitfield: grid, mean and bitfield bit for bit -- and the oracle's K9 / K11 on the same inputs.  Densities in
+    every cascade, so that what is pooled into a cascade from below meets bits of its own."""
+    from xrnerf_amd import ops
+    rng = np.random.default_rng(90 + n_casc)
+    cells = 128 ** 3
+    grid = (lego['grid'] * 0.02).astype(np.float32)
+    grid[rng.uniform(0, 1, grid.shape) < 0.05] = -1.0
+    for c in range(1, 8):                                   # sparse own bits in the outer cascades, some inside the pooled centre
+        k = rng.integers(0, cells, 3000)
+        grid[c * cells + k] = rng.uniform(0.0, 0.05, k.size).astype(np.float32)
+    n_used = n_casc * cells
+    tmp = np.zeros_like(grid)
+    k = rng.integers(0, n_used, 400000)
+    tmp[k] = rng.uniform(0, 0.2, k.size).astype(np.float32)
+    # the two entry points of the reference's order
+    g_a = T(grid.copy(), dev)                               # (copies: on the host build T() aliases the numpy array)
+    ops.ema_grid_samples(T(tmp.copy(), dev), n_used, 0.95, g_a)
+    mean_a = torch.zeros(16384, dtype=torch.float32, device=dev); bf_a = torch.full((cells,), 0x55, dtype=torch.uint8, device=dev)
+    ops.update_bitfield(g_a, mean_a, bf_a)
+    # one entry point, three launches
+    g_b = T(grid.copy(), dev)
+    mean_b = torch.zeros_like(mean_a); bf_b = torch.full((cells,), 0xaa, dtype=torch.uint8, device=dev)
+    ops.ema_update_bitfield(T(tmp.copy(), dev), n_used, 0.95, g_b, mean_b, bf_b)
+    assert np.array_equal(bits(g_b.cpu().numpy()), bits(g_a.cpu().numpy()))
+    assert float(mean_b[0]) == float(mean_a[0])
+    assert torch.equal(bf_b, bf_a)
+    # against the oracle: K9 on the cells in use, K11 at the same mean
+    ref_grid = grid.copy()
+    ref_grid[:n_used] = O.ema(tmp[:n_used].copy(), grid[:n_used].copy())
+    assert np.array_equal(bits(g_b.cpu().numpy()), bits(ref_grid))
+    exact = np.maximum(ref_grid[:cells].astype(np.float64), 0).sum() / cells
+    assert abs(float(mean_b[0]) - exact) <= 1e-5 * exact
+    ref_bf = O.bitfield_given_mean(ref_grid, np.float32(float(mean_b[0])))
+    assert np.array_equal(bf_b.cpu().numpy(), ref_bf)
+    assert ref_bf[cells // 8:].any() and ref_bf[7 * cells // 8:].any()          # something did reach the outermost cascade
+
+
 def test_gen_rays_huber_adam(O, lego, dev):
     from xrnerf_amd import ops, synthetic as S
     pose = lego['poses'][3]

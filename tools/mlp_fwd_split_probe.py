@@ -77,3 +77,7 @@ for mode in ('mfma', 'bf16x3', 'f16x2'):
     print('%-7s forward at 2^18 rows: %.1f us   density only: %.1f us' % (mode, 1e3 * timeit(lambda: ops.nerf_mlp_fwd(enc, dirs, n, twd, twc, 1, 2, raw=raw)),
           1e3 * timeit(lambda: ops.nerf_mlp_fwd(enc, None, n, twd, None, 1, 2, raw=raw))))
 ops.set_f32_forward('f16x2')
+ops.mlp_range_tracking(dev, False)        # the training loop's normal iterations: saturation without the count
+print('f16x2 without the range count (xr_set_mlp_range_word(NULL)): forward at 2^18 rows: %.1f us   density only: %.1f us' % (
+    1e3 * timeit(lambda: ops.nerf_mlp_fwd(enc, dirs, n, twd, twc, 1, 2, raw=raw)), 1e3 * timeit(lambda: ops.nerf_mlp_fwd(enc, None, n, twd, None, 1, 2, raw=raw))))
+ops.mlp_range_tracking(dev, True)

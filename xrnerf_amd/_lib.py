@@ -99,6 +99,7 @@ SIGNATURES = {
     'xr_ema_grid_samples': (_i32, [_vp, _u32, _f, _vp, _vp]),
     'xr_update_bitfield_workspace_bytes': (_sz, []),
     'xr_update_bitfield': (_i32, [_vp, _vp, _vp, _vp, _sz, _vp]),
+    'xr_ema_update_bitfield': (_i32, [_vp, _u32, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     'xr_bitfield_from_mean': (_i32, [_vp, _vp, _vp, _vp]),
     'xr_hashgrid_meta': (None, [_i32, _i32, _i32, _d, _vp, _vp, _vp]),
     'xr_hashgrid_fwd': (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _u32, _vp]),

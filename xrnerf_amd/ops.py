@@ -630,6 +630,15 @@ def update_bitfield(grid, mean, bitfield):
     return bitfield, mean
 
 
+def ema_update_bitfield(grid_tmp, n_elements, decay, grid, mean, bitfield):
+    """K9 + K10 + K11 of one refresh in three launches (xr_ema_update_bitfield) == ema_grid_samples then update_bitfield, bit for bit"""
+    L = _lib.load()
+    ws = _ws(grid.device, L.xr_update_bitfield_workspace_bytes(), 'k10')
+    _lib.check(L.xr_ema_update_bitfield(_ptr(grid_tmp), n_elements, decay, _ptr(grid), _ptr(mean), _ptr(bitfield), _ptr(ws), ws.numel(), _stream()),
+               'xr_ema_update_bitfield')
+    return grid
+
+
 def bitfield_from_mean(grid, mean, bitfield):
     _lib.check(_lib.load().xr_bitfield_from_mean(_ptr(grid), _ptr(mean), _ptr(bitfield), _stream()),
                'xr_bitfield_from_mean')

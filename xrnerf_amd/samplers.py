@@ -179,9 +179,10 @@ class NGPGridSampler(_FastAttr, nn.Module):
                     density = mlp.run_density(positions[i:i + self.update_block_size])   # [m,1] view, row stride 4
                     ops.splat_grid_samples(density, indices[i:i + self.update_block_size], density.stride(0),
                                            density.shape[0], self.density_grid_tmp)
-        ops.ema_grid_samples(self.density_grid_tmp, n_used, self.ema_grid_decay, self.density_grid)
+        # K9, K10, K11 (ngp_grid_sampler.py:150-174: ema_grid_samples_nerf, then update_bitfield) as three launches instead of eleven
+        ops.ema_update_bitfield(self.density_grid_tmp, n_used, self.ema_grid_decay, self.density_grid, self.density_grid_mean,
+                                self.density_grid_bitfield)
         self.density_grid_ema_step += 1
-        ops.update_bitfield(self.density_grid, self.density_grid_mean, self.density_grid_bitfield)
         if self._streams():
             if getattr(self, '_bitfield_event', None) is None:
                 self._bitfield_event = torch.cuda.Event()        # ONE event, recorded again at every refresh (waits capture the record
