@@ -28,7 +28,13 @@ tr = Trainer(dev, n_img=3, H=128, W=128, world_size=world, rank=rank, ema=False,
 assert tr.net._fused_ok() and tr.net.grad_sync is not None
 sig = []
 bufs_seen, mem = set(), []
+render_mid = os.environ.get('DP_RENDER_MID') == '1'
 for it in range(18):
+    if render_mid and it == 6 and rank == 0:
+        # a frame on ONE rank in the middle of a window: its sampler takes back the marches issued ahead, so this rank has no native
+        # span for the next iteration -- the path choice is collective (Trainer._agreed_span), the other rank follows it
+        from xrnerf_amd.train import render_frame
+        render_frame(tr.net, tr.data.poses[0], 32, 32, tr.data.focal * 32.0 / 128.0)
     if it == 9 and native:
         tr.run(4); continue_from = 13            # a window of several iterations in one native call
     elif it in (10, 11, 12) and native:
@@ -54,7 +60,8 @@ assert mem[1] - mem[0] < (8 << 20), mem
 assert tr.iter == 18
 if native:
     # the iterations between the refreshes went through xr_ngp_loop_run with the exchange hooks (callbacks into torch.distributed here)
-    assert tr._loop is not None and tr._loop.enqueued == 16 and tr._loop.exchange is not None, (tr._loop and tr._loop.enqueued)
+    assert tr._loop is not None and tr._loop.exchange is not None
+    assert (1 <= tr._loop.enqueued < 16) if render_mid else tr._loop.enqueued == 16, tr._loop.enqueued
 else:
     assert tr._loop is None
 print('SIG', rank, ' '.join(a + b + c for a, b, c, _ in sig), flush=True)
@@ -72,7 +79,7 @@ dist.barrier(); dist.destroy_process_group()
 '''
 
 
-def _two_ranks(tmp_path, dp_mode, native):
+def _two_ranks(tmp_path, dp_mode, native, render_mid=False):
     import socket
     script = tmp_path / ('w%d.py' % native)
     script.write_text(WORKER % ROOT)
@@ -82,7 +89,7 @@ def _two_ranks(tmp_path, dp_mode, native):
             sk.bind(('127.0.0.1', 0))
             port = sk.getsockname()[1]
         env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE='2', HSA_ENABLE_IPC_MODE_LEGACY='0', XRNERF_DP=dp_mode,
-                   DP_NATIVE='1' if native else '0')
+                   DP_NATIVE='1' if native else '0', DP_RENDER_MID='1' if render_mid else '0')
         procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
         outs = [p.communicate(timeout=600)[0].decode() for p in procs]
@@ -112,6 +119,14 @@ def test_two_ranks_stay_identical_replicas(tmp_path, dp_mode):
             return
         print('attempt %d: the two jobs differ' % attempt)
     assert nat[0] == per[0] and nat[1] == per[1]
+
+
+def test_a_frame_on_one_rank_in_the_middle_of_a_window_keeps_both_ranks_on_one_path(tmp_path):
+    """rank 0 renders a frame between iterations 5 and 6: its marches are rewound, it cannot run iteration 6 natively -- and rank 1,
+    which could, must not (the native loop and the per-iteration path exchange gradients through different communicators).  The span
+    is agreed (Trainer._agreed_span): both take the per-iteration path for that iteration, both return to the native loop, and the
+    replicas are identical at every checkpoint (the worker's own assertions)."""
+    _two_ranks(tmp_path, 'allreduce', True, render_mid=True)
 
 
 NCCL_WORKER = r'''

@@ -272,20 +272,40 @@ class Trainer:
         # ray table); anything else keeps the per-iteration path.
         self.native_loop = opts['native_loop']
         self._loop = None
+        # data parallel: which path an iteration takes is a COLLECTIVE decision (_agreed_span): the native loop exchanges gradients through
+        # its own communicator, the per-iteration path through torch.distributed's -- a rank that took the other path than its peers (a
+        # frame rendered on rank 0 only rewinds that rank's marches; an error fallback) would pair its collectives with the wrong
+        # ones.  The agreement runs over a host-side (gloo) group so that it never drains the GPU.
+        self._ctrl_group = None
+        if world_size > 1:
+            import torch.distributed as tdist
+            if tdist.is_available() and tdist.is_initialized():
+                self._ctrl_group = tdist.group.WORLD if tdist.get_backend() == 'gloo' else tdist.new_group(backend='gloo')
         self._queue = []               # [(iteration, the sampler's queued entry)] marched ahead, in order (entry.batch(): its batch dict)
         self._one = None
 
     def step(self):
-        if self._native_span(1):
+        if self._agreed_span(self._native_span(1)):
             return self._run_native(1)
         return self._step_py()
+
+    def _agreed_span(self, n):
+        """data parallel: the smallest span any rank can run natively (0: every rank takes the per-iteration path for this iteration).
+        Refresh iterations are per-iteration on every rank by construction (no message); everything else is agreed with one 8-byte
+        host-side all-reduce -- once per refresh window in the steady state."""
+        if self._ctrl_group is None or self.iter % self.net.sampler.update_grid_freq == 0:
+            return n
+        import torch.distributed as tdist
+        t = torch.tensor([int(n)], dtype=torch.int64)
+        tdist.all_reduce(t, op=tdist.ReduceOp.MIN, group=self._ctrl_group)
+        return int(t[0])
 
     def run(self, k, iter_events=None):
         """k iterations.  `iter_events` (k + 1 ops._CEvent timing events, optional): recorded on the compute stream in front of every
         iteration and behind the last (bench.py's per-iteration device times)."""
         out, done = None, 0
         while done < k:
-            n = self._native_span(k - done)
+            n = self._agreed_span(self._native_span(k - done))
             if n:
                 out = self._run_native(n, iter_events[done:done + n + 1] if iter_events is not None else None)
             else:
