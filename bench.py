@@ -629,6 +629,14 @@ def main():
         _respawn_under_torchrun(args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: there is no CPU path')
+    # N > 1 over RCCL: keep what RCCL says about the rings / trees, channels and protocols it chose (its INFO log of rank 0, digested into
+    # the line's `collective.rccl_log` -- whether the 48.8-MB all-reduce runs as a ring or direct decides the 8-GPU number: dist.comm_model)
+    rccl_log = None
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1 and os.environ.get('XRNERF_DIST_BACKEND', 'nccl') == 'nccl' and os.environ.get('RANK', '0') == '0':
+        rccl_log = os.path.join(os.environ.get('TMPDIR', '/tmp'), 'xrnerf_rccl_rank0_%d.log' % os.getpid())
+        os.environ.setdefault('NCCL_DEBUG', 'INFO')
+        os.environ.setdefault('NCCL_DEBUG_SUBSYS', 'INIT,GRAPH,TUNING')
+        os.environ.setdefault('NCCL_DEBUG_FILE', rccl_log)
     # XRNERF_DIST_BACKEND=gloo + XRNERF_SHARE_GPU=1: protocol test of the N>1 path on a single-GPU box
     rank, local, world = xdist.init_from_env(os.environ.get('XRNERF_DIST_BACKEND', 'nccl'))
     if os.environ.get('XRNERF_SHARE_GPU') == '1':
@@ -798,6 +806,24 @@ def main():
             out['arithmetic'] = ('XR_MLP_BWD_DW=%s: %.0f flop/sample on the fp32 MFMA (157.3 TFLOP/s), %.0f on the 16-bit matrix cores as 3 products '
                                  'each (2-way operand split, 2500 TFLOP/s dense); peak = the rate of this mix' % (arith, on_f32, on_b16))
             out['frac_of_fp32_mfma_peak'] = achieved / MFMA_F32_PEAK_TFLOPS
+        if name == 'xr_hashgrid_fwd' and launches:
+            # The lookup against the roofline that binds it.  It is not HBM: the table slices are L2-resident (one XCD per level) and every
+            # (y, z) corner pair of a (sample, level) is one random 16-byte access = one 128-byte line pulled from the L2 into the CU's L1
+            # (the two x-neighbours share the line; an odd x issues two 8-byte loads to it).  tools/gather_probe.hip: random 16-byte gathers
+            # from L2-resident slices of 0.5 .. 4 MiB retire at 263 G accesses/s chip-wide (profiles/r02_gather_probe.txt; 970 G/s only
+            # when the slice fits the 16-KiB L1), whatever their width -- the 64 B/clk/CU L2 -> L1 path moving whole lines.
+            n_levels = tr.net.mlp.embedder_pos.meta.n_levels
+            req = units / launches * n_levels * 4.0
+            rate = req / (total_ms * 1e-3 / launches)
+            out['requests_per_launch'] = req
+            out['request_rate'] = rate
+            out['request_ceiling'] = 263e9
+            out['request_frac'] = rate / 263e9
+            out['request_note'] = ('requests = samples x %d levels x 4 corner pairs (one 128-B line each from the XCD-local L2); ceiling = random L2-resident '
+                                   'gathers, tools/gather_probe.hip (263 G/s).  At that ceiling the launch moves its 1164 algorithmic bytes per sample at %.2f of '
+                                   'the HBM peak: the 0.60 of north_star is above what the L2 -> L1 path delivers for this access pattern '
+                                   '(profiles/r06_lookup_cell_major_probe.txt: the one structural cut of the request count that was on the table, measured)'
+                                   % (n_levels, 263e9 / (n_levels * 4.0) * per_unit / (HBM_PEAK_GBS * 1e9)))
         if halves:
             out['note'] = 'entry point called twice per step (levels 8..15, then 0..7, each handed to the all-reduce): figures are per step'
         if fused_adam:
@@ -950,6 +976,13 @@ def main():
                                'bytes_on_wire_per_rank_total': getattr(sync, 'bytes_on_wire', None),
                                'bytes_reduced_per_rank_total': getattr(sync, 'bytes_reduced', None),
                                'bytes_gathered_per_rank_total': getattr(sync, 'bytes_gathered', None)}
+        if rank == 0 and rccl_log is not None:
+            try:    # what RCCL chose: the lines of its INFO log that name rings / trees, channel counts, algorithms, protocols, the transport
+                keys = ('Ring', 'Tree', 'hannel', 'lgorithm', 'rotocol', 'via', 'xGMI', 'XGMI', 'P2P', 'comm 0x')
+                lines = [l.strip()[-200:] for l in open(os.environ.get('NCCL_DEBUG_FILE', rccl_log)) if any(k in l for k in keys)]
+                extra['collective']['rccl_log'] = {'lines_kept': len(lines), 'first': lines[:24], 'env': {k: v for k, v in os.environ.items() if k.startswith(('NCCL_', 'RCCL_'))}}
+            except Exception as e:  # noqa: BLE001
+                extra['collective']['rccl_log'] = {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
 
     if rank == 0:
         n_refresh = sum(1 for i in range(it0, it1) if i % sampler.update_grid_freq == 0)

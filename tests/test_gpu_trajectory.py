@@ -37,19 +37,19 @@ def test_training_trajectory_follows_the_reference_python_stack(dev):
     # replaced by the fixture's: iterations 0..15 then march the SAME occupancy with the same rays and the same jitter stream,
     # so their sample counts (and the batch size adapted from them at iteration 15) must equal the fixture's exactly.
     from xrnerf_amd import ops
-    real_update, seeded = ops.update_bitfield, {}
+    real_update, seeded = ops.ema_update_bitfield, {}          # (the sampler's refresh tail: K9 + K10 + K11 as one entry point)
 
-    def update_then_seed(grid, mean, bitfield):
-        out = real_update(grid, mean, bitfield)
+    def update_then_seed(grid_tmp, n_elements, decay, grid, mean, bitfield):
+        out = real_update(grid_tmp, n_elements, decay, grid, mean, bitfield)
         if not seeded:
             seeded['own'] = bitfield[:128 ** 3 // 8].cpu().numpy().copy()
             bitfield[:128 ** 3 // 8].copy_(torch.from_numpy(fx['bitfield_it0']).to(bitfield.device))
         return out
-    ops.update_bitfield = update_then_seed
+    ops.ema_update_bitfield = update_then_seed
     try:
         rec, bitfields = _run(net, opt, poses, fx, dev, Hn, rec, bitfields)
     finally:
-        ops.update_bitfield = real_update
+        ops.ema_update_bitfield = real_update
     bitfields[0] = seeded['own']
     _check(rec, bitfields, fx, net)
 
