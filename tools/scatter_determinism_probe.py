@@ -37,7 +37,7 @@ def sweep(tag, alternate=False):
     a launch that picked up anything left behind by the launch before it shows, which identical launches would hide"""
     refs, bad, worst = [None, None], [0] * meta.n_levels, 0.0
     dencs = [b.denc_t, -b.denc_t] if alternate else [b.denc_t, b.denc_t]
-    cref, cbad = None, 0
+    cref, cbad, bref = None, 0, None
     for k in range(K):
         ref = refs[k & 1]
         g = torch.full((meta.n_params,), float('nan'), device=dev)
@@ -54,6 +54,19 @@ def sweep(tag, alternate=False):
                 d = torch.nonzero(cnt != cref).reshape(-1)
                 print('   launch %d: %d sub-bin fill counts differ from the first launch (words %d..%d; first: %d instead of %d)'
                       % (k, d.numel(), int(d[0]), int(d[-1]), int(cnt[d[0]]), int(cref[d[0]])), flush=True)
+        # the bin kernel's OTHER output, the items themselves: an order-free checksum per float4 component over the whole bin area (the order
+        # of a sub-bin's items follows the wave schedule; slots behind the fill counts are never written).  Default layout only:
+        # 13 binned levels, 2048-sample blocks, 262144 rows -> counts 399872 B, bins 13 x 1572864 items
+        if ws is not None and os.environ.get('CHECK_BINS') and b.n_rows == 262144 and not alternate:
+            # (the hashed levels' part: the two dense binned levels come first in the bin area and do overflow their sub-bins on coherent rays --
+            # WHICH of a sub-bin's items go to the overflow list follows the schedule)
+            items = ws[399872 + 2 * 1572864 * 16:399872 + 13 * 1572864 * 16].view(torch.int32).view(-1, 4)
+            cs = items.to(torch.int64).sum(0)
+            if k == 0:
+                bref = cs
+            elif not torch.equal(cs, bref):
+                print('   launch %d: the bin area differs from the first launch in components %s (x = entry pair, y = feature-0 value, z = feature-1 '
+                      'value, w = x weight): checksum deltas %s' % (k, [c for c in range(4) if int(cs[c]) != int(bref[c])], (cs - bref).tolist()), flush=True)
         if ref is None:
             refs[k & 1] = g
             continue
@@ -108,7 +121,11 @@ NOISE = int(os.environ.get('NOISE_PROCS', '1'))
 if not os.environ.get('SHARED_ONLY'):
     sweep('alone, same input every launch        ')
     sweep('alone, alternating inputs             ', True)
-ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), 'noise', os.environ.get('NOISE_SECONDS', '110')]) for _ in range(NOISE)]
+# NOISE_CU_MASK (e.g. "0:128-255", with HSA_CU_MASK=0:0-127 for this process): the competitors on their own compute units
+nenv = dict(os.environ)
+if os.environ.get('NOISE_CU_MASK'):
+    nenv['HSA_CU_MASK'] = os.environ['NOISE_CU_MASK']
+ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), 'noise', os.environ.get('NOISE_SECONDS', '110')], env=nenv) for _ in range(NOISE)]
 time.sleep(15)
 sweep('GPU shared (%d other), same input every launch   ' % NOISE)
 if not os.environ.get('SHARED_ONLY'):

@@ -169,7 +169,11 @@ __device__ __forceinline__ void s3_bin_block(const S3Level& L, uint32_t lg, uint
             uint32_t i = min(rb0 + s * S3_BIN_THREADS + threadIdx.x, n - 1);
             if (rows) i = rows[i];
             const float* xp = x + (size_t)i * x_stride;
+#ifdef S3_PROBE_LOAD_ORDER      // (probe builds, tools/build_variant.sh: does the two-process deviation follow the FIRST load of the fetch?)
+            nx0[s] = xp[0]; nx1[s] = xp[1]; nx2[s] = xp[2]; nd1[s] = d1p[i]; nd0[s] = d0p[i];
+#else
             nd0[s] = d0p[i]; nd1[s] = d1p[i]; nx0[s] = xp[0]; nx1[s] = xp[1]; nx2[s] = xp[2];
+#endif
         }
     };
     fetch(b0);
@@ -225,7 +229,9 @@ __device__ __forceinline__ void s3_bin_block(const S3Level& L, uint32_t lg, uint
         };
         uint32_t irank[NI];
         items([&](auto K_, uint32_t part, uint32_t, float, float, float) __attribute__((always_inline)) { irank[decltype(K_)::value] = atomicAdd(&s_cnt[part], 1u); });
+#ifndef S3_PROBE_NO_PREFETCH    // (probe build: no load in flight across the round's barriers -- fetched at the round's end instead)
         if (r + 1 < (uint32_t)ROUNDS && rb0 + ROUND < n) fetch(rb0 + ROUND);   // next round's inputs under this round's ranking
+#endif
         __syncthreads();
         if (threadIdx.x < 64) {                                             // exclusive scan of the round's partition counts
             uint32_t loc[4], sum = 0;
@@ -262,6 +268,18 @@ __device__ __forceinline__ void s3_bin_block(const S3Level& L, uint32_t lg, uint
                 if (e0 != e1) ovo[o + 1] = make_float4(__uint_as_float(e1 | (part << S3_LOG2)), w * va, w * vb, 0.f);
             }
         });
+#ifdef S3_PROBE_REREAD           // (probe build: is the value this round worked with what the row holds?  read it again, uncached, and say so if not)
+#pragma unroll
+        for (int s = 0; s < SPT; ++s) {
+            uint32_t i = min(rb0 + s * S3_BIN_THREADS + threadIdx.x, n - 1);
+            if (rows) i = rows[i];
+            const float a0 = __builtin_nontemporal_load(d0p + i), a1 = __builtin_nontemporal_load(d1p + i);
+            if (__float_as_uint(a0) != __float_as_uint(ld0[s]) || __float_as_uint(a1) != __float_as_uint(ld1[s]))
+                printf("REREAD level-slot %u drow %u block %u round %u thread %u s %d sample %u: d0 held %08x now %08x | d1 held %08x now %08x | neighbours now %08x %08x\n",
+                       (unsigned)(&L - (const S3Level*)nullptr) & 0u, L.drow, sb, r, threadIdx.x, s, i, __float_as_uint(ld0[s]), __float_as_uint(a0),
+                       __float_as_uint(ld1[s]), __float_as_uint(a1), __float_as_uint(d0p[i > 0 ? i - 1 : 0]), __float_as_uint(d0p[min(i + 1, n - 1)]));
+        }
+#endif
         __syncthreads();
         const uint32_t total = KIND == S3_H ? s_off[parts] : min(s_off[parts], (uint32_t)S3_ROUND_ITEMS);
         for (uint32_t q = threadIdx.x; q < total; q += S3_BIN_THREADS) {
@@ -285,6 +303,9 @@ __device__ __forceinline__ void s3_bin_block(const S3Level& L, uint32_t lg, uint
         // (kind D: items of a partition that went straight to the overflow list do not take sub-bin slots)
         for (uint32_t p = threadIdx.x; p < parts; p += S3_BIN_THREADS)
             s_base[p] += KIND == S3_H ? s_cnt[p] : min(s_off[p] + s_cnt[p], (uint32_t)S3_ROUND_ITEMS) - min(s_off[p], (uint32_t)S3_ROUND_ITEMS);
+#ifdef S3_PROBE_NO_PREFETCH
+        if (r + 1 < (uint32_t)ROUNDS && rb0 + ROUND < n) fetch(rb0 + ROUND);
+#endif
     }
     __syncthreads();
     for (uint32_t p = threadIdx.x; p < parts; p += S3_BIN_THREADS) cnt_out[(size_t)p * nsb] = min(s_base[p], cap);
