@@ -647,18 +647,24 @@ int xr_nerf_render_forward(const float* raw, const float* z_vals, const float* r
  *   backward, input:  dx [M,K] = (dy [M,N] where mask_src > 0) . w    (mask_src nullable: the layer's relu output)
  *   backward, weight: dw_partials [splits,N,K] = per-M-range partial sums of (dy masked)^T . x; the caller adds them in
  *                     order (bit-reproducible); splits = xr_linear_backward_splits(M, N, K)
- *   backward, bias:   db_partials [splits,N] = per-M-range column sums of (dy masked); splits = xr_linear_backward_splits(M, 0, 0) */
-int xr_linear_forward(const float* x, const float* w, const float* bias, uint32_t M, uint32_t N, uint32_t K, int relu,
-                      float* y, void* stream);
-/* w_transposed != 0: the weight is handed over transposed by the caller (w_t [K,N] row-major): served by the forward's split-operand kernel */
-int xr_linear_backward_input(const float* dy, const float* mask_src, const float* w, int w_transposed, uint32_t M, uint32_t N, uint32_t K,
-                             float* dx, void* stream);
+ *   backward, bias:   db_partials [splits,N] = per-M-range column sums of (dy masked); splits = xr_linear_backward_splits(M, 0, 0)
+ * Row strides (floats, multiples of 4; 0 = dense): a layer may read its input from, and write its output into, a column range of a wider
+ * buffer, and take its output gradient from a column range of the next layer's input gradient -- the skip connection's [x | h]
+ * (nerf_mlp.py:70-72) and the view branch's [feature | dir] (:80-85) are then never concatenated or split (xrnerf_amd/vanilla.py). */
+int xr_linear_forward(const float* x, uint32_t ldx, const float* w, const float* bias, uint32_t M, uint32_t N, uint32_t K, int relu,
+                      float* y, uint32_t ldy, void* stream);
+/* w_transposed != 0: the weight is handed over transposed by the caller (w_t [K,N] row-major): served by the forward's split-operand kernel.
+ * lddy: row stride of dy and of mask_src */
+int xr_linear_backward_input(const float* dy, uint32_t lddy, const float* mask_src, const float* w, int w_transposed, uint32_t M, uint32_t N,
+                             uint32_t K, float* dx, void* stream);
 /* M ranges of the weight gradient of an N x K layer; N == K == 0: of the bias gradient alone (xr_linear_backward_bias) */
 uint32_t xr_linear_backward_splits(uint32_t M, uint32_t N, uint32_t K);
 /* db_partials (nullable): weight and bias gradient in one launch: db_partials [splits,N] over the SAME M ranges as dw_partials (taken from
- * the operand panels the product stages anyway; no pass of its own over dy and the mask) */
-int xr_linear_backward_weight(const float* dy, const float* mask_src, const float* x, uint32_t M, uint32_t N, uint32_t K,
-                              uint32_t splits, float* dw_partials, float* db_partials, void* stream);
+ * the operand panels the product stages anyway; no pass of its own over dy and the mask).  lddy (dy, mask_src) / ldx: row strides.
+ * part_stride: floats between two splits' partials (0 = N * K); db_partials == dw_partials + N * K with part_stride = N * K + N puts both
+ * sets into one [splits, N * K + N] buffer (one reduction over the splits finishes both gradients). */
+int xr_linear_backward_weight(const float* dy, uint32_t lddy, const float* mask_src, const float* x, uint32_t ldx, uint32_t M, uint32_t N,
+                              uint32_t K, uint32_t splits, float* dw_partials, float* db_partials, size_t part_stride, void* stream);
 int xr_linear_backward_bias(const float* dy, const float* mask_src, uint32_t M, uint32_t N, uint32_t splits,
                             float* db_partials, void* stream);
 

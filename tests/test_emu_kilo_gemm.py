@@ -153,16 +153,16 @@ def test_linear_kernels_on_the_host(E, M, N, K, gemm_kernel):
     x, w, b = E.aligned((M, K), fill=rng.normal(0, 1, (M, K))), E.aligned((N, K), fill=rng.normal(0, 1, (N, K)) / K ** 0.5), E.f32(rng.normal(0, 1, N))
     dy = E.aligned((M, N), fill=rng.normal(0, 1, (M, N)))
     y = E.aligned((M, N))
-    E.check(L.xr_linear_forward(E.p(x), E.p(w), E.p(b), M, N, K, 1, E.p(y), None), L)
+    E.check(L.xr_linear_forward(E.p(x), 0, E.p(w), E.p(b), M, N, K, 1, E.p(y), 0, None), L)
     ref = x.astype(np.float64) @ w.astype(np.float64).T + b
     assert np.abs(y - np.maximum(ref, 0)).max() <= 2e-5 * max(1.0, np.abs(ref).max())
     dym = dy.astype(np.float64) * (y > 0)
     dx = E.aligned((M, K))
-    E.check(L.xr_linear_backward_input(E.p(dy), E.p(y), E.p(w), 0, M, N, K, E.p(dx), None), L)
+    E.check(L.xr_linear_backward_input(E.p(dy), 0, E.p(y), E.p(w), 0, M, N, K, E.p(dx), None), L)
     assert np.abs(dx - dym @ w.astype(np.float64)).max() <= 5e-5 * max(1.0, np.abs(dym @ w).max())
     splits = int(L.xr_linear_backward_splits(M, N, K))
     part = E.aligned((splits, N, K))
-    E.check(L.xr_linear_backward_weight(E.p(dy), E.p(y), E.p(x), M, N, K, splits, E.p(part), None, None), L)
+    E.check(L.xr_linear_backward_weight(E.p(dy), 0, E.p(y), E.p(x), 0, M, N, K, splits, E.p(part), None, C.c_size_t(0), None), L)
     rw = dym.T @ x.astype(np.float64)
     assert np.abs(part.sum(0) - rw).max() <= 5e-5 * max(1.0, np.abs(rw).max())
     bs = int(L.xr_linear_backward_splits(M, 0, 0))
@@ -172,9 +172,26 @@ def test_linear_kernels_on_the_host(E, M, N, K, gemm_kernel):
     # the input gradient with the weight handed over transposed (the forward's kernel), and weight + bias gradient in one launch
     wt = E.aligned((K, N), fill=np.ascontiguousarray(w.T))
     dx2 = E.aligned((M, K))
-    E.check(L.xr_linear_backward_input(E.p(dy), E.p(y), E.p(wt), 1, M, N, K, E.p(dx2), None), L)
+    E.check(L.xr_linear_backward_input(E.p(dy), 0, E.p(y), E.p(wt), 1, M, N, K, E.p(dx2), None), L)
     assert np.abs(dx2 - dym @ w.astype(np.float64)).max() <= 5e-5 * max(1.0, np.abs(dym @ w).max())
     part2, pb2 = E.aligned((splits, N, K)), E.aligned((splits, N))
-    E.check(L.xr_linear_backward_weight(E.p(dy), E.p(y), E.p(x), M, N, K, splits, E.p(part2), E.p(pb2), None), L)
+    E.check(L.xr_linear_backward_weight(E.p(dy), 0, E.p(y), E.p(x), 0, M, N, K, splits, E.p(part2), E.p(pb2), C.c_size_t(0), None), L)
     assert np.array_equal(part2, part)
     assert np.abs(pb2.sum(0) - dym.sum(0)).max() <= 5e-5 * max(1.0, np.abs(dym.sum(0)).max())
+    # ---- row strides: the same operands as column ranges of wider buffers (the skip connection's [x | h], the view layer's input)
+    # give the same bits -- input x at columns [8, 8 + K) of a [M, K + 12] buffer, output / mask / dy at columns [4, 4 + N) of [M, N + 8]
+    if gemm_kernel in ('split2', 'mfma'):
+        xw = E.aligned((M, K + 12), fill=7.0); xw[:, 8:8 + K] = x
+        yw = E.aligned((M, N + 8), fill=-3.0)
+        voidp = lambda a, col: C.c_void_p(a.ctypes.data + 4 * col)
+        E.check(L.xr_linear_forward(voidp(xw, 8), K + 12, E.p(w), E.p(b), M, N, K, 1, voidp(yw, 4), N + 8, None), L)
+        assert np.array_equal(yw[:, 4:4 + N], y) and np.all(yw[:, :4] == -3.0) and np.all(yw[:, 4 + N:] == -3.0)
+        dyw = E.aligned((M, N + 8), fill=5.0); dyw[:, 4:4 + N] = dy
+        dx3 = E.aligned((M, K))
+        E.check(L.xr_linear_backward_input(voidp(dyw, 4), N + 8, voidp(yw, 4), E.p(wt), 1, M, N, K, E.p(dx3), None), L)
+        assert np.array_equal(dx3, dx2)
+        # weight and bias partials in ONE [splits, N K + N] buffer
+        joint = E.aligned((splits, N * K + N))
+        E.check(L.xr_linear_backward_weight(voidp(dyw, 4), N + 8, voidp(yw, 4), voidp(xw, 8), K + 12, M, N, K, splits, E.p(joint),
+                                            C.c_void_p(joint.ctypes.data + 4 * N * K), C.c_size_t(N * K + N), None), L)
+        assert np.array_equal(joint[:, :N * K].reshape(splits, N, K), part2) and np.array_equal(joint[:, N * K:], pb2)

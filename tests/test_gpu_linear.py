@@ -75,6 +75,39 @@ def test_autograd_node_equals_torch_linear(dev):
     assert torch.equal(linear_act(x2, w2, None, True), torch.relu(torch.nn.functional.linear(x2, w2)))
 
 
+@pytest.mark.parametrize('M,padded_rows', [(3000, True), (257, False)])
+def test_whole_mlp_as_one_autograd_node_equals_the_layer_by_layer_graph(dev, M, padded_rows):
+    """NerfMLP.run_mlp on the device is ONE autograd node (vanilla._NerfMlpFn): the skip layer writes into the [x | h] buffer, feature and
+    alpha heads land in the view layer's input buffer, gradients come from column ranges of the next layer's input gradient -- no cat /
+    split / pad kernels.  Output and every parameter gradient against the same module evaluated layer by layer in float64 on the host
+    (the reference's graph, nerf_mlp.py:62-94), for the Mip-NeRF widths (96 + 27 inputs, skip at 4): 1e-4 of the largest entry."""
+    import copy
+    from xrnerf_amd.vanilla import NerfMLP
+    torch.manual_seed(5)
+    emb = dict(type='MipNerfEmbedder', min_deg_point=0, max_deg_point=16, min_deg_view=0, max_deg_view=4, use_viewdirs=True, append_identity=True)
+    import xrnerf_amd.mip  # noqa: F401  (registers the embedder)
+    mlp = NerfMLP(skips=[4], netdepth=8, netwidth=256, use_viewdirs=True, embedder=emb).to(dev)
+    assert (mlp.input_ch, mlp.input_ch_dirs) == (96, 27)
+    ref = copy.deepcopy(mlp).double().cpu()
+    x64 = torch.randn(M, 123, dtype=torch.float64)
+    if padded_rows:                                          # what ops.mip_encode hands over: rows padded to 124 floats
+        x = torch.empty((M, 124), device=dev)[:, :123]
+        x.copy_(x64.float())
+    else:
+        x = x64.float().to(dev)                              # 123-float rows: one aligned copy inside the node
+    assert mlp._device_graph_ok(x)
+    g = torch.randn(M, 4, dtype=torch.float64)
+    out = mlp.run_mlp(x)
+    assert out.grad_fn is not None and type(out.grad_fn).__name__ == '_NerfMlpFnBackward'
+    out.backward(g.float().to(dev))
+    want = ref.run_mlp(x64)
+    want.backward(g)
+    assert (out.detach().cpu().double() - want.detach()).abs().max() <= 1e-4 * max(1.0, float(want.abs().max()))
+    for (name, p), (_, q) in zip(mlp.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None and p.grad.shape == q.grad.shape, name
+        assert (p.grad.cpu().double() - q.grad).abs().max() <= 1e-4 * max(1.0, float(q.grad.abs().max())), name
+
+
 def test_vanilla_nerf_config1_on_the_device_equals_the_host_path(dev):
     """BASELINE config #1's model dict (8x256 MLPs, 64 coarse + 128 fine samples): the device path (fp32-MFMA linear
     layers incl. the padded narrow heads and the shared alpha/feature product, fused NerfRender at inference) against the

@@ -144,11 +144,11 @@ SIGNATURES = {
                                     _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     'xr_nerf_render_forward': (_i32, [_vp, _vp, _vp, _u32, _u32, _i32, _vp, _vp, _vp, _vp, _vp]),
     'xr_nerf_density_splat': (_i32, [_i32, _vp, _u32, _u32, _vp, _i32, _i32, _vp, _vp, _vp]),
-    'xr_linear_forward': (_i32, [_vp, _vp, _vp, _u32, _u32, _u32, _i32, _vp, _vp]),
-    'xr_linear_backward_input': (_i32, [_vp, _vp, _vp, _i32, _u32, _u32, _u32, _vp, _vp]),
+    'xr_linear_forward': (_i32, [_vp, _u32, _vp, _vp, _u32, _u32, _u32, _i32, _vp, _u32, _vp]),
+    'xr_linear_backward_input': (_i32, [_vp, _u32, _vp, _vp, _i32, _u32, _u32, _u32, _vp, _vp]),
     'xr_linear_backward_splits': (_u32, [_u32, _u32, _u32]),
     'xr_linear_backward_bias': (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp]),
-    'xr_linear_backward_weight': (_i32, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
+    'xr_linear_backward_weight': (_i32, [_vp, _u32, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _sz, _vp]),
     'xr_kilo_render_workspace_bytes': (_sz, [_u32, _u32, _u32]),
     'xr_kilo_render_rays': (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32,
                                    _u32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -40,6 +40,7 @@ struct GemmArgs {
     int tload;                                   // k_gemm_split: [k, rows] operands are read with per-k dword loads (k-contiguous in registers)
     float* colsum;                               // k_gemm_f32 with a_km: nullable [splits, Mc]: sums of A's (masked) rows over the split's k range
     int a_gradient = 0;                          // A holds gradients (any magnitude): a 16-bit split of it must keep the fp32 range (bf16 parts)
+    size_t colsum_stride = 0;                    // floats between two splits' column sums (0 = Mc)
 };
 
 // one 128 x GBK panel of an operand into registers: GNJ float4 per thread.
@@ -166,7 +167,7 @@ __global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g) {
             float s = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) s += red[i * GBM + threadIdx.x];
-            if (m0 + threadIdx.x < g.Mc) g.colsum[(size_t)blockIdx.z * g.Mc + m0 + threadIdx.x] = s;
+            if (m0 + threadIdx.x < g.Mc) g.colsum[(size_t)blockIdx.z * (g.colsum_stride ? g.colsum_stride : (size_t)g.Mc) + m0 + threadIdx.x] = s;
         }
     }
 }
@@ -528,7 +529,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_split_kt(GemmArgs g) {
             float sum = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) sum += red[i * GBM + threadIdx.x];
-            if (m0 + threadIdx.x < g.Mc) g.colsum[(size_t)blockIdx.z * g.Mc + m0 + threadIdx.x] = sum;
+            if (m0 + threadIdx.x < g.Mc) g.colsum[(size_t)blockIdx.z * (g.colsum_stride ? g.colsum_stride : (size_t)g.Mc) + m0 + threadIdx.x] = sum;
         }
     }
 }
@@ -584,23 +585,32 @@ static int gemm_launch(GemmArgs g, uint32_t splits, void* stream) {
 }
 
 // y [M,N] = act(x [M,K] . w [N,K]^T + bias [N])
-extern "C" int xr_linear_forward(const float* x, const float* w, const float* bias, uint32_t M, uint32_t N, uint32_t K,
-                                 int relu, float* y, void* stream) {
-    GemmArgs g{x, w, y, bias, nullptr, M, N, K, K, K, N, 0, 0, relu, 0, 0, 0, nullptr};
+// ldx / ldy: row strides of x and y in floats (0 = dense; multiples of 4): a layer can read its input from, and write its output into, a
+// column range of a wider buffer -- the skip connection's [x | h] and the view layer's [feature | alpha | dir] are then never concatenated
+extern "C" int xr_linear_forward(const float* x, uint32_t ldx, const float* w, const float* bias, uint32_t M, uint32_t N, uint32_t K,
+                                 int relu, float* y, uint32_t ldy, void* stream) {
+    if (ldx == 0) ldx = K;
+    if (ldy == 0) ldy = N;
+    XR_REQUIRE(ldx >= K && ldy >= N && ldy % 4 == 0 && ((uintptr_t)y & 15) == 0, "bad row stride / output alignment");
+    GemmArgs g{x, w, y, bias, nullptr, M, N, K, ldx, K, ldy, 0, 0, relu, 0, 0, 0, nullptr};
     return gemm_launch(g, 1, stream);
 }
 
 // dx [M,K] = (dy [M,N] masked by mask_src [M,N] > 0 when given) . w [N,K].  w_transposed != 0: the weight is handed over TRANSPOSED
 // (w_t [K,N] row-major): both operands are then [rows, contraction] like the forward's, and the product runs on the split-operand kernel
 // (163 us against 267 us on the fp32 MFMA at 131072 x 256 x 256)
-extern "C" int xr_linear_backward_input(const float* dy, const float* mask_src, const float* w, int w_transposed, uint32_t M, uint32_t N,
+// lddy: row stride of dy AND of mask_src (0 = dense): the gradient of a layer whose output sits in a column range of a wider buffer is the
+// same column range of the next layer's input gradient
+extern "C" int xr_linear_backward_input(const float* dy, uint32_t lddy, const float* mask_src, const float* w, int w_transposed, uint32_t M, uint32_t N,
                                         uint32_t K, float* dx, void* stream) {
+    if (lddy == 0) lddy = N;
+    XR_REQUIRE(lddy >= N, "bad row stride");
     if (w_transposed) {
-        GemmArgs g{dy, w, dx, nullptr, mask_src, M, K, N, N, N, K, 0, 0, 0, 0, 0, 0, nullptr};
+        GemmArgs g{dy, w, dx, nullptr, mask_src, M, K, N, lddy, N, K, 0, 0, 0, 0, 0, 0, nullptr};
         g.a_gradient = 1;
         return gemm_launch(g, 1, stream);
     }
-    GemmArgs g{dy, w, dx, nullptr, mask_src, M, K, N, N, K, K, 0, 1, 0, 0, 0, 0, nullptr};
+    GemmArgs g{dy, w, dx, nullptr, mask_src, M, K, N, lddy, K, K, 0, 1, 0, 0, 0, 0, nullptr};
     g.a_gradient = 1;
     return gemm_launch(g, 1, stream);
 }
@@ -664,10 +674,17 @@ extern "C" int xr_linear_backward_bias(const float* dy, const float* mask_src, u
 
 // db_partials (nullable) [splits, N]: weight AND bias gradient of a layer in one launch -- the same M-range column sums of (dy masked) that
 // xr_linear_backward_bias computes with a pass of its own, taken from the panels the weight-gradient product stages anyway
-extern "C" int xr_linear_backward_weight(const float* dy, const float* mask_src, const float* x, uint32_t M, uint32_t N, uint32_t K,
-                                         uint32_t splits, float* dw_partials, float* db_partials, void* stream) {
+// lddy (dy and mask_src) / ldx: row strides, 0 = dense.  part_stride: floats between two splits' partials (0 = N * K); with db_partials ==
+// dw_partials + N * K and part_stride = N * K + N both partial sets sit in ONE [splits, N * K + N] buffer and one reduction finishes both
+extern "C" int xr_linear_backward_weight(const float* dy, uint32_t lddy, const float* mask_src, const float* x, uint32_t ldx, uint32_t M, uint32_t N,
+                                         uint32_t K, uint32_t splits, float* dw_partials, float* db_partials, size_t part_stride, void* stream) {
+    if (lddy == 0) lddy = N;
+    if (ldx == 0) ldx = K;
+    if (part_stride == 0) part_stride = (size_t)N * K;
+    XR_REQUIRE(lddy >= N && ldx >= K && part_stride >= (size_t)N * K && part_stride % 4 == 0, "bad stride");
     const char* env = getenv("XR_GEMM_F32");
     if (db_partials && env && strcmp(env, "bf16x3all") == 0) {   // that measurement mode has no column sums in its kernel: two launches
+        XR_REQUIRE(lddy == N && part_stride == (size_t)N * K, "the bf16x3all measurement mode takes dense operands");
         GemmArgs g0{dy, x, dw_partials, nullptr, mask_src, N, K, M, N, K, K, 1, 1, 0, 0, (size_t)N * K, 0, nullptr};
         const int rc = gemm_launch(g0, splits, stream);
         if (rc != XR_OK) return rc;
@@ -678,6 +695,7 @@ extern "C" int xr_linear_backward_weight(const float* dy, const float* mask_src,
         XR_LAUNCH_CHECK();
         return XR_OK;
     }
-    GemmArgs g{dy, x, dw_partials, nullptr, mask_src, N, K, M, N, K, K, 1, 1, 0, 0, (size_t)N * K, 0, db_partials};
+    GemmArgs g{dy, x, dw_partials, nullptr, mask_src, N, K, M, lddy, ldx, K, 1, 1, 0, 0, part_stride, 0, db_partials};
+    g.colsum_stride = db_partials ? (db_partials == dw_partials + (size_t)N * K ? part_stride : (size_t)N) : 0;
     return gemm_launch(g, splits, stream);
 }

@@ -1108,12 +1108,16 @@ def mip_encode(rays_o, rays_d, viewdirs, radii, z_vals, min_deg, max_deg, min_de
     R, n_z = z_vals.shape
     ch = mip_encode_channels(min_deg, max_deg, min_deg_view, max_deg_view, append_identity)
     if out is None:
-        out = torch.empty((R * (n_z - 1), ch), dtype=torch.float32, device=z_vals.device)
+        # rows padded to a multiple of 4 floats: the encoding (123 channels in the reference's config) is then a [M, ch] view whose rows start
+        # on 16-byte boundaries, which the linear kernels read in place (ops._rows) -- no contiguous copy of the first layer's input
+        out = torch.empty((R * (n_z - 1), (ch + 3) // 4 * 4), dtype=torch.float32, device=z_vals.device)[:, :ch]
+    if not _on_device(out) or out.dtype != torch.float32 or out.dim() != 2 or out.stride(1) != 1 or out.shape[1] < ch:
+        raise _lib.XrError('mip_encode: out must be a float32 device matrix with contiguous rows of >= %d channels' % ch)
     shape = {'cone': 0, 'cylinder': 1}[ray_shape]
     with _span('xr_mip_encode', R * (n_z - 1)):
         _lib.check(L.xr_mip_encode(_ptr(_f32c(rays_o)), _ptr(_f32c(rays_d)), _ptr(_f32c(viewdirs)),
                                    _ptr(_f32c(radii.reshape(-1))), _ptr(_f32c(z_vals)), R, n_z, min_deg, max_deg,
-                                   min_deg_view, max_deg_view, int(bool(append_identity)), shape, _ptr(out),
+                                   min_deg_view, max_deg_view, int(bool(append_identity)), shape, C.c_void_p(out.data_ptr()),
                                    out.stride(0), _stream()), 'xr_mip_encode')
     return out
 
@@ -1308,60 +1312,92 @@ def linear_ok(x, w):
             and x.shape[1] % 4 == 0 and w.shape[0] % 4 == 0 and x.shape[0] > 0)
 
 
-def linear_forward(x, w, bias, relu):
-    """y [M,N] = act(x [M,K] . w [N,K]^T + bias)"""
-    x, w = _f32c(x), _f32c(w)
+def _rows(t):
+    """(tensor as the linear kernels take it, row stride): a [M, C] fp32 matrix whose rows are contiguous and start on 16-byte boundaries --
+    dense, or a column range of a wider buffer.  Anything else is copied."""
+    if t.dtype != torch.float32:
+        raise _lib.XrError('the linear kernels take float32 tensors (got %s)' % t.dtype)
+    if not _on_device(t):
+        raise _lib.XrError('xrnerf_amd ops need ROCm device tensors (got a %s tensor): there is no CPU fallback' % t.device)
+    if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.stride(0) >= t.shape[1] and t.data_ptr() % 16 == 0:
+        return t, t.stride(0)
+    t = t.contiguous()
+    return t, t.shape[1]
+
+
+def linear_forward(x, w, bias, relu, out=None):
+    """y [M,N] = act(x [M,K] . w [N,K]^T + bias).  x and `out` may be column ranges of wider buffers (row strides)."""
+    x, ldx = _rows(x)
+    w = _f32c(w)
     M, K = x.shape
     N = w.shape[0]
-    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device) if out is None else out
+    if tuple(y.shape) != (M, N) or y.stride(1) != 1 or y.stride(0) % 4 or y.data_ptr() % 16 or y.dtype != torch.float32:
+        raise _lib.XrError('linear_forward: out must be an [M, N] float32 view with contiguous, 16-byte aligned rows')
     with _span('xr_linear_forward', M):
-        _lib.check(_lib.load().xr_linear_forward(_ptr(x), _ptr(w), _ptr(_f32c(bias)) if bias is not None else None, M, N, K,
-                                                 int(bool(relu)), _ptr(y), _stream()), 'xr_linear_forward')
+        _lib.check(_lib.load().xr_linear_forward(C.c_void_p(x.data_ptr()), ldx, _ptr(w), _ptr(_f32c(bias)) if bias is not None else None, M, N, K,
+                                                 int(bool(relu)), C.c_void_p(y.data_ptr()), y.stride(0), _stream()), 'xr_linear_forward')
     return y
 
 
-def linear_backward_input(dy, mask_src, w):
-    """dx [M,K] = (dy where mask_src > 0) . w.  The weight goes in transposed (one 64 K-element copy): both operands of the product are
-    then [rows, contraction] like the forward's and it runs on the forward's split-operand kernel instead of the fp32 MFMA (1.6x)."""
-    dy, w = _f32c(dy), _f32c(w)
+def _dy_and_mask(dy, mask_src):
+    dy, ld = _rows(dy)
+    if mask_src is not None:
+        mask_src, ldm = _rows(mask_src)
+        if ldm != ld:                                  # one stride for both in the kernel: bring them to dense rows
+            dy, mask_src = dy.contiguous(), mask_src.contiguous()
+            ld = dy.shape[1]
+    return dy, mask_src, ld
+
+
+def linear_backward_input(dy, mask_src, w, w_t=None):
+    """dx [M,K] = (dy where mask_src > 0) . w.  The weight goes in transposed (one 64 K-element copy, or the caller's `w_t`): both operands
+    of the product are then [rows, contraction] like the forward's and it runs on the forward's split-operand kernel instead of the fp32
+    MFMA (1.6x).  dy / mask_src may be column ranges of wider buffers (same row stride)."""
+    dy, mask_src, ld = _dy_and_mask(dy, mask_src)
     M, N = dy.shape
     K = w.shape[1]
     dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
-    w_t = w.t().contiguous()
+    if w_t is None:
+        w_t = _f32c(w).t().contiguous()
     with _span('xr_linear_backward_input', M):
-        _lib.check(_lib.load().xr_linear_backward_input(_ptr(dy), _ptr(mask_src), _ptr(w_t), 1, M, N, K, _ptr(dx), _stream()),
-                   'xr_linear_backward_input')
+        _lib.check(_lib.load().xr_linear_backward_input(C.c_void_p(dy.data_ptr()), ld, C.c_void_p(mask_src.data_ptr()) if mask_src is not None else None,
+                                                        _ptr(w_t), 1, M, N, K, _ptr(dx), _stream()), 'xr_linear_backward_input')
     return dx
 
 
 def linear_backward_weight(dy, mask_src, x):
     """dw [N,K] = (dy where mask_src > 0)^T . x   (fixed-order sum of the per-M-range partials)"""
     L = _lib.load()
-    dy, x = _f32c(dy), _f32c(x)
+    dy, mask_src, ld = _dy_and_mask(dy, mask_src)
+    x, ldx = _rows(x)
     M, N = dy.shape
     K = x.shape[1]
     splits = int(L.xr_linear_backward_splits(M, N, K))
     part = torch.empty((splits, N, K), dtype=torch.float32, device=dy.device)
     with _span('xr_linear_backward_weight', M):
-        _lib.check(L.xr_linear_backward_weight(_ptr(dy), _ptr(mask_src), _ptr(x), M, N, K, splits, _ptr(part), None, _stream()),
+        _lib.check(L.xr_linear_backward_weight(C.c_void_p(dy.data_ptr()), ld, C.c_void_p(mask_src.data_ptr()) if mask_src is not None else None,
+                                               C.c_void_p(x.data_ptr()), ldx, M, N, K, splits, _ptr(part), None, 0, _stream()),
                    'xr_linear_backward_weight')
     return part[0] if splits == 1 else part.sum(0)
 
 
 def linear_backward_weight_bias(dy, mask_src, x):
-    """(dw [N,K], db [N]) of one layer from ONE launch: the bias gradient's column sums ride on the weight-gradient product"""
+    """(dw [N,K], db [N]) of one layer from ONE launch and ONE reduction: the bias gradient's column sums ride on the weight-gradient
+    product, and both sets of per-M-range partials sit in one [splits, N K + N] buffer"""
     L = _lib.load()
-    dy, x = _f32c(dy), _f32c(x)
+    dy, mask_src, ld = _dy_and_mask(dy, mask_src)
+    x, ldx = _rows(x)
     M, N = dy.shape
     K = x.shape[1]
     splits = int(L.xr_linear_backward_splits(M, N, K))
-    dwp, dbp = torch.empty((splits, N, K), dtype=torch.float32, device=dy.device), torch.empty((splits, N), dtype=torch.float32, device=dy.device)
+    part = torch.empty((splits, N * K + N), dtype=torch.float32, device=dy.device)
     with _span('xr_linear_backward_weight', M):
-        _lib.check(L.xr_linear_backward_weight(_ptr(dy), _ptr(mask_src), _ptr(x), M, N, K, splits, _ptr(dwp), _ptr(dbp), _stream()),
-                   'xr_linear_backward_weight')
-    if splits == 1:
-        return dwp[0], dbp[0]
-    return dwp.sum(0), dbp.sum(0)
+        _lib.check(L.xr_linear_backward_weight(C.c_void_p(dy.data_ptr()), ld, C.c_void_p(mask_src.data_ptr()) if mask_src is not None else None,
+                                               C.c_void_p(x.data_ptr()), ldx, M, N, K, splits, _ptr(part), C.c_void_p(part.data_ptr() + 4 * N * K),
+                                               N * K + N, _stream()), 'xr_linear_backward_weight')
+    g = part[0] if splits == 1 else part.sum(0)
+    return g[:N * K].view(N, K), g[N * K:]
 
 
 def linear_backward_bias(dy, mask_src):

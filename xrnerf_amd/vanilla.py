@@ -84,7 +84,24 @@ class NerfMLP(nn.Module):
         else:
             self.output_linear = nn.Linear(W, output_ch)
 
+    def _device_graph_ok(self, x):
+        W = self.pts_linears[0].weight.shape[0]
+        from . import ops
+        return (ops._on_device(x) and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] > 0 and self.use_viewdirs and len(self.views_linears) == 1
+                and self.input_ch % 4 == 0 and W % 4 == 0 and (W // 2) % 4 == 0 and (len(self.pts_linears) - 1) not in self.skips
+                and all(l.weight.shape[0] == W for l in self.pts_linears))
+
     def run_mlp(self, x):
+        if self._device_graph_ok(x):
+            # device: the whole MLP as ONE autograd node over the linear kernels, every activation in a buffer of its own layout
+            # (_NerfMlpFn below): no concatenations, splits, paddings or per-layer autograd glue between the products
+            params = []
+            for layer in self.pts_linears:
+                params += [layer.weight, layer.bias]
+            v = self.views_linears[0]
+            params += [v.weight, v.bias, self.feature_linear.weight, self.feature_linear.bias, self.alpha_linear.weight, self.alpha_linear.bias,
+                       self.rgb_linear.weight, self.rgb_linear.bias]
+            return _NerfMlpFn.apply(x, tuple(self.skips), self.input_ch, self.input_ch_dirs, *params)
         x_pts, x_dir = torch.split(x, [self.input_ch, self.input_ch_dirs], dim=-1)
         if x.is_cuda:
             # device: linear + bias + relu (and their gradients) on the fp32-MFMA kernels (xrnerf_amd/linear.py); same
@@ -128,6 +145,89 @@ class NerfMLP(nn.Module):
         data['raw'] = out.reshape(list(data['unflatten_shape']) + [out.shape[-1]])
         del data['unflatten_shape']
         return data
+
+
+class _NerfMlpFn(torch.autograd.Function):
+    """NerfMLP.run_mlp on the device (nerf_mlp.py:62-94) as one autograd node.  Same products, same order of the concatenated inputs; what is
+    gone is the glue around them (19 % of the Mip-NeRF step's GPU time in round 5: cat / split / pad copies, masked copies, two reductions per
+    layer, per-layer autograd nodes):
+      * the skip connection's [x_pts | h] is a buffer the skip layer writes its output INTO (xr_linear_forward with an output row stride);
+        the gradient of that output is the same column range of the next layer's input gradient (row stride on dy and the relu mask);
+      * feature and alpha heads are one product whose output lands in the view layer's input buffer [feature | alpha 0 0 0 | dir | 0]; the
+        view layer's weight has zero columns under alpha and the padding (exact: the products are w * 0), so nothing is concatenated;
+      * the rgb head has a fourth, zero output row; the node's output [rgb | alpha] is that product with alpha copied into column 3;
+      * every layer's weight and bias gradient come from one launch and one reduction over the M ranges (ops.linear_backward_weight_bias).
+    x: the embedded batch [M, input_ch + input_ch_dirs], rows 16-byte aligned (ops.mip_encode pads its rows for this; otherwise one copy)."""
+
+    @staticmethod
+    def forward(ctx, x, skips, ic, idr, *params):
+        from . import ops
+        D = (len(params) - 8) // 2
+        vw, vb, fw, fb, aw, ab, rw, rb = [p.detach() for p in params[2 * D:]]
+        pts = [p.detach() for p in params[:2 * D]]
+        xr, _ = ops._rows(x.detach())
+        M, W, W2 = xr.shape[0], pts[0].shape[0], vw.shape[0]
+        x_pts, x_dir = xr[:, :ic], xr[:, ic:ic + idr]
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=xr.device)
+        acts, h = [], x_pts
+        for i in range(D):
+            if i in skips:
+                cat = new(M, ic + W)
+                cat[:, :ic].copy_(x_pts)
+                y = ops.linear_forward(h, pts[2 * i], pts[2 * i + 1], True, out=cat[:, ic:])
+                acts.append((h, y))
+                h = cat
+            else:
+                y = ops.linear_forward(h, pts[2 * i], pts[2 * i + 1], True)
+                acts.append((h, y))
+                h = y
+        o_dir = W + 4
+        KV = o_dir + (idr + 3) // 4 * 4
+        V = new(M, KV)
+        wb = torch.cat([fw, aw, fw.new_zeros((3, W))], 0)
+        bb = torch.cat([fb, ab, fb.new_zeros((3,))], 0)
+        ops.linear_forward(h, wb, bb, False, out=V[:, :o_dir])
+        V[:, o_dir:o_dir + idr].copy_(x_dir)
+        if KV > o_dir + idr:
+            V[:, o_dir + idr:].zero_()
+        wv2 = vw.new_zeros((W2, KV))
+        wv2[:, :W] = vw[:, :W]
+        wv2[:, o_dir:o_dir + idr] = vw[:, W:]
+        hv = ops.linear_forward(V, wv2, vb, True)
+        wr2 = torch.cat([rw, rw.new_zeros((1, W2))], 0)
+        br2 = torch.cat([rb, rb.new_zeros((1,))], 0)
+        raw = ops.linear_forward(hv, wr2, br2, False)
+        raw[:, 3].copy_(V[:, W])
+        ctx.cfg = (tuple(skips), ic, idr, D, W, W2, o_dir, KV)
+        ctx.acts, ctx.h_last, ctx.V, ctx.hv = acts, h, V, hv
+        ctx.w = (pts, wb, wv2, wr2)
+        return raw
+
+    @staticmethod
+    def backward(ctx, d_raw):
+        from . import ops
+        skips, ic, idr, D, W, W2, o_dir, KV = ctx.cfg
+        pts, wb, wv2, wr2 = ctx.w
+        acts, V, hv = ctx.acts, ctx.V, ctx.hv
+        d_raw = d_raw.contiguous()
+        dwr2, dbr2 = ops.linear_backward_weight_bias(d_raw, None, hv)
+        dhv = ops.linear_backward_input(d_raw, None, wr2)
+        dwv2, dbv = ops.linear_backward_weight_bias(dhv, hv, V)
+        dV = ops.linear_backward_input(dhv, hv, wv2)
+        dV[:, W].copy_(d_raw[:, 3])                          # alpha's gradient joins the feature gradient: one product for both heads
+        dyb = dV[:, :o_dir]
+        dwb, dbb = ops.linear_backward_weight_bias(dyb, None, ctx.h_last)
+        dh = ops.linear_backward_input(dyb, None, wb)
+        grads = [None] * (2 * D)
+        for i in range(D - 1, -1, -1):
+            xin, y = acts[i]
+            dy = dh[:, ic:] if i in skips else dh
+            grads[2 * i], grads[2 * i + 1] = ops.linear_backward_weight_bias(dy, y, xin)
+            if i > 0:
+                dh = ops.linear_backward_input(dy, y, pts[2 * i])
+        dvw = torch.cat([dwv2[:, :W], dwv2[:, o_dir:o_dir + idr]], 1)
+        ctx.acts = ctx.h_last = ctx.V = ctx.hv = None
+        return (None, None, None, None) + tuple(grads) + (dvw, dbv, dwb[:W], dbb[:W], dwb[W:W + 1], dbb[W:W + 1], dwr2[:3], dbr2[:3])
 
 
 # ------------------------------------------------------------------ classic volume rendering
