@@ -617,7 +617,22 @@ int xr_kilo_mlp_backward(const float* pts, const float* rays_o, const float* ray
                          const float* gmax_host, const int32_t* fixed_res_host, const int32_t* occ_res_host,
                          const uint8_t* occupancy, const float* domain_mins, const float* domain_maxs, const float* params,
                          uint32_t param_stride, uint32_t num_networks, int pos_freqs, int dir_freqs, int n_hidden,
-                         const float* draw, float* grad_params, void* workspace, size_t workspace_bytes, void* stream);
+                         const float* draw, float* grad_params, int reuse_assignment, void* workspace, size_t workspace_bytes, void* stream);
+/* reuse_assignment != 0: `workspace` still holds what the xr_kilo_mlp_forward call on these very samples left there (network of every
+ * sample, the order and the segments): the backward skips the assignment / offsets / scatter launches over all n_rays * n_samples
+ * samples -- in a fine-tuning step (8192 x 384 samples of which ~1.5 % meet an occupied cell) that is most of its time.  The caller
+ * vouches that nothing else used the workspace in between (the host side keeps a generation count: xrnerf_amd/ops.py).
+ *
+ * The reference keeps ONE TENSOR PER LAYER of all networks (multi_modules.py:238-340: weight [N, in, out], bias [N, out]); the kernels
+ * take one packed block per network.  One launch each way instead of a dozen concatenations / strided copies per step:
+ *   xr_kilo_pack_params: tensors_host = 2 (n_hidden + 4) device pointers in block order -- (weight, bias) of pts_linears.*, alpha_linear,
+ *     feature_linear, direction_layer, rgb_linear, contiguous fp32 -- -> blocks [N, param_stride];
+ *   xr_kilo_unpack_grads: the gradient blocks -> one contiguous tensor per parameter (same order and shapes); clear_blocks != 0 leaves
+ *     the blocks zero-filled for the next xr_kilo_mlp_backward (which accumulates). */
+int xr_kilo_pack_params(const float* const* tensors_host, uint32_t num_networks, int pos_freqs, int dir_freqs, int n_hidden, float* blocks,
+                        uint32_t param_stride, void* stream);
+int xr_kilo_unpack_grads(float* blocks, uint32_t param_stride, uint32_t num_networks, int pos_freqs, int dir_freqs, int n_hidden,
+                         float* const* grads_host, int clear_blocks, void* stream);
 /* One frame (or chunk) of the reference's KiloNeRF test path in one call, for the real-time bench: GetZvals (not
  * randomized; datasets/pipelines/create.py:486-531) + GetPts + KiloNerfMLP.forward + NerfRender.forward.  Same values
  * as xr_mip_zvals -> xr_kilo_mlp_forward -> xr_nerf_render_forward, but no [n_rays, n_samples] tensor other than the

@@ -141,7 +141,9 @@ SIGNATURES = {
     'xr_kilo_mlp_forward': (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32,
                                    _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     'xr_kilo_mlp_backward': (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32,
-                                    _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
+                                    _i32, _i32, _i32, _vp, _vp, _i32, _vp, _sz, _vp]),
+    'xr_kilo_pack_params': (_i32, [_vp, _u32, _i32, _i32, _i32, _vp, _u32, _vp]),
+    'xr_kilo_unpack_grads': (_i32, [_vp, _u32, _u32, _i32, _i32, _i32, _vp, _i32, _vp]),
     'xr_nerf_render_forward': (_i32, [_vp, _vp, _vp, _u32, _u32, _i32, _vp, _vp, _vp, _vp, _vp]),
     'xr_nerf_density_splat': (_i32, [_i32, _vp, _u32, _u32, _vp, _i32, _i32, _vp, _vp, _vp]),
     'xr_linear_forward': (_i32, [_vp, _u32, _vp, _vp, _u32, _u32, _u32, _i32, _vp, _u32, _vp]),

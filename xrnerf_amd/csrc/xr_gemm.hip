@@ -632,7 +632,10 @@ extern "C" uint32_t xr_linear_backward_splits(uint32_t M, uint32_t N, uint32_t K
 // thread = 4 consecutive columns, workgroup = 64 column groups x 4 row phases; 16-byte loads, coalesced along N.
 __global__ void __launch_bounds__(256) k_masked_colsum(const float* __restrict__ dy, const float* __restrict__ mask,
                                                        uint32_t M, uint32_t N, uint32_t rows_per_split,
-                                                       float* __restrict__ out) {
+                                                       float* __restrict__ out, uint32_t ld = 0 /* row stride of dy / mask, 0 = N */,
+                                                       size_t out_stride = 0 /* floats between two splits' sums, 0 = N */) {
+    if (ld == 0) ld = N;
+    if (out_stride == 0) out_stride = N;
     __shared__ float4 s_part[256];
     const uint32_t cg = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
     const uint32_t r0 = blockIdx.y * rows_per_split;
@@ -640,7 +643,7 @@ __global__ void __launch_bounds__(256) k_masked_colsum(const float* __restrict__
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (cg * 4 < N) {
         for (uint32_t r = r0 + ph; r < r1; r += 4) {
-            const size_t off = (size_t)r * N + cg * 4;
+            const size_t off = (size_t)r * ld + cg * 4;
             float4 v = *reinterpret_cast<const float4*>(dy + off);
             if (mask != nullptr) {
                 const float4 m = *reinterpret_cast<const float4*>(mask + off);
@@ -654,7 +657,7 @@ __global__ void __launch_bounds__(256) k_masked_colsum(const float* __restrict__
     if (ph == 0 && cg * 4 < N) {
         float4 t = s_part[threadIdx.x];
         for (int p = 1; p < 4; ++p) { const float4 o = s_part[threadIdx.x + 64 * p]; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
-        *reinterpret_cast<float4*>(out + (size_t)blockIdx.y * N + cg * 4) = t;
+        *reinterpret_cast<float4*>(out + (size_t)blockIdx.y * out_stride + cg * 4) = t;
     }
 }
 
@@ -684,14 +687,13 @@ extern "C" int xr_linear_backward_weight(const float* dy, uint32_t lddy, const f
     XR_REQUIRE(lddy >= N && ldx >= K && part_stride >= (size_t)N * K && part_stride % 4 == 0, "bad stride");
     const char* env = getenv("XR_GEMM_F32");
     if (db_partials && env && strcmp(env, "bf16x3all") == 0) {   // that measurement mode has no column sums in its kernel: two launches
-        XR_REQUIRE(lddy == N && part_stride == (size_t)N * K, "the bf16x3all measurement mode takes dense operands");
-        GemmArgs g0{dy, x, dw_partials, nullptr, mask_src, N, K, M, N, K, K, 1, 1, 0, 0, (size_t)N * K, 0, nullptr};
+        GemmArgs g0{dy, x, dw_partials, nullptr, mask_src, N, K, M, lddy, ldx, K, 1, 1, 0, 0, part_stride, 0, nullptr};
         const int rc = gemm_launch(g0, splits, stream);
         if (rc != XR_OK) return rc;
         // per-split column sums over the same M ranges: k_masked_colsum with `splits` row ranges of k_per_split rows
         const uint32_t rows = (uint32_t)(((uint64_t)(M + splits - 1) / splits + GBK - 1) / GBK * GBK);
         hipLaunchKernelGGL(k_masked_colsum, dim3(xr_div_up(N / 4, 64), splits), dim3(256), 0, (hipStream_t)stream, dy, mask_src, M, N, rows ? rows : 1,
-                           db_partials);
+                           db_partials, lddy, db_partials == dw_partials + (size_t)N * K ? part_stride : (size_t)N);
         XR_LAUNCH_CHECK();
         return XR_OK;
     }

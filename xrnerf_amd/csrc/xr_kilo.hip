@@ -707,7 +707,8 @@ static int kilo_mlp_launch(const KiloRays& rays, const float* gmin_host, const f
                            const float* domain_maxs, const float* params, uint32_t param_stride, uint32_t num_networks,
                            int pos_freqs, int dir_freqs, int n_hidden, float* raw, bool dense, uint32_t* counts_out,
                            void* workspace, size_t workspace_bytes, hipStream_t st, KiloWs* ws_out,
-                           const float* draw = nullptr, float* grad = nullptr /* non-null: gradients instead of raw */) {
+                           const float* draw = nullptr, float* grad = nullptr /* non-null: gradients instead of raw */,
+                           bool reuse_assignment = false /* the workspace still holds the assignment / order / segments of these very samples */) {
     // per-ray spans: only where the z lattice is evaluated on the fly and nothing dense is promised to the caller
     const bool use_spans = !dense && rays.pts == nullptr && rays.z_vals == nullptr;
     const bool backward = grad != nullptr;
@@ -743,6 +744,7 @@ static int kilo_mlp_launch(const KiloRays& rays, const float* gmin_host, const f
     KiloWs ws;
     kilo_ws_layout(n, num_networks, use_spans ? rays.n_rays : 0, (char*)workspace, &ws);
     if (ws_out) *ws_out = ws;
+    if (!reuse_assignment) {
     XR_HIP(hipMemsetAsync(ws.counts, 0, (size_t)num_networks * 4, st));
     // work per workgroup: the per-workgroup histogram costs ~3 passes over the bins, so give each one enough samples
     // (span mode: per_block counts rays)
@@ -765,6 +767,7 @@ static int kilo_mlp_launch(const KiloRays& rays, const float* gmin_host, const f
     hipLaunchKernelGGL(k_kilo_scatter, dim3(blocks), dim3(threads), hist_lds, st, ws.net_of, num_networks, n, per_block,
                        ws.spans, rays.n_s, rays.n_rays, ws.seg_start, ws.cursor, ws.order);
     XR_LAUNCH_CHECK();
+    }
     KiloMlpArgs a{rays, domain_mins, domain_maxs, params, param_stride, num_networks, pos_freqs, dir_freqs, n_hidden,
                   ws.seg_start, ws.tile_start, ws.order, reinterpret_cast<float4*>(raw)};
     const uint64_t max_tiles = n / KILO_TILE + num_networks;
@@ -806,14 +809,90 @@ extern "C" int xr_kilo_mlp_backward(const float* pts, const float* rays_o, const
                                     const float* gmax_host, const int32_t* fixed_res_host, const int32_t* occ_res_host,
                                     const uint8_t* occupancy, const float* domain_mins, const float* domain_maxs,
                                     const float* params, uint32_t param_stride, uint32_t num_networks, int pos_freqs,
-                                    int dir_freqs, int n_hidden, const float* draw, float* grad_params, void* workspace,
+                                    int dir_freqs, int n_hidden, const float* draw, float* grad_params, int reuse_assignment, void* workspace,
                                     size_t workspace_bytes, void* stream) {
     if ((uint64_t)n_rays * n_samples == 0) return XR_OK;
     XR_REQUIRE(grad_params != nullptr, "null pointer");
     KiloRays rays{pts, rays_o, rays_d, z_vals, viewdirs, n_rays, n_samples, nullptr, nullptr, 0};
     return kilo_mlp_launch(rays, gmin_host, gmax_host, fixed_res_host, occ_res_host, occupancy, domain_mins, domain_maxs,
                            params, param_stride, num_networks, pos_freqs, dir_freqs, n_hidden, nullptr, false, nullptr,
-                           workspace, workspace_bytes, (hipStream_t)stream, nullptr, draw, grad_params);
+                           workspace, workspace_bytes, (hipStream_t)stream, nullptr, draw, grad_params, reuse_assignment != 0);
+}
+
+// ------------------------------------------------------------------------------------------ parameter blocks <-> the reference's tensors
+// The reference keeps one tensor per layer of ALL networks (multi_modules.py:238-340: weight [N, in, out], bias [N, out]); the kernels
+// above take one packed block per network.  Going from one form to the other was a dozen torch.cat / slice-copy launches per fine-tuning
+// step in each direction; here it is one launch each: a thread per packed float finds its segment in a 16-entry table.
+#define KILO_MAX_SEGS 16
+struct KiloSegs {
+    float* t[KILO_MAX_SEGS];                // tensor of the segment (nullptr: padding)
+    uint32_t off[KILO_MAX_SEGS + 1];        // first packed float of the segment
+    uint32_t cols[KILO_MAX_SEGS];           // floats per network in the tensor
+    uint32_t rgbw[KILO_MAX_SEGS];           // != 0: the rgb weight, [H, 3] in the tensor, [H, 4] (4th column zero) in the block
+    uint32_t n_seg, n_floats;
+};
+static int kilo_segments(float* const* tensors, int pos_freqs, int dir_freqs, int n_hidden, KiloSegs* out) {
+    const uint32_t P = 3u * (2u * pos_freqs + 1u), D = 3u * (2u * dir_freqs + 1u), H = KILO_H;
+    KiloSegs& S = *out;
+    uint32_t n = 0, off = 0;
+    auto seg = [&](float* t, uint32_t width, uint32_t cols, uint32_t rgbw) { S.t[n] = t; S.off[n] = off; S.cols[n] = cols; S.rgbw[n] = rgbw; off += width; ++n; };
+    int k = 0;
+    for (int l = 0; l < n_hidden; ++l) { const uint32_t in = l == 0 ? P : H; seg(tensors[k], in * H, in * H, 0); seg(tensors[k + 1], H, H, 0); k += 2; }
+    seg(tensors[k], H, H, 0); seg(tensors[k + 1], 1, 1, 0); seg(nullptr, 3, 0, 0); k += 2;            // alpha: W, b, 3 pad
+    seg(tensors[k], H * H, H * H, 0); seg(tensors[k + 1], H, H, 0); k += 2;                            // feature
+    seg(tensors[k], (H + D) * H, (H + D) * H, 0); seg(tensors[k + 1], H, H, 0); k += 2;                // direction
+    seg(tensors[k], H * 4, H * 3, 1); seg(tensors[k + 1], 3, 3, 0); seg(nullptr, 1, 0, 0);             // rgb: W (3 -> 4 columns), b, 1 pad
+    S.off[n] = off; S.n_seg = n; S.n_floats = off;
+    return off == kilo_param_floats(pos_freqs, dir_freqs, n_hidden) && n <= KILO_MAX_SEGS ? XR_OK : XR_EINVAL;
+}
+template <bool UNPACK>
+__global__ void __launch_bounds__(256) k_kilo_repack(KiloSegs S, float* __restrict__ blocks, uint32_t param_stride, uint32_t num_networks, int clear) {
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+    if (e >= S.n_floats) return;
+    uint32_t s = 0;
+    while (s + 1 < S.n_seg && e >= S.off[s + 1]) ++s;
+    const uint32_t idx = e - S.off[s];
+    float* b = blocks + (size_t)n * param_stride + e;
+    float* t = S.t[s];
+    size_t src = 0;
+    bool has = t != nullptr;
+    if (has) {
+        if (S.rgbw[s]) { has = (idx & 3u) != 3u; src = (size_t)n * S.cols[s] + (idx >> 2) * 3u + (idx & 3u); }
+        else src = (size_t)n * S.cols[s] + idx;
+    }
+    if (UNPACK) {
+        if (has) t[src] = *b;
+        if (clear) *b = 0.f;
+    } else {
+        *b = has ? t[src] : 0.f;
+    }
+}
+static int kilo_repack(bool unpack, float* const* tensors_host, uint32_t num_networks, int pos_freqs, int dir_freqs, int n_hidden, float* blocks,
+                       uint32_t param_stride, int clear, void* stream) {
+    XR_REQUIRE(tensors_host && blocks && num_networks >= 1 && num_networks <= 65535, "null pointer / network count");
+    XR_REQUIRE(pos_freqs >= 0 && pos_freqs <= 16 && dir_freqs >= 0 && dir_freqs <= 16 && n_hidden >= 1 && 2 * n_hidden + 11 <= KILO_MAX_SEGS, "architecture out of range");
+    for (int k = 0; k < 2 * (n_hidden + 4); ++k) XR_REQUIRE(tensors_host[k] != nullptr, "null parameter tensor");
+    KiloSegs S;
+    XR_REQUIRE(kilo_segments(tensors_host, pos_freqs, dir_freqs, n_hidden, &S) == XR_OK, "segment table does not match the block layout");
+    XR_REQUIRE(param_stride >= S.n_floats, "param_stride too small");
+    const dim3 grid(xr_div_up(S.n_floats, 256), num_networks);
+    if (unpack) hipLaunchKernelGGL(k_kilo_repack<true>, grid, dim3(256), 0, (hipStream_t)stream, S, blocks, param_stride, num_networks, clear);
+    else hipLaunchKernelGGL(k_kilo_repack<false>, grid, dim3(256), 0, (hipStream_t)stream, S, blocks, param_stride, num_networks, 0);
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}
+// tensors_host: 2 (n_hidden + 4) device pointers in MultiNetwork.ordered_parameters() order (weight, bias of pts_linears.*, alpha, feature,
+// direction, rgb; contiguous fp32) -> blocks [N, param_stride]
+extern "C" int xr_kilo_pack_params(const float* const* tensors_host, uint32_t num_networks, int pos_freqs, int dir_freqs, int n_hidden,
+                                   float* blocks, uint32_t param_stride, void* stream) {
+    return kilo_repack(false, const_cast<float* const*>(reinterpret_cast<const float* const*>(tensors_host)), num_networks, pos_freqs, dir_freqs,
+                       n_hidden, blocks, param_stride, 0, stream);
+}
+// the packed gradient blocks -> one tensor per parameter (same order and shapes); clear_blocks != 0 leaves the blocks zero-filled for the
+// next xr_kilo_mlp_backward, which accumulates into them
+extern "C" int xr_kilo_unpack_grads(float* blocks, uint32_t param_stride, uint32_t num_networks, int pos_freqs, int dir_freqs, int n_hidden,
+                                    float* const* grads_host, int clear_blocks, void* stream) {
+    return kilo_repack(true, grads_host, num_networks, pos_freqs, dir_freqs, n_hidden, blocks, param_stride, clear_blocks, stream);
 }
 
 extern "C" size_t xr_kilo_render_workspace_bytes(uint32_t n_rays, uint32_t n_samples, uint32_t num_networks) {

@@ -270,17 +270,34 @@ class _KiloMlpFn(torch.autograd.Function):
     one forward call, one backward call (xr_kilo_mlp_backward) that re-runs the tiny MLPs and accumulates the packed
     gradient blocks; sample positions / directions carry no gradient (they are data)"""
 
+    _grad_blocks = {}          # (device, N, stride) -> a zero-filled gradient block buffer (the unpack launch leaves it zero again)
+
     @staticmethod
     def forward(ctx, args, tail, kw, *params):
-        packed = MultiNetwork.pack([p.detach() for p in params])
-        ctx.args, ctx.tail, ctx.kw, ctx.packed, ctx.params = args, tail, kw, packed, params
-        return ops.kilo_mlp_forward(*args, packed, *tail, **kw)
+        on_dev = ops._on_device(params[0]) and hasattr(_lib_handle(), 'xr_kilo_pack_params')
+        packed = ops.kilo_pack_params(params, *tail) if on_dev else MultiNetwork.pack([p.detach() for p in params])
+        ctx.args, ctx.tail, ctx.kw, ctx.packed, ctx.params, ctx.native = args, tail, kw, packed, params, on_dev
+        raw = ops.kilo_mlp_forward(*args, packed, *tail, **kw)
+        ctx.ws_gen = ops.kilo_ws_generation()      # the workspace holds these samples' assignment until the next kilo call
+        return raw
 
     @staticmethod
     def backward(ctx, draw):
-        g = ops.kilo_mlp_backward(draw.contiguous(), *ctx.args, ctx.packed, *ctx.tail, **ctx.kw)
-        grads = MultiNetwork.unpack_like(g, ctx.params)
+        if not ctx.native:
+            g = ops.kilo_mlp_backward(draw.contiguous(), *ctx.args, ctx.packed, *ctx.tail, **ctx.kw)
+            return (None, None, None) + tuple(MultiNetwork.unpack_like(g, ctx.params))
+        key = (str(ctx.packed.device), ) + tuple(ctx.packed.shape)
+        buf = _KiloMlpFn._grad_blocks.get(key)
+        if buf is None:
+            buf = _KiloMlpFn._grad_blocks[key] = torch.zeros_like(ctx.packed)
+        ops.kilo_mlp_backward(draw.contiguous(), *ctx.args, ctx.packed, *ctx.tail, reuse_generation=ctx.ws_gen, grad=buf, **ctx.kw)
+        grads = ops.kilo_unpack_grads(buf, ctx.params, *ctx.tail, clear=True)
         return (None, None, None) + tuple(grads)
+
+
+def _lib_handle():
+    from . import _lib
+    return _lib.load()
 
 
 @NETWORKS.register_module()

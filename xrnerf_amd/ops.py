@@ -1190,6 +1190,42 @@ def kilo_param_floats(pos_freqs, dir_freqs, n_hidden):
     return int(_lib.load().xr_kilo_param_floats(pos_freqs, dir_freqs, n_hidden))
 
 
+_KILO_WS_GEN = [0]        # bumped by every call that rewrites the 'kilo' workspace's assignment arrays
+
+
+def kilo_ws_generation():
+    return _KILO_WS_GEN[0]
+
+
+def kilo_pack_params(tensors, pos_freqs, dir_freqs, n_hidden, out=None):
+    """MultiNetwork.ordered_parameters() -> the packed blocks [N, stride] the kernels take, in one launch (xr_kilo_pack_params)"""
+    L = _lib.load()
+    N = tensors[0].shape[0]
+    stride = int(L.xr_kilo_param_floats(int(pos_freqs), int(dir_freqs), int(n_hidden)))
+    ts = [_f32c(t.detach()) for t in tensors]
+    if out is None:
+        out = torch.empty((N, stride), dtype=torch.float32, device=ts[0].device)
+    arr = (C.c_void_p * len(ts))(*[_ptr(t).value for t in ts])
+    _lib.check(L.xr_kilo_pack_params(arr, N, int(pos_freqs), int(dir_freqs), int(n_hidden), _ptr(out), out.stride(0), _stream()), 'xr_kilo_pack_params')
+    return out
+
+
+def kilo_unpack_grads(blocks, like, pos_freqs, dir_freqs, n_hidden, clear=True):
+    """the packed gradient blocks -> one contiguous tensor per parameter of `like` (views of ONE allocation), in one launch; clear: the
+    blocks are left zero-filled for the next backward"""
+    L = _lib.load()
+    sizes = [t.numel() for t in like]
+    flat = torch.empty((sum(sizes),), dtype=torch.float32, device=blocks.device)
+    outs, o = [], 0
+    for t, n in zip(like, sizes):
+        outs.append(flat[o:o + n].view(t.shape))
+        o += n
+    arr = (C.c_void_p * len(outs))(*[t.data_ptr() for t in outs])
+    _lib.check(L.xr_kilo_unpack_grads(_ptr(blocks), blocks.stride(0), blocks.shape[0], int(pos_freqs), int(dir_freqs), int(n_hidden), arr,
+                                      1 if clear else 0, _stream()), 'xr_kilo_unpack_grads')
+    return outs
+
+
 def kilo_mlp_forward(viewdirs, gmin, gmax, fixed_res, occ_res, occupancy, domain_mins, domain_maxs, params, pos_freqs,
                      dir_freqs, n_hidden, pts=None, rays_o=None, rays_d=None, z_vals=None, want_counts=False):
     """KiloNerfMLP.forward: raw [R,S,4] (zeros where no network is evaluated) (+ batch_size_per_network [N] int32).
@@ -1208,6 +1244,7 @@ def kilo_mlp_forward(viewdirs, gmin, gmax, fixed_res, occ_res, occupancy, domain
     raw = torch.empty((R, S, 4), dtype=torch.float32, device=dev)
     counts = torch.empty((N,), dtype=torch.int32, device=dev) if want_counts else None
     ws = _ws(dev, L.xr_kilo_workspace_bytes(R * S, N), 'kilo')
+    _KILO_WS_GEN[0] += 1              # the workspace now holds THIS call's assignment (kilo_mlp_backward(reuse=...) checks the count)
     if occupancy is not None:
         occupancy = occupancy.reshape(-1)
         if occupancy.dtype == torch.bool:
@@ -1227,8 +1264,10 @@ def kilo_mlp_forward(viewdirs, gmin, gmax, fixed_res, occ_res, occupancy, domain
 
 
 def kilo_mlp_backward(draw, viewdirs, gmin, gmax, fixed_res, occ_res, occupancy, domain_mins, domain_maxs, params, pos_freqs,
-                      dir_freqs, n_hidden, pts=None, rays_o=None, rays_d=None, z_vals=None):
-    """gradient of the packed parameter blocks [N, stride] for dL/draw [R,S,4] (same sample arguments as the forward)"""
+                      dir_freqs, n_hidden, pts=None, rays_o=None, rays_d=None, z_vals=None, reuse_generation=None, grad=None):
+    """gradient of the packed parameter blocks [N, stride] for dL/draw [R,S,4] (same sample arguments as the forward).
+    reuse_generation: kilo_ws_generation() as it stood right after the forward call on these samples -- if nothing has touched the
+    workspace since, the assignment / offsets / scatter launches are skipped.  grad: a zero-filled [N, stride] buffer to accumulate into."""
     L = _lib.load()
     draw = _f32c(draw)
     if pts is not None:
@@ -1239,8 +1278,12 @@ def kilo_mlp_backward(draw, viewdirs, gmin, gmax, fixed_res, occ_res, occupancy,
         R, S = z_vals.shape
     dev = draw.device
     N = params.shape[0]
-    grad = torch.zeros_like(params)
+    if grad is None:
+        grad = torch.zeros_like(params)
     ws = _ws(dev, L.xr_kilo_workspace_bytes(R * S, N), 'kilo')
+    reuse = reuse_generation is not None and reuse_generation == _KILO_WS_GEN[0]
+    if not reuse:
+        _KILO_WS_GEN[0] += 1
     if occupancy is not None:
         occupancy = occupancy.reshape(-1)
         if occupancy.dtype == torch.bool:
@@ -1253,7 +1296,7 @@ def kilo_mlp_backward(draw, viewdirs, gmin, gmax, fixed_res, occ_res, occupancy,
                                           i3(*[int(v) for v in fixed_res]), i3(*[int(v) for v in occ_res]) if occ_res is not None else None,
                                           _ptr(occupancy), _ptr(_f32c(domain_mins)), _ptr(_f32c(domain_maxs)), _ptr(params),
                                           params.stride(0), N, int(pos_freqs), int(dir_freqs), int(n_hidden), _ptr(draw),
-                                          _ptr(grad), _ptr(ws), ws.numel(), _stream()), 'xr_kilo_mlp_backward')
+                                          _ptr(grad), 1 if reuse else 0, _ptr(ws), ws.numel(), _stream()), 'xr_kilo_mlp_backward')
     return grad
 
 
