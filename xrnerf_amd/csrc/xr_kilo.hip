@@ -463,8 +463,10 @@ __device__ __forceinline__ void kfourier_to_lds(float* __restrict__ T, float x, 
     }
 }
 
+#define KB_WAVES 4                               // waves per workgroup = 32-sample parts of a 128-sample tile (round 6: four waves side by side
+                                                 // instead of two waves taking two parts each in turn -- the kernel is one long dependent MFMA chain per wave)
 template <int NH>
-__global__ void __launch_bounds__(128) k_kilo_mlp_bwd(KiloBwdArgs b) {
+__global__ void __launch_bounds__(64 * KB_WAVES) k_kilo_mlp_bwd(KiloBwdArgs b) {
     extern __shared__ float s_w[];                      // [parameter block | per-wave tiles]
     __shared__ uint32_t s_net;
     const KiloMlpArgs& a = b.f;
@@ -494,15 +496,16 @@ __global__ void __launch_bounds__(128) k_kilo_mlp_bwd(KiloBwdArgs b) {
         {
             const float4* src = reinterpret_cast<const float4*>(a.params + (size_t)net * a.param_stride);
             float4* dst = reinterpret_cast<float4*>(s_w);
-            for (uint32_t q = threadIdx.x; q < n_floats / 4; q += 128) dst[q] = src[q];
+            for (uint32_t q = threadIdx.x; q < n_floats / 4; q += 64 * KB_WAVES) dst[q] = src[q];
         }
         __syncthreads();
         const float* w = s_w;
         float* g = b.grad + (size_t)net * a.param_stride;
         const uint32_t seg0 = a.seg_start[net], seg1 = a.seg_start[net + 1];
-        for (int part = 0; part < 2; ++part) {
-            const uint32_t wave0 = seg0 + (tile - a.tile_start[net]) * KILO_TILE + part * 64 + wave * 32;
-            if (wave0 >= seg1) break;
+        static_assert(KB_WAVES * 32 == KILO_TILE, "one 32-sample part per wave");
+        {
+            const uint32_t wave0 = seg0 + (tile - a.tile_start[net]) * KILO_TILE + wave * 32;
+            if (wave0 >= seg1) continue;                // (uniform per wave; the loop's barriers are at its top, every wave reaches them)
             const uint32_t slot = wave0 + col;
             const bool live = slot < seg1;
             const uint32_t i = a.order[live ? slot : seg1 - 1];
@@ -778,9 +781,16 @@ static int kilo_mlp_launch(const KiloRays& rays, const float* gmin_host, const f
         hipLaunchKernelGGL(k_kilo_mlp, dim3(grid), dim3(256), (size_t)n_floats * 4, st, a);
     } else {
         KiloBwdArgs bw{a, reinterpret_cast<const float4*>(draw), grad};
-        const size_t lds = (size_t)n_floats * 4 + 2 * (size_t)KB_WAVE_FLOATS * 4;
-        if (n_hidden == 1) hipLaunchKernelGGL(k_kilo_mlp_bwd<1>, dim3(grid), dim3(128), lds, st, bw);
-        else hipLaunchKernelGGL(k_kilo_mlp_bwd<2>, dim3(grid), dim3(128), lds, st, bw);
+        const size_t lds = (size_t)n_floats * 4 + (size_t)KB_WAVES * KB_WAVE_FLOATS * 4;
+        static bool attr = false;
+        if (!attr) {
+            XR_HIP(hipFuncSetAttribute((const void*)k_kilo_mlp_bwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            XR_HIP(hipFuncSetAttribute((const void*)k_kilo_mlp_bwd<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            attr = true;
+        }
+        XR_REQUIRE(lds <= 96 * 1024, "parameter block + the waves' tiles do not fit the LDS");
+        if (n_hidden == 1) hipLaunchKernelGGL(k_kilo_mlp_bwd<1>, dim3(grid), dim3(64 * KB_WAVES), lds, st, bw);
+        else hipLaunchKernelGGL(k_kilo_mlp_bwd<2>, dim3(grid), dim3(64 * KB_WAVES), lds, st, bw);
     }
     XR_LAUNCH_CHECK();
     if (counts_out != nullptr)

@@ -1190,7 +1190,7 @@ def kilo_param_floats(pos_freqs, dir_freqs, n_hidden):
     return int(_lib.load().xr_kilo_param_floats(pos_freqs, dir_freqs, n_hidden))
 
 
-_KILO_WS_GEN = [0]        # bumped by every call that rewrites the 'kilo' workspace's assignment arrays
+_KILO_WS_GEN = [0, 0]     # [count bumped by every call that rewrites the 'kilo' workspace's assignment arrays, that workspace's address]
 
 
 def kilo_ws_generation():
@@ -1244,7 +1244,8 @@ def kilo_mlp_forward(viewdirs, gmin, gmax, fixed_res, occ_res, occupancy, domain
     raw = torch.empty((R, S, 4), dtype=torch.float32, device=dev)
     counts = torch.empty((N,), dtype=torch.int32, device=dev) if want_counts else None
     ws = _ws(dev, L.xr_kilo_workspace_bytes(R * S, N), 'kilo')
-    _KILO_WS_GEN[0] += 1              # the workspace now holds THIS call's assignment (kilo_mlp_backward(reuse=...) checks the count)
+    _KILO_WS_GEN[0] += 1              # the workspace now holds THIS call's assignment (kilo_mlp_backward(reuse=...) checks the count
+    _KILO_WS_GEN[1] = ws.data_ptr()   # ... and that it is handed the same memory)
     if occupancy is not None:
         occupancy = occupancy.reshape(-1)
         if occupancy.dtype == torch.bool:
@@ -1281,7 +1282,7 @@ def kilo_mlp_backward(draw, viewdirs, gmin, gmax, fixed_res, occ_res, occupancy,
     if grad is None:
         grad = torch.zeros_like(params)
     ws = _ws(dev, L.xr_kilo_workspace_bytes(R * S, N), 'kilo')
-    reuse = reuse_generation is not None and reuse_generation == _KILO_WS_GEN[0]
+    reuse = reuse_generation is not None and reuse_generation == _KILO_WS_GEN[0] and ws.data_ptr() == _KILO_WS_GEN[1]
     if not reuse:
         _KILO_WS_GEN[0] += 1
     if occupancy is not None:
