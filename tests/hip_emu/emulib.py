@@ -146,9 +146,15 @@ class emulated_ops:
             return C.c_void_p(t.data_ptr())
 
         def ws(device, nbytes, tag):
-            raw = torch.empty(max(int(nbytes), 256) + 256, dtype=torch.uint8)
-            off = (-raw.data_ptr()) % 256
-            return raw[off:off + max(int(nbytes), 256)]
+            # persistent per tag and grow-only, like ops._ws: callers rely on a workspace keeping its contents between two entry
+            # points (the KiloNeRF backward reuses the forward's assignment arrays; the mlpbwd block holds running totals)
+            key, need = (str(device), tag), max(int(nbytes), 256)
+            w = ops._workspaces.get(key)
+            if w is None or w.numel() < need:
+                raw = torch.zeros(need + 256, dtype=torch.uint8)
+                off = (-raw.data_ptr()) % 256
+                w = ops._workspaces[key] = raw[off:off + need]
+            return w
 
         def check(rc, what=''):
             if rc != 0:

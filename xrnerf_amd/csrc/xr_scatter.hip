@@ -507,7 +507,10 @@ __global__ __launch_bounds__(TH) void k_scatter_accum3(S3Plan pl, const uint32_t
     }
     // fused optimiser update, hashed levels: this thread's 8 entries are 4 pairs of neighbours (16 B of p / m / v / ema each), taken
     // in two rounds of two pairs; the first round's loads go out before the barrier that waits for every wave's LDS atomics
-    constexpr uint32_t FP = ENTRIES / (2 * THREADS), FH = 2, ROUNDS = FP / FH;
+    // (round 6: with 8 waves the whole partition's optimiser state -- 8 pairs x (p, m, v, ema) = 128 VGPRs -- is requested before the
+    // barrier, one round instead of four dependent ones: 254 VGPRs, no spill, -2..3 us per launch in the loop; with 16 waves that
+    // would spill, so they keep the rounds of two pairs.  profiles/r06_scatter_counters.txt)
+    constexpr uint32_t FP = ENTRIES / (2 * THREADS), FH = THREADS <= 512 ? FP : 2, ROUNDS = FP / FH;
     static_assert(FP % FH == 0 && ROUNDS >= 1, "rounds of two pairs");
     const bool fuse_h = pl.fuse != 0u && L.kind == S3_H;
     float4 fp_[FH], fm_[FH], fv_[FH], fq_[FH];
