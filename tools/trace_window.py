@@ -1,9 +1,12 @@
-"""print the kernel sequence of the last full training iteration (between the last two k_adam_multi) from a
+"""print the kernel sequence of one full training iteration (between two end-of-iteration kernels) from a
 rocprofv3 kernel_trace.csv: start offset, duration, queue, name"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'k_adam_multi' in r['Kernel_Name']]
+# an iteration ends with the table scatter's fold kernel (round 6: one in-order stream, the MLP tensors' update rides inside the scatter's
+# binning launch); traces of earlier rounds end it with the k_adam_multi launch of the helper stream
+_last = 'k_scatter_fold' if any('k_scatter_fold' in r['Kernel_Name'] for r in rows) else 'k_adam_multi'
+idx = [i for i, r in enumerate(rows) if _last in r['Kernel_Name']]
 arg = sys.argv[2] if len(sys.argv) > 2 else '-2'
 if arg == 'spans':            # one line per window: its span and the longest kernel in it (to find the steady state)
     for w in range(1, len(idx)):

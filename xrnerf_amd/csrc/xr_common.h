@@ -133,7 +133,3 @@ int xr_internal_hashgrid_bwd_adam_supported(uint32_t n, int n_levels, const floa
 // library-internal (not part of the C ABI): see xr_mlp.hip
 void xr_internal_defer_mlp_reduce(bool on);
 int xr_internal_mlp_bwd_reduce(const void* workspace, uint32_t n, int n_hidden_density, int n_hidden_color, float* grad_w_density, float* grad_w_color, int overwrite, void* stream);
-// see xr_scatter.hip: work the next xr_scatter3 call of this thread enqueues on its helper stream right after forking it (in
-// front of its own helper-stream kernels); `done` tells the caller whether a fork happened.  nullptr clears.
-struct XrAuxPrologue { int (*fn)(hipStream_t, void*); void* arg; bool done; };
-void xr_internal_scatter_aux_prologue(XrAuxPrologue* p);

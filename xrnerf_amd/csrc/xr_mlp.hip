@@ -33,6 +33,7 @@
 //     output row m for m<16, so density_out registers feed the color net in place and its input
 //     gradient lands back on the density-output registers with no data movement either.
 #include "xr_common.h"
+#include "xr_aux.h"
 #include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -1033,28 +1034,10 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict
                                                           uint32_t split, float* __restrict__ g_density,
                                                           float* __restrict__ g_color, int overwrite = 0) {
     __shared__ float red[4][64];
-    const uint32_t c = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const uint32_t j = blockIdx.x * 64 + c;
-    float s = 0.f;
-    if (j < gw) {
-        // 16 loads in flight, summed in the same fixed order (a plain loop exposes one memory latency per term)
-        uint32_t b = rg;
-        for (; b + 4 * 15 < nb; b += 4 * 16) {
-            float v[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = partial[(size_t)(b + 4 * u) * gw + j];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) s += v[u];
-        }
-        for (; b < nb; b += 4) s += partial[(size_t)b * gw + j];
-    }
-    red[rg][c] = s;
-    __syncthreads();
-    if (rg == 0 && j < gw) {
-        const float t = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
-        // overwrite: the sums REPLACE what the buffers held (xr_ngp_train_step: no zero-fill of its gradient buffers)
-        if (j < split) g_density[j] = overwrite ? t : g_density[j] + t; else g_color[j - split] = overwrite ? t : g_color[j - split] + t;
-    }
+    XrAuxWork w;                                   // (xr_aux.h: the one definition of this sum; the training step runs it inside
+    w.partial = partial; w.nb = nb; w.gw = gw; w.split = split; w.g0 = g_density; w.g1 = g_color;     //  the table scatter's binning launch)
+    w.overwrite = overwrite; w.adam = 0;
+    xr_aux_reduce_block<256>(w, blockIdx.x, red);
 }
 
 // ------------------------------------------------------------------ generic single network
@@ -2464,6 +2447,18 @@ int xr_internal_mlp_bwd_reduce(const void* workspace, uint32_t n, int nhd, int n
     hipLaunchKernelGGL(k_reduce_partials, dim3(xr_div_up(GW, 64)), dim3(256), 0, (hipStream_t)stream_, (const float*)bwd_partials(workspace, n),
                        deep ? bwd_grid_deep(n) : bwd_grid(n), GW, gwd, grad_w_density, grad_w_color, overwrite);
     XR_LAUNCH_CHECK();
+    return XR_OK;
+}
+
+// the same sum as (1) of an XrAuxWork (xr_aux.h): the caller's launch runs it (overwrite / adam are the caller's to set)
+int xr_internal_mlp_bwd_reduce_desc(const void* workspace, uint32_t n, int nhd, int nhc, XrAuxWork* w) {
+    XR_REQUIRE(workspace && w, "null pointer");
+    const bool deep = bwd_is_deep(nhd, nhc);
+    const uint32_t gwd = deep ? (uint32_t)deep_glb_floats(nhd) : (uint32_t)NetShape<1>::glb_floats;
+    w->partial = (const float*)bwd_partials(const_cast<void*>(workspace), n);
+    w->nb = deep ? bwd_grid_deep(n) : bwd_grid(n);
+    w->gw = gwd + (deep ? (uint32_t)deep_glb_floats(nhc) : (uint32_t)NetShape<2>::glb_floats);
+    w->split = gwd;
     return XR_OK;
 }
 

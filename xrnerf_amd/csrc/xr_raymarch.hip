@@ -6,6 +6,7 @@
 // Reference: /root/reference/extensions/ngp_raymarch/src/{ray_sampler,compacted_coord,calc_rgb}.cu
 // and include/{ray_sampler_header,raymarch_shared}.h (line cites inline).
 #include "xr_common.h"
+#include "xr_aux.h"
 #include <cfloat>
 #include <cstdlib>
 
@@ -1184,31 +1185,12 @@ __global__ __launch_bounds__(64 * CW_RAYS) void k_composite_train_w(
 
 // scale * sum HuberLoss(rgb - target) and sum ((rgb - target) * alpha)^2 as ONE workgroup's fixed-order sum: out[0], out[1] are
 // WRITTEN (utils/metrics.py:8-16, networks/hashnerf.py:36-44)
-#define LS_THREADS 1024
+#define LS_THREADS XR_AUX_LS_VTHREADS
 __global__ __launch_bounds__(LS_THREADS) void k_train_loss_scalars(const float* __restrict__ rgb, const float* __restrict__ target,
                                                                   const float* __restrict__ alpha_mask, uint32_t n_rays, float delta,
                                                                   float scale, float* __restrict__ out) {
     __shared__ float ws[LS_THREADS / 64], ws2[LS_THREADS / 64];
-    float acc = 0.f, mse = 0.f;
-    for (uint32_t i = threadIdx.x; i < n_rays; i += LS_THREADS) {
-        const float am = alpha_mask[i];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float d = rgb[3 * i + c] - target[3 * i + c], a = fabsf(d);
-            acc += a > delta ? a - 0.5f * delta : 0.5f / delta * a * a;
-            const float mm = d * am; mse += mm * mm;
-        }
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) { acc += __shfl_xor(acc, d, 64); mse += __shfl_xor(mse, d, 64); }
-    if ((threadIdx.x & 63) == 0) { ws[threadIdx.x >> 6] = acc; ws2[threadIdx.x >> 6] = mse; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float a = 0.f, b = 0.f;
-#pragma unroll
-        for (int w = 0; w < LS_THREADS / 64; ++w) { a += ws[w]; b += ws2[w]; }
-        out[0] = scale * a; out[1] = b;
-    }
+    xr_aux_loss_block<LS_THREADS>(rgb, target, alpha_mask, n_rays, delta, scale, out, ws, ws2);      // (xr_aux.h: the one definition)
 }
 extern "C" int xr_train_loss_scalars(const float* rgb, const float* target, const float* alpha_mask, uint32_t n_rays, float delta,
                                      float scale, float* loss_mse_out, void* stream_) {

@@ -30,6 +30,7 @@
 #include "xr_hashgrid.h"
 #include "xr_scatter.h"
 #include "xr_adam.h"
+#include "xr_aux.h"
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -54,7 +55,6 @@ __device__ __forceinline__ void s3_static_for(F&& f) { s3_static_for_impl(f, std
 #define S3_ROUND_ITEMS 4096                          // items staged in LDS per binning round
 #define S3_R_MAX_ENTRIES 65536u                      // dense levels up to this size take the run-length kernel
 #define S3_R_ROWS 16                                 // consecutive rows per thread there
-#define S3_R_THREADS 1024
 
 enum { S3_H = 0, S3_D = 1 };
 #ifndef S3_PERMUTE
@@ -317,11 +317,15 @@ __global__ __launch_bounds__(S3_BIN_THREADS) void k_scatter_bin3(S3Plan pl, cons
                                                                  const float* __restrict__ denc_t, uint32_t ld, uint32_t n,
                                                                  const uint32_t* __restrict__ n_dev, const uint32_t* __restrict__ rows,
                                                                  uint32_t* __restrict__ counts, float4* __restrict__ bins,
-                                                                 float4* __restrict__ ovf) {
+                                                                 float4* __restrict__ ovf, uint32_t n_aux_blocks, XrAuxWork aux) {
     __shared__ float4 s_items[S3_ROUND_ITEMS];
     __shared__ uint8_t s_ipart[S3_ROUND_ITEMS];
     __shared__ uint32_t s_cnt[S3_MAX_PARTS], s_off[S3_MAX_PARTS + 1], s_base[S3_MAX_PARTS], s_ovf;
-    const uint32_t e = pl.n_lv - 1u - blockIdx.x % pl.n_lv, sb = blockIdx.x / pl.n_lv;   // the levels of one sample block are neighbours
+    // the workgroups in front of the binning ones (dispatched first, they run beside them): the sum of a training step's MLP gradient partials + those tensors' update (xr_aux.h) --
+    // they depend on what ran before this launch only, and they have to be finished when the scatter is
+    if (blockIdx.x < n_aux_blocks) { xr_aux_reduce_block<S3_BIN_THREADS>(aux, blockIdx.x, reinterpret_cast<float (*)[64]>(s_items)); return; }
+    const uint32_t bidx = blockIdx.x - n_aux_blocks;
+    const uint32_t e = pl.n_lv - 1u - bidx % pl.n_lv, sb = bidx / pl.n_lv;               // the levels of one sample block are neighbours
     const S3Level& L = pl.lv[e];
     if (n_dev) n = min(n, *n_dev);
     uint32_t* __restrict__ cnt_out = counts + L.counts_off + sb;            // [part][sample block]
@@ -386,16 +390,15 @@ __device__ __forceinline__ void s3_adam_entries(const XrAdamArgs& A, const size_
 
 // TH: threads per workgroup.  1024 (16 waves) or 512 (8 waves: the same time, profiles/r03_accumulate_512_threads_ab.txt, with half
 // the register file left to whatever else is resident -- the side-stream march, for one).
-template <int LG, int TH = (1 << (LG - 3))>
-__global__ __launch_bounds__(TH) void k_scatter_accum3(S3Plan pl, const uint32_t* __restrict__ counts,
-                                                                  const float4* __restrict__ bins, const float4* __restrict__ ovf,
-                                                                  float* __restrict__ grad_table) {
+template <int LG, int TH>
+__device__ __forceinline__ void s3_accum_block(const S3Plan& pl, const uint32_t blk, const uint32_t* __restrict__ counts,
+                                               const float4* __restrict__ bins, const float4* __restrict__ ovf,
+                                               float* __restrict__ grad_table, double* s_acc /* [ENTRIES][2] */) {
     constexpr uint32_t ENTRIES = 1u << LG, THREADS = (uint32_t)TH, WAVES = THREADS / 64;
-    extern __shared__ __attribute__((aligned(16))) double s_acc[];       // [ENTRIES][2]
     uint32_t e = 0;
-    while (e + 1 < pl.n_lv && blockIdx.x >= pl.lv[e + 1].acc_block0) ++e;   // levels in accumulate order (heaviest first)
+    while (e + 1 < pl.n_lv && blk >= pl.lv[e + 1].acc_block0) ++e;          // levels in accumulate order (heaviest first)
     const S3Level& L = pl.lv[e];
-    const uint32_t part = blockIdx.x - L.acc_block0, nsb = pl.nsb, cap = L.cap;
+    const uint32_t part = blk - L.acc_block0, nsb = pl.nsb, cap = L.cap;
     double2* acc2 = reinterpret_cast<double2*>(s_acc);
     S3_T(0);
     // entries this partition owns
@@ -626,16 +629,15 @@ __device__ __forceinline__ void s3_r_flush(double* s_acc, const float (&acc)[16]
     }
 }
 
-__global__ __launch_bounds__(S3_R_THREADS) void k_scatter_dense_rl(S3RPlan pl, const float* __restrict__ x, uint32_t x_stride,
-                                                                   const float* __restrict__ denc_t, uint32_t ld, uint32_t n,
-                                                                   const uint32_t* __restrict__ n_dev, const uint32_t* __restrict__ rows,
-                                                                   float2* __restrict__ slabs) {
-    extern __shared__ __attribute__((aligned(16))) double s_acc[];       // [<= S3_ENTRIES][2]
+template <int TH>
+__device__ __forceinline__ void s3_rl_block(const S3RPlan& pl, const uint32_t blk, const float* __restrict__ x, uint32_t x_stride,
+                                            const float* __restrict__ denc_t, uint32_t ld, uint32_t n, const uint32_t* __restrict__ rows,
+                                            float2* __restrict__ slabs, double* s_acc /* [<= S3_ENTRIES][2] */) {
+    constexpr uint32_t S3_R_THREADS = (uint32_t)TH;
     uint32_t e = 0;
-    while (e + 1 < pl.n_lv && blockIdx.x >= pl.lv[e + 1].block0) ++e;
+    while (e + 1 < pl.n_lv && blk >= pl.lv[e + 1].block0) ++e;
     const S3RLevel& L = pl.lv[e];
-    const uint32_t rel = blockIdx.x - L.block0, part = rel / pl.chunks, chunk = rel % pl.chunks;
-    if (n_dev) n = min(n, *n_dev);
+    const uint32_t rel = blk - L.block0, part = rel / pl.chunks, chunk = rel % pl.chunks;
     const uint32_t p_lo = part << S3_LOG2, n_loc = min(S3_ENTRIES, L.hsize - p_lo);
     double2* acc2 = reinterpret_cast<double2*>(s_acc);
     for (uint32_t q = threadIdx.x; q < n_loc; q += S3_R_THREADS) acc2[q] = make_double2(0.0, 0.0);
@@ -695,6 +697,29 @@ __global__ __launch_bounds__(S3_R_THREADS) void k_scatter_dense_rl(S3RPlan pl, c
     }
 }
 
+// The accumulate launch: the run-length workgroups of the small dense levels first (the longest ones: each walks 1 / chunks of the
+// rows), then one workgroup per (binned level, partition).  Rounds 3-5 ran the two as separate kernels on two streams; as ONE launch
+// they share the chip the same way without a fork and a join on the step's queue.
+template <int LG, int TH>
+__global__ __launch_bounds__(TH) void k_scatter_acc(S3Plan pl, S3RPlan rpl, const float* __restrict__ x, uint32_t x_stride,
+                                                    const float* __restrict__ denc_t, uint32_t ld, uint32_t n,
+                                                    const uint32_t* __restrict__ n_dev, const uint32_t* __restrict__ rows,
+                                                    const uint32_t* __restrict__ counts, const float4* __restrict__ bins,
+                                                    const float4* __restrict__ ovf, float2* __restrict__ slabs, float* __restrict__ grad_table,
+                                                    uint32_t n_tail, XrAuxWork aux) {
+    extern __shared__ __attribute__((aligned(16))) double s_acc[];       // [1 << LG][2]
+    // (n_tail = 1: workgroup 0 is a training step's loss scalars + a clear, xr_aux.h -- a chain of dependent loads as long as the
+    // binning launch, hidden in this one)
+    if (blockIdx.x < n_tail) { xr_aux_tail_block<TH>(aux, reinterpret_cast<float*>(s_acc)); return; }
+    const uint32_t blk = blockIdx.x - n_tail;
+    if (blk < rpl.blocks) {
+        if (n_dev) n = min(n, *n_dev);
+        s3_rl_block<TH>(rpl, blk, x, x_stride, denc_t, ld, n, rows, slabs, s_acc);
+    } else
+        s3_accum_block<LG, TH>(pl, blk - rpl.blocks, counts, bins, ovf, grad_table, s_acc);
+}
+
+// slabs of the run-length workgroups -> the table slice (or the optimiser update), in chunk order; 8 slab loads in flight
 __global__ __launch_bounds__(256) void k_scatter_fold(S3RPlan pl, const float2* __restrict__ slabs, float* __restrict__ grad_table) {
     const uint32_t q = blockIdx.x * 256 + threadIdx.x;
     if (q >= pl.slab_entries) return;
@@ -702,7 +727,15 @@ __global__ __launch_bounds__(256) void k_scatter_fold(S3RPlan pl, const float2* 
     while (e + 1 < pl.n_lv && q >= pl.lv[e + 1].poff) ++e;
     float2* __restrict__ dst = reinterpret_cast<float2*>(grad_table) + pl.lv[e].toff + (q - pl.lv[e].poff);
     float2 t = (pl.overwrite || pl.fuse) ? make_float2(0.f, 0.f) : *dst;
-    for (uint32_t c = 0; c < pl.chunks; ++c) {                              // fixed order
+    uint32_t c = 0;
+    for (; c + 8 <= pl.chunks; c += 8) {                                    // fixed order
+        float2 a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = slabs[(size_t)(c + u) * pl.slab_entries + q];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { t.x += a[u].x; t.y += a[u].y; }
+    }
+    for (; c < pl.chunks; ++c) {
         const float2 a = slabs[(size_t)c * pl.slab_entries + q];
         t.x += a.x; t.y += a.y;
     }
@@ -720,7 +753,7 @@ __global__ __launch_bounds__(256) void k_scatter_fold(S3RPlan pl, const float2* 
 // quickly), samples per binning workgroup (1024 | 2048 | 4096), row chunks per partition of the run-length kernel, rl=0 the small
 // dense levels through the bins.  Measurement-only alternatives of earlier rounds are compile-time now (S3_LOG2, S3_ACC_THREADS,
 // S3_RL_ASYNC: tools/build_variant.sh) or gone with their records under profiles/.
-struct S3Test { int min_n = 16384, block = 2048, rl_chunks = 16, rl = 1; };
+struct S3Test { int min_n = 16384, block = 2048, rl_chunks = 8, rl = 1; };
 static const S3Test& s3_test() {
     static const S3Test t = []() {
         S3Test v;
@@ -729,7 +762,7 @@ static const S3Test& s3_test() {
             int val = 0;
             if (sscanf(e, "min_n=%d", &val) == 1) v.min_n = val;
             else if (sscanf(e, "block=%d", &val) == 1) v.block = (val == 1024 || val == 4096) ? val : 2048;
-            else if (sscanf(e, "rl_chunks=%d", &val) == 1) v.rl_chunks = (val >= 1 && val <= 64) ? val : 16;
+            else if (sscanf(e, "rl_chunks=%d", &val) == 1) v.rl_chunks = (val >= 1 && val <= 64) ? val : 8;
             else if (sscanf(e, "rl=%d", &val) == 1) v.rl = val != 0;
             const char* c = strchr(e, ',');
             e = c ? c + 1 : nullptr;
@@ -739,13 +772,10 @@ static const S3Test& s3_test() {
     return t;
 }
 static uint32_t s3_block_samples() { return (uint32_t)s3_test().block; }     // measured 152 / 139 / 155 us for 4096 / 2048 / 1024
-static uint32_t s3_chunks() { return (uint32_t)s3_test().rl_chunks; }
+static uint32_t s3_chunks() { return (uint32_t)s3_test().rl_chunks; }     // (round 6, inside the accumulate launch with 8 waves: 147-155 us at 8, 158-160 at 16 / 6, 170 at 4)
 #ifndef S3_ACC_THREADS_DEFAULT
-#define S3_ACC_THREADS_DEFAULT 512      // 512 | 1024 threads per accumulate workgroup: the same time alone; with 8 waves the march the trainer
-#endif                                  // runs beside this kernel finds registers on every SIMD (profiles/r03_accumulate_512_threads_ab.txt)
-#ifndef S3_RL_ASYNC
-#define S3_RL_ASYNC 1                   // the small dense levels on an internal helper stream beside the bin / accumulate pair
-#endif
+#define S3_ACC_THREADS_DEFAULT 512      // 512 | 1024 threads per workgroup of the accumulate launch: the same time alone
+#endif                                  // (profiles/r03_accumulate_512_threads_ab.txt); 8 waves can hold a partition's optimiser state in registers
 
 struct S3Layout {
     S3Plan bin; S3RPlan rl;
@@ -826,10 +856,11 @@ uint32_t xr_scatter3_atomic_mask(uint32_t n, const GridMeta& gm, uint32_t hashed
     return P.atomic_mask;
 }
 
-static thread_local XrAuxPrologue* g_aux_prologue = nullptr;
-// The scatter runs its small dense levels (and a training step's reductions / small updates) on a HELPER stream beside the bin /
-// accumulate pair.  The stream and the two events that fork it from and join it into the caller's stream are the CALLER's
-// (xr_set_helper_stream, per host thread): the library creates nothing.  Without them everything runs on the caller's stream.
+// A training step's small sums and updates ride inside the binning launch (xr_aux.h); the caller hands them over here
+static thread_local XrAuxWork* g_aux_work = nullptr;
+void xr_internal_scatter_aux_work(XrAuxWork* w) { g_aux_work = w; }
+// The helper stream of earlier rounds (xr_set_helper_stream: a stream + its fork and join events, the caller's) is still what the
+// atomic-level fallback of xr_hashgrid_bwd forks onto (xr_encode.hip); the binned scatter below no longer uses it: one in-order stream.
 static thread_local XrHelper g_helper = {nullptr, nullptr, nullptr};
 const XrHelper* xr_internal_helper() { return g_helper.stream ? &g_helper : nullptr; }
 extern "C" int xr_set_helper_stream(void* stream, void* fork_event, void* join_event) {
@@ -837,7 +868,6 @@ extern "C" int xr_set_helper_stream(void* stream, void* fork_event, void* join_e
     g_helper.stream = (hipStream_t)stream; g_helper.fork = (hipEvent_t)fork_event; g_helper.join = (hipEvent_t)join_event;
     return XR_OK;
 }
-void xr_internal_scatter_aux_prologue(XrAuxPrologue* p) { g_aux_prologue = p; }
 
 int xr_scatter3(const float* x, uint32_t x_stride, const float* denc_t, uint32_t ld, uint32_t n, const uint32_t* n_dev,
                 const uint32_t* rows, const GridMeta& gm, uint32_t hashed_mask, float* grad_table, void* workspace,
@@ -861,66 +891,40 @@ int xr_scatter3(const float* x, uint32_t x_stride, const float* denc_t, uint32_t
     float2* slabs = (float2*)((char*)workspace + P.counts_bytes + P.bins_bytes + P.ovf_bytes);
     static thread_local bool attr_set = false;        // (idempotent: a second thread setting it again is harmless)
     if (!attr_set) {
-        XR_HIP(hipFuncSetAttribute((const void*)k_scatter_accum3<S3_LOG2, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES));
-        XR_HIP(hipFuncSetAttribute((const void*)k_scatter_accum3<S3_LOG2, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES));
-        XR_HIP(hipFuncSetAttribute((const void*)k_scatter_dense_rl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES));
+        XR_HIP(hipFuncSetAttribute((const void*)k_scatter_acc<S3_LOG2, S3_ACC_THREADS_DEFAULT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES));
         attr_set = true;
     }
-    // the small dense levels' two kernels are enqueued first, on an internal helper stream beside the bin / accumulate pair (disjoint
-    // table slices, read-only inputs), forked from and joined back into the caller's stream with events
-    const int rl_first = 1, rl_async = S3_RL_ASYNC;
-    const XrHelper* hp = xr_internal_helper();
-    const bool fork = rl_async && hp && P.rl.n_lv > 0 && P.bin.n_lv > 0;
-    const hipStream_t aux = hp ? hp->stream : nullptr;
-    const hipEvent_t ev_fork = hp ? hp->fork : nullptr, ev_join = hp ? hp->join : nullptr;
-    // the caller's small kernels (xr_ngp_train_step: reduction of the MLP partials, MLP Adam, loss scalars, a clear) run on the helper
-    // stream BEHIND the dense levels' two kernels: those then start beside the bin kernel instead of 40 us into the accumulate
-    // kernel, whose HBM streams they disturb (scatter 181 -> 172 us, profiles/r03_aux_kernels_last_ab.txt)
-    const bool aux_last = true;
-    auto launch_rl = [&]() -> int {
-        if (P.rl.n_lv == 0) return XR_OK;
-        hipStream_t rs = stream;
-        if (fork) {
-            XR_HIP(hipEventRecord(ev_fork, stream));
-            XR_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
-            rs = aux;
-            if (!aux_last && g_aux_prologue && !g_aux_prologue->done) {   // a caller's small kernels that only have to finish by the join
-                g_aux_prologue->done = true;
-                const int rc = g_aux_prologue->fn(aux, g_aux_prologue->arg);
-                if (rc != XR_OK) return rc;
-            }
-        }
-        hipLaunchKernelGGL(k_scatter_dense_rl, dim3(P.rl.blocks), dim3(S3_R_THREADS), S3_LDS_BYTES, rs, P.rl, x, x_stride, denc_t, ld, n,
-                           n_dev, rows, slabs);
-        XR_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_scatter_fold, dim3(xr_div_up(P.rl.slab_entries, 256)), dim3(256), 0, rs, P.rl, (const float2*)slabs, grad_table);
-        XR_LAUNCH_CHECK();
-        if (fork && aux_last && g_aux_prologue && !g_aux_prologue->done) {
-            g_aux_prologue->done = true;
-            const int rc = g_aux_prologue->fn(aux, g_aux_prologue->arg);
-            if (rc != XR_OK) return rc;
-        }
-        if (fork) XR_HIP(hipEventRecord(ev_join, aux));
-        return XR_OK;
-    };
-    if (rl_first) { const int rc = launch_rl(); if (rc != XR_OK) return rc; }
+    // Three launches on the caller's stream, no event (rounds 3-5: the small dense levels' two kernels on a helper stream beside the
+    // bin / accumulate pair -- a fork before the bin kernel and a join behind the accumulate kernel, ~14 + ~20 us of the step's queue
+    // per iteration, profiles/r06_trace_single_stream.txt):
+    //   1. binning of the hashed / large dense levels  (+ the caller's gradient-partial sums and MLP update as extra workgroups, xr_aux.h)
+    //   2. (the caller's loss scalars +) run-length workgroups of the small dense levels + one accumulate workgroup per (binned level, partition)
+    //   3. fold of the run-length slabs (fixed order)
+    XrAuxWork aux; memset(&aux, 0, sizeof(aux));
+    uint32_t aux_blocks = 0;
+    uint32_t n_tail = 0;
+    if (g_aux_work && !g_aux_work->done && P.bin.n_lv) {
+        aux = *g_aux_work; g_aux_work->done = true;
+        aux_blocks = aux.partial ? xr_aux_reduce_blocks<S3_BIN_THREADS>(aux.gw) : 0u;
+        n_tail = (aux.rgb || aux.clear) ? 1u : 0u;
+    }
     if (P.bin.n_lv) {
-        const uint32_t bs = s3_block_samples();
-        const dim3 grid(P.bin.n_lv * P.bin.nsb), block(S3_BIN_THREADS);
-        if (bs == 4096) hipLaunchKernelGGL(k_scatter_bin3<4096>, grid, block, 0, stream, P.bin, x, x_stride, denc_t, ld, n, n_dev, rows, counts, bins, ovf);
-        else if (bs == 2048) hipLaunchKernelGGL(k_scatter_bin3<2048>, grid, block, 0, stream, P.bin, x, x_stride, denc_t, ld, n, n_dev, rows, counts, bins, ovf);
-        else hipLaunchKernelGGL(k_scatter_bin3<1024>, grid, block, 0, stream, P.bin, x, x_stride, denc_t, ld, n, n_dev, rows, counts, bins, ovf);
-        XR_LAUNCH_CHECK();
-        const int acc_threads = S3_ACC_THREADS_DEFAULT;
-        if (acc_threads == 512)
-            hipLaunchKernelGGL((k_scatter_accum3<S3_LOG2, 512>), dim3(P.bin.acc_blocks), dim3(512), S3_LDS_BYTES, stream, P.bin, (const uint32_t*)counts,
-                               (const float4*)bins, (const float4*)ovf, grad_table);
-        else
-            hipLaunchKernelGGL((k_scatter_accum3<S3_LOG2, 1024>), dim3(P.bin.acc_blocks), dim3(1024), S3_LDS_BYTES, stream, P.bin, (const uint32_t*)counts,
-                               (const float4*)bins, (const float4*)ovf, grad_table);
+        const uint32_t bs = s3_block_samples(), nb = P.bin.n_lv * P.bin.nsb;
+        const dim3 grid(nb + aux_blocks), block(S3_BIN_THREADS);
+        if (bs == 4096) hipLaunchKernelGGL(k_scatter_bin3<4096>, grid, block, 0, stream, P.bin, x, x_stride, denc_t, ld, n, n_dev, rows, counts, bins, ovf, aux_blocks, aux);
+        else if (bs == 2048) hipLaunchKernelGGL(k_scatter_bin3<2048>, grid, block, 0, stream, P.bin, x, x_stride, denc_t, ld, n, n_dev, rows, counts, bins, ovf, aux_blocks, aux);
+        else hipLaunchKernelGGL(k_scatter_bin3<1024>, grid, block, 0, stream, P.bin, x, x_stride, denc_t, ld, n, n_dev, rows, counts, bins, ovf, aux_blocks, aux);
         XR_LAUNCH_CHECK();
     }
-    if (!rl_first) { const int rc = launch_rl(); if (rc != XR_OK) return rc; }
-    if (fork) XR_HIP(hipStreamWaitEvent(stream, ev_join, 0));
+    if (P.rl.blocks + P.bin.acc_blocks) {
+        hipLaunchKernelGGL((k_scatter_acc<S3_LOG2, S3_ACC_THREADS_DEFAULT>), dim3(n_tail + P.rl.blocks + P.bin.acc_blocks), dim3(S3_ACC_THREADS_DEFAULT),
+                           S3_LDS_BYTES, stream, P.bin, P.rl, x, x_stride, denc_t, ld, n, n_dev, rows, (const uint32_t*)counts, (const float4*)bins,
+                           (const float4*)ovf, slabs, grad_table, n_tail, aux);
+        XR_LAUNCH_CHECK();
+    }
+    if (P.rl.n_lv) {
+        hipLaunchKernelGGL(k_scatter_fold, dim3(xr_div_up(P.rl.slab_entries, 256)), dim3(256), 0, stream, P.rl, (const float2*)slabs, grad_table);
+        XR_LAUNCH_CHECK();
+    }
     return XR_OK;
 }

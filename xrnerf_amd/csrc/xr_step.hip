@@ -6,6 +6,7 @@
 // existing entry points of this library called in sequence (same kernels, same results); buffers are caller-owned, nothing
 // is allocated or synchronised.
 #include "xr_common.h"
+#include "xr_aux.h"
 #include <cstdlib>
 #include <initializer_list>
 
@@ -119,26 +120,30 @@ extern "C" int xr_ngp_train_step(
     xr_internal_defer_mlp_reduce(false);
     if (rc != XR_OK) return rc;
     if ((rc = end("xr_nerf_mlp_bwd")) != XR_OK) return rc;
-    struct TailArgs { void* ws; uint32_t n; int nhd, nhc; float *gd, *gc; const float *rgb, *target, *alpha; uint32_t n_rays; float delta, scale; float* loss;
-                      const xr_adam_fuse *ad, *ac; uint32_t* seg_clear; size_t seg_bytes; }
-        ta = {ws_mlp_bwd, n_rows, n_hidden_density, n_hidden_color, grad_w_density, grad_w_color, rgb_out, target, alpha_mask, n_rays, huber_delta, loss_scale, loss_mse,
-              w_density_adam, w_color_adam, (live_on && live_seg_count) ? live_seg_count : nullptr, XR_LIVE_ROWS_SEGMENTS(n_rows) * sizeof(uint32_t)};
-    XrAuxPrologue pro = {[](hipStream_t st, void* a) -> int {
-                             auto* r = (TailArgs*)a;
-                             int rc1 = xr_internal_mlp_bwd_reduce(r->ws, r->n, r->nhd, r->nhc, r->gd, r->gc, 1, st);      // writes the two gradient buffers
-                             if (rc1 != XR_OK) return rc1;
-                             if (r->seg_clear) XR_HIP(hipMemsetAsync(r->seg_clear, 0, r->seg_bytes, st));      // read by the ranking pass long ago
-                             if (r->ad) {                      // the MLP tensors' optimiser update, right behind their gradients
-                                 float* p[2] = {r->ad->param, r->ac->param}; const float* g[2] = {r->gd, r->gc};
-                                 float* m[2] = {r->ad->m, r->ac->m}; float* v[2] = {r->ad->v, r->ac->v}; float* e[2] = {r->ad->ema, r->ac->ema};
-                                 const size_t nn[2] = {(size_t)r->ad->n, (size_t)r->ac->n};
-                                 rc1 = xr_adam_step_multi(2, p, g, m, v, (e[0] && e[1]) ? e : nullptr, nn, r->ad->step, r->ad->lr, r->ad->beta1, r->ad->beta2,
-                                                          r->ad->eps, r->ad->weight_decay, r->ad->ema_momentum, r->ad->grad_scale, st);
-                                 if (rc1 != XR_OK) return rc1;
-                             }
-                             return xr_train_loss_scalars(r->rgb, r->target, r->alpha, r->n_rays, r->delta, r->scale, r->loss, st);
-                         }, &ta, false};
-    if (reduce_aux) xr_internal_scatter_aux_prologue(&pro);
+    // The small work behind the backward -- the fixed-order sum of its per-workgroup partials into the two gradient buffers (written),
+    // the two MLP tensors' optimiser update right behind their gradients, the loss scalars, the clear of the caller's live-row segment
+    // counts (read by the ranking pass long ago) -- rides inside the scatter's binning launch as a few extra workgroups (xr_aux.h).
+    // Where the scatter has no such launch for this call it runs here, behind it, as launches of its own.
+    XrAuxWork aux; memset(&aux, 0, sizeof(aux));
+    if ((rc = xr_internal_mlp_bwd_reduce_desc(ws_mlp_bwd, n_rows, n_hidden_density, n_hidden_color, &aux)) != XR_OK) return rc;
+    aux.g0 = grad_w_density; aux.g1 = grad_w_color; aux.overwrite = 1;
+    const bool aux_adam = w_density_adam && w_color_adam && (uint32_t)w_density_adam->n == aux.split && (uint32_t)w_color_adam->n == aux.gw - aux.split;
+    if (aux_adam) {
+        const xr_adam_fuse* ad[2] = {w_density_adam, w_color_adam};
+        XrAdamArgs* A[2] = {&aux.a0, &aux.a1};
+        // the constants exactly as xr_adam_step_multi hands them to its kernel: ONE set (the first tensor's) for both tensors, the EMA
+        // copies only where both tensors have one
+        const xr_adam_fuse& H = *w_density_adam;
+        const float bc1 = 1.f - powf(H.beta1, (float)H.step), bc2 = 1.f - powf(H.beta2, (float)H.step);
+        const bool ema = ad[0]->ema && ad[1]->ema;
+        for (int k = 0; k < 2; ++k)
+            *A[k] = XrAdamArgs{ad[k]->param, ad[k]->m, ad[k]->v, ema ? ad[k]->ema : nullptr, H.beta1, H.beta2, H.lr / bc1, sqrtf(bc2), H.eps,
+                               H.weight_decay, H.ema_momentum, H.grad_scale};
+        aux.adam = 1;
+    }
+    aux.rgb = rgb_out; aux.target = target; aux.alpha = alpha_mask; aux.n_rays = n_rays; aux.delta = huber_delta; aux.scale = loss_scale; aux.loss = loss_mse;
+    if (live_on && live_seg_count) { aux.clear = live_seg_count; aux.clear_words = XR_LIVE_ROWS_SEGMENTS(n_rows); }
+    if (reduce_aux) xr_internal_scatter_aux_work(&aux);
     if ((rc = begin("xr_hashgrid_bwd")) != XR_OK) return rc;
     // data-parallel callers scatter the levels below scatter_level0 themselves (xr_hashgrid_bwd with the same row list, found
     // through xr_nerf_mlp_bwd_list_slots) AFTER handing the finer levels' gradient slice to the collective: table offsets are
@@ -151,9 +156,32 @@ extern "C" int xr_ngp_train_step(
         rc = xr_hashgrid_bwd(coords, 7, denc_t + (size_t)2 * scatter_level0 * ld, ld, n_rows, live_on ? n_live : n_dev, rows, n_levels - scatter_level0,
                               scale_host + scatter_level0, resolution_host + scatter_level0, offset_host + scatter_level0, grad_table,
                               ws_scatter, ws_scatter_bytes, XR_SCATTER_OVERWRITE, stream_);
-    xr_internal_scatter_aux_prologue(nullptr);
+    xr_internal_scatter_aux_work(nullptr);
     if (rc != XR_OK) return rc;
-    if (!pro.done && (rc = pro.fn(stream, pro.arg)) != XR_OK) return rc;     // the scatter did not fork (or the build keeps them on this stream)
+    if (!aux.done) {                                  // the scatter had no binning launch for this call (or the build keeps them apart)
+        if ((rc = xr_internal_mlp_bwd_reduce(ws_mlp_bwd, n_rows, n_hidden_density, n_hidden_color, grad_w_density, grad_w_color, 1, stream_)) != XR_OK) return rc;
+        if (aux.clear) XR_HIP(hipMemsetAsync(aux.clear, 0, (size_t)aux.clear_words * sizeof(uint32_t), stream));
+        if (w_density_adam) {
+            float* p[2] = {w_density_adam->param, w_color_adam->param}; const float* g[2] = {grad_w_density, grad_w_color};
+            float* m[2] = {w_density_adam->m, w_color_adam->m}; float* v[2] = {w_density_adam->v, w_color_adam->v};
+            float* e[2] = {w_density_adam->ema, w_color_adam->ema};
+            const size_t nn[2] = {(size_t)w_density_adam->n, (size_t)w_color_adam->n};
+            rc = xr_adam_step_multi(2, p, g, m, v, (e[0] && e[1]) ? e : nullptr, nn, w_density_adam->step, w_density_adam->lr, w_density_adam->beta1,
+                                    w_density_adam->beta2, w_density_adam->eps, w_density_adam->weight_decay, w_density_adam->ema_momentum,
+                                    w_density_adam->grad_scale, stream_);
+            if (rc != XR_OK) return rc;
+        }
+        if ((rc = xr_train_loss_scalars(rgb_out, target, alpha_mask, n_rays, huber_delta, loss_scale, loss_mse, stream_)) != XR_OK) return rc;
+    } else if (w_density_adam && !aux_adam) {         // (tensor sizes that are not the backward's gradient widths: the update as its own launch)
+        float* p[2] = {w_density_adam->param, w_color_adam->param}; const float* g[2] = {grad_w_density, grad_w_color};
+        float* m[2] = {w_density_adam->m, w_color_adam->m}; float* v[2] = {w_density_adam->v, w_color_adam->v};
+        float* e[2] = {w_density_adam->ema, w_color_adam->ema};
+        const size_t nn[2] = {(size_t)w_density_adam->n, (size_t)w_color_adam->n};
+        rc = xr_adam_step_multi(2, p, g, m, v, (e[0] && e[1]) ? e : nullptr, nn, w_density_adam->step, w_density_adam->lr, w_density_adam->beta1,
+                                w_density_adam->beta2, w_density_adam->eps, w_density_adam->weight_decay, w_density_adam->ema_momentum,
+                                w_density_adam->grad_scale, stream_);
+        if (rc != XR_OK) return rc;
+    }
     if ((rc = end("xr_hashgrid_bwd")) != XR_OK) return rc;
     return XR_OK;
 }
