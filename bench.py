@@ -853,12 +853,12 @@ def main():
 
     # ---- every hot kernel's roofline: 16 more iterations per entry point with events around THAT entry point only, so that every
     # window runs the product's native step (a timer that wants several stages of the step at once forces the per-entry-point
-    # Python sequence, which has neither the fused optimiser update nor the helper-stream tail).  Out of the timed region.
+    # Python sequence, which has neither the fused optimiser update nor the small sums inside the scatter's launches).  Out of the timed region.
     roofs = {}
     s_win = 0
     for k in ALGO:
         if k in ('xr_rays_sampler', 'xr_calc_rgb_forward', 'xr_calc_rgb_backward'):
-            continue          # K1 runs on the side stream beside other kernels (its span is not its duration); K3 / K4 alone are not on the training path
+            continue          # K1 runs once per refresh window as a series (xr_ngp_window_march), not per iteration; K3 / K4 alone are not on the training path
         s0 = tr.samples_done
         ops.TIMER = ops.KernelTimer(only={k}, train_only=True)
         if ops.LIVE_STATS is not None:

@@ -10,7 +10,7 @@ import collections, csv, json, sys
 
 ENTRY = {   # entry point -> kernels launched by it (include/xrnerf_mi355.h)
     'xr_hashgrid_bwd': ['k_scatter_bin2', 'k_scatter_accum2', 'k_scatter_bin', 'k_scatter_accum', 'k_hashgrid_bwd', 'k_reduce_replicas',
-                        'void k_scatter_bin3<4096>', 'void k_scatter_bin3<2048>', 'void k_scatter_bin3<1024>', 'void k_scatter_accum3<13>', 'void k_scatter_accum3<13, 512>', 'void k_scatter_accum3<13, 1024>', 'k_scatter_dense_rl',
+                        'void k_scatter_bin3<4096>', 'void k_scatter_bin3<2048>', 'void k_scatter_bin3<1024>', 'void k_scatter_accum3<13>', 'void k_scatter_accum3<13, 512>', 'void k_scatter_accum3<13, 1024>', 'k_scatter_dense_rl', 'void k_scatter_acc<13, 512>', 'void k_scatter_acc<13, 1024>',
                         'k_scatter_fold'],
     'xr_hashgrid_fwd': ['k_hashgrid_fwd'],
     'xr_nerf_mlp_bwd': ['k_nerf_mlp_bwd_1_2', 'void k_nerf_mlp_bwd_1_2<true>', 'void k_nerf_mlp_bwd_1_2<false>', 'k_reduce_partials'] +

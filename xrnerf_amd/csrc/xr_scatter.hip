@@ -1,6 +1,7 @@
 // Third generation of the hash-grid scatter (backward of tcnn's HashGrid encoding as called from
-// /root/reference/xrnerf/models/mlps/hashnerf_mlp.py:34-37,59-61): EVERY level without a global atomic, no helper
-// stream, results independent of the launch schedule up to the order of fp64 additions inside one workgroup.
+// /root/reference/xrnerf/models/mlps/hashnerf_mlp.py:34-37,59-61): EVERY level without a global atomic, three launches on
+// the caller's stream (round 6: no helper stream, no event), results independent of the launch schedule BIT FOR BIT (round 6:
+// the LDS sums are 64-bit fixed point, see S3_FIX below; fp64 until round 5 -- schedule-dependent in the last bit).
 //
 // What round 2 measured on the second generation (profiles/r02_scatter_phase_timing.txt, profiles/NOTES_r01_r03.md 5b):
 //   * the dense levels' atomic kernel (55 us alone) beside the bin / accumulate pair stretches that pair from 39 + 56 to
@@ -18,7 +19,7 @@
 //           tcnn's linear index runs into the next row or wraps, become two single-entry items);
 //   kind R  dense levels up to 2^16 entries (levels 0-2 of the Lego geometry: 4 096 + 12 168 + 29 792 entries, where a
 //           ray's 20 samples fall into two or three cells): one THREAD walks 16 consecutive rows with the 16 corner sums of
-//           the current cell in registers and flushes them into a workgroup-private fp64 LDS copy of its 2^13-entry
+//           the current cell in registers and flushes them into a workgroup-private LDS copy of its 2^13-entry
 //           partition on a cell change (run-length reduction: ~10x fewer LDS atomics, lanes of a wave sit on different
 //           rays, so no same-address serialisation); per-chunk partials are folded in fixed order by k_scatter_fold;
 //   items that do not fit their sub-bin (capacity 1.5x the expected fill) go to the workgroup's private overflow list and
@@ -49,10 +50,15 @@ __device__ __forceinline__ void s3_static_for(F&& f) { s3_static_for_impl(f, std
 #define S3_LDS_BYTES (S3_ENTRIES * 2 * sizeof(double))
 #define S3_MAX_PARTS 256
 #define S3_MAX_SB 1024
+#ifndef S3_BIN_THREADS
 #define S3_BIN_THREADS 512
+#endif
 #define S3_ACC_THREADS 1024
 #define S3_ACC_WAVES (S3_ACC_THREADS / 64)
-#define S3_ROUND_ITEMS 4096                          // items staged in LDS per binning round
+#ifndef S3_SPT
+#define S3_SPT 2                                     // samples per thread and binning round
+#endif
+#define S3_ROUND_ITEMS (4 * S3_BIN_THREADS * S3_SPT)   // items staged in LDS per binning round (4 per sample)
 #define S3_R_MAX_ENTRIES 65536u                      // dense levels up to this size take the run-length kernel
 #define S3_R_ROWS 16                                 // consecutive rows per thread there
 
@@ -91,6 +97,9 @@ struct S3Plan {
     uint32_t acc_blocks;
     uint32_t lg;                     // log2 of the entries of one partition (13, or 12: two accumulate workgroups per CU)
     uint32_t fuse;                   // != 0: the accumulate kernel applies Adam to the entries instead of writing their gradient
+    uint32_t amax_off, ramax_off;    // words into counts: [lv][nsb] / [run-length lv][nsb] -- max |dL/d feature| per (level, sample block), as bits
+    uint32_t n_rl, n_bound;          // run-length levels (their feature-0 rows in rl_drow), an upper bound of the row count
+    uint32_t rl_drow[EN_MAX_LEVELS];
     XrAdamArgs ad;
 };
 struct S3RLevel {
@@ -102,6 +111,7 @@ struct S3RLevel {
 struct S3RPlan {
     S3RLevel lv[EN_MAX_LEVELS];
     uint32_t n_lv, chunks, slab_entries, overwrite, blocks;
+    uint32_t nsb, ramax_off, n_bound;  // as in S3Plan (the binning launch writes the maxima, the run-length workgroups read them)
     uint32_t fuse;                   // != 0: the fold kernel applies Adam instead of writing the gradient
     XrAdamArgs ad;
 };
@@ -131,12 +141,66 @@ __device__ inline uint32_t s3_readlane(uint32_t v, uint32_t lane) { return __shf
 __device__ inline uint32_t s3_readlane(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
 #endif
 
+// ---- Fixed-point accumulators (round 6).  The LDS sums were fp64 (ds_add_f64) until round 5: exact enough, but their last bit depended
+// on the order the atomics arrived in (one ulp, rarely).  Now every contribution is rounded ONCE to a multiple of 2^-S and summed as a
+// 64-bit integer (ds_add_u64: 4.7 ns per wave instruction against 8.6, tools/lds_probe.hip): integer addition is associative, so a
+// launch's result is the same bits whatever the schedule.  S is chosen per level from max |dL/d feature| of the launch (the binning
+// workgroups record it per sample block; every contribution is a weight in [0, 1] times such a value) and the row count n: an entry
+// receives at most 8 n contributions, so with max < 2^e and 8 n <= 2^L, S = min(62 - L, 50) - e keeps every sum below 2^63 -- for
+// n = 2^18 that is a quantum of 2^-41 of the level's largest gradient (fp32 carries 2^-24 of each value).  A non-finite gradient
+// makes the level's entries NaN (what the fp64 sums did to the entries it touched).
+#ifndef S3_FIX
+#define S3_FIX 1
+#endif
+struct S3Scale { double mul, inv; bool bad; };
+__device__ __forceinline__ S3Scale s3_scale(uint32_t max_bits, uint32_t n_bound) {
+    S3Scale sc;
+    float m; __builtin_memcpy(&m, &max_bits, 4);
+    sc.bad = !(m <= 3.4028235e38f);
+    const int e = (m > 0.f && !sc.bad) ? ilogbf(m) + 1 : 0;                       // m < 2^e
+    const int L = 64 - __builtin_clzll(8ull * (unsigned long long)(n_bound ? n_bound : 1u));   // 8 n < 2^L
+    const int S = (62 - L < 50 ? 62 - L : 50) - e;                                // (<= 50 - e: a single contribution stays below 2^50, see s3_q)
+    sc.mul = ldexp(1.0, S); sc.inv = ldexp(1.0, -S);
+    return sc;
+}
+#if S3_FIX
+typedef long long s3_acc_t;
+// round(x 2^S) as an integer: |x 2^S| < 2^50, so adding 1.5 * 2^52 leaves the (round-to-nearest-even) integer in the sum's low mantissa
+// bits -- one FMA and a 64-bit subtraction instead of the ~12 instructions of a double -> int64 conversion
+__device__ __forceinline__ s3_acc_t s3_q(float x, const S3Scale& sc) {
+    const double t = fma((double)x, sc.mul, 6755399441055744.0);
+    long long b; __builtin_memcpy(&b, &t, 8);
+    return b - 0x4338000000000000LL;
+}
+__device__ __forceinline__ void s3_lds_add(double* s_acc, uint32_t i, s3_acc_t v) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(s_acc) + i, (unsigned long long)v);
+}
+__device__ __forceinline__ float s3_val(double cell, const S3Scale& sc) {
+    long long v; __builtin_memcpy(&v, &cell, 8);
+    return sc.bad ? __builtin_nanf("") : (float)((double)v * sc.inv);
+}
+#else
+typedef double s3_acc_t;
+__device__ __forceinline__ s3_acc_t s3_q(float x, const S3Scale&) { return (double)x; }
+__device__ __forceinline__ void s3_lds_add(double* s_acc, uint32_t i, s3_acc_t v) { atomicAdd(&s_acc[i], v); }
+__device__ __forceinline__ float s3_val(double cell, const S3Scale&) { return (float)cell; }
+#endif
+// max over the nsb per-sample-block maxima of one level: every wave on its own (a few words; positive floats order like their bits)
+__device__ __forceinline__ uint32_t s3_level_max(const uint32_t* __restrict__ slots, uint32_t nsb) {
+    uint32_t vm = 0;
+    for (uint32_t q = threadIdx.x & 63u; q < nsb; q += 64u) vm = max(vm, slots[q]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) vm = max(vm, (uint32_t)__shfl_xor((int)vm, d, 64));
+    return vm;
+}
+__device__ __forceinline__ uint32_t s3_abs_bits(float v) { uint32_t b; __builtin_memcpy(&b, &v, 4); return b & 0x7fffffffu; }
+
 // ------------------------------------------------------------------------------------------------ binning
 // One workgroup = (level, block of BS samples).  Per round of <= 1024 samples: items ranked per partition with LDS counters,
 // placed in LDS in partition order, copied out as contiguous runs (full-line stores).  The inputs of round r + 1 are
 // fetched before round r is ranked and copied out.
 template <int KIND> struct S3Bin {
-    static constexpr int SPT = 2;                               // samples per thread and round
+    static constexpr int SPT = S3_SPT;                          // samples per thread and round
     static constexpr int IPS = KIND == S3_H ? 4 : 8;            // items per sample, worst case (kind D: every pair split)
     static constexpr int ROUND = S3_BIN_THREADS * SPT;
 };
@@ -145,7 +209,7 @@ template <int KIND, int BS>
 __device__ __forceinline__ void s3_bin_block(const S3Level& L, uint32_t lg, uint32_t nsb, uint32_t ovf_cap, uint32_t sb, const float* __restrict__ x,
                                              uint32_t x_stride, const float* __restrict__ denc_t, uint32_t ld, uint32_t n,
                                              const uint32_t* __restrict__ rows, uint32_t* __restrict__ cnt_out,
-                                             uint32_t* __restrict__ ovfcnt_out, float4* __restrict__ bins, float4* __restrict__ ovf,
+                                             uint32_t* __restrict__ ovfcnt_out, uint32_t* __restrict__ amax_out, float4* __restrict__ bins, float4* __restrict__ ovf,
                                              float4* s_items, uint8_t* s_ipart, uint32_t* s_cnt, uint32_t* s_off, uint32_t* s_base,
                                              uint32_t* s_ovf) {
     using B = S3Bin<KIND>;
@@ -177,11 +241,15 @@ __device__ __forceinline__ void s3_bin_block(const S3Level& L, uint32_t lg, uint
         }
     };
     fetch(b0);
+    uint32_t amax = 0;                                                      // max |dL/d feature| of this thread's rows, as bits
     for (uint32_t r = 0; r < (uint32_t)ROUNDS; ++r) {
         const uint32_t rb0 = b0 + r * ROUND;
         if (rb0 >= n) break;                                                // uniform
 #pragma unroll
         for (int s = 0; s < SPT; ++s) { ld0[s] = nd0[s]; ld1[s] = nd1[s]; lx0[s] = nx0[s]; lx1[s] = nx1[s]; lx2[s] = nx2[s]; }
+#pragma unroll
+        for (int s = 0; s < SPT; ++s)
+            if (rb0 + s * S3_BIN_THREADS + threadIdx.x < n) amax = max(amax, max(s3_abs_bits(ld0[s]), s3_abs_bits(ld1[s])));
         for (uint32_t p = threadIdx.x; p < parts; p += S3_BIN_THREADS) s_cnt[p] = 0;
         __syncthreads();
         // The thread's items are GENERATED twice -- once to rank them per partition, once to place them -- instead of being
@@ -310,6 +378,39 @@ __device__ __forceinline__ void s3_bin_block(const S3Level& L, uint32_t lg, uint
     __syncthreads();
     for (uint32_t p = threadIdx.x; p < parts; p += S3_BIN_THREADS) cnt_out[(size_t)p * nsb] = min(s_base[p], cap);
     if (threadIdx.x == 0) *ovfcnt_out = *s_ovf;
+    // the block's maximum: waves through s_cnt (free again behind the barrier above)
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) amax = max(amax, (uint32_t)__shfl_xor((int)amax, d, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63u) == 0) s_cnt[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t m = 0;
+        for (uint32_t w = 0; w < S3_BIN_THREADS / 64; ++w) m = max(m, s_cnt[w]);
+        *amax_out = m;
+    }
+}
+
+// max |dL/d feature| of the rows [b0, b0 + bs) of one feature-row pair (the run-length levels' maxima: their workgroups run in the
+// accumulate launch, behind this one)
+__device__ __forceinline__ void s3_rows_absmax(const float* __restrict__ d0p, uint32_t ld, uint32_t b0, uint32_t bs, uint32_t n,
+                                               const uint32_t* __restrict__ rows, uint32_t* s_red, uint32_t* __restrict__ out) {
+    uint32_t amax = 0;
+    for (uint32_t q = b0 + threadIdx.x; q < min(b0 + bs, n); q += S3_BIN_THREADS) {
+        const uint32_t i = rows ? rows[q] : q;
+        amax = max(amax, max(s3_abs_bits(d0p[i]), s3_abs_bits(d0p[(size_t)ld + i])));
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) amax = max(amax, (uint32_t)__shfl_xor((int)amax, d, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63u) == 0) s_red[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t m = 0;
+        for (uint32_t w = 0; w < S3_BIN_THREADS / 64; ++w) m = max(m, s_red[w]);
+        *out = m;
+    }
+    __syncthreads();                                                        // (s_red is the caller's to reuse)
 }
 
 template <int BS>
@@ -330,22 +431,40 @@ __global__ __launch_bounds__(S3_BIN_THREADS) void k_scatter_bin3(S3Plan pl, cons
     if (n_dev) n = min(n, *n_dev);
     uint32_t* __restrict__ cnt_out = counts + L.counts_off + sb;            // [part][sample block]
     uint32_t* __restrict__ ovfcnt_out = counts + pl.ovfcnt_off + e * pl.nsb + sb;
+    uint32_t* __restrict__ amax_out = counts + pl.amax_off + e * pl.nsb + sb;
     if (sb * BS >= n) {                                                     // uniform: an empty sample block has empty sub-bins
         for (uint32_t p = threadIdx.x; p < L.parts; p += S3_BIN_THREADS) cnt_out[(size_t)p * pl.nsb] = 0;
-        if (threadIdx.x == 0) *ovfcnt_out = 0;
+        if (threadIdx.x == 0) {
+            *ovfcnt_out = 0; *amax_out = 0;
+            for (uint32_t r = e; r < pl.n_rl; r += pl.n_lv) counts[pl.ramax_off + r * pl.nsb + sb] = 0;
+        }
         return;
     }
+    // (the workgroups of binned level e look at run-length level e, e + n_lv, ... of their sample block)
+    for (uint32_t r = e; r < pl.n_rl; r += pl.n_lv)
+        s3_rows_absmax(denc_t + (size_t)pl.rl_drow[r] * ld, ld, sb * BS, BS, n, rows, s_cnt, counts + pl.ramax_off + r * pl.nsb + sb);
     if (L.kind == S3_H)
-        s3_bin_block<S3_H, BS>(L, pl.lg, pl.nsb, pl.ovf_cap, sb, x, x_stride, denc_t, ld, n, rows, cnt_out, ovfcnt_out, bins, ovf, s_items, s_ipart,
+        s3_bin_block<S3_H, BS>(L, pl.lg, pl.nsb, pl.ovf_cap, sb, x, x_stride, denc_t, ld, n, rows, cnt_out, ovfcnt_out, amax_out, bins, ovf, s_items, s_ipart,
                                s_cnt, s_off, s_base, &s_ovf);
     else
-        s3_bin_block<S3_D, BS>(L, pl.lg, pl.nsb, pl.ovf_cap, sb, x, x_stride, denc_t, ld, n, rows, cnt_out, ovfcnt_out, bins, ovf, s_items, s_ipart,
+        s3_bin_block<S3_D, BS>(L, pl.lg, pl.nsb, pl.ovf_cap, sb, x, x_stride, denc_t, ld, n, rows, cnt_out, ovfcnt_out, amax_out, bins, ovf, s_items, s_ipart,
                                s_cnt, s_off, s_base, &s_ovf);
 }
 
+// (geometries with run-length levels but no binned level: nobody else records their maxima)
+__global__ __launch_bounds__(S3_BIN_THREADS) void k_scatter_rl_absmax(S3Plan pl, uint32_t bs, const float* __restrict__ denc_t, uint32_t ld, uint32_t n,
+                                                                      const uint32_t* __restrict__ n_dev, const uint32_t* __restrict__ rows,
+                                                                      uint32_t* __restrict__ counts) {
+    __shared__ uint32_t s_red[S3_BIN_THREADS / 64];
+    if (n_dev) n = min(n, *n_dev);
+    const uint32_t r = blockIdx.x % pl.n_rl, sb = blockIdx.x / pl.n_rl;
+    s3_rows_absmax(denc_t + (size_t)pl.rl_drow[r] * ld, ld, sb * bs, bs, n, rows, s_red, counts + pl.ramax_off + r * pl.nsb + sb);
+}
+
 // ------------------------------------------------------------------------------------------------ accumulate
-// One workgroup = (level, partition): fp64 LDS accumulators (returnless ds_add_f64: 8.6 ns per wave instruction, against 81 ns
-// for ds_add_f32 -- tools/lds_probe.hip), rounded to fp32 once when the partition is written to the table.
+// One workgroup = (level, partition): 8-byte LDS accumulators -- 64-bit fixed point (returnless ds_add_u64: 4.7 ns per wave instruction;
+// ds_add_f64, the accumulators of rounds 3-5 and of -DS3_FIX=0: 8.6 ns; ds_add_f32: 81 ns -- tools/lds_probe.hip), rounded to fp32
+// once when the partition is written to the table.
 // ---- Adam applied where the gradient of an entry is complete (XrAdamArgs, xr_adam.h): the scatter owns every table entry of
 // its levels exactly once per launch (what XR_SCATTER_OVERWRITE relies on), so instead of writing 48.8 MB of gradient that the
 // optimiser launch reads back next, the accumulate / fold kernels run the optimiser's update on (p, m, v, ema) themselves:
@@ -411,6 +530,7 @@ __device__ __forceinline__ void s3_accum_block(const S3Plan& pl, const uint32_t 
     const uint32_t my_sb = wave + WAVES * lane;
     const uint32_t vfill = my_sb < nsb ? cnt[my_sb] : 0u;
     const uint32_t vovf = my_sb < nsb ? counts[pl.ovfcnt_off + e * nsb + my_sb] : 0u;
+    const S3Scale sc = s3_scale(s3_level_max(counts + pl.amax_off + e * nsb, nsb), pl.n_bound);
     const float4* __restrict__ src = bins + L.bins_off + (size_t)part * nsb * cap;
     constexpr uint32_t U = 8;
     const uint32_t n_mine = nsb > wave ? (nsb - wave + WAVES - 1u) / WAVES : 0u;   // sub-bins of this wave
@@ -451,7 +571,7 @@ __device__ __forceinline__ void s3_accum_block(const S3Plan& pl, const uint32_t 
     __syncthreads();
     S3_T(3);
     uint32_t run_pr = 0xffffffffu;                                          // entry pair of the lane's current run (no item packs to all ones)
-    double r00 = 0.0, r01 = 0.0, r10 = 0.0, r11 = 0.0;
+    s3_acc_t r00 = 0, r01 = 0, r10 = 0, r11 = 0;
     for (;;) {
         float4 it[U];
         bool on[U];
@@ -466,32 +586,32 @@ __device__ __forceinline__ void s3_accum_block(const S3Plan& pl, const uint32_t 
             const float w0 = it[u].w, a = it[u].y, b = it[u].z;
             if (S3_MERGE) {
                 // a lane's successive items are successive items of its sub-bins (the permuted mapping): while they name the same
-                // entry pair -- samples of one ray inside one cell -- their four products are summed in registers (in fp64, like
+                // entry pair -- samples of one ray inside one cell -- their four products are summed in registers (as fixed-point integers, like
                 // the LDS accumulators) and go to the LDS once per run
                 if (pr != run_pr) {
                     if (run_pr != 0xffffffffu) {
                         const uint32_t i0 = run_pr & (S3_ENTRIES - 1), i1 = run_pr >> S3_LOG2;
-                        atomicAdd(&s_acc[2 * i0], r00); atomicAdd(&s_acc[2 * i0 + 1], r01);
-                        atomicAdd(&s_acc[2 * i1], r10); atomicAdd(&s_acc[2 * i1 + 1], r11);
+                        s3_lds_add(s_acc, 2 * i0, r00); s3_lds_add(s_acc, 2 * i0 + 1, r01);
+                        s3_lds_add(s_acc, 2 * i1, r10); s3_lds_add(s_acc, 2 * i1 + 1, r11);
                     }
-                    run_pr = pr; r00 = r01 = r10 = r11 = 0.0;
+                    run_pr = pr; r00 = r01 = r10 = r11 = 0;
                 }
-                r00 += (double)((1.f - w0) * a); r01 += (double)((1.f - w0) * b);
-                r10 += (double)(w0 * a); r11 += (double)(w0 * b);
+                r00 += s3_q((1.f - w0) * a, sc); r01 += s3_q((1.f - w0) * b, sc);
+                r10 += s3_q(w0 * a, sc); r11 += s3_q(w0 * b, sc);
             } else {
                 const uint32_t i0 = pr & (S3_ENTRIES - 1), i1 = pr >> S3_LOG2;
-                atomicAdd(&s_acc[2 * i0], (double)((1.f - w0) * a));
-                atomicAdd(&s_acc[2 * i0 + 1], (double)((1.f - w0) * b));
-                atomicAdd(&s_acc[2 * i1], (double)(w0 * a));
-                atomicAdd(&s_acc[2 * i1 + 1], (double)(w0 * b));
+                s3_lds_add(s_acc, 2 * i0, s3_q((1.f - w0) * a, sc));
+                s3_lds_add(s_acc, 2 * i0 + 1, s3_q((1.f - w0) * b, sc));
+                s3_lds_add(s_acc, 2 * i1, s3_q(w0 * a, sc));
+                s3_lds_add(s_acc, 2 * i1 + 1, s3_q(w0 * b, sc));
             }
         }
         if (!more) break;
     }
     if (S3_MERGE && run_pr != 0xffffffffu) {
         const uint32_t i0 = run_pr & (S3_ENTRIES - 1), i1 = run_pr >> S3_LOG2;
-        atomicAdd(&s_acc[2 * i0], r00); atomicAdd(&s_acc[2 * i0 + 1], r01);
-        atomicAdd(&s_acc[2 * i1], r10); atomicAdd(&s_acc[2 * i1 + 1], r11);
+        s3_lds_add(s_acc, 2 * i0, r00); s3_lds_add(s_acc, 2 * i0 + 1, r01);
+        s3_lds_add(s_acc, 2 * i1, r10); s3_lds_add(s_acc, 2 * i1 + 1, r11);
     }
     S3_T(4);
     // overflow records of the level's sample blocks (none unless the samples cluster): every partition scans them all
@@ -503,8 +623,8 @@ __device__ __forceinline__ void s3_accum_block(const S3Plan& pl, const uint32_t 
                 const float4 rcd = ov[q];
                 const uint32_t key = __float_as_uint(rcd.x);
                 if ((key >> S3_LOG2) != part) continue;
-                atomicAdd(&s_acc[2 * (key & (S3_ENTRIES - 1))], (double)rcd.y);
-                atomicAdd(&s_acc[2 * (key & (S3_ENTRIES - 1)) + 1], (double)rcd.z);
+                s3_lds_add(s_acc, 2 * (key & (S3_ENTRIES - 1)), s3_q(rcd.y, sc));
+                s3_lds_add(s_acc, 2 * (key & (S3_ENTRIES - 1)) + 1, s3_q(rcd.z, sc));
             }
         }
     }
@@ -540,10 +660,10 @@ __device__ __forceinline__ void s3_accum_block(const S3Plan& pl, const uint32_t 
             for (uint32_t k = 0; k < FH; ++k) { const uint32_t q = 2u * ((r * FH + k) * THREADS + threadIdx.x); a0[k] = acc2[q]; a1[k] = acc2[q + 1]; }
 #pragma unroll
             for (uint32_t k = 0; k < FH; ++k) {
-                adam1(fp_[k].x, (float)a0[k].x, fm_[k].x, fv_[k].x, A.b1, A.b2, A.step_size, A.bc2s, A.eps, A.wd, A.gs);
-                adam1(fp_[k].y, (float)a0[k].y, fm_[k].y, fv_[k].y, A.b1, A.b2, A.step_size, A.bc2s, A.eps, A.wd, A.gs);
-                adam1(fp_[k].z, (float)a1[k].x, fm_[k].z, fv_[k].z, A.b1, A.b2, A.step_size, A.bc2s, A.eps, A.wd, A.gs);
-                adam1(fp_[k].w, (float)a1[k].y, fm_[k].w, fv_[k].w, A.b1, A.b2, A.step_size, A.bc2s, A.eps, A.wd, A.gs);
+                adam1(fp_[k].x, s3_val(a0[k].x, sc), fm_[k].x, fv_[k].x, A.b1, A.b2, A.step_size, A.bc2s, A.eps, A.wd, A.gs);
+                adam1(fp_[k].y, s3_val(a0[k].y, sc), fm_[k].y, fv_[k].y, A.b1, A.b2, A.step_size, A.bc2s, A.eps, A.wd, A.gs);
+                adam1(fp_[k].z, s3_val(a1[k].x, sc), fm_[k].z, fv_[k].z, A.b1, A.b2, A.step_size, A.bc2s, A.eps, A.wd, A.gs);
+                adam1(fp_[k].w, s3_val(a1[k].y, sc), fm_[k].w, fv_[k].w, A.b1, A.b2, A.step_size, A.bc2s, A.eps, A.wd, A.gs);
                 const size_t i4 = f4_0 + (r * FH + k) * THREADS + threadIdx.x;
                 reinterpret_cast<float4*>(A.p)[i4] = fp_[k]; s3_st4nt(A.m, i4, fm_[k]); s3_st4nt(A.v, i4, fv_[k]);
                 if (A.ema) {
@@ -570,7 +690,7 @@ __device__ __forceinline__ void s3_accum_block(const S3Plan& pl, const uint32_t 
                     else if (q < lat) { const uint32_t rl = q / res; idx = ((rl << L.plog2) | part) * res + (q - rl * res); }
                     else idx = res * res * res + (q - lat);
                     const double2 a = acc2[q];
-                    g[k] = make_float2((float)a.x, (float)a.y);
+                    g[k] = make_float2(s3_val(a.x, sc), s3_val(a.y, sc));
                 }
                 e[k] = (size_t)L.toff + idx;
             }
@@ -585,7 +705,7 @@ __device__ __forceinline__ void s3_accum_block(const S3Plan& pl, const uint32_t 
 #pragma unroll
         for (uint32_t k = 0; k < F; ++k) {
             const double2 a = acc2[k * THREADS + threadIdx.x];
-            t[k].x += (float)a.x; t[k].y += (float)a.y;
+            t[k].x += s3_val(a.x, sc); t[k].y += s3_val(a.y, sc);
             dst[k * THREADS + threadIdx.x] = t[k];
         }
     } else {
@@ -596,7 +716,7 @@ __device__ __forceinline__ void s3_accum_block(const S3Plan& pl, const uint32_t 
             else idx = res * res * res + (q - lat);                          // padding entries behind the lattice (partition 0)
             const double2 a = acc2[q];
             float2 t = add ? tab[idx] : make_float2(0.f, 0.f);
-            t.x += (float)a.x; t.y += (float)a.y;
+            t.x += s3_val(a.x, sc); t.y += s3_val(a.y, sc);
             tab[idx] = t;
         }
     }
@@ -612,32 +732,34 @@ __device__ __forceinline__ void s3_accum_block(const S3Plan& pl, const uint32_t 
 // ------------------------------------------------------------------------------------------------ small dense levels
 // kind R.  Workgroup = (level, 2^13-entry partition, chunk of the rows): thread t walks rows [16 t, 16 t + 16) of its chunk
 // keeping the 8 corners x 2 features of the CURRENT cell in registers; on a cell change the 16 sums go to the workgroup's
-// fp64 LDS copy of the partition (only the corners that fall into it).  The chunk's partition is then written as fp32 into
+// 8-byte-per-sum LDS copy of the partition (only the corners that fall into it).  The chunk's partition is then written as fp32 into
 // slab `chunk` of the workspace; k_scatter_fold adds the slabs in fixed order.
 // Measured and dropped (round 3): a variant that reads the rows with coalesced loads (lane = row) and transposes them through
 // a per-wave LDS tile so that lane l can walk rows 16 l .. 16 l + 15 -- 46.6 us against 36.8: with any lane of a wave flushing at
 // nearly every step, the kernel issues its 16 LDS atomic instructions per step either way, and those, not the loads, set its time.
 __device__ __forceinline__ void s3_r_flush(double* s_acc, const float (&acc)[16], uint32_t g0, uint32_t g1, uint32_t g2, uint32_t res,
-                                           uint32_t hsize, uint32_t part) {
+                                           uint32_t hsize, uint32_t part, const S3Scale& sc) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const uint32_t idx = s3_wrap((g0 + (c & 1)) + (g1 + ((c >> 1) & 1)) * res + (g2 + (c >> 2)) * res * res, hsize);
         if ((idx >> S3_LOG2) != part) continue;
         const uint32_t q = idx & (S3_ENTRIES - 1);
-        if (acc[2 * c] != 0.f) atomicAdd(&s_acc[2 * q], (double)acc[2 * c]);
-        if (acc[2 * c + 1] != 0.f) atomicAdd(&s_acc[2 * q + 1], (double)acc[2 * c + 1]);
+        if (acc[2 * c] != 0.f) s3_lds_add(s_acc, 2 * q, s3_q(acc[2 * c], sc));
+        if (acc[2 * c + 1] != 0.f) s3_lds_add(s_acc, 2 * q + 1, s3_q(acc[2 * c + 1], sc));
     }
 }
 
 template <int TH>
 __device__ __forceinline__ void s3_rl_block(const S3RPlan& pl, const uint32_t blk, const float* __restrict__ x, uint32_t x_stride,
                                             const float* __restrict__ denc_t, uint32_t ld, uint32_t n, const uint32_t* __restrict__ rows,
-                                            float2* __restrict__ slabs, double* s_acc /* [<= S3_ENTRIES][2] */) {
+                                            const uint32_t* __restrict__ counts, float2* __restrict__ slabs, double* s_acc /* [<= S3_ENTRIES][2] */) {
     constexpr uint32_t S3_R_THREADS = (uint32_t)TH;
     uint32_t e = 0;
     while (e + 1 < pl.n_lv && blk >= pl.lv[e + 1].block0) ++e;
     const S3RLevel& L = pl.lv[e];
     const uint32_t rel = blk - L.block0, part = rel / pl.chunks, chunk = rel % pl.chunks;
+    // (a thread's run sums are fp32 sums of <= 16 rows' contributions in row order: partial sums of the terms the bound counts)
+    const S3Scale sc = s3_scale(s3_level_max(counts + pl.ramax_off + e * pl.nsb, pl.nsb), pl.n_bound);
     const uint32_t p_lo = part << S3_LOG2, n_loc = min(S3_ENTRIES, L.hsize - p_lo);
     double2* acc2 = reinterpret_cast<double2*>(s_acc);
     for (uint32_t q = threadIdx.x; q < n_loc; q += S3_R_THREADS) acc2[q] = make_double2(0.0, 0.0);
@@ -675,7 +797,7 @@ __device__ __forceinline__ void s3_rl_block(const S3RPlan& pl, const uint32_t bl
                 const uint32_t g0 = (uint32_t)(int)f0, g1 = (uint32_t)(int)f1, g2 = (uint32_t)(int)f2;
                 const float w0 = p0 - f0, w1 = p1 - f1, w2 = p2 - f2;
                 if (!(g0 == c0 && g1 == c1 && g2 == c2)) {
-                    if (c0 != 0xffffffffu) s3_r_flush(s_acc, acc, c0, c1, c2, res, hsize, part);
+                    if (c0 != 0xffffffffu) s3_r_flush(s_acc, acc, c0, c1, c2, res, hsize, part, sc);
                     c0 = g0; c1 = g1; c2 = g2;
 #pragma unroll
                     for (int k = 0; k < 16; ++k) acc[k] = 0.f;
@@ -687,13 +809,13 @@ __device__ __forceinline__ void s3_rl_block(const S3RPlan& pl, const uint32_t bl
                 }
             }
         }
-        if (c0 != 0xffffffffu) s3_r_flush(s_acc, acc, c0, c1, c2, res, hsize, part);
+        if (c0 != 0xffffffffu) s3_r_flush(s_acc, acc, c0, c1, c2, res, hsize, part, sc);
     }
     __syncthreads();
     float2* __restrict__ dst = slabs + (size_t)chunk * pl.slab_entries + L.poff + p_lo;
     for (uint32_t q = threadIdx.x; q < n_loc; q += S3_R_THREADS) {
         const double2 a = acc2[q];
-        dst[q] = make_float2((float)a.x, (float)a.y);
+        dst[q] = make_float2(s3_val(a.x, sc), s3_val(a.y, sc));
     }
 }
 
@@ -714,7 +836,7 @@ __global__ __launch_bounds__(TH) void k_scatter_acc(S3Plan pl, S3RPlan rpl, cons
     const uint32_t blk = blockIdx.x - n_tail;
     if (blk < rpl.blocks) {
         if (n_dev) n = min(n, *n_dev);
-        s3_rl_block<TH>(rpl, blk, x, x_stride, denc_t, ld, n, rows, slabs, s_acc);
+        s3_rl_block<TH>(rpl, blk, x, x_stride, denc_t, ld, n, rows, counts, slabs, s_acc);
     } else
         s3_accum_block<LG, TH>(pl, blk - rpl.blocks, counts, bins, ovf, grad_table, s_acc);
 }
@@ -753,7 +875,7 @@ __global__ __launch_bounds__(256) void k_scatter_fold(S3RPlan pl, const float2* 
 // quickly), samples per binning workgroup (1024 | 2048 | 4096), row chunks per partition of the run-length kernel, rl=0 the small
 // dense levels through the bins.  Measurement-only alternatives of earlier rounds are compile-time now (S3_LOG2, S3_ACC_THREADS,
 // S3_RL_ASYNC: tools/build_variant.sh) or gone with their records under profiles/.
-struct S3Test { int min_n = 16384, block = 2048, rl_chunks = 8, rl = 1; };
+struct S3Test { int min_n = 16384, block = 4096, rl_chunks = 8, rl = 1; };
 static const S3Test& s3_test() {
     static const S3Test t = []() {
         S3Test v;
@@ -761,7 +883,7 @@ static const S3Test& s3_test() {
         while (e && *e) {
             int val = 0;
             if (sscanf(e, "min_n=%d", &val) == 1) v.min_n = val;
-            else if (sscanf(e, "block=%d", &val) == 1) v.block = (val == 1024 || val == 4096) ? val : 2048;
+            else if (sscanf(e, "block=%d", &val) == 1) v.block = (val == 1024 || val == 2048) ? val : 4096;
             else if (sscanf(e, "rl_chunks=%d", &val) == 1) v.rl_chunks = (val >= 1 && val <= 64) ? val : 8;
             else if (sscanf(e, "rl=%d", &val) == 1) v.rl = val != 0;
             const char* c = strchr(e, ',');
@@ -771,7 +893,7 @@ static const S3Test& s3_test() {
     }();
     return t;
 }
-static uint32_t s3_block_samples() { return (uint32_t)s3_test().block; }     // measured 152 / 139 / 155 us for 4096 / 2048 / 1024
+static uint32_t s3_block_samples() { return (uint32_t)s3_test().block; }     // round 3 (beside the run-length kernel): 152 / 139 / 155 us for 4096 / 2048 / 1024; round 6 (one stream): 148-150 / 152-153 / 166
 static uint32_t s3_chunks() { return (uint32_t)s3_test().rl_chunks; }     // (round 6, inside the accumulate launch with 8 waves: 147-155 us at 8, 158-160 at 16 / 6, 170 at 4)
 #ifndef S3_ACC_THREADS_DEFAULT
 #define S3_ACC_THREADS_DEFAULT 512      // 512 | 1024 threads per workgroup of the accumulate launch: the same time alone
@@ -836,6 +958,11 @@ static bool s3_layout(uint32_t n, const GridMeta& gm, uint32_t hashed_mask, int 
             L.acc_block0 = P.bin.acc_blocks; P.bin.acc_blocks += L.parts;
         }
     P.bin.ovfcnt_off = counts_off; counts_off += P.bin.n_lv * nsb;
+    P.bin.amax_off = counts_off; counts_off += P.bin.n_lv * nsb;
+    P.bin.ramax_off = P.rl.ramax_off = counts_off; counts_off += P.rl.n_lv * nsb;
+    P.bin.n_rl = P.rl.n_lv; P.rl.nsb = nsb;
+    for (uint32_t r = 0; r < P.rl.n_lv; ++r) P.bin.rl_drow[r] = P.rl.lv[r].drow;
+    P.bin.n_bound = P.rl.n_bound = (nsb * (uint64_t)bs > 0xffffffffull) ? 0xffffffffu : nsb * bs;
     P.counts_bytes = (((size_t)counts_off * sizeof(uint32_t)) + 255) & ~(size_t)255;
     P.bins_bytes = (size_t)bins_off * sizeof(float4);
     P.ovf_bytes = (size_t)ovf_off * sizeof(float4);
@@ -914,6 +1041,10 @@ int xr_scatter3(const float* x, uint32_t x_stride, const float* denc_t, uint32_t
         if (bs == 4096) hipLaunchKernelGGL(k_scatter_bin3<4096>, grid, block, 0, stream, P.bin, x, x_stride, denc_t, ld, n, n_dev, rows, counts, bins, ovf, aux_blocks, aux);
         else if (bs == 2048) hipLaunchKernelGGL(k_scatter_bin3<2048>, grid, block, 0, stream, P.bin, x, x_stride, denc_t, ld, n, n_dev, rows, counts, bins, ovf, aux_blocks, aux);
         else hipLaunchKernelGGL(k_scatter_bin3<1024>, grid, block, 0, stream, P.bin, x, x_stride, denc_t, ld, n, n_dev, rows, counts, bins, ovf, aux_blocks, aux);
+        XR_LAUNCH_CHECK();
+    }
+    if (!P.bin.n_lv && P.rl.n_lv) {                   // nobody else records the run-length levels' maxima
+        hipLaunchKernelGGL(k_scatter_rl_absmax, dim3(P.rl.n_lv * P.bin.nsb), dim3(S3_BIN_THREADS), 0, stream, P.bin, s3_block_samples(), denc_t, ld, n, n_dev, rows, counts);
         XR_LAUNCH_CHECK();
     }
     if (P.rl.blocks + P.bin.acc_blocks) {
