@@ -184,3 +184,27 @@ def test_raymarch_cuda_shim_like_the_reference_wrappers(O, lego, dev):
     ro, rnc, rrc, rsc = O.compacted_coord(ref[0][:s], ref[2], 1 << 18)
     assert np.array_equal(nc.cpu().numpy(), rnc) and int(c2) == int(rsc[0]) and int(c1) == int(rrc[0])
     assert np.array_equal(bits(out[:s].cpu().numpy()), bits(ro[:s])) and float(out[s:].abs().max()) == 0.0
+
+
+def test_training_at_full_size_is_the_same_bits_run_to_run(dev):
+    """The headline configuration (800 x 800 rays, 2^18-sample batches, native loop, every update inside the scatter) twice from the
+    same seed, 40 iterations across three grid refreshes: parameters, Adam moments, EMA copies, occupancy grid, bitfield and every
+    counter bit for bit.  Every sum of the step has a fixed order -- the MLP backward's partials, the compositor's prefixes, the loss
+    scalars -- and since round 6 the table scatter's LDS sums are integers (xr_scatter.hip, S3_FIX)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_network import _trainer_state
+    from xrnerf_amd.train import Trainer
+    out = []
+    for _ in range(2):
+        tr = Trainer(dev, n_img=4, H=800, W=800, seed=11)
+        last = tr.run(40)
+        torch.cuda.synchronize()
+        assert tr._loop is not None
+        out.append(_trainer_state(tr) + (float(last['loss']),))
+        del tr
+    a, b = out
+    assert a[1] == b[1] and a[4] == b[4]
+    for s, t in zip(a[0], b[0]):
+        assert torch.equal(s, t)
+    assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])

@@ -10,7 +10,18 @@
 // caller's stream behind all of them.
 #include "xr_common.h"
 #include <dlfcn.h>
+#include <mutex>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+// A ROCm install without the RCCL development headers still builds the library (a single-GPU process never calls in here): the few
+// types this file hands through are NCCL's stable ABI -- a 128-byte id, an opaque communicator, the float / sum enumerators.
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef struct ncclComm* ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclFloat = 7 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+#endif
 
 namespace {
 struct RcclApi {
@@ -25,7 +36,9 @@ struct RcclApi {
 };
 RcclApi g_api;
 
+std::mutex g_api_lock;
 int load_rccl(const char* path) {
+    std::lock_guard<std::mutex> hold(g_api_lock);       // (two threads creating their communicators at once)
     if (g_api.lib) return XR_OK;
     // a copy the process has already mapped (torch.distributed's) is reused; else the given path, else the system library
     void* h = nullptr;
@@ -33,14 +46,16 @@ int load_rccl(const char* path) {
     for (const char* nm : names) if (nm && !h) h = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);
     for (const char* nm : names) if (nm && !h) h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
     if (!h) { xr_set_error("xr_rccl: cannot load librccl (%s)", dlerror()); return XR_EHIP; }
-    g_api.lib = h;
+    RcclApi api;                                        // filled completely before it is published: a missing symbol leaves g_api untouched
 #define XR_SYM(field, name) \
-    *(void**)(&g_api.field) = dlsym(h, name); \
-    if (!g_api.field) { xr_set_error("xr_rccl: librccl has no %s", name); g_api.lib = nullptr; return XR_EHIP; }
+    *(void**)(&api.field) = dlsym(h, name); \
+    if (!api.field) { xr_set_error("xr_rccl: librccl has no %s", name); return XR_EHIP; }
     XR_SYM(GetUniqueId, "ncclGetUniqueId") XR_SYM(CommInitRank, "ncclCommInitRank") XR_SYM(CommDestroy, "ncclCommDestroy")
     XR_SYM(AllReduce, "ncclAllReduce") XR_SYM(ReduceScatter, "ncclReduceScatter") XR_SYM(AllGather, "ncclAllGather")
     XR_SYM(GetErrorString, "ncclGetErrorString")
 #undef XR_SYM
+    api.lib = h;
+    g_api = api;
     return XR_OK;
 }
 
@@ -112,6 +127,7 @@ extern "C" int xr_rccl_unique_id(const char* librccl_path, void* id128) {
 }
 // collective call (every rank of the job): a communicator over the current device, its stream and two events.  The one place of this
 // library that creates a handle: communicators cannot be caller-provided memory.
+extern "C" int xr_rccl_destroy(void* handle);
 extern "C" void* xr_rccl_create(const char* librccl_path, const void* id128, int world_size, int rank) {
     if (!id128 || world_size < 1 || rank < 0 || rank >= world_size) { xr_set_error("xr_rccl_create: bad argument"); return nullptr; }
     if (load_rccl(librccl_path) != XR_OK) return nullptr;
@@ -125,7 +141,8 @@ extern "C" void* xr_rccl_create(const char* librccl_path, const void* id128, int
         hipEventCreateWithFlags(&C->ready, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&C->done, hipEventDisableTiming) != hipSuccess) {
         xr_set_error("xr_rccl_create: cannot create the stream / events");
-        g_api.CommDestroy(C->comm); delete C; return nullptr;
+        (void)xr_rccl_destroy(C);                       // releases whatever of the three exists, and the communicator
+        return nullptr;
     }
     return C;
 }

@@ -112,7 +112,9 @@ if _PRECISION not in ('f32', 'f16'):
 # block, fp32 accumulate: within a few ulps of fp32 at half the matrix instructions of the 3-way split), 'bf16x3' =
 # XR_MLP_BF16X3 (three bf16 parts, six MFMAs: fp32-rounding accuracy), 'mfma' = XR_MLP_F32 (v_mfma_f32_32x32x2_f32).
 # Depths other than (1, 2) run the streamed kernel (f16x2 arithmetic) whatever this says, except (1,1), (2,2), (2,3) under 'mfma'.
-_F32_FORWARD = 'f16x2'          # (set_f32_forward)
+_F32_FORWARD = os.environ.get('XRNERF_F32_FORWARD', 'f16x2')          # (set_f32_forward; switches.py)
+if _F32_FORWARD not in ('f16x2', 'bf16x3', 'mfma'):
+    raise ValueError("XRNERF_F32_FORWARD must be 'f16x2', 'bf16x3' or 'mfma' (got %r)" % _F32_FORWARD)
 
 
 def f32_forward():

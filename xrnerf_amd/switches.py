@@ -3,7 +3,13 @@ itself).  tools/README.md lists every switch with the test that covers it; every
 a compile-time constant of one source (tools/build_variant.sh + XRNERF_LIB) or gone, with its record under profiles/.
 
   XRNERF_LIB                   path of another build of the library (_lib.py)
-  XRNERF_MLP_PRECISION         f32 (default, parity mode) | f16 (the reference's tcnn arithmetic) -- ops.set_precision
+  XRNERF_MLP_PRECISION         f32 (default: fp32 storage, gradients and accumulation) | f16 (the reference's tcnn arithmetic) -- ops.set_precision
+  XRNERF_F32_FORWARD           the fused MLP's product arithmetic in the f32 mode (ops.set_f32_forward): f16x2 (default -- every fp32
+                               operand as two fp16 parts, three fp16 MFMAs per product block: ~4e-7 relative on the raw outputs, NOT
+                               fp32-exact; operands above 65504 are saturated and counted, the trainer warns) | bf16x3 (three bf16
+                               parts, fp32-rounding accuracy, no range limit below fp32's) | mfma (v_mfma_f32_32x32x2_f32: plain fp32).
+                               The backward follows through XR_MLP_BWD_DW (h2f default | b2x | f32): `mfma` + XR_MLP_BWD_DW=f32 is
+                               the fp32-exact pair the strict gradient bars of the tests are held against
   XRNERF_DP                    allreduce (default) | allreduce_bf16 (the table gradient crosses the links as bf16) | zero1 -- the
                                data-parallel gradient exchange (train.Trainer, dist.py)
   XRNERF_TRAINER               "k=v,..." overrides of Trainer's keyword switches: native_loop, fuse_adam, direct_step, march_window
