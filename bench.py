@@ -106,7 +106,10 @@ def mipnerf_config3(dev, steps=20, warmup=5, cpu_seconds=10.0):
     R, S = cfg['N_rand_per_sampler'], cfg['num_samples']
     torch.manual_seed(0)
     net = xrnerf_amd.build_network(cfg['model']).to(dev)
-    opt = torch.optim.Adam(net.parameters(), lr=cfg['optimizer']['lr'])
+    # the config's Adam (torch.optim.Adam's update rule and defaults) as this package's multi-tensor launches: four tensors per launch
+    # instead of torch's chain of foreach kernels over the 44 parameter tensors
+    from xrnerf_amd.train import FusedAdam
+    opt = FusedAdam(list(net.parameters()), lr=cfg['optimizer']['lr'], betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, ema_momentum=None)
     rays = mip.synthetic_multiscale_rays(R, dev, seed=1)
 
     def step():

@@ -239,10 +239,11 @@ int xr_hashgrid_bwd(const float* x, uint32_t x_stride, const float* denc_t, uint
                     const uint32_t* n_dev, const uint32_t* rows, int n_levels, const float* scale_host, const uint32_t* resolution_host,
                     const uint32_t* offset_host, float* grad_table, void* workspace, size_t workspace_bytes, int flags,
                     void* stream);
-/* The scatter (and with it xr_ngp_train_step / xr_ngp_loop_run) can run its small dense levels, the reduction of the MLP gradients and
- * the small optimiser launches on a HELPER stream beside its two large kernels.  The library creates no stream or event: the caller
- * hands over one stream and two events (fork / join; plain hipEvent_t, timing not needed) once per host thread; null stream = none,
- * everything then runs in order on the caller's stream (same results). */
+/* A HELPER stream for xr_hashgrid_bwd's fallback: geometries where some levels take the atomic kernel and others the binned path run the
+ * two beside each other on it.  The library creates no stream or event: the caller hands over one stream and two events (fork / join;
+ * plain hipEvent_t, timing not needed) once per host thread; null stream = none, everything then runs in order on the caller's stream
+ * (same results).  (Rounds 3-5 also ran the binned scatter's small dense levels and xr_ngp_train_step's small sums and updates on it;
+ * since round 6 those ride inside the scatter's own launches on the caller's stream -- a training iteration records and waits for no event.) */
 int xr_set_helper_stream(void* stream, void* fork_event, void* join_event);
 /* tcnn.Encoding otype=SphericalHarmonics degree 4; dirs in [0,1] (the sampler's warp_direction);
  * out row-major [n,16] */
@@ -366,10 +367,10 @@ int xr_nerf_density_splat(int mlp_mode, const float* enc_t, uint32_t ld, uint32_
  * grad_table's slices of the scattered levels are WRITTEN (no zero-fill; whatever they held is gone).
  * table_adam (nullable): the scatter becomes xr_hashgrid_bwd_adam -- the table is UPDATED by this call and grad_table (then
  * nullable) is not written; single GPU, scatter_level0 == 0.
- * w_density_adam / w_color_adam (both or neither, same step and constants): xr_adam_step_multi on the two MLP tensors right behind
- * the reduction of their gradients, on the helper stream the scatter forks (joined before the call's work ends on `stream`).
+ * w_density_adam / w_color_adam (both or neither, same step and constants): xr_adam_step_multi's update of the two MLP tensors right
+ * behind the fixed-order sum of their gradient partials -- both inside the scatter's binning launch (same bits as the two launches).
  * live_seg_count (nullable): XR_LIVE_ROWS_SEGMENTS(n_rows) words for the per-segment counts, ZERO on entry; the call leaves them
- * zero again (cleared on its helper stream after use).  Null: the slot in ws_mlp_bwd, cleared by a fill on `stream`.
+ * zero again (cleared inside the scatter's accumulate launch).  Null: the slot in ws_mlp_bwd, cleared by a fill on `stream`.
  * zero_block / zero_floats: kept for the layout (grad_w_density, grad_w_color, loss_mse live in it); nothing in it is zero-filled
  * any more -- the two gradient buffers and loss_mse[0..1] are WRITTEN.
  * coords: K1's [n_rows,7] rows (positions / directions consumed in place); n_dev: device count of valid rows; every buffer
@@ -682,6 +683,10 @@ int xr_linear_backward_weight(const float* dy, uint32_t lddy, const float* mask_
                               uint32_t K, uint32_t splits, float* dw_partials, float* db_partials, size_t part_stride, void* stream);
 int xr_linear_backward_bias(const float* dy, const float* mask_src, uint32_t M, uint32_t N, uint32_t splits,
                             float* db_partials, void* stream);
+/* out[j] = sum over b of partials[b * stride + j], j < n, in a FIXED order (every 4th partial per row group, 16 loads in flight, the four
+ * group sums as (0 + 1) + (2 + 3)): what finishes the split weight / bias gradients above -- and the fused MLP's gradient partials -- with
+ * one launch at memory speed (torch's `partials.sum(0)` took 17 us per 67-MB set of a 256 x 256 layer, this 11).  out is WRITTEN. */
+int xr_sum_partials(const float* partials, uint32_t n_partials, size_t stride, uint32_t n, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -150,6 +150,7 @@ SIGNATURES = {
     'xr_linear_backward_input': (_i32, [_vp, _u32, _vp, _vp, _i32, _u32, _u32, _u32, _vp, _vp]),
     'xr_linear_backward_splits': (_u32, [_u32, _u32, _u32]),
     'xr_linear_backward_bias': (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp]),
+    'xr_sum_partials': (_i32, [_vp, _u32, _sz, _u32, _vp, _vp]),
     'xr_linear_backward_weight': (_i32, [_vp, _u32, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _sz, _vp]),
     'xr_kilo_render_workspace_bytes': (_sz, [_u32, _u32, _u32]),
     'xr_kilo_render_rays': (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32,

@@ -623,7 +623,10 @@ extern "C" uint32_t xr_linear_backward_splits(uint32_t M, uint32_t N, uint32_t K
     // workgroups exist, but keep >= 8 k-panels (256 rows) per split (measured: 16 splits of 2048 rows = 64 workgroups
     // left 3/4 of the chip idle, 110-290 us per 32768-row call)
     const uint32_t tiles = xr_div_up(N, GBM) * xr_div_up(K, GBN);
-    uint32_t s = 1024 / (tiles ? tiles : 1);
+#ifndef XR_GEMM_SPLIT_WGS
+#define XR_GEMM_SPLIT_WGS 1024
+#endif
+    uint32_t s = XR_GEMM_SPLIT_WGS / (tiles ? tiles : 1);
     const uint32_t by_rows = M / 256;
     if (s > by_rows) s = by_rows;
     return s < 1 ? 1 : (s > 4096 ? 4096 : s);

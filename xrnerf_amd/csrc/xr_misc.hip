@@ -12,7 +12,7 @@ void xr_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* xr_last_error(void) { return g_err; }
-extern "C" int xr_version(void) { return 121; }    // 121: xr_nerf_mlp_fwd / _bwd take their arithmetic as an argument; small merges.  120 (round 5): one generation per entry point (xr_rays_sampler, xr_hashgrid_fwd / _bwd, xr_composite_train,
+extern "C" int xr_version(void) { return 122; }    // 122 (round 6): xr_sum_partials, xr_set_mlp_range_word, xr_ema_update_bitfield, strided linear kernels, the scatter on one stream.  121: xr_nerf_mlp_fwd / _bwd take their arithmetic as an argument; small merges.  120 (round 5): one generation per entry point (xr_rays_sampler, xr_hashgrid_fwd / _bwd, xr_composite_train,
                                                    // xr_live_rows, xr_generate_grid_samples, xr_clip_numsteps take their newest signatures), window march, loop without a handle
 
 extern "C" void xr_pcg32_host_state(uint64_t seed, uint64_t ncalls, uint64_t* state_host, uint64_t* inc_host) {

@@ -1040,6 +1040,27 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict
     xr_aux_reduce_block<256>(w, blockIdx.x, red);
 }
 
+// the same fixed-order sum for any [n_partials][stride] buffer (xr_sum_partials): columns j < n
+__global__ __launch_bounds__(256) void k_sum_partials(const float* __restrict__ partial, uint32_t nb, uint32_t stride, uint32_t n, float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const uint32_t c = threadIdx.x & 63u, rg = threadIdx.x >> 6, j = blockIdx.x * 64 + c;
+    float s = 0.f;
+    if (j < n) {
+        uint32_t b = rg;
+        for (; b + 4 * 15 < nb; b += 4 * 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = partial[(size_t)(b + 4 * u) * stride + j];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += v[u];
+        }
+        for (; b < nb; b += 4) s += partial[(size_t)b * stride + j];
+    }
+    red[rg][c] = s;
+    __syncthreads();
+    if (rg == 0 && j < n) out[j] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
 // ------------------------------------------------------------------ generic single network
 // tcnn.Network(FullyFusedMLP) used on its own: x [n, n_in] (arbitrary row / column strides, n_in <= 32,
 // missing input columns are filled with pad_value like tcnn's Identity-encoded input) -> y [n, 16] row-major.
@@ -2446,6 +2467,15 @@ int xr_internal_mlp_bwd_reduce(const void* workspace, uint32_t n, int nhd, int n
     const uint32_t GW = gwd + (deep ? (uint32_t)deep_glb_floats(nhc) : (uint32_t)NetShape<2>::glb_floats);
     hipLaunchKernelGGL(k_reduce_partials, dim3(xr_div_up(GW, 64)), dim3(256), 0, (hipStream_t)stream_, (const float*)bwd_partials(workspace, n),
                        deep ? bwd_grid_deep(n) : bwd_grid(n), GW, gwd, grad_w_density, grad_w_color, overwrite);
+    XR_LAUNCH_CHECK();
+    return XR_OK;
+}
+
+extern "C" int xr_sum_partials(const float* partials, uint32_t n_partials, size_t stride, uint32_t n, float* out, void* stream_) {
+    if (n == 0) return XR_OK;
+    XR_REQUIRE(partials && out && n_partials >= 1 && stride >= n && stride <= 0xffffffffull, "bad argument");
+    // (k_reduce_partials addresses partial[b][j] with a row length of gw: the stride is the row length, columns >= n are not touched)
+    hipLaunchKernelGGL(k_sum_partials, dim3(xr_div_up(n, 64)), dim3(256), 0, (hipStream_t)stream_, partials, n_partials, (uint32_t)stride, n, out);
     XR_LAUNCH_CHECK();
     return XR_OK;
 }

@@ -1412,6 +1412,15 @@ def linear_backward_input(dy, mask_src, w, w_t=None):
     return dx
 
 
+def sum_partials(part):
+    """[splits, n] per-range partial sums -> [n]: one fixed-order launch (xr_sum_partials)"""
+    if part.shape[0] == 1:
+        return part[0]
+    out = torch.empty((part.shape[1],), dtype=torch.float32, device=part.device)
+    _lib.check(_lib.load().xr_sum_partials(_ptr(part), part.shape[0], part.stride(0), part.shape[1], _ptr(out), _stream()), 'xr_sum_partials')
+    return out
+
+
 def linear_backward_weight(dy, mask_src, x):
     """dw [N,K] = (dy where mask_src > 0)^T . x   (fixed-order sum of the per-M-range partials)"""
     L = _lib.load()
@@ -1425,7 +1434,7 @@ def linear_backward_weight(dy, mask_src, x):
         _lib.check(L.xr_linear_backward_weight(C.c_void_p(dy.data_ptr()), ld, C.c_void_p(mask_src.data_ptr()) if mask_src is not None else None,
                                                C.c_void_p(x.data_ptr()), ldx, M, N, K, splits, _ptr(part), None, 0, _stream()),
                    'xr_linear_backward_weight')
-    return part[0] if splits == 1 else part.sum(0)
+    return sum_partials(part.view(splits, N * K)).view(N, K)
 
 
 def linear_backward_weight_bias(dy, mask_src, x):
@@ -1442,7 +1451,7 @@ def linear_backward_weight_bias(dy, mask_src, x):
         _lib.check(L.xr_linear_backward_weight(C.c_void_p(dy.data_ptr()), ld, C.c_void_p(mask_src.data_ptr()) if mask_src is not None else None,
                                                C.c_void_p(x.data_ptr()), ldx, M, N, K, splits, _ptr(part), C.c_void_p(part.data_ptr() + 4 * N * K),
                                                N * K + N, _stream()), 'xr_linear_backward_weight')
-    g = part[0] if splits == 1 else part.sum(0)
+    g = sum_partials(part)
     return g[:N * K].view(N, K), g[N * K:]
 
 
@@ -1454,4 +1463,4 @@ def linear_backward_bias(dy, mask_src):
     splits = int(L.xr_linear_backward_splits(M, 0, 0))
     part = torch.empty((splits, N), dtype=torch.float32, device=dy.device)
     _lib.check(L.xr_linear_backward_bias(_ptr(dy), _ptr(mask_src), M, N, splits, _ptr(part), _stream()), 'xr_linear_backward_bias')
-    return part[0] if splits == 1 else part.sum(0)
+    return sum_partials(part)
