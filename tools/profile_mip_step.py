@@ -10,7 +10,8 @@ cfg = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'mip_model_cfg.json')
 R, S = cfg['N_rand_per_sampler'], cfg['num_samples']
 torch.manual_seed(0)
 net = xrnerf_amd.build_network(cfg['model']).to(dev)
-opt = torch.optim.Adam(net.parameters(), lr=cfg['optimizer']['lr'])
+from xrnerf_amd.train import FusedAdam
+opt = FusedAdam(list(net.parameters()), lr=cfg['optimizer']['lr'], betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, ema_momentum=None)
 rays = mip.synthetic_multiscale_rays(R, dev, seed=1)
 for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 12):
     data = mip.get_z_vals(dict(rays), S + 1, randomized=True)
