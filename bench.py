@@ -994,6 +994,10 @@ def main():
             'value': rays_all / elapsed_max, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': elapsed_max * 1e3 / args.steps, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'dtype_note': 'f32 tables, parameters, gradients, accumulation, compositor, optimiser state; the fused MLP multiplies on the fp16 '
+                          'matrix cores with every f32 operand split into two fp16 parts (XRNERF_F32_FORWARD=%s: ~4e-7 relative on raw, not '
+                          'f32-exact, operands above 65504 saturated and counted -- mlp_range_events); the reference (tiny-cuda-nn) '
+                          'computes the MLP in plain fp16' % ops.f32_forward(),
             'library_build': __import__('xrnerf_amd.build', fromlist=['info']).info(),
             'parity': 'partial: sampling / compositing / grid upkeep pinned to the reference kernels (bit-exact indices and '
                       'counts, <=1e-4 fp32); hash grid + SH + fused MLP restate tiny-cuda-nn, which is absent from the '

@@ -18,7 +18,7 @@ ENTRY = {   # entry point -> kernels launched by it (include/xrnerf_mi355.h)
                        ['void k_nerf_mlp_bwd_deep<true>', 'void k_nerf_mlp_bwd_deep<false>'],
     'xr_live_rows': ['k_live_count', 'k_live_fill'],
     'xr_composite_train': ['k_composite_train', 'k_composite_train_w'],
-    'xr_nerf_mlp_fwd': ['void k_nerf_mlp_fwd<1, 2, true>', 'void k_nerf_mlp_fwd_b3<true>', 'void k_nerf_mlp_fwd_h2<true>', 'void k_nerf_mlp_fwd_deep<true>'],
+    'xr_nerf_mlp_fwd': ['void k_nerf_mlp_fwd<1, 2, true>', 'void k_nerf_mlp_fwd_b3<true>', 'void k_nerf_mlp_fwd_h2<true>', 'void k_nerf_mlp_fwd_h2<true, false>', 'void k_nerf_mlp_fwd_h2<true, true>', 'void k_nerf_mlp_fwd_deep<true>'],
     'xr_calc_rgb_backward': ['k_composite_bwd'],
     'xr_adam_step': ['k_adam_multi', 'void k_adam_multi<true>', 'void k_adam_multi<false>'],
 }

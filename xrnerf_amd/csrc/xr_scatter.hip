@@ -99,6 +99,7 @@ struct S3Plan {
     uint32_t fuse;                   // != 0: the accumulate kernel applies Adam to the entries instead of writing their gradient
     uint32_t amax_off, ramax_off;    // words into counts: [lv][nsb] / [run-length lv][nsb] -- max |dL/d feature| per (level, sample block), as bits
     uint32_t n_rl, n_bound;          // run-length levels (their feature-0 rows in rl_drow), an upper bound of the row count
+    uint32_t rl_slices;              // slots per (run-length level, sample block) in the maxima: ceil(n_lv / n_rl) (level r uses the first kr of them)
     uint32_t rl_drow[EN_MAX_LEVELS];
     XrAdamArgs ad;
 };
@@ -112,6 +113,7 @@ struct S3RPlan {
     S3RLevel lv[EN_MAX_LEVELS];
     uint32_t n_lv, chunks, slab_entries, overwrite, blocks;
     uint32_t nsb, ramax_off, n_bound;  // as in S3Plan (the binning launch writes the maxima, the run-length workgroups read them)
+    uint32_t rl_slices, n_bin_lv;      // slots per (level, sample block) and the number of binned levels (0: one slot, k_scatter_rl_absmax)
     uint32_t fuse;                   // != 0: the fold kernel applies Adam instead of writing the gradient
     XrAdamArgs ad;
 };
@@ -436,13 +438,23 @@ __global__ __launch_bounds__(S3_BIN_THREADS) void k_scatter_bin3(S3Plan pl, cons
         for (uint32_t p = threadIdx.x; p < L.parts; p += S3_BIN_THREADS) cnt_out[(size_t)p * pl.nsb] = 0;
         if (threadIdx.x == 0) {
             *ovfcnt_out = 0; *amax_out = 0;
-            for (uint32_t r = e; r < pl.n_rl; r += pl.n_lv) counts[pl.ramax_off + r * pl.nsb + sb] = 0;
+            if (pl.n_rl && pl.n_lv >= pl.n_rl) counts[pl.ramax_off + ((e % pl.n_rl) * pl.nsb + sb) * pl.rl_slices + e / pl.n_rl] = 0;
+            else for (uint32_t r = e; r < pl.n_rl; r += pl.n_lv) counts[pl.ramax_off + (r * pl.nsb + sb) * pl.rl_slices] = 0;
         }
         return;
     }
-    // (the workgroups of binned level e look at run-length level e, e + n_lv, ... of their sample block)
-    for (uint32_t r = e; r < pl.n_rl; r += pl.n_lv)
-        s3_rows_absmax(denc_t + (size_t)pl.rl_drow[r] * ld, ld, sb * BS, BS, n, rows, s_cnt, counts + pl.ramax_off + r * pl.nsb + sb);
+    // the run-length levels' maxima: the workgroup of binned level e looks at run-length level e mod n_rl over slice e / n_rl of its
+    // sample block (a quarter of it with 13 binned and 3 run-length levels: every workgroup scans a little instead of three scanning a lot)
+    // (fewer binned than run-length levels -- odd geometries: level e, e + n_lv, ... over the whole block, one slot each)
+    if (pl.n_rl && pl.n_lv < pl.n_rl) {
+        for (uint32_t r = e; r < pl.n_rl; r += pl.n_lv)
+            s3_rows_absmax(denc_t + (size_t)pl.rl_drow[r] * ld, ld, sb * BS, BS, n, rows, s_cnt, counts + pl.ramax_off + (r * pl.nsb + sb) * pl.rl_slices);
+    } else if (pl.n_rl) {
+        const uint32_t r = e % pl.n_rl, k = e / pl.n_rl, kr = (pl.n_lv - r + pl.n_rl - 1) / pl.n_rl;     // kr slices for level r
+        const uint32_t per = (BS + kr - 1) / kr;
+        s3_rows_absmax(denc_t + (size_t)pl.rl_drow[r] * ld, ld, sb * BS + k * per, min(per, BS - min(BS, k * per)), n, rows, s_cnt,
+                       counts + pl.ramax_off + (r * pl.nsb + sb) * pl.rl_slices + k);
+    }
     if (L.kind == S3_H)
         s3_bin_block<S3_H, BS>(L, pl.lg, pl.nsb, pl.ovf_cap, sb, x, x_stride, denc_t, ld, n, rows, cnt_out, ovfcnt_out, amax_out, bins, ovf, s_items, s_ipart,
                                s_cnt, s_off, s_base, &s_ovf);
@@ -458,7 +470,7 @@ __global__ __launch_bounds__(S3_BIN_THREADS) void k_scatter_rl_absmax(S3Plan pl,
     __shared__ uint32_t s_red[S3_BIN_THREADS / 64];
     if (n_dev) n = min(n, *n_dev);
     const uint32_t r = blockIdx.x % pl.n_rl, sb = blockIdx.x / pl.n_rl;
-    s3_rows_absmax(denc_t + (size_t)pl.rl_drow[r] * ld, ld, sb * bs, bs, n, rows, s_red, counts + pl.ramax_off + r * pl.nsb + sb);
+    s3_rows_absmax(denc_t + (size_t)pl.rl_drow[r] * ld, ld, sb * bs, bs, n, rows, s_red, counts + pl.ramax_off + (r * pl.nsb + sb) * pl.rl_slices);
 }
 
 // ------------------------------------------------------------------------------------------------ accumulate
@@ -759,7 +771,15 @@ __device__ __forceinline__ void s3_rl_block(const S3RPlan& pl, const uint32_t bl
     const S3RLevel& L = pl.lv[e];
     const uint32_t rel = blk - L.block0, part = rel / pl.chunks, chunk = rel % pl.chunks;
     // (a thread's run sums are fp32 sums of <= 16 rows' contributions in row order: partial sums of the terms the bound counts)
-    const S3Scale sc = s3_scale(s3_level_max(counts + pl.ramax_off + e * pl.nsb, pl.nsb), pl.n_bound);
+    uint32_t vm = 0;
+    {
+        const uint32_t kr = pl.n_bin_lv >= pl.n_lv ? (pl.n_bin_lv - e + pl.n_lv - 1) / pl.n_lv : 1u;     // slots of this level that are written
+        const uint32_t* __restrict__ slots = counts + pl.ramax_off + (size_t)e * pl.nsb * pl.rl_slices;
+        for (uint32_t q = threadIdx.x & 63u; q < pl.nsb * kr; q += 64u) vm = max(vm, slots[(q / kr) * pl.rl_slices + q % kr]);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) vm = max(vm, (uint32_t)__shfl_xor((int)vm, d, 64));
+    }
+    const S3Scale sc = s3_scale(vm, pl.n_bound);
     const uint32_t p_lo = part << S3_LOG2, n_loc = min(S3_ENTRIES, L.hsize - p_lo);
     double2* acc2 = reinterpret_cast<double2*>(s_acc);
     for (uint32_t q = threadIdx.x; q < n_loc; q += S3_R_THREADS) acc2[q] = make_double2(0.0, 0.0);
@@ -959,8 +979,9 @@ static bool s3_layout(uint32_t n, const GridMeta& gm, uint32_t hashed_mask, int 
         }
     P.bin.ovfcnt_off = counts_off; counts_off += P.bin.n_lv * nsb;
     P.bin.amax_off = counts_off; counts_off += P.bin.n_lv * nsb;
-    P.bin.ramax_off = P.rl.ramax_off = counts_off; counts_off += P.rl.n_lv * nsb;
-    P.bin.n_rl = P.rl.n_lv; P.rl.nsb = nsb;
+    P.bin.n_rl = P.rl.n_lv; P.rl.nsb = nsb; P.rl.n_bin_lv = P.bin.n_lv;
+    P.bin.rl_slices = P.rl.rl_slices = (P.rl.n_lv && P.bin.n_lv >= P.rl.n_lv) ? (P.bin.n_lv + P.rl.n_lv - 1) / P.rl.n_lv : 1u;
+    P.bin.ramax_off = P.rl.ramax_off = counts_off; counts_off += P.rl.n_lv * nsb * P.bin.rl_slices;
     for (uint32_t r = 0; r < P.rl.n_lv; ++r) P.bin.rl_drow[r] = P.rl.lv[r].drow;
     P.bin.n_bound = P.rl.n_bound = (nsb * (uint64_t)bs > 0xffffffffull) ? 0xffffffffu : nsb * bs;
     P.counts_bytes = (((size_t)counts_off * sizeof(uint32_t)) + 255) & ~(size_t)255;
