@@ -71,6 +71,12 @@ def main(n, mode):
         ops.hashgrid_bwd(tx, dt, meta, g, levels=(3, 16), overwrite=True)
         ops.hashgrid_bwd(tx, dt, meta, g, levels=(0, 3), overwrite=True)
         report('overwrite 3-16, then 0-3', g, ref)
+        # one binned level beside three run-length levels (fewer bin workgroups per sample block than run-length levels whose maxima
+        # they record: the other mapping of xr_scatter.hip's k_scatter_bin3)
+        g = torch.full((meta.n_params,), 3.0)
+        ops.hashgrid_bwd(tx, dt, meta, g, levels=(0, 4), overwrite=True)
+        ops.hashgrid_bwd(tx, dt, meta, g, levels=(4, 16), overwrite=True)
+        report('overwrite 0-4, then 4-16', g, ref)
         live = np.flatnonzero(rng.uniform(size=n) < 0.45).astype(np.int32)
         dy2 = np.zeros_like(dy)
         dy2[live] = dy[live]

@@ -148,7 +148,7 @@ __device__ inline uint32_t s3_readlane(uint32_t v, uint32_t lane) { return (uint
 // 64-bit integer (ds_add_u64: 4.7 ns per wave instruction against 8.6, tools/lds_probe.hip): integer addition is associative, so a
 // launch's result is the same bits whatever the schedule.  S is chosen per level from max |dL/d feature| of the launch (the binning
 // workgroups record it per sample block; every contribution is a weight in [0, 1] times such a value) and the row count n: an entry
-// receives at most 8 n contributions, so with max < 2^e and 8 n <= 2^L, S = min(62 - L, 50) - e keeps every sum below 2^63 -- for
+// receives at most 8 n contributions, so with max < 2^e and 8 n <= 2^L, S = min(62 - L, 46) - e keeps every sum below 2^63 -- for
 // n = 2^18 that is a quantum of 2^-41 of the level's largest gradient (fp32 carries 2^-24 of each value).  A non-finite gradient
 // makes the level's entries NaN (what the fp64 sums did to the entries it touched).
 #ifndef S3_FIX
@@ -161,13 +161,13 @@ __device__ __forceinline__ S3Scale s3_scale(uint32_t max_bits, uint32_t n_bound)
     sc.bad = !(m <= 3.4028235e38f);
     const int e = (m > 0.f && !sc.bad) ? ilogbf(m) + 1 : 0;                       // m < 2^e
     const int L = 64 - __builtin_clzll(8ull * (unsigned long long)(n_bound ? n_bound : 1u));   // 8 n < 2^L
-    const int S = (62 - L < 50 ? 62 - L : 50) - e;                                // (<= 50 - e: a single contribution stays below 2^50, see s3_q)
+    const int S = (62 - L < 46 ? 62 - L : 46) - e;                                // (<= 46 - e: a value handed to s3_q -- a contribution, or a run-length thread's sum of <= 16 of them -- stays below 2^50)
     sc.mul = ldexp(1.0, S); sc.inv = ldexp(1.0, -S);
     return sc;
 }
 #if S3_FIX
 typedef long long s3_acc_t;
-// round(x 2^S) as an integer: |x 2^S| < 2^50, so adding 1.5 * 2^52 leaves the (round-to-nearest-even) integer in the sum's low mantissa
+// round(x 2^S) as an integer: |x 2^S| < 2^50 (s3_scale), so adding 1.5 * 2^52 leaves the (round-to-nearest-even) integer in the sum's low mantissa
 // bits -- one FMA and a 64-bit subtraction instead of the ~12 instructions of a double -> int64 conversion
 __device__ __forceinline__ s3_acc_t s3_q(float x, const S3Scale& sc) {
     const double t = fma((double)x, sc.mul, 6755399441055744.0);
