@@ -59,7 +59,9 @@ __device__ __forceinline__ void s3_static_for(F&& f) { s3_static_for_impl(f, std
 #define S3_SPT 2                                     // samples per thread and binning round
 #endif
 #define S3_ROUND_ITEMS (4 * S3_BIN_THREADS * S3_SPT)   // items staged in LDS per binning round (4 per sample)
+#ifndef S3_R_MAX_ENTRIES
 #define S3_R_MAX_ENTRIES 65536u                      // dense levels up to this size take the run-length kernel
+#endif
 #define S3_R_ROWS 16                                 // consecutive rows per thread there
 
 enum { S3_H = 0, S3_D = 1 };
