@@ -222,8 +222,10 @@ int xr_hashgrid_fwd(const float* table, const float* x, uint32_t x_stride, uint3
  * workspace (nullable; xr_hashgrid_bwd_workspace_bytes(n, n_levels, resolution_host, offset_host), 16-byte
  * aligned): with it and n >= 16384 NO level touches the table with an atomic -- hashed levels and the larger dense levels
  * are binned by table partition (16-byte items in workgroup-private sub-bins, overflow lists for clustered inputs) and
- * one workgroup per partition sums its bins in fp64 in LDS; dense levels up to 2^16 entries are run-length reduced per
+ * one workgroup per partition sums its bins in LDS in 64-bit fixed point (scaled per level from the launch's largest gradient: integer
+ * sums, so the result is the same bits whatever the schedule); dense levels up to 2^16 entries are run-length reduced per
  * thread into workgroup-private LDS partitions whose per-chunk partials are folded in fixed order (csrc/xr_scatter.hip).
+ * Three launches on `stream`, no event.  A non-finite gradient makes every entry of its level NaN.
  * Without a workspace, for small n and for table shapes outside those rules a level takes the atomic scatter.
  * Positions must lie in the unit cube (the sampler's aabb): a hashed level's x-neighbour pair is kept in one partition
  * by x < 2^13. */
