@@ -1,3 +1,6 @@
+// NOTE (round 6): written against the two-kernel scatter of rounds 3-5 (k_scatter_accum3 / k_scatter_dense_rl as kernels of their own).  The
+// library's accumulate launch is k_scatter_acc now (run-length + accumulate workgroups in one launch, integer LDS sums): this file builds
+// against the history (git show abe25a6:xrnerf_amd/csrc/xr_scatter.hip), not against HEAD; its records are profiles/r03_* / r04_*.
 // phase timing of the third-generation accumulate kernel (k_scatter_accum3<S3_LOG2, 1024>) on ray-like samples (20 consecutive steps of
 // sqrt(3)/1024 per ray), all 16 levels of the Lego geometry: wall_clock64 (100 MHz) stamps of workgroups 0, 96, 192, ... + event
 // times of the kernels.  build + run on the GPU box:
