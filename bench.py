@@ -385,7 +385,7 @@ def ngp_tcnn_strict_defaults(dev, n_img, steps):
             fl = flop[name] * units
             kern[name] = {'avg_launch_us': ms_l * 1e3 / max(n_l, 1), 'launches': n_l, 'achieved_TFLOPs': fl / (ms_l * 1e-3) / 1e12,
                           'peak_TFLOPs': MFMA_PEAK['f16'], 'frac': fl / (ms_l * 1e-3) / 1e12 / MFMA_PEAK['f16'],
-                          'frac_of_fp32_mfma_peak': fl / (ms_l * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 'flop_per_sample': flop[name],
+                          'issued_frac': 3.0 * fl / (ms_l * 1e-3) / 1e12 / MFMA_PEAK['f16'], 'flop_per_sample': flop[name],
                           'units': 'marched samples' if name == 'xr_nerf_mlp_fwd' else 'live rows (fraction %.3f)' % live_frac}
         return {'workload': 'the headline iterations with 5 + 5 hidden layers (XRNERF_TCNN_STRICT_DEFAULTS=1: what tcnn builds if it ignores '
                             'the config\'s num_layers key), %d timed iterations %d..%d after %d pre-roll iterations at this network\'s own '
@@ -784,16 +784,14 @@ def main():
         if split and ops._mlp_mode() == 3:
             out['arithmetic'] = ('xr_nerf_mlp_fwd(XR_MLP_F16X2): fp32 operands split into 2 fp16 parts (hi + lo, ~22 bits), 3 v_mfma_f32_32x32x16_f16 per '
                                  'product block, fp32 accumulate (4e-7 relative against float64, the fp32 MFMA path: 2e-7 -- '
-                                 'profiles/r05_mlp_fwd_f16x2_split_probe.txt); priced on the ALGORITHMIC flops against the fp16 MFMA peak -- the '
+                                 'profiles/r06_mlp_fwd_f16x2_split_probe.txt); priced on the ALGORITHMIC flops against the fp16 MFMA peak -- the '
                                  'matrix cores execute 3x these flops (issued_frac)')
             out['issued_frac'] = 3.0 * achieved / peak
-            out['frac_of_fp32_mfma_peak'] = achieved / MFMA_F32_PEAK_TFLOPS
         elif split:
             out['arithmetic'] = ('xr_nerf_mlp_fwd(XR_MLP_BF16X3): fp32 operands split exactly into 3 bf16 parts, 6 v_mfma_f32_32x32x16_bf16 per '
                                  'product block, fp32 accumulate (fp32-rounding accuracy); priced on the ALGORITHMIC flops against the '
                                  'bf16 MFMA peak -- the matrix cores execute 6x these flops (issued_frac)')
             out['issued_frac'] = 6.0 * achieved / peak
-            out['frac_of_fp32_mfma_peak'] = achieved / MFMA_F32_PEAK_TFLOPS
         if name == 'xr_nerf_mlp_bwd' and ops.precision() == 'f32' and bound == 'mfma':
             # mixed arithmetic (XR_MLP_BWD_DW, default h2f): the forward recompute (18432 of the 59392 flop / sample) with the forward's
             # own arithmetic (fp16 2-way split; b2x: on the fp32 MFMA), the dW products and the dX chain on the bf16 matrix cores with
@@ -804,11 +802,15 @@ def main():
             on_f32 = {'f32': f_fwd + f_dx + f_dw, 'b2': f_fwd + f_dx, 'b2x': f_fwd, 'b2f': 0.0, 'h2f': 0.0}.get(arith, f_fwd)
             on_b16 = (f_fwd + f_dx + f_dw) - on_f32
             t_unit = on_f32 / (MFMA_F32_PEAK_TFLOPS * 1e12) + 3.0 * on_b16 / (MFMA_PEAK['f16'] * 1e12)
-            peak = (on_f32 + on_b16) / t_unit / 1e12
-            out['peak'], out['frac'] = peak, achieved / peak
+            mix_peak = (on_f32 + on_b16) / t_unit / 1e12
+            if on_f32 == 0.0:
+                # everything on the 16-bit matrix cores: `frac` = ALGORITHMIC flops against their dense peak, like the forward's; the mix rate
+                # (833 TFLOP/s: three products per algorithmic one) is the issued fraction
+                out['peak'], out['frac'], out['issued_frac'] = MFMA_PEAK['f16'], achieved / MFMA_PEAK['f16'], achieved / mix_peak
+            else:
+                out['peak'], out['frac'] = mix_peak, achieved / mix_peak
             out['arithmetic'] = ('XR_MLP_BWD_DW=%s: %.0f flop/sample on the fp32 MFMA (157.3 TFLOP/s), %.0f on the 16-bit matrix cores as 3 products '
-                                 'each (2-way operand split, 2500 TFLOP/s dense); peak = the rate of this mix' % (arith, on_f32, on_b16))
-            out['frac_of_fp32_mfma_peak'] = achieved / MFMA_F32_PEAK_TFLOPS
+                                 'each (2-way operand split, 2500 TFLOP/s dense); the rate of this mix: %.0f TFLOP/s' % (arith, on_f32, on_b16, mix_peak))
         if name == 'xr_hashgrid_fwd' and launches:
             # The lookup against the roofline that binds it.  It is not HBM: the table slices are L2-resident (one XCD per level) and every
             # (y, z) corner pair of a (sample, level) is one random 16-byte access = one 128-byte line pulled from the L2 into the CU's L1
