@@ -154,3 +154,25 @@ def test_vanilla_nerf_config1_on_the_device_equals_the_host_path(dev):
         r, g = hp[name].grad, dp[name].grad.cpu()
         # bias / weight gradients are sums of ~1e5 signed terms: the summation order shows at the 1e-6 level
         assert (r - g).abs().max() <= 1e-3 * float(r.abs().max()) + 3e-6, name
+
+
+@pytest.mark.parametrize('nb,n,stride', [(1, 100, 100), (7, 65, 80), (256, 65792, 65792), (300, 4097, 4100)])
+def test_sum_partials_is_the_fixed_order_sum(dev, nb, n, stride):
+    """xr_sum_partials (what finishes the split weight / bias gradients): out[j] = sum_b partials[b][j] for j < n, columns behind n untouched
+    by the read, the same bits every launch, within fp32 summation error of the float64 sum"""
+    from xrnerf_amd import ops
+    torch.manual_seed(nb + n)
+    buf = torch.randn((nb, stride), dtype=torch.float32, device=dev)
+    buf[:, n:] = float('nan')                                  # padding columns must never be read
+    part = buf[:, :n] if stride > n else buf
+    outs = []
+    for _ in range(2):
+        out = torch.empty((n,), dtype=torch.float32, device=dev)
+        from xrnerf_amd import _lib
+        _lib.check(_lib.load().xr_sum_partials(ops._ptr(buf), nb, stride, n, ops._ptr(out), ops._stream()), 'xr_sum_partials')
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    want = part.double().sum(0)
+    assert float((outs[0].double() - want).abs().max()) <= 1e-6 * nb ** 0.5 * max(1.0, float(part.abs().max()))
+    if stride == n:
+        assert torch.equal(ops.sum_partials(buf), outs[0])
