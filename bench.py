@@ -472,7 +472,16 @@ def value_all_rows(args):
     if r.returncode != 0 or not line:
         raise RuntimeError('child failed: %s' % r.stderr[-300:])
     d = json.loads(line[-1])
-    return {'value': d['value'], 'ms_per_step': d['ms_per_step'], 'note': 'MLP backward and table scatter over every marched row (XR_MLP_LIVE=0), same results'}
+    res = {'value': d['value'], 'ms_per_step': d['ms_per_step'], 'note': 'MLP backward and table scatter over every marched row (XR_MLP_LIVE=0), same results'}
+    if d.get('dominant') == 'xr_hashgrid_bwd' and d.get('dominant_avg_launch_us'):
+        # the dominant entry point's roofline in THIS mode -- the table scatter over every marched row (live fraction 1) with the update inside:
+        # 2188 B per row + 32 B per table parameter, like the headline's `roofline`; three times the rows, the same fixed part
+        by = d['samples_per_step'] * ALGO['xr_hashgrid_bwd'][1] + 32.0 * d['table_params']
+        gbs = by / (d['dominant_avg_launch_us'] * 1e-6) / 1e9
+        res['roofline'] = {'kernel': 'xr_hashgrid_bwd', 'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
+                           'avg_launch_us': d['dominant_avg_launch_us'], 'launches': d['dominant_launches'],
+                           'algorithmic_bytes_or_flops_per_launch': by, 'live_row_fraction': 1.0}
+    return res
 
 
 def ngp_config4_unbounded(dev, steps=64):
@@ -742,7 +751,14 @@ def main():
 
     if args.headline_only:
         if rank == 0:
-            print(json.dumps({'value': rays_all / elapsed_max, 'ms_per_step': elapsed_max * 1e3 / args.steps, 'steps': args.steps}))
+            hl = {'value': rays_all / elapsed_max, 'ms_per_step': elapsed_max * 1e3 / args.steps, 'steps': args.steps}
+            try:      # the dominant entry point's launches in this window (events around it inside the native loop), for the caller's roofline
+                n_l, ms_l, _ = timer.summary()[dom_pick]
+                hl.update(dominant=dom_pick, dominant_launches=n_l, dominant_avg_launch_us=ms_l * 1e3 / max(n_l, 1),
+                          samples_per_step=samples / args.steps, table_params=int(tr.net.mlp.embedder_pos.params.numel()))
+            except Exception:  # noqa: BLE001
+                pass
+            print(json.dumps(hl))
         if world > 1:
             torch.distributed.destroy_process_group()
         return
