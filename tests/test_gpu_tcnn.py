@@ -747,3 +747,36 @@ def test_binned_scatter_is_the_same_bits_every_launch_and_keeps_small_gradients(
     big = np.abs(ref) >= 1e-7 * top
     rel = np.abs(g - ref)[big] / np.abs(ref)[big]
     assert big.sum() > 1000 and np.quantile(rel, 0.99) <= 1e-5, float(np.quantile(rel, 0.99))     # (the rest: sums that cancel)
+
+
+@pytest.mark.gpu
+def test_binned_scatter_fixed_point_scale_follows_the_gradients_magnitude(O, dev):
+    """The fixed-point scale is chosen per level from the launch's largest gradient: gradients of 1e-30 and of 1e+30 give the gradients of
+    order 1 times that factor (no underflow to zero, no overflow), and a non-finite gradient makes the entries of ITS level NaN and leaves the
+    other levels alone."""
+    from xrnerf_amd import ops
+    meta, om = ops.GridMeta(), O.GridMeta()
+    n = 40000
+    rng = np.random.default_rng(11)
+    x = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    dy = rng.normal(0, 1, (n, 32)).astype(np.float32)
+    ref = O.hashgrid_bwd(x, dy, om).astype(np.float64)
+    ld = (n + 63) // 64 * 64
+    xt = T(x, dev)
+
+    def run(d):
+        dt = torch.zeros((32, ld), dtype=torch.float32, device=dev); dt[:, :n] = T(d, dev).t()
+        g = torch.full((meta.n_params,), 2.0, dtype=torch.float32, device=dev)
+        ops.hashgrid_bwd(xt, dt, meta, g, overwrite=True)
+        return g.cpu().numpy().astype(np.float64)
+    for f in (1e-30, 1.0, 1e30):
+        g = run((dy.astype(np.float64) * f).astype(np.float32))
+        assert np.isfinite(g).all()
+        assert np.abs(g / f - ref).max() <= 1e-4 * np.abs(ref).max(), f
+    bad = dy.copy()
+    bad[123, 2 * 9] = np.inf                                    # feature 0 of level 9
+    g = run(bad)
+    lo, hi = 2 * int(meta.offset[9]), 2 * int(meta.offset[10])
+    assert np.isnan(g[lo:hi]).all()
+    rest = np.concatenate([g[:lo], g[hi:]]); rref = np.concatenate([ref[:lo], ref[hi:]])
+    assert np.isfinite(rest).all() and np.abs(rest - rref).max() <= 1e-4 * np.abs(ref).max()
