@@ -77,6 +77,10 @@ def main(n, mode):
         ops.hashgrid_bwd(tx, dt, meta, g, levels=(0, 4), overwrite=True)
         ops.hashgrid_bwd(tx, dt, meta, g, levels=(4, 16), overwrite=True)
         report('overwrite 0-4, then 4-16', g, ref)
+        # the fixed-point scale of the LDS sums follows the gradients' magnitude (xr_scatter.hip, S3_FIX): the same gradients times 2^-70
+        g = torch.full((meta.n_params,), 3.0)
+        ops.hashgrid_bwd(tx, (dt * 2.0 ** -70).contiguous(), meta, g, overwrite=True)
+        report('gradients x 2^-70', g * 2.0 ** 70, ref)
         live = np.flatnonzero(rng.uniform(size=n) < 0.45).astype(np.int32)
         dy2 = np.zeros_like(dy)
         dy2[live] = dy[live]
